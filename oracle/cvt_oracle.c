@@ -1,0 +1,482 @@
+/*
+ * cvt_oracle.c -- CPU restatement of the cvt OPQ-encode / ADC-search hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under cvt_amd/ (the product) may link, import or
+ * call this file.  It is used by tests/, by __graft_entry__.smoke() and by bench.py's
+ * `cpu_baseline` leg, always as the checker / the reported CPU baseline, never as the
+ * thing that is shipped or measured as the GPU path.
+ *
+ * Every function restates, on flat arrays, the arithmetic of the reference lines it
+ * cites (paths relative to /root/reference).  Operation ORDER is part of the contract:
+ * the reference accumulates `tmp = a - b; acc += tmp * tmp` left to right in fp32 with
+ * separate multiply and add, so this file must be compiled with -ffp-contract=off and
+ * without -ffast-math (oracle/Makefile does that).
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - OPQ reorder / encode / LUT+ADC / video-min aggregation / top-k, and the three
+ *     brute-force metrics, are pinned bit-for-bit against the reference's own sources
+ *     compiled in place (oracle/_ref, recipe in oracle/Makefile) and against the golden
+ *     vectors under tests/golden/ that were generated from those binaries.
+ *   - Scalar quantisation (orc_sq8_*): PARITY UNPINNED.  The reference delegates to
+ *     faiss 1.5.3 (not vendored, not installable here) and holds no expected outputs;
+ *     the functions below follow the in-tree formulas of int8_quan.cc line by line.
+ *   - orc_rotate_fma: the general d x d rotation is NOT in the reference (which only
+ *     permutes); it is the specification of the MFMA GEMM kernel (k-ordered fmaf chain).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * "OPQ rotation" = dimension permutation.  opq/src/IVFOPQ.cpp:424-439 (reorder),
+ * applied to every row by LoadSingleFeatFile :459-461.   y[i] = x[perm[i]].
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_reorder(const int32_t *perm, int D, const float *x, int64_t n, float *y)
+{
+    for (int64_t r = 0; r < n; ++r) {
+        const float *src = x + r * D;
+        float *dst = y + r * D;
+        for (int i = 0; i < D; ++i) dst[i] = src[perm[i]];
+    }
+}
+
+/* General rotation Y = X * R^T as the GPU kernel computes it: one rounding per product,
+ * products folded in ascending k by fused multiply-add starting from +0
+ * (MI355X f32 MFMA == k-ordered fmaf chain).  With R a 0/1 permutation matrix this is
+ * exactly orc_reorder for finite inputs. */
+ORC_API void orc_rotate_fma(const float *R, int D, const float *x, int64_t n, float *y)
+{
+    for (int64_t r = 0; r < n; ++r) {
+        const float *src = x + r * D;
+        for (int i = 0; i < D; ++i) {
+            float acc = 0.0f;
+            const float *row = R + (int64_t)i * D;
+            for (int k = 0; k < D; ++k) acc = fmaf(row[k], src[k], acc);
+            y[r * D + i] = acc;
+        }
+    }
+}
+
+/* squared L2 distance, sequential fp32, no contraction.  IVFOPQ.cpp:117-122 / :147-154 */
+static inline float sq_dist_seq(const float *a, const float *b, int n)
+{
+    float acc = 0.0f;
+    for (int k = 0; k < n; ++k) {
+        float t = a[k] - b[k];
+        acc += t * t;
+    }
+    return acc;
+}
+
+/* Coarse assignment of Add(): IVFOPQ.cpp:110-129.  dismin starts at float(UINT_MAX),
+ * strict '<' keeps the first minimum, vw stays -1 if nothing beats the start value. */
+ORC_API void orc_coarse_assign(const float *x, int64_t n, int D, const float *coarse, int coarseK,
+                               int32_t *out_vw)
+{
+    for (int64_t r = 0; r < n; ++r) {
+        float best = (float)4294967295u; /* UINT_MAX -> 4294967296.0f */
+        int32_t vw = -1;
+        for (int i = 0; i < coarseK; ++i) {
+            float d = sq_dist_seq(x + r * D, coarse + (int64_t)i * D, D);
+            if (d < best) { best = d; vw = i; }
+        }
+        out_vw[r] = vw;
+    }
+}
+
+/* PQ encode of Add(): residual :135-139, per-sub-quantiser argmin :141-161.
+ * books layout = LoadModel's: [M][K][step] contiguous (:88-93).
+ * A row whose coarse assignment is -1 (all-NaN row) is undefined behaviour in the
+ * reference (m_ppCoarseCluster[-1]); here its residual is taken against list 0 and the
+ * list id is reported as -1. */
+ORC_API void orc_pq_encode(const float *x, int64_t n, int D, const float *coarse, int coarseK,
+                           const float *books, int M, int K, int32_t *out_list, uint8_t *out_codes)
+{
+    const int step = D / M;
+    float *res = (float *)malloc(sizeof(float) * (size_t)D);
+    for (int64_t r = 0; r < n; ++r) {
+        int32_t vw;
+        orc_coarse_assign(x + r * D, 1, D, coarse, coarseK, &vw);
+        const float *cen = coarse + (int64_t)(vw < 0 ? 0 : vw) * D;
+        for (int i = 0; i < D; ++i) res[i] = x[r * D + i] - cen[i];
+        for (int m = 0; m < M; ++m) {
+            float best = (float)4294967295u;
+            int bj = -1;
+            const float *cb = books + (int64_t)m * K * step;
+            for (int j = 0; j < K; ++j) {
+                float d = sq_dist_seq(res + m * step, cb + (int64_t)j * step, step);
+                if (d < best) { best = d; bj = j; }
+            }
+            out_codes[r * M + m] = (uint8_t)bj; /* -1 -> 255, IVFOPQ.cpp:161 */
+        }
+        if (out_list) out_list[r] = vw;
+    }
+    free(res);
+}
+
+/* Distance look-up table of Query(): IVFOPQ.cpp:273-291.  centroid may be NULL (= zeros
+ * is NOT the same as skipping the subtraction for -0.0 inputs, so NULL means "subtract
+ * an explicit +0.0f", which is what a zero coarse centroid does in the reference). */
+ORC_API void orc_lut(const float *q, int D, const float *centroid, const float *books, int M, int K,
+                     float *lut /* [M][K] */)
+{
+    const int step = D / M;
+    float *res = (float *)malloc(sizeof(float) * (size_t)D);
+    for (int i = 0; i < D; ++i) res[i] = q[i] - (centroid ? centroid[i] : 0.0f);
+    for (int m = 0; m < M; ++m)
+        for (int j = 0; j < K; ++j)
+            lut[m * K + j] = sq_dist_seq(res + m * step, books + ((int64_t)m * K + j) * step, step);
+    free(res);
+}
+
+/* ADC scan: IVFOPQ.cpp:300-306.  score = sum_{k<M} LUT[k][code[k]], fp32, from 0.0f. */
+ORC_API void orc_adc_scan(const float *lut, int M, int K, const uint8_t *codes, int64_t n,
+                          float *out_scores)
+{
+    for (int64_t r = 0; r < n; ++r) {
+        float s = 0.0f;
+        for (int k = 0; k < M; ++k) s += lut[k * K + codes[r * M + k]];
+        out_scores[r] = s;
+    }
+}
+
+/* ---- (dist,id) lexicographic ordering: std::pair<float,uint> operator<, used by
+ * get_sort_results (opq/src/common.h:25-37) and by the max-heap in
+ * brutoforce.hpp:73-93. ---- */
+typedef struct { float d; int64_t id; } orc_pair;
+
+static int pair_less(const orc_pair *a, const orc_pair *b)
+{
+    if (a->d < b->d) return 1;
+    if (b->d < a->d) return 0;
+    return a->id < b->id;
+}
+static int pair_cmp_qsort(const void *pa, const void *pb)
+{
+    const orc_pair *a = (const orc_pair *)pa, *b = (const orc_pair *)pb;
+    if (pair_less(a, b)) return -1;
+    if (pair_less(b, a)) return 1;
+    return 0;
+}
+
+/* k smallest (score, index) pairs ascending == std::partial_sort_copy of common.h:34.
+ * Writes min(k, n) entries, returns that count. */
+ORC_API int64_t orc_topk_pairs(const float *scores, const int64_t *ids /* NULL -> 0..n-1 */,
+                               int64_t n, int64_t k, float *out_d, int64_t *out_id)
+{
+    orc_pair *p = (orc_pair *)malloc(sizeof(orc_pair) * (size_t)(n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; ++i) { p[i].d = scores[i]; p[i].id = ids ? ids[i] : i; }
+    qsort(p, (size_t)n, sizeof(orc_pair), pair_cmp_qsort);
+    int64_t m = k < n ? k : n;
+    for (int64_t i = 0; i < m; ++i) { out_d[i] = p[i].d; out_id[i] = p[i].id; }
+    free(p);
+    return m;
+}
+
+/* Bounded running selection used by the exhaustive-search oracles below: same result as
+ * the reference's heap (k smallest lexicographic pairs) without materialising n pairs. */
+typedef struct { orc_pair *h; int64_t k, size; } orc_heap; /* max-heap on pair_less */
+
+static void heap_sift_up(orc_heap *hp, int64_t i)
+{
+    while (i > 0) {
+        int64_t par = (i - 1) / 2;
+        if (pair_less(&hp->h[par], &hp->h[i])) {
+            orc_pair t = hp->h[par]; hp->h[par] = hp->h[i]; hp->h[i] = t; i = par;
+        } else break;
+    }
+}
+static void heap_sift_down(orc_heap *hp, int64_t i)
+{
+    for (;;) {
+        int64_t l = 2 * i + 1, r = l + 1, big = i;
+        if (l < hp->size && pair_less(&hp->h[big], &hp->h[l])) big = l;
+        if (r < hp->size && pair_less(&hp->h[big], &hp->h[r])) big = r;
+        if (big == i) break;
+        orc_pair t = hp->h[big]; hp->h[big] = hp->h[i]; hp->h[i] = t; i = big;
+    }
+}
+/* brutoforce.hpp:74-92: the first k rows are pushed unconditionally; afterwards a row is
+ * pushed when dist <= current worst and the worst is popped when the heap exceeds k. */
+static void heap_offer(orc_heap *hp, float d, int64_t id)
+{
+    if (hp->size < hp->k) {
+        hp->h[hp->size].d = d; hp->h[hp->size].id = id; hp->size++;
+        heap_sift_up(hp, hp->size - 1);
+        return;
+    }
+    if (!(d <= hp->h[0].d)) return;
+    orc_pair cand = { d, id };
+    if (pair_less(&cand, &hp->h[0])) { hp->h[0] = cand; heap_sift_down(hp, 0); }
+    /* else: pushed then immediately popped again as the new maximum -> no change */
+}
+static int64_t heap_drain_sorted(orc_heap *hp, float *out_d, int64_t *out_id)
+{
+    int64_t m = hp->size;
+    qsort(hp->h, (size_t)m, sizeof(orc_pair), pair_cmp_qsort);
+    for (int64_t i = 0; i < m; ++i) { out_d[i] = hp->h[i].d; out_id[i] = hp->h[i].id; }
+    return m;
+}
+
+/* Exhaustive ADC top-k (north-star form of Query: coarseK = 1, nprobe = 1, one vector
+ * per "video", no 1.0 clamp): LUT per query (IVFOPQ.cpp:279-291), scan (:300-306),
+ * k smallest (score,id) (common.h:25-37).  q must already be rotated.  Output rows are
+ * padded with (+inf, -1) when n < k. */
+ORC_API void orc_adc_search(const float *q, int64_t nq, int D, const float *centroid,
+                            const float *books, int M, int K, const uint8_t *codes, int64_t n,
+                            int64_t id_base, int64_t k, float *out_d, int64_t *out_id)
+{
+    float *lut = (float *)malloc(sizeof(float) * (size_t)M * K);
+    orc_heap hp; hp.h = (orc_pair *)malloc(sizeof(orc_pair) * (size_t)(k > 0 ? k : 1)); hp.k = k;
+    for (int64_t qi = 0; qi < nq; ++qi) {
+        orc_lut(q + qi * D, D, centroid, books, M, K, lut);
+        hp.size = 0;
+        for (int64_t r = 0; r < n; ++r) {
+            float s = 0.0f;
+            const uint8_t *c = codes + r * M;
+            for (int kk = 0; kk < M; ++kk) s += lut[kk * K + c[kk]];
+            heap_offer(&hp, s, id_base + r);
+        }
+        int64_t m = heap_drain_sorted(&hp, out_d + qi * k, out_id + qi * k);
+        for (int64_t i = m; i < k; ++i) { out_d[qi * k + i] = INFINITY; out_id[qi * k + i] = -1; }
+    }
+    free(hp.h); free(lut);
+}
+
+/* Full reference Query()/QueryThrehold() semantics, IVFOPQ.cpp:232-315 / :341-417.
+ *   - coarse scan keeps the nk nearest lists in a max-heap of (dist, i): the first nk
+ *     lists are pushed unconditionally, later ones replace the top when strictly closer
+ *     (:248-259);  lists are then visited in heap-pop order = farthest first (:264-267).
+ *   - matchScore[f][video] starts at 1.0 (threhold, :5, :262) and takes the min over
+ *     every code of that video met in the probed lists (:308).
+ * Inverted lists are given CSR-style: list l owns entries [list_off[l], list_off[l+1]).
+ * q must already be rotated. */
+ORC_API void orc_query_video(const float *q, int64_t nq, int D, const float *coarse, int coarseK,
+                             const float *books, int M, int K, int nk, const int64_t *list_off,
+                             const uint8_t *codes, const int32_t *video_id, int img_num,
+                             float *match_score /* [nq][img_num] */)
+{
+    float *lut = (float *)malloc(sizeof(float) * (size_t)M * K);
+    orc_pair *hp = (orc_pair *)malloc(sizeof(orc_pair) * (size_t)(nk > 0 ? nk : 1));
+    for (int64_t f = 0; f < nq; ++f) {
+        orc_heap h; h.h = hp; h.k = nk; h.size = 0;
+        for (int i = 0; i < coarseK; ++i) {
+            float d = sq_dist_seq(q + f * D, coarse + (int64_t)i * D, D);
+            if (i < nk) {
+                hp[h.size].d = d; hp[h.size].id = i; h.size++; heap_sift_up(&h, h.size - 1);
+            } else if (d < hp[0].d) {
+                hp[0].d = d; hp[0].id = i; heap_sift_down(&h, 0);
+            }
+        }
+        float *ms = match_score + f * img_num;
+        for (int v = 0; v < img_num; ++v) ms[v] = 1.0f;
+        while (h.size > 0) {
+            int vw = (int)hp[0].id;
+            hp[0] = hp[h.size - 1]; h.size--; heap_sift_down(&h, 0);
+            orc_lut(q + f * D, D, coarse + (int64_t)vw * D, books, M, K, lut);
+            for (int64_t j = list_off[vw]; j < list_off[vw + 1]; ++j) {
+                float s = 0.0f;
+                for (int kk = 0; kk < M; ++kk) s += lut[kk * K + codes[j * M + kk]];
+                int v = video_id[j];
+                if (s < ms[v]) ms[v] = s; /* min(score, current), :308 */
+            }
+        }
+    }
+    free(hp); free(lut);
+}
+
+/* Frame aggregation of the query main: multi_frame_index_test.cpp:60-67, then
+ * get_sort_results (:68).  total[v] = sum_f matchScore[f][v] in frame order. */
+ORC_API void orc_video_rank(const float *match_score, int64_t nq, int img_num, int64_t k,
+                            float *total /* [img_num] */, float *out_d, int64_t *out_id)
+{
+    for (int v = 0; v < img_num; ++v) total[v] = 0.0f;
+    for (int64_t f = 0; f < nq; ++f)
+        for (int v = 0; v < img_num; ++v) total[v] += match_score[f * img_num + v];
+    orc_topk_pairs(total, NULL, img_num, k, out_d, out_id);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Exhaustive-search distance functions.
+ * ---------------------------------------------------------------------------------------- */
+/* brute_force_search/src/space_ip.hpp:25-34  (scalar path) */
+static float ip_scalar(const float *a, const float *b, int n)
+{
+    float res = 0;
+    for (int i = 0; i < n; ++i) res += a[i] * b[i];
+    return 1.0f - res;
+}
+/* space_ip.hpp:168-206 (non-AVX branch of InnerProductSIMD16Ext, what the reference's own
+ * CMake flags build): one 4-lane accumulator, 4 lanes per step, lanes added left to right. */
+static float ip_lanes(const float *a, const float *b, int n, int lanes)
+{
+    float acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    int n16 = (n / 16) * 16;
+    for (int i = 0; i < n16; i += lanes)
+        for (int l = 0; l < lanes; ++l) acc[l] += a[i + l] * b[i + l];
+    float s = acc[0];
+    for (int l = 1; l < lanes; ++l) s += acc[l];
+    return 1.0f - s;
+}
+/* hnsw_sifts_retrieval/hnswlib/space_l2.h:26-37 */
+static float l2_scalar(const float *a, const float *b, int n) { return sq_dist_seq(a, b, n); }
+/* space_l2.h:40-73: AVX branch is hard-enabled by `#define USE_AVX` (:12): 8 lanes. */
+static float l2_lanes8(const float *a, const float *b, int n)
+{
+    float acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    int n16 = (n >> 4) << 4;
+    for (int i = 0; i < n16; i += 8)
+        for (int l = 0; l < 8; ++l) { float t = a[i + l] - b[i + l]; acc[l] += t * t; }
+    return acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5] + acc[6] + acc[7];
+}
+/* space_l2.h:186-219: integer L2 over groups of four uint8; a dim%4 tail is dropped. */
+static int l2_u8(const uint8_t *a, const uint8_t *b, int n)
+{
+    int res = 0;
+    int groups = n >> 2;
+    for (int i = 0; i < groups * 4; ++i) { int t = (int)a[i] - (int)b[i]; res += t * t; }
+    return res;
+}
+
+/* metric ids shared with include/cvtmi.h */
+enum { ORC_IP = 0, ORC_L2F = 1, ORC_L2U8 = 2 };
+/* flavour: 0 scalar loop, 4 = SSE lane order, 8 = AVX lane order (IP only; L2F uses 8 when
+ * D%16==0 like L2Space's selection at space_l2.h:159-164, else scalar) */
+ORC_API float orc_dist(int metric, int flavour, const void *a, const void *b, int D)
+{
+    if (metric == ORC_IP) {
+        if (flavour == 0 || D % 16 != 0) return ip_scalar((const float *)a, (const float *)b, D);
+        return ip_lanes((const float *)a, (const float *)b, D, flavour);
+    }
+    if (metric == ORC_L2F) {
+        if (flavour == 0 || D % 16 != 0) return l2_scalar((const float *)a, (const float *)b, D);
+        return l2_lanes8((const float *)a, (const float *)b, D);
+    }
+    return (float)l2_u8((const uint8_t *)a, (const uint8_t *)b, D);
+}
+
+/* BruteforceSearch::searchKnn, brutoforce.hpp:73-93: k smallest (dist,label) pairs.
+ * Integer distances are returned as float (exact below 2^24; D*255^2 <= 2^24 for D<=258,
+ * so out_di carries the exact int for the uint8 metric). */
+ORC_API void orc_flat_search(int metric, int flavour, int D, const void *data, const int64_t *labels,
+                             int64_t n, const void *queries, int64_t nq, int64_t k, float *out_d,
+                             int32_t *out_di, int64_t *out_label)
+{
+    const size_t row = (metric == ORC_L2U8) ? (size_t)D : (size_t)D * 4;
+    orc_heap hp; hp.h = (orc_pair *)malloc(sizeof(orc_pair) * (size_t)(k > 0 ? k : 1)); hp.k = k;
+    for (int64_t qi = 0; qi < nq; ++qi) {
+        const char *qp = (const char *)queries + qi * row;
+        hp.size = 0;
+        for (int64_t r = 0; r < n; ++r) {
+            const char *xp = (const char *)data + r * row;
+            float d;
+            if (metric == ORC_L2U8) d = (float)l2_u8((const uint8_t *)qp, (const uint8_t *)xp, D);
+            else d = orc_dist(metric, flavour, qp, xp, D);
+            heap_offer(&hp, d, labels ? labels[r] : r);
+        }
+        int64_t m = heap_drain_sorted(&hp, out_d + qi * k, out_label + qi * k);
+        for (int64_t i = m; i < k; ++i) { out_d[qi * k + i] = INFINITY; out_label[qi * k + i] = -1; }
+        if (out_di) {
+            /* exact integer distances recomputed for the winners */
+            for (int64_t i = 0; i < k; ++i) out_di[qi * k + i] = -1;
+            if (metric == ORC_L2U8) {
+                for (int64_t i = 0; i < m; ++i) {
+                    int64_t lab = out_label[qi * k + i], rr = lab;
+                    if (labels) { for (rr = 0; rr < n && labels[rr] != lab; ++rr) {} }
+                    out_di[qi * k + i] = l2_u8((const uint8_t *)qp, (const uint8_t *)data + rr * row, D);
+                }
+            }
+        }
+    }
+    free(hp.h);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Scalar quantisation (PARITY UNPINNED -- see header).
+ * ---------------------------------------------------------------------------------------- */
+/* scalar_quantization/scalar_quantization/int8_quan.cc:46-56 (== utils/math_util.h:29-39):
+ * float product, double accumulate, double sqrt, float(max(1e-12, norm)), float divide. */
+ORC_API void orc_sq8_l2norm(float *v, int d)
+{
+    double accum = 0.0;
+    for (int i = 0; i < d; ++i) accum += v[i] * v[i];
+    accum = sqrt(accum);
+    float den = (float)(accum > 1e-12 ? accum : 1e-12);
+    for (int i = 0; i < d; ++i) v[i] = v[i] / den;
+}
+
+/* Int8Encode, int8_quan.cc:72-94, applied to each of n vectors (the reference encodes only
+ * the first; callers pass n = 1 for the literal behaviour).  x is normalised IN PLACE when
+ * l2norm != 0, as the reference does to its caller's buffer. */
+ORC_API void orc_sq8_encode(const float *vmin, const float *vdiff, int d, float *x, int64_t n,
+                            int l2norm, uint8_t *out)
+{
+    for (int64_t r = 0; r < n; ++r) {
+        float *row = x + r * d;
+        if (l2norm) orc_sq8_l2norm(row, d);
+        for (int i = 0; i < d; ++i) {
+            float xi = 0;
+            if (vdiff[i] != 0) xi = (row[i] - vmin[i]) / vdiff[i];
+            if (xi < 0) xi = 0;
+            if (xi > 1.0) xi = 1.0;
+            out[r * d + i] = (uint8_t)(int)(255 * xi);
+        }
+    }
+}
+
+/* Int8Decode(std::string&), int8_quan.cc:117-132: evaluated in double, stored as float. */
+ORC_API void orc_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_t *codes,
+                            int64_t n, float *out)
+{
+    for (int64_t r = 0; r < n; ++r)
+        for (int i = 0; i < d; ++i)
+            out[r * d + i] = (float)(vmin[i] + vdiff[i] * (codes[r * d + i] + 0.5) / 255.0);
+}
+
+/* sq_train.cpp:84-103: rows are L2-normalised (:84) and handed to
+ * faiss::IndexScalarQuantizer(d, QT_8bit).train, whose default range statistic (RS_minmax,
+ * rangestat_arg 0) is per-dimension min and max-min.  x is normalised in place. */
+ORC_API void orc_sq8_train(float *x, int64_t n, int d, int l2norm, float *vmin, float *vdiff)
+{
+    for (int i = 0; i < d; ++i) { vmin[i] = HUGE_VALF; vdiff[i] = -HUGE_VALF; }
+    for (int64_t r = 0; r < n; ++r) {
+        float *row = x + r * d;
+        if (l2norm) orc_sq8_l2norm(row, d);
+        for (int i = 0; i < d; ++i) {
+            if (row[i] < vmin[i]) vmin[i] = row[i];
+            if (row[i] > vdiff[i]) vdiff[i] = row[i];
+        }
+    }
+    for (int i = 0; i < d; ++i) vdiff[i] = vdiff[i] - vmin[i];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-way merge of per-shard top-k lists (the exchange step of SURVEY 8e; same shape as
+ * FLANN-MPI's ResultsMerger, retrieval/vlindex/lib/FLANN/mpi/index.h:74-108).
+ * in_d/in_id: [nq][L][k]; entries with id < 0 are padding.  Output [nq][k].
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_merge_topk(const float *in_d, const int64_t *in_id, int64_t nq, int64_t L, int64_t k,
+                            float *out_d, int64_t *out_id)
+{
+    orc_pair *p = (orc_pair *)malloc(sizeof(orc_pair) * (size_t)(L * k > 0 ? L * k : 1));
+    for (int64_t qi = 0; qi < nq; ++qi) {
+        int64_t m = 0;
+        for (int64_t i = 0; i < L * k; ++i) {
+            int64_t id = in_id[qi * L * k + i];
+            if (id < 0) continue;
+            p[m].d = in_d[qi * L * k + i]; p[m].id = id; ++m;
+        }
+        qsort(p, (size_t)m, sizeof(orc_pair), pair_cmp_qsort);
+        for (int64_t i = 0; i < k; ++i) {
+            if (i < m) { out_d[qi * k + i] = p[i].d; out_id[qi * k + i] = p[i].id; }
+            else { out_d[qi * k + i] = INFINITY; out_id[qi * k + i] = -1; }
+        }
+    }
+    free(p);
+}
+
+/* OpenMP-free multi-thread helper is deliberately absent: bench.py's cpu_baseline times the
+ * single-thread loop (cores = 1) exactly as the reference runs it. */
