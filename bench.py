@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of the OPQ-ADC search hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of nq synthetic queries against the HBM-resident
+code index: query rotation (fp32 MFMA GEMM) -> per-query distance tables built in LDS -> ADC scan of
+every code row -> k smallest (distance, id) per query [-> for N > 1: RCCL all-gather of the per-shard
+top-k and a k-way merge on every rank].  Inputs are resident in HBM when the timed region starts.
+
+Workload at every N: BASELINE.json configs[1], SIFT-1M (synthetic SIFT-shaped 128-d rows), OPQ M=16
+K=256, top-100, nq=10000 per step.  N > 1 row-shards the SAME database over the ranks (strong scaling).
+
+    python bench.py                       # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--M", type=int, default=16)
+    ap.add_argument("--qtile", type=int, default=0)
+    ap.add_argument("--splits", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=256, help="queries timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--recall-sample", type=int, default=1000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import cvt_amd
+    from cvt_amd import sharded, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with --nproc-per-node equal to --gpus (got WORLD_SIZE=%d)" % world
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+    cvt_amd.lib()
+
+    D, M, K, k, nq = 128, args.M, 256, args.k, args.nq
+    zero_coarse = np.zeros((1, D), np.float32)
+    R = synth.random_rotation(D, seed=7)
+
+    # ---- model: rank 0 trains the sub-codebooks on a 100K-row sample, everyone gets the same bytes ----
+    books_t = torch.empty((M, K, D // M), dtype=torch.float32, device=dev)
+    if rank == 0:
+        tmp = cvt_amd.OpqIndex(zero_coarse, np.zeros((M, K, D // M), np.float32), R=R)
+        sample = tmp.rotate(synth.sift_like(100_000, D, seed=0xC0FFEE, device=dev))
+        books_t.copy_(torch.from_numpy(synth.train_books(sample, M, K, iters=4)))
+        tmp.close(); del sample
+    if world > 1:
+        dist.broadcast(books_t, src=0)
+    books = books_t.cpu().numpy()
+
+    # ---- index build on device: generate -> rotate (MFMA GEMM) -> encode -> append; only codes stay ----
+    idx = cvt_amd.OpqIndex(zero_coarse, books, R=R)
+    r0, r1 = sharded.shard_range(args.rows, rank, world)
+    idx.reserve(r1 - r0); idx.set_id_base(r0)
+    enc_rows, enc_time = 0, 0.0
+    for a in range(r0, r1, synth.CHUNK):
+        b = min(r1, a + synth.CHUNK)
+        x = synth.sift_like(b - a, D, seed=0xC0FFEE, row_begin=a, device=dev)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _, codes = idx.encode(idx.rotate(x))
+        idx.add_codes(codes)
+        torch.cuda.synchronize(); enc_time += time.perf_counter() - t0  # data generation excluded
+        enc_rows += b - a
+    q = synth.sift_like(nq, D, seed=0xBEEF, device=dev)  # identical on every rank
+    idx.set_param("qtile", args.qtile); idx.set_param("splits", args.splits)
+    idx.set_param("profile", 1)
+
+    searcher = sharded.ShardedSearch(lambda qq, kk: idx.search(qq, kk, rotate=True), cvt_amd.topk_merge, world, rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = searcher.search(q, k)
+    barrier()
+    idx.last_scan()  # drop the warm-up launches from the kernel-time statistics
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = searcher.search(q, k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    scan = idx.last_scan()  # mean HIP-event duration of the scan kernel over the timed steps
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        qps = nq * args.steps / elapsed
+        achieved = scan["code_bytes"] / (scan["ms"] * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "scan_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "queries/sec, OPQ-ADC top-%d over 128-d SIFT-1M" % k,
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8 codes / f32 distances", "data": "synthetic",
+            "config": {"workload": "SIFT-1M synthetic 128-d, OPQ M=%d K=256 (dense 128x128 rotation), ADC scan + top-%d, "
+                                   "nq=%d queries per step" % (M, k, nq),
+                       "rows": args.rows, "rows_per_gpu": r1 - r0, "nq_per_step": nq, "k": k, "M": M,
+                       "parallelism": "row-sharded x%d + RCCL all-gather of per-shard top-k" % world if world > 1 else "1 GPU",
+                       "qtile": scan["qtile"], "row_splits": scan["splits"]},
+            "roofline": {"bound": "hbm", "kernel": "adc_scan_kernel<M=%d,QT=%d>" % (M, scan["qtile"]),
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": scan["code_bytes"], "kernel_ms": round(scan["ms"], 4),
+                         "per_query_equivalent_GBs": round(nq * (r1 - r0) * M / (scan["ms"] * 1e-3) / 1e9, 1)},
+            "encode": {"rows_per_s": round(enc_rows / enc_time, 1), "what": "rotate (MFMA GEMM) + PQ encode + append, this rank"},
+        }
+
+    # ---- outside the timed region: recall@1 and the CPU baseline (rank 0, N = 1 only) ----
+    if rank == 0 and world == 1:
+        d_gpu, i_gpu = out
+        ns = min(args.recall_sample, nq)
+        if ns > 0:
+            best = torch.full((ns,), float("inf"), device=dev); arg = torch.zeros((ns,), dtype=torch.int64, device=dev)
+            qs = q[:ns]
+            for a in range(0, args.rows, synth.CHUNK):
+                b = min(args.rows, a + synth.CHUNK)
+                x = synth.sift_like(b - a, D, seed=0xC0FFEE, row_begin=a, device=dev)
+                dd = torch.cdist(qs, x)
+                m, j = dd.min(dim=1)
+                upd = m < best
+                best = torch.where(upd, m, best); arg = torch.where(upd, j + a, arg)
+            result["recall_at_1"] = round(float((i_gpu[:ns, 0] == arg).float().mean().item()), 4)
+            result["recall_at_1_what"] = "ADC top-1 == exact fp32 L2 nearest neighbour, first %d queries" % ns
+        if args.cpu_sample > 0:
+            from oracle import binding as ob  # the CPU restatement of the reference path (checker + baseline)
+            ob.build(o3=True)
+            orc = ob.Oracle(o3=True)
+            cs = min(args.cpu_sample, nq)
+            codes_h = np.empty((args.rows, M), dtype=np.uint8)
+            _, _, codes_h = idx.get_entries()
+            q_rot = orc.rotate_fma(R, q[:cs].cpu().numpy())
+            t0 = time.perf_counter()
+            od, oi = orc.adc_search(q_rot, books, codes_h, k)
+            t_cpu = time.perf_counter() - t0
+            same_ids = bool(np.array_equal(oi, i_gpu[:cs].cpu().numpy()))
+            same_d = bool(np.array_equal(od.view(np.uint32), d_gpu[:cs].cpu().numpy().view(np.uint32)))
+            result["cpu_baseline"] = {
+                "value": round(cs / t_cpu, 2), "unit": "queries/s", "cores": 1, "kind": "port",
+                "sample": "%d of the %d queries against the full %d-row code matrix, LUT + scan + top-%d "
+                          "(oracle/cvt_oracle.c -O3, 1 thread); host: %s" % (cs, nq, args.rows, k, _cpu_model()),
+                "gpu_topk_ids_identical": same_ids, "gpu_distances_bit_identical": same_d}
+            result["recall_at_1_identical_to_cpu"] = bool(np.array_equal(oi[:, 0], i_gpu[:cs, 0].cpu().numpy()))
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip() + " (%d logical cores)" % os.cpu_count()
+    except Exception:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,11 @@
+"""cvt_amd -- MI355X-native OPQ encode + ADC search path of willard-yuan/cvt.
+
+The product is the C-ABI shared library ``cvt_amd/lib/libcvtmi.so`` (include/cvtmi.h), built from
+the hand-written HIP kernels in ``cvt_amd/csrc`` and wrapped by the C++ mirror of the reference
+classes in ``cvt_amd/host``.  This Python package is only the thin ctypes binding the tests and
+bench.py drive it through; torch is used for device memory, streams and torch.distributed.
+"""
+from .capi import (CvtmiError, FlatIndex, OpqIndex, lib, load_library, sq8_decode, sq8_encode, sq8_train,  # noqa: F401
+                   topk_merge)
+
+IP, L2F, L2U8 = 0, 1, 2

@@ -1,0 +1,315 @@
+"""ctypes binding of include/cvtmi.h.
+
+There is NO fallback: if libcvtmi.so is missing or a call fails, an exception is raised.  Arrays
+may be numpy (host-pointer entry points) or torch CUDA tensors (``*_dev`` entry points on the
+tensor's device, launched on torch's current stream so torch events/streams order them).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcvtmi.so")
+_lib = None
+
+
+class CvtmiError(RuntimeError):
+    pass
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CvtmiError("libcvtmi.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "or `make -C cvt_amd/csrc`" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.cvtmi_last_error.restype = C.c_char_p
+    return _lib
+
+
+def lib():
+    return load_library()
+
+
+def _check(rc):
+    if rc != 0:
+        raise CvtmiError("cvtmi error %d: %s" % (rc, lib().cvtmi_last_error().decode(errors="replace")))
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _ptr(a):
+    if a is None:
+        return C.c_void_p(0)
+    if _is_torch(a):
+        assert a.is_contiguous()
+        return C.c_void_p(a.data_ptr())
+    assert a.flags["C_CONTIGUOUS"]
+    return C.c_void_p(a.ctypes.data)
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _np(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().cvtmi_device_count(C.byref(n)))
+    return n.value
+
+
+class OpqIndex:
+    """cvtmi_opq_t: OPQ model (coarse, sub-codebooks, rotation) + HBM-resident code index."""
+
+    def __init__(self, coarse, books, perm=None, R=None):
+        coarse = _np(coarse, np.float32); books = _np(books, np.float32)
+        self.coarseK, self.D = coarse.shape
+        self.M, self.K, step = books.shape
+        assert self.M * step == self.D
+        perm_a = None if perm is None else _np(perm, np.int32)
+        R_a = None if R is None else _np(R, np.float32)
+        self.h = C.c_void_p(0)
+        _check(lib().cvtmi_opq_create(C.c_int(self.D), C.c_int(self.coarseK), C.c_int(self.M), C.c_int(self.K),
+                                      _ptr(coarse), _ptr(books), _ptr(R_a), _ptr(perm_a), C.byref(self.h)))
+
+    def close(self):
+        if self.h and self.h.value:
+            lib().cvtmi_opq_destroy(self.h)
+            self.h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- rotate ----
+    def rotate(self, x):
+        if _is_torch(x):
+            import torch
+            y = torch.empty_like(x)
+            _check(lib().cvtmi_opq_rotate_dev(self.h, _ptr(x), C.c_int64(x.shape[0]), _ptr(y), _stream()))
+            return y
+        x = _np(x, np.float32)
+        y = np.empty_like(x)
+        _check(lib().cvtmi_opq_rotate(self.h, _ptr(x), C.c_int64(x.shape[0]), _ptr(y)))
+        return y
+
+    # ---- encode ----
+    def encode(self, x_rot):
+        n = x_rot.shape[0]
+        if _is_torch(x_rot):
+            import torch
+            lists = torch.empty(n, dtype=torch.int32, device=x_rot.device)
+            codes = torch.empty((n, self.M), dtype=torch.uint8, device=x_rot.device)
+            _check(lib().cvtmi_opq_encode_dev(self.h, _ptr(x_rot), C.c_int64(n), _ptr(lists), _ptr(codes), _stream()))
+            return lists, codes
+        x_rot = _np(x_rot, np.float32)
+        lists = np.empty(n, dtype=np.int32)
+        codes = np.empty((n, self.M), dtype=np.uint8)
+        _check(lib().cvtmi_opq_encode(self.h, _ptr(x_rot), C.c_int64(n), _ptr(lists), _ptr(codes)))
+        return lists, codes
+
+    # ---- index ----
+    def add_codes(self, codes, list_id=None, video_id=None):
+        n = codes.shape[0]
+        if _is_torch(codes):
+            _check(lib().cvtmi_opq_add_codes_dev(self.h, _ptr(codes), _ptr(list_id), _ptr(video_id), C.c_int64(n),
+                                                 _stream()))
+            return
+        codes = _np(codes, np.uint8)
+        l = None if list_id is None else _np(list_id, np.int32)
+        v = None if video_id is None else _np(video_id, np.int32)
+        _check(lib().cvtmi_opq_add_codes(self.h, _ptr(codes), _ptr(l), _ptr(v), C.c_int64(n)))
+
+    def reserve(self, n):
+        _check(lib().cvtmi_opq_reserve(self.h, C.c_int64(n)))
+
+    def reset(self):
+        _check(lib().cvtmi_opq_reset(self.h))
+
+    @property
+    def ntotal(self):
+        n = C.c_int64(0)
+        _check(lib().cvtmi_opq_ntotal(self.h, C.byref(n)))
+        return n.value
+
+    def set_id_base(self, base):
+        _check(lib().cvtmi_opq_set_id_base(self.h, C.c_int64(base)))
+
+    def get_entries(self):
+        n = self.ntotal
+        off = np.empty(self.coarseK + 1, dtype=np.int64)
+        vid = np.empty(n, dtype=np.int32)
+        codes = np.empty((n, self.M), dtype=np.uint8)
+        _check(lib().cvtmi_opq_get_entries(self.h, _ptr(off), _ptr(vid), _ptr(codes)))
+        tot = int(off[-1])
+        return off, vid[:tot], codes[:tot]
+
+    # ---- query ----
+    def lut(self, q_rot, list_id=None):
+        nq = q_rot.shape[0]
+        if _is_torch(q_rot):
+            import torch
+            out = torch.empty((nq, self.M, self.K), dtype=torch.float32, device=q_rot.device)
+            _check(lib().cvtmi_opq_lut_dev(self.h, _ptr(q_rot), C.c_int64(nq), _ptr(list_id), _ptr(out), _stream()))
+            return out
+        q_rot = _np(q_rot, np.float32)
+        l = None if list_id is None else _np(list_id, np.int32)
+        out = np.empty((nq, self.M, self.K), dtype=np.float32)
+        _check(lib().cvtmi_opq_lut(self.h, _ptr(q_rot), C.c_int64(nq), _ptr(l), _ptr(out)))
+        return out
+
+    def search(self, q, k, rotate=True, out=None):
+        nq = q.shape[0]
+        if _is_torch(q):
+            import torch
+            if out is None:
+                d = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+                i = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            else:
+                d, i = out
+            _check(lib().cvtmi_opq_search_dev(self.h, _ptr(q), C.c_int64(nq), C.c_int(1 if rotate else 0), C.c_int(k),
+                                              _ptr(d), _ptr(i), _stream()))
+            return d, i
+        q = _np(q, np.float32)
+        d = np.empty((nq, k), dtype=np.float32); i = np.empty((nq, k), dtype=np.int64)
+        _check(lib().cvtmi_opq_search(self.h, _ptr(q), C.c_int64(nq), C.c_int(1 if rotate else 0), C.c_int(k),
+                                      _ptr(d), _ptr(i)))
+        return d, i
+
+    def query_video(self, q, nprobe, img_num, rotate=True):
+        q = _np(q, np.float32)
+        ms = np.empty((q.shape[0], img_num), dtype=np.float32)
+        _check(lib().cvtmi_opq_query_video(self.h, _ptr(q), C.c_int64(q.shape[0]), C.c_int(1 if rotate else 0),
+                                           C.c_int(nprobe), C.c_int(img_num), _ptr(ms)))
+        return ms
+
+    def set_param(self, name, value):
+        _check(lib().cvtmi_opq_set_param(self.h, name.encode(), C.c_int64(value)))
+
+    def last_scan(self):
+        ms = C.c_float(0); b = C.c_int64(0); qt = C.c_int(0); sp = C.c_int(0)
+        _check(lib().cvtmi_opq_last_scan(self.h, C.byref(ms), C.byref(b), C.byref(qt), C.byref(sp)))
+        return dict(ms=ms.value, code_bytes=b.value, qtile=qt.value, splits=sp.value)
+
+
+def topk_merge(in_d, in_i, k):
+    """[nq][L][k] lists -> [nq][k]"""
+    nq, L, kk = in_d.shape
+    assert kk == k
+    if _is_torch(in_d):
+        import torch
+        d = torch.empty((nq, k), dtype=torch.float32, device=in_d.device)
+        i = torch.empty((nq, k), dtype=torch.int64, device=in_d.device)
+        _check(lib().cvtmi_topk_merge_dev(_ptr(in_d), _ptr(in_i), C.c_int64(nq), C.c_int(L), C.c_int(k), _ptr(d),
+                                          _ptr(i), _stream()))
+        return d, i
+    in_d = _np(in_d, np.float32); in_i = _np(in_i, np.int64)
+    d = np.empty((nq, k), dtype=np.float32); i = np.empty((nq, k), dtype=np.int64)
+    _check(lib().cvtmi_topk_merge(_ptr(in_d), _ptr(in_i), C.c_int64(nq), C.c_int(L), C.c_int(k), _ptr(d), _ptr(i)))
+    return d, i
+
+
+class FlatIndex:
+    """cvtmi_flat_t: exhaustive search over fp32 (IP, L2) or uint8 (L2) rows."""
+
+    def __init__(self, metric, D):
+        self.metric, self.D = metric, D
+        self.h = C.c_void_p(0)
+        _check(lib().cvtmi_flat_create(C.c_int(metric), C.c_int(D), C.byref(self.h)))
+
+    def close(self):
+        if self.h and self.h.value:
+            lib().cvtmi_flat_destroy(self.h)
+            self.h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _dt(self):
+        return np.uint8 if self.metric == 2 else np.float32
+
+    def add(self, x, labels=None):
+        if _is_torch(x):
+            _check(lib().cvtmi_flat_add_dev(self.h, _ptr(x), _ptr(labels), C.c_int64(x.shape[0]), _stream()))
+            return
+        x = _np(x, self._dt())
+        lab = None if labels is None else _np(labels, np.int64)
+        _check(lib().cvtmi_flat_add(self.h, _ptr(x), _ptr(lab), C.c_int64(x.shape[0])))
+
+    @property
+    def ntotal(self):
+        n = C.c_int64(0)
+        _check(lib().cvtmi_flat_ntotal(self.h, C.byref(n)))
+        return n.value
+
+    def search(self, q, k):
+        nq = q.shape[0]
+        if _is_torch(q):
+            import torch
+            d = torch.empty((nq, k), dtype=torch.int32 if self.metric == 2 else torch.float32, device=q.device)
+            i = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            _check(lib().cvtmi_flat_search_dev(self.h, _ptr(q), C.c_int64(nq), C.c_int(k), _ptr(d), _ptr(i), _stream()))
+            return d, i
+        q = _np(q, self._dt())
+        d = np.empty((nq, k), dtype=np.int32 if self.metric == 2 else np.float32)
+        i = np.empty((nq, k), dtype=np.int64)
+        _check(lib().cvtmi_flat_search(self.h, _ptr(q), C.c_int64(nq), C.c_int(k), _ptr(d), _ptr(i)))
+        return d, i
+
+
+def sq8_train(x, l2norm=True):
+    n, d = x.shape
+    if _is_torch(x):
+        import torch
+        vmin = torch.empty(d, dtype=torch.float32, device=x.device); vdiff = torch.empty_like(vmin)
+        _check(lib().cvtmi_sq8_train_dev(_ptr(x), C.c_int64(n), C.c_int(d), C.c_int(int(l2norm)), _ptr(vmin), _ptr(vdiff),
+                                         _stream()))
+        return vmin, vdiff
+    x = _np(x, np.float32)
+    vmin = np.empty(d, dtype=np.float32); vdiff = np.empty(d, dtype=np.float32)
+    _check(lib().cvtmi_sq8_train(_ptr(x), C.c_int64(n), C.c_int(d), C.c_int(int(l2norm)), _ptr(vmin), _ptr(vdiff)))
+    return vmin, vdiff
+
+
+def sq8_encode(vmin, vdiff, x, l2norm=True):
+    """Returns codes; x is normalised IN PLACE when l2norm (reference behaviour)."""
+    n, d = x.shape
+    if _is_torch(x):
+        import torch
+        codes = torch.empty((n, d), dtype=torch.uint8, device=x.device)
+        _check(lib().cvtmi_sq8_encode_dev(_ptr(vmin), _ptr(vdiff), C.c_int(d), _ptr(x), C.c_int64(n), C.c_int(int(l2norm)),
+                                          _ptr(codes), _stream()))
+        return codes
+    assert x.dtype == np.float32 and x.flags["C_CONTIGUOUS"]
+    vmin = _np(vmin, np.float32); vdiff = _np(vdiff, np.float32)
+    codes = np.empty((n, d), dtype=np.uint8)
+    _check(lib().cvtmi_sq8_encode(_ptr(vmin), _ptr(vdiff), C.c_int(d), _ptr(x), C.c_int64(n), C.c_int(int(l2norm)),
+                                  _ptr(codes)))
+    return codes
+
+
+def sq8_decode(vmin, vdiff, codes):
+    n, d = codes.shape
+    if _is_torch(codes):
+        import torch
+        x = torch.empty((n, d), dtype=torch.float32, device=codes.device)
+        _check(lib().cvtmi_sq8_decode_dev(_ptr(vmin), _ptr(vdiff), C.c_int(d), _ptr(codes), C.c_int64(n), _ptr(x), _stream()))
+        return x
+    codes = _np(codes, np.uint8); vmin = _np(vmin, np.float32); vdiff = _np(vdiff, np.float32)
+    x = np.empty((n, d), dtype=np.float32)
+    _check(lib().cvtmi_sq8_decode(_ptr(vmin), _ptr(vdiff), C.c_int(d), _ptr(codes), C.c_int64(n), _ptr(x)))
+    return x

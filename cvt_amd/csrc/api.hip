@@ -1,0 +1,834 @@
+// api.hip -- the C ABI of libcvtmi (include/cvtmi.h): handles, HBM residency, host<->device
+// staging for the host-pointer entry points, and dispatch to the HIP kernels.  No compute happens
+// on the CPU here; without a HIP device every entry fails with CVTMI_EHIP.
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <numeric>
+#include <vector>
+
+#include "kernels.h"
+
+namespace cvtmi {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+// growable device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return CVTMI_OK;
+        if (p) { CVTMI_HIP(hipFree(p)); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return fail(CVTMI_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        cap = bytes;
+        return CVTMI_OK;
+    }
+    // keeps the first `keep` bytes
+    int grow(size_t bytes, size_t keep, hipStream_t st)
+    {
+        if (bytes <= cap) return CVTMI_OK;
+        void *np = nullptr;
+        hipError_t e = hipMalloc(&np, bytes);
+        if (e != hipSuccess) return fail(CVTMI_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        if (p && keep) {
+            CVTMI_HIP(hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, st));
+            CVTMI_HIP(hipStreamSynchronize(st));
+        }
+        if (p) CVTMI_HIP(hipFree(p));
+        p = np; cap = bytes;
+        return CVTMI_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+template <class T>
+static int dev_alloc_copy(T **out, const T *host, size_t count)
+{
+    *out = nullptr;
+    if (count == 0) return CVTMI_OK;
+    CVTMI_HIP(hipMalloc((void **)out, count * sizeof(T)));
+    CVTMI_HIP(hipMemcpy(*out, host, count * sizeof(T), hipMemcpyHostToDevice));
+    return CVTMI_OK;
+}
+
+// temporary device allocation for the host-pointer entry points
+struct Tmp {
+    void *p = nullptr;
+    ~Tmp() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        if (bytes == 0) bytes = 16;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return fail(CVTMI_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        return CVTMI_OK;
+    }
+    int upload(const void *host, size_t bytes)
+    {
+        CVTMI_TRY(alloc(bytes));
+        if (bytes) CVTMI_HIP(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+        return CVTMI_OK;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace cvtmi
+
+using namespace cvtmi;
+
+// ================================================================ handles =====================
+struct cvtmi_opq_s {
+    int device = 0;
+    OpqModelDev m{};
+    float *d_coarse = nullptr, *d_books = nullptr, *d_R = nullptr;
+    int32_t *d_perm = nullptr;
+    // resident entries, insertion order
+    DevBuf codes, lists, videos;
+    int64_t n = 0;
+    bool has_lists = false, has_videos = false;
+    int64_t id_base = 0;
+    // list-ordered (CSR) copy for the per-video query path, built lazily
+    bool csr_valid = false;
+    DevBuf csr_codes, csr_videos, csr_off;
+    std::vector<int64_t> h_off;
+    std::vector<int32_t> h_csr_video;
+    std::vector<uint8_t> h_csr_codes;
+    // scratch
+    DevBuf s_qrot, s_part_d, s_part_id, s_probe;
+    // tuning / measurement
+    int p_splits = 0, p_qtile = 0, p_profile = 0;
+    static constexpr int kEvRing = 64;
+    hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
+    int ev_count = 0;  // scan launches recorded since the last cvtmi_opq_last_scan
+    int64_t last_bytes = 0;
+    int last_qt = 0, last_splits = 0;
+};
+
+struct cvtmi_flat_s {
+    int device = 0;
+    int metric = 0, D = 0;
+    size_t row_bytes = 0;
+    DevBuf data, labels;
+    int64_t n = 0;
+    bool identity = true;  // label == row
+    DevBuf s_part_d, s_part_id;
+};
+
+static int use_device(int dev)
+{
+    int cur = -1;
+    CVTMI_HIP(hipGetDevice(&cur));
+    if (cur != dev) CVTMI_HIP(hipSetDevice(dev));
+    return CVTMI_OK;
+}
+
+#define CHECK_H(h) \
+    if (!(h)) return fail(CVTMI_EINVAL, "%s: null handle", __func__); \
+    CVTMI_TRY(use_device((h)->device))
+
+extern "C" {
+
+// ================================================================ library =====================
+int cvtmi_version(void) { return CVTMI_VERSION; }
+const char *cvtmi_last_error(void) { return g_err.c_str(); }
+
+int cvtmi_device_count(int *count)
+{
+    if (!count) return fail(CVTMI_EINVAL, "cvtmi_device_count: null");
+    *count = 0;
+    CVTMI_HIP(hipGetDeviceCount(count));
+    return CVTMI_OK;
+}
+
+int cvtmi_set_device(int device)
+{
+    CVTMI_HIP(hipSetDevice(device));
+    return CVTMI_OK;
+}
+
+// ================================================================ OPQ =========================
+int cvtmi_opq_create(int D, int coarseK, int M, int K, const float *coarse, const float *books, const float *R,
+                     const int32_t *perm, cvtmi_opq_t *out)
+{
+    if (!out) return fail(CVTMI_EINVAL, "cvtmi_opq_create: null out");
+    *out = nullptr;
+    if (D < 1 || coarseK < 1 || M < 1 || K < 1 || !coarse || !books)
+        return fail(CVTMI_EINVAL, "cvtmi_opq_create: bad model shape D=%d coarseK=%d M=%d K=%d", D, coarseK, M, K);
+    if (D % M != 0) return fail(CVTMI_EINVAL, "cvtmi_opq_create: D=%d not divisible by M=%d", D, M);
+    if (M > 16) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_create: M=%d > 16 (IVFelem::PQindex[16])", M);
+    if (K > 256) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_create: K=%d > 256 (codes are uint8)", K);
+    if (R && perm) return fail(CVTMI_EINVAL, "cvtmi_opq_create: give R or perm, not both");
+    if (perm)
+        for (int i = 0; i < D; ++i)
+            if (perm[i] < 0 || perm[i] >= D) return fail(CVTMI_EINVAL, "cvtmi_opq_create: perm[%d]=%d out of range", i, perm[i]);
+    int dev = 0;
+    CVTMI_HIP(hipGetDevice(&dev));
+    cvtmi_opq_s *h = new (std::nothrow) cvtmi_opq_s();
+    if (!h) return fail(CVTMI_ENOMEM, "cvtmi_opq_create: out of host memory");
+    h->device = dev;
+    int rc = dev_alloc_copy(&h->d_coarse, coarse, (size_t)coarseK * D);
+    if (rc == CVTMI_OK) rc = dev_alloc_copy(&h->d_books, books, (size_t)D * K);
+    if (rc == CVTMI_OK && R) rc = dev_alloc_copy(&h->d_R, R, (size_t)D * D);
+    if (rc == CVTMI_OK && perm) rc = dev_alloc_copy(&h->d_perm, perm, (size_t)D);
+    if (rc != CVTMI_OK) { cvtmi_opq_destroy(h); return rc; }
+    h->m.D = D; h->m.coarseK = coarseK; h->m.M = M; h->m.K = K; h->m.step = D / M;
+    h->m.coarse = h->d_coarse; h->m.books = h->d_books; h->m.R = h->d_R; h->m.perm = h->d_perm;
+    *out = h;
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_destroy(cvtmi_opq_t h)
+{
+    if (!h) return CVTMI_OK;
+    (void)hipSetDevice(h->device);
+    if (h->d_coarse) (void)hipFree(h->d_coarse);
+    if (h->d_books) (void)hipFree(h->d_books);
+    if (h->d_R) (void)hipFree(h->d_R);
+    if (h->d_perm) (void)hipFree(h->d_perm);
+    h->codes.release(); h->lists.release(); h->videos.release();
+    h->csr_codes.release(); h->csr_videos.release(); h->csr_off.release();
+    h->s_qrot.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_probe.release();
+    for (int e = 0; e < cvtmi_opq_s::kEvRing; ++e) {
+        if (h->ev0[e]) (void)hipEventDestroy(h->ev0[e]);
+        if (h->ev1[e]) (void)hipEventDestroy(h->ev1[e]);
+    }
+    delete h;
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_rotate_dev(cvtmi_opq_t h, const float *x, int64_t n, float *y, void *stream)
+{
+    CHECK_H(h);
+    if (n < 0 || (n > 0 && (!x || !y))) return fail(CVTMI_EINVAL, "cvtmi_opq_rotate: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (h->m.perm) return launch_permute(h->m.perm, h->m.D, x, n, y, st);
+    if (h->m.R) return launch_rotate_gemm(h->m.R, h->m.D, x, n, y, st);
+    if (n > 0) CVTMI_HIP(hipMemcpyAsync(y, x, (size_t)n * h->m.D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_rotate(cvtmi_opq_t h, const float *x, int64_t n, float *y)
+{
+    CHECK_H(h);
+    if (n < 0 || (n > 0 && (!x || !y))) return fail(CVTMI_EINVAL, "cvtmi_opq_rotate: bad arguments");
+    if (n == 0) return CVTMI_OK;
+    const size_t bytes = (size_t)n * h->m.D * sizeof(float);
+    Tmp dx, dy;
+    CVTMI_TRY(dx.upload(x, bytes));
+    CVTMI_TRY(dy.alloc(bytes));
+    CVTMI_TRY(cvtmi_opq_rotate_dev(h, dx.as<float>(), n, dy.as<float>(), nullptr));
+    CVTMI_HIP(hipMemcpy(y, dy.p, bytes, hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_encode_dev(cvtmi_opq_t h, const float *x_rot, int64_t n, int32_t *list_id, uint8_t *codes, void *stream)
+{
+    CHECK_H(h);
+    if (n < 0 || (n > 0 && (!x_rot || !codes))) return fail(CVTMI_EINVAL, "cvtmi_opq_encode: bad arguments");
+    if (n == 0) return CVTMI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *lists = list_id;
+    if (h->m.coarseK > 1 && !lists) {
+        CVTMI_TRY(h->s_probe.reserve((size_t)n * sizeof(int32_t)));
+        lists = h->s_probe.as<int32_t>();
+    }
+    if (lists) CVTMI_TRY(launch_coarse_assign(h->m, x_rot, n, lists, st));
+    // coarseK == 1: every valid row lands in list 0; the residual is taken against centroid 0 either way
+    return launch_pq_encode(h->m, x_rot, n, h->m.coarseK > 1 ? lists : nullptr, codes, st);
+}
+
+int cvtmi_opq_encode(cvtmi_opq_t h, const float *x_rot, int64_t n, int32_t *list_id, uint8_t *codes)
+{
+    CHECK_H(h);
+    if (n < 0 || (n > 0 && (!x_rot || !codes))) return fail(CVTMI_EINVAL, "cvtmi_opq_encode: bad arguments");
+    if (n == 0) return CVTMI_OK;
+    Tmp dx, dl, dc;
+    CVTMI_TRY(dx.upload(x_rot, (size_t)n * h->m.D * sizeof(float)));
+    CVTMI_TRY(dl.alloc((size_t)n * sizeof(int32_t)));
+    CVTMI_TRY(dc.alloc((size_t)n * h->m.M));
+    CVTMI_TRY(cvtmi_opq_encode_dev(h, dx.as<float>(), n, dl.as<int32_t>(), dc.as<uint8_t>(), nullptr));
+    CVTMI_HIP(hipMemcpy(codes, dc.p, (size_t)n * h->m.M, hipMemcpyDeviceToHost));
+    if (list_id) CVTMI_HIP(hipMemcpy(list_id, dl.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
+static int opq_ensure_rows(cvtmi_opq_t h, int64_t total, hipStream_t st)
+{
+    const size_t M = (size_t)h->m.M;
+    if ((size_t)total * M > h->codes.cap) {
+        size_t want = std::max((size_t)total, (size_t)(h->codes.cap / M) * 2);
+        want = std::max(want, (size_t)4096);
+        CVTMI_TRY(h->codes.grow(want * M, (size_t)h->n * M, st));
+    }
+    if (h->has_lists && (size_t)total * 4 > h->lists.cap)
+        CVTMI_TRY(h->lists.grow(std::max((size_t)total, h->lists.cap / 2) * 4, (size_t)h->n * 4, st));
+    if (h->has_videos && (size_t)total * 4 > h->videos.cap)
+        CVTMI_TRY(h->videos.grow(std::max((size_t)total, h->videos.cap / 2) * 4, (size_t)h->n * 4, st));
+    return CVTMI_OK;
+}
+
+__global__ void iota_i32_kernel(int32_t *p, int64_t begin, int64_t end, int32_t value, int is_iota)
+{
+    for (int64_t i = begin + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < end; i += (int64_t)gridDim.x * kBlock)
+        p[i] = is_iota ? (int32_t)i : value;
+}
+
+static int fill_i32(int32_t *p, int64_t begin, int64_t end, int32_t value, int is_iota, hipStream_t st)
+{
+    if (end <= begin) return CVTMI_OK;
+    int64_t blocks = (end - begin + kBlock - 1) / kBlock;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(iota_i32_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, p, begin, end, value, is_iota);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+static int opq_add_common(cvtmi_opq_t h, const uint8_t *codes, const int32_t *list_id, const int32_t *video_id, int64_t n,
+                          hipMemcpyKind kind, hipStream_t st)
+{
+    if (n < 0 || (n > 0 && !codes)) return fail(CVTMI_EINVAL, "cvtmi_opq_add_codes: bad arguments");
+    if (n == 0) return CVTMI_OK;
+    if (!list_id && h->m.coarseK > 1) return fail(CVTMI_EINVAL, "cvtmi_opq_add_codes: list_id required when coarseK > 1");
+    const int64_t total = h->n + n;
+    if (total > 0xfffffffeLL) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_add_codes: more than 2^32-2 entries per handle");
+    // first explicit list / video ids: materialise the implicit prefix
+    if (list_id && h->m.coarseK > 1 && !h->has_lists) {
+        h->has_lists = true;
+        CVTMI_TRY(h->lists.grow((size_t)std::max<int64_t>(total, 4096) * 4, 0, st));
+        CVTMI_TRY(fill_i32(h->lists.as<int32_t>(), 0, h->n, 0, 0, st));
+    }
+    if (video_id && !h->has_videos) {
+        h->has_videos = true;
+        CVTMI_TRY(h->videos.grow((size_t)std::max<int64_t>(total, 4096) * 4, 0, st));
+        CVTMI_TRY(fill_i32(h->videos.as<int32_t>(), 0, h->n, 0, 1, st));
+    }
+    CVTMI_TRY(opq_ensure_rows(h, total, st));
+    const size_t M = (size_t)h->m.M;
+    CVTMI_HIP(hipMemcpyAsync(h->codes.as<uint8_t>() + (size_t)h->n * M, codes, (size_t)n * M, kind, st));
+    if (h->has_lists) {
+        if (list_id) CVTMI_HIP(hipMemcpyAsync(h->lists.as<int32_t>() + h->n, list_id, (size_t)n * 4, kind, st));
+        else CVTMI_TRY(fill_i32(h->lists.as<int32_t>(), h->n, total, 0, 0, st));
+    }
+    if (h->has_videos) {
+        if (video_id) CVTMI_HIP(hipMemcpyAsync(h->videos.as<int32_t>() + h->n, video_id, (size_t)n * 4, kind, st));
+        else CVTMI_TRY(fill_i32(h->videos.as<int32_t>(), h->n, total, 0, 1, st));
+    }
+    if (kind == hipMemcpyHostToDevice) CVTMI_HIP(hipStreamSynchronize(st));
+    h->n = total;
+    h->csr_valid = false;
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_add_codes(cvtmi_opq_t h, const uint8_t *codes, const int32_t *list_id, const int32_t *video_id, int64_t n)
+{
+    CHECK_H(h);
+    return opq_add_common(h, codes, list_id, video_id, n, hipMemcpyHostToDevice, nullptr);
+}
+
+int cvtmi_opq_add_codes_dev(cvtmi_opq_t h, const uint8_t *codes, const int32_t *list_id, const int32_t *video_id,
+                            int64_t n, void *stream)
+{
+    CHECK_H(h);
+    return opq_add_common(h, codes, list_id, video_id, n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+}
+
+int cvtmi_opq_reserve(cvtmi_opq_t h, int64_t n_total)
+{
+    CHECK_H(h);
+    if (n_total < 0 || n_total > 0xfffffffeLL) return fail(CVTMI_EINVAL, "cvtmi_opq_reserve: bad size");
+    return h->codes.grow((size_t)n_total * h->m.M, (size_t)h->n * h->m.M, nullptr);
+}
+
+int cvtmi_opq_ntotal(cvtmi_opq_t h, int64_t *n)
+{
+    if (!h || !n) return fail(CVTMI_EINVAL, "cvtmi_opq_ntotal: null");
+    *n = h->n;
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_reset(cvtmi_opq_t h)
+{
+    CHECK_H(h);
+    h->n = 0; h->has_lists = false; h->has_videos = false; h->csr_valid = false;
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_set_id_base(cvtmi_opq_t h, int64_t base)
+{
+    if (!h) return fail(CVTMI_EINVAL, "cvtmi_opq_set_id_base: null");
+    h->id_base = base;
+    return CVTMI_OK;
+}
+
+// list-ordered copy of the entries (stable: insertion order inside a list, as m_ivfList holds them)
+static int opq_build_csr(cvtmi_opq_t h)
+{
+    if (h->csr_valid) return CVTMI_OK;
+    CVTMI_HIP(hipDeviceSynchronize());
+    const int64_t n = h->n;
+    const int M = h->m.M, L = h->m.coarseK;
+    std::vector<uint8_t> codes((size_t)n * M);
+    std::vector<int32_t> lists((size_t)n, 0), videos((size_t)n);
+    if (n) CVTMI_HIP(hipMemcpy(codes.data(), h->codes.p, (size_t)n * M, hipMemcpyDeviceToHost));
+    if (n && h->has_lists) CVTMI_HIP(hipMemcpy(lists.data(), h->lists.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (n && h->has_videos) CVTMI_HIP(hipMemcpy(videos.data(), h->videos.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    else std::iota(videos.begin(), videos.end(), 0);
+    h->h_off.assign((size_t)L + 1, 0);
+    int64_t dropped = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (lists[i] >= 0 && lists[i] < L) h->h_off[(size_t)lists[i] + 1]++;
+        else ++dropped;  // list -1 (row no centroid could claim): the reference's .at(-1) throws; skipped here
+    }
+    for (int l = 0; l < L; ++l) h->h_off[(size_t)l + 1] += h->h_off[l];
+    const int64_t kept = n - dropped;
+    h->h_csr_codes.assign((size_t)kept * M, 0);
+    h->h_csr_video.assign((size_t)kept, 0);
+    std::vector<int64_t> cur(h->h_off.begin(), h->h_off.end() - 1);
+    for (int64_t i = 0; i < n; ++i) {
+        if (lists[i] < 0 || lists[i] >= L) continue;
+        const int64_t o = cur[lists[i]]++;
+        memcpy(&h->h_csr_codes[(size_t)o * M], &codes[(size_t)i * M], M);
+        h->h_csr_video[o] = videos[i];
+    }
+    CVTMI_TRY(h->csr_codes.reserve(std::max<size_t>((size_t)kept * M, 16)));
+    CVTMI_TRY(h->csr_videos.reserve(std::max<size_t>((size_t)kept * 4, 16)));
+    CVTMI_TRY(h->csr_off.reserve(((size_t)L + 1) * 8));
+    if (kept) {
+        CVTMI_HIP(hipMemcpy(h->csr_codes.p, h->h_csr_codes.data(), (size_t)kept * M, hipMemcpyHostToDevice));
+        CVTMI_HIP(hipMemcpy(h->csr_videos.p, h->h_csr_video.data(), (size_t)kept * 4, hipMemcpyHostToDevice));
+    }
+    CVTMI_HIP(hipMemcpy(h->csr_off.p, h->h_off.data(), ((size_t)L + 1) * 8, hipMemcpyHostToDevice));
+    h->csr_valid = true;
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_get_entries(cvtmi_opq_t h, int64_t *list_off, int32_t *video_id, uint8_t *codes)
+{
+    CHECK_H(h);
+    CVTMI_TRY(opq_build_csr(h));
+    if (list_off) memcpy(list_off, h->h_off.data(), h->h_off.size() * sizeof(int64_t));
+    if (video_id && !h->h_csr_video.empty()) memcpy(video_id, h->h_csr_video.data(), h->h_csr_video.size() * 4);
+    if (codes && !h->h_csr_codes.empty()) memcpy(codes, h->h_csr_codes.data(), h->h_csr_codes.size());
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_lut_dev(cvtmi_opq_t h, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut, void *stream)
+{
+    CHECK_H(h);
+    if (nq < 0 || (nq > 0 && (!q_rot || !lut))) return fail(CVTMI_EINVAL, "cvtmi_opq_lut: bad arguments");
+    return launch_lut(h->m, q_rot, nq, list_id, lut, (hipStream_t)stream);
+}
+
+int cvtmi_opq_lut(cvtmi_opq_t h, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut)
+{
+    CHECK_H(h);
+    if (nq < 0 || (nq > 0 && (!q_rot || !lut))) return fail(CVTMI_EINVAL, "cvtmi_opq_lut: bad arguments");
+    if (nq == 0) return CVTMI_OK;
+    if (list_id)
+        for (int64_t i = 0; i < nq; ++i)
+            if (list_id[i] >= h->m.coarseK) return fail(CVTMI_EINVAL, "cvtmi_opq_lut: list_id[%lld] out of range", (long long)i);
+    Tmp dq, dl, dt;
+    CVTMI_TRY(dq.upload(q_rot, (size_t)nq * h->m.D * sizeof(float)));
+    if (list_id) CVTMI_TRY(dl.upload(list_id, (size_t)nq * sizeof(int32_t)));
+    const size_t lb = (size_t)nq * h->m.M * h->m.K * sizeof(float);
+    CVTMI_TRY(dt.alloc(lb));
+    CVTMI_TRY(cvtmi_opq_lut_dev(h, dq.as<float>(), nq, list_id ? dl.as<int32_t>() : nullptr, dt.as<float>(), nullptr));
+    CVTMI_HIP(hipMemcpy(lut, dt.p, lb, hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int k, float *dist, int64_t *ids,
+                         void *stream)
+{
+    CHECK_H(h);
+    if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search: bad arguments");
+    if (h->m.coarseK != 1)
+        return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: exhaustive search needs coarseK == 1 (use cvtmi_opq_query_video)");
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: k=%d outside 1..128", k);
+    if (nq == 0) return CVTMI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const float *q_rot = q;
+    if (rotate && (h->m.perm || h->m.R)) {
+        CVTMI_TRY(h->s_qrot.reserve((size_t)nq * h->m.D * sizeof(float)));
+        CVTMI_TRY(cvtmi_opq_rotate_dev(h, q, nq, h->s_qrot.as<float>(), stream));
+        q_rot = h->s_qrot.as<float>();
+    }
+    const ScanPlan plan = plan_scan(h->m, h->n, nq, k, h->p_qtile, h->p_splits);
+    float *pd = dist;
+    int64_t *pi = ids;
+    if (plan.splits > 1) {
+        const size_t cnt = (size_t)nq * plan.splits * k;
+        CVTMI_TRY(h->s_part_d.reserve(cnt * sizeof(float)));
+        CVTMI_TRY(h->s_part_id.reserve(cnt * sizeof(int64_t)));
+        pd = h->s_part_d.as<float>();
+        pi = h->s_part_id.as<int64_t>();
+    }
+    const int slot = h->ev_count % cvtmi_opq_s::kEvRing;
+    if (h->p_profile) {
+        if (!h->ev0[slot]) { CVTMI_HIP(hipEventCreate(&h->ev0[slot])); CVTMI_HIP(hipEventCreate(&h->ev1[slot])); }
+        CVTMI_HIP(hipEventRecord(h->ev0[slot], st));
+    }
+    CVTMI_TRY(launch_adc_scan(h->m, h->codes.as<uint8_t>(), h->n, h->id_base, q_rot, nq, k, plan, pd, pi, st));
+    if (h->p_profile) {
+        CVTMI_HIP(hipEventRecord(h->ev1[slot], st));
+        h->ev_count++;
+        const int64_t groups = (nq + plan.qtile - 1) / plan.qtile;
+        h->last_bytes = groups * h->n * h->m.M;  // passes x rows x M code bytes
+        h->last_qt = plan.qtile; h->last_splits = plan.splits;
+    }
+    if (plan.splits > 1) CVTMI_TRY(launch_topk_merge(pd, pi, nq, plan.splits, k, dist, ids, st));
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int k, float *dist, int64_t *ids)
+{
+    CHECK_H(h);
+    if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search: bad arguments");
+    if (nq == 0) return CVTMI_OK;
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: k=%d outside 1..128", k);
+    Tmp dq, dd, di;
+    CVTMI_TRY(dq.upload(q, (size_t)nq * h->m.D * sizeof(float)));
+    CVTMI_TRY(dd.alloc((size_t)nq * k * sizeof(float)));
+    CVTMI_TRY(di.alloc((size_t)nq * k * sizeof(int64_t)));
+    CVTMI_TRY(cvtmi_opq_search_dev(h, dq.as<float>(), nq, rotate, k, dd.as<float>(), di.as<int64_t>(), nullptr));
+    CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
+    CVTMI_HIP(hipMemcpy(ids, di.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_query_video(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int nprobe, int img_num,
+                          float *match_score)
+{
+    CHECK_H(h);
+    if (nq < 0 || img_num < 0 || (nq > 0 && img_num > 0 && (!q || !match_score)))
+        return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: bad arguments");
+    if (nprobe < 1) return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: nprobe=%d", nprobe);
+    if (nq == 0 || img_num == 0) return CVTMI_OK;
+    if (nprobe > h->m.coarseK) nprobe = h->m.coarseK;  // the reference pops an empty heap here (UB)
+    CVTMI_TRY(opq_build_csr(h));
+    for (int32_t v : h->h_csr_video)
+        if (v < 0 || v >= img_num) return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: video id %d outside img_num=%d", v, img_num);
+    Tmp dq, dr, dp, dm;
+    CVTMI_TRY(dq.upload(q, (size_t)nq * h->m.D * sizeof(float)));
+    const float *q_rot = dq.as<float>();
+    if (rotate && (h->m.perm || h->m.R)) {
+        CVTMI_TRY(dr.alloc((size_t)nq * h->m.D * sizeof(float)));
+        CVTMI_TRY(cvtmi_opq_rotate_dev(h, dq.as<float>(), nq, dr.as<float>(), nullptr));
+        q_rot = dr.as<float>();
+    }
+    CVTMI_TRY(dp.alloc((size_t)nq * nprobe * sizeof(int32_t)));
+    CVTMI_TRY(dm.alloc((size_t)nq * img_num * sizeof(float)));
+    CVTMI_TRY(launch_coarse_probe(h->m, q_rot, nq, nprobe, dp.as<int32_t>(), nullptr));
+    CVTMI_TRY(launch_query_video(h->m, q_rot, nq, nprobe, dp.as<int32_t>(), h->csr_off.as<int64_t>(),
+                                 h->csr_codes.as<uint8_t>(), h->csr_videos.as<int32_t>(), img_num, dm.as<float>(), nullptr));
+    CVTMI_HIP(hipMemcpy(match_score, dm.p, (size_t)nq * img_num * sizeof(float), hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value)
+{
+    if (!h || !name) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: null");
+    if (!strcmp(name, "splits")) { h->p_splits = (int)value; return CVTMI_OK; }
+    if (!strcmp(name, "qtile")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+            return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: qtile must be 0, 1, 2, 4 or 8");
+        h->p_qtile = (int)value;
+        return CVTMI_OK;
+    }
+    if (!strcmp(name, "profile")) { h->p_profile = value != 0; return CVTMI_OK; }
+    return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: unknown parameter '%s'", name);
+}
+
+int cvtmi_opq_last_scan(cvtmi_opq_t h, float *ms, int64_t *code_bytes, int *qtile, int *splits)
+{
+    CHECK_H(h);
+    if (h->ev_count == 0) return fail(CVTMI_ESTATE, "cvtmi_opq_last_scan: no profiled search since the last call");
+    const int cnt = h->ev_count < cvtmi_opq_s::kEvRing ? h->ev_count : cvtmi_opq_s::kEvRing;
+    double sum = 0.0;
+    for (int e = 0; e < cnt; ++e) {
+        CVTMI_HIP(hipEventSynchronize(h->ev1[e]));
+        float t = 0.f;
+        CVTMI_HIP(hipEventElapsedTime(&t, h->ev0[e], h->ev1[e]));
+        sum += t;
+    }
+    h->ev_count = 0;
+    if (ms) *ms = (float)(sum / cnt);
+    if (code_bytes) *code_bytes = h->last_bytes;
+    if (qtile) *qtile = h->last_qt;
+    if (splits) *splits = h->last_splits;
+    return CVTMI_OK;
+}
+
+// ================================================================ merge =======================
+int cvtmi_topk_merge_dev(const float *in_dist, const int64_t *in_ids, int64_t nq, int L, int k, float *dist, int64_t *ids,
+                         void *stream)
+{
+    if (nq < 0 || L < 1 || (nq > 0 && (!in_dist || !in_ids || !dist || !ids)))
+        return fail(CVTMI_EINVAL, "cvtmi_topk_merge: bad arguments");
+    return launch_topk_merge(in_dist, in_ids, nq, L, k, dist, ids, (hipStream_t)stream);
+}
+
+int cvtmi_topk_merge(const float *in_dist, const int64_t *in_ids, int64_t nq, int L, int k, float *dist, int64_t *ids)
+{
+    if (nq < 0 || L < 1 || k < 1 || (nq > 0 && (!in_dist || !in_ids || !dist || !ids)))
+        return fail(CVTMI_EINVAL, "cvtmi_topk_merge: bad arguments");
+    if (nq == 0) return CVTMI_OK;
+    const size_t cnt = (size_t)nq * L * k, oc = (size_t)nq * k;
+    Tmp a, b, c, d;
+    CVTMI_TRY(a.upload(in_dist, cnt * sizeof(float)));
+    CVTMI_TRY(b.upload(in_ids, cnt * sizeof(int64_t)));
+    CVTMI_TRY(c.alloc(oc * sizeof(float)));
+    CVTMI_TRY(d.alloc(oc * sizeof(int64_t)));
+    CVTMI_TRY(cvtmi_topk_merge_dev(a.as<float>(), b.as<int64_t>(), nq, L, k, c.as<float>(), d.as<int64_t>(), nullptr));
+    CVTMI_HIP(hipMemcpy(dist, c.p, oc * sizeof(float), hipMemcpyDeviceToHost));
+    CVTMI_HIP(hipMemcpy(ids, d.p, oc * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
+// ================================================================ flat ========================
+int cvtmi_flat_create(int metric, int D, cvtmi_flat_t *out)
+{
+    if (!out) return fail(CVTMI_EINVAL, "cvtmi_flat_create: null out");
+    *out = nullptr;
+    if (metric != CVTMI_METRIC_IP && metric != CVTMI_METRIC_L2F && metric != CVTMI_METRIC_L2U8)
+        return fail(CVTMI_EINVAL, "cvtmi_flat_create: unknown metric %d", metric);
+    if (D < 1 || D > 4096) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_create: D=%d outside 1..4096", D);
+    int dev = 0;
+    CVTMI_HIP(hipGetDevice(&dev));
+    cvtmi_flat_s *h = new (std::nothrow) cvtmi_flat_s();
+    if (!h) return fail(CVTMI_ENOMEM, "cvtmi_flat_create: out of host memory");
+    h->device = dev; h->metric = metric; h->D = D;
+    h->row_bytes = metric == CVTMI_METRIC_L2U8 ? (size_t)D : (size_t)D * sizeof(float);
+    *out = h;
+    return CVTMI_OK;
+}
+
+int cvtmi_flat_destroy(cvtmi_flat_t h)
+{
+    if (!h) return CVTMI_OK;
+    (void)hipSetDevice(h->device);
+    h->data.release(); h->labels.release(); h->s_part_d.release(); h->s_part_id.release();
+    delete h;
+    return CVTMI_OK;
+}
+
+__global__ void iota_i64_kernel(int64_t *p, int64_t begin, int64_t end)
+{
+    for (int64_t i = begin + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < end; i += (int64_t)gridDim.x * kBlock) p[i] = i;
+}
+
+static int flat_add_common(cvtmi_flat_t h, const void *x, const int64_t *labels, int64_t n, hipMemcpyKind kind,
+                           hipStream_t st)
+{
+    if (n < 0 || (n > 0 && !x)) return fail(CVTMI_EINVAL, "cvtmi_flat_add: bad arguments");
+    if (n == 0) return CVTMI_OK;
+    const int64_t total = h->n + n;
+    if (total > 0xfffffffeLL) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_add: more than 2^32-2 rows per handle");
+    bool explicit_labels = labels != nullptr;
+    if (explicit_labels && kind == hipMemcpyHostToDevice && h->identity) {
+        bool same = true;
+        for (int64_t i = 0; i < n && same; ++i) same = labels[i] == h->n + i;
+        if (same) explicit_labels = false;
+    }
+    if ((size_t)total * h->row_bytes > h->data.cap) {
+        size_t rows = std::max<size_t>((size_t)total, (h->data.cap / h->row_bytes) * 2);
+        rows = std::max<size_t>(rows, 1024);
+        CVTMI_TRY(h->data.grow(rows * h->row_bytes, (size_t)h->n * h->row_bytes, st));
+    }
+    if (explicit_labels && h->identity) {
+        h->identity = false;
+        CVTMI_TRY(h->labels.grow((size_t)std::max<int64_t>(total, 1024) * 8, 0, st));
+        if (h->n) {
+            hipLaunchKernelGGL(iota_i64_kernel, dim3(1024), dim3(kBlock), 0, st, h->labels.as<int64_t>(), (int64_t)0, h->n);
+            CVTMI_HIP(hipGetLastError());
+        }
+    }
+    if (!h->identity && (size_t)total * 8 > h->labels.cap)
+        CVTMI_TRY(h->labels.grow(std::max<size_t>((size_t)total, h->labels.cap / 4) * 8, (size_t)h->n * 8, st));
+    CVTMI_HIP(hipMemcpyAsync(h->data.as<uint8_t>() + (size_t)h->n * h->row_bytes, x, (size_t)n * h->row_bytes, kind, st));
+    if (!h->identity) {
+        if (labels) CVTMI_HIP(hipMemcpyAsync(h->labels.as<int64_t>() + h->n, labels, (size_t)n * 8, kind, st));
+        else {
+            hipLaunchKernelGGL(iota_i64_kernel, dim3(1024), dim3(kBlock), 0, st, h->labels.as<int64_t>(), h->n, total);
+            CVTMI_HIP(hipGetLastError());
+        }
+    }
+    if (kind == hipMemcpyHostToDevice) CVTMI_HIP(hipStreamSynchronize(st));
+    h->n = total;
+    return CVTMI_OK;
+}
+
+int cvtmi_flat_add(cvtmi_flat_t h, const void *x, const int64_t *labels, int64_t n)
+{
+    CHECK_H(h);
+    return flat_add_common(h, x, labels, n, hipMemcpyHostToDevice, nullptr);
+}
+
+int cvtmi_flat_add_dev(cvtmi_flat_t h, const void *x, const int64_t *labels, int64_t n, void *stream)
+{
+    CHECK_H(h);
+    return flat_add_common(h, x, labels, n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+}
+
+int cvtmi_flat_ntotal(cvtmi_flat_t h, int64_t *n)
+{
+    if (!h || !n) return fail(CVTMI_EINVAL, "cvtmi_flat_ntotal: null");
+    *n = h->n;
+    return CVTMI_OK;
+}
+
+int cvtmi_flat_reset(cvtmi_flat_t h)
+{
+    CHECK_H(h);
+    h->n = 0; h->identity = true;
+    return CVTMI_OK;
+}
+
+int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels, void *stream)
+{
+    CHECK_H(h);
+    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_flat_search: bad arguments");
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search: k=%d outside 1..128", k);
+    if (nq == 0) return CVTMI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int qt = flat_qtile(nq);
+    const int splits = flat_plan_splits(h->n, nq, qt);
+    float *pd = reinterpret_cast<float *>(dist);
+    int64_t *pi = labels;
+    if (splits > 1) {
+        const size_t cnt = (size_t)nq * splits * k;
+        CVTMI_TRY(h->s_part_d.reserve(cnt * sizeof(float)));
+        CVTMI_TRY(h->s_part_id.reserve(cnt * sizeof(int64_t)));
+        pd = h->s_part_d.as<float>();
+        pi = h->s_part_id.as<int64_t>();
+    }
+    CVTMI_TRY(launch_flat_search(h->metric, h->D, h->data.p, h->n, q, nq, k, qt, splits, pd, pi, st));
+    if (splits > 1) CVTMI_TRY(launch_topk_merge(pd, pi, nq, splits, k, reinterpret_cast<float *>(dist), labels, st));
+    if (!h->identity) CVTMI_TRY(launch_gather_labels(labels, nq * k, h->labels.as<int64_t>(), st));
+    return CVTMI_OK;
+}
+
+int cvtmi_flat_search(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels)
+{
+    CHECK_H(h);
+    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_flat_search: bad arguments");
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search: k=%d outside 1..128", k);
+    if (nq == 0) return CVTMI_OK;
+    Tmp dq, dd, di;
+    CVTMI_TRY(dq.upload(q, (size_t)nq * h->row_bytes));
+    CVTMI_TRY(dd.alloc((size_t)nq * k * 4));
+    CVTMI_TRY(di.alloc((size_t)nq * k * 8));
+    CVTMI_TRY(cvtmi_flat_search_dev(h, dq.p, nq, k, dd.p, di.as<int64_t>(), nullptr));
+    CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    CVTMI_HIP(hipMemcpy(labels, di.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
+// ================================================================ SQ8 =========================
+int cvtmi_sq8_train_dev(const float *x, int64_t n, int d, int l2norm, float *vmin, float *vdiff, void *stream)
+{
+    if (n < 0 || d < 1 || !vmin || !vdiff || (n > 0 && !x)) return fail(CVTMI_EINVAL, "cvtmi_sq8_train: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    Tmp den, keys;
+    if (l2norm && n > 0) {
+        CVTMI_TRY(den.alloc((size_t)n * sizeof(float)));
+        CVTMI_TRY(launch_sq8_rownorm(x, n, d, den.as<float>(), st));
+    }
+    CVTMI_TRY(keys.alloc((size_t)d * 2 * sizeof(uint32_t)));
+    CVTMI_TRY(launch_sq8_train(x, n, d, (l2norm && n > 0) ? den.as<float>() : nullptr, keys.as<uint32_t>(),
+                               keys.as<uint32_t>() + d, vmin, vdiff, st));
+    CVTMI_HIP(hipStreamSynchronize(st));  // the temporaries die with this frame
+    return CVTMI_OK;
+}
+
+int cvtmi_sq8_train(const float *x, int64_t n, int d, int l2norm, float *vmin, float *vdiff)
+{
+    if (n < 0 || d < 1 || !vmin || !vdiff || (n > 0 && !x)) return fail(CVTMI_EINVAL, "cvtmi_sq8_train: bad arguments");
+    Tmp dx, dmin, ddiff;
+    CVTMI_TRY(dx.upload(x, (size_t)n * d * sizeof(float)));
+    CVTMI_TRY(dmin.alloc((size_t)d * sizeof(float)));
+    CVTMI_TRY(ddiff.alloc((size_t)d * sizeof(float)));
+    CVTMI_TRY(cvtmi_sq8_train_dev(dx.as<float>(), n, d, l2norm, dmin.as<float>(), ddiff.as<float>(), nullptr));
+    CVTMI_HIP(hipMemcpy(vmin, dmin.p, (size_t)d * sizeof(float), hipMemcpyDeviceToHost));
+    CVTMI_HIP(hipMemcpy(vdiff, ddiff.p, (size_t)d * sizeof(float), hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
+int cvtmi_sq8_encode_dev(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm, uint8_t *codes,
+                         void *stream)
+{
+    if (n < 0 || d < 1 || !vmin || !vdiff || (n > 0 && (!x || !codes))) return fail(CVTMI_EINVAL, "cvtmi_sq8_encode: bad arguments");
+    if (n == 0) return CVTMI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Tmp den;
+    if (l2norm) {
+        CVTMI_TRY(den.alloc((size_t)n * sizeof(float)));
+        CVTMI_TRY(launch_sq8_rownorm(x, n, d, den.as<float>(), st));
+    }
+    CVTMI_TRY(launch_sq8_encode(vmin, vdiff, d, x, n, l2norm ? den.as<float>() : nullptr, 1, codes, st));
+    if (l2norm) CVTMI_HIP(hipStreamSynchronize(st));
+    return CVTMI_OK;
+}
+
+int cvtmi_sq8_encode(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm, uint8_t *codes)
+{
+    if (n < 0 || d < 1 || !vmin || !vdiff || (n > 0 && (!x || !codes))) return fail(CVTMI_EINVAL, "cvtmi_sq8_encode: bad arguments");
+    if (n == 0) return CVTMI_OK;
+    Tmp dmin, ddiff, dx, dc;
+    CVTMI_TRY(dmin.upload(vmin, (size_t)d * sizeof(float)));
+    CVTMI_TRY(ddiff.upload(vdiff, (size_t)d * sizeof(float)));
+    CVTMI_TRY(dx.upload(x, (size_t)n * d * sizeof(float)));
+    CVTMI_TRY(dc.alloc((size_t)n * d));
+    CVTMI_TRY(cvtmi_sq8_encode_dev(dmin.as<float>(), ddiff.as<float>(), d, dx.as<float>(), n, l2norm, dc.as<uint8_t>(), nullptr));
+    CVTMI_HIP(hipMemcpy(codes, dc.p, (size_t)n * d, hipMemcpyDeviceToHost));
+    if (l2norm) CVTMI_HIP(hipMemcpy(x, dx.p, (size_t)n * d * sizeof(float), hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
+int cvtmi_sq8_decode_dev(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x, void *stream)
+{
+    if (n < 0 || d < 1 || !vmin || !vdiff || (n > 0 && (!x || !codes))) return fail(CVTMI_EINVAL, "cvtmi_sq8_decode: bad arguments");
+    return launch_sq8_decode(vmin, vdiff, d, codes, n, x, (hipStream_t)stream);
+}
+
+int cvtmi_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x)
+{
+    if (n < 0 || d < 1 || !vmin || !vdiff || (n > 0 && (!x || !codes))) return fail(CVTMI_EINVAL, "cvtmi_sq8_decode: bad arguments");
+    if (n == 0) return CVTMI_OK;
+    Tmp dmin, ddiff, dx, dc;
+    CVTMI_TRY(dmin.upload(vmin, (size_t)d * sizeof(float)));
+    CVTMI_TRY(ddiff.upload(vdiff, (size_t)d * sizeof(float)));
+    CVTMI_TRY(dc.upload(codes, (size_t)n * d));
+    CVTMI_TRY(dx.alloc((size_t)n * d * sizeof(float)));
+    CVTMI_TRY(cvtmi_sq8_decode_dev(dmin.as<float>(), ddiff.as<float>(), d, dc.as<uint8_t>(), n, dx.as<float>(), nullptr));
+    CVTMI_HIP(hipMemcpy(x, dx.p, (size_t)n * d * sizeof(float), hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+// block_topk.h -- streaming "k smallest (key, payload)" selection shared by one workgroup.
+//
+// Semantics to reproduce: std::partial_sort_copy on pair<float,uint> (opq/src/common.h:25-37)
+// and the max-heap of pair<dist,label> in BruteforceSearch::searchKnn
+// (brute_force_search/src/brutoforce.hpp:73-93): the k smallest pairs in LEXICOGRAPHIC
+// (distance, id) order.
+//
+// Design (MI355X): candidates are 64-bit words (ordered-distance key << 32 | payload) appended to a
+// per-query LDS buffer with one LDS atomic per candidate.  A candidate is appended only if its key
+// beats the current k-th key ("thr"), so after a short warm-up almost no row reaches the buffer and
+// the scan kernels stay bound by their data path, not by selection.  When a buffer passes TRIG
+// entries the workgroup sorts it in LDS (bitonic network, all comparators ascending so the
+// power-of-two padding never has to be stored), keeps the k smallest and tightens thr.
+//
+// Tie rule: payloads must grow with the id order and tiles must be fed in ascending payload order.
+// Then a later candidate whose key EQUALS thr can never displace the current k-th entry (it has a
+// larger id), so the fast path compares with '<'.  Only candidates of the tile that overflowed the
+// buffer are retried with '<=', because those may precede entries already stored.
+#pragma once
+#include "common.h"
+
+namespace cvtmi {
+
+template <int QT, int CAP>
+struct TopKShared {
+    unsigned long long buf[QT][CAP];
+    int cnt[QT];
+    uint32_t thr[QT];
+    int flag[4];  // [0..2] rotating "compaction wanted" flags, [3] "some candidate still pending"
+};
+
+template <int QT, int CAP>
+__device__ __forceinline__ void topk_init(TopKShared<QT, CAP> &s)
+{
+    if (threadIdx.x < QT) {
+        s.cnt[threadIdx.x] = 0;
+        s.thr[threadIdx.x] = KEY_MAX;
+    }
+    if (threadIdx.x < 4) s.flag[threadIdx.x] = 0;
+}
+
+// Append one candidate.  Returns false when the buffer was full (caller keeps it pending).
+template <int QT, int CAP, int TRIG>
+__device__ __forceinline__ bool topk_push(TopKShared<QT, CAP> &s, int q, uint32_t key, uint32_t payload,
+                                          bool &want_compact)
+{
+    const int pos = atomicAdd(&s.cnt[q], 1);
+    if (pos >= TRIG) want_compact = true;
+    if (pos < CAP) {
+        s.buf[q][pos] = ((unsigned long long)key << 32) | payload;
+        return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ void lds_cmpx(unsigned long long *b, int i, int j)
+{
+    const unsigned long long x = b[i], y = b[j];
+    if (x > y) {
+        b[i] = y;
+        b[j] = x;
+    }
+}
+
+// Sort every query's buffer, keep the k smallest entries, refresh thr.  Must be called by all
+// kBlock threads after a barrier that made the pushes visible; ends with a barrier.
+template <int QT, int CAP>
+__device__ void topk_compact(TopKShared<QT, CAP> &s, int k)
+{
+    constexpr int NW = kBlock / 64;
+    constexpr int G = QT < NW ? QT : NW;   // queries sorted concurrently
+    constexpr int TPQ = kBlock / G;        // threads cooperating on one query
+    constexpr int ROUNDS = (QT + G - 1) / G;
+
+    // uniform network size: smallest power of two covering the fullest buffer
+    int nmax = 0;
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        int c = s.cnt[q];
+        c = c < CAP ? c : CAP;
+        nmax = c > nmax ? c : nmax;
+    }
+    int np = 2;
+    while (np < nmax) np <<= 1;
+    const int lim = np < CAP ? np : CAP;  // stored slots that take part
+
+    const int grp = threadIdx.x / TPQ, t = threadIdx.x % TPQ;
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int q = rd * G + grp;
+        const bool act = q < QT;
+        unsigned long long *b = s.buf[act ? q : 0];
+        int n = 0;
+        if (act) {
+            n = s.cnt[q];
+            n = n < CAP ? n : CAP;
+            for (int i = n + t; i < lim; i += TPQ) b[i] = ~0ull;
+        }
+        __syncthreads();
+        for (int size = 2; size <= np; size <<= 1) {
+            const int half = size >> 1;
+            if (act) {
+                for (int c = t; c < (np >> 1); c += TPQ) {
+                    const int blk = c / half, off = c - blk * half;
+                    const int i = blk * size + off, j = blk * size + size - 1 - off;
+                    if (j < lim) lds_cmpx(b, i, j);
+                }
+            }
+            __syncthreads();
+            for (int stride = half >> 1; stride >= 1; stride >>= 1) {
+                if (act) {
+                    for (int c = t; c < (np >> 1); c += TPQ) {
+                        const int blk = c / stride, off = c - blk * stride;
+                        const int i = blk * 2 * stride + off, j = i + stride;
+                        if (j < lim) lds_cmpx(b, i, j);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (act && t == 0) {
+            s.cnt[q] = n < k ? n : k;
+            s.thr[q] = (n >= k) ? (uint32_t)(b[k - 1] >> 32) : KEY_MAX;
+        }
+        __syncthreads();
+    }
+}
+
+// Per-tile protocol.  Every thread holds R x QT candidate keys (KEY_MAX = not a candidate) and R
+// payloads.  `tile` is the workgroup-uniform tile counter.  One barrier on the fast path.
+template <int QT, int R, int CAP, int TRIG>
+__device__ __forceinline__ void topk_tile(TopKShared<QT, CAP> &s, int k, int tile, const uint32_t (&key)[R][QT],
+                                          const uint32_t (&pay)[R])
+{
+    uint32_t thr[QT];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) thr[q] = s.thr[q];
+    bool want = false;
+    uint32_t pending = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            if (key[r][q] < thr[q]) {
+                if (!topk_push<QT, CAP, TRIG>(s, q, key[r][q], pay[r], want)) pending |= 1u << (r * QT + q);
+            }
+        }
+    }
+    const int f = tile % 3;
+    if (want) s.flag[f] = 1;
+    __syncthreads();
+    if (s.flag[f]) {  // workgroup-uniform
+        for (;;) {
+            topk_compact(s, k);
+            if (pending) s.flag[3] = 1;
+            __syncthreads();
+            const int again = s.flag[3];
+            __syncthreads();
+            if (!again) break;
+            if (threadIdx.x == 0) s.flag[3] = 0;
+#pragma unroll
+            for (int q = 0; q < QT; ++q) thr[q] = s.thr[q];
+            uint32_t still = 0;
+            bool dummy = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+                    const uint32_t bit = 1u << (r * QT + q);
+                    if ((pending & bit) && key[r][q] <= thr[q] && key[r][q] != KEY_MAX) {
+                        if (!topk_push<QT, CAP, TRIG>(s, q, key[r][q], pay[r], dummy)) still |= bit;
+                    }
+                }
+            }
+            pending = still;
+            __syncthreads();
+        }
+    }
+    // flag (tile-1)%3 was last read before this tile's barrier: safe to clear for tile+2
+    if (threadIdx.x == 0) s.flag[(tile + 2) % 3] = 0;
+}
+
+}  // namespace cvtmi

@@ -1,0 +1,333 @@
+// flat.hip -- exhaustive nearest-neighbour search over un-compressed rows:
+// hnswlib::BruteforceSearch<dist_t>::searchKnn (brute_force_search/src/brutoforce.hpp:73-93) with
+//   InnerProductSpace (space_ip.hpp:211-239)      dist = 1 - sum q*x          fp32
+//   L2Space           (space_l2.h:153-184)         dist = sum (q-x)^2          fp32
+//   L2SpaceI          (space_l2.h:186-245)         dist = sum (q-x)^2          uint8 -> int32
+//
+// Summation order (so that fp32 distances are BIT-EXACT against the reference as its own build
+// flags compile it, see oracle/Makefile):
+//   IP,  D % 4 == 0 : the SSE branch (space_ip.hpp:84-131, :168-206): four lane accumulators,
+//                     acc[l] += q[i+l]*x[i+l] (separate mul/add), result 1 - (((a0+a1)+a2)+a3)
+//   L2F, D % 16 == 0: the AVX branch hard-enabled by `#define USE_AVX` (space_l2.h:12, :46-73):
+//                     eight lane accumulators, summed left to right
+//   L2F, D % 4 == 0 : L2SqrSIMD4Ext (:123-151): four lanes
+//   otherwise       : the scalar loops (space_ip.hpp:25-34, space_l2.h:26-37)
+//   uint8           : exact integers, any order; groups of four bytes, dim % 4 tail dropped (:198-215)
+//
+// Round-1 mapping: one lane per row, QT queries staged in LDS share every row read; selection by
+// the shared LDS top-k (block_topk.h).  The uint8 metric runs on v_dot4_u32_u8:
+// sum (q-x)^2 = |q|^2 + |x|^2 - 2<q,x>, all three exact in 32-bit integers (<= 512*255^2).
+#include "block_topk.h"
+#include "kernels.h"
+
+namespace cvtmi {
+
+constexpr int FLAT_CAP = 384;
+constexpr int FLAT_TRIG = 256;
+constexpr int FLAT_R = 2;
+
+struct FlatArgs {
+    const void *data;
+    int64_t n;
+    const void *q;
+    int nq;
+    int D, k, splits;
+    int64_t rows_per_split;
+    float *part_d;
+    int64_t *part_id;
+};
+
+// LANES = 1 (scalar loop), 4 or 8;  IP = inner product, else squared L2
+template <bool IP, int LANES, int QT>
+__device__ __forceinline__ void dist_f32_row(const float *__restrict__ row, const float *qs, int D, float (&out)[QT])
+{
+    float acc[QT][LANES];
+#pragma unroll
+    for (int q = 0; q < QT; ++q)
+#pragma unroll
+        for (int l = 0; l < LANES; ++l) acc[q][l] = 0.0f;
+    if constexpr (LANES == 1) {
+        for (int i = 0; i < D; ++i) {
+            const float xv = row[i];
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                if constexpr (IP) {
+                    acc[q][0] = __fadd_rn(acc[q][0], __fmul_rn(qs[q * D + i], xv));
+                } else {
+                    const float t = __fsub_rn(qs[q * D + i], xv);
+                    acc[q][0] = __fadd_rn(acc[q][0], __fmul_rn(t, t));
+                }
+            }
+        }
+    } else {
+        for (int i = 0; i < D; i += LANES) {
+            float xv[LANES];
+#pragma unroll
+            for (int l4 = 0; l4 < LANES / 4; ++l4) {
+                const float4 v = *reinterpret_cast<const float4 *>(row + i + 4 * l4);
+                xv[4 * l4 + 0] = v.x; xv[4 * l4 + 1] = v.y; xv[4 * l4 + 2] = v.z; xv[4 * l4 + 3] = v.w;
+            }
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+#pragma unroll
+                for (int l = 0; l < LANES; ++l) {
+                    if constexpr (IP) {
+                        acc[q][l] = __fadd_rn(acc[q][l], __fmul_rn(qs[q * D + i + l], xv[l]));
+                    } else {
+                        const float t = __fsub_rn(qs[q * D + i + l], xv[l]);
+                        acc[q][l] = __fadd_rn(acc[q][l], __fmul_rn(t, t));
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        float s = acc[q][0];
+#pragma unroll
+        for (int l = 1; l < LANES; ++l) s = __fadd_rn(s, acc[q][l]);
+        out[q] = IP ? __fsub_rn(1.0f, s) : s;
+    }
+}
+
+template <bool IP, int LANES, int QT>
+__global__ __launch_bounds__(kBlock) void flat_f32_kernel(const FlatArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float qs[];  // [QT][D]
+    __shared__ TopKShared<QT, FLAT_CAP> tk;
+    const int split = blockIdx.x % a.splits, group = blockIdx.x / a.splits;
+    const int tid = threadIdx.x;
+    const float *Q = reinterpret_cast<const float *>(a.q);
+    for (int i = tid; i < QT * a.D; i += kBlock) {
+        const int q = i / a.D, d = i - q * a.D;
+        int qi = group * QT + q;
+        qi = qi < a.nq ? qi : a.nq - 1;
+        qs[i] = Q[(int64_t)qi * a.D + d];
+    }
+    topk_init(tk);
+    __syncthreads();
+    const int64_t row_begin = (int64_t)split * a.rows_per_split;
+    int64_t row_end = row_begin + a.rows_per_split;
+    row_end = row_end < a.n ? row_end : a.n;
+    const float *X = reinterpret_cast<const float *>(a.data);
+    int tile = 0;
+    for (int64_t base = row_begin; base < row_end; base += (int64_t)kBlock * FLAT_R, ++tile) {
+        uint32_t key[FLAT_R][QT];
+        uint32_t pay[FLAT_R];
+#pragma unroll
+        for (int r = 0; r < FLAT_R; ++r) {
+            const int64_t row = base + r * kBlock + tid;
+            const bool valid = row < row_end;
+            float d[QT];
+            dist_f32_row<IP, LANES, QT>(X + (valid ? row : row_begin) * a.D, qs, a.D, d);
+            pay[r] = (uint32_t)row;
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                uint32_t kk = f32_key(d[q]);
+                kk = kk == KEY_MAX ? KEY_MAX - 1 : kk;
+                key[r][q] = valid ? kk : KEY_MAX;
+            }
+        }
+        topk_tile<QT, FLAT_R, FLAT_CAP, FLAT_TRIG>(tk, a.k, tile, key, pay);
+    }
+    __syncthreads();
+    topk_compact(tk, a.k);
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        const int qi = group * QT + q;
+        if (qi >= a.nq) break;
+        const int cnt = tk.cnt[q];
+        const int64_t o = ((int64_t)qi * a.splits + split) * a.k;
+        for (int i = tid; i < a.k; i += kBlock) {
+            if (i < cnt) {
+                const unsigned long long e = tk.buf[q][i];
+                a.part_d[o + i] = key_f32((uint32_t)(e >> 32));
+                a.part_id[o + i] = (int64_t)(uint32_t)e;
+            } else {
+                a.part_d[o + i] = __uint_as_float(0x7f800000u);
+                a.part_id[o + i] = -1;
+            }
+        }
+    }
+}
+
+// uint8 rows.  VEC: rows are 16-byte aligned multiples of 16 (D % 16 == 0) -> dwordx4 loads + dot4
+template <bool VEC, int QT>
+__global__ __launch_bounds__(kBlock) void flat_u8_kernel(const FlatArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t qw[];  // [QT][ceil(D/4)] packed query bytes
+    __shared__ TopKShared<QT, FLAT_CAP> tk;
+    __shared__ uint32_t qq[QT];
+    const int split = blockIdx.x % a.splits, group = blockIdx.x / a.splits;
+    const int tid = threadIdx.x;
+    const int Dq = (a.D >> 2) << 2;  // the reference drops a dim % 4 tail (space_l2.h:198)
+    const int W = Dq >> 2;           // 32-bit words per row that take part
+    const uint8_t *Q = reinterpret_cast<const uint8_t *>(a.q);
+    for (int i = tid; i < QT * W; i += kBlock) {
+        const int q = i / W, w = i - q * W;
+        int qi = group * QT + q;
+        qi = qi < a.nq ? qi : a.nq - 1;
+        const uint8_t *p = Q + (int64_t)qi * a.D + 4 * w;
+        qw[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    }
+    topk_init(tk);
+    __syncthreads();
+    if (tid < QT) {
+        uint32_t s = 0;
+        for (int w = 0; w < W; ++w) s = __builtin_amdgcn_udot4(qw[tid * W + w], qw[tid * W + w], s, false);
+        qq[tid] = s;
+    }
+    __syncthreads();
+    const int64_t row_begin = (int64_t)split * a.rows_per_split;
+    int64_t row_end = row_begin + a.rows_per_split;
+    row_end = row_end < a.n ? row_end : a.n;
+    const uint8_t *X = reinterpret_cast<const uint8_t *>(a.data);
+    int tile = 0;
+    for (int64_t base = row_begin; base < row_end; base += (int64_t)kBlock * FLAT_R, ++tile) {
+        uint32_t key[FLAT_R][QT];
+        uint32_t pay[FLAT_R];
+#pragma unroll
+        for (int r = 0; r < FLAT_R; ++r) {
+            const int64_t row = base + r * kBlock + tid;
+            const bool valid = row < row_end;
+            const uint8_t *xr = X + (valid ? row : row_begin) * a.D;
+            uint32_t xx = 0, qx[QT];
+#pragma unroll
+            for (int q = 0; q < QT; ++q) qx[q] = 0;
+            if constexpr (VEC) {
+                for (int w = 0; w < W; w += 4) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(xr + 4 * w);
+                    const uint32_t xv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xx = __builtin_amdgcn_udot4(xv[e], xv[e], xx, false);
+#pragma unroll
+                        for (int q = 0; q < QT; ++q) qx[q] = __builtin_amdgcn_udot4(qw[q * W + w + e], xv[e], qx[q], false);
+                    }
+                }
+            } else {
+                for (int w = 0; w < W; ++w) {
+                    const uint8_t *p = xr + 4 * w;
+                    const uint32_t xv = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+                    xx = __builtin_amdgcn_udot4(xv, xv, xx, false);
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) qx[q] = __builtin_amdgcn_udot4(qw[q * W + w], xv, qx[q], false);
+                }
+            }
+            pay[r] = (uint32_t)row;
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                const uint32_t d = qq[q] + xx - 2u * qx[q];  // exact: every term < 2^26
+                key[r][q] = valid ? d : KEY_MAX;
+            }
+        }
+        topk_tile<QT, FLAT_R, FLAT_CAP, FLAT_TRIG>(tk, a.k, tile, key, pay);
+    }
+    __syncthreads();
+    topk_compact(tk, a.k);
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        const int qi = group * QT + q;
+        if (qi >= a.nq) break;
+        const int cnt = tk.cnt[q];
+        const int64_t o = ((int64_t)qi * a.splits + split) * a.k;
+        for (int i = tid; i < a.k; i += kBlock) {
+            if (i < cnt) {
+                const unsigned long long e = tk.buf[q][i];
+                a.part_d[o + i] = __uint_as_float((uint32_t)(e >> 32));  // int32 distance bits
+                a.part_id[o + i] = (int64_t)(uint32_t)e;
+            } else {
+                a.part_d[o + i] = __uint_as_float(0x7f800000u);
+                a.part_id[o + i] = -1;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_labels_kernel(int64_t *ids, int64_t count, const int64_t *labels)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < count) {
+        const int64_t r = ids[i];
+        ids[i] = r >= 0 ? labels[r] : -1;
+    }
+}
+
+int launch_gather_labels(int64_t *ids, int64_t count, const int64_t *labels, hipStream_t st)
+{
+    if (count <= 0) return CVTMI_OK;
+    hipLaunchKernelGGL(gather_labels_kernel, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, ids,
+                       count, labels);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+int flat_qtile(int64_t nq) { return nq >= 4 ? 4 : 1; }
+
+int flat_plan_splits(int64_t n, int64_t nq, int qtile)
+{
+    const int64_t groups = (nq + qtile - 1) / qtile;
+    int64_t need = (2048 + groups - 1) / groups;
+    int64_t max_by_rows = n / 2048;
+    if (max_by_rows < 1) max_by_rows = 1;
+    if (need > max_by_rows) need = max_by_rows;
+    if (need < 1) need = 1;
+    if (need > 1024) need = 1024;
+    return (int)need;
+}
+
+template <bool IP, int LANES>
+static int launch_f32(const FlatArgs &a, int qtile, unsigned blocks, size_t lds, hipStream_t st)
+{
+    if (qtile == 4) hipLaunchKernelGGL((flat_f32_kernel<IP, LANES, 4>), dim3(blocks), dim3(kBlock), lds, st, a);
+    else hipLaunchKernelGGL((flat_f32_kernel<IP, LANES, 1>), dim3(blocks), dim3(kBlock), lds, st, a);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+int launch_flat_search(int metric, int D, const void *data, int64_t n, const void *q, int64_t nq, int k, int qtile,
+                       int splits, float *part_d, int64_t *part_id, hipStream_t st)
+{
+    if (nq <= 0) return CVTMI_OK;
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "flat_search: k=%d outside 1..128", k);
+    if (n > 0xfffffffeLL || nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "flat_search: index too large");
+    if (qtile != 1 && qtile != 4) return fail(CVTMI_EINVAL, "flat_search: qtile %d", qtile);
+    if (D < 1 || D > 4096) return fail(CVTMI_EUNSUPPORTED, "flat_search: D=%d outside 1..4096", D);
+    FlatArgs a;
+    a.data = data; a.n = n; a.q = q; a.nq = (int)nq; a.D = D; a.k = k; a.splits = splits;
+    int64_t rps = (n + splits - 1) / splits;
+    const int64_t tile_rows = (int64_t)kBlock * FLAT_R;
+    rps = ((rps + tile_rows - 1) / tile_rows) * tile_rows;
+    if (rps < tile_rows) rps = tile_rows;
+    a.rows_per_split = rps;
+    a.part_d = part_d; a.part_id = part_id;
+    const int64_t groups = (nq + qtile - 1) / qtile;
+    const int64_t blocks = groups * splits;
+    if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "flat_search: grid too large");
+    const size_t lds_f = (size_t)qtile * D * sizeof(float);
+    switch (metric) {
+        case CVTMI_METRIC_IP:
+            if (D % 4 == 0) return launch_f32<true, 4>(a, qtile, (unsigned)blocks, lds_f, st);
+            return launch_f32<true, 1>(a, qtile, (unsigned)blocks, lds_f, st);
+        case CVTMI_METRIC_L2F:
+            if (D % 16 == 0) return launch_f32<false, 8>(a, qtile, (unsigned)blocks, lds_f, st);
+            if (D % 4 == 0) return launch_f32<false, 4>(a, qtile, (unsigned)blocks, lds_f, st);
+            return launch_f32<false, 1>(a, qtile, (unsigned)blocks, lds_f, st);
+        case CVTMI_METRIC_L2U8: {
+            const size_t lds_u = (size_t)qtile * ((D >> 2) + 1) * sizeof(uint32_t);
+            if (D % 16 == 0) {
+                if (qtile == 4) hipLaunchKernelGGL((flat_u8_kernel<true, 4>), dim3((unsigned)blocks), dim3(kBlock), lds_u, st, a);
+                else hipLaunchKernelGGL((flat_u8_kernel<true, 1>), dim3((unsigned)blocks), dim3(kBlock), lds_u, st, a);
+            } else {
+                if (qtile == 4) hipLaunchKernelGGL((flat_u8_kernel<false, 4>), dim3((unsigned)blocks), dim3(kBlock), lds_u, st, a);
+                else hipLaunchKernelGGL((flat_u8_kernel<false, 1>), dim3((unsigned)blocks), dim3(kBlock), lds_u, st, a);
+            }
+            CVTMI_HIP(hipGetLastError());
+            return CVTMI_OK;
+        }
+        default: break;
+    }
+    return fail(CVTMI_EINVAL, "flat_search: unknown metric %d", metric);
+}
+
+}  // namespace cvtmi

@@ -1,0 +1,72 @@
+// kernels.h -- internal launch interface between the C-ABI glue (api.hip) and the HIP kernels.
+// All pointers are device pointers; every launcher is asynchronous on `st`.
+#pragma once
+#include "common.h"
+
+namespace cvtmi {
+
+struct OpqModelDev {
+    int D, coarseK, M, K, step;
+    const float *coarse;  // [coarseK][D]
+    const float *books;   // [M][K][step]
+    const float *R;       // [D][D] or null
+    const int32_t *perm;  // [D] or null
+};
+
+// ---- rotate.hip ----
+int launch_permute(const int32_t *perm, int D, const float *x, int64_t n, float *y, hipStream_t st);
+int launch_rotate_gemm(const float *R, int D, const float *x, int64_t n, float *y, hipStream_t st);
+
+// ---- opq_encode.hip ----
+int launch_coarse_assign(const OpqModelDev &m, const float *x_rot, int64_t n, int32_t *list_id, hipStream_t st);
+// list_id may be null (=> list 0 for every row)
+int launch_pq_encode(const OpqModelDev &m, const float *x_rot, int64_t n, const int32_t *list_id, uint8_t *codes,
+                     hipStream_t st);
+int launch_lut(const OpqModelDev &m, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut,
+               hipStream_t st);
+
+// ---- adc_scan.hip ----
+struct ScanPlan {
+    int qtile;   // 1,2,4,8
+    int splits;  // row splits per query group
+};
+ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int want_qtile, int want_splits);
+// part_d / part_id: [nq][splits][k]
+int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, int64_t id_base, const float *q_rot,
+                    int64_t nq, int k, const ScanPlan &plan, float *part_d, int64_t *part_id, hipStream_t st);
+
+// ---- topk_merge.hip ----
+int launch_topk_merge(const float *in_d, const int64_t *in_id, int64_t nq, int L, int k, float *out_d, int64_t *out_id,
+                      hipStream_t st);
+
+// ---- query_video.hip ----
+// probe[nq][nprobe] list ids in visiting order; list_off[coarseK+1]; codes/video_id in list order.
+int launch_coarse_probe(const OpqModelDev &m, const float *q_rot, int64_t nq, int nprobe, int32_t *probe,
+                        hipStream_t st);
+int launch_query_video(const OpqModelDev &m, const float *q_rot, int64_t nq, int nprobe, const int32_t *probe,
+                       const int64_t *list_off, const uint8_t *codes, const int32_t *video_id, int img_num,
+                       float *match_score, hipStream_t st);
+
+// ---- flat.hip ----
+int flat_plan_splits(int64_t n, int64_t nq, int qtile);
+int flat_qtile(int64_t nq);
+// part_d / part_id: [nq][splits][k]; for CVTMI_METRIC_L2U8 part_d carries the int32 distance BITS
+// (non-negative ints order like their float bit patterns, nothing does float arithmetic on them).
+int launch_flat_search(int metric, int D, const void *data, int64_t n, const void *q, int64_t nq, int k, int qtile,
+                       int splits, float *part_d, int64_t *part_id, hipStream_t st);
+// ids[i] = ids[i] >= 0 ? labels[ids[i]] : -1
+int launch_gather_labels(int64_t *ids, int64_t count, const int64_t *labels, hipStream_t st);
+
+// ---- sq8.hip ----
+// den[n] = float(max(1e-12, sqrt(sum_i double(x_i * x_i))))   (int8_quan.cc:46-52)
+int launch_sq8_rownorm(const float *x, int64_t n, int d, float *den, hipStream_t st);
+// den may be null (no normalisation); write_back != 0 stores x / den over x
+int launch_sq8_encode(const float *vmin, const float *vdiff, int d, float *x, int64_t n, const float *den,
+                      int write_back, uint8_t *codes, hipStream_t st);
+int launch_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x,
+                      hipStream_t st);
+// kmin/kmax: [d] ordered-uint32 scratch (initialised inside); results in vmin / vdiff
+int launch_sq8_train(const float *x, int64_t n, int d, const float *den, uint32_t *kmin, uint32_t *kmax, float *vmin,
+                     float *vdiff, hipStream_t st);
+
+}  // namespace cvtmi

@@ -1,0 +1,73 @@
+// topk_merge.hip -- merge L sorted (distance, id) lists per query into the k smallest pairs.
+// Used twice: across the row splits of one GPU's scan, and across GPUs after the RCCL all-gather
+// of per-shard results (same shape as FLANN-MPI's ResultsMerger,
+// retrieval/vlindex/lib/FLANN/mpi/index.h:74-108).
+//
+// One workgroup per query streams the L*k candidates through the shared selection buffer
+// (block_topk.h).  The payload is the candidate's position in the input; lists are ordered by
+// ascending id range and each list is (distance, id)-sorted, so position order equals id order among
+// equal distances -- exactly the tie rule the selection needs.
+#include "block_topk.h"
+#include "kernels.h"
+
+namespace cvtmi {
+
+constexpr int MERGE_CAP = 1024;
+constexpr int MERGE_TRIG = 768;
+constexpr int MERGE_R = 4;
+
+__global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restrict__ in_d,
+                                                            const int64_t *__restrict__ in_id, int n_cand, int k,
+                                                            float *__restrict__ out_d, int64_t *__restrict__ out_id)
+{
+    __shared__ TopKShared<1, MERGE_CAP> tk;
+    const int64_t q = blockIdx.x;
+    const float *d = in_d + q * n_cand;
+    const int64_t *id = in_id + q * n_cand;
+    const int tid = threadIdx.x;
+    topk_init(tk);
+    __syncthreads();
+    int tile = 0;
+    for (int base = 0; base < n_cand; base += kBlock * MERGE_R, ++tile) {
+        uint32_t key[MERGE_R][1];
+        uint32_t pay[MERGE_R];
+#pragma unroll
+        for (int r = 0; r < MERGE_R; ++r) {
+            const int i = base + r * kBlock + tid;
+            pay[r] = (uint32_t)i;
+            key[r][0] = KEY_MAX;
+            if (i < n_cand && id[i] >= 0) {
+                const uint32_t kk = f32_key(d[i]);
+                key[r][0] = kk == KEY_MAX ? KEY_MAX - 1 : kk;  // keep the "not a candidate" code free
+            }
+        }
+        topk_tile<1, MERGE_R, MERGE_CAP, MERGE_TRIG>(tk, k, tile, key, pay);
+    }
+    __syncthreads();
+    topk_compact(tk, k);
+    const int cnt = tk.cnt[0];
+    for (int i = tid; i < k; i += kBlock) {
+        if (i < cnt) {
+            const uint32_t p = (uint32_t)tk.buf[0][i];
+            out_d[q * k + i] = d[p];
+            out_id[q * k + i] = id[p];
+        } else {
+            out_d[q * k + i] = __uint_as_float(0x7f800000u);
+            out_id[q * k + i] = -1;
+        }
+    }
+}
+
+int launch_topk_merge(const float *in_d, const int64_t *in_id, int64_t nq, int L, int k, float *out_d, int64_t *out_id,
+                      hipStream_t st)
+{
+    if (nq <= 0) return CVTMI_OK;
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "topk_merge: k=%d outside 1..128", k);
+    if (L < 1 || (int64_t)L * k > 0x7fffffff) return fail(CVTMI_EINVAL, "topk_merge: bad list count %d", L);
+    if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "topk_merge: nq too large");
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, L * k, k, out_d, out_id);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+}  // namespace cvtmi

@@ -1,0 +1,77 @@
+"""Synthetic inputs for tests and bench.py: SIFT-shaped 128-d vectors, random
+rotations, quickly-trained sub-codebooks.  Deterministic per (seed, row chunk) so that any row shard
+can generate exactly its own rows on its own GPU, with no host round trip.
+"""
+import numpy as np
+
+CHUNK = 1 << 18  # rows per generator chunk; shards are generated chunk by chunk
+
+
+def _sift_chunk_torch(torch, n, D, seed, chunk_idx, device):
+    g = torch.Generator(device=device)
+    g.manual_seed((seed * 1000003 + chunk_idx) & 0x7FFFFFFFFFFFFFFF)
+    # heavy-tailed non-negative integers, ~25 % exact zeros, clipped at 255 like SIFT bins
+    x = torch.randn((n, D), generator=g, device=device).abs_() * 42.0
+    z = torch.rand((n, D), generator=g, device=device) < 0.25
+    x = torch.where(z, torch.zeros_like(x), x).floor_().clamp_(max=255.0)
+    # cluster structure: a per-row "scene" offset on a few dimensions keeps neighbours meaningful
+    return x
+
+
+def sift_like(n, D=128, seed=0xC0FFEE, row_begin=0, device="cpu", rootsift=True):
+    """rows [row_begin, row_begin+n) of the infinite synthetic SIFT-like matrix, fp32 torch tensor.
+
+    rootsift=True applies the RootSIFT map of the reference's indexer
+    (hnsw_sifts_retrieval/siftsIndex.cpp:54-71: L1-normalise, sqrt, L2-normalise) so that vectors are
+    unit-norm like the features the reference actually indexes (opq/data)."""
+    import torch
+    out = torch.empty((n, D), dtype=torch.float32, device=device)
+    r = row_begin
+    end = row_begin + n
+    while r < end:
+        c = r // CHUNK
+        c0 = c * CHUNK
+        full = _sift_chunk_torch(torch, CHUNK, D, seed, c, device)
+        lo, hi = r - c0, min(end, c0 + CHUNK) - c0
+        out[r - row_begin:r - row_begin + (hi - lo)] = full[lo:hi]
+        r = c0 + hi
+    if rootsift:
+        out = out / (out.abs().sum(dim=1, keepdim=True) + 1e-7)
+        out = out.sqrt_()
+        out = out / out.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    return out.contiguous()
+
+
+def random_rotation(D, seed=7):
+    """Random orthonormal fp32 matrix (QR of a Gaussian)."""
+    rng = np.random.default_rng(seed)
+    q, r = np.linalg.qr(rng.normal(size=(D, D)))
+    q = q * np.sign(np.diag(r))
+    return np.ascontiguousarray(q.astype(np.float32))
+
+
+def random_permutation(D, seed=7):
+    return np.random.default_rng(seed).permutation(D).astype(np.int32)
+
+
+def train_books(x_rot, M, K=256, iters=6, seed=1234):
+    """A few Lloyd iterations per sub-space on a (rotated) torch sample -> numpy [M][K][step]."""
+    import torch
+    n, D = x_rot.shape
+    step = D // M
+    g = torch.Generator(device=x_rot.device)
+    g.manual_seed(seed)
+    books = torch.empty((M, K, step), dtype=torch.float32, device=x_rot.device)
+    for m in range(M):
+        sub = x_rot[:, m * step:(m + 1) * step].contiguous()
+        cen = sub[torch.randperm(n, generator=g, device=x_rot.device)[:K]].clone()
+        for _ in range(iters):
+            d = torch.cdist(sub, cen)
+            a = d.argmin(dim=1)
+            sums = torch.zeros_like(cen).index_add_(0, a, sub)
+            cnt = torch.bincount(a, minlength=K).clamp_min(1).unsqueeze(1)
+            new = sums / cnt
+            empty = (torch.bincount(a, minlength=K) == 0)
+            cen = torch.where(empty.unsqueeze(1), cen, new)
+        books[m] = cen
+    return books.cpu().numpy()

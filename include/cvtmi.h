@@ -1,0 +1,184 @@
+/*
+ * cvtmi.h -- C ABI of the MI355X-native OPQ-encode / ADC-search hot path of willard-yuan/cvt.
+ *
+ * This is the drop-in boundary: a C++ (or cgo / ctypes / JNI) caller that today runs the loops
+ * of the reference's L1 layer on the CPU binds these entry points instead.  Each entry names the
+ * reference interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, opaque handles, no C++ / torch types.
+ *   - Every function returns 0 (CVTMI_OK) or a negative cvtmi_status; the message of the last
+ *     failure on the calling thread is cvtmi_last_error().  No exception crosses the boundary.
+ *   - Functions without a suffix take HOST pointers (caller-owned buffers, like the reference's
+ *     float** / float* arguments) and return when the result is in the caller's buffer.
+ *     Functions ending in `_dev` take DEVICE pointers (HBM-resident) plus a `stream`
+ *     (a hipStream_t passed as void*, NULL = the default stream) and are asynchronous.
+ *   - Handles are thread-compatible: concurrent searches on an unchanging handle are fine,
+ *     mutation needs external synchronisation (same as the reference classes).
+ *   - One handle lives on the HIP device that was current when it was created.
+ *   - The library has no CPU fallback: without a usable HIP device every compute entry fails
+ *     with CVTMI_EHIP.
+ *
+ * Numerics contract (tests/ enforce it against oracle/ and the golden vectors):
+ *   uint8 PQ codes, list ids, SQ8 codes, uint8-L2 distances: bit-exact.
+ *   LUT entries and ADC distances: bit-exact (same fp32 operation order as the reference,
+ *   separate multiply and add), which implies the 1e-4 relative bound of the north star.
+ *   top-k: the k smallest (distance, id) pairs in lexicographic order, ascending.
+ */
+#ifndef CVTMI_H
+#define CVTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVTMI_VERSION 100 /* 0.1.0 */
+
+typedef enum cvtmi_status {
+    CVTMI_OK = 0,
+    CVTMI_EINVAL = -1,       /* bad argument */
+    CVTMI_ENOMEM = -2,       /* host or device allocation failed */
+    CVTMI_EHIP = -3,         /* HIP runtime error / no device */
+    CVTMI_ESTATE = -4,       /* handle not in a state that allows the call */
+    CVTMI_EUNSUPPORTED = -5  /* shape outside what the kernels are built for */
+} cvtmi_status;
+
+typedef enum cvtmi_metric {
+    CVTMI_METRIC_IP = 0,   /* 1 - <q,x>, fp32   : brute_force_search/src/space_ip.hpp:211-239 */
+    CVTMI_METRIC_L2F = 1,  /* sum (q-x)^2, fp32  : hnsw_sifts_retrieval/hnswlib/space_l2.h:153-184 */
+    CVTMI_METRIC_L2U8 = 2  /* sum (q-x)^2, uint8 -> int32 : space_l2.h:186-245 (L2SqrI / L2SpaceI) */
+} cvtmi_metric;
+
+typedef struct cvtmi_opq_s *cvtmi_opq_t;
+typedef struct cvtmi_flat_s *cvtmi_flat_t;
+
+/* ---------------------------------------------------------------- library / device ---------- */
+int cvtmi_version(void);
+const char *cvtmi_last_error(void);
+int cvtmi_device_count(int *count);
+int cvtmi_set_device(int device);
+
+/* ---------------------------------------------------------------- OPQ model + code index ---- */
+/*
+ * Replaces IVFOPQ::LoadModel's in-memory tables (opq/src/IVFOPQ.cpp:64-102):
+ *   coarse [coarseK][D] fp32, books [M][K][D/M] fp32 (each sub-codebook contiguous), and the
+ *   "rotation": either perm[D] (the reference's reorder_, y[i] = x[perm[i]], IVFOPQ.cpp:424-439)
+ *   or a dense row-major R[D][D] (y = R x, the general OPQ rotation run as an fp32 MFMA GEMM);
+ *   both NULL = identity.  K <= 256, M <= 16 (IVFelem::PQindex[16], IVFOPQ.h:28), D % M == 0.
+ */
+int cvtmi_opq_create(int D, int coarseK, int M, int K, const float *coarse, const float *books,
+                     const float *R, const int32_t *perm, cvtmi_opq_t *out);
+int cvtmi_opq_destroy(cvtmi_opq_t h);
+
+/* IVFOPQ::reorder over n rows (IVFOPQ.cpp:424-439, :459-461).  x and y may not alias. */
+int cvtmi_opq_rotate(cvtmi_opq_t h, const float *x, int64_t n, float *y);
+int cvtmi_opq_rotate_dev(cvtmi_opq_t h, const float *x, int64_t n, float *y, void *stream);
+
+/* The encode loop of IVFOPQ::Add (IVFOPQ.cpp:107-163) on already-rotated rows:
+ * list_id[n] = coarse argmin (first minimum, -1 if none), codes[n][M] = per-sub-quantiser argmin
+ * (255 if none).  list_id may be NULL. */
+int cvtmi_opq_encode(cvtmi_opq_t h, const float *x_rot, int64_t n, int32_t *list_id, uint8_t *codes);
+int cvtmi_opq_encode_dev(cvtmi_opq_t h, const float *x_rot, int64_t n, int32_t *list_id, uint8_t *codes,
+                         void *stream);
+
+/* m_ivfList[vw].push_back(elem) of Add (IVFOPQ.cpp:167): append n entries to the resident index.
+ * list_id NULL = list 0 (only valid when coarseK == 1); video_id NULL = one "video" per entry,
+ * numbered by insertion order.  Entry ids are id_base + insertion index. */
+int cvtmi_opq_add_codes(cvtmi_opq_t h, const uint8_t *codes, const int32_t *list_id,
+                        const int32_t *video_id, int64_t n);
+int cvtmi_opq_add_codes_dev(cvtmi_opq_t h, const uint8_t *codes, const int32_t *list_id,
+                            const int32_t *video_id, int64_t n, void *stream);
+int cvtmi_opq_reserve(cvtmi_opq_t h, int64_t n_total);
+int cvtmi_opq_ntotal(cvtmi_opq_t h, int64_t *n);
+int cvtmi_opq_reset(cvtmi_opq_t h);                      /* drop all entries, keep the model */
+int cvtmi_opq_set_id_base(cvtmi_opq_t h, int64_t base);  /* first id of this row shard */
+/* Copy the resident entries back in list order (the SaveIndex order, IVFOPQ.cpp:557-575).
+ * list_off[coarseK+1], video_id[ntotal], codes[ntotal][M]; any may be NULL. */
+int cvtmi_opq_get_entries(cvtmi_opq_t h, int64_t *list_off, int32_t *video_id, uint8_t *codes);
+
+/* PQ_table of Query (IVFOPQ.cpp:273-291): lut[nq][M][K] for rotated queries; list_id[nq] selects
+ * the coarse centroid each residual is taken against (NULL = list 0). */
+int cvtmi_opq_lut(cvtmi_opq_t h, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut);
+int cvtmi_opq_lut_dev(cvtmi_opq_t h, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut,
+                      void *stream);
+
+/* The north-star search: (optional rotation) + LUT + exhaustive ADC scan (IVFOPQ.cpp:300-306)
+ * + k smallest (distance, id) (opq/src/common.h:25-37) per query, over every resident entry.
+ * Requires coarseK == 1.  dist[nq][k] / ids[nq][k] ascending; rows short of k entries are padded
+ * with (+inf, -1).  rotate != 0 applies cvtmi_opq_rotate to the queries first.  k <= 128. */
+int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int k, float *dist,
+                     int64_t *ids);
+int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int k, float *dist,
+                         int64_t *ids, void *stream);
+
+/* IVFOPQ::Query / QueryThrehold (IVFOPQ.cpp:213-320 / :322-422): per query frame probe the nprobe
+ * nearest coarse lists and keep, per video, the minimum ADC score clamped at 1.0.
+ * match_score[nq][img_num].  rotate as above. */
+int cvtmi_opq_query_video(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int nprobe,
+                          int img_num, float *match_score);
+
+/* Tuning / measurement hooks (no effect on results).
+ *   "splits"   row splits per query group of the scan (0 = automatic)
+ *   "qtile"    queries sharing one pass over the codes: 1, 2, 4 or 8 (0 = automatic)
+ *   "profile"  1 = bracket the scan kernel with HIP events on its stream */
+int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value);
+/* With "profile" on: MEAN duration of the scan-kernel launches recorded since the previous call
+ * (the 64 most recent are kept) and the algorithmic code bytes ONE launch reads
+ * (passes x rows x M, passes = ceil(nq / qtile)).  Synchronises on the profiling events only. */
+int cvtmi_opq_last_scan(cvtmi_opq_t h, float *ms, int64_t *code_bytes, int *qtile, int *splits);
+
+/* ---------------------------------------------------------------- top-k merge ---------------- */
+/* Exchange step of a row-sharded search: merge L sorted (distance, id) lists per query
+ * (in_dist / in_ids [nq][L][k], id < 0 = padding, lists ordered by ascending id range) into the
+ * k smallest pairs.  Same shape as FLANN-MPI's ResultsMerger
+ * (retrieval/vlindex/lib/FLANN/mpi/index.h:74-108). */
+int cvtmi_topk_merge(const float *in_dist, const int64_t *in_ids, int64_t nq, int L, int k,
+                     float *dist, int64_t *ids);
+int cvtmi_topk_merge_dev(const float *in_dist, const int64_t *in_ids, int64_t nq, int L, int k,
+                         float *dist, int64_t *ids, void *stream);
+
+/* ---------------------------------------------------------------- exhaustive (flat) search -- */
+/* hnswlib::BruteforceSearch<dist_t> + SpaceInterface (brute_force_search/src/brutoforce.hpp:9-136,
+ * hnswlib.hpp:34-58).  Rows are D fp32 (IP, L2F) or D uint8 (L2U8). */
+int cvtmi_flat_create(int metric, int D, cvtmi_flat_t *out);
+int cvtmi_flat_destroy(cvtmi_flat_t h);
+/* addPoint (brutoforce.hpp:43-56) for n rows; labels NULL = row numbers continuing from ntotal.
+ * Labels must be unique and ascending in insertion order for the (distance, label) tie rule to
+ * hold on device; the C++ BruteforceSearch mirror re-orders rows by label when they are not. */
+int cvtmi_flat_add(cvtmi_flat_t h, const void *x, const int64_t *labels, int64_t n);
+int cvtmi_flat_add_dev(cvtmi_flat_t h, const void *x, const int64_t *labels, int64_t n, void *stream);
+int cvtmi_flat_ntotal(cvtmi_flat_t h, int64_t *n);
+int cvtmi_flat_reset(cvtmi_flat_t h);
+/* searchKnn (brutoforce.hpp:73-93) for nq queries: k smallest (distance, label), ascending.
+ * dist is float[nq][k] for IP / L2F and int32_t[nq][k] for L2U8.  k <= 128. */
+int cvtmi_flat_search(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels);
+int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels,
+                          void *stream);
+
+/* ---------------------------------------------------------------- int8 scalar quantisation -- */
+/* Per-dimension min / (max - min) over (optionally L2-normalised) rows: what
+ * faiss::IndexScalarQuantizer(d, QT_8bit).train leaves in sq.trained
+ * (scalar_quantization/train/src/sq_train.cpp:84-103).  x is not modified. */
+int cvtmi_sq8_train(const float *x, int64_t n, int d, int l2norm, float *vmin, float *vdiff);
+int cvtmi_sq8_train_dev(const float *x, int64_t n, int d, int l2norm, float *vmin, float *vdiff,
+                        void *stream);
+/* Int8Quan::Int8Encode arithmetic (scalar_quantization/scalar_quantization/int8_quan.cc:72-94)
+ * over n rows; with l2norm != 0 each row of x is L2-normalised IN PLACE first (:46-56), as the
+ * reference does to its caller's buffer. */
+int cvtmi_sq8_encode(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm,
+                     uint8_t *codes);
+int cvtmi_sq8_encode_dev(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm,
+                         uint8_t *codes, void *stream);
+/* Int8Quan::Int8Decode(std::string&) arithmetic (int8_quan.cc:117-132) over n rows. */
+int cvtmi_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n,
+                     float *x);
+int cvtmi_sq8_decode_dev(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n,
+                         float *x, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVTMI_H */

@@ -309,13 +309,15 @@ static float ip_scalar(const float *a, const float *b, int n)
     for (int i = 0; i < n; ++i) res += a[i] * b[i];
     return 1.0f - res;
 }
-/* space_ip.hpp:168-206 (non-AVX branch of InnerProductSIMD16Ext, what the reference's own
- * CMake flags build): one 4-lane accumulator, 4 lanes per step, lanes added left to right. */
+/* space_ip.hpp:84-131 / :168-206 (non-AVX branches of InnerProductSIMD4Ext / SIMD16Ext, what the
+ * reference's own CMake flags build): ONE 4-lane accumulator walks the row 4 floats at a time
+ * (16-blocks first, then 4-blocks: same accumulator, same order), lanes are then added left to
+ * right.  `lanes` = 8 models the AVX branch of SIMD16Ext (:140-167) for D % 16 == 0. */
 static float ip_lanes(const float *a, const float *b, int n, int lanes)
 {
     float acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    int n16 = (n / 16) * 16;
-    for (int i = 0; i < n16; i += lanes)
+    int nl = (n / lanes) * lanes;
+    for (int i = 0; i < nl; i += lanes)
         for (int l = 0; l < lanes; ++l) acc[l] += a[i + l] * b[i + l];
     float s = acc[0];
     for (int l = 1; l < lanes; ++l) s += acc[l];
@@ -323,14 +325,17 @@ static float ip_lanes(const float *a, const float *b, int n, int lanes)
 }
 /* hnsw_sifts_retrieval/hnswlib/space_l2.h:26-37 */
 static float l2_scalar(const float *a, const float *b, int n) { return sq_dist_seq(a, b, n); }
-/* space_l2.h:40-73: AVX branch is hard-enabled by `#define USE_AVX` (:12): 8 lanes. */
-static float l2_lanes8(const float *a, const float *b, int n)
+/* space_l2.h:40-73 (L2SqrSIMD16Ext, AVX branch hard-enabled by `#define USE_AVX` at :12): 8 lanes;
+ * space_l2.h:123-151 (L2SqrSIMD4Ext): 4 lanes.  Lanes are added left to right. */
+static float l2_lanes(const float *a, const float *b, int n, int lanes)
 {
     float acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    int n16 = (n >> 4) << 4;
-    for (int i = 0; i < n16; i += 8)
-        for (int l = 0; l < 8; ++l) { float t = a[i + l] - b[i + l]; acc[l] += t * t; }
-    return acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5] + acc[6] + acc[7];
+    int nl = (n / lanes) * lanes;
+    for (int i = 0; i < nl; i += lanes)
+        for (int l = 0; l < lanes; ++l) { float t = a[i + l] - b[i + l]; acc[l] += t * t; }
+    float s = acc[0];
+    for (int l = 1; l < lanes; ++l) s += acc[l];
+    return s;
 }
 /* space_l2.h:186-219: integer L2 over groups of four uint8; a dim%4 tail is dropped. */
 static int l2_u8(const uint8_t *a, const uint8_t *b, int n)
@@ -343,17 +348,20 @@ static int l2_u8(const uint8_t *a, const uint8_t *b, int n)
 
 /* metric ids shared with include/cvtmi.h */
 enum { ORC_IP = 0, ORC_L2F = 1, ORC_L2U8 = 2 };
-/* flavour: 0 scalar loop, 4 = SSE lane order, 8 = AVX lane order (IP only; L2F uses 8 when
- * D%16==0 like L2Space's selection at space_l2.h:159-164, else scalar) */
+/* flavour 0 forces the scalar loops; any other value applies the reference's own function
+ * selection (InnerProductSpace ctor space_ip.hpp:217-225, L2Space ctor space_l2.h:159-164):
+ *   IP : D%4==0 -> 4-lane SSE order (flavour 8 and D%16==0 -> the 8-lane AVX order instead)
+ *   L2F: D%16==0 -> 8-lane AVX order, else D%4==0 -> 4-lane, else scalar */
 ORC_API float orc_dist(int metric, int flavour, const void *a, const void *b, int D)
 {
     if (metric == ORC_IP) {
-        if (flavour == 0 || D % 16 != 0) return ip_scalar((const float *)a, (const float *)b, D);
-        return ip_lanes((const float *)a, (const float *)b, D, flavour);
+        if (flavour == 0 || D % 4 != 0) return ip_scalar((const float *)a, (const float *)b, D);
+        if (flavour == 8 && D % 16 == 0) return ip_lanes((const float *)a, (const float *)b, D, 8);
+        return ip_lanes((const float *)a, (const float *)b, D, 4);
     }
     if (metric == ORC_L2F) {
-        if (flavour == 0 || D % 16 != 0) return l2_scalar((const float *)a, (const float *)b, D);
-        return l2_lanes8((const float *)a, (const float *)b, D);
+        if (flavour == 0 || D % 4 != 0) return l2_scalar((const float *)a, (const float *)b, D);
+        return l2_lanes((const float *)a, (const float *)b, D, D % 16 == 0 ? 8 : 4);
     }
     return (float)l2_u8((const uint8_t *)a, (const uint8_t *)b, D);
 }

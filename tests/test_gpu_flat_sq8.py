@@ -1,0 +1,141 @@
+"""GPU parity: exhaustive (flat) search, int8 scalar quantisation and the top-k merge, through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+IP, L2F, L2U8 = 0, 1, 2
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import cvt_amd
+    cvt_amd.lib()
+    return cvt_amd
+
+
+def test_flat_golden(amd, golden):
+    f = golden.flat
+    ix = amd.FlatIndex(IP, 128); ix.add(f["ip_db"])
+    d, i = ix.search(f["ip_q"], 100)
+    assert np.array_equal(i, f["ip_i"])
+    assert np.array_equal(bits(d), bits(f["ip_d"]))       # bit-exact vs the reference's SSE build
+    # labels that are not row numbers (ascending order is the documented device-side requirement)
+    lab = f["ipl_labels"]
+    order = np.argsort(lab)
+    ix = amd.FlatIndex(IP, 128); ix.add(f["ip_db"][order], labels=lab[order])
+    d, i = ix.search(f["ip_q"], 10)
+    assert np.array_equal(i, f["ipl_i"]) and np.array_equal(bits(d), bits(f["ipl_d"]))
+    ix = amd.FlatIndex(L2F, 64); ix.add(f["l2_db"])
+    d, i = ix.search(f["l2_q"], 10)
+    assert np.array_equal(i, f["l2_i"]) and np.array_equal(bits(d), bits(f["l2_d"]))
+    for tag in ("u8a", "u8b", "u8c"):
+        db = f[tag + "_db"]
+        ix = amd.FlatIndex(L2U8, db.shape[1]); ix.add(db[:100]); ix.add(db[100:])
+        d, i = ix.search(f[tag + "_q"], 10)
+        assert d.dtype == np.int32
+        assert np.array_equal(d, f[tag + "_d"]), tag
+        assert np.array_equal(i, f[tag + "_i"]), tag
+
+
+@pytest.mark.parametrize("metric,D", [(IP, 128), (IP, 20), (IP, 7), (L2F, 128), (L2F, 36), (L2F, 5), (L2U8, 512), (L2U8, 21)])
+def test_flat_seeded(amd, orc, metric, D):
+    rng = np.random.default_rng(metric * 100 + D)
+    n, nq, k = 9000 + 5, 11, 37
+    if metric == L2U8:
+        db = rng.integers(0, 256, size=(n, D), dtype=np.uint8); q = rng.integers(0, 256, size=(nq, D), dtype=np.uint8)
+    else:
+        db = rng.normal(size=(n, D)).astype(np.float32); q = rng.normal(size=(nq, D)).astype(np.float32)
+    db[4000] = db[10]; q[0] = db[10]
+    ix = amd.FlatIndex(metric, D); ix.add(db)
+    d, i = ix.search(q, k)
+    od, odi, oi = orc.flat_search(metric, db, q, k)
+    assert np.array_equal(i, oi)
+    if metric == L2U8:
+        assert np.array_equal(d, odi)
+    else:
+        assert np.array_equal(bits(d), bits(od))
+    # single query (qtile 1 path) and k > n
+    d1, i1 = ix.search(q[:1], k)
+    assert np.array_equal(i1, oi[:1])
+    small = amd.FlatIndex(metric, D); small.add(db[:5])
+    d5, i5 = small.search(q[:2], 8)
+    assert np.all(i5[:, 5:] == -1) and np.array_equal(i5[:, :5], orc.flat_search(metric, db[:5], q[:2], 5)[2])
+
+
+def test_flat_full_size_u8_property(amd):
+    """Config 3 shape (512-d uint8) at a size that needs row splits: self-queries come back first with
+    distance 0 and the result is invariant to how the rows were appended."""
+    import torch
+    n, D = 400_000, 512
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    db = torch.randint(0, 256, (n, D), generator=g, device="cuda", dtype=torch.uint8)
+    ix = amd.FlatIndex(L2U8, D); ix.add(db)
+    rows = torch.tensor([0, 12345, n - 1], device="cuda")
+    d, i = ix.search(db[rows].contiguous(), 10)
+    assert torch.equal(i[:, 0], rows) and torch.all(d[:, 0] == 0)
+    assert torch.all(d[:, 1:] > 0) and torch.all(d[:, 1:] >= d[:, :-1])
+    ix2 = amd.FlatIndex(L2U8, D)
+    for a in range(0, n, 150_000):
+        ix2.add(db[a:a + 150_000].contiguous())
+    d2, i2 = ix2.search(db[rows].contiguous(), 10)
+    assert torch.equal(d2, d) and torch.equal(i2, i)
+
+
+def test_sq8_parity(amd, orc, golden):
+    rng = np.random.default_rng(8)
+    for d in (64, 512, 300):
+        x = np.abs(rng.normal(size=(777, d))).astype(np.float32)
+        x[0, :64] = golden.sq8["int8_quan_test_x"]
+        x[5] = 0
+        vmin, vdiff = amd.sq8_train(x, l2norm=True)
+        ovmin, ovdiff = orc.sq8_train(x, l2norm=True)
+        assert np.array_equal(bits(vmin), bits(ovmin)) and np.array_equal(bits(vdiff), bits(ovdiff))
+        vdiff2 = vdiff.copy(); vdiff2[1] = 0
+        for l2 in (True, False):
+            xg = x.copy()
+            codes = amd.sq8_encode(vmin, vdiff2, xg, l2norm=l2)
+            ocodes, ox = orc.sq8_encode(vmin, vdiff2, x, l2norm=l2)
+            assert np.array_equal(codes, ocodes), (d, l2)
+            assert np.array_equal(bits(xg), bits(ox)), "in-place normalisation differs"
+        dec = amd.sq8_decode(vmin, vdiff, codes)
+        assert np.array_equal(bits(dec), bits(orc.sq8_decode(vmin, vdiff, codes)))
+        v3, d3 = amd.sq8_train(x, l2norm=False)
+        o3, od3 = orc.sq8_train(x, l2norm=False)
+        assert np.array_equal(bits(v3), bits(o3)) and np.array_equal(bits(d3), bits(od3))
+
+
+def test_sq8_device_roundtrip_full_width(amd):
+    """Config 3 width (512-d) on device pointers: decode(encode(x)) lands within one bucket of x."""
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    x = torch.randn((200_000, 512), generator=g, device="cuda").relu_()
+    vmin, vdiff = amd.sq8_train(x, l2norm=True)
+    xn = x.clone()
+    codes = amd.sq8_encode(vmin, vdiff, xn, l2norm=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(xn.norm(dim=1), torch.ones(x.shape[0], device="cuda"), atol=1e-5)
+    dec = amd.sq8_decode(vmin, vdiff, codes)
+    assert torch.all((dec - xn).abs() <= vdiff / 255 * 1.0001 + 1e-7)
+    assert int(codes.max()) == 255
+
+
+def test_merge_parity(amd, orc):
+    rng = np.random.default_rng(21)
+    for nq, L, k in ((5, 2, 100), (3, 8, 100), (4, 64, 10), (2, 300, 128), (1, 1, 1)):
+        d = np.sort(rng.integers(0, 50, size=(nq, L, k)).astype(np.float32) - 10.0, axis=2)  # negative dists too, many ties
+        ids = np.empty((nq, L, k), dtype=np.int64)
+        for l in range(L):
+            ids[:, l, :] = l * 100000 + np.sort(rng.choice(100000, k, replace=False))
+        # restore the (dist,id) order inside each list and pad some tails
+        for q in range(nq):
+            for l in range(L):
+                o = np.lexsort((ids[q, l], d[q, l])); d[q, l] = d[q, l][o]; ids[q, l] = ids[q, l][o]
+        ids[:, L // 2, k - k // 3:] = -1
+        md, mi = amd.topk_merge(d, ids, k)
+        od, oi = orc.merge_topk(d, ids, k)
+        assert np.array_equal(mi, oi), (nq, L, k)
+        assert np.array_equal(bits(md), bits(od))

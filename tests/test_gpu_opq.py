@@ -1,0 +1,260 @@
+"""GPU parity tests of the OPQ path through the C ABI: HIP kernels vs the golden vectors (outputs of
+the reference itself) and vs the CPU oracle on seeded inputs.  Codes / list ids / LUT entries / ADC
+distances / top-k ids are all required to be BIT-EXACT (stronger than the 1e-4 relative bound of the
+north star)."""
+import numpy as np
+import pytest
+
+from conftest import OPQ_CASES, bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import cvt_amd
+    cvt_amd.lib()  # raises if the HIP library is missing: there is no fallback
+    return cvt_amd
+
+
+def make_index(amd, g, rotation="perm"):
+    D = g["coarse"].shape[1]
+    if rotation == "perm":
+        return amd.OpqIndex(g["coarse"], g["books"], perm=g["perm"])
+    R = np.zeros((D, D), dtype=np.float32)
+    R[np.arange(D), g["perm"]] = 1.0
+    return amd.OpqIndex(g["coarse"], g["books"], R=R)
+
+
+@pytest.mark.parametrize("case", OPQ_CASES)
+def test_golden_rotate_encode_query(amd, golden, case):
+    g = golden.opq[case]
+    idx = make_index(amd, g)
+    # rotation (IVFOPQ::reorder)
+    assert np.array_equal(idx.rotate(g["queries"]), g["q_rot"])
+    db_rot = idx.rotate(g["db"])
+    assert np.array_equal(db_rot, g["db_rot"])
+    # encode (IVFOPQ::Add)
+    lists, codes = idx.encode(db_rot)
+    idx.add_codes(codes, list_id=lists, video_id=golden.video_of_row(case))
+    off, vid, ccodes = idx.get_entries()
+    assert np.array_equal(off, g["list_off"])
+    assert np.array_equal(ccodes, g["codes"]), "PQ codes differ from the reference"
+    assert np.array_equal(vid, g["video_id"])
+    # query (IVFOPQ::QueryThrehold) incl. rotation of the raw query file contents
+    ms = idx.query_video(g["queries"], int(g["nk"]), len(g["video_rows"]), rotate=True)
+    assert np.array_equal(bits(ms), bits(g["match_score"])), "match scores differ from the reference"
+
+
+@pytest.mark.parametrize("case", ["opq_exh_m8", "opq_vec_m16", "opq_real_q9"])
+def test_golden_rotation_as_mfma_gemm(amd, golden, case):
+    """The permutation fed to the MFMA fp32 GEMM as a 0/1 matrix reproduces the reference's gather."""
+    g = golden.opq[case]
+    idx = make_index(amd, g, rotation="R")
+    assert np.array_equal(idx.rotate(g["queries"]), g["q_rot"])
+    assert np.array_equal(idx.rotate(g["db"]), g["db_rot"])
+
+
+def test_golden_exhaustive_topk(amd, golden, orc):
+    """North-star form on the reference's numbers: one vector per video, no clamp."""
+    g = golden.opq["opq_vec_m16"]
+    idx = make_index(amd, g)
+    idx.add_codes(g["codes"])
+    ms = g["match_score"]
+    for qt in (0, 1, 2, 4):
+        for splits in (0, 1, 3, 8):
+            idx.set_param("qtile", qt); idx.set_param("splits", splits)
+            d, i = idx.search(g["queries"], 100, rotate=True)
+            for f in range(ms.shape[0]):
+                order = np.lexsort((np.arange(ms.shape[1]), ms[f]))[:100]
+                assert np.array_equal(i[f], order), (qt, splits, f)
+                assert np.array_equal(bits(d[f]), bits(ms[f][order])), (qt, splits, f)
+    assert list(i[0][:3]) == [7, 100, 200]  # exact duplicates: ties resolved by id
+
+
+def test_golden_lut(amd, golden, orc):
+    for case in ("opq_m1", "opq_vec_m16", "opq_ivf"):
+        g = golden.opq[case]
+        idx = make_index(amd, g)
+        nq = g["q_rot"].shape[0]
+        lists = (np.arange(nq) % g["coarse"].shape[0]).astype(np.int32)
+        lut = idx.lut(g["q_rot"], lists)
+        for f in range(nq):
+            ref = orc.lut(g["q_rot"][f], g["coarse"][lists[f]], g["books"])
+            assert np.array_equal(bits(lut[f]), bits(ref)), (case, f)
+    g = golden.opq["opq_m1"]  # M = 1: the reference's scores are single LUT entries
+    idx = make_index(amd, g)
+    lut = idx.lut(g["q_rot"])
+    for f in range(g["q_rot"].shape[0]):
+        assert np.array_equal(bits(lut[f, 0][g["codes"][:, 0]]), bits(g["match_score"][f]))
+
+
+def synth_model(rng, D, M, K, n_train=4000, scale=1.0):
+    x = (rng.normal(size=(n_train, D)) * scale).astype(np.float32)
+    step = D // M
+    books = np.stack([x[rng.integers(0, n_train, K), m * step:(m + 1) * step] for m in range(M)]).astype(np.float32)
+    return np.ascontiguousarray(books)
+
+
+@pytest.mark.parametrize("D,M,K,coarseK", [(128, 16, 256, 1), (128, 8, 256, 1), (64, 16, 256, 5), (32, 4, 200, 40),
+                                           (128, 4, 256, 1), (96, 2, 17, 3), (24, 3, 256, 1)])
+def test_encode_parity_seeded(amd, orc, D, M, K, coarseK):
+    rng = np.random.default_rng(D * 1000 + M)
+    books = synth_model(rng, D, M, K)
+    coarse = np.zeros((1, D), np.float32) if coarseK == 1 else rng.normal(size=(coarseK, D)).astype(np.float32)
+    n = 3000 + 37
+    x = rng.normal(size=(n, D)).astype(np.float32)
+    x[5] = np.nan          # no centroid can claim it: list -1, codes 255 (IVFOPQ.cpp:144,161)
+    x[6, 3] = np.inf
+    x[7] = books[:, 9, :].reshape(-1) + (coarse[0] if coarseK == 1 else 0)  # exact codeword
+    idx = amd.OpqIndex(coarse, books)
+    lists, codes = idx.encode(x)
+    ol, oc = orc.pq_encode(x, coarse, books)
+    assert np.array_equal(lists, ol)
+    assert np.array_equal(codes, oc)
+    assert lists[5] == -1 and np.all(codes[5] == 255)
+    # ragged sizes around the tile width, and the empty input
+    for nn in (0, 1, 255, 1025):
+        l2, c2 = idx.encode(x[:nn])
+        assert np.array_equal(c2, oc[:nn]) and np.array_equal(l2, ol[:nn])
+
+
+def test_encode_tie_takes_first_minimum(amd, orc):
+    D, M, K = 32, 4, 256
+    rng = np.random.default_rng(1)
+    books = synth_model(rng, D, M, K)
+    books[:, 200] = books[:, 40]   # duplicate codewords: strict '<' keeps index 40
+    x = np.tile(books[:, 40].reshape(1, -1), (300, 1)).astype(np.float32)
+    idx = amd.OpqIndex(np.zeros((1, D), np.float32), books)
+    _, codes = idx.encode(x)
+    assert np.all(codes == 40)
+
+
+@pytest.mark.parametrize("M", [16, 8, 4])
+@pytest.mark.parametrize("k", [1, 10, 100, 128])
+def test_search_parity_seeded(amd, orc, M, k):
+    D, K = 128, 256
+    rng = np.random.default_rng(M * 7 + k)
+    books = synth_model(rng, D, M, K, scale=0.1)
+    n = 20000 + 13
+    codes = rng.integers(0, K, size=(n, M), dtype=np.uint8)
+    codes[100] = codes[50]; codes[15000] = codes[50]           # exact ties straddling splits
+    q = (rng.normal(size=(9, D)) * 0.1).astype(np.float32)
+    R = None
+    idx = amd.OpqIndex(np.zeros((1, D), np.float32), books, R=R)
+    idx.add_codes(codes[:7000]); idx.add_codes(codes[7000:])   # two appends
+    assert idx.ntotal == n
+    od, oi = orc.adc_search(q, books, codes, k)
+    for qt, splits in ((0, 0), (1, 1), (2, 5), (4, 8), (4, 16), (1, 64)):
+        idx.set_param("qtile", qt); idx.set_param("splits", splits)
+        d, i = idx.search(q, k, rotate=False)
+        assert np.array_equal(i, oi), (qt, splits)
+        assert np.array_equal(bits(d), bits(od)), (qt, splits)
+
+
+def test_search_edge_cases(amd, orc):
+    D, M, K = 128, 16, 256
+    rng = np.random.default_rng(2)
+    books = synth_model(rng, D, M, K, scale=0.1)
+    idx = amd.OpqIndex(np.zeros((1, D), np.float32), books)
+    q = (rng.normal(size=(3, D)) * 0.1).astype(np.float32)
+    # empty index: every slot padded with (+inf, -1)
+    d, i = idx.search(q, 10, rotate=False)
+    assert np.all(np.isinf(d)) and np.all(i == -1)
+    # fewer rows than k
+    codes = rng.integers(0, K, size=(7, M), dtype=np.uint8)
+    idx.add_codes(codes)
+    d, i = idx.search(q, 10, rotate=False)
+    od, oi = orc.adc_search(q, books, codes, 10)
+    assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od))
+    assert np.all(i[:, 7:] == -1)
+    # all rows identical (worst case for the selection: every distance ties) and an id base
+    idx.reset()
+    same = np.tile(codes[:1], (5000, 1))
+    idx.add_codes(same)
+    idx.set_id_base(1 << 33)
+    d, i = idx.search(q, 100, rotate=False)
+    assert np.array_equal(i, np.tile((1 << 33) + np.arange(100), (3, 1)))
+    # descending distances: every new row beats the threshold (stresses buffer overflow + retry path)
+    idx.reset(); idx.set_id_base(0)
+    order_books = books.copy()
+    lut = orc.lut(q[0], np.zeros(D, np.float32), order_books)
+    ranks = np.argsort(-lut[0], kind="stable")          # code values by descending LUT[0] entry
+    n = 6000
+    desc = np.zeros((n, M), dtype=np.uint8)
+    desc[:, 0] = ranks[(np.arange(n) * 256 // n)]
+    idx.add_codes(desc)
+    for splits in (1, 2):
+        idx.set_param("splits", splits)
+        d, i = idx.search(q[:1], 100, rotate=False)
+        od, oi = orc.adc_search(q[:1], order_books, desc, 100)
+        assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od))
+    # error path: k out of range is refused, not truncated
+    with pytest.raises(amd.CvtmiError):
+        idx.search(q, 129, rotate=False)
+
+
+def test_search_device_pointers_and_rotation(amd, orc):
+    """_dev entry points on torch tensors, rotation by a dense orthonormal R through the MFMA GEMM."""
+    import torch
+    from cvt_amd import synth
+    D, M, K = 128, 16, 256
+    R = synth.random_rotation(D, seed=7)
+    x = synth.sift_like(6000, D, device="cuda")
+    qs = synth.sift_like(33, D, seed=0xBEEF, device="cuda")
+    xr_ref = orc.rotate_fma(R, x.cpu().numpy())
+    books = synth_model(np.random.default_rng(4), D, M, K, scale=0.1)
+    books = np.ascontiguousarray(np.stack([xr_ref[np.random.default_rng(m).integers(0, 6000, K), m * 8:(m + 1) * 8] for m in range(M)]))
+    idx = amd.OpqIndex(np.zeros((1, D), np.float32), books, R=R)
+    xr = idx.rotate(x)
+    assert np.array_equal(bits(xr.cpu().numpy()), bits(xr_ref)), "MFMA rotation != k-ordered fmaf chain"
+    lists, codes = idx.encode(xr)
+    ol, oc = orc.pq_encode(xr_ref, np.zeros((1, D), np.float32), books)
+    assert np.array_equal(codes.cpu().numpy(), oc)
+    idx.add_codes(codes)
+    d, i = idx.search(qs, 100, rotate=True)
+    torch.cuda.synchronize()
+    od, oi = orc.adc_search(orc.rotate_fma(R, qs.cpu().numpy()), books, oc, 100)
+    assert np.array_equal(i.cpu().numpy(), oi)
+    assert np.array_equal(bits(d.cpu().numpy()), bits(od))
+
+
+def test_full_size_properties(amd, orc):
+    """BASELINE config sizes (SIFT-1M, M=16, top-100) through size-independent properties:
+    split-invariance, merge-of-shards == whole, sortedness, and an oracle check on a query sample."""
+    import torch
+    from cvt_amd import synth
+    D, M, K, n, nq, k = 128, 16, 256, 1_000_000, 64, 100
+    R = synth.random_rotation(D)
+    x = synth.sift_like(n, D, device="cuda")
+    q = synth.sift_like(nq, D, seed=0xBEEF, device="cuda")
+    idx0 = amd.OpqIndex(np.zeros((1, D), np.float32), np.zeros((M, K, D // M), np.float32), R=R)
+    books = synth.train_books(idx0.rotate(x[:50000]), M, K, iters=3)
+    idx = amd.OpqIndex(np.zeros((1, D), np.float32), books, R=R)
+    _, codes = idx.encode(idx.rotate(x))
+    idx.add_codes(codes)
+    d, i = idx.search(q, k)
+    dn, inn = d.cpu().numpy(), i.cpu().numpy()
+    assert np.all(np.diff(dn, axis=1) >= 0)                                   # ascending
+    tie = np.diff(dn, axis=1) == 0
+    assert np.all(np.diff(inn, axis=1)[tie] > 0)                              # ties in id order
+    for qt, splits in ((1, 8), (2, 16), (4, 1), (4, 24)):
+        idx.set_param("qtile", qt); idx.set_param("splits", splits)
+        d2, i2 = idx.search(q, k)
+        assert torch.equal(i2, i) and torch.equal(d2.view(torch.int32), d.view(torch.int32)), (qt, splits)
+    # two row shards searched separately and merged == the whole index
+    half = n // 2
+    parts_d, parts_i = [], []
+    for s, (a, b) in enumerate(((0, half), (half, n))):
+        sh = amd.OpqIndex(np.zeros((1, D), np.float32), books, R=R)
+        sh.add_codes(codes[a:b].contiguous()); sh.set_id_base(a)
+        dd, ii = sh.search(q, k)
+        parts_d.append(dd); parts_i.append(ii)
+    md, mi = amd.topk_merge(torch.stack(parts_d, 1).contiguous(), torch.stack(parts_i, 1).contiguous(), k)
+    assert torch.equal(mi, i) and torch.equal(md.view(torch.int32), d.view(torch.int32))
+    # oracle on a sample of queries at full N
+    qr = idx.rotate(q[:4]).cpu().numpy()
+    od, oi = orc.adc_search(qr, books, codes.cpu().numpy(), k)
+    assert np.array_equal(inn[:4], oi) and np.array_equal(bits(dn[:4]), bits(od))
