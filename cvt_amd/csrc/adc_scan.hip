@@ -235,23 +235,277 @@ __global__ __launch_bounds__(kBlock, ScanOcc<QT>::waves) void adc_scan_kernel(co
     }
 }
 
+// ==========================================================================================
+// adc_scan16: the M = 16 scan with CONFLICT-FREE table reads.
+//
+// Problem measured on the kernel above (rocprofv3, profiles/r01_*): with one code row per lane, the 64
+// lanes of a ds_read look up the SAME sub-quantiser with random codes, so 63-66 % of all LDS cycles
+// are bank-conflict replays and the LDS pipe, ~80 % busy, is the bound.
+//
+// Fix: ds_read_b128 is serviced in groups of 16 lanes over 16 slots of 16 bytes.  With M = 16 and
+// QT = 4, one table entry (4 queries x fp32) IS one slot, so if the 16 lanes of a group look up 16
+// DIFFERENT sub-quantisers and the table is laid out [code][m][q] (slot = m), every group is
+// conflict-free regardless of the codes.  Lane l therefore walks its own row in the rotated order
+// m = (t + l) & 15, t = 0..15 (its 16 code bytes are rotated once in registers so the byte for step t
+// sits at a compile-time position).
+//
+// The rotated order changes the fp32 rounding of the sum, so it is used ONLY as a filter: a row is
+// pushed to the selection buffer when its rotated-order sum is below thr * (1 + 2^-17), a bound that
+// provably admits every row whose reference-order sum is below thr (both are sums of the same 16
+// non-negative floats: each is within 15 ulp-steps, 8.9e-7 relative, of the real sum).  At
+// compaction each newly pushed row is re-read and summed in the REFERENCE order (m ascending,
+// IVFOPQ.cpp:302-306) before the sort, so thr, the kept set and the reported distances are exactly
+// the reference's.  Pushes are ~0.1 % of rows, the exact pass is noise.
+// ==========================================================================================
+constexpr int S16_CAP = 384;
+constexpr int S16_TRIG = 256;
+
+// thr key -> the bound the rotated-order sums are compared with
+struct InflateThr {
+    __device__ __forceinline__ uint32_t operator()(uint32_t t) const
+    {
+        if (t >= 0x7f800000u) return t;  // no finite threshold yet (KEY_MAX) or +inf: compare as is
+        const float f = __uint_as_float(t);
+        return __float_as_uint(fmaf(f, 7.62939453125e-06f /* 2^-17 */, f));
+    }
+};
+
+// exact reference-order distance of a pushed row, read through the table layout of adc_scan16
+// (float index of (code j, sub-quantiser m, query q) = j*16*QT + (q>>2)*64 + m*4 + (q&3))
+template <int QT>
+struct ExactFix {
+    static constexpr bool enabled = true;
+    const float *lut;
+    const uint4 *rows;
+    __device__ __forceinline__ unsigned long long operator()(int q, unsigned long long e) const
+    {
+        const uint32_t row = (uint32_t)e;
+        const uint4 c = rows[row];
+        const uint32_t w[4] = { c.x, c.y, c.z, c.w };
+        float s = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const uint32_t j = (w[m >> 2] >> (8 * (m & 3))) & 0xffu;
+            s = __fadd_rn(s, lut[j * (16 * QT) + (q >> 2) * 64 + m * 4 + (q & 3)]);
+        }
+        return ((unsigned long long)__float_as_uint(s) << 32) | row;
+    }
+};
+
+// NT threads per workgroup.  The 64 KB of tables are shared by NT/64 waves; two workgroups fit a CU's
+// LDS, so NT = 512 gives 4 waves per SIMD, NT = 1024 gives 8 (register budget 128 / 64 VGPRs).
+// Measured on the bare loop (tools/ubench/scan_loop.hip): 256 threads 15.8, 512 threads 21.2,
+// 1024 threads 24.9 T table reads/s -- more waves hide the LDS latency the skewed loop exposes.
+template <int NT>
+__global__ __launch_bounds__(NT, NT / 128) void adc_scan16_kernel(const ScanArgs a)
+{
+    constexpr int M = 16, QT = 4;
+    constexpr int R = NT >= 1024 ? 1 : 2;  // rows per lane per tile (64-VGPR budget at 8 waves/SIMD)
+    __shared__ __attribute__((aligned(16))) float lut[256 * 16 * QT];  // [code j][m][q]: one 16-byte slot per (j, m)
+    __shared__ TopKShared<QT, S16_CAP> tk;
+
+    int group, split;
+    {
+        const int b = blockIdx.x;
+        if ((a.splits & 7) == 0) {
+            const int s8 = a.splits >> 3;
+            const int xcd = b & 7, i = b >> 3;
+            split = xcd + 8 * (i % s8);
+            group = i / s8;
+        } else {
+            split = b % a.splits;
+            group = b / a.splits;
+        }
+    }
+    const int tid = threadIdx.x;
+    topk_init(tk);
+
+    // ---- tables: the arithmetic of build_lut_lds (IVFOPQ.cpp:273-291), stored [j][m][q] ----
+    {
+        float *res = reinterpret_cast<float *>(&tk.buf[0][0]);
+        for (int i = tid; i < QT * a.D; i += NT) {
+            const int q = i / a.D, d = i - q * a.D;
+            int qi = group * QT + q;
+            qi = qi < a.nq ? qi : a.nq - 1;
+            res[i] = __fsub_rn(a.q_rot[(int64_t)qi * a.D + d], a.centroid[d]);
+        }
+        __syncthreads();
+        for (int e = tid; e < M * 256; e += NT) {  // (m, j) pairs; consecutive lanes -> consecutive j
+            const int m = e >> 8, j = e & 255;
+            float acc[QT];
+#pragma unroll
+            for (int q = 0; q < QT; ++q) acc[q] = 0.0f;
+            if (j < a.K) {
+                const float *cb = a.books + ((int64_t)m * a.K + j) * a.step;
+                for (int kk = 0; kk < a.step; ++kk) {
+                    const float c = cb[kk];
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) {
+                        const float t = __fsub_rn(res[q * a.D + m * a.step + kk], c);
+                        acc[q] = __fadd_rn(acc[q], __fmul_rn(t, t));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < QT; ++q) acc[q] = __uint_as_float(0x7f800000u);
+            }
+            *reinterpret_cast<float4 *>(&lut[(j * 16 + m) * QT]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        __syncthreads();
+    }
+    const uint4 *rows = reinterpret_cast<const uint4 *>(a.codes);
+    using Fix = ExactFix<QT>;
+    const Fix fix{ lut, rows };
+    const InflateThr thrx;
+
+    const int64_t row_begin = (int64_t)split * a.rows_per_split;
+    int64_t row_end = row_begin + a.rows_per_split;
+    row_end = row_end < a.n_rows ? row_end : a.n_rows;
+
+    // lane constants: rotation amount c and, packed one byte per step, the byte offset m*16 of
+    // sub-quantiser m = (t + c) & 15 inside a 256-byte table row
+    const uint32_t c = tid & 15;
+    const uint32_t cr8 = (c & 3) * 8, cq = c >> 2;
+    uint32_t moffp[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        moffp[w] = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) moffp[w] |= (((4 * w + b + c) & 15u) * 16u) << (8 * b);
+    }
+    const char *lut_b = reinterpret_cast<const char *>(lut);
+
+    // Row indices inside the split are 32-bit (the launcher keeps a split below 2^28 rows) so that the
+    // loads are "scalar base + 32-bit lane offset".  Rows past the end are CLAMPED to the last row
+    // instead of predicated off: an exec-masked load made the compiler wait vmcnt(0) on the prefetch
+    // it had just issued; clamped rows are rejected by the range check in the (rare) push path.
+    const uint32_t n_local = (uint32_t)(row_end > row_begin ? row_end - row_begin : 0);
+    const char *rows_b = reinterpret_cast<const char *>(rows + row_begin);
+    const uint32_t last = n_local ? n_local - 1 : 0;
+    auto load_row = [&](uint32_t lrow) -> uint4 {
+        const uint32_t cl = lrow < last ? lrow : last;
+        return *reinterpret_cast<const uint4 *>(rows_b + (size_t)(cl * 16u));
+    };
+    uint4 cur[R], nxt[R];
+    if (n_local) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) cur[r] = load_row(r * NT + tid);
+    }
+    int tile = 0;
+    for (uint32_t base = 0; base < n_local; base += NT * R, ++tile) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) nxt[r] = load_row(base + NT * R + r * NT + tid);
+        uint32_t thr[QT];
+#pragma unroll
+        for (int q = 0; q < QT; ++q) thr[q] = tk.thr_x[q];
+        uint32_t key[R][QT];
+        bool want = false;
+        uint32_t pending = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            // rotate the 16 code bytes right by c: byte t of `rot` = code[(t + c) & 15]
+            uint32_t d0 = __builtin_amdgcn_alignbit(cur[r].y, cur[r].x, cr8);
+            uint32_t d1 = __builtin_amdgcn_alignbit(cur[r].z, cur[r].y, cr8);
+            uint32_t d2 = __builtin_amdgcn_alignbit(cur[r].w, cur[r].z, cr8);
+            uint32_t d3 = __builtin_amdgcn_alignbit(cur[r].x, cur[r].w, cr8);
+            {
+                const bool b0 = cq & 1;
+                const uint32_t e0 = b0 ? d1 : d0, e1 = b0 ? d2 : d1, e2 = b0 ? d3 : d2, e3 = b0 ? d0 : d3;
+                const bool b1 = cq & 2;
+                d0 = b1 ? e2 : e0; d1 = b1 ? e3 : e1; d2 = b1 ? e0 : e2; d3 = b1 ? e1 : e3;
+            }
+            const uint32_t rot[4] = { d0, d1, d2, d3 };
+            float a0, a1, a2, a3;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                // LDS byte address = code*256 + m*16, formed by ONE v_perm_b32:
+                // byte0 <- moffp[t>>2].byte[t&3], byte1 <- rot[t>>2].byte[t&3], bytes 2,3 <- 0
+                const uint32_t sel = 0x0c0c0000u | ((4u + (t & 3)) << 8) | (uint32_t)(t & 3);
+                const uint32_t addr = __builtin_amdgcn_perm(rot[t >> 2], moffp[t >> 2], sel);
+                const float4 v = *reinterpret_cast<const float4 *>(lut_b + addr);
+                if (t == 0) { a0 = v.x; a1 = v.y; a2 = v.z; a3 = v.w; }
+                else { a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            key[r][0] = __float_as_uint(a0); key[r][1] = __float_as_uint(a1);
+            key[r][2] = __float_as_uint(a2); key[r][3] = __float_as_uint(a3);
+            // wave-level test on scalar masks: 4 v_cmp + 3 s_or, no per-lane boolean materialised
+            const unsigned long long pm = __ballot(key[r][0] < thr[0]) | __ballot(key[r][1] < thr[1]) |
+                                          __ballot(key[r][2] < thr[2]) | __ballot(key[r][3] < thr[3]);
+            if (pm) {  // rare once the threshold has tightened
+                const uint32_t lrow = base + r * NT + tid;
+                if (lrow < n_local) {
+#pragma unroll
+                    for (int q = 0; q < QT; ++q)
+                        if (key[r][q] < thr[q])
+                            if (!topk_push<QT, S16_CAP, S16_TRIG>(tk, q, key[r][q], (uint32_t)(row_begin + lrow), want))
+                                pending |= 1u << (r * QT + q);
+                }
+            }
+        }
+        topk_tile_end<QT, S16_CAP, NT>(tk, a.k, tile, want, pending, fix, thrx, [&](uint32_t pend) {
+            uint32_t still = 0;
+            bool dummy = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+                    const uint32_t bit = 1u << (r * QT + q);
+                    if ((pend & bit) && key[r][q] <= tk.thr_x[q]) {
+                        if (!topk_push<QT, S16_CAP, S16_TRIG>(tk, q, key[r][q], (uint32_t)(row_begin + base + r * NT + tid), dummy))
+                            still |= bit;
+                    }
+                }
+            }
+            return still;
+        });
+#pragma unroll
+        for (int r = 0; r < R; ++r) cur[r] = nxt[r];
+    }
+
+    __syncthreads();
+    topk_compact<QT, S16_CAP, NT, Fix, InflateThr>(tk, a.k, fix, thrx);
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        const int qi = group * QT + q;
+        if (qi >= a.nq) break;
+        const int cnt = tk.cnt[q];
+        const int64_t o = ((int64_t)qi * a.splits + split) * a.k;
+        for (int i = tid; i < a.k; i += NT) {
+            if (i < cnt) {
+                const unsigned long long e = tk.buf[q][i];
+                a.part_d[o + i] = __uint_as_float((uint32_t)(e >> 32));
+                a.part_id[o + i] = a.id_base + (int64_t)(uint32_t)e;
+            } else {
+                a.part_d[o + i] = __uint_as_float(0x7f800000u);
+                a.part_id[o + i] = -1;
+            }
+        }
+    }
+}
+
 // Row ids travel as 32-bit payloads: one launch covers at most 2^32-1 rows.
-ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int want_qtile, int want_splits)
+ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int want_qtile, int want_splits,
+                   int want_variant)
 {
     ScanPlan p;
     int qt = want_qtile;
     if (qt != 1 && qt != 2 && qt != 4 && qt != 8) qt = (nq >= 4) ? 4 : (nq >= 2 ? 2 : 1);
-    if (qt == 8 && m.M == 16) qt = 4;  // 8 x 16 KB tables + buffers would leave one workgroup per CU
+    if (qt == 8 && m.M == 16) qt = 4;  // 8 x 16 KB tables do not fit beside the selection buffers
+    // conflict-free skewed kernel: M = 16 with 4 queries per pass (variant 1: 512-thread, 2: 1024-thread workgroups)
+    p.variant = (want_variant != 0 && m.M == 16 && qt == 4) ? want_variant : 0;
     p.qtile = qt;
     const int64_t groups = (nq + qt - 1) / qt;
     int s = want_splits;
     if (s <= 0) {
-        // enough workgroups to fill 256 CUs x 2 several times over, a multiple of 8 so that each XCD
-        // keeps to its own slice of the codes, but never fewer than ~4K rows per workgroup.
-        const int64_t target = 4096;
+        // Measured (profiles/r01_sweep.txt): per-workgroup fixed cost (table build + selection warm-up)
+        // makes FEWER, LONGER workgroups faster as long as the chip is full: aim at ~1024 workgroups
+        // (2 per CU x 2 rounds), splits a multiple of 8 so that each XCD keeps to its own slice of the
+        // codes, never fewer than 16K rows per workgroup.
+        const int64_t target = 1024;
         int64_t need = (target + groups - 1) / groups;
-        need = ((need + 7) / 8) * 8;
-        int64_t max_by_rows = n_rows / 4096;
+        if (need > 1) need = ((need + 7) / 8) * 8;
+        int64_t max_by_rows = n_rows / 16384;
         if (max_by_rows < 1) max_by_rows = 1;
         if (need > max_by_rows) need = max_by_rows >= 8 ? (max_by_rows / 8) * 8 : max_by_rows;
         if (need < 1) need = 1;
@@ -308,11 +562,19 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
     a.groups = (int)((nq + plan.qtile - 1) / plan.qtile);
     // split boundaries on whole tiles so that every workgroup's rows are 16-byte-row aligned tiles
     int64_t rps = (n_rows + plan.splits - 1) / plan.splits;
-    const int64_t tile_rows = (int64_t)kBlock * 4;
+    const int64_t tile_rows = 2048;  // multiple of every kernel's tile (NT x R rows)
     rps = ((rps + tile_rows - 1) / tile_rows) * tile_rows;
     if (rps < tile_rows) rps = tile_rows;
     a.rows_per_split = rps;
     a.part_d = part_d; a.part_id = part_id;
+    if (plan.variant >= 1 && m.M == 16 && plan.qtile == 4) {
+        const int64_t blocks = (int64_t)a.groups * a.splits;
+        if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "adc_scan: grid too large (%lld)", (long long)blocks);
+        if (plan.variant == 2) hipLaunchKernelGGL((adc_scan16_kernel<1024>), dim3((unsigned)blocks), dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((adc_scan16_kernel<512>), dim3((unsigned)blocks), dim3(512), 0, st, a);
+        CVTMI_HIP(hipGetLastError());
+        return CVTMI_OK;
+    }
     switch (m.M) {
         case 16: return launch_m<16>(a, plan.qtile, st);
         case 8: return launch_m<8>(a, plan.qtile, st);

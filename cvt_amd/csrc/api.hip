@@ -122,7 +122,7 @@ struct cvtmi_opq_s {
     // scratch
     DevBuf s_qrot, s_part_d, s_part_id, s_probe;
     // tuning / measurement
-    int p_splits = 0, p_qtile = 0, p_profile = 0;
+    int p_splits = 0, p_qtile = 0, p_profile = 0, p_variant = 1;
     static constexpr int kEvRing = 64;
     hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
     int ev_count = 0;  // scan launches recorded since the last cvtmi_opq_last_scan
@@ -479,7 +479,7 @@ int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, 
         CVTMI_TRY(cvtmi_opq_rotate_dev(h, q, nq, h->s_qrot.as<float>(), stream));
         q_rot = h->s_qrot.as<float>();
     }
-    const ScanPlan plan = plan_scan(h->m, h->n, nq, k, h->p_qtile, h->p_splits);
+    const ScanPlan plan = plan_scan(h->m, h->n, nq, k, h->p_qtile, h->p_splits, h->p_variant);
     float *pd = dist;
     int64_t *pi = ids;
     if (plan.splits > 1) {
@@ -562,6 +562,11 @@ int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value)
         return CVTMI_OK;
     }
     if (!strcmp(name, "profile")) { h->p_profile = value != 0; return CVTMI_OK; }
+    if (!strcmp(name, "scan_variant")) {
+        if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: scan_variant must be 0, 1 or 2");
+        h->p_variant = (int)value;
+        return CVTMI_OK;
+    }
     return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: unknown parameter '%s'", name);
 }
 

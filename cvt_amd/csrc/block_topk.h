@@ -16,6 +16,8 @@
 // Then a later candidate whose key EQUALS thr can never displace the current k-th entry (it has a
 // larger id), so the fast path compares with '<'.  Only candidates of the tile that overflowed the
 // buffer are retried with '<=', because those may precede entries already stored.
+// Kernels that push under a LOOSER bound than thr (adc_scan16: approximate keys) are exempt from the
+// ordering rule: every tie reaches the buffer and the sort of exact (key, payload) words decides.
 #pragma once
 #include "common.h"
 
@@ -25,8 +27,21 @@ template <int QT, int CAP>
 struct TopKShared {
     unsigned long long buf[QT][CAP];
     int cnt[QT];
-    uint32_t thr[QT];
-    int flag[4];  // [0..2] rotating "compaction wanted" flags, [3] "some candidate still pending"
+    int exact_n[QT];    // entries [0, exact_n) carry final keys; later ones may still need Fix
+    uint32_t thr[QT];   // key of the current k-th entry (KEY_MAX while fewer than k are known)
+    uint32_t thr_x[QT]; // ThrX(thr): the bound the fast path compares with
+    int flag[4];        // [0..2] rotating "compaction wanted" flags, [3] "some candidate still pending"
+};
+
+// Hooks for kernels whose fast path pushes candidates under an APPROXIMATE key (adc_scan16):
+//   Fix   rewrites a freshly pushed entry with its exact key before the sort;
+//   ThrX  maps the exact k-th key to the (looser) bound the approximate keys are compared with.
+struct NoFix {
+    static constexpr bool enabled = false;
+    __device__ __forceinline__ unsigned long long operator()(int, unsigned long long e) const { return e; }
+};
+struct IdThr {
+    __device__ __forceinline__ uint32_t operator()(uint32_t t) const { return t; }
 };
 
 template <int QT, int CAP>
@@ -34,7 +49,9 @@ __device__ __forceinline__ void topk_init(TopKShared<QT, CAP> &s)
 {
     if (threadIdx.x < QT) {
         s.cnt[threadIdx.x] = 0;
+        s.exact_n[threadIdx.x] = 0;
         s.thr[threadIdx.x] = KEY_MAX;
+        s.thr_x[threadIdx.x] = KEY_MAX;
     }
     if (threadIdx.x < 4) s.flag[threadIdx.x] = 0;
 }
@@ -62,14 +79,14 @@ __device__ __forceinline__ void lds_cmpx(unsigned long long *b, int i, int j)
     }
 }
 
-// Sort every query's buffer, keep the k smallest entries, refresh thr.  Must be called by all
-// kBlock threads after a barrier that made the pushes visible; ends with a barrier.
-template <int QT, int CAP>
-__device__ void topk_compact(TopKShared<QT, CAP> &s, int k)
+// Sort every query's buffer, keep the k smallest entries, refresh thr.  Must be called by all NT
+// threads after a barrier that made the pushes visible; ends with a barrier.
+template <int QT, int CAP, int NT = kBlock, class Fix = NoFix, class ThrX = IdThr>
+__device__ void topk_compact(TopKShared<QT, CAP> &s, int k, const Fix &fix = Fix(), const ThrX &thrx = ThrX())
 {
-    constexpr int NW = kBlock / 64;
+    constexpr int NW = NT / 64;
     constexpr int G = QT < NW ? QT : NW;   // queries sorted concurrently
-    constexpr int TPQ = kBlock / G;        // threads cooperating on one query
+    constexpr int TPQ = NT / G;            // threads cooperating on one query
     constexpr int ROUNDS = (QT + G - 1) / G;
 
     // uniform network size: smallest power of two covering the fullest buffer
@@ -93,6 +110,8 @@ __device__ void topk_compact(TopKShared<QT, CAP> &s, int k)
         if (act) {
             n = s.cnt[q];
             n = n < CAP ? n : CAP;
+            if constexpr (Fix::enabled)
+                for (int i = s.exact_n[q] + t; i < n; i += TPQ) b[i] = fix(q, b[i]);
             for (int i = n + t; i < lim; i += TPQ) b[i] = ~0ull;
         }
         __syncthreads();
@@ -119,21 +138,52 @@ __device__ void topk_compact(TopKShared<QT, CAP> &s, int k)
         }
         if (act && t == 0) {
             s.cnt[q] = n < k ? n : k;
-            s.thr[q] = (n >= k) ? (uint32_t)(b[k - 1] >> 32) : KEY_MAX;
+            s.exact_n[q] = n < k ? n : k;
+            const uint32_t th = (n >= k) ? (uint32_t)(b[k - 1] >> 32) : KEY_MAX;
+            s.thr[q] = th;
+            s.thr_x[q] = thrx(th);
         }
         __syncthreads();
     }
 }
 
-// Per-tile protocol.  Every thread holds R x QT candidate keys (KEY_MAX = not a candidate) and R
-// payloads.  `tile` is the workgroup-uniform tile counter.  One barrier on the fast path.
-template <int QT, int R, int CAP, int TRIG>
+// End-of-tile protocol.  `want` = some push of this thread crossed TRIG; `pending` = bit mask of this
+// thread's candidates that found the buffer full; retry(pending) re-offers them (comparing against
+// the refreshed s.thr_x with '<=') and returns the mask of those still not stored.
+// One barrier on the fast path.  `tile` is the workgroup-uniform tile counter.
+template <int QT, int CAP, int NT, class Fix, class ThrX, class Retry>
+__device__ __forceinline__ void topk_tile_end(TopKShared<QT, CAP> &s, int k, int tile, bool want, uint32_t pending,
+                                              const Fix &fix, const ThrX &thrx, Retry &&retry)
+{
+    const int f = tile % 3;
+    if (want) s.flag[f] = 1;
+    __syncthreads();
+    if (s.flag[f]) {  // workgroup-uniform
+        for (;;) {
+            topk_compact<QT, CAP, NT, Fix, ThrX>(s, k, fix, thrx);
+            if (pending) s.flag[3] = 1;
+            __syncthreads();
+            const int again = s.flag[3];
+            __syncthreads();
+            if (!again) break;
+            if (threadIdx.x == 0) s.flag[3] = 0;
+            pending = retry(pending);
+            __syncthreads();
+        }
+    }
+    // flag (tile-1)%3 was last read before this tile's barrier: safe to clear for tile+2
+    if (threadIdx.x == 0) s.flag[(tile + 2) % 3] = 0;
+}
+
+// Convenience form for kernels that hold R x QT exact keys (KEY_MAX = not a candidate) and R payloads
+// per thread and obey the ordering rule above.
+template <int QT, int R, int CAP, int TRIG, int NT = kBlock>
 __device__ __forceinline__ void topk_tile(TopKShared<QT, CAP> &s, int k, int tile, const uint32_t (&key)[R][QT],
                                           const uint32_t (&pay)[R])
 {
     uint32_t thr[QT];
 #pragma unroll
-    for (int q = 0; q < QT; ++q) thr[q] = s.thr[q];
+    for (int q = 0; q < QT; ++q) thr[q] = s.thr_x[q];
     bool want = false;
     uint32_t pending = 0;
 #pragma unroll
@@ -145,38 +195,21 @@ __device__ __forceinline__ void topk_tile(TopKShared<QT, CAP> &s, int k, int til
             }
         }
     }
-    const int f = tile % 3;
-    if (want) s.flag[f] = 1;
-    __syncthreads();
-    if (s.flag[f]) {  // workgroup-uniform
-        for (;;) {
-            topk_compact(s, k);
-            if (pending) s.flag[3] = 1;
-            __syncthreads();
-            const int again = s.flag[3];
-            __syncthreads();
-            if (!again) break;
-            if (threadIdx.x == 0) s.flag[3] = 0;
+    topk_tile_end<QT, CAP, NT>(s, k, tile, want, pending, NoFix(), IdThr(), [&](uint32_t pend) {
+        uint32_t still = 0;
+        bool dummy = false;
 #pragma unroll
-            for (int q = 0; q < QT; ++q) thr[q] = s.thr[q];
-            uint32_t still = 0;
-            bool dummy = false;
+        for (int r = 0; r < R; ++r) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-#pragma unroll
-                for (int q = 0; q < QT; ++q) {
-                    const uint32_t bit = 1u << (r * QT + q);
-                    if ((pending & bit) && key[r][q] <= thr[q] && key[r][q] != KEY_MAX) {
-                        if (!topk_push<QT, CAP, TRIG>(s, q, key[r][q], pay[r], dummy)) still |= bit;
-                    }
+            for (int q = 0; q < QT; ++q) {
+                const uint32_t bit = 1u << (r * QT + q);
+                if ((pend & bit) && key[r][q] <= s.thr_x[q] && key[r][q] != KEY_MAX) {
+                    if (!topk_push<QT, CAP, TRIG>(s, q, key[r][q], pay[r], dummy)) still |= bit;
                 }
             }
-            pending = still;
-            __syncthreads();
         }
-    }
-    // flag (tile-1)%3 was last read before this tile's barrier: safe to clear for tile+2
-    if (threadIdx.x == 0) s.flag[(tile + 2) % 3] = 0;
+        return still;
+    });
 }
 
 }  // namespace cvtmi

@@ -27,10 +27,12 @@ int launch_lut(const OpqModelDev &m, const float *q_rot, int64_t nq, const int32
 
 // ---- adc_scan.hip ----
 struct ScanPlan {
-    int qtile;   // 1,2,4,8
-    int splits;  // row splits per query group
+    int qtile;    // 1,2,4,8
+    int splits;   // row splits per query group
+    int variant;  // 0 = one row per lane, same sub-quantiser across the wave; 1 = skewed conflict-free (M = 16)
 };
-ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int want_qtile, int want_splits);
+ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int want_qtile, int want_splits,
+                   int want_variant);
 // part_d / part_id: [nq][splits][k]
 int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, int64_t id_base, const float *q_rot,
                     int64_t nq, int k, const ScanPlan &plan, float *part_d, int64_t *part_id, hipStream_t st);

@@ -63,14 +63,15 @@ def test_golden_exhaustive_topk(amd, golden, orc):
     idx = make_index(amd, g)
     idx.add_codes(g["codes"])
     ms = g["match_score"]
-    for qt in (0, 1, 2, 4):
-        for splits in (0, 1, 3, 8):
-            idx.set_param("qtile", qt); idx.set_param("splits", splits)
-            d, i = idx.search(g["queries"], 100, rotate=True)
-            for f in range(ms.shape[0]):
-                order = np.lexsort((np.arange(ms.shape[1]), ms[f]))[:100]
-                assert np.array_equal(i[f], order), (qt, splits, f)
-                assert np.array_equal(bits(d[f]), bits(ms[f][order])), (qt, splits, f)
+    for variant in (1, 2, 0):
+        for qt in (0, 1, 2, 4, 8):
+            for splits in (0, 1, 3, 8):
+                idx.set_param("scan_variant", variant); idx.set_param("qtile", qt); idx.set_param("splits", splits)
+                d, i = idx.search(g["queries"], 100, rotate=True)
+                for f in range(ms.shape[0]):
+                    order = np.lexsort((np.arange(ms.shape[1]), ms[f]))[:100]
+                    assert np.array_equal(i[f], order), (variant, qt, splits, f)
+                    assert np.array_equal(bits(d[f]), bits(ms[f][order])), (variant, qt, splits, f)
     assert list(i[0][:3]) == [7, 100, 200]  # exact duplicates: ties resolved by id
 
 
@@ -147,11 +148,12 @@ def test_search_parity_seeded(amd, orc, M, k):
     idx.add_codes(codes[:7000]); idx.add_codes(codes[7000:])   # two appends
     assert idx.ntotal == n
     od, oi = orc.adc_search(q, books, codes, k)
-    for qt, splits in ((0, 0), (1, 1), (2, 5), (4, 8), (4, 16), (1, 64)):
-        idx.set_param("qtile", qt); idx.set_param("splits", splits)
+    for variant, qt, splits in ((1, 0, 0), (1, 4, 1), (1, 4, 8), (2, 4, 3), (2, 0, 0), (0, 0, 0), (0, 1, 1), (0, 2, 5), (0, 4, 8),
+                                (0, 4, 16), (0, 1, 64)):
+        idx.set_param("scan_variant", variant); idx.set_param("qtile", qt); idx.set_param("splits", splits)
         d, i = idx.search(q, k, rotate=False)
-        assert np.array_equal(i, oi), (qt, splits)
-        assert np.array_equal(bits(d), bits(od)), (qt, splits)
+        assert np.array_equal(i, oi), (variant, qt, splits)
+        assert np.array_equal(bits(d), bits(od)), (variant, qt, splits)
 
 
 def test_search_edge_cases(amd, orc):
@@ -186,11 +188,12 @@ def test_search_edge_cases(amd, orc):
     desc = np.zeros((n, M), dtype=np.uint8)
     desc[:, 0] = ranks[(np.arange(n) * 256 // n)]
     idx.add_codes(desc)
-    for splits in (1, 2):
-        idx.set_param("splits", splits)
-        d, i = idx.search(q[:1], 100, rotate=False)
-        od, oi = orc.adc_search(q[:1], order_books, desc, 100)
-        assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od))
+    od, oi = orc.adc_search(q, order_books, desc, 100)
+    for variant in (1, 2, 0):
+        for splits in (1, 2):
+            idx.set_param("scan_variant", variant); idx.set_param("splits", splits)
+            d, i = idx.search(q, 100, rotate=False)
+            assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od)), (variant, splits)
     # error path: k out of range is refused, not truncated
     with pytest.raises(amd.CvtmiError):
         idx.search(q, 129, rotate=False)
@@ -240,10 +243,11 @@ def test_full_size_properties(amd, orc):
     assert np.all(np.diff(dn, axis=1) >= 0)                                   # ascending
     tie = np.diff(dn, axis=1) == 0
     assert np.all(np.diff(inn, axis=1)[tie] > 0)                              # ties in id order
-    for qt, splits in ((1, 8), (2, 16), (4, 1), (4, 24)):
-        idx.set_param("qtile", qt); idx.set_param("splits", splits)
+    for variant, qt, splits in ((0, 1, 8), (0, 2, 16), (0, 4, 1), (1, 4, 24), (2, 4, 1), (2, 4, 16), (1, 4, 1)):
+        idx.set_param("scan_variant", variant); idx.set_param("qtile", qt); idx.set_param("splits", splits)
         d2, i2 = idx.search(q, k)
-        assert torch.equal(i2, i) and torch.equal(d2.view(torch.int32), d.view(torch.int32)), (qt, splits)
+        assert torch.equal(i2, i) and torch.equal(d2.view(torch.int32), d.view(torch.int32)), (variant, qt, splits)
+    idx.set_param("scan_variant", 1); idx.set_param("qtile", 0); idx.set_param("splits", 0)
     # two row shards searched separately and merged == the whole index
     half = n // 2
     parts_d, parts_i = [], []
