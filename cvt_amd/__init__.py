@@ -6,6 +6,6 @@ classes in ``cvt_amd/host``.  This Python package is only the thin ctypes bindin
 bench.py drive it through; torch is used for device memory, streams and torch.distributed.
 """
 from .capi import (CvtmiError, FlatIndex, OpqIndex, lib, load_library, sq8_decode, sq8_encode, sq8_train,  # noqa: F401
-                   topk_merge)
+                   topk_merge, topk_select)
 
 IP, L2F, L2U8 = 0, 1, 2

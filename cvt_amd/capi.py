@@ -220,6 +220,15 @@ def topk_merge(in_d, in_i, k):
     return d, i
 
 
+def topk_select(scores, k):
+    """scores [nq][n] (numpy, host) -> k smallest (score, index) per row"""
+    scores = _np(scores, np.float32)
+    nq, n = scores.shape
+    d = np.empty((nq, k), dtype=np.float32); i = np.empty((nq, k), dtype=np.int64)
+    _check(lib().cvtmi_topk_select(_ptr(scores), C.c_int64(nq), C.c_int64(n), C.c_int(k), _ptr(d), _ptr(i)))
+    return d, i
+
+
 class FlatIndex:
     """cvtmi_flat_t: exhaustive search over fp32 (IP, L2) or uint8 (L2) rows."""
 

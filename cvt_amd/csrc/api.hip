@@ -616,6 +616,28 @@ int cvtmi_topk_merge(const float *in_dist, const int64_t *in_ids, int64_t nq, in
     return CVTMI_OK;
 }
 
+int cvtmi_topk_select_dev(const float *scores, int64_t nq, int64_t n, int k, float *dist, int64_t *ids, void *stream)
+{
+    if (nq < 0 || n < 0 || (nq > 0 && (!dist || !ids || (n > 0 && !scores))))
+        return fail(CVTMI_EINVAL, "cvtmi_topk_select: bad arguments");
+    return launch_topk_select(scores, nullptr, nq, n, k, dist, ids, (hipStream_t)stream);
+}
+
+int cvtmi_topk_select(const float *scores, int64_t nq, int64_t n, int k, float *dist, int64_t *ids)
+{
+    if (nq < 0 || n < 0 || k < 1 || (nq > 0 && (!dist || !ids || (n > 0 && !scores))))
+        return fail(CVTMI_EINVAL, "cvtmi_topk_select: bad arguments");
+    if (nq == 0) return CVTMI_OK;
+    Tmp a, c, d;
+    CVTMI_TRY(a.upload(scores, (size_t)nq * n * sizeof(float)));
+    CVTMI_TRY(c.alloc((size_t)nq * k * sizeof(float)));
+    CVTMI_TRY(d.alloc((size_t)nq * k * sizeof(int64_t)));
+    CVTMI_TRY(cvtmi_topk_select_dev(a.as<float>(), nq, n, k, c.as<float>(), d.as<int64_t>(), nullptr));
+    CVTMI_HIP(hipMemcpy(dist, c.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
+    CVTMI_HIP(hipMemcpy(ids, d.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
 // ================================================================ flat ========================
 int cvtmi_flat_create(int metric, int D, cvtmi_flat_t *out)
 {

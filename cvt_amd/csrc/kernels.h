@@ -41,6 +41,9 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
 int launch_topk_merge(const float *in_d, const int64_t *in_id, int64_t nq, int L, int k, float *out_d, int64_t *out_id,
                       hipStream_t st);
 
+int launch_topk_select(const float *in_d, const int64_t *in_id, int64_t nq, int64_t n_cand, int k, float *out_d,
+                       int64_t *out_id, hipStream_t st);
+
 // ---- query_video.hip ----
 // probe[nq][nprobe] list ids in visiting order; list_off[coarseK+1]; codes/video_id in list order.
 int launch_coarse_probe(const OpqModelDev &m, const float *q_rot, int64_t nq, int nprobe, int32_t *probe,

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restr
             const int i = base + r * kBlock + tid;
             pay[r] = (uint32_t)i;
             key[r][0] = KEY_MAX;
-            if (i < n_cand && id[i] >= 0) {
+            if (i < n_cand && (in_id == nullptr || id[i] >= 0)) {
                 const uint32_t kk = f32_key(d[i]);
                 key[r][0] = kk == KEY_MAX ? KEY_MAX - 1 : kk;  // keep the "not a candidate" code free
             }
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restr
         if (i < cnt) {
             const uint32_t p = (uint32_t)tk.buf[0][i];
             out_d[q * k + i] = d[p];
-            out_id[q * k + i] = id[p];
+            out_id[q * k + i] = in_id ? id[p] : (int64_t)p;
         } else {
             out_d[q * k + i] = __uint_as_float(0x7f800000u);
             out_id[q * k + i] = -1;
@@ -61,11 +61,19 @@ __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restr
 int launch_topk_merge(const float *in_d, const int64_t *in_id, int64_t nq, int L, int k, float *out_d, int64_t *out_id,
                       hipStream_t st)
 {
-    if (nq <= 0) return CVTMI_OK;
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "topk_merge: k=%d outside 1..128", k);
     if (L < 1 || (int64_t)L * k > 0x7fffffff) return fail(CVTMI_EINVAL, "topk_merge: bad list count %d", L);
-    if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "topk_merge: nq too large");
-    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, L * k, k, out_d, out_id);
+    return launch_topk_select(in_d, in_id, nq, (int64_t)L * k, k, out_d, out_id, st);
+}
+
+// k smallest (value, id) of n_cand candidates per query; in_id == nullptr: id = position
+int launch_topk_select(const float *in_d, const int64_t *in_id, int64_t nq, int64_t n_cand, int k, float *out_d,
+                       int64_t *out_id, hipStream_t st)
+{
+    if (nq <= 0) return CVTMI_OK;
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "topk: k=%d outside 1..128", k);
+    if (n_cand < 0 || n_cand > 0x7fffffff) return fail(CVTMI_EINVAL, "topk: bad candidate count");
+    if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "topk: nq too large");
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, (int)n_cand, k, out_d, out_id);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

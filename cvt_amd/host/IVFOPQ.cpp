@@ -1,0 +1,312 @@
+// IVFOPQ.cpp -- host side of the reference's IVFOPQ class above the C ABI (see IVFOPQ.h).
+#include "IVFOPQ.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "../../include/cvtmi.h"
+
+using namespace std;
+
+void IVFOPQ::init()
+{
+    m_h = NULL; m_imgLocation = NULL;
+    m_coarseK = m_pq_m = m_pq_k = m_pq_step = m_featDim = 0;
+    m_imgNum = 0; m_imgCap = 0;
+}
+IVFOPQ::IVFOPQ(int maxIndexNum) : m_maxIndexNum(maxIndexNum) { init(); }
+IVFOPQ::IVFOPQ() : m_maxIndexNum(1 << 30) { init(); }
+IVFOPQ::~IVFOPQ()
+{
+    if (m_h) cvtmi_opq_destroy(m_h);
+    delete[] m_imgLocation;
+}
+std::string IVFOPQ::lastError() const { return cvtmi_last_error(); }
+long long IVFOPQ::numEntries() const
+{
+    int64_t n = 0;
+    if (m_h) cvtmi_opq_ntotal(m_h, &n);
+    return n;
+}
+
+bool IVFOPQ::ensureHandle()
+{
+    if (m_h) return true;
+    if (m_featDim <= 0) return false;
+    int rc = cvtmi_opq_create(m_featDim, m_coarseK, m_pq_m, m_pq_k, m_coarse.data(), m_books.data(), NULL,
+                              m_reorder.empty() ? NULL : m_reorder.data(), &m_h);
+    if (rc != CVTMI_OK) {
+        printf("cvtmi_opq_create failed: %s\n", cvtmi_last_error());
+        m_h = NULL;
+        return false;
+    }
+    return true;
+}
+
+// model file: int32 D, coarseK, M, K; fp32 coarse[coarseK][D]; fp32 books[M][K][D/M]; int32 reorder[D]
+int IVFOPQ::LoadModel(std::string modelFile)
+{
+    printf("load training file....\n");
+    ifstream fin(modelFile.c_str(), ios::binary);
+    if (!fin.is_open()) {
+        printf("Can not open the model file!\n");
+        return 0;
+    }
+    fin.read((char *)&m_featDim, sizeof(int));
+    fin.read((char *)&m_coarseK, sizeof(int));
+    fin.read((char *)&m_pq_m, sizeof(int));
+    fin.read((char *)&m_pq_k, sizeof(int));
+    if (!fin || m_featDim <= 0 || m_coarseK <= 0 || m_pq_m <= 0 || m_pq_k <= 0 || m_featDim % m_pq_m) {
+        printf("Bad model header!\n");
+        return 0;
+    }
+    m_pq_step = m_featDim / m_pq_m;
+    printf("feature dimension: %d, coarse codebook size: %d, subspace dimension: %d, number of subspace codebook: %d, "
+           "finetune codebook size: %d\n", m_featDim, m_coarseK, m_pq_step, m_pq_m, m_pq_k);
+    m_coarse.resize((size_t)m_coarseK * m_featDim);
+    fin.read((char *)m_coarse.data(), sizeof(float) * m_coarse.size());
+    m_books.resize((size_t)m_featDim * m_pq_k);
+    fin.read((char *)m_books.data(), sizeof(float) * m_books.size());
+    m_reorder.resize(m_featDim);
+    fin.read((char *)m_reorder.data(), sizeof(int) * m_featDim);
+    if (!fin) {
+        printf("Model file truncated!\n");
+        return 0;
+    }
+    fin.close();
+    if (m_h) { cvtmi_opq_destroy(m_h); m_h = NULL; }
+    return ensureHandle() ? 1 : 0;
+}
+
+// IVFOPQ::Add: coarse argmin + residual PQ argmin per row on the GPU, entries appended with
+// videoId = m_imgNum (IVFOPQ.cpp:105-170)
+void IVFOPQ::Add(float **m_ppFeat, const int m_frameNum)
+{
+    if (m_frameNum <= 0 || !ensureHandle()) return;
+    std::vector<int32_t> lists(m_frameNum), vids(m_frameNum, m_imgNum);
+    std::vector<uint8_t> codes((size_t)m_frameNum * m_pq_m);
+    // Init2DArray rows are one contiguous block (common.h:62-72); tolerate scattered rows as well
+    const float *x = m_ppFeat[0];
+    std::vector<float> tmp;
+    bool contiguous = true;
+    for (int i = 1; i < m_frameNum && contiguous; ++i) contiguous = m_ppFeat[i] == m_ppFeat[0] + (size_t)i * m_featDim;
+    if (!contiguous) {
+        tmp.resize((size_t)m_frameNum * m_featDim);
+        for (int i = 0; i < m_frameNum; ++i) memcpy(&tmp[(size_t)i * m_featDim], m_ppFeat[i], sizeof(float) * m_featDim);
+        x = tmp.data();
+    }
+    if (cvtmi_opq_encode(m_h, x, m_frameNum, lists.data(), codes.data()) != CVTMI_OK ||
+        cvtmi_opq_add_codes(m_h, codes.data(), m_coarseK > 1 ? lists.data() : NULL, vids.data(), m_frameNum) != CVTMI_OK)
+        printf("Add failed: %s\n", cvtmi_last_error());
+}
+
+void IVFOPQ::IndexDatabase(vector<string> featFiles)
+{
+    int num = min(int(featFiles.size()), m_maxIndexNum);
+    delete[] m_imgLocation;
+    m_imgLocation = new ImgNameStruct[num > 0 ? num : 1];
+    m_imgCap = num;
+    for (int i = 0; i < num; i++) {
+        std::cout << featFiles.at(i) << std::endl;
+        float **m_ppFeat = NULL;
+        int m_frameNum = 0;
+        std::string srcFile = featFiles.at(i);
+        LoadSingleFeatFile(srcFile, m_ppFeat, m_frameNum);
+        if (m_frameNum > 0) {
+            Add(m_ppFeat, m_frameNum);
+            memset(m_imgLocation[m_imgNum].ptr, 0, max_path * sizeof(char));
+            strncpy(m_imgLocation[m_imgNum].ptr, srcFile.c_str(), max_path - 1);
+            m_imgNum++;
+        }
+        Delete2DArray(m_ppFeat);
+    }
+}
+
+void IVFOPQ::queryImpl(const std::string &featFile, vector<vector<float> > &matchScore, int nk)
+{
+    float **m_ppFeat = NULL;
+    int m_frameNum = 0;
+    LoadSingleFeatFile(featFile, m_ppFeat, m_frameNum);
+    if (m_frameNum == 0) return;
+    matchScore.resize(m_frameNum);
+    std::vector<float> ms((size_t)m_frameNum * std::max(m_imgNum, 1));
+    int rc = CVTMI_OK;
+    if (m_imgNum > 0) rc = cvtmi_opq_query_video(m_h, m_ppFeat[0], m_frameNum, /*rotate=*/0, nk, m_imgNum, ms.data());
+    if (rc != CVTMI_OK) printf("Query failed: %s\n", cvtmi_last_error());
+    for (int f = 0; f < m_frameNum; ++f)
+        matchScore.at(f).assign(ms.begin() + (size_t)f * m_imgNum, ms.begin() + (size_t)(f + 1) * m_imgNum);
+    Delete2DArray(m_ppFeat);
+}
+void IVFOPQ::Query(string featFile, vector<vector<float> > &matchScore, int nk) { queryImpl(featFile, matchScore, nk); }
+void IVFOPQ::QueryThrehold(string featFile, vector<vector<float> > &matchScore, int nk) { queryImpl(featFile, matchScore, nk); }
+
+int IVFOPQ::SearchTopK(const float *q, int nq, int k, float *dist, long long *ids)
+{
+    if (!ensureHandle()) return 0;
+    static_assert(sizeof(long long) == sizeof(int64_t), "id width");
+    return cvtmi_opq_search(m_h, q, nq, /*rotate=*/1, k, dist, (int64_t *)ids) == CVTMI_OK ? 1 : 0;
+}
+
+// raw fp32 [n][D] file, n = bytes / (4 D); every row goes through the model's rotation (:441-462)
+void IVFOPQ::LoadSingleFeatFile(string srcFile, float **&m_ppFeat, int &m_frameNum)
+{
+    ifstream fin(srcFile.c_str(), ios::binary);
+    if (!fin.is_open()) {
+        cout << "Error open the feat file: " << srcFile << endl;
+        return;
+    }
+    fin.seekg(0, ios::end);
+    long long file_size = (long long)fin.tellg();
+    fin.seekg(0, ios::beg);
+    m_frameNum = m_featDim > 0 ? (int)(file_size / (sizeof(float) * m_featDim)) : 0;
+    if (m_frameNum <= 0) { m_frameNum = 0; return; }
+    std::vector<float> raw((size_t)m_frameNum * m_featDim);
+    fin.read((char *)raw.data(), sizeof(float) * raw.size());
+    fin.close();
+    Init2DArray(m_ppFeat, m_frameNum, m_featDim);
+    if (!ensureHandle() || cvtmi_opq_rotate(m_h, raw.data(), m_frameNum, m_ppFeat[0]) != CVTMI_OK) {
+        printf("rotation failed: %s\n", cvtmi_last_error());
+        Delete2DArray(m_ppFeat);
+        m_frameNum = 0;
+    }
+}
+
+static string index_file_name(const string &dir, int imgNum, int D, int K, int m, int k)
+{
+    stringstream ss;
+    ss << dir << "/OPQ_Index_db_" << imgNum << "_dim_" << D << "_k_" << K << "_PQ_m" << m << "_k" << k << ".fvecs";
+    return ss.str();
+}
+
+// int32 D, coarseK, M, K, imgNum; coarse; books; per list: int32 n, n x {int32 videoId, uint8 code[M]};
+// imgNum x char[260]   (IVFOPQ.cpp:544-580).  log.txt is written like the reference does.
+void IVFOPQ::SaveIndex(string desDir)
+{
+    cout << "save index file..." << endl;
+    if (!ensureHandle()) return;
+    string path = index_file_name(desDir, m_imgNum, m_featDim, m_coarseK, m_pq_m, m_pq_k);
+    ofstream outFile(path.c_str(), ios::binary);
+    outFile.write((char *)&m_featDim, sizeof(int));
+    outFile.write((char *)&m_coarseK, sizeof(int));
+    outFile.write((char *)&m_pq_m, sizeof(int));
+    outFile.write((char *)&m_pq_k, sizeof(int));
+    outFile.write((char *)&m_imgNum, sizeof(int));
+    outFile.write((char *)m_coarse.data(), sizeof(float) * m_coarse.size());
+    outFile.write((char *)m_books.data(), sizeof(float) * m_books.size());
+    int64_t n = 0;
+    cvtmi_opq_ntotal(m_h, &n);
+    std::vector<int64_t> off((size_t)m_coarseK + 1);
+    std::vector<int32_t> vid((size_t)n);
+    std::vector<uint8_t> codes((size_t)n * m_pq_m);
+    if (cvtmi_opq_get_entries(m_h, off.data(), vid.data(), codes.data()) != CVTMI_OK)
+        printf("SaveIndex failed: %s\n", cvtmi_last_error());
+    ofstream fout("log.txt");
+    for (int i = 0; i < m_coarseK; i++) {
+        int cnt = (int)(off[i + 1] - off[i]);
+        if (cnt > 0) {
+            fout << "coarse center: " << i << ", " << cnt << std::endl;
+            std::cout << "coarse center: " << i << ", " << cnt << std::endl;
+        }
+        outFile.write((char *)&cnt, sizeof(int));
+        for (int64_t j = off[i]; j < off[i + 1]; j++) {
+            outFile.write((char *)&vid[j], sizeof(int));
+            outFile.write((char *)&codes[(size_t)j * m_pq_m], m_pq_m);
+        }
+    }
+    fout.close();
+    for (int i = 0; i < m_imgNum; i++) outFile.write(m_imgLocation[i].ptr, sizeof(char) * max_path);
+    outFile.close();
+}
+
+void IVFOPQ::LoadIndex(string srcFile)
+{
+    cout << "load index..." << endl;
+    ifstream fin(srcFile.c_str(), ios::binary);
+    if (!fin.is_open()) {
+        cout << "Can not open the index file." << endl;
+        exit(0);
+    }
+    fin.read((char *)&m_featDim, sizeof(int));
+    fin.read((char *)&m_coarseK, sizeof(int));
+    fin.read((char *)&m_pq_m, sizeof(int));
+    fin.read((char *)&m_pq_k, sizeof(int));
+    fin.read((char *)&m_imgNum, sizeof(int));
+    if (!fin || m_featDim <= 0 || m_pq_m <= 0 || m_featDim % m_pq_m) {
+        cout << "Bad index header." << endl;
+        exit(0);
+    }
+    m_pq_step = m_featDim / m_pq_m;
+    m_coarse.resize((size_t)m_coarseK * m_featDim);
+    fin.read((char *)m_coarse.data(), sizeof(float) * m_coarse.size());
+    m_books.resize((size_t)m_featDim * m_pq_k);
+    fin.read((char *)m_books.data(), sizeof(float) * m_books.size());
+    // the rotation is not part of the index file (the reference loads the model first, multi_frame_index_test.cpp:46-47)
+    if ((int)m_reorder.size() != m_featDim) {
+        m_reorder.resize(m_featDim);
+        for (int i = 0; i < m_featDim; ++i) m_reorder[i] = i;
+    }
+    if (m_h) { cvtmi_opq_destroy(m_h); m_h = NULL; }
+    if (!ensureHandle()) exit(0);
+    std::vector<int32_t> lists, vids;
+    std::vector<uint8_t> codes;
+    for (int i = 0; i < m_coarseK; i++) {
+        int cnt = 0;
+        fin.read((char *)&cnt, sizeof(int));
+        for (int j = 0; j < cnt; ++j) {
+            int v = 0;
+            fin.read((char *)&v, sizeof(int));
+            size_t o = codes.size();
+            codes.resize(o + m_pq_m);
+            fin.read((char *)&codes[o], m_pq_m);
+            lists.push_back(i); vids.push_back(v);
+        }
+    }
+    if (!lists.empty() &&
+        cvtmi_opq_add_codes(m_h, codes.data(), m_coarseK > 1 ? lists.data() : NULL, vids.data(), (int64_t)lists.size()) != CVTMI_OK)
+        printf("LoadIndex failed: %s\n", cvtmi_last_error());
+    delete[] m_imgLocation;
+    m_imgLocation = new ImgNameStruct[m_imgNum > 0 ? m_imgNum : 1];
+    m_imgCap = m_imgNum;
+    for (int i = 0; i < m_imgNum; i++) fin.read(m_imgLocation[i].ptr, sizeof(char) * max_path);
+    fin.close();
+}
+
+// ---- opq/src/common.h helpers ----
+std::vector<std::pair<float, unsigned> > get_sort_results(const std::vector<float> &match_score, int results_per_query)
+{
+    // the k smallest (score, index) pairs, selected on the device
+    const int n = (int)match_score.size();
+    std::vector<std::pair<float, unsigned> > t(results_per_query > 0 ? results_per_query : 0);
+    if (n == 0 || results_per_query <= 0) return t;
+    const int k = results_per_query > 128 ? 128 : results_per_query;
+    std::vector<float> od(k);
+    std::vector<int64_t> oi(k);
+    if (cvtmi_topk_select(match_score.data(), 1, n, k, od.data(), oi.data()) != CVTMI_OK) {
+        printf("get_sort_results failed: %s\n", cvtmi_last_error());
+        return t;
+    }
+    for (int i = 0; i < k; ++i) t[i] = std::make_pair(od[i], (unsigned)oi[i]);
+    return t;
+}
+
+std::string get_base_name(const std::string path)
+{
+    size_t pos = path.find_last_of("/\\");
+    std::string s1 = path.substr(pos + 1);
+    pos = s1.find_last_of('.');
+    return s1.substr(0, pos);
+}
+
+void get_vector_of_strings_from_file_lines(const std::string file_name, std::vector<std::string> &out)
+{
+    std::ifstream in_file(file_name.c_str());
+    std::string line;
+    out.clear();
+    while (std::getline(in_file, line))
+        if (!line.empty()) out.push_back(line);
+}

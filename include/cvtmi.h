@@ -141,6 +141,12 @@ int cvtmi_topk_merge(const float *in_dist, const int64_t *in_ids, int64_t nq, in
 int cvtmi_topk_merge_dev(const float *in_dist, const int64_t *in_ids, int64_t nq, int L, int k,
                          float *dist, int64_t *ids, void *stream);
 
+/* get_sort_results (opq/src/common.h:25-37): the k smallest (score, index) pairs of scores[nq][n],
+ * ascending; rows short of k entries are padded with (+inf, -1).  k <= 128. */
+int cvtmi_topk_select(const float *scores, int64_t nq, int64_t n, int k, float *dist, int64_t *ids);
+int cvtmi_topk_select_dev(const float *scores, int64_t nq, int64_t n, int k, float *dist, int64_t *ids,
+                          void *stream);
+
 /* ---------------------------------------------------------------- exhaustive (flat) search -- */
 /* hnswlib::BruteforceSearch<dist_t> + SpaceInterface (brute_force_search/src/brutoforce.hpp:9-136,
  * hnswlib.hpp:34-58).  Rows are D fp32 (IP, L2F) or D uint8 (L2U8). */

@@ -66,6 +66,16 @@ def run_opq_case(name, rng, D, coarseK, M, K, videos, queries, nk, orc, scale=1.
         total += ms[f]
     kk = min(topk, img_num)
     rank_d, rank_i = ref.sort_results(total, kk)
+    # the reference's SaveIndex file (IVFOPQ.cpp:516-583) minus the trailing imgNum x char[260] path block
+    import glob as _glob
+    ref.save_index(ref.tmp.name)
+    idx_files = _glob.glob(os.path.join(ref.tmp.name, "OPQ_Index_db_*.fvecs"))
+    assert len(idx_files) == 1
+    raw = np.fromfile(idx_files[0], dtype=np.uint8)
+    index_head = raw[:raw.size - img_num * 260].copy()
+    index_name = os.path.basename(idx_files[0])
+    if os.path.exists("log.txt"):
+        os.remove("log.txt")  # SaveIndex drops a log.txt in the cwd
     ref.close()
 
     # ---- the restatement must reproduce the reference bit for bit ----
@@ -89,7 +99,8 @@ def run_opq_case(name, rng, D, coarseK, M, K, videos, queries, nk, orc, scale=1.
         name, D, coarseK, M, K, allv.shape[0], queries.shape[0], nk, 100.0 * np.mean(ms == 1.0)))
     return dict(perm=perm, coarse=coarse, books=books, db=allv, video_rows=np.array([v.shape[0] for v in videos]),
                 queries=queries, nk=np.int32(nk), db_rot=db_rot, q_rot=q_rot, list_off=list_off,
-                video_id=video_id, codes=codes, match_score=ms, total=total, rank_d=rank_d, rank_i=rank_i)
+                video_id=video_id, codes=codes, match_score=ms, total=total, rank_d=rank_d, rank_i=rank_i,
+                index_head=index_head, index_name=np.frombuffer(index_name.encode(), dtype=np.uint8))
 
 
 def main():

@@ -1,0 +1,110 @@
+"""GPU: the C++ mirror of the reference classes (cvt_amd/host: IVFOPQ, hnswlib::BruteforceSearch,
+cvtk::quant::Int8Quan) driven through its CLIs, the way the reference's own mains drive the originals.
+Expected outputs are the golden vectors produced by the reference (index file bytes, ranks, top-k)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "cvt_amd", "bin")
+NAMES = ["6231519245", "6231075428", "6230951284", "6230880830", "6231307582"]  # opq/data/5_feats_list.txt order
+
+
+def run(args, cwd):
+    r = subprocess.run(args, cwd=cwd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (args, r.stdout[-2000:], r.stderr[-2000:])
+    return r.stdout
+
+
+def write_model(path, g):
+    from oracle import binding as ob
+    ob.write_opq_model(path, g["coarse"], g["books"], g["perm"])
+
+
+def test_opq_index_and_query_cli(tmp_path, golden):
+    for exe in ("opq_index", "opq_query"):
+        assert os.path.exists(os.path.join(BIN, exe)), "host CLIs not built: __graft_entry__.build()"
+    g = golden.opq["opq_real_q9"]
+    model = str(tmp_path / "model.bin")
+    write_model(model, g)
+    lst = tmp_path / "feats.txt"
+    lst.write_text("\n".join(os.path.join(golden.dir, "opq_data", "db", n + "_feat.bin") for n in NAMES) + "\n")
+    out_dir = tmp_path / "out"; out_dir.mkdir()
+    run([os.path.join(BIN, "opq_index"), model, str(lst), str(out_dir)], cwd=str(tmp_path))
+    name = bytes(g["index_name"]).decode()
+    idx_file = out_dir / name
+    assert idx_file.exists(), os.listdir(out_dir)                       # same file name as the reference builds
+    raw = np.fromfile(idx_file, dtype=np.uint8)
+    head = raw[:raw.size - 5 * 260]
+    assert np.array_equal(head, g["index_head"]), "index file differs from the reference's SaveIndex bytes"
+    paths = raw[raw.size - 5 * 260:].reshape(5, 260)
+    assert bytes(paths[0]).split(b"\0")[0].decode().endswith(NAMES[0] + "_feat.bin")
+    # query: both reference query files, nprobe 3, top 5
+    for case, qf in (("opq_real_q1", "6231519245_6_feat.bin"), ("opq_real_q9", "6231519245_feat.bin")):
+        gg = golden.opq[case]
+        res = tmp_path / ("res_%s.txt" % case)
+        run([os.path.join(BIN, "opq_query"), model, str(idx_file), str(res),
+             os.path.join(golden.dir, "opq_data", "query", qf), "--nearest", "3", "--show", "5"], cwd=str(tmp_path))
+        lines = res.read_text().splitlines()
+        names = lines[1].split()
+        scores = [float(x) for x in lines[2].split()]
+        assert names == [NAMES[i] + "_feat" for i in gg["rank_i"]]
+        assert np.allclose(scores, gg["rank_d"], rtol=2e-5)            # text output: 6 significant digits
+    assert names[0] == "6231519245_feat"                                # the known answer of SURVEY.md 4
+
+
+def write_records(path, ids, x):
+    with open(path, "wb") as f:
+        f.write(struct.pack("i", len(ids)))
+        for s, row in zip(ids, x):
+            b = s.encode()
+            f.write(struct.pack("i", len(b))); f.write(b)
+            f.write(struct.pack("i", row.shape[0])); f.write(np.ascontiguousarray(row, dtype=np.float32).tobytes())
+
+
+def test_brute_force_cli(tmp_path, golden):
+    f = golden.flat
+    db, q = f["ip_db"], f["ip_q"]
+    write_records(tmp_path / "db.bin", ["id%05d" % i for i in range(db.shape[0])], db)
+    write_records(tmp_path / "querys.bin", ["q%03d" % i for i in range(q.shape[0])], q)
+    run([os.path.join(BIN, "brute_force"), "db.bin", "querys.bin", "index.bin", "gt.txt", "128", "100"], cwd=str(tmp_path))
+    lines = (tmp_path / "gt.txt").read_text().splitlines()
+    assert len(lines) == q.shape[0]
+    for qi, line in enumerate(lines):
+        head, rest = line.split(" topK: ")
+        ids_s, d_s = rest.split("dists: ")
+        ids = [int(t[2:]) for t in ids_s.split()]
+        ds = np.array([float(t) for t in d_s.split()])
+        assert head == "q%03d" % qi
+        assert ids == list(f["ip_i"][qi])                                # same neighbours, same order as the reference
+        assert np.allclose(ds, 1.0 - f["ip_d"][qi].astype(np.float64), rtol=1e-5, atol=1e-6)
+    # index.bin layout: size_t max, size_t per_elem, size_t count, rows of [vector][size_t label]
+    raw = (tmp_path / "index.bin").read_bytes()
+    mx, per, cnt = struct.unpack("QQQ", raw[:24])
+    assert (mx, per, cnt) == (db.shape[0], 128 * 4 + 8, db.shape[0])
+    row3 = np.frombuffer(raw[24 + 3 * per:24 + 3 * per + 512], dtype=np.float32)
+    assert np.array_equal(row3, db[3]) and struct.unpack("Q", raw[24 + 3 * per + 512:24 + 4 * per])[0] == 3
+
+
+def test_sq8_cli(tmp_path, orc, golden):
+    rng = np.random.default_rng(6)
+    d, n = 64, 500
+    x = np.abs(rng.normal(size=(n, d))).astype(np.float32)
+    x[0] = golden.sq8["int8_quan_test_x"]
+    write_records(tmp_path / "feats.bin", ["v%d" % i for i in range(n)], x)
+    run([os.path.join(BIN, "sq_train"), "feats.bin", "model.bin", str(d)], cwd=str(tmp_path))
+    raw = (tmp_path / "model.bin").read_bytes()
+    assert struct.unpack("i", raw[:4])[0] == d
+    vmin = np.frombuffer(raw[4:4 + 4 * d], dtype=np.float32); vdiff = np.frombuffer(raw[4 + 4 * d:], dtype=np.float32)
+    ovmin, ovdiff = orc.sq8_train(x)
+    assert np.array_equal(bits(vmin), bits(ovmin)) and np.array_equal(bits(vdiff), bits(ovdiff))
+    out = run([os.path.join(BIN, "int8_quan_demo"), "model.bin"], cwd=str(tmp_path))
+    codes = [int(t) for t in [l for l in out.splitlines() if l.startswith("int8: ")][0].split()[1:]]
+    ocodes, _ = orc.sq8_encode(ovmin, ovdiff, x[:1])
+    assert codes == list(ocodes[0])
