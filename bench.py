@@ -135,7 +135,7 @@ def main():
                        "rows": args.rows, "rows_per_gpu": r1 - r0, "nq_per_step": nq, "k": k, "M": M,
                        "parallelism": "row-sharded x%d + RCCL all-gather of per-shard top-k" % world if world > 1 else "1 GPU",
                        "qtile": scan["qtile"], "row_splits": scan["splits"]},
-            "roofline": {"bound": "hbm", "kernel": "adc_scan_kernel<M=%d,QT=%d>" % (M, scan["qtile"]),
+            "roofline": {"bound": "hbm", "kernel": "adc_scan16q_kernel (M=%d, %d queries per pass)" % (M, scan["qtile"]) if (M == 16 and scan["qtile"] == 8) else "adc_scan kernel (M=%d, %d queries per pass)" % (M, scan["qtile"]),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": scan["code_bytes"], "kernel_ms": round(scan["ms"], 4),

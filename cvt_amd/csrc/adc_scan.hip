@@ -41,6 +41,7 @@ struct ScanArgs {
     int groups;
     float *part_d;
     int64_t *part_id;
+    const float *lut_g;  // [nq][M][K] fp32 tables in HBM (adc_scan16q only)
 };
 
 template <int M> struct CodeRow;
@@ -262,7 +263,7 @@ constexpr int S16_TRIG = 256;
 
 // thr key -> the bound the rotated-order sums are compared with
 struct InflateThr {
-    __device__ __forceinline__ uint32_t operator()(uint32_t t) const
+    __device__ __forceinline__ uint32_t operator()(int /*q*/, uint32_t t) const
     {
         if (t >= 0x7f800000u) return t;  // no finite threshold yet (KEY_MAX) or +inf: compare as is
         const float f = __uint_as_float(t);
@@ -484,6 +485,404 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16_kernel(const ScanArgs
     }
 }
 
+// ==========================================================================================
+// adc_scan16q: 8 queries per pass over the codes, filter on 15-bit FIXED-POINT LOWER BOUNDS.
+//
+// adc_scan16 above is bound by LDS bandwidth: 4 bytes of table per look-up, 256 B/clk/CU.  Since its
+// rotated-order sums are only a filter anyway, the filter table does not have to be fp32.  Here each
+// table entry is a 16-bit integer  qv = floor((LUT[m][j] - min_m) / scale) - 1  (>= 0, per-query scale
+// chosen so that sum_m max_j qv <= 32766), i.e. a rigorous LOWER bound of the entry in units of `scale`:
+//     sum_m qv_m  <=  (exact_real_sum - sum_m min_m) / scale .
+// One ds_read_b128 now serves EIGHT queries, sums are exact integers (v_pk_add_u16, order-free), and a
+// row is a candidate when  sum < T  with  T = floor((thr*(1+1e-6) - bias)/scale) + 2  -- every row whose
+// reference-order fp32 distance is below thr passes.  Candidates (~0.1 % of rows) are re-evaluated
+// EXACTLY at compaction straight from the codebooks in the reference's operation order
+// (IVFOPQ.cpp:279-291 + :302-306), so results stay bit-identical; no fp32 table is kept in LDS.
+// Measured on the bare loop (tools/ubench/scan_loop_u16.hip): 36-45 T look-ups/s vs 21-25 for fp32.
+// ==========================================================================================
+#ifdef CVTMI_SCAN_TIMING
+__device__ unsigned long long g_scan_dbg[8];
+#define SQ_T(i) do { if (threadIdx.x == 0) { const unsigned long long now__ = clock64(); t_acc__[i] += now__ - t_last__; t_last__ = now__; } } while (0)
+#define SQ_T0() unsigned long long t_last__ = clock64(); unsigned long long t_acc__[5] = { 0, 0, 0, 0, 0 }
+#define SQ_TEND() do { if (threadIdx.x == 0) for (int i__ = 0; i__ < 5; ++i__) atomicAdd(&g_scan_dbg[i__], t_acc__[i__]); } while (0)
+#else
+#define SQ_T(i) do { } while (0)
+#define SQ_T0() do { } while (0)
+#define SQ_TEND() do { } while (0)
+#endif
+constexpr int SQ_QT = 8;
+constexpr int SQ_CAP = 238;   // two workgroups per CU: (81920 - 65536 table - ~1 KB control) / 8 queries / 8 bytes
+constexpr int SQ_TRIG = 192;
+constexpr int SQ_MAXSUM = 32766;
+
+struct QuantParams {
+    union {
+        float mn[SQ_QT][16];          // per (query, sub-quantiser) minimum finite table entry
+        uint32_t mn_bits[SQ_QT][16];  // same words while the minimum is being reduced (non-negative floats)
+    };
+    float inv_scale[SQ_QT];
+    double scale_eff[SQ_QT];  // 1 / inv_scale, the scale the integers are really in
+    double bias[SQ_QT];       // sum_m mn[m]
+};
+
+struct QuantThr {
+    const QuantParams *qp;
+    __device__ __forceinline__ uint32_t operator()(int q, uint32_t t) const
+    {
+        if (t >= 0x7f800000u) return 32767u;  // no finite threshold yet: every sum (<= 32766) passes
+        const double x = ((double)__uint_as_float(t) * (1.0 + 1e-6) - qp->bias[q]) / qp->scale_eff[q];
+        if (!(x > 0.0)) return 2u;
+        const double f = floor(x) + 2.0;
+        return f > 32767.0 ? 32767u : (uint32_t)f;
+    }
+};
+
+// exact reference-order distance of (row, query): sum over m ascending of the fp32 table entries
+// (IVFOPQ.cpp:302-306) gathered from the per-query tables in HBM -- 16 independent loads.
+struct ExactFromLut {
+    static constexpr bool enabled = true;
+    const uint4 *rows;
+    const float *lut_g;
+    int K, nq, group;
+    __device__ __forceinline__ unsigned long long operator()(int q, unsigned long long e) const
+    {
+        const uint32_t row = (uint32_t)e;
+        const uint4 c = rows[row];
+        const uint32_t w[4] = { c.x, c.y, c.z, c.w };
+        int qi = group * SQ_QT + q;
+        qi = qi < nq ? qi : nq - 1;
+        const float *t = lut_g + (int64_t)qi * 16 * K;
+        float v[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int j = (int)((w[m >> 2] >> (8 * (m & 3))) & 0xffu);
+            v[m] = j < K ? t[m * K + j] : __uint_as_float(0x7f800000u);
+        }
+        float s = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) s = __fadd_rn(s, v[m]);
+        return ((unsigned long long)__float_as_uint(s) << 32) | row;
+    }
+};
+
+// batched form for the register compaction: up to 4 entries per lane, all row loads first, then all
+// 64 table gathers, then the in-order sums -- two dependent memory round trips per batch instead of 2 x 4
+struct ExactFromLutBatch {
+    const uint4 *rows;
+    const float *lut_g;
+    int K, nq, group;
+    __device__ __forceinline__ void operator()(int q, unsigned long long (&e)[4], const bool (&need)[4]) const
+    {
+        int qi = group * SQ_QT + q;
+        qi = qi < nq ? qi : nq - 1;
+        const float *t = lut_g + (int64_t)qi * 16 * K;
+        uint4 c[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = rows[need[r] ? (uint32_t)e[r] : 0u];
+#pragma unroll
+        for (int h = 0; h < 4; h += 2) {  // two entries at a time: 32 gathers in flight, 32 registers
+            float v[2][16];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t w[4] = { c[h + r].x, c[h + r].y, c[h + r].z, c[h + r].w };
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    const int j = (int)((w[m >> 2] >> (8 * (m & 3))) & 0xffu);
+                    v[r][m] = j < K ? t[m * K + j] : __uint_as_float(0x7f800000u);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                float s = 0.0f;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) s = __fadd_rn(s, v[r][m]);
+                if (need[h + r]) e[h + r] = ((unsigned long long)__float_as_uint(s) << 32) | (uint32_t)e[h + r];
+            }
+        }
+    }
+};
+
+typedef unsigned short cvt_us2 __attribute__((ext_vector_type(2)));
+typedef short cvt_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (cvt_us2)(__builtin_bit_cast(cvt_us2, a) + __builtin_bit_cast(cvt_us2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (cvt_s2)(__builtin_bit_cast(cvt_s2, a) - __builtin_bit_cast(cvt_s2, b)));
+}
+
+template <int NT, int R>
+__global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArgs a)
+{
+    constexpr int M = 16, QT = SQ_QT;
+    __shared__ __attribute__((aligned(16))) uint32_t lut[256 * 16 * QT / 2];  // u16 [code j][m][q]: 16 B per (j, m)
+    __shared__ TopKShared<QT, SQ_CAP> tk;
+    __shared__ QuantParams qp;
+    __shared__ struct { int stop, done_waves; uint32_t next_chunk; uint32_t thr_pk[QT / 2]; } ck;
+
+    SQ_T0();
+    int group, split;
+    {
+        const int b = blockIdx.x;
+        if ((a.splits & 7) == 0) {
+            const int s8 = a.splits >> 3;
+            const int xcd = b & 7, i = b >> 3;
+            split = xcd + 8 * (i % s8);
+            group = i / s8;
+        } else {
+            split = b % a.splits;
+            group = b / a.splits;
+        }
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    topk_init(tk);
+    uint32_t(*mx_bits)[16] = reinterpret_cast<uint32_t(*)[16]>(&tk.buf[0][0]);  // 128 words on the (still unused) buffers
+    if (tid < QT * 16) {
+        qp.mn_bits[tid >> 4][tid & 15] = 0x7f7fffffu;  // FLT_MAX
+        mx_bits[tid >> 4][tid & 15] = 0u;
+    }
+    __syncthreads();
+    // fp32 table entries of (m, j) for the QT queries, from the per-query tables a.lut_g
+    // (lut_kernel: IVFOPQ.cpp:279-291); lanes walk consecutive j -> coalesced
+    int qis[QT];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        const int qi = group * QT + q;
+        qis[q] = qi < a.nq ? qi : a.nq - 1;
+    }
+    auto entry = [&](int m, int j, float (&acc)[QT]) {
+#pragma unroll
+        for (int q = 0; q < QT; ++q)
+            acc[q] = j < a.K ? a.lut_g[((int64_t)qis[q] * M + m) * a.K + j] : __uint_as_float(0x7f800000u);
+    };
+    // pass A: per (query, m) range of the finite entries (a wave covers 64 consecutive j of one m)
+    for (int e = tid; e < M * 256; e += NT) {
+        const int m = e >> 8, j = e & 255;
+        float acc[QT];
+        entry(m, j, acc);
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            const uint32_t bits = __float_as_uint(acc[q]);
+            uint32_t lo = bits < 0x7f800000u ? bits : 0x7f7fffffu;  // non-finite: ignored
+            uint32_t hi = bits < 0x7f800000u ? bits : 0u;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const uint32_t l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+                lo = l2 < lo ? l2 : lo;
+                hi = h2 > hi ? h2 : hi;
+            }
+            if (lane == 0) {
+                atomicMin(&qp.mn_bits[q][m], lo);
+                atomicMax(&mx_bits[q][m], hi);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < QT) {
+        const int q = tid;
+        float range = 0.0f;
+        double bias = 0.0;
+        for (int m = 0; m < M; ++m) {
+            uint32_t lo = qp.mn_bits[q][m], hi = mx_bits[q][m];
+            if (lo > hi) { lo = 0u; hi = 0u; }  // no finite entry at all
+            const float fl = __uint_as_float(lo), fh = __uint_as_float(hi);
+            qp.mn[q][m] = fl;
+            range += fh - fl;
+            bias += (double)fl;
+        }
+        float scale = range > 0.0f ? range / (float)SQ_MAXSUM * 1.001f : 1.0f;
+        if (!(scale > 1e-37f)) scale = 1e-37f;
+        const float inv = 1.0f / scale;
+        qp.inv_scale[q] = inv;
+        qp.scale_eff[q] = 1.0 / (double)inv;
+        qp.bias[q] = bias;
+    }
+    __syncthreads();
+    // pass B: quantise  qv = max(0, floor((v - min_m) * inv) - 1), non-finite entries -> 0 (a lower bound of anything)
+    for (int e = tid; e < M * 256; e += NT) {
+        const int m = e >> 8, j = e & 255;
+        float acc[QT];
+        entry(m, j, acc);
+        uint32_t qv[QT];
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            const float v = acc[q];
+            int iv = 0;
+            if (__float_as_uint(v) < 0x7f800000u) {
+                const float f = __fmul_rn(__fsub_rn(v, qp.mn[q][m]), qp.inv_scale[q]);
+                iv = (int)floorf(f) - 1;
+                iv = iv < 0 ? 0 : (iv > SQ_MAXSUM ? SQ_MAXSUM : iv);
+            }
+            qv[q] = (uint32_t)iv;
+        }
+        *reinterpret_cast<uint4 *>(&lut[(j * 16 + m) * (QT / 2)]) =
+            make_uint4(qv[0] | (qv[1] << 16), qv[2] | (qv[3] << 16), qv[4] | (qv[5] << 16), qv[6] | (qv[7] << 16));
+    }
+    __syncthreads();  // tables ready; the scratch words on tk.buf are dead from here on
+    SQ_T(0);  // prologue
+
+    const uint4 *rows = reinterpret_cast<const uint4 *>(a.codes);
+    const ExactFromLutBatch fixb{ rows, a.lut_g, a.K, a.nq, group };
+    const QuantThr thrx{ &qp };
+    if (tid < QT) tk.thr_x[tid] = 32767u;  // pass-all until k exact distances are known
+    if (tid < QT / 2) ck.thr_pk[tid] = 0x7fff7fffu;
+    if (tid == 0) { ck.stop = 0; ck.done_waves = 0; ck.next_chunk = 0; }
+    __syncthreads();
+
+    const int64_t row_begin = (int64_t)split * a.rows_per_split;
+    int64_t row_end = row_begin + a.rows_per_split;
+    row_end = row_end < a.n_rows ? row_end : a.n_rows;
+    const uint32_t n_local = (uint32_t)(row_end > row_begin ? row_end - row_begin : 0);
+    const char *rows_b = reinterpret_cast<const char *>(rows + row_begin);
+    const uint32_t last = n_local ? n_local - 1 : 0;
+    auto load_row = [&](uint32_t lrow) -> uint4 {
+        const uint32_t cl = lrow < last ? lrow : last;
+        return *reinterpret_cast<const uint4 *>(rows_b + (size_t)(cl * 16u));
+    };
+    const uint32_t c = tid & 15;
+    const uint32_t cr8 = (c & 3) * 8, cq = c >> 2;
+    uint32_t moffp[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        moffp[w] = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) moffp[w] |= (((4 * w + b + c) & 15u) * 16u) << (8 * b);
+    }
+    const char *lut_b = reinterpret_cast<const char *>(lut);
+
+    // ---- main loop: waves run on their own between checkpoints ----
+    // Between two checkpoints a wave processes 64*R-row chunks with NO workgroup barrier: candidates go to the shared buffers with LDS atomics.  A push that
+    // finds its buffer full raises `stop`, the wave keeps its position (the `done` bits remember what it
+    // already stored from that chunk) and everybody meets at the checkpoint, where the buffers are
+    // compacted when one is full or past TRIG.  Row order across waves is arbitrary: legal here because
+    // the filter is a superset test and the exact (distance, id) sort decides (block_topk.h).
+    constexpr int NW = NT / 64;
+    constexpr uint32_t WROWS = 64 * R;
+    const uint32_t n_chunks = (n_local + WROWS - 1) / WROWS;
+    // chunks are handed out dynamically (one LDS atomic per 64*R rows): waves that run faster take more,
+    // so nobody waits long at the final checkpoint.  `it` = chunk in hand, `it_next` = already reserved
+    // and being prefetched.
+    auto grab = [&]() -> uint32_t {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&ck.next_chunk, 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    uint32_t it = grab(), it_next = grab(), done = 0;
+    bool counted = false;
+    uint4 cur[R], nxt[R];
+    if (n_local) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) cur[r] = load_row(it * WROWS + r * 64 + lane);
+    }
+    for (;;) {
+        uint32_t tpk[QT / 2];
+#pragma unroll
+        for (int i = 0; i < QT / 2; ++i) tpk[i] = ck.thr_pk[i];
+        while (it < n_chunks) {
+            const int stop_seen = ck.stop;  // read early, used after the chunk
+            const uint32_t base = it * WROWS;
+#pragma unroll
+            for (int r = 0; r < R; ++r) nxt[r] = load_row(it_next * WROWS + r * 64 + lane);
+            bool failed = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                uint32_t d0 = __builtin_amdgcn_alignbit(cur[r].y, cur[r].x, cr8);
+                uint32_t d1 = __builtin_amdgcn_alignbit(cur[r].z, cur[r].y, cr8);
+                uint32_t d2 = __builtin_amdgcn_alignbit(cur[r].w, cur[r].z, cr8);
+                uint32_t d3 = __builtin_amdgcn_alignbit(cur[r].x, cur[r].w, cr8);
+                {
+                    const bool b0 = cq & 1;
+                    const uint32_t e0 = b0 ? d1 : d0, e1 = b0 ? d2 : d1, e2 = b0 ? d3 : d2, e3 = b0 ? d0 : d3;
+                    const bool b1 = cq & 2;
+                    d0 = b1 ? e2 : e0; d1 = b1 ? e3 : e1; d2 = b1 ? e0 : e2; d3 = b1 ? e1 : e3;
+                }
+                const uint32_t rot[4] = { d0, d1, d2, d3 };
+                uint32_t s0, s1, s2, s3;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const uint32_t sel = 0x0c0c0000u | ((4u + (t & 3)) << 8) | (uint32_t)(t & 3);
+                    const uint32_t addr = __builtin_amdgcn_perm(rot[t >> 2], moffp[t >> 2], sel);  // code*256 + m*16
+                    const uint4 v = *reinterpret_cast<const uint4 *>(lut_b + addr);
+                    if (t == 0) { s0 = v.x; s1 = v.y; s2 = v.z; s3 = v.w; }
+                    else { s0 = pk_add_u16(s0, v.x); s1 = pk_add_u16(s1, v.y); s2 = pk_add_u16(s2, v.z); s3 = pk_add_u16(s3, v.w); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // sum < T for any of the 8 queries  <=>  a sign bit in the packed (sum - T)  (both < 2^15)
+                const uint32_t sg = (pk_sub_i16(s0, tpk[0]) | pk_sub_i16(s1, tpk[1]) | pk_sub_i16(s2, tpk[2]) | pk_sub_i16(s3, tpk[3])) & 0x80008000u;
+                if (__ballot(sg != 0)) {  // rare once the threshold has tightened
+                    const uint32_t lrow = base + r * 64 + lane;
+                    if (sg != 0 && lrow < n_local) {
+                        const uint32_t sums[4] = { s0, s1, s2, s3 };
+#pragma unroll
+                        for (int q = 0; q < QT; ++q) {
+                            const uint32_t bit = 1u << (r * QT + q);
+                            const uint32_t sq = (sums[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                            const uint32_t tq = (tpk[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                            if (sq < tq && !(done & bit)) {
+                                bool dummy = false;
+                                if (topk_push<QT, SQ_CAP, SQ_TRIG>(tk, q, sq, (uint32_t)(row_begin + lrow), dummy)) done |= bit;
+                                else failed = true;
+                            }
+                        }
+                    }
+                }
+            }
+            if (__any(failed)) {  // some buffer is full: stop everyone, come back to this chunk after the compaction
+                if (lane == 0) ck.stop = 1;
+                break;
+            }
+            done = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) cur[r] = nxt[r];
+            it = it_next;
+            it_next = grab();
+            if (__builtin_amdgcn_readfirstlane(stop_seen)) break;
+        }
+        SQ_T(1);  // look-ups + pushes
+        if (it >= n_chunks && !counted) {
+            counted = true;
+            if (lane == 0) atomicAdd(&ck.done_waves, 1);
+        }
+        __syncthreads();  // checkpoint (A)
+        bool need = ck.stop != 0;
+#pragma unroll
+        for (int q = 0; q < QT; ++q) need |= tk.cnt[q] >= SQ_TRIG;
+        const bool all_done = ck.done_waves == NW;
+        if (need) {  // workgroup-uniform
+            topk_compact_wave<QT, SQ_CAP, NT>(tk, a.k, fixb, thrx);
+            if (tid < QT / 2) ck.thr_pk[tid] = tk.thr_x[2 * tid] | (tk.thr_x[2 * tid + 1] << 16);
+            if (tid == 0) ck.stop = 0;
+        }
+        __syncthreads();  // checkpoint (B)
+        SQ_T(3);  // checkpoint protocol + compactions
+        if (all_done && !need) break;
+    }
+
+    __syncthreads();
+    topk_compact_wave<QT, SQ_CAP, NT>(tk, a.k, fixb, thrx);
+    SQ_T(4);  // final compaction
+    SQ_TEND();
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        const int qi = group * QT + q;
+        if (qi >= a.nq) break;
+        const int cnt = tk.cnt[q];
+        const int64_t o = ((int64_t)qi * a.splits + split) * a.k;
+        for (int i = tid; i < a.k; i += NT) {
+            if (i < cnt) {
+                const unsigned long long e = tk.buf[q][i];
+                a.part_d[o + i] = __uint_as_float((uint32_t)(e >> 32));
+                a.part_id[o + i] = a.id_base + (int64_t)(uint32_t)e;
+            } else {
+                a.part_d[o + i] = __uint_as_float(0x7f800000u);
+                a.part_id[o + i] = -1;
+            }
+        }
+    }
+}
+
 // Row ids travel as 32-bit payloads: one launch covers at most 2^32-1 rows.
 ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int want_qtile, int want_splits,
                    int want_variant)
@@ -491,9 +890,16 @@ ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int 
     ScanPlan p;
     int qt = want_qtile;
     if (qt != 1 && qt != 2 && qt != 4 && qt != 8) qt = (nq >= 4) ? 4 : (nq >= 2 ? 2 : 1);
-    if (qt == 8 && m.M == 16) qt = 4;  // 8 x 16 KB tables do not fit beside the selection buffers
-    // conflict-free skewed kernel: M = 16 with 4 queries per pass (variant 1: 512-thread, 2: 1024-thread workgroups)
-    p.variant = (want_variant != 0 && m.M == 16 && qt == 4) ? want_variant : 0;
+    // M = 16 kernels with conflict-free skewed table reads:
+    //   variant 1 / 2: fp32 tables, 4 queries per pass, 512- / 1024-thread workgroups (adc_scan16)
+    //   variant 3 / 4: 15-bit lower-bound tables, 8 queries per pass, 1024- / 512-thread workgroups (adc_scan16q)
+    p.variant = 0;
+    if (m.M == 16 && want_variant >= 3 && nq >= 4 && m.D <= 256) { p.variant = want_variant; qt = 8; }
+    else if (m.M == 16 && want_variant >= 1) {
+        if (want_variant <= 2 && (want_qtile == 0 || want_qtile == 4) && nq >= 4) { p.variant = want_variant; qt = 4; }
+        else if (want_variant >= 3 && nq >= 2) { p.variant = 1; qt = 4; }
+    }
+    if (qt == 8 && m.M == 16 && p.variant < 3) qt = 4;  // row-per-lane: 8 x 16 KB fp32 tables do not fit beside the buffers
     p.qtile = qt;
     const int64_t groups = (nq + qt - 1) / qt;
     int s = want_splits;
@@ -544,7 +950,8 @@ static int launch_m(const ScanArgs &a, int qt, hipStream_t st)
 }
 
 int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, int64_t id_base, const float *q_rot,
-                    int64_t nq, int k, const ScanPlan &plan, float *part_d, int64_t *part_id, hipStream_t st)
+                    int64_t nq, int k, const ScanPlan &plan, float *part_d, int64_t *part_id, float *lut_scratch,
+                    hipStream_t st)
 {
     if (nq <= 0) return CVTMI_OK;
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "adc_scan: k=%d outside 1..128", k);
@@ -566,7 +973,17 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
     rps = ((rps + tile_rows - 1) / tile_rows) * tile_rows;
     if (rps < tile_rows) rps = tile_rows;
     a.rows_per_split = rps;
-    a.part_d = part_d; a.part_id = part_id;
+    a.part_d = part_d; a.part_id = part_id; a.lut_g = lut_scratch;
+    if (plan.variant >= 3 && m.M == 16 && plan.qtile == 8) {
+        if (!lut_scratch) return fail(CVTMI_EINVAL, "adc_scan16q: table scratch missing");
+        CVTMI_TRY(launch_lut(m, q_rot, nq, nullptr, lut_scratch, st));  // [nq][16][K] fp32, once per query
+        const int64_t blocks = (int64_t)a.groups * a.splits;
+        if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "adc_scan: grid too large (%lld)", (long long)blocks);
+        if (plan.variant == 3) hipLaunchKernelGGL((adc_scan16q_kernel<1024, 1>), dim3((unsigned)blocks), dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((adc_scan16q_kernel<512, 2>), dim3((unsigned)blocks), dim3(512), 0, st, a);
+        CVTMI_HIP(hipGetLastError());
+        return CVTMI_OK;
+    }
     if (plan.variant >= 1 && m.M == 16 && plan.qtile == 4) {
         const int64_t blocks = (int64_t)a.groups * a.splits;
         if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "adc_scan: grid too large (%lld)", (long long)blocks);
@@ -583,5 +1000,15 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
     }
     return fail(CVTMI_EUNSUPPORTED, "adc_scan: M=%d not built (4, 8, 16)", m.M);
 }
+
+#ifdef CVTMI_SCAN_TIMING
+extern "C" int cvtmi_debug_scan_timing(unsigned long long *out, int reset)
+{
+    unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_dbg), sizeof z) != hipSuccess) return -3;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_scan_dbg), z, sizeof z) != hipSuccess) return -3;
+    return 0;
+}
+#endif
 
 }  // namespace cvtmi

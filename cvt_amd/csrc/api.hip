@@ -120,9 +120,9 @@ struct cvtmi_opq_s {
     std::vector<int32_t> h_csr_video;
     std::vector<uint8_t> h_csr_codes;
     // scratch
-    DevBuf s_qrot, s_part_d, s_part_id, s_probe;
+    DevBuf s_qrot, s_part_d, s_part_id, s_probe, s_lut;
     // tuning / measurement
-    int p_splits = 0, p_qtile = 0, p_profile = 0, p_variant = 1;
+    int p_splits = 0, p_qtile = 0, p_profile = 0, p_variant = 4;
     static constexpr int kEvRing = 64;
     hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
     int ev_count = 0;  // scan launches recorded since the last cvtmi_opq_last_scan
@@ -213,7 +213,7 @@ int cvtmi_opq_destroy(cvtmi_opq_t h)
     if (h->d_perm) (void)hipFree(h->d_perm);
     h->codes.release(); h->lists.release(); h->videos.release();
     h->csr_codes.release(); h->csr_videos.release(); h->csr_off.release();
-    h->s_qrot.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_probe.release();
+    h->s_qrot.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_probe.release(); h->s_lut.release();
     for (int e = 0; e < cvtmi_opq_s::kEvRing; ++e) {
         if (h->ev0[e]) (void)hipEventDestroy(h->ev0[e]);
         if (h->ev1[e]) (void)hipEventDestroy(h->ev1[e]);
@@ -494,7 +494,12 @@ int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, 
         if (!h->ev0[slot]) { CVTMI_HIP(hipEventCreate(&h->ev0[slot])); CVTMI_HIP(hipEventCreate(&h->ev1[slot])); }
         CVTMI_HIP(hipEventRecord(h->ev0[slot], st));
     }
-    CVTMI_TRY(launch_adc_scan(h->m, h->codes.as<uint8_t>(), h->n, h->id_base, q_rot, nq, k, plan, pd, pi, st));
+    float *lut_scratch = nullptr;
+    if (plan.variant >= 3) {  // per-query fp32 tables in HBM (16 KB per query at M=16, K=256)
+        CVTMI_TRY(h->s_lut.reserve((size_t)nq * h->m.M * h->m.K * sizeof(float)));
+        lut_scratch = h->s_lut.as<float>();
+    }
+    CVTMI_TRY(launch_adc_scan(h->m, h->codes.as<uint8_t>(), h->n, h->id_base, q_rot, nq, k, plan, pd, pi, lut_scratch, st));
     if (h->p_profile) {
         CVTMI_HIP(hipEventRecord(h->ev1[slot], st));
         h->ev_count++;
@@ -563,7 +568,7 @@ int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value)
     }
     if (!strcmp(name, "profile")) { h->p_profile = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "scan_variant")) {
-        if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: scan_variant must be 0, 1 or 2");
+        if (value < 0 || value > 4) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: scan_variant must be 0..4");
         h->p_variant = (int)value;
         return CVTMI_OK;
     }

@@ -41,7 +41,7 @@ struct NoFix {
     __device__ __forceinline__ unsigned long long operator()(int, unsigned long long e) const { return e; }
 };
 struct IdThr {
-    __device__ __forceinline__ uint32_t operator()(uint32_t t) const { return t; }
+    __device__ __forceinline__ uint32_t operator()(int /*q*/, uint32_t t) const { return t; }
 };
 
 template <int QT, int CAP>
@@ -141,10 +141,106 @@ __device__ void topk_compact(TopKShared<QT, CAP> &s, int k, const Fix &fix = Fix
             s.exact_n[q] = n < k ? n : k;
             const uint32_t th = (n >= k) ? (uint32_t)(b[k - 1] >> 32) : KEY_MAX;
             s.thr[q] = th;
-            s.thr_x[q] = thrx(th);
+            s.thr_x[q] = thrx(q, th);
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Barrier-free compaction for buffers of at most 256 entries: ONE WAVE per query keeps the buffer in
+// registers (entry idx = r*64 + lane, r < 4) and sorts it with a bitonic network whose exchanges at
+// distance >= 64 are register swaps and below 64 lane shuffles -- no LDS traffic, no s_barrier inside.
+// FixB(q, e[4], need[4]) rewrites, in one batch, the entries that still carry approximate keys.
+// Same contract as topk_compact: call after a barrier that made the pushes visible; ends with a barrier.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, mask);
+    hi = __shfl_xor(hi, mask);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ void wave_bitonic_sort256(unsigned long long (&e)[4])
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            if (j >= 64) {
+                const int dr = j >> 6;  // partner register r ^ dr of the same lane
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pr = r ^ dr;
+                    if (pr > r) {
+                        const bool asc = ((r * 64 + lane) & k) == 0;
+                        const unsigned long long x = e[r], y = e[pr];
+                        const bool sw = asc ? (x > y) : (x < y);
+                        e[r] = sw ? y : x;
+                        e[pr] = sw ? x : y;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned long long mine = e[r];
+                    const unsigned long long other = shfl_xor_u64(mine, j);
+                    const bool asc = ((r * 64 + lane) & k) == 0;
+                    const bool lower = (lane & j) == 0;
+                    const bool take_min = lower == asc;
+                    const unsigned long long mn = mine < other ? mine : other, mx = mine < other ? other : mine;
+                    e[r] = take_min ? mn : mx;
+                }
+            }
+        }
+    }
+}
+
+template <int QT, int CAP, int NT, class FixB, class ThrX>
+__device__ __attribute__((noinline)) void topk_compact_wave(TopKShared<QT, CAP> &s, int k, const FixB &fixb, const ThrX &thrx)
+{
+    static_assert(CAP <= 256, "register sort holds 256 entries per wave");
+    constexpr int NW = NT / 64;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int q = wv; q < QT; q += NW) {  // wave-uniform
+        unsigned long long *b = s.buf[q];
+        int n = s.cnt[q];
+        n = n < CAP ? n : CAP;
+        const int ex = s.exact_n[q];
+        unsigned long long e[4];
+        bool need[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = r * 64 + lane;
+            e[r] = idx < n ? b[idx] : ~0ull;
+            need[r] = idx >= ex && idx < n;
+        }
+        fixb(q, e, need);
+        wave_bitonic_sort256(e);
+        const int keep = n < k ? n : k;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = r * 64 + lane;
+            if (idx < keep) b[idx] = e[r];
+        }
+        // k-th entry: element index k-1 lives in register (k-1)>>6 of lane (k-1)&63
+        unsigned long long kth = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (((k - 1) >> 6) == r) kth = e[r];
+        const uint32_t th_lane = (uint32_t)(kth >> 32);
+        const uint32_t th_k = (uint32_t)__shfl((int)th_lane, (k - 1) & 63);
+        if (lane == 0) {
+            s.cnt[q] = keep;
+            s.exact_n[q] = keep;
+            const uint32_t th = (n >= k) ? th_k : KEY_MAX;
+            s.thr[q] = th;
+            s.thr_x[q] = thrx(q, th);
+        }
+    }
+    __syncthreads();
 }
 
 // End-of-tile protocol.  `want` = some push of this thread crossed TRIG; `pending` = bit mask of this

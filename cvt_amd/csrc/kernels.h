@@ -34,8 +34,10 @@ struct ScanPlan {
 ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int want_qtile, int want_splits,
                    int want_variant);
 // part_d / part_id: [nq][splits][k]
+// lut_scratch: nq * M * K floats, needed when plan.variant >= 3 (see scan_lut_floats)
 int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, int64_t id_base, const float *q_rot,
-                    int64_t nq, int k, const ScanPlan &plan, float *part_d, int64_t *part_id, hipStream_t st);
+                    int64_t nq, int k, const ScanPlan &plan, float *part_d, int64_t *part_id, float *lut_scratch,
+                    hipStream_t st);
 
 // ---- topk_merge.hip ----
 int launch_topk_merge(const float *in_d, const int64_t *in_id, int64_t nq, int L, int k, float *out_d, int64_t *out_id,

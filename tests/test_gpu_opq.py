@@ -63,7 +63,7 @@ def test_golden_exhaustive_topk(amd, golden, orc):
     idx = make_index(amd, g)
     idx.add_codes(g["codes"])
     ms = g["match_score"]
-    for variant in (1, 2, 0):
+    for variant in (4, 3, 1, 2, 0):
         for qt in (0, 1, 2, 4, 8):
             for splits in (0, 1, 3, 8):
                 idx.set_param("scan_variant", variant); idx.set_param("qtile", qt); idx.set_param("splits", splits)
@@ -148,7 +148,7 @@ def test_search_parity_seeded(amd, orc, M, k):
     idx.add_codes(codes[:7000]); idx.add_codes(codes[7000:])   # two appends
     assert idx.ntotal == n
     od, oi = orc.adc_search(q, books, codes, k)
-    for variant, qt, splits in ((1, 0, 0), (1, 4, 1), (1, 4, 8), (2, 4, 3), (2, 0, 0), (0, 0, 0), (0, 1, 1), (0, 2, 5), (0, 4, 8),
+    for variant, qt, splits in ((4, 0, 0), (4, 0, 1), (4, 0, 8), (3, 0, 3), (3, 0, 1), (1, 0, 0), (1, 4, 1), (1, 4, 8), (2, 4, 3), (2, 0, 0), (0, 0, 0), (0, 1, 1), (0, 2, 5), (0, 4, 8),
                                 (0, 4, 16), (0, 1, 64)):
         idx.set_param("scan_variant", variant); idx.set_param("qtile", qt); idx.set_param("splits", splits)
         d, i = idx.search(q, k, rotate=False)
@@ -189,7 +189,7 @@ def test_search_edge_cases(amd, orc):
     desc[:, 0] = ranks[(np.arange(n) * 256 // n)]
     idx.add_codes(desc)
     od, oi = orc.adc_search(q, order_books, desc, 100)
-    for variant in (1, 2, 0):
+    for variant in (4, 3, 1, 2, 0):
         for splits in (1, 2):
             idx.set_param("scan_variant", variant); idx.set_param("splits", splits)
             d, i = idx.search(q, 100, rotate=False)
@@ -243,7 +243,7 @@ def test_full_size_properties(amd, orc):
     assert np.all(np.diff(dn, axis=1) >= 0)                                   # ascending
     tie = np.diff(dn, axis=1) == 0
     assert np.all(np.diff(inn, axis=1)[tie] > 0)                              # ties in id order
-    for variant, qt, splits in ((0, 1, 8), (0, 2, 16), (0, 4, 1), (1, 4, 24), (2, 4, 1), (2, 4, 16), (1, 4, 1)):
+    for variant, qt, splits in ((0, 1, 8), (0, 2, 16), (0, 4, 1), (1, 4, 24), (2, 4, 1), (2, 4, 16), (1, 4, 1), (3, 0, 1), (3, 0, 8), (4, 0, 1), (4, 0, 2)):
         idx.set_param("scan_variant", variant); idx.set_param("qtile", qt); idx.set_param("splits", splits)
         d2, i2 = idx.search(q, k)
         assert torch.equal(i2, i) and torch.equal(d2.view(torch.int32), d.view(torch.int32)), (variant, qt, splits)

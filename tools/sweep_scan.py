@@ -42,7 +42,7 @@ for var in [int(x) for x in a.variants.split(",")]:
                 idx.search(q, a.k)
             torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / a.reps * 1e3
             s = idx.last_scan()
-            print("variant=%d " % var + "qtile=%d splits=%-4d scan=%.3f ms wall=%.3f ms  q-lookups/s=%.2fT  alg=%.0f GB/s  QPS=%.0f" % (
+            print("variant=%d(req) " % var + "qtile=%d splits=%-4d scan=%.3f ms wall=%.3f ms  q-lookups/s=%.2fT  alg=%.0f GB/s  QPS=%.0f" % (
                 s["qtile"], s["splits"], s["ms"], wall, a.nq * a.rows * M / s["ms"] / 1e9, s["code_bytes"] / s["ms"] / 1e6,
                 a.nq / wall * 1e3), flush=True)
         except Exception as e:
