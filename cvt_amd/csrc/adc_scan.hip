@@ -799,15 +799,22 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
                     d0 = b1 ? e2 : e0; d1 = b1 ? e3 : e1; d2 = b1 ? e0 : e2; d3 = b1 ? e1 : e3;
                 }
                 const uint32_t rot[4] = { d0, d1, d2, d3 };
-                uint32_t s0, s1, s2, s3;
+                // 16 look-ups; the packed 15-bit sums can never carry across the 16-bit halves, so they are
+                // accumulated with plain 32-bit adds, two look-ups per v_add3_u32 (half the VALU of v_pk_add_u16)
+                uint4 v[16];
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     const uint32_t sel = 0x0c0c0000u | ((4u + (t & 3)) << 8) | (uint32_t)(t & 3);
                     const uint32_t addr = __builtin_amdgcn_perm(rot[t >> 2], moffp[t >> 2], sel);  // code*256 + m*16
-                    const uint4 v = *reinterpret_cast<const uint4 *>(lut_b + addr);
-                    if (t == 0) { s0 = v.x; s1 = v.y; s2 = v.z; s3 = v.w; }
-                    else { s0 = pk_add_u16(s0, v.x); s1 = pk_add_u16(s1, v.y); s2 = pk_add_u16(s2, v.z); s3 = pk_add_u16(s3, v.w); }
+                    v[t] = *reinterpret_cast<const uint4 *>(lut_b + addr);
                 }
+                uint32_t s0 = v[0].x, s1 = v[0].y, s2 = v[0].z, s3 = v[0].w;
+#pragma unroll
+                for (int t = 1; t < 15; t += 2) {
+                    s0 = s0 + v[t].x + v[t + 1].x; s1 = s1 + v[t].y + v[t + 1].y;
+                    s2 = s2 + v[t].z + v[t + 1].z; s3 = s3 + v[t].w + v[t + 1].w;
+                }
+                s0 += v[15].x; s1 += v[15].y; s2 += v[15].z; s3 += v[15].w;
                 __builtin_amdgcn_sched_barrier(0);
                 // sum < T for any of the 8 queries  <=>  a sign bit in the packed (sum - T)  (both < 2^15)
                 const uint32_t sg = (pk_sub_i16(s0, tpk[0]) | pk_sub_i16(s1, tpk[1]) | pk_sub_i16(s2, tpk[2]) | pk_sub_i16(s3, tpk[3])) & 0x80008000u;

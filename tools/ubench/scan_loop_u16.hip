@@ -20,7 +20,7 @@ __device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b)
 }
 
 // QT = 8 (one b128 per code byte) or 16 (two: second at +256)
-template <int NT, int R, int QT, int MINW>
+template <int NT, int R, int QT, int MINW, int ADD3 = 0>
 __global__ __launch_bounds__(NT, MINW) void scan_kernel(const uint4 *__restrict__ rows, int64_t n_rows, const uint32_t *__restrict__ lut_g,
                                                         uint32_t thr, uint32_t *out)
 {
@@ -70,6 +70,23 @@ __global__ __launch_bounds__(NT, MINW) void scan_kernel(const uint4 *__restrict_
             d0 = b1 ? e2 : e0; d1 = b1 ? e3 : e1; d2 = b1 ? e0 : e2; d3 = b1 ? e1 : e3;
             const uint32_t rot[4] = { d0, d1, d2, d3 };
             uint32_t acc[QT / 2];
+            if (ADD3 && QT == 8) {
+                // packed 15-bit sums never carry across the 16-bit halves: plain 32-bit adds, two look-ups per v_add3_u32
+                uint4 v[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const uint32_t sel = 0x0c0c0000u | ((4u + (t & 3)) << 8) | (uint32_t)(t & 3);
+                    const uint32_t addr = __builtin_amdgcn_perm(rot[t >> 2], moffp[t >> 2], sel);
+                    v[t] = *reinterpret_cast<const uint4 *>(lut_b + addr);
+                }
+                acc[0] = v[0].x; acc[1] = v[0].y; acc[2] = v[0].z; acc[3] = v[0].w;
+#pragma unroll
+                for (int t = 1; t < 15; t += 2) {
+                    acc[0] = acc[0] + v[t].x + v[t + 1].x; acc[1] = acc[1] + v[t].y + v[t + 1].y;
+                    acc[2] = acc[2] + v[t].z + v[t + 1].z; acc[3] = acc[3] + v[t].w + v[t + 1].w;
+                }
+                acc[0] += v[15].x; acc[1] += v[15].y; acc[2] += v[15].z; acc[3] += v[15].w;
+            } else {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const uint32_t sel = 0x0c0c0000u | ((4u + (t & 3)) << 8) | (uint32_t)(t & 3);
@@ -83,6 +100,7 @@ __global__ __launch_bounds__(NT, MINW) void scan_kernel(const uint4 *__restrict_
                     if (t == 0) { acc[4] = u.x; acc[5] = u.y; acc[6] = u.z; acc[7] = u.w; }
                     else { acc[4] = pk_add_u16(acc[4], u.x); acc[5] = pk_add_u16(acc[5], u.y); acc[6] = pk_add_u16(acc[6], u.z); acc[7] = pk_add_u16(acc[7], u.w); }
                 }
+            }
             }
             __builtin_amdgcn_sched_barrier(0);
             // any (sum < thr) over the QT packed 15-bit sums: sign bits of (sum - thr)
@@ -105,7 +123,7 @@ __global__ __launch_bounds__(NT, MINW) void scan_kernel(const uint4 *__restrict_
     out[(int64_t)blockIdx.x * NT + tid] = chk + cnt;
 }
 
-template <int NT, int R, int QT, int MINW>
+template <int NT, int R, int QT, int MINW, int ADD3 = 0>
 static void run(const char *name, const uint4 *rows, int64_t n_rows, int nq, const uint32_t *lut, uint32_t *out)
 {
     hipEvent_t e0, e1;
@@ -113,7 +131,7 @@ static void run(const char *name, const uint4 *rows, int64_t n_rows, int nq, con
     const int groups = nq / QT;
     for (int it = 0; it < 2; ++it) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((scan_kernel<NT, R, QT, MINW>), dim3(groups), dim3(NT), 0, 0, rows, n_rows, lut, 1u, out);
+        hipLaunchKernelGGL((scan_kernel<NT, R, QT, MINW, ADD3>), dim3(groups), dim3(NT), 0, 0, rows, n_rows, lut, 1u, out);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
     }
@@ -143,6 +161,10 @@ int main()
     run<1024, 1, 8, 4>("u16 QT=8", rows, n, nq, lut, out);
     run<1024, 2, 8, 4>("u16 QT=8", rows, n, nq, lut, out);
     run<256, 2, 8, 2>("u16 QT=8", rows, n, nq, lut, out);
+    run<512, 2, 8, 4, 1>("u16 QT=8 add3", rows, n, nq, lut, out);
+    run<512, 4, 8, 4, 1>("u16 QT=8 add3", rows, n, nq, lut, out);
+    run<1024, 1, 8, 4, 1>("u16 QT=8 add3", rows, n, nq, lut, out);
+    run<1024, 2, 8, 4, 1>("u16 QT=8 add3", rows, n, nq, lut, out);
     run<512, 2, 16, 2>("u16 QT=16 (1 WG/CU)", rows, n, nq, lut, out);
     run<1024, 1, 16, 4>("u16 QT=16 (1 WG/CU)", rows, n, nq, lut, out);
     run<1024, 2, 16, 4>("u16 QT=16 (1 WG/CU)", rows, n, nq, lut, out);
