@@ -853,6 +853,7 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
             if (lane == 0) atomicAdd(&ck.done_waves, 1);
         }
         __syncthreads();  // checkpoint (A)
+        SQ_T(2);  // wait for the other waves
         bool need = ck.stop != 0;
 #pragma unroll
         for (int q = 0; q < QT; ++q) need |= tk.cnt[q] >= SQ_TRIG;

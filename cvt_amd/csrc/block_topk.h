@@ -198,47 +198,57 @@ __device__ __forceinline__ void wave_bitonic_sort256(unsigned long long (&e)[4])
     }
 }
 
-template <int QT, int CAP, int NT, class FixB, class ThrX>
-__device__ __attribute__((noinline)) void topk_compact_wave(TopKShared<QT, CAP> &s, int k, const FixB &fixb, const ThrX &thrx)
+// one query, one wave, no barrier: returns the number of entries kept
+template <int QT, int CAP, class FixB, class ThrX>
+__device__ __attribute__((noinline)) int topk_compact_wave_q(TopKShared<QT, CAP> &s, int q, int k, const FixB &fixb,
+                                                            const ThrX &thrx)
 {
     static_assert(CAP <= 256, "register sort holds 256 entries per wave");
+    const int lane = threadIdx.x & 63;
+    unsigned long long *b = s.buf[q];
+    int n = s.cnt[q];
+    n = n < CAP ? n : CAP;
+    const int ex = s.exact_n[q];
+    unsigned long long e[4];
+    bool need[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int idx = r * 64 + lane;
+        e[r] = idx < n ? b[idx] : ~0ull;
+        need[r] = idx >= ex && idx < n;
+    }
+    fixb(q, e, need);
+    wave_bitonic_sort256(e);
+    const int keep = n < k ? n : k;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int idx = r * 64 + lane;
+        if (idx < keep) b[idx] = e[r];
+    }
+    // k-th entry: element index k-1 lives in register (k-1)>>6 of lane (k-1)&63
+    unsigned long long kth = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (((k - 1) >> 6) == r) kth = e[r];
+    const uint32_t th_lane = (uint32_t)(kth >> 32);
+    const uint32_t th_k = (uint32_t)__shfl((int)th_lane, (k - 1) & 63);
+    if (lane == 0) {
+        s.exact_n[q] = keep;
+        const uint32_t th = (n >= k) ? th_k : KEY_MAX;
+        s.thr[q] = th;
+        s.thr_x[q] = thrx(q, th);
+    }
+    return keep;
+}
+
+template <int QT, int CAP, int NT, class FixB, class ThrX>
+__device__ __forceinline__ void topk_compact_wave(TopKShared<QT, CAP> &s, int k, const FixB &fixb, const ThrX &thrx)
+{
     constexpr int NW = NT / 64;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int q = wv; q < QT; q += NW) {  // wave-uniform
-        unsigned long long *b = s.buf[q];
-        int n = s.cnt[q];
-        n = n < CAP ? n : CAP;
-        const int ex = s.exact_n[q];
-        unsigned long long e[4];
-        bool need[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int idx = r * 64 + lane;
-            e[r] = idx < n ? b[idx] : ~0ull;
-            need[r] = idx >= ex && idx < n;
-        }
-        fixb(q, e, need);
-        wave_bitonic_sort256(e);
-        const int keep = n < k ? n : k;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int idx = r * 64 + lane;
-            if (idx < keep) b[idx] = e[r];
-        }
-        // k-th entry: element index k-1 lives in register (k-1)>>6 of lane (k-1)&63
-        unsigned long long kth = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (((k - 1) >> 6) == r) kth = e[r];
-        const uint32_t th_lane = (uint32_t)(kth >> 32);
-        const uint32_t th_k = (uint32_t)__shfl((int)th_lane, (k - 1) & 63);
-        if (lane == 0) {
-            s.cnt[q] = keep;
-            s.exact_n[q] = keep;
-            const uint32_t th = (n >= k) ? th_k : KEY_MAX;
-            s.thr[q] = th;
-            s.thr_x[q] = thrx(q, th);
-        }
+        const int keep = topk_compact_wave_q<QT, CAP>(s, q, k, fixb, thrx);
+        if (lane == 0) s.cnt[q] = keep;
     }
     __syncthreads();
 }
