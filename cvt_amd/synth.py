@@ -7,14 +7,27 @@ import numpy as np
 CHUNK = 1 << 18  # rows per generator chunk; shards are generated chunk by chunk
 
 
-def _sift_chunk_torch(torch, n, D, seed, chunk_idx, device):
+N_CENTERS = 4096  # synthetic "visual words": rows are a word plus per-row variation, like real descriptors
+
+
+def _centers(torch, D, seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed((seed * 7919 + 17) & 0x7FFFFFFFFFFFFFFF)
+    c = torch.randn((N_CENTERS, D), generator=g, device=device).abs_() * 42.0
+    z = torch.rand((N_CENTERS, D), generator=g, device=device) < 0.3
+    return torch.where(z, torch.zeros_like(c), c)
+
+
+def _sift_chunk_torch(torch, n, D, seed, chunk_idx, device, centers):
     g = torch.Generator(device=device)
     g.manual_seed((seed * 1000003 + chunk_idx) & 0x7FFFFFFFFFFFFFFF)
-    # heavy-tailed non-negative integers, ~25 % exact zeros, clipped at 255 like SIFT bins
-    x = torch.randn((n, D), generator=g, device=device).abs_() * 42.0
-    z = torch.rand((n, D), generator=g, device=device) < 0.25
+    # heavy-tailed non-negative integers, many exact zeros, clipped at 255 like SIFT bins:
+    # a cluster centre ("visual word") plus multiplicative and additive per-row variation
+    cid = torch.randint(0, N_CENTERS, (n,), generator=g, device=device)
+    x = centers[cid] * (0.75 + 0.5 * torch.rand((n, D), generator=g, device=device))
+    x = x + torch.randn((n, D), generator=g, device=device).abs_() * 9.0
+    z = torch.rand((n, D), generator=g, device=device) < 0.1
     x = torch.where(z, torch.zeros_like(x), x).floor_().clamp_(max=255.0)
-    # cluster structure: a per-row "scene" offset on a few dimensions keeps neighbours meaningful
     return x
 
 
@@ -26,12 +39,13 @@ def sift_like(n, D=128, seed=0xC0FFEE, row_begin=0, device="cpu", rootsift=True)
     unit-norm like the features the reference actually indexes (opq/data)."""
     import torch
     out = torch.empty((n, D), dtype=torch.float32, device=device)
+    centers = _centers(torch, D, 0xC0FFEE, device)  # the SAME words for database and queries, whatever `seed`
     r = row_begin
     end = row_begin + n
     while r < end:
         c = r // CHUNK
         c0 = c * CHUNK
-        full = _sift_chunk_torch(torch, CHUNK, D, seed, c, device)
+        full = _sift_chunk_torch(torch, CHUNK, D, seed, c, device, centers)
         lo, hi = r - c0, min(end, c0 + CHUNK) - c0
         out[r - row_begin:r - row_begin + (hi - lo)] = full[lo:hi]
         r = c0 + hi
