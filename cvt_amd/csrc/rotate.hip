@@ -11,10 +11,10 @@
 //                       it reproduces the gather bit for bit on finite inputs, and with a dense R
 //                       it matches a k-ordered fmaf chain (the test oracle restates that) bit for bit.
 //
-// MI355X mapping of the GEMM (D = 32*NT, NT <= 4): a workgroup keeps R in LDS (row stride D+1
-// floats: the 32 lanes that read one k column hit 32 different banks) and loops over 128-row
-// slabs; each wave owns 32 rows x D outputs = NT accumulators of 32x32 (16 VGPRs each), stages its
-// 32 x D slab of X through LDS with coalesced 16-byte loads, and issues NT MFMAs per k-pair.
+// MI355X mapping of the GEMM (D = 32*NT, NT <= 4): a persistent 8-wave workgroup per CU keeps R in LDS
+// (row stride D+1 floats: the 32 lanes that read one k column hit 32 different banks); each wave owns
+// 32 rows x D outputs = NT accumulators of 32x32 (16 VGPRs each), holds its 32 x D slab of X in
+// registers (loaded straight from HBM) and issues NT MFMAs per k-pair with B read from LDS.
 #include "kernels.h"
 
 namespace cvtmi {
@@ -43,56 +43,86 @@ int launch_permute(const int32_t *perm, int D, const float *x, int64_t n, float 
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// 512 threads = 8 waves per CU (2 per SIMD).  Each wave walks its 32-row slab in K-chunks of 32 columns:
+// chunk c+1 is fetched from HBM with coalesced 16-byte loads (4 per lane) while chunk c feeds 64 MFMAs
+// from a wave-private, double-buffered 32 x 33 LDS tile (stride 33: the 32 lanes that read one k column
+// hit 32 banks).  With two waves per SIMD the matrix pipe also stays busy across a wave's prologue/epilogue.
+constexpr int ROT_THREADS = 512;
+constexpr int ROT_KC = 32;             // columns per chunk
+constexpr int ROT_XLD = ROT_KC + 1;    // padded chunk stride (floats)
+
 template <int NT>
-__global__ __launch_bounds__(kBlock, 1) void rotate_gemm_kernel(const float *__restrict__ R,
-                                                                const float *__restrict__ x, int64_t n,
-                                                                float *__restrict__ y)
+__global__ __launch_bounds__(ROT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void rotate_gemm_kernel(
+    const float *__restrict__ R, const float *__restrict__ x, int64_t n, float *__restrict__ y)
 {
     constexpr int D = 32 * NT;
-    constexpr int LD = D + 1;  // padded leading dimension (floats)
+    constexpr int LD = D + 1;  // padded leading dimension of R in LDS
+    constexpr int WAVES = ROT_THREADS / 64;
+    constexpr int NCH = D / ROT_KC;  // chunks per slab (== NT)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Rs = smem;                 // [D][LD]   Rs[j][k] = R[j][k]
-    float *Xs = smem + D * LD;        // 4 waves x [32][LD]
+    float *Rs = smem;                                   // [D][LD], Rs[j][k] = R[j][k]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < D * D; i += kBlock) {
+    float *Xw = smem + D * LD + wave * (2 * 32 * ROT_XLD);  // two chunk buffers per wave
+    for (int i = tid; i < D * D; i += ROT_THREADS) {
         const int j = i / D, k = i - j * D;
         Rs[j * LD + k] = R[i];
     }
     __syncthreads();
-    float *Xw = Xs + wave * 32 * LD;
-    const int64_t n_slabs = (n + 127) / 128;
-    for (int64_t slab = blockIdx.x; slab < n_slabs; slab += gridDim.x) {
-        const int64_t row0 = slab * 128 + wave * 32;
-        // stage this wave's 32 x D slab (coalesced float4 loads; ragged tail rows read as zero)
-        for (int i = lane; i < 32 * (D / 4); i += 64) {
-            const int r = i / (D / 4), c4 = i - r * (D / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + r < n) v = reinterpret_cast<const float4 *>(x + (row0 + r) * D)[c4];
-            float *dst = Xw + r * LD + c4 * 4;
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    const int li = lane & 31, lk = lane >> 5;
+    const float *Rl = Rs + li * LD + lk;
+    // chunk loader: lane handles float4 number f = p*64 + lane (p < 4) of the 32 x 32 chunk: row f/8, cols 4*(f%8)
+    const int64_t n_slabs = (n + 31) / 32;
+    const int64_t first = (int64_t)blockIdx.x * WAVES + wave, step = (int64_t)gridDim.x * WAVES;
+    auto fetch = [&](int64_t slab, int c, float4 (&v)[4]) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int f = p * 64 + lane, r = f >> 3, c4 = f & 7;
+            int64_t row = slab * 32 + r;
+            row = row < n ? row : n - 1;  // clamped: tail rows are never stored
+            v[p] = *reinterpret_cast<const float4 *>(x + row * D + c * ROT_KC + c4 * 4);
         }
-        // wave-private LDS slab: make the stores visible to the wave's own reads
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto stash = [&](float *buf, const float4 (&v)[4]) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int f = p * 64 + lane, r = f >> 3, c4 = f & 7;
+            float *d = buf + r * ROT_XLD + c4 * 4;
+            d[0] = v[p].x; d[1] = v[p].y; d[2] = v[p].z; d[3] = v[p].w;
+        }
+    };
+    float4 pre[4];
+    if (first < n_slabs) fetch(first, 0, pre);
+    int cur = 0;
+    for (int64_t slab = first; slab < n_slabs; slab += step) {
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
-        const int li = lane & 31, lk = lane >> 5;
-        // A[i][k] = X[row0+i][k0+k]  (lane: i = lane&31, k = lane>>5)
-        // B[k][j] = R^T[k0+k][j0+j] = R[j0+j][k0+k]  (lane: k = lane>>5, j = lane&31)
-#pragma unroll 4
-        for (int k0 = 0; k0 < D; k0 += 2) {
-            const float a = Xw[li * LD + k0 + lk];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float b = Rs[(t * 32 + li) * LD + k0 + lk];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        for (int c = 0; c < NCH; ++c) {
+            float *buf = Xw + cur * (32 * ROT_XLD);
+            stash(buf, pre);  // chunk c of this slab -> LDS (the buffer was last read two chunks ago)
+            // next chunk (or chunk 0 of the next slab) goes in flight now, lands while the MFMAs below run
+            if (c + 1 < NCH) fetch(slab, c + 1, pre);
+            else if (slab + step < n_slabs) fetch(slab + step, 0, pre);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // A[i][k] = X[row0+i][k0+k] (lane: i = lane&31, k = lane>>5);  B[k][j] = R[j0+j][k0+k];
+            // k ascends with the instruction order: one product per k, single rounding (== fmaf chain)
+            const float *xa = buf + li * ROT_XLD + lk;
+#pragma unroll
+            for (int kk = 0; kk < ROT_KC; kk += 2) {
+                const float a = xa[kk];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Rl[(t * 32) * LD + c * ROT_KC + kk], acc[t], 0, 0, 0);
             }
+            cur ^= 1;
         }
         // C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+        const int64_t row0 = slab * 32;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -101,7 +131,6 @@ __global__ __launch_bounds__(kBlock, 1) void rotate_gemm_kernel(const float *__r
                 if (row0 + r < n) y[(row0 + r) * D + t * 32 + li] = acc[t][e];
             }
         }
-        __builtin_amdgcn_wave_barrier();  // all lanes done reading Xw before the next slab overwrites it
     }
 }
 
@@ -111,14 +140,15 @@ int launch_rotate_gemm(const float *R, int D, const float *x, int64_t n, float *
     if (D % 32 != 0 || D < 32 || D > 128)
         return fail(CVTMI_EUNSUPPORTED, "rotate_gemm: D=%d (built for 32, 64, 96, 128)", D);
     const int NT = D / 32;
-    const size_t lds = (size_t)(D + 4 * 32) * (D + 1) * sizeof(float);
-    const int64_t n_slabs = (n + 127) / 128;
-    int64_t blocks = n_slabs < 256 ? n_slabs : 256;  // one persistent workgroup per CU (LDS-bound occupancy)
+    const size_t lds = ((size_t)D * (D + 1) + (size_t)(ROT_THREADS / 64) * 2 * 32 * ROT_XLD) * sizeof(float);
+    const int64_t n_slabs = (n + 31) / 32;
+    int64_t blocks = (n_slabs + 7) / 8;
+    if (blocks > 256) blocks = 256;  // one persistent 8-wave workgroup per CU
 #define CVTMI_ROT(T)                                                                                              \
     case T:                                                                                                       \
         CVTMI_HIP(hipFuncSetAttribute((const void *)rotate_gemm_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds));                                                                 \
-        hipLaunchKernelGGL((rotate_gemm_kernel<T>), dim3((unsigned)blocks), dim3(kBlock), lds, st, R, x, n, y);   \
+        hipLaunchKernelGGL((rotate_gemm_kernel<T>), dim3((unsigned)blocks), dim3(ROT_THREADS), lds, st, R, x, n, y); \
         break;
     switch (NT) {
         CVTMI_ROT(1) CVTMI_ROT(2) CVTMI_ROT(3) CVTMI_ROT(4)
