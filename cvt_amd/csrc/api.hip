@@ -134,7 +134,7 @@ struct cvtmi_flat_s {
     int device = 0;
     int metric = 0, D = 0;
     size_t row_bytes = 0;
-    DevBuf data, labels;
+    DevBuf data, labels, norms;  // norms: int32 |x-128|^2 per row, uint8 metric with D % 32 == 0 (MFMA path)
     int64_t n = 0;
     bool identity = true;  // label == row
     DevBuf s_part_d, s_part_id;
@@ -665,7 +665,7 @@ int cvtmi_flat_destroy(cvtmi_flat_t h)
 {
     if (!h) return CVTMI_OK;
     (void)hipSetDevice(h->device);
-    h->data.release(); h->labels.release(); h->s_part_d.release(); h->s_part_id.release();
+    h->data.release(); h->labels.release(); h->norms.release(); h->s_part_d.release(); h->s_part_id.release();
     delete h;
     return CVTMI_OK;
 }
@@ -711,6 +711,12 @@ static int flat_add_common(cvtmi_flat_t h, const void *x, const int64_t *labels,
             CVTMI_HIP(hipGetLastError());
         }
     }
+    if (h->metric == CVTMI_METRIC_L2U8 && h->D % 32 == 0 && h->D <= 512) {
+        if ((size_t)total * 4 > h->norms.cap)
+            CVTMI_TRY(h->norms.grow(std::max<size_t>((size_t)total, h->norms.cap / 2) * 4, (size_t)h->n * 4, st));
+        CVTMI_TRY(launch_flat_u8_norms(h->data.as<uint8_t>() + (size_t)h->n * h->row_bytes, n, h->D,
+                                       h->norms.as<int32_t>() + h->n, st));
+    }
     if (kind == hipMemcpyHostToDevice) CVTMI_HIP(hipStreamSynchronize(st));
     h->n = total;
     return CVTMI_OK;
@@ -749,8 +755,10 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search: k=%d outside 1..128", k);
     if (nq == 0) return CVTMI_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int qt = flat_qtile(nq);
-    const int splits = flat_plan_splits(h->n, nq, qt);
+    const bool mfma = h->metric == CVTMI_METRIC_L2U8 && flat_u8_mfma_qtile(h->D, k, nq) > 0;
+    const int qt = mfma ? flat_u8_mfma_qtile(h->D, k, nq) : flat_qtile(nq);
+    int splits = flat_plan_splits(h->n, nq, qt);
+    if (mfma && splits >= 8) splits = (splits / 8) * 8;  // a row split per XCD: query groups share its L2
     float *pd = reinterpret_cast<float *>(dist);
     int64_t *pi = labels;
     if (splits > 1) {
@@ -760,7 +768,11 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
         pd = h->s_part_d.as<float>();
         pi = h->s_part_id.as<int64_t>();
     }
-    CVTMI_TRY(launch_flat_search(h->metric, h->D, h->data.p, h->n, q, nq, k, qt, splits, pd, pi, st));
+    if (mfma)
+        CVTMI_TRY(launch_flat_u8_mfma(h->D, h->data.as<uint8_t>(), h->norms.as<int32_t>(), h->n,
+                                      reinterpret_cast<const uint8_t *>(q), nq, k, splits, pd, pi, st));
+    else
+        CVTMI_TRY(launch_flat_search(h->metric, h->D, h->data.p, h->n, q, nq, k, qt, splits, pd, pi, st));
     if (splits > 1) CVTMI_TRY(launch_topk_merge(pd, pi, nq, splits, k, reinterpret_cast<float *>(dist), labels, st));
     if (!h->identity) CVTMI_TRY(launch_gather_labels(labels, nq * k, h->labels.as<int64_t>(), st));
     return CVTMI_OK;

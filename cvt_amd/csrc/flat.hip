@@ -244,6 +244,239 @@ __global__ __launch_bounds__(kBlock) void flat_u8_kernel(const FlatArgs a)
     }
 }
 
+// ==========================================================================================
+// uint8 L2 on the matrix cores (D % 32 == 0): sum (q-x)^2 = |q'|^2 + |x'|^2 - 2 <q',x'> with q' = q-128,
+// x' = x-128 in [-128,127] (one v_xor with 0x80808080 per dword), every term exact in int32
+// (<= 512*128^2*... < 2^31).  v_mfma_i32_32x32x32_i8: A = 32 queries x 32 dims, B = 32 rows x 32 dims;
+// lane l supplies 16 consecutive dims (l>>5)*16.. of query / row (l&31) and receives, for ITS row, the dot
+// products with 16 of the 32 queries.  A workgroup serves QT = 32*QB queries over one row split; a wave owns
+// 32 rows per tile, rows come straight from HBM as 16-byte loads (next tile in flight while this one is
+// multiplied), queries sit in LDS with a +16-byte row pad (conflict-free ds_read_b128).
+// |x'|^2 per row is computed once when rows are added (flat_u8_norms_kernel).
+// ==========================================================================================
+typedef int mf_v4i __attribute__((ext_vector_type(4)));
+typedef int mf_v16i __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(kBlock) void flat_u8_norms_kernel(const uint8_t *__restrict__ x, int64_t n, int D,
+                                                               int32_t *__restrict__ norms)
+{
+    const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= n) return;
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(x + row * D);  // D % 32 == 0
+    int s = 0;
+    for (int w = 0; w < D / 4; ++w) {
+        const int v = (int)(p[w] ^ 0x80808080u);
+        s = __builtin_amdgcn_sdot4(v, v, s, false);
+    }
+    norms[row] = s;
+}
+
+int launch_flat_u8_norms(const uint8_t *x, int64_t n, int D, int32_t *norms, hipStream_t st)
+{
+    if (n <= 0) return CVTMI_OK;
+    hipLaunchKernelGGL(flat_u8_norms_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, x, n, D, norms);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+struct FlatMfmaArgs {
+    const uint8_t *data;
+    const int32_t *norms;
+    int64_t n;
+    const uint8_t *q;
+    int nq, D, k, splits;
+    int64_t rows_per_split;
+    float *part_d;
+    int64_t *part_id;
+};
+
+template <int QB, int CAP, int TRIG, int DMAX>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void flat_u8_mfma_kernel(const FlatMfmaArgs a)
+{
+    constexpr int QT = 32 * QB;
+    constexpr int KS = DMAX / 32;  // k-steps held in registers per row (D <= DMAX)
+    extern __shared__ __attribute__((aligned(16))) uint8_t q8s[];  // [QT][D + 16] query bytes ^ 0x80
+    __shared__ TopKShared<QT, CAP> tk;
+    __shared__ int qq[QT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int group, split;
+    {
+        const int b = blockIdx.x;
+        if ((a.splits & 7) == 0) {  // a row split stays on one XCD: the query groups of that split share its L2
+            const int s8 = a.splits >> 3;
+            const int xcd = b & 7, i = b >> 3;
+            split = xcd + 8 * (i % s8);
+            group = i / s8;
+        } else {
+            split = b % a.splits;
+            group = b / a.splits;
+        }
+    }
+    const int D = a.D, LDQ = D + 16, nks = D / 32;
+    for (int i = tid; i < QT * (D / 4); i += kBlock) {
+        const int q = i / (D / 4), w = i - q * (D / 4);
+        int qi = group * QT + q;
+        qi = qi < a.nq ? qi : a.nq - 1;
+        const uint32_t v = reinterpret_cast<const uint32_t *>(a.q + (int64_t)qi * D)[w];
+        *reinterpret_cast<uint32_t *>(q8s + q * LDQ + 4 * w) = v ^ 0x80808080u;
+    }
+    topk_init(tk);
+    __syncthreads();
+    for (int q = tid; q < QT; q += kBlock) {
+        int s = 0;
+        for (int w = 0; w < D / 4; ++w) {
+            const int v = *reinterpret_cast<const int *>(q8s + q * LDQ + 4 * w);
+            s = __builtin_amdgcn_sdot4(v, v, s, false);
+        }
+        qq[q] = s;
+    }
+    __syncthreads();
+
+    const int64_t row_begin = (int64_t)split * a.rows_per_split;
+    int64_t row_end = row_begin + a.rows_per_split;
+    row_end = row_end < a.n ? row_end : a.n;
+    const uint32_t n_local = (uint32_t)(row_end > row_begin ? row_end - row_begin : 0);
+    const uint32_t last = n_local ? n_local - 1 : 0;
+    const int lj = lane & 31, lh = lane >> 5;
+    const uint8_t *xb = a.data + row_begin * D;
+    const int32_t *nb = a.norms + row_begin;
+    auto fetch = [&](uint32_t tile_base, mf_v4i (&v)[KS], int &xx) {
+        uint32_t r = tile_base + wave * 32 + lj;
+        r = r < last ? r : last;  // clamped, rejected at push time
+        const uint8_t *p = xb + (size_t)r * D + lh * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            if (s < nks) v[s] = *reinterpret_cast<const mf_v4i *>(p + 32 * s);
+        xx = nb[r];
+    };
+    mf_v4i cur[KS], nxt[KS];
+    int xx_cur = 0, xx_nxt = 0;
+    if (n_local) fetch(0, cur, xx_cur);
+    int tile = 0;
+    for (uint32_t base = 0; base < n_local; base += 128, ++tile) {
+        fetch(base + 128, nxt, xx_nxt);
+        mf_v16i acc[QB];
+#pragma unroll
+        for (int b = 0; b < QB; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][e] = 0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s < nks) {
+                mf_v4i bv = cur[s];
+                bv ^= (int)0x80808080;
+#pragma unroll
+                for (int b = 0; b < QB; ++b) {
+                    const mf_v4i av = *reinterpret_cast<const mf_v4i *>(q8s + (b * 32 + lj) * LDQ + 32 * s + lh * 16);
+                    acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, acc[b], 0, 0, 0);
+                }
+            }
+        }
+        const uint32_t lrow = base + wave * 32 + lj;
+        const bool valid = lrow < n_local;
+        uint32_t key[QB][16];
+        bool want = false;
+        uint32_t pending = 0;
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                // per-query norm and threshold come from LDS (half-wave broadcast reads): holding them in
+                // registers next to two row buffers and the accumulators spilled
+                const int q = b * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                key[b][e] = (uint32_t)(qq[q] + xx_cur - 2 * acc[b][e]);  // exact, >= 0
+                if (valid && key[b][e] < tk.thr_x[q]) {
+                    if (!topk_push<QT, CAP, TRIG>(tk, q, key[b][e], (uint32_t)(row_begin + lrow), want)) pending |= 1u << (b * 16 + e);
+                }
+            }
+        }
+        const int f = tile % 3;
+        if (want) tk.flag[f] = 1;
+        __syncthreads();
+        if (tk.flag[f]) {  // workgroup-uniform
+            for (;;) {
+                topk_compact<QT, CAP, kBlock>(tk, a.k);
+                if (pending) tk.flag[3] = 1;
+                __syncthreads();
+                const int again = tk.flag[3];
+                __syncthreads();
+                if (!again) break;
+                if (tid == 0) tk.flag[3] = 0;
+                uint32_t still = 0;
+                bool dummy = false;
+#pragma unroll
+                for (int b = 0; b < QB; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const uint32_t bit = 1u << (b * 16 + e);
+                        const int q = b * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        if ((pending & bit) && key[b][e] <= tk.thr_x[q])
+                            if (!topk_push<QT, CAP, TRIG>(tk, q, key[b][e], (uint32_t)(row_begin + lrow), dummy)) still |= bit;
+                    }
+                pending = still;
+                __syncthreads();
+            }
+        }
+        if (tid == 0) tk.flag[(tile + 2) % 3] = 0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) cur[s] = nxt[s];
+        xx_cur = xx_nxt;
+    }
+    __syncthreads();
+    topk_compact<QT, CAP, kBlock>(tk, a.k);
+    for (int q = 0; q < QT; ++q) {
+        const int qi = group * QT + q;
+        if (qi >= a.nq) break;
+        const int cnt = tk.cnt[q];
+        const int64_t o = ((int64_t)qi * a.splits + split) * a.k;
+        for (int i = tid; i < a.k; i += kBlock) {
+            if (i < cnt) {
+                const unsigned long long e = tk.buf[q][i];
+                a.part_d[o + i] = __uint_as_float((uint32_t)(e >> 32));  // int32 distance bits
+                a.part_id[o + i] = (int64_t)(uint32_t)e;
+            } else {
+                a.part_d[o + i] = __uint_as_float(0x7f800000u);
+                a.part_id[o + i] = -1;
+            }
+        }
+    }
+}
+
+// plan + launch of the MFMA path; returns CVTMI_EUNSUPPORTED when the shape is not covered (caller falls back)
+int flat_u8_mfma_qtile(int D, int k, int64_t nq)
+{
+    if (D % 32 != 0 || D > 512 || nq < 8 || k > 128) return 0;
+    return 32;  // (a 64-query variant halves the HBM passes but spills at D = 512 with two waves per SIMD)
+}
+
+int launch_flat_u8_mfma(int D, const uint8_t *data, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int k,
+                        int splits, float *part_d, int64_t *part_id, hipStream_t st)
+{
+    const int qt = flat_u8_mfma_qtile(D, k, nq);
+    if (!qt) return fail(CVTMI_EUNSUPPORTED, "flat_u8_mfma: shape not covered");
+    FlatMfmaArgs a;
+    a.data = data; a.norms = norms; a.n = n; a.q = q; a.nq = (int)nq; a.D = D; a.k = k; a.splits = splits;
+    int64_t rps = (n + splits - 1) / splits;
+    rps = ((rps + 127) / 128) * 128;
+    if (rps < 128) rps = 128;
+    a.rows_per_split = rps;
+    a.part_d = part_d; a.part_id = part_id;
+    const int64_t groups = (nq + qt - 1) / qt;
+    const int64_t blocks = groups * splits;
+    if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "flat_u8_mfma: grid too large");
+    const size_t lds = (size_t)qt * (D + 16);
+#define CVTMI_FM(QB, CAP, TRIG, DMAX)                                                                                   \
+    do {                                                                                                                \
+        CVTMI_HIP(hipFuncSetAttribute((const void *)flat_u8_mfma_kernel<QB, CAP, TRIG, DMAX>,                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+        hipLaunchKernelGGL((flat_u8_mfma_kernel<QB, CAP, TRIG, DMAX>), dim3((unsigned)blocks), dim3(kBlock), lds, st, a); \
+    } while (0)
+    if (D <= 128) CVTMI_FM(1, 208, 176, 128); else CVTMI_FM(1, 208, 176, 512);
+#undef CVTMI_FM
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
 __global__ __launch_bounds__(kBlock) void gather_labels_kernel(int64_t *ids, int64_t count, const int64_t *labels)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
