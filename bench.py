@@ -7,7 +7,15 @@ every code row -> k smallest (distance, id) per query [-> for N > 1: RCCL all-ga
 top-k and a k-way merge on every rank].  Inputs are resident in HBM when the timed region starts.
 
 Workload at every N: BASELINE.json configs[1], SIFT-1M (synthetic SIFT-shaped 128-d rows), OPQ M=16
-K=256, top-100, nq=10000 per step.  N > 1 row-shards the SAME database over the ranks (strong scaling).
+K=256, top-100, nq=10000 per step; the SAME database and query batch at every N (strong scaling).
+Multi-GPU layout (--layout):
+  rows     the north-star layout: rank r owns a contiguous row shard, every rank scans all queries, then ONE
+           RCCL all-gather of the per-shard top-k and a k-way merge on every rank;
+  queries  the code matrix is replicated (16 MB at SIFT-1M) and the query batch is split over the ranks:
+           no data-path collective at all;
+  auto     queries when the code matrix is < 1 GiB per GPU (replication is free and a 125 K-row shard is too
+           small to amortise a workgroup's fixed cost), rows otherwise (SIFT-1B: 2 GB per GPU).
+At N > 1 the JSON line also carries the throughput of the row-sharded path measured in the same run.
 
     python bench.py                       # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -39,6 +47,8 @@ def main():
     ap.add_argument("--M", type=int, default=16)
     ap.add_argument("--qtile", type=int, default=0)
     ap.add_argument("--splits", type=int, default=0)
+    ap.add_argument("--layout", choices=["auto", "rows", "queries"], default="auto")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo = debug: several ranks on one GPU")
     ap.add_argument("--cpu-sample", type=int, default=256, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--recall-sample", type=int, default=1000)
     args = ap.parse_args()
@@ -53,10 +63,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with --nproc-per-node equal to --gpus (got WORLD_SIZE=%d)" % world
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    if args.backend == "gloo":
+        local_rank = 0  # debug: every rank on GPU 0, collectives staged through the host
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
     cvt_amd.lib()
 
     D, M, K, k, nq = 128, args.M, 256, args.k, args.nq
@@ -71,46 +86,87 @@ def main():
         books_t.copy_(torch.from_numpy(synth.train_books(sample, M, K, iters=4)))
         tmp.close(); del sample
     if world > 1:
-        dist.broadcast(books_t, src=0)
+        if args.backend == "nccl":
+            dist.broadcast(books_t, src=0)
+        else:
+            bc = books_t.cpu(); dist.broadcast(bc, src=0); books_t.copy_(bc)
     books = books_t.cpu().numpy()
 
-    # ---- index build on device: generate -> rotate (MFMA GEMM) -> encode -> append; only codes stay ----
-    idx = cvt_amd.OpqIndex(zero_coarse, books, R=R)
-    r0, r1 = sharded.shard_range(args.rows, rank, world)
-    idx.reserve(r1 - r0); idx.set_id_base(r0)
-    enc_rows, enc_time = 0, 0.0
-    for a in range(r0, r1, synth.CHUNK):
-        b = min(r1, a + synth.CHUNK)
-        x = synth.sift_like(b - a, D, seed=0xC0FFEE, row_begin=a, device=dev)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        _, codes = idx.encode(idx.rotate(x))
-        idx.add_codes(codes)
-        torch.cuda.synchronize(); enc_time += time.perf_counter() - t0  # data generation excluded
-        enc_rows += b - a
-    q = synth.sift_like(nq, D, seed=0xBEEF, device=dev)  # identical on every rank
-    idx.set_param("qtile", args.qtile); idx.set_param("splits", args.splits)
-    idx.set_param("profile", 1)
+    layout = args.layout
+    if layout == "auto":
+        layout = "queries" if args.rows * M < (1 << 30) else "rows"
+    if world == 1:
+        layout = "rows"
 
-    searcher = sharded.ShardedSearch(lambda qq, kk: idx.search(qq, kk, rotate=True), cvt_amd.topk_merge, world, rank)
+    # ---- index build on device: generate -> rotate (MFMA GEMM) -> encode -> append; only codes stay ----
+    def build_index(r0, r1):
+        ix = cvt_amd.OpqIndex(zero_coarse, books, R=R)
+        ix.reserve(r1 - r0); ix.set_id_base(r0)
+        rows_done, t_acc = 0, 0.0
+        for a in range(r0, r1, synth.CHUNK):
+            b = min(r1, a + synth.CHUNK)
+            x = synth.sift_like(b - a, D, seed=0xC0FFEE, row_begin=a, device=dev)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            _, codes = ix.encode(ix.rotate(x))
+            ix.add_codes(codes)
+            torch.cuda.synchronize(); t_acc += time.perf_counter() - t0  # data generation excluded
+            rows_done += b - a
+        ix.set_param("qtile", args.qtile); ix.set_param("splits", args.splits); ix.set_param("profile", 1)
+        return ix, rows_done, t_acc
+
+    q = synth.sift_like(nq, D, seed=0xBEEF, device=dev)  # identical on every rank
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = searcher.search(q, k)
-    barrier()
-    idx.last_scan()  # drop the warm-up launches from the kernel-time statistics
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = searcher.search(q, k)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            out = fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
+
+    r0, r1 = sharded.shard_range(args.rows, rank, world)
+    extra = {}
+    if layout == "rows":
+        idx, enc_rows, enc_time = build_index(r0, r1)
+        searcher = sharded.ShardedSearch(lambda qq, kk: idx.search(qq, kk, rotate=True), cvt_amd.topk_merge, world, rank)
+        for _ in range(args.warmup):
+            searcher.search(q, k)
+        barrier(); idx.last_scan()  # drop the warm-up launches from the kernel-time statistics
+        elapsed, out = timed(lambda: searcher.search(q, k), args.steps, 0)
+        rows_here = r1 - r0
+        par = "row-sharded x%d + RCCL all-gather of per-shard top-k + merge" % world if world > 1 else "1 GPU"
+    else:
+        idx, enc_rows, enc_time = build_index(0, args.rows)  # replica of the whole code matrix
+        q0, q1 = sharded.shard_range(nq, rank, world)
+        q_mine = q[q0:q1].contiguous()
+        for _ in range(args.warmup):
+            idx.search(q_mine, k, rotate=True)
+        barrier(); idx.last_scan()
+        elapsed, out = timed(lambda: idx.search(q_mine, k, rotate=True), args.steps, 0)
+        rows_here = args.rows
+        par = "code matrix replicated x%d, query batch split over the ranks, no data-path collective" % world
+        # the north-star layout measured in the same run (row shard of the replica + all-gather + merge)
+        shard = cvt_amd.OpqIndex(zero_coarse, books, R=R)
+        codes_t = torch.from_numpy(idx.get_entries()[2][r0:r1]).to(dev)
+        shard.add_codes(codes_t); shard.set_id_base(r0)
+        rs = sharded.ShardedSearch(lambda qq, kk: shard.search(qq, kk, rotate=True), cvt_amd.topk_merge, world, rank)
+        el2, out2 = timed(lambda: rs.search(q, k), args.steps, args.warmup)
+        extra["row_sharded"] = {"value": round(nq * args.steps / el2, 1), "unit": "queries/s",
+                                "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                                "what": "same database row-sharded x%d, all queries on every rank, RCCL all-gather of "
+                                        "per-shard top-%d + merge" % (world, k)}
     scan = idx.last_scan()  # mean HIP-event duration of the scan kernel over the timed steps
 
     result = None
@@ -120,7 +176,8 @@ def main():
         achieved = scan["code_bytes"] / (scan["ms"] * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "scan_traffic.json")
-        if os.path.exists(pmc):
+        default_shape = world == 1 and args.rows == 1_000_000 and nq == 10_000 and k == 100 and M == 16 and not args.qtile and not args.splits
+        if default_shape and os.path.exists(pmc):  # PMC passes were taken on exactly this launch shape
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
@@ -132,16 +189,18 @@ def main():
             "dtype": "u8 codes / f32 distances", "data": "synthetic",
             "config": {"workload": "SIFT-1M synthetic 128-d, OPQ M=%d K=256 (dense 128x128 rotation), ADC scan + top-%d, "
                                    "nq=%d queries per step" % (M, k, nq),
-                       "rows": args.rows, "rows_per_gpu": r1 - r0, "nq_per_step": nq, "k": k, "M": M,
-                       "parallelism": "row-sharded x%d + RCCL all-gather of per-shard top-k" % world if world > 1 else "1 GPU",
+                       "rows": args.rows, "rows_per_gpu": rows_here, "nq_per_step": nq, "k": k, "M": M,
+                       "parallelism": par, "layout": layout,
                        "qtile": scan["qtile"], "row_splits": scan["splits"]},
             "roofline": {"bound": "hbm", "kernel": "adc_scan16q_kernel (M=%d, %d queries per pass)" % (M, scan["qtile"]) if (M == 16 and scan["qtile"] == 8) else "adc_scan kernel (M=%d, %d queries per pass)" % (M, scan["qtile"]),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": scan["code_bytes"], "kernel_ms": round(scan["ms"], 4),
-                         "per_query_equivalent_GBs": round(nq * (r1 - r0) * M / (scan["ms"] * 1e-3) / 1e9, 1)},
+                         "lds_lookups_per_s": round(scan["code_bytes"] * scan["qtile"] / (scan["ms"] * 1e-3) / 1e12, 2),
+                         "lds_lookups_per_s_unit": "T table look-ups/s (LDS ceiling of this kernel: 78)"},
             "encode": {"rows_per_s": round(enc_rows / enc_time, 1), "what": "rotate (MFMA GEMM) + PQ encode + append, this rank"},
         }
+        result.update(extra)
 
     # ---- outside the timed region: recall@1 and the CPU baseline (rank 0, N = 1 only) ----
     if rank == 0 and world == 1:

@@ -892,6 +892,18 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
 }
 
 // Row ids travel as 32-bit payloads: one launch covers at most 2^32-1 rows.
+static int cu_count()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
 ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int want_qtile, int want_splits,
                    int want_variant)
 {
@@ -912,19 +924,21 @@ ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int 
     const int64_t groups = (nq + qt - 1) / qt;
     int s = want_splits;
     if (s <= 0) {
-        // Measured (profiles/r01_sweep.txt): per-workgroup fixed cost (table build + selection warm-up)
-        // makes FEWER, LONGER workgroups faster as long as the chip is full: aim at ~1024 workgroups
-        // (2 per CU x 2 rounds), splits a multiple of 8 so that each XCD keeps to its own slice of the
-        // codes, never fewer than 16K rows per workgroup.
-        const int64_t target = 1024;
-        int64_t need = (target + groups - 1) / groups;
-        if (need > 1) need = ((need + 7) / 8) * 8;
-        int64_t max_by_rows = n_rows / 16384;
-        if (max_by_rows < 1) max_by_rows = 1;
-        if (need > max_by_rows) need = max_by_rows >= 8 ? (max_by_rows / 8) * 8 : max_by_rows;
-        if (need < 1) need = 1;
-        if (need > 4096) need = 4096;
-        s = (int)need;
+        // Cost model fitted to profiles/r01_sweep_*.txt and tools/scan_timing.py: a workgroup costs a fixed
+        // ~0.25 M row-equivalents (table build, selection warm-up, compactions) plus its rows, and `slots`
+        // workgroups run at a time (2 per CU), so time ~ ceil(groups*S / slots) * (FIX + rows/S).
+        // Pick the S that minimises it (at least 16 K rows per workgroup).
+        const int64_t slots = 2 * (int64_t)cu_count();
+        const double fix = 250000.0;
+        int64_t best = 1;
+        double best_cost = 1e300;
+        for (int64_t cand = 1; cand <= 64; ++cand) {
+            if (cand > 1 && n_rows / cand < 16384) break;
+            const double rounds = (double)((groups * cand + slots - 1) / slots);
+            const double cost = rounds * (fix + (double)n_rows / (double)cand);
+            if (cost < best_cost * 0.999) { best_cost = cost; best = cand; }
+        }
+        s = (int)best;
     }
     p.splits = s;
     (void)k;

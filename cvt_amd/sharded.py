@@ -30,12 +30,17 @@ class ShardedSearch:
         import torch
         import torch.distributed as dist
         nq = d.shape[0]
+        # gloo has no device collectives: stage through the host (debug runs of bench.py on one GPU only;
+        # the RCCL path exchanges HBM buffers directly)
+        dev = d.device
+        stage = d.is_cuda and dist.get_backend(self.group) == "gloo"
+        sd, si = (d.cpu(), i.cpu()) if stage else (d, i)
         # flat 1-D buffers: the one shape every backend's all_gather_into_tensor agrees on
-        gd = torch.empty(self.world * nq * k, dtype=d.dtype, device=d.device)
-        gi = torch.empty(self.world * nq * k, dtype=i.dtype, device=i.device)
+        gd = torch.empty(self.world * nq * k, dtype=sd.dtype, device=sd.device)
+        gi = torch.empty(self.world * nq * k, dtype=si.dtype, device=si.device)
         # rank order == ascending id range: the merge's tie rule relies on it
-        dist.all_gather_into_tensor(gd, d.contiguous().view(-1), group=self.group)
-        dist.all_gather_into_tensor(gi, i.contiguous().view(-1), group=self.group)
-        gd = gd.view(self.world, nq, k).permute(1, 0, 2).contiguous()
-        gi = gi.view(self.world, nq, k).permute(1, 0, 2).contiguous()
+        dist.all_gather_into_tensor(gd, sd.contiguous().view(-1), group=self.group)
+        dist.all_gather_into_tensor(gi, si.contiguous().view(-1), group=self.group)
+        gd = gd.view(self.world, nq, k).permute(1, 0, 2).contiguous().to(dev)
+        gi = gi.view(self.world, nq, k).permute(1, 0, 2).contiguous().to(dev)
         return self.merge(gd, gi, k)
