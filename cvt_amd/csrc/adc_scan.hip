@@ -41,7 +41,7 @@ struct ScanArgs {
     int groups;
     float *part_d;
     int64_t *part_id;
-    const float *lut_g;  // [nq][M][K] fp32 tables in HBM (adc_scan16q only)
+    const float *lut_g;  // [nq][M][256] fp32 tables in HBM, +inf past K (adc_scan16q only)
 };
 
 template <int M> struct CodeRow;
@@ -551,12 +551,12 @@ struct ExactFromLut {
         const uint32_t w[4] = { c.x, c.y, c.z, c.w };
         int qi = group * SQ_QT + q;
         qi = qi < nq ? qi : nq - 1;
-        const float *t = lut_g + (int64_t)qi * 16 * K;
+        const float *t = lut_g + (int64_t)qi * 16 * 256;
         float v[16];
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             const int j = (int)((w[m >> 2] >> (8 * (m & 3))) & 0xffu);
-            v[m] = j < K ? t[m * K + j] : __uint_as_float(0x7f800000u);
+            v[m] = t[m * 256 + j];  // padded with +inf past K
         }
         float s = 0.0f;
 #pragma unroll
@@ -575,7 +575,7 @@ struct ExactFromLutBatch {
     {
         int qi = group * SQ_QT + q;
         qi = qi < nq ? qi : nq - 1;
-        const float *t = lut_g + (int64_t)qi * 16 * K;
+        const float *t = lut_g + (int64_t)qi * 16 * 256;
         uint4 c[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) c[r] = rows[need[r] ? (uint32_t)e[r] : 0u];
@@ -588,7 +588,9 @@ struct ExactFromLutBatch {
 #pragma unroll
                 for (int m = 0; m < 16; ++m) {
                     const int j = (int)((w[m >> 2] >> (8 * (m & 3))) & 0xffu);
-                    v[r][m] = j < K ? t[m * K + j] : __uint_as_float(0x7f800000u);
+                    // (a predicated gather made hipcc wait vmcnt(0) after every one of the 64 loads:
+                    //  64 serialized memory round trips, 14 us per compaction)
+                    v[r][m] = t[m * 256 + j];  // scratch tables are padded to 256 entries (+inf past K): no predicate
                 }
             }
 #pragma unroll
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
     auto entry = [&](int m, int j, float (&acc)[QT]) {
 #pragma unroll
         for (int q = 0; q < QT; ++q)
-            acc[q] = j < a.K ? a.lut_g[((int64_t)qis[q] * M + m) * a.K + j] : __uint_as_float(0x7f800000u);
+            acc[q] = a.lut_g[((int64_t)qis[q] * M + m) * 256 + j];  // padded with +inf past K
     };
     // pass A: per (query, m) range of the finite entries (a wave covers 64 consecutive j of one m)
     for (int e = tid; e < M * 256; e += NT) {
@@ -998,7 +1000,7 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
     a.part_d = part_d; a.part_id = part_id; a.lut_g = lut_scratch;
     if (plan.variant >= 3 && m.M == 16 && plan.qtile == 8) {
         if (!lut_scratch) return fail(CVTMI_EINVAL, "adc_scan16q: table scratch missing");
-        CVTMI_TRY(launch_lut(m, q_rot, nq, nullptr, lut_scratch, st));  // [nq][16][K] fp32, once per query
+        CVTMI_TRY(launch_lut(m, q_rot, nq, nullptr, lut_scratch, st, 256));  // [nq][16][256] fp32 (+inf past K), once per query
         const int64_t blocks = (int64_t)a.groups * a.splits;
         if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "adc_scan: grid too large (%lld)", (long long)blocks);
         if (plan.variant == 3) hipLaunchKernelGGL((adc_scan16q_kernel<1024, 1>), dim3((unsigned)blocks), dim3(1024), 0, st, a);

@@ -496,7 +496,7 @@ int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, 
     }
     float *lut_scratch = nullptr;
     if (plan.variant >= 3) {  // per-query fp32 tables in HBM (16 KB per query at M=16, K=256)
-        CVTMI_TRY(h->s_lut.reserve((size_t)nq * h->m.M * h->m.K * sizeof(float)));
+        CVTMI_TRY(h->s_lut.reserve((size_t)nq * h->m.M * 256 * sizeof(float)));
         lut_scratch = h->s_lut.as<float>();
     }
     CVTMI_TRY(launch_adc_scan(h->m, h->codes.as<uint8_t>(), h->n, h->id_base, q_rot, nq, k, plan, pd, pi, lut_scratch, st));

@@ -22,8 +22,9 @@ int launch_coarse_assign(const OpqModelDev &m, const float *x_rot, int64_t n, in
 // list_id may be null (=> list 0 for every row)
 int launch_pq_encode(const OpqModelDev &m, const float *x_rot, int64_t n, const int32_t *list_id, uint8_t *codes,
                      hipStream_t st);
+// ld: entries per (query, m) row of the output, 0 = K; ld > K pads with +inf
 int launch_lut(const OpqModelDev &m, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut,
-               hipStream_t st);
+               hipStream_t st, int ld = 0);
 
 // ---- adc_scan.hip ----
 struct ScanPlan {

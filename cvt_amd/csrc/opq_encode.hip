@@ -249,10 +249,11 @@ int launch_pq_encode(const OpqModelDev &m, const float *x_rot, int64_t n, const 
 // ------------------------------------------------------------------------------------------
 // stand-alone LUT: lut[nq][M][K]  (the scan kernel builds its own copy straight into LDS)
 // ------------------------------------------------------------------------------------------
+// ld = entries per (query, m) row in the output: K (the API layout) or 256 with +inf padding (scan scratch)
 __global__ __launch_bounds__(kBlock) void lut_kernel(const float *__restrict__ q_rot, int D, int M, int K, int step,
                                                      const float *__restrict__ coarse,
                                                      const int32_t *__restrict__ list_id,
-                                                     const float *__restrict__ books, float *__restrict__ lut)
+                                                     const float *__restrict__ books, float *__restrict__ lut, int ld)
 {
     extern __shared__ __attribute__((aligned(16))) float res[];  // D floats
     const int64_t qi = blockIdx.x;
@@ -260,24 +261,29 @@ __global__ __launch_bounds__(kBlock) void lut_kernel(const float *__restrict__ q
     if (l < 0) l = 0;
     for (int d = threadIdx.x; d < D; d += kBlock) res[d] = __fsub_rn(q_rot[qi * D + d], coarse[(int64_t)l * D + d]);
     __syncthreads();
-    for (int e = threadIdx.x; e < M * K; e += kBlock) {
-        const int m = e / K;
-        const float *c = books + (int64_t)e * step;
-        float acc = 0.0f;
-        for (int kk = 0; kk < step; ++kk) {
-            const float t = __fsub_rn(res[m * step + kk], c[kk]);
-            acc = __fadd_rn(acc, __fmul_rn(t, t));
+    for (int e = threadIdx.x; e < M * ld; e += kBlock) {
+        const int m = e / ld, j = e - m * ld;
+        float acc = __uint_as_float(0x7f800000u);
+        if (j < K) {
+            const float *c = books + ((int64_t)m * K + j) * step;
+            acc = 0.0f;
+            for (int kk = 0; kk < step; ++kk) {
+                const float t = __fsub_rn(res[m * step + kk], c[kk]);
+                acc = __fadd_rn(acc, __fmul_rn(t, t));
+            }
         }
-        lut[qi * M * K + e] = acc;
+        lut[qi * M * ld + e] = acc;
     }
 }
 
-int launch_lut(const OpqModelDev &m, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut, hipStream_t st)
+int launch_lut(const OpqModelDev &m, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut, hipStream_t st,
+               int ld)
 {
+    if (ld <= 0) ld = m.K;
     if (nq <= 0) return CVTMI_OK;
     if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "lut: nq too large");
     hipLaunchKernelGGL(lut_kernel, dim3((unsigned)nq), dim3(kBlock), (size_t)m.D * sizeof(float), st, q_rot, m.D, m.M,
-                       m.K, m.step, m.coarse, list_id, m.books, lut);
+                       m.K, m.step, m.coarse, list_id, m.books, lut, ld);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
