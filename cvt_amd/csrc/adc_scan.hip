@@ -39,6 +39,8 @@ struct ScanArgs {
     int splits;
     int64_t rows_per_split;
     int groups;
+    int groups_a, splits_b, stride;  // two-region plan (kernels.h), adc_scan16q only; stride = partial slots per query
+    int64_t rows_per_split_b;
     float *part_d;
     int64_t *part_id;
     const float *lut_g;  // [nq][M][256] fp32 tables in HBM, +inf past K (adc_scan16q only)
@@ -502,9 +504,14 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16_kernel(const ScanArgs
 // ==========================================================================================
 #ifdef CVTMI_SCAN_TIMING
 __device__ unsigned long long g_scan_dbg[8];
+__device__ unsigned long long g_scan_trace[4 * 16384];  // per workgroup: wall start, wall end (100 MHz), shader clocks, HW_ID | XCC_ID << 32
 #define SQ_T(i) do { if (threadIdx.x == 0) { const unsigned long long now__ = clock64(); t_acc__[i] += now__ - t_last__; t_last__ = now__; } } while (0)
-#define SQ_T0() unsigned long long t_last__ = clock64(); unsigned long long t_acc__[5] = { 0, 0, 0, 0, 0 }
-#define SQ_TEND() do { if (threadIdx.x == 0) for (int i__ = 0; i__ < 5; ++i__) atomicAdd(&g_scan_dbg[i__], t_acc__[i__]); } while (0)
+#define SQ_T0() unsigned long long t_last__ = clock64(); unsigned long long t_acc__[5] = { 0, 0, 0, 0, 0 }; \
+    const unsigned long long t_first__ = t_last__, w_first__ = wall_clock64()
+#define SQ_TEND() do { if (threadIdx.x == 0) { for (int i__ = 0; i__ < 5; ++i__) atomicAdd(&g_scan_dbg[i__], t_acc__[i__]); \
+    if (blockIdx.x < 16384) { unsigned long long *tr__ = g_scan_trace + 4 * blockIdx.x; tr__[0] = w_first__; tr__[1] = wall_clock64(); \
+        tr__[2] = clock64() - t_first__; \
+        tr__[3] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); } } } while (0)
 #else
 #define SQ_T(i) do { } while (0)
 #define SQ_T0() do { } while (0)
@@ -581,6 +588,7 @@ struct ExactFromLutBatch {
         for (int r = 0; r < 4; ++r) c[r] = rows[need[r] ? (uint32_t)e[r] : 0u];
 #pragma unroll
         for (int h = 0; h < 4; h += 2) {  // two entries at a time: 32 gathers in flight, 32 registers
+            if (__ballot(need[h] || need[h + 1]) == 0) continue;  // wave-uniform: nothing to fix in this pair
             float v[2][16];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -625,17 +633,24 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
     __shared__ struct { int stop, done_waves; uint32_t next_chunk; uint32_t thr_pk[QT / 2]; } ck;
 
     SQ_T0();
-    int group, split;
+    int group, split, my_splits = a.splits;
+    int64_t my_rps = a.rows_per_split;
     {
-        const int b = blockIdx.x;
-        if ((a.splits & 7) == 0) {
-            const int s8 = a.splits >> 3;
+        int b = blockIdx.x, g0 = 0;
+        if (b >= a.groups_a * a.splits) {  // region B: the tail groups, split finer (dispatched last)
+            b -= a.groups_a * a.splits;
+            g0 = a.groups_a;
+            my_splits = a.splits_b;
+            my_rps = a.rows_per_split_b;
+        }
+        if ((my_splits & 7) == 0) {
+            const int s8 = my_splits >> 3;
             const int xcd = b & 7, i = b >> 3;
             split = xcd + 8 * (i % s8);
-            group = i / s8;
+            group = g0 + i / s8;
         } else {
-            split = b % a.splits;
-            group = b / a.splits;
+            split = b % my_splits;
+            group = g0 + b / my_splits;
         }
     }
     const int tid = threadIdx.x, lane = tid & 63;
@@ -733,8 +748,8 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
     if (tid == 0) { ck.stop = 0; ck.done_waves = 0; ck.next_chunk = 0; }
     __syncthreads();
 
-    const int64_t row_begin = (int64_t)split * a.rows_per_split;
-    int64_t row_end = row_begin + a.rows_per_split;
+    const int64_t row_begin = (int64_t)split * my_rps;
+    int64_t row_end = row_begin + my_rps;
     row_end = row_end < a.n_rows ? row_end : a.n_rows;
     const uint32_t n_local = (uint32_t)(row_end > row_begin ? row_end - row_begin : 0);
     const char *rows_b = reinterpret_cast<const char *>(rows + row_begin);
@@ -861,7 +876,7 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
         for (int q = 0; q < QT; ++q) need |= tk.cnt[q] >= SQ_TRIG;
         const bool all_done = ck.done_waves == NW;
         if (need) {  // workgroup-uniform
-            topk_compact_wave<QT, SQ_CAP, NT>(tk, a.k, fixb, thrx);
+            topk_compact_wave<QT, SQ_CAP, NT, false>(tk, a.k, fixb, thrx);
             if (tid < QT / 2) ck.thr_pk[tid] = tk.thr_x[2 * tid] | (tk.thr_x[2 * tid + 1] << 16);
             if (tid == 0) ck.stop = 0;
         }
@@ -871,7 +886,7 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
     }
 
     __syncthreads();
-    topk_compact_wave<QT, SQ_CAP, NT>(tk, a.k, fixb, thrx);
+    topk_compact_wave<QT, SQ_CAP, NT, true>(tk, a.k, fixb, thrx);
     SQ_T(4);  // final compaction
     SQ_TEND();
 #pragma unroll
@@ -879,7 +894,7 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
         const int qi = group * QT + q;
         if (qi >= a.nq) break;
         const int cnt = tk.cnt[q];
-        const int64_t o = ((int64_t)qi * a.splits + split) * a.k;
+        const int64_t o = ((int64_t)qi * a.stride + split) * a.k;
         for (int i = tid; i < a.k; i += NT) {
             if (i < cnt) {
                 const unsigned long long e = tk.buf[q][i];
@@ -888,6 +903,14 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
             } else {
                 a.part_d[o + i] = __uint_as_float(0x7f800000u);
                 a.part_id[o + i] = -1;
+            }
+        }
+        // a region with fewer splits than the partial stride leaves the other slots empty for the merge
+        if (split == 0 && my_splits < a.stride) {
+            const int64_t o2 = ((int64_t)qi * a.stride + my_splits) * a.k;
+            for (int i = tid; i < (a.stride - my_splits) * a.k; i += NT) {
+                a.part_d[o2 + i] = __uint_as_float(0x7f800000u);
+                a.part_id[o2 + i] = -1;
             }
         }
     }
@@ -926,21 +949,45 @@ ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int 
     const int64_t groups = (nq + qt - 1) / qt;
     int s = want_splits;
     if (s <= 0) {
-        // Cost model fitted to profiles/r01_sweep_*.txt and tools/scan_timing.py: a workgroup costs a fixed
-        // ~0.25 M row-equivalents (table build, selection warm-up, compactions) plus its rows, and `slots`
-        // workgroups run at a time (2 per CU), so time ~ ceil(groups*S / slots) * (FIX + rows/S).
-        // Pick the S that minimises it (at least 16 K rows per workgroup).
+        // Cost model fitted to tools/sweep_scan.py runs on 1 M rows (nq = 1250 ... 10000, splits 1-3) and
+        // tools/scan_trace.py: a workgroup costs a fixed ~0.38 M row-equivalents (table build, selection warm-up,
+        // compactions, and the slowdown of sharing its CU) plus its rows; `slots` workgroups run at a time
+        // (2 per CU); a partly filled last round is not as bad as its occupancy, because a workgroup alone on
+        // its CU runs ~1.27x faster: at <= 50 % occupancy the round takes 0.78 of a full one.
+        // Pick the S that minimises rounds(groups * S) * (FIX + rows / S), at least 16 K rows per workgroup.
         const int64_t slots = 2 * (int64_t)cu_count();
-        const double fix = 250000.0;
-        int64_t best = 1;
+        const double fix = 380000.0;
+        const auto wg_cost = [&](int64_t S) { return fix + (double)n_rows / (double)S; };
+        const auto rounds_of = [&](int64_t blocks) {
+            const int64_t full = blocks / slots, last = blocks % slots;
+            if (!last) return (double)full;
+            const double f = (double)last / (double)slots;
+            return (double)full + (f <= 0.5 ? 0.78 : 0.78 + 0.44 * (f - 0.5));
+        };
+        int64_t best = 1, best_ga = 0, best_sb = 0;
         double best_cost = 1e300;
         for (int64_t cand = 1; cand <= 64; ++cand) {
             if (cand > 1 && n_rows / cand < 16384) break;
-            const double rounds = (double)((groups * cand + slots - 1) / slots);
-            const double cost = rounds * (fix + (double)n_rows / (double)cand);
-            if (cost < best_cost * 0.999) { best_cost = cost; best = cand; }
+            const double cost = rounds_of(groups * cand) * wg_cost(cand);
+            if (cost < best_cost * 0.98) { best_cost = cost; best = cand; }
+        }
+        // adc_scan16q can also run two regions: `full` whole rounds of S-split workgroups, then the remaining
+        // groups split finer (S2 > S) so that the last round is short instead of mostly idle.  Taken only when
+        // the model promises > 15 % (measured on 1 M rows: 8-14 % at nq = 4500-5000 where it promises ~20 %,
+        // nothing at nq = 6000-10000 where it promises < 10 %).
+        const int64_t full = groups * best / slots;  // whole rounds of region A
+        if (p.variant >= 3 && full >= 1 && groups * best % slots != 0) {
+            const int64_t ga = full * slots / best, rem = groups - ga;
+            double c_best = best_cost * 0.85;
+            for (int64_t sb = best + 1; sb <= 64 && sb <= 12 * best; ++sb) {
+                if (n_rows / sb < 16384) break;
+                const double c2 = (double)full * wg_cost(best) + rounds_of(rem * sb) * wg_cost(sb) + 20000.0;  // + merge
+                if (c2 < c_best) { c_best = c2; best_ga = ga; best_sb = sb; }
+            }
         }
         s = (int)best;
+        p.groups_a = (int)best_ga;
+        p.splits_b = (int)best_sb;
     }
     p.splits = s;
     (void)k;
@@ -997,11 +1044,19 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
     rps = ((rps + tile_rows - 1) / tile_rows) * tile_rows;
     if (rps < tile_rows) rps = tile_rows;
     a.rows_per_split = rps;
+    a.groups_a = a.groups; a.splits_b = 0; a.stride = plan.splits; a.rows_per_split_b = rps;
     a.part_d = part_d; a.part_id = part_id; a.lut_g = lut_scratch;
     if (plan.variant >= 3 && m.M == 16 && plan.qtile == 8) {
         if (!lut_scratch) return fail(CVTMI_EINVAL, "adc_scan16q: table scratch missing");
         CVTMI_TRY(launch_lut(m, q_rot, nq, nullptr, lut_scratch, st, 256));  // [nq][16][256] fp32 (+inf past K), once per query
-        const int64_t blocks = (int64_t)a.groups * a.splits;
+        int64_t blocks = (int64_t)a.groups * a.splits;
+        if (plan.splits_b > plan.splits && plan.groups_a > 0 && plan.groups_a < a.groups) {
+            a.groups_a = plan.groups_a; a.splits_b = plan.splits_b; a.stride = plan.stride();
+            int64_t rb = (n_rows + plan.splits_b - 1) / plan.splits_b;
+            rb = ((rb + tile_rows - 1) / tile_rows) * tile_rows;
+            a.rows_per_split_b = rb < tile_rows ? tile_rows : rb;
+            blocks = (int64_t)a.groups_a * a.splits + (int64_t)(a.groups - a.groups_a) * a.splits_b;
+        }
         if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "adc_scan: grid too large (%lld)", (long long)blocks);
         if (plan.variant == 3) hipLaunchKernelGGL((adc_scan16q_kernel<1024, 1>), dim3((unsigned)blocks), dim3(1024), 0, st, a);
         else hipLaunchKernelGGL((adc_scan16q_kernel<512, 2>), dim3((unsigned)blocks), dim3(512), 0, st, a);
@@ -1032,6 +1087,18 @@ extern "C" int cvtmi_debug_scan_timing(unsigned long long *out, int reset)
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_dbg), sizeof z) != hipSuccess) return -3;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_scan_dbg), z, sizeof z) != hipSuccess) return -3;
     return 0;
+}
+extern "C" int cvtmi_debug_topk(unsigned long long *out, int reset)
+{
+    unsigned long long z[4] = { 0, 0, 0, 0 };
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_topk_dbg), sizeof z) != hipSuccess) return -3;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_topk_dbg), z, sizeof z) != hipSuccess) return -3;
+    return 0;
+}
+extern "C" int cvtmi_debug_scan_trace(unsigned long long *out, int n_blocks)
+{
+    if (n_blocks > 16384) n_blocks = 16384;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_trace), (size_t)n_blocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }
 #endif
 

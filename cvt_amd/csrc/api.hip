@@ -123,6 +123,7 @@ struct cvtmi_opq_s {
     DevBuf s_qrot, s_part_d, s_part_id, s_probe, s_lut;
     // tuning / measurement
     int p_splits = 0, p_qtile = 0, p_profile = 0, p_variant = 4;
+    int p_tail = 1, p_groups_a = 0, p_splits_b = 0;  // two-region scan plan: on / forced shape (tests)
     static constexpr int kEvRing = 64;
     hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
     int ev_count = 0;  // scan launches recorded since the last cvtmi_opq_last_scan
@@ -479,11 +480,16 @@ int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, 
         CVTMI_TRY(cvtmi_opq_rotate_dev(h, q, nq, h->s_qrot.as<float>(), stream));
         q_rot = h->s_qrot.as<float>();
     }
-    const ScanPlan plan = plan_scan(h->m, h->n, nq, k, h->p_qtile, h->p_splits, h->p_variant);
+    ScanPlan plan = plan_scan(h->m, h->n, nq, k, h->p_qtile, h->p_splits, h->p_variant);
+    if (!h->p_tail) { plan.groups_a = 0; plan.splits_b = 0; }
+    if (h->p_groups_a > 0 && h->p_splits_b > plan.splits && plan.variant >= 3 &&
+        h->p_groups_a < (nq + plan.qtile - 1) / plan.qtile) {
+        plan.groups_a = h->p_groups_a; plan.splits_b = h->p_splits_b;
+    }
     float *pd = dist;
     int64_t *pi = ids;
-    if (plan.splits > 1) {
-        const size_t cnt = (size_t)nq * plan.splits * k;
+    if (plan.stride() > 1) {
+        const size_t cnt = (size_t)nq * plan.stride() * k;
         CVTMI_TRY(h->s_part_d.reserve(cnt * sizeof(float)));
         CVTMI_TRY(h->s_part_id.reserve(cnt * sizeof(int64_t)));
         pd = h->s_part_d.as<float>();
@@ -507,7 +513,7 @@ int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, 
         h->last_bytes = groups * h->n * h->m.M;  // passes x rows x M code bytes
         h->last_qt = plan.qtile; h->last_splits = plan.splits;
     }
-    if (plan.splits > 1) CVTMI_TRY(launch_topk_merge(pd, pi, nq, plan.splits, k, dist, ids, st));
+    if (plan.stride() > 1) CVTMI_TRY(launch_topk_merge(pd, pi, nq, plan.stride(), k, dist, ids, st));
     return CVTMI_OK;
 }
 
@@ -560,6 +566,9 @@ int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value)
 {
     if (!h || !name) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: null");
     if (!strcmp(name, "splits")) { h->p_splits = (int)value; return CVTMI_OK; }
+    if (!strcmp(name, "tail_split")) { h->p_tail = value != 0; return CVTMI_OK; }
+    if (!strcmp(name, "groups_a")) { h->p_groups_a = (int)value; return CVTMI_OK; }
+    if (!strcmp(name, "splits_b")) { h->p_splits_b = (int)value; return CVTMI_OK; }
     if (!strcmp(name, "qtile")) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
             return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: qtile must be 0, 1, 2, 4 or 8");

@@ -198,8 +198,73 @@ __device__ __forceinline__ void wave_bitonic_sort256(unsigned long long (&e)[4])
     }
 }
 
-// one query, one wave, no barrier: returns the number of entries kept
-template <int QT, int CAP, class FixB, class ThrX>
+// k-th smallest (k = 1..number of valid entries) of the wave's 256 register entries (4 per lane), by an MSB-first
+// radix select on lane masks: per bit one compare + ballot per register and scalar popcounts, no cross-lane data
+// movement, and it stops as soon as a single candidate is left (~20 of 64 bits for distinct fp32 keys).
+// Slots that hold no entry must be ~0ull.
+__device__ __forceinline__ unsigned long long wave_select256(const unsigned long long (&e)[4], int k)
+{
+    unsigned long long alive[4] = { ~0ull, ~0ull, ~0ull, ~0ull };  // wave-uniform lane masks
+    int kk = k, n_alive = 256;
+    unsigned long long prefix = 0;
+#pragma unroll
+    for (int half = 1; half >= 0; --half) {
+        uint32_t w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = half ? (uint32_t)(e[r] >> 32) : (uint32_t)e[r];
+        for (int b = 31; b >= 0 && n_alive > 1; --b) {  // wave-uniform
+            const uint32_t m = 1u << b;
+            unsigned long long z[4];
+            int c0 = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                z[r] = __ballot((w[r] & m) == 0) & alive[r];
+                c0 += __popcll(z[r]);
+            }
+            if (kk <= c0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) alive[r] = z[r];
+                n_alive = c0;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) alive[r] &= ~z[r];
+                kk -= c0;
+                n_alive -= c0;
+                prefix |= (unsigned long long)m << (half * 32);
+            }
+        }
+    }
+    if (n_alive == 1) {  // the survivor's value (the loop may have stopped before its low bits were walked)
+        unsigned long long v = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (alive[r]) {  // wave-uniform
+                const int src = __ffsll((long long)alive[r]) - 1;
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e[r], src);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e[r] >> 32), src);
+                v = ((unsigned long long)hi << 32) | lo;
+            }
+        }
+        return v;
+    }
+    return prefix;  // duplicates of the k-th value: every bit was walked
+}
+
+#ifdef CVTMI_SCAN_TIMING
+static __device__ unsigned long long g_topk_dbg[4];  // compaction rounds, fix cycles, sort cycles, new entries (thread 0's view)
+#define TK_T(i, t0) do { if (threadIdx.x == 0) atomicAdd(&g_topk_dbg[i], (unsigned long long)(clock64() - (t0))); } while (0)
+#else
+#define TK_T(i, t0) do { } while (0)
+#endif
+
+// one query, one wave, no barrier: returns the number of entries kept.
+// SORTED: the kept entries are left in ascending order (needed once, for the result); otherwise they are the k
+// smallest in arbitrary order, found by selection instead of a sort (the intermediate compactions only need the
+// set and the k-th value).
+// Register slot p = 64 r + lane holds new entry ex + p for p < n - ex and exact entry p - (256 - ex) for
+// p >= 256 - ex: the entries to be fixed sit in the first registers, so fixb can skip its second batch when
+// there are at most 128 of them.
+template <int QT, int CAP, bool SORTED, class FixB, class ThrX>
 __device__ __attribute__((noinline)) int topk_compact_wave_q(TopKShared<QT, CAP> &s, int q, int k, const FixB &fixb,
                                                             const ThrX &thrx)
 {
@@ -213,25 +278,54 @@ __device__ __attribute__((noinline)) int topk_compact_wave_q(TopKShared<QT, CAP>
     bool need[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int idx = r * 64 + lane;
-        e[r] = idx < n ? b[idx] : ~0ull;
-        need[r] = idx >= ex && idx < n;
+        const int p = r * 64 + lane;
+        need[r] = p < n - ex;
+        const bool old = p >= 256 - ex;
+        const int idx = need[r] ? ex + p : p - (256 - ex);
+        e[r] = (need[r] || old) ? b[idx] : ~0ull;
     }
+#ifdef CVTMI_SCAN_TIMING
+    const long long tk0 = clock64();
+    if (threadIdx.x == 0) { atomicAdd(&g_topk_dbg[0], 1ull); atomicAdd(&g_topk_dbg[3], (unsigned long long)(n - ex)); }
+#endif
     fixb(q, e, need);
-    wave_bitonic_sort256(e);
+#ifdef CVTMI_SCAN_TIMING
+    TK_T(1, tk0);
+    const long long tk1 = clock64();
+#endif
     const int keep = n < k ? n : k;
+    uint32_t th_k;
+    if constexpr (SORTED) {
+        wave_bitonic_sort256(e);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int idx = r * 64 + lane;
-        if (idx < keep) b[idx] = e[r];
+        for (int r = 0; r < 4; ++r) {
+            const int idx = r * 64 + lane;
+            if (idx < keep) b[idx] = e[r];
+        }
+        // k-th entry: element index k-1 lives in register (k-1)>>6 of lane (k-1)&63
+        unsigned long long kth = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (((k - 1) >> 6) == r) kth = e[r];
+        const uint32_t th_lane = (uint32_t)(kth >> 32);
+        th_k = (uint32_t)__shfl((int)th_lane, (k - 1) & 63);
+    } else {
+        // n < k: everything stays (all entries are below ~0ull - 1)
+        const unsigned long long kth = n >= k ? wave_select256(e, k) : 0xfffffffffffffffeull;
+        th_k = (uint32_t)(kth >> 32);
+        int base = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool in = e[r] <= kth;
+            const unsigned long long m = __ballot(in);
+            const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (in && pos < keep) b[pos] = e[r];
+            base += __popcll(m);
+        }
     }
-    // k-th entry: element index k-1 lives in register (k-1)>>6 of lane (k-1)&63
-    unsigned long long kth = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (((k - 1) >> 6) == r) kth = e[r];
-    const uint32_t th_lane = (uint32_t)(kth >> 32);
-    const uint32_t th_k = (uint32_t)__shfl((int)th_lane, (k - 1) & 63);
+#ifdef CVTMI_SCAN_TIMING
+    TK_T(2, tk1);
+#endif
     if (lane == 0) {
         s.exact_n[q] = keep;
         const uint32_t th = (n >= k) ? th_k : KEY_MAX;
@@ -241,13 +335,13 @@ __device__ __attribute__((noinline)) int topk_compact_wave_q(TopKShared<QT, CAP>
     return keep;
 }
 
-template <int QT, int CAP, int NT, class FixB, class ThrX>
+template <int QT, int CAP, int NT, bool SORTED, class FixB, class ThrX>
 __device__ __forceinline__ void topk_compact_wave(TopKShared<QT, CAP> &s, int k, const FixB &fixb, const ThrX &thrx)
 {
     constexpr int NW = NT / 64;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int q = wv; q < QT; q += NW) {  // wave-uniform
-        const int keep = topk_compact_wave_q<QT, CAP>(s, q, k, fixb, thrx);
+        const int keep = topk_compact_wave_q<QT, CAP, SORTED>(s, q, k, fixb, thrx);
         if (lane == 0) s.cnt[q] = keep;
     }
     __syncthreads();

@@ -31,10 +31,15 @@ struct ScanPlan {
     int qtile;    // 1,2,4,8
     int splits;   // row splits per query group
     int variant;  // 0 = one row per lane, same sub-quantiser across the wave; 1 = skewed conflict-free (M = 16)
+    // two-region plan (adc_scan16q only): the first groups_a query groups use `splits` row splits, the rest use
+    // splits_b (> splits) so that the last, partly filled round of workgroups is made of shorter ones.
+    // splits_b == 0: one region.  Partial results are laid out [nq][stride()][k].
+    int groups_a = 0, splits_b = 0;
+    int stride() const { return splits_b > splits ? splits_b : splits; }
 };
 ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int want_qtile, int want_splits,
                    int want_variant);
-// part_d / part_id: [nq][splits][k]
+// part_d / part_id: [nq][plan.stride()][k]
 // lut_scratch: nq * M * K floats, needed when plan.variant >= 3 (see scan_lut_floats)
 int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, int64_t id_base, const float *q_rot,
                     int64_t nq, int k, const ScanPlan &plan, float *part_d, int64_t *part_id, float *lut_scratch,

@@ -199,6 +199,25 @@ def test_search_edge_cases(amd, orc):
         idx.search(q, 129, rotate=False)
 
 
+def test_two_region_scan_plan(amd, orc):
+    """Tail groups split finer than the leading ones (kernels.h ScanPlan::groups_a / splits_b): same results."""
+    D, M, K = 128, 16, 256
+    rng = np.random.default_rng(21)
+    books = synth_model(rng, D, M, K, scale=0.1)
+    codes = rng.integers(0, K, size=(9000, M), dtype=np.uint8)
+    q = (rng.normal(size=(77, D)) * 0.1).astype(np.float32)
+    od, oi = orc.adc_search(q, books, codes, 100)
+    idx = amd.OpqIndex(np.zeros((1, D), np.float32), books)
+    idx.add_codes(codes)
+    for variant in (4, 3):
+        for splits, ga, sb in ((1, 3, 2), (1, 9, 3), (2, 1, 5), (8, 4, 16), (1, 10, 4), (1, 3, 8)):
+            idx.set_param("scan_variant", variant); idx.set_param("splits", splits)
+            idx.set_param("groups_a", ga); idx.set_param("splits_b", sb)
+            d, i = idx.search(q, 100, rotate=False)
+            assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od)), (variant, splits, ga, sb)
+    idx.set_param("groups_a", 0); idx.set_param("splits_b", 0); idx.set_param("splits", 0)
+
+
 def test_search_device_pointers_and_rotation(amd, orc):
     """_dev entry points on torch tensors, rotation by a dense orthonormal R through the MFMA GEMM."""
     import torch

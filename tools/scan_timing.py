@@ -23,10 +23,15 @@ for var, sp in ((4, 1), (3, 1)):
     idx.search(q, k); torch.cuda.synchronize(); idx.last_scan()
     out = (C.c_ulonglong * 8)()
     lib.cvtmi_debug_scan_timing(out, 1)
+    tko = (C.c_ulonglong * 4)()
+    lib.cvtmi_debug_topk(tko, 1)
     idx.search(q, k); torch.cuda.synchronize()
     s = idx.last_scan()
     lib.cvtmi_debug_scan_timing(out, 1)
+    lib.cvtmi_debug_topk(tko, 1)
     nb = (nq + 7) // 8 * sp
     names = ["prologue", "lookups+push", "wait at checkpoint", "compaction + barrier", "final compaction"]
     print("variant %d splits %d k %d: kernel %.3f ms, %d blocks; per-block us (shader clock @ ~2.35 GHz): " % (var, sp, k, s["ms"], nb) +
           ", ".join("%s %.1f" % (n, out[i] / nb / 2350.0) for i, n in enumerate(names)), flush=True)
+    print("   compactions of query 0 per block %.1f, new entries each %.1f, exact-fix %.2f us, sort %.2f us (thread 0, @2.35 GHz)" % (
+        tko[0] / nb, tko[3] / max(1, tko[0]), tko[1] / max(1, tko[0]) / 2350.0, tko[2] / max(1, tko[0]) / 2350.0), flush=True)

@@ -18,6 +18,7 @@ ap.add_argument("--qtiles", default="1,2,4")
 ap.add_argument("--splits", default="1,8,16,32,64")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--variants", default="1,0")
+ap.add_argument("--tail", type=int, default=1)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 D, M, K = 128, a.M, 256
@@ -31,6 +32,7 @@ codes = torch.randint(0, 256, (a.rows, M), generator=g, device=dev, dtype=torch.
 idx.add_codes(codes)
 q = synth.sift_like(a.nq, D, seed=0xBEEF, device=dev)
 idx.set_param("profile", 1)
+idx.set_param("tail_split", a.tail)
 for var in [int(x) for x in a.variants.split(",")]:
   for qt in [int(x) for x in a.qtiles.split(",")]:
     for sp in [int(x) for x in a.splits.split(",")]:
