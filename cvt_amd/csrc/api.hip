@@ -809,13 +809,10 @@ int cvtmi_sq8_train_dev(const float *x, int64_t n, int d, int l2norm, float *vmi
     if (n < 0 || d < 1 || !vmin || !vdiff || (n > 0 && !x)) return fail(CVTMI_EINVAL, "cvtmi_sq8_train: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     Tmp den, keys;
-    if (l2norm && n > 0) {
-        CVTMI_TRY(den.alloc((size_t)n * sizeof(float)));
-        CVTMI_TRY(launch_sq8_rownorm(x, n, d, den.as<float>(), st));
-    }
+    if (l2norm && n > 0 && !sq8_single_pass(d, x, nullptr, nullptr, nullptr)) CVTMI_TRY(den.alloc((size_t)n * sizeof(float)));
     CVTMI_TRY(keys.alloc((size_t)d * 2 * sizeof(uint32_t)));
-    CVTMI_TRY(launch_sq8_train(x, n, d, (l2norm && n > 0) ? den.as<float>() : nullptr, keys.as<uint32_t>(),
-                               keys.as<uint32_t>() + d, vmin, vdiff, st));
+    CVTMI_TRY(launch_sq8_train(x, n, d, l2norm, den.as<float>(), keys.as<uint32_t>(), keys.as<uint32_t>() + d, vmin, vdiff,
+                               st));
     CVTMI_HIP(hipStreamSynchronize(st));  // the temporaries die with this frame
     return CVTMI_OK;
 }
@@ -840,12 +837,10 @@ int cvtmi_sq8_encode_dev(const float *vmin, const float *vdiff, int d, float *x,
     if (n == 0) return CVTMI_OK;
     hipStream_t st = (hipStream_t)stream;
     Tmp den;
-    if (l2norm) {
-        CVTMI_TRY(den.alloc((size_t)n * sizeof(float)));
-        CVTMI_TRY(launch_sq8_rownorm(x, n, d, den.as<float>(), st));
-    }
-    CVTMI_TRY(launch_sq8_encode(vmin, vdiff, d, x, n, l2norm ? den.as<float>() : nullptr, 1, codes, st));
-    if (l2norm) CVTMI_HIP(hipStreamSynchronize(st));
+    const bool two_pass = l2norm && !sq8_single_pass(d, x, codes, vmin, vdiff);
+    if (two_pass) CVTMI_TRY(den.alloc((size_t)n * sizeof(float)));
+    CVTMI_TRY(launch_sq8_encode_rows(vmin, vdiff, d, x, n, l2norm, 1, codes, den.as<float>(), st));
+    if (two_pass) CVTMI_HIP(hipStreamSynchronize(st));  // the temporary dies with this frame
     return CVTMI_OK;
 }
 

@@ -78,13 +78,16 @@ int launch_gather_labels(int64_t *ids, int64_t count, const int64_t *labels, hip
 // ---- sq8.hip ----
 // den[n] = float(max(1e-12, sqrt(sum_i double(x_i * x_i))))   (int8_quan.cc:46-52)
 int launch_sq8_rownorm(const float *x, int64_t n, int d, float *den, hipStream_t st);
-// den may be null (no normalisation); write_back != 0 stores x / den over x
-int launch_sq8_encode(const float *vmin, const float *vdiff, int d, float *x, int64_t n, const float *den,
-                      int write_back, uint8_t *codes, hipStream_t st);
+// Int8Encode over n rows (int8_quan.cc:72-94): optional L2 normalisation (written back over x when write_back),
+// then the bytes.  den_scratch: n floats, used only for row widths the single-pass kernel does not take.
+int launch_sq8_encode_rows(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm, int write_back,
+                           uint8_t *codes, float *den_scratch, hipStream_t st);
 int launch_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x,
                       hipStream_t st);
-// kmin/kmax: [d] ordered-uint32 scratch (initialised inside); results in vmin / vdiff
-int launch_sq8_train(const float *x, int64_t n, int d, const float *den, uint32_t *kmin, uint32_t *kmax, float *vmin,
-                     float *vdiff, hipStream_t st);
+// kmin/kmax: [d] ordered-uint32 scratch (initialised inside); results in vmin / vdiff; den_scratch as above
+int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_scratch, uint32_t *kmin, uint32_t *kmax,
+                     float *vmin, float *vdiff, hipStream_t st);
+// true when (d, pointers) take the single-pass kernel, i.e. no den_scratch is needed
+bool sq8_single_pass(int d, const void *x, const void *codes, const void *vmin, const void *vdiff);
 
 }  // namespace cvtmi

@@ -9,13 +9,236 @@
 // sq_train.cpp:84-103: rows L2-normalised, then per-dimension min and max - min (faiss
 // ScalarQuantizer default RS_minmax; that library is not vendored: parity unpinned).
 //
-// All three are streaming, HBM-bound kernels (2.5 KB moved per 512-d row on encode).  The only
-// serial part is the double-precision norm, whose addition order is part of bit-exactness: rows are
-// staged through LDS with coalesced loads and one lane per row folds them in index order.
+// All of it is streaming work whose roofline is HBM (encode: 4d bytes in + d out per row), so the kernels
+// are built to read every row exactly once and to keep the VALU cost per element below the HBM time:
+//
+//  * sq8_tile_kernel (d % 4 == 0, d <= 512): a 1024-thread workgroup owns 64-row tiles.  A tile is loaded
+//    ONCE (16-byte coalesced loads into registers, the next tile already in flight) and parked in LDS,
+//    where wave 0 folds the double-precision norms -- one lane per row, in index order, because the order
+//    of the additions is part of bit-exactness -- before all waves encode it (or min/max-reduce it, for
+//    training).
+//  * IEEE division is ~11 VALU instructions and there are two per element.  Both divisors are shared (one
+//    per row, one per column), so their correctly rounded reciprocals y = RN(1/b) are computed once and
+//    each quotient costs three instructions: q = RN(a*y), e = fma(-b, q, a), RN(q + e*y).  That is RN(a/b)
+//    whenever b's significand is not all ones and nothing leaves the normal range (Markstein's
+//    theorem; tools/ubench/div_check.c brute-forces 1.1e9 quotients incl. every significand of b);
+//    operands outside the guarded range take __fdiv_rn.
+//  * decode divides by the constant 255.0 in double the same way (3 full-rate fp64 ops instead of a ddiv).
+//  * rows of other widths take the two-pass kernels at the bottom (norms, then an element-wise pass).
 #include "kernels.h"
 
 namespace cvtmi {
 
+// ---- correctly rounded a / b with a shared divisor ------------------------------------------------
+struct DivBy {
+    float b, y;  // divisor, RN(1 / b)
+    bool ok;     // fast path allowed for this divisor
+};
+__device__ __forceinline__ DivBy div_by(float b)
+{
+    DivBy d;
+    d.b = b;
+    d.ok = b >= 0x1p-40f && b <= 0x1p40f && (__float_as_uint(b) & 0x7fffffu) != 0x7fffffu;
+    d.y = d.ok ? __fdiv_rn(1.0f, b) : 0.0f;
+    return d;
+}
+__device__ __attribute__((noinline)) float div_slow(float a, float b) { return __fdiv_rn(a, b); }
+__device__ __forceinline__ float div_rn(float a, const DivBy &d)
+{
+    const float aa = fabsf(a);
+    const float q = __fmul_rn(a, d.y);
+    const float e = __fmaf_rn(-d.b, q, a);
+    float r = __fmaf_rn(e, d.y, q);
+    r = aa == 0.0f ? a : r;  // +-0 / positive b keeps its sign
+    if (!(d.ok && (aa <= 0x1p60f && (aa >= 0x1p-60f || aa == 0.0f)))) r = div_slow(a, d.b);  // rare: out of line
+    return r;
+}
+
+__device__ __forceinline__ uint32_t sq8_byte(float v, float lo, const DivBy &df)
+{
+    float xi = 0.0f;
+    if (df.b != 0.0f) xi = div_rn(__fsub_rn(v, lo), df);
+    if (xi < 0.0f) xi = 0.0f;
+    if (xi > 1.0f) xi = 1.0f;
+    return (uint32_t)(uint8_t)(int)__fmul_rn(255.0f, xi);
+}
+
+// ---- the single-pass tile kernel -------------------------------------------------------------------
+constexpr int SQ_NT = 1024;     // threads per workgroup
+constexpr int SQ_ROWS = 64;     // rows per tile = lanes of the folding wave
+constexpr int SQ_PF = 8;        // float4 registers per thread and tile (d = 512: 64 rows x 128 float4 / 1024)
+
+struct Sq8Args {
+    const float *vmin, *vdiff;  // encode
+    float *x;                   // rows (written back normalised when write_back)
+    uint8_t *codes;
+    uint32_t *kmin, *kmax;      // train: per-column ordered-uint keys
+    int64_t n;
+    int d, l2norm, write_back;
+};
+
+template <bool TRAIN>
+__global__ __launch_bounds__(SQ_NT) void sq8_tile_kernel(const Sq8Args a)
+{
+    extern __shared__ float4 sq_tile[];  // [SQ_ROWS][CG + 1]
+    __shared__ float den_s[SQ_ROWS], rcp_s[SQ_ROWS];
+    __shared__ int ok_s[SQ_ROWS];
+    const int CG = a.d >> 2;            // float4 per row
+    const int TY = SQ_NT / CG;          // rows covered by one sweep of the workgroup
+    const int tid = threadIdx.x;
+    const int ty = tid / CG, tx = tid - ty * CG;
+    const bool active = ty < TY;
+    const int64_t n_tiles = (a.n + SQ_ROWS - 1) / SQ_ROWS;
+    const float4 *x4 = reinterpret_cast<const float4 *>(a.x);
+
+    float4 lo4 = make_float4(0, 0, 0, 0);
+    DivBy df[4];
+    float4 mn = make_float4(__uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u),
+                            __uint_as_float(0x7f800000u));
+    float4 mx = make_float4(__uint_as_float(0xff800000u), __uint_as_float(0xff800000u), __uint_as_float(0xff800000u),
+                            __uint_as_float(0xff800000u));
+    if constexpr (!TRAIN) {
+        if (active) {
+            lo4 = reinterpret_cast<const float4 *>(a.vmin)[tx];
+            const float4 d4 = reinterpret_cast<const float4 *>(a.vdiff)[tx];
+            df[0] = div_by(d4.x); df[1] = div_by(d4.y); df[2] = div_by(d4.z); df[3] = div_by(d4.w);
+        }
+    }
+
+    auto load_tile = [&](int64_t tile, float4 (&v)[SQ_PF]) {
+#pragma unroll
+        for (int i = 0; i < SQ_PF; ++i) {
+            const int r = ty + i * TY;
+            const int64_t row = tile * SQ_ROWS + r;
+            v[i] = make_float4(0, 0, 0, 0);
+            if (active && r < SQ_ROWS && row < a.n) v[i] = x4[row * CG + tx];
+        }
+    };
+
+    // One register set: the tile in hand goes to LDS, then the registers take the next tile's loads, which stay
+    // in flight during the fold and the encode (which reads the tile back from LDS).
+    float4 pf[SQ_PF];
+    int64_t tile = blockIdx.x;
+    if (tile < n_tiles) load_tile(tile, pf);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();  // previous tile's readers are done
+#pragma unroll
+        for (int i = 0; i < SQ_PF; ++i) {
+            const int r = ty + i * TY;
+            if (active && r < SQ_ROWS) sq_tile[r * (CG + 1) + tx] = pf[i];
+        }
+        const int64_t tile_next = tile + gridDim.x;
+        if (tile_next < n_tiles) load_tile(tile_next, pf);
+        __syncthreads();
+        if (a.l2norm) {
+            if (tid < SQ_ROWS) {  // wave 0: one lane per row, index order (int8_quan.cc:48-51)
+                const float4 *rowp = sq_tile + tid * (CG + 1);
+                double accum = 0.0;
+                // The additions form one dependent fp64 chain per row; everything else (LDS reads, squares,
+                // conversions) is done one group of 8 elements ahead so that the chain never waits for it.
+                auto squares = [&](int j, double (&o)[8]) {
+                    const float4 t0 = rowp[j], t1 = rowp[j + 1];
+                    o[0] = (double)__fmul_rn(t0.x, t0.x); o[1] = (double)__fmul_rn(t0.y, t0.y);
+                    o[2] = (double)__fmul_rn(t0.z, t0.z); o[3] = (double)__fmul_rn(t0.w, t0.w);
+                    o[4] = (double)__fmul_rn(t1.x, t1.x); o[5] = (double)__fmul_rn(t1.y, t1.y);
+                    o[6] = (double)__fmul_rn(t1.z, t1.z); o[7] = (double)__fmul_rn(t1.w, t1.w);
+                };
+                int j = 0;
+                if (CG >= 2) {
+                    double dn[8];
+                    squares(0, dn);
+                    for (j = 2; j + 2 <= CG; j += 2) {
+                        double dc[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) dc[u] = dn[u];
+                        squares(j, dn);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) accum += dc[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) accum += dn[u];
+                }
+                for (; j < CG; ++j) {
+                    const float4 t = rowp[j];
+                    accum += (double)__fmul_rn(t.x, t.x);
+                    accum += (double)__fmul_rn(t.y, t.y);
+                    accum += (double)__fmul_rn(t.z, t.z);
+                    accum += (double)__fmul_rn(t.w, t.w);
+                }
+                const double nrm = __dsqrt_rn(accum);
+                const DivBy dd = div_by((float)(nrm > 1e-12 ? nrm : 1e-12));
+                den_s[tid] = dd.b;
+                rcp_s[tid] = dd.y;
+                ok_s[tid] = dd.ok;
+            }
+            __syncthreads();
+        }
+#pragma unroll 2
+        for (int i = 0; i < SQ_PF; ++i) {
+            const int r = ty + i * TY;
+            const int64_t row = tile * SQ_ROWS + r;
+            if (!(active && r < SQ_ROWS && row < a.n)) continue;
+            float4 v = sq_tile[r * (CG + 1) + tx];
+            if (a.l2norm) {
+                DivBy dd;
+                dd.b = den_s[r]; dd.y = rcp_s[r]; dd.ok = ok_s[r] != 0;
+                v.x = div_rn(v.x, dd); v.y = div_rn(v.y, dd); v.z = div_rn(v.z, dd); v.w = div_rn(v.w, dd);
+                if (!TRAIN && a.write_back) reinterpret_cast<float4 *>(a.x)[row * CG + tx] = v;
+            }
+            if constexpr (TRAIN) {
+                mn.x = v.x < mn.x ? v.x : mn.x; mn.y = v.y < mn.y ? v.y : mn.y;
+                mn.z = v.z < mn.z ? v.z : mn.z; mn.w = v.w < mn.w ? v.w : mn.w;
+                mx.x = v.x > mx.x ? v.x : mx.x; mx.y = v.y > mx.y ? v.y : mx.y;
+                mx.z = v.z > mx.z ? v.z : mx.z; mx.w = v.w > mx.w ? v.w : mx.w;
+            } else {
+                const uint32_t w = sq8_byte(v.x, lo4.x, df[0]) | (sq8_byte(v.y, lo4.y, df[1]) << 8) |
+                                   (sq8_byte(v.z, lo4.z, df[2]) << 16) | (sq8_byte(v.w, lo4.w, df[3]) << 24);
+                reinterpret_cast<uint32_t *>(a.codes)[row * CG + tx] = w;
+            }
+        }
+    }
+    if constexpr (TRAIN) {
+        if (active) {  // min / max are order-independent: one atomic per thread and column
+            const float lo[4] = { mn.x, mn.y, mn.z, mn.w }, hi[4] = { mx.x, mx.y, mx.z, mx.w };
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                atomicMin(&a.kmin[4 * tx + c], f32_key(lo[c]));
+                atomicMax(&a.kmax[4 * tx + c], f32_key(hi[c]));
+            }
+        }
+    }
+}
+
+static bool sq8_tile_ok(int d, const void *x, const void *codes, const void *vmin, const void *vdiff);
+bool sq8_single_pass(int d, const void *x, const void *codes, const void *vmin, const void *vdiff)
+{
+    return sq8_tile_ok(d, x, codes, vmin, vdiff);
+}
+static bool sq8_tile_ok(int d, const void *x, const void *codes, const void *vmin, const void *vdiff)
+{
+    return d >= 4 && d <= 512 && (d & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)codes & 3) == 0 &&
+           ((uintptr_t)vmin & 15) == 0 && ((uintptr_t)vdiff & 15) == 0;
+}
+
+template <bool TRAIN>
+static int launch_sq8_tile(const Sq8Args &a, hipStream_t st)
+{
+    const size_t lds = (size_t)SQ_ROWS * ((a.d >> 2) + 1) * sizeof(float4);
+    static bool attr_set[2] = { false, false };
+    if (!attr_set[TRAIN]) {
+        CVTMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sq8_tile_kernel<TRAIN>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 129 * 16));
+        attr_set[TRAIN] = true;
+    }
+    const int64_t n_tiles = (a.n + SQ_ROWS - 1) / SQ_ROWS;
+    int64_t blocks = lds > 72 * 1024 ? 256 : 512;  // one or two workgroups per CU
+    if (blocks > n_tiles) blocks = n_tiles;
+    hipLaunchKernelGGL(sq8_tile_kernel<TRAIN>, dim3((unsigned)blocks), dim3(SQ_NT), lds, st, a);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+// ---- two-pass kernels for the other row widths ----------------------------------------------------
 constexpr int NORM_ROWS = 64;   // rows per workgroup
 constexpr int NORM_COLS = 256;  // columns staged per step
 
@@ -59,25 +282,27 @@ int launch_sq8_rownorm(const float *x, int64_t n, int d, float *den, hipStream_t
     return CVTMI_OK;
 }
 
+constexpr int EW_ROWS = 16;  // rows per workgroup of the element-wise kernels
+
 __global__ __launch_bounds__(kBlock) void sq8_encode_kernel(const float *__restrict__ vmin,
-                                                            const float *__restrict__ vdiff, int d, float *x,
-                                                            int64_t total, const float *__restrict__ den,
-                                                            int write_back, uint8_t *__restrict__ codes)
+                                                            const float *__restrict__ vdiff, int d, float *x, int64_t n,
+                                                            const float *__restrict__ den, int write_back,
+                                                            uint8_t *__restrict__ codes)
 {
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
-        const int64_t r = e / d;
-        const int i = (int)(e - r * d);
-        float v = x[e];
-        if (den) {
-            v = __fdiv_rn(v, den[r]);
-            if (write_back) x[e] = v;
+    for (int64_t r0 = (int64_t)blockIdx.x * EW_ROWS; r0 < n; r0 += (int64_t)gridDim.x * EW_ROWS) {
+        for (int c = threadIdx.x; c < d; c += kBlock) {  // lanes walk adjacent columns: coalesced
+            const float lo = vmin[c];
+            const DivBy df = div_by(vdiff[c]);
+            for (int r = 0; r < EW_ROWS && r0 + r < n; ++r) {
+                const int64_t e = (r0 + r) * d + c;
+                float v = x[e];
+                if (den) {
+                    v = __fdiv_rn(v, den[r0 + r]);
+                    if (write_back) x[e] = v;
+                }
+                codes[e] = (uint8_t)sq8_byte(v, lo, df);
+            }
         }
-        float xi = 0.0f;
-        const float df = vdiff[i];
-        if (df != 0.0f) xi = __fdiv_rn(__fsub_rn(v, vmin[i]), df);
-        if (xi < 0.0f) xi = 0.0f;
-        if (xi > 1.0f) xi = 1.0f;
-        codes[e] = (uint8_t)(int)__fmul_rn(255.0f, xi);
     }
 }
 
@@ -85,24 +310,93 @@ int launch_sq8_encode(const float *vmin, const float *vdiff, int d, float *x, in
                       int write_back, uint8_t *codes, hipStream_t st)
 {
     if (n <= 0) return CVTMI_OK;
-    const int64_t total = n * d;
-    int64_t blocks = (total + kBlock - 1) / kBlock;
+    int64_t blocks = (n + EW_ROWS - 1) / EW_ROWS;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(sq8_encode_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, vmin, vdiff, d, x, total, den,
+    hipLaunchKernelGGL(sq8_encode_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, vmin, vdiff, d, x, n, den,
                        write_back, codes);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
 
+int launch_sq8_encode_rows(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm, int write_back,
+                           uint8_t *codes, float *den_scratch, hipStream_t st)
+{
+    if (n <= 0) return CVTMI_OK;
+    if (sq8_tile_ok(d, x, codes, vmin, vdiff)) {
+        Sq8Args a{};
+        a.vmin = vmin; a.vdiff = vdiff; a.x = x; a.codes = codes; a.n = n; a.d = d; a.l2norm = l2norm;
+        a.write_back = write_back;
+        return launch_sq8_tile<false>(a, st);
+    }
+    if (l2norm) {
+        if (!den_scratch) return fail(CVTMI_EINVAL, "sq8_encode: norm scratch missing");
+        CVTMI_TRY(launch_sq8_rownorm(x, n, d, den_scratch, st));
+    }
+    return launch_sq8_encode(vmin, vdiff, d, x, n, l2norm ? den_scratch : nullptr, write_back, codes, st);
+}
+
+// x = vmin + vdiff * (b + 0.5) / 255.0 in double (int8_quan.cc:126-130).  vdiff * (b + 0.5) is exact in
+// double (24 + 9 bits); the division by the constant uses RN(1/255) and two fmas (255's significand is
+// not all ones), guarded to the range where no intermediate can underflow.
+__device__ __forceinline__ float sq8_decode_one(float lo, float df, bool fast, uint32_t b)
+{
+    const double t0 = __dmul_rn((double)df, __dadd_rn((double)b, 0.5));
+    double t;
+    if (fast) {
+        const double y = 1.0 / 255.0;  // constant-folded, correctly rounded
+        const double q = __dmul_rn(t0, y);
+        const double e = __fma_rn(-255.0, q, t0);
+        t = __fma_rn(e, y, q);
+    } else {
+        t = __ddiv_rn(t0, 255.0);
+    }
+    return (float)__dadd_rn((double)lo, t);
+}
+
 __global__ __launch_bounds__(kBlock) void sq8_decode_kernel(const float *__restrict__ vmin,
                                                             const float *__restrict__ vdiff, int d,
-                                                            const uint8_t *__restrict__ codes, int64_t total,
+                                                            const uint8_t *__restrict__ codes, int64_t n,
                                                             float *__restrict__ x)
 {
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
-        const int i = (int)(e % d);
-        const double t = __ddiv_rn(__dmul_rn((double)vdiff[i], __dadd_rn((double)codes[e], 0.5)), 255.0);
-        x[e] = (float)__dadd_rn((double)vmin[i], t);
+    // d % 4 == 0 and aligned: a thread owns 4 adjacent columns (one dword of codes, one float4 out)
+    const int CG = d >> 2;
+    for (int64_t r0 = (int64_t)blockIdx.x * EW_ROWS; r0 < n; r0 += (int64_t)gridDim.x * EW_ROWS) {
+        for (int c = threadIdx.x; c < CG; c += kBlock) {
+            const float4 lo = reinterpret_cast<const float4 *>(vmin)[c];
+            const float4 df = reinterpret_cast<const float4 *>(vdiff)[c];
+            const float dfa[4] = { df.x, df.y, df.z, df.w }, loa[4] = { lo.x, lo.y, lo.z, lo.w };
+            bool fast[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float m = fabsf(dfa[u]);
+                fast[u] = (m >= 0x1p-100f && m <= 0x1p100f) || m == 0.0f;
+            }
+#pragma unroll 4
+            for (int r = 0; r < EW_ROWS; ++r) {
+                if (r0 + r >= n) break;
+                const uint32_t w = reinterpret_cast<const uint32_t *>(codes)[(r0 + r) * CG + c];
+                float4 o;
+                o.x = sq8_decode_one(loa[0], dfa[0], fast[0], w & 0xffu);
+                o.y = sq8_decode_one(loa[1], dfa[1], fast[1], (w >> 8) & 0xffu);
+                o.z = sq8_decode_one(loa[2], dfa[2], fast[2], (w >> 16) & 0xffu);
+                o.w = sq8_decode_one(loa[3], dfa[3], fast[3], w >> 24);
+                reinterpret_cast<float4 *>(x)[(r0 + r) * CG + c] = o;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void sq8_decode_any_kernel(const float *__restrict__ vmin,
+                                                                const float *__restrict__ vdiff, int d,
+                                                                const uint8_t *__restrict__ codes, int64_t n,
+                                                                float *__restrict__ x)
+{
+    for (int64_t r0 = (int64_t)blockIdx.x * EW_ROWS; r0 < n; r0 += (int64_t)gridDim.x * EW_ROWS) {
+        for (int c = threadIdx.x; c < d; c += kBlock) {
+            const float lo = vmin[c], df = vdiff[c];
+            for (int r = 0; r < EW_ROWS && r0 + r < n; ++r)
+                x[(r0 + r) * d + c] = sq8_decode_one(lo, df, false, codes[(r0 + r) * d + c]);
+        }
     }
 }
 
@@ -110,10 +404,12 @@ int launch_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_
                       hipStream_t st)
 {
     if (n <= 0) return CVTMI_OK;
-    const int64_t total = n * d;
-    int64_t blocks = (total + kBlock - 1) / kBlock;
+    int64_t blocks = (n + EW_ROWS - 1) / EW_ROWS;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(sq8_decode_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, vmin, vdiff, d, codes, total, x);
+    const bool vec = (d & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)codes & 3) == 0 &&
+                     ((uintptr_t)vmin & 15) == 0 && ((uintptr_t)vdiff & 15) == 0;
+    if (vec) hipLaunchKernelGGL(sq8_decode_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, vmin, vdiff, d, codes, n, x);
+    else hipLaunchKernelGGL(sq8_decode_any_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, vmin, vdiff, d, codes, n, x);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
@@ -160,15 +456,27 @@ __global__ void sq8_train_finish_kernel(const uint32_t *kmin, const uint32_t *km
     }
 }
 
-int launch_sq8_train(const float *x, int64_t n, int d, const float *den, uint32_t *kmin, uint32_t *kmax, float *vmin,
-                     float *vdiff, hipStream_t st)
+// den_scratch: n floats, only used for row widths the tile kernel does not take
+int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_scratch, uint32_t *kmin, uint32_t *kmax,
+                     float *vmin, float *vdiff, hipStream_t st)
 {
     const unsigned db = (unsigned)((d + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(sq8_train_init_kernel, dim3(db), dim3(kBlock), 0, st, kmin, kmax, d);
     if (n > 0) {
-        const int64_t blocks = (n + TRAIN_ROWS - 1) / TRAIN_ROWS;
-        if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "sq8_train: n too large");
-        hipLaunchKernelGGL(sq8_train_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, n, d, den, kmin, kmax);
+        if (sq8_tile_ok(d, x, nullptr, nullptr, nullptr)) {
+            Sq8Args a{};
+            a.x = const_cast<float *>(x); a.kmin = kmin; a.kmax = kmax; a.n = n; a.d = d; a.l2norm = l2norm;
+            CVTMI_TRY(launch_sq8_tile<true>(a, st));
+        } else {
+            if (l2norm) {
+                if (!den_scratch) return fail(CVTMI_EINVAL, "sq8_train: norm scratch missing");
+                CVTMI_TRY(launch_sq8_rownorm(x, n, d, den_scratch, st));
+            }
+            const int64_t blocks = (n + TRAIN_ROWS - 1) / TRAIN_ROWS;
+            if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "sq8_train: n too large");
+            hipLaunchKernelGGL(sq8_train_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, n, d,
+                               l2norm ? den_scratch : nullptr, kmin, kmax);
+        }
     }
     hipLaunchKernelGGL(sq8_train_finish_kernel, dim3(db), dim3(kBlock), 0, st, kmin, kmax, d, vmin, vdiff);
     CVTMI_HIP(hipGetLastError());

@@ -108,6 +108,39 @@ def test_sq8_parity(amd, orc, golden):
         assert np.array_equal(bits(v3), bits(o3)) and np.array_equal(bits(d3), bits(od3))
 
 
+def test_sq8_parity_hard_values(amd, orc):
+    """The fast correctly-rounded division (reciprocal + 2 fma) and its guards: signed values over 60 binades,
+    zeros of both signs, denormals, huge values, divisors with an all-ones significand, tiny and zero ranges,
+    widths on and off the single-pass kernel, row counts off the 64-row tile."""
+    rng = np.random.default_rng(88)
+    for d, n in ((512, 1000), (256, 130), (4, 65), (12, 64), (100, 333), (516, 70), (1024, 40), (7, 5)):
+        x = (rng.normal(size=(n, d)) * np.exp2(rng.integers(-30, 30, size=(n, d)))).astype(np.float32)
+        x[rng.random(size=(n, d)) < 0.3] = 0.0
+        x[rng.random(size=(n, d)) < 0.05] = -0.0
+        x[1] = 0.0                                   # zero norm: den = 1e-12
+        x[2] = np.float32(1e-30) * rng.normal(size=d).astype(np.float32)   # products underflow: tiny den
+        x[3, 0] = np.float32(3e18)                   # one huge element
+        x[4] = np.float32(1e-42)                     # denormals
+        if n > 9:
+            x[9] = 0.0; x[9, d // 2] = np.frombuffer(np.uint32(0x3fffffff).tobytes(), np.float32)[0]  # norm = 1.9999999
+        vmin, vdiff = amd.sq8_train(x, l2norm=True)
+        ovmin, ovdiff = orc.sq8_train(x, l2norm=True)
+        assert np.array_equal(bits(vmin), bits(ovmin)) and np.array_equal(bits(vdiff), bits(ovdiff)), (d, n)
+        vdiff2 = vdiff.copy()
+        vdiff2[0] = 0.0
+        vdiff2[1 % d] = np.frombuffer(np.uint32(0x3d7fffff).tobytes(), np.float32)[0]   # all-ones significand
+        vdiff2[2 % d] = np.float32(1e-41)
+        vdiff2[3 % d] = np.float32(1e30)
+        for l2 in (True, False):
+            xg = x.copy()
+            codes = amd.sq8_encode(vmin, vdiff2, xg, l2norm=l2)
+            ocodes, ox = orc.sq8_encode(vmin, vdiff2, x, l2norm=l2)
+            assert np.array_equal(bits(xg), bits(ox)), ("in-place normalisation differs", d, n, l2)
+            assert np.array_equal(codes, ocodes), (d, n, l2)
+        dec = amd.sq8_decode(vmin, vdiff2, codes)
+        assert np.array_equal(bits(dec), bits(orc.sq8_decode(vmin, vdiff2, codes))), (d, n)
+
+
 def test_sq8_device_roundtrip_full_width(amd):
     """Config 3 width (512-d) on device pointers: decode(encode(x)) lands within one bucket of x."""
     import torch
