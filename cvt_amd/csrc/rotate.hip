@@ -19,24 +19,49 @@
 
 namespace cvtmi {
 
+// y[r][i] = x[r][perm[i]] (IVFOPQ.cpp:424-439).  Pure data movement, 2 x 4D bytes per row: a thread owns VEC
+// adjacent output columns (its perm entries stay in registers), gathers inside the row -- the row's cache
+// lines are shared by the threads around it -- and writes one VEC-wide store; rows are walked grid-stride.
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void permute_kernel(const int32_t *__restrict__ perm, int D,
-                                                         const float *__restrict__ x, int64_t total,
+                                                         const float *__restrict__ x, int64_t n,
                                                          float *__restrict__ y)
 {
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
-        const int64_t r = e / D;
-        const int i = (int)(e - r * D);
-        y[e] = x[r * D + perm[i]];
+    const int CG = D / VEC;                 // column groups per row
+    const int TY = kBlock / CG;             // rows per sweep of the workgroup (CG <= kBlock, checked by the launcher)
+    const int ty = threadIdx.x / CG, tx = threadIdx.x - ty * CG;
+    if (ty >= TY) return;
+    int p[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) p[c] = perm[tx * VEC + c];
+    for (int64_t r = (int64_t)blockIdx.x * TY + ty; r < n; r += (int64_t)gridDim.x * TY) {
+        const float *xr = x + r * D;
+        float v[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) v[c] = xr[p[c]];
+        if constexpr (VEC == 4) reinterpret_cast<float4 *>(y + r * D)[tx] = make_float4(v[0], v[1], v[2], v[3]);
+        else y[r * D + tx] = v[0];
     }
+}
+
+__global__ __launch_bounds__(kBlock) void permute_wide_kernel(const int32_t *__restrict__ perm, int D,
+                                                              const float *__restrict__ x, int64_t n,
+                                                              float *__restrict__ y)
+{
+    for (int64_t r = blockIdx.x; r < n; r += gridDim.x)
+        for (int i = threadIdx.x; i < D; i += kBlock) y[r * D + i] = x[r * D + perm[i]];
 }
 
 int launch_permute(const int32_t *perm, int D, const float *x, int64_t n, float *y, hipStream_t st)
 {
     if (n <= 0) return CVTMI_OK;
-    const int64_t total = n * D;
-    int64_t blocks = (total + kBlock - 1) / kBlock;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(permute_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, perm, D, x, total, y);
+    const unsigned grid = 256 * 8;
+    if ((D & 3) == 0 && D / 4 <= kBlock && ((uintptr_t)y & 15) == 0)
+        hipLaunchKernelGGL(permute_kernel<4>, dim3(grid), dim3(kBlock), 0, st, perm, D, x, n, y);
+    else if (D <= kBlock)
+        hipLaunchKernelGGL(permute_kernel<1>, dim3(grid), dim3(kBlock), 0, st, perm, D, x, n, y);
+    else
+        hipLaunchKernelGGL(permute_wide_kernel, dim3(grid), dim3(kBlock), 0, st, perm, D, x, n, y);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
