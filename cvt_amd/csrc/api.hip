@@ -138,7 +138,7 @@ struct cvtmi_flat_s {
     DevBuf data, labels, norms;  // norms: int32 |x-128|^2 per row, uint8 metric with D % 32 == 0 (MFMA path)
     int64_t n = 0;
     bool identity = true;  // label == row
-    DevBuf s_part_d, s_part_id;
+    DevBuf s_part_d, s_part_id, s_gthr;
 };
 
 static int use_device(int dev)
@@ -674,7 +674,7 @@ int cvtmi_flat_destroy(cvtmi_flat_t h)
 {
     if (!h) return CVTMI_OK;
     (void)hipSetDevice(h->device);
-    h->data.release(); h->labels.release(); h->norms.release(); h->s_part_d.release(); h->s_part_id.release();
+    h->data.release(); h->labels.release(); h->norms.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_gthr.release();
     delete h;
     return CVTMI_OK;
 }
@@ -766,7 +766,7 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
     hipStream_t st = (hipStream_t)stream;
     const bool mfma = h->metric == CVTMI_METRIC_L2U8 && flat_u8_mfma_qtile(h->D, k, nq) > 0;
     const int qt = mfma ? flat_u8_mfma_qtile(h->D, k, nq) : flat_qtile(nq);
-    int splits = flat_plan_splits(h->n, nq, qt);
+    int splits = mfma ? flat_u8_mfma_splits(h->n, nq, qt) : flat_plan_splits(h->n, nq, qt);
     if (mfma && splits >= 8) splits = (splits / 8) * 8;  // a row split per XCD: query groups share its L2
     float *pd = reinterpret_cast<float *>(dist);
     int64_t *pi = labels;
@@ -777,9 +777,11 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
         pd = h->s_part_d.as<float>();
         pi = h->s_part_id.as<int64_t>();
     }
-    if (mfma)
+    if (mfma) {
+        CVTMI_TRY(h->s_gthr.reserve((size_t)nq * sizeof(uint32_t)));
         CVTMI_TRY(launch_flat_u8_mfma(h->D, h->data.as<uint8_t>(), h->norms.as<int32_t>(), h->n,
-                                      reinterpret_cast<const uint8_t *>(q), nq, k, splits, pd, pi, st));
+                                      reinterpret_cast<const uint8_t *>(q), nq, k, splits, pd, pi, h->s_gthr.as<uint32_t>(), st));
+    }
     else
         CVTMI_TRY(launch_flat_search(h->metric, h->D, h->data.p, h->n, q, nq, k, qt, splits, pd, pi, st));
     if (splits > 1) CVTMI_TRY(launch_topk_merge(pd, pi, nq, splits, k, reinterpret_cast<float *>(dist), labels, st));

@@ -162,17 +162,20 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__device__ __forceinline__ void wave_bitonic_sort256(unsigned long long (&e)[4])
+// ascending bitonic sort of the 64 * NR entries a wave holds in registers (entry 64 r + lane in e[r]); NR = 1, 2, 4
+template <int NR>
+__device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&e)[NR])
 {
+    static_assert(NR == 1 || NR == 2 || NR == 4, "register sort: 64, 128 or 256 entries");
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 2; k <= 256; k <<= 1) {
+    for (int k = 2; k <= 64 * NR; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j >= 1; j >>= 1) {
             if (j >= 64) {
                 const int dr = j >> 6;  // partner register r ^ dr of the same lane
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < NR; ++r) {
                     const int pr = r ^ dr;
                     if (pr > r) {
                         const bool asc = ((r * 64 + lane) & k) == 0;
@@ -184,7 +187,7 @@ __device__ __forceinline__ void wave_bitonic_sort256(unsigned long long (&e)[4])
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < NR; ++r) {
                     const unsigned long long mine = e[r];
                     const unsigned long long other = shfl_xor_u64(mine, j);
                     const bool asc = ((r * 64 + lane) & k) == 0;
@@ -197,37 +200,41 @@ __device__ __forceinline__ void wave_bitonic_sort256(unsigned long long (&e)[4])
         }
     }
 }
+__device__ __forceinline__ void wave_bitonic_sort256(unsigned long long (&e)[4]) { wave_bitonic_sort<4>(e); }
 
-// k-th smallest (k = 1..number of valid entries) of the wave's 256 register entries (4 per lane), by an MSB-first
+// k-th smallest (k = 1..number of valid entries) of the wave's 64 * NR register entries (NR per lane), by an MSB-first
 // radix select on lane masks: per bit one compare + ballot per register and scalar popcounts, no cross-lane data
 // movement, and it stops as soon as a single candidate is left (~20 of 64 bits for distinct fp32 keys).
 // Slots that hold no entry must be ~0ull.
-__device__ __forceinline__ unsigned long long wave_select256(const unsigned long long (&e)[4], int k)
+template <int NR>
+__device__ __forceinline__ unsigned long long wave_select(const unsigned long long (&e)[NR], int k)
 {
-    unsigned long long alive[4] = { ~0ull, ~0ull, ~0ull, ~0ull };  // wave-uniform lane masks
-    int kk = k, n_alive = 256;
+    unsigned long long alive[NR];  // wave-uniform lane masks
+#pragma unroll
+    for (int r = 0; r < NR; ++r) alive[r] = ~0ull;
+    int kk = k, n_alive = 64 * NR;
     unsigned long long prefix = 0;
 #pragma unroll
     for (int half = 1; half >= 0; --half) {
-        uint32_t w[4];
+        uint32_t w[NR];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = half ? (uint32_t)(e[r] >> 32) : (uint32_t)e[r];
+        for (int r = 0; r < NR; ++r) w[r] = half ? (uint32_t)(e[r] >> 32) : (uint32_t)e[r];
         for (int b = 31; b >= 0 && n_alive > 1; --b) {  // wave-uniform
             const uint32_t m = 1u << b;
-            unsigned long long z[4];
+            unsigned long long z[NR];
             int c0 = 0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < NR; ++r) {
                 z[r] = __ballot((w[r] & m) == 0) & alive[r];
                 c0 += __popcll(z[r]);
             }
             if (kk <= c0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) alive[r] = z[r];
+                for (int r = 0; r < NR; ++r) alive[r] = z[r];
                 n_alive = c0;
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) alive[r] &= ~z[r];
+                for (int r = 0; r < NR; ++r) alive[r] &= ~z[r];
                 kk -= c0;
                 n_alive -= c0;
                 prefix |= (unsigned long long)m << (half * 32);
@@ -237,7 +244,7 @@ __device__ __forceinline__ unsigned long long wave_select256(const unsigned long
     if (n_alive == 1) {  // the survivor's value (the loop may have stopped before its low bits were walked)
         unsigned long long v = 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < NR; ++r) {
             if (alive[r]) {  // wave-uniform
                 const int src = __ffsll((long long)alive[r]) - 1;
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e[r], src);
@@ -261,27 +268,29 @@ static __device__ unsigned long long g_topk_dbg[4];  // compaction rounds, fix c
 // SORTED: the kept entries are left in ascending order (needed once, for the result); otherwise they are the k
 // smallest in arbitrary order, found by selection instead of a sort (the intermediate compactions only need the
 // set and the k-th value).
-// Register slot p = 64 r + lane holds new entry ex + p for p < n - ex and exact entry p - (256 - ex) for
-// p >= 256 - ex: the entries to be fixed sit in the first registers, so fixb can skip its second batch when
+// Register slot p = 64 r + lane (NE = 64 NR slots) holds new entry ex + p for p < n - ex and exact entry
+// p - (NE - ex) for p >= NE - ex: the entries to be fixed sit in the first registers, so fixb can skip its second batch when
 // there are at most 128 of them.
 template <int QT, int CAP, bool SORTED, class FixB, class ThrX>
 __device__ __attribute__((noinline)) int topk_compact_wave_q(TopKShared<QT, CAP> &s, int q, int k, const FixB &fixb,
                                                             const ThrX &thrx)
 {
     static_assert(CAP <= 256, "register sort holds 256 entries per wave");
+    constexpr int NR = CAP <= 64 ? 1 : (CAP <= 128 ? 2 : 4);  // registers per lane
+    constexpr int NE = 64 * NR;
     const int lane = threadIdx.x & 63;
     unsigned long long *b = s.buf[q];
     int n = s.cnt[q];
     n = n < CAP ? n : CAP;
     const int ex = s.exact_n[q];
-    unsigned long long e[4];
-    bool need[4];
+    unsigned long long e[NR];
+    bool need[NR];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NR; ++r) {
         const int p = r * 64 + lane;
         need[r] = p < n - ex;
-        const bool old = p >= 256 - ex;
-        const int idx = need[r] ? ex + p : p - (256 - ex);
+        const bool old = p >= NE - ex;
+        const int idx = need[r] ? ex + p : p - (NE - ex);
         e[r] = (need[r] || old) ? b[idx] : ~0ull;
     }
 #ifdef CVTMI_SCAN_TIMING
@@ -296,26 +305,26 @@ __device__ __attribute__((noinline)) int topk_compact_wave_q(TopKShared<QT, CAP>
     const int keep = n < k ? n : k;
     uint32_t th_k;
     if constexpr (SORTED) {
-        wave_bitonic_sort256(e);
+        wave_bitonic_sort<NR>(e);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < NR; ++r) {
             const int idx = r * 64 + lane;
             if (idx < keep) b[idx] = e[r];
         }
         // k-th entry: element index k-1 lives in register (k-1)>>6 of lane (k-1)&63
         unsigned long long kth = 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < NR; ++r)
             if (((k - 1) >> 6) == r) kth = e[r];
         const uint32_t th_lane = (uint32_t)(kth >> 32);
         th_k = (uint32_t)__shfl((int)th_lane, (k - 1) & 63);
     } else {
         // n < k: everything stays (all entries are below ~0ull - 1)
-        const unsigned long long kth = n >= k ? wave_select256(e, k) : 0xfffffffffffffffeull;
+        const unsigned long long kth = n >= k ? wave_select<NR>(e, k) : 0xfffffffffffffffeull;
         th_k = (uint32_t)(kth >> 32);
         int base = 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < NR; ++r) {
             const bool in = e[r] <= kth;
             const unsigned long long m = __ballot(in);
             const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));

@@ -43,6 +43,15 @@ __device__ __forceinline__ float key_f32(uint32_t k)
 
 constexpr int kBlock = 256;  // every kernel in this library runs 256-thread (4-wave) workgroups
 
+#ifdef __HIPCC__
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load
+// (s_waitcnt vmcnt(0)), which throws away a register prefetch that is meant to stay in flight across it.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+#endif
+
 __host__ __device__ constexpr int next_pow2(int v)
 {
     int p = 1;

@@ -271,10 +271,36 @@ __global__ __launch_bounds__(kBlock) void flat_u8_norms_kernel(const uint8_t *__
     norms[row] = s;
 }
 
+// D / 16 a power of two (D = 32 ... 512): a row is read by D / 16 adjacent lanes, 16 bytes each (coalesced), and
+// folded with shuffles -- the one-thread-per-row form above walks memory at a D-byte stride (0.24 TB/s).
+__global__ __launch_bounds__(kBlock) void flat_u8_norms_coalesced_kernel(const uint8_t *__restrict__ x, int64_t n, int D,
+                                                                         int32_t *__restrict__ norms)
+{
+    const int lpr = D >> 4;  // lanes per row
+    const int64_t f = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t row = f / lpr;
+    int s = 0;
+    if (row < n) {
+        const uint4 v = reinterpret_cast<const uint4 *>(x)[f];
+        const int w[4] = { (int)(v.x ^ 0x80808080u), (int)(v.y ^ 0x80808080u), (int)(v.z ^ 0x80808080u), (int)(v.w ^ 0x80808080u) };
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s = __builtin_amdgcn_sdot4(w[c], w[c], s, false);
+    }
+    for (int o = lpr >> 1; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (row < n && (f & (lpr - 1)) == 0) norms[row] = s;
+}
+
 int launch_flat_u8_norms(const uint8_t *x, int64_t n, int D, int32_t *norms, hipStream_t st)
 {
     if (n <= 0) return CVTMI_OK;
-    hipLaunchKernelGGL(flat_u8_norms_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, x, n, D, norms);
+    const int lpr = D >> 4;
+    if (D % 32 == 0 && D <= 1024 && (lpr & (lpr - 1)) == 0 && ((uintptr_t)x & 15) == 0) {
+        const int64_t threads = n * lpr;
+        hipLaunchKernelGGL(flat_u8_norms_coalesced_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           st, x, n, D, norms);
+    } else {
+        hipLaunchKernelGGL(flat_u8_norms_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, x, n, D, norms);
+    }
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
@@ -288,6 +314,7 @@ struct FlatMfmaArgs {
     int64_t rows_per_split;
     float *part_d;
     int64_t *part_id;
+    uint32_t *gthr;  // [nq] smallest k-th-best distance any row split of the query has reached (row-tile kernel)
 };
 
 template <int QB, int CAP, int TRIG, int DMAX>
@@ -442,15 +469,267 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
 }
 
-// plan + launch of the MFMA path; returns CVTMI_EUNSUPPORTED when the shape is not covered (caller falls back)
+// ---- row-tile variant: the workgroup shares ROWS, every wave owns 32 QUERIES ----------------------------
+// The kernel above lets each wave fetch its own 32 rows straight into the MFMA operand layout: a lane reads
+// 16 bytes at a 512-byte stride, i.e. every load instruction touches 32 different cache lines for 1 KB of
+// data, and the L1/TA path -- not HBM, not the matrix cores -- sets the pace (4.9 TB/s of row traffic,
+// 6 % of the i8 MFMA peak).  Here a 32-row tile is fetched ONCE per workgroup with fully coalesced 16-byte
+// loads, parked in LDS (double-buffered, one barrier per tile) and read by all NW waves in operand layout;
+// each wave keeps its own 32 queries in registers for the whole launch (64 VGPRs at D = 512) and owns their
+// selection buffers outright, so compaction is wave-local (register radix select, block_topk.h) and needs no
+// workgroup protocol.  One pass over the rows now serves 32 * NW queries.
+struct NoFixBatch {
+    template <int NR>
+    __device__ __forceinline__ void operator()(int, unsigned long long (&)[NR], const bool (&)[NR]) const {}
+};
+
+template <int NW, int CAP, int DMAX>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW >= 4 ? NW / 4 : 1, NW >= 4 ? NW / 4 : 1)))
+void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
+{
+    constexpr int NT = 64 * NW, QT = 32 * NW;
+    constexpr int KS = DMAX / 32;
+    extern __shared__ __attribute__((aligned(16))) uint8_t rows_s[];  // [2][32][D + 16] row bytes ^ 0x80
+    __shared__ TopKShared<QT, CAP> tk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int group, split;
+    {
+        const int b = blockIdx.x;
+        if ((a.splits & 7) == 0) {  // a row split stays on one XCD: the query groups of that split share its L2
+            const int s8 = a.splits >> 3;
+            const int xcd = b & 7, i = b >> 3;
+            split = xcd + 8 * (i % s8);
+            group = i / s8;
+        } else {
+            split = b % a.splits;
+            group = b / a.splits;
+        }
+    }
+    const int D = a.D, LDR = D + 16, nks = D / 32;
+    const int lj = lane & 31, lh = lane >> 5;
+    topk_init(tk);
+
+    // this wave's 32 queries in MFMA A layout: lane (lj, lh) holds dims 32 s + 16 lh .. + 16 of query lj
+    mf_v4i qreg[KS];
+    int qq_l = 0;  // |q'|^2 of query lj (both half-waves compute it)
+    {
+        int qi = group * QT + wave * 32 + lj;
+        qi = qi < a.nq ? qi : a.nq - 1;
+        const uint8_t *qp = a.q + (int64_t)qi * D;
+        // unconditional (clamped) loads: predicated ones make hipcc wait for each before issuing the next
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qreg[s] = *reinterpret_cast<const mf_v4i *>(qp + 32 * (s < nks ? s : 0) + 16 * lh);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qreg[s] ^= (int)0x80808080;
+            if (s >= nks) qreg[s] = mf_v4i{ 0, 0, 0, 0 };
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qq_l = __builtin_amdgcn_sdot4(qreg[s][c], qreg[s][c], qq_l, false);
+        }
+        qq_l += __shfl_xor(qq_l, 32);
+    }
+    // The 16 queries this lane scores: q_e = (e & 3) + 8 (e >> 2) + 4 lh  (MFMA C layout).
+    // dist = |q'|^2 + |x'|^2 - 2<q',x'> < thr  <=>  |x'|^2 - 2<q',x'> < thr - |q'|^2: one register per query
+    // (all terms are below 2^26, so the signed compare is exact; "no threshold yet" = INT_MAX).
+    // Row splits of a query run concurrently and each would warm its own threshold up from scratch
+    // (~k (1 + ln(rows/k)) candidates per split, and handling candidates is what this kernel's time goes to).
+    // They share it instead: after a compaction a wave publishes its k-th best distance with atomicMin on
+    // gthr[query]; every PD tiles it reads the value back and filters with min(own k-th, shared k-th + 1).
+    // "+ 1": a row that ties the shared k-th may win the (distance, id) tie against rows of another split, so
+    // it must survive; every row of the final top-k is <= every published k-th, hence never dropped.
+    __shared__ int qq_s[QT];
+    __shared__ uint32_t eff_s[QT];
+    if (lane < 32) qq_s[wave * 32 + lj] = qq_l;
+    int qi_l = group * QT + wave * 32 + lj;
+    qi_l = qi_l < a.nq ? qi_l : a.nq - 1;
+    uint32_t g_l = __hip_atomic_load(&a.gthr[qi_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // shared threshold of query lj as last read 
+    int thq[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) thq[e] = 0x7fffffff;
+    __syncthreads();
+    const int64_t row_begin = (int64_t)split * a.rows_per_split;
+    int64_t row_end = row_begin + a.rows_per_split;
+    row_end = row_end < a.n ? row_end : a.n;
+    const uint32_t n_local = (uint32_t)(row_end > row_begin ? row_end - row_begin : 0);
+    const uint32_t last = n_local ? n_local - 1 : 0;
+    const uint8_t *xb = a.data + row_begin * D;
+    const int32_t *nb = a.norms + row_begin;
+    // tile loader: the 32 x D bytes of a tile are 2 D 16-byte pieces, piece f = row f / (D/16), column f % (D/16)
+    const int P16 = D >> 4, pieces = 32 * P16;
+    constexpr int LPT = (32 * (DMAX / 16) + NT - 1) / NT;  // pieces per thread
+    // (piece and row indices are clamped instead of predicated: every load is issued unconditionally, so the
+    //  compiler can keep PD tiles in flight with counted waits)
+    int pr[LPT], pc[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        int f = tid + i * NT;
+        f = f < pieces ? f : pieces - 1;
+        pr[i] = f / P16;
+        pc[i] = f - pr[i] * P16;
+    }
+    auto fetch = [&](uint32_t base, mf_v4i (&v)[LPT], int &xx) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            uint32_t row = base + pr[i];
+            row = row < last ? row : last;  // clamped, rejected at push time
+            v[i] = *reinterpret_cast<const mf_v4i *>(xb + (size_t)row * D + 16 * pc[i]);
+        }
+        uint32_t row = base + lj;
+        row = row < last ? row : last;
+        xx = nb[row];
+    };
+    auto park = [&](int buf, const mf_v4i (&v)[LPT]) {
+        uint8_t *dst = rows_s + buf * 32 * LDR;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            mf_v4i t = v[i];
+            t ^= (int)0x80808080;
+            if (tid + i * NT < pieces) *reinterpret_cast<mf_v4i *>(dst + pr[i] * LDR + 16 * pc[i]) = t;
+        }
+    };
+    const NoFixBatch nofix;
+    const IdThr idthr;
+    // Row tiles are small (32 x D bytes), HBM latency is ~2 us: PD tiles are kept in flight in a register ring
+    // (tile t sits in slot t % PD until it is parked in LDS one iteration before its turn).
+    constexpr int PD = LPT <= 4 ? 4 : 2;
+    const uint32_t n_tiles = (n_local + 31) / 32;
+    mf_v4i pf[PD][LPT];
+    int xxr[PD];
+#pragma unroll
+    for (int u = 0; u < PD; ++u) fetch(32u * u, pf[u], xxr[u]);  // rows past the split are clamped
+    if (n_tiles) park(0, pf[0]);
+    __syncthreads();
+    // The tile loop runs to a multiple of PD and has no memory-related control flow (tiles past the end are
+    // clamped duplicates whose rows are rejected at push time): with branches around the loads the compiler
+    // falls back to s_waitcnt vmcnt(0) and the ring drains every iteration.
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const uint32_t t = t0 + u;
+            const int buf = u & 1;    // PD is even: tile t lives in LDS buffer t & 1 = u & 1
+            const int xx_cur = xxr[u];
+            fetch(32u * (t + PD), pf[u], xxr[u]);  // slot u is free: tile t is in LDS (clamped past the end)
+            const uint8_t *rt = rows_s + buf * 32 * LDR + lj * LDR + 16 * lh;
+            mf_v16i acc0, acc1;  // two chains: consecutive MFMAs do not wait on each other's result
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc0[e] = 0; acc1[e] = 0; }
+#pragma unroll
+            for (int s = 0; s < KS; s += 2) {
+                if (s < nks) {
+                    const mf_v4i bv = *reinterpret_cast<const mf_v4i *>(rt + 32 * s);
+                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(qreg[s], bv, acc0, 0, 0, 0);
+                }
+                if (s + 1 < nks) {
+                    const mf_v4i bv = *reinterpret_cast<const mf_v4i *>(rt + 32 * (s + 1));
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(qreg[s + 1], bv, acc1, 0, 0, 0);
+                }
+            }
+            const uint32_t lrow = 32u * t + lj;
+            const bool valid = lrow < n_local;
+            // Candidates go straight to the wave's own buffers; a buffer is compacted only when a push finds it
+            // full (the lane keeps that candidate and offers it again afterwards with '<=': it may tie the new
+            // k-th entry and carry the smaller id).  All of it is wave-local: no workgroup protocol.
+            bool dummy = false;
+            uint32_t pend = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int part = xx_cur - 2 * (acc0[e] + acc1[e]);
+                if (valid && part < thq[e]) {
+                    const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const uint32_t key = (uint32_t)(qq_s[q] + part);  // exact, >= 0
+                    if (!topk_push<QT, CAP, CAP>(tk, q, key, (uint32_t)(row_begin + lrow), dummy)) pend |= 1u << e;
+                }
+            }
+            bool refresh = u == 0;  // consume the shared thresholds requested one ring turn ago
+            while (__any(pend != 0)) {
+                unsigned long long m = __ballot(lane < 32 && tk.cnt[wave * 32 + lj] >= CAP);
+                while (m) {
+                    const int ql = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int keep = topk_compact_wave_q<QT, CAP, false>(tk, wave * 32 + ql, a.k, nofix, idthr);
+                    if (lane == 0) tk.cnt[wave * 32 + ql] = keep;
+                }
+                if (lane < 32) {
+                    const uint32_t th = tk.thr[wave * 32 + lj];
+                    if (th != KEY_MAX && th < g_l) atomicMin(&a.gthr[qi_l], th);
+                }
+                uint32_t still = 0;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (pend & (1u << e)) {
+                        const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        const uint32_t key = (uint32_t)(qq_s[q] + xx_cur - 2 * (acc0[e] + acc1[e]));
+                        if (key <= tk.thr_x[q])
+                            if (!topk_push<QT, CAP, CAP>(tk, q, key, (uint32_t)(row_begin + lrow), dummy)) still |= 1u << e;
+                    }
+                }
+                pend = still;
+                refresh = true;
+            }
+            if (refresh) {  // wave-uniform
+                if (lane < 32) {
+                    const uint32_t own = tk.thr_x[wave * 32 + lj];
+                    const uint32_t sh = g_l == KEY_MAX ? KEY_MAX : g_l + 1u;
+                    eff_s[wave * 32 + lj] = own < sh ? own : sh;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const uint32_t th = eff_s[q];
+                    thq[e] = th == KEY_MAX ? 0x7fffffff : (int)th - qq_s[q];
+                }
+            }
+            if (u == 0) g_l = __hip_atomic_load(&a.gthr[qi_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // used at the next refresh, PD tiles on
+            park(buf ^ 1, pf[(u + 1) % PD]);
+            lds_barrier();  // next tile parked by everyone, this tile read by everyone (global prefetch stays in flight)
+        }
+    }
+    // sorted result of this wave's queries
+    for (int ql = 0; ql < 32; ++ql) {
+        const int q = wave * 32 + ql, qi = group * QT + q;
+        if (qi >= a.nq) break;  // wave-uniform
+        const int cnt = topk_compact_wave_q<QT, CAP, true>(tk, q, a.k, nofix, idthr);
+        if (lane == 0 && tk.thr[q] != KEY_MAX) atomicMin(&a.gthr[qi], tk.thr[q]);
+        const int64_t o = ((int64_t)qi * a.splits + split) * a.k;
+        for (int i = lane; i < a.k; i += 64) {
+            if (i < cnt) {
+                const unsigned long long e = tk.buf[q][i];
+                a.part_d[o + i] = __uint_as_float((uint32_t)(e >> 32));  // int32 distance bits
+                a.part_id[o + i] = (int64_t)(uint32_t)e;
+            } else {
+                a.part_d[o + i] = __uint_as_float(0x7f800000u);
+                a.part_id[o + i] = -1;
+            }
+        }
+    }
+}
+
+// Queries per workgroup of the MFMA paths, 0 = shape not covered (caller falls back to the dot4 kernel).
+// More queries per workgroup = fewer passes over the rows; what bounds it is LDS: two row tiles
+// (32 x (D + 16) bytes each) next to the selection buffers (8 * CAP bytes per query, CAP >= k + 32).
 int flat_u8_mfma_qtile(int D, int k, int64_t nq)
 {
     if (D % 32 != 0 || D > 512 || nq < 8 || k > 128) return 0;
-    return 32;  // (a 64-query variant halves the HBM passes but spills at D = 512 with two waves per SIMD)
+    // measured on 2 M x 512-d (tools/bench_flat_u8.py): the row-tile kernel wins wherever its selection buffers
+    // leave room for >= 4 waves of queries; large k falls back to one query block per workgroup
+    if (k <= 24) return nq > 128 ? 256 : (nq > 64 ? 128 : (nq > 32 ? 64 : 32));
+    if (k <= 80) return nq > 64 ? 128 : 32;
+    return 32;
+}
+
+int flat_u8_mfma_splits(int64_t n, int64_t nq, int qt)
+{
+    if (qt <= 32) return flat_plan_splits(n, nq, qt);
+    const int64_t groups = (nq + qt - 1) / qt;
+    int64_t s = (512 + groups - 1) / groups;
+    const int64_t max_by_rows = n / 8192 > 1 ? n / 8192 : 1;
+    if (s > max_by_rows) s = max_by_rows;
+    if (s >= 8) s = (s / 8) * 8;  // a row split per XCD: the query groups of a split share its L2
+    return (int)(s < 1 ? 1 : s);
 }
 
 int launch_flat_u8_mfma(int D, const uint8_t *data, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int k,
-                        int splits, float *part_d, int64_t *part_id, hipStream_t st)
+                        int splits, float *part_d, int64_t *part_id, uint32_t *gthr, hipStream_t st)
 {
     const int qt = flat_u8_mfma_qtile(D, k, nq);
     if (!qt) return fail(CVTMI_EUNSUPPORTED, "flat_u8_mfma: shape not covered");
@@ -460,19 +739,42 @@ int launch_flat_u8_mfma(int D, const uint8_t *data, const int32_t *norms, int64_
     rps = ((rps + 127) / 128) * 128;
     if (rps < 128) rps = 128;
     a.rows_per_split = rps;
-    a.part_d = part_d; a.part_id = part_id;
+    a.part_d = part_d; a.part_id = part_id; a.gthr = gthr;
     const int64_t groups = (nq + qt - 1) / qt;
     const int64_t blocks = groups * splits;
     if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "flat_u8_mfma: grid too large");
-    const size_t lds = (size_t)qt * (D + 16);
+    if (qt > 32) {
+        if (!gthr) return fail(CVTMI_EINVAL, "flat_u8_mfma: threshold scratch missing");
+        CVTMI_HIP(hipMemsetAsync(gthr, 0xff, (size_t)nq * sizeof(uint32_t), st));
+    }
+    if (qt == 32) {
+        const size_t lds = (size_t)qt * (D + 16);
 #define CVTMI_FM(QB, CAP, TRIG, DMAX)                                                                                   \
     do {                                                                                                                \
         CVTMI_HIP(hipFuncSetAttribute((const void *)flat_u8_mfma_kernel<QB, CAP, TRIG, DMAX>,                           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
         hipLaunchKernelGGL((flat_u8_mfma_kernel<QB, CAP, TRIG, DMAX>), dim3((unsigned)blocks), dim3(kBlock), lds, st, a); \
     } while (0)
-    if (D <= 128) CVTMI_FM(1, 208, 176, 128); else CVTMI_FM(1, 208, 176, 512);
+        if (D <= 128) CVTMI_FM(1, 208, 176, 128); else CVTMI_FM(1, 208, 176, 512);
 #undef CVTMI_FM
+    } else {
+        const size_t lds = (size_t)2 * 32 * (D + 16);
+#define CVTMI_RT(NW, CAP, DMAX)                                                                                         \
+    do {                                                                                                                \
+        CVTMI_HIP(hipFuncSetAttribute((const void *)flat_u8_rowtile_kernel<NW, CAP, DMAX>,                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+        hipLaunchKernelGGL((flat_u8_rowtile_kernel<NW, CAP, DMAX>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, a);  \
+    } while (0)
+        // CAP by k: k <= 24 -> 56, k <= 80 -> 112 (CAP - k >= 32: a compacted buffer takes a whole tile)
+        if (k <= 24) {
+            if (qt == 256) { if (D <= 128) CVTMI_RT(8, 56, 128); else CVTMI_RT(8, 56, 512); }
+            else if (qt == 128) { if (D <= 128) CVTMI_RT(4, 56, 128); else CVTMI_RT(4, 56, 512); }
+            else { if (D <= 128) CVTMI_RT(2, 56, 128); else CVTMI_RT(2, 56, 512); }
+        } else {  // k <= 80, 128 queries
+            if (D <= 128) CVTMI_RT(4, 112, 128); else CVTMI_RT(4, 112, 512);
+        }
+#undef CVTMI_RT
+    }
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

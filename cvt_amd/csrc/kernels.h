@@ -70,8 +70,10 @@ int launch_flat_search(int metric, int D, const void *data, int64_t n, const voi
 // uint8 L2 on the i8 matrix cores (D % 32 == 0, D <= 512, nq >= 8); norms[n] = sum (x-128)^2 per row
 int launch_flat_u8_norms(const uint8_t *x, int64_t n, int D, int32_t *norms, hipStream_t st);
 int flat_u8_mfma_qtile(int D, int k, int64_t nq);  // queries per workgroup, 0 = shape not covered
+int flat_u8_mfma_splits(int64_t n, int64_t nq, int qt);
+// gthr: nq uint32 scratch (set to 0xff.. inside) through which the row splits of a query share their k-th best
 int launch_flat_u8_mfma(int D, const uint8_t *data, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int k,
-                        int splits, float *part_d, int64_t *part_id, hipStream_t st);
+                        int splits, float *part_d, int64_t *part_id, uint32_t *gthr, hipStream_t st);
 // ids[i] = ids[i] >= 0 ? labels[ids[i]] : -1
 int launch_gather_labels(int64_t *ids, int64_t count, const int64_t *labels, hipStream_t st);
 

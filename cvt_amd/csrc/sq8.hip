@@ -121,7 +121,7 @@ __global__ __launch_bounds__(SQ_NT) void sq8_tile_kernel(const Sq8Args a)
     int64_t tile = blockIdx.x;
     if (tile < n_tiles) load_tile(tile, pf);
     for (; tile < n_tiles; tile += gridDim.x) {
-        __syncthreads();  // previous tile's readers are done
+        lds_barrier();  // previous tile's readers are done
 #pragma unroll
         for (int i = 0; i < SQ_PF; ++i) {
             const int r = ty + i * TY;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(SQ_NT) void sq8_tile_kernel(const Sq8Args a)
         }
         const int64_t tile_next = tile + gridDim.x;
         if (tile_next < n_tiles) load_tile(tile_next, pf);
-        __syncthreads();
+        lds_barrier();
         if (a.l2norm) {
             if (tid < SQ_ROWS) {  // wave 0: one lane per row, index order (int8_quan.cc:48-51)
                 const float4 *rowp = sq_tile + tid * (CG + 1);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(SQ_NT) void sq8_tile_kernel(const Sq8Args a)
                 rcp_s[tid] = dd.y;
                 ok_s[tid] = dd.ok;
             }
-            __syncthreads();
+            lds_barrier();
         }
 #pragma unroll 2
         for (int i = 0; i < SQ_PF; ++i) {

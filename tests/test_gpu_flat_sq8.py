@@ -66,6 +66,27 @@ def test_flat_seeded(amd, orc, metric, D):
     assert np.all(i5[:, 5:] == -1) and np.array_equal(i5[:, :5], orc.flat_search(metric, db[:5], q[:2], 5)[2])
 
 
+@pytest.mark.parametrize("D,nq,k", [(512, 200, 10), (512, 70, 16), (256, 100, 40), (128, 40, 48), (512, 150, 100),
+                                     (64, 300, 1), (512, 33, 5), (96, 129, 12)])
+def test_flat_u8_mfma_query_tiles(amd, orc, D, nq, k):
+    """i8 matrix-core path with 32 / 64 / 128 queries per workgroup (chosen by k and nq): bit-exact distances
+    and ids incl. duplicate rows (id tie-break) and rows sorted by decreasing distance to a query (every row
+    beats the running threshold: buffer-overflow + retry path)."""
+    rng = np.random.default_rng(D * 7 + nq)
+    n = 20000 + 3
+    db = rng.integers(0, 256, size=(n, D), dtype=np.uint8)
+    q = rng.integers(0, 256, size=(nq, D), dtype=np.uint8)
+    db[7000] = db[11]; db[15000] = db[11]; q[1] = db[11]
+    # rows 0..4999 ordered by decreasing distance to q[0]
+    dist0 = ((db[:5000].astype(np.int64) - q[0].astype(np.int64)) ** 2).sum(axis=1)
+    db[:5000] = db[:5000][np.argsort(-dist0, kind="stable")]
+    ix = amd.FlatIndex(L2U8, D); ix.add(db)
+    d, i = ix.search(q, k)
+    _, odi, oi = orc.flat_search(L2U8, db, q, k)
+    assert np.array_equal(d, odi), (D, nq, k)
+    assert np.array_equal(i, oi), (D, nq, k)
+
+
 def test_flat_full_size_u8_property(amd):
     """Config 3 shape (512-d uint8) at a size that needs row splits: self-queries come back first with
     distance 0 and the result is invariant to how the rows were appended."""
