@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--M", type=int, default=16)
     ap.add_argument("--qtile", type=int, default=0)
     ap.add_argument("--splits", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=-1, help="scan kernel variant (cvtmi.h), -1 = library default")
     ap.add_argument("--layout", choices=["auto", "rows", "queries"], default="auto")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo = debug: several ranks on one GPU")
     ap.add_argument("--cpu-sample", type=int, default=256, help="queries timed on the CPU baseline (0 = skip)")
@@ -112,6 +113,7 @@ def main():
             torch.cuda.synchronize(); t_acc += time.perf_counter() - t0  # data generation excluded
             rows_done += b - a
         ix.set_param("qtile", args.qtile); ix.set_param("splits", args.splits); ix.set_param("profile", 1)
+        if args.variant >= 0: ix.set_param("scan_variant", args.variant)
         return ix, rows_done, t_acc
 
     q = synth.sift_like(nq, D, seed=0xBEEF, device=dev)  # identical on every rank

@@ -122,7 +122,7 @@ struct cvtmi_opq_s {
     // scratch
     DevBuf s_qrot, s_part_d, s_part_id, s_probe, s_lut;
     // tuning / measurement
-    int p_splits = 0, p_qtile = 0, p_profile = 0, p_variant = 4;
+    int p_splits = 0, p_qtile = 0, p_profile = 0, p_variant = 3;
     int p_tail = 1, p_groups_a = 0, p_splits_b = 0;  // two-region scan plan: on / forced shape (tests)
     static constexpr int kEvRing = 64;
     hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};

@@ -125,7 +125,7 @@ int cvtmi_opq_query_video(cvtmi_opq_t h, const float *q, int64_t nq, int rotate,
  *   "qtile"    queries sharing one pass over the codes: 1, 2, 4 or 8 (0 = automatic)
  *   "profile"  1 = bracket the scan kernel with HIP events on its stream
  *   "scan_variant"  M = 16 kernel choice: 0 row-per-lane; 1 / 2 skewed fp32 tables (512 / 1024 threads);
- *                   3 / 4 skewed 15-bit lower-bound tables, 8 queries per pass (1024 / 512 threads; 4 = default)
+ *                   3 / 4 skewed 15-bit lower-bound tables, 8 queries per pass (1024 / 512 threads; 3 = default)
  *   "tail_split"  1 (default) = with automatic splits, the query groups of the last, partly filled round of
  *                 workgroups may be split finer than the others (variants 3 / 4); 0 = one split count for all
  *   "groups_a", "splits_b"  force that two-region shape: the first groups_a query groups use "splits" row
