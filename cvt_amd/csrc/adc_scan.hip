@@ -44,6 +44,7 @@ struct ScanArgs {
     float *part_d;
     int64_t *part_id;
     const float *lut_g;  // [nq][M][256] fp32 tables in HBM, +inf past K (adc_scan16q only)
+    const uint8_t *codes_rot;  // adc_scan16q: copy of the code rows with row r rotated left by r & 15 bytes (or null)
 };
 
 template <int M> struct CodeRow;
@@ -623,7 +624,7 @@ __device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, (cvt_s2)(__builtin_bit_cast(cvt_s2, a) - __builtin_bit_cast(cvt_s2, b)));
 }
 
-template <int NT, int R>
+template <int NT, int R, bool PREROT>
 __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArgs a)
 {
     constexpr int M = 16, QT = SQ_QT;
@@ -752,7 +753,10 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
     int64_t row_end = row_begin + my_rps;
     row_end = row_end < a.n_rows ? row_end : a.n_rows;
     const uint32_t n_local = (uint32_t)(row_end > row_begin ? row_end - row_begin : 0);
-    const char *rows_b = reinterpret_cast<const char *>(rows + row_begin);
+    // PREROT: the main loop streams the pre-rotated copy (lane l needs its row rotated by l & 15 = row & 15 bytes;
+    // doing that in registers costs 12 of the loop's ~83 VALU instructions per row, and VALU is what bounds it)
+    const char *rows_b = PREROT ? reinterpret_cast<const char *>(reinterpret_cast<const uint4 *>(a.codes_rot) + row_begin)
+                                : reinterpret_cast<const char *>(rows + row_begin);
     const uint32_t last = n_local ? n_local - 1 : 0;
     auto load_row = [&](uint32_t lrow) -> uint4 {
         const uint32_t cl = lrow < last ? lrow : last;
@@ -805,11 +809,12 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
             bool failed = false;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                uint32_t d0 = __builtin_amdgcn_alignbit(cur[r].y, cur[r].x, cr8);
-                uint32_t d1 = __builtin_amdgcn_alignbit(cur[r].z, cur[r].y, cr8);
-                uint32_t d2 = __builtin_amdgcn_alignbit(cur[r].w, cur[r].z, cr8);
-                uint32_t d3 = __builtin_amdgcn_alignbit(cur[r].x, cur[r].w, cr8);
-                {
+                uint32_t d0 = cur[r].x, d1 = cur[r].y, d2 = cur[r].z, d3 = cur[r].w;
+                if constexpr (!PREROT) {
+                    d0 = __builtin_amdgcn_alignbit(cur[r].y, cur[r].x, cr8);
+                    d1 = __builtin_amdgcn_alignbit(cur[r].z, cur[r].y, cr8);
+                    d2 = __builtin_amdgcn_alignbit(cur[r].w, cur[r].z, cr8);
+                    d3 = __builtin_amdgcn_alignbit(cur[r].x, cur[r].w, cr8);
                     const bool b0 = cq & 1;
                     const uint32_t e0 = b0 ? d1 : d0, e1 = b0 ? d2 : d1, e2 = b0 ? d3 : d2, e3 = b0 ? d0 : d3;
                     const bool b1 = cq & 2;
@@ -1020,9 +1025,37 @@ static int launch_m(const ScanArgs &a, int qt, hipStream_t st)
     return fail(CVTMI_EUNSUPPORTED, "adc_scan: qtile %d not built for M=%d", qt, M);
 }
 
+// codes_rot[r] = codes[r] rotated left by r & 15 bytes: stored byte j = code byte (j + r) & 15   (M = 16 rows)
+__global__ __launch_bounds__(kBlock) void rotate_codes_kernel(const uint4 *__restrict__ codes, uint4 *__restrict__ out,
+                                                              int64_t row0, int64_t n)
+{
+    const int64_t r = row0 + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    const uint4 v = codes[r];
+    const uint32_t c = (uint32_t)r & 15u, cr8 = (c & 3) * 8, cq = c >> 2;
+    uint32_t d0 = __builtin_amdgcn_alignbit(v.y, v.x, cr8), d1 = __builtin_amdgcn_alignbit(v.z, v.y, cr8);
+    uint32_t d2 = __builtin_amdgcn_alignbit(v.w, v.z, cr8), d3 = __builtin_amdgcn_alignbit(v.x, v.w, cr8);
+    const bool b0 = cq & 1;
+    const uint32_t e0 = b0 ? d1 : d0, e1 = b0 ? d2 : d1, e2 = b0 ? d3 : d2, e3 = b0 ? d0 : d3;
+    const bool b1 = cq & 2;
+    d0 = b1 ? e2 : e0; d1 = b1 ? e3 : e1; d2 = b1 ? e0 : e2; d3 = b1 ? e1 : e3;
+    out[r] = make_uint4(d0, d1, d2, d3);
+}
+
+int launch_rotate_codes(const uint8_t *codes, uint8_t *codes_rot, int64_t row0, int64_t n, hipStream_t st)
+{
+    if (n <= row0) return CVTMI_OK;
+    const int64_t blocks = (n - row0 + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "rotate_codes: too many rows");
+    hipLaunchKernelGGL(rotate_codes_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, reinterpret_cast<const uint4 *>(codes),
+                       reinterpret_cast<uint4 *>(codes_rot), row0, n);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
 int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, int64_t id_base, const float *q_rot,
                     int64_t nq, int k, const ScanPlan &plan, float *part_d, int64_t *part_id, float *lut_scratch,
-                    hipStream_t st)
+                    const uint8_t *codes_rot, hipStream_t st)
 {
     if (nq <= 0) return CVTMI_OK;
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "adc_scan: k=%d outside 1..128", k);
@@ -1045,7 +1078,7 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
     if (rps < tile_rows) rps = tile_rows;
     a.rows_per_split = rps;
     a.groups_a = a.groups; a.splits_b = 0; a.stride = plan.splits; a.rows_per_split_b = rps;
-    a.part_d = part_d; a.part_id = part_id; a.lut_g = lut_scratch;
+    a.part_d = part_d; a.part_id = part_id; a.lut_g = lut_scratch; a.codes_rot = codes_rot;
     if (plan.variant >= 3 && m.M == 16 && plan.qtile == 8) {
         if (!lut_scratch) return fail(CVTMI_EINVAL, "adc_scan16q: table scratch missing");
         CVTMI_TRY(launch_lut(m, q_rot, nq, nullptr, lut_scratch, st, 256));  // [nq][16][256] fp32 (+inf past K), once per query
@@ -1058,8 +1091,13 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
             blocks = (int64_t)a.groups_a * a.splits + (int64_t)(a.groups - a.groups_a) * a.splits_b;
         }
         if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "adc_scan: grid too large (%lld)", (long long)blocks);
-        if (plan.variant == 3) hipLaunchKernelGGL((adc_scan16q_kernel<1024, 1>), dim3((unsigned)blocks), dim3(1024), 0, st, a);
-        else hipLaunchKernelGGL((adc_scan16q_kernel<512, 2>), dim3((unsigned)blocks), dim3(512), 0, st, a);
+        if (codes_rot) {
+            if (plan.variant == 3) hipLaunchKernelGGL((adc_scan16q_kernel<1024, 1, true>), dim3((unsigned)blocks), dim3(1024), 0, st, a);
+            else hipLaunchKernelGGL((adc_scan16q_kernel<512, 2, true>), dim3((unsigned)blocks), dim3(512), 0, st, a);
+        } else {
+            if (plan.variant == 3) hipLaunchKernelGGL((adc_scan16q_kernel<1024, 1, false>), dim3((unsigned)blocks), dim3(1024), 0, st, a);
+            else hipLaunchKernelGGL((adc_scan16q_kernel<512, 2, false>), dim3((unsigned)blocks), dim3(512), 0, st, a);
+        }
         CVTMI_HIP(hipGetLastError());
         return CVTMI_OK;
     }

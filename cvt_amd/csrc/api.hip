@@ -110,6 +110,8 @@ struct cvtmi_opq_s {
     int32_t *d_perm = nullptr;
     // resident entries, insertion order
     DevBuf codes, lists, videos;
+    DevBuf codes_rot;     // M = 16: rows rotated by (row & 15) bytes for adc_scan16q, built lazily at search time
+    int64_t rot_n = 0;    // rows of codes_rot that are up to date
     int64_t n = 0;
     bool has_lists = false, has_videos = false;
     int64_t id_base = 0;
@@ -123,6 +125,7 @@ struct cvtmi_opq_s {
     DevBuf s_qrot, s_part_d, s_part_id, s_probe, s_lut;
     // tuning / measurement
     int p_splits = 0, p_qtile = 0, p_profile = 0, p_variant = 3;
+    int p_prerot = 1;  // adc_scan16q reads a pre-rotated copy of the code rows (+16 bytes of HBM per row)
     int p_tail = 1, p_groups_a = 0, p_splits_b = 0;  // two-region scan plan: on / forced shape (tests)
     static constexpr int kEvRing = 64;
     hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
@@ -212,7 +215,7 @@ int cvtmi_opq_destroy(cvtmi_opq_t h)
     if (h->d_books) (void)hipFree(h->d_books);
     if (h->d_R) (void)hipFree(h->d_R);
     if (h->d_perm) (void)hipFree(h->d_perm);
-    h->codes.release(); h->lists.release(); h->videos.release();
+    h->codes.release(); h->lists.release(); h->videos.release(); h->codes_rot.release();
     h->csr_codes.release(); h->csr_videos.release(); h->csr_off.release();
     h->s_qrot.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_probe.release(); h->s_lut.release();
     for (int e = 0; e < cvtmi_opq_s::kEvRing; ++e) {
@@ -376,7 +379,7 @@ int cvtmi_opq_ntotal(cvtmi_opq_t h, int64_t *n)
 int cvtmi_opq_reset(cvtmi_opq_t h)
 {
     CHECK_H(h);
-    h->n = 0; h->has_lists = false; h->has_videos = false; h->csr_valid = false;
+    h->n = 0; h->has_lists = false; h->has_videos = false; h->csr_valid = false; h->rot_n = 0;
     return CVTMI_OK;
 }
 
@@ -505,7 +508,19 @@ int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, 
         CVTMI_TRY(h->s_lut.reserve((size_t)nq * h->m.M * 256 * sizeof(float)));
         lut_scratch = h->s_lut.as<float>();
     }
-    CVTMI_TRY(launch_adc_scan(h->m, h->codes.as<uint8_t>(), h->n, h->id_base, q_rot, nq, k, plan, pd, pi, lut_scratch, st));
+    const uint8_t *codes_rot = nullptr;
+    if (plan.variant >= 3 && h->m.M == 16 && h->p_prerot) {  // the scan streams a pre-rotated copy of the rows
+        if (h->rot_n > h->n) h->rot_n = 0;
+        if (h->codes_rot.cap < (size_t)h->n * 16) {
+            CVTMI_TRY(h->codes_rot.reserve(std::max<size_t>(h->codes.cap, (size_t)h->n * 16)));
+            h->rot_n = 0;  // reserve() does not keep the old contents
+        }
+        CVTMI_TRY(launch_rotate_codes(h->codes.as<uint8_t>(), h->codes_rot.as<uint8_t>(), h->rot_n, h->n, st));
+        h->rot_n = h->n;
+        codes_rot = h->codes_rot.as<uint8_t>();
+    }
+    CVTMI_TRY(launch_adc_scan(h->m, h->codes.as<uint8_t>(), h->n, h->id_base, q_rot, nq, k, plan, pd, pi, lut_scratch,
+                              codes_rot, st));
     if (h->p_profile) {
         CVTMI_HIP(hipEventRecord(h->ev1[slot], st));
         h->ev_count++;
@@ -567,6 +582,7 @@ int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value)
     if (!h || !name) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: null");
     if (!strcmp(name, "splits")) { h->p_splits = (int)value; return CVTMI_OK; }
     if (!strcmp(name, "tail_split")) { h->p_tail = value != 0; return CVTMI_OK; }
+    if (!strcmp(name, "prerotate")) { h->p_prerot = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "groups_a")) { h->p_groups_a = (int)value; return CVTMI_OK; }
     if (!strcmp(name, "splits_b")) { h->p_splits_b = (int)value; return CVTMI_OK; }
     if (!strcmp(name, "qtile")) {

@@ -43,7 +43,10 @@ ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int 
 // lut_scratch: nq * M * K floats, needed when plan.variant >= 3 (see scan_lut_floats)
 int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, int64_t id_base, const float *q_rot,
                     int64_t nq, int k, const ScanPlan &plan, float *part_d, int64_t *part_id, float *lut_scratch,
-                    hipStream_t st);
+                    const uint8_t *codes_rot, hipStream_t st);
+// M = 16 only: codes_rot rows [row0, n) = the code rows rotated left by (row & 15) bytes, the layout adc_scan16q
+// (plan.variant >= 3) streams when codes_rot is given
+int launch_rotate_codes(const uint8_t *codes, uint8_t *codes_rot, int64_t row0, int64_t n, hipStream_t st);
 
 // ---- topk_merge.hip ----
 int launch_topk_merge(const float *in_d, const int64_t *in_id, int64_t nq, int L, int k, float *out_d, int64_t *out_id,

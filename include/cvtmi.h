@@ -126,6 +126,9 @@ int cvtmi_opq_query_video(cvtmi_opq_t h, const float *q, int64_t nq, int rotate,
  *   "profile"  1 = bracket the scan kernel with HIP events on its stream
  *   "scan_variant"  M = 16 kernel choice: 0 row-per-lane; 1 / 2 skewed fp32 tables (512 / 1024 threads);
  *                   3 / 4 skewed 15-bit lower-bound tables, 8 queries per pass (1024 / 512 threads; 3 = default)
+ *   "prerotate"   1 (default) = variants 3 / 4 stream a copy of the code rows in which row r is rotated by r & 15
+ *                 bytes (the lane skew of the conflict-free table reads), kept next to the rows: +16 bytes of HBM
+ *                 per row, 12 VALU instructions fewer per row in the VALU-bound scan loop; 0 = rotate in registers
  *   "tail_split"  1 (default) = with automatic splits, the query groups of the last, partly filled round of
  *                 workgroups may be split finer than the others (variants 3 / 4); 0 = one split count for all
  *   "groups_a", "splits_b"  force that two-region shape: the first groups_a query groups use "splits" row

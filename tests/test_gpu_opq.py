@@ -216,6 +216,22 @@ def test_two_region_scan_plan(amd, orc):
             d, i = idx.search(q, 100, rotate=False)
             assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od)), (variant, splits, ga, sb)
     idx.set_param("groups_a", 0); idx.set_param("splits_b", 0); idx.set_param("splits", 0)
+    # rows rotated in registers instead of streamed from the pre-rotated copy; appended rows extend the copy
+    for pre in (0, 1):
+        idx.set_param("prerotate", pre)
+        for variant in (4, 3):
+            idx.set_param("scan_variant", variant)
+            d, i = idx.search(q, 100, rotate=False)
+            assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od)), (pre, variant)
+    more = rng.integers(0, K, size=(777, M), dtype=np.uint8)
+    idx.add_codes(more)
+    od2, oi2 = orc.adc_search(q, books, np.concatenate([codes, more]), 100)
+    d, i = idx.search(q, 100, rotate=False)
+    assert np.array_equal(i, oi2) and np.array_equal(bits(d), bits(od2))
+    idx.reset(); idx.add_codes(more)
+    od3, oi3 = orc.adc_search(q, books, more, 100)
+    d, i = idx.search(q, 100, rotate=False)
+    assert np.array_equal(i, oi3) and np.array_equal(bits(d), bits(od3))
 
 
 def test_search_device_pointers_and_rotation(amd, orc):

@@ -19,6 +19,7 @@ ap.add_argument("--splits", default="1,8,16,32,64")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--variants", default="1,0")
 ap.add_argument("--tail", type=int, default=1)
+ap.add_argument("--prerot", type=int, default=1)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 D, M, K = 128, a.M, 256
@@ -33,6 +34,7 @@ idx.add_codes(codes)
 q = synth.sift_like(a.nq, D, seed=0xBEEF, device=dev)
 idx.set_param("profile", 1)
 idx.set_param("tail_split", a.tail)
+idx.set_param("prerotate", a.prerot)
 for var in [int(x) for x in a.variants.split(",")]:
   for qt in [int(x) for x in a.qtiles.split(",")]:
     for sp in [int(x) for x in a.splits.split(",")]:
