@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 export PYTHONUNBUFFERED=1
 cd /tmp && export TMPDIR=/tmp
-B="python $REPO/bench.py --cpu-sample 0 --recall-sample 0"
+B="python $REPO/bench.py --cpu-sample 0 --recall-sample 0 --large-rows 0"
 rm -rf /tmp/prof_stats
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o $TAG -- $B --steps 10 --warmup 3 > $OUT/stats_run.log 2>&1
 echo "stats rc=$?"
