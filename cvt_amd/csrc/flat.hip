@@ -591,7 +591,7 @@ void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
     const IdThr idthr;
     // Row tiles are small (32 x D bytes), HBM latency is ~2 us: PD tiles are kept in flight in a register ring
     // (tile t sits in slot t % PD until it is parked in LDS one iteration before its turn).
-    constexpr int PD = LPT <= 4 ? 4 : 2;
+    constexpr int PD = LPT <= 2 ? 6 : (LPT <= 4 ? 4 : 2);
     const uint32_t n_tiles = (n_local + 31) / 32;
     mf_v4i pf[PD][LPT];
     int xxr[PD];
