@@ -280,6 +280,43 @@ class FlatIndex:
         return d, i
 
 
+def kmeans(x, k, niter=0, seed=1):
+    """cvtmi_kmeans: (centroids [k][d], assign [n], iterations)."""
+    n, d = x.shape
+    it = C.c_int(0)
+    if _is_torch(x):
+        import torch
+        assert x.is_contiguous() and x.dtype == torch.float32
+        cent = torch.empty((k, d), dtype=torch.float32, device=x.device)
+        assign = torch.empty((n,), dtype=torch.int32, device=x.device)
+        _check(lib().cvtmi_kmeans_dev(_ptr(x), C.c_int64(d), C.c_int64(n), C.c_int(d), C.c_int(k), C.c_int(niter),
+                                      C.c_uint64(seed), _ptr(cent), _ptr(assign), C.byref(it), _stream()))
+        return cent, assign, it.value
+    x = _np(x, np.float32)
+    cent = np.empty((k, d), dtype=np.float32); assign = np.empty(n, dtype=np.int32)
+    _check(lib().cvtmi_kmeans(_ptr(x), C.c_int64(n), C.c_int(d), C.c_int(k), C.c_int(niter), C.c_uint64(seed),
+                              _ptr(cent), _ptr(assign), C.byref(it)))
+    return cent, assign, it.value
+
+
+def opq_train(x, coarseK, M, K, niter=0, seed=1):
+    """cvtmi_opq_train on already permuted / rotated rows: (coarse [coarseK][D], books [M][K][D/M])."""
+    n, D = x.shape
+    if _is_torch(x):
+        import torch
+        assert x.is_contiguous() and x.dtype == torch.float32
+        coarse = torch.empty((coarseK, D), dtype=torch.float32, device=x.device)
+        books = torch.empty((M, K, D // M), dtype=torch.float32, device=x.device)
+        _check(lib().cvtmi_opq_train_dev(_ptr(x), C.c_int64(n), C.c_int(D), C.c_int(coarseK), C.c_int(M), C.c_int(K),
+                                         C.c_int(niter), C.c_uint64(seed), _ptr(coarse), _ptr(books), _stream()))
+        return coarse, books
+    x = _np(x, np.float32)
+    coarse = np.empty((coarseK, D), dtype=np.float32); books = np.empty((M, K, D // M), dtype=np.float32)
+    _check(lib().cvtmi_opq_train(_ptr(x), C.c_int64(n), C.c_int(D), C.c_int(coarseK), C.c_int(M), C.c_int(K), C.c_int(niter),
+                                 C.c_uint64(seed), _ptr(coarse), _ptr(books)))
+    return coarse, books
+
+
 def sq8_train(x, l2norm=True):
     n, d = x.shape
     if _is_torch(x):

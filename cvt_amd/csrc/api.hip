@@ -898,3 +898,105 @@ int cvtmi_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_t
 }
 
 }  // extern "C"
+
+// ================================================================ codebook training ===========
+static uint64_t splitmix64(uint64_t &s)
+{
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int cvtmi_kmeans_dev(const float *x, int64_t ld, int64_t n, int d, int k, int niter, uint64_t seed, float *centroids,
+                     int32_t *assign, int *iters_done, void *stream)
+{
+    if (!x || !centroids || n < 1 || d < 1 || k < 1 || ld < d) return fail(CVTMI_EINVAL, "cvtmi_kmeans: bad arguments");
+    if (n < k) return fail(CVTMI_EINVAL, "cvtmi_kmeans: fewer rows (%lld) than centroids (%d)", (long long)n, k);
+    if (d > 512) return fail(CVTMI_EUNSUPPORTED, "cvtmi_kmeans: d=%d > 512", d);
+    hipStream_t st = (hipStream_t)stream;
+    // seeding: k distinct rows, index = splitmix64() % n, redraw on repeats (host side, k values)
+    std::vector<int64_t> rows((size_t)k);
+    {
+        std::vector<uint8_t> taken((size_t)n, 0);
+        uint64_t s = seed;
+        for (int c = 0; c < k; ++c) {
+            int64_t r;
+            do { r = (int64_t)(splitmix64(s) % (uint64_t)n); } while (taken[(size_t)r]);
+            taken[(size_t)r] = 1;
+            rows[(size_t)c] = r;
+        }
+    }
+    Tmp drows, dassign, dchanged;
+    CVTMI_TRY(drows.upload(rows.data(), (size_t)k * sizeof(int64_t)));
+    CVTMI_TRY(launch_kmeans_gather(x, ld, d, drows.as<int64_t>(), k, centroids, st));
+    int32_t *as = assign;
+    if (!as) {
+        CVTMI_TRY(dassign.alloc((size_t)n * sizeof(int32_t)));
+        as = dassign.as<int32_t>();
+    }
+    CVTMI_TRY(launch_kmeans_fill(as, n, -2, st));
+    CVTMI_TRY(dchanged.alloc(sizeof(unsigned long long)));
+    const int max_iter = niter > 0 ? niter : 100;
+    int it = 0;
+    for (;;) {
+        CVTMI_HIP(hipMemsetAsync(dchanged.p, 0, sizeof(unsigned long long), st));
+        CVTMI_TRY(launch_kmeans_assign(x, ld, n, d, centroids, k, as, dchanged.as<unsigned long long>(), st));
+        unsigned long long changed = 0;
+        CVTMI_HIP(hipMemcpyAsync(&changed, dchanged.p, sizeof changed, hipMemcpyDeviceToHost, st));
+        CVTMI_HIP(hipStreamSynchronize(st));
+        if (changed == 0 || it >= max_iter) break;
+        CVTMI_TRY(launch_kmeans_update(x, ld, n, d, as, k, centroids, st));
+        ++it;
+    }
+    if (iters_done) *iters_done = it;
+    CVTMI_HIP(hipStreamSynchronize(st));  // the temporaries die with this frame
+    return CVTMI_OK;
+}
+
+int cvtmi_kmeans(const float *x, int64_t n, int d, int k, int niter, uint64_t seed, float *centroids, int32_t *assign,
+                 int *iters_done)
+{
+    if (!x || !centroids || n < 1 || d < 1 || k < 1) return fail(CVTMI_EINVAL, "cvtmi_kmeans: bad arguments");
+    Tmp dx, dc, da;
+    CVTMI_TRY(dx.upload(x, (size_t)n * d * sizeof(float)));
+    CVTMI_TRY(dc.alloc((size_t)k * d * sizeof(float)));
+    CVTMI_TRY(da.alloc((size_t)n * sizeof(int32_t)));
+    CVTMI_TRY(cvtmi_kmeans_dev(dx.as<float>(), d, n, d, k, niter, seed, dc.as<float>(), da.as<int32_t>(), iters_done, nullptr));
+    CVTMI_HIP(hipMemcpy(centroids, dc.p, (size_t)k * d * sizeof(float), hipMemcpyDeviceToHost));
+    if (assign) CVTMI_HIP(hipMemcpy(assign, da.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_train_dev(const float *x, int64_t n, int D, int coarseK, int M, int K, int niter, uint64_t seed, float *coarse,
+                        float *books, void *stream)
+{
+    if (!x || !coarse || !books || n < 1 || D < 1 || M < 1 || M > 16 || D % M != 0 || K < 1 || K > 256 || coarseK < 1)
+        return fail(CVTMI_EINVAL, "cvtmi_opq_train: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int step = D / M;
+    Tmp assign, res;
+    CVTMI_TRY(assign.alloc((size_t)n * sizeof(int32_t)));
+    CVTMI_TRY(res.alloc((size_t)n * D * sizeof(float)));
+    CVTMI_TRY(cvtmi_kmeans_dev(x, D, n, D, coarseK, niter, seed, coarse, assign.as<int32_t>(), nullptr, stream));
+    CVTMI_TRY(launch_kmeans_residual(x, n, D, coarse, assign.as<int32_t>(), res.as<float>(), st));
+    for (int m = 0; m < M; ++m)
+        CVTMI_TRY(cvtmi_kmeans_dev(res.as<float>() + m * step, D, n, step, K, niter, seed, books + (size_t)m * K * step,
+                                   assign.as<int32_t>(), nullptr, stream));
+    CVTMI_HIP(hipStreamSynchronize(st));
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_train(const float *x, int64_t n, int D, int coarseK, int M, int K, int niter, uint64_t seed, float *coarse,
+                    float *books)
+{
+    if (!x || !coarse || !books || n < 1 || D < 1) return fail(CVTMI_EINVAL, "cvtmi_opq_train: bad arguments");
+    Tmp dx, dc, db;
+    CVTMI_TRY(dx.upload(x, (size_t)n * D * sizeof(float)));
+    CVTMI_TRY(dc.alloc((size_t)coarseK * D * sizeof(float)));
+    CVTMI_TRY(db.alloc((size_t)K * D * sizeof(float)));
+    CVTMI_TRY(cvtmi_opq_train_dev(dx.as<float>(), n, D, coarseK, M, K, niter, seed, dc.as<float>(), db.as<float>(), nullptr));
+    CVTMI_HIP(hipMemcpy(coarse, dc.p, (size_t)coarseK * D * sizeof(float), hipMemcpyDeviceToHost));
+    CVTMI_HIP(hipMemcpy(books, db.p, (size_t)K * D * sizeof(float), hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}

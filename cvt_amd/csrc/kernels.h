@@ -95,4 +95,17 @@ int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_sc
 // true when (d, pointers) take the single-pass kernel, i.e. no den_scratch is needed
 bool sq8_single_pass(int d, const void *x, const void *codes, const void *vmin, const void *vdiff);
 
+// ---- kmeans.hip (codebook training) ----
+// assign[r] = nearest of cent[k][d] (first minimum; -1 when no distance is below float(UINT_MAX)); *changed +=
+// number of rows whose assignment moved.  x rows are ld floats apart.
+int launch_kmeans_assign(const float *x, int64_t ld, int64_t n, int d, const float *cent, int k, int32_t *assign,
+                         unsigned long long *changed, hipStream_t st);
+// cent[c] = float(double sum of the rows assigned to c, ascending row order / count); empty clusters untouched
+int launch_kmeans_update(const float *x, int64_t ld, int64_t n, int d, const int32_t *assign, int k, float *cent,
+                         hipStream_t st);
+int launch_kmeans_gather(const float *x, int64_t ld, int d, const int64_t *rows, int k, float *cent, hipStream_t st);
+int launch_kmeans_fill(int32_t *p, int64_t n, int32_t v, hipStream_t st);
+int launch_kmeans_residual(const float *x, int64_t n, int d, const float *cent, const int32_t *assign, float *res,
+                           hipStream_t st);
+
 }  // namespace cvtmi

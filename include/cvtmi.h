@@ -193,6 +193,28 @@ int cvtmi_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_t
 int cvtmi_sq8_decode_dev(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n,
                          float *x, void *stream);
 
+/* ---------------------------------------------------------------- codebook training ---------- */
+/* TrainPQ::CoarseQuan / ProdQuan (opq/train_codebook/train_PQ_codebook.cpp:150-244).  The reference calls
+ * yael's kmeans(d, n, k, niter = 0, v, nt, seed = 1, redo = 1, ...), which is not vendored: PARITY UNPINNED.
+ * What runs here is a fully specified Lloyd iteration (the tests hold it bit-exact against the CPU checker):
+ * k distinct seed rows drawn with splitmix64(seed); nearest-centroid assignment with the arithmetic of
+ * IVFOPQ::Add (sequential fp32 distance, strict '<'); centroid = float(double sum in ascending row order /
+ * count), empty clusters keep their centroid; stops when a pass changes no assignment or after niter updates
+ * (niter = 0: until convergence, at most 100).  x: [n] rows, ld floats apart, d <= 512 columns used.
+ * centroids [k][d]; assign [n] may be NULL; iters_done may be NULL. */
+int cvtmi_kmeans(const float *x, int64_t n, int d, int k, int niter, uint64_t seed, float *centroids,
+                 int32_t *assign, int *iters_done);
+int cvtmi_kmeans_dev(const float *x, int64_t ld, int64_t n, int d, int k, int niter, uint64_t seed,
+                     float *centroids, int32_t *assign, int *iters_done, void *stream);
+/* TrainPQ::IFVPQ (:144-148) on already permuted rows (LoadFeatureSample :77-82): coarse k-means on the whole
+ * vectors, residuals x - coarse[assign] (:190-197), one k-means per sub-space on the residual columns
+ * (:214-233), every k-means with the same seed as in the reference.  coarse [coarseK][D], books [M][K][D/M]
+ * = the SaveCodebook / LoadModel layout (:283-287, IVFOPQ.cpp:75-95). */
+int cvtmi_opq_train(const float *x, int64_t n, int D, int coarseK, int M, int K, int niter, uint64_t seed,
+                    float *coarse, float *books);
+int cvtmi_opq_train_dev(const float *x, int64_t n, int D, int coarseK, int M, int K, int niter, uint64_t seed,
+                        float *coarse, float *books, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

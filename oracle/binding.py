@@ -191,6 +191,22 @@ class Oracle:
                                _p(vmin, C.c_float), _p(vdiff, C.c_float))
         return vmin, vdiff
 
+    def kmeans(self, x, k, niter=0, seed=1):
+        x = _f32(x); n, d = x.shape
+        cent = np.empty((k, d), np.float32); assign = np.empty(n, np.int32); it = C.c_int(0)
+        rc = self.lib.orc_kmeans(_p(x, C.c_float), C.c_int64(d), C.c_int64(n), C.c_int(d), C.c_int(k), C.c_int(niter),
+                                 C.c_uint64(seed), _p(cent, C.c_float), _p(assign, C.c_int32), C.byref(it))
+        assert rc == 0
+        return cent, assign, it.value
+
+    def opq_train(self, x, coarseK, M, K, niter=0, seed=1):
+        x = _f32(x); n, D = x.shape
+        coarse = np.empty((coarseK, D), np.float32); books = np.empty((M, K, D // M), np.float32)
+        rc = self.lib.orc_opq_train(_p(x, C.c_float), C.c_int64(n), C.c_int(D), C.c_int(coarseK), C.c_int(M), C.c_int(K),
+                                    C.c_int(niter), C.c_uint64(seed), _p(coarse, C.c_float), _p(books, C.c_float))
+        assert rc == 0
+        return coarse, books
+
     def merge_topk(self, in_d, in_id, k):
         in_d = _f32(in_d); in_id = np.ascontiguousarray(in_id, dtype=np.int64)
         nq, L, kk = in_d.shape

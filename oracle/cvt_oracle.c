@@ -486,5 +486,99 @@ ORC_API void orc_merge_topk(const float *in_d, const int64_t *in_id, int64_t nq,
     free(p);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Codebook training: TrainPQ::CoarseQuan / ProdQuan (opq/train_codebook/train_PQ_codebook.cpp:150-244).
+ * The reference delegates to yael's kmeans(d, n, k, niter = 0, v, nt, seed = 1, redo = 1, ...), a library
+ * that is not vendored: PARITY UNPINNED.  What is restated here is the structure the reference fixes --
+ * coarse k-means on the (permuted) vectors, residuals x - coarse[assign] (:190-197), one k-means per
+ * sub-space on the residual columns (:214-233) -- around a plain, fully specified Lloyd iteration:
+ *   init      k distinct rows drawn with splitmix64(seed) (index = next() % n, redraw on repeats);
+ *   assign    nearest centroid, sequential fp32 distance, strict '<' keeps the first minimum
+ *             (the arithmetic of IVFOPQ::Add, IVFOPQ.cpp:110-129);
+ *   update    centroid = float(sum_double(members, ascending row order) / count); an empty cluster keeps
+ *             its centroid;
+ *   stop      when an assignment pass changes nothing, or after max_iter updates (niter = 0 -> 100);
+ *             assignments returned are those of the last pass, made against the returned centroids
+ *             whenever the loop ended on convergence.
+ * x has leading dimension ld (floats per row), d <= ld columns are used.
+ * ---------------------------------------------------------------------------------------- */
+static uint64_t orc_splitmix64(uint64_t *s)
+{
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+ORC_API int orc_kmeans(const float *x, int64_t ld, int64_t n, int d, int k, int niter, uint64_t seed,
+                       float *cent /* [k][d] */, int32_t *assign /* [n] */, int *iters_done)
+{
+    if (n < k || k < 1 || d < 1) return -1;
+    const int max_iter = niter > 0 ? niter : 100;
+    unsigned char *taken = (unsigned char *)calloc((size_t)n, 1);
+    uint64_t st = seed;
+    for (int c = 0; c < k; ++c) {
+        int64_t r;
+        do { r = (int64_t)(orc_splitmix64(&st) % (uint64_t)n); } while (taken[r]);
+        taken[r] = 1;
+        memcpy(cent + (int64_t)c * d, x + r * ld, sizeof(float) * (size_t)d);
+    }
+    free(taken);
+    double *sum = (double *)malloc(sizeof(double) * (size_t)k * d);
+    int64_t *cnt = (int64_t *)malloc(sizeof(int64_t) * (size_t)k);
+    for (int64_t r = 0; r < n; ++r) assign[r] = -2;
+    int it = 0;
+    for (;;) {
+        int64_t changed = 0;
+        for (int64_t r = 0; r < n; ++r) {
+            float best = (float)4294967295u;
+            int32_t bi = -1;
+            for (int c = 0; c < k; ++c) {
+                float dd = sq_dist_seq(x + r * ld, cent + (int64_t)c * d, d);
+                if (dd < best) { best = dd; bi = c; }
+            }
+            if (bi != assign[r]) { ++changed; assign[r] = bi; }
+        }
+        if (changed == 0 || it >= max_iter) break;
+        memset(sum, 0, sizeof(double) * (size_t)k * d);
+        memset(cnt, 0, sizeof(int64_t) * (size_t)k);
+        for (int64_t r = 0; r < n; ++r) {
+            const int32_t c = assign[r];
+            if (c < 0) continue; /* a row no centroid claims (NaN) */
+            for (int i = 0; i < d; ++i) sum[(int64_t)c * d + i] += (double)x[r * ld + i];
+            ++cnt[c];
+        }
+        for (int c = 0; c < k; ++c)
+            if (cnt[c] > 0)
+                for (int i = 0; i < d; ++i) cent[(int64_t)c * d + i] = (float)(sum[(int64_t)c * d + i] / (double)cnt[c]);
+        ++it;
+    }
+    if (iters_done) *iters_done = it;
+    free(sum); free(cnt);
+    return 0;
+}
+
+/* TrainPQ::IFVPQ (:144-148): x is already permuted (LoadFeatureSample :77-82).  coarse [coarseK][D],
+ * books [M][K][D/M] (the SaveCodebook layout, :283-287).  Every k-means uses the same seed, as the
+ * reference passes seed = 1 to each. */
+ORC_API int orc_opq_train(const float *x, int64_t n, int D, int coarseK, int M, int K, int niter, uint64_t seed,
+                          float *coarse, float *books)
+{
+    const int step = D / M;
+    int32_t *assign = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    float *res = (float *)malloc(sizeof(float) * (size_t)n * D);
+    int rc = orc_kmeans(x, D, n, D, coarseK, niter, seed, coarse, assign, NULL);
+    if (rc == 0) {
+        for (int64_t r = 0; r < n; ++r) {
+            const int32_t c = assign[r] < 0 ? 0 : assign[r];
+            for (int i = 0; i < D; ++i) res[r * D + i] = x[r * D + i] - coarse[(int64_t)c * D + i];
+        }
+        for (int m = 0; m < M && rc == 0; ++m)
+            rc = orc_kmeans(res + m * step, D, n, step, K, niter, seed, books + (int64_t)m * K * step, assign, NULL);
+    }
+    free(assign); free(res);
+    return rc;
+}
+
 /* OpenMP-free multi-thread helper is deliberately absent: bench.py's cpu_baseline times the
  * single-thread loop (cores = 1) exactly as the reference runs it. */

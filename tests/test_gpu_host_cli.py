@@ -108,3 +108,39 @@ def test_sq8_cli(tmp_path, orc, golden):
     codes = [int(t) for t in [l for l in out.splitlines() if l.startswith("int8: ")][0].split()[1:]]
     ocodes, _ = orc.sq8_encode(ovmin, ovdiff, x[:1])
     assert codes == list(ocodes[0])
+
+
+def test_opq_train_cli(tmp_path, orc):
+    """train_PQ's main with its 8 arguments: reorder file of `long int`, raw fp32 features in, model file out.
+    The model equals the oracle's training of the permuted rows bit for bit (yael is not vendored: the
+    reference's own centroids are unpinned), carries the reference's file layout incl. its truncated reorder
+    block, and is loadable by the IVFOPQ mirror (opq_index)."""
+    assert os.path.exists(os.path.join(BIN, "opq_train")), "host CLIs not built: __graft_entry__.build()"
+    rng = np.random.default_rng(5)
+    D, M, K, coarseK, n = 32, 4, 32, 3, 2500
+    cen = rng.normal(size=(12, D)).astype(np.float32) * 2
+    x = (cen[rng.integers(0, 12, n + 100)] + 0.3 * rng.normal(size=(n + 100, D))).astype(np.float32)
+    perm = rng.permutation(D).astype(np.int64)
+    (tmp_path / "reorder.bin").write_bytes(perm.tobytes())
+    (tmp_path / "feats.bin").write_bytes(x.tobytes())
+    out = run([os.path.join(BIN, "opq_train"), str(tmp_path / "reorder.bin"), str(tmp_path / "feats.bin"), str(tmp_path),
+               str(n), str(coarseK), str(D), str(M), str(K)], cwd=str(tmp_path))
+    path = tmp_path / ("OPQ_db_%d_dim_%d_k_%d_PQ_m%d_k%d.fvecs" % (n, D, coarseK, M, K))
+    assert path.exists(), out
+    raw = path.read_bytes()
+    assert struct.unpack("4i", raw[:16]) == (D, coarseK, M, K)
+    o = 16
+    coarse = np.frombuffer(raw, np.float32, coarseK * D, o).reshape(coarseK, D); o += coarse.nbytes
+    books = np.frombuffer(raw, np.float32, K * D, o).reshape(M, K, D // M); o += books.nbytes
+    assert raw[o:] == perm.tobytes()[:4 * D] and len(raw) == o + 4 * D     # train_PQ_codebook.cpp:287
+    oc, ob = orc.opq_train(x[:n][:, perm], coarseK, M, K, 0, 1)
+    assert np.array_equal(bits(coarse), bits(oc)) and np.array_equal(bits(books), bits(ob))
+    # the file is a valid LoadModel input: index two small "videos" with it
+    proper = tmp_path / "model_int32.bin"
+    proper.write_bytes(raw[:o] + perm.astype(np.int32).tobytes())
+    v0 = tmp_path / "v0_feat.bin"; v0.write_bytes(x[:40].tobytes())
+    v1 = tmp_path / "v1_feat.bin"; v1.write_bytes(x[40:100].tobytes())
+    (tmp_path / "list.txt").write_text("%s\n%s\n" % (v0, v1))
+    (tmp_path / "idx").mkdir()
+    run([os.path.join(BIN, "opq_index"), str(proper), str(tmp_path / "list.txt"), str(tmp_path / "idx")], cwd=str(tmp_path))
+    assert any(f.startswith("OPQ_Index_db_2_dim_%d_k_%d_PQ_m%d_k%d" % (D, coarseK, M, K)) for f in os.listdir(tmp_path / "idx"))

@@ -146,3 +146,26 @@ def test_oracle_against_live_reference(orc):
     assert np.array_equal(oc[order], codes)
     oms = orc.query_video(orc.reorder(perm, q), coarse, books, 3, off, codes, vid, 3)
     assert np.array_equal(bits(oms), bits(ms))
+
+
+def test_oracle_kmeans_is_a_lloyd_fixed_point(orc):
+    """orc_kmeans (the specification of cvtmi_kmeans; yael itself is not vendored): deterministic in the seed,
+    converges to a fixed point, never increases the distortion, leaves NaN rows unassigned."""
+    rng = np.random.default_rng(3)
+    cen = rng.normal(size=(10, 6)).astype(np.float32) * 4
+    x = (cen[rng.integers(0, 10, 3000)] + 0.4 * rng.normal(size=(3000, 6))).astype(np.float32)
+    x[11] = np.nan
+    c, a, it = orc.kmeans(x, 10, 0, 1)
+    c2, a2, it2 = orc.kmeans(x, 10, 0, 1)
+    assert it == it2 and np.array_equal(a, a2) and np.array_equal(c.view(np.uint32), c2.view(np.uint32))
+    assert a[11] == -1 and it >= 1
+    ok = a >= 0
+    d = ((x[ok, None, :] - c[None]) ** 2).sum(-1)
+    assert np.array_equal(d.argmin(1), a[ok])                       # assignments are nearest-centroid
+    for j in range(10):
+        if (a == j).any():
+            assert np.allclose(c[j], x[a == j].astype(np.float64).mean(0), atol=1e-5)   # centroids are member means
+    dist = [((x[ok] - orc.kmeans(x, 10, n, 1)[0][orc.kmeans(x, 10, n, 1)[1][ok]]) ** 2).sum() for n in (1, 2, 4, 8)]
+    assert all(b <= a_ * (1 + 1e-6) for a_, b in zip(dist, dist[1:]))
+    c3, _, _ = orc.kmeans(x, 10, 0, 2)
+    assert not np.array_equal(c3, c)                                 # the seed matters
