@@ -280,6 +280,45 @@ class FlatIndex:
         return d, i
 
 
+class HnswIndex:
+    """cvtmi_hnsw_*: batched search over a graph file written by the reference's HierarchicalNSW::saveIndex."""
+    def __init__(self, index_bytes, metric, D):
+        self.h = C.c_void_p()
+        self.D = D
+        buf = np.frombuffer(index_bytes, dtype=np.uint8)
+        _check(lib().cvtmi_hnsw_load(_ptr(buf), C.c_int64(buf.size), C.c_int(metric), C.c_int(D), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().cvtmi_hnsw_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def ntotal(self):
+        lib().cvtmi_hnsw_ntotal.restype = C.c_int64
+        return int(lib().cvtmi_hnsw_ntotal(self.h))
+
+    def search(self, q, k, ef):
+        nq = q.shape[0]
+        if _is_torch(q):
+            import torch
+            assert q.is_contiguous() and q.dtype == torch.float32
+            d = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+            lab = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            _check(lib().cvtmi_hnsw_search_dev(self.h, _ptr(q), C.c_int64(nq), C.c_int(k), C.c_int(ef), _ptr(d), _ptr(lab), _stream()))
+            return d, lab
+        q = _np(q, np.float32)
+        d = np.empty((nq, k), dtype=np.float32); lab = np.empty((nq, k), dtype=np.int64)
+        _check(lib().cvtmi_hnsw_search(self.h, _ptr(q), C.c_int64(nq), C.c_int(k), C.c_int(ef), _ptr(d), _ptr(lab)))
+        return d, lab
+
+
 def kmeans(x, k, niter=0, seed=1):
     """cvtmi_kmeans: (centroids [k][d], assign [n], iterations)."""
     n, d = x.shape

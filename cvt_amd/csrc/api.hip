@@ -1000,3 +1000,155 @@ int cvtmi_opq_train(const float *x, int64_t n, int D, int coarseK, int M, int K,
     CVTMI_HIP(hipMemcpy(books, db.p, (size_t)K * D * sizeof(float), hipMemcpyDeviceToHost));
     return CVTMI_OK;
 }
+
+// ================================================================ HNSW search ==================
+struct cvtmi_hnsw_s {
+    uint32_t magic = 0x484e5357u;
+    int device = 0, metric = 0, D = 0;
+    HnswDevGraph g{};
+    DevBuf vec, links0, labels, upper_off, upper;
+    DevBuf s_vis, s_cand, s_err;
+};
+#define CHECK_HN(h) do { if (!(h) || (h)->magic != 0x484e5357u) return fail(CVTMI_EINVAL, "bad hnsw handle"); CVTMI_TRY(use_device((h)->device)); } while (0)
+
+int cvtmi_hnsw_load(const void *file, int64_t bytes, int metric, int D, cvtmi_hnsw_t *out)
+{
+    if (!file || !out || D < 1 || (metric != CVTMI_METRIC_IP && metric != CVTMI_METRIC_L2F))
+        return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: bad arguments (metric must be IP or L2F)");
+    if (bytes < 96) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: not a saveIndex file (too short)");
+    const uint8_t *f = static_cast<const uint8_t *>(file), *p = f;
+    uint64_t offsetLevel0, max_elements, cur_count, size_per, label_off, offsetData, maxM, maxM0, M, efc;
+    int32_t maxlevel; uint32_t enterpoint; double mult;
+    auto rd = [&](void *dst, size_t nb) { memcpy(dst, p, nb); p += nb; };
+    rd(&offsetLevel0, 8); rd(&max_elements, 8); rd(&cur_count, 8); rd(&size_per, 8); rd(&label_off, 8); rd(&offsetData, 8);
+    rd(&maxlevel, 4); rd(&enterpoint, 4); rd(&maxM, 8); rd(&maxM0, 8); rd(&M, 8); rd(&mult, 8); rd(&efc, 8);
+    (void)M; (void)mult; (void)efc;
+    if (size_per != 4 + 4 * maxM0 + 4 * (uint64_t)D + 8 || offsetData != 4 + 4 * maxM0 || label_off != offsetData + 4 * (uint64_t)D ||
+        offsetLevel0 != 0 || cur_count > max_elements || maxM0 > 4096 || maxM > 4096)
+        return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: header does not describe %d-d fp32 vectors (size_data_per_element=%llu)", D,
+                    (unsigned long long)size_per);
+    if ((uint64_t)bytes < 96 + max_elements * size_per) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: truncated level-0 block");
+    const int64_t n = (int64_t)cur_count;
+    const uint8_t *l0 = p;
+    p += max_elements * size_per;
+    std::vector<float> vec((size_t)n * D);
+    std::vector<uint32_t> links0((size_t)n * (maxM0 + 1));
+    std::vector<int64_t> labels((size_t)n), uoff((size_t)n, -1);
+    std::vector<uint32_t> upper;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint8_t *e = l0 + (uint64_t)i * size_per;
+        memcpy(&links0[(size_t)i * (maxM0 + 1)], e, 4 * (maxM0 + 1));
+        if (links0[(size_t)i * (maxM0 + 1)] > maxM0) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: corrupt link count");
+        memcpy(&vec[(size_t)i * D], e + offsetData, 4 * (size_t)D);
+        uint64_t lab; memcpy(&lab, e + label_off, 8);
+        labels[(size_t)i] = (int64_t)lab;
+    }
+    const uint64_t links_per = 4 * maxM + 4;
+    for (uint64_t i = 0; i < max_elements; ++i) {
+        if (p + 4 > f + bytes) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: truncated link lists");
+        uint32_t sz; memcpy(&sz, p, 4); p += 4;
+        if (sz) {
+            if (p + sz > f + bytes || sz % links_per != 0) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: corrupt link list");
+            if ((int64_t)i < n) {
+                uoff[(size_t)i] = (int64_t)upper.size();
+                upper.resize(upper.size() + sz / 4);
+                memcpy(&upper[(size_t)uoff[(size_t)i]], p, sz);
+            }
+            p += sz;
+        }
+    }
+    // every link must point inside the graph (the kernel trusts them)
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t *l = &links0[(size_t)i * (maxM0 + 1)];
+        for (uint32_t j = 1; j <= l[0]; ++j) if (l[j] >= (uint64_t)n) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: link out of range");
+    }
+    for (size_t b = 0; b + maxM < upper.size(); b += maxM + 1) {
+        if (upper[b] > maxM) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: corrupt upper link count");
+        for (uint32_t j = 1; j <= upper[b]; ++j) if (upper[b + j] >= (uint64_t)n) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: link out of range");
+    }
+    if (n > 0 && (enterpoint >= (uint64_t)n || (maxlevel > 0 && uoff[enterpoint] < 0)))
+        return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: bad entry point");
+    int dev = 0;
+    CVTMI_HIP(hipGetDevice(&dev));  // no device: fails here, there is no CPU path
+    cvtmi_hnsw_s *h = new cvtmi_hnsw_s();
+    h->device = dev; h->metric = metric; h->D = D;
+    auto up = [&](DevBuf &b, const void *src, size_t nb) -> int {
+        CVTMI_TRY(b.reserve(nb ? nb : 16));
+        if (nb) CVTMI_HIP(hipMemcpy(b.p, src, nb, hipMemcpyHostToDevice));
+        return CVTMI_OK;
+    };
+    int rc = up(h->vec, vec.data(), vec.size() * 4);
+    if (rc == CVTMI_OK) rc = up(h->links0, links0.data(), links0.size() * 4);
+    if (rc == CVTMI_OK) rc = up(h->labels, labels.data(), labels.size() * 8);
+    if (rc == CVTMI_OK) rc = up(h->upper_off, uoff.data(), uoff.size() * 8);
+    if (rc == CVTMI_OK) rc = up(h->upper, upper.data(), upper.size() * 4);
+    if (rc != CVTMI_OK) { cvtmi_hnsw_destroy(h); return rc; }
+    h->g.vec = h->vec.as<float>(); h->g.links0 = h->links0.as<uint32_t>(); h->g.labels = h->labels.as<int64_t>();
+    h->g.upper_off = h->upper_off.as<int64_t>(); h->g.upper = h->upper.as<uint32_t>();
+    h->g.n = n; h->g.D = D; h->g.maxM = (int)maxM; h->g.maxM0 = (int)maxM0; h->g.maxlevel = n > 0 ? maxlevel : 0;
+    h->g.enterpoint = enterpoint;
+    *out = h;
+    return CVTMI_OK;
+}
+
+int cvtmi_hnsw_destroy(cvtmi_hnsw_t h)
+{
+    if (!h) return CVTMI_OK;
+    CHECK_HN(h);
+    h->vec.release(); h->links0.release(); h->labels.release(); h->upper_off.release(); h->upper.release();
+    h->s_vis.release(); h->s_cand.release(); h->s_err.release();
+    h->magic = 0;
+    delete h;
+    return CVTMI_OK;
+}
+
+int64_t cvtmi_hnsw_ntotal(cvtmi_hnsw_t h) { return (h && h->magic == 0x484e5357u) ? h->g.n : -1; }
+
+int cvtmi_hnsw_search_dev(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int ef, float *dist, int64_t *labels, void *stream)
+{
+    CHECK_HN(h);
+    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search: bad arguments");
+    if (k < 1 || k > hnsw_ef_max()) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search: k=%d outside 1..%d", k, hnsw_ef_max());
+    if (ef < 1 || ef > hnsw_ef_max()) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search: ef=%d outside 1..%d", ef, hnsw_ef_max());
+    if (nq == 0) return CVTMI_OK;
+    if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search: nq too large");
+    hipStream_t st = (hipStream_t)stream;
+    int slots = 256 * 7;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) slots = prop.multiProcessorCount * 7;
+    }
+    if (slots > nq) slots = (int)nq;
+    const int64_t words = (h->g.n + 31) / 32 + 1;
+    const int efe = ef > k ? ef : k;
+    int64_t gcap = (int64_t)efe * h->g.maxM0 * 2;
+    if (gcap > h->g.n) gcap = h->g.n;
+    gcap = gcap > hnsw_lcap() ? gcap - hnsw_lcap() : 0;
+    gcap += 64;
+    CVTMI_TRY(h->s_vis.reserve((size_t)slots * words * 4));
+    CVTMI_TRY(h->s_cand.reserve((size_t)slots * gcap * 8));
+    CVTMI_TRY(h->s_err.reserve(16));
+    CVTMI_HIP(hipMemsetAsync(h->s_err.p, 0, 4, st));
+    CVTMI_TRY(launch_hnsw_search(h->g, h->metric, q, nq, k, ef, dist, labels, h->s_vis.as<uint32_t>(), h->s_cand.p, slots, words,
+                                 gcap, h->s_err.as<int>(), st));
+    int err = 0;
+    CVTMI_HIP(hipMemcpyAsync(&err, h->s_err.p, 4, hipMemcpyDeviceToHost, st));
+    CVTMI_HIP(hipStreamSynchronize(st));
+    if (err) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search: candidate queue overflow (ef=%d)", ef);
+    return CVTMI_OK;
+}
+
+int cvtmi_hnsw_search(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int ef, float *dist, int64_t *labels)
+{
+    CHECK_HN(h);
+    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search: bad arguments");
+    if (nq == 0) return CVTMI_OK;
+    Tmp dq, dd, dl;
+    CVTMI_TRY(dq.upload(q, (size_t)nq * h->D * sizeof(float)));
+    CVTMI_TRY(dd.alloc((size_t)nq * k * 4));
+    CVTMI_TRY(dl.alloc((size_t)nq * k * 8));
+    CVTMI_TRY(cvtmi_hnsw_search_dev(h, dq.as<float>(), nq, k, ef, dd.as<float>(), dl.as<int64_t>(), nullptr));
+    CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    CVTMI_HIP(hipMemcpy(labels, dl.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}

@@ -1,0 +1,260 @@
+// hnsw.hip -- batched HNSW search over a graph built and saved by the reference:
+// HierarchicalNSW::searchKnn (hnsw_sifts_retrieval/hnswlib/hnswalg.h:688-729) = greedy descent through the
+// upper levels (:692-712), searchBaseLayerST (:217-280) with ef = max(ef_, k), then the k best.
+//
+// One wave per query (the traversal is a chain of dependent gathers: latency-bound, not roofline-bound;
+// throughput comes from thousands of queries in flight).  What a wave does per expanded node:
+//   * its <= 64 level-0 neighbours are taken one per lane: visited test-and-set on a per-query bitmap in
+//     HBM, then every unvisited lane computes its neighbour's full distance in the reference's summation
+//     order (dist_f32.h), reading its 4D-byte vector with 16-byte loads;
+//   * the accept / push / pop decisions are replayed in list order, exactly as the scalar loop makes them.
+// Both queues of the reference are std::priority_queue with CompareByFirst (:78-83), so ties between equal
+// distances are decided by the binary-heap mechanics: push_heap / pop_heap of libstdc++ (__push_heap,
+// __adjust_heap) are restated literally on arrays in LDS (the candidate queue spills to HBM past LCAP).
+// With that, labels and distances are bit-identical to the reference's on the same graph, duplicates included.
+#include "dist_f32.h"
+#include "kernels.h"
+
+namespace cvtmi {
+
+constexpr int HN_EF_MAX = 1024;  // top queue: ef + 1 entries in LDS
+constexpr int HN_LCAP = 1536;    // candidate queue entries kept in LDS; the rest lives in HBM
+
+struct HnEnt { float d; uint32_t id; };
+
+// max-heap on d over an array addressed through A (get / set), n entries
+template <class A>
+__device__ __forceinline__ void hn_push_heap(A &a, int hole, HnEnt v)
+{
+    int parent = (hole - 1) / 2;
+    while (hole > 0) {
+        const HnEnt p = a.get(parent);
+        if (!(p.d < v.d)) break;
+        a.set(hole, p);
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a.set(hole, v);
+}
+template <class A>
+__device__ __forceinline__ void hn_push(A &a, int &n, float d, uint32_t id)
+{
+    HnEnt v; v.d = d; v.id = id;
+    hn_push_heap(a, n, v);
+    ++n;
+}
+template <class A>
+__device__ __forceinline__ void hn_pop(A &a, int &n)
+{
+    if (n > 1) {
+        const int len = n - 1;
+        const HnEnt value = a.get(len);
+        int hole = 0, second = 0;
+        while (second < (len - 1) / 2) {
+            second = 2 * (second + 1);
+            const HnEnt r = a.get(second), l = a.get(second - 1);
+            HnEnt pick = r;
+            if (r.d < l.d) { --second; pick = l; }
+            a.set(hole, pick);
+            hole = second;
+        }
+        if ((len & 1) == 0 && second == (len - 2) / 2) {
+            second = 2 * (second + 1);
+            a.set(hole, a.get(second - 1));
+            hole = second - 1;
+        }
+        hn_push_heap(a, hole, value);
+    }
+    --n;
+}
+
+// Every lane runs the heap code with wave-uniform values; loads broadcast, lane 0 stores.
+struct LdsArr {
+    HnEnt *p; bool w;
+    __device__ __forceinline__ HnEnt get(int i) const { return p[i]; }
+    __device__ __forceinline__ void set(int i, HnEnt v) const { if (w) p[i] = v; }
+};
+struct SplitArr {
+    HnEnt *l; HnEnt *g; bool w;
+    __device__ __forceinline__ HnEnt get(int i) const { return i < HN_LCAP ? l[i] : g[i - HN_LCAP]; }
+    __device__ __forceinline__ void set(int i, HnEnt v) const { if (w) { if (i < HN_LCAP) l[i] = v; else g[i - HN_LCAP] = v; } }
+};
+
+struct HnswArgs {
+    const float *vec;         // [n][D]
+    const uint32_t *links0;   // [n][maxM0 + 1]: count, then neighbours
+    const int64_t *labels;    // [n]
+    const int64_t *upper_off; // [n]: first word of the element's upper-level block in `upper`, -1 if none
+    const uint32_t *upper;    // per element: levels x (maxM + 1) words
+    int64_t n;
+    int D, maxM, maxM0, maxlevel;
+    uint32_t enterpoint;
+    const float *q;
+    int nq, k, ef;
+    float *out_d;
+    int64_t *out_label;
+    uint32_t *visited;        // [slots][words]
+    HnEnt *cand_g;            // [slots][gcap]
+    int64_t words, gcap;
+    int *err;
+};
+
+template <bool IP, int LANES>
+__global__ __launch_bounds__(64) void hnsw_search_kernel(const HnswArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float hn_smem[];
+    float *qs = hn_smem;                                               // D floats (padded to 16 bytes)
+    HnEnt *top_l = reinterpret_cast<HnEnt *>(hn_smem + ((a.D + 3) & ~3));
+    HnEnt *cand_l = top_l + (HN_EF_MAX + 1);
+    const int lane = threadIdx.x;
+    const bool w = lane == 0;
+    uint32_t *vis = a.visited + (int64_t)blockIdx.x * a.words;
+    const LdsArr top{ top_l, w };
+    const SplitArr cand{ cand_l, a.cand_g + (int64_t)blockIdx.x * a.gcap, w };
+    const int ef = a.ef > a.k ? a.ef : a.k;
+    const int64_t cand_cap = HN_LCAP + a.gcap;
+
+    for (int qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
+        for (int i = lane; i < a.D; i += 64) qs[i] = a.q[(int64_t)qi * a.D + i];
+        for (int64_t i = lane; i < a.words; i += 64) vis[i] = 0u;
+        for (int i = lane; i < a.k; i += 64) { a.out_d[(int64_t)qi * a.k + i] = 0.0f; a.out_label[(int64_t)qi * a.k + i] = -1; }
+        __builtin_amdgcn_s_waitcnt(0);
+        __threadfence_block();
+        if (a.n == 0) continue;
+
+        // ---- upper levels: first minimum among the neighbours that beats the current distance (:692-712) ----
+        uint32_t cur = a.enterpoint;
+        float curdist;
+        {
+            float o[1];
+            dist_f32_row<IP, LANES, 1>(a.vec + (int64_t)cur * a.D, qs, a.D, o);
+            curdist = o[0];
+        }
+        for (int level = a.maxlevel; level > 0; --level) {
+            bool changed = true;
+            while (changed) {
+                changed = false;
+                const uint32_t *ll = a.upper + a.upper_off[cur] + (int64_t)(level - 1) * (a.maxM + 1);
+                const int size = (int)ll[0];
+                for (int base = 0; base < size; base += 64) {
+                    const int j = base + lane;
+                    const bool act = j < size;
+                    const uint32_t nb = act ? ll[1 + j] : cur;
+                    float o[1];
+                    dist_f32_row<IP, LANES, 1>(a.vec + (int64_t)nb * a.D, qs, a.D, o);
+                    // the scalar loop keeps the FIRST neighbour that reaches the running minimum
+                    unsigned long long better = __ballot(act && o[0] < curdist);
+                    while (better) {
+                        const int b = __ffsll((long long)better) - 1;
+                        const float db = __shfl(o[0], b);
+                        const uint32_t ib = (uint32_t)__shfl((int)nb, b);
+                        if (db < curdist) { curdist = db; cur = ib; changed = true; }
+                        better &= better - 1;
+                        better &= __ballot(act && o[0] < curdist);
+                    }
+                }
+            }
+        }
+
+        // ---- level 0: searchBaseLayerST (:217-280) ----
+        int top_n = 0, cand_n = 0;
+        {
+            float o[1];
+            dist_f32_row<IP, LANES, 1>(a.vec + (int64_t)cur * a.D, qs, a.D, o);
+            hn_push(top, top_n, o[0], cur);
+            hn_push(cand, cand_n, -o[0], cur);
+            if (w) vis[cur >> 5] |= 1u << (cur & 31);
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+        float lower = top_l[0].d;
+        bool overflow = false;
+        while (cand_n > 0) {
+            const HnEnt c = cand.get(0);
+            if (-c.d > lower) break;
+            hn_pop(cand, cand_n);
+            const uint32_t *ll = a.links0 + (int64_t)c.id * (a.maxM0 + 1);
+            const int size = (int)ll[0];
+            for (int base = 0; base < size; base += 64) {
+                const int j = base + lane;
+                bool act = j < size;
+                const uint32_t nb = act ? ll[1 + j] : 0u;
+                if (act) {
+                    const uint32_t bit = 1u << (nb & 31);
+                    act = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;
+                }
+                float o[1] = { 0.0f };
+                if (act) dist_f32_row<IP, LANES, 1>(a.vec + (int64_t)nb * a.D, qs, a.D, o);
+                unsigned long long m = __ballot(act);
+                while (m) {  // list order
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const float d = __shfl(o[0], b);
+                    const uint32_t id = (uint32_t)__shfl((int)nb, b);
+                    if (top.get(0).d > d || top_n < ef) {
+                        if (cand_n >= cand_cap) { overflow = true; break; }
+                        hn_push(cand, cand_n, -d, id);
+                        hn_push(top, top_n, d, id);
+                        if (top_n > ef) hn_pop(top, top_n);
+                        lower = top.get(0).d;
+                    }
+                }
+                if (overflow) break;
+            }
+            if (overflow) break;
+        }
+        if (overflow) {
+            if (w) atomicExch(a.err, 1);
+            continue;
+        }
+        while (top_n > a.k) hn_pop(top, top_n);
+        // pops come out in non-increasing distance: write them back to front, then order ties by label,
+        // which is the (dist, label) order of the reference's result queue (:719-726)
+        const int m = top_n;
+        for (int i = m - 1; i >= 0; --i) {
+            const HnEnt e = top.get(0);
+            if (w) {
+                a.out_d[(int64_t)qi * a.k + i] = e.d;
+                a.out_label[(int64_t)qi * a.k + i] = a.labels[e.id];
+            }
+            hn_pop(top, top_n);
+        }
+        if (w) {
+            float *od = a.out_d + (int64_t)qi * a.k;
+            int64_t *ol = a.out_label + (int64_t)qi * a.k;
+            for (int i = 1; i < m; ++i) {
+                const float d = od[i];
+                const int64_t l = ol[i];
+                int j = i - 1;
+                while (j >= 0 && od[j] == d && ol[j] > l) { ol[j + 1] = ol[j]; --j; }
+                ol[j + 1] = l;
+            }
+        }
+    }
+}
+
+int launch_hnsw_search(const HnswDevGraph &g, int metric, const float *q, int64_t nq, int k, int ef, float *out_d,
+                       int64_t *out_label, uint32_t *visited, void *cand_scratch, int slots, int64_t words, int64_t gcap,
+                       int *err, hipStream_t st)
+{
+    if (nq <= 0) return CVTMI_OK;
+    HnswArgs a;
+    a.vec = g.vec; a.links0 = g.links0; a.labels = g.labels; a.upper_off = g.upper_off; a.upper = g.upper;
+    a.n = g.n; a.D = g.D; a.maxM = g.maxM; a.maxM0 = g.maxM0; a.maxlevel = g.maxlevel; a.enterpoint = g.enterpoint;
+    a.q = q; a.nq = (int)nq; a.k = k; a.ef = ef; a.out_d = out_d; a.out_label = out_label;
+    a.visited = visited; a.cand_g = reinterpret_cast<HnEnt *>(cand_scratch); a.words = words; a.gcap = gcap; a.err = err;
+    const size_t lds = (size_t)((g.D + 3) & ~3) * sizeof(float) + (size_t)(HN_EF_MAX + 1 + HN_LCAP) * sizeof(HnEnt);
+    const bool ip = metric == CVTMI_METRIC_IP;
+    const int lanes = (g.D % 4 != 0) ? 1 : (ip ? 4 : (g.D % 16 == 0 ? 8 : 4));
+#define CVTMI_HN(IPV, L) hipLaunchKernelGGL((hnsw_search_kernel<IPV, L>), dim3((unsigned)slots), dim3(64), lds, st, a)
+    if (ip) { if (lanes == 4) CVTMI_HN(true, 4); else CVTMI_HN(true, 1); }
+    else { if (lanes == 8) CVTMI_HN(false, 8); else if (lanes == 4) CVTMI_HN(false, 4); else CVTMI_HN(false, 1); }
+#undef CVTMI_HN
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+int hnsw_lds_bytes(int D) { return (int)(((D + 3) & ~3) * sizeof(float) + (size_t)(HN_EF_MAX + 1 + HN_LCAP) * sizeof(HnEnt)); }
+int hnsw_ef_max() { return HN_EF_MAX; }
+int hnsw_lcap() { return HN_LCAP; }
+
+}  // namespace cvtmi

@@ -108,4 +108,23 @@ int launch_kmeans_fill(int32_t *p, int64_t n, int32_t v, hipStream_t st);
 int launch_kmeans_residual(const float *x, int64_t n, int d, const float *cent, const int32_t *assign, float *res,
                            hipStream_t st);
 
+// ---- hnsw.hip ----
+struct HnswDevGraph {
+    const float *vec;          // [n][D] vectors, internal-id order
+    const uint32_t *links0;    // [n][maxM0 + 1]: count, neighbours
+    const int64_t *labels;     // [n] external labels
+    const int64_t *upper_off;  // [n] first word of the element's upper-level block, -1 if it lives on level 0 only
+    const uint32_t *upper;     // levels x (maxM + 1) words per element that has upper levels
+    int64_t n;
+    int D, maxM, maxM0, maxlevel;
+    uint32_t enterpoint;
+};
+// one wave per slot; visited: slots x words uint32; cand_scratch: slots x gcap 8-byte entries; *err set on overflow
+int launch_hnsw_search(const HnswDevGraph &g, int metric, const float *q, int64_t nq, int k, int ef, float *out_d,
+                       int64_t *out_label, uint32_t *visited, void *cand_scratch, int slots, int64_t words, int64_t gcap,
+                       int *err, hipStream_t st);
+int hnsw_lds_bytes(int D);
+int hnsw_ef_max();
+int hnsw_lcap();
+
 }  // namespace cvtmi

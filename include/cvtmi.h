@@ -54,6 +54,7 @@ typedef enum cvtmi_metric {
 
 typedef struct cvtmi_opq_s *cvtmi_opq_t;
 typedef struct cvtmi_flat_s *cvtmi_flat_t;
+typedef struct cvtmi_hnsw_s *cvtmi_hnsw_t;
 
 /* ---------------------------------------------------------------- library / device ---------- */
 int cvtmi_version(void);
@@ -214,6 +215,25 @@ int cvtmi_opq_train(const float *x, int64_t n, int D, int coarseK, int M, int K,
                     float *coarse, float *books);
 int cvtmi_opq_train_dev(const float *x, int64_t n, int D, int coarseK, int M, int K, int niter, uint64_t seed,
                         float *coarse, float *books, void *stream);
+
+/* ---------------------------------------------------------------- HNSW search ---------------- */
+/* hnswlib::HierarchicalNSW<float> (hnsw_sifts_retrieval/hnswlib/hnswalg.h), search side.
+ * cvtmi_hnsw_load  = loadIndex (:522-581): takes the bytes of a file written by the reference's saveIndex
+ *   (:491-519) for D-dimensional fp32 vectors and moves vectors, level-0 links, upper-level links and labels
+ *   to HBM.  metric: CVTMI_METRIC_IP (InnerProductSpace) or CVTMI_METRIC_L2F (L2Space).
+ * cvtmi_hnsw_search = setEf(ef) + searchKnn(query, k) (:688-729) for nq queries at once, one wave per query:
+ *   dist / labels [nq][k] in ascending (distance, label) order -- the order the reference's result queue
+ *   yields back to front --, padded with (0, -1) when the graph returns fewer than k.  Distances use the
+ *   summation order of the reference's distance functions and both priority queues replay libstdc++'s
+ *   push_heap / pop_heap (the reference compares by distance only, so heap mechanics decide ties): labels
+ *   and distances are bit-identical to the reference's on the same graph.  k, ef <= 1024.
+ * Graph construction (addPoint) is not offered here: graphs are built with the reference's tools. */
+int cvtmi_hnsw_load(const void *file, int64_t bytes, int metric, int D, cvtmi_hnsw_t *out);
+int cvtmi_hnsw_destroy(cvtmi_hnsw_t h);
+int64_t cvtmi_hnsw_ntotal(cvtmi_hnsw_t h);
+int cvtmi_hnsw_search(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int ef, float *dist, int64_t *labels);
+int cvtmi_hnsw_search_dev(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int ef, float *dist, int64_t *labels,
+                          void *stream);
 
 #ifdef __cplusplus
 }

@@ -207,6 +207,16 @@ class Oracle:
         assert rc == 0
         return coarse, books
 
+    def hnsw_search(self, index_bytes, metric, D, queries, k, ef):
+        """searchKnn over a graph file written by the reference's saveIndex; ascending (dist, label)."""
+        buf = np.frombuffer(index_bytes, dtype=np.uint8)
+        q = _f32(queries); nq = q.shape[0]
+        d = np.empty((nq, k), np.float32); lab = np.empty((nq, k), np.int64)
+        rc = self.lib.orc_hnsw_search(_p(buf, C.c_uint8), C.c_int64(buf.size), C.c_int(metric), C.c_int(D), _p(q, C.c_float),
+                                      C.c_int64(nq), C.c_int64(k), C.c_int64(ef), _p(d, C.c_float), _p(lab, C.c_int64))
+        assert rc == 0
+        return d, lab
+
     def merge_topk(self, in_d, in_id, k):
         in_d = _f32(in_d); in_id = np.ascontiguousarray(in_id, dtype=np.int64)
         nq, L, kk = in_d.shape
@@ -327,3 +337,24 @@ class RefFlat:
         fn(C.c_int(data.shape[1]), _p(data, C.c_float), _p(lab, C.c_int64), C.c_int64(data.shape[0]),
            _p(queries, C.c_float), C.c_int64(queries.shape[0]), C.c_int64(k), _p(d, C.c_float), _p(i, C.c_int64))
         return d, i
+
+
+class RefHnsw:
+    """The reference's HierarchicalNSW compiled in place (oracle/_ref/libref_hnsw.so)."""
+    def __init__(self):
+        self.lib = C.CDLL(os.path.join(_HERE, "_ref", "libref_hnsw.so"))
+
+    def build(self, metric, data, path, M=16, ef_construction=200, labels=None, max_elements=None):
+        data = _f32(data); n, D = data.shape
+        lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.int64)
+        rc = self.lib.ref_hnsw_build(C.c_int(metric), C.c_int(D), _p(data, C.c_float), _p(lab, C.c_int64), C.c_int64(n),
+                                     C.c_int64(max_elements or n), C.c_int(M), C.c_int(ef_construction), path.encode())
+        assert rc == 0
+
+    def search(self, metric, D, path, queries, k, ef):
+        q = _f32(queries); nq = q.shape[0]
+        d = np.empty((nq, k), np.float32); lab = np.empty((nq, k), np.int64)
+        rc = self.lib.ref_hnsw_search(C.c_int(metric), C.c_int(D), path.encode(), _p(q, C.c_float), C.c_int64(nq), C.c_int64(k),
+                                      C.c_int64(ef), _p(d, C.c_float), _p(lab, C.c_int64))
+        assert rc == 0
+        return d, lab

@@ -580,5 +580,169 @@ ORC_API int orc_opq_train(const float *x, int64_t n, int D, int coarseK, int M, 
     return rc;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * HNSW search over a graph saved by the reference: HierarchicalNSW::searchKnn
+ * (hnsw_sifts_retrieval/hnswlib/hnswalg.h:688-729) = greedy descent through the upper levels (:692-712),
+ * then searchBaseLayerST (:217-280) with ef = max(ef_, k), then the k best.
+ * File layout = saveIndex (:491-519): 96-byte header (size_t offsetLevel0, max_elements, cur_element_count,
+ * size_data_per_element, label_offset, offsetData; int maxlevel; unsigned enterpoint; size_t maxM, maxM0, M;
+ * double mult; size_t ef_construction), level-0 block [max_elements][size_data_per_element] =
+ * {unsigned count; unsigned link[maxM0]; vector bytes; size_t label}, then per element
+ * {unsigned linkListSize; level 1.. link lists of (maxM + 1) unsigned each}.
+ *
+ * Both queues are std::priority_queue with CompareByFirst (:78-83): ties between equal distances are
+ * decided by the binary-heap mechanics, so libstdc++'s push_heap / pop_heap are restated literally
+ * (bits/stl_heap.h: __push_heap, __adjust_heap) -- a different but valid heap would pick different
+ * duplicates.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { float d; uint32_t id; } hn_ent;
+typedef struct { hn_ent *a; int64_t n, cap; } hn_heap;  /* max-heap on d (CompareByFirst) */
+
+static void hn_push_heap(hn_ent *first, int64_t hole, int64_t top, hn_ent v)
+{
+    int64_t parent = (hole - 1) / 2;
+    while (hole > top && first[parent].d < v.d) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = v;
+}
+static void hn_push(hn_heap *h, float d, uint32_t id)
+{
+    if (h->n == h->cap) { h->cap = h->cap ? h->cap * 2 : 64; h->a = (hn_ent *)realloc(h->a, sizeof(hn_ent) * (size_t)h->cap); }
+    hn_ent v; v.d = d; v.id = id;
+    h->a[h->n] = v;
+    h->n++;
+    hn_push_heap(h->a, h->n - 1, 0, v);
+}
+static void hn_pop(hn_heap *h)
+{
+    if (h->n > 1) {
+        hn_ent *first = h->a;
+        const int64_t len = h->n - 1;
+        hn_ent value = first[len];
+        first[len] = first[0];
+        int64_t hole = 0, second = 0;
+        while (second < (len - 1) / 2) {
+            second = 2 * (second + 1);
+            if (first[second].d < first[second - 1].d) second--;
+            first[hole] = first[second];
+            hole = second;
+        }
+        if ((len & 1) == 0 && second == (len - 2) / 2) {
+            second = 2 * (second + 1);
+            first[hole] = first[second - 1];
+            hole = second - 1;
+        }
+        hn_push_heap(first, hole, 0, value);
+    }
+    h->n--;
+}
+
+typedef struct {
+    uint64_t offsetLevel0, max_elements, cur_count, size_per_elem, label_offset, offsetData;
+    int32_t maxlevel; uint32_t enterpoint;
+    uint64_t maxM, maxM0, M; double mult; uint64_t efc;
+    const uint8_t *level0;
+    const uint8_t **lists; /* per element: pointer to its upper-level link block or NULL */
+} hn_index;
+
+static int hn_parse(const uint8_t *f, int64_t bytes, hn_index *ix)
+{
+    if (bytes < 96) return -1;
+    const uint8_t *p = f;
+    memcpy(&ix->offsetLevel0, p, 8); p += 8; memcpy(&ix->max_elements, p, 8); p += 8;
+    memcpy(&ix->cur_count, p, 8); p += 8; memcpy(&ix->size_per_elem, p, 8); p += 8;
+    memcpy(&ix->label_offset, p, 8); p += 8; memcpy(&ix->offsetData, p, 8); p += 8;
+    memcpy(&ix->maxlevel, p, 4); p += 4; memcpy(&ix->enterpoint, p, 4); p += 4;
+    memcpy(&ix->maxM, p, 8); p += 8; memcpy(&ix->maxM0, p, 8); p += 8; memcpy(&ix->M, p, 8); p += 8;
+    memcpy(&ix->mult, p, 8); p += 8; memcpy(&ix->efc, p, 8); p += 8;
+    ix->level0 = p;
+    p += ix->max_elements * ix->size_per_elem;
+    ix->lists = (const uint8_t **)calloc((size_t)ix->max_elements, sizeof(uint8_t *));
+    for (uint64_t i = 0; i < ix->max_elements; ++i) {
+        if (p + 4 > f + bytes) return -1;
+        uint32_t sz; memcpy(&sz, p, 4); p += 4;
+        if (sz) { ix->lists[i] = p; p += sz; }
+    }
+    return p <= f + bytes ? 0 : -1;
+}
+
+/* metric: ORC_IP / ORC_L2F with the distance functions the reference's Space classes select for D
+ * (InnerProductSpace space_ip.h:213-222: SSE 4-lane order for D % 4 == 0 -- the AVX branches are '#if 0' in
+ * this tree --; L2Space space_l2.h:159-164).  Output ascending (dist, label), padded with (0, -1). */
+ORC_API int orc_hnsw_search(const uint8_t *file, int64_t bytes, int metric, int D, const float *queries, int64_t nq,
+                            int64_t k, int64_t ef_param, float *out_d, int64_t *out_label)
+{
+    hn_index ix;
+    if (hn_parse(file, bytes, &ix) != 0) return -1;
+    const int flavour = 4;
+    const uint64_t links_per = ix.maxM * 4 + 4;
+    uint8_t *visited = (uint8_t *)malloc((size_t)ix.max_elements);
+    hn_heap top = { NULL, 0, 0 }, cand = { NULL, 0, 0 };
+    orc_pair *res = (orc_pair *)malloc(sizeof(orc_pair) * (size_t)(k > 0 ? k : 1));
+#define HN_VEC(i) ((const void *)(ix.level0 + (uint64_t)(i) * ix.size_per_elem + ix.offsetData))
+    for (int64_t qi = 0; qi < nq; ++qi) {
+        const float *q = queries + qi * D;
+        for (int64_t i = 0; i < k; ++i) { out_d[qi * k + i] = 0.0f; out_label[qi * k + i] = -1; }
+        if (ix.cur_count == 0) continue;
+        uint32_t cur = ix.enterpoint;
+        float curdist = orc_dist(metric, flavour, q, HN_VEC(cur), D);
+        for (int level = ix.maxlevel; level > 0; --level) {
+            int changed = 1;
+            while (changed) {
+                changed = 0;
+                const uint8_t *ll = ix.lists[cur] + (uint64_t)(level - 1) * links_per;
+                uint32_t size; memcpy(&size, ll, 4);
+                for (uint32_t i = 0; i < size; ++i) {
+                    uint32_t c; memcpy(&c, ll + 4 + 4 * (uint64_t)i, 4);
+                    const float d = orc_dist(metric, flavour, q, HN_VEC(c), D);
+                    if (d < curdist) { curdist = d; cur = c; changed = 1; }
+                }
+            }
+        }
+        const int64_t ef = ef_param > k ? ef_param : k;
+        memset(visited, 0, (size_t)ix.max_elements);
+        top.n = 0; cand.n = 0;
+        float dist = orc_dist(metric, flavour, q, HN_VEC(cur), D);
+        hn_push(&top, dist, cur);
+        hn_push(&cand, -dist, cur);
+        visited[cur] = 1;
+        float lower = dist;
+        while (cand.n) {
+            const hn_ent c = cand.a[0];
+            if (-c.d > lower) break;
+            hn_pop(&cand);
+            const uint8_t *ll = ix.level0 + (uint64_t)c.id * ix.size_per_elem + ix.offsetLevel0;
+            uint32_t size; memcpy(&size, ll, 4);
+            for (uint32_t j = 1; j <= size; ++j) {
+                uint32_t nb; memcpy(&nb, ll + 4 * (uint64_t)j, 4);
+                if (visited[nb]) continue;
+                visited[nb] = 1;
+                const float d = orc_dist(metric, flavour, q, HN_VEC(nb), D);
+                if (top.a[0].d > d || top.n < ef) {
+                    hn_push(&cand, -d, nb);
+                    hn_push(&top, d, nb);
+                    if (top.n > ef) hn_pop(&top);
+                    lower = top.a[0].d;
+                }
+            }
+        }
+        while (top.n > k) hn_pop(&top);
+        int64_t m = 0;
+        while (top.n > 0) {
+            uint64_t lab; memcpy(&lab, ix.level0 + (uint64_t)top.a[0].id * ix.size_per_elem + ix.label_offset, 8);
+            res[m].d = top.a[0].d; res[m].id = (int64_t)lab; ++m;
+            hn_pop(&top);
+        }
+        qsort(res, (size_t)m, sizeof(orc_pair), pair_cmp_qsort);  /* the (dist, label) order of `results` (:719-726) */
+        for (int64_t i = 0; i < m; ++i) { out_d[qi * k + i] = res[i].d; out_label[qi * k + i] = res[i].id; }
+    }
+#undef HN_VEC
+    free(visited); free(top.a); free(cand.a); free(res); free((void *)ix.lists);
+    return 0;
+}
+
 /* OpenMP-free multi-thread helper is deliberately absent: bench.py's cpu_baseline times the
  * single-thread loop (cores = 1) exactly as the reference runs it. */

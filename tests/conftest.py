@@ -41,6 +41,7 @@ class Golden:
             self.opq[tag]["queries"] = np.fromfile(os.path.join(g, "opq_data", "query", f), dtype=np.float32).reshape(-1, 128)
         self.flat = dict(np.load(os.path.join(g, "flat_golden.npz")))
         self.sq8 = dict(np.load(os.path.join(g, "sq8_inputs.npz")))
+        self.hnsw = dict(np.load(os.path.join(g, "hnsw_golden.npz")))
 
     def video_of_row(self, case):
         rows = self.opq[case]["video_rows"]

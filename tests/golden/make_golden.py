@@ -208,6 +208,36 @@ def main():
                       0.0, 0.0, 0.0, 0.0, 2.5779805, 0.0, 0.0, 0.7728174, 0.0, 2.21898, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
                       0.0, 0.0], dtype=np.float32)  # int8_quan_test.cpp:26 (input vector, data)
     np.savez_compressed(os.path.join(OUT, "sq8_inputs.npz"), int8_quan_test_x=sq_in)
+    # HNSW: graphs BUILT AND SAVED by the reference's HierarchicalNSW (oracle/_ref/libref_hnsw.so =
+    # hnswalg.h compiled in place), queries answered by its own searchKnn.  The saved index files are data the
+    # reference wrote, committed as fixtures; the C restatement must reproduce every answer bit for bit.
+    import tempfile
+    rh = ob.RefHnsw()
+    hn = {}
+    cases = (("ip32", ob.IP, 32, 2500, 8, 40, (10, 50), True), ("l2f16", ob.L2F, 16, 2000, 6, 30, (5, 10), False),
+             ("ip20", ob.IP, 20, 1500, 8, 40, (7, 200), True), ("l2f7", ob.L2F, 7, 800, 4, 20, (3, 30), False),
+             ("ip128", ob.IP, 128, 1200, 16, 80, (5, 1000), True))
+    for name, metric, D, n, M, efc, (k, ef), norm in cases:
+        x = rng.normal(size=(n, D)).astype(np.float32)
+        if norm:
+            x = unit(x)
+        x[100] = x[7]; x[101] = x[7]; x[500] = x[7]      # exact duplicates: equal distances, heap order decides
+        labels = (np.arange(n, dtype=np.int64) * 3 + 11) if name == "ip20" else None
+        q = rng.normal(size=(48, D)).astype(np.float32)
+        if norm:
+            q = unit(q)
+        q[0] = x[7]
+        path = os.path.join(tempfile.gettempdir(), "cvt_golden_%s.hnsw" % name)
+        rh.build(metric, x, path, M, efc, labels=labels)
+        rd, rl = rh.search(metric, D, path, q, k, ef)
+        blob = np.fromfile(path, dtype=np.uint8)
+        od, ol = orc.hnsw_search(blob.tobytes(), metric, D, q, k, ef)
+        assert np.array_equal(rl, ol) and np.array_equal(rd.view(np.uint32), od.view(np.uint32)), name
+        hn[name + "_index"] = blob; hn[name + "_q"] = q; hn[name + "_d"] = rd; hn[name + "_l"] = rl
+        hn[name + "_meta"] = np.array([metric, D, n, M, efc, k, ef], dtype=np.int64)
+        os.remove(path)
+    np.savez_compressed(os.path.join(OUT, "hnsw_golden.npz"), **hn)
+    print("  HNSW x%d (reference-built graphs, reference answers)  OK" % len(cases))
     print("wrote", OUT)
 
 

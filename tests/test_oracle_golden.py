@@ -169,3 +169,20 @@ def test_oracle_kmeans_is_a_lloyd_fixed_point(orc):
     assert all(b <= a_ * (1 + 1e-6) for a_, b in zip(dist, dist[1:]))
     c3, _, _ = orc.kmeans(x, 10, 0, 2)
     assert not np.array_equal(c3, c)                                 # the seed matters
+
+
+HNSW_CASES = ["ip32", "l2f16", "ip20", "l2f7", "ip128"]
+
+
+@pytest.mark.parametrize("case", HNSW_CASES)
+def test_oracle_hnsw_search_matches_reference(orc, golden, case):
+    """orc_hnsw_search on graph files written by the reference's saveIndex == the reference's own searchKnn
+    answers (labels and distance bits), duplicates / custom labels / ef < k included."""
+    g = golden.hnsw
+    metric, D, n, M, efc, k, ef = (int(v) for v in g[case + "_meta"])
+    d, lab = orc.hnsw_search(g[case + "_index"].tobytes(), metric, D, g[case + "_q"], k, ef)
+    assert np.array_equal(lab, g[case + "_l"])
+    assert np.array_equal(d.view(np.uint32), g[case + "_d"].view(np.uint32))
+    # a different ef / k still runs and returns sorted (dist, label) lists
+    d2, lab2 = orc.hnsw_search(g[case + "_index"].tobytes(), metric, D, g[case + "_q"], 3, 5)
+    assert np.all(d2[:, 1:] >= d2[:, :-1])
