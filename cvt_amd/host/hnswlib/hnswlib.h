@@ -47,3 +47,4 @@ template <typename MTYPE> static MTYPE device_only_dist(const void *, const void
 #include "space_ip.h"
 #include "space_l2.h"
 #include "bruteforce.h"
+#include "hnswalg.h"

@@ -144,3 +144,22 @@ def test_opq_train_cli(tmp_path, orc):
     (tmp_path / "idx").mkdir()
     run([os.path.join(BIN, "opq_index"), str(proper), str(tmp_path / "list.txt"), str(tmp_path / "idx")], cwd=str(tmp_path))
     assert any(f.startswith("OPQ_Index_db_2_dim_%d_k_%d_PQ_m%d_k%d" % (D, coarseK, M, K)) for f in os.listdir(tmp_path / "idx"))
+
+
+def test_hnsw_search_cli(tmp_path, golden):
+    """hnswlib::HierarchicalNSW mirror (loadIndex + setEf + searchKnnBatch) through its CLI, on a graph file the
+    reference wrote: labels and distances of every query equal the reference's own answers."""
+    assert os.path.exists(os.path.join(BIN, "hnsw_search")), "host CLIs not built: __graft_entry__.build()"
+    g = golden.hnsw
+    for case, space in (("ip32", "ip"), ("l2f16", "l2")):
+        metric, D, n, M, efc, k, ef = (int(v) for v in g[case + "_meta"])
+        idx = tmp_path / (case + ".hnsw"); idx.write_bytes(g[case + "_index"].tobytes())
+        qf = tmp_path / (case + "_q.bin"); qf.write_bytes(np.ascontiguousarray(g[case + "_q"], np.float32).tobytes())
+        out = tmp_path / (case + "_out.txt")
+        run([os.path.join(BIN, "hnsw_search"), str(idx), str(qf), str(D), str(k), str(ef), str(out), space], cwd=str(tmp_path))
+        lines = out.read_text().splitlines()
+        assert len(lines) == g[case + "_q"].shape[0]
+        for qi, line in enumerate(lines):
+            pairs = [p.split(":") for p in line.split()]
+            assert [int(p[0]) for p in pairs] == list(g[case + "_l"][qi])
+            assert np.array_equal(np.array([float(p[1]) for p in pairs], np.float32).view(np.uint32), g[case + "_d"][qi].view(np.uint32))
