@@ -318,6 +318,23 @@ class HnswIndex:
         _check(lib().cvtmi_hnsw_search(self.h, _ptr(q), C.c_int64(nq), C.c_int(k), C.c_int(ef), _ptr(d), _ptr(lab)))
         return d, lab
 
+    def search_adc(self, opq, q, k, ef, rotate=True):
+        """Same graph, distances = ADC over the PQ codes held by the OpqIndex `opq` (one row per node)."""
+        nq = q.shape[0]
+        if _is_torch(q):
+            import torch
+            assert q.is_contiguous() and q.dtype == torch.float32
+            d = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+            lab = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            _check(lib().cvtmi_hnsw_search_adc_dev(self.h, opq.h, _ptr(q), C.c_int64(nq), C.c_int(int(rotate)), C.c_int(k), C.c_int(ef),
+                                                   _ptr(d), _ptr(lab), _stream()))
+            return d, lab
+        q = _np(q, np.float32)
+        d = np.empty((nq, k), dtype=np.float32); lab = np.empty((nq, k), dtype=np.int64)
+        _check(lib().cvtmi_hnsw_search_adc(self.h, opq.h, _ptr(q), C.c_int64(nq), C.c_int(int(rotate)), C.c_int(k), C.c_int(ef),
+                                           _ptr(d), _ptr(lab)))
+        return d, lab
+
 
 def kmeans(x, k, niter=0, seed=1):
     """cvtmi_kmeans: (centroids [k][d], assign [n], iterations)."""

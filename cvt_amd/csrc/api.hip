@@ -1152,3 +1152,70 @@ int cvtmi_hnsw_search(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int ef,
     CVTMI_HIP(hipMemcpy(labels, dl.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
     return CVTMI_OK;
 }
+
+// HNSW over OPQ-compressed vectors: the graph of `h`, distances = ADC over the codes held by `opq` (one code
+// row per graph node, appended in internal-id order).  Queries are rotated and their tables built by the OPQ
+// handle's own kernels (cvtmi_opq_rotate_dev, lut_kernel).
+int cvtmi_hnsw_search_adc_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef, float *dist,
+                              int64_t *labels, void *stream)
+{
+    CHECK_HN(h);
+    if (!opq) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: null OPQ handle");
+    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: bad arguments");
+    if (opq->m.coarseK != 1) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search_adc: needs an OPQ model with coarseK == 1");
+    if (opq->m.D != h->D) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: OPQ model is %d-d, graph is %d-d", opq->m.D, h->D);
+    if (opq->n != h->g.n) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: %lld code rows for %lld graph nodes", (long long)opq->n,
+                                      (long long)h->g.n);
+    if (opq->device != h->device) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: handles live on different devices");
+    if (k < 1 || k > hnsw_ef_max()) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search_adc: k=%d outside 1..%d", k, hnsw_ef_max());
+    if (ef < 1 || ef > hnsw_ef_max()) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search_adc: ef=%d outside 1..%d", ef, hnsw_ef_max());
+    if (nq == 0) return CVTMI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const float *q_rot = q;
+    if (rotate && (opq->m.perm || opq->m.R)) {
+        CVTMI_TRY(opq->s_qrot.reserve((size_t)nq * opq->m.D * sizeof(float)));
+        CVTMI_TRY(cvtmi_opq_rotate_dev(opq, q, nq, opq->s_qrot.as<float>(), stream));
+        q_rot = opq->s_qrot.as<float>();
+    }
+    CVTMI_TRY(opq->s_lut.reserve((size_t)nq * opq->m.M * opq->m.K * sizeof(float)));
+    CVTMI_TRY(launch_lut(opq->m, q_rot, nq, nullptr, opq->s_lut.as<float>(), st));
+    int slots = 256 * 4;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) slots = prop.multiProcessorCount * 4;
+    }
+    if (slots > nq) slots = (int)nq;
+    const int64_t words = (h->g.n + 31) / 32 + 1;
+    const int efe = ef > k ? ef : k;
+    int64_t gcap = (int64_t)efe * h->g.maxM0 * 2;
+    if (gcap > h->g.n) gcap = h->g.n;
+    gcap = gcap > hnsw_lcap() ? gcap - hnsw_lcap() : 0;
+    gcap += 64;
+    CVTMI_TRY(h->s_vis.reserve((size_t)slots * words * 4));
+    CVTMI_TRY(h->s_cand.reserve((size_t)slots * gcap * 8));
+    CVTMI_TRY(h->s_err.reserve(16));
+    CVTMI_HIP(hipMemsetAsync(h->s_err.p, 0, 4, st));
+    CVTMI_TRY(launch_hnsw_search_adc(h->g, opq->s_lut.as<float>(), opq->codes.as<uint8_t>(), opq->m.M, opq->m.K, nq, k, ef, dist,
+                                     labels, h->s_vis.as<uint32_t>(), h->s_cand.p, slots, words, gcap, h->s_err.as<int>(), st));
+    int err = 0;
+    CVTMI_HIP(hipMemcpyAsync(&err, h->s_err.p, 4, hipMemcpyDeviceToHost, st));
+    CVTMI_HIP(hipStreamSynchronize(st));
+    if (err) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search_adc: candidate queue overflow (ef=%d)", ef);
+    return CVTMI_OK;
+}
+
+int cvtmi_hnsw_search_adc(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef, float *dist,
+                          int64_t *labels)
+{
+    CHECK_HN(h);
+    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: bad arguments");
+    if (nq == 0) return CVTMI_OK;
+    Tmp dq, dd, dl;
+    CVTMI_TRY(dq.upload(q, (size_t)nq * h->D * sizeof(float)));
+    CVTMI_TRY(dd.alloc((size_t)nq * k * 4));
+    CVTMI_TRY(dl.alloc((size_t)nq * k * 8));
+    CVTMI_TRY(cvtmi_hnsw_search_adc_dev(h, opq, dq.as<float>(), nq, rotate, k, ef, dd.as<float>(), dl.as<int64_t>(), nullptr));
+    CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    CVTMI_HIP(hipMemcpy(labels, dl.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}

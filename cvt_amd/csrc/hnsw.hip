@@ -89,7 +89,10 @@ struct HnswArgs {
     int64_t n;
     int D, maxM, maxM0, maxlevel;
     uint32_t enterpoint;
-    const float *q;
+    const float *q;           // fp32 mode: queries [nq][D]
+    const float *lut;         // ADC mode: per-query tables [nq][M][K] (lut_kernel), codes [n][M]
+    const uint8_t *codes;
+    int M, K;
     int nq, k, ef;
     float *out_d;
     int64_t *out_label;
@@ -99,12 +102,57 @@ struct HnswArgs {
     int *err;
 };
 
+// Distance evaluators: per-query state in LDS (`prepare`), one neighbour per lane (`operator()`).
 template <bool IP, int LANES>
+struct DistF32 {
+    const HnswArgs &a;
+    float *qs;
+    __device__ __forceinline__ int smem_floats() const { return (a.D + 3) & ~3; }
+    __device__ __forceinline__ void prepare(int qi, int lane) const
+    {
+        for (int i = lane; i < a.D; i += 64) qs[i] = a.q[(int64_t)qi * a.D + i];
+    }
+    __device__ __forceinline__ float operator()(uint32_t id) const
+    {
+        float o[1];
+        dist_f32_row<IP, LANES, 1>(a.vec + (int64_t)id * a.D, qs, a.D, o);
+        return o[0];
+    }
+};
+// "HNSW over OPQ-compressed vectors": the node's M code bytes index the query's distance tables, summed in m
+// order from +0.0f exactly as the ADC scan does (IVFOPQ.cpp:302-306) -- 16 bytes gathered per neighbour
+// instead of 4 D.
+struct DistADC {
+    const HnswArgs &a;
+    float *lut;  // [M][K]
+    __device__ __forceinline__ int smem_floats() const { return (a.M * a.K + 3) & ~3; }
+    __device__ __forceinline__ void prepare(int qi, int lane) const
+    {
+        const float *src = a.lut + (int64_t)qi * a.M * a.K;
+        for (int i = lane; i < a.M * a.K; i += 64) lut[i] = src[i];
+    }
+    __device__ __forceinline__ float operator()(uint32_t id) const
+    {
+        const uint8_t *c = a.codes + (int64_t)id * a.M;
+        float s = 0.0f;
+        if (a.M == 16) {  // one 16-byte gather per neighbour
+            const uint4 v = *reinterpret_cast<const uint4 *>(c);
+            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int m = 0; m < 16; ++m) s = __fadd_rn(s, lut[m * a.K + ((w[m >> 2] >> (8 * (m & 3))) & 0xffu)]);
+        } else {
+            for (int m = 0; m < a.M; ++m) s = __fadd_rn(s, lut[m * a.K + c[m]]);
+        }
+        return s;
+    }
+};
+
+template <class DIST>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(const HnswArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float hn_smem[];
-    float *qs = hn_smem;                                               // D floats (padded to 16 bytes)
-    HnEnt *top_l = reinterpret_cast<HnEnt *>(hn_smem + ((a.D + 3) & ~3));
+    const DIST dist{ a, hn_smem };                                     // query state first (padded to 16 bytes)
+    HnEnt *top_l = reinterpret_cast<HnEnt *>(hn_smem + dist.smem_floats());
     HnEnt *cand_l = top_l + (HN_EF_MAX + 1);
     const int lane = threadIdx.x;
     const bool w = lane == 0;
@@ -115,7 +163,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const HnswArgs a)
     const int64_t cand_cap = HN_LCAP + a.gcap;
 
     for (int qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
-        for (int i = lane; i < a.D; i += 64) qs[i] = a.q[(int64_t)qi * a.D + i];
+        dist.prepare(qi, lane);
         for (int64_t i = lane; i < a.words; i += 64) vis[i] = 0u;
         for (int i = lane; i < a.k; i += 64) { a.out_d[(int64_t)qi * a.k + i] = 0.0f; a.out_label[(int64_t)qi * a.k + i] = -1; }
         __builtin_amdgcn_s_waitcnt(0);
@@ -124,12 +172,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const HnswArgs a)
 
         // ---- upper levels: first minimum among the neighbours that beats the current distance (:692-712) ----
         uint32_t cur = a.enterpoint;
-        float curdist;
-        {
-            float o[1];
-            dist_f32_row<IP, LANES, 1>(a.vec + (int64_t)cur * a.D, qs, a.D, o);
-            curdist = o[0];
-        }
+        float curdist = dist(cur);
         for (int level = a.maxlevel; level > 0; --level) {
             bool changed = true;
             while (changed) {
@@ -141,7 +184,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const HnswArgs a)
                     const bool act = j < size;
                     const uint32_t nb = act ? ll[1 + j] : cur;
                     float o[1];
-                    dist_f32_row<IP, LANES, 1>(a.vec + (int64_t)nb * a.D, qs, a.D, o);
+                    o[0] = dist(nb);
                     // the scalar loop keeps the FIRST neighbour that reaches the running minimum
                     unsigned long long better = __ballot(act && o[0] < curdist);
                     while (better) {
@@ -160,7 +203,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const HnswArgs a)
         int top_n = 0, cand_n = 0;
         {
             float o[1];
-            dist_f32_row<IP, LANES, 1>(a.vec + (int64_t)cur * a.D, qs, a.D, o);
+            o[0] = dist(cur);
             hn_push(top, top_n, o[0], cur);
             hn_push(cand, cand_n, -o[0], cur);
             if (w) vis[cur >> 5] |= 1u << (cur & 31);
@@ -183,7 +226,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const HnswArgs a)
                     act = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;
                 }
                 float o[1] = { 0.0f };
-                if (act) dist_f32_row<IP, LANES, 1>(a.vec + (int64_t)nb * a.D, qs, a.D, o);
+                if (act) o[0] = dist(nb);
                 unsigned long long m = __ballot(act);
                 while (m) {  // list order
                     const int b = __ffsll((long long)m) - 1;
@@ -232,23 +275,47 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const HnswArgs a)
     }
 }
 
+static void hnsw_fill_args(HnswArgs &a, const HnswDevGraph &g, int64_t nq, int k, int ef, float *out_d, int64_t *out_label,
+                           uint32_t *visited, void *cand_scratch, int64_t words, int64_t gcap, int *err)
+{
+    a.vec = g.vec; a.links0 = g.links0; a.labels = g.labels; a.upper_off = g.upper_off; a.upper = g.upper;
+    a.n = g.n; a.D = g.D; a.maxM = g.maxM; a.maxM0 = g.maxM0; a.maxlevel = g.maxlevel; a.enterpoint = g.enterpoint;
+    a.q = nullptr; a.lut = nullptr; a.codes = nullptr; a.M = 0; a.K = 0;
+    a.nq = (int)nq; a.k = k; a.ef = ef; a.out_d = out_d; a.out_label = out_label;
+    a.visited = visited; a.cand_g = reinterpret_cast<HnEnt *>(cand_scratch); a.words = words; a.gcap = gcap; a.err = err;
+}
+
 int launch_hnsw_search(const HnswDevGraph &g, int metric, const float *q, int64_t nq, int k, int ef, float *out_d,
                        int64_t *out_label, uint32_t *visited, void *cand_scratch, int slots, int64_t words, int64_t gcap,
                        int *err, hipStream_t st)
 {
     if (nq <= 0) return CVTMI_OK;
     HnswArgs a;
-    a.vec = g.vec; a.links0 = g.links0; a.labels = g.labels; a.upper_off = g.upper_off; a.upper = g.upper;
-    a.n = g.n; a.D = g.D; a.maxM = g.maxM; a.maxM0 = g.maxM0; a.maxlevel = g.maxlevel; a.enterpoint = g.enterpoint;
-    a.q = q; a.nq = (int)nq; a.k = k; a.ef = ef; a.out_d = out_d; a.out_label = out_label;
-    a.visited = visited; a.cand_g = reinterpret_cast<HnEnt *>(cand_scratch); a.words = words; a.gcap = gcap; a.err = err;
+    hnsw_fill_args(a, g, nq, k, ef, out_d, out_label, visited, cand_scratch, words, gcap, err);
+    a.q = q;
     const size_t lds = (size_t)((g.D + 3) & ~3) * sizeof(float) + (size_t)(HN_EF_MAX + 1 + HN_LCAP) * sizeof(HnEnt);
     const bool ip = metric == CVTMI_METRIC_IP;
     const int lanes = (g.D % 4 != 0) ? 1 : (ip ? 4 : (g.D % 16 == 0 ? 8 : 4));
-#define CVTMI_HN(IPV, L) hipLaunchKernelGGL((hnsw_search_kernel<IPV, L>), dim3((unsigned)slots), dim3(64), lds, st, a)
+#define CVTMI_HN(IPV, L) hipLaunchKernelGGL((hnsw_search_kernel<DistF32<IPV, L> >), dim3((unsigned)slots), dim3(64), lds, st, a)
     if (ip) { if (lanes == 4) CVTMI_HN(true, 4); else CVTMI_HN(true, 1); }
     else { if (lanes == 8) CVTMI_HN(false, 8); else if (lanes == 4) CVTMI_HN(false, 4); else CVTMI_HN(false, 1); }
 #undef CVTMI_HN
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+// same traversal, distances = ADC over the nodes' PQ codes (codes [n][M] in internal-id order, lut [nq][M][K])
+int launch_hnsw_search_adc(const HnswDevGraph &g, const float *lut, const uint8_t *codes, int M, int K, int64_t nq, int k, int ef,
+                           float *out_d, int64_t *out_label, uint32_t *visited, void *cand_scratch, int slots, int64_t words,
+                           int64_t gcap, int *err, hipStream_t st)
+{
+    if (nq <= 0) return CVTMI_OK;
+    HnswArgs a;
+    hnsw_fill_args(a, g, nq, k, ef, out_d, out_label, visited, cand_scratch, words, gcap, err);
+    a.lut = lut; a.codes = codes; a.M = M; a.K = K;
+    const size_t lds = (size_t)((M * K + 3) & ~3) * sizeof(float) + (size_t)(HN_EF_MAX + 1 + HN_LCAP) * sizeof(HnEnt);
+    CVTMI_HIP(hipFuncSetAttribute((const void *)hnsw_search_kernel<DistADC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((hnsw_search_kernel<DistADC>), dim3((unsigned)slots), dim3(64), lds, st, a);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

@@ -234,6 +234,16 @@ int64_t cvtmi_hnsw_ntotal(cvtmi_hnsw_t h);
 int cvtmi_hnsw_search(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int ef, float *dist, int64_t *labels);
 int cvtmi_hnsw_search_dev(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int ef, float *dist, int64_t *labels,
                           void *stream);
+/* HNSW over OPQ-compressed vectors (BASELINE config 5; not in the reference, whose HNSW holds fp32 vectors):
+ * the same traversal over the same graph, but a node's distance is the ADC sum of the query's tables over the
+ * node's PQ code (IVFOPQ.cpp:273-291 tables, :302-306 sum) -- M bytes gathered per neighbour instead of 4 D.
+ * `opq` must hold exactly one code row per graph node, appended in the graph's internal-id order (the order
+ * the vectors were added to the graph), with a coarseK == 1 model of the graph's dimension; rotate as in
+ * cvtmi_opq_search.  Output as cvtmi_hnsw_search, distances = ADC distances. */
+int cvtmi_hnsw_search_adc(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef,
+                          float *dist, int64_t *labels);
+int cvtmi_hnsw_search_adc_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef,
+                              float *dist, int64_t *labels, void *stream);
 
 #ifdef __cplusplus
 }

@@ -217,6 +217,18 @@ class Oracle:
         assert rc == 0
         return d, lab
 
+    def hnsw_search_adc(self, index_bytes, books, codes, q_rot, k, ef):
+        buf = np.frombuffer(index_bytes, dtype=np.uint8)
+        q = _f32(q_rot); nq, D = q.shape
+        books = _f32(books); M, K, _ = books.shape
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        d = np.empty((nq, k), np.float32); lab = np.empty((nq, k), np.int64)
+        rc = self.lib.orc_hnsw_search_adc(_p(buf, C.c_uint8), C.c_int64(buf.size), C.c_int(D), _p(books, C.c_float), C.c_int(M),
+                                          C.c_int(K), _p(codes, C.c_uint8), _p(q, C.c_float), C.c_int64(nq), C.c_int64(k),
+                                          C.c_int64(ef), _p(d, C.c_float), _p(lab, C.c_int64))
+        assert rc == 0
+        return d, lab
+
     def merge_topk(self, in_d, in_id, k):
         in_d = _f32(in_d); in_id = np.ascontiguousarray(in_id, dtype=np.int64)
         nq, L, kk = in_d.shape

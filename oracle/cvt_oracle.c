@@ -669,26 +669,23 @@ static int hn_parse(const uint8_t *f, int64_t bytes, hn_index *ix)
     return p <= f + bytes ? 0 : -1;
 }
 
-/* metric: ORC_IP / ORC_L2F with the distance functions the reference's Space classes select for D
- * (InnerProductSpace space_ip.h:213-222: SSE 4-lane order for D % 4 == 0 -- the AVX branches are '#if 0' in
- * this tree --; L2Space space_l2.h:159-164).  Output ascending (dist, label), padded with (0, -1). */
-ORC_API int orc_hnsw_search(const uint8_t *file, int64_t bytes, int metric, int D, const float *queries, int64_t nq,
-                            int64_t k, int64_t ef_param, float *out_d, int64_t *out_label)
+typedef float (*hn_dist_fn)(void *ctx, const float *q, uint32_t id);
+
+/* the traversal of searchKnn with a pluggable node distance; output ascending (dist, label), padded (0, -1) */
+static void hn_search_core(const hn_index *ixp, hn_dist_fn dist, void *ctx, int qdim, const float *queries, int64_t nq,
+                           int64_t k, int64_t ef_param, float *out_d, int64_t *out_label)
 {
-    hn_index ix;
-    if (hn_parse(file, bytes, &ix) != 0) return -1;
-    const int flavour = 4;
+    const hn_index ix = *ixp;
     const uint64_t links_per = ix.maxM * 4 + 4;
     uint8_t *visited = (uint8_t *)malloc((size_t)ix.max_elements);
     hn_heap top = { NULL, 0, 0 }, cand = { NULL, 0, 0 };
     orc_pair *res = (orc_pair *)malloc(sizeof(orc_pair) * (size_t)(k > 0 ? k : 1));
-#define HN_VEC(i) ((const void *)(ix.level0 + (uint64_t)(i) * ix.size_per_elem + ix.offsetData))
     for (int64_t qi = 0; qi < nq; ++qi) {
-        const float *q = queries + qi * D;
+        const float *q = queries + qi * qdim;
         for (int64_t i = 0; i < k; ++i) { out_d[qi * k + i] = 0.0f; out_label[qi * k + i] = -1; }
         if (ix.cur_count == 0) continue;
         uint32_t cur = ix.enterpoint;
-        float curdist = orc_dist(metric, flavour, q, HN_VEC(cur), D);
+        float curdist = dist(ctx, q, cur);
         for (int level = ix.maxlevel; level > 0; --level) {
             int changed = 1;
             while (changed) {
@@ -697,7 +694,7 @@ ORC_API int orc_hnsw_search(const uint8_t *file, int64_t bytes, int metric, int 
                 uint32_t size; memcpy(&size, ll, 4);
                 for (uint32_t i = 0; i < size; ++i) {
                     uint32_t c; memcpy(&c, ll + 4 + 4 * (uint64_t)i, 4);
-                    const float d = orc_dist(metric, flavour, q, HN_VEC(c), D);
+                    const float d = dist(ctx, q, c);
                     if (d < curdist) { curdist = d; cur = c; changed = 1; }
                 }
             }
@@ -705,11 +702,11 @@ ORC_API int orc_hnsw_search(const uint8_t *file, int64_t bytes, int metric, int 
         const int64_t ef = ef_param > k ? ef_param : k;
         memset(visited, 0, (size_t)ix.max_elements);
         top.n = 0; cand.n = 0;
-        float dist = orc_dist(metric, flavour, q, HN_VEC(cur), D);
-        hn_push(&top, dist, cur);
-        hn_push(&cand, -dist, cur);
+        float d0 = dist(ctx, q, cur);
+        hn_push(&top, d0, cur);
+        hn_push(&cand, -d0, cur);
         visited[cur] = 1;
-        float lower = dist;
+        float lower = d0;
         while (cand.n) {
             const hn_ent c = cand.a[0];
             if (-c.d > lower) break;
@@ -720,7 +717,7 @@ ORC_API int orc_hnsw_search(const uint8_t *file, int64_t bytes, int metric, int 
                 uint32_t nb; memcpy(&nb, ll + 4 * (uint64_t)j, 4);
                 if (visited[nb]) continue;
                 visited[nb] = 1;
-                const float d = orc_dist(metric, flavour, q, HN_VEC(nb), D);
+                const float d = dist(ctx, q, nb);
                 if (top.a[0].d > d || top.n < ef) {
                     hn_push(&cand, -d, nb);
                     hn_push(&top, d, nb);
@@ -739,8 +736,52 @@ ORC_API int orc_hnsw_search(const uint8_t *file, int64_t bytes, int metric, int 
         qsort(res, (size_t)m, sizeof(orc_pair), pair_cmp_qsort);  /* the (dist, label) order of `results` (:719-726) */
         for (int64_t i = 0; i < m; ++i) { out_d[qi * k + i] = res[i].d; out_label[qi * k + i] = res[i].id; }
     }
-#undef HN_VEC
-    free(visited); free(top.a); free(cand.a); free(res); free((void *)ix.lists);
+    free(visited); free(top.a); free(cand.a); free(res);
+}
+
+typedef struct { const hn_index *ix; int metric, D; } hn_vec_ctx;
+static float hn_vec_dist(void *c, const float *q, uint32_t id)
+{
+    const hn_vec_ctx *x = (const hn_vec_ctx *)c;
+    return orc_dist(x->metric, 4, q, x->ix->level0 + (uint64_t)id * x->ix->size_per_elem + x->ix->offsetData, x->D);
+}
+
+/* metric: ORC_IP / ORC_L2F with the distance functions the reference's Space classes select for D
+ * (InnerProductSpace space_ip.h:213-222: SSE 4-lane order for D % 4 == 0 -- the AVX branches are '#if 0' in
+ * this tree --; L2Space space_l2.h:159-164). */
+ORC_API int orc_hnsw_search(const uint8_t *file, int64_t bytes, int metric, int D, const float *queries, int64_t nq,
+                            int64_t k, int64_t ef_param, float *out_d, int64_t *out_label)
+{
+    hn_index ix;
+    if (hn_parse(file, bytes, &ix) != 0) return -1;
+    hn_vec_ctx c = { &ix, metric, D };
+    hn_search_core(&ix, hn_vec_dist, &c, D, queries, nq, k, ef_param, out_d, out_label);
+    free((void *)ix.lists);
+    return 0;
+}
+
+/* "HNSW over OPQ-compressed vectors" (BASELINE config 5; not in the reference): the same traversal, node
+ * distance = ADC sum of the query's table over the node's PQ code, tables and sum as in IVFOPQ::Query
+ * (IVFOPQ.cpp:273-291, :302-306) with a zero coarse centroid.  q_rot: rotated queries [nq][D];
+ * codes [n][M] in internal-id order. */
+typedef struct { const float *books; const uint8_t *codes; int D, M, K; float *lut; const float *lut_for; } hn_adc_ctx;
+static float hn_adc_dist(void *c, const float *q, uint32_t id)
+{
+    hn_adc_ctx *x = (hn_adc_ctx *)c;
+    if (x->lut_for != q) { orc_lut(q, x->D, NULL, x->books, x->M, x->K, x->lut); x->lut_for = q; }
+    float s = 0.0f;
+    for (int m = 0; m < x->M; ++m) s += x->lut[m * x->K + x->codes[(int64_t)id * x->M + m]];
+    return s;
+}
+ORC_API int orc_hnsw_search_adc(const uint8_t *file, int64_t bytes, int D, const float *books, int M, int K,
+                                const uint8_t *codes, const float *q_rot, int64_t nq, int64_t k, int64_t ef_param,
+                                float *out_d, int64_t *out_label)
+{
+    hn_index ix;
+    if (hn_parse(file, bytes, &ix) != 0) return -1;
+    hn_adc_ctx c = { books, codes, D, M, K, (float *)malloc(sizeof(float) * (size_t)M * K), NULL };
+    hn_search_core(&ix, hn_adc_dist, &c, D, q_rot, nq, k, ef_param, out_d, out_label);
+    free(c.lut); free((void *)ix.lists);
     return 0;
 }
 

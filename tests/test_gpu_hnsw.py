@@ -78,3 +78,51 @@ def test_hnsw_larger_graph_device_pointers(amd, orc):
     # recall against the exact answer, for the record (a property of the graph, identical on CPU and GPU)
     exact = np.argmax(q @ x.T, axis=1)
     assert (lab[:, 0].cpu().numpy() == exact).mean() > 0.9
+
+
+def vectors_of(blob, D):
+    """the fp32 vectors stored in a saveIndex file, internal-id order"""
+    hdr = np.frombuffer(blob, np.uint64, 6, 0)
+    max_elements, cur, size_per, off_data = int(hdr[1]), int(hdr[2]), int(hdr[3]), int(hdr[5])
+    raw = np.frombuffer(blob, np.uint8, max_elements * size_per, 96).reshape(max_elements, size_per)
+    return np.ascontiguousarray(raw[:cur, off_data:off_data + 4 * D]).view(np.float32).reshape(cur, D)
+
+
+@pytest.mark.parametrize("case,M,K", [("ip128", 16, 256), ("ip32", 8, 64), ("l2f16", 4, 256)])
+def test_hnsw_over_opq_codes(amd, orc, golden, case, M, K):
+    """BASELINE config 5: the reference-built graph traversed with ADC distances over PQ codes (dense rotation,
+    codes from the GPU encoder).  Specification = the oracle's traversal with the oracle's ADC arithmetic."""
+    from cvt_amd import synth
+    g = golden.hnsw
+    metric, D, n, _, _, k, ef = (int(v) for v in g[case + "_meta"])
+    blob = g[case + "_index"].tobytes()
+    x = vectors_of(blob, D)
+    if D % 32 == 0:
+        R = synth.random_rotation(D, seed=3)                  # dense rotation: MFMA GEMM (built for D = 32 .. 128)
+        mk = lambda books: amd.OpqIndex(np.zeros((1, D), np.float32), books, R=R)
+        rot = lambda v: orc.rotate_fma(R, v)
+    else:
+        perm = synth.random_permutation(D, seed=3)            # the reference's own "rotation"
+        mk = lambda books: amd.OpqIndex(np.zeros((1, D), np.float32), books, perm=perm)
+        rot = lambda v: orc.reorder(perm, v)
+    xr = rot(x)
+    rng = np.random.default_rng(1)
+    step = D // M
+    books = np.ascontiguousarray(np.stack([xr[rng.integers(0, n, K), m * step:(m + 1) * step] for m in range(M)]))
+    opq = mk(books)
+    _, codes = opq.encode(opq.rotate(x))
+    opq.add_codes(codes)
+    _, ocodes = orc.pq_encode(xr, np.zeros((1, D), np.float32), books)
+    assert np.array_equal(codes, ocodes)
+    ix = amd.HnswIndex(blob, metric, D)
+    q = g[case + "_q"]
+    for k2, ef2 in ((k, ef), (10, 40), (1, 1)):
+        d, lab = ix.search_adc(opq, q, k2, ef2)
+        od, ol = orc.hnsw_search_adc(blob, books, ocodes, rot(q), k2, ef2)
+        assert np.array_equal(lab, ol), (case, k2, ef2)
+        assert np.array_equal(bits(d), bits(od)), (case, k2, ef2)
+    # mismatched handles are refused
+    small = mk(books)
+    small.add_codes(codes[:10])
+    with pytest.raises(amd.CvtmiError):
+        ix.search_adc(small, q, 5, 10)

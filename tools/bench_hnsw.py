@@ -33,4 +33,19 @@ for k, ef in ((5, 1000), (5, 200), (10, 64)):
     same = np.array_equal(rl, lab[:cs].cpu().numpy()) and np.array_equal(rd.view(np.uint32), d[:cs].cpu().numpy().view(np.uint32))
     print("k=%d ef=%d: GPU %.1f ms for %d queries = %.0f queries/s; reference CPU (1 core, %d queries) %.0f queries/s; identical=%s; recall@1 %.3f" % (
         k, ef, ms, nq, nq / ms * 1e3, cs, cs / t_cpu, same, float((lab[:, 0].cpu().numpy() == exact).mean())), flush=True)
+# ---- over OPQ-compressed vectors (BASELINE config 5): same graph, 16-byte codes instead of 512-byte vectors ----
+from cvt_amd import synth
+R = synth.random_rotation(D, seed=7)
+tmp = cvt_amd.OpqIndex(np.zeros((1, D), np.float32), np.zeros((16, 256, D // 16), np.float32), R=R)
+xr = tmp.rotate(torch.from_numpy(x).cuda())
+_, books = cvt_amd.opq_train(xr[:50_000].contiguous(), 1, 16, 256, 8, 1)
+opq = cvt_amd.OpqIndex(np.zeros((1, D), np.float32), books.cpu().numpy(), R=R)
+_, codes = opq.encode(xr)
+opq.add_codes(codes)
+for k, ef in ((5, 1000), (5, 200), (10, 64)):
+    ix.search_adc(opq, qd, k, ef); torch.cuda.synchronize()
+    t0 = time.perf_counter(); d, lab = ix.search_adc(opq, qd, k, ef); torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3
+    print("ADC over OPQ codes (M=16) k=%d ef=%d: GPU %.1f ms for %d queries = %.0f queries/s; recall@1 vs exact %.3f; recall@%d %.3f" % (
+        k, ef, ms, nq, nq / ms * 1e3, float((lab[:, 0].cpu().numpy() == exact).mean()), k,
+        float((lab.cpu().numpy() == exact[:, None]).any(axis=1).mean())), flush=True)
 os.remove(path)
