@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--large-nq", type=int, default=1024)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo = debug: several ranks on one GPU")
     ap.add_argument("--cpu-sample", type=int, default=256, help="queries timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=-1, help="threads of the all-cores CPU leg (-1 = all logical cores, 0 = skip)")
     ap.add_argument("--recall-sample", type=int, default=1000)
     args = ap.parse_args()
 
@@ -285,10 +286,33 @@ def main():
                           "(oracle/cvt_oracle.c -O3, 1 thread); host: %s" % (cs, nq, args.rows, k, _cpu_model()),
                 "gpu_topk_ids_identical": same_ids, "gpu_distances_bit_identical": same_d}
             result["recall_at_1_identical_to_cpu"] = bool(np.array_equal(oi[:, 0], i_gpu[:cs, 0].cpu().numpy()))
+            # the same loop on all host cores: queries split over threads (ctypes releases the GIL), bounded sample
+            nth = os.cpu_count() if args.cpu_threads < 0 else args.cpu_threads
+            if nth and nth > 1:
+                from concurrent.futures import ThreadPoolExecutor
+                per = 8
+                qs_mt = min(nq, nth * per)
+                q_rot_mt = orc.rotate_fma(R, q[:qs_mt].cpu().numpy())
+                chunks = [(a, min(qs_mt, a + per)) for a in range(0, qs_mt, per)]
+                def work(ab):
+                    return orc.adc_search(q_rot_mt[ab[0]:ab[1]], books, codes_h, k)
+                with ThreadPoolExecutor(max_workers=nth) as ex:
+                    t0 = time.perf_counter()
+                    parts = list(ex.map(work, chunks))
+                    t_mt = time.perf_counter() - t0
+                oi_mt = np.concatenate([p[1] for p in parts])
+                result["cpu_baseline_all_cores"] = {
+                    "value": round(qs_mt / t_cpu_fix(t_mt), 2), "unit": "queries/s", "cores": nth, "kind": "port",
+                    "sample": "%d queries in chunks of %d over %d threads, same loop as cpu_baseline" % (qs_mt, per, nth),
+                    "gpu_topk_ids_identical": bool(np.array_equal(oi_mt, i_gpu[:qs_mt].cpu().numpy()))}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def t_cpu_fix(t):
+    return max(t, 1e-9)
 
 
 def _cpu_model():
