@@ -272,8 +272,7 @@ static __device__ unsigned long long g_topk_dbg[4];  // compaction rounds, fix c
 // p - (NE - ex) for p >= NE - ex: the entries to be fixed sit in the first registers, so fixb can skip its second batch when
 // there are at most 128 of them.
 template <int QT, int CAP, bool SORTED, class FixB, class ThrX>
-__device__ __attribute__((noinline)) int topk_compact_wave_q(TopKShared<QT, CAP> &s, int q, int k, const FixB &fixb,
-                                                            const ThrX &thrx)
+__device__ __forceinline__ int topk_compact_wave_q_inl(TopKShared<QT, CAP> &s, int q, int k, const FixB &fixb, const ThrX &thrx)
 {
     static_assert(CAP <= 256, "register sort holds 256 entries per wave");
     constexpr int NR = CAP <= 64 ? 1 : (CAP <= 128 ? 2 : 4);  // registers per lane
@@ -342,6 +341,15 @@ __device__ __attribute__((noinline)) int topk_compact_wave_q(TopKShared<QT, CAP>
         s.thr_x[q] = thrx(q, th);
     }
     return keep;
+}
+
+// out-of-line form: a call keeps the caller's hot loop small, but values live across it must sit in the
+// callee-saved half of the register file (kernels near the VGPR limit use the _inl form instead)
+template <int QT, int CAP, bool SORTED, class FixB, class ThrX>
+__device__ __attribute__((noinline)) int topk_compact_wave_q(TopKShared<QT, CAP> &s, int q, int k, const FixB &fixb,
+                                                            const ThrX &thrx)
+{
+    return topk_compact_wave_q_inl<QT, CAP, SORTED>(s, q, k, fixb, thrx);
 }
 
 template <int QT, int CAP, int NT, bool SORTED, class FixB, class ThrX>

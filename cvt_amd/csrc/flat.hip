@@ -426,6 +426,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // each wave keeps its own 32 queries in registers for the whole launch (64 VGPRs at D = 512) and owns their
 // selection buffers outright, so compaction is wave-local (register radix select, block_topk.h) and needs no
 // workgroup protocol.  One pass over the rows now serves 32 * NW queries.
+#ifdef CVTMI_FLAT_TIMING
+__device__ unsigned long long g_flat_dbg[8];
+#define FT_T(i) do { if (threadIdx.x == 0) { const unsigned long long now__ = clock64(); ft_acc__[i] += now__ - ft_last__; ft_last__ = now__; } } while (0)
+#define FT_T0() unsigned long long ft_last__ = clock64(); unsigned long long ft_acc__[5] = { 0, 0, 0, 0, 0 }
+#define FT_TEND() do { if (threadIdx.x == 0) for (int i__ = 0; i__ < 5; ++i__) atomicAdd(&g_flat_dbg[i__], ft_acc__[i__]); } while (0)
+extern "C" int cvtmi_debug_flat_timing(unsigned long long *out, int reset)
+{
+    unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_flat_dbg), sizeof z) != hipSuccess) return -3;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_flat_dbg), z, sizeof z) != hipSuccess) return -3;
+    return 0;
+}
+#else
+#define FT_T(i) do { } while (0)
+#define FT_T0() do { } while (0)
+#define FT_TEND() do { } while (0)
+#endif
+
 struct NoFixBatch {
     template <int NR>
     __device__ __forceinline__ void operator()(int, unsigned long long (&)[NR], const bool (&)[NR]) const {}
@@ -486,14 +504,12 @@ void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
     // "+ 1": a row that ties the shared k-th may win the (distance, id) tie against rows of another split, so
     // it must survive; every row of the final top-k is <= every published k-th, hence never dropped.
     __shared__ int qq_s[QT];
-    __shared__ uint32_t eff_s[QT];
+    __shared__ int thq_s[QT];  // filter bound per query in the 'partial distance' domain (see below), INT_MAX = none yet
     if (lane < 32) qq_s[wave * 32 + lj] = qq_l;
     int qi_l = group * QT + wave * 32 + lj;
     qi_l = qi_l < a.nq ? qi_l : a.nq - 1;
     uint32_t g_l = __hip_atomic_load(&a.gthr[qi_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // shared threshold of query lj as last read 
-    int thq[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) thq[e] = 0x7fffffff;
+    if (lane < 32) thq_s[wave * 32 + lj] = 0x7fffffff;
     __syncthreads();
     const int64_t row_begin = (int64_t)split * a.rows_per_split;
     int64_t row_end = row_begin + a.rows_per_split;
@@ -539,7 +555,7 @@ void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
     const IdThr idthr;
     // Row tiles are small (32 x D bytes), HBM latency is ~2 us: PD tiles are kept in flight in a register ring
     // (tile t sits in slot t % PD until it is parked in LDS one iteration before its turn).
-    constexpr int PD = LPT <= 2 ? 6 : (LPT <= 4 ? 4 : 2);
+    constexpr int PD = LPT <= 4 ? 4 : 2;
     const uint32_t n_tiles = (n_local + 31) / 32;
     mf_v4i pf[PD][LPT];
     int xxr[PD];
@@ -547,54 +563,38 @@ void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
     for (int u = 0; u < PD; ++u) fetch(32u * u, pf[u], xxr[u]);  // rows past the split are clamped
     if (n_tiles) park(0, pf[0]);
     __syncthreads();
+    FT_T0();
     // The tile loop runs to a multiple of PD and has no memory-related control flow (tiles past the end are
     // clamped duplicates whose rows are rejected at push time): with branches around the loads the compiler
     // falls back to s_waitcnt vmcnt(0) and the ring drains every iteration.
-    for (uint32_t t0 = 0; t0 < n_tiles; t0 += PD) {
-#pragma unroll
-        for (int u = 0; u < PD; ++u) {
-            const uint32_t t = t0 + u;
-            const int buf = u & 1;    // PD is even: tile t lives in LDS buffer t & 1 = u & 1
-            const int xx_cur = xxr[u];
-            fetch(32u * (t + PD), pf[u], xxr[u]);  // slot u is free: tile t is in LDS (clamped past the end)
-            const uint8_t *rt = rows_s + buf * 32 * LDR + lj * LDR + 16 * lh;
-            mf_v16i acc0, acc1;  // two chains: consecutive MFMAs do not wait on each other's result
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { acc0[e] = 0; acc1[e] = 0; }
-#pragma unroll
-            for (int s = 0; s < KS; s += 2) {
-                if (s < nks) {
-                    const mf_v4i bv = *reinterpret_cast<const mf_v4i *>(rt + 32 * s);
-                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(qreg[s], bv, acc0, 0, 0, 0);
-                }
-                if (s + 1 < nks) {
-                    const mf_v4i bv = *reinterpret_cast<const mf_v4i *>(rt + 32 * (s + 1));
-                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(qreg[s + 1], bv, acc1, 0, 0, 0);
-                }
-            }
-            const uint32_t lrow = 32u * t + lj;
-            const bool valid = lrow < n_local;
+    // Software pipeline inside the wave: the 16 MFMAs of tile t are issued, then the test of tile t-1 (whose
+    // accumulator is the other register set) runs on the VALU while the matrix pipe works -- the two used to
+    // take turns (1.9 K + 2.0 K clocks per tile, tools/flat_timing.py).
+    // epilogue(acc, xx, t): test the 16 (row, query) results of one tile, push the hits, compact on overflow.
+    auto epilogue = [&](const mf_v16i &acc, int xx_t, uint32_t t, bool refresh, uint32_t hit) {
+        const uint32_t lrow = 32u * t + lj;
+        const bool valid = lrow < n_local;
+        hit = valid ? hit : 0u;
+        uint32_t pend = 0;
+        if (__any(hit != 0)) {
             // Candidates go straight to the wave's own buffers; a buffer is compacted only when a push finds it
             // full (the lane keeps that candidate and offers it again afterwards with '<=': it may tie the new
             // k-th entry and carry the smaller id).  All of it is wave-local: no workgroup protocol.
             bool dummy = false;
-            uint32_t pend = 0;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int part = xx_cur - 2 * (acc0[e] + acc1[e]);
-                if (valid && part < thq[e]) {
+                if (hit & (1u << e)) {
                     const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const uint32_t key = (uint32_t)(qq_s[q] + part);  // exact, >= 0
+                    const uint32_t key = (uint32_t)(qq_s[q] + xx_t - 2 * acc[e]);  // exact, >= 0
                     if (!topk_push<QT, CAP, CAP>(tk, q, key, (uint32_t)(row_begin + lrow), dummy)) pend |= 1u << e;
                 }
             }
-            bool refresh = u == 0;  // consume the shared thresholds requested one ring turn ago
             while (__any(pend != 0)) {
                 unsigned long long m = __ballot(lane < 32 && tk.cnt[wave * 32 + lj] >= CAP);
                 while (m) {
                     const int ql = __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    const int keep = topk_compact_wave_q<QT, CAP, false>(tk, wave * 32 + ql, a.k, nofix, idthr);
+                    const int keep = topk_compact_wave_q_inl<QT, CAP, false>(tk, wave * 32 + ql, a.k, nofix, idthr);
                     if (lane == 0) tk.cnt[wave * 32 + ql] = keep;
                 }
                 if (lane < 32) {
@@ -606,7 +606,7 @@ void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
                 for (int e = 0; e < 16; ++e) {
                     if (pend & (1u << e)) {
                         const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                        const uint32_t key = (uint32_t)(qq_s[q] + xx_cur - 2 * (acc0[e] + acc1[e]));
+                        const uint32_t key = (uint32_t)(qq_s[q] + xx_t - 2 * acc[e]);
                         if (key <= tk.thr_x[q])
                             if (!topk_push<QT, CAP, CAP>(tk, q, key, (uint32_t)(row_begin + lrow), dummy)) still |= 1u << e;
                     }
@@ -614,24 +614,69 @@ void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
                 pend = still;
                 refresh = true;
             }
-            if (refresh) {  // wave-uniform
-                if (lane < 32) {
-                    const uint32_t own = tk.thr_x[wave * 32 + lj];
-                    const uint32_t sh = g_l == KEY_MAX ? KEY_MAX : g_l + 1u;
-                    eff_s[wave * 32 + lj] = own < sh ? own : sh;
+        }
+        if (refresh) {  // wave-uniform
+            if (lane < 32) {
+                const uint32_t own = tk.thr_x[wave * 32 + lj];
+                const uint32_t sh = g_l == KEY_MAX ? KEY_MAX : g_l + 1u;
+                const uint32_t th = own < sh ? own : sh;
+                thq_s[wave * 32 + lj] = th == KEY_MAX ? 0x7fffffff : (int)th - qq_s[wave * 32 + lj];
+            }
+        }
+    };
+    // branch-free test of result e of a finished tile (bounds come from LDS: 2 distinct addresses per wave,
+    // broadcast); issued between the MFMAs of the next tile so that it runs in their shadow
+    auto hit_bit = [&](const mf_v16i &acc, int xx_t, int e) -> uint32_t {
+        return ((xx_t - 2 * acc[e]) < thq_s[wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh] ? 1u : 0u) << e;
+    };
+    mf_v16i accs[2];
+    int xx_prev = 0;
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const uint32_t t = t0 + u;
+            const int buf = u & 1;    // PD is even: tile t lives in LDS buffer t & 1 = u & 1
+            const int xx_cur = xxr[u];
+            fetch(32u * (t + PD), pf[u], xxr[u]);  // slot u is free: tile t is in LDS (clamped past the end)
+            const uint8_t *rt = rows_s + buf * 32 * LDR + lj * LDR + 16 * lh;
+            mf_v16i acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0;
+            const mf_v16i &prev = accs[(u & 1) ^ 1];
+            uint32_t hit = 0;
+            constexpr int EPS = 16 / KS;  // results of the previous tile tested per MFMA of this one
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s < nks) {
+                    const mf_v4i bv = *reinterpret_cast<const mf_v4i *>(rt + 32 * s);
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(qreg[s], bv, acc, 0, 0, 0);
                 }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const uint32_t th = eff_s[q];
-                    thq[e] = th == KEY_MAX ? 0x7fffffff : (int)th - qq_s[q];
-                }
+                for (int j = 0; j < EPS; ++j) hit |= hit_bit(prev, xx_prev, s * EPS + j);
+                // keep the order written here: operand reads a few MFMAs ahead at most (64 VGPRs if all 16 were
+                // hoisted), the tests of the previous tile between the MFMAs
+                if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0);
             }
+            accs[u & 1] = acc;
+            FT_T(0);  // LDS reads + MFMAs issued, previous tile tested
+            if (t > 0) epilogue(prev, xx_prev, t - 1, u == 0, hit);  // pushes (rare) + threshold refresh
+            xx_prev = xx_cur;
             if (u == 0) g_l = __hip_atomic_load(&a.gthr[qi_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // used at the next refresh, PD tiles on
+            FT_T(1);  // test + pushes + compactions
             park(buf ^ 1, pf[(u + 1) % PD]);
+            FT_T(2);  // wait for the prefetched tile + LDS store
             lds_barrier();  // next tile parked by everyone, this tile read by everyone (global prefetch stays in flight)
+            FT_T(3);  // barrier
         }
     }
+    if (n_tiles) {  // the last tile processed by the loop (the loop runs to a multiple of PD: its parity is known)
+        const uint32_t t_last = ((n_tiles + PD - 1) / PD) * PD - 1;
+        uint32_t hit = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) hit |= hit_bit(accs[(PD - 1) & 1], xx_prev, e);
+        epilogue(accs[(PD - 1) & 1], xx_prev, t_last, false, hit);
+    }
+    FT_TEND();
     // sorted result of this wave's queries
     for (int ql = 0; ql < 32; ++ql) {
         const int q = wave * 32 + ql, qi = group * QT + q;
