@@ -69,10 +69,18 @@ def random_permutation(D, seed=7):
 
 
 def train_books(x_rot, M, K=256, iters=6, seed=1234):
-    """A few Lloyd iterations per sub-space on a (rotated) torch sample -> numpy [M][K][step]."""
+    """Sub-space codebooks for a zero-coarse-centroid model (the exhaustive configs): cvtmi_kmeans (the library's
+    own Lloyd iteration, csrc/kmeans.hip) per sub-space on a (rotated) device sample -> numpy [M][K][step]."""
     import torch
+    from . import capi
     n, D = x_rot.shape
     step = D // M
+    if x_rot.is_cuda:
+        books = np.empty((M, K, step), dtype=np.float32)
+        for m in range(M):
+            cen, _, _ = capi.kmeans(x_rot[:, m * step:(m + 1) * step].contiguous(), K, iters, seed)
+            books[m] = cen.cpu().numpy()
+        return books
     g = torch.Generator(device=x_rot.device)
     g.manual_seed(seed)
     books = torch.empty((M, K, step), dtype=torch.float32, device=x_rot.device)
