@@ -141,7 +141,7 @@ struct cvtmi_flat_s {
     DevBuf data, labels, norms;  // norms: int32 |x-128|^2 per row, uint8 metric with D % 32 == 0 (MFMA path)
     int64_t n = 0;
     bool identity = true;  // label == row
-    DevBuf s_part_d, s_part_id, s_gthr;
+    DevBuf s_part_d, s_part_id, s_gthr, s_stage;
 };
 
 static int use_device(int dev)
@@ -690,7 +690,7 @@ int cvtmi_flat_destroy(cvtmi_flat_t h)
 {
     if (!h) return CVTMI_OK;
     (void)hipSetDevice(h->device);
-    h->data.release(); h->labels.release(); h->norms.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_gthr.release();
+    h->data.release(); h->labels.release(); h->norms.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_gthr.release(); h->s_stage.release();
     delete h;
     return CVTMI_OK;
 }
@@ -713,10 +713,13 @@ static int flat_add_common(cvtmi_flat_t h, const void *x, const int64_t *labels,
         for (int64_t i = 0; i < n && same; ++i) same = labels[i] == h->n + i;
         if (same) explicit_labels = false;
     }
-    if ((size_t)total * h->row_bytes > h->data.cap) {
-        size_t rows = std::max<size_t>((size_t)total, (h->data.cap / h->row_bytes) * 2);
+    const bool blocked = flat_blocked(h->metric, h->D);  // fp32 rows live in 64-row blocks: whole blocks are kept
+    const size_t rows_held = blocked ? (size_t)((h->n + 63) / 64 * 64) : (size_t)h->n;
+    const size_t rows_need = blocked ? (size_t)((total + 63) / 64 * 64) : (size_t)total;
+    if (rows_need * h->row_bytes > h->data.cap) {
+        size_t rows = std::max<size_t>(rows_need, (h->data.cap / h->row_bytes) * 2);
         rows = std::max<size_t>(rows, 1024);
-        CVTMI_TRY(h->data.grow(rows * h->row_bytes, (size_t)h->n * h->row_bytes, st));
+        CVTMI_TRY(h->data.grow(rows * h->row_bytes, rows_held * h->row_bytes, st));
     }
     if (explicit_labels && h->identity) {
         h->identity = false;
@@ -728,7 +731,17 @@ static int flat_add_common(cvtmi_flat_t h, const void *x, const int64_t *labels,
     }
     if (!h->identity && (size_t)total * 8 > h->labels.cap)
         CVTMI_TRY(h->labels.grow(std::max<size_t>((size_t)total, h->labels.cap / 4) * 8, (size_t)h->n * 8, st));
-    CVTMI_HIP(hipMemcpyAsync(h->data.as<uint8_t>() + (size_t)h->n * h->row_bytes, x, (size_t)n * h->row_bytes, kind, st));
+    if (blocked) {
+        const float *src = static_cast<const float *>(x);
+        if (kind == hipMemcpyHostToDevice || ((uintptr_t)x & 15) != 0) {  // staged: host rows, or a device pointer off 16 bytes
+            CVTMI_TRY(h->s_stage.reserve((size_t)n * h->row_bytes));
+            CVTMI_HIP(hipMemcpyAsync(h->s_stage.p, x, (size_t)n * h->row_bytes, kind, st));
+            src = h->s_stage.as<float>();
+        }
+        CVTMI_TRY(launch_flat_block(src, n, h->D, h->n, h->data.as<float>(), st));
+    } else {
+        CVTMI_HIP(hipMemcpyAsync(h->data.as<uint8_t>() + (size_t)h->n * h->row_bytes, x, (size_t)n * h->row_bytes, kind, st));
+    }
     if (!h->identity) {
         if (labels) CVTMI_HIP(hipMemcpyAsync(h->labels.as<int64_t>() + h->n, labels, (size_t)n * 8, kind, st));
         else {

@@ -99,6 +99,146 @@ __global__ __launch_bounds__(kBlock) void flat_f32_kernel(const FlatArgs a)
     }
 }
 
+// Same search with the queries in SCALAR registers.  The kernel above re-reads every query value from LDS for
+// every row (QT * D / 4 broadcast ds_read_b128 per row and lane: the LDS pipe, not the VALU, sets its pace).
+// A query value is the same for all 64 lanes, so it belongs in an SGPR: the queries are read with uniform
+// addresses straight from global memory (s_load through the scalar cache), the rows stay one per lane, and the
+// multiply / subtract take the SGPR as an operand -- no LDS traffic at all in the distance loop.  Same
+// per-lane accumulation order as dist_f32.h, hence the same bits.
+template <bool IP, int LANES, int QT>
+__global__ __launch_bounds__(kBlock) void flat_f32_sq_kernel(const FlatArgs a)
+{
+    __shared__ TopKShared<QT, FLAT_CAP> tk;
+    const int split = blockIdx.x % a.splits, group = blockIdx.x / a.splits;
+    const int tid = threadIdx.x;
+    // constant address space + uniform address = s_load_dword*: the values land in SGPRs
+    typedef const __attribute__((address_space(4))) float cfloat;
+    cfloat *Q = (cfloat *)(uintptr_t)a.q;
+    cfloat *qp[QT];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        int qi = group * QT + q;
+        qi = qi < a.nq ? qi : a.nq - 1;
+        qp[q] = Q + (int64_t)qi * a.D;  // wave-uniform
+    }
+    topk_init(tk);
+    __syncthreads();
+    const int64_t row_begin = (int64_t)split * a.rows_per_split;
+    int64_t row_end = row_begin + a.rows_per_split;
+    row_end = row_end < a.n ? row_end : a.n;
+    const float *X = reinterpret_cast<const float *>(a.data);
+    const int D = a.D;
+    int tile = 0;
+    for (int64_t base = row_begin; base < row_end; base += (int64_t)kBlock * FLAT_R, ++tile) {
+        uint32_t key[FLAT_R][QT];
+        uint32_t pay[FLAT_R];
+        // blocked layout (flat_block_kernel): float4 c of the 64 rows of block b are contiguous, so the 64 lanes
+        // of a wave read 1 KB in one piece; row = 64 b + lane (tiles start on multiples of 64)
+        const float4 *rowp[FLAT_R];
+        bool valid[FLAT_R];
+#pragma unroll
+        for (int r = 0; r < FLAT_R; ++r) {
+            const int64_t row = base + r * kBlock + tid;
+            valid[r] = row < row_end;
+            const int64_t rc = valid[r] ? row : row_begin;  // rows past the end read a valid row, rejected by the key
+            rowp[r] = reinterpret_cast<const float4 *>(X) + (rc >> 6) * (int64_t)(D >> 2) * 64 + (rc & 63);
+            pay[r] = (uint32_t)row;
+        }
+        float acc[FLAT_R][QT][LANES];
+#pragma unroll
+        for (int r = 0; r < FLAT_R; ++r)
+#pragma unroll
+            for (int q = 0; q < QT; ++q)
+#pragma unroll
+                for (int l = 0; l < LANES; ++l) acc[r][q][l] = 0.0f;
+        // unrolled so that the scalar loads of 16 dimensions x QT queries (64 SGPRs) are in flight together
+#pragma unroll(16 / LANES)
+        for (int i = 0; i < D; i += LANES) {  // D % LANES == 0 (the launcher picks LANES)
+            float xv[FLAT_R][LANES];
+#pragma unroll
+            for (int r = 0; r < FLAT_R; ++r)
+#pragma unroll
+                for (int l4 = 0; l4 < LANES / 4; ++l4) {
+                    const float4 v = rowp[r][(int64_t)((i >> 2) + l4) * 64];
+                    xv[r][4 * l4 + 0] = v.x; xv[r][4 * l4 + 1] = v.y; xv[r][4 * l4 + 2] = v.z; xv[r][4 * l4 + 3] = v.w;
+                }
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+#pragma unroll
+                for (int l = 0; l < LANES; ++l) {
+                    const float qv = qp[q][i + l];  // uniform address: scalar load
+#pragma unroll
+                    for (int r = 0; r < FLAT_R; ++r) {
+                        if constexpr (IP) {
+                            acc[r][q][l] = __fadd_rn(acc[r][q][l], __fmul_rn(qv, xv[r][l]));
+                        } else {
+                            const float t = __fsub_rn(qv, xv[r][l]);
+                            acc[r][q][l] = __fadd_rn(acc[r][q][l], __fmul_rn(t, t));
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < FLAT_R; ++r)
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                float sum = acc[r][q][0];
+#pragma unroll
+                for (int l = 1; l < LANES; ++l) sum = __fadd_rn(sum, acc[r][q][l]);
+                const float d = IP ? __fsub_rn(1.0f, sum) : sum;
+                uint32_t kk = f32_key(d);
+                kk = kk == KEY_MAX ? KEY_MAX - 1 : kk;
+                key[r][q] = valid[r] ? kk : KEY_MAX;
+            }
+        topk_tile<QT, FLAT_R, FLAT_CAP, FLAT_TRIG>(tk, a.k, tile, key, pay);
+    }
+    __syncthreads();
+    topk_compact(tk, a.k);
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        const int qi = group * QT + q;
+        if (qi >= a.nq) break;
+        const int cnt = tk.cnt[q];
+        const int64_t o = ((int64_t)qi * a.splits + split) * a.k;
+        for (int i = tid; i < a.k; i += kBlock) {
+            if (i < cnt) {
+                const unsigned long long e = tk.buf[q][i];
+                a.part_d[o + i] = key_f32((uint32_t)(e >> 32));
+                a.part_id[o + i] = (int64_t)(uint32_t)e;
+            } else {
+                a.part_d[o + i] = __uint_as_float(0x7f800000u);
+                a.part_id[o + i] = -1;
+            }
+        }
+    }
+}
+
+// rows [row0, row0 + n) of a row-major [n][D] fp32 block -> the blocked layout above (D % 4 == 0):
+// float4 index of (row r, float4 c) = ((r >> 6) * (D / 4) + c) * 64 + (r & 63)
+__global__ __launch_bounds__(kBlock) void flat_block_kernel(const float4 *__restrict__ src, int64_t n, int D4, int64_t row0,
+                                                            float4 *__restrict__ dst)
+{
+    const int64_t total = n * D4;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = e / D4;
+        const int c = (int)(e - r * D4);
+        const int64_t row = row0 + r;
+        dst[((row >> 6) * D4 + c) * 64 + (row & 63)] = src[e];  // coalesced read, 16-byte scattered write (add time only)
+    }
+}
+
+int launch_flat_block(const float *src, int64_t n, int D, int64_t row0, float *dst, hipStream_t st)
+{
+    if (n <= 0) return CVTMI_OK;
+    int64_t blocks = (n * (D / 4) + kBlock - 1) / kBlock;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(flat_block_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, reinterpret_cast<const float4 *>(src), n, D / 4,
+                       row0, reinterpret_cast<float4 *>(dst));
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
 // uint8 rows.  VEC: rows are 16-byte aligned multiples of 16 (D % 16 == 0) -> dwordx4 loads + dot4
 template <bool VEC, int QT>
 __global__ __launch_bounds__(kBlock) void flat_u8_kernel(const FlatArgs a)
@@ -794,8 +934,12 @@ int flat_qtile(int64_t nq) { return nq >= 4 ? 4 : 1; }
 
 int flat_plan_splits(int64_t n, int64_t nq, int qtile)
 {
+    // 8 workgroups of 256 threads fit a CU: 2048 run at a time on 256 CUs.  One round of long workgroups beats
+    // two rounds of short ones (tools/bench_flat_f32.py: 2250 workgroups took as long as 2 x their own length),
+    // so the row splits fill the machine once and no more: the largest split count with groups * splits <= 2048.
     const int64_t groups = (nq + qtile - 1) / qtile;
-    int64_t need = (2048 + groups - 1) / groups;
+    const int64_t slots = 2048;
+    int64_t need = slots / groups;
     int64_t max_by_rows = n / 2048;
     if (max_by_rows < 1) max_by_rows = 1;
     if (need > max_by_rows) need = max_by_rows;
@@ -807,8 +951,13 @@ int flat_plan_splits(int64_t n, int64_t nq, int qtile)
 template <bool IP, int LANES>
 static int launch_f32(const FlatArgs &a, int qtile, unsigned blocks, size_t lds, hipStream_t st)
 {
-    if (qtile == 4) hipLaunchKernelGGL((flat_f32_kernel<IP, LANES, 4>), dim3(blocks), dim3(kBlock), lds, st, a);
-    else hipLaunchKernelGGL((flat_f32_kernel<IP, LANES, 1>), dim3(blocks), dim3(kBlock), lds, st, a);
+    if constexpr (LANES >= 4) {  // queries in SGPRs (rows are 16-byte aligned: D % 4 == 0)
+        if (qtile == 4) hipLaunchKernelGGL((flat_f32_sq_kernel<IP, LANES, 4>), dim3(blocks), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((flat_f32_sq_kernel<IP, LANES, 1>), dim3(blocks), dim3(kBlock), 0, st, a);
+    } else {
+        if (qtile == 4) hipLaunchKernelGGL((flat_f32_kernel<IP, LANES, 4>), dim3(blocks), dim3(kBlock), lds, st, a);
+        else hipLaunchKernelGGL((flat_f32_kernel<IP, LANES, 1>), dim3(blocks), dim3(kBlock), lds, st, a);
+    }
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

@@ -72,6 +72,10 @@ int launch_flat_search(int metric, int D, const void *data, int64_t n, const voi
                        int splits, float *part_d, int64_t *part_id, hipStream_t st);
 // uint8 L2 on the i8 matrix cores (D % 32 == 0, D <= 512, nq >= 8); norms[n] = sum (x-128)^2 per row
 int launch_flat_u8_norms(const uint8_t *x, int64_t n, int D, int32_t *norms, hipStream_t st);
+// fp32 metrics with D % 4 == 0 keep their rows in a blocked layout (float4 c of 64 consecutive rows contiguous)
+// so that a wave's row reads are coalesced; launch_flat_search expects that layout for those shapes
+inline bool flat_blocked(int metric, int D) { return metric != CVTMI_METRIC_L2U8 && (D % 4) == 0; }
+int launch_flat_block(const float *src, int64_t n, int D, int64_t row0, float *dst, hipStream_t st);
 int flat_u8_mfma_qtile(int D, int k, int64_t nq);  // queries per workgroup, 0 = shape not covered
 int flat_u8_mfma_splits(int64_t n, int64_t nq, int qt);
 // gthr: nq uint32 scratch (set to 0xff.. inside) through which the row splits of a query share their k-th best
