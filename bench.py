@@ -19,7 +19,7 @@ Multi-GPU layout (--layout):
   auto     queries when the code matrix is < 1 GiB per GPU (replication is free and a 125 K-row shard is too
            small to amortise a workgroup's fixed cost), rows otherwise (SIFT-1B: 2 GB per GPU).
 At N > 1 the JSON line also carries the throughput of the row-sharded path measured in the same run, and at
-every N a SIFT-1B-shaped probe ("row_sharded_large"): --large-rows code rows in total (default 32 M) sharded by
+every N the SIFT-1B probe ("row_sharded_large"): --large-rows code rows in total (default 2^30 = 16 GiB of codes) sharded by
 row over the ranks, 1024 queries on every rank, RCCL all-gather of the per-shard top-k + merge -- the north-star
 layout at a shard size where the scan streams from HBM (strong scaling in rows: compare its value across N).
 
@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--variant", type=int, default=-1, help="scan kernel variant (cvtmi.h), -1 = library default")
     ap.add_argument("--layout", choices=["auto", "rows", "queries"], default="auto")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1 with the queries layout: per-GPU batch fixed (weak) or the one batch split (strong)")
-    ap.add_argument("--large-rows", type=int, default=32 << 20, help="total rows of the row-sharded SIFT-1B-shaped probe (0 = skip)")
+    ap.add_argument("--large-rows", type=int, default=1 << 30, help="total rows of the row-sharded SIFT-1B probe (0 = skip): 16 GiB of codes in all")
     ap.add_argument("--large-nq", type=int, default=1024)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo = debug: several ranks on one GPU")
     ap.add_argument("--cpu-sample", type=int, default=256, help="queries timed on the CPU baseline (0 = skip)")
@@ -188,33 +188,44 @@ def main():
 
     # ---- SIFT-1B-shaped probe: a large code matrix row-sharded over the ranks (north-star layout) ----
     if args.large_rows > 0:
-        l0, l1 = sharded.shard_range(args.large_rows, rank, world)
-        g = torch.Generator(device=dev); g.manual_seed(0x51F7 + rank)
-        big = cvt_amd.OpqIndex(zero_coarse, books, R=R)
-        big.reserve(l1 - l0); big.set_id_base(l0)
-        for a in range(l0, l1, 1 << 24):
-            b = min(l1, a + (1 << 24))
-            big.add_codes(torch.randint(0, 256, (b - a, M), generator=g, device=dev, dtype=torch.uint8))
-        big.set_param("profile", 1)
-        if args.variant >= 0: big.set_param("scan_variant", args.variant)
-        ql = q[:min(args.large_nq, nq)].contiguous()
-        ls = sharded.ShardedSearch(lambda qq, kk: big.search(qq, kk, rotate=True), cvt_amd.topk_merge, world, rank)
-        for _ in range(2):
-            ls.search(ql, k)
-        barrier(); big.last_scan()
-        lsteps = max(2, min(args.steps, 5))
-        el3, _ = timed(lambda: ls.search(ql, k), lsteps, 0)
-        sc3 = big.last_scan()
-        extra["row_sharded_large"] = {
-            "value": round(ql.shape[0] * lsteps / el3, 1), "unit": "queries/s", "ms_per_step": round(el3 / lsteps * 1e3, 4),
-            "rows_total": args.large_rows, "rows_per_gpu": l1 - l0, "nq": int(ql.shape[0]), "scaling": "strong (rows)",
-            "scan_kernel_ms": round(sc3["ms"], 4),
-            "scan_algorithmic_GBps": round(sc3["code_bytes"] / (sc3["ms"] * 1e-3) / 1e9, 1),
-            "scan_frac_of_hbm_peak": round(sc3["code_bytes"] / (sc3["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "what": "uniform random codes, %d rows row-sharded x%d, %d queries on every rank, top-%d, %s" % (
-                args.large_rows, world, ql.shape[0], k,
-                "RCCL all-gather of per-shard top-k + merge" if world > 1 else "single shard")}
-        big.close(); del big
+        try:
+            l0, l1 = sharded.shard_range(args.large_rows, rank, world)
+            # codes + the scan's rotated copy + generation chunks must fit; every rank takes the same decision
+            free_b, _ = torch.cuda.mem_get_info(dev)
+            fits = torch.tensor([1 if free_b > (l1 - l0) * M * 2.3 + (2 << 30) else 0], dtype=torch.int32,
+                                device=dev if args.backend == "nccl" else "cpu")
+            if world > 1:
+                dist.all_reduce(fits, op=dist.ReduceOp.MIN)
+            if int(fits.item()) == 0:
+                raise MemoryError("not enough free HBM for %d code rows per GPU" % (l1 - l0))
+            g = torch.Generator(device=dev); g.manual_seed(0x51F7 + rank)
+            big = cvt_amd.OpqIndex(zero_coarse, books, R=R)
+            big.reserve(l1 - l0); big.set_id_base(l0)
+            for a in range(l0, l1, 1 << 24):
+                b = min(l1, a + (1 << 24))
+                big.add_codes(torch.randint(0, 256, (b - a, M), generator=g, device=dev, dtype=torch.uint8))
+            big.set_param("profile", 1)
+            if args.variant >= 0: big.set_param("scan_variant", args.variant)
+            ql = q[:min(args.large_nq, nq)].contiguous()
+            ls = sharded.ShardedSearch(lambda qq, kk: big.search(qq, kk, rotate=True), cvt_amd.topk_merge, world, rank)
+            for _ in range(2):
+                ls.search(ql, k)
+            barrier(); big.last_scan()
+            lsteps = max(2, min(args.steps, 5))
+            el3, _ = timed(lambda: ls.search(ql, k), lsteps, 0)
+            sc3 = big.last_scan()
+            extra["row_sharded_large"] = {
+                "value": round(ql.shape[0] * lsteps / el3, 1), "unit": "queries/s", "ms_per_step": round(el3 / lsteps * 1e3, 4),
+                "rows_total": args.large_rows, "rows_per_gpu": l1 - l0, "nq": int(ql.shape[0]), "scaling": "strong (rows)",
+                "scan_kernel_ms": round(sc3["ms"], 4),
+                "scan_algorithmic_GBps": round(sc3["code_bytes"] / (sc3["ms"] * 1e-3) / 1e9, 1),
+                "scan_frac_of_hbm_peak": round(sc3["code_bytes"] / (sc3["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "what": "uniform random codes, %d rows row-sharded x%d, %d queries on every rank, top-%d, %s" % (
+                    args.large_rows, world, ql.shape[0], k,
+                    "RCCL all-gather of per-shard top-k + merge" if world > 1 else "single shard")}
+            big.close(); del big
+        except MemoryError as e:  # decided identically on every rank (all-reduce above): skip, keep the headline line
+            extra["row_sharded_large"] = {"error": str(e)}
 
     result = None
     if rank == 0:

@@ -994,6 +994,12 @@ ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int 
         p.groups_a = (int)best_ga;
         p.splits_b = (int)best_sb;
     }
+    // the skewed kernels address a split's rows with 32-bit byte offsets (row * 16): at most 2^28 - 4096 rows per split
+    if (p.variant >= 1) {
+        const int64_t max_rows = (1LL << 28) - 4096;
+        const int64_t min_splits = (n_rows + max_rows - 1) / max_rows;
+        if (s < min_splits) { s = (int)min_splits; p.groups_a = 0; p.splits_b = 0; }
+    }
     p.splits = s;
     (void)k;
     return p;

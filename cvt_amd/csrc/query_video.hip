@@ -101,7 +101,14 @@ __global__ __launch_bounds__(kBlock) void query_video_kernel(const float *__rest
     for (int64_t r = b + tid; r < e; r += kBlock) {
         const uint8_t *c = codes + r * M;
         float s = 0.0f;
-        for (int m = 0; m < M; ++m) s = __fadd_rn(s, lut[m * 256 + c[m]]);
+        if (M == 16) {  // one 16-byte load per code row
+            const uint4 v = *reinterpret_cast<const uint4 *>(c);
+            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int m = 0; m < 16; ++m) s = __fadd_rn(s, lut[m * 256 + ((w[m >> 2] >> (8 * (m & 3))) & 0xffu)]);
+        } else {
+            for (int m = 0; m < M; ++m) s = __fadd_rn(s, lut[m * 256 + c[m]]);
+        }
         const int v = video_id[r];
         if (v >= 0 && v < img_num) atomicMin(&ms[v], __float_as_uint(s));
     }
