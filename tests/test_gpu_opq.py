@@ -297,3 +297,40 @@ def test_full_size_properties(amd, orc):
     qr = idx.rotate(q[:4]).cpu().numpy()
     od, oi = orc.adc_search(qr, books, codes.cpu().numpy(), k)
     assert np.array_equal(inn[:4], oi) and np.array_equal(bits(dn[:4]), bits(od))
+
+
+def test_scan_row_offsets_beyond_2pow28(amd, orc):
+    """300 M code rows on one GPU (4.8 GB + the rotated copy): rows planted past 2^28 and at the very end with the
+    query's best code per sub-quantiser must come back first, in id order (32-bit byte offsets inside a split,
+    64-bit everywhere else)."""
+    import torch
+    D, M, K = 128, 16, 256
+    n = 300_000_000
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < n * M * 2.5:
+        pytest.skip("not enough free HBM")
+    rng = np.random.default_rng(5)
+    books = synth_model(rng, D, M, K, scale=0.1)
+    q = (rng.normal(size=(9, D)) * 0.1).astype(np.float32)
+    idx = amd.OpqIndex(np.zeros((1, D), np.float32), books)
+    idx.reserve(n)
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    planted = [123, (1 << 28) + 5, 290_000_007, n - 1]
+    lut0 = orc.lut(q[0], np.zeros(D, np.float32), books)            # [M][K]
+    best = lut0.argmin(axis=1).astype(np.uint8)
+    done = 0
+    while done < n:
+        m = min(1 << 25, n - done)
+        chunk = torch.randint(0, 256, (m, M), generator=g, device="cuda", dtype=torch.uint8)
+        for p in planted:
+            if done <= p < done + m:
+                chunk[p - done] = torch.from_numpy(best).cuda()
+        idx.add_codes(chunk)
+        done += m
+    d, i = idx.search(q, 10, rotate=False)
+    assert list(i[0, :4]) == planted, i[0]
+    dmin = np.float32(0)
+    for m_ in range(M):
+        dmin = np.float32(dmin + lut0[m_, best[m_]])
+    assert np.all(bits(d[0, :4]) == bits(np.array([dmin], np.float32))[0])
+    assert np.all(d[:, 1:] >= d[:, :-1]) and i.min() >= 0 and i.max() < n
