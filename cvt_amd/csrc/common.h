@@ -41,7 +41,7 @@ __device__ __forceinline__ float key_f32(uint32_t k)
     return __uint_as_float(u);
 }
 
-constexpr int kBlock = 256;  // every kernel in this library runs 256-thread (4-wave) workgroups
+constexpr int kBlock = 256;  // default workgroup: 256 threads (4 waves); the scan, row-tile and SQ8 tile kernels pick their own
 
 #ifdef __HIPCC__
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load
