@@ -807,7 +807,7 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
         pi = h->s_part_id.as<int64_t>();
     }
     if (mfma) {
-        CVTMI_TRY(h->s_gthr.reserve((size_t)nq * sizeof(uint32_t)));
+        CVTMI_TRY(h->s_gthr.reserve((size_t)nq * (1 + 16) * sizeof(uint32_t)));
         CVTMI_TRY(launch_flat_u8_mfma(h->D, h->data.as<uint8_t>(), h->norms.as<int32_t>(), h->n,
                                       reinterpret_cast<const uint8_t *>(q), nq, k, splits, pd, pi, h->s_gthr.as<uint32_t>(), st));
     }

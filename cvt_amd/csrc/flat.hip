@@ -403,6 +403,8 @@ struct FlatMfmaArgs {
     float *part_d;
     int64_t *part_id;
     uint32_t *gthr;  // [nq] smallest k-th-best distance any row split of the query has reached (row-tile kernel)
+    uint32_t *gslot; // [nq][nslot] slot j = smallest distance seen by any split with split % nslot == j (nslot = k, or 0)
+    int nslot;
 };
 
 template <int QB, int CAP, int TRIG, int DMAX>
@@ -645,6 +647,13 @@ void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
     // it must survive; every row of the final top-k is <= every published k-th, hence never dropped.
     __shared__ int qq_s[QT];
     __shared__ int thq_s[QT];  // filter bound per query in the 'partial distance' domain (see below), INT_MAX = none yet
+    // A tighter shared bound than "some split's k-th best": every split also publishes the SMALLEST distance it
+    // has seen into slot (split % k) of its query (atomicMin).  The k slots then hold k distances of k different
+    // rows (different splits), so their maximum bounds the global k-th best -- with S splits that is roughly the
+    // k-th best of everything scanned so far, S/k times tighter than a single split's k-th.  Needs S >= k.
+    __shared__ uint32_t min_s[QT];   // smallest key this workgroup has pushed per query
+    __shared__ uint32_t bmax_s[QT];  // max over the k slots as last read (KEY_MAX until every slot is filled)
+    if (lane < 32) { min_s[wave * 32 + lj] = KEY_MAX; bmax_s[wave * 32 + lj] = KEY_MAX; }
     if (lane < 32) qq_s[wave * 32 + lj] = qq_l;
     int qi_l = group * QT + wave * 32 + lj;
     qi_l = qi_l < a.nq ? qi_l : a.nq - 1;
@@ -726,6 +735,7 @@ void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
                 if (hit & (1u << e)) {
                     const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                     const uint32_t key = (uint32_t)(qq_s[q] + xx_t - 2 * acc[e]);  // exact, >= 0
+                    if (a.nslot) atomicMin(&min_s[q], key);
                     if (!topk_push<QT, CAP, CAP>(tk, q, key, (uint32_t)(row_begin + lrow), dummy)) pend |= 1u << e;
                 }
             }
@@ -758,7 +768,9 @@ void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
         if (refresh) {  // wave-uniform
             if (lane < 32) {
                 const uint32_t own = tk.thr_x[wave * 32 + lj];
-                const uint32_t sh = g_l == KEY_MAX ? KEY_MAX : g_l + 1u;
+                uint32_t sh = g_l == KEY_MAX ? KEY_MAX : g_l + 1u;
+                const uint32_t bm = bmax_s[wave * 32 + lj];
+                if (bm != KEY_MAX && bm + 1u < sh) sh = bm + 1u;
                 const uint32_t th = own < sh ? own : sh;
                 thq_s[wave * 32 + lj] = th == KEY_MAX ? 0x7fffffff : (int)th - qq_s[wave * 32 + lj];
             }
@@ -802,6 +814,23 @@ void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
             if (t > 0) epilogue(prev, xx_prev, t - 1, u == 0, hit);  // pushes (rare) + threshold refresh
             xx_prev = xx_cur;
             if (u == 0) g_l = __hip_atomic_load(&a.gthr[qi_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // used at the next refresh, PD tiles on
+            if (u == 0 && a.nslot && (t0 & 63) == 0) {  // every 64 tiles: publish this split's minima, fold last round's slot reads
+                if (lane < 32) {
+                    const uint32_t mine = min_s[wave * 32 + lj];
+                    if (mine != KEY_MAX) atomicMin(&a.gslot[(int64_t)qi_l * a.nslot + split % a.nslot], mine);
+                }
+                // per-query maximum over the k slots (KEY_MAX while any slot is empty).  The reads are consumed at
+                // once -- this drains the prefetch ring, once per 16 tiles -- rather than held in registers the
+                // kernel does not have
+                if (lane < 32) bmax_s[wave * 32 + lj] = 0u;
+                for (int idx = lane; idx < 32 * a.nslot; idx += 64) {
+                    const int ql = idx / a.nslot, j = idx - ql * a.nslot;
+                    int qq2 = group * QT + wave * 32 + ql;
+                    qq2 = qq2 < a.nq ? qq2 : a.nq - 1;
+                    const uint32_t v = __hip_atomic_load(&a.gslot[(int64_t)qq2 * a.nslot + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicMax(&bmax_s[wave * 32 + ql], v);
+                }
+            }
             FT_T(1);  // test + pushes + compactions
             park(buf ^ 1, pf[(u + 1) % PD]);
             FT_T(2);  // wait for the prefetched tile + LDS store
@@ -873,12 +902,14 @@ int launch_flat_u8_mfma(int D, const uint8_t *data, const int32_t *norms, int64_
     if (rps < 128) rps = 128;
     a.rows_per_split = rps;
     a.part_d = part_d; a.part_id = part_id; a.gthr = gthr;
+    a.nslot = (qt > 32 && k <= 16 && splits >= 2 * k) ? k : 0;
+    a.gslot = gthr ? gthr + nq : nullptr;
     const int64_t groups = (nq + qt - 1) / qt;
     const int64_t blocks = groups * splits;
     if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "flat_u8_mfma: grid too large");
     if (qt > 32) {
         if (!gthr) return fail(CVTMI_EINVAL, "flat_u8_mfma: threshold scratch missing");
-        CVTMI_HIP(hipMemsetAsync(gthr, 0xff, (size_t)nq * sizeof(uint32_t), st));
+        CVTMI_HIP(hipMemsetAsync(gthr, 0xff, (size_t)nq * (1 + 16) * sizeof(uint32_t), st));  // k-th bests + up to 16 slots per query
     }
     if (qt == 32) {
         const size_t lds = (size_t)qt * (D + 16);
