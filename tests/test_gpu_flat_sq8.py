@@ -87,6 +87,24 @@ def test_flat_u8_mfma_query_tiles(amd, orc, D, nq, k):
     assert np.array_equal(i, oi), (D, nq, k)
 
 
+def test_flat_u8_many_splits_parity(amd, orc):
+    """200 K rows -> 24 row splits of one 128-query workgroup column: the splits exchange their k-th best and, for
+    k <= 16, their minima (k slots per query) to tighten each other's filter; the merged result must still be
+    the oracle's, bit for bit, incl. duplicate rows in different splits."""
+    rng = np.random.default_rng(31)
+    n, D, nq = 200_000, 128, 100
+    db = rng.integers(0, 256, size=(n, D), dtype=np.uint8)
+    q = rng.integers(0, 256, size=(nq, D), dtype=np.uint8)
+    db[150_000] = db[11]; db[199_999] = db[11]; q[1] = db[11]      # ties across splits: ids decide
+    q[2] = db[77_777]
+    ix = amd.FlatIndex(L2U8, D); ix.add(db)
+    for k in (10, 3, 16):
+        d, i = ix.search(q, k)
+        _, odi, oi = orc.flat_search(L2U8, db, q, k)
+        assert np.array_equal(d, odi), k
+        assert np.array_equal(i, oi), k
+
+
 def test_flat_full_size_u8_property(amd):
     """Config 3 shape (512-d uint8) at a size that needs row splits: self-queries come back first with
     distance 0 and the result is invariant to how the rows were appended."""
