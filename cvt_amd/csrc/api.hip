@@ -1126,10 +1126,13 @@ int cvtmi_hnsw_search_dev(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int
     if (nq == 0) return CVTMI_OK;
     if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search: nq too large");
     hipStream_t st = (hipStream_t)stream;
-    int slots = 256 * 7;
+    const int efe0 = ef > k ? ef : k;
+    int per_cu = (150 * 1024) / hnsw_lds_bytes(h->D, efe0);  // query slots (one wave each) a CU's LDS holds
+    per_cu = per_cu > 32 ? 32 : (per_cu < 1 ? 1 : per_cu);
+    int slots = 256 * per_cu;
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) slots = prop.multiProcessorCount * 7;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) slots = prop.multiProcessorCount * per_cu;
     }
     if (slots > nq) slots = (int)nq;
     const int64_t words = (h->g.n + 31) / 32 + 1;
@@ -1192,10 +1195,13 @@ int cvtmi_hnsw_search_adc_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, i
     }
     CVTMI_TRY(opq->s_lut.reserve((size_t)nq * opq->m.M * opq->m.K * sizeof(float)));
     CVTMI_TRY(launch_lut(opq->m, q_rot, nq, nullptr, opq->s_lut.as<float>(), st));
-    int slots = 256 * 4;
+    const int efe0 = ef > k ? ef : k;
+    int per_cu = (150 * 1024) / hnsw_lds_bytes(opq->m.M * opq->m.K, efe0);
+    per_cu = per_cu > 32 ? 32 : (per_cu < 1 ? 1 : per_cu);
+    int slots = 256 * per_cu;
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) slots = prop.multiProcessorCount * 4;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) slots = prop.multiProcessorCount * per_cu;
     }
     if (slots > nq) slots = (int)nq;
     const int64_t words = (h->g.n + 31) / 32 + 1;

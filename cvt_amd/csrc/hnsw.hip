@@ -18,7 +18,7 @@
 namespace cvtmi {
 
 constexpr int HN_EF_MAX = 1024;  // top queue: ef + 1 entries in LDS
-constexpr int HN_LCAP = 1536;    // candidate queue entries kept in LDS; the rest lives in HBM
+constexpr int HN_LCAP = 256;    // candidate queue entries kept in LDS; the rest lives in HBM
 
 struct HnEnt { float d; uint32_t id; };
 
@@ -153,7 +153,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const HnswArgs a)
     extern __shared__ __attribute__((aligned(16))) float hn_smem[];
     const DIST dist{ a, hn_smem };                                     // query state first (padded to 16 bytes)
     HnEnt *top_l = reinterpret_cast<HnEnt *>(hn_smem + dist.smem_floats());
-    HnEnt *cand_l = top_l + (HN_EF_MAX + 1);
+    const int ef_cap = (a.ef > a.k ? a.ef : a.k) + 1;   // the top queue never holds more than ef + 1 entries
+    HnEnt *cand_l = top_l + ef_cap;
     const int lane = threadIdx.x;
     const bool w = lane == 0;
     uint32_t *vis = a.visited + (int64_t)blockIdx.x * a.words;
@@ -293,7 +294,7 @@ int launch_hnsw_search(const HnswDevGraph &g, int metric, const float *q, int64_
     HnswArgs a;
     hnsw_fill_args(a, g, nq, k, ef, out_d, out_label, visited, cand_scratch, words, gcap, err);
     a.q = q;
-    const size_t lds = (size_t)((g.D + 3) & ~3) * sizeof(float) + (size_t)(HN_EF_MAX + 1 + HN_LCAP) * sizeof(HnEnt);
+    const size_t lds = (size_t)((g.D + 3) & ~3) * sizeof(float) + (size_t)((ef > k ? ef : k) + 1 + HN_LCAP) * sizeof(HnEnt);
     const bool ip = metric == CVTMI_METRIC_IP;
     const int lanes = (g.D % 4 != 0) ? 1 : (ip ? 4 : (g.D % 16 == 0 ? 8 : 4));
 #define CVTMI_HN(IPV, L) hipLaunchKernelGGL((hnsw_search_kernel<DistF32<IPV, L> >), dim3((unsigned)slots), dim3(64), lds, st, a)
@@ -313,14 +314,15 @@ int launch_hnsw_search_adc(const HnswDevGraph &g, const float *lut, const uint8_
     HnswArgs a;
     hnsw_fill_args(a, g, nq, k, ef, out_d, out_label, visited, cand_scratch, words, gcap, err);
     a.lut = lut; a.codes = codes; a.M = M; a.K = K;
-    const size_t lds = (size_t)((M * K + 3) & ~3) * sizeof(float) + (size_t)(HN_EF_MAX + 1 + HN_LCAP) * sizeof(HnEnt);
+    const size_t lds = (size_t)((M * K + 3) & ~3) * sizeof(float) + (size_t)((ef > k ? ef : k) + 1 + HN_LCAP) * sizeof(HnEnt);
     CVTMI_HIP(hipFuncSetAttribute((const void *)hnsw_search_kernel<DistADC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((hnsw_search_kernel<DistADC>), dim3((unsigned)slots), dim3(64), lds, st, a);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
 
-int hnsw_lds_bytes(int D) { return (int)(((D + 3) & ~3) * sizeof(float) + (size_t)(HN_EF_MAX + 1 + HN_LCAP) * sizeof(HnEnt)); }
+// LDS bytes of one query slot: query state (floats) + top queue (ef + 1) + the LDS part of the candidate queue
+int hnsw_lds_bytes(int state_floats, int ef) { return (int)(((state_floats + 3) & ~3) * sizeof(float) + (size_t)(ef + 1 + HN_LCAP) * sizeof(HnEnt)); }
 int hnsw_ef_max() { return HN_EF_MAX; }
 int hnsw_lcap() { return HN_LCAP; }
 

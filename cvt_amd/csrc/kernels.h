@@ -130,7 +130,7 @@ int launch_hnsw_search(const HnswDevGraph &g, int metric, const float *q, int64_
 int launch_hnsw_search_adc(const HnswDevGraph &g, const float *lut, const uint8_t *codes, int M, int K, int64_t nq, int k, int ef,
                            float *out_d, int64_t *out_label, uint32_t *visited, void *cand_scratch, int slots, int64_t words,
                            int64_t gcap, int *err, hipStream_t st);
-int hnsw_lds_bytes(int D);
+int hnsw_lds_bytes(int state_floats, int ef);
 int hnsw_ef_max();
 int hnsw_lcap();
 
