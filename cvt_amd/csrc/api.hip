@@ -1142,7 +1142,7 @@ int cvtmi_hnsw_search_dev(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int
     gcap = gcap > hnsw_lcap() ? gcap - hnsw_lcap() : 0;
     gcap += 64;
     CVTMI_TRY(h->s_vis.reserve((size_t)slots * words * 4));
-    CVTMI_TRY(h->s_cand.reserve((size_t)slots * gcap * 8));
+    CVTMI_TRY(h->s_cand.reserve((size_t)slots * (gcap + efe + 1) * 8));  // per slot: spilled top queue + spilled candidates
     CVTMI_TRY(h->s_err.reserve(16));
     CVTMI_HIP(hipMemsetAsync(h->s_err.p, 0, 4, st));
     CVTMI_TRY(launch_hnsw_search(h->g, h->metric, q, nq, k, ef, dist, labels, h->s_vis.as<uint32_t>(), h->s_cand.p, slots, words,
@@ -1211,7 +1211,7 @@ int cvtmi_hnsw_search_adc_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, i
     gcap = gcap > hnsw_lcap() ? gcap - hnsw_lcap() : 0;
     gcap += 64;
     CVTMI_TRY(h->s_vis.reserve((size_t)slots * words * 4));
-    CVTMI_TRY(h->s_cand.reserve((size_t)slots * gcap * 8));
+    CVTMI_TRY(h->s_cand.reserve((size_t)slots * (gcap + efe + 1) * 8));  // per slot: spilled top queue + spilled candidates
     CVTMI_TRY(h->s_err.reserve(16));
     CVTMI_HIP(hipMemsetAsync(h->s_err.p, 0, 4, st));
     CVTMI_TRY(launch_hnsw_search_adc(h->g, opq->s_lut.as<float>(), opq->codes.as<uint8_t>(), opq->m.M, opq->m.K, nq, k, ef, dist,

@@ -74,6 +74,7 @@ struct LdsArr {
     __device__ __forceinline__ HnEnt get(int i) const { return p[i]; }
     __device__ __forceinline__ void set(int i, HnEnt v) const { if (w) p[i] = v; }
 };
+// first HN_LCAP entries (the upper heap levels, touched by every operation) in LDS, the rest in HBM
 struct SplitArr {
     HnEnt *l; HnEnt *g; bool w;
     __device__ __forceinline__ HnEnt get(int i) const { return i < HN_LCAP ? l[i] : g[i - HN_LCAP]; }
@@ -148,18 +149,20 @@ struct DistADC {
 };
 
 template <class DIST>
-__global__ __launch_bounds__(64) void hnsw_search_kernel(const HnswArgs a)
+__global__ __launch_bounds__(64, 8) void hnsw_search_kernel(const HnswArgs a)  // <= 64 VGPRs: 8 waves per SIMD, the traversal lives on queries in flight
 {
     extern __shared__ __attribute__((aligned(16))) float hn_smem[];
     const DIST dist{ a, hn_smem };                                     // query state first (padded to 16 bytes)
     HnEnt *top_l = reinterpret_cast<HnEnt *>(hn_smem + dist.smem_floats());
     const int ef_cap = (a.ef > a.k ? a.ef : a.k) + 1;   // the top queue never holds more than ef + 1 entries
-    HnEnt *cand_l = top_l + ef_cap;
+    HnEnt *cand_l = top_l + (ef_cap < HN_LCAP ? ef_cap : HN_LCAP);
     const int lane = threadIdx.x;
     const bool w = lane == 0;
     uint32_t *vis = a.visited + (int64_t)blockIdx.x * a.words;
-    const LdsArr top{ top_l, w };
-    const SplitArr cand{ cand_l, a.cand_g + (int64_t)blockIdx.x * a.gcap, w };
+    // per-slot HBM scratch: [top queue past HN_LCAP: ef + 1 entries][candidate queue past HN_LCAP: gcap entries]
+    HnEnt *slot_g = a.cand_g + (int64_t)blockIdx.x * (a.gcap + ef_cap);
+    const SplitArr top{ top_l, slot_g, w };
+    const SplitArr cand{ cand_l, slot_g + ef_cap, w };
     const int ef = a.ef > a.k ? a.ef : a.k;
     const int64_t cand_cap = HN_LCAP + a.gcap;
 
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const HnswArgs a)
             if (w) vis[cur >> 5] |= 1u << (cur & 31);
             __builtin_amdgcn_s_waitcnt(0);
         }
-        float lower = top_l[0].d;
+        float lower = top.get(0).d;
         bool overflow = false;
         while (cand_n > 0) {
             const HnEnt c = cand.get(0);
@@ -294,7 +297,7 @@ int launch_hnsw_search(const HnswDevGraph &g, int metric, const float *q, int64_
     HnswArgs a;
     hnsw_fill_args(a, g, nq, k, ef, out_d, out_label, visited, cand_scratch, words, gcap, err);
     a.q = q;
-    const size_t lds = (size_t)((g.D + 3) & ~3) * sizeof(float) + (size_t)((ef > k ? ef : k) + 1 + HN_LCAP) * sizeof(HnEnt);
+    const size_t lds = (size_t)hnsw_lds_bytes(g.D, ef > k ? ef : k);
     const bool ip = metric == CVTMI_METRIC_IP;
     const int lanes = (g.D % 4 != 0) ? 1 : (ip ? 4 : (g.D % 16 == 0 ? 8 : 4));
 #define CVTMI_HN(IPV, L) hipLaunchKernelGGL((hnsw_search_kernel<DistF32<IPV, L> >), dim3((unsigned)slots), dim3(64), lds, st, a)
@@ -314,7 +317,7 @@ int launch_hnsw_search_adc(const HnswDevGraph &g, const float *lut, const uint8_
     HnswArgs a;
     hnsw_fill_args(a, g, nq, k, ef, out_d, out_label, visited, cand_scratch, words, gcap, err);
     a.lut = lut; a.codes = codes; a.M = M; a.K = K;
-    const size_t lds = (size_t)((M * K + 3) & ~3) * sizeof(float) + (size_t)((ef > k ? ef : k) + 1 + HN_LCAP) * sizeof(HnEnt);
+    const size_t lds = (size_t)hnsw_lds_bytes(M * K, ef > k ? ef : k);
     CVTMI_HIP(hipFuncSetAttribute((const void *)hnsw_search_kernel<DistADC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((hnsw_search_kernel<DistADC>), dim3((unsigned)slots), dim3(64), lds, st, a);
     CVTMI_HIP(hipGetLastError());
@@ -322,7 +325,11 @@ int launch_hnsw_search_adc(const HnswDevGraph &g, const float *lut, const uint8_
 }
 
 // LDS bytes of one query slot: query state (floats) + top queue (ef + 1) + the LDS part of the candidate queue
-int hnsw_lds_bytes(int state_floats, int ef) { return (int)(((state_floats + 3) & ~3) * sizeof(float) + (size_t)(ef + 1 + HN_LCAP) * sizeof(HnEnt)); }
+int hnsw_lds_bytes(int state_floats, int ef)
+{
+    const int top = ef + 1 < HN_LCAP ? ef + 1 : HN_LCAP;
+    return (int)(((state_floats + 3) & ~3) * sizeof(float) + (size_t)(top + HN_LCAP) * sizeof(HnEnt));
+}
 int hnsw_ef_max() { return HN_EF_MAX; }
 int hnsw_lcap() { return HN_LCAP; }
 
