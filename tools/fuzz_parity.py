@@ -52,5 +52,37 @@ for it in range(iters):
     _, odi, oi = orc.flat_search(2, xu, qu, ku)
     if not (np.array_equal(i, oi) and np.array_equal(d, odi)):
         print("MISMATCH u8", dict(it=it, D=Du, n=nf, nq=nqf, k=ku)); sys.exit(1)
+    # encode (coarse + PQ), IVF query with per-video min, SQ8, k-means
+    De = int(rng.choice([128, 64, 32])); Me = int(rng.choice([16, 8, 4])); Ke = int(rng.choice([256, 100])); cK = int(rng.choice([1, 7, 40]))
+    ne = int(rng.integers(50, 5000)); img = int(rng.integers(1, 30))
+    xe = rng.normal(size=(ne, De)).astype(np.float32)
+    coarse = np.zeros((1, De), np.float32) if cK == 1 else rng.normal(size=(cK, De)).astype(np.float32)
+    be = (rng.normal(size=(Me, Ke, De // Me))).astype(np.float32)
+    ie = cvt_amd.OpqIndex(coarse, be)
+    lists, ce = ie.encode(xe)
+    ol, oc = orc.pq_encode(xe, coarse, be)
+    if not (np.array_equal(ce, oc) and (cK == 1 or np.array_equal(lists, ol))):
+        print("MISMATCH encode", dict(it=it, D=De, M=Me, K=Ke, coarseK=cK, n=ne)); sys.exit(1)
+    vid = rng.integers(0, img, size=ne).astype(np.int32)
+    ie.add_codes(ce, list_id=ol if cK > 1 else None, video_id=vid)
+    qe = rng.normal(size=(int(rng.integers(1, 12)), De)).astype(np.float32) * 0.3
+    nk = int(rng.integers(1, min(cK, 5) + 1))
+    ms = ie.query_video(qe, nk, img, rotate=False)
+    order = np.argsort(ol if cK > 1 else np.zeros(ne, np.int32), kind="stable")
+    off = np.concatenate([[0], np.cumsum(np.bincount((ol if cK > 1 else np.zeros(ne, np.int64))[order], minlength=cK))]).astype(np.int64)
+    oms = orc.query_video(qe, coarse, be, nk, off, oc[order], vid[order], img)
+    if not np.array_equal(bits(ms), bits(oms)):
+        print("MISMATCH query_video", dict(it=it, D=De, M=Me, K=Ke, coarseK=cK, n=ne, nk=nk, img=img)); sys.exit(1)
+    ds = int(rng.choice([512, 64, 300, 20])); ns = int(rng.integers(1, 3000))
+    xs = (rng.normal(size=(ns, ds)) * np.exp2(rng.integers(-8, 8, size=(ns, ds)))).astype(np.float32)
+    l2 = bool(rng.integers(0, 2))
+    vm, vd = cvt_amd.sq8_train(xs, l2norm=l2); ovm, ovd = orc.sq8_train(xs, l2norm=l2)
+    xg = xs.copy(); cs = cvt_amd.sq8_encode(vm, vd, xg, l2norm=l2); ocs, ox = orc.sq8_encode(vm, vd, xs, l2norm=l2)
+    if not (np.array_equal(bits(vm), bits(ovm)) and np.array_equal(bits(vd), bits(ovd)) and np.array_equal(cs, ocs) and np.array_equal(bits(xg), bits(ox))
+            and np.array_equal(bits(cvt_amd.sq8_decode(vm, vd, cs)), bits(orc.sq8_decode(vm, vd, cs)))):
+        print("MISMATCH sq8", dict(it=it, d=ds, n=ns, l2=l2)); sys.exit(1)
+    kk = int(rng.integers(1, min(64, ne))); gc, ga, git = cvt_amd.kmeans(xe, kk, 4, it + 1); oc2, oa2, oit = orc.kmeans(xe, kk, 4, it + 1)
+    if not (git == oit and np.array_equal(ga, oa2) and np.array_equal(bits(gc), bits(oc2))):
+        print("MISMATCH kmeans", dict(it=it, n=ne, d=De, k=kk)); sys.exit(1)
     print("iter %d ok (adc M=%d K=%d n=%d nq=%d k=%d | flat D=%d n=%d nq=%d k=%d | u8 D=%d k=%d)" % (it, M, K, n, nq, k, Df, nf, nqf, kf, Du, ku), flush=True)
 print("fuzz: %d iterations, no mismatch" % iters)
