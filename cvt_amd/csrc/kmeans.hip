@@ -66,8 +66,72 @@ __global__ __launch_bounds__(kBlock) void kmeans_assign_kernel(const float *__re
         ch = assign[row] != bi;
         assign[row] = bi;
     }
-    const unsigned long long m = __ballot(ch);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(changed, (unsigned long long)__popcll(m));
+    if (changed) {
+        const unsigned long long m = __ballot(ch);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(changed, (unsigned long long)__popcll(m));
+    }
+}
+
+// d <= 128: the row stays in registers for the whole launch (the kernel above re-reads it from memory for every
+// tile of 16 centroids, one 4-byte load per dimension and lane at a row stride: as many loads as arithmetic),
+// and two centroids ride in the halves of every packed-fp32 register (x broadcast to both).  Same sub, mul, add
+// per (row, centroid, dimension) in ascending dimension order, same first-minimum rule: same bits.
+template <int DMAX>
+__global__ __launch_bounds__(kBlock) void kmeans_assign_reg_kernel(const float *__restrict__ x, int64_t ld, int64_t n, int d,
+                                                                   const float *__restrict__ cent, int k,
+                                                                   int32_t *__restrict__ assign,
+                                                                   unsigned long long *__restrict__ changed)
+{
+    __shared__ __attribute__((aligned(16))) float cen[DMAX][KM_CT];  // transposed: [dim][centroid]
+    const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = row < n;
+    const float *xr = x + (valid ? row : 0) * ld;
+    float xv[DMAX];
+#pragma unroll
+    for (int dd = 0; dd < DMAX; ++dd) xv[dd] = dd < d ? xr[dd] : 0.0f;
+    float best = kKmStart;
+    int bi = -1;
+    for (int c0 = 0; c0 < k; c0 += KM_CT) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < DMAX * KM_CT; i += kBlock) {
+            const int c = i / DMAX, dd = i - c * DMAX;  // coalesced along the dimension
+            float v = 0.0f;
+            if (c0 + c < k && dd < d) v = cent[(int64_t)(c0 + c) * d + dd];
+            cen[dd][c] = v;
+        }
+        __syncthreads();
+        float2 acc[KM_CT / 2];
+#pragma unroll
+        for (int p = 0; p < KM_CT / 2; ++p) acc[p] = make_float2(0.0f, 0.0f);
+#pragma unroll
+        for (int dd = 0; dd < DMAX; ++dd) {
+            if (dd < d) {  // wave-uniform
+                const float2 xb = make_float2(xv[dd], xv[dd]);
+                const float4 *cp = reinterpret_cast<const float4 *>(&cen[dd][0]);
+#pragma unroll
+                for (int g = 0; g < KM_CT / 4; ++g) {
+                    const float4 c4 = cp[g];  // broadcast read: 4 centroids of this dimension
+                    const float2 t0 = xb - make_float2(c4.x, c4.y), t1 = xb - make_float2(c4.z, c4.w);
+                    acc[2 * g] = acc[2 * g] + t0 * t0;
+                    acc[2 * g + 1] = acc[2 * g + 1] + t1 * t1;
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < KM_CT / 2; ++p) {
+            if (c0 + 2 * p < k && acc[p].x < best) { best = acc[p].x; bi = c0 + 2 * p; }
+            if (c0 + 2 * p + 1 < k && acc[p].y < best) { best = acc[p].y; bi = c0 + 2 * p + 1; }
+        }
+    }
+    bool ch = false;
+    if (valid) {
+        ch = assign[row] != bi;
+        assign[row] = bi;
+    }
+    if (changed) {
+        const unsigned long long m = __ballot(ch);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(changed, (unsigned long long)__popcll(m));
+    }
 }
 
 constexpr int KM_DPL = 8;  // dimensions per lane of the update: d <= 512
@@ -145,7 +209,13 @@ int launch_kmeans_assign(const float *x, int64_t ld, int64_t n, int d, const flo
     if (n <= 0) return CVTMI_OK;
     const int64_t blocks = (n + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "kmeans: n too large");
-    hipLaunchKernelGGL(kmeans_assign_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, ld, n, d, cent, k, assign, changed);
+    const dim3 g((unsigned)blocks), b(kBlock);
+    if (d <= 8) hipLaunchKernelGGL(kmeans_assign_reg_kernel<8>, g, b, 0, st, x, ld, n, d, cent, k, assign, changed);
+    else if (d <= 16) hipLaunchKernelGGL(kmeans_assign_reg_kernel<16>, g, b, 0, st, x, ld, n, d, cent, k, assign, changed);
+    else if (d <= 32) hipLaunchKernelGGL(kmeans_assign_reg_kernel<32>, g, b, 0, st, x, ld, n, d, cent, k, assign, changed);
+    else if (d <= 64) hipLaunchKernelGGL(kmeans_assign_reg_kernel<64>, g, b, 0, st, x, ld, n, d, cent, k, assign, changed);
+    else if (d <= 128) hipLaunchKernelGGL(kmeans_assign_reg_kernel<128>, g, b, 0, st, x, ld, n, d, cent, k, assign, changed);
+    else hipLaunchKernelGGL(kmeans_assign_kernel, g, b, 0, st, x, ld, n, d, cent, k, assign, changed);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

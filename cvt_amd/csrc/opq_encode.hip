@@ -75,6 +75,9 @@ __global__ __launch_bounds__(kBlock) void coarse_assign_kernel(const float *__re
 int launch_coarse_assign(const OpqModelDev &m, const float *x_rot, int64_t n, int32_t *list_id, hipStream_t st)
 {
     if (n <= 0) return CVTMI_OK;
+    // the k-means assignment kernel is this computation (same arithmetic, same first-minimum rule); for D <= 128
+    // it keeps the row in registers and packs two centroids per instruction (kmeans.hip)
+    if (m.D <= 128) return launch_kmeans_assign(x_rot, m.D, n, m.D, m.coarse, m.coarseK, list_id, nullptr, st);
     const int64_t blocks = (n + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "coarse_assign: n too large");
     hipLaunchKernelGGL(coarse_assign_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, x_rot, n, m.D, m.coarse,
