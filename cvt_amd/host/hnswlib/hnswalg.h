@@ -1,75 +1,146 @@
-// HierarchicalNSW<float> -- search-side mirror of hnsw_sifts_retrieval/hnswlib/hnswalg.h above the C ABI.
-// Same constructor for a saved graph (space, location), loadIndex, setEf, searchKnn with the reference's
-// return type; the traversal runs on the MI355X (cvtmi_hnsw_search) and returns the reference's labels and
-// distances bit for bit.  searchKnnBatch is the call that fills the GPU: one wave per query.
-// Graph CONSTRUCTION (addPoint on an empty index, saveIndex) is not offered in this build: graphs are
-// built and saved with the reference's tools; the members say so loudly instead of falling back to a host
-// implementation.
+// HierarchicalNSW<float> -- mirror of hnsw_sifts_retrieval/hnswlib/hnswalg.h above the C ABI.
+//
+//  * SEARCH runs on the MI355X (cvtmi_hnsw_search: one wave per query, the reference's labels and distances
+//    bit for bit).  searchKnnBatch is the call that fills the GPU.
+//  * CONSTRUCTION is a host algorithm in the reference (one insertion at a time, every insertion sees the
+//    graph the previous ones left) and stays one here: addPoint follows hnswalg.h:584-684 -- level drawn from
+//    std::default_random_engine(100) (:139-149), greedy descent through the upper levels, a best-first search
+//    with ef_construction on every level the new node lives on (:152-216), neighbour selection by the
+//    "closer to the query than to any already selected neighbour" rule (:283-325), mutual links with
+//    re-selection when a neighbour's list is full (:340-440).  The queues are the same std::priority_queue
+//    types with the same comparators as the reference's, so ties fall the same way, and saveIndex writes the
+//    reference's file layout (:491-519): a graph built here is byte-identical to one built by the reference
+//    from the same rows in the same order (tests/test_oracle_golden.py).  The graph is uploaded to the GPU
+//    lazily, on the first search after a change.
+//
+// Host data layout is the mirror's own (separate arrays for vectors / links / labels); only the file is the
+// reference's interleaved block.
 #pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
 #include <fstream>
+#include <random>
+#include <unordered_set>
 #include <vector>
 
 #include "../../../include/cvtmi.h"
 
 namespace hnswlib {
+typedef unsigned int tableint;
+
 template <typename dist_t> class HierarchicalNSW : public AlgorithmInterface<dist_t> {
+    typedef std::pair<dist_t, tableint> Cand;
+    struct ByDist {
+        bool operator()(const Cand &a, const Cand &b) const { return a.first < b.first; }
+    };
+    typedef std::priority_queue<Cand, std::vector<Cand>, ByDist> DistHeap;  // max-heap on the distance only
+
 public:
-    HierarchicalNSW(SpaceInterface<dist_t> *s) : h_(NULL), ef_(10), dim_(0) { (void)s; }
-    HierarchicalNSW(SpaceInterface<dist_t> *s, const std::string &location, bool nmslib = false) : h_(NULL), ef_(10), dim_(0)
+    HierarchicalNSW(SpaceInterface<dist_t> *s) : dev_(NULL) { bind(s); }
+    HierarchicalNSW(SpaceInterface<dist_t> *s, const std::string &location, bool nmslib = false) : dev_(NULL)
     {
         (void)nmslib;
         loadIndex(location, s);
     }
-    HierarchicalNSW(SpaceInterface<dist_t> *, size_t, size_t = 16, size_t = 200) : h_(NULL), ef_(10), dim_(0)
+    HierarchicalNSW(SpaceInterface<dist_t> *s, size_t max_elements, size_t M = 16, size_t ef_construction = 200) : dev_(NULL)
     {
-        throw std::runtime_error("cvt_amd: HierarchicalNSW graph construction is not offered on the MI355X build; "
-                                 "build and save the graph with the reference's tools, then load it here");
+        bind(s);
+        cap_ = max_elements;
+        M_ = M; maxM_ = M; maxM0_ = 2 * M;
+        efc_ = std::max(ef_construction, M_);
+        mult_ = 1 / log(1.0 * M_);
+        vec_.assign(cap_ * dim_, 0.0f);
+        label_.assign(cap_, 0);
+        level_.assign(cap_, 0);
+        link0_.assign(cap_ * (maxM0_ + 1), 0u);
+        upper_.assign(cap_, std::vector<tableint>());
     }
     ~HierarchicalNSW()
     {
-        if (h_) cvtmi_hnsw_destroy(h_);
+        if (dev_) cvtmi_hnsw_destroy(dev_);
     }
 
     void setEf(size_t ef) { ef_ = ef; }
+    size_t ntotal() const { return count_; }
+
+    // ---- construction (host) ----
+    void addPoint(void *data_point, labeltype label)
+    {
+        if (count_ >= cap_) throw std::runtime_error("The number of elements exceeds the specified limit");
+        const tableint id = (tableint)count_++;
+        const float *x = (const float *)data_point;
+        std::uniform_real_distribution<double> u01(0.0, 1.0);
+        const int lvl = (int)(-log(u01(rng_)) * mult_);
+        level_[id] = lvl;
+        std::copy(x, x + dim_, &vec_[(size_t)id * dim_]);
+        label_[id] = label;
+        std::fill(&link0_[(size_t)id * (maxM0_ + 1)], &link0_[(size_t)(id + 1) * (maxM0_ + 1)], 0u);
+        upper_[id].assign((size_t)lvl * (maxM_ + 1), 0u);
+        dirty_ = true;
+        if (entry_ < 0) {  // the first element only seeds the graph
+            entry_ = 0;
+            top_level_ = lvl;
+            return;
+        }
+        const int top = top_level_;
+        tableint cur = (tableint)entry_;
+        if (lvl < top) {  // greedy descent to the first level the new node lives on
+            dist_t cd = dist(x, row(cur));
+            for (int l = top; l > lvl; --l) {
+                bool moved = true;
+                while (moved) {
+                    moved = false;
+                    const tableint *ll = links(cur, l);
+                    for (tableint i = 0; i < ll[0]; ++i) {
+                        const dist_t d = dist(x, row(ll[1 + i]));
+                        if (d < cd) { cd = d; cur = ll[1 + i]; moved = true; }
+                    }
+                }
+            }
+        }
+        for (int l = std::min(lvl, top); l >= 0; --l) {  // every search starts from the same entry (:660-667)
+            DistHeap found = search_level(cur, x, l);
+            connect(id, found, l);
+        }
+        if (lvl > top) { entry_ = (int)id; top_level_ = lvl; }
+    }
+
+    // the reference's file (:491-519)
+    void saveIndex(const std::string &location)
+    {
+        const std::vector<char> bytes = serialise();
+        std::ofstream out(location, std::ios::binary);
+        out.write(bytes.data(), (std::streamsize)bytes.size());
+    }
 
     void loadIndex(const std::string &location, SpaceInterface<dist_t> *s)
     {
+        bind(s);
         std::ifstream in(location, std::ios::binary | std::ios::ate);
         if (!in) throw std::runtime_error("Cannot open file " + location);
         const std::streamsize bytes = in.tellg();
         in.seekg(0);
         std::vector<char> buf((size_t)bytes);
         in.read(buf.data(), bytes);
-        dim_ = s->get_data_size() / sizeof(float);
-        if (h_) { cvtmi_hnsw_destroy(h_); h_ = NULL; }
-        if (cvtmi_hnsw_load(buf.data(), (int64_t)bytes, s->device_metric(), (int)dim_, &h_) != CVTMI_OK)
-            throw std::runtime_error(std::string("cvt_amd: ") + cvtmi_last_error());
+        parse(buf);
         ef_ = 10;  // hnswalg.h:560
+        dirty_ = true;
     }
 
-    void addPoint(void *, labeltype)
-    {
-        throw std::runtime_error("cvt_amd: HierarchicalNSW::addPoint is not offered on the MI355X build");
-    }
-    void saveIndex(const std::string &)
-    {
-        throw std::runtime_error("cvt_amd: HierarchicalNSW::saveIndex is not offered on the MI355X build");
-    }
-
-    // hnswalg.h:688-729
+    // ---- search (device) ----
     std::priority_queue<std::pair<dist_t, labeltype> > searchKnn(void *query_data, size_t k)
     {
-        std::vector<std::priority_queue<std::pair<dist_t, labeltype> > > r = searchKnnBatch(query_data, 1, k);
-        return r[0];
+        return searchKnnBatch(query_data, 1, k)[0];
     }
 
-    // nq queries, contiguous [nq][dim] floats: what keeps the GPU busy
+    // nq queries, contiguous [nq][dim] floats
     std::vector<std::priority_queue<std::pair<dist_t, labeltype> > > searchKnnBatch(const void *queries, size_t nq, size_t k)
     {
-        if (!h_) throw std::runtime_error("cvt_amd: HierarchicalNSW: no graph loaded");
+        upload();
         std::vector<float> d(nq * k);
         std::vector<int64_t> l(nq * k);
-        if (cvtmi_hnsw_search(h_, (const float *)queries, (int64_t)nq, (int)k, (int)ef_, d.data(), l.data()) != CVTMI_OK)
+        if (cvtmi_hnsw_search(dev_, (const float *)queries, (int64_t)nq, (int)k, (int)ef_, d.data(), l.data()) != CVTMI_OK)
             throw std::runtime_error(std::string("cvt_amd: ") + cvtmi_last_error());
         std::vector<std::priority_queue<std::pair<dist_t, labeltype> > > out(nq);
         for (size_t q = 0; q < nq; ++q)
@@ -77,10 +148,224 @@ public:
         return out;
     }
 
-    size_t ntotal() const { return h_ ? (size_t)cvtmi_hnsw_ntotal(h_) : 0; }
-
 private:
-    cvtmi_hnsw_t h_;
-    size_t ef_, dim_;
+    void bind(SpaceInterface<dist_t> *s)
+    {
+        dim_ = s->get_data_size() / sizeof(float);
+        metric_ = s->device_metric();
+        if (metric_ != CVTMI_METRIC_IP && metric_ != CVTMI_METRIC_L2F)
+            throw std::runtime_error("cvt_amd: HierarchicalNSW needs InnerProductSpace or L2Space");
+    }
+    const float *row(tableint id) const { return &vec_[(size_t)id * dim_]; }
+    tableint *links(tableint id, int l) { return l == 0 ? &link0_[(size_t)id * (maxM0_ + 1)] : &upper_[id][(size_t)(l - 1) * (maxM_ + 1)]; }
+
+    // Distances in the summation order of the reference's own functions for this width (space_ip.h: one 4-lane
+    // accumulator for D % 4 == 0, the AVX branches are compiled out; space_l2.h: 8 lanes for D % 16 == 0, 4 for
+    // D % 4 == 0), so that construction takes the decisions the reference takes.
+    dist_t dist(const float *a, const float *b) const
+    {
+        const size_t n = dim_;
+        if (n % 4 != 0) {
+            float r = 0;
+            if (metric_ == CVTMI_METRIC_IP) { for (size_t i = 0; i < n; ++i) r += a[i] * b[i]; return 1.0f - r; }
+            for (size_t i = 0; i < n; ++i) { const float t = a[i] - b[i]; r += t * t; }
+            return r;
+        }
+        const size_t lanes = (metric_ == CVTMI_METRIC_IP) ? 4 : (n % 16 == 0 ? 8 : 4);
+        float acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (metric_ == CVTMI_METRIC_IP) {
+            for (size_t i = 0; i < n; i += lanes)
+                for (size_t l = 0; l < lanes; ++l) acc[l] += a[i + l] * b[i + l];
+        } else {
+            for (size_t i = 0; i < n; i += lanes)
+                for (size_t l = 0; l < lanes; ++l) { const float t = a[i + l] - b[i + l]; acc[l] += t * t; }
+        }
+        float s = acc[0];
+        for (size_t l = 1; l < lanes; ++l) s += acc[l];
+        return metric_ == CVTMI_METRIC_IP ? 1.0f - s : s;
+    }
+
+    // best-first search on one level with ef_construction results (:152-216)
+    DistHeap search_level(tableint start, const float *x, int l)
+    {
+        if (seen_.size() < cap_) seen_.assign(cap_, 0);
+        if (++stamp_ == 0) { std::fill(seen_.begin(), seen_.end(), 0); stamp_ = 1; }
+        DistHeap best, frontier;
+        const dist_t d0 = dist(x, row(start));
+        best.emplace(d0, start);
+        frontier.emplace(-d0, start);
+        seen_[start] = stamp_;
+        dist_t bound = d0;
+        while (!frontier.empty()) {
+            const Cand c = frontier.top();
+            if (-c.first > bound) break;
+            frontier.pop();
+            const tableint *ll = links(c.second, l);
+            for (tableint j = 0; j < ll[0]; ++j) {
+                const tableint nb = ll[1 + j];
+                if (seen_[nb] == stamp_) continue;
+                seen_[nb] = stamp_;
+                const dist_t d = dist(x, row(nb));
+                if (best.top().first > d || best.size() < efc_) {
+                    frontier.emplace(-d, nb);
+                    best.emplace(d, nb);
+                    if (best.size() > efc_) best.pop();
+                    bound = best.top().first;
+                }
+            }
+        }
+        return best;
+    }
+
+    // keep at most m of the candidates: nearest first, a candidate survives when it is closer to the query point
+    // than to every neighbour kept so far (:283-325).  Untouched when fewer than m candidates.
+    void select(DistHeap &cands, size_t m)
+    {
+        if (cands.size() < m) return;
+        std::priority_queue<Cand> nearest;  // (negated distance, id): largest first = nearest first
+        while (!cands.empty()) { nearest.emplace(-cands.top().first, cands.top().second); cands.pop(); }
+        std::vector<Cand> kept;
+        while (!nearest.empty() && kept.size() < m) {
+            const Cand c = nearest.top();
+            nearest.pop();
+            const dist_t to_query = -c.first;
+            bool ok = true;
+            for (size_t i = 0; i < kept.size() && ok; ++i)
+                if (dist(row(kept[i].second), row(c.second)) < to_query) ok = false;
+            if (ok) kept.push_back(c);
+        }
+        for (size_t i = 0; i < kept.size(); ++i) cands.emplace(-kept[i].first, kept[i].second);
+    }
+
+    // links of the new node on level l, and the back links (:340-440)
+    void connect(tableint id, DistHeap found, int l)
+    {
+        const size_t room = l ? maxM_ : maxM0_;
+        select(found, M_);
+        if (found.size() > M_) throw std::runtime_error("Should be not be more than M_ candidates returned by the heuristic");
+        std::vector<tableint> chosen;
+        while (!found.empty()) { chosen.push_back(found.top().second); found.pop(); }
+        tableint *mine = links(id, l);
+        if (mine[0]) throw std::runtime_error("The newly inserted element should have blank link list");
+        mine[0] = (tableint)chosen.size();
+        for (size_t i = 0; i < chosen.size(); ++i) {
+            if (l > level_[chosen[i]]) throw std::runtime_error("Trying to make a link on a non-existent level");
+            mine[1 + i] = chosen[i];
+        }
+        for (size_t i = 0; i < chosen.size(); ++i) {
+            const tableint other = chosen[i];
+            if (other == id) throw std::runtime_error("Trying to connect an element to itself");
+            tableint *ol = links(other, l);
+            const size_t have = ol[0];
+            if (have > room) throw std::runtime_error("Bad value of sz_link_list_other");
+            if (have < room) {
+                ol[1 + have] = id;
+                ol[0] = (tableint)(have + 1);
+            } else {  // full: re-select among its neighbours and the new node
+                DistHeap pool;
+                pool.emplace(dist(row(id), row(other)), id);
+                for (size_t j = 0; j < have; ++j) pool.emplace(dist(row(ol[1 + j]), row(other)), ol[1 + j]);
+                select(pool, room);
+                size_t w = 0;
+                while (!pool.empty()) { ol[1 + w++] = pool.top().second; pool.pop(); }
+                ol[0] = (tableint)w;
+            }
+        }
+    }
+
+    // ---- the reference's file image ----
+    template <typename T> static void put(std::vector<char> &b, const T &v)
+    {
+        const char *p = (const char *)&v;
+        b.insert(b.end(), p, p + sizeof(T));
+    }
+    std::vector<char> serialise() const
+    {
+        const size_t link0_bytes = maxM0_ * sizeof(tableint) + sizeof(unsigned int);
+        const size_t per_elem = link0_bytes + dim_ * sizeof(float) + sizeof(labeltype);
+        const size_t off_level0 = 0, off_data = link0_bytes, off_label = link0_bytes + dim_ * sizeof(float);
+        const size_t upper_bytes = maxM_ * sizeof(tableint) + sizeof(unsigned int);
+        std::vector<char> b;
+        b.reserve(96 + cap_ * per_elem + cap_ * 4);
+        put(b, off_level0); put(b, (size_t)cap_); put(b, (size_t)count_); put(b, per_elem); put(b, off_label); put(b, off_data);
+        put(b, (int)top_level_); put(b, (tableint)entry_);
+        put(b, (size_t)maxM_); put(b, (size_t)maxM0_); put(b, (size_t)M_); put(b, (double)mult_); put(b, (size_t)efc_);
+        const size_t base = b.size();
+        b.resize(base + cap_ * per_elem, 0);  // unused elements stay zero (the reference leaves them as malloc returned them)
+        for (size_t i = 0; i < count_; ++i) {
+            char *e = &b[base + i * per_elem];
+            memcpy(e, &link0_[i * (maxM0_ + 1)], link0_bytes);
+            memcpy(e + off_data, &vec_[i * dim_], dim_ * sizeof(float));
+            memcpy(e + off_label, &label_[i], sizeof(labeltype));
+        }
+        for (size_t i = 0; i < cap_; ++i) {
+            const unsigned int sz = (i < count_ && level_[i] > 0) ? (unsigned int)(upper_bytes * (size_t)level_[i]) : 0u;
+            put(b, sz);
+            if (sz) {
+                const char *p = (const char *)upper_[i].data();
+                b.insert(b.end(), p, p + sz);
+            }
+        }
+        return b;
+    }
+    void parse(const std::vector<char> &buf)
+    {
+        if (buf.size() < 96) throw std::runtime_error("cvt_amd: not a saveIndex file");
+        const char *p = buf.data();
+        size_t off_level0, per_elem, off_label, off_data, a, b2, c, efc;
+        int maxlevel; tableint ep; double mult;
+        auto get = [&](void *dst, size_t nb) { memcpy(dst, p, nb); p += nb; };
+        get(&off_level0, 8); get(&cap_, 8); get(&count_, 8); get(&per_elem, 8); get(&off_label, 8); get(&off_data, 8);
+        get(&maxlevel, 4); get(&ep, 4); get(&a, 8); get(&b2, 8); get(&c, 8); get(&mult, 8); get(&efc, 8);
+        maxM_ = a; maxM0_ = b2; M_ = c; mult_ = mult; efc_ = efc; top_level_ = maxlevel; entry_ = count_ ? (int)ep : -1;
+        if (per_elem != 4 + 4 * maxM0_ + 4 * dim_ + 8 || buf.size() < 96 + cap_ * per_elem)
+            throw std::runtime_error("cvt_amd: saveIndex file does not match the space's dimension");
+        vec_.assign(cap_ * dim_, 0.0f); label_.assign(cap_, 0); level_.assign(cap_, 0);
+        link0_.assign(cap_ * (maxM0_ + 1), 0u); upper_.assign(cap_, std::vector<tableint>());
+        for (size_t i = 0; i < count_; ++i) {
+            const char *e = p + i * per_elem;
+            memcpy(&link0_[i * (maxM0_ + 1)], e + off_level0, 4 + 4 * maxM0_);
+            memcpy(&vec_[i * dim_], e + off_data, 4 * dim_);
+            memcpy(&label_[i], e + off_label, 8);
+        }
+        p += cap_ * per_elem;
+        const size_t upper_bytes = 4 * maxM_ + 4;
+        for (size_t i = 0; i < cap_; ++i) {
+            if (p + 4 > buf.data() + buf.size()) throw std::runtime_error("cvt_amd: truncated saveIndex file");
+            unsigned int sz; get(&sz, 4);
+            if (sz) {
+                if (p + sz > buf.data() + buf.size() || sz % upper_bytes) throw std::runtime_error("cvt_amd: corrupt saveIndex file");
+                if (i < count_) {
+                    level_[i] = (int)(sz / upper_bytes);
+                    upper_[i].resize(sz / 4);
+                    memcpy(upper_[i].data(), p, sz);
+                }
+                p += sz;
+            }
+        }
+    }
+    void upload()
+    {
+        if (!dirty_ && dev_) return;
+        if (dev_) { cvtmi_hnsw_destroy(dev_); dev_ = NULL; }
+        const std::vector<char> bytes = serialise();
+        if (cvtmi_hnsw_load(bytes.data(), (int64_t)bytes.size(), metric_, (int)dim_, &dev_) != CVTMI_OK)
+            throw std::runtime_error(std::string("cvt_amd: ") + cvtmi_last_error());
+        dirty_ = false;
+    }
+
+    size_t dim_ = 0, cap_ = 0, count_ = 0, M_ = 16, maxM_ = 16, maxM0_ = 32, efc_ = 200, ef_ = 10;
+    int metric_ = 0, entry_ = -1, top_level_ = -1;
+    double mult_ = 0;
+    std::vector<float> vec_;
+    std::vector<labeltype> label_;
+    std::vector<int> level_;
+    std::vector<tableint> link0_;                 // [cap][maxM0 + 1]: count, neighbours
+    std::vector<std::vector<tableint> > upper_;   // per node: levels x (maxM + 1)
+    std::vector<unsigned short> seen_;
+    unsigned short stamp_ = 0;
+    std::default_random_engine rng_ = std::default_random_engine(100);  // hnswalg.h:139
+    cvtmi_hnsw_t dev_;
+    bool dirty_ = true;
 };
 }  // namespace hnswlib

@@ -1,7 +1,7 @@
 // hnswlib.h -- the plugin interfaces of the reference (brute_force_search/src/hnswlib.hpp:22-58), unchanged in
 // shape: SpaceInterface<MTYPE>, DISTFUNC<MTYPE>, AlgorithmInterface<dist_t>, labeltype.  A space additionally
-// says which device metric it stands for; distances are evaluated by the HIP kernels behind
-// BruteforceSearch, never by a host loop.
+// says which device metric it stands for; searches evaluate distances in the HIP kernels, never in a host loop
+// (the one host algorithm is HNSW graph construction, hnswalg.h, sequential in the reference as well).
 #pragma once
 #include <queue>
 #include <stdexcept>

@@ -163,3 +163,23 @@ def test_hnsw_search_cli(tmp_path, golden):
             pairs = [p.split(":") for p in line.split()]
             assert [int(p[0]) for p in pairs] == list(g[case + "_l"][qi])
             assert np.array_equal(np.array([float(p[1]) for p in pairs], np.float32).view(np.uint32), g[case + "_d"][qi].view(np.uint32))
+
+
+def test_hnsw_build_then_search_cli(tmp_path, golden):
+    """hnsw_build (host addPoint + saveIndex of the mirror) -> hnsw_search (GPU) on the file it wrote: the
+    reference's answers for the graph the reference built from the same rows."""
+    import struct
+    g = golden.hnsw
+    case = "ip20"
+    metric, D, n, M, efc, k, ef = (int(v) for v in g[case + "_meta"])
+    blob = g[case + "_index"]
+    off0, cap, cnt, per, offl, offd = struct.unpack("<6Q", blob[:48].tobytes())
+    body = blob[96:96 + cap * per].reshape(cap, per)
+    (tmp_path / "rows.bin").write_bytes(body[:, offd:offd + 4 * D].tobytes())
+    (tmp_path / "labels.bin").write_bytes(body[:, offl:offl + 8].tobytes())
+    run([os.path.join(BIN, "hnsw_build"), "rows.bin", str(D), str(M), str(efc), "built.hnsw", "ip", "labels.bin"], cwd=str(tmp_path))
+    assert (tmp_path / "built.hnsw").read_bytes() == blob.tobytes()
+    (tmp_path / "q.bin").write_bytes(np.ascontiguousarray(g[case + "_q"], np.float32).tobytes())
+    run([os.path.join(BIN, "hnsw_search"), "built.hnsw", "q.bin", str(D), str(k), str(ef), "out.txt", "ip"], cwd=str(tmp_path))
+    for qi, line in enumerate((tmp_path / "out.txt").read_text().splitlines()):
+        assert [int(p.split(":")[0]) for p in line.split()] == list(g[case + "_l"][qi])
