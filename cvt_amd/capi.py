@@ -404,6 +404,24 @@ def sq8_encode(vmin, vdiff, x, l2norm=True):
     return codes
 
 
+def pca_project(mean, vectors, x, l2norm=True):
+    """cvtk::PCAUtils::reduceDim (pca_utils.cc:25-35): (x - mean) * vectors^T, rows L2-normalised.  numpy in ->
+    numpy out (host entry); torch CUDA tensors in -> torch tensor out (device entry, current stream)."""
+    n, din = x.shape
+    dout = vectors.shape[0]
+    if _is_torch(x):
+        import torch
+        y = torch.empty((n, dout), dtype=torch.float32, device=x.device)
+        _check(lib().cvtmi_pca_project_dev(_ptr(mean), _ptr(vectors), C.c_int(din), C.c_int(dout), _ptr(x), C.c_int64(n),
+                                           C.c_int(1 if l2norm else 0), _ptr(y), _stream()))
+        return y
+    x = _np(x, np.float32); vectors = _np(vectors, np.float32); mean = _np(mean, np.float32)
+    y = np.empty((n, dout), dtype=np.float32)
+    _check(lib().cvtmi_pca_project(_ptr(mean), _ptr(vectors), C.c_int(din), C.c_int(dout), _ptr(x), C.c_int64(n),
+                                   C.c_int(1 if l2norm else 0), _ptr(y)))
+    return y
+
+
 def sq8_decode(vmin, vdiff, codes):
     n, d = codes.shape
     if _is_torch(codes):

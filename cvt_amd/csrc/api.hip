@@ -890,6 +890,28 @@ int cvtmi_sq8_encode(const float *vmin, const float *vdiff, int d, float *x, int
     return CVTMI_OK;
 }
 
+// ================================================================ PCA =========================
+int cvtmi_pca_project_dev(const float *mean, const float *vectors, int din, int dout, const float *x, int64_t n, int l2norm,
+                          float *y, void *stream)
+{
+    if (n < 0 || !mean || !vectors || (n > 0 && (!x || !y))) return fail(CVTMI_EINVAL, "cvtmi_pca_project: bad arguments");
+    return launch_pca_project(mean, vectors, din, dout, x, n, l2norm, y, (hipStream_t)stream);
+}
+
+int cvtmi_pca_project(const float *mean, const float *vectors, int din, int dout, const float *x, int64_t n, int l2norm, float *y)
+{
+    if (n < 0 || din < 1 || dout < 1 || !mean || !vectors || (n > 0 && (!x || !y))) return fail(CVTMI_EINVAL, "cvtmi_pca_project: bad arguments");
+    if (n == 0) return CVTMI_OK;
+    Tmp dm, de, dx, dy;
+    CVTMI_TRY(dm.upload(mean, (size_t)din * sizeof(float)));
+    CVTMI_TRY(de.upload(vectors, (size_t)dout * din * sizeof(float)));
+    CVTMI_TRY(dx.upload(x, (size_t)n * din * sizeof(float)));
+    CVTMI_TRY(dy.alloc((size_t)n * dout * sizeof(float)));
+    CVTMI_TRY(cvtmi_pca_project_dev(dm.as<float>(), de.as<float>(), din, dout, dx.as<float>(), n, l2norm, dy.as<float>(), nullptr));
+    CVTMI_HIP(hipMemcpy(y, dy.p, (size_t)n * dout * sizeof(float), hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
 int cvtmi_sq8_decode_dev(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x, void *stream)
 {
     if (n < 0 || d < 1 || !vmin || !vdiff || (n > 0 && (!x || !codes))) return fail(CVTMI_EINVAL, "cvtmi_sq8_decode: bad arguments");

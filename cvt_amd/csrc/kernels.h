@@ -102,6 +102,9 @@ bool sq8_single_pass(int d, const void *x, const void *codes, const void *vmin, 
 // ---- kmeans.hip (codebook training) ----
 // assign[r] = nearest of cent[k][d] (first minimum; -1 when no distance is below float(UINT_MAX)); *changed +=
 // number of rows whose assignment moved.  x rows are ld floats apart.
+// pca.hip: y = normalise((x - mean) * E^T), E [dout][din] (pca_utils.cc:25-35)
+int launch_pca_project(const float *mean, const float *E, int din, int dout, const float *x, int64_t n, int l2norm, float *y,
+                       hipStream_t st);
 int launch_kmeans_assign(const float *x, int64_t ld, int64_t n, int d, const float *cent, int k, int32_t *assign,
                          unsigned long long *changed, hipStream_t st);
 // cent[c] = float(double sum of the rows assigned to c, ascending row order / count); empty clusters untouched

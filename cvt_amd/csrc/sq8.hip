@@ -25,34 +25,10 @@
 //    operands outside the guarded range take __fdiv_rn.
 //  * decode divides by the constant 255.0 in double the same way (3 full-rate fp64 ops instead of a ddiv).
 //  * rows of other widths take the two-pass kernels at the bottom (norms, then an element-wise pass).
+#include "div_rn.h"
 #include "kernels.h"
 
 namespace cvtmi {
-
-// ---- correctly rounded a / b with a shared divisor ------------------------------------------------
-struct DivBy {
-    float b, y;  // divisor, RN(1 / b)
-    bool ok;     // fast path allowed for this divisor
-};
-__device__ __forceinline__ DivBy div_by(float b)
-{
-    DivBy d;
-    d.b = b;
-    d.ok = b >= 0x1p-40f && b <= 0x1p40f && (__float_as_uint(b) & 0x7fffffu) != 0x7fffffu;
-    d.y = d.ok ? __fdiv_rn(1.0f, b) : 0.0f;
-    return d;
-}
-__device__ __attribute__((noinline)) float div_slow(float a, float b) { return __fdiv_rn(a, b); }
-__device__ __forceinline__ float div_rn(float a, const DivBy &d)
-{
-    const float aa = fabsf(a);
-    const float q = __fmul_rn(a, d.y);
-    const float e = __fmaf_rn(-d.b, q, a);
-    float r = __fmaf_rn(e, d.y, q);
-    r = aa == 0.0f ? a : r;  // +-0 / positive b keeps its sign
-    if (!(d.ok && (aa <= 0x1p60f && (aa >= 0x1p-60f || aa == 0.0f)))) r = div_slow(a, d.b);  // rare: out of line
-    return r;
-}
 
 __device__ __forceinline__ uint32_t sq8_byte(float v, float lo, const DivBy &df)
 {

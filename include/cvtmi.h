@@ -194,6 +194,20 @@ int cvtmi_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_t
 int cvtmi_sq8_decode_dev(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n,
                          float *x, void *stream);
 
+/* ---------------------------------------------------------------- PCA projection ------------- */
+/* cvtk::PCAUtils::reduceDim (pca_train_project/pca_online/pca_utils.cc:25-35; same arithmetic in
+ * project/pca_dimension.h:47-58): y = cv::PCA::project(x) = (x - mean) * vectors^T, then with l2norm != 0 every
+ * row divided by float(max(1e-12, sqrt(y . y))).  mean [din], vectors [dout][din] row-major (the "mean" and
+ * "vectors" matrices of the model file), x [n][din], y [n][dout].  din % 4 == 0, dout <= 256.
+ * cv::PCA::project is OpenCV (3.2 / 3.3 per the reference's comments), absent here: PARITY UNPINNED.  The
+ * projection is evaluated as the k-ascending fp32 fused multiply-add chain of (x[k] - mean[k]) * vectors[j][k]
+ * (OpenCV's own gemm accumulates in double or calls a BLAS, depending on its build); tests hold it within
+ * 2e-6 absolute of the double-accumulated value on unit-norm outputs. */
+int cvtmi_pca_project(const float *mean, const float *vectors, int din, int dout, const float *x, int64_t n,
+                      int l2norm, float *y);
+int cvtmi_pca_project_dev(const float *mean, const float *vectors, int din, int dout, const float *x,
+                          int64_t n, int l2norm, float *y, void *stream);
+
 /* ---------------------------------------------------------------- codebook training ---------- */
 /* TrainPQ::CoarseQuan / ProdQuan (opq/train_codebook/train_PQ_codebook.cpp:150-244).  The reference calls
  * yael's kmeans(d, n, k, niter = 0, v, nt, seed = 1, redo = 1, ...), which is not vendored: PARITY UNPINNED.

@@ -54,6 +54,16 @@ class Oracle:
         self.lib.orc_rotate_fma(_p(R, C.c_float), C.c_int(D), _p(x, C.c_float), C.c_int64(n), _p(y, C.c_float))
         return y
 
+    def pca_project(self, mean, vectors, x, l2norm=True, flavour=0):
+        """flavour 0: OpenCV's built-in gemm (double accumulators); 1: the k-ordered fmaf chain (kernel spec)"""
+        x = _f32(x); vectors = _f32(vectors); mean = _f32(mean).ravel()
+        n, din = x.shape; dout = vectors.shape[0]
+        assert vectors.shape[1] == din and mean.size == din
+        y = np.empty((n, dout), np.float32)
+        self.lib.orc_pca_project(_p(mean, C.c_float), _p(vectors, C.c_float), C.c_int(din), C.c_int(dout), _p(x, C.c_float),
+                                 C.c_int64(n), C.c_int(1 if l2norm else 0), C.c_int(flavour), _p(y, C.c_float))
+        return y
+
     def coarse_assign(self, x, coarse):
         x = _f32(x); coarse = _f32(coarse)
         n, D = x.shape

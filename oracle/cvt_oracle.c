@@ -22,6 +22,9 @@
  *     the functions below follow the in-tree formulas of int8_quan.cc line by line.
  *   - orc_rotate_fma: the general d x d rotation is NOT in the reference (which only
  *     permutes); it is the specification of the MFMA GEMM kernel (k-ordered fmaf chain).
+ *   - orc_pca_project: PARITY UNPINNED.  The reference calls cv::PCA::project (OpenCV 3.2 / 3.3,
+ *     not vendored, not installed here) and holds no expected outputs; flavour 0 restates OpenCV's
+ *     own gemm (double accumulators), flavour 1 is the specification of the MFMA kernel.
  */
 #include <math.h>
 #include <stdint.h>
@@ -58,6 +61,52 @@ ORC_API void orc_rotate_fma(const float *R, int D, const float *x, int64_t n, fl
             y[r * D + i] = acc;
         }
     }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * PCA projection + L2 normalisation.  cvtk::PCAUtils::reduceDim,
+ * pca_train_project/pca_online/pca_utils.cc:25-35 (twin: project/pca_dimension.h:47-58):
+ *     reduceMat = pca_.project(mat)                      -- OpenCV: (x - mean) * vectors^T
+ *     per row: norm = row * row.t() (a 1 x d gemm), denomv = float(max(1e-12, (double)sqrt(norm))),
+ *              row[j] /= denomv
+ * cv::PCA::project (modules/core/src/pca.cpp) subtracts the mean in the type of `mean` (fp32 here)
+ * and calls gemm(tmp, eigenvectors, 1, Mat(), 0, result, GEMM_2_T).  OpenCV's built-in gemm for
+ * CV_32F keeps DOUBLE accumulators and walks k in ascending order (GEMMSingleMul / GEMMBlockMul
+ * <float, double>, modules/core/src/matmul.cpp); a build with LAPACK/IPP calls sgemm instead.
+ *   flavour 0: the built-in gemm: y[j] = float(sum_k double(t[k]) * double(E[j][k])), t = x - mean in fp32
+ *   flavour 1: what the MI355X kernel is specified to compute: the k-ascending fmaf chain in fp32
+ * The row norm is the same 1 x d gemm: double accumulation, one rounding to float.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_pca_project(const float *mean, const float *vectors, int din, int dout, const float *x, int64_t n,
+                             int l2norm, int flavour, float *y)
+{
+    float *t = (float *)malloc((size_t)din * sizeof(float));
+    for (int64_t r = 0; r < n; ++r) {
+        const float *src = x + r * din;
+        float *dst = y + r * dout;
+        for (int k = 0; k < din; ++k) t[k] = src[k] - mean[k];
+        for (int j = 0; j < dout; ++j) {
+            const float *e = vectors + (int64_t)j * din;
+            if (flavour == 0) {
+                double acc = 0.0;
+                for (int k = 0; k < din; ++k) acc += (double)t[k] * (double)e[k];
+                dst[j] = (float)acc;
+            } else {
+                float acc = 0.0f;
+                for (int k = 0; k < din; ++k) acc = fmaf(t[k], e[k], acc);
+                dst[j] = acc;
+            }
+        }
+        if (l2norm) {
+            double ss = 0.0;
+            for (int j = 0; j < dout; ++j) ss += (double)dst[j] * (double)dst[j];
+            const float norm = (float)ss;
+            const double root = (double)sqrtf(norm);
+            const float denomv = (float)(root > 1e-12 ? root : 1e-12);
+            for (int j = 0; j < dout; ++j) dst[j] = dst[j] / denomv;
+        }
+    }
+    free(t);
 }
 
 /* squared L2 distance, sequential fp32, no contraction.  IVFOPQ.cpp:117-122 / :147-154 */

@@ -42,6 +42,7 @@ class Golden:
         self.flat = dict(np.load(os.path.join(g, "flat_golden.npz")))
         self.sq8 = dict(np.load(os.path.join(g, "sq8_inputs.npz")))
         self.hnsw = dict(np.load(os.path.join(g, "hnsw_golden.npz")))
+        self.pca = dict(np.load(os.path.join(g, "pca_model.npz")))
 
     def video_of_row(self, case):
         rows = self.opq[case]["video_rows"]

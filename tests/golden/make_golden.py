@@ -238,8 +238,39 @@ def main():
         os.remove(path)
     np.savez_compressed(os.path.join(OUT, "hnsw_golden.npz"), **hn)
     print("  HNSW x%d (reference-built graphs, reference answers)  OK" % len(cases))
+    make_pca(orc)
     print("wrote", OUT)
 
 
+def read_opencv_matrix(text, name):
+    """one `name: !!opencv-matrix` node of an OpenCV FileStorage YAML -> fp32 array"""
+    import re
+    m = re.search(r"^%s: !!opencv-matrix\s+rows: (\d+)\s+cols: (\d+)\s+dt: (\w)\s+data: \[(.*?)\]" % name, text, re.S | re.M)
+    vals = np.array([float(v) for v in m.group(4).replace("\n", " ").split(",")], dtype=np.float64)
+    return vals.astype(np.float32).reshape(int(m.group(1)), int(m.group(2)))
+
+
+def make_pca(orc):
+    """PCA.  The reference's projection is an OpenCV call and OpenCV is not installed: no expected
+    outputs can be produced here (PARITY UNPINNED).  The fixture holds DATA only: the reference's own model
+    (pca_train_project/model/pca_1024_128_300w_googlenet.yml: `vectors` 128 x 1024, `mean`, `values`) as fp32 arrays,
+    inputs are seeded in the tests and the checker's outputs are recomputed there, not stored."""
+    print("PCA (model data of pca_train_project/model; OpenCV absent -> unpinned)")
+    text = open("/root/reference/pca_train_project/model/pca_1024_128_300w_googlenet.yml").read()
+    vectors, mean, values = (read_opencv_matrix(text, k) for k in ("vectors", "mean", "values"))
+    assert vectors.shape == (128, 1024) and mean.shape == (1, 1024) and values.shape == (128, 1)
+    rng = np.random.default_rng(0x9CA)
+    x = np.maximum(rng.normal(size=(300, 1024)), 0).astype(np.float32) * rng.gamma(2.0, 1.0, size=(1, 1024)).astype(np.float32)
+    x = unit(x)                                   # pooled CNN features: non-negative, sparse-ish, unit norm
+    x[7] = mean[0]                                # projects to (almost) zero: the 1e-12 clamp region
+    y = orc.pca_project(mean, vectors, x, True, flavour=0)
+    assert np.all(np.abs(np.linalg.norm(y[:7].astype(np.float64), axis=1) - 1) < 1e-6)
+    np.savez_compressed(os.path.join(OUT, "pca_model.npz"), vectors=vectors, mean=mean, values=values)
+    print("  model 1024 -> 128  OK")
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["pca"]:
+        make_pca(ob.Oracle())
+    else:
+        main()
