@@ -125,6 +125,7 @@ struct cvtmi_opq_s {
     DevBuf s_qrot, s_part_d, s_part_id, s_probe, s_lut;
     // tuning / measurement
     int p_splits = 0, p_qtile = 0, p_profile = 0, p_variant = 3;
+    int p_encode = 0;  // 0 = choose, 1 = VALU encode, 2 = matrix-core filter + exact resolution
     int p_prerot = 1;  // adc_scan16q reads a pre-rotated copy of the code rows (+16 bytes of HBM per row)
     int p_tail = 1, p_groups_a = 0, p_splits_b = 0;  // two-region scan plan: on / forced shape (tests)
     static constexpr int kEvRing = 64;
@@ -264,7 +265,7 @@ int cvtmi_opq_encode_dev(cvtmi_opq_t h, const float *x_rot, int64_t n, int32_t *
     }
     if (lists) CVTMI_TRY(launch_coarse_assign(h->m, x_rot, n, lists, st));
     // coarseK == 1: every valid row lands in list 0; the residual is taken against centroid 0 either way
-    return launch_pq_encode(h->m, x_rot, n, h->m.coarseK > 1 ? lists : nullptr, codes, st);
+    return launch_pq_encode(h->m, x_rot, n, h->m.coarseK > 1 ? lists : nullptr, codes, st, h->p_encode);
 }
 
 int cvtmi_opq_encode(cvtmi_opq_t h, const float *x_rot, int64_t n, int32_t *list_id, uint8_t *codes)
@@ -592,6 +593,11 @@ int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value)
         return CVTMI_OK;
     }
     if (!strcmp(name, "profile")) { h->p_profile = value != 0; return CVTMI_OK; }
+    if (!strcmp(name, "encode_variant")) {
+        if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: encode_variant must be 0, 1 or 2");
+        h->p_encode = (int)value;
+        return CVTMI_OK;
+    }
     if (!strcmp(name, "scan_variant")) {
         if (value < 0 || value > 4) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: scan_variant must be 0..4");
         h->p_variant = (int)value;

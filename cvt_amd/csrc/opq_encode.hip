@@ -15,6 +15,8 @@
 // codebook (8 KB at step 8) is staged in LDS once and every lane walks all K centroids for its V
 // rows (LDS broadcast reads, row sub-vectors in registers).  Codes are packed in registers and
 // leave as one 16-byte (M=16) store per row.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace cvtmi {
@@ -192,6 +194,259 @@ __global__ __launch_bounds__(kBlock) void pq_encode_kernel(const float *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// PQ encode, matrix-core filter + exact resolution (K = 256, D <= 128, step 8 or 16)
+//
+// The code byte is an argmin: only WHICH centroid wins has to equal the reference, not the distances.  For
+// row sub-vector r and centroid c_j, |r - c_j|^2 = |r|^2 - 2 T_j with T_j = r.c_j - |c_j|^2 / 2, so the winner
+// is the largest T_j -- a 256 x step by step x 32 product per (32 rows, sub-quantiser), which the fp32 matrix
+// cores evaluate 6x faster than the VALU can walk the reference's sub/mul/add chain.  The product is only a
+// FILTER: T_j carries rounding error, and the reference's own sum carries its own.  Both are bounded
+// (derivation below), so when the best T beats the runner-up by more than the bound the reference's argmin is
+// that centroid, bit for bit; otherwise (near ties, duplicates, non-finite input: ~0.3 % of the (row, m) pairs
+// on SIFT-like data) the wave evaluates all 256 centroids of that pair in the reference's operation order
+// with the reference's first-minimum rule.  Output = the reference's codes for every input.
+//
+// Layout: one persistent workgroup per CU keeps the whole codebook (D x 1 KB) and -|c|^2/2 in LDS; a wave owns
+// 32 rows at a time.  Centroids are the A side of v_mfma_f32_32x32x2_f32, rows the B side, so a lane ends up
+// holding 16 centroids x 8 tiles of ITS row (lane & 31) and the running best / second best stay in two
+// registers per lane: key = T with its low 6 bits replaced by the position (v_and_or_b32), best2 =
+// v_med3_f32(best, best2, key), best = v_max_f32(best, key) -- 3 VALU ops per (row, centroid) instead of the
+// 24 of the exact chain.  The two lane halves (k = 0..step/2-1 | step/2..step-1 of the product, and centroid
+// rows 4*(lane>>5) of the output) merge with one cross-half exchange per (32 rows, m).
+//
+// Bound.  u = 2^-24, Q = |r|^2 + max_j |c_j|^2.  |T_j| <= Q and d_j = |r - c_j|^2 <= 2Q.
+//   computed T (k-ordered fma chain of step+1 terms, |c|^2/2 itself a rounded fp32 chain):  <= 17 u Q  (step 16: 33 u Q)
+//   position bits (7 low mantissa bits overwritten):                                         <= 256 u Q
+//   the reference's D_j (sub, mul, step-1 adds):  |D_j - d_j| <= (step + 3) u d_j            <= 19 u Q in T units (step 16)
+// best - second > 2 (33 + 256 + 19) u Q = 616 u Q  =>  D_second - D_best > 0 for every other centroid.
+// The kernel uses 1024 u Q = 2^-14 Q and requires Q < 2^30 (so no distance reaches the reference's start value
+// float(UINT_MAX)); anything else, NaN included, takes the exact path.
+// ------------------------------------------------------------------------------------------
+constexpr int ENCM_THREADS = 512;
+#ifdef CVTMI_ENC_STATS
+__device__ unsigned long long g_enc_stats[2];  // (row, m) pairs seen / resolved by the exact chain
+__device__ int g_enc_mode;  // timing experiments: 1 = skip the exact chain, 2 = skip the reduction, 4 = skip the products
+#endif
+
+__device__ __forceinline__ float vmax_f32(float a, float b)
+{
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));  // no canonicalising pre-pass: the keys are plain bit patterns
+    return d;
+}
+// (best, second) of the union of two (best, second) pairs
+__device__ __forceinline__ void top2_merge(float &a1, float &a2, float b1, float b2)
+{
+    const float lo = fminf(a1, b1);
+    a1 = fmaxf(a1, b1);
+    a2 = fmaxf(lo, fmaxf(a2, b2));
+}
+
+template <int STEP>
+__global__ __launch_bounds__(ENCM_THREADS) void pq_encode_mfma_kernel(const float *__restrict__ x, int64_t n, int D, int M,
+                                                                       const float *__restrict__ coarse,
+                                                                       const int32_t *__restrict__ list_id,
+                                                                       const float *__restrict__ books,
+                                                                       uint8_t *__restrict__ codes)
+{
+    constexpr int SH = STEP / 2;  // dimensions per lane half
+    constexpr int WAVES = ENCM_THREADS / 64;
+    using f32x16 = __attribute__((ext_vector_type(16))) float;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *cb = smem;                                             // [M][256][STEP]
+    float *nhc = cb + (size_t)M * 256 * STEP;                     // [M][256]  -|c|^2 / 2
+    uint32_t *cmax = reinterpret_cast<uint32_t *>(nhc + M * 256); // [M]       max_j |c|^2 (non-negative: bits order as uint)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+    for (int i = tid; i < M * 256 * STEP / 4; i += ENCM_THREADS)
+        reinterpret_cast<float4 *>(cb)[i] = reinterpret_cast<const float4 *>(books)[i];
+    if (tid < M) cmax[tid] = 0u;
+    __syncthreads();
+    for (int c = tid; c < M * 256; c += ENCM_THREADS) {
+        float s = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < STEP; ++kk) s = __fmaf_rn(cb[c * STEP + kk], cb[c * STEP + kk], s);
+        nhc[c] = -0.5f * s;
+        atomicMax(&cmax[c >> 8], __float_as_uint(s));  // a NaN / inf codebook ends up as NaN / inf here: exact path
+    }
+    __syncthreads();
+
+    const int64_t nbatch = (n + 31) / 32;
+    for (int64_t batch = (int64_t)blockIdx.x * WAVES + wave; batch < nbatch; batch += (int64_t)gridDim.x * WAVES) {
+        const int64_t row = batch * 32 + li;
+        const int64_t rowc = row < n ? row : n - 1;  // clamped: tail rows are computed, never stored
+        int l = list_id ? list_id[rowc] : 0;
+        if (l < 0) l = 0;  // all-NaN row: see pq_encode_kernel
+        const float *xp = x + rowc * D + lk * SH;
+        const float *cp = coarse + (int64_t)l * D + lk * SH;
+        uint32_t packed[4] = { 0u, 0u, 0u, 0u };
+#ifdef CVTMI_ENC_STATS
+        const int dbg_mode = g_enc_mode;
+#endif
+        // Software pipeline over the 2 M units (sub-quantiser m, centroid half h): the 20 products of the NEXT unit
+        // are issued between the ~200 VALU instructions that reduce the CURRENT unit's 64 accumulators, so the matrix
+        // pipe (64 cycles per product) runs under the reduction instead of after it.
+        float xv[SH], cv[SH], r[SH], rn[SH];
+        auto fetch = [&](int m) {
+#pragma unroll
+            for (int q = 0; q < SH; q += 4) {
+                *reinterpret_cast<float4 *>(&xv[q]) = *reinterpret_cast<const float4 *>(xp + m * STEP + q);
+                *reinterpret_cast<float4 *>(&cv[q]) = *reinterpret_cast<const float4 *>(cp + m * STEP + q);
+            }
+        };
+        // D[centroid i][row j]: A = centroids (i = lane & 31, k = lane >> 5), B = rows; last step adds -|c|^2 / 2
+        auto products = [&](int m, int half, const float (&rv)[SH], f32x16 (&acc)[4]) {
+            float a[4][SH], ax[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = (half * 4 + t) * 32 + li;
+                const float *src = cb + ((size_t)(m * 256 + j) * STEP + lk * SH);
+#pragma unroll
+                for (int q = 0; q < SH; q += 4) *reinterpret_cast<float4 *>(&a[t][q]) = *reinterpret_cast<const float4 *>(src + q);
+                const float hv = nhc[m * 256 + j];  // unconditional read, then a select: no branch inside the pipeline
+                ax[t] = lk ? 0.0f : hv;
+            }
+            const f32x16 zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#ifdef CVTMI_ENC_STATS
+            if (dbg_mode & 4) { for (int t = 0; t < 4; ++t) for (int e2 = 0; e2 < 16; ++e2) acc[t][e2] = a[t][e2 % SH] * rv[0] + ax[t]; return; }
+#endif
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][0], rv[0], zero, 0, 0, 0);
+#pragma unroll
+            for (int sidx = 1; sidx < SH; ++sidx)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][sidx], rv[sidx], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[t], lk ? 0.0f : 1.0f, acc[t], 0, 0, 0);
+        };
+        const float pinf = __uint_as_float(0x7f800000u | (uint32_t)(n < 0));  // +inf the optimiser cannot see through:
+        const float ninf = -pinf;                                             // v_med3(a, b, +inf) = max without a canonicalising pre-pass
+        auto reduce = [&](const f32x16 (&acc)[4], float &b1, float &b2) {
+            // two independent (best, second) chains, tiles {0, 1} and {2, 3}, interleaved: back-to-back VALU
+            // instructions never depend on each other
+            float c1 = ninf, c2 = ninf;
+            b1 = ninf;
+            b2 = ninf;
+#ifdef CVTMI_ENC_STATS
+            if (dbg_mode & 2) { b1 = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3]; return; }
+#endif
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float k0 = __uint_as_float((__float_as_uint(acc[t][e]) & 0xffffffc0u) | (uint32_t)(t * 16 + e));
+                    const float k1 = __uint_as_float((__float_as_uint(acc[t + 2][e]) & 0xffffffc0u) | (uint32_t)((t + 2) * 16 + e));
+                    b2 = __builtin_amdgcn_fmed3f(b1, b2, k0);
+                    c2 = __builtin_amdgcn_fmed3f(c1, c2, k1);
+                    b1 = __builtin_amdgcn_fmed3f(b1, k0, pinf);
+                    c1 = __builtin_amdgcn_fmed3f(c1, k1, pinf);
+                }
+            // union of the two chains: second = max(min(b1, c1), max(b2, c2)), via med3 with the opaque infinities
+            const float lo = __builtin_amdgcn_fmed3f(b1, c1, ninf), s2 = __builtin_amdgcn_fmed3f(b2, c2, pinf);
+            b1 = __builtin_amdgcn_fmed3f(b1, c1, pinf);
+            b2 = __builtin_amdgcn_fmed3f(lo, s2, pinf);
+        };
+        constexpr int NPROD = 4 * (SH + 1);
+        auto interleave = [&]() {  // one product, then its share of the 3 x 64 reduction instructions
+#pragma unroll
+            for (int i = 0; i < NPROD; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (192 + NPROD - 1) / NPROD, 0);
+            }
+        };
+        f32x16 accA[4], accB[4];
+        fetch(0);
+#pragma unroll
+        for (int kk = 0; kk < SH; ++kk) r[kk] = __fsub_rn(xv[kk], cv[kk]);  // the reference's residual (:135-139)
+        fetch(M > 1 ? 1 : 0);
+        products(0, 0, r, accA);
+#pragma unroll 1
+        for (int m = 0; m < M; ++m) {
+            float best[2], second[2];
+            products(m, 1, r, accB);
+            reduce(accA, best[0], second[0]);
+            interleave();
+#pragma unroll
+            for (int kk = 0; kk < SH; ++kk) rn[kk] = __fsub_rn(xv[kk], cv[kk]);
+            fetch(m + 2 < M ? m + 2 : M - 1);                 // clamped instead of branched: the pipeline stays one basic block
+            products(m + 1 < M ? m + 1 : M - 1, 0, rn, accA);  // (the last round's products are discarded)
+            reduce(accB, best[1], second[1]);
+            interleave();
+
+            float rr = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < SH; ++kk) rr = __fmaf_rn(r[kk], r[kk], rr);
+            rr += __shfl_xor(rr, 32, 64);
+            const float Q = (rr + __uint_as_float(cmax[m])) * 1.001f;
+            // halves of the centroid range, then the two lane halves; the winner's origin rides in bit 6 / is compared
+            const bool hiwin = best[1] > best[0];
+            const float w1 = __uint_as_float((__float_as_uint(hiwin ? best[1] : best[0]) & ~64u) | (hiwin ? 64u : 0u));
+            const float w2 = fmaxf(fminf(best[0], best[1]), fmaxf(second[0], second[1]));
+            const float p1 = __shfl_xor(w1, 32, 64), p2 = __shfl_xor(w2, 32, 64);
+            const int win_lk = p1 > w1 ? (lk ^ 1) : lk;
+            float f1 = w1, f2 = w2;
+            top2_merge(f1, f2, p1, p2);
+            const uint32_t pos = __float_as_uint(f1) & 127u;  // bit 6: centroid half, bits 5..4: tile, bits 3..0: accumulator element
+            const int e = (int)(pos & 15u);
+            int code = (int)(pos >> 4) * 32 + (e & 3) + 8 * (e >> 2) + 4 * win_lk;
+            const bool sure = (f1 - f2 > Q * 0x1p-14f) && (Q < 0x1p30f);  // false for NaN anywhere
+            uint64_t todo = __ballot(!sure) & 0xffffffffull;              // both lane halves agree: rows = low half
+#ifdef CVTMI_ENC_STATS
+            if (lane == 0 && (dbg_mode & 8)) { atomicAdd(&g_enc_stats[0], 32ull); atomicAdd(&g_enc_stats[1], (unsigned long long)__popcll(todo)); }
+#endif
+#ifdef CVTMI_ENC_STATS
+            if (dbg_mode & 1) todo = 0;
+#endif
+            while (todo) {
+                const int rl = __ffsll((unsigned long long)todo) - 1;
+                todo &= todo - 1;
+                // the reference's loop for row rl (IVFOPQ.cpp:141-161): 4 centroids per lane, then the first minimum
+                float rs[STEP];
+#pragma unroll
+                for (int kk = 0; kk < SH; ++kk) {
+                    rs[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r[kk]), rl));
+                    rs[SH + kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r[kk]), rl + 32));
+                }
+                uint64_t bk = ~0ull;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = i * 64 + lane;
+                    const float *c = cb + (size_t)(m * 256 + j) * STEP;
+                    float d = 0.0f;
+#pragma unroll
+                    for (int kk = 0; kk < STEP; ++kk) {
+                        const float t = __fsub_rn(rs[kk], c[kk]);
+                        d = __fadd_rn(d, __fmul_rn(t, t));
+                    }
+                    const uint64_t k64 = d < kStartDist ? (((uint64_t)__float_as_uint(d) << 32) | (uint32_t)j) : ~0ull;  // d >= 0
+                    bk = k64 < bk ? k64 : bk;
+                }
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint64_t other = __shfl_xor(bk, o, 64);
+                    bk = other < bk ? other : bk;
+                }
+                const int exact = bk == ~0ull ? 255 : (int)(uint32_t)bk;  // nothing beat the start value: (uchar)-1
+                if (li == rl) code = exact;
+            }
+            const uint32_t b = (uint32_t)(code & 0xff) << (8 * (m & 3));
+            packed[0] |= (m >> 2) == 0 ? b : 0u;
+            packed[1] |= (m >> 2) == 1 ? b : 0u;
+            packed[2] |= (m >> 2) == 2 ? b : 0u;
+            packed[3] |= (m >> 2) == 3 ? b : 0u;
+#pragma unroll
+            for (int kk = 0; kk < SH; ++kk) r[kk] = rn[kk];
+        }
+        if (lk == 0 && row < n) {
+            uint8_t *dst = codes + row * M;
+            if (M == 16) *reinterpret_cast<uint4 *>(dst) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+            else if (M == 8) *reinterpret_cast<uint2 *>(dst) = make_uint2(packed[0], packed[1]);
+            else
+                for (int mm = 0; mm < M; ++mm) dst[mm] = (uint8_t)(packed[mm >> 2] >> (8 * (mm & 3)));
+        }
+    }
+}
+
 // generic sub-vector length (any step): one row per lane, codebook read through the caches
 __global__ __launch_bounds__(kBlock) void pq_encode_generic_kernel(const float *__restrict__ x, int64_t n, int D, int M,
                                                                    int K, int step, const float *__restrict__ coarse,
@@ -222,11 +477,45 @@ __global__ __launch_bounds__(kBlock) void pq_encode_generic_kernel(const float *
     }
 }
 
+static int encm_cus()
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+    }
+    return cus;
+}
+
+// variant: 0 = choose, 1 = the VALU kernel (reference chain for every centroid), 2 = matrix-core filter + exact resolution
 int launch_pq_encode(const OpqModelDev &m, const float *x_rot, int64_t n, const int32_t *list_id, uint8_t *codes,
-                     hipStream_t st)
+                     hipStream_t st, int variant)
 {
     if (n <= 0) return CVTMI_OK;
     if (m.K > 256) return fail(CVTMI_EUNSUPPORTED, "pq_encode: K=%d > 256", m.K);
+    const size_t lds_mfma = ((size_t)m.M * 256 * m.step + (size_t)m.M * 256 + m.M) * sizeof(float);
+    const bool mfma_ok = m.K == 256 && (m.step == 8 || m.step == 16) && m.M <= 16 && m.D == m.M * m.step && lds_mfma <= 160 * 1024 &&
+                         ((((uintptr_t)x_rot) | ((uintptr_t)m.books) | ((uintptr_t)m.coarse)) & 15) == 0;
+    if (variant == 2 && !mfma_ok) return fail(CVTMI_EUNSUPPORTED, "pq_encode: the matrix-core encode needs K = 256, step 8 or 16, M <= 16, D <= 128");
+    if (mfma_ok && (variant == 2 || (variant == 0 && n >= 8192))) {
+        constexpr int waves = ENCM_THREADS / 64;
+        const int64_t nbatch = (n + 31) / 32;
+        const int64_t blocks = std::min<int64_t>(encm_cus(), (nbatch + waves - 1) / waves);
+        if (m.step == 8) {
+            CVTMI_HIP(hipFuncSetAttribute((const void *)pq_encode_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
+            hipLaunchKernelGGL((pq_encode_mfma_kernel<8>), dim3((unsigned)blocks), dim3(ENCM_THREADS), lds_mfma, st, x_rot, n, m.D, m.M,
+                               m.coarse, list_id, m.books, codes);
+        } else {
+            CVTMI_HIP(hipFuncSetAttribute((const void *)pq_encode_mfma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
+            hipLaunchKernelGGL((pq_encode_mfma_kernel<16>), dim3((unsigned)blocks), dim3(ENCM_THREADS), lds_mfma, st, x_rot, n, m.D, m.M,
+                               m.coarse, list_id, m.books, codes);
+        }
+        CVTMI_HIP(hipGetLastError());
+        return CVTMI_OK;
+    }
     const int64_t rows_per_block = (int64_t)kBlock * ENC_V;
     const int64_t blocks = (n + rows_per_block - 1) / rows_per_block;
     if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "pq_encode: n too large");
@@ -248,6 +537,17 @@ int launch_pq_encode(const OpqModelDev &m, const float *x_rot, int64_t n, const 
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
+
+#ifdef CVTMI_ENC_STATS
+extern "C" int cvtmi_debug_encode_mode(int mode) { return hipMemcpyToSymbol(HIP_SYMBOL(g_enc_mode), &mode, sizeof mode) == hipSuccess ? 0 : -3; }
+extern "C" int cvtmi_debug_encode_stats(unsigned long long *out, int reset)
+{
+    unsigned long long z[2] = { 0, 0 };
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_enc_stats), sizeof z) != hipSuccess) return -3;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_enc_stats), z, sizeof z) != hipSuccess) return -3;
+    return 0;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // stand-alone LUT: lut[nq][M][K]  (the scan kernel builds its own copy straight into LDS)

@@ -125,6 +125,9 @@ int cvtmi_opq_query_video(cvtmi_opq_t h, const float *q, int64_t nq, int rotate,
  *   "splits"   row splits per query group of the scan (0 = automatic)
  *   "qtile"    queries sharing one pass over the codes: 1, 2, 4 or 8 (0 = automatic)
  *   "profile"  1 = bracket the scan kernel with HIP events on its stream
+ *   "encode_variant"  PQ encode kernel: 0 = choose (default); 1 = every centroid through the reference's sub / mul / add
+ *                 chain on the VALU; 2 = fp32 matrix-core filter, exact chain only for pairs it cannot separate
+ *                 (K = 256, step 8 or 16, D <= 128; chosen automatically from 8192 rows up).  Same codes either way.
  *   "scan_variant"  M = 16 kernel choice: 0 row-per-lane; 1 / 2 skewed fp32 tables (512 / 1024 threads);
  *                   3 / 4 skewed 15-bit lower-bound tables, 8 queries per pass (1024 / 512 threads; 3 = default)
  *   "prerotate"   1 (default) = variants 3 / 4 stream a copy of the code rows in which row r is rotated by r & 15

@@ -116,6 +116,13 @@ def test_encode_parity_seeded(amd, orc, D, M, K, coarseK):
     assert np.array_equal(lists, ol)
     assert np.array_equal(codes, oc)
     assert lists[5] == -1 and np.all(codes[5] == 255)
+    if K == 256 and D // M in (8, 16) and M <= 16:   # the matrix-core filter kernel is chosen from 8192 rows up: force it
+        idx.set_param("encode_variant", 2)
+        l2, c2 = idx.encode(x)
+        assert np.array_equal(l2, ol) and np.array_equal(c2, oc)
+        for nn in (1, 31, 33, 1025):
+            assert np.array_equal(idx.encode(x[:nn])[1], oc[:nn])
+        idx.set_param("encode_variant", 0)
     # ragged sizes around the tile width, and the empty input
     for nn in (0, 1, 255, 1025):
         l2, c2 = idx.encode(x[:nn])
@@ -131,6 +138,40 @@ def test_encode_tie_takes_first_minimum(amd, orc):
     idx = amd.OpqIndex(np.zeros((1, D), np.float32), books)
     _, codes = idx.encode(x)
     assert np.all(codes == 40)
+
+
+@pytest.mark.parametrize("M", [16, 8])
+def test_encode_matrix_core_filter_hard_cases(amd, orc, M):
+    """the fp32 matrix-core filter must hand every pair it cannot separate to the exact chain: duplicate codewords,
+    rows equidistant from two codewords, codewords one ulp apart, huge / tiny / non-finite magnitudes, a codebook
+    with an infinite entry -- and agree with the reference's codes on clustered data at its natural tie rate"""
+    D, K = 128, 256
+    step = D // M
+    rng = np.random.default_rng(77 + M)
+    cen = rng.normal(size=(K, D)).astype(np.float32)
+    books = np.ascontiguousarray(np.stack([cen[:, m * step:(m + 1) * step] for m in range(M)]))
+    books[:, 200] = books[:, 40]                                         # exact duplicates
+    books[:, 201] = np.nextafter(books[:, 41], np.float32(np.inf))       # one ulp apart
+    books[0, 17] = books[0, 3] + np.float32(2.0)                         # for the midpoint rows
+    n = 20000
+    x = (cen[rng.integers(0, K, n)] + 0.3 * rng.normal(size=(n, D))).astype(np.float32)
+    x[:300] = cen[40]                                                    # on a duplicated codeword
+    x[300:600] = cen[41]
+    x[600:700, :step] = (books[0, 3] + books[0, 17]) / 2                 # equidistant in sub-space 0
+    x[700:720] *= np.float32(3e4); x[720:740] *= np.float32(1e-30)       # |d| past the start value / denormal products
+    x[740, 5] = np.inf; x[741, 77] = -np.inf; x[742] = np.nan; x[743, 9] = np.nan
+    x[744:760] = 0
+    zero = np.zeros((1, D), np.float32)
+    for bk in (books, np.where(np.arange(K)[None, :, None] == 99, np.float32(np.inf), books).astype(np.float32)):
+        bk = np.ascontiguousarray(bk)
+        idx = amd.OpqIndex(zero, bk)
+        idx.set_param("encode_variant", 2)
+        _, codes = idx.encode(x)
+        _, oc = orc.pq_encode(x, zero, bk)
+        bad = np.argwhere(codes != oc)
+        assert bad.size == 0, (bad[:10], codes[bad[:10, 0], bad[:10, 1]], oc[bad[:10, 0], bad[:10, 1]])
+        idx.set_param("encode_variant", 1)
+        assert np.array_equal(idx.encode(x)[1], oc)
 
 
 @pytest.mark.parametrize("M", [16, 8, 4])
