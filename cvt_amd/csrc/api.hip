@@ -263,8 +263,11 @@ int cvtmi_opq_encode_dev(cvtmi_opq_t h, const float *x_rot, int64_t n, int32_t *
         CVTMI_TRY(h->s_probe.reserve((size_t)n * sizeof(int32_t)));
         lists = h->s_probe.as<int32_t>();
     }
+    // coarseK == 1: every valid row lands in list 0; the residual is taken against centroid 0 either way, and the
+    // matrix-core encode kernel writes the assignment itself
+    if (lists && h->m.coarseK == 1 && pq_encode_fuses_lists(h->m, x_rot, n, h->p_encode))
+        return launch_pq_encode(h->m, x_rot, n, nullptr, codes, st, h->p_encode, lists);
     if (lists) CVTMI_TRY(launch_coarse_assign(h->m, x_rot, n, lists, st));
-    // coarseK == 1: every valid row lands in list 0; the residual is taken against centroid 0 either way
     return launch_pq_encode(h->m, x_rot, n, h->m.coarseK > 1 ? lists : nullptr, codes, st, h->p_encode);
 }
 

@@ -21,8 +21,11 @@ int launch_rotate_gemm(const float *R, int D, const float *x, int64_t n, float *
 int launch_coarse_assign(const OpqModelDev &m, const float *x_rot, int64_t n, int32_t *list_id, hipStream_t st);
 // list_id may be null (=> list 0 for every row)
 // variant: 0 = choose, 1 = VALU kernel, 2 = matrix-core filter + exact resolution
+// single_list_out (coarseK == 1 only, and only when pq_encode_fuses_lists() says so): the encode kernel writes the list
+// assignment (0, or -1 for rows no centroid can claim) itself, sparing the separate pass over the rows
 int launch_pq_encode(const OpqModelDev &m, const float *x_rot, int64_t n, const int32_t *list_id, uint8_t *codes,
-                     hipStream_t st, int variant = 0);
+                     hipStream_t st, int variant = 0, int32_t *single_list_out = nullptr);
+bool pq_encode_fuses_lists(const OpqModelDev &m, const float *x_rot, int64_t n, int variant);
 // ld: entries per (query, m) row of the output, 0 = K; ld > K pads with +inf
 int launch_lut(const OpqModelDev &m, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut,
                hipStream_t st, int ld = 0);

@@ -8,13 +8,14 @@
 //   PQ argmin      :141-161  per sub-quantiser m: argmin_j sum_k (r[m*step+k] - book[m][j][k])^2,
 //                            same start value and tie rule; code = (uchar)vw1  (-1 -> 255)
 //   LUT            :273-291
-// Bit-exactness rules out the |x|^2 - 2xc + |c|^2 GEMM form: every distance is evaluated in the
-// reference's operation order with __fsub_rn/__fmul_rn/__fadd_rn (no contraction), on the VALU.
-//
-// MI355X mapping of the encode: a workgroup owns 256*V rows; for each sub-quantiser the 256 x step
-// codebook (8 KB at step 8) is staged in LDS once and every lane walks all K centroids for its V
-// rows (LDS broadcast reads, row sub-vectors in registers).  Codes are packed in registers and
-// leave as one 16-byte (M=16) store per row.
+// Bit-exactness rules out taking distances from the |x|^2 - 2xc + |c|^2 GEMM form.  Two encode kernels:
+//   pq_encode_kernel       every distance in the reference's operation order (__fsub_rn/__fmul_rn/__fadd_rn, no
+//                          contraction) on the VALU: a workgroup owns 256*V rows; per sub-quantiser the 256 x step
+//                          codebook slice (8 KB at step 8) is staged in LDS and every lane walks all K centroids for
+//                          its V rows (LDS broadcast reads, row sub-vectors in registers)
+//   pq_encode_mfma_kernel  the GEMM form on the bf16 matrix cores as a FILTER with a proven error bound; pairs it
+//                          cannot separate go through the reference's chain (K = 256, step 8 / 16, D <= 128)
+// Codes are packed in registers and leave as one 16-byte (M=16) store per row.
 #include <algorithm>
 
 #include "kernels.h"
@@ -199,42 +200,47 @@ __global__ __launch_bounds__(kBlock) void pq_encode_kernel(const float *__restri
 //
 // The code byte is an argmin: only WHICH centroid wins has to equal the reference, not the distances.  For
 // row sub-vector r and centroid c_j, |r - c_j|^2 = |r|^2 - 2 T_j with T_j = r.c_j - |c_j|^2 / 2, so the winner
-// is the largest T_j -- a 256 x step by step x 32 product per (32 rows, sub-quantiser), which the fp32 matrix
-// cores evaluate 6x faster than the VALU can walk the reference's sub/mul/add chain.  The product is only a
-// FILTER: T_j carries rounding error, and the reference's own sum carries its own.  Both are bounded
-// (derivation below), so when the best T beats the runner-up by more than the bound the reference's argmin is
-// that centroid, bit for bit; otherwise (near ties, duplicates, non-finite input: ~0.3 % of the (row, m) pairs
-// on SIFT-like data) the wave evaluates all 256 centroids of that pair in the reference's operation order
-// with the reference's first-minimum rule.  Output = the reference's codes for every input.
+// is the largest T_j -- a (256 x step) x (step x 32) product per (32 rows, sub-quantiser).  The product is only
+// a FILTER: T_j carries rounding error and the reference's own sum carries its own.  Both are bounded (below),
+// so when the best T beats the runner-up by more than the bound the reference's argmin is that centroid, bit
+// for bit; otherwise (near ties, duplicate codewords, non-finite input: ~1 % of the (row, m) pairs on
+// SIFT-shaped data) the wave evaluates all 256 centroids of that pair in the reference's operation order with
+// the reference's first-minimum rule.  Output = the reference's codes for every input.
 //
-// Layout: one persistent workgroup per CU keeps the whole codebook (D x 1 KB) and -|c|^2/2 in LDS; a wave owns
-// 32 rows at a time.  Centroids are the A side of v_mfma_f32_32x32x2_f32, rows the B side, so a lane ends up
-// holding 16 centroids x 8 tiles of ITS row (lane & 31) and the running best / second best stay in two
-// registers per lane: key = T with its low 6 bits replaced by the position (v_and_or_b32), best2 =
-// v_med3_f32(best, best2, key), best = v_max_f32(best, key) -- 3 VALU ops per (row, centroid) instead of the
-// 24 of the exact chain.  The two lane halves (k = 0..step/2-1 | step/2..step-1 of the product, and centroid
-// rows 4*(lane>>5) of the output) merge with one cross-half exchange per (32 rows, m).
+// Which matrix instruction.  v_mfma_f32_32x32x2_f32 is exact enough by itself, but the fp32 matrix rate equals
+// the fp32 vector rate and (measured: SQ_VALU_MFMA_BUSY + SQ_ACTIVE_INST_VALU add up to the kernel's cycles) it
+// does not run beside VALU work -- and the reduction below is VALU work.  The bf16 matrix pipe does run beside
+// the VALU and is 16x faster, so the fp32 operands are split into two bf16 terms each (c = c1 + c2 + O(2^-18 |c|),
+// r likewise): (c1 + c2).(r1 + r2) costs two v_mfma_f32_32x32x16_bf16 per 32 x 32 tile at step 8 (the 16-deep K
+// holds c_x.r1 | c_x.r2 side by side), four at step 16; products of bf16 pairs are exact in the fp32 accumulator.
+// One more product adds -|c|^2/2 (two bf16 terms against ones).  The codebook is split once per workgroup, into LDS.
 //
-// Bound.  u = 2^-24, Q = |r|^2 + max_j |c_j|^2.  |T_j| <= Q and d_j = |r - c_j|^2 <= 2Q.
-//   computed T (k-ordered fma chain of step+1 terms, |c|^2/2 itself a rounded fp32 chain):  <= 17 u Q  (step 16: 33 u Q)
-//   position bits (7 low mantissa bits overwritten):                                         <= 256 u Q
-//   the reference's D_j (sub, mul, step-1 adds):  |D_j - d_j| <= (step + 3) u d_j            <= 19 u Q in T units (step 16)
-// best - second > 2 (33 + 256 + 19) u Q = 616 u Q  =>  D_second - D_best > 0 for every other centroid.
-// The kernel uses 1024 u Q = 2^-14 Q and requires Q < 2^30 (so no distance reaches the reference's start value
-// float(UINT_MAX)); anything else, NaN included, takes the exact path.
+// Layout: one persistent workgroup per CU keeps both bf16 halves of the whole codebook (D x 1 KB) and -|c|^2/2 in
+// LDS; a wave owns 32 rows at a time.  Centroids are the A side of the product, rows the B side, so a lane ends
+// up holding 16 centroids x 8 tiles of ITS row (lane & 31) and the running best / second best stay in registers:
+// key = T with its low 6 bits replaced by the position (v_and_or_b32), second = v_med3_f32(best, second, key),
+// best = max(best, key) -- 3 VALU ops per (row, centroid) instead of the 24 of the exact chain, issued between
+// the products of the NEXT tile group.  The two lane halves (centroid rows 4*(lane>>5) of the output) merge with
+// one cross-half exchange per (32 rows, m).
+//
+// Bound.  u = 2^-24, Q = |r|^2 + max_j |c_j|^2, so |T_j| <= Q and d_j = |r - c_j|^2 <= 2Q.  Per key:
+//   bf16 split of r and of c (round to nearest, twice): 2^-18 |r||c| each             <=  64 u Q
+//   split of |c|^2/2 into two bf16 terms, and its own fp32 rounding                   <=  24 u Q
+//   accumulation inside the matrix unit: 3 (5) products of <= 17 terms, taken as 2u per term even if it truncates <= 102 (170) u Q
+//   position bits (7 low mantissa bits overwritten)                                   <= 256 u Q
+// and the reference's D_j (sub, mul, step-1 adds): |D_j - d_j| <= (step + 3) u d_j    <=  19 u Q in T units.
+// best - second > 2 (514 + 19) u Q = 1066 u Q (step 16)  =>  D_second - D_best > 0 for every other centroid.
+// The kernel asks for 1536 u Q = 1.5 * 2^-14 Q, and for 2^-60 < Q < 2^30 (no distance reaches the reference's start
+// value float(UINT_MAX), no split term is flushed); anything else, NaN included, takes the exact path.
 // ------------------------------------------------------------------------------------------
 constexpr int ENCM_THREADS = 512;
 #ifdef CVTMI_ENC_STATS
 __device__ unsigned long long g_enc_stats[2];  // (row, m) pairs seen / resolved by the exact chain
-__device__ int g_enc_mode;  // timing experiments: 1 = skip the exact chain, 2 = skip the reduction, 4 = skip the products
+__device__ int g_enc_mode;  // timing experiments: 1 = skip the exact chain, 2 = skip the reduction, 8 = count
 #endif
 
-__device__ __forceinline__ float vmax_f32(float a, float b)
-{
-    float d;
-    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));  // no canonicalising pre-pass: the keys are plain bit patterns
-    return d;
-}
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
 // (best, second) of the union of two (best, second) pairs
 __device__ __forceinline__ void top2_merge(float &a1, float &a2, float b1, float b2)
 {
@@ -248,25 +254,32 @@ __global__ __launch_bounds__(ENCM_THREADS) void pq_encode_mfma_kernel(const floa
                                                                        const float *__restrict__ coarse,
                                                                        const int32_t *__restrict__ list_id,
                                                                        const float *__restrict__ books,
-                                                                       uint8_t *__restrict__ codes)
+                                                                       uint8_t *__restrict__ codes, int32_t *__restrict__ list_out)
 {
-    constexpr int SH = STEP / 2;  // dimensions per lane half
     constexpr int WAVES = ENCM_THREADS / 64;
+    constexpr int LOFF = STEP == 16 ? 8 : 0;  // step 16: a lane half owns dimensions [8 * (lane >> 5), +8); step 8: all 8
     using f32x16 = __attribute__((ext_vector_type(16))) float;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *cb = smem;                                             // [M][256][STEP]
-    float *nhc = cb + (size_t)M * 256 * STEP;                     // [M][256]  -|c|^2 / 2
-    uint32_t *cmax = reinterpret_cast<uint32_t *>(nhc + M * 256); // [M]       max_j |c|^2 (non-negative: bits order as uint)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16 *c1 = reinterpret_cast<__bf16 *>(smem_raw);                 // [M][256][STEP]  first bf16 term of the codebook
+    __bf16 *c2 = c1 + (size_t)M * 256 * STEP;                          // [M][256][STEP]  second term
+    uint32_t *nhc = reinterpret_cast<uint32_t *>(c2 + (size_t)M * 256 * STEP);  // [M][256]  -|c|^2/2 as two bf16 terms
+    uint32_t *cmax = nhc + M * 256;                                    // [M]  max_j |c|^2 (non-negative: bits order as uint)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
-    for (int i = tid; i < M * 256 * STEP / 4; i += ENCM_THREADS)
-        reinterpret_cast<float4 *>(cb)[i] = reinterpret_cast<const float4 *>(books)[i];
     if (tid < M) cmax[tid] = 0u;
     __syncthreads();
     for (int c = tid; c < M * 256; c += ENCM_THREADS) {
         float s = 0.0f;
 #pragma unroll
-        for (int kk = 0; kk < STEP; ++kk) s = __fmaf_rn(cb[c * STEP + kk], cb[c * STEP + kk], s);
-        nhc[c] = -0.5f * s;
+        for (int kk = 0; kk < STEP; ++kk) {
+            const float v = books[(size_t)c * STEP + kk];
+            s = __fmaf_rn(v, v, s);
+            const __bf16 h = (__bf16)v;
+            c1[(size_t)c * STEP + kk] = h;
+            c2[(size_t)c * STEP + kk] = (__bf16)(v - (float)h);
+        }
+        const float nh = -0.5f * s;
+        const __bf16 h1 = (__bf16)nh, h2 = (__bf16)(nh - (float)h1);
+        nhc[c] = (uint32_t)__builtin_bit_cast(unsigned short, h1) | ((uint32_t)__builtin_bit_cast(unsigned short, h2) << 16);
         atomicMax(&cmax[c >> 8], __float_as_uint(s));  // a NaN / inf codebook ends up as NaN / inf here: exact path
     }
     __syncthreads();
@@ -277,54 +290,75 @@ __global__ __launch_bounds__(ENCM_THREADS) void pq_encode_mfma_kernel(const floa
         const int64_t rowc = row < n ? row : n - 1;  // clamped: tail rows are computed, never stored
         int l = list_id ? list_id[rowc] : 0;
         if (l < 0) l = 0;  // all-NaN row: see pq_encode_kernel
-        const float *xp = x + rowc * D + lk * SH;
-        const float *cp = coarse + (int64_t)l * D + lk * SH;
+        const float *xp = x + rowc * D + lk * LOFF;
+        const float *cp = coarse + (int64_t)l * D + lk * LOFF;
         uint32_t packed[4] = { 0u, 0u, 0u, 0u };
+        float norm2 = 0.0f;  // |x - coarse[0]|^2 up to rounding: decides the single-list assignment (list_out)
 #ifdef CVTMI_ENC_STATS
         const int dbg_mode = g_enc_mode;
 #endif
-        // Software pipeline over the 2 M units (sub-quantiser m, centroid half h): the 20 products of the NEXT unit
-        // are issued between the ~200 VALU instructions that reduce the CURRENT unit's 64 accumulators, so the matrix
-        // pipe (64 cycles per product) runs under the reduction instead of after it.
-        float xv[SH], cv[SH], r[SH], rn[SH];
+        // Software pipeline over the 2 M units (sub-quantiser m, centroid half h): the products of the NEXT unit are
+        // issued between the ~200 VALU instructions that reduce the CURRENT unit's 64 accumulators.
+        float xv[8], cv[8], r[8], rn[8];
         auto fetch = [&](int m) {
 #pragma unroll
-            for (int q = 0; q < SH; q += 4) {
+            for (int q = 0; q < 8; q += 4) {
                 *reinterpret_cast<float4 *>(&xv[q]) = *reinterpret_cast<const float4 *>(xp + m * STEP + q);
                 *reinterpret_cast<float4 *>(&cv[q]) = *reinterpret_cast<const float4 *>(cp + m * STEP + q);
             }
         };
-        // D[centroid i][row j]: A = centroids (i = lane & 31, k = lane >> 5), B = rows; last step adds -|c|^2 / 2
-        auto products = [&](int m, int half, const float (&rv)[SH], f32x16 (&acc)[4]) {
-            float a[4][SH], ax[4];
+        // the row side of the products: r = r1 + r2 (+ 2^-18 |r|) in bf16
+        auto split_row = [&](const float (&rv)[8], bf16x8 &r1, bf16x8 &r2) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const __bf16 h = (__bf16)rv[kk];
+                r1[kk] = h;
+                r2[kk] = (__bf16)(rv[kk] - (float)h);
+            }
+        };
+        // D[centroid i][row j]: A = centroids (i = lane & 31, k = 8 * (lane >> 5) ..), B = rows
+        auto products = [&](int m, int half, const bf16x8 &r1, const bf16x8 &r2, f32x16 (&acc)[4]) {
+            const f32x16 zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            const bf16x8 bzero = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            bf16x8 ones = bzero;  // the row side of the -|c|^2/2 product: (1, 1, 0, ...) in the low lane half only
+            ones[0] = lk ? (__bf16)0.0f : (__bf16)1.0f;
+            ones[1] = ones[0];
+            bf16x8 a1[4], a2[4], ab[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int j = (half * 4 + t) * 32 + li;
-                const float *src = cb + ((size_t)(m * 256 + j) * STEP + lk * SH);
-#pragma unroll
-                for (int q = 0; q < SH; q += 4) *reinterpret_cast<float4 *>(&a[t][q]) = *reinterpret_cast<const float4 *>(src + q);
-                const float hv = nhc[m * 256 + j];  // unconditional read, then a select: no branch inside the pipeline
-                ax[t] = lk ? 0.0f : hv;
+                const size_t off = (size_t)(m * 256 + j) * STEP + lk * LOFF;
+                a1[t] = *reinterpret_cast<const bf16x8 *>(c1 + off);
+                a2[t] = *reinterpret_cast<const bf16x8 *>(c2 + off);
+                const uint32_t hv = nhc[m * 256 + j];  // unconditional read, then a select: no branch inside the pipeline
+                union { uint32_t u[4]; bf16x8 v; } cvt = { { lk ? 0u : hv, 0u, 0u, 0u } };
+                ab[t] = cvt.v;
             }
-            const f32x16 zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-#ifdef CVTMI_ENC_STATS
-            if (dbg_mode & 4) { for (int t = 0; t < 4; ++t) for (int e2 = 0; e2 < 16; ++e2) acc[t][e2] = a[t][e2 % SH] * rv[0] + ax[t]; return; }
-#endif
+            if constexpr (STEP == 8) {
+                const bf16x8 rb = lk ? r2 : r1;  // K = 0..7: c_x . r1, K = 8..15: c_x . r2
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][0], rv[0], zero, 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[t], rb, zero, 0, 0, 0);
 #pragma unroll
-            for (int sidx = 1; sidx < SH; ++sidx)
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[t], rb, acc[t], 0, 0, 0);
+            } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][sidx], rv[sidx], acc[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[t], r1, zero, 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[t], lk ? 0.0f : 1.0f, acc[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[t], r2, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[t], r1, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[t], r2, acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[t], ones, acc[t], 0, 0, 0);  // - |c|^2 / 2
         };
         const float pinf = __uint_as_float(0x7f800000u | (uint32_t)(n < 0));  // +inf the optimiser cannot see through:
         const float ninf = -pinf;                                             // v_med3(a, b, +inf) = max without a canonicalising pre-pass
         auto reduce = [&](const f32x16 (&acc)[4], float &b1, float &b2) {
             // two independent (best, second) chains, tiles {0, 1} and {2, 3}, interleaved: back-to-back VALU
             // instructions never depend on each other
-            float c1 = ninf, c2 = ninf;
+            float d1 = ninf, d2 = ninf;
             b1 = ninf;
             b2 = ninf;
 #ifdef CVTMI_ENC_STATS
@@ -337,46 +371,50 @@ __global__ __launch_bounds__(ENCM_THREADS) void pq_encode_mfma_kernel(const floa
                     const float k0 = __uint_as_float((__float_as_uint(acc[t][e]) & 0xffffffc0u) | (uint32_t)(t * 16 + e));
                     const float k1 = __uint_as_float((__float_as_uint(acc[t + 2][e]) & 0xffffffc0u) | (uint32_t)((t + 2) * 16 + e));
                     b2 = __builtin_amdgcn_fmed3f(b1, b2, k0);
-                    c2 = __builtin_amdgcn_fmed3f(c1, c2, k1);
+                    d2 = __builtin_amdgcn_fmed3f(d1, d2, k1);
                     b1 = __builtin_amdgcn_fmed3f(b1, k0, pinf);
-                    c1 = __builtin_amdgcn_fmed3f(c1, k1, pinf);
+                    d1 = __builtin_amdgcn_fmed3f(d1, k1, pinf);
                 }
-            // union of the two chains: second = max(min(b1, c1), max(b2, c2)), via med3 with the opaque infinities
-            const float lo = __builtin_amdgcn_fmed3f(b1, c1, ninf), s2 = __builtin_amdgcn_fmed3f(b2, c2, pinf);
-            b1 = __builtin_amdgcn_fmed3f(b1, c1, pinf);
+            // union of the two chains: second = max(min(b1, d1), max(b2, d2)), via med3 with the opaque infinities
+            const float lo = __builtin_amdgcn_fmed3f(b1, d1, ninf), s2 = __builtin_amdgcn_fmed3f(b2, d2, pinf);
+            b1 = __builtin_amdgcn_fmed3f(b1, d1, pinf);
             b2 = __builtin_amdgcn_fmed3f(lo, s2, pinf);
         };
-        constexpr int NPROD = 4 * (SH + 1);
+        constexpr int NPROD = 4 * (STEP == 8 ? 3 : 5);
         auto interleave = [&]() {  // one product, then its share of the 3 x 64 reduction instructions
 #pragma unroll
             for (int i = 0; i < NPROD; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, (192 + NPROD - 1) / NPROD, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (200 + NPROD - 1) / NPROD, 0);
             }
         };
         f32x16 accA[4], accB[4];
+        bf16x8 r1, r2, n1, n2;
         fetch(0);
 #pragma unroll
-        for (int kk = 0; kk < SH; ++kk) r[kk] = __fsub_rn(xv[kk], cv[kk]);  // the reference's residual (:135-139)
+        for (int kk = 0; kk < 8; ++kk) r[kk] = __fsub_rn(xv[kk], cv[kk]);  // the reference's residual (:135-139)
+        split_row(r, r1, r2);
         fetch(M > 1 ? 1 : 0);
-        products(0, 0, r, accA);
+        products(0, 0, r1, r2, accA);
 #pragma unroll 1
         for (int m = 0; m < M; ++m) {
             float best[2], second[2];
-            products(m, 1, r, accB);
+            products(m, 1, r1, r2, accB);
             reduce(accA, best[0], second[0]);
             interleave();
 #pragma unroll
-            for (int kk = 0; kk < SH; ++kk) rn[kk] = __fsub_rn(xv[kk], cv[kk]);
-            fetch(m + 2 < M ? m + 2 : M - 1);                 // clamped instead of branched: the pipeline stays one basic block
-            products(m + 1 < M ? m + 1 : M - 1, 0, rn, accA);  // (the last round's products are discarded)
+            for (int kk = 0; kk < 8; ++kk) rn[kk] = __fsub_rn(xv[kk], cv[kk]);
+            split_row(rn, n1, n2);
+            fetch(m + 2 < M ? m + 2 : M - 1);                     // clamped instead of branched: the pipeline stays one basic block
+            products(m + 1 < M ? m + 1 : M - 1, 0, n1, n2, accA);  // (the last round's products are discarded)
             reduce(accB, best[1], second[1]);
             interleave();
 
             float rr = 0.0f;
 #pragma unroll
-            for (int kk = 0; kk < SH; ++kk) rr = __fmaf_rn(r[kk], r[kk], rr);
-            rr += __shfl_xor(rr, 32, 64);
+            for (int kk = 0; kk < 8; ++kk) rr = __fmaf_rn(r[kk], r[kk], rr);
+            if (STEP == 16) rr += __shfl_xor(rr, 32, 64);
+            norm2 += rr;
             const float Q = (rr + __uint_as_float(cmax[m])) * 1.001f;
             // halves of the centroid range, then the two lane halves; the winner's origin rides in bit 6 / is compared
             const bool hiwin = best[1] > best[0];
@@ -389,44 +427,56 @@ __global__ __launch_bounds__(ENCM_THREADS) void pq_encode_mfma_kernel(const floa
             const uint32_t pos = __float_as_uint(f1) & 127u;  // bit 6: centroid half, bits 5..4: tile, bits 3..0: accumulator element
             const int e = (int)(pos & 15u);
             int code = (int)(pos >> 4) * 32 + (e & 3) + 8 * (e >> 2) + 4 * win_lk;
-            const bool sure = (f1 - f2 > Q * 0x1p-14f) && (Q < 0x1p30f);  // false for NaN anywhere
-            uint64_t todo = __ballot(!sure) & 0xffffffffull;              // both lane halves agree: rows = low half
+            const bool sure = (f1 - f2 > Q * 0x1.8p-14f) && (Q < 0x1p30f) && (Q > 0x1p-60f);  // false for NaN anywhere
+            uint64_t todo = __ballot(!sure) & 0xffffffffull;  // both lane halves agree: rows = low half
 #ifdef CVTMI_ENC_STATS
             if (lane == 0 && (dbg_mode & 8)) { atomicAdd(&g_enc_stats[0], 32ull); atomicAdd(&g_enc_stats[1], (unsigned long long)__popcll(todo)); }
-#endif
-#ifdef CVTMI_ENC_STATS
             if (dbg_mode & 1) todo = 0;
 #endif
             while (todo) {
                 const int rl = __ffsll((unsigned long long)todo) - 1;
                 todo &= todo - 1;
-                // the reference's loop for row rl (IVFOPQ.cpp:141-161): 4 centroids per lane, then the first minimum
+                // the reference's loop for row rl (IVFOPQ.cpp:141-161): 4 centroids per lane (fp32 codebook through
+                // the caches: the LDS copy is the bf16 split), then the first minimum
                 float rs[STEP];
 #pragma unroll
-                for (int kk = 0; kk < SH; ++kk) {
+                for (int kk = 0; kk < 8; ++kk) {
                     rs[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r[kk]), rl));
-                    rs[SH + kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r[kk]), rl + 32));
+                    if (STEP == 16) rs[(8 + kk) % STEP] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r[kk]), rl + 32));
                 }
-                uint64_t bk = ~0ull;
+                // lane owns centroids 4 * lane .. 4 * lane + 3: lane order = centroid order, so "first minimum" is the
+                // lowest lane holding the wave-wide minimum, and inside the lane the strict '<' in ascending j
+                float bd = kStartDist;
+                int bi = 0;
+                const float *c = books + (size_t)(m * 256 + 4 * lane) * STEP;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int j = i * 64 + lane;
-                    const float *c = cb + (size_t)(m * 256 + j) * STEP;
+                    float cf[STEP];
+#pragma unroll
+                    for (int q = 0; q < STEP; q += 4) *reinterpret_cast<float4 *>(&cf[q]) = *reinterpret_cast<const float4 *>(c + i * STEP + q);
                     float d = 0.0f;
 #pragma unroll
                     for (int kk = 0; kk < STEP; ++kk) {
-                        const float t = __fsub_rn(rs[kk], c[kk]);
+                        const float t = __fsub_rn(rs[kk], cf[kk]);
                         d = __fadd_rn(d, __fmul_rn(t, t));
                     }
-                    const uint64_t k64 = d < kStartDist ? (((uint64_t)__float_as_uint(d) << 32) | (uint32_t)j) : ~0ull;  // d >= 0
-                    bk = k64 < bk ? k64 : bk;
+                    if (d < bd) { bd = d; bi = i; }  // NaN never wins, as in the reference
                 }
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint64_t other = __shfl_xor(bk, o, 64);
-                    bk = other < bk ? other : bk;
+                // wave minimum of bd (no NaN among them): 4 DPP steps inside each row of 16 lanes, then the 4 rows
+                float v = bd;
+                v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
+                v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
+                v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x141, 0xf, 0xf, false)));  // row_half_mirror
+                v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x140, 0xf, 0xf, false)));  // row_mirror
+                const float dmin = fminf(fminf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)),
+                                               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))),
+                                         fminf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)),
+                                               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48))));
+                int exact = 255;  // nothing beat the start value: (uchar)-1
+                if (dmin < kStartDist) {
+                    const int wl = __ffsll((unsigned long long)__ballot(bd == dmin)) - 1;
+                    exact = 4 * wl + __builtin_amdgcn_readlane(bi, wl);
                 }
-                const int exact = bk == ~0ull ? 255 : (int)(uint32_t)bk;  // nothing beat the start value: (uchar)-1
                 if (li == rl) code = exact;
             }
             const uint32_t b = (uint32_t)(code & 0xff) << (8 * (m & 3));
@@ -435,7 +485,24 @@ __global__ __launch_bounds__(ENCM_THREADS) void pq_encode_mfma_kernel(const floa
             packed[2] |= (m >> 2) == 2 ? b : 0u;
             packed[3] |= (m >> 2) == 3 ? b : 0u;
 #pragma unroll
-            for (int kk = 0; kk < SH; ++kk) r[kk] = rn[kk];
+            for (int kk = 0; kk < 8; ++kk) r[kk] = rn[kk];
+            r1 = n1;
+            r2 = n2;
+        }
+        if (list_out && lk == 0 && row < n) {
+            // coarseK == 1 (IVFOPQ.cpp:110-129 with one centroid): list 0 when the sequential fp32 sum of (x - c0)^2 stays
+            // below the start value float(UINT_MAX), else -1.  norm2 is that sum up to ~1e-5 relative: far from 2^32 it
+            // decides; otherwise (huge or non-finite rows) the lane walks the reference's chain.
+            int lst = 0;
+            if (!(norm2 * 1.01f < 0x1p31f)) {
+                float acc = 0.0f;
+                for (int kk = 0; kk < D; ++kk) {
+                    const float t = __fsub_rn(x[row * D + kk], coarse[kk]);
+                    acc = __fadd_rn(acc, __fmul_rn(t, t));
+                }
+                lst = acc < kStartDist ? 0 : -1;
+            }
+            list_out[row] = lst;
         }
         if (lk == 0 && row < n) {
             uint8_t *dst = codes + row * M;
@@ -490,16 +557,29 @@ static int encm_cus()
     return cus;
 }
 
+static size_t encm_lds(const OpqModelDev &m) { return ((size_t)m.M * 256 * m.step + (size_t)m.M * 256 + m.M) * sizeof(float); }
+static bool encm_ok(const OpqModelDev &m, const float *x_rot)
+{
+    return m.K == 256 && (m.step == 8 || m.step == 16) && m.M <= 16 && m.D == m.M * m.step && encm_lds(m) <= 160 * 1024 &&
+           ((((uintptr_t)x_rot) | ((uintptr_t)m.books) | ((uintptr_t)m.coarse)) & 15) == 0;
+}
+// does launch_pq_encode take the matrix-core kernel (which can also write the single-list assignment)?
+bool pq_encode_fuses_lists(const OpqModelDev &m, const float *x_rot, int64_t n, int variant)
+{
+    return m.coarseK == 1 && encm_ok(m, x_rot) && (variant == 2 || (variant == 0 && n >= 8192));
+}
+
 // variant: 0 = choose, 1 = the VALU kernel (reference chain for every centroid), 2 = matrix-core filter + exact resolution
+// single_list_out: coarseK == 1 and pq_encode_fuses_lists(): the kernel also writes the list assignment (0 / -1)
 int launch_pq_encode(const OpqModelDev &m, const float *x_rot, int64_t n, const int32_t *list_id, uint8_t *codes,
-                     hipStream_t st, int variant)
+                     hipStream_t st, int variant, int32_t *single_list_out)
 {
     if (n <= 0) return CVTMI_OK;
     if (m.K > 256) return fail(CVTMI_EUNSUPPORTED, "pq_encode: K=%d > 256", m.K);
-    const size_t lds_mfma = ((size_t)m.M * 256 * m.step + (size_t)m.M * 256 + m.M) * sizeof(float);
-    const bool mfma_ok = m.K == 256 && (m.step == 8 || m.step == 16) && m.M <= 16 && m.D == m.M * m.step && lds_mfma <= 160 * 1024 &&
-                         ((((uintptr_t)x_rot) | ((uintptr_t)m.books) | ((uintptr_t)m.coarse)) & 15) == 0;
+    const size_t lds_mfma = encm_lds(m);
+    const bool mfma_ok = encm_ok(m, x_rot);
     if (variant == 2 && !mfma_ok) return fail(CVTMI_EUNSUPPORTED, "pq_encode: the matrix-core encode needs K = 256, step 8 or 16, M <= 16, D <= 128");
+    if (single_list_out && !pq_encode_fuses_lists(m, x_rot, n, variant)) return fail(CVTMI_EINVAL, "pq_encode: list output without the fused kernel");
     if (mfma_ok && (variant == 2 || (variant == 0 && n >= 8192))) {
         constexpr int waves = ENCM_THREADS / 64;
         const int64_t nbatch = (n + 31) / 32;
@@ -507,11 +587,11 @@ int launch_pq_encode(const OpqModelDev &m, const float *x_rot, int64_t n, const 
         if (m.step == 8) {
             CVTMI_HIP(hipFuncSetAttribute((const void *)pq_encode_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
             hipLaunchKernelGGL((pq_encode_mfma_kernel<8>), dim3((unsigned)blocks), dim3(ENCM_THREADS), lds_mfma, st, x_rot, n, m.D, m.M,
-                               m.coarse, list_id, m.books, codes);
+                               m.coarse, list_id, m.books, codes, single_list_out);
         } else {
             CVTMI_HIP(hipFuncSetAttribute((const void *)pq_encode_mfma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
             hipLaunchKernelGGL((pq_encode_mfma_kernel<16>), dim3((unsigned)blocks), dim3(ENCM_THREADS), lds_mfma, st, x_rot, n, m.D, m.M,
-                               m.coarse, list_id, m.books, codes);
+                               m.coarse, list_id, m.books, codes, single_list_out);
         }
         CVTMI_HIP(hipGetLastError());
         return CVTMI_OK;

@@ -161,17 +161,21 @@ def test_encode_matrix_core_filter_hard_cases(amd, orc, M):
     x[700:720] *= np.float32(3e4); x[720:740] *= np.float32(1e-30)       # |d| past the start value / denormal products
     x[740, 5] = np.inf; x[741, 77] = -np.inf; x[742] = np.nan; x[743, 9] = np.nan
     x[744:760] = 0
+    for i, f in enumerate((1 - 1e-3, 1 - 1e-6, 1 - 1e-7, 1.0, 1 + 1e-7, 1 + 1e-6, 1 + 1e-3, 0.4, 0.6)):   # |x|^2 around the start value 2^32
+        v = rng.normal(size=D); x[760 + i] = (v / np.linalg.norm(v) * np.sqrt(2.0 ** 32 * f)).astype(np.float32)
     zero = np.zeros((1, D), np.float32)
     for bk in (books, np.where(np.arange(K)[None, :, None] == 99, np.float32(np.inf), books).astype(np.float32)):
         bk = np.ascontiguousarray(bk)
         idx = amd.OpqIndex(zero, bk)
         idx.set_param("encode_variant", 2)
-        _, codes = idx.encode(x)
-        _, oc = orc.pq_encode(x, zero, bk)
+        lists, codes = idx.encode(x)
+        ol, oc = orc.pq_encode(x, zero, bk)
         bad = np.argwhere(codes != oc)
         assert bad.size == 0, (bad[:10], codes[bad[:10, 0], bad[:10, 1]], oc[bad[:10, 0], bad[:10, 1]])
+        assert np.array_equal(lists, ol) and set(np.unique(ol)) == {-1, 0}   # the kernel's own single-list assignment
         idx.set_param("encode_variant", 1)
-        assert np.array_equal(idx.encode(x)[1], oc)
+        l1, c1 = idx.encode(x)
+        assert np.array_equal(c1, oc) and np.array_equal(l1, ol)
 
 
 @pytest.mark.parametrize("M", [16, 8, 4])
