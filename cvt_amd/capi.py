@@ -336,6 +336,11 @@ class HnswIndex:
         return d, lab
 
 
+def set_tuning(name, value):
+    """library-wide tuning / measurement hooks (cvtmi_set_tuning): no effect on results"""
+    _check(lib().cvtmi_set_tuning(name.encode(), C.c_int64(int(value))))
+
+
 def kmeans(x, k, niter=0, seed=1):
     """cvtmi_kmeans: (centroids [k][d], assign [n], iterations)."""
     n, d = x.shape

@@ -171,6 +171,17 @@ int cvtmi_device_count(int *count)
     return CVTMI_OK;
 }
 
+int cvtmi_set_tuning(const char *name, int64_t value)
+{
+    if (!name) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: null name");
+    if (!strcmp(name, "assign_variant")) {
+        if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: assign_variant must be 0, 1 or 2");
+        set_assign_variant((int)value);
+        return CVTMI_OK;
+    }
+    return fail(CVTMI_EINVAL, "cvtmi_set_tuning: unknown parameter '%s'", name);
+}
+
 int cvtmi_set_device(int device)
 {
     CVTMI_HIP(hipSetDevice(device));

@@ -109,6 +109,17 @@ bool sq8_single_pass(int d, const void *x, const void *codes, const void *vmin, 
 // pca.hip: y = normalise((x - mean) * E^T), E [dout][din] (pca_utils.cc:25-35)
 int launch_pca_project(const float *mean, const float *E, int din, int dout, const float *x, int64_t n, int l2norm, float *y,
                        hipStream_t st);
+// assign_mfma.hip: nearest centroid through the bf16 matrix-core filter (32 <= d <= 128), exact kernels for undecided rows
+bool assign_filter_applies(const float *x, int64_t ld, int64_t n, int d, const float *cent, int k);
+int launch_assign_filtered(const float *x, int64_t ld, int64_t n, int d, const float *cent, int k, int32_t *assign,
+                           unsigned long long *changed, hipStream_t st);
+int launch_kmeans_assign_exact(const float *x, int64_t ld, int64_t n, int d, const float *cent, int k, int32_t *assign,
+                               unsigned long long *changed, hipStream_t st);
+// exact assignment of few rows: centroid range cut into `splits` workgroup columns, folded in ascending order; part_* hold
+// splits * n entries each
+int launch_kmeans_assign_split(const float *x, int64_t ld, int64_t n, int d, const float *cent, int k, int32_t *assign, int splits,
+                               float *part_d, int32_t *part_i, hipStream_t st);
+void set_assign_variant(int v);  // 0 = choose, 1 = exact kernels, 2 = filter wherever it applies
 int launch_kmeans_assign(const float *x, int64_t ld, int64_t n, int d, const float *cent, int k, int32_t *assign,
                          unsigned long long *changed, hipStream_t st);
 // cent[c] = float(double sum of the rows assigned to c, ascending row order / count); empty clusters untouched

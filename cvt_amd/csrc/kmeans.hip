@@ -5,6 +5,8 @@
 // IVFOPQ::Add (sequential fp32 distance, strict '<'), centroid = float(double sum in ascending row order /
 // count), empty clusters keep their centroid, stop when an assignment pass changes nothing.
 //
+//  * assign, 32 <= d <= 128: bf16 matrix-core filter with a proven bound, exact kernel for the rows it cannot decide
+//    (assign_mfma.hip).  Otherwise, and for those rows:
 //  * assign: one lane per row, CT centroids at a time from an LDS tile transposed [dim][centroid]
 //    (broadcast reads), squared distances kept in registers -- VALU fp32 bound, 3 d k flop per row.
 //  * update: the order of the double additions is part of bit-exactness, so there is no atomic scatter:
@@ -80,8 +82,11 @@ template <int DMAX>
 __global__ __launch_bounds__(kBlock) void kmeans_assign_reg_kernel(const float *__restrict__ x, int64_t ld, int64_t n, int d,
                                                                    const float *__restrict__ cent, int k,
                                                                    int32_t *__restrict__ assign,
-                                                                   unsigned long long *__restrict__ changed)
+                                                                   unsigned long long *__restrict__ changed, int csplit,
+                                                                   float *__restrict__ part_d, int32_t *__restrict__ part_i)
 {
+    // part_d != null: blockIdx.y walks only centroids [y * csplit, (y + 1) * csplit) and leaves its (best distance, index)
+    // in part_*[y][row]; the caller folds the ranges in ascending order with the same strict '<' (few rows, many centroids)
     __shared__ __attribute__((aligned(16))) float cen[DMAX][KM_CT];  // transposed: [dim][centroid]
     const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool valid = row < n;
@@ -91,7 +96,9 @@ __global__ __launch_bounds__(kBlock) void kmeans_assign_reg_kernel(const float *
     for (int dd = 0; dd < DMAX; ++dd) xv[dd] = dd < d ? xr[dd] : 0.0f;
     float best = kKmStart;
     int bi = -1;
-    for (int c0 = 0; c0 < k; c0 += KM_CT) {
+    const int c_lo = part_d ? (int)blockIdx.y * csplit : 0;
+    if (part_d) k = k < c_lo + csplit ? k : c_lo + csplit;
+    for (int c0 = c_lo; c0 < k; c0 += KM_CT) {
         __syncthreads();
         for (int i = threadIdx.x; i < DMAX * KM_CT; i += kBlock) {
             const int c = i / DMAX, dd = i - c * DMAX;  // coalesced along the dimension
@@ -122,6 +129,13 @@ __global__ __launch_bounds__(kBlock) void kmeans_assign_reg_kernel(const float *
             if (c0 + 2 * p < k && acc[p].x < best) { best = acc[p].x; bi = c0 + 2 * p; }
             if (c0 + 2 * p + 1 < k && acc[p].y < best) { best = acc[p].y; bi = c0 + 2 * p + 1; }
         }
+    }
+    if (part_d) {
+        if (valid) {
+            part_d[(int64_t)blockIdx.y * n + row] = best;
+            part_i[(int64_t)blockIdx.y * n + row] = bi;
+        }
+        return;
     }
     bool ch = false;
     if (valid) {
@@ -203,19 +217,66 @@ __global__ __launch_bounds__(kBlock) void kmeans_residual_kernel(const float *__
     }
 }
 
+static int g_assign_variant = 0;  // 0 = choose, 1 = exact kernels for every row, 2 = matrix-core filter wherever it applies
+void set_assign_variant(int v) { g_assign_variant = v; }
+
 int launch_kmeans_assign(const float *x, int64_t ld, int64_t n, int d, const float *cent, int k, int32_t *assign,
                          unsigned long long *changed, hipStream_t st)
+{
+    if (n <= 0) return CVTMI_OK;
+    // 32 <= d <= 128: matrix-core filter + exact resolution of the rows it cannot decide (assign_mfma.hip); same result
+    if (g_assign_variant != 1 && assign_filter_applies(x, ld, g_assign_variant == 2 && n < 4096 ? 4096 : n, d, cent, k) && n < 0x7fffffff)
+        return launch_assign_filtered(x, ld, n, d, cent, k, assign, changed, st);
+    return launch_kmeans_assign_exact(x, ld, n, d, cent, k, assign, changed, st);
+}
+
+int launch_kmeans_assign_exact(const float *x, int64_t ld, int64_t n, int d, const float *cent, int k, int32_t *assign,
+                               unsigned long long *changed, hipStream_t st)
 {
     if (n <= 0) return CVTMI_OK;
     const int64_t blocks = (n + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "kmeans: n too large");
     const dim3 g((unsigned)blocks), b(kBlock);
-    if (d <= 8) hipLaunchKernelGGL(kmeans_assign_reg_kernel<8>, g, b, 0, st, x, ld, n, d, cent, k, assign, changed);
-    else if (d <= 16) hipLaunchKernelGGL(kmeans_assign_reg_kernel<16>, g, b, 0, st, x, ld, n, d, cent, k, assign, changed);
-    else if (d <= 32) hipLaunchKernelGGL(kmeans_assign_reg_kernel<32>, g, b, 0, st, x, ld, n, d, cent, k, assign, changed);
-    else if (d <= 64) hipLaunchKernelGGL(kmeans_assign_reg_kernel<64>, g, b, 0, st, x, ld, n, d, cent, k, assign, changed);
-    else if (d <= 128) hipLaunchKernelGGL(kmeans_assign_reg_kernel<128>, g, b, 0, st, x, ld, n, d, cent, k, assign, changed);
+    if (d <= 8) hipLaunchKernelGGL(kmeans_assign_reg_kernel<8>, g, b, 0, st, x, ld, n, d, cent, k, assign, changed, 0, nullptr, nullptr);
+    else if (d <= 16) hipLaunchKernelGGL(kmeans_assign_reg_kernel<16>, g, b, 0, st, x, ld, n, d, cent, k, assign, changed, 0, nullptr, nullptr);
+    else if (d <= 32) hipLaunchKernelGGL(kmeans_assign_reg_kernel<32>, g, b, 0, st, x, ld, n, d, cent, k, assign, changed, 0, nullptr, nullptr);
+    else if (d <= 64) hipLaunchKernelGGL(kmeans_assign_reg_kernel<64>, g, b, 0, st, x, ld, n, d, cent, k, assign, changed, 0, nullptr, nullptr);
+    else if (d <= 128) hipLaunchKernelGGL(kmeans_assign_reg_kernel<128>, g, b, 0, st, x, ld, n, d, cent, k, assign, changed, 0, nullptr, nullptr);
     else hipLaunchKernelGGL(kmeans_assign_kernel, g, b, 0, st, x, ld, n, d, cent, k, assign, changed);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+// few rows against many centroids (the rows the matrix-core filter of assign_mfma.hip could not decide): the centroid
+// range is cut into `splits` pieces that run as separate workgroups, then folded in ascending order -- the same strict '<'
+__global__ __launch_bounds__(kBlock) void kmeans_assign_fold_kernel(const float *__restrict__ part_d, const int32_t *__restrict__ part_i,
+                                                                    int64_t n, int splits, int32_t *__restrict__ assign)
+{
+    const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= n) return;
+    float best = kKmStart;
+    int bi = -1;
+    for (int s = 0; s < splits; ++s) {
+        const float dd = part_d[(int64_t)s * n + row];
+        if (dd < best) { best = dd; bi = part_i[(int64_t)s * n + row]; }
+    }
+    assign[row] = bi;
+}
+
+int launch_kmeans_assign_split(const float *x, int64_t ld, int64_t n, int d, const float *cent, int k, int32_t *assign, int splits,
+                               float *part_d, int32_t *part_i, hipStream_t st)
+{
+    if (n <= 0) return CVTMI_OK;
+    if (d > 128) return fail(CVTMI_EUNSUPPORTED, "kmeans_assign_split: d=%d > 128", d);
+    const int csplit = ((k + splits - 1) / splits + KM_CT - 1) / KM_CT * KM_CT;
+    splits = (k + csplit - 1) / csplit;
+    const dim3 g((unsigned)((n + kBlock - 1) / kBlock), (unsigned)splits), b(kBlock);
+    if (d <= 8) hipLaunchKernelGGL(kmeans_assign_reg_kernel<8>, g, b, 0, st, x, ld, n, d, cent, k, assign, nullptr, csplit, part_d, part_i);
+    else if (d <= 16) hipLaunchKernelGGL(kmeans_assign_reg_kernel<16>, g, b, 0, st, x, ld, n, d, cent, k, assign, nullptr, csplit, part_d, part_i);
+    else if (d <= 32) hipLaunchKernelGGL(kmeans_assign_reg_kernel<32>, g, b, 0, st, x, ld, n, d, cent, k, assign, nullptr, csplit, part_d, part_i);
+    else if (d <= 64) hipLaunchKernelGGL(kmeans_assign_reg_kernel<64>, g, b, 0, st, x, ld, n, d, cent, k, assign, nullptr, csplit, part_d, part_i);
+    else hipLaunchKernelGGL(kmeans_assign_reg_kernel<128>, g, b, 0, st, x, ld, n, d, cent, k, assign, nullptr, csplit, part_d, part_i);
+    hipLaunchKernelGGL(kmeans_assign_fold_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), b, 0, st, part_d, part_i, n, splits, assign);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

@@ -61,6 +61,11 @@ int cvtmi_version(void);
 const char *cvtmi_last_error(void);
 int cvtmi_device_count(int *count);
 int cvtmi_set_device(int device);
+/* Library-wide tuning / measurement hooks (no effect on results).
+ *   "assign_variant"  nearest-centroid assignment (coarse argmin of cvtmi_opq_encode, cvtmi_kmeans): 0 = choose (default);
+ *                     1 = the reference's chain for every centroid on the VALU; 2 = bf16 matrix-core filter with exact
+ *                     resolution of undecided rows wherever it applies (32 <= d <= 128, d % 16 == 0, k >= 64) */
+int cvtmi_set_tuning(const char *name, int64_t value);
 
 /* ---------------------------------------------------------------- OPQ model + code index ---- */
 /*

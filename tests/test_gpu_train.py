@@ -68,3 +68,38 @@ def test_opq_train_parity_and_use(amd, orc):
     lists, codes = idx.encode(x[:500])
     olists, ocodes = orc.pq_encode(x[:500], oc, ob)
     assert np.array_equal(lists, olists) and np.array_equal(codes, ocodes)
+
+
+@pytest.mark.parametrize("n,d,k", [(6000, 128, 200), (5000, 64, 1000), (4200, 32, 64), (7000, 96, 77), (9000, 128, 2048)])
+def test_assignment_matrix_core_filter(amd, orc, n, d, k):
+    """nearest-centroid assignment through the bf16 matrix-core filter (assign_variant 2): coarse lists of encode and a
+    whole k-means run equal the checker's, on clustered rows with duplicate / one-ulp-apart centroids, rows sitting
+    exactly on centroids and exactly between two, huge, tiny and non-finite rows"""
+    rng = np.random.default_rng(n + d + k)
+    cen = (rng.normal(size=(k, d)) * 2).astype(np.float32)
+    cen[k // 2] = cen[3]                                              # duplicate centroid: the lower index wins
+    cen[k // 2 + 1] = np.nextafter(cen[4], np.float32(np.inf))        # one ulp apart
+    x = (cen[rng.integers(0, k, n)] + 0.4 * rng.normal(size=(n, d))).astype(np.float32)
+    x[:50] = cen[3]; x[50:100] = cen[4]
+    x[100:150] = (cen[7] + cen[8]) / 2                                # equidistant up to rounding
+    x[150:160] *= np.float32(1e5); x[160:170] *= np.float32(1e-25)
+    x[170, 1] = np.inf; x[171] = np.nan; x[172, d - 1] = np.nan
+    M = d // 8
+    books = (rng.normal(size=(M, 16, 8))).astype(np.float32)
+    try:
+        for variant in (2, 1):
+            amd.set_tuning("assign_variant", variant)
+            idx = amd.OpqIndex(cen, books)
+            lists, codes = idx.encode(x)
+            ol, oc = orc.pq_encode(x, cen, books)
+            assert np.array_equal(lists, ol), (variant, np.argwhere(lists != ol)[:10].ravel())
+            assert np.array_equal(codes, oc)
+        amd.set_tuning("assign_variant", 2)
+        kk = min(k, 96)
+        xs = x[np.isfinite(x).all(axis=1)][:5000]
+        xs[9] = np.nan
+        oc_, oa, oit = orc.kmeans(xs, kk, 4, 7)
+        gc, ga, git = amd.kmeans(xs, kk, 4, 7)
+        assert git == oit and np.array_equal(ga, oa) and np.array_equal(bits(gc), bits(oc_))
+    finally:
+        amd.set_tuning("assign_variant", 0)
