@@ -279,6 +279,12 @@ class FlatIndex:
         _check(lib().cvtmi_flat_search(self.h, _ptr(q), C.c_int64(nq), C.c_int(k), _ptr(d), _ptr(i)))
         return d, i
 
+    def last_search(self):
+        """(answered through the matrix-core filter?, largest candidate list) of the last search"""
+        f = C.c_int(0); m = C.c_int64(0)
+        _check(lib().cvtmi_flat_last_search(self.h, C.byref(f), C.byref(m)))
+        return bool(f.value), m.value
+
 
 class HnswIndex:
     """cvtmi_hnsw_*: batched search over a graph file written by the reference's HierarchicalNSW::saveIndex."""

@@ -143,6 +143,12 @@ struct cvtmi_flat_s {
     int64_t n = 0;
     bool identity = true;  // label == row
     DevBuf s_part_d, s_part_id, s_gthr, s_stage;
+    // matrix-core filter of the fp32 search (flat_mfma.hip): bf16 operand copy of the rows, built on first use
+    DevBuf f_pack, f_bias, f_stats, f_thr, f_cnt, f_cand, f_sd, f_si, f_seld, f_seli;
+    int64_t f_pack_n = -1;      // rows the copy covers (-1: none)
+    bool f_nonfinite = false;   // a row holds inf / NaN: the filter is not used
+    int f_last_filtered = 0;    // the last search was answered through the filter
+    int64_t f_last_worst = 0;   // its largest candidate list
 };
 
 static int use_device(int dev)
@@ -156,6 +162,8 @@ static int use_device(int dev)
 #define CHECK_H(h) \
     if (!(h)) return fail(CVTMI_EINVAL, "%s: null handle", __func__); \
     CVTMI_TRY(use_device((h)->device))
+
+static int g_flat_variant = 0;  // cvtmi_set_tuning("flat_variant"): 0 = choose, 1 = exact kernels only, 2 = matrix-core filter wherever it applies
 
 extern "C" {
 
@@ -177,6 +185,11 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "assign_variant")) {
         if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: assign_variant must be 0, 1 or 2");
         set_assign_variant((int)value);
+        return CVTMI_OK;
+    }
+    if (!strcmp(name, "flat_variant")) {
+        if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_variant must be 0, 1 or 2");
+        g_flat_variant = (int)value;
         return CVTMI_OK;
     }
     return fail(CVTMI_EINVAL, "cvtmi_set_tuning: unknown parameter '%s'", name);
@@ -727,6 +740,7 @@ static int flat_add_common(cvtmi_flat_t h, const void *x, const int64_t *labels,
     if (n == 0) return CVTMI_OK;
     const int64_t total = h->n + n;
     if (total > 0xfffffffeLL) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_add: more than 2^32-2 rows per handle");
+    h->f_pack_n = -1;
     bool explicit_labels = labels != nullptr;
     if (explicit_labels && kind == hipMemcpyHostToDevice && h->identity) {
         bool same = true;
@@ -802,7 +816,83 @@ int cvtmi_flat_ntotal(cvtmi_flat_t h, int64_t *n)
 int cvtmi_flat_reset(cvtmi_flat_t h)
 {
     CHECK_H(h);
-    h->n = 0; h->identity = true;
+    h->n = 0; h->identity = true; h->f_pack_n = -1;
+    return CVTMI_OK;
+}
+
+// the exact search over rows [0, n_rows) of the handle: k smallest (distance, row) per query, rows not yet mapped to labels
+static int flat_search_rows(cvtmi_flat_t h, int64_t n_rows, const void *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st)
+{
+    const bool mfma = h->metric == CVTMI_METRIC_L2U8 && flat_u8_mfma_qtile(h->D, k, nq) > 0;
+    const int qt = mfma ? flat_u8_mfma_qtile(h->D, k, nq) : flat_qtile(nq);
+    int splits = mfma ? flat_u8_mfma_splits(n_rows, nq, qt) : flat_plan_splits(n_rows, nq, qt);
+    if (mfma && splits >= 8) splits = (splits / 8) * 8;  // a row split per XCD: query groups share its L2
+    float *pd = dist;
+    int64_t *pi = rows;
+    if (splits > 1) {
+        const size_t cnt = (size_t)nq * splits * k;
+        CVTMI_TRY(h->s_part_d.reserve(cnt * sizeof(float)));
+        CVTMI_TRY(h->s_part_id.reserve(cnt * sizeof(int64_t)));
+        pd = h->s_part_d.as<float>();
+        pi = h->s_part_id.as<int64_t>();
+    }
+    if (mfma) {
+        CVTMI_TRY(h->s_gthr.reserve((size_t)nq * (1 + 16) * sizeof(uint32_t)));
+        CVTMI_TRY(launch_flat_u8_mfma(h->D, h->data.as<uint8_t>(), h->norms.as<int32_t>(), n_rows,
+                                      reinterpret_cast<const uint8_t *>(q), nq, k, splits, pd, pi, h->s_gthr.as<uint32_t>(), st));
+    }
+    else
+        CVTMI_TRY(launch_flat_search(h->metric, h->D, h->data.p, n_rows, q, nq, k, qt, splits, pd, pi, st));
+    if (splits > 1) CVTMI_TRY(launch_topk_merge(pd, pi, nq, splits, k, dist, rows, st));
+    return CVTMI_OK;
+}
+
+// fp32 search through the matrix-core filter (flat_mfma.hip).  *done = false: not applicable / gave up, take the exact path
+static int flat_search_filtered(cvtmi_flat_t h, const float *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st, bool *done)
+{
+    *done = false;
+    const int D = h->D;
+    const int64_t n = h->n;
+    if (h->f_pack_n != n) {  // bf16 operand copy of the rows (same bytes as the fp32 rows), once per index state
+        CVTMI_TRY(h->f_pack.reserve(flat_pack_bytes(D, n)));
+        CVTMI_TRY(h->f_bias.reserve((size_t)((n + 31) / 32) * 32 * sizeof(uint32_t)));
+        CVTMI_TRY(h->f_stats.reserve(16));
+        CVTMI_TRY(launch_flat_pack(h->data.as<float>(), n, D, h->metric, h->f_pack.as<uint4>(), h->f_bias.as<uint32_t>(),
+                                   h->f_stats.as<uint32_t>(), st));
+        uint32_t stats[2] = { 0, 0 };
+        CVTMI_HIP(hipMemcpyAsync(stats, h->f_stats.p, sizeof stats, hipMemcpyDeviceToHost, st));
+        CVTMI_HIP(hipStreamSynchronize(st));
+        h->f_nonfinite = stats[1] != 0 || !(__builtin_bit_cast(float, stats[0]) <= 3.0e38f);
+        h->f_pack_n = n;
+    }
+    if (h->f_nonfinite) return CVTMI_OK;
+    // 1. exact search of a leading sample: its k-th best bounds the global k-th best
+    int64_t ns = std::max<int64_t>(65536, (n / 16 + 63) / 64 * 64);
+    const int cap = (24 * k + 1024 + 63) / 64 * 64;
+    CVTMI_TRY(h->f_sd.reserve((size_t)nq * k * sizeof(float)));
+    CVTMI_TRY(h->f_si.reserve((size_t)nq * k * sizeof(int64_t)));
+    CVTMI_TRY(h->f_thr.reserve((size_t)nq * sizeof(float)));
+    CVTMI_TRY(h->f_cnt.reserve((size_t)nq * sizeof(uint32_t)));
+    CVTMI_TRY(h->f_cand.reserve((size_t)nq * cap * sizeof(int32_t)));
+    CVTMI_TRY(h->f_seld.reserve((size_t)nq * (k + cap) * sizeof(float)));
+    CVTMI_TRY(h->f_seli.reserve((size_t)nq * (k + cap) * sizeof(int64_t)));
+    CVTMI_TRY(flat_search_rows(h, ns, q, nq, k, h->f_sd.as<float>(), h->f_si.as<int64_t>(), st));
+    // 2. thresholds, filter over the remaining rows, 3. exact distances of the survivors
+    CVTMI_HIP(hipMemsetAsync(h->f_stats.as<uint32_t>() + 2, 0, 4, st));
+    CVTMI_TRY(launch_flat_thr(q, nq, D, h->metric, h->f_sd.as<float>(), k, h->f_stats.as<uint32_t>(), h->f_thr.as<float>(), st));
+    CVTMI_HIP(hipMemsetAsync(h->f_cnt.p, 0, (size_t)nq * sizeof(uint32_t), st));
+    CVTMI_TRY(launch_flat_filter(q, nq, D, h->f_pack.as<uint4>(), h->f_bias.as<uint32_t>(), h->f_thr.as<float>(), ns, n, cap,
+                                 h->f_cnt.as<uint32_t>(), h->f_cand.as<int32_t>(), st));
+    CVTMI_TRY(launch_flat_rerank(h->metric, h->data.as<float>(), n, D, q, nq, h->f_cnt.as<uint32_t>(), h->f_cand.as<int32_t>(), cap, k,
+                                 h->f_sd.as<float>(), h->f_si.as<int64_t>(), h->f_seld.as<float>(), h->f_seli.as<int64_t>(),
+                                 h->f_stats.as<uint32_t>() + 2, st));
+    uint32_t worst = 0;
+    CVTMI_HIP(hipMemcpyAsync(&worst, h->f_stats.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost, st));
+    CVTMI_HIP(hipStreamSynchronize(st));
+    h->f_last_worst = worst;
+    if (worst > (uint32_t)cap) return CVTMI_OK;  // a candidate list overflowed: the exact path answers this call
+    CVTMI_TRY(launch_topk_select_byid(h->f_seld.as<float>(), h->f_seli.as<int64_t>(), nq, k + cap, k, dist, rows, st));
+    *done = true;
     return CVTMI_OK;
 }
 
@@ -813,28 +903,23 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search: k=%d outside 1..128", k);
     if (nq == 0) return CVTMI_OK;
     hipStream_t st = (hipStream_t)stream;
-    const bool mfma = h->metric == CVTMI_METRIC_L2U8 && flat_u8_mfma_qtile(h->D, k, nq) > 0;
-    const int qt = mfma ? flat_u8_mfma_qtile(h->D, k, nq) : flat_qtile(nq);
-    int splits = mfma ? flat_u8_mfma_splits(h->n, nq, qt) : flat_plan_splits(h->n, nq, qt);
-    if (mfma && splits >= 8) splits = (splits / 8) * 8;  // a row split per XCD: query groups share its L2
-    float *pd = reinterpret_cast<float *>(dist);
-    int64_t *pi = labels;
-    if (splits > 1) {
-        const size_t cnt = (size_t)nq * splits * k;
-        CVTMI_TRY(h->s_part_d.reserve(cnt * sizeof(float)));
-        CVTMI_TRY(h->s_part_id.reserve(cnt * sizeof(int64_t)));
-        pd = h->s_part_d.as<float>();
-        pi = h->s_part_id.as<int64_t>();
-    }
-    if (mfma) {
-        CVTMI_TRY(h->s_gthr.reserve((size_t)nq * (1 + 16) * sizeof(uint32_t)));
-        CVTMI_TRY(launch_flat_u8_mfma(h->D, h->data.as<uint8_t>(), h->norms.as<int32_t>(), h->n,
-                                      reinterpret_cast<const uint8_t *>(q), nq, k, splits, pd, pi, h->s_gthr.as<uint32_t>(), st));
-    }
-    else
-        CVTMI_TRY(launch_flat_search(h->metric, h->D, h->data.p, h->n, q, nq, k, qt, splits, pd, pi, st));
-    if (splits > 1) CVTMI_TRY(launch_topk_merge(pd, pi, nq, splits, k, reinterpret_cast<float *>(dist), labels, st));
+    bool done = false;
+    h->f_last_worst = 0;
+    if (g_flat_variant != 1 && ((uintptr_t)q & 15) == 0 && nq <= 65535 &&
+        flat_filter_applies(h->metric, h->D, g_flat_variant == 2 ? std::max<int64_t>(h->n, 131072) : h->n, g_flat_variant == 2 ? std::max<int64_t>(nq, 64) : nq, k) &&
+        h->n >= 2 * 65536)
+        CVTMI_TRY(flat_search_filtered(h, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
+    h->f_last_filtered = done ? 1 : 0;
+    if (!done) CVTMI_TRY(flat_search_rows(h, h->n, q, nq, k, reinterpret_cast<float *>(dist), labels, st));
     if (!h->identity) CVTMI_TRY(launch_gather_labels(labels, nq * k, h->labels.as<int64_t>(), st));
+    return CVTMI_OK;
+}
+
+int cvtmi_flat_last_search(cvtmi_flat_t h, int *filtered, int64_t *max_candidates)
+{
+    if (!h) return fail(CVTMI_EINVAL, "cvtmi_flat_last_search: null handle");
+    if (filtered) *filtered = h->f_last_filtered;
+    if (max_candidates) *max_candidates = h->f_last_worst;
     return CVTMI_OK;
 }
 

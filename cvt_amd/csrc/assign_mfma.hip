@@ -21,6 +21,7 @@
 // chain (d + 3) u d_j = 131 uQ in T units.  best - second > 2 * 620 + 131 = 1371 uQ proves the argmin; the kernel asks
 // for 2048 uQ = 2^-13 Q and 2^-60 < Q < 2^30.
 #include <algorithm>
+#include <mutex>
 
 #include "common.h"
 #include "kernels.h"
@@ -218,8 +219,8 @@ __global__ __launch_bounds__(kBlock) void assign_scatter_kernel(const int32_t *_
     }
 }
 
-// grow-only device scratch of this translation unit (the library is thread-compatible, not thread-safe: callers
-// serialise mutation per device, include/cvtmi.h)
+// grow-only device scratch of this translation unit; calls that use it are serialised (they end in a stream
+// synchronisation anyway)
 struct AssignScratch {
     void *p = nullptr;
     size_t bytes = 0;
@@ -239,6 +240,7 @@ struct AssignScratch {
     }
 };
 static AssignScratch g_scr;
+static std::mutex g_scr_mutex;
 
 bool assign_filter_applies(const float *x, int64_t ld, int64_t n, int d, const float *cent, int k)
 {
@@ -250,6 +252,7 @@ bool assign_filter_applies(const float *x, int64_t ld, int64_t n, int d, const f
 int launch_assign_filtered(const float *x, int64_t ld, int64_t n, int d, const float *cent, int k, int32_t *assign,
                            unsigned long long *changed, hipStream_t st)
 {
+    std::lock_guard<std::mutex> guard(g_scr_mutex);
     const int nch = d / 16, ntiles = (k + 31) / 32;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t b_pack = up((size_t)ntiles * nch * 2 * 64 * sizeof(uint4)), b_nhc = up((size_t)ntiles * 32 * 4), b_misc = 256,

@@ -1,0 +1,321 @@
+// flat_mfma.hip -- exhaustive fp32 search (BruteforceSearch + InnerProductSpace / L2Space, brutoforce.hpp:73-93,
+// space_ip.hpp, space_l2.h) through a matrix-core FILTER, for 32 <= D <= 128 (D % 16 == 0) and batches of queries.
+//
+// The result -- k smallest (distance, row) per query with the distances in the reference's summation order --
+// must come out bit for bit, so the distances themselves are evaluated by the exact code (dist_f32.h).  What the
+// matrix cores do is decide WHICH rows need an exact distance:
+//   1. the first n/16 rows are searched exactly (flat.hip).  The k-th best of that sample, tau_q, bounds the k-th
+//      best of the whole set from above.
+//   2. T = q.x + b_x ranks the remaining rows (b_x = -|x|^2/2 for L2, 0 for the inner product); a bf16 two-term
+//      split of both operands evaluates it to ~2^-17 on v_mfma_f32_32x32x16_bf16.  A row can only be in the
+//      top k if its reference distance is <= tau_q, which implies T >= thr_q once every rounding (the split,
+//      the accumulation inside the matrix unit, the reference's own sum) is bounded -- all other rows are
+//      provably out.  Survivors (~15 k per query) are appended to a per-query candidate list.
+//   3. candidates get their exact distance (same code, same order as flat.hip) and the k best of
+//      sample + candidates are selected with the usual (distance, row) order.
+// A query whose list overflows (adversarial row order, masses of duplicates), non-finite rows or queries, or
+// magnitudes outside the bound's range send the whole call down the exact path: same answer, old speed.
+//
+// Bound (u = 2^-24, Q = |q|^2 + max |x|^2, |T| <= Q, distances <= 2Q): accumulation of 4 D + 2 terms taken as 2u per
+// term 516 uQ, bf16 splits 64 uQ, |x|^2/2 split and its fp32 rounding 24 uQ: 604 uQ on T; the reference's sum
+// (D + 4) u 2Q and |q|^2 (D + 1) u Q in distance units, i.e. ~200 uQ in T units.  thr_q is lowered by 2048 uQ = 2^-13 Q.
+#include <algorithm>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace cvtmi {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr float kPadBias = -1.0e30f;  // rows past n in the last tile: never candidates (ids >= n are skipped anyway)
+
+// element (row, dim) of the blocked fp32 layout of flat.hip
+__device__ __forceinline__ float blocked_at(const float *X, int D, int64_t row, int dim)
+{
+    return X[(((row >> 6) * (D >> 2) + (dim >> 2)) * 64 + (row & 63)) * 4 + (dim & 3)];
+}
+
+// one thread per (tile, lane): lane (li, lk) of tile t owns row 32 t + li, dimensions 16 c + 8 lk .. + 8 of chunk c.
+// stats[0] = max |x|^2 (uint bits), stats[1] = number of rows holding a non-finite value
+__global__ __launch_bounds__(kBlock) void flat_pack_kernel(const float *__restrict__ X, int64_t n, int D, int l2, int64_t ntiles,
+                                                           uint4 *__restrict__ pack, uint32_t *__restrict__ bias,
+                                                           uint32_t *__restrict__ stats)
+{
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= ntiles * 64) return;
+    const int64_t t = g >> 6;
+    const int lane = (int)(g & 63), li = lane & 31, lk = lane >> 5, nch = D / 16;
+    const int64_t row = t * 32 + li;
+    bool finite = true;
+    for (int c = 0; c < nch; ++c) {
+        union { bf16x8 v; uint4 u; } h1, h2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = row < n ? blocked_at(X, D, row, 16 * c + 8 * lk + e) : 0.0f;
+            finite = finite && (fabsf(v) <= 3.0e38f);
+            const __bf16 a = (__bf16)v;
+            h1.v[e] = a;
+            h2.v[e] = (__bf16)(v - (float)a);
+        }
+        pack[((t * nch + c) * 2 + 0) * 64 + lane] = h1.u;
+        pack[((t * nch + c) * 2 + 1) * 64 + lane] = h2.u;
+    }
+    if (!finite) atomicAdd(&stats[1], 1u);
+    if (lk == 0) {
+        float b = kPadBias;
+        if (row < n) {
+            float s = 0.0f;
+            for (int e = 0; e < D; ++e) {
+                const float v = blocked_at(X, D, row, e);
+                s = __fmaf_rn(v, v, s);
+            }
+            b = l2 ? -0.5f * s : 0.0f;
+            atomicMax(&stats[0], __float_as_uint(s));  // NaN / inf show up as such: the call takes the exact path
+        }
+        const __bf16 a = (__bf16)b, c2 = (__bf16)(b - (float)a);
+        bias[row] = (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, c2) << 16);
+    }
+}
+
+// thr[q]: a row whose reference distance is <= tau_q = sample_d[q][k-1] has T >= thr[q] (see the bound above);
+// -inf (everything passes -> overflow -> exact path) whenever the bound does not apply
+__global__ __launch_bounds__(kBlock) void flat_thr_kernel(const float *__restrict__ q, int64_t nq, int D, int l2,
+                                                          const float *__restrict__ sample_d, int k,
+                                                          uint32_t *__restrict__ stats, float *__restrict__ thr)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nq) return;
+    float qq = 0.0f;
+    for (int e = 0; e < D; ++e) qq = __fmaf_rn(q[i * D + e], q[i * D + e], qq);
+    if (!(qq <= 3.0e38f)) atomicMax(&stats[2], 0xffffffffu);  // a non-finite query: reads as an overflow, the exact path answers
+    const float tau = sample_d[i * k + k - 1];
+    const float Q = (qq + __uint_as_float(stats[0])) * 1.001f;
+    float t = l2 ? 0.5f * (qq - tau) - Q * 0x1p-13f : (1.0f - tau) - Q * 0x1p-13f - (1.0f + fabsf(tau)) * 0x1p-20f;
+    if (!(Q > 0x1p-60f && Q < 0x1p60f) || !(fabsf(t) <= 3.0e38f) || !(fabsf(tau) <= 3.0e38f)) t = -__uint_as_float(0x7f800000u);
+    thr[i] = t;
+}
+
+constexpr int FF_THREADS = 512;  // 8 waves = 256 queries per workgroup; the row tile is shared through LDS
+
+template <int NCH>
+__global__ __launch_bounds__(FF_THREADS) void flat_filter_kernel(const float *__restrict__ q, int64_t nq, const uint4 *__restrict__ pack,
+                                                                 const uint32_t *__restrict__ bias, const float *__restrict__ thr,
+                                                                 int64_t tile_begin, int64_t tile_end, int64_t tiles_per_split,
+                                                                 int cap, uint32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand_id)
+{
+    constexpr int D = 16 * NCH;
+    constexpr int TILE = NCH * 2 * 64;                          // uint4 per row tile (both bf16 halves, operand order)
+    constexpr int LPT = (TILE + FF_THREADS - 1) / FF_THREADS;   // uint4 per thread and tile
+    __shared__ uint4 tile_s[2][TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+    const int64_t qi = ((int64_t)blockIdx.y * (FF_THREADS / 64) + wave) * 32 + li;
+    const int64_t qc = qi < nq ? qi : nq - 1;  // clamped: padding queries compute, never push
+    const float *qp = q + qc * D + 8 * lk;
+    bf16x8 q1[NCH], q2[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float v[8];
+        *reinterpret_cast<float4 *>(&v[0]) = *reinterpret_cast<const float4 *>(qp + 16 * c);
+        *reinterpret_cast<float4 *>(&v[4]) = *reinterpret_cast<const float4 *>(qp + 16 * c + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const __bf16 h = (__bf16)v[e];
+            q1[c][e] = h;
+            q2[c][e] = (__bf16)(v[e] - (float)h);
+        }
+    }
+    const float th = qi < nq ? thr[qc] : __uint_as_float(0x7f800000u);  // +inf: nothing passes
+    const bf16x8 bzero = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    bf16x8 ones = bzero;
+    ones[0] = lk ? (__bf16)0.0f : (__bf16)1.0f;
+    ones[1] = ones[0];
+    const int64_t t0 = tile_begin + (int64_t)blockIdx.x * tiles_per_split;
+    int64_t t1 = t0 + tiles_per_split;
+    t1 = t1 < tile_end ? t1 : tile_end;
+    if (t0 >= t1) return;
+    // tile t+1 travels HBM -> registers while tile t (in LDS) feeds the products; one LDS-only barrier per tile
+    uint4 pre[LPT];
+    auto fetch = [&](int64_t t) {
+        t = t < t1 ? t : t1 - 1;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            int f = tid + i * FF_THREADS;
+            f = f < TILE ? f : TILE - 1;
+            pre[i] = pack[t * TILE + f];
+        }
+    };
+    fetch(t0);
+    for (int64_t t = t0; t < t1; ++t) {
+        uint4 *stage = tile_s[(t - t0) & 1];
+#pragma unroll
+        for (int i = 0; i < LPT; ++i)
+            if (tid + i * FF_THREADS < TILE) stage[tid + i * FF_THREADS] = pre[i];
+        fetch(t + 1);
+        const uint32_t hv = bias[t * 32 + li];
+        lds_barrier();
+        const uint4 *pa = stage + lane;
+        const f32x16 zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        f32x16 acc0 = zero, acc1 = zero;  // two chains: dependent products are two apart
+        // D[row i of the tile][query j]: A = rows (i = lane & 31, k = 8 * (lane >> 5) ..), B = queries
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            union { uint4 u; bf16x8 v; } a1, a2;
+            a1.u = pa[(c * 2 + 0) * 64];
+            a2.u = pa[(c * 2 + 1) * 64];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, q1[c], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, q2[c], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, q1[c], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, q2[c], acc1, 0, 0, 0);
+        }
+        {
+            union { uint32_t u[4]; bf16x8 v; } ab = { { lk ? 0u : hv, 0u, 0u, 0u } };
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab.v, ones, acc0, 0, 0, 0);  // + b_x
+        }
+        uint32_t hit = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) hit |= ((acc0[e] + acc1[e]) >= th ? 1u : 0u) << e;
+        if (__any(hit != 0)) {  // rare: ~15 k rows per query over the whole scan
+            while (hit) {
+                const int e = __ffs((int)hit) - 1;
+                hit &= hit - 1;
+                const uint32_t pos = atomicAdd(&cand_cnt[qc], 1u);
+                if (pos < (uint32_t)cap) cand_id[qc * cap + pos] = (int32_t)(t * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk);
+            }
+        }
+    }
+}
+
+// exact distances of the candidates, in the reference's summation order (dist_f32.h): out [nq][k + cap], the first k
+// columns are the sample's results (copied by the caller), column k + s is candidate s (+inf / INT64_MAX padding)
+template <bool IP, int LANES>
+__global__ __launch_bounds__(kBlock) void flat_rerank_kernel(const float *__restrict__ X, int64_t n, int D, const float *__restrict__ q,
+                                                             int64_t nq, const uint32_t *__restrict__ cand_cnt,
+                                                             const int32_t *__restrict__ cand_id, int cap, int k,
+                                                             float *__restrict__ out_d, int64_t *__restrict__ out_i)
+{
+    const int64_t qi = blockIdx.y;
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= cap) return;
+    const uint32_t cnt = cand_cnt[qi];
+    float d = __uint_as_float(0x7f800000u);
+    int64_t id = 0x7fffffffffffffffLL;
+    if ((uint32_t)s < cnt) {
+        const int64_t row = cand_id[qi * cap + s];
+        if (row < n) {
+            float acc[LANES];
+#pragma unroll
+            for (int l = 0; l < LANES; ++l) acc[l] = 0.0f;
+            const float *qv = q + qi * D;
+            for (int i = 0; i < D; i += LANES) {
+#pragma unroll
+                for (int l = 0; l < LANES; ++l) {
+                    const float xv = blocked_at(X, D, row, i + l);
+                    if constexpr (IP) {
+                        acc[l] = __fadd_rn(acc[l], __fmul_rn(qv[i + l], xv));
+                    } else {
+                        const float t = __fsub_rn(qv[i + l], xv);
+                        acc[l] = __fadd_rn(acc[l], __fmul_rn(t, t));
+                    }
+                }
+            }
+            float sum = acc[0];
+#pragma unroll
+            for (int l = 1; l < LANES; ++l) sum = __fadd_rn(sum, acc[l]);
+            d = IP ? __fsub_rn(1.0f, sum) : sum;
+            id = row;
+        }
+    }
+    out_d[qi * (k + cap) + k + s] = d;
+    out_i[qi * (k + cap) + k + s] = id;
+}
+
+__global__ __launch_bounds__(kBlock) void flat_copy_sample_kernel(const float *__restrict__ sd, const int64_t *__restrict__ si, int64_t nq,
+                                                                  int k, int cap, float *__restrict__ out_d, int64_t *__restrict__ out_i)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nq * k) return;
+    const int64_t qi = i / k;
+    const int j = (int)(i - qi * k);
+    out_d[qi * (k + cap) + j] = sd[i];
+    out_i[qi * (k + cap) + j] = si[i] < 0 ? 0x7fffffffffffffffLL : si[i];
+}
+
+// max over queries of the candidate count, and the non-finite row count: decides the fallback
+__global__ __launch_bounds__(kBlock) void flat_overflow_kernel(const uint32_t *__restrict__ cand_cnt, int64_t nq, uint32_t *__restrict__ out)
+{
+    uint32_t m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nq; i += (int64_t)gridDim.x * kBlock) m = cand_cnt[i] > m ? cand_cnt[i] : m;
+    atomicMax(out, m);
+}
+
+bool flat_filter_applies(int metric, int D, int64_t n, int64_t nq, int k)
+{
+    return (metric == CVTMI_METRIC_IP || metric == CVTMI_METRIC_L2F) && D >= 32 && D <= 128 && D % 16 == 0 && nq >= 64 && n >= 131072 &&
+           k <= 128;
+}
+
+size_t flat_pack_bytes(int D, int64_t n) { return (size_t)((n + 31) / 32) * (D / 16) * 2 * 64 * sizeof(uint4); }
+
+int launch_flat_pack(const float *X, int64_t n, int D, int metric, uint4 *pack, uint32_t *bias, uint32_t *stats, hipStream_t st)
+{
+    const int64_t ntiles = (n + 31) / 32;
+    CVTMI_HIP(hipMemsetAsync(stats, 0, 8, st));
+    hipLaunchKernelGGL(flat_pack_kernel, dim3((unsigned)((ntiles * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, X, n, D,
+                       metric == CVTMI_METRIC_L2F ? 1 : 0, ntiles, pack, bias, stats);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+int launch_flat_thr(const float *q, int64_t nq, int D, int metric, const float *sample_d, int k, uint32_t *stats, float *thr,
+                    hipStream_t st)
+{
+    hipLaunchKernelGGL(flat_thr_kernel, dim3((unsigned)((nq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, q, nq, D,
+                       metric == CVTMI_METRIC_L2F ? 1 : 0, sample_d, k, stats, thr);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+// rows [row_begin, n) (row_begin % 32 == 0) against all queries; cand_cnt must be zeroed by the caller
+int launch_flat_filter(const float *q, int64_t nq, int D, const uint4 *pack, const uint32_t *bias, const float *thr, int64_t row_begin,
+                       int64_t n, int cap, uint32_t *cand_cnt, int32_t *cand_id, hipStream_t st)
+{
+    const int64_t tile_begin = row_begin / 32, tile_end = (n + 31) / 32;
+    if (tile_end <= tile_begin) return CVTMI_OK;
+    const int64_t qblocks = (nq + 255) / 256;
+    int64_t splits = std::max<int64_t>(1, (256 * 4 + qblocks - 1) / qblocks);   // ~4 workgroups per CU in flight
+    int64_t tps = std::max<int64_t>(16, (tile_end - tile_begin + splits - 1) / splits);
+    splits = (tile_end - tile_begin + tps - 1) / tps;
+    if (qblocks > 65535) return fail(CVTMI_EUNSUPPORTED, "flat filter: nq too large");
+    const dim3 g((unsigned)splits, (unsigned)qblocks), b(FF_THREADS);
+#define CVTMI_FF(N)                                                                                                               \
+    case N:                                                                                                                       \
+        hipLaunchKernelGGL((flat_filter_kernel<N>), g, b, 0, st, q, nq, pack, bias, thr, tile_begin, tile_end, tps, cap, cand_cnt, cand_id); \
+        break;
+    switch (D / 16) {
+        CVTMI_FF(2) CVTMI_FF(3) CVTMI_FF(4) CVTMI_FF(5) CVTMI_FF(6) CVTMI_FF(7) CVTMI_FF(8)
+        default: return fail(CVTMI_EUNSUPPORTED, "flat filter: D=%d", D);
+    }
+#undef CVTMI_FF
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+int launch_flat_rerank(int metric, const float *X, int64_t n, int D, const float *q, int64_t nq, const uint32_t *cand_cnt,
+                       const int32_t *cand_id, int cap, int k, const float *sample_d, const int64_t *sample_i, float *out_d,
+                       int64_t *out_i, uint32_t *overflow, hipStream_t st)
+{
+    if (nq > 65535 * 16) return fail(CVTMI_EUNSUPPORTED, "flat rerank: nq too large");
+    hipLaunchKernelGGL(flat_copy_sample_kernel, dim3((unsigned)((nq * k + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sample_d, sample_i, nq, k,
+                       cap, out_d, out_i);
+    const dim3 g((unsigned)((cap + kBlock - 1) / kBlock), (unsigned)nq), b(kBlock);
+    if (nq > 65535) return fail(CVTMI_EUNSUPPORTED, "flat rerank: nq too large");
+    if (metric == CVTMI_METRIC_IP) hipLaunchKernelGGL((flat_rerank_kernel<true, 4>), g, b, 0, st, X, n, D, q, nq, cand_cnt, cand_id, cap, k, out_d, out_i);
+    else hipLaunchKernelGGL((flat_rerank_kernel<false, 8>), g, b, 0, st, X, n, D, q, nq, cand_cnt, cand_id, cap, k, out_d, out_i);
+    hipLaunchKernelGGL(flat_overflow_kernel, dim3(64), dim3(kBlock), 0, st, cand_cnt, nq, overflow);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+}  // namespace cvtmi

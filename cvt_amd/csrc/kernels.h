@@ -59,6 +59,10 @@ int launch_topk_merge(const float *in_d, const int64_t *in_id, int64_t nq, int L
 int launch_topk_select(const float *in_d, const int64_t *in_id, int64_t nq, int64_t n_cand, int k, float *out_d,
                        int64_t *out_id, hipStream_t st);
 
+// unordered candidates with ids in [0, 2^32): equal distances order by id (flat_mfma.hip)
+int launch_topk_select_byid(const float *in_d, const int64_t *in_id, int64_t nq, int64_t n_cand, int k, float *out_d,
+                            int64_t *out_id, hipStream_t st);
+
 // ---- query_video.hip ----
 // probe[nq][nprobe] list ids in visiting order; list_off[coarseK+1]; codes/video_id in list order.
 int launch_coarse_probe(const OpqModelDev &m, const float *q_rot, int64_t nq, int nprobe, int32_t *probe,
@@ -79,6 +83,17 @@ int launch_flat_u8_norms(const uint8_t *x, int64_t n, int D, int32_t *norms, hip
 // fp32 metrics with D % 4 == 0 keep their rows in a blocked layout (float4 c of 64 consecutive rows contiguous)
 // so that a wave's row reads are coalesced; launch_flat_search expects that layout for those shapes
 inline bool flat_blocked(int metric, int D) { return metric != CVTMI_METRIC_L2U8 && (D % 4) == 0; }
+// flat_mfma.hip: fp32 IP / L2 search through the bf16 matrix-core filter (32 <= D <= 128, D % 16 == 0, nq >= 64)
+bool flat_filter_applies(int metric, int D, int64_t n, int64_t nq, int k);
+size_t flat_pack_bytes(int D, int64_t n);
+int launch_flat_pack(const float *X, int64_t n, int D, int metric, uint4 *pack, uint32_t *bias, uint32_t *stats, hipStream_t st);
+int launch_flat_thr(const float *q, int64_t nq, int D, int metric, const float *sample_d, int k, uint32_t *stats, float *thr,
+                    hipStream_t st);
+int launch_flat_filter(const float *q, int64_t nq, int D, const uint4 *pack, const uint32_t *bias, const float *thr, int64_t row_begin,
+                       int64_t n, int cap, uint32_t *cand_cnt, int32_t *cand_id, hipStream_t st);
+int launch_flat_rerank(int metric, const float *X, int64_t n, int D, const float *q, int64_t nq, const uint32_t *cand_cnt,
+                       const int32_t *cand_id, int cap, int k, const float *sample_d, const int64_t *sample_i, float *out_d,
+                       int64_t *out_i, uint32_t *overflow, hipStream_t st);
 int launch_flat_block(const float *src, int64_t n, int D, int64_t row0, float *dst, hipStream_t st);
 int flat_u8_mfma_qtile(int D, int k, int64_t nq);  // queries per workgroup, 0 = shape not covered
 int flat_u8_mfma_splits(int64_t n, int64_t nq, int qt);

@@ -64,7 +64,8 @@ int cvtmi_set_device(int device);
 /* Library-wide tuning / measurement hooks (no effect on results).
  *   "assign_variant"  nearest-centroid assignment (coarse argmin of cvtmi_opq_encode, cvtmi_kmeans): 0 = choose (default);
  *                     1 = the reference's chain for every centroid on the VALU; 2 = bf16 matrix-core filter with exact
- *                     resolution of undecided rows wherever it applies (32 <= d <= 128, d % 16 == 0, k >= 64) */
+ *                     resolution of undecided rows wherever it applies (32 <= d <= 128, d % 16 == 0, k >= 64)
+ *   "flat_variant"    fp32 exhaustive search: 0 = choose (default); 1 = exact kernels; 2 = matrix-core filter wherever it applies */
 int cvtmi_set_tuning(const char *name, int64_t value);
 
 /* ---------------------------------------------------------------- OPQ model + code index ---- */
@@ -181,6 +182,11 @@ int cvtmi_flat_reset(cvtmi_flat_t h);
 int cvtmi_flat_search(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels);
 int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels,
                           void *stream);
+/* Measurement hook: was the last search answered through the matrix-core filter (fp32 metrics, 32 <= D <= 128, D % 16 == 0,
+ * >= 64 queries, >= 131072 rows: exact search of a leading sample, bf16 matrix-core products decide which other rows need
+ * an exact distance; same results), and the largest candidate list it produced.  cvtmi_set_tuning("flat_variant", 1)
+ * turns the filter off, 2 applies it to smaller batches too. */
+int cvtmi_flat_last_search(cvtmi_flat_t h, int *filtered, int64_t *max_candidates);
 
 /* ---------------------------------------------------------------- int8 scalar quantisation -- */
 /* Per-dimension min / (max - min) over (optionally L2-normalised) rows: what

@@ -211,3 +211,74 @@ def test_merge_parity(amd, orc):
         od, oi = orc.merge_topk(d, ids, k)
         assert np.array_equal(mi, oi), (nq, L, k)
         assert np.array_equal(bits(md), bits(od))
+
+
+@pytest.mark.parametrize("metric,D,k", [(IP, 128, 100), (L2F, 128, 100), (IP, 64, 10), (L2F, 32, 1), (L2F, 96, 128), (IP, 128, 5)])
+def test_flat_f32_matrix_core_filter(amd, orc, metric, D, k):
+    """fp32 search through the bf16 matrix-core filter (flat_variant 2) against the exact kernels (flat_variant 1) on the
+    whole batch, and against the checker on a few queries: clustered rows with exact duplicates of rows and of queries
+    (ties broken by row), appends between searches, unit-norm and large-magnitude data"""
+    rng = np.random.default_rng(D * 7 + k + metric)
+    n, nq = 150_000, 200
+    cen = rng.normal(size=(500, D)).astype(np.float32)
+    x = (cen[rng.integers(0, 500, n)] + 0.5 * rng.normal(size=(n, D))).astype(np.float32)
+    if metric == IP:
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+    else:
+        x *= np.float32(37.0)
+    x[100_000:100_300] = x[5]; x[140_000:140_050] = x[70_000]          # duplicates inside and outside the leading sample
+    q = x[rng.integers(0, n, nq)] + (0.05 * rng.normal(size=(nq, D))).astype(np.float32)
+    q[:20] = x[rng.integers(0, n, 20)]                                  # queries that are rows: zero distances, ties
+    q[20] = x[5]
+    q = np.ascontiguousarray(q, np.float32)
+    try:
+        res = {}
+        for v in (2, 1):
+            amd.set_tuning("flat_variant", v)
+            ix = amd.FlatIndex(metric, D); ix.add(x[:130_000]); ix.add(x[130_000:])
+            res[v] = ix.search(q, k)
+            used, worst = ix.last_search()
+            assert used == (v == 2) and (v == 1 or 0 < worst < 24 * k + 1024), (used, worst)
+            if v == 2:   # append after a search: the operand copy is rebuilt
+                ix.add(x[:1000] * np.float32(0.5))
+                d2, i2 = ix.search(q, k)
+                assert ix.last_search()[0]
+                amd.set_tuning("flat_variant", 1)
+                d1, i1 = ix.search(q, k)
+                assert np.array_equal(i2, i1) and np.array_equal(bits(d2), bits(d1))
+        assert np.array_equal(res[2][1], res[1][1])
+        assert np.array_equal(bits(res[2][0]), bits(res[1][0]))
+        od, _, oi = orc.flat_search(metric, x, q[:24], k, flavour=4 if metric == IP else 8)
+        assert np.array_equal(res[2][1][:24], oi) and np.array_equal(bits(res[2][0][:24]), bits(od))
+    finally:
+        amd.set_tuning("flat_variant", 0)
+
+
+def test_flat_f32_filter_gives_up_cleanly(amd):
+    """rows sorted by similarity to the queries (the leading sample says nothing about the rest: candidate lists
+    overflow), a non-finite row, non-finite queries, labels: the exact path answers, same results"""
+    rng = np.random.default_rng(11)
+    n, D, nq, k = 140_000, 128, 80, 10
+    x = rng.normal(size=(n, D)).astype(np.float32)
+    q = rng.normal(size=(nq, D)).astype(np.float32)
+    order = np.argsort(-(x @ q[0]))[::-1]        # best matches of query 0 last
+    xs = np.ascontiguousarray(x[order])
+    labels = (np.arange(n, dtype=np.int64) * 3 + 5)
+    cases = [("sorted", xs, q, None), ("labels", x, q, labels)]
+    xn = x.copy(); xn[135_000, 7] = np.inf
+    cases.append(("inf row", xn, q, None))
+    qn = q.copy(); qn[3, 0] = np.nan; qn[4, 5] = np.inf
+    cases.append(("nan query", x, qn, None))
+    try:
+        for name, xx, qq, lab in cases:
+            out = {}
+            for v in (2, 1):
+                amd.set_tuning("flat_variant", v)
+                ix = amd.FlatIndex(1, D); ix.add(xx, labels=lab)
+                out[v] = ix.search(qq, k)
+                if v == 2:
+                    assert ix.last_search()[0] == (name == "labels"), name   # labels do not stop the filter, the others do
+            assert np.array_equal(out[2][1], out[1][1]), name
+            assert np.array_equal(bits(out[2][0]), bits(out[1][0])), name
+    finally:
+        amd.set_tuning("flat_variant", 0)

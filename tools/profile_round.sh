@@ -47,5 +47,5 @@ PY
 # one line per secondary kernel / sibling path (not profiled, just timed)
 cd $REPO
 { python tools/bench_kernels.py; python tools/bench_sq8.py; python tools/bench_flat_f32.py;
-  ROWS=10000000 CASES=1000:10,4096:10,1:10 python tools/bench_flat_u8.py; python tools/bench_train.py; python tools/bench_hnsw.py; python tools/bench_pca.py; python tools/bench_encode.py; python tools/bench_assign.py; } 2>&1 | grep -v amdgpu > $OUT/other_kernels.txt
+  ROWS=10000000 CASES=1000:10,4096:10,1:10 python tools/bench_flat_u8.py; python tools/bench_train.py; python tools/bench_hnsw.py; python tools/bench_pca.py; python tools/bench_encode.py; python tools/bench_assign.py; python tools/bench_flat_filter.py; } 2>&1 | grep -v amdgpu > $OUT/other_kernels.txt
 ls -la $OUT
