@@ -103,12 +103,17 @@ template <int NCH>
 __global__ __launch_bounds__(FF_THREADS) void flat_filter_kernel(const float *__restrict__ q, int64_t nq, const uint4 *__restrict__ pack,
                                                                  const uint32_t *__restrict__ bias, const float *__restrict__ thr,
                                                                  int64_t tile_begin, int64_t tile_end, int64_t tiles_per_split,
-                                                                 int cap, uint32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand_id)
+                                                                 uint32_t pair_cap, uint32_t *__restrict__ pair_cnt, uint2 *__restrict__ pairs)
 {
     constexpr int D = 16 * NCH;
     constexpr int TILE = NCH * 2 * 64;                          // uint4 per row tile (both bf16 halves, operand order)
     constexpr int LPT = (TILE + FF_THREADS - 1) / FF_THREADS;   // uint4 per thread and tile
     __shared__ uint4 tile_s[2][TILE];
+    // survivors are parked per wave in LDS (slots handed out with ballots: no atomics) and leave in batches: one global
+    // atomic and one coalesced write per ~190 survivors instead of a 2 us round trip per survivor in the tile loop
+    constexpr int PBUF = 256;
+    __shared__ uint2 park_s[FF_THREADS / 64][PBUF];
+    int parked = 0;  // wave-uniform
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
     const int64_t qi = ((int64_t)blockIdx.y * (FF_THREADS / 64) + wave) * 32 + li;
     const int64_t qc = qi < nq ? qi : nq - 1;  // clamped: padding queries compute, never push
@@ -176,59 +181,82 @@ __global__ __launch_bounds__(FF_THREADS) void flat_filter_kernel(const float *__
         uint32_t hit = 0;
 #pragma unroll
         for (int e = 0; e < 16; ++e) hit |= ((acc0[e] + acc1[e]) >= th ? 1u : 0u) << e;
-        if (__any(hit != 0)) {  // rare: ~15 k rows per query over the whole scan
-            while (hit) {
+        if (qi >= nq) hit = 0;
+        while (__any(hit != 0)) {  // ~15 k survivors per query over the whole scan: a couple per wave and tile
+            const unsigned long long m = __ballot(hit != 0);
+            const int cnt = __popcll(m);
+            if (parked + cnt > PBUF) {  // flush (wave-uniform branch)
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(pair_cnt, (uint32_t)parked);
+                base = __shfl(base, 0, 64);
+                for (int i = lane; i < parked; i += 64)
+                    if (base + i < pair_cap) pairs[base + i] = park_s[wave][i];
+                parked = 0;
+            }
+            if (hit) {
                 const int e = __ffs((int)hit) - 1;
                 hit &= hit - 1;
-                const uint32_t pos = atomicAdd(&cand_cnt[qc], 1u);
-                if (pos < (uint32_t)cap) cand_id[qc * cap + pos] = (int32_t)(t * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk);
+                park_s[wave][parked + __popcll(m & ((1ull << lane) - 1))] =
+                    make_uint2((uint32_t)qi, (uint32_t)(t * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk));
             }
+            parked += cnt;
         }
+    }
+    if (parked) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(pair_cnt, (uint32_t)parked);
+        base = __shfl(base, 0, 64);
+        for (int i = lane; i < parked; i += 64)
+            if (base + i < pair_cap) pairs[base + i] = park_s[wave][i];
     }
 }
 
-// exact distances of the candidates, in the reference's summation order (dist_f32.h): out [nq][k + cap], the first k
-// columns are the sample's results (copied by the caller), column k + s is candidate s (+inf / INT64_MAX padding)
+// exact distance of every surviving (query, row) pair, in the reference's summation order (dist_f32.h), appended to the
+// query's columns of sel_* [nq][k + cap]: the first k columns hold the sample's results, column k + slot the survivors
 template <bool IP, int LANES>
 __global__ __launch_bounds__(kBlock) void flat_rerank_kernel(const float *__restrict__ X, int64_t n, int D, const float *__restrict__ q,
-                                                             int64_t nq, const uint32_t *__restrict__ cand_cnt,
-                                                             const int32_t *__restrict__ cand_id, int cap, int k,
-                                                             float *__restrict__ out_d, int64_t *__restrict__ out_i)
+                                                             const uint32_t *__restrict__ pair_cnt, uint32_t pair_cap,
+                                                             const uint2 *__restrict__ pairs, int cap, int k,
+                                                             uint32_t *__restrict__ cand_cnt, float *__restrict__ sel_d,
+                                                             int64_t *__restrict__ sel_i)
 {
-    const int64_t qi = blockIdx.y;
-    const int s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= cap) return;
-    const uint32_t cnt = cand_cnt[qi];
-    float d = __uint_as_float(0x7f800000u);
-    int64_t id = 0x7fffffffffffffffLL;
-    if ((uint32_t)s < cnt) {
-        const int64_t row = cand_id[qi * cap + s];
-        if (row < n) {
-            float acc[LANES];
+    uint32_t total = *pair_cnt;
+    total = total < pair_cap ? total : pair_cap;
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < total; p += gridDim.x * kBlock) {
+        const uint2 pr = pairs[p];
+        const int64_t qi = pr.x, row = pr.y;
+        if (row >= n) continue;  // padding rows of the last tile
+        float acc[LANES];
 #pragma unroll
-            for (int l = 0; l < LANES; ++l) acc[l] = 0.0f;
-            const float *qv = q + qi * D;
-            for (int i = 0; i < D; i += LANES) {
+        for (int l = 0; l < LANES; ++l) acc[l] = 0.0f;
+        const float4 *qv = reinterpret_cast<const float4 *>(q + qi * D);
+        // blocked layout: float4 c of a row sits at ((row >> 6) * (D / 4) + c) * 64 + (row & 63)
+        const float4 *xr = reinterpret_cast<const float4 *>(X) + (row >> 6) * (int64_t)(D >> 2) * 64 + (row & 63);
+        for (int i4 = 0; i4 < D / 4; i4 += LANES / 4) {
 #pragma unroll
-                for (int l = 0; l < LANES; ++l) {
-                    const float xv = blocked_at(X, D, row, i + l);
+            for (int g = 0; g < LANES / 4; ++g) {
+                const float4 xv = xr[(int64_t)(i4 + g) * 64], qq = qv[i4 + g];
+                const float xs[4] = { xv.x, xv.y, xv.z, xv.w }, qs[4] = { qq.x, qq.y, qq.z, qq.w };
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
                     if constexpr (IP) {
-                        acc[l] = __fadd_rn(acc[l], __fmul_rn(qv[i + l], xv));
+                        acc[4 * g + l] = __fadd_rn(acc[4 * g + l], __fmul_rn(qs[l], xs[l]));
                     } else {
-                        const float t = __fsub_rn(qv[i + l], xv);
-                        acc[l] = __fadd_rn(acc[l], __fmul_rn(t, t));
+                        const float t = __fsub_rn(qs[l], xs[l]);
+                        acc[4 * g + l] = __fadd_rn(acc[4 * g + l], __fmul_rn(t, t));
                     }
                 }
             }
-            float sum = acc[0];
+        }
+        float sum = acc[0];
 #pragma unroll
-            for (int l = 1; l < LANES; ++l) sum = __fadd_rn(sum, acc[l]);
-            d = IP ? __fsub_rn(1.0f, sum) : sum;
-            id = row;
+        for (int l = 1; l < LANES; ++l) sum = __fadd_rn(sum, acc[l]);
+        const uint32_t slot = atomicAdd(&cand_cnt[qi], 1u);
+        if (slot < (uint32_t)cap) {
+            sel_d[qi * (k + cap) + k + slot] = IP ? __fsub_rn(1.0f, sum) : sum;
+            sel_i[qi * (k + cap) + k + slot] = row;
         }
     }
-    out_d[qi * (k + cap) + k + s] = d;
-    out_i[qi * (k + cap) + k + s] = id;
 }
 
 __global__ __launch_bounds__(kBlock) void flat_copy_sample_kernel(const float *__restrict__ sd, const int64_t *__restrict__ si, int64_t nq,
@@ -243,9 +271,10 @@ __global__ __launch_bounds__(kBlock) void flat_copy_sample_kernel(const float *_
 }
 
 // max over queries of the candidate count, and the non-finite row count: decides the fallback
-__global__ __launch_bounds__(kBlock) void flat_overflow_kernel(const uint32_t *__restrict__ cand_cnt, int64_t nq, uint32_t *__restrict__ out)
+__global__ __launch_bounds__(kBlock) void flat_overflow_kernel(const uint32_t *__restrict__ cand_cnt, int64_t nq, const uint32_t *__restrict__ pair_cnt,
+                                                               uint32_t pair_cap, uint32_t *__restrict__ out)
 {
-    uint32_t m = 0;
+    uint32_t m = *pair_cnt > pair_cap ? 0xffffffffu : 0u;  // the pair list itself ran over
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nq; i += (int64_t)gridDim.x * kBlock) m = cand_cnt[i] > m ? cand_cnt[i] : m;
     atomicMax(out, m);
 }
@@ -277,9 +306,9 @@ int launch_flat_thr(const float *q, int64_t nq, int D, int metric, const float *
     return CVTMI_OK;
 }
 
-// rows [row_begin, n) (row_begin % 32 == 0) against all queries; cand_cnt must be zeroed by the caller
+// rows [row_begin, n) (row_begin % 32 == 0) against all queries; *pair_cnt must be zeroed by the caller
 int launch_flat_filter(const float *q, int64_t nq, int D, const uint4 *pack, const uint32_t *bias, const float *thr, int64_t row_begin,
-                       int64_t n, int cap, uint32_t *cand_cnt, int32_t *cand_id, hipStream_t st)
+                       int64_t n, uint32_t pair_cap, uint32_t *pair_cnt, uint2 *pairs, hipStream_t st)
 {
     const int64_t tile_begin = row_begin / 32, tile_end = (n + 31) / 32;
     if (tile_end <= tile_begin) return CVTMI_OK;
@@ -291,7 +320,7 @@ int launch_flat_filter(const float *q, int64_t nq, int D, const uint4 *pack, con
     const dim3 g((unsigned)splits, (unsigned)qblocks), b(FF_THREADS);
 #define CVTMI_FF(N)                                                                                                               \
     case N:                                                                                                                       \
-        hipLaunchKernelGGL((flat_filter_kernel<N>), g, b, 0, st, q, nq, pack, bias, thr, tile_begin, tile_end, tps, cap, cand_cnt, cand_id); \
+        hipLaunchKernelGGL((flat_filter_kernel<N>), g, b, 0, st, q, nq, pack, bias, thr, tile_begin, tile_end, tps, pair_cap, pair_cnt, pairs); \
         break;
     switch (D / 16) {
         CVTMI_FF(2) CVTMI_FF(3) CVTMI_FF(4) CVTMI_FF(5) CVTMI_FF(6) CVTMI_FF(7) CVTMI_FF(8)
@@ -302,18 +331,19 @@ int launch_flat_filter(const float *q, int64_t nq, int D, const uint4 *pack, con
     return CVTMI_OK;
 }
 
-int launch_flat_rerank(int metric, const float *X, int64_t n, int D, const float *q, int64_t nq, const uint32_t *cand_cnt,
-                       const int32_t *cand_id, int cap, int k, const float *sample_d, const int64_t *sample_i, float *out_d,
-                       int64_t *out_i, uint32_t *overflow, hipStream_t st)
+// cand_cnt [nq] must be zeroed by the caller; overflow receives max(candidates per query), 0xffffffff if the pair list ran over
+int launch_flat_rerank(int metric, const float *X, int64_t n, int D, const float *q, int64_t nq, const uint32_t *pair_cnt, uint32_t pair_cap,
+                       const uint2 *pairs, int cap, int k, const float *sample_d, const int64_t *sample_i, uint32_t *cand_cnt,
+                       float *sel_d, int64_t *sel_i, uint32_t *overflow, hipStream_t st)
 {
-    if (nq > 65535 * 16) return fail(CVTMI_EUNSUPPORTED, "flat rerank: nq too large");
     hipLaunchKernelGGL(flat_copy_sample_kernel, dim3((unsigned)((nq * k + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sample_d, sample_i, nq, k,
-                       cap, out_d, out_i);
-    const dim3 g((unsigned)((cap + kBlock - 1) / kBlock), (unsigned)nq), b(kBlock);
-    if (nq > 65535) return fail(CVTMI_EUNSUPPORTED, "flat rerank: nq too large");
-    if (metric == CVTMI_METRIC_IP) hipLaunchKernelGGL((flat_rerank_kernel<true, 4>), g, b, 0, st, X, n, D, q, nq, cand_cnt, cand_id, cap, k, out_d, out_i);
-    else hipLaunchKernelGGL((flat_rerank_kernel<false, 8>), g, b, 0, st, X, n, D, q, nq, cand_cnt, cand_id, cap, k, out_d, out_i);
-    hipLaunchKernelGGL(flat_overflow_kernel, dim3(64), dim3(kBlock), 0, st, cand_cnt, nq, overflow);
+                       cap, sel_d, sel_i);
+    const dim3 g(256 * 16), b(kBlock);
+    if (metric == CVTMI_METRIC_IP)
+        hipLaunchKernelGGL((flat_rerank_kernel<true, 4>), g, b, 0, st, X, n, D, q, pair_cnt, pair_cap, pairs, cap, k, cand_cnt, sel_d, sel_i);
+    else
+        hipLaunchKernelGGL((flat_rerank_kernel<false, 8>), g, b, 0, st, X, n, D, q, pair_cnt, pair_cap, pairs, cap, k, cand_cnt, sel_d, sel_i);
+    hipLaunchKernelGGL(flat_overflow_kernel, dim3(64), dim3(kBlock), 0, st, cand_cnt, nq, pair_cnt, pair_cap, overflow);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

@@ -60,8 +60,9 @@ int launch_topk_select(const float *in_d, const int64_t *in_id, int64_t nq, int6
                        int64_t *out_id, hipStream_t st);
 
 // unordered candidates with ids in [0, 2^32): equal distances order by id (flat_mfma.hip)
+// counts != null: query q holds base + min(counts[q], n_cand - base) valid candidates (the rest of its row is not read)
 int launch_topk_select_byid(const float *in_d, const int64_t *in_id, int64_t nq, int64_t n_cand, int k, float *out_d,
-                            int64_t *out_id, hipStream_t st);
+                            int64_t *out_id, hipStream_t st, const uint32_t *counts = nullptr, int base = 0);
 
 // ---- query_video.hip ----
 // probe[nq][nprobe] list ids in visiting order; list_off[coarseK+1]; codes/video_id in list order.
@@ -90,10 +91,10 @@ int launch_flat_pack(const float *X, int64_t n, int D, int metric, uint4 *pack, 
 int launch_flat_thr(const float *q, int64_t nq, int D, int metric, const float *sample_d, int k, uint32_t *stats, float *thr,
                     hipStream_t st);
 int launch_flat_filter(const float *q, int64_t nq, int D, const uint4 *pack, const uint32_t *bias, const float *thr, int64_t row_begin,
-                       int64_t n, int cap, uint32_t *cand_cnt, int32_t *cand_id, hipStream_t st);
-int launch_flat_rerank(int metric, const float *X, int64_t n, int D, const float *q, int64_t nq, const uint32_t *cand_cnt,
-                       const int32_t *cand_id, int cap, int k, const float *sample_d, const int64_t *sample_i, float *out_d,
-                       int64_t *out_i, uint32_t *overflow, hipStream_t st);
+                       int64_t n, uint32_t pair_cap, uint32_t *pair_cnt, uint2 *pairs, hipStream_t st);
+int launch_flat_rerank(int metric, const float *X, int64_t n, int D, const float *q, int64_t nq, const uint32_t *pair_cnt, uint32_t pair_cap,
+                       const uint2 *pairs, int cap, int k, const float *sample_d, const int64_t *sample_i, uint32_t *cand_cnt,
+                       float *sel_d, int64_t *sel_i, uint32_t *overflow, hipStream_t st);
 int launch_flat_block(const float *src, int64_t n, int D, int64_t row0, float *dst, hipStream_t st);
 int flat_u8_mfma_qtile(int D, int k, int64_t nq);  // queries per workgroup, 0 = shape not covered
 int flat_u8_mfma_splits(int64_t n, int64_t nq, int qt);

@@ -21,12 +21,17 @@ constexpr int MERGE_R = 4;
 template <bool BYID>
 __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restrict__ in_d,
                                                             const int64_t *__restrict__ in_id, int n_cand, int k,
-                                                            float *__restrict__ out_d, int64_t *__restrict__ out_id)
+                                                            float *__restrict__ out_d, int64_t *__restrict__ out_id,
+                                                            const uint32_t *__restrict__ counts, int cbase)
 {
     __shared__ TopKShared<1, MERGE_CAP> tk;
     const int64_t q = blockIdx.x;
     const float *d = in_d + q * n_cand;
     const int64_t *id = in_id + q * n_cand;
+    if (counts) {  // only the leading cbase + counts[q] entries of the row are filled
+        const uint32_t c = counts[q], room = (uint32_t)(n_cand - cbase);
+        n_cand = cbase + (int)(c < room ? c : room);
+    }
     const int tid = threadIdx.x;
     topk_init(tk);
     __syncthreads();
@@ -86,7 +91,7 @@ int launch_topk_select(const float *in_d, const int64_t *in_id, int64_t nq, int6
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "topk: k=%d outside 1..128", k);
     if (n_cand < 0 || n_cand > 0x7fffffff) return fail(CVTMI_EINVAL, "topk: bad candidate count");
     if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "topk: nq too large");
-    hipLaunchKernelGGL(topk_merge_kernel<false>, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, (int)n_cand, k, out_d, out_id);
+    hipLaunchKernelGGL(topk_merge_kernel<false>, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, (int)n_cand, k, out_d, out_id, nullptr, 0);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
@@ -94,13 +99,13 @@ int launch_topk_select(const float *in_d, const int64_t *in_id, int64_t nq, int6
 // k smallest (value, id) of n_cand UNORDERED candidates per query, ids in [0, 2^32); other ids are padding.
 // Distances must not be NaN (the output distance is rebuilt from its order-preserving key).
 int launch_topk_select_byid(const float *in_d, const int64_t *in_id, int64_t nq, int64_t n_cand, int k, float *out_d,
-                            int64_t *out_id, hipStream_t st)
+                            int64_t *out_id, hipStream_t st, const uint32_t *counts, int base)
 {
     if (nq <= 0) return CVTMI_OK;
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "topk: k=%d outside 1..128", k);
     if (n_cand < 0 || n_cand > 0x7fffffff || !in_id) return fail(CVTMI_EINVAL, "topk: bad candidate count");
     if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "topk: nq too large");
-    hipLaunchKernelGGL(topk_merge_kernel<true>, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, (int)n_cand, k, out_d, out_id);
+    hipLaunchKernelGGL(topk_merge_kernel<true>, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, (int)n_cand, k, out_d, out_id, counts, base);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
