@@ -12,13 +12,13 @@
 //             matrix operand and wave), -|c|^2/2 as two bf16 terms per centroid, max |c|^2
 //   filter    a wave owns 32 rows (B side; both bf16 halves of the row stay in registers: 16 d bytes); the 8 waves of a
 //             workgroup sweep the centroid tiles together (A side: tile t+1 HBM/L2 -> registers -> LDS under the products
-//             of tile t, one LDS-only barrier per tile) with 4 d/16 + 1 products per 32 x 32 tile, keeps (best, second, tile of best)
+//             of tile t, one LDS-only barrier per tile) with 3 d/16 + 1 products per 32 x 32 tile (c1.r1, c1.r2, c2.r1; c2.r2 is below the bound), keeps (best, second, tile of best)
 //             per lane: key = T with its low 4 bits replaced by the accumulator element
 //   resolve   flagged rows: gathered, assigned by the exact kernel, scattered back
 //
-// Bound (u = 2^-24, Q = |x|^2 + max |c|^2, |T| <= Q, d_j <= 2Q), d = 128: accumulation of 4 d + 2 terms taken as
-// 2u per term 516 uQ, bf16 splits 64 uQ, |c|^2/2 split 24 uQ, position bits 16 uQ: 620 uQ per key; the reference's
-// chain (d + 3) u d_j = 131 uQ in T units.  best - second > 2 * 620 + 131 = 1371 uQ proves the argmin; the kernel asks
+// Bound (u = 2^-24, Q = |x|^2 + max |c|^2, |T| <= Q, d_j <= 2Q), d = 128: accumulation of 3 d + 2 terms taken as
+// 2u per term 388 uQ, bf16 splits 64 uQ, the omitted c2.r2 term 32 uQ, |c|^2/2 split 24 uQ, position bits 16 uQ: 524 uQ per
+// key; the reference's chain (d + 3) u d_j = 131 uQ in T units.  best - second > 2 * 524 + 131 = 1179 uQ proves the argmin; the kernel asks
 // for 2048 uQ = 2^-13 Q and 2^-60 < Q < 2^30.
 #include <algorithm>
 #include <mutex>
@@ -143,8 +143,7 @@ __global__ __launch_bounds__(AF_THREADS) void assign_filter_kernel(const float *
                 a2.u = pa[(c * 2 + 1) * 64];
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, r1[c], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, r2[c], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, r1[c], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, r2[c], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, r1[c], acc0, 0, 0, 0);  // c2.r2 <= 2^-18 |c||r| is left out (bound)
             }
             {
                 union { uint32_t u[4]; bf16x8 v; } ab = { { lk ? 0u : hv, 0u, 0u, 0u } };

@@ -16,8 +16,9 @@
 // A query whose list overflows (adversarial row order, masses of duplicates), non-finite rows or queries, or
 // magnitudes outside the bound's range send the whole call down the exact path: same answer, old speed.
 //
-// Bound (u = 2^-24, Q = |q|^2 + max |x|^2, |T| <= Q, distances <= 2Q): accumulation of 4 D + 2 terms taken as 2u per
-// term 516 uQ, bf16 splits 64 uQ, |x|^2/2 split and its fp32 rounding 24 uQ: 604 uQ on T; the reference's sum
+// Bound (u = 2^-24, Q = |q|^2 + max |x|^2, |T| <= Q, distances <= 2Q): accumulation of 3 D + 2 terms (x1.q1, x1.q2, x2.q1)
+// taken as 2u per term 388 uQ, bf16 splits 64 uQ, the omitted x2.q2 term 32 uQ, |x|^2/2 split and its fp32 rounding 24 uQ:
+// 508 uQ on T; the reference's sum
 // (D + 4) u 2Q and |q|^2 (D + 1) u Q in distance units, i.e. ~200 uQ in T units.  thr_q is lowered by 2048 uQ = 2^-13 Q.
 #include <algorithm>
 
@@ -171,8 +172,7 @@ __global__ __launch_bounds__(FF_THREADS) void flat_filter_kernel(const float *__
             a2.u = pa[(c * 2 + 1) * 64];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, q1[c], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, q2[c], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, q1[c], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, q2[c], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, q1[c], acc0, 0, 0, 0);  // x2.q2 <= 2^-18 |x||q| is left out (bound)
         }
         {
             union { uint32_t u[4]; bf16x8 v; } ab = { { lk ? 0u : hv, 0u, 0u, 0u } };
