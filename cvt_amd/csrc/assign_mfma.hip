@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void assign_pack_kernel(const float *__rest
 constexpr int AF_THREADS = 512;  // 8 waves = 256 rows per workgroup pass; the centroid tile is shared through LDS
 
 template <int NCH>
-__global__ __launch_bounds__(AF_THREADS) void assign_filter_kernel(const float *__restrict__ x, int64_t ld, int64_t n,
+__global__ __launch_bounds__(AF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void assign_filter_kernel(const float *__restrict__ x, int64_t ld, int64_t n,
                                                                    const uint4 *__restrict__ packA, const uint32_t *__restrict__ nhcp,
                                                                    const uint32_t *__restrict__ cmax2, int ntiles,
                                                                    int32_t *__restrict__ assign, unsigned long long *__restrict__ changed,

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void flat_thr_kernel(const float *__restric
 constexpr int FF_THREADS = 512;  // 8 waves = 256 queries per workgroup; the row tile is shared through LDS
 
 template <int NCH>
-__global__ __launch_bounds__(FF_THREADS) void flat_filter_kernel(const float *__restrict__ q, int64_t nq, const uint4 *__restrict__ pack,
+__global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void flat_filter_kernel(const float *__restrict__ q, int64_t nq, const uint4 *__restrict__ pack,
                                                                  const uint32_t *__restrict__ bias, const float *__restrict__ thr,
                                                                  int64_t tile_begin, int64_t tile_end, int64_t tiles_per_split,
                                                                  uint32_t pair_cap, uint32_t *__restrict__ pair_cnt, uint2 *__restrict__ pairs)

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restr
                 key[r][0] = kk == KEY_MAX ? KEY_MAX - 1 : kk;  // keep the "not a candidate" code free
             }
         }
-        topk_tile<1, MERGE_R, MERGE_CAP, MERGE_TRIG>(tk, k, tile, key, pay);
+        topk_tile<1, MERGE_R, MERGE_CAP, MERGE_TRIG, kBlock, BYID>(tk, k, tile, key, pay);
     }
     __syncthreads();
     topk_compact(tk, k);

@@ -282,3 +282,24 @@ def test_flat_f32_filter_gives_up_cleanly(amd):
             assert np.array_equal(bits(out[2][0]), bits(out[1][0])), name
     finally:
         amd.set_tuning("flat_variant", 0)
+
+
+def test_flat_f32_filter_ties_arrive_out_of_order(amd):
+    """hundreds of rows at exactly the same distance, reaching the final selection in no particular order: the k best are
+    still the lowest row numbers (the selection must offer candidates that tie the current k-th key)"""
+    rng = np.random.default_rng(3)
+    n, D, nq, k = 131072, 48, 300, 100
+    x = rng.normal(size=(n, D)).astype(np.float32)
+    x = x[np.argsort(x[:, 0])]
+    x[100_000:100_900] = x[70_000]                    # 900 duplicates outside the leading sample
+    q = (x[rng.integers(0, n, nq)] + 0.1 * rng.normal(size=(nq, D))).astype(np.float32)
+    q[:40] = x[70_000] + (0.01 * rng.normal(size=(40, D))).astype(np.float32)
+    out = {}
+    try:
+        for v in (2, 1):
+            amd.set_tuning("flat_variant", v)
+            ix = amd.FlatIndex(1, D); ix.add(x)
+            out[v] = ix.search(q, k)
+    finally:
+        amd.set_tuning("flat_variant", 0)
+    assert np.array_equal(out[2][1], out[1][1]) and np.array_equal(bits(out[2][0]), bits(out[1][0]))

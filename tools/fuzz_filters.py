@@ -45,6 +45,14 @@ for it in range(iters):
     ok2 = torch.equal(res[1], res[2])
     print("it %d flat(metric=%d D=%d n=%d nq=%d k=%d kind=%d scale=%g filter=%s worst=%d) %s | assign(k=%d) %s" % (
         it, metric, D, n, nq, k, kind, scale, u, worst, "ok" if ok else "MISMATCH", kc, "ok" if ok2 else "MISMATCH"), flush=True)
+    if not ok:
+        di = (out[1][1] != out[2][1]) | (out[1][0].view(torch.int32) != out[2][0].view(torch.int32))
+        qs = torch.nonzero(di.any(dim=1)).ravel()
+        print('  queries affected:', qs.numel(), qs[:8].tolist())
+        r = int(qs[0]); c = int(torch.nonzero(di[r]).ravel()[0])
+        lo = max(0, c - 2)
+        print('  query', r, 'col', c, 'exact ids', out[1][1][r, lo:c + 4].tolist(), 'd', out[1][0][r, lo:c + 4].tolist())
+        print('  query', r, 'col', c, 'filt  ids', out[2][1][r, lo:c + 4].tolist(), 'd', out[2][0][r, lo:c + 4].tolist())
     if not (ok and ok2): sys.exit(1)
 cvt_amd.set_tuning("flat_variant", 0); cvt_amd.set_tuning("assign_variant", 0)
 print("fuzz_filters: %d iterations, filter answered %d of them, no mismatch" % (iters, used))
