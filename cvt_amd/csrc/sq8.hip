@@ -58,7 +58,7 @@ __global__ __launch_bounds__(SQ_NT) void sq8_tile_kernel(const Sq8Args a)
 {
     extern __shared__ float4 sq_tile[];  // [SQ_ROWS][CG + 1]
     __shared__ float den_s[SQ_ROWS], rcp_s[SQ_ROWS];
-    __shared__ int ok_s[SQ_ROWS];
+    __shared__ int ok_s[SQ_ROWS], seq_s[SQ_ROWS];
     const int CG = a.d >> 2;            // float4 per row
     const int TY = SQ_NT / CG;          // rows covered by one sweep of the workgroup
     const int tid = threadIdx.x;
@@ -107,7 +107,43 @@ __global__ __launch_bounds__(SQ_NT) void sq8_tile_kernel(const Sq8Args a)
         if (tile_next < n_tiles) load_tile(tile_next, pf);
         lds_barrier();
         if (a.l2norm) {
-            if (tid < SQ_ROWS) {  // wave 0: one lane per row, index order (int8_quan.cc:48-51)
+            // The reference adds the squares into one double in index order (int8_quan.cc:48-51).  That order only
+            // matters through float(sqrt(sum)): sixteen lanes per row add their share in any order (each sum is within
+            // 2^-43 of the other, 512 roundings of 2^-53 on either side), and when the float roots of sum (1 -+ 2^-42)
+            // coincide the reference's root is that float, proven.  Otherwise (~4 rows in a million, and every non-finite
+            // row) the row is summed again in index order below.
+            {
+                const int row = tid >> 4, part = tid & 15;
+                const float4 *rowp = sq_tile + row * (CG + 1);
+                double s0 = 0.0, s1 = 0.0;
+                for (int j = part; j < CG; j += 32) {
+                    const float4 t0 = rowp[j];
+                    s0 += (double)__fmul_rn(t0.x, t0.x); s0 += (double)__fmul_rn(t0.y, t0.y);
+                    s0 += (double)__fmul_rn(t0.z, t0.z); s0 += (double)__fmul_rn(t0.w, t0.w);
+                    if (j + 16 < CG) {
+                        const float4 t1 = rowp[j + 16];
+                        s1 += (double)__fmul_rn(t1.x, t1.x); s1 += (double)__fmul_rn(t1.y, t1.y);
+                        s1 += (double)__fmul_rn(t1.z, t1.z); s1 += (double)__fmul_rn(t1.w, t1.w);
+                    }
+                }
+                double sum = s0 + s1;
+#pragma unroll
+                for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                if (part == 0 && row < SQ_ROWS) {
+                    const double rlo = __dsqrt_rn(sum * (1.0 - 0x1p-42)), rhi = __dsqrt_rn(sum * (1.0 + 0x1p-42));
+                    const float flo = (float)(rlo > 1e-12 ? rlo : 1e-12), fhi = (float)(rhi > 1e-12 ? rhi : 1e-12);
+                    const bool proven = flo == fhi;  // false for NaN
+                    seq_s[row] = proven ? 0 : 1;
+                    if (proven) {
+                        const DivBy dd = div_by(flo);
+                        den_s[row] = dd.b;
+                        rcp_s[row] = dd.y;
+                        ok_s[row] = dd.ok;
+                    }
+                }
+            }
+            lds_barrier();
+            if (tid < SQ_ROWS && seq_s[tid]) {  // index order, one lane per row
                 const float4 *rowp = sq_tile + tid * (CG + 1);
                 double accum = 0.0;
                 // The additions form one dependent fp64 chain per row; everything else (LDS reads, squares,
