@@ -144,7 +144,7 @@ struct cvtmi_flat_s {
     bool identity = true;  // label == row
     DevBuf s_part_d, s_part_id, s_gthr, s_stage;
     // matrix-core filter of the fp32 search (flat_mfma.hip): bf16 operand copy of the rows, built on first use
-    DevBuf f_pack, f_bias, f_stats, f_thr, f_cnt, f_cand, f_sd, f_si, f_seld, f_seli;
+    DevBuf f_pack, f_bias, f_stats, f_thr, f_marg, f_cnt, f_cand, f_sd, f_si, f_seld, f_seli;
     int64_t f_pack_n = -1;      // rows the copy covers (-1: none)
     bool f_nonfinite = false;   // a row holds inf / NaN: the filter is not used
     int f_last_filtered = 0;    // the last search was answered through the filter
@@ -874,27 +874,27 @@ static int flat_search_filtered(cvtmi_flat_t h, const float *q, int64_t nq, int 
     CVTMI_TRY(h->f_thr.reserve((size_t)nq * sizeof(float)));
     CVTMI_TRY(h->f_cnt.reserve((size_t)nq * sizeof(uint32_t)));
     const uint64_t pair_cap64 = (uint64_t)nq * cap;
-    const uint32_t pair_cap = pair_cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)pair_cap64;
-    CVTMI_TRY(h->f_cand.reserve((size_t)pair_cap * sizeof(uint2)));
-    CVTMI_TRY(h->f_seld.reserve((size_t)nq * (k + cap) * sizeof(float)));
-    CVTMI_TRY(h->f_seli.reserve((size_t)nq * (k + cap) * sizeof(int64_t)));
+    const uint32_t pair_cap = pair_cap64 > 0x7ffffff0ull ? 0x7ffffff0u : (uint32_t)pair_cap64;
+    CVTMI_TRY(h->f_cand.reserve((size_t)pair_cap * sizeof(uint4)));
+    CVTMI_TRY(h->f_seld.reserve((size_t)nq * cap * sizeof(float)));     // per-query survivor scores
+    CVTMI_TRY(h->f_seli.reserve((size_t)nq * cap * sizeof(int32_t)));   // per-query survivor rows
+    CVTMI_TRY(h->f_marg.reserve((size_t)nq * sizeof(float)));
     CVTMI_TRY(flat_search_rows(h, ns, q, nq, k, h->f_sd.as<float>(), h->f_si.as<int64_t>(), st));
-    // 2. thresholds, filter over the remaining rows, 3. exact distances of the survivors
+    // 2. thresholds, filter over the remaining rows, 3. second cut on approximate scores, exact distances of what is left
     uint32_t *stats = h->f_stats.as<uint32_t>();  // [0] max |x|^2, [1] non-finite rows, [2] overflow / worst list, [3] pair count
     CVTMI_HIP(hipMemsetAsync(stats + 2, 0, 8, st));
-    CVTMI_TRY(launch_flat_thr(q, nq, D, h->metric, h->f_sd.as<float>(), k, stats, h->f_thr.as<float>(), st));
+    CVTMI_TRY(launch_flat_thr(q, nq, D, h->metric, h->f_sd.as<float>(), k, stats, h->f_thr.as<float>(), h->f_marg.as<float>(), st));
     CVTMI_HIP(hipMemsetAsync(h->f_cnt.p, 0, (size_t)nq * sizeof(uint32_t), st));
     CVTMI_TRY(launch_flat_filter(q, nq, D, h->f_pack.as<uint4>(), h->f_bias.as<uint32_t>(), h->f_thr.as<float>(), ns, n, pair_cap,
-                                 stats + 3, h->f_cand.as<uint2>(), st));
-    CVTMI_TRY(launch_flat_rerank(h->metric, h->data.as<float>(), n, D, q, nq, stats + 3, pair_cap, h->f_cand.as<uint2>(), cap, k,
-                                 h->f_sd.as<float>(), h->f_si.as<int64_t>(), h->f_cnt.as<uint32_t>(), h->f_seld.as<float>(),
-                                 h->f_seli.as<int64_t>(), stats + 2, st));
+                                 stats + 3, h->f_cand.as<uint4>(), st));
+    CVTMI_TRY(launch_flat_finish(h->metric, h->data.as<float>(), n, D, q, nq, stats + 3, pair_cap, h->f_cand.as<uint4>(), cap, k,
+                                 h->f_marg.as<float>(), h->f_sd.as<float>(), h->f_si.as<int64_t>(), h->f_cnt.as<uint32_t>(),
+                                 h->f_seld.as<float>(), h->f_seli.as<int32_t>(), dist, rows, stats + 2, st));
     uint32_t worst = 0;
-    CVTMI_HIP(hipMemcpyAsync(&worst, h->f_stats.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost, st));
+    CVTMI_HIP(hipMemcpyAsync(&worst, stats + 2, 4, hipMemcpyDeviceToHost, st));
     CVTMI_HIP(hipStreamSynchronize(st));
     h->f_last_worst = worst;
-    if (worst > (uint32_t)cap) return CVTMI_OK;  // a candidate list overflowed: the exact path answers this call
-    CVTMI_TRY(launch_topk_select_byid(h->f_seld.as<float>(), h->f_seli.as<int64_t>(), nq, k + cap, k, dist, rows, st, h->f_cnt.as<uint32_t>(), k));
+    if (worst > (uint32_t)cap) return CVTMI_OK;  // a list ran over: the exact path answers this call (and overwrites the output)
     *done = true;
     return CVTMI_OK;
 }

@@ -11,8 +11,9 @@
 //      top k if its reference distance is <= tau_q, which implies T >= thr_q once every rounding (the split,
 //      the accumulation inside the matrix unit, the reference's own sum) is bounded -- all other rows are
 //      provably out.  Survivors (~15 k per query) are appended to a per-query candidate list.
-//   3. candidates get their exact distance (same code, same order as flat.hip) and the k best of
-//      sample + candidates are selected with the usual (distance, row) order.
+//   3. a second cut on the approximate scores (a survivor far enough below the k-th best survivor is beaten by k rows),
+//      then the few rows left get their exact distance (same code, same order as flat.hip) and are sorted with the
+//      sample's results by (distance, row).
 // A query whose list overflows (adversarial row order, masses of duplicates), non-finite rows or queries, or
 // magnitudes outside the bound's range send the whole call down the exact path: same answer, old speed.
 //
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void flat_pack_kernel(const float *__restri
 // -inf (everything passes -> overflow -> exact path) whenever the bound does not apply
 __global__ __launch_bounds__(kBlock) void flat_thr_kernel(const float *__restrict__ q, int64_t nq, int D, int l2,
                                                           const float *__restrict__ sample_d, int k,
-                                                          uint32_t *__restrict__ stats, float *__restrict__ thr)
+                                                          uint32_t *__restrict__ stats, float *__restrict__ thr, float *__restrict__ margin)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= nq) return;
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(kBlock) void flat_thr_kernel(const float *__restric
     float t = l2 ? 0.5f * (qq - tau) - Q * 0x1p-13f : (1.0f - tau) - Q * 0x1p-13f - (1.0f + fabsf(tau)) * 0x1p-20f;
     if (!(Q > 0x1p-60f && Q < 0x1p60f) || !(fabsf(t) <= 3.0e38f) || !(fabsf(tau) <= 3.0e38f)) t = -__uint_as_float(0x7f800000u);
     thr[i] = t;
+    margin[i] = Q * 0x1p-13f + (l2 ? 0.0f : (1.0f + fabsf(tau)) * 0x1p-20f);  // the pairwise cut of flat_finish_kernel
 }
 
 constexpr int FF_THREADS = 512;  // 8 waves = 256 queries per workgroup; the row tile is shared through LDS
@@ -104,7 +106,7 @@ template <int NCH>
 __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void flat_filter_kernel(const float *__restrict__ q, int64_t nq, const uint4 *__restrict__ pack,
                                                                  const uint32_t *__restrict__ bias, const float *__restrict__ thr,
                                                                  int64_t tile_begin, int64_t tile_end, int64_t tiles_per_split,
-                                                                 uint32_t pair_cap, uint32_t *__restrict__ pair_cnt, uint2 *__restrict__ pairs)
+                                                                 uint32_t pair_cap, uint32_t *__restrict__ pair_cnt, uint4 *__restrict__ pairs)
 {
     constexpr int D = 16 * NCH;
     constexpr int TILE = NCH * 2 * 64;                          // uint4 per row tile (both bf16 halves, operand order)
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     // survivors are parked per wave in LDS (slots handed out with ballots: no atomics) and leave in batches: one global
     // atomic and one coalesced write per ~190 survivors instead of a 2 us round trip per survivor in the tile loop
     constexpr int PBUF = 256;
-    __shared__ uint2 park_s[FF_THREADS / 64][PBUF];
+    __shared__ uint4 park_s[FF_THREADS / 64][PBUF];  // (query, row, T bits, -)
     int parked = 0;  // wave-uniform
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
     const int64_t qi = ((int64_t)blockIdx.y * (FF_THREADS / 64) + wave) * 32 + li;
@@ -179,8 +181,12 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab.v, ones, acc0, 0, 0, 0);  // + b_x
         }
         uint32_t hit = 0;
+        float tv[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) hit |= ((acc0[e] + acc1[e]) >= th ? 1u : 0u) << e;
+        for (int e = 0; e < 16; ++e) {
+            tv[e] = acc0[e] + acc1[e];
+            hit |= (tv[e] >= th ? 1u : 0u) << e;
+        }
         if (qi >= nq) hit = 0;
         while (__any(hit != 0)) {  // ~15 k survivors per query over the whole scan: a couple per wave and tile
             const unsigned long long m = __ballot(hit != 0);
@@ -196,8 +202,11 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             if (hit) {
                 const int e = __ffs((int)hit) - 1;
                 hit &= hit - 1;
+                float tsel = tv[0];  // tv[e] without dynamic register indexing
+#pragma unroll
+                for (int j = 1; j < 16; ++j) tsel = e == j ? tv[j] : tsel;
                 park_s[wave][parked + __popcll(m & ((1ull << lane) - 1))] =
-                    make_uint2((uint32_t)qi, (uint32_t)(t * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk));
+                    make_uint4((uint32_t)qi, (uint32_t)(t * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk), __float_as_uint(tsel), 0u);
             }
             parked += cnt;
         }
@@ -211,72 +220,145 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     }
 }
 
-// exact distance of every surviving (query, row) pair, in the reference's summation order (dist_f32.h), appended to the
-// query's columns of sel_* [nq][k + cap]: the first k columns hold the sample's results, column k + slot the survivors
-template <bool IP, int LANES>
-__global__ __launch_bounds__(kBlock) void flat_rerank_kernel(const float *__restrict__ X, int64_t n, int D, const float *__restrict__ q,
-                                                             const uint32_t *__restrict__ pair_cnt, uint32_t pair_cap,
-                                                             const uint2 *__restrict__ pairs, int cap, int k,
-                                                             uint32_t *__restrict__ cand_cnt, float *__restrict__ sel_d,
-                                                             int64_t *__restrict__ sel_i)
+// survivors -> per-query lists (approximate score, row); the list order is arbitrary
+__global__ __launch_bounds__(kBlock) void flat_scatter_kernel(const uint32_t *__restrict__ pair_cnt, uint32_t pair_cap,
+                                                              const uint4 *__restrict__ pairs, int cap, uint32_t *__restrict__ cand_cnt,
+                                                              float *__restrict__ cand_t, int32_t *__restrict__ cand_row,
+                                                              uint32_t *__restrict__ overflow)
 {
     uint32_t total = *pair_cnt;
-    total = total < pair_cap ? total : pair_cap;
+    if (total > pair_cap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(overflow, 0xffffffffu);
+        total = pair_cap;
+    }
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < total; p += gridDim.x * kBlock) {
-        const uint2 pr = pairs[p];
-        const int64_t qi = pr.x, row = pr.y;
-        if (row >= n) continue;  // padding rows of the last tile
-        float acc[LANES];
-#pragma unroll
-        for (int l = 0; l < LANES; ++l) acc[l] = 0.0f;
-        const float4 *qv = reinterpret_cast<const float4 *>(q + qi * D);
-        // blocked layout: float4 c of a row sits at ((row >> 6) * (D / 4) + c) * 64 + (row & 63)
-        const float4 *xr = reinterpret_cast<const float4 *>(X) + (row >> 6) * (int64_t)(D >> 2) * 64 + (row & 63);
-        for (int i4 = 0; i4 < D / 4; i4 += LANES / 4) {
-#pragma unroll
-            for (int g = 0; g < LANES / 4; ++g) {
-                const float4 xv = xr[(int64_t)(i4 + g) * 64], qq = qv[i4 + g];
-                const float xs[4] = { xv.x, xv.y, xv.z, xv.w }, qs[4] = { qq.x, qq.y, qq.z, qq.w };
-#pragma unroll
-                for (int l = 0; l < 4; ++l) {
-                    if constexpr (IP) {
-                        acc[4 * g + l] = __fadd_rn(acc[4 * g + l], __fmul_rn(qs[l], xs[l]));
-                    } else {
-                        const float t = __fsub_rn(qs[l], xs[l]);
-                        acc[4 * g + l] = __fadd_rn(acc[4 * g + l], __fmul_rn(t, t));
-                    }
-                }
-            }
-        }
-        float sum = acc[0];
-#pragma unroll
-        for (int l = 1; l < LANES; ++l) sum = __fadd_rn(sum, acc[l]);
-        const uint32_t slot = atomicAdd(&cand_cnt[qi], 1u);
+        const uint4 pr = pairs[p];
+        const uint32_t slot = atomicAdd(&cand_cnt[pr.x], 1u);
         if (slot < (uint32_t)cap) {
-            sel_d[qi * (k + cap) + k + slot] = IP ? __fsub_rn(1.0f, sum) : sum;
-            sel_i[qi * (k + cap) + k + slot] = row;
+            cand_t[(int64_t)pr.x * cap + slot] = __uint_as_float(pr.z);
+            cand_row[(int64_t)pr.x * cap + slot] = (int32_t)pr.y;
+        } else {
+            atomicMax(overflow, slot + 1u);
         }
     }
 }
 
-__global__ __launch_bounds__(kBlock) void flat_copy_sample_kernel(const float *__restrict__ sd, const int64_t *__restrict__ si, int64_t nq,
-                                                                  int k, int cap, float *__restrict__ out_d, int64_t *__restrict__ out_i)
+// in-place bitonic sort of s[0 .. n2) (n2 a power of two) by the whole workgroup
+template <typename T, bool DESC>
+__device__ __forceinline__ void block_bitonic(T *s, int n2)
 {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nq * k) return;
-    const int64_t qi = i / k;
-    const int j = (int)(i - qi * k);
-    out_d[qi * (k + cap) + j] = sd[i];
-    out_i[qi * (k + cap) + j] = si[i] < 0 ? 0x7fffffffffffffffLL : si[i];
+    for (int k2 = 2; k2 <= n2; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += kBlock) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const T a = s[i], b = s[p];
+                    const bool up = ((i & k2) == 0) != DESC;
+                    if (up ? a > b : a < b) { s[i] = b; s[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
 }
 
-// max over queries of the candidate count, and the non-finite row count: decides the fallback
-__global__ __launch_bounds__(kBlock) void flat_overflow_kernel(const uint32_t *__restrict__ cand_cnt, int64_t nq, const uint32_t *__restrict__ pair_cnt,
-                                                               uint32_t pair_cap, uint32_t *__restrict__ out)
+constexpr int FIN_CAND = 4096;  // survivors per query the finishing kernel takes (>= the caller's cap)
+constexpr int FIN_KEEP = 896;   // survivors that get an exact distance
+
+// One workgroup per query.  Second cut, still on approximate scores: with theta = the k-th largest T among the survivors,
+// a survivor with T < theta - 2^-13 Q is beaten -- in the reference's own arithmetic -- by k others (pairwise: 2 x 508 uQ
+// of filter error + 2 x ~200 uQ of reference rounding < 2048 uQ), so it is out.  What is left (k and a few) gets its exact
+// distance in the reference's summation order (dist_f32.h) and meets the sample's k results in a (distance, row) sort.
+template <bool IP, int LANES>
+__global__ __launch_bounds__(kBlock) void flat_finish_kernel(const float *__restrict__ X, int64_t n, int D, const float *__restrict__ q,
+                                                             const uint32_t *__restrict__ cand_cnt, const float *__restrict__ cand_t,
+                                                             const int32_t *__restrict__ cand_row, int cap, int k,
+                                                             const float *__restrict__ margin, const float *__restrict__ sample_d,
+                                                             const int64_t *__restrict__ sample_i, float *__restrict__ out_d,
+                                                             int64_t *__restrict__ out_i, uint32_t *__restrict__ overflow)
 {
-    uint32_t m = *pair_cnt > pair_cap ? 0xffffffffu : 0u;  // the pair list itself ran over
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nq; i += (int64_t)gridDim.x * kBlock) m = cand_cnt[i] > m ? cand_cnt[i] : m;
-    atomicMax(out, m);
+    __shared__ uint32_t tk_s[FIN_CAND];                    // order-preserving keys of T, sorted descending
+    __shared__ unsigned long long fin_s[1024];             // (distance key << 32 | row), sorted ascending
+    __shared__ int kept_s[FIN_KEEP];
+    __shared__ int nkeep_s;
+    const int64_t qi = blockIdx.x;
+    const int tid = threadIdx.x;
+    uint32_t c = cand_cnt[qi];
+    if (tid == 0) atomicMax(overflow, c);  // the largest list of the call (> cap: ran over)
+    c = c < (uint32_t)cap ? c : (uint32_t)cap;
+    const float *ct = cand_t + qi * cap;
+    const int32_t *cr = cand_row + qi * cap;
+    int n2 = 1;
+    while (n2 < (int)c) n2 <<= 1;
+    if (tid == 0) nkeep_s = 0;
+    float theta = -__uint_as_float(0x7f800000u);
+    if ((int)c > k) {  // workgroup-uniform
+        for (int i = tid; i < n2; i += kBlock) tk_s[i] = i < (int)c ? f32_key(ct[i]) : 0u;
+        __syncthreads();
+        block_bitonic<uint32_t, true>(tk_s, n2);
+        theta = key_f32(tk_s[k - 1]);
+    }
+    __syncthreads();
+    const float cut = theta - margin[qi];
+    for (int i = tid; i < (int)c; i += kBlock) {
+        if (ct[i] >= cut && cr[i] < n) {
+            const int slot = atomicAdd(&nkeep_s, 1);
+            if (slot < FIN_KEEP) kept_s[slot] = cr[i];
+        }
+    }
+    __syncthreads();
+    int nk = nkeep_s;
+    if (nk > FIN_KEEP) {  // masses of near ties: the exact path answers the call
+        if (tid == 0) atomicMax(overflow, 0xffffffffu);
+        nk = FIN_KEEP;
+    }
+    const int total = nk + k;  // <= 1024
+    int m2 = 1;
+    while (m2 < total) m2 <<= 1;
+    for (int i = tid; i < m2; i += kBlock) {
+        unsigned long long e = ~0ull;
+        if (i < nk) {
+            const int64_t row = kept_s[i];
+            float acc[LANES];
+#pragma unroll
+            for (int l = 0; l < LANES; ++l) acc[l] = 0.0f;
+            const float4 *qv = reinterpret_cast<const float4 *>(q + qi * D);
+            // blocked layout: float4 c of a row sits at ((row >> 6) * (D / 4) + c) * 64 + (row & 63)
+            const float4 *xr = reinterpret_cast<const float4 *>(X) + (row >> 6) * (int64_t)(D >> 2) * 64 + (row & 63);
+            for (int i4 = 0; i4 < D / 4; i4 += LANES / 4) {
+#pragma unroll
+                for (int g = 0; g < LANES / 4; ++g) {
+                    const float4 xv = xr[(int64_t)(i4 + g) * 64], qq = qv[i4 + g];
+                    const float xs[4] = { xv.x, xv.y, xv.z, xv.w }, qs[4] = { qq.x, qq.y, qq.z, qq.w };
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) {
+                        if constexpr (IP) {
+                            acc[4 * g + l] = __fadd_rn(acc[4 * g + l], __fmul_rn(qs[l], xs[l]));
+                        } else {
+                            const float t = __fsub_rn(qs[l], xs[l]);
+                            acc[4 * g + l] = __fadd_rn(acc[4 * g + l], __fmul_rn(t, t));
+                        }
+                    }
+                }
+            }
+            float sum = acc[0];
+#pragma unroll
+            for (int l = 1; l < LANES; ++l) sum = __fadd_rn(sum, acc[l]);
+            const float d = IP ? __fsub_rn(1.0f, sum) : sum;
+            e = ((unsigned long long)f32_key(d) << 32) | (uint32_t)row;
+        } else if (i < total) {
+            const int64_t id = sample_i[qi * k + (i - nk)];
+            if (id >= 0) e = ((unsigned long long)f32_key(sample_d[qi * k + (i - nk)]) << 32) | (uint32_t)id;
+        }
+        fin_s[i] = e;
+    }
+    __syncthreads();
+    block_bitonic<unsigned long long, false>(fin_s, m2);
+    for (int i = tid; i < k; i += kBlock) {
+        const unsigned long long e = fin_s[i];
+        const bool ok = e != ~0ull;
+        out_d[qi * k + i] = ok ? key_f32((uint32_t)(e >> 32)) : __uint_as_float(0x7f800000u);
+        out_i[qi * k + i] = ok ? (int64_t)(uint32_t)e : -1;
+    }
 }
 
 bool flat_filter_applies(int metric, int D, int64_t n, int64_t nq, int k)
@@ -298,17 +380,17 @@ int launch_flat_pack(const float *X, int64_t n, int D, int metric, uint4 *pack, 
 }
 
 int launch_flat_thr(const float *q, int64_t nq, int D, int metric, const float *sample_d, int k, uint32_t *stats, float *thr,
-                    hipStream_t st)
+                    float *margin, hipStream_t st)
 {
     hipLaunchKernelGGL(flat_thr_kernel, dim3((unsigned)((nq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, q, nq, D,
-                       metric == CVTMI_METRIC_L2F ? 1 : 0, sample_d, k, stats, thr);
+                       metric == CVTMI_METRIC_L2F ? 1 : 0, sample_d, k, stats, thr, margin);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
 
 // rows [row_begin, n) (row_begin % 32 == 0) against all queries; *pair_cnt must be zeroed by the caller
 int launch_flat_filter(const float *q, int64_t nq, int D, const uint4 *pack, const uint32_t *bias, const float *thr, int64_t row_begin,
-                       int64_t n, uint32_t pair_cap, uint32_t *pair_cnt, uint2 *pairs, hipStream_t st)
+                       int64_t n, uint32_t pair_cap, uint32_t *pair_cnt, uint4 *pairs, hipStream_t st)
 {
     const int64_t tile_begin = row_begin / 32, tile_end = (n + 31) / 32;
     if (tile_end <= tile_begin) return CVTMI_OK;
@@ -331,19 +413,20 @@ int launch_flat_filter(const float *q, int64_t nq, int D, const uint4 *pack, con
     return CVTMI_OK;
 }
 
-// cand_cnt [nq] must be zeroed by the caller; overflow receives max(candidates per query), 0xffffffff if the pair list ran over
-int launch_flat_rerank(int metric, const float *X, int64_t n, int D, const float *q, int64_t nq, const uint32_t *pair_cnt, uint32_t pair_cap,
-                       const uint2 *pairs, int cap, int k, const float *sample_d, const int64_t *sample_i, uint32_t *cand_cnt,
-                       float *sel_d, int64_t *sel_i, uint32_t *overflow, hipStream_t st)
+// cand_cnt [nq] must be zeroed by the caller; *overflow > cap afterwards: a list ran over, the results are not to be used
+int launch_flat_finish(int metric, const float *X, int64_t n, int D, const float *q, int64_t nq, const uint32_t *pair_cnt, uint32_t pair_cap,
+                       const uint4 *pairs, int cap, int k, const float *margin, const float *sample_d, const int64_t *sample_i,
+                       uint32_t *cand_cnt, float *cand_t, int32_t *cand_row, float *out_d, int64_t *out_i, uint32_t *overflow,
+                       hipStream_t st)
 {
-    hipLaunchKernelGGL(flat_copy_sample_kernel, dim3((unsigned)((nq * k + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sample_d, sample_i, nq, k,
-                       cap, sel_d, sel_i);
-    const dim3 g(256 * 16), b(kBlock);
+    if (cap > FIN_CAND || k > 128) return fail(CVTMI_EUNSUPPORTED, "flat finish: cap=%d k=%d", cap, k);
+    hipLaunchKernelGGL(flat_scatter_kernel, dim3(256 * 8), dim3(kBlock), 0, st, pair_cnt, pair_cap, pairs, cap, cand_cnt, cand_t, cand_row, overflow);
     if (metric == CVTMI_METRIC_IP)
-        hipLaunchKernelGGL((flat_rerank_kernel<true, 4>), g, b, 0, st, X, n, D, q, pair_cnt, pair_cap, pairs, cap, k, cand_cnt, sel_d, sel_i);
+        hipLaunchKernelGGL((flat_finish_kernel<true, 4>), dim3((unsigned)nq), dim3(kBlock), 0, st, X, n, D, q, cand_cnt, cand_t, cand_row, cap, k,
+                           margin, sample_d, sample_i, out_d, out_i, overflow);
     else
-        hipLaunchKernelGGL((flat_rerank_kernel<false, 8>), g, b, 0, st, X, n, D, q, pair_cnt, pair_cap, pairs, cap, k, cand_cnt, sel_d, sel_i);
-    hipLaunchKernelGGL(flat_overflow_kernel, dim3(64), dim3(kBlock), 0, st, cand_cnt, nq, pair_cnt, pair_cap, overflow);
+        hipLaunchKernelGGL((flat_finish_kernel<false, 8>), dim3((unsigned)nq), dim3(kBlock), 0, st, X, n, D, q, cand_cnt, cand_t, cand_row, cap, k,
+                           margin, sample_d, sample_i, out_d, out_i, overflow);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

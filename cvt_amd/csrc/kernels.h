@@ -89,12 +89,13 @@ bool flat_filter_applies(int metric, int D, int64_t n, int64_t nq, int k);
 size_t flat_pack_bytes(int D, int64_t n);
 int launch_flat_pack(const float *X, int64_t n, int D, int metric, uint4 *pack, uint32_t *bias, uint32_t *stats, hipStream_t st);
 int launch_flat_thr(const float *q, int64_t nq, int D, int metric, const float *sample_d, int k, uint32_t *stats, float *thr,
-                    hipStream_t st);
+                    float *margin, hipStream_t st);
 int launch_flat_filter(const float *q, int64_t nq, int D, const uint4 *pack, const uint32_t *bias, const float *thr, int64_t row_begin,
-                       int64_t n, uint32_t pair_cap, uint32_t *pair_cnt, uint2 *pairs, hipStream_t st);
-int launch_flat_rerank(int metric, const float *X, int64_t n, int D, const float *q, int64_t nq, const uint32_t *pair_cnt, uint32_t pair_cap,
-                       const uint2 *pairs, int cap, int k, const float *sample_d, const int64_t *sample_i, uint32_t *cand_cnt,
-                       float *sel_d, int64_t *sel_i, uint32_t *overflow, hipStream_t st);
+                       int64_t n, uint32_t pair_cap, uint32_t *pair_cnt, uint4 *pairs, hipStream_t st);
+int launch_flat_finish(int metric, const float *X, int64_t n, int D, const float *q, int64_t nq, const uint32_t *pair_cnt, uint32_t pair_cap,
+                       const uint4 *pairs, int cap, int k, const float *margin, const float *sample_d, const int64_t *sample_i,
+                       uint32_t *cand_cnt, float *cand_t, int32_t *cand_row, float *out_d, int64_t *out_i, uint32_t *overflow,
+                       hipStream_t st);
 int launch_flat_block(const float *src, int64_t n, int D, int64_t row0, float *dst, hipStream_t st);
 int flat_u8_mfma_qtile(int D, int k, int64_t nq);  // queries per workgroup, 0 = shape not covered
 int flat_u8_mfma_splits(int64_t n, int64_t nq, int qt);
