@@ -867,8 +867,10 @@ static int flat_search_filtered(cvtmi_flat_t h, const float *q, int64_t nq, int 
     }
     if (h->f_nonfinite) return CVTMI_OK;
     // 1. exact search of a leading sample: its k-th best bounds the global k-th best
-    int64_t ns = std::max<int64_t>(65536, (n / 16 + 63) / 64 * 64);
-    const int cap = (24 * k + 1024 + 63) / 64 * 64;
+    // a smaller sample costs less exact work but doubles the survivors: worth it while k is small
+    const int frac = k <= 16 ? 32 : 16;
+    int64_t ns = std::max<int64_t>(frac == 32 ? 32768 : 65536, (n / frac + 63) / 64 * 64);
+    const int cap = ((frac == 32 ? 48 : 24) * k + 1024 + 63) / 64 * 64;
     CVTMI_TRY(h->f_sd.reserve((size_t)nq * k * sizeof(float)));
     CVTMI_TRY(h->f_si.reserve((size_t)nq * k * sizeof(int64_t)));
     CVTMI_TRY(h->f_thr.reserve((size_t)nq * sizeof(float)));
