@@ -854,7 +854,7 @@ static int flat_search_filtered(cvtmi_flat_t h, const float *q, int64_t nq, int 
     const int D = h->D;
     const int64_t n = h->n;
     if (h->f_pack_n != n) {  // bf16 operand copy of the rows (same bytes as the fp32 rows), once per index state
-        CVTMI_TRY(h->f_pack.reserve(flat_pack_bytes(D, n)));
+        if (h->f_pack.reserve(flat_pack_bytes(D, n)) != CVTMI_OK) return CVTMI_OK;  // no room for the operand copy: exact path
         CVTMI_TRY(h->f_bias.reserve((size_t)((n + 31) / 32) * 32 * sizeof(uint32_t)));
         CVTMI_TRY(h->f_stats.reserve(16));
         CVTMI_TRY(launch_flat_pack(h->data.as<float>(), n, D, h->metric, h->f_pack.as<uint4>(), h->f_bias.as<uint32_t>(),
@@ -877,9 +877,10 @@ static int flat_search_filtered(cvtmi_flat_t h, const float *q, int64_t nq, int 
     CVTMI_TRY(h->f_cnt.reserve((size_t)nq * sizeof(uint32_t)));
     const uint64_t pair_cap64 = (uint64_t)nq * cap;
     const uint32_t pair_cap = pair_cap64 > 0x7ffffff0ull ? 0x7ffffff0u : (uint32_t)pair_cap64;
-    CVTMI_TRY(h->f_cand.reserve((size_t)pair_cap * sizeof(uint4)));
-    CVTMI_TRY(h->f_seld.reserve((size_t)nq * cap * sizeof(float)));     // per-query survivor scores
-    CVTMI_TRY(h->f_seli.reserve((size_t)nq * cap * sizeof(int32_t)));   // per-query survivor rows
+    // the big scratch (16 bytes per survivor slot + 8 per list entry): if it does not fit, the exact path answers
+    if (h->f_cand.reserve((size_t)pair_cap * sizeof(uint4)) != CVTMI_OK || h->f_seld.reserve((size_t)nq * cap * sizeof(float)) != CVTMI_OK ||
+        h->f_seli.reserve((size_t)nq * cap * sizeof(int32_t)) != CVTMI_OK)
+        return CVTMI_OK;
     CVTMI_TRY(h->f_marg.reserve((size_t)nq * sizeof(float)));
     CVTMI_TRY(flat_search_rows(h, ns, q, nq, k, h->f_sd.as<float>(), h->f_si.as<int64_t>(), st));
     // 2. thresholds, filter over the remaining rows, 3. second cut on approximate scores, exact distances of what is left
