@@ -902,6 +902,46 @@ static int flat_search_filtered(cvtmi_flat_t h, const float *q, int64_t nq, int 
     return CVTMI_OK;
 }
 
+// uint8 L2 through the filter pipeline (flat_mfma.hip): exact integer distances on the i8 matrix cores, thresholds from an
+// exactly searched leading sample.  *done = false: not applicable / a list ran over, the row-tile kernels answer
+static int flat_search_filtered_u8(cvtmi_flat_t h, const uint8_t *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st, bool *done)
+{
+    *done = false;
+    const int D = h->D;
+    const int64_t n = h->n;
+    if (h->f_pack_n != n) {  // operand-ordered copy of the rows (x - 128 as int8), once per index state
+        if (h->f_pack.reserve(flat_u8_pack_bytes(D, n)) != CVTMI_OK) return CVTMI_OK;
+        CVTMI_TRY(launch_flat_u8_pack(h->data.as<uint8_t>(), n, D, h->f_pack.as<uint4>(), st));
+        h->f_pack_n = n;
+    }
+    const int64_t ns = std::max<int64_t>(65536, (n / 32 + 63) / 64 * 64);
+    const int cap = std::min(4096 - k, (48 * k + 1024 + 63) / 64 * 64);
+    const uint64_t pair_cap64 = (uint64_t)nq * cap;
+    const uint32_t pair_cap = pair_cap64 > 0x7ffffff0ull ? 0x7ffffff0u : (uint32_t)pair_cap64;
+    CVTMI_TRY(h->f_stats.reserve(16));
+    CVTMI_TRY(h->f_sd.reserve((size_t)nq * k * sizeof(float)));
+    CVTMI_TRY(h->f_si.reserve((size_t)nq * k * sizeof(int64_t)));
+    CVTMI_TRY(h->f_cnt.reserve((size_t)nq * sizeof(uint32_t)));
+    if (h->f_cand.reserve((size_t)pair_cap * sizeof(uint4)) != CVTMI_OK || h->f_seld.reserve((size_t)nq * cap * sizeof(float)) != CVTMI_OK ||
+        h->f_seli.reserve((size_t)nq * cap * sizeof(int32_t)) != CVTMI_OK)
+        return CVTMI_OK;
+    CVTMI_TRY(flat_search_rows(h, ns, q, nq, k, h->f_sd.as<float>(), h->f_si.as<int64_t>(), st));
+    uint32_t *stats = h->f_stats.as<uint32_t>();  // [2] worst list / overflow, [3] pair count
+    CVTMI_HIP(hipMemsetAsync(stats + 2, 0, 8, st));
+    CVTMI_HIP(hipMemsetAsync(h->f_cnt.p, 0, (size_t)nq * sizeof(uint32_t), st));
+    CVTMI_TRY(launch_flat_u8_filter(q, nq, D, h->f_pack.as<uint4>(), h->norms.as<int32_t>(), h->f_sd.as<float>(), k, ns, n, pair_cap,
+                                    stats + 3, h->f_cand.as<uint4>(), st));
+    CVTMI_TRY(launch_flat_u8_finish(nq, stats + 3, pair_cap, h->f_cand.as<uint4>(), cap, k, h->f_sd.as<float>(), h->f_si.as<int64_t>(),
+                                    h->f_cnt.as<uint32_t>(), h->f_seld.as<float>(), h->f_seli.as<int32_t>(), dist, rows, stats + 2, st));
+    uint32_t worst = 0;
+    CVTMI_HIP(hipMemcpyAsync(&worst, stats + 2, 4, hipMemcpyDeviceToHost, st));
+    CVTMI_HIP(hipStreamSynchronize(st));
+    h->f_last_worst = worst;
+    if (worst > (uint32_t)cap) return CVTMI_OK;
+    *done = true;
+    return CVTMI_OK;
+}
+
 int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels, void *stream)
 {
     CHECK_H(h);
@@ -915,6 +955,11 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
         flat_filter_applies(h->metric, h->D, g_flat_variant == 2 ? std::max<int64_t>(h->n, 131072) : h->n, g_flat_variant == 2 ? std::max<int64_t>(nq, 64) : nq, k) &&
         h->n >= 2 * 65536)
         CVTMI_TRY(flat_search_filtered(h, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
+    // uint8: the row-tile kernels stay the default (the pipeline below measures the same at the C3 shape: both sit at a third
+    // of the i8 matrix pipe); flat_variant 2 selects it
+    if (g_flat_variant == 2 && h->metric == CVTMI_METRIC_L2U8 && ((uintptr_t)q & 15) == 0 && nq <= 65535 * 256 && h->norms.p &&
+        flat_u8_filter_applies(h->D, std::max<int64_t>(h->n, 262144), std::max<int64_t>(nq, 256), k) && h->n >= 2 * 65536)
+        CVTMI_TRY(flat_search_filtered_u8(h, reinterpret_cast<const uint8_t *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
     h->f_last_filtered = done ? 1 : 0;
     if (!done) CVTMI_TRY(flat_search_rows(h, h->n, q, nq, k, reinterpret_cast<float *>(dist), labels, st));
     if (!h->identity) CVTMI_TRY(launch_gather_labels(labels, nq * k, h->labels.as<int64_t>(), st));

@@ -106,9 +106,16 @@ template <int NCH>
 __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void flat_filter_kernel(const float *__restrict__ q, int64_t nq, const uint4 *__restrict__ pack,
                                                                  const uint32_t *__restrict__ bias, const float *__restrict__ thr,
                                                                  int64_t tile_begin, int64_t tile_end, int64_t tiles_per_split,
-                                                                 uint32_t pair_cap, uint32_t *__restrict__ pair_cnt, uint4 *__restrict__ pairs)
+                                                                 uint32_t pair_cap, uint32_t *__restrict__ pair_cnt, uint4 *__restrict__ pairs,
+                                                                 int qblocks)
 {
     constexpr int D = 16 * NCH;
+    // 1-D grid, XCD-aware: workgroups are dealt to the 8 XCDs round-robin, so b % 8 is the XCD.  All query blocks of one row
+    // split sit on the same XCD next to each other in dispatch order: they stream the same row tiles through that XCD's L2
+    // (otherwise every query block re-reads its rows from HBM: 16 x 5 GB at the C3 shape).
+    const int64_t bi = blockIdx.x >> 3;
+    const int split_id = (int)(blockIdx.x & 7) + 8 * (int)(bi / qblocks), qb_id = (int)(bi % qblocks);
+
     constexpr int TILE = NCH * 2 * 64;                          // uint4 per row tile (both bf16 halves, operand order)
     constexpr int LPT = (TILE + FF_THREADS - 1) / FF_THREADS;   // uint4 per thread and tile
     __shared__ uint4 tile_s[2][TILE];
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     __shared__ uint4 park_s[FF_THREADS / 64][PBUF];  // (query, row, T bits, -)
     int parked = 0;  // wave-uniform
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
-    const int64_t qi = ((int64_t)blockIdx.y * (FF_THREADS / 64) + wave) * 32 + li;
+    const int64_t qi = ((int64_t)qb_id * (FF_THREADS / 64) + wave) * 32 + li;
     const int64_t qc = qi < nq ? qi : nq - 1;  // clamped: padding queries compute, never push
     const float *qp = q + qc * D + 8 * lk;
     bf16x8 q1[NCH], q2[NCH];
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     bf16x8 ones = bzero;
     ones[0] = lk ? (__bf16)0.0f : (__bf16)1.0f;
     ones[1] = ones[0];
-    const int64_t t0 = tile_begin + (int64_t)blockIdx.x * tiles_per_split;
+    const int64_t t0 = tile_begin + (int64_t)split_id * tiles_per_split;
     int64_t t1 = t0 + tiles_per_split;
     t1 = t1 < tile_end ? t1 : tile_end;
     if (t0 >= t1) return;
@@ -361,6 +368,269 @@ __global__ __launch_bounds__(kBlock) void flat_finish_kernel(const float *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// uint8 L2 (L2SpaceI, space_l2.h:186-245) through the same pipeline.  Here the matrix cores (v_mfma_i32_32x32x32_i8 on
+// x - 128) give the EXACT integer distance, so there is no bound to prove and no second cut: the k-th best of an exactly
+// searched leading sample is the threshold, the filter kernel streams the remaining rows with thresholds in registers (no
+// selection state, no threshold traffic between workgroups), survivors are sorted with the sample's results.
+// ------------------------------------------------------------------------------------------------------------------
+using i32x16 = __attribute__((ext_vector_type(16))) int;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+// [tile][s][lane] 16 bytes: row 32 t + (lane & 31), dimensions 32 s + 16 (lane >> 5) .. + 16, each byte ^ 0x80 (x - 128 as int8)
+__global__ __launch_bounds__(kBlock) void flat_u8_pack_kernel(const uint8_t *__restrict__ X, int64_t n, int D, int64_t ntiles,
+                                                              uint4 *__restrict__ pack)
+{
+    const int ks = D / 32;
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= ntiles * ks * 64) return;
+    const int lane = (int)(g & 63);
+    const int64_t ts = g >> 6, t = ts / ks;
+    const int s_ = (int)(ts - t * ks);
+    const int64_t row = t * 32 + (lane & 31);
+    uint4 v = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);  // rows past n: x = 0 (never reported)
+    if (row < n) v = *reinterpret_cast<const uint4 *>(X + row * D + 32 * s_ + 16 * (lane >> 5));
+    v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+    pack[g] = v;
+}
+
+// A workgroup of NT / 64 waves scores 32 QS queries per wave against its whole row range.  QS = 2: every 1 KB row operand
+// read from LDS feeds two matrix instructions (LDS delivers ~1 KB per 8 cycles and CU, which is what four SIMDs of
+// v_mfma_i32_32x32x32_i8 consume with one query set per wave: that, not HBM, bounded the one-set kernels at ~35 % of the
+// matrix pipe), and the rows are streamed nq / (16 QS NT / 32) times in all instead of twice as often.
+template <int KS, int NT, int QS>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(QS == 1 ? 4 : 2, QS == 1 ? 4 : 2))) void flat_u8_filter_kernel(
+    const uint8_t *__restrict__ q, int64_t nq, int D, const uint4 *__restrict__ pack, const int32_t *__restrict__ norms, int64_t n,
+    const float *__restrict__ sample_d, int k, int64_t tile_begin, int64_t tile_end, int64_t tiles_per_split, uint32_t pair_cap,
+    uint32_t *__restrict__ pair_cnt, uint4 *__restrict__ pairs, int qblocks)
+{
+    constexpr int TILE = KS * 64;             // uint4 per row tile at most (D = 32 KS)
+    constexpr int LPT = (TILE + NT - 1) / NT;
+    constexpr int PBUF = 256;
+    constexpr int QPB = (NT / 64) * 32 * QS;  // queries per workgroup
+    // 1-D grid, XCD-aware: workgroups are dealt to the 8 XCDs round-robin, so b % 8 is the XCD.  All query blocks of one row
+    // split sit on the same XCD next to each other in dispatch order and share its L2.
+    const int64_t bi = blockIdx.x >> 3;
+    const int split_id = (int)(blockIdx.x & 7) + 8 * (int)(bi / qblocks), qb_id = (int)(bi % qblocks);
+    const int tile_len = (D / 32) * 64;       // uint4 per row tile of this index (<= TILE)
+    __shared__ uint4 tile_s[2][TILE];
+    __shared__ uint4 park_s[NT / 64][PBUF];   // (query, row, distance, -)
+    __shared__ int qq_s[QPB], thr_s[QPB];     // per query of the workgroup: |q'|^2, tau - |q'|^2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lj = lane & 31, lk = lane >> 5;
+    const int nks = D / 32;
+    i32x4 qreg[QS][KS];
+#pragma unroll
+    for (int u = 0; u < QS; ++u) {
+        const int ql = (wave * QS + u) * 32 + lj;
+        const int64_t qi = (int64_t)qb_id * QPB + ql;
+        const int64_t qc = qi < nq ? qi : nq - 1;
+        const uint8_t *qp = q + qc * D;
+        int qq = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) qreg[u][s_] = *reinterpret_cast<const i32x4 *>(qp + 32 * (s_ < nks ? s_ : 0) + 16 * lk);
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            qreg[u][s_] ^= (int)0x80808080;
+            if (s_ >= nks) qreg[u][s_] = i32x4{ 0, 0, 0, 0 };
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qq = __builtin_amdgcn_sdot4(qreg[u][s_][c], qreg[u][s_][c], qq, false);
+        }
+        qq += __shfl_xor(qq, 32, 64);
+        if (lk == 0) {
+            const int tau = (int)__float_as_uint(sample_d[qc * k + k - 1]);  // integer distance bits (0x7f800000 = none: everything passes)
+            qq_s[ql] = qq;
+            thr_s[ql] = qi < nq ? tau - qq : (int)0x80000000;               // padding queries: nothing passes
+        }
+    }
+    __syncthreads();
+    // the 16 queries of set u this lane scores: q_e = (e & 3) + 8 (e >> 2) + 4 lk  (MFMA C layout: D[query][row], lane = row)
+    // (with one query set the 16 thresholds sit in registers; with two they are read from LDS per tile -- two distinct
+    //  addresses per wave, broadcast -- because 128 query registers leave no room)
+    int thr[QS == 1 ? 16 : 1];
+    if constexpr (QS == 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) thr[e] = thr_s[wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk];
+    }
+    const int64_t t0 = tile_begin + (int64_t)split_id * tiles_per_split;
+    int64_t t1 = t0 + tiles_per_split;
+    t1 = t1 < tile_end ? t1 : tile_end;
+    if (t0 >= t1) return;
+    int parked = 0;  // wave-uniform
+    uint4 pre[LPT];
+    int xx_next = 0;
+    auto fetch = [&](int64_t t) {
+        t = t < t1 ? t : t1 - 1;
+        int64_t row = t * 32 + lj;
+        row = row < n ? row : n - 1;
+        xx_next = norms[row];
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            int f = tid + i * NT;
+            f = f < tile_len ? f : tile_len - 1;
+            pre[i] = pack[t * tile_len + f];
+        }
+    };
+    fetch(t0);
+    for (int64_t t = t0; t < t1; ++t) {
+        uint4 *stage = tile_s[(t - t0) & 1];
+#pragma unroll
+        for (int i = 0; i < LPT; ++i)
+            if (tid + i * NT < tile_len) stage[tid + i * NT] = pre[i];
+        const int xx = xx_next;
+        fetch(t + 1);
+        lds_barrier();
+        const i32x4 *pb = reinterpret_cast<const i32x4 *>(stage) + lane;
+        i32x16 acc[QS];
+#pragma unroll
+        for (int u = 0; u < QS; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[u][e] = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_)
+            if (s_ < nks) {
+                const i32x4 bv = pb[s_ * 64];
+#pragma unroll
+                for (int u = 0; u < QS; ++u) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qreg[u][s_], bv, acc[u], 0, 0, 0);
+            }
+        const int64_t row = t * 32 + lj;
+#pragma unroll
+        for (int u = 0; u < QS; ++u) {
+            uint32_t hit = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int th = QS == 1 ? thr[QS == 1 ? e : 0] : thr_s[(wave * QS + u) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk];
+                hit |= (xx - 2 * acc[u][e] <= th ? 1u : 0u) << e;  // distance - |q'|^2, exact
+            }
+            if (row >= n) hit = 0;
+            while (__any(hit != 0)) {
+                const unsigned long long m = __ballot(hit != 0);
+                const int cnt = __popcll(m);
+                if (parked + cnt > PBUF) {  // flush (wave-uniform branch)
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(pair_cnt, (uint32_t)parked);
+                    base = __shfl(base, 0, 64);
+                    for (int i = lane; i < parked; i += 64)
+                        if (base + i < pair_cap) pairs[base + i] = park_s[wave][i];
+                    parked = 0;
+                }
+                if (hit) {
+                    const int e = __ffs((int)hit) - 1;
+                    hit &= hit - 1;
+                    int asel = acc[u][0];
+#pragma unroll
+                    for (int j = 1; j < 16; ++j) asel = e == j ? acc[u][j] : asel;
+                    const int ql = (wave * QS + u) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                    park_s[wave][parked + __popcll(m & ((1ull << lane) - 1))] =
+                        make_uint4((uint32_t)(qb_id * QPB + ql), (uint32_t)row, (uint32_t)(xx - 2 * asel + qq_s[ql]), 0u);
+                }
+                parked += cnt;
+            }
+        }
+    }
+    if (parked) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(pair_cnt, (uint32_t)parked);
+        base = __shfl(base, 0, 64);
+        for (int i = lane; i < parked; i += 64)
+            if (base + i < pair_cap) pairs[base + i] = park_s[wave][i];
+    }
+}
+
+// one workgroup per query: (distance, row) sort of the survivors and the sample's k results; distances are int32 bits
+__global__ __launch_bounds__(kBlock) void flat_u8_finish_kernel(const uint32_t *__restrict__ cand_cnt, const float *__restrict__ cand_d,
+                                                                const int32_t *__restrict__ cand_row, int cap, int k,
+                                                                const float *__restrict__ sample_d, const int64_t *__restrict__ sample_i,
+                                                                float *__restrict__ out_d, int64_t *__restrict__ out_i,
+                                                                uint32_t *__restrict__ overflow)
+{
+    __shared__ unsigned long long key_s[4096];
+    const int64_t qi = blockIdx.x;
+    const int tid = threadIdx.x;
+    uint32_t c = cand_cnt[qi];
+    if (tid == 0) atomicMax(overflow, c);
+    c = c < (uint32_t)cap ? c : (uint32_t)cap;
+    const int total = (int)c + k;  // <= 4096
+    int n2 = 1;
+    while (n2 < total) n2 <<= 1;
+    for (int i = tid; i < n2; i += kBlock) {
+        unsigned long long e = ~0ull;
+        if (i < (int)c) e = ((unsigned long long)__float_as_uint(cand_d[qi * cap + i]) << 32) | (uint32_t)cand_row[qi * cap + i];
+        else if (i < total) {
+            const int64_t id = sample_i[qi * k + (i - (int)c)];
+            if (id >= 0) e = ((unsigned long long)__float_as_uint(sample_d[qi * k + (i - (int)c)]) << 32) | (uint32_t)id;
+        }
+        key_s[i] = e;
+    }
+    __syncthreads();
+    block_bitonic<unsigned long long, false>(key_s, n2);
+    for (int i = tid; i < k; i += kBlock) {
+        const unsigned long long e = key_s[i];
+        const bool ok = e != ~0ull;
+        out_d[qi * k + i] = ok ? __uint_as_float((uint32_t)(e >> 32)) : __uint_as_float(0x7f800000u);
+        out_i[qi * k + i] = ok ? (int64_t)(uint32_t)e : -1;
+    }
+}
+
+bool flat_u8_filter_applies(int D, int64_t n, int64_t nq, int k)
+{
+    return D % 32 == 0 && D >= 32 && D <= 512 && nq >= 256 && n >= 262144 && k <= 64;
+}
+size_t flat_u8_pack_bytes(int D, int64_t n) { return (size_t)((n + 31) / 32) * (D / 32) * 64 * sizeof(uint4); }
+
+int launch_flat_u8_pack(const uint8_t *X, int64_t n, int D, uint4 *pack, hipStream_t st)
+{
+    const int64_t ntiles = (n + 31) / 32, total = ntiles * (D / 32) * 64;
+    hipLaunchKernelGGL(flat_u8_pack_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, X, n, D, ntiles, pack);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+// rows [row_begin, n) against all queries; thresholds = the sample's k-th best; *pair_cnt zeroed by the caller
+int launch_flat_u8_filter(const uint8_t *q, int64_t nq, int D, const uint4 *pack, const int32_t *norms, const float *sample_d, int k,
+                          int64_t row_begin, int64_t n, uint32_t pair_cap, uint32_t *pair_cnt, uint4 *pairs, hipStream_t st)
+{
+    const int64_t tile_begin = row_begin / 32, tile_end = (n + 31) / 32;
+    if (tile_end <= tile_begin) return CVTMI_OK;
+    const bool wide = nq >= 1024;  // 16 waves: 512 queries per workgroup
+    const int qpb = wide ? 512 : 256;
+    const int64_t qblocks = (nq + qpb - 1) / qpb;
+    int64_t splits = std::max<int64_t>(1, (256 * 2 + qblocks - 1) / qblocks);
+    int64_t tps = std::max<int64_t>(16, (tile_end - tile_begin + splits - 1) / splits);
+    splits = (tile_end - tile_begin + tps - 1) / tps;
+    const int64_t splits8 = (splits + 7) / 8 * 8;
+    if (splits8 * qblocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "flat u8 filter: nq too large");
+    const dim3 g((unsigned)(splits8 * qblocks));
+#define CVTMI_FU(N)                                                                                                              \
+    do {                                                                                                                         \
+        if (wide)                                                                                                                \
+            hipLaunchKernelGGL((flat_u8_filter_kernel<N, 1024, 1>), g, dim3(1024), 0, st, q, nq, D, pack, norms, n, sample_d, k, tile_begin,   \
+                               tile_end, tps, pair_cap, pair_cnt, pairs, (int)qblocks);                                          \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((flat_u8_filter_kernel<N, 512, 1>), g, dim3(512), 0, st, q, nq, D, pack, norms, n, sample_d, k, tile_begin,   \
+                               tile_end, tps, pair_cap, pair_cnt, pairs, (int)qblocks);                                          \
+    } while (0)
+    const int ks = D / 32;
+    if (ks <= 2) CVTMI_FU(2);
+    else if (ks <= 4) CVTMI_FU(4);
+    else if (ks <= 8) CVTMI_FU(8);
+    else CVTMI_FU(16);
+#undef CVTMI_FU
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+int launch_flat_u8_finish(int64_t nq, const uint32_t *pair_cnt, uint32_t pair_cap, const uint4 *pairs, int cap, int k, const float *sample_d,
+                          const int64_t *sample_i, uint32_t *cand_cnt, float *cand_d, int32_t *cand_row, float *out_d, int64_t *out_i,
+                          uint32_t *overflow, hipStream_t st)
+{
+    if (cap + k > 4096) return fail(CVTMI_EUNSUPPORTED, "flat u8 finish: cap=%d k=%d", cap, k);
+    hipLaunchKernelGGL(flat_scatter_kernel, dim3(256 * 8), dim3(kBlock), 0, st, pair_cnt, pair_cap, pairs, cap, cand_cnt, cand_d, cand_row, overflow);
+    hipLaunchKernelGGL(flat_u8_finish_kernel, dim3((unsigned)nq), dim3(kBlock), 0, st, cand_cnt, cand_d, cand_row, cap, k, sample_d, sample_i, out_d,
+                       out_i, overflow);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
 bool flat_filter_applies(int metric, int D, int64_t n, int64_t nq, int k)
 {
     return (metric == CVTMI_METRIC_IP || metric == CVTMI_METRIC_L2F) && D >= 32 && D <= 128 && D % 16 == 0 && nq >= 64 && n >= 131072 &&
@@ -398,11 +668,12 @@ int launch_flat_filter(const float *q, int64_t nq, int D, const uint4 *pack, con
     int64_t splits = std::max<int64_t>(1, (256 * 4 + qblocks - 1) / qblocks);   // ~4 workgroups per CU in flight
     int64_t tps = std::max<int64_t>(16, (tile_end - tile_begin + splits - 1) / splits);
     splits = (tile_end - tile_begin + tps - 1) / tps;
-    if (qblocks > 65535) return fail(CVTMI_EUNSUPPORTED, "flat filter: nq too large");
-    const dim3 g((unsigned)splits, (unsigned)qblocks), b(FF_THREADS);
+    const int64_t splits8 = (splits + 7) / 8 * 8;  // empty splits return at once
+    if (splits8 * qblocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "flat filter: nq too large");
+    const dim3 g((unsigned)(splits8 * qblocks)), b(FF_THREADS);
 #define CVTMI_FF(N)                                                                                                               \
     case N:                                                                                                                       \
-        hipLaunchKernelGGL((flat_filter_kernel<N>), g, b, 0, st, q, nq, pack, bias, thr, tile_begin, tile_end, tps, pair_cap, pair_cnt, pairs); \
+        hipLaunchKernelGGL((flat_filter_kernel<N>), g, b, 0, st, q, nq, pack, bias, thr, tile_begin, tile_end, tps, pair_cap, pair_cnt, pairs, (int)qblocks); \
         break;
     switch (D / 16) {
         CVTMI_FF(2) CVTMI_FF(3) CVTMI_FF(4) CVTMI_FF(5) CVTMI_FF(6) CVTMI_FF(7) CVTMI_FF(8)

@@ -96,6 +96,15 @@ int launch_flat_finish(int metric, const float *X, int64_t n, int D, const float
                        const uint4 *pairs, int cap, int k, const float *margin, const float *sample_d, const int64_t *sample_i,
                        uint32_t *cand_cnt, float *cand_t, int32_t *cand_row, float *out_d, int64_t *out_i, uint32_t *overflow,
                        hipStream_t st);
+// uint8 L2 through the same pipeline (exact integer distances on the i8 matrix cores: no bound, no second cut)
+bool flat_u8_filter_applies(int D, int64_t n, int64_t nq, int k);
+size_t flat_u8_pack_bytes(int D, int64_t n);
+int launch_flat_u8_pack(const uint8_t *X, int64_t n, int D, uint4 *pack, hipStream_t st);
+int launch_flat_u8_filter(const uint8_t *q, int64_t nq, int D, const uint4 *pack, const int32_t *norms, const float *sample_d, int k,
+                          int64_t row_begin, int64_t n, uint32_t pair_cap, uint32_t *pair_cnt, uint4 *pairs, hipStream_t st);
+int launch_flat_u8_finish(int64_t nq, const uint32_t *pair_cnt, uint32_t pair_cap, const uint4 *pairs, int cap, int k, const float *sample_d,
+                          const int64_t *sample_i, uint32_t *cand_cnt, float *cand_d, int32_t *cand_row, float *out_d, int64_t *out_i,
+                          uint32_t *overflow, hipStream_t st);
 int launch_flat_block(const float *src, int64_t n, int D, int64_t row0, float *dst, hipStream_t st);
 int flat_u8_mfma_qtile(int D, int k, int64_t nq);  // queries per workgroup, 0 = shape not covered
 int flat_u8_mfma_splits(int64_t n, int64_t nq, int qt);

@@ -65,7 +65,9 @@ int cvtmi_set_device(int device);
  *   "assign_variant"  nearest-centroid assignment (coarse argmin of cvtmi_opq_encode, cvtmi_kmeans): 0 = choose (default);
  *                     1 = the reference's chain for every centroid on the VALU; 2 = bf16 matrix-core filter with exact
  *                     resolution of undecided rows wherever it applies (32 <= d <= 128, d % 16 == 0, k >= 64)
- *   "flat_variant"    fp32 exhaustive search: 0 = choose (default); 1 = exact kernels; 2 = matrix-core filter wherever it applies */
+ *   "flat_variant"    exhaustive search: 0 = choose (default: fp32 through the matrix-core filter for large batches, uint8 on
+ *                     the row-tile kernels); 1 = exact / row-tile kernels only; 2 = the filter pipelines wherever they apply
+ *                     (uint8 too: exact sample, i8 matrix-core threshold filter, sort -- measures like the row-tile kernels) */
 int cvtmi_set_tuning(const char *name, int64_t value);
 
 /* ---------------------------------------------------------------- OPQ model + code index ---- */

@@ -303,3 +303,32 @@ def test_flat_f32_filter_ties_arrive_out_of_order(amd):
     finally:
         amd.set_tuning("flat_variant", 0)
     assert np.array_equal(out[2][1], out[1][1]) and np.array_equal(bits(out[2][0]), bits(out[1][0]))
+
+
+@pytest.mark.parametrize("D,k,hi", [(512, 10, 256), (64, 64, 6), (96, 1, 256), (256, 33, 40)])
+def test_flat_u8_filter_pipeline(amd, orc, D, k, hi):
+    """uint8 L2 through sample + i8 matrix-core filter + sort (flat_variant 2) against the row-tile kernels (flat_variant 1) and
+    the checker: few distinct byte values (masses of equal distances), duplicates of rows and of queries, appends"""
+    rng = np.random.default_rng(D + k)
+    n, nq = 270_000, 300
+    x = rng.integers(0, hi, size=(n, D), dtype=np.uint8)
+    x[200_000:200_400] = x[9]; x[100:140] = x[9]
+    q = x[rng.integers(0, n, nq)].copy()
+    flip = rng.integers(0, D, size=(nq, 3))
+    for i in range(nq):
+        q[i, flip[i]] ^= 1
+    q[0] = x[9]
+    out = {}
+    try:
+        for v in (2, 1):
+            amd.set_tuning("flat_variant", v)
+            ix = amd.FlatIndex(L2U8, D); ix.add(x[:150_000]); ix.add(x[150_000:])
+            out[v] = ix.search(q, k)
+            if v == 2:
+                used, worst = ix.last_search()
+                assert used, worst
+    finally:
+        amd.set_tuning("flat_variant", 0)
+    assert np.array_equal(out[2][1], out[1][1]) and np.array_equal(out[2][0], out[1][0])
+    od, odi, oi = orc.flat_search(L2U8, x, q[:16], k)
+    assert np.array_equal(out[2][1][:16], oi) and np.array_equal(out[2][0][:16], odi)
