@@ -144,7 +144,7 @@ struct cvtmi_flat_s {
     bool identity = true;  // label == row
     DevBuf s_part_d, s_part_id, s_gthr, s_stage;
     // matrix-core filter of the fp32 search (flat_mfma.hip): bf16 operand copy of the rows, built on first use
-    DevBuf f_pack, f_bias, f_stats, f_thr, f_marg, f_cnt, f_cand, f_sd, f_si, f_seld, f_seli;
+    DevBuf f_pack, f_bias, f_stats, f_thr, f_marg, f_cnt, f_cand, f_sd, f_si, f_sd2, f_si2, f_seld, f_seli;
     int64_t f_pack_n = -1;      // rows the copy covers (-1: none)
     bool f_nonfinite = false;   // a row holds inf / NaN: the filter is not used
     int f_last_filtered = 0;    // the last search was answered through the filter
@@ -882,20 +882,37 @@ static int flat_search_filtered(cvtmi_flat_t h, const float *q, int64_t nq, int 
         h->f_seli.reserve((size_t)nq * cap * sizeof(int32_t)) != CVTMI_OK)
         return CVTMI_OK;
     CVTMI_TRY(h->f_marg.reserve((size_t)nq * sizeof(float)));
-    CVTMI_TRY(flat_search_rows(h, ns, q, nq, k, h->f_sd.as<float>(), h->f_si.as<int64_t>(), st));
-    // 2. thresholds, filter over the remaining rows, 3. second cut on approximate scores, exact distances of what is left
     uint32_t *stats = h->f_stats.as<uint32_t>();  // [0] max |x|^2, [1] non-finite rows, [2] overflow / worst list, [3] pair count
-    CVTMI_HIP(hipMemsetAsync(stats + 2, 0, 8, st));
-    CVTMI_TRY(launch_flat_thr(q, nq, D, h->metric, h->f_sd.as<float>(), k, stats, h->f_thr.as<float>(), h->f_marg.as<float>(), st));
-    CVTMI_HIP(hipMemsetAsync(h->f_cnt.p, 0, (size_t)nq * sizeof(uint32_t), st));
-    CVTMI_TRY(launch_flat_filter(q, nq, D, h->f_pack.as<uint4>(), h->f_bias.as<uint32_t>(), h->f_thr.as<float>(), ns, n, pair_cap,
-                                 stats + 3, h->f_cand.as<uint4>(), st));
-    CVTMI_TRY(launch_flat_finish(h->metric, h->data.as<float>(), n, D, q, nq, stats + 3, pair_cap, h->f_cand.as<uint4>(), cap, k,
-                                 h->f_marg.as<float>(), h->f_sd.as<float>(), h->f_si.as<int64_t>(), h->f_cnt.as<uint32_t>(),
-                                 h->f_seld.as<float>(), h->f_seli.as<int32_t>(), dist, rows, stats + 2, st));
+    // one filter stage: given the exact top k of rows [0, r0) in (sd, si), the exact top k of rows [0, r1) into (od, oi):
+    // thresholds, filter over [r0, r1), second cut on approximate scores, exact distances of what is left, sort
+    auto stage = [&](int64_t r0, int64_t r1, const float *sd, const int64_t *si, float *od, int64_t *oi, uint32_t *worst) -> int {
+        CVTMI_HIP(hipMemsetAsync(stats + 2, 0, 8, st));
+        CVTMI_TRY(launch_flat_thr(q, nq, D, h->metric, sd, k, stats, h->f_thr.as<float>(), h->f_marg.as<float>(), st));
+        CVTMI_HIP(hipMemsetAsync(h->f_cnt.p, 0, (size_t)nq * sizeof(uint32_t), st));
+        CVTMI_TRY(launch_flat_filter(q, nq, D, h->f_pack.as<uint4>(), h->f_bias.as<uint32_t>(), h->f_thr.as<float>(), r0, r1, pair_cap,
+                                     stats + 3, h->f_cand.as<uint4>(), st));
+        CVTMI_TRY(launch_flat_finish(h->metric, h->data.as<float>(), r1, D, q, nq, stats + 3, pair_cap, h->f_cand.as<uint4>(), cap, k,
+                                     h->f_marg.as<float>(), sd, si, h->f_cnt.as<uint32_t>(), h->f_seld.as<float>(), h->f_seli.as<int32_t>(),
+                                     od, oi, stats + 2, st));
+        CVTMI_HIP(hipMemcpyAsync(worst, stats + 2, 4, hipMemcpyDeviceToHost, st));
+        CVTMI_HIP(hipStreamSynchronize(st));
+        return CVTMI_OK;
+    };
+    // 1. the exact top k of the leading ns rows.  The exact kernels only see a sample of the sample (ns / 16 rows); a first
+    //    filter stage extends it to ns (falling back to the exact kernels on all ns rows if a list runs over)
     uint32_t worst = 0;
-    CVTMI_HIP(hipMemcpyAsync(&worst, stats + 2, 4, hipMemcpyDeviceToHost, st));
-    CVTMI_HIP(hipStreamSynchronize(st));
+    const int64_t ns0 = std::max<int64_t>(8192, (ns / 16 + 63) / 64 * 64);
+    bool have_sample = false;
+    if (ns0 * 4 <= ns && nq >= 256) {  // (small batches: the extra launches and the sync cost more than the exact work saved)
+        CVTMI_TRY(h->f_sd2.reserve((size_t)nq * k * sizeof(float)));
+        CVTMI_TRY(h->f_si2.reserve((size_t)nq * k * sizeof(int64_t)));
+        CVTMI_TRY(flat_search_rows(h, ns0, q, nq, k, h->f_sd2.as<float>(), h->f_si2.as<int64_t>(), st));
+        CVTMI_TRY(stage(ns0, ns, h->f_sd2.as<float>(), h->f_si2.as<int64_t>(), h->f_sd.as<float>(), h->f_si.as<int64_t>(), &worst));
+        have_sample = worst <= (uint32_t)cap;
+    }
+    if (!have_sample) CVTMI_TRY(flat_search_rows(h, ns, q, nq, k, h->f_sd.as<float>(), h->f_si.as<int64_t>(), st));
+    // 2. the remaining rows
+    CVTMI_TRY(stage(ns, n, h->f_sd.as<float>(), h->f_si.as<int64_t>(), dist, rows, &worst));
     h->f_last_worst = worst;
     if (worst > (uint32_t)cap) return CVTMI_OK;  // a list ran over: the exact path answers this call (and overwrites the output)
     *done = true;

@@ -4,7 +4,8 @@
 // The result -- k smallest (distance, row) per query with the distances in the reference's summation order --
 // must come out bit for bit, so the distances themselves are evaluated by the exact code (dist_f32.h).  What the
 // matrix cores do is decide WHICH rows need an exact distance:
-//   1. the first n/16 rows (n/32 for k <= 16) are searched exactly (flat.hip).  The k-th best of that sample, tau_q, bounds the k-th
+//   1. the first n/16 rows (n/32 for k <= 16) are searched exactly (flat.hip; for large batches in two levels: the exact
+//      kernels see a sixteenth of that sample and one filter stage extends it).  The k-th best of that sample, tau_q, bounds the k-th
 //      best of the whole set from above.
 //   2. T = q.x + b_x ranks the remaining rows (b_x = -|x|^2/2 for L2, 0 for the inner product); a bf16 two-term
 //      split of both operands evaluates it to ~2^-17 on v_mfma_f32_32x32x16_bf16.  A row can only be in the
