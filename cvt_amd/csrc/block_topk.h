@@ -393,9 +393,8 @@ __device__ __forceinline__ void topk_tile_end(TopKShared<QT, CAP> &s, int k, int
 }
 
 // Convenience form for kernels that hold R x QT exact keys (KEY_MAX = not a candidate) and R payloads
-// per thread and obey the ordering rule above.  TIES: payloads do NOT arrive in ascending order (ids of unordered
-// candidates), so a candidate that ties the current k-th key may still carry a smaller payload and must be offered.
-template <int QT, int R, int CAP, int TRIG, int NT = kBlock, bool TIES = false>
+// per thread and obey the ordering rule above.
+template <int QT, int R, int CAP, int TRIG, int NT = kBlock>
 __device__ __forceinline__ void topk_tile(TopKShared<QT, CAP> &s, int k, int tile, const uint32_t (&key)[R][QT],
                                           const uint32_t (&pay)[R])
 {
@@ -408,7 +407,7 @@ __device__ __forceinline__ void topk_tile(TopKShared<QT, CAP> &s, int k, int til
     for (int r = 0; r < R; ++r) {
 #pragma unroll
         for (int q = 0; q < QT; ++q) {
-            if (TIES ? (key[r][q] <= thr[q] && key[r][q] != KEY_MAX) : (key[r][q] < thr[q])) {
+            if (key[r][q] < thr[q]) {
                 if (!topk_push<QT, CAP, TRIG>(s, q, key[r][q], pay[r], want)) pending |= 1u << (r * QT + q);
             }
         }

@@ -59,11 +59,6 @@ int launch_topk_merge(const float *in_d, const int64_t *in_id, int64_t nq, int L
 int launch_topk_select(const float *in_d, const int64_t *in_id, int64_t nq, int64_t n_cand, int k, float *out_d,
                        int64_t *out_id, hipStream_t st);
 
-// unordered candidates with ids in [0, 2^32): equal distances order by id (flat_mfma.hip)
-// counts != null: query q holds base + min(counts[q], n_cand - base) valid candidates (the rest of its row is not read)
-int launch_topk_select_byid(const float *in_d, const int64_t *in_id, int64_t nq, int64_t n_cand, int k, float *out_d,
-                            int64_t *out_id, hipStream_t st, const uint32_t *counts = nullptr, int base = 0);
-
 // ---- query_video.hip ----
 // probe[nq][nprobe] list ids in visiting order; list_off[coarseK+1]; codes/video_id in list order.
 int launch_coarse_probe(const OpqModelDev &m, const float *q_rot, int64_t nq, int nprobe, int32_t *probe,

@@ -16,22 +16,14 @@ constexpr int MERGE_CAP = 1024;
 constexpr int MERGE_TRIG = 768;
 constexpr int MERGE_R = 4;
 
-// BYID: the candidates come in no particular order (flat_mfma.hip), so the payload is the id itself (< 2^32) and equal
-// distances order by id value, not by position; ids < 0 or >= 2^32 mark padding.  The distance is recovered from the key.
-template <bool BYID>
 __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restrict__ in_d,
                                                             const int64_t *__restrict__ in_id, int n_cand, int k,
-                                                            float *__restrict__ out_d, int64_t *__restrict__ out_id,
-                                                            const uint32_t *__restrict__ counts, int cbase)
+                                                            float *__restrict__ out_d, int64_t *__restrict__ out_id)
 {
     __shared__ TopKShared<1, MERGE_CAP> tk;
     const int64_t q = blockIdx.x;
     const float *d = in_d + q * n_cand;
     const int64_t *id = in_id + q * n_cand;
-    if (counts) {  // only the leading cbase + counts[q] entries of the row are filled
-        const uint32_t c = counts[q], room = (uint32_t)(n_cand - cbase);
-        n_cand = cbase + (int)(c < room ? c : room);
-    }
     const int tid = threadIdx.x;
     topk_init(tk);
     __syncthreads();
@@ -44,17 +36,12 @@ __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restr
             const int i = base + r * kBlock + tid;
             pay[r] = (uint32_t)i;
             key[r][0] = KEY_MAX;
-            bool ok = i < n_cand && (in_id == nullptr || id[i] >= 0);
-            if (BYID && ok) {
-                ok = id[i] <= 0xffffffffLL;
-                pay[r] = (uint32_t)id[i];
-            }
-            if (ok) {
+            if (i < n_cand && (in_id == nullptr || id[i] >= 0)) {
                 const uint32_t kk = f32_key(d[i]);
                 key[r][0] = kk == KEY_MAX ? KEY_MAX - 1 : kk;  // keep the "not a candidate" code free
             }
         }
-        topk_tile<1, MERGE_R, MERGE_CAP, MERGE_TRIG, kBlock, BYID>(tk, k, tile, key, pay);
+        topk_tile<1, MERGE_R, MERGE_CAP, MERGE_TRIG>(tk, k, tile, key, pay);
     }
     __syncthreads();
     topk_compact(tk, k);
@@ -62,13 +49,8 @@ __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restr
     for (int i = tid; i < k; i += kBlock) {
         if (i < cnt) {
             const uint32_t p = (uint32_t)tk.buf[0][i];
-            if (BYID) {
-                out_d[q * k + i] = key_f32((uint32_t)(tk.buf[0][i] >> 32));
-                out_id[q * k + i] = (int64_t)p;
-            } else {
-                out_d[q * k + i] = d[p];
-                out_id[q * k + i] = in_id ? id[p] : (int64_t)p;
-            }
+            out_d[q * k + i] = d[p];
+            out_id[q * k + i] = in_id ? id[p] : (int64_t)p;
         } else {
             out_d[q * k + i] = __uint_as_float(0x7f800000u);
             out_id[q * k + i] = -1;
@@ -91,21 +73,7 @@ int launch_topk_select(const float *in_d, const int64_t *in_id, int64_t nq, int6
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "topk: k=%d outside 1..128", k);
     if (n_cand < 0 || n_cand > 0x7fffffff) return fail(CVTMI_EINVAL, "topk: bad candidate count");
     if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "topk: nq too large");
-    hipLaunchKernelGGL(topk_merge_kernel<false>, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, (int)n_cand, k, out_d, out_id, nullptr, 0);
-    CVTMI_HIP(hipGetLastError());
-    return CVTMI_OK;
-}
-
-// k smallest (value, id) of n_cand UNORDERED candidates per query, ids in [0, 2^32); other ids are padding.
-// Distances must not be NaN (the output distance is rebuilt from its order-preserving key).
-int launch_topk_select_byid(const float *in_d, const int64_t *in_id, int64_t nq, int64_t n_cand, int k, float *out_d,
-                            int64_t *out_id, hipStream_t st, const uint32_t *counts, int base)
-{
-    if (nq <= 0) return CVTMI_OK;
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "topk: k=%d outside 1..128", k);
-    if (n_cand < 0 || n_cand > 0x7fffffff || !in_id) return fail(CVTMI_EINVAL, "topk: bad candidate count");
-    if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "topk: nq too large");
-    hipLaunchKernelGGL(topk_merge_kernel<true>, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, (int)n_cand, k, out_d, out_id, counts, base);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, (int)n_cand, k, out_d, out_id);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
