@@ -9,10 +9,13 @@
 //    (assign_mfma.hip).  Otherwise, and for those rows:
 //  * assign: one lane per row, CT centroids at a time from an LDS tile transposed [dim][centroid]
 //    (broadcast reads), squared distances kept in registers -- VALU fp32 bound, 3 d k flop per row.
+//  * update, k <= 512: scatter in any order + a proof that the float result is the index-order one (below); otherwise:
 //  * update: the order of the double additions is part of bit-exactness, so there is no atomic scatter:
 //    one wave owns one centroid, walks the assignment array 64 rows at a time (ballot of the matches) and
 //    folds the matching rows in ascending order, lane = dimension.  k waves re-read n assignments from
 //    L2 (k n 4 bytes): for coarseK = 8192, n = 1 M that is ~3 ms per iteration, noise next to the assign pass.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace cvtmi {
@@ -281,11 +284,169 @@ int launch_kmeans_assign_split(const float *x, int64_t ld, int64_t n, int d, con
     return CVTMI_OK;
 }
 
+// ---- update, fast path -------------------------------------------------------------------------------------
+// centroid[c][j] = float(double sum over the members of c in ascending row order / count).  The order only matters through
+// the final rounding to float: sums accumulated in ANY order differ from the index-order sum by at most
+// 2 (count) 2^-53 sum |x| (each of the <= count - 1 additions of either order rounds within 2^-53 of a partial sum that
+// is bounded by sum |x|).  So rows are scattered with double atomics (sum, sum of |x|, count), and where
+// float((S - E) / count) == float((S + E) / count) that float is the reference's centroid, proven; where it is not (and
+// for non-finite sums) the centroid is flagged and recomputed in index order by the wave-per-centroid kernel.
+__global__ __launch_bounds__(kBlock) void kmeans_scatter_kernel(const float *__restrict__ x, int64_t ld, int64_t n, int d,
+                                                                const int32_t *__restrict__ assign, double *__restrict__ sum,
+                                                                double *__restrict__ asum, unsigned int *__restrict__ cnt)
+{
+    const int rows_per_block = kBlock / 64;
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * rows_per_block) {
+        const int c = assign[r];
+        if (c < 0) continue;  // a row no centroid claims
+        if (lane == 0) atomicAdd(&cnt[c], 1u);
+        for (int j = lane; j < d; j += 64) {
+            const double v = (double)x[r * ld + j];
+            atomicAdd(&sum[(int64_t)c * d + j], v);
+            atomicAdd(&asum[(int64_t)c * d + j], fabs(v));
+        }
+    }
+}
+
+// k <= 512: the partial sums of a block of rows are kept in LDS (8 dimensions per workgroup column: k x 8 doubles twice),
+// one LDS atomic per element, and reach the global arrays once per workgroup
+constexpr int KM_LK = 512;   // centroids the LDS variant holds
+constexpr int KM_DG = 8;     // dimensions per workgroup column
+__global__ __launch_bounds__(kBlock) void kmeans_scatter_lds_kernel(const float *__restrict__ x, int64_t ld, int64_t n, int d,
+                                                                    const int32_t *__restrict__ assign, int k, int64_t rows_per_block,
+                                                                    double *__restrict__ sum, double *__restrict__ asum,
+                                                                    unsigned int *__restrict__ cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) double km_s[];  // [k][KM_DG] sums, [k][KM_DG] sums of |x|, then k counts
+    double *s_sum = km_s, *s_abs = km_s + (size_t)k * KM_DG;
+    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_abs + (size_t)k * KM_DG);
+    const int d0 = blockIdx.y * KM_DG;
+    for (int i = threadIdx.x; i < k * KM_DG; i += kBlock) { s_sum[i] = 0.0; s_abs[i] = 0.0; }
+    for (int i = threadIdx.x; i < k; i += kBlock) s_cnt[i] = 0u;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    r1 = r1 < n ? r1 : n;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += kBlock) {
+        const int c = assign[r];
+        if (c < 0) continue;  // a row no centroid claims
+        if (blockIdx.y == 0) atomicAdd(&s_cnt[c], 1u);
+#pragma unroll
+        for (int j = 0; j < KM_DG; ++j) {
+            if (d0 + j < d) {
+                const double v = (double)x[r * ld + d0 + j];
+                atomicAdd(&s_sum[c * KM_DG + j], v);
+                atomicAdd(&s_abs[c * KM_DG + j], fabs(v));
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < k * KM_DG; i += kBlock) {
+        const int c = i / KM_DG, j = i - c * KM_DG;
+        if (d0 + j < d && s_abs[i] != 0.0) {
+            atomicAdd(&sum[(int64_t)c * d + d0 + j], s_sum[i]);
+            atomicAdd(&asum[(int64_t)c * d + d0 + j], s_abs[i]);
+        }
+    }
+    if (blockIdx.y == 0)
+        for (int i = threadIdx.x; i < k; i += kBlock)
+            if (s_cnt[i]) atomicAdd(&cnt[i], s_cnt[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void kmeans_finalize_kernel(const double *__restrict__ sum, const double *__restrict__ asum,
+                                                                 const unsigned int *__restrict__ cnt, int k, int d,
+                                                                 float *__restrict__ cent, int *__restrict__ redo)
+{
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= (int64_t)k * d) return;
+    const int c = (int)(e / d);
+    const unsigned int m = cnt[c];
+    if (m == 0) return;  // an empty cluster keeps its centroid
+    const double S = sum[e], E = 2.0 * (double)m * 0x1p-53 * asum[e] * 1.0000001, dm = (double)m;
+    const float lo = (float)__ddiv_rn(S - E, dm), hi = (float)__ddiv_rn(S + E, dm);
+    if (lo == hi) cent[e] = lo;  // proven: the index-order sum lies in [S - E, S + E], division and rounding are monotone
+    else redo[c] = 1;            // (also NaN / inf): index order decides
+}
+
+// index-order recomputation of the flagged centroids (the kernel above, one wave per centroid)
+__global__ __launch_bounds__(kBlock) void kmeans_update_flagged_kernel(const float *__restrict__ x, int64_t ld, int64_t n, int d,
+                                                                       const int32_t *__restrict__ assign, int k,
+                                                                       const int *__restrict__ redo, float *__restrict__ cent)
+{
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (c >= k || !redo[c]) return;
+    double sum[KM_DPL];
+#pragma unroll
+    for (int i = 0; i < KM_DPL; ++i) sum[i] = 0.0;
+    long long cnt = 0;
+    // one wave walks all n assignments: 8 chunks of 64 are loaded at once so that the walk is not one memory latency per chunk
+    for (int64_t base0 = 0; base0 < n; base0 += 512) {
+        int a8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t r = base0 + 64 * u + lane;
+            a8[u] = r < n ? assign[r] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t base = base0 + 64 * u;
+            unsigned long long m = __ballot(a8[u] == c);
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float *xr = x + (base + b) * ld;
+#pragma unroll
+                for (int i = 0; i < KM_DPL; ++i) {
+                    const int dd = lane + 64 * i;
+                    if (dd < d) sum[i] = __dadd_rn(sum[i], (double)xr[dd]);
+                }
+                ++cnt;
+            }
+        }
+    }
+    if (cnt > 0) {
+#pragma unroll
+        for (int i = 0; i < KM_DPL; ++i) {
+            const int dd = lane + 64 * i;
+            if (dd < d) cent[(int64_t)c * d + dd] = (float)__ddiv_rn(sum[i], (double)cnt);
+        }
+    }
+}
+
 int launch_kmeans_update(const float *x, int64_t ld, int64_t n, int d, const int32_t *assign, int k, float *cent,
                          hipStream_t st)
 {
     if (d > 64 * KM_DPL) return fail(CVTMI_EUNSUPPORTED, "kmeans: d=%d > %d", d, 64 * KM_DPL);
     const int wpb = kBlock / 64;
+    const size_t kd = (size_t)k * d;
+    const size_t need = kd * 16 + (size_t)k * 8 + 256;
+    if (n >= 4096 && k <= KM_LK) {  // fast path: scatter + proof, index order only where the proof fails (larger k: the
+                                    // wave-per-centroid kernel below measures faster than scattering with global atomics)
+        void *scratch = nullptr;  // stream-ordered: lives exactly as long as the kernels below
+        CVTMI_HIP(hipMallocAsync(&scratch, need, st));
+        double *sum = static_cast<double *>(scratch), *asum = sum + kd;
+        unsigned int *cnt = reinterpret_cast<unsigned int *>(asum + kd);
+        int *redo = reinterpret_cast<int *>(cnt + k);
+        CVTMI_HIP(hipMemsetAsync(scratch, 0, need, st));
+        if (k <= KM_LK) {
+            const int64_t rpb = std::max<int64_t>(2048, (n + 255) / 256);
+            const dim3 g((unsigned)((n + rpb - 1) / rpb), (unsigned)((d + KM_DG - 1) / KM_DG));
+            const size_t lds = (size_t)k * KM_DG * 16 + (size_t)k * 4;
+            CVTMI_HIP(hipFuncSetAttribute((const void *)kmeans_scatter_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kmeans_scatter_lds_kernel, g, dim3(kBlock), lds, st, x, ld, n, d, assign, k, rpb, sum, asum, cnt);
+        } else {
+            const int64_t blocks = std::min<int64_t>((n + wpb - 1) / wpb, 256 * 16);
+            hipLaunchKernelGGL(kmeans_scatter_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, ld, n, d, assign, sum, asum, cnt);
+        }
+        hipLaunchKernelGGL(kmeans_finalize_kernel, dim3((unsigned)((kd + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sum, asum, cnt, k, d, cent, redo);
+        hipLaunchKernelGGL(kmeans_update_flagged_kernel, dim3((unsigned)((k + wpb - 1) / wpb)), dim3(kBlock), 0, st, x, ld, n, d, assign, k, redo, cent);
+        const hipError_t le = hipGetLastError();
+        CVTMI_HIP(hipFreeAsync(scratch, st));
+        CVTMI_HIP(le);
+        return CVTMI_OK;
+    }
     hipLaunchKernelGGL(kmeans_update_kernel, dim3((unsigned)((k + wpb - 1) / wpb)), dim3(kBlock), 0, st, x, ld, n, d, assign, k, cent);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
