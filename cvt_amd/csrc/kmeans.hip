@@ -288,27 +288,9 @@ int launch_kmeans_assign_split(const float *x, int64_t ld, int64_t n, int d, con
 // centroid[c][j] = float(double sum over the members of c in ascending row order / count).  The order only matters through
 // the final rounding to float: sums accumulated in ANY order differ from the index-order sum by at most
 // 2 (count) 2^-53 sum |x| (each of the <= count - 1 additions of either order rounds within 2^-53 of a partial sum that
-// is bounded by sum |x|).  So rows are scattered with double atomics (sum, sum of |x|, count), and where
+// is bounded by sum |x|).  So rows are scattered with double atomics in LDS (sum, sum of |x|, count), and where
 // float((S - E) / count) == float((S + E) / count) that float is the reference's centroid, proven; where it is not (and
 // for non-finite sums) the centroid is flagged and recomputed in index order by the wave-per-centroid kernel.
-__global__ __launch_bounds__(kBlock) void kmeans_scatter_kernel(const float *__restrict__ x, int64_t ld, int64_t n, int d,
-                                                                const int32_t *__restrict__ assign, double *__restrict__ sum,
-                                                                double *__restrict__ asum, unsigned int *__restrict__ cnt)
-{
-    const int rows_per_block = kBlock / 64;
-    const int lane = threadIdx.x & 63;
-    for (int64_t r = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * rows_per_block) {
-        const int c = assign[r];
-        if (c < 0) continue;  // a row no centroid claims
-        if (lane == 0) atomicAdd(&cnt[c], 1u);
-        for (int j = lane; j < d; j += 64) {
-            const double v = (double)x[r * ld + j];
-            atomicAdd(&sum[(int64_t)c * d + j], v);
-            atomicAdd(&asum[(int64_t)c * d + j], fabs(v));
-        }
-    }
-}
-
 // k <= 512: the partial sums of a block of rows are kept in LDS (8 dimensions per workgroup column: k x 8 doubles twice),
 // one LDS atomic per element, and reach the global arrays once per workgroup
 constexpr int KM_LK = 512;   // centroids the LDS variant holds
@@ -430,16 +412,11 @@ int launch_kmeans_update(const float *x, int64_t ld, int64_t n, int d, const int
         unsigned int *cnt = reinterpret_cast<unsigned int *>(asum + kd);
         int *redo = reinterpret_cast<int *>(cnt + k);
         CVTMI_HIP(hipMemsetAsync(scratch, 0, need, st));
-        if (k <= KM_LK) {
-            const int64_t rpb = std::max<int64_t>(2048, (n + 255) / 256);
-            const dim3 g((unsigned)((n + rpb - 1) / rpb), (unsigned)((d + KM_DG - 1) / KM_DG));
-            const size_t lds = (size_t)k * KM_DG * 16 + (size_t)k * 4;
-            CVTMI_HIP(hipFuncSetAttribute((const void *)kmeans_scatter_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kmeans_scatter_lds_kernel, g, dim3(kBlock), lds, st, x, ld, n, d, assign, k, rpb, sum, asum, cnt);
-        } else {
-            const int64_t blocks = std::min<int64_t>((n + wpb - 1) / wpb, 256 * 16);
-            hipLaunchKernelGGL(kmeans_scatter_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, ld, n, d, assign, sum, asum, cnt);
-        }
+        const int64_t rpb = std::max<int64_t>(2048, (n + 255) / 256);
+        const dim3 g((unsigned)((n + rpb - 1) / rpb), (unsigned)((d + KM_DG - 1) / KM_DG));
+        const size_t lds = (size_t)k * KM_DG * 16 + (size_t)k * 4;
+        CVTMI_HIP(hipFuncSetAttribute((const void *)kmeans_scatter_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kmeans_scatter_lds_kernel, g, dim3(kBlock), lds, st, x, ld, n, d, assign, k, rpb, sum, asum, cnt);
         hipLaunchKernelGGL(kmeans_finalize_kernel, dim3((unsigned)((kd + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sum, asum, cnt, k, d, cent, redo);
         hipLaunchKernelGGL(kmeans_update_flagged_kernel, dim3((unsigned)((k + wpb - 1) / wpb)), dim3(kBlock), 0, st, x, ld, n, d, assign, k, redo, cent);
         const hipError_t le = hipGetLastError();
