@@ -75,3 +75,16 @@ def test_argument_validation_is_reported():
     rc = lib.cvtmi_flat_create(7, 128, ctypes.byref(h))
     assert rc == -1
     assert lib.cvtmi_opq_destroy(None) == 0
+
+
+def test_tuning_hooks_validate_their_arguments():
+    """cvtmi_set_tuning needs no device: unknown names and out-of-range values are refused with a message"""
+    import cvt_amd
+    lib = cvt_amd.lib()
+    lib.cvtmi_last_error.restype = ctypes.c_char_p
+    for name in (b"assign_variant", b"flat_variant"):
+        assert lib.cvtmi_set_tuning(name, ctypes.c_int64(2)) == 0
+        assert lib.cvtmi_set_tuning(name, ctypes.c_int64(0)) == 0
+        assert lib.cvtmi_set_tuning(name, ctypes.c_int64(7)) != 0 and name in lib.cvtmi_last_error()
+    assert lib.cvtmi_set_tuning(b"no_such_knob", ctypes.c_int64(1)) != 0 and b"no_such_knob" in lib.cvtmi_last_error()
+    assert lib.cvtmi_set_tuning(None, ctypes.c_int64(1)) != 0
