@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <numeric>
 #include <vector>
@@ -98,6 +99,41 @@ struct Tmp {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Per-handle serialisation.  Every search borrows scratch buffers that belong to the handle (tables, partial top-k
+// lists, visited bitmaps, lazily built copies of the rows), so two calls on one handle must not overlap -- neither on the
+// host (two threads inside the library) nor on the device (two streams).  Serial holds the handle's lock for the duration
+// of the host-side call, and when a call arrives on another stream than the previous one it makes that stream wait for
+// the previous call's work (an event recorded when each outermost call returns).  Calls nest (host-pointer entries call
+// their _dev twins), hence the recursive lock and the depth count.
+struct HandleSync {
+    std::recursive_mutex mu;
+    hipEvent_t done = nullptr;
+    hipStream_t last = nullptr;
+    int depth = 0;
+    bool pending = false;
+    void destroy() { if (done) (void)hipEventDestroy(done); done = nullptr; }
+};
+
+struct Serial {
+    HandleSync &s;
+    hipStream_t st;
+    Serial(HandleSync &sync, hipStream_t stream) : s(sync), st(stream)
+    {
+        s.mu.lock();
+        if (s.depth++ == 0 && s.pending && s.last != st) (void)hipStreamWaitEvent(st, s.done, 0);
+    }
+    ~Serial()
+    {
+        if (--s.depth == 0) {
+            if (!s.done) (void)hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+            if (s.done && hipEventRecord(s.done, st) == hipSuccess) { s.last = st; s.pending = true; }
+        }
+        s.mu.unlock();
+    }
+    Serial(const Serial &) = delete;
+    Serial &operator=(const Serial &) = delete;
+};
+
 }  // namespace cvtmi
 
 using namespace cvtmi;
@@ -105,6 +141,7 @@ using namespace cvtmi;
 // ================================================================ handles =====================
 struct cvtmi_opq_s {
     int device = 0;
+    HandleSync sync;
     OpqModelDev m{};
     float *d_coarse = nullptr, *d_books = nullptr, *d_R = nullptr;
     int32_t *d_perm = nullptr;
@@ -137,6 +174,7 @@ struct cvtmi_opq_s {
 
 struct cvtmi_flat_s {
     int device = 0;
+    HandleSync sync;
     int metric = 0, D = 0;
     size_t row_bytes = 0;
     DevBuf data, labels, norms;  // norms: int32 |x-128|^2 per row, uint8 metric with D % 32 == 0 (MFMA path)
@@ -162,6 +200,10 @@ static int use_device(int dev)
 #define CHECK_H(h) \
     if (!(h)) return fail(CVTMI_EINVAL, "%s: null handle", __func__); \
     CVTMI_TRY(use_device((h)->device))
+// + the handle's lock and stream ordering (see Serial) for the rest of the enclosing scope
+#define CHECK_H_SERIAL(h, stream) \
+    CHECK_H(h); \
+    Serial serial_##h((h)->sync, (hipStream_t)(stream))
 
 static int g_flat_variant = 0;  // cvtmi_set_tuning("flat_variant"): 0 = choose, 1 = exact kernels only, 2 = matrix-core filter wherever it applies
 
@@ -247,13 +289,14 @@ int cvtmi_opq_destroy(cvtmi_opq_t h)
         if (h->ev0[e]) (void)hipEventDestroy(h->ev0[e]);
         if (h->ev1[e]) (void)hipEventDestroy(h->ev1[e]);
     }
+    h->sync.destroy();
     delete h;
     return CVTMI_OK;
 }
 
 int cvtmi_opq_rotate_dev(cvtmi_opq_t h, const float *x, int64_t n, float *y, void *stream)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, stream);
     if (n < 0 || (n > 0 && (!x || !y))) return fail(CVTMI_EINVAL, "cvtmi_opq_rotate: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (h->m.perm) return launch_permute(h->m.perm, h->m.D, x, n, y, st);
@@ -264,7 +307,7 @@ int cvtmi_opq_rotate_dev(cvtmi_opq_t h, const float *x, int64_t n, float *y, voi
 
 int cvtmi_opq_rotate(cvtmi_opq_t h, const float *x, int64_t n, float *y)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, nullptr);
     if (n < 0 || (n > 0 && (!x || !y))) return fail(CVTMI_EINVAL, "cvtmi_opq_rotate: bad arguments");
     if (n == 0) return CVTMI_OK;
     const size_t bytes = (size_t)n * h->m.D * sizeof(float);
@@ -278,7 +321,7 @@ int cvtmi_opq_rotate(cvtmi_opq_t h, const float *x, int64_t n, float *y)
 
 int cvtmi_opq_encode_dev(cvtmi_opq_t h, const float *x_rot, int64_t n, int32_t *list_id, uint8_t *codes, void *stream)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, stream);
     if (n < 0 || (n > 0 && (!x_rot || !codes))) return fail(CVTMI_EINVAL, "cvtmi_opq_encode: bad arguments");
     if (n == 0) return CVTMI_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -297,7 +340,7 @@ int cvtmi_opq_encode_dev(cvtmi_opq_t h, const float *x_rot, int64_t n, int32_t *
 
 int cvtmi_opq_encode(cvtmi_opq_t h, const float *x_rot, int64_t n, int32_t *list_id, uint8_t *codes)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, nullptr);
     if (n < 0 || (n > 0 && (!x_rot || !codes))) return fail(CVTMI_EINVAL, "cvtmi_opq_encode: bad arguments");
     if (n == 0) return CVTMI_OK;
     Tmp dx, dl, dc;
@@ -379,20 +422,20 @@ static int opq_add_common(cvtmi_opq_t h, const uint8_t *codes, const int32_t *li
 
 int cvtmi_opq_add_codes(cvtmi_opq_t h, const uint8_t *codes, const int32_t *list_id, const int32_t *video_id, int64_t n)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, nullptr);
     return opq_add_common(h, codes, list_id, video_id, n, hipMemcpyHostToDevice, nullptr);
 }
 
 int cvtmi_opq_add_codes_dev(cvtmi_opq_t h, const uint8_t *codes, const int32_t *list_id, const int32_t *video_id,
                             int64_t n, void *stream)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, stream);
     return opq_add_common(h, codes, list_id, video_id, n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
 }
 
 int cvtmi_opq_reserve(cvtmi_opq_t h, int64_t n_total)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, nullptr);
     if (n_total < 0 || n_total > 0xfffffffeLL) return fail(CVTMI_EINVAL, "cvtmi_opq_reserve: bad size");
     return h->codes.grow((size_t)n_total * h->m.M, (size_t)h->n * h->m.M, nullptr);
 }
@@ -406,7 +449,7 @@ int cvtmi_opq_ntotal(cvtmi_opq_t h, int64_t *n)
 
 int cvtmi_opq_reset(cvtmi_opq_t h)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, nullptr);
     h->n = 0; h->has_lists = false; h->has_videos = false; h->csr_valid = false; h->rot_n = 0;
     return CVTMI_OK;
 }
@@ -462,7 +505,7 @@ static int opq_build_csr(cvtmi_opq_t h)
 
 int cvtmi_opq_get_entries(cvtmi_opq_t h, int64_t *list_off, int32_t *video_id, uint8_t *codes)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, nullptr);
     CVTMI_TRY(opq_build_csr(h));
     if (list_off) memcpy(list_off, h->h_off.data(), h->h_off.size() * sizeof(int64_t));
     if (video_id && !h->h_csr_video.empty()) memcpy(video_id, h->h_csr_video.data(), h->h_csr_video.size() * 4);
@@ -472,14 +515,14 @@ int cvtmi_opq_get_entries(cvtmi_opq_t h, int64_t *list_off, int32_t *video_id, u
 
 int cvtmi_opq_lut_dev(cvtmi_opq_t h, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut, void *stream)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, stream);
     if (nq < 0 || (nq > 0 && (!q_rot || !lut))) return fail(CVTMI_EINVAL, "cvtmi_opq_lut: bad arguments");
     return launch_lut(h->m, q_rot, nq, list_id, lut, (hipStream_t)stream);
 }
 
 int cvtmi_opq_lut(cvtmi_opq_t h, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, nullptr);
     if (nq < 0 || (nq > 0 && (!q_rot || !lut))) return fail(CVTMI_EINVAL, "cvtmi_opq_lut: bad arguments");
     if (nq == 0) return CVTMI_OK;
     if (list_id)
@@ -498,7 +541,7 @@ int cvtmi_opq_lut(cvtmi_opq_t h, const float *q_rot, int64_t nq, const int32_t *
 int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int k, float *dist, int64_t *ids,
                          void *stream)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, stream);
     if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search: bad arguments");
     if (h->m.coarseK != 1)
         return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: exhaustive search needs coarseK == 1 (use cvtmi_opq_query_video)");
@@ -562,7 +605,7 @@ int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, 
 
 int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int k, float *dist, int64_t *ids)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, nullptr);
     if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search: bad arguments");
     if (nq == 0) return CVTMI_OK;
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: k=%d outside 1..128", k);
@@ -579,7 +622,7 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
 int cvtmi_opq_query_video(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int nprobe, int img_num,
                           float *match_score)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, nullptr);
     if (nq < 0 || img_num < 0 || (nq > 0 && img_num > 0 && (!q || !match_score)))
         return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: bad arguments");
     if (nprobe < 1) return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: nprobe=%d", nprobe);
@@ -635,7 +678,7 @@ int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value)
 
 int cvtmi_opq_last_scan(cvtmi_opq_t h, float *ms, int64_t *code_bytes, int *qtile, int *splits)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, nullptr);
     if (h->ev_count == 0) return fail(CVTMI_ESTATE, "cvtmi_opq_last_scan: no profiled search since the last call");
     const int cnt = h->ev_count < cvtmi_opq_s::kEvRing ? h->ev_count : cvtmi_opq_s::kEvRing;
     double sum = 0.0;
@@ -723,7 +766,12 @@ int cvtmi_flat_destroy(cvtmi_flat_t h)
 {
     if (!h) return CVTMI_OK;
     (void)hipSetDevice(h->device);
-    h->data.release(); h->labels.release(); h->norms.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_gthr.release(); h->s_stage.release();
+    (void)hipDeviceSynchronize();
+    for (DevBuf *b : { &h->data, &h->labels, &h->norms, &h->s_part_d, &h->s_part_id, &h->s_gthr, &h->s_stage, &h->f_pack, &h->f_bias,
+                       &h->f_stats, &h->f_thr, &h->f_marg, &h->f_cnt, &h->f_cand, &h->f_sd, &h->f_si, &h->f_sd2, &h->f_si2, &h->f_seld,
+                       &h->f_seli })
+        b->release();
+    h->sync.destroy();
     delete h;
     return CVTMI_OK;
 }
@@ -796,13 +844,13 @@ static int flat_add_common(cvtmi_flat_t h, const void *x, const int64_t *labels,
 
 int cvtmi_flat_add(cvtmi_flat_t h, const void *x, const int64_t *labels, int64_t n)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, nullptr);
     return flat_add_common(h, x, labels, n, hipMemcpyHostToDevice, nullptr);
 }
 
 int cvtmi_flat_add_dev(cvtmi_flat_t h, const void *x, const int64_t *labels, int64_t n, void *stream)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, stream);
     return flat_add_common(h, x, labels, n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
 }
 
@@ -815,8 +863,10 @@ int cvtmi_flat_ntotal(cvtmi_flat_t h, int64_t *n)
 
 int cvtmi_flat_reset(cvtmi_flat_t h)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, nullptr);
     h->n = 0; h->identity = true; h->f_pack_n = -1;
+    (void)hipDeviceSynchronize();
+    h->f_pack.release(); h->f_bias.release();  // the filter's operand copy is as large as the rows: give it back
     return CVTMI_OK;
 }
 
@@ -961,7 +1011,7 @@ static int flat_search_filtered_u8(cvtmi_flat_t h, const uint8_t *q, int64_t nq,
 
 int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels, void *stream)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, stream);
     if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_flat_search: bad arguments");
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search: k=%d outside 1..128", k);
     if (nq == 0) return CVTMI_OK;
@@ -993,7 +1043,7 @@ int cvtmi_flat_last_search(cvtmi_flat_t h, int *filtered, int64_t *max_candidate
 
 int cvtmi_flat_search(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels)
 {
-    CHECK_H(h);
+    CHECK_H_SERIAL(h, nullptr);
     if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_flat_search: bad arguments");
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search: k=%d outside 1..128", k);
     if (nq == 0) return CVTMI_OK;
@@ -1213,6 +1263,7 @@ int cvtmi_opq_train(const float *x, int64_t n, int D, int coarseK, int M, int K,
 struct cvtmi_hnsw_s {
     uint32_t magic = 0x484e5357u;
     int device = 0, metric = 0, D = 0;
+    HandleSync sync;
     HnswDevGraph g{};
     DevBuf vec, links0, labels, upper_off, upper;
     DevBuf s_vis, s_cand, s_err;
@@ -1235,50 +1286,68 @@ int cvtmi_hnsw_load(const void *file, int64_t bytes, int metric, int D, cvtmi_hn
         offsetLevel0 != 0 || cur_count > max_elements || maxM0 > 4096 || maxM > 4096)
         return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: header does not describe %d-d fp32 vectors (size_data_per_element=%llu)", D,
                     (unsigned long long)size_per);
-    if ((uint64_t)bytes < 96 + max_elements * size_per) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: truncated level-0 block");
+    // the header is untrusted: the product below must not wrap, and the counts size host allocations
+    if (max_elements > ((uint64_t)bytes - 96) / size_per) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: truncated level-0 block");
+    if (cur_count > 0 && maxlevel < 0) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: negative maxlevel");
     const int64_t n = (int64_t)cur_count;
     const uint8_t *l0 = p;
     p += max_elements * size_per;
-    std::vector<float> vec((size_t)n * D);
-    std::vector<uint32_t> links0((size_t)n * (maxM0 + 1));
-    std::vector<int64_t> labels((size_t)n), uoff((size_t)n, -1);
-    std::vector<uint32_t> upper;
-    for (int64_t i = 0; i < n; ++i) {
-        const uint8_t *e = l0 + (uint64_t)i * size_per;
-        memcpy(&links0[(size_t)i * (maxM0 + 1)], e, 4 * (maxM0 + 1));
-        if (links0[(size_t)i * (maxM0 + 1)] > maxM0) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: corrupt link count");
-        memcpy(&vec[(size_t)i * D], e + offsetData, 4 * (size_t)D);
-        uint64_t lab; memcpy(&lab, e + label_off, 8);
-        labels[(size_t)i] = (int64_t)lab;
-    }
+    std::vector<float> vec;
+    std::vector<uint32_t> links0, upper;
+    std::vector<int64_t> labels, uoff;
+    std::vector<int32_t> levels;  // upper levels a node has link blocks for
     const uint64_t links_per = 4 * maxM + 4;
-    for (uint64_t i = 0; i < max_elements; ++i) {
-        if (p + 4 > f + bytes) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: truncated link lists");
-        uint32_t sz; memcpy(&sz, p, 4); p += 4;
-        if (sz) {
-            if (p + sz > f + bytes || sz % links_per != 0) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: corrupt link list");
-            if ((int64_t)i < n) {
-                uoff[(size_t)i] = (int64_t)upper.size();
-                upper.resize(upper.size() + sz / 4);
-                memcpy(&upper[(size_t)uoff[(size_t)i]], p, sz);
-            }
-            p += sz;
+    try {
+        vec.resize((size_t)n * D);
+        links0.resize((size_t)n * (maxM0 + 1));
+        labels.resize((size_t)n);
+        uoff.assign((size_t)n, -1);
+        levels.assign((size_t)n, 0);
+        for (int64_t i = 0; i < n; ++i) {
+            const uint8_t *e = l0 + (uint64_t)i * size_per;
+            memcpy(&links0[(size_t)i * (maxM0 + 1)], e, 4 * (maxM0 + 1));
+            if (links0[(size_t)i * (maxM0 + 1)] > maxM0) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: corrupt link count");
+            memcpy(&vec[(size_t)i * D], e + offsetData, 4 * (size_t)D);
+            uint64_t lab; memcpy(&lab, e + label_off, 8);
+            labels[(size_t)i] = (int64_t)lab;
         }
+        for (uint64_t i = 0; i < max_elements; ++i) {
+            if ((uint64_t)(f + bytes - p) < 4) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: truncated link lists");
+            uint32_t sz; memcpy(&sz, p, 4); p += 4;
+            if (sz) {
+                if ((uint64_t)(f + bytes - p) < sz || sz % links_per != 0) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: corrupt link list");
+                if ((int64_t)i < n) {
+                    uoff[(size_t)i] = (int64_t)upper.size();
+                    levels[(size_t)i] = (int32_t)(sz / links_per);
+                    upper.resize(upper.size() + sz / 4);
+                    memcpy(&upper[(size_t)uoff[(size_t)i]], p, sz);
+                }
+                p += sz;
+            }
+        }
+    } catch (const std::exception &) {
+        return fail(CVTMI_ENOMEM, "cvtmi_hnsw_load: out of host memory for %llu elements", (unsigned long long)cur_count);
     }
-    // every link must point inside the graph (the kernel trusts them)
+    // every link must point inside the graph, and a link at level L at a node that HAS a level-L block: the kernel
+    // follows them without further checks (hnsw.hip: a.upper + a.upper_off[cur] + (level - 1) * (maxM + 1))
     for (int64_t i = 0; i < n; ++i) {
         const uint32_t *l = &links0[(size_t)i * (maxM0 + 1)];
         for (uint32_t j = 1; j <= l[0]; ++j) if (l[j] >= (uint64_t)n) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: link out of range");
+        for (int32_t lv = 1; lv <= levels[(size_t)i]; ++lv) {
+            const uint32_t *u = &upper[(size_t)uoff[(size_t)i] + (size_t)(lv - 1) * (maxM + 1)];
+            if (u[0] > maxM) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: corrupt upper link count");
+            for (uint32_t j = 1; j <= u[0]; ++j) {
+                if (u[j] >= (uint64_t)n) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: link out of range");
+                if (levels[u[j]] < lv) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: level-%d link to a node without that level", lv);
+            }
+        }
     }
-    for (size_t b = 0; b + maxM < upper.size(); b += maxM + 1) {
-        if (upper[b] > maxM) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: corrupt upper link count");
-        for (uint32_t j = 1; j <= upper[b]; ++j) if (upper[b + j] >= (uint64_t)n) return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: link out of range");
-    }
-    if (n > 0 && (enterpoint >= (uint64_t)n || (maxlevel > 0 && uoff[enterpoint] < 0)))
+    if (n > 0 && (enterpoint >= (uint64_t)n || levels[enterpoint] < maxlevel))
         return fail(CVTMI_EINVAL, "cvtmi_hnsw_load: bad entry point");
     int dev = 0;
     CVTMI_HIP(hipGetDevice(&dev));  // no device: fails here, there is no CPU path
-    cvtmi_hnsw_s *h = new cvtmi_hnsw_s();
+    cvtmi_hnsw_s *h = new (std::nothrow) cvtmi_hnsw_s();
+    if (!h) return fail(CVTMI_ENOMEM, "cvtmi_hnsw_load: out of host memory");
     h->device = dev; h->metric = metric; h->D = D;
     auto up = [&](DevBuf &b, const void *src, size_t nb) -> int {
         CVTMI_TRY(b.reserve(nb ? nb : 16));
@@ -1305,6 +1374,7 @@ int cvtmi_hnsw_destroy(cvtmi_hnsw_t h)
     CHECK_HN(h);
     h->vec.release(); h->links0.release(); h->labels.release(); h->upper_off.release(); h->upper.release();
     h->s_vis.release(); h->s_cand.release(); h->s_err.release();
+    h->sync.destroy();
     h->magic = 0;
     delete h;
     return CVTMI_OK;
@@ -1315,6 +1385,7 @@ int64_t cvtmi_hnsw_ntotal(cvtmi_hnsw_t h) { return (h && h->magic == 0x484e5357u
 int cvtmi_hnsw_search_dev(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int ef, float *dist, int64_t *labels, void *stream)
 {
     CHECK_HN(h);
+    Serial serial_h(h->sync, (hipStream_t)(stream));
     if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search: bad arguments");
     if (k < 1 || k > hnsw_ef_max()) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search: k=%d outside 1..%d", k, hnsw_ef_max());
     if (ef < 1 || ef > hnsw_ef_max()) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search: ef=%d outside 1..%d", ef, hnsw_ef_max());
@@ -1352,6 +1423,7 @@ int cvtmi_hnsw_search_dev(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int
 int cvtmi_hnsw_search(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int ef, float *dist, int64_t *labels)
 {
     CHECK_HN(h);
+    Serial serial_h(h->sync, (hipStream_t)(nullptr));
     if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search: bad arguments");
     if (nq == 0) return CVTMI_OK;
     Tmp dq, dd, dl;
@@ -1371,6 +1443,7 @@ int cvtmi_hnsw_search_adc_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, i
                               int64_t *labels, void *stream)
 {
     CHECK_HN(h);
+    Serial serial_h(h->sync, (hipStream_t)(stream));
     if (!opq) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: null OPQ handle");
     if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: bad arguments");
     if (opq->m.coarseK != 1) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search_adc: needs an OPQ model with coarseK == 1");
@@ -1382,6 +1455,7 @@ int cvtmi_hnsw_search_adc_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, i
     if (ef < 1 || ef > hnsw_ef_max()) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search_adc: ef=%d outside 1..%d", ef, hnsw_ef_max());
     if (nq == 0) return CVTMI_OK;
     hipStream_t st = (hipStream_t)stream;
+    Serial serial_opq(opq->sync, st);  // the tables live in the OPQ handle's scratch
     const float *q_rot = q;
     if (rotate && (opq->m.perm || opq->m.R)) {
         CVTMI_TRY(opq->s_qrot.reserve((size_t)nq * opq->m.D * sizeof(float)));
@@ -1422,6 +1496,7 @@ int cvtmi_hnsw_search_adc(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64
                           int64_t *labels)
 {
     CHECK_HN(h);
+    Serial serial_h(h->sync, (hipStream_t)(nullptr));
     if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: bad arguments");
     if (nq == 0) return CVTMI_OK;
     Tmp dq, dd, dl;

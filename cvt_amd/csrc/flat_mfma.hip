@@ -96,7 +96,12 @@ __global__ __launch_bounds__(kBlock) void flat_thr_kernel(const float *__restric
     const float tau = sample_d[i * k + k - 1];
     const float Q = (qq + __uint_as_float(stats[0])) * 1.001f;
     float t = l2 ? 0.5f * (qq - tau) - Q * 0x1p-13f : (1.0f - tau) - Q * 0x1p-13f - (1.0f + fabsf(tau)) * 0x1p-20f;
-    if (!(Q > 0x1p-60f && Q < 0x1p60f) || !(fabsf(t) <= 3.0e38f) || !(fabsf(tau) <= 3.0e38f)) t = -__uint_as_float(0x7f800000u);
+    if (!(Q > 0x1p-60f && Q < 0x1p60f) || !(fabsf(t) <= 3.0e38f) || !(fabsf(tau) <= 3.0e38f)) {
+        // the bound does not apply: every row would pass.  Flag the overflow directly -- the 32-bit pair counter could wrap
+        // (nq * n >= 2^32) and land below pair_cap, which would read as a complete candidate list
+        t = -__uint_as_float(0x7f800000u);
+        atomicMax(&stats[2], 0xffffffffu);
+    }
     thr[i] = t;
     margin[i] = Q * 0x1p-13f + (l2 ? 0.0f : (1.0f + fabsf(tau)) * 0x1p-20f);  // the pairwise cut of flat_finish_kernel
 }

@@ -71,29 +71,13 @@ def random_permutation(D, seed=7):
 def train_books(x_rot, M, K=256, iters=6, seed=1234):
     """Sub-space codebooks for a zero-coarse-centroid model (the exhaustive configs): cvtmi_kmeans (the library's
     own Lloyd iteration, csrc/kmeans.hip) per sub-space on a (rotated) device sample -> numpy [M][K][step]."""
-    import torch
     from . import capi
     n, D = x_rot.shape
     step = D // M
-    if x_rot.is_cuda:
-        books = np.empty((M, K, step), dtype=np.float32)
-        for m in range(M):
-            cen, _, _ = capi.kmeans(x_rot[:, m * step:(m + 1) * step].contiguous(), K, iters, seed)
-            books[m] = cen.cpu().numpy()
-        return books
-    g = torch.Generator(device=x_rot.device)
-    g.manual_seed(seed)
-    books = torch.empty((M, K, step), dtype=torch.float32, device=x_rot.device)
+    if not x_rot.is_cuda:
+        raise RuntimeError("train_books needs a device sample: the k-means runs in libcvtmi (csrc/kmeans.hip), there is no CPU path")
+    books = np.empty((M, K, step), dtype=np.float32)
     for m in range(M):
-        sub = x_rot[:, m * step:(m + 1) * step].contiguous()
-        cen = sub[torch.randperm(n, generator=g, device=x_rot.device)[:K]].clone()
-        for _ in range(iters):
-            d = torch.cdist(sub, cen)
-            a = d.argmin(dim=1)
-            sums = torch.zeros_like(cen).index_add_(0, a, sub)
-            cnt = torch.bincount(a, minlength=K).clamp_min(1).unsqueeze(1)
-            new = sums / cnt
-            empty = (torch.bincount(a, minlength=K) == 0)
-            cen = torch.where(empty.unsqueeze(1), cen, new)
-        books[m] = cen
-    return books.cpu().numpy()
+        cen, _, _ = capi.kmeans(x_rot[:, m * step:(m + 1) * step].contiguous(), K, iters, seed)
+        books[m] = cen.cpu().numpy()
+    return books

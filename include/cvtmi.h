@@ -13,8 +13,14 @@
  *     float** / float* arguments) and return when the result is in the caller's buffer.
  *     Functions ending in `_dev` take DEVICE pointers (HBM-resident) plus a `stream`
  *     (a hipStream_t passed as void*, NULL = the default stream) and are asynchronous.
- *   - Handles are thread-compatible: concurrent searches on an unchanging handle are fine,
- *     mutation needs external synchronisation (same as the reference classes).
+ *   - Handles may be shared between threads and streams: every search borrows scratch that
+ *     belongs to the handle (tables, partial top-k lists, visited bitmaps), so calls on ONE handle
+ *     are serialised by the library -- a per-handle lock on the host, and when a call arrives on
+ *     another stream than the previous call on that handle, that stream first waits for the
+ *     previous call's work.  Results are those of some serial order.  For searches that really
+ *     overlap on the device, use one handle per stream (a handle is cheap next to its rows only
+ *     for small indexes) or batch the queries into one call.  The small accessors (ntotal,
+ *     set_id_base, set_param) take no lock: do not race them with searches.
  *   - One handle lives on the HIP device that was current when it was created.
  *   - The library has no CPU fallback: without a usable HIP device every compute entry fails
  *     with CVTMI_EHIP.
