@@ -1,27 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec of the OPQ-ADC search hot path on MI355X.
 
-One "step" = one pass of the hot path over one batch of nq synthetic queries against the HBM-resident
-code index: query rotation (fp32 MFMA GEMM) -> per-query distance tables built in LDS -> ADC scan of
-every code row -> k smallest (distance, id) per query [-> for N > 1: RCCL all-gather of the per-shard
-top-k and a k-way merge on every rank].  Inputs are resident in HBM when the timed region starts.
+One "step" = one pass of the hot path over one batch of nq synthetic queries against the HBM-resident code index:
+query rotation (fp32 MFMA GEMM) -> per-query distance tables -> ADC scan of every code row -> k smallest
+(distance, id) per query [-> N > 1: ONE RCCL all-gather of the per-shard top-k + k-way merge on every rank, issued by
+libcvtmi itself (cvtmi_opq_search_sharded_dev, csrc/shard.hip)].  Inputs are resident in HBM when the timed region starts.
 
-Workload: BASELINE.json configs[1], SIFT-1M (synthetic SIFT-shaped 128-d rows), OPQ M=16 K=256, top-100,
-nq=10000 queries per step and GPU.  At N > 1 (--scaling):
-  weak     (default) every rank serves its own batch of nq queries against its replica of the 16 MB code matrix:
-           per-GPU work is fixed, value = N * nq queries per step -- how a database this small is served;
-  strong   the SAME nq-query batch is split over the ranks (per-GPU batches of nq / N).
-Multi-GPU layout (--layout):
-  rows     the north-star layout: rank r owns a contiguous row shard, every rank scans all queries, then ONE
-           RCCL all-gather of the per-shard top-k and a k-way merge on every rank;
-  queries  the code matrix is replicated (16 MB at SIFT-1M) and the query batch is split over the ranks:
-           no data-path collective at all;
-  auto     queries when the code matrix is < 1 GiB per GPU (replication is free and a 125 K-row shard is too
-           small to amortise a workgroup's fixed cost), rows otherwise (SIFT-1B: 2 GB per GPU).
-At N > 1 the JSON line also carries the throughput of the row-sharded path measured in the same run, and at
-every N the SIFT-1B probe ("row_sharded_large"): --large-rows code rows in total (default 2^30 = 16 GiB of codes) sharded by
-row over the ranks, 1024 queries on every rank, RCCL all-gather of the per-shard top-k + merge -- the north-star
-layout at a shard size where the scan streams from HBM (strong scaling in rows: compare its value across N).
+Headline workload:
+  N = 1   BASELINE.json configs[1]: SIFT-1M (synthetic SIFT-shaped 128-d rows), OPQ M=16 K=256, top-100, nq = 10 000.
+          The same line carries "sift1b": the N > 1 headline workload on this one GPU (the N = 1 point of its curve),
+          and "secondary": rotation / encode / SQ8 / config 3 (10 M x 512-d uint8 flat search) / config 5 (HNSW).
+  N > 1   BASELINE.json configs[3], the north-star multi-GPU case: SIFT-1B-shaped -- --large-rows (2^30) synthetic rows,
+          generated, rotated and encoded on device, ROW-SHARDED over the N ranks (2 GB of codes per GPU at N = 8), the
+          same nq = 10 000 queries on every rank, all-gather + merge: "scaling": "strong" (total work fixed).  A 16 MB
+          database is not a multi-GPU workload; what N GPUs do with it (row-sharded, and as N replicas) is reported
+          under "sift1m_row_sharded" / "sift1m_replicas", never as `value`.
 
     python bench.py                       # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -30,7 +23,9 @@ layout at a shard size where the scan streams from HBM (strong scaling in rows: 
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -39,7 +34,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+# /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0      # HBM3E
+F32_MFMA_PEAK_TF = 157.3   # dense fp32 matrix
+I8_MFMA_PEAK_TOPS = 5033.0  # dense int8 matrix (= the dense fp8 rate)
+LDS_BYTES_PER_CLK_CU = 256.0
+N_CU, CLK_GHZ = 256, 2.4
 
 
 def main():
@@ -54,20 +54,21 @@ def main():
     ap.add_argument("--qtile", type=int, default=0)
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--variant", type=int, default=-1, help="scan kernel variant (cvtmi.h), -1 = library default")
-    ap.add_argument("--layout", choices=["auto", "rows", "queries"], default="auto")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1 with the queries layout: per-GPU batch fixed (weak) or the one batch split (strong)")
-    ap.add_argument("--large-rows", type=int, default=1 << 30, help="total rows of the row-sharded SIFT-1B probe (0 = skip): 16 GiB of codes in all")
-    ap.add_argument("--large-nq", type=int, default=1024)
-    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo = debug: several ranks on one GPU")
+    ap.add_argument("--large-rows", type=int, default=1 << 30, help="total rows of the SIFT-1B-shaped workload (0 = skip at N = 1)")
+    ap.add_argument("--large-nq", type=int, default=10_000)
+    ap.add_argument("--large-data", choices=["sift", "random"], default="sift",
+                    help="sift = synthetic rows rotated + encoded on device; random = uniform random code bytes (quick)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo = debug: several ranks on one GPU, exchange staged through the host")
     ap.add_argument("--cpu-sample", type=int, default=256, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=-1, help="threads of the all-cores CPU leg (-1 = all logical cores, 0 = skip)")
     ap.add_argument("--recall-sample", type=int, default=1000)
+    ap.add_argument("--secondary", type=int, default=1, help="N = 1: also measure rotation / encode / SQ8 / config 3 / config 5 (0 = skip)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import cvt_amd
-    from cvt_amd import sharded, synth
+    from cvt_amd import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -75,15 +76,22 @@ def main():
     assert world == args.gpus, "launch with --nproc-per-node equal to --gpus (got WORLD_SIZE=%d)" % world
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
     if args.backend == "gloo":
-        local_rank = 0  # debug: every rank on GPU 0, collectives staged through the host
+        local_rank = 0  # debug: every rank on GPU 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cvt_amd.lib()
+    comm = None
     if world > 1:
+        # torch.distributed: launcher glue (barriers, max-over-ranks clock, bootstrap of the id).  The data-path collective
+        # is the library's own ncclAllGather on its own communicator.
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+            box = [cvt_amd.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = cvt_amd.Comm(box[0], rank, world)
         else:
             dist.init_process_group("gloo")
-    cvt_amd.lib()
+            comm = cvt_amd.Comm.over_torch_group(rank, world)
 
     D, M, K, k, nq = 128, args.M, 256, args.k, args.nq
     zero_coarse = np.zeros((1, D), np.float32)
@@ -103,37 +111,13 @@ def main():
             bc = books_t.cpu(); dist.broadcast(bc, src=0); books_t.copy_(bc)
     books = books_t.cpu().numpy()
 
-    layout = args.layout
-    if layout == "auto":
-        layout = "queries" if args.rows * M < (1 << 30) else "rows"
-    if world == 1:
-        layout = "rows"
-
-    # ---- index build on device: generate -> rotate (MFMA GEMM) -> encode -> append; only codes stay ----
-    def build_index(r0, r1):
-        ix = cvt_amd.OpqIndex(zero_coarse, books, R=R)
-        ix.reserve(r1 - r0); ix.set_id_base(r0)
-        rows_done, t_acc = 0, 0.0
-        for a in range(r0, r1, synth.CHUNK):
-            b = min(r1, a + synth.CHUNK)
-            x = synth.sift_like(b - a, D, seed=0xC0FFEE, row_begin=a, device=dev)
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            _, codes = ix.encode(ix.rotate(x))
-            ix.add_codes(codes)
-            torch.cuda.synchronize(); t_acc += time.perf_counter() - t0  # data generation excluded
-            rows_done += b - a
-        ix.set_param("qtile", args.qtile); ix.set_param("splits", args.splits); ix.set_param("profile", 1)
-        if args.variant >= 0: ix.set_param("scan_variant", args.variant)
-        return ix, rows_done, t_acc
-
-    q = synth.sift_like(nq, D, seed=0xBEEF, device=dev)  # identical on every rank
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     def timed(fn, steps, warmup):
+        out = None
         for _ in range(warmup):
             out = fn()
         barrier()
@@ -148,121 +132,164 @@ def main():
             el = float(t.item())
         return el, out
 
-    r0, r1 = sharded.shard_range(args.rows, rank, world)
-    extra = {}
-    if layout == "rows":
-        idx, enc_rows, enc_time = build_index(r0, r1)
-        searcher = sharded.ShardedSearch(lambda qq, kk: idx.search(qq, kk, rotate=True), cvt_amd.topk_merge, world, rank)
-        for _ in range(args.warmup):
-            searcher.search(q, k)
-        barrier(); idx.last_scan()  # drop the warm-up launches from the kernel-time statistics
-        elapsed, out = timed(lambda: searcher.search(q, k), args.steps, 0)
-        rows_here = r1 - r0
-        par = "row-sharded x%d + RCCL all-gather of per-shard top-k + merge" % world if world > 1 else "1 GPU"
-    else:
-        idx, enc_rows, enc_time = build_index(0, args.rows)  # replica of the whole code matrix
-        if args.scaling == "weak":
-            q_mine = synth.sift_like(nq, D, seed=0xBEEF + 7919 * rank, device=dev) if rank else q
-        else:
-            q0, q1 = sharded.shard_range(nq, rank, world)
-            q_mine = q[q0:q1].contiguous()
-        for _ in range(args.warmup):
-            idx.search(q_mine, k, rotate=True)
-        barrier(); idx.last_scan()
-        elapsed, out = timed(lambda: idx.search(q_mine, k, rotate=True), args.steps, 0)
-        rows_here = args.rows
-        par = ("code matrix replicated x%d, every rank serves its own batch of %d queries, no data-path collective" % (world, nq)
-               if args.scaling == "weak" else
-               "code matrix replicated x%d, one batch of %d queries split over the ranks, no data-path collective" % (world, nq))
-        # the north-star layout measured in the same run (row shard of the replica + all-gather + merge)
-        shard = cvt_amd.OpqIndex(zero_coarse, books, R=R)
-        codes_t = torch.from_numpy(idx.get_entries()[2][r0:r1]).to(dev)
-        shard.add_codes(codes_t); shard.set_id_base(r0)
-        rs = sharded.ShardedSearch(lambda qq, kk: shard.search(qq, kk, rotate=True), cvt_amd.topk_merge, world, rank)
-        el2, out2 = timed(lambda: rs.search(q, k), args.steps, args.warmup)
-        extra["row_sharded"] = {"value": round(nq * args.steps / el2, 1), "unit": "queries/s",
-                                "ms_per_step": round(el2 / args.steps * 1e3, 4),
-                                "what": "same database row-sharded x%d, all queries on every rank, RCCL all-gather of "
-                                        "per-shard top-%d + merge" % (world, k)}
-    scan = idx.last_scan()  # mean HIP-event duration of the scan kernel over the timed steps
-
-    # ---- SIFT-1B-shaped probe: a large code matrix row-sharded over the ranks (north-star layout) ----
-    if args.large_rows > 0:
-        try:
-            l0, l1 = sharded.shard_range(args.large_rows, rank, world)
-            # codes + the scan's rotated copy + generation chunks must fit; every rank takes the same decision
-            free_b, _ = torch.cuda.mem_get_info(dev)
-            fits = torch.tensor([1 if free_b > (l1 - l0) * M * 2.3 + (2 << 30) else 0], dtype=torch.int32,
-                                device=dev if args.backend == "nccl" else "cpu")
-            if world > 1:
-                dist.all_reduce(fits, op=dist.ReduceOp.MIN)
-            if int(fits.item()) == 0:
-                raise MemoryError("not enough free HBM for %d code rows per GPU" % (l1 - l0))
+    # ---- index build on device: generate -> rotate (MFMA GEMM) -> encode -> append; only codes stay ----
+    def build_index(r0, r1, data="sift", seed=0xC0FFEE):
+        ix = cvt_amd.OpqIndex(zero_coarse, books, R=R)
+        ix.reserve(r1 - r0); ix.set_id_base(r0)
+        rows_done, t_acc = 0, 0.0
+        if data == "random":
             g = torch.Generator(device=dev); g.manual_seed(0x51F7 + rank)
-            big = cvt_amd.OpqIndex(zero_coarse, books, R=R)
-            big.reserve(l1 - l0); big.set_id_base(l0)
-            for a in range(l0, l1, 1 << 24):
-                b = min(l1, a + (1 << 24))
-                big.add_codes(torch.randint(0, 256, (b - a, M), generator=g, device=dev, dtype=torch.uint8))
-            big.set_param("profile", 1)
-            if args.variant >= 0: big.set_param("scan_variant", args.variant)
-            ql = q[:min(args.large_nq, nq)].contiguous()
-            ls = sharded.ShardedSearch(lambda qq, kk: big.search(qq, kk, rotate=True), cvt_amd.topk_merge, world, rank)
-            for _ in range(2):
-                ls.search(ql, k)
-            barrier(); big.last_scan()
-            lsteps = max(2, min(args.steps, 5))
-            el3, _ = timed(lambda: ls.search(ql, k), lsteps, 0)
-            sc3 = big.last_scan()
-            extra["row_sharded_large"] = {
-                "value": round(ql.shape[0] * lsteps / el3, 1), "unit": "queries/s", "ms_per_step": round(el3 / lsteps * 1e3, 4),
-                "rows_total": args.large_rows, "rows_per_gpu": l1 - l0, "nq": int(ql.shape[0]), "scaling": "strong (rows)",
-                "scan_kernel_ms": round(sc3["ms"], 4),
-                "scan_algorithmic_GBps": round(sc3["code_bytes"] / (sc3["ms"] * 1e-3) / 1e9, 1),
-                "scan_frac_of_hbm_peak": round(sc3["code_bytes"] / (sc3["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "what": "uniform random codes, %d rows row-sharded x%d, %d queries on every rank, top-%d, %s" % (
-                    args.large_rows, world, ql.shape[0], k,
-                    "RCCL all-gather of per-shard top-k + merge" if world > 1 else "single shard")}
-            big.close(); del big
-        except MemoryError as e:  # decided identically on every rank (all-reduce above): skip, keep the headline line
-            extra["row_sharded_large"] = {"error": str(e)}
+            for a in range(r0, r1, 1 << 24):
+                b = min(r1, a + (1 << 24))
+                ix.add_codes(torch.randint(0, 256, (b - a, M), generator=g, device=dev, dtype=torch.uint8))
+        else:
+            step = synth.CHUNK * 4
+            for a in range(r0, r1, step):
+                b = min(r1, a + step)
+                x = synth.sift_like(b - a, D, seed=seed, row_begin=a, device=dev)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                _, codes = ix.encode(ix.rotate(x))
+                ix.add_codes(codes)
+                torch.cuda.synchronize(); t_acc += time.perf_counter() - t0  # data generation excluded
+                rows_done += b - a
+        ix.set_param("qtile", args.qtile); ix.set_param("splits", args.splits); ix.set_param("profile", 1)
+        if args.variant >= 0:
+            ix.set_param("scan_variant", args.variant)
+        return ix, rows_done, t_acc
 
-    result = None
-    if rank == 0:
+    def searcher(ix):
+        if comm is not None:
+            return lambda qq: ix.search_sharded(comm, qq, k, rotate=True)
+        return lambda qq: ix.search(qq, k, rotate=True)
+
+    def scan_roofline(sc):
+        ach = sc["code_bytes"] / (sc["ms"] * 1e-3) / 1e9
+        return {"kernel_ms": round(sc["ms"], 4), "algorithmic_bytes_per_launch": sc["code_bytes"], "achieved_GBps": round(ach, 1),
+                "frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 4), "queries_per_pass": sc["qtile"], "row_splits": sc["splits"]}
+
+    q = synth.sift_like(nq, D, seed=0xBEEF, device=dev)  # identical on every rank
+
+    # ---- the SIFT-1B-shaped workload, row-sharded over the ranks (N > 1: the headline; N = 1: the first point of its curve) ----
+    def run_sift1b(steps, warmup):
+        l0, l1 = cvt_amd.shard_range(args.large_rows, rank, world)
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        # codes + the scan's rotated copy + generation chunks + tables must fit; every rank takes the same decision
+        fits = torch.tensor([1 if free_b > (l1 - l0) * M * 2.3 + (3 << 30) else 0], dtype=torch.int32,
+                            device=dev if args.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(fits, op=dist.ReduceOp.MIN)
+        if int(fits.item()) == 0:
+            return {"error": "not enough free HBM for %d code rows per GPU" % (l1 - l0)}, None
+        t0 = time.perf_counter()
+        big, enc_rows, enc_t = build_index(l0, l1, data=args.large_data, seed=0xC0FFEE)
+        torch.cuda.synchronize(); t_build = time.perf_counter() - t0
+        ql = q[:min(args.large_nq, nq)].contiguous()
+        fn = searcher(big)
+        for _ in range(warmup):
+            fn(ql)
+        barrier(); big.last_scan()
+        el, out = timed(lambda: fn(ql), steps, 0)
+        sc = big.last_scan()
+        res = {"value": round(ql.shape[0] * steps / el, 1), "unit": "queries/s", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
+               "rows_total": args.large_rows, "rows_per_gpu": l1 - l0, "nq": int(ql.shape[0]), "k": k, "n_gpus": world,
+               "scan": scan_roofline(sc),
+               "index_build_s_this_rank": round(t_build, 2),
+               "encode_rows_per_s_this_rank": round(enc_rows / enc_t, 1) if enc_t > 0 else None,
+               "data": ("synthetic SIFT-shaped rows generated, rotated and PQ-encoded on device" if args.large_data == "sift"
+                        else "uniform random code bytes"),
+               "what": "%d rows row-sharded x%d (%.2f GB of codes per GPU), the same %d queries on every rank, top-%d, %s" % (
+                   args.large_rows, world, (l1 - l0) * M / 1e9, ql.shape[0], k,
+                   "ONE ncclAllGather of the per-shard top-k inside libcvtmi + merge" if world > 1 else "single shard")}
+        if comm is not None:
+            res["comm"] = comm.info()
+        big.close()
+        return res, sc
+
+    result, extra = None, {}
+    if world == 1:
+        # ================= N = 1: SIFT-1M, configs[1] =================
+        idx, enc_rows, enc_time = build_index(0, args.rows)
+        fn = searcher(idx)
+        for _ in range(args.warmup):
+            fn(q)
+        barrier(); idx.last_scan()  # drop the warm-up launches from the kernel-time statistics
+        elapsed, out = timed(lambda: fn(q), args.steps, 0)
+        scan = idx.last_scan()  # mean HIP-event duration of the scan kernel over the timed steps
         ms_per_step = elapsed / args.steps * 1e3
-        weak = world > 1 and layout == "queries" and args.scaling == "weak"
-        nq_step = nq * world if weak else nq
-        qps = nq_step * args.steps / elapsed
-        achieved = scan["code_bytes"] / (scan["ms"] * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "scan_traffic.json")
-        default_shape = world == 1 and args.rows == 1_000_000 and nq == 10_000 and k == 100 and M == 16 and not args.qtile and not args.splits
-        if default_shape and os.path.exists(pmc):  # PMC passes were taken on exactly this launch shape
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        rf = scan_roofline(scan)
+        lookups = scan["code_bytes"] * scan["qtile"] / (scan["ms"] * 1e-3)  # one table look-up per code byte and query
+        lds_bytes = lookups * 2.0                                          # 2 bytes of LDS read per look-up (15-bit tables, 8 queries per 16-byte read)
+        lds_peak = LDS_BYTES_PER_CLK_CU * N_CU * CLK_GHZ * 1e9
+        traffic, traffic_src = _pmc_traffic(args, nq, k, M)
         result = {
             "metric": "queries/sec, OPQ-ADC top-%d over 128-d SIFT-1M" % k,
-            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
+            "value": round(nq * args.steps / elapsed, 1), "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 codes / f32 distances", "data": "synthetic",
             "config": {"workload": "SIFT-1M synthetic 128-d, OPQ M=%d K=256 (dense 128x128 rotation), ADC scan + top-%d, "
-                                   "nq=%d queries per step and GPU" % (M, k, nq),
-                       "rows": args.rows, "rows_per_gpu": rows_here, "nq_per_step": nq_step, "nq_per_gpu": nq if (weak or world == 1 or layout == "rows") else nq // world, "k": k, "M": M,
-                       "parallelism": par, "layout": layout,
+                                   "nq=%d queries per step" % (M, k, nq),
+                       "rows": args.rows, "rows_per_gpu": args.rows, "nq_per_step": nq, "k": k, "M": M, "parallelism": "1 GPU",
                        "qtile": scan["qtile"], "row_splits": scan["splits"]},
-            "roofline": {"bound": "hbm", "kernel": "adc_scan16q_kernel (M=%d, %d queries per pass)" % (M, scan["qtile"]) if (M == 16 and scan["qtile"] == 8) else "adc_scan kernel (M=%d, %d queries per pass)" % (M, scan["qtile"]),
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": scan["code_bytes"], "kernel_ms": round(scan["ms"], 4),
-                         "lds_lookups_per_s": round(scan["code_bytes"] * scan["qtile"] / (scan["ms"] * 1e-3) / 1e12, 2),
-                         "lds_lookups_per_s_unit": "T table look-ups/s (LDS ceiling of this kernel, 256 B/clk/CU: 78 at 2.35 GHz, 66 at the ~2.0 GHz it sustains)"},
-            "encode": {"rows_per_s": round(enc_rows / enc_time, 1), "what": "rotate (MFMA GEMM) + PQ encode + append, this rank"},
+            "roofline": {"bound": "hbm", "kernel": "adc_scan kernel (M=%d, %d queries per pass)" % (M, scan["qtile"]),
+                         "achieved": rf["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rf["frac_of_hbm_peak"],
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": scan["code_bytes"], "kernel_ms": rf["kernel_ms"],
+                         "operative_bound": "lds+valu",
+                         "operative_note": "the 16 MB code matrix is cache-resident at this size (traffic << algorithmic bytes): the kernel is "
+                                           "bound by its LDS table look-ups and the VALU work around them, not by HBM; the HBM-streaming "
+                                           "figure is sift1b.scan",
+                         "lds_lookups_per_s": round(lookups / 1e12, 2),
+                         "lds_frac": round(lds_bytes / lds_peak, 4),
+                         "lds_frac_what": "table look-ups/s x 2 B per look-up / (256 B/clk/CU x 256 CU x 2.4 GHz)"},
+            "encode": {"rows_per_s": round(enc_rows / enc_time, 1), "what": "rotate (MFMA GEMM) + PQ encode + append of the 1 M rows"},
         }
-        result.update(extra)
+        if args.large_rows > 0:
+            try:
+                res, _ = run_sift1b(max(1, min(args.steps, 2)), 1)
+                result["sift1b"] = res
+            except cvt_amd.CvtmiError as e:
+                result["sift1b"] = {"error": str(e)}
+    else:
+        # ================= N > 1: SIFT-1B-shaped, row-sharded, configs[3] =================
+        res, sc = run_sift1b(args.steps, args.warmup)
+        if "error" in res:
+            raise SystemExit("bench.py: " + res["error"])
+        # the small database on N GPUs, for the record: row-sharded through the same library path, and as N replicas
+        r0, r1 = cvt_amd.shard_range(args.rows, rank, world)
+        shard, _, _ = build_index(r0, r1)
+        fn = searcher(shard)
+        el2, _ = timed(lambda: fn(q), args.steps, args.warmup)
+        extra["sift1m_row_sharded"] = {"value": round(nq * args.steps / el2, 1), "unit": "queries/s", "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                                       "what": "the 1 M-row database row-sharded x%d (%d rows per GPU), all %d queries on every rank, all-gather + merge: "
+                                               "strong scaling of a 16 MB problem" % (world, r1 - r0, nq)}
+        shard.close()
+        rep, _, _ = build_index(0, args.rows)
+        q_mine = synth.sift_like(nq, D, seed=0xBEEF + 7919 * rank, device=dev) if rank else q
+        el3, _ = timed(lambda: rep.search(q_mine, k, rotate=True), args.steps, args.warmup)
+        extra["sift1m_replicas"] = {"value": round(world * nq * args.steps / el3, 1), "unit": "queries/s", "ms_per_step": round(el3 / args.steps * 1e3, 4),
+                                    "what": "code matrix replicated x%d, every rank serves its own batch of %d queries, no collective: "
+                                            "N independent replicas (Nx by construction)" % (world, nq)}
+        rep.close()
+        if rank == 0:
+            rf = res["scan"]
+            result = {
+                "metric": "queries/sec, OPQ-ADC top-%d over 128-d SIFT-1B-shaped rows, row-sharded x%d" % (k, world),
+                "value": res["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "u8 codes / f32 distances", "data": "synthetic",
+                "config": {"workload": "SIFT-1B-shaped: %d synthetic 128-d rows, OPQ M=%d K=256, row-sharded over %d GPUs, ADC scan + top-%d, nq=%d "
+                                       "queries per step (the same batch on every rank)" % (args.large_rows, M, world, k, res["nq"]),
+                           "rows": args.large_rows, "rows_per_gpu": res["rows_per_gpu"], "nq_per_step": res["nq"], "k": k, "M": M,
+                           "parallelism": "row-sharded x%d, ONE ncclAllGather (RCCL, issued inside libcvtmi) of per-shard top-%d + merge on every rank" % (world, k),
+                           "n1_point_of_this_curve": "the N = 1 line's \"sift1b\".value (same rows, same queries, one GPU)"},
+                "roofline": {"bound": "hbm", "kernel": "adc_scan kernel (M=%d, %d queries per pass), rank 0's shard" % (M, rf["queries_per_pass"]),
+                             "achieved": rf["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rf["frac_of_hbm_peak"], "traffic": None,
+                             "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"], "kernel_ms": rf["kernel_ms"]},
+                "sift1b": res,
+            }
+            result.update(extra)
 
-    # ---- outside the timed region: recall@1 and the CPU baseline (rank 0, N = 1 only) ----
+    # ---- outside the timed region: recall@1, the CPU baseline and the secondary kernels (rank 0, N = 1 only) ----
     if rank == 0 and world == 1:
         d_gpu, i_gpu = out
         ns = min(args.recall_sample, nq)
@@ -283,7 +310,6 @@ def main():
             ob.build(o3=True)
             orc = ob.Oracle(o3=True)
             cs = min(args.cpu_sample, nq)
-            codes_h = np.empty((args.rows, M), dtype=np.uint8)
             _, _, codes_h = idx.get_entries()
             q_rot = orc.rotate_fma(R, q[:cs].cpu().numpy())
             t0 = time.perf_counter()
@@ -305,6 +331,7 @@ def main():
                 qs_mt = min(nq, nth * per)
                 q_rot_mt = orc.rotate_fma(R, q[:qs_mt].cpu().numpy())
                 chunks = [(a, min(qs_mt, a + per)) for a in range(0, qs_mt, per)]
+
                 def work(ab):
                     return orc.adc_search(q_rot_mt[ab[0]:ab[1]], books, codes_h, k)
                 with ThreadPoolExecutor(max_workers=nth) as ex:
@@ -313,17 +340,214 @@ def main():
                     t_mt = time.perf_counter() - t0
                 oi_mt = np.concatenate([p[1] for p in parts])
                 result["cpu_baseline_all_cores"] = {
-                    "value": round(qs_mt / t_cpu_fix(t_mt), 2), "unit": "queries/s", "cores": nth, "kind": "port",
+                    "value": round(qs_mt / max(t_mt, 1e-9), 2), "unit": "queries/s", "cores": nth, "kind": "port",
                     "sample": "%d queries in chunks of %d over %d threads, same loop as cpu_baseline" % (qs_mt, per, nth),
                     "gpu_topk_ids_identical": bool(np.array_equal(oi_mt, i_gpu[:qs_mt].cpu().numpy()))}
+        idx.close()
+        if args.secondary:
+            try:
+                result["secondary"] = secondary(args, dev, books, R)
+            except Exception as e:  # the headline line must survive a failing side measurement
+                result["secondary"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def t_cpu_fix(t):
-    return max(t, 1e-9)
+def _pmc_traffic(args, nq, k, M):
+    """HBM bytes per scan launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, of this
+    same command; tools/profile_round.sh).  Counters cannot be collected inside the timed run, so the JSON says where the
+    number comes from; null when the launch shape differs from the profiled one."""
+    default_shape = args.rows == 1_000_000 and nq == 10_000 and k == 100 and M == 16 and not args.qtile and not args.splits and args.variant < 0
+    if not default_shape:
+        return None, None
+    for tag in ("r02", "r01"):
+        p = os.path.join(ROOT, "profiles", "%s_scan_traffic.json" % tag)
+        if os.path.exists(p):
+            try:
+                d = json.load(open(p))
+                return d.get("hbm_bytes_per_launch"), "profiles/%s_scan_traffic.json: %s; kernel %s" % (
+                    tag, d.get("note", "rocprofv3 --pmc passes"), d.get("kernel", "?"))
+            except Exception:
+                pass
+    return None, None
+
+
+def _ev_ms(torch, fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()  # the library launches on torch's current stream (capi._stream), so torch events bracket its kernels
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def secondary(args, dev, books, R):
+    """The other rows of SURVEY.md 8 / BASELINE configs, one short measurement each (N = 1, outside the timed region)."""
+    import torch
+    import cvt_amd
+    from cvt_amd import synth
+    from concurrent.futures import ThreadPoolExecutor
+    sec = {}
+    D, M = 128, books.shape[0]
+    zero = np.zeros((1, D), np.float32)
+    # ---- a-R rotation (fp32 MFMA GEMM) and a-E encode, 2^20 rows ----
+    n = 1 << 20
+    ix = cvt_amd.OpqIndex(zero, books, R=R)
+    x = synth.sift_like(n, D, seed=0xC0FFEE, device=dev)
+    ms = _ev_ms(torch, lambda: ix.rotate(x))
+    tf = 2.0 * n * D * D / (ms * 1e-3) / 1e12
+    sec["rotation"] = {"rows": n, "ms": round(ms, 4), "tflops": round(tf, 1), "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TF, 4),
+                       "hbm_GBps": round(n * D * 8 / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(n * D * 8 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "what": "Y = X R^T, dense 128 x 128 fp32 R on v_mfma_f32_32x32x2_f32 (2 D^2 flop and 1 KB moved per row)"}
+    xr = ix.rotate(x)
+    ms = _ev_ms(torch, lambda: ix.encode(xr))
+    sec["encode"] = {"rows": n, "ms": round(ms, 4), "rows_per_s": round(n / (ms * 1e-3), 1), "what": "PQ encode of rotated rows, M=%d K=256 (bf16 matrix-core filter + exact chain)" % M}
+    try:
+        ms = _ev_ms(torch, lambda: ix.rotate_encode(x))
+        sec["rotate_encode_fused"] = {"rows": n, "ms": round(ms, 4), "rows_per_s": round(n / (ms * 1e-3), 1),
+                                      "what": "raw rows -> codes in one kernel (rotation in registers, no 1 KB/row round trip)"}
+    except AttributeError:
+        pass
+    ix.close(); del x, xr
+    # ---- a-Q / a-T SQ8: train + encode, 2 M x 512-d ----
+    d3 = 512
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    feats = torch.randn((1 << 21, d3), generator=g, device=dev).clamp_(min=0)  # "CNN-like": ReLU'd Gaussian
+    nb = feats.numel() * 4
+    ms_t = _ev_ms(torch, lambda: cvt_amd.sq8_train(feats, l2norm=True), reps=3, warm=1)
+    vmin, vdiff = cvt_amd.sq8_train(feats, l2norm=True)
+    ms_e = _ev_ms(torch, lambda: cvt_amd.sq8_encode(vmin, vdiff, feats.clone(), l2norm=False), reps=3, warm=1)
+    ms_c = _ev_ms(torch, lambda: feats.clone(), reps=3, warm=1)
+    ms_e = max(ms_e - ms_c, 1e-3)
+    sec["sq8"] = {"rows": 1 << 21, "d": d3,
+                  "train_l2norm_GBps": round(nb / (ms_t * 1e-3) / 1e9, 1), "train_frac_of_hbm_peak": round(nb / (ms_t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                  "encode_GBps": round(nb * 1.25 / (ms_e * 1e-3) / 1e9, 1), "encode_frac_of_hbm_peak": round(nb * 1.25 / (ms_e * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                  "what": "per-dimension min / max-min over L2-normalised rows (4d bytes per row); encode 4d in + d out per row"}
+    del feats
+    # ---- config 3: 10 M x 512-d uint8 codes (SQ8 of CNN-like features), brute-force L2 top-10 ----
+    n3, k3 = 10_000_000, 10
+    flat = cvt_amd.FlatIndex(cvt_amd.L2U8, d3)
+    chunk = 1 << 20
+    rows_h = np.empty((n3, d3), dtype=np.uint8) if args.cpu_sample > 0 else None  # host copy for the CPU baseline only
+    for a in range(0, n3, chunk):
+        b = min(n3, a + chunk)
+        g.manual_seed(1000 + a // chunk)
+        f = torch.randn((b - a, d3), generator=g, device=dev).clamp_(min=0)
+        c = cvt_amd.sq8_encode(vmin, vdiff, f, l2norm=True)
+        flat.add(c)
+        if rows_h is not None:
+            rows_h[a:b] = c.cpu().numpy()
+    g.manual_seed(77)
+    qf = torch.randn((4096, d3), generator=g, device=dev).clamp_(min=0)
+    q3 = cvt_amd.sq8_encode(vmin, vdiff, qf, l2norm=True)
+    c3 = {"rows": n3, "d": d3, "k": k3, "cases": {}}
+    outs = {}
+    for nq3 in (1, 1000, 4096):
+        qq = q3[:nq3].contiguous()
+        ms = _ev_ms(torch, lambda: flat.search(qq, k3), reps=3, warm=1)
+        outs[nq3] = flat.search(qq, k3)
+        ops = 2.0 * nq3 * n3 * d3 / (ms * 1e-3)
+        c = {"ms": round(ms, 4), "queries_per_s": round(nq3 / (ms * 1e-3), 1)}
+        if nq3 == 1:
+            gb = n3 * d3 / (ms * 1e-3) / 1e9
+            c["roofline"] = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 4)}
+        else:
+            c["roofline"] = {"bound": "mfma", "achieved": round(ops / 1e12, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s (int8, 2 per MAC)",
+                             "frac": round(ops / 1e12 / I8_MFMA_PEAK_TOPS, 4)}
+        c3["cases"]["nq=%d" % nq3] = c
+    if args.cpu_sample > 0:
+        from oracle import binding as ob
+        orc = ob.Oracle(o3=True)
+        cs = 4
+        qh = q3[:cs].cpu().numpy()
+        t0 = time.perf_counter()
+        _, od, oi = orc.flat_search(ob.L2U8, rows_h, qh, k3)
+        t_cpu = time.perf_counter() - t0
+        gd, gi = outs[1000]
+        c3["cpu_baseline"] = {"value": round(cs / t_cpu, 3), "unit": "queries/s", "cores": 1, "kind": "port",
+                              "sample": "%d queries against all %d rows (oracle L2SqrI loop, -O3, 1 thread)" % (cs, n3),
+                              "gpu_topk_ids_identical": bool(np.array_equal(oi, gi[:cs].cpu().numpy())),
+                              "gpu_distances_identical": bool(np.array_equal(np.asarray(od).astype(np.int64), gd[:cs].cpu().numpy().astype(np.int64)))}
+        del rows_h
+    flat.close()
+    sec["flat_u8_c3"] = c3
+    # ---- config 5: HNSW graph in HBM, batched 10 K queries, fp32 vectors and OPQ codes ----
+    try:
+        sec["hnsw_c5"] = _hnsw_c5(args, dev, torch, cvt_amd, synth, R)
+    except Exception as e:
+        sec["hnsw_c5"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return sec
+
+
+def _hnsw_c5(args, dev, torch, cvt_amd, synth, R):
+    n, D, nq, Mg, efc = 100_000, 128, 10_000, 32, 80
+    rng = np.random.default_rng(5)
+    cen = rng.normal(size=(1000, D)).astype(np.float32)
+    x = cen[rng.integers(0, 1000, n)] + 0.6 * rng.normal(size=(n, D)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    q = x[rng.integers(0, n, nq)] + 0.15 * rng.normal(size=(nq, D)).astype(np.float32)
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    tmpd = tempfile.mkdtemp()
+    rows_p, idx_p = os.path.join(tmpd, "rows.bin"), os.path.join(tmpd, "graph.hnsw")
+    x.astype(np.float32).tofile(rows_p)
+    t0 = time.perf_counter()
+    subprocess.run([os.path.join(ROOT, "cvt_amd", "bin", "hnsw_build"), rows_p, str(D), str(Mg), str(efc), idx_p, "ip"], check=True,
+                   capture_output=True)
+    t_build = time.perf_counter() - t0
+    blob = open(idx_p, "rb").read()
+    ix = cvt_amd.HnswIndex(blob, cvt_amd.IP, D)
+    qd = torch.from_numpy(q).to(dev)
+    exact = torch.argmax(qd @ torch.from_numpy(x).to(dev).T, dim=1)
+    res = {"nodes": n, "d": D, "M": Mg, "ef_construction": efc, "nq": nq, "graph_build_s_host": round(t_build, 1),
+           "what": "one wave per query over a graph built on the host (hnsw_build CLI = the reference's addPoint order, M=32 efC=80, makeIdx.cpp:303-304)",
+           "fp32": {}, "adc": {}}
+    for kk, ef in ((5, 1000), (10, 64)):
+        ms = _ev_ms(torch, lambda: ix.search(qd, kk, ef), reps=2, warm=1)
+        _, lab = ix.search(qd, kk, ef)
+        res["fp32"]["ef=%d" % ef] = {"ms": round(ms, 3), "queries_per_s": round(nq / (ms * 1e-3), 1), "k": kk,
+                                     "recall_at_1": round(float((lab[:, 0] == exact).float().mean().item()), 4)}
+    tmp = cvt_amd.OpqIndex(np.zeros((1, D), np.float32), np.zeros((16, 256, D // 16), np.float32), R=R)
+    xr = tmp.rotate(torch.from_numpy(x).to(dev))
+    _, books5 = cvt_amd.opq_train(xr[:50_000].contiguous(), 1, 16, 256, 8, 1)
+    opq = cvt_amd.OpqIndex(np.zeros((1, D), np.float32), books5.cpu().numpy(), R=R)
+    _, codes = opq.encode(xr)
+    opq.add_codes(codes)
+    for kk, ef in ((5, 1000), (10, 64)):
+        ms = _ev_ms(torch, lambda: ix.search_adc(opq, qd, kk, ef), reps=2, warm=1)
+        _, lab = ix.search_adc(opq, qd, kk, ef)
+        res["adc"]["ef=%d" % ef] = {"ms": round(ms, 3), "queries_per_s": round(nq / (ms * 1e-3), 1), "k": kk,
+                                    "recall_at_1": round(float((lab[:, 0] == exact).float().mean().item()), 4),
+                                    "recall_at_k": round(float((lab == exact[:, None]).any(dim=1).float().mean().item()), 4)}
+        rr = getattr(ix, "search_adc_rerank", None)
+        if rr is not None:
+            ms = _ev_ms(torch, lambda: rr(opq, qd, kk, ef), reps=2, warm=1)
+            _, lab = rr(opq, qd, kk, ef)
+            res["adc"]["ef=%d+rerank" % ef] = {"ms": round(ms, 3), "queries_per_s": round(nq / (ms * 1e-3), 1), "k": kk,
+                                               "recall_at_1": round(float((lab[:, 0] == exact).float().mean().item()), 4)}
+    if args.cpu_sample > 0:
+        from oracle import binding as ob
+        if ob.ref_available():
+            rh = ob.RefHnsw()
+            cs = 200
+            t0 = time.perf_counter(); rd, rl = rh.search(0, D, idx_p, q[:cs], 5, 1000); t_cpu = time.perf_counter() - t0
+            gd, gl = ix.search(qd[:cs].contiguous(), 5, 1000)
+            res["cpu_baseline"] = {"value": round(cs / t_cpu, 1), "unit": "queries/s", "cores": 1, "kind": "reference",
+                                   "sample": "%d of the queries, the reference's own searchKnn (oracle/_ref/libref_hnsw.so), ef=1000, same graph file" % cs,
+                                   "gpu_labels_identical": bool(np.array_equal(rl, gl.cpu().numpy())),
+                                   "gpu_distances_bit_identical": bool(np.array_equal(rd.view(np.uint32), gd.cpu().numpy().view(np.uint32)))}
+    ix.close(); opq.close(); tmp.close()
+    for p in (rows_p, idx_p):
+        if os.path.exists(p):
+            os.remove(p)
+    os.rmdir(tmpd)
+    return res
 
 
 def _cpu_model():

@@ -187,6 +187,22 @@ class OpqIndex:
                                       _ptr(d), _ptr(i)))
         return d, i
 
+    def search_sharded(self, comm, q, k, rotate=True):
+        """Row-sharded search: this handle holds the rank's row block; one all-gather + merge inside the library."""
+        nq = q.shape[0]
+        if _is_torch(q):
+            import torch
+            d = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+            i = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            _check(lib().cvtmi_opq_search_sharded_dev(self.h, comm.h, _ptr(q), C.c_int64(nq), C.c_int(1 if rotate else 0),
+                                                      C.c_int(k), _ptr(d), _ptr(i), _stream()))
+            return d, i
+        q = _np(q, np.float32)
+        d = np.empty((nq, k), dtype=np.float32); i = np.empty((nq, k), dtype=np.int64)
+        _check(lib().cvtmi_opq_search_sharded(self.h, comm.h, _ptr(q), C.c_int64(nq), C.c_int(1 if rotate else 0), C.c_int(k),
+                                              _ptr(d), _ptr(i)))
+        return d, i
+
     def query_video(self, q, nprobe, img_num, rotate=True):
         q = _np(q, np.float32)
         ms = np.empty((q.shape[0], img_num), dtype=np.float32)
@@ -201,6 +217,102 @@ class OpqIndex:
         ms = C.c_float(0); b = C.c_int64(0); qt = C.c_int(0); sp = C.c_int(0)
         _check(lib().cvtmi_opq_last_scan(self.h, C.byref(ms), C.byref(b), C.byref(qt), C.byref(sp)))
         return dict(ms=ms.value, code_bytes=b.value, qtile=qt.value, splits=sp.value)
+
+
+COMM_ID_BYTES = 128
+_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class Comm:
+    """cvtmi_comm_t: the communicator of the row-sharded search (one process per GPU).
+
+    Comm.unique_id() on rank 0 -> bytes handed to the other ranks by any means -> Comm(id, rank, world) on every
+    rank at the same time: RCCL (ncclCommInitRank inside libcvtmi).  Comm.over_torch_group(...) runs the same library
+    path over a caller-supplied all-gather (torch.distributed, staged through the host): how several ranks share
+    ONE GPU in tests, or what a gloo / MPI job would plug in."""
+
+    def __init__(self, uid, rank, world):
+        self.h = C.c_void_p(0)
+        self._cb = None
+        buf = None
+        if uid is not None:
+            assert len(uid) == COMM_ID_BYTES
+            buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(uid))
+        _check(lib().cvtmi_comm_create(buf, C.c_int(rank), C.c_int(world), C.byref(self.h)))
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * COMM_ID_BYTES)()
+        _check(lib().cvtmi_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    @classmethod
+    def custom(cls, fn, rank, world):
+        """fn(send_ptr, recv_ptr, nbytes, stream_ptr) -> 0: gather nbytes from every rank into recv (device pointers)."""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p(0)
+        self._cb = _ALLGATHER_FN(lambda ctx, s, r, nb, st: int(fn(s, r, nb, st) or 0))
+        _check(lib().cvtmi_comm_create_custom(self._cb, None, C.c_int(rank), C.c_int(world), C.byref(self.h)))
+        self.rank, self.world = rank, world
+        return self
+
+    @classmethod
+    def over_torch_group(cls, rank, world, group=None):
+        """All-gather through torch.distributed on host buffers (any backend): D2H of this rank's slot, all_gather,
+        H2D of everybody's.  The library side (slot layout, merge kernel) is the one the RCCL transport uses."""
+        import torch
+        import torch.distributed as dist
+
+        def fn(send, recv, nbytes, stream):
+            st = torch.cuda.current_stream()
+            assert (stream or 0) == st.cuda_stream, "library work was enqueued on another stream than torch's current one"
+            st.synchronize()
+            hip = C.CDLL("libamdhip64.so")
+            mine = torch.empty(nbytes, dtype=torch.uint8)
+            if hip.hipMemcpy(C.c_void_p(mine.data_ptr()), C.c_void_p(send), C.c_size_t(nbytes), C.c_int(2)) != 0:
+                return 1
+            allb = torch.empty(nbytes * world, dtype=torch.uint8)
+            dist.all_gather_into_tensor(allb, mine, group=group)
+            if hip.hipMemcpy(C.c_void_p(recv), C.c_void_p(allb.data_ptr()), C.c_size_t(nbytes * world), C.c_int(1)) != 0:
+                return 1
+            return 0
+
+        return cls.custom(fn, rank, world)
+
+    def info(self):
+        r, w, t = C.c_int(0), C.c_int(0), C.c_int(0)
+        n, b = C.c_int64(0), C.c_int64(0)
+        _check(lib().cvtmi_comm_info(self.h, C.byref(r), C.byref(w), C.byref(t), C.byref(n), C.byref(b)))
+        return {"rank": r.value, "world": w.value, "transport": ("none", "rccl", "custom")[t.value],
+                "collectives": n.value, "bytes_per_rank": b.value}
+
+    def merge_topk(self, d, i, k):
+        """The exchange step alone for per-shard lists (torch device tensors [nq][k], global ids)."""
+        import torch
+        nq = d.shape[0]
+        od = torch.empty((nq, k), dtype=torch.float32, device=d.device)
+        oi = torch.empty((nq, k), dtype=torch.int64, device=d.device)
+        _check(lib().cvtmi_shard_merge_topk_dev(self.h, _ptr(d.contiguous()), _ptr(i.contiguous()), C.c_int64(nq), C.c_int(k),
+                                                _ptr(od), _ptr(oi), _stream()))
+        return od, oi
+
+    def close(self):
+        if self.h and self.h.value:
+            lib().cvtmi_comm_destroy(self.h)
+            self.h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_range(n_total, rank, world):
+    b, e = C.c_int64(0), C.c_int64(0)
+    _check(lib().cvtmi_shard_range(C.c_int64(n_total), C.c_int(rank), C.c_int(world), C.byref(b), C.byref(e)))
+    return b.value, e.value
 
 
 def topk_merge(in_d, in_i, k):

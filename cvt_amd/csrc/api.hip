@@ -10,7 +10,9 @@
 #include <numeric>
 #include <vector>
 
+#include "host_util.h"
 #include "kernels.h"
+#include "shard.h"
 
 namespace cvtmi {
 
@@ -36,103 +38,6 @@ int fail(int code, const char *fmt, ...)
     g_err = buf;
     return code;
 }
-
-// growable device buffer
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    int reserve(size_t bytes)
-    {
-        if (bytes <= cap) return CVTMI_OK;
-        if (p) { CVTMI_HIP(hipFree(p)); p = nullptr; cap = 0; }
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) { p = nullptr; return fail(CVTMI_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
-        cap = bytes;
-        return CVTMI_OK;
-    }
-    // keeps the first `keep` bytes
-    int grow(size_t bytes, size_t keep, hipStream_t st)
-    {
-        if (bytes <= cap) return CVTMI_OK;
-        void *np = nullptr;
-        hipError_t e = hipMalloc(&np, bytes);
-        if (e != hipSuccess) return fail(CVTMI_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-        if (p && keep) {
-            CVTMI_HIP(hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, st));
-            CVTMI_HIP(hipStreamSynchronize(st));
-        }
-        if (p) CVTMI_HIP(hipFree(p));
-        p = np; cap = bytes;
-        return CVTMI_OK;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-template <class T>
-static int dev_alloc_copy(T **out, const T *host, size_t count)
-{
-    *out = nullptr;
-    if (count == 0) return CVTMI_OK;
-    CVTMI_HIP(hipMalloc((void **)out, count * sizeof(T)));
-    CVTMI_HIP(hipMemcpy(*out, host, count * sizeof(T), hipMemcpyHostToDevice));
-    return CVTMI_OK;
-}
-
-// temporary device allocation for the host-pointer entry points
-struct Tmp {
-    void *p = nullptr;
-    ~Tmp() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes)
-    {
-        if (bytes == 0) bytes = 16;
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) { p = nullptr; return fail(CVTMI_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
-        return CVTMI_OK;
-    }
-    int upload(const void *host, size_t bytes)
-    {
-        CVTMI_TRY(alloc(bytes));
-        if (bytes) CVTMI_HIP(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
-        return CVTMI_OK;
-    }
-    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-// Per-handle serialisation.  Every search borrows scratch buffers that belong to the handle (tables, partial top-k
-// lists, visited bitmaps, lazily built copies of the rows), so two calls on one handle must not overlap -- neither on the
-// host (two threads inside the library) nor on the device (two streams).  Serial holds the handle's lock for the duration
-// of the host-side call, and when a call arrives on another stream than the previous one it makes that stream wait for
-// the previous call's work (an event recorded when each outermost call returns).  Calls nest (host-pointer entries call
-// their _dev twins), hence the recursive lock and the depth count.
-struct HandleSync {
-    std::recursive_mutex mu;
-    hipEvent_t done = nullptr;
-    hipStream_t last = nullptr;
-    int depth = 0;
-    bool pending = false;
-    void destroy() { if (done) (void)hipEventDestroy(done); done = nullptr; }
-};
-
-struct Serial {
-    HandleSync &s;
-    hipStream_t st;
-    Serial(HandleSync &sync, hipStream_t stream) : s(sync), st(stream)
-    {
-        s.mu.lock();
-        if (s.depth++ == 0 && s.pending && s.last != st) (void)hipStreamWaitEvent(st, s.done, 0);
-    }
-    ~Serial()
-    {
-        if (--s.depth == 0) {
-            if (!s.done) (void)hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
-            if (s.done && hipEventRecord(s.done, st) == hipSuccess) { s.last = st; s.pending = true; }
-        }
-        s.mu.unlock();
-    }
-    Serial(const Serial &) = delete;
-    Serial &operator=(const Serial &) = delete;
-};
 
 }  // namespace cvtmi
 
@@ -234,6 +139,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         g_flat_variant = (int)value;
         return CVTMI_OK;
     }
+    if (!strcmp(name, "comm_force_rccl")) { comm_set_force_rccl(value != 0); return CVTMI_OK; }
     return fail(CVTMI_EINVAL, "cvtmi_set_tuning: unknown parameter '%s'", name);
 }
 
@@ -614,6 +520,42 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
     CVTMI_TRY(dd.alloc((size_t)nq * k * sizeof(float)));
     CVTMI_TRY(di.alloc((size_t)nq * k * sizeof(int64_t)));
     CVTMI_TRY(cvtmi_opq_search_dev(h, dq.as<float>(), nq, rotate, k, dd.as<float>(), di.as<int64_t>(), nullptr));
+    CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
+    CVTMI_HIP(hipMemcpy(ids, di.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
+// row-sharded search: the local scan writes its lists straight into this rank's slot of the communicator's gather buffer,
+// then one all-gather + merge (shard.hip)
+int cvtmi_opq_search_sharded_dev(cvtmi_opq_t h, cvtmi_comm_t c, const float *q, int64_t nq, int rotate, int k, float *dist,
+                                 int64_t *ids, void *stream)
+{
+    CHECK_H_SERIAL(h, stream);
+    if (!c) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: null communicator");
+    if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: bad arguments");
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search_sharded: k=%d outside 1..128", k);
+    if (comm_device(c) != h->device) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: handle and communicator live on different devices");
+    if (nq == 0) return CVTMI_OK;
+    if (comm_world(c) == 1 && !comm_has_transport(c)) return cvtmi_opq_search_dev(h, q, nq, rotate, k, dist, ids, stream);
+    Serial serial_c(*comm_sync(c), (hipStream_t)stream);
+    float *sd = nullptr;
+    int64_t *si = nullptr;
+    CVTMI_TRY(comm_local_slot(c, nq, k, &sd, &si));
+    CVTMI_TRY(cvtmi_opq_search_dev(h, q, nq, rotate, k, sd, si, stream));
+    return comm_exchange_merge(c, nq, k, dist, ids, (hipStream_t)stream);
+}
+
+int cvtmi_opq_search_sharded(cvtmi_opq_t h, cvtmi_comm_t c, const float *q, int64_t nq, int rotate, int k, float *dist, int64_t *ids)
+{
+    CHECK_H_SERIAL(h, nullptr);
+    if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: bad arguments");
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search_sharded: k=%d outside 1..128", k);
+    if (nq == 0) return CVTMI_OK;
+    Tmp dq, dd, di;
+    CVTMI_TRY(dq.upload(q, (size_t)nq * h->m.D * sizeof(float)));
+    CVTMI_TRY(dd.alloc((size_t)nq * k * sizeof(float)));
+    CVTMI_TRY(di.alloc((size_t)nq * k * sizeof(int64_t)));
+    CVTMI_TRY(cvtmi_opq_search_sharded_dev(h, c, dq.as<float>(), nq, rotate, k, dd.as<float>(), di.as<int64_t>(), nullptr));
     CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
     CVTMI_HIP(hipMemcpy(ids, di.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost));
     return CVTMI_OK;

@@ -58,6 +58,9 @@ int launch_topk_merge(const float *in_d, const int64_t *in_id, int64_t nq, int L
 
 int launch_topk_select(const float *in_d, const int64_t *in_id, int64_t nq, int64_t n_cand, int k, float *out_d,
                        int64_t *out_id, hipStream_t st);
+// L per-rank lists of k per query in the all-gather layout: list r of query q at in_d[r * stride_d + q * k ..] / in_id[r * stride_id + ..]
+int launch_topk_merge_gathered(const float *in_d, const int64_t *in_id, int64_t stride_d, int64_t stride_id, int64_t nq, int L, int k,
+                               float *out_d, int64_t *out_id, hipStream_t st);
 
 // ---- query_video.hip ----
 // probe[nq][nprobe] list ids in visiting order; list_off[coarseK+1]; codes/video_id in list order.

@@ -16,15 +16,24 @@ constexpr int MERGE_CAP = 1024;
 constexpr int MERGE_TRIG = 768;
 constexpr int MERGE_R = 4;
 
+// GATHERED = false: candidate i of query q sits at in_d[q * n_cand + i].
+// GATHERED = true : the all-gather layout of the row-sharded search -- list r (one per rank, k entries) of query q sits at
+//                   in_d[r * stride_d + q * k + j] / in_id[r * stride_id + q * k + j], i = r * k + j.
+template <bool GATHERED>
 __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restrict__ in_d,
                                                             const int64_t *__restrict__ in_id, int n_cand, int k,
-                                                            float *__restrict__ out_d, int64_t *__restrict__ out_id)
+                                                            float *__restrict__ out_d, int64_t *__restrict__ out_id,
+                                                            int64_t stride_d, int64_t stride_id)
 {
     __shared__ TopKShared<1, MERGE_CAP> tk;
     const int64_t q = blockIdx.x;
-    const float *d = in_d + q * n_cand;
-    const int64_t *id = in_id + q * n_cand;
     const int tid = threadIdx.x;
+    auto at = [&](int i) -> int64_t {  // element offset of candidate i inside the distance / id arrays (before the stride term)
+        if (!GATHERED) return q * n_cand + i;
+        return q * k + (i % k);
+    };
+    auto dist_of = [&](int i) -> float { return GATHERED ? in_d[(int64_t)(i / k) * stride_d + at(i)] : in_d[at(i)]; };
+    auto id_of = [&](int i) -> int64_t { return GATHERED ? in_id[(int64_t)(i / k) * stride_id + at(i)] : in_id[at(i)]; };
     topk_init(tk);
     __syncthreads();
     int tile = 0;
@@ -36,8 +45,8 @@ __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restr
             const int i = base + r * kBlock + tid;
             pay[r] = (uint32_t)i;
             key[r][0] = KEY_MAX;
-            if (i < n_cand && (in_id == nullptr || id[i] >= 0)) {
-                const uint32_t kk = f32_key(d[i]);
+            if (i < n_cand && (in_id == nullptr || id_of(i) >= 0)) {
+                const uint32_t kk = f32_key(dist_of(i));
                 key[r][0] = kk == KEY_MAX ? KEY_MAX - 1 : kk;  // keep the "not a candidate" code free
             }
         }
@@ -49,13 +58,26 @@ __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restr
     for (int i = tid; i < k; i += kBlock) {
         if (i < cnt) {
             const uint32_t p = (uint32_t)tk.buf[0][i];
-            out_d[q * k + i] = d[p];
-            out_id[q * k + i] = in_id ? id[p] : (int64_t)p;
+            out_d[q * k + i] = dist_of((int)p);
+            out_id[q * k + i] = in_id ? id_of((int)p) : (int64_t)p;
         } else {
             out_d[q * k + i] = __uint_as_float(0x7f800000u);
             out_id[q * k + i] = -1;
         }
     }
+}
+
+// merge of the all-gathered per-rank lists (shard.hip): L lists of k per query, list r at base + r * stride
+int launch_topk_merge_gathered(const float *in_d, const int64_t *in_id, int64_t stride_d, int64_t stride_id, int64_t nq, int L, int k,
+                               float *out_d, int64_t *out_id, hipStream_t st)
+{
+    if (nq <= 0) return CVTMI_OK;
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "topk: k=%d outside 1..128", k);
+    if (L < 1 || (int64_t)L * k > 0x7fffffff || nq > 0x7fffffff) return fail(CVTMI_EINVAL, "topk_merge: bad list count %d", L);
+    hipLaunchKernelGGL(topk_merge_kernel<true>, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, L * k, k, out_d, out_id, stride_d,
+                       stride_id);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
 }
 
 int launch_topk_merge(const float *in_d, const int64_t *in_id, int64_t nq, int L, int k, float *out_d, int64_t *out_id,
@@ -73,7 +95,8 @@ int launch_topk_select(const float *in_d, const int64_t *in_id, int64_t nq, int6
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "topk: k=%d outside 1..128", k);
     if (n_cand < 0 || n_cand > 0x7fffffff) return fail(CVTMI_EINVAL, "topk: bad candidate count");
     if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "topk: nq too large");
-    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, (int)n_cand, k, out_d, out_id);
+    hipLaunchKernelGGL(topk_merge_kernel<false>, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, (int)n_cand, k, out_d, out_id,
+                       (int64_t)0, (int64_t)0);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

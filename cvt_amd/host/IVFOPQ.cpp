@@ -15,7 +15,7 @@ using namespace std;
 
 void IVFOPQ::init()
 {
-    m_h = NULL; m_imgLocation = NULL;
+    m_h = NULL; m_imgLocation = NULL; m_comm = NULL; m_idBase = 0;
     m_coarseK = m_pq_m = m_pq_k = m_pq_step = m_featDim = 0;
     m_imgNum = 0; m_imgCap = 0;
 }
@@ -45,6 +45,7 @@ bool IVFOPQ::ensureHandle()
         m_h = NULL;
         return false;
     }
+    if (m_idBase) cvtmi_opq_set_id_base(m_h, m_idBase);
     return true;
 }
 
@@ -149,7 +150,29 @@ int IVFOPQ::SearchTopK(const float *q, int nq, int k, float *dist, long long *id
 {
     if (!ensureHandle()) return 0;
     static_assert(sizeof(long long) == sizeof(int64_t), "id width");
+    if (m_comm) return cvtmi_opq_search_sharded(m_h, m_comm, q, nq, /*rotate=*/1, k, dist, (int64_t *)ids) == CVTMI_OK ? 1 : 0;
     return cvtmi_opq_search(m_h, q, nq, /*rotate=*/1, k, dist, (int64_t *)ids) == CVTMI_OK ? 1 : 0;
+}
+
+void IVFOPQ::SetShard(cvtmi_comm_s *comm, long long id_base)
+{
+    m_comm = comm; m_idBase = id_base;
+    if (ensureHandle()) cvtmi_opq_set_id_base(m_h, id_base);
+}
+
+int IVFOPQ::AddRows(const float *raw, int n)
+{
+    if (n <= 0) return 1;
+    if (!ensureHandle()) return 0;
+    std::vector<float> rot((size_t)n * m_featDim);
+    std::vector<int32_t> lists(n);
+    std::vector<uint8_t> codes((size_t)n * m_pq_m);
+    if (cvtmi_opq_rotate(m_h, raw, n, rot.data()) != CVTMI_OK || cvtmi_opq_encode(m_h, rot.data(), n, lists.data(), codes.data()) != CVTMI_OK ||
+        cvtmi_opq_add_codes(m_h, codes.data(), m_coarseK > 1 ? lists.data() : NULL, NULL, n) != CVTMI_OK) {
+        printf("AddRows failed: %s\n", cvtmi_last_error());
+        return 0;
+    }
+    return 1;
 }
 
 // raw fp32 [n][D] file, n = bytes / (4 D); every row goes through the model's rotation (:441-462)

@@ -21,6 +21,7 @@ struct ImgNameStruct {
 };
 
 struct cvtmi_opq_s;
+struct cvtmi_comm_s;
 
 class IVFOPQ {
 public:
@@ -45,6 +46,12 @@ public:
     // k smallest (ADC distance, entry id) per query over every entry; needs coarseK == 1.  q is RAW (un-rotated).
     int SearchTopK(const float *q, int nq, int k, float *dist, long long *ids);
     std::string lastError() const;
+    // row-sharded operation (one process per GPU): this object holds the row block that starts at global
+    // row id_base; with a communicator set (cvtmi_comm_t, include/cvtmi.h) SearchTopK returns the GLOBAL top k on every
+    // rank -- local scan, one RCCL all-gather of the per-shard lists, merge.  comm == NULL: back to single-GPU.
+    void SetShard(cvtmi_comm_s *comm, long long id_base);
+    // rotate + encode + append n RAW rows, one entry per row (the per-vector form of IndexDatabase); 1 ok / 0 failure
+    int AddRows(const float *raw, int n);
 
 private:
     void init();
@@ -52,6 +59,8 @@ private:
     void queryImpl(const std::string &featFile, std::vector<std::vector<float> > &matchScore, int nk);
 
     cvtmi_opq_s *m_h;
+    cvtmi_comm_s *m_comm;
+    long long m_idBase;
     std::vector<float> m_coarse, m_books;
     std::vector<int> m_reorder;
     int m_coarseK, m_pq_m, m_pq_k, m_pq_step, m_featDim, m_imgNum, m_maxIndexNum, m_imgCap;

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CVTMI_VERSION 100 /* 0.1.0 */
+#define CVTMI_VERSION 200 /* 0.2.0 */
 
 typedef enum cvtmi_status {
     CVTMI_OK = 0,
@@ -49,7 +49,8 @@ typedef enum cvtmi_status {
     CVTMI_ENOMEM = -2,       /* host or device allocation failed */
     CVTMI_EHIP = -3,         /* HIP runtime error / no device */
     CVTMI_ESTATE = -4,       /* handle not in a state that allows the call */
-    CVTMI_EUNSUPPORTED = -5  /* shape outside what the kernels are built for */
+    CVTMI_EUNSUPPORTED = -5, /* shape outside what the kernels are built for */
+    CVTMI_ECOMM = -6         /* RCCL not loadable / a collective failed */
 } cvtmi_status;
 
 typedef enum cvtmi_metric {
@@ -61,6 +62,7 @@ typedef enum cvtmi_metric {
 typedef struct cvtmi_opq_s *cvtmi_opq_t;
 typedef struct cvtmi_flat_s *cvtmi_flat_t;
 typedef struct cvtmi_hnsw_s *cvtmi_hnsw_t;
+typedef struct cvtmi_comm_s *cvtmi_comm_t;
 
 /* ---------------------------------------------------------------- library / device ---------- */
 int cvtmi_version(void);
@@ -73,7 +75,9 @@ int cvtmi_set_device(int device);
  *                     resolution of undecided rows wherever it applies (32 <= d <= 128, d % 16 == 0, k >= 64)
  *   "flat_variant"    exhaustive search: 0 = choose (default: fp32 through the matrix-core filter for large batches, uint8 on
  *                     the row-tile kernels); 1 = exact / row-tile kernels only; 2 = the filter pipelines wherever they apply
- *                     (uint8 too: exact sample, i8 matrix-core threshold filter, sort -- measures like the row-tile kernels) */
+ *                     (uint8 too: exact sample, i8 matrix-core threshold filter, sort -- measures like the row-tile kernels)
+ *   "comm_force_rccl" 1 = cvtmi_comm_create goes through RCCL (ncclCommInitRank, ncclAllGather) for world == 1 too, which
+ *                     otherwise needs no transport (test hook for 1-GPU boxes) */
 int cvtmi_set_tuning(const char *name, int64_t value);
 
 /* ---------------------------------------------------------------- OPQ model + code index ---- */
@@ -166,6 +170,47 @@ int cvtmi_topk_merge(const float *in_dist, const int64_t *in_ids, int64_t nq, in
                      float *dist, int64_t *ids);
 int cvtmi_topk_merge_dev(const float *in_dist, const int64_t *in_ids, int64_t nq, int L, int k,
                          float *dist, int64_t *ids, void *stream);
+
+/* ---------------------------------------------------------------- row-sharded search --------- */
+/* The north-star multi-GPU layout: the code rows are split into contiguous blocks, one per GPU, one
+ * process per GPU; a search scans the local block, then ONE RCCL all-gather (xGMI) of the per-shard top-k lists and a
+ * k-way merge on every rank.  The reference tree's only distributed search has this shape: FLANN-MPI's
+ * mpi::Index::knnSearch (retrieval/vlindex/lib/FLANN/mpi/index.h:196-226: local knnSearch, indices += offset_,
+ * boost::mpi reduce with ResultsMerger :74-108).
+ *
+ * A communicator spans `world` ranks, this process being `rank` on the HIP device current at creation:
+ *   cvtmi_comm_unique_id   rank 0 draws the job's id (ncclGetUniqueId) and hands its CVTMI_COMM_ID_BYTES bytes to the
+ *                          other ranks by any means (env, file, MPI, torch.distributed ...);
+ *   cvtmi_comm_create      every rank calls it at the same time (ncclCommInitRank).  world == 1 needs no id and no RCCL;
+ *   cvtmi_comm_create_custom  the same exchange over a caller-supplied all-gather instead of RCCL (an MPI job like the
+ *                          reference's, or several ranks sharing one GPU in tests): fn must gather `bytes` bytes from
+ *                          every rank into recv_dev in rank order, IN PLACE (send_dev == recv_dev + rank * bytes), ordered
+ *                          after the work already enqueued on `stream` and complete, or enqueued on `stream`, on return;
+ *                          0 = success.  All pointers are device pointers.
+ * Collectives must be entered by all ranks in the same order; a rank whose local search fails leaves the others waiting
+ * (as with any collective).  Calls on one communicator are serialised like calls on one handle. */
+#define CVTMI_COMM_ID_BYTES 128
+typedef int (*cvtmi_allgather_fn)(void *ctx, const void *send_dev, void *recv_dev, size_t bytes, void *stream);
+int cvtmi_comm_unique_id(void *id /* [CVTMI_COMM_ID_BYTES] */);
+int cvtmi_comm_create(const void *id, int rank, int world, cvtmi_comm_t *out);
+int cvtmi_comm_create_custom(cvtmi_allgather_fn fn, void *ctx, int rank, int world, cvtmi_comm_t *out);
+int cvtmi_comm_destroy(cvtmi_comm_t c);
+/* rank / world; transport: 0 none (world == 1), 1 RCCL, 2 caller-supplied; all-gathers issued so far and the bytes
+ * each rank contributed to the last one.  Any pointer may be NULL. */
+int cvtmi_comm_info(cvtmi_comm_t c, int *rank, int *world, int *transport, int64_t *collectives, int64_t *bytes_per_rank);
+/* Row block of `rank`: [begin, end) of n_total rows, the first n_total % world ranks own one row more. */
+int cvtmi_shard_range(int64_t n_total, int rank, int world, int64_t *begin, int64_t *end);
+/* cvtmi_opq_search on a row shard: `h` holds this rank's block of rows (cvtmi_opq_set_id_base = its first row), every
+ * rank passes the same queries; dist / ids [nq][k] = the global result, identical on every rank and identical to a
+ * single handle holding all rows. */
+int cvtmi_opq_search_sharded(cvtmi_opq_t h, cvtmi_comm_t c, const float *q, int64_t nq, int rotate, int k, float *dist,
+                             int64_t *ids);
+int cvtmi_opq_search_sharded_dev(cvtmi_opq_t h, cvtmi_comm_t c, const float *q, int64_t nq, int rotate, int k,
+                                 float *dist, int64_t *ids, void *stream);
+/* The exchange step alone, for per-shard lists produced by any search: local_dist / local_ids [nq][k] ascending
+ * (distance, id) with GLOBAL ids (id < 0 = padding), ranks holding ascending id ranges. */
+int cvtmi_shard_merge_topk_dev(cvtmi_comm_t c, const float *local_dist, const int64_t *local_ids, int64_t nq, int k,
+                               float *dist, int64_t *ids, void *stream);
 
 /* get_sort_results (opq/src/common.h:25-37): the k smallest (score, index) pairs of scores[nq][n],
  * ascending; rows short of k entries are padded with (+inf, -1).  k <= 128. */

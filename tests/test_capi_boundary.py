@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 40
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.cvtmi_version() == 100
+    assert lib.cvtmi_version() == 200
 
 
 def test_no_oracle_in_product():

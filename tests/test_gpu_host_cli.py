@@ -183,3 +183,39 @@ def test_hnsw_build_then_search_cli(tmp_path, golden):
     run([os.path.join(BIN, "hnsw_search"), "built.hnsw", "q.bin", str(D), str(k), str(ef), "out.txt", "ip"], cwd=str(tmp_path))
     for qi, line in enumerate((tmp_path / "out.txt").read_text().splitlines()):
         assert [int(p.split(":")[0]) for p in line.split()] == list(g[case + "_l"][qi])
+
+
+@pytest.mark.parametrize("gpus,transport", [(1, "rccl"), (2, "shm"), (3, "shm")])
+def test_opq_search_cli_row_sharded(tmp_path, orc, gpus, transport):
+    """opq_search --gpus N: one process per rank (forked by the CLI), each indexes its row block of the feature file, one
+    all-gather inside libcvtmi, rank 0 writes the global top-k.  N = 1 goes through real RCCL; N > 1 on this one-GPU box
+    through the shm transport (RCCL refuses two ranks per device).  Expected = the oracle over the whole file."""
+    from oracle import binding as ob
+    exe = os.path.join(BIN, "opq_search")
+    assert os.path.exists(exe), "host CLIs not built: __graft_entry__.build()"
+    rng = np.random.default_rng(5 + gpus)
+    D, M, K, n, nq, k = 128, 16, 256, 30_001, 21, 20
+    perm = rng.permutation(D).astype(np.int32)
+    books = (rng.normal(size=(M, K, D // M)) * 0.05).astype(np.float32)
+    coarse = np.zeros((1, D), np.float32)
+    x = (rng.normal(size=(n, D)) * 0.1).astype(np.float32)
+    x[n // 2 - 3:n // 2 + 3] = x[n // 2]  # duplicates across the shard boundary
+    x[n // 3 - 2:n // 3 + 2] = x[n // 3]
+    q = (rng.normal(size=(nq, D)) * 0.1).astype(np.float32)
+    q[0] = x[n // 2]
+    model = str(tmp_path / "model.bin")
+    ob.write_opq_model(model, coarse, books, perm)
+    x.tofile(tmp_path / "db.bin"); q.tofile(tmp_path / "q.bin")
+    out = run([exe, model, "db.bin", "q.bin", "res.txt", "--k", str(k), "--gpus", str(gpus), "--transport", transport], cwd=str(tmp_path))
+    assert ("transport %s" % transport) in out and ("all-gathers 1 x" in out), out
+    xr, qr = orc.reorder(perm, x), orc.reorder(perm, q)
+    _, codes = orc.pq_encode(xr, coarse, books)
+    od, oi = orc.adc_search(qr, books, codes, k)
+    lines = (tmp_path / "res.txt").read_text().splitlines()
+    assert len(lines) == nq
+    for qi, line in enumerate(lines):
+        head, rest = line.split(" topK: ")
+        ids_s, d_s = rest.split(" dists: ")
+        assert int(head) == qi
+        assert [int(v) for v in ids_s.split()] == oi[qi].tolist()
+        assert np.array_equal(bits(np.array([float(v) for v in d_s.split()], dtype=np.float32)), bits(od[qi]))

@@ -1,0 +1,141 @@
+"""GPU: the row-sharded search INSIDE the library (cvtmi_comm_*, cvtmi_opq_search_sharded*, csrc/shard.hip).
+
+* world 1 through real RCCL ("comm_force_rccl"): ncclGetUniqueId / ncclCommInitRank / ncclAllGather are bound and run.
+* world 2 and 3 as separate processes sharing this box's one GPU: RCCL refuses two ranks on one device, so the ranks
+  exchange through the caller-supplied transport (gloo, staged through the host) -- the slot layout, the zero-copy
+  local search into the slot and topk_merge_kernel<true> are exactly what the RCCL transport feeds.
+Results must equal a single handle holding every row, and the oracle, bit for bit (ids and distance bits)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _case(seed, n, nq, D=128, M=16, K=256, dup=0):
+    rng = np.random.default_rng(seed)
+    books = (rng.normal(size=(M, K, D // M)) * 0.1).astype(np.float32)
+    codes = rng.integers(0, K, size=(n, M), dtype=np.uint8)
+    if dup and n > 4:  # exact duplicates on both sides of every shard boundary: ties across ranks
+        for w in (2, 3):
+            for r in range(1, w):
+                b = (n // w) * r + min(r, n % w)
+                lo, hi = max(0, b - dup), min(n, b + dup)
+                codes[lo:hi] = codes[lo]
+    q = rng.normal(size=(nq, D)).astype(np.float32) * 0.1
+    return books, codes, q
+
+
+def test_world1_through_rccl(orc):
+    import torch
+    import cvt_amd
+    cvt_amd.set_tuning("comm_force_rccl", 1)
+    try:
+        comm = cvt_amd.Comm(cvt_amd.Comm.unique_id(), 0, 1)
+    finally:
+        cvt_amd.set_tuning("comm_force_rccl", 0)
+    assert comm.info()["transport"] == "rccl"
+    books, codes, q = _case(1, 50_000, 37, dup=3)
+    idx = cvt_amd.OpqIndex(np.zeros((1, 128), np.float32), books)
+    idx.add_codes(torch.from_numpy(codes).cuda())
+    qd = torch.from_numpy(q).cuda()
+    for k in (1, 10, 100):
+        d0, i0 = idx.search(qd, k, rotate=False)
+        d1, i1 = idx.search_sharded(comm, qd, k, rotate=False)
+        torch.cuda.synchronize()
+        assert torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32))
+    inf = comm.info()
+    assert inf["collectives"] == 3, inf  # ONE all-gather per search
+    assert inf["bytes_per_rank"] == ((37 * 100 * 4 + 15) // 16 * 16) + ((37 * 100 * 8 + 15) // 16 * 16)
+    od, oi = orc.adc_search(q, books, codes, 100)
+    assert np.array_equal(oi, i1.cpu().numpy()) and np.array_equal(bits(od), bits(d1.cpu().numpy()))
+    # the host-pointer entry and the exchange step alone
+    d2, i2 = idx.search_sharded(comm, q, 100, rotate=False)
+    assert np.array_equal(i2, oi) and np.array_equal(bits(d2), bits(od))
+    d3, i3 = comm.merge_topk(d1, i1, 100)
+    assert torch.equal(i3, i1)
+    comm.close(); idx.close()
+
+
+WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["CVT_ROOT"])
+import cvt_amd
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+z = np.load(os.environ["CVT_CASE"])
+books, codes, q, ks = z["books"], z["codes"], z["q"], [int(v) for v in z["ks"]]
+n = codes.shape[0]
+a, b = cvt_amd.shard_range(n, rank, world)
+comm = cvt_amd.Comm.over_torch_group(rank, world)
+idx = cvt_amd.OpqIndex(np.zeros((1, books.shape[0] * books.shape[2]), np.float32), books)
+if b > a:
+    idx.add_codes(torch.from_numpy(codes[a:b]).cuda())
+idx.set_id_base(a)
+qd = torch.from_numpy(q).cuda()
+out = {}
+for k in ks:
+    d, i = idx.search_sharded(comm, qd, k, rotate=False)
+    torch.cuda.synchronize()
+    out["d%d" % k] = d.cpu().numpy(); out["i%d" % k] = i.cpu().numpy()
+inf = comm.info()
+assert inf["transport"] == "custom" and inf["collectives"] == len(ks), inf
+np.savez(os.environ["CVT_OUT"] + ".%d.npz" % rank, **out)
+comm.close(); idx.close()
+dist.destroy_process_group()
+"""
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,n,nq", [(2, 200_000, 64), (3, 100_001, 33), (3, 2, 5), (2, 300, 9)])
+def test_multi_rank_one_gpu_matches_single_handle(world, n, nq, tmp_path, orc):
+    import torch
+    import cvt_amd
+    books, codes, q = _case(100 + world + n, n, nq, dup=2)
+    ks = [1, 10, 100]
+    case = str(tmp_path / "case.npz")
+    np.savez(case, books=books, codes=codes, q=q, ks=np.array(ks))
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   CVT_ROOT=ROOT, CVT_CASE=case, CVT_OUT=str(tmp_path / "out"))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for pp in procs:
+                pp.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    one = cvt_amd.OpqIndex(np.zeros((1, 128), np.float32), books)
+    one.add_codes(torch.from_numpy(codes).cuda())
+    for k in ks:
+        d0, i0 = one.search(torch.from_numpy(q).cuda(), k, rotate=False)
+        d0, i0 = d0.cpu().numpy(), i0.cpu().numpy()
+        od, oi = orc.adc_search(q, books, codes, k)
+        kk = min(k, n)
+        assert np.array_equal(oi[:, :kk], i0[:, :kk]) and np.array_equal(bits(od[:, :kk]), bits(d0[:, :kk]))
+        for r in range(world):
+            z = np.load(str(tmp_path / "out") + ".%d.npz" % r)
+            assert np.array_equal(z["i%d" % k], i0), (world, n, k, r)
+            assert np.array_equal(bits(z["d%d" % k]), bits(d0)), (world, n, k, r)
+    one.close()
