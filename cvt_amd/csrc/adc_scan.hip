@@ -45,6 +45,8 @@ struct ScanArgs {
     int64_t *part_id;
     const float *lut_g;  // [nq][M][256] fp32 tables in HBM, +inf past K (adc_scan16q only)
     const uint8_t *codes_rot;  // adc_scan16q: copy of the code rows with row r rotated left by r & 15 bytes (or null)
+    uint32_t *gthr;            // adc_scan16q: [nq] filter thresholds (table units) shared by the row splits of a query, or null
+    int lazy;                  // adc_scan16q: 1 = intermediate compactions select on the integer lower bounds (exact sums only at the end)
 };
 
 template <int M> struct CodeRow;
@@ -531,6 +533,7 @@ struct QuantParams {
     float inv_scale[SQ_QT];
     double scale_eff[SQ_QT];  // 1 / inv_scale, the scale the integers are really in
     double bias[SQ_QT];       // sum_m mn[m]
+    uint32_t slack[SQ_QT];    // lazy selection: a row whose integer sum is >= (k-th smallest integer sum) + slack is out (0 = not usable)
 };
 
 struct QuantThr {
@@ -624,6 +627,84 @@ __device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, (cvt_s2)(__builtin_bit_cast(cvt_s2, a) - __builtin_bit_cast(cvt_s2, b)));
 }
 
+// ---- lazy selection (intermediate compactions of adc_scan16q) -----------------------------------------------------------
+// The integer sum S of a row is a two-sided bound of its real table sum D in table units u = (D - bias) / scale_eff:
+//     S <= u < S + 32.01        (each entry: qv = max(0, floor(f) - 1), f = fl((v - mn) * inv) within 2^-22 of (v - mn) / scale_eff)
+// and the reference's fp32 sum d_ref is within 15 rounding steps (9e-7 relative) of D.  Let S_k be the k-th smallest S seen
+// so far.  A row with S >= S_k + slack, slack = 34 + ceil(4e-6 * (32767 + bias / scale_eff)), has
+//     D >= bias + scale (S_k + slack)  >  (bias + scale (S_k + 32.01)) (1 + 2e-6)  >  D_i (1 + 2e-6)   for each of the k rows i with S_i <= S_k,
+// hence d_ref > d_ref,i for k rows: it is not among the k smallest (distance, id) pairs, ties included.  So between checkpoints
+// the buffer only needs the integer keys: keep every entry with S < T = S_k + slack (k plus the few rows within `slack` units
+// of the k-th), push under the same T, and compute exact reference-order sums ONCE, in the final compaction (entries keep
+// exact_n = 0, so the final pass re-sums all of them).  The two dependent memory round trips of the exact re-sum leave every
+// intermediate compaction.  If the band [S_k, S_k + slack) is crowded (more than `keep_max` entries stay), the query switches to
+// the exact-key protocol for the rest of the scan: its entries are re-summed now and from then on it is compacted by
+// topk_compact_wave_q.  Queries whose tables hold non-finite entries never start lazy (slack = 0): S is no upper bound there.
+template <int QT, int CAP, class FixB, class ThrX>
+__device__ __attribute__((noinline)) int scan_compact_lazy_q(TopKShared<QT, CAP> &s, int q, int k, const FixB &fixb, const ThrX &thrx,
+                                                            uint32_t slack, int keep_max, int *lazy_flag)
+{
+    static_assert(CAP <= 256, "register selection holds 256 entries per wave");
+    constexpr int NR = CAP <= 64 ? 1 : (CAP <= 128 ? 2 : 4);
+    const int lane = threadIdx.x & 63;
+    unsigned long long *b = s.buf[q];
+    int n = s.cnt[q];
+    n = n < CAP ? n : CAP;
+    unsigned long long e[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int p = r * 64 + lane;
+        e[r] = p < n ? b[p] : ~0ull;
+    }
+    if (n < k) {  // fewer than k rows seen: everything stays where it is, every sum passes
+        if (lane == 0) { s.exact_n[q] = 0; s.thr[q] = KEY_MAX; s.thr_x[q] = 32767u; }
+        return n;
+    }
+    const unsigned long long kth = wave_select<NR>(e, k);
+    const uint32_t T = (uint32_t)(kth >> 32) + slack;
+    int total = 0;
+    unsigned long long in_m[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        in_m[r] = __ballot((uint32_t)(e[r] >> 32) < T);  // empty slots carry 0xffffffff: never in
+        total += __popcll(in_m[r]);
+    }
+    if (total <= keep_max) {  // wave-uniform
+        int base = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const bool in = (in_m[r] >> lane) & 1ull;
+            const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(in_m[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)in_m[r], 0u));
+            if (in) b[pos] = e[r];
+            base += __popcll(in_m[r]);
+        }
+        if (lane == 0) { s.exact_n[q] = 0; s.thr[q] = KEY_MAX; s.thr_x[q] = T < 32767u ? T : 32767u; }
+        return total;
+    }
+    // crowded band: this query leaves the lazy protocol -- exact keys for everything it holds, then the ordinary selection
+    bool need[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) need[r] = r * 64 + lane < n;
+    fixb(q, e, need);
+    const unsigned long long kx = wave_select<NR>(e, k);
+    int base = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const bool in = e[r] <= kx;
+        const unsigned long long m = __ballot(in);
+        const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (in && pos < k) b[pos] = e[r];
+        base += __popcll(m);
+    }
+    if (lane == 0) {
+        *lazy_flag = 0;
+        s.exact_n[q] = k;
+        s.thr[q] = (uint32_t)(kx >> 32);
+        s.thr_x[q] = thrx(q, (uint32_t)(kx >> 32));
+    }
+    return k;
+}
+
 template <int NT, int R, bool PREROT>
 __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArgs a)
 {
@@ -631,7 +712,7 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
     __shared__ __attribute__((aligned(16))) uint32_t lut[256 * 16 * QT / 2];  // u16 [code j][m][q]: 16 B per (j, m)
     __shared__ TopKShared<QT, SQ_CAP> tk;
     __shared__ QuantParams qp;
-    __shared__ struct { int stop, done_waves; uint32_t next_chunk; uint32_t thr_pk[QT / 2]; } ck;
+    __shared__ struct { int stop, done_waves; uint32_t next_chunk; uint32_t thr_pk[QT / 2]; int lazy[QT]; int nonfinite[QT]; } ck;
 
     SQ_T0();
     int group, split, my_splits = a.splits;
@@ -661,6 +742,7 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
         qp.mn_bits[tid >> 4][tid & 15] = 0x7f7fffffu;  // FLT_MAX
         mx_bits[tid >> 4][tid & 15] = 0u;
     }
+    if (tid < QT) ck.nonfinite[tid] = 0;
     __syncthreads();
     // fp32 table entries of (m, j) for the QT queries, from the per-query tables a.lut_g
     // (lut_kernel: IVFOPQ.cpp:279-291); lanes walk consecutive j -> coalesced
@@ -685,6 +767,7 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
             const uint32_t bits = __float_as_uint(acc[q]);
             uint32_t lo = bits < 0x7f800000u ? bits : 0x7f7fffffu;  // non-finite: ignored
             uint32_t hi = bits < 0x7f800000u ? bits : 0u;
+            if (__ballot(bits >= 0x7f800000u) != 0 && lane == 0) ck.nonfinite[q] = 1;  // (the +inf padding past K counts: a code >= K reaches it)
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) {
                 const uint32_t l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
@@ -716,6 +799,11 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
         qp.inv_scale[q] = inv;
         qp.scale_eff[q] = 1.0 / (double)inv;
         qp.bias[q] = bias;
+        // lazy selection (scan_compact_lazy_q): usable when every table entry is finite and the band stays narrow
+        const double sl = 34.0 + ceil(4e-6 * (32767.0 + bias * (double)inv));
+        const bool lazy_ok = a.lazy && !ck.nonfinite[q] && sl < 1024.0 && bias >= 0.0;
+        qp.slack[q] = lazy_ok ? (uint32_t)sl : 0u;
+        ck.lazy[q] = lazy_ok ? 1 : 0;
     }
     __syncthreads();
     // pass B: quantise  qv = max(0, floor((v - min_m) * inv) - 1), non-finite entries -> 0 (a lower bound of anything)
@@ -744,8 +832,21 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
     const uint4 *rows = reinterpret_cast<const uint4 *>(a.codes);
     const ExactFromLutBatch fixb{ rows, a.lut_g, a.K, a.nq, group };
     const QuantThr thrx{ &qp };
-    if (tid < QT) tk.thr_x[tid] = 32767u;  // pass-all until k exact distances are known
-    if (tid < QT / 2) ck.thr_pk[tid] = 0x7fff7fffu;
+    if (tid < QT / 2) {  // pass-all until k rows are known -- or what the other row splits of these queries have already established
+        uint32_t t2[2] = { 32767u, 32767u };
+        if (a.gthr) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int qi = group * QT + 2 * tid + h;
+                if (qi < a.nq) {  // a stale value is an older, looser, still valid bound
+                    const uint32_t g = __hip_atomic_load(&a.gthr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    t2[h] = g < t2[h] ? g : t2[h];
+                }
+            }
+        }
+        tk.thr_x[2 * tid] = t2[0]; tk.thr_x[2 * tid + 1] = t2[1];
+        ck.thr_pk[tid] = t2[0] | (t2[1] << 16);
+    }
     if (tid == 0) { ck.stop = 0; ck.done_waves = 0; ck.next_chunk = 0; }
     __syncthreads();
 
@@ -881,7 +982,26 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
         for (int q = 0; q < QT; ++q) need |= tk.cnt[q] >= SQ_TRIG;
         const bool all_done = ck.done_waves == NW;
         if (need) {  // workgroup-uniform
-            topk_compact_wave<QT, SQ_CAP, NT, false>(tk, a.k, fixb, thrx);
+            {
+                const int wv = tid >> 6;
+                const int keep_max = a.k + 48 < SQ_TRIG - 24 ? a.k + 48 : SQ_TRIG - 24;
+                for (int q = wv; q < QT; q += NW) {  // wave-uniform: one wave per query, in registers
+                    const int keep = ck.lazy[q] ? scan_compact_lazy_q<QT, SQ_CAP>(tk, q, a.k, fixb, thrx, qp.slack[q], keep_max, &ck.lazy[q])
+                                                : topk_compact_wave_q<QT, SQ_CAP, false>(tk, q, a.k, fixb, thrx);
+                    if (lane == 0) {
+                        tk.cnt[q] = keep;
+                        if (a.gthr) {  // the row splits of a query tighten each other's filter (same tables -> same units)
+                            const int qi = group * QT + q;
+                            if (qi < a.nq) {
+                                const uint32_t mine = tk.thr_x[q];
+                                const uint32_t seen = atomicMin(&a.gthr[qi], mine);
+                                tk.thr_x[q] = seen < mine ? seen : mine;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
             if (tid < QT / 2) ck.thr_pk[tid] = tk.thr_x[2 * tid] | (tk.thr_x[2 * tid + 1] << 16);
             if (tid == 0) ck.stop = 0;
         }
@@ -1061,7 +1181,7 @@ int launch_rotate_codes(const uint8_t *codes, uint8_t *codes_rot, int64_t row0, 
 
 int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, int64_t id_base, const float *q_rot,
                     int64_t nq, int k, const ScanPlan &plan, float *part_d, int64_t *part_id, float *lut_scratch,
-                    const uint8_t *codes_rot, hipStream_t st)
+                    const uint8_t *codes_rot, hipStream_t st, uint32_t *gthr, int lazy)
 {
     if (nq <= 0) return CVTMI_OK;
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "adc_scan: k=%d outside 1..128", k);
@@ -1085,6 +1205,7 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
     a.rows_per_split = rps;
     a.groups_a = a.groups; a.splits_b = 0; a.stride = plan.splits; a.rows_per_split_b = rps;
     a.part_d = part_d; a.part_id = part_id; a.lut_g = lut_scratch; a.codes_rot = codes_rot;
+    a.gthr = nullptr; a.lazy = lazy;
     if (plan.variant >= 3 && m.M == 16 && plan.qtile == 8) {
         if (!lut_scratch) return fail(CVTMI_EINVAL, "adc_scan16q: table scratch missing");
         CVTMI_TRY(launch_lut(m, q_rot, nq, nullptr, lut_scratch, st, 256));  // [nq][16][256] fp32 (+inf past K), once per query
@@ -1097,6 +1218,10 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
             blocks = (int64_t)a.groups_a * a.splits + (int64_t)(a.groups - a.groups_a) * a.splits_b;
         }
         if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "adc_scan: grid too large (%lld)", (long long)blocks);
+        if (gthr && a.stride > 1) {  // the row splits of a query share their filter threshold
+            CVTMI_HIP(hipMemsetAsync(gthr, 0xff, (size_t)nq * sizeof(uint32_t), st));
+            a.gthr = gthr;
+        }
         if (codes_rot) {
             if (plan.variant == 3) hipLaunchKernelGGL((adc_scan16q_kernel<1024, 1, true>), dim3((unsigned)blocks), dim3(1024), 0, st, a);
             else hipLaunchKernelGGL((adc_scan16q_kernel<512, 2, true>), dim3((unsigned)blocks), dim3(512), 0, st, a);

@@ -64,12 +64,13 @@ struct cvtmi_opq_s {
     std::vector<int32_t> h_csr_video;
     std::vector<uint8_t> h_csr_codes;
     // scratch
-    DevBuf s_qrot, s_part_d, s_part_id, s_probe, s_lut;
+    DevBuf s_qrot, s_part_d, s_part_id, s_probe, s_lut, s_gthr;
     // tuning / measurement
     int p_splits = 0, p_qtile = 0, p_profile = 0, p_variant = 3;
     int p_encode = 0;  // 0 = choose, 1 = VALU encode, 2 = matrix-core filter + exact resolution
     int p_prerot = 1;  // adc_scan16q reads a pre-rotated copy of the code rows (+16 bytes of HBM per row)
     int p_tail = 1, p_groups_a = 0, p_splits_b = 0;  // two-region scan plan: on / forced shape (tests)
+    int p_lazy = 1, p_share = 1;  // adc_scan16q: lazy selection between checkpoints; row splits share their thresholds
     static constexpr int kEvRing = 64;
     hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
     int ev_count = 0;  // scan launches recorded since the last cvtmi_opq_last_scan
@@ -190,7 +191,7 @@ int cvtmi_opq_destroy(cvtmi_opq_t h)
     if (h->d_perm) (void)hipFree(h->d_perm);
     h->codes.release(); h->lists.release(); h->videos.release(); h->codes_rot.release();
     h->csr_codes.release(); h->csr_videos.release(); h->csr_off.release();
-    h->s_qrot.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_probe.release(); h->s_lut.release();
+    h->s_qrot.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_probe.release(); h->s_lut.release(); h->s_gthr.release();
     for (int e = 0; e < cvtmi_opq_s::kEvRing; ++e) {
         if (h->ev0[e]) (void)hipEventDestroy(h->ev0[e]);
         if (h->ev1[e]) (void)hipEventDestroy(h->ev1[e]);
@@ -454,6 +455,8 @@ int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, 
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: k=%d outside 1..128", k);
     if (nq == 0) return CVTMI_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (h->n == 0)  // an empty index (e.g. a rank whose row block is empty): all padding, (+inf, -1)
+        return launch_topk_select(nullptr, nullptr, nq, 0, k, dist, ids, st);
     const float *q_rot = q;
     if (rotate && (h->m.perm || h->m.R)) {
         CVTMI_TRY(h->s_qrot.reserve((size_t)nq * h->m.D * sizeof(float)));
@@ -496,8 +499,13 @@ int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, 
         h->rot_n = h->n;
         codes_rot = h->codes_rot.as<uint8_t>();
     }
+    uint32_t *gthr = nullptr;
+    if (plan.variant >= 3 && plan.stride() > 1 && h->p_share) {
+        CVTMI_TRY(h->s_gthr.reserve((size_t)nq * sizeof(uint32_t)));
+        gthr = h->s_gthr.as<uint32_t>();
+    }
     CVTMI_TRY(launch_adc_scan(h->m, h->codes.as<uint8_t>(), h->n, h->id_base, q_rot, nq, k, plan, pd, pi, lut_scratch,
-                              codes_rot, st));
+                              codes_rot, st, gthr, h->p_lazy));
     if (h->p_profile) {
         CVTMI_HIP(hipEventRecord(h->ev1[slot], st));
         h->ev_count++;
@@ -605,6 +613,8 @@ int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value)
         return CVTMI_OK;
     }
     if (!strcmp(name, "profile")) { h->p_profile = value != 0; return CVTMI_OK; }
+    if (!strcmp(name, "scan_lazy")) { h->p_lazy = value != 0; return CVTMI_OK; }
+    if (!strcmp(name, "scan_share")) { h->p_share = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "encode_variant")) {
         if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: encode_variant must be 0, 1 or 2");
         h->p_encode = (int)value;

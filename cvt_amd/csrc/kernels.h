@@ -45,9 +45,11 @@ ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int 
                    int want_variant);
 // part_d / part_id: [nq][plan.stride()][k]
 // lut_scratch: nq * M * K floats, needed when plan.variant >= 3 (see scan_lut_floats)
+// gthr: nq words of scratch (adc_scan16q with more than one row split: shared filter thresholds) or null;
+// lazy: adc_scan16q selects on its integer lower bounds between checkpoints and re-sums exactly once, at the end
 int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, int64_t id_base, const float *q_rot,
                     int64_t nq, int k, const ScanPlan &plan, float *part_d, int64_t *part_id, float *lut_scratch,
-                    const uint8_t *codes_rot, hipStream_t st);
+                    const uint8_t *codes_rot, hipStream_t st, uint32_t *gthr = nullptr, int lazy = 1);
 // M = 16 only: codes_rot rows [row0, n) = the code rows rotated left by (row & 15) bytes, the layout adc_scan16q
 // (plan.variant >= 3) streams when codes_rot is given
 int launch_rotate_codes(const uint8_t *codes, uint8_t *codes_rot, int64_t row0, int64_t n, hipStream_t st);

@@ -153,6 +153,9 @@ int cvtmi_opq_query_video(cvtmi_opq_t h, const float *q, int64_t nq, int rotate,
  *                 per row, 12 VALU instructions fewer per row in the VALU-bound scan loop; 0 = rotate in registers
  *   "tail_split"  1 (default) = with automatic splits, the query groups of the last, partly filled round of
  *                 workgroups may be split finer than the others (variants 3 / 4); 0 = one split count for all
+ *   "scan_lazy"   1 (default) = variants 3 / 4 select on their integer lower bounds between checkpoints and compute exact
+ *                 reference-order sums once, for the rows still held at the end; 0 = exact sums at every checkpoint
+ *   "scan_share"  1 (default) = the row splits of a query publish their filter thresholds to each other (variants 3 / 4)
  *   "groups_a", "splits_b"  force that two-region shape: the first groups_a query groups use "splits" row
  *                 splits, the others splits_b (> splits); 0 = planner's choice */
 int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value);

@@ -379,3 +379,53 @@ def test_scan_row_offsets_beyond_2pow28(amd, orc):
         dmin = np.float32(dmin + lut0[m_, best[m_]])
     assert np.all(bits(d[0, :4]) == bits(np.array([dmin], np.float32))[0])
     assert np.all(d[:, 1:] >= d[:, :-1]) and i.min() >= 0 and i.max() < n
+
+
+def test_scan_lazy_selection_and_shared_thresholds(amd, orc):
+    """adc_scan16q between checkpoints: selection on the integer lower bounds (exact sums once, at the end) and row splits
+    that publish their thresholds to each other.  Same answers with either switch on or off, on the cases that stress them:
+    a crowded band around the k-th row (masses of equal / near-equal rows: the query must fall back to exact keys),
+    tables with non-finite entries (K < 256: the +inf padding a stray code reaches; lazy must not start), large common
+    offsets (bias >> range: the slack grows with bias / scale) and many row splits."""
+    D, M, K = 128, 16, 256
+    rng = np.random.default_rng(77)
+    books = synth_model(rng, D, M, K, scale=0.1)
+    n = 60_000
+    codes = rng.integers(0, K, size=(n, M), dtype=np.uint8)
+    near = codes[123].copy()
+    crowd = np.tile(near, (4000, 1))                      # 4000 rows that differ from one another in one byte only
+    crowd[:, 5] = rng.integers(0, K, size=4000)
+    crowd[:700] = near                                    # ... 700 of them exact duplicates
+    codes[20_000:24_000] = crowd
+    q = (rng.normal(size=(19, D)) * 0.1).astype(np.float32)
+    # query 0 sits on the crowd's codewords: the k-th best is deep inside the duplicates
+    q[0] = np.concatenate([books[m, near[m]] for m in range(M)])
+    shifted = books + 3.0                                 # every table entry ~ 8 * 9 = 72 with a tiny spread: bias / scale is large
+    for bk, tag in ((books, "plain"), (shifted.astype(np.float32), "shifted")):
+        idx = amd.OpqIndex(np.zeros((1, D), np.float32), bk)
+        idx.add_codes(codes)
+        for k in (1, 100, 128):
+            od, oi = orc.adc_search(q, bk, codes, k)
+            for variant in (3, 4):
+                for lazy, share, splits in ((1, 1, 0), (1, 1, 1), (1, 1, 3), (1, 0, 3), (0, 1, 3), (0, 0, 1), (1, 1, 16)):
+                    idx.set_param("scan_variant", variant); idx.set_param("scan_lazy", lazy); idx.set_param("scan_share", share)
+                    idx.set_param("splits", splits)
+                    d, i = idx.search(q, k, rotate=False)
+                    assert np.array_equal(i, oi), (tag, k, variant, lazy, share, splits)
+                    assert np.array_equal(bits(d), bits(od)), (tag, k, variant, lazy, share, splits)
+        idx.close()
+    # non-finite tables: K = 200 (codes >= 200 read the +inf padding) and a NaN / inf query
+    K2 = 200
+    books2 = synth_model(rng, D, M, K2, scale=0.1)
+    codes2 = rng.integers(0, K2, size=(30_000, M), dtype=np.uint8)
+    codes2[777, 3] = 250                                   # stray code past K: its distance is +inf, it must rank last
+    q2 = (rng.normal(size=(9, D)) * 0.1).astype(np.float32)
+    idx = amd.OpqIndex(np.zeros((1, D), np.float32), books2)
+    idx.add_codes(codes2)
+    od, oi = orc.adc_search(q2, books2, codes2, 100)
+    assert np.all(np.isfinite(od)) and not np.any(oi == 777)
+    for splits in (0, 1, 4):
+        idx.set_param("splits", splits)
+        d, i = idx.search(q2, 100, rotate=False)
+        assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od)), splits
+    idx.close()
