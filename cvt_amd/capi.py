@@ -204,6 +204,12 @@ class OpqIndex:
         return d, i
 
     def query_video(self, q, nprobe, img_num, rotate=True):
+        if _is_torch(q):
+            import torch
+            ms = torch.empty((q.shape[0], img_num), dtype=torch.float32, device=q.device)
+            _check(lib().cvtmi_opq_query_video_dev(self.h, _ptr(q), C.c_int64(q.shape[0]), C.c_int(1 if rotate else 0),
+                                                   C.c_int(nprobe), C.c_int(img_num), _ptr(ms), _stream()))
+            return ms
         q = _np(q, np.float32)
         ms = np.empty((q.shape[0], img_num), dtype=np.float32)
         _check(lib().cvtmi_opq_query_video(self.h, _ptr(q), C.c_int64(q.shape[0]), C.c_int(1 if rotate else 0),
@@ -452,6 +458,28 @@ class HnswIndex:
         _check(lib().cvtmi_hnsw_search_adc(self.h, opq.h, _ptr(q), C.c_int64(nq), C.c_int(int(rotate)), C.c_int(k), C.c_int(ef),
                                            _ptr(d), _ptr(lab)))
         return d, lab
+
+
+def _hnsw_search_adc_rerank(self, opq, q, k, ef, rerank=None, rotate=True):
+    """ADC traversal + exact fp32 re-rank of its `rerank` best nodes (default: ef)."""
+    rerank = ef if rerank is None else rerank
+    nq = q.shape[0]
+    if _is_torch(q):
+        import torch
+        assert q.is_contiguous() and q.dtype == torch.float32
+        d = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        lab = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        _check(lib().cvtmi_hnsw_search_adc_rerank_dev(self.h, opq.h, _ptr(q), C.c_int64(nq), C.c_int(int(rotate)), C.c_int(k), C.c_int(ef),
+                                                      C.c_int(rerank), _ptr(d), _ptr(lab), _stream()))
+        return d, lab
+    q = _np(q, np.float32)
+    d = np.empty((nq, k), dtype=np.float32); lab = np.empty((nq, k), dtype=np.int64)
+    _check(lib().cvtmi_hnsw_search_adc_rerank(self.h, opq.h, _ptr(q), C.c_int64(nq), C.c_int(int(rotate)), C.c_int(k), C.c_int(ef),
+                                              C.c_int(rerank), _ptr(d), _ptr(lab)))
+    return d, lab
+
+
+HnswIndex.search_adc_rerank = _hnsw_search_adc_rerank
 
 
 def set_tuning(name, value):

@@ -59,10 +59,9 @@ struct cvtmi_opq_s {
     int64_t id_base = 0;
     // list-ordered (CSR) copy for the per-video query path, built lazily
     bool csr_valid = false;
-    DevBuf csr_codes, csr_videos, csr_off;
-    std::vector<int64_t> h_off;
-    std::vector<int32_t> h_csr_video;
-    std::vector<uint8_t> h_csr_codes;
+    DevBuf csr_codes, csr_videos, csr_off, csr_scratch, csr_stats;
+    int64_t csr_kept = 0, csr_longest = 0;  // entries in the CSR copy (list ids outside [0, coarseK) are dropped), longest list
+    int32_t csr_vmin = 0, csr_vmax = -1;    // range of the video ids it holds
     // scratch
     DevBuf s_qrot, s_part_d, s_part_id, s_probe, s_lut, s_gthr;
     // tuning / measurement
@@ -190,7 +189,7 @@ int cvtmi_opq_destroy(cvtmi_opq_t h)
     if (h->d_R) (void)hipFree(h->d_R);
     if (h->d_perm) (void)hipFree(h->d_perm);
     h->codes.release(); h->lists.release(); h->videos.release(); h->codes_rot.release();
-    h->csr_codes.release(); h->csr_videos.release(); h->csr_off.release();
+    h->csr_codes.release(); h->csr_videos.release(); h->csr_off.release(); h->csr_scratch.release(); h->csr_stats.release();
     h->s_qrot.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_probe.release(); h->s_lut.release(); h->s_gthr.release();
     for (int e = 0; e < cvtmi_opq_s::kEvRing; ++e) {
         if (h->ev0[e]) (void)hipEventDestroy(h->ev0[e]);
@@ -368,44 +367,28 @@ int cvtmi_opq_set_id_base(cvtmi_opq_t h, int64_t base)
     return CVTMI_OK;
 }
 
-// list-ordered copy of the entries (stable: insertion order inside a list, as m_ivfList holds them)
-static int opq_build_csr(cvtmi_opq_t h)
+// list-ordered copy of the entries (stable: insertion order inside a list, as m_ivfList holds them), built on the device
+// by a counting sort (query_video.hip); only 16 bytes of statistics come back to the host
+static int opq_build_csr(cvtmi_opq_t h, hipStream_t st)
 {
     if (h->csr_valid) return CVTMI_OK;
-    CVTMI_HIP(hipDeviceSynchronize());
     const int64_t n = h->n;
     const int M = h->m.M, L = h->m.coarseK;
-    std::vector<uint8_t> codes((size_t)n * M);
-    std::vector<int32_t> lists((size_t)n, 0), videos((size_t)n);
-    if (n) CVTMI_HIP(hipMemcpy(codes.data(), h->codes.p, (size_t)n * M, hipMemcpyDeviceToHost));
-    if (n && h->has_lists) CVTMI_HIP(hipMemcpy(lists.data(), h->lists.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (n && h->has_videos) CVTMI_HIP(hipMemcpy(videos.data(), h->videos.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    else std::iota(videos.begin(), videos.end(), 0);
-    h->h_off.assign((size_t)L + 1, 0);
-    int64_t dropped = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        if (lists[i] >= 0 && lists[i] < L) h->h_off[(size_t)lists[i] + 1]++;
-        else ++dropped;  // list -1 (row no centroid could claim): the reference's .at(-1) throws; skipped here
-    }
-    for (int l = 0; l < L; ++l) h->h_off[(size_t)l + 1] += h->h_off[l];
-    const int64_t kept = n - dropped;
-    h->h_csr_codes.assign((size_t)kept * M, 0);
-    h->h_csr_video.assign((size_t)kept, 0);
-    std::vector<int64_t> cur(h->h_off.begin(), h->h_off.end() - 1);
-    for (int64_t i = 0; i < n; ++i) {
-        if (lists[i] < 0 || lists[i] >= L) continue;
-        const int64_t o = cur[lists[i]]++;
-        memcpy(&h->h_csr_codes[(size_t)o * M], &codes[(size_t)i * M], M);
-        h->h_csr_video[o] = videos[i];
-    }
-    CVTMI_TRY(h->csr_codes.reserve(std::max<size_t>((size_t)kept * M, 16)));
-    CVTMI_TRY(h->csr_videos.reserve(std::max<size_t>((size_t)kept * 4, 16)));
+    int nb = 1;
+    CVTMI_TRY(h->csr_scratch.reserve(csr_scratch_bytes(n, L, &nb)));
+    CVTMI_TRY(h->csr_codes.reserve(std::max<size_t>((size_t)n * M, 16)));
+    CVTMI_TRY(h->csr_videos.reserve(std::max<size_t>((size_t)n * 4, 16)));
     CVTMI_TRY(h->csr_off.reserve(((size_t)L + 1) * 8));
-    if (kept) {
-        CVTMI_HIP(hipMemcpy(h->csr_codes.p, h->h_csr_codes.data(), (size_t)kept * M, hipMemcpyHostToDevice));
-        CVTMI_HIP(hipMemcpy(h->csr_videos.p, h->h_csr_video.data(), (size_t)kept * 4, hipMemcpyHostToDevice));
-    }
-    CVTMI_HIP(hipMemcpy(h->csr_off.p, h->h_off.data(), ((size_t)L + 1) * 8, hipMemcpyHostToDevice));
+    CVTMI_TRY(h->csr_stats.reserve(16));
+    CVTMI_TRY(launch_csr_build(h->has_lists ? h->lists.as<int32_t>() : nullptr, h->has_videos ? h->videos.as<int32_t>() : nullptr,
+                               h->codes.as<uint8_t>(), n, L, M, h->csr_scratch.p, h->csr_off.as<int64_t>(), h->csr_codes.as<uint8_t>(),
+                               h->csr_videos.as<int32_t>(), h->csr_stats.p, st));
+    struct { int64_t longest; int32_t vmin, vmax; } stats;
+    int64_t kept = 0;
+    CVTMI_HIP(hipMemcpyAsync(&stats, h->csr_stats.p, sizeof stats, hipMemcpyDeviceToHost, st));
+    CVTMI_HIP(hipMemcpyAsync(&kept, h->csr_off.as<int64_t>() + L, sizeof kept, hipMemcpyDeviceToHost, st));
+    CVTMI_HIP(hipStreamSynchronize(st));
+    h->csr_longest = stats.longest; h->csr_vmin = stats.vmin; h->csr_vmax = stats.vmax; h->csr_kept = kept;
     h->csr_valid = true;
     return CVTMI_OK;
 }
@@ -413,10 +396,10 @@ static int opq_build_csr(cvtmi_opq_t h)
 int cvtmi_opq_get_entries(cvtmi_opq_t h, int64_t *list_off, int32_t *video_id, uint8_t *codes)
 {
     CHECK_H_SERIAL(h, nullptr);
-    CVTMI_TRY(opq_build_csr(h));
-    if (list_off) memcpy(list_off, h->h_off.data(), h->h_off.size() * sizeof(int64_t));
-    if (video_id && !h->h_csr_video.empty()) memcpy(video_id, h->h_csr_video.data(), h->h_csr_video.size() * 4);
-    if (codes && !h->h_csr_codes.empty()) memcpy(codes, h->h_csr_codes.data(), h->h_csr_codes.size());
+    CVTMI_TRY(opq_build_csr(h, nullptr));
+    if (list_off) CVTMI_HIP(hipMemcpy(list_off, h->csr_off.p, ((size_t)h->m.coarseK + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (video_id && h->csr_kept) CVTMI_HIP(hipMemcpy(video_id, h->csr_videos.p, (size_t)h->csr_kept * 4, hipMemcpyDeviceToHost));
+    if (codes && h->csr_kept) CVTMI_HIP(hipMemcpy(codes, h->csr_codes.p, (size_t)h->csr_kept * h->m.M, hipMemcpyDeviceToHost));
     return CVTMI_OK;
 }
 
@@ -569,31 +552,42 @@ int cvtmi_opq_search_sharded(cvtmi_opq_t h, cvtmi_comm_t c, const float *q, int6
     return CVTMI_OK;
 }
 
+int cvtmi_opq_query_video_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int nprobe, int img_num, float *match_score,
+                              void *stream)
+{
+    CHECK_H_SERIAL(h, stream);
+    if (nq < 0 || img_num < 0 || (nq > 0 && img_num > 0 && (!q || !match_score)))
+        return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: bad arguments");
+    if (nprobe < 1) return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: nprobe=%d", nprobe);
+    if (nq == 0 || img_num == 0) return CVTMI_OK;
+    if (nprobe > h->m.coarseK) nprobe = h->m.coarseK;  // the reference pops an empty heap here (UB)
+    hipStream_t st = (hipStream_t)stream;
+    CVTMI_TRY(opq_build_csr(h, st));
+    if (h->csr_kept > 0 && (h->csr_vmin < 0 || h->csr_vmax >= img_num))
+        return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: video id %d outside img_num=%d", h->csr_vmin < 0 ? h->csr_vmin : h->csr_vmax, img_num);
+    const float *q_rot = q;
+    if (rotate && (h->m.perm || h->m.R)) {
+        CVTMI_TRY(h->s_qrot.reserve((size_t)nq * h->m.D * sizeof(float)));
+        CVTMI_TRY(cvtmi_opq_rotate_dev(h, q, nq, h->s_qrot.as<float>(), stream));
+        q_rot = h->s_qrot.as<float>();
+    }
+    CVTMI_TRY(h->s_probe.reserve((size_t)nq * nprobe * sizeof(int32_t)));
+    CVTMI_TRY(launch_coarse_probe(h->m, q_rot, nq, nprobe, h->s_probe.as<int32_t>(), st));
+    return launch_query_video(h->m, q_rot, nq, nprobe, h->s_probe.as<int32_t>(), h->csr_off.as<int64_t>(), h->csr_codes.as<uint8_t>(),
+                              h->csr_videos.as<int32_t>(), img_num, match_score, h->csr_longest, st);
+}
+
 int cvtmi_opq_query_video(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int nprobe, int img_num,
                           float *match_score)
 {
     CHECK_H_SERIAL(h, nullptr);
     if (nq < 0 || img_num < 0 || (nq > 0 && img_num > 0 && (!q || !match_score)))
         return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: bad arguments");
-    if (nprobe < 1) return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: nprobe=%d", nprobe);
     if (nq == 0 || img_num == 0) return CVTMI_OK;
-    if (nprobe > h->m.coarseK) nprobe = h->m.coarseK;  // the reference pops an empty heap here (UB)
-    CVTMI_TRY(opq_build_csr(h));
-    for (int32_t v : h->h_csr_video)
-        if (v < 0 || v >= img_num) return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: video id %d outside img_num=%d", v, img_num);
-    Tmp dq, dr, dp, dm;
+    Tmp dq, dm;
     CVTMI_TRY(dq.upload(q, (size_t)nq * h->m.D * sizeof(float)));
-    const float *q_rot = dq.as<float>();
-    if (rotate && (h->m.perm || h->m.R)) {
-        CVTMI_TRY(dr.alloc((size_t)nq * h->m.D * sizeof(float)));
-        CVTMI_TRY(cvtmi_opq_rotate_dev(h, dq.as<float>(), nq, dr.as<float>(), nullptr));
-        q_rot = dr.as<float>();
-    }
-    CVTMI_TRY(dp.alloc((size_t)nq * nprobe * sizeof(int32_t)));
     CVTMI_TRY(dm.alloc((size_t)nq * img_num * sizeof(float)));
-    CVTMI_TRY(launch_coarse_probe(h->m, q_rot, nq, nprobe, dp.as<int32_t>(), nullptr));
-    CVTMI_TRY(launch_query_video(h->m, q_rot, nq, nprobe, dp.as<int32_t>(), h->csr_off.as<int64_t>(),
-                                 h->csr_codes.as<uint8_t>(), h->csr_videos.as<int32_t>(), img_num, dm.as<float>(), nullptr));
+    CVTMI_TRY(cvtmi_opq_query_video_dev(h, dq.as<float>(), nq, rotate, nprobe, img_num, dm.as<float>(), nullptr));
     CVTMI_HIP(hipMemcpy(match_score, dm.p, (size_t)nq * img_num * sizeof(float), hipMemcpyDeviceToHost));
     return CVTMI_OK;
 }
@@ -1218,7 +1212,7 @@ struct cvtmi_hnsw_s {
     HandleSync sync;
     HnswDevGraph g{};
     DevBuf vec, links0, labels, upper_off, upper;
-    DevBuf s_vis, s_cand, s_err;
+    DevBuf s_vis, s_cand, s_err, s_rr_d, s_rr_id;
 };
 #define CHECK_HN(h) do { if (!(h) || (h)->magic != 0x484e5357u) return fail(CVTMI_EINVAL, "bad hnsw handle"); CVTMI_TRY(use_device((h)->device)); } while (0)
 
@@ -1325,7 +1319,7 @@ int cvtmi_hnsw_destroy(cvtmi_hnsw_t h)
     if (!h) return CVTMI_OK;
     CHECK_HN(h);
     h->vec.release(); h->links0.release(); h->labels.release(); h->upper_off.release(); h->upper.release();
-    h->s_vis.release(); h->s_cand.release(); h->s_err.release();
+    h->s_vis.release(); h->s_cand.release(); h->s_err.release(); h->s_rr_d.release(); h->s_rr_id.release();
     h->sync.destroy();
     h->magic = 0;
     delete h;
@@ -1391,8 +1385,8 @@ int cvtmi_hnsw_search(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int ef,
 // HNSW over OPQ-compressed vectors: the graph of `h`, distances = ADC over the codes held by `opq` (one code
 // row per graph node, appended in internal-id order).  Queries are rotated and their tables built by the OPQ
 // handle's own kernels (cvtmi_opq_rotate_dev, lut_kernel).
-int cvtmi_hnsw_search_adc_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef, float *dist,
-                              int64_t *labels, void *stream)
+static int hnsw_search_adc_impl(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef, float *dist,
+                                int64_t *labels, void *stream, int raw_ids)
 {
     CHECK_HN(h);
     Serial serial_h(h->sync, (hipStream_t)(stream));
@@ -1436,11 +1430,54 @@ int cvtmi_hnsw_search_adc_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, i
     CVTMI_TRY(h->s_err.reserve(16));
     CVTMI_HIP(hipMemsetAsync(h->s_err.p, 0, 4, st));
     CVTMI_TRY(launch_hnsw_search_adc(h->g, opq->s_lut.as<float>(), opq->codes.as<uint8_t>(), opq->m.M, opq->m.K, nq, k, ef, dist,
-                                     labels, h->s_vis.as<uint32_t>(), h->s_cand.p, slots, words, gcap, h->s_err.as<int>(), st));
+                                     labels, h->s_vis.as<uint32_t>(), h->s_cand.p, slots, words, gcap, h->s_err.as<int>(), st, raw_ids));
     int err = 0;
     CVTMI_HIP(hipMemcpyAsync(&err, h->s_err.p, 4, hipMemcpyDeviceToHost, st));
     CVTMI_HIP(hipStreamSynchronize(st));
     if (err) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search_adc: candidate queue overflow (ef=%d)", ef);
+    return CVTMI_OK;
+}
+
+int cvtmi_hnsw_search_adc_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef, float *dist,
+                              int64_t *labels, void *stream)
+{
+    return hnsw_search_adc_impl(h, opq, q, nq, rotate, k, ef, dist, labels, stream, 0);
+}
+
+// ADC traversal with a result list of `rerank` nodes, then their exact fp32 distances (the graph's own vectors, the summation
+// order of the reference's distance functions) and the k smallest; equal exact distances keep their ADC order
+int cvtmi_hnsw_search_adc_rerank_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef, int rerank,
+                                     float *dist, int64_t *labels, void *stream)
+{
+    CHECK_HN(h);
+    Serial serial_h(h->sync, (hipStream_t)(stream));
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search_adc_rerank: k=%d outside 1..128", k);
+    if (rerank < k || rerank > hnsw_ef_max()) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc_rerank: rerank=%d outside k..%d", rerank, hnsw_ef_max());
+    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc_rerank: bad arguments");
+    if (nq == 0) return CVTMI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    CVTMI_TRY(h->s_rr_d.reserve((size_t)nq * rerank * sizeof(float)));
+    CVTMI_TRY(h->s_rr_id.reserve((size_t)nq * rerank * sizeof(int64_t)));
+    CVTMI_TRY(hnsw_search_adc_impl(h, opq, q, nq, rotate, rerank, ef, h->s_rr_d.as<float>(), h->s_rr_id.as<int64_t>(), stream, 1));
+    CVTMI_TRY(launch_hnsw_rerank(h->g, h->metric, q, nq, rerank, h->s_rr_id.as<int64_t>(), h->s_rr_d.as<float>(), st));
+    CVTMI_TRY(launch_topk_select(h->s_rr_d.as<float>(), h->s_rr_id.as<int64_t>(), nq, rerank, k, dist, labels, st));
+    return launch_gather_labels(labels, nq * k, h->g.labels, st);
+}
+
+int cvtmi_hnsw_search_adc_rerank(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef, int rerank,
+                                 float *dist, int64_t *labels)
+{
+    CHECK_HN(h);
+    Serial serial_h(h->sync, (hipStream_t)(nullptr));
+    if (nq < 0 || k < 1 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc_rerank: bad arguments");
+    if (nq == 0) return CVTMI_OK;
+    Tmp dq, dd, dl;
+    CVTMI_TRY(dq.upload(q, (size_t)nq * h->D * sizeof(float)));
+    CVTMI_TRY(dd.alloc((size_t)nq * k * 4));
+    CVTMI_TRY(dl.alloc((size_t)nq * k * 8));
+    CVTMI_TRY(cvtmi_hnsw_search_adc_rerank_dev(h, opq, dq.as<float>(), nq, rotate, k, ef, rerank, dd.as<float>(), dl.as<int64_t>(), nullptr));
+    CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    CVTMI_HIP(hipMemcpy(labels, dl.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
     return CVTMI_OK;
 }
 

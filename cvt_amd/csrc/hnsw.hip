@@ -101,6 +101,7 @@ struct HnswArgs {
     HnEnt *cand_g;            // [slots][gcap]
     int64_t words, gcap;
     int *err;
+    int raw_ids;              // 1 = out_label receives internal ids instead of labels (the re-rank pass needs the node)
 };
 
 // Distance evaluators: per-query state in LDS (`prepare`), one neighbour per lane (`operator()`).
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(64, 8) void hnsw_search_kernel(const HnswArgs a)  /
             const HnEnt e = top.get(0);
             if (w) {
                 a.out_d[(int64_t)qi * a.k + i] = e.d;
-                a.out_label[(int64_t)qi * a.k + i] = a.labels[e.id];
+                a.out_label[(int64_t)qi * a.k + i] = a.raw_ids ? (int64_t)e.id : a.labels[e.id];
             }
             hn_pop(top, top_n);
         }
@@ -287,6 +288,7 @@ static void hnsw_fill_args(HnswArgs &a, const HnswDevGraph &g, int64_t nq, int k
     a.q = nullptr; a.lut = nullptr; a.codes = nullptr; a.M = 0; a.K = 0;
     a.nq = (int)nq; a.k = k; a.ef = ef; a.out_d = out_d; a.out_label = out_label;
     a.visited = visited; a.cand_g = reinterpret_cast<HnEnt *>(cand_scratch); a.words = words; a.gcap = gcap; a.err = err;
+    a.raw_ids = 0;
 }
 
 int launch_hnsw_search(const HnswDevGraph &g, int metric, const float *q, int64_t nq, int k, int ef, float *out_d,
@@ -311,15 +313,47 @@ int launch_hnsw_search(const HnswDevGraph &g, int metric, const float *q, int64_
 // same traversal, distances = ADC over the nodes' PQ codes (codes [n][M] in internal-id order, lut [nq][M][K])
 int launch_hnsw_search_adc(const HnswDevGraph &g, const float *lut, const uint8_t *codes, int M, int K, int64_t nq, int k, int ef,
                            float *out_d, int64_t *out_label, uint32_t *visited, void *cand_scratch, int slots, int64_t words,
-                           int64_t gcap, int *err, hipStream_t st)
+                           int64_t gcap, int *err, hipStream_t st, int raw_ids)
 {
     if (nq <= 0) return CVTMI_OK;
     HnswArgs a;
     hnsw_fill_args(a, g, nq, k, ef, out_d, out_label, visited, cand_scratch, words, gcap, err);
-    a.lut = lut; a.codes = codes; a.M = M; a.K = K;
+    a.lut = lut; a.codes = codes; a.M = M; a.K = K; a.raw_ids = raw_ids;
     const size_t lds = (size_t)hnsw_lds_bytes(M * K, ef > k ? ef : k);
     CVTMI_HIP(hipFuncSetAttribute((const void *)hnsw_search_kernel<DistADC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((hnsw_search_kernel<DistADC>), dim3((unsigned)slots), dim3(64), lds, st, a);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+// Exact re-rank of an ADC result list: ids [nq][R] internal ids (-1 = padding) -> out_d [nq][R] = the fp32 distance of the
+// raw query to the node's own vector, in the summation order of the reference's distance functions (+inf for padding).
+// One lane per candidate; a wave's 64 gathers of 4 D bytes are what the fp32 traversal pays per expanded node.
+template <bool IP, int LANES>
+__global__ __launch_bounds__(kBlock) void hnsw_rerank_kernel(const float *__restrict__ vec, int D, const float *__restrict__ q,
+                                                             const int64_t *__restrict__ ids, int64_t total, int R,
+                                                             float *__restrict__ out_d)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total) return;
+    const int64_t id = ids[i];
+    float o[1] = { __uint_as_float(0x7f800000u) };
+    if (id >= 0) dist_f32_row<IP, LANES, 1>(vec + id * D, q + (i / R) * D, D, o);
+    out_d[i] = o[0];
+}
+
+int launch_hnsw_rerank(const HnswDevGraph &g, int metric, const float *q, int64_t nq, int R, const int64_t *ids, float *out_d,
+                       hipStream_t st)
+{
+    const int64_t total = nq * R;
+    if (total <= 0) return CVTMI_OK;
+    const unsigned blocks = (unsigned)((total + kBlock - 1) / kBlock);
+    const bool ip = metric == CVTMI_METRIC_IP;
+    const int lanes = (g.D % 4 != 0) ? 1 : (ip ? 4 : (g.D % 16 == 0 ? 8 : 4));  // as launch_hnsw_search picks them
+#define CVTMI_RR(IPV, L) hipLaunchKernelGGL((hnsw_rerank_kernel<IPV, L>), dim3(blocks), dim3(kBlock), 0, st, g.vec, g.D, q, ids, total, R, out_d)
+    if (ip) { if (lanes == 4) CVTMI_RR(true, 4); else CVTMI_RR(true, 1); }
+    else { if (lanes == 8) CVTMI_RR(false, 8); else if (lanes == 4) CVTMI_RR(false, 4); else CVTMI_RR(false, 1); }
+#undef CVTMI_RR
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

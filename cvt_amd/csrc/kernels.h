@@ -70,7 +70,12 @@ int launch_coarse_probe(const OpqModelDev &m, const float *q_rot, int64_t nq, in
                         hipStream_t st);
 int launch_query_video(const OpqModelDev &m, const float *q_rot, int64_t nq, int nprobe, const int32_t *probe,
                        const int64_t *list_off, const uint8_t *codes, const int32_t *video_id, int img_num,
-                       float *match_score, hipStream_t st);
+                       float *match_score, int64_t longest_list, hipStream_t st);
+// list-ordered (CSR) copy of the entries by a stable counting sort on the device; scratch of csr_scratch_bytes();
+// stats_out (16 bytes, device): int64 longest list, int32 min / max video id
+size_t csr_scratch_bytes(int64_t n, int L, int *nb_out);
+int launch_csr_build(const int32_t *lists, const int32_t *videos, const uint8_t *codes, int64_t n, int L, int M, void *scratch,
+                     int64_t *list_off, uint8_t *out_codes, int32_t *out_videos, void *stats_out, hipStream_t st);
 
 // ---- flat.hip ----
 int flat_plan_splits(int64_t n, int64_t nq, int qtile);
@@ -173,7 +178,10 @@ int launch_hnsw_search(const HnswDevGraph &g, int metric, const float *q, int64_
                        int *err, hipStream_t st);
 int launch_hnsw_search_adc(const HnswDevGraph &g, const float *lut, const uint8_t *codes, int M, int K, int64_t nq, int k, int ef,
                            float *out_d, int64_t *out_label, uint32_t *visited, void *cand_scratch, int slots, int64_t words,
-                           int64_t gcap, int *err, hipStream_t st);
+                           int64_t gcap, int *err, hipStream_t st, int raw_ids = 0);
+// exact fp32 distances (reference summation order) of the raw queries to the nodes ids [nq][R] (-1 = padding -> +inf)
+int launch_hnsw_rerank(const HnswDevGraph &g, int metric, const float *q, int64_t nq, int R, const int64_t *ids, float *out_d,
+                       hipStream_t st);
 int hnsw_lds_bytes(int state_floats, int ef);
 int hnsw_ef_max();
 int hnsw_lcap();

@@ -138,6 +138,8 @@ int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, 
  * match_score[nq][img_num].  rotate as above. */
 int cvtmi_opq_query_video(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int nprobe,
                           int img_num, float *match_score);
+int cvtmi_opq_query_video_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int nprobe,
+                              int img_num, float *match_score, void *stream);
 
 /* Tuning / measurement hooks (no effect on results).
  *   "splits"   row splits per query group of the scan (0 = automatic)
@@ -328,6 +330,15 @@ int cvtmi_hnsw_search_adc(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64
                           float *dist, int64_t *labels);
 int cvtmi_hnsw_search_adc_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef,
                               float *dist, int64_t *labels, void *stream);
+/* cvtmi_hnsw_search_adc followed by an exact re-rank: the ADC traversal returns its `rerank` best nodes (k <= rerank <= 1024), their
+ * fp32 distances to the RAW query are computed from the graph's own vectors in the summation order of the reference's distance
+ * functions, and the k smallest come back (k <= 128); nodes with equal exact distances keep their ADC order.  16-byte codes steer
+ * the traversal, full vectors are only touched for `rerank` nodes per query: the recall of the fp32 graph at a fraction of its
+ * gather traffic. */
+int cvtmi_hnsw_search_adc_rerank(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef,
+                                 int rerank, float *dist, int64_t *labels);
+int cvtmi_hnsw_search_adc_rerank_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef,
+                                     int rerank, float *dist, int64_t *labels, void *stream);
 
 #ifdef __cplusplus
 }

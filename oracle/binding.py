@@ -366,9 +366,15 @@ class RefHnsw:
     def __init__(self):
         self.lib = C.CDLL(os.path.join(_HERE, "_ref", "libref_hnsw.so"))
 
-    def build(self, metric, data, path, M=16, ef_construction=200, labels=None, max_elements=None):
+    def build(self, metric, data, path, M=16, ef_construction=200, labels=None, max_elements=None, threads=1):
         data = _f32(data); n, D = data.shape
         lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.int64)
+        if threads > 1:  # the reference's addPoint from several host threads (its own per-node locks): order-dependent graph
+            rc = self.lib.ref_hnsw_build_mt(C.c_int(metric), C.c_int(D), _p(data, C.c_float), _p(lab, C.c_int64), C.c_int64(n),
+                                            C.c_int64(max_elements or n), C.c_int(M), C.c_int(ef_construction), path.encode(),
+                                            C.c_int(threads))
+            assert rc == 0
+            return
         rc = self.lib.ref_hnsw_build(C.c_int(metric), C.c_int(D), _p(data, C.c_float), _p(lab, C.c_int64), C.c_int64(n),
                                      C.c_int64(max_elements or n), C.c_int(M), C.c_int(ef_construction), path.encode())
         assert rc == 0

@@ -124,6 +124,53 @@ def test_flat_full_size_u8_property(amd):
     assert torch.equal(d2, d) and torch.equal(i2, i)
 
 
+def test_config3_full_size(amd, orc):
+    """BASELINE config 3 at its real size: 10 M x 512-d int8 codes (SQ8 of CNN-like features: ReLU'd Gaussians, L2-normalised,
+    encoded on device), brute-force L2 top-10.  Checked against the oracle's L2SqrI loop over ALL 10 M rows for a sample of the
+    queries (host threads split the queries), for nq = 1, a mid-size and a large batch -- the three kernel regimes -- and through
+    size-independent properties: self-queries come back first at distance 0, distances ascend, every batch size agrees."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    n, D, k = 10_000_000, 512, 10
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    train = torch.randn((1 << 18, D), generator=g, device=dev).clamp_(min=0)
+    vmin, vdiff = amd.sq8_train(train, l2norm=True)
+    ix = amd.FlatIndex(L2U8, D)
+    host = np.empty((n, D), dtype=np.uint8)
+    chunk = 1 << 20
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        g.manual_seed(1000 + a // chunk)
+        c = amd.sq8_encode(vmin, vdiff, torch.randn((b - a, D), generator=g, device=dev).clamp_(min=0), l2norm=True)
+        if a == 0:
+            c[77] = c[5]; c[900_000] = c[5]                       # exact duplicates: (distance, label) ties
+        ix.add(c)
+        host[a:b] = c.cpu().numpy()
+    assert ix.ntotal == n
+    g.manual_seed(77)
+    q = amd.sq8_encode(vmin, vdiff, torch.randn((4096, D), generator=g, device=dev).clamp_(min=0), l2norm=True)
+    q[0] = torch.from_numpy(host[5]).to(dev)                       # lands on the duplicates
+    q[1] = torch.from_numpy(host[n - 1]).to(dev)
+    d_big, i_big = ix.search(q, k)
+    d_mid, i_mid = ix.search(q[:1000].contiguous(), k)
+    assert torch.equal(d_mid, d_big[:1000]) and torch.equal(i_mid, i_big[:1000])
+    for j in (0, 1, 2):
+        d1, i1 = ix.search(q[j:j + 1].contiguous(), k)
+        assert torch.equal(d1[0], d_big[j]) and torch.equal(i1[0], i_big[j])
+    assert i_big[0, :3].tolist() == [5, 77, 900_000] and torch.all(d_big[0, :3] == 0)
+    assert int(i_big[1, 0]) == n - 1 and int(d_big[1, 0]) == 0
+    assert torch.all(d_big[:, 1:] >= d_big[:, :-1])
+    cs = 16
+    qh = q[:cs].cpu().numpy()
+    with ThreadPoolExecutor(max_workers=cs) as ex:                 # ctypes releases the GIL: one query per host thread
+        parts = list(ex.map(lambda j: orc.flat_search(L2U8, host, qh[j:j + 1], k), range(cs)))
+    odi = np.concatenate([p[1] for p in parts]); oi = np.concatenate([p[2] for p in parts])
+    assert np.array_equal(i_big[:cs].cpu().numpy(), oi)
+    assert np.array_equal(d_big[:cs].cpu().numpy(), odi)
+    ix.close()
+
+
 def test_sq8_parity(amd, orc, golden):
     rng = np.random.default_rng(8)
     for d in (64, 512, 300):

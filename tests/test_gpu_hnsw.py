@@ -126,3 +126,84 @@ def test_hnsw_over_opq_codes(amd, orc, golden, case, M, K):
     small.add_codes(codes[:10])
     with pytest.raises(amd.CvtmiError):
         ix.search_adc(small, q, 5, 10)
+    # exact re-rank of the ADC result list (cvtmi_hnsw_search_adc_rerank): the ADC traversal's `rerank` best nodes, their fp32
+    # distances in the reference's summation order (the oracle's orc_dist, default flavour), the k smallest, ties in ADC order
+    labels_of = np.frombuffer(blob, np.uint8)  # labels of the golden graphs are read back through a plain search
+    for k2, ef2, rr in ((5, 40, 40), (10, 64, 30), (1, 16, 8)):
+        d, lab = ix.search_adc_rerank(opq, q, k2, ef2, rr)
+        _, cand = orc.hnsw_search_adc(blob, books, ocodes, rot(q), rr, ef2)       # labels of the ADC list, ADC order
+        lab2row = {int(l): r for r, l in enumerate(_graph_labels(blob, D))}
+        for qi in range(q.shape[0]):
+            rows = [lab2row[int(l)] for l in cand[qi] if l >= 0]
+            ex = np.array([orc.dist(metric, 4, q[qi], x[r]) for r in rows], dtype=np.float32)
+            order = np.argsort(ex, kind="stable")[:k2]
+            want_l = [int(cand[qi][j]) for j in order]
+            assert lab[qi, :len(want_l)].tolist() == want_l, (case, k2, ef2, rr, qi)
+            assert np.array_equal(bits(d[qi, :len(want_l)]), bits(ex[order])), (case, k2, ef2, rr, qi)
+    with pytest.raises(amd.CvtmiError):
+        ix.search_adc_rerank(opq, q, 10, 40, 5)                                   # rerank < k is refused
+
+
+def _graph_labels(blob, D):
+    hdr = np.frombuffer(blob, np.uint64, 6, 0)
+    max_elements, cur, size_per, label_off = int(hdr[1]), int(hdr[2]), int(hdr[3]), int(hdr[4])
+    raw = np.frombuffer(blob, np.uint8, max_elements * size_per, 96).reshape(max_elements, size_per)
+    return np.ascontiguousarray(raw[:cur, label_off:label_off + 8]).view(np.uint64).reshape(cur).astype(np.int64)
+
+
+def test_hnsw_config5_scale(amd, orc):
+    """BASELINE config 5 at scale: a 1 M-node graph (M = 16, efC = 40; built by the reference's own addPoint on all host
+    cores -- its per-node locks make that legal, hnswalg.h:178,386,594), a batch of 10 000 queries.  fp32 traversal:
+    labels and distance bits equal the reference's searchKnn on a sample; ADC traversal equals the oracle's on a sample;
+    the exact re-rank recovers the fp32 graph's recall."""
+    import torch
+    from oracle import binding as ob
+    if not os.path.exists(os.path.join(os.path.dirname(ob.__file__), "_ref", "libref_hnsw.so")):
+        pytest.skip("oracle/_ref/libref_hnsw.so not built")
+    from cvt_amd import synth
+    n, D, nq = int(os.environ.get("CVT_C5_NODES", 1_000_000)), 128, 10_000
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(55)
+    cen = torch.randn((4000, D), generator=g, device=dev)
+    xd = cen[torch.randint(0, 4000, (n,), generator=g, device=dev)] + 0.6 * torch.randn((n, D), generator=g, device=dev)
+    xd = xd / xd.norm(dim=1, keepdim=True)
+    qd = xd[torch.randint(0, n, (nq,), generator=g, device=dev)] + 0.15 * torch.randn((nq, D), generator=g, device=dev)
+    qd = (qd / qd.norm(dim=1, keepdim=True)).contiguous()
+    x, q = xd.cpu().numpy(), qd.cpu().numpy()
+    path = os.path.join(tempfile.gettempdir(), "cvt_test_c5.hnsw")
+    rh = ob.RefHnsw()
+    rh.build(0, x, path, 16, 40, threads=os.cpu_count() or 8)
+    blob = open(path, "rb").read()
+    ix = amd.HnswIndex(blob, 0, D)
+    assert ix.ntotal == n
+    d, lab = ix.search(qd, 10, 100)
+    cs = 300
+    rd, rl = rh.search(0, D, path, q[:cs], 10, 100)                                # the reference itself, same file
+    os.remove(path)
+    assert np.array_equal(lab[:cs].cpu().numpy(), rl) and np.array_equal(bits(d[:cs].cpu().numpy()), bits(rd))
+    exact = torch.empty(nq, dtype=torch.int64, device=dev)
+    for a in range(0, nq, 1000):
+        exact[a:a + 1000] = torch.argmax(qd[a:a + 1000] @ xd.T, dim=1)
+    labels = torch.from_numpy(_graph_labels(blob, D)).to(dev)                       # parallel build: label != internal id
+    rec_fp32 = float((lab[:, 0] == exact).float().mean().item())
+    assert rec_fp32 > 0.85, rec_fp32
+    # over OPQ codes (16 bytes per node), internal-id order
+    R = synth.random_rotation(D, seed=3)
+    xi = torch.from_numpy(vectors_of(blob, D)).to(dev)
+    tmp = amd.OpqIndex(np.zeros((1, D), np.float32), np.zeros((16, 256, D // 16), np.float32), R=R)
+    xr = tmp.rotate(xi)
+    _, books = amd.opq_train(xr[:100_000].contiguous(), 1, 16, 256, 6, 1)
+    books = books.cpu().numpy()
+    opq = amd.OpqIndex(np.zeros((1, D), np.float32), books, R=R)
+    _, codes = opq.encode(xr)
+    opq.add_codes(codes)
+    da, la = ix.search_adc(opq, qd, 10, 100)
+    cs2 = 60
+    od, ol = orc.hnsw_search_adc(blob, books, codes.cpu().numpy(), orc.rotate_fma(R, q[:cs2]), 10, 100)
+    assert np.array_equal(la[:cs2].cpu().numpy(), ol) and np.array_equal(bits(da[:cs2].cpu().numpy()), bits(od))
+    dr, lr = ix.search_adc_rerank(opq, qd, 10, 100, 100)
+    rec_adc = float((la[:, 0] == exact).float().mean().item())
+    rec_rr = float((lr[:, 0] == exact).float().mean().item())
+    assert rec_rr > rec_adc and rec_rr > rec_fp32 - 0.1, (rec_fp32, rec_adc, rec_rr)
+    print("config 5, %d nodes, %d queries: recall@1 fp32 %.3f, ADC %.3f, ADC + re-rank %.3f" % (n, nq, rec_fp32, rec_adc, rec_rr))
+    del labels
