@@ -139,6 +139,11 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         g_flat_variant = (int)value;
         return CVTMI_OK;
     }
+    if (!strcmp(name, "flat_u8_opt")) {
+        if (value < 0 || value > 3) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_u8_opt must be 0..3");
+        set_flat_u8_opt((int)value);
+        return CVTMI_OK;
+    }
     if (!strcmp(name, "comm_force_rccl")) { comm_set_force_rccl(value != 0); return CVTMI_OK; }
     return fail(CVTMI_EINVAL, "cvtmi_set_tuning: unknown parameter '%s'", name);
 }

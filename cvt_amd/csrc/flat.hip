@@ -591,7 +591,10 @@ struct NoFixBatch {
     __device__ __forceinline__ void operator()(int, unsigned long long (&)[NR], const bool (&)[NR]) const {}
 };
 
-template <int NW, int CAP, int DMAX>
+// OPT (measurement switch, cvtmi_set_tuning("flat_u8_opt")): bit 0 = two accumulator chains per tile (even / odd K steps, summed at
+// the end) so that back-to-back matrix instructions never wait for each other's result; bit 1 = all K-step operands of a tile are
+// read from LDS before its first matrix instruction (64 VGPRs at D = 512) instead of one read in front of each.
+template <int NW, int CAP, int DMAX, int OPT>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW >= 4 ? NW / 4 : 1, NW >= 4 ? NW / 4 : 1)))
 void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
 {
@@ -797,17 +800,42 @@ void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
             const mf_v16i &prev = accs[(u & 1) ^ 1];
             uint32_t hit = 0;
             constexpr int EPS = 16 / KS;  // results of the previous tile tested per MFMA of this one
+            if constexpr (OPT == 0) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                if (s < nks) {
-                    const mf_v4i bv = *reinterpret_cast<const mf_v4i *>(rt + 32 * s);
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(qreg[s], bv, acc, 0, 0, 0);
+                for (int s = 0; s < KS; ++s) {
+                    if (s < nks) {
+                        const mf_v4i bv = *reinterpret_cast<const mf_v4i *>(rt + 32 * s);
+                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(qreg[s], bv, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < EPS; ++j) hit |= hit_bit(prev, xx_prev, s * EPS + j);
+                    // keep the order written here: operand reads a few MFMAs ahead at most (64 VGPRs if all 16 were
+                    // hoisted), the tests of the previous tile between the MFMAs
+                    if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                mf_v16i acc2;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[e] = 0;
+                mf_v4i bvs[KS];
+                if constexpr ((OPT & 2) != 0) {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) bvs[s] = *reinterpret_cast<const mf_v4i *>(rt + 32 * (s < nks ? s : 0));
                 }
 #pragma unroll
-                for (int j = 0; j < EPS; ++j) hit |= hit_bit(prev, xx_prev, s * EPS + j);
-                // keep the order written here: operand reads a few MFMAs ahead at most (64 VGPRs if all 16 were
-                // hoisted), the tests of the previous tile between the MFMAs
-                if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                for (int s = 0; s < KS; ++s) {
+                    if (s < nks) {
+                        const mf_v4i bv = (OPT & 2) ? bvs[s] : *reinterpret_cast<const mf_v4i *>(rt + 32 * s);
+                        if ((OPT & 1) && (s & 1)) acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(qreg[s], bv, acc2, 0, 0, 0);
+                        else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(qreg[s], bv, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < EPS; ++j) hit |= hit_bit(prev, xx_prev, s * EPS + j);
+                }
+                if constexpr ((OPT & 1) != 0) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
+                }
             }
             accs[u & 1] = acc;
             FT_T(0);  // LDS reads + MFMAs issued, previous tile tested
@@ -866,6 +894,9 @@ void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
     }
 }
 
+static int g_flat_u8_opt = 0;
+void set_flat_u8_opt(int v) { g_flat_u8_opt = v; }
+
 // Queries per workgroup of the MFMA paths, 0 = shape not covered (caller falls back to the dot4 kernel).
 // More queries per workgroup = fewer passes over the rows; what bounds it is LDS: two row tiles
 // (32 x (D + 16) bytes each) next to the selection buffers (8 * CAP bytes per query, CAP >= k + 32).
@@ -923,11 +954,19 @@ int launch_flat_u8_mfma(int D, const uint8_t *data, const int32_t *norms, int64_
 #undef CVTMI_FM
     } else {
         const size_t lds = (size_t)2 * 32 * (D + 16);
+#define CVTMI_RT1(NW, CAP, DMAX, OPT)                                                                                   \
+    do {                                                                                                                \
+        CVTMI_HIP(hipFuncSetAttribute((const void *)flat_u8_rowtile_kernel<NW, CAP, DMAX, OPT>,                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+        hipLaunchKernelGGL((flat_u8_rowtile_kernel<NW, CAP, DMAX, OPT>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, a); \
+    } while (0)
 #define CVTMI_RT(NW, CAP, DMAX)                                                                                         \
     do {                                                                                                                \
-        CVTMI_HIP(hipFuncSetAttribute((const void *)flat_u8_rowtile_kernel<NW, CAP, DMAX>,                              \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-        hipLaunchKernelGGL((flat_u8_rowtile_kernel<NW, CAP, DMAX>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, a);  \
+        if (NW == 8 && DMAX == 512 && g_flat_u8_opt == 0) CVTMI_RT1(NW, CAP, DMAX, 0);                                  \
+        else if (NW == 8 && DMAX == 512 && g_flat_u8_opt == 1) CVTMI_RT1(NW, CAP, DMAX, 1);                             \
+        else if (NW == 8 && DMAX == 512 && g_flat_u8_opt == 2) CVTMI_RT1(NW, CAP, DMAX, 2);                             \
+        else if (NW == 8 && DMAX == 512) CVTMI_RT1(NW, CAP, DMAX, 3);                                                   \
+        else CVTMI_RT1(NW, CAP, DMAX, 0);                                                                               \
     } while (0)
         // CAP by k: k <= 24 -> 56, k <= 80 -> 112 (CAP - k >= 32: a compacted buffer takes a whole tile)
         if (k <= 24) {
@@ -938,6 +977,7 @@ int launch_flat_u8_mfma(int D, const uint8_t *data, const int32_t *norms, int64_
             if (D <= 128) CVTMI_RT(4, 112, 128); else CVTMI_RT(4, 112, 512);
         }
 #undef CVTMI_RT
+#undef CVTMI_RT1
     }
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;

@@ -117,6 +117,7 @@ int flat_u8_mfma_splits(int64_t n, int64_t nq, int qt);
 int launch_flat_u8_mfma(int D, const uint8_t *data, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int k,
                         int splits, float *part_d, int64_t *part_id, uint32_t *gthr, hipStream_t st);
 // ids[i] = ids[i] >= 0 ? labels[ids[i]] : -1
+void set_flat_u8_opt(int v);
 int launch_gather_labels(int64_t *ids, int64_t count, const int64_t *labels, hipStream_t st);
 
 // ---- sq8.hip ----
