@@ -139,6 +139,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         g_flat_variant = (int)value;
         return CVTMI_OK;
     }
+    if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_opt")) {
         if (value < 0 || value > 3) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_u8_opt must be 0..3");
         set_flat_u8_opt((int)value);
@@ -973,9 +974,11 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
         flat_filter_applies(h->metric, h->D, g_flat_variant == 2 ? std::max<int64_t>(h->n, 131072) : h->n, g_flat_variant == 2 ? std::max<int64_t>(nq, 64) : nq, k) &&
         h->n >= 2 * 65536)
         CVTMI_TRY(flat_search_filtered(h, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
-    // uint8: the row-tile kernels stay the default (the pipeline below measures the same at the C3 shape: both sit at a third
-    // of the i8 matrix pipe); flat_variant 2 selects it
-    if (g_flat_variant == 2 && h->metric == CVTMI_METRIC_L2U8 && ((uintptr_t)q & 15) == 0 && nq <= 65535 * 256 && h->norms.p &&
+    // uint8: large batches go through the filter pipeline with the software-pipelined (LDS-DMA) kernel -- measured at 10 M x 512-d:
+    // 4096 queries 27.4 -> 21.0 ms, 512 queries 4.6 -> 3.8 ms, break-even near nq * D = 128 K; smaller batches stay on the row-tile
+    // kernels.  flat_variant 2 forces the pipeline wherever it applies, 1 forbids it.
+    const bool u8_auto = g_flat_variant == 0 && flat_u8_gfilter_shape(h->D) && nq * h->D >= 131072 && h->n >= (1 << 20) && k <= 64;
+    if ((g_flat_variant == 2 || u8_auto) && h->metric == CVTMI_METRIC_L2U8 && ((uintptr_t)q & 15) == 0 && nq <= 65535 * 256 && h->norms.p &&
         flat_u8_filter_applies(h->D, std::max<int64_t>(h->n, 262144), std::max<int64_t>(nq, 256), k) && h->n >= 2 * 65536)
         CVTMI_TRY(flat_search_filtered_u8(h, reinterpret_cast<const uint8_t *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
     h->f_last_filtered = done ? 1 : 0;

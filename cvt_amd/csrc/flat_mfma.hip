@@ -542,6 +542,263 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(QS == 1 ? 4 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same filter as a software-pipelined GEMM (flat_u8_gfilter_kernel): 8 waves, 32 queries per wave in registers (A side),
+// row tiles streamed HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: the packed copy IS the operand order, one 1 KB piece
+// per wave-instruction, lane-linear), no staging registers and no LDS store pass.  What the kernels above leave on the table
+// (v_mfma_i32_32x32x32_i8 busy a third of the time) is structure, not bandwidth:
+//   * one barrier per 32-row tile and 16 matrix instructions between barriers          -> G tiles (64 rows) per barrier;
+//   * every matrix instruction waited for the LDS read issued right in front of it, and for its predecessor's result (all 16
+//     K steps of a tile accumulate into ONE register set)                              -> the G tiles of a group are G
+//     independent accumulator chains fed alternately, sharing each query operand;
+//   * the register prefetch ring (32 VGPRs) plus its LDS stores                         -> DMA into a ring of 3 groups, counted
+//     s_waitcnt vmcnt(OPS): a group's data is requested two barriers before it is read.
+// Synchronisation (one s_barrier per group): at the top of iteration g a wave waits until at most the OPS requests of group g + 1
+// are outstanding (its own share of group g has landed: requests retire in order), then the barrier (everyone's share of g has
+// landed, everyone has finished reading group g - 1), then it requests group g + 2 into the slot group g - 1 occupied, then reads
+// group g.  The DMA is issued from inline asm, so hipcc neither counts it nor drains it (it waits vmcnt(0) in front of every
+// LDS read when it sees the builtin); ordinary memory operations in the loop are confined to the rare survivor flush.
+// Row norms |x'|^2 travel the same way (one 4-byte-per-lane piece per group, requested by every wave: same request count in
+// every wave, same bytes to the same place).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// NW waves (32 queries each) per workgroup, G row tiles per barrier.  <8, 2>: one workgroup per CU, its two waves per SIMD move in
+// lock step (same barrier).  <4, 1>: two independent workgroups per CU, one wave per SIMD each -- the pair on a SIMD drifts apart,
+// so one wave's matrix instructions run beside the other's reads / waits / barrier.
+template <int KS, int NW, int G>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void flat_u8_gfilter_kernel(
+    const uint8_t *__restrict__ q, int64_t nq, const uint4 *__restrict__ pack, const int32_t *__restrict__ norms, int64_t n,
+    const float *__restrict__ sample_d, int k, int64_t tile_begin, int64_t tile_end, int64_t tiles_per_split, uint32_t pair_cap,
+    uint32_t *__restrict__ pair_cnt, uint4 *__restrict__ pairs, int qblocks)
+{
+    constexpr int D = 32 * KS;
+    constexpr int NB = 3;                     // groups in the LDS ring
+    constexpr int PPW = G * KS / NW;          // 1 KB pieces each wave requests per group
+    constexpr int OPS = PPW + 1;              // + the norms piece
+    constexpr int PBUF = 128;
+    constexpr int QPB = 32 * NW;
+    constexpr int C = G == 1 ? 2 : G;         // accumulator chains: the G tiles, or the even / odd K steps of a single tile
+    static_assert(G * KS % NW == 0 && (G == 1 || G == 2 || G == 4), "pieces per group must split evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) uint4 gf_ring[];   // [NB][G][KS * 64]
+    __shared__ int xx_s[NB][G * 32 < 64 ? 64 : G * 32];
+    __shared__ uint4 park_s[NW][PBUF];         // (query, row, distance, -)
+    __shared__ int qq_s[QPB], thr_s[QPB];
+    const int tid = threadIdx.x, lane = tid & 63, lj = lane & 31, lk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t bi = blockIdx.x >> 3;
+    const int split_id = (int)(blockIdx.x & 7) + 8 * (int)(bi / qblocks), qb_id = (int)(bi % qblocks);
+    // ---- this wave's 32 queries: operands in registers, |q'|^2 and tau - |q'|^2 in LDS ----
+    i32x4 qreg[KS];
+    {
+        const int ql = wave * 32 + lj;
+        const int64_t qi = (int64_t)qb_id * QPB + ql;
+        const int64_t qc = qi < nq ? qi : nq - 1;
+        const uint8_t *qp = q + qc * D;
+        int qq = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) qreg[s_] = *reinterpret_cast<const i32x4 *>(qp + 32 * s_ + 16 * lk);
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            qreg[s_] ^= (int)0x80808080;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qq = __builtin_amdgcn_sdot4(qreg[s_][c], qreg[s_][c], qq, false);
+        }
+        qq += __shfl_xor(qq, 32, 64);
+        if (lk == 0) {
+            const int tau = (int)__float_as_uint(sample_d[qc * k + k - 1]);  // integer distance bits (0x7f800000 = none: everything passes)
+            qq_s[ql] = qq;
+            thr_s[ql] = qi < nq ? tau - qq : (int)0x80000000;               // padding queries: nothing passes
+        }
+    }
+    __syncthreads();   // (also drains the ordinary loads above: from here on the loop's only memory traffic is the DMA)
+    // Threshold test folded into the accumulation.  A (row, query) pair survives when  xx - 2 dot <= thr  (xx = |x'|^2, thr = tau - |q'|^2).
+    // With thr = 2 a + b and xx = 2 c + d (b, d in {0, 1}) that is  dot + a >= c + [d = 1 and b = 0], so  dot + a >= c  is a superset
+    // test -- and dot + a is what the matrix unit delivers when a = thr >> 1 is the initial accumulator.  A tile then costs 8 v_max3
+    // and one compare per lane (max over the lane's 16 queries against c) instead of four instructions per result; the rare lane
+    // that passes re-tests its 16 results exactly.
+    i32x16 thrh;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) thrh[e] = thr_s[wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk] >> 1;
+    const int64_t t0 = tile_begin + (int64_t)split_id * tiles_per_split;
+    int64_t t1 = t0 + tiles_per_split;
+    t1 = t1 < tile_end ? t1 : tile_end;
+    if (t0 >= t1) return;   // workgroup-uniform
+    const int64_t n_groups = (t1 - t0 + G - 1) / G;
+    const uint32_t ring_b = (uint32_t)(uintptr_t)gf_ring, xx_b = (uint32_t)(uintptr_t)&xx_s[0][0];
+    // requests of group g: pieces p = wave * PPW + i (tile g G + p / KS, K step p % KS); tiles past the split are clamped duplicates
+    auto request = [&](int64_t g, int slot) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave * PPW + i;
+            int64_t t = t0 + g * G + p / KS;
+            t = t < t1 ? t : t1 - 1;
+            glds16(pack + (t * KS + p % KS) * 64 + lane, ring_b + (uint32_t)(((slot * G * KS) + p) * 64 * 16));
+        }
+        int64_t t = t0 + g * G + (lane >> 5);   // norms of the group's first two tiles per piece; G = 4 takes two pieces' worth in one
+        int64_t row;
+        if (G <= 2) {
+            if (G == 1) t = t0 + g;
+            t = t < t1 ? t : t1 - 1;
+            row = t * 32 + lj;
+            row = row < n ? row : n - 1;
+            glds4(norms + row, xx_b + (uint32_t)(slot * (G * 32 < 64 ? 64 : G * 32) * 4));
+        } else {  // G = 4: lanes cover tiles 0..1 here, tiles 2..3 are fetched by the second half of the waves' pieces
+            const int half = wave & 1;
+            t += 2 * half;
+            t = t < t1 ? t : t1 - 1;
+            row = t * 32 + lj;
+            row = row < n ? row : n - 1;
+            glds4(norms + row, xx_b + (uint32_t)((slot * (G * 32 < 64 ? 64 : G * 32) + half * 64) * 4));
+        }
+    };
+    int parked = 0;  // wave-uniform
+    // survivors of one tile (rare: ~k ln(n / sample) rows per query in all).  accq = dot + (thr >> 1) per result.
+    auto collect = [&](const i32x16 &accq, int xx, int64_t row, bool cand) {
+        uint32_t hit = 0;
+        if (cand && row < n) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int th = thr_s[wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk];
+                const int dot = accq[e] - (th >> 1);
+                hit |= (xx - 2 * dot <= th ? 1u : 0u) << e;   // distance - |q'|^2 <= tau - |q'|^2, exact
+            }
+        }
+        while (__any(hit != 0)) {
+            const unsigned long long m = __ballot(hit != 0);
+            const int cnt = __popcll(m);
+            if (parked + cnt > PBUF) {  // flush (wave-uniform branch)
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(pair_cnt, (uint32_t)parked);
+                base = __shfl(base, 0, 64);
+                for (int i = lane; i < parked; i += 64)
+                    if (base + i < pair_cap) pairs[base + i] = park_s[wave][i];
+                parked = 0;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ordinary traffic must not sit between counted DMA requests
+            }
+            if (hit) {
+                const int e = __ffs((int)hit) - 1;
+                hit &= hit - 1;
+                int asel = accq[0];
+#pragma unroll
+                for (int j = 1; j < 16; ++j) asel = e == j ? accq[j] : asel;
+                const int ql = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                const int dot = asel - (thr_s[ql] >> 1);
+                park_s[wave][parked + __popcll(m & ((1ull << lane) - 1))] =
+                    make_uint4((uint32_t)(qb_id * QPB + ql), (uint32_t)row, (uint32_t)(xx - 2 * dot + qq_s[ql]), 0u);
+            }
+            parked += cnt;
+        }
+    };
+    request(0, 0);
+    request(n_groups > 1 ? 1 : 0, 1);   // always two groups of requests: the counted waits below rely on it
+    // The reduction of group g - 1's results (8 v_max3 per tile) is issued between the matrix instructions of group g (second
+    // accumulator set): the matrix pipe of a SIMD is shared by two waves, what a wave does between its own matrix instructions is free.
+    constexpr int PD = KS >= 8 ? 4 : (KS >= 4 ? 2 : 1);   // K steps of operand reads in flight ahead of the matrix instructions
+    constexpr int MPS = (8 * G + KS - 1) / KS;            // v_max3 per K step
+    i32x16 prev[G];
+    int xx_prev[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        xx_prev[u] = 0x7fffffff;
+        prev[u] = thrh;
+    }
+    for (int64_t g = 0; g < n_groups; ++g) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");  // own share of group g has landed (g + 1 may be in flight)
+        __builtin_amdgcn_s_barrier();                                // everyone's share has; everyone is done with group g - 1
+        request(g + 2 < n_groups ? g + 2 : n_groups - 1, (int)((g + 2) % NB));  // into the slot group g - 1 occupied (past the end: a duplicate nobody reads)
+        const int slot = (int)(g % NB);
+        const i32x4 *pb = reinterpret_cast<const i32x4 *>(gf_ring) + (size_t)slot * G * KS * 64 + lane;
+        int xx_cur[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) xx_cur[u] = xx_s[slot][u * 32 + lj];
+        i32x16 acc[C];
+        int mx[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) mx[u] = (int)0x80000000;
+        i32x4 bv[G][KS];
+#pragma unroll
+        for (int s_ = 0; s_ < PD; ++s_)
+#pragma unroll
+            for (int u = 0; u < G; ++u) bv[u][s_] = pb[(u * KS + s_) * 64];
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            if (s_ + PD < KS) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) bv[u][s_ + PD] = pb[(u * KS + s_ + PD) * 64];
+            }
+            if constexpr (G == 1) {   // one tile: even and odd K steps are the two chains (summed below)
+                const i32x16 zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+                acc[s_ & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qreg[s_], bv[0][s_], s_ == 0 ? thrh : (s_ == 1 ? zero : acc[s_ & 1]), 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int u = 0; u < G; ++u)   // G independent chains: consecutive matrix instructions never wait for each other
+                    acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qreg[s_], bv[u][s_], s_ == 0 ? thrh : acc[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < MPS; ++j) {
+                const int idx = s_ * MPS + j;   // max3 number idx of the 8 G: tile idx / 8, results 2 (idx % 8), + 1
+                if (idx < 8 * G) {
+                    const int u2 = idx >> 3, e = (idx & 7) * 2;
+                    const int m2 = prev[u2][e] > prev[u2][e + 1] ? prev[u2][e] : prev[u2][e + 1];
+                    mx[u2] = mx[u2] > m2 ? mx[u2] : m2;
+                }
+            }
+        }
+        // pin the issue order: PD steps of operand reads up front, then per K step {G reads, G matrix instructions, the max3s}
+        __builtin_amdgcn_sched_group_barrier(0x100, G * PD, 0);
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            if (s_ + PD < KS) __builtin_amdgcn_sched_group_barrier(0x100, G, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, G, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, MPS, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int64_t t = t0 + (g - 1) * G + u;
+            const bool cand = mx[u] >= (xx_prev[u] >> 1) && t < t1;     // xx_prev = INT_MAX before the first group: nothing passes
+            if (__any(cand)) collect(prev[u], xx_prev[u], t * 32 + lj, cand);
+            if constexpr (G == 1) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) prev[0][e] = acc[0][e] + acc[1][e];
+            } else {
+                prev[u] = acc[u];
+            }
+            xx_prev[u] = xx_cur[u];
+        }
+    }
+    {   // the last group's tests
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            int m = prev[u][0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) m = m > prev[u][e] ? m : prev[u][e];
+            const int64_t t = t0 + (n_groups - 1) * G + u;
+            const bool cand = m >= (xx_prev[u] >> 1) && t < t1;
+            if (__any(cand)) collect(prev[u], xx_prev[u], t * 32 + lj, cand);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (parked) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(pair_cnt, (uint32_t)parked);
+        base = __shfl(base, 0, 64);
+        for (int i = lane; i < parked; i += 64)
+            if (base + i < pair_cap) pairs[base + i] = park_s[wave][i];
+    }
+}
+
 // one workgroup per query: (distance, row) sort of the survivors and the sample's k results; distances are int32 bits
 __global__ __launch_bounds__(kBlock) void flat_u8_finish_kernel(const uint32_t *__restrict__ cand_cnt, const float *__restrict__ cand_d,
                                                                 const int32_t *__restrict__ cand_row, int cap, int k,
@@ -577,6 +834,10 @@ __global__ __launch_bounds__(kBlock) void flat_u8_finish_kernel(const uint32_t *
     }
 }
 
+static int g_u8_gfilter = 1;  // cvtmi_set_tuning("flat_u8_gfilter"): 1 = the software-pipelined filter kernel where it applies (D = 64 .. 512, power of two)
+void set_flat_u8_gfilter(int v) { g_u8_gfilter = v; }  // 0 off, 1 choose, 2 two 4-wave workgroups per CU, 3 one 8-wave workgroup per CU
+bool flat_u8_gfilter_shape(int D) { return g_u8_gfilter && (D == 64 || D == 128 || D == 256 || D == 512); }
+
 bool flat_u8_filter_applies(int D, int64_t n, int64_t nq, int k)
 {
     return D % 32 == 0 && D >= 32 && D <= 512 && nq >= 256 && n >= 262144 && k <= 64;
@@ -597,6 +858,35 @@ int launch_flat_u8_filter(const uint8_t *q, int64_t nq, int D, const uint4 *pack
 {
     const int64_t tile_begin = row_begin / 32, tile_end = (n + 31) / 32;
     if (tile_end <= tile_begin) return CVTMI_OK;
+    if (flat_u8_gfilter_shape(D)) {  // the software-pipelined kernel
+        const bool two = g_u8_gfilter == 2;   // two 4-wave workgroups per CU: measured 15 % slower than one 8-wave workgroup (16 matrix instructions per barrier)
+        const int qpb = two ? 128 : 256;
+        const int64_t qblocks = (nq + qpb - 1) / qpb;
+        const int64_t want = two ? 512 : 256;                                     // workgroups resident at a time
+        int64_t splits = std::max<int64_t>(1, (want + qblocks - 1) / qblocks);
+        int64_t tps = std::max<int64_t>(64, (tile_end - tile_begin + splits - 1) / splits);
+        splits = (tile_end - tile_begin + tps - 1) / tps;
+        const int64_t splits8 = (splits + 7) / 8 * 8;
+        if (splits8 * qblocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "flat u8 filter: nq too large");
+        const dim3 g((unsigned)(splits8 * qblocks));
+#define CVTMI_GF(N, NW, G)                                                                                                        \
+    do {                                                                                                                         \
+        const size_t lds = (size_t)3 * (G) * (N) * 64 * sizeof(uint4);                                                           \
+        CVTMI_HIP(hipFuncSetAttribute((const void *)flat_u8_gfilter_kernel<N, NW, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((flat_u8_gfilter_kernel<N, NW, G>), g, dim3(64 * (NW)), lds, st, q, nq, pack, norms, n, sample_d, k, tile_begin, tile_end, \
+                           tps, pair_cap, pair_cnt, pairs, (int)qblocks);                                                        \
+    } while (0)
+        switch (D / 32) {
+            case 2: CVTMI_GF(2, 8, 4); break;
+            case 4: if (two) CVTMI_GF(4, 4, 1); else CVTMI_GF(4, 8, 2); break;
+            case 8: if (two) CVTMI_GF(8, 4, 1); else CVTMI_GF(8, 8, 2); break;
+            case 16: if (two) CVTMI_GF(16, 4, 1); else CVTMI_GF(16, 8, 2); break;
+            default: return fail(CVTMI_EUNSUPPORTED, "flat u8 pipelined filter: D=%d (64, 128, 256 or 512)", D);
+        }
+#undef CVTMI_GF
+        CVTMI_HIP(hipGetLastError());
+        return CVTMI_OK;
+    }
     const bool wide = nq >= 1024;  // 16 waves: 512 queries per workgroup
     const int qpb = wide ? 512 : 256;
     const int64_t qblocks = (nq + qpb - 1) / qpb;

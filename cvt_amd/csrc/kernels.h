@@ -118,6 +118,8 @@ int launch_flat_u8_mfma(int D, const uint8_t *data, const int32_t *norms, int64_
                         int splits, float *part_d, int64_t *part_id, uint32_t *gthr, hipStream_t st);
 // ids[i] = ids[i] >= 0 ? labels[ids[i]] : -1
 void set_flat_u8_opt(int v);
+void set_flat_u8_gfilter(int v);   // flat_mfma.hip: the software-pipelined (LDS-DMA) uint8 filter kernel on / off
+bool flat_u8_gfilter_shape(int D);
 int launch_gather_labels(int64_t *ids, int64_t count, const int64_t *labels, hipStream_t st);
 
 // ---- sq8.hip ----

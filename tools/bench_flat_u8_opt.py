@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""uint8 L2 flat search, row-tile kernel measurement variants (cvtmi_set_tuning("flat_u8_opt", 0..3)), config 3 shape."""
+"""uint8 L2 flat search at the config 3 shape: row-tile kernels vs the filter pipeline with the old / the software-pipelined
+(LDS-DMA) filter kernel.  Results compared bit for bit."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,12 +12,11 @@ ix = cvt_amd.FlatIndex(2, D)
 for a in range(0, n, 1 << 21):
     ix.add(torch.randint(0, 256, (min(n, a + (1 << 21)) - a, D), generator=g, device=dev, dtype=torch.uint8))
 qs = torch.randint(0, 256, (4096, D), generator=g, device=dev, dtype=torch.uint8)
-cvt_amd.set_tuning("flat_variant", 1)
-for nq, k in ((4096, 10), (1000, 10)):
+for nq, k in ((4096, 10), (1000, 10), (512, 10), (256, 10)):
     q = qs[:nq].contiguous()
     ref = None
-    for opt in [int(v) for v in os.environ.get("OPTS", "0,1,2,3,0").split(",")]:
-        cvt_amd.set_tuning("flat_u8_opt", opt)
+    for name, fv, gf in (("row-tile", 1, 0), ("filter(old kernel)", 2, 0), ("filter(8 waves x1)", 2, 3), ("filter(4 waves x2)", 2, 2), ("row-tile", 1, 0)):
+        cvt_amd.set_tuning("flat_variant", fv); cvt_amd.set_tuning("flat_u8_gfilter", gf)
         out = ix.search(q, k); torch.cuda.synchronize()
         if ref is None: ref = out
         same = bool(torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]))
@@ -25,5 +25,6 @@ for nq, k in ((4096, 10), (1000, 10)):
         for _ in range(reps): ix.search(q, k)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / reps * 1e3
-        print("flat L2 u8 %d-d n=%d nq=%d k=%d opt=%d: %.3f ms  %.0f QPS  %.0f TOP/s  same=%s" % (D, n, nq, k, opt, ms, nq / ms * 1e3, 2.0 * n * D * nq / ms / 1e9, same), flush=True)
-cvt_amd.set_tuning("flat_u8_opt", 0); cvt_amd.set_tuning("flat_variant", 0)
+        print("flat L2 u8 %d-d n=%d nq=%d k=%d %-20s: %.3f ms  %.0f QPS  %.0f TOP/s  filtered=%s same=%s" % (
+            D, n, nq, k, name, ms, nq / ms * 1e3, 2.0 * n * D * nq / ms / 1e9, ix.last_search()[0], same), flush=True)
+cvt_amd.set_tuning("flat_variant", 0); cvt_amd.set_tuning("flat_u8_gfilter", 1)
