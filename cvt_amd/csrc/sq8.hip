@@ -25,6 +25,8 @@
 //    operands outside the guarded range take __fdiv_rn.
 //  * decode divides by the constant 255.0 in double the same way (3 full-rate fp64 ops instead of a ddiv).
 //  * rows of other widths take the two-pass kernels at the bottom (norms, then an element-wise pass).
+#include <algorithm>
+
 #include "div_rn.h"
 #include "kernels.h"
 
@@ -458,6 +460,89 @@ __global__ __launch_bounds__(kBlock) void sq8_train_kernel(const float *__restri
     }
 }
 
+// ---- train with normalisation, d = 256 / 512: one WAVE per row, no LDS tile, no barriers in the row loop --------------
+// The tile kernel above is built for encode (every element is read back from LDS by another thread).  Training only needs
+// min / max of x / |x| per column: a wave reads a whole row (NF float4 per lane, one coalesced 1-2 KB piece), adds the squares
+// in double (any order: the same proof as in the tile kernel -- when the float roots of sum (1 -+ 2^-42) coincide that float is
+// the reference's root; otherwise lane order is replayed, rare), divides its own elements by the row norm and keeps running
+// min / max of ITS columns in registers.  Rows are prefetched two ahead; nothing synchronises until the end, where the waves
+// of a workgroup fold their column extremes through LDS before one atomic per column.  HBM traffic = the 4 d bytes per row.
+template <int NF>
+__global__ __launch_bounds__(kBlock) void sq8_train_wave_kernel(const float *__restrict__ x, int64_t n, uint32_t *kmin,
+                                                                uint32_t *kmax)
+{
+    constexpr int CG = 64 * NF, D = 4 * CG;
+    __shared__ uint32_t smin[D], smax[D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < D; c += kBlock) { smin[c] = 0xffffffffu; smax[c] = 0u; }
+    __syncthreads();
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    const int64_t nw = (int64_t)gridDim.x * (kBlock / 64), w0 = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    float4 mn[NF], mx[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        mn[i] = make_float4(__uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u));
+        mx[i] = make_float4(__uint_as_float(0xff800000u), __uint_as_float(0xff800000u), __uint_as_float(0xff800000u), __uint_as_float(0xff800000u));
+    }
+    constexpr int PF = 3;  // rows in flight per wave
+    float4 v[PF][NF];
+    auto fetch = [&](int64_t row, float4 (&o)[NF]) {
+        const int64_t r = row < n ? row : n - 1;  // clamped: the tail re-reads the last row, which changes no extreme
+#pragma unroll
+        for (int i = 0; i < NF; ++i) o[i] = x4[r * CG + lane + 64 * i];
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) fetch(w0 + p * nw, v[p]);
+    for (int64_t row = w0; row < n; row += PF * nw) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            float4 cur[NF];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) cur[i] = v[p][i];
+            fetch(row + (p + PF) * nw, v[p]);
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                s += (double)__fmul_rn(cur[i].x, cur[i].x); s += (double)__fmul_rn(cur[i].y, cur[i].y);
+                s += (double)__fmul_rn(cur[i].z, cur[i].z); s += (double)__fmul_rn(cur[i].w, cur[i].w);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+            const double rlo = __dsqrt_rn(s * (1.0 - 0x1p-42)), rhi = __dsqrt_rn(s * (1.0 + 0x1p-42));
+            float den = (float)(rlo > 1e-12 ? rlo : 1e-12);
+            const float fhi = (float)(rhi > 1e-12 ? rhi : 1e-12);
+            if (!(den == fhi)) {  // wave-uniform (s is): not proven, or not finite -- the reference's own order (int8_quan.cc:48-51)
+                const int64_t r = row + p * nw < n ? row + p * nw : n - 1;
+                double accum = 0.0;
+                for (int e = 0; e < D; ++e) {
+                    const float t = x[r * D + e];
+                    accum += (double)__fmul_rn(t, t);
+                }
+                const double nrm = __dsqrt_rn(accum);
+                den = (float)(nrm > 1e-12 ? nrm : 1e-12);
+            }
+            const DivBy dd = div_by(den);
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const float a0 = div_rn(cur[i].x, dd), a1 = div_rn(cur[i].y, dd), a2 = div_rn(cur[i].z, dd), a3 = div_rn(cur[i].w, dd);
+                mn[i].x = a0 < mn[i].x ? a0 : mn[i].x; mn[i].y = a1 < mn[i].y ? a1 : mn[i].y;
+                mn[i].z = a2 < mn[i].z ? a2 : mn[i].z; mn[i].w = a3 < mn[i].w ? a3 : mn[i].w;
+                mx[i].x = a0 > mx[i].x ? a0 : mx[i].x; mx[i].y = a1 > mx[i].y ? a1 : mx[i].y;
+                mx[i].z = a2 > mx[i].z ? a2 : mx[i].z; mx[i].w = a3 > mx[i].w ? a3 : mx[i].w;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int c = 4 * (lane + 64 * i);
+        const float lo[4] = { mn[i].x, mn[i].y, mn[i].z, mn[i].w }, hi[4] = { mx[i].x, mx[i].y, mx[i].z, mx[i].w };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { atomicMin(&smin[c + j], f32_key(lo[j])); atomicMax(&smax[c + j], f32_key(hi[j])); }
+    }
+    __syncthreads();
+    for (int c = tid; c < D; c += kBlock) { atomicMin(&kmin[c], smin[c]); atomicMax(&kmax[c], smax[c]); }
+}
+
 __global__ void sq8_train_finish_kernel(const uint32_t *kmin, const uint32_t *kmax, int d, float *vmin, float *vdiff)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -475,7 +560,13 @@ int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_sc
     const unsigned db = (unsigned)((d + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(sq8_train_init_kernel, dim3(db), dim3(kBlock), 0, st, kmin, kmax, d);
     if (n > 0) {
-        if (sq8_tile_ok(d, x, nullptr, nullptr, nullptr)) {
+        if (l2norm && (d == 256 || d == 512) && (((uintptr_t)x) & 15) == 0 && n >= 4096) {
+            // whole rows per wave, no LDS tile (the tile kernel's phases serialise behind its barriers: 3.3 TB/s at d = 512)
+            const int64_t rows_per_wg = kBlock / 64;
+            const unsigned blocks = (unsigned)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 256 * 8);
+            if (d == 512) hipLaunchKernelGGL((sq8_train_wave_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax);
+            else hipLaunchKernelGGL((sq8_train_wave_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax);
+        } else if (sq8_tile_ok(d, x, nullptr, nullptr, nullptr)) {
             Sq8Args a{};
             a.x = const_cast<float *>(x); a.kmin = kmin; a.kmax = kmax; a.n = n; a.d = d; a.l2norm = l2norm;
             CVTMI_TRY(launch_sq8_tile<true>(a, st));

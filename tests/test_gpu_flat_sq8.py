@@ -171,6 +171,28 @@ def test_config3_full_size(amd, orc):
     ix.close()
 
 
+@pytest.mark.parametrize("d", [512, 256])
+def test_sq8_train_wave_kernel(amd, orc, d):
+    """Training with normalisation at d = 256 / 512 and >= 4096 rows takes the wave-per-row kernel: min / max - min must equal
+    the oracle's bit for bit, including rows whose norm needs the index-order sum (huge dynamic range), zero rows and a
+    non-finite row."""
+    import torch
+    rng = np.random.default_rng(d)
+    n = 20_000 + 37
+    x = np.abs(rng.normal(size=(n, d))).astype(np.float32)
+    x[5] = 0
+    x[17] *= 1e-30; x[18] *= 1e18
+    x[100:600] *= np.exp(rng.normal(size=(500, 1)) * 8).astype(np.float32)      # wide range of norms
+    x[700:1200] = (x[700:1200] * np.exp(rng.normal(size=(500, d)) * 6)).astype(np.float32)   # wide range inside a row
+    vmin, vdiff = amd.sq8_train(torch.from_numpy(x).cuda(), l2norm=True)
+    ovmin, ovdiff = orc.sq8_train(x, l2norm=True)
+    assert np.array_equal(bits(vmin.cpu().numpy()), bits(ovmin)) and np.array_equal(bits(vdiff.cpu().numpy()), bits(ovdiff))
+    x[9, 3] = np.inf
+    vmin, vdiff = amd.sq8_train(torch.from_numpy(x).cuda(), l2norm=True)
+    ovmin, ovdiff = orc.sq8_train(x, l2norm=True)
+    assert np.array_equal(bits(vmin.cpu().numpy()), bits(ovmin)) and np.array_equal(bits(vdiff.cpu().numpy()), bits(ovdiff))
+
+
 def test_sq8_parity(amd, orc, golden):
     rng = np.random.default_rng(8)
     for d in (64, 512, 300):
