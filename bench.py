@@ -148,7 +148,7 @@ def main():
                 b = min(r1, a + step)
                 x = synth.sift_like(b - a, D, seed=seed, row_begin=a, device=dev)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
-                _, codes = ix.encode(ix.rotate(x))
+                _, codes = ix.rotate_encode(x)
                 ix.add_codes(codes)
                 torch.cuda.synchronize(); t_acc += time.perf_counter() - t0  # data generation excluded
                 rows_done += b - a
@@ -241,7 +241,7 @@ def main():
                          "lds_lookups_per_s": round(lookups / 1e12, 2),
                          "lds_frac": round(lds_bytes / lds_peak, 4),
                          "lds_frac_what": "table look-ups/s x 2 B per look-up / (256 B/clk/CU x 256 CU x 2.4 GHz)"},
-            "encode": {"rows_per_s": round(enc_rows / enc_time, 1), "what": "rotate (MFMA GEMM) + PQ encode + append of the 1 M rows"},
+            "encode": {"rows_per_s": round(enc_rows / enc_time, 1), "what": "rotate (MFMA GEMM) + PQ encode (cvtmi_opq_rotate_encode) + append of the 1 M rows"},
         }
         if args.large_rows > 0:
             try:
@@ -411,8 +411,8 @@ def secondary(args, dev, books, R):
     sec["encode"] = {"rows": n, "ms": round(ms, 4), "rows_per_s": round(n / (ms * 1e-3), 1), "what": "PQ encode of rotated rows, M=%d K=256 (bf16 matrix-core filter + exact chain)" % M}
     try:
         ms = _ev_ms(torch, lambda: ix.rotate_encode(x))
-        sec["rotate_encode_fused"] = {"rows": n, "ms": round(ms, 4), "rows_per_s": round(n / (ms * 1e-3), 1),
-                                      "what": "raw rows -> codes in one kernel (rotation in registers, no 1 KB/row round trip)"}
+        sec["rotate_encode"] = {"rows": n, "ms": round(ms, 4), "rows_per_s": round(n / (ms * 1e-3), 1),
+                                      "what": "raw rows -> codes in one call: rotation and encode chunk by chunk through a cache-resident scratch (cvtmi_opq_rotate_encode)"}
     except AttributeError:
         pass
     ix.close(); del x, xr

@@ -119,6 +119,21 @@ class OpqIndex:
         _check(lib().cvtmi_opq_encode(self.h, _ptr(x_rot), C.c_int64(n), _ptr(lists), _ptr(codes)))
         return lists, codes
 
+    def rotate_encode(self, x):
+        """rotate + encode of RAW rows (cvtmi_opq_rotate_encode): (list ids, codes)"""
+        n = x.shape[0]
+        if _is_torch(x):
+            import torch
+            lists = torch.empty(n, dtype=torch.int32, device=x.device)
+            codes = torch.empty((n, self.M), dtype=torch.uint8, device=x.device)
+            _check(lib().cvtmi_opq_rotate_encode_dev(self.h, _ptr(x), C.c_int64(n), _ptr(lists), _ptr(codes), _stream()))
+            return lists, codes
+        x = _np(x, np.float32)
+        lists = np.empty(n, dtype=np.int32)
+        codes = np.empty((n, self.M), dtype=np.uint8)
+        _check(lib().cvtmi_opq_rotate_encode(self.h, _ptr(x), C.c_int64(n), _ptr(lists), _ptr(codes)))
+        return lists, codes
+
     # ---- index ----
     def add_codes(self, codes, list_id=None, video_id=None):
         n = codes.shape[0]

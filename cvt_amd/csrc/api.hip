@@ -63,7 +63,7 @@ struct cvtmi_opq_s {
     int64_t csr_kept = 0, csr_longest = 0;  // entries in the CSR copy (list ids outside [0, coarseK) are dropped), longest list
     int32_t csr_vmin = 0, csr_vmax = -1;    // range of the video ids it holds
     // scratch
-    DevBuf s_qrot, s_part_d, s_part_id, s_probe, s_lut, s_gthr;
+    DevBuf s_qrot, s_part_d, s_part_id, s_probe, s_lut, s_gthr, s_rot;
     // tuning / measurement
     int p_splits = 0, p_qtile = 0, p_profile = 0, p_variant = 3;
     int p_encode = 0;  // 0 = choose, 1 = VALU encode, 2 = matrix-core filter + exact resolution
@@ -196,7 +196,7 @@ int cvtmi_opq_destroy(cvtmi_opq_t h)
     if (h->d_perm) (void)hipFree(h->d_perm);
     h->codes.release(); h->lists.release(); h->videos.release(); h->codes_rot.release();
     h->csr_codes.release(); h->csr_videos.release(); h->csr_off.release(); h->csr_scratch.release(); h->csr_stats.release();
-    h->s_qrot.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_probe.release(); h->s_lut.release(); h->s_gthr.release();
+    h->s_qrot.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_probe.release(); h->s_lut.release(); h->s_gthr.release(); h->s_rot.release();
     for (int e = 0; e < cvtmi_opq_s::kEvRing; ++e) {
         if (h->ev0[e]) (void)hipEventDestroy(h->ev0[e]);
         if (h->ev1[e]) (void)hipEventDestroy(h->ev1[e]);
@@ -260,6 +260,42 @@ int cvtmi_opq_encode(cvtmi_opq_t h, const float *x_rot, int64_t n, int32_t *list
     CVTMI_TRY(dl.alloc((size_t)n * sizeof(int32_t)));
     CVTMI_TRY(dc.alloc((size_t)n * h->m.M));
     CVTMI_TRY(cvtmi_opq_encode_dev(h, dx.as<float>(), n, dl.as<int32_t>(), dc.as<uint8_t>(), nullptr));
+    CVTMI_HIP(hipMemcpy(codes, dc.p, (size_t)n * h->m.M, hipMemcpyDeviceToHost));
+    if (list_id) CVTMI_HIP(hipMemcpy(list_id, dl.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
+// Rotation + encode of raw rows without a caller-side buffer of rotated rows: the rows go through a handle-owned scratch in
+// chunks of 128 K rows (64 MB at D = 128) that is reused for every chunk, so the rotated rows live in the 256 MB Infinity
+// Cache between the two kernels and their 2 x 4 D bytes per row need not reach HBM.  (The two kernels are bound by different
+// pipes -- fp32 matrix cores vs VALU -- but the encode kernel owns the whole register file of its CU, so they cannot share a CU;
+// a single fused kernel would have to give up the encode's software pipeline for the rotation's accumulators.)
+int cvtmi_opq_rotate_encode_dev(cvtmi_opq_t h, const float *x, int64_t n, int32_t *list_id, uint8_t *codes, void *stream)
+{
+    CHECK_H_SERIAL(h, stream);
+    if (n < 0 || (n > 0 && (!x || !codes))) return fail(CVTMI_EINVAL, "cvtmi_opq_rotate_encode: bad arguments");
+    if (n == 0) return CVTMI_OK;
+    if (!h->m.perm && !h->m.R) return cvtmi_opq_encode_dev(h, x, n, list_id, codes, stream);
+    const int64_t chunk = 131072;
+    CVTMI_TRY(h->s_rot.reserve((size_t)std::min(n, chunk) * h->m.D * sizeof(float)));
+    for (int64_t a = 0; a < n; a += chunk) {
+        const int64_t m = std::min(chunk, n - a);
+        CVTMI_TRY(cvtmi_opq_rotate_dev(h, x + a * h->m.D, m, h->s_rot.as<float>(), stream));
+        CVTMI_TRY(cvtmi_opq_encode_dev(h, h->s_rot.as<float>(), m, list_id ? list_id + a : nullptr, codes + a * h->m.M, stream));
+    }
+    return CVTMI_OK;
+}
+
+int cvtmi_opq_rotate_encode(cvtmi_opq_t h, const float *x, int64_t n, int32_t *list_id, uint8_t *codes)
+{
+    CHECK_H_SERIAL(h, nullptr);
+    if (n < 0 || (n > 0 && (!x || !codes))) return fail(CVTMI_EINVAL, "cvtmi_opq_rotate_encode: bad arguments");
+    if (n == 0) return CVTMI_OK;
+    Tmp dx, dl, dc;
+    CVTMI_TRY(dx.upload(x, (size_t)n * h->m.D * sizeof(float)));
+    CVTMI_TRY(dl.alloc((size_t)n * sizeof(int32_t)));
+    CVTMI_TRY(dc.alloc((size_t)n * h->m.M));
+    CVTMI_TRY(cvtmi_opq_rotate_encode_dev(h, dx.as<float>(), n, dl.as<int32_t>(), dc.as<uint8_t>(), nullptr));
     CVTMI_HIP(hipMemcpy(codes, dc.p, (size_t)n * h->m.M, hipMemcpyDeviceToHost));
     if (list_id) CVTMI_HIP(hipMemcpy(list_id, dl.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return CVTMI_OK;

@@ -103,6 +103,13 @@ int cvtmi_opq_encode(cvtmi_opq_t h, const float *x_rot, int64_t n, int32_t *list
 int cvtmi_opq_encode_dev(cvtmi_opq_t h, const float *x_rot, int64_t n, int32_t *list_id, uint8_t *codes,
                          void *stream);
 
+/* LoadSingleFeatFile's reorder + Add's encode (IVFOPQ.cpp:459-461 + :107-163) on RAW rows in one call: what cvtmi_opq_rotate followed
+ * by cvtmi_opq_encode computes, without a caller-side buffer of rotated rows (they pass through a cache-resident scratch of the
+ * handle).  Same codes and list ids. */
+int cvtmi_opq_rotate_encode(cvtmi_opq_t h, const float *x, int64_t n, int32_t *list_id, uint8_t *codes);
+int cvtmi_opq_rotate_encode_dev(cvtmi_opq_t h, const float *x, int64_t n, int32_t *list_id, uint8_t *codes,
+                                void *stream);
+
 /* m_ivfList[vw].push_back(elem) of Add (IVFOPQ.cpp:167): append n entries to the resident index.
  * list_id NULL = list 0 (only valid when coarseK == 1); video_id NULL = one "video" per entry,
  * numbered by insertion order.  Entry ids are id_base + insertion index. */

@@ -429,3 +429,25 @@ def test_scan_lazy_selection_and_shared_thresholds(amd, orc):
         d, i = idx.search(q2, 100, rotate=False)
         assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od)), splits
     idx.close()
+
+
+def test_rotate_encode_one_call(amd, orc):
+    """cvtmi_opq_rotate_encode = rotate then encode, chunked through the handle's scratch (several chunks, a ragged tail,
+    permutation and dense rotation, coarse lists, host and device entry points)."""
+    import torch
+    from cvt_amd import synth
+    D, M, K = 128, 16, 256
+    rng = np.random.default_rng(321)
+    books = synth_model(rng, D, M, K)
+    for coarseK, rot in ((1, "R"), (7, "perm")):
+        coarse = np.zeros((1, D), np.float32) if coarseK == 1 else rng.normal(size=(coarseK, D)).astype(np.float32)
+        kw = {"R": synth.random_rotation(D, seed=5)} if rot == "R" else {"perm": synth.random_permutation(D, seed=5)}
+        idx = amd.OpqIndex(coarse, books, **kw)
+        n = 131072 * 2 + 777
+        x = torch.from_numpy(rng.normal(size=(n, D)).astype(np.float32)).cuda()
+        l0, c0 = idx.encode(idx.rotate(x))
+        l1, c1 = idx.rotate_encode(x)
+        assert torch.equal(c0, c1) and torch.equal(l0, l1)
+        l2, c2 = idx.rotate_encode(x[:5000].cpu().numpy())
+        assert np.array_equal(c2, c0[:5000].cpu().numpy()) and np.array_equal(l2, l0[:5000].cpu().numpy())
+        idx.close()
