@@ -139,6 +139,11 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         g_flat_variant = (int)value;
         return CVTMI_OK;
     }
+    if (!strcmp(name, "probe_variant")) {
+        if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: probe_variant must be 0, 1 or 2");
+        set_probe_variant((int)value);
+        return CVTMI_OK;
+    }
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_opt")) {
         if (value < 0 || value > 3) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_u8_opt must be 0..3");

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <mutex>
 
+#include "block_topk.h"
 #include "common.h"
 #include "kernels.h"
 
@@ -218,6 +219,214 @@ __global__ __launch_bounds__(kBlock) void assign_scatter_kernel(const int32_t *_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Coarse top-nk of IVFOPQ::Query (IVFOPQ.cpp:238-260) through the same filter: the nk nearest of coarseK centroids per query
+// frame, by the reference's sequential fp32 distance, (distance, index) order.
+//   score    T[query][centroid] = q.c - |c|^2/2 for every pair, on the matrix cores (the products of assign_filter_kernel with the
+//            operand roles swapped: D[query i][centroid j], so a lane holds one centroid column and 16 queries, and a store
+//            instruction writes two 128-byte runs of one query's row)
+//   select   one workgroup per query: theta = the nk-th largest T; a centroid with T < theta - 2^-13 Q is beaten by nk others in
+//            the reference's own arithmetic (the assignment's pairwise bound: 2 x 524 uQ of filter error + 131 uQ of reference
+//            rounding < 2048 uQ), so only the few with T >= theta - 2^-13 Q get the reference's distance chain; those are sorted
+//            by (distance, index).  A query whose candidate list overflows (near-equidistant centroids), or whose magnitudes
+//            leave the bound's range (non-finite values), walks all centroids exactly inside the same workgroup.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(AF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void probe_score_kernel(const float *__restrict__ x, int64_t ld, int64_t n,
+                                                                 const uint4 *__restrict__ packA, const uint32_t *__restrict__ nhcp, int ntiles,
+                                                                 float *__restrict__ T, int64_t ldT)
+{
+    constexpr int WAVES = AF_THREADS / 64;
+    constexpr int TILE = NCH * 2 * 64;
+    constexpr int LPT = (TILE + AF_THREADS - 1) / AF_THREADS;
+    __shared__ uint4 tile_s[2][TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+    const int64_t nblk = (n + 32 * WAVES - 1) / (32 * WAVES);
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t row0 = (blk * WAVES + wave) * 32;
+        const int64_t row = row0 + li;
+        const int64_t rowc = row < n ? row : n - 1;
+        const float *xp = x + rowc * ld + 8 * lk;
+        bf16x8 r1[NCH], r2[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float v[8];
+            *reinterpret_cast<float4 *>(&v[0]) = *reinterpret_cast<const float4 *>(xp + 16 * c);
+            *reinterpret_cast<float4 *>(&v[4]) = *reinterpret_cast<const float4 *>(xp + 16 * c + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const __bf16 h = (__bf16)v[e];
+                r1[c][e] = h;
+                r2[c][e] = (__bf16)(v[e] - (float)h);
+            }
+        }
+        const bf16x8 bzero = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        bf16x8 ones = bzero;
+        ones[0] = lk ? (__bf16)0.0f : (__bf16)1.0f;
+        ones[1] = ones[0];
+        uint4 pre[LPT];
+        auto fetch = [&](int t) {
+            t = t < ntiles ? t : ntiles - 1;
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) {
+                int f = tid + i * AF_THREADS;
+                f = f < TILE ? f : TILE - 1;
+                pre[i] = packA[(int64_t)t * TILE + f];
+            }
+        };
+        fetch(0);
+        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            uint4 *stage = tile_s[t & 1];
+#pragma unroll
+            for (int i = 0; i < LPT; ++i)
+                if (tid + i * AF_THREADS < TILE) stage[tid + i * AF_THREADS] = pre[i];
+            fetch(t + 1);
+            const uint32_t hv = nhcp[t * 32 + li];
+            lds_barrier();
+            const uint4 *pa = stage + lane;
+            const f32x16 zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            f32x16 acc0 = zero, acc1 = zero;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {  // queries are the A side here: D[query i][centroid j], lane = centroid li
+                union { uint4 u; bf16x8 v; } a1, a2;
+                a1.u = pa[(c * 2 + 0) * 64];
+                a2.u = pa[(c * 2 + 1) * 64];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1[c], a1.v, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r2[c], a1.v, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1[c], a2.v, acc0, 0, 0, 0);
+            }
+            {
+                union { uint32_t u[4]; bf16x8 v; } ab = { { lk ? 0u : hv, 0u, 0u, 0u } };
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, ab.v, acc0, 0, 0, 0);  // - |c|^2 / 2 of centroid li
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t qrow = row0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                if (qrow < n) T[qrow * ldT + t * 32 + li] = acc0[e] + acc1[e];
+            }
+        }
+    }
+}
+
+constexpr int PS_CAND = 96;    // candidates per query that get an exact distance
+constexpr int PS_CAP = 1024;   // selection buffer of the theta pass
+constexpr int PS_TRIG = 768;
+
+__global__ __launch_bounds__(kBlock) void probe_select_kernel(const float *__restrict__ T, int64_t ldT, const float *__restrict__ q, int D,
+                                                              const float *__restrict__ coarse, int coarseK, const uint32_t *__restrict__ cmax2,
+                                                              int nprobe, int32_t *__restrict__ probe)
+{
+    extern __shared__ __attribute__((aligned(16))) float ps_q[];  // D floats
+    __shared__ TopKShared<1, PS_CAP> tk;
+    __shared__ int cand_s[PS_CAND];
+    __shared__ unsigned long long key_s[128];
+    __shared__ int ncand_s;
+    __shared__ float red_s[kBlock / 64];
+    const int64_t qi = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    float part = 0.0f;
+    for (int d = tid; d < D; d += kBlock) {
+        const float v = q[qi * D + d];
+        ps_q[d] = v;
+        part = __fmaf_rn(v, v, part);
+    }
+    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) red_s[tid >> 6] = part;
+    if (tid == 0) ncand_s = 0;
+    topk_init(tk);
+    __syncthreads();
+    float qq = 0.0f;
+    for (int w = 0; w < kBlock / 64; ++w) qq += red_s[w];
+    const float Q = (qq + __uint_as_float(*cmax2)) * 1.001f;
+    const bool bounded = Q < 0x1p30f && Q > 0x1p-60f;  // false for NaN / inf anywhere
+    auto exact_dist = [&](int c) -> float {  // the reference's chain (IVFOPQ.cpp:244-248)
+        const float *cp = coarse + (int64_t)c * D;
+        float acc = 0.0f;
+        for (int d = 0; d < D; ++d) {
+            const float t = __fsub_rn(ps_q[d], cp[d]);
+            acc = __fadd_rn(acc, __fmul_rn(t, t));
+        }
+        return acc;
+    };
+    bool exact_all = !bounded || nprobe > PS_CAND / 2;
+    if (!exact_all) {
+        // theta = the nprobe-th largest T of this query's row (keys ascending = T descending)
+        const float *Tr = T + qi * ldT;
+        int tile = 0;
+        for (int base = 0; base < coarseK; base += kBlock * 4, ++tile) {
+            uint32_t key[4][1];
+            uint32_t pay[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = base + r * kBlock + tid;
+                pay[r] = (uint32_t)c;
+                key[r][0] = KEY_MAX;
+                if (c < coarseK) {
+                    const uint32_t kk = ~f32_key(Tr[c]);
+                    key[r][0] = kk == KEY_MAX ? KEY_MAX - 1 : kk;
+                }
+            }
+            topk_tile<1, 4, PS_CAP, PS_TRIG>(tk, nprobe, tile, key, pay);
+        }
+        __syncthreads();
+        topk_compact<1, PS_CAP>(tk, nprobe);
+        const int cnt = tk.cnt[0];
+        const float theta = cnt >= nprobe ? key_f32(~(uint32_t)(tk.buf[0][nprobe - 1] >> 32)) : -__uint_as_float(0x7f800000u);
+        const float cut = theta - Q * 0x1p-13f;
+        for (int c = tid; c < coarseK; c += kBlock) {
+            if (Tr[c] >= cut) {
+                const int slot = atomicAdd(&ncand_s, 1);
+                if (slot < PS_CAND) cand_s[slot] = c;
+            }
+        }
+        __syncthreads();
+        const int nc = ncand_s;
+        if (nc > PS_CAND || nc < (nprobe < coarseK ? nprobe : coarseK)) exact_all = true;  // crowded band (or a NaN score hid a centroid)
+        else {
+            if (tid < 128) {
+                unsigned long long e = ~0ull;
+                if (tid < nc) e = ((unsigned long long)__float_as_uint(exact_dist(cand_s[tid])) << 32) | (uint32_t)cand_s[tid];
+                key_s[tid] = e;
+            }
+            __syncthreads();
+            for (int k2 = 2; k2 <= 128; k2 <<= 1)
+                for (int j = k2 >> 1; j > 0; j >>= 1) {
+                    if (tid < 128) {
+                        const int p = tid ^ j;
+                        if (p > tid) {
+                            const unsigned long long a = key_s[tid], b = key_s[p];
+                            const bool up = (tid & k2) == 0;
+                            if (up ? a > b : a < b) { key_s[tid] = b; key_s[p] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int i = tid; i < nprobe; i += kBlock) probe[qi * nprobe + i] = i < nc ? (int32_t)(uint32_t)key_s[i] : -1;
+        }
+    }
+    if (exact_all) {  // workgroup-uniform: every centroid through the reference's chain
+        __syncthreads();
+        topk_init(tk);
+        __syncthreads();
+        int tile = 0;
+        for (int base = 0; base < coarseK; base += kBlock, ++tile) {
+            const int c = base + tid;
+            uint32_t key[1][1] = { { KEY_MAX } };
+            uint32_t pay[1] = { (uint32_t)c };
+            if (c < coarseK) {
+                const uint32_t kk = __float_as_uint(exact_dist(c));
+                key[0][0] = kk == KEY_MAX ? KEY_MAX - 1 : kk;
+            }
+            topk_tile<1, 1, PS_CAP, PS_TRIG>(tk, nprobe, tile, key, pay);
+        }
+        __syncthreads();
+        topk_compact<1, PS_CAP>(tk, nprobe);
+        const int cnt = tk.cnt[0];
+        for (int i = tid; i < nprobe; i += kBlock) probe[qi * nprobe + i] = i < cnt ? (int32_t)(uint32_t)tk.buf[0][i] : -1;
+    }
+}
+
 // grow-only device scratch of this translation unit; calls that use it are serialised (they end in a stream
 // synchronisation anyway)
 struct AssignScratch {
@@ -306,6 +515,52 @@ int launch_assign_filtered(const float *x, int64_t ld, int64_t n, int d, const f
     (void)hipStreamSynchronize(st);  // the temporaries die with this frame
     (void)hipFree(tmp);
     return rc;
+}
+
+bool coarse_probe_filter_applies(const float *q, int64_t nq, int d, const float *cent, int k, int nprobe)
+{
+    return d >= 32 && d <= 128 && d % 16 == 0 && k >= 256 && nq >= 256 && nprobe <= PS_CAND / 2 && nq < 0x7fffffff &&
+           ((((uintptr_t)q) | ((uintptr_t)cent)) & 15) == 0;
+}
+
+// probe[nq][nprobe] = the nprobe nearest centroids per query, (distance, index) order, -1 padding
+int launch_coarse_probe_filtered(const float *q, int64_t nq, int d, const float *cent, int k, int nprobe, int32_t *probe, hipStream_t st)
+{
+    std::lock_guard<std::mutex> guard(g_scr_mutex);
+    const int nch = d / 16, ntiles = (k + 31) / 32;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const int64_t ldT = (int64_t)ntiles * 32;
+    const int64_t chunk = std::max<int64_t>(256, std::min<int64_t>(nq, (int64_t)((512ull << 20) / ((size_t)ldT * sizeof(float)))));
+    const size_t b_pack = up((size_t)ntiles * nch * 2 * 64 * sizeof(uint4)), b_nhc = up((size_t)ntiles * 32 * 4), b_misc = 256,
+                 b_T = up((size_t)chunk * ldT * sizeof(float));
+    CVTMI_TRY(g_scr.reserve(b_pack + b_nhc + b_misc + b_T));
+    char *base = static_cast<char *>(g_scr.p);
+    uint4 *packA = reinterpret_cast<uint4 *>(base);
+    uint32_t *nhcp = reinterpret_cast<uint32_t *>(base + b_pack);
+    uint32_t *cmax2 = reinterpret_cast<uint32_t *>(base + b_pack + b_nhc);
+    float *T = reinterpret_cast<float *>(base + b_pack + b_nhc + b_misc);
+    CVTMI_HIP(hipMemsetAsync(cmax2, 0, 8, st));
+    hipLaunchKernelGGL(assign_pack_kernel, dim3((unsigned)((ntiles * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, cent, k, d, ntiles,
+                       packA, nhcp, cmax2);
+    constexpr int rows_per_block = 32 * (AF_THREADS / 64);
+    for (int64_t a = 0; a < nq; a += chunk) {
+        const int64_t m = std::min(chunk, nq - a);
+        const int64_t blocks = std::min<int64_t>((m + rows_per_block - 1) / rows_per_block, 256 * 4);
+#define CVTMI_PS(N)                                                                                                                   \
+    case N:                                                                                                                           \
+        hipLaunchKernelGGL((probe_score_kernel<N>), dim3((unsigned)blocks), dim3(AF_THREADS), 0, st, q + a * d, (int64_t)d, m, packA, nhcp, ntiles, T, ldT); \
+        break;
+        switch (nch) {
+            CVTMI_PS(2) CVTMI_PS(3) CVTMI_PS(4) CVTMI_PS(5) CVTMI_PS(6) CVTMI_PS(7) CVTMI_PS(8)
+            default: return fail(CVTMI_EUNSUPPORTED, "probe filter: d=%d", d);
+        }
+#undef CVTMI_PS
+        hipLaunchKernelGGL(probe_select_kernel, dim3((unsigned)m), dim3(kBlock), (size_t)d * sizeof(float), st, T, ldT, q + a * d, d, cent, k,
+                           cmax2, nprobe, probe + a * nprobe);
+        CVTMI_HIP(hipGetLastError());
+    }
+    CVTMI_HIP(hipStreamSynchronize(st));  // the shared scratch is free for the next caller when the lock is dropped
+    return CVTMI_OK;
 }
 
 }  // namespace cvtmi

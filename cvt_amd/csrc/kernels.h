@@ -68,6 +68,10 @@ int launch_topk_merge_gathered(const float *in_d, const int64_t *in_id, int64_t 
 // probe[nq][nprobe] list ids in visiting order; list_off[coarseK+1]; codes/video_id in list order.
 int launch_coarse_probe(const OpqModelDev &m, const float *q_rot, int64_t nq, int nprobe, int32_t *probe,
                         hipStream_t st);
+// coarse top-nprobe through the matrix-core filter (assign_mfma.hip): same probes as the exact kernels
+void set_probe_variant(int v);
+bool coarse_probe_filter_applies(const float *q, int64_t nq, int d, const float *cent, int k, int nprobe);
+int launch_coarse_probe_filtered(const float *q, int64_t nq, int d, const float *cent, int k, int nprobe, int32_t *probe, hipStream_t st);
 int launch_query_video(const OpqModelDev &m, const float *q_rot, int64_t nq, int nprobe, const int32_t *probe,
                        const int64_t *list_off, const uint8_t *codes, const int32_t *video_id, int img_num,
                        float *match_score, int64_t longest_list, hipStream_t st);

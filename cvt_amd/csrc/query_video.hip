@@ -117,8 +117,13 @@ __global__ __launch_bounds__(kBlock) void coarse_probe_tile_kernel(const float *
     }
 }
 
+static int g_probe_variant = 0;  // cvtmi_set_tuning("probe_variant"): 0 choose, 1 exact kernels only, 2 matrix-core filter wherever it applies
+void set_probe_variant(int v) { g_probe_variant = v; }
+
 int launch_coarse_probe(const OpqModelDev &m, const float *q_rot, int64_t nq, int nprobe, int32_t *probe, hipStream_t st)
 {
+    if (g_probe_variant != 1 && coarse_probe_filter_applies(q_rot, g_probe_variant == 2 ? std::max<int64_t>(nq, 256) : nq, m.D, m.coarse, m.coarseK, nprobe))
+        return launch_coarse_probe_filtered(q_rot, nq, m.D, m.coarse, m.coarseK, nprobe, probe, st);
     if (nq >= 64 && nprobe <= 128 && m.D <= 256) {
         const size_t lds = ((size_t)CPT_Q * m.D + (size_t)m.D * (CPT_TILE + 1)) * sizeof(float);
         const int64_t blocks = (nq + CPT_Q - 1) / CPT_Q;

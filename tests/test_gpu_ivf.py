@@ -72,6 +72,18 @@ def test_ivf_query_reference_shape(amd, orc):
     oms2 = orc.query_video(qr, coarse, books, nk, off2, codes2, vid2, n_videos)
     assert np.array_equal(bits(ms_half.cpu().numpy()), bits(oms2))
     assert (oms < 1.0).sum() > nq                             # the probes do find entries below the 1.0 clamp
+    # coarse probing through the exact kernels and through the matrix-core filter: same scores
+    for variant in (1, 2):
+        amd.set_tuning("probe_variant", variant)
+        msv = idx.query_video(q, nk, n_videos, rotate=True)
+        assert np.array_equal(bits(msv.cpu().numpy()), bits(oms)), variant
+        for nkk in (1, 8, 40):                                     # other probe counts, incl. more than the filter's candidate list takes
+            a = idx.query_video(q[:260].contiguous(), nkk, n_videos, rotate=True)
+            amd.set_tuning("probe_variant", 1)
+            b = idx.query_video(q[:260].contiguous(), nkk, n_videos, rotate=True)
+            amd.set_tuning("probe_variant", variant)
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (variant, nkk)
+    amd.set_tuning("probe_variant", 0)
     # the host-pointer entry gives the same
     msh = idx.query_video(q[:7].cpu().numpy(), nk, n_videos, rotate=True)
     assert np.array_equal(bits(msh), bits(oms[:7]))
