@@ -468,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void sq8_train_kernel(const float *__restri
 // min / max of ITS columns in registers.  Rows are prefetched two ahead; nothing synchronises until the end, where the waves
 // of a workgroup fold their column extremes through LDS before one atomic per column.  HBM traffic = the 4 d bytes per row.
 template <int NF>
-__global__ __launch_bounds__(kBlock) void sq8_train_wave_kernel(const float *__restrict__ x, int64_t n, uint32_t *kmin,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void sq8_train_wave_kernel(const float *__restrict__ x, int64_t n, uint32_t *kmin,
                                                                 uint32_t *kmax)
 {
     constexpr int CG = 64 * NF, D = 4 * CG;
@@ -484,47 +484,70 @@ __global__ __launch_bounds__(kBlock) void sq8_train_wave_kernel(const float *__r
         mn[i] = make_float4(__uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u), __uint_as_float(0x7f800000u));
         mx[i] = make_float4(__uint_as_float(0xff800000u), __uint_as_float(0xff800000u), __uint_as_float(0xff800000u), __uint_as_float(0xff800000u));
     }
-    constexpr int PF = 3;  // rows in flight per wave
-    float4 v[PF][NF];
+    // Rows are taken RB at a time: the RB sums of squares are reduced across the wave together, then lanes 0 .. RB - 1 do the
+    // per-row work ONCE for their row (two double square roots, the reciprocal of the norm: ~60 instructions that every lane used
+    // to repeat for every row), and the RB (norm, reciprocal) pairs come back as scalars (readlane).
+    constexpr int RB = 4;
+    float4 cur[RB][NF], nxt[RB][NF];
     auto fetch = [&](int64_t row, float4 (&o)[NF]) {
         const int64_t r = row < n ? row : n - 1;  // clamped: the tail re-reads the last row, which changes no extreme
 #pragma unroll
         for (int i = 0; i < NF; ++i) o[i] = x4[r * CG + lane + 64 * i];
     };
 #pragma unroll
-    for (int p = 0; p < PF; ++p) fetch(w0 + p * nw, v[p]);
-    for (int64_t row = w0; row < n; row += PF * nw) {
+    for (int p = 0; p < RB; ++p) fetch(w0 + p * nw, nxt[p]);
+    for (int64_t row = w0; row < n; row += RB * nw) {
 #pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            float4 cur[NF];
+        for (int p = 0; p < RB; ++p) {
 #pragma unroll
-            for (int i = 0; i < NF; ++i) cur[i] = v[p][i];
-            fetch(row + (p + PF) * nw, v[p]);
-            double s = 0.0;
+            for (int i = 0; i < NF; ++i) cur[p][i] = nxt[p][i];
+            fetch(row + (p + RB) * nw, nxt[p]);
+        }
+        double s[RB];
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            s[p] = 0.0;
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
-                s += (double)__fmul_rn(cur[i].x, cur[i].x); s += (double)__fmul_rn(cur[i].y, cur[i].y);
-                s += (double)__fmul_rn(cur[i].z, cur[i].z); s += (double)__fmul_rn(cur[i].w, cur[i].w);
+                s[p] += (double)__fmul_rn(cur[p][i].x, cur[p][i].x); s[p] += (double)__fmul_rn(cur[p][i].y, cur[p][i].y);
+                s[p] += (double)__fmul_rn(cur[p][i].z, cur[p][i].z); s[p] += (double)__fmul_rn(cur[p][i].w, cur[p][i].w);
             }
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-            const double rlo = __dsqrt_rn(s * (1.0 - 0x1p-42)), rhi = __dsqrt_rn(s * (1.0 + 0x1p-42));
-            float den = (float)(rlo > 1e-12 ? rlo : 1e-12);
-            const float fhi = (float)(rhi > 1e-12 ? rhi : 1e-12);
-            if (!(den == fhi)) {  // wave-uniform (s is): not proven, or not finite -- the reference's own order (int8_quan.cc:48-51)
-                const int64_t r = row + p * nw < n ? row + p * nw : n - 1;
-                double accum = 0.0;
-                for (int e = 0; e < D; ++e) {
-                    const float t = x[r * D + e];
-                    accum += (double)__fmul_rn(t, t);
+            for (int o = 32; o >= 1; o >>= 1) s[p] += __shfl_xor(s[p], o, 64);
+        }
+        // lane p < RB finishes row p
+        double mine = s[0];
+#pragma unroll
+        for (int p = 1; p < RB; ++p) mine = lane == p ? s[p] : mine;
+        const double rlo = __dsqrt_rn(mine * (1.0 - 0x1p-42)), rhi = __dsqrt_rn(mine * (1.0 + 0x1p-42));
+        float den = (float)(rlo > 1e-12 ? rlo : 1e-12);
+        const float fhi = (float)(rhi > 1e-12 ? rhi : 1e-12);
+        const unsigned long long unproven = __ballot(lane < RB && !(den == fhi));
+        if (unproven) {  // rare: not proven, or not finite -- the reference's own order for those rows (int8_quan.cc:48-51)
+#pragma unroll
+            for (int p = 0; p < RB; ++p) {
+                if ((unproven >> p) & 1ull) {  // wave-uniform
+                    const int64_t r = row + p * nw < n ? row + p * nw : n - 1;
+                    double accum = 0.0;
+                    for (int e = 0; e < D; ++e) {
+                        const float t = x[r * D + e];
+                        accum += (double)__fmul_rn(t, t);
+                    }
+                    const double nrm = __dsqrt_rn(accum);
+                    if (lane == p) den = (float)(nrm > 1e-12 ? nrm : 1e-12);
                 }
-                const double nrm = __dsqrt_rn(accum);
-                den = (float)(nrm > 1e-12 ? nrm : 1e-12);
             }
-            const DivBy dd = div_by(den);
+        }
+        const DivBy dl = div_by(den);
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            DivBy dd;
+            dd.b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl.b), p));
+            dd.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl.y), p));
+            dd.ok = __builtin_amdgcn_readlane((int)dl.ok, p) != 0;
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
-                const float a0 = div_rn(cur[i].x, dd), a1 = div_rn(cur[i].y, dd), a2 = div_rn(cur[i].z, dd), a3 = div_rn(cur[i].w, dd);
+                const float a0 = div_rn(cur[p][i].x, dd), a1 = div_rn(cur[p][i].y, dd), a2 = div_rn(cur[p][i].z, dd), a3 = div_rn(cur[p][i].w, dd);
                 mn[i].x = a0 < mn[i].x ? a0 : mn[i].x; mn[i].y = a1 < mn[i].y ? a1 : mn[i].y;
                 mn[i].z = a2 < mn[i].z ? a2 : mn[i].z; mn[i].w = a3 < mn[i].w ? a3 : mn[i].w;
                 mx[i].x = a0 > mx[i].x ? a0 : mx[i].x; mx[i].y = a1 > mx[i].y ? a1 : mx[i].y;
