@@ -1,51 +1,71 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): rocprofv3 kernel-trace stats + separate PMC passes for bench.py,
-# summaries only (the raw .db/.csv stay in /tmp) -> gpurun_out/<tag>/
+# Run on the GPU box (through gpurun): rocprofv3 kernel-trace stats + separate PMC passes, summaries only (the raw .db/.csv stay
+# in /tmp) -> gpurun_out/<tag>/, from where they are copied to profiles/.
+#   1. bench.py as the driver runs it (kernel-trace --stats): every kernel of the N = 1 line incl. sift1b and the secondary configs
+#   2. bench.py, headline only, once per PMC group (counters never share a run with a trace domain other than kernel-trace)
+#   3. the scan at an HBM-resident shard (128 M rows = the per-GPU shard of SIFT-1B): kernel-trace + FETCH_SIZE / WRITE_SIZE passes
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 export PYTHONUNBUFFERED=1
 cd /tmp && export TMPDIR=/tmp
-B="python $REPO/bench.py --cpu-sample 0 --recall-sample 0 --large-rows 0"
+HEAD="python $REPO/bench.py --cpu-sample 0 --recall-sample 0 --large-rows 0 --secondary 0"
 rm -rf /tmp/prof_stats
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o $TAG -- $B --steps 10 --warmup 3 > $OUT/stats_run.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o $TAG -- python $REPO/bench.py --cpu-sample 0 --recall-sample 0 --steps 10 --warmup 3 > $OUT/stats_run.log 2>&1
 echo "stats rc=$?"
-cp /tmp/prof_stats/*kernel_stats.csv $OUT/ 2>/dev/null
-python $REPO/tools/pmc_summary.py /tmp/prof_stats > $OUT/kernel_trace_summary.json
-grep '"metric"' $OUT/stats_run.log > $OUT/bench_under_rocprof.json
+cp $(ls /tmp/prof_stats/*/*kernel_stats.csv /tmp/prof_stats/*kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_kernel_stats.csv
+python $REPO/tools/pmc_summary.py /tmp/prof_stats > $OUT/${TAG}_kernel_trace_summary.json
+grep '"metric"' $OUT/stats_run.log > $OUT/${TAG}_bench_under_rocprof.json
 i=0
 for pmc in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAVES" \
            "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_MOPS_F32"; do
   i=$((i+1))
   rm -rf /tmp/prof_pmc
-  timeout 900 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d /tmp/prof_pmc -o $TAG -- $B --steps 3 --warmup 1 > /tmp/pmc_run.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d /tmp/prof_pmc -o $TAG -- $HEAD --steps 3 --warmup 1 > /tmp/pmc_run.log 2>&1
   echo "pmc [$pmc] rc=$?"
   python $REPO/tools/pmc_summary.py /tmp/prof_pmc > $OUT/pmc_$i.json
 done
+# 3. HBM-resident shard: 128 M rows, 2048 queries
+BIG="python $REPO/bench.py --cpu-sample 0 --recall-sample 0 --large-rows 0 --secondary 0 --rows 134217728 --nq 2048 --steps 3 --warmup 1"
+j=0
+for pmc in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
+  j=$((j+1))
+  rm -rf /tmp/prof_big
+  timeout 600 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d /tmp/prof_big -o big -- $BIG > /tmp/big_run.log 2>&1
+  echo "big pmc [$pmc] rc=$?"
+  python $REPO/tools/pmc_summary.py /tmp/prof_big adc_scan > $OUT/big_pmc_$j.json
+  grep '"metric"' /tmp/big_run.log > $OUT/${TAG}_bench_128m_under_rocprof.json
+done
 python - <<PY
 import json, glob, os
-out = "$OUT"
-ctr = {}
-for f in sorted(glob.glob(os.path.join(out, "pmc_*.json"))):
-    d = json.load(open(f)).get("counters", {})
-    for k, v in d.items():
-        ctr.setdefault(k, {}).update(v)
-json.dump(ctr, open(os.path.join(out, "pmc_by_kernel.json"), "w"), indent=1)
-scan = [k for k in ctr if "adc_scan" in k]
-if scan:
+out, tag = "$OUT", "$TAG"
+def merge(pattern):
+    ctr, trace = {}, {}
+    for f in sorted(glob.glob(os.path.join(out, pattern))):
+        d = json.load(open(f))
+        for k, v in d.get("counters", {}).items():
+            ctr.setdefault(k, {}).update(v)
+        trace.update(d.get("kernel_trace", {}))
+    return ctr, trace
+ctr, _ = merge("pmc_*.json")
+json.dump(ctr, open(os.path.join(out, tag + "_pmc_by_kernel.json"), "w"), indent=1)
+note = "FETCH_SIZE x1024 x2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE x1024; separate --pmc passes"
+def traffic(ctr, trace, name):
+    scan = [k for k in ctr if "adc_scan" in k]
+    if not scan: return
     c = ctr[scan[0]]
-    # MI355X_MICROARCH.md "HBM": FETCH_SIZE (KB) reports 1/2 of a wide coalesced stream on gfx950 -> x2; WRITE_SIZE uncalibrated
-    fetch = c.get("FETCH_SIZE", 0) * 1024 * 2
-    write = c.get("WRITE_SIZE", 0) * 1024
-    json.dump({"kernel": scan[0], "hbm_bytes_per_launch": int(fetch + write), "fetch_bytes_x2_corrected": int(fetch),
-               "write_bytes": int(write), "note": "FETCH_SIZE x1024 x2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE x1024; separate --pmc passes"},
-              open(os.path.join(out, "scan_traffic.json"), "w"), indent=1)
+    fetch, write = c.get("FETCH_SIZE", 0) * 1024 * 2, c.get("WRITE_SIZE", 0) * 1024
+    t = trace.get(scan[0], {})
+    json.dump({"kernel": scan[0], "hbm_bytes_per_launch": int(fetch + write), "fetch_bytes_x2_corrected": int(fetch), "write_bytes": int(write),
+               "kernel_avg_us_under_pmc": t.get("avg_us"), "l2_hit_rate": (c.get("TCC_HIT_sum", 0) / max(1.0, c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0))),
+               "note": note}, open(os.path.join(out, name), "w"), indent=1)
+c1, t1 = merge("pmc_*.json"); traffic(c1, t1, tag + "_scan_traffic.json")
+c2, t2 = merge("big_pmc_*.json"); traffic(c2, t2, tag + "_scan_traffic_128m.json")
 PY
-# one line per secondary kernel / sibling path (not profiled, just timed)
 cd $REPO
-{ python tools/bench_kernels.py; python tools/bench_sq8.py; python tools/bench_flat_f32.py;
-  ROWS=10000000 CASES=1000:10,4096:10,1:10 python tools/bench_flat_u8.py; python tools/bench_train.py; python tools/bench_hnsw.py; python tools/bench_pca.py; python tools/bench_encode.py; python tools/bench_assign.py; python tools/bench_flat_filter.py; } 2>&1 | grep -v amdgpu > $OUT/other_kernels.txt
+{ python tools/bench_kernels.py; python tools/bench_sq8.py; python tools/bench_flat_f32.py; python tools/bench_flat_u8_opt.py; python tools/bench_train.py; python tools/bench_pca.py; python tools/bench_encode.py; python tools/bench_assign.py; python tools/bench_flat_filter.py; python tools/bench_ivf.py; NQ=9 python tools/bench_ivf.py; } 2>&1 | grep -v amdgpu > $OUT/${TAG}_other_kernels.txt
+rm -f $OUT/pmc_*.json $OUT/big_pmc_*.json
 ls -la $OUT
