@@ -12,12 +12,19 @@ mkdir -p $OUT
 export PYTHONUNBUFFERED=1
 cd /tmp && export TMPDIR=/tmp
 HEAD="python $REPO/bench.py --cpu-sample 0 --recall-sample 0 --large-rows 0 --secondary 0"
+# 1a. the headline alone: every launch of the scan kernel in this trace is a C2 launch, so its average is comparable with roofline.kernel_ms
 rm -rf /tmp/prof_stats
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o $TAG -- python $REPO/bench.py --cpu-sample 0 --recall-sample 0 --steps 10 --warmup 3 > $OUT/stats_run.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o $TAG -- $HEAD --steps 10 --warmup 3 > $OUT/stats_run.log 2>&1
 echo "stats rc=$?"
 cp $(ls /tmp/prof_stats/*/*kernel_stats.csv /tmp/prof_stats/*kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_kernel_stats.csv
 python $REPO/tools/pmc_summary.py /tmp/prof_stats > $OUT/${TAG}_kernel_trace_summary.json
 grep '"metric"' $OUT/stats_run.log > $OUT/${TAG}_bench_under_rocprof.json
+# 1b. the whole N = 1 line as the driver runs it (sift1b + secondary configs: their kernels, and the scan kernel's 2^30-row launches)
+rm -rf /tmp/prof_full
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_full -o $TAG -- python $REPO/bench.py --cpu-sample 0 --recall-sample 0 --steps 10 --warmup 3 > $OUT/stats_full_run.log 2>&1
+echo "full stats rc=$?"
+cp $(ls /tmp/prof_full/*/*kernel_stats.csv /tmp/prof_full/*kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_kernel_stats_full_line.csv
+grep '"metric"' $OUT/stats_full_run.log > $OUT/${TAG}_bench_full_line_under_rocprof.json
 i=0
 for pmc in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAVES" \
