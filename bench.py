@@ -222,12 +222,12 @@ def main():
         lds_peak = LDS_BYTES_PER_CLK_CU * N_CU * CLK_GHZ * 1e9
         traffic, traffic_src = _pmc_traffic(args, nq, k, M)
         result = {
-            "metric": "queries/sec, OPQ-ADC top-%d over 128-d SIFT-1M" % k,
+            "metric": "queries/sec, OPQ-ADC top-%d over 128-d %s" % (k, "SIFT-1M" if args.rows == 1_000_000 else "%d synthetic rows" % args.rows),
             "value": round(nq * args.steps / elapsed, 1), "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 codes / f32 distances", "data": "synthetic",
-            "config": {"workload": "SIFT-1M synthetic 128-d, OPQ M=%d K=256 (dense 128x128 rotation), ADC scan + top-%d, "
-                                   "nq=%d queries per step" % (M, k, nq),
+            "config": {"workload": "%s synthetic 128-d, OPQ M=%d K=256 (dense 128x128 rotation), ADC scan + top-%d, "
+                                   "nq=%d queries per step" % ("SIFT-1M" if args.rows == 1_000_000 else "%d-row" % args.rows, M, k, nq),
                        "rows": args.rows, "rows_per_gpu": args.rows, "nq_per_step": nq, "k": k, "M": M, "parallelism": "1 GPU",
                        "qtile": scan["qtile"], "row_splits": scan["splits"]},
             "roofline": {"bound": "hbm", "kernel": "adc_scan kernel (M=%d, %d queries per pass)" % (M, scan["qtile"]),
@@ -235,9 +235,10 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": scan["code_bytes"], "kernel_ms": rf["kernel_ms"],
                          "operative_bound": "lds+valu",
-                         "operative_note": "the 16 MB code matrix is cache-resident at this size (traffic << algorithmic bytes): the kernel is "
-                                           "bound by its LDS table look-ups and the VALU work around them, not by HBM; the HBM-streaming "
-                                           "figure is sift1b.scan",
+                         "operative_note": "the kernel is bound by its LDS table look-ups at every size: the query groups of a row split share each "
+                                           "row chunk through L2 / Infinity Cache, so HBM-side traffic (PMC) is a fraction of the algorithmic bytes "
+                                           "(0.10 at SIFT-1M, 0.03 at a 128 M-row shard: profiles/r02_scan_traffic*.json); `achieved` is the "
+                                           "algorithmic rate SURVEY 8(d) prescribes",
                          "lds_lookups_per_s": round(lookups / 1e12, 2),
                          "lds_frac": round(lds_bytes / lds_peak, 4),
                          "lds_frac_what": "table look-ups/s x 2 B per look-up / (256 B/clk/CU x 256 CU x 2.4 GHz)"},
