@@ -68,6 +68,7 @@ public:
         memcpy(data_ + size_per_element_ * cur_c, data_ + size_per_element_ * (cur_element_count - 1), data_size_ + sizeof(labeltype));
         cur_element_count--;
         dirty_ = true;
+        rebuild_ = true;  // a row moved: the device copy is re-ordered from scratch on the next search
     }
 
     std::priority_queue<std::pair<dist_t, labeltype> > searchKnn(void *query_data, size_t k)
@@ -118,11 +119,15 @@ public:
         for (size_t i = 0; i < cur_element_count; ++i)
             dict_external_to_internal[*((labeltype *)(data_ + size_per_element_ * i + data_size_))] = i;
         dirty_ = true;
+        rebuild_ = true;
     }
 
 private:
     cvtmi_flat_s *h_;
     bool dirty_;
+    bool rebuild_ = true;        // the device copy must be rebuilt (rows removed / loaded / labels not ascending)
+    size_t synced_ = 0;          // rows [0, synced_) of data_ are on the device, in this order
+    labeltype synced_max_ = 0;   // the largest label among them
     int metric_;
 
     void bind(SpaceInterface<dist_t> *s)
@@ -141,6 +146,35 @@ private:
         const size_t dim = *((size_t *)dist_func_param_);
         if (!h_ && cvtmi_flat_create(metric_, (int)dim, &h_) != CVTMI_OK)
             throw std::runtime_error(std::string("cvtmi_flat_create: ") + cvtmi_last_error());
+        // The device keeps rows in ascending label order (the (distance, label) tie rule of searchKnn's heap).  The common
+        // case -- addPoint with ever larger labels, as brute_force.cpp does (labels = row numbers) -- only appends the new
+        // rows; anything else (removePoint, loadIndex, a label below one already uploaded) re-sorts and re-uploads everything.
+        if (!rebuild_ && synced_ <= cur_element_count) {
+            bool ascending = true;
+            labeltype prev = synced_max_;
+            for (size_t i = synced_; i < cur_element_count && ascending; ++i) {
+                const labeltype lab = *((const labeltype *)(data_ + size_per_element_ * i + data_size_));
+                ascending = (i == 0 && synced_ == 0) || lab > prev;
+                prev = lab;
+            }
+            if (ascending) {
+                const size_t m = cur_element_count - synced_;
+                if (m) {
+                    std::vector<char> rows(m * data_size_ + 1);
+                    std::vector<int64_t> labels(m);
+                    for (size_t i = 0; i < m; ++i) {
+                        memcpy(&rows[i * data_size_], data_ + size_per_element_ * (synced_ + i), data_size_);
+                        labels[i] = (int64_t) * ((const labeltype *)(data_ + size_per_element_ * (synced_ + i) + data_size_));
+                    }
+                    if (cvtmi_flat_add(h_, rows.data(), labels.data(), (int64_t)m) != CVTMI_OK)
+                        throw std::runtime_error(std::string("cvtmi_flat_add: ") + cvtmi_last_error());
+                    synced_max_ = (labeltype)labels[m - 1];
+                    synced_ = cur_element_count;
+                }
+                dirty_ = false;
+                return;
+            }
+        }
         cvtmi_flat_reset(h_);
         const size_t n = cur_element_count;
         std::vector<size_t> order(n);
@@ -159,6 +193,9 @@ private:
         if (n && cvtmi_flat_add(h_, rows.data(), labels.data(), (int64_t)n) != CVTMI_OK)
             throw std::runtime_error(std::string("cvtmi_flat_add: ") + cvtmi_last_error());
         dirty_ = false;
+        rebuild_ = false;
+        synced_ = n;
+        synced_max_ = n ? (labeltype)labels[n - 1] : 0;
     }
 };
 }  // namespace hnswlib

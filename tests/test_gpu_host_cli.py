@@ -219,3 +219,10 @@ def test_opq_search_cli_row_sharded(tmp_path, orc, gpus, transport):
         assert int(head) == qi
         assert [int(v) for v in ids_s.split()] == oi[qi].tolist()
         assert np.array_equal(bits(np.array([float(v) for v in d_s.split()], dtype=np.float32)), bits(od[qi]))
+
+
+def test_bruteforce_mirror_incremental_sync(tmp_path):
+    """hnswlib::BruteforceSearch (host mirror): searches interleaved with addPoint / removePoint answer like an index built from
+    scratch -- ascending labels are appended to the device copy, anything else re-sorts it (cvt_amd/host/cli/bf_sync_check.cpp)."""
+    out = run([os.path.join(BIN, "bf_sync_check")], cwd=str(tmp_path))
+    assert out.strip().endswith("OK"), out
