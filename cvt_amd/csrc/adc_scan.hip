@@ -660,8 +660,7 @@ __device__ __attribute__((noinline)) int scan_compact_lazy_q(TopKShared<QT, CAP>
         if (lane == 0) { s.exact_n[q] = 0; s.thr[q] = KEY_MAX; s.thr_x[q] = 32767u; }
         return n;
     }
-    const unsigned long long kth = wave_select<NR>(e, k);
-    const uint32_t T = (uint32_t)(kth >> 32) + slack;
+    const uint32_t T = wave_select_field<NR, 15>(e, k) + slack;  // the k-th smallest integer sum (sums are below 2^15) + the band
     int total = 0;
     unsigned long long in_m[NR];
 #pragma unroll

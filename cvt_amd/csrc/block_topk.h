@@ -257,6 +257,43 @@ __device__ __forceinline__ unsigned long long wave_select(const unsigned long lo
     return prefix;  // duplicates of the k-th value: every bit was walked
 }
 
+// k-th smallest VALUE of the NBITS-bit field that starts at bit 32 of the wave's 64 * NR register entries (the key of an entry
+// whose keys are small integers): the radix select above restricted to that field -- NBITS rounds, ties need no resolving
+// because only the value is wanted.  Slots that hold no entry must be ~0ull (their field reads as all ones: never below a real key).
+template <int NR, int NBITS>
+__device__ __forceinline__ uint32_t wave_select_field(const unsigned long long (&e)[NR], int k)
+{
+    unsigned long long alive[NR];  // wave-uniform lane masks; entries wider than the field (empty slots) never take part
+    int kk = k;
+    uint32_t prefix = 0;
+    uint32_t w[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        w[r] = (uint32_t)(e[r] >> 32);
+        alive[r] = __ballot((w[r] >> NBITS) == 0);
+    }
+    for (int b = NBITS - 1; b >= 0; --b) {  // wave-uniform
+        const uint32_t m = 1u << b;
+        unsigned long long z[NR];
+        int c0 = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            z[r] = __ballot((w[r] & m) == 0) & alive[r];
+            c0 += __popcll(z[r]);
+        }
+        if (kk <= c0) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) alive[r] = z[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) alive[r] &= ~z[r];
+            kk -= c0;
+            prefix |= m;
+        }
+    }
+    return prefix;
+}
+
 #ifdef CVTMI_SCAN_TIMING
 static __device__ unsigned long long g_topk_dbg[4];  // compaction rounds, fix cycles, sort cycles, new entries (thread 0's view)
 #define TK_T(i, t0) do { if (threadIdx.x == 0) atomicAdd(&g_topk_dbg[i], (unsigned long long)(clock64() - (t0))); } while (0)

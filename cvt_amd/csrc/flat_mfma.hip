@@ -577,14 +577,13 @@ __device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_dst)
 // NW waves (32 queries each) per workgroup, G row tiles per barrier.  <8, 2>: one workgroup per CU, its two waves per SIMD move in
 // lock step (same barrier).  <4, 1>: two independent workgroups per CU, one wave per SIMD each -- the pair on a SIMD drifts apart,
 // so one wave's matrix instructions run beside the other's reads / waits / barrier.
-template <int KS, int NW, int G>
+template <int KS, int NW, int G, int NB>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void flat_u8_gfilter_kernel(
     const uint8_t *__restrict__ q, int64_t nq, const uint4 *__restrict__ pack, const int32_t *__restrict__ norms, int64_t n,
     const float *__restrict__ sample_d, int k, int64_t tile_begin, int64_t tile_end, int64_t tiles_per_split, uint32_t pair_cap,
     uint32_t *__restrict__ pair_cnt, uint4 *__restrict__ pairs, int qblocks)
 {
     constexpr int D = 32 * KS;
-    constexpr int NB = 3;                     // groups in the LDS ring
     constexpr int PPW = G * KS / NW;          // 1 KB pieces each wave requests per group
     constexpr int OPS = PPW + 1;              // + the norms piece
     constexpr int PBUF = 128;
@@ -701,8 +700,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             parked += cnt;
         }
     };
-    request(0, 0);
-    request(n_groups > 1 ? 1 : 0, 1);   // always two groups of requests: the counted waits below rely on it
+    // NB - 1 groups of requests go out up front, one more per iteration: the counted waits below rely on exactly that
+#pragma unroll
+    for (int p = 0; p < NB - 1; ++p) request(p < n_groups ? p : n_groups - 1, p);
     // The reduction of group g - 1's results (8 v_max3 per tile) is issued between the matrix instructions of group g (second
     // accumulator set): the matrix pipe of a SIMD is shared by two waves, what a wave does between its own matrix instructions is free.
     constexpr int PD = KS >= 8 ? 4 : (KS >= 4 ? 2 : 1);   // K steps of operand reads in flight ahead of the matrix instructions
@@ -715,9 +715,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         prev[u] = thrh;
     }
     for (int64_t g = 0; g < n_groups; ++g) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");  // own share of group g has landed (g + 1 may be in flight)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * OPS) : "memory");  // own share of group g has landed (later groups may be in flight)
         __builtin_amdgcn_s_barrier();                                // everyone's share has; everyone is done with group g - 1
-        request(g + 2 < n_groups ? g + 2 : n_groups - 1, (int)((g + 2) % NB));  // into the slot group g - 1 occupied (past the end: a duplicate nobody reads)
+        request(g + NB - 1 < n_groups ? g + NB - 1 : n_groups - 1, (int)((g + NB - 1) % NB));  // into the slot group g - 1 occupied (past the end: a duplicate nobody reads)
         const int slot = (int)(g % NB);
         const i32x4 *pb = reinterpret_cast<const i32x4 *>(gf_ring) + (size_t)slot * G * KS * 64 + lane;
         int xx_cur[G];
@@ -869,18 +869,18 @@ int launch_flat_u8_filter(const uint8_t *q, int64_t nq, int D, const uint4 *pack
         const int64_t splits8 = (splits + 7) / 8 * 8;
         if (splits8 * qblocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "flat u8 filter: nq too large");
         const dim3 g((unsigned)(splits8 * qblocks));
-#define CVTMI_GF(N, NW, G)                                                                                                        \
+#define CVTMI_GF(N, NW, G, NB)                                                                                                    \
     do {                                                                                                                         \
-        const size_t lds = (size_t)3 * (G) * (N) * 64 * sizeof(uint4);                                                           \
-        CVTMI_HIP(hipFuncSetAttribute((const void *)flat_u8_gfilter_kernel<N, NW, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((flat_u8_gfilter_kernel<N, NW, G>), g, dim3(64 * (NW)), lds, st, q, nq, pack, norms, n, sample_d, k, tile_begin, tile_end, \
+        const size_t lds = (size_t)(NB) * (G) * (N) * 64 * sizeof(uint4);                                                        \
+        CVTMI_HIP(hipFuncSetAttribute((const void *)flat_u8_gfilter_kernel<N, NW, G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((flat_u8_gfilter_kernel<N, NW, G, NB>), g, dim3(64 * (NW)), lds, st, q, nq, pack, norms, n, sample_d, k, tile_begin, tile_end, \
                            tps, pair_cap, pair_cnt, pairs, (int)qblocks);                                                        \
     } while (0)
         switch (D / 32) {
-            case 2: CVTMI_GF(2, 8, 4); break;
-            case 4: if (two) CVTMI_GF(4, 4, 1); else CVTMI_GF(4, 8, 2); break;
-            case 8: if (two) CVTMI_GF(8, 4, 1); else CVTMI_GF(8, 8, 2); break;
-            case 16: if (two) CVTMI_GF(16, 4, 1); else CVTMI_GF(16, 8, 2); break;
+            case 2: CVTMI_GF(2, 8, 4, 3); break;
+            case 4: if (two) CVTMI_GF(4, 4, 2, 3); else CVTMI_GF(4, 8, 2, 3); break;
+            case 8: if (two) CVTMI_GF(8, 4, 2, 3); else CVTMI_GF(8, 8, 2, 3); break;
+            case 16: if (two) CVTMI_GF(16, 4, 2, 2); else CVTMI_GF(16, 8, 2, 3); break;   // 4 waves: ring of 2 groups, two workgroups fit a CU's LDS
             default: return fail(CVTMI_EUNSUPPORTED, "flat u8 pipelined filter: D=%d (64, 128, 256 or 512)", D);
         }
 #undef CVTMI_GF

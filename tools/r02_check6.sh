@@ -6,4 +6,3 @@ mkdir -p $OUT
 cd $REPO
 export PYTHONUNBUFFERED=1
 timeout 300 python tools/bench_flat_u8_opt.py > $OUT/flat_u8_gf.log 2>&1; echo "gf rc=$?"; grep -v amdgpu $OUT/flat_u8_gf.log | tail -24
-D=128 ROWS=4000000 timeout 300 python tools/bench_flat_u8_opt.py > $OUT/flat_u8_gf_d128.log 2>&1; echo "gf128 rc=$?"; grep -v amdgpu $OUT/flat_u8_gf_d128.log | tail -24
