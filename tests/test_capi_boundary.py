@@ -88,3 +88,49 @@ def test_tuning_hooks_validate_their_arguments():
         assert lib.cvtmi_set_tuning(name, ctypes.c_int64(7)) != 0 and name in lib.cvtmi_last_error()
     assert lib.cvtmi_set_tuning(b"no_such_knob", ctypes.c_int64(1)) != 0 and b"no_such_knob" in lib.cvtmi_last_error()
     assert lib.cvtmi_set_tuning(None, ctypes.c_int64(1)) != 0
+
+
+def test_hnsw_load_rejects_hostile_headers(golden):
+    """cvtmi_hnsw_load validates the file before it touches the device (so this runs without one): header products that would
+    wrap, element counts that would exhaust host memory, and upper-level links into nodes that do not have that level must all
+    come back as CVTMI_EINVAL / ENOMEM -- never a crash, never an exception across the C ABI."""
+    import cvt_amd
+    lib = cvt_amd.lib()
+    g = golden.hnsw
+    metric, D = int(g["ip32_meta"][0]), int(g["ip32_meta"][1])
+    blob = bytearray(g["ip32_index"].tobytes())
+
+    def load(b):
+        h = ctypes.c_void_p()
+        buf = (ctypes.c_char * len(b)).from_buffer_copy(bytes(b))
+        rc = lib.cvtmi_hnsw_load(buf, ctypes.c_int64(len(b)), ctypes.c_int(metric), ctypes.c_int(D), ctypes.byref(h))
+        if rc == 0:
+            lib.cvtmi_hnsw_destroy(h)
+        return rc
+
+    hdr = np.frombuffer(bytes(blob[:48]), np.uint64).copy()   # offsetLevel0, max_elements, cur_count, size_per, label_off, offsetData
+    size_per = int(hdr[3])
+    bad = bytearray(blob); bad[8:16] = np.uint64((1 << 64) // size_per + 1).tobytes()           # max_elements * size_per wraps to ~0
+    bad[16:24] = np.uint64(1).tobytes()
+    assert load(bad) == -1
+    bad = bytearray(blob); bad[8:16] = np.uint64(1 << 54).tobytes(); bad[16:24] = np.uint64(1 << 54).tobytes()  # huge counts
+    assert load(bad) in (-1, -2)
+    bad = bytearray(blob); bad[48:52] = np.int32(-3).tobytes()                                   # negative maxlevel
+    assert load(bad) == -1
+    # an upper-level link that points at a node living on level 0 only
+    max_elements, cur = int(hdr[1]), int(hdr[2])
+    maxM = int(np.frombuffer(bytes(blob[56:64]), np.uint64)[0])
+    p = 96 + max_elements * size_per
+    levels = []
+    for i in range(max_elements):
+        sz = int(np.frombuffer(bytes(blob[p:p + 4]), np.uint32)[0]); levels.append((p + 4, sz)); p += 4 + sz
+    flat = [i for i, (_, sz) in enumerate(levels[:cur]) if sz == 0]
+    tall = [(i, off) for i, (off, sz) in enumerate(levels[:cur]) if sz > 0]
+    if flat and tall:
+        i, off = tall[0]
+        cnt = int(np.frombuffer(bytes(blob[off:off + 4]), np.uint32)[0])
+        if cnt > 0:
+            bad = bytearray(blob); bad[off + 4:off + 8] = np.uint32(flat[0]).tobytes()
+            assert load(bad) == -1
+    # and the untouched file still fails only for lack of a device here (or loads, on a GPU box)
+    assert load(blob) in (0, -3)
