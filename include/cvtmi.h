@@ -73,9 +73,15 @@ int cvtmi_set_device(int device);
  *   "assign_variant"  nearest-centroid assignment (coarse argmin of cvtmi_opq_encode, cvtmi_kmeans): 0 = choose (default);
  *                     1 = the reference's chain for every centroid on the VALU; 2 = bf16 matrix-core filter with exact
  *                     resolution of undecided rows wherever it applies (32 <= d <= 128, d % 16 == 0, k >= 64)
- *   "flat_variant"    exhaustive search: 0 = choose (default: fp32 through the matrix-core filter for large batches, uint8 on
- *                     the row-tile kernels); 1 = exact / row-tile kernels only; 2 = the filter pipelines wherever they apply
- *                     (uint8 too: exact sample, i8 matrix-core threshold filter, sort -- measures like the row-tile kernels)
+ *   "flat_variant"    exhaustive search: 0 = choose (default: large batches through the filter pipelines -- fp32: bf16 matrix-core
+ *                     filter with a proven bound; uint8: exact sample, software-pipelined i8 matrix-core threshold filter, sort,
+ *                     from nq * D >= 128 K on >= 1 M rows -- smaller ones on the exact / row-tile kernels); 1 = exact / row-tile
+ *                     kernels only; 2 = the filter pipelines wherever they apply
+ *   "flat_u8_gfilter" the uint8 filter stage: 1 (default) / 3 = LDS-DMA pipelined kernel, one 8-wave workgroup per CU; 2 = two 4-wave
+ *                     workgroups per CU; 0 = the round-1 filter kernel (register-staged tiles)
+ *   "flat_u8_opt"     measurement variants of the uint8 row-tile kernel (0 = shipped; 1..3 spill registers and are slower)
+ *   "probe_variant"   coarse top-nk of cvtmi_opq_query_video: 0 = choose (matrix-core filter + exact distances of the candidates
+ *                     from 256 query frames, 32 <= D <= 128, coarseK >= 256); 1 = exact kernels only; 2 = filter wherever it applies
  *   "comm_force_rccl" 1 = cvtmi_comm_create goes through RCCL (ncclCommInitRank, ncclAllGather) for world == 1 too, which
  *                     otherwise needs no transport (test hook for 1-GPU boxes) */
 int cvtmi_set_tuning(const char *name, int64_t value);
@@ -142,7 +148,9 @@ int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, 
 
 /* IVFOPQ::Query / QueryThrehold (IVFOPQ.cpp:213-320 / :322-422): per query frame probe the nprobe
  * nearest coarse lists and keep, per video, the minimum ADC score clamped at 1.0.
- * match_score[nq][img_num].  rotate as above. */
+ * match_score[nq][img_num].  rotate as above.  The list-ordered copy of the entries is (re)built on the device by the
+ * first query after an append (a stable counting sort; ~2.5 ms per million entries); entries whose list id is outside
+ * [0, coarseK) are skipped; a video id outside [0, img_num) fails the call. */
 int cvtmi_opq_query_video(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int nprobe,
                           int img_num, float *match_score);
 int cvtmi_opq_query_video_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int nprobe,
