@@ -122,6 +122,12 @@ int launch_flat_u8_mfma(int D, const uint8_t *data, const int32_t *norms, int64_
                         int splits, float *part_d, int64_t *part_id, uint32_t *gthr, hipStream_t st);
 // ids[i] = ids[i] >= 0 ? labels[ids[i]] : -1
 void set_flat_u8_opt(int v);
+// uint8 L2, 1..4 queries: coalesced streaming of the rows into an int32 distance array + selection (flat.hip)
+bool flat_u8_stream_applies(int D, int64_t n, int64_t nq, int k);
+int set_flat_u8_stream_blocks(int v);   // measurement hook
+size_t flat_u8_stream_scratch(int64_t n, int64_t nq, int *slices, int64_t *ld);
+int launch_flat_u8_stream(int D, const uint8_t *data, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int k, float *scratch,
+                          float *part_d, int64_t *part_id, float *out_d, int64_t *out_rows, hipStream_t st);
 void set_flat_u8_gfilter(int v);   // flat_mfma.hip: the software-pipelined (LDS-DMA) uint8 filter kernel on / off
 bool flat_u8_gfilter_shape(int D);
 int launch_gather_labels(int64_t *ids, int64_t count, const int64_t *labels, hipStream_t st);

@@ -401,3 +401,31 @@ def test_flat_u8_filter_pipeline(amd, orc, D, k, hi):
     assert np.array_equal(out[2][1], out[1][1]) and np.array_equal(out[2][0], out[1][0])
     od, odi, oi = orc.flat_search(L2U8, x, q[:16], k)
     assert np.array_equal(out[2][1][:16], oi) and np.array_equal(out[2][0][:16], odi)
+
+
+@pytest.mark.parametrize("D,nq,k,hi", [(512, 1, 10, 256), (128, 3, 128, 4), (256, 4, 1, 256), (512, 2, 33, 256)])
+def test_flat_u8_tiny_batch_stream(amd, orc, D, nq, k, hi):
+    """1..4 uint8 queries go through the coalesced streaming kernel + per-split selection + merge (flat_variant 0) -- against the
+    row-per-lane kernels (flat_variant 1) and the checker; ragged row count (last split partly empty), duplicate rows at both
+    ends of the table (ties resolved by row), few distinct byte values (masses of equal distances), a far query (distances > 2^24, not exact in f32)"""
+    rng = np.random.default_rng(D * 7 + k)
+    n = 262_144 + 12_345
+    x = rng.integers(0, hi, size=(n, D), dtype=np.uint8)
+    x[n - 1] = x[3]; x[131_072] = x[3]
+    q = x[rng.integers(0, n, nq)].copy()
+    q[0] = x[3]
+    if nq > 1:
+        q[-1] = np.where(x[7] < 128, 255, 0)                    # far query: distances near 512 * 200^2 > 2^24
+    out = {}
+    try:
+        for v in (0, 1):
+            amd.set_tuning("flat_variant", v)
+            ix = amd.FlatIndex(L2U8, D); ix.add(x[:100_000]); ix.add(x[100_000:])
+            out[v] = ix.search(q, k)
+            ix.close()
+    finally:
+        amd.set_tuning("flat_variant", 0)
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+    od, odi, oi = orc.flat_search(L2U8, x, q, k)
+    assert np.array_equal(out[0][1], oi) and np.array_equal(out[0][0], odi)
+    assert out[0][1][0, :min(k, 3)].tolist() == [3, 131_072, n - 1][:min(k, 3)]
