@@ -462,16 +462,17 @@ __global__ __launch_bounds__(kBlock) void flat_u8_stream_kernel(const uint8_t *_
     }
 }
 
-// grid = nq * S workgroups; workgroup (q, s) derives theta from all G wave minima of its query, then selects among the rows of the
-// qualifying waves of ITS slice of G / S waves.  Wave w owns rows (w + t G) rpi + j, t = 0.., j < rpi; the slice's entries are fed
+// grid = nq * S workgroups; workgroup (q, s) derives theta from all G wave minima of its query, then selects among the rows the
+// qualifying waves wrote inside ITS slice of the rows.  Wave w owns rows (w + t G) rpi + j, t = 0.., j < rpi; the slice's entries are fed
 // in ascending row order (t outermost, then wave, then j), which is the order block_topk.h's tie rule asks for.
-constexpr int FIN_CAP = 1024, FIN_TRIG = 768, FIN_R = 4, FIN_MAXG = 512;
+constexpr int FIN_CAP = 1024, FIN_TRIG = 768, FIN_R = 4, FIN_MAXG = 8192, FIN_MAXR = 160;
 __global__ __launch_bounds__(kBlock) void flat_u8_stream_finish_kernel(const int32_t *__restrict__ dist, int64_t ld, int64_t n,
                                                                        const int32_t *__restrict__ gmin, int G, int S, int rpi_log2, int k,
                                                                        float *__restrict__ part_d, int64_t *__restrict__ part_id)
 {
     __shared__ TopKShared<1, FIN_CAP> tk;
-    __shared__ int ql[FIN_MAXG];
+    __shared__ uint16_t ql[FIN_MAXG];          // qualifying waves, ascending
+    __shared__ int r_first[FIN_MAXR], r_off[FIN_MAXR + 1];
     __shared__ int qn_s;
     const int tid = threadIdx.x;
     const int64_t q = blockIdx.x / S;
@@ -511,14 +512,14 @@ __global__ __launch_bounds__(kBlock) void flat_u8_stream_finish_kernel(const int
     topk_compact(tk, k);
     const uint32_t theta = tk.thr[0];                     // KEY_MAX when fewer than k waves exist: everything qualifies
     __syncthreads();
-    const int gps = G / S, w0 = sl * gps;                 // G % S == 0, gps <= FIN_MAXG
+    // all qualifying waves, ascending (wave 0: one ballot per 64 waves)
     if (tid < 64) {
         int cnt = 0;
-        for (int c = 0; c < gps; c += 64) {
+        for (int c = 0; c < G; c += 64) {
             const int g = c + tid;
-            const bool yes = g < gps && (uint32_t)gm[w0 + g] <= theta;
+            const bool yes = g < G && (uint32_t)gm[g] <= theta;
             const unsigned long long m = __ballot(yes);
-            if (yes) ql[cnt + __popcll(m & ((1ull << tid) - 1))] = w0 + g;
+            if (yes) ql[cnt + __popcll(m & ((1ull << tid) - 1))] = (uint16_t)g;
             cnt += __popcll(m);
         }
         if (tid == 0) qn_s = cnt;
@@ -526,9 +527,28 @@ __global__ __launch_bounds__(kBlock) void flat_u8_stream_finish_kernel(const int
     topk_init(tk);
     __syncthreads();
     const int qn = qn_s;
-    const int64_t rows_per_round = (int64_t)G << rpi_log2;
-    const int64_t rounds = (n + rows_per_round - 1) / rows_per_round;
-    const int64_t total = (rounds * qn) << rpi_log2;
+    // This workgroup's slice is a CONTIGUOUS range of row chunks (chunk c = rpi rows, written by wave c % G in its round c / G), so
+    // the S lists of a query cover ascending row ranges and topk_merge_kernel's tie rule (position order = row order) holds.  Per
+    // round of the slice, the qualifying waves inside the slice's window are a sub-range of ql (two binary searches).
+    const int64_t c_total = (n + ((int64_t)1 << rpi_log2) - 1) >> rpi_log2;
+    const int64_t c_lo = c_total * sl / S, c_hi = c_total * (sl + 1) / S;
+    const int64_t t_a = c_lo / G;
+    const int n_rounds = c_hi > c_lo ? (int)((c_hi - 1) / G - t_a + 1) : 0;   // <= FIN_MAXR: n < 2^31, G * rpi >= 2^16, S = 64
+    if (tid < n_rounds) {
+        const int64_t first = (t_a + tid) * G;
+        const int lo_w = (int)(c_lo > first ? c_lo - first : 0), hi_w = (int)(c_hi - first < G ? c_hi - first : G);
+        auto lower = [&](int w) { int a_ = 0, b_ = qn; while (a_ < b_) { const int m_ = (a_ + b_) >> 1; if ((int)ql[m_] < w) a_ = m_ + 1; else b_ = m_; } return a_; };
+        const int i0 = lower(lo_w), i1 = lower(hi_w);
+        r_first[tid] = i0;
+        r_off[tid + 1] = i1 - i0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        r_off[0] = 0;
+        for (int r = 0; r < n_rounds; ++r) r_off[r + 1] += r_off[r];
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)(n_rounds ? r_off[n_rounds] : 0) << rpi_log2;
     const int32_t *dq = dist + q * ld;
     tile = 0;
     for (int64_t base = 0; base < total; base += kBlock * FIN_R, ++tile) {
@@ -539,9 +559,11 @@ __global__ __launch_bounds__(kBlock) void flat_u8_stream_finish_kernel(const int
             key[r][0] = KEY_MAX;
             pay[r] = 0;
             if (e < total) {
-                const int64_t eg = e >> rpi_log2;
-                const int64_t t = eg / qn;
-                const int64_t row = (((t * G) + ql[eg - t * qn]) << rpi_log2) + (e & ((1 << rpi_log2) - 1));
+                const int ci = (int)(e >> rpi_log2);
+                int a_ = 0, b_ = n_rounds - 1;   // the round whose [r_off, r_off + 1) holds ci
+                while (a_ < b_) { const int m_ = (a_ + b_ + 1) >> 1; if (r_off[m_] <= ci) a_ = m_; else b_ = m_ - 1; }
+                const int64_t chunk = (t_a + a_) * G + ql[r_first[a_] + (ci - r_off[a_])];
+                const int64_t row = (chunk << rpi_log2) + (e & ((1 << rpi_log2) - 1));
                 if (row < n) {
                     const uint32_t d = (uint32_t)dq[row];
                     pay[r] = (uint32_t)row;
@@ -1137,7 +1159,7 @@ void set_flat_u8_opt(int v) { g_flat_u8_opt = v; }
 // (32 x (D + 16) bytes each) next to the selection buffers (8 * CAP bytes per query, CAP >= k + 32).
 int flat_u8_mfma_qtile(int D, int k, int64_t nq)
 {
-    if (D % 32 != 0 || D > 512 || nq < 8 || k > 128) return 0;
+    if (D % 32 != 0 || D > 512 || nq < 5 || k > 128) return 0;   // 1..4 queries: streaming / row-per-lane kernels (5 on those took 3.4 ms against 1.7 here)
     // measured on 2 M x 512-d (tools/bench_flat_u8.py): the row-tile kernel wins wherever its selection buffers
     // leave room for >= 4 waves of queries; large k falls back to one query block per workgroup
     if (k <= 24) return nq > 128 ? 256 : (nq > 64 ? 128 : (nq > 32 ? 64 : 32));
@@ -1236,15 +1258,19 @@ int launch_gather_labels(int64_t *ids, int64_t count, const int64_t *labels, hip
     return CVTMI_OK;
 }
 
+constexpr int STREAM_SLICES = 64;
+static int g_stream_blocks_get();
 bool flat_u8_stream_applies(int D, int64_t n, int64_t nq, int k)
 {
-    return nq >= 1 && nq <= 4 && (D == 128 || D == 256 || D == 512) && n >= 262144 && n < 0x7fffffff && k <= 128;
+    if (!(nq >= 1 && nq <= 4 && (D == 128 || D == 256 || D == 512) && n >= 262144 && n < 0x7fffffff && k <= 128)) return false;
+    const int64_t rows_per_round = (int64_t)g_stream_blocks_get() * (kBlock / 64) * (64 / (D / 16) * 8);   // waves x rows per wave iteration
+    return n / STREAM_SLICES / rows_per_round + 2 <= FIN_MAXR;   // rounds a finish slice can span (always true at the default grid)
 }
-constexpr int STREAM_SLICES = 64;
 static int g_stream_blocks = 1024;   // waves = 4 x blocks = 4 per SIMD: every wave resident at once for any QT (measured 10 M x 512: 1024 blocks 0.917 / 0.911 / 0.988 ms for 1 / 2 / 4 queries, 2048: 0.909 / 0.958 / 1.127); a multiple of 16 so that the finish slices divide the waves evenly
+static int g_stream_blocks_get() { return g_stream_blocks; }
 int set_flat_u8_stream_blocks(int v)
 {
-    if (v < 256 || v > 8192 || v % 16) return CVTMI_EINVAL;
+    if (v < 256 || v > 2048 || v % 16) return CVTMI_EINVAL;   // 4 v waves <= FIN_MAXG
     g_stream_blocks = v;
     return CVTMI_OK;
 }
@@ -1265,7 +1291,7 @@ int launch_flat_u8_stream(int D, const uint8_t *data, const int32_t *norms, int6
     (void)flat_u8_stream_scratch(n, nq, nullptr, &ld);
     int32_t *dist = reinterpret_cast<int32_t *>(scratch);
     int32_t *gmin = dist + nq * ld;
-    const int STREAM_BLOCKS = g_stream_blocks, STREAM_WAVES = STREAM_BLOCKS * (kBlock / 64);   // 8192 / 64 slices <= FIN_MAXG waves per slice
+    const int STREAM_BLOCKS = g_stream_blocks, STREAM_WAVES = STREAM_BLOCKS * (kBlock / 64);   // <= FIN_MAXG waves
     int rpi_log2 = 0;
 #define CVTMI_FS(L)                                                                                                                          \
     do {                                                                                                                                     \

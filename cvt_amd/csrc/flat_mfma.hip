@@ -581,8 +581,11 @@ template <int KS, int NW, int G, int NB>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void flat_u8_gfilter_kernel(
     const uint8_t *__restrict__ q, int64_t nq, const uint4 *__restrict__ pack, const int32_t *__restrict__ norms, int64_t n,
     const float *__restrict__ sample_d, int k, int64_t tile_begin, int64_t tile_end, int64_t tiles_per_split, uint32_t pair_cap,
-    uint32_t *__restrict__ pair_cnt, uint4 *__restrict__ pairs, int qblocks)
+    uint32_t *__restrict__ pair_cnt, uint4 *__restrict__ pairs, int qblocks, int dbg)
 {
+#ifndef CVTMI_GF_DBG
+    dbg = 0;   // the experiment switches exist in -DCVTMI_GF_DBG builds only
+#endif
     constexpr int D = 32 * KS;
     constexpr int PPW = G * KS / NW;          // 1 KB pieces each wave requests per group
     constexpr int OPS = PPW + 1;              // + the norms piece
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int64_t g = 0; g < n_groups; ++g) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * OPS) : "memory");  // own share of group g has landed (later groups may be in flight)
         __builtin_amdgcn_s_barrier();                                // everyone's share has; everyone is done with group g - 1
-        request(g + NB - 1 < n_groups ? g + NB - 1 : n_groups - 1, (int)((g + NB - 1) % NB));  // into the slot group g - 1 occupied (past the end: a duplicate nobody reads)
+        if (!(dbg & 1)) request(g + NB - 1 < n_groups ? g + NB - 1 : n_groups - 1, (int)((g + NB - 1) % NB));  // into the slot group g - 1 occupied (past the end: a duplicate nobody reads)
         const int slot = (int)(g % NB);
         const i32x4 *pb = reinterpret_cast<const i32x4 *>(gf_ring) + (size_t)slot * G * KS * 64 + lane;
         int xx_cur[G];
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int u = 0; u < G; ++u) {
             const int64_t t = t0 + (g - 1) * G + u;
-            const bool cand = mx[u] >= (xx_prev[u] >> 1) && t < t1;     // xx_prev = INT_MAX before the first group: nothing passes
+            const bool cand = mx[u] >= (xx_prev[u] >> 1) && t < t1 && !(dbg & 2);     // xx_prev = INT_MAX before the first group: nothing passes
             if (__any(cand)) collect(prev[u], xx_prev[u], t * 32 + lj, cand);
             if constexpr (G == 1) {
 #pragma unroll
@@ -788,6 +791,221 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const bool cand = m >= (xx_prev[u] >> 1) && t < t1;
             if (__any(cand)) collect(prev[u], xx_prev[u], t * 32 + lj, cand);
         }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (parked) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(pair_cnt, (uint32_t)parked);
+        base = __shfl(base, 0, 64);
+        for (int i = lane; i < parked; i += 64)
+            if (base + i < pair_cap) pairs[base + i] = park_s[wave][i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The GEMM-shaped form of the same filter (flat_u8_gfilter_wide_kernel): ONE wave per SIMD that owns the SIMD's whole register file.
+// The 8-wave kernel above left the matrix pipe half idle for structural reasons: every wave reads every row tile from LDS (8 x 16 KB
+// per 32-row tile = half of the LDS bandwidth a tile's matrix time offers, arriving in lock-step bursts after the shared barrier), and
+// a tile gives a wave only 16 matrix instructions between barriers.  Here a wave keeps AQ x 32 queries in registers (AQ = 4: 256 of its
+// 512 registers), so one 16 KB tile read from LDS feeds AQ x KS matrix instructions in AQ independent chains (64 per barrier at
+// D = 512), LDS traffic per matrix instruction drops 4x, L2 -> LDS traffic 2x (512 queries per workgroup), and nothing on the SIMD
+// competes with the wave for the matrix pipe.  Synchronisation, DMA ring, threshold folding and the survivor path are the 8-wave
+// kernel's; the thr >> 1 start values come from LDS straight into the accumulators at the top of each tile (no registers held), and
+// the two accumulator sets swap roles from tile to tile (the previous tile's results are reduced while this tile accumulates).
+// ------------------------------------------------------------------------------------------------------------------
+template <int KS, int AQ, int NB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flat_u8_gfilter_wide_kernel(
+    const uint8_t *__restrict__ q, int64_t nq, const uint4 *__restrict__ pack, const int32_t *__restrict__ norms, int64_t n,
+    const float *__restrict__ sample_d, int k, int64_t tile_begin, int64_t tile_end, int64_t tiles_per_split, uint32_t pair_cap,
+    uint32_t *__restrict__ pair_cnt, uint4 *__restrict__ pairs, int qblocks, int dbg)
+{
+#ifndef CVTMI_GF_DBG
+    dbg = 0;
+#endif
+    constexpr int D = 32 * KS, NW = 4;
+    constexpr int PPW = KS / NW;              // 1 KB pieces each wave requests per tile
+    constexpr int OPS = PPW + 1;              // + the norms piece
+    constexpr int PBUF = 128;
+    constexpr int QPB = 32 * NW * AQ;
+    static_assert(KS % NW == 0, "pieces per tile must split evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) uint4 gf_ring[];   // [NB][KS * 64]
+    __shared__ int xx_s[NB][64];
+    __shared__ uint4 park_s[NW][PBUF];         // (query, row, distance, -)
+    __shared__ int qq_s[QPB], thr_s[QPB];
+    __shared__ __attribute__((aligned(16))) int thh_s[NW][AQ][2][16];   // thr >> 1 in accumulator order, per (wave, query set, lane half)
+    const int tid = threadIdx.x, lane = tid & 63, lj = lane & 31, lk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t bi = blockIdx.x >> 3;
+    const int split_id = (int)(blockIdx.x & 7) + 8 * (int)(bi / qblocks), qb_id = (int)(bi % qblocks);
+    i32x4 qreg[AQ][KS];
+#pragma unroll
+    for (int a = 0; a < AQ; ++a) {
+        const int ql = (wave * AQ + a) * 32 + lj;
+        const int64_t qi = (int64_t)qb_id * QPB + ql;
+        const int64_t qc = qi < nq ? qi : nq - 1;
+        const uint8_t *qp = q + qc * D;
+        int qq = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) qreg[a][s_] = *reinterpret_cast<const i32x4 *>(qp + 32 * s_ + 16 * lk);
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            qreg[a][s_] ^= (int)0x80808080;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qq = __builtin_amdgcn_sdot4(qreg[a][s_][c], qreg[a][s_][c], qq, false);
+        }
+        qq += __shfl_xor(qq, 32, 64);
+        if (lk == 0) {
+            const int tau = (int)__float_as_uint(sample_d[qc * k + k - 1]);  // integer distance bits (0x7f800000 = none: everything passes)
+            qq_s[ql] = qq;
+            thr_s[ql] = qi < nq ? tau - qq : (int)0x80000000;               // padding queries: nothing passes
+        }
+    }
+    __syncthreads();
+    if (lj < 16) {
+#pragma unroll
+        for (int a = 0; a < AQ; ++a) thh_s[wave][a][lk][lj] = thr_s[(wave * AQ + a) * 32 + (lj & 3) + 8 * (lj >> 2) + 4 * lk] >> 1;
+    }
+    __syncthreads();   // (also drains the ordinary loads above: from here on the loop's only memory traffic is the DMA)
+    const int64_t t0 = tile_begin + (int64_t)split_id * tiles_per_split;
+    int64_t t1 = t0 + tiles_per_split;
+    t1 = t1 < tile_end ? t1 : tile_end;
+    if (t0 >= t1) return;   // workgroup-uniform
+    const int64_t n_groups = t1 - t0;
+    const uint32_t ring_b = (uint32_t)(uintptr_t)gf_ring, xx_b = (uint32_t)(uintptr_t)&xx_s[0][0];
+    auto request = [&](int64_t g, int slot) {
+        int64_t t = t0 + g;
+        t = t < t1 ? t : t1 - 1;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave * PPW + i;
+            glds16(pack + (t * KS + p) * 64 + lane, ring_b + (uint32_t)(((slot * KS) + p) * 64 * 16));
+        }
+        int64_t row = t * 32 + lj;
+        row = row < n ? row : n - 1;
+        glds4(norms + row, xx_b + (uint32_t)(slot * 64 * 4));
+    };
+    int parked = 0;  // wave-uniform
+    auto collect = [&](const i32x16 &accq, int a, int xx, int64_t row, bool cand) {
+        uint32_t hit = 0;
+        const int qbase = (wave * AQ + a) * 32;
+        if (cand && row < n) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int th = thr_s[qbase + (e & 3) + 8 * (e >> 2) + 4 * lk];
+                const int dot = accq[e] - (th >> 1);
+                hit |= (xx - 2 * dot <= th ? 1u : 0u) << e;   // distance - |q'|^2 <= tau - |q'|^2, exact
+            }
+        }
+        while (__any(hit != 0)) {
+            const unsigned long long m = __ballot(hit != 0);
+            const int cnt = __popcll(m);
+            if (parked + cnt > PBUF) {  // flush (wave-uniform branch)
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(pair_cnt, (uint32_t)parked);
+                base = __shfl(base, 0, 64);
+                for (int i = lane; i < parked; i += 64)
+                    if (base + i < pair_cap) pairs[base + i] = park_s[wave][i];
+                parked = 0;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ordinary traffic must not sit between counted DMA requests
+            }
+            if (hit) {
+                const int e = __ffs((int)hit) - 1;
+                hit &= hit - 1;
+                int asel = accq[0];
+#pragma unroll
+                for (int j = 1; j < 16; ++j) asel = e == j ? accq[j] : asel;
+                const int ql = qbase + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                const int dot = asel - (thr_s[ql] >> 1);
+                park_s[wave][parked + __popcll(m & ((1ull << lane) - 1))] =
+                    make_uint4((uint32_t)(qb_id * QPB + ql), (uint32_t)row, (uint32_t)(xx - 2 * dot + qq_s[ql]), 0u);
+            }
+            parked += cnt;
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < NB - 1; ++p) request(p < n_groups ? p : n_groups - 1, p);
+    constexpr int PD = KS >= 8 ? 4 : 2;                   // K steps of operand reads in flight ahead of the matrix instructions
+    constexpr int MPS = (8 * AQ + KS - 1) / KS;           // v_max3 per K step
+    int xx_prev = 0x7fffffff;                             // nothing passes before the first tile
+    // one tile: accumulate into acc while prev (the tile before) is reduced and tested
+    auto body = [&](i32x16 (&acc)[AQ], i32x16 (&prev)[AQ], int64_t g) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * OPS) : "memory");  // own share of tile g has landed (later tiles may be in flight)
+        __builtin_amdgcn_s_barrier();                                // everyone's share has; everyone is done with tile g - 1
+        if (!(dbg & 1)) request(g + NB - 1 < n_groups ? g + NB - 1 : n_groups - 1, (int)((g + NB - 1) % NB));
+        const int slot = (int)(g % NB);
+        const i32x4 *pb = reinterpret_cast<const i32x4 *>(gf_ring) + (size_t)slot * KS * 64 + lane;
+        const int xx_cur = xx_s[slot][lj];
+#pragma unroll
+        for (int a = 0; a < AQ; ++a) {
+            const i32x4 *tp = reinterpret_cast<const i32x4 *>(&thh_s[wave][a][lk][0]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const i32x4 v = tp[c];
+                acc[a][4 * c] = v[0]; acc[a][4 * c + 1] = v[1]; acc[a][4 * c + 2] = v[2]; acc[a][4 * c + 3] = v[3];
+            }
+        }
+        int mx[AQ];
+#pragma unroll
+        for (int a = 0; a < AQ; ++a) mx[a] = (int)0x80000000;
+        i32x4 bv[KS];
+#pragma unroll
+        for (int s_ = 0; s_ < PD; ++s_) bv[s_] = pb[s_ * 64];
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            if (s_ + PD < KS) bv[s_ + PD] = pb[(s_ + PD) * 64];
+#pragma unroll
+            for (int a = 0; a < AQ; ++a) acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qreg[a][s_], bv[s_], acc[a], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < MPS; ++j) {
+                const int idx = s_ * MPS + j;   // max3 number idx of the 8 AQ: query set idx / 8, results 2 (idx % 8), + 1
+                if (idx < 8 * AQ) {
+                    const int a2 = idx >> 3, e = (idx & 7) * 2;
+                    const int m2 = prev[a2][e] > prev[a2][e + 1] ? prev[a2][e] : prev[a2][e + 1];
+                    mx[a2] = mx[a2] > m2 ? mx[a2] : m2;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * AQ + PD + 1, 0);
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            if (s_ + PD < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, AQ, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, MPS, 0);
+        }
+        const int64_t t = t0 + g - 1;
+#pragma unroll
+        for (int a = 0; a < AQ; ++a) {
+            const bool cand = mx[a] >= (xx_prev >> 1) && g > 0 && !(dbg & 2);
+            if (__any(cand)) collect(prev[a], a, xx_prev, t * 32 + lj, cand);
+        }
+        xx_prev = xx_cur;
+    };
+    auto tail = [&](i32x16 (&prev)[AQ]) __attribute__((always_inline)) {   // the last tile's tests
+        const int64_t t = t0 + n_groups - 1;
+#pragma unroll
+        for (int a = 0; a < AQ; ++a) {
+            int m = prev[a][0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) m = m > prev[a][e] ? m : prev[a][e];
+            const bool cand = m >= (xx_prev >> 1);
+            if (__any(cand)) collect(prev[a], a, xx_prev, t * 32 + lj, cand);
+        }
+    };
+    i32x16 ra[AQ], rb[AQ];
+#pragma unroll
+    for (int a = 0; a < AQ; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rb[a][e] = (int)0x80000000;
+    int64_t g = 0;
+    for (; g + 1 < n_groups; g += 2) {
+        body(ra, rb, g);
+        body(rb, ra, g + 1);
+    }
+    if (g < n_groups) {
+        body(ra, rb, g);
+        tail(ra);
+    } else {
+        tail(rb);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (parked) {
@@ -834,8 +1052,23 @@ __global__ __launch_bounds__(kBlock) void flat_u8_finish_kernel(const uint32_t *
     }
 }
 
+// timing experiments (results are WRONG when non-zero; honoured by -DCVTMI_GF_DBG builds only): bit 0 no DMA after the first groups,
+// bit 1 no survivor tests.  What they showed on 10 M x 512-d, nq = 4096 (tools/bench_flat_u8_opt.py, DBG=0,2,3): filter kernel 18.7 ms,
+// without the tests 17.6, without tests and DMA 14.4 = 2.8 P int-op/s -- against 3.2-3.5 P for a loop of nothing but matrix
+// instructions on random bytes (tools/ubench/mfma_i8_feed.hip; 4.4-4.9 P on constant bytes: the ceiling is the power the operands draw)
+static int g_u8_dbg = 0;
+int set_flat_u8_dbg(int v)
+{
+#ifdef CVTMI_GF_DBG
+    g_u8_dbg = v;
+    return CVTMI_OK;
+#else
+    (void)v;
+    return CVTMI_EUNSUPPORTED;
+#endif
+}
 static int g_u8_gfilter = 1;  // cvtmi_set_tuning("flat_u8_gfilter"): 1 = the software-pipelined filter kernel where it applies (D = 64 .. 512, power of two)
-void set_flat_u8_gfilter(int v) { g_u8_gfilter = v; }  // 0 off, 1 choose, 2 two 4-wave workgroups per CU, 3 one 8-wave workgroup per CU
+void set_flat_u8_gfilter(int v) { g_u8_gfilter = v; }  // 0 off, 1 choose, 2 two 4-wave workgroups per CU, 3 one 8-wave workgroup per CU, 4 one wave per SIMD x 128 queries
 bool flat_u8_gfilter_shape(int D) { return g_u8_gfilter && (D == 64 || D == 128 || D == 256 || D == 512); }
 
 bool flat_u8_filter_applies(int D, int64_t n, int64_t nq, int k)
@@ -860,12 +1093,23 @@ int launch_flat_u8_filter(const uint8_t *q, int64_t nq, int D, const uint4 *pack
     if (tile_end <= tile_begin) return CVTMI_OK;
     if (flat_u8_gfilter_shape(D)) {  // the software-pipelined kernel
         const bool two = g_u8_gfilter == 2;   // two 4-wave workgroups per CU: measured 15 % slower than one 8-wave workgroup (16 matrix instructions per barrier)
-        const int qpb = two ? 128 : 256;
+        const bool wide4 = g_u8_gfilter == 4 && D >= 128;   // one wave per SIMD, 96-128 queries per wave (flat_u8_gfilter_wide_kernel): measured equal at nq = 4096, 10 % slower at nq = 1000
+        const int qpb = wide4 ? (D == 512 ? 384 : 512) : (two ? 128 : 256);
         const int64_t qblocks = (nq + qpb - 1) / qpb;
         const int64_t want = two ? 512 : 256;                                     // workgroups resident at a time
-        int64_t splits = std::max<int64_t>(1, (want + qblocks - 1) / qblocks);
-        int64_t tps = std::max<int64_t>(64, (tile_end - tile_begin + splits - 1) / splits);
-        splits = (tile_end - tile_begin + tps - 1) / tps;
+        // row splits: a multiple of 8 (one split per XCD at a time), chosen so that rounds(grid / resident) x tiles per split is smallest --
+        // qblocks x splits rarely lands on a multiple of the resident count, and a 3 % overhang used to cost a whole second round
+        // (nq = 3840: 15 x 24 = 360 workgroups on 256 slots, 33 ms against 21 ms for nq = 4096)
+        const int64_t tiles = tile_end - tile_begin;
+        int64_t tps = tiles, best_cost = INT64_MAX;
+        for (int64_t m = 1; m <= 256; ++m) {
+            const int64_t t = std::max<int64_t>(64, (tiles + 8 * m - 1) / (8 * m));
+            const int64_t s_used = (tiles + t - 1) / t, grid = (s_used + 7) / 8 * 8 * qblocks;
+            const int64_t cost = (grid + want - 1) / want * (t + 24);              // + start-up of a workgroup, in tiles
+            if (cost < best_cost) { best_cost = cost; tps = t; }
+            if (t == 64) break;
+        }
+        const int64_t splits = (tiles + tps - 1) / tps;
         const int64_t splits8 = (splits + 7) / 8 * 8;
         if (splits8 * qblocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "flat u8 filter: nq too large");
         const dim3 g((unsigned)(splits8 * qblocks));
@@ -874,8 +1118,25 @@ int launch_flat_u8_filter(const uint8_t *q, int64_t nq, int D, const uint4 *pack
         const size_t lds = (size_t)(NB) * (G) * (N) * 64 * sizeof(uint4);                                                        \
         CVTMI_HIP(hipFuncSetAttribute((const void *)flat_u8_gfilter_kernel<N, NW, G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((flat_u8_gfilter_kernel<N, NW, G, NB>), g, dim3(64 * (NW)), lds, st, q, nq, pack, norms, n, sample_d, k, tile_begin, tile_end, \
-                           tps, pair_cap, pair_cnt, pairs, (int)qblocks);                                                        \
+                           tps, pair_cap, pair_cnt, pairs, (int)qblocks, g_u8_dbg);                                              \
     } while (0)
+#define CVTMI_GW(N, AQ, NB)                                                                                                      \
+    do {                                                                                                                         \
+        const size_t lds = (size_t)(NB) * (N) * 64 * sizeof(uint4);                                                              \
+        CVTMI_HIP(hipFuncSetAttribute((const void *)flat_u8_gfilter_wide_kernel<N, AQ, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((flat_u8_gfilter_wide_kernel<N, AQ, NB>), g, dim3(256), lds, st, q, nq, pack, norms, n, sample_d, k, tile_begin, tile_end, \
+                           tps, pair_cap, pair_cnt, pairs, (int)qblocks, g_u8_dbg);                                              \
+    } while (0)
+        if (wide4) {
+            switch (D / 32) {
+                case 4: CVTMI_GW(4, 4, 4); break;
+                case 8: CVTMI_GW(8, 4, 4); break;
+                default: CVTMI_GW(16, 3, 4); break;   // 3 x 64 operand registers (an 8-slot ring measured the same as 4: the DMA is not latency-bound): the fourth query set does not fit beside two accumulator sets
+            }
+            CVTMI_HIP(hipGetLastError());
+            return CVTMI_OK;
+        }
+#undef CVTMI_GW
         switch (D / 32) {
             case 2: CVTMI_GF(2, 8, 4, 3); break;
             case 4: if (two) CVTMI_GF(4, 4, 2, 3); else CVTMI_GF(4, 8, 2, 3); break;

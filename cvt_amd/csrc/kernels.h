@@ -122,6 +122,7 @@ int launch_flat_u8_mfma(int D, const uint8_t *data, const int32_t *norms, int64_
                         int splits, float *part_d, int64_t *part_id, uint32_t *gthr, hipStream_t st);
 // ids[i] = ids[i] >= 0 ? labels[ids[i]] : -1
 void set_flat_u8_opt(int v);
+int set_flat_u8_dbg(int v);   // -DCVTMI_GF_DBG builds only
 // uint8 L2, 1..4 queries: coalesced streaming of the rows into an int32 distance array + selection (flat.hip)
 bool flat_u8_stream_applies(int D, int64_t n, int64_t nq, int k);
 int set_flat_u8_stream_blocks(int v);   // measurement hook

@@ -78,8 +78,10 @@ int cvtmi_set_device(int device);
  *                     from nq * D >= 128 K on >= 1 M rows -- smaller ones on the exact / row-tile kernels); 1 = exact / row-tile
  *                     kernels only; 2 = the filter pipelines wherever they apply
  *   "flat_u8_gfilter" the uint8 filter stage: 1 (default) / 3 = LDS-DMA pipelined kernel, one 8-wave workgroup per CU; 2 = two 4-wave
- *                     workgroups per CU; 0 = the round-1 filter kernel (register-staged tiles)
- *   "flat_u8_stream_blocks"  workgroups of the 1..4-query uint8 streaming kernel (default 1024 = 4 waves per SIMD; multiple of 16, 256..8192)
+ *                     workgroups per CU; 4 = one wave per SIMD holding 96-128 queries (GEMM-shaped; measured equal / slower);
+ *                     0 = the round-1 filter kernel (register-staged tiles)
+ *   "flat_u8_dbg"     timing experiments of the filter kernel (-DCVTMI_GF_DBG builds only; EUNSUPPORTED otherwise: results are wrong)
+ *   "flat_u8_stream_blocks"  workgroups of the 1..4-query uint8 streaming kernel (default 1024 = 4 waves per SIMD; multiple of 16, 256..2048)
  *   "flat_u8_opt"     measurement variants of the uint8 row-tile kernel (0 = shipped; 1..3 spill registers and are slower)
  *   "probe_variant"   coarse top-nk of cvtmi_opq_query_video: 0 = choose (matrix-core filter + exact distances of the candidates
  *                     from 256 query frames, 32 <= D <= 128, coarseK >= 256); 1 = exact kernels only; 2 = filter wherever it applies

@@ -67,7 +67,7 @@ def test_flat_seeded(amd, orc, metric, D):
 
 
 @pytest.mark.parametrize("D,nq,k", [(512, 200, 10), (512, 70, 16), (256, 100, 40), (128, 40, 48), (512, 150, 100),
-                                     (64, 300, 1), (512, 33, 5), (96, 129, 12)])
+                                     (64, 300, 1), (512, 33, 5), (96, 129, 12), (512, 5, 10), (128, 7, 128)])
 def test_flat_u8_mfma_query_tiles(amd, orc, D, nq, k):
     """i8 matrix-core path with 32 / 64 / 128 queries per workgroup (chosen by k and nq): bit-exact distances
     and ids incl. duplicate rows (id tie-break) and rows sorted by decreasing distance to a query (every row
@@ -372,6 +372,33 @@ def test_flat_f32_filter_ties_arrive_out_of_order(amd):
     finally:
         amd.set_tuning("flat_variant", 0)
     assert np.array_equal(out[2][1], out[1][1]) and np.array_equal(bits(out[2][0]), bits(out[1][0]))
+
+
+@pytest.mark.parametrize("D,nq", [(512, 500), (128, 700), (256, 130)])
+def test_flat_u8_filter_wide_kernel_variant(amd, orc, D, nq):
+    """flat_u8_gfilter 4 (one wave per SIMD, 96 / 128 queries per wave, ring of 4 tiles) against the default 8-wave filter kernel
+    and the checker: query counts that leave the last query block partly empty, duplicates, odd and even tile counts per split"""
+    rng = np.random.default_rng(D + nq)
+    n, k = 262_144 + 32 * 7 + 5, 10
+    x = rng.integers(0, 256, size=(n, D), dtype=np.uint8)
+    x[200_000:200_050] = x[9]; x[n - 1] = x[9]
+    q = x[rng.integers(0, n, nq)].copy()
+    q[:, :3] ^= 1
+    q[0] = x[9]
+    out = {}
+    try:
+        amd.set_tuning("flat_variant", 2)
+        for gf in (1, 4):
+            amd.set_tuning("flat_u8_gfilter", gf)
+            ix = amd.FlatIndex(L2U8, D); ix.add(x)
+            out[gf] = ix.search(q, k)
+            assert ix.last_search()[0]
+            ix.close()
+    finally:
+        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_u8_gfilter", 1)
+    assert np.array_equal(out[4][1], out[1][1]) and np.array_equal(out[4][0], out[1][0])
+    od, odi, oi = orc.flat_search(L2U8, x, q[:12], k)
+    assert np.array_equal(out[4][1][:12], oi) and np.array_equal(out[4][0][:12], odi)
 
 
 @pytest.mark.parametrize("D,k,hi", [(512, 10, 256), (64, 64, 6), (96, 1, 256), (256, 33, 40)])
