@@ -1036,7 +1036,7 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
     bool done = false;
     h->f_last_worst = 0;
     if (g_flat_variant != 1 && ((uintptr_t)q & 15) == 0 && nq <= 65535 &&
-        flat_filter_applies(h->metric, h->D, g_flat_variant == 2 ? std::max<int64_t>(h->n, 131072) : h->n, g_flat_variant == 2 ? std::max<int64_t>(nq, 64) : nq, k) &&
+        flat_filter_applies(h->metric, h->D, g_flat_variant == 2 ? std::max<int64_t>(h->n, 131072) : h->n, g_flat_variant == 2 ? std::max<int64_t>(nq, 16) : nq, k) &&
         h->n >= 2 * 65536)
         CVTMI_TRY(flat_search_filtered(h, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
     // uint8: large batches go through the filter pipeline with the software-pipelined (LDS-DMA) kernel -- measured at 10 M x 512-d:

@@ -456,3 +456,29 @@ def test_flat_u8_tiny_batch_stream(amd, orc, D, nq, k, hi):
     od, odi, oi = orc.flat_search(L2U8, x, q, k)
     assert np.array_equal(out[0][1], oi) and np.array_equal(out[0][0], odi)
     assert out[0][1][0, :min(k, 3)].tolist() == [3, 131_072, n - 1][:min(k, 3)]
+
+
+@pytest.mark.parametrize("metric,nq", [(IP, 16), (L2F, 17), (IP, 40), (L2F, 63)])
+def test_flat_f32_filter_small_batches(amd, orc, metric, nq):
+    """16..63 queries take the matrix-core filter by default (flat_variant 0): same answer as the exact kernels and the checker,
+    distances bit for bit; duplicates of a row give (distance, row) ties"""
+    rng = np.random.default_rng(nq)
+    n, D, k = 300_000, 128, 10
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    x[250_000:250_020] = x[11]
+    q = (x[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, D))).astype(np.float32)
+    q[0] = x[11]
+    bits = lambda a: np.asarray(a, dtype=np.float32).view(np.uint32)
+    ix = amd.FlatIndex(metric, D); ix.add(x)
+    try:
+        d0, i0 = ix.search(q, k)
+        assert ix.last_search()[0]
+        amd.set_tuning("flat_variant", 1)
+        d1, i1 = ix.search(q, k)
+        assert not ix.last_search()[0]
+    finally:
+        amd.set_tuning("flat_variant", 0)
+    assert np.array_equal(i0, i1) and np.array_equal(bits(d0), bits(d1))
+    od, _, oi = orc.flat_search(metric, x, q[:8], k, flavour=4 if metric == IP else 8)
+    assert np.array_equal(i0[:8], oi) and np.array_equal(bits(d0[:8]), bits(od))
+    ix.close()
