@@ -416,6 +416,14 @@ def secondary(args, dev, books, R):
                                       "what": "raw rows -> codes in one call: rotation and encode chunk by chunk through a cache-resident scratch (cvtmi_opq_rotate_encode)"}
     except AttributeError:
         pass
+    # the reference's own rotation is a permutation of the dimensions (reorder_, IVFOPQ.cpp:424-439): the encode kernel gathers through it
+    ixp = cvt_amd.OpqIndex(zero, books, perm=synth.random_permutation(D, seed=5))
+    ms_two = _ev_ms(torch, lambda: ixp.encode(ixp.rotate(x)))
+    ms = _ev_ms(torch, lambda: ixp.rotate_encode(x))
+    sec["reorder_encode"] = {"rows": n, "ms": round(ms, 4), "rows_per_s": round(n / (ms * 1e-3), 1),
+                             "rows_per_s_permute_then_encode": round(n / (ms_two * 1e-3), 1),
+                             "what": "raw rows -> codes for a permutation model (the reference's IVFOPQ::reorder + Add): one kernel, the rows are read through the permutation"}
+    ixp.close()
     ix.close(); del x, xr
     # ---- a-Q / a-T SQ8: train + encode, 2 M x 512-d ----
     d3 = 512

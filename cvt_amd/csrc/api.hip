@@ -289,6 +289,10 @@ int cvtmi_opq_rotate_encode_dev(cvtmi_opq_t h, const float *x, int64_t n, int32_
     if (n < 0 || (n > 0 && (!x || !codes))) return fail(CVTMI_EINVAL, "cvtmi_opq_rotate_encode: bad arguments");
     if (n == 0) return CVTMI_OK;
     if (!h->m.perm && !h->m.R) return cvtmi_opq_encode_dev(h, x, n, list_id, codes, stream);
+    // the reference's own rotation is a permutation (reorder_, IVFOPQ.cpp:424-439): the exhaustive-model encode gathers through it,
+    // no permuted copy of the rows is made
+    if (h->m.perm && h->m.coarseK == 1 && pq_encode_takes_perm(h->m, x, n, h->p_encode))
+        return launch_pq_encode(h->m, x, n, nullptr, codes, (hipStream_t)stream, h->p_encode, list_id, h->m.perm);
     const int64_t chunk = 131072;
     CVTMI_TRY(h->s_rot.reserve((size_t)std::min(n, chunk) * h->m.D * sizeof(float)));
     for (int64_t a = 0; a < n; a += chunk) {

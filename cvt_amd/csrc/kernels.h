@@ -24,7 +24,9 @@ int launch_coarse_assign(const OpqModelDev &m, const float *x_rot, int64_t n, in
 // single_list_out (coarseK == 1 only, and only when pq_encode_fuses_lists() says so): the encode kernel writes the list
 // assignment (0, or -1 for rows no centroid can claim) itself, sparing the separate pass over the rows
 int launch_pq_encode(const OpqModelDev &m, const float *x_rot, int64_t n, const int32_t *list_id, uint8_t *codes,
-                     hipStream_t st, int variant = 0, int32_t *single_list_out = nullptr);
+                     hipStream_t st, int variant = 0, int32_t *single_list_out = nullptr, const int32_t *perm = nullptr);
+// perm != nullptr: x_rot holds the rows BEFORE the model's permutation and the kernel gathers through it (needs pq_encode_takes_perm)
+bool pq_encode_takes_perm(const OpqModelDev &m, const float *x, int64_t n, int variant);
 bool pq_encode_fuses_lists(const OpqModelDev &m, const float *x_rot, int64_t n, int variant);
 // ld: entries per (query, m) row of the output, 0 = K; ld > K pads with +inf
 int launch_lut(const OpqModelDev &m, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut,

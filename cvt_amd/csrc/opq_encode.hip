@@ -249,13 +249,18 @@ __device__ __forceinline__ void top2_merge(float &a1, float &a2, float b1, float
     a2 = fmaxf(lo, fmaxf(a2, b2));
 }
 
-template <int STEP>
+// PERM (STEP == 8): x holds the rows BEFORE the reference's reorder_ (IVFOPQ.cpp:424-439, y[i] = x[perm[i]]); the eight values of a
+// sub-quantiser are gathered from the row through perm (wave-uniform indices: scalar loads) instead of read as two float4 -- the
+// permuted copy of the rows, 2 x 4 D bytes per row of traffic and a launch, never exists (cvtmi_opq_rotate_encode on a perm model).
+template <int STEP, bool PERM = false>
 __global__ __launch_bounds__(ENCM_THREADS) void pq_encode_mfma_kernel(const float *__restrict__ x, int64_t n, int D, int M,
                                                                        const float *__restrict__ coarse,
                                                                        const int32_t *__restrict__ list_id,
                                                                        const float *__restrict__ books,
-                                                                       uint8_t *__restrict__ codes, int32_t *__restrict__ list_out)
+                                                                       uint8_t *__restrict__ codes, int32_t *__restrict__ list_out,
+                                                                       const int32_t *__restrict__ perm = nullptr)
 {
+    static_assert(!PERM || STEP == 8, "the gathered read is wave-uniform only when a lane owns all 8 values of a sub-quantiser");
     constexpr int WAVES = ENCM_THREADS / 64;
     constexpr int LOFF = STEP == 16 ? 8 : 0;  // step 16: a lane half owns dimensions [8 * (lane >> 5), +8); step 8: all 8
     using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -301,10 +306,27 @@ __global__ __launch_bounds__(ENCM_THREADS) void pq_encode_mfma_kernel(const floa
         // issued between the ~200 VALU instructions that reduce the CURRENT unit's 64 accumulators.
         float xv[8], cv[8], r[8], rn[8];
         auto fetch = [&](int m) {
+            if constexpr (PERM) {
+                // Both lane halves need all eight values (K = 0..7 against r1, 8..15 against r2), but a gathered dword load costs the
+                // texture path a cycle per row whatever its width: each half fetches four (its own scalar-selected index) and
+                // v_permlane32_swap hands them across -- 4 loads + 4 swaps per sub-quantiser instead of 8 loads
+                const int32_t *pm = perm + m * STEP;   // uniform address
 #pragma unroll
-            for (int q = 0; q < 8; q += 4) {
-                *reinterpret_cast<float4 *>(&xv[q]) = *reinterpret_cast<const float4 *>(xp + m * STEP + q);
-                *reinterpret_cast<float4 *>(&cv[q]) = *reinterpret_cast<const float4 *>(cp + m * STEP + q);
+                for (int j = 0; j < 4; ++j) {
+                    const int i0 = pm[j], i1 = pm[4 + j];
+                    const uint32_t a = __float_as_uint(xp[lk ? i1 : i0]);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(a, a, false, false);   // [0]: low half's value everywhere, [1]: high half's
+                    xv[j] = __uint_as_float(sw[0]);
+                    xv[4 + j] = __uint_as_float(sw[1]);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q += 4) *reinterpret_cast<float4 *>(&cv[q]) = *reinterpret_cast<const float4 *>(cp + m * STEP + q);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; q += 4) {
+                    *reinterpret_cast<float4 *>(&xv[q]) = *reinterpret_cast<const float4 *>(xp + m * STEP + q);
+                    *reinterpret_cast<float4 *>(&cv[q]) = *reinterpret_cast<const float4 *>(cp + m * STEP + q);
+                }
             }
         };
         // the row side of the products: r = r1 + r2 (+ 2^-18 |r|) in bf16
@@ -571,10 +593,17 @@ bool pq_encode_fuses_lists(const OpqModelDev &m, const float *x_rot, int64_t n, 
 
 // variant: 0 = choose, 1 = the VALU kernel (reference chain for every centroid), 2 = matrix-core filter + exact resolution
 // single_list_out: coarseK == 1 and pq_encode_fuses_lists(): the kernel also writes the list assignment (0 / -1)
+// can launch_pq_encode read the rows through the model's permutation (x = rows before reorder_)?
+bool pq_encode_takes_perm(const OpqModelDev &m, const float *x, int64_t n, int variant)
+{
+    return m.perm && m.step == 8 && encm_ok(m, x) && (variant == 2 || (variant == 0 && n >= 8192));
+}
+
 int launch_pq_encode(const OpqModelDev &m, const float *x_rot, int64_t n, const int32_t *list_id, uint8_t *codes,
-                     hipStream_t st, int variant, int32_t *single_list_out)
+                     hipStream_t st, int variant, int32_t *single_list_out, const int32_t *perm)
 {
     if (n <= 0) return CVTMI_OK;
+    if (perm && !pq_encode_takes_perm(m, x_rot, n, variant)) return fail(CVTMI_EINVAL, "pq_encode: gathered rows without the matrix-core kernel");
     if (m.K > 256) return fail(CVTMI_EUNSUPPORTED, "pq_encode: K=%d > 256", m.K);
     const size_t lds_mfma = encm_lds(m);
     const bool mfma_ok = encm_ok(m, x_rot);
@@ -584,14 +613,18 @@ int launch_pq_encode(const OpqModelDev &m, const float *x_rot, int64_t n, const 
         constexpr int waves = ENCM_THREADS / 64;
         const int64_t nbatch = (n + 31) / 32;
         const int64_t blocks = std::min<int64_t>(encm_cus(), (nbatch + waves - 1) / waves);
-        if (m.step == 8) {
+        if (perm) {
+            CVTMI_HIP(hipFuncSetAttribute((const void *)pq_encode_mfma_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
+            hipLaunchKernelGGL((pq_encode_mfma_kernel<8, true>), dim3((unsigned)blocks), dim3(ENCM_THREADS), lds_mfma, st, x_rot, n, m.D, m.M,
+                               m.coarse, list_id, m.books, codes, single_list_out, perm);
+        } else if (m.step == 8) {
             CVTMI_HIP(hipFuncSetAttribute((const void *)pq_encode_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
             hipLaunchKernelGGL((pq_encode_mfma_kernel<8>), dim3((unsigned)blocks), dim3(ENCM_THREADS), lds_mfma, st, x_rot, n, m.D, m.M,
-                               m.coarse, list_id, m.books, codes, single_list_out);
+                               m.coarse, list_id, m.books, codes, single_list_out, nullptr);
         } else {
             CVTMI_HIP(hipFuncSetAttribute((const void *)pq_encode_mfma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
             hipLaunchKernelGGL((pq_encode_mfma_kernel<16>), dim3((unsigned)blocks), dim3(ENCM_THREADS), lds_mfma, st, x_rot, n, m.D, m.M,
-                               m.coarse, list_id, m.books, codes, single_list_out);
+                               m.coarse, list_id, m.books, codes, single_list_out, nullptr);
         }
         CVTMI_HIP(hipGetLastError());
         return CVTMI_OK;

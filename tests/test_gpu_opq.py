@@ -439,15 +439,20 @@ def test_rotate_encode_one_call(amd, orc):
     D, M, K = 128, 16, 256
     rng = np.random.default_rng(321)
     books = synth_model(rng, D, M, K)
-    for coarseK, rot in ((1, "R"), (7, "perm")):
+    for coarseK, rot in ((1, "R"), (7, "perm"), (1, "perm")):   # (1, perm): the encode kernel gathers through the permutation itself
         coarse = np.zeros((1, D), np.float32) if coarseK == 1 else rng.normal(size=(coarseK, D)).astype(np.float32)
         kw = {"R": synth.random_rotation(D, seed=5)} if rot == "R" else {"perm": synth.random_permutation(D, seed=5)}
         idx = amd.OpqIndex(coarse, books, **kw)
         n = 131072 * 2 + 777
         x = torch.from_numpy(rng.normal(size=(n, D)).astype(np.float32)).cuda()
+        x[17, 5] = float("nan"); x[18] = float("inf"); x[19] = 0.0; x[20] = x[21]      # hard rows: same answer on either path
         l0, c0 = idx.encode(idx.rotate(x))
         l1, c1 = idx.rotate_encode(x)
         assert torch.equal(c0, c1) and torch.equal(l0, l1)
         l2, c2 = idx.rotate_encode(x[:5000].cpu().numpy())
         assert np.array_equal(c2, c0[:5000].cpu().numpy()) and np.array_equal(l2, l0[:5000].cpu().numpy())
+        if rot == "perm" and coarseK == 1:   # and the checker's encode of the permuted rows (rows without non-finite values)
+            xp = x[100:400].cpu().numpy()[:, kw["perm"]]
+            _, oc = orc.pq_encode(np.ascontiguousarray(xp), coarse, books)
+            assert np.array_equal(oc, c1[100:400].cpu().numpy())
         idx.close()
