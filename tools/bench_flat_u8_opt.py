@@ -5,6 +5,9 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, cvt_amd
+if os.environ.get("DBG_LIB"):   # a -DCVTMI_GF_DBG build of the library (tools/README.md)
+    from cvt_amd import capi
+    capi.LIB_PATH = os.environ["DBG_LIB"]
 dev = torch.device("cuda", 0)
 n, D = int(os.environ.get("ROWS", 10_000_000)), int(os.environ.get("D", 512))
 g = torch.Generator(device=dev); g.manual_seed(5)
