@@ -365,13 +365,14 @@ __device__ __forceinline__ void stream_fold(int (&s)[V], int sub)
     }
 }
 constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v / 2); }
+constexpr int stream_u(int qt) { return qt <= 4 ? 8 : (qt == 8 ? 4 : 2); }   // loads in flight per lane: 32 sums per iteration at most
 
 template <int LPR, int QT>   // lanes per row (D = 16 LPR), queries
 __global__ __launch_bounds__(kBlock) void flat_u8_stream_kernel(const uint8_t *__restrict__ X, const int32_t *__restrict__ norms, int64_t n,
                                                                 const uint8_t *__restrict__ Q, int nq, int64_t ld_out,
                                                                 int32_t *__restrict__ out, int32_t *__restrict__ gmin)
 {
-    constexpr int RPL = 64 / LPR, U = 8, V = U * QT;      // rows per wave-load, loads in flight per lane, sums per iteration
+    constexpr int RPL = 64 / LPR, U = stream_u(QT), V = U * QT;   // rows per wave-load, loads in flight per lane, sums per iteration
     constexpr int LB = ilog2_c(LPR), VB = ilog2_c(V);
     constexpr int T = LB < VB ? LB : VB;                  // halving steps
     constexpr int R = V >> T;                             // sums a lane ends up with: v = (top T bits of sub) * R + i, v = u * QT + q
@@ -1262,8 +1263,10 @@ constexpr int STREAM_SLICES = 64;
 static int g_stream_blocks_get();
 bool flat_u8_stream_applies(int D, int64_t n, int64_t nq, int k)
 {
-    if (!(nq >= 1 && nq <= 4 && (D == 128 || D == 256 || D == 512) && n >= 262144 && n < 0x7fffffff && k <= 128)) return false;
-    const int64_t rows_per_round = (int64_t)g_stream_blocks_get() * (kBlock / 64) * (64 / (D / 16) * 8);   // waves x rows per wave iteration
+    // 9..16 queries: the dot products start to bound the stream (10 M rows: D = 512 1.9-2.0 ms against 1.75 on the matrix-core row tiles,
+    // D = 256 1.25 against 1.45, D = 128 0.81 against 1.28)
+    if (!(nq >= 1 && (nq <= 8 || (nq <= 16 && D <= 256)) && (D == 128 || D == 256 || D == 512) && n >= 262144 && n < 0x7fffffff && k <= 128)) return false;
+    const int64_t rows_per_round = (int64_t)g_stream_blocks_get() * (kBlock / 64) * (64 / (D / 16) * 2);   // waves x rows per wave iteration (at least)
     return n / STREAM_SLICES / rows_per_round + 2 <= FIN_MAXR;   // rounds a finish slice can span (always true at the default grid)
 }
 static int g_stream_blocks = 1024;   // waves = 4 x blocks = 4 per SIMD: every wave resident at once for any QT (measured 10 M x 512: 1024 blocks 0.917 / 0.911 / 0.988 ms for 1 / 2 / 4 queries, 2048: 0.909 / 0.958 / 1.127); a multiple of 16 so that the finish slices divide the waves evenly
@@ -1295,10 +1298,13 @@ int launch_flat_u8_stream(int D, const uint8_t *data, const int32_t *norms, int6
     int rpi_log2 = 0;
 #define CVTMI_FS(L)                                                                                                                          \
     do {                                                                                                                                     \
-        rpi_log2 = ilog2_c(64 / L * 8);                                                                                                      \
-        if (nq == 1) hipLaunchKernelGGL((flat_u8_stream_kernel<L, 1>), dim3(STREAM_BLOCKS), dim3(kBlock), 0, st, data, norms, n, q, (int)nq, ld, dist, gmin); \
-        else if (nq == 2) hipLaunchKernelGGL((flat_u8_stream_kernel<L, 2>), dim3(STREAM_BLOCKS), dim3(kBlock), 0, st, data, norms, n, q, (int)nq, ld, dist, gmin); \
-        else hipLaunchKernelGGL((flat_u8_stream_kernel<L, 4>), dim3(STREAM_BLOCKS), dim3(kBlock), 0, st, data, norms, n, q, (int)nq, ld, dist, gmin); \
+        const int qt = nq <= 1 ? 1 : (nq <= 2 ? 2 : (nq <= 4 ? 4 : (nq <= 8 ? 8 : 16)));                                                     \
+        rpi_log2 = ilog2_c(64 / L * stream_u(qt));                                                                                           \
+        if (qt == 1) hipLaunchKernelGGL((flat_u8_stream_kernel<L, 1>), dim3(STREAM_BLOCKS), dim3(kBlock), 0, st, data, norms, n, q, (int)nq, ld, dist, gmin); \
+        else if (qt == 2) hipLaunchKernelGGL((flat_u8_stream_kernel<L, 2>), dim3(STREAM_BLOCKS), dim3(kBlock), 0, st, data, norms, n, q, (int)nq, ld, dist, gmin); \
+        else if (qt == 4) hipLaunchKernelGGL((flat_u8_stream_kernel<L, 4>), dim3(STREAM_BLOCKS), dim3(kBlock), 0, st, data, norms, n, q, (int)nq, ld, dist, gmin); \
+        else if (qt == 8) hipLaunchKernelGGL((flat_u8_stream_kernel<L, 8>), dim3(STREAM_BLOCKS), dim3(kBlock), 0, st, data, norms, n, q, (int)nq, ld, dist, gmin); \
+        else hipLaunchKernelGGL((flat_u8_stream_kernel<L, 16>), dim3(STREAM_BLOCKS), dim3(kBlock), 0, st, data, norms, n, q, (int)nq, ld, dist, gmin); \
     } while (0)
     switch (D) {
         case 128: CVTMI_FS(8); break;

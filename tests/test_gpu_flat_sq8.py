@@ -430,9 +430,10 @@ def test_flat_u8_filter_pipeline(amd, orc, D, k, hi):
     assert np.array_equal(out[2][1][:16], oi) and np.array_equal(out[2][0][:16], odi)
 
 
-@pytest.mark.parametrize("D,nq,k,hi", [(512, 1, 10, 256), (128, 3, 128, 4), (256, 4, 1, 256), (512, 2, 33, 256)])
+@pytest.mark.parametrize("D,nq,k,hi", [(512, 1, 10, 256), (128, 3, 128, 4), (256, 4, 1, 256), (512, 2, 33, 256), (512, 8, 10, 256), (128, 16, 5, 256),
+                                        (256, 11, 20, 4), (512, 7, 128, 256)])
 def test_flat_u8_tiny_batch_stream(amd, orc, D, nq, k, hi):
-    """1..4 uint8 queries go through the coalesced streaming kernel + per-split selection + merge (flat_variant 0) -- against the
+    """1..16 uint8 queries go through the coalesced streaming kernel + per-split selection + merge (flat_variant 0) -- against the
     row-per-lane kernels (flat_variant 1) and the checker; ragged row count (last split partly empty), duplicate rows at both
     ends of the table (ties resolved by row), few distinct byte values (masses of equal distances), a far query (distances > 2^24, not exact in f32)"""
     rng = np.random.default_rng(D * 7 + k)
