@@ -145,8 +145,9 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         return CVTMI_OK;
     }
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
-    if (!strcmp(name, "flat_u8_stream_blocks")) {
-        if (set_flat_u8_stream_blocks((int)value) != CVTMI_OK) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_u8_stream_blocks must be a multiple of 16 in 256..2048");
+    if (!strcmp(name, "flat_u8_mstream_min")) {
+        if (value < 1 || value > 129) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_u8_mstream_min must be 1..129");
+        set_flat_u8_mstream_min((int)value);
         return CVTMI_OK;
     }
     if (!strcmp(name, "flat_u8_dbg")) {
@@ -878,14 +879,17 @@ int cvtmi_flat_reset(cvtmi_flat_t h)
 // the exact search over rows [0, n_rows) of the handle: k smallest (distance, row) per query, rows not yet mapped to labels
 static int flat_search_rows(cvtmi_flat_t h, int64_t n_rows, const void *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st)
 {
-    if (h->metric == CVTMI_METRIC_L2U8 && g_flat_variant != 1 && h->norms.p && flat_u8_stream_applies(h->D, n_rows, nq, k) && ((uintptr_t)q & 15) == 0) {
-        int S = 1;
-        const size_t bytes = flat_u8_stream_scratch(n_rows, nq, &S, nullptr);
+    if (h->metric == CVTMI_METRIC_L2U8 && g_flat_variant != 1 && h->norms.p && flat_u8_mstream_applies(h->D, n_rows, nq, k) && ((uintptr_t)q & 15) == 0) {
+        int nqp = 0, waves = 0;
+        const size_t bytes = flat_u8_mstream_scratch(n_rows, nq, &nqp, &waves);
+        const int S = flat_u8_stream_slices();
         CVTMI_TRY(h->s_stage.reserve(bytes));
         CVTMI_TRY(h->s_part_d.reserve((size_t)nq * S * k * sizeof(float)));
         CVTMI_TRY(h->s_part_id.reserve((size_t)nq * S * k * sizeof(int64_t)));
-        return launch_flat_u8_stream(h->D, h->data.as<uint8_t>(), h->norms.as<int32_t>(), n_rows, reinterpret_cast<const uint8_t *>(q), nq, k,
-                                     h->s_stage.as<float>(), h->s_part_d.as<float>(), h->s_part_id.as<int64_t>(), dist, rows, st);
+        int32_t *tmin = h->s_stage.as<int32_t>(), *wmin = tmin + (size_t)((n_rows + 31) / 32) * nqp;
+        CVTMI_TRY(launch_flat_u8_mstream(h->D, h->data.as<uint8_t>(), h->norms.as<int32_t>(), n_rows, reinterpret_cast<const uint8_t *>(q), nq, tmin, wmin, st));
+        return launch_flat_u8_mstream_finish(h->D, h->data.as<uint8_t>(), n_rows, reinterpret_cast<const uint8_t *>(q), nq, k, wmin, waves, tmin, nqp,
+                                             h->s_part_d.as<float>(), h->s_part_id.as<int64_t>(), dist, rows, st);
     }
     const bool mfma = h->metric == CVTMI_METRIC_L2U8 && flat_u8_mfma_qtile(h->D, k, nq) > 0;
     const int qt = mfma ? flat_u8_mfma_qtile(h->D, k, nq) : flat_qtile(nq);

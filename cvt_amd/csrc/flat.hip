@@ -332,152 +332,43 @@ __global__ __launch_bounds__(kBlock) void flat_u8_kernel(const FlatArgs a)
     }
 }
 
-// ---- tiny batches (1..4 queries): coalesced streaming + selection through wave minima --------------------------------------
-// flat_u8_kernel above gives each lane its own row (16-byte loads at a D-byte stride: every load instruction touches 64 cache
-// lines), and its selection rides along in the streaming loop; one query over 10 M x 512 ran at 4.6 TB/s, two at 2.4.  Here
-//   1. a row is read by D/16 CONSECUTIVE lanes -- a wave-load is 1 KB of contiguous rows --, each lane takes the dot product of
-//      its 16 bytes with the query bytes it keeps in registers, and the U * QT partial sums of an iteration are folded across the
-//      row's lanes by a halving butterfly (each step a lane keeps half of its values and trades the other half: V-1 shuffles
-//      for V values instead of V log2(lanes)); the exact distance |q'|^2 + |x'|^2 - 2<q',x'> (|x'|^2 from the norms computed at
-//      add time) goes out as one int32 per (query, row) -- 4 bytes against the D just streamed;
-//   2. every wave also leaves the MINIMUM distance it saw per query.  The k-th smallest of those minima, theta, bounds the true
-//      k-th distance from above (the k smallest minima are k distinct rows), and with thousands of waves against k <= 128 the
-//      waves whose minimum is <= theta are the k that hold the answer plus the rare collision.  The finish kernel derives theta,
-//      revisits only those waves' slices of the distance array and selects; ties at theta are all revisited, so the result is
-//      exact whatever the data (all-equal distances degrade to a full pass over the int32 array, not to a wrong answer).
-template <int O, int CNT, int V>
-__device__ __forceinline__ void stream_fold(int (&s)[V], int sub)
-{
-    if constexpr (O >= 1) {
-        if constexpr (CNT > 1) {
-            const bool hi = (sub & O) != 0;
-#pragma unroll
-            for (int i = 0; i < CNT / 2; ++i) {
-                const int keep = hi ? s[i + CNT / 2] : s[i];
-                const int send = hi ? s[i] : s[i + CNT / 2];
-                s[i] = keep + __shfl_xor(send, O, 64);
-            }
-            stream_fold<O / 2, CNT / 2, V>(s, sub);
-        } else {
-            s[0] += __shfl_xor(s[0], O, 64);
-            stream_fold<O / 2, 1, V>(s, sub);
-        }
-    }
-}
-constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v / 2); }
-constexpr int stream_u(int qt) { return qt <= 4 ? 8 : (qt == 8 ? 4 : 2); }   // loads in flight per lane: 32 sums per iteration at most
-
-template <int LPR, int QT>   // lanes per row (D = 16 LPR), queries
-__global__ __launch_bounds__(kBlock) void flat_u8_stream_kernel(const uint8_t *__restrict__ X, const int32_t *__restrict__ norms, int64_t n,
-                                                                const uint8_t *__restrict__ Q, int nq, int64_t ld_out,
-                                                                int32_t *__restrict__ out, int32_t *__restrict__ gmin)
-{
-    constexpr int RPL = 64 / LPR, U = stream_u(QT), V = U * QT;   // rows per wave-load, loads in flight per lane, sums per iteration
-    constexpr int LB = ilog2_c(LPR), VB = ilog2_c(V);
-    constexpr int T = LB < VB ? LB : VB;                  // halving steps
-    constexpr int R = V >> T;                             // sums a lane ends up with: v = (top T bits of sub) * R + i, v = u * QT + q
-    const int lane = threadIdx.x & 63, sub = lane % LPR, grp = lane / LPR;
-    uint4 qv[QT];
-    int qq[QT];
-#pragma unroll
-    for (int q = 0; q < QT; ++q) {
-        const int qi = q < nq ? q : nq - 1;
-        qv[q] = *reinterpret_cast<const uint4 *>(Q + (int64_t)qi * (16 * LPR) + 16 * sub);
-        qv[q].x ^= 0x80808080u; qv[q].y ^= 0x80808080u; qv[q].z ^= 0x80808080u; qv[q].w ^= 0x80808080u;  // q' = q - 128 as int8
-        const int w[4] = { (int)qv[q].x, (int)qv[q].y, (int)qv[q].z, (int)qv[q].w };
-        int s = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_sdot4(w[e], w[e], s, false);
-#pragma unroll
-        for (int o = LPR / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-        qq[q] = s;
-    }
-    // what this lane holds after the fold (fixed for the whole kernel)
-    const bool writer = (sub & ((1 << (LB - T)) - 1)) == 0;
-    const int pfx = sub >> (LB - T);
-    int my_u[R], my_q[R], my_qq[R], mn[R];
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const int v = pfx * R + i;
-        my_u[i] = v / QT;
-        my_q[i] = v % QT;
-        my_qq[i] = qq[0];
-#pragma unroll
-        for (int q = 1; q < QT; ++q) my_qq[i] = my_q[i] == q ? qq[q] : my_qq[i];
-        mn[i] = 0x7fffffff;
-    }
-    const int64_t wave_id = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
-    constexpr int64_t RPI = (int64_t)RPL * U;             // rows per wave iteration
-    const uint4 *X4 = reinterpret_cast<const uint4 *>(X);
-    for (int64_t base = wave_id * RPI; base < n; base += n_waves * RPI) {
-        uint4 v[U];
-        int xx[R];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int64_t row = base + u * RPL + grp;
-            row = row < n ? row : n - 1;
-            v[u] = X4[row * LPR + sub];
-        }
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            int64_t row = base + my_u[i] * RPL + grp;
-            row = row < n ? row : n - 1;
-            xx[i] = norms[row];
-        }
-        int s[V];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            // shifted domain, like the matrix kernels: sum (q - x)^2 = |q'|^2 + |x'|^2 - 2 <q', x'> with x' = x - 128 (norms = |x'|^2)
-            const int w[4] = { (int)(v[u].x ^ 0x80808080u), (int)(v[u].y ^ 0x80808080u), (int)(v[u].z ^ 0x80808080u), (int)(v[u].w ^ 0x80808080u) };
-#pragma unroll
-            for (int q = 0; q < QT; ++q) {
-                const int qw[4] = { (int)qv[q].x, (int)qv[q].y, (int)qv[q].z, (int)qv[q].w };
-                int acc = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_sdot4(qw[e], w[e], acc, false);
-                s[u * QT + q] = acc;
-            }
-        }
-        stream_fold<LPR / 2, V, V>(s, sub);
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int64_t row = base + my_u[i] * RPL + grp;
-            const int d = my_qq[i] + xx[i] - 2 * s[i];   // exact, >= 0
-            if (writer && row < n && my_q[i] < nq) {
-                out[(int64_t)my_q[i] * ld_out + row] = d;
-                mn[i] = d < mn[i] ? d : mn[i];
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < QT; ++q) {
-        int m = 0x7fffffff;
-#pragma unroll
-        for (int i = 0; i < R; ++i) m = (my_q[i] == q && mn[i] < m) ? mn[i] : m;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const int t = __shfl_xor(m, o, 64);
-            m = t < m ? t : m;
-        }
-        if (lane == 0 && q < nq) gmin[(int64_t)q * n_waves + wave_id] = m;
-    }
-}
-
+// ---- selection behind the streaming matrix-core kernel (flat_u8_mstream_kernel, flat_mfma.hip; 1 .. 128 queries) ---------------
+// That kernel streams the rows once and keeps only MINIMA of the exact distances: per 32-row tile and query (tmin[tile][query]) and
+// per wave and query (gmin[query][wave]).  The k-th smallest wave minimum, theta, bounds the true k-th distance from above (the k
+// smallest minima are k distinct rows), and with a thousand waves against k <= 128 the tiles whose minimum is <= theta are the ~k
+// that hold the answer plus the rare collision.  The finish kernel derives theta, revisits only those tiles and recomputes their 32
+// distances from the rows.  Ties at theta are all revisited, so the result is exact whatever the data (all-equal distances degrade
+// to a pass over the tile minima and a recomputation of every row, not to a wrong answer).
 // grid = nq * S workgroups; workgroup (q, s) derives theta from all G wave minima of its query, then selects among the rows the
 // qualifying waves wrote inside ITS slice of the rows.  Wave w owns rows (w + t G) rpi + j, t = 0.., j < rpi; the slice's entries are fed
 // in ascending row order (t outermost, then wave, then j), which is the order block_topk.h's tie rule asks for.
 constexpr int FIN_CAP = 1024, FIN_TRIG = 768, FIN_R = 4, FIN_MAXG = 8192, FIN_MAXR = 160;
-__global__ __launch_bounds__(kBlock) void flat_u8_stream_finish_kernel(const int32_t *__restrict__ dist, int64_t ld, int64_t n,
-                                                                       const int32_t *__restrict__ gmin, int G, int S, int rpi_log2, int k,
-                                                                       float *__restrict__ part_d, int64_t *__restrict__ part_id)
+struct StreamFinishArgs {
+    int64_t n;
+    const int32_t *gmin;
+    int G, S, rpi_log2, k;
+    float *part_d; int64_t *part_id;
+    const int32_t *tmin; int nqp; const uint8_t *X; const uint8_t *Q; int D;
+};
+__global__ __launch_bounds__(kBlock) void flat_u8_stream_finish_kernel(const StreamFinishArgs a)
 {
     __shared__ TopKShared<1, FIN_CAP> tk;
     __shared__ uint16_t ql[FIN_MAXG];          // qualifying waves, ascending
     __shared__ int r_first[FIN_MAXR], r_off[FIN_MAXR + 1];
     __shared__ int qn_s;
+    __shared__ __attribute__((aligned(16))) uint32_t q_s[128];   // the query's bytes
+    const int64_t n = a.n;
+    const int G = a.G, S = a.S, rpi_log2 = a.rpi_log2, k = a.k;
+    const int32_t *gmin = a.gmin;
     const int tid = threadIdx.x;
     const int64_t q = blockIdx.x / S;
     const int sl = blockIdx.x % S;
+    int qq_t = 0;
+    {
+        if (tid < a.D / 4) q_s[tid] = reinterpret_cast<const uint32_t *>(a.Q + q * a.D)[tid];
+        __syncthreads();
+        for (int w = 0; w < a.D / 4; ++w) qq_t = (int)__builtin_amdgcn_udot4(q_s[w], q_s[w], (uint32_t)qq_t, false);
+    }
     const int32_t *gm = gmin + q * G;
     // theta in two rounds of the same bound: the k-th smallest of the 256 per-thread minima (k <= 128 distinct waves) is an upper
     // bound theta1 that already excludes nearly every wave, so the pass over all G minima pushes ~k entries and never compacts early
@@ -550,7 +441,6 @@ __global__ __launch_bounds__(kBlock) void flat_u8_stream_finish_kernel(const int
     }
     __syncthreads();
     const int64_t total = (int64_t)(n_rounds ? r_off[n_rounds] : 0) << rpi_log2;
-    const int32_t *dq = dist + q * ld;
     tile = 0;
     for (int64_t base = 0; base < total; base += kBlock * FIN_R, ++tile) {
         uint32_t key[FIN_R][1], pay[FIN_R];
@@ -566,7 +456,21 @@ __global__ __launch_bounds__(kBlock) void flat_u8_stream_finish_kernel(const int
                 const int64_t chunk = (t_a + a_) * G + ql[r_first[a_] + (ci - r_off[a_])];
                 const int64_t row = (chunk << rpi_log2) + (e & ((1 << rpi_log2) - 1));
                 if (row < n) {
-                    const uint32_t d = (uint32_t)dq[row];
+                    uint32_t d = KEY_MAX;
+                    if ((uint32_t)a.tmin[chunk * a.nqp + q] <= theta) {   // exact sum (q - x)^2 = |q|^2 + |x|^2 - 2 <q, x>, every term < 2^27
+                        const uint4 *xr = reinterpret_cast<const uint4 *>(a.X + row * a.D);
+                        uint32_t xx = 0, qx = 0;
+                        for (int c = 0; c < a.D / 16; ++c) {
+                            const uint4 v = xr[c];
+                            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                xx = __builtin_amdgcn_udot4(w[e], w[e], xx, false);
+                                qx = __builtin_amdgcn_udot4(w[e], q_s[4 * c + e], qx, false);
+                            }
+                        }
+                        d = (uint32_t)qq_t + xx - 2u * qx;
+                    }
                     pay[r] = (uint32_t)row;
                     if (d <= theta) key[r][0] = d;
                 }
@@ -577,8 +481,8 @@ __global__ __launch_bounds__(kBlock) void flat_u8_stream_finish_kernel(const int
     __syncthreads();
     topk_compact(tk, k);
     const int cnt = tk.cnt[0];
-    float *pd = part_d + ((int64_t)blockIdx.x) * k;
-    int64_t *pi = part_id + ((int64_t)blockIdx.x) * k;
+    float *pd = a.part_d + ((int64_t)blockIdx.x) * k;
+    int64_t *pi = a.part_id + ((int64_t)blockIdx.x) * k;
     for (int i = tid; i < k; i += kBlock) {
         if (i < cnt) {
             pd[i] = __uint_as_float((uint32_t)(tk.buf[0][i] >> 32));   // the int32 distance's bits: what the uint8 metric returns
@@ -919,7 +823,10 @@ void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
     int qi_l = group * QT + wave * 32 + lj;
     qi_l = qi_l < a.nq ? qi_l : a.nq - 1;
     uint32_t g_l = __hip_atomic_load(&a.gthr[qi_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // shared threshold of query lj as last read 
-    if (lane < 32) thq_s[wave * 32 + lj] = 0x7fffffff;
+    // queries past nq are copies of the last one (clamped loads): left alone they select, compact and hammer the same gthr / gslot words as
+    // the original (nq = 65 took 6.4 ms against 1.7 for 64, nq = 257 22.7 against 2.5 for 256).  Their bound is INT_MIN: nothing ever passes.
+    const bool pad_l = group * QT + wave * 32 + lj >= a.nq;
+    if (lane < 32) thq_s[wave * 32 + lj] = pad_l ? (int)0x80000000 : 0x7fffffff;
     __syncthreads();
     const int64_t row_begin = (int64_t)split * a.rows_per_split;
     int64_t row_end = row_begin + a.rows_per_split;
@@ -1033,7 +940,7 @@ void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
                 const uint32_t bm = bmax_s[wave * 32 + lj];
                 if (bm != KEY_MAX && bm + 1u < sh) sh = bm + 1u;
                 const uint32_t th = own < sh ? own : sh;
-                thq_s[wave * 32 + lj] = th == KEY_MAX ? 0x7fffffff : (int)th - qq_s[wave * 32 + lj];
+                thq_s[wave * 32 + lj] = pad_l ? (int)0x80000000 : (th == KEY_MAX ? 0x7fffffff : (int)th - qq_s[wave * 32 + lj]);
             }
         }
     };
@@ -1260,65 +1167,18 @@ int launch_gather_labels(int64_t *ids, int64_t count, const int64_t *labels, hip
 }
 
 constexpr int STREAM_SLICES = 64;
-static int g_stream_blocks_get();
-bool flat_u8_stream_applies(int D, int64_t n, int64_t nq, int k)
+// selection after flat_u8_mstream_kernel (flat_mfma.hip): wave minima wmin[nq][G], tile minima tmin[tiles][nqp] -> part [nq][slices][k] -> merge
+int launch_flat_u8_mstream_finish(int D, const uint8_t *data, int64_t n, const uint8_t *q, int64_t nq, int k, const int32_t *wmin, int G,
+                                  const int32_t *tmin, int nqp, float *part_d, int64_t *part_id, float *out_d, int64_t *out_rows, hipStream_t st)
 {
-    // 9..16 queries: the dot products start to bound the stream (10 M rows: D = 512 1.9-2.0 ms against 1.75 on the matrix-core row tiles,
-    // D = 256 1.25 against 1.45, D = 128 0.81 against 1.28)
-    if (!(nq >= 1 && (nq <= 8 || (nq <= 16 && D <= 256)) && (D == 128 || D == 256 || D == 512) && n >= 262144 && n < 0x7fffffff && k <= 128)) return false;
-    const int64_t rows_per_round = (int64_t)g_stream_blocks_get() * (kBlock / 64) * (64 / (D / 16) * 2);   // waves x rows per wave iteration (at least)
-    return n / STREAM_SLICES / rows_per_round + 2 <= FIN_MAXR;   // rounds a finish slice can span (always true at the default grid)
-}
-static int g_stream_blocks = 1024;   // waves = 4 x blocks = 4 per SIMD: every wave resident at once for any QT (measured 10 M x 512: 1024 blocks 0.917 / 0.911 / 0.988 ms for 1 / 2 / 4 queries, 2048: 0.909 / 0.958 / 1.127); a multiple of 16 so that the finish slices divide the waves evenly
-static int g_stream_blocks_get() { return g_stream_blocks; }
-int set_flat_u8_stream_blocks(int v)
-{
-    if (v < 256 || v > 2048 || v % 16) return CVTMI_EINVAL;   // 4 v waves <= FIN_MAXG
-    g_stream_blocks = v;
-    return CVTMI_OK;
-}
-// scratch: int32 distances [nq][ld] followed by the wave minima [nq][waves]; partial lists are [nq][STREAM_SLICES][k]
-size_t flat_u8_stream_scratch(int64_t n, int64_t nq, int *slices, int64_t *ld)
-{
-    const int64_t l = (n + 3) / 4 * 4;
-    if (slices) *slices = STREAM_SLICES;
-    if (ld) *ld = l;
-    return (size_t)nq * (l + g_stream_blocks * (kBlock / 64)) * sizeof(int32_t);
-}
-
-// k smallest (distance, row) of nq <= 4 queries: stream -> distances + wave minima, finish -> part [nq][slices][k], merge
-int launch_flat_u8_stream(int D, const uint8_t *data, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int k, float *scratch,
-                          float *part_d, int64_t *part_id, float *out_d, int64_t *out_rows, hipStream_t st)
-{
-    int64_t ld = 0;
-    (void)flat_u8_stream_scratch(n, nq, nullptr, &ld);
-    int32_t *dist = reinterpret_cast<int32_t *>(scratch);
-    int32_t *gmin = dist + nq * ld;
-    const int STREAM_BLOCKS = g_stream_blocks, STREAM_WAVES = STREAM_BLOCKS * (kBlock / 64);   // <= FIN_MAXG waves
-    int rpi_log2 = 0;
-#define CVTMI_FS(L)                                                                                                                          \
-    do {                                                                                                                                     \
-        const int qt = nq <= 1 ? 1 : (nq <= 2 ? 2 : (nq <= 4 ? 4 : (nq <= 8 ? 8 : 16)));                                                     \
-        rpi_log2 = ilog2_c(64 / L * stream_u(qt));                                                                                           \
-        if (qt == 1) hipLaunchKernelGGL((flat_u8_stream_kernel<L, 1>), dim3(STREAM_BLOCKS), dim3(kBlock), 0, st, data, norms, n, q, (int)nq, ld, dist, gmin); \
-        else if (qt == 2) hipLaunchKernelGGL((flat_u8_stream_kernel<L, 2>), dim3(STREAM_BLOCKS), dim3(kBlock), 0, st, data, norms, n, q, (int)nq, ld, dist, gmin); \
-        else if (qt == 4) hipLaunchKernelGGL((flat_u8_stream_kernel<L, 4>), dim3(STREAM_BLOCKS), dim3(kBlock), 0, st, data, norms, n, q, (int)nq, ld, dist, gmin); \
-        else if (qt == 8) hipLaunchKernelGGL((flat_u8_stream_kernel<L, 8>), dim3(STREAM_BLOCKS), dim3(kBlock), 0, st, data, norms, n, q, (int)nq, ld, dist, gmin); \
-        else hipLaunchKernelGGL((flat_u8_stream_kernel<L, 16>), dim3(STREAM_BLOCKS), dim3(kBlock), 0, st, data, norms, n, q, (int)nq, ld, dist, gmin); \
-    } while (0)
-    switch (D) {
-        case 128: CVTMI_FS(8); break;
-        case 256: CVTMI_FS(16); break;
-        case 512: CVTMI_FS(32); break;
-        default: return fail(CVTMI_EUNSUPPORTED, "flat_u8_stream: D=%d", D);
-    }
-#undef CVTMI_FS
-    CVTMI_HIP(hipGetLastError());
-    hipLaunchKernelGGL(flat_u8_stream_finish_kernel, dim3((unsigned)(nq * STREAM_SLICES)), dim3(kBlock), 0, st, dist, ld, n, gmin, STREAM_WAVES,
-                       STREAM_SLICES, rpi_log2, k, part_d, part_id);
+    StreamFinishArgs fa = {};
+    fa.n = n; fa.gmin = wmin; fa.G = G; fa.S = STREAM_SLICES; fa.rpi_log2 = 5; fa.k = k; fa.part_d = part_d; fa.part_id = part_id;
+    fa.tmin = tmin; fa.nqp = nqp; fa.X = data; fa.Q = q; fa.D = D;
+    hipLaunchKernelGGL(flat_u8_stream_finish_kernel, dim3((unsigned)(nq * STREAM_SLICES)), dim3(kBlock), 0, st, fa);
     CVTMI_HIP(hipGetLastError());
     return launch_topk_merge(part_d, part_id, nq, STREAM_SLICES, k, out_d, out_rows, st);
 }
+int flat_u8_stream_slices() { return STREAM_SLICES; }
 
 int flat_qtile(int64_t nq) { return nq >= 4 ? 4 : 1; }
 

@@ -1017,6 +1017,150 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Small and mid-size batches (1 .. 128 queries) as a STREAM over the raw rows (flat_u8_mstream_kernel): the row-tile kernels read the rows
+// lane-per-row (64 cache lines per load instruction) and top out near 3 TB/s on 512-byte rows and 1 TB/s on 128-byte rows; the
+// filter pipeline needs the packed copy and a sample stage and only pays from ~256 queries.  Here each wave streams whole 32-row
+// tiles (32 D contiguous bytes) into a wave-private LDS ring by LDS-DMA -- coalesced 1 KB pieces, no barrier anywhere: the ring, the
+// waits and the matrix chain all belong to one wave --, reads them back as v_mfma_i32_32x32x32_i8 B operands (rows of a piece keep
+// their 256-byte alignment, so the reads run 2- to 4-way bank-conflicted: 64-128 LDS cycles per tile, a few per cent of a tile's
+// time), multiplies against QB x 32 queries held in registers, and keeps only MINIMA: per tile and query (one coalesced 128 QB-byte
+// store per tile) and per wave and query.  Selection is flat_u8_stream_finish_kernel<true>: theta from the wave minima, then the
+// ~k tiles whose minimum is <= theta get their 32 distances recomputed from the rows.  One wave per SIMD (QB x D/8 operand registers).
+// ------------------------------------------------------------------------------------------------------------------
+template <int O, int CNT, int V>
+__device__ __forceinline__ void fold_min(int (&s_)[V], int sub)
+{
+    if constexpr (O >= 1) {
+        if constexpr (CNT > 1) {
+            const bool hi = (sub & O) != 0;
+#pragma unroll
+            for (int i = 0; i < CNT / 2; ++i) {
+                const int keep = hi ? s_[i + CNT / 2] : s_[i];
+                const int send = hi ? s_[i] : s_[i + CNT / 2];
+                const int got = __shfl_xor(send, O, 64);
+                s_[i] = keep < got ? keep : got;
+            }
+            fold_min<O / 2, CNT / 2, V>(s_, sub);
+        } else {
+            const int got = __shfl_xor(s_[0], O, 64);
+            s_[0] = s_[0] < got ? s_[0] : got;
+            fold_min<O / 2, 1, V>(s_, sub);
+        }
+    }
+}
+constexpr int ms_log2(int v) { return v <= 1 ? 0 : 1 + ms_log2(v / 2); }
+constexpr int MS_PAD = 32;   // bytes between the 1 KB pieces of a tile in LDS
+
+template <int KS, int QB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flat_u8_mstream_kernel(
+    const uint8_t *__restrict__ X, const int32_t *__restrict__ norms, int64_t n, const uint8_t *__restrict__ Q, int nq,
+    int32_t *__restrict__ tmin, int32_t *__restrict__ wmin)
+{
+    constexpr int D = 32 * KS, NB = 32 / KS >= 2 ? 32 / KS : 2;       // ring slots per wave: 32 KB of tiles
+    constexpr int PIECE = 1024 + MS_PAD, SLOT = KS * PIECE + 256;      // + the tile's 32 norms (glds4: 64 lanes x 4 B)
+    constexpr int OPS = KS + 1;
+    constexpr int V = 16 * QB, LB = 5, VB = ms_log2(V), T = LB < VB ? LB : VB, R = V >> T;
+    constexpr int NQP = 32 * QB;
+    extern __shared__ __attribute__((aligned(16))) uint8_t ms_ring[];  // [4 waves][NB][SLOT]
+    __shared__ int qq_s[NQP];
+    const int tid = threadIdx.x, lane = tid & 63, lj = lane & 31, lk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    i32x4 qreg[QB][KS];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const int ql = b * 32 + lj;
+        const int qc = ql < nq ? ql : nq - 1;
+        const uint8_t *qp = Q + (int64_t)qc * D;
+        int qq = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) qreg[b][s_] = *reinterpret_cast<const i32x4 *>(qp + 32 * s_ + 16 * lk);
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            qreg[b][s_] ^= (int)0x80808080;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qq = __builtin_amdgcn_sdot4(qreg[b][s_][c], qreg[b][s_][c], qq, false);
+        }
+        qq += __shfl_xor(qq, 32, 64);
+        if (wave == 0 && lk == 0) qq_s[ql] = ql < nq ? qq : 0x3fffffff;   // padding queries: minima that never qualify
+    }
+    __syncthreads();   // (drains the ordinary loads: from here on the wave's loads are the DMA)
+    // what this lane holds after the min-fold over the 32 rows of its half: values v = pfx * R + i, v = 16 b + e, query = 32 b + (e & 3) + 8 (e >> 2) + 4 lk
+    const int sub = lj;
+    const bool writer = (sub & ((1 << (LB - T)) - 1)) == 0;
+    const int pfx = sub >> (LB - T);
+    int my_q[R], my_qq[R], mn[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int v = pfx * R + i, b = v >> 4, e = v & 15;
+        my_q[i] = 32 * b + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        my_qq[i] = qq_s[my_q[i]];
+        mn[i] = 0x7fffffff;
+    }
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t G = (int64_t)gridDim.x * 4, wave_g = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t my_tiles = wave_g < n_tiles ? (n_tiles - wave_g + G - 1) / G : 0;
+    const uint32_t ring_b = (uint32_t)(uintptr_t)ms_ring + (uint32_t)(wave * NB * SLOT);
+    // this lane's share of a tile: piece p covers tile bytes [1024 p + 16 lane, +16) = row (1024 p + 16 lane) / D; rows past n are clamped
+    auto request = [&](int64_t i, int slot) {
+        const int64_t t = wave_g + (i < my_tiles ? i : my_tiles - 1) * G;
+#pragma unroll
+        for (int p = 0; p < KS; ++p) {
+            const int byte = 1024 * p + 16 * lane;
+            int64_t row = t * 32 + byte / D;
+            row = row < n ? row : n - 1;
+            glds16(X + row * D + (byte % D), ring_b + (uint32_t)(slot * SLOT + p * PIECE));
+        }
+        int64_t row = t * 32 + lj;
+        row = row < n ? row : n - 1;
+        glds4(norms + row, ring_b + (uint32_t)(slot * SLOT + KS * PIECE));
+    };
+    if (my_tiles > 0) {
+#pragma unroll
+        for (int p = 0; p < NB - 1; ++p) request(p, p);
+    }
+    // B operand of row lj, K step s: tile byte lj D + 32 s + 16 lk -> piece (lj D) >> 10, offset (lj D) & 1023
+    const uint32_t rd_off = (uint32_t)(((lj * D) >> 10) * PIECE + ((lj * D) & 1023) + 16 * lk);
+    for (int64_t i = 0; i < my_tiles; ++i) {
+        request(i + NB - 1, (int)((i + NB - 1) % NB));
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 1) * OPS) : "memory");   // tile i has landed (loads complete in order; the stores below can only add to the wait)
+        const int slot = (int)(i % NB);
+        const uint8_t *base = ms_ring + (size_t)wave * NB * SLOT + (size_t)slot * SLOT;
+        const int64_t t = wave_g + i * G;
+        const int64_t row = t * 32 + lj;
+        const int xx = reinterpret_cast<const int *>(base + KS * PIECE)[lj];
+        i32x16 acc[QB];
+#pragma unroll
+        for (int b = 0; b < QB; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][e] = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            i32x4 bv = *reinterpret_cast<const i32x4 *>(base + rd_off + 32 * s_);
+            bv ^= (int)0x80808080;
+#pragma unroll
+            for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qreg[b][s_], bv, acc[b], 0, 0, 0);
+        }
+        int dv[V];
+        const int xr = row < n ? xx : 0x3fffffff;   // rows past the end never set a minimum
+#pragma unroll
+        for (int b = 0; b < QB; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dv[16 * b + e] = xr - 2 * acc[b][e];   // + |q'|^2 after the fold (constant per query)
+        fold_min<16, V, V>(dv, sub);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int d = dv[r] + my_qq[r];
+            if (writer) tmin[t * NQP + my_q[r]] = d;
+            mn[r] = d < mn[r] ? d : mn[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (writer && my_q[r] < nq) wmin[(int64_t)my_q[r] * G + wave_g] = mn[r];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // one workgroup per query: (distance, row) sort of the survivors and the sample's k results; distances are int32 bits
 __global__ __launch_bounds__(kBlock) void flat_u8_finish_kernel(const uint32_t *__restrict__ cand_cnt, const float *__restrict__ cand_d,
                                                                 const int32_t *__restrict__ cand_row, int cap, int k,
@@ -1070,6 +1214,50 @@ int set_flat_u8_dbg(int v)
 static int g_u8_gfilter = 1;  // cvtmi_set_tuning("flat_u8_gfilter"): 1 = the software-pipelined filter kernel where it applies (D = 64 .. 512, power of two)
 void set_flat_u8_gfilter(int v) { g_u8_gfilter = v; }  // 0 off, 1 choose, 2 two 4-wave workgroups per CU, 3 one 8-wave workgroup per CU, 4 one wave per SIMD x 128 queries
 bool flat_u8_gfilter_shape(int D) { return g_u8_gfilter && (D == 64 || D == 128 || D == 256 || D == 512); }
+
+// 1 .. 128 queries over raw rows: stream + minima (the selection is launch_flat_u8_mstream_finish, flat.hip)
+constexpr int MSTREAM_BLOCKS = 256;   // one 4-wave workgroup per CU (one wave per SIMD)
+static int g_mstream_min_nq = 1;       // measurement hook (flat_u8_mstream_min): below it the row-per-lane / row-tile kernels answer
+void set_flat_u8_mstream_min(int v) { g_mstream_min_nq = v; }
+bool flat_u8_mstream_applies(int D, int64_t n, int64_t nq, int k)
+{
+    return (D == 128 || D == 256 || D == 512) && nq >= g_mstream_min_nq && nq <= 128 && n >= 262144 && n < 0x7fffffff && k <= 128 &&
+           n / 32 / 64 / (MSTREAM_BLOCKS * 4) + 2 <= 160;   // rounds a finish slice can span (FIN_MAXR, flat.hip): 331 M rows
+}
+// scratch (int32): tile minima [tiles][32 QB] then wave minima [nq][waves]
+size_t flat_u8_mstream_scratch(int64_t n, int64_t nq, int *nqp, int *waves)
+{
+    const int qb = nq <= 32 ? 1 : (nq <= 64 ? 2 : 4);
+    if (nqp) *nqp = 32 * qb;
+    if (waves) *waves = MSTREAM_BLOCKS * 4;
+    return ((size_t)((n + 31) / 32) * 32 * qb + (size_t)nq * MSTREAM_BLOCKS * 4) * sizeof(int32_t);
+}
+int launch_flat_u8_mstream(int D, const uint8_t *data, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int32_t *tmin,
+                           int32_t *wmin, hipStream_t st)
+{
+    const int qb = nq <= 32 ? 1 : (nq <= 64 ? 2 : 4);
+#define CVTMI_MS(KS_, QB_)                                                                                                         \
+    do {                                                                                                                          \
+        constexpr int NB_ = 32 / (KS_) >= 2 ? 32 / (KS_) : 2;                                                                     \
+        const size_t lds = (size_t)4 * NB_ * ((KS_) * (1024 + MS_PAD) + 256);                                                     \
+        CVTMI_HIP(hipFuncSetAttribute((const void *)flat_u8_mstream_kernel<KS_, QB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((flat_u8_mstream_kernel<KS_, QB_>), dim3(MSTREAM_BLOCKS), dim3(256), lds, st, data, norms, n, q, (int)nq, tmin, wmin); \
+    } while (0)
+#define CVTMI_MSQ(KS_)                                                                                                             \
+    do {                                                                                                                          \
+        if (qb == 1) CVTMI_MS(KS_, 1); else if (qb == 2) CVTMI_MS(KS_, 2); else CVTMI_MS(KS_, 4);                                   \
+    } while (0)
+    switch (D) {
+        case 128: CVTMI_MSQ(4); break;
+        case 256: CVTMI_MSQ(8); break;
+        case 512: CVTMI_MSQ(16); break;
+        default: return fail(CVTMI_EUNSUPPORTED, "flat_u8_mstream: D=%d", D);
+    }
+#undef CVTMI_MSQ
+#undef CVTMI_MS
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
 
 bool flat_u8_filter_applies(int D, int64_t n, int64_t nq, int k)
 {

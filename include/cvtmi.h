@@ -81,7 +81,7 @@ int cvtmi_set_device(int device);
  *                     workgroups per CU; 4 = one wave per SIMD holding 96-128 queries (GEMM-shaped; measured equal / slower);
  *                     0 = the round-1 filter kernel (register-staged tiles)
  *   "flat_u8_dbg"     timing experiments of the filter kernel (-DCVTMI_GF_DBG builds only; EUNSUPPORTED otherwise: results are wrong)
- *   "flat_u8_stream_blocks"  workgroups of the 1..4-query uint8 streaming kernel (default 1024 = 4 waves per SIMD; multiple of 16, 256..2048)
+ *   "flat_u8_mstream_min"  smallest uint8 batch that takes the streaming matrix-core kernel (default 1; 129 = never: row-per-lane / row-tile kernels)
  *   "flat_u8_opt"     measurement variants of the uint8 row-tile kernel (0 = shipped; 1..3 spill registers and are slower)
  *   "probe_variant"   coarse top-nk of cvtmi_opq_query_video: 0 = choose (matrix-core filter + exact distances of the candidates
  *                     from 256 query frames, 32 <= D <= 128, coarseK >= 256); 1 = exact kernels only; 2 = filter wherever it applies

@@ -433,8 +433,8 @@ def test_flat_u8_filter_pipeline(amd, orc, D, k, hi):
 @pytest.mark.parametrize("D,nq,k,hi", [(512, 1, 10, 256), (128, 3, 128, 4), (256, 4, 1, 256), (512, 2, 33, 256), (512, 8, 10, 256), (128, 16, 5, 256),
                                         (256, 11, 20, 4), (512, 7, 128, 256)])
 def test_flat_u8_tiny_batch_stream(amd, orc, D, nq, k, hi):
-    """1..16 uint8 queries go through the coalesced streaming kernel + per-split selection + merge (flat_variant 0) -- against the
-    row-per-lane kernels (flat_variant 1) and the checker; ragged row count (last split partly empty), duplicate rows at both
+    """1..16 uint8 queries through the streaming matrix-core kernel + minima-based selection (flat_variant 0) -- against the
+    row-per-lane / row-tile kernels (flat_variant 1) and the checker; ragged row count (last tile partly empty), duplicate rows at both
     ends of the table (ties resolved by row), few distinct byte values (masses of equal distances), a far query (distances > 2^24, not exact in f32)"""
     rng = np.random.default_rng(D * 7 + k)
     n = 262_144 + 12_345
@@ -483,3 +483,32 @@ def test_flat_f32_filter_small_batches(amd, orc, metric, nq):
     od, _, oi = orc.flat_search(metric, x, q[:8], k, flavour=4 if metric == IP else 8)
     assert np.array_equal(i0[:8], oi) and np.array_equal(bits(d0[:8]), bits(od))
     ix.close()
+
+
+@pytest.mark.parametrize("D,nq,k,hi", [(512, 9, 10, 256), (128, 17, 128, 4), (256, 33, 1, 256), (512, 64, 33, 256), (128, 100, 10, 256),
+                                        (256, 128, 20, 6), (512, 40, 128, 256)])
+def test_flat_u8_mid_batch_stream(amd, orc, D, nq, k, hi):
+    """9..128 uint8 queries: matrix-core stream over the raw rows keeping tile / wave minima, then selection among the ~k tiles that
+    qualify (flat_variant 0) -- against the row-tile kernels (flat_variant 1) and the checker; ragged row count (last tile partly
+    empty), duplicate rows at both ends and in the middle (ties resolved by row across finish slices), few distinct byte values"""
+    rng = np.random.default_rng(D * 11 + nq)
+    n = 262_144 + 32 * 333 + 7
+    x = rng.integers(0, hi, size=(n, D), dtype=np.uint8)
+    x[n - 1] = x[3]; x[131_072] = x[3]; x[40_000:40_040] = x[3]
+    q = x[rng.integers(0, n, nq)].copy()
+    q[:, :2] ^= 1
+    q[0] = x[3]
+    q[-1] = np.where(x[7] < 128, 255, 0)                      # far query: distances > 2^24
+    out = {}
+    try:
+        for v in (0, 1):
+            amd.set_tuning("flat_variant", v)
+            ix = amd.FlatIndex(L2U8, D); ix.add(x[:100_000]); ix.add(x[100_000:])
+            out[v] = ix.search(q, k)
+            ix.close()
+    finally:
+        amd.set_tuning("flat_variant", 0)
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+    od, odi, oi = orc.flat_search(L2U8, x, q[:6], k)
+    assert np.array_equal(out[0][1][:6], oi) and np.array_equal(out[0][0][:6], odi)
+    assert out[0][1][0, 0] == 3

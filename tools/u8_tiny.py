@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""uint8 flat search, 1..4 queries over ROWS x D: streaming path (flat_variant 0) vs the row-per-lane kernels (flat_variant 1)."""
+"""uint8 flat search, 1, 2, 4 queries over ROWS x D: streaming matrix-core path (flat_variant 0) vs the row-per-lane kernels (flat_variant 1)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,8 +11,6 @@ ix = cvt_amd.FlatIndex(2, D)
 for a in range(0, n, 1 << 21):
     ix.add(torch.randint(0, 256, (min(n, a + (1 << 21)) - a, D), generator=g, device=dev, dtype=torch.uint8))
 k = int(os.environ.get("K", 10))
-if os.environ.get("BLOCKS"):
-    cvt_amd.set_tuning("flat_u8_stream_blocks", int(os.environ["BLOCKS"]))
 variants = tuple(int(v) for v in os.environ.get("VARIANTS", "0,1").split(","))
 for nq in (1, 2, 4):
     q = torch.randint(0, 256, (nq, D), generator=g, device=dev, dtype=torch.uint8)
