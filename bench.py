@@ -458,13 +458,13 @@ def secondary(args, dev, books, R):
     q3 = cvt_amd.sq8_encode(vmin, vdiff, qf, l2norm=True)
     c3 = {"rows": n3, "d": d3, "k": k3, "cases": {}}
     outs = {}
-    for nq3 in (1, 4, 1000, 4096):
+    for nq3 in (1, 8, 64, 1000, 4096):
         qq = q3[:nq3].contiguous()
         ms = _ev_ms(torch, lambda: flat.search(qq, k3), reps=3, warm=1)
         outs[nq3] = flat.search(qq, k3)
         ops = 2.0 * nq3 * n3 * d3 / (ms * 1e-3)
         c = {"ms": round(ms, 4), "queries_per_s": round(nq3 / (ms * 1e-3), 1)}
-        if nq3 <= 4:
+        if nq3 <= 128:   # one stream over the rows (flat_u8_mstream_kernel): bound by HBM
             gb = n3 * d3 / (ms * 1e-3) / 1e9
             c["roofline"] = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 4)}
         else:
