@@ -36,15 +36,33 @@ __device__ __forceinline__ void hn_push_heap(A &a, int hole, HnEnt v)
     }
     a.set(hole, v);
 }
+// The same sift-up with the whole ancestor chain taken at once: lane i reads ancestor i of the hole (the chain is known before
+// anything is compared: positions (hole + 1) >> (i + 1), 1-based), one ballot finds the first ancestor that stays, the ancestors
+// below it move down one step each and v lands above them -- two memory round trips whatever the depth, instead of one per level.
+// Same comparisons, same final layout as __push_heap.
 template <class A>
-__device__ __forceinline__ void hn_push(A &a, int &n, float d, uint32_t id)
+__device__ __forceinline__ void hn_push_heap_wave(A &a, int hole, HnEnt v, int lane)
+{
+    const int h1 = hole + 1;
+    const int anc1 = lane < 31 ? (h1 >> (lane + 1)) : 0;      // 1-based ancestor i, 0 = past the root
+    const bool valid = anc1 >= 1;
+    HnEnt p; p.d = 0.0f; p.id = 0u;
+    if (valid) p = a.get_l(anc1 - 1);
+    const unsigned long long up = __ballot(valid && p.d < v.d);   // ancestor i is passed
+    const int s_ = __ffsll((long long)~up) - 1;                    // first ancestor that stays (or the first lane past the root)
+    const int below = lane == 0 ? hole : (h1 >> lane) - 1;         // the position one step below ancestor `lane` on the chain
+    if (lane < s_) a.set_l(below, p);
+    else if (lane == s_) a.set_l(below, v);
+}
+template <class A>
+__device__ __forceinline__ void hn_push(A &a, int &n, float d, uint32_t id, int lane)
 {
     HnEnt v; v.d = d; v.id = id;
-    hn_push_heap(a, n, v);
+    hn_push_heap_wave(a, n, v, lane);
     ++n;
 }
 template <class A>
-__device__ __forceinline__ void hn_pop(A &a, int &n)
+__device__ __forceinline__ void hn_pop(A &a, int &n, int lane)
 {
     if (n > 1) {
         const int len = n - 1;
@@ -63,7 +81,7 @@ __device__ __forceinline__ void hn_pop(A &a, int &n)
             a.set(hole, a.get(second - 1));
             hole = second - 1;
         }
-        hn_push_heap(a, hole, value);
+        hn_push_heap_wave(a, hole, value, lane);
     }
     --n;
 }
@@ -73,12 +91,16 @@ struct LdsArr {
     HnEnt *p; bool w;
     __device__ __forceinline__ HnEnt get(int i) const { return p[i]; }
     __device__ __forceinline__ void set(int i, HnEnt v) const { if (w) p[i] = v; }
+    __device__ __forceinline__ HnEnt get_l(int i) const { return p[i]; }            // per-lane index
+    __device__ __forceinline__ void set_l(int i, HnEnt v) const { p[i] = v; }
 };
 // first HN_LCAP entries (the upper heap levels, touched by every operation) in LDS, the rest in HBM
 struct SplitArr {
     HnEnt *l; HnEnt *g; bool w;
     __device__ __forceinline__ HnEnt get(int i) const { return i < HN_LCAP ? l[i] : g[i - HN_LCAP]; }
     __device__ __forceinline__ void set(int i, HnEnt v) const { if (w) { if (i < HN_LCAP) l[i] = v; else g[i - HN_LCAP] = v; } }
+    __device__ __forceinline__ HnEnt get_l(int i) const { return i < HN_LCAP ? l[i] : g[i - HN_LCAP]; }   // per-lane index
+    __device__ __forceinline__ void set_l(int i, HnEnt v) const { if (i < HN_LCAP) l[i] = v; else g[i - HN_LCAP] = v; }
 };
 
 struct HnswArgs {
@@ -209,8 +231,8 @@ __global__ __launch_bounds__(64, 8) void hnsw_search_kernel(const HnswArgs a)  /
         {
             float o[1];
             o[0] = dist(cur);
-            hn_push(top, top_n, o[0], cur);
-            hn_push(cand, cand_n, -o[0], cur);
+            hn_push(top, top_n, o[0], cur, lane);
+            hn_push(cand, cand_n, -o[0], cur, lane);
             if (w) vis[cur >> 5] |= 1u << (cur & 31);
             __builtin_amdgcn_s_waitcnt(0);
         }
@@ -219,31 +241,37 @@ __global__ __launch_bounds__(64, 8) void hnsw_search_kernel(const HnswArgs a)  /
         while (cand_n > 0) {
             const HnEnt c = cand.get(0);
             if (-c.d > lower) break;
-            hn_pop(cand, cand_n);
+            // the expanded node's links are requested BEFORE the pop walks the queue (the walk's deeper levels live in HBM): the two
+            // latencies overlap instead of adding up
             const uint32_t *ll = a.links0 + (int64_t)c.id * (a.maxM0 + 1);
             const int size = (int)ll[0];
+            const uint32_t nb0 = lane < size ? ll[1 + lane] : 0u;
+            hn_pop(cand, cand_n, lane);
             for (int base = 0; base < size; base += 64) {
                 const int j = base + lane;
                 bool act = j < size;
-                const uint32_t nb = act ? ll[1 + j] : 0u;
+                const uint32_t nb = base == 0 ? nb0 : (act ? ll[1 + j] : 0u);
                 if (act) {
                     const uint32_t bit = 1u << (nb & 31);
                     act = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;
                 }
                 float o[1] = { 0.0f };
                 if (act) o[0] = dist(nb);
-                unsigned long long m = __ballot(act);
-                while (m) {  // list order
+                // list order.  Once the top queue is full its maximum only falls, so a neighbour that fails `lower > d` now fails it
+                // for the rest of this list: the rejected ones are dropped by ballot, and the walk visits accepted neighbours only
+                unsigned long long m = __ballot(act && (top_n < ef || lower > o[0]));
+                while (m) {
                     const int b = __ffsll((long long)m) - 1;
                     m &= m - 1;
                     const float d = __shfl(o[0], b);
                     const uint32_t id = (uint32_t)__shfl((int)nb, b);
-                    if (top.get(0).d > d || top_n < ef) {
+                    if (lower > d || top_n < ef) {   // lower == top.get(0).d whenever the queue is non-empty
                         if (cand_n >= cand_cap) { overflow = true; break; }
-                        hn_push(cand, cand_n, -d, id);
-                        hn_push(top, top_n, d, id);
-                        if (top_n > ef) hn_pop(top, top_n);
+                        hn_push(cand, cand_n, -d, id, lane);
+                        hn_push(top, top_n, d, id, lane);
+                        if (top_n > ef) hn_pop(top, top_n, lane);
                         lower = top.get(0).d;
+                        if (top_n >= ef) m &= __ballot(act && lower > o[0]);
                     }
                 }
                 if (overflow) break;
@@ -254,7 +282,7 @@ __global__ __launch_bounds__(64, 8) void hnsw_search_kernel(const HnswArgs a)  /
             if (w) atomicExch(a.err, 1);
             continue;
         }
-        while (top_n > a.k) hn_pop(top, top_n);
+        while (top_n > a.k) hn_pop(top, top_n, lane);
         // pops come out in non-increasing distance: write them back to front, then order ties by label,
         // which is the (dist, label) order of the reference's result queue (:719-726)
         const int m = top_n;
@@ -264,7 +292,7 @@ __global__ __launch_bounds__(64, 8) void hnsw_search_kernel(const HnswArgs a)  /
                 a.out_d[(int64_t)qi * a.k + i] = e.d;
                 a.out_label[(int64_t)qi * a.k + i] = a.raw_ids ? (int64_t)e.id : a.labels[e.id];
             }
-            hn_pop(top, top_n);
+            hn_pop(top, top_n, lane);
         }
         if (w) {
             float *od = a.out_d + (int64_t)qi * a.k;
