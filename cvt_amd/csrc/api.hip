@@ -145,6 +145,11 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         return CVTMI_OK;
     }
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
+    if (!strcmp(name, "sq8_wave_blocks")) {
+        if (value < 1 || value > 64) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: sq8_wave_blocks must be 1..64");
+        set_sq8_wave_blocks((int)value);
+        return CVTMI_OK;
+    }
     if (!strcmp(name, "flat_u8_mstream_min")) {
         if (value < 1 || value > 129) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_u8_mstream_min must be 1..129");
         set_flat_u8_mstream_min((int)value);

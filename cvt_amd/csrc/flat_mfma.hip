@@ -1216,7 +1216,7 @@ void set_flat_u8_gfilter(int v) { g_u8_gfilter = v; }  // 0 off, 1 choose, 2 two
 bool flat_u8_gfilter_shape(int D) { return g_u8_gfilter && (D == 64 || D == 128 || D == 256 || D == 512); }
 
 // 1 .. 128 queries over raw rows: stream + minima (the selection is launch_flat_u8_mstream_finish, flat.hip)
-constexpr int MSTREAM_BLOCKS = 256;   // one 4-wave workgroup per CU (one wave per SIMD)
+constexpr int MSTREAM_BLOCKS = 256;   // one 4-wave workgroup per CU (one wave per SIMD); 192 / 240 / 252 / 255 measured the same or worse
 static int g_mstream_min_nq = 1;       // measurement hook (flat_u8_mstream_min): below it the row-per-lane / row-tile kernels answer
 void set_flat_u8_mstream_min(int v) { g_mstream_min_nq = v; }
 bool flat_u8_mstream_applies(int D, int64_t n, int64_t nq, int k)

@@ -576,6 +576,11 @@ __global__ void sq8_train_finish_kernel(const uint32_t *kmin, const uint32_t *km
     }
 }
 
+// workgroups per CU of the wave-per-row training kernel.  A wave keeps RB rows in flight that lie (waves in the grid) rows apart: with a
+// power-of-two grid those streams are a power-of-two distance apart and fall on the same HBM channels -- measured on 2 M x 512-d:
+// 8 per CU 4.62-4.67 TB/s, 4: 4.38, 16: 4.89, 3: 5.04, 24: 5.09 (tools: cvtmi_set_tuning("sq8_wave_blocks"))
+static int g_sq8_wave_blocks = 3;
+void set_sq8_wave_blocks(int v) { g_sq8_wave_blocks = v; }
 // den_scratch: n floats, only used for row widths the tile kernel does not take
 int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_scratch, uint32_t *kmin, uint32_t *kmax,
                      float *vmin, float *vdiff, hipStream_t st)
@@ -586,7 +591,7 @@ int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_sc
         if (l2norm && (d == 256 || d == 512) && (((uintptr_t)x) & 15) == 0 && n >= 4096) {
             // whole rows per wave, no LDS tile (the tile kernel's phases serialise behind its barriers: 3.3 TB/s at d = 512)
             const int64_t rows_per_wg = kBlock / 64;
-            const unsigned blocks = (unsigned)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 256 * 8);
+            const unsigned blocks = (unsigned)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 256 * g_sq8_wave_blocks);
             if (d == 512) hipLaunchKernelGGL((sq8_train_wave_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax);
             else hipLaunchKernelGGL((sq8_train_wave_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax);
         } else if (sq8_tile_ok(d, x, nullptr, nullptr, nullptr)) {

@@ -87,6 +87,7 @@ def test_tuning_hooks_validate_their_arguments():
         assert lib.cvtmi_set_tuning(name, ctypes.c_int64(0)) == 0
         assert lib.cvtmi_set_tuning(name, ctypes.c_int64(7)) != 0 and name in lib.cvtmi_last_error()
     assert lib.cvtmi_set_tuning(b"flat_u8_dbg", ctypes.c_int64(1)) != 0 and b"CVTMI_GF_DBG" in lib.cvtmi_last_error()   # shipping build: refused
+    assert lib.cvtmi_set_tuning(b"sq8_wave_blocks", ctypes.c_int64(0)) != 0 and lib.cvtmi_set_tuning(b"sq8_wave_blocks", ctypes.c_int64(3)) == 0
     assert lib.cvtmi_set_tuning(b"flat_u8_mstream_min", ctypes.c_int64(0)) != 0 and b"flat_u8_mstream_min" in lib.cvtmi_last_error()
     assert lib.cvtmi_set_tuning(b"flat_u8_mstream_min", ctypes.c_int64(130)) != 0
     assert lib.cvtmi_set_tuning(b"flat_u8_mstream_min", ctypes.c_int64(1)) == 0
