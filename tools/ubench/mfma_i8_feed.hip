@@ -8,6 +8,7 @@
 // hipcc --offload-arch=gfx950 -O3 -o mfma_i8_feed mfma_i8_feed.hip && ./mfma_i8_feed
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, 
 template <int CH, int FEED, int WPS>
 static void run(const v4i *src, int *out)
 {
-    const int tiles = 4000, blocks = 256;
+    const int tiles = getenv("TILES") ? atoi(getenv("TILES")) : 4000, blocks = 256;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL((k<CH, FEED, WPS>), dim3(blocks), dim3(256 * WPS), 0, 0, src, out, 10);
     hipDeviceSynchronize();
