@@ -882,19 +882,32 @@ int cvtmi_flat_reset(cvtmi_flat_t h)
 }
 
 // the exact search over rows [0, n_rows) of the handle: k smallest (distance, row) per query, rows not yet mapped to labels
-static int flat_search_rows(cvtmi_flat_t h, int64_t n_rows, const void *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st)
+// max_stream_passes: the uint8 streaming kernel serves 128 queries per pass; callers that search a short row range for many queries (the
+// filter pipeline's sample stage) cap the passes and fall through to the row-tile kernels beyond
+static int flat_search_rows(cvtmi_flat_t h, int64_t n_rows, const void *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st,
+                            int64_t max_stream_passes = INT64_MAX)
 {
-    if (h->metric == CVTMI_METRIC_L2U8 && g_flat_variant != 1 && h->norms.p && flat_u8_mstream_applies(h->D, n_rows, nq, k) && ((uintptr_t)q & 15) == 0) {
-        int nqp = 0, waves = 0;
-        const size_t bytes = flat_u8_mstream_scratch(n_rows, nq, &nqp, &waves);
+    // uint8: anything the filter pipeline did not take goes through the streaming matrix-core kernel, 128 queries per pass (its cost hardly
+    // depends on k: 10 M x 512-d, k = 128: nq = 1000 40.6 -> 10 ms, nq = 4096 117 -> 40 ms against the row-tile kernels)
+    if (h->metric == CVTMI_METRIC_L2U8 && g_flat_variant != 1 && h->norms.p && nq >= 1 && flat_u8_mstream_applies(h->D, n_rows, std::min<int64_t>(nq, 128), k) &&
+        ((uintptr_t)q & 15) == 0 && (nq + 127) / 128 <= max_stream_passes) {
+        const int64_t passes = (nq + 127) / 128, per = (nq + passes - 1) / passes;   // balanced: 129 queries = 65 + 64
         const int S = flat_u8_stream_slices();
+        int nqp = 0, waves = 0;
+        const size_t bytes = flat_u8_mstream_scratch(n_rows, per, &nqp, &waves);
         CVTMI_TRY(h->s_stage.reserve(bytes));
-        CVTMI_TRY(h->s_part_d.reserve((size_t)nq * S * k * sizeof(float)));
-        CVTMI_TRY(h->s_part_id.reserve((size_t)nq * S * k * sizeof(int64_t)));
-        int32_t *tmin = h->s_stage.as<int32_t>(), *wmin = tmin + (size_t)((n_rows + 31) / 32) * nqp;
-        CVTMI_TRY(launch_flat_u8_mstream(h->D, h->data.as<uint8_t>(), h->norms.as<int32_t>(), n_rows, reinterpret_cast<const uint8_t *>(q), nq, tmin, wmin, st));
-        return launch_flat_u8_mstream_finish(h->D, h->data.as<uint8_t>(), n_rows, reinterpret_cast<const uint8_t *>(q), nq, k, wmin, waves, tmin, nqp,
-                                             h->s_part_d.as<float>(), h->s_part_id.as<int64_t>(), dist, rows, st);
+        CVTMI_TRY(h->s_part_d.reserve((size_t)per * S * k * sizeof(float)));
+        CVTMI_TRY(h->s_part_id.reserve((size_t)per * S * k * sizeof(int64_t)));
+        for (int64_t a = 0; a < nq; a += per) {
+            const int64_t m = std::min(per, nq - a);
+            (void)flat_u8_mstream_scratch(n_rows, m, &nqp, &waves);
+            const uint8_t *qa = reinterpret_cast<const uint8_t *>(q) + a * h->D;
+            int32_t *tmin = h->s_stage.as<int32_t>(), *wmin = tmin + (size_t)((n_rows + 31) / 32) * nqp;
+            CVTMI_TRY(launch_flat_u8_mstream(h->D, h->data.as<uint8_t>(), h->norms.as<int32_t>(), n_rows, qa, m, tmin, wmin, st));
+            CVTMI_TRY(launch_flat_u8_mstream_finish(h->D, h->data.as<uint8_t>(), n_rows, qa, m, k, wmin, waves, tmin, nqp, h->s_part_d.as<float>(),
+                                                    h->s_part_id.as<int64_t>(), dist + a * k, rows + a * k, st));
+        }
+        return CVTMI_OK;
     }
     const bool mfma = h->metric == CVTMI_METRIC_L2U8 && flat_u8_mfma_qtile(h->D, k, nq) > 0;
     const int qt = mfma ? flat_u8_mfma_qtile(h->D, k, nq) : flat_qtile(nq);
@@ -1031,7 +1044,8 @@ static int flat_search_filtered_u8(cvtmi_flat_t h, const uint8_t *q, int64_t nq,
     };
     // (a two-level sample -- exact kernels on ns / 8 rows, a first filter stage up to ns, as the fp32 path does -- was measured and lost:
     //  the second stage's launches and host sync cost more than the 1.2 ms of exact search they save; nq = 1000: 6.4 -> 7.0 ms)
-    CVTMI_TRY(flat_search_rows(h, ns, q, nq, k, h->f_sd.as<float>(), h->f_si.as<int64_t>(), st));
+    // (the sample through the streaming kernel: 10 M x 512-d nq = 256 2.5 -> 1.8 ms in all, but 32 passes for nq = 4096 cost 6 ms against 2.1)
+    CVTMI_TRY(flat_search_rows(h, ns, q, nq, k, h->f_sd.as<float>(), h->f_si.as<int64_t>(), st, 2));
     CVTMI_TRY(stage(ns, n, h->f_sd.as<float>(), h->f_si.as<int64_t>(), dist, rows));
     h->f_last_worst = worst;
     if (worst > (uint32_t)cap) return CVTMI_OK;

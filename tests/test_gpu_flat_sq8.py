@@ -486,10 +486,10 @@ def test_flat_f32_filter_small_batches(amd, orc, metric, nq):
 
 
 @pytest.mark.parametrize("D,nq,k,hi", [(512, 9, 10, 256), (128, 17, 128, 4), (256, 33, 1, 256), (512, 64, 33, 256), (128, 100, 10, 256),
-                                        (256, 128, 20, 6), (512, 40, 128, 256)])
+                                        (256, 128, 20, 6), (512, 40, 128, 256), (512, 300, 100, 256), (128, 129, 70, 4)])
 def test_flat_u8_mid_batch_stream(amd, orc, D, nq, k, hi):
-    """9..128 uint8 queries: matrix-core stream over the raw rows keeping tile / wave minima, then selection among the ~k tiles that
-    qualify (flat_variant 0) -- against the row-tile kernels (flat_variant 1) and the checker; ragged row count (last tile partly
+    """9..128 uint8 queries -- and larger batches the filter pipeline does not take (k > 64), in balanced passes of <= 128 --: matrix-core
+    stream over the raw rows keeping tile / wave minima, then selection among the ~k tiles that qualify (flat_variant 0) -- against the row-tile kernels (flat_variant 1) and the checker; ragged row count (last tile partly
     empty), duplicate rows at both ends and in the middle (ties resolved by row across finish slices), few distinct byte values"""
     rng = np.random.default_rng(D * 11 + nq)
     n = 262_144 + 32 * 333 + 7
