@@ -46,6 +46,33 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE";
   python $REPO/tools/pmc_summary.py /tmp/prof_big adc_scan > $OUT/big_pmc_$j.json
   grep '"metric"' /tmp/big_run.log > $OUT/${TAG}_bench_128m_under_rocprof.json
 done
+# 4. config 3 kernels (10 M x 512-d uint8): the filter kernel at nq = 4096 and the streaming kernel at nq = 1 / 64, one PMC group per run
+u=0
+for pmc in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS"; do
+  u=$((u+1))
+  for nq in 4096 64 1; do
+    rm -rf /tmp/prof_u8
+    NQ=$nq VARIANT=0 REPS=3 timeout 600 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d /tmp/prof_u8 -o u8 -- python $REPO/tools/u8_one.py > /tmp/u8_run.log 2>&1
+    echo "u8 nq=$nq pmc [$pmc] rc=$?"
+    python $REPO/tools/pmc_summary.py /tmp/prof_u8 flat_u8 > $OUT/u8_pmc_${u}_$nq.json
+  done
+done
+python - <<PY
+import json, glob, os
+out, tag = "$OUT", "$TAG"
+u8 = {}
+for f in sorted(glob.glob(os.path.join(out, "u8_pmc_*_*.json"))):
+    nq = f.rsplit("_", 1)[1].split(".")[0]
+    d = json.load(open(f))
+    for k, v in d.get("counters", {}).items():
+        if "gfilter" in k or "mstream" in k or "stream_finish" in k:
+            e = u8.setdefault("nq=" + nq, {}).setdefault(k, {})
+            e.update(v)
+            e.setdefault("kernel_trace", {}).update(d.get("kernel_trace", {}).get(k, {}))
+json.dump({"what": "10 M x 512-d uint8 rows, top-10, default dispatch; counters are sums over the run's dispatches of that kernel (3 searches + warm-up); FETCH_SIZE is in KB and needs the x2 gfx950 correction", "by_batch": u8},
+          open(os.path.join(out, tag + "_pmc_flat_u8.json"), "w"), indent=1)
+PY
 python - <<PY
 import json, glob, os
 out, tag = "$OUT", "$TAG"
@@ -73,6 +100,6 @@ c1, t1 = merge("pmc_*.json"); traffic(c1, t1, tag + "_scan_traffic.json")
 c2, t2 = merge("big_pmc_*.json"); traffic(c2, t2, tag + "_scan_traffic_128m.json")
 PY
 cd $REPO
-{ python tools/bench_kernels.py; python tools/bench_sq8.py; python tools/bench_flat_f32.py; python tools/bench_flat_u8_opt.py; python tools/bench_train.py; python tools/bench_pca.py; python tools/bench_encode.py; python tools/bench_assign.py; python tools/bench_flat_filter.py; python tools/bench_ivf.py; NQ=9 python tools/bench_ivf.py; } 2>&1 | grep -v amdgpu > $OUT/${TAG}_other_kernels.txt
-rm -f $OUT/pmc_*.json $OUT/big_pmc_*.json
+{ python tools/bench_kernels.py; python tools/bench_sq8.py; python tools/bench_flat_f32.py; python tools/bench_flat_u8_opt.py; python tools/bench_train.py; python tools/bench_pca.py; python tools/bench_encode.py; python tools/bench_assign.py; python tools/bench_flat_filter.py; python tools/bench_ivf.py; NQ=9 python tools/bench_ivf.py; python tools/bench_hnsw.py; METRIC=2 ROWS=10000000 D=512 python tools/flat_nq_sweep.py; METRIC=2 ROWS=10000000 D=128 python tools/flat_nq_sweep.py; METRIC=1 python tools/flat_nq_sweep.py; python tools/opq_nq_sweep.py; } 2>&1 | grep -v amdgpu > $OUT/${TAG}_other_kernels.txt
+rm -f $OUT/pmc_*.json $OUT/big_pmc_*.json $OUT/u8_pmc_*.json
 ls -la $OUT
