@@ -332,10 +332,17 @@ int launch_sq8_encode(const float *vmin, const float *vdiff, int d, float *x, in
     return CVTMI_OK;
 }
 
+static int launch_sq8_encode_wave(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm, int write_back,
+                                  uint8_t *codes, hipStream_t st);
+static int g_sq8_encode_wave = 1;   // cvtmi_set_tuning("sq8_encode_wave"): 0 = the tile kernel for every width
+void set_sq8_encode_wave(int v) { g_sq8_encode_wave = v; }
+
 int launch_sq8_encode_rows(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm, int write_back,
                            uint8_t *codes, float *den_scratch, hipStream_t st)
 {
     if (n <= 0) return CVTMI_OK;
+    if (g_sq8_encode_wave && (d == 256 || d == 512) && n >= 4096 && sq8_tile_ok(d, x, codes, vmin, vdiff))
+        return launch_sq8_encode_wave(vmin, vdiff, d, x, n, l2norm, write_back, codes, st);
     if (sq8_tile_ok(d, x, codes, vmin, vdiff)) {
         Sq8Args a{};
         a.vmin = vmin; a.vdiff = vdiff; a.x = x; a.codes = codes; a.n = n; a.d = d; a.l2norm = l2norm;
@@ -576,6 +583,108 @@ __global__ void sq8_train_finish_kernel(const uint32_t *kmin, const uint32_t *km
     }
 }
 
+// Encode with whole rows per wave (d = 256 / 512), the layout of sq8_train_wave_kernel: a lane owns 4 NF columns (their vmin and
+// the reciprocal of their vdiff stay in registers), RB rows are in flight, the norm of a row -- when asked for -- is reduced across
+// the wave and finished once by one lane, the normalised row goes back to x (the reference normalises its caller's buffer) and the
+// codes leave as NF coalesced dword stores per lane.  No LDS tile, no barrier: the tile kernel's phases wait for each other behind
+// three barriers with one workgroup per CU.
+template <int NF, bool NORM>
+__global__ __launch_bounds__(kBlock) void sq8_encode_wave_kernel(const float *__restrict__ vmin, const float *__restrict__ vdiff, float *x, int64_t n,
+                                                                int write_back, uint8_t *__restrict__ codes)
+{
+    constexpr int CG = 64 * NF, D = 4 * CG;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 *x4 = reinterpret_cast<float4 *>(x);
+    uint32_t *c4 = reinterpret_cast<uint32_t *>(codes);
+    const int64_t nw = (int64_t)gridDim.x * (kBlock / 64), w0 = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    float4 lo[NF];
+    DivBy df[NF][4];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        lo[i] = reinterpret_cast<const float4 *>(vmin)[lane + 64 * i];
+        const float4 d4 = reinterpret_cast<const float4 *>(vdiff)[lane + 64 * i];
+        df[i][0] = div_by(d4.x); df[i][1] = div_by(d4.y); df[i][2] = div_by(d4.z); df[i][3] = div_by(d4.w);
+    }
+    constexpr int RB = 4;
+    float4 cur[RB][NF], nxt[RB][NF];
+    auto fetch = [&](int64_t row, float4 (&o)[NF]) {
+        const int64_t r = row < n ? row : n - 1;  // clamped: rows past the end are computed, never stored
+#pragma unroll
+        for (int i = 0; i < NF; ++i) o[i] = x4[r * CG + lane + 64 * i];
+    };
+#pragma unroll
+    for (int p = 0; p < RB; ++p) fetch(w0 + p * nw, nxt[p]);
+    for (int64_t row = w0; row < n; row += RB * nw) {
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) cur[p][i] = nxt[p][i];
+            fetch(row + (p + RB) * nw, nxt[p]);
+        }
+        DivBy dl;
+        dl.b = 1.0f; dl.y = 1.0f; dl.ok = true;
+        if constexpr (NORM) {
+            double s[RB];
+#pragma unroll
+            for (int p = 0; p < RB; ++p) {
+                s[p] = 0.0;
+#pragma unroll
+                for (int i = 0; i < NF; ++i) {
+                    s[p] += (double)__fmul_rn(cur[p][i].x, cur[p][i].x); s[p] += (double)__fmul_rn(cur[p][i].y, cur[p][i].y);
+                    s[p] += (double)__fmul_rn(cur[p][i].z, cur[p][i].z); s[p] += (double)__fmul_rn(cur[p][i].w, cur[p][i].w);
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) s[p] += __shfl_xor(s[p], o, 64);
+            }
+            double mine = s[0];
+#pragma unroll
+            for (int p = 1; p < RB; ++p) mine = lane == p ? s[p] : mine;
+            // same proof as the tile kernel: the float root is order-independent when the roots of sum (1 -+ 2^-42) coincide
+            const double rlo = __dsqrt_rn(mine * (1.0 - 0x1p-42)), rhi = __dsqrt_rn(mine * (1.0 + 0x1p-42));
+            float den = (float)(rlo > 1e-12 ? rlo : 1e-12);
+            const float fhi = (float)(rhi > 1e-12 ? rhi : 1e-12);
+            const unsigned long long unproven = __ballot(lane < RB && !(den == fhi));
+            if (unproven) {  // rare: the reference's own order for those rows (int8_quan.cc:48-51)
+#pragma unroll
+                for (int p = 0; p < RB; ++p) {
+                    if ((unproven >> p) & 1ull) {  // wave-uniform
+                        const int64_t r = row + p * nw < n ? row + p * nw : n - 1;
+                        double accum = 0.0;
+                        for (int e = 0; e < D; ++e) {
+                            const float t = x[r * D + e];
+                            accum += (double)__fmul_rn(t, t);
+                        }
+                        const double nrm = __dsqrt_rn(accum);
+                        if (lane == p) den = (float)(nrm > 1e-12 ? nrm : 1e-12);
+                    }
+                }
+            }
+            dl = div_by(den);
+        }
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            const int64_t r = row + p * nw;
+            DivBy dd = dl;
+            if constexpr (NORM) {
+                dd.b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl.b), p));
+                dd.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl.y), p));
+                dd.ok = __builtin_amdgcn_readlane((int)dl.ok, p) != 0;
+            }
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                float4 v = cur[p][i];
+                if constexpr (NORM) {
+                    v.x = div_rn(v.x, dd); v.y = div_rn(v.y, dd); v.z = div_rn(v.z, dd); v.w = div_rn(v.w, dd);
+                    if (write_back && r < n) x4[r * CG + lane + 64 * i] = v;
+                }
+                const uint32_t w = sq8_byte(v.x, lo[i].x, df[i][0]) | (sq8_byte(v.y, lo[i].y, df[i][1]) << 8) |
+                                   (sq8_byte(v.z, lo[i].z, df[i][2]) << 16) | (sq8_byte(v.w, lo[i].w, df[i][3]) << 24);
+                if (r < n) c4[r * CG + lane + 64 * i] = w;
+            }
+        }
+    }
+}
+
 // workgroups per CU of the wave-per-row training kernel.  A wave keeps RB rows in flight that lie (waves in the grid) rows apart: with a
 // power-of-two grid those streams are a power-of-two distance apart and fall on the same HBM channels -- measured on 2 M x 512-d:
 // 8 per CU 4.62-4.67 TB/s, 4: 4.38, 16: 4.89, 3: 5.04, 24: 5.09 (tools: cvtmi_set_tuning("sq8_wave_blocks"))
@@ -610,6 +719,22 @@ int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_sc
         }
     }
     hipLaunchKernelGGL(sq8_train_finish_kernel, dim3(db), dim3(kBlock), 0, st, kmin, kmax, d, vmin, vdiff);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+static int launch_sq8_encode_wave(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm, int write_back,
+                                  uint8_t *codes, hipStream_t st)
+{
+    const int64_t rows_per_wg = kBlock / 64;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 256 * g_sq8_wave_blocks);
+    if (d == 512) {
+        if (l2norm) hipLaunchKernelGGL((sq8_encode_wave_kernel<2, true>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes);
+        else hipLaunchKernelGGL((sq8_encode_wave_kernel<2, false>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes);
+    } else {
+        if (l2norm) hipLaunchKernelGGL((sq8_encode_wave_kernel<1, true>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes);
+        else hipLaunchKernelGGL((sq8_encode_wave_kernel<1, false>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes);
+    }
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

@@ -82,6 +82,7 @@ int cvtmi_set_device(int device);
  *                     0 = the round-1 filter kernel (register-staged tiles)
  *   "flat_u8_dbg"     timing experiments of the filter kernel (-DCVTMI_GF_DBG builds only; EUNSUPPORTED otherwise: results are wrong)
  *   "flat_u8_mstream_min"  smallest uint8 batch that takes the streaming matrix-core kernel (default 1; 129 = never: row-per-lane / row-tile kernels)
+ *   "sq8_encode_wave" 0 = SQ8 encode through the 64-row tile kernel for every width (default 1: wave-per-row kernel at d = 256 / 512)
  *   "sq8_wave_blocks" workgroups per CU of the wave-per-row SQ8 training kernel (default 3; powers of two lose 8 % to HBM channel conflicts)
  *   "flat_u8_opt"     measurement variants of the uint8 row-tile kernel (0 = shipped; 1..3 spill registers and are slower)
  *   "probe_variant"   coarse top-nk of cvtmi_opq_query_video: 0 = choose (matrix-core filter + exact distances of the candidates

@@ -193,6 +193,39 @@ def test_sq8_train_wave_kernel(amd, orc, d):
     assert np.array_equal(bits(vmin.cpu().numpy()), bits(ovmin)) and np.array_equal(bits(vdiff.cpu().numpy()), bits(ovdiff))
 
 
+@pytest.mark.parametrize("d", [512, 256])
+def test_sq8_encode_wave_kernel(amd, orc, d):
+    """Encode at d = 256 / 512 and >= 4096 rows takes the wave-per-row kernel, with and without normalisation: codes and the
+    normalised rows written back must equal the oracle's bit for bit (and the tile kernel's), including rows whose norm needs the
+    index-order sum, zero rows, a non-finite row, a column with vdiff = 0 and a ragged tail."""
+    import torch
+    rng = np.random.default_rng(d + 1)
+    n = 20_000 + 37
+    x = np.abs(rng.normal(size=(n, d))).astype(np.float32)
+    x[5] = 0
+    x[17] *= 1e-30; x[18] *= 1e18
+    x[100:600] *= np.exp(rng.normal(size=(500, 1)) * 8).astype(np.float32)
+    x[700:1200] = (x[700:1200] * np.exp(rng.normal(size=(500, d)) * 6)).astype(np.float32)
+    x[9, 3] = np.inf
+    x[:, 7] = 0.25                                            # constant column
+    for l2 in (True, False):
+        base = x.copy() if l2 else (x / np.maximum(np.linalg.norm(np.where(np.isfinite(x), x, 0), axis=1, keepdims=True), 1e-12)).astype(np.float32)
+        ovmin, ovdiff = orc.sq8_train(base[20:], l2norm=l2)   # train without the hard rows: codes clamp outside [vmin, vmin + vdiff]
+        oc, ox = orc.sq8_encode(ovmin, ovdiff, base, l2norm=l2)
+        out = {}
+        try:
+            for wave in (1, 0):
+                amd.set_tuning("sq8_encode_wave", wave)
+                xt = torch.from_numpy(base.copy()).cuda()
+                codes = amd.sq8_encode(torch.from_numpy(ovmin).cuda(), torch.from_numpy(ovdiff).cuda(), xt, l2norm=l2)
+                out[wave] = (codes.cpu().numpy(), xt.cpu().numpy())
+        finally:
+            amd.set_tuning("sq8_encode_wave", 1)
+        assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(bits(out[1][1]), bits(out[0][1]))
+        assert np.array_equal(out[1][0], oc)
+        assert np.array_equal(bits(out[1][1]), bits(ox))
+
+
 def test_sq8_parity(amd, orc, golden):
     rng = np.random.default_rng(8)
     for d in (64, 512, 300):
