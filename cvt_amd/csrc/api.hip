@@ -1457,7 +1457,7 @@ int cvtmi_hnsw_search_dev(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int
     CVTMI_TRY(h->s_vis.reserve((size_t)slots * words * 4));
     CVTMI_TRY(h->s_cand.reserve((size_t)slots * (gcap + efe + 1) * 8));  // per slot: spilled top queue + spilled candidates
     CVTMI_TRY(h->s_err.reserve(16));
-    CVTMI_HIP(hipMemsetAsync(h->s_err.p, 0, 4, st));
+    CVTMI_HIP(hipMemsetAsync(h->s_err.p, 0, 8, st));  // [0] overflow flag, [1] query counter
     CVTMI_TRY(launch_hnsw_search(h->g, h->metric, q, nq, k, ef, dist, labels, h->s_vis.as<uint32_t>(), h->s_cand.p, slots, words,
                                  gcap, h->s_err.as<int>(), st));
     int err = 0;
@@ -1529,7 +1529,7 @@ static int hnsw_search_adc_impl(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q,
     CVTMI_TRY(h->s_vis.reserve((size_t)slots * words * 4));
     CVTMI_TRY(h->s_cand.reserve((size_t)slots * (gcap + efe + 1) * 8));  // per slot: spilled top queue + spilled candidates
     CVTMI_TRY(h->s_err.reserve(16));
-    CVTMI_HIP(hipMemsetAsync(h->s_err.p, 0, 4, st));
+    CVTMI_HIP(hipMemsetAsync(h->s_err.p, 0, 8, st));  // [0] overflow flag, [1] query counter
     CVTMI_TRY(launch_hnsw_search_adc(h->g, opq->s_lut.as<float>(), opq->codes.as<uint8_t>(), opq->m.M, opq->m.K, nq, k, ef, dist,
                                      labels, h->s_vis.as<uint32_t>(), h->s_cand.p, slots, words, gcap, h->s_err.as<int>(), st, raw_ids));
     int err = 0;

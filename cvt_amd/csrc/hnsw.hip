@@ -124,6 +124,7 @@ struct HnswArgs {
     int64_t words, gcap;
     int *err;
     int raw_ids;              // 1 = out_label receives internal ids instead of labels (the re-rank pass needs the node)
+    int dynamic;              // 1 = queries handed out by the counter err[1] (64 per wave: nq < 2^25), 0 = static stride
 };
 
 // Distance evaluators: per-query state in LDS (`prepare`), one neighbour per lane (`operator()`).
@@ -189,7 +190,19 @@ __global__ __launch_bounds__(64, 8) void hnsw_search_kernel(const HnswArgs a)  /
     const int ef = a.ef > a.k ? a.ef : a.k;
     const int64_t cand_cap = HN_LCAP + a.gcap;
 
-    for (int qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
+    // Queries are drawn from a counter (err[1], zeroed with the flag) instead of a static stride: traversals differ in length, and the last
+    // of the 1.2 - 2.6 rounds used to wait for its slowest waves.  EVERY lane takes part in the atomic (the compiler folds it into one
+    // add of 64 per wave): a header that only lane 0 executes lets the compiler send lane 0 and the other lanes through the loop on
+    // different paths, and the wave-level operations of the body then run without lane 0 (observed: the kernel never ended).
+    for (int it = 0;; ++it) {
+        int qi;
+        if (a.dynamic) {
+            const unsigned t = atomicAdd(reinterpret_cast<unsigned *>(a.err) + 1, 1u);
+            qi = (int)((unsigned)__builtin_amdgcn_readfirstlane((int)t) >> 6);
+        } else {
+            qi = (int)blockIdx.x + it * (int)gridDim.x;
+        }
+        if (qi >= a.nq) break;
         dist.prepare(qi, lane);
         for (int64_t i = lane; i < a.words; i += 64) vis[i] = 0u;
         for (int i = lane; i < a.k; i += 64) { a.out_d[(int64_t)qi * a.k + i] = 0.0f; a.out_label[(int64_t)qi * a.k + i] = -1; }
@@ -317,6 +330,7 @@ static void hnsw_fill_args(HnswArgs &a, const HnswDevGraph &g, int64_t nq, int k
     a.nq = (int)nq; a.k = k; a.ef = ef; a.out_d = out_d; a.out_label = out_label;
     a.visited = visited; a.cand_g = reinterpret_cast<HnEnt *>(cand_scratch); a.words = words; a.gcap = gcap; a.err = err;
     a.raw_ids = 0;
+    a.dynamic = nq < (1 << 25) ? 1 : 0;
 }
 
 int launch_hnsw_search(const HnswDevGraph &g, int metric, const float *q, int64_t nq, int k, int ef, float *out_d,
