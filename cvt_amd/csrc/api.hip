@@ -1068,9 +1068,11 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
         h->n >= 2 * 65536)
         CVTMI_TRY(flat_search_filtered(h, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
     // uint8: large batches go through the filter pipeline with the software-pipelined (LDS-DMA) kernel -- measured at 10 M x 512-d:
-    // 4096 queries 27.4 -> 21.0 ms, 512 queries 4.6 -> 3.8 ms, break-even near nq * D = 128 K; smaller batches stay on the row-tile
-    // kernels.  flat_variant 2 forces the pipeline wherever it applies, 1 forbids it.
-    const bool u8_auto = g_flat_variant == 0 && flat_u8_gfilter_shape(h->D) && nq * h->D >= 131072 && h->n >= (1 << 20) && k <= 64;
+    // 4096 queries 27.4 -> 21.0 ms, 512 queries 4.6 -> 3.8 ms; smaller batches are one stream over the raw rows (flat_search_rows).
+    // flat_variant 2 forces the pipeline wherever it applies, 1 forbids it.
+    // (from 256 queries at every width: 10 M x 128-d nq = 256 / 512 / 1000 1.52 / 2.78 / 5.5 ms in streaming passes, 1.03 / 2.08 / 3.25 here;
+    //  256-d nq = 256 1.87 against 1.26; between 257 and ~400 queries the two are within 5 %)
+    const bool u8_auto = g_flat_variant == 0 && flat_u8_gfilter_shape(h->D) && nq >= 256 && h->n >= (1 << 20) && k <= 64;
     if ((g_flat_variant == 2 || u8_auto) && h->metric == CVTMI_METRIC_L2U8 && ((uintptr_t)q & 15) == 0 && nq <= 65535 * 256 && h->norms.p &&
         flat_u8_filter_applies(h->D, std::max<int64_t>(h->n, 262144), std::max<int64_t>(nq, 256), k) && h->n >= 2 * 65536)
         CVTMI_TRY(flat_search_filtered_u8(h, reinterpret_cast<const uint8_t *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));

@@ -75,7 +75,7 @@ int cvtmi_set_device(int device);
  *                     resolution of undecided rows wherever it applies (32 <= d <= 128, d % 16 == 0, k >= 64)
  *   "flat_variant"    exhaustive search: 0 = choose (default: large batches through the filter pipelines -- fp32: bf16 matrix-core
  *                     filter with a proven bound; uint8: exact sample, software-pipelined i8 matrix-core threshold filter, sort,
- *                     from nq * D >= 128 K on >= 1 M rows -- smaller ones on the exact / row-tile kernels); 1 = exact / row-tile
+ *                     from 256 queries on >= 1 M rows; smaller uint8 batches are one stream over the rows, 128 queries per pass); 1 = exact / row-tile
  *                     kernels only; 2 = the filter pipelines wherever they apply
  *   "flat_u8_gfilter" the uint8 filter stage: 1 (default) / 3 = LDS-DMA pipelined kernel, one 8-wave workgroup per CU; 2 = two 4-wave
  *                     workgroups per CU; 4 = one wave per SIMD holding 96-128 queries (GEMM-shaped; measured equal / slower);
