@@ -903,9 +903,9 @@ static int flat_search_rows(cvtmi_flat_t h, int64_t n_rows, const void *q, int64
             const int64_t m = std::min(per, nq - a);
             (void)flat_u8_mstream_scratch(n_rows, m, &nqp, &waves);
             const uint8_t *qa = reinterpret_cast<const uint8_t *>(q) + a * h->D;
-            int32_t *tmin = h->s_stage.as<int32_t>(), *wmin = tmin + (size_t)((n_rows + 31) / 32) * nqp;
+            int32_t *tmin = h->s_stage.as<int32_t>(), *wmin = tmin + (size_t)flat_u8_mstream_groups(n_rows) * nqp;
             CVTMI_TRY(launch_flat_u8_mstream(h->D, h->data.as<uint8_t>(), h->norms.as<int32_t>(), n_rows, qa, m, tmin, wmin, st));
-            CVTMI_TRY(launch_flat_u8_mstream_finish(h->D, h->data.as<uint8_t>(), n_rows, qa, m, k, wmin, waves, tmin, nqp, h->s_part_d.as<float>(),
+            CVTMI_TRY(launch_flat_u8_mstream_finish(h->D, h->data.as<uint8_t>(), n_rows, qa, m, k, wmin, waves, tmin, nqp, flat_u8_mstream_group(), h->s_part_d.as<float>(),
                                                     h->s_part_id.as<int64_t>(), dist + a * k, rows + a * k, st));
         }
         return CVTMI_OK;

@@ -348,7 +348,7 @@ struct StreamFinishArgs {
     const int32_t *gmin;
     int G, S, rpi_log2, k;
     float *part_d; int64_t *part_id;
-    const int32_t *tmin; int nqp; const uint8_t *X; const uint8_t *Q; int D;
+    const int32_t *tmin; int nqp; int tile_group; const uint8_t *X; const uint8_t *Q; int D;   // tmin[((round / tile_group) * G + wave) * nqp + q]
 };
 __global__ __launch_bounds__(kBlock) void flat_u8_stream_finish_kernel(const StreamFinishArgs a)
 {
@@ -453,11 +453,12 @@ __global__ __launch_bounds__(kBlock) void flat_u8_stream_finish_kernel(const Str
                 const int ci = (int)(e >> rpi_log2);
                 int a_ = 0, b_ = n_rounds - 1;   // the round whose [r_off, r_off + 1) holds ci
                 while (a_ < b_) { const int m_ = (a_ + b_ + 1) >> 1; if (r_off[m_] <= ci) a_ = m_; else b_ = m_ - 1; }
-                const int64_t chunk = (t_a + a_) * G + ql[r_first[a_] + (ci - r_off[a_])];
+                const int wv = ql[r_first[a_] + (ci - r_off[a_])];
+                const int64_t chunk = (t_a + a_) * G + wv, tgrp = ((t_a + a_) / a.tile_group) * G + wv;
                 const int64_t row = (chunk << rpi_log2) + (e & ((1 << rpi_log2) - 1));
                 if (row < n) {
                     uint32_t d = KEY_MAX;
-                    if ((uint32_t)a.tmin[chunk * a.nqp + q] <= theta) {   // exact sum (q - x)^2 = |q|^2 + |x|^2 - 2 <q, x>, every term < 2^27
+                    if ((uint32_t)a.tmin[tgrp * a.nqp + q] <= theta) {   // exact sum (q - x)^2 = |q|^2 + |x|^2 - 2 <q, x>, every term < 2^27
                         const uint4 *xr = reinterpret_cast<const uint4 *>(a.X + row * a.D);
                         uint32_t xx = 0, qx = 0;
                         for (int c = 0; c < a.D / 16; ++c) {
@@ -1169,11 +1170,11 @@ int launch_gather_labels(int64_t *ids, int64_t count, const int64_t *labels, hip
 constexpr int STREAM_SLICES = 64;
 // selection after flat_u8_mstream_kernel (flat_mfma.hip): wave minima wmin[nq][G], tile minima tmin[tiles][nqp] -> part [nq][slices][k] -> merge
 int launch_flat_u8_mstream_finish(int D, const uint8_t *data, int64_t n, const uint8_t *q, int64_t nq, int k, const int32_t *wmin, int G,
-                                  const int32_t *tmin, int nqp, float *part_d, int64_t *part_id, float *out_d, int64_t *out_rows, hipStream_t st)
+                                  const int32_t *tmin, int nqp, int tile_group, float *part_d, int64_t *part_id, float *out_d, int64_t *out_rows, hipStream_t st)
 {
     StreamFinishArgs fa = {};
     fa.n = n; fa.gmin = wmin; fa.G = G; fa.S = STREAM_SLICES; fa.rpi_log2 = 5; fa.k = k; fa.part_d = part_d; fa.part_id = part_id;
-    fa.tmin = tmin; fa.nqp = nqp; fa.X = data; fa.Q = q; fa.D = D;
+    fa.tmin = tmin; fa.nqp = nqp; fa.tile_group = tile_group; fa.X = data; fa.Q = q; fa.D = D;
     hipLaunchKernelGGL(flat_u8_stream_finish_kernel, dim3((unsigned)(nq * STREAM_SLICES)), dim3(kBlock), 0, st, fa);
     CVTMI_HIP(hipGetLastError());
     return launch_topk_merge(part_d, part_id, nq, STREAM_SLICES, k, out_d, out_rows, st);

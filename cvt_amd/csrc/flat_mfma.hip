@@ -1051,6 +1051,7 @@ __device__ __forceinline__ void fold_min(int (&s_)[V], int sub)
 }
 constexpr int ms_log2(int v) { return v <= 1 ? 0 : 1 + ms_log2(v / 2); }
 constexpr int MS_PAD = 32;   // bytes between the 1 KB pieces of a tile in LDS
+constexpr int MS_GROUP = 4;  // tiles of a wave whose minima are kept as one (tmin[(i / MS_GROUP) * waves + wave])
 
 template <int KS, int QB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flat_u8_mstream_kernel(
@@ -1121,6 +1122,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     // B operand of row lj, K step s: tile byte lj D + 32 s + 16 lk -> piece (lj D) >> 10, offset (lj D) & 1023
     const uint32_t rd_off = (uint32_t)(((lj * D) >> 10) * PIECE + ((lj * D) & 1023) + 16 * lk);
+    int dmin[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) dmin[v] = 0x7fffffff;
     for (int64_t i = 0; i < my_tiles; ++i) {
         request(i + NB - 1, (int)((i + NB - 1) % NB));
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 1) * OPS) : "memory");   // tile i has landed (loads complete in order; the stores below can only add to the wait)
@@ -1141,18 +1145,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(qreg[b][s_], bv, acc[b], 0, 0, 0);
         }
-        int dv[V];
         const int xr = row < n ? xx : 0x3fffffff;   // rows past the end never set a minimum
 #pragma unroll
         for (int b = 0; b < QB; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) dv[16 * b + e] = xr - 2 * acc[b][e];   // + |q'|^2 after the fold (constant per query)
-        fold_min<16, V, V>(dv, sub);
+            for (int e = 0; e < 16; ++e) {
+                const int d = xr - 2 * acc[b][e];   // + |q'|^2 after the fold (constant per query)
+                dmin[16 * b + e] = d < dmin[16 * b + e] ? d : dmin[16 * b + e];
+            }
+        // the butterfly across the 32 rows costs ~5 instructions per value: it runs once per MS_GROUP of the wave's tiles (their
+        // minima are first combined lane by lane, one v_min each), and the finish kernel treats those tiles as one unit
+        if ((i & (MS_GROUP - 1)) == MS_GROUP - 1 || i == my_tiles - 1) {
+            fold_min<16, V, V>(dmin, sub);
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int d = dv[r] + my_qq[r];
-            if (writer) tmin[t * NQP + my_q[r]] = d;
-            mn[r] = d < mn[r] ? d : mn[r];
+            for (int r = 0; r < R; ++r) {
+                const int d = dmin[r] + my_qq[r];
+                if (writer) tmin[((i / MS_GROUP) * G + wave_g) * NQP + my_q[r]] = d;
+                mn[r] = d < mn[r] ? d : mn[r];
+            }
+#pragma unroll
+            for (int v = 0; v < V; ++v) dmin[v] = 0x7fffffff;
         }
     }
 #pragma unroll
@@ -1224,13 +1236,21 @@ bool flat_u8_mstream_applies(int D, int64_t n, int64_t nq, int k)
     return (D == 128 || D == 256 || D == 512) && nq >= g_mstream_min_nq && nq <= 128 && n >= 262144 && n < 0x7fffffff && k <= 128 &&
            n / 32 / 64 / (MSTREAM_BLOCKS * 4) + 2 <= 160;   // rounds a finish slice can span (FIN_MAXR, flat.hip): 331 M rows
 }
-// scratch (int32): tile minima [tiles][32 QB] then wave minima [nq][waves]
+// entries of the tile-group minima array: groups of MS_GROUP tiles per wave, (group, wave) major
+int64_t flat_u8_mstream_groups(int64_t n)
+{
+    const int64_t waves = (int64_t)MSTREAM_BLOCKS * 4, tiles = (n + 31) / 32;
+    const int64_t per_wave = (tiles + waves - 1) / waves;
+    return (per_wave + MS_GROUP - 1) / MS_GROUP * waves;
+}
+int flat_u8_mstream_group() { return MS_GROUP; }
+// scratch (int32): tile-group minima [groups][32 QB] then wave minima [nq][waves]
 size_t flat_u8_mstream_scratch(int64_t n, int64_t nq, int *nqp, int *waves)
 {
     const int qb = nq <= 32 ? 1 : (nq <= 64 ? 2 : 4);
     if (nqp) *nqp = 32 * qb;
     if (waves) *waves = MSTREAM_BLOCKS * 4;
-    return ((size_t)((n + 31) / 32) * 32 * qb + (size_t)nq * MSTREAM_BLOCKS * 4) * sizeof(int32_t);
+    return ((size_t)flat_u8_mstream_groups(n) * 32 * qb + (size_t)nq * MSTREAM_BLOCKS * 4) * sizeof(int32_t);
 }
 int launch_flat_u8_mstream(int D, const uint8_t *data, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int32_t *tmin,
                            int32_t *wmin, hipStream_t st)

@@ -128,10 +128,12 @@ int set_flat_u8_dbg(int v);   // -DCVTMI_GF_DBG builds only
 // uint8 L2, 1..128 queries: matrix-core stream over the raw rows keeping tile / wave minima (flat_mfma.hip) + selection (flat.hip)
 bool flat_u8_mstream_applies(int D, int64_t n, int64_t nq, int k);
 size_t flat_u8_mstream_scratch(int64_t n, int64_t nq, int *nqp, int *waves);
+int64_t flat_u8_mstream_groups(int64_t n);   // entries of the tile-group minima array
+int flat_u8_mstream_group();                 // tiles per group
 int launch_flat_u8_mstream(int D, const uint8_t *data, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int32_t *tmin,
                            int32_t *wmin, hipStream_t st);
 int launch_flat_u8_mstream_finish(int D, const uint8_t *data, int64_t n, const uint8_t *q, int64_t nq, int k, const int32_t *wmin, int G,
-                                  const int32_t *tmin, int nqp, float *part_d, int64_t *part_id, float *out_d, int64_t *out_rows, hipStream_t st);
+                                  const int32_t *tmin, int nqp, int tile_group, float *part_d, int64_t *part_id, float *out_d, int64_t *out_rows, hipStream_t st);
 int flat_u8_stream_slices();
 void set_flat_u8_mstream_min(int v);
 void set_sq8_wave_blocks(int v);
