@@ -238,12 +238,8 @@ template <bool TRAIN>
 static int launch_sq8_tile(const Sq8Args &a, hipStream_t st)
 {
     const size_t lds = (size_t)SQ_ROWS * ((a.d >> 2) + 1) * sizeof(float4);
-    static bool attr_set[2] = { false, false };
-    if (!attr_set[TRAIN]) {
-        CVTMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sq8_tile_kernel<TRAIN>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 129 * 16));
-        attr_set[TRAIN] = true;
-    }
+    // set on every call: the attribute belongs to the (function, device) pair, and a process may hold handles on several devices
+    CVTMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sq8_tile_kernel<TRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 129 * 16));
     const int64_t n_tiles = (a.n + SQ_ROWS - 1) / SQ_ROWS;
     int64_t blocks = lds > 72 * 1024 ? 256 : 512;  // one or two workgroups per CU
     if (blocks > n_tiles) blocks = n_tiles;
