@@ -413,10 +413,10 @@ class FlatIndex:
         return d, i
 
     def last_search(self):
-        """(answered through the matrix-core filter?, largest candidate list) of the last search"""
+        """(how the last search was answered: 0 exact kernels, 1 sample + matrix-core filter, 2 fp32 stream; largest candidate list)"""
         f = C.c_int(0); m = C.c_int64(0)
         _check(lib().cvtmi_flat_last_search(self.h, C.byref(f), C.byref(m)))
-        return bool(f.value), m.value
+        return f.value, m.value
 
 
 class HnswIndex:

@@ -90,8 +90,12 @@ struct cvtmi_flat_s {
     DevBuf f_pack, f_bias, f_stats, f_thr, f_marg, f_cnt, f_cand, f_sd, f_si, f_sd2, f_si2, f_seld, f_seli;
     int64_t f_pack_n = -1;      // rows the copy covers (-1: none)
     bool f_nonfinite = false;   // a row holds inf / NaN: the filter is not used
-    int f_last_filtered = 0;    // the last search was answered through the filter
+    int f_last_filtered = 0;    // the last search was answered through the filter (1) / the fp32 stream (2)
     int64_t f_last_worst = 0;   // its largest candidate list
+    // fp32 stream (flat_f32_stream.hip): per-row score bias, statistics of the rows ([0] max |x|^2, [1] non-finite rows), redo flags
+    DevBuf fs_bias, fs_stats, fs_redo, fs_scratch;
+    int64_t fs_stats_n = -1;    // index size the host copy of the statistics belongs to
+    bool fs_nonfinite = false;
 };
 
 static int use_device(int dev)
@@ -111,6 +115,7 @@ static int use_device(int dev)
     Serial serial_##h((h)->sync, (hipStream_t)(stream))
 
 static int g_flat_variant = 0;  // cvtmi_set_tuning("flat_variant"): 0 = choose, 1 = exact kernels only, 2 = matrix-core filter wherever it applies
+static int g_flat_f32_stream = 1;  // cvtmi_set_tuning("flat_f32_stream"): 0 = off, 1 = choose, 2 = wherever it applies
 
 extern "C" {
 
@@ -142,6 +147,11 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "probe_variant")) {
         if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: probe_variant must be 0, 1 or 2");
         set_probe_variant((int)value);
+        return CVTMI_OK;
+    }
+    if (!strcmp(name, "flat_f32_stream")) {
+        if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_f32_stream must be 0, 1 or 2");
+        g_flat_f32_stream = (int)value;
         return CVTMI_OK;
     }
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
@@ -781,7 +791,7 @@ int cvtmi_flat_destroy(cvtmi_flat_t h)
     (void)hipDeviceSynchronize();
     for (DevBuf *b : { &h->data, &h->labels, &h->norms, &h->s_part_d, &h->s_part_id, &h->s_gthr, &h->s_stage, &h->f_pack, &h->f_bias,
                        &h->f_stats, &h->f_thr, &h->f_marg, &h->f_cnt, &h->f_cand, &h->f_sd, &h->f_si, &h->f_sd2, &h->f_si2, &h->f_seld,
-                       &h->f_seli })
+                       &h->f_seli, &h->fs_bias, &h->fs_stats, &h->fs_redo, &h->fs_scratch })
         b->release();
     h->sync.destroy();
     delete h;
@@ -833,6 +843,16 @@ static int flat_add_common(cvtmi_flat_t h, const void *x, const int64_t *labels,
             src = h->s_stage.as<float>();
         }
         CVTMI_TRY(launch_flat_block(src, n, h->D, h->n, h->data.as<float>(), st));
+        if (flat_f32_stream_qmax(h->D) > 0) {   // score bias + row statistics of the streaming search, padding rows zeroed
+            if (!h->fs_stats.p) {
+                CVTMI_TRY(h->fs_stats.reserve(16));
+                CVTMI_HIP(hipMemsetAsync(h->fs_stats.p, 0, 16, st));
+            }
+            if (rows_need * 4 > h->fs_bias.cap)
+                CVTMI_TRY(h->fs_bias.grow(std::max<size_t>(rows_need, h->fs_bias.cap / 2) * 4, rows_held * 4, st));
+            CVTMI_TRY(launch_flat_f32_bias(h->data.as<float>(), h->D, h->metric, h->n, total, h->fs_bias.as<float>(), h->fs_stats.as<uint32_t>(), st));
+            h->fs_stats_n = -1;
+        }
     } else {
         CVTMI_HIP(hipMemcpyAsync(h->data.as<uint8_t>() + (size_t)h->n * h->row_bytes, x, (size_t)n * h->row_bytes, kind, st));
     }
@@ -877,7 +897,9 @@ int cvtmi_flat_reset(cvtmi_flat_t h)
 {
     CHECK_H_SERIAL(h, nullptr);
     h->n = 0; h->identity = true; h->f_pack_n = -1;
+    h->fs_stats_n = -1; h->fs_nonfinite = false;
     (void)hipDeviceSynchronize();
+    if (h->fs_stats.p) CVTMI_HIP(hipMemset(h->fs_stats.p, 0, 16));
     h->f_pack.release(); h->f_bias.release();  // the filter's operand copy is as large as the rows: give it back
     return CVTMI_OK;
 }
@@ -886,7 +908,7 @@ int cvtmi_flat_reset(cvtmi_flat_t h)
 // max_stream_passes: the uint8 streaming kernel serves 128 queries per pass; callers that search a short row range for many queries (the
 // filter pipeline's sample stage) cap the passes and fall through to the row-tile kernels beyond
 static int flat_search_rows(cvtmi_flat_t h, int64_t n_rows, const void *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st,
-                            int64_t max_stream_passes = INT64_MAX)
+                            int64_t max_stream_passes = INT64_MAX, const uint32_t *only_if = nullptr)
 {
     // uint8: anything the filter pipeline did not take goes through the streaming matrix-core kernel, 128 queries per pass (its cost hardly
     // depends on k: 10 M x 512-d, k = 128: nq = 1000 40.6 -> 10 ms, nq = 4096 117 -> 40 ms against the row-tile kernels)
@@ -914,6 +936,8 @@ static int flat_search_rows(cvtmi_flat_t h, int64_t n_rows, const void *q, int64
     const int qt = mfma ? flat_u8_mfma_qtile(h->D, k, nq) : flat_qtile(nq);
     int splits = mfma ? flat_u8_mfma_splits(n_rows, nq, qt) : flat_plan_splits(n_rows, nq, qt);
     if (mfma && splits >= 8) splits = (splits / 8) * 8;  // a row split per XCD: query groups share its L2
+    // a predicated re-run normally finds nothing to do: keep its grid small (an empty workgroup still costs a dispatch)
+    if (only_if) splits = (int)std::max<int64_t>(std::min<int64_t>(splits, 8), std::min<int64_t>(splits, 128 / ((nq + qt - 1) / qt)));
     float *pd = dist;
     int64_t *pi = rows;
     if (splits > 1) {
@@ -929,8 +953,39 @@ static int flat_search_rows(cvtmi_flat_t h, int64_t n_rows, const void *q, int64
                                       reinterpret_cast<const uint8_t *>(q), nq, k, splits, pd, pi, h->s_gthr.as<uint32_t>(), st));
     }
     else
-        CVTMI_TRY(launch_flat_search(h->metric, h->D, h->data.p, n_rows, q, nq, k, qt, splits, pd, pi, st));
-    if (splits > 1) CVTMI_TRY(launch_topk_merge(pd, pi, nq, splits, k, dist, rows, st));
+        CVTMI_TRY(launch_flat_search(h->metric, h->D, h->data.p, n_rows, q, nq, k, qt, splits, pd, pi, st, only_if));
+    if (splits > 1) CVTMI_TRY(launch_topk_merge(pd, pi, nq, splits, k, dist, rows, st, only_if));
+    return CVTMI_OK;
+}
+
+// fp32 search as a stream over the rows (flat_f32_stream.hip).  *done = false: not applicable, the other paths answer
+static int flat_search_streamed(cvtmi_flat_t h, const float *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st, bool *done)
+{
+    *done = false;
+    const int D = h->D;
+    const int64_t n = h->n;
+    if (!h->fs_bias.p || !h->fs_stats.p) return CVTMI_OK;
+    if (h->fs_stats_n != n) {   // once per index state: do the rows hold non-finite values?
+        uint32_t stats[2] = { 0, 0 };
+        CVTMI_HIP(hipMemcpyAsync(stats, h->fs_stats.p, sizeof stats, hipMemcpyDeviceToHost, st));
+        CVTMI_HIP(hipStreamSynchronize(st));
+        h->fs_nonfinite = stats[1] != 0;
+        h->fs_stats_n = n;
+    }
+    if (h->fs_nonfinite) return CVTMI_OK;
+    const int qmax = flat_f32_stream_qmax(D);
+    const int64_t passes = (nq + qmax - 1) / qmax, per = (nq + passes - 1) / passes;
+    if (h->fs_scratch.reserve(flat_f32_stream_scratch(n, per)) != CVTMI_OK) return CVTMI_OK;   // no room: the exact path answers
+    CVTMI_TRY(h->fs_redo.reserve((size_t)nq * 2 * sizeof(uint32_t)));   // redo flags, then list counters
+    for (int64_t a = 0; a < nq; a += per) {
+        const int64_t m = std::min(per, nq - a);
+        CVTMI_TRY(launch_flat_f32_stream(h->metric, D, h->data.as<float>(), h->fs_bias.as<float>(), h->fs_stats.as<uint32_t>(), n, q + a * D, m, k,
+                                         h->fs_scratch.p, dist + a * k, rows + a * k, h->fs_redo.as<uint32_t>() + a,
+                                         h->fs_redo.as<uint32_t>() + nq + a, st));
+    }
+    // queries the bound does not cover / whose lists ran over: the exact kernels, predicated on the flags (they exit at once otherwise)
+    CVTMI_TRY(flat_search_rows(h, n, q, nq, k, dist, rows, st, INT64_MAX, h->fs_redo.as<uint32_t>()));
+    *done = true;
     return CVTMI_OK;
 }
 
@@ -1063,7 +1118,14 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
     hipStream_t st = (hipStream_t)stream;
     bool done = false;
     h->f_last_worst = 0;
-    if (g_flat_variant != 1 && ((uintptr_t)q & 15) == 0 && nq <= 65535 &&
+    int how = 0;
+    // fp32: one stream over the rows (flat_f32_stream.hip).  flat_variant 2 asks for the older sample + filter pipeline, 1 for the exact kernels
+    if (((g_flat_variant == 0 && g_flat_f32_stream == 1 && nq <= 256) || (g_flat_variant != 1 && g_flat_f32_stream == 2)) &&
+        ((uintptr_t)q & 15) == 0 && flat_f32_stream_applies(h->metric, h->D, h->n, k)) {
+        CVTMI_TRY(flat_search_streamed(h, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
+        if (done) how = 2;
+    }
+    if (!done && g_flat_variant != 1 && ((uintptr_t)q & 15) == 0 && nq <= 65535 &&
         flat_filter_applies(h->metric, h->D, g_flat_variant == 2 ? std::max<int64_t>(h->n, 131072) : h->n, g_flat_variant == 2 ? std::max<int64_t>(nq, 16) : nq, k) &&
         h->n >= 2 * 65536)
         CVTMI_TRY(flat_search_filtered(h, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
@@ -1076,7 +1138,7 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
     if ((g_flat_variant == 2 || u8_auto) && h->metric == CVTMI_METRIC_L2U8 && ((uintptr_t)q & 15) == 0 && nq <= 65535 * 256 && h->norms.p &&
         flat_u8_filter_applies(h->D, std::max<int64_t>(h->n, 262144), std::max<int64_t>(nq, 256), k) && h->n >= 2 * 65536)
         CVTMI_TRY(flat_search_filtered_u8(h, reinterpret_cast<const uint8_t *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
-    h->f_last_filtered = done ? 1 : 0;
+    h->f_last_filtered = done ? (how ? how : 1) : 0;
     if (!done) CVTMI_TRY(flat_search_rows(h, h->n, q, nq, k, reinterpret_cast<float *>(dist), labels, st));
     if (!h->identity) CVTMI_TRY(launch_gather_labels(labels, nq * k, h->labels.as<int64_t>(), st));
     return CVTMI_OK;

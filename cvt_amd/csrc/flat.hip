@@ -36,7 +36,21 @@ struct FlatArgs {
     int64_t rows_per_split;
     float *part_d;
     int64_t *part_id;
+    const uint32_t *only_if;   // [nq] or null: a workgroup none of whose queries is flagged exits at once
 };
+
+template <int QT>
+__device__ __forceinline__ bool flat_skip(const FlatArgs &a, int group)
+{
+    if (!a.only_if) return false;
+    uint32_t any = 0;
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        const int qi = group * QT + q;
+        if (qi < a.nq) any |= a.only_if[qi];
+    }
+    return any == 0;
+}
 
 template <bool IP, int LANES, int QT>
 __global__ __launch_bounds__(kBlock) void flat_f32_kernel(const FlatArgs a)
@@ -44,6 +58,7 @@ __global__ __launch_bounds__(kBlock) void flat_f32_kernel(const FlatArgs a)
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [QT][D]
     __shared__ TopKShared<QT, FLAT_CAP> tk;
     const int split = blockIdx.x % a.splits, group = blockIdx.x / a.splits;
+    if (flat_skip<QT>(a, group)) return;
     const int tid = threadIdx.x;
     const float *Q = reinterpret_cast<const float *>(a.q);
     for (int i = tid; i < QT * a.D; i += kBlock) {
@@ -110,6 +125,7 @@ __global__ __launch_bounds__(kBlock) void flat_f32_sq_kernel(const FlatArgs a)
 {
     __shared__ TopKShared<QT, FLAT_CAP> tk;
     const int split = blockIdx.x % a.splits, group = blockIdx.x / a.splits;
+    if (flat_skip<QT>(a, group)) return;
     const int tid = threadIdx.x;
     // constant address space + uniform address = s_load_dword*: the values land in SGPRs
     typedef const __attribute__((address_space(4))) float cfloat;
@@ -1214,7 +1230,7 @@ static int launch_f32(const FlatArgs &a, int qtile, unsigned blocks, size_t lds,
 }
 
 int launch_flat_search(int metric, int D, const void *data, int64_t n, const void *q, int64_t nq, int k, int qtile,
-                       int splits, float *part_d, int64_t *part_id, hipStream_t st)
+                       int splits, float *part_d, int64_t *part_id, hipStream_t st, const uint32_t *only_if)
 {
     if (nq <= 0) return CVTMI_OK;
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "flat_search: k=%d outside 1..128", k);
@@ -1229,6 +1245,8 @@ int launch_flat_search(int metric, int D, const void *data, int64_t n, const voi
     if (rps < tile_rows) rps = tile_rows;
     a.rows_per_split = rps;
     a.part_d = part_d; a.part_id = part_id;
+    a.only_if = only_if;
+    if (only_if && metric == CVTMI_METRIC_L2U8) return fail(CVTMI_EINVAL, "flat_search: predicate on the uint8 metric");
     const int64_t groups = (nq + qtile - 1) / qtile;
     const int64_t blocks = groups * splits;
     if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "flat_search: grid too large");

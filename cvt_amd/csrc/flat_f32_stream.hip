@@ -1,0 +1,755 @@
+// flat_f32_stream.hip -- exhaustive fp32 search (BruteforceSearch<float>::searchKnn, brutoforce.hpp:73-93, with
+// InnerProductSpace, space_ip.hpp:211-239, or L2Space, space_l2.h:153-184) as ONE stream over the fp32 rows.
+//
+// The answer -- the k smallest (distance, row) per query, distances in the reference's own summation order -- has to come out
+// bit for bit, so every distance that is reported is evaluated by the exact code (dist_f32.h order) in the finishing kernel.
+// The stream only decides WHICH rows need one:
+//   * flat_f32_mstream_kernel: every wave streams 32-row tiles of the blocked fp32 layout (flat.hip) into a wave-private LDS
+//     ring by LDS-DMA (no barrier anywhere: ring, waits and matrix chain belong to one wave), splits the fp32 values into two
+//     bf16 terms on the fly (no operand copy of the rows in HBM), and scores T = q.x + b_x (b_x = -|x|^2/2 for L2, 0 for the
+//     inner product; rides in as the accumulator's start value) for 32 QB queries held in registers on
+//     v_mfma_f32_32x32x16_bf16 (x1.q1 + x2.q1 + x1.q2).  A lane ends up with the scores of ITS row against 16 QB queries, so
+//     the running best and second best of a lane's rows over a GROUP of up to 32 consecutive tiles cost three VALU
+//     instructions per score and no cross-lane traffic: key = T with its low five bits replaced by the tile's position
+//     in the group, second = med3(best, second, key), best = max(best, key).  Per group, lane and query one (best, second)
+//     pair goes to HBM: 8 bytes per 32 rows and query.
+//   * flat_f32_stream_finish_kernel (one workgroup per query): theta = the k-th largest best (k distinct groups = k distinct
+//     rows); a row whose score is below theta - margin is beaten, in the reference's own arithmetic, by k rows (bound below),
+//     so the candidates are the best rows of the groups with best >= theta - margin, plus ALL rows of a group whose second best
+//     also reaches the cut (two answers in one group: rare).  The k-and-a-few candidates get exact distances and are sorted by
+//     (distance, row).
+// A query the bound does not cover (non-finite values, magnitudes outside 2^-60 .. 2^60) or whose lists run over (masses of
+// near ties) is flagged in redo[]; the caller then launches the exact kernels of flat.hip with that array as a predicate --
+// they exit at once for every query that is not flagged.  No host synchronisation anywhere on the path.
+//
+// Bound (u = 2^-24, Q = |q|^2 + max |x|^2, |T| <= Q; same accounting as flat_mfma.hip): accumulation of 3 D + 1 terms taken as
+// 2u per term <= 388 uQ (D <= 128; 772 uQ at D = 256), bf16 splits 64 uQ, the omitted x2.q2 term 32 uQ, b_x in fp32 8 uQ, the
+// position bits 2^-18 |T| = 64 uQ: <= 556 uQ (940 uQ at D = 256) on a key; the reference's own sum ~200 uQ (400 uQ) in T units.
+// Two rows are ordered the same way by their keys and by the reference whenever the keys differ by more than
+// 2 x (556 + 200) uQ = 1512 uQ (D <= 128) / 2 x (940 + 400) = 2680 uQ (D = 256); margin = 2^-13 Q = 2048 uQ, 2^-12 Q for D > 128.
+#include <algorithm>
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace cvtmi {
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr float FS_PAD_BIAS = -3.0e38f;  // rows past n inside the last 64-row block: their keys never win
+constexpr float FS_EMPTY = -1.0e37f;     // best <= this: the lane saw no valid row in that group
+constexpr int FS_BLOCKS = 256;           // one 4-wave workgroup per CU, one wave per SIMD
+constexpr int FS_WAVES = FS_BLOCKS * 4;
+constexpr int FS_POS_BITS = 5;           // tiles per group <= 32
+
+#ifdef CVTMI_FS_TIMING
+// phase clocks (100 MHz wall clock) of workgroup 0 of the collect ([0..7]) and finish ([8..15]) kernels: tools/fs_timing.py
+__device__ unsigned long long g_fs_dbg[16];
+#define FS_T0() unsigned long long fs_last__ = wall_clock64()
+#define FS_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now__ = wall_clock64(); g_fs_dbg[i] += now__ - fs_last__; fs_last__ = now__; } } while (0)
+#else
+#define FS_T0() do { } while (0)
+#define FS_T(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ void fs_glds16(const void *gsrc, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void fs_glds4(const void *gsrc, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// v = hi + lo + O(2^-17 |v|), both bf16 (round to nearest even)
+__device__ __forceinline__ void fs_split(const float (&v)[8], bf16x8 &hi, bf16x8 &lo)
+{
+    union { bf16x8 v; uint32_t u[4]; } h, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const f32x2 x = { v[2 * p], v[2 * p + 1] };
+        const bf16x2 hp = __builtin_convertvector(x, bf16x2);
+        const uint32_t hu = __builtin_bit_cast(uint32_t, hp);
+        const f32x2 r = { v[2 * p] - __uint_as_float(hu << 16), v[2 * p + 1] - __uint_as_float(hu & 0xffff0000u) };
+        const bf16x2 lp = __builtin_convertvector(r, bf16x2);
+        h.u[p] = hu;
+        l.u[p] = __builtin_bit_cast(uint32_t, lp);
+    }
+    hi = h.v;
+    lo = l.v;
+}
+
+// max-fold of V values per lane across the 32 lanes of a half wave (lanes differ in sub = lane & 31): every step halves the
+// values a lane keeps, so after the steps lane sub holds R = V >> T of them, maxima over all 32 lanes: value pfx * R + i with
+// pfx = sub >> (5 - T), T = min(5, log2 V); when V < 32 the last 5 - T steps are plain butterflies
+template <int O, int CNT, int V>
+__device__ __forceinline__ void fs_fold_max(float (&s_)[V], int sub)
+{
+    if constexpr (O >= 1) {
+        if constexpr (CNT > 1) {
+            const bool hi = (sub & O) != 0;
+#pragma unroll
+            for (int i = 0; i < CNT / 2; ++i) {
+                const float keep = hi ? s_[i + CNT / 2] : s_[i];
+                const float send = hi ? s_[i] : s_[i + CNT / 2];
+                s_[i] = fmaxf(keep, __shfl_xor(send, O, 64));
+            }
+            fs_fold_max<O / 2, CNT / 2, V>(s_, sub);
+        } else {
+            s_[0] = fmaxf(s_[0], __shfl_xor(s_[0], O, 64));
+            fs_fold_max<O / 2, 1, V>(s_, sub);
+        }
+    }
+}
+constexpr int fs_log2(int v) { return v <= 1 ? 0 : 1 + fs_log2(v / 2); }
+
+// ring geometry: a UNIT is UK K steps (16 dimensions each) of one tile = 2 UK pieces of 1 KB
+template <int NCH> struct FsGeom {
+    static constexpr int UK = NCH % 4 == 0 ? 4 : (NCH % 2 == 0 ? 2 : 1);
+    static constexpr int NU = NCH / UK;                        // units per tile
+    static constexpr int UNIT = UK * 2048;                     // bytes
+    static constexpr int RU = 32768 / UNIT;                    // ring units per wave (32 KB)
+    static constexpr int RB = RU / NU + 3;                     // bias slots (256 B each): tiles that can be in flight + 1
+    static constexpr int WAVE_LDS = RU * UNIT + RB * 256;
+    static constexpr int OPS = 2 * UK + 1;                     // DMA requests per unit
+};
+
+// X: blocked fp32 rows (float4 c of the 64 rows of block b contiguous: ((b * D/4 + c) * 64 + r) float4); bias[n_tiles * 32];
+// gb[((q * NG + g) * FS_WAVES + wave) * 32 + j] = (best, second) of rows (wave + (g G + p) FS_WAVES) * 32 + j, p < G;
+// wm[q * FS_WAVES + wave] = the largest best of the wave (the finish derives its first threshold from these 1024 values)
+template <int NCH, int QB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flat_f32_mstream_kernel(
+    const float *__restrict__ X, const float *__restrict__ bias, int64_t n_tiles, const float *__restrict__ Q, int nq, int G, int NG,
+    float2 *__restrict__ gb, float *__restrict__ wm, uint32_t *__restrict__ zero_a, uint32_t *__restrict__ zero_b)
+{
+    using Ge = FsGeom<NCH>;
+    constexpr int D = 16 * NCH, UK = Ge::UK, NU = Ge::NU, UNIT = Ge::UNIT, RU = Ge::RU, RB = Ge::RB, OPS = Ge::OPS;
+    constexpr int NACC = QB == 1 ? 2 : QB;                     // QB == 1: two chains so that back-to-back products are independent
+    extern __shared__ __attribute__((aligned(16))) uint8_t fs_ring[];   // [4 waves][RU units | RB bias slots]
+    const int tid = threadIdx.x, lane = tid & 63, lj = lane & 31, lk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (blockIdx.x == 0 && tid < nq) zero_a[tid] = zero_b[tid] = 0u;   // redo flags / list counters of this pass (read by later launches)
+    // queries: lane (i, half) holds dimensions 16 s + 8 half .. + 8 of query 32 b + i, as two bf16 terms
+    bf16x8 qh[QB][NCH], ql[QB][NCH];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const int qi = b * 32 + lj;
+        const float *qp = Q + (int64_t)(qi < nq ? qi : nq - 1) * D + 8 * lk;
+#pragma unroll
+        for (int s = 0; s < NCH; ++s) {
+            float v[8];
+            *reinterpret_cast<float4 *>(&v[0]) = *reinterpret_cast<const float4 *>(qp + 16 * s);
+            *reinterpret_cast<float4 *>(&v[4]) = *reinterpret_cast<const float4 *>(qp + 16 * s + 4);
+            fs_split(v, qh[b][s], ql[b][s]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // from here on the wave's outstanding loads are the DMA requests only
+    const int64_t wave_g = (int64_t)blockIdx.x * 4 + wave;
+    const int my_tiles = wave_g < n_tiles ? (int)((n_tiles - wave_g + FS_WAVES - 1) / FS_WAVES) : 0;
+    const int my_units = my_tiles * NU;
+    const uint32_t ring_b = (uint32_t)(uintptr_t)fs_ring + (uint32_t)(wave * Ge::WAVE_LDS);
+    const uint32_t bias_b = ring_b + (uint32_t)(RU * UNIT);
+    // piece (s, h) of tile t: lanes 0-31 fetch float4 c = 4 s + h of rows 0-31 of the tile, lanes 32-63 float4 c = 4 s + 2 + h:
+    // lane (j, half) then finds dimensions 16 s + 8 half .. + 8 of row j at its own slot of pieces (s, 0) and (s, 1)
+    auto request = [&](int u) {
+        const int uc = u < my_units ? u : my_units - 1;
+        const int i = uc / NU;
+        const int part = uc - i * NU;
+        const int64_t t = wave_g + (int64_t)i * FS_WAVES;
+        const float *tile = X + ((t >> 1) * (int64_t)(D / 4) * 64 + (t & 1) * 32 + lj) * 4;   // row j of the tile, float4 0
+        const uint32_t dst = ring_b + (uint32_t)((uc % RU) * UNIT);
+#pragma unroll
+        for (int s = 0; s < UK; ++s)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                fs_glds16(tile + (int64_t)(4 * (part * UK + s) + 2 * lk + h) * 256, dst + (uint32_t)((2 * s + h) * 1024));
+        fs_glds4(bias + t * 32 + lj, bias_b + (uint32_t)((i % RB) * 256));
+    };
+    if (my_tiles > 0) {
+#pragma unroll
+        for (int u = 0; u < RU - 1; ++u) request(u);
+    }
+    // wave maxima: the fold leaves lane sub with R of the V values (see fs_fold_max)
+    constexpr int QBP = QB == 3 ? 4 : QB, V = 16 * QBP, T = fs_log2(V) < 5 ? fs_log2(V) : 5, R = V >> T;
+    float wmax[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wmax[r] = FS_PAD_BIAS;
+    float best[QB][16], second[QB][16];
+#pragma unroll
+    for (int b = 0; b < QB; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) best[b][e] = second[b][e] = FS_PAD_BIAS;
+    f32x16 acc[NACC];
+    const int gmask = G - 1, glog = 31 - __builtin_clz(G);
+    for (int i = 0; i < my_tiles; ++i) {
+#pragma unroll
+        for (int part = 0; part < NU; ++part) {
+            const int u = i * NU + part;
+            request(u + RU - 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RU - 1) * OPS) : "memory");   // unit u has landed (requests retire in order)
+            const uint8_t *ub = fs_ring + (size_t)wave * Ge::WAVE_LDS + (size_t)(u % RU) * UNIT + lane * 16;
+            if (part == 0) {
+                const float bx = reinterpret_cast<const float *>(fs_ring + (size_t)wave * Ge::WAVE_LDS + RU * UNIT + (size_t)(i % RB) * 256)[lj];
+#pragma unroll
+                for (int a = 0; a < NACC; ++a)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[a][e] = (QB == 1 && a == 1) ? 0.0f : bx;
+            }
+#pragma unroll
+            for (int s = 0; s < UK; ++s) {
+                float v[8];
+                *reinterpret_cast<float4 *>(&v[0]) = *reinterpret_cast<const float4 *>(ub + (2 * s) * 1024);
+                *reinterpret_cast<float4 *>(&v[4]) = *reinterpret_cast<const float4 *>(ub + (2 * s + 1) * 1024);
+                bf16x8 xh, xl;
+                fs_split(v, xh, xl);
+                const int ks = part * UK + s;
+                if constexpr (QB == 1) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[0][ks], xh, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[0][ks], xl, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql[0][ks], xh, acc[0], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[b][ks], xh, acc[b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[b][ks], xl, acc[b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql[b][ks], xh, acc[b], 0, 0, 0);
+                }
+            }
+        }
+        const uint32_t pos = (uint32_t)(i & gmask);
+#pragma unroll
+        for (int b = 0; b < QB; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float t = QB == 1 ? acc[0][e] + acc[1][e] : acc[b][e];
+                const float key = __uint_as_float((__float_as_uint(t) & ~((1u << FS_POS_BITS) - 1)) | pos);
+                second[b][e] = __builtin_amdgcn_fmed3f(best[b][e], second[b][e], key);
+                best[b][e] = fmaxf(best[b][e], key);
+            }
+        if (pos == (uint32_t)gmask || i == my_tiles - 1) {
+            const int g = i >> glog;
+#pragma unroll
+            for (int b = 0; b < QB; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int qi = 32 * b + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                    if (qi < nq) gb[(((int64_t)qi * NG + g) * FS_WAVES + wave_g) * 32 + lj] = make_float2(best[b][e], second[b][e]);
+                }
+            float fold[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) fold[v] = (v >> 4) < QB ? best[(v >> 4) < QB ? (v >> 4) : 0][v & 15] : FS_PAD_BIAS;
+            fs_fold_max<16, V, V>(fold, lj);
+#pragma unroll
+            for (int r = 0; r < R; ++r) wmax[r] = fmaxf(wmax[r], fold[r]);
+#pragma unroll
+            for (int b = 0; b < QB; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) best[b][e] = second[b][e] = FS_PAD_BIAS;
+        }
+    }
+    if ((lj & ((1 << (5 - T)) - 1)) == 0) {
+        const int pfx = lj >> (5 - T);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int v = pfx * R + r, qi = 32 * (v >> 4) + (v & 3) + 8 * ((v & 15) >> 2) + 4 * lk;
+            if (qi < nq) wm[(int64_t)qi * FS_WAVES + wave_g] = wmax[r];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// bias[r] for rows [row0, row1) of the blocked layout (+ the padding rows up to the end of the last 64-row block, whose
+// values are zeroed): -|x|^2 / 2 (L2) or 0 (inner product); stats[0] = max |x|^2 (bits), stats[1] = rows with a non-finite value
+__global__ __launch_bounds__(kBlock) void flat_f32_bias_kernel(float *__restrict__ X, int D, int l2, int64_t row0, int64_t row1,
+                                                               int64_t row_pad, float *__restrict__ bias, uint32_t *__restrict__ stats)
+{
+    const int64_t row = row0 + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= row_pad) return;
+    float4 *xr = reinterpret_cast<float4 *>(X) + (row >> 6) * (int64_t)(D >> 2) * 64 + (row & 63);
+    if (row >= row1) {
+        for (int c = 0; c < D / 4; ++c) xr[(int64_t)c * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        bias[row] = FS_PAD_BIAS;
+        return;
+    }
+    float s = 0.0f;
+    bool finite = true;
+    for (int c = 0; c < D / 4; ++c) {
+        const float4 v = xr[(int64_t)c * 64];
+        const float w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            finite = finite && fabsf(w[e]) <= 3.0e38f;
+            s = __fmaf_rn(w[e], w[e], s);
+        }
+    }
+    bias[row] = l2 ? -0.5f * s : 0.0f;
+    if (!finite || !(s <= 3.0e38f)) atomicAdd(&stats[1], 1u);
+    else atomicMax(&stats[0], __float_as_uint(s));
+}
+
+constexpr int FSF_LIST = 2048;   // groups that may reach the first cut
+constexpr int FSF_KEEP = 1024;   // rows that get an exact distance
+
+struct FsFinishArgs {
+    const float *X; int64_t n; int D;
+    const float *Q; int64_t nq; int k;
+    const float2 *gb; const float *wm; int G, NG, S;
+    const uint32_t *stats;       // [0] max |x|^2
+    uint32_t *cnt;               // [nq] listed groups (zeroed by the caller)
+    float *qb;                   // [nq] Q = (|q|^2 + max |x|^2) * 1.001 of the query (collect -> finish)
+    uint4 *list;                 // [nq][FSF_LIST] (best bits, second bits, entry, -)
+    float *out_d; int64_t *out_i;
+    uint32_t *redo;              // [nq]: 1 = the exact kernels must answer this query
+};
+
+__device__ __forceinline__ float fs_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t fs_wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64); v = v > w ? v : w; }
+    return v;
+}
+__device__ __forceinline__ uint32_t fs_wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64); v = v < w ? v : w; }
+    return v;
+}
+// |q|^2 by one wave (any order: it only scales the margin)
+__device__ __forceinline__ float fs_qnorm(const float *q, int D)
+{
+    float s = 0.0f;
+    for (int e = threadIdx.x & 63; e < D; e += 64) s = __fmaf_rn(q[e], q[e], s);
+    return fs_wave_sum(s);
+}
+template <bool IP>
+__device__ __forceinline__ float fs_margin(float Qb, int D, float theta)
+{
+    float m = Qb * (D > 128 ? 0x1p-12f : 0x1p-13f);
+    if (IP) m += (2.0f + fabsf(theta)) * 0x1p-20f;   // the rounding of 1 - sum in the reference
+    return m;
+}
+
+// exact distance of blocked row `row` to the query qv (LDS) in the reference's summation order (dist_f32.h): the row's D / 4
+// pieces (16 bytes each, 1 KB apart in the blocked layout) are requested 32 at a time
+template <bool IP, int LANES>
+__device__ __forceinline__ float fs_exact(const float *X, int D, int64_t row, const float4 *qv)
+{
+    float acc[LANES];
+#pragma unroll
+    for (int l = 0; l < LANES; ++l) acc[l] = 0.0f;
+    const float4 *xr = reinterpret_cast<const float4 *>(X) + (row >> 6) * (int64_t)(D >> 2) * 64 + (row & 63);
+    for (int c0 = 0; c0 < D / 4; c0 += 32) {
+        float4 xv[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) xv[c] = xr[(int64_t)(c0 + c < D / 4 ? c0 + c : 0) * 64];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            if (c0 + c < D / 4) {
+                const float4 qw = qv[c0 + c];
+                const float xs[4] = { xv[c].x, xv[c].y, xv[c].z, xv[c].w }, qs[4] = { qw.x, qw.y, qw.z, qw.w };
+                const int l0 = 4 * (c % (LANES / 4));   // (c0 is a multiple of 32)
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    if constexpr (IP) {
+                        acc[l0 + l] = __fadd_rn(acc[l0 + l], __fmul_rn(qs[l], xs[l]));
+                    } else {
+                        const float t = __fsub_rn(qs[l], xs[l]);
+                        acc[l0 + l] = __fadd_rn(acc[l0 + l], __fmul_rn(t, t));
+                    }
+                }
+            }
+        }
+    }
+    float sum = acc[0];
+#pragma unroll
+    for (int l = 1; l < LANES; ++l) sum = __fadd_rn(sum, acc[l]);
+    return IP ? __fsub_rn(1.0f, sum) : sum;
+}
+
+// The k-th largest of a wave's keys (order-preserving uint32 keys, NK per lane; absent ones = 0), by ONE wave and without a
+// barrier: MSB-first, a bit of the answer per round (keep the bit if at least k keys reach the trial value), starting below the
+// common prefix of the largest and the smallest key.  Stops early at a trial value that between k and kmax keys reach -- any such
+// value serves as a first threshold.  Returns the largest c found with count(keys >= c) >= k (0 if fewer than k keys are non-zero).
+template <int NK>
+__device__ __forceinline__ uint32_t fs_wave_select(const uint32_t (&key)[NK], int k, int kmax)
+{
+    uint32_t hi = 0, lo = 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        hi = key[j] > hi ? key[j] : hi;
+        lo = (key[j] < lo && key[j] != 0u) ? key[j] : lo;
+    }
+    hi = fs_wave_max_u32(hi);
+    lo = fs_wave_min_u32(lo);
+    if (hi <= lo) return hi;   // all present keys equal (or none present: 0)
+    const int top = 31 - __builtin_clz(hi ^ lo);             // highest bit in which two keys differ
+    uint32_t c = top == 31 ? 0u : (hi >> (top + 1)) << (top + 1);   // the common prefix (every key reaches it)
+    for (int bit = top; bit >= 0; --bit) {
+        const uint32_t trial = c | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) cnt += __popcll(__ballot(key[j] >= trial));
+        if (cnt >= k) {
+            c = trial;
+            if (cnt <= kmax) break;
+        }
+    }
+    return c;
+}
+
+// workgroup (q, s): theta1 = (about) the k-th largest of the query's 1024 wave maxima -- at least k distinct waves = k distinct
+// rows reach it, so it bounds theta from below; every group of slice s whose best reaches theta1 - margin joins the query's list.
+// Every wave derives theta1 for itself (registers only, no barrier).
+template <bool IP, int LANES>
+__global__ __launch_bounds__(kBlock) void flat_f32_stream_collect_kernel(const FsFinishArgs a)
+{
+    constexpr int U = 8;                    // entries per thread: one batch of loads in flight
+    __shared__ uint4 hit_s[kBlock * U];     // this workgroup's hits (all of its entries may qualify when rows tie in masses)
+    __shared__ __attribute__((aligned(16))) float q_s[256];
+    __shared__ float cut_s;
+    __shared__ int nh_s;
+    __shared__ uint32_t base_s;
+    const int64_t qi = blockIdx.x / a.S;
+    const int sl = blockIdx.x % a.S, tid = threadIdx.x, lane = tid & 63;
+    FS_T0();
+    const int64_t E = (int64_t)a.NG * FS_WAVES * 32;
+    const int64_t e0 = E * sl / a.S, e1 = E * (sl + 1) / a.S;
+    const float2 *gb = a.gb + qi * E;
+    // the slice's first batch is requested before the threshold is known
+    float2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t e = e0 + tid + (int64_t)u * kBlock;
+        v[u] = e < e1 ? gb[e] : make_float2(FS_PAD_BIAS, FS_PAD_BIAS);
+    }
+    if (tid < a.D) q_s[tid] = a.Q[qi * a.D + tid];   // D <= 256
+    if (tid < 64) {   // wave 0: theta1 (registers only)
+        uint32_t key[FS_WAVES / 64];
+#pragma unroll
+        for (int j = 0; j < FS_WAVES / 64; ++j) key[j] = f32_key(a.wm[qi * FS_WAVES + j * 64 + lane]);
+        const float qq = fs_qnorm(a.Q + qi * a.D, a.D);
+        const float Qb = (qq + __uint_as_float(a.stats[0])) * 1.001f;
+        float cut1 = __uint_as_float(0x7fc00000u);   // NaN: give up
+        FS_T(0);
+        if (Qb > 0x1p-60f && Qb < 0x1p60f) {   // (false for a non-finite query as well)
+            const float theta1 = key_f32(fs_wave_select(key, a.k, a.k + a.k / 4 + 8));
+            if (theta1 > FS_EMPTY) {           // else: fewer than k waves saw a row, not this kernel's case
+                cut1 = theta1 - fs_margin<IP>(Qb, a.D, theta1);
+                if (sl == 0 && lane == 0) a.qb[qi] = Qb;
+            }
+        }
+        if (lane == 0) {
+            cut_s = cut1;
+            nh_s = 0;
+            if (!(cut1 == cut1) && sl == 0) a.redo[qi] = 1u;
+        }
+        FS_T(1);
+    }
+    __syncthreads();
+    const float cut1 = cut_s;
+    if (!(cut1 == cut1)) return;
+    uint4 *list = a.list + qi * FSF_LIST;
+    for (int64_t base = e0 + tid; base < e1; base += (int64_t)kBlock * U) {
+        if (base != e0 + tid) {
+            __syncthreads();   // (hit_s is free again)
+            if (tid == 0) nh_s = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t e = base + (int64_t)u * kBlock;
+                v[u] = e < e1 ? gb[e] : make_float2(FS_PAD_BIAS, FS_PAD_BIAS);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (v[u].x >= cut1)
+                hit_s[atomicAdd(&nh_s, 1)] = make_uint4(__float_as_uint(v[u].x), __float_as_uint(v[u].y), (uint32_t)(base + (int64_t)u * kBlock), 0u);
+        __syncthreads();
+        const int nh = nh_s;
+        if (tid == 0 && nh > 0) base_s = atomicAdd(&a.cnt[qi], (uint32_t)nh);   // one global atomic per workgroup and batch
+        __syncthreads();
+        // the exact distance of every hit's best row rides along (the hits are spread over many workgroups here: their rows'
+        // pieces are fetched side by side; the finish only computes for the rare group whose second best qualifies too)
+        for (int i = tid; i < nh; i += kBlock) {
+            if (base_s + i >= (uint32_t)FSF_LIST) break;
+            uint4 h = hit_s[i];
+            const uint32_t e = h.z;
+            const int64_t j = e & 31, wv = (e >> 5) & (FS_WAVES - 1), g = e >> 15, pp = h.x & ((1u << FS_POS_BITS) - 1);
+            const int64_t row = (wv + (g * a.G + pp) * FS_WAVES) * 32 + j;
+            h.w = row < a.n ? __float_as_uint(fs_exact<IP, LANES>(a.X, a.D, row, reinterpret_cast<const float4 *>(q_s))) : 0x7fc00000u;
+            list[base_s + i] = h;
+        }
+    }
+    FS_T(2);
+}
+
+// one workgroup per query: theta = the k-th largest listed best, cut = theta - margin, candidate rows, exact distances, the k
+// smallest (distance, row) in order
+template <bool IP, int LANES>
+__global__ __launch_bounds__(kBlock) void flat_f32_stream_finish_kernel(const FsFinishArgs a)
+{
+    __shared__ unsigned long long sort_s[FSF_KEEP];   // (distance key) << 32 | row of a candidate
+    __shared__ uint32_t row_s[FSF_KEEP];
+    // the listed groups (best key, entry, second best, exact distance of the best row); later the query
+    __shared__ __attribute__((aligned(16))) float work_s[4 * FSF_LIST];
+    __shared__ int cnt_s;
+    __shared__ uint32_t theta_s;
+    uint32_t *best_s = reinterpret_cast<uint32_t *>(work_s), *ent_s = best_s + FSF_LIST;
+    float *sec_s = work_s + 2 * FSF_LIST, *dist_s = work_s + 3 * FSF_LIST;
+    const int64_t qi = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int D = a.D, k = a.k, G = a.G;
+    const float *q = a.Q + qi * D;
+    FS_T0();
+    if (a.redo[qi]) return;   // (set by the collect kernel: workgroup-uniform)
+    auto give_up = [&]() {
+        if (tid == 0) a.redo[qi] = 1u;
+    };
+    const int nl = (int)a.cnt[qi];
+    if (nl > FSF_LIST || nl < k) {   // the list ran over (nl >= k holds whenever theta1 was valid)
+        give_up();
+        return;
+    }
+    const float Qb = a.qb[qi];
+    if (tid == 0) cnt_s = 0;
+    const uint4 *list = a.list + qi * FSF_LIST;
+    for (int i = tid; i < nl; i += kBlock) {
+        const uint4 v = list[i];
+        best_s[i] = f32_key(__uint_as_float(v.x));
+        sec_s[i] = __uint_as_float(v.y);
+        ent_s[i] = v.z;
+        dist_s[i] = __uint_as_float(v.w);
+    }
+    for (int i = tid; i < k; i += kBlock) {   // fewer candidates than k (cannot happen for n >= k): the tail stays empty
+        a.out_d[qi * k + i] = __uint_as_float(0x7f800000u);
+        a.out_i[qi * k + i] = -1;
+    }
+    __syncthreads();
+    FS_T(8);
+    if (tid < 64) {   // theta: exact k-th largest, by one wave
+        auto sel = [&](auto nk_tag) {
+            constexpr int NK = decltype(nk_tag)::value;
+            uint32_t key[NK];
+#pragma unroll
+            for (int j = 0; j < NK; ++j) key[j] = (j * 64 + lane < nl) ? best_s[j * 64 + lane] : 0u;
+            const uint32_t c = fs_wave_select(key, k, k);
+            if (lane == 0) theta_s = c;
+        };
+        if (nl <= 256) sel(std::integral_constant<int, 4>());
+        else if (nl <= 512) sel(std::integral_constant<int, 8>());
+        else sel(std::integral_constant<int, FSF_LIST / 64>());
+    }
+    __syncthreads();
+    FS_T(9);
+    const float theta = key_f32(theta_s);
+    const float cut = theta - fs_margin<IP>(Qb, D, theta);
+    // candidates: the best row of a qualifying group comes with its exact distance; a group whose second best qualifies as well
+    // has all its rows evaluated here
+    __shared__ int ndone_s;
+    if (tid == 0) ndone_s = 0;
+    __syncthreads();
+    auto dist_key = [](float d) {
+        uint32_t dk = f32_key(d);
+        return dk >= 0xfffffff0u ? 0xffffffefu : dk;   // (NaN patterns: keep the absent-row codes free)
+    };
+    for (int i = tid; i < nl; i += kBlock) {
+        const float bestv = key_f32(best_s[i]);
+        if (!(bestv >= cut)) continue;
+        const uint32_t e = ent_s[i];
+        const int64_t j = e & 31, wv = (e >> 5) & (FS_WAVES - 1), g = e >> 15;   // FS_WAVES = 1024
+        if (sec_s[i] >= cut) {
+            const int base = atomicAdd(&cnt_s, G);
+            for (int p = 0; p < G; ++p) {
+                const int64_t row = (wv + (g * G + p) * FS_WAVES) * 32 + j;
+                if (base + p < FSF_KEEP) row_s[base + p] = row < a.n ? (uint32_t)row : 0xffffffffu;
+            }
+        } else {
+            const uint32_t p = __float_as_uint(bestv) & ((1u << FS_POS_BITS) - 1);
+            const int64_t row = (wv + (g * G + p) * FS_WAVES) * 32 + j;
+            const int slot = atomicAdd(&ndone_s, 1);
+            if (slot < FSF_KEEP && row < a.n) sort_s[slot] = ((unsigned long long)dist_key(dist_s[i]) << 32) | (uint32_t)row;
+            else if (slot < FSF_KEEP) sort_s[slot] = ~0ull - (unsigned)slot;
+        }
+    }
+    __syncthreads();
+    const int nrow = cnt_s, ndone = ndone_s, nc = nrow + ndone;
+    if (nc > FSF_KEEP) {
+        give_up();
+        return;
+    }
+    FS_T(10);
+    if (nrow > 0) {   // (workgroup-uniform)
+        for (int e = tid; e < D; e += kBlock) work_s[e] = q[e];   // (the listed groups are not needed any more)
+        __syncthreads();
+        for (int i = tid; i < nrow; i += kBlock) {
+            unsigned long long ekey = ~0ull - (unsigned)(ndone + i);   // an absent row: a key above every real one, distinct per slot
+            if (row_s[i] != 0xffffffffu)
+                ekey = ((unsigned long long)dist_key(fs_exact<IP, LANES>(a.X, D, row_s[i], reinterpret_cast<const float4 *>(work_s))) << 32) | row_s[i];
+            sort_s[ndone + i] = ekey;
+        }
+        __syncthreads();
+    }
+    FS_T(11);
+    // rank of every candidate among the (distinct) keys: its place in the output
+    for (int i = tid; i < nc; i += kBlock) {
+        const unsigned long long e = sort_s[i];
+        int rank = 0;
+#pragma unroll 8
+        for (int j = 0; j < nc; ++j) rank += sort_s[j] < e ? 1 : 0;
+        if (rank < k && (uint32_t)(e >> 32) < 0xfffffff0u) {
+            a.out_d[qi * k + rank] = key_f32((uint32_t)(e >> 32));
+            a.out_i[qi * k + rank] = (int64_t)(uint32_t)e;
+        }
+    }
+    FS_T(12);
+}
+
+#ifdef CVTMI_FS_TIMING
+extern "C" int cvtmi_debug_fs_timing(unsigned long long *out, int reset)
+{
+    unsigned long long z[16] = {};
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fs_dbg), sizeof z) != hipSuccess) return -3;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_fs_dbg), z, sizeof z) != hipSuccess) return -3;
+    return 0;
+}
+#endif
+
+}  // namespace
+
+// ---- host side -----------------------------------------------------------------------------------------------------------
+// D in {32, 64, 96, 128, 192, 256}; queries per pass = 32 QB, QB the largest of 1..4 whose registers fit one wave per SIMD
+// (8 NCH operand registers + 48 of accumulators / best / second per 32 queries)
+static int fs_qb_max(int nch)
+{
+    int qb = 4;
+    while (qb > 1 && qb * (8 * nch + 48) > 368) --qb;
+    return qb;
+}
+int flat_f32_stream_qmax(int D)
+{
+    if (D != 32 && D != 64 && D != 96 && D != 128 && D != 192 && D != 256) return 0;
+    return 32 * fs_qb_max(D / 16);
+}
+bool flat_f32_stream_applies(int metric, int D, int64_t n, int k)
+{
+    return (metric == CVTMI_METRIC_IP || metric == CVTMI_METRIC_L2F) && flat_f32_stream_qmax(D) > 0 && n >= 32768 && n < 0xffffffffLL &&
+           k >= 1 && k <= 128 && (n + 31) / 32 < ((int64_t)1 << 17) * FS_WAVES * 32;   // entry index: 32 bits
+}
+// groups per wave and tiles per group for n rows
+static void fs_groups(int64_t n, int *G, int *NG)
+{
+    const int64_t n_tiles = (n + 31) / 32, per_wave = (n_tiles + FS_WAVES - 1) / FS_WAVES;
+    int g = 32;
+    while (g > 1 && g / 2 >= per_wave) g >>= 1;   // short indexes: one group, no wider than the tiles a wave sees
+    *G = g;
+    *NG = (int)((per_wave + g - 1) / g);
+}
+// scratch of one pass: group entries [nq][NG][1024][32] float2, wave maxima [nq][1024] float, lists [nq][FSF_LIST] uint4
+static size_t fs_gb_bytes(int64_t n, int64_t nq_pass)
+{
+    int G, NG;
+    fs_groups(n, &G, &NG);
+    return (size_t)nq_pass * NG * FS_WAVES * 32 * sizeof(float2);
+}
+size_t flat_f32_stream_scratch(int64_t n, int64_t nq_pass)
+{
+    return fs_gb_bytes(n, nq_pass) + (size_t)nq_pass * (FS_WAVES + 4) * sizeof(float) + (size_t)nq_pass * FSF_LIST * sizeof(uint4);
+}
+
+int launch_flat_f32_bias(float *X, int D, int metric, int64_t row0, int64_t row1, float *bias, uint32_t *stats, hipStream_t st)
+{
+    const int64_t row_pad = (row1 + 63) / 64 * 64;
+    if (row_pad <= row0) return CVTMI_OK;
+    hipLaunchKernelGGL(flat_f32_bias_kernel, dim3((unsigned)((row_pad - row0 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, X, D,
+                       metric == CVTMI_METRIC_L2F ? 1 : 0, row0, row1, row_pad, bias, stats);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+template <int NCH, int QB>
+static int fs_launch_stream(const float *X, const float *bias, int64_t n_tiles, const float *q, int nq, int G, int NG, float2 *gb,
+                            float *wm, uint32_t *redo, uint32_t *cnt, hipStream_t st)
+{
+    const size_t lds = (size_t)4 * FsGeom<NCH>::WAVE_LDS;
+    static bool attr_set[16] = {};
+    int dev = 0;
+    CVTMI_HIP(hipGetDevice(&dev));
+    if (dev < 16 && !attr_set[dev]) {
+        CVTMI_HIP(hipFuncSetAttribute((const void *)flat_f32_mstream_kernel<NCH, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev] = true;
+    } else if (dev >= 16) {
+        CVTMI_HIP(hipFuncSetAttribute((const void *)flat_f32_mstream_kernel<NCH, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL((flat_f32_mstream_kernel<NCH, QB>), dim3(FS_BLOCKS), dim3(256), lds, st, X, bias, n_tiles, q, nq, G, NG, gb, wm, redo, cnt);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+// one pass: nq <= flat_f32_stream_qmax(D) queries against rows [0, n); results for queries whose redo flag stays 0.
+// redo[nq] and cnt[nq] are zeroed inside
+int launch_flat_f32_stream(int metric, int D, const float *X, const float *bias, const uint32_t *stats, int64_t n, const float *q, int64_t nq,
+                           int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, uint32_t *cnt, hipStream_t st)
+{
+    const int qmax = flat_f32_stream_qmax(D);
+    if (qmax == 0 || nq < 1 || nq > qmax) return fail(CVTMI_EINVAL, "flat_f32_stream: D=%d nq=%lld", D, (long long)nq);
+    int G, NG;
+    fs_groups(n, &G, &NG);
+    const int64_t n_tiles = (n + 31) / 32;
+    float2 *gb = reinterpret_cast<float2 *>(scratch);
+    float *wm = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(scratch) + fs_gb_bytes(n, nq));
+    uint4 *list = reinterpret_cast<uint4 *>(wm + (size_t)nq * FS_WAVES);
+    float *qbuf = reinterpret_cast<float *>(list + (size_t)nq * FSF_LIST);
+    const int nch = D / 16, qb = (int)((nq + 31) / 32);
+#define CVTMI_FS(NCH_)                                                                                              \
+    case NCH_:                                                                                                      \
+        if constexpr (4 * (8 * (NCH_) + 48) <= 368) {                                                               \
+            if (qb == 4) { CVTMI_TRY((fs_launch_stream<NCH_, 4>(X, bias, n_tiles, q, (int)nq, G, NG, gb, wm, redo, cnt, st))); break; } \
+        }                                                                                                           \
+        if constexpr (3 * (8 * (NCH_) + 48) <= 368) {                                                               \
+            if (qb == 3) { CVTMI_TRY((fs_launch_stream<NCH_, 3>(X, bias, n_tiles, q, (int)nq, G, NG, gb, wm, redo, cnt, st))); break; } \
+        }                                                                                                           \
+        if (qb == 2) { CVTMI_TRY((fs_launch_stream<NCH_, 2>(X, bias, n_tiles, q, (int)nq, G, NG, gb, wm, redo, cnt, st))); break; }   \
+        if (qb == 1) { CVTMI_TRY((fs_launch_stream<NCH_, 1>(X, bias, n_tiles, q, (int)nq, G, NG, gb, wm, redo, cnt, st))); break; }   \
+        return fail(CVTMI_EINVAL, "flat_f32_stream: %d query blocks at D=%d", qb, D);
+    switch (nch) {
+        CVTMI_FS(2) CVTMI_FS(4) CVTMI_FS(6) CVTMI_FS(8) CVTMI_FS(12) CVTMI_FS(16)
+        default: return fail(CVTMI_EUNSUPPORTED, "flat_f32_stream: D=%d", D);
+    }
+#undef CVTMI_FS
+    FsFinishArgs fa;
+    fa.X = X; fa.n = n; fa.D = D; fa.Q = q; fa.nq = nq; fa.k = k; fa.gb = gb; fa.wm = wm; fa.G = G; fa.NG = NG; fa.stats = stats;
+    fa.cnt = cnt; fa.list = list; fa.qb = qbuf; fa.out_d = out_d; fa.out_i = out_i; fa.redo = redo;
+    // slices per query: one batch of loads per thread (2048 entries per slice) while that keeps the grid within ~2048 workgroups
+    const int64_t E = (int64_t)NG * FS_WAVES * 32;
+    int S = (int)std::min<int64_t>(std::max<int64_t>(1, 2048 / nq), std::max<int64_t>(1, E / 2048));
+    fa.S = S;
+    const unsigned cgrid = (unsigned)(nq * S);
+    if (metric == CVTMI_METRIC_IP) {
+        hipLaunchKernelGGL((flat_f32_stream_collect_kernel<true, 4>), dim3(cgrid), dim3(kBlock), 0, st, fa);
+        hipLaunchKernelGGL((flat_f32_stream_finish_kernel<true, 4>), dim3((unsigned)nq), dim3(kBlock), 0, st, fa);
+    } else {
+        hipLaunchKernelGGL((flat_f32_stream_collect_kernel<false, 8>), dim3(cgrid), dim3(kBlock), 0, st, fa);
+        hipLaunchKernelGGL((flat_f32_stream_finish_kernel<false, 8>), dim3((unsigned)nq), dim3(kBlock), 0, st, fa);
+    }
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+}  // namespace cvtmi

@@ -58,10 +58,10 @@ int launch_rotate_codes(const uint8_t *codes, uint8_t *codes_rot, int64_t row0, 
 
 // ---- topk_merge.hip ----
 int launch_topk_merge(const float *in_d, const int64_t *in_id, int64_t nq, int L, int k, float *out_d, int64_t *out_id,
-                      hipStream_t st);
+                      hipStream_t st, const uint32_t *only_if = nullptr);
 
 int launch_topk_select(const float *in_d, const int64_t *in_id, int64_t nq, int64_t n_cand, int k, float *out_d,
-                       int64_t *out_id, hipStream_t st);
+                       int64_t *out_id, hipStream_t st, const uint32_t *only_if = nullptr);
 // L per-rank lists of k per query in the all-gather layout: list r of query q at in_d[r * stride_d + q * k ..] / in_id[r * stride_id + ..]
 int launch_topk_merge_gathered(const float *in_d, const int64_t *in_id, int64_t stride_d, int64_t stride_id, int64_t nq, int L, int k,
                                float *out_d, int64_t *out_id, hipStream_t st);
@@ -88,8 +88,10 @@ int flat_plan_splits(int64_t n, int64_t nq, int qtile);
 int flat_qtile(int64_t nq);
 // part_d / part_id: [nq][splits][k]; for CVTMI_METRIC_L2U8 part_d carries the int32 distance BITS
 // (non-negative ints order like their float bit patterns, nothing does float arithmetic on them).
+// only_if != nullptr: [nq] predicate words, a workgroup whose queries are all 0 exits at once (the conditional re-run of
+// queries a filter gave up on)
 int launch_flat_search(int metric, int D, const void *data, int64_t n, const void *q, int64_t nq, int k, int qtile,
-                       int splits, float *part_d, int64_t *part_id, hipStream_t st);
+                       int splits, float *part_d, int64_t *part_id, hipStream_t st, const uint32_t *only_if = nullptr);
 // uint8 L2 on the i8 matrix cores (D % 32 == 0, D <= 512, nq >= 8); norms[n] = sum (x-128)^2 per row
 int launch_flat_u8_norms(const uint8_t *x, int64_t n, int D, int32_t *norms, hipStream_t st);
 // fp32 metrics with D % 4 == 0 keep their rows in a blocked layout (float4 c of 64 consecutive rows contiguous)
@@ -117,6 +119,16 @@ int launch_flat_u8_finish(int64_t nq, const uint32_t *pair_cnt, uint32_t pair_ca
                           const int64_t *sample_i, uint32_t *cand_cnt, float *cand_d, int32_t *cand_row, float *out_d, int64_t *out_i,
                           uint32_t *overflow, hipStream_t st);
 int launch_flat_block(const float *src, int64_t n, int D, int64_t row0, float *dst, hipStream_t st);
+// flat_f32_stream.hip: fp32 IP / L2 search as one stream over the blocked rows (bf16 matrix-core scores, group best / second best,
+// exact distances of the candidates); D % 16 == 0, 16 <= D <= 256, up to flat_f32_stream_qmax(D) queries per pass
+int flat_f32_stream_qmax(int D);
+bool flat_f32_stream_applies(int metric, int D, int64_t n, int k);
+size_t flat_f32_stream_scratch(int64_t n, int64_t nq_pass);
+// bias[r] (and zeroed padding rows) for rows [row0, row1); stats[0] = max |x|^2 bits, stats[1] = non-finite rows (both accumulate)
+int launch_flat_f32_bias(float *X, int D, int metric, int64_t row0, int64_t row1, float *bias, uint32_t *stats, hipStream_t st);
+// redo[nq], cnt[nq] (zeroed inside): redo is set to 1 for queries the exact kernels must answer
+int launch_flat_f32_stream(int metric, int D, const float *X, const float *bias, const uint32_t *stats, int64_t n, const float *q, int64_t nq,
+                           int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, uint32_t *cnt, hipStream_t st);
 int flat_u8_mfma_qtile(int D, int k, int64_t nq);  // queries per workgroup, 0 = shape not covered
 int flat_u8_mfma_splits(int64_t n, int64_t nq, int qt);
 // gthr: nq uint32 scratch (set to 0xff.. inside) through which the row splits of a query share their k-th best

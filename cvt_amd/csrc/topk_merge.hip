@@ -23,10 +23,11 @@ template <bool GATHERED>
 __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restrict__ in_d,
                                                             const int64_t *__restrict__ in_id, int n_cand, int k,
                                                             float *__restrict__ out_d, int64_t *__restrict__ out_id,
-                                                            int64_t stride_d, int64_t stride_id)
+                                                            int64_t stride_d, int64_t stride_id, const uint32_t *__restrict__ only_if)
 {
     __shared__ TopKShared<1, MERGE_CAP> tk;
     const int64_t q = blockIdx.x;
+    if (only_if && only_if[q] == 0) return;   // (workgroup-uniform)
     const int tid = threadIdx.x;
     auto at = [&](int i) -> int64_t {  // element offset of candidate i inside the distance / id arrays (before the stride term)
         if (!GATHERED) return q * n_cand + i;
@@ -75,28 +76,28 @@ int launch_topk_merge_gathered(const float *in_d, const int64_t *in_id, int64_t 
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "topk: k=%d outside 1..128", k);
     if (L < 1 || (int64_t)L * k > 0x7fffffff || nq > 0x7fffffff) return fail(CVTMI_EINVAL, "topk_merge: bad list count %d", L);
     hipLaunchKernelGGL(topk_merge_kernel<true>, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, L * k, k, out_d, out_id, stride_d,
-                       stride_id);
+                       stride_id, (const uint32_t *)nullptr);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
 
 int launch_topk_merge(const float *in_d, const int64_t *in_id, int64_t nq, int L, int k, float *out_d, int64_t *out_id,
-                      hipStream_t st)
+                      hipStream_t st, const uint32_t *only_if)
 {
     if (L < 1 || (int64_t)L * k > 0x7fffffff) return fail(CVTMI_EINVAL, "topk_merge: bad list count %d", L);
-    return launch_topk_select(in_d, in_id, nq, (int64_t)L * k, k, out_d, out_id, st);
+    return launch_topk_select(in_d, in_id, nq, (int64_t)L * k, k, out_d, out_id, st, only_if);
 }
 
 // k smallest (value, id) of n_cand candidates per query; in_id == nullptr: id = position
 int launch_topk_select(const float *in_d, const int64_t *in_id, int64_t nq, int64_t n_cand, int k, float *out_d,
-                       int64_t *out_id, hipStream_t st)
+                       int64_t *out_id, hipStream_t st, const uint32_t *only_if)
 {
     if (nq <= 0) return CVTMI_OK;
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "topk: k=%d outside 1..128", k);
     if (n_cand < 0 || n_cand > 0x7fffffff) return fail(CVTMI_EINVAL, "topk: bad candidate count");
     if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "topk: nq too large");
     hipLaunchKernelGGL(topk_merge_kernel<false>, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, (int)n_cand, k, out_d, out_id,
-                       (int64_t)0, (int64_t)0);
+                       (int64_t)0, (int64_t)0, only_if);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

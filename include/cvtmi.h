@@ -260,10 +260,13 @@ int cvtmi_flat_reset(cvtmi_flat_t h);
 int cvtmi_flat_search(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels);
 int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels,
                           void *stream);
-/* Measurement hook: was the last search answered through the matrix-core filter (fp32 metrics, 32 <= D <= 128, D % 16 == 0,
- * >= 64 queries, >= 131072 rows: exact search of a leading sample, bf16 matrix-core products decide which other rows need
- * an exact distance; same results), and the largest candidate list it produced.  cvtmi_set_tuning("flat_variant", 1)
- * turns the filter off, 2 applies it to smaller batches too. */
+/* Measurement hook: how the last search was answered -- *filtered = 0 the exact kernels; 1 the sample + matrix-core filter
+ * pipeline (fp32 metrics, 32 <= D <= 128, D % 16 == 0, >= 131072 rows: exact search of a leading sample, bf16 matrix-core
+ * products decide which other rows need an exact distance); 2 the fp32 stream (D in {32, 64, 96, 128, 192, 256}, >= 32768 rows:
+ * one pass over the rows scores them on the bf16 matrix cores, the k-and-a-few candidates get exact distances; queries its
+ * error bound does not cover are re-run by the exact kernels inside the same call) -- same results every way -- and the largest
+ * candidate list of the pipeline.  cvtmi_set_tuning("flat_variant", 1) allows the exact kernels only, 2 prefers the pipeline;
+ * cvtmi_set_tuning("flat_f32_stream", 0 / 1 / 2) = never / choose / wherever it applies. */
 int cvtmi_flat_last_search(cvtmi_flat_t h, int *filtered, int64_t *max_candidates);
 
 /* ---------------------------------------------------------------- int8 scalar quantisation -- */

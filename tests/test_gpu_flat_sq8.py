@@ -340,7 +340,7 @@ def test_flat_f32_matrix_core_filter(amd, orc, metric, D, k):
             ix = amd.FlatIndex(metric, D); ix.add(x[:130_000]); ix.add(x[130_000:])
             res[v] = ix.search(q, k)
             used, worst = ix.last_search()
-            assert used == (v == 2) and (v == 1 or 0 < worst < 24 * k + 1024), (used, worst)
+            assert used == (1 if v == 2 else 0) and (v == 1 or 0 < worst < 24 * k + 1024), (used, worst)
             if v == 2:   # append after a search: the operand copy is rebuilt
                 ix.add(x[:1000] * np.float32(0.5))
                 d2, i2 = ix.search(q, k)
@@ -545,3 +545,85 @@ def test_flat_u8_mid_batch_stream(amd, orc, D, nq, k, hi):
     od, odi, oi = orc.flat_search(L2U8, x, q[:6], k)
     assert np.array_equal(out[0][1][:6], oi) and np.array_equal(out[0][0][:6], odi)
     assert out[0][1][0, 0] == 3
+
+
+def _clustered(rng, n, D, metric):
+    cen = rng.normal(size=(300, D)).astype(np.float32)
+    x = (cen[rng.integers(0, 300, n)] + 0.5 * rng.normal(size=(n, D))).astype(np.float32)
+    if metric == IP:
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+    else:
+        x *= np.float32(11.0)
+    return x
+
+
+@pytest.mark.parametrize("metric,D,nq,k", [(IP, 128, 1, 100), (L2F, 128, 1, 100), (IP, 128, 7, 10), (L2F, 128, 33, 100), (IP, 128, 64, 100),
+                                            (L2F, 128, 96, 128), (IP, 128, 97, 1), (L2F, 64, 128, 10), (IP, 32, 100, 50), (L2F, 96, 70, 20),
+                                            (IP, 192, 40, 100), (L2F, 256, 33, 100), (IP, 256, 5, 3), (L2F, 128, 250, 100)])
+def test_flat_f32_stream(amd, orc, metric, D, nq, k):
+    """fp32 search as one stream over the rows (flat_f32_stream 2: bf16 matrix-core scores, group best / second best, exact
+    distances of the candidates) against the exact kernels (flat_variant 1) on the whole batch and against the checker on a few
+    queries: ragged row count (last 64-row block partly empty), duplicates of rows inside one group and across groups, queries that
+    are rows (zero distances, (distance, row) ties), appends between searches"""
+    rng = np.random.default_rng(D * 13 + nq * 3 + k + metric)
+    n = 70_000 + 37
+    x = _clustered(rng, n, D, metric)
+    x[60_000:60_150] = x[5]                 # 150 duplicates: more than k for small k, ties by row number
+    x[32 * 1024 + 5] = x[5]                 # same wave, same lane, next tile of the group (the second best matters)
+    x[69_999] = x[123]
+    q = (x[rng.integers(0, n, nq)] + 0.05 * rng.normal(size=(nq, D))).astype(np.float32)
+    q[0] = x[5]
+    if nq > 3:
+        q[3] = x[123]
+    q = np.ascontiguousarray(q, np.float32)
+    try:
+        amd.set_tuning("flat_f32_stream", 2)
+        ix = amd.FlatIndex(metric, D); ix.add(x[:50_001]); ix.add(x[50_001:])
+        ds, is_ = ix.search(q, k)
+        assert ix.last_search()[0] == 2
+        ix.add(x[:777] * np.float32(0.5))   # append after a search
+        ds2, is2 = ix.search(q, k)
+        assert ix.last_search()[0] == 2
+        amd.set_tuning("flat_variant", 1)
+        de2, ie2 = ix.search(q, k)
+        assert ix.last_search()[0] == 0
+        ix.close()
+        ix = amd.FlatIndex(metric, D); ix.add(x)
+        de, ie = ix.search(q, k)
+        ix.close()
+    finally:
+        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_stream", 1)
+    assert np.array_equal(is_, ie) and np.array_equal(bits(ds), bits(de))
+    assert np.array_equal(is2, ie2) and np.array_equal(bits(ds2), bits(de2))
+    m = min(nq, 6)
+    od, _, oi = orc.flat_search(metric, x, q[:m], k, flavour=4 if metric == IP else 8)
+    assert np.array_equal(is_[:m], oi) and np.array_equal(bits(ds[:m]), bits(od))
+
+
+def test_flat_f32_stream_hands_hard_queries_to_the_exact_kernels(amd):
+    """what the stream's bound does not cover is re-run by the exact kernels inside the same call, per query: non-finite queries,
+    a query 2^70 times larger than the rows, masses of exact ties around the k-th place (lists run over); a non-finite ROW sends
+    the whole index down the exact path.  Same results as flat_variant 1 everywhere, labels included"""
+    rng = np.random.default_rng(5)
+    n, D, nq, k = 66_000, 128, 40, 10
+    x = rng.normal(size=(n, D)).astype(np.float32)
+    x[2_000:7_000] = x[1]                                   # 5000 equal rows: every one ties at the k-th place of query 1
+    q = rng.normal(size=(nq, D)).astype(np.float32)
+    q[1] = x[1]
+    q[3, 0] = np.nan; q[4, 5] = np.inf; q[6] *= np.float32(2.0 ** 70)
+    labels = np.arange(n, dtype=np.int64) * 3 + 5
+    xn = x.copy(); xn[65_000, 7] = np.inf
+    try:
+        for name, xx, lab in (("ties", x, None), ("labels", x, labels), ("inf row", xn, None)):
+            out = {}
+            for v in (0, 1):
+                amd.set_tuning("flat_variant", v); amd.set_tuning("flat_f32_stream", 2 if v == 0 else 0)
+                ix = amd.FlatIndex(L2F, D); ix.add(xx, labels=lab)
+                out[v] = ix.search(q, k)
+                if v == 0:
+                    assert ix.last_search()[0] == (0 if name == "inf row" else 2), name
+                ix.close()
+            assert np.array_equal(out[0][1], out[1][1]), name
+            assert np.array_equal(bits(out[0][0]), bits(out[1][0])), name
+    finally:
+        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_stream", 1)
