@@ -154,6 +154,12 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         g_flat_f32_stream = (int)value;
         return CVTMI_OK;
     }
+    if (!strcmp(name, "flat_f32_dbg")) { set_flat_f32_dbg((int)value); return CVTMI_OK; }
+    if (!strcmp(name, "flat_f32_share")) {
+        if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_f32_share must be 0, 1 or 2");
+        set_flat_f32_share((int)value);
+        return CVTMI_OK;
+    }
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "sq8_wave_blocks")) {
@@ -975,7 +981,7 @@ static int flat_search_streamed(cvtmi_flat_t h, const float *q, int64_t nq, int 
     if (h->fs_nonfinite) return CVTMI_OK;
     const int qmax = flat_f32_stream_qmax(D);
     const int64_t passes = (nq + qmax - 1) / qmax, per = (nq + passes - 1) / passes;
-    if (h->fs_scratch.reserve(flat_f32_stream_scratch(n, per)) != CVTMI_OK) return CVTMI_OK;   // no room: the exact path answers
+    if (h->fs_scratch.reserve(flat_f32_stream_scratch(D, n, per)) != CVTMI_OK) return CVTMI_OK;   // no room: the exact path answers
     CVTMI_TRY(h->fs_redo.reserve((size_t)nq * 2 * sizeof(uint32_t)));   // redo flags, then list counters
     for (int64_t a = 0; a < nq; a += per) {
         const int64_t m = std::min(per, nq - a);
@@ -1120,7 +1126,7 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
     h->f_last_worst = 0;
     int how = 0;
     // fp32: one stream over the rows (flat_f32_stream.hip).  flat_variant 2 asks for the older sample + filter pipeline, 1 for the exact kernels
-    if (((g_flat_variant == 0 && g_flat_f32_stream == 1 && nq <= 256) || (g_flat_variant != 1 && g_flat_f32_stream == 2)) &&
+    if (((g_flat_variant == 0 && g_flat_f32_stream == 1) || (g_flat_variant != 1 && g_flat_f32_stream == 2)) &&
         ((uintptr_t)q & 15) == 0 && flat_f32_stream_applies(h->metric, h->D, h->n, k)) {
         CVTMI_TRY(flat_search_streamed(h, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
         if (done) how = 2;

@@ -53,9 +53,16 @@ constexpr int FS_POS_BITS = 5;           // tiles per group <= 32
 __device__ unsigned long long g_fs_dbg[16];
 #define FS_T0() unsigned long long fs_last__ = wall_clock64()
 #define FS_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now__ = wall_clock64(); g_fs_dbg[i] += now__ - fs_last__; fs_last__ = now__; } } while (0)
+__device__ unsigned long long g_fss_dbg[2][8];   // shader clocks of waves 0 and 4 of workgroup 0 of the shared-ring kernel, per section
+#define FSS_T0() unsigned long long fss_last__ = clock64(); unsigned long long fss_acc__[8] = {}
+#define FSS_T(i) do { const unsigned long long now__ = clock64(); fss_acc__[i] += now__ - fss_last__; fss_last__ = now__; } while (0)
+#define FSS_TEND() do { if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0) for (int i__ = 0; i__ < 8; ++i__) g_fss_dbg[wave >> 2][i__] = fss_acc__[i__]; } while (0)
 #else
 #define FS_T0() do { } while (0)
 #define FS_T(i) do { } while (0)
+#define FSS_T0() do { } while (0)
+#define FSS_T(i) do { } while (0)
+#define FSS_TEND() do { } while (0)
 #endif
 
 __device__ __forceinline__ void fs_glds16(const void *gsrc, uint32_t lds_dst)
@@ -269,6 +276,264 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- batches beyond one wave's registers: the four waves of a workgroup hold DIFFERENT queries and share the row tiles -------
+// One workgroup per CU streams tiles t = block + 256 i through ONE ring in LDS (RU whole tiles, 128 KB): every wave requests a
+// quarter of a tile's pieces, one s_barrier per tile says "tile i has landed for everyone and tile i - 1 has been read by
+// everyone", the request for tile i + RU - 1 goes into the slot tile i - 1 leaves.  A wave scores the tile against ITS 32 QB
+// queries, so a pass serves 128 QB queries (384 at D = 128) per read of the rows and the matrix pipe, not HBM, sets the pace.
+// Groups, (best, second) entries and the finish are those of the kernel above with 256 row streams instead of 1024; the first
+// threshold's 1024 maxima are per (workgroup, lane & 3): the lanes are folded down to four classes, disjoint row sets.
+constexpr int FSS_STREAMS = 256;
+template <int NCH, int NW> struct FssGeom {
+    static constexpr int TILE = NCH * 2048;                    // bytes
+    static constexpr int RU = 131072 / TILE;                   // tiles in the ring
+    static constexpr int RB = RU + 1;                          // bias slots
+    static constexpr int LDS = RU * TILE + RB * 256;
+    static constexpr int PW = 2 * NCH / NW;                    // pieces a wave requests per tile (even: whole K steps)
+    static constexpr int OPS = PW + 1;
+};
+// score key = t with its low FS_POS_BITS bits replaced by pos (one v_bfi_b32)
+__device__ __forceinline__ float fs_key(float t, uint32_t pos)
+{
+    constexpr uint32_t m = (1u << FS_POS_BITS) - 1;
+    return __uint_as_float((pos & m) | (__float_as_uint(t) & ~m));
+}
+// max without the canonicalising v_max the compiler puts in front of fmaxf (the operands are never signalling NaNs)
+__device__ __forceinline__ float fs_max(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// NW waves (4: one per SIMD, 8: two per SIMD) of 32 QB queries each
+template <int NCH, int QB, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void flat_f32_mshare_kernel(
+    const float *__restrict__ X, const float *__restrict__ bias, int64_t n_tiles, const float *__restrict__ Q, int nq, int G, int NG,
+    float2 *__restrict__ gb, float *__restrict__ wm, uint32_t *__restrict__ zero_a, uint32_t *__restrict__ zero_b, int dbg)
+{
+    using Ge = FssGeom<NCH, NW>;
+    constexpr int D = 16 * NCH, TILE = Ge::TILE, RU = Ge::RU, RB = Ge::RB, PW = Ge::PW, OPS = Ge::OPS;
+    static_assert(PW >= 2 && PW % 2 == 0, "a wave converts whole K steps");
+    constexpr int NACC = QB == 1 ? 2 : QB;
+    extern __shared__ __attribute__((aligned(16))) uint8_t fs_ring[];   // [RU tiles | RB bias slots]
+    const int tid = threadIdx.x, lane = tid & 63, lj = lane & 31, lk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (blockIdx.x == 0)
+        for (int i = tid; i < nq; i += 64 * NW) zero_a[i] = zero_b[i] = 0u;
+    bf16x8 qh[QB][NCH], ql[QB][NCH];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const int qi = (wave * QB + b) * 32 + lj;
+        const float *qp = Q + (int64_t)(qi < nq ? qi : nq - 1) * D + 8 * lk;
+#pragma unroll
+        for (int s = 0; s < NCH; ++s) {
+            float v[8];
+            *reinterpret_cast<float4 *>(&v[0]) = *reinterpret_cast<const float4 *>(qp + 16 * s);
+            *reinterpret_cast<float4 *>(&v[4]) = *reinterpret_cast<const float4 *>(qp + 16 * s + 4);
+            fs_split(v, qh[b][s], ql[b][s]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int64_t stream = blockIdx.x;
+    const int my_tiles = stream < n_tiles ? (int)((n_tiles - stream + FSS_STREAMS - 1) / FSS_STREAMS) : 0;
+    const uint32_t ring_b = (uint32_t)(uintptr_t)fs_ring;
+    const uint32_t bias_b = ring_b + (uint32_t)(RU * TILE);
+    // this wave's share of tile i: pieces p = wave PW .. + PW, piece p = 2 s + h as in the kernel above
+    auto request = [&](int i) {
+        const int ic = i < my_tiles ? i : my_tiles - 1;
+        const int64_t t = stream + (int64_t)ic * FSS_STREAMS;
+        const float *tile = X + ((t >> 1) * (int64_t)(D / 4) * 64 + (t & 1) * 32 + lj) * 4;
+        // (past the end: the last tile again, into the slot that is free anyway -- never the slot of a converted tile)
+        const uint32_t dst = ring_b + (uint32_t)((i % RU) * TILE);
+#pragma unroll
+        for (int pp = 0; pp < PW; ++pp) {
+            const int p = wave * PW + pp, s = p >> 1, h = p & 1;
+            fs_glds16(tile + (int64_t)(4 * s + 2 * lk + h) * 256, dst + (uint32_t)(p * 1024));
+        }
+        fs_glds4(bias + t * 32 + lj, bias_b + (uint32_t)((i % RB) * 256));
+    };
+    // Operand conversion happens ONCE per workgroup: the pieces a wave requested are exactly K steps wave PW/2 .. of the tile,
+    // so the wave that fetched them splits them into the two bf16 terms IN PLACE (piece 2 s keeps the high terms of its lanes,
+    // piece 2 s + 1 the low terms: same bytes) as soon as its own requests have landed -- one tile ahead of the products, no
+    // extra barrier -- and the product loop of every wave reads ready-made operands.
+    auto convert = [&](int i) {   // own share of tile i (requests retired: the caller waited)
+        uint8_t *tb = fs_ring + (size_t)(i % RU) * TILE + lane * 16;
+#pragma unroll
+        for (int ss = 0; ss < PW / 2; ++ss) {
+            const int s = wave * (PW / 2) + ss;
+            float v[8];
+            *reinterpret_cast<float4 *>(&v[0]) = *reinterpret_cast<const float4 *>(tb + (2 * s) * 1024);
+            *reinterpret_cast<float4 *>(&v[4]) = *reinterpret_cast<const float4 *>(tb + (2 * s + 1) * 1024);
+            bf16x8 xh, xl;
+            fs_split(v, xh, xl);
+            *reinterpret_cast<bf16x8 *>(tb + (2 * s) * 1024) = xh;
+            *reinterpret_cast<bf16x8 *>(tb + (2 * s + 1) * 1024) = xl;
+        }
+    };
+    if (my_tiles > 0) {
+#pragma unroll
+        for (int i = 0; i < RU - 1; ++i) request(i);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RU - 2) * OPS) : "memory");
+        convert(0);
+    }
+    constexpr int QBP = QB == 3 ? 4 : QB, V = 16 * QBP, R = V / 8;   // three fold steps: 32 lanes -> the 4 classes lane & 3
+    float wmax[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wmax[r] = FS_PAD_BIAS;
+    float best[QB][16], second[QB][16];
+#pragma unroll
+    for (int b = 0; b < QB; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) best[b][e] = second[b][e] = FS_PAD_BIAS;
+    f32x16 acc[NACC];
+    const int gmask = G - 1, glog = 31 - __builtin_clz(G);
+    // the products of tile i (operands ready in LDS) into acc
+    auto products = [&](int i) {
+        const uint8_t *ub = fs_ring + (size_t)(i % RU) * TILE + lane * 16;
+        {
+            const float bx = reinterpret_cast<const float *>(fs_ring + RU * TILE + (size_t)(i % RB) * 256)[lj];
+#pragma unroll
+            for (int a = 0; a < NACC; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][e] = (QB == 1 && a == 1) ? 0.0f : bx;
+        }
+        // operands of K step s + 1 are read while the products of K step s run (the order is pinned below)
+        bf16x8 xh[2], xl[2];
+        xh[0] = *reinterpret_cast<const bf16x8 *>(ub);
+        xl[0] = *reinterpret_cast<const bf16x8 *>(ub + 1024);
+#pragma unroll
+        for (int s = 0; s < NCH; ++s) {
+            if (s + 1 < NCH) {
+                xh[(s + 1) & 1] = *reinterpret_cast<const bf16x8 *>(ub + (2 * s + 2) * 1024);
+                xl[(s + 1) & 1] = *reinterpret_cast<const bf16x8 *>(ub + (2 * s + 3) * 1024);
+            }
+            const bf16x8 ch = xh[s & 1], cl = xl[s & 1];
+            if constexpr (QB == 1) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[0][s], ch, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[0][s], cl, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql[0][s], ch, acc[0], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[b][s], ch, acc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[b][s], cl, acc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql[b][s], ch, acc[b], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int s = 0; s < NCH; ++s) {
+            if (s + 1 < NCH) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * QB, 0);
+        }
+    };
+    // the scores of tile i into the group's best / second
+    float tv[QB][16];
+    auto take = [&]() {
+#pragma unroll
+        for (int b = 0; b < QB; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tv[b][e] = QB == 1 ? acc[0][e] + acc[1][e] : acc[b][e];
+    };
+    auto fold_in = [&](int i) {
+        const uint32_t pos = (uint32_t)(i & gmask);
+#pragma unroll
+        for (int b = 0; b < QB; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float key = fs_key(tv[b][e], pos);
+                second[b][e] = __builtin_amdgcn_fmed3f(best[b][e], second[b][e], key);
+                best[b][e] = fs_max(best[b][e], key);
+            }
+    };
+    // at the end of a group the entries leave
+    auto group_end = [&](int i) {
+        const uint32_t pos = (uint32_t)(i & gmask);
+        if (pos == (uint32_t)gmask || i == my_tiles - 1) {
+            const int g = i >> glog;
+#pragma unroll
+            for (int b = 0; b < QB; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int qi = 32 * (wave * QB + b) + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                    if (qi < nq) gb[(((int64_t)qi * NG + g) * FSS_STREAMS + stream) * 32 + lj] = make_float2(best[b][e], second[b][e]);
+                }
+            float fold[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) fold[v] = (v >> 4) < QB ? best[(v >> 4) < QB ? (v >> 4) : 0][v & 15] : FS_PAD_BIAS;
+            // three halving steps (lane bits 4, 3, 2): lane sub keeps the R values of prefix sub >> 2, maxima over its class sub & 3
+            {
+                const bool h4 = (lj & 16) != 0, h3 = (lj & 8) != 0, h2 = (lj & 4) != 0;
+#pragma unroll
+                for (int i2 = 0; i2 < V / 2; ++i2) {
+                    const float keep = h4 ? fold[i2 + V / 2] : fold[i2], send = h4 ? fold[i2] : fold[i2 + V / 2];
+                    fold[i2] = fmaxf(keep, __shfl_xor(send, 16, 64));
+                }
+#pragma unroll
+                for (int i2 = 0; i2 < V / 4; ++i2) {
+                    const float keep = h3 ? fold[i2 + V / 4] : fold[i2], send = h3 ? fold[i2] : fold[i2 + V / 4];
+                    fold[i2] = fmaxf(keep, __shfl_xor(send, 8, 64));
+                }
+#pragma unroll
+                for (int i2 = 0; i2 < V / 8; ++i2) {
+                    const float keep = h2 ? fold[i2 + V / 8] : fold[i2], send = h2 ? fold[i2] : fold[i2 + V / 8];
+                    fold[i2] = fmaxf(keep, __shfl_xor(send, 4, 64));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) wmax[r] = fmaxf(wmax[r], fold[r]);
+#pragma unroll
+            for (int b = 0; b < QB; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) best[b][e] = second[b][e] = FS_PAD_BIAS;
+        }
+    };
+    auto update = [&](int i) {
+        take();
+        fold_in(i);
+        group_end(i);
+    };
+    // the request for tile i + RU - 1 (into the slot tile i - 1 has left) and the conversion of the own share of tile i + 1
+    FSS_T0();
+    auto feed = [&](int i) {
+        if (!(dbg & 1)) request(i + RU - 1);
+        FSS_T(3);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RU - 2) * OPS) : "memory");   // own share of tile i + 1 (requested RU - 2 tiles ago) has landed
+        FSS_T(4);
+        if (i + 1 < my_tiles && !(dbg & 8)) convert(i + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        FSS_T(5);
+    };
+    // All waves move in lock step, one barrier per tile.  (Measured on 1 M x 128-d, 256 queries per pass: eight waves of 32
+    // queries 210 us per pass, four waves of 64 queries 254 us; the matrix instructions of a pass take 89 us at the pipe's
+    // rate -- the vector work of a tile (folding 16 scores per 32 queries into best / second, the operand conversion, the
+    // requests) does not run beside them: letting the two waves of a SIMD alternate between a matrix phase and a vector phase
+    // (two barriers per tile) measured 254 us, a single wave per SIMD with the vector work pinned between its matrix
+    // instructions by sched_group_barrier 290 us.)
+    for (int i = 0; i < my_tiles; ++i) {
+        // everyone's converted share of tile i is in LDS, everyone has read tile i - 1
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        FSS_T(0);
+        feed(i);
+        if (!(dbg & 2)) products(i);
+        FSS_T(1);
+        if (!(dbg & 4)) update(i);
+        FSS_T(2);
+    }
+    FSS_TEND();
+    {
+        const int pfx = lj >> 2;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int v = pfx * R + r, qi = 32 * (wave * QB + (v >> 4)) + (v & 3) + 8 * ((v & 15) >> 2) + 4 * lk;
+            if ((v >> 4) < QB && qi < nq) wm[(int64_t)qi * FS_WAVES + stream * 4 + (lj & 3)] = wmax[r];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // bias[r] for rows [row0, row1) of the blocked layout (+ the padding rows up to the end of the last 64-row block, whose
 // values are zeroed): -|x|^2 / 2 (L2) or 0 (inner product); stats[0] = max |x|^2 (bits), stats[1] = rows with a non-finite value
 __global__ __launch_bounds__(kBlock) void flat_f32_bias_kernel(float *__restrict__ X, int D, int l2, int64_t row0, int64_t row1,
@@ -305,6 +570,7 @@ struct FsFinishArgs {
     const float *X; int64_t n; int D;
     const float *Q; int64_t nq; int k;
     const float2 *gb; const float *wm; int G, NG, S;
+    int ns_log;                  // log2 of the row streams of the pass (1024 waves, or 256 workgroups of the shared-ring kernel)
     const uint32_t *stats;       // [0] max |x|^2
     uint32_t *cnt;               // [nq] listed groups (zeroed by the caller)
     float *qb;                   // [nq] Q = (|q|^2 + max |x|^2) * 1.001 of the query (collect -> finish)
@@ -429,7 +695,7 @@ __global__ __launch_bounds__(kBlock) void flat_f32_stream_collect_kernel(const F
     const int64_t qi = blockIdx.x / a.S;
     const int sl = blockIdx.x % a.S, tid = threadIdx.x, lane = tid & 63;
     FS_T0();
-    const int64_t E = (int64_t)a.NG * FS_WAVES * 32;
+    const int64_t E = ((int64_t)a.NG << a.ns_log) * 32;
     const int64_t e0 = E * sl / a.S, e1 = E * (sl + 1) / a.S;
     const float2 *gb = a.gb + qi * E;
     // the slice's first batch is requested before the threshold is known
@@ -466,36 +732,40 @@ __global__ __launch_bounds__(kBlock) void flat_f32_stream_collect_kernel(const F
     const float cut1 = cut_s;
     if (!(cut1 == cut1)) return;
     uint4 *list = a.list + qi * FSF_LIST;
+    // hits go to LDS as they are found (no barrier between batches); more than the list could take anyway: the exact kernels answer
     for (int64_t base = e0 + tid; base < e1; base += (int64_t)kBlock * U) {
         if (base != e0 + tid) {
-            __syncthreads();   // (hit_s is free again)
-            if (tid == 0) nh_s = 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t e = base + (int64_t)u * kBlock;
                 v[u] = e < e1 ? gb[e] : make_float2(FS_PAD_BIAS, FS_PAD_BIAS);
             }
-            __syncthreads();
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (v[u].x >= cut1)
-                hit_s[atomicAdd(&nh_s, 1)] = make_uint4(__float_as_uint(v[u].x), __float_as_uint(v[u].y), (uint32_t)(base + (int64_t)u * kBlock), 0u);
-        __syncthreads();
-        const int nh = nh_s;
-        if (tid == 0 && nh > 0) base_s = atomicAdd(&a.cnt[qi], (uint32_t)nh);   // one global atomic per workgroup and batch
-        __syncthreads();
-        // the exact distance of every hit's best row rides along (the hits are spread over many workgroups here: their rows'
-        // pieces are fetched side by side; the finish only computes for the rare group whose second best qualifies too)
-        for (int i = tid; i < nh; i += kBlock) {
-            if (base_s + i >= (uint32_t)FSF_LIST) break;
-            uint4 h = hit_s[i];
-            const uint32_t e = h.z;
-            const int64_t j = e & 31, wv = (e >> 5) & (FS_WAVES - 1), g = e >> 15, pp = h.x & ((1u << FS_POS_BITS) - 1);
-            const int64_t row = (wv + (g * a.G + pp) * FS_WAVES) * 32 + j;
-            h.w = row < a.n ? __float_as_uint(fs_exact<IP, LANES>(a.X, a.D, row, reinterpret_cast<const float4 *>(q_s))) : 0x7fc00000u;
-            list[base_s + i] = h;
-        }
+            if (v[u].x >= cut1) {
+                const int slot = atomicAdd(&nh_s, 1);
+                if (slot < kBlock * U) hit_s[slot] = make_uint4(__float_as_uint(v[u].x), __float_as_uint(v[u].y), (uint32_t)(base + (int64_t)u * kBlock), 0u);
+            }
+    }
+    __syncthreads();
+    const int nh = nh_s;
+    if (nh > kBlock * U) {
+        if (tid == 0) a.redo[qi] = 1u;
+        return;
+    }
+    if (tid == 0 && nh > 0) base_s = atomicAdd(&a.cnt[qi], (uint32_t)nh);   // one global atomic per workgroup
+    __syncthreads();
+    // the exact distance of every hit's best row rides along (the hits are spread over many workgroups here: their rows'
+    // pieces are fetched side by side; the finish only computes for the rare group whose second best qualifies too)
+    for (int i = tid; i < nh; i += kBlock) {
+        if (base_s + i >= (uint32_t)FSF_LIST) break;
+        uint4 h = hit_s[i];
+        const uint32_t e = h.z;
+        const int64_t j = e & 31, wv = (e >> 5) & ((1u << a.ns_log) - 1), g = e >> (5 + a.ns_log), pp = h.x & ((1u << FS_POS_BITS) - 1);
+        const int64_t row = (wv + ((g * a.G + pp) << a.ns_log)) * 32 + j;
+        h.w = row < a.n ? __float_as_uint(fs_exact<IP, LANES>(a.X, a.D, row, reinterpret_cast<const float4 *>(q_s))) : 0x7fc00000u;
+        list[base_s + i] = h;
     }
     FS_T(2);
 }
@@ -573,16 +843,16 @@ __global__ __launch_bounds__(kBlock) void flat_f32_stream_finish_kernel(const Fs
         const float bestv = key_f32(best_s[i]);
         if (!(bestv >= cut)) continue;
         const uint32_t e = ent_s[i];
-        const int64_t j = e & 31, wv = (e >> 5) & (FS_WAVES - 1), g = e >> 15;   // FS_WAVES = 1024
+        const int64_t j = e & 31, wv = (e >> 5) & ((1u << a.ns_log) - 1), g = e >> (5 + a.ns_log);
         if (sec_s[i] >= cut) {
             const int base = atomicAdd(&cnt_s, G);
             for (int p = 0; p < G; ++p) {
-                const int64_t row = (wv + (g * G + p) * FS_WAVES) * 32 + j;
+                const int64_t row = (wv + ((g * G + p) << a.ns_log)) * 32 + j;
                 if (base + p < FSF_KEEP) row_s[base + p] = row < a.n ? (uint32_t)row : 0xffffffffu;
             }
         } else {
             const uint32_t p = __float_as_uint(bestv) & ((1u << FS_POS_BITS) - 1);
-            const int64_t row = (wv + (g * G + p) * FS_WAVES) * 32 + j;
+            const int64_t row = (wv + ((g * G + p) << a.ns_log)) * 32 + j;
             const int slot = atomicAdd(&ndone_s, 1);
             if (slot < FSF_KEEP && row < a.n) sort_s[slot] = ((unsigned long long)dist_key(dist_s[i]) << 32) | (uint32_t)row;
             else if (slot < FSF_KEEP) sort_s[slot] = ~0ull - (unsigned)slot;
@@ -629,48 +899,62 @@ extern "C" int cvtmi_debug_fs_timing(unsigned long long *out, int reset)
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_fs_dbg), z, sizeof z) != hipSuccess) return -3;
     return 0;
 }
+extern "C" int cvtmi_debug_fss_timing(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fss_dbg), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
 #endif
 
 }  // namespace
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
-// D in {32, 64, 96, 128, 192, 256}; queries per pass = 32 QB, QB the largest of 1..4 whose registers fit one wave per SIMD
-// (8 NCH operand registers + 48 of accumulators / best / second per 32 queries)
+// D in {32, 64, 96, 128, 192, 256}; a wave holds 32 QB queries, QB the largest of 1..4 whose registers fit one wave per SIMD
+// (8 NCH operand registers + 48 of accumulators / best / second per 32 queries).  A pass of the private-ring kernel serves
+// 32 QB queries, a pass of the shared-ring kernel 128 QB.
 static int fs_qb_max(int nch)
 {
     int qb = 4;
     while (qb > 1 && qb * (8 * nch + 48) > 368) --qb;
     return qb;
 }
+static int g_fs_dbgflags = 0;     // timing experiments (results wrong when non-zero): cvtmi_set_tuning("flat_f32_dbg")
+void set_flat_f32_dbg(int v) { g_fs_dbgflags = v; }
+static int g_fs_share = 0;   // cvtmi_set_tuning("flat_f32_share"): 0 = choose, 1 = four waves of 32 QB queries, 2 = eight waves of 32 queries
+void set_flat_f32_share(int v) { g_fs_share = v; }
+// the shared-ring kernel wants whole K steps per wave: D / 16 a multiple of the wave count
+static bool fs_eight(int D) { return g_fs_share != 1 && (D / 16) % 8 == 0; }   // (measured faster per query than four waves x 32 QB)
+static bool fs_four(int D) { return (D / 16) % 4 == 0; }
 int flat_f32_stream_qmax(int D)
 {
     if (D != 32 && D != 64 && D != 96 && D != 128 && D != 192 && D != 256) return 0;
-    return 32 * fs_qb_max(D / 16);
+    return fs_eight(D) ? 256 : (fs_four(D) ? 128 : 32) * fs_qb_max(D / 16);
 }
+static bool fs_shared(int D, int64_t nq) { return nq > 32 * fs_qb_max(D / 16); }
 bool flat_f32_stream_applies(int metric, int D, int64_t n, int k)
 {
     return (metric == CVTMI_METRIC_IP || metric == CVTMI_METRIC_L2F) && flat_f32_stream_qmax(D) > 0 && n >= 32768 && n < 0xffffffffLL &&
-           k >= 1 && k <= 128 && (n + 31) / 32 < ((int64_t)1 << 17) * FS_WAVES * 32;   // entry index: 32 bits
+           k >= 1 && k <= 128 && (n + 31) / 32 < ((int64_t)1 << 17) * FSS_STREAMS * 32;   // entry index: 32 bits
 }
-// groups per wave and tiles per group for n rows
-static void fs_groups(int64_t n, int *G, int *NG)
+// tiles per group and groups per row stream for n rows on `streams` streams
+static void fs_groups(int64_t n, int streams, int *G, int *NG)
 {
-    const int64_t n_tiles = (n + 31) / 32, per_wave = (n_tiles + FS_WAVES - 1) / FS_WAVES;
+    const int64_t n_tiles = (n + 31) / 32, per = (n_tiles + streams - 1) / streams;
     int g = 32;
-    while (g > 1 && g / 2 >= per_wave) g >>= 1;   // short indexes: one group, no wider than the tiles a wave sees
+    while (g > 1 && g / 2 >= per) g >>= 1;   // short indexes: one group, no wider than the tiles a stream sees
     *G = g;
-    *NG = (int)((per_wave + g - 1) / g);
+    *NG = (int)((per + g - 1) / g);
 }
-// scratch of one pass: group entries [nq][NG][1024][32] float2, wave maxima [nq][1024] float, lists [nq][FSF_LIST] uint4
-static size_t fs_gb_bytes(int64_t n, int64_t nq_pass)
+// scratch of one pass: group entries [nq][NG][streams][32] float2, 1024 maxima per query, lists [nq][FSF_LIST] uint4, Q per query
+static size_t fs_gb_bytes(int D, int64_t n, int64_t nq_pass)
 {
     int G, NG;
-    fs_groups(n, &G, &NG);
-    return (size_t)nq_pass * NG * FS_WAVES * 32 * sizeof(float2);
+    const int streams = fs_shared(D, nq_pass) ? FSS_STREAMS : FS_WAVES;
+    fs_groups(n, streams, &G, &NG);
+    return (size_t)nq_pass * NG * streams * 32 * sizeof(float2);
 }
-size_t flat_f32_stream_scratch(int64_t n, int64_t nq_pass)
+size_t flat_f32_stream_scratch(int D, int64_t n, int64_t nq_pass)
 {
-    return fs_gb_bytes(n, nq_pass) + (size_t)nq_pass * (FS_WAVES + 4) * sizeof(float) + (size_t)nq_pass * FSF_LIST * sizeof(uint4);
+    return fs_gb_bytes(D, n, nq_pass) + (size_t)nq_pass * (FS_WAVES + 4) * sizeof(float) + (size_t)nq_pass * FSF_LIST * sizeof(uint4);
 }
 
 int launch_flat_f32_bias(float *X, int D, int metric, int64_t row0, int64_t row1, float *bias, uint32_t *stats, hipStream_t st)
@@ -683,23 +967,66 @@ int launch_flat_f32_bias(float *X, int D, int metric, int64_t row0, int64_t row1
     return CVTMI_OK;
 }
 
-template <int NCH, int QB>
-static int fs_launch_stream(const float *X, const float *bias, int64_t n_tiles, const float *q, int nq, int G, int NG, float2 *gb,
-                            float *wm, uint32_t *redo, uint32_t *cnt, hipStream_t st)
+struct FsStreamArgs {
+    const float *X, *bias; int64_t n_tiles; const float *q; int nq, G, NG; float2 *gb; float *wm; uint32_t *redo, *cnt;
+};
+static int fs_set_lds(const void *fn, size_t lds, bool (&done)[16])
 {
-    const size_t lds = (size_t)4 * FsGeom<NCH>::WAVE_LDS;
-    static bool attr_set[16] = {};
     int dev = 0;
     CVTMI_HIP(hipGetDevice(&dev));
-    if (dev < 16 && !attr_set[dev]) {
-        CVTMI_HIP(hipFuncSetAttribute((const void *)flat_f32_mstream_kernel<NCH, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev] = true;
-    } else if (dev >= 16) {
-        CVTMI_HIP(hipFuncSetAttribute((const void *)flat_f32_mstream_kernel<NCH, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (dev >= 16 || !done[dev]) {   // the attribute is per device
+        CVTMI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev < 16) done[dev] = true;
     }
-    hipLaunchKernelGGL((flat_f32_mstream_kernel<NCH, QB>), dim3(FS_BLOCKS), dim3(256), lds, st, X, bias, n_tiles, q, nq, G, NG, gb, wm, redo, cnt);
+    return CVTMI_OK;
+}
+template <int NCH>
+static int fs_launch_eight(const FsStreamArgs &a, hipStream_t st)
+{
+    if constexpr (NCH % 8 == 0) {
+        static bool attr_set[16] = {};
+        const size_t lds = FssGeom<NCH, 8>::LDS;
+        CVTMI_TRY(fs_set_lds((const void *)flat_f32_mshare_kernel<NCH, 1, 8>, lds, attr_set));
+        hipLaunchKernelGGL((flat_f32_mshare_kernel<NCH, 1, 8>), dim3(FSS_STREAMS), dim3(512), lds, st, a.X, a.bias, a.n_tiles, a.q, a.nq, a.G, a.NG,
+                           a.gb, a.wm, a.redo, a.cnt, g_fs_dbgflags);
+        CVTMI_HIP(hipGetLastError());
+        return CVTMI_OK;
+    } else {
+        return fail(CVTMI_EINVAL, "flat_f32_stream: eight waves at D=%d", 16 * NCH);
+    }
+}
+template <int NCH, int QB, bool SHARED>
+static int fs_launch_stream(const FsStreamArgs &a, hipStream_t st)
+{
+    static bool attr_set[16] = {};
+    if constexpr (SHARED && NCH % 4 != 0) {
+        return fail(CVTMI_EINVAL, "flat_f32_stream: shared ring at D=%d", 16 * NCH);
+    } else if constexpr (SHARED) {
+        const size_t lds = FssGeom<NCH, 4>::LDS;
+        CVTMI_TRY(fs_set_lds((const void *)flat_f32_mshare_kernel<NCH, QB, 4>, lds, attr_set));
+        hipLaunchKernelGGL((flat_f32_mshare_kernel<NCH, QB, 4>), dim3(FSS_STREAMS), dim3(256), lds, st, a.X, a.bias, a.n_tiles, a.q, a.nq, a.G, a.NG,
+                           a.gb, a.wm, a.redo, a.cnt, g_fs_dbgflags);
+    } else {
+        const size_t lds = (size_t)4 * FsGeom<NCH>::WAVE_LDS;
+        CVTMI_TRY(fs_set_lds((const void *)flat_f32_mstream_kernel<NCH, QB>, lds, attr_set));
+        hipLaunchKernelGGL((flat_f32_mstream_kernel<NCH, QB>), dim3(FS_BLOCKS), dim3(256), lds, st, a.X, a.bias, a.n_tiles, a.q, a.nq, a.G, a.NG,
+                           a.gb, a.wm, a.redo, a.cnt);
+    }
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
+}
+template <int NCH, bool SHARED>
+static int fs_launch_qb(int qb, const FsStreamArgs &a, hipStream_t st)
+{
+    if constexpr (4 * (8 * NCH + 48) <= 368) {
+        if (qb == 4) return fs_launch_stream<NCH, 4, SHARED>(a, st);
+    }
+    if constexpr (3 * (8 * NCH + 48) <= 368) {
+        if (qb == 3) return fs_launch_stream<NCH, 3, SHARED>(a, st);
+    }
+    if (qb == 2) return fs_launch_stream<NCH, 2, SHARED>(a, st);
+    if (qb == 1) return fs_launch_stream<NCH, 1, SHARED>(a, st);
+    return fail(CVTMI_EINVAL, "flat_f32_stream: %d query blocks per wave at D=%d", qb, 16 * NCH);
 }
 
 // one pass: nq <= flat_f32_stream_qmax(D) queries against rows [0, n); results for queries whose redo flag stays 0.
@@ -709,38 +1036,32 @@ int launch_flat_f32_stream(int metric, int D, const float *X, const float *bias,
 {
     const int qmax = flat_f32_stream_qmax(D);
     if (qmax == 0 || nq < 1 || nq > qmax) return fail(CVTMI_EINVAL, "flat_f32_stream: D=%d nq=%lld", D, (long long)nq);
+    const bool shared = fs_shared(D, nq);
+    const int streams = shared ? FSS_STREAMS : FS_WAVES;
     int G, NG;
-    fs_groups(n, &G, &NG);
-    const int64_t n_tiles = (n + 31) / 32;
+    fs_groups(n, streams, &G, &NG);
     float2 *gb = reinterpret_cast<float2 *>(scratch);
-    float *wm = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(scratch) + fs_gb_bytes(n, nq));
+    float *wm = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(scratch) + fs_gb_bytes(D, n, nq));
     uint4 *list = reinterpret_cast<uint4 *>(wm + (size_t)nq * FS_WAVES);
     float *qbuf = reinterpret_cast<float *>(list + (size_t)nq * FSF_LIST);
-    const int nch = D / 16, qb = (int)((nq + 31) / 32);
-#define CVTMI_FS(NCH_)                                                                                              \
-    case NCH_:                                                                                                      \
-        if constexpr (4 * (8 * (NCH_) + 48) <= 368) {                                                               \
-            if (qb == 4) { CVTMI_TRY((fs_launch_stream<NCH_, 4>(X, bias, n_tiles, q, (int)nq, G, NG, gb, wm, redo, cnt, st))); break; } \
-        }                                                                                                           \
-        if constexpr (3 * (8 * (NCH_) + 48) <= 368) {                                                               \
-            if (qb == 3) { CVTMI_TRY((fs_launch_stream<NCH_, 3>(X, bias, n_tiles, q, (int)nq, G, NG, gb, wm, redo, cnt, st))); break; } \
-        }                                                                                                           \
-        if (qb == 2) { CVTMI_TRY((fs_launch_stream<NCH_, 2>(X, bias, n_tiles, q, (int)nq, G, NG, gb, wm, redo, cnt, st))); break; }   \
-        if (qb == 1) { CVTMI_TRY((fs_launch_stream<NCH_, 1>(X, bias, n_tiles, q, (int)nq, G, NG, gb, wm, redo, cnt, st))); break; }   \
-        return fail(CVTMI_EINVAL, "flat_f32_stream: %d query blocks at D=%d", qb, D);
-    switch (nch) {
+    const FsStreamArgs sa = { X, bias, (n + 31) / 32, q, (int)nq, G, NG, gb, wm, redo, cnt };
+    const int qb = shared ? (int)((nq + 127) / 128) : (int)((nq + 31) / 32);
+    const bool eight = shared && fs_eight(D);
+#define CVTMI_FS(NCH_) \
+    case NCH_: CVTMI_TRY(eight ? fs_launch_eight<NCH_>(sa, st) : shared ? (fs_launch_qb<NCH_, true>(qb, sa, st)) : (fs_launch_qb<NCH_, false>(qb, sa, st))); break;
+    switch (D / 16) {
         CVTMI_FS(2) CVTMI_FS(4) CVTMI_FS(6) CVTMI_FS(8) CVTMI_FS(12) CVTMI_FS(16)
         default: return fail(CVTMI_EUNSUPPORTED, "flat_f32_stream: D=%d", D);
     }
 #undef CVTMI_FS
     FsFinishArgs fa;
     fa.X = X; fa.n = n; fa.D = D; fa.Q = q; fa.nq = nq; fa.k = k; fa.gb = gb; fa.wm = wm; fa.G = G; fa.NG = NG; fa.stats = stats;
+    fa.ns_log = shared ? 8 : 10;
     fa.cnt = cnt; fa.list = list; fa.qb = qbuf; fa.out_d = out_d; fa.out_i = out_i; fa.redo = redo;
-    // slices per query: one batch of loads per thread (2048 entries per slice) while that keeps the grid within ~2048 workgroups
-    const int64_t E = (int64_t)NG * FS_WAVES * 32;
-    int S = (int)std::min<int64_t>(std::max<int64_t>(1, 2048 / nq), std::max<int64_t>(1, E / 2048));
-    fa.S = S;
-    const unsigned cgrid = (unsigned)(nq * S);
+    // slices per query: one batch of loads per thread (2048 entries per slice) while that keeps the grid near one round of workgroups
+    const int64_t E = (int64_t)NG * streams * 32;
+    fa.S = (int)std::min<int64_t>(std::max<int64_t>(1, 1024 / nq), std::max<int64_t>(1, E / 2048));
+    const unsigned cgrid = (unsigned)(nq * fa.S);
     if (metric == CVTMI_METRIC_IP) {
         hipLaunchKernelGGL((flat_f32_stream_collect_kernel<true, 4>), dim3(cgrid), dim3(kBlock), 0, st, fa);
         hipLaunchKernelGGL((flat_f32_stream_finish_kernel<true, 4>), dim3((unsigned)nq), dim3(kBlock), 0, st, fa);

@@ -122,8 +122,10 @@ int launch_flat_block(const float *src, int64_t n, int D, int64_t row0, float *d
 // flat_f32_stream.hip: fp32 IP / L2 search as one stream over the blocked rows (bf16 matrix-core scores, group best / second best,
 // exact distances of the candidates); D % 16 == 0, 16 <= D <= 256, up to flat_f32_stream_qmax(D) queries per pass
 int flat_f32_stream_qmax(int D);
+void set_flat_f32_dbg(int v);     // timing experiments, results wrong when non-zero
+void set_flat_f32_share(int v);   // shared-ring kernel: 0 choose, 1 four waves x 32 QB queries, 2 eight waves x 32 queries
 bool flat_f32_stream_applies(int metric, int D, int64_t n, int k);
-size_t flat_f32_stream_scratch(int64_t n, int64_t nq_pass);
+size_t flat_f32_stream_scratch(int D, int64_t n, int64_t nq_pass);
 // bias[r] (and zeroed padding rows) for rows [row0, row1); stats[0] = max |x|^2 bits, stats[1] = non-finite rows (both accumulate)
 int launch_flat_f32_bias(float *X, int D, int metric, int64_t row0, int64_t row1, float *bias, uint32_t *stats, hipStream_t st);
 // redo[nq], cnt[nq] (zeroed inside): redo is set to 1 for queries the exact kernels must answer

@@ -559,7 +559,8 @@ def _clustered(rng, n, D, metric):
 
 @pytest.mark.parametrize("metric,D,nq,k", [(IP, 128, 1, 100), (L2F, 128, 1, 100), (IP, 128, 7, 10), (L2F, 128, 33, 100), (IP, 128, 64, 100),
                                             (L2F, 128, 96, 128), (IP, 128, 97, 1), (L2F, 64, 128, 10), (IP, 32, 100, 50), (L2F, 96, 70, 20),
-                                            (IP, 192, 40, 100), (L2F, 256, 33, 100), (IP, 256, 5, 3), (L2F, 128, 250, 100)])
+                                            (IP, 192, 40, 100), (L2F, 256, 33, 100), (IP, 256, 5, 3), (L2F, 128, 250, 100), (IP, 128, 384, 100),
+                                            (L2F, 128, 500, 10), (IP, 256, 100, 10), (L2F, 32, 600, 128), (IP, 96, 129, 7)])
 def test_flat_f32_stream(amd, orc, metric, D, nq, k):
     """fp32 search as one stream over the rows (flat_f32_stream 2: bf16 matrix-core scores, group best / second best, exact
     distances of the candidates) against the exact kernels (flat_variant 1) on the whole batch and against the checker on a few
@@ -627,3 +628,28 @@ def test_flat_f32_stream_hands_hard_queries_to_the_exact_kernels(amd):
             assert np.array_equal(bits(out[0][0]), bits(out[1][0])), name
     finally:
         amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_stream", 1)
+
+
+@pytest.mark.parametrize("share", [1, 2])
+def test_flat_f32_stream_shared_ring_variants(amd, share):
+    """both forms of the shared-ring kernel (four waves x 32 QB queries, eight waves x 32 queries) against the exact kernels,
+    batch sizes around the pass boundaries, ragged last tile"""
+    rng = np.random.default_rng(17 + share)
+    n, D, k = 40_000 + 21, 128, 50
+    x = _clustered(rng, n, D, L2F)
+    x[30_000:30_060] = x[9]
+    try:
+        amd.set_tuning("flat_f32_share", share)
+        ix = amd.FlatIndex(L2F, D); ix.add(x)
+        for nq in (97, 256, 257, 385, 600):
+            q = (x[rng.integers(0, n, nq)] + 0.05 * rng.normal(size=(nq, D))).astype(np.float32)
+            q[0] = x[9]
+            amd.set_tuning("flat_variant", 0)
+            ds, is_ = ix.search(q, k)
+            assert ix.last_search()[0] == 2
+            amd.set_tuning("flat_variant", 1)
+            de, ie = ix.search(q, k)
+            assert np.array_equal(is_, ie) and np.array_equal(bits(ds), bits(de)), nq
+        ix.close()
+    finally:
+        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_share", 0)

@@ -14,6 +14,8 @@ def rows(m):
 for a in range(0, n, 1 << 21):
     ix.add(rows(min(n, a + (1 << 21)) - a))
 k = int(os.environ.get("K", 10))
+if os.environ.get("DBG"): cvt_amd.set_tuning("flat_f32_dbg", int(os.environ["DBG"]))
+if os.environ.get("SHARE"): cvt_amd.set_tuning("flat_f32_share", int(os.environ["SHARE"]))
 eb = 1 if metric == 2 else 4
 for nq in [int(v) for v in os.environ.get("NQS", "1,2,4,8,16,32,64,128,256,512,1000,4096").split(",")]:
     q = rows(nq)
