@@ -6,6 +6,6 @@ classes in ``cvt_amd/host``.  This Python package is only the thin ctypes bindin
 bench.py drive it through; torch is used for device memory, streams and torch.distributed.
 """
 from .capi import (Comm, CvtmiError, FlatIndex, HnswIndex, OpqIndex, kmeans, lib, load_library, opq_train, pca_project, set_tuning, sq8_decode,  # noqa: F401
-                   sq8_encode, sq8_train, shard_range, topk_merge, topk_select)
+                   sq8_encode, sq8_train, search_sharded_all, shard_range, topk_merge, topk_select)
 
 IP, L2F, L2U8 = 0, 1, 2

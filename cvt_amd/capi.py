@@ -269,6 +269,19 @@ class Comm:
         return bytes(buf.raw)
 
     @classmethod
+    def create_all(cls, ndev, devices=None):
+        """ONE process driving `ndev` GPUs: ncclCommInitAll inside the library; returns the list of per-device communicators."""
+        hs = (C.c_void_p * ndev)()
+        dv = None if devices is None else (C.c_int * ndev)(*devices)
+        _check(lib().cvtmi_comm_create_all(C.c_int(ndev), dv, hs))
+        out = []
+        for d in range(ndev):
+            self = cls.__new__(cls)
+            self.h = C.c_void_p(hs[d]); self._cb = None; self.rank, self.world = d, ndev
+            out.append(self)
+        return out
+
+    @classmethod
     def custom(cls, fn, rank, world):
         """fn(send_ptr, recv_ptr, nbytes, stream_ptr) -> 0: gather nbytes from every rank into recv (device pointers)."""
         self = cls.__new__(cls)
@@ -328,6 +341,26 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def search_sharded_all(indexes, comms, q, k, rotate=True):
+    """Single-process multi-GPU search: indexes[d] (OpqIndex or FlatIndex with its id base set) holds the row block of device d,
+    comms = Comm.create_all(len(indexes)); q, results: host arrays."""
+    nd = len(indexes)
+    hs = (C.c_void_p * nd)(*[ix.h.value for ix in indexes])
+    cs = (C.c_void_p * nd)(*[c.h.value for c in comms])
+    nq = q.shape[0]
+    i = np.empty((nq, k), dtype=np.int64)
+    if isinstance(indexes[0], FlatIndex):
+        q = _np(q, indexes[0]._dt())
+        d = np.empty((nq, k), dtype=np.int32 if indexes[0].metric == 2 else np.float32)
+        _check(lib().cvtmi_flat_search_sharded_all(hs, cs, C.c_int(nd), _ptr(q), C.c_int64(nq), C.c_int(k), _ptr(d), _ptr(i)))
+    else:
+        q = _np(q, np.float32)
+        d = np.empty((nq, k), dtype=np.float32)
+        _check(lib().cvtmi_opq_search_sharded_all(hs, cs, C.c_int(nd), _ptr(q), C.c_int64(nq), C.c_int(1 if rotate else 0), C.c_int(k),
+                                                  _ptr(d), _ptr(i)))
+    return d, i
 
 
 def shard_range(n_total, rank, world):
@@ -410,6 +443,24 @@ class FlatIndex:
         d = np.empty((nq, k), dtype=np.int32 if self.metric == 2 else np.float32)
         i = np.empty((nq, k), dtype=np.int64)
         _check(lib().cvtmi_flat_search(self.h, _ptr(q), C.c_int64(nq), C.c_int(k), _ptr(d), _ptr(i)))
+        return d, i
+
+    def set_id_base(self, base):
+        _check(lib().cvtmi_flat_set_id_base(self.h, C.c_int64(base)))
+
+    def search_sharded(self, comm, q, k):
+        """Row-sharded exhaustive search: this handle holds the rank's row block (set_id_base = its first row)."""
+        nq = q.shape[0]
+        if _is_torch(q):
+            import torch
+            d = torch.empty((nq, k), dtype=torch.int32 if self.metric == 2 else torch.float32, device=q.device)
+            i = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            _check(lib().cvtmi_flat_search_sharded_dev(self.h, comm.h, _ptr(q), C.c_int64(nq), C.c_int(k), _ptr(d), _ptr(i), _stream()))
+            return d, i
+        q = _np(q, self._dt())
+        d = np.empty((nq, k), dtype=np.int32 if self.metric == 2 else np.float32)
+        i = np.empty((nq, k), dtype=np.int64)
+        _check(lib().cvtmi_flat_search_sharded(self.h, comm.h, _ptr(q), C.c_int64(nq), C.c_int(k), _ptr(d), _ptr(i)))
         return d, i
 
     def last_search(self):

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <numeric>
@@ -84,6 +85,7 @@ struct cvtmi_flat_s {
     size_t row_bytes = 0;
     DevBuf data, labels, norms;  // norms: int32 |x-128|^2 per row, uint8 metric with D % 32 == 0 (MFMA path)
     int64_t n = 0;
+    int64_t id_base = 0;   // row r reports label id_base + r while labels are implicit (row shards, cvtmi_flat_set_id_base)
     bool identity = true;  // label == row
     DevBuf s_part_d, s_part_id, s_gthr, s_stage;
     // matrix-core filter of the fp32 search (flat_mfma.hip): bf16 operand copy of the rows, built on first use
@@ -114,8 +116,51 @@ static int use_device(int dev)
     CHECK_H(h); \
     Serial serial_##h((h)->sync, (hipStream_t)(stream))
 
+static int g_inject_failure = -1;  // cvtmi_set_tuning("comm_inject_failure", r): the local search of rank r of a sharded search fails (tests)
 static int g_flat_variant = 0;  // cvtmi_set_tuning("flat_variant"): 0 = choose, 1 = exact kernels only, 2 = matrix-core filter wherever it applies
 static int g_flat_f32_stream = 1;  // cvtmi_set_tuning("flat_f32_stream"): 0 = off, 1 = choose, 2 = wherever it applies
+
+static int sharded_local_failure(cvtmi_comm_t c)
+{
+    if (g_inject_failure >= 0 && g_inject_failure == comm_rank(c)) return fail(CVTMI_ESTATE, "injected failure of rank %d (comm_inject_failure)", comm_rank(c));
+    return CVTMI_OK;
+}
+
+// One process, every GPU: handles[d] holds the row block of device d (its id base set), comms = cvtmi_comm_create_all.  The
+// queries go up to every device, the local searches are enqueued device after device (they run side by side), the all-gathers
+// leave as one group, the merge runs on the first device.
+using ShardLocalSearch = std::function<int(int, const void *, float *, int64_t *)>;
+static int sharded_all(cvtmi_comm_t *comms, int ndev, const void *q, size_t q_bytes, int64_t nq, int k, void *dist, int64_t *ids,
+                       const int *devices, const ShardLocalSearch &local_search)
+{
+    std::vector<Tmp> dq(ndev);
+    std::vector<int> status(ndev, CVTMI_OK);
+    for (int d = 0; d < ndev; ++d) {
+        CVTMI_HIP(hipSetDevice(devices[d]));
+        float *sd = nullptr;
+        int64_t *si = nullptr;
+        int rc = sharded_local_failure(comms[d]);
+        if (rc == CVTMI_OK) rc = dq[d].alloc(q_bytes);
+        if (rc == CVTMI_OK && hipMemcpyAsync(dq[d].p, q, q_bytes, hipMemcpyHostToDevice, nullptr) != hipSuccess) rc = fail(CVTMI_EHIP, "query upload to device %d failed", devices[d]);
+        if (rc == CVTMI_OK) rc = comm_local_slot(comms[d], nq, k, &sd, &si);
+        if (rc == CVTMI_OK) rc = local_search(d, dq[d].p, sd, si);
+        status[d] = rc;
+    }
+    CVTMI_HIP(hipSetDevice(devices[0]));
+    Tmp dd, di;
+    CVTMI_TRY(dd.alloc((size_t)nq * k * 4));
+    CVTMI_TRY(di.alloc((size_t)nq * k * 8));
+    const int rc = comm_exchange_merge_all(comms, ndev, nq, k, status.data(), dd.as<float>(), di.as<int64_t>());
+    for (int d = 0; d < ndev; ++d) {   // the temporaries die with this frame: drain every device first
+        (void)hipSetDevice(devices[d]);
+        (void)hipDeviceSynchronize();
+    }
+    CVTMI_HIP(hipSetDevice(devices[0]));
+    if (rc != CVTMI_OK) return rc;
+    CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    CVTMI_HIP(hipMemcpy(ids, di.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
 
 extern "C" {
 
@@ -182,6 +227,8 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         return CVTMI_OK;
     }
     if (!strcmp(name, "comm_force_rccl")) { comm_set_force_rccl(value != 0); return CVTMI_OK; }
+    if (!strcmp(name, "comm_check_status")) { comm_set_check_status(value != 0); return CVTMI_OK; }
+    if (!strcmp(name, "comm_inject_failure")) { g_inject_failure = (int)value; return CVTMI_OK; }
     return fail(CVTMI_EINVAL, "cvtmi_set_tuning: unknown parameter '%s'", name);
 }
 
@@ -599,28 +646,34 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
 }
 
 // row-sharded search: the local scan writes its lists straight into this rank's slot of the communicator's gather buffer,
-// then one all-gather + merge (shard.hip)
+// then one all-gather + merge (shard.hip).  Lock order: communicator first, then the handle -- collectives on one
+// communicator leave in the order its lock was taken, which therefore has to be the same on every rank (drive one
+// communicator from one thread, or issue the searches that share it in one order everywhere).
 int cvtmi_opq_search_sharded_dev(cvtmi_opq_t h, cvtmi_comm_t c, const float *q, int64_t nq, int rotate, int k, float *dist,
                                  int64_t *ids, void *stream)
 {
-    CHECK_H_SERIAL(h, stream);
-    if (!c) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: null communicator");
-    if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: bad arguments");
+    CVTMI_TRY(comm_validate(c));
+    if (!h) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: null handle");
+    if (nq < 0 || (nq > 0 && (!dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: bad arguments");
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search_sharded: k=%d outside 1..128", k);
-    if (comm_device(c) != h->device) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: handle and communicator live on different devices");
     if (nq == 0) return CVTMI_OK;
-    if (comm_world(c) == 1 && !comm_has_transport(c)) return cvtmi_opq_search_dev(h, q, nq, rotate, k, dist, ids, stream);
     Serial serial_c(*comm_sync(c), (hipStream_t)stream);
+    CHECK_H_SERIAL(h, stream);
+    if (comm_world(c) == 1 && !comm_has_transport(c)) return cvtmi_opq_search_dev(h, q, nq, rotate, k, dist, ids, stream);
+    // from here on every rank reaches the collective, whatever its local search did
+    int rc = comm_device(c) != h->device ? fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: handle and communicator live on different devices") : CVTMI_OK;
     float *sd = nullptr;
     int64_t *si = nullptr;
-    CVTMI_TRY(comm_local_slot(c, nq, k, &sd, &si));
-    CVTMI_TRY(cvtmi_opq_search_dev(h, q, nq, rotate, k, sd, si, stream));
-    return comm_exchange_merge(c, nq, k, dist, ids, (hipStream_t)stream);
+    if (rc == CVTMI_OK) rc = !q ? fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: null queries") : sharded_local_failure(c);
+    if (rc == CVTMI_OK) rc = comm_local_slot(c, nq, k, &sd, &si);
+    if (rc == CVTMI_OK) rc = cvtmi_opq_search_dev(h, q, nq, rotate, k, sd, si, stream);
+    return comm_exchange_merge(c, nq, k, rc, dist, ids, (hipStream_t)stream);
 }
 
 int cvtmi_opq_search_sharded(cvtmi_opq_t h, cvtmi_comm_t c, const float *q, int64_t nq, int rotate, int k, float *dist, int64_t *ids)
 {
-    CHECK_H_SERIAL(h, nullptr);
+    CVTMI_TRY(comm_validate(c));
+    CHECK_H(h);
     if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: bad arguments");
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search_sharded: k=%d outside 1..128", k);
     if (nq == 0) return CVTMI_OK;
@@ -632,6 +685,27 @@ int cvtmi_opq_search_sharded(cvtmi_opq_t h, cvtmi_comm_t c, const float *q, int6
     CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
     CVTMI_HIP(hipMemcpy(ids, di.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost));
     return CVTMI_OK;
+}
+
+int cvtmi_opq_search_sharded_all(cvtmi_opq_t *handles, cvtmi_comm_t *comms, int ndev, const float *q, int64_t nq, int rotate, int k,
+                                 float *dist, int64_t *ids)
+{
+    if (!handles || !comms || ndev < 1) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded_all: bad arguments");
+    if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded_all: bad arguments");
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search_sharded_all: k=%d outside 1..128", k);
+    std::vector<int> devices(ndev);
+    for (int d = 0; d < ndev; ++d) {
+        CVTMI_TRY(comm_validate(comms[d]));
+        if (!handles[d]) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded_all: null handle %d", d);
+        if (comm_world(comms[d]) != ndev || comm_rank(comms[d]) != d || comm_device(comms[d]) != handles[d]->device)
+            return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded_all: communicator %d does not belong to handle %d", d, d);
+        devices[d] = handles[d]->device;
+    }
+    if (nq == 0) return CVTMI_OK;
+    return sharded_all(comms, ndev, q, (size_t)nq * handles[0]->m.D * sizeof(float), nq, k, dist, ids, devices.data(),
+                       [&](int d, const void *qd, float *sd, int64_t *si) {
+                           return cvtmi_opq_search_dev(handles[d], static_cast<const float *>(qd), nq, rotate, k, sd, si, nullptr);
+                       });
 }
 
 int cvtmi_opq_query_video_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int nprobe, int img_num, float *match_score,
@@ -1147,7 +1221,72 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
     h->f_last_filtered = done ? (how ? how : 1) : 0;
     if (!done) CVTMI_TRY(flat_search_rows(h, h->n, q, nq, k, reinterpret_cast<float *>(dist), labels, st));
     if (!h->identity) CVTMI_TRY(launch_gather_labels(labels, nq * k, h->labels.as<int64_t>(), st));
+    else if (h->id_base != 0) CVTMI_TRY(launch_offset_labels(labels, nq * k, h->id_base, st));
     return CVTMI_OK;
+}
+
+int cvtmi_flat_set_id_base(cvtmi_flat_t h, int64_t base)
+{
+    if (!h) return fail(CVTMI_EINVAL, "cvtmi_flat_set_id_base: null");
+    h->id_base = base;
+    return CVTMI_OK;
+}
+
+// row-sharded exhaustive search (the flat twin of cvtmi_opq_search_sharded_dev): local search into the communicator's slot,
+// one all-gather, merge.  uint8 L2: the int32 distances travel and merge as their bit patterns (shard.hip).
+int cvtmi_flat_search_sharded_dev(cvtmi_flat_t h, cvtmi_comm_t c, const void *q, int64_t nq, int k, void *dist, int64_t *labels, void *stream)
+{
+    CVTMI_TRY(comm_validate(c));
+    if (!h) return fail(CVTMI_EINVAL, "cvtmi_flat_search_sharded: null handle");
+    if (nq < 0 || (nq > 0 && (!dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_flat_search_sharded: bad arguments");
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search_sharded: k=%d outside 1..128", k);
+    if (nq == 0) return CVTMI_OK;
+    Serial serial_c(*comm_sync(c), (hipStream_t)stream);
+    CHECK_H_SERIAL(h, stream);
+    if (comm_world(c) == 1 && !comm_has_transport(c)) return cvtmi_flat_search_dev(h, q, nq, k, dist, labels, stream);
+    int rc = comm_device(c) != h->device ? fail(CVTMI_EINVAL, "cvtmi_flat_search_sharded: handle and communicator live on different devices") : CVTMI_OK;
+    float *sd = nullptr;
+    int64_t *si = nullptr;
+    if (rc == CVTMI_OK) rc = !q ? fail(CVTMI_EINVAL, "cvtmi_flat_search_sharded: null queries") : sharded_local_failure(c);
+    if (rc == CVTMI_OK) rc = comm_local_slot(c, nq, k, &sd, &si);
+    if (rc == CVTMI_OK) rc = cvtmi_flat_search_dev(h, q, nq, k, sd, si, stream);
+    return comm_exchange_merge(c, nq, k, rc, reinterpret_cast<float *>(dist), labels, (hipStream_t)stream);
+}
+
+int cvtmi_flat_search_sharded(cvtmi_flat_t h, cvtmi_comm_t c, const void *q, int64_t nq, int k, void *dist, int64_t *labels)
+{
+    CVTMI_TRY(comm_validate(c));
+    CHECK_H(h);
+    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_flat_search_sharded: bad arguments");
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search_sharded: k=%d outside 1..128", k);
+    if (nq == 0) return CVTMI_OK;
+    Tmp dq, dd, di;
+    CVTMI_TRY(dq.upload(q, (size_t)nq * h->row_bytes));
+    CVTMI_TRY(dd.alloc((size_t)nq * k * 4));
+    CVTMI_TRY(di.alloc((size_t)nq * k * 8));
+    CVTMI_TRY(cvtmi_flat_search_sharded_dev(h, c, dq.p, nq, k, dd.p, di.as<int64_t>(), nullptr));
+    CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    CVTMI_HIP(hipMemcpy(labels, di.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+    return CVTMI_OK;
+}
+
+int cvtmi_flat_search_sharded_all(cvtmi_flat_t *handles, cvtmi_comm_t *comms, int ndev, const void *q, int64_t nq, int k, void *dist,
+                                  int64_t *labels)
+{
+    if (!handles || !comms || ndev < 1) return fail(CVTMI_EINVAL, "cvtmi_flat_search_sharded_all: bad arguments");
+    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_flat_search_sharded_all: bad arguments");
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search_sharded_all: k=%d outside 1..128", k);
+    std::vector<int> devices(ndev);
+    for (int d = 0; d < ndev; ++d) {
+        CVTMI_TRY(comm_validate(comms[d]));
+        if (!handles[d]) return fail(CVTMI_EINVAL, "cvtmi_flat_search_sharded_all: null handle %d", d);
+        if (comm_world(comms[d]) != ndev || comm_rank(comms[d]) != d || comm_device(comms[d]) != handles[d]->device)
+            return fail(CVTMI_EINVAL, "cvtmi_flat_search_sharded_all: communicator %d does not belong to handle %d", d, d);
+        devices[d] = handles[d]->device;
+    }
+    if (nq == 0) return CVTMI_OK;
+    return sharded_all(comms, ndev, q, (size_t)nq * handles[0]->row_bytes, nq, k, dist, labels, devices.data(),
+                       [&](int d, const void *qd, float *sd, int64_t *si) { return cvtmi_flat_search_dev(handles[d], qd, nq, k, sd, si, nullptr); });
 }
 
 int cvtmi_flat_last_search(cvtmi_flat_t h, int *filtered, int64_t *max_candidates)

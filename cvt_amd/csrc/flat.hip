@@ -1183,6 +1183,19 @@ int launch_gather_labels(int64_t *ids, int64_t count, const int64_t *labels, hip
     return CVTMI_OK;
 }
 
+__global__ __launch_bounds__(kBlock) void offset_labels_kernel(int64_t *ids, int64_t count, int64_t base)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < count && ids[i] >= 0) ids[i] += base;
+}
+int launch_offset_labels(int64_t *ids, int64_t count, int64_t base, hipStream_t st)
+{
+    if (count <= 0) return CVTMI_OK;
+    hipLaunchKernelGGL(offset_labels_kernel, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, ids, count, base);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
 constexpr int STREAM_SLICES = 64;
 // selection after flat_u8_mstream_kernel (flat_mfma.hip): wave minima wmin[nq][G], tile minima tmin[tiles][nqp] -> part [nq][slices][k] -> merge
 int launch_flat_u8_mstream_finish(int D, const uint8_t *data, int64_t n, const uint8_t *q, int64_t nq, int k, const int32_t *wmin, int G,

@@ -124,7 +124,7 @@ struct HnswArgs {
     int64_t words, gcap;
     int *err;
     int raw_ids;              // 1 = out_label receives internal ids instead of labels (the re-rank pass needs the node)
-    int dynamic;              // 1 = queries handed out by the counter err[1] (64 per wave: nq < 2^25), 0 = static stride
+    int dynamic;              // 1 = queries handed out by the counter err[1] (one ticket per wave), 0 = static stride
 };
 
 // Distance evaluators: per-query state in LDS (`prepare`), one neighbour per lane (`operator()`).
@@ -191,14 +191,15 @@ __global__ __launch_bounds__(64, 8) void hnsw_search_kernel(const HnswArgs a)  /
     const int64_t cand_cap = HN_LCAP + a.gcap;
 
     // Queries are drawn from a counter (err[1], zeroed with the flag) instead of a static stride: traversals differ in length, and the last
-    // of the 1.2 - 2.6 rounds used to wait for its slowest waves.  EVERY lane takes part in the atomic (the compiler folds it into one
-    // add of 64 per wave): a header that only lane 0 executes lets the compiler send lane 0 and the other lanes through the loop on
-    // different paths, and the wave-level operations of the body then run without lane 0 (observed: the kernel never ended).
+    // of the 1.2 - 2.6 rounds used to wait for its slowest waves.  EVERY lane executes the atomic (a header that only lane 0 executes
+    // lets the compiler send lane 0 and the other lanes through the loop on different paths, and the wave-level operations of the
+    // body then run without lane 0 -- observed: the kernel never ended), but only lane 0 adds: its old value is a ticket that is
+    // unique per wave whether or not the compiler folds the wave's atomics into one.
     for (int it = 0;; ++it) {
         int qi;
         if (a.dynamic) {
-            const unsigned t = atomicAdd(reinterpret_cast<unsigned *>(a.err) + 1, 1u);
-            qi = (int)((unsigned)__builtin_amdgcn_readfirstlane((int)t) >> 6);
+            const unsigned t = atomicAdd(reinterpret_cast<unsigned *>(a.err) + 1, lane == 0 ? 1u : 0u);
+            qi = __builtin_amdgcn_readfirstlane((int)t);
         } else {
             qi = (int)blockIdx.x + it * (int)gridDim.x;
         }
@@ -330,7 +331,7 @@ static void hnsw_fill_args(HnswArgs &a, const HnswDevGraph &g, int64_t nq, int k
     a.nq = (int)nq; a.k = k; a.ef = ef; a.out_d = out_d; a.out_label = out_label;
     a.visited = visited; a.cand_g = reinterpret_cast<HnEnt *>(cand_scratch); a.words = words; a.gcap = gcap; a.err = err;
     a.raw_ids = 0;
-    a.dynamic = nq < (1 << 25) ? 1 : 0;
+    a.dynamic = 1;
 }
 
 int launch_hnsw_search(const HnswDevGraph &g, int metric, const float *q, int64_t nq, int k, int ef, float *out_d,

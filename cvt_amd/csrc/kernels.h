@@ -158,6 +158,8 @@ int launch_flat_u8_stream(int D, const uint8_t *data, const int32_t *norms, int6
 void set_flat_u8_gfilter(int v);   // flat_mfma.hip: the software-pipelined (LDS-DMA) uint8 filter kernel on / off
 bool flat_u8_gfilter_shape(int D);
 int launch_gather_labels(int64_t *ids, int64_t count, const int64_t *labels, hipStream_t st);
+// ids[i] = ids[i] >= 0 ? ids[i] + base : -1
+int launch_offset_labels(int64_t *ids, int64_t count, int64_t base, hipStream_t st);
 
 // ---- sq8.hip ----
 // den[n] = float(max(1e-12, sqrt(sum_i double(x_i * x_i))))   (int8_quan.cc:46-52)

@@ -258,7 +258,7 @@ size_t csr_scratch_bytes(int64_t n, int L, int *nb_out)
     int nb = (int)std::min<int64_t>(512, std::max<int64_t>(1, (8 << 20) / std::max(L, 1)));
     nb = (int)std::min<int64_t>(nb, std::max<int64_t>(1, (n + 4095) / 4096));
     if (nb_out) *nb_out = nb;
-    return (size_t)nb * L * sizeof(uint32_t) + (size_t)L * sizeof(int64_t) + 64;
+    return (((size_t)nb * L * sizeof(uint32_t) + 7) & ~(size_t)7) + (size_t)L * sizeof(int64_t) + 64;   // the int64 part starts on 8 bytes
 }
 
 // scratch: csr_scratch_bytes(); list_off [L + 1]; stats_out (device): [0] longest list (int64), then int32 min / max video id at byte 8 / 12
@@ -268,14 +268,14 @@ int launch_csr_build(const int32_t *lists, const int32_t *videos, const uint8_t 
     int nb = 1;
     const size_t sb = csr_scratch_bytes(n, L, &nb);
     uint32_t *hist = static_cast<uint32_t *>(scratch);
-    int64_t *total = reinterpret_cast<int64_t *>(static_cast<char *>(scratch) + (size_t)nb * L * sizeof(uint32_t));
+    int64_t *total = reinterpret_cast<int64_t *>(static_cast<char *>(scratch) + (((size_t)nb * L * sizeof(uint32_t) + 7) & ~(size_t)7));
     (void)sb;
     CVTMI_HIP(hipMemsetAsync(hist, 0, (size_t)nb * L * sizeof(uint32_t), st));
     int64_t *st64 = static_cast<int64_t *>(stats_out);
     int32_t *vst = reinterpret_cast<int32_t *>(st64 + 1);
-    const int32_t vinit[2] = { 0x7fffffff, -0x7fffffff - 1 };
     CVTMI_HIP(hipMemsetAsync(st64, 0, 8, st));
-    CVTMI_HIP(hipMemcpyAsync(vst, vinit, sizeof vinit, hipMemcpyHostToDevice, st));
+    CVTMI_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(vst), 0x7fffffff, 1, st));        // min video id
+    CVTMI_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(vst + 1), (int)0x80000000u, 1, st));   // max video id
     if (n > 0) {
         hipLaunchKernelGGL(csr_count_kernel, dim3(nb), dim3(64), 0, st, lists, n, L, hist);
         CVTMI_HIP(hipGetLastError());

@@ -4,7 +4,9 @@
 
 namespace cvtmi {
 
+int comm_validate(cvtmi_comm_t c);   // CVTMI_EINVAL for a null / stale / destroyed handle
 int comm_world(cvtmi_comm_t c);
+int comm_rank(cvtmi_comm_t c);
 int comm_device(cvtmi_comm_t c);
 bool comm_has_transport(cvtmi_comm_t c);
 HandleSync *comm_sync(cvtmi_comm_t c);
@@ -12,7 +14,11 @@ size_t comm_slot_bytes(int64_t nq, int k);
 // this rank's slot of the gather buffer for an [nq][k] result: the local search writes its lists there
 int comm_local_slot(cvtmi_comm_t c, int64_t nq, int k, float **dist, int64_t **ids);
 // ONE all-gather of the slots (RCCL, or the caller's transport) + merge of the per-rank lists into dist / ids
-int comm_exchange_merge(cvtmi_comm_t c, int64_t nq, int k, float *dist, int64_t *ids, hipStream_t st);
+// status: the return code of this rank's local search (it travels with the slot: a failure anywhere fails every rank)
+int comm_exchange_merge(cvtmi_comm_t c, int64_t nq, int k, int status, float *dist, int64_t *ids, hipStream_t st);
+// the communicators of one process (cvtmi_comm_create_all): grouped all-gathers, merge on comms[0]'s device
+int comm_exchange_merge_all(cvtmi_comm_t *comms, int ndev, int64_t nq, int k, const int *status, float *dist, int64_t *ids);
 void comm_set_force_rccl(int v);
+void comm_set_check_status(int v);
 
 }  // namespace cvtmi

@@ -6,10 +6,19 @@
 // rank at 10 K queries x top-100) and xGMI is a full point-to-point mesh, so one all-gather costs one latency.
 //
 // Buffer layout: the communicator owns `world` slots of
-//     [nq * k fp32 distances, padded to 16 B][nq * k int64 ids, padded to 16 B]
+//     [status word, padded to 16 B][nq * k fp32 distances, padded to 16 B][nq * k int64 ids, padded to 16 B]
 // The local search writes straight into slot `rank` (no pack kernel, no copy), ncclAllGather runs IN PLACE over the
 // slots as one byte message per rank, and topk_merge_kernel<true> reads the gathered lists where they landed.  Rank
 // order is ascending id range, which is the merge's tie rule.  Everything is enqueued on the caller's stream.
+// (uint8 L2 searches send their int32 distances through the same fp32 fields: non-negative ints order like their bit
+// patterns read as floats, and nothing does arithmetic on them.)
+//
+// Failure: a rank whose local search failed still enters the collective -- with its error code in the status word --
+// so nobody is left waiting; after the all-gather every rank reads the `world` status words back (one small copy + a
+// stream synchronisation; cvtmi_set_tuning("comm_check_status", 0) skips it) and ALL ranks return CVTMI_ECOMM.
+//
+// One process can also drive every GPU of the node (cvtmi_comm_create_all: ncclCommInitAll; the searches of the
+// devices are enqueued one after the other, the all-gathers go out as one ncclGroupStart / ncclGroupEnd group).
 //
 // RCCL is bound at run time (dlopen of librccl.so.1 on the first communicator): processes that never shard -- the CPU
 // boundary tests, the single-GPU CLIs -- do not load it, and a process that already has RCCL mapped (torch) shares it.
@@ -19,6 +28,8 @@
 
 #include <algorithm>
 #include <new>
+#include <string>
+#include <vector>
 
 #include "host_util.h"
 #include "kernels.h"
@@ -32,6 +43,9 @@ struct RcclApi {
     void *so = nullptr;
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -43,12 +57,17 @@ RcclApi *rccl()
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
+      try {   // nothing may throw across the C ABI (std::string can)
         const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
         for (const char *nm : names) {
             api.so = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
             if (api.so) break;
         }
-        if (!api.so) { api.why = dlerror() ? dlerror() : "librccl.so.1 not found"; return; }
+        if (!api.so) {
+            const char *e = dlerror();   // (one call: dlerror() clears the state it reports)
+            api.why = e ? e : "librccl.so.1 not found";
+            return;
+        }
         auto sym = [&](const char *nm) -> void * {
             void *p = dlsym(api.so, nm);
             if (!p && api.why.empty()) api.why = std::string("symbol missing in librccl: ") + nm;
@@ -56,9 +75,15 @@ RcclApi *rccl()
         };
         api.GetUniqueId = reinterpret_cast<decltype(&ncclGetUniqueId)>(sym("ncclGetUniqueId"));
         api.CommInitRank = reinterpret_cast<decltype(&ncclCommInitRank)>(sym("ncclCommInitRank"));
+        api.CommInitAll = reinterpret_cast<decltype(&ncclCommInitAll)>(sym("ncclCommInitAll"));
+        api.GroupStart = reinterpret_cast<decltype(&ncclGroupStart)>(sym("ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(&ncclGroupEnd)>(sym("ncclGroupEnd"));
         api.AllGather = reinterpret_cast<decltype(&ncclAllGather)>(sym("ncclAllGather"));
         api.CommDestroy = reinterpret_cast<decltype(&ncclCommDestroy)>(sym("ncclCommDestroy"));
         api.GetErrorString = reinterpret_cast<decltype(&ncclGetErrorString)>(sym("ncclGetErrorString"));
+      } catch (...) {
+        api.so = nullptr;
+      }
     });
     return &api;
 }
@@ -66,7 +91,7 @@ RcclApi *rccl()
 int rccl_ready(RcclApi **out)
 {
     RcclApi *a = rccl();
-    if (!a->so || !a->why.empty()) return fail(CVTMI_ECOMM, "RCCL is not available: %s", a->why.c_str());
+    if (!a->so || !a->why.empty()) return fail(CVTMI_ECOMM, "RCCL is not available: %s", a->why.empty() ? "librccl could not be loaded" : a->why.c_str());
     *out = a;
     return CVTMI_OK;
 }
@@ -79,6 +104,8 @@ int rccl_ready(RcclApi **out)
     } while (0)
 
 int g_force_rccl = 0;  // cvtmi_set_tuning("comm_force_rccl"): world == 1 communicators go through RCCL too (tests on a 1-GPU box)
+int g_check_status = 1;  // cvtmi_set_tuning("comm_check_status"): read the ranks' status words back after every all-gather
+constexpr size_t kSlotHeader = 16;
 
 constexpr uint32_t kCommMagic = 0x434f4d4du;
 
@@ -87,6 +114,7 @@ inline size_t align16(size_t b) { return (b + 15) & ~(size_t)15; }
 }  // namespace
 
 void comm_set_force_rccl(int v) { g_force_rccl = v; }
+void comm_set_check_status(int v) { g_check_status = v; }
 
 }  // namespace cvtmi
 
@@ -101,6 +129,7 @@ struct cvtmi_comm_s {
     HandleSync sync;
     DevBuf gather;  // world slots, see the layout note on top
     int64_t n_collectives = 0, last_bytes_per_rank = 0;
+    uint32_t *h_status = nullptr;   // [world] host copy of the status words of the last exchange
 };
 
 namespace cvtmi {
@@ -114,9 +143,18 @@ static int comm_check(cvtmi_comm_t c)
     return CVTMI_OK;
 }
 
-size_t comm_slot_bytes(int64_t nq, int k) { return align16((size_t)nq * k * sizeof(float)) + align16((size_t)nq * k * sizeof(int64_t)); }
+size_t comm_slot_bytes(int64_t nq, int k)
+{
+    return kSlotHeader + align16((size_t)nq * k * sizeof(float)) + align16((size_t)nq * k * sizeof(int64_t));
+}
 
+int comm_validate(cvtmi_comm_t c)
+{
+    if (!c || c->magic != kCommMagic) return fail(CVTMI_EINVAL, "bad communicator handle");
+    return CVTMI_OK;
+}
 int comm_world(cvtmi_comm_t c) { return c ? c->world : 1; }
+int comm_rank(cvtmi_comm_t c) { return c ? c->rank : 0; }
 int comm_device(cvtmi_comm_t c) { return c ? c->device : -1; }
 bool comm_has_transport(cvtmi_comm_t c) { return c && (c->nccl || c->fn); }
 HandleSync *comm_sync(cvtmi_comm_t c) { return &c->sync; }
@@ -127,20 +165,23 @@ int comm_local_slot(cvtmi_comm_t c, int64_t nq, int k, float **dist, int64_t **i
     CVTMI_TRY(comm_check(c));
     const size_t slot = comm_slot_bytes(nq, k);
     CVTMI_TRY(c->gather.reserve(std::max<size_t>(slot * c->world, 16)));
-    uint8_t *mine = c->gather.as<uint8_t>() + (size_t)c->rank * slot;
+    uint8_t *mine = c->gather.as<uint8_t>() + (size_t)c->rank * slot + kSlotHeader;
     *dist = reinterpret_cast<float *>(mine);
     *ids = reinterpret_cast<int64_t *>(mine + align16((size_t)nq * k * sizeof(float)));
     return CVTMI_OK;
 }
 
-// all-gather of the slots (one collective) + merge of the world lists per query into dist / ids
-int comm_exchange_merge(cvtmi_comm_t c, int64_t nq, int k, float *dist, int64_t *ids, hipStream_t st)
+// the status word of this rank's slot (enqueued); the slot exists afterwards even if comm_local_slot never ran
+static int comm_post_status(cvtmi_comm_t c, int64_t nq, int k, int status, hipStream_t st)
 {
-    CVTMI_TRY(comm_check(c));
-    if (nq <= 0) return CVTMI_OK;
     const size_t slot = comm_slot_bytes(nq, k);
+    CVTMI_TRY(c->gather.reserve(std::max<size_t>(slot * c->world, 16)));
+    CVTMI_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->gather.as<uint8_t>() + (size_t)c->rank * slot), status, 1, st));
+    return CVTMI_OK;
+}
+static int comm_allgather(cvtmi_comm_t c, size_t slot, hipStream_t st)
+{
     uint8_t *base = c->gather.as<uint8_t>();
-    if (c->gather.cap < slot * c->world) return fail(CVTMI_ESTATE, "comm_exchange_merge: slot not prepared");
     if (c->nccl) {
         RcclApi *api = nullptr;
         CVTMI_TRY(rccl_ready(&api));
@@ -152,9 +193,76 @@ int comm_exchange_merge(cvtmi_comm_t c, int64_t nq, int k, float *dist, int64_t 
     }  // world == 1 without a transport: the one slot is already the gathered buffer
     c->n_collectives += (c->nccl || c->fn) ? 1 : 0;
     c->last_bytes_per_rank = (int64_t)slot;
+    return CVTMI_OK;
+}
+// every rank's status word -> host; non-zero anywhere: CVTMI_ECOMM on every rank
+static int comm_check_statuses(cvtmi_comm_t c, size_t slot, int own_status, hipStream_t st)
+{
+    if (!g_check_status) return own_status == CVTMI_OK ? CVTMI_OK : fail(CVTMI_ECOMM, "the local search of rank %d failed with %d", c->rank, own_status);
+    if (!c->h_status) {
+        c->h_status = new (std::nothrow) uint32_t[c->world];
+        if (!c->h_status) return fail(CVTMI_ENOMEM, "communicator: out of host memory");
+    }
+    CVTMI_HIP(hipMemcpy2DAsync(c->h_status, sizeof(uint32_t), c->gather.p, slot, sizeof(uint32_t), (size_t)c->world, hipMemcpyDeviceToHost, st));
+    CVTMI_HIP(hipStreamSynchronize(st));
+    for (int r = 0; r < c->world; ++r)
+        if (c->h_status[r] != 0u)
+            return fail(CVTMI_ECOMM, "row-sharded search: rank %d reported error %d%s", r, (int)c->h_status[r], r == c->rank ? " (this rank)" : "");
+    return CVTMI_OK;
+}
+
+// all-gather of the slots (one collective) + merge of the world lists per query into dist / ids.  status: what the local
+// search of this rank returned -- it travels in the slot header, and a failure anywhere fails the call on every rank
+int comm_exchange_merge(cvtmi_comm_t c, int64_t nq, int k, int status, float *dist, int64_t *ids, hipStream_t st)
+{
+    CVTMI_TRY(comm_check(c));
+    if (nq <= 0) return CVTMI_OK;
+    const size_t slot = comm_slot_bytes(nq, k);
+    const std::string own = status != CVTMI_OK ? std::string(cvtmi_last_error()) : std::string();
+    CVTMI_TRY(comm_post_status(c, nq, k, status, st));
+    CVTMI_TRY(comm_allgather(c, slot, st));
+    const int rc = comm_check_statuses(c, slot, status, st);
+    if (rc != CVTMI_OK) {
+        if (status != CVTMI_OK) return fail(CVTMI_ECOMM, "row-sharded search: the local search of rank %d failed with %d: %s", c->rank, status, own.c_str());
+        return rc;
+    }
+    uint8_t *base = c->gather.as<uint8_t>() + kSlotHeader;
     const size_t ids_off = align16((size_t)nq * k * sizeof(float));
     return launch_topk_merge_gathered(reinterpret_cast<const float *>(base), reinterpret_cast<const int64_t *>(base + ids_off),
                                       (int64_t)(slot / sizeof(float)), (int64_t)(slot / sizeof(int64_t)), nq, c->world, k, dist, ids, st);
+}
+
+// The same exchange for the communicators of ONE process (cvtmi_comm_create_all), one per device: status words, ONE group of
+// all-gathers (ncclGroupStart .. ncclGroupEnd: issued from a single thread they would otherwise wait for each other), status
+// check, merge on the device of comms[0] only (dist / ids live there).  Everything on the devices' null streams.
+int comm_exchange_merge_all(cvtmi_comm_t *comms, int ndev, int64_t nq, int k, const int *status, float *dist, int64_t *ids)
+{
+    if (nq <= 0) return CVTMI_OK;
+    const size_t slot = comm_slot_bytes(nq, k);
+    RcclApi *api = nullptr;
+    CVTMI_TRY(rccl_ready(&api));
+    for (int d = 0; d < ndev; ++d) {
+        CVTMI_TRY(comm_check(comms[d]));
+        CVTMI_TRY(comm_post_status(comms[d], nq, k, status[d], nullptr));
+    }
+    CVTMI_NCCL(api, api->GroupStart());
+    for (int d = 0; d < ndev; ++d) {
+        cvtmi_comm_t c = comms[d];
+        if (comm_check(c) != CVTMI_OK) { (void)api->GroupEnd(); return CVTMI_EHIP; }
+        uint8_t *base = c->gather.as<uint8_t>();
+        ncclResult_t r = api->AllGather(base + (size_t)c->rank * slot, base, slot, ncclUint8, c->nccl, nullptr);
+        if (r != ncclSuccess) { (void)api->GroupEnd(); return fail(CVTMI_ECOMM, "ncclAllGather (device %d) failed: %s", c->device, api->GetErrorString(r)); }
+        c->n_collectives += 1;
+        c->last_bytes_per_rank = (int64_t)slot;
+    }
+    CVTMI_NCCL(api, api->GroupEnd());
+    cvtmi_comm_t c0 = comms[0];
+    CVTMI_TRY(comm_check(c0));
+    CVTMI_TRY(comm_check_statuses(c0, slot, status[0], nullptr));
+    uint8_t *base = c0->gather.as<uint8_t>() + kSlotHeader;
+    const size_t ids_off = align16((size_t)nq * k * sizeof(float));
+    return launch_topk_merge_gathered(reinterpret_cast<const float *>(base), reinterpret_cast<const int64_t *>(base + ids_off),
+                                      (int64_t)(slot / sizeof(float)), (int64_t)(slot / sizeof(int64_t)), nq, c0->world, k, dist, ids, nullptr);
 }
 
 }  // namespace cvtmi
@@ -200,6 +308,37 @@ int cvtmi_comm_create(const void *id, int rank, int world, cvtmi_comm_t *out)
     return CVTMI_OK;
 }
 
+int cvtmi_comm_create_all(int ndev, const int *devices, cvtmi_comm_t *comms)
+{
+    if (ndev < 1 || !comms) return fail(CVTMI_EINVAL, "cvtmi_comm_create_all: bad arguments");
+    for (int d = 0; d < ndev; ++d) comms[d] = nullptr;
+    int avail = 0;
+    CVTMI_HIP(hipGetDeviceCount(&avail));
+    std::vector<int> devs(ndev);
+    for (int d = 0; d < ndev; ++d) {
+        devs[d] = devices ? devices[d] : d;
+        if (devs[d] < 0 || devs[d] >= avail) return fail(CVTMI_EINVAL, "cvtmi_comm_create_all: device %d of %d", devs[d], avail);
+        for (int e = 0; e < d; ++e)
+            if (devs[e] == devs[d]) return fail(CVTMI_EINVAL, "cvtmi_comm_create_all: device %d listed twice", devs[d]);
+    }
+    RcclApi *api = nullptr;
+    CVTMI_TRY(rccl_ready(&api));
+    if (!api->CommInitAll || !api->GroupStart || !api->GroupEnd) return fail(CVTMI_ECOMM, "RCCL lacks ncclCommInitAll / ncclGroupStart");
+    std::vector<ncclComm_t> nc(ndev, nullptr);
+    ncclResult_t r = api->CommInitAll(nc.data(), ndev, devs.data());
+    if (r != ncclSuccess) return fail(CVTMI_ECOMM, "ncclCommInitAll(%d devices) failed: %s", ndev, api->GetErrorString(r));
+    for (int d = 0; d < ndev; ++d) {
+        cvtmi_comm_s *c = new (std::nothrow) cvtmi_comm_s();
+        if (!c) {
+            for (int e = 0; e < ndev; ++e) { if (comms[e]) { comms[e]->nccl = nullptr; delete comms[e]; comms[e] = nullptr; } (void)api->CommDestroy(nc[e]); }
+            return fail(CVTMI_ENOMEM, "cvtmi_comm_create_all: out of host memory");
+        }
+        c->device = devs[d]; c->rank = d; c->world = ndev; c->nccl = nc[d];
+        comms[d] = c;
+    }
+    return CVTMI_OK;
+}
+
 int cvtmi_comm_create_custom(cvtmi_allgather_fn fn, void *ctx, int rank, int world, cvtmi_comm_t *out)
 {
     if (!out) return fail(CVTMI_EINVAL, "cvtmi_comm_create_custom: null out");
@@ -226,6 +365,7 @@ int cvtmi_comm_destroy(cvtmi_comm_t c)
     }
     c->gather.release();
     c->sync.destroy();
+    delete[] c->h_status;
     c->magic = 0;
     delete c;
     return CVTMI_OK;
@@ -239,6 +379,13 @@ int cvtmi_comm_info(cvtmi_comm_t c, int *rank, int *world, int *transport, int64
     if (transport) *transport = c->nccl ? 1 : (c->fn ? 2 : 0);
     if (collectives) *collectives = c->n_collectives;
     if (bytes_per_rank) *bytes_per_rank = c->last_bytes_per_rank;
+    return CVTMI_OK;
+}
+
+int cvtmi_comm_slot_bytes(int64_t nq, int k, size_t *bytes)
+{
+    if (nq < 0 || k < 1 || !bytes) return fail(CVTMI_EINVAL, "cvtmi_comm_slot_bytes: bad arguments");
+    *bytes = comm_slot_bytes(nq, k);
     return CVTMI_OK;
 }
 
@@ -265,7 +412,7 @@ int cvtmi_shard_merge_topk_dev(cvtmi_comm_t c, const float *local_dist, const in
     CVTMI_TRY(comm_local_slot(c, nq, k, &sd, &si));
     CVTMI_HIP(hipMemcpyAsync(sd, local_dist, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToDevice, st));
     CVTMI_HIP(hipMemcpyAsync(si, local_ids, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
-    return comm_exchange_merge(c, nq, k, dist, ids, st);
+    return comm_exchange_merge(c, nq, k, CVTMI_OK, dist, ids, st);
 }
 
 }  // extern "C"

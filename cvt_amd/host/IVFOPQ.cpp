@@ -15,7 +15,7 @@ using namespace std;
 
 void IVFOPQ::init()
 {
-    m_h = NULL; m_imgLocation = NULL; m_comm = NULL; m_idBase = 0;
+    m_h = NULL; m_imgLocation = NULL; m_comm = NULL; m_idBase = 0; m_devCap = 0;
     m_coarseK = m_pq_m = m_pq_k = m_pq_step = m_featDim = 0;
     m_imgNum = 0; m_imgCap = 0;
 }
@@ -23,15 +23,52 @@ IVFOPQ::IVFOPQ(int maxIndexNum) : m_maxIndexNum(maxIndexNum) { init(); }
 IVFOPQ::IVFOPQ() : m_maxIndexNum(1 << 30) { init(); }
 IVFOPQ::~IVFOPQ()
 {
+    for (size_t d = 1; d < m_hs.size(); ++d) cvtmi_opq_destroy(m_hs[d]);   // (m_hs[0] == m_h)
+    for (size_t d = 0; d < m_comms.size(); ++d) cvtmi_comm_destroy(m_comms[d]);
     if (m_h) cvtmi_opq_destroy(m_h);
     delete[] m_imgLocation;
 }
 std::string IVFOPQ::lastError() const { return cvtmi_last_error(); }
 long long IVFOPQ::numEntries() const
 {
-    int64_t n = 0;
+    int64_t total = 0, n = 0;
+    if (m_hs.size() > 1) {
+        for (size_t d = 0; d < m_hs.size(); ++d) { n = 0; cvtmi_opq_ntotal(m_hs[d], &n); total += n; }
+        return total;
+    }
     if (m_h) cvtmi_opq_ntotal(m_h, &n);
     return n;
+}
+
+int IVFOPQ::SetDevices(int ndev, long long expected_rows)
+{
+    if (ndev < 1 || expected_rows < 0 || !ensureHandle() || m_hs.size() > 1 || m_comm) { printf("SetDevices: bad state or arguments\n"); return 0; }
+    if (numEntries() != 0) { printf("SetDevices: the index already holds entries\n"); return 0; }
+    if (ndev == 1) return 1;
+    int avail = 0;
+    if (cvtmi_device_count(&avail) != CVTMI_OK || avail < ndev) { printf("SetDevices: %d devices asked for, %d present\n", ndev, avail); return 0; }
+    m_devCap = std::max<long long>(1, (expected_rows + ndev - 1) / ndev);
+    // device 0 must be the one m_h lives on: re-create the handles in device order
+    cvtmi_opq_destroy(m_h); m_h = NULL;
+    std::vector<cvtmi_opq_s *> hs(ndev, (cvtmi_opq_s *)NULL);
+    bool ok = true;
+    for (int d = 0; d < ndev && ok; ++d) {
+        ok = cvtmi_set_device(d) == CVTMI_OK &&
+             cvtmi_opq_create(m_featDim, m_coarseK, m_pq_m, m_pq_k, m_coarse.data(), m_books.data(), NULL,
+                              m_reorder.empty() ? NULL : m_reorder.data(), &hs[d]) == CVTMI_OK &&
+             cvtmi_opq_set_id_base(hs[d], (long long)d * m_devCap) == CVTMI_OK;
+    }
+    std::vector<cvtmi_comm_s *> cs(ndev, (cvtmi_comm_s *)NULL);
+    ok = ok && cvtmi_comm_create_all(ndev, NULL, cs.data()) == CVTMI_OK;
+    cvtmi_set_device(0);
+    if (!ok) {
+        printf("SetDevices failed: %s\n", cvtmi_last_error());
+        for (int d = 0; d < ndev; ++d) { if (hs[d]) cvtmi_opq_destroy(hs[d]); if (cs[d]) cvtmi_comm_destroy(cs[d]); }
+        ensureHandle();
+        return 0;
+    }
+    m_hs = hs; m_comms = cs; m_h = hs[0];
+    return 1;
 }
 
 bool IVFOPQ::ensureHandle()
@@ -150,6 +187,8 @@ int IVFOPQ::SearchTopK(const float *q, int nq, int k, float *dist, long long *id
 {
     if (!ensureHandle()) return 0;
     static_assert(sizeof(long long) == sizeof(int64_t), "id width");
+    if (m_hs.size() > 1)
+        return cvtmi_opq_search_sharded_all(m_hs.data(), m_comms.data(), (int)m_hs.size(), q, nq, /*rotate=*/1, k, dist, (int64_t *)ids) == CVTMI_OK ? 1 : 0;
     if (m_comm) return cvtmi_opq_search_sharded(m_h, m_comm, q, nq, /*rotate=*/1, k, dist, (int64_t *)ids) == CVTMI_OK ? 1 : 0;
     return cvtmi_opq_search(m_h, q, nq, /*rotate=*/1, k, dist, (int64_t *)ids) == CVTMI_OK ? 1 : 0;
 }
@@ -164,6 +203,35 @@ int IVFOPQ::AddRows(const float *raw, int n)
 {
     if (n <= 0) return 1;
     if (!ensureHandle()) return 0;
+    if (m_hs.size() > 1) {   // fill the devices in order: device d owns ids [d cap, (d + 1) cap), the last one whatever is left
+        long long done = 0;
+        while (done < n) {
+            int d = 0;
+            long long held = 0;
+            for (; d < (int)m_hs.size(); ++d) {
+                int64_t have = 0;
+                cvtmi_opq_ntotal(m_hs[d], &have);
+                held = have;
+                if (d + 1 == (int)m_hs.size() || have < m_devCap) break;
+            }
+            const long long room = d + 1 == (int)m_hs.size() ? (long long)n - done : std::min<long long>(m_devCap - held, (long long)n - done);
+            cvtmi_opq_s *h = m_hs[d];
+            std::vector<uint8_t> codes((size_t)room * m_pq_m);
+            std::vector<int32_t> lists((size_t)room);
+            std::vector<float> rot((size_t)room * m_featDim);
+            const float *src = raw + (size_t)done * m_featDim;
+            if (cvtmi_set_device(d) != CVTMI_OK || cvtmi_opq_rotate(h, src, room, rot.data()) != CVTMI_OK ||
+                cvtmi_opq_encode(h, rot.data(), room, lists.data(), codes.data()) != CVTMI_OK ||
+                cvtmi_opq_add_codes(h, codes.data(), m_coarseK > 1 ? lists.data() : NULL, NULL, room) != CVTMI_OK) {
+                printf("AddRows (device %d) failed: %s\n", d, cvtmi_last_error());
+                cvtmi_set_device(0);
+                return 0;
+            }
+            done += room;
+        }
+        cvtmi_set_device(0);
+        return 1;
+    }
     std::vector<float> rot((size_t)n * m_featDim);
     std::vector<int32_t> lists(n);
     std::vector<uint8_t> codes((size_t)n * m_pq_m);

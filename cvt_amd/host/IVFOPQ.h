@@ -52,15 +52,26 @@ public:
     void SetShard(cvtmi_comm_s *comm, long long id_base);
     // rotate + encode + append n RAW rows, one entry per row (the per-vector form of IndexDatabase); 1 ok / 0 failure
     int AddRows(const float *raw, int n);
+    // ONE process, ndev GPUs (what a single-process caller like multi_frame_index_test.cpp:32-91 needs to scale): call after
+    // LoadModel and before the first AddRows.  Device d keeps rows [d * cap, (d + 1) * cap), cap = ceil(expected_rows / ndev)
+    // (the last device takes whatever comes beyond), in insertion order, so entry ids equal those of a single-GPU index;
+    // SearchTopK scans every block side by side and merges after one grouped RCCL all-gather (cvtmi_comm_create_all +
+    // cvtmi_opq_search_sharded_all).  AddRows / SearchTopK / numEntries work in this mode, the per-video calls do not.
+    // 1 ok / 0 failure (fewer devices than asked for, RCCL not loadable, entries already present).
+    int SetDevices(int ndev, long long expected_rows);
+    int numDevices() const { return (int)m_hs.size() > 1 ? (int)m_hs.size() : 1; }
 
 private:
     void init();
     bool ensureHandle();
     void queryImpl(const std::string &featFile, std::vector<std::vector<float> > &matchScore, int nk);
 
-    cvtmi_opq_s *m_h;
+    cvtmi_opq_s *m_h;                     // single-GPU handle (= device 0's in multi-device mode)
     cvtmi_comm_s *m_comm;
     long long m_idBase;
+    std::vector<cvtmi_opq_s *> m_hs;      // multi-device mode: one handle and one communicator per device
+    std::vector<cvtmi_comm_s *> m_comms;
+    long long m_devCap;
     std::vector<float> m_coarse, m_books;
     std::vector<int> m_reorder;
     int m_coarseK, m_pq_m, m_pq_k, m_pq_step, m_featDim, m_imgNum, m_maxIndexNum, m_imgCap;

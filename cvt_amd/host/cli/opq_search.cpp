@@ -4,15 +4,20 @@
 // search (retrieval/vlindex/lib/FLANN/mpi/index.h:196-226): every rank indexes a contiguous block of rows, searches it,
 // then ONE all-gather of the per-shard top-k + merge (inside libcvtmi: cvtmi_opq_search_sharded).
 //
-//   opq_search <model> <db_feat.bin> <query_feat.bin> <result.txt> [--k 100] [--gpus N] [--transport rccl|shm]
+//   opq_search <model> <db_feat.bin> <query_feat.bin> <result.txt> [--k 100] [--gpus N] [--fork] [--transport rccl|shm]
 //
 // model: LoadModel format with coarseK == 1; feature files: raw fp32 [n][D] (IVFOPQ.cpp:451-457).
-// --gpus N forks one process per GPU (rank r -> device r % device_count) BEFORE any GPU work; rank 0 draws the RCCL id
-// and shares it through a process-shared page.  --transport shm exchanges through host shared memory instead of RCCL
-// (cvtmi_comm_create_custom): the stand-in for an MPI job, and how N ranks run on a box with ONE GPU (RCCL refuses two
-// ranks on one device).  result.txt (rank 0): one line per query, "<qid> topK: id ... dists: d ..." like gt.txt
+// --gpus N: ONE process drives the N GPUs (IVFOPQ::SetDevices: ncclCommInitAll + grouped all-gathers inside libcvtmi) -- the
+// shape of the reference's own single-process mains.  --fork: one process per GPU instead (rank r -> device r %
+// device_count, forked BEFORE any GPU work; rank 0 draws the RCCL id and shares it through a process-shared page).
+// --transport shm (implies --fork) exchanges through host shared memory instead of RCCL (cvtmi_comm_create_custom): the
+// stand-in for an MPI job, and how N ranks run on a box with ONE GPU (RCCL refuses two ranks on one device).
+// A rank that fails before or inside a collective cannot leave the others waiting for ever: the library carries every
+// rank's status through the all-gather (cvtmi.h), ranks waiting for the id give up when rank 0 reports failure, and the
+// parent kills the surviving ranks as soon as one child exits with an error.  result.txt (rank 0): one line per query, "<qid> topK: id ... dists: d ..." like gt.txt
 // (brute_force.cpp:106).
 #include <pthread.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
@@ -64,6 +69,17 @@ static long long file_rows(const string &path, int D)
 static int run_rank(int rank, int world, bool use_shm, Shared *sh, const string &model, const string &db, const string &qf,
                     const string &out, int k)
 {
+    // rank 0 owes the others an answer about the id on EVERY path out of this function
+    struct IdGuard {
+        Shared *sh; bool armed;
+        ~IdGuard() { if (armed && !sh->id_ready) { sh->failed = 1; __sync_synchronize(); sh->id_ready = 1; } }
+    } guard = { sh, rank == 0 };
+    {   // inputs are checked before anybody enters a collective
+        int D0 = 0;
+        ifstream fm(model.c_str(), ios::binary);
+        fm.read((char *)&D0, sizeof(int));
+        if (!fm || D0 <= 0 || file_rows(db, D0) < 0 || file_rows(qf, D0) < 0) { fprintf(stderr, "rank %d: cannot read the model / feature files\n", rank); return 1; }
+    }
     int ndev = 0;
     if (cvtmi_device_count(&ndev) != CVTMI_OK || ndev < 1) { fprintf(stderr, "rank %d: no GPU: %s\n", rank, cvtmi_last_error()); return 1; }
     if (cvtmi_set_device(rank % ndev) != CVTMI_OK) return 1;
@@ -78,8 +94,11 @@ static int run_rank(int rank, int world, bool use_shm, Shared *sh, const string 
                 __sync_synchronize();
                 sh->id_ready = 1;
             }
-            while (!sh->id_ready) usleep(1000);
-            if (sh->failed) return 1;
+            for (int waited_ms = 0; !sh->id_ready; ++waited_ms) {
+                if (waited_ms > 120000) { fprintf(stderr, "rank %d: no RCCL id from rank 0 after 120 s\n", rank); return 1; }
+                usleep(1000);
+            }
+            if (sh->failed) { fprintf(stderr, "rank %d: rank 0 could not provide the RCCL id\n", rank); return 1; }
             if (world == 1) cvtmi_set_tuning("comm_force_rccl", 1);  // --transport rccl was asked for: go through it even alone
             if (cvtmi_comm_create(sh->id, rank, world, &comm) != CVTMI_OK) { fprintf(stderr, "rank %d: %s\n", rank, cvtmi_last_error()); return 1; }
         }
@@ -135,22 +154,69 @@ static int run_rank(int rank, int world, bool use_shm, Shared *sh, const string 
     return 0;
 }
 
+// one process, `gpus` devices: IVFOPQ::SetDevices
+static int run_single_process(int gpus, const string &model, const string &db, const string &qf, const string &out, int k)
+{
+    IVFOPQ index;
+    if (index.LoadModel(model) != 1) return 1;
+    const int D = index.dim();
+    const long long n = file_rows(db, D), nq = file_rows(qf, D);
+    if (n < 0 || nq < 0) { fprintf(stderr, "cannot stat the feature files\n"); return 1; }
+    if (index.SetDevices(gpus, n) != 1) return 1;
+    {
+        ifstream fin(db.c_str(), ios::binary);
+        const long long chunk = 1 << 18;
+        vector<float> buf;
+        for (long long r = 0; r < n; r += chunk) {
+            const long long m = min(chunk, n - r);
+            buf.resize((size_t)m * D);
+            fin.read((char *)buf.data(), sizeof(float) * buf.size());
+            if (!fin || index.AddRows(buf.data(), (int)m) != 1) { fprintf(stderr, "indexing failed\n"); return 1; }
+        }
+    }
+    vector<float> q((size_t)nq * D);
+    {
+        ifstream fin(qf.c_str(), ios::binary);
+        fin.read((char *)q.data(), sizeof(float) * q.size());
+    }
+    vector<float> dist((size_t)nq * k);
+    vector<long long> ids((size_t)nq * k);
+    if (nq > 0 && index.SearchTopK(q.data(), (int)nq, k, dist.data(), ids.data()) != 1) {
+        fprintf(stderr, "search failed: %s\n", index.lastError().c_str());
+        return 1;
+    }
+    ofstream fout(out.c_str());
+    char num[64];
+    for (long long i = 0; i < nq; ++i) {
+        fout << i << " topK: ";
+        for (int j = 0; j < k; ++j) fout << ids[(size_t)i * k + j] << " ";
+        fout << "dists: ";
+        for (int j = 0; j < k; ++j) { snprintf(num, sizeof num, "%.9g ", dist[(size_t)i * k + j]); fout << num; }
+        fout << "\n";
+    }
+    cout << "opq_search: " << n << " rows over " << index.numDevices() << " device(s) of one process, " << nq << " queries, top-" << k << endl;
+    return 0;
+}
+
 int main(int argc, char *argv[])
 {
     int k = 100, gpus = 1;
+    bool forked = false;
     string transport = "rccl";
     vector<string> pos;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--k") && i + 1 < argc) k = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--fork")) forked = true;
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--transport") && i + 1 < argc) transport = argv[++i];
         else pos.push_back(argv[i]);
     }
     if (pos.size() != 4 || k < 1 || k > 128 || gpus < 1 || (transport != "rccl" && transport != "shm")) {
-        cerr << "usage: opq_search <model> <db_feat.bin> <query_feat.bin> <result.txt> [--k 100] [--gpus N] [--transport rccl|shm]" << endl;
+        cerr << "usage: opq_search <model> <db_feat.bin> <query_feat.bin> <result.txt> [--k 100] [--gpus N] [--fork] [--transport rccl|shm]" << endl;
         return 2;
     }
     const bool use_shm = transport == "shm";
+    if (!use_shm && !forked) return run_single_process(gpus, pos[0], pos[1], pos[2], pos[3], k);
     // staging area of the shm transport: world slots of one [nq][k] (f32, i64) result; D comes from the model header
     size_t stage = 0;
     if (use_shm) {
@@ -159,7 +225,9 @@ int main(int argc, char *argv[])
         fin.read((char *)&D, sizeof(int));
         const long long nq = file_rows(pos[2], D);
         if (!fin || nq < 0) { cerr << "cannot read the model / query file" << endl; return 1; }
-        stage = (size_t)gpus * ((((size_t)nq * k * 4 + 15) & ~(size_t)15) + (((size_t)nq * k * 8 + 15) & ~(size_t)15));
+        size_t slot = 0;
+        if (cvtmi_comm_slot_bytes(nq, k, &slot) != CVTMI_OK) { cerr << cvtmi_last_error() << endl; return 1; }
+        stage = (size_t)gpus * slot;
     }
     // no GPU work before the fork: the children each own a fresh HIP runtime
     Shared *sh = (Shared *)mmap(NULL, sizeof(Shared) + stage, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
@@ -178,11 +246,18 @@ int main(int argc, char *argv[])
         if (p == 0) _exit(run_rank(r, gpus, use_shm, sh, pos[0], pos[1], pos[2], pos[3], k));
         kids.push_back(p);
     }
+    // a rank that dies leaves its peers in a barrier or a collective: the first failure ends them all
     int rc = 0;
-    for (pid_t p : kids) {
+    for (size_t left = kids.size(); left > 0; --left) {
         int st = 0;
-        waitpid(p, &st, 0);
-        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
+        const pid_t p = waitpid(-1, &st, 0);
+        if (p < 0) break;
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+            if (rc == 0)
+                for (pid_t o : kids)
+                    if (o != p) kill(o, SIGKILL);
+            rc = 1;
+        }
     }
     return rc;
 }

@@ -212,17 +212,29 @@ int cvtmi_topk_merge_dev(const float *in_dist, const int64_t *in_ids, int64_t nq
  *                          every rank into recv_dev in rank order, IN PLACE (send_dev == recv_dev + rank * bytes), ordered
  *                          after the work already enqueued on `stream` and complete, or enqueued on `stream`, on return;
  *                          0 = success.  All pointers are device pointers.
- * Collectives must be entered by all ranks in the same order; a rank whose local search fails leaves the others waiting
- * (as with any collective).  Calls on one communicator are serialised like calls on one handle. */
+ * Collectives must be entered by all ranks in the same order.  A rank whose LOCAL search fails still enters the
+ * all-gather, with its error code in its slot's status word, and every rank then returns CVTMI_ECOMM (the status words are
+ * read back after each all-gather: one stream synchronisation per sharded search; cvtmi_set_tuning("comm_check_status", 0)
+ * drops the check and the synchronisation).  Calls on one communicator are serialised like calls on one handle (the
+ * communicator's lock is taken before the handle's): drive one communicator from one thread, or issue the searches that
+ * share it in the same order on every rank. */
 #define CVTMI_COMM_ID_BYTES 128
 typedef int (*cvtmi_allgather_fn)(void *ctx, const void *send_dev, void *recv_dev, size_t bytes, void *stream);
 int cvtmi_comm_unique_id(void *id /* [CVTMI_COMM_ID_BYTES] */);
 int cvtmi_comm_create(const void *id, int rank, int world, cvtmi_comm_t *out);
 int cvtmi_comm_create_custom(cvtmi_allgather_fn fn, void *ctx, int rank, int world, cvtmi_comm_t *out);
+/* ONE process driving every GPU (the reference's callers are single processes: opq/src/multi_frame_index_test.cpp:32-91):
+ * ncclCommInitAll over `ndev` devices (devices == NULL: 0 .. ndev - 1); comms[d] is rank d of ndev on devices[d].  Use with
+ * the *_sharded_all searches below (their all-gathers leave as one ncclGroupStart / ncclGroupEnd group); each communicator is
+ * destroyed with cvtmi_comm_destroy. */
+int cvtmi_comm_create_all(int ndev, const int *devices, cvtmi_comm_t *comms /* [ndev] */);
 int cvtmi_comm_destroy(cvtmi_comm_t c);
 /* rank / world; transport: 0 none (world == 1), 1 RCCL, 2 caller-supplied; all-gathers issued so far and the bytes
  * each rank contributed to the last one.  Any pointer may be NULL. */
 int cvtmi_comm_info(cvtmi_comm_t c, int *rank, int *world, int *transport, int64_t *collectives, int64_t *bytes_per_rank);
+/* Bytes one rank contributes to the all-gather of an [nq][k] result (status word + fp32 + int64 fields, 16-byte aligned): the
+ * size a caller-supplied transport has to stage per rank. */
+int cvtmi_comm_slot_bytes(int64_t nq, int k, size_t *bytes);
 /* Row block of `rank`: [begin, end) of n_total rows, the first n_total % world ranks own one row more. */
 int cvtmi_shard_range(int64_t n_total, int rank, int world, int64_t *begin, int64_t *end);
 /* cvtmi_opq_search on a row shard: `h` holds this rank's block of rows (cvtmi_opq_set_id_base = its first row), every
@@ -232,8 +244,12 @@ int cvtmi_opq_search_sharded(cvtmi_opq_t h, cvtmi_comm_t c, const float *q, int6
                              int64_t *ids);
 int cvtmi_opq_search_sharded_dev(cvtmi_opq_t h, cvtmi_comm_t c, const float *q, int64_t nq, int rotate, int k,
                                  float *dist, int64_t *ids, void *stream);
+/* The same on one process: handles[d] = the row block of device d, comms from cvtmi_comm_create_all; host pointers. */
+int cvtmi_opq_search_sharded_all(cvtmi_opq_t *handles, cvtmi_comm_t *comms, int ndev, const float *q, int64_t nq, int rotate,
+                                 int k, float *dist, int64_t *ids);
 /* The exchange step alone, for per-shard lists produced by any search: local_dist / local_ids [nq][k] ascending
- * (distance, id) with GLOBAL ids (id < 0 = padding), ranks holding ascending id ranges. */
+ * (distance, id) with GLOBAL ids (id < 0 = padding), ranks holding ascending id ranges.  Distances are 4-byte fields: fp32,
+ * or non-negative int32 (the uint8 metric) passed as their bit patterns -- they order the same way. */
 int cvtmi_shard_merge_topk_dev(cvtmi_comm_t c, const float *local_dist, const int64_t *local_ids, int64_t nq, int k,
                                float *dist, int64_t *ids, void *stream);
 
@@ -268,6 +284,16 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
  * candidate list of the pipeline.  cvtmi_set_tuning("flat_variant", 1) allows the exact kernels only, 2 prefers the pipeline;
  * cvtmi_set_tuning("flat_f32_stream", 0 / 1 / 2) = never / choose / wherever it applies. */
 int cvtmi_flat_last_search(cvtmi_flat_t h, int *filtered, int64_t *max_candidates);
+/* Row shards of an exhaustive index (BruteforceSearch<dist_t>::searchKnn over rows split across GPUs: config 3's 5 GB of
+ * uint8 rows shard like config 4's codes).  Rows added without labels report label = id_base + row; the sharded searches
+ * return the global k best -- float distances, or the int32 distances of the uint8 metric (same 4-byte fields) -- identical
+ * on every rank and to one handle holding all rows.  See cvtmi_opq_search_sharded* for the communicator rules. */
+int cvtmi_flat_set_id_base(cvtmi_flat_t h, int64_t base);
+int cvtmi_flat_search_sharded(cvtmi_flat_t h, cvtmi_comm_t c, const void *q, int64_t nq, int k, void *dist, int64_t *labels);
+int cvtmi_flat_search_sharded_dev(cvtmi_flat_t h, cvtmi_comm_t c, const void *q, int64_t nq, int k, void *dist, int64_t *labels,
+                                  void *stream);
+int cvtmi_flat_search_sharded_all(cvtmi_flat_t *handles, cvtmi_comm_t *comms, int ndev, const void *q, int64_t nq, int k,
+                                  void *dist, int64_t *labels);
 
 /* ---------------------------------------------------------------- int8 scalar quantisation -- */
 /* Per-dimension min / (max - min) over (optionally L2-normalised) rows: what

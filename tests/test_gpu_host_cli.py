@@ -185,11 +185,12 @@ def test_hnsw_build_then_search_cli(tmp_path, golden):
         assert [int(p.split(":")[0]) for p in line.split()] == list(g[case + "_l"][qi])
 
 
-@pytest.mark.parametrize("gpus,transport", [(1, "rccl"), (2, "shm"), (3, "shm")])
+@pytest.mark.parametrize("gpus,transport", [(1, "rccl"), (2, "shm"), (3, "shm"), (1, "single")])
 def test_opq_search_cli_row_sharded(tmp_path, orc, gpus, transport):
-    """opq_search --gpus N: one process per rank (forked by the CLI), each indexes its row block of the feature file, one
+    """opq_search --gpus N --fork: one process per rank (forked by the CLI), each indexes its row block of the feature file, one
     all-gather inside libcvtmi, rank 0 writes the global top-k.  N = 1 goes through real RCCL; N > 1 on this one-GPU box
-    through the shm transport (RCCL refuses two ranks per device).  Expected = the oracle over the whole file."""
+    through the shm transport (RCCL refuses two ranks per device).  "single": the default form, ONE process driving the
+    devices through IVFOPQ::SetDevices (this box: one).  Expected = the oracle over the whole file."""
     from oracle import binding as ob
     exe = os.path.join(BIN, "opq_search")
     assert os.path.exists(exe), "host CLIs not built: __graft_entry__.build()"
@@ -206,8 +207,12 @@ def test_opq_search_cli_row_sharded(tmp_path, orc, gpus, transport):
     model = str(tmp_path / "model.bin")
     ob.write_opq_model(model, coarse, books, perm)
     x.tofile(tmp_path / "db.bin"); q.tofile(tmp_path / "q.bin")
-    out = run([exe, model, "db.bin", "q.bin", "res.txt", "--k", str(k), "--gpus", str(gpus), "--transport", transport], cwd=str(tmp_path))
-    assert ("transport %s" % transport) in out and ("all-gathers 1 x" in out), out
+    if transport == "single":
+        out = run([exe, model, "db.bin", "q.bin", "res.txt", "--k", str(k), "--gpus", str(gpus)], cwd=str(tmp_path))
+        assert "device(s) of one process" in out, out
+    else:
+        out = run([exe, model, "db.bin", "q.bin", "res.txt", "--k", str(k), "--gpus", str(gpus), "--fork", "--transport", transport], cwd=str(tmp_path))
+        assert ("transport %s" % transport) in out and ("all-gathers 1 x" in out), out
     xr, qr = orc.reorder(perm, x), orc.reorder(perm, q)
     _, codes = orc.pq_encode(xr, coarse, books)
     od, oi = orc.adc_search(qr, books, codes, k)
@@ -226,3 +231,17 @@ def test_bruteforce_mirror_incremental_sync(tmp_path):
     scratch -- ascending labels are appended to the device copy, anything else re-sorts it (cvt_amd/host/cli/bf_sync_check.cpp)."""
     out = run([os.path.join(BIN, "bf_sync_check")], cwd=str(tmp_path))
     assert out.strip().endswith("OK"), out
+
+
+def test_opq_search_cli_failing_rank_does_not_hang(tmp_path):
+    """a rank that fails (here: every rank, the model file does not exist -- rank 0 before it could publish the RCCL id) must not
+    leave its peers or the parent waiting: the CLI comes back with a non-zero status well inside the timeout"""
+    import subprocess, time
+    exe = os.path.join(BIN, "opq_search")
+    np.zeros((10, 128), np.float32).tofile(tmp_path / "db.bin")
+    t0 = time.time()
+    for extra in (["--fork", "--transport", "rccl"], ["--fork", "--transport", "shm"]):
+        p = subprocess.run([exe, "missing_model.bin", "db.bin", "db.bin", "res.txt", "--gpus", "3"] + extra, cwd=str(tmp_path),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+        assert p.returncode != 0
+    assert time.time() - t0 < 100

@@ -53,7 +53,7 @@ def test_world1_through_rccl(orc):
         assert torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32))
     inf = comm.info()
     assert inf["collectives"] == 3, inf  # ONE all-gather per search
-    assert inf["bytes_per_rank"] == ((37 * 100 * 4 + 15) // 16 * 16) + ((37 * 100 * 8 + 15) // 16 * 16)
+    assert inf["bytes_per_rank"] == 16 + ((37 * 100 * 4 + 15) // 16 * 16) + ((37 * 100 * 8 + 15) // 16 * 16)   # status word + lists
     od, oi = orc.adc_search(q, books, codes, 100)
     assert np.array_equal(oi, i1.cpu().numpy()) and np.array_equal(bits(od), bits(d1.cpu().numpy()))
     # the host-pointer entry and the exchange step alone
@@ -139,3 +139,135 @@ def test_multi_rank_one_gpu_matches_single_handle(world, n, nq, tmp_path, orc):
             assert np.array_equal(z["i%d" % k], i0), (world, n, k, r)
             assert np.array_equal(bits(z["d%d" % k]), bits(d0)), (world, n, k, r)
     one.close()
+
+
+def test_one_process_all_devices(orc):
+    """cvtmi_comm_create_all (ncclCommInitAll) + the *_sharded_all searches: one process, one handle and one communicator per
+    device, grouped all-gathers -- on this box over its single GPU (ndev = 1 through real RCCL); OPQ and flat (fp32 + uint8)"""
+    import torch
+    import cvt_amd
+    nd = torch.cuda.device_count()
+    comms = cvt_amd.Comm.create_all(nd)
+    assert [c.info()["transport"] for c in comms] == ["rccl"] * nd and comms[0].info()["world"] == nd
+    books, codes, q = _case(7, 60_000, 21, dup=2)
+    idxs = []
+    for d in range(nd):
+        a, b = cvt_amd.shard_range(codes.shape[0], d, nd)
+        with torch.cuda.device(d):
+            ix = cvt_amd.OpqIndex(np.zeros((1, 128), np.float32), books)
+            ix.add_codes(torch.from_numpy(codes[a:b]).cuda(d)); ix.set_id_base(a)
+        idxs.append(ix)
+    dd, ii = cvt_amd.search_sharded_all(idxs, comms, q, 100, rotate=False)
+    od, oi = orc.adc_search(q, books, codes, 100)
+    assert np.array_equal(ii, oi) and np.array_equal(bits(dd), bits(od))
+    assert comms[0].info()["collectives"] == 1
+    rng = np.random.default_rng(3)
+    for metric, D in ((2, 64), (0, 32)):
+        n = 30_000
+        x = rng.integers(0, 256, size=(n, D), dtype=np.uint8) if metric == 2 else rng.normal(size=(n, D)).astype(np.float32)
+        qq = x[rng.integers(0, n, 9)].copy()
+        fl = []
+        for d in range(nd):
+            a, b = cvt_amd.shard_range(n, d, nd)
+            with torch.cuda.device(d):
+                f = cvt_amd.FlatIndex(metric, D); f.add(x[a:b]); f.set_id_base(a)
+            fl.append(f)
+        fd, fi = cvt_amd.search_sharded_all(fl, comms, qq, 10)
+        odf, odi, oif = orc.flat_search(metric, x, qq, 10)
+        assert np.array_equal(fi, oif)
+        assert np.array_equal(fd, odi) if metric == 2 else np.array_equal(bits(fd), bits(odf))
+        for f in fl:
+            f.close()
+    # a device whose local search fails: every caller gets CVTMI_ECOMM, nobody hangs
+    cvt_amd.set_tuning("comm_inject_failure", nd - 1)
+    try:
+        with pytest.raises(cvt_amd.CvtmiError, match="error -6"):
+            cvt_amd.search_sharded_all(idxs, comms, q, 10, rotate=False)
+    finally:
+        cvt_amd.set_tuning("comm_inject_failure", -1)
+    dd2, ii2 = cvt_amd.search_sharded_all(idxs, comms, q, 100, rotate=False)   # and the communicators keep working
+    assert np.array_equal(ii2, oi)
+    for c in comms:
+        c.close()
+    for ix in idxs:
+        ix.close()
+
+
+FLAT_WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["CVT_ROOT"])
+import cvt_amd
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+z = np.load(os.environ["CVT_CASE"])
+x, q, metric, k = z["x"], z["q"], int(z["metric"]), int(z["k"])
+a, b = cvt_amd.shard_range(x.shape[0], rank, world)
+comm = cvt_amd.Comm.over_torch_group(rank, world)
+ix = cvt_amd.FlatIndex(metric, x.shape[1])
+if b > a:
+    ix.add(torch.from_numpy(x[a:b]).cuda())
+ix.set_id_base(a)
+qd = torch.from_numpy(q).cuda()
+d, i = ix.search_sharded(comm, qd, k)
+torch.cuda.synchronize()
+out = {"d": d.cpu().numpy(), "i": i.cpu().numpy()}
+# a rank whose local search fails: EVERY rank must come back with CVTMI_ECOMM (-6) instead of waiting in the collective
+cvt_amd.set_tuning("comm_inject_failure", world - 1)
+try:
+    ix.search_sharded(comm, qd, k)
+    out["failed"] = np.array(0)
+except cvt_amd.CvtmiError as e:
+    out["failed"] = np.array(1 if "error -6" in str(e) else -1)
+cvt_amd.set_tuning("comm_inject_failure", -1)
+d2, i2 = ix.search_sharded(comm, qd, k)          # the communicator is still usable
+torch.cuda.synchronize()
+out["again"] = np.array(int(torch.equal(i2, i)))
+np.savez(os.environ["CVT_OUT"] + ".%d.npz" % rank, **out)
+comm.close(); ix.close()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world,metric,D,n", [(2, 2, 512, 50_001), (3, 2, 64, 9_000), (2, 1, 128, 40_000), (3, 0, 36, 7_001)])
+def test_flat_row_shards_match_single_handle(world, metric, D, n, tmp_path, orc):
+    """cvtmi_flat_search_sharded_dev at world 2 / 3 on one GPU (custom transport): uint8 (int32 distances through the fp32 fields)
+    and fp32 metrics, exact duplicates on both sides of every shard boundary, against the checker over all rows; then a rank that
+    fails locally makes every rank return CVTMI_ECOMM, and the next search works again"""
+    rng = np.random.default_rng(world * 1000 + D)
+    nq, k = 13, 20
+    if metric == 2:
+        x = rng.integers(0, 256, size=(n, D), dtype=np.uint8); q = rng.integers(0, 256, size=(nq, D), dtype=np.uint8)
+    else:
+        x = rng.normal(size=(n, D)).astype(np.float32); q = rng.normal(size=(nq, D)).astype(np.float32)
+    for r in range(1, world):
+        b = (n // world) * r + min(r, n % world)
+        x[b - 3:b + 3] = x[b - 3]
+        q[r] = x[b - 3]
+    case = str(tmp_path / "case.npz")
+    np.savez(case, x=x, q=q, metric=np.array(metric), k=np.array(k))
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   CVT_ROOT=ROOT, CVT_CASE=case, CVT_OUT=str(tmp_path / "out"))
+        procs.append(subprocess.Popen([sys.executable, "-c", FLAT_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for pp in procs:
+                pp.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    od, odi, oi = orc.flat_search(metric, x, q, k)
+    for r in range(world):
+        z = np.load(str(tmp_path / "out") + ".%d.npz" % r)
+        assert np.array_equal(z["i"], oi), (world, metric, r)
+        assert np.array_equal(z["d"], odi) if metric == 2 else np.array_equal(bits(z["d"]), bits(od)), (world, metric, r)
+        assert int(z["failed"]) == 1 and int(z["again"]) == 1, (r, int(z["failed"]), int(z["again"]))
