@@ -314,6 +314,29 @@ class Comm:
 
         return cls.custom(fn, rank, world)
 
+    @classmethod
+    def over_rendezvous(cls, rv):
+        """All-gather staged through the host over a cvt_amd.rendezvous.Rendezvous (plain TCP, no torch.distributed): the
+        debug transport that lets several ranks share ONE GPU (bench.py --backend host)."""
+        import torch
+
+        def fn(send, recv, nbytes, stream):
+            st = torch.cuda.current_stream()
+            assert (stream or 0) == st.cuda_stream, "library work was enqueued on another stream than torch's current one"
+            st.synchronize()
+            hip = C.CDLL("libamdhip64.so")
+            mine = (C.c_char * nbytes)()
+            if hip.hipMemcpy(mine, C.c_void_p(send), C.c_size_t(nbytes), C.c_int(2)) != 0:
+                return 1
+            allb = rv.allgather_bytes(mine.raw)
+            if len(allb) != nbytes * rv.world:
+                return 2
+            if hip.hipMemcpy(C.c_void_p(recv), allb, C.c_size_t(len(allb)), C.c_int(1)) != 0:
+                return 1
+            return 0
+
+        return cls.custom(fn, rv.rank, rv.world)
+
     def info(self):
         r, w, t = C.c_int(0), C.c_int(0), C.c_int(0)
         n, b = C.c_int64(0), C.c_int64(0)
@@ -605,7 +628,7 @@ def sq8_train(x, l2norm=True):
 
 
 def sq8_encode(vmin, vdiff, x, l2norm=True):
-    """Returns codes; x is normalised IN PLACE when l2norm (reference behaviour)."""
+    """Returns codes; x is normalised IN PLACE when l2norm is True / 1 (reference behaviour), left alone when l2norm == 2."""
     n, d = x.shape
     if _is_torch(x):
         import torch

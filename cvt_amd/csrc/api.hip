@@ -1349,7 +1349,7 @@ int cvtmi_sq8_encode_dev(const float *vmin, const float *vdiff, int d, float *x,
     Tmp den;
     const bool two_pass = l2norm && !sq8_single_pass(d, x, codes, vmin, vdiff);
     if (two_pass) CVTMI_TRY(den.alloc((size_t)n * sizeof(float)));
-    CVTMI_TRY(launch_sq8_encode_rows(vmin, vdiff, d, x, n, l2norm, 1, codes, den.as<float>(), st));
+    CVTMI_TRY(launch_sq8_encode_rows(vmin, vdiff, d, x, n, l2norm ? 1 : 0, l2norm == 2 ? 0 : 1, codes, den.as<float>(), st));
     if (two_pass) CVTMI_HIP(hipStreamSynchronize(st));  // the temporary dies with this frame
     return CVTMI_OK;
 }
@@ -1365,7 +1365,7 @@ int cvtmi_sq8_encode(const float *vmin, const float *vdiff, int d, float *x, int
     CVTMI_TRY(dc.alloc((size_t)n * d));
     CVTMI_TRY(cvtmi_sq8_encode_dev(dmin.as<float>(), ddiff.as<float>(), d, dx.as<float>(), n, l2norm, dc.as<uint8_t>(), nullptr));
     CVTMI_HIP(hipMemcpy(codes, dc.p, (size_t)n * d, hipMemcpyDeviceToHost));
-    if (l2norm) CVTMI_HIP(hipMemcpy(x, dx.p, (size_t)n * d * sizeof(float), hipMemcpyDeviceToHost));
+    if (l2norm == 1) CVTMI_HIP(hipMemcpy(x, dx.p, (size_t)n * d * sizeof(float), hipMemcpyDeviceToHost));
     return CVTMI_OK;
 }
 

@@ -303,8 +303,9 @@ int cvtmi_sq8_train(const float *x, int64_t n, int d, int l2norm, float *vmin, f
 int cvtmi_sq8_train_dev(const float *x, int64_t n, int d, int l2norm, float *vmin, float *vdiff,
                         void *stream);
 /* Int8Quan::Int8Encode arithmetic (scalar_quantization/scalar_quantization/int8_quan.cc:72-94)
- * over n rows; with l2norm != 0 each row of x is L2-normalised IN PLACE first (:46-56), as the
- * reference does to its caller's buffer. */
+ * over n rows; with l2norm == 1 each row of x is L2-normalised IN PLACE first (:46-56), as the
+ * reference does to its caller's buffer; l2norm == 2 encodes the normalised rows but leaves x as it
+ * was (same codes, 4 d bytes of write traffic per row less: for callers that do not read x again). */
 int cvtmi_sq8_encode(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm,
                      uint8_t *codes);
 int cvtmi_sq8_encode_dev(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm,

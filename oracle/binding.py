@@ -361,6 +361,18 @@ class RefFlat:
         return d, i
 
 
+    def ip_search_timed(self, data, queries, k):
+        """the reference's BruteforceSearch<float> + InnerProductSpace: (dist, labels, seconds of addPoint, seconds of searchKnn)"""
+        data = _f32(data); queries = _f32(queries)
+        d = np.empty((queries.shape[0], k), dtype=np.float32)
+        i = np.empty((queries.shape[0], k), dtype=np.int64)
+        ta, ts = C.c_double(0), C.c_double(0)
+        self.ip.ref_bf_ip_search_timed(C.c_int(data.shape[1]), _p(data, C.c_float), C.c_int64(data.shape[0]), _p(queries, C.c_float),
+                                       C.c_int64(queries.shape[0]), C.c_int64(k), _p(d, C.c_float), _p(i, C.c_int64),
+                                       C.byref(ta), C.byref(ts))
+        return d, i, ta.value, ts.value
+
+
 class RefHnsw:
     """The reference's HierarchicalNSW compiled in place (oracle/_ref/libref_hnsw.so)."""
     def __init__(self):
