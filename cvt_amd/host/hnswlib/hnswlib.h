@@ -1,7 +1,8 @@
 // hnswlib.h -- the plugin interfaces of the reference (brute_force_search/src/hnswlib.hpp:22-58), unchanged in
 // shape: SpaceInterface<MTYPE>, DISTFUNC<MTYPE>, AlgorithmInterface<dist_t>, labeltype.  A space additionally
 // says which device metric it stands for; searches evaluate distances in the HIP kernels, never in a host loop
-// (the one host algorithm is HNSW graph construction, hnswalg.h, sequential in the reference as well).
+// (the one host algorithm is HNSW graph construction, hnswalg.h, sequential in the reference as well);
+// get_dist_func() hands out a host function for single distances, as the reference's spaces do.
 #pragma once
 #include <queue>
 #include <stdexcept>
@@ -35,12 +36,51 @@ public:
     virtual ~AlgorithmInterface() {}
 };
 
-// The reference hands out CPU distance functions through get_dist_func(); this build has no CPU path, so
-// the function a space returns only reports that fact if something calls it.
-template <typename MTYPE> static MTYPE device_only_dist(const void *, const void *, const void *)
+// get_dist_func() of the three built-in spaces: host functions with the summation order of the reference's own builds (the
+// order the device kernels reproduce, csrc/dist_f32.h), for callers that evaluate single distances through the plugin
+// seam -- recall harnesses like hnsw_sifts_retrieval/makeIdx.cpp:231-285.  Searches never come here: searchKnn runs on the
+// MI355X.  Separate multiply and add (the file is built with -ffp-contract=off), so the bits match the device's.
+//   inner product  dim % 4 == 0: four lane accumulators, 1 - (((a0 + a1) + a2) + a3)   (space_ip.hpp:84-131, :168-206: the SSE
+//                  branches its CMake flags build); otherwise the scalar loop (:25-34)
+//   squared L2     dim % 16 == 0: eight lanes summed left to right (space_l2.h:46-73, USE_AVX is hard-defined at :12);
+//                  dim % 4 == 0: four lanes (:123-151); otherwise the scalar loop (:26-37)
+//   uint8 L2       groups of four bytes, a dim % 4 tail is dropped (:198-215); exact integers
+static float host_dist_ip(const void *pa, const void *pb, const void *pd)
 {
-    throw std::runtime_error("cvt_amd: distances are evaluated on the MI355X (BruteforceSearch::searchKnn); "
-                             "there is no host distance function");
+    const float *a = (const float *)pa, *b = (const float *)pb;
+    const size_t d = *(const size_t *)pd;
+    if (d % 4 == 0) {
+        float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        for (size_t i = 0; i < d; i += 4)
+            for (int l = 0; l < 4; ++l) { const float p = a[i + l] * b[i + l]; acc[l] = acc[l] + p; }
+        float s = acc[0] + acc[1];
+        s = s + acc[2];
+        s = s + acc[3];
+        return 1.0f - s;
+    }
+    float s = 0.0f;
+    for (size_t i = 0; i < d; ++i) { const float p = a[i] * b[i]; s = s + p; }
+    return 1.0f - s;
+}
+static float host_dist_l2(const void *pa, const void *pb, const void *pd)
+{
+    const float *a = (const float *)pa, *b = (const float *)pb;
+    const size_t d = *(const size_t *)pd;
+    const int lanes = d % 16 == 0 ? 8 : (d % 4 == 0 ? 4 : 1);
+    float acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (size_t i = 0; i < d; i += lanes)
+        for (int l = 0; l < lanes; ++l) { const float t = a[i + l] - b[i + l]; const float p = t * t; acc[l] = acc[l] + p; }
+    float s = acc[0];
+    for (int l = 1; l < lanes; ++l) s = s + acc[l];
+    return s;
+}
+static int host_dist_l2u8(const void *pa, const void *pb, const void *pd)
+{
+    const unsigned char *a = (const unsigned char *)pa, *b = (const unsigned char *)pb;
+    const size_t d = *(const size_t *)pd & ~(size_t)3;
+    int s = 0;
+    for (size_t i = 0; i < d; ++i) { const int t = (int)a[i] - (int)b[i]; s += t * t; }
+    return s;
 }
 }  // namespace hnswlib
 

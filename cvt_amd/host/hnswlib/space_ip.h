@@ -6,7 +6,7 @@ class InnerProductSpace : public SpaceInterface<float> {
 public:
     InnerProductSpace(size_t dim) : data_size_(dim * sizeof(float)), dim_(dim) {}
     size_t get_data_size() { return data_size_; }
-    DISTFUNC<float> get_dist_func() { return device_only_dist<float>; }
+    DISTFUNC<float> get_dist_func() { return host_dist_ip; }
     void *get_dist_func_param() { return &dim_; }
     int device_metric() { return 0; /* CVTMI_METRIC_IP */ }
 };

@@ -7,7 +7,7 @@ class L2Space : public SpaceInterface<float> {
 public:
     L2Space(size_t dim) : data_size_(dim * sizeof(float)), dim_(dim) {}
     size_t get_data_size() { return data_size_; }
-    DISTFUNC<float> get_dist_func() { return device_only_dist<float>; }
+    DISTFUNC<float> get_dist_func() { return host_dist_l2; }
     void *get_dist_func_param() { return &dim_; }
     int device_metric() { return 1; /* CVTMI_METRIC_L2F */ }
 };
@@ -16,7 +16,7 @@ class L2SpaceI : public SpaceInterface<int> {
 public:
     L2SpaceI(size_t dim) : data_size_(dim * sizeof(unsigned char)), dim_(dim) {}
     size_t get_data_size() { return data_size_; }
-    DISTFUNC<int> get_dist_func() { return device_only_dist<int>; }
+    DISTFUNC<int> get_dist_func() { return host_dist_l2u8; }
     void *get_dist_func_param() { return &dim_; }
     int device_metric() { return 2; /* CVTMI_METRIC_L2U8 */ }
 };
