@@ -417,10 +417,68 @@ __global__ __launch_bounds__(kBlock) void sq8_decode_any_kernel(const float *__r
     }
 }
 
+// Decode through a table.  A column has only 256 possible outputs, and the per-element arithmetic above is ~10 fp64
+// instructions -- more vector time than the HBM time of the 5 bytes the element moves.  A workgroup therefore takes a slab of
+// 128 columns, evaluates all 128 x 256 outputs once (the arithmetic above, bit for bit) into LDS as lut[j][byte][l] (column
+// 4 l + j of the slab: the 32 lanes of a half wave read 32 consecutive words whatever their bytes are -- no bank conflict), and
+// streams its share of the rows: a half wave per row, a lane loads one dword of codes, looks its four bytes up and stores one
+// float4.  128 KB of LDS, one 512-thread workgroup per CU, DEC_U rows per lane in flight.
+constexpr int DEC_NT = 512, DEC_U = 8, DEC_SLAB = 128;
+__global__ __launch_bounds__(DEC_NT) void sq8_decode_lut_kernel(const float *__restrict__ vmin, const float *__restrict__ vdiff, int d,
+                                                                const uint8_t *__restrict__ codes, int64_t n, float *__restrict__ x, int row_splits)
+{
+    extern __shared__ float dec_lut[];   // [4][256][32]
+    const int tid = threadIdx.x;
+    const int slab = blockIdx.x / row_splits, rs = blockIdx.x % row_splits;
+    const int col0 = slab * DEC_SLAB;
+    for (int e = tid; e < 4 * 256 * 32; e += DEC_NT) {
+        const int l = e & 31, b = (e >> 5) & 255, j = e >> 13;
+        const int c = col0 + 4 * l + j;
+        float v = 0.0f;
+        if (c < d) {
+            const float df = vdiff[c];
+            const float m = fabsf(df);
+            v = sq8_decode_one(vmin[c], df, (m >= 0x1p-100f && m <= 0x1p100f) || m == 0.0f, (uint32_t)b);
+        }
+        dec_lut[e] = v;
+    }
+    __syncthreads();
+    const int l = tid & 31, hw = tid >> 5;                     // 16 half waves
+    if (col0 + 4 * l >= d) return;                             // (d % 4 == 0: a lane's four columns are all in or all out)
+    const int64_t rows_per = (n + row_splits - 1) / row_splits;
+    const int64_t r_begin = rows_per * rs, r_end = r_begin + rows_per < n ? r_begin + rows_per : n;
+    const float *t0 = dec_lut + l, *t1 = dec_lut + 8192 + l, *t2 = dec_lut + 16384 + l, *t3 = dec_lut + 24576 + l;
+    for (int64_t r0 = r_begin + hw; r0 < r_end; r0 += (int64_t)16 * DEC_U) {
+        uint32_t w[DEC_U];
+#pragma unroll
+        for (int u = 0; u < DEC_U; ++u) {
+            const int64_t r = r0 + 16 * u;
+            w[u] = r < r_end ? *reinterpret_cast<const uint32_t *>(codes + r * d + col0 + 4 * l) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < DEC_U; ++u) {
+            const int64_t r = r0 + 16 * u;
+            const float4 o = make_float4(t0[(w[u] & 0xffu) * 32], t1[((w[u] >> 8) & 0xffu) * 32], t2[((w[u] >> 16) & 0xffu) * 32],
+                                         t3[(w[u] >> 24) * 32]);
+            if (r < r_end) *reinterpret_cast<float4 *>(x + r * d + col0 + 4 * l) = o;
+        }
+    }
+}
+
 int launch_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x,
                       hipStream_t st)
 {
     if (n <= 0) return CVTMI_OK;
+    if ((d & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)codes & 3) == 0 && n >= 16384) {
+        const int slabs = (d + DEC_SLAB - 1) / DEC_SLAB;
+        int rs = (256 + slabs - 1) / slabs;                    // one workgroup per CU
+        if ((int64_t)rs * 2048 > n) rs = (int)std::max<int64_t>(1, n / 2048);
+        const size_t lds = 4 * 256 * 32 * sizeof(float);
+        CVTMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sq8_decode_lut_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(sq8_decode_lut_kernel, dim3((unsigned)(slabs * rs)), dim3(DEC_NT), lds, st, vmin, vdiff, d, codes, n, x, rs);
+        CVTMI_HIP(hipGetLastError());
+        return CVTMI_OK;
+    }
     int64_t blocks = (n + EW_ROWS - 1) / EW_ROWS;
     if (blocks > 256 * 16) blocks = 256 * 16;
     const bool vec = (d & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)codes & 3) == 0 &&

@@ -653,3 +653,28 @@ def test_flat_f32_stream_shared_ring_variants(amd, share):
         ix.close()
     finally:
         amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_share", 0)
+
+
+@pytest.mark.parametrize("d,n", [(512, 20_000), (256, 17_001), (128, 40_000), (100, 16_385), (516, 16_400), (4, 70_000)])
+def test_sq8_decode_through_table(amd, orc, d, n):
+    """>= 16384 rows decode through the per-column tables in LDS (sq8_decode_lut_kernel): every byte value of every column,
+    slabs that end inside a row, hard vdiff values (zero, all-ones significand, tiny, huge) -- bit for bit with the checker's
+    double arithmetic; and the no-write-back form of the normalising encode gives the same codes and leaves x alone"""
+    rng = np.random.default_rng(d + n)
+    vmin = (rng.normal(size=d) * np.exp2(rng.integers(-20, 20, size=d))).astype(np.float32)
+    vdiff = np.abs(rng.normal(size=d) * np.exp2(rng.integers(-20, 20, size=d))).astype(np.float32)
+    vdiff[0] = 0.0
+    vdiff[1 % d] = np.frombuffer(np.uint32(0x3d7fffff).tobytes(), np.float32)[0]
+    vdiff[2 % d] = np.float32(1e-41)
+    vdiff[3 % d] = np.float32(1e30)
+    codes = rng.integers(0, 256, size=(n, d), dtype=np.uint8)
+    codes[:256] = np.arange(256, dtype=np.uint8)[:, None]          # every byte value in every column
+    dec = amd.sq8_decode(vmin, vdiff, codes)
+    assert np.array_equal(bits(dec), bits(orc.sq8_decode(vmin, vdiff, codes)))
+    if d in (512, 256, 100):
+        x = np.abs(rng.normal(size=(5000, d))).astype(np.float32)
+        tv, td = amd.sq8_train(x, l2norm=True)
+        x1, x2 = x.copy(), x.copy()
+        c1 = amd.sq8_encode(tv, td, x1, l2norm=True)
+        c2 = amd.sq8_encode(tv, td, x2, l2norm=2)
+        assert np.array_equal(c1, c2) and np.array_equal(bits(x2), bits(x)) and not np.array_equal(bits(x1), bits(x))
