@@ -5,6 +5,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <shared_mutex>
 #include <functional>
 #include <mutex>
 #include <new>
@@ -78,26 +81,102 @@ struct cvtmi_opq_s {
     int last_qt = 0, last_splits = 0;
 };
 
+// per-call scratch of a flat search.  A handle keeps a small pool of these: a search leases one for the duration of the call, so
+// searches on one handle overlap -- on the host (several threads inside the library) and on the device (several streams).  The
+// set remembers the stream it was last used on and an event recorded when that call returned: the next lessee on ANOTHER
+// stream waits for the event first.
+struct FlatScratch {
+    DevBuf s_part_d, s_part_id, s_gthr, s_stage;
+    DevBuf f_stats, f_thr, f_marg, f_cnt, f_cand, f_sd, f_si, f_sd2, f_si2, f_seld, f_seli;   // matrix-core filter pipelines
+    DevBuf fs_redo, fs_scratch;                                                                // fp32 stream
+    DevBuf io_q, io_d, io_i;                                                                   // staging of the host-pointer entry
+    hipStream_t own = nullptr;      // stream of the host-pointer entry (created on first use)
+    hipEvent_t done = nullptr;
+    hipStream_t last = nullptr;
+    bool pending = false, busy = false;
+    void release_all()
+    {
+        for (DevBuf *b : { &s_part_d, &s_part_id, &s_gthr, &s_stage, &f_stats, &f_thr, &f_marg, &f_cnt, &f_cand, &f_sd, &f_si, &f_sd2,
+                           &f_si2, &f_seld, &f_seli, &fs_redo, &fs_scratch, &io_q, &io_d, &io_i })
+            b->release();
+        if (own) (void)hipStreamDestroy(own);
+        if (done) (void)hipEventDestroy(done);
+        own = nullptr; done = nullptr;
+    }
+};
+
 struct cvtmi_flat_s {
     int device = 0;
-    HandleSync sync;
+    // searches hold `rw` shared, everything that changes the index (add, reset, the lazily built operand copies) exclusively
+    std::shared_timed_mutex rw;
+    std::mutex pool_mu;
+    std::vector<FlatScratch *> pool;
+    hipEvent_t mutated = nullptr;   // recorded on the stream of the last mutation: searches on other streams wait for it
+    hipStream_t mut_stream = nullptr;
+    bool mut_pending = false;
     int metric = 0, D = 0;
     size_t row_bytes = 0;
     DevBuf data, labels, norms;  // norms: int32 |x-128|^2 per row, uint8 metric with D % 32 == 0 (MFMA path)
+    DevBuf add_stage;            // staging of host rows on their way into the blocked layout
     int64_t n = 0;
     int64_t id_base = 0;   // row r reports label id_base + r while labels are implicit (row shards, cvtmi_flat_set_id_base)
     bool identity = true;  // label == row
-    DevBuf s_part_d, s_part_id, s_gthr, s_stage;
     // matrix-core filter of the fp32 search (flat_mfma.hip): bf16 operand copy of the rows, built on first use
-    DevBuf f_pack, f_bias, f_stats, f_thr, f_marg, f_cnt, f_cand, f_sd, f_si, f_sd2, f_si2, f_seld, f_seli;
+    DevBuf f_pack, f_bias, f_istats;   // f_istats: [0] max |x|^2, [1] rows with a non-finite value (of the operand copy)
     int64_t f_pack_n = -1;      // rows the copy covers (-1: none)
     bool f_nonfinite = false;   // a row holds inf / NaN: the filter is not used
-    int f_last_filtered = 0;    // the last search was answered through the filter (1) / the fp32 stream (2)
-    int64_t f_last_worst = 0;   // its largest candidate list
-    // fp32 stream (flat_f32_stream.hip): per-row score bias, statistics of the rows ([0] max |x|^2, [1] non-finite rows), redo flags
-    DevBuf fs_bias, fs_stats, fs_redo, fs_scratch;
+    std::atomic<int> f_last_filtered{0};    // how the last search was answered (0 exact, 1 filter pipeline, 2 fp32 stream)
+    std::atomic<long long> f_last_worst{0};  // its largest candidate list
+    // fp32 stream (flat_f32_stream.hip): per-row score bias, statistics of the rows ([0] max |x|^2, [1] non-finite rows)
+    DevBuf fs_bias, fs_stats;
     int64_t fs_stats_n = -1;    // index size the host copy of the statistics belongs to
     bool fs_nonfinite = false;
+};
+
+// a scratch set for the duration of one call on stream st (nullptr + host = true: the set's own stream)
+struct FlatLease {
+    cvtmi_flat_s *h;
+    FlatScratch *s = nullptr;
+    hipStream_t st;
+    int open(cvtmi_flat_s *handle, hipStream_t stream, bool host)
+    {
+        h = handle; st = stream;
+        {
+            std::lock_guard<std::mutex> g(h->pool_mu);
+            FlatScratch *any = nullptr;
+            for (FlatScratch *c : h->pool) {
+                if (c->busy) continue;
+                if (!host && c->pending && c->last == stream) { s = c; break; }   // same stream as before: nothing to wait for
+                if (!any) any = c;
+            }
+            if (!s) s = any;
+            if (!s) {
+                s = new (std::nothrow) FlatScratch();
+                if (!s) return fail(CVTMI_ENOMEM, "flat search: out of host memory");
+                h->pool.push_back(s);
+            }
+            s->busy = true;
+        }
+        if (host) {
+            if (!s->own && hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking) != hipSuccess) { close(false); return fail(CVTMI_EHIP, "hipStreamCreate failed"); }
+            st = s->own;
+        }
+        if (s->pending && s->last != st) (void)hipStreamWaitEvent(st, s->done, 0);
+        if (h->mut_pending && h->mut_stream != st) (void)hipStreamWaitEvent(st, h->mutated, 0);
+        return CVTMI_OK;
+    }
+    void close(bool used = true)
+    {
+        if (!s) return;
+        if (used) {
+            if (!s->done) (void)hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+            if (s->done && hipEventRecord(s->done, st) == hipSuccess) { s->last = st; s->pending = true; }
+        }
+        std::lock_guard<std::mutex> g(h->pool_mu);
+        s->busy = false;
+        s = nullptr;
+    }
+    ~FlatLease() { close(); }
 };
 
 static int use_device(int dev)
@@ -869,11 +948,10 @@ int cvtmi_flat_destroy(cvtmi_flat_t h)
     if (!h) return CVTMI_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf *b : { &h->data, &h->labels, &h->norms, &h->s_part_d, &h->s_part_id, &h->s_gthr, &h->s_stage, &h->f_pack, &h->f_bias,
-                       &h->f_stats, &h->f_thr, &h->f_marg, &h->f_cnt, &h->f_cand, &h->f_sd, &h->f_si, &h->f_sd2, &h->f_si2, &h->f_seld,
-                       &h->f_seli, &h->fs_bias, &h->fs_stats, &h->fs_redo, &h->fs_scratch })
+    for (DevBuf *b : { &h->data, &h->labels, &h->norms, &h->add_stage, &h->f_pack, &h->f_bias, &h->f_istats, &h->fs_bias, &h->fs_stats })
         b->release();
-    h->sync.destroy();
+    for (FlatScratch *c : h->pool) { c->release_all(); delete c; }
+    if (h->mutated) (void)hipEventDestroy(h->mutated);
     delete h;
     return CVTMI_OK;
 }
@@ -918,9 +996,9 @@ static int flat_add_common(cvtmi_flat_t h, const void *x, const int64_t *labels,
     if (blocked) {
         const float *src = static_cast<const float *>(x);
         if (kind == hipMemcpyHostToDevice || ((uintptr_t)x & 15) != 0) {  // staged: host rows, or a device pointer off 16 bytes
-            CVTMI_TRY(h->s_stage.reserve((size_t)n * h->row_bytes));
-            CVTMI_HIP(hipMemcpyAsync(h->s_stage.p, x, (size_t)n * h->row_bytes, kind, st));
-            src = h->s_stage.as<float>();
+            CVTMI_TRY(h->add_stage.reserve((size_t)n * h->row_bytes));
+            CVTMI_HIP(hipMemcpyAsync(h->add_stage.p, x, (size_t)n * h->row_bytes, kind, st));
+            src = h->add_stage.as<float>();
         }
         CVTMI_TRY(launch_flat_block(src, n, h->D, h->n, h->data.as<float>(), st));
         if (flat_f32_stream_qmax(h->D) > 0) {   // score bias + row statistics of the streaming search, padding rows zeroed
@@ -954,15 +1032,37 @@ static int flat_add_common(cvtmi_flat_t h, const void *x, const int64_t *labels,
     return CVTMI_OK;
 }
 
+// a mutation on stream st: exclusive, ordered after every search that is still in flight on another stream, and searches
+// that come later on other streams wait for it (FlatLease::open)
+struct FlatMutation {
+    cvtmi_flat_s *h;
+    hipStream_t st;
+    std::unique_lock<std::shared_timed_mutex> lk;
+    FlatMutation(cvtmi_flat_s *handle, hipStream_t stream) : h(handle), st(stream), lk(handle->rw)
+    {
+        std::lock_guard<std::mutex> g(h->pool_mu);
+        for (FlatScratch *c : h->pool)
+            if (c->pending && c->last != st) (void)hipStreamWaitEvent(st, c->done, 0);
+        if (h->mut_pending && h->mut_stream != st) (void)hipStreamWaitEvent(st, h->mutated, 0);
+    }
+    ~FlatMutation()
+    {
+        if (!h->mutated) (void)hipEventCreateWithFlags(&h->mutated, hipEventDisableTiming);
+        if (h->mutated && hipEventRecord(h->mutated, st) == hipSuccess) { h->mut_stream = st; h->mut_pending = true; }
+    }
+};
+
 int cvtmi_flat_add(cvtmi_flat_t h, const void *x, const int64_t *labels, int64_t n)
 {
-    CHECK_H_SERIAL(h, nullptr);
+    CHECK_H(h);
+    FlatMutation mut(h, nullptr);
     return flat_add_common(h, x, labels, n, hipMemcpyHostToDevice, nullptr);
 }
 
 int cvtmi_flat_add_dev(cvtmi_flat_t h, const void *x, const int64_t *labels, int64_t n, void *stream)
 {
-    CHECK_H_SERIAL(h, stream);
+    CHECK_H(h);
+    FlatMutation mut(h, (hipStream_t)stream);
     return flat_add_common(h, x, labels, n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
 }
 
@@ -975,7 +1075,8 @@ int cvtmi_flat_ntotal(cvtmi_flat_t h, int64_t *n)
 
 int cvtmi_flat_reset(cvtmi_flat_t h)
 {
-    CHECK_H_SERIAL(h, nullptr);
+    CHECK_H(h);
+    FlatMutation mut(h, nullptr);
     h->n = 0; h->identity = true; h->f_pack_n = -1;
     h->fs_stats_n = -1; h->fs_nonfinite = false;
     (void)hipDeviceSynchronize();
@@ -987,7 +1088,7 @@ int cvtmi_flat_reset(cvtmi_flat_t h)
 // the exact search over rows [0, n_rows) of the handle: k smallest (distance, row) per query, rows not yet mapped to labels
 // max_stream_passes: the uint8 streaming kernel serves 128 queries per pass; callers that search a short row range for many queries (the
 // filter pipeline's sample stage) cap the passes and fall through to the row-tile kernels beyond
-static int flat_search_rows(cvtmi_flat_t h, int64_t n_rows, const void *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st,
+static int flat_search_rows(cvtmi_flat_t h, FlatScratch &S, int64_t n_rows, const void *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st,
                             int64_t max_stream_passes = INT64_MAX, const uint32_t *only_if = nullptr)
 {
     // uint8: anything the filter pipeline did not take goes through the streaming matrix-core kernel, 128 queries per pass (its cost hardly
@@ -995,20 +1096,20 @@ static int flat_search_rows(cvtmi_flat_t h, int64_t n_rows, const void *q, int64
     if (h->metric == CVTMI_METRIC_L2U8 && g_flat_variant != 1 && h->norms.p && nq >= 1 && flat_u8_mstream_applies(h->D, n_rows, std::min<int64_t>(nq, 128), k) &&
         ((uintptr_t)q & 15) == 0 && (nq + 127) / 128 <= max_stream_passes) {
         const int64_t passes = (nq + 127) / 128, per = (nq + passes - 1) / passes;   // balanced: 129 queries = 65 + 64
-        const int S = flat_u8_stream_slices();
+        const int NS = flat_u8_stream_slices();
         int nqp = 0, waves = 0;
         const size_t bytes = flat_u8_mstream_scratch(n_rows, per, &nqp, &waves);
-        CVTMI_TRY(h->s_stage.reserve(bytes));
-        CVTMI_TRY(h->s_part_d.reserve((size_t)per * S * k * sizeof(float)));
-        CVTMI_TRY(h->s_part_id.reserve((size_t)per * S * k * sizeof(int64_t)));
+        CVTMI_TRY(S.s_stage.reserve(bytes));
+        CVTMI_TRY(S.s_part_d.reserve((size_t)per * NS * k * sizeof(float)));
+        CVTMI_TRY(S.s_part_id.reserve((size_t)per * NS * k * sizeof(int64_t)));
         for (int64_t a = 0; a < nq; a += per) {
             const int64_t m = std::min(per, nq - a);
             (void)flat_u8_mstream_scratch(n_rows, m, &nqp, &waves);
             const uint8_t *qa = reinterpret_cast<const uint8_t *>(q) + a * h->D;
-            int32_t *tmin = h->s_stage.as<int32_t>(), *wmin = tmin + (size_t)flat_u8_mstream_groups(n_rows) * nqp;
+            int32_t *tmin = S.s_stage.as<int32_t>(), *wmin = tmin + (size_t)flat_u8_mstream_groups(n_rows) * nqp;
             CVTMI_TRY(launch_flat_u8_mstream(h->D, h->data.as<uint8_t>(), h->norms.as<int32_t>(), n_rows, qa, m, tmin, wmin, st));
-            CVTMI_TRY(launch_flat_u8_mstream_finish(h->D, h->data.as<uint8_t>(), n_rows, qa, m, k, wmin, waves, tmin, nqp, flat_u8_mstream_group(), h->s_part_d.as<float>(),
-                                                    h->s_part_id.as<int64_t>(), dist + a * k, rows + a * k, st));
+            CVTMI_TRY(launch_flat_u8_mstream_finish(h->D, h->data.as<uint8_t>(), n_rows, qa, m, k, wmin, waves, tmin, nqp, flat_u8_mstream_group(), S.s_part_d.as<float>(),
+                                                    S.s_part_id.as<int64_t>(), dist + a * k, rows + a * k, st));
         }
         return CVTMI_OK;
     }
@@ -1022,15 +1123,15 @@ static int flat_search_rows(cvtmi_flat_t h, int64_t n_rows, const void *q, int64
     int64_t *pi = rows;
     if (splits > 1) {
         const size_t cnt = (size_t)nq * splits * k;
-        CVTMI_TRY(h->s_part_d.reserve(cnt * sizeof(float)));
-        CVTMI_TRY(h->s_part_id.reserve(cnt * sizeof(int64_t)));
-        pd = h->s_part_d.as<float>();
-        pi = h->s_part_id.as<int64_t>();
+        CVTMI_TRY(S.s_part_d.reserve(cnt * sizeof(float)));
+        CVTMI_TRY(S.s_part_id.reserve(cnt * sizeof(int64_t)));
+        pd = S.s_part_d.as<float>();
+        pi = S.s_part_id.as<int64_t>();
     }
     if (mfma) {
-        CVTMI_TRY(h->s_gthr.reserve((size_t)nq * (1 + 16) * sizeof(uint32_t)));
+        CVTMI_TRY(S.s_gthr.reserve((size_t)nq * (1 + 16) * sizeof(uint32_t)));
         CVTMI_TRY(launch_flat_u8_mfma(h->D, h->data.as<uint8_t>(), h->norms.as<int32_t>(), n_rows,
-                                      reinterpret_cast<const uint8_t *>(q), nq, k, splits, pd, pi, h->s_gthr.as<uint32_t>(), st));
+                                      reinterpret_cast<const uint8_t *>(q), nq, k, splits, pd, pi, S.s_gthr.as<uint32_t>(), st));
     }
     else
         CVTMI_TRY(launch_flat_search(h->metric, h->D, h->data.p, n_rows, q, nq, k, qt, splits, pd, pi, st, only_if));
@@ -1039,82 +1140,64 @@ static int flat_search_rows(cvtmi_flat_t h, int64_t n_rows, const void *q, int64
 }
 
 // fp32 search as a stream over the rows (flat_f32_stream.hip).  *done = false: not applicable, the other paths answer
-static int flat_search_streamed(cvtmi_flat_t h, const float *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st, bool *done)
+static int flat_search_streamed(cvtmi_flat_t h, FlatScratch &S, const float *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st, bool *done)
 {
     *done = false;
     const int D = h->D;
     const int64_t n = h->n;
-    if (!h->fs_bias.p || !h->fs_stats.p) return CVTMI_OK;
-    if (h->fs_stats_n != n) {   // once per index state: do the rows hold non-finite values?
-        uint32_t stats[2] = { 0, 0 };
-        CVTMI_HIP(hipMemcpyAsync(stats, h->fs_stats.p, sizeof stats, hipMemcpyDeviceToHost, st));
-        CVTMI_HIP(hipStreamSynchronize(st));
-        h->fs_nonfinite = stats[1] != 0;
-        h->fs_stats_n = n;
-    }
-    if (h->fs_nonfinite) return CVTMI_OK;
+    if (!h->fs_bias.p || !h->fs_stats.p || h->fs_stats_n != n || h->fs_nonfinite) return CVTMI_OK;
     const int qmax = flat_f32_stream_qmax(D);
     const int64_t passes = (nq + qmax - 1) / qmax, per = (nq + passes - 1) / passes;
-    if (h->fs_scratch.reserve(flat_f32_stream_scratch(D, n, per)) != CVTMI_OK) return CVTMI_OK;   // no room: the exact path answers
-    CVTMI_TRY(h->fs_redo.reserve((size_t)nq * 2 * sizeof(uint32_t)));   // redo flags, then list counters
+    if (S.fs_scratch.reserve(flat_f32_stream_scratch(D, n, per)) != CVTMI_OK) return CVTMI_OK;   // no room: the exact path answers
+    CVTMI_TRY(S.fs_redo.reserve((size_t)nq * 2 * sizeof(uint32_t)));   // redo flags, then list counters
     for (int64_t a = 0; a < nq; a += per) {
         const int64_t m = std::min(per, nq - a);
         CVTMI_TRY(launch_flat_f32_stream(h->metric, D, h->data.as<float>(), h->fs_bias.as<float>(), h->fs_stats.as<uint32_t>(), n, q + a * D, m, k,
-                                         h->fs_scratch.p, dist + a * k, rows + a * k, h->fs_redo.as<uint32_t>() + a,
-                                         h->fs_redo.as<uint32_t>() + nq + a, st));
+                                         S.fs_scratch.p, dist + a * k, rows + a * k, S.fs_redo.as<uint32_t>() + a,
+                                         S.fs_redo.as<uint32_t>() + nq + a, st));
     }
     // queries the bound does not cover / whose lists ran over: the exact kernels, predicated on the flags (they exit at once otherwise)
-    CVTMI_TRY(flat_search_rows(h, n, q, nq, k, dist, rows, st, INT64_MAX, h->fs_redo.as<uint32_t>()));
+    CVTMI_TRY(flat_search_rows(h, S, n, q, nq, k, dist, rows, st, INT64_MAX, S.fs_redo.as<uint32_t>()));
     *done = true;
     return CVTMI_OK;
 }
 
 // fp32 search through the matrix-core filter (flat_mfma.hip).  *done = false: not applicable / gave up, take the exact path
-static int flat_search_filtered(cvtmi_flat_t h, const float *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st, bool *done)
+static int flat_search_filtered(cvtmi_flat_t h, FlatScratch &S, const float *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st, bool *done)
 {
     *done = false;
     const int D = h->D;
     const int64_t n = h->n;
-    if (h->f_pack_n != n) {  // bf16 operand copy of the rows (same bytes as the fp32 rows), once per index state
-        if (h->f_pack.reserve(flat_pack_bytes(D, n)) != CVTMI_OK) return CVTMI_OK;  // no room for the operand copy: exact path
-        CVTMI_TRY(h->f_bias.reserve((size_t)((n + 31) / 32) * 32 * sizeof(uint32_t)));
-        CVTMI_TRY(h->f_stats.reserve(16));
-        CVTMI_TRY(launch_flat_pack(h->data.as<float>(), n, D, h->metric, h->f_pack.as<uint4>(), h->f_bias.as<uint32_t>(),
-                                   h->f_stats.as<uint32_t>(), st));
-        uint32_t stats[2] = { 0, 0 };
-        CVTMI_HIP(hipMemcpyAsync(stats, h->f_stats.p, sizeof stats, hipMemcpyDeviceToHost, st));
-        CVTMI_HIP(hipStreamSynchronize(st));
-        h->f_nonfinite = stats[1] != 0 || !(__builtin_bit_cast(float, stats[0]) <= 3.0e38f);
-        h->f_pack_n = n;
-    }
-    if (h->f_nonfinite) return CVTMI_OK;
+    if (h->f_pack_n != n || h->f_nonfinite) return CVTMI_OK;   // no operand copy (flat_prepare could not build it) / non-finite rows: exact path
+    CVTMI_TRY(S.f_stats.reserve(16));
+    CVTMI_HIP(hipMemcpyAsync(S.f_stats.p, h->f_istats.p, 8, hipMemcpyDeviceToDevice, st));   // [0] max |x|^2, [1] non-finite rows; [2], [3] are this call's
     // 1. exact search of a leading sample: its k-th best bounds the global k-th best
     // a smaller sample costs less exact work but doubles the survivors: worth it while k is small
     const int frac = k <= 16 ? 32 : 16;
     int64_t ns = std::max<int64_t>(frac == 32 ? 32768 : 65536, (n / frac + 63) / 64 * 64);
     const int cap = ((frac == 32 ? 48 : 24) * k + 1024 + 63) / 64 * 64;
-    CVTMI_TRY(h->f_sd.reserve((size_t)nq * k * sizeof(float)));
-    CVTMI_TRY(h->f_si.reserve((size_t)nq * k * sizeof(int64_t)));
-    CVTMI_TRY(h->f_thr.reserve((size_t)nq * sizeof(float)));
-    CVTMI_TRY(h->f_cnt.reserve((size_t)nq * sizeof(uint32_t)));
+    CVTMI_TRY(S.f_sd.reserve((size_t)nq * k * sizeof(float)));
+    CVTMI_TRY(S.f_si.reserve((size_t)nq * k * sizeof(int64_t)));
+    CVTMI_TRY(S.f_thr.reserve((size_t)nq * sizeof(float)));
+    CVTMI_TRY(S.f_cnt.reserve((size_t)nq * sizeof(uint32_t)));
     const uint64_t pair_cap64 = (uint64_t)nq * cap;
     const uint32_t pair_cap = pair_cap64 > 0x7ffffff0ull ? 0x7ffffff0u : (uint32_t)pair_cap64;
     // the big scratch (16 bytes per survivor slot + 8 per list entry): if it does not fit, the exact path answers
-    if (h->f_cand.reserve((size_t)pair_cap * sizeof(uint4)) != CVTMI_OK || h->f_seld.reserve((size_t)nq * cap * sizeof(float)) != CVTMI_OK ||
-        h->f_seli.reserve((size_t)nq * cap * sizeof(int32_t)) != CVTMI_OK)
+    if (S.f_cand.reserve((size_t)pair_cap * sizeof(uint4)) != CVTMI_OK || S.f_seld.reserve((size_t)nq * cap * sizeof(float)) != CVTMI_OK ||
+        S.f_seli.reserve((size_t)nq * cap * sizeof(int32_t)) != CVTMI_OK)
         return CVTMI_OK;
-    CVTMI_TRY(h->f_marg.reserve((size_t)nq * sizeof(float)));
-    uint32_t *stats = h->f_stats.as<uint32_t>();  // [0] max |x|^2, [1] non-finite rows, [2] overflow / worst list, [3] pair count
+    CVTMI_TRY(S.f_marg.reserve((size_t)nq * sizeof(float)));
+    uint32_t *stats = S.f_stats.as<uint32_t>();  // [0] max |x|^2, [1] non-finite rows, [2] overflow / worst list, [3] pair count
     // one filter stage: given the exact top k of rows [0, r0) in (sd, si), the exact top k of rows [0, r1) into (od, oi):
     // thresholds, filter over [r0, r1), second cut on approximate scores, exact distances of what is left, sort
     auto stage = [&](int64_t r0, int64_t r1, const float *sd, const int64_t *si, float *od, int64_t *oi, uint32_t *worst) -> int {
         CVTMI_HIP(hipMemsetAsync(stats + 2, 0, 8, st));
-        CVTMI_TRY(launch_flat_thr(q, nq, D, h->metric, sd, k, stats, h->f_thr.as<float>(), h->f_marg.as<float>(), st));
-        CVTMI_HIP(hipMemsetAsync(h->f_cnt.p, 0, (size_t)nq * sizeof(uint32_t), st));
-        CVTMI_TRY(launch_flat_filter(q, nq, D, h->f_pack.as<uint4>(), h->f_bias.as<uint32_t>(), h->f_thr.as<float>(), r0, r1, pair_cap,
-                                     stats + 3, h->f_cand.as<uint4>(), st));
-        CVTMI_TRY(launch_flat_finish(h->metric, h->data.as<float>(), r1, D, q, nq, stats + 3, pair_cap, h->f_cand.as<uint4>(), cap, k,
-                                     h->f_marg.as<float>(), sd, si, h->f_cnt.as<uint32_t>(), h->f_seld.as<float>(), h->f_seli.as<int32_t>(),
+        CVTMI_TRY(launch_flat_thr(q, nq, D, h->metric, sd, k, stats, S.f_thr.as<float>(), S.f_marg.as<float>(), st));
+        CVTMI_HIP(hipMemsetAsync(S.f_cnt.p, 0, (size_t)nq * sizeof(uint32_t), st));
+        CVTMI_TRY(launch_flat_filter(q, nq, D, h->f_pack.as<uint4>(), h->f_bias.as<uint32_t>(), S.f_thr.as<float>(), r0, r1, pair_cap,
+                                     stats + 3, S.f_cand.as<uint4>(), st));
+        CVTMI_TRY(launch_flat_finish(h->metric, h->data.as<float>(), r1, D, q, nq, stats + 3, pair_cap, S.f_cand.as<uint4>(), cap, k,
+                                     S.f_marg.as<float>(), sd, si, S.f_cnt.as<uint32_t>(), S.f_seld.as<float>(), S.f_seli.as<int32_t>(),
                                      od, oi, stats + 2, st));
         CVTMI_HIP(hipMemcpyAsync(worst, stats + 2, 4, hipMemcpyDeviceToHost, st));
         CVTMI_HIP(hipStreamSynchronize(st));
@@ -1126,16 +1209,16 @@ static int flat_search_filtered(cvtmi_flat_t h, const float *q, int64_t nq, int 
     const int64_t ns0 = std::max<int64_t>(8192, (ns / 16 + 63) / 64 * 64);
     bool have_sample = false;
     if (ns0 * 4 <= ns && nq >= 256) {  // (small batches: the extra launches and the sync cost more than the exact work saved)
-        CVTMI_TRY(h->f_sd2.reserve((size_t)nq * k * sizeof(float)));
-        CVTMI_TRY(h->f_si2.reserve((size_t)nq * k * sizeof(int64_t)));
-        CVTMI_TRY(flat_search_rows(h, ns0, q, nq, k, h->f_sd2.as<float>(), h->f_si2.as<int64_t>(), st));
-        CVTMI_TRY(stage(ns0, ns, h->f_sd2.as<float>(), h->f_si2.as<int64_t>(), h->f_sd.as<float>(), h->f_si.as<int64_t>(), &worst));
+        CVTMI_TRY(S.f_sd2.reserve((size_t)nq * k * sizeof(float)));
+        CVTMI_TRY(S.f_si2.reserve((size_t)nq * k * sizeof(int64_t)));
+        CVTMI_TRY(flat_search_rows(h, S, ns0, q, nq, k, S.f_sd2.as<float>(), S.f_si2.as<int64_t>(), st));
+        CVTMI_TRY(stage(ns0, ns, S.f_sd2.as<float>(), S.f_si2.as<int64_t>(), S.f_sd.as<float>(), S.f_si.as<int64_t>(), &worst));
         have_sample = worst <= (uint32_t)cap;
     }
-    if (!have_sample) CVTMI_TRY(flat_search_rows(h, ns, q, nq, k, h->f_sd.as<float>(), h->f_si.as<int64_t>(), st));
+    if (!have_sample) CVTMI_TRY(flat_search_rows(h, S, ns, q, nq, k, S.f_sd.as<float>(), S.f_si.as<int64_t>(), st));
     // 2. the remaining rows
-    CVTMI_TRY(stage(ns, n, h->f_sd.as<float>(), h->f_si.as<int64_t>(), dist, rows, &worst));
-    h->f_last_worst = worst;
+    CVTMI_TRY(stage(ns, n, S.f_sd.as<float>(), S.f_si.as<int64_t>(), dist, rows, &worst));
+    h->f_last_worst = (long long)worst;
     if (worst > (uint32_t)cap) return CVTMI_OK;  // a list ran over: the exact path answers this call (and overwrites the output)
     *done = true;
     return CVTMI_OK;
@@ -1143,37 +1226,33 @@ static int flat_search_filtered(cvtmi_flat_t h, const float *q, int64_t nq, int 
 
 // uint8 L2 through the filter pipeline (flat_mfma.hip): exact integer distances on the i8 matrix cores, thresholds from an
 // exactly searched leading sample.  *done = false: not applicable / a list ran over, the row-tile kernels answer
-static int flat_search_filtered_u8(cvtmi_flat_t h, const uint8_t *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st, bool *done)
+static int flat_search_filtered_u8(cvtmi_flat_t h, FlatScratch &S, const uint8_t *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st, bool *done)
 {
     *done = false;
     const int D = h->D;
     const int64_t n = h->n;
-    if (h->f_pack_n != n) {  // operand-ordered copy of the rows (x - 128 as int8), once per index state
-        if (h->f_pack.reserve(flat_u8_pack_bytes(D, n)) != CVTMI_OK) return CVTMI_OK;
-        CVTMI_TRY(launch_flat_u8_pack(h->data.as<uint8_t>(), n, D, h->f_pack.as<uint4>(), st));
-        h->f_pack_n = n;
-    }
+    if (h->f_pack_n != n) return CVTMI_OK;   // no operand copy (flat_prepare could not build it): the row-tile kernels answer
     const int64_t ns = std::max<int64_t>(65536, (n / 32 + 63) / 64 * 64);
     const int cap = std::min(4096 - k, (48 * k + 1024 + 63) / 64 * 64);
     const uint64_t pair_cap64 = (uint64_t)nq * cap;
     const uint32_t pair_cap = pair_cap64 > 0x7ffffff0ull ? 0x7ffffff0u : (uint32_t)pair_cap64;
-    CVTMI_TRY(h->f_stats.reserve(16));
-    CVTMI_TRY(h->f_sd.reserve((size_t)nq * k * sizeof(float)));
-    CVTMI_TRY(h->f_si.reserve((size_t)nq * k * sizeof(int64_t)));
-    CVTMI_TRY(h->f_cnt.reserve((size_t)nq * sizeof(uint32_t)));
-    if (h->f_cand.reserve((size_t)pair_cap * sizeof(uint4)) != CVTMI_OK || h->f_seld.reserve((size_t)nq * cap * sizeof(float)) != CVTMI_OK ||
-        h->f_seli.reserve((size_t)nq * cap * sizeof(int32_t)) != CVTMI_OK)
+    CVTMI_TRY(S.f_stats.reserve(16));
+    CVTMI_TRY(S.f_sd.reserve((size_t)nq * k * sizeof(float)));
+    CVTMI_TRY(S.f_si.reserve((size_t)nq * k * sizeof(int64_t)));
+    CVTMI_TRY(S.f_cnt.reserve((size_t)nq * sizeof(uint32_t)));
+    if (S.f_cand.reserve((size_t)pair_cap * sizeof(uint4)) != CVTMI_OK || S.f_seld.reserve((size_t)nq * cap * sizeof(float)) != CVTMI_OK ||
+        S.f_seli.reserve((size_t)nq * cap * sizeof(int32_t)) != CVTMI_OK)
         return CVTMI_OK;
-    uint32_t *stats = h->f_stats.as<uint32_t>();  // [2] worst list / overflow, [3] pair count
+    uint32_t *stats = S.f_stats.as<uint32_t>();  // [2] worst list / overflow, [3] pair count
     // one filter stage: the exact top k of rows [0, r0) in (sd, si) -> the exact top k of rows [0, r1) in (od, oi)
     uint32_t worst = 0;
     auto stage = [&](int64_t r0, int64_t r1, const float *sd, const int64_t *si, float *od, int64_t *oi) -> int {
         CVTMI_HIP(hipMemsetAsync(stats + 2, 0, 8, st));
-        CVTMI_HIP(hipMemsetAsync(h->f_cnt.p, 0, (size_t)nq * sizeof(uint32_t), st));
+        CVTMI_HIP(hipMemsetAsync(S.f_cnt.p, 0, (size_t)nq * sizeof(uint32_t), st));
         CVTMI_TRY(launch_flat_u8_filter(q, nq, D, h->f_pack.as<uint4>(), h->norms.as<int32_t>(), sd, k, r0, r1, pair_cap, stats + 3,
-                                        h->f_cand.as<uint4>(), st));
-        CVTMI_TRY(launch_flat_u8_finish(nq, stats + 3, pair_cap, h->f_cand.as<uint4>(), cap, k, sd, si, h->f_cnt.as<uint32_t>(),
-                                        h->f_seld.as<float>(), h->f_seli.as<int32_t>(), od, oi, stats + 2, st));
+                                        S.f_cand.as<uint4>(), st));
+        CVTMI_TRY(launch_flat_u8_finish(nq, stats + 3, pair_cap, S.f_cand.as<uint4>(), cap, k, sd, si, S.f_cnt.as<uint32_t>(),
+                                        S.f_seld.as<float>(), S.f_seli.as<int32_t>(), od, oi, stats + 2, st));
         CVTMI_HIP(hipMemcpyAsync(&worst, stats + 2, 4, hipMemcpyDeviceToHost, st));
         CVTMI_HIP(hipStreamSynchronize(st));
         return CVTMI_OK;
@@ -1181,48 +1260,121 @@ static int flat_search_filtered_u8(cvtmi_flat_t h, const uint8_t *q, int64_t nq,
     // (a two-level sample -- exact kernels on ns / 8 rows, a first filter stage up to ns, as the fp32 path does -- was measured and lost:
     //  the second stage's launches and host sync cost more than the 1.2 ms of exact search they save; nq = 1000: 6.4 -> 7.0 ms)
     // (the sample through the streaming kernel: 10 M x 512-d nq = 256 2.5 -> 1.8 ms in all, but 32 passes for nq = 4096 cost 6 ms against 2.1)
-    CVTMI_TRY(flat_search_rows(h, ns, q, nq, k, h->f_sd.as<float>(), h->f_si.as<int64_t>(), st, 2));
-    CVTMI_TRY(stage(ns, n, h->f_sd.as<float>(), h->f_si.as<int64_t>(), dist, rows));
-    h->f_last_worst = worst;
+    CVTMI_TRY(flat_search_rows(h, S, ns, q, nq, k, S.f_sd.as<float>(), S.f_si.as<int64_t>(), st, 2));
+    CVTMI_TRY(stage(ns, n, S.f_sd.as<float>(), S.f_si.as<int64_t>(), dist, rows));
+    h->f_last_worst = (long long)worst;
     if (worst > (uint32_t)cap) return CVTMI_OK;
     *done = true;
     return CVTMI_OK;
 }
 
-int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels, void *stream)
+// which of the pipelines a search of nq queries takes (the dispatch rules, in one place: flat_prepare builds what they need)
+struct FlatRoute { bool stream, filt_f32, filt_u8; };
+static FlatRoute flat_route(const cvtmi_flat_s *h, const void *q, int64_t nq, int k)
 {
-    CHECK_H_SERIAL(h, stream);
-    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_flat_search: bad arguments");
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search: k=%d outside 1..128", k);
-    if (nq == 0) return CVTMI_OK;
-    hipStream_t st = (hipStream_t)stream;
-    bool done = false;
-    h->f_last_worst = 0;
-    int how = 0;
+    FlatRoute r = { false, false, false };
+    const bool aligned = ((uintptr_t)q & 15) == 0;
     // fp32: one stream over the rows (flat_f32_stream.hip).  flat_variant 2 asks for the older sample + filter pipeline, 1 for the exact kernels
-    if (((g_flat_variant == 0 && g_flat_f32_stream == 1) || (g_flat_variant != 1 && g_flat_f32_stream == 2)) &&
-        ((uintptr_t)q & 15) == 0 && flat_f32_stream_applies(h->metric, h->D, h->n, k)) {
-        CVTMI_TRY(flat_search_streamed(h, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
-        if (done) how = 2;
-    }
-    if (!done && g_flat_variant != 1 && ((uintptr_t)q & 15) == 0 && nq <= 65535 &&
-        flat_filter_applies(h->metric, h->D, g_flat_variant == 2 ? std::max<int64_t>(h->n, 131072) : h->n, g_flat_variant == 2 ? std::max<int64_t>(nq, 16) : nq, k) &&
-        h->n >= 2 * 65536)
-        CVTMI_TRY(flat_search_filtered(h, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
+    r.stream = ((g_flat_variant == 0 && g_flat_f32_stream == 1) || (g_flat_variant != 1 && g_flat_f32_stream == 2)) && aligned &&
+               flat_f32_stream_applies(h->metric, h->D, h->n, k) && h->fs_bias.p && h->fs_stats.p;
+    r.filt_f32 = g_flat_variant != 1 && aligned && nq <= 65535 &&
+                 flat_filter_applies(h->metric, h->D, g_flat_variant == 2 ? std::max<int64_t>(h->n, 131072) : h->n,
+                                     g_flat_variant == 2 ? std::max<int64_t>(nq, 16) : nq, k) && h->n >= 2 * 65536;
     // uint8: large batches go through the filter pipeline with the software-pipelined (LDS-DMA) kernel -- measured at 10 M x 512-d:
     // 4096 queries 27.4 -> 21.0 ms, 512 queries 4.6 -> 3.8 ms; smaller batches are one stream over the raw rows (flat_search_rows).
     // flat_variant 2 forces the pipeline wherever it applies, 1 forbids it.
     // (from 256 queries at every width: 10 M x 128-d nq = 256 / 512 / 1000 1.52 / 2.78 / 5.5 ms in streaming passes, 1.03 / 2.08 / 3.25 here;
     //  256-d nq = 256 1.87 against 1.26; between 257 and ~400 queries the two are within 5 %)
     const bool u8_auto = g_flat_variant == 0 && flat_u8_gfilter_shape(h->D) && nq >= 256 && h->n >= (1 << 20) && k <= 64;
-    if ((g_flat_variant == 2 || u8_auto) && h->metric == CVTMI_METRIC_L2U8 && ((uintptr_t)q & 15) == 0 && nq <= 65535 * 256 && h->norms.p &&
-        flat_u8_filter_applies(h->D, std::max<int64_t>(h->n, 262144), std::max<int64_t>(nq, 256), k) && h->n >= 2 * 65536)
-        CVTMI_TRY(flat_search_filtered_u8(h, reinterpret_cast<const uint8_t *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
+    r.filt_u8 = (g_flat_variant == 2 || u8_auto) && h->metric == CVTMI_METRIC_L2U8 && aligned && nq <= 65535 * 256 && h->norms.p &&
+                flat_u8_filter_applies(h->D, std::max<int64_t>(h->n, 262144), std::max<int64_t>(nq, 256), k) && h->n >= 2 * 65536;
+    return r;
+}
+
+// The lazily built parts of the index a route needs -- the host copy of the row statistics (fp32 stream), the operand copies of
+// the filter pipelines -- are built under the EXCLUSIVE lock, once per index state, and the stream is drained before the lock
+// is given back.  Called before the search takes its shared lock.
+static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStream_t st)
+{
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        FlatRoute r;
+        bool need_fs, need_f32, need_u8;
+        {
+            std::shared_lock<std::shared_timed_mutex> rd(h->rw);
+            r = flat_route(h, q, nq, k);
+            need_fs = r.stream && h->fs_stats_n != h->n;
+            need_f32 = r.filt_f32 && h->f_pack_n != h->n && !(r.stream && !need_fs && !h->fs_nonfinite);   // (the stream answers: no copy needed)
+            need_u8 = r.filt_u8 && h->f_pack_n != h->n;
+            if (!need_fs && !need_f32 && !need_u8) return CVTMI_OK;
+        }
+        FlatMutation mut(h, st);
+        const int64_t n = h->n;
+        if (need_fs && h->fs_stats_n != n) {   // once per index state: do the rows hold non-finite values?
+            uint32_t stats[2] = { 0, 0 };
+            CVTMI_HIP(hipMemcpyAsync(stats, h->fs_stats.p, sizeof stats, hipMemcpyDeviceToHost, st));
+            CVTMI_HIP(hipStreamSynchronize(st));
+            h->fs_nonfinite = stats[1] != 0;
+            h->fs_stats_n = n;
+            continue;   // the route may not need an operand copy after all
+        }
+        if (need_f32 && h->f_pack_n != n) {   // bf16 operand copy of the rows (same bytes as the fp32 rows)
+            if (h->f_pack.reserve(flat_pack_bytes(h->D, n)) != CVTMI_OK) return CVTMI_OK;   // no room: the exact path answers
+            CVTMI_TRY(h->f_bias.reserve((size_t)((n + 31) / 32) * 32 * sizeof(uint32_t)));
+            CVTMI_TRY(h->f_istats.reserve(16));
+            CVTMI_TRY(launch_flat_pack(h->data.as<float>(), n, h->D, h->metric, h->f_pack.as<uint4>(), h->f_bias.as<uint32_t>(),
+                                       h->f_istats.as<uint32_t>(), st));
+            uint32_t stats[2] = { 0, 0 };
+            CVTMI_HIP(hipMemcpyAsync(stats, h->f_istats.p, sizeof stats, hipMemcpyDeviceToHost, st));
+            CVTMI_HIP(hipStreamSynchronize(st));
+            h->f_nonfinite = stats[1] != 0 || !(__builtin_bit_cast(float, stats[0]) <= 3.0e38f);
+            h->f_pack_n = n;
+        }
+        if (need_u8 && h->f_pack_n != n) {    // operand-ordered copy of the rows (x - 128 as int8)
+            if (h->f_pack.reserve(flat_u8_pack_bytes(h->D, n)) != CVTMI_OK) return CVTMI_OK;
+            CVTMI_TRY(launch_flat_u8_pack(h->data.as<uint8_t>(), n, h->D, h->f_pack.as<uint4>(), st));
+            CVTMI_HIP(hipStreamSynchronize(st));
+            h->f_pack_n = n;
+        }
+        return CVTMI_OK;
+    }
+    return CVTMI_OK;
+}
+
+// the search proper, on a leased scratch set, under the shared lock
+static int flat_search_leased(cvtmi_flat_t h, FlatScratch &S, const void *q, int64_t nq, int k, void *dist, int64_t *labels, hipStream_t st)
+{
+    bool done = false;
+    long long worst0 = 0;
+    h->f_last_worst = worst0;
+    int how = 0;
+    const FlatRoute r = flat_route(h, q, nq, k);
+    if (r.stream) {
+        CVTMI_TRY(flat_search_streamed(h, S, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
+        if (done) how = 2;
+    }
+    if (!done && r.filt_f32)
+        CVTMI_TRY(flat_search_filtered(h, S, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
+    if (!done && r.filt_u8)
+        CVTMI_TRY(flat_search_filtered_u8(h, S, reinterpret_cast<const uint8_t *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
     h->f_last_filtered = done ? (how ? how : 1) : 0;
-    if (!done) CVTMI_TRY(flat_search_rows(h, h->n, q, nq, k, reinterpret_cast<float *>(dist), labels, st));
+    if (!done) CVTMI_TRY(flat_search_rows(h, S, h->n, q, nq, k, reinterpret_cast<float *>(dist), labels, st));
     if (!h->identity) CVTMI_TRY(launch_gather_labels(labels, nq * k, h->labels.as<int64_t>(), st));
     else if (h->id_base != 0) CVTMI_TRY(launch_offset_labels(labels, nq * k, h->id_base, st));
     return CVTMI_OK;
+}
+
+int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels, void *stream)
+{
+    CHECK_H(h);
+    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_flat_search: bad arguments");
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search: k=%d outside 1..128", k);
+    if (nq == 0) return CVTMI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    CVTMI_TRY(flat_prepare(h, q, nq, k, st));
+    std::shared_lock<std::shared_timed_mutex> rd(h->rw);
+    FlatLease lease;
+    CVTMI_TRY(lease.open(h, st, false));
+    return flat_search_leased(h, *lease.s, q, nq, k, dist, labels, st);
 }
 
 int cvtmi_flat_set_id_base(cvtmi_flat_t h, int64_t base)
@@ -1242,7 +1394,7 @@ int cvtmi_flat_search_sharded_dev(cvtmi_flat_t h, cvtmi_comm_t c, const void *q,
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search_sharded: k=%d outside 1..128", k);
     if (nq == 0) return CVTMI_OK;
     Serial serial_c(*comm_sync(c), (hipStream_t)stream);
-    CHECK_H_SERIAL(h, stream);
+    CHECK_H(h);
     if (comm_world(c) == 1 && !comm_has_transport(c)) return cvtmi_flat_search_dev(h, q, nq, k, dist, labels, stream);
     int rc = comm_device(c) != h->device ? fail(CVTMI_EINVAL, "cvtmi_flat_search_sharded: handle and communicator live on different devices") : CVTMI_OK;
     float *sd = nullptr;
@@ -1297,19 +1449,29 @@ int cvtmi_flat_last_search(cvtmi_flat_t h, int *filtered, int64_t *max_candidate
     return CVTMI_OK;
 }
 
+// host pointers in and out.  Every call runs on the stream of its own scratch set (staging buffers included), so callers on
+// several threads -- the reference's searchKnn is a pure read, brutoforce.hpp:73-93 -- proceed side by side.
 int cvtmi_flat_search(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels)
 {
-    CHECK_H_SERIAL(h, nullptr);
+    CHECK_H(h);
     if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_flat_search: bad arguments");
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search: k=%d outside 1..128", k);
     if (nq == 0) return CVTMI_OK;
-    Tmp dq, dd, di;
-    CVTMI_TRY(dq.upload(q, (size_t)nq * h->row_bytes));
-    CVTMI_TRY(dd.alloc((size_t)nq * k * 4));
-    CVTMI_TRY(di.alloc((size_t)nq * k * 8));
-    CVTMI_TRY(cvtmi_flat_search_dev(h, dq.p, nq, k, dd.p, di.as<int64_t>(), nullptr));
-    CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-    CVTMI_HIP(hipMemcpy(labels, di.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+    alignas(16) static const char aligned_probe[16] = {};
+    CVTMI_TRY(flat_prepare(h, aligned_probe, nq, k, nullptr));   // (the staged queries are 16-byte aligned)
+    std::shared_lock<std::shared_timed_mutex> rd(h->rw);
+    FlatLease lease;
+    CVTMI_TRY(lease.open(h, nullptr, true));
+    FlatScratch &S = *lease.s;
+    hipStream_t st = lease.st;
+    CVTMI_TRY(S.io_q.reserve((size_t)nq * h->row_bytes));
+    CVTMI_TRY(S.io_d.reserve((size_t)nq * k * 4));
+    CVTMI_TRY(S.io_i.reserve((size_t)nq * k * 8));
+    CVTMI_HIP(hipMemcpyAsync(S.io_q.p, q, (size_t)nq * h->row_bytes, hipMemcpyHostToDevice, st));
+    CVTMI_TRY(flat_search_leased(h, S, S.io_q.p, nq, k, S.io_d.p, S.io_i.as<int64_t>(), st));
+    CVTMI_HIP(hipMemcpyAsync(dist, S.io_d.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
+    CVTMI_HIP(hipMemcpyAsync(labels, S.io_i.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+    CVTMI_HIP(hipStreamSynchronize(st));
     return CVTMI_OK;
 }
 

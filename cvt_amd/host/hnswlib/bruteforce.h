@@ -8,7 +8,9 @@
 // reference's insertion order for saveIndex).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <fstream>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 #include <stdlib.h>
@@ -124,7 +126,8 @@ public:
 
 private:
     cvtmi_flat_s *h_;
-    bool dirty_;
+    std::atomic<bool> dirty_;
+    std::mutex sync_mu_;
     bool rebuild_ = true;        // the device copy must be rebuilt (rows removed / loaded / labels not ascending)
     size_t synced_ = 0;          // rows [0, synced_) of data_ are on the device, in this order
     labeltype synced_max_ = 0;   // the largest label among them
@@ -140,9 +143,13 @@ private:
         if (metric_ < 0) throw std::runtime_error("cvt_amd BruteforceSearch: the space has no MI355X metric");
     }
 
+    // concurrent searchKnn calls (a pure read in the reference, brutoforce.hpp:73-93) may arrive together after a change: the
+    // first one brings the device copy up to date, the others wait for it; afterwards nobody takes the lock
     void sync_device()
     {
-        if (!dirty_ && h_) return;
+        if (!dirty_.load(std::memory_order_acquire) && h_) return;
+        std::lock_guard<std::mutex> g(sync_mu_);
+        if (!dirty_.load(std::memory_order_acquire) && h_) return;
         const size_t dim = *((size_t *)dist_func_param_);
         if (!h_ && cvtmi_flat_create(metric_, (int)dim, &h_) != CVTMI_OK)
             throw std::runtime_error(std::string("cvtmi_flat_create: ") + cvtmi_last_error());
@@ -171,7 +178,7 @@ private:
                     synced_max_ = (labeltype)labels[m - 1];
                     synced_ = cur_element_count;
                 }
-                dirty_ = false;
+                dirty_.store(false, std::memory_order_release);
                 return;
             }
         }
@@ -192,10 +199,10 @@ private:
         }
         if (n && cvtmi_flat_add(h_, rows.data(), labels.data(), (int64_t)n) != CVTMI_OK)
             throw std::runtime_error(std::string("cvtmi_flat_add: ") + cvtmi_last_error());
-        dirty_ = false;
         rebuild_ = false;
         synced_ = n;
         synced_max_ = n ? (labeltype)labels[n - 1] : 0;
+        dirty_.store(false, std::memory_order_release);
     }
 };
 }  // namespace hnswlib

@@ -245,3 +245,10 @@ def test_opq_search_cli_failing_rank_does_not_hang(tmp_path):
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
         assert p.returncode != 0
     assert time.time() - t0 < 100
+
+
+def test_bruteforce_mirror_concurrent_searchknn(tmp_path):
+    """four host threads inside BruteforceSearch::searchKnn on ONE index at once: same answers as one thread (the library leases
+    a scratch set and a stream per call; only index mutation is exclusive)"""
+    out = run([os.path.join(BIN, "bf_concurrent"), "200000", "128", "4", "32", "50"], cwd=str(tmp_path))
+    assert out.strip().endswith("OK"), out
