@@ -56,7 +56,7 @@ __device__ unsigned long long g_fs_dbg[16];
 __device__ unsigned long long g_fss_dbg[2][8];   // shader clocks of waves 0 and 4 of workgroup 0 of the shared-ring kernel, per section
 #define FSS_T0() unsigned long long fss_last__ = clock64(); unsigned long long fss_acc__[8] = {}
 #define FSS_T(i) do { const unsigned long long now__ = clock64(); fss_acc__[i] += now__ - fss_last__; fss_last__ = now__; } while (0)
-#define FSS_TEND() do { if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0) for (int i__ = 0; i__ < 8; ++i__) g_fss_dbg[wave >> 2][i__] = fss_acc__[i__]; } while (0)
+#define FSS_TEND() do { if (blockIdx.x == 0 && (wave & 3) == 0 && wave_id < 8 && lane == 0) for (int i__ = 0; i__ < 8; ++i__) g_fss_dbg[wave_id >> 2][i__] = fss_acc__[i__]; } while (0)
 #else
 #define FS_T0() do { } while (0)
 #define FS_T(i) do { } while (0)
@@ -67,12 +67,14 @@ __device__ unsigned long long g_fss_dbg[2][8];   // shader clocks of waves 0 and
 
 __device__ __forceinline__ void fs_glds16(const void *gsrc, uint32_t lds_dst)
 {
+    lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst);   // wave-uniform by construction: keep it in an SGPR
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void fs_glds4(const void *gsrc, uint32_t lds_dst)
 {
+    lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
@@ -306,19 +308,29 @@ __device__ __forceinline__ float fs_max(float a, float b)
     return r;
 }
 
-// NW waves (4: one per SIMD, 8: two per SIMD) of 32 QB queries each
-template <int NCH, int QB, int NW>
+// NW waves of 32 QB queries each, the first NF of them also request and convert the tiles (NF divides the 2 NCH pieces of a
+// tile into whole K steps).  <QB, 4, 4>: one wave per SIMD with up to 96 queries in its registers.  <1, 12, NCH>: three waves
+// per SIMD with 32 queries each -- a wave issues a vector instruction every ~5 cycles at best, so the vector work of a tile
+// (folding the scores into best / second, the conversion) only disappears behind the matrix instructions when several
+// waves share the SIMD.  Measured per pass on 1 M x 128-d: one wave per SIMD 254 us (256 queries) / 340 us (384), two waves per
+// SIMD in lock step 210 us (256), two waves alternating between a matrix and a vector phase 254 us, two waves with separate
+// jobs (four multiply, four feed) 280 us, one wave with the vector work pinned between its matrix instructions by
+// sched_group_barrier 290 us, three waves per SIMD (this form) 265 us for 384 queries = 0.69 us per query against 0.82-0.89.
+template <int NCH, int QB, int NW, int NF>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void flat_f32_mshare_kernel(
     const float *__restrict__ X, const float *__restrict__ bias, int64_t n_tiles, const float *__restrict__ Q, int nq, int G, int NG,
     float2 *__restrict__ gb, float *__restrict__ wm, uint32_t *__restrict__ zero_a, uint32_t *__restrict__ zero_b, int dbg)
 {
-    using Ge = FssGeom<NCH, NW>;
+    using Ge = FssGeom<NCH, NF>;
     constexpr int D = 16 * NCH, TILE = Ge::TILE, RU = Ge::RU, RB = Ge::RB, PW = Ge::PW, OPS = Ge::OPS;
     static_assert(PW >= 2 && PW % 2 == 0, "a wave converts whole K steps");
-    constexpr int NACC = QB == 1 ? 2 : QB;
+    constexpr bool TWO_CHAINS = QB == 1 && NW <= 8;          // one wave per SIMD: two chains so that back-to-back products are independent
+    constexpr int NACC = TWO_CHAINS ? 2 : QB;
     extern __shared__ __attribute__((aligned(16))) uint8_t fs_ring[];   // [RU tiles | RB bias slots]
     const int tid = threadIdx.x, lane = tid & 63, lj = lane & 31, lk = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool computes = true, feeds = wave_id < NF;
+    const int wave = wave_id;
     if (blockIdx.x == 0)
         for (int i = tid; i < nq; i += 64 * NW) zero_a[i] = zero_b[i] = 0u;
     bf16x8 qh[QB][NCH], ql[QB][NCH];
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     const uint32_t ring_b = (uint32_t)(uintptr_t)fs_ring;
     const uint32_t bias_b = ring_b + (uint32_t)(RU * TILE);
     // this wave's share of tile i: pieces p = wave PW .. + PW, piece p = 2 s + h as in the kernel above
-    auto request = [&](int i) {
+    auto request = [&](int i) __attribute__((always_inline)) {
         const int ic = i < my_tiles ? i : my_tiles - 1;
         const int64_t t = stream + (int64_t)ic * FSS_STREAMS;
         const float *tile = X + ((t >> 1) * (int64_t)(D / 4) * 64 + (t & 1) * 32 + lj) * 4;
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     // so the wave that fetched them splits them into the two bf16 terms IN PLACE (piece 2 s keeps the high terms of its lanes,
     // piece 2 s + 1 the low terms: same bytes) as soon as its own requests have landed -- one tile ahead of the products, no
     // extra barrier -- and the product loop of every wave reads ready-made operands.
-    auto convert = [&](int i) {   // own share of tile i (requests retired: the caller waited)
+    auto convert = [&](int i) __attribute__((always_inline)) {   // own share of tile i (requests retired: the caller waited)
         uint8_t *tb = fs_ring + (size_t)(i % RU) * TILE + lane * 16;
 #pragma unroll
         for (int ss = 0; ss < PW / 2; ++ss) {
@@ -371,7 +383,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
             *reinterpret_cast<bf16x8 *>(tb + (2 * s + 1) * 1024) = xl;
         }
     };
-    if (my_tiles > 0) {
+    if (my_tiles > 0 && feeds) {
 #pragma unroll
         for (int i = 0; i < RU - 1; ++i) request(i);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RU - 2) * OPS) : "memory");
@@ -389,14 +401,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     f32x16 acc[NACC];
     const int gmask = G - 1, glog = 31 - __builtin_clz(G);
     // the products of tile i (operands ready in LDS) into acc
-    auto products = [&](int i) {
+    auto products = [&](int i) __attribute__((always_inline)) {
         const uint8_t *ub = fs_ring + (size_t)(i % RU) * TILE + lane * 16;
         {
             const float bx = reinterpret_cast<const float *>(fs_ring + RU * TILE + (size_t)(i % RB) * 256)[lj];
 #pragma unroll
             for (int a = 0; a < NACC; ++a)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[a][e] = (QB == 1 && a == 1) ? 0.0f : bx;
+                for (int e = 0; e < 16; ++e) acc[a][e] = (TWO_CHAINS && a == 1) ? 0.0f : bx;
         }
         // operands of K step s + 1 are read while the products of K step s run (the order is pinned below)
         bf16x8 xh[2], xl[2];
@@ -409,7 +421,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                 xl[(s + 1) & 1] = *reinterpret_cast<const bf16x8 *>(ub + (2 * s + 3) * 1024);
             }
             const bf16x8 ch = xh[s & 1], cl = xl[s & 1];
-            if constexpr (QB == 1) {
+            if constexpr (TWO_CHAINS) {
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[0][s], ch, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[0][s], cl, acc[1], 0, 0, 0);
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql[0][s], ch, acc[0], 0, 0, 0);
@@ -431,13 +443,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     };
     // the scores of tile i into the group's best / second
     float tv[QB][16];
-    auto take = [&]() {
+    auto take = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int b = 0; b < QB; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) tv[b][e] = QB == 1 ? acc[0][e] + acc[1][e] : acc[b][e];
+            for (int e = 0; e < 16; ++e) tv[b][e] = TWO_CHAINS ? acc[0][e] + acc[1][e] : acc[b][e];
     };
-    auto fold_in = [&](int i) {
+    auto fold_in = [&](int i) __attribute__((always_inline)) {
         const uint32_t pos = (uint32_t)(i & gmask);
 #pragma unroll
         for (int b = 0; b < QB; ++b)
@@ -449,7 +461,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
             }
     };
     // at the end of a group the entries leave
-    auto group_end = [&](int i) {
+    auto group_end = [&](int i) __attribute__((always_inline)) {
         const uint32_t pos = (uint32_t)(i & gmask);
         if (pos == (uint32_t)gmask || i == my_tiles - 1) {
             const int g = i >> glog;
@@ -490,14 +502,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                 for (int e = 0; e < 16; ++e) best[b][e] = second[b][e] = FS_PAD_BIAS;
         }
     };
-    auto update = [&](int i) {
+    auto update = [&](int i) __attribute__((always_inline)) {
         take();
         fold_in(i);
         group_end(i);
     };
     // the request for tile i + RU - 1 (into the slot tile i - 1 has left) and the conversion of the own share of tile i + 1
     FSS_T0();
-    auto feed = [&](int i) {
+    auto feed = [&](int i) __attribute__((always_inline)) {
         if (!(dbg & 1)) request(i + RU - 1);
         FSS_T(3);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RU - 2) * OPS) : "memory");   // own share of tile i + 1 (requested RU - 2 tiles ago) has landed
@@ -512,18 +524,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     // requests) does not run beside them: letting the two waves of a SIMD alternate between a matrix phase and a vector phase
     // (two barriers per tile) measured 254 us, a single wave per SIMD with the vector work pinned between its matrix
     // instructions by sched_group_barrier 290 us.)
+    // The waves of one SIMD (w, w + 4, w + 8) do not walk the phases of a tile in the same order: the first feeds (requests +
+    // conversion), then multiplies and folds; the others multiply and fold first -- one of them feeds afterwards.  One barrier
+    // per tile for all of them.
+    const bool feed_first = NW <= 4 || (wave_id >> 2) == 0;
     for (int i = 0; i < my_tiles; ++i) {
         // everyone's converted share of tile i is in LDS, everyone has read tile i - 1
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         FSS_T(0);
-        feed(i);
+        if (feeds && feed_first) feed(i);
         if (!(dbg & 2)) products(i);
         FSS_T(1);
         if (!(dbg & 4)) update(i);
         FSS_T(2);
+        if (feeds && !feed_first) feed(i);
     }
     FSS_TEND();
-    {
+    if (computes) {
         const int pfx = lj >> 2;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -919,15 +936,16 @@ static int fs_qb_max(int nch)
 }
 static int g_fs_dbgflags = 0;     // timing experiments (results wrong when non-zero): cvtmi_set_tuning("flat_f32_dbg")
 void set_flat_f32_dbg(int v) { g_fs_dbgflags = v; }
-static int g_fs_share = 0;   // cvtmi_set_tuning("flat_f32_share"): 0 = choose, 1 = four waves of 32 QB queries, 2 = eight waves of 32 queries
+static int g_fs_share = 0;   // cvtmi_set_tuning("flat_f32_share"): 0 = choose, 1 = four waves x 32 QB queries, 2 = FS_MANY waves x 32 queries
 void set_flat_f32_share(int v) { g_fs_share = v; }
 // the shared-ring kernel wants whole K steps per wave: D / 16 a multiple of the wave count
-static bool fs_eight(int D) { return g_fs_share != 1 && (D / 16) % 8 == 0; }   // (measured faster per query than four waves x 32 QB)
+constexpr int FS_MANY = 12;   // waves of the many-wave form of the shared-ring kernel (three per SIMD)
+static bool fs_eight(int D) { return g_fs_share != 1 && (D == 64 || D == 128); }
 static bool fs_four(int D) { return (D / 16) % 4 == 0; }
 int flat_f32_stream_qmax(int D)
 {
     if (D != 32 && D != 64 && D != 96 && D != 128 && D != 192 && D != 256) return 0;
-    return fs_eight(D) ? 256 : (fs_four(D) ? 128 : 32) * fs_qb_max(D / 16);
+    return fs_eight(D) ? 32 * FS_MANY : (fs_four(D) ? 128 : 32) * fs_qb_max(D / 16);
 }
 static bool fs_shared(int D, int64_t nq) { return nq > 32 * fs_qb_max(D / 16); }
 bool flat_f32_stream_applies(int metric, int D, int64_t n, int k)
@@ -983,12 +1001,12 @@ static int fs_set_lds(const void *fn, size_t lds, bool (&done)[16])
 template <int NCH>
 static int fs_launch_eight(const FsStreamArgs &a, hipStream_t st)
 {
-    if constexpr (NCH % 8 == 0) {
+    if constexpr (NCH == 4 || NCH == 8) {
         static bool attr_set[16] = {};
-        const size_t lds = FssGeom<NCH, 8>::LDS;
-        CVTMI_TRY(fs_set_lds((const void *)flat_f32_mshare_kernel<NCH, 1, 8>, lds, attr_set));
-        hipLaunchKernelGGL((flat_f32_mshare_kernel<NCH, 1, 8>), dim3(FSS_STREAMS), dim3(512), lds, st, a.X, a.bias, a.n_tiles, a.q, a.nq, a.G, a.NG,
-                           a.gb, a.wm, a.redo, a.cnt, g_fs_dbgflags);
+        const size_t lds = FssGeom<NCH, NCH>::LDS;
+        CVTMI_TRY(fs_set_lds((const void *)flat_f32_mshare_kernel<NCH, 1, FS_MANY, NCH>, lds, attr_set));
+        hipLaunchKernelGGL((flat_f32_mshare_kernel<NCH, 1, FS_MANY, NCH>), dim3(FSS_STREAMS), dim3(64 * FS_MANY), lds, st, a.X, a.bias, a.n_tiles, a.q,
+                           a.nq, a.G, a.NG, a.gb, a.wm, a.redo, a.cnt, g_fs_dbgflags);
         CVTMI_HIP(hipGetLastError());
         return CVTMI_OK;
     } else {
@@ -1003,8 +1021,8 @@ static int fs_launch_stream(const FsStreamArgs &a, hipStream_t st)
         return fail(CVTMI_EINVAL, "flat_f32_stream: shared ring at D=%d", 16 * NCH);
     } else if constexpr (SHARED) {
         const size_t lds = FssGeom<NCH, 4>::LDS;
-        CVTMI_TRY(fs_set_lds((const void *)flat_f32_mshare_kernel<NCH, QB, 4>, lds, attr_set));
-        hipLaunchKernelGGL((flat_f32_mshare_kernel<NCH, QB, 4>), dim3(FSS_STREAMS), dim3(256), lds, st, a.X, a.bias, a.n_tiles, a.q, a.nq, a.G, a.NG,
+        CVTMI_TRY(fs_set_lds((const void *)flat_f32_mshare_kernel<NCH, QB, 4, 4>, lds, attr_set));
+        hipLaunchKernelGGL((flat_f32_mshare_kernel<NCH, QB, 4, 4>), dim3(FSS_STREAMS), dim3(256), lds, st, a.X, a.bias, a.n_tiles, a.q, a.nq, a.G, a.NG,
                            a.gb, a.wm, a.redo, a.cnt, g_fs_dbgflags);
     } else {
         const size_t lds = (size_t)4 * FsGeom<NCH>::WAVE_LDS;
