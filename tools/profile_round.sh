@@ -5,7 +5,7 @@
 #   2. bench.py, headline only, once per PMC group (counters never share a run with a trace domain other than kernel-trace)
 #   3. the scan at an HBM-resident shard (128 M rows = the per-GPU shard of SIFT-1B): kernel-trace + FETCH_SIZE / WRITE_SIZE passes
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
@@ -73,6 +73,32 @@ for f in sorted(glob.glob(os.path.join(out, "u8_pmc_*_*.json"))):
 json.dump({"what": "10 M x 512-d uint8 rows, top-10, default dispatch; counters are sums over the run's dispatches of that kernel (3 searches + warm-up); FETCH_SIZE is in KB and needs the x2 gfx950 correction", "by_batch": u8},
           open(os.path.join(out, tag + "_pmc_flat_u8.json"), "w"), indent=1)
 PY
+# 5. fp32 flat search (1 M x 128-d, top-100): the stream kernels at nq = 1 / 64 / 1000, one PMC group per run
+v=0
+for pmc in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS"; do
+  v=$((v+1))
+  for nq in 1000 64 1; do
+    rm -rf /tmp/prof_f32
+    NQ=$nq REPS=3 timeout 600 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d /tmp/prof_f32 -o f32 -- python $REPO/tools/f32_one.py > /tmp/f32_run.log 2>&1
+    echo "f32 nq=$nq pmc [$pmc] rc=$?"
+    python $REPO/tools/pmc_summary.py /tmp/prof_f32 flat_f32 > $OUT/f32_pmc_${v}_$nq.json
+  done
+done
+python - <<PY
+import json, glob, os
+out, tag = "$OUT", "$TAG"
+f32 = {}
+for f in sorted(glob.glob(os.path.join(out, "f32_pmc_*_*.json"))):
+    nq = f.rsplit("_", 1)[1].split(".")[0]
+    d = json.load(open(f))
+    for k, v in d.get("counters", {}).items():
+        e = f32.setdefault("nq=" + nq, {}).setdefault(k, {})
+        e.update(v)
+        e.setdefault("kernel_trace", {}).update(d.get("kernel_trace", {}).get(k, {}))
+json.dump({"what": "1 M x 128-d fp32 rows (inner product), top-100, default dispatch; counters are per-dispatch means of that kernel; FETCH_SIZE is in KB and needs the x2 gfx950 correction", "by_batch": f32},
+          open(os.path.join(out, tag + "_pmc_flat_f32.json"), "w"), indent=1)
+PY
 python - <<PY
 import json, glob, os
 out, tag = "$OUT", "$TAG"
@@ -100,6 +126,6 @@ c1, t1 = merge("pmc_*.json"); traffic(c1, t1, tag + "_scan_traffic.json")
 c2, t2 = merge("big_pmc_*.json"); traffic(c2, t2, tag + "_scan_traffic_128m.json")
 PY
 cd $REPO
-{ python tools/bench_kernels.py; python tools/bench_sq8.py; python tools/bench_flat_f32.py; python tools/bench_flat_u8_opt.py; python tools/bench_train.py; python tools/bench_pca.py; python tools/bench_encode.py; python tools/bench_assign.py; python tools/bench_flat_filter.py; python tools/bench_ivf.py; NQ=9 python tools/bench_ivf.py; python tools/bench_hnsw.py; METRIC=2 ROWS=10000000 D=512 python tools/flat_nq_sweep.py; METRIC=2 ROWS=10000000 D=128 python tools/flat_nq_sweep.py; METRIC=1 python tools/flat_nq_sweep.py; python tools/opq_nq_sweep.py; } 2>&1 | grep -v amdgpu > $OUT/${TAG}_other_kernels.txt
-rm -f $OUT/pmc_*.json $OUT/big_pmc_*.json $OUT/u8_pmc_*.json
+{ exec < /dev/null; python tools/bench_kernels.py; python tools/bench_sq8.py; METRIC=0 python tools/flat_nq_sweep.py; python tools/bench_flat_u8_opt.py; python tools/bench_train.py; python tools/bench_pca.py; python tools/bench_encode.py; python tools/bench_assign.py; python tools/bench_flat_filter.py; python tools/bench_ivf.py; NQ=9 python tools/bench_ivf.py; python tools/bench_hnsw.py; METRIC=2 ROWS=10000000 D=512 python tools/flat_nq_sweep.py; METRIC=2 ROWS=10000000 D=128 python tools/flat_nq_sweep.py; METRIC=1 python tools/flat_nq_sweep.py; python tools/opq_nq_sweep.py; } 2>&1 | grep -v amdgpu > $OUT/${TAG}_other_kernels.txt
+rm -f $OUT/pmc_*.json $OUT/big_pmc_*.json $OUT/u8_pmc_*.json $OUT/f32_pmc_*.json
 ls -la $OUT
