@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcvtmi.so")
+LIB_PATH = os.environ.get("CVTMI_LIB") or os.path.join(_HERE, "lib", "libcvtmi.so")   # CVTMI_LIB: an instrumented / experimental build
 _lib = None
 
 

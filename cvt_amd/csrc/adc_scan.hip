@@ -47,6 +47,7 @@ struct ScanArgs {
     const uint8_t *codes_rot;  // adc_scan16q: copy of the code rows with row r rotated left by r & 15 bytes (or null)
     uint32_t *gthr;            // adc_scan16q: [nq] filter thresholds (table units) shared by the row splits of a query, or null
     int lazy;                  // adc_scan16q: 1 = intermediate compactions select on the integer lower bounds (exact sums only at the end)
+    int seed;                  // adc_scan16q / 16a: 1 = first thresholds from a histogram of the split's first rows (scan16q_seed)
 };
 
 template <int M> struct CodeRow;
@@ -507,6 +508,7 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16_kernel(const ScanArgs
 // ==========================================================================================
 #ifdef CVTMI_SCAN_TIMING
 __device__ unsigned long long g_scan_dbg[8];
+__device__ unsigned long long g_scan_dbg2[8];  // adc_scan16a slow path, lane 0 of every wave: calls, cycles, compactions, compaction cycles, cycles waiting for stores, retry rounds
 __device__ unsigned long long g_scan_trace[4 * 16384];  // per workgroup: wall start, wall end (100 MHz), shader clocks, HW_ID | XCC_ID << 32
 #define SQ_T(i) do { if (threadIdx.x == 0) { const unsigned long long now__ = clock64(); t_acc__[i] += now__ - t_last__; t_last__ = now__; } } while (0)
 #define SQ_T0() unsigned long long t_last__ = clock64(); unsigned long long t_acc__[5] = { 0, 0, 0, 0, 0 }; \
@@ -515,7 +517,13 @@ __device__ unsigned long long g_scan_trace[4 * 16384];  // per workgroup: wall s
     if (blockIdx.x < 16384) { unsigned long long *tr__ = g_scan_trace + 4 * blockIdx.x; tr__[0] = w_first__; tr__[1] = wall_clock64(); \
         tr__[2] = clock64() - t_first__; \
         tr__[3] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); } } } while (0)
+#define SQA_ADD(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&ck.dbg[i], (unsigned long long)(v)); } while (0)  // LDS; flushed once per workgroup
+#define SQA_SET(i, v) do { if ((threadIdx.x & 63) == 0) ck.dbg[i] += (unsigned long long)(v); } while (0)
+#define SQA_NOW() clock64()
 #else
+#define SQA_SET(i, v) do { } while (0)
+#define SQA_ADD(i, v) do { } while (0)
+#define SQA_NOW() 0ll
 #define SQ_T(i) do { } while (0)
 #define SQ_T0() do { } while (0)
 #define SQ_TEND() do { } while (0)
@@ -642,13 +650,13 @@ __device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b)
 // topk_compact_wave_q.  Queries whose tables hold non-finite entries never start lazy (slack = 0): S is no upper bound there.
 template <int QT, int CAP, class FixB, class ThrX>
 __device__ __attribute__((noinline)) int scan_compact_lazy_q(TopKShared<QT, CAP> &s, int q, int k, const FixB &fixb, const ThrX &thrx,
-                                                            uint32_t slack, int keep_max, int *lazy_flag)
+                                                            uint32_t slack, int keep_max, int *lazy_flag, int n_in = -1)
 {
     static_assert(CAP <= 256, "register selection holds 256 entries per wave");
     constexpr int NR = CAP <= 64 ? 1 : (CAP <= 128 ? 2 : 4);
     const int lane = threadIdx.x & 63;
     unsigned long long *b = s.buf[q];
-    int n = s.cnt[q];
+    int n = n_in >= 0 ? n_in : s.cnt[q];
     n = n < CAP ? n : CAP;
     unsigned long long e[NR];
 #pragma unroll
@@ -704,44 +712,20 @@ __device__ __attribute__((noinline)) int scan_compact_lazy_q(TopKShared<QT, CAP>
     return k;
 }
 
-template <int NT, int R, bool PREROT>
-__global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArgs a)
+// The QT queries' tables of `group`, quantised into LDS: lut[code j][m][q] u16, with the per-query scale / bias /
+// lazy-selection parameters in qp.  mx_bits = QT x 16 words of scratch; nonfinite / lazy = QT flags each.
+// Called by the whole workgroup; ends with a barrier.
+template <int NT>
+__device__ __forceinline__ void scan16q_build_tables(const ScanArgs &a, int group, uint32_t *lut, QuantParams &qp, uint32_t (*mx_bits)[16],
+                                                     int *nonfinite, int *lazy)
 {
     constexpr int M = 16, QT = SQ_QT;
-    __shared__ __attribute__((aligned(16))) uint32_t lut[256 * 16 * QT / 2];  // u16 [code j][m][q]: 16 B per (j, m)
-    __shared__ TopKShared<QT, SQ_CAP> tk;
-    __shared__ QuantParams qp;
-    __shared__ struct { int stop, done_waves; uint32_t next_chunk; uint32_t thr_pk[QT / 2]; int lazy[QT]; int nonfinite[QT]; } ck;
-
-    SQ_T0();
-    int group, split, my_splits = a.splits;
-    int64_t my_rps = a.rows_per_split;
-    {
-        int b = blockIdx.x, g0 = 0;
-        if (b >= a.groups_a * a.splits) {  // region B: the tail groups, split finer (dispatched last)
-            b -= a.groups_a * a.splits;
-            g0 = a.groups_a;
-            my_splits = a.splits_b;
-            my_rps = a.rows_per_split_b;
-        }
-        if ((my_splits & 7) == 0) {
-            const int s8 = my_splits >> 3;
-            const int xcd = b & 7, i = b >> 3;
-            split = xcd + 8 * (i % s8);
-            group = g0 + i / s8;
-        } else {
-            split = b % my_splits;
-            group = g0 + b / my_splits;
-        }
-    }
     const int tid = threadIdx.x, lane = tid & 63;
-    topk_init(tk);
-    uint32_t(*mx_bits)[16] = reinterpret_cast<uint32_t(*)[16]>(&tk.buf[0][0]);  // 128 words on the (still unused) buffers
     if (tid < QT * 16) {
         qp.mn_bits[tid >> 4][tid & 15] = 0x7f7fffffu;  // FLT_MAX
         mx_bits[tid >> 4][tid & 15] = 0u;
     }
-    if (tid < QT) ck.nonfinite[tid] = 0;
+    if (tid < QT) nonfinite[tid] = 0;
     __syncthreads();
     // fp32 table entries of (m, j) for the QT queries, from the per-query tables a.lut_g
     // (lut_kernel: IVFOPQ.cpp:279-291); lanes walk consecutive j -> coalesced
@@ -766,7 +750,7 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
             const uint32_t bits = __float_as_uint(acc[q]);
             uint32_t lo = bits < 0x7f800000u ? bits : 0x7f7fffffu;  // non-finite: ignored
             uint32_t hi = bits < 0x7f800000u ? bits : 0u;
-            if (__ballot(bits >= 0x7f800000u) != 0 && lane == 0) ck.nonfinite[q] = 1;  // (the +inf padding past K counts: a code >= K reaches it)
+            if (__ballot(bits >= 0x7f800000u) != 0 && lane == 0) nonfinite[q] = 1;  // (the +inf padding past K counts: a code >= K reaches it)
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) {
                 const uint32_t l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
@@ -800,9 +784,9 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
         qp.bias[q] = bias;
         // lazy selection (scan_compact_lazy_q): usable when every table entry is finite and the band stays narrow
         const double sl = 34.0 + ceil(4e-6 * (32767.0 + bias * (double)inv));
-        const bool lazy_ok = a.lazy && !ck.nonfinite[q] && sl < 1024.0 && bias >= 0.0;
+        const bool lazy_ok = a.lazy && !nonfinite[q] && sl < 1024.0 && bias >= 0.0;
         qp.slack[q] = lazy_ok ? (uint32_t)sl : 0u;
-        ck.lazy[q] = lazy_ok ? 1 : 0;
+        lazy[q] = lazy_ok ? 1 : 0;
     }
     __syncthreads();
     // pass B: quantise  qv = max(0, floor((v - min_m) * inv) - 1), non-finite entries -> 0 (a lower bound of anything)
@@ -826,6 +810,140 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
             make_uint4(qv[0] | (qv[1] << 16), qv[2] | (qv[3] << 16), qv[4] | (qv[5] << 16), qv[6] | (qv[7] << 16));
     }
     __syncthreads();  // tables ready; the scratch words on tk.buf are dead from here on
+}
+
+// the 16 look-ups of one row: packed 15-bit sums of the SQ_QT queries, two per word.  In groups of four -- the scheduler
+// would otherwise form all 16 addresses first, more registers than a wave of these kernels has.  Integer sums, any order.
+template <bool PREROT>
+__device__ __forceinline__ void scan16q_row_sums(const uint4 &row, const uint32_t (&moffp)[4], uint32_t cr8, uint32_t cq, const char *lut_b,
+                                                 uint32_t &s0, uint32_t &s1, uint32_t &s2, uint32_t &s3)
+{
+    uint32_t d0 = row.x, d1 = row.y, d2 = row.z, d3 = row.w;
+    if constexpr (!PREROT) {
+        d0 = __builtin_amdgcn_alignbit(row.y, row.x, cr8);
+        d1 = __builtin_amdgcn_alignbit(row.z, row.y, cr8);
+        d2 = __builtin_amdgcn_alignbit(row.w, row.z, cr8);
+        d3 = __builtin_amdgcn_alignbit(row.x, row.w, cr8);
+        const bool b0 = cq & 1;
+        const uint32_t e0 = b0 ? d1 : d0, e1 = b0 ? d2 : d1, e2 = b0 ? d3 : d2, e3 = b0 ? d0 : d3;
+        const bool b1 = cq & 2;
+        d0 = b1 ? e2 : e0; d1 = b1 ? e3 : e1; d2 = b1 ? e0 : e2; d3 = b1 ? e1 : e3;
+    }
+    const uint32_t rot[4] = { d0, d1, d2, d3 };
+    constexpr int NG = 4;
+    s0 = 0; s1 = 0; s2 = 0; s3 = 0;
+#pragma unroll
+    for (int h = 0; h < 16 / NG; ++h) {
+        uint4 v[NG];
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            const int tt = NG * h + t;
+            const uint32_t sel = 0x0c0c0000u | ((4u + (tt & 3)) << 8) | (uint32_t)(tt & 3);
+            const uint32_t addr = __builtin_amdgcn_perm(rot[tt >> 2], moffp[tt >> 2], sel);  // code*256 + m*16
+            v[t] = *reinterpret_cast<const uint4 *>(lut_b + addr);
+        }
+#pragma unroll
+        for (int t = 0; t < NG; t += 2) {
+            s0 = s0 + v[t].x + v[t + 1].x; s1 = s1 + v[t].y + v[t + 1].y;
+            s2 = s2 + v[t].z + v[t + 1].z; s3 = s3 + v[t].w + v[t + 1].w;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Seed: a first filter threshold per query from a histogram of the split's first SQ_SEED_CHUNKS x 64 rows.
+// Without it a scan starts with "every row passes": a thousand rows in flight against SQ_CAP slots, and four to five rounds of
+// the whole workgroup waiting for compactions before the pass rate has fallen.  bin = sum >> 7; the first bin b at which the
+// cumulative count reaches k proves k rows with sum < (b + 1) << 7 =: S, hence S_k <= S, and T = S + slack is a valid (looser)
+// lazy-selection threshold (scan_compact_lazy_q).  Queries that cannot select lazily keep "pass all".  The seed rows are
+// scanned again by the main loop.  hist = SQ_QT x 256 words (the still unused selection buffers).  Whole workgroup; ends with a barrier.
+constexpr uint32_t SQ_SEED_CHUNKS = 32;
+template <int NT, bool PREROT, class LoadRow>
+__device__ __forceinline__ void scan16q_seed(int k, const LoadRow &load_row, const uint32_t (&moffp)[4], uint32_t cr8, uint32_t cq, const char *lut_b,
+                                             uint32_t *hist, const QuantParams &qp, const int *lazy, uint32_t *thr_x, uint32_t *thr_pk)
+{
+    constexpr int QT = SQ_QT, NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < QT * 256; i += NT) hist[i] = 0;
+    __syncthreads();
+    for (uint32_t ch = wave; ch < SQ_SEED_CHUNKS; ch += NW) {
+        const uint4 row = load_row(ch * 64 + lane);
+        uint32_t sm[4];
+        scan16q_row_sums<PREROT>(row, moffp, cr8, cq, lut_b, sm[0], sm[1], sm[2], sm[3]);
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            const uint32_t sq = (sm[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+            atomicAdd(&hist[q * 256 + (sq >> 7)], 1u);
+        }
+    }
+    __syncthreads();
+    if (wave < QT && lazy[wave]) {
+        const int q = wave;
+        uint32_t c4[4], mine = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c4[j] = hist[q * 256 + lane * 4 + j]; mine += c4[j]; }
+        uint32_t incl = mine;  // inclusive prefix over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        const unsigned long long reach = __ballot(incl >= (uint32_t)k);
+        if (reach) {  // wave-uniform
+            const int l0 = __ffsll((long long)reach) - 1;
+            if (lane == l0) {
+                uint32_t cum = incl - mine;
+                int b = lane * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cum += c4[j];
+                    if (cum >= (uint32_t)k) { b = lane * 4 + j; break; }
+                }
+                uint32_t t = ((uint32_t)(b + 1) << 7) + qp.slack[q];
+                t = t < 32767u ? t : 32767u;
+                const uint32_t have = thr_x[q];  // what the other row splits have established already
+                t = have < t ? have : t;
+                thr_x[q] = t;
+                reinterpret_cast<uint16_t *>(thr_pk)[q] = (uint16_t)t;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int NT, int R, bool PREROT>
+__global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArgs a)
+{
+    constexpr int QT = SQ_QT;
+    __shared__ __attribute__((aligned(16))) uint32_t lut[256 * 16 * QT / 2];  // u16 [code j][m][q]: 16 B per (j, m)
+    __shared__ TopKShared<QT, SQ_CAP> tk;
+    __shared__ QuantParams qp;
+    __shared__ struct { int stop, done_waves; uint32_t next_chunk; uint32_t thr_pk[QT / 2]; int lazy[QT]; int nonfinite[QT]; } ck;
+
+    SQ_T0();
+    int group, split, my_splits = a.splits;
+    int64_t my_rps = a.rows_per_split;
+    {
+        int b = blockIdx.x, g0 = 0;
+        if (b >= a.groups_a * a.splits) {  // region B: the tail groups, split finer (dispatched last)
+            b -= a.groups_a * a.splits;
+            g0 = a.groups_a;
+            my_splits = a.splits_b;
+            my_rps = a.rows_per_split_b;
+        }
+        if ((my_splits & 7) == 0) {
+            const int s8 = my_splits >> 3;
+            const int xcd = b & 7, i = b >> 3;
+            split = xcd + 8 * (i % s8);
+            group = g0 + i / s8;
+        } else {
+            split = b % my_splits;
+            group = g0 + b / my_splits;
+        }
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    topk_init(tk);
+    scan16q_build_tables<NT>(a, group, lut, qp, reinterpret_cast<uint32_t(*)[16]>(&tk.buf[0][0]), ck.nonfinite, ck.lazy);  // scratch on the (still unused) buffers
     SQ_T(0);  // prologue
 
     const uint4 *rows = reinterpret_cast<const uint4 *>(a.codes);
@@ -872,6 +990,9 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
         for (int b = 0; b < 4; ++b) moffp[w] |= (((4 * w + b + c) & 15u) * 16u) << (8 * b);
     }
     const char *lut_b = reinterpret_cast<const char *>(lut);
+    if (a.seed && (n_local + 63) / 64 >= 4 * SQ_SEED_CHUNKS)  // workgroup-uniform
+        scan16q_seed<NT, PREROT>(a.k, load_row, moffp, cr8, cq, lut_b, reinterpret_cast<uint32_t *>(&tk.buf[0][0]), qp, ck.lazy, tk.thr_x, ck.thr_pk);
+    SQ_T(0);
 
     // ---- main loop: waves run on their own between checkpoints ----
     // Between two checkpoints a wave processes 64*R-row chunks with NO workgroup barrier: candidates go to the shared buffers with LDS atomics.  A push that
@@ -1040,6 +1161,376 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
     }
 }
 
+// ==========================================================================================
+// adc_scan16a: adc_scan16q without checkpoints -- compactions run BESIDE the scan.
+//
+// In adc_scan16q every compaction parks the whole workgroup: all waves meet at a barrier, one wave per query
+// compacts, a second barrier releases them (13 such stops per workgroup over 1 M rows: 15 % of its life, and the
+// reason a row split costs as much as 0.38 M rows).  Here nobody waits for a compaction that is not in his way:
+//   * a push takes its slot with one LDS atomic (cnt[q]) and stores the entry with one 8-byte store (free slots hold SQA_EMPTY);
+//   * the pusher that takes slot TRIG-1 raises bit q of `duty`; the workgroup's last wave does not scan: it sleeps on
+//     `duty` and compacts query q ON ITS OWN while the 15 scanning waves keep scanning and keep pushing into the
+//     CAP-TRIG slots above the trigger (the loop is bound by VALU issue, not by the number of waves: the scanning waves
+//     take the slots the 16th would have used);
+//   * the service wave LOCKS the counter (cnt[q] += LOCK: every later push sees "full"), waits until none of the
+//     slots handed out before the lock reads SQA_EMPTY any more, selects (scan_compact_lazy_q / topk_compact_wave_q as
+//     in adc_scan16q), resets the slots it freed, publishes the new 15-bit threshold (a 2-byte store into thr_pk,
+//     then epoch++), and unlocks with cnt[q] = kept;
+//   * a scanning wave reads `epoch` once per chunk (where adc_scan16q read `stop`) and reloads the packed
+//     thresholds only when it moved;
+//   * a lane whose push found the buffer full keeps its candidate, sleeps, re-reads the threshold (the candidate may
+//     have dropped out) and tries again -- rare, because a histogram of the first 2048 rows seeds the thresholds
+//     (see "seed" in the kernel), so the scan never goes through the phase in which every row passes.
+// Progress: the trigger slot lies below the capacity, so a full buffer always has its duty bit up or its compaction
+// running; a compaction only waits for stores that follow their atomic unconditionally.  Results: the buffers hold a
+// superset of the rows below the final threshold, exactly as before (a push under an older, looser threshold is still
+// a valid candidate), and the final compaction re-sums in the reference's order.
+// ==========================================================================================
+constexpr int SQA_LOCK = 1 << 20;
+#ifndef SQA_SERVERS
+#define SQA_SERVERS 2
+#endif
+
+
+struct ScanAsyncCtl {
+    __attribute__((aligned(16))) uint32_t thr_pk[SQ_QT / 2];  // 15-bit thresholds, two per word
+    uint32_t next_chunk, epoch;
+    uint32_t duty;  // bit q: query q wants a compaction
+    int done_waves;  // scanning waves that are out of rows
+    int lazy[SQ_QT], nonfinite[SQ_QT];
+    // what the slow path needs of the kernel's arguments (uniform; kept here so that its call passes three pointers)
+    const uint4 *rows;
+    const float *lut_g;
+    uint32_t *gthr;
+    int K, nq, group, k;
+#ifdef CVTMI_SCAN_TIMING
+    unsigned long long dbg[8];
+#endif
+};
+using ScanAsyncTopK = TopKShared<SQ_QT, SQ_CAP>;
+constexpr unsigned long long SQA_EMPTY = ~0ull;  // a slot nobody has stored into since the last compaction (no entry looks like it: row ids stop at 2^32 - 2)
+
+__device__ __forceinline__ void scan16a_load_thr(const ScanAsyncCtl &ck, uint32_t (&tpk)[SQ_QT / 2])
+{
+#pragma unroll
+    for (int i = 0; i < SQ_QT / 2; ++i) tpk[i] = __hip_atomic_load(&ck.thr_pk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// one attempt to store the candidates in `pend` (bit q = this lane's row is a candidate of query q); the stored ones leave
+// `pend`; the pusher that takes the trigger slot raises the query's duty bit.  Returns the duties this lane raised.
+__device__ __forceinline__ uint32_t scan16a_push(ScanAsyncTopK &tk, ScanAsyncCtl &ck, uint32_t &pend, const uint32_t (&sums)[4], uint32_t row)
+{
+    uint32_t trig = 0;
+#pragma unroll
+    for (int q = 0; q < SQ_QT; ++q) {
+        if (!(pend & (1u << q))) continue;
+        const int pos = atomicAdd(&tk.cnt[q], 1);
+        if (pos < SQ_CAP) {
+            const uint32_t sq = (sums[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+            tk.buf[q][pos] = ((unsigned long long)sq << 32) | row;  // one 8-byte store: a reader sees SQA_EMPTY or the entry
+            pend &= ~(1u << q);
+            if (pos == SQ_TRIG - 1) trig |= 1u << q;
+        }
+    }
+    if (trig) atomicOr(&ck.duty, trig);
+    return trig;
+}
+
+// ---- the compaction side of adc_scan16a ----
+// Coding rule for these wave-level loops: no `if (lane == 0)` region next to a loop's back edge.  Steps that only one lane
+// may take effect in are atomics whose operand is neutral in the other lanes (add 0, and ~0) or stores of a wave-uniform
+// value.  (With one-lane regions at the end of the service loop hipcc once structured it so that lanes 1..63 left the
+// loop after the first compaction and lane 0 compacted alone from then on: four entries seen, threshold back at "pass all",
+// a compaction every 40 rows -- 100x the run time, results still exact.)
+
+// takes one raised duty bit: the query to compact, -1 if none is up, -2 if another wave was faster (look again)
+__device__ __forceinline__ int scan16a_claim(ScanAsyncCtl &ck)
+{
+    const bool l0 = (threadIdx.x & 63) == 0;
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ck.duty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (m == 0) return -1;
+    const int q = __ffs((int)m) - 1;
+    const uint32_t old = (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicAnd(&ck.duty, l0 ? ~(1u << q) : ~0u));
+    return (old >> q) & 1u ? q : -2;
+}
+
+// query q is compacted by the calling wave alone (q wave-uniform, its duty bit taken by the caller)
+__device__ __forceinline__ void scan16a_compact(ScanAsyncTopK &tk, ScanAsyncCtl &ck, QuantParams &qp, int q)
+{
+    constexpr int QT = SQ_QT;
+    const int lane = threadIdx.x & 63;
+    const bool l0 = lane == 0;
+    const int k = ck.k, group = ck.group;
+    const ExactFromLutBatch fixb{ ck.rows, ck.lut_g, ck.K, ck.nq, group };
+    const QuantThr thrx{ &qp };
+    const int keep_max = k + 48 < SQ_TRIG - 24 ? k + 48 : SQ_TRIG - 24;
+    [[maybe_unused]] const long long t_c0 = SQA_NOW();
+    const int n_old = __builtin_amdgcn_readfirstlane(atomicAdd(&tk.cnt[q], l0 ? SQA_LOCK : 0));  // from here on every push to q fails
+    const int n = n_old < SQ_CAP ? n_old : SQ_CAP;
+    for (;;) {  // the slots handed out before the lock may still be on their way
+        bool hole = false;
+#pragma unroll
+        for (int r = 0; r < (SQ_CAP + 63) / 64; ++r) {
+            const int p = r * 64 + lane;
+            const unsigned long long e = __hip_atomic_load(&tk.buf[q][p < n ? p : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            hole |= p < n && e == SQA_EMPTY;
+        }
+        if (!__ballot(hole)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int lazy = __builtin_amdgcn_readfirstlane(ck.lazy[q]);
+    const int keep = lazy ? scan_compact_lazy_q<QT, SQ_CAP>(tk, q, k, fixb, thrx, qp.slack[q], keep_max, &ck.lazy[q], n)
+                          : topk_compact_wave_q<QT, SQ_CAP, false>(tk, q, k, fixb, thrx, n);
+#pragma unroll
+    for (int r = 0; r < (SQ_CAP + 63) / 64; ++r) {  // the slots above the kept entries are free again
+        const int p = r * 64 + lane;
+        if (p >= keep && p < n) tk.buf[q][p] = SQA_EMPTY;
+    }
+    uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk.thr_x[q]);
+    const int qi = group * QT + q;
+    if (ck.gthr && qi < ck.nq) {  // (wave-uniform) the row splits of a query tighten each other's filter (same tables -> same units)
+        uint32_t seen = 0xffffffffu;
+        if (l0) seen = atomicMin(&ck.gthr[qi], t);  // one lane: 64 lanes on one global address cost 10 us
+        seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen);
+        t = seen < t ? seen : t;
+        tk.thr_x[q] = t;
+    }
+    t = t < 32767u ? t : 32767u;
+    __hip_atomic_store(reinterpret_cast<uint16_t *>(ck.thr_pk) + q, (uint16_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    atomicAdd(&ck.epoch, l0 ? 1u : 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    atomicExch(&tk.cnt[q], keep);  // unlock (every lane writes the same value)
+    SQA_ADD(2, 1);
+    SQA_ADD(3, SQA_NOW() - t_c0);
+    SQA_ADD(0, n);
+    SQA_ADD(1, keep);
+    SQA_ADD(6, lazy);
+    SQA_ADD(7, n_old > SQ_CAP ? 1 : 0);
+}
+
+// The service wave: compacts the queries whose duty bit is up until the `scanners` scanning waves have all run out of rows.
+// At raised priority: under eight waves per SIMD an instruction of this wave would otherwise issue every ~32 cycles, and every
+// counter it holds locked meanwhile stalls pushes.
+__device__ __attribute__((noinline)) void scan16a_serve(ScanAsyncTopK &tk, ScanAsyncCtl &ck, QuantParams &qp, int scanners)
+{
+    __builtin_amdgcn_s_setprio(3);
+    for (;;) {
+        const int q = scan16a_claim(ck);
+        if (q >= 0) {
+            scan16a_compact(tk, ck, qp, q);
+        } else if (q == -1) {
+            // (a bit raised after this look by a wave that then finishes is left to the final compaction: nobody waits for it)
+            const int done = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ck.done_waves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (done == scanners) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+template <int NT, int R, bool PREROT>
+__global__ __launch_bounds__(NT, NT / 128) void adc_scan16a_kernel(const ScanArgs a)
+{
+    constexpr int QT = SQ_QT;
+    __shared__ __attribute__((aligned(16))) uint32_t lut[256 * 16 * QT / 2];  // u16 [code j][m][q]: 16 B per (j, m)
+    __shared__ TopKShared<QT, SQ_CAP> tk;
+    __shared__ QuantParams qp;
+    __shared__ ScanAsyncCtl ck;
+
+    SQ_T0();
+    int group, split, my_splits = a.splits;
+    int64_t my_rps = a.rows_per_split;
+    {
+        int b = blockIdx.x, g0 = 0;
+        if (b >= a.groups_a * a.splits) {  // region B: the tail groups, split finer (dispatched last)
+            b -= a.groups_a * a.splits;
+            g0 = a.groups_a;
+            my_splits = a.splits_b;
+            my_rps = a.rows_per_split_b;
+        }
+        if ((my_splits & 7) == 0) {
+            const int s8 = my_splits >> 3;
+            const int xcd = b & 7, i = b >> 3;
+            split = xcd + 8 * (i % s8);
+            group = g0 + i / s8;
+        } else {
+            split = b % my_splits;
+            group = g0 + b / my_splits;
+        }
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    topk_init(tk);
+    scan16q_build_tables<NT>(a, group, lut, qp, reinterpret_cast<uint32_t(*)[16]>(&tk.buf[0][0]), ck.nonfinite, ck.lazy);
+    SQ_T(0);  // prologue
+
+    const uint4 *rows = reinterpret_cast<const uint4 *>(a.codes);
+    const ExactFromLutBatch fixb{ rows, a.lut_g, a.K, a.nq, group };
+    const QuantThr thrx{ &qp };
+    if (tid < QT / 2) {  // pass-all until k rows are known -- or what the other row splits of these queries have already established
+        uint32_t t2[2] = { 32767u, 32767u };
+        if (a.gthr) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int qi = group * QT + 2 * tid + h;
+                if (qi < a.nq) {  // a stale value is an older, looser, still valid bound
+                    const uint32_t g = __hip_atomic_load(&a.gthr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    t2[h] = g < t2[h] ? g : t2[h];
+                }
+            }
+        }
+        tk.thr_x[2 * tid] = t2[0]; tk.thr_x[2 * tid + 1] = t2[1];
+        ck.thr_pk[tid] = t2[0] | (t2[1] << 16);
+    }
+#ifdef CVTMI_SCAN_TIMING
+    if (tid < 8) ck.dbg[tid] = 0;
+#endif
+    if (tid == 0) {
+        ck.next_chunk = 0; ck.epoch = 0; ck.duty = 0; ck.done_waves = 0;
+        ck.rows = rows; ck.lut_g = a.lut_g; ck.gthr = a.gthr; ck.K = a.K; ck.nq = a.nq; ck.group = group; ck.k = a.k;
+    }
+    __syncthreads();
+
+    const int64_t row_begin = (int64_t)split * my_rps;
+    int64_t row_end = row_begin + my_rps;
+    row_end = row_end < a.n_rows ? row_end : a.n_rows;
+    const uint32_t n_local = (uint32_t)(row_end > row_begin ? row_end - row_begin : 0);
+    const char *rows_b = PREROT ? reinterpret_cast<const char *>(reinterpret_cast<const uint4 *>(a.codes_rot) + row_begin)
+                                : reinterpret_cast<const char *>(rows + row_begin);
+    const uint32_t last = n_local ? n_local - 1 : 0;
+    auto load_row = [&](uint32_t lrow) -> uint4 {
+        const uint32_t cl = lrow < last ? lrow : last;
+        return *reinterpret_cast<const uint4 *>(rows_b + (size_t)(cl * 16u));
+    };
+    const uint32_t c = tid & 15;
+    const uint32_t cr8 = (c & 3) * 8, cq = c >> 2;
+    uint32_t moffp[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        moffp[w] = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) moffp[w] |= (((4 * w + b + c) & 15u) * 16u) << (8 * b);
+    }
+    const char *lut_b = reinterpret_cast<const char *>(lut);
+    static_assert(R == 1, "adc_scan16a: one row per lane and chunk");
+    constexpr uint32_t WROWS = 64;
+    constexpr int NW = NT / 64, NSV = SQA_SERVERS, SV = NW - NSV;  // waves SV.. serve the compactions, the others scan
+    const int wave = tid >> 6;
+    const uint32_t n_chunks = (n_local + WROWS - 1) / WROWS;
+
+    if (a.seed && n_chunks >= 4 * SQ_SEED_CHUNKS)  // workgroup-uniform
+        scan16q_seed<NT, PREROT>(a.k, load_row, moffp, cr8, cq, lut_b, reinterpret_cast<uint32_t *>(&tk.buf[0][0]), qp, ck.lazy, tk.thr_x, ck.thr_pk);
+    for (int i = tid; i < QT * SQ_CAP; i += NT) (&tk.buf[0][0])[i] = SQA_EMPTY;
+    __syncthreads();
+    SQ_T(3);  // seed
+
+    // ---- main loop: no workgroup barrier until the rows are exhausted ----
+    if (wave >= SV) {
+        scan16a_serve(tk, ck, qp, SV);
+    } else {
+        auto grab = [&]() -> uint32_t {
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(&ck.next_chunk, 1u);
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        };
+        uint32_t it = grab(), it_next = grab();
+        uint4 cur = make_uint4(0, 0, 0, 0), nxt;
+        if (n_local) cur = load_row(it * WROWS + lane);
+        uint32_t tpk[QT / 2];
+        scan16a_load_thr(ck, tpk);
+        uint32_t epoch_seen = 0;
+        while (it < n_chunks) {
+            const uint32_t ep = __hip_atomic_load(&ck.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // read early, used after the chunk
+            const uint32_t base = it * WROWS;
+            nxt = load_row(it_next * WROWS + lane);
+            uint32_t s0, s1, s2, s3;
+            scan16q_row_sums<PREROT>(cur, moffp, cr8, cq, lut_b, s0, s1, s2, s3);
+            // sum < T for any of the 8 queries  <=>  a sign bit in the packed (sum - T)  (both < 2^15)
+            const uint32_t sg = (pk_sub_i16(s0, tpk[0]) | pk_sub_i16(s1, tpk[1]) | pk_sub_i16(s2, tpk[2]) | pk_sub_i16(s3, tpk[3])) & 0x80008000u;
+            if (__ballot(sg != 0)) {  // rare once the threshold has tightened
+                const uint32_t lrow = base + lane;
+                const uint32_t sums[4] = { s0, s1, s2, s3 };
+                uint32_t cand = 0;
+                if (sg != 0 && lrow < n_local) {
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) {
+                        const uint32_t sq = (sums[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                        const uint32_t tq = (tpk[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                        if (sq < tq) cand |= 1u << q;
+                    }
+                }
+                const uint32_t row = (uint32_t)(row_begin + lrow);
+                scan16a_push(tk, ck, cand, sums, row);
+                while (__ballot(cand != 0)) {  // a buffer was full: its compaction is under way (the trigger slot lies below) -- wait for room
+                    SQA_ADD(5, 1);
+                    __builtin_amdgcn_s_sleep(4);
+                    int cnt[QT];
+                    scan16a_load_thr(ck, tpk);  // a waiting candidate may have dropped out meanwhile
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) cnt[q] = __hip_atomic_load(&tk.cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    uint32_t tryq = 0;
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) {
+                        const uint32_t sq = (sums[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                        const uint32_t tq = (tpk[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                        if (!(sq < tq)) cand &= ~(1u << q);
+                        else if ((cand & (1u << q)) && cnt[q] < SQ_CAP) tryq |= 1u << q;  // (a full or locked counter is left alone)
+                    }
+                    const uint32_t before = tryq;
+                    scan16a_push(tk, ck, tryq, sums, row);
+                    cand &= ~(before & ~tryq);
+                }
+            }
+            cur = nxt;
+            it = it_next;
+            it_next = grab();
+            const uint32_t ep_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)ep);
+            if (ep_u != epoch_seen) {
+                epoch_seen = ep_u;
+                scan16a_load_thr(ck, tpk);
+            }
+        }
+        if (lane == 0) atomicAdd(&ck.done_waves, 1);
+    }
+    SQ_T(1);  // look-ups + pushes
+    __syncthreads();  // every scanning wave is out of rows, the service wave has left its loop: no counter is locked
+    SQ_T(2);
+    topk_compact_wave<QT, SQ_CAP, NT, true>(tk, a.k, fixb, thrx);
+    SQ_T(4);  // final compaction
+    SQ_TEND();
+#ifdef CVTMI_SCAN_TIMING
+    if (tid < 8) atomicAdd(&g_scan_dbg2[tid], ck.dbg[tid]);
+#endif
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        const int qi = group * QT + q;
+        if (qi >= a.nq) break;
+        const int cnt = tk.cnt[q];
+        const int64_t o = ((int64_t)qi * a.stride + split) * a.k;
+        for (int i = tid; i < a.k; i += NT) {
+            if (i < cnt) {
+                const unsigned long long e = tk.buf[q][i];
+                a.part_d[o + i] = __uint_as_float((uint32_t)(e >> 32));
+                a.part_id[o + i] = a.id_base + (int64_t)(uint32_t)e;
+            } else {
+                a.part_d[o + i] = __uint_as_float(0x7f800000u);
+                a.part_id[o + i] = -1;
+            }
+        }
+        if (split == 0 && my_splits < a.stride) {  // a region with fewer splits than the partial stride: the other slots stay empty
+            const int64_t o2 = ((int64_t)qi * a.stride + my_splits) * a.k;
+            for (int i = tid; i < (a.stride - my_splits) * a.k; i += NT) {
+                a.part_d[o2 + i] = __uint_as_float(0x7f800000u);
+                a.part_id[o2 + i] = -1;
+            }
+        }
+    }
+}
+
+static int g_scan_seed = 1;
+void set_scan_seed(int v) { g_scan_seed = v != 0; }
+
 // Row ids travel as 32-bit payloads: one launch covers at most 2^32-1 rows.
 static int cu_count()
 {
@@ -1204,7 +1695,7 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
     a.rows_per_split = rps;
     a.groups_a = a.groups; a.splits_b = 0; a.stride = plan.splits; a.rows_per_split_b = rps;
     a.part_d = part_d; a.part_id = part_id; a.lut_g = lut_scratch; a.codes_rot = codes_rot;
-    a.gthr = nullptr; a.lazy = lazy;
+    a.gthr = nullptr; a.lazy = lazy; a.seed = g_scan_seed;
     if (plan.variant >= 3 && m.M == 16 && plan.qtile == 8) {
         if (!lut_scratch) return fail(CVTMI_EINVAL, "adc_scan16q: table scratch missing");
         CVTMI_TRY(launch_lut(m, q_rot, nq, nullptr, lut_scratch, st, 256));  // [nq][16][256] fp32 (+inf past K), once per query
@@ -1221,12 +1712,15 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
             CVTMI_HIP(hipMemsetAsync(gthr, 0xff, (size_t)nq * sizeof(uint32_t), st));
             a.gthr = gthr;
         }
+        const dim3 g((unsigned)blocks);
         if (codes_rot) {
-            if (plan.variant == 3) hipLaunchKernelGGL((adc_scan16q_kernel<1024, 1, true>), dim3((unsigned)blocks), dim3(1024), 0, st, a);
-            else hipLaunchKernelGGL((adc_scan16q_kernel<512, 2, true>), dim3((unsigned)blocks), dim3(512), 0, st, a);
+            if (plan.variant == 3) hipLaunchKernelGGL((adc_scan16q_kernel<1024, 1, true>), g, dim3(1024), 0, st, a);
+            else if (plan.variant == 4) hipLaunchKernelGGL((adc_scan16q_kernel<512, 2, true>), g, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((adc_scan16a_kernel<1024, 1, true>), g, dim3(1024), 0, st, a);
         } else {
-            if (plan.variant == 3) hipLaunchKernelGGL((adc_scan16q_kernel<1024, 1, false>), dim3((unsigned)blocks), dim3(1024), 0, st, a);
-            else hipLaunchKernelGGL((adc_scan16q_kernel<512, 2, false>), dim3((unsigned)blocks), dim3(512), 0, st, a);
+            if (plan.variant == 3) hipLaunchKernelGGL((adc_scan16q_kernel<1024, 1, false>), g, dim3(1024), 0, st, a);
+            else if (plan.variant == 4) hipLaunchKernelGGL((adc_scan16q_kernel<512, 2, false>), g, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((adc_scan16a_kernel<1024, 1, false>), g, dim3(1024), 0, st, a);
         }
         CVTMI_HIP(hipGetLastError());
         return CVTMI_OK;
@@ -1254,6 +1748,13 @@ extern "C" int cvtmi_debug_scan_timing(unsigned long long *out, int reset)
     unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_dbg), sizeof z) != hipSuccess) return -3;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_scan_dbg), z, sizeof z) != hipSuccess) return -3;
+    return 0;
+}
+extern "C" int cvtmi_debug_scan_async(unsigned long long *out, int reset)
+{
+    unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_dbg2), sizeof z) != hipSuccess) return -3;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_scan_dbg2), z, sizeof z) != hipSuccess) return -3;
     return 0;
 }
 extern "C" int cvtmi_debug_topk(unsigned long long *out, int reset)

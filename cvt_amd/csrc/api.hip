@@ -273,6 +273,11 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         set_probe_variant((int)value);
         return CVTMI_OK;
     }
+    if (!strcmp(name, "scan_seed")) {
+        if (value < 0 || value > 1) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: scan_seed must be 0 or 1");
+        set_scan_seed((int)value);
+        return CVTMI_OK;
+    }
     if (!strcmp(name, "flat_f32_stream")) {
         if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_f32_stream must be 0, 1 or 2");
         g_flat_f32_stream = (int)value;
@@ -850,7 +855,7 @@ int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value)
         return CVTMI_OK;
     }
     if (!strcmp(name, "scan_variant")) {
-        if (value < 0 || value > 4) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: scan_variant must be 0..4");
+        if (value < 0 || value > 5) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: scan_variant must be 0..5");
         h->p_variant = (int)value;
         return CVTMI_OK;
     }

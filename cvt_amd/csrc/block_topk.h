@@ -308,15 +308,17 @@ static __device__ unsigned long long g_topk_dbg[4];  // compaction rounds, fix c
 // Register slot p = 64 r + lane (NE = 64 NR slots) holds new entry ex + p for p < n - ex and exact entry
 // p - (NE - ex) for p >= NE - ex: the entries to be fixed sit in the first registers, so fixb can skip its second batch when
 // there are at most 128 of them.
+// n_in >= 0: the number of entries to take (callers that keep s.cnt[q] locked while they compact), otherwise s.cnt[q]
 template <int QT, int CAP, bool SORTED, class FixB, class ThrX>
-__device__ __forceinline__ int topk_compact_wave_q_inl(TopKShared<QT, CAP> &s, int q, int k, const FixB &fixb, const ThrX &thrx)
+__device__ __forceinline__ int topk_compact_wave_q_inl(TopKShared<QT, CAP> &s, int q, int k, const FixB &fixb, const ThrX &thrx,
+                                                       int n_in = -1)
 {
     static_assert(CAP <= 256, "register sort holds 256 entries per wave");
     constexpr int NR = CAP <= 64 ? 1 : (CAP <= 128 ? 2 : 4);  // registers per lane
     constexpr int NE = 64 * NR;
     const int lane = threadIdx.x & 63;
     unsigned long long *b = s.buf[q];
-    int n = s.cnt[q];
+    int n = n_in >= 0 ? n_in : s.cnt[q];
     n = n < CAP ? n : CAP;
     const int ex = s.exact_n[q];
     unsigned long long e[NR];
@@ -384,9 +386,9 @@ __device__ __forceinline__ int topk_compact_wave_q_inl(TopKShared<QT, CAP> &s, i
 // callee-saved half of the register file (kernels near the VGPR limit use the _inl form instead)
 template <int QT, int CAP, bool SORTED, class FixB, class ThrX>
 __device__ __attribute__((noinline)) int topk_compact_wave_q(TopKShared<QT, CAP> &s, int q, int k, const FixB &fixb,
-                                                            const ThrX &thrx)
+                                                            const ThrX &thrx, int n_in = -1)
 {
-    return topk_compact_wave_q_inl<QT, CAP, SORTED>(s, q, k, fixb, thrx);
+    return topk_compact_wave_q_inl<QT, CAP, SORTED>(s, q, k, fixb, thrx, n_in);
 }
 
 template <int QT, int CAP, int NT, bool SORTED, class FixB, class ThrX>

@@ -72,6 +72,7 @@ int launch_coarse_probe(const OpqModelDev &m, const float *q_rot, int64_t nq, in
                         hipStream_t st);
 // coarse top-nprobe through the matrix-core filter (assign_mfma.hip): same probes as the exact kernels
 void set_probe_variant(int v);
+void set_scan_seed(int v);  // adc_scan16q / 16a: 1 (default) = first thresholds from a histogram of the split's first 2048 rows
 bool coarse_probe_filter_applies(const float *q, int64_t nq, int d, const float *cent, int k, int nprobe);
 int launch_coarse_probe_filtered(const float *q, int64_t nq, int d, const float *cent, int k, int nprobe, int32_t *probe, hipStream_t st);
 int launch_query_video(const OpqModelDev &m, const float *q_rot, int64_t nq, int nprobe, const int32_t *probe,

@@ -87,6 +87,8 @@ int cvtmi_set_device(int device);
  *   "flat_u8_opt"     measurement variants of the uint8 row-tile kernel (0 = shipped; 1..3 spill registers and are slower)
  *   "probe_variant"   coarse top-nk of cvtmi_opq_query_video: 0 = choose (matrix-core filter + exact distances of the candidates
  *                     from 256 query frames, 32 <= D <= 128, coarseK >= 256); 1 = exact kernels only; 2 = filter wherever it applies
+ *   "scan_seed"       1 (default) = scan variants 3 / 4 / 5 take their first filter thresholds from a histogram of the first 2048 rows of
+ *                     a row split instead of starting with "every row passes" (1-4 % on 1 M rows, more on short splits); 0 = off
  *   "comm_force_rccl" 1 = cvtmi_comm_create goes through RCCL (ncclCommInitRank, ncclAllGather) for world == 1 too, which
  *                     otherwise needs no transport (test hook for 1-GPU boxes) */
 int cvtmi_set_tuning(const char *name, int64_t value);
@@ -169,7 +171,9 @@ int cvtmi_opq_query_video_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rot
  *                 chain on the VALU; 2 = fp32 matrix-core filter, exact chain only for pairs it cannot separate
  *                 (K = 256, step 8 or 16, D <= 128; chosen automatically from 8192 rows up).  Same codes either way.
  *   "scan_variant"  M = 16 kernel choice: 0 row-per-lane; 1 / 2 skewed fp32 tables (512 / 1024 threads);
- *                   3 / 4 skewed 15-bit lower-bound tables, 8 queries per pass (1024 / 512 threads; 3 = default)
+ *                   3 / 4 skewed 15-bit lower-bound tables, 8 queries per pass (1024 / 512 threads; 3 = default);
+ *                   5 = variant 3 without checkpoints: one wave of the workgroup compacts beside the 15 that scan
+ *                   (adc_scan16a; measured 7-10 % slower than 3 on 1 M rows, kept for comparison)
  *   "prerotate"   1 (default) = variants 3 / 4 stream a copy of the code rows in which row r is rotated by r & 15
  *                 bytes (the lane skew of the conflict-free table reads), kept next to the rows: +16 bytes of HBM
  *                 per row, 12 VALU instructions fewer per row in the VALU-bound scan loop; 0 = rotate in registers

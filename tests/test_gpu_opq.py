@@ -63,7 +63,7 @@ def test_golden_exhaustive_topk(amd, golden, orc):
     idx = make_index(amd, g)
     idx.add_codes(g["codes"])
     ms = g["match_score"]
-    for variant in (4, 3, 1, 2, 0):
+    for variant in (5, 4, 3, 1, 2, 0):
         for qt in (0, 1, 2, 4, 8):
             for splits in (0, 1, 3, 8):
                 idx.set_param("scan_variant", variant); idx.set_param("qtile", qt); idx.set_param("splits", splits)
@@ -193,7 +193,7 @@ def test_search_parity_seeded(amd, orc, M, k):
     idx.add_codes(codes[:7000]); idx.add_codes(codes[7000:])   # two appends
     assert idx.ntotal == n
     od, oi = orc.adc_search(q, books, codes, k)
-    for variant, qt, splits in ((4, 0, 0), (4, 0, 1), (4, 0, 8), (3, 0, 3), (3, 0, 1), (1, 0, 0), (1, 4, 1), (1, 4, 8), (2, 4, 3), (2, 0, 0), (0, 0, 0), (0, 1, 1), (0, 2, 5), (0, 4, 8),
+    for variant, qt, splits in ((5, 0, 0), (5, 0, 1), (5, 0, 8), (5, 0, 3), (4, 0, 0), (4, 0, 1), (4, 0, 8), (3, 0, 3), (3, 0, 1), (1, 0, 0), (1, 4, 1), (1, 4, 8), (2, 4, 3), (2, 0, 0), (0, 0, 0), (0, 1, 1), (0, 2, 5), (0, 4, 8),
                                 (0, 4, 16), (0, 1, 64)):
         idx.set_param("scan_variant", variant); idx.set_param("qtile", qt); idx.set_param("splits", splits)
         d, i = idx.search(q, k, rotate=False)
@@ -234,7 +234,7 @@ def test_search_edge_cases(amd, orc):
     desc[:, 0] = ranks[(np.arange(n) * 256 // n)]
     idx.add_codes(desc)
     od, oi = orc.adc_search(q, order_books, desc, 100)
-    for variant in (4, 3, 1, 2, 0):
+    for variant in (5, 4, 3, 1, 2, 0):
         for splits in (1, 2):
             idx.set_param("scan_variant", variant); idx.set_param("splits", splits)
             d, i = idx.search(q, 100, rotate=False)
@@ -254,7 +254,7 @@ def test_two_region_scan_plan(amd, orc):
     od, oi = orc.adc_search(q, books, codes, 100)
     idx = amd.OpqIndex(np.zeros((1, D), np.float32), books)
     idx.add_codes(codes)
-    for variant in (4, 3):
+    for variant in (5, 4, 3):
         for splits, ga, sb in ((1, 3, 2), (1, 9, 3), (2, 1, 5), (8, 4, 16), (1, 10, 4), (1, 3, 8)):
             idx.set_param("scan_variant", variant); idx.set_param("splits", splits)
             idx.set_param("groups_a", ga); idx.set_param("splits_b", sb)
@@ -264,7 +264,7 @@ def test_two_region_scan_plan(amd, orc):
     # rows rotated in registers instead of streamed from the pre-rotated copy; appended rows extend the copy
     for pre in (0, 1):
         idx.set_param("prerotate", pre)
-        for variant in (4, 3):
+        for variant in (5, 4, 3):
             idx.set_param("scan_variant", variant)
             d, i = idx.search(q, 100, rotate=False)
             assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od)), (pre, variant)
@@ -323,7 +323,7 @@ def test_full_size_properties(amd, orc):
     assert np.all(np.diff(dn, axis=1) >= 0)                                   # ascending
     tie = np.diff(dn, axis=1) == 0
     assert np.all(np.diff(inn, axis=1)[tie] > 0)                              # ties in id order
-    for variant, qt, splits in ((0, 1, 8), (0, 2, 16), (0, 4, 1), (1, 4, 24), (2, 4, 1), (2, 4, 16), (1, 4, 1), (3, 0, 1), (3, 0, 8), (4, 0, 1), (4, 0, 2)):
+    for variant, qt, splits in ((0, 1, 8), (0, 2, 16), (0, 4, 1), (1, 4, 24), (2, 4, 1), (2, 4, 16), (1, 4, 1), (3, 0, 1), (3, 0, 8), (4, 0, 1), (4, 0, 2), (5, 0, 1), (5, 0, 2), (5, 0, 8)):
         idx.set_param("scan_variant", variant); idx.set_param("qtile", qt); idx.set_param("splits", splits)
         d2, i2 = idx.search(q, k)
         assert torch.equal(i2, i) and torch.equal(d2.view(torch.int32), d.view(torch.int32)), (variant, qt, splits)
@@ -406,7 +406,7 @@ def test_scan_lazy_selection_and_shared_thresholds(amd, orc):
         idx.add_codes(codes)
         for k in (1, 100, 128):
             od, oi = orc.adc_search(q, bk, codes, k)
-            for variant in (3, 4):
+            for variant in (3, 4, 5):
                 for lazy, share, splits in ((1, 1, 0), (1, 1, 1), (1, 1, 3), (1, 0, 3), (0, 1, 3), (0, 0, 1), (1, 1, 16)):
                     idx.set_param("scan_variant", variant); idx.set_param("scan_lazy", lazy); idx.set_param("scan_share", share)
                     idx.set_param("splits", splits)
