@@ -273,6 +273,11 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         set_probe_variant((int)value);
         return CVTMI_OK;
     }
+    if (!strcmp(name, "flat_f32_nt")) {
+        if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_f32_nt must be 0, 1 or 2");
+        set_flat_f32_nt((int)value);
+        return CVTMI_OK;
+    }
     if (!strcmp(name, "scan_seed")) {
         if (value < 0 || value > 1) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: scan_seed must be 0 or 1");
         set_scan_seed((int)value);

@@ -59,4 +59,27 @@ __host__ __device__ constexpr int next_pow2(int v)
     return p;
 }
 
+
+// ---- non-temporal streaming accesses -------------------------------------------------------------------------------
+// For data one CU touches once per launch (row streams in, result streams out): no place in L2 / Infinity Cache is asked for,
+// which shortens issued -> landed by ~18 % on this chip (MI355X_MICROARCH.md "nt-weights") -- measured gains are quoted where
+// a kernel uses them.  Never for data that concurrent workgroups share through L2 (the ADC scan's code rows, the filter
+// kernels' row tiles: those lose 6-10 % with it).
+#ifdef __HIPCC__
+typedef float cvt_nt_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_nt(const float4 *p)
+{
+    const cvt_nt_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const cvt_nt_f32x4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t ld_nt(const uint32_t *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_nt(float4 *p, const float4 &v)
+{
+    cvt_nt_f32x4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<cvt_nt_f32x4 *>(p));
+}
+__device__ __forceinline__ void st_nt(uint32_t *p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+#endif
+
 }  // namespace cvtmi

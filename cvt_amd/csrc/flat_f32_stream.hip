@@ -65,12 +65,18 @@ __device__ unsigned long long g_fss_dbg[2][8];   // shader clocks of waves 0 and
 #define FSS_TEND() do { } while (0)
 #endif
 
-__device__ __forceinline__ void fs_glds16(const void *gsrc, uint32_t lds_dst)
+// nt: non-temporal hint -- rows that one CU reads once per launch need no place in L2 / Infinity Cache (issued -> landed
+// 18 % sooner, MI355X_MICROARCH.md "nt-weights"; 1 M x 128-d, one query: 0.119 -> 0.106 ms)
+__device__ __forceinline__ void fs_glds16(const void *gsrc, uint32_t lds_dst, int nt)
 {
     lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst);   // wave-uniform by construction: keep it in an SGPR
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    if (nt)  // kernel argument: scalar branch
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void fs_glds4(const void *gsrc, uint32_t lds_dst)
 {
@@ -139,7 +145,7 @@ template <int NCH> struct FsGeom {
 template <int NCH, int QB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flat_f32_mstream_kernel(
     const float *__restrict__ X, const float *__restrict__ bias, int64_t n_tiles, const float *__restrict__ Q, int nq, int G, int NG,
-    float2 *__restrict__ gb, float *__restrict__ wm, uint32_t *__restrict__ zero_a, uint32_t *__restrict__ zero_b)
+    float2 *__restrict__ gb, float *__restrict__ wm, uint32_t *__restrict__ zero_a, uint32_t *__restrict__ zero_b, int nt)
 {
     using Ge = FsGeom<NCH>;
     constexpr int D = 16 * NCH, UK = Ge::UK, NU = Ge::NU, UNIT = Ge::UNIT, RU = Ge::RU, RB = Ge::RB, OPS = Ge::OPS;
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int s = 0; s < UK; ++s)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-                fs_glds16(tile + (int64_t)(4 * (part * UK + s) + 2 * lk + h) * 256, dst + (uint32_t)((2 * s + h) * 1024));
+                fs_glds16(tile + (int64_t)(4 * (part * UK + s) + 2 * lk + h) * 256, dst + (uint32_t)((2 * s + h) * 1024), nt);
         fs_glds4(bias + t * 32 + lj, bias_b + (uint32_t)((i % RB) * 256));
     };
     if (my_tiles > 0) {
@@ -322,6 +328,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     float2 *__restrict__ gb, float *__restrict__ wm, uint32_t *__restrict__ zero_a, uint32_t *__restrict__ zero_b, int dbg)
 {
     using Ge = FssGeom<NCH, NF>;
+    const int nt = dbg & 16;   // (not a timing experiment: the non-temporal hint of fs_glds16)
     constexpr int D = 16 * NCH, TILE = Ge::TILE, RU = Ge::RU, RB = Ge::RB, PW = Ge::PW, OPS = Ge::OPS;
     static_assert(PW >= 2 && PW % 2 == 0, "a wave converts whole K steps");
     constexpr bool TWO_CHAINS = QB == 1 && NW <= 8;          // one wave per SIMD: two chains so that back-to-back products are independent
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
         for (int pp = 0; pp < PW; ++pp) {
             const int p = wave * PW + pp, s = p >> 1, h = p & 1;
-            fs_glds16(tile + (int64_t)(4 * s + 2 * lk + h) * 256, dst + (uint32_t)(p * 1024));
+            fs_glds16(tile + (int64_t)(4 * s + 2 * lk + h) * 256, dst + (uint32_t)(p * 1024), nt);
         }
         fs_glds4(bias + t * 32 + lj, bias_b + (uint32_t)((i % RB) * 256));
     };
@@ -936,6 +943,11 @@ static int fs_qb_max(int nch)
 }
 static int g_fs_dbgflags = 0;     // timing experiments (results wrong when non-zero): cvtmi_set_tuning("flat_f32_dbg")
 void set_flat_f32_dbg(int v) { g_fs_dbgflags = v; }
+static int g_fs_nt = 1;      // cvtmi_set_tuning("flat_f32_nt"): 0 = never, 1 = choose, 2 = always
+void set_flat_f32_nt(int v) { g_fs_nt = v; }
+// non-temporal row loads: measured better wherever the stream kernel is bound by the rows (one query 0.119 -> 0.106 ms,
+// 64 queries 0.147 -> 0.14, the shared ring 1.09 -> 1.07 at 1000), worse at three query blocks per wave (0.155 -> 0.165)
+static bool fs_nt(bool shared, int qb) { return g_fs_nt == 2 || (g_fs_nt == 1 && (shared || qb <= 2)); }
 static int g_fs_share = 0;   // cvtmi_set_tuning("flat_f32_share"): 0 = choose, 1 = four waves x 32 QB queries, 2 = FS_MANY waves x 32 queries
 void set_flat_f32_share(int v) { g_fs_share = v; }
 // the shared-ring kernel wants whole K steps per wave: D / 16 a multiple of the wave count
@@ -1006,7 +1018,7 @@ static int fs_launch_eight(const FsStreamArgs &a, hipStream_t st)
         const size_t lds = FssGeom<NCH, NCH>::LDS;
         CVTMI_TRY(fs_set_lds((const void *)flat_f32_mshare_kernel<NCH, 1, FS_MANY, NCH>, lds, attr_set));
         hipLaunchKernelGGL((flat_f32_mshare_kernel<NCH, 1, FS_MANY, NCH>), dim3(FSS_STREAMS), dim3(64 * FS_MANY), lds, st, a.X, a.bias, a.n_tiles, a.q,
-                           a.nq, a.G, a.NG, a.gb, a.wm, a.redo, a.cnt, g_fs_dbgflags);
+                           a.nq, a.G, a.NG, a.gb, a.wm, a.redo, a.cnt, g_fs_dbgflags | (fs_nt(true, 1) ? 16 : 0));
         CVTMI_HIP(hipGetLastError());
         return CVTMI_OK;
     } else {
@@ -1023,12 +1035,12 @@ static int fs_launch_stream(const FsStreamArgs &a, hipStream_t st)
         const size_t lds = FssGeom<NCH, 4>::LDS;
         CVTMI_TRY(fs_set_lds((const void *)flat_f32_mshare_kernel<NCH, QB, 4, 4>, lds, attr_set));
         hipLaunchKernelGGL((flat_f32_mshare_kernel<NCH, QB, 4, 4>), dim3(FSS_STREAMS), dim3(256), lds, st, a.X, a.bias, a.n_tiles, a.q, a.nq, a.G, a.NG,
-                           a.gb, a.wm, a.redo, a.cnt, g_fs_dbgflags);
+                           a.gb, a.wm, a.redo, a.cnt, g_fs_dbgflags | (fs_nt(true, QB) ? 16 : 0));
     } else {
         const size_t lds = (size_t)4 * FsGeom<NCH>::WAVE_LDS;
         CVTMI_TRY(fs_set_lds((const void *)flat_f32_mstream_kernel<NCH, QB>, lds, attr_set));
         hipLaunchKernelGGL((flat_f32_mstream_kernel<NCH, QB>), dim3(FS_BLOCKS), dim3(256), lds, st, a.X, a.bias, a.n_tiles, a.q, a.nq, a.G, a.NG,
-                           a.gb, a.wm, a.redo, a.cnt);
+                           a.gb, a.wm, a.redo, a.cnt, fs_nt(false, QB) ? 1 : 0);
     }
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;

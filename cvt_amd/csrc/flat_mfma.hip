@@ -561,12 +561,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(QS == 1 ? 4 
 // Row norms |x'|^2 travel the same way (one 4-byte-per-lane piece per group, requested by every wave: same request count in
 // every wave, same bytes to the same place).
 // ------------------------------------------------------------------------------------------------------------------
+// NT: non-temporal hint for rows a CU reads once per launch (MI355X_MICROARCH.md "nt-weights")
+template <bool NT = false>
 __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
 {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    if constexpr (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// measured (10 M x 512-d): the streaming kernel, whose rows are read once per pass, 0.908 -> 0.83 ms for one query (6.2 TB/s end
+// to end), 1.27 -> 1.22 ms for 128; the filter kernels, whose query blocks share each row tile through L2, lose 6-10 % with it
+constexpr bool U8_NT_GF = false, U8_NT_MS = true;
 __device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_dst)
 {
     unsigned keep;
@@ -646,7 +655,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const int p = wave * PPW + i;
             int64_t t = t0 + g * G + p / KS;
             t = t < t1 ? t : t1 - 1;
-            glds16(pack + (t * KS + p % KS) * 64 + lane, ring_b + (uint32_t)(((slot * G * KS) + p) * 64 * 16));
+            glds16<U8_NT_GF>(pack + (t * KS + p % KS) * 64 + lane, ring_b + (uint32_t)(((slot * G * KS) + p) * 64 * 16));
         }
         int64_t t = t0 + g * G + (lane >> 5);   // norms of the group's first two tiles per piece; G = 4 takes two pieces' worth in one
         int64_t row;
@@ -878,7 +887,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int p = wave * PPW + i;
-            glds16(pack + (t * KS + p) * 64 + lane, ring_b + (uint32_t)(((slot * KS) + p) * 64 * 16));
+            glds16<U8_NT_GF>(pack + (t * KS + p) * 64 + lane, ring_b + (uint32_t)(((slot * KS) + p) * 64 * 16));
         }
         int64_t row = t * 32 + lj;
         row = row < n ? row : n - 1;
@@ -1110,7 +1119,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int byte = 1024 * p + 16 * lane;
             int64_t row = t * 32 + byte / D;
             row = row < n ? row : n - 1;
-            glds16(X + row * D + (byte % D), ring_b + (uint32_t)(slot * SLOT + p * PIECE));
+            glds16<U8_NT_MS>(X + row * D + (byte % D), ring_b + (uint32_t)(slot * SLOT + p * PIECE));
         }
         int64_t row = t * 32 + lj;
         row = row < n ? row : n - 1;

@@ -125,6 +125,7 @@ int launch_flat_block(const float *src, int64_t n, int D, int64_t row0, float *d
 int flat_f32_stream_qmax(int D);
 void set_flat_f32_dbg(int v);     // timing experiments, results wrong when non-zero
 void set_flat_f32_share(int v);   // shared-ring kernel: 0 choose, 1 four waves x 32 QB queries, 2 eight waves x 32 queries
+void set_flat_f32_nt(int v);     // 0 = never, 1 = choose (default), 2 = always: non-temporal hint on the stream kernels' row loads
 bool flat_f32_stream_applies(int metric, int D, int64_t n, int k);
 size_t flat_f32_stream_scratch(int D, int64_t n, int64_t nq_pass);
 // bias[r] (and zeroed padding rows) for rows [row0, row1); stats[0] = max |x|^2 bits, stats[1] = non-finite rows (both accumulate)

@@ -87,6 +87,8 @@ int cvtmi_set_device(int device);
  *   "flat_u8_opt"     measurement variants of the uint8 row-tile kernel (0 = shipped; 1..3 spill registers and are slower)
  *   "probe_variant"   coarse top-nk of cvtmi_opq_query_video: 0 = choose (matrix-core filter + exact distances of the candidates
  *                     from 256 query frames, 32 <= D <= 128, coarseK >= 256); 1 = exact kernels only; 2 = filter wherever it applies
+ *   "flat_f32_nt"     non-temporal hint on the row loads of the fp32 stream kernels (rows a CU reads once per launch need no place in
+ *                     L2 / Infinity Cache): 0 = never, 1 = choose (default: everywhere except three query blocks per wave), 2 = always
  *   "scan_seed"       1 (default) = scan variants 3 / 4 / 5 take their first filter thresholds from a histogram of the first 2048 rows of
  *                     a row split instead of starting with "every row passes" (1-4 % on 1 M rows, more on short splits); 0 = off
  *   "comm_force_rccl" 1 = cvtmi_comm_create goes through RCCL (ncclCommInitRank, ncclAllGather) for world == 1 too, which
