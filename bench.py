@@ -301,19 +301,19 @@ def headline_n1(ctx, q):
     # the reference's API takes host pointers: the same step through cvtmi_opq_search (queries up, results down over
     # PCIe)
     qh = q.cpu().numpy()
-    idx.search(qh, k, rotate=True)
+    # the caller's result arrays, reused across calls (fresh ones cost a page fault per 4 KB)
+    out_h = (np.zeros((nq, k), np.float32), np.zeros((nq, k), np.int64))
+    idx.search(qh, k, rotate=True, out=out_h)
     t0 = time.perf_counter()
     reps = max(1, min(3, args.steps))
     for _ in range(reps):
-        idx.search(qh, k, rotate=True)
+        idx.search(qh, k, rotate=True, out=out_h)
     el_h = (time.perf_counter() - t0) / reps
-    result["host_pointer_api"] = {"value": round(nq / el_h, 1), "unit": "queries/s", "ms_per_step": round(el_h * 1e3,
-                                                                                                          4),
-                                  "what": "cvtmi_opq_search with host buffers: %.1f MB of queries in, %.1f MB of "
-                                          "results out "
-                                          "per step over PCIe, temporaries allocated per call -- reported beside "
-                                          "`value`, "
-                                          "never as it" % (nq * D * 4 / 1e6, nq * k * 12 / 1e6)}
+    what = ("cvtmi_opq_search with host buffers: %.1f MB of queries in, %.1f MB of results out per step over PCIe through "
+            "the handle's pinned staging area, result arrays reused -- reported beside `value`, never as it"
+            % (nq * D * 4 / 1e6, nq * k * 12 / 1e6))
+    result["host_pointer_api"] = {"value": round(nq / el_h, 1), "unit": "queries/s",
+                                  "ms_per_step": round(el_h * 1e3, 4), "what": what}
     return result, idx, out
 
 

@@ -197,7 +197,12 @@ class OpqIndex:
                                               _ptr(d), _ptr(i), _stream()))
             return d, i
         q = _np(q, np.float32)
-        d = np.empty((nq, k), dtype=np.float32); i = np.empty((nq, k), dtype=np.int64)
+        if out is None:
+            d = np.empty((nq, k), dtype=np.float32); i = np.empty((nq, k), dtype=np.int64)
+        else:   # the caller's own (already touched) arrays: freshly allocated ones cost a page fault per 4 KB written
+            d, i = out
+            assert d.dtype == np.float32 and i.dtype == np.int64 and d.shape == (nq, k) and i.shape == (nq, k)
+            assert d.flags.c_contiguous and i.flags.c_contiguous
         _check(lib().cvtmi_opq_search(self.h, _ptr(q), C.c_int64(nq), C.c_int(1 if rotate else 0), C.c_int(k),
                                       _ptr(d), _ptr(i)))
         return d, i

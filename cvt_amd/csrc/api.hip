@@ -68,6 +68,8 @@ struct cvtmi_opq_s {
     int32_t csr_vmin = 0, csr_vmax = -1;    // range of the video ids it holds
     // scratch
     DevBuf s_qrot, s_part_d, s_part_id, s_probe, s_lut, s_gthr, s_rot;
+    DevBuf io_q, io_d, io_i;   // device side of the host-pointer search (cvtmi_opq_search)
+    PinBuf io_pin;             // its pinned staging area
     // tuning / measurement
     int p_splits = 0, p_qtile = 0, p_profile = 0, p_variant = 3;
     int p_encode = 0;  // 0 = choose, 1 = VALU encode, 2 = matrix-core filter + exact resolution
@@ -369,6 +371,7 @@ int cvtmi_opq_destroy(cvtmi_opq_t h)
     h->codes.release(); h->lists.release(); h->videos.release(); h->codes_rot.release();
     h->csr_codes.release(); h->csr_videos.release(); h->csr_off.release(); h->csr_scratch.release(); h->csr_stats.release();
     h->s_qrot.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_probe.release(); h->s_lut.release(); h->s_gthr.release(); h->s_rot.release();
+    h->io_q.release(); h->io_d.release(); h->io_i.release(); h->io_pin.release();
     for (int e = 0; e < cvtmi_opq_s::kEvRing; ++e) {
         if (h->ev0[e]) (void)hipEventDestroy(h->ev0[e]);
         if (h->ev1[e]) (void)hipEventDestroy(h->ev1[e]);
@@ -724,13 +727,30 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
     if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search: bad arguments");
     if (nq == 0) return CVTMI_OK;
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: k=%d outside 1..128", k);
-    Tmp dq, dd, di;
-    CVTMI_TRY(dq.upload(q, (size_t)nq * h->m.D * sizeof(float)));
-    CVTMI_TRY(dd.alloc((size_t)nq * k * sizeof(float)));
-    CVTMI_TRY(di.alloc((size_t)nq * k * sizeof(int64_t)));
-    CVTMI_TRY(cvtmi_opq_search_dev(h, dq.as<float>(), nq, rotate, k, dd.as<float>(), di.as<int64_t>(), nullptr));
-    CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
-    CVTMI_HIP(hipMemcpy(ids, di.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost));
+    const size_t qb = (size_t)nq * h->m.D * sizeof(float), db = (size_t)nq * k * sizeof(float), ib = (size_t)nq * k * sizeof(int64_t);
+    if (std::max(qb, db + ib) > ((size_t)256 << 20)) {  // very large batches: no staging area of that size is kept around
+        Tmp dq, dd, di;
+        CVTMI_TRY(dq.upload(q, qb));
+        CVTMI_TRY(dd.alloc(db));
+        CVTMI_TRY(di.alloc(ib));
+        CVTMI_TRY(cvtmi_opq_search_dev(h, dq.as<float>(), nq, rotate, k, dd.as<float>(), di.as<int64_t>(), nullptr));
+        CVTMI_HIP(hipMemcpy(dist, dd.p, db, hipMemcpyDeviceToHost));
+        CVTMI_HIP(hipMemcpy(ids, di.p, ib, hipMemcpyDeviceToHost));
+        return CVTMI_OK;
+    }
+    // through buffers the handle keeps: queries -> pinned -> device, results device -> pinned -> caller
+    CVTMI_TRY(h->io_q.reserve(qb));
+    CVTMI_TRY(h->io_d.reserve(db));
+    CVTMI_TRY(h->io_i.reserve(ib));
+    CVTMI_TRY(h->io_pin.reserve(std::max(qb, db + ib)));
+    memcpy(h->io_pin.p, q, qb);
+    CVTMI_HIP(hipMemcpyAsync(h->io_q.p, h->io_pin.p, qb, hipMemcpyHostToDevice, nullptr));
+    CVTMI_TRY(cvtmi_opq_search_dev(h, h->io_q.as<float>(), nq, rotate, k, h->io_d.as<float>(), h->io_i.as<int64_t>(), nullptr));
+    CVTMI_HIP(hipMemcpyAsync(h->io_pin.p, h->io_d.p, db, hipMemcpyDeviceToHost, nullptr));
+    CVTMI_HIP(hipMemcpyAsync(h->io_pin.as<char>() + db, h->io_i.p, ib, hipMemcpyDeviceToHost, nullptr));
+    CVTMI_HIP(hipStreamSynchronize(nullptr));
+    memcpy(dist, h->io_pin.p, db);
+    memcpy(ids, h->io_pin.as<char>() + db, ib);
     return CVTMI_OK;
 }
 

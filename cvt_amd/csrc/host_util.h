@@ -50,6 +50,24 @@ inline int dev_alloc_copy(T **out, const T *host, size_t count)
 }
 
 // temporary device allocation for the host-pointer entry points
+// pinned host staging area of a handle (grow-only): host-pointer entry points copy through it instead of handing pageable
+// memory to the runtime -- no per-call hipMalloc / hipFree (the free synchronises the device), and a stable DMA path
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return CVTMI_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return fail(CVTMI_ENOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        cap = bytes;
+        return CVTMI_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 struct Tmp {
     void *p = nullptr;
     ~Tmp() { if (p) (void)hipFree(p); }
