@@ -28,7 +28,7 @@ for a in range(0, rows, step):
     idx.add_codes(codes)
 q = synth.sift_like(nq, D, seed=0xBEEF, device=dev)
 idx.set_param("profile", 1)
-for _ in range(30):   # clocks and caches settle first: the first configuration of a run used to read 10-15 % slow
+for _ in range(int(os.environ.get("WARM", 30))):   # clocks and caches settle first: the first configuration of a run used to read 10-15 % slow
     idx.search(q, k)
 torch.cuda.synchronize()
 if "SEED" in os.environ:
