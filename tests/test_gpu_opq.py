@@ -456,3 +456,44 @@ def test_rotate_encode_one_call(amd, orc):
             _, oc = orc.pq_encode(np.ascontiguousarray(xp), coarse, books)
             assert np.array_equal(oc, c1[100:400].cpu().numpy())
         idx.close()
+
+
+@pytest.mark.gpu
+def test_scan_seed_thresholds(amd, orc):
+    """scan16q_seed: the first thresholds come from a histogram of a split's first 2048 rows.  Seed regions made of duplicates of
+    the best row, of the worst rows only (the true neighbours all come later), of rows far apart (one per bin), k = 1 / 100 / 128,
+    every split count, seed on == seed off == the checker."""
+    D, M, K = 128, 16, 256
+    rng = np.random.default_rng(77)
+    books = synth_model(rng, D, M, K, scale=0.1)
+    n = 40_000
+    base = rng.integers(0, K, size=(n, M), dtype=np.uint8)
+    q = (rng.normal(size=(17, D)) * 0.1).astype(np.float32)
+    lut0 = orc.lut(q[0], np.zeros(D, np.float32), books)                 # [M][K] table of query 0
+    best = np.argmin(lut0, axis=1).astype(np.uint8)                       # its nearest code word per sub-quantiser
+    worst = np.argmax(lut0, axis=1).astype(np.uint8)
+    cases = {}
+    c = base.copy(); c[:2048] = best; cases["seed region = 2048 copies of query 0's best row"] = c
+    c = base.copy(); c[:2048] = worst; c[30_000:30_300] = best; cases["seed region = the worst row, neighbours much later"] = c
+    c = base.copy()
+    order = np.argsort(lut0, axis=1)                                      # rows walking from best to worst: sums spread over every bin
+    for r in range(2048):
+        c[r] = order[np.arange(M), (r * K // 2048)]
+    cases["seed region spread over the whole range"] = c
+    try:
+        for tag, codes in cases.items():
+            idx = amd.OpqIndex(np.zeros((1, D), np.float32), books)
+            idx.add_codes(codes)
+            for k in (1, 100, 128):
+                od, oi = orc.adc_search(q, books, codes, k)
+                for variant in (3, 4, 5):
+                    for splits in (0, 1, 2, 4):
+                        for seed in (1, 0):
+                            amd.set_tuning("scan_seed", seed)
+                            idx.set_param("scan_variant", variant); idx.set_param("splits", splits)
+                            d, i = idx.search(q, k, rotate=False)
+                            assert np.array_equal(i, oi), (tag, k, variant, splits, seed)
+                            assert np.array_equal(bits(d), bits(od)), (tag, k, variant, splits, seed)
+            idx.close()
+    finally:
+        amd.set_tuning("scan_seed", 1)
