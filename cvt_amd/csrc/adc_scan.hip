@@ -814,9 +814,11 @@ __device__ __forceinline__ void scan16q_build_tables(const ScanArgs &a, int grou
     __syncthreads();  // tables ready; the scratch words on tk.buf are dead from here on
 }
 
-// the 16 look-ups of one row: packed 15-bit sums of the SQ_QT queries, two per word.  In groups of four -- the scheduler
-// would otherwise form all 16 addresses first, more registers than a wave of these kernels has.  Integer sums, any order.
-template <bool PREROT>
+// the 16 look-ups of one row: packed 15-bit sums of the SQ_QT queries, two per word -- they can never carry across the 16-bit
+// halves, so they are accumulated with plain 32-bit adds, two look-ups per v_add3_u32 (half the VALU of v_pk_add_u16).  Integer
+// sums, any order.  NG look-ups are in flight at a time: 16 in adc_scan16q; adc_scan16a takes groups of four -- there the scheduler
+// would otherwise form all 16 addresses first, more registers than its waves have left.
+template <bool PREROT, int NG = 4>
 __device__ __forceinline__ void scan16q_row_sums(const uint4 &row, const uint32_t (&moffp)[4], uint32_t cr8, uint32_t cq, const char *lut_b,
                                                  uint32_t &s0, uint32_t &s1, uint32_t &s2, uint32_t &s3)
 {
@@ -832,7 +834,6 @@ __device__ __forceinline__ void scan16q_row_sums(const uint4 &row, const uint32_
         d0 = b1 ? e2 : e0; d1 = b1 ? e3 : e1; d2 = b1 ? e0 : e2; d3 = b1 ? e1 : e3;
     }
     const uint32_t rot[4] = { d0, d1, d2, d3 };
-    constexpr int NG = 4;
     s0 = 0; s1 = 0; s2 = 0; s3 = 0;
 #pragma unroll
     for (int h = 0; h < 16 / NG; ++h) {
@@ -1032,35 +1033,9 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
             bool failed = false;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                uint32_t d0 = cur[r].x, d1 = cur[r].y, d2 = cur[r].z, d3 = cur[r].w;
-                if constexpr (!PREROT) {
-                    d0 = __builtin_amdgcn_alignbit(cur[r].y, cur[r].x, cr8);
-                    d1 = __builtin_amdgcn_alignbit(cur[r].z, cur[r].y, cr8);
-                    d2 = __builtin_amdgcn_alignbit(cur[r].w, cur[r].z, cr8);
-                    d3 = __builtin_amdgcn_alignbit(cur[r].x, cur[r].w, cr8);
-                    const bool b0 = cq & 1;
-                    const uint32_t e0 = b0 ? d1 : d0, e1 = b0 ? d2 : d1, e2 = b0 ? d3 : d2, e3 = b0 ? d0 : d3;
-                    const bool b1 = cq & 2;
-                    d0 = b1 ? e2 : e0; d1 = b1 ? e3 : e1; d2 = b1 ? e0 : e2; d3 = b1 ? e1 : e3;
-                }
-                const uint32_t rot[4] = { d0, d1, d2, d3 };
-                // 16 look-ups; the packed 15-bit sums can never carry across the 16-bit halves, so they are
-                // accumulated with plain 32-bit adds, two look-ups per v_add3_u32 (half the VALU of v_pk_add_u16)
-                uint4 v[16];
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const uint32_t sel = 0x0c0c0000u | ((4u + (t & 3)) << 8) | (uint32_t)(t & 3);
-                    const uint32_t addr = __builtin_amdgcn_perm(rot[t >> 2], moffp[t >> 2], sel);  // code*256 + m*16
-                    v[t] = *reinterpret_cast<const uint4 *>(lut_b + addr);
-                }
-                uint32_t s0 = v[0].x, s1 = v[0].y, s2 = v[0].z, s3 = v[0].w;
-#pragma unroll
-                for (int t = 1; t < 15; t += 2) {
-                    s0 = s0 + v[t].x + v[t + 1].x; s1 = s1 + v[t].y + v[t + 1].y;
-                    s2 = s2 + v[t].z + v[t + 1].z; s3 = s3 + v[t].w + v[t + 1].w;
-                }
-                s0 += v[15].x; s1 += v[15].y; s2 += v[15].z; s3 += v[15].w;
-                __builtin_amdgcn_sched_barrier(0);
+                // 16 look-ups, packed 15-bit sums (scan16q_row_sums; all 16 reads in flight here: this kernel has the registers)
+                uint32_t s0, s1, s2, s3;
+                scan16q_row_sums<PREROT, 16>(cur[r], moffp, cr8, cq, lut_b, s0, s1, s2, s3);
                 // sum < T for any of the 8 queries  <=>  a sign bit in the packed (sum - T)  (both < 2^15)
                 const uint32_t sg = (pk_sub_i16(s0, tpk[0]) | pk_sub_i16(s1, tpk[1]) | pk_sub_i16(s2, tpk[2]) | pk_sub_i16(s3, tpk[3])) & 0x80008000u;
                 if (__ballot(sg != 0)) {  // rare once the threshold has tightened
