@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void flat_u8_kernel(const FlatArgs a)
 // grid = nq * S workgroups; workgroup (q, s) derives theta from all G wave minima of its query, then selects among the rows the
 // qualifying waves wrote inside ITS slice of the rows.  Wave w owns rows (w + t G) rpi + j, t = 0.., j < rpi; the slice's entries are fed
 // in ascending row order (t outermost, then wave, then j), which is the order block_topk.h's tie rule asks for.
-constexpr int FIN_CAP = 1024, FIN_TRIG = 768, FIN_R = 4, FIN_MAXG = 8192, FIN_MAXR = 160;
+constexpr int FIN_CAP = 1024, FIN_TRIG = 768, FIN_R = 4, FIN_MAXG = 8192, FIN_MAXR = 160, FIN_CL = 1024;
 struct StreamFinishArgs {
     int64_t n;
     const int32_t *gmin;
@@ -372,6 +372,7 @@ __global__ __launch_bounds__(kBlock) void flat_u8_stream_finish_kernel(const Str
     __shared__ uint16_t ql[FIN_MAXG];          // qualifying waves, ascending
     __shared__ int r_first[FIN_MAXR], r_off[FIN_MAXR + 1];
     __shared__ int qn_s;
+    __shared__ int32_t cl_s[FIN_CL];             // this slice's chunks whose tile minimum is under theta, ascending
     __shared__ __attribute__((aligned(16))) uint32_t q_s[128];   // the query's bytes
     const int64_t n = a.n;
     const int G = a.G, S = a.S, rpi_log2 = a.rpi_log2, k = a.k;
@@ -386,40 +387,79 @@ __global__ __launch_bounds__(kBlock) void flat_u8_stream_finish_kernel(const Str
         for (int w = 0; w < a.D / 4; ++w) qq_t = (int)__builtin_amdgcn_udot4(q_s[w], q_s[w], (uint32_t)qq_t, false);
     }
     const int32_t *gm = gmin + q * G;
-    // theta in two rounds of the same bound: the k-th smallest of the 256 per-thread minima (k <= 128 distinct waves) is an upper
-    // bound theta1 that already excludes nearly every wave, so the pass over all G minima pushes ~k entries and never compacts early
-    topk_init(tk);
-    __syncthreads();
+    // theta = the k-th smallest of the G wave minima, in two rounds of the same bound: the k-th smallest of the 256 per-thread minima
+    // (k <= 128 distinct waves) is an upper bound theta1 that already excludes nearly every wave; the few minima under it are
+    // gathered in LDS and ONE wave selects among them in registers (radix select on lane masks, block_topk.h) -- the two LDS
+    // bitonic sorts this used to take were most of the kernel (64 queries over 10 M rows: 112 us of a 0.88 ms search).
+    uint32_t theta;
     {
-        uint32_t key[1][1] = { { KEY_MAX } }, pay[1] = { (uint32_t)tid };
+        uint32_t *sel_v = reinterpret_cast<uint32_t *>(&tk.buf[0][0]);   // 1024 words of the (not yet used) selection buffer
+        uint32_t mymin = KEY_MAX;
         for (int i = tid; i < G; i += kBlock) {
             const uint32_t v = (uint32_t)gm[i];
-            key[0][0] = v < key[0][0] ? v : key[0][0];
+            mymin = v < mymin ? v : mymin;
         }
-        topk_tile<1, 1, FIN_CAP, FIN_TRIG>(tk, k, 0, key, pay);
-    }
-    __syncthreads();
-    topk_compact(tk, k);
-    const uint32_t theta1 = tk.thr[0];
-    __syncthreads();
-    topk_init(tk);
-    __syncthreads();
-    int tile = 0;
-    for (int base = 0; base < G; base += kBlock * FIN_R, ++tile) {
-        uint32_t key[FIN_R][1], pay[FIN_R];
+        sel_v[tid] = mymin;
+        if (tid == 0) qn_s = 0;
+        __syncthreads();
+        if (tid < 64) {
+            unsigned long long e[4];
 #pragma unroll
-        for (int r = 0; r < FIN_R; ++r) {
-            const int i = base + r * kBlock + tid;
-            pay[r] = (uint32_t)i;
-            const uint32_t v = i < G ? (uint32_t)gm[i] : KEY_MAX;
-            key[r][0] = v <= theta1 ? v : KEY_MAX;
+            for (int r = 0; r < 4; ++r) {
+                const int p = r * 64 + tid;
+                e[r] = p < G ? ((unsigned long long)sel_v[p] << 32) | (uint32_t)p : ~0ull;   // (thread p has an element iff p < G)
+            }
+            const uint32_t t1 = (G < kBlock ? G : kBlock) >= k ? (uint32_t)(wave_select<4>(e, k) >> 32) : KEY_MAX;
+            if (tid == 0) r_first[0] = (int)t1;
         }
-        topk_tile<1, FIN_R, FIN_CAP, FIN_TRIG>(tk, k, tile, key, pay);
+        __syncthreads();
+        const uint32_t theta1 = (uint32_t)r_first[0];
+        __syncthreads();   // (sel_v is written again below)
+        for (int i = tid; i < G; i += kBlock) {
+            const uint32_t v = (uint32_t)gm[i];
+            if (v <= theta1) {
+                const int pos = atomicAdd(&qn_s, 1);
+                if (pos < FIN_CAP) sel_v[pos] = v;
+            }
+        }
+        __syncthreads();
+        const int n2 = qn_s;
+        if (n2 <= FIN_CAP) {   // workgroup-uniform; the usual case by far (n2 is about k)
+            if (tid < 64) {
+                unsigned long long e[FIN_CAP / 64];
+#pragma unroll
+                for (int r = 0; r < FIN_CAP / 64; ++r) {
+                    const int p = r * 64 + tid;
+                    e[r] = p < n2 ? ((unsigned long long)sel_v[p] << 32) | (uint32_t)p : ~0ull;
+                }
+                const uint32_t t = n2 >= k ? (uint32_t)(wave_select<FIN_CAP / 64>(e, k) >> 32) : KEY_MAX;   // fewer than k waves: everything qualifies
+                if (tid == 0) r_first[0] = (int)t;
+            }
+            __syncthreads();
+            theta = (uint32_t)r_first[0];
+            __syncthreads();
+        } else {               // masses of equal minima: the sorting path
+            __syncthreads();
+            topk_init(tk);
+            __syncthreads();
+            int tile = 0;
+            for (int base = 0; base < G; base += kBlock * FIN_R, ++tile) {
+                uint32_t key[FIN_R][1], pay[FIN_R];
+#pragma unroll
+                for (int r = 0; r < FIN_R; ++r) {
+                    const int i = base + r * kBlock + tid;
+                    pay[r] = (uint32_t)i;
+                    const uint32_t v = i < G ? (uint32_t)gm[i] : KEY_MAX;
+                    key[r][0] = v <= theta1 ? v : KEY_MAX;
+                }
+                topk_tile<1, FIN_R, FIN_CAP, FIN_TRIG>(tk, k, tile, key, pay);
+            }
+            __syncthreads();
+            topk_compact(tk, k);
+            theta = tk.thr[0];
+            __syncthreads();
+        }
     }
-    __syncthreads();
-    topk_compact(tk, k);
-    const uint32_t theta = tk.thr[0];                     // KEY_MAX when fewer than k waves exist: everything qualifies
-    __syncthreads();
     // all qualifying waves, ascending (wave 0: one ballot per 64 waves)
     if (tid < 64) {
         int cnt = 0;
@@ -456,44 +496,105 @@ __global__ __launch_bounds__(kBlock) void flat_u8_stream_finish_kernel(const Str
         for (int r = 0; r < n_rounds; ++r) r_off[r + 1] += r_off[r];
     }
     __syncthreads();
-    const int64_t total = (int64_t)(n_rounds ? r_off[n_rounds] : 0) << rpi_log2;
-    tile = 0;
-    for (int64_t base = 0; base < total; base += kBlock * FIN_R, ++tile) {
-        uint32_t key[FIN_R][1], pay[FIN_R];
+    // The slice's candidate chunks are the (round, qualifying wave) pairs; what decides is the TILE minimum of a chunk, and only
+    // ~k / S of the slice's few hundred chunks have one under theta.  Wave 0 lists those first (in ascending order: ballots, no
+    // atomics -- the selection below wants ascending rows), then the workgroup computes exact distances for the listed chunks' rows
+    // only.  (Checking the tile minimum per ROW cost ten rounds of the selection protocol per slice: 78 us of a 0.86 ms search.)
+    const int nch = n_rounds ? r_off[n_rounds] : 0;
+    auto chunk_of = [&](int ci, int64_t &chunk, int64_t &tgrp) {
+        int a_ = 0, b_ = n_rounds - 1;   // the round whose [r_off, r_off + 1) holds ci
+        while (a_ < b_) { const int m_ = (a_ + b_ + 1) >> 1; if (r_off[m_] <= ci) a_ = m_; else b_ = m_ - 1; }
+        const int wv = ql[r_first[a_] + (ci - r_off[a_])];
+        chunk = (t_a + a_) * G + wv;
+        tgrp = ((t_a + a_) / a.tile_group) * G + wv;
+    };
+    if (tid < 64) {
+        int cnt = 0;
+        for (int c0 = 0; c0 < nch; c0 += 64) {
+            const int ci = c0 + tid;
+            bool yes = false;
+            int64_t chunk = 0, tgrp = 0;
+            if (ci < nch) {
+                chunk_of(ci, chunk, tgrp);
+                yes = (chunk << rpi_log2) < n && (uint32_t)a.tmin[tgrp * a.nqp + q] <= theta;
+            }
+            const unsigned long long m = __ballot(yes);
+            const int pos = cnt + __popcll(m & ((1ull << tid) - 1));
+            if (yes && pos < FIN_CL) cl_s[pos] = (int32_t)chunk;   // chunk < 2^31 / 32
+            cnt += __popcll(m);
+        }
+        if (tid == 0) qn_s = cnt;
+    }
+    __syncthreads();
+    const int n_cl = qn_s;
+    int tile = 0;
+    if (n_cl <= FIN_CL) {   // workgroup-uniform
+        const int64_t total = (int64_t)n_cl << rpi_log2;
+        for (int64_t base = 0; base < total; base += kBlock * FIN_R, ++tile) {
+            uint32_t key[FIN_R][1], pay[FIN_R];
 #pragma unroll
-        for (int r = 0; r < FIN_R; ++r) {
-            const int64_t e = base + r * kBlock + tid;
-            key[r][0] = KEY_MAX;
-            pay[r] = 0;
-            if (e < total) {
-                const int ci = (int)(e >> rpi_log2);
-                int a_ = 0, b_ = n_rounds - 1;   // the round whose [r_off, r_off + 1) holds ci
-                while (a_ < b_) { const int m_ = (a_ + b_ + 1) >> 1; if (r_off[m_] <= ci) a_ = m_; else b_ = m_ - 1; }
-                const int wv = ql[r_first[a_] + (ci - r_off[a_])];
-                const int64_t chunk = (t_a + a_) * G + wv, tgrp = ((t_a + a_) / a.tile_group) * G + wv;
-                const int64_t row = (chunk << rpi_log2) + (e & ((1 << rpi_log2) - 1));
-                if (row < n) {
-                    uint32_t d = KEY_MAX;
-                    if ((uint32_t)a.tmin[tgrp * a.nqp + q] <= theta) {   // exact sum (q - x)^2 = |q|^2 + |x|^2 - 2 <q, x>, every term < 2^27
+            for (int r = 0; r < FIN_R; ++r) {
+                const int64_t e = base + r * kBlock + tid;
+                key[r][0] = KEY_MAX;
+                pay[r] = 0;
+                if (e < total) {
+                    const int64_t row = ((int64_t)cl_s[e >> rpi_log2] << rpi_log2) + (e & ((1 << rpi_log2) - 1));
+                    if (row < n) {   // exact sum (q - x)^2 = |q|^2 + |x|^2 - 2 <q, x>, every term < 2^27
                         const uint4 *xr = reinterpret_cast<const uint4 *>(a.X + row * a.D);
                         uint32_t xx = 0, qx = 0;
                         for (int c = 0; c < a.D / 16; ++c) {
                             const uint4 v = xr[c];
                             const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                xx = __builtin_amdgcn_udot4(w[e], w[e], xx, false);
-                                qx = __builtin_amdgcn_udot4(w[e], q_s[4 * c + e], qx, false);
+                            for (int e2 = 0; e2 < 4; ++e2) {
+                                xx = __builtin_amdgcn_udot4(w[e2], w[e2], xx, false);
+                                qx = __builtin_amdgcn_udot4(w[e2], q_s[4 * c + e2], qx, false);
                             }
                         }
-                        d = (uint32_t)qq_t + xx - 2u * qx;
+                        const uint32_t d = (uint32_t)qq_t + xx - 2u * qx;
+                        pay[r] = (uint32_t)row;
+                        if (d <= theta) key[r][0] = d;
                     }
-                    pay[r] = (uint32_t)row;
-                    if (d <= theta) key[r][0] = d;
                 }
             }
+            topk_tile<1, FIN_R, FIN_CAP, FIN_TRIG>(tk, k, tile, key, pay);
         }
-        topk_tile<1, FIN_R, FIN_CAP, FIN_TRIG>(tk, k, tile, key, pay);
+    } else {               // a slice full of tiles under theta (masses of equal rows): every chunk, tile minimum checked per row
+        const int64_t total = (int64_t)nch << rpi_log2;
+        for (int64_t base = 0; base < total; base += kBlock * FIN_R, ++tile) {
+            uint32_t key[FIN_R][1], pay[FIN_R];
+#pragma unroll
+            for (int r = 0; r < FIN_R; ++r) {
+                const int64_t e = base + r * kBlock + tid;
+                key[r][0] = KEY_MAX;
+                pay[r] = 0;
+                if (e < total) {
+                    int64_t chunk, tgrp;
+                    chunk_of((int)(e >> rpi_log2), chunk, tgrp);
+                    const int64_t row = (chunk << rpi_log2) + (e & ((1 << rpi_log2) - 1));
+                    if (row < n) {
+                        uint32_t d = KEY_MAX;
+                        if ((uint32_t)a.tmin[tgrp * a.nqp + q] <= theta) {
+                            const uint4 *xr = reinterpret_cast<const uint4 *>(a.X + row * a.D);
+                            uint32_t xx = 0, qx = 0;
+                            for (int c = 0; c < a.D / 16; ++c) {
+                                const uint4 v = xr[c];
+                                const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                                for (int e2 = 0; e2 < 4; ++e2) {
+                                    xx = __builtin_amdgcn_udot4(w[e2], w[e2], xx, false);
+                                    qx = __builtin_amdgcn_udot4(w[e2], q_s[4 * c + e2], qx, false);
+                                }
+                            }
+                            d = (uint32_t)qq_t + xx - 2u * qx;
+                        }
+                        pay[r] = (uint32_t)row;
+                        if (d <= theta) key[r][0] = d;
+                    }
+                }
+            }
+            topk_tile<1, FIN_R, FIN_CAP, FIN_TRIG>(tk, k, tile, key, pay);
+        }
     }
     __syncthreads();
     topk_compact(tk, k);
@@ -1201,12 +1302,17 @@ constexpr int STREAM_SLICES = 64;
 int launch_flat_u8_mstream_finish(int D, const uint8_t *data, int64_t n, const uint8_t *q, int64_t nq, int k, const int32_t *wmin, int G,
                                   const int32_t *tmin, int nqp, int tile_group, float *part_d, int64_t *part_id, float *out_d, int64_t *out_rows, hipStream_t st)
 {
+    // slices per query: every slice repeats the query's threshold selection, so no more of them than fill the chip once
+    // (64 queries x 64 slices = 4096 workgroups took 112 us; x 16 ...); long indexes keep 64 (rounds per slice <= FIN_MAXR)
+    int S = STREAM_SLICES;
+    if (n <= ((int64_t)64 << 20))
+        while (S > 4 && nq * S > 1024) S >>= 1;
     StreamFinishArgs fa = {};
-    fa.n = n; fa.gmin = wmin; fa.G = G; fa.S = STREAM_SLICES; fa.rpi_log2 = 5; fa.k = k; fa.part_d = part_d; fa.part_id = part_id;
+    fa.n = n; fa.gmin = wmin; fa.G = G; fa.S = S; fa.rpi_log2 = 5; fa.k = k; fa.part_d = part_d; fa.part_id = part_id;
     fa.tmin = tmin; fa.nqp = nqp; fa.tile_group = tile_group; fa.X = data; fa.Q = q; fa.D = D;
-    hipLaunchKernelGGL(flat_u8_stream_finish_kernel, dim3((unsigned)(nq * STREAM_SLICES)), dim3(kBlock), 0, st, fa);
+    hipLaunchKernelGGL(flat_u8_stream_finish_kernel, dim3((unsigned)(nq * S)), dim3(kBlock), 0, st, fa);
     CVTMI_HIP(hipGetLastError());
-    return launch_topk_merge(part_d, part_id, nq, STREAM_SLICES, k, out_d, out_rows, st);
+    return launch_topk_merge(part_d, part_id, nq, S, k, out_d, out_rows, st);
 }
 int flat_u8_stream_slices() { return STREAM_SLICES; }
 
