@@ -862,7 +862,7 @@ __device__ __forceinline__ void scan16q_row_sums(const uint4 &row, const uint32_
 // scanned again by the main loop.  hist = SQ_QT x 256 words (the still unused selection buffers).  Whole workgroup; ends with a barrier.
 constexpr uint32_t SQ_SEED_CHUNKS = 32;
 template <int NT, bool PREROT, class LoadRow>
-__device__ __forceinline__ void scan16q_seed(int k, const LoadRow &load_row, const uint32_t (&moffp)[4], uint32_t cr8, uint32_t cq, const char *lut_b,
+__device__ __forceinline__ void scan16q_seed(int k, const LoadRow &load64, const uint32_t (&moffp)[4], uint32_t cr8, uint32_t cq, const char *lut_b,
                                              uint32_t *hist, const QuantParams &qp, const int *lazy, uint32_t *thr_x, uint32_t *thr_pk)
 {
     constexpr int QT = SQ_QT, NW = NT / 64;
@@ -870,7 +870,7 @@ __device__ __forceinline__ void scan16q_seed(int k, const LoadRow &load_row, con
     for (int i = tid; i < QT * 256; i += NT) hist[i] = 0;
     __syncthreads();
     for (uint32_t ch = wave; ch < SQ_SEED_CHUNKS; ch += NW) {
-        const uint4 row = load_row(ch * 64 + lane);
+        const uint4 row = load64(ch);
         uint32_t sm[4];
         scan16q_row_sums<PREROT>(row, moffp, cr8, cq, lut_b, sm[0], sm[1], sm[2], sm[3]);
 #pragma unroll
@@ -978,10 +978,20 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
     // doing that in registers costs 12 of the loop's ~83 VALU instructions per row, and VALU is what bounds it)
     const char *rows_b = PREROT ? reinterpret_cast<const char *>(reinterpret_cast<const uint4 *>(a.codes_rot) + row_begin)
                                 : reinterpret_cast<const char *>(rows + row_begin);
-    const uint32_t last = n_local ? n_local - 1 : 0;
-    auto load_row = [&](uint32_t lrow) -> uint4 {
-        const uint32_t cl = lrow < last ? lrow : last;
-        return *reinterpret_cast<const uint4 *>(rows_b + (size_t)(cl * 16u));
+    // 64 rows of chunk c (row group r): one 16-byte load per lane off a scalar base.  Chunks past the end (the prefetch of a wave that
+    // is about to finish) read the last one; there is NO per-lane clamp: the last chunk may read up to 64 R - 1 rows past the
+    // split -- the next split's rows, or the kDevSlack bytes every device buffer carries (host_util.h) -- and what is read there is
+    // never used (lrow < n_local where candidates are taken).  (The clamp was 2 of the loop's ~66 vector instructions per row.)
+    constexpr uint32_t WROWS = 64 * R;
+    const uint32_t n_chunks = (n_local + WROWS - 1) / WROWS;
+    const uint32_t last_chunk = n_chunks ? n_chunks - 1 : 0;
+    const uint32_t lane16 = (uint32_t)(threadIdx.x & 63) * 16u;
+    auto load_rows = [&](uint32_t chunk, int r) -> uint4 {
+        const uint32_t cc = chunk < last_chunk ? chunk : last_chunk;  // wave-uniform
+        return *reinterpret_cast<const uint4 *>(rows_b + (size_t)cc * (WROWS * 16u) + (uint32_t)(r * 1024) + lane16);
+    };
+    auto load64 = [&](uint32_t c64) -> uint4 {  // rows 64 c64 .. 64 c64 + 63, all inside the split (the seed's reads)
+        return *reinterpret_cast<const uint4 *>(rows_b + (size_t)c64 * 1024u + lane16);
     };
     const uint32_t c = tid & 15;
     const uint32_t cr8 = (c & 3) * 8, cq = c >> 2;
@@ -994,7 +1004,7 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
     }
     const char *lut_b = reinterpret_cast<const char *>(lut);
     if (a.seed && (n_local + 63) / 64 >= 4 * SQ_SEED_CHUNKS)  // workgroup-uniform
-        scan16q_seed<NT, PREROT>(a.k, load_row, moffp, cr8, cq, lut_b, reinterpret_cast<uint32_t *>(&tk.buf[0][0]), qp, ck.lazy, tk.thr_x, ck.thr_pk);
+        scan16q_seed<NT, PREROT>(a.k, load64, moffp, cr8, cq, lut_b, reinterpret_cast<uint32_t *>(&tk.buf[0][0]), qp, ck.lazy, tk.thr_x, ck.thr_pk);
     SQ_T(0);
 
     // ---- main loop: waves run on their own between checkpoints ----
@@ -1004,22 +1014,26 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
     // compacted when one is full or past TRIG.  Row order across waves is arbitrary: legal here because
     // the filter is a superset test and the exact (distance, id) sort decides (block_topk.h).
     constexpr int NW = NT / 64;
-    constexpr uint32_t WROWS = 64 * R;
-    const uint32_t n_chunks = (n_local + WROWS - 1) / WROWS;
     // chunks are handed out dynamically (one LDS atomic per 64*R rows): waves that run faster take more,
     // so nobody waits long at the final checkpoint.  `it` = chunk in hand, `it_next` = already reserved
     // and being prefetched.
-    auto grab = [&]() -> uint32_t {
-        uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(&ck.next_chunk, 1u);
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    // (the atomic is spelled out: for `if (lane == 0) atomicAdd(...)` hipcc emits its wave-aggregation sequence -- two mbcnt, a
+    //  compare, a population count and two moves -- around the one-lane atomic: 6 of the loop's 66 vector instructions per row)
+    const uint32_t next_chunk_addr = (uint32_t)(uintptr_t)&ck.next_chunk;
+    // Chunks go out in PAIRS (2 p, 2 p + 1): one atomic per two chunks, the odd one follows without asking.
+    auto grab_pair = [&]() -> uint32_t {
+        uint32_t v;
+        asm volatile("" : "=v"(v));  // (only lane 0's value is read: no instruction to define the others)
+        if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(next_chunk_addr), "v"(1u) : "memory");
+        return 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     };
-    uint32_t it = grab(), it_next = grab(), done = 0;
+    auto after = [&](uint32_t chunk) -> uint32_t { return (chunk & 1u) ? grab_pair() : chunk + 1u; };  // wave-uniform branch
+    uint32_t it = grab_pair(), it_next = it + 1u, done = 0, done_for = 0xffffffffu;
     bool counted = false;
     uint4 cur[R], nxt[R];
     if (n_local) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) cur[r] = load_row(it * WROWS + r * 64 + lane);
+        for (int r = 0; r < R; ++r) cur[r] = load_rows(it, r);
     }
     for (;;) {
         uint32_t tpk[QT / 2];
@@ -1029,8 +1043,8 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
             const int stop_seen = ck.stop;  // read early, used after the chunk
             const uint32_t base = it * WROWS;
 #pragma unroll
-            for (int r = 0; r < R; ++r) nxt[r] = load_row(it_next * WROWS + r * 64 + lane);
-            bool failed = false;
+            for (int r = 0; r < R; ++r) nxt[r] = load_rows(it_next, r);
+            bool failed_any = false;  // wave-uniform (a ballot inside the rare path): the common path tests a scalar
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 // 16 look-ups, packed 15-bit sums (scan16q_row_sums; all 16 reads in flight here: this kernel has the registers)
@@ -1039,7 +1053,10 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
                 // sum < T for any of the 8 queries  <=>  a sign bit in the packed (sum - T)  (both < 2^15)
                 const uint32_t sg = (pk_sub_i16(s0, tpk[0]) | pk_sub_i16(s1, tpk[1]) | pk_sub_i16(s2, tpk[2]) | pk_sub_i16(s3, tpk[3])) & 0x80008000u;
                 if (__ballot(sg != 0)) {  // rare once the threshold has tightened
-                    const uint32_t lrow = base + r * 64 + lane;
+                    if (done_for != it) { done = 0; done_for = it; }  // (the bits belong to one chunk; only this path sets or reads them)
+                    bool failed = false;
+                    uint32_t lrow = base + r * 64 + lane;
+                    asm volatile("" : "+v"(lrow));  // (keeps the tail test in here: hipcc otherwise folds it into the common path's branch)
                     if (sg != 0 && lrow < n_local) {
                         const uint32_t sums[4] = { s0, s1, s2, s3 };
 #pragma unroll
@@ -1054,17 +1071,17 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
                             }
                         }
                     }
+                    failed_any |= __ballot(failed) != 0;
                 }
             }
-            if (__any(failed)) {  // some buffer is full: stop everyone, come back to this chunk after the compaction
+            if (failed_any) {  // some buffer is full: stop everyone, come back to this chunk after the compaction
                 if (lane == 0) ck.stop = 1;
                 break;
             }
-            done = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) cur[r] = nxt[r];
             it = it_next;
-            it_next = grab();
+            it_next = after(it);
             if (__builtin_amdgcn_readfirstlane(stop_seen)) break;
         }
         SQ_T(1);  // look-ups + pushes
@@ -1375,10 +1392,20 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16a_kernel(const ScanArg
     const uint32_t n_local = (uint32_t)(row_end > row_begin ? row_end - row_begin : 0);
     const char *rows_b = PREROT ? reinterpret_cast<const char *>(reinterpret_cast<const uint4 *>(a.codes_rot) + row_begin)
                                 : reinterpret_cast<const char *>(rows + row_begin);
-    const uint32_t last = n_local ? n_local - 1 : 0;
-    auto load_row = [&](uint32_t lrow) -> uint4 {
-        const uint32_t cl = lrow < last ? lrow : last;
-        return *reinterpret_cast<const uint4 *>(rows_b + (size_t)(cl * 16u));
+    // 64 rows of chunk c (row group r): one 16-byte load per lane off a scalar base.  Chunks past the end (the prefetch of a wave that
+    // is about to finish) read the last one; there is NO per-lane clamp: the last chunk may read up to 64 R - 1 rows past the
+    // split -- the next split's rows, or the kDevSlack bytes every device buffer carries (host_util.h) -- and what is read there is
+    // never used (lrow < n_local where candidates are taken).  (The clamp was 2 of the loop's ~66 vector instructions per row.)
+    constexpr uint32_t WROWS = 64 * R;
+    const uint32_t n_chunks = (n_local + WROWS - 1) / WROWS;
+    const uint32_t last_chunk = n_chunks ? n_chunks - 1 : 0;
+    const uint32_t lane16 = (uint32_t)(threadIdx.x & 63) * 16u;
+    auto load_rows = [&](uint32_t chunk, int r) -> uint4 {
+        const uint32_t cc = chunk < last_chunk ? chunk : last_chunk;  // wave-uniform
+        return *reinterpret_cast<const uint4 *>(rows_b + (size_t)cc * (WROWS * 16u) + (uint32_t)(r * 1024) + lane16);
+    };
+    auto load64 = [&](uint32_t c64) -> uint4 {  // rows 64 c64 .. 64 c64 + 63, all inside the split (the seed's reads)
+        return *reinterpret_cast<const uint4 *>(rows_b + (size_t)c64 * 1024u + lane16);
     };
     const uint32_t c = tid & 15;
     const uint32_t cr8 = (c & 3) * 8, cq = c >> 2;
@@ -1391,13 +1418,11 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16a_kernel(const ScanArg
     }
     const char *lut_b = reinterpret_cast<const char *>(lut);
     static_assert(R == 1, "adc_scan16a: one row per lane and chunk");
-    constexpr uint32_t WROWS = 64;
     constexpr int NW = NT / 64, NSV = SQA_SERVERS, SV = NW - NSV;  // waves SV.. serve the compactions, the others scan
     const int wave = tid >> 6;
-    const uint32_t n_chunks = (n_local + WROWS - 1) / WROWS;
 
     if (a.seed && n_chunks >= 4 * SQ_SEED_CHUNKS)  // workgroup-uniform
-        scan16q_seed<NT, PREROT>(a.k, load_row, moffp, cr8, cq, lut_b, reinterpret_cast<uint32_t *>(&tk.buf[0][0]), qp, ck.lazy, tk.thr_x, ck.thr_pk);
+        scan16q_seed<NT, PREROT>(a.k, load64, moffp, cr8, cq, lut_b, reinterpret_cast<uint32_t *>(&tk.buf[0][0]), qp, ck.lazy, tk.thr_x, ck.thr_pk);
     for (int i = tid; i < QT * SQ_CAP; i += NT) (&tk.buf[0][0])[i] = SQA_EMPTY;
     __syncthreads();
     SQ_T(3);  // seed
@@ -1413,14 +1438,14 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16a_kernel(const ScanArg
         };
         uint32_t it = grab(), it_next = grab();
         uint4 cur = make_uint4(0, 0, 0, 0), nxt;
-        if (n_local) cur = load_row(it * WROWS + lane);
+        if (n_local) cur = load_rows(it, 0);
         uint32_t tpk[QT / 2];
         scan16a_load_thr(ck, tpk);
         uint32_t epoch_seen = 0;
         while (it < n_chunks) {
             const uint32_t ep = __hip_atomic_load(&ck.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // read early, used after the chunk
             const uint32_t base = it * WROWS;
-            nxt = load_row(it_next * WROWS + lane);
+            nxt = load_rows(it_next, 0);
             uint32_t s0, s1, s2, s3;
             scan16q_row_sums<PREROT>(cur, moffp, cr8, cq, lut_b, s0, s1, s2, s3);
             // sum < T for any of the 8 queries  <=>  a sign bit in the packed (sum - T)  (both < 2^15)

@@ -8,6 +8,9 @@
 namespace cvtmi {
 
 // growable device buffer
+// Every allocation carries kDevSlack bytes beyond `cap`: streaming kernels may READ up to that far past the end of a buffer
+// instead of clamping each lane's row index (the ADC scan's last 64-row chunk; what is read there is never used).
+constexpr size_t kDevSlack = 4096;
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -15,7 +18,7 @@ struct DevBuf {
     {
         if (bytes <= cap) return CVTMI_OK;
         if (p) { CVTMI_HIP(hipFree(p)); p = nullptr; cap = 0; }
-        hipError_t e = hipMalloc(&p, bytes);
+        hipError_t e = hipMalloc(&p, bytes + kDevSlack);
         if (e != hipSuccess) { p = nullptr; return fail(CVTMI_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
         cap = bytes;
         return CVTMI_OK;
@@ -25,7 +28,7 @@ struct DevBuf {
     {
         if (bytes <= cap) return CVTMI_OK;
         void *np = nullptr;
-        hipError_t e = hipMalloc(&np, bytes);
+        hipError_t e = hipMalloc(&np, bytes + kDevSlack);
         if (e != hipSuccess) return fail(CVTMI_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         if (p && keep) {
             CVTMI_HIP(hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, st));
