@@ -960,6 +960,8 @@ int flat_f32_stream_qmax(int D)
     return fs_eight(D) ? 32 * FS_MANY : (fs_four(D) ? 128 : 32) * fs_qb_max(D / 16);
 }
 static bool fs_shared(int D, int64_t nq) { return nq > 32 * fs_qb_max(D / 16); }
+// the most queries a pass of the private-ring kernel takes (more go to the shared ring, up to flat_f32_stream_qmax)
+int flat_f32_stream_private_max(int D) { return flat_f32_stream_qmax(D) > 0 ? 32 * fs_qb_max(D / 16) : 0; }
 bool flat_f32_stream_applies(int metric, int D, int64_t n, int k)
 {
     return (metric == CVTMI_METRIC_IP || metric == CVTMI_METRIC_L2F) && flat_f32_stream_qmax(D) > 0 && n >= 32768 && n < 0xffffffffLL &&

@@ -123,6 +123,7 @@ int launch_flat_block(const float *src, int64_t n, int D, int64_t row0, float *d
 // flat_f32_stream.hip: fp32 IP / L2 search as one stream over the blocked rows (bf16 matrix-core scores, group best / second best,
 // exact distances of the candidates); D % 16 == 0, 16 <= D <= 256, up to flat_f32_stream_qmax(D) queries per pass
 int flat_f32_stream_qmax(int D);
+int flat_f32_stream_private_max(int D);   // queries per pass of the private-ring kernel
 void set_flat_f32_dbg(int v);     // timing experiments, results wrong when non-zero
 void set_flat_f32_share(int v);   // shared-ring kernel: 0 choose, 1 four waves x 32 QB queries, 2 eight waves x 32 queries
 void set_flat_f32_nt(int v);     // 0 = never, 1 = choose (default), 2 = always: non-temporal hint on the stream kernels' row loads
