@@ -26,7 +26,7 @@ for it in range(iters):
         q[0] = np.inf if rng.random() < 0.5 else np.nan
     idx = cvt_amd.OpqIndex(np.zeros((1, D), np.float32), books)
     idx.add_codes(codes)
-    for variant in (3, 4, 1, 0):
+    for variant in (3, 4, 5, 1, 0):
         idx.set_param("scan_variant", variant); idx.set_param("splits", int(rng.choice([0, 0, 1, 2, 5])))
         idx.set_param("prerotate", int(rng.integers(0, 2)))
         d, i = idx.search(q, k, rotate=False)
