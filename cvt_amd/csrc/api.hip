@@ -68,6 +68,11 @@ struct cvtmi_opq_s {
     int32_t csr_vmin = 0, csr_vmax = -1;    // range of the video ids it holds
     // scratch
     DevBuf s_qrot, s_part_d, s_part_id, s_probe, s_lut, s_gthr, s_rot;
+    // adc_scan16h (scan_variant 6): quantised table images, their parameters, the candidate spill areas, the item table
+    DevBuf s_qlut, s_qp, s_spill, s_items;
+    ScanHPlan hplan;                       // the item table s_items holds ...
+    int64_t hplan_n = -1, hplan_nq = -1;   // ... and the (rows, queries, forced splits, planner settings) it was built for
+    int hplan_splits = 0, hplan_key = 0;
     DevBuf io_q, io_d, io_i;   // device side of the host-pointer search (cvtmi_opq_search)
     PinBuf io_pin;             // its pinned staging area
     // tuning / measurement
@@ -197,6 +202,7 @@ static int use_device(int dev)
     CHECK_H(h); \
     Serial serial_##h((h)->sync, (hipStream_t)(stream))
 
+static int g_scanh_key = 0;  // bumped when a planner setting of adc_scan16h changes: cached item tables are rebuilt
 static int g_inject_failure = -1;  // cvtmi_set_tuning("comm_inject_failure", r): the local search of rank r of a sharded search fails (tests)
 static int g_flat_variant = 0;  // cvtmi_set_tuning("flat_variant"): 0 = choose, 1 = exact kernels only, 2 = matrix-core filter wherever it applies
 static int g_flat_f32_stream = 1;  // cvtmi_set_tuning("flat_f32_stream"): 0 = off, 1 = choose, 2 = wherever it applies
@@ -278,6 +284,18 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "flat_f32_nt")) {
         if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_f32_nt must be 0, 1 or 2");
         set_flat_f32_nt((int)value);
+        return CVTMI_OK;
+    }
+    if (!strcmp(name, "scanh_balance")) {
+        if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: scanh_balance must be 0, 1 or 2");
+        set_scanh_balance((int)value);
+        ++g_scanh_key;
+        return CVTMI_OK;
+    }
+    if (!strcmp(name, "scanh_min_rows")) {
+        if (value < 1) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: scanh_min_rows must be positive");
+        set_scanh_min_rows(value);
+        ++g_scanh_key;
         return CVTMI_OK;
     }
     if (!strcmp(name, "scan_seed")) {
@@ -371,6 +389,7 @@ int cvtmi_opq_destroy(cvtmi_opq_t h)
     h->codes.release(); h->lists.release(); h->videos.release(); h->codes_rot.release();
     h->csr_codes.release(); h->csr_videos.release(); h->csr_off.release(); h->csr_scratch.release(); h->csr_stats.release();
     h->s_qrot.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_probe.release(); h->s_lut.release(); h->s_gthr.release(); h->s_rot.release();
+    h->s_qlut.release(); h->s_qp.release(); h->s_spill.release(); h->s_items.release();
     h->io_q.release(); h->io_d.release(); h->io_i.release(); h->io_pin.release();
     for (int e = 0; e < cvtmi_opq_s::kEvRing; ++e) {
         if (h->ev0[e]) (void)hipEventDestroy(h->ev0[e]);
@@ -649,6 +668,65 @@ int cvtmi_opq_lut(cvtmi_opq_t h, const float *q_rot, int64_t nq, const int32_t *
     return CVTMI_OK;
 }
 
+// scan_variant 6 (adc_scan16h, adc_scan_h.hip): tables once per query group, a persistent grid over a host-built item table,
+// candidates in per-workgroup spill areas, one selection per (segment, query), merge of the groups' partial lists
+static int opq_search_h(cvtmi_opq_t h, const float *q_rot, int64_t nq, int k, float *dist, int64_t *ids, hipStream_t st)
+{
+    if (h->hplan_n != h->n || h->hplan_nq != nq || h->hplan_splits != h->p_splits || h->hplan_key != g_scanh_key) {
+        scanh_plan(h->n, nq, h->p_splits, h->hplan);
+        const size_t bytes = h->hplan.items.size() * sizeof(ScanItem);
+        CVTMI_TRY(h->s_items.reserve(std::max<size_t>(bytes, 16)));
+        // (pageable source: the runtime stages it before the call returns, so the vector may change afterwards)
+        if (bytes) CVTMI_HIP(hipMemcpyAsync(h->s_items.p, h->hplan.items.data(), bytes, hipMemcpyHostToDevice, st));
+        h->hplan_n = h->n; h->hplan_nq = nq; h->hplan_splits = h->p_splits; h->hplan_key = g_scanh_key;
+    }
+    const ScanHPlan &hp = h->hplan;
+    float *pd = dist;
+    int64_t *pi = ids;
+    if (hp.stride > 1) {
+        const size_t cnt = (size_t)nq * hp.stride * k;
+        CVTMI_TRY(h->s_part_d.reserve(cnt * sizeof(float)));
+        CVTMI_TRY(h->s_part_id.reserve(cnt * sizeof(int64_t)));
+        pd = h->s_part_d.as<float>();
+        pi = h->s_part_id.as<int64_t>();
+    }
+    CVTMI_TRY(h->s_lut.reserve((size_t)nq * 16 * 256 * sizeof(float)));
+    CVTMI_TRY(h->s_qlut.reserve(scanh_qlut_bytes(nq)));
+    CVTMI_TRY(h->s_qp.reserve(scanh_qp_bytes(nq)));
+    CVTMI_TRY(h->s_spill.reserve(scanh_spill_bytes(hp.grid)));
+    const uint8_t *codes_rot = nullptr;
+    if (h->p_prerot) {  // the scan streams a pre-rotated copy of the rows
+        if (h->rot_n > h->n) h->rot_n = 0;
+        if (h->codes_rot.cap < (size_t)h->n * 16) {
+            CVTMI_TRY(h->codes_rot.reserve(std::max<size_t>(h->codes.cap, (size_t)h->n * 16)));
+            h->rot_n = 0;  // reserve() does not keep the old contents
+        }
+        CVTMI_TRY(launch_rotate_codes(h->codes.as<uint8_t>(), h->codes_rot.as<uint8_t>(), h->rot_n, h->n, st));
+        h->rot_n = h->n;
+        codes_rot = h->codes_rot.as<uint8_t>();
+    }
+    uint32_t *gthr = nullptr;
+    if (hp.stride > 1 && h->p_share) {
+        CVTMI_TRY(h->s_gthr.reserve((size_t)nq * sizeof(uint32_t)));
+        gthr = h->s_gthr.as<uint32_t>();
+    }
+    const int slot = h->ev_count % cvtmi_opq_s::kEvRing;
+    if (h->p_profile) {
+        if (!h->ev0[slot]) { CVTMI_HIP(hipEventCreate(&h->ev0[slot])); CVTMI_HIP(hipEventCreate(&h->ev1[slot])); }
+        CVTMI_HIP(hipEventRecord(h->ev0[slot], st));
+    }
+    CVTMI_TRY(launch_adc_scan_h(h->m, h->codes.as<uint8_t>(), codes_rot, h->n, h->id_base, q_rot, nq, k, hp, h->s_items.as<ScanItem>(), pd, pi,
+                                h->s_lut.as<float>(), h->s_qlut.p, h->s_qp.p, h->s_spill.p, gthr, h->p_lazy, scan_seed_enabled(), st));
+    if (h->p_profile) {
+        CVTMI_HIP(hipEventRecord(h->ev1[slot], st));
+        h->ev_count++;
+        h->last_bytes = ((nq + 7) / 8) * h->n * h->m.M;  // passes x rows x M code bytes
+        h->last_qt = 8; h->last_splits = hp.stride;
+    }
+    if (hp.stride > 1) CVTMI_TRY(launch_topk_merge(pd, pi, nq, hp.stride, k, dist, ids, st));
+    return CVTMI_OK;
+}
+
 int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int k, float *dist, int64_t *ids,
                          void *stream)
 {
@@ -668,6 +746,7 @@ int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, 
         q_rot = h->s_qrot.as<float>();
     }
     ScanPlan plan = plan_scan(h->m, h->n, nq, k, h->p_qtile, h->p_splits, h->p_variant);
+    if (plan.variant == 6) return opq_search_h(h, q_rot, nq, k, dist, ids, st);
     if (!h->p_tail) { plan.groups_a = 0; plan.splits_b = 0; }
     if (h->p_groups_a > 0 && h->p_splits_b > plan.splits && plan.variant >= 3 &&
         h->p_groups_a < (nq + plan.qtile - 1) / plan.qtile) {
@@ -880,7 +959,7 @@ int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value)
         return CVTMI_OK;
     }
     if (!strcmp(name, "scan_variant")) {
-        if (value < 0 || value > 5) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: scan_variant must be 0..5");
+        if (value < 0 || value > 6) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: scan_variant must be 0..6");
         h->p_variant = (int)value;
         return CVTMI_OK;
     }

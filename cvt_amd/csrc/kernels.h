@@ -1,6 +1,8 @@
 // kernels.h -- internal launch interface between the C-ABI glue (api.hip) and the HIP kernels.
 // All pointers are device pointers; every launcher is asynchronous on `st`.
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 namespace cvtmi {
@@ -55,6 +57,31 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
 // M = 16 only: codes_rot rows [row0, n) = the code rows rotated left by (row & 15) bytes, the layout adc_scan16q
 // (plan.variant >= 3) streams when codes_rot is given
 int launch_rotate_codes(const uint8_t *codes, uint8_t *codes_rot, int64_t row0, int64_t n, hipStream_t st);
+
+// ---- adc_scan_h.hip: adc_scan16h (plan.variant == 6), a persistent grid walking a host-built item table ----
+// one item = one row segment of one query group: rows [64 * row0_64, 64 * row0_64 + rows) scanned for the group's 8 queries;
+// its k best go to partial list `sidx` of the group's `nseg` (ascending rows); nseg == 0 marks an unused table entry
+struct ScanItem {
+    int32_t group;
+    uint32_t row0_64, rows;
+    uint16_t sidx, nseg;
+};
+struct ScanHPlan {
+    std::vector<ScanItem> items;  // [rounds][grid]
+    int grid = 0, rounds = 0, stride = 1;  // workgroups, items per workgroup, partial lists per query
+};
+void scanh_plan(int64_t n_rows, int64_t nq, int splits, ScanHPlan &p);
+size_t scanh_spill_bytes(int grid);
+size_t scanh_qlut_bytes(int64_t nq);
+size_t scanh_qp_bytes(int64_t nq);
+void set_scanh_balance(int v);       // 0 = choose, 1 = equal shares of the flat (group x row) space, 2 = (group, split) blocks
+void set_scanh_min_rows(int64_t v);  // smallest share of a workgroup in the balanced plan
+// part_d / part_id: [nq][plan.stride][k]; lut_g: nq * 16 * 256 floats; qlut / qp_g / spill: scanh_*_bytes; gthr: nq words or null
+int launch_adc_scan_h(const OpqModelDev &m, const uint8_t *codes, const uint8_t *codes_rot, int64_t n_rows, int64_t id_base,
+                      const float *q_rot, int64_t nq, int k, const ScanHPlan &plan, const ScanItem *items_dev, float *part_d,
+                      int64_t *part_id, float *lut_g, void *qlut, void *qp_g, void *spill, uint32_t *gthr, int lazy, int seed,
+                      hipStream_t st);
+int scan_seed_enabled();
 
 // ---- topk_merge.hip ----
 int launch_topk_merge(const float *in_d, const int64_t *in_id, int64_t nq, int L, int k, float *out_d, int64_t *out_id,

@@ -176,6 +176,10 @@ int cvtmi_opq_query_video_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rot
  *                   3 / 4 skewed 15-bit lower-bound tables, 8 queries per pass (1024 / 512 threads; 3 = default);
  *                   5 = variant 3 without checkpoints: one wave of the workgroup compacts beside the 15 that scan
  *                   (adc_scan16a; measured 7-10 % slower than 3 on 1 M rows, kept for comparison)
+ *                   6 = adc_scan16h: the tables of variant 3, quantised once per query group by a preparation kernel; a
+ *                   persistent grid (two workgroups per CU) walks a host-built item table (cvtmi_opq_scan_plan); candidates go
+ *                   to per-workgroup areas in HBM and are selected once per (row segment, query), the filter bounds come from
+ *                   a histogram of the candidates' integer sums; takes any number of queries
  *   "prerotate"   1 (default) = variants 3 / 4 stream a copy of the code rows in which row r is rotated by r & 15
  *                 bytes (the lane skew of the conflict-free table reads), kept next to the rows: +16 bytes of HBM
  *                 per row, 12 VALU instructions fewer per row in the VALU-bound scan loop; 0 = rotate in registers
@@ -191,6 +195,14 @@ int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value);
  * (the 64 most recent are kept) and the algorithmic code bytes ONE launch reads
  * (passes x rows x M, passes = ceil(nq / qtile)).  Synchronises on the profiling events only. */
 int cvtmi_opq_last_scan(cvtmi_opq_t h, float *ms, int64_t *code_bytes, int *qtile, int *splits);
+/* The item table "scan_variant" 6 would walk for n_rows code rows and nq queries (pure host logic: no device needed; the
+ * number of workgroup slots is taken as 2 x `cus`, 0 = the current device's CU count or 256 without one).  splits > 0 forces
+ * (query group, row split) blocks, 0 lets the planner choose (equal shares of the flat group x row space when the code matrix
+ * is cache-resident).  items: up to cap entries of 5 ints {query group, first row / 64, rows, partial-list index inside the
+ * group, partial lists of the group (0 = unused entry)}, item i of workgroup w at [i * grid + w].  Returns the number of
+ * entries (rounds * grid; nothing is written past cap) or a negative status. */
+int64_t cvtmi_opq_scan_plan(int64_t n_rows, int64_t nq, int splits, int cus, int64_t *items, int64_t cap, int *grid, int *rounds,
+                            int *stride);
 
 /* ---------------------------------------------------------------- top-k merge ---------------- */
 /* Exchange step of a row-sharded search: merge L sorted (distance, id) lists per query

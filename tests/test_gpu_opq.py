@@ -63,7 +63,7 @@ def test_golden_exhaustive_topk(amd, golden, orc):
     idx = make_index(amd, g)
     idx.add_codes(g["codes"])
     ms = g["match_score"]
-    for variant in (5, 4, 3, 1, 2, 0):
+    for variant in (6, 5, 4, 3, 1, 2, 0):
         for qt in (0, 1, 2, 4, 8):
             for splits in (0, 1, 3, 8):
                 idx.set_param("scan_variant", variant); idx.set_param("qtile", qt); idx.set_param("splits", splits)
@@ -193,7 +193,7 @@ def test_search_parity_seeded(amd, orc, M, k):
     idx.add_codes(codes[:7000]); idx.add_codes(codes[7000:])   # two appends
     assert idx.ntotal == n
     od, oi = orc.adc_search(q, books, codes, k)
-    for variant, qt, splits in ((5, 0, 0), (5, 0, 1), (5, 0, 8), (5, 0, 3), (4, 0, 0), (4, 0, 1), (4, 0, 8), (3, 0, 3), (3, 0, 1), (1, 0, 0), (1, 4, 1), (1, 4, 8), (2, 4, 3), (2, 0, 0), (0, 0, 0), (0, 1, 1), (0, 2, 5), (0, 4, 8),
+    for variant, qt, splits in ((6, 0, 0), (6, 0, 1), (6, 0, 8), (6, 0, 3), (5, 0, 0), (5, 0, 1), (5, 0, 8), (5, 0, 3), (4, 0, 0), (4, 0, 1), (4, 0, 8), (3, 0, 3), (3, 0, 1), (1, 0, 0), (1, 4, 1), (1, 4, 8), (2, 4, 3), (2, 0, 0), (0, 0, 0), (0, 1, 1), (0, 2, 5), (0, 4, 8),
                                 (0, 4, 16), (0, 1, 64)):
         idx.set_param("scan_variant", variant); idx.set_param("qtile", qt); idx.set_param("splits", splits)
         d, i = idx.search(q, k, rotate=False)
@@ -222,8 +222,11 @@ def test_search_edge_cases(amd, orc):
     same = np.tile(codes[:1], (5000, 1))
     idx.add_codes(same)
     idx.set_id_base(1 << 33)
-    d, i = idx.search(q, 100, rotate=False)
-    assert np.array_equal(i, np.tile((1 << 33) + np.arange(100), (3, 1)))
+    for variant in (3, 6):
+        idx.set_param("scan_variant", variant)
+        d, i = idx.search(q, 100, rotate=False)
+        assert np.array_equal(i, np.tile((1 << 33) + np.arange(100), (3, 1))), variant
+    idx.set_param("scan_variant", 3)
     # descending distances: every new row beats the threshold (stresses buffer overflow + retry path)
     idx.reset(); idx.set_id_base(0)
     order_books = books.copy()
@@ -234,7 +237,7 @@ def test_search_edge_cases(amd, orc):
     desc[:, 0] = ranks[(np.arange(n) * 256 // n)]
     idx.add_codes(desc)
     od, oi = orc.adc_search(q, order_books, desc, 100)
-    for variant in (5, 4, 3, 1, 2, 0):
+    for variant in (6, 5, 4, 3, 1, 2, 0):
         for splits in (1, 2):
             idx.set_param("scan_variant", variant); idx.set_param("splits", splits)
             d, i = idx.search(q, 100, rotate=False)
@@ -323,7 +326,7 @@ def test_full_size_properties(amd, orc):
     assert np.all(np.diff(dn, axis=1) >= 0)                                   # ascending
     tie = np.diff(dn, axis=1) == 0
     assert np.all(np.diff(inn, axis=1)[tie] > 0)                              # ties in id order
-    for variant, qt, splits in ((0, 1, 8), (0, 2, 16), (0, 4, 1), (1, 4, 24), (2, 4, 1), (2, 4, 16), (1, 4, 1), (3, 0, 1), (3, 0, 8), (4, 0, 1), (4, 0, 2), (5, 0, 1), (5, 0, 2), (5, 0, 8)):
+    for variant, qt, splits in ((0, 1, 8), (0, 2, 16), (0, 4, 1), (1, 4, 24), (2, 4, 1), (2, 4, 16), (1, 4, 1), (3, 0, 1), (3, 0, 8), (4, 0, 1), (4, 0, 2), (5, 0, 1), (5, 0, 2), (5, 0, 8), (6, 0, 0), (6, 0, 1), (6, 0, 2), (6, 0, 8)):
         idx.set_param("scan_variant", variant); idx.set_param("qtile", qt); idx.set_param("splits", splits)
         d2, i2 = idx.search(q, k)
         assert torch.equal(i2, i) and torch.equal(d2.view(torch.int32), d.view(torch.int32)), (variant, qt, splits)
@@ -406,7 +409,7 @@ def test_scan_lazy_selection_and_shared_thresholds(amd, orc):
         idx.add_codes(codes)
         for k in (1, 100, 128):
             od, oi = orc.adc_search(q, bk, codes, k)
-            for variant in (3, 4, 5):
+            for variant in (3, 4, 5, 6):
                 for lazy, share, splits in ((1, 1, 0), (1, 1, 1), (1, 1, 3), (1, 0, 3), (0, 1, 3), (0, 0, 1), (1, 1, 16)):
                     idx.set_param("scan_variant", variant); idx.set_param("scan_lazy", lazy); idx.set_param("scan_share", share)
                     idx.set_param("splits", splits)
@@ -424,10 +427,19 @@ def test_scan_lazy_selection_and_shared_thresholds(amd, orc):
     idx.add_codes(codes2)
     od, oi = orc.adc_search(q2, books2, codes2, 100)
     assert np.all(np.isfinite(od)) and not np.any(oi == 777)
-    for splits in (0, 1, 4):
-        idx.set_param("splits", splits)
-        d, i = idx.search(q2, 100, rotate=False)
-        assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od)), splits
+    for variant in (3, 6):
+        for splits in (0, 1, 4):
+            idx.set_param("scan_variant", variant); idx.set_param("splits", splits)
+            d, i = idx.search(q2, 100, rotate=False)
+            assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od)), (variant, splits)
+    # a NaN and an inf query beside ordinary ones (their sums bound nothing: the spill area overflows, exact reductions take over)
+    q3 = q2.copy(); q3[2, 5] = np.nan; q3[6, 77] = np.inf
+    od, oi = orc.adc_search(q3, books2, codes2, 100)
+    for variant in (3, 6):
+        idx.set_param("scan_variant", variant); idx.set_param("splits", 0)
+        d, i = idx.search(q3, 100, rotate=False)
+        ok = np.array([f not in (2, 6) for f in range(len(q3))])   # the finite queries of the batch must not notice
+        assert np.array_equal(i[ok], oi[ok]) and np.array_equal(bits(d)[ok], bits(od)[ok]), variant
     idx.close()
 
 
@@ -497,3 +509,46 @@ def test_scan_seed_thresholds(amd, orc):
             idx.close()
     finally:
         amd.set_tuning("scan_seed", 1)
+
+
+@pytest.mark.gpu
+def test_scan_h_item_tables(amd, orc):
+    """adc_scan16h (scan_variant 6): every shape of its item table gives the oracle's answer -- equal shares of the flat
+    (query group x row) space (groups cut at arbitrary tiles, several items per workgroup, shares smaller than a group and
+    larger than several), (group, split) blocks taken round-robin, one query, a ragged last group, k larger than a segment,
+    and an index whose candidates overflow the spill areas (more rows below the bound than 4096: the mid-scan reduction)."""
+    D, M, K = 128, 16, 256
+    rng = np.random.default_rng(606)
+    books = synth_model(rng, D, M, K, scale=0.1)
+    n = 70_000 + 5
+    codes = rng.integers(0, K, size=(n, M), dtype=np.uint8)
+    codes[100] = codes[50]; codes[40_000] = codes[50]; codes[69_999] = codes[50]
+    idx = amd.OpqIndex(np.zeros((1, D), np.float32), books)
+    idx.add_codes(codes)
+    idx.set_param("scan_variant", 6)
+    try:
+        for nq in (1, 3, 8, 9, 77, 530):
+            q = (rng.normal(size=(nq, D)) * 0.1).astype(np.float32)
+            for k in (1, 100, 128):
+                od, oi = orc.adc_search(q, books, codes, k)
+                for balance, min_rows, splits in ((1, 2048, 0), (1, 8192, 0), (1, 16384, 0), (1, 1 << 20, 0), (2, 0, 0), (2, 0, 5), (2, 0, 16), (0, 0, 0)):
+                    amd.set_tuning("scanh_balance", balance)
+                    if min_rows: amd.set_tuning("scanh_min_rows", min_rows)
+                    idx.set_param("splits", splits)
+                    d, i = idx.search(q, k, rotate=False)
+                    assert np.array_equal(i, oi), (nq, k, balance, min_rows, splits)
+                    assert np.array_equal(bits(d), bits(od)), (nq, k, balance, min_rows, splits)
+        # 9000 rows of which 6000 are one and the same vector, the query on it: every one of them is a candidate
+        same = codes[:9000].copy(); same[1000:7000] = codes[7]
+        idx.reset(); idx.add_codes(same)
+        q = (rng.normal(size=(5, D)) * 0.1).astype(np.float32)
+        q[1] = np.concatenate([books[m, codes[7][m]] for m in range(M)])
+        for k in (10, 128):
+            od, oi = orc.adc_search(q, books, same, k)
+            for balance, splits in ((1, 0), (2, 1), (2, 2)):
+                amd.set_tuning("scanh_balance", balance); idx.set_param("splits", splits)
+                d, i = idx.search(q, k, rotate=False)
+                assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od)), (k, balance, splits)
+    finally:
+        amd.set_tuning("scanh_balance", 0); amd.set_tuning("scanh_min_rows", 16384)
+        idx.close()

@@ -1,0 +1,57 @@
+"""Host logic of the persistent ADC scan (scan_variant 6, cvt_amd/csrc/adc_scan_h.hip): the item table must cover every
+(query group, row) exactly once, segment indices must follow the rows (the merge's tie rule), and every workgroup must get
+its items in round order.  Pure host code: runs without a GPU (cvtmi_opq_scan_plan)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cvt_amd
+
+
+def plan(n_rows, nq, splits=0, cus=256):
+    lib = cvt_amd.lib()
+    lib.cvtmi_opq_scan_plan.restype = C.c_int64
+    lib.cvtmi_opq_scan_plan.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int)]
+    g, r, s = C.c_int(), C.c_int(), C.c_int()
+    n = lib.cvtmi_opq_scan_plan(n_rows, nq, splits, cus, None, 0, C.byref(g), C.byref(r), C.byref(s))
+    assert n >= 0 and n == g.value * r.value
+    items = np.zeros((max(n, 1), 5), np.int64)
+    assert lib.cvtmi_opq_scan_plan(n_rows, nq, splits, cus, items.ctypes.data, n, C.byref(g), C.byref(r), C.byref(s)) == n
+    return items[:n].reshape(r.value, g.value, 5), g.value, r.value, s.value
+
+
+@pytest.mark.parametrize("n_rows,nq,splits", [
+    (1_000_000, 10_000, 0), (1_000_000, 1000, 0), (1_000_000, 8, 0), (1_000_000, 1, 0), (1_000_000, 4500, 0), (20_013, 9, 0), (7, 3, 0),
+    (7, 3, 2), (20_013, 77, 3), (20_013, 77, 8), (1_000_000, 64, 16), (1 << 30, 10_000, 0), (128_000_000, 2048, 0), (300_000_000, 16, 0),
+    (2049, 8, 0), (70_005, 530, 0), (5_999_999, 100, 0), (6_000_001, 100, 0)])
+def test_item_table_covers_every_row_once(n_rows, nq, splits):
+    items, grid, rounds, stride = plan(n_rows, nq, splits)
+    groups = (nq + 7) // 8
+    assert 1 <= grid <= 512
+    used = items[items[:, :, 4] > 0]
+    assert np.all(used[:, 0] < groups) and np.all(used[:, 2] <= (1 << 28) - 4096)
+    u = items[:, :, 4] > 0                     # unused entries only after a workgroup's used ones
+    assert rounds == 1 or np.all(u[:-1] | ~u[1:])
+    sample = range(groups) if groups <= 200 else list(range(0, groups, max(1, groups // 150))) + [groups - 1]
+    for g in sample:
+        seg = used[used[:, 0] == g]
+        seg = seg[np.argsort(seg[:, 3])]
+        assert len(seg) >= 1 and np.array_equal(seg[:, 3], np.arange(len(seg))) and np.all(seg[:, 4] == len(seg)) and len(seg) <= stride
+        row = 0
+        for _, r0, rows, _, _ in seg:          # ascending, gap-free, ending at n_rows
+            assert r0 * 64 == row or rows == 0
+            row += rows
+        assert row == n_rows
+    assert stride == max(1, used[:, 4].max())
+    assert int(used[:, 2].sum()) == groups * n_rows
+
+
+def test_balanced_shares_are_equal():
+    items, grid, rounds, stride = plan(1_000_000, 10_000)
+    per_wg = (items[:, :, 2] * (items[:, :, 4] > 0)).sum(axis=0)
+    assert grid == 512 and stride in (2, 3)
+    assert per_wg.max() - per_wg.min() <= 2 * 4 * 2048 + 2048        # boundaries snap by at most 4 tiles
+    seg = items[items[:, :, 4] > 0][:, 2]
+    assert seg.min() >= 4 * 2048 - 2048                              # no sliver segments
