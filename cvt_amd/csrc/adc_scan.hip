@@ -1232,6 +1232,9 @@ ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int 
     p.variant = 0;
     //   variant 5: adc_scan16a (compactions beside the scan); variant 6: adc_scan16h (adc_scan_h.hip: histogram bounds, spilled
     //   candidates, persistent grid) -- takes any number of queries
+    // want_variant 7 = the library's own choice between 3 and 6: adc_scan16h where it measured ahead on a cache-resident index
+    // (63 ... 500 query groups at 1 M rows: -6 % at 1000 queries, -10 ... -14 % at 2500; tools/sweep_scan_h.py), adc_scan16q elsewhere
+    if (want_variant == 7) want_variant = (m.M == 16 && nq >= 500 && nq <= 4000 && n_rows >= 131072 && n_rows * 16 <= (96LL << 20)) ? 6 : 3;
     if (m.M == 16 && want_variant >= 3 && (nq >= 4 || want_variant == 6) && m.D <= 256) { p.variant = want_variant; qt = 8; }
     else if (m.M == 16 && want_variant >= 1) {
         if (want_variant <= 2 && (want_qtile == 0 || want_qtile == 4) && nq >= 4) { p.variant = want_variant; qt = 4; }

@@ -37,7 +37,6 @@ namespace cvtmi {
 constexpr int SH_CAPG = 4096;   // spill entries per (workgroup, query)
 constexpr int SH_BINS = 256;    // histogram bins of 128 table units (sums are below 2^15)
 constexpr uint32_t SH_UPD = 32; // a query's bound is recomputed every SH_UPD stored candidates
-constexpr uint32_t SH_STOP = 0x80000000u;
 
 struct ScanHArgs {
     const uint8_t *codes, *codes_rot;
@@ -53,6 +52,8 @@ struct ScanHArgs {
     int stride;                 // partial lists per query
     float *part_d;
     int64_t *part_id;
+    float *out_d;               // final lists [nq][k]: groups with one segment write here when stride > 1 (with stride 1, part_* ARE the final lists)
+    int64_t *out_id;
     int seed;
 };
 
@@ -173,23 +174,35 @@ __global__ __launch_bounds__(1024) void scan16h_prep_kernel(const float *__restr
 // control words of one workgroup
 struct ScanHCtl {
     __attribute__((aligned(16))) uint32_t thr_pk[SQ_QT / 2];  // 15-bit bounds, two per word (what the loop compares with)
-    uint32_t ctl;         // epoch of thr_pk (low bits) | SH_STOP
+    uint32_t epoch;       // bumped whenever thr_pk (or stop) changes: the scanning waves look at it once per 64 rows
+    uint32_t stop;        // a spill area is full: everybody meets at the barrier
     uint32_t next_chunk;
     int done_waves;
-    int cnt[SQ_QT];       // candidates stored (or refused, past SH_CAPG) per query
+    int cnt[SQ_QT];       // spill positions handed out per query (beyond SH_CAPG: refused)
     uint32_t thr_x[SQ_QT];
     int exact_n[SQ_QT];   // leading spill entries that carry exact keys (after a mid-scan reduction)
     int lazy[SQ_QT];      // the integer sums bound the real sums from both sides (slack != 0)
-    // what the out-of-line candidate path needs of the kernel's arguments (uniform; kept here so that its call passes one pointer)
-    unsigned long long *spill;
-    uint32_t *gthr;
-    int k, group, nq;
 };
+constexpr int SH_STAGE = 32;  // candidates a wave collects in its own LDS area before it moves them to the spill areas
 struct ScanHShared {
     __attribute__((aligned(16))) uint32_t hist[SQ_QT][SH_BINS];
+    unsigned long long stage[16][SH_STAGE];
     QuantParams qp;
     ScanHCtl ck;
 };
+
+// inclusive prefix sum over the wave in the DPP network (no LDS traffic: under the scan's load an LDS round trip of one wave
+// takes ~0.4 us); the sequence of LLVM's AMDGPUAtomicOptimizer::buildScan for gfx9
+__device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
 
 // bound of one query from its histogram: (upper edge of the first bin at which the cumulative count reaches k) + slack,
 // 0xffffffff while fewer than k rows are counted.  Whole wave, wave-uniform result; counts only grow, so any snapshot of
@@ -199,12 +212,7 @@ __device__ __forceinline__ uint32_t scanh_hist_bound(const uint32_t *hq, int k, 
     const int lane = threadIdx.x & 63;
     const uint4 c = *reinterpret_cast<const uint4 *>(hq + lane * 4);
     const uint32_t mine = c.x + c.y + c.z + c.w;
-    uint32_t incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o);
-        if (lane >= o) incl += up;
-    }
+    const uint32_t incl = wave_incl_scan_add(mine);
     const unsigned long long reach = __ballot(incl >= (uint32_t)k);
     if (!reach) return 0xffffffffu;
     const int l0 = __ffsll((long long)reach) - 1;
@@ -218,17 +226,17 @@ __device__ __forceinline__ uint32_t scanh_hist_bound(const uint32_t *hq, int k, 
     return t < 32767u ? t : 32767u;
 }
 
-// publish a (possibly) tighter bound of query q: thr_x, its half of thr_pk, the epoch; the segments of the query group share
-// it through gthr.  Whole wave (no one-lane regions in the callers' loops: adc_scan.hip "coding rule"); t wave-uniform.
-__device__ __forceinline__ void scanh_publish(ScanHCtl &ck, int q, uint32_t t, uint32_t *gthr, int qi, int nq)
+// publish a (possibly) tighter bound of query q: thr_x, its half of thr_pk, the epoch.  Whole wave, t wave-uniform.  Plain loads and stores: two waves that publish at once leave one of two
+// valid bounds, and an epoch that moved at least once.
+__device__ __forceinline__ bool scanh_publish(ScanHCtl &ck, int q, uint32_t t)
 {
-    const bool l0 = (threadIdx.x & 63) == 0;
-    const uint32_t old = (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicMin(&ck.thr_x[q], l0 ? t : 0xffffffffu));
-    if (t < old) {  // wave-uniform
-        __hip_atomic_store(reinterpret_cast<uint16_t *>(ck.thr_pk) + q, (uint16_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        atomicAdd(&ck.ctl, l0 ? 1u : 0u);
-        if (gthr && qi < nq && l0) __hip_atomic_fetch_min(&gthr[qi], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    const uint32_t old = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ck.thr_x[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (t >= old) return false;  // wave-uniform
+    __hip_atomic_store(&ck.thr_x[q], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(reinterpret_cast<uint16_t *>(ck.thr_pk) + q, (uint16_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ck.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    __hip_atomic_store(&ck.epoch, e + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return true;
 }
 
 // Selection of one query's spilled candidates by ONE wave through the register selection of block_topk.h: entries
@@ -244,24 +252,45 @@ __device__ __attribute__((noinline)) int scanh_select_q(TopKShared<SQ_QT, SQ_CAP
     for (int i = lane; i < ex; i += 64) b[i] = sp[i];  // ex <= k <= 128 < SQ_CAP
     if (lane == 0) { tk.exact_n[q] = ex; tk.thr[q] = KEY_MAX; tk.thr_x[q] = T; }
     int have = ex;
-    for (int base = ex; base < n; base += 64) {  // wave-uniform trip count
-        const int i = base + lane;
-        const unsigned long long e = i < n ? sp[i] : ~0ull;
-        bool in = i < n && (uint32_t)(e >> 32) < T;
-        unsigned long long m = __ballot(in);
-        if (have + __popcll(m) > SQ_CAP) {  // wave-uniform
-            have = topk_compact_wave_q<SQ_QT, SQ_CAP, false>(tk, q, k, fixb, thrx, have);
-            const uint32_t t2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk.thr_x[q]);
-            T = t2 < T ? t2 : T;
-            in = in && (uint32_t)(e >> 32) < T;
-            m = __ballot(in);
+    for (int base0 = ex; base0 < n; base0 += 256) {  // wave-uniform trip count; four loads per lane in flight
+        unsigned long long e4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = base0 + r * 64 + lane;
+            e4[r] = i < n ? sp[i] : ~0ull;
         }
-        const int pos = have + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (in) b[pos] = e;
-        have += __popcll(m);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (base0 + r * 64 >= n) break;  // wave-uniform
+            const unsigned long long e = e4[r];
+            bool in = e != ~0ull && (uint32_t)(e >> 32) < T;
+            unsigned long long m = __ballot(in);
+            if (have + __popcll(m) > SQ_CAP) {  // wave-uniform
+                have = topk_compact_wave_q<SQ_QT, SQ_CAP, false>(tk, q, k, fixb, thrx, have);
+                const uint32_t t2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk.thr_x[q]);
+                T = t2 < T ? t2 : T;
+                in = in && (uint32_t)(e >> 32) < T;
+                m = __ballot(in);
+            }
+            const int pos = have + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (in) b[pos] = e;
+            have += __popcll(m);
+        }
     }
     return topk_compact_wave_q<SQ_QT, SQ_CAP, SORTED>(tk, q, k, fixb, thrx, have);
 }
+
+#ifdef CVTMI_SCAN_TIMING
+static __device__ unsigned long long g_scanh_cnt[8];  // candidates stored, rare-path entries (wave 0), rare-path cycles (wave 0), bound updates (wave 0), update cycles, items, stops
+// (accumulated in thread 0's registers, flushed once per item: an atomic per event would sit in the loop's vmcnt queue)
+#define SH_CNT(i, v) do { if (threadIdx.x == 0) sh_cnt__[i] += (unsigned long long)(v); } while (0)
+#define SH_CNT_DECL() unsigned long long sh_cnt__[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
+#define SH_CNT_FLUSH() do { if (threadIdx.x == 0) { for (int i__ = 0; i__ < 8; ++i__) { if (sh_cnt__[i__]) atomicAdd(&g_scanh_cnt[i__], sh_cnt__[i__]); sh_cnt__[i__] = 0; } } } while (0)
+#else
+#define SH_CNT(i, v) do { } while (0)
+#define SH_CNT_DECL() do { } while (0)
+#define SH_CNT_FLUSH() do { } while (0)
+#endif
 
 template <bool PREROT>
 __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
@@ -276,6 +305,7 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
     ScanHCtl &ck = sh.ck;
 
     SQ_T0();
+    SH_CNT_DECL();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TopK &tk = *reinterpret_cast<TopK *>(lut);
     const uint4 *rows = reinterpret_cast<const uint4 *>(a.codes);
@@ -306,6 +336,7 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
             item.group = __builtin_amdgcn_readfirstlane(item.group);
             item.row0_64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.row0_64);
             item.rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.rows);
+            item.chunk0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.chunk0);
             const int sn = __builtin_amdgcn_readfirstlane((int)item.sidx | ((int)item.nseg << 16));
             item.sidx = (uint16_t)sn; item.nseg = (uint16_t)(sn >> 16);
         }
@@ -314,6 +345,9 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
         const int64_t row_begin = (int64_t)item.row0_64 * 64;
         const uint32_t n_local = item.rows;
         const ExactFromLutBatch fixb{ rows, a.lut_g, a.K, a.nq, group };
+        // bounds shared by the segments of a group: read when a segment starts, written when it ends (a global atomic per published bound
+        // sat in the scan loop's vmcnt queue: the row prefetch waited for its acknowledgement)
+        uint32_t *const gthr = item.nseg > 1 ? a.gthr : nullptr;
 
         auto load_tables = [&]() {
             const uint4 *src = a.qlut + (size_t)group * 4096;
@@ -329,12 +363,12 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
         for (int i = tid; i < QT * SH_BINS; i += NT) (&hist[0][0])[i] = 0;
         if (tid < QT / 2) {  // pass-all until k rows are counted -- or what the other segments of these queries have established
             uint32_t t2[2] = { 32767u, 32767u };
-            if (a.gthr) {
+            if (gthr) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int qi = group * QT + 2 * tid + h;
                     if (qi < a.nq) {  // a stale value is an older, looser, still valid bound
-                        const uint32_t g = __hip_atomic_load(&a.gthr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t g = __hip_atomic_load(&gthr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         t2[h] = g < t2[h] ? g : t2[h];
                     }
                 }
@@ -344,8 +378,7 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
         }
         if (tid < QT) { ck.cnt[tid] = 0; ck.exact_n[tid] = 0; }
         if (tid == 0) {
-            ck.ctl = 0; ck.next_chunk = 0; ck.done_waves = 0;
-            ck.spill = spill; ck.gthr = a.gthr; ck.k = a.k; ck.group = group; ck.nq = a.nq;
+            ck.epoch = 0; ck.stop = 0; ck.next_chunk = 0; ck.done_waves = 0;
         }
         __syncthreads();
         if (tid < QT) ck.lazy[tid] = qp.slack[tid] != 0;
@@ -357,8 +390,15 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
         const uint32_t last_chunk = n_chunks ? n_chunks - 1 : 0;
         // 64 rows of chunk c: one 16-byte load per lane off a scalar base; chunks past the end read the last one, whose lanes past
         // n_local read the next segment's rows or the slack every device buffer carries (never used: adc_scan16q_kernel)
-        auto load_rows = [&](uint32_t chunk) -> uint4 {
-            const uint32_t cc = chunk < last_chunk ? chunk : last_chunk;  // wave-uniform
+        // walk position -> chunk of the segment: the walk starts at chunk0 and wraps around (positions past the end, the prefetch of a
+        // wave that is about to finish, stay on the last position)
+        const uint32_t chunk0 = item.chunk0;
+        auto chunk_at = [&](uint32_t pos) -> uint32_t {  // wave-uniform
+            uint32_t cc = (pos < last_chunk ? pos : last_chunk) + chunk0;
+            return cc >= n_chunks && n_chunks ? cc - n_chunks : cc;
+        };
+        auto load_rows = [&](uint32_t pos) -> uint4 {
+            const uint32_t cc = chunk_at(pos);
             // scalar base + 32-bit lane offset (spelled out: hipcc otherwise keeps rows_b + lane16 as a vector register pair across the loop)
             const uint64_t sb = (uint64_t)(uintptr_t)rows_b + (uint64_t)cc * 1024u;
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sb), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sb >> 32));
@@ -384,8 +424,65 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
             return 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
         };
         auto after = [&](uint32_t chunk) -> uint32_t { return (chunk & 1u) ? grab_pair() : chunk + 1u; };
-        uint32_t it = grab_pair(), it_next = it + 1u, done = 0, done_for = 0xffffffffu;
+        uint32_t it = grab_pair(), it_next = it + 1u;
         bool counted = false;
+        int wn = 0;  // candidates in this wave's staging area (wave-uniform)
+        unsigned long long *stage_w = sh.stage[wave];
+        // a chunk whose candidates could not all be staged because a spill area was full (it is walked again after the reduction),
+        // and per query the lanes whose candidate was still to come
+        uint32_t fail_it = 0xffffffffu;
+        unsigned long long fail_mq[QT] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+
+        // Moves the wave's staged candidates to the spill areas: ONE LDS round trip hands out the positions of all eight queries
+        // (lane q adds query q's count to its counter), then one 8-byte global store per entry.  Queries whose count crossed a multiple
+        // of SH_UPD get their bound recomputed from the histogram.  Returns false when a spill area is full: the refused entries stay
+        // (at the head of the staging area) and the workgroup has to stop.  `moved`: a bound was published.
+        auto flush = [&](bool &moved) -> bool {
+            const bool have = lane < wn;
+            const unsigned long long e = have ? stage_w[lane] : 0ull;
+            const uint32_t eq = (uint32_t)(e >> 47) & 7u;
+            uint32_t cntv = 0, rank = 0;
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                const unsigned long long m = __ballot(have && eq == (uint32_t)q);
+                cntv = lane == q ? (uint32_t)__popcll(m) : cntv;
+                const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                rank = eq == (uint32_t)q ? r : rank;
+            }
+            uint32_t basev = 0;
+            if (lane < QT && cntv) basev = (uint32_t)atomicAdd(&ck.cnt[lane], (int)cntv);
+            uint32_t mybase = 0, upd = 0;
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                const uint32_t bq = (uint32_t)__builtin_amdgcn_readlane((int)basev, q), cq_ = (uint32_t)__builtin_amdgcn_readlane((int)cntv, q);
+                mybase = eq == (uint32_t)q ? bq : mybase;
+                if (cq_ && ((bq + cq_) / SH_UPD != bq / SH_UPD)) upd |= 1u << q;  // scalar
+            }
+            const uint32_t pos = mybase + rank;
+            const bool ok = have && pos < (uint32_t)SH_CAPG;
+            if (ok) spill[(size_t)eq * SH_CAPG + pos] = e & 0x00007fffffffffffull;  // (the query tag leaves the key)
+            const unsigned long long bad = __ballot(have && !ok);
+            if (upd) {  // wave-uniform
+                [[maybe_unused]] const long long t_u0 = SQA_NOW();
+#pragma unroll 1
+                for (int q = 0; q < QT; ++q) {
+                    if (!((upd >> q) & 1u)) continue;
+                    if (!__builtin_amdgcn_readfirstlane(ck.lazy[q])) continue;
+                    const uint32_t t = scanh_hist_bound(hist[q], a.k, qp.slack[q]);
+                    if (t != 0xffffffffu && scanh_publish(ck, q, t)) moved = true;
+                }
+                SH_CNT(3, 1); SH_CNT(4, SQA_NOW() - t_u0);
+            }
+            if (!bad) { wn = 0; return true; }
+            const int r2 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bad >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bad, 0u));
+            if (have && !ok) stage_w[r2] = e;
+            wn = __popcll(bad);
+            __hip_atomic_store(&ck.stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t ep = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ck.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            __hip_atomic_store(&ck.epoch, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return false;
+        };
+
         for (;;) {
             // (after a stop the wave comes back to chunk `it`: its rows are loaded again rather than kept across the reduction's calls)
             uint32_t moffp[4], cr8, cq;
@@ -393,92 +490,110 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
             uint4 cur = make_uint4(0, 0, 0, 0), nxt;
             if (it < n_chunks) cur = load_rows(it);
             bool raised = false;  // this wave asked for a stop
-            for (;;) {  // one round per set of bounds: inside the chunk loop they are constants (re-read here whenever the epoch moved)
+            if (wn) {  // entries a full spill area refused before the reduction
+                bool mv = false;
+                raised = !flush(mv);
+            }
+            while (!raised) {  // one round per set of bounds: inside the chunk loop they are constants (re-read here whenever the epoch moved)
                 uint32_t tpk[QT / 2];
 #pragma unroll
                 for (int i = 0; i < QT / 2; ++i) tpk[i] = __hip_atomic_load(&ck.thr_pk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const uint32_t ctl_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ck.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                if (it >= n_chunks || (ctl_seen & SH_STOP)) break;
+                const uint32_t ep_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ck.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (it >= n_chunks || __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ck.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
                 while (it < n_chunks) {
-                    const uint32_t ctl_now = __hip_atomic_load(&ck.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // read early, used after the chunk
-                    const uint32_t base = it * 64u;
+                    const uint32_t ep_now = __hip_atomic_load(&ck.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // read early, used after the chunk
+                    const uint32_t base = chunk_at(it) * 64u;
                     nxt = load_rows(it_next);
                     uint32_t s0, s1, s2, s3;
                     scan16q_row_sums<PREROT, 16>(cur, moffp, cr8, cq, lut_b, s0, s1, s2, s3);
                     // sum < T for any of the 8 queries  <=>  a sign bit in the packed (sum - T)  (both < 2^15)
-                    const uint32_t sg = (pk_sub_i16(s0, tpk[0]) | pk_sub_i16(s1, tpk[1]) | pk_sub_i16(s2, tpk[2]) | pk_sub_i16(s3, tpk[3])) & 0x80008000u;
-                    bool failed_any = false, moved = false;  // wave-uniform
-                    if (__builtin_expect(__ballot(sg != 0) != 0, 0)) {  // rare once the bounds have tightened (and the register allocator must know: the loops in here are not the hot ones)
-                        if (done_for != it) { done = 0; done_for = it; }  // (the bits belong to one chunk; only this path sets or reads them)
-                        uint32_t lrow = base + lane;
-                        asm volatile("" : "+v"(lrow));  // (keeps the tail test in here)
-                        bool failed = false;
-                        uint32_t upd = 0;
-                        if (sg != 0 && lrow < n_local) {
-                            // ONE copy of the store code, walked by a rolled loop over the query pairs (the sums and bounds rotate through
-                            // element 0): unrolled eight times, hipcc kept the eight spill bases and counter / histogram addresses in vector
-                            // registers across the whole scan loop and spilled the current rows instead
-                            uint32_t sr[4] = { s0, s1, s2, s3 }, tr[4] = { tpk[0], tpk[1], tpk[2], tpk[3] };
-                            const uint32_t row = (uint32_t)(row_begin + lrow);
-#pragma unroll 1
-                            for (int q2 = 0; q2 < QT / 2; ++q2) {
+                    const uint32_t d0 = pk_sub_i16(s0, tpk[0]), d1 = pk_sub_i16(s1, tpk[1]), d2 = pk_sub_i16(s2, tpk[2]), d3 = pk_sub_i16(s3, tpk[3]);
+                    const uint32_t sg = (d0 | d1 | d2 | d3) & 0x80008000u;
+                    bool moved = false;  // wave-uniform
+                    if (__builtin_expect(__ballot(sg != 0) != 0, 0)) {  // one chunk in five (and the register allocator must know: the loops in here are not the hot ones)
+                        // Every vector instruction in here is paid for twice: the wave issues one per ~32 cycles beside seven others, and the
+                        // look-up loops of those seven are bound by the same issue port.  So: which queries have candidates is decided on
+                        // scalar masks (eight compares), and only those queries cost vector work -- rank by lane count (no atomic, no round
+                        // trip), one 8-byte LDS store into the wave's own staging area, one histogram increment.
+                        [[maybe_unused]] const long long t_r0 = SQA_NOW();
+                        unsigned long long tail = ~0ull;
+                        if (base + 64u > n_local) tail = n_local > base ? ((1ull << (n_local - base)) - 1ull) : 0ull;  // scalar: lanes inside the segment
+                        const bool redo = it == fail_it;  // scalar: second walk over a chunk a stop interrupted
+                        // (the lane number is recomputed: kept in a register across the scan loop it ends up in scratch, and its reload would wait for the row prefetch)
+                        uint32_t ones = ~0u;
+                        asm volatile("" : "+s"(ones));  // (or hipcc recognises the lane number and reloads the spilled one)
+                        const uint32_t row = (uint32_t)row_begin + base + __builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+                        const uint32_t dd[4] = { d0, d1, d2, d3 }, ss[4] = { s0, s1, s2, s3 };
+                        unsigned long long mq[QT];  // per query: lanes whose row is a candidate (scalar masks)
 #pragma unroll
-                                for (int h = 0; h < 2; ++h) {
-                                    const int q = 2 * q2 + h;
-                                    const uint32_t bit = 1u << q;
-                                    const uint32_t sq = h ? sr[0] >> 16 : sr[0] & 0xffffu;
-                                    const uint32_t tq = h ? tr[0] >> 16 : tr[0] & 0xffffu;
-                                    if (sq < tq && !(done & bit)) {
-                                        const int pos = atomicAdd(&ck.cnt[q], 1);
-                                        if (pos < SH_CAPG) {
-                                            spill[(size_t)q * SH_CAPG + pos] = ((unsigned long long)sq << 32) | row;
-                                            atomicAdd(&hist[q][sq >> 7], 1u);
-                                            done |= bit;
-                                            if ((((uint32_t)pos + 1u) & (SH_UPD - 1u)) == 0) upd |= bit;
-                                        } else {
-                                            failed = true;
-                                        }
-                                    }
-                                }
-                                const uint32_t s_ = sr[0], t_ = tr[0];
-                                sr[0] = sr[1]; sr[1] = sr[2]; sr[2] = sr[3]; sr[3] = s_;
-                                tr[0] = tr[1]; tr[1] = tr[2]; tr[2] = tr[3]; tr[3] = t_;
-                            }
+                        for (int i = 0; i < QT / 2; ++i) {
+                            mq[2 * i] = __ballot((dd[i] & 0x8000u) != 0) & tail;
+                            mq[2 * i + 1] = __ballot((int32_t)dd[i] < 0) & tail;
                         }
-                        failed_any = __ballot(failed) != 0;
-                        if (__builtin_expect(__ballot(upd != 0) != 0, 0)) {  // some query of this wave reached its next multiple of SH_UPD candidates: recompute its bound
-#pragma unroll 1
+                        if (redo) {
+#pragma unroll
+                            for (int q = 0; q < QT; ++q) mq[q] &= fail_mq[q];
+                        }
+                        for (;;) {  // one round, unless the chunk holds more candidates than the staging area has room for
+                            bool left = false;
+#pragma unroll
                             for (int q = 0; q < QT; ++q) {
-                                if (!__ballot((upd >> q) & 1u)) continue;  // wave-uniform
-                                if (!__builtin_amdgcn_readfirstlane(ck.lazy[q])) continue;
-                                const uint32_t t = scanh_hist_bound(hist[q], a.k, qp.slack[q]);
-                                if (t != 0xffffffffu) { scanh_publish(ck, q, t, a.gthr, group * QT + q, a.nq); moved = true; }
+                                if (!mq[q]) continue;  // scalar
+                                const unsigned long long m = mq[q];
+                                const int room = SH_STAGE - wn;
+                                const int n = __popcll(m);
+                                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                                unsigned long long take = m;
+                                if (n > room) take = __ballot(__builtin_amdgcn_inverse_ballot_w64(m) && rank < (uint32_t)room);
+                                if (__builtin_amdgcn_inverse_ballot_w64(take)) {  // exec = take: no vector compare
+                                    uint32_t sw = ss[q >> 1];
+                                    asm volatile("" : "+v"(sw));  // (keeps the entry's arithmetic inside this branch: hipcc otherwise computes all eight queries' entries up front)
+                                    const uint32_t sq = (q & 1) ? sw >> 16 : sw & 0xffffu;
+                                    stage_w[(uint32_t)wn + rank] = ((unsigned long long)(((uint32_t)q << 15) | sq) << 32) | row;
+                                    atomicAdd(&hist[q][sq >> 7], 1u);
+                                }
+                                wn += n > room ? room : n;
+                                mq[q] = m & ~take;
+                                left |= mq[q] != 0;
                             }
+                            if (left || wn > SH_STAGE - 6) {
+                                if (!flush(moved)) {
+                                    raised = true;
+                                    fail_it = it;
+#pragma unroll
+                                    for (int q = 0; q < QT; ++q) fail_mq[q] = mq[q];
+                                    break;
+                                }
+                            }
+                            if (!left) break;
                         }
+                        if (redo && !raised) fail_it = 0xffffffffu;
+                        SH_CNT(1, 1); SH_CNT(2, SQA_NOW() - t_r0);
                     }
-                    if (failed_any) {  // a spill area is full: stop everyone, come back to this chunk after the reduction
-                        atomicOr(&ck.ctl, lane == 0 ? SH_STOP : 0u);
-                        raised = true;
-                        break;
-                    }
+                    if (raised) break;  // a spill area is full: everybody stops, this wave comes back to this chunk after the reduction
                     cur = nxt;
                     it = it_next;
                     it_next = after(it);
+                    SH_CNT(7, 1);
                     // scalar compare: somebody (this wave included) published a bound or asked for a stop -> next round
-                    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)ctl_now) != ctl_seen || moved) break;
+                    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)ep_now) != ep_seen || moved) break;
                 }
-                if (raised) break;
             }
-            if (it >= n_chunks && !counted) {
+            if (!raised && it >= n_chunks && wn) {  // out of rows: the rest of the staging area
+                bool mv = false;
+                raised = !flush(mv);
+            }
+            if (it >= n_chunks && wn == 0 && !counted) {
                 counted = true;
                 atomicAdd(&ck.done_waves, lane == 0 ? 1 : 0);
             }
             __syncthreads();  // (A) every wave is out of rows, or a stop is up
-            const bool stop = (ck.ctl & SH_STOP) != 0;
+            const bool stop = ck.stop != 0;
             const bool all_done = ck.done_waves == NW;
             if (!stop && all_done) break;  // workgroup-uniform
-            __syncthreads();  // (B) everybody has read ctl and done_waves
+            __syncthreads();  // (B) everybody has read stop and done_waves
             if (__builtin_expect(stop, 0)) {
+                SH_CNT(6, 1);
                 // mid-scan reduction: the tables make room for the selection buffers, every query keeps its k best exact
                 // entries (back at the head of its spill area), then the tables come back
                 if (wave < QT) {
@@ -496,16 +611,21 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
                         ck.thr_x[q] = nt;
                         reinterpret_cast<uint16_t *>(ck.thr_pk)[q] = (uint16_t)(nt < 32767u ? nt : 32767u);
                         const int qi = group * QT + q;
-                        if (a.gthr && qi < a.nq) atomicMin(&a.gthr[qi], nt);
+                        if (gthr && qi < a.nq) atomicMin(&gthr[qi], nt);
                     }
                 }
                 __syncthreads();
                 load_tables();
-                if (tid == 0) ck.ctl = (ck.ctl & ~SH_STOP) + 1u;
+                if (tid == 0) { ck.stop = 0; ck.epoch = ck.epoch + 1u; }
                 __syncthreads();
             }
         }
         SQ_T(2);  // look-ups + candidates
+#ifdef CVTMI_SCAN_TIMING
+        if (tid < QT) atomicAdd(&g_scanh_cnt[0], (unsigned long long)ck.cnt[tid]);
+        SH_CNT(5, 1);
+        SH_CNT_FLUSH();
+#endif
 
         // ---- the segment's k best: one selection per query, on the dead tables' space ----
         if (wave < QT) {
@@ -516,9 +636,10 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
             if (lane == 0) {
                 tk.cnt[q] = keep;
                 const int qi = group * QT + q;
-                if (a.gthr && qi < a.nq) {  // the exact k-th distance of this segment bounds the other segments' filters too
-                    const uint32_t t = tk.thr_x[q];
-                    if (t < 32767u) atomicMin(&a.gthr[qi], t);
+                if (gthr && qi < a.nq) {  // the other segments of the group start from this one's bound (integer or from its exact k-th distance)
+                    const uint32_t t = tk.thr_x[q], t0 = ck.thr_x[q];
+                    const uint32_t tm = t < t0 ? t : t0;
+                    if (tm < 32767u) atomicMin(&gthr[qi], tm);
                 }
             }
         }
@@ -529,17 +650,22 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
             const int qi = group * QT + q;
             if (qi >= a.nq) break;
             const int cnt = tk.cnt[q];
-            const int64_t o = ((int64_t)qi * a.stride + item.sidx) * a.k;
+            // a group scanned in one piece reports straight into the result arrays (the merge skips its queries)
+            const bool whole = item.nseg == 1 && a.stride > 1;
+            float *od = whole ? a.out_d : a.part_d;
+            int64_t *oi = whole ? a.out_id : a.part_id;
+            const int64_t o = whole ? (int64_t)qi * a.k : ((int64_t)qi * a.stride + item.sidx) * a.k;
             for (int i = tid; i < a.k; i += NT) {
                 if (i < cnt) {
                     const unsigned long long e = tk.buf[q][i];
-                    a.part_d[o + i] = __uint_as_float((uint32_t)(e >> 32));
-                    a.part_id[o + i] = a.id_base + (int64_t)(uint32_t)e;
+                    od[o + i] = __uint_as_float((uint32_t)(e >> 32));
+                    oi[o + i] = a.id_base + (int64_t)(uint32_t)e;
                 } else {
-                    a.part_d[o + i] = __uint_as_float(0x7f800000u);
-                    a.part_id[o + i] = -1;
+                    od[o + i] = __uint_as_float(0x7f800000u);
+                    oi[o + i] = -1;
                 }
             }
+            if (whole) continue;
             if (item.sidx == 0 && item.nseg < a.stride) {  // a group with fewer segments than the partial stride: the other slots stay empty
                 const int64_t o2 = ((int64_t)qi * a.stride + item.nseg) * a.k;
                 for (int i = tid; i < (a.stride - item.nseg) * a.k; i += NT) {
@@ -559,6 +685,8 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
 // ---------------------------------------------------------------------------------------------------------------------
 static int g_scanh_balance = 0;       // 0 = choose, 1 = equal shares of the flat (group x row) space, 2 = (group, split) blocks
 static int64_t g_scanh_min_rows = 16384;  // smallest share of a workgroup in the balanced plan
+static int g_scanh_tail = 0;              // (group, split) blocks: the groups of the last, partly filled round may be cut finer (measured: no gain, off)
+void set_scanh_tail(int v) { g_scanh_tail = v != 0; }
 void set_scanh_balance(int v) { g_scanh_balance = v; }
 void set_scanh_min_rows(int64_t v) { g_scanh_min_rows = v < 2048 ? 2048 : v; }
 
@@ -583,11 +711,15 @@ void scanh_plan(int64_t n_rows, int64_t nq, int splits, ScanHPlan &p)
     const int64_t groups = (nq + SQ_QT - 1) / SQ_QT;
     const int64_t slots = scanh_slots();
     p.items.clear();
+    p.multi.clear();
     p.grid = 0; p.rounds = 0; p.stride = 1;
     if (groups <= 0 || n_rows <= 0) return;
     const bool resident = n_rows * 16 <= (96LL << 20);  // the pre-rotated rows stay in the Infinity Cache (and mostly in L2)
-    const bool balanced = splits <= 0 && n_rows <= MAX_SEG && (g_scanh_balance == 1 || (g_scanh_balance == 0 && resident));
-    struct Seg { int64_t group, row0, rows; int wg; };
+    const bool balanced = splits <= 0 && n_rows <= MAX_SEG && (g_scanh_balance == 1 || (g_scanh_balance == 0 && resident && 2 * groups > slots && groups < slots));
+    // (planner's own choice: equal shares when S = 1 would fill the slots between half and whole -- 1 M rows x 2500 queries: 1.02-1.07 ms
+    //  against 1.24 for whole groups and 1.18 for adc_scan16q; with more groups than slots the shares cost an item more per workgroup
+    //  than blocks do and measured 2-10 % behind them, tools/sweep_scan_h.py)
+    struct Seg { int64_t group, row0, rows; int wg; int64_t chunk0; };
     std::vector<Seg> segs;
     if (balanced) {
         const int64_t tg = (n_rows + TILE - 1) / TILE, total = groups * tg;
@@ -600,13 +732,24 @@ void scanh_plan(int64_t n_rows, int64_t nq, int splits, ScanHPlan &p)
             else if (r != 0 && tg - r < MINT) b += tg - r;
             return b;
         };
+        // Shares of at least one group (the shape the planner itself picks: as many groups as slots, or more) are laid out in "row time":
+        // a workgroup that has worked through t tiles of its share is at tile t mod tg of whatever group it is in -- a whole group is walked
+        // from that phase on, wrapping around; a group cut by a share boundary gives its FIRST rows to the workgroup that starts with it
+        // (time 0) and its last rows to the one that ends with it.  So the workgroups of an XCD read the same rows at the same time.
+        const bool row_time = total / P >= tg;
         for (int64_t w = 0; w < P; ++w) {
-            int64_t u = bound(w);
-            const int64_t end = w + 1 == P ? total : bound(w + 1);
+            const int64_t begin = bound(w), end = w + 1 == P ? total : bound(w + 1);
+            int64_t u = begin;
             while (u < end) {
                 const int64_t g = u / tg, t0 = u - g * tg, t1 = std::min(tg, t0 + (end - u));
-                const int64_t r0 = t0 * TILE, r1 = std::min(n_rows, t1 * TILE);
-                if (r1 > r0) segs.push_back({ g, r0, r1 - r0, (int)w });
+                int64_t a = t0, b = t1, c0 = 0;
+                if (row_time) {
+                    if (t0 == 0 && t1 == tg) c0 = ((u - begin) % tg) * (TILE / 64);   // whole group: start at the share's row time
+                    else if (t0 > 0) { a = 0; b = t1 - t0; }                            // the group began in the previous share: its first rows
+                    else { a = tg - t1; b = tg; }                                       // the group goes on in the next share: its last rows
+                }
+                const int64_t r0 = a * TILE, r1 = std::min(n_rows, b * TILE);
+                if (r1 > r0) segs.push_back({ g, r0, r1 - r0, (int)w, c0 });
                 u += t1 - t0;
             }
         }
@@ -615,31 +758,67 @@ void scanh_plan(int64_t n_rows, int64_t nq, int splits, ScanHPlan &p)
         int64_t S = splits > 0 ? splits : 1;
         const int64_t min_splits = (n_rows + MAX_SEG - 1) / MAX_SEG;
         if (splits <= 0) {
-            // blocks of one round share their rows through L2 when a row split stays on one XCD (multiples of 8); enough of them
-            // to fill the slots, at least 16 K rows each
+            // blocks of one round share their rows through L2 when a row split stays on one XCD (split counts that divide 8, or multiples
+            // of 8).  Cost of a plan: rounds of `slots` items x (rows per item + what an item costs besides its rows: tables, seed, the
+            // candidates of its warm-up, the final selection -- measured at ~0.17 M row-equivalents, tools/sweep_scan_h.py); a last round
+            // that is at most half full counts 0.78 (a workgroup alone on its CU runs 1.27x faster).
+            const double fix = 170000.0;
+            const auto rounds_of = [&](int64_t blocks) {
+                const int64_t full = blocks / slots, last = blocks % slots;
+                if (!last) return (double)full;
+                const double f = (double)last / (double)slots;
+                return (double)full + (f <= 0.5 ? 0.78 : 0.78 + 0.44 * (f - 0.5));
+            };
+            double best_cost = 1e300;
             S = min_splits;
-            while (groups * S < slots && n_rows / (S * 2) >= 16384) S *= 2;
-            if (S > 1 && S < 8 && min_splits > 1) S = 8;
+            for (int64_t cand = min_splits; cand <= 64; ++cand) {
+                if (cand > min_splits && n_rows / cand < 16384) break;
+                double cost = rounds_of(groups * cand) * (fix + (double)n_rows / (double)cand);
+                if (cand % 8 == 0 || 8 % cand == 0) cost *= 0.97;
+                if (cost < best_cost * 0.99) { best_cost = cost; S = cand; }
+            }
         }
         if (S < min_splits) S = min_splits;
-        int64_t rps = (n_rows + S - 1) / S;
-        rps = ((rps + TILE - 1) / TILE) * TILE;
-        const int64_t blocks = groups * S;
-        const int64_t P = std::min<int64_t>(slots, blocks);
-        for (int64_t b = 0; b < blocks; ++b) {
-            int64_t split, group;
-            if ((S & 7) == 0) {
-                const int64_t s8 = S >> 3, xcd = b & 7, i = b >> 3;
-                split = xcd + 8 * (i % s8);
-                group = i / s8;
-            } else {
-                split = b % S;
-                group = b / S;
+        // blocks of `cnt` groups from group g0 on, each cut into Sx row splits, appended in the order a grid of blocks would run them
+        const auto add_blocks = [&](int64_t g0, int64_t cnt, int64_t Sx, int64_t first_slot, int64_t P) {
+            int64_t rps = (n_rows + Sx - 1) / Sx;
+            rps = ((rps + TILE - 1) / TILE) * TILE;
+            for (int64_t b = 0; b < cnt * Sx; ++b) {
+                int64_t split, group;
+                if ((Sx & 7) == 0) {
+                    const int64_t s8 = Sx >> 3, xcd = b & 7, i = b >> 3;
+                    split = xcd + 8 * (i % s8);
+                    group = i / s8;
+                } else {
+                    split = b % Sx;
+                    group = b / Sx;
+                }
+                const int64_t r0 = split * rps, r1 = std::min(n_rows, r0 + rps);
+                // (an empty split still reports: its slot of the partial lists must be written)
+                segs.push_back({ g0 + group, std::min(r0, n_rows), r1 > r0 ? r1 - r0 : 0, (int)((first_slot + b) % P), 0 });
             }
-            const int64_t r0 = split * rps, r1 = std::min(n_rows, r0 + rps);
-            // (an empty split still reports: its slot of the partial lists must be written)
-            segs.push_back({ group, std::min(r0, n_rows), r1 > r0 ? r1 - r0 : 0, (int)(b % P) });
+        };
+        const int64_t P = std::min<int64_t>(slots, groups * S);
+        // Two regions (planner's choice only, whole groups in the first): the groups that fill whole rounds of slots stay whole, those
+        // of the last, partly filled round are cut finer, so that every CU keeps two workgroups until the end instead of running the
+        // tail at half its look-up rate.  (adc_scan16q's planner has the same option and rarely takes it: there a split costs 0.38 M
+        // row-equivalents.)
+        int64_t ga = groups, Sb = S;
+        if (splits <= 0 && S == 1 && groups > slots && groups % slots != 0 && g_scanh_tail) {
+            const int64_t rem = groups % slots;
+            const double fix = 170000.0;
+            double best = 1e300;
+            for (int64_t cand = 1; cand <= 32 && n_rows / cand >= 16384; ++cand) {
+                const int64_t blocks = rem * cand;
+                const double rounds = (double)((blocks + slots - 1) / slots);
+                const double solo = blocks <= slots / 2 ? 0.78 : 1.0;   // one workgroup per CU runs 1.27x faster
+                const double cost = rounds * solo * (fix + (double)n_rows / (double)cand);
+                if (cost < best * 0.98) { best = cost; Sb = cand; }
+            }
+            if (Sb > 1) ga = groups - rem;
         }
+        add_blocks(0, ga, S, 0, P);
+        if (ga < groups) add_blocks(ga, groups - ga, Sb, ga * S, P);
         p.grid = (int)P;
     }
     // segment index inside its group (ascending rows = ascending ids: the merge's tie rule), segments per group
@@ -658,7 +837,7 @@ void scanh_plan(int64_t n_rows, int64_t nq, int splits, ScanHPlan &p)
     for (const Seg &s : segs) per_wg[(size_t)s.wg]++;
     int rounds = 0;
     for (int c : per_wg) rounds = std::max(rounds, c);
-    p.items.assign((size_t)rounds * p.grid, ScanItem{ 0, 0, 0, 0, 0 });
+    p.items.assign((size_t)rounds * p.grid, ScanItem{ 0, 0, 0, 0, 0, 0, 0 });
     std::fill(per_wg.begin(), per_wg.end(), 0);
     for (size_t i = 0; i < segs.size(); ++i) {
         const Seg &s = segs[i];
@@ -666,12 +845,16 @@ void scanh_plan(int64_t n_rows, int64_t nq, int splits, ScanHPlan &p)
         it.group = (int32_t)s.group;
         it.row0_64 = (uint32_t)(s.row0 / 64);
         it.rows = (uint32_t)s.rows;
+        it.chunk0 = (uint32_t)s.chunk0;
+        it.pad = 0;
         it.sidx = (uint16_t)sidx[i];
         it.nseg = (uint16_t)nseg[(size_t)s.group];
         p.items[(size_t)per_wg[(size_t)s.wg]++ * p.grid + s.wg] = it;
     }
     p.rounds = rounds;
     p.stride = stride;
+    p.multi.assign((size_t)nq, 0u);
+    for (int64_t qi = 0; qi < nq; ++qi) p.multi[(size_t)qi] = nseg[(size_t)(qi / SQ_QT)] > 1 ? 1u : 0u;
 }
 
 size_t scanh_spill_bytes(int grid) { return (size_t)grid * SQ_QT * SH_CAPG * sizeof(unsigned long long); }
@@ -680,7 +863,7 @@ size_t scanh_qp_bytes(int64_t nq) { return (size_t)((nq + SQ_QT - 1) / SQ_QT) * 
 
 int launch_adc_scan_h(const OpqModelDev &m, const uint8_t *codes, const uint8_t *codes_rot, int64_t n_rows, int64_t id_base,
                       const float *q_rot, int64_t nq, int k, const ScanHPlan &plan, const ScanItem *items_dev, float *part_d,
-                      int64_t *part_id, float *lut_g, void *qlut, void *qp_g, void *spill, uint32_t *gthr, int lazy, int seed,
+                      int64_t *part_id, float *out_d, int64_t *out_id, float *lut_g, void *qlut, void *qp_g, void *spill, uint32_t *gthr, int lazy, int seed,
                       hipStream_t st)
 {
     if (nq <= 0 || plan.grid <= 0) return CVTMI_OK;
@@ -699,7 +882,7 @@ int launch_adc_scan_h(const OpqModelDev &m, const uint8_t *codes, const uint8_t 
     a.qlut = reinterpret_cast<const uint4 *>(qlut); a.qp_g = reinterpret_cast<const QuantParams *>(qp_g); a.lut_g = lut_g;
     a.spill = reinterpret_cast<unsigned long long *>(spill);
     a.gthr = (gthr && plan.stride > 1) ? gthr : nullptr;
-    a.stride = plan.stride; a.part_d = part_d; a.part_id = part_id; a.seed = seed;
+    a.stride = plan.stride; a.part_d = part_d; a.part_id = part_id; a.out_d = out_d; a.out_id = out_id; a.seed = seed;
     if (codes_rot) hipLaunchKernelGGL((adc_scan16h_kernel<true>), dim3((unsigned)plan.grid), dim3(1024), 0, st, a);
     else hipLaunchKernelGGL((adc_scan16h_kernel<false>), dim3((unsigned)plan.grid), dim3(1024), 0, st, a);
     CVTMI_HIP(hipGetLastError());
@@ -723,7 +906,8 @@ extern "C" int64_t cvtmi_opq_scan_plan(int64_t n_rows, int64_t nq, int splits, i
     const int64_t n = (int64_t)p.items.size();
     for (int64_t i = 0; i < n && i < cap; ++i) {
         const ScanItem &it = p.items[(size_t)i];
-        items[5 * i + 0] = it.group; items[5 * i + 1] = it.row0_64; items[5 * i + 2] = it.rows; items[5 * i + 3] = it.sidx; items[5 * i + 4] = it.nseg;
+        items[6 * i + 0] = it.group; items[6 * i + 1] = it.row0_64; items[6 * i + 2] = it.rows; items[6 * i + 3] = it.sidx; items[6 * i + 4] = it.nseg;
+        items[6 * i + 5] = it.chunk0;
     }
     return n;
 }
@@ -736,6 +920,13 @@ extern "C" int cvtmi_debug_scanh_timing(unsigned long long *out, int reset)
     unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_dbg), sizeof z) != hipSuccess) return -3;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_scan_dbg), z, sizeof z) != hipSuccess) return -3;
+    return 0;
+}
+extern "C" int cvtmi_debug_scanh_counters(unsigned long long *out, int reset)
+{
+    unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scanh_cnt), sizeof z) != hipSuccess) return -3;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_scanh_cnt), z, sizeof z) != hipSuccess) return -3;
     return 0;
 }
 #endif

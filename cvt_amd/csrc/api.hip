@@ -76,7 +76,7 @@ struct cvtmi_opq_s {
     DevBuf io_q, io_d, io_i;   // device side of the host-pointer search (cvtmi_opq_search)
     PinBuf io_pin;             // its pinned staging area
     // tuning / measurement
-    int p_splits = 0, p_qtile = 0, p_profile = 0, p_variant = 3;
+    int p_splits = 0, p_qtile = 0, p_profile = 0, p_variant = 7;
     int p_encode = 0;  // 0 = choose, 1 = VALU encode, 2 = matrix-core filter + exact resolution
     int p_prerot = 1;  // adc_scan16q reads a pre-rotated copy of the code rows (+16 bytes of HBM per row)
     int p_tail = 1, p_groups_a = 0, p_splits_b = 0;  // two-region scan plan: on / forced shape (tests)
@@ -289,6 +289,11 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "scanh_balance")) {
         if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: scanh_balance must be 0, 1 or 2");
         set_scanh_balance((int)value);
+        ++g_scanh_key;
+        return CVTMI_OK;
+    }
+    if (!strcmp(name, "scanh_tail")) {
+        set_scanh_tail((int)value);
         ++g_scanh_key;
         return CVTMI_OK;
     }
@@ -674,10 +679,11 @@ static int opq_search_h(cvtmi_opq_t h, const float *q_rot, int64_t nq, int k, fl
 {
     if (h->hplan_n != h->n || h->hplan_nq != nq || h->hplan_splits != h->p_splits || h->hplan_key != g_scanh_key) {
         scanh_plan(h->n, nq, h->p_splits, h->hplan);
-        const size_t bytes = h->hplan.items.size() * sizeof(ScanItem);
-        CVTMI_TRY(h->s_items.reserve(std::max<size_t>(bytes, 16)));
-        // (pageable source: the runtime stages it before the call returns, so the vector may change afterwards)
+        const size_t bytes = h->hplan.items.size() * sizeof(ScanItem), mbytes = h->hplan.multi.size() * sizeof(uint32_t);
+        CVTMI_TRY(h->s_items.reserve(std::max<size_t>(bytes + mbytes, 16)));
+        // (pageable sources: the runtime stages them before the call returns, so the vectors may change afterwards)
         if (bytes) CVTMI_HIP(hipMemcpyAsync(h->s_items.p, h->hplan.items.data(), bytes, hipMemcpyHostToDevice, st));
+        if (mbytes) CVTMI_HIP(hipMemcpyAsync(h->s_items.as<char>() + bytes, h->hplan.multi.data(), mbytes, hipMemcpyHostToDevice, st));
         h->hplan_n = h->n; h->hplan_nq = nq; h->hplan_splits = h->p_splits; h->hplan_key = g_scanh_key;
     }
     const ScanHPlan &hp = h->hplan;
@@ -715,7 +721,7 @@ static int opq_search_h(cvtmi_opq_t h, const float *q_rot, int64_t nq, int k, fl
         if (!h->ev0[slot]) { CVTMI_HIP(hipEventCreate(&h->ev0[slot])); CVTMI_HIP(hipEventCreate(&h->ev1[slot])); }
         CVTMI_HIP(hipEventRecord(h->ev0[slot], st));
     }
-    CVTMI_TRY(launch_adc_scan_h(h->m, h->codes.as<uint8_t>(), codes_rot, h->n, h->id_base, q_rot, nq, k, hp, h->s_items.as<ScanItem>(), pd, pi,
+    CVTMI_TRY(launch_adc_scan_h(h->m, h->codes.as<uint8_t>(), codes_rot, h->n, h->id_base, q_rot, nq, k, hp, h->s_items.as<ScanItem>(), pd, pi, dist, ids,
                                 h->s_lut.as<float>(), h->s_qlut.p, h->s_qp.p, h->s_spill.p, gthr, h->p_lazy, scan_seed_enabled(), st));
     if (h->p_profile) {
         CVTMI_HIP(hipEventRecord(h->ev1[slot], st));
@@ -723,7 +729,9 @@ static int opq_search_h(cvtmi_opq_t h, const float *q_rot, int64_t nq, int k, fl
         h->last_bytes = ((nq + 7) / 8) * h->n * h->m.M;  // passes x rows x M code bytes
         h->last_qt = 8; h->last_splits = hp.stride;
     }
-    if (hp.stride > 1) CVTMI_TRY(launch_topk_merge(pd, pi, nq, hp.stride, k, dist, ids, st));
+    if (hp.stride > 1)  // (queries of groups scanned in one piece are already in place: the merge skips them)
+        CVTMI_TRY(launch_topk_merge(pd, pi, nq, hp.stride, k, dist, ids, st,
+                                    reinterpret_cast<const uint32_t *>(h->s_items.as<char>() + hp.items.size() * sizeof(ScanItem))));
     return CVTMI_OK;
 }
 
@@ -959,7 +967,7 @@ int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value)
         return CVTMI_OK;
     }
     if (!strcmp(name, "scan_variant")) {
-        if (value < 0 || value > 6) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: scan_variant must be 0..6");
+        if (value < 0 || value > 7) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: scan_variant must be 0..7");
         h->p_variant = (int)value;
         return CVTMI_OK;
     }

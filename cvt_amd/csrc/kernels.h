@@ -60,14 +60,18 @@ int launch_rotate_codes(const uint8_t *codes, uint8_t *codes_rot, int64_t row0, 
 
 // ---- adc_scan_h.hip: adc_scan16h (plan.variant == 6), a persistent grid walking a host-built item table ----
 // one item = one row segment of one query group: rows [64 * row0_64, 64 * row0_64 + rows) scanned for the group's 8 queries;
-// its k best go to partial list `sidx` of the group's `nseg` (ascending rows); nseg == 0 marks an unused table entry
+// its k best go to partial list `sidx` of the group's `nseg` (ascending rows); nseg == 0 marks an unused table entry.  The 64-row
+// chunks of the segment are walked from chunk `chunk0` on, wrapping around: the planner picks it so that the workgroups that are
+// busy at the same time are at the same rows (they share them through their XCD's L2)
 struct ScanItem {
     int32_t group;
-    uint32_t row0_64, rows;
+    uint32_t row0_64, rows, chunk0;
     uint16_t sidx, nseg;
+    uint32_t pad;
 };
 struct ScanHPlan {
     std::vector<ScanItem> items;  // [rounds][grid]
+    std::vector<uint32_t> multi;  // [nq]: 1 = the query's group was scanned in several segments (its partial lists need the merge)
     int grid = 0, rounds = 0, stride = 1;  // workgroups, items per workgroup, partial lists per query
 };
 void scanh_plan(int64_t n_rows, int64_t nq, int splits, ScanHPlan &p);
@@ -76,10 +80,11 @@ size_t scanh_qlut_bytes(int64_t nq);
 size_t scanh_qp_bytes(int64_t nq);
 void set_scanh_balance(int v);       // 0 = choose, 1 = equal shares of the flat (group x row) space, 2 = (group, split) blocks
 void set_scanh_min_rows(int64_t v);  // smallest share of a workgroup in the balanced plan
-// part_d / part_id: [nq][plan.stride][k]; lut_g: nq * 16 * 256 floats; qlut / qp_g / spill: scanh_*_bytes; gthr: nq words or null
+void set_scanh_tail(int v);          // 1 (default) = the groups of the last, partly filled round of blocks may be cut finer
+// part_d / part_id: [nq][plan.stride][k]; out_d / out_id: the final [nq][k] lists (groups scanned in one piece write there); lut_g: nq * 16 * 256 floats; qlut / qp_g / spill: scanh_*_bytes; gthr: nq words or null
 int launch_adc_scan_h(const OpqModelDev &m, const uint8_t *codes, const uint8_t *codes_rot, int64_t n_rows, int64_t id_base,
                       const float *q_rot, int64_t nq, int k, const ScanHPlan &plan, const ScanItem *items_dev, float *part_d,
-                      int64_t *part_id, float *lut_g, void *qlut, void *qp_g, void *spill, uint32_t *gthr, int lazy, int seed,
+                      int64_t *part_id, float *out_d, int64_t *out_id, float *lut_g, void *qlut, void *qp_g, void *spill, uint32_t *gthr, int lazy, int seed,
                       hipStream_t st);
 int scan_seed_enabled();
 

@@ -198,8 +198,9 @@ int cvtmi_opq_last_scan(cvtmi_opq_t h, float *ms, int64_t *code_bytes, int *qtil
 /* The item table "scan_variant" 6 would walk for n_rows code rows and nq queries (pure host logic: no device needed; the
  * number of workgroup slots is taken as 2 x `cus`, 0 = the current device's CU count or 256 without one).  splits > 0 forces
  * (query group, row split) blocks, 0 lets the planner choose (equal shares of the flat group x row space when the code matrix
- * is cache-resident).  items: up to cap entries of 5 ints {query group, first row / 64, rows, partial-list index inside the
- * group, partial lists of the group (0 = unused entry)}, item i of workgroup w at [i * grid + w].  Returns the number of
+ * is cache-resident and there are at least as many query groups as slots).  items: up to cap entries of 6 ints {query group, first
+ * row / 64, rows, partial-list index inside the group, partial lists of the group (0 = unused entry), first 64-row chunk of the
+ * wrap-around walk over the segment}, item i of workgroup w at [i * grid + w].  Returns the number of
  * entries (rounds * grid; nothing is written past cap) or a negative status. */
 int64_t cvtmi_opq_scan_plan(int64_t n_rows, int64_t nq, int splits, int cus, int64_t *items, int64_t cap, int *grid, int *rounds,
                             int *stride);
