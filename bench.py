@@ -48,6 +48,8 @@ I8_MFMA_PEAK_TOPS = 5033.0      # dense int8 matrix, spec (= the dense fp8 rate)
 I8_MFMA_MEASURED_TOPS = 3944.0  # the guide's measured ceiling of the int8 matrix instruction
 LDS_BYTES_PER_CLK_CU = 256.0
 N_CU, CLK_GHZ = 256, 2.4
+LDS_PEAK_TBS = LDS_BYTES_PER_CLK_CU * N_CU * CLK_GHZ / 1e3   # 157.3 TB/s: ds_read_b128 at the nominal clock, every CU
+LDS_MEASURED_TBS = 150.0        # the guide's aggregate with every CU streaming ds_read_b64/b128
 D, K = 128, 256
 
 
@@ -75,6 +77,8 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=-1,
                     help="threads of the all-cores CPU leg (-1 = all logical cores, 0 = skip)")
     ap.add_argument("--recall-sample", type=int, default=1000)
+    ap.add_argument("--ref-rows", type=int, default=200_000, help="rows of the index the reference itself builds for cpu_baseline (0 = skip)")
+    ap.add_argument("--ref-queries", type=int, default=64)
     ap.add_argument("--secondary", type=int, default=1,
                     help="N = 1: also measure rotation / encode / SQ8 / flat searches / config 5 (0 = skip)")
     return ap.parse_args()
@@ -187,11 +191,30 @@ class Ctx:
         return lambda qq: ix.search(qq, self.k, rotate=True)
 
 
-def scan_roofline(sc):
-    ach = sc["code_bytes"] / (sc["ms"] * 1e-3) / 1e9
-    return {"kernel_ms": round(sc["ms"], 4), "algorithmic_bytes_per_launch": sc["code_bytes"],
-            "achieved_GBps": round(ach, 1), "frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 4),
-            "queries_per_pass": sc["qtile"], "row_splits": sc["splits"]}
+def scan_roofline(sc, traffic=None):
+    """Roofline of one ADC-scan launch.  The kernel's bound is the LDS look-up rate (one 2-byte table entry per code byte and
+    query: 15-bit tables, 8 queries per 16-byte read): that is `achieved` / `peak` / `frac`, and no input can push it past 1.
+    SURVEY 8(d)'s algorithmic code bytes (passes x rows x M, 8 queries per pass) are kept as `algorithmic_hbm_equiv` -- an
+    equivalent rate, NOT HBM utilisation: the query groups of a row split read each row chunk through L2 / Infinity Cache, so one
+    HBM read of the codes serves `effective_queries_per_hbm_read` queries (algorithmic bytes x 8 / PMC bytes), far more than 8."""
+    sec = sc["ms"] * 1e-3
+    lookups = sc["code_bytes"] * sc["qtile"] / sec          # table look-ups per second
+    lds_tbs = lookups * 2.0 / 1e12
+    alg = sc["code_bytes"] / sec / 1e9
+    return {"bound": "lds", "achieved": round(lds_tbs, 2), "peak": round(LDS_PEAK_TBS, 1), "unit": "TB/s",
+            "frac": round(lds_tbs / LDS_PEAK_TBS, 4), "frac_of_measured_lds_peak": round(lds_tbs / LDS_MEASURED_TBS, 4),
+            "what": "table look-ups/s x 2 B per look-up against 256 B/clk/CU x 256 CU x 2.4 GHz (the guide measures ~150 TB/s)",
+            "lds_lookups_per_s_T": round(lookups / 1e12, 2), "kernel_ms": round(sc["ms"], 4),
+            "kernel_ms_what": "mean over the timed steps, HIP events on the launch stream inside the library (they bracket the "
+                              "launch: 1-2 % above the kernel's own duration)",
+            "queries_per_pass": sc["qtile"], "row_splits": sc["splits"],
+            "traffic": traffic,
+            "algorithmic_hbm_equiv": {
+                "bytes_per_launch": sc["code_bytes"], "achieved_GBps": round(alg, 1), "frac_of_hbm_peak": round(alg / HBM_PEAK_GBS, 4),
+                "effective_queries_per_hbm_read": (round(sc["code_bytes"] * sc["qtile"] / traffic, 1) if traffic else None),
+                "hbm_frac_measured": (round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+                "what": "SURVEY 8(d): passes x rows x M code bytes per launch / kernel time; may exceed the HBM peak because the "
+                        "passes share their reads on chip -- hbm_frac_measured (PMC bytes / kernel time / 8 TB/s) is what HBM sees"}}
 
 
 def run_sift1b(ctx, q, steps, warmup):
@@ -216,7 +239,8 @@ def run_sift1b(ctx, q, steps, warmup):
     sc = big.last_scan()
     res = {"value": round(ql.shape[0] * steps / el, 1), "unit": "queries/s", "ms_per_step": round(el / steps * 1e3, 4),
            "steps": steps, "rows_total": args.large_rows, "rows_per_gpu": l1 - l0, "nq": int(ql.shape[0]), "k": ctx.k,
-           "n_gpus": ctx.world, "scan": scan_roofline(sc), "index_build_s_this_rank": round(t_build, 2),
+           "n_gpus": ctx.world, "scan": scan_roofline(sc, _pmc_traffic_large(args, l1 - l0, int(ql.shape[0]), ctx.k)),
+           "index_build_s_this_rank": round(t_build, 2),
            "encode_rows_per_s_this_rank": round(enc_rows / enc_t, 1) if enc_t > 0 else None,
            "data": ("synthetic SIFT-shaped rows generated, rotated and PQ-encoded on device"
                     if args.large_data == "sift" else "uniform random code bytes"),
@@ -239,7 +263,7 @@ def _pmc_traffic(args, nq, k, M):
                      and not args.splits and args.variant < 0)
     if not default_shape:
         return None, None
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         p = os.path.join(ROOT, "profiles", "%s_scan_traffic.json" % tag)
         if os.path.exists(p):
             try:
@@ -249,6 +273,20 @@ def _pmc_traffic(args, nq, k, M):
             except Exception:
                 pass
     return None, None
+
+
+def _pmc_traffic_large(args, rows, nq, k):
+    """the same for the HBM-resident shard shape the round's profile covers (128 M rows x 2048 queries), else null"""
+    for tag in ("r04", "r03", "r02"):
+        p = os.path.join(ROOT, "profiles", "%s_scan_traffic_128m.json" % tag)
+        if os.path.exists(p):
+            try:
+                d = json.load(open(p))
+                if d.get("rows") == rows and d.get("nq") == nq and k == 100:
+                    return d.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+    return None
 
 
 def headline_n1(ctx, q):
@@ -261,29 +299,11 @@ def headline_n1(ctx, q):
     ctx.barrier(); idx.last_scan()  # drop the warm-up launches from the kernel-time statistics
     elapsed, out = ctx.timed(lambda: fn(q), args.steps, 0)
     scan = idx.last_scan()  # mean HIP-event duration of the scan kernel over the timed steps
-    rf = scan_roofline(scan)
-    lookups = scan["code_bytes"] * scan["qtile"] / (scan["ms"] * 1e-3)  # one table look-up per code byte and query
-    lds_bytes = lookups * 2.0  # 2 bytes of LDS read per look-up (15-bit tables, 8 queries per 16-byte read)
-    lds_peak = LDS_BYTES_PER_CLK_CU * N_CU * CLK_GHZ * 1e9
     traffic, traffic_src = _pmc_traffic(args, nq, k, M)
     name = "SIFT-1M" if args.rows == 1_000_000 else "%d synthetic rows" % args.rows
-    roof = {"bound": "hbm", "kernel": "adc_scan kernel (M=%d, %d queries per pass)" % (M, scan["qtile"]),
-            "achieved": rf["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rf["frac_of_hbm_peak"],
-            "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": scan["code_bytes"], "kernel_ms": rf["kernel_ms"],
-            "kernel_ms_what": "HIP events on the launch stream inside the library: brackets the launch, reads 1-2 % "
-                              "above the "
-                              "kernel's own duration",
-            "hbm_frac_measured": (round(traffic / (scan["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
-            "hbm_frac_measured_what": "PMC bytes per launch (committed profile) / this run's kernel time / 8 TB/s: the "
-                                      "fraction of HBM peak the kernel really draws -- `frac` is the ALGORITHMIC rate",
-            "operative_bound": "lds+valu",
-            "operative_note": "the kernel is bound by its LDS table look-ups at every size: the query groups of a row "
-                              "split share each row chunk through L2 / Infinity Cache, so HBM-side traffic (PMC) is a "
-                              "fraction of the algorithmic bytes; `achieved` is the algorithmic rate SURVEY 8(d) "
-                              "prescribes",
-            "lds_lookups_per_s": round(lookups / 1e12, 2), "lds_frac": round(lds_bytes / lds_peak, 4),
-            "lds_frac_what": "table look-ups/s x 2 B per look-up / (256 B/clk/CU x 256 CU x 2.4 GHz)"}
+    roof = scan_roofline(scan, traffic)
+    roof["kernel"] = "adc_scan kernel (M=%d, %d queries per pass)" % (M, scan["qtile"])
+    roof["traffic_source"] = traffic_src
     result = {
         "metric": "queries/sec, OPQ-ADC top-%d over 128-d %s" % (k, name),
         "value": round(nq * args.steps / elapsed, 1), "unit": "queries/s", "n_gpus": 1, "steps": args.steps,
@@ -362,13 +382,7 @@ def headline_multi(ctx, q):
                                   "top-%d + "
                                   "merge on every rank" % (world, k),
                    "n1_point_of_this_curve": "the N = 1 line's 'sift1b'.value (same rows, same queries, one GPU)"},
-        "roofline": {"bound": "hbm",
-                     "kernel": "adc_scan kernel (M=%d, %d queries per pass), rank 0's shard" % (M,
-                                                                                                rf["queries_per_pass"]),
-                     "achieved": rf["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": rf["frac_of_hbm_peak"],
-                     "traffic": None, "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"],
-                     "kernel_ms": rf["kernel_ms"]},
+        "roofline": dict(rf, kernel="adc_scan kernel (M=%d, %d queries per pass), rank 0's shard" % (M, rf["queries_per_pass"])),
         "sift1b": res,
     }
     result.update(extra)
@@ -407,7 +421,7 @@ def cpu_baseline_opq(ctx, idx, q, out, result):
     t0 = time.perf_counter()
     od, oi = orc.adc_search(q_rot, ctx.books, codes_h, k)
     t_cpu = time.perf_counter() - t0
-    result["cpu_baseline"] = {
+    result["cpu_baseline_port"] = {
         "value": round(cs / t_cpu, 2), "unit": "queries/s", "cores": 1, "kind": "port",
         "sample": "%d of the %d queries against the full %d-row code matrix, LUT + scan + top-%d (oracle/cvt_oracle.c "
                   "-O3, 1 thread); host: %s" % (cs, nq, args.rows, k, _cpu_model()),
@@ -434,6 +448,36 @@ def cpu_baseline_opq(ctx, idx, q, out, result):
         "gpu_topk_ids_identical": bool(np.array_equal(oi_mt, i_gpu[:qs_mt].cpu().numpy()))}
 
 
+def cpu_baseline_reference(ctx, q, result):
+    """the reference's OWN code (opq/src/IVFOPQ.cpp compiled in place: oracle/_ref/libref_opq.so) on a bounded sample: IndexDatabase
+    over one feature file of --ref-rows rows (Add: coarse argmin + PQ encode, IVFOPQ.cpp:105-170), then QueryThrehold
+    (:322-422: tables + the scan over its 56-byte IVFelem entries + the per-video minimum) for --ref-queries queries.  One file =
+    one video, so the call returns the minimum score per query -- clamped at 1.0 by the reference (:5, :262) and therefore not
+    comparable with the unclamped top-k here: this leg is the timing, the identity check is the port's (cpu_baseline_port)."""
+    from oracle import binding as ob
+    args = ctx.args
+    if not ob.ref_available() or args.ref_rows <= 0:
+        result["cpu_baseline"] = dict(result["cpu_baseline_port"], note="oracle/_ref/libref_opq.so not built: the port stands in")
+        return
+    rows_s, nqs = min(args.rows, args.ref_rows), min(ctx.nq, args.ref_queries)
+    x = ctx.synth.sift_like(rows_s, D, seed=0xC0FFEE, device=ctx.dev).cpu().numpy()
+    ref = ob.RefOPQ(ctx.zero_coarse, ctx.books, np.arange(D, dtype=np.int32), max_index_num=max(rows_s, 1) + 16)
+    try:
+        t0 = time.perf_counter(); ref.index([x]); t_index = time.perf_counter() - t0
+        t0 = time.perf_counter(); ms = ref.query(q[:nqs].cpu().numpy(), 1, 1); t_q = time.perf_counter() - t0
+    finally:
+        ref.close()
+    result["cpu_baseline"] = {
+        "value": round(nqs / t_q * rows_s / args.rows, 2), "unit": "queries/s", "cores": 1, "kind": "reference",
+        "sample": "the reference's IVFOPQ::QueryThrehold, %d queries over a %d-row index it built itself from one feature file "
+                  "(IndexDatabase), %.2f s; value = queries/s x %d / %d rows (its scan is linear in the rows); host: %s" % (
+                      nqs, rows_s, t_q, rows_s, args.rows, _cpu_model()),
+        "queries_per_s_on_the_sample": round(nqs / t_q, 2),
+        "reference_index_build_rows_per_s": round(rows_s / t_index, 1),
+        "min_score_clamped_at_1": bool(np.all(ms == 1.0)),
+        "identity_check": "cpu_baseline_port (same arithmetic restated, unclamped): gpu_topk_ids_identical / gpu_distances_bit_identical"}
+
+
 def main():
     args = parse_args()
     ctx = Ctx(args)
@@ -457,6 +501,7 @@ def main():
         recall_at_1(ctx, q, out[1], result)
         if args.cpu_sample > 0:
             cpu_baseline_opq(ctx, idx, q, out, result)
+            cpu_baseline_reference(ctx, q, result)
         idx.close()
         if args.secondary:
             try:

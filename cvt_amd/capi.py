@@ -214,12 +214,12 @@ class OpqIndex:
             import torch
             d = torch.empty((nq, k), dtype=torch.float32, device=q.device)
             i = torch.empty((nq, k), dtype=torch.int64, device=q.device)
-            _check(lib().cvtmi_opq_search_sharded_dev(self.h, comm.h, _ptr(q), C.c_int64(nq), C.c_int(1 if rotate else 0),
+            comm.check(lib().cvtmi_opq_search_sharded_dev(self.h, comm.h, _ptr(q), C.c_int64(nq), C.c_int(1 if rotate else 0),
                                                       C.c_int(k), _ptr(d), _ptr(i), _stream()))
             return d, i
         q = _np(q, np.float32)
         d = np.empty((nq, k), dtype=np.float32); i = np.empty((nq, k), dtype=np.int64)
-        _check(lib().cvtmi_opq_search_sharded(self.h, comm.h, _ptr(q), C.c_int64(nq), C.c_int(1 if rotate else 0), C.c_int(k),
+        comm.check(lib().cvtmi_opq_search_sharded(self.h, comm.h, _ptr(q), C.c_int64(nq), C.c_int(1 if rotate else 0), C.c_int(k),
                                               _ptr(d), _ptr(i)))
         return d, i
 
@@ -291,10 +291,32 @@ class Comm:
         """fn(send_ptr, recv_ptr, nbytes, stream_ptr) -> 0: gather nbytes from every rank into recv (device pointers)."""
         self = cls.__new__(cls)
         self.h = C.c_void_p(0)
-        self._cb = _ALLGATHER_FN(lambda ctx, s, r, nb, st: int(fn(s, r, nb, st) or 0))
+        self._cb_error = None
+
+        def guarded(ctx, s, r, nb, st):
+            # an exception must not escape a ctypes callback: ctypes would print it and return 0, and the library would merge
+            # whatever the gather buffer held (stale lists included) as if the all-gather had happened
+            try:
+                return int(fn(s, r, nb, st) or 0)
+            except BaseException as e:  # noqa: B902 -- KeyboardInterrupt included: re-raised by the caller below
+                self._cb_error = e
+                return -1
+
+        self._cb = _ALLGATHER_FN(guarded)
         _check(lib().cvtmi_comm_create_custom(self._cb, None, C.c_int(rank), C.c_int(world), C.byref(self.h)))
         self.rank, self.world = rank, world
         return self
+
+    def check(self, rc):
+        """_check for calls that may run a caller-supplied all-gather: when that callback raised, the call failed with
+        CVTMI_ECOMM -- the callback's own exception is what the caller gets (chained to the library's error)"""
+        try:
+            _check(rc)
+        except CvtmiError as err:
+            e, self._cb_error = getattr(self, "_cb_error", None), None
+            if e is not None:
+                raise e from err
+            raise
 
     @classmethod
     def over_torch_group(cls, rank, world, group=None):
@@ -355,7 +377,7 @@ class Comm:
         nq = d.shape[0]
         od = torch.empty((nq, k), dtype=torch.float32, device=d.device)
         oi = torch.empty((nq, k), dtype=torch.int64, device=d.device)
-        _check(lib().cvtmi_shard_merge_topk_dev(self.h, _ptr(d.contiguous()), _ptr(i.contiguous()), C.c_int64(nq), C.c_int(k),
+        self.check(lib().cvtmi_shard_merge_topk_dev(self.h, _ptr(d.contiguous()), _ptr(i.contiguous()), C.c_int64(nq), C.c_int(k),
                                                 _ptr(od), _ptr(oi), _stream()))
         return od, oi
 
@@ -483,12 +505,12 @@ class FlatIndex:
             import torch
             d = torch.empty((nq, k), dtype=torch.int32 if self.metric == 2 else torch.float32, device=q.device)
             i = torch.empty((nq, k), dtype=torch.int64, device=q.device)
-            _check(lib().cvtmi_flat_search_sharded_dev(self.h, comm.h, _ptr(q), C.c_int64(nq), C.c_int(k), _ptr(d), _ptr(i), _stream()))
+            comm.check(lib().cvtmi_flat_search_sharded_dev(self.h, comm.h, _ptr(q), C.c_int64(nq), C.c_int(k), _ptr(d), _ptr(i), _stream()))
             return d, i
         q = _np(q, self._dt())
         d = np.empty((nq, k), dtype=np.int32 if self.metric == 2 else np.float32)
         i = np.empty((nq, k), dtype=np.int64)
-        _check(lib().cvtmi_flat_search_sharded(self.h, comm.h, _ptr(q), C.c_int64(nq), C.c_int(k), _ptr(d), _ptr(i)))
+        comm.check(lib().cvtmi_flat_search_sharded(self.h, comm.h, _ptr(q), C.c_int64(nq), C.c_int(k), _ptr(d), _ptr(i)))
         return d, i
 
     def last_search(self):

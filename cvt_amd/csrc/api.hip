@@ -202,14 +202,14 @@ static int use_device(int dev)
     CHECK_H(h); \
     Serial serial_##h((h)->sync, (hipStream_t)(stream))
 
-static int g_scanh_key = 0;  // bumped when a planner setting of adc_scan16h changes: cached item tables are rebuilt
-static int g_inject_failure = -1;  // cvtmi_set_tuning("comm_inject_failure", r): the local search of rank r of a sharded search fails (tests)
-static int g_flat_variant = 0;  // cvtmi_set_tuning("flat_variant"): 0 = choose, 1 = exact kernels only, 2 = matrix-core filter wherever it applies
-static int g_flat_f32_stream = 1;  // cvtmi_set_tuning("flat_f32_stream"): 0 = off, 1 = choose, 2 = wherever it applies
+static std::atomic<int> g_scanh_key{0};  // bumped when a planner setting of adc_scan16h changes: cached item tables are rebuilt
+static std::atomic<int> g_inject_failure{-1};  // cvtmi_set_tuning("comm_inject_failure", r): the local search of rank r of a sharded search fails (tests)
+static std::atomic<int> g_flat_variant{0};  // cvtmi_set_tuning("flat_variant"): 0 = choose, 1 = exact kernels only, 2 = matrix-core filter wherever it applies
+static std::atomic<int> g_flat_f32_stream{1};  // cvtmi_set_tuning("flat_f32_stream"): 0 = off, 1 = choose, 2 = wherever it applies
 
 static int sharded_local_failure(cvtmi_comm_t c)
 {
-    if (g_inject_failure >= 0 && g_inject_failure == comm_rank(c)) return fail(CVTMI_ESTATE, "injected failure of rank %d (comm_inject_failure)", comm_rank(c));
+    if (const int inj = g_inject_failure.load(); inj >= 0 && inj == comm_rank(c)) return fail(CVTMI_ESTATE, "injected failure of rank %d (comm_inject_failure)", comm_rank(c));
     return CVTMI_OK;
 }
 
@@ -1390,8 +1390,15 @@ static int flat_search_filtered_u8(cvtmi_flat_t h, FlatScratch &S, const uint8_t
 
 // which of the pipelines a search of nq queries takes (the dispatch rules, in one place: flat_prepare builds what they need)
 struct FlatRoute { bool stream, filt_f32, filt_u8; };
-static FlatRoute flat_route(const cvtmi_flat_s *h, const void *q, int64_t nq, int k)
+// the tuning values a search dispatches on, read ONCE per call: flat_prepare and flat_search_leased must see the same route even if
+// another thread calls cvtmi_set_tuning between the two
+struct FlatTuning {
+    int variant, f32_stream;
+    static FlatTuning now() { return { g_flat_variant.load(), g_flat_f32_stream.load() }; }
+};
+static FlatRoute flat_route(const cvtmi_flat_s *h, const void *q, int64_t nq, int k, const FlatTuning &tun)
 {
+    const int g_flat_variant = tun.variant, g_flat_f32_stream = tun.f32_stream;  // (this call's snapshot shadows the globals)
     FlatRoute r = { false, false, false };
     const bool aligned = ((uintptr_t)q & 15) == 0;
     // fp32: one stream over the rows (flat_f32_stream.hip).  flat_variant 2 asks for the older sample + filter pipeline, 1 for the exact kernels
@@ -1414,14 +1421,14 @@ static FlatRoute flat_route(const cvtmi_flat_s *h, const void *q, int64_t nq, in
 // The lazily built parts of the index a route needs -- the host copy of the row statistics (fp32 stream), the operand copies of
 // the filter pipelines -- are built under the EXCLUSIVE lock, once per index state, and the stream is drained before the lock
 // is given back.  Called before the search takes its shared lock.
-static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStream_t st)
+static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStream_t st, const FlatTuning &tun)
 {
     for (int attempt = 0; attempt < 2; ++attempt) {
         FlatRoute r;
         bool need_fs, need_f32, need_u8;
         {
             std::shared_lock<std::shared_timed_mutex> rd(h->rw);
-            r = flat_route(h, q, nq, k);
+            r = flat_route(h, q, nq, k, tun);
             need_fs = r.stream && h->fs_stats_n != h->n;
             need_f32 = r.filt_f32 && h->f_pack_n != h->n && !(r.stream && !need_fs && !h->fs_nonfinite);   // (the stream answers: no copy needed)
             need_u8 = r.filt_u8 && h->f_pack_n != h->n;
@@ -1461,13 +1468,14 @@ static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStr
 }
 
 // the search proper, on a leased scratch set, under the shared lock
-static int flat_search_leased(cvtmi_flat_t h, FlatScratch &S, const void *q, int64_t nq, int k, void *dist, int64_t *labels, hipStream_t st)
+static int flat_search_leased(cvtmi_flat_t h, FlatScratch &S, const void *q, int64_t nq, int k, void *dist, int64_t *labels, hipStream_t st,
+                              const FlatTuning &tun)
 {
     bool done = false;
     long long worst0 = 0;
     h->f_last_worst = worst0;
     int how = 0;
-    const FlatRoute r = flat_route(h, q, nq, k);
+    const FlatRoute r = flat_route(h, q, nq, k, tun);
     if (r.stream) {
         CVTMI_TRY(flat_search_streamed(h, S, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
         if (done) how = 2;
@@ -1490,11 +1498,12 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search: k=%d outside 1..128", k);
     if (nq == 0) return CVTMI_OK;
     hipStream_t st = (hipStream_t)stream;
-    CVTMI_TRY(flat_prepare(h, q, nq, k, st));
+    const FlatTuning tun = FlatTuning::now();
+    CVTMI_TRY(flat_prepare(h, q, nq, k, st, tun));
     std::shared_lock<std::shared_timed_mutex> rd(h->rw);
     FlatLease lease;
     CVTMI_TRY(lease.open(h, st, false));
-    return flat_search_leased(h, *lease.s, q, nq, k, dist, labels, st);
+    return flat_search_leased(h, *lease.s, q, nq, k, dist, labels, st, tun);
 }
 
 int cvtmi_flat_set_id_base(cvtmi_flat_t h, int64_t base)
@@ -1578,7 +1587,8 @@ int cvtmi_flat_search(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *di
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search: k=%d outside 1..128", k);
     if (nq == 0) return CVTMI_OK;
     alignas(16) static const char aligned_probe[16] = {};
-    CVTMI_TRY(flat_prepare(h, aligned_probe, nq, k, nullptr));   // (the staged queries are 16-byte aligned)
+    const FlatTuning tun = FlatTuning::now();
+    CVTMI_TRY(flat_prepare(h, aligned_probe, nq, k, nullptr, tun));   // (the staged queries are 16-byte aligned)
     std::shared_lock<std::shared_timed_mutex> rd(h->rw);
     FlatLease lease;
     CVTMI_TRY(lease.open(h, nullptr, true));
@@ -1588,7 +1598,7 @@ int cvtmi_flat_search(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *di
     CVTMI_TRY(S.io_d.reserve((size_t)nq * k * 4));
     CVTMI_TRY(S.io_i.reserve((size_t)nq * k * 8));
     CVTMI_HIP(hipMemcpyAsync(S.io_q.p, q, (size_t)nq * h->row_bytes, hipMemcpyHostToDevice, st));
-    CVTMI_TRY(flat_search_leased(h, S, S.io_q.p, nq, k, S.io_d.p, S.io_i.as<int64_t>(), st));
+    CVTMI_TRY(flat_search_leased(h, S, S.io_q.p, nq, k, S.io_d.p, S.io_i.as<int64_t>(), st, tun));
     CVTMI_HIP(hipMemcpyAsync(dist, S.io_d.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
     CVTMI_HIP(hipMemcpyAsync(labels, S.io_i.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
     CVTMI_HIP(hipStreamSynchronize(st));

@@ -30,6 +30,8 @@
 #include <algorithm>
 #include <type_traits>
 
+#include <atomic>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -941,14 +943,14 @@ static int fs_qb_max(int nch)
     while (qb > 1 && qb * (8 * nch + 48) > 368) --qb;
     return qb;
 }
-static int g_fs_dbgflags = 0;     // timing experiments (results wrong when non-zero): cvtmi_set_tuning("flat_f32_dbg")
+static std::atomic<int> g_fs_dbgflags{0};     // timing experiments (results wrong when non-zero): cvtmi_set_tuning("flat_f32_dbg")
 void set_flat_f32_dbg(int v) { g_fs_dbgflags = v; }
-static int g_fs_nt = 1;      // cvtmi_set_tuning("flat_f32_nt"): 0 = never, 1 = choose, 2 = always
+static std::atomic<int> g_fs_nt{1};      // cvtmi_set_tuning("flat_f32_nt"): 0 = never, 1 = choose, 2 = always
 void set_flat_f32_nt(int v) { g_fs_nt = v; }
 // non-temporal row loads: measured better wherever the stream kernel is bound by the rows (one query 0.119 -> 0.106 ms,
 // 64 queries 0.147 -> 0.14, the shared ring 1.09 -> 1.07 at 1000), worse at three query blocks per wave (0.155 -> 0.165)
 static bool fs_nt(bool shared, int qb) { return g_fs_nt == 2 || (g_fs_nt == 1 && (shared || qb <= 2)); }
-static int g_fs_share = 0;   // cvtmi_set_tuning("flat_f32_share"): 0 = choose, 1 = four waves x 32 QB queries, 2 = FS_MANY waves x 32 queries
+static std::atomic<int> g_fs_share{0};   // cvtmi_set_tuning("flat_f32_share"): 0 = choose, 1 = four waves x 32 QB queries, 2 = FS_MANY waves x 32 queries
 void set_flat_f32_share(int v) { g_fs_share = v; }
 // the shared-ring kernel wants whole K steps per wave: D / 16 a multiple of the wave count
 constexpr int FS_MANY = 12;   // waves of the many-wave form of the shared-ring kernel (three per SIMD)
@@ -1002,13 +1004,13 @@ int launch_flat_f32_bias(float *X, int D, int metric, int64_t row0, int64_t row1
 struct FsStreamArgs {
     const float *X, *bias; int64_t n_tiles; const float *q; int nq, G, NG; float2 *gb; float *wm; uint32_t *redo, *cnt;
 };
-static int fs_set_lds(const void *fn, size_t lds, bool (&done)[16])
+static int fs_set_lds(const void *fn, size_t lds, std::atomic<bool> (&done)[16])
 {
     int dev = 0;
     CVTMI_HIP(hipGetDevice(&dev));
-    if (dev >= 16 || !done[dev]) {   // the attribute is per device
+    if (dev >= 16 || !done[dev].load(std::memory_order_acquire)) {   // the attribute is per device (several host threads may search at once: setting it twice is harmless)
         CVTMI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (dev < 16) done[dev] = true;
+        if (dev < 16) done[dev].store(true, std::memory_order_release);
     }
     return CVTMI_OK;
 }
@@ -1016,7 +1018,7 @@ template <int NCH>
 static int fs_launch_eight(const FsStreamArgs &a, hipStream_t st)
 {
     if constexpr (NCH == 4 || NCH == 8) {
-        static bool attr_set[16] = {};
+        static std::atomic<bool> attr_set[16] = {};
         const size_t lds = FssGeom<NCH, NCH>::LDS;
         CVTMI_TRY(fs_set_lds((const void *)flat_f32_mshare_kernel<NCH, 1, FS_MANY, NCH>, lds, attr_set));
         hipLaunchKernelGGL((flat_f32_mshare_kernel<NCH, 1, FS_MANY, NCH>), dim3(FSS_STREAMS), dim3(64 * FS_MANY), lds, st, a.X, a.bias, a.n_tiles, a.q,
@@ -1030,7 +1032,7 @@ static int fs_launch_eight(const FsStreamArgs &a, hipStream_t st)
 template <int NCH, int QB, bool SHARED>
 static int fs_launch_stream(const FsStreamArgs &a, hipStream_t st)
 {
-    static bool attr_set[16] = {};
+    static std::atomic<bool> attr_set[16] = {};
     if constexpr (SHARED && NCH % 4 != 0) {
         return fail(CVTMI_EINVAL, "flat_f32_stream: shared ring at D=%d", 16 * NCH);
     } else if constexpr (SHARED) {

@@ -171,7 +171,11 @@ int comm_local_slot(cvtmi_comm_t c, int64_t nq, int k, float **dist, int64_t **i
     return CVTMI_OK;
 }
 
-// the status word of this rank's slot (enqueued); the slot exists afterwards even if comm_local_slot never ran
+// the status word of this rank's slot (enqueued); the slot exists afterwards even if comm_local_slot never ran.
+// The ONE failure that cannot travel through the collective is this rank running out of device memory for the gather buffer
+// itself (world x slot bytes): there is nothing to all-gather into, the call returns CVTMI_ENOMEM before the collective and the
+// peers stay inside theirs (RCCL has no time-out).  cvtmi_comm_reserve takes that allocation out of the search path: call it
+// once per communicator with the largest (nq, k) it will see, at a point where a failure can still be reported out of band.
 static int comm_post_status(cvtmi_comm_t c, int64_t nq, int k, int status, hipStream_t st)
 {
     const size_t slot = comm_slot_bytes(nq, k);
@@ -241,6 +245,13 @@ int comm_exchange_merge_all(cvtmi_comm_t *comms, int ndev, int64_t nq, int k, co
     const size_t slot = comm_slot_bytes(nq, k);
     RcclApi *api = nullptr;
     CVTMI_TRY(rccl_ready(&api));
+    // every device is driven by this process: the local statuses are all here, on the host.  A failed local search fails the call
+    // before any collective is issued (nobody else could be left waiting), whatever "comm_check_status" says -- the read-back
+    // below only looks at comms[0]'s copy, and with it switched off a failure on device d > 0 would merge that device's stale slot.
+    for (int d = 0; d < ndev; ++d)
+        if (status[d] != CVTMI_OK)
+            return fail(CVTMI_ECOMM, "row-sharded search: the local search on device %d (rank %d) failed with %d: %s", comms[d] ? comms[d]->device : -1, d,
+                        status[d], std::string(cvtmi_last_error()).c_str());
     for (int d = 0; d < ndev; ++d) {
         CVTMI_TRY(comm_check(comms[d]));
         CVTMI_TRY(comm_post_status(comms[d], nq, k, status[d], nullptr));
@@ -268,6 +279,15 @@ int comm_exchange_merge_all(cvtmi_comm_t *comms, int ndev, int64_t nq, int k, co
 }  // namespace cvtmi
 
 extern "C" {
+
+int cvtmi_comm_reserve(cvtmi_comm_t c, int64_t nq, int k)
+{
+    CVTMI_TRY(comm_validate(c));
+    if (nq < 0 || k < 1) return fail(CVTMI_EINVAL, "cvtmi_comm_reserve: bad arguments");
+    Serial serial(*comm_sync(c), nullptr);
+    CVTMI_TRY(comm_check(c));
+    return c->gather.reserve(std::max<size_t>(comm_slot_bytes(nq, k) * c->world, 16));
+}
 
 int cvtmi_comm_unique_id(void *id)
 {

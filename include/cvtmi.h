@@ -254,6 +254,12 @@ int cvtmi_comm_info(cvtmi_comm_t c, int *rank, int *world, int *transport, int64
 /* Bytes one rank contributes to the all-gather of an [nq][k] result (status word + fp32 + int64 fields, 16-byte aligned): the
  * size a caller-supplied transport has to stage per rank. */
 int cvtmi_comm_slot_bytes(int64_t nq, int k, size_t *bytes);
+/* Allocates the communicator's gather buffer (world x slot bytes) for results of up to [nq][k] ahead of the searches.  A sharded
+ * search whose LOCAL part fails still enters the all-gather and fails on every rank (the status word travels in the slot); the one
+ * failure that cannot be signalled that way is running out of device memory for this buffer inside a search -- the rank returns
+ * CVTMI_ENOMEM before the collective and its peers wait in theirs.  Reserving up front moves that failure to a point where the
+ * caller can still tell the other ranks. */
+int cvtmi_comm_reserve(cvtmi_comm_t c, int64_t nq, int k);
 /* Row block of `rank`: [begin, end) of n_total rows, the first n_total % world ranks own one row more. */
 int cvtmi_shard_range(int64_t n_total, int rank, int world, int64_t *begin, int64_t *end);
 /* cvtmi_opq_search on a row shard: `h` holds this rank's block of rows (cvtmi_opq_set_id_base = its first row), every
