@@ -329,11 +329,26 @@ def headline_n1(ctx, q):
     for _ in range(reps):
         idx.search(qh, k, rotate=True, out=out_h)
     el_h = (time.perf_counter() - t0) / reps
-    what = ("cvtmi_opq_search with host buffers: %.1f MB of queries in, %.1f MB of results out per step over PCIe through "
-            "the handle's pinned staging area, result arrays reused -- reported beside `value`, never as it"
-            % (nq * D * 4 / 1e6, nq * k * 12 / 1e6))
+    what = ("cvtmi_opq_search with host buffers (the reference's call shape): %.1f MB of queries in, %.1f MB of results out per step over "
+            "PCIe, in pieces of 4096 queries that alternate between two scratch sets / streams of the handle (upload of piece i+1 and "
+            "download of piece i-1 beside the scan of piece i); pageable numpy arrays, reused across calls -- reported beside `value`, "
+            "never as it" % (nq * D * 4 / 1e6, nq * k * 12 / 1e6))
     result["host_pointer_api"] = {"value": round(nq / el_h, 1), "unit": "queries/s",
                                   "ms_per_step": round(el_h * 1e3, 4), "what": what}
+    try:   # the same with page-locked arrays from the library's allocator: no staging copy on either side
+        qp = ctx.cvt.pinned_empty((nq, D), np.float32); qp[:] = qh
+        outp = (ctx.cvt.pinned_empty((nq, k), np.float32), ctx.cvt.pinned_empty((nq, k), np.int64))
+        idx.search(qp, k, rotate=True, out=outp)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            idx.search(qp, k, rotate=True, out=outp)
+        el_p = (time.perf_counter() - t0) / reps
+        result["host_pointer_api"]["page_locked_arrays"] = {
+            "value": round(nq / el_p, 1), "unit": "queries/s", "ms_per_step": round(el_p * 1e3, 4),
+            "identical": bool(np.array_equal(outp[1], out_h[1]) and np.array_equal(outp[0].view(np.uint32), out_h[0].view(np.uint32))),
+            "what": "queries and result arrays from cvtmi_host_alloc"}
+    except Exception as e:
+        result["host_pointer_api"]["page_locked_arrays"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return result, idx, out
 
 

@@ -598,6 +598,37 @@ def _hnsw_search_adc_rerank(self, opq, q, k, ef, rerank=None, rotate=True):
 HnswIndex.search_adc_rerank = _hnsw_search_adc_rerank
 
 
+class _PinnedOwner:
+    """keeps a cvtmi_host_alloc block alive as long as a numpy array views it"""
+
+    def __init__(self, nbytes):
+        self.p = C.c_void_p(0)
+        _check(lib().cvtmi_host_alloc(C.c_size_t(nbytes), C.byref(self.p)))
+        self.nbytes = nbytes
+
+    def __del__(self):
+        try:
+            if self.p and self.p.value:
+                lib().cvtmi_host_free(self.p)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """numpy array in page-locked host memory (cvtmi_host_alloc): the host-pointer entries move such arrays without a staging copy"""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    own = _PinnedOwner(max(n, 16))
+    buf = (C.c_char * max(n, 16)).from_address(own.p.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    _PINNED[id(buf)] = own   # (the ctypes buffer does not own the memory: tie the owner's life to the module-level table)
+    arr.flags.writeable = True
+    return arr
+
+
+_PINNED = {}
+
+
 def set_tuning(name, value):
     """library-wide tuning / measurement hooks (cvtmi_set_tuning): no effect on results"""
     _check(lib().cvtmi_set_tuning(name.encode(), C.c_int64(int(value))))

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "host_util.h"
@@ -48,6 +49,30 @@ int fail(int code, const char *fmt, ...)
 using namespace cvtmi;
 
 // ================================================================ handles =====================
+// per-call scratch of an OPQ search: rotated queries, tables (fp32 + the quantised images of adc_scan16h), partial lists, shared
+// bounds, spill areas, the item table and the plan it was built from, the staging of the host-pointer entry.  The set remembers
+// the stream it was last used on and an event recorded when that call returned: the next lessee on ANOTHER stream waits first.
+struct OpqScratch {
+    DevBuf s_qrot, s_part_d, s_part_id, s_lut, s_gthr, s_qlut, s_qp, s_spill, s_items;
+    ScanHPlan hplan;                       // the item table s_items holds ...
+    int64_t hplan_n = -1, hplan_nq = -1;   // ... and the (rows, queries, forced splits, planner settings) it was built for
+    int hplan_splits = 0, hplan_key = 0;
+    DevBuf io_q, io_d, io_i;   // device side of the host-pointer search (cvtmi_opq_search)
+    PinBuf io_pin;             // its pinned staging area
+    hipStream_t own = nullptr; // stream of the host-pointer entry (created on first use)
+    hipEvent_t done = nullptr;
+    hipStream_t last = nullptr;
+    bool pending = false, busy = false;
+    void release_all()
+    {
+        for (DevBuf *b : { &s_qrot, &s_part_d, &s_part_id, &s_lut, &s_gthr, &s_qlut, &s_qp, &s_spill, &s_items, &io_q, &io_d, &io_i }) b->release();
+        io_pin.release();
+        if (own) (void)hipStreamDestroy(own);
+        if (done) (void)hipEventDestroy(done);
+        own = nullptr; done = nullptr;
+    }
+};
+
 struct cvtmi_opq_s {
     int device = 0;
     HandleSync sync;
@@ -66,15 +91,18 @@ struct cvtmi_opq_s {
     DevBuf csr_codes, csr_videos, csr_off, csr_scratch, csr_stats;
     int64_t csr_kept = 0, csr_longest = 0;  // entries in the CSR copy (list ids outside [0, coarseK) are dropped), longest list
     int32_t csr_vmin = 0, csr_vmax = -1;    // range of the video ids it holds
-    // scratch
-    DevBuf s_qrot, s_part_d, s_part_id, s_probe, s_lut, s_gthr, s_rot;
-    // adc_scan16h (scan_variant 6): quantised table images, their parameters, the candidate spill areas, the item table
-    DevBuf s_qlut, s_qp, s_spill, s_items;
-    ScanHPlan hplan;                       // the item table s_items holds ...
-    int64_t hplan_n = -1, hplan_nq = -1;   // ... and the (rows, queries, forced splits, planner settings) it was built for
-    int hplan_splits = 0, hplan_key = 0;
-    DevBuf io_q, io_d, io_i;   // device side of the host-pointer search (cvtmi_opq_search)
-    PinBuf io_pin;             // its pinned staging area
+    // scratch of the calls that run one at a time (query_video: probe lists, rotated queries)
+    DevBuf s_qrot, s_probe, s_rot, s_lut;   // (s_lut: the tables of cvtmi_hnsw_search_adc, which borrows this handle)
+    // Searches (cvtmi_opq_search*) run CONCURRENTLY, as the reference's QueryThrehold de facto may (opq/src/IVFOPQ.cpp:322-422 only
+    // reads the index): each leases a scratch set from this pool for the duration of the call (OpqLease) and holds `rw` shared;
+    // everything else -- add / reset / reserve, the lazily built copies of the rows, the one-at-a-time entries above -- holds it
+    // exclusively (OpqExclusive, on top of the per-handle Serial that orders those calls among themselves).
+    std::shared_timed_mutex rw;
+    std::mutex pool_mu;
+    std::vector<struct OpqScratch *> pool;
+    hipEvent_t mutated = nullptr;   // recorded on the stream of the last exclusive call: searches on other streams wait for it
+    hipStream_t mut_stream = nullptr;
+    bool mut_pending = false;
     // tuning / measurement
     int p_splits = 0, p_qtile = 0, p_profile = 0, p_variant = 7;
     int p_encode = 0;  // 0 = choose, 1 = VALU encode, 2 = matrix-core filter + exact resolution
@@ -200,8 +228,98 @@ static int use_device(int dev)
 // + the handle's lock and stream ordering (see Serial) for the rest of the enclosing scope
 #define CHECK_H_SERIAL(h, stream) \
     CHECK_H(h); \
-    Serial serial_##h((h)->sync, (hipStream_t)(stream))
+    Serial serial_##h((h)->sync, (hipStream_t)(stream)); \
+    OpqExclusive excl_##h((h), (hipStream_t)(stream))
 
+// a scratch set of an OPQ handle for the duration of one search on stream st (nullptr + host = true: the set's own stream).
+// The caller holds h->rw shared.
+struct OpqLease {
+    cvtmi_opq_s *h = nullptr;
+    OpqScratch *s = nullptr;
+    hipStream_t st = nullptr;
+    bool used = false;
+    int open(cvtmi_opq_s *handle, hipStream_t stream, bool host)
+    {
+        h = handle; st = stream;
+        {
+            std::lock_guard<std::mutex> g(h->pool_mu);
+            OpqScratch *any = nullptr;
+            for (OpqScratch *c : h->pool) {
+                if (c->busy) continue;
+                if (!host && c->pending && c->last == stream) { s = c; break; }   // same stream as before: nothing to wait for
+                if (!any) any = c;
+            }
+            if (!s) s = any;
+            if (!s) {
+                s = new (std::nothrow) OpqScratch();
+                if (!s) return fail(CVTMI_ENOMEM, "opq search: out of host memory");
+                h->pool.push_back(s);
+            }
+            s->busy = true;
+        }
+        if (host) {
+            if (!s->own && hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking) != hipSuccess) { close(); return fail(CVTMI_EHIP, "hipStreamCreate failed"); }
+            st = s->own;
+        }
+        if (s->pending && s->last != st) (void)hipStreamWaitEvent(st, s->done, 0);
+        if (h->mut_pending && h->mut_stream != st) (void)hipStreamWaitEvent(st, h->mutated, 0);
+        used = true;
+        return CVTMI_OK;
+    }
+    void close()
+    {
+        if (!s) return;
+        if (used) {
+            if (!s->done) (void)hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+            if (s->done && hipEventRecord(s->done, st) == hipSuccess) { s->last = st; s->pending = true; }
+        }
+        std::lock_guard<std::mutex> g(h->pool_mu);
+        s->busy = false;
+        s = nullptr;
+    }
+    ~OpqLease() { close(); }
+    OpqLease() = default;
+    OpqLease(const OpqLease &) = delete;
+    OpqLease &operator=(const OpqLease &) = delete;
+};
+
+// the exclusive side: taken by the outermost of the (Serial-ordered) non-search calls of an OPQ handle; the stream first waits for
+// the searches that are still in flight on other streams, and the searches that follow wait for this call
+struct OpqExclusive {
+    cvtmi_opq_s *h;
+    hipStream_t st;
+    bool own = false;
+    OpqExclusive(cvtmi_opq_s *handle, hipStream_t stream) : h(handle), st(stream)
+    {
+        if (h->sync.depth != 1) return;   // an inner call of this thread: the outermost one holds the lock
+        h->rw.lock();
+        own = true;
+        std::lock_guard<std::mutex> g(h->pool_mu);
+        for (OpqScratch *c : h->pool)
+            if (c->pending && c->last != st) (void)hipStreamWaitEvent(st, c->done, 0);
+        if (h->mut_pending && h->mut_stream != st) (void)hipStreamWaitEvent(st, h->mutated, 0);
+    }
+    ~OpqExclusive()
+    {
+        if (!own) return;
+        if (!h->mutated) (void)hipEventCreateWithFlags(&h->mutated, hipEventDisableTiming);
+        if (h->mutated && hipEventRecord(h->mutated, st) == hipSuccess) { h->mut_stream = st; h->mut_pending = true; }
+        h->rw.unlock();
+    }
+    OpqExclusive(const OpqExclusive &) = delete;
+    OpqExclusive &operator=(const OpqExclusive &) = delete;
+};
+
+// true when p points into page-locked host memory the device can reach (cvtmi_host_alloc, or the caller's own hipHostMalloc /
+// hipHostRegister): such buffers are handed to the copy engines as they are, without the staging copy
+static bool host_pinned(const void *p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+static std::atomic<int> g_host_chunks{4096};  // cvtmi_set_tuning("opq_host_chunk"): queries per piece of a pipelined host-pointer OPQ batch (0 = one piece)
 static std::atomic<int> g_scanh_key{0};  // bumped when a planner setting of adc_scan16h changes: cached item tables are rebuilt
 static std::atomic<int> g_inject_failure{-1};  // cvtmi_set_tuning("comm_inject_failure", r): the local search of rank r of a sharded search fails (tests)
 static std::atomic<int> g_flat_variant{0};  // cvtmi_set_tuning("flat_variant"): 0 = choose, 1 = exact kernels only, 2 = matrix-core filter wherever it applies
@@ -290,6 +408,11 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: scanh_balance must be 0, 1 or 2");
         set_scanh_balance((int)value);
         ++g_scanh_key;
+        return CVTMI_OK;
+    }
+    if (!strcmp(name, "opq_host_chunk")) {
+        if (value < 0 || value > (1 << 24)) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: opq_host_chunk must be 0..2^24");
+        g_host_chunks = (int)value;
         return CVTMI_OK;
     }
     if (!strcmp(name, "scanh_tail")) {
@@ -393,9 +516,10 @@ int cvtmi_opq_destroy(cvtmi_opq_t h)
     if (h->d_perm) (void)hipFree(h->d_perm);
     h->codes.release(); h->lists.release(); h->videos.release(); h->codes_rot.release();
     h->csr_codes.release(); h->csr_videos.release(); h->csr_off.release(); h->csr_scratch.release(); h->csr_stats.release();
-    h->s_qrot.release(); h->s_part_d.release(); h->s_part_id.release(); h->s_probe.release(); h->s_lut.release(); h->s_gthr.release(); h->s_rot.release();
-    h->s_qlut.release(); h->s_qp.release(); h->s_spill.release(); h->s_items.release();
-    h->io_q.release(); h->io_d.release(); h->io_i.release(); h->io_pin.release();
+    h->s_qrot.release(); h->s_probe.release(); h->s_rot.release(); h->s_lut.release();
+    for (OpqScratch *c : h->pool) { c->release_all(); delete c; }
+    h->pool.clear();
+    if (h->mutated) (void)hipEventDestroy(h->mutated);
     for (int e = 0; e < cvtmi_opq_s::kEvRing; ++e) {
         if (h->ev0[e]) (void)hipEventDestroy(h->ev0[e]);
         if (h->ev1[e]) (void)hipEventDestroy(h->ev1[e]);
@@ -405,15 +529,13 @@ int cvtmi_opq_destroy(cvtmi_opq_t h)
     return CVTMI_OK;
 }
 
+static int opq_rotate_impl(cvtmi_opq_t h, const float *x, int64_t n, float *y, hipStream_t st);
+
 int cvtmi_opq_rotate_dev(cvtmi_opq_t h, const float *x, int64_t n, float *y, void *stream)
 {
     CHECK_H_SERIAL(h, stream);
     if (n < 0 || (n > 0 && (!x || !y))) return fail(CVTMI_EINVAL, "cvtmi_opq_rotate: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    if (h->m.perm) return launch_permute(h->m.perm, h->m.D, x, n, y, st);
-    if (h->m.R) return launch_rotate_gemm(h->m.R, h->m.D, x, n, y, st);
-    if (n > 0) CVTMI_HIP(hipMemcpyAsync(y, x, (size_t)n * h->m.D * sizeof(float), hipMemcpyDeviceToDevice, st));
-    return CVTMI_OK;
+    return opq_rotate_impl(h, x, n, y, (hipStream_t)stream);
 }
 
 int cvtmi_opq_rotate(cvtmi_opq_t h, const float *x, int64_t n, float *y)
@@ -673,133 +795,150 @@ int cvtmi_opq_lut(cvtmi_opq_t h, const float *q_rot, int64_t nq, const int32_t *
     return CVTMI_OK;
 }
 
+static int opq_rotate_impl(cvtmi_opq_t h, const float *x, int64_t n, float *y, hipStream_t st)
+{
+    if (h->m.perm) return launch_permute(h->m.perm, h->m.D, x, n, y, st);
+    if (h->m.R) return launch_rotate_gemm(h->m.R, h->m.D, x, n, y, st);
+    if (n > 0) CVTMI_HIP(hipMemcpyAsync(y, x, (size_t)n * h->m.D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return CVTMI_OK;
+}
+
+// profile mode: a slot of the handle's event ring for one scan launch (searches may run side by side)
+static int opq_profile_slot(cvtmi_opq_t h, int *slot)
+{
+    std::lock_guard<std::mutex> g(h->pool_mu);
+    *slot = h->ev_count++ % cvtmi_opq_s::kEvRing;
+    if (!h->ev0[*slot]) { CVTMI_HIP(hipEventCreate(&h->ev0[*slot])); CVTMI_HIP(hipEventCreate(&h->ev1[*slot])); }
+    return CVTMI_OK;
+}
+
 // scan_variant 6 (adc_scan16h, adc_scan_h.hip): tables once per query group, a persistent grid over a host-built item table,
 // candidates in per-workgroup spill areas, one selection per (segment, query), merge of the groups' partial lists
-static int opq_search_h(cvtmi_opq_t h, const float *q_rot, int64_t nq, int k, float *dist, int64_t *ids, hipStream_t st)
+static int opq_search_h(cvtmi_opq_t h, OpqScratch &S, const float *q_rot, int64_t nq, int k, float *dist, int64_t *ids, const uint8_t *codes_rot,
+                        hipStream_t st)
 {
-    if (h->hplan_n != h->n || h->hplan_nq != nq || h->hplan_splits != h->p_splits || h->hplan_key != g_scanh_key) {
-        scanh_plan(h->n, nq, h->p_splits, h->hplan);
-        const size_t bytes = h->hplan.items.size() * sizeof(ScanItem), mbytes = h->hplan.multi.size() * sizeof(uint32_t);
-        CVTMI_TRY(h->s_items.reserve(std::max<size_t>(bytes + mbytes, 16)));
+    if (S.hplan_n != h->n || S.hplan_nq != nq || S.hplan_splits != h->p_splits || S.hplan_key != g_scanh_key) {
+        scanh_plan(h->n, nq, h->p_splits, S.hplan);
+        const size_t bytes = S.hplan.items.size() * sizeof(ScanItem), mbytes = S.hplan.multi.size() * sizeof(uint32_t);
+        CVTMI_TRY(S.s_items.reserve(std::max<size_t>(bytes + mbytes, 16)));
         // (pageable sources: the runtime stages them before the call returns, so the vectors may change afterwards)
-        if (bytes) CVTMI_HIP(hipMemcpyAsync(h->s_items.p, h->hplan.items.data(), bytes, hipMemcpyHostToDevice, st));
-        if (mbytes) CVTMI_HIP(hipMemcpyAsync(h->s_items.as<char>() + bytes, h->hplan.multi.data(), mbytes, hipMemcpyHostToDevice, st));
-        h->hplan_n = h->n; h->hplan_nq = nq; h->hplan_splits = h->p_splits; h->hplan_key = g_scanh_key;
+        if (bytes) CVTMI_HIP(hipMemcpyAsync(S.s_items.p, S.hplan.items.data(), bytes, hipMemcpyHostToDevice, st));
+        if (mbytes) CVTMI_HIP(hipMemcpyAsync(S.s_items.as<char>() + bytes, S.hplan.multi.data(), mbytes, hipMemcpyHostToDevice, st));
+        S.hplan_n = h->n; S.hplan_nq = nq; S.hplan_splits = h->p_splits; S.hplan_key = g_scanh_key;
     }
-    const ScanHPlan &hp = h->hplan;
+    const ScanHPlan &hp = S.hplan;
     float *pd = dist;
     int64_t *pi = ids;
     if (hp.stride > 1) {
         const size_t cnt = (size_t)nq * hp.stride * k;
-        CVTMI_TRY(h->s_part_d.reserve(cnt * sizeof(float)));
-        CVTMI_TRY(h->s_part_id.reserve(cnt * sizeof(int64_t)));
-        pd = h->s_part_d.as<float>();
-        pi = h->s_part_id.as<int64_t>();
+        CVTMI_TRY(S.s_part_d.reserve(cnt * sizeof(float)));
+        CVTMI_TRY(S.s_part_id.reserve(cnt * sizeof(int64_t)));
+        pd = S.s_part_d.as<float>();
+        pi = S.s_part_id.as<int64_t>();
     }
-    CVTMI_TRY(h->s_lut.reserve((size_t)nq * 16 * 256 * sizeof(float)));
-    CVTMI_TRY(h->s_qlut.reserve(scanh_qlut_bytes(nq)));
-    CVTMI_TRY(h->s_qp.reserve(scanh_qp_bytes(nq)));
-    CVTMI_TRY(h->s_spill.reserve(scanh_spill_bytes(hp.grid)));
-    const uint8_t *codes_rot = nullptr;
-    if (h->p_prerot) {  // the scan streams a pre-rotated copy of the rows
-        if (h->rot_n > h->n) h->rot_n = 0;
-        if (h->codes_rot.cap < (size_t)h->n * 16) {
-            CVTMI_TRY(h->codes_rot.reserve(std::max<size_t>(h->codes.cap, (size_t)h->n * 16)));
-            h->rot_n = 0;  // reserve() does not keep the old contents
-        }
-        CVTMI_TRY(launch_rotate_codes(h->codes.as<uint8_t>(), h->codes_rot.as<uint8_t>(), h->rot_n, h->n, st));
-        h->rot_n = h->n;
-        codes_rot = h->codes_rot.as<uint8_t>();
-    }
+    CVTMI_TRY(S.s_lut.reserve((size_t)nq * 16 * 256 * sizeof(float)));
+    CVTMI_TRY(S.s_qlut.reserve(scanh_qlut_bytes(nq)));
+    CVTMI_TRY(S.s_qp.reserve(scanh_qp_bytes(nq)));
+    CVTMI_TRY(S.s_spill.reserve(scanh_spill_bytes(hp.grid)));
     uint32_t *gthr = nullptr;
     if (hp.stride > 1 && h->p_share) {
-        CVTMI_TRY(h->s_gthr.reserve((size_t)nq * sizeof(uint32_t)));
-        gthr = h->s_gthr.as<uint32_t>();
+        CVTMI_TRY(S.s_gthr.reserve((size_t)nq * sizeof(uint32_t)));
+        gthr = S.s_gthr.as<uint32_t>();
     }
-    const int slot = h->ev_count % cvtmi_opq_s::kEvRing;
+    int slot = 0;
     if (h->p_profile) {
-        if (!h->ev0[slot]) { CVTMI_HIP(hipEventCreate(&h->ev0[slot])); CVTMI_HIP(hipEventCreate(&h->ev1[slot])); }
+        CVTMI_TRY(opq_profile_slot(h, &slot));
         CVTMI_HIP(hipEventRecord(h->ev0[slot], st));
     }
-    CVTMI_TRY(launch_adc_scan_h(h->m, h->codes.as<uint8_t>(), codes_rot, h->n, h->id_base, q_rot, nq, k, hp, h->s_items.as<ScanItem>(), pd, pi, dist, ids,
-                                h->s_lut.as<float>(), h->s_qlut.p, h->s_qp.p, h->s_spill.p, gthr, h->p_lazy, scan_seed_enabled(), st));
+    CVTMI_TRY(launch_adc_scan_h(h->m, h->codes.as<uint8_t>(), codes_rot, h->n, h->id_base, q_rot, nq, k, hp, S.s_items.as<ScanItem>(), pd, pi, dist, ids,
+                                S.s_lut.as<float>(), S.s_qlut.p, S.s_qp.p, S.s_spill.p, gthr, h->p_lazy, scan_seed_enabled(), st));
     if (h->p_profile) {
         CVTMI_HIP(hipEventRecord(h->ev1[slot], st));
-        h->ev_count++;
         h->last_bytes = ((nq + 7) / 8) * h->n * h->m.M;  // passes x rows x M code bytes
         h->last_qt = 8; h->last_splits = hp.stride;
     }
     if (hp.stride > 1)  // (queries of groups scanned in one piece are already in place: the merge skips them)
         CVTMI_TRY(launch_topk_merge(pd, pi, nq, hp.stride, k, dist, ids, st,
-                                    reinterpret_cast<const uint32_t *>(h->s_items.as<char>() + hp.items.size() * sizeof(ScanItem))));
+                                    reinterpret_cast<const uint32_t *>(S.s_items.as<char>() + hp.items.size() * sizeof(ScanItem))));
     return CVTMI_OK;
 }
 
-int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int k, float *dist, int64_t *ids,
-                         void *stream)
+static ScanPlan opq_plan(cvtmi_opq_t h, int64_t nq, int k)
 {
-    CHECK_H_SERIAL(h, stream);
-    if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search: bad arguments");
-    if (h->m.coarseK != 1)
-        return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: exhaustive search needs coarseK == 1 (use cvtmi_opq_query_video)");
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: k=%d outside 1..128", k);
-    if (nq == 0) return CVTMI_OK;
-    hipStream_t st = (hipStream_t)stream;
-    if (h->n == 0)  // an empty index (e.g. a rank whose row block is empty): all padding, (+inf, -1)
-        return launch_topk_select(nullptr, nullptr, nq, 0, k, dist, ids, st);
-    const float *q_rot = q;
-    if (rotate && (h->m.perm || h->m.R)) {
-        CVTMI_TRY(h->s_qrot.reserve((size_t)nq * h->m.D * sizeof(float)));
-        CVTMI_TRY(cvtmi_opq_rotate_dev(h, q, nq, h->s_qrot.as<float>(), stream));
-        q_rot = h->s_qrot.as<float>();
-    }
     ScanPlan plan = plan_scan(h->m, h->n, nq, k, h->p_qtile, h->p_splits, h->p_variant);
-    if (plan.variant == 6) return opq_search_h(h, q_rot, nq, k, dist, ids, st);
+    if (plan.variant == 6) return plan;
     if (!h->p_tail) { plan.groups_a = 0; plan.splits_b = 0; }
     if (h->p_groups_a > 0 && h->p_splits_b > plan.splits && plan.variant >= 3 &&
         h->p_groups_a < (nq + plan.qtile - 1) / plan.qtile) {
         plan.groups_a = h->p_groups_a; plan.splits_b = h->p_splits_b;
     }
+    return plan;
+}
+
+// what a search needs of the index beyond the rows: the pre-rotated copy the M = 16 scans stream, extended under the EXCLUSIVE lock
+// (once per index state; the searches that follow on other streams wait for the event the exclusive call leaves)
+static int opq_prepare(cvtmi_opq_t h, int64_t nq, int k, hipStream_t st)
+{
+    {
+        std::shared_lock<std::shared_timed_mutex> rd(h->rw);
+        if (h->n == 0 || !(h->m.M == 16 && h->p_prerot && opq_plan(h, nq, k).variant >= 3)) return CVTMI_OK;
+        if (h->rot_n == h->n && h->codes_rot.cap >= (size_t)h->n * 16) return CVTMI_OK;
+    }
+    Serial serial(h->sync, st);
+    OpqExclusive excl(h, st);
+    if (h->rot_n > h->n) h->rot_n = 0;
+    if (h->codes_rot.cap < (size_t)h->n * 16) {
+        CVTMI_TRY(h->codes_rot.reserve(std::max<size_t>(h->codes.cap, (size_t)h->n * 16)));
+        h->rot_n = 0;  // reserve() does not keep the old contents
+    }
+    CVTMI_TRY(launch_rotate_codes(h->codes.as<uint8_t>(), h->codes_rot.as<uint8_t>(), h->rot_n, h->n, st));
+    h->rot_n = h->n;
+    return CVTMI_OK;
+}
+
+// one search on stream st with the scratch set S; the caller holds h->rw shared
+static int opq_search_leased(cvtmi_opq_t h, OpqScratch &S, const float *q, int64_t nq, int rotate, int k, float *dist, int64_t *ids, hipStream_t st)
+{
+    if (h->n == 0)  // an empty index (e.g. a rank whose row block is empty): all padding, (+inf, -1)
+        return launch_topk_select(nullptr, nullptr, nq, 0, k, dist, ids, st);
+    const float *q_rot = q;
+    if (rotate && (h->m.perm || h->m.R)) {
+        CVTMI_TRY(S.s_qrot.reserve((size_t)nq * h->m.D * sizeof(float)));
+        CVTMI_TRY(opq_rotate_impl(h, q, nq, S.s_qrot.as<float>(), st));
+        q_rot = S.s_qrot.as<float>();
+    }
+    const ScanPlan plan = opq_plan(h, nq, k);
+    // the scan streams the pre-rotated copy of the rows when it is up to date (opq_prepare); otherwise it rotates in registers
+    const uint8_t *codes_rot = (plan.variant >= 3 && h->m.M == 16 && h->p_prerot && h->rot_n == h->n && h->codes_rot.p) ? h->codes_rot.as<uint8_t>() : nullptr;
+    if (plan.variant == 6) return opq_search_h(h, S, q_rot, nq, k, dist, ids, codes_rot, st);
     float *pd = dist;
     int64_t *pi = ids;
     if (plan.stride() > 1) {
         const size_t cnt = (size_t)nq * plan.stride() * k;
-        CVTMI_TRY(h->s_part_d.reserve(cnt * sizeof(float)));
-        CVTMI_TRY(h->s_part_id.reserve(cnt * sizeof(int64_t)));
-        pd = h->s_part_d.as<float>();
-        pi = h->s_part_id.as<int64_t>();
+        CVTMI_TRY(S.s_part_d.reserve(cnt * sizeof(float)));
+        CVTMI_TRY(S.s_part_id.reserve(cnt * sizeof(int64_t)));
+        pd = S.s_part_d.as<float>();
+        pi = S.s_part_id.as<int64_t>();
     }
-    const int slot = h->ev_count % cvtmi_opq_s::kEvRing;
+    int slot = 0;
     if (h->p_profile) {
-        if (!h->ev0[slot]) { CVTMI_HIP(hipEventCreate(&h->ev0[slot])); CVTMI_HIP(hipEventCreate(&h->ev1[slot])); }
+        CVTMI_TRY(opq_profile_slot(h, &slot));
         CVTMI_HIP(hipEventRecord(h->ev0[slot], st));
     }
     float *lut_scratch = nullptr;
     if (plan.variant >= 3) {  // per-query fp32 tables in HBM (16 KB per query at M=16, K=256)
-        CVTMI_TRY(h->s_lut.reserve((size_t)nq * h->m.M * 256 * sizeof(float)));
-        lut_scratch = h->s_lut.as<float>();
-    }
-    const uint8_t *codes_rot = nullptr;
-    if (plan.variant >= 3 && h->m.M == 16 && h->p_prerot) {  // the scan streams a pre-rotated copy of the rows
-        if (h->rot_n > h->n) h->rot_n = 0;
-        if (h->codes_rot.cap < (size_t)h->n * 16) {
-            CVTMI_TRY(h->codes_rot.reserve(std::max<size_t>(h->codes.cap, (size_t)h->n * 16)));
-            h->rot_n = 0;  // reserve() does not keep the old contents
-        }
-        CVTMI_TRY(launch_rotate_codes(h->codes.as<uint8_t>(), h->codes_rot.as<uint8_t>(), h->rot_n, h->n, st));
-        h->rot_n = h->n;
-        codes_rot = h->codes_rot.as<uint8_t>();
+        CVTMI_TRY(S.s_lut.reserve((size_t)nq * h->m.M * 256 * sizeof(float)));
+        lut_scratch = S.s_lut.as<float>();
     }
     uint32_t *gthr = nullptr;
     if (plan.variant >= 3 && plan.stride() > 1 && h->p_share) {
-        CVTMI_TRY(h->s_gthr.reserve((size_t)nq * sizeof(uint32_t)));
-        gthr = h->s_gthr.as<uint32_t>();
+        CVTMI_TRY(S.s_gthr.reserve((size_t)nq * sizeof(uint32_t)));
+        gthr = S.s_gthr.as<uint32_t>();
     }
     CVTMI_TRY(launch_adc_scan(h->m, h->codes.as<uint8_t>(), h->n, h->id_base, q_rot, nq, k, plan, pd, pi, lut_scratch,
                               codes_rot, st, gthr, h->p_lazy));
     if (h->p_profile) {
         CVTMI_HIP(hipEventRecord(h->ev1[slot], st));
-        h->ev_count++;
         const int64_t groups = (nq + plan.qtile - 1) / plan.qtile;
         h->last_bytes = groups * h->n * h->m.M;  // passes x rows x M code bytes
         h->last_qt = plan.qtile; h->last_splits = plan.splits;
@@ -808,15 +947,47 @@ int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, 
     return CVTMI_OK;
 }
 
+int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int k, float *dist, int64_t *ids,
+                         void *stream)
+{
+    CHECK_H(h);
+    if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search: bad arguments");
+    if (h->m.coarseK != 1)
+        return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: exhaustive search needs coarseK == 1 (use cvtmi_opq_query_video)");
+    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: k=%d outside 1..128", k);
+    if (nq == 0) return CVTMI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    CVTMI_TRY(opq_prepare(h, nq, k, st));
+    std::shared_lock<std::shared_timed_mutex> rd(h->rw);
+    OpqLease lease;
+    CVTMI_TRY(lease.open(h, st, false));
+    return opq_search_leased(h, *lease.s, q, nq, rotate, k, dist, ids, st);
+}
+
+
+// Host-pointer search, the reference's own call shape (opq/src/multi_frame_index_test.cpp:45-54 hands over host buffers).  A large
+// batch is cut into chunks that alternate between TWO scratch sets with their own streams: while chunk i is scanned, the queries of
+// chunk i + 1 go up and the results of chunk i - 1 come down (pinned staging areas the sets keep), and the scan kernels of
+// neighbouring chunks fill each other's last, partly occupied round of workgroups.
 int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int k, float *dist, int64_t *ids)
 {
-    CHECK_H_SERIAL(h, nullptr);
+    CHECK_H(h);
     if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search: bad arguments");
     if (nq == 0) return CVTMI_OK;
+    if (h->m.coarseK != 1)
+        return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: exhaustive search needs coarseK == 1 (use cvtmi_opq_query_video)");
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: k=%d outside 1..128", k);
-    const size_t qb = (size_t)nq * h->m.D * sizeof(float), db = (size_t)nq * k * sizeof(float), ib = (size_t)nq * k * sizeof(int64_t);
-    if (std::max(qb, db + ib) > ((size_t)256 << 20)) {  // very large batches: no staging area of that size is kept around
+    const int D = h->m.D;
+    // pieces of `per` queries: 4096 by default = 512 query groups = ONE full round of the scan's workgroups on 256 CUs, so cutting
+    // the batch there costs the scan nothing (10 000 queries: 1 + 1 + 0.44 rounds either way)
+    int64_t per = g_host_chunks.load();
+    if (per <= 0 || nq < per + per / 4) per = nq;
+    per = (per + 7) / 8 * 8;   // whole query groups
+    const int chunks = (int)((nq + per - 1) / per);
+    if (per > (64 << 20) / (int64_t)(D * 4) || (size_t)per * k * 12 > ((size_t)256 << 20)) {
+        // very large pieces: no staging area of that size is kept around
         Tmp dq, dd, di;
+        const size_t qb = (size_t)nq * D * sizeof(float), db = (size_t)nq * k * sizeof(float), ib = (size_t)nq * k * sizeof(int64_t);
         CVTMI_TRY(dq.upload(q, qb));
         CVTMI_TRY(dd.alloc(db));
         CVTMI_TRY(di.alloc(ib));
@@ -825,19 +996,63 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
         CVTMI_HIP(hipMemcpy(ids, di.p, ib, hipMemcpyDeviceToHost));
         return CVTMI_OK;
     }
-    // through buffers the handle keeps: queries -> pinned -> device, results device -> pinned -> caller
-    CVTMI_TRY(h->io_q.reserve(qb));
-    CVTMI_TRY(h->io_d.reserve(db));
-    CVTMI_TRY(h->io_i.reserve(ib));
-    CVTMI_TRY(h->io_pin.reserve(std::max(qb, db + ib)));
-    memcpy(h->io_pin.p, q, qb);
-    CVTMI_HIP(hipMemcpyAsync(h->io_q.p, h->io_pin.p, qb, hipMemcpyHostToDevice, nullptr));
-    CVTMI_TRY(cvtmi_opq_search_dev(h, h->io_q.as<float>(), nq, rotate, k, h->io_d.as<float>(), h->io_i.as<int64_t>(), nullptr));
-    CVTMI_HIP(hipMemcpyAsync(h->io_pin.p, h->io_d.p, db, hipMemcpyDeviceToHost, nullptr));
-    CVTMI_HIP(hipMemcpyAsync(h->io_pin.as<char>() + db, h->io_i.p, ib, hipMemcpyDeviceToHost, nullptr));
-    CVTMI_HIP(hipStreamSynchronize(nullptr));
-    memcpy(dist, h->io_pin.p, db);
-    memcpy(ids, h->io_pin.as<char>() + db, ib);
+    CVTMI_TRY(opq_prepare(h, per, k, nullptr));
+    std::shared_lock<std::shared_timed_mutex> rd(h->rw);
+    OpqLease lease[2];
+    const int nsets = chunks > 1 ? 2 : 1;
+    for (int i = 0; i < nsets; ++i) CVTMI_TRY(lease[i].open(h, nullptr, true));
+    const size_t qb = (size_t)per * D * sizeof(float), db = (size_t)per * k * sizeof(float), ib = (size_t)per * k * sizeof(int64_t);
+    for (int i = 0; i < nsets; ++i) {
+        OpqScratch &S = *lease[i].s;
+        CVTMI_TRY(S.io_q.reserve(qb));
+        CVTMI_TRY(S.io_d.reserve(db));
+        CVTMI_TRY(S.io_i.reserve(ib));
+        CVTMI_TRY(S.io_pin.reserve(qb + db + ib));   // [queries | distances | ids]
+    }
+    struct InFlight { int64_t q0 = 0, n = 0; } fl[2];
+    // pinned staging -> the caller's (pageable) arrays: a large copy is shared with a helper thread (one core moves ~10 GB/s: the
+    // 12 MB of a 10 000 x 100 result would otherwise cost a third of the scan's time)
+    const auto copy_out = [](void *dst, const void *src, size_t bytes) {
+        if (bytes < ((size_t)1 << 20)) { memcpy(dst, src, bytes); return; }
+        const size_t half = (bytes / 2) & ~(size_t)63;
+        std::thread helper([=]() { memcpy(static_cast<char *>(dst) + half, static_cast<const char *>(src) + half, bytes - half); });
+        memcpy(dst, src, half);
+        helper.join();
+    };
+    // results of the chunk a set holds -> the caller's arrays (after its stream has drained)
+    const auto drain = [&](int i) -> int {
+        if (!fl[i].n) return CVTMI_OK;
+        OpqScratch &S = *lease[i].s;
+        CVTMI_HIP(hipStreamSynchronize(lease[i].st));
+        copy_out(dist + fl[i].q0 * k, S.io_pin.as<char>() + qb, (size_t)fl[i].n * k * sizeof(float));
+        copy_out(ids + fl[i].q0 * k, S.io_pin.as<char>() + qb + db, (size_t)fl[i].n * k * sizeof(int64_t));
+        fl[i].n = 0;
+        return CVTMI_OK;
+    };
+    const bool q_pinned = host_pinned(q), out_pinned = host_pinned(dist) && host_pinned(ids);
+    int c = 0;
+    for (int64_t q0 = 0; q0 < nq; q0 += per, ++c) {
+        const int i = c % nsets;
+        const int64_t n = std::min(per, nq - q0);
+        CVTMI_TRY(drain(i));   // the set's previous chunk: its staging area is about to be overwritten
+        OpqScratch &S = *lease[i].s;
+        hipStream_t st = lease[i].st;
+        const void *src = q + q0 * D;
+        if (!q_pinned) { memcpy(S.io_pin.p, src, (size_t)n * D * sizeof(float)); src = S.io_pin.p; }
+        CVTMI_HIP(hipMemcpyAsync(S.io_q.p, src, (size_t)n * D * sizeof(float), hipMemcpyHostToDevice, st));
+        CVTMI_TRY(opq_search_leased(h, S, S.io_q.as<float>(), n, rotate, k, S.io_d.as<float>(), S.io_i.as<int64_t>(), st));
+        if (out_pinned) {  // straight into the caller's page-locked arrays; the final drain only waits for the streams
+            CVTMI_HIP(hipMemcpyAsync(dist + q0 * k, S.io_d.p, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost, st));
+            CVTMI_HIP(hipMemcpyAsync(ids + q0 * k, S.io_i.p, (size_t)n * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        } else {
+            CVTMI_HIP(hipMemcpyAsync(S.io_pin.as<char>() + qb, S.io_d.p, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost, st));
+            CVTMI_HIP(hipMemcpyAsync(S.io_pin.as<char>() + qb + db, S.io_i.p, (size_t)n * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+            fl[i].q0 = q0; fl[i].n = n;
+        }
+    }
+    if (out_pinned)
+        for (int i = 0; i < nsets; ++i) CVTMI_HIP(hipStreamSynchronize(lease[i].st));
+    for (int i = 0; i < nsets; ++i) CVTMI_TRY(drain((c + i) % nsets));
     return CVTMI_OK;
 }
 
@@ -854,7 +1069,7 @@ int cvtmi_opq_search_sharded_dev(cvtmi_opq_t h, cvtmi_comm_t c, const float *q, 
     if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search_sharded: k=%d outside 1..128", k);
     if (nq == 0) return CVTMI_OK;
     Serial serial_c(*comm_sync(c), (hipStream_t)stream);
-    CHECK_H_SERIAL(h, stream);
+    CHECK_H(h);
     if (comm_world(c) == 1 && !comm_has_transport(c)) return cvtmi_opq_search_dev(h, q, nq, rotate, k, dist, ids, stream);
     // from here on every rank reaches the collective, whatever its local search did
     int rc = comm_device(c) != h->device ? fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: handle and communicator live on different devices") : CVTMI_OK;
@@ -991,6 +1206,22 @@ int cvtmi_opq_last_scan(cvtmi_opq_t h, float *ms, int64_t *code_bytes, int *qtil
     if (code_bytes) *code_bytes = h->last_bytes;
     if (qtile) *qtile = h->last_qt;
     if (splits) *splits = h->last_splits;
+    return CVTMI_OK;
+}
+
+// page-locked host memory for the arrays of the host-pointer entries (queries in, results out)
+int cvtmi_host_alloc(size_t bytes, void **p)
+{
+    if (!p) return fail(CVTMI_EINVAL, "cvtmi_host_alloc: null");
+    *p = nullptr;
+    hipError_t e = hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) { *p = nullptr; return fail(CVTMI_ENOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    return CVTMI_OK;
+}
+
+int cvtmi_host_free(void *p)
+{
+    if (p) CVTMI_HIP(hipHostFree(p));
     return CVTMI_OK;
 }
 
@@ -2004,6 +2235,7 @@ static int hnsw_search_adc_impl(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q,
     if (nq == 0) return CVTMI_OK;
     hipStream_t st = (hipStream_t)stream;
     Serial serial_opq(opq->sync, st);  // the tables live in the OPQ handle's scratch
+    OpqExclusive excl_opq(opq, st);
     const float *q_rot = q;
     if (rotate && (opq->m.perm || opq->m.R)) {
         CVTMI_TRY(opq->s_qrot.reserve((size_t)nq * opq->m.D * sizeof(float)));

@@ -252,3 +252,14 @@ def test_bruteforce_mirror_concurrent_searchknn(tmp_path):
     a scratch set and a stream per call; only index mutation is exclusive)"""
     out = run([os.path.join(BIN, "bf_concurrent"), "200000", "128", "4", "32", "50"], cwd=str(tmp_path))
     assert out.strip().endswith("OK"), out
+
+
+def test_ivfopq_mirror_concurrent_searchtopk(tmp_path):
+    """four host threads inside IVFOPQ::SearchTopK (8 queries per call, the reference's call pattern: 1-9 query frames per Query,
+    opq/src/multi_frame_index_test.cpp:45-54) on ONE index at once: the answers of one thread, bit for bit -- every search leases its
+    own scratch set and stream from the OPQ handle, only add / reset and the lazily built row copy are exclusive"""
+    out = run([os.path.join(BIN, "opq_concurrent"), "300000", "4", "24", "8", "100"], cwd=str(tmp_path))
+    assert out.strip().endswith("OK"), out
+    # larger batches through the pipelined host-pointer entry (chunks alternating between two scratch sets / streams)
+    out = run([os.path.join(BIN, "opq_concurrent"), "100000", "3", "4", "5000", "10"], cwd=str(tmp_path))
+    assert out.strip().endswith("OK"), out
