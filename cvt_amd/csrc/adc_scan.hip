@@ -122,13 +122,13 @@ __device__ __forceinline__ void build_lut_lds(float *lut, float *res, const Scan
 // workgroups per CU at QT = 1 / 2 / 4 / 8 (M = 16), i.e. that many waves per SIMD.
 template <int QT> struct ScanOcc { static constexpr int waves = QT == 1 ? 6 : QT == 2 ? 3 : QT == 4 ? 2 : 1; };
 
-template <int M, int QT>
-__global__ __launch_bounds__(kBlock, ScanOcc<QT>::waves) void adc_scan_kernel(const ScanArgs a)
+template <int M, int QT, int CAP = SCAN_CAP, int TRIG = SCAN_TRIG>
+__global__ __launch_bounds__(kBlock, CAP > SCAN_CAP ? 1 : ScanOcc<QT>::waves) void adc_scan_kernel(const ScanArgs a)
 {
     using Row = typename CodeRow<M>::type;
     constexpr int R = scan_rows(M, QT);
     __shared__ __attribute__((aligned(32))) float lut[M * 256 * QT];
-    __shared__ TopKShared<QT, SCAN_CAP> tk;
+    __shared__ TopKShared<QT, CAP> tk;
 
     // ---- block -> (query group, row split); a row split stays on one XCD when splits % 8 == 0 ----
     int group, split;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kBlock, ScanOcc<QT>::waves) void adc_scan_kernel(co
 #pragma unroll
             for (int q = 0; q < QT; ++q) key[r][q] = valid ? __float_as_uint(acc[q]) : KEY_MAX;  // sums are >= +0
         }
-        topk_tile<QT, R, SCAN_CAP, SCAN_TRIG>(tk, a.k, tile, key, pay);
+        topk_tile<QT, R, CAP, TRIG>(tk, a.k, tile, key, pay);
 #pragma unroll
         for (int r = 0; r < R; ++r) cur[r] = nxt[r];
     }
@@ -1226,6 +1226,7 @@ ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int 
     ScanPlan p;
     int qt = want_qtile;
     if (qt != 1 && qt != 2 && qt != 4 && qt != 8) qt = (nq >= 4) ? 4 : (nq >= 2 ? 2 : 1);
+    if (k > 128) qt = 1;
     // M = 16 kernels with conflict-free skewed table reads:
     //   variant 1 / 2: fp32 tables, 4 queries per pass, 512- / 1024-thread workgroups (adc_scan16)
     //   variant 3 / 4: 15-bit lower-bound tables, 8 queries per pass, 1024- / 512-thread workgroups (adc_scan16q)
@@ -1234,6 +1235,7 @@ ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int 
     //   candidates, persistent grid) -- takes any number of queries
     // want_variant 7 = the library's own choice between 3 and 6: adc_scan16h where it measured ahead on a cache-resident index
     // (63 ... 500 query groups at 1 M rows: -6 % at 1000 queries, -10 ... -14 % at 2500; tools/sweep_scan_h.py), adc_scan16q elsewhere
+    if (k > 128) { want_variant = 0; want_qtile = 1; }  // the exact row-per-lane kernel, one query per workgroup (kernels.h: kBigK)
     if (want_variant == 7) want_variant = (m.M == 16 && nq >= 500 && nq <= 4000 && n_rows >= 131072 && n_rows * 16 <= (96LL << 20)) ? 6 : 3;
     if (m.M == 16 && want_variant >= 3 && (nq >= 4 || want_variant == 6) && m.D <= 256) { p.variant = want_variant; qt = 8; }
     else if (m.M == 16 && want_variant >= 1) {
@@ -1316,6 +1318,15 @@ static int launch_t(const ScanArgs &a, hipStream_t st)
 template <int M>
 static int launch_m(const ScanArgs &a, int qt, hipStream_t st)
 {
+    if (a.k > 128) {  // one query per workgroup, the large selection buffer (kernels.h: kBigK)
+        const int64_t blocks = (int64_t)a.groups * a.splits;
+        if (qt != 1) return fail(CVTMI_EINVAL, "adc_scan: k=%d needs qtile 1", a.k);
+        if (blocks <= 0) return CVTMI_OK;
+        if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "adc_scan: grid too large (%lld)", (long long)blocks);
+        hipLaunchKernelGGL((adc_scan_kernel<M, 1, kBigCap, kBigTrig>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+        CVTMI_HIP(hipGetLastError());
+        return CVTMI_OK;
+    }
     switch (qt) {
         case 1: return launch_t<M, 1>(a, st);
         case 2: return launch_t<M, 2>(a, st);
@@ -1361,7 +1372,7 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
                     const uint8_t *codes_rot, hipStream_t st, uint32_t *gthr, int lazy)
 {
     if (nq <= 0) return CVTMI_OK;
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "adc_scan: k=%d outside 1..128", k);
+    if (k < 1 || k > kBigK) return fail(CVTMI_EUNSUPPORTED, "adc_scan: k=%d outside 1..%d", k, kBigK);
     if (m.K > 256 || m.K < 1) return fail(CVTMI_EUNSUPPORTED, "adc_scan: K=%d outside 1..256", m.K);
     if (n_rows > 0xfffffffeLL) return fail(CVTMI_EUNSUPPORTED, "adc_scan: more than 2^32-2 rows per shard");
     if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "adc_scan: nq too large");

@@ -954,7 +954,7 @@ int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, 
     if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search: bad arguments");
     if (h->m.coarseK != 1)
         return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: exhaustive search needs coarseK == 1 (use cvtmi_opq_query_video)");
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: k=%d outside 1..128", k);
+    if (k < 1 || k > CVTMI_K_MAX) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: k=%d outside 1..%d", k, CVTMI_K_MAX);
     if (nq == 0) return CVTMI_OK;
     hipStream_t st = (hipStream_t)stream;
     CVTMI_TRY(opq_prepare(h, nq, k, st));
@@ -976,7 +976,7 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
     if (nq == 0) return CVTMI_OK;
     if (h->m.coarseK != 1)
         return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: exhaustive search needs coarseK == 1 (use cvtmi_opq_query_video)");
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: k=%d outside 1..128", k);
+    if (k < 1 || k > CVTMI_K_MAX) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search: k=%d outside 1..%d", k, CVTMI_K_MAX);
     const int D = h->m.D;
     // pieces of `per` queries: 4096 by default = 512 query groups = ONE full round of the scan's workgroups on 256 CUs, so cutting
     // the batch there costs the scan nothing (10 000 queries: 1 + 1 + 0.44 rounds either way)
@@ -1066,7 +1066,7 @@ int cvtmi_opq_search_sharded_dev(cvtmi_opq_t h, cvtmi_comm_t c, const float *q, 
     CVTMI_TRY(comm_validate(c));
     if (!h) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: null handle");
     if (nq < 0 || (nq > 0 && (!dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: bad arguments");
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search_sharded: k=%d outside 1..128", k);
+    if (k < 1 || k > CVTMI_K_MAX) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search_sharded: k=%d outside 1..%d", k, CVTMI_K_MAX);
     if (nq == 0) return CVTMI_OK;
     Serial serial_c(*comm_sync(c), (hipStream_t)stream);
     CHECK_H(h);
@@ -1086,7 +1086,7 @@ int cvtmi_opq_search_sharded(cvtmi_opq_t h, cvtmi_comm_t c, const float *q, int6
     CVTMI_TRY(comm_validate(c));
     CHECK_H(h);
     if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded: bad arguments");
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search_sharded: k=%d outside 1..128", k);
+    if (k < 1 || k > CVTMI_K_MAX) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search_sharded: k=%d outside 1..%d", k, CVTMI_K_MAX);
     if (nq == 0) return CVTMI_OK;
     Tmp dq, dd, di;
     CVTMI_TRY(dq.upload(q, (size_t)nq * h->m.D * sizeof(float)));
@@ -1103,7 +1103,7 @@ int cvtmi_opq_search_sharded_all(cvtmi_opq_t *handles, cvtmi_comm_t *comms, int 
 {
     if (!handles || !comms || ndev < 1) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded_all: bad arguments");
     if (nq < 0 || (nq > 0 && (!q || !dist || !ids))) return fail(CVTMI_EINVAL, "cvtmi_opq_search_sharded_all: bad arguments");
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search_sharded_all: k=%d outside 1..128", k);
+    if (k < 1 || k > CVTMI_K_MAX) return fail(CVTMI_EUNSUPPORTED, "cvtmi_opq_search_sharded_all: k=%d outside 1..%d", k, CVTMI_K_MAX);
     std::vector<int> devices(ndev);
     for (int d = 0; d < ndev; ++d) {
         CVTMI_TRY(comm_validate(comms[d]));
@@ -1462,7 +1462,7 @@ static int flat_search_rows(cvtmi_flat_t h, FlatScratch &S, int64_t n_rows, cons
         return CVTMI_OK;
     }
     const bool mfma = h->metric == CVTMI_METRIC_L2U8 && flat_u8_mfma_qtile(h->D, k, nq) > 0;
-    const int qt = mfma ? flat_u8_mfma_qtile(h->D, k, nq) : flat_qtile(nq);
+    const int qt = mfma ? flat_u8_mfma_qtile(h->D, k, nq) : (k > 128 ? 1 : flat_qtile(nq));   // k > 128: one query per workgroup (kernels.h: kBigK)
     int splits = mfma ? flat_u8_mfma_splits(n_rows, nq, qt) : flat_plan_splits(n_rows, nq, qt);
     if (mfma && splits >= 8) splits = (splits / 8) * 8;  // a row split per XCD: query groups share its L2
     // a predicated re-run normally finds nothing to do: keep its grid small (an empty workgroup still costs a dispatch)
@@ -1726,7 +1726,7 @@ int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void
 {
     CHECK_H(h);
     if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_flat_search: bad arguments");
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search: k=%d outside 1..128", k);
+    if (k < 1 || k > CVTMI_K_MAX) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search: k=%d outside 1..%d", k, CVTMI_K_MAX);
     if (nq == 0) return CVTMI_OK;
     hipStream_t st = (hipStream_t)stream;
     const FlatTuning tun = FlatTuning::now();
@@ -1751,7 +1751,7 @@ int cvtmi_flat_search_sharded_dev(cvtmi_flat_t h, cvtmi_comm_t c, const void *q,
     CVTMI_TRY(comm_validate(c));
     if (!h) return fail(CVTMI_EINVAL, "cvtmi_flat_search_sharded: null handle");
     if (nq < 0 || (nq > 0 && (!dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_flat_search_sharded: bad arguments");
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search_sharded: k=%d outside 1..128", k);
+    if (k < 1 || k > CVTMI_K_MAX) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search_sharded: k=%d outside 1..%d", k, CVTMI_K_MAX);
     if (nq == 0) return CVTMI_OK;
     Serial serial_c(*comm_sync(c), (hipStream_t)stream);
     CHECK_H(h);
@@ -1770,7 +1770,7 @@ int cvtmi_flat_search_sharded(cvtmi_flat_t h, cvtmi_comm_t c, const void *q, int
     CVTMI_TRY(comm_validate(c));
     CHECK_H(h);
     if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_flat_search_sharded: bad arguments");
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search_sharded: k=%d outside 1..128", k);
+    if (k < 1 || k > CVTMI_K_MAX) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search_sharded: k=%d outside 1..%d", k, CVTMI_K_MAX);
     if (nq == 0) return CVTMI_OK;
     Tmp dq, dd, di;
     CVTMI_TRY(dq.upload(q, (size_t)nq * h->row_bytes));
@@ -1787,7 +1787,7 @@ int cvtmi_flat_search_sharded_all(cvtmi_flat_t *handles, cvtmi_comm_t *comms, in
 {
     if (!handles || !comms || ndev < 1) return fail(CVTMI_EINVAL, "cvtmi_flat_search_sharded_all: bad arguments");
     if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_flat_search_sharded_all: bad arguments");
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search_sharded_all: k=%d outside 1..128", k);
+    if (k < 1 || k > CVTMI_K_MAX) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search_sharded_all: k=%d outside 1..%d", k, CVTMI_K_MAX);
     std::vector<int> devices(ndev);
     for (int d = 0; d < ndev; ++d) {
         CVTMI_TRY(comm_validate(comms[d]));
@@ -1815,7 +1815,7 @@ int cvtmi_flat_search(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *di
 {
     CHECK_H(h);
     if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_flat_search: bad arguments");
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search: k=%d outside 1..128", k);
+    if (k < 1 || k > CVTMI_K_MAX) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_search: k=%d outside 1..%d", k, CVTMI_K_MAX);
     if (nq == 0) return CVTMI_OK;
     alignas(16) static const char aligned_probe[16] = {};
     const FlatTuning tun = FlatTuning::now();
@@ -2285,7 +2285,7 @@ int cvtmi_hnsw_search_adc_rerank_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const floa
 {
     CHECK_HN(h);
     Serial serial_h(h->sync, (hipStream_t)(stream));
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search_adc_rerank: k=%d outside 1..128", k);
+    if (k < 1 || k > CVTMI_K_MAX) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search_adc_rerank: k=%d outside 1..%d", k, CVTMI_K_MAX);
     if (rerank < k || rerank > hnsw_ef_max()) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc_rerank: rerank=%d outside k..%d", rerank, hnsw_ef_max());
     if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc_rerank: bad arguments");
     if (nq == 0) return CVTMI_OK;

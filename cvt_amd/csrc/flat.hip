@@ -52,11 +52,11 @@ __device__ __forceinline__ bool flat_skip(const FlatArgs &a, int group)
     return any == 0;
 }
 
-template <bool IP, int LANES, int QT>
+template <bool IP, int LANES, int QT, int CAP = FLAT_CAP, int TRIG = FLAT_TRIG>
 __global__ __launch_bounds__(kBlock) void flat_f32_kernel(const FlatArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [QT][D]
-    __shared__ TopKShared<QT, FLAT_CAP> tk;
+    __shared__ TopKShared<QT, CAP> tk;
     const int split = blockIdx.x % a.splits, group = blockIdx.x / a.splits;
     if (flat_skip<QT>(a, group)) return;
     const int tid = threadIdx.x;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void flat_f32_kernel(const FlatArgs a)
                 key[r][q] = valid ? kk : KEY_MAX;
             }
         }
-        topk_tile<QT, FLAT_R, FLAT_CAP, FLAT_TRIG>(tk, a.k, tile, key, pay);
+        topk_tile<QT, FLAT_R, CAP, TRIG>(tk, a.k, tile, key, pay);
     }
     __syncthreads();
     topk_compact(tk, a.k);
@@ -120,10 +120,10 @@ __global__ __launch_bounds__(kBlock) void flat_f32_kernel(const FlatArgs a)
 // addresses straight from global memory (s_load through the scalar cache), the rows stay one per lane, and the
 // multiply / subtract take the SGPR as an operand -- no LDS traffic at all in the distance loop.  Same
 // per-lane accumulation order as dist_f32.h, hence the same bits.
-template <bool IP, int LANES, int QT>
+template <bool IP, int LANES, int QT, int CAP = FLAT_CAP, int TRIG = FLAT_TRIG>
 __global__ __launch_bounds__(kBlock) void flat_f32_sq_kernel(const FlatArgs a)
 {
-    __shared__ TopKShared<QT, FLAT_CAP> tk;
+    __shared__ TopKShared<QT, CAP> tk;
     const int split = blockIdx.x % a.splits, group = blockIdx.x / a.splits;
     if (flat_skip<QT>(a, group)) return;
     const int tid = threadIdx.x;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void flat_f32_sq_kernel(const FlatArgs a)
                 kk = kk == KEY_MAX ? KEY_MAX - 1 : kk;
                 key[r][q] = valid[r] ? kk : KEY_MAX;
             }
-        topk_tile<QT, FLAT_R, FLAT_CAP, FLAT_TRIG>(tk, a.k, tile, key, pay);
+        topk_tile<QT, FLAT_R, CAP, TRIG>(tk, a.k, tile, key, pay);
     }
     __syncthreads();
     topk_compact(tk, a.k);
@@ -256,11 +256,11 @@ int launch_flat_block(const float *src, int64_t n, int D, int64_t row0, float *d
 }
 
 // uint8 rows.  VEC: rows are 16-byte aligned multiples of 16 (D % 16 == 0) -> dwordx4 loads + dot4
-template <bool VEC, int QT>
+template <bool VEC, int QT, int CAP = FLAT_CAP, int TRIG = FLAT_TRIG>
 __global__ __launch_bounds__(kBlock) void flat_u8_kernel(const FlatArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t qw[];  // [QT][ceil(D/4)] packed query bytes
-    __shared__ TopKShared<QT, FLAT_CAP> tk;
+    __shared__ TopKShared<QT, CAP> tk;
     __shared__ uint32_t qq[QT];
     const int split = blockIdx.x % a.splits, group = blockIdx.x / a.splits;
     const int tid = threadIdx.x;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void flat_u8_kernel(const FlatArgs a)
                 key[r][q] = valid ? d : KEY_MAX;
             }
         }
-        topk_tile<QT, FLAT_R, FLAT_CAP, FLAT_TRIG>(tk, a.k, tile, key, pay);
+        topk_tile<QT, FLAT_R, CAP, TRIG>(tk, a.k, tile, key, pay);
     }
     __syncthreads();
     topk_compact(tk, a.k);
@@ -1337,6 +1337,12 @@ int flat_plan_splits(int64_t n, int64_t nq, int qtile)
 template <bool IP, int LANES>
 static int launch_f32(const FlatArgs &a, int qtile, unsigned blocks, size_t lds, hipStream_t st)
 {
+    if (a.k > 128) {  // one query per workgroup, the large selection buffer (kernels.h: kBigK)
+        if constexpr (LANES >= 4) hipLaunchKernelGGL((flat_f32_sq_kernel<IP, LANES, 1, kBigCap, kBigTrig>), dim3(blocks), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((flat_f32_kernel<IP, LANES, 1, kBigCap, kBigTrig>), dim3(blocks), dim3(kBlock), lds, st, a);
+        CVTMI_HIP(hipGetLastError());
+        return CVTMI_OK;
+    }
     if constexpr (LANES >= 4) {  // queries in SGPRs (rows are 16-byte aligned: D % 4 == 0)
         if (qtile == 4) hipLaunchKernelGGL((flat_f32_sq_kernel<IP, LANES, 4>), dim3(blocks), dim3(kBlock), 0, st, a);
         else hipLaunchKernelGGL((flat_f32_sq_kernel<IP, LANES, 1>), dim3(blocks), dim3(kBlock), 0, st, a);
@@ -1352,9 +1358,10 @@ int launch_flat_search(int metric, int D, const void *data, int64_t n, const voi
                        int splits, float *part_d, int64_t *part_id, hipStream_t st, const uint32_t *only_if)
 {
     if (nq <= 0) return CVTMI_OK;
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "flat_search: k=%d outside 1..128", k);
+    if (k < 1 || k > kBigK) return fail(CVTMI_EUNSUPPORTED, "flat_search: k=%d outside 1..%d", k, kBigK);
     if (n > 0xfffffffeLL || nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "flat_search: index too large");
     if (qtile != 1 && qtile != 4) return fail(CVTMI_EINVAL, "flat_search: qtile %d", qtile);
+    if (k > 128 && qtile != 1) return fail(CVTMI_EINVAL, "flat_search: k=%d needs qtile 1", k);
     if (D < 1 || D > 4096) return fail(CVTMI_EUNSUPPORTED, "flat_search: D=%d outside 1..4096", D);
     FlatArgs a;
     a.data = data; a.n = n; a.q = q; a.nq = (int)nq; a.D = D; a.k = k; a.splits = splits;
@@ -1380,7 +1387,10 @@ int launch_flat_search(int metric, int D, const void *data, int64_t n, const voi
             return launch_f32<false, 1>(a, qtile, (unsigned)blocks, lds_f, st);
         case CVTMI_METRIC_L2U8: {
             const size_t lds_u = (size_t)qtile * ((D >> 2) + 1) * sizeof(uint32_t);
-            if (D % 16 == 0) {
+            if (k > 128) {
+                if (D % 16 == 0) hipLaunchKernelGGL((flat_u8_kernel<true, 1, kBigCap, kBigTrig>), dim3((unsigned)blocks), dim3(kBlock), lds_u, st, a);
+                else hipLaunchKernelGGL((flat_u8_kernel<false, 1, kBigCap, kBigTrig>), dim3((unsigned)blocks), dim3(kBlock), lds_u, st, a);
+            } else if (D % 16 == 0) {
                 if (qtile == 4) hipLaunchKernelGGL((flat_u8_kernel<true, 4>), dim3((unsigned)blocks), dim3(kBlock), lds_u, st, a);
                 else hipLaunchKernelGGL((flat_u8_kernel<true, 1>), dim3((unsigned)blocks), dim3(kBlock), lds_u, st, a);
             } else {

@@ -7,6 +7,11 @@
 
 namespace cvtmi {
 
+// k of a search: up to 128 through every kernel; 129 .. kBigK through the exact kernels only, one query per workgroup with a
+// 4096-entry selection buffer (block_topk.h is generic in k: the buffer has to hold k entries below its compaction trigger)
+constexpr int kBigK = CVTMI_K_MAX, kBigCap = 4096, kBigTrig = 3072;
+static_assert(kBigK <= kBigTrig && 2 * kBigK <= kBigCap, "selection buffer too small for kBigK");
+
 struct OpqModelDev {
     int D, coarseK, M, K, step;
     const float *coarse;  // [coarseK][D]

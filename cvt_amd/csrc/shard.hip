@@ -422,7 +422,7 @@ int cvtmi_shard_merge_topk_dev(cvtmi_comm_t c, const float *local_dist, const in
                                int64_t *ids, void *stream)
 {
     CVTMI_TRY(comm_check(c));
-    if (nq < 0 || k < 1 || k > 128 || (nq > 0 && (!local_dist || !local_ids || !dist || !ids)))
+    if (nq < 0 || k < 1 || k > CVTMI_K_MAX || (nq > 0 && (!local_dist || !local_ids || !dist || !ids)))
         return fail(CVTMI_EINVAL, "cvtmi_shard_merge_topk: bad arguments");
     if (nq == 0) return CVTMI_OK;
     hipStream_t st = (hipStream_t)stream;

@@ -19,13 +19,13 @@ constexpr int MERGE_R = 4;
 // GATHERED = false: candidate i of query q sits at in_d[q * n_cand + i].
 // GATHERED = true : the all-gather layout of the row-sharded search -- list r (one per rank, k entries) of query q sits at
 //                   in_d[r * stride_d + q * k + j] / in_id[r * stride_id + q * k + j], i = r * k + j.
-template <bool GATHERED>
+template <bool GATHERED, int CAP = MERGE_CAP, int TRIG = MERGE_TRIG>
 __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restrict__ in_d,
                                                             const int64_t *__restrict__ in_id, int n_cand, int k,
                                                             float *__restrict__ out_d, int64_t *__restrict__ out_id,
                                                             int64_t stride_d, int64_t stride_id, const uint32_t *__restrict__ only_if)
 {
-    __shared__ TopKShared<1, MERGE_CAP> tk;
+    __shared__ TopKShared<1, CAP> tk;
     const int64_t q = blockIdx.x;
     if (only_if && only_if[q] == 0) return;   // (workgroup-uniform)
     const int tid = threadIdx.x;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restr
                 key[r][0] = kk == KEY_MAX ? KEY_MAX - 1 : kk;  // keep the "not a candidate" code free
             }
         }
-        topk_tile<1, MERGE_R, MERGE_CAP, MERGE_TRIG>(tk, k, tile, key, pay);
+        topk_tile<1, MERGE_R, CAP, TRIG>(tk, k, tile, key, pay);
     }
     __syncthreads();
     topk_compact(tk, k);
@@ -73,10 +73,14 @@ int launch_topk_merge_gathered(const float *in_d, const int64_t *in_id, int64_t 
                                float *out_d, int64_t *out_id, hipStream_t st)
 {
     if (nq <= 0) return CVTMI_OK;
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "topk: k=%d outside 1..128", k);
+    if (k < 1 || k > kBigK) return fail(CVTMI_EUNSUPPORTED, "topk: k=%d outside 1..%d", k, kBigK);
     if (L < 1 || (int64_t)L * k > 0x7fffffff || nq > 0x7fffffff) return fail(CVTMI_EINVAL, "topk_merge: bad list count %d", L);
-    hipLaunchKernelGGL(topk_merge_kernel<true>, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, L * k, k, out_d, out_id, stride_d,
-                       stride_id, (const uint32_t *)nullptr);
+    if (k > MERGE_TRIG / 2)
+        hipLaunchKernelGGL((topk_merge_kernel<true, kBigCap, kBigTrig>), dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, L * k, k, out_d, out_id,
+                           stride_d, stride_id, (const uint32_t *)nullptr);
+    else
+        hipLaunchKernelGGL(topk_merge_kernel<true>, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, L * k, k, out_d, out_id, stride_d,
+                           stride_id, (const uint32_t *)nullptr);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
@@ -93,11 +97,15 @@ int launch_topk_select(const float *in_d, const int64_t *in_id, int64_t nq, int6
                        int64_t *out_id, hipStream_t st, const uint32_t *only_if)
 {
     if (nq <= 0) return CVTMI_OK;
-    if (k < 1 || k > 128) return fail(CVTMI_EUNSUPPORTED, "topk: k=%d outside 1..128", k);
+    if (k < 1 || k > kBigK) return fail(CVTMI_EUNSUPPORTED, "topk: k=%d outside 1..%d", k, kBigK);
     if (n_cand < 0 || n_cand > 0x7fffffff) return fail(CVTMI_EINVAL, "topk: bad candidate count");
     if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "topk: nq too large");
-    hipLaunchKernelGGL(topk_merge_kernel<false>, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, (int)n_cand, k, out_d, out_id,
-                       (int64_t)0, (int64_t)0, only_if);
+    if (k > MERGE_TRIG / 2)
+        hipLaunchKernelGGL((topk_merge_kernel<false, kBigCap, kBigTrig>), dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, (int)n_cand, k, out_d,
+                           out_id, (int64_t)0, (int64_t)0, only_if);
+    else
+        hipLaunchKernelGGL(topk_merge_kernel<false>, dim3((unsigned)nq), dim3(kBlock), 0, st, in_d, in_id, (int)n_cand, k, out_d, out_id,
+                           (int64_t)0, (int64_t)0, only_if);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

@@ -42,6 +42,10 @@ extern "C" {
 #endif
 
 #define CVTMI_VERSION 200 /* 0.2.0 */
+/* Largest k of the search entries (cvtmi_opq_search*, cvtmi_flat_search*, cvtmi_topk_*): searchKnn(query, k) and
+ * get_sort_results(score, num_show) of the reference take any k (brutoforce.hpp:73-93, opq/src/common.h:25-37).  k <= 128 runs on
+ * every kernel; 129 .. CVTMI_K_MAX on the exact kernels (one query per workgroup, 4096-entry selection buffer) -- slower per query. */
+#define CVTMI_K_MAX 2048
 
 typedef enum cvtmi_status {
     CVTMI_OK = 0,

@@ -66,6 +66,34 @@ def test_flat_seeded(amd, orc, metric, D):
     assert np.all(i5[:, 5:] == -1) and np.array_equal(i5[:, :5], orc.flat_search(metric, db[:5], q[:2], 5)[2])
 
 
+@pytest.mark.parametrize("metric,D", [(IP, 128), (L2F, 96), (L2F, 33), (L2U8, 512), (L2U8, 50)])
+def test_flat_any_k(amd, orc, metric, D):
+    """searchKnn(query, k) takes any k (brutoforce.hpp:73-93): 129 ... 2048 through the exact kernels with the large selection buffer,
+    one query and a batch, duplicate rows, k larger than the index"""
+    rng = np.random.default_rng(metric * 1000 + D)
+    n, nq = 12000 + 3, 9
+    if metric == L2U8:
+        db = rng.integers(0, 256, size=(n, D), dtype=np.uint8); q = rng.integers(0, 256, size=(nq, D), dtype=np.uint8)
+    else:
+        db = rng.normal(size=(n, D)).astype(np.float32); q = rng.normal(size=(nq, D)).astype(np.float32)
+    db[4000:4200] = db[10]; q[0] = db[10]
+    ix = amd.FlatIndex(metric, D); ix.add(db)
+    for k in (129, 700, 2048):
+        od, odi, oi = orc.flat_search(metric, db, q, k)
+        for qq, sl in ((q, slice(None)), (q[:1], slice(0, 1))):
+            d, i = ix.search(qq, k)
+            assert np.array_equal(i, oi[sl]), (k, len(qq))
+            if metric == L2U8:
+                assert np.array_equal(d, odi[sl])
+            else:
+                assert np.array_equal(bits(d), bits(od[sl]))
+    small = amd.FlatIndex(metric, D); small.add(db[:150])
+    d, i = small.search(q[:2], 400)
+    assert np.all(i[:, 150:] == -1) and np.array_equal(i[:, :150], orc.flat_search(metric, db[:150], q[:2], 150)[2])
+    with pytest.raises(amd.CvtmiError):
+        ix.search(q, 2049)
+
+
 @pytest.mark.parametrize("D,nq,k", [(512, 200, 10), (512, 70, 16), (256, 100, 40), (128, 40, 48), (512, 150, 100),
                                      (64, 300, 1), (512, 33, 5), (96, 129, 12), (512, 5, 10), (128, 7, 128)])
 def test_flat_u8_mfma_query_tiles(amd, orc, D, nq, k):

@@ -244,7 +244,9 @@ def test_search_edge_cases(amd, orc):
             assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od)), (variant, splits)
     # error path: k out of range is refused, not truncated
     with pytest.raises(amd.CvtmiError):
-        idx.search(q, 129, rotate=False)
+        idx.search(q, 2049, rotate=False)
+    with pytest.raises(amd.CvtmiError):
+        idx.search(q, 0, rotate=False)
 
 
 def test_two_region_scan_plan(amd, orc):
@@ -552,3 +554,33 @@ def test_scan_h_item_tables(amd, orc):
     finally:
         amd.set_tuning("scanh_balance", 0); amd.set_tuning("scanh_min_rows", 16384)
         idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [16, 8])
+def test_search_any_k(amd, orc, M):
+    """k beyond 128 (get_sort_results(score, num_show) takes any, opq/src/common.h:25-37): 129 ... 2048 through the exact kernel with
+    the large selection buffer -- row splits, ties straddling them, k larger than a split and larger than the index"""
+    D, K = 128, 256
+    rng = np.random.default_rng(900 + M)
+    books = synth_model(rng, D, M, K, scale=0.1)
+    n = 30000 + 7
+    codes = rng.integers(0, K, size=(n, M), dtype=np.uint8)
+    codes[100] = codes[50]; codes[29000] = codes[50]; codes[12000:12300] = codes[77]
+    q = (rng.normal(size=(6, D)) * 0.1).astype(np.float32)
+    q[1] = np.concatenate([books[m, codes[77][m]] for m in range(M)])   # 300 exact ties at the top
+    idx = amd.OpqIndex(np.zeros((1, D), np.float32), books)
+    idx.add_codes(codes)
+    for k in (129, 500, 1000, 2048):
+        od, oi = orc.adc_search(q, books, codes, k)
+        for variant, splits in ((7, 0), (3, 1), (6, 3), (0, 7), (0, 64)):
+            idx.set_param("scan_variant", variant); idx.set_param("splits", splits)
+            d, i = idx.search(q, k, rotate=False)
+            assert np.array_equal(i, oi), (k, variant, splits)
+            assert np.array_equal(bits(d), bits(od)), (k, variant, splits)
+    idx.reset(); idx.add_codes(codes[:300])                                   # k > rows: padded with (+inf, -1)
+    idx.set_param("scan_variant", 7); idx.set_param("splits", 0)
+    d, i = idx.search(q, 1000, rotate=False)
+    od, oi = orc.adc_search(q, books, codes[:300], 300)
+    assert np.array_equal(i[:, :300], oi) and np.all(i[:, 300:] == -1) and np.all(np.isinf(d[:, 300:]))
+    idx.close()

@@ -107,7 +107,7 @@ def test_multi_rank_one_gpu_matches_single_handle(world, n, nq, tmp_path, orc):
     import torch
     import cvt_amd
     books, codes, q = _case(100 + world + n, n, nq, dup=2)
-    ks = [1, 10, 100]
+    ks = [1, 10, 100] + ([300, 1000] if n in (100_001, 300) else [])   # beyond 128: the exact kernels, incl. k > rows per shard
     case = str(tmp_path / "case.npz")
     np.savez(case, books=books, codes=codes, q=q, ks=np.array(ks))
     port = _free_port()
