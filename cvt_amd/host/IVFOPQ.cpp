@@ -374,7 +374,9 @@ std::vector<std::pair<float, unsigned> > get_sort_results(const std::vector<floa
     const int n = (int)match_score.size();
     std::vector<std::pair<float, unsigned> > t(results_per_query > 0 ? results_per_query : 0);
     if (n == 0 || results_per_query <= 0) return t;
-    const int k = results_per_query > 128 ? 128 : results_per_query;
+    // (the device selection takes k <= CVTMI_K_MAX = 2048; entries beyond stay value-initialised, as the reference's partial_sort_copy
+    //  leaves those beyond match_score.size())
+    const int k = results_per_query > CVTMI_K_MAX ? CVTMI_K_MAX : results_per_query;
     std::vector<float> od(k);
     std::vector<int64_t> oi(k);
     if (cvtmi_topk_select(match_score.data(), 1, n, k, od.data(), oi.data()) != CVTMI_OK) {
