@@ -57,11 +57,44 @@ struct ScanHArgs {
     int seed;
 };
 
+// minimum / maximum over the wave in the DPP network (no LDS traffic; __shfl_xor is a ds_bpermute, a dependent LDS round trip per step:
+// the 384 of them a thread of the table kernel used to issue were 18 of its 37 us).  Result in every lane.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    const int id = (int)0xffffffffu;
+#define CVTMI_DPP_MIN(ctrl, rmask) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, ctrl, rmask, 0xf, false); v = t < v ? t : v; }
+    CVTMI_DPP_MIN(0x111, 0xf) CVTMI_DPP_MIN(0x112, 0xf) CVTMI_DPP_MIN(0x114, 0xf) CVTMI_DPP_MIN(0x118, 0xf)
+    CVTMI_DPP_MIN(0x142, 0xa) CVTMI_DPP_MIN(0x143, 0xc)
+#undef CVTMI_DPP_MIN
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#define CVTMI_DPP_MAX(ctrl, rmask) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false); v = t > v ? t : v; }
+    CVTMI_DPP_MAX(0x111, 0xf) CVTMI_DPP_MAX(0x112, 0xf) CVTMI_DPP_MAX(0x114, 0xf) CVTMI_DPP_MAX(0x118, 0xf)
+    CVTMI_DPP_MAX(0x142, 0xa) CVTMI_DPP_MAX(0x143, 0xc)
+#undef CVTMI_DPP_MAX
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+#ifdef CVTMI_SCAN_TIMING
+static __device__ unsigned long long g_prep_dbg[8];
+#define PREP_T(i) do { if (threadIdx.x == 0) { const unsigned long long n__ = clock64(); atomicAdd(&g_prep_dbg[i], n__ - pt__); pt__ = n__; } } while (0)
+#define PREP_T0() unsigned long long pt__ = clock64()
+#else
+#define PREP_T(i) do { } while (0)
+#define PREP_T0() do { } while (0)
+#endif
 // ---- tables of one query group, once: fp32 (IVFOPQ.cpp:279-291 arithmetic) + the quantised LDS image + its parameters ----
+// rot_R / rot_perm (at most one non-null): q_rot holds the RAW queries and the rotation is applied here -- y[i] = the k-ordered fmaf
+// chain over R[i][k] x[k] (the arithmetic of the MFMA rotation kernel, rotate.hip) or x[perm[i]] (IVFOPQ.cpp:424-439): the small-batch
+// path saves a launch.  zero / zero_words: a scratch area cleared by workgroup 0 (the small-batch path's counters and histograms).
 __global__ __launch_bounds__(1024) void scan16h_prep_kernel(const float *__restrict__ q_rot, int nq, int D, int step, int K,
                                                             const float *__restrict__ books, const float *__restrict__ centroid,
                                                             float *__restrict__ lut_g, uint4 *__restrict__ qlut,
-                                                            QuantParams *__restrict__ qp_g, int lazy_on)
+                                                            QuantParams *__restrict__ qp_g, int lazy_on,
+                                                            const float *__restrict__ rot_R = nullptr, const int32_t *__restrict__ rot_perm = nullptr,
+                                                            uint32_t *__restrict__ zero = nullptr, int zero_words = 0)
 {
     constexpr int NT = 1024, M = 16, QT = SQ_QT;
     __shared__ __attribute__((aligned(16))) uint4 stage[256 * 16];
@@ -70,18 +103,71 @@ __global__ __launch_bounds__(1024) void scan16h_prep_kernel(const float *__restr
     __shared__ uint32_t mx_bits[QT][16];
     __shared__ int nonfinite[QT];
     const int tid = threadIdx.x, lane = tid & 63, group = blockIdx.x;
-    for (int i = tid; i < QT * D; i += NT) {
-        const int q = i / D, d = i - q * D;
-        int qi = group * QT + q;
-        qi = qi < nq ? qi : nq - 1;  // ragged last group: the last query again (its slots are never reported)
-        res[q * 256 + d] = __fsub_rn(q_rot[(int64_t)qi * D + d], centroid[d]);
+    PREP_T0();
+    if (rot_R) {
+        // R (D <= 128: 64 KB) and the raw queries go through LDS: entry (i, k) of R sits at i * D + ((k + i) & (D - 1)), so the lanes
+        // of a wave (consecutive i) read column k from different banks; the k-ordered fmaf chain per output is the arithmetic of the
+        // MFMA rotation kernel (rotate.hip).  (Read straight from memory, lane i streaming row i, the chain cost 90 us.)
+        float *Rs = reinterpret_cast<float *>(stage);   // the stage area is not needed before the quantised image is built
+        {   // (all loads first: one load, one wait, one store at a time this loop alone took 16 us of a workgroup running by itself)
+            constexpr int R4 = 128 * 128 / 4 / NT;   // float4 pieces per thread at D = 128
+            float4 rv[R4];
+            const int n4 = D * D / 4, dsh = 31 - __clz(D);   // D is a power of two (scans_fuses_rotation)
+#pragma unroll
+            for (int j = 0; j < R4; ++j) rv[j] = tid + j * NT < n4 ? reinterpret_cast<const float4 *>(rot_R)[tid + j * NT] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < R4; ++j) {
+                const int e = 4 * (tid + j * NT);
+                if (e < D * D) {
+                    const int i = e >> dsh, kk = e & (D - 1);
+                    const float v4[4] = { rv[j].x, rv[j].y, rv[j].z, rv[j].w };
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) Rs[i * D + ((kk + t + i) & (D - 1))] = v4[t];
+                }
+            }
+        }
+        for (int i = tid; i < QT * D; i += NT) {
+            const int q = i / D, d = i - q * D;
+            int qi = group * QT + q;
+            qi = qi < nq ? qi : nq - 1;
+            res[q * 256 + d] = q_rot[(int64_t)qi * D + d];   // raw, for now
+        }
+        __syncthreads();
+        float y[(QT * 256 + NT - 1) / NT];
+        int cnt = 0;
+        for (int i = tid; i < QT * D; i += NT, ++cnt) {
+            const int q = i / D, d = i - q * D;
+            float acc = 0.0f;
+#pragma unroll 8
+            for (int kk = 0; kk < D; ++kk) acc = __fmaf_rn(Rs[d * D + ((kk + d) & (D - 1))], res[q * 256 + kk], acc);
+            y[cnt] = acc;
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int i = tid; i < QT * D; i += NT, ++cnt) {
+            const int q = i / D, d = i - q * D;
+            res[q * 256 + d] = __fsub_rn(y[cnt], centroid[d]);
+        }
+        __syncthreads();
+    } else {
+        for (int i = tid; i < QT * D; i += NT) {
+            const int q = i / D, d = i - q * D;
+            int qi = group * QT + q;
+            qi = qi < nq ? qi : nq - 1;  // ragged last group: the last query again (its slots are never reported)
+            const float *x = q_rot + (int64_t)qi * D;
+            const float y = rot_perm ? x[rot_perm[d]] : x[d];
+            res[q * 256 + d] = __fsub_rn(y, centroid[d]);
+        }
     }
+    if (zero && blockIdx.x == 0)
+        for (int i = tid; i < zero_words; i += NT) zero[i] = 0u;
     if (tid < QT * 16) {
         qp.mn_bits[tid >> 4][tid & 15] = 0x7f7fffffu;
         mx_bits[tid >> 4][tid & 15] = 0u;
     }
     if (tid < QT) nonfinite[tid] = 0;
     __syncthreads();
+    PREP_T(0);  // queries in (rotated)
     float acc[4][QT];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -90,12 +176,26 @@ __global__ __launch_bounds__(1024) void scan16h_prep_kernel(const float *__restr
             const float *cb = books + ((int64_t)m * K + j) * step;
 #pragma unroll
             for (int q = 0; q < QT; ++q) acc[i][q] = 0.0f;
-            for (int kk = 0; kk < step; ++kk) {
-                const float c = cb[kk];
+            if (step == 8) {  // the usual sub-vector: the centroid in two 16-byte loads (a dword at a time, each waited for, the eight
+                              // loads of a pair were most of this kernel's 39 us when one workgroup runs alone)
+                const float4 c0 = reinterpret_cast<const float4 *>(cb)[0], c1 = reinterpret_cast<const float4 *>(cb)[1];
+                const float cv[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
 #pragma unroll
-                for (int q = 0; q < QT; ++q) {
-                    const float t = __fsub_rn(res[q * 256 + m * step + kk], c);
-                    acc[i][q] = __fadd_rn(acc[i][q], __fmul_rn(t, t));
+                for (int kk = 0; kk < 8; ++kk) {
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) {
+                        const float t = __fsub_rn(res[q * 256 + m * 8 + kk], cv[kk]);
+                        acc[i][q] = __fadd_rn(acc[i][q], __fmul_rn(t, t));
+                    }
+                }
+            } else {
+                for (int kk = 0; kk < step; ++kk) {
+                    const float c = cb[kk];
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) {
+                        const float t = __fsub_rn(res[q * 256 + m * step + kk], c);
+                        acc[i][q] = __fadd_rn(acc[i][q], __fmul_rn(t, t));
+                    }
                 }
             }
         } else {
@@ -110,19 +210,17 @@ __global__ __launch_bounds__(1024) void scan16h_prep_kernel(const float *__restr
             uint32_t lo = bits < 0x7f800000u ? bits : 0x7f7fffffu;  // non-finite: ignored
             uint32_t hi = bits < 0x7f800000u ? bits : 0u;
             if (__ballot(bits >= 0x7f800000u) != 0 && lane == 0) nonfinite[q] = 1;  // (the +inf padding past K counts: a code >= K reaches it)
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const uint32_t l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
-                lo = l2 < lo ? l2 : lo;
-                hi = h2 > hi ? h2 : hi;
-            }
+            lo = wave_min_u32(lo);
+            hi = wave_max_u32(hi);
             if (lane == 0) {
                 atomicMin(&qp.mn_bits[q][m], lo);
                 atomicMax(&mx_bits[q][m], hi);
             }
         }
     }
+    PREP_T(1);  // table entries, fp32 tables out, ranges
     __syncthreads();
+    PREP_T(2);
     if (tid < QT) {  // scale, bias, lazy-selection band: as scan16q_build_tables (adc_scan.hip)
         const int q = tid;
         float range = 0.0f;
@@ -163,12 +261,14 @@ __global__ __launch_bounds__(1024) void scan16h_prep_kernel(const float *__restr
         }
         stage[j * 16 + m] = make_uint4(qv[0] | (qv[1] << 16), qv[2] | (qv[3] << 16), qv[4] | (qv[5] << 16), qv[6] | (qv[7] << 16));
     }
+    PREP_T(3);  // scales + quantisation into the stage
     __syncthreads();
     uint4 *dst = qlut + (size_t)group * 4096;
     for (int i = tid; i < 4096; i += NT) dst[i] = stage[i];
     static_assert(sizeof(QuantParams) % 4 == 0, "QuantParams is copied word by word");
     if (tid < (int)(sizeof(QuantParams) / 4))
         reinterpret_cast<uint32_t *>(qp_g + group)[tid] = reinterpret_cast<const uint32_t *>(&qp)[tid];
+    PREP_T(4);  // image out
 }
 
 // control words of one workgroup
@@ -680,6 +780,369 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
     SQ_TEND();
 }
 
+// =====================================================================================================================
+// Small batches (1 .. 8 queries: the reference's own call pattern is 1-9 query frames per Query, multi_frame_index_test.cpp:45-54).
+//
+// One query group cannot amortise adc_scan16h's per-segment costs: with the rows cut into a few hundred segments every segment
+// would warm its bounds up on its own (~500 candidates per query each).  Here the bound is global and comes first:
+//   scan16s_hist_kernel     G workgroups, each over its row block: integer sums of every 4th 64-row chunk into a histogram per
+//                           query (bin = sum >> 7), added to one global histogram.  The first bin at which the cumulative count
+//                           reaches k proves k rows below its edge, so T = edge + slack admits every row that can be among the
+//                           k best (the lazy-selection argument, adc_scan16.h) -- about 4 k rows pass it.
+//   scan16s_collect_kernel  the same row blocks again, all chunks, against T: the rows below it go to one global list per query
+//                           (one atomic per wave and query).  The workgroup that finishes last selects: k-th smallest integer
+//                           sum of the list by two histogram passes, exact reference-order sums of the rows within `slack` of
+//                           it, sort, results.  A list that overflows (masses of equal rows) or a query whose sums bound nothing
+//                           (non-finite tables) is answered by that workgroup with an exact pass over all rows.
+// Three launches with scan16h_prep_kernel (rotation folded in), none of them waiting for another workgroup.
+// =====================================================================================================================
+static int scanh_slots();
+constexpr int SS_WCAP = 64;        // candidates per (workgroup, query) of the collect pass; more: the query takes the exact fall-back
+constexpr int SS_NMAX = 2048;      // candidates per query the selection takes (LDS); more: exact fall-back
+constexpr int SS_SAMPLE_SHIFT = 2; // the histogram pass looks at every 4th chunk
+// scratch words: [0, 2048) histograms, [2048, 2056) the bounds T (written by workgroup 0 of the collect pass)
+constexpr int SS_WORDS = SQ_QT * SH_BINS + SQ_QT + 8;
+
+struct ScanSArgs {
+    const uint8_t *codes, *codes_rot;
+    int64_t n_rows, id_base, rows_per_wg, rows_per_hist_wg;
+    int nq, k, K, G;              // G = workgroups of the collect pass
+    const uint4 *qlut;
+    const QuantParams *qp_g;
+    const float *lut_g;
+    uint32_t *ctl;                // SS_WORDS, zeroed by the prep kernel
+    uint32_t *wcnt;               // [G][8]: candidates workgroup g found for query q (> SS_WCAP: it dropped some)
+    unsigned long long *gcand;    // [G][8][SS_WCAP]
+    float *out_d;
+    int64_t *out_id;
+    int dbg;   // timing experiments (results wrong when non-zero): 1 = no selection, 2 = no row pass either
+};
+
+template <bool PREROT>
+__global__ __launch_bounds__(1024) void scan16s_hist_kernel(const ScanSArgs a)   // (one workgroup per CU: 128 registers per lane)
+{
+    constexpr int NT = 1024, QT = SQ_QT;
+    __shared__ __attribute__((aligned(16))) uint32_t lut[256 * 16 * QT / 2];
+    __shared__ uint32_t hist[QT][SH_BINS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        uint4 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = a.qlut[tid + i * NT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) reinterpret_cast<uint4 *>(lut)[tid + i * NT] = t[i];
+    }
+    for (int i = tid; i < QT * SH_BINS; i += NT) (&hist[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t c = tid & 15, cr8 = (c & 3) * 8, cq = c >> 2;
+    uint32_t moffp[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        moffp[w] = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) moffp[w] |= (((4 * w + b + c) & 15u) * 16u) << (8 * b);
+    }
+    const char *lut_b = reinterpret_cast<const char *>(lut);
+    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_hist_wg;
+    int64_t r1 = r0 + a.rows_per_hist_wg;
+    r1 = r1 < a.n_rows ? r1 : a.n_rows;
+    const uint4 *rows = reinterpret_cast<const uint4 *>(PREROT ? a.codes_rot : a.codes);
+    for (int64_t base = r0 + ((int64_t)wave << (6 + SS_SAMPLE_SHIFT)); base < r1; base += (int64_t)(NT / 64) << (6 + SS_SAMPLE_SHIFT)) {
+        const int64_t row = base + lane;
+        const uint4 v = rows[row < r1 ? row : r1 - 1];
+        uint32_t sm[4];
+        scan16q_row_sums<PREROT>(v, moffp, cr8, cq, lut_b, sm[0], sm[1], sm[2], sm[3]);
+        if (row < r1) {
+#pragma unroll
+            for (int q = 0; q < QT; ++q) atomicAdd(&hist[q][((sm[q >> 1] >> (16 * (q & 1))) & 0xffffu) >> 7], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < QT * SH_BINS; i += NT) {
+        const uint32_t v = (&hist[0][0])[i];
+        if (v) atomicAdd(&a.ctl[i], v);
+    }
+}
+
+// exact answer of ONE query by the calling workgroup alone: every row, fp32 sums in the reference's order from the query's table
+// (IVFOPQ.cpp:302-306), k smallest (distance, id) through block_topk.h -- the fall-back of the small-batch path.  lds: >= 16 KB of
+// table + the selection buffer; ends with the results written.
+template <int NT>
+__device__ void scans_exact_query(const ScanSArgs &a, int q, uint32_t *lds)
+{
+    constexpr int CAPX = 384, TRIGX = 256, RX = 2;
+    float *lutf = reinterpret_cast<float *>(lds);
+    TopKShared<1, CAPX> &tk = *reinterpret_cast<TopKShared<1, CAPX> *>(lds + 16 * 256);
+    const int tid = threadIdx.x;
+    __syncthreads();
+    for (int i = tid; i < 16 * 256; i += NT) lutf[i] = a.lut_g[(int64_t)q * 16 * 256 + i];
+    topk_init(tk);
+    __syncthreads();
+    const uint4 *rows = reinterpret_cast<const uint4 *>(a.codes);
+    int tile = 0;
+    for (int64_t base = 0; base < a.n_rows; base += (int64_t)NT * RX, ++tile) {
+        uint32_t key[RX][1], pay[RX];
+#pragma unroll
+        for (int r = 0; r < RX; ++r) {
+            const int64_t row = base + r * NT + tid;
+            const bool valid = row < a.n_rows;
+            const uint4 cw = rows[valid ? row : 0];
+            const uint32_t w[4] = { cw.x, cw.y, cw.z, cw.w };
+            float sum = 0.0f;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) sum = __fadd_rn(sum, lutf[m * 256 + ((w[m >> 2] >> (8 * (m & 3))) & 0xffu)]);
+            pay[r] = (uint32_t)row;
+            key[r][0] = valid ? __float_as_uint(sum) : KEY_MAX;  // sums are >= +0
+        }
+        topk_tile<1, RX, CAPX, TRIGX, NT>(tk, a.k, tile, key, pay);
+    }
+    __syncthreads();
+    topk_compact<1, CAPX, NT>(tk, a.k);
+    const int cnt = tk.cnt[0];
+    for (int i = tid; i < a.k; i += NT) {
+        if (i < cnt) {
+            const unsigned long long e = tk.buf[0][i];
+            a.out_d[(int64_t)q * a.k + i] = __uint_as_float((uint32_t)(e >> 32));
+            a.out_id[(int64_t)q * a.k + i] = a.id_base + (int64_t)(uint32_t)e;
+        } else {
+            a.out_d[(int64_t)q * a.k + i] = __uint_as_float(0x7f800000u);
+            a.out_id[(int64_t)q * a.k + i] = -1;
+        }
+    }
+    __syncthreads();
+}
+
+// the rows of the workgroup's block below the bounds -> its own candidate lists (no global atomic: 256 workgroups bumping eight shared
+// counters, and one "who is last" ticket, cost 70 us of a 130 us kernel)
+template <bool PREROT>
+__global__ __launch_bounds__(1024) void scan16s_collect_kernel(const ScanSArgs a)
+{
+    constexpr int NT = 1024, QT = SQ_QT;
+    __shared__ __attribute__((aligned(16))) uint32_t lut[256 * 16 * QT / 2];
+    __shared__ __attribute__((aligned(16))) uint32_t hist[QT][SH_BINS];
+    __shared__ QuantParams qp;
+    __shared__ uint32_t T[QT], tpk_s[QT / 2];
+    __shared__ uint32_t cnt[QT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        uint4 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = a.qlut[tid + i * NT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) reinterpret_cast<uint4 *>(lut)[tid + i * NT] = t[i];
+    }
+    if (tid < (int)(sizeof(QuantParams) / 4)) reinterpret_cast<uint32_t *>(&qp)[tid] = reinterpret_cast<const uint32_t *>(a.qp_g)[tid];
+    for (int i = tid; i < QT * SH_BINS; i += NT) (&hist[0][0])[i] = a.ctl[i];
+    if (tid < QT) cnt[tid] = 0;
+    __syncthreads();
+    if (wave < QT) {  // the bound of query `wave` from the global histogram (a sample: every 4th chunk of every row block)
+        const uint32_t sl = qp.slack[wave];
+        uint32_t t = sl ? scanh_hist_bound(hist[wave], a.k, sl) : 0xffffffffu;
+        if (t > 32767u) t = 32767u;  // fewer than k rows sampled, or sums that bound nothing: every row is a candidate
+        if (lane == 0) {
+            T[wave] = t;
+            if (blockIdx.x == 0) a.ctl[QT * SH_BINS + wave] = t;   // for the selection kernel
+        }
+    }
+    __syncthreads();
+    if (tid < QT / 2) tpk_s[tid] = T[2 * tid] | (T[2 * tid + 1] << 16);
+    __syncthreads();
+    const uint32_t c = tid & 15, cr8 = (c & 3) * 8, cq = c >> 2;
+    uint32_t moffp[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        moffp[w] = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) moffp[w] |= (((4 * w + b + c) & 15u) * 16u) << (8 * b);
+    }
+    const char *lut_b = reinterpret_cast<const char *>(lut);
+    uint32_t tpk[QT / 2];
+#pragma unroll
+    for (int i = 0; i < QT / 2; ++i) tpk[i] = tpk_s[i];
+    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_wg;
+    int64_t r1 = r0 + a.rows_per_wg;
+    r1 = r1 < a.n_rows ? r1 : a.n_rows;
+    const uint4 *rows = reinterpret_cast<const uint4 *>(PREROT ? a.codes_rot : a.codes);
+    unsigned long long *mine = a.gcand + (size_t)blockIdx.x * QT * SS_WCAP;
+    for (int64_t base = r0 + ((int64_t)wave << 6); base < r1 && a.dbg < 2; base += NT) {
+        const int64_t row = base + lane;
+        const uint4 v = rows[row < r1 ? row : r1 - 1];
+        uint32_t s4[4];
+        scan16q_row_sums<PREROT, 16>(v, moffp, cr8, cq, lut_b, s4[0], s4[1], s4[2], s4[3]);
+        uint32_t d4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d4[i] = pk_sub_i16(s4[i], tpk[i]);
+        const bool inr = row < r1;
+        if (__ballot(inr && ((d4[0] | d4[1] | d4[2] | d4[3]) & 0x80008000u) != 0) == 0) continue;  // wave-uniform
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            const bool cand = inr && ((q & 1) ? (int32_t)d4[q >> 1] < 0 : (d4[q >> 1] & 0x8000u) != 0);
+            const unsigned long long m = __ballot(cand);
+            if (!m) continue;  // scalar
+            uint32_t basep = 0;
+            if (lane == 0) basep = atomicAdd(&cnt[q], (uint32_t)__popcll(m));   // LDS
+            basep = (uint32_t)__builtin_amdgcn_readfirstlane((int)basep);
+            const uint32_t pos = basep + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (cand && pos < (uint32_t)SS_WCAP) {
+                const uint32_t sq = (q & 1) ? s4[q >> 1] >> 16 : s4[q >> 1] & 0xffffu;
+                mine[q * SS_WCAP + pos] = ((unsigned long long)sq << 32) | (uint32_t)row;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < QT) a.wcnt[(size_t)blockIdx.x * QT + tid] = cnt[tid];
+}
+
+// one workgroup per query: the candidates of all collect workgroups, the k-th smallest integer sum among them (two histogram
+// passes), exact reference-order sums of the rows within `slack` of it, sort, results -- or, when a workgroup dropped candidates
+// (masses of equal rows), the list is too long, or the query's sums bound nothing (non-finite tables), the exact pass over all rows
+// (the launch bounds of adc_scan16h_kernel: the out-of-line selection code is shared with it, and the callee is compiled for the loosest
+//  bound among its callers -- with 128 registers allowed here the scan kernel grew to 120 and lost its second workgroup per CU: +15 %)
+__global__ __launch_bounds__(1024, 8) void scan16s_select_kernel(const ScanSArgs a)
+{
+    constexpr int NT = 1024, QT = SQ_QT;
+    using TopK = TopKShared<QT, SQ_CAP>;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[16 * 256 + 1024];   // exact fall-back: table + selection buffer
+    __shared__ __attribute__((aligned(16))) unsigned long long cand[SS_NMAX];
+    __shared__ __attribute__((aligned(16))) uint32_t h[SH_BINS];
+    __shared__ TopK tk;
+    __shared__ QuantParams qp;
+    __shared__ uint32_t off[1024 + 1];
+    __shared__ int s_slow;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
+    if (a.dbg) return;
+    if (tid < (int)(sizeof(QuantParams) / 4)) reinterpret_cast<uint32_t *>(&qp)[tid] = reinterpret_cast<const uint32_t *>(a.qp_g)[tid];
+    // candidates per collect workgroup (G <= 1024) -> exclusive offsets
+    uint32_t c = tid < a.G ? a.wcnt[(size_t)tid * QT + q] : 0u;
+    const bool dropped = c > (uint32_t)SS_WCAP;
+    off[tid] = c;
+    if (tid == 0) s_slow = 0;
+    __syncthreads();
+    if (dropped) s_slow = 1;
+    if (tid == 0) {   // (G values: a serial prefix is a few microseconds at most; workgroups are few)
+        uint32_t run = 0;
+        for (int g = 0; g < a.G; ++g) { const uint32_t v = off[g]; off[g] = run; run += v; }
+        off[a.G] = run;
+    }
+    __syncthreads();
+    const uint32_t n = off[a.G];
+    const uint32_t Tq = a.ctl[QT * SH_BINS + q];
+    if (s_slow || n > (uint32_t)SS_NMAX || Tq >= 32767u) {   // workgroup-uniform
+        scans_exact_query<NT>(a, q, lds);
+        return;
+    }
+    if (tid < a.G) {
+        const unsigned long long *src = a.gcand + ((size_t)tid * QT + q) * SS_WCAP;
+        for (uint32_t j = 0; j < c; ++j) cand[off[tid] + j] = src[j];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    uint32_t Tsel = Tq;
+    if ((int)n > a.k + 64 && qp.slack[q]) {
+        // k-th smallest integer sum of the list: bin of 128 by one histogram pass, position inside the bin by a second; rows at
+        // S_k + slack and beyond are beaten by k rows (adc_scan16.h), the few below it get exact sums
+        for (int i = lane; i < SH_BINS; i += 64) h[i] = 0;
+        for (uint32_t i = lane; i < n; i += 64) atomicAdd(&h[(uint32_t)(cand[i] >> 32) >> 7], 1u);
+        const uint4 cb = *reinterpret_cast<const uint4 *>(h + lane * 4);
+        const uint32_t mine = cb.x + cb.y + cb.z + cb.w, incl = wave_incl_scan_add(mine);
+        const unsigned long long reach = __ballot(incl >= (uint32_t)a.k);
+        if (reach) {
+            const int l0 = __ffsll((long long)reach) - 1;
+            uint32_t cum = (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), l0);
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cb.x, l0), c1 = (uint32_t)__builtin_amdgcn_readlane((int)cb.y, l0),
+                           c2 = (uint32_t)__builtin_amdgcn_readlane((int)cb.z, l0);
+            uint32_t b = (uint32_t)l0 * 4u;
+            if (cum + c0 < (uint32_t)a.k) { cum += c0; ++b; if (cum + c1 < (uint32_t)a.k) { cum += c1; ++b; if (cum + c2 < (uint32_t)a.k) { cum += c2; ++b; } } }
+            // cum rows lie below bin b; the k-th is the (k - cum)-th smallest inside it
+            for (int i = lane; i < 128; i += 64) h[i] = 0;
+            for (uint32_t i = lane; i < n; i += 64) {
+                const uint32_t sv = (uint32_t)(cand[i] >> 32);
+                if ((sv >> 7) == b) atomicAdd(&h[sv & 127u], 1u);
+            }
+            const uint32_t f0 = h[lane * 2], f1 = h[lane * 2 + 1];
+            const uint32_t inc2 = wave_incl_scan_add(f0 + f1);
+            const uint32_t need = (uint32_t)a.k - cum;
+            const unsigned long long r2 = __ballot(inc2 >= need);
+            if (r2) {
+                const int l2 = __ffsll((long long)r2) - 1;
+                const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)(inc2 - f0 - f1), l2);
+                const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)f0, l2);
+                const uint32_t sk = (b << 7) + (uint32_t)l2 * 2u + (before + g0 >= need ? 0u : 1u);
+                const uint32_t t2 = sk + qp.slack[q];
+                Tsel = t2 < Tsel ? t2 : Tsel;
+            }
+        }
+    }
+    const QuantThr thrx{ &qp };
+    const ExactFromLutBatch fixb{ reinterpret_cast<const uint4 *>(a.codes), a.lut_g, a.K, a.nq, 0 };
+    const int keep = scanh_select_q<true>(tk, q, a.k, cand, (int)n, 0, Tsel, fixb, thrx);
+    for (int i = lane; i < a.k; i += 64) {
+        if (i < keep) {
+            const unsigned long long e = tk.buf[q][i];
+            a.out_d[(int64_t)q * a.k + i] = __uint_as_float((uint32_t)(e >> 32));
+            a.out_id[(int64_t)q * a.k + i] = a.id_base + (int64_t)(uint32_t)e;
+        } else {
+            a.out_d[(int64_t)q * a.k + i] = __uint_as_float(0x7f800000u);
+            a.out_id[(int64_t)q * a.k + i] = -1;
+        }
+    }
+}
+
+static int g_scans_dbg = 0;
+void set_scans_dbg(int v) { g_scans_dbg = v; }
+constexpr int SS_GMAX = 1024;   // collect workgroups at most (the selection kernel's prefix over them)
+size_t scans_scratch_bytes()
+{
+    return ((size_t)SS_WORDS * 4 + 63) / 64 * 64 + (size_t)SS_GMAX * SQ_QT * 4 + (size_t)SS_GMAX * SQ_QT * SS_WCAP * sizeof(unsigned long long);
+}
+// the preparation kernel rotates in LDS: a dense R needs D a power of two <= 128 (64 KB); a permutation or no rotation: any D
+bool scans_fuses_rotation(const OpqModelDev &m) { return !m.R || (m.D <= 128 && m.D >= 4 && (m.D & (m.D - 1)) == 0); }
+bool scans_applies(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k)
+{
+    return m.M == 16 && m.D <= 256 && m.K >= 1 && m.K <= 256 && nq >= 1 && nq <= SQ_QT && k >= 1 && k <= 128 && n_rows >= 65536 && n_rows <= 0xfffffffeLL;
+}
+
+// q: RAW queries when rotate != 0 (the model's rotation is applied by the preparation kernel), rotated ones otherwise
+int launch_adc_scan_small(const OpqModelDev &m, const uint8_t *codes, const uint8_t *codes_rot, int64_t n_rows, int64_t id_base, const float *q,
+                          int rotate, int64_t nq, int k, float *dist, int64_t *ids, float *lut_g, void *qlut, void *qp_g, void *scratch, int lazy,
+                          hipStream_t st)
+{
+    if (!scans_applies(m, n_rows, nq, k)) return fail(CVTMI_EUNSUPPORTED, "adc_scan16s: shape not covered");
+    uint32_t *ctl = reinterpret_cast<uint32_t *>(scratch);
+    hipLaunchKernelGGL(scan16h_prep_kernel, dim3(1), dim3(1024), 0, st, q, (int)nq, m.D, m.step, m.K, m.books, m.coarse, lut_g,
+                       reinterpret_cast<uint4 *>(qlut), reinterpret_cast<QuantParams *>(qp_g), lazy, rotate ? m.R : nullptr, rotate ? m.perm : nullptr,
+                       ctl, SS_WORDS);   // (a dense rotation: D a power of two <= 128, checked by the caller through scans_fuses_rotation)
+    CVTMI_HIP(hipGetLastError());
+    ScanSArgs a;
+    a.codes = codes; a.codes_rot = codes_rot; a.n_rows = n_rows; a.id_base = id_base;
+    const int64_t grid = std::min<int64_t>(scanh_slots() / 2, (n_rows + 4095) / 4096);   // one workgroup per CU, at least 4096 rows each
+    a.rows_per_wg = ((n_rows + grid - 1) / grid + 255) / 256 * 256;                       // (whole groups of four chunks: the histogram's sample)
+    a.nq = (int)nq; a.k = k; a.K = m.K;
+    a.qlut = reinterpret_cast<const uint4 *>(qlut); a.qp_g = reinterpret_cast<const QuantParams *>(qp_g); a.lut_g = lut_g;
+    a.ctl = ctl;
+    char *sc = reinterpret_cast<char *>(scratch) + ((size_t)SS_WORDS * 4 + 63) / 64 * 64;
+    a.wcnt = reinterpret_cast<uint32_t *>(sc);
+    a.gcand = reinterpret_cast<unsigned long long *>(sc + (size_t)SS_GMAX * SQ_QT * 4);
+    a.out_d = dist; a.out_id = ids; a.dbg = g_scans_dbg;
+    const unsigned g = (unsigned)((n_rows + a.rows_per_wg - 1) / a.rows_per_wg);
+    a.G = (int)g;
+    // the histogram pass: few workgroups (every bin they share costs a global atomic each: 256 of them on ~240 hot bins took 70 us),
+    // each sampling every 4th chunk of a 1/32 slab
+    const int64_t hg = std::min<int64_t>(32, (n_rows + 16383) / 16384);
+    a.rows_per_hist_wg = ((n_rows + hg - 1) / hg + 255) / 256 * 256;
+    const unsigned gh = (unsigned)((n_rows + a.rows_per_hist_wg - 1) / a.rows_per_hist_wg);
+    if (codes_rot) {
+        hipLaunchKernelGGL((scan16s_hist_kernel<true>), dim3(gh), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL((scan16s_collect_kernel<true>), dim3(g), dim3(1024), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((scan16s_hist_kernel<false>), dim3(gh), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL((scan16s_collect_kernel<false>), dim3(g), dim3(1024), 0, st, a);
+    }
+    hipLaunchKernelGGL(scan16s_select_kernel, dim3((unsigned)nq), dim3(1024), 0, st, a);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side: the item table
 // ---------------------------------------------------------------------------------------------------------------------
@@ -920,6 +1383,13 @@ extern "C" int cvtmi_debug_scanh_timing(unsigned long long *out, int reset)
     unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_dbg), sizeof z) != hipSuccess) return -3;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_scan_dbg), z, sizeof z) != hipSuccess) return -3;
+    return 0;
+}
+extern "C" int cvtmi_debug_prep_timing(unsigned long long *out, int reset)
+{
+    unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prep_dbg), sizeof z) != hipSuccess) return -3;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_prep_dbg), z, sizeof z) != hipSuccess) return -3;
     return 0;
 }
 extern "C" int cvtmi_debug_scanh_counters(unsigned long long *out, int reset)

@@ -109,6 +109,7 @@ struct cvtmi_opq_s {
     int p_prerot = 1;  // adc_scan16q reads a pre-rotated copy of the code rows (+16 bytes of HBM per row)
     int p_tail = 1, p_groups_a = 0, p_splits_b = 0;  // two-region scan plan: on / forced shape (tests)
     int p_lazy = 1, p_share = 1;  // adc_scan16q: lazy selection between checkpoints; row splits share their thresholds
+    int p_small = 1;              // 1 .. 8 queries take the small-batch path (adc_scan_h.hip) when the library chooses the scan (scan_variant 7)
     static constexpr int kEvRing = 64;
     hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
     int ev_count = 0;  // scan launches recorded since the last cvtmi_opq_last_scan
@@ -410,6 +411,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         ++g_scanh_key;
         return CVTMI_OK;
     }
+    if (!strcmp(name, "scans_dbg")) { set_scans_dbg((int)value); return CVTMI_OK; }
     if (!strcmp(name, "opq_host_chunk")) {
         if (value < 0 || value > (1 << 24)) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: opq_host_chunk must be 0..2^24");
         g_host_chunks = (int)value;
@@ -881,7 +883,7 @@ static int opq_prepare(cvtmi_opq_t h, int64_t nq, int k, hipStream_t st)
 {
     {
         std::shared_lock<std::shared_timed_mutex> rd(h->rw);
-        if (h->n == 0 || !(h->m.M == 16 && h->p_prerot && opq_plan(h, nq, k).variant >= 3)) return CVTMI_OK;
+        if (h->n == 0 || !(h->m.M == 16 && h->p_prerot && (opq_plan(h, nq, k).variant >= 3 || scans_applies(h->m, h->n, nq, k)))) return CVTMI_OK;
         if (h->rot_n == h->n && h->codes_rot.cap >= (size_t)h->n * 16) return CVTMI_OK;
     }
     Serial serial(h->sync, st);
@@ -901,6 +903,35 @@ static int opq_search_leased(cvtmi_opq_t h, OpqScratch &S, const float *q, int64
 {
     if (h->n == 0)  // an empty index (e.g. a rank whose row block is empty): all padding, (+inf, -1)
         return launch_topk_select(nullptr, nullptr, nq, 0, k, dist, ids, st);
+    if (h->p_variant == 7 && h->p_splits == 0 && h->p_qtile == 0 && h->p_small && scans_applies(h->m, h->n, nq, k)) {
+        // 1 .. 8 queries: global bound first, candidate lists, selection by the last workgroup (adc_scan_h.hip) -- three launches,
+        // the rotation folded into the first
+        const uint8_t *crot = (h->m.M == 16 && h->p_prerot && h->rot_n == h->n && h->codes_rot.p) ? h->codes_rot.as<uint8_t>() : nullptr;
+        CVTMI_TRY(S.s_lut.reserve((size_t)8 * 16 * 256 * sizeof(float)));
+        CVTMI_TRY(S.s_qlut.reserve(scanh_qlut_bytes(nq)));
+        CVTMI_TRY(S.s_qp.reserve(scanh_qp_bytes(nq)));
+        CVTMI_TRY(S.s_spill.reserve(scans_scratch_bytes()));
+        int slot = 0;
+        if (h->p_profile) {
+            CVTMI_TRY(opq_profile_slot(h, &slot));
+            CVTMI_HIP(hipEventRecord(h->ev0[slot], st));
+        }
+        const float *qs = q;
+        int rot = rotate && (h->m.perm || h->m.R);
+        if (rot && !scans_fuses_rotation(h->m)) {   // a dense rotation wider than 128: the rotation kernel first
+            CVTMI_TRY(S.s_qrot.reserve((size_t)nq * h->m.D * sizeof(float)));
+            CVTMI_TRY(opq_rotate_impl(h, q, nq, S.s_qrot.as<float>(), st));
+            qs = S.s_qrot.as<float>(); rot = 0;
+        }
+        CVTMI_TRY(launch_adc_scan_small(h->m, h->codes.as<uint8_t>(), crot, h->n, h->id_base, qs, rot, nq, k, dist, ids, S.s_lut.as<float>(), S.s_qlut.p,
+                                        S.s_qp.p, S.s_spill.p, h->p_lazy, st));
+        if (h->p_profile) {
+            CVTMI_HIP(hipEventRecord(h->ev1[slot], st));
+            h->last_bytes = h->n * h->m.M;
+            h->last_qt = 8; h->last_splits = 1;
+        }
+        return CVTMI_OK;
+    }
     const float *q_rot = q;
     if (rotate && (h->m.perm || h->m.R)) {
         CVTMI_TRY(S.s_qrot.reserve((size_t)nq * h->m.D * sizeof(float)));
@@ -1175,6 +1206,7 @@ int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value)
     }
     if (!strcmp(name, "profile")) { h->p_profile = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "scan_lazy")) { h->p_lazy = value != 0; return CVTMI_OK; }
+    if (!strcmp(name, "scan_small")) { h->p_small = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "scan_share")) { h->p_share = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "encode_variant")) {
         if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_opq_set_param: encode_variant must be 0, 1 or 2");

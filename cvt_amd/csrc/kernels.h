@@ -92,6 +92,15 @@ int launch_adc_scan_h(const OpqModelDev &m, const uint8_t *codes, const uint8_t 
                       int64_t *part_id, float *out_d, int64_t *out_id, float *lut_g, void *qlut, void *qp_g, void *spill, uint32_t *gthr, int lazy, int seed,
                       hipStream_t st);
 int scan_seed_enabled();
+// adc_scan_h.hip: 1 .. 8 queries -- global bound from a histogram pass, candidate lists, selection by the last workgroup (3 launches,
+// the rotation of RAW queries folded into the first when rotate != 0)
+bool scans_applies(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k);
+bool scans_fuses_rotation(const OpqModelDev &m);
+void set_scans_dbg(int v);   // timing experiments, results wrong when non-zero   // else the caller rotates and passes rotate = 0
+size_t scans_scratch_bytes();
+int launch_adc_scan_small(const OpqModelDev &m, const uint8_t *codes, const uint8_t *codes_rot, int64_t n_rows, int64_t id_base, const float *q,
+                          int rotate, int64_t nq, int k, float *dist, int64_t *ids, float *lut_g, void *qlut, void *qp_g, void *scratch, int lazy,
+                          hipStream_t st);
 
 // ---- topk_merge.hip ----
 int launch_topk_merge(const float *in_d, const int64_t *in_id, int64_t nq, int L, int k, float *out_d, int64_t *out_id,

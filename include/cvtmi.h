@@ -184,6 +184,8 @@ int cvtmi_opq_query_video_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rot
  *                   persistent grid (two workgroups per CU) walks a host-built item table (cvtmi_opq_scan_plan); candidates go
  *                   to per-workgroup areas in HBM and are selected once per (row segment, query), the filter bounds come from
  *                   a histogram of the candidates' integer sums; takes any number of queries
+ *                   7 = (default) the library's choice: 6 where it measured ahead (500 ... 4000 queries on a cache-resident
+ *                   index), 3 elsewhere
  *   "prerotate"   1 (default) = variants 3 / 4 stream a copy of the code rows in which row r is rotated by r & 15
  *                 bytes (the lane skew of the conflict-free table reads), kept next to the rows: +16 bytes of HBM
  *                 per row, 12 VALU instructions fewer per row in the VALU-bound scan loop; 0 = rotate in registers
@@ -192,6 +194,9 @@ int cvtmi_opq_query_video_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rot
  *   "scan_lazy"   1 (default) = variants 3 / 4 select on their integer lower bounds between checkpoints and compute exact
  *                 reference-order sums once, for the rows still held at the end; 0 = exact sums at every checkpoint
  *   "scan_share"  1 (default) = the row splits of a query publish their filter thresholds to each other (variants 3 / 4)
+ *   "scan_small"  1 (default) = batches of 1 .. 8 queries (M = 16, >= 65 536 rows, k <= 128, "scan_variant" 7) take the small-batch
+ *                 path: a histogram pass over a quarter of the rows fixes one global bound per query, a second pass collects the
+ *                 rows below it, the workgroup that finishes last selects -- three launches, rotation included
  *   "groups_a", "splits_b"  force that two-region shape: the first groups_a query groups use "splits" row
  *                 splits, the others splits_b (> splits); 0 = planner's choice */
 int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value);

@@ -584,3 +584,68 @@ def test_search_any_k(amd, orc, M):
     od, oi = orc.adc_search(q, books, codes[:300], 300)
     assert np.array_equal(i[:, :300], oi) and np.all(i[:, 300:] == -1) and np.all(np.isinf(d[:, 300:]))
     idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rotation", ["dense", "perm", "none"])
+def test_small_batch_path(amd, orc, rotation):
+    """1 .. 8 queries (the reference's own call pattern: 1-9 query frames per Query) through the small-batch path -- rotation folded
+    into the table kernel, a global bound from a histogram pass, candidate lists, selection by the last workgroup -- against the oracle
+    and against the ordinary path: k = 1 .. 128, exact ties, a list that overflows (7000 copies of the query's nearest row: the exact
+    fall-back inside the kernel), a NaN query beside ordinary ones, appended rows, an id base, device and host pointers."""
+    import torch
+    from cvt_amd import synth
+    D, M, K = 128, 16, 256
+    rng = np.random.default_rng({"dense": 1, "perm": 2, "none": 3}[rotation])
+    books = synth_model(rng, D, M, K, scale=0.1)
+    kw = {}
+    if rotation == "dense":
+        kw["R"] = synth.random_rotation(D, seed=5)
+    elif rotation == "perm":
+        kw["perm"] = rng.permutation(D).astype(np.int32)
+    idx = amd.OpqIndex(np.zeros((1, D), np.float32), books, **kw)
+    n = 150_000 + 11
+    codes = rng.integers(0, K, size=(n, M), dtype=np.uint8)
+    codes[100] = codes[50]; codes[140_000] = codes[50]
+    idx.add_codes(codes[:90_000]); idx.add_codes(codes[90_000:])
+    idx.set_id_base(1 << 34)
+    q = (rng.normal(size=(8, D)) * 0.1).astype(np.float32)
+
+    def rot(x):
+        if rotation == "dense":
+            return orc.rotate_fma(kw["R"], x)
+        if rotation == "perm":
+            return x[:, kw["perm"]]
+        return x
+
+    for nq in (1, 2, 5, 8):
+        for k in (1, 10, 100, 128):
+            od, oi = orc.adc_search(rot(q[:nq]), books, codes, k)
+            for small in (1, 0):
+                idx.set_param("scan_small", small)
+                d, i = idx.search(q[:nq], k, rotate=True)
+                assert np.array_equal(i, oi + (1 << 34)), (nq, k, small)
+                assert np.array_equal(bits(d), bits(od)), (nq, k, small)
+            idx.set_param("scan_small", 1)
+            dd, ii = idx.search(torch.from_numpy(q[:nq]).cuda(), k, rotate=True)
+            assert np.array_equal(ii.cpu().numpy(), oi + (1 << 34)) and np.array_equal(bits(dd.cpu().numpy()), bits(od))
+    # a candidate list that overflows, and sums that bound nothing
+    idx.set_id_base(0)
+    crowd = codes.copy(); crowd[20_000:27_000] = codes[7]
+    idx.reset(); idx.add_codes(crowd)
+    q2 = q.copy()
+    raw7 = np.concatenate([books[m, codes[7][m]] for m in range(M)])            # the rotated point that sits on row 7's codewords
+    if rotation == "dense":
+        q2[3] = (kw["R"].T.astype(np.float64) @ raw7.astype(np.float64)).astype(np.float32)
+    elif rotation == "perm":
+        q2[3][kw["perm"]] = raw7
+    else:
+        q2[3] = raw7
+    q2[5, 17] = np.nan
+    for k in (10, 128):
+        od, oi = orc.adc_search(rot(q2), books, crowd, k)
+        d, i = idx.search(q2, k, rotate=True)
+        ok = np.array([f != 5 for f in range(8)])
+        assert np.array_equal(i[ok], oi[ok]) and np.array_equal(bits(d)[ok], bits(od)[ok]), k
+        assert np.array_equal(i[3], np.sort(i[3])) and i[3][0] == 7 or rotation == "dense"   # the crowd's ties come in id order
+    idx.close()

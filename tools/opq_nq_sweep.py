@@ -24,6 +24,7 @@ for a in range(0, rows, step):
     idx.add_codes(codes)
 qs = synth.sift_like(20_000, D, seed=0xBEEF, device=dev)
 idx.set_param("profile", 1)
+cvt_amd.set_tuning("scans_dbg", int(os.environ.get("SDBG", 0)))
 for nq in [int(v) for v in os.environ.get("NQS", "1,2,4,8,16,32,64,128,256,512,1000,2000,3000,4096,5000,6000,8000,10000,12000,16000,20000").split(",")]:
     q = qs[:nq].contiguous()
     for _ in range(2):
