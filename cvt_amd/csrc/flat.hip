@@ -735,8 +735,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const uint32_t n_local = (uint32_t)(row_end > row_begin ? row_end - row_begin : 0);
     const uint32_t last = n_local ? n_local - 1 : 0;
     const int lj = lane & 31, lh = lane >> 5;
-    const uint8_t *xb = a.data + row_begin * D;
-    const int32_t *nb = a.norms + row_begin;
+    // (rows_per_split is rounded up to whole tiles, so the last splits of a plan can start past the end: their clamped loads read row 0)
+    const int64_t row_base = n_local ? row_begin : 0;
+    const uint8_t *xb = a.data + row_base * D;
+    const int32_t *nb = a.norms + row_base;
     auto fetch = [&](uint32_t tile_base, mf_v4i (&v)[KS], int &xx) {
         uint32_t r = tile_base + wave * 32 + lj;
         r = r < last ? r : last;  // clamped, rejected at push time
@@ -951,8 +953,11 @@ void flat_u8_rowtile_kernel(const FlatMfmaArgs a)
     row_end = row_end < a.n ? row_end : a.n;
     const uint32_t n_local = (uint32_t)(row_end > row_begin ? row_end - row_begin : 0);
     const uint32_t last = n_local ? n_local - 1 : 0;
-    const uint8_t *xb = a.data + row_begin * D;
-    const int32_t *nb = a.norms + row_begin;
+    // (rows_per_split is rounded up to whole tiles, so the last splits of a plan can start past the end -- 1 M rows in 120 splits of 8448:
+    //  their clamped loads read row 0 instead of memory past the index)
+    const int64_t row_base = n_local ? row_begin : 0;
+    const uint8_t *xb = a.data + row_base * D;
+    const int32_t *nb = a.norms + row_base;
     // tile loader: the 32 x D bytes of a tile are 2 D 16-byte pieces, piece f = row f / (D/16), column f % (D/16)
     const int P16 = D >> 4, pieces = 32 * P16;
     constexpr int LPT = (32 * (DMAX / 16) + NT - 1) / NT;  // pieces per thread

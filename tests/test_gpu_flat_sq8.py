@@ -133,6 +133,26 @@ def test_flat_u8_many_splits_parity(amd, orc):
         assert np.array_equal(i, oi), k
 
 
+def test_flat_u8_row_tile_empty_last_split(amd, orc):
+    """1 M rows x 1000 queries on the row-tile kernels: the planner asks for 120 splits, whole tiles make them 8448 rows each, and
+    the last split starts PAST the index (119 x 8448 > 1 M).  It used to fetch its first tiles from there (a memory fault at 512-d);
+    now an empty split reads row 0 and reports nothing.  Against the default route on all queries and the checker on a few."""
+    rng = np.random.default_rng(77)
+    n, D, nq, k = 1_000_000, 64, 1000, 10
+    db = rng.integers(0, 256, size=(n, D), dtype=np.uint8)
+    q = rng.integers(0, 256, size=(nq, D), dtype=np.uint8)
+    ix = amd.FlatIndex(L2U8, D); ix.add(db)
+    try:
+        amd.set_tuning("flat_variant", 1)
+        d1, i1 = ix.search(q, k)
+    finally:
+        amd.set_tuning("flat_variant", 0)
+    d0, i0 = ix.search(q, k)
+    assert np.array_equal(d1, d0) and np.array_equal(i1, i0)
+    _, odi, oi = orc.flat_search(L2U8, db, q[:4], k)
+    assert np.array_equal(d1[:4], odi) and np.array_equal(i1[:4], oi)
+
+
 def test_flat_full_size_u8_property(amd):
     """Config 3 shape (512-d uint8) at a size that needs row splits: self-queries come back first with
     distance 0 and the result is invariant to how the rows were appended."""
