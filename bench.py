@@ -79,6 +79,7 @@ def parse_args():
     ap.add_argument("--recall-sample", type=int, default=1000)
     ap.add_argument("--ref-rows", type=int, default=200_000, help="rows of the index the reference itself builds for cpu_baseline (0 = skip)")
     ap.add_argument("--ref-queries", type=int, default=64)
+    ap.add_argument("--hnsw-nodes", type=int, default=1_000_000, help="nodes of the config-5 graph (secondary.hnsw_c5)")
     ap.add_argument("--secondary", type=int, default=1,
                     help="N = 1: also measure rotation / encode / SQ8 / flat searches / config 5 (0 = skip)")
     return ap.parse_args()
@@ -771,7 +772,7 @@ def _ivf_query(ctx):
 def _hnsw_c5(ctx):
     """config 5: HNSW graph in HBM, batched 10 K queries, fp32 vectors and OPQ codes"""
     torch, cvt, args, dev = ctx.torch, ctx.cvt, ctx.args, ctx.dev
-    n, nq, Mg, efc = 100_000, 10_000, 32, 80
+    n, nq, Mg, efc = int(args.hnsw_nodes), 10_000, 32, 80
     rng = np.random.default_rng(5)
     cen = rng.normal(size=(1000, D)).astype(np.float32)
     x = cen[rng.integers(0, 1000, n)] + 0.6 * rng.normal(size=(n, D)).astype(np.float32)
@@ -782,15 +783,20 @@ def _hnsw_c5(ctx):
     rows_p, idx_p = os.path.join(tmpd, "rows.bin"), os.path.join(tmpd, "graph.hnsw")
     x.astype(np.float32).tofile(rows_p)
     t0 = time.perf_counter()
-    subprocess.run([os.path.join(ROOT, "cvt_amd", "bin", "hnsw_build"), rows_p, str(D), str(Mg), str(efc), idx_p, "ip"],
+    # the graph is built on the host, as in the reference: hnsw_build with all hardware threads = addPoints, the reference's locked
+    # parallel insertion (hnswalg.h:594-608); one thread (the byte-identical file) is what tests/test_host_hnsw_build.py pins
+    subprocess.run([os.path.join(ROOT, "cvt_amd", "bin", "hnsw_build"), rows_p, str(D), str(Mg), str(efc), idx_p, "ip", "-", "0"],
                    check=True, capture_output=True)
     t_build = time.perf_counter() - t0
     ix = cvt.HnswIndex(open(idx_p, "rb").read(), cvt.IP, D)
     qd = torch.from_numpy(q).to(dev)
-    exact = torch.argmax(qd @ torch.from_numpy(x).to(dev).T, dim=1)
+    xd = torch.from_numpy(x).to(dev)
+    exact = torch.cat([torch.argmax(qd[a:a + 500] @ xd.T, dim=1) for a in range(0, nq, 500)])
+    del xd
     res = {"nodes": n, "d": D, "M": Mg, "ef_construction": efc, "nq": nq, "graph_build_s_host": round(t_build, 1),
-           "what": "one wave per query over a graph built on the host (hnsw_build CLI = the reference's addPoint "
-                   "order, "
+           "graph_build_threads": os.cpu_count(),
+           "what": "one wave per query over a graph built on the host (hnsw_build CLI: the reference's addPoint under its own "
+                   "lock discipline on every hardware thread, ids and levels in row order, "
                    "M=32 efC=80, makeIdx.cpp:303-304)", "fp32": {}, "adc": {}}
 
     def r1(lab):

@@ -1,7 +1,9 @@
 // hnsw_build -- build and save a HierarchicalNSW graph the way makeIdx.cpp:325-396 does: one addPoint per row,
 // in row order, then saveIndex.  The file is byte-identical to the one the reference writes for the same rows.
-//   hnsw_build <rows.bin> <dim> <M> <efConstruction> <out index> [ip|l2] [labels.bin]
-// rows.bin: raw fp32 [n][dim]; labels.bin: raw uint64 [n] (default: the row number, makeIdx.cpp:364).
+//   hnsw_build <rows.bin> <dim> <M> <efConstruction> <out index> [ip|l2] [labels.bin|-] [threads]
+// rows.bin: raw fp32 [n][dim]; labels.bin: raw uint64 [n] (default / "-": the row number, makeIdx.cpp:364).
+// threads (absent: one addPoint per row): given = addPoints, the reference's locked parallel insertion (hnswalg.h:594-608; 0 = all hardware
+// threads) -- ids and levels stay those of the row order, the links depend on the interleaving.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,7 +27,7 @@ template <typename T> static bool slurp(const char *path, std::vector<T> &v)
 int main(int argc, char *argv[])
 {
     if (argc < 6) {
-        std::cout << "usage: hnsw_build <rows.bin> <dim> <M> <efConstruction> <out index> [ip|l2] [labels.bin]\n";
+        std::cout << "usage: hnsw_build <rows.bin> <dim> <M> <efConstruction> <out index> [ip|l2] [labels.bin|-] [threads]\n";
         return -1;
     }
     const size_t dim = (size_t)atoi(argv[2]), M = (size_t)atoi(argv[3]), efc = (size_t)atoi(argv[4]);
@@ -33,7 +35,8 @@ int main(int argc, char *argv[])
     std::vector<float> rows;
     std::vector<uint64_t> labels;
     if (!slurp(argv[1], rows)) { std::cout << "cannot open " << argv[1] << "\n"; return 1; }
-    if (argc > 7 && !slurp(argv[7], labels)) { std::cout << "cannot open " << argv[7] << "\n"; return 1; }
+    const int threads = argc > 8 ? atoi(argv[8]) : -1;   // -1: the addPoint loop
+    if (argc > 7 && strcmp(argv[7], "-") && !slurp(argv[7], labels)) { std::cout << "cannot open " << argv[7] << "\n"; return 1; }
     const size_t n = rows.size() / dim;
     if (!labels.empty() && labels.size() != n) { std::cout << "labels.bin does not hold one label per row\n"; return 1; }
     try {
@@ -41,7 +44,12 @@ int main(int argc, char *argv[])
         hnswlib::L2Space l2s(dim);
         hnswlib::SpaceInterface<float> *space = l2 ? (hnswlib::SpaceInterface<float> *)&l2s : (hnswlib::SpaceInterface<float> *)&ip;
         hnswlib::HierarchicalNSW<float> alg(space, n, M, efc);
-        for (size_t i = 0; i < n; ++i) alg.addPoint(&rows[i * dim], labels.empty() ? (hnswlib::labeltype)i : (hnswlib::labeltype)labels[i]);
+        if (threads < 0) {
+            for (size_t i = 0; i < n; ++i) alg.addPoint(&rows[i * dim], labels.empty() ? (hnswlib::labeltype)i : (hnswlib::labeltype)labels[i]);
+        } else {
+            std::vector<hnswlib::labeltype> lab(labels.begin(), labels.end());
+            alg.addPoints(rows.data(), lab.empty() ? NULL : lab.data(), n, (unsigned)threads);
+        }
         alg.saveIndex(argv[5]);
         std::cout << n << " rows indexed" << std::endl;
     } catch (const std::exception &e) {

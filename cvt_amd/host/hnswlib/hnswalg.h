@@ -12,6 +12,13 @@
 //    reference's file layout (:491-519): a graph built here is byte-identical to one built by the reference
 //    from the same rows in the same order (tests/test_oracle_golden.py).  The graph is uploaded to the GPU
 //    lazily, on the first search after a change.
+//  * PARALLEL CONSTRUCTION follows the reference's lock discipline (hnswalg.h:178,386,594-608): addPoint may be called from
+//    several threads -- a guard around the element counter, one lock per node taken while its link lists are read
+//    (search) or rewritten (back links), the new node's own lock held for the whole insertion, a global lock held by
+//    an insertion that raises the top level.  addPoints(rows, labels, n, threads) is the batch form makeIdx-style
+//    builders want: ids and levels are handed out in row order first (so the level of row i is the same draw
+//    whatever the thread count), then `threads` workers insert.  One thread = the sequential algorithm, the
+//    byte-identical file; more threads = a graph that depends on the interleaving, as in the reference.
 //
 // Host data layout is the mirror's own (separate arrays for vectors / links / labels); only the file is the
 // reference's interleaved block.
@@ -19,8 +26,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <atomic>
 #include <fstream>
+#include <memory>
+#include <mutex>
 #include <random>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
@@ -48,6 +59,7 @@ public:
         bind(s);
         cap_ = max_elements;
         M_ = M; maxM_ = M; maxM0_ = 2 * M;
+        if (maxM0_ > kMaxLinks) throw std::runtime_error("cvt_amd: more than 512 links per node");
         efc_ = std::max(ef_construction, M_);
         mult_ = 1 / log(1.0 * M_);
         vec_.assign(cap_ * dim_, 0.0f);
@@ -55,6 +67,7 @@ public:
         level_.assign(cap_, 0);
         link0_.assign(cap_ * (maxM0_ + 1), 0u);
         upper_.assign(cap_, std::vector<tableint>());
+        locks_.reset(new std::mutex[cap_]);
     }
     ~HierarchicalNSW()
     {
@@ -65,45 +78,62 @@ public:
     size_t ntotal() const { return count_; }
 
     // ---- construction (host) ----
+    // thread-safe, as the reference's (hnswalg.h:591-684)
     void addPoint(void *data_point, labeltype label)
     {
-        if (count_ >= cap_) throw std::runtime_error("The number of elements exceeds the specified limit");
-        const tableint id = (tableint)count_++;
-        const float *x = (const float *)data_point;
-        std::uniform_real_distribution<double> u01(0.0, 1.0);
-        const int lvl = (int)(-log(u01(rng_)) * mult_);
-        level_[id] = lvl;
-        std::copy(x, x + dim_, &vec_[(size_t)id * dim_]);
-        label_[id] = label;
-        std::fill(&link0_[(size_t)id * (maxM0_ + 1)], &link0_[(size_t)(id + 1) * (maxM0_ + 1)], 0u);
-        upper_[id].assign((size_t)lvl * (maxM_ + 1), 0u);
-        dirty_ = true;
-        if (entry_ < 0) {  // the first element only seeds the graph
-            entry_ = 0;
-            top_level_ = lvl;
+        tableint id;
+        int lvl;
+        {
+            std::lock_guard<std::mutex> g(count_guard_);
+            if (count_ >= cap_) throw std::runtime_error("The number of elements exceeds the specified limit");
+            id = (tableint)count_++;
+            lvl = draw_level();
+            dirty_ = true;
+        }
+        insert(id, (const float *)data_point, label, lvl);
+    }
+
+    // rows [n][dim], labels [n] (NULL: the row number past the current count): ids and levels in row order, insertion by `threads`
+    // workers (0 = one per hardware thread).  The first row of an empty graph goes in alone (it only seeds the graph).
+    void addPoints(const void *rows, const labeltype *labels, size_t n, unsigned threads = 0)
+    {
+        if (!n) return;
+        if (!threads) threads = std::max(1u, std::thread::hardware_concurrency());
+        size_t base;
+        std::vector<int> lv(n);
+        {
+            std::lock_guard<std::mutex> g(count_guard_);
+            if (count_ + n > cap_) throw std::runtime_error("The number of elements exceeds the specified limit");
+            base = count_;
+            count_ += n;
+            dirty_ = true;
+            for (size_t i = 0; i < n; ++i) lv[i] = draw_level();
+        }
+        const float *x = (const float *)rows;
+        auto one = [&](size_t i) { insert((tableint)(base + i), x + i * dim_, labels ? labels[i] : (labeltype)(base + i), lv[i]); };
+        size_t first = 0;
+        if (base == 0) one(first++);
+        if (threads == 1 || n - first < 2 * (size_t)threads) {
+            for (size_t i = first; i < n; ++i) one(i);
             return;
         }
-        const int top = top_level_;
-        tableint cur = (tableint)entry_;
-        if (lvl < top) {  // greedy descent to the first level the new node lives on
-            dist_t cd = dist(x, row(cur));
-            for (int l = top; l > lvl; --l) {
-                bool moved = true;
-                while (moved) {
-                    moved = false;
-                    const tableint *ll = links(cur, l);
-                    for (tableint i = 0; i < ll[0]; ++i) {
-                        const dist_t d = dist(x, row(ll[1 + i]));
-                        if (d < cd) { cd = d; cur = ll[1 + i]; moved = true; }
-                    }
-                }
+        std::atomic<size_t> next(first);
+        std::mutex err_mu;
+        std::string err;
+        auto work = [&]() {
+            try {
+                for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) one(i);
+            } catch (const std::exception &e) {
+                std::lock_guard<std::mutex> g(err_mu);
+                if (err.empty()) err = e.what();
+                next.store(n);
             }
-        }
-        for (int l = std::min(lvl, top); l >= 0; --l) {  // every search starts from the same entry (:660-667)
-            DistHeap found = search_level(cur, x, l);
-            connect(id, found, l);
-        }
-        if (lvl > top) { entry_ = (int)id; top_level_ = lvl; }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work);
+        work();
+        for (size_t t = 0; t < pool.size(); ++t) pool[t].join();
+        if (!err.empty()) throw std::runtime_error(err);
     }
 
     // the reference's file (:491-519)
@@ -149,6 +179,63 @@ public:
     }
 
 private:
+    int draw_level()   // under count_guard_: the i-th element gets the i-th draw (hnswalg.h:139-149)
+    {
+        std::uniform_real_distribution<double> u01(0.0, 1.0);
+        return (int)(-log(u01(rng_)) * mult_);
+    }
+
+    void insert(tableint id, const float *x, labeltype label, int lvl)
+    {
+        std::unique_lock<std::mutex> own(locks_[id]);       // the new node's lists are its own until it returns (:602)
+        std::unique_lock<std::mutex> top_lock(global_);     // kept only by an insertion that raises the top level (:610-613)
+        const int top = top_level_;
+        if (lvl <= top) top_lock.unlock();
+        tableint cur = (tableint)entry_;
+        const bool seed = entry_ < 0;
+        level_[id] = lvl;
+        std::copy(x, x + dim_, &vec_[(size_t)id * dim_]);
+        label_[id] = label;
+        std::fill(&link0_[(size_t)id * (maxM0_ + 1)], &link0_[(size_t)(id + 1) * (maxM0_ + 1)], 0u);
+        upper_[id].assign((size_t)lvl * (maxM_ + 1), 0u);
+        if (seed) {  // the first element only seeds the graph
+            entry_ = (int)id;
+            top_level_ = lvl;
+            return;
+        }
+        if (lvl < top) {  // greedy descent to the first level the new node lives on
+            dist_t cd = dist(x, row(cur));
+            tableint nb[kMaxLinks];
+            for (int l = top; l > lvl; --l) {
+                bool moved = true;
+                while (moved) {
+                    moved = false;
+                    const tableint cnt = snapshot(cur, l, nb);
+                    for (tableint i = 0; i < cnt; ++i) {
+                        const dist_t d = dist(x, row(nb[i]));
+                        if (d < cd) { cd = d; cur = nb[i]; moved = true; }
+                    }
+                }
+            }
+        }
+        for (int l = std::min(lvl, top); l >= 0; --l) {  // every search starts from the same entry (:660-667)
+            DistHeap found = search_level(cur, x, l);
+            connect(id, found, l);
+        }
+        if (lvl > top) { entry_ = (int)id; top_level_ = lvl; }
+    }
+
+    // a node's neighbours on level l, copied under its lock (the reference reads them in place under the same lock, :178-186)
+    enum { kMaxLinks = 512 };
+    tableint snapshot(tableint node, int l, tableint *out)
+    {
+        std::lock_guard<std::mutex> g(locks_[node]);
+        const tableint *ll = links(node, l);
+        const tableint cnt = std::min<tableint>(ll[0], (tableint)kMaxLinks);
+        std::copy(ll + 1, ll + 1 + cnt, out);
+        return cnt;
+    }
+
     void bind(SpaceInterface<dist_t> *s)
     {
         dim_ = s->get_data_size() / sizeof(float);
@@ -185,26 +272,29 @@ private:
         return metric_ == CVTMI_METRIC_IP ? 1.0f - s : s;
     }
 
-    // best-first search on one level with ef_construction results (:152-216)
+    // best-first search on one level with ef_construction results (:152-216); visited marks are per thread
     DistHeap search_level(tableint start, const float *x, int l)
     {
-        if (seen_.size() < cap_) seen_.assign(cap_, 0);
-        if (++stamp_ == 0) { std::fill(seen_.begin(), seen_.end(), 0); stamp_ = 1; }
+        static thread_local std::vector<unsigned short> seen;
+        static thread_local unsigned short stamp = 0;
+        if (seen.size() < cap_) { seen.assign(cap_, 0); stamp = 0; }
+        if (++stamp == 0) { std::fill(seen.begin(), seen.end(), 0); stamp = 1; }
         DistHeap best, frontier;
         const dist_t d0 = dist(x, row(start));
         best.emplace(d0, start);
         frontier.emplace(-d0, start);
-        seen_[start] = stamp_;
+        seen[start] = stamp;
         dist_t bound = d0;
+        tableint nbs[kMaxLinks];
         while (!frontier.empty()) {
             const Cand c = frontier.top();
             if (-c.first > bound) break;
             frontier.pop();
-            const tableint *ll = links(c.second, l);
-            for (tableint j = 0; j < ll[0]; ++j) {
-                const tableint nb = ll[1 + j];
-                if (seen_[nb] == stamp_) continue;
-                seen_[nb] = stamp_;
+            const tableint cnt = snapshot(c.second, l, nbs);
+            for (tableint j = 0; j < cnt; ++j) {
+                const tableint nb = nbs[j];
+                if (seen[nb] == stamp) continue;
+                seen[nb] = stamp;
                 const dist_t d = dist(x, row(nb));
                 if (best.top().first > d || best.size() < efc_) {
                     frontier.emplace(-d, nb);
@@ -255,6 +345,7 @@ private:
         for (size_t i = 0; i < chosen.size(); ++i) {
             const tableint other = chosen[i];
             if (other == id) throw std::runtime_error("Trying to connect an element to itself");
+            std::lock_guard<std::mutex> g(locks_[other]);   // (:386)
             tableint *ol = links(other, l);
             const size_t have = ol[0];
             if (have > room) throw std::runtime_error("Bad value of sz_link_list_other");
@@ -322,6 +413,8 @@ private:
             throw std::runtime_error("cvt_amd: saveIndex file does not match the space's dimension");
         vec_.assign(cap_ * dim_, 0.0f); label_.assign(cap_, 0); level_.assign(cap_, 0);
         link0_.assign(cap_ * (maxM0_ + 1), 0u); upper_.assign(cap_, std::vector<tableint>());
+        locks_.reset(new std::mutex[cap_]);
+        if (maxM0_ > kMaxLinks) throw std::runtime_error("cvt_amd: more than 512 links per node");
         for (size_t i = 0; i < count_; ++i) {
             const char *e = p + i * per_elem;
             memcpy(&link0_[i * (maxM0_ + 1)], e + off_level0, 4 + 4 * maxM0_);
@@ -362,8 +455,8 @@ private:
     std::vector<int> level_;
     std::vector<tableint> link0_;                 // [cap][maxM0 + 1]: count, neighbours
     std::vector<std::vector<tableint> > upper_;   // per node: levels x (maxM + 1)
-    std::vector<unsigned short> seen_;
-    unsigned short stamp_ = 0;
+    std::unique_ptr<std::mutex[]> locks_;         // one per node (hnswalg.h:76 link_list_locks_)
+    std::mutex count_guard_, global_;
     std::default_random_engine rng_ = std::default_random_engine(100);  // hnswalg.h:139
     cvtmi_hnsw_t dev_;
     bool dirty_ = true;
