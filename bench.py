@@ -80,6 +80,8 @@ def parse_args():
     ap.add_argument("--ref-rows", type=int, default=200_000, help="rows of the index the reference itself builds for cpu_baseline (0 = skip)")
     ap.add_argument("--ref-queries", type=int, default=64)
     ap.add_argument("--hnsw-nodes", type=int, default=1_000_000, help="nodes of the config-5 graph (secondary.hnsw_c5)")
+    ap.add_argument("--only", default="", help="development: comma list of secondary sections to run (rotation_encode, sq8, flat_f32, "
+                                               "flat_u8_c3, ivf_query, hnsw_c5); default all")
     ap.add_argument("--secondary", type=int, default=1,
                     help="N = 1: also measure rotation / encode / SQ8 / flat searches / config 5 (0 = skip)")
     return ap.parse_args()
@@ -446,7 +448,7 @@ def cpu_baseline_opq(ctx, idx, q, out, result):
                                                            d_gpu[:cs].cpu().numpy().view(np.uint32)))}
     result["recall_at_1_identical_to_cpu"] = bool(np.array_equal(oi[:, 0], i_gpu[:cs, 0].cpu().numpy()))
     # the same loop on all host cores: queries split over threads (ctypes releases the GIL), bounded sample
-    nth = os.cpu_count() if args.cpu_threads < 0 else args.cpu_threads
+    nth = _usable_cpus() if args.cpu_threads < 0 else args.cpu_threads
     if not nth or nth <= 1:
         return
     per = 8
@@ -557,11 +559,15 @@ def _hbm(nbytes, ms):
 
 def secondary(ctx):
     sec = {}
-    sec.update(_sec_rotation_encode(ctx))
-    vmin, vdiff = _sec_sq8(ctx, sec)
+    only = [v for v in ctx.args.only.split(",") if v]
+    if not only or "rotation_encode" in only:
+        sec.update(_sec_rotation_encode(ctx))
+    vmin, vdiff = _sec_sq8(ctx, sec) if (not only or "sq8" in only or "flat_u8_c3" in only) else (None, None)
     for name, fn in (("flat_f32", lambda: _sec_flat_f32(ctx)), ("flat_u8_c3", lambda: _sec_flat_u8_c3(ctx, vmin,
                                                                                                       vdiff)),
                      ("ivf_query", lambda: _ivf_query(ctx)), ("hnsw_c5", lambda: _hnsw_c5(ctx))):
+        if only and name not in only:
+            continue
         try:
             sec[name] = fn()
         except Exception as e:
@@ -794,7 +800,7 @@ def _hnsw_c5(ctx):
     exact = torch.cat([torch.argmax(qd[a:a + 500] @ xd.T, dim=1) for a in range(0, nq, 500)])
     del xd
     res = {"nodes": n, "d": D, "M": Mg, "ef_construction": efc, "nq": nq, "graph_build_s_host": round(t_build, 1),
-           "graph_build_threads": os.cpu_count(),
+           "graph_build_threads": _usable_cpus(),
            "what": "one wave per query over a graph built on the host (hnsw_build CLI: the reference's addPoint under its own "
                    "lock discipline on every hardware thread, ids and levels in row order, "
                    "M=32 efC=80, makeIdx.cpp:303-304)", "fp32": {}, "adc": {}}
@@ -848,11 +854,34 @@ def _hnsw_c5(ctx):
     return res
 
 
+def _usable_cpus():
+    """hardware threads this process can really use: affinity mask and container CPU quota (the MI355X boxes show 256 logical CPUs and
+    cgroup cpu.max = 16 CPUs; the same rule as HierarchicalNSW::usable_threads)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        try:
+            qv = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); pv = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if qv > 0 and pv > 0:
+                n = min(n, max(1, -(-qv // pv)))
+        except Exception:
+            pass
+    return n
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
             if line.startswith("model name"):
-                return line.split(":", 1)[1].strip() + " (%d logical cores)" % os.cpu_count()
+                return line.split(":", 1)[1].strip() + " (%d logical cores, %d usable under the container's CPU quota)" % (
+                    os.cpu_count(), _usable_cpus())
     except Exception:
         pass
     return "unknown"

@@ -6,6 +6,7 @@
 // threads) -- ids and levels stay those of the row order, the links depend on the interleaving.
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -43,6 +44,7 @@ int main(int argc, char *argv[])
         hnswlib::InnerProductSpace ip(dim);
         hnswlib::L2Space l2s(dim);
         hnswlib::SpaceInterface<float> *space = l2 ? (hnswlib::SpaceInterface<float> *)&l2s : (hnswlib::SpaceInterface<float> *)&ip;
+        const auto t0 = std::chrono::steady_clock::now();
         hnswlib::HierarchicalNSW<float> alg(space, n, M, efc);
         if (threads < 0) {
             for (size_t i = 0; i < n; ++i) alg.addPoint(&rows[i * dim], labels.empty() ? (hnswlib::labeltype)i : (hnswlib::labeltype)labels[i]);
@@ -50,8 +52,11 @@ int main(int argc, char *argv[])
             std::vector<hnswlib::labeltype> lab(labels.begin(), labels.end());
             alg.addPoints(rows.data(), lab.empty() ? NULL : lab.data(), n, (unsigned)threads);
         }
+        const auto t1 = std::chrono::steady_clock::now();
         alg.saveIndex(argv[5]);
-        std::cout << n << " rows indexed" << std::endl;
+        const auto t2 = std::chrono::steady_clock::now();
+        std::cout << n << " rows indexed (insert " << std::chrono::duration<double>(t1 - t0).count() << " s, save "
+                  << std::chrono::duration<double>(t2 - t1).count() << " s)" << std::endl;
     } catch (const std::exception &e) {
         std::cout << "error: " << e.what() << std::endl;
         return 1;
