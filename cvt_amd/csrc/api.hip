@@ -92,7 +92,7 @@ struct cvtmi_opq_s {
     int64_t csr_kept = 0, csr_longest = 0;  // entries in the CSR copy (list ids outside [0, coarseK) are dropped), longest list
     int32_t csr_vmin = 0, csr_vmax = -1;    // range of the video ids it holds
     // scratch of the calls that run one at a time (query_video: probe lists, rotated queries)
-    DevBuf s_qrot, s_probe, s_rot, s_lut;   // (s_lut: the tables of cvtmi_hnsw_search_adc, which borrows this handle)
+    DevBuf s_qrot, s_probe, s_rot;
     // Searches (cvtmi_opq_search*) run CONCURRENTLY, as the reference's QueryThrehold de facto may (opq/src/IVFOPQ.cpp:322-422 only
     // reads the index): each leases a scratch set from this pool for the duration of the call (OpqLease) and holds `rw` shared;
     // everything else -- add / reset / reserve, the lazily built copies of the rows, the one-at-a-time entries above -- holds it
@@ -518,7 +518,7 @@ int cvtmi_opq_destroy(cvtmi_opq_t h)
     if (h->d_perm) (void)hipFree(h->d_perm);
     h->codes.release(); h->lists.release(); h->videos.release(); h->codes_rot.release();
     h->csr_codes.release(); h->csr_videos.release(); h->csr_off.release(); h->csr_scratch.release(); h->csr_stats.release();
-    h->s_qrot.release(); h->s_probe.release(); h->s_rot.release(); h->s_lut.release();
+    h->s_qrot.release(); h->s_probe.release(); h->s_rot.release();
     for (OpqScratch *c : h->pool) { c->release_all(); delete c; }
     h->pool.clear();
     if (h->mutated) (void)hipEventDestroy(h->mutated);
@@ -2071,13 +2071,73 @@ int cvtmi_opq_train(const float *x, int64_t n, int D, int coarseK, int M, int K,
 }
 
 // ================================================================ HNSW search ==================
+// The graph is immutable once loaded and searchKnn is a pure read in the reference (hnswalg.h:688-728): searches on one handle run side
+// by side, each on a leased scratch set (visited bits, spilled queues, re-rank lists, host staging) and the stream of its caller (the
+// host-pointer entries: the set's own stream).
+struct HnswScratch {
+    DevBuf s_vis, s_cand, s_err, s_rr_d, s_rr_id, io_q, io_d, io_l;
+    hipStream_t own = nullptr;
+    hipEvent_t done = nullptr;
+    hipStream_t last = nullptr;
+    bool pending = false, busy = false;
+    void release_all()
+    {
+        for (DevBuf *b : { &s_vis, &s_cand, &s_err, &s_rr_d, &s_rr_id, &io_q, &io_d, &io_l }) b->release();
+        if (own) (void)hipStreamDestroy(own);
+        if (done) (void)hipEventDestroy(done);
+        own = nullptr; done = nullptr;
+    }
+};
 struct cvtmi_hnsw_s {
     uint32_t magic = 0x484e5357u;
     int device = 0, metric = 0, D = 0;
-    HandleSync sync;
     HnswDevGraph g{};
     DevBuf vec, links0, labels, upper_off, upper;
-    DevBuf s_vis, s_cand, s_err, s_rr_d, s_rr_id;
+    std::mutex pool_mu;
+    std::vector<HnswScratch *> pool;
+    int slots_per_cu_max = 32, cus = 256;
+};
+struct HnswLease {
+    cvtmi_hnsw_s *h = nullptr;
+    HnswScratch *s = nullptr;
+    hipStream_t st = nullptr;
+    int open(cvtmi_hnsw_s *handle, hipStream_t stream, bool host)
+    {
+        h = handle; st = stream;
+        {
+            std::lock_guard<std::mutex> g(h->pool_mu);
+            HnswScratch *any = nullptr;
+            for (HnswScratch *c : h->pool) {
+                if (c->busy) continue;
+                if (!host && c->pending && c->last == stream) { s = c; break; }   // same stream as before: nothing to wait for
+                if (!any) any = c;
+            }
+            if (!s) s = any;
+            if (!s) {
+                s = new (std::nothrow) HnswScratch();
+                if (!s) return fail(CVTMI_ENOMEM, "hnsw search: out of host memory");
+                h->pool.push_back(s);
+            }
+            s->busy = true;
+        }
+        if (host) {
+            if (!s->own && hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking) != hipSuccess) { s->busy = false; s = nullptr; return fail(CVTMI_EHIP, "hipStreamCreate failed"); }
+            st = s->own;
+        }
+        if (s->pending && s->last != st) (void)hipStreamWaitEvent(st, s->done, 0);
+        return CVTMI_OK;
+    }
+    ~HnswLease()
+    {
+        if (!s) return;
+        if (!s->done) (void)hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+        if (s->done && hipEventRecord(s->done, st) == hipSuccess) { s->last = st; s->pending = true; }
+        std::lock_guard<std::mutex> g(h->pool_mu);
+        s->busy = false;
+    }
+    HnswLease() = default;
+    HnswLease(const HnswLease &) = delete;
+    HnswLease &operator=(const HnswLease &) = delete;
 };
 #define CHECK_HN(h) do { if (!(h) || (h)->magic != 0x484e5357u) return fail(CVTMI_EINVAL, "bad hnsw handle"); CVTMI_TRY(use_device((h)->device)); } while (0)
 
@@ -2160,6 +2220,10 @@ int cvtmi_hnsw_load(const void *file, int64_t bytes, int metric, int D, cvtmi_hn
     cvtmi_hnsw_s *h = new (std::nothrow) cvtmi_hnsw_s();
     if (!h) return fail(CVTMI_ENOMEM, "cvtmi_hnsw_load: out of host memory");
     h->device = dev; h->metric = metric; h->D = D;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->cus = prop.multiProcessorCount;
+    }
     auto up = [&](DevBuf &b, const void *src, size_t nb) -> int {
         CVTMI_TRY(b.reserve(nb ? nb : 16));
         if (nb) CVTMI_HIP(hipMemcpy(b.p, src, nb, hipMemcpyHostToDevice));
@@ -2184,8 +2248,9 @@ int cvtmi_hnsw_destroy(cvtmi_hnsw_t h)
     if (!h) return CVTMI_OK;
     CHECK_HN(h);
     h->vec.release(); h->links0.release(); h->labels.release(); h->upper_off.release(); h->upper.release();
-    h->s_vis.release(); h->s_cand.release(); h->s_err.release(); h->s_rr_d.release(); h->s_rr_id.release();
-    h->sync.destroy();
+    (void)hipDeviceSynchronize();   // searches still in flight on other streams read the graph
+    for (HnswScratch *c : h->pool) { c->release_all(); delete c; }
+    h->pool.clear();
     h->magic = 0;
     delete h;
     return CVTMI_OK;
@@ -2193,173 +2258,180 @@ int cvtmi_hnsw_destroy(cvtmi_hnsw_t h)
 
 int64_t cvtmi_hnsw_ntotal(cvtmi_hnsw_t h) { return (h && h->magic == 0x484e5357u) ? h->g.n : -1; }
 
-int cvtmi_hnsw_search_dev(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int ef, float *dist, int64_t *labels, void *stream)
+// scratch of one traversal launch: `slots` concurrent queries (one wave each), a visited bit per node and the spilled queues per slot
+struct HnswPlan { int slots; int64_t words, gcap; };
+static int hnsw_plan(cvtmi_hnsw_t h, HnswScratch &S, int lds_dim, int64_t nq, int k, int ef, HnswPlan &pl, hipStream_t st)
 {
-    CHECK_HN(h);
-    Serial serial_h(h->sync, (hipStream_t)(stream));
-    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search: bad arguments");
-    if (k < 1 || k > hnsw_ef_max()) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search: k=%d outside 1..%d", k, hnsw_ef_max());
-    if (ef < 1 || ef > hnsw_ef_max()) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search: ef=%d outside 1..%d", ef, hnsw_ef_max());
-    if (nq == 0) return CVTMI_OK;
-    if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search: nq too large");
-    hipStream_t st = (hipStream_t)stream;
-    const int efe0 = ef > k ? ef : k;
-    int per_cu = (150 * 1024) / hnsw_lds_bytes(h->D, efe0);  // query slots (one wave each) a CU's LDS holds
-    per_cu = per_cu > 32 ? 32 : (per_cu < 1 ? 1 : per_cu);
-    int slots = 256 * per_cu;
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) slots = prop.multiProcessorCount * per_cu;
-    }
-    if (slots > nq) slots = (int)nq;
-    const int64_t words = (h->g.n + 31) / 32 + 1;
     const int efe = ef > k ? ef : k;
+    int per_cu = (150 * 1024) / hnsw_lds_bytes(lds_dim, efe);  // query slots (one wave each) a CU's LDS holds
+    per_cu = per_cu > 32 ? 32 : (per_cu < 1 ? 1 : per_cu);
+    pl.slots = h->cus * per_cu;
+    if (pl.slots > nq) pl.slots = (int)nq;
+    pl.words = (h->g.n + 31) / 32 + 1;
     int64_t gcap = (int64_t)efe * h->g.maxM0 * 2;
     if (gcap > h->g.n) gcap = h->g.n;
     gcap = gcap > hnsw_lcap() ? gcap - hnsw_lcap() : 0;
-    gcap += 64;
-    CVTMI_TRY(h->s_vis.reserve((size_t)slots * words * 4));
-    CVTMI_TRY(h->s_cand.reserve((size_t)slots * (gcap + efe + 1) * 8));  // per slot: spilled top queue + spilled candidates
-    CVTMI_TRY(h->s_err.reserve(16));
-    CVTMI_HIP(hipMemsetAsync(h->s_err.p, 0, 8, st));  // [0] overflow flag, [1] query counter
-    CVTMI_TRY(launch_hnsw_search(h->g, h->metric, q, nq, k, ef, dist, labels, h->s_vis.as<uint32_t>(), h->s_cand.p, slots, words,
-                                 gcap, h->s_err.as<int>(), st));
+    pl.gcap = gcap + 64;
+    CVTMI_TRY(S.s_vis.reserve((size_t)pl.slots * pl.words * 4));
+    CVTMI_TRY(S.s_cand.reserve((size_t)pl.slots * (pl.gcap + efe + 1) * 8));  // per slot: spilled top queue + spilled candidates
+    CVTMI_TRY(S.s_err.reserve(16));
+    CVTMI_HIP(hipMemsetAsync(S.s_err.p, 0, 8, st));  // [0] overflow flag, [1] query counter
+    return CVTMI_OK;
+}
+static int hnsw_check_overflow(HnswScratch &S, const char *who, int ef, hipStream_t st)
+{
     int err = 0;
-    CVTMI_HIP(hipMemcpyAsync(&err, h->s_err.p, 4, hipMemcpyDeviceToHost, st));
+    CVTMI_HIP(hipMemcpyAsync(&err, S.s_err.p, 4, hipMemcpyDeviceToHost, st));
     CVTMI_HIP(hipStreamSynchronize(st));
-    if (err) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search: candidate queue overflow (ef=%d)", ef);
+    if (err) return fail(CVTMI_EUNSUPPORTED, "%s: candidate queue overflow (ef=%d)", who, ef);
+    return CVTMI_OK;
+}
+
+static int hnsw_search_leased(cvtmi_hnsw_t h, HnswScratch &S, const float *q, int64_t nq, int k, int ef, float *dist, int64_t *labels, hipStream_t st)
+{
+    HnswPlan pl;
+    CVTMI_TRY(hnsw_plan(h, S, h->D, nq, k, ef, pl, st));
+    CVTMI_TRY(launch_hnsw_search(h->g, h->metric, q, nq, k, ef, dist, labels, S.s_vis.as<uint32_t>(), S.s_cand.p, pl.slots, pl.words,
+                                 pl.gcap, S.s_err.as<int>(), st));
+    return hnsw_check_overflow(S, "cvtmi_hnsw_search", ef, st);
+}
+
+static int hnsw_search_args(cvtmi_hnsw_t h, const char *who, const void *q, int64_t nq, int k, int ef, const void *dist, const void *labels)
+{
+    (void)h;
+    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "%s: bad arguments", who);
+    if (k < 1 || k > hnsw_ef_max()) return fail(CVTMI_EUNSUPPORTED, "%s: k=%d outside 1..%d", who, k, hnsw_ef_max());
+    if (ef < 1 || ef > hnsw_ef_max()) return fail(CVTMI_EUNSUPPORTED, "%s: ef=%d outside 1..%d", who, ef, hnsw_ef_max());
+    if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "%s: nq too large", who);
+    return CVTMI_OK;
+}
+
+int cvtmi_hnsw_search_dev(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int ef, float *dist, int64_t *labels, void *stream)
+{
+    CHECK_HN(h);
+    CVTMI_TRY(hnsw_search_args(h, "cvtmi_hnsw_search", q, nq, k, ef, dist, labels));
+    if (nq == 0) return CVTMI_OK;
+    HnswLease lease;
+    CVTMI_TRY(lease.open(h, (hipStream_t)stream, false));
+    return hnsw_search_leased(h, *lease.s, q, nq, k, ef, dist, labels, lease.st);
+}
+
+// host pointers in and out: staged through the leased set's own buffers, on its own stream
+template <typename F> static int hnsw_host_call(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, float *dist, int64_t *labels, F &&run)
+{
+    HnswLease lease;
+    CVTMI_TRY(lease.open(h, nullptr, true));
+    HnswScratch &S = *lease.s;
+    hipStream_t st = lease.st;
+    const size_t qb = (size_t)nq * h->D * sizeof(float), db = (size_t)nq * k * 4, lb = (size_t)nq * k * 8;
+    CVTMI_TRY(S.io_q.reserve(qb));
+    CVTMI_TRY(S.io_d.reserve(db));
+    CVTMI_TRY(S.io_l.reserve(lb));
+    CVTMI_HIP(hipMemcpyAsync(S.io_q.p, q, qb, hipMemcpyHostToDevice, st));
+    CVTMI_TRY(run(S, S.io_q.as<float>(), S.io_d.as<float>(), S.io_l.as<int64_t>(), st));
+    CVTMI_HIP(hipMemcpyAsync(dist, S.io_d.p, db, hipMemcpyDeviceToHost, st));
+    CVTMI_HIP(hipMemcpyAsync(labels, S.io_l.p, lb, hipMemcpyDeviceToHost, st));
+    CVTMI_HIP(hipStreamSynchronize(st));
     return CVTMI_OK;
 }
 
 int cvtmi_hnsw_search(cvtmi_hnsw_t h, const float *q, int64_t nq, int k, int ef, float *dist, int64_t *labels)
 {
     CHECK_HN(h);
-    Serial serial_h(h->sync, (hipStream_t)(nullptr));
-    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search: bad arguments");
+    CVTMI_TRY(hnsw_search_args(h, "cvtmi_hnsw_search", q, nq, k, ef, dist, labels));
     if (nq == 0) return CVTMI_OK;
-    Tmp dq, dd, dl;
-    CVTMI_TRY(dq.upload(q, (size_t)nq * h->D * sizeof(float)));
-    CVTMI_TRY(dd.alloc((size_t)nq * k * 4));
-    CVTMI_TRY(dl.alloc((size_t)nq * k * 8));
-    CVTMI_TRY(cvtmi_hnsw_search_dev(h, dq.as<float>(), nq, k, ef, dd.as<float>(), dl.as<int64_t>(), nullptr));
-    CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-    CVTMI_HIP(hipMemcpy(labels, dl.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
-    return CVTMI_OK;
+    return hnsw_host_call(h, q, nq, k, dist, labels, [&](HnswScratch &S, const float *dq, float *dd, int64_t *dl, hipStream_t st) {
+        return hnsw_search_leased(h, S, dq, nq, k, ef, dd, dl, st);
+    });
 }
 
 // HNSW over OPQ-compressed vectors: the graph of `h`, distances = ADC over the codes held by `opq` (one code
 // row per graph node, appended in internal-id order).  Queries are rotated and their tables built by the OPQ
-// handle's own kernels (cvtmi_opq_rotate_dev, lut_kernel).
-static int hnsw_search_adc_impl(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef, float *dist,
-                                int64_t *labels, void *stream, int raw_ids)
+// handle's own kernels, into a scratch set leased from the OPQ handle (so a later cvtmi_opq_add waits for this search);
+// the OPQ handle is held shared for the duration, like a search of its own.
+static int hnsw_search_adc_leased(cvtmi_hnsw_t h, HnswScratch &S, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef,
+                                  float *dist, int64_t *labels, hipStream_t st, int raw_ids)
 {
-    CHECK_HN(h);
-    Serial serial_h(h->sync, (hipStream_t)(stream));
     if (!opq) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: null OPQ handle");
-    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: bad arguments");
+    CVTMI_TRY(hnsw_search_args(h, "cvtmi_hnsw_search_adc", q, nq, k, ef, dist, labels));
     if (opq->m.coarseK != 1) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search_adc: needs an OPQ model with coarseK == 1");
     if (opq->m.D != h->D) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: OPQ model is %d-d, graph is %d-d", opq->m.D, h->D);
+    if (opq->device != h->device) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: handles live on different devices");
+    if (nq == 0) return CVTMI_OK;
+    std::shared_lock<std::shared_timed_mutex> rd(opq->rw);
     if (opq->n != h->g.n) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: %lld code rows for %lld graph nodes", (long long)opq->n,
                                       (long long)h->g.n);
-    if (opq->device != h->device) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: handles live on different devices");
-    if (k < 1 || k > hnsw_ef_max()) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search_adc: k=%d outside 1..%d", k, hnsw_ef_max());
-    if (ef < 1 || ef > hnsw_ef_max()) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search_adc: ef=%d outside 1..%d", ef, hnsw_ef_max());
-    if (nq == 0) return CVTMI_OK;
-    hipStream_t st = (hipStream_t)stream;
-    Serial serial_opq(opq->sync, st);  // the tables live in the OPQ handle's scratch
-    OpqExclusive excl_opq(opq, st);
+    OpqLease ol;
+    CVTMI_TRY(ol.open(opq, st, false));
+    OpqScratch &OS = *ol.s;
     const float *q_rot = q;
     if (rotate && (opq->m.perm || opq->m.R)) {
-        CVTMI_TRY(opq->s_qrot.reserve((size_t)nq * opq->m.D * sizeof(float)));
-        CVTMI_TRY(cvtmi_opq_rotate_dev(opq, q, nq, opq->s_qrot.as<float>(), stream));
-        q_rot = opq->s_qrot.as<float>();
+        CVTMI_TRY(OS.s_qrot.reserve((size_t)nq * opq->m.D * sizeof(float)));
+        CVTMI_TRY(opq_rotate_impl(opq, q, nq, OS.s_qrot.as<float>(), st));
+        q_rot = OS.s_qrot.as<float>();
     }
-    CVTMI_TRY(opq->s_lut.reserve((size_t)nq * opq->m.M * opq->m.K * sizeof(float)));
-    CVTMI_TRY(launch_lut(opq->m, q_rot, nq, nullptr, opq->s_lut.as<float>(), st));
-    const int efe0 = ef > k ? ef : k;
-    int per_cu = (150 * 1024) / hnsw_lds_bytes(opq->m.M * opq->m.K, efe0);
-    per_cu = per_cu > 32 ? 32 : (per_cu < 1 ? 1 : per_cu);
-    int slots = 256 * per_cu;
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) slots = prop.multiProcessorCount * per_cu;
-    }
-    if (slots > nq) slots = (int)nq;
-    const int64_t words = (h->g.n + 31) / 32 + 1;
-    const int efe = ef > k ? ef : k;
-    int64_t gcap = (int64_t)efe * h->g.maxM0 * 2;
-    if (gcap > h->g.n) gcap = h->g.n;
-    gcap = gcap > hnsw_lcap() ? gcap - hnsw_lcap() : 0;
-    gcap += 64;
-    CVTMI_TRY(h->s_vis.reserve((size_t)slots * words * 4));
-    CVTMI_TRY(h->s_cand.reserve((size_t)slots * (gcap + efe + 1) * 8));  // per slot: spilled top queue + spilled candidates
-    CVTMI_TRY(h->s_err.reserve(16));
-    CVTMI_HIP(hipMemsetAsync(h->s_err.p, 0, 8, st));  // [0] overflow flag, [1] query counter
-    CVTMI_TRY(launch_hnsw_search_adc(h->g, opq->s_lut.as<float>(), opq->codes.as<uint8_t>(), opq->m.M, opq->m.K, nq, k, ef, dist,
-                                     labels, h->s_vis.as<uint32_t>(), h->s_cand.p, slots, words, gcap, h->s_err.as<int>(), st, raw_ids));
-    int err = 0;
-    CVTMI_HIP(hipMemcpyAsync(&err, h->s_err.p, 4, hipMemcpyDeviceToHost, st));
-    CVTMI_HIP(hipStreamSynchronize(st));
-    if (err) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search_adc: candidate queue overflow (ef=%d)", ef);
-    return CVTMI_OK;
+    CVTMI_TRY(OS.s_lut.reserve((size_t)nq * opq->m.M * opq->m.K * sizeof(float)));
+    CVTMI_TRY(launch_lut(opq->m, q_rot, nq, nullptr, OS.s_lut.as<float>(), st));
+    HnswPlan pl;
+    CVTMI_TRY(hnsw_plan(h, S, opq->m.M * opq->m.K, nq, k, ef, pl, st));
+    CVTMI_TRY(launch_hnsw_search_adc(h->g, OS.s_lut.as<float>(), opq->codes.as<uint8_t>(), opq->m.M, opq->m.K, nq, k, ef, dist,
+                                     labels, S.s_vis.as<uint32_t>(), S.s_cand.p, pl.slots, pl.words, pl.gcap, S.s_err.as<int>(), st, raw_ids));
+    return hnsw_check_overflow(S, "cvtmi_hnsw_search_adc", ef, st);
 }
 
 int cvtmi_hnsw_search_adc_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef, float *dist,
                               int64_t *labels, void *stream)
 {
-    return hnsw_search_adc_impl(h, opq, q, nq, rotate, k, ef, dist, labels, stream, 0);
+    CHECK_HN(h);
+    HnswLease lease;
+    CVTMI_TRY(lease.open(h, (hipStream_t)stream, false));
+    return hnsw_search_adc_leased(h, *lease.s, opq, q, nq, rotate, k, ef, dist, labels, lease.st, 0);
 }
 
 // ADC traversal with a result list of `rerank` nodes, then their exact fp32 distances (the graph's own vectors, the summation
 // order of the reference's distance functions) and the k smallest; equal exact distances keep their ADC order
-int cvtmi_hnsw_search_adc_rerank_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef, int rerank,
-                                     float *dist, int64_t *labels, void *stream)
+static int hnsw_search_adc_rerank_leased(cvtmi_hnsw_t h, HnswScratch &S, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef,
+                                         int rerank, float *dist, int64_t *labels, hipStream_t st)
 {
-    CHECK_HN(h);
-    Serial serial_h(h->sync, (hipStream_t)(stream));
     if (k < 1 || k > CVTMI_K_MAX) return fail(CVTMI_EUNSUPPORTED, "cvtmi_hnsw_search_adc_rerank: k=%d outside 1..%d", k, CVTMI_K_MAX);
     if (rerank < k || rerank > hnsw_ef_max()) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc_rerank: rerank=%d outside k..%d", rerank, hnsw_ef_max());
     if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc_rerank: bad arguments");
     if (nq == 0) return CVTMI_OK;
-    hipStream_t st = (hipStream_t)stream;
-    CVTMI_TRY(h->s_rr_d.reserve((size_t)nq * rerank * sizeof(float)));
-    CVTMI_TRY(h->s_rr_id.reserve((size_t)nq * rerank * sizeof(int64_t)));
-    CVTMI_TRY(hnsw_search_adc_impl(h, opq, q, nq, rotate, rerank, ef, h->s_rr_d.as<float>(), h->s_rr_id.as<int64_t>(), stream, 1));
-    CVTMI_TRY(launch_hnsw_rerank(h->g, h->metric, q, nq, rerank, h->s_rr_id.as<int64_t>(), h->s_rr_d.as<float>(), st));
-    CVTMI_TRY(launch_topk_select(h->s_rr_d.as<float>(), h->s_rr_id.as<int64_t>(), nq, rerank, k, dist, labels, st));
+    CVTMI_TRY(S.s_rr_d.reserve((size_t)nq * rerank * sizeof(float)));
+    CVTMI_TRY(S.s_rr_id.reserve((size_t)nq * rerank * sizeof(int64_t)));
+    CVTMI_TRY(hnsw_search_adc_leased(h, S, opq, q, nq, rotate, rerank, ef, S.s_rr_d.as<float>(), S.s_rr_id.as<int64_t>(), st, 1));
+    CVTMI_TRY(launch_hnsw_rerank(h->g, h->metric, q, nq, rerank, S.s_rr_id.as<int64_t>(), S.s_rr_d.as<float>(), st));
+    CVTMI_TRY(launch_topk_select(S.s_rr_d.as<float>(), S.s_rr_id.as<int64_t>(), nq, rerank, k, dist, labels, st));
     return launch_gather_labels(labels, nq * k, h->g.labels, st);
+}
+
+int cvtmi_hnsw_search_adc_rerank_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef, int rerank,
+                                     float *dist, int64_t *labels, void *stream)
+{
+    CHECK_HN(h);
+    HnswLease lease;
+    CVTMI_TRY(lease.open(h, (hipStream_t)stream, false));
+    return hnsw_search_adc_rerank_leased(h, *lease.s, opq, q, nq, rotate, k, ef, rerank, dist, labels, lease.st);
 }
 
 int cvtmi_hnsw_search_adc_rerank(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef, int rerank,
                                  float *dist, int64_t *labels)
 {
     CHECK_HN(h);
-    Serial serial_h(h->sync, (hipStream_t)(nullptr));
     if (nq < 0 || k < 1 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc_rerank: bad arguments");
     if (nq == 0) return CVTMI_OK;
-    Tmp dq, dd, dl;
-    CVTMI_TRY(dq.upload(q, (size_t)nq * h->D * sizeof(float)));
-    CVTMI_TRY(dd.alloc((size_t)nq * k * 4));
-    CVTMI_TRY(dl.alloc((size_t)nq * k * 8));
-    CVTMI_TRY(cvtmi_hnsw_search_adc_rerank_dev(h, opq, dq.as<float>(), nq, rotate, k, ef, rerank, dd.as<float>(), dl.as<int64_t>(), nullptr));
-    CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-    CVTMI_HIP(hipMemcpy(labels, dl.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
-    return CVTMI_OK;
+    return hnsw_host_call(h, q, nq, k, dist, labels, [&](HnswScratch &S, const float *dq, float *dd, int64_t *dl, hipStream_t st) {
+        return hnsw_search_adc_rerank_leased(h, S, opq, dq, nq, rotate, k, ef, rerank, dd, dl, st);
+    });
 }
 
 int cvtmi_hnsw_search_adc(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef, float *dist,
                           int64_t *labels)
 {
     CHECK_HN(h);
-    Serial serial_h(h->sync, (hipStream_t)(nullptr));
-    if (nq < 0 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: bad arguments");
+    if (nq < 0 || k < 1 || (nq > 0 && (!q || !dist || !labels))) return fail(CVTMI_EINVAL, "cvtmi_hnsw_search_adc: bad arguments");
     if (nq == 0) return CVTMI_OK;
-    Tmp dq, dd, dl;
-    CVTMI_TRY(dq.upload(q, (size_t)nq * h->D * sizeof(float)));
-    CVTMI_TRY(dd.alloc((size_t)nq * k * 4));
-    CVTMI_TRY(dl.alloc((size_t)nq * k * 8));
-    CVTMI_TRY(cvtmi_hnsw_search_adc_dev(h, opq, dq.as<float>(), nq, rotate, k, ef, dd.as<float>(), dl.as<int64_t>(), nullptr));
-    CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-    CVTMI_HIP(hipMemcpy(labels, dl.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
-    return CVTMI_OK;
+    return hnsw_host_call(h, q, nq, k, dist, labels, [&](HnswScratch &S, const float *dq, float *dd, int64_t *dl, hipStream_t st) {
+        return hnsw_search_adc_leased(h, S, opq, dq, nq, rotate, k, ef, dd, dl, st, 0);
+    });
 }

@@ -13,14 +13,16 @@
  *     float** / float* arguments) and return when the result is in the caller's buffer.
  *     Functions ending in `_dev` take DEVICE pointers (HBM-resident) plus a `stream`
  *     (a hipStream_t passed as void*, NULL = the default stream) and are asynchronous.
- *   - Handles may be shared between threads and streams: every search borrows scratch that
- *     belongs to the handle (tables, partial top-k lists, visited bitmaps), so calls on ONE handle
- *     are serialised by the library -- a per-handle lock on the host, and when a call arrives on
- *     another stream than the previous call on that handle, that stream first waits for the
- *     previous call's work.  Results are those of some serial order.  For searches that really
- *     overlap on the device, use one handle per stream (a handle is cheap next to its rows only
- *     for small indexes) or batch the queries into one call.  The small accessors (ntotal,
- *     set_id_base, set_param) take no lock: do not race them with searches.
+ *   - Handles may be shared between threads and streams.  SEARCHES on one handle (cvtmi_opq_search*, cvtmi_opq_query_video*,
+ *     cvtmi_flat_search*, cvtmi_hnsw_search*) are reads, as QueryThrehold / searchKnn are in the reference
+ *     (opq/src/IVFOPQ.cpp:322-422, brutoforce.hpp:73-93, hnswalg.h:688-728): each call leases a scratch set from the
+ *     handle's pool (tables, partial top-k lists, visited bitmaps, staging buffers; the pool grows to the number of calls
+ *     in flight) and runs on its caller's stream (host-pointer entries: the set's own stream), so searches from several
+ *     threads or streams proceed side by side and every one returns what a search alone would.  Calls that CHANGE a
+ *     handle (add, add_codes, set_param, load) take it exclusively: they wait for the searches in flight, and searches
+ *     issued later wait for them; the result is that of some serial order.  cvtmi_hnsw_search_adc* holds its OPQ handle
+ *     the way a search of that handle would.  A sharded search additionally serialises on its communicator (below).  The
+ *     small accessors (ntotal, set_id_base) take no lock: do not race them with calls that change the handle.
  *   - One handle lives on the HIP device that was current when it was created.
  *   - The library has no CPU fallback: without a usable HIP device every compute entry fails
  *     with CVTMI_EHIP.

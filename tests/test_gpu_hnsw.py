@@ -144,6 +144,45 @@ def test_hnsw_over_opq_codes(amd, orc, golden, case, M, K):
         ix.search_adc_rerank(opq, q, 10, 40, 5)                                   # rerank < k is refused
 
 
+def test_hnsw_concurrent_searches_on_one_handle(amd, orc, golden):
+    """searchKnn is a read in the reference (hnswalg.h:688-728): six host threads search one graph handle at once -- plain, ADC and
+    ADC + re-rank, host arrays in, each call on a scratch set leased from the handle -- while the OPQ handle the ADC calls borrow is
+    searched too; every call returns exactly what it returns alone."""
+    import threading
+    from cvt_amd import synth
+    g = golden.hnsw
+    case = "ip128"
+    metric, D, n, _, _, k, ef = (int(v) for v in g[case + "_meta"])
+    blob = g[case + "_index"].tobytes()
+    x = vectors_of(blob, D)
+    R = synth.random_rotation(D, seed=3)
+    xr = orc.rotate_fma(R, x)
+    rng = np.random.default_rng(2)
+    books = np.ascontiguousarray(np.stack([xr[rng.integers(0, n, 256), m * 8:(m + 1) * 8] for m in range(16)]))
+    opq = amd.OpqIndex(np.zeros((1, D), np.float32), books, R=R)
+    _, codes = opq.encode(opq.rotate(x)); opq.add_codes(codes)
+    ix = amd.HnswIndex(blob, metric, D)
+    q = g[case + "_q"]
+    jobs = [("plain", lambda: ix.search(q, 10, 64)), ("adc", lambda: ix.search_adc(opq, q, 10, 64)),
+            ("rerank", lambda: ix.search_adc_rerank(opq, q, 5, 64, 32)), ("opq", lambda: opq.search(q, 10)),
+            ("plain1", lambda: ix.search(q[:3], 1, 16)), ("adc1", lambda: ix.search_adc(opq, q[:5], 3, 20))]
+    want = {name: fn() for name, fn in jobs}
+    bad, start = [], threading.Barrier(len(jobs))
+
+    def worker(name, fn):
+        start.wait()
+        for _ in range(25):
+            d, l = fn()
+            if not (np.array_equal(np.asarray(l), np.asarray(want[name][1])) and np.array_equal(bits(np.asarray(d)), bits(np.asarray(want[name][0])))):
+                bad.append(name)
+                return
+    ts = [threading.Thread(target=worker, args=j) for j in jobs]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not bad, bad
+    ix.close(); opq.close()
+
+
 def _graph_labels(blob, D):
     hdr = np.frombuffer(blob, np.uint64, 6, 0)
     max_elements, cur, size_per, label_off = int(hdr[1]), int(hdr[2]), int(hdr[3]), int(hdr[4])
