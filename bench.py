@@ -82,6 +82,7 @@ def parse_args():
     ap.add_argument("--hnsw-nodes", type=int, default=1_000_000, help="nodes of the config-5 graph (secondary.hnsw_c5)")
     ap.add_argument("--only", default="", help="development: comma list of secondary sections to run (rotation_encode, sq8, flat_f32, "
                                                "flat_u8_c3, ivf_query, hnsw_c5); default all")
+    ap.add_argument("--tune", default="", help="development: cvtmi_set_tuning pairs, name=value,name=value")
     ap.add_argument("--secondary", type=int, default=1,
                     help="N = 1: also measure rotation / encode / SQ8 / flat searches / config 5 (0 = skip)")
     return ap.parse_args()
@@ -499,6 +500,9 @@ def cpu_baseline_reference(ctx, q, result):
 def main():
     args = parse_args()
     ctx = Ctx(args)
+    for pair in [v for v in args.tune.split(",") if v]:
+        name, value = pair.split("=")
+        ctx.cvt.set_tuning(name, float(value))
     ctx.train_books()
     ready, why = True, ""
     try:  # a rank that cannot use its GPU must say so before anybody enters the (blocking) communicator creation

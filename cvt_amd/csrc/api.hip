@@ -444,6 +444,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         set_flat_f32_share((int)value);
         return CVTMI_OK;
     }
+    if (!strcmp(name, "hnsw_top_lds")) { set_hnsw_top_lds((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "sq8_wave_blocks")) {
@@ -2263,7 +2264,7 @@ struct HnswPlan { int slots; int64_t words, gcap; };
 static int hnsw_plan(cvtmi_hnsw_t h, HnswScratch &S, int lds_dim, int64_t nq, int k, int ef, HnswPlan &pl, hipStream_t st)
 {
     const int efe = ef > k ? ef : k;
-    int per_cu = (150 * 1024) / hnsw_lds_bytes(lds_dim, efe);  // query slots (one wave each) a CU's LDS holds
+    int per_cu = (159 * 1024) / hnsw_lds_bytes(lds_dim, efe);  // query slots (one wave each) a CU's 160 KB of LDS hold
     per_cu = per_cu > 32 ? 32 : (per_cu < 1 ? 1 : per_cu);
     pl.slots = h->cus * per_cu;
     if (pl.slots > nq) pl.slots = (int)nq;

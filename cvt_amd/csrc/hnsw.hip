@@ -12,6 +12,8 @@
 // distances are decided by the binary-heap mechanics: push_heap / pop_heap of libstdc++ (__push_heap,
 // __adjust_heap) are restated literally on arrays in LDS (the candidate queue spills to HBM past LCAP).
 // With that, labels and distances are bit-identical to the reference's on the same graph, duplicates included.
+#include <atomic>
+
 #include "dist_f32.h"
 #include "kernels.h"
 
@@ -61,21 +63,53 @@ __device__ __forceinline__ void hn_push(A &a, int &n, float d, uint32_t id, int 
     hn_push_heap_wave(a, n, v, lane);
     ++n;
 }
+// __adjust_heap walks from the root to a leaf, one comparison of two children per level: a chain of dependent reads, eleven deep for a
+// queue of 2000 entries, the lower three or four of them in HBM.  Here the wave fetches the next FIVE levels below the hole at once --
+// level j of that subtree is the 2^j consecutive entries from (hole + 1) 2^j - 1, lanes 2^j - 2 .. 2^(j+1) - 3 take it -- and the five
+// comparisons run on register values (v_readlane with a uniform lane number): one memory round trip per five levels, same
+// comparisons, same moves, same final layout.
+__device__ __forceinline__ HnEnt hn_lane(const HnEnt &e, int src)
+{
+    HnEnt r;
+    r.d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.d), src));
+    r.id = (uint32_t)__builtin_amdgcn_readlane((int)e.id, src);
+    return r;
+}
 template <class A>
 __device__ __forceinline__ void hn_pop(A &a, int &n, int lane)
 {
     if (n > 1) {
         const int len = n - 1;
-        const HnEnt value = a.get(len);
         int hole = 0, second = 0;
-        while (second < (len - 1) / 2) {
-            second = 2 * (second + 1);
-            const HnEnt r = a.get(second), l = a.get(second - 1);
-            HnEnt pick = r;
-            if (r.d < l.d) { --second; pick = l; }
-            a.set(hole, pick);
-            hole = second;
+        const int limit = (len - 1) / 2;
+        const int j = 31 - __clz(lane + 2);          // level of this lane's entry in the subtree (1 .. 5; lanes 62, 63 idle)
+        const int off = lane + 2 - (1 << j);
+        HnEnt value; value.d = 0.0f; value.id = 0u;
+        bool have_value = false;
+        while (second < limit) {
+            const int pos = ((second + 1) << j) - 1 + off;
+            HnEnt e; e.d = 0.0f; e.id = 0u;
+            if (j <= 5 && pos < len) e = a.get_l(pos);
+            if (!have_value) {                         // the entry that leaves the end of the array rides along with the first fetch (lane 63)
+                if (lane == 63) e = a.get_l(len);
+                value = hn_lane(e, 63);
+                have_value = true;
+            }
+            int rel = 0;                               // offset of the hole within its level of the subtree
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                if (second >= limit) break;
+                second = 2 * (second + 1);
+                const int lr = __builtin_amdgcn_readfirstlane((2 << t) - 2 + 2 * rel + 1);   // lane of the right child
+                const HnEnt r = hn_lane(e, lr), l = hn_lane(e, lr - 1);
+                HnEnt pick = r;
+                rel = 2 * rel + 1;
+                if (r.d < l.d) { --second; --rel; pick = l; }
+                a.set(hole, pick);
+                hole = second;
+            }
         }
+        if (!have_value) value = a.get(len);           // (len <= 2: no level to walk)
         if ((len & 1) == 0 && second == (len - 2) / 2) {
             second = 2 * (second + 1);
             a.set(hole, a.get(second - 1));
@@ -94,13 +128,13 @@ struct LdsArr {
     __device__ __forceinline__ HnEnt get_l(int i) const { return p[i]; }            // per-lane index
     __device__ __forceinline__ void set_l(int i, HnEnt v) const { p[i] = v; }
 };
-// first HN_LCAP entries (the upper heap levels, touched by every operation) in LDS, the rest in HBM
+// first `cap` entries (the upper heap levels, touched by every operation) in LDS, the rest in HBM
 struct SplitArr {
-    HnEnt *l; HnEnt *g; bool w;
-    __device__ __forceinline__ HnEnt get(int i) const { return i < HN_LCAP ? l[i] : g[i - HN_LCAP]; }
-    __device__ __forceinline__ void set(int i, HnEnt v) const { if (w) { if (i < HN_LCAP) l[i] = v; else g[i - HN_LCAP] = v; } }
-    __device__ __forceinline__ HnEnt get_l(int i) const { return i < HN_LCAP ? l[i] : g[i - HN_LCAP]; }   // per-lane index
-    __device__ __forceinline__ void set_l(int i, HnEnt v) const { if (i < HN_LCAP) l[i] = v; else g[i - HN_LCAP] = v; }
+    HnEnt *l; HnEnt *g; bool w; int cap;
+    __device__ __forceinline__ HnEnt get(int i) const { return i < cap ? l[i] : g[i - cap]; }
+    __device__ __forceinline__ void set(int i, HnEnt v) const { if (w) { if (i < cap) l[i] = v; else g[i - cap] = v; } }
+    __device__ __forceinline__ HnEnt get_l(int i) const { return i < cap ? l[i] : g[i - cap]; }   // per-lane index
+    __device__ __forceinline__ void set_l(int i, HnEnt v) const { if (i < cap) l[i] = v; else g[i - cap] = v; }
 };
 
 struct HnswArgs {
@@ -124,6 +158,7 @@ struct HnswArgs {
     int64_t words, gcap;
     int *err;
     int raw_ids;              // 1 = out_label receives internal ids instead of labels (the re-rank pass needs the node)
+    int top_lds;              // entries of the top queue kept in LDS (the candidate queue: HN_LCAP)
     int dynamic;              // 1 = queries handed out by the counter err[1] (one ticket per wave), 0 = static stride
 };
 
@@ -143,6 +178,10 @@ struct DistF32 {
         dist_f32_row<IP, LANES, 1>(a.vec + (int64_t)id * a.D, qs, a.D, o);
         return o[0];
     }
+    // level 0: nothing is fetched before the visited test (4 D bytes per neighbour is what bounds this traversal)
+    struct Early {};
+    __device__ __forceinline__ Early early(uint32_t) const { return Early(); }
+    __device__ __forceinline__ float finish(uint32_t id, const Early &) const { return (*this)(id); }
 };
 // "HNSW over OPQ-compressed vectors": the node's M code bytes index the query's distance tables, summed in m
 // order from +0.0f exactly as the ADC scan does (IVFOPQ.cpp:302-306) -- 16 bytes gathered per neighbour
@@ -156,20 +195,33 @@ struct DistADC {
         const float *src = a.lut + (int64_t)qi * a.M * a.K;
         for (int i = lane; i < a.M * a.K; i += 64) lut[i] = src[i];
     }
+    __device__ __forceinline__ float sum16(const uint4 &v) const
+    {
+        const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+        float s = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) s = __fadd_rn(s, lut[m * a.K + ((w[m >> 2] >> (8 * (m & 3))) & 0xffu)]);
+        return s;
+    }
     __device__ __forceinline__ float operator()(uint32_t id) const
     {
         const uint8_t *c = a.codes + (int64_t)id * a.M;
+        if (a.M == 16) return sum16(*reinterpret_cast<const uint4 *>(c));  // one 16-byte gather per neighbour
         float s = 0.0f;
-        if (a.M == 16) {  // one 16-byte gather per neighbour
-            const uint4 v = *reinterpret_cast<const uint4 *>(c);
-            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-            for (int m = 0; m < 16; ++m) s = __fadd_rn(s, lut[m * a.K + ((w[m >> 2] >> (8 * (m & 3))) & 0xffu)]);
-        } else {
-            for (int m = 0; m < a.M; ++m) s = __fadd_rn(s, lut[m * a.K + c[m]]);
-        }
+        for (int m = 0; m < a.M; ++m) s = __fadd_rn(s, lut[m * a.K + c[m]]);
         return s;
     }
+    // level 0: a neighbour's 16 code bytes are requested together with its visited bit -- 1 KB per expanded node, and the traversal
+    // is a chain of dependent round trips: this one now overlaps the test-and-set instead of following it
+    struct Early { uint4 v; };
+    __device__ __forceinline__ Early early(uint32_t id) const
+    {
+        Early e;
+        e.v = make_uint4(0u, 0u, 0u, 0u);
+        if (a.M == 16) e.v = *reinterpret_cast<const uint4 *>(a.codes + (int64_t)id * 16);
+        return e;
+    }
+    __device__ __forceinline__ float finish(uint32_t id, const Early &e) const { return a.M == 16 ? sum16(e.v) : (*this)(id); }
 };
 
 template <class DIST>
@@ -179,14 +231,15 @@ __global__ __launch_bounds__(64, 8) void hnsw_search_kernel(const HnswArgs a)  /
     const DIST dist{ a, hn_smem };                                     // query state first (padded to 16 bytes)
     HnEnt *top_l = reinterpret_cast<HnEnt *>(hn_smem + dist.smem_floats());
     const int ef_cap = (a.ef > a.k ? a.ef : a.k) + 1;   // the top queue never holds more than ef + 1 entries
-    HnEnt *cand_l = top_l + (ef_cap < HN_LCAP ? ef_cap : HN_LCAP);
+    const int top_cap = ef_cap < a.top_lds ? ef_cap : a.top_lds;
+    HnEnt *cand_l = top_l + top_cap;
     const int lane = threadIdx.x;
     const bool w = lane == 0;
     uint32_t *vis = a.visited + (int64_t)blockIdx.x * a.words;
     // per-slot HBM scratch: [top queue past HN_LCAP: ef + 1 entries][candidate queue past HN_LCAP: gcap entries]
     HnEnt *slot_g = a.cand_g + (int64_t)blockIdx.x * (a.gcap + ef_cap);
-    const SplitArr top{ top_l, slot_g, w };
-    const SplitArr cand{ cand_l, slot_g + ef_cap, w };
+    const SplitArr top{ top_l, slot_g, w, top_cap };
+    const SplitArr cand{ cand_l, slot_g + ef_cap, w, HN_LCAP };
     const int ef = a.ef > a.k ? a.ef : a.k;
     const int64_t cand_cap = HN_LCAP + a.gcap;
 
@@ -257,20 +310,23 @@ __global__ __launch_bounds__(64, 8) void hnsw_search_kernel(const HnswArgs a)  /
             if (-c.d > lower) break;
             // the expanded node's links are requested BEFORE the pop walks the queue (the walk's deeper levels live in HBM): the two
             // latencies overlap instead of adding up
+            // (count and first 64 neighbours in ONE round trip: a node's row always holds maxM0 + 1 words, stale ones past the count
+            //  are masked below once the count is known)
             const uint32_t *ll = a.links0 + (int64_t)c.id * (a.maxM0 + 1);
+            const uint32_t nb0 = lane < a.maxM0 ? ll[1 + lane] : 0u;
             const int size = (int)ll[0];
-            const uint32_t nb0 = lane < size ? ll[1 + lane] : 0u;
             hn_pop(cand, cand_n, lane);
             for (int base = 0; base < size; base += 64) {
                 const int j = base + lane;
                 bool act = j < size;
                 const uint32_t nb = base == 0 ? nb0 : (act ? ll[1 + j] : 0u);
+                typename DIST::Early pre = dist.early(act ? nb : c.id);
                 if (act) {
                     const uint32_t bit = 1u << (nb & 31);
                     act = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;
                 }
                 float o[1] = { 0.0f };
-                if (act) o[0] = dist(nb);
+                if (act) o[0] = dist.finish(nb, pre);
                 // list order.  Once the top queue is full its maximum only falls, so a neighbour that fails `lower > d` now fails it
                 // for the rest of this list: the rejected ones are dropped by ballot, and the walk visits accepted neighbours only
                 unsigned long long m = __ballot(act && (top_n < ef || lower > o[0]));
@@ -332,6 +388,7 @@ static void hnsw_fill_args(HnswArgs &a, const HnswDevGraph &g, int64_t nq, int k
     a.visited = visited; a.cand_g = reinterpret_cast<HnEnt *>(cand_scratch); a.words = words; a.gcap = gcap; a.err = err;
     a.raw_ids = 0;
     a.dynamic = 1;
+    a.top_lds = hnsw_top_lds(ef > k ? ef : k);
 }
 
 int launch_hnsw_search(const HnswDevGraph &g, int metric, const float *q, int64_t nq, int k, int ef, float *out_d,
@@ -345,7 +402,11 @@ int launch_hnsw_search(const HnswDevGraph &g, int metric, const float *q, int64_
     const size_t lds = (size_t)hnsw_lds_bytes(g.D, ef > k ? ef : k);
     const bool ip = metric == CVTMI_METRIC_IP;
     const int lanes = (g.D % 4 != 0) ? 1 : (ip ? 4 : (g.D % 16 == 0 ? 8 : 4));
-#define CVTMI_HN(IPV, L) hipLaunchKernelGGL((hnsw_search_kernel<DistF32<IPV, L> >), dim3((unsigned)slots), dim3(64), lds, st, a)
+#define CVTMI_HN(IPV, L)                                                                                                                   \
+    do {                                                                                                                                   \
+        CVTMI_HIP(hipFuncSetAttribute((const void *)hnsw_search_kernel<DistF32<IPV, L> >, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((hnsw_search_kernel<DistF32<IPV, L> >), dim3((unsigned)slots), dim3(64), lds, st, a);                            \
+    } while (0)
     if (ip) { if (lanes == 4) CVTMI_HN(true, 4); else CVTMI_HN(true, 1); }
     else { if (lanes == 8) CVTMI_HN(false, 8); else if (lanes == 4) CVTMI_HN(false, 4); else CVTMI_HN(false, 1); }
 #undef CVTMI_HN
@@ -402,10 +463,21 @@ int launch_hnsw_rerank(const HnswDevGraph &g, int metric, const float *q, int64_
 }
 
 // LDS bytes of one query slot: query state (floats) + top queue (ef + 1) + the LDS part of the candidate queue
+// Entries of the top queue (ef + 1) kept in LDS; the rest of it lives in HBM like the candidate queue's.  Keeping all of it in LDS (8 KB at
+// ef = 1000) was measured: fp32 ef = 1000 174 K -> 151 K queries/s, ADC 101 K -> 97 K at 1 M nodes -- the query slots lost per CU cost more than
+// the HBM levels of the heap walks, which the wave-wide pop already crosses in one or two round trips.  cvtmi_set_tuning("hnsw_top_lds", n),
+// 0 = everything.
+static std::atomic<int> g_hnsw_top_lds{ 256 };
+void set_hnsw_top_lds(int v) { g_hnsw_top_lds = v < 0 ? 0 : v; }
+int hnsw_top_lds(int ef)
+{
+    const int cap = g_hnsw_top_lds.load();
+    const int want = ef + 1;
+    return cap > 0 && cap < want ? (cap < 16 ? 16 : cap) : want;
+}
 int hnsw_lds_bytes(int state_floats, int ef)
 {
-    const int top = ef + 1 < HN_LCAP ? ef + 1 : HN_LCAP;
-    return (int)(((state_floats + 3) & ~3) * sizeof(float) + (size_t)(top + HN_LCAP) * sizeof(HnEnt));
+    return (int)(((state_floats + 3) & ~3) * sizeof(float) + (size_t)(hnsw_top_lds(ef) + HN_LCAP) * sizeof(HnEnt));
 }
 int hnsw_ef_max() { return HN_EF_MAX; }
 int hnsw_lcap() { return HN_LCAP; }

@@ -276,5 +276,7 @@ int launch_hnsw_rerank(const HnswDevGraph &g, int metric, const float *q, int64_
 int hnsw_lds_bytes(int state_floats, int ef);
 int hnsw_ef_max();
 int hnsw_lcap();
+int hnsw_top_lds(int ef);
+void set_hnsw_top_lds(int v);
 
 }  // namespace cvtmi
