@@ -731,3 +731,17 @@ def sq8_decode(vmin, vdiff, codes):
     x = np.empty((n, d), dtype=np.float32)
     _check(lib().cvtmi_sq8_decode(_ptr(vmin), _ptr(vdiff), C.c_int(d), _ptr(codes), C.c_int64(n), _ptr(x)))
     return x
+
+
+def sq8_decode_faiss(vmin, vdiff, codes):
+    """Int8Decode(uint8_t*) / Int8DecodeFaiss arithmetic: the fp32 8-bit codec of faiss (cvtmi_sq8_decode_faiss)"""
+    n, d = codes.shape
+    if _is_torch(codes):
+        import torch
+        x = torch.empty((n, d), dtype=torch.float32, device=codes.device)
+        _check(lib().cvtmi_sq8_decode_faiss_dev(_ptr(vmin), _ptr(vdiff), C.c_int(d), _ptr(codes), C.c_int64(n), _ptr(x), _stream()))
+        return x
+    codes = _np(codes, np.uint8); vmin = _np(vmin, np.float32); vdiff = _np(vdiff, np.float32)
+    x = np.empty((n, d), dtype=np.float32)
+    _check(lib().cvtmi_sq8_decode_faiss(_ptr(vmin), _ptr(vdiff), C.c_int(d), _ptr(codes), C.c_int64(n), _ptr(x)))
+    return x

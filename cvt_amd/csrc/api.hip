@@ -1947,13 +1947,12 @@ int cvtmi_pca_project(const float *mean, const float *vectors, int din, int dout
     return CVTMI_OK;
 }
 
-int cvtmi_sq8_decode_dev(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x, void *stream)
+static int sq8_decode_dev_mode(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x, void *stream, int mode)
 {
     if (n < 0 || d < 1 || !vmin || !vdiff || (n > 0 && (!x || !codes))) return fail(CVTMI_EINVAL, "cvtmi_sq8_decode: bad arguments");
-    return launch_sq8_decode(vmin, vdiff, d, codes, n, x, (hipStream_t)stream);
+    return launch_sq8_decode(vmin, vdiff, d, codes, n, x, (hipStream_t)stream, mode);
 }
-
-int cvtmi_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x)
+static int sq8_decode_host_mode(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x, int mode)
 {
     if (n < 0 || d < 1 || !vmin || !vdiff || (n > 0 && (!x || !codes))) return fail(CVTMI_EINVAL, "cvtmi_sq8_decode: bad arguments");
     if (n == 0) return CVTMI_OK;
@@ -1962,9 +1961,26 @@ int cvtmi_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_t
     CVTMI_TRY(ddiff.upload(vdiff, (size_t)d * sizeof(float)));
     CVTMI_TRY(dc.upload(codes, (size_t)n * d));
     CVTMI_TRY(dx.alloc((size_t)n * d * sizeof(float)));
-    CVTMI_TRY(cvtmi_sq8_decode_dev(dmin.as<float>(), ddiff.as<float>(), d, dc.as<uint8_t>(), n, dx.as<float>(), nullptr));
+    CVTMI_TRY(sq8_decode_dev_mode(dmin.as<float>(), ddiff.as<float>(), d, dc.as<uint8_t>(), n, dx.as<float>(), nullptr, mode));
     CVTMI_HIP(hipMemcpy(x, dx.p, (size_t)n * d * sizeof(float), hipMemcpyDeviceToHost));
     return CVTMI_OK;
+}
+
+int cvtmi_sq8_decode_dev(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x, void *stream)
+{
+    return sq8_decode_dev_mode(vmin, vdiff, d, codes, n, x, stream, 0);
+}
+int cvtmi_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x)
+{
+    return sq8_decode_host_mode(vmin, vdiff, d, codes, n, x, 0);
+}
+int cvtmi_sq8_decode_faiss_dev(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x, void *stream)
+{
+    return sq8_decode_dev_mode(vmin, vdiff, d, codes, n, x, stream, 1);
+}
+int cvtmi_sq8_decode_faiss(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x)
+{
+    return sq8_decode_host_mode(vmin, vdiff, d, codes, n, x, 1);
 }
 
 }  // extern "C"

@@ -218,7 +218,7 @@ int launch_sq8_rownorm(const float *x, int64_t n, int d, float *den, hipStream_t
 int launch_sq8_encode_rows(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm, int write_back,
                            uint8_t *codes, float *den_scratch, hipStream_t st);
 int launch_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x,
-                      hipStream_t st);
+                      hipStream_t st, int mode = 0);
 // kmin/kmax: [d] ordered-uint32 scratch (initialised inside); results in vmin / vdiff; den_scratch as above
 int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_scratch, uint32_t *kmin, uint32_t *kmax,
                      float *vmin, float *vdiff, hipStream_t st);

@@ -360,8 +360,11 @@ int launch_sq8_encode_rows(const float *vmin, const float *vdiff, int d, float *
 // x = vmin + vdiff * (b + 0.5) / 255.0 in double (int8_quan.cc:126-130).  vdiff * (b + 0.5) is exact in
 // double (24 + 9 bits); the division by the constant uses RN(1/255) and two fmas (255's significand is
 // not all ones), guarded to the range where no intermediate can underflow.
-__device__ __forceinline__ float sq8_decode_one(float lo, float df, bool fast, uint32_t b)
+// mode 1: the 8-bit codec of faiss 1.5.3 that Int8Decode(uint8_t*) / Int8DecodeFaiss delegate to (int8_quan.cc:96-115 -> sq.decode):
+// fp32 throughout, xi = (code + 0.5f) / 255.0f, x = vmin + xi * vdiff, product and sum rounded separately
+__device__ __forceinline__ float sq8_decode_one(float lo, float df, bool fast, uint32_t b, int mode = 0)
 {
+    if (mode == 1) return __fadd_rn(lo, __fmul_rn(__fdiv_rn(__fadd_rn((float)b, 0.5f), 255.0f), df));
     const double t0 = __dmul_rn((double)df, __dadd_rn((double)b, 0.5));
     double t;
     if (fast) {
@@ -378,7 +381,7 @@ __device__ __forceinline__ float sq8_decode_one(float lo, float df, bool fast, u
 __global__ __launch_bounds__(kBlock) void sq8_decode_kernel(const float *__restrict__ vmin,
                                                             const float *__restrict__ vdiff, int d,
                                                             const uint8_t *__restrict__ codes, int64_t n,
-                                                            float *__restrict__ x)
+                                                            float *__restrict__ x, int mode)
 {
     // d % 4 == 0 and aligned: a thread owns 4 adjacent columns (one dword of codes, one float4 out)
     const int CG = d >> 2;
@@ -398,10 +401,10 @@ __global__ __launch_bounds__(kBlock) void sq8_decode_kernel(const float *__restr
                 if (r0 + r >= n) break;
                 const uint32_t w = reinterpret_cast<const uint32_t *>(codes)[(r0 + r) * CG + c];
                 float4 o;
-                o.x = sq8_decode_one(loa[0], dfa[0], fast[0], w & 0xffu);
-                o.y = sq8_decode_one(loa[1], dfa[1], fast[1], (w >> 8) & 0xffu);
-                o.z = sq8_decode_one(loa[2], dfa[2], fast[2], (w >> 16) & 0xffu);
-                o.w = sq8_decode_one(loa[3], dfa[3], fast[3], w >> 24);
+                o.x = sq8_decode_one(loa[0], dfa[0], fast[0], w & 0xffu, mode);
+                o.y = sq8_decode_one(loa[1], dfa[1], fast[1], (w >> 8) & 0xffu, mode);
+                o.z = sq8_decode_one(loa[2], dfa[2], fast[2], (w >> 16) & 0xffu, mode);
+                o.w = sq8_decode_one(loa[3], dfa[3], fast[3], w >> 24, mode);
                 reinterpret_cast<float4 *>(x)[(r0 + r) * CG + c] = o;
             }
         }
@@ -411,13 +414,13 @@ __global__ __launch_bounds__(kBlock) void sq8_decode_kernel(const float *__restr
 __global__ __launch_bounds__(kBlock) void sq8_decode_any_kernel(const float *__restrict__ vmin,
                                                                 const float *__restrict__ vdiff, int d,
                                                                 const uint8_t *__restrict__ codes, int64_t n,
-                                                                float *__restrict__ x)
+                                                                float *__restrict__ x, int mode)
 {
     for (int64_t r0 = (int64_t)blockIdx.x * EW_ROWS; r0 < n; r0 += (int64_t)gridDim.x * EW_ROWS) {
         for (int c = threadIdx.x; c < d; c += kBlock) {
             const float lo = vmin[c], df = vdiff[c];
             for (int r = 0; r < EW_ROWS && r0 + r < n; ++r)
-                x[(r0 + r) * d + c] = sq8_decode_one(lo, df, false, codes[(r0 + r) * d + c]);
+                x[(r0 + r) * d + c] = sq8_decode_one(lo, df, false, codes[(r0 + r) * d + c], mode);
         }
     }
 }
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(kBlock) void sq8_decode_any_kernel(const float *__r
 // float4.  128 KB of LDS, one 512-thread workgroup per CU, DEC_U rows per lane in flight.
 constexpr int DEC_NT = 512, DEC_U = 8, DEC_SLAB = 128;
 __global__ __launch_bounds__(DEC_NT) void sq8_decode_lut_kernel(const float *__restrict__ vmin, const float *__restrict__ vdiff, int d,
-                                                                const uint8_t *__restrict__ codes, int64_t n, float *__restrict__ x, int row_splits)
+                                                                const uint8_t *__restrict__ codes, int64_t n, float *__restrict__ x, int row_splits, int mode)
 {
     extern __shared__ float dec_lut[];   // [4][256][32]
     const int tid = threadIdx.x;
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(DEC_NT) void sq8_decode_lut_kernel(const float *__r
         if (c < d) {
             const float df = vdiff[c];
             const float m = fabsf(df);
-            v = sq8_decode_one(vmin[c], df, (m >= 0x1p-100f && m <= 0x1p100f) || m == 0.0f, (uint32_t)b);
+            v = sq8_decode_one(vmin[c], df, (m >= 0x1p-100f && m <= 0x1p100f) || m == 0.0f, (uint32_t)b, mode);
         }
         dec_lut[e] = v;
     }
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(DEC_NT) void sq8_decode_lut_kernel(const float *__r
 }
 
 int launch_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n, float *x,
-                      hipStream_t st)
+                      hipStream_t st, int mode)
 {
     if (n <= 0) return CVTMI_OK;
     if ((d & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)codes & 3) == 0 && n >= 16384) {
@@ -480,7 +483,7 @@ int launch_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_
         if ((int64_t)rs * 2048 > n) rs = (int)std::max<int64_t>(1, n / 2048);
         const size_t lds = 4 * 256 * 32 * sizeof(float);
         CVTMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sq8_decode_lut_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(sq8_decode_lut_kernel, dim3((unsigned)(slabs * rs)), dim3(DEC_NT), lds, st, vmin, vdiff, d, codes, n, x, rs);
+        hipLaunchKernelGGL(sq8_decode_lut_kernel, dim3((unsigned)(slabs * rs)), dim3(DEC_NT), lds, st, vmin, vdiff, d, codes, n, x, rs, mode);
         CVTMI_HIP(hipGetLastError());
         return CVTMI_OK;
     }
@@ -488,8 +491,8 @@ int launch_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_
     if (blocks > 256 * 16) blocks = 256 * 16;
     const bool vec = (d & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)codes & 3) == 0 &&
                      ((uintptr_t)vmin & 15) == 0 && ((uintptr_t)vdiff & 15) == 0;
-    if (vec) hipLaunchKernelGGL(sq8_decode_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, vmin, vdiff, d, codes, n, x);
-    else hipLaunchKernelGGL(sq8_decode_any_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, vmin, vdiff, d, codes, n, x);
+    if (vec) hipLaunchKernelGGL(sq8_decode_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, vmin, vdiff, d, codes, n, x, mode);
+    else hipLaunchKernelGGL(sq8_decode_any_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, vmin, vdiff, d, codes, n, x, mode);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

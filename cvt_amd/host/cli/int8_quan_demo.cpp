@@ -1,5 +1,7 @@
 // int8_quan_demo -- scalar_quantization/scalar_quantization/int8_quan_test.cpp:10-65: encode / decode one vector.
 //   int8_quan_demo <model.bin> [raw fp32 vector file]      (default input: the 64-d vector of the reference demo)
+#include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <vector>
@@ -28,5 +30,12 @@ int main(int argc, char *argv[])
     std::cout << std::endl << "int8: "; for (uint8_t b : bytes) std::cout << unsigned(b) << " ";
     std::cout << std::endl << "decoded: "; for (float v : dec) std::cout << v << " ";
     std::cout << std::endl << "inner_product: " << ip << std::endl;
+    // the other decode entry: Int8Decode(uint8_t*) = faiss' own fp32 codec in the reference (int8_quan.cc:96-104); bit patterns, so a
+    // test can compare them exactly (they differ from `decoded` by one ulp in about a third of the places)
+    std::vector<float> dec2(x.size());
+    if (!q.Int8Decode(bytes.data(), dec2.data(), x.size(), 0)) { std::cerr << "faiss-path decode failed" << std::endl; return 1; }
+    std::cout << "decoded_faiss_bits:";
+    for (float v : dec2) { unsigned u; memcpy(&u, &v, 4); char b[16]; snprintf(b, sizeof b, " %08x", u); std::cout << b; }
+    std::cout << std::endl;
     return 0;
 }

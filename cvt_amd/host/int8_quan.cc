@@ -113,7 +113,9 @@ int Int8Quan::Int8Decode(uint8_t *bytes, float *x, size_t n_dims, int source)
     if (source < 0 || source >= (int)models_.size()) return 0;
     const Sq8Model &m = models_[source];
     if (n_dims % m.d != 0) return 0;
-    return cvtmi_sq8_decode(m.vmin.data(), m.vdiff.data(), m.d, bytes, (int64_t)(n_dims / m.d), x) == CVTMI_OK;
+    // all n_dims / d vectors, in the arithmetic of faiss' own 8-bit codec (int8_quan.cc:96-104 -> sq.decode): fp32, not the double
+    // formula of Int8Decode(std::string&)
+    return cvtmi_sq8_decode_faiss(m.vmin.data(), m.vdiff.data(), m.d, bytes, (int64_t)(n_dims / m.d), x) == CVTMI_OK;
 }
 
 int Int8Quan::Int8DecodeFaiss(std::string &embedding, float *x, int source)

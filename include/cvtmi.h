@@ -357,6 +357,15 @@ int cvtmi_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_t
                      float *x);
 int cvtmi_sq8_decode_dev(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n,
                          float *x, void *stream);
+/* Int8Quan::Int8Decode(uint8_t*) and Int8DecodeFaiss (int8_quan.cc:96-115) do NOT use the formula above: they call
+ * faiss::ScalarQuantizer::decode.  faiss is a dependency that is not vendored in the reference (pinned 1.5.3 by its build notes);
+ * its published QT_8bit codec is fp32 throughout: xi = (code + 0.5f) / 255.0f, x = vmin + xi * vdiff, product and sum rounded
+ * separately (a faiss built with FMA contraction could fuse the two; this is the ISO evaluation).  About a third of the floats
+ * differ from cvtmi_sq8_decode's by one ulp. */
+int cvtmi_sq8_decode_faiss(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n,
+                           float *x);
+int cvtmi_sq8_decode_faiss_dev(const float *vmin, const float *vdiff, int d, const uint8_t *codes, int64_t n,
+                               float *x, void *stream);
 
 /* ---------------------------------------------------------------- PCA projection ------------- */
 /* cvtk::PCAUtils::reduceDim (pca_train_project/pca_online/pca_utils.cc:25-35; same arithmetic in

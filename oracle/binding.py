@@ -193,6 +193,14 @@ class Oracle:
                                 C.c_int64(n), _p(out, C.c_float))
         return out
 
+    def sq8_decode_faiss(self, vmin, vdiff, codes):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8); vmin = _f32(vmin); vdiff = _f32(vdiff)
+        n, d = codes.shape
+        out = np.empty((n, d), dtype=np.float32)
+        self.lib.orc_sq8_decode_faiss(_p(vmin, C.c_float), _p(vdiff, C.c_float), C.c_int(d), _p(codes, C.c_uint8),
+                                C.c_int64(n), _p(out, C.c_float))
+        return out
+
     def sq8_train(self, x, l2norm=True):
         x = _f32(x).copy()
         n, d = x.shape

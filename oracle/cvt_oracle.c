@@ -493,6 +493,21 @@ ORC_API void orc_sq8_decode(const float *vmin, const float *vdiff, int d, const 
             out[r * d + i] = (float)(vmin[i] + vdiff[i] * (codes[r * d + i] + 0.5) / 255.0);
 }
 
+/* Int8Decode(uint8_t*) / Int8DecodeFaiss, int8_quan.cc:96-115: faiss::ScalarQuantizer::decode.  faiss is not in /root/reference
+ * (external dependency, 1.5.3 per the reference's build notes); its QT_8bit codec as published: Codec8bit::decode_component =
+ * (code[i] + 0.5f) / 255.0f, QuantizerTemplate<Codec, false>::reconstruct_component = vmin[i] + xi * vdiff[i], all float.
+ * volatile keeps the product and the sum two roundings whatever -ffp-contract says.  PARITY UNPINNED (no faiss to run). */
+ORC_API void orc_sq8_decode_faiss(const float *vmin, const float *vdiff, int d, const uint8_t *codes,
+                                  int64_t n, float *out)
+{
+    for (int64_t r = 0; r < n; ++r)
+        for (int i = 0; i < d; ++i) {
+            const float xi = (codes[r * d + i] + 0.5f) / 255.0f;
+            volatile float prod = xi * vdiff[i];
+            out[r * d + i] = vmin[i] + prod;
+        }
+}
+
 /* sq_train.cpp:84-103: rows are L2-normalised (:84) and handed to
  * faiss::IndexScalarQuantizer(d, QT_8bit).train, whose default range statistic (RS_minmax,
  * rangestat_arg 0) is per-dimension min and max-min.  x is normalised in place. */

@@ -719,6 +719,13 @@ def test_sq8_decode_through_table(amd, orc, d, n):
     codes[:256] = np.arange(256, dtype=np.uint8)[:, None]          # every byte value in every column
     dec = amd.sq8_decode(vmin, vdiff, codes)
     assert np.array_equal(bits(dec), bits(orc.sq8_decode(vmin, vdiff, codes)))
+    # the faiss-path arithmetic (Int8Decode(uint8_t*), int8_quan.cc:96-104): fp32 codec, through the same table kernel and, on a few
+    # rows, the element-wise kernels; it is a different function of the same bytes
+    decf = amd.sq8_decode_faiss(vmin, vdiff, codes)
+    wantf = orc.sq8_decode_faiss(vmin, vdiff, codes)
+    assert np.array_equal(bits(decf), bits(wantf))
+    assert np.array_equal(bits(amd.sq8_decode_faiss(vmin, vdiff, codes[:300])), bits(wantf[:300]))
+    assert not np.array_equal(bits(decf), bits(dec))
     if d in (512, 256, 100):
         x = np.abs(rng.normal(size=(5000, d))).astype(np.float32)
         tv, td = amd.sq8_train(x, l2norm=True)

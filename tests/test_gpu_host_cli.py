@@ -108,6 +108,10 @@ def test_sq8_cli(tmp_path, orc, golden):
     codes = [int(t) for t in [l for l in out.splitlines() if l.startswith("int8: ")][0].split()[1:]]
     ocodes, _ = orc.sq8_encode(ovmin, ovdiff, x[:1])
     assert codes == list(ocodes[0])
+    # Int8Decode(uint8_t*): the faiss-path arithmetic (fp32), not the double formula of Int8Decode(std::string&)
+    fb = [int(t, 16) for t in [l for l in out.splitlines() if l.startswith("decoded_faiss_bits:")][0].split()[1:]]
+    want = orc.sq8_decode_faiss(ovmin, ovdiff, ocodes[:1])
+    assert fb == [int(v) for v in bits(want)[0]]
 
 
 def test_opq_train_cli(tmp_path, orc):

@@ -98,6 +98,12 @@ def test_sq8_restatement_properties(orc, golden):
     assert codes.min() >= 0 and codes.max() == 255  # the per-dimension maximum maps to 255
     dec = orc.sq8_decode(vmin, vdiff, codes)
     assert np.max(np.abs(dec - xn) / np.maximum(vdiff, 1e-12)) <= 1.0 / 255 + 1e-6  # within one bucket
+    # the faiss-path decode (Int8Decode(uint8_t*) -> sq.decode, fp32 codec): the same values to within an ulp, not the same bits
+    decf = orc.sq8_decode_faiss(vmin, vdiff, codes)
+    want = (vmin[None, :] + ((codes.astype(np.float32) + np.float32(0.5)) / np.float32(255.0)) * vdiff[None, :]).astype(np.float32)
+    assert np.array_equal(decf.view(np.uint32), want.view(np.uint32))     # numpy float32 arithmetic = separate roundings
+    ulp = np.abs(decf.view(np.int32).astype(np.int64) - dec.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 4 and 0.05 < (ulp != 0).mean() < 0.7   # (three fp32 roundings against one: a few ulps where vmin cancels)
     # zero-range dimension encodes to 0 (int8_quan.cc:81)
     v2 = vdiff.copy(); v2[3] = 0
     c2, _ = orc.sq8_encode(vmin, v2, x, l2norm=True)
