@@ -318,6 +318,11 @@ class Comm:
                 raise e from err
             raise
 
+    def status(self):
+        """cvtmi_comm_status: raises CvtmiError (CVTMI_ECOMM) once if a search since the last report failed on some rank under the deferred
+        status check (its results were voided: +inf / -1).  Does not synchronise -- synchronise the searches' stream first."""
+        _check(lib().cvtmi_comm_status(self.h))
+
     @classmethod
     def over_torch_group(cls, rank, world, group=None):
         """All-gather through torch.distributed on host buffers (any backend): D2H of this rank's slot, all_gather,

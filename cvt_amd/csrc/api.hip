@@ -1127,6 +1127,10 @@ int cvtmi_opq_search_sharded(cvtmi_opq_t h, cvtmi_comm_t c, const float *q, int6
     CVTMI_TRY(cvtmi_opq_search_sharded_dev(h, c, dq.as<float>(), nq, rotate, k, dd.as<float>(), di.as<int64_t>(), nullptr));
     CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
     CVTMI_HIP(hipMemcpy(ids, di.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost));
+    {   // the copies above synchronised: a failure the deferred status check saw in THIS search is known now
+        Serial serial_c(*comm_sync(c), nullptr);
+        CVTMI_TRY(comm_take_deferred(c));
+    }
     return CVTMI_OK;
 }
 
@@ -1812,6 +1816,10 @@ int cvtmi_flat_search_sharded(cvtmi_flat_t h, cvtmi_comm_t c, const void *q, int
     CVTMI_TRY(cvtmi_flat_search_sharded_dev(h, c, dq.p, nq, k, dd.p, di.as<int64_t>(), nullptr));
     CVTMI_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
     CVTMI_HIP(hipMemcpy(labels, di.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+    {   // (as in cvtmi_opq_search_sharded)
+        Serial serial_c(*comm_sync(c), nullptr);
+        CVTMI_TRY(comm_take_deferred(c));
+    }
     return CVTMI_OK;
 }
 

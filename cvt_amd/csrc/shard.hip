@@ -104,7 +104,13 @@ int rccl_ready(RcclApi **out)
     } while (0)
 
 int g_force_rccl = 0;  // cvtmi_set_tuning("comm_force_rccl"): world == 1 communicators go through RCCL too (tests on a 1-GPU box)
-int g_check_status = 1;  // cvtmi_set_tuning("comm_check_status"): read the ranks' status words back after every all-gather
+// cvtmi_set_tuning("comm_check_status"): what happens to the ranks' status words after every all-gather.
+//   2 (default) deferred: a kernel behind the merge looks at them on the device; if any rank failed it overwrites the call's results with
+//     (+inf, -1) and leaves (code, rank) in a host-mapped word of the communicator -- no stream synchronisation.  The error is returned by
+//     the NEXT call on the communicator, by cvtmi_comm_status, and by the host-pointer entries at once (they synchronise for their copy anyway).
+//   1 immediate: read back + stream synchronisation inside the call (every rank returns CVTMI_ECOMM from the failing call itself).
+//   0 ignored (only this rank's own failure is reported).
+int g_check_status = 2;
 constexpr size_t kSlotHeader = 16;
 
 constexpr uint32_t kCommMagic = 0x434f4d4du;
@@ -129,7 +135,9 @@ struct cvtmi_comm_s {
     HandleSync sync;
     DevBuf gather;  // world slots, see the layout note on top
     int64_t n_collectives = 0, last_bytes_per_rank = 0;
-    uint32_t *h_status = nullptr;   // [world] host copy of the status words of the last exchange
+    uint32_t *h_status = nullptr;   // [world] host copy of the status words of the last exchange (comm_check_status = 1)
+    uint32_t *h_sticky = nullptr;   // host-mapped [2]: (code, rank + 1) of the first failure a deferred check saw; 0 = none
+    uint32_t *d_sticky = nullptr;   // its device address
 };
 
 namespace cvtmi {
@@ -199,10 +207,55 @@ static int comm_allgather(cvtmi_comm_t c, size_t slot, hipStream_t st)
     c->last_bytes_per_rank = (int64_t)slot;
     return CVTMI_OK;
 }
+// deferred check (comm_check_status = 2): runs behind the merge.  Any non-zero status word: the results are void on every rank (the failing
+// rank's slot holds lists of an earlier search) -- they are overwritten with the padding pattern (+inf, -1) -- and the first failure is
+// left where the host finds it without asking the device.
+__global__ void comm_status_fold_kernel(const uint8_t *__restrict__ gather, size_t slot, int world, uint32_t *sticky, float *dist, int64_t *ids,
+                                        int64_t count)
+{
+    uint32_t code = 0, who = 0;
+    for (int r = world - 1; r >= 0; --r) {
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(gather + (size_t)r * slot);
+        if (v) { code = v; who = (uint32_t)r + 1; }
+    }
+    if (!code) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        dist[i] = __uint_as_float(0x7f800000u);
+        ids[i] = -1;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && __hip_atomic_load(&sticky[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+        __hip_atomic_store(&sticky[0], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&sticky[1], who, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+static int comm_sticky_ready(cvtmi_comm_t c)
+{
+    if (c->h_sticky) return CVTMI_OK;
+    void *hp = nullptr, *dp = nullptr;
+    CVTMI_HIP(hipHostMalloc(&hp, 16, hipHostMallocMapped));
+    memset(hp, 0, 16);
+    if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipHostFree(hp); return fail(CVTMI_EHIP, "communicator: no device view of pinned memory"); }
+    c->h_sticky = static_cast<uint32_t *>(hp);
+    c->d_sticky = static_cast<uint32_t *>(dp);
+    return CVTMI_OK;
+}
+// a failure a deferred check has recorded since the last report: CVTMI_ECOMM once, then forgotten
+int comm_take_deferred(cvtmi_comm_t c)
+{
+    if (!c || !c->h_sticky) return CVTMI_OK;
+    const uint32_t who = __atomic_load_n(&c->h_sticky[1], __ATOMIC_ACQUIRE);
+    if (!who) return CVTMI_OK;
+    const int code = (int)c->h_sticky[0], r = (int)who - 1;
+    c->h_sticky[0] = 0u;
+    __atomic_store_n(&c->h_sticky[1], 0u, __ATOMIC_RELEASE);
+    return fail(CVTMI_ECOMM, "row-sharded search: rank %d reported error %d%s in an earlier search on this communicator (its results were voided: +inf / -1)",
+                r, code, r == c->rank ? " (this rank)" : "");
+}
+
 // every rank's status word -> host; non-zero anywhere: CVTMI_ECOMM on every rank
 static int comm_check_statuses(cvtmi_comm_t c, size_t slot, int own_status, hipStream_t st)
 {
-    if (!g_check_status) return own_status == CVTMI_OK ? CVTMI_OK : fail(CVTMI_ECOMM, "the local search of rank %d failed with %d", c->rank, own_status);
+    if (g_check_status != 1) return own_status == CVTMI_OK ? CVTMI_OK : fail(CVTMI_ECOMM, "the local search of rank %d failed with %d", c->rank, own_status);
     if (!c->h_status) {
         c->h_status = new (std::nothrow) uint32_t[c->world];
         if (!c->h_status) return fail(CVTMI_ENOMEM, "communicator: out of host memory");
@@ -223,6 +276,11 @@ int comm_exchange_merge(cvtmi_comm_t c, int64_t nq, int k, int status, float *di
     if (nq <= 0) return CVTMI_OK;
     const size_t slot = comm_slot_bytes(nq, k);
     const std::string own = status != CVTMI_OK ? std::string(cvtmi_last_error()) : std::string();
+    const bool deferred = g_check_status == 2 && c->world > 1;
+    if (deferred) CVTMI_TRY(comm_sticky_ready(c));
+    // what an earlier search left behind is reported AFTER this rank has entered the collective: the other ranks are on their way into it
+    const int earlier = comm_take_deferred(c);
+    const std::string earlier_msg = earlier != CVTMI_OK ? std::string(cvtmi_last_error()) : std::string();
     CVTMI_TRY(comm_post_status(c, nq, k, status, st));
     CVTMI_TRY(comm_allgather(c, slot, st));
     const int rc = comm_check_statuses(c, slot, status, st);
@@ -232,8 +290,16 @@ int comm_exchange_merge(cvtmi_comm_t c, int64_t nq, int k, int status, float *di
     }
     uint8_t *base = c->gather.as<uint8_t>() + kSlotHeader;
     const size_t ids_off = align16((size_t)nq * k * sizeof(float));
-    return launch_topk_merge_gathered(reinterpret_cast<const float *>(base), reinterpret_cast<const int64_t *>(base + ids_off),
-                                      (int64_t)(slot / sizeof(float)), (int64_t)(slot / sizeof(int64_t)), nq, c->world, k, dist, ids, st);
+    CVTMI_TRY(launch_topk_merge_gathered(reinterpret_cast<const float *>(base), reinterpret_cast<const int64_t *>(base + ids_off),
+                                         (int64_t)(slot / sizeof(float)), (int64_t)(slot / sizeof(int64_t)), nq, c->world, k, dist, ids, st));
+    if (deferred) {
+        const int64_t count = nq * k;
+        hipLaunchKernelGGL(comm_status_fold_kernel, dim3((unsigned)std::min<int64_t>(256, (count + 255) / 256)), dim3(256), 0, st, c->gather.as<uint8_t>(), slot,
+                           c->world, c->d_sticky, dist, ids, count);
+        CVTMI_HIP(hipGetLastError());
+    }
+    if (earlier != CVTMI_OK) return fail(CVTMI_ECOMM, "%s", earlier_msg.c_str());
+    return CVTMI_OK;
 }
 
 // The same exchange for the communicators of ONE process (cvtmi_comm_create_all), one per device: status words, ONE group of
@@ -269,7 +335,7 @@ int comm_exchange_merge_all(cvtmi_comm_t *comms, int ndev, int64_t nq, int k, co
     CVTMI_NCCL(api, api->GroupEnd());
     cvtmi_comm_t c0 = comms[0];
     CVTMI_TRY(comm_check(c0));
-    CVTMI_TRY(comm_check_statuses(c0, slot, status[0], nullptr));
+    // (no read-back: every rank of this communicator set is driven by this process, and their statuses were checked above)
     uint8_t *base = c0->gather.as<uint8_t>() + kSlotHeader;
     const size_t ids_off = align16((size_t)nq * k * sizeof(float));
     return launch_topk_merge_gathered(reinterpret_cast<const float *>(base), reinterpret_cast<const int64_t *>(base + ids_off),
@@ -279,6 +345,13 @@ int comm_exchange_merge_all(cvtmi_comm_t *comms, int ndev, int64_t nq, int k, co
 }  // namespace cvtmi
 
 extern "C" {
+
+int cvtmi_comm_status(cvtmi_comm_t c)
+{
+    CVTMI_TRY(comm_validate(c));
+    Serial serial(*comm_sync(c), nullptr);
+    return comm_take_deferred(c);
+}
 
 int cvtmi_comm_reserve(cvtmi_comm_t c, int64_t nq, int k)
 {
@@ -386,6 +459,7 @@ int cvtmi_comm_destroy(cvtmi_comm_t c)
     c->gather.release();
     c->sync.destroy();
     delete[] c->h_status;
+    if (c->h_sticky) (void)hipHostFree(c->h_sticky);
     c->magic = 0;
     delete c;
     return CVTMI_OK;

@@ -249,15 +249,24 @@ int cvtmi_topk_merge_dev(const float *in_dist, const int64_t *in_ids, int64_t nq
  *                          after the work already enqueued on `stream` and complete, or enqueued on `stream`, on return;
  *                          0 = success.  All pointers are device pointers.
  * Collectives must be entered by all ranks in the same order.  A rank whose LOCAL search fails still enters the
- * all-gather, with its error code in its slot's status word, and every rank then returns CVTMI_ECOMM (the status words are
- * read back after each all-gather: one stream synchronisation per sharded search; cvtmi_set_tuning("comm_check_status", 0)
- * drops the check and the synchronisation).  Calls on one communicator are serialised like calls on one handle (the
- * communicator's lock is taken before the handle's): drive one communicator from one thread, or issue the searches that
- * share it in the same order on every rank. */
+ * all-gather, with its error code in its slot's status word, so nobody is left waiting.  What the other ranks do with the
+ * status words is cvtmi_set_tuning("comm_check_status", v):
+ *   2 (default)  checked on the device, behind the merge, without synchronising the stream: if any rank failed, the results
+ *                of that search are overwritten with the padding pattern (+inf, -1) on EVERY rank, and every rank gets
+ *                CVTMI_ECOMM from its next call on the communicator, from cvtmi_comm_status, or -- host-pointer entries,
+ *                which synchronise for their copy anyway -- from the failing call itself;
+ *   1            read back inside the call (one stream synchronisation per sharded search): every rank returns
+ *                CVTMI_ECOMM from the failing call itself, `_dev` entries included;
+ *   0            ignored: only the rank that failed returns an error.
+ * Calls on one communicator are serialised like calls that change a handle (the communicator's lock is taken before the
+ * handle's): drive one communicator from one thread, or issue the searches that share it in the same order on every rank. */
 #define CVTMI_COMM_ID_BYTES 128
 typedef int (*cvtmi_allgather_fn)(void *ctx, const void *send_dev, void *recv_dev, size_t bytes, void *stream);
 int cvtmi_comm_unique_id(void *id /* [CVTMI_COMM_ID_BYTES] */);
 int cvtmi_comm_create(const void *id, int rank, int world, cvtmi_comm_t *out);
+/* CVTMI_ECOMM (once) if a search since the last report failed on some rank under the deferred status check, else CVTMI_OK.
+ * Does not synchronise: call it after the stream of the searches in question has been synchronised. */
+int cvtmi_comm_status(cvtmi_comm_t c);
 int cvtmi_comm_create_custom(cvtmi_allgather_fn fn, void *ctx, int rank, int world, cvtmi_comm_t *out);
 /* ONE process driving every GPU (the reference's callers are single processes: opq/src/multi_frame_index_test.cpp:32-91):
  * ncclCommInitAll over `ndev` devices (devices == NULL: 0 .. ndev - 1); comms[d] is rank d of ndev on devices[d].  Use with

@@ -215,13 +215,34 @@ qd = torch.from_numpy(q).cuda()
 d, i = ix.search_sharded(comm, qd, k)
 torch.cuda.synchronize()
 out = {"d": d.cpu().numpy(), "i": i.cpu().numpy()}
-# a rank whose local search fails: EVERY rank must come back with CVTMI_ECOMM (-6) instead of waiting in the collective
+# a rank whose local search fails: nobody waits in the collective, and EVERY rank learns of it (CVTMI_ECOMM, -6):
+#  - deferred check (default): the device-pointer call itself returns on the ranks that are fine, with the results voided
+#    (+inf / -1) on every rank; cvtmi_comm_status reports the failure once the stream is synchronised -- and only once
+#  - immediate check (comm_check_status = 1): every rank gets the error from the failing call
 cvt_amd.set_tuning("comm_inject_failure", world - 1)
 try:
-    ix.search_sharded(comm, qd, k)
-    out["failed"] = np.array(0)
+    fd, fi = ix.search_sharded(comm, qd, k)
+    torch.cuda.synchronize()
+    voided = bool((fi == -1).all().item())
+    own_failed = False
 except cvt_amd.CvtmiError as e:
-    out["failed"] = np.array(1 if "error -6" in str(e) else -1)
+    voided, own_failed = True, "error -6" in str(e)          # the failing rank itself still gets its error at once
+if own_failed:
+    out["failed"] = np.array(1 if rank == world - 1 else -2)
+else:
+    try:
+        comm.status()
+        out["failed"] = np.array(0)
+    except cvt_amd.CvtmiError as e:
+        out["failed"] = np.array(1 if ("error -6" in str(e) and voided) else -1)
+comm.status()                                                 # reported once: nothing left
+cvt_amd.set_tuning("comm_check_status", 1)
+try:
+    ix.search_sharded(comm, qd, k)
+    out["failed_now"] = np.array(0)
+except cvt_amd.CvtmiError as e:
+    out["failed_now"] = np.array(1 if "error -6" in str(e) else -1)
+cvt_amd.set_tuning("comm_check_status", 2)
 cvt_amd.set_tuning("comm_inject_failure", -1)
 d2, i2 = ix.search_sharded(comm, qd, k)          # the communicator is still usable
 torch.cuda.synchronize()
@@ -270,4 +291,4 @@ def test_flat_row_shards_match_single_handle(world, metric, D, n, tmp_path, orc)
         z = np.load(str(tmp_path / "out") + ".%d.npz" % r)
         assert np.array_equal(z["i"], oi), (world, metric, r)
         assert np.array_equal(z["d"], odi) if metric == 2 else np.array_equal(bits(z["d"]), bits(od)), (world, metric, r)
-        assert int(z["failed"]) == 1 and int(z["again"]) == 1, (r, int(z["failed"]), int(z["again"]))
+        assert int(z["failed"]) == 1 and int(z["failed_now"]) == 1 and int(z["again"]) == 1, (r, int(z["failed"]), int(z["failed_now"]), int(z["again"]))
