@@ -46,6 +46,8 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE";
   python $REPO/tools/pmc_summary.py /tmp/prof_big adc_scan > $OUT/big_pmc_$j.json
   grep '"metric"' /tmp/big_run.log > $OUT/${TAG}_bench_128m_under_rocprof.json
 done
+# SKIP_FLAT=1 leaves sections 4 and 5 out (rounds that did not change the flat kernels keep the previous summaries)
+if [ -z "${SKIP_FLAT:-}" ]; then
 # 4. config 3 kernels (10 M x 512-d uint8): the filter kernel at nq = 4096 and the streaming kernel at nq = 1 / 64, one PMC group per run
 u=0
 for pmc in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
@@ -99,6 +101,7 @@ for f in sorted(glob.glob(os.path.join(out, "f32_pmc_*_*.json"))):
 json.dump({"what": "1 M x 128-d fp32 rows (inner product), top-100, default dispatch; counters are per-dispatch means of that kernel; FETCH_SIZE is in KB and needs the x2 gfx950 correction", "by_batch": f32},
           open(os.path.join(out, tag + "_pmc_flat_f32.json"), "w"), indent=1)
 PY
+fi
 python - <<PY
 import json, glob, os
 out, tag = "$OUT", "$TAG"
