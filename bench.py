@@ -82,6 +82,7 @@ def parse_args():
     ap.add_argument("--hnsw-nodes", type=int, default=1_000_000, help="nodes of the config-5 graph (secondary.hnsw_c5)")
     ap.add_argument("--only", default="", help="development: comma list of secondary sections to run (rotation_encode, sq8, flat_f32, "
                                                "flat_u8_c3, ivf_query, hnsw_c5); default all")
+    ap.add_argument("--host-api", type=int, default=1, help="0 = skip the host-pointer leg (its 4096-query pieces are scan launches too)")
     ap.add_argument("--tune", default="", help="development: cvtmi_set_tuning pairs, name=value,name=value")
     ap.add_argument("--secondary", type=int, default=1,
                     help="N = 1: also measure rotation / encode / SQ8 / flat searches / config 5 (0 = skip)")
@@ -322,6 +323,8 @@ def headline_n1(ctx, q):
         "encode": {"rows_per_s": round(enc_rows / enc_time, 1),
                    "what": "rotate (MFMA GEMM) + PQ encode (cvtmi_opq_rotate_encode) + append of the 1 M rows"},
     }
+    if not args.host_api:   # (profiling runs: every scan launch of the process is then a headline launch)
+        return result, idx, out
     # the reference's API takes host pointers: the same step through cvtmi_opq_search (queries up, results down over
     # PCIe)
     qh = q.cpu().numpy()

@@ -11,7 +11,7 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 export PYTHONUNBUFFERED=1
 cd /tmp && export TMPDIR=/tmp
-HEAD="python $REPO/bench.py --cpu-sample 0 --recall-sample 0 --large-rows 0 --secondary 0"
+HEAD="python $REPO/bench.py --cpu-sample 0 --recall-sample 0 --large-rows 0 --secondary 0 --host-api 0 --ref-rows 0"
 # 1a. the headline alone: every launch of the scan kernel in this trace is a C2 launch, so its average is comparable with roofline.kernel_ms
 rm -rf /tmp/prof_stats
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o $TAG -- $HEAD --steps 10 --warmup 3 > $OUT/stats_run.log 2>&1
@@ -36,7 +36,7 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" 
   python $REPO/tools/pmc_summary.py /tmp/prof_pmc > $OUT/pmc_$i.json
 done
 # 3. HBM-resident shard: 128 M rows, 2048 queries
-BIG="python $REPO/bench.py --cpu-sample 0 --recall-sample 0 --large-rows 0 --secondary 0 --rows 134217728 --nq 2048 --steps 3 --warmup 1"
+BIG="python $REPO/bench.py --cpu-sample 0 --recall-sample 0 --large-rows 0 --secondary 0 --host-api 0 --ref-rows 0 --rows 134217728 --nq 2048 --steps 3 --warmup 1"
 j=0
 for pmc in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   j=$((j+1))
@@ -116,7 +116,7 @@ def merge(pattern):
 ctr, _ = merge("pmc_*.json")
 json.dump(ctr, open(os.path.join(out, tag + "_pmc_by_kernel.json"), "w"), indent=1)
 note = "FETCH_SIZE x1024 x2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE x1024; separate --pmc passes"
-def traffic(ctr, trace, name):
+def traffic(ctr, trace, name, **shape):
     scan = [k for k in ctr if "adc_scan" in k]
     if not scan: return
     c = ctr[scan[0]]
@@ -124,9 +124,9 @@ def traffic(ctr, trace, name):
     t = trace.get(scan[0], {})
     json.dump({"kernel": scan[0], "hbm_bytes_per_launch": int(fetch + write), "fetch_bytes_x2_corrected": int(fetch), "write_bytes": int(write),
                "kernel_avg_us_under_pmc": t.get("avg_us"), "l2_hit_rate": (c.get("TCC_HIT_sum", 0) / max(1.0, c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0))),
-               "note": note}, open(os.path.join(out, name), "w"), indent=1)
-c1, t1 = merge("pmc_*.json"); traffic(c1, t1, tag + "_scan_traffic.json")
-c2, t2 = merge("big_pmc_*.json"); traffic(c2, t2, tag + "_scan_traffic_128m.json")
+               "note": note, **shape}, open(os.path.join(out, name), "w"), indent=1)
+c1, t1 = merge("pmc_*.json"); traffic(c1, t1, tag + "_scan_traffic.json", rows=1000000, nq=10000, k=100)
+c2, t2 = merge("big_pmc_*.json"); traffic(c2, t2, tag + "_scan_traffic_128m.json", rows=134217728, nq=2048, k=100)
 PY
 cd $REPO
 { exec < /dev/null; python tools/bench_kernels.py; python tools/bench_sq8.py; METRIC=0 python tools/flat_nq_sweep.py; python tools/bench_flat_u8_opt.py; python tools/bench_train.py; python tools/bench_pca.py; python tools/bench_encode.py; python tools/bench_assign.py; python tools/bench_flat_filter.py; python tools/bench_ivf.py; NQ=9 python tools/bench_ivf.py; python tools/bench_hnsw.py; METRIC=2 ROWS=10000000 D=512 python tools/flat_nq_sweep.py; METRIC=2 ROWS=10000000 D=128 python tools/flat_nq_sweep.py; METRIC=1 python tools/flat_nq_sweep.py; python tools/opq_nq_sweep.py; } 2>&1 | grep -v amdgpu > $OUT/${TAG}_other_kernels.txt
