@@ -21,6 +21,12 @@
 
 namespace cvtmi {
 
+static int host_spin_default()
+{
+    const char *e = getenv("CVTMI_HOST_SPIN_US");   // (measurement aid: the CLIs have no tuning switch)
+    return e ? atoi(e) : 200;
+}
+std::atomic<int> g_host_spin_us{host_spin_default()};   // host_util.h: stream_wait
 static thread_local std::string g_err;
 
 void set_error(const char *fmt, ...)
@@ -444,6 +450,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         set_flat_f32_share((int)value);
         return CVTMI_OK;
     }
+    if (!strcmp(name, "host_spin_us")) { g_host_spin_us = value < 0 ? 0 : (int)value; return CVTMI_OK; }
     if (!strcmp(name, "hnsw_top_lds")) { set_hnsw_top_lds((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }
@@ -690,7 +697,7 @@ static int opq_add_common(cvtmi_opq_t h, const uint8_t *codes, const int32_t *li
         if (video_id) CVTMI_HIP(hipMemcpyAsync(h->videos.as<int32_t>() + h->n, video_id, (size_t)n * 4, kind, st));
         else CVTMI_TRY(fill_i32(h->videos.as<int32_t>(), h->n, total, 0, 1, st));
     }
-    if (kind == hipMemcpyHostToDevice) CVTMI_HIP(hipStreamSynchronize(st));
+    if (kind == hipMemcpyHostToDevice) CVTMI_HIP(stream_wait(st));
     h->n = total;
     h->csr_valid = false;
     return CVTMI_OK;
@@ -757,7 +764,7 @@ static int opq_build_csr(cvtmi_opq_t h, hipStream_t st)
     int64_t kept = 0;
     CVTMI_HIP(hipMemcpyAsync(&stats, h->csr_stats.p, sizeof stats, hipMemcpyDeviceToHost, st));
     CVTMI_HIP(hipMemcpyAsync(&kept, h->csr_off.as<int64_t>() + L, sizeof kept, hipMemcpyDeviceToHost, st));
-    CVTMI_HIP(hipStreamSynchronize(st));
+    CVTMI_HIP(stream_wait(st));
     h->csr_longest = stats.longest; h->csr_vmin = stats.vmin; h->csr_vmax = stats.vmax; h->csr_kept = kept;
     h->csr_valid = true;
     return CVTMI_OK;
@@ -1055,7 +1062,7 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
     const auto drain = [&](int i) -> int {
         if (!fl[i].n) return CVTMI_OK;
         OpqScratch &S = *lease[i].s;
-        CVTMI_HIP(hipStreamSynchronize(lease[i].st));
+        CVTMI_HIP(stream_wait(lease[i].st));
         copy_out(dist + fl[i].q0 * k, S.io_pin.as<char>() + qb, (size_t)fl[i].n * k * sizeof(float));
         copy_out(ids + fl[i].q0 * k, S.io_pin.as<char>() + qb + db, (size_t)fl[i].n * k * sizeof(int64_t));
         fl[i].n = 0;
@@ -1083,7 +1090,7 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
         }
     }
     if (out_pinned)
-        for (int i = 0; i < nsets; ++i) CVTMI_HIP(hipStreamSynchronize(lease[i].st));
+        for (int i = 0; i < nsets; ++i) CVTMI_HIP(stream_wait(lease[i].st));
     for (int i = 0; i < nsets; ++i) CVTMI_TRY(drain((c + i) % nsets));
     return CVTMI_OK;
 }
@@ -1412,7 +1419,7 @@ static int flat_add_common(cvtmi_flat_t h, const void *x, const int64_t *labels,
         CVTMI_TRY(launch_flat_u8_norms(h->data.as<uint8_t>() + (size_t)h->n * h->row_bytes, n, h->D,
                                        h->norms.as<int32_t>() + h->n, st));
     }
-    if (kind == hipMemcpyHostToDevice) CVTMI_HIP(hipStreamSynchronize(st));
+    if (kind == hipMemcpyHostToDevice) CVTMI_HIP(stream_wait(st));
     h->n = total;
     return CVTMI_OK;
 }
@@ -1588,7 +1595,7 @@ static int flat_search_filtered(cvtmi_flat_t h, FlatScratch &S, const float *q, 
                                      S.f_marg.as<float>(), sd, si, S.f_cnt.as<uint32_t>(), S.f_seld.as<float>(), S.f_seli.as<int32_t>(),
                                      od, oi, stats + 2, st));
         CVTMI_HIP(hipMemcpyAsync(worst, stats + 2, 4, hipMemcpyDeviceToHost, st));
-        CVTMI_HIP(hipStreamSynchronize(st));
+        CVTMI_HIP(stream_wait(st));
         return CVTMI_OK;
     };
     // 1. the exact top k of the leading ns rows.  The exact kernels only see a sample of the sample (ns / 16 rows); a first
@@ -1642,7 +1649,7 @@ static int flat_search_filtered_u8(cvtmi_flat_t h, FlatScratch &S, const uint8_t
         CVTMI_TRY(launch_flat_u8_finish(nq, stats + 3, pair_cap, S.f_cand.as<uint4>(), cap, k, sd, si, S.f_cnt.as<uint32_t>(),
                                         S.f_seld.as<float>(), S.f_seli.as<int32_t>(), od, oi, stats + 2, st));
         CVTMI_HIP(hipMemcpyAsync(&worst, stats + 2, 4, hipMemcpyDeviceToHost, st));
-        CVTMI_HIP(hipStreamSynchronize(st));
+        CVTMI_HIP(stream_wait(st));
         return CVTMI_OK;
     };
     // (a two-level sample -- exact kernels on ns / 8 rows, a first filter stage up to ns, as the fp32 path does -- was measured and lost:
@@ -1707,7 +1714,7 @@ static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStr
         if (need_fs && h->fs_stats_n != n) {   // once per index state: do the rows hold non-finite values?
             uint32_t stats[2] = { 0, 0 };
             CVTMI_HIP(hipMemcpyAsync(stats, h->fs_stats.p, sizeof stats, hipMemcpyDeviceToHost, st));
-            CVTMI_HIP(hipStreamSynchronize(st));
+            CVTMI_HIP(stream_wait(st));
             h->fs_nonfinite = stats[1] != 0;
             h->fs_stats_n = n;
             continue;   // the route may not need an operand copy after all
@@ -1720,14 +1727,14 @@ static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStr
                                        h->f_istats.as<uint32_t>(), st));
             uint32_t stats[2] = { 0, 0 };
             CVTMI_HIP(hipMemcpyAsync(stats, h->f_istats.p, sizeof stats, hipMemcpyDeviceToHost, st));
-            CVTMI_HIP(hipStreamSynchronize(st));
+            CVTMI_HIP(stream_wait(st));
             h->f_nonfinite = stats[1] != 0 || !(__builtin_bit_cast(float, stats[0]) <= 3.0e38f);
             h->f_pack_n = n;
         }
         if (need_u8 && h->f_pack_n != n) {    // operand-ordered copy of the rows (x - 128 as int8)
             if (h->f_pack.reserve(flat_u8_pack_bytes(h->D, n)) != CVTMI_OK) return CVTMI_OK;
             CVTMI_TRY(launch_flat_u8_pack(h->data.as<uint8_t>(), n, h->D, h->f_pack.as<uint4>(), st));
-            CVTMI_HIP(hipStreamSynchronize(st));
+            CVTMI_HIP(stream_wait(st));
             h->f_pack_n = n;
         }
         return CVTMI_OK;
@@ -1873,7 +1880,7 @@ int cvtmi_flat_search(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *di
     CVTMI_TRY(flat_search_leased(h, S, S.io_q.p, nq, k, S.io_d.p, S.io_i.as<int64_t>(), st, tun));
     CVTMI_HIP(hipMemcpyAsync(dist, S.io_d.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
     CVTMI_HIP(hipMemcpyAsync(labels, S.io_i.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
-    CVTMI_HIP(hipStreamSynchronize(st));
+    CVTMI_HIP(stream_wait(st));
     return CVTMI_OK;
 }
 
@@ -1887,7 +1894,7 @@ int cvtmi_sq8_train_dev(const float *x, int64_t n, int d, int l2norm, float *vmi
     CVTMI_TRY(keys.alloc((size_t)d * 2 * sizeof(uint32_t)));
     CVTMI_TRY(launch_sq8_train(x, n, d, l2norm, den.as<float>(), keys.as<uint32_t>(), keys.as<uint32_t>() + d, vmin, vdiff,
                                st));
-    CVTMI_HIP(hipStreamSynchronize(st));  // the temporaries die with this frame
+    CVTMI_HIP(stream_wait(st));  // the temporaries die with this frame
     return CVTMI_OK;
 }
 
@@ -1914,7 +1921,7 @@ int cvtmi_sq8_encode_dev(const float *vmin, const float *vdiff, int d, float *x,
     const bool two_pass = l2norm && !sq8_single_pass(d, x, codes, vmin, vdiff);
     if (two_pass) CVTMI_TRY(den.alloc((size_t)n * sizeof(float)));
     CVTMI_TRY(launch_sq8_encode_rows(vmin, vdiff, d, x, n, l2norm ? 1 : 0, l2norm == 2 ? 0 : 1, codes, den.as<float>(), st));
-    if (two_pass) CVTMI_HIP(hipStreamSynchronize(st));  // the temporary dies with this frame
+    if (two_pass) CVTMI_HIP(stream_wait(st));  // the temporary dies with this frame
     return CVTMI_OK;
 }
 
@@ -2038,13 +2045,13 @@ int cvtmi_kmeans_dev(const float *x, int64_t ld, int64_t n, int d, int k, int ni
         CVTMI_TRY(launch_kmeans_assign(x, ld, n, d, centroids, k, as, dchanged.as<unsigned long long>(), st));
         unsigned long long changed = 0;
         CVTMI_HIP(hipMemcpyAsync(&changed, dchanged.p, sizeof changed, hipMemcpyDeviceToHost, st));
-        CVTMI_HIP(hipStreamSynchronize(st));
+        CVTMI_HIP(stream_wait(st));
         if (changed == 0 || it >= max_iter) break;
         CVTMI_TRY(launch_kmeans_update(x, ld, n, d, as, k, centroids, st));
         ++it;
     }
     if (iters_done) *iters_done = it;
-    CVTMI_HIP(hipStreamSynchronize(st));  // the temporaries die with this frame
+    CVTMI_HIP(stream_wait(st));  // the temporaries die with this frame
     return CVTMI_OK;
 }
 
@@ -2077,7 +2084,7 @@ int cvtmi_opq_train_dev(const float *x, int64_t n, int D, int coarseK, int M, in
     for (int m = 0; m < M; ++m)
         CVTMI_TRY(cvtmi_kmeans_dev(res.as<float>() + m * step, D, n, step, K, niter, seed, books + (size_t)m * K * step,
                                    assign.as<int32_t>(), nullptr, stream));
-    CVTMI_HIP(hipStreamSynchronize(st));
+    CVTMI_HIP(stream_wait(st));
     return CVTMI_OK;
 }
 
@@ -2307,7 +2314,7 @@ static int hnsw_check_overflow(HnswScratch &S, const char *who, int ef, hipStrea
 {
     int err = 0;
     CVTMI_HIP(hipMemcpyAsync(&err, S.s_err.p, 4, hipMemcpyDeviceToHost, st));
-    CVTMI_HIP(hipStreamSynchronize(st));
+    CVTMI_HIP(stream_wait(st));
     if (err) return fail(CVTMI_EUNSUPPORTED, "%s: candidate queue overflow (ef=%d)", who, ef);
     return CVTMI_OK;
 }
@@ -2356,7 +2363,7 @@ template <typename F> static int hnsw_host_call(cvtmi_hnsw_t h, const float *q, 
     CVTMI_TRY(run(S, S.io_q.as<float>(), S.io_d.as<float>(), S.io_l.as<int64_t>(), st));
     CVTMI_HIP(hipMemcpyAsync(dist, S.io_d.p, db, hipMemcpyDeviceToHost, st));
     CVTMI_HIP(hipMemcpyAsync(labels, S.io_l.p, lb, hipMemcpyDeviceToHost, st));
-    CVTMI_HIP(hipStreamSynchronize(st));
+    CVTMI_HIP(stream_wait(st));
     return CVTMI_OK;
 }
 

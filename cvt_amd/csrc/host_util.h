@@ -1,6 +1,8 @@
 // host_util.h -- host-side helpers shared by the C-ABI glue (api.hip, shard.hip): device buffers and the
 // per-handle serialisation of calls.
 #pragma once
+#include <atomic>
+#include <chrono>
 #include <mutex>
 
 #include "common.h"
@@ -96,6 +98,27 @@ struct Tmp {
 // of the host-side call, and when a call arrives on another stream than the previous one it makes that stream wait for
 // the previous call's work (an event recorded when each outermost call returns).  Calls nest (host-pointer entries call
 // their _dev twins), hence the recursive lock and the depth count.
+// Waiting for a stream from a host-pointer entry: a blocking hipStreamSynchronize parks the thread on an interrupt, which costs tens of
+// microseconds to wake from -- as much again as a whole small search.  Short waits therefore poll (hipStreamQuery) for up to
+// cvtmi_set_tuning("host_spin_us") microseconds (default 200) before they block.
+extern std::atomic<int> g_host_spin_us;
+inline hipError_t stream_wait(hipStream_t st)
+{
+    const int budget = g_host_spin_us.load(std::memory_order_relaxed);
+    if (budget > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0;; ++i) {
+            const hipError_t e = hipStreamQuery(st);
+            if (e != hipErrorNotReady) return e;
+            if ((i & 7) == 7 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(budget)) break;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+    return hipStreamSynchronize(st);
+}
+
 struct HandleSync {
     std::recursive_mutex mu;
     hipEvent_t done = nullptr;

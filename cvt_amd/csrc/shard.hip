@@ -261,7 +261,7 @@ static int comm_check_statuses(cvtmi_comm_t c, size_t slot, int own_status, hipS
         if (!c->h_status) return fail(CVTMI_ENOMEM, "communicator: out of host memory");
     }
     CVTMI_HIP(hipMemcpy2DAsync(c->h_status, sizeof(uint32_t), c->gather.p, slot, sizeof(uint32_t), (size_t)c->world, hipMemcpyDeviceToHost, st));
-    CVTMI_HIP(hipStreamSynchronize(st));
+    CVTMI_HIP(stream_wait(st));
     for (int r = 0; r < c->world; ++r)
         if (c->h_status[r] != 0u)
             return fail(CVTMI_ECOMM, "row-sharded search: rank %d reported error %d%s", r, (int)c->h_status[r], r == c->rank ? " (this rank)" : "");
