@@ -326,6 +326,7 @@ static bool host_pinned(const void *p)
     return at.type == hipMemoryTypeHost;
 }
 
+static std::atomic<int> g_small_zero_copy{1};   // cvtmi_set_tuning("opq_small_zero_copy"): 1 .. 8-query host-pointer searches read / write the pinned staging area from the kernels
 static std::atomic<int> g_host_chunks{4096};  // cvtmi_set_tuning("opq_host_chunk"): queries per piece of a pipelined host-pointer OPQ batch (0 = one piece)
 static std::atomic<int> g_scanh_key{0};  // bumped when a planner setting of adc_scan16h changes: cached item tables are rebuilt
 static std::atomic<int> g_inject_failure{-1};  // cvtmi_set_tuning("comm_inject_failure", r): the local search of rank r of a sharded search fails (tests)
@@ -450,6 +451,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         set_flat_f32_share((int)value);
         return CVTMI_OK;
     }
+    if (!strcmp(name, "opq_small_zero_copy")) { g_small_zero_copy = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "host_spin_us")) { g_host_spin_us = value < 0 ? 0 : (int)value; return CVTMI_OK; }
     if (!strcmp(name, "hnsw_top_lds")) { set_hnsw_top_lds((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
@@ -1068,6 +1070,27 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
         fl[i].n = 0;
         return CVTMI_OK;
     };
+    // 1 .. 8 queries (the reference's call pattern: a handful of frames per Query): the copies are a third of such a call.  The table
+    // kernel reads the 4 KB of queries and the selection kernel writes the results straight from / to the pinned staging area (page-locked
+    // host memory is device-visible: one PCIe read of the queries, posted writes of the lists) -- no copy engine in the chain.
+    if (chunks == 1 && g_small_zero_copy.load() && h->n > 0 && h->p_variant == 7 && h->p_splits == 0 && h->p_qtile == 0 && h->p_small &&
+        scans_applies(h->m, h->n, nq, k)) {
+        OpqScratch &S = *lease[0].s;
+        hipStream_t st = lease[0].st;
+        void *pin_dev = nullptr;
+        if (hipHostGetDevicePointer(&pin_dev, S.io_pin.p, 0) == hipSuccess && pin_dev) {
+            char *pin = S.io_pin.as<char>(), *pd = static_cast<char *>(pin_dev);
+            const size_t qn = (size_t)nq * D * sizeof(float), dn = (size_t)nq * k * sizeof(float), in = (size_t)nq * k * sizeof(int64_t);
+            memcpy(pin, q, qn);
+            CVTMI_TRY(opq_search_leased(h, S, reinterpret_cast<const float *>(pd), nq, rotate, k, reinterpret_cast<float *>(pd + qb),
+                                        reinterpret_cast<int64_t *>(pd + qb + db), st));
+            CVTMI_HIP(stream_wait(st));
+            memcpy(dist, pin + qb, dn);
+            memcpy(ids, pin + qb + db, in);
+            return CVTMI_OK;
+        }
+        (void)hipGetLastError();
+    }
     const bool q_pinned = host_pinned(q), out_pinned = host_pinned(dist) && host_pinned(ids);
     int c = 0;
     for (int64_t q0 = 0; q0 < nq; q0 += per, ++c) {
