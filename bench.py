@@ -356,6 +356,35 @@ def headline_n1(ctx, q):
             "what": "queries and result arrays from cvtmi_host_alloc"}
     except Exception as e:
         result["host_pointer_api"]["page_locked_arrays"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # the reference's own call pattern is a handful of query frames per Query (opq/src/multi_frame_index_test.cpp:45-54): wall time of a
+    # call of 1 / 8 queries on the same index, device pointers (call + synchronise) and host pointers (the call returns the results)
+    small = {"what": "wall time per search call of 1 / 8 queries, top-%d over the same %d rows: four launches (tables incl. the rotation, "
+                     "sampled histogram, candidate lists, selection), no partial lists, no merge; host pointers: queries read and results "
+                     "written through the handle's pinned staging area by the kernels" % (k, args.rows)}
+    torch = ctx.torch
+    for n_small in (1, 8):
+        qs = q[:n_small].contiguous()
+        qsh = qs.cpu().numpy()
+        outs = (np.zeros((n_small, k), np.float32), np.zeros((n_small, k), np.int64))
+        for _ in range(20):
+            idx.search(qs, k, rotate=True); idx.search(qsh, k, rotate=True, out=outs)
+        torch.cuda.synchronize()
+        reps = 200
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            d_s, i_s = idx.search(qs, k, rotate=True)
+            torch.cuda.synchronize()
+        t_dev = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            idx.search(qsh, k, rotate=True, out=outs)
+        t_host = (time.perf_counter() - t0) / reps
+        small["nq=%d" % n_small] = {
+            "device_pointers_ms": round(t_dev * 1e3, 4), "host_pointers_ms": round(t_host * 1e3, 4),
+            "identical_to_the_batch": bool(np.array_equal(outs[1], out[1][:n_small].cpu().numpy()) and
+                                           np.array_equal(outs[0].view(np.uint32), out[0][:n_small].cpu().numpy().view(np.uint32)) and
+                                           torch.equal(i_s, out[1][:n_small]))}
+    result["small_batch_latency"] = small
     return result, idx, out
 
 
