@@ -155,7 +155,7 @@ int cvtmi_opq_lut_dev(cvtmi_opq_t h, const float *q_rot, int64_t nq, const int32
 /* The north-star search: (optional rotation) + LUT + exhaustive ADC scan (IVFOPQ.cpp:300-306)
  * + k smallest (distance, id) (opq/src/common.h:25-37) per query, over every resident entry.
  * Requires coarseK == 1.  dist[nq][k] / ids[nq][k] ascending; rows short of k entries are padded
- * with (+inf, -1).  rotate != 0 applies cvtmi_opq_rotate to the queries first.  k <= 128. */
+ * with (+inf, -1).  rotate != 0 applies cvtmi_opq_rotate to the queries first.  1 <= k <= CVTMI_K_MAX. */
 int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int k, float *dist,
                      int64_t *ids);
 int cvtmi_opq_search_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int k, float *dist,
@@ -305,7 +305,7 @@ int cvtmi_shard_merge_topk_dev(cvtmi_comm_t c, const float *local_dist, const in
                                float *dist, int64_t *ids, void *stream);
 
 /* get_sort_results (opq/src/common.h:25-37): the k smallest (score, index) pairs of scores[nq][n],
- * ascending; rows short of k entries are padded with (+inf, -1).  k <= 128. */
+ * ascending; rows short of k entries are padded with (+inf, -1).  1 <= k <= CVTMI_K_MAX. */
 int cvtmi_topk_select(const float *scores, int64_t nq, int64_t n, int k, float *dist, int64_t *ids);
 int cvtmi_topk_select_dev(const float *scores, int64_t nq, int64_t n, int k, float *dist, int64_t *ids,
                           void *stream);
@@ -323,7 +323,9 @@ int cvtmi_flat_add_dev(cvtmi_flat_t h, const void *x, const int64_t *labels, int
 int cvtmi_flat_ntotal(cvtmi_flat_t h, int64_t *n);
 int cvtmi_flat_reset(cvtmi_flat_t h);
 /* searchKnn (brutoforce.hpp:73-93) for nq queries: k smallest (distance, label), ascending.
- * dist is float[nq][k] for IP / L2F and int32_t[nq][k] for L2U8.  k <= 128. */
+ * dist is float[nq][k] for IP / L2F and int32_t[nq][k] for L2U8.  1 <= k <= CVTMI_K_MAX.  An index with fewer than k rows pads:
+ * label -1, distance field 0x7f800000 -- +inf as a float, and for L2U8 the same bit pattern read as int32 (2139095040: larger than
+ * any real distance, which is what lets the padded lists of row shards merge like all others). */
 int cvtmi_flat_search(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels);
 int cvtmi_flat_search_dev(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *dist, int64_t *labels,
                           void *stream);
@@ -442,7 +444,7 @@ int cvtmi_hnsw_search_adc_dev(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, i
                               float *dist, int64_t *labels, void *stream);
 /* cvtmi_hnsw_search_adc followed by an exact re-rank: the ADC traversal returns its `rerank` best nodes (k <= rerank <= 1024), their
  * fp32 distances to the RAW query are computed from the graph's own vectors in the summation order of the reference's distance
- * functions, and the k smallest come back (k <= 128); nodes with equal exact distances keep their ADC order.  16-byte codes steer
+ * functions, and the k smallest come back (k <= CVTMI_K_MAX); nodes with equal exact distances keep their ADC order.  16-byte codes steer
  * the traversal, full vectors are only touched for `rerank` nodes per query: the recall of the fp32 graph at a fraction of its
  * gather traffic. */
 int cvtmi_hnsw_search_adc_rerank(cvtmi_hnsw_t h, cvtmi_opq_t opq, const float *q, int64_t nq, int rotate, int k, int ef,

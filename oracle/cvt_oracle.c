@@ -438,7 +438,9 @@ ORC_API void orc_flat_search(int metric, int flavour, int D, const void *data, c
         for (int64_t i = m; i < k; ++i) { out_d[qi * k + i] = INFINITY; out_label[qi * k + i] = -1; }
         if (out_di) {
             /* exact integer distances recomputed for the winners */
-            for (int64_t i = 0; i < k; ++i) out_di[qi * k + i] = -1;
+            /* fewer than k rows: the reference's queue simply ends; the C ABI pads a fixed-size row with label -1 and the +inf bit
+             * pattern in the 4-byte distance field (include/cvtmi.h), for integer distances too */
+            for (int64_t i = 0; i < k; ++i) out_di[qi * k + i] = 0x7f800000;
             if (metric == ORC_L2U8) {
                 for (int64_t i = 0; i < m; ++i) {
                     int64_t lab = out_label[qi * k + i], rr = lab;

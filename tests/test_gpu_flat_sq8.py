@@ -90,6 +90,14 @@ def test_flat_any_k(amd, orc, metric, D):
     small = amd.FlatIndex(metric, D); small.add(db[:150])
     d, i = small.search(q[:2], 400)
     assert np.all(i[:, 150:] == -1) and np.array_equal(i[:, :150], orc.flat_search(metric, db[:150], q[:2], 150)[2])
+    # k larger than the index at small k too (every kernel family pads alike): label -1, the +inf bit pattern in the distance field
+    tiny = amd.FlatIndex(metric, D); tiny.add(db[:52])
+    for nq2, k2 in ((9, 80), (1, 60), (9, 128)):
+        d, i = tiny.search(q[:nq2], k2)
+        od, odi, oi = orc.flat_search(metric, db[:52], q[:nq2], k2)
+        assert np.array_equal(i, oi) and np.all(i[:, 52:] == -1), (nq2, k2)
+        assert np.array_equal(d, odi) if metric == L2U8 else np.array_equal(bits(d), bits(od)), (nq2, k2)
+        assert np.all(np.asarray(d[:, 52:]).view(np.uint32) == 0x7f800000)
     with pytest.raises(amd.CvtmiError):
         ix.search(q, 2049)
 

@@ -16,6 +16,10 @@ for it in range(iters):
     M = int(rng.choice([16, 16, 16, 8, 4])); K = int(rng.choice([256, 256, 200, 64, 17])); step = int(rng.choice([8, 4, 2, 16]))
     D = M * step
     n = int(rng.integers(1, 60000)); nq = int(rng.integers(1, 90)); k = int(rng.integers(1, 129))
+    if it % 3 == 1:    # the small-batch path (1 .. 8 queries, >= 65536 rows) and the big-k kernels (k > 128)
+        n = int(rng.integers(65536, 300000)); nq = int(rng.integers(1, 9)); k = int(rng.choice([1, 10, 100, 128, 129, 300]))
+    elif it % 3 == 2:  # enough query groups for the persistent grid to cut a group into segments
+        n = int(rng.integers(20000, 200000)); nq = int(rng.integers(60, 700)); k = int(rng.choice([1, 10, 100, 128, 200]))
     scale = float(rng.choice([1.0, 1e-3, 30.0]))
     books = (rng.normal(size=(M, K, step)) * scale).astype(np.float32)
     codes = rng.integers(0, K, size=(n, M), dtype=np.uint8)
@@ -26,7 +30,7 @@ for it in range(iters):
         q[0] = np.inf if rng.random() < 0.5 else np.nan
     idx = cvt_amd.OpqIndex(np.zeros((1, D), np.float32), books)
     idx.add_codes(codes)
-    for variant in (3, 4, 5, 1, 0):
+    for variant in (7, 6, 3, 4, 5, 1, 0):
         idx.set_param("scan_variant", variant); idx.set_param("splits", int(rng.choice([0, 0, 1, 2, 5])))
         idx.set_param("prerotate", int(rng.integers(0, 2)))
         d, i = idx.search(q, k, rotate=False)
