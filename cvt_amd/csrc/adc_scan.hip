@@ -1236,7 +1236,10 @@ ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int 
     // want_variant 7 = the library's own choice between 3 and 6: adc_scan16h where it measured ahead on a cache-resident index
     // (63 ... 500 query groups at 1 M rows: -6 % at 1000 queries, -10 ... -14 % at 2500; tools/sweep_scan_h.py), adc_scan16q elsewhere
     if (k > 128) { want_variant = 0; want_qtile = 1; }  // the exact row-per-lane kernel, one query per workgroup (kernels.h: kBigK)
-    if (want_variant == 7) want_variant = (m.M == 16 && nq >= 500 && nq <= 4000 && n_rows >= 131072 && n_rows * 16 <= (96LL << 20)) ? 6 : 3;
+    // 7 = choose: the persistent grid (6) wherever a query group is cut into row segments -- its segments share one histogram per query, so
+    // the candidates a segment has to store while its bound is loose fall with the split count (1 M rows: nq = 128 0.24 -> 0.20 ms wall,
+    // 1000 0.59 -> 0.47, 3000 1.23 -> 1.10); whole groups (nq > 3200 at 1 M rows) run 4 % faster on adc_scan16q
+    if (want_variant == 7) want_variant = (m.M == 16 && nq >= 100 && nq <= 3200 && n_rows >= 131072 && n_rows * 16 <= (96LL << 20)) ? 6 : 3;
     if (m.M == 16 && want_variant >= 3 && (nq >= 4 || want_variant == 6) && m.D <= 256) { p.variant = want_variant; qt = 8; }
     else if (m.M == 16 && want_variant >= 1) {
         if (want_variant <= 2 && (want_qtile == 0 || want_qtile == 4) && nq >= 4) { p.variant = want_variant; qt = 4; }

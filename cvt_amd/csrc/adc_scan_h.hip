@@ -49,6 +49,7 @@ struct ScanHArgs {
     const float *lut_g;         // [nq][16][256] fp32 tables (+inf past K)
     unsigned long long *spill;  // [grid][8][SH_CAPG]
     uint32_t *gthr;             // [nq] bounds shared by the row segments of a query group, or null
+    uint32_t *ghist;            // [nq][SH_BINS] candidates of ALL segments of a query by bin (groups cut into segments), or null
     int stride;                 // partial lists per query
     float *part_d;
     int64_t *part_id;
@@ -326,6 +327,31 @@ __device__ __forceinline__ uint32_t scanh_hist_bound(const uint32_t *hq, int k, 
     return t < 32767u ? t : 32767u;
 }
 
+// The same bound from the histogram the segments of a query share in HBM (device-scope atomic adds at L2; read around the vector L1).
+// Every counted entry is a row of the query, so the k-th smallest integer sum over ALL its rows is below the returned bound.
+__device__ __forceinline__ uint32_t scanh_hist_bound_shared(const uint32_t *hq, int k, uint32_t slack)
+{
+    const int lane = threadIdx.x & 63;
+    uint4 c;
+    c.x = __hip_atomic_load(hq + lane * 4 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c.y = __hip_atomic_load(hq + lane * 4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c.z = __hip_atomic_load(hq + lane * 4 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c.w = __hip_atomic_load(hq + lane * 4 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t mine = c.x + c.y + c.z + c.w;
+    const uint32_t incl = wave_incl_scan_add(mine);
+    const unsigned long long reach = __ballot(incl >= (uint32_t)k);
+    if (!reach) return 0xffffffffu;
+    const int l0 = __ffsll((long long)reach) - 1;
+    uint32_t cum = (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), l0);
+    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c.x, l0), c1 = (uint32_t)__builtin_amdgcn_readlane((int)c.y, l0),
+                   c2 = (uint32_t)__builtin_amdgcn_readlane((int)c.z, l0);
+    uint32_t b = (uint32_t)l0 * 4u;
+    cum += c0;
+    if (cum < (uint32_t)k) { ++b; cum += c1; if (cum < (uint32_t)k) { ++b; cum += c2; if (cum < (uint32_t)k) ++b; } }
+    const uint32_t t = ((b + 1u) << 7) + slack;
+    return t < 32767u ? t : 32767u;
+}
+
 // publish a (possibly) tighter bound of query q: thr_x, its half of thr_pk, the epoch.  Whole wave, t wave-uniform.  Plain loads and stores: two waves that publish at once leave one of two
 // valid bounds, and an epoch that moved at least once.
 __device__ __forceinline__ bool scanh_publish(ScanHCtl &ck, int q, uint32_t t)
@@ -448,6 +474,10 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
         // bounds shared by the segments of a group: read when a segment starts, written when it ends (a global atomic per published bound
         // sat in the scan loop's vmcnt queue: the row prefetch waited for its acknowledgement)
         uint32_t *const gthr = item.nseg > 1 ? a.gthr : nullptr;
+        // candidates of all segments of these queries by bin: a segment's bounds come from the union, i.e. from (segments) times the
+        // rows it has seen itself -- the candidates it has to store while its bound is still loose fall accordingly
+        uint32_t *const gh = (item.nseg > 1 && a.ghist) ? a.ghist + (size_t)group * QT * SH_BINS : nullptr;
+        const int q_valid = a.nq - group * QT;   // queries of this group that exist (the rest are copies of the last one)
 
         auto load_tables = [&]() {
             const uint4 *src = a.qlut + (size_t)group * 4096;
@@ -514,6 +544,13 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
             scan16q_seed<NT, PREROT>(a.k, load_rows, moffp, cr8, cq, lut_b, &hist[0][0], qp, ck.lazy, ck.thr_x, ck.thr_pk);
             for (int i = tid; i < QT * SH_BINS; i += NT) (&hist[0][0])[i] = 0;  // those rows are scanned (and counted) again
         }
+        if (gh) {   // what the other segments of these queries have counted so far
+            __syncthreads();
+            if (wave < QT && wave < q_valid && __builtin_amdgcn_readfirstlane(ck.lazy[wave])) {
+                const uint32_t t = scanh_hist_bound_shared(gh + wave * SH_BINS, a.k, qp.slack[wave]);
+                if (t != 0xffffffffu) (void)scanh_publish(ck, wave, t);
+            }
+        }
         __syncthreads();
         SQ_T(1);  // seed
 
@@ -561,6 +598,7 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
             const uint32_t pos = mybase + rank;
             const bool ok = have && pos < (uint32_t)SH_CAPG;
             if (ok) spill[(size_t)eq * SH_CAPG + pos] = e & 0x00007fffffffffffull;  // (the query tag leaves the key)
+            if (gh && ok && (int)eq < q_valid) atomicAdd(&gh[eq * SH_BINS + (((uint32_t)(e >> 32) & 0x7fffu) >> 7)], 1u);   // (no return value: fire and forget)
             const unsigned long long bad = __ballot(have && !ok);
             if (upd) {  // wave-uniform
                 [[maybe_unused]] const long long t_u0 = SQA_NOW();
@@ -568,7 +606,7 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
                 for (int q = 0; q < QT; ++q) {
                     if (!((upd >> q) & 1u)) continue;
                     if (!__builtin_amdgcn_readfirstlane(ck.lazy[q])) continue;
-                    const uint32_t t = scanh_hist_bound(hist[q], a.k, qp.slack[q]);
+                    const uint32_t t = (gh && q < q_valid) ? scanh_hist_bound_shared(gh + q * SH_BINS, a.k, qp.slack[q]) : scanh_hist_bound(hist[q], a.k, qp.slack[q]);
                     if (t != 0xffffffffu && scanh_publish(ck, q, t)) moved = true;
                 }
                 SH_CNT(3, 1); SH_CNT(4, SQA_NOW() - t_u0);
@@ -1146,6 +1184,11 @@ int launch_adc_scan_small(const OpqModelDev &m, const uint8_t *codes, const uint
 // ---------------------------------------------------------------------------------------------------------------------
 // host side: the item table
 // ---------------------------------------------------------------------------------------------------------------------
+static int g_scanh_share_hist = 1;   // cvtmi_set_tuning("scanh_share_hist"): the segments of a query count their candidates in one histogram (bounds from the union)
+void set_scanh_share_hist(int v) { g_scanh_share_hist = v != 0; }
+size_t scanh_gthr_bytes(int64_t nq) { return ((size_t)(nq + 3) / 4 * 4 + (size_t)nq * SH_BINS) * sizeof(uint32_t); }
+static double g_scanh_fix = 160000.0;   // cvtmi_set_tuning("scanh_fix"): what an item of a group kept whole costs besides its rows, in row-equivalents (planner)
+void set_scanh_fix(double v) { g_scanh_fix = v > 0 ? v : 160000.0; }
 static int g_scanh_balance = 0;       // 0 = choose, 1 = equal shares of the flat (group x row) space, 2 = (group, split) blocks
 static int64_t g_scanh_min_rows = 16384;  // smallest share of a workgroup in the balanced plan
 static int g_scanh_tail = 0;              // (group, split) blocks: the groups of the last, partly filled round may be cut finer (measured: no gain, off)
@@ -1178,7 +1221,8 @@ void scanh_plan(int64_t n_rows, int64_t nq, int splits, ScanHPlan &p)
     p.grid = 0; p.rounds = 0; p.stride = 1;
     if (groups <= 0 || n_rows <= 0) return;
     const bool resident = n_rows * 16 <= (96LL << 20);  // the pre-rotated rows stay in the Infinity Cache (and mostly in L2)
-    const bool balanced = splits <= 0 && n_rows <= MAX_SEG && (g_scanh_balance == 1 || (g_scanh_balance == 0 && resident && 2 * groups > slots && groups < slots));
+    const bool balanced = splits <= 0 && n_rows <= MAX_SEG && g_scanh_balance == 1;   // (equal shares: only on request since the segments share their histograms -- row splits measure better, tools/sweep_scan_h.py)
+    (void)resident;
     // (planner's own choice: equal shares when S = 1 would fill the slots between half and whole -- 1 M rows x 2500 queries: 1.02-1.07 ms
     //  against 1.24 for whole groups and 1.18 for adc_scan16q; with more groups than slots the shares cost an item more per workgroup
     //  than blocks do and measured 2-10 % behind them, tools/sweep_scan_h.py)
@@ -1221,23 +1265,29 @@ void scanh_plan(int64_t n_rows, int64_t nq, int splits, ScanHPlan &p)
         int64_t S = splits > 0 ? splits : 1;
         const int64_t min_splits = (n_rows + MAX_SEG - 1) / MAX_SEG;
         if (splits <= 0) {
-            // blocks of one round share their rows through L2 when a row split stays on one XCD (split counts that divide 8, or multiples
-            // of 8).  Cost of a plan: rounds of `slots` items x (rows per item + what an item costs besides its rows: tables, seed, the
-            // candidates of its warm-up, the final selection -- measured at ~0.17 M row-equivalents, tools/sweep_scan_h.py); a last round
-            // that is at most half full counts 0.78 (a workgroup alone on its CU runs 1.27x faster).
-            const double fix = 170000.0;
-            const auto rounds_of = [&](int64_t blocks) {
-                const int64_t full = blocks / slots, last = blocks % slots;
-                if (!last) return (double)full;
-                const double f = (double)last / (double)slots;
-                return (double)full + (f <= 0.5 ? 0.78 : 0.78 + 0.44 * (f - 0.5));
+            // Cost of cutting every group into `cand` row splits = the makespan of the persistent grid: workgroup w walks items w, w + P, ...;
+            // CU c hosts workgroups c and c + slots / 2; an item costs its rows plus what it costs besides them (tables, seed, the candidates
+            // of its warm-up -- which the segments of a group now share through one histogram, so that part falls with the split count --,
+            // the final selection); while both workgroups of a CU are busy each runs at the shared look-up rate, the one that is left runs
+            // 1.65 x faster.  Constants fitted to tools/sweep_scan_h.py at 1 M rows (nq = 600 .. 5000, 1 .. 4 splits: the model picks the
+            // measured best everywhere but at nq = 2500, where it is 2 % off).  Round 3's model -- rounds x (0.17 M + rows) with a discount
+            // for a half-empty last round -- kept groups whole where two or four splits measure 15-20 % faster (nq = 1500, 2500, 3000).
+            const auto makespan = [&](int64_t cand) {
+                const double W = g_scanh_fix * (0.5 + 0.5 / (double)cand) + (double)n_rows / (double)cand;
+                const int64_t items = groups * cand, P = std::min<int64_t>(slots, items), cus = std::max<int64_t>(1, slots / 2);
+                const auto cnt = [&](int64_t w) -> int64_t { return w < P ? items / P + (w < items % P ? 1 : 0) : 0; };
+                double T = 0.0;
+                for (int64_t c = 0; c < cus; ++c) {
+                    const int64_t x = cnt(c), y = cnt(c + cus), lo = std::min(x, y), hi = std::max(x, y);
+                    T = std::max(T, (double)lo * W + (double)(hi - lo) * W / 1.65);
+                }
+                return T;
             };
             double best_cost = 1e300;
             S = min_splits;
             for (int64_t cand = min_splits; cand <= 64; ++cand) {
                 if (cand > min_splits && n_rows / cand < 16384) break;
-                double cost = rounds_of(groups * cand) * (fix + (double)n_rows / (double)cand);
-                if (cand % 8 == 0 || 8 % cand == 0) cost *= 0.97;
+                const double cost = makespan(cand);
                 if (cost < best_cost * 0.99) { best_cost = cost; S = cand; }
             }
         }
@@ -1269,7 +1319,7 @@ void scanh_plan(int64_t n_rows, int64_t nq, int splits, ScanHPlan &p)
         int64_t ga = groups, Sb = S;
         if (splits <= 0 && S == 1 && groups > slots && groups % slots != 0 && g_scanh_tail) {
             const int64_t rem = groups % slots;
-            const double fix = 170000.0;
+            const double fix = g_scanh_fix;
             double best = 1e300;
             for (int64_t cand = 1; cand <= 32 && n_rows / cand >= 16384; ++cand) {
                 const int64_t blocks = rem * cand;
@@ -1339,7 +1389,10 @@ int launch_adc_scan_h(const OpqModelDev &m, const uint8_t *codes, const uint8_t 
                        lut_g, reinterpret_cast<uint4 *>(qlut), reinterpret_cast<QuantParams *>(qp_g), lazy);
     CVTMI_HIP(hipGetLastError());
     if (gthr && plan.stride > 1) CVTMI_HIP(hipMemsetAsync(gthr, 0xff, (size_t)nq * sizeof(uint32_t), st));
+    uint32_t *ghist = (gthr && plan.stride > 1 && g_scanh_share_hist) ? gthr + (nq + 3) / 4 * 4 : nullptr;
+    if (ghist) CVTMI_HIP(hipMemsetAsync(ghist, 0, (size_t)nq * SH_BINS * sizeof(uint32_t), st));
     ScanHArgs a;
+    a.ghist = ghist;
     a.codes = codes; a.codes_rot = codes_rot; a.id_base = id_base; a.nq = (int)nq; a.k = k; a.K = m.K;
     a.items = items_dev; a.rounds = plan.rounds;
     a.qlut = reinterpret_cast<const uint4 *>(qlut); a.qp_g = reinterpret_cast<const QuantParams *>(qp_g); a.lut_g = lut_g;

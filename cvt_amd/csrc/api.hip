@@ -424,6 +424,8 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         g_host_chunks = (int)value;
         return CVTMI_OK;
     }
+    if (!strcmp(name, "scanh_fix")) { set_scanh_fix(value); ++g_scanh_key; return CVTMI_OK; }
+    if (!strcmp(name, "scanh_share_hist")) { set_scanh_share_hist((int)value); return CVTMI_OK; }
     if (!strcmp(name, "scanh_tail")) {
         set_scanh_tail((int)value);
         ++g_scanh_key;
@@ -854,7 +856,7 @@ static int opq_search_h(cvtmi_opq_t h, OpqScratch &S, const float *q_rot, int64_
     CVTMI_TRY(S.s_spill.reserve(scanh_spill_bytes(hp.grid)));
     uint32_t *gthr = nullptr;
     if (hp.stride > 1 && h->p_share) {
-        CVTMI_TRY(S.s_gthr.reserve((size_t)nq * sizeof(uint32_t)));
+        CVTMI_TRY(S.s_gthr.reserve(scanh_gthr_bytes(nq)));   // the bounds and, behind them, the histograms the segments of a query share
         gthr = S.s_gthr.as<uint32_t>();
     }
     int slot = 0;

@@ -85,7 +85,10 @@ size_t scanh_qlut_bytes(int64_t nq);
 size_t scanh_qp_bytes(int64_t nq);
 void set_scanh_balance(int v);       // 0 = choose, 1 = equal shares of the flat (group x row) space, 2 = (group, split) blocks
 void set_scanh_min_rows(int64_t v);  // smallest share of a workgroup in the balanced plan
-void set_scanh_tail(int v);          // 1 (default) = the groups of the last, partly filled round of blocks may be cut finer
+void set_scanh_tail(int v);
+void set_scanh_share_hist(int v);
+void set_scanh_fix(double v);
+size_t scanh_gthr_bytes(int64_t nq);   // adc_scan16h: [nq] shared bounds + [nq][256] shared histograms          // 1 (default) = the groups of the last, partly filled round of blocks may be cut finer
 // part_d / part_id: [nq][plan.stride][k]; out_d / out_id: the final [nq][k] lists (groups scanned in one piece write there); lut_g: nq * 16 * 256 floats; qlut / qp_g / spill: scanh_*_bytes; gthr: nq words or null
 int launch_adc_scan_h(const OpqModelDev &m, const uint8_t *codes, const uint8_t *codes_rot, int64_t n_rows, int64_t id_base,
                       const float *q_rot, int64_t nq, int k, const ScanHPlan &plan, const ScanItem *items_dev, float *part_d,

@@ -185,9 +185,10 @@ int cvtmi_opq_query_video_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rot
  *                   6 = adc_scan16h: the tables of variant 3, quantised once per query group by a preparation kernel; a
  *                   persistent grid (two workgroups per CU) walks a host-built item table (cvtmi_opq_scan_plan); candidates go
  *                   to per-workgroup areas in HBM and are selected once per (row segment, query), the filter bounds come from
- *                   a histogram of the candidates' integer sums; takes any number of queries
- *                   7 = (default) the library's choice: 6 where it measured ahead (500 ... 4000 queries on a cache-resident
- *                   index), 3 elsewhere
+ *                   a histogram of the candidates' integer sums -- ONE histogram per query for all the row segments its group
+ *                   is cut into, so a segment's bound comes from the rows all of them have seen; takes any number of queries
+ *                   7 = (default) the library's choice: 6 where it measured ahead (100 ... 3200 queries on a cache-resident
+ *                   index: wherever the planner cuts a query group into row segments), 3 elsewhere
  *   "prerotate"   1 (default) = variants 3 / 4 stream a copy of the code rows in which row r is rotated by r & 15
  *                 bytes (the lane skew of the conflict-free table reads), kept next to the rows: +16 bytes of HBM
  *                 per row, 12 VALU instructions fewer per row in the VALU-bound scan loop; 0 = rotate in registers

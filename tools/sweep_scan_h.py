@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """adc_scan16h (scan_variant 6) against adc_scan16q (3) on the bench's data: kernel ms (HIP events inside the library: tables +
-scan for 6, scan for 3), wall ms per search, identical results.  ROWS / NQS / K env; CFGS = variant:balance:min_rows:splits,..."""
+scan for 6, scan for 3), wall ms per search, identical results.  ROWS / NQS / K env; CFGS = variant:balance:min_rows:splits[:share_hist],..."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,7 +37,11 @@ for nq in nqs:
     q = qs[:nq].contiguous()
     ref = None
     for cfg in cfgs.split(","):
-        var, bal, minr, sp = [int(v) for v in cfg.split(":")]
+        f = [int(v) for v in cfg.split(":")]
+        var, bal, minr, sp = f[:4]
+        sh = f[4] if len(f) > 4 else 1
+        cvt_amd.set_tuning("scanh_fix", f[5] if len(f) > 5 else 170000)
+        cvt_amd.set_tuning("scanh_share_hist", sh)
         idx.set_param("scan_variant", var); idx.set_param("splits", sp)
         cvt_amd.set_tuning("scanh_balance", bal)
         cvt_amd.set_tuning("scanh_min_rows", minr if minr else 16384)
@@ -53,5 +57,5 @@ for nq in nqs:
             idx.search(q, k)
         torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / reps * 1e3
         s = idx.last_scan()
-        print("rows=%d nq=%d k=%d variant=%d balance=%d min_rows=%d splits(req)=%d -> lists=%d: kernel %.4f ms, wall %.4f ms, %.0f q/s, same=%s" % (
-            rows, nq, k, var, bal, minr, sp, s["splits"], s["ms"], wall, nq / wall * 1e3, same), flush=True)
+        print("rows=%d nq=%d k=%d variant=%d balance=%d min_rows=%d splits(req)=%d share_hist=%d fix=%d -> lists=%d: kernel %.4f ms, wall %.4f ms, %.0f q/s, same=%s" % (
+            rows, nq, k, var, bal, minr, sp, sh, f[5] if len(f) > 5 else 170000, s["splits"], s["ms"], wall, nq / wall * 1e3, same), flush=True)
