@@ -160,8 +160,8 @@ __global__ __launch_bounds__(1024) void scan16h_prep_kernel(const float *__restr
             res[q * 256 + d] = __fsub_rn(y, centroid[d]);
         }
     }
-    if (zero && blockIdx.x == 0)
-        for (int i = tid; i < zero_words; i += NT) zero[i] = 0u;
+    if (zero)   // (small-batch path: the control words of this query group)
+        for (int i = tid; i < zero_words; i += NT) zero[(size_t)blockIdx.x * zero_words + i] = 0u;
     if (tid < QT * 16) {
         qp.mn_bits[tid >> 4][tid & 15] = 0x7f7fffffu;
         mx_bits[tid >> 4][tid & 15] = 0u;
@@ -862,11 +862,13 @@ __global__ __launch_bounds__(1024) void scan16s_hist_kernel(const ScanSArgs a)  
     constexpr int NT = 1024, QT = SQ_QT;
     __shared__ __attribute__((aligned(16))) uint32_t lut[256 * 16 * QT / 2];
     __shared__ uint32_t hist[QT][SH_BINS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = blockIdx.y;   // one grid row per query group
+    const uint4 *qlut = a.qlut + (size_t)grp * 4096;
+    uint32_t *ctl = a.ctl + (size_t)grp * SS_WORDS;
     {
         uint4 t[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) t[i] = a.qlut[tid + i * NT];
+        for (int i = 0; i < 4; ++i) t[i] = qlut[tid + i * NT];
 #pragma unroll
         for (int i = 0; i < 4; ++i) reinterpret_cast<uint4 *>(lut)[tid + i * NT] = t[i];
     }
@@ -898,7 +900,7 @@ __global__ __launch_bounds__(1024) void scan16s_hist_kernel(const ScanSArgs a)  
     __syncthreads();
     for (int i = tid; i < QT * SH_BINS; i += NT) {
         const uint32_t v = (&hist[0][0])[i];
-        if (v) atomicAdd(&a.ctl[i], v);
+        if (v) atomicAdd(&ctl[i], v);
     }
 }
 
@@ -961,16 +963,18 @@ __global__ __launch_bounds__(1024) void scan16s_collect_kernel(const ScanSArgs a
     __shared__ QuantParams qp;
     __shared__ uint32_t T[QT], tpk_s[QT / 2];
     __shared__ uint32_t cnt[QT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = blockIdx.y;   // one grid row per query group
+    const uint4 *qlut = a.qlut + (size_t)grp * 4096;
+    uint32_t *ctl = a.ctl + (size_t)grp * SS_WORDS;
     {
         uint4 t[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) t[i] = a.qlut[tid + i * NT];
+        for (int i = 0; i < 4; ++i) t[i] = qlut[tid + i * NT];
 #pragma unroll
         for (int i = 0; i < 4; ++i) reinterpret_cast<uint4 *>(lut)[tid + i * NT] = t[i];
     }
-    if (tid < (int)(sizeof(QuantParams) / 4)) reinterpret_cast<uint32_t *>(&qp)[tid] = reinterpret_cast<const uint32_t *>(a.qp_g)[tid];
-    for (int i = tid; i < QT * SH_BINS; i += NT) (&hist[0][0])[i] = a.ctl[i];
+    if (tid < (int)(sizeof(QuantParams) / 4)) reinterpret_cast<uint32_t *>(&qp)[tid] = reinterpret_cast<const uint32_t *>(a.qp_g + grp)[tid];
+    for (int i = tid; i < QT * SH_BINS; i += NT) (&hist[0][0])[i] = ctl[i];
     if (tid < QT) cnt[tid] = 0;
     __syncthreads();
     if (wave < QT) {  // the bound of query `wave` from the global histogram (a sample: every 4th chunk of every row block)
@@ -979,7 +983,7 @@ __global__ __launch_bounds__(1024) void scan16s_collect_kernel(const ScanSArgs a
         if (t > 32767u) t = 32767u;  // fewer than k rows sampled, or sums that bound nothing: every row is a candidate
         if (lane == 0) {
             T[wave] = t;
-            if (blockIdx.x == 0) a.ctl[QT * SH_BINS + wave] = t;   // for the selection kernel
+            if (blockIdx.x == 0) ctl[QT * SH_BINS + wave] = t;   // for the selection kernel
         }
     }
     __syncthreads();
@@ -1001,7 +1005,7 @@ __global__ __launch_bounds__(1024) void scan16s_collect_kernel(const ScanSArgs a
     int64_t r1 = r0 + a.rows_per_wg;
     r1 = r1 < a.n_rows ? r1 : a.n_rows;
     const uint4 *rows = reinterpret_cast<const uint4 *>(PREROT ? a.codes_rot : a.codes);
-    unsigned long long *mine = a.gcand + (size_t)blockIdx.x * QT * SS_WCAP;
+    unsigned long long *mine = a.gcand + ((size_t)grp * a.G + blockIdx.x) * QT * SS_WCAP;
     for (int64_t base = r0 + ((int64_t)wave << 6); base < r1 && a.dbg < 2; base += NT) {
         const int64_t row = base + lane;
         const uint4 v = rows[row < r1 ? row : r1 - 1];
@@ -1028,7 +1032,7 @@ __global__ __launch_bounds__(1024) void scan16s_collect_kernel(const ScanSArgs a
         }
     }
     __syncthreads();
-    if (tid < QT) a.wcnt[(size_t)blockIdx.x * QT + tid] = cnt[tid];
+    if (tid < QT) a.wcnt[((size_t)grp * a.G + blockIdx.x) * QT + tid] = cnt[tid];
 }
 
 // one workgroup per query: the candidates of all collect workgroups, the k-th smallest integer sum among them (two histogram
@@ -1047,11 +1051,11 @@ __global__ __launch_bounds__(1024, 8) void scan16s_select_kernel(const ScanSArgs
     __shared__ QuantParams qp;
     __shared__ uint32_t off[1024 + 1];
     __shared__ int s_slow;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x, grp = q / QT, ql = q % QT;   // query, its group, its place there
     if (a.dbg) return;
-    if (tid < (int)(sizeof(QuantParams) / 4)) reinterpret_cast<uint32_t *>(&qp)[tid] = reinterpret_cast<const uint32_t *>(a.qp_g)[tid];
+    if (tid < (int)(sizeof(QuantParams) / 4)) reinterpret_cast<uint32_t *>(&qp)[tid] = reinterpret_cast<const uint32_t *>(a.qp_g + grp)[tid];
     // candidates per collect workgroup (G <= 1024) -> exclusive offsets
-    uint32_t c = tid < a.G ? a.wcnt[(size_t)tid * QT + q] : 0u;
+    uint32_t c = tid < a.G ? a.wcnt[((size_t)grp * a.G + tid) * QT + ql] : 0u;
     const bool dropped = c > (uint32_t)SS_WCAP;
     off[tid] = c;
     if (tid == 0) s_slow = 0;
@@ -1064,19 +1068,19 @@ __global__ __launch_bounds__(1024, 8) void scan16s_select_kernel(const ScanSArgs
     }
     __syncthreads();
     const uint32_t n = off[a.G];
-    const uint32_t Tq = a.ctl[QT * SH_BINS + q];
+    const uint32_t Tq = a.ctl[(size_t)grp * SS_WORDS + QT * SH_BINS + ql];
     if (s_slow || n > (uint32_t)SS_NMAX || Tq >= 32767u) {   // workgroup-uniform
         scans_exact_query<NT>(a, q, lds);
         return;
     }
     if (tid < a.G) {
-        const unsigned long long *src = a.gcand + ((size_t)tid * QT + q) * SS_WCAP;
+        const unsigned long long *src = a.gcand + (((size_t)grp * a.G + tid) * QT + ql) * SS_WCAP;
         for (uint32_t j = 0; j < c; ++j) cand[off[tid] + j] = src[j];
     }
     __syncthreads();
     if (wave != 0) return;
     uint32_t Tsel = Tq;
-    if ((int)n > a.k + 64 && qp.slack[q]) {
+    if ((int)n > a.k + 64 && qp.slack[ql]) {
         // k-th smallest integer sum of the list: bin of 128 by one histogram pass, position inside the bin by a second; rows at
         // S_k + slack and beyond are beaten by k rows (adc_scan16.h), the few below it get exact sums
         for (int i = lane; i < SH_BINS; i += 64) h[i] = 0;
@@ -1106,17 +1110,17 @@ __global__ __launch_bounds__(1024, 8) void scan16s_select_kernel(const ScanSArgs
                 const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)(inc2 - f0 - f1), l2);
                 const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)f0, l2);
                 const uint32_t sk = (b << 7) + (uint32_t)l2 * 2u + (before + g0 >= need ? 0u : 1u);
-                const uint32_t t2 = sk + qp.slack[q];
+                const uint32_t t2 = sk + qp.slack[ql];
                 Tsel = t2 < Tsel ? t2 : Tsel;
             }
         }
     }
     const QuantThr thrx{ &qp };
-    const ExactFromLutBatch fixb{ reinterpret_cast<const uint4 *>(a.codes), a.lut_g, a.K, a.nq, 0 };
-    const int keep = scanh_select_q<true>(tk, q, a.k, cand, (int)n, 0, Tsel, fixb, thrx);
+    const ExactFromLutBatch fixb{ reinterpret_cast<const uint4 *>(a.codes), a.lut_g, a.K, a.nq, grp };
+    const int keep = scanh_select_q<true>(tk, ql, a.k, cand, (int)n, 0, Tsel, fixb, thrx);
     for (int i = lane; i < a.k; i += 64) {
         if (i < keep) {
-            const unsigned long long e = tk.buf[q][i];
+            const unsigned long long e = tk.buf[ql][i];
             a.out_d[(int64_t)q * a.k + i] = __uint_as_float((uint32_t)(e >> 32));
             a.out_id[(int64_t)q * a.k + i] = a.id_base + (int64_t)(uint32_t)e;
         } else {
@@ -1129,15 +1133,18 @@ __global__ __launch_bounds__(1024, 8) void scan16s_select_kernel(const ScanSArgs
 static int g_scans_dbg = 0;
 void set_scans_dbg(int v) { g_scans_dbg = v; }
 constexpr int SS_GMAX = 1024;   // collect workgroups at most (the selection kernel's prefix over them)
+constexpr int SS_GROUPS = 16;   // query groups the small-batch path takes (128 queries; the dispatch stops earlier, where the persistent grid catches up)
+static int scans_collect_max() { const int g = scanh_slots() / 2; return g < SS_GMAX ? g : SS_GMAX; }   // collect workgroups per group: one per CU
 size_t scans_scratch_bytes()
 {
-    return ((size_t)SS_WORDS * 4 + 63) / 64 * 64 + (size_t)SS_GMAX * SQ_QT * 4 + (size_t)SS_GMAX * SQ_QT * SS_WCAP * sizeof(unsigned long long);
+    const size_t gm = (size_t)scans_collect_max();
+    return ((size_t)SS_GROUPS * SS_WORDS * 4 + 63) / 64 * 64 + (size_t)SS_GROUPS * gm * SQ_QT * 4 + (size_t)SS_GROUPS * gm * SQ_QT * SS_WCAP * sizeof(unsigned long long);
 }
 // the preparation kernel rotates in LDS: a dense R needs D a power of two <= 128 (64 KB); a permutation or no rotation: any D
 bool scans_fuses_rotation(const OpqModelDev &m) { return !m.R || (m.D <= 128 && m.D >= 4 && (m.D & (m.D - 1)) == 0); }
 bool scans_applies(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k)
 {
-    return m.M == 16 && m.D <= 256 && m.K >= 1 && m.K <= 256 && nq >= 1 && nq <= SQ_QT && k >= 1 && k <= 128 && n_rows >= 65536 && n_rows <= 0xfffffffeLL;
+    return m.M == 16 && m.D <= 256 && m.K >= 1 && m.K <= 256 && nq >= 1 && nq <= SS_GROUPS * SQ_QT && k >= 1 && k <= 128 && n_rows >= 65536 && n_rows <= 0xfffffffeLL;
 }
 
 // q: RAW queries when rotate != 0 (the model's rotation is applied by the preparation kernel), rotated ones otherwise
@@ -1147,7 +1154,8 @@ int launch_adc_scan_small(const OpqModelDev &m, const uint8_t *codes, const uint
 {
     if (!scans_applies(m, n_rows, nq, k)) return fail(CVTMI_EUNSUPPORTED, "adc_scan16s: shape not covered");
     uint32_t *ctl = reinterpret_cast<uint32_t *>(scratch);
-    hipLaunchKernelGGL(scan16h_prep_kernel, dim3(1), dim3(1024), 0, st, q, (int)nq, m.D, m.step, m.K, m.books, m.coarse, lut_g,
+    const unsigned ng = (unsigned)((nq + SQ_QT - 1) / SQ_QT);   // query groups: a grid row each in the two row passes
+    hipLaunchKernelGGL(scan16h_prep_kernel, dim3(ng), dim3(1024), 0, st, q, (int)nq, m.D, m.step, m.K, m.books, m.coarse, lut_g,
                        reinterpret_cast<uint4 *>(qlut), reinterpret_cast<QuantParams *>(qp_g), lazy, rotate ? m.R : nullptr, rotate ? m.perm : nullptr,
                        ctl, SS_WORDS);   // (a dense rotation: D a power of two <= 128, checked by the caller through scans_fuses_rotation)
     CVTMI_HIP(hipGetLastError());
@@ -1158,9 +1166,9 @@ int launch_adc_scan_small(const OpqModelDev &m, const uint8_t *codes, const uint
     a.nq = (int)nq; a.k = k; a.K = m.K;
     a.qlut = reinterpret_cast<const uint4 *>(qlut); a.qp_g = reinterpret_cast<const QuantParams *>(qp_g); a.lut_g = lut_g;
     a.ctl = ctl;
-    char *sc = reinterpret_cast<char *>(scratch) + ((size_t)SS_WORDS * 4 + 63) / 64 * 64;
+    char *sc = reinterpret_cast<char *>(scratch) + ((size_t)SS_GROUPS * SS_WORDS * 4 + 63) / 64 * 64;
     a.wcnt = reinterpret_cast<uint32_t *>(sc);
-    a.gcand = reinterpret_cast<unsigned long long *>(sc + (size_t)SS_GMAX * SQ_QT * 4);
+    a.gcand = reinterpret_cast<unsigned long long *>(sc + (size_t)SS_GROUPS * scans_collect_max() * SQ_QT * 4);
     a.out_d = dist; a.out_id = ids; a.dbg = g_scans_dbg;
     const unsigned g = (unsigned)((n_rows + a.rows_per_wg - 1) / a.rows_per_wg);
     a.G = (int)g;
@@ -1170,11 +1178,11 @@ int launch_adc_scan_small(const OpqModelDev &m, const uint8_t *codes, const uint
     a.rows_per_hist_wg = ((n_rows + hg - 1) / hg + 255) / 256 * 256;
     const unsigned gh = (unsigned)((n_rows + a.rows_per_hist_wg - 1) / a.rows_per_hist_wg);
     if (codes_rot) {
-        hipLaunchKernelGGL((scan16s_hist_kernel<true>), dim3(gh), dim3(1024), 0, st, a);
-        hipLaunchKernelGGL((scan16s_collect_kernel<true>), dim3(g), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL((scan16s_hist_kernel<true>), dim3(gh, ng), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL((scan16s_collect_kernel<true>), dim3(g, ng), dim3(1024), 0, st, a);
     } else {
-        hipLaunchKernelGGL((scan16s_hist_kernel<false>), dim3(gh), dim3(1024), 0, st, a);
-        hipLaunchKernelGGL((scan16s_collect_kernel<false>), dim3(g), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL((scan16s_hist_kernel<false>), dim3(gh, ng), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL((scan16s_collect_kernel<false>), dim3(g, ng), dim3(1024), 0, st, a);
     }
     hipLaunchKernelGGL(scan16s_select_kernel, dim3((unsigned)nq), dim3(1024), 0, st, a);
     CVTMI_HIP(hipGetLastError());

@@ -916,10 +916,10 @@ static int opq_search_leased(cvtmi_opq_t h, OpqScratch &S, const float *q, int64
     if (h->n == 0)  // an empty index (e.g. a rank whose row block is empty): all padding, (+inf, -1)
         return launch_topk_select(nullptr, nullptr, nq, 0, k, dist, ids, st);
     if (h->p_variant == 7 && h->p_splits == 0 && h->p_qtile == 0 && h->p_small && scans_applies(h->m, h->n, nq, k)) {
-        // 1 .. 8 queries: global bound first, candidate lists, selection by the last workgroup (adc_scan_h.hip) -- three launches,
-        // the rotation folded into the first
+        // 1 .. 128 queries (up to sixteen query groups): global bounds first, candidate lists, one selection workgroup per query
+        // (adc_scan_h.hip) -- four launches, the rotation folded into the first
         const uint8_t *crot = (h->m.M == 16 && h->p_prerot && h->rot_n == h->n && h->codes_rot.p) ? h->codes_rot.as<uint8_t>() : nullptr;
-        CVTMI_TRY(S.s_lut.reserve((size_t)8 * 16 * 256 * sizeof(float)));
+        CVTMI_TRY(S.s_lut.reserve((size_t)((nq + 7) / 8 * 8) * 16 * 256 * sizeof(float)));
         CVTMI_TRY(S.s_qlut.reserve(scanh_qlut_bytes(nq)));
         CVTMI_TRY(S.s_qp.reserve(scanh_qp_bytes(nq)));
         CVTMI_TRY(S.s_spill.reserve(scans_scratch_bytes()));
@@ -1072,8 +1072,8 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
         fl[i].n = 0;
         return CVTMI_OK;
     };
-    // 1 .. 8 queries (the reference's call pattern: a handful of frames per Query): the copies are a third of such a call.  The table
-    // kernel reads the 4 KB of queries and the selection kernel writes the results straight from / to the pinned staging area (page-locked
+    // Small batches (the reference's call pattern: a handful of frames per Query; here whatever takes the small-batch path, up to 128
+    // queries): the copies are a third of such a call.  The table kernel reads the queries and the selection kernel writes the results straight from / to the pinned staging area (page-locked
     // host memory is device-visible: one PCIe read of the queries, posted writes of the lists) -- no copy engine in the chain.
     if (chunks == 1 && g_small_zero_copy.load() && h->n > 0 && h->p_variant == 7 && h->p_splits == 0 && h->p_qtile == 0 && h->p_small &&
         scans_applies(h->m, h->n, nq, k)) {

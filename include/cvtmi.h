@@ -197,9 +197,10 @@ int cvtmi_opq_query_video_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rot
  *   "scan_lazy"   1 (default) = variants 3 / 4 select on their integer lower bounds between checkpoints and compute exact
  *                 reference-order sums once, for the rows still held at the end; 0 = exact sums at every checkpoint
  *   "scan_share"  1 (default) = the row splits of a query publish their filter thresholds to each other (variants 3 / 4)
- *   "scan_small"  1 (default) = batches of 1 .. 8 queries (M = 16, >= 65 536 rows, k <= 128, "scan_variant" 7) take the small-batch
- *                 path: a histogram pass over a quarter of the rows fixes one global bound per query, a second pass collects the
- *                 rows below it, the workgroup that finishes last selects -- three launches, rotation included
+ *   "scan_small"  1 (default) = batches of 1 .. 128 queries (M = 16, >= 65 536 rows, k <= 128, "scan_variant" 7) take the small-batch
+ *                 path: per group of 8 queries a histogram pass over a quarter of the rows fixes one global bound per query, a second
+ *                 pass collects the rows below it into per-workgroup lists, one workgroup per query selects (exact fall-back inside the
+ *                 kernel when a list overflows) -- four launches, rotation included, no partial lists and no merge
  *   "groups_a", "splits_b"  force that two-region shape: the first groups_a query groups use "splits" row
  *                 splits, the others splits_b (> splits); 0 = planner's choice */
 int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value);

@@ -589,7 +589,7 @@ def test_search_any_k(amd, orc, M):
 @pytest.mark.gpu
 @pytest.mark.parametrize("rotation", ["dense", "perm", "none"])
 def test_small_batch_path(amd, orc, rotation):
-    """1 .. 8 queries (the reference's own call pattern: 1-9 query frames per Query) through the small-batch path -- rotation folded
+    """1 .. 128 queries (the reference's own call pattern: 1-9 query frames per Query) through the small-batch path -- rotation folded
     into the table kernel, a global bound from a histogram pass, candidate lists, selection by the last workgroup -- against the oracle
     and against the ordinary path: k = 1 .. 128, exact ties, a list that overflows (7000 copies of the query's nearest row: the exact
     fall-back inside the kernel), a NaN query beside ordinary ones, appended rows, an id base, device and host pointers."""
@@ -609,7 +609,7 @@ def test_small_batch_path(amd, orc, rotation):
     codes[100] = codes[50]; codes[140_000] = codes[50]
     idx.add_codes(codes[:90_000]); idx.add_codes(codes[90_000:])
     idx.set_id_base(1 << 34)
-    q = (rng.normal(size=(8, D)) * 0.1).astype(np.float32)
+    q = (rng.normal(size=(128, D)) * 0.1).astype(np.float32)
 
     def rot(x):
         if rotation == "dense":
@@ -618,8 +618,8 @@ def test_small_batch_path(amd, orc, rotation):
             return x[:, kw["perm"]]
         return x
 
-    for nq in (1, 2, 5, 8):
-        for k in (1, 10, 100, 128):
+    for nq in (1, 2, 5, 8, 9, 17, 32, 100, 128):   # up to sixteen query groups; 9 and 17: a last group with one real query and seven copies
+        for k in ((1, 10, 100, 128) if nq <= 32 else (100,)):
             od, oi = orc.adc_search(rot(q[:nq]), books, codes, k)
             for small in (1, 0):
                 idx.set_param("scan_small", small)
@@ -633,7 +633,7 @@ def test_small_batch_path(amd, orc, rotation):
     idx.set_id_base(0)
     crowd = codes.copy(); crowd[20_000:27_000] = codes[7]
     idx.reset(); idx.add_codes(crowd)
-    q2 = q.copy()
+    q2 = q[:8].copy()
     raw7 = np.concatenate([books[m, codes[7][m]] for m in range(M)])            # the rotated point that sits on row 7's codewords
     if rotation == "dense":
         q2[3] = (kw["R"].T.astype(np.float64) @ raw7.astype(np.float64)).astype(np.float32)
@@ -648,4 +648,9 @@ def test_small_batch_path(amd, orc, rotation):
         ok = np.array([f != 5 for f in range(8)])
         assert np.array_equal(i[ok], oi[ok]) and np.array_equal(bits(d)[ok], bits(od)[ok]), k
         assert np.array_equal(i[3], np.sort(i[3])) and i[3][0] == 7 or rotation == "dense"   # the crowd's ties come in id order
+    # the same crowd in the SECOND group of a 12-query call (group-local indices in the selection kernel)
+    q3 = np.concatenate([q[8:16], q2[:4]])
+    od, oi = orc.adc_search(rot(q3), books, crowd, 100)
+    d, i = idx.search(q3, 100, rotate=True)
+    assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od))
     idx.close()

@@ -16,8 +16,8 @@ for it in range(iters):
     M = int(rng.choice([16, 16, 16, 8, 4])); K = int(rng.choice([256, 256, 200, 64, 17])); step = int(rng.choice([8, 4, 2, 16]))
     D = M * step
     n = int(rng.integers(1, 60000)); nq = int(rng.integers(1, 90)); k = int(rng.integers(1, 129))
-    if it % 3 == 1:    # the small-batch path (1 .. 8 queries, >= 65536 rows) and the big-k kernels (k > 128)
-        n = int(rng.integers(65536, 300000)); nq = int(rng.integers(1, 9)); k = int(rng.choice([1, 10, 100, 128, 129, 300]))
+    if it % 3 == 1:    # the small-batch path (1 .. 32 queries, >= 65536 rows) and the big-k kernels (k > 128)
+        n = int(rng.integers(65536, 300000)); nq = int(rng.integers(1, 33)); k = int(rng.choice([1, 10, 100, 128, 129, 300]))
     elif it % 3 == 2:  # enough query groups for the persistent grid to cut a group into segments
         n = int(rng.integers(20000, 200000)); nq = int(rng.integers(60, 700)); k = int(rng.choice([1, 10, 100, 128, 200]))
     scale = float(rng.choice([1.0, 1e-3, 30.0]))

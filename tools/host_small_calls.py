@@ -16,7 +16,7 @@ rng = np.random.default_rng(1)
 books = rng.normal(size=(M, K, D // M)).astype(np.float32)
 idx = cvt_amd.OpqIndex(zero, books, R=synth.random_rotation(D, seed=7))
 idx.add_codes(torch.randint(0, 256, (rows, M), dtype=torch.uint8, device=dev))
-for nq in [int(v) for v in os.environ.get("NQS", "1,8,64,1000").split(",")]:
+for nq in [int(v) for v in os.environ.get("NQS", "1,8,32,128,1000").split(",")]:
     qh = rng.normal(size=(nq, D)).astype(np.float32)
     out = (np.zeros((nq, k), np.float32), np.zeros((nq, k), np.int64))
     ref = None
