@@ -1206,8 +1206,9 @@ int cvtmi_opq_query_video_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rot
         CVTMI_TRY(cvtmi_opq_rotate_dev(h, q, nq, h->s_qrot.as<float>(), stream));
         q_rot = h->s_qrot.as<float>();
     }
-    CVTMI_TRY(h->s_probe.reserve((size_t)nq * nprobe * sizeof(int32_t)));
-    CVTMI_TRY(launch_coarse_probe(h->m, q_rot, nq, nprobe, h->s_probe.as<int32_t>(), st));
+    const size_t probe_bytes = ((size_t)nq * nprobe * sizeof(int32_t) + 15) / 16 * 16;
+    CVTMI_TRY(h->s_probe.reserve(probe_bytes + coarse_probe_scratch_bytes(nq, nprobe)));
+    CVTMI_TRY(launch_coarse_probe(h->m, q_rot, nq, nprobe, h->s_probe.as<int32_t>(), st, h->s_probe.as<char>() + probe_bytes));
     return launch_query_video(h->m, q_rot, nq, nprobe, h->s_probe.as<int32_t>(), h->csr_off.as<int64_t>(), h->csr_codes.as<uint8_t>(),
                               h->csr_videos.as<int32_t>(), img_num, match_score, h->csr_longest, st);
 }

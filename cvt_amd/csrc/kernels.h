@@ -118,7 +118,8 @@ int launch_topk_merge_gathered(const float *in_d, const int64_t *in_id, int64_t 
 // ---- query_video.hip ----
 // probe[nq][nprobe] list ids in visiting order; list_off[coarseK+1]; codes/video_id in list order.
 int launch_coarse_probe(const OpqModelDev &m, const float *q_rot, int64_t nq, int nprobe, int32_t *probe,
-                        hipStream_t st);
+                        hipStream_t st, void *scratch = nullptr);
+size_t coarse_probe_scratch_bytes(int64_t nq, int nprobe);   // the few-queries form's partial lists (placed behind the probe array)
 // coarse top-nprobe through the matrix-core filter (assign_mfma.hip): same probes as the exact kernels
 void set_probe_variant(int v);
 void set_scan_seed(int v);  // adc_scan16q / 16a: 1 (default) = first thresholds from a histogram of the split's first 2048 rows

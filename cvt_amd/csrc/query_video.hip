@@ -50,6 +50,81 @@ __global__ __launch_bounds__(kBlock) void coarse_probe_kernel(const float *__res
     for (int i = tid; i < nprobe; i += kBlock) probe[qi * nprobe + i] = i < cnt ? (int32_t)(uint32_t)tk.buf[0][i] : -1;
 }
 
+// Few queries (the reference's own Query call: a handful of frames) against many lists: one workgroup per query walks all coarseK
+// centroids by itself -- 9 frames x 8192 lists kept 9 CUs busy for 169 us.  Here the centroids are cut into `splits` ranges, workgroup
+// (split, query) keeps the nprobe nearest of its range (same distance arithmetic, same (distance, list) order), and one workgroup per
+// query merges the splits' short lists.  The nprobe smallest (distance, list) pairs of a union are the nprobe smallest of the parts'.
+__global__ __launch_bounds__(kBlock) void coarse_probe_split_kernel(const float *__restrict__ q_rot, int D, const float *__restrict__ coarse, int coarseK,
+                                                                    int nprobe, int chunk, uint32_t *__restrict__ part_key, int32_t *__restrict__ part_id)
+{
+    extern __shared__ __attribute__((aligned(16))) float qv[];  // D floats
+    __shared__ TopKShared<1, PROBE_CAP> tk;
+    const int64_t qi = blockIdx.y;
+    const int split = blockIdx.x, splits = gridDim.x, tid = threadIdx.x;
+    for (int d = tid; d < D; d += kBlock) qv[d] = q_rot[qi * D + d];
+    topk_init(tk);
+    __syncthreads();
+    const int c0 = split * chunk, c1 = c0 + chunk < coarseK ? c0 + chunk : coarseK;
+    int tile = 0;
+    for (int base = c0; base < c1; base += kBlock, ++tile) {
+        const int c = base + tid;
+        uint32_t key[1][1] = { { KEY_MAX } };
+        uint32_t pay[1] = { (uint32_t)c };
+        if (c < c1) {
+            const float *cp = coarse + (int64_t)c * D;
+            float acc = 0.0f;
+            if ((D & 3) == 0) {   // (rows are 16-byte aligned when D is a multiple of 4: four dimensions per load, same operation order)
+                for (int d = 0; d < D; d += 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(cp + d);
+                    const float t0 = __fsub_rn(qv[d], v.x), t1 = __fsub_rn(qv[d + 1], v.y), t2 = __fsub_rn(qv[d + 2], v.z), t3 = __fsub_rn(qv[d + 3], v.w);
+                    acc = __fadd_rn(acc, __fmul_rn(t0, t0)); acc = __fadd_rn(acc, __fmul_rn(t1, t1));
+                    acc = __fadd_rn(acc, __fmul_rn(t2, t2)); acc = __fadd_rn(acc, __fmul_rn(t3, t3));
+                }
+            } else {
+                for (int d = 0; d < D; ++d) {
+                    const float t = __fsub_rn(qv[d], cp[d]);
+                    acc = __fadd_rn(acc, __fmul_rn(t, t));
+                }
+            }
+            const uint32_t kk = __float_as_uint(acc);
+            key[0][0] = kk == KEY_MAX ? KEY_MAX - 1 : kk;
+        }
+        topk_tile<1, 1, PROBE_CAP, PROBE_TRIG>(tk, nprobe, tile, key, pay);
+    }
+    __syncthreads();
+    topk_compact(tk, nprobe);
+    const int cnt = tk.cnt[0];
+    const int64_t o = (qi * splits + split) * nprobe;
+    for (int i = tid; i < nprobe; i += kBlock) {
+        part_key[o + i] = i < cnt ? (uint32_t)(tk.buf[0][i] >> 32) : KEY_MAX;
+        part_id[o + i] = i < cnt ? (int32_t)(uint32_t)tk.buf[0][i] : -1;
+    }
+}
+__global__ __launch_bounds__(kBlock) void coarse_probe_merge_kernel(const uint32_t *__restrict__ part_key, const int32_t *__restrict__ part_id, int splits, int nprobe,
+                                                                    int32_t *__restrict__ probe)
+{
+    __shared__ TopKShared<1, PROBE_CAP> tk;
+    const int64_t qi = blockIdx.x;
+    const int tid = threadIdx.x, total = splits * nprobe;
+    topk_init(tk);
+    __syncthreads();
+    int tile = 0;
+    for (int base = 0; base < total; base += kBlock, ++tile) {
+        const int e = base + tid;
+        uint32_t key[1][1] = { { KEY_MAX } };
+        uint32_t pay[1] = { 0u };
+        if (e < total && part_id[qi * total + e] >= 0) {
+            key[0][0] = part_key[qi * total + e];
+            pay[0] = (uint32_t)part_id[qi * total + e];
+        }
+        topk_tile<1, 1, PROBE_CAP, PROBE_TRIG>(tk, nprobe, tile, key, pay);
+    }
+    __syncthreads();
+    topk_compact(tk, nprobe);
+    const int cnt = tk.cnt[0];
+    for (int i = tid; i < nprobe; i += kBlock) probe[qi * nprobe + i] = i < cnt ? (int32_t)(uint32_t)tk.buf[0][i] : -1;
+}
+
 // Batched form (nq >= 64): a workgroup serves 16 queries against 64-centroid tiles staged in LDS -- a centroid row is read
 // from memory once per 16 queries, with coalesced 16-byte loads, instead of once per query at a 4 D-byte stride.  Wave w owns
 // queries 4 w .. 4 w + 3, lane = centroid of the tile; distances in the reference's order (d ascending, separate multiply and add).
@@ -120,8 +195,34 @@ __global__ __launch_bounds__(kBlock) void coarse_probe_tile_kernel(const float *
 static int g_probe_variant = 0;  // cvtmi_set_tuning("probe_variant"): 0 choose, 1 exact kernels only, 2 matrix-core filter wherever it applies
 void set_probe_variant(int v) { g_probe_variant = v; }
 
-int launch_coarse_probe(const OpqModelDev &m, const float *q_rot, int64_t nq, int nprobe, int32_t *probe, hipStream_t st)
+// scratch the few-queries form needs behind the probe array: per (query, split) nprobe keys + nprobe list ids
+constexpr int PROBE_SPLITS_MAX = 64;
+// below this many queries the split form runs: the matrix-core filter (assign_mfma.hip) costs ~0.9 ms whatever the batch (8192 lists:
+// 256 frames 0.93 ms, 1000 frames 0.97 ms, 10 000 frames 1.47 ms), the split form ~0.5 us per frame
+constexpr int64_t PROBE_SPLIT_NQ = 1536;
+size_t coarse_probe_scratch_bytes(int64_t nq, int nprobe)
 {
+    const size_t b = (size_t)nq * PROBE_SPLITS_MAX * nprobe * 8;
+    return nq < PROBE_SPLIT_NQ && b <= ((size_t)64 << 20) ? b : 0;
+}
+
+int launch_coarse_probe(const OpqModelDev &m, const float *q_rot, int64_t nq, int nprobe, int32_t *probe, hipStream_t st, void *scratch)
+{
+    // few queries, many lists: every CU takes a range of the centroids (64 frames x 8192 lists on the 16-queries-per-workgroup kernel
+    // below: four workgroups, 2.05 ms)
+    if (scratch && g_probe_variant == 0 && m.coarseK >= 1024 && nq > 0 && coarse_probe_scratch_bytes(nq, nprobe) > 0 && nprobe >= 1 && nprobe <= 128) {
+        int splits = (m.coarseK + kBlock - 1) / kBlock;
+        if (splits > PROBE_SPLITS_MAX) splits = PROBE_SPLITS_MAX;
+        const int chunk = ((m.coarseK + splits - 1) / splits + kBlock - 1) / kBlock * kBlock;
+        splits = (m.coarseK + chunk - 1) / chunk;
+        uint32_t *pk = reinterpret_cast<uint32_t *>(scratch);
+        int32_t *pid = reinterpret_cast<int32_t *>(pk + (size_t)nq * splits * nprobe);
+        hipLaunchKernelGGL(coarse_probe_split_kernel, dim3((unsigned)splits, (unsigned)nq), dim3(kBlock), (size_t)m.D * sizeof(float), st, q_rot, m.D, m.coarse,
+                           m.coarseK, nprobe, chunk, pk, pid);
+        hipLaunchKernelGGL(coarse_probe_merge_kernel, dim3((unsigned)nq), dim3(kBlock), 0, st, pk, pid, splits, nprobe, probe);
+        CVTMI_HIP(hipGetLastError());
+        return CVTMI_OK;
+    }
     if (g_probe_variant != 1 && coarse_probe_filter_applies(q_rot, g_probe_variant == 2 ? std::max<int64_t>(nq, 256) : nq, m.D, m.coarse, m.coarseK, nprobe))
         return launch_coarse_probe_filtered(q_rot, nq, m.D, m.coarse, m.coarseK, nprobe, probe, st);
     if (nq >= 64 && nprobe <= 128 && m.D <= 256) {

@@ -84,6 +84,15 @@ def test_ivf_query_reference_shape(amd, orc):
             amd.set_tuning("probe_variant", variant)
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (variant, nkk)
     amd.set_tuning("probe_variant", 0)
+    # the library's own choice below 1536 frames: the centroids cut into ranges over all CUs, one merge per frame (coarse_probe_split_kernel)
+    # -- batch sizes on both sides of the old kernels' switch points, probe counts from 1 to more than a range's share
+    for nf in (1, 9, 64, 255, 300):
+        for nkk in (1, 3, 40):
+            a = idx.query_video(q[:nf].contiguous(), nkk, n_videos, rotate=True)
+            amd.set_tuning("probe_variant", 1)
+            b = idx.query_video(q[:nf].contiguous(), nkk, n_videos, rotate=True)
+            amd.set_tuning("probe_variant", 0)
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (nf, nkk)
     # the host-pointer entry gives the same
     msh = idx.query_video(q[:7].cpu().numpy(), nk, n_videos, rotate=True)
     assert np.array_equal(bits(msh), bits(oms[:7]))
