@@ -274,9 +274,11 @@ __global__ __launch_bounds__(AF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 pre[i] = packA[(int64_t)t * TILE + f];
             }
         };
-        fetch(0);
+        // (grid row y scores its own range of centroid tiles: with the queries alone -- 256 per workgroup -- 10 000 frames made 40 workgroups)
+        const int tpb = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y, t0 = (int)blockIdx.y * tpb, t1 = t0 + tpb < ntiles ? t0 + tpb : ntiles;
+        fetch(t0);
         __syncthreads();
-        for (int t = 0; t < ntiles; ++t) {
+        for (int t = t0; t < t1; ++t) {
             uint4 *stage = tile_s[t & 1];
 #pragma unroll
             for (int i = 0; i < LPT; ++i)
@@ -546,9 +548,11 @@ int launch_coarse_probe_filtered(const float *q, int64_t nq, int d, const float 
     for (int64_t a = 0; a < nq; a += chunk) {
         const int64_t m = std::min(chunk, nq - a);
         const int64_t blocks = std::min<int64_t>((m + rows_per_block - 1) / rows_per_block, 256 * 4);
+        // centroid-tile ranges per query block: enough workgroups for two per CU, at least 8 tiles (256 centroids) each
+        const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ntiles / 8, 32), (512 + blocks - 1) / blocks));
 #define CVTMI_PS(N)                                                                                                                   \
     case N:                                                                                                                           \
-        hipLaunchKernelGGL((probe_score_kernel<N>), dim3((unsigned)blocks), dim3(AF_THREADS), 0, st, q + a * d, (int64_t)d, m, packA, nhcp, ntiles, T, ldT); \
+        hipLaunchKernelGGL((probe_score_kernel<N>), dim3((unsigned)blocks, gy), dim3(AF_THREADS), 0, st, q + a * d, (int64_t)d, m, packA, nhcp, ntiles, T, ldT); \
         break;
         switch (nch) {
             CVTMI_PS(2) CVTMI_PS(3) CVTMI_PS(4) CVTMI_PS(5) CVTMI_PS(6) CVTMI_PS(7) CVTMI_PS(8)

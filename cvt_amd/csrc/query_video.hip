@@ -197,9 +197,9 @@ void set_probe_variant(int v) { g_probe_variant = v; }
 
 // scratch the few-queries form needs behind the probe array: per (query, split) nprobe keys + nprobe list ids
 constexpr int PROBE_SPLITS_MAX = 64;
-// below this many queries the split form runs: the matrix-core filter (assign_mfma.hip) costs ~0.9 ms whatever the batch (8192 lists:
-// 256 frames 0.93 ms, 1000 frames 0.97 ms, 10 000 frames 1.47 ms), the split form ~0.5 us per frame
-constexpr int64_t PROBE_SPLIT_NQ = 1536;
+// below this many queries the split form runs; from 256 on the matrix-core filter (assign_mfma.hip) applies and is faster (8192 lists:
+// 256 frames 0.167 ms against 0.178, 1000 frames 0.21 against 0.56 -- once its score kernel stopped running on nq / 256 workgroups)
+constexpr int64_t PROBE_SPLIT_NQ = 256;
 size_t coarse_probe_scratch_bytes(int64_t nq, int nprobe)
 {
     const size_t b = (size_t)nq * PROBE_SPLITS_MAX * nprobe * 8;
