@@ -692,12 +692,62 @@ __global__ __launch_bounds__(kBlock) void lut_kernel(const float *__restrict__ q
     }
 }
 
+// The same tables for sub-vectors of 8 (the usual shape), QB queries per workgroup: a thread fetches its centroid once, in two 16-byte
+// loads, and uses it for all QB queries -- the kernel above reads the 128 KB of codebooks once per query, a dword at a time (10 000
+// queries: 134 us, 1.2 TB/s of table writes).  Same operations in the same order per entry.
+template <int QB>
+__global__ __launch_bounds__(kBlock) void lut8_kernel(const float *__restrict__ q_rot, int64_t nq, int D, int M, int K, const float *__restrict__ coarse,
+                                                      const int32_t *__restrict__ list_id, const float *__restrict__ books, float *__restrict__ lut, int ld)
+{
+    extern __shared__ __attribute__((aligned(16))) float res[];  // [QB][D]
+    const int64_t q0 = (int64_t)blockIdx.x * QB;
+    for (int i = threadIdx.x; i < QB * D; i += kBlock) {
+        const int q = i / D, d = i - q * D;
+        const int64_t qi = q0 + q < nq ? q0 + q : nq - 1;
+        int l = list_id ? list_id[qi] : 0;
+        if (l < 0) l = 0;
+        res[i] = __fsub_rn(q_rot[qi * D + d], coarse[(int64_t)l * D + d]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < M * ld; e += kBlock) {
+        const int m = e / ld, j = e - m * ld;
+        float acc[QB];
+#pragma unroll
+        for (int q = 0; q < QB; ++q) acc[q] = __uint_as_float(0x7f800000u);
+        if (j < K) {
+            const float4 *c = reinterpret_cast<const float4 *>(books + ((int64_t)m * K + j) * 8);
+            const float4 c0 = c[0], c1 = c[1];
+            const float cv[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                float a = 0.0f;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float t = __fsub_rn(res[q * D + m * 8 + kk], cv[kk]);
+                    a = __fadd_rn(a, __fmul_rn(t, t));
+                }
+                acc[q] = a;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < QB; ++q)
+            if (q0 + q < nq) lut[(q0 + q) * M * ld + e] = acc[q];
+    }
+}
+
 int launch_lut(const OpqModelDev &m, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut, hipStream_t st,
                int ld)
 {
     if (ld <= 0) ld = m.K;
     if (nq <= 0) return CVTMI_OK;
     if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "lut: nq too large");
+    if (m.step == 8 && nq >= 64 && (((uintptr_t)m.books) & 15) == 0) {
+        constexpr int QB = 4;
+        hipLaunchKernelGGL((lut8_kernel<QB>), dim3((unsigned)((nq + QB - 1) / QB)), dim3(kBlock), (size_t)QB * m.D * sizeof(float), st, q_rot, nq, m.D, m.M, m.K,
+                           m.coarse, list_id, m.books, lut, ld);
+        CVTMI_HIP(hipGetLastError());
+        return CVTMI_OK;
+    }
     hipLaunchKernelGGL(lut_kernel, dim3((unsigned)nq), dim3(kBlock), (size_t)m.D * sizeof(float), st, q_rot, m.D, m.M,
                        m.K, m.step, m.coarse, list_id, m.books, lut, ld);
     CVTMI_HIP(hipGetLastError());
