@@ -59,7 +59,7 @@ using namespace cvtmi;
 // bounds, spill areas, the item table and the plan it was built from, the staging of the host-pointer entry.  The set remembers
 // the stream it was last used on and an event recorded when that call returned: the next lessee on ANOTHER stream waits first.
 struct OpqScratch {
-    DevBuf s_qrot, s_part_d, s_part_id, s_lut, s_gthr, s_qlut, s_qp, s_spill, s_items;
+    DevBuf s_qrot, s_part_d, s_part_id, s_lut, s_gthr, s_qlut, s_qp, s_spill, s_items, s_probe;
     ScanHPlan hplan;                       // the item table s_items holds ...
     int64_t hplan_n = -1, hplan_nq = -1;   // ... and the (rows, queries, forced splits, planner settings) it was built for
     int hplan_splits = 0, hplan_key = 0;
@@ -71,7 +71,7 @@ struct OpqScratch {
     bool pending = false, busy = false;
     void release_all()
     {
-        for (DevBuf *b : { &s_qrot, &s_part_d, &s_part_id, &s_lut, &s_gthr, &s_qlut, &s_qp, &s_spill, &s_items, &io_q, &io_d, &io_i }) b->release();
+        for (DevBuf *b : { &s_qrot, &s_part_d, &s_part_id, &s_lut, &s_gthr, &s_qlut, &s_qp, &s_spill, &s_items, &s_probe, &io_q, &io_d, &io_i }) b->release();
         io_pin.release();
         if (own) (void)hipStreamDestroy(own);
         if (done) (void)hipEventDestroy(done);
@@ -1187,45 +1187,85 @@ int cvtmi_opq_search_sharded_all(cvtmi_opq_t *handles, cvtmi_comm_t *comms, int 
                        });
 }
 
-int cvtmi_opq_query_video_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int nprobe, int img_num, float *match_score,
-                              void *stream)
+// IVFOPQ::Query / QueryThrehold (IVFOPQ.cpp:213-422) only read the index: like the exhaustive search, a query leases a scratch set
+// (rotated frames, probe lists) and holds the handle shared, so callers on several threads proceed side by side.  The list-ordered
+// copy of the entries is (re)built under the exclusive lock by the first query after an append.
+static int opq_query_prepare(cvtmi_opq_t h, hipStream_t st)
 {
-    CHECK_H_SERIAL(h, stream);
-    if (nq < 0 || img_num < 0 || (nq > 0 && img_num > 0 && (!q || !match_score)))
-        return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: bad arguments");
-    if (nprobe < 1) return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: nprobe=%d", nprobe);
-    if (nq == 0 || img_num == 0) return CVTMI_OK;
+    {
+        std::shared_lock<std::shared_timed_mutex> rd(h->rw);
+        if (h->csr_valid) return CVTMI_OK;
+    }
+    Serial serial(h->sync, st);
+    OpqExclusive excl(h, st);
+    return opq_build_csr(h, st);
+}
+static int opq_query_video_leased(cvtmi_opq_t h, OpqScratch &S, const float *q, int64_t nq, int rotate, int nprobe, int img_num, float *match_score,
+                                  hipStream_t st)
+{
+    if (!h->csr_valid) return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: the index changed while the query was being prepared");
     if (nprobe > h->m.coarseK) nprobe = h->m.coarseK;  // the reference pops an empty heap here (UB)
-    hipStream_t st = (hipStream_t)stream;
-    CVTMI_TRY(opq_build_csr(h, st));
     if (h->csr_kept > 0 && (h->csr_vmin < 0 || h->csr_vmax >= img_num))
         return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: video id %d outside img_num=%d", h->csr_vmin < 0 ? h->csr_vmin : h->csr_vmax, img_num);
     const float *q_rot = q;
     if (rotate && (h->m.perm || h->m.R)) {
-        CVTMI_TRY(h->s_qrot.reserve((size_t)nq * h->m.D * sizeof(float)));
-        CVTMI_TRY(cvtmi_opq_rotate_dev(h, q, nq, h->s_qrot.as<float>(), stream));
-        q_rot = h->s_qrot.as<float>();
+        CVTMI_TRY(S.s_qrot.reserve((size_t)nq * h->m.D * sizeof(float)));
+        CVTMI_TRY(opq_rotate_impl(h, q, nq, S.s_qrot.as<float>(), st));
+        q_rot = S.s_qrot.as<float>();
     }
     const size_t probe_bytes = ((size_t)nq * nprobe * sizeof(int32_t) + 15) / 16 * 16;
-    CVTMI_TRY(h->s_probe.reserve(probe_bytes + coarse_probe_scratch_bytes(nq, nprobe)));
-    CVTMI_TRY(launch_coarse_probe(h->m, q_rot, nq, nprobe, h->s_probe.as<int32_t>(), st, h->s_probe.as<char>() + probe_bytes));
-    return launch_query_video(h->m, q_rot, nq, nprobe, h->s_probe.as<int32_t>(), h->csr_off.as<int64_t>(), h->csr_codes.as<uint8_t>(),
+    CVTMI_TRY(S.s_probe.reserve(probe_bytes + coarse_probe_scratch_bytes(nq, nprobe)));
+    CVTMI_TRY(launch_coarse_probe(h->m, q_rot, nq, nprobe, S.s_probe.as<int32_t>(), st, S.s_probe.as<char>() + probe_bytes));
+    return launch_query_video(h->m, q_rot, nq, nprobe, S.s_probe.as<int32_t>(), h->csr_off.as<int64_t>(), h->csr_codes.as<uint8_t>(),
                               h->csr_videos.as<int32_t>(), img_num, match_score, h->csr_longest, st);
 }
 
+int cvtmi_opq_query_video_dev(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int nprobe, int img_num, float *match_score,
+                              void *stream)
+{
+    CHECK_H(h);
+    if (nq < 0 || img_num < 0 || (nq > 0 && img_num > 0 && (!q || !match_score)))
+        return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: bad arguments");
+    if (nprobe < 1) return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: nprobe=%d", nprobe);
+    if (nq == 0 || img_num == 0) return CVTMI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    for (int attempt = 0;; ++attempt) {   // (an append between the preparation and the shared lock sends the query round again)
+        CVTMI_TRY(opq_query_prepare(h, st));
+        std::shared_lock<std::shared_timed_mutex> rd(h->rw);
+        if (!h->csr_valid && attempt < 8) continue;
+        OpqLease lease;
+        CVTMI_TRY(lease.open(h, st, false));
+        return opq_query_video_leased(h, *lease.s, q, nq, rotate, nprobe, img_num, match_score, st);
+    }
+}
+
+// host pointers: frames in and the dense [frames][videos] score matrix out through the leased set's staging buffers (kept between
+// calls: the reference's own call is a handful of frames, a device allocation per call would cost more than the query)
 int cvtmi_opq_query_video(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int nprobe, int img_num,
                           float *match_score)
 {
-    CHECK_H_SERIAL(h, nullptr);
+    CHECK_H(h);
     if (nq < 0 || img_num < 0 || (nq > 0 && img_num > 0 && (!q || !match_score)))
         return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: bad arguments");
+    if (nprobe < 1) return fail(CVTMI_EINVAL, "cvtmi_opq_query_video: nprobe=%d", nprobe);
     if (nq == 0 || img_num == 0) return CVTMI_OK;
-    Tmp dq, dm;
-    CVTMI_TRY(dq.upload(q, (size_t)nq * h->m.D * sizeof(float)));
-    CVTMI_TRY(dm.alloc((size_t)nq * img_num * sizeof(float)));
-    CVTMI_TRY(cvtmi_opq_query_video_dev(h, dq.as<float>(), nq, rotate, nprobe, img_num, dm.as<float>(), nullptr));
-    CVTMI_HIP(hipMemcpy(match_score, dm.p, (size_t)nq * img_num * sizeof(float), hipMemcpyDeviceToHost));
-    return CVTMI_OK;
+    for (int attempt = 0;; ++attempt) {
+        CVTMI_TRY(opq_query_prepare(h, nullptr));
+        std::shared_lock<std::shared_timed_mutex> rd(h->rw);
+        if (!h->csr_valid && attempt < 8) continue;
+        OpqLease lease;
+        CVTMI_TRY(lease.open(h, nullptr, true));
+        OpqScratch &S = *lease.s;
+        hipStream_t st = lease.st;
+        const size_t qb = (size_t)nq * h->m.D * sizeof(float), mb = (size_t)nq * img_num * sizeof(float);
+        CVTMI_TRY(S.io_q.reserve(qb));
+        CVTMI_TRY(S.io_d.reserve(mb));
+        CVTMI_HIP(hipMemcpyAsync(S.io_q.p, q, qb, hipMemcpyHostToDevice, st));
+        CVTMI_TRY(opq_query_video_leased(h, S, S.io_q.as<float>(), nq, rotate, nprobe, img_num, S.io_d.as<float>(), st));
+        CVTMI_HIP(hipMemcpyAsync(match_score, S.io_d.p, mb, hipMemcpyDeviceToHost, st));
+        CVTMI_HIP(stream_wait(st));
+        return CVTMI_OK;
+    }
 }
 
 int cvtmi_opq_set_param(cvtmi_opq_t h, const char *name, int64_t value)

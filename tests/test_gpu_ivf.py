@@ -96,6 +96,30 @@ def test_ivf_query_reference_shape(amd, orc):
     # the host-pointer entry gives the same
     msh = idx.query_video(q[:7].cpu().numpy(), nk, n_videos, rotate=True)
     assert np.array_equal(bits(msh), bits(oms[:7]))
+    # Query only reads the index (IVFOPQ.cpp:213-320): four host threads query one handle at once -- host arrays in and out, each call on a
+    # scratch set leased from the handle -- and every call returns what it returns alone
+    import threading
+    qh = q.cpu().numpy()
+    jobs = [(0, 9), (9, 18), (100, 164), (200, 201)]
+    want = {j: idx.query_video(qh[j[0]:j[1]], nk, n_videos, rotate=True) for j in jobs}
+    bad, go = [], threading.Barrier(len(jobs))
+
+    def worker(j):
+        go.wait()
+        for _ in range(30):
+            if not np.array_equal(bits(idx.query_video(qh[j[0]:j[1]], nk, n_videos, rotate=True)), bits(want[j])):
+                bad.append(j)
+                return
+    ts = [threading.Thread(target=worker, args=(j,)) for j in jobs]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not bad, bad
+    for j in jobs:
+        assert np.array_equal(bits(want[j]), bits(oms[j[0]:j[1]]))
+    tq0 = time.perf_counter()
+    for _ in range(200):
+        idx.query_video(qh[:9], nk, n_videos, rotate=True)
+    print("ivf query, host pointers, 9 frames: %.1f us per call" % ((time.perf_counter() - tq0) / 200 * 1e6))
     print("ivf query: %d frames x nk=%d over %d entries in %d lists: %.3f ms" % (nq, nk, n, L, (t1 - t0) * 1e3))
     idx.close()
 
