@@ -98,3 +98,13 @@ def test_balanced_shares_are_equal():
     assert per_wg.max() - per_wg.min() <= 2 * 4 * 2048 + 2048        # boundaries snap by at most 4 tiles
     seg = items[items[:, :, 4] > 0][:, 2]
     assert seg.min() >= 4 * 2048 - 2048                              # no sliver segments
+
+
+@pytest.mark.parametrize("nq,want", [(600, 6), (1000, 4), (1300, 3), (1500, 4), (1800, 2), (3000, 2), (3500, 1), (4000, 1), (10_000, 1)])
+def test_planner_follows_the_measured_split_counts(nq, want):
+    """The planner prices a split count by the makespan of the persistent grid (items round-robin over 512 workgroups, two per CU, the
+    one that is left running 1.65 x faster, an item = 80 K + 80 K / S + rows / S row-equivalents).  At 1 M rows it has to land on the
+    split counts tools/sweep_scan_h.py measured fastest on an MI355X: e.g. 1000 queries 4 splits (0.43 ms; 2 splits
+    0.70), 3000 queries 2 (1.04 ms; whole groups 1.24), whole groups from 3500 queries on."""
+    _, grid, rounds, stride = plan(1_000_000, nq)
+    assert stride == want, (nq, stride, grid, rounds)
