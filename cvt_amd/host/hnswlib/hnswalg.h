@@ -359,8 +359,16 @@ private:
             if (-c.first > bound) break;
             frontier.pop();
             const tableint cnt = snapshot(c.second, l, nbs);
+            // (the neighbours' vectors are scattered over hundreds of megabytes: ask for the next one while this one is scored -- the
+            //  reference does the same with _mm_prefetch, hnswalg.h:190-205)
+            if (cnt) { __builtin_prefetch(&seen[nbs[0]]); __builtin_prefetch(row(nbs[0])); }
             for (tableint j = 0; j < cnt; ++j) {
                 const tableint nb = nbs[j];
+                if (j + 1 < cnt) {
+                    __builtin_prefetch(&seen[nbs[j + 1]]);
+                    const char *nx = (const char *)row(nbs[j + 1]);
+                    __builtin_prefetch(nx); __builtin_prefetch(nx + 64); __builtin_prefetch(nx + 128); __builtin_prefetch(nx + 192);
+                }
                 if (seen[nb] == stamp) continue;
                 seen[nb] = stamp;
                 const dist_t d = dist(x, row(nb));
