@@ -347,7 +347,10 @@ private:
         static thread_local unsigned short stamp = 0;
         if (seen.size() < cap_) { seen.assign(cap_, 0); stamp = 0; }
         if (++stamp == 0) { std::fill(seen.begin(), seen.end(), 0); stamp = 1; }
-        DistHeap best, frontier;
+        // (the two queues get their storage up front: growing from empty cost a dozen reallocations per level and insertion)
+        std::vector<Cand> best_store, frontier_store;
+        best_store.reserve(efc_ + 2); frontier_store.reserve(4 * efc_ + 64);
+        DistHeap best(ByDist(), std::move(best_store)), frontier(ByDist(), std::move(frontier_store));
         const dist_t d0 = dist(x, row(start));
         best.emplace(d0, start);
         frontier.emplace(-d0, start);
