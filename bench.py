@@ -23,8 +23,16 @@ barriers, the max-over-ranks clock and the hand-over of the communicator id need
 "index built, ready" BEFORE anyone enters the blocking communicator creation.  torch is used for device memory only.
 
     python bench.py                       # 1 GPU
+    python bench.py --gpus N              # no launcher: bench.py starts its N ranks itself (self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+The N > 1 line proves what it measured: `rccl_ranks` / `collectives_per_search` from the library's own counters
+(cvtmi_comm_info), `identical_to_oracle_sample` (every rank scans ITS shard with the CPU oracle for a few queries, rank 0 merges
+the per-shard lists with the oracle's merge and compares ids and distance bits with the GPUs' merged answer -- the shape of
+FLANN-MPI's local search + offset + reduce, retrieval/vlindex/lib/FLANN/mpi/index.h:196-226, :74-108), `recall_at_1` and a
+`cpu_baseline` from that same oracle run.  If the RCCL communicator cannot be created (fewer devices than ranks, creation
+fails or times out) the line still appears, with "error" and the result of the same library path over the host transport.
 """
 import argparse
 import json
@@ -73,6 +81,10 @@ def parse_args():
                          "(quick)")
     ap.add_argument("--backend", choices=["nccl", "host", "gloo"], default="nccl",
                     help="host (alias gloo) = debug: several ranks on ONE GPU, exchange staged through the host")
+    ap.add_argument("--comm-timeout", type=float, default=180.0,
+                    help="seconds the RCCL communicator creation may take before the ranks fall back to the host transport")
+    ap.add_argument("--oracle-queries", type=int, default=8,
+                    help="N > 1: queries every rank scans over its own shard with the CPU oracle (identity check + cpu_baseline; 0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=-1,
                     help="threads of the all-cores CPU leg (-1 = all logical cores, 0 = skip)")
@@ -103,9 +115,17 @@ class Ctx:
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         assert self.world == args.gpus, "launch with --nproc-per-node equal to --gpus (got WORLD_SIZE=%d)" % self.world
         assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+        ndev = torch.cuda.device_count()
         self.host_transport = args.backend != "nccl"
+        self.error = None          # why the N > 1 line is not the RCCL measurement it was asked for (it is printed either way)
+        self.hung_thread = False   # a communicator creation that never returned: the process leaves through os._exit
+        if not self.host_transport and ndev < self.world:
+            # RCCL refuses two ranks on one device: every rank sees the same device count and takes the same decision
+            self.error = ("%d ranks asked for, %d device(s) visible: RCCL needs one device per rank; the figures are the same library "
+                          "path (local scan -> all-gather -> merge) over the host transport, several ranks per device" % (self.world, ndev))
+            self.host_transport = True
         if self.host_transport:
-            local_rank = 0  # debug: every rank on GPU 0
+            local_rank = local_rank % max(ndev, 1)   # debug / fall-back: ranks share the visible devices
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
         cvt_amd.lib()
@@ -115,6 +135,7 @@ class Ctx:
         self.zero_coarse = np.zeros((1, D), np.float32)
         self.R = synth.random_rotation(D, seed=7)
         self.books = None
+        self.nn = None
 
     def barrier(self):
         self.rv.barrier()
@@ -132,19 +153,57 @@ class Ctx:
         self.barrier()
         return self.rv.max(time.perf_counter() - t0), out
 
+    def _create_rccl(self):
+        """ncclCommInitRank inside the library, on a helper thread so that a creation that never returns (a peer died on its
+        way in) costs --comm-timeout seconds instead of the job; returns None or the reason it did not happen"""
+        import threading
+        msg = None
+        if self.rank == 0:
+            try:
+                msg = (True, self.cvt.Comm.unique_id())
+            except Exception as e:   # RCCL not loadable: the others are waiting for this broadcast
+                msg = (False, "%s: %s" % (type(e).__name__, e))
+        ok, uid = self.rv.bcast(msg)
+        if not ok:
+            return "rank 0 could not get a communicator id: %s" % uid
+        box = {}
+
+        def work():
+            try:
+                self.torch.cuda.set_device(self.dev)   # the current device is per-thread state
+                box["comm"] = self.cvt.Comm(uid, self.rank, self.world)
+            except Exception as e:
+                box["err"] = "%s: %s" % (type(e).__name__, e)
+
+        t = threading.Thread(target=work, daemon=True)
+        t.start(); t.join(self.args.comm_timeout)
+        if t.is_alive():
+            self.hung_thread = True
+            return "rank %d: communicator creation did not return within %g s" % (self.rank, self.args.comm_timeout)
+        if "err" in box:
+            return "rank %d: %s" % (self.rank, box["err"])
+        self.comm = box["comm"]
+        return None
+
     def make_comm(self, ready, what=""):
-        """the library's communicator -- only after EVERY rank has said it is ready (the creation is a
-        blocking collective)"""
+        """the library's communicator -- only after EVERY rank has said it is ready (the creation is a blocking collective).
+        RCCL first; when any rank cannot create it, every rank falls back to the host transport (the same library path with the
+        all-gather staged through the rendezvous) and the JSON line carries "error"."""
         ok, bad = self.rv.all_ok(ready, what)
         if not ok:
             raise SystemExit("bench.py: rank(s) not ready, nobody creates the communicator: %s" % bad)
         if self.world == 1:
             return
-        if self.host_transport:
-            self.comm = self.cvt.Comm.over_rendezvous(self.rv)
-        else:
-            uid = self.rv.bcast(self.cvt.Comm.unique_id() if self.rank == 0 else None)
-            self.comm = self.cvt.Comm(uid, self.rank, self.world)
+        if not self.host_transport:
+            why = self._create_rccl()
+            ok, bad = self.rv.all_ok(why is None, why or "")
+            if ok:
+                return
+            self.error = ("RCCL communicator not created (%s); the figures are the same library path over the host transport"
+                          % "; ".join(w for _, w in bad))
+            self.comm = None       # a half-created communicator is leaked on purpose: destroying it is a collective too
+            self.host_transport = True
+        self.comm = self.cvt.Comm.over_rendezvous(self.rv)
 
     def train_books(self):
         """rank 0 trains the sub-codebooks on a 100K-row sample, everyone gets the same bytes"""
@@ -164,18 +223,24 @@ class Ctx:
             raise SystemExit("bench.py: rank 0 could not train the codebooks: %s" % blob)
         self.books = np.frombuffer(blob, dtype=np.float32).reshape(self.M, K, D // self.M).copy()
 
-    def build_index(self, r0, r1, data="sift", seed=0xC0FFEE):
-        """rows [r0, r1) on device: generate -> rotate (MFMA GEMM) -> encode -> append; only codes stay"""
+    def build_index(self, r0, r1, data="sift", seed=0xC0FFEE, nn_q=None):
+        """rows [r0, r1) on device: generate -> rotate (MFMA GEMM) -> encode -> append; only codes stay.  nn_q (a few
+        queries): the exact fp32 L2 nearest neighbour of each among THESE rows is tracked while the rows exist (they are
+        never stored) -> self.nn = (distance, row id), the ground truth of recall_at_1 at sizes no fp32 matrix fits"""
         args, torch, synth = self.args, self.torch, self.synth
         ix = self.cvt.OpqIndex(self.zero_coarse, self.books, R=self.R)
         ix.reserve(r1 - r0); ix.set_id_base(r0)
         rows_done, t_acc = 0, 0.0
+        self.nn = None
         if data == "random":
             g = torch.Generator(device=self.dev); g.manual_seed(0x51F7 + self.rank)
             for a in range(r0, r1, 1 << 24):
                 b = min(r1, a + (1 << 24))
                 ix.add_codes(torch.randint(0, 256, (b - a, self.M), generator=g, device=self.dev, dtype=torch.uint8))
         else:
+            if nn_q is not None and nn_q.shape[0] > 0:
+                self.nn = (torch.full((nn_q.shape[0],), float("inf"), device=self.dev),
+                           torch.full((nn_q.shape[0],), -1, dtype=torch.int64, device=self.dev))
             step = synth.CHUNK * 4
             for a in range(r0, r1, step):
                 b = min(r1, a + step)
@@ -185,6 +250,10 @@ class Ctx:
                 ix.add_codes(codes)
                 torch.cuda.synchronize(); t_acc += time.perf_counter() - t0  # data generation excluded
                 rows_done += b - a
+                if self.nn is not None:
+                    m, j = torch.cdist(nn_q, x).min(dim=1)
+                    upd = m < self.nn[0]
+                    self.nn = (torch.where(upd, m, self.nn[0]), torch.where(upd, j + a, self.nn[1]))
         ix.set_param("qtile", args.qtile); ix.set_param("splits", args.splits); ix.set_param("profile", 1)
         if args.variant >= 0:
             ix.set_param("scan_variant", args.variant)
@@ -222,6 +291,59 @@ def scan_roofline(sc, traffic=None):
                         "passes share their reads on chip -- hbm_frac_measured (PMC bytes / kernel time / 8 TB/s) is what HBM sees"}}
 
 
+def shard_evidence(ctx, ix, r0, q, out, res):
+    """What the row-sharded line has to prove (BASELINE.md parity gates: "multi-GPU result identical", "recall@1 identical
+    to the CPU reference"), measured, not asserted: (i) every rank scans ITS OWN shard with the CPU oracle for a few of the
+    queries (orc_adc_search, ids = local row + shard offset), rank 0 merges the per-shard lists with the oracle's merge
+    (orc_merge_topk: (distance, id) order) and compares ids and distance bits with what the GPUs' all-gather + merge
+    returned -- FLANN-MPI's local search / offset / reduce (mpi/index.h:196-226, :74-108) restated on the CPU;
+    (ii) the same oracle run, all ranks side by side, is the CPU baseline of this workload; (iii) recall@1 against the
+    exact fp32 neighbour tracked while the rows were generated."""
+    args, k, world = ctx.args, ctx.k, ctx.world
+    d_gpu, i_gpu = out
+    nqs = min(args.oracle_queries, q.shape[0]) if args.cpu_sample > 0 else 0
+    if nqs > 0:
+        from oracle import binding as ob
+        if ctx.rank == 0:
+            ob.build(o3=True)
+        ctx.rv.barrier()
+        orc = ob.Oracle(o3=True)
+        _, _, codes_h = ix.get_entries()
+        q_rot = orc.rotate_fma(ctx.R, q[:nqs].cpu().numpy())
+        t0 = time.perf_counter()
+        od, oi = orc.adc_search(q_rot, ctx.books, codes_h, k, id_base=r0)
+        t_cpu = time.perf_counter() - t0
+        del codes_h
+        parts = ctx.rv.gather((od.tobytes(), oi.tobytes(), t_cpu))
+        if ctx.rank == 0:
+            ods = np.stack([np.frombuffer(p[0], np.float32).reshape(nqs, k) for p in parts], axis=1)   # [nq][world][k]
+            ois = np.stack([np.frombuffer(p[1], np.int64).reshape(nqs, k) for p in parts], axis=1)
+            md, mi = orc.merge_topk(ods, ois, k)
+            gd, gi = d_gpu[:nqs].cpu().numpy(), i_gpu[:nqs].cpu().numpy()
+            t_max = max(p[2] for p in parts)
+            res["identical_to_oracle_sample"] = {
+                "queries": nqs, "ids_identical": bool(np.array_equal(mi, gi)),
+                "distances_bit_identical": bool(np.array_equal(md.view(np.uint32), gd.view(np.uint32))),
+                "recall_at_1_identical_to_cpu": bool(np.array_equal(mi[:, 0], gi[:, 0])),
+                "what": "every rank: oracle ADC scan + top-%d of its own shard (ids offset by the shard's first row); rank 0: "
+                        "oracle merge of the %d per-shard lists vs the GPUs' all-gather + merge" % (k, world)}
+            res["cpu_baseline"] = {
+                "value": round(nqs / t_max, 3), "unit": "queries/s", "cores": world, "kind": "port",
+                "sample": "%d of the queries against all %d rows: %d processes side by side, one thread and one shard each "
+                          "(oracle/cvt_oracle.c -O3: tables + scan + top-%d), slowest rank %.1f s, the merge excluded; host: %s" % (
+                              nqs, res["rows_total"], world, k, t_max, _cpu_model())}
+    if ctx.nn is not None:
+        ns = ctx.nn[0].shape[0]
+        parts = ctx.rv.gather((ctx.nn[0].cpu().numpy().tobytes(), ctx.nn[1].cpu().numpy().tobytes()))
+        if ctx.rank == 0:
+            bd = np.stack([np.frombuffer(p[0], np.float32) for p in parts])      # [world][ns]
+            bi = np.stack([np.frombuffer(p[1], np.int64) for p in parts])
+            exact = bi[np.argmin(bd, axis=0), np.arange(ns)]
+            res["recall_at_1"] = round(float((i_gpu[:ns, 0].cpu().numpy() == exact).mean()), 4)
+            res["recall_at_1_what"] = ("ADC top-1 == exact fp32 L2 nearest neighbour among all %d rows (tracked chunk by chunk "
+                                       "while the rows were generated), first %d queries" % (res["rows_total"], ns))
+
+
 def run_sift1b(ctx, q, steps, warmup):
     """the SIFT-1B-shaped workload, row-sharded over the ranks (N > 1: the headline; N = 1: the first
     point of its curve)"""
@@ -229,18 +351,21 @@ def run_sift1b(ctx, q, steps, warmup):
     l0, l1 = cvt.shard_range(args.large_rows, ctx.rank, ctx.world)
     free_b, _ = torch.cuda.mem_get_info(ctx.dev)
     # codes + the scan's rotated copy + generation chunks + tables must fit; every rank takes the same decision
-    fits = ctx.rv.min(1 if free_b > (l1 - l0) * ctx.M * 2.3 + (3 << 30) else 0)
+    sharing = 1 if not ctx.host_transport else -(-ctx.world // max(1, torch.cuda.device_count()))   # ranks per device
+    fits = ctx.rv.min(1 if free_b > sharing * ((l1 - l0) * ctx.M * 2.3 + (3 << 30)) else 0)
     if fits == 0:
         return {"error": "not enough free HBM for %d code rows per GPU" % (l1 - l0)}, None
-    t0 = time.perf_counter()
-    big, enc_rows, enc_t = ctx.build_index(l0, l1, data=args.large_data, seed=0xC0FFEE)
-    torch.cuda.synchronize(); t_build = time.perf_counter() - t0
     ql = q[:min(args.large_nq, ctx.nq)].contiguous()
+    ns = min(args.recall_sample, 256, ql.shape[0])
+    t0 = time.perf_counter()
+    big, enc_rows, enc_t = ctx.build_index(l0, l1, data=args.large_data, seed=0xC0FFEE, nn_q=ql[:ns] if ns > 0 else None)
+    torch.cuda.synchronize(); t_build = time.perf_counter() - t0
     fn = ctx.searcher(big)
     for _ in range(warmup):
         fn(ql)
     ctx.barrier(); big.last_scan()
-    el, _ = ctx.timed(lambda: fn(ql), steps, 0)
+    c0 = ctx.comm.info() if ctx.comm is not None else None
+    el, out = ctx.timed(lambda: fn(ql), steps, 0)
     sc = big.last_scan()
     res = {"value": round(ql.shape[0] * steps / el, 1), "unit": "queries/s", "ms_per_step": round(el / steps * 1e3, 4),
            "steps": steps, "rows_total": args.large_rows, "rows_per_gpu": l1 - l0, "nq": int(ql.shape[0]), "k": ctx.k,
@@ -252,9 +377,20 @@ def run_sift1b(ctx, q, steps, warmup):
            "what": "%d rows row-sharded x%d (%.2f GB of codes per GPU), the same %d queries on every rank, top-%d, "
                    "%s" % (
                args.large_rows, ctx.world, (l1 - l0) * ctx.M / 1e9, ql.shape[0], ctx.k,
-               "ONE ncclAllGather of the per-shard top-k inside libcvtmi + merge" if ctx.world > 1 else "single shard")}
+               "ONE all-gather of the per-shard top-k inside libcvtmi + merge" if ctx.world > 1 else "single shard")}
     if ctx.comm is not None:
-        res["comm"] = ctx.comm.info()
+        ctx.comm.status()   # deferred status check of the sharded searches: a rank that failed locally surfaces here
+        c1 = ctx.comm.info()
+        res["comm"] = c1
+        res["transport"] = c1["transport"]
+        res["rccl_ranks"] = c1["world"] if c1["transport"] == "rccl" else 0
+        res["collectives_per_search"] = round((c1["collectives"] - c0["collectives"]) / max(steps, 1), 3)
+    if ctx.world > 1:
+        shard_evidence(ctx, big, l0, ql, out, res)
+    elif ctx.nn is not None:
+        ns = ctx.nn[0].shape[0]
+        res["recall_at_1"] = round(float((out[1][:ns, 0] == ctx.nn[1]).float().mean().item()), 4)
+        res["recall_at_1_what"] = "ADC top-1 == exact fp32 L2 nearest neighbour among all %d rows, first %d queries" % (args.large_rows, ns)
     big.close()
     return res, sc
 
@@ -392,8 +528,10 @@ def headline_multi(ctx, q):
     """N > 1: SIFT-1B-shaped, row-sharded, configs[3]"""
     args, cvt, nq, k, M, world = ctx.args, ctx.cvt, ctx.nq, ctx.k, ctx.M, ctx.world
     res, _ = run_sift1b(ctx, q, args.steps, args.warmup)
-    if "error" in res:
-        raise SystemExit("bench.py: " + res["error"])
+    if "error" in res:   # (every rank took the same decision) the line still appears, with the reason
+        return {"metric": "queries/sec, OPQ-ADC top-%d over 128-d SIFT-1B-shaped rows, row-sharded x%d" % (k, world), "value": None,
+                "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                "scaling": "strong", "error": res["error"]} if ctx.rank == 0 else None
     extra = {}
     # the small database on N GPUs, for the record: row-sharded through the same library path, and as N replicas
     r0, r1 = cvt.shard_range(args.rows, ctx.rank, world)
@@ -429,13 +567,20 @@ def headline_multi(ctx, q):
                                    args.large_rows, M, world, k, res["nq"]),
                    "rows": args.large_rows, "rows_per_gpu": res["rows_per_gpu"], "nq_per_step": res["nq"], "k": k,
                        "M": M,
-                   "parallelism": "row-sharded x%d, ONE ncclAllGather (RCCL, issued inside libcvtmi) of per-shard "
-                                  "top-%d + "
-                                  "merge on every rank" % (world, k),
+                   "parallelism": "row-sharded x%d, ONE %s of per-shard top-%d + merge on every rank" % (
+                       world, "ncclAllGather (RCCL, issued inside libcvtmi)" if res.get("transport") == "rccl"
+                       else "all-gather through the HOST transport (cvtmi_comm_create_custom over the TCP rendezvous)", k),
                    "n1_point_of_this_curve": "the N = 1 line's 'sift1b'.value (same rows, same queries, one GPU)"},
         "roofline": dict(rf, kernel="adc_scan kernel (M=%d, %d queries per pass), rank 0's shard" % (M, rf["queries_per_pass"])),
-        "sift1b": res,
     }
+    # the evidence, at the top level of the line: who exchanged what, and that the answer is the CPU reference's
+    for key in ("transport", "rccl_ranks", "collectives_per_search", "recall_at_1", "recall_at_1_what",
+                "identical_to_oracle_sample", "cpu_baseline"):
+        if key in res:
+            result[key] = res[key]
+    if ctx.error:
+        result["error"] = ctx.error
+    result["sift1b"] = res
     result.update(extra)
     return result
 
@@ -529,8 +674,47 @@ def cpu_baseline_reference(ctx, q, result):
         "identity_check": "cpu_baseline_port (same arithmetic restated, unclamped): gpu_topk_ids_identical / gpu_distances_bit_identical"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks (this same script, one process per GPU) with the
+    environment torch.distributed.run would give them, pass rank 0's stdout (the JSON line) through, and stop everybody as soon
+    as one of them fails.  Only the exact processes started here are ever signalled."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    base = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                LOCAL_WORLD_SIZE=str(args.gpus), TORCHELASTIC_RUN_ID="cvtmi-self-%d" % os.getpid(),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdin=subprocess.DEVNULL,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        live = list(procs)
+        while live and rc == 0:
+            time.sleep(0.2)
+            for p in list(live):
+                c = p.poll()
+                if c is not None:
+                    live.remove(p)
+                    if c != 0:
+                        rc = c
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                if rc != 0:
+                    p.terminate()
+                try:
+                    p.wait(timeout=30 if rc != 0 else None)
+                except subprocess.TimeoutExpired:
+                    p.kill(); p.wait()
+    return rc
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
     ctx = Ctx(args)
     for pair in [v for v in args.tune.split(",") if v]:
         name, value = pair.split("=")
@@ -570,6 +754,9 @@ def main():
         ctx.comm.close()
     ctx.rv.barrier()
     ctx.rv.close()
+    if ctx.hung_thread:   # a helper thread is still inside ncclCommInitRank: the interpreter's shutdown would wait for RCCL
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 # ------------------------------------------------------------------------------------------------------------------

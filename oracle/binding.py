@@ -381,6 +381,29 @@ class RefFlat:
         return d, i, ta.value, ts.value
 
 
+class RefMath:
+    """cvtk::MathUtil of the reference's utils/math_util.h compiled in place (oracle/_ref/libref_math.so): the L2
+    normalisation in front of Int8Encode / SQ training, the one part of that path that runs here without faiss."""
+
+    def __init__(self):
+        self.lib = C.CDLL(os.path.join(_HERE, "_ref", "libref_math.so"))
+
+    @staticmethod
+    def available():
+        return os.path.exists(os.path.join(_HERE, "_ref", "libref_math.so"))
+
+    def l2norm_array(self, x):
+        x = np.atleast_2d(_f32(x)).copy()
+        assert self.lib.ref_l2norm_array(_p(x, C.c_float), C.c_int64(x.shape[0]), C.c_int(x.shape[1])) == 0
+        return x
+
+    def l2norm_vec(self, x):
+        x = np.atleast_2d(_f32(x))
+        out = np.empty_like(x)
+        assert self.lib.ref_l2norm_vec(_p(x, C.c_float), C.c_int64(x.shape[0]), C.c_int(x.shape[1]), _p(out, C.c_float)) == 0
+        return out
+
+
 class RefHnsw:
     """The reference's HierarchicalNSW compiled in place (oracle/_ref/libref_hnsw.so)."""
     def __init__(self):

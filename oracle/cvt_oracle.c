@@ -17,9 +17,12 @@
  *     brute-force metrics, are pinned bit-for-bit against the reference's own sources
  *     compiled in place (oracle/_ref, recipe in oracle/Makefile) and against the golden
  *     vectors under tests/golden/ that were generated from those binaries.
- *   - Scalar quantisation (orc_sq8_*): PARITY UNPINNED.  The reference delegates to
- *     faiss 1.5.3 (not vendored, not installable here) and holds no expected outputs;
- *     the functions below follow the in-tree formulas of int8_quan.cc line by line.
+ *   - Scalar quantisation (orc_sq8_*): the L2 normalisation (orc_sq8_l2norm; int8_quan.cc:46-56 ==
+ *     utils/math_util.h:29-39) IS PINNED: the reference's own MathUtil::L2NormArray is compiled in place
+ *     (oracle/_ref/libref_math.so) and its outputs are golden data (tests/golden/sq8_norm_golden.npz).
+ *     The quantise / decode formulas (int8_quan.cc:72-94, :117-132) and training (faiss RS_minmax) stay
+ *     RESTATED ONLY: the reference delegates those to faiss 1.5.3 (not vendored, not installable here)
+ *     and holds no expected outputs; the functions below follow the in-tree formulas line by line.
  *   - orc_rotate_fma: the general d x d rotation is NOT in the reference (which only
  *     permutes); it is the specification of the MFMA GEMM kernel (k-ordered fmaf chain).
  *   - orc_pca_project: PARITY UNPINNED.  The reference calls cv::PCA::project (OpenCV 3.2 / 3.3,
@@ -454,7 +457,7 @@ ORC_API void orc_flat_search(int metric, int flavour, int D, const void *data, c
 }
 
 /* ------------------------------------------------------------------------------------------
- * Scalar quantisation (PARITY UNPINNED -- see header).
+ * Scalar quantisation (normalisation pinned, quantise / decode / train restated -- see header).
  * ---------------------------------------------------------------------------------------- */
 /* scalar_quantization/scalar_quantization/int8_quan.cc:46-56 (== utils/math_util.h:29-39):
  * float product, double accumulate, double sqrt, float(max(1e-12, norm)), float divide. */

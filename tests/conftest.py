@@ -41,6 +41,7 @@ class Golden:
             self.opq[tag]["queries"] = np.fromfile(os.path.join(g, "opq_data", "query", f), dtype=np.float32).reshape(-1, 128)
         self.flat = dict(np.load(os.path.join(g, "flat_golden.npz")))
         self.sq8 = dict(np.load(os.path.join(g, "sq8_inputs.npz")))
+        self.sq8_norm = dict(np.load(os.path.join(g, "sq8_norm_golden.npz")))   # MathUtil::L2NormArray / L2NormVec outputs
         self.hnsw = dict(np.load(os.path.join(g, "hnsw_golden.npz")))
         self.pca = dict(np.load(os.path.join(g, "pca_model.npz")))
 
@@ -54,6 +55,7 @@ def golden():
     return Golden()
 
 
+SQ8_NORM_GROUPS = ["demo64", "cnn64", "cnn512", "cnn2048", "cnn37", "corners64", "clamp16"]
 OPQ_CASES = ["opq_exh_m8", "opq_vec_m16", "opq_ivf", "opq_m1", "opq_real_q1", "opq_real_q9"]
 
 

@@ -200,14 +200,11 @@ def main():
     np.savez_compressed(os.path.join(OUT, "flat_golden.npz"), **fl)
     print("  IP / IP+labels / L2F / L2U8 x3  OK")
 
-    # SQ8: the reference cannot be built here (faiss 1.5.3 absent) -> inputs only, from the reference's
-    # own demo mains; expected outputs are NOT available ("parity unpinned").
-    sq_in = np.array([0.7678224, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 2.6331244, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
-                      0.583638, 0.76271933, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.21529453, 0.0, 0.0, 1.2015152, 0.0,
-                      0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.88310665, 0.0, 0.0, 0.19277531, 0.0, 0.0,
-                      0.0, 0.0, 0.0, 0.0, 2.5779805, 0.0, 0.0, 0.7728174, 0.0, 2.21898, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
-                      0.0, 0.0], dtype=np.float32)  # int8_quan_test.cpp:26 (input vector, data)
+    # SQ8: int8_quan.cc / sq_train.cpp cannot be built here (faiss 1.5.3 absent) -> their quantise / decode formulas stay
+    # restated-only.  What CAN run is the normalisation in front of them: utils/math_util.h:29-39 (MathUtil::L2NormArray,
+    # header-only) is the same arithmetic as Int8Quan::L2NormalizeVector (int8_quan.cc:46-56) -> oracle/_ref/libref_math.so.
     np.savez_compressed(os.path.join(OUT, "sq8_inputs.npz"), int8_quan_test_x=sq_in)
+    make_sq8_norm(orc, sq_in)
     # HNSW: graphs BUILT AND SAVED by the reference's HierarchicalNSW (oracle/_ref/libref_hnsw.so =
     # hnswalg.h compiled in place), queries answered by its own searchKnn.  The saved index files are data the
     # reference wrote, committed as fixtures; the C restatement must reproduce every answer bit for bit.
@@ -242,6 +239,48 @@ def main():
     print("wrote", OUT)
 
 
+def make_sq8_norm(orc, sq_in):
+    """rows normalised by the reference's own MathUtil::L2NormArray / L2NormVec -> tests/golden/sq8_norm_golden.npz.  Row groups
+    (one width each): the reference's demo vector (int8_quan_test.cpp:26), CNN-like rows at d = 64 / 512 / 2048 / 37, and the
+    corners of the formula: all-zero rows (0 / 1e-12 -> 0), norms below the 1e-12 clamp, denormal entries, entries whose
+    squares overflow fp32 (the product is a FLOAT product: inf -> 0 or NaN rows), a norm that overflows only as a sum of
+    finite squares (never in double), -0.0, one huge entry among small ones, NaN / inf entries."""
+    rm = ob.RefMath()
+    rng = np.random.default_rng(0x5108)   # its own stream: the other sections' draws do not move
+    out = {}
+
+    def put(tag, rows):
+        rows = np.atleast_2d(np.asarray(rows, dtype=np.float32))
+        ref = rm.l2norm_array(rows)
+        mine = np.stack([orc.sq8_l2norm(r) for r in rows])
+        assert np.array_equal(ref.view(np.uint32), mine.view(np.uint32)), "sq8_l2norm restatement: " + tag
+        out[tag + "_x"] = rows; out[tag + "_array"] = ref; out[tag + "_vec"] = rm.l2norm_vec(rows)
+
+    put("demo64", sq_in)
+    for d in (64, 512, 2048, 37):
+        put("cnn%d" % d, np.maximum(rng.normal(size=(48, d)), 0).astype(np.float32) * rng.uniform(0.01, 30, size=(48, 1)).astype(np.float32))
+    d = 64
+    rows = np.zeros((12, d), np.float32)
+    rows[1, 3] = 5e-13                       # norm below the clamp: divided by float(1e-12)
+    rows[2, :] = 1e-14                       # norm 8e-14
+    rows[3, :4] = (1e-40, 3e-41, 1.4e-45, 7e-42)   # denormal entries: their float squares are 0
+    rows[4, :] = 1e-22; rows[4, 0] = 1e-20   # squares are denormal floats
+    rows[5, :3] = (3e19, 1e19, -2e19)        # squares near FLT_MAX / overflow -> inf float product -> norm inf -> 0
+    rows[6, :] = 1.5e19                      # every square finite (2.25e38), the sum exceeds FLT_MAX but not double
+    rows[7, 0] = 3.0e38; rows[7, 1] = 1.0    # one square overflows
+    rows[8, :] = -0.0; rows[8, 5] = -2.0
+    rows[9, :] = 1e-3; rows[9, 17] = 1e30
+    rows[10, 2] = np.nan; rows[10, 3] = 1.0
+    rows[11, 2] = np.inf; rows[11, 3] = 1.0; rows[11, 4] = -np.inf
+    with np.errstate(all="ignore"):
+        put("corners64", rows)
+        # norms straddling the clamp: float(1e-12) = 9.99999996e-13 sits BELOW 1e-12, so L2NormArray (clamp in double, then
+        # round) and L2NormVec (round, then clamp in double) can part ways here -- both are recorded
+        put("clamp16", np.array([[v] + [0.0] * 15 for v in np.float32(1e-12) * (1 + np.arange(-6, 7) * np.float32(2.0 ** -23))]))
+    np.savez_compressed(os.path.join(OUT, "sq8_norm_golden.npz"), **out)
+    print("  SQ8 normalisation (MathUtil::L2NormArray / L2NormVec, %d row groups)  OK" % (len(out) // 3))
+
+
 def read_opencv_matrix(text, name):
     """one `name: !!opencv-matrix` node of an OpenCV FileStorage YAML -> fp32 array"""
     import re
@@ -272,5 +311,7 @@ def make_pca(orc):
 if __name__ == "__main__":
     if sys.argv[1:] == ["pca"]:
         make_pca(ob.Oracle())
+    elif sys.argv[1:] == ["sq8_norm"]:
+        make_sq8_norm(ob.Oracle(), np.load(os.path.join(OUT, "sq8_inputs.npz"))["int8_quan_test_x"])
     else:
         main()

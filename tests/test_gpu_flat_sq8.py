@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import bits
+from conftest import SQ8_NORM_GROUPS, bits
 
 pytestmark = pytest.mark.gpu
 IP, L2F, L2U8 = 0, 1, 2
@@ -280,6 +280,35 @@ def test_sq8_encode_wave_kernel(amd, orc, d):
         assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(bits(out[1][1]), bits(out[0][1]))
         assert np.array_equal(out[1][0], oc)
         assert np.array_equal(bits(out[1][1]), bits(ox))
+
+
+@pytest.mark.parametrize("group", SQ8_NORM_GROUPS)
+def test_sq8_normalisation_golden(amd, golden, group):
+    """a-Q / a-T against the REFERENCE's own bits: rows normalised by MathUtil::L2NormArray (utils/math_util.h:29-39 == Int8Quan::
+    L2NormalizeVector, int8_quan.cc:46-56; compiled in place, tests/golden/sq8_norm_golden.npz).  cvtmi_sq8_encode(l2norm = 1)
+    writes the normalised rows back as the reference does to its caller's buffer: those rows must be the golden rows bit for bit --
+    host-pointer entry, device entry, and (d = 256 / 512 at >= 4096 rows) the wave-per-row kernel; training = min / max - min of them."""
+    import torch
+    x, want = golden.sq8_norm[group + "_x"], golden.sq8_norm[group + "_array"]
+    n, d = x.shape
+    vmin, vdiff = np.zeros(d, np.float32), np.ones(d, np.float32)
+    xg = x.copy()
+    amd.sq8_encode(vmin, vdiff, xg, l2norm=True)
+    assert np.array_equal(bits(xg), bits(want)), "host-pointer entry"
+    reps = -(-4200 // n)                       # enough rows for the wave-per-row kernels where the width has one
+    xt = torch.from_numpy(np.tile(x, (reps, 1))).cuda()
+    codes = amd.sq8_encode(torch.from_numpy(vmin).cuda(), torch.from_numpy(vdiff).cuda(), xt, l2norm=True)
+    assert np.array_equal(bits(xt.cpu().numpy()), bits(np.tile(want, (reps, 1)))), "device entry"
+    with np.errstate(all="ignore"):   # codes = (int)(255 * clamp(row)) of the golden rows (vmin 0, vdiff 1: x / 1 is exact)
+        expect = (np.float32(255) * np.clip(np.nan_to_num(want, nan=0.0), 0, 1)).astype(np.int32).astype(np.uint8)
+    ok = np.all(np.isfinite(want), axis=1)
+    assert np.array_equal(codes.cpu().numpy()[:n][ok], expect[ok])
+    if ok.any():
+        w = want[ok]
+        for rows in (x[ok], np.tile(x[ok], (-(-4200 // int(ok.sum())), 1))):
+            tv, td = amd.sq8_train(torch.from_numpy(rows.copy()).cuda(), l2norm=True)
+            assert np.array_equal(bits(tv.cpu().numpy()), bits(w.min(axis=0)))
+            assert np.array_equal(bits(td.cpu().numpy()), bits(w.max(axis=0) - w.min(axis=0)))
 
 
 def test_sq8_parity(amd, orc, golden):

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import OPQ_CASES, bits
+from conftest import OPQ_CASES, SQ8_NORM_GROUPS, bits
 
 
 @pytest.mark.parametrize("case", OPQ_CASES)
@@ -86,9 +86,49 @@ def test_rotate_fma_equals_permutation(orc):
     assert np.array_equal(orc.rotate_fma(R, x), orc.reorder(perm, x))
 
 
+@pytest.mark.parametrize("group", SQ8_NORM_GROUPS)
+def test_sq8_normalisation_pinned_by_reference(orc, golden, group):
+    """a-Q / a-T: the L2 normalisation in front of Int8Encode and SQ training (int8_quan.cc:46-56 == utils/math_util.h:29-39)
+    IS pinned: the golden rows are outputs of the reference's own MathUtil::L2NormArray compiled in place
+    (oracle/_ref/libref_math.so), incl. zero rows, norms under the 1e-12 clamp, denormals, squares that overflow fp32, NaN / inf."""
+    x, want = golden.sq8_norm[group + "_x"], golden.sq8_norm[group + "_array"]
+    with np.errstate(all="ignore"):
+        got = np.stack([orc.sq8_l2norm(r) for r in x])
+    assert np.array_equal(bits(got), bits(want))
+    # the encode entry normalises through the same function, row by row, and writes the rows back
+    d = x.shape[1]
+    _, xn = orc.sq8_encode(np.zeros(d, np.float32), np.ones(d, np.float32), x, l2norm=True)
+    assert np.array_equal(bits(xn), bits(want))
+    # train = per-dimension min / max - min of exactly these normalised rows (faiss RS_minmax; order-free, so nothing to round)
+    finite = np.all(np.isfinite(want), axis=1)
+    if finite.any():
+        vmin, vdiff = orc.sq8_train(x[finite], l2norm=True)
+        w = want[finite]
+        assert np.array_equal(bits(vmin), bits(w.min(axis=0))) and np.array_equal(bits(vdiff), bits(w.max(axis=0) - w.min(axis=0)))
+
+
+def test_sq8_normalisation_against_live_reference(orc, golden):
+    """the same, re-run against oracle/_ref/libref_math.so when it is present (build container), on fresh rows; and the
+    std::vector twin L2NormVec (:18-27: norm rounded to float before the clamp) agrees wherever the golden says it does"""
+    from oracle import binding as ob
+    if not ob.RefMath.available():
+        pytest.skip("oracle/_ref/libref_math.so not built (no /root/reference here)")
+    rm = ob.RefMath()
+    rng = np.random.default_rng(77)
+    for d in (3, 64, 129, 512):
+        x = (rng.normal(size=(200, d)) * np.exp2(rng.integers(-40, 40, size=(200, 1)))).astype(np.float32)
+        x[rng.random(size=x.shape) < 0.4] = 0
+        want = rm.l2norm_array(x)
+        got = np.stack([orc.sq8_l2norm(r) for r in x])
+        assert np.array_equal(bits(got), bits(want)), d
+    for g in SQ8_NORM_GROUPS:
+        assert np.array_equal(bits(rm.l2norm_array(golden.sq8_norm[g + "_x"])), bits(golden.sq8_norm[g + "_array"]))
+        assert np.array_equal(bits(rm.l2norm_vec(golden.sq8_norm[g + "_x"])), bits(golden.sq8_norm[g + "_vec"]))
+
+
 def test_sq8_restatement_properties(orc, golden):
-    """Scalar quantisation is PARITY UNPINNED (faiss absent, no expected outputs in the reference):
-    only self-consistency of the restated in-tree formulas is checked here."""
+    """The quantise / decode formulas of scalar quantisation stay restated-only (int8_quan.cc:72-94, :117-132; faiss absent, no
+    expected outputs in the reference) -- the normalisation in front of them is pinned above; here: self-consistency."""
     rng = np.random.default_rng(11)
     x = np.abs(rng.normal(size=(200, 64))).astype(np.float32)
     x[0] = golden.sq8["int8_quan_test_x"]  # the reference demo's input vector
