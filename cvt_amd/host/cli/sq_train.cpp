@@ -1,14 +1,17 @@
 // sq_train -- scalar_quantization/train/src/sq_train.cpp:40-103 above the C ABI:
-//   sq_train <feats.bin> <model.bin> [dim=64]       (feats.bin: int32 count; per record int32 idLen, id, int32 dim, fp32[dim])
+//   sq_train <feats.bin> <model.bin> [dim=64] [--faiss]  (feats.bin: int32 count; per record int32 idLen, id, int32 dim, fp32[dim])
 // Rows are L2-normalised, per-dimension min / max-min are computed on the GPU, the model is written as
-// int32 d; float vmin[d]; float vdiff[d].
+// int32 d; float vmin[d]; float vdiff[d] -- or, with --faiss, as the empty faiss "IxSQ" container sq_train.cpp:103 writes.
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <vector>
 #include "../int8_quan.h"
 int main(int argc, char *argv[])
 {
-    if (argc < 3) { std::cerr << "usage: sq_train <feats.bin> <model.bin> [dim]" << std::endl; return 2; }
+    bool faiss_form = false;
+    if (argc > 3 && !strcmp(argv[argc - 1], "--faiss")) { faiss_form = true; --argc; }
+    if (argc < 3) { std::cerr << "usage: sq_train <feats.bin> <model.bin> [dim] [--faiss]" << std::endl; return 2; }
     size_t d = argc > 3 ? (size_t)atoi(argv[3]) : 64;
     std::ifstream fp(argv[1], std::ios::in | std::ios::binary);
     if (!fp.is_open()) { std::cerr << "cannot open " << argv[1] << std::endl; return 1; }
@@ -29,7 +32,7 @@ int main(int argc, char *argv[])
     }
     cvtk::quant::Sq8Model m;
     if (!cvtk::quant::train_sq8_model(xb.data(), (size_t)num_db, (int)d, true, m)) return 1;
-    if (!cvtk::quant::write_sq8_model(argv[2], m)) { std::cerr << "cannot write " << argv[2] << std::endl; return 1; }
+    if (!(faiss_form ? cvtk::quant::write_ixsq_model(argv[2], m) : cvtk::quant::write_sq8_model(argv[2], m))) { std::cerr << "cannot write " << argv[2] << std::endl; return 1; }
     std::cout << "vmin (from model data): " << std::endl;
     for (size_t i = 0; i < d; ++i) std::cout << m.vmin[i] << " ";
     std::cout << std::endl << "vdiff (from model data): " << std::endl;

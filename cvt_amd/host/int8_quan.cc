@@ -10,10 +10,67 @@
 namespace cvtk {
 namespace quant {
 
+// The faiss 1.5.3 container of an IndexScalarQuantizer (index_io: write_index -> "IxSQ"), little endian, no padding:
+//   uint32 fourcc "IxSQ"
+//   index header: int32 d; int64 ntotal; int64 dummy (1 << 20) x 2; uint8 is_trained; int32 metric_type (0 IP, 1 L2)
+//   scalar quantiser: int32 qtype (0 = QT_8bit); int32 rangestat (0 = RS_minmax); float rangestat_arg;
+//                     uint64 d; uint64 code_size; uint64 n_trained; float trained[n_trained]   (QT_8bit: vmin[d] | vdiff[d])
+//   uint64 n_codes; uint8 codes[n_codes]                                                       (ntotal x code_size; ignored)
+// Call sites in the reference: faiss::read_index (int8_quan.cc:14, :35-36), sq.trained / sq.code_size (:59-60, :81-83,
+// :126-129), faiss::write_index (sq_train.cpp:103).
+namespace {
+const uint32_t kIxSQ = 'I' | ('x' << 8) | ('S' << 16) | ((uint32_t)'Q' << 24);
+template <class T> bool rd(std::istream &f, T &v) { f.read((char *)&v, sizeof v); return (bool)f; }
+template <class T> void wr(std::ostream &f, const T &v) { f.write((const char *)&v, sizeof v); }
+}
+
+bool read_ixsq_model(const std::string &path, Sq8Model &m, std::string *why)
+{
+    auto fail = [&](const char *w) { if (why) *why = w; return false; };
+    std::ifstream f(path.c_str(), std::ios::binary);
+    if (!f.good()) return fail("cannot open");
+    uint32_t h = 0; int32_t d = 0, metric = 0, qtype = 0, rangestat = 0; int64_t ntotal = 0, dummy = 0; uint8_t trained_flag = 0;
+    float rs_arg = 0; uint64_t sq_d = 0, code_size = 0, n_tr = 0;
+    if (!rd(f, h) || h != kIxSQ) return fail("not an IxSQ container");
+    if (!rd(f, d) || !rd(f, ntotal) || !rd(f, dummy) || !rd(f, dummy) || !rd(f, trained_flag) || !rd(f, metric)) return fail("truncated index header");
+    if (!rd(f, qtype) || !rd(f, rangestat) || !rd(f, rs_arg) || !rd(f, sq_d) || !rd(f, code_size) || !rd(f, n_tr)) return fail("truncated quantiser header");
+    if (d <= 0 || d > (1 << 20) || sq_d != (uint64_t)d) return fail("bad dimension");
+    if (qtype != 0) return fail("quantiser type is not QT_8bit (the only one Int8Quan's in-tree formulas cover, int8_quan.cc:79-92)");
+    if (code_size != (uint64_t)d || n_tr != 2 * (uint64_t)d) return fail("code_size / trained size do not fit QT_8bit");
+    if (!trained_flag) return fail("index is not trained");
+    m.d = d; m.vmin.resize(d); m.vdiff.resize(d);
+    f.read((char *)m.vmin.data(), sizeof(float) * d);
+    f.read((char *)m.vdiff.data(), sizeof(float) * d);
+    if (!f) return fail("truncated trained vector");
+    return true;
+}
+
+bool write_ixsq_model(const std::string &path, const Sq8Model &m)
+{
+    std::ofstream f(path.c_str(), std::ios::binary);
+    if (!f.good()) return false;
+    const int64_t dummy = 1 << 20;
+    wr(f, kIxSQ); wr(f, (int32_t)m.d); wr(f, (int64_t)0); wr(f, dummy); wr(f, dummy); wr(f, (uint8_t)1); wr(f, (int32_t)1 /* METRIC_L2, sq_train.cpp:100 */);
+    wr(f, (int32_t)0); wr(f, (int32_t)0); wr(f, 0.0f); wr(f, (uint64_t)m.d); wr(f, (uint64_t)m.d); wr(f, (uint64_t)(2 * m.d));
+    f.write((const char *)m.vmin.data(), sizeof(float) * m.d);
+    f.write((const char *)m.vdiff.data(), sizeof(float) * m.d);
+    wr(f, (uint64_t)0);
+    return (bool)f;
+}
+
 bool read_sq8_model(const std::string &path, Sq8Model &m)
 {
     std::ifstream fin(path.c_str(), std::ios::binary);
     if (!fin.good()) return false;
+    uint32_t h = 0;
+    fin.read((char *)&h, sizeof h);
+    if (fin && h == kIxSQ) {
+        std::string why;
+        if (read_ixsq_model(path, m, &why)) return true;
+        std::cout << "faiss IxSQ model " << path << ": " << why << std::endl;
+        return false;
+    }
+    fin.clear(); fin.seekg(0);
     int32_t d = 0;
     fin.read((char *)&d, sizeof d);
     if (!fin || d <= 0 || d > (1 << 20)) return false;

@@ -112,6 +112,12 @@ def test_sq8_cli(tmp_path, orc, golden):
     fb = [int(t, 16) for t in [l for l in out.splitlines() if l.startswith("decoded_faiss_bits:")][0].split()[1:]]
     want = orc.sq8_decode_faiss(ovmin, ovdiff, ocodes[:1])
     assert fb == [int(v) for v in bits(want)[0]]
+    # the same through the faiss "IxSQ" container (what sq_train.cpp:103 writes and Int8Quan(model_path) loads, int8_quan.cc:14)
+    run([os.path.join(BIN, "sq_train"), "feats.bin", "model_faiss.bin", str(d), "--faiss"], cwd=str(tmp_path))
+    raw = (tmp_path / "model_faiss.bin").read_bytes()
+    assert raw[:4] == b"IxSQ" and struct.unpack("<i", raw[4:8])[0] == d and len(raw) == 4 + 33 + 36 + 8 * d + 8
+    assert np.array_equal(np.frombuffer(raw[73:73 + 8 * d], dtype=np.float32), np.concatenate([vmin, vdiff]))
+    assert run([os.path.join(BIN, "int8_quan_demo"), "model_faiss.bin"], cwd=str(tmp_path)) == out
 
 
 def test_opq_train_cli(tmp_path, orc):
