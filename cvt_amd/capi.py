@@ -208,7 +208,10 @@ class OpqIndex:
         return d, i
 
     def search_sharded(self, comm, q, k, rotate=True):
-        """Row-sharded search: this handle holds the rank's row block; one all-gather + merge inside the library."""
+        """Row-sharded search: this handle holds the rank's row block; one all-gather + merge inside the library.
+        Device tensors: nothing synchronises, so another rank's failure cannot be known when this returns -- its results are
+        voided on the device (+inf / -1) and the error is raised by the next call on `comm`, by comm.status() after a
+        synchronise, or at the latest by comm.close()."""
         nq = q.shape[0]
         if _is_torch(q):
             import torch
@@ -387,13 +390,23 @@ class Comm:
         return od, oi
 
     def close(self):
+        """Destroys the communicator.  Under the deferred status check (the library default) a rank's failed search voids the
+        results (+inf / -1) and leaves the error ON the communicator until the next call or status() collects it: an error nobody
+        collected must not vanish with the handle, so close() raises it (after the handle is gone)."""
         if self.h and self.h.value:
+            rc = lib().cvtmi_comm_status(self.h)
+            msg = lib().cvtmi_last_error().decode(errors="replace") if rc != 0 else ""
             lib().cvtmi_comm_destroy(self.h)
             self.h = C.c_void_p(0)
+            if rc != 0:
+                raise CvtmiError("cvtmi error %d (uncollected when the communicator was closed): %s" % (rc, msg))
 
     def __del__(self):
         try:
             self.close()
+        except CvtmiError as e:   # nowhere to raise from a finaliser: say it
+            import sys
+            print("cvt_amd.Comm: %s" % e, file=sys.stderr)
         except Exception:
             pass
 
@@ -604,7 +617,7 @@ HnswIndex.search_adc_rerank = _hnsw_search_adc_rerank
 
 
 class _PinnedOwner:
-    """keeps a cvtmi_host_alloc block alive as long as a numpy array views it"""
+    """a cvtmi_host_alloc block; freed when the last numpy view of it goes away (pinned_empty ties the two together)"""
 
     def __init__(self, nbytes):
         self.p = C.c_void_p(0)
@@ -615,23 +628,23 @@ class _PinnedOwner:
         try:
             if self.p and self.p.value:
                 lib().cvtmi_host_free(self.p)
+                self.p = C.c_void_p(0)
         except Exception:
             pass
 
 
 def pinned_empty(shape, dtype):
-    """numpy array in page-locked host memory (cvtmi_host_alloc): the host-pointer entries move such arrays without a staging copy"""
+    """numpy array in page-locked host memory (cvtmi_host_alloc): the host-pointer entries move such arrays without a staging
+    copy.  The block lives exactly as long as an array views it: the ctypes buffer every view keeps as its base carries the
+    owner, so the last view's death frees the page-locked block (no module-level table, nothing leaks)."""
     dtype = np.dtype(dtype)
     n = int(np.prod(shape)) * dtype.itemsize
     own = _PinnedOwner(max(n, 16))
     buf = (C.c_char * max(n, 16)).from_address(own.p.value)
+    buf._cvtmi_owner = own   # numpy keeps `buf` alive as the base of the array and of every view / reshape of it
     arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-    _PINNED[id(buf)] = own   # (the ctypes buffer does not own the memory: tie the owner's life to the module-level table)
     arr.flags.writeable = True
     return arr
-
-
-_PINNED = {}
 
 
 def set_tuning(name, value):

@@ -1204,10 +1204,10 @@ void set_scanh_tail(int v) { g_scanh_tail = v != 0; }
 void set_scanh_balance(int v) { g_scanh_balance = v; }
 void set_scanh_min_rows(int64_t v) { g_scanh_min_rows = v < 2048 ? 2048 : v; }
 
-static int g_scanh_cus = 0;  // cvtmi_opq_scan_plan: planning for a given CU count (0 = the device's)
+// Workgroup slots of the device: a constant of the process once read (every grid and scratch size of a search derives from this ONE
+// value; cvtmi_opq_scan_plan plans for another CU count through scanh_plan's own parameter, never through shared state).
 static int scanh_slots()
 {
-    if (g_scanh_cus > 0) return 2 * g_scanh_cus;
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -1219,11 +1219,11 @@ static int scanh_slots()
 }
 
 // Builds the item table of one search.  splits > 0 forces (group, split) blocks with that many row splits.
-void scanh_plan(int64_t n_rows, int64_t nq, int splits, ScanHPlan &p)
+void scanh_plan(int64_t n_rows, int64_t nq, int splits, ScanHPlan &p, int cus)
 {
     constexpr int64_t TILE = 2048, MINT = 4, MAX_SEG = (1LL << 28) - 4096;  // rows: segment granule; 32-bit byte offsets inside a segment
     const int64_t groups = (nq + SQ_QT - 1) / SQ_QT;
-    const int64_t slots = scanh_slots();
+    const int64_t slots = cus > 0 ? 2 * (int64_t)cus : scanh_slots();   // cus > 0: cvtmi_opq_scan_plan planning for a given CU count
     p.items.clear();
     p.multi.clear();
     p.grid = 0; p.rounds = 0; p.stride = 1;
@@ -1421,9 +1421,7 @@ extern "C" int64_t cvtmi_opq_scan_plan(int64_t n_rows, int64_t nq, int splits, i
     using namespace cvtmi;
     if (n_rows < 0 || nq < 0 || cus < 0 || cap < 0 || (cap > 0 && !items)) return fail(CVTMI_EINVAL, "cvtmi_opq_scan_plan: bad arguments");
     ScanHPlan p;
-    g_scanh_cus = cus;
-    scanh_plan(n_rows, nq, splits, p);
-    g_scanh_cus = 0;
+    scanh_plan(n_rows, nq, splits, p, cus);
     if (grid) *grid = p.grid;
     if (rounds) *rounds = p.rounds;
     if (stride) *stride = p.stride;

@@ -238,6 +238,13 @@ static int use_device(int dev)
     Serial serial_##h((h)->sync, (hipStream_t)(stream)); \
     OpqExclusive excl_##h((h), (hipStream_t)(stream))
 
+// Pure reads of the MODEL (rotation matrix / permutation, codebooks: immutable after cvtmi_opq_create) into the caller's own buffers:
+// shared, like a search -- they neither drain the searches in flight nor make later searches wait on their stream.  Entries that hold
+// this must not call each other (the shared lock is not recursive): they share the *_impl / launch_* functions instead.
+#define CHECK_H_SHARED(h) \
+    CHECK_H(h); \
+    std::shared_lock<std::shared_timed_mutex> rd_##h((h)->rw)
+
 // a scratch set of an OPQ handle for the duration of one search on stream st (nullptr + host = true: the set's own stream).
 // The caller holds h->rw shared.
 struct OpqLease {
@@ -547,21 +554,21 @@ static int opq_rotate_impl(cvtmi_opq_t h, const float *x, int64_t n, float *y, h
 
 int cvtmi_opq_rotate_dev(cvtmi_opq_t h, const float *x, int64_t n, float *y, void *stream)
 {
-    CHECK_H_SERIAL(h, stream);
+    CHECK_H_SHARED(h);
     if (n < 0 || (n > 0 && (!x || !y))) return fail(CVTMI_EINVAL, "cvtmi_opq_rotate: bad arguments");
     return opq_rotate_impl(h, x, n, y, (hipStream_t)stream);
 }
 
 int cvtmi_opq_rotate(cvtmi_opq_t h, const float *x, int64_t n, float *y)
 {
-    CHECK_H_SERIAL(h, nullptr);
+    CHECK_H_SHARED(h);
     if (n < 0 || (n > 0 && (!x || !y))) return fail(CVTMI_EINVAL, "cvtmi_opq_rotate: bad arguments");
     if (n == 0) return CVTMI_OK;
     const size_t bytes = (size_t)n * h->m.D * sizeof(float);
     Tmp dx, dy;
     CVTMI_TRY(dx.upload(x, bytes));
     CVTMI_TRY(dy.alloc(bytes));
-    CVTMI_TRY(cvtmi_opq_rotate_dev(h, dx.as<float>(), n, dy.as<float>(), nullptr));
+    CVTMI_TRY(opq_rotate_impl(h, dx.as<float>(), n, dy.as<float>(), nullptr));
     CVTMI_HIP(hipMemcpy(y, dy.p, bytes, hipMemcpyDeviceToHost));
     return CVTMI_OK;
 }
@@ -619,7 +626,7 @@ int cvtmi_opq_rotate_encode_dev(cvtmi_opq_t h, const float *x, int64_t n, int32_
     CVTMI_TRY(h->s_rot.reserve((size_t)std::min(n, chunk) * h->m.D * sizeof(float)));
     for (int64_t a = 0; a < n; a += chunk) {
         const int64_t m = std::min(chunk, n - a);
-        CVTMI_TRY(cvtmi_opq_rotate_dev(h, x + a * h->m.D, m, h->s_rot.as<float>(), stream));
+        CVTMI_TRY(opq_rotate_impl(h, x + a * h->m.D, m, h->s_rot.as<float>(), (hipStream_t)stream));   // (this call holds the handle exclusively)
         CVTMI_TRY(cvtmi_opq_encode_dev(h, h->s_rot.as<float>(), m, list_id ? list_id + a : nullptr, codes + a * h->m.M, stream));
     }
     return CVTMI_OK;
@@ -786,14 +793,14 @@ int cvtmi_opq_get_entries(cvtmi_opq_t h, int64_t *list_off, int32_t *video_id, u
 
 int cvtmi_opq_lut_dev(cvtmi_opq_t h, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut, void *stream)
 {
-    CHECK_H_SERIAL(h, stream);
+    CHECK_H_SHARED(h);
     if (nq < 0 || (nq > 0 && (!q_rot || !lut))) return fail(CVTMI_EINVAL, "cvtmi_opq_lut: bad arguments");
     return launch_lut(h->m, q_rot, nq, list_id, lut, (hipStream_t)stream);
 }
 
 int cvtmi_opq_lut(cvtmi_opq_t h, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut)
 {
-    CHECK_H_SERIAL(h, nullptr);
+    CHECK_H_SHARED(h);
     if (nq < 0 || (nq > 0 && (!q_rot || !lut))) return fail(CVTMI_EINVAL, "cvtmi_opq_lut: bad arguments");
     if (nq == 0) return CVTMI_OK;
     if (list_id)
@@ -804,7 +811,7 @@ int cvtmi_opq_lut(cvtmi_opq_t h, const float *q_rot, int64_t nq, const int32_t *
     if (list_id) CVTMI_TRY(dl.upload(list_id, (size_t)nq * sizeof(int32_t)));
     const size_t lb = (size_t)nq * h->m.M * h->m.K * sizeof(float);
     CVTMI_TRY(dt.alloc(lb));
-    CVTMI_TRY(cvtmi_opq_lut_dev(h, dq.as<float>(), nq, list_id ? dl.as<int32_t>() : nullptr, dt.as<float>(), nullptr));
+    CVTMI_TRY(launch_lut(h->m, dq.as<float>(), nq, list_id ? dl.as<int32_t>() : nullptr, dt.as<float>(), nullptr));
     CVTMI_HIP(hipMemcpy(lut, dt.p, lb, hipMemcpyDeviceToHost));
     return CVTMI_OK;
 }
@@ -815,6 +822,13 @@ static int opq_rotate_impl(cvtmi_opq_t h, const float *x, int64_t n, float *y, h
     if (h->m.R) return launch_rotate_gemm(h->m.R, h->m.D, x, n, y, st);
     if (n > 0) CVTMI_HIP(hipMemcpyAsync(y, x, (size_t)n * h->m.D * sizeof(float), hipMemcpyDeviceToDevice, st));
     return CVTMI_OK;
+}
+
+// profile mode: shape of the last scan launch, one consistent triple however many searches run side by side
+static void opq_note_scan(cvtmi_opq_t h, int64_t bytes, int qt, int splits)
+{
+    std::lock_guard<std::mutex> g(h->pool_mu);
+    h->last_bytes = bytes; h->last_qt = qt; h->last_splits = splits;
 }
 
 // profile mode: a slot of the handle's event ring for one scan launch (searches may run side by side)
@@ -868,8 +882,7 @@ static int opq_search_h(cvtmi_opq_t h, OpqScratch &S, const float *q_rot, int64_
                                 S.s_lut.as<float>(), S.s_qlut.p, S.s_qp.p, S.s_spill.p, gthr, h->p_lazy, scan_seed_enabled(), st));
     if (h->p_profile) {
         CVTMI_HIP(hipEventRecord(h->ev1[slot], st));
-        h->last_bytes = ((nq + 7) / 8) * h->n * h->m.M;  // passes x rows x M code bytes
-        h->last_qt = 8; h->last_splits = hp.stride;
+        opq_note_scan(h, ((nq + 7) / 8) * h->n * h->m.M, 8, hp.stride);  // passes x rows x M code bytes
     }
     if (hp.stride > 1)  // (queries of groups scanned in one piece are already in place: the merge skips them)
         CVTMI_TRY(launch_topk_merge(pd, pi, nq, hp.stride, k, dist, ids, st,
@@ -939,8 +952,7 @@ static int opq_search_leased(cvtmi_opq_t h, OpqScratch &S, const float *q, int64
                                         S.s_qp.p, S.s_spill.p, h->p_lazy, st));
         if (h->p_profile) {
             CVTMI_HIP(hipEventRecord(h->ev1[slot], st));
-            h->last_bytes = h->n * h->m.M;
-            h->last_qt = 8; h->last_splits = 1;
+            opq_note_scan(h, h->n * h->m.M, 8, 1);
         }
         return CVTMI_OK;
     }
@@ -983,8 +995,7 @@ static int opq_search_leased(cvtmi_opq_t h, OpqScratch &S, const float *q, int64
     if (h->p_profile) {
         CVTMI_HIP(hipEventRecord(h->ev1[slot], st));
         const int64_t groups = (nq + plan.qtile - 1) / plan.qtile;
-        h->last_bytes = groups * h->n * h->m.M;  // passes x rows x M code bytes
-        h->last_qt = plan.qtile; h->last_splits = plan.splits;
+        opq_note_scan(h, groups * h->n * h->m.M, plan.qtile, plan.splits);  // passes x rows x M code bytes
     }
     if (plan.stride() > 1) CVTMI_TRY(launch_topk_merge(pd, pi, nq, plan.stride(), k, dist, ids, st));
     return CVTMI_OK;
@@ -1058,9 +1069,13 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
     const auto copy_out = [](void *dst, const void *src, size_t bytes) {
         if (bytes < ((size_t)1 << 20)) { memcpy(dst, src, bytes); return; }
         const size_t half = (bytes / 2) & ~(size_t)63;
-        std::thread helper([=]() { memcpy(static_cast<char *>(dst) + half, static_cast<const char *>(src) + half, bytes - half); });
-        memcpy(dst, src, half);
-        helper.join();
+        try {   // (thread creation can throw std::system_error: nothing may cross the C ABI)
+            std::thread helper([=]() { memcpy(static_cast<char *>(dst) + half, static_cast<const char *>(src) + half, bytes - half); });
+            memcpy(dst, src, half);
+            helper.join();
+        } catch (...) {
+            memcpy(dst, src, bytes);
+        }
     };
     // results of the chunk a set holds -> the caller's arrays (after its stream has drained)
     const auto drain = [&](int i) -> int {
@@ -1313,6 +1328,7 @@ int cvtmi_opq_last_scan(cvtmi_opq_t h, float *ms, int64_t *code_bytes, int *qtil
     }
     h->ev_count = 0;
     if (ms) *ms = (float)(sum / cnt);
+    std::lock_guard<std::mutex> g(h->pool_mu);
     if (code_bytes) *code_bytes = h->last_bytes;
     if (qtile) *qtile = h->last_qt;
     if (splits) *splits = h->last_splits;

@@ -79,7 +79,7 @@ struct ScanHPlan {
     std::vector<uint32_t> multi;  // [nq]: 1 = the query's group was scanned in several segments (its partial lists need the merge)
     int grid = 0, rounds = 0, stride = 1;  // workgroups, items per workgroup, partial lists per query
 };
-void scanh_plan(int64_t n_rows, int64_t nq, int splits, ScanHPlan &p);
+void scanh_plan(int64_t n_rows, int64_t nq, int splits, ScanHPlan &p, int cus = 0);   // cus = 0: the device's CU count
 size_t scanh_spill_bytes(int grid);
 size_t scanh_qlut_bytes(int64_t nq);
 size_t scanh_qp_bytes(int64_t nq);

@@ -285,8 +285,12 @@ int comm_exchange_merge(cvtmi_comm_t c, int64_t nq, int k, int status, float *di
     CVTMI_TRY(comm_allgather(c, slot, st));
     const int rc = comm_check_statuses(c, slot, status, st);
     if (rc != CVTMI_OK) {
-        if (status != CVTMI_OK) return fail(CVTMI_ECOMM, "row-sharded search: the local search of rank %d failed with %d: %s", c->rank, status, own.c_str());
-        return rc;
+        // (a failure an EARLIER search left behind was taken off the communicator above: it is reported with this one, not dropped)
+        const std::string now = status != CVTMI_OK ? own : std::string(cvtmi_last_error());
+        const char *sep = earlier != CVTMI_OK ? "; and before that: " : "";
+        if (status != CVTMI_OK)
+            return fail(CVTMI_ECOMM, "row-sharded search: the local search of rank %d failed with %d: %s%s%s", c->rank, status, now.c_str(), sep, earlier_msg.c_str());
+        return fail(CVTMI_ECOMM, "%s%s%s", now.c_str(), sep, earlier_msg.c_str());
     }
     uint8_t *base = c->gather.as<uint8_t>() + kSlotHeader;
     const size_t ids_off = align16((size_t)nq * k * sizeof(float));
@@ -385,14 +389,18 @@ int cvtmi_comm_create(const void *id, int rank, int world, cvtmi_comm_t *out)
     cvtmi_comm_s *c = new (std::nothrow) cvtmi_comm_s();
     if (!c) return fail(CVTMI_ENOMEM, "cvtmi_comm_create: out of host memory");
     c->device = dev; c->rank = rank; c->world = world;
+    // the word of the deferred status check is allocated HERE, before anybody is inside a collective: a rank that cannot get it fails at
+    // creation, not on its way into a search's all-gather (where its peers would wait for ever)
+    if (world > 1) { const int rs = comm_sticky_ready(c); if (rs != CVTMI_OK) { delete c; return rs; } }
     if (world > 1 || g_force_rccl) {
         RcclApi *api = nullptr;
         int rc = rccl_ready(&api);
-        if (rc != CVTMI_OK) { delete c; return rc; }
+        if (rc != CVTMI_OK) { if (c->h_sticky) (void)hipHostFree(c->h_sticky); delete c; return rc; }
         ncclUniqueId u;
         memcpy(&u, id, sizeof u);
         ncclResult_t r = api->CommInitRank(&c->nccl, world, u, rank);  // collective: every rank of the job is in here now
         if (r != ncclSuccess) {
+            if (c->h_sticky) (void)hipHostFree(c->h_sticky);
             delete c;
             return fail(CVTMI_ECOMM, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, dev, api->GetErrorString(r));
         }
@@ -442,6 +450,7 @@ int cvtmi_comm_create_custom(cvtmi_allgather_fn fn, void *ctx, int rank, int wor
     cvtmi_comm_s *c = new (std::nothrow) cvtmi_comm_s();
     if (!c) return fail(CVTMI_ENOMEM, "cvtmi_comm_create_custom: out of host memory");
     c->device = dev; c->rank = rank; c->world = world; c->fn = fn; c->ctx = ctx;
+    if (world > 1) { const int rs = comm_sticky_ready(c); if (rs != CVTMI_OK) { delete c; return rs; } }   // (as in cvtmi_comm_create)
     *out = c;
     return CVTMI_OK;
 }

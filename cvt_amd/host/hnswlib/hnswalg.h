@@ -99,8 +99,14 @@ public:
             id = (tableint)count_++;
             lvl = draw_level();
             dirty_ = true;
+            link0_[(size_t)id * (maxM0_ + 1)] = 0u;   // (the row is uninitialised storage until insert() fills it)
         }
-        insert(id, (const float *)data_point, label, lvl);
+        try {
+            insert(id, (const float *)data_point, label, lvl);
+        } catch (...) {   // count_ already covers the row: the graph must not be saved, uploaded or searched in this state
+            broken_ = true;
+            throw;
+        }
     }
 
     // worker count for `threads` = 0: the hardware threads this process may actually use -- its affinity mask and, in a container, its CPU
@@ -140,13 +146,18 @@ public:
             count_ += n;
             dirty_ = true;
             for (size_t i = 0; i < n; ++i) lv[i] = draw_level();
+            // vec_ / link0_ are uninitialised storage (first touch belongs to the worker that inserts the row): at least the link COUNT of
+            // every reserved row is zeroed here, so that a row no worker reached can never be followed anywhere
+            for (size_t i = 0; i < n; ++i) link0_[(base + i) * (maxM0_ + 1)] = 0u;
         }
         const float *x = (const float *)rows;
         auto one = [&](size_t i) { insert((tableint)(base + i), x + i * dim_, labels ? labels[i] : (labeltype)(base + i), lv[i]); };
         size_t first = 0;
-        if (base == 0) one(first++);
+        if (base == 0) { try { one(first++); } catch (...) { broken_ = true; throw; } }
         if (threads == 1 || n - first < 2 * (size_t)threads) {
-            for (size_t i = first; i < n; ++i) one(i);
+            try {
+                for (size_t i = first; i < n; ++i) one(i);
+            } catch (...) { broken_ = true; throw; }
             return;
         }
         std::atomic<size_t> next(first);
@@ -165,7 +176,10 @@ public:
         for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work);
         work();
         for (size_t t = 0; t < pool.size(); ++t) pool[t].join();
-        if (!err.empty()) throw std::runtime_error(err);
+        if (!err.empty()) {   // count_ covers rows that were never inserted: saveIndex / upload / search refuse from here on
+            broken_ = true;
+            throw std::runtime_error(err);
+        }
     }
 
     // the reference's file (:491-519)
@@ -481,6 +495,7 @@ private:
     }
     std::vector<char> serialise() const
     {
+        if (broken_) throw std::runtime_error("HierarchicalNSW: an insertion failed part-way, the graph holds rows that were never linked; rebuild it");
         const size_t link0_bytes = maxM0_ * sizeof(tableint) + sizeof(unsigned int);
         const size_t per_elem = link0_bytes + dim_ * sizeof(float) + sizeof(labeltype);
         const size_t off_level0 = 0, off_data = link0_bytes, off_label = link0_bytes + dim_ * sizeof(float);
@@ -510,6 +525,7 @@ private:
     }
     void parse(const std::vector<char> &buf)
     {
+        broken_ = false;
         if (buf.size() < 96) throw std::runtime_error("cvt_amd: not a saveIndex file");
         const char *p = buf.data();
         size_t off_level0, per_elem, off_label, off_data, a, b2, c, efc;
@@ -563,6 +579,7 @@ private:
     std::unique_ptr<float[]> vec_;                // [cap][dim]; elements past count_ are never read
     std::vector<labeltype> label_;
     std::vector<int> level_;
+    bool broken_ = false;                         // an insertion threw after count_ had been advanced
     std::unique_ptr<tableint[]> link0_;           // [cap][maxM0 + 1]: count, neighbours
     std::vector<std::vector<tableint> > upper_;   // per node: levels x (maxM + 1)
     std::unique_ptr<std::atomic<uint32_t>[]> seq_;   // one sequence lock per node (the reference: link_list_locks_, hnswalg.h:76)
