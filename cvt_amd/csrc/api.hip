@@ -463,8 +463,10 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "opq_small_zero_copy")) { g_small_zero_copy = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "host_spin_us")) { g_host_spin_us = value < 0 ? 0 : (int)value; return CVTMI_OK; }
     if (!strcmp(name, "hnsw_top_lds")) { set_hnsw_top_lds((int)value); return CVTMI_OK; }
+    if (!strcmp(name, "hnsw_adc_tables")) { set_hnsw_adc_tables((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }
+    if (!strcmp(name, "sq8_filter")) { set_sq8_filter(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "sq8_wave_blocks")) {
         if (value < 1 || value > 64) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: sq8_wave_blocks must be 1..64");
         set_sq8_wave_blocks((int)value);
@@ -2487,7 +2489,7 @@ static int hnsw_search_adc_leased(cvtmi_hnsw_t h, HnswScratch &S, cvtmi_opq_t op
     CVTMI_TRY(OS.s_lut.reserve((size_t)nq * opq->m.M * opq->m.K * sizeof(float)));
     CVTMI_TRY(launch_lut(opq->m, q_rot, nq, nullptr, OS.s_lut.as<float>(), st));
     HnswPlan pl;
-    CVTMI_TRY(hnsw_plan(h, S, opq->m.M * opq->m.K, nq, k, ef, pl, st));
+    CVTMI_TRY(hnsw_plan(h, S, hnsw_adc_state_floats(opq->m.M * opq->m.K), nq, k, ef, pl, st));
     CVTMI_TRY(launch_hnsw_search_adc(h->g, OS.s_lut.as<float>(), opq->codes.as<uint8_t>(), opq->m.M, opq->m.K, nq, k, ef, dist,
                                      labels, S.s_vis.as<uint32_t>(), S.s_cand.p, pl.slots, pl.words, pl.gcap, S.s_err.as<int>(), st, raw_ids));
     return hnsw_check_overflow(S, "cvtmi_hnsw_search_adc", ef, st);

@@ -186,21 +186,36 @@ struct DistF32 {
 // "HNSW over OPQ-compressed vectors": the node's M code bytes index the query's distance tables, summed in m
 // order from +0.0f exactly as the ADC scan does (IVFOPQ.cpp:302-306) -- 16 bytes gathered per neighbour
 // instead of 4 D.
+// Where the fp32 tables live (round 5).  LDS_TABLES = true: copied into LDS per query (16 KB at M = 16: 8 query slots per CU, and 64 loads
+// per lane before a traversal can start).  LDS_TABLES = false (default): read where lut_kernel left them -- a lane's 16 entries are 16
+// independent 4-byte gathers from the query's 16 KB table (hot in L2 / Infinity Cache: a traversal touches it ~10^4 times), ONE more memory
+// round trip per expanded node, the same one the fp32 traversal spends on its 4 D-byte vector gather -- and the slot shrinks to its two
+// queues (4 KB): 32 traversals per CU instead of 8.  The traversal is latency-bound, so queries in flight are what it lives on.
+template <bool LDS_TABLES>
 struct DistADC {
     const HnswArgs &a;
-    float *lut;  // [M][K]
-    __device__ __forceinline__ int smem_floats() const { return (a.M * a.K + 3) & ~3; }
+    float *lds;          // [M][K] (LDS_TABLES)
+    mutable const float *lut;
+    __device__ __forceinline__ int smem_floats() const { return LDS_TABLES ? ((a.M * a.K + 3) & ~3) : 0; }
     __device__ __forceinline__ void prepare(int qi, int lane) const
     {
         const float *src = a.lut + (int64_t)qi * a.M * a.K;
-        for (int i = lane; i < a.M * a.K; i += 64) lut[i] = src[i];
+        if (LDS_TABLES) {
+            for (int i = lane; i < a.M * a.K; i += 64) lds[i] = src[i];
+            lut = lds;
+        } else {
+            lut = src;
+        }
     }
     __device__ __forceinline__ float sum16(const uint4 &v) const
     {
         const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+        float e[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) e[m] = lut[m * a.K + ((w[m >> 2] >> (8 * (m & 3))) & 0xffu)];   // 16 independent look-ups first
         float s = 0.0f;
 #pragma unroll
-        for (int m = 0; m < 16; ++m) s = __fadd_rn(s, lut[m * a.K + ((w[m >> 2] >> (8 * (m & 3))) & 0xffu)]);
+        for (int m = 0; m < 16; ++m) s = __fadd_rn(s, e[m]);
         return s;
     }
     __device__ __forceinline__ float operator()(uint32_t id) const
@@ -228,7 +243,7 @@ template <class DIST>
 __global__ __launch_bounds__(64, 8) void hnsw_search_kernel(const HnswArgs a)  // <= 64 VGPRs: 8 waves per SIMD, the traversal lives on queries in flight
 {
     extern __shared__ __attribute__((aligned(16))) float hn_smem[];
-    const DIST dist{ a, hn_smem };                                     // query state first (padded to 16 bytes)
+    const DIST dist{ a, hn_smem };                                     // query state first (padded to 16 bytes; lut: set by prepare)
     HnEnt *top_l = reinterpret_cast<HnEnt *>(hn_smem + dist.smem_floats());
     const int ef_cap = (a.ef > a.k ? a.ef : a.k) + 1;   // the top queue never holds more than ef + 1 entries
     const int top_cap = ef_cap < a.top_lds ? ef_cap : a.top_lds;
@@ -423,9 +438,15 @@ int launch_hnsw_search_adc(const HnswDevGraph &g, const float *lut, const uint8_
     HnswArgs a;
     hnsw_fill_args(a, g, nq, k, ef, out_d, out_label, visited, cand_scratch, words, gcap, err);
     a.lut = lut; a.codes = codes; a.M = M; a.K = K; a.raw_ids = raw_ids;
-    const size_t lds = (size_t)hnsw_lds_bytes(M * K, ef > k ? ef : k);
-    CVTMI_HIP(hipFuncSetAttribute((const void *)hnsw_search_kernel<DistADC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((hnsw_search_kernel<DistADC>), dim3((unsigned)slots), dim3(64), lds, st, a);
+    const bool lds_tables = hnsw_adc_state_floats(M * K) != 0;
+    const size_t lds = (size_t)hnsw_lds_bytes(hnsw_adc_state_floats(M * K), ef > k ? ef : k);
+    if (lds_tables) {
+        CVTMI_HIP(hipFuncSetAttribute((const void *)hnsw_search_kernel<DistADC<true> >, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((hnsw_search_kernel<DistADC<true> >), dim3((unsigned)slots), dim3(64), lds, st, a);
+    } else {
+        CVTMI_HIP(hipFuncSetAttribute((const void *)hnsw_search_kernel<DistADC<false> >, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((hnsw_search_kernel<DistADC<false> >), dim3((unsigned)slots), dim3(64), lds, st, a);
+    }
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
@@ -479,6 +500,10 @@ int hnsw_lds_bytes(int state_floats, int ef)
 {
     return (int)(((state_floats + 3) & ~3) * sizeof(float) + (size_t)(hnsw_top_lds(ef) + HN_LCAP) * sizeof(HnEnt));
 }
+// cvtmi_set_tuning("hnsw_adc_tables"): 0 = a query's fp32 tables are read from the scratch lut_kernel wrote (default), 1 = copied into LDS
+static std::atomic<int> g_hnsw_adc_tables_lds{ 0 };
+void set_hnsw_adc_tables(int v) { g_hnsw_adc_tables_lds = v != 0; }
+int hnsw_adc_state_floats(int MK) { return g_hnsw_adc_tables_lds.load() ? MK : 0; }   // per-slot query state of the ADC traversal, in floats
 int hnsw_ef_max() { return HN_EF_MAX; }
 int hnsw_lcap() { return HN_LCAP; }
 

@@ -747,6 +747,294 @@ __global__ __launch_bounds__(kBlock) void sq8_encode_wave_kernel(const float *__
     }
 }
 
+// ---- round 5: the same two kernels with the per-element work turned into a DECISION FILTER ----------------------------
+// The wave kernels above are bound by their vector work, not by HBM (normalising encode 0.36-0.45 of the peak, training 0.63):
+// two correctly rounded divisions per element (8 instructions each with their guards) and the byte conversion.  But what leaves
+// per element is one BYTE (encode) or nothing at all (training: a column extreme changes a handful of times per wave), so the
+// exact chain is only needed where a cheap approximation cannot decide.
+//
+// Encode.  Reference chain (int8_quan.cc:46-56, :79-92), u = 2^-24:  a = RN(v / den), b = RN(a - lo), x = RN(b / df),
+// x' = clamp(x, 0, 1), y = RN(255 x'), code = (int) y.  Real value t* = 255 (v / den - lo) / df, R = |lo| / |df|.
+//   the chain:      |y - t*| <= 255 u (R + |t*| / 255) [rounding of a] + 3.01 u |t*| [b, x, y]   <= u (255 R + 1030)   for |t*| <= 256
+//   the filter:     T = fma(p, s, c),  p = RN(v RN(1 / den)) (or the exact a when the row is written back),  s = RN(255 RN(1 / df)),
+//                   c = RN(-lo s):  |T - t*| <= 255 (R + |t*| / 255) 5.01 u + 255 R 4.01 u               <= u (2300 R + 1290)
+//   so with E = 2^-24 (2600 R + 2400) (+ 2^-60 for products that underflow): a T that is farther than E from every integer has
+//   floor(T) = floor(y) whenever 0 <= T < 255, T <= -E means x < 0 (code 0: the sign of b / df is exact), T >= 255 + E means y = 255.
+//   => code = clamp(floor(T), 0, 255) when |frac(T) - 1/2| < 1/2 - E; every other element -- about 2 E of them, NaN / inf / huge
+//   values (their frac test fails by itself), columns with R > 16 or |df|, |lo| outside 2^-40 .. 2^40 (h = -1: never sure), rows
+//   whose norm is outside div_by's guarded range -- takes the chain itself.  Exact zeros (half of a ReLU'd feature matrix) would
+//   sit ON an integer when lo = 0: a = +-0 exactly, and their code is a per-column constant computed by the chain once.
+// Training.  Only min / max of a = RN(v / den) per column leave.  With p' = RN(v RN(1 / den) 2^60):  p' / 2^60 = a (1 +- 3.01 u), and
+//   p' = +-0 only if a = +-0 (the scaling keeps tiny quotients away from the underflow threshold).  An element whose p' is not below
+//   tmn' = (mn + 8 u |mn|) 2^60 has a >= mn and cannot change the minimum (same for the maximum); the others -- new extremes and the
+//   few inside the 8 u band -- are divided exactly.  Every wave starts from the extremes of the first rows (a sample pass over
+//   8192 rows through the same kernel), so "new extreme" is rare from its first row on.
+// cvtmi_set_tuning("sq8_filter", 0) restores the kernels above (tests run both; results are identical bit for bit).
+struct ColF { float s, c, h; uint32_t code0; };
+__device__ __forceinline__ ColF sq8_col_filter(float lo, float df)
+{
+    ColF f;
+    const float adf = fabsf(df), alo = fabsf(lo);
+    const float rdf = __fdiv_rn(1.0f, df);
+    f.s = __fmul_rn(255.0f, rdf);
+    f.c = __fmul_rn(-lo, f.s);
+    const float R = __fmul_rn(alo, fabsf(rdf));
+    const bool usable = adf >= 0x1p-40f && adf <= 0x1p40f && alo <= 0x1p40f && R <= 16.0f;   // false for NaN anywhere
+    const float E = __fmaf_rn(__fmaf_rn(2600.0f, R, 2400.0f), 0x1.01p-24f, 0x1p-60f);
+    f.h = usable ? __fsub_rn(0.5f, E) : -1.0f;
+    f.code0 = sq8_byte(0.0f, lo, div_by(df));
+    return f;
+}
+
+template <int NF>
+__global__ __launch_bounds__(kBlock) void sq8_encode_wave_f_kernel(const float *__restrict__ vmin, const float *__restrict__ vdiff, float *x, int64_t n,
+                                                                  int write_back, uint8_t *__restrict__ codes)
+{
+    constexpr int CG = 64 * NF, D = 4 * CG;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 *x4 = reinterpret_cast<float4 *>(x);
+    uint32_t *c4 = reinterpret_cast<uint32_t *>(codes);
+    const int64_t nw = (int64_t)gridDim.x * (kBlock / 64), w0 = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    ColF cf[NF][4];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const float4 l4 = reinterpret_cast<const float4 *>(vmin)[lane + 64 * i];
+        const float4 d4 = reinterpret_cast<const float4 *>(vdiff)[lane + 64 * i];
+        cf[i][0] = sq8_col_filter(l4.x, d4.x); cf[i][1] = sq8_col_filter(l4.y, d4.y);
+        cf[i][2] = sq8_col_filter(l4.z, d4.z); cf[i][3] = sq8_col_filter(l4.w, d4.w);
+    }
+    constexpr int RB = 4;
+    float4 cur[RB][NF], nxt[RB][NF];
+    auto fetch = [&](int64_t row, float4 (&o)[NF]) {
+        const int64_t r = row < n ? row : n - 1;  // clamped: rows past the end are computed, never stored
+#pragma unroll
+        for (int i = 0; i < NF; ++i) o[i] = SQ8_LD(&x4[r * CG + lane + 64 * i]);
+    };
+#pragma unroll
+    for (int p = 0; p < RB; ++p) fetch(w0 + p * nw, nxt[p]);
+    for (int64_t row = w0; row < n; row += RB * nw) {
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) cur[p][i] = nxt[p][i];
+            fetch(row + (p + RB) * nw, nxt[p]);
+        }
+        double s[RB];
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            s[p] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                s[p] += (double)__fmul_rn(cur[p][i].x, cur[p][i].x); s[p] += (double)__fmul_rn(cur[p][i].y, cur[p][i].y);
+                s[p] += (double)__fmul_rn(cur[p][i].z, cur[p][i].z); s[p] += (double)__fmul_rn(cur[p][i].w, cur[p][i].w);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) s[p] += __shfl_xor(s[p], o, 64);
+        }
+        double mine = s[0];
+#pragma unroll
+        for (int p = 1; p < RB; ++p) mine = lane == p ? s[p] : mine;
+        // same proof as the tile kernel: the float root is order-independent when the roots of sum (1 -+ 2^-42) coincide
+        const double rlo = __dsqrt_rn(mine * (1.0 - 0x1p-42)), rhi = __dsqrt_rn(mine * (1.0 + 0x1p-42));
+        float den = (float)(rlo > 1e-12 ? rlo : 1e-12);
+        const float fhi = (float)(rhi > 1e-12 ? rhi : 1e-12);
+        const unsigned long long unproven = __ballot(lane < RB && !(den == fhi));
+        if (unproven) {  // rare: the reference's own order for those rows (int8_quan.cc:48-51)
+#pragma unroll
+            for (int p = 0; p < RB; ++p) {
+                if ((unproven >> p) & 1ull) {  // wave-uniform
+                    const int64_t r = row + p * nw < n ? row + p * nw : n - 1;
+                    double accum = 0.0;
+                    for (int e = 0; e < D; ++e) {
+                        const float t = x[r * D + e];
+                        accum += (double)__fmul_rn(t, t);
+                    }
+                    const double nrm = __dsqrt_rn(accum);
+                    if (lane == p) den = (float)(nrm > 1e-12 ? nrm : 1e-12);
+                }
+            }
+        }
+        const DivBy dl = div_by(den);
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            const int64_t r = row + p * nw;
+            DivBy dd;
+            dd.b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl.b), p));
+            dd.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl.y), p));
+            dd.ok = __builtin_amdgcn_readlane((int)dl.ok, p) != 0;
+            if (!dd.ok) {   // wave-uniform, rare: a norm outside the guarded range (zero / huge / non-finite rows) -- the chain for the whole row
+#pragma unroll
+                for (int i = 0; i < NF; ++i) {
+                    float4 v = cur[p][i];
+                    v.x = div_rn(v.x, dd); v.y = div_rn(v.y, dd); v.z = div_rn(v.z, dd); v.w = div_rn(v.w, dd);
+                    if (write_back && r < n) SQ8_ST(&x4[r * CG + lane + 64 * i], v);
+                    const float4 l4 = reinterpret_cast<const float4 *>(vmin)[lane + 64 * i];
+                    const float4 d4 = reinterpret_cast<const float4 *>(vdiff)[lane + 64 * i];
+                    const uint32_t w = sq8_byte(v.x, l4.x, div_by(d4.x)) | (sq8_byte(v.y, l4.y, div_by(d4.y)) << 8) |
+                                       (sq8_byte(v.z, l4.z, div_by(d4.z)) << 16) | (sq8_byte(v.w, l4.w, div_by(d4.w)) << 24);
+                    if (r < n) SQ8_ST(&c4[r * CG + lane + 64 * i], w);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const float4 v = cur[p][i];
+                float e[4] = { v.x, v.y, v.z, v.w };
+                if (write_back) {   // (uniform) the reference's in-place normalisation: the exact quotients are needed anyway
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e[j] = div_rn(e[j], dd);
+                    if (r < n) SQ8_ST(&x4[r * CG + lane + 64 * i], make_float4(e[0], e[1], e[2], e[3]));
+                }
+                uint32_t w = 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const ColF &f = cf[i][j];
+                    const float pq = write_back ? e[j] : __fmul_rn(e[j], dd.y);
+                    const float T = __fmaf_rn(pq, f.s, f.c);
+                    const float fl = floorf(T);
+                    const bool sure = fabsf(__fsub_rn(__fsub_rn(T, fl), 0.5f)) < f.h;
+                    const bool zero = e[j] == 0.0f;   // +-0 in, +-0 out of the division: the column's constant
+                    uint32_t b = (uint32_t)__builtin_amdgcn_fmed3f(fl, 0.0f, 255.0f);
+                    b = zero ? f.code0 : b;
+                    if (!(sure || zero)) {   // ~2 E of the elements, and whatever the bound does not cover: the chain itself
+                        const int col = 4 * (lane + 64 * i) + j;
+                        const float a = write_back ? e[j] : div_rn(e[j], dd);
+                        b = sq8_byte(a, vmin[col], div_by(vdiff[col]));
+                    }
+                    w |= b << (8 * j);
+                }
+                if (r < n) SQ8_ST(&c4[r * CG + lane + 64 * i], w);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float sq8_thr_lo(float mn)   // p' >= this  =>  a >= mn   (p' = a 2^60 (1 +- 3.01 u))
+{
+    const float am = fabsf(mn);
+    if (am == 0.0f) return 0.0f;
+    if (!(am >= 0x1p-120f)) return __uint_as_float(0x7f800000u);   // a denormal extreme: every element is divided exactly
+    return __fmul_rn(__fmaf_rn(am, 0x1p-21f, mn), 0x1p60f);
+}
+__device__ __forceinline__ float sq8_thr_hi(float mx)   // p' <= this  =>  a <= mx
+{
+    const float am = fabsf(mx);
+    if (am == 0.0f) return 0.0f;
+    if (!(am >= 0x1p-120f)) return __uint_as_float(0xff800000u);
+    return __fmul_rn(__fmaf_rn(am, -0x1p-21f, mx), 0x1p60f);
+}
+
+// seeded != 0: every lane starts from the column extremes already in kmin / kmax (the sample pass)
+template <int NF>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void sq8_train_wave_f_kernel(const float *__restrict__ x, int64_t n, uint32_t *kmin,
+                                                                  uint32_t *kmax, int seeded)
+{
+    constexpr int CG = 64 * NF, D = 4 * CG;
+    __shared__ uint32_t smin[D], smax[D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < D; c += kBlock) { smin[c] = 0xffffffffu; smax[c] = 0u; }
+    __syncthreads();
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    const int64_t nw = (int64_t)gridDim.x * (kBlock / 64), w0 = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    float mn[NF][4], mx[NF][4], tlo[NF][4], thi[NF][4];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * (lane + 64 * i) + j;
+            mn[i][j] = seeded ? key_f32(kmin[c]) : __uint_as_float(0x7f800000u);
+            mx[i][j] = seeded ? key_f32(kmax[c]) : __uint_as_float(0xff800000u);
+            if (!(mn[i][j] <= mx[i][j])) { mn[i][j] = __uint_as_float(0x7f800000u); mx[i][j] = __uint_as_float(0xff800000u); }   // an empty / all-NaN sample
+            tlo[i][j] = sq8_thr_lo(mn[i][j]);
+            thi[i][j] = sq8_thr_hi(mx[i][j]);
+        }
+    constexpr int RB = 4;
+    float4 cur[RB][NF], nxt[RB][NF];
+    auto fetch = [&](int64_t row, float4 (&o)[NF]) {
+        const int64_t r = row < n ? row : n - 1;  // clamped: the tail re-reads the last row, which changes no extreme
+#pragma unroll
+        for (int i = 0; i < NF; ++i) o[i] = SQ8_LD(&x4[r * CG + lane + 64 * i]);
+    };
+#pragma unroll
+    for (int p = 0; p < RB; ++p) fetch(w0 + p * nw, nxt[p]);
+    for (int64_t row = w0; row < n; row += RB * nw) {
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) cur[p][i] = nxt[p][i];
+            fetch(row + (p + RB) * nw, nxt[p]);
+        }
+        double s[RB];
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            s[p] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                s[p] += (double)__fmul_rn(cur[p][i].x, cur[p][i].x); s[p] += (double)__fmul_rn(cur[p][i].y, cur[p][i].y);
+                s[p] += (double)__fmul_rn(cur[p][i].z, cur[p][i].z); s[p] += (double)__fmul_rn(cur[p][i].w, cur[p][i].w);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) s[p] += __shfl_xor(s[p], o, 64);
+        }
+        double mine = s[0];
+#pragma unroll
+        for (int p = 1; p < RB; ++p) mine = lane == p ? s[p] : mine;
+        const double rlo = __dsqrt_rn(mine * (1.0 - 0x1p-42)), rhi = __dsqrt_rn(mine * (1.0 + 0x1p-42));
+        float den = (float)(rlo > 1e-12 ? rlo : 1e-12);
+        const float fhi = (float)(rhi > 1e-12 ? rhi : 1e-12);
+        const unsigned long long unproven = __ballot(lane < RB && !(den == fhi));
+        if (unproven) {  // rare: not proven, or not finite -- the reference's own order for those rows (int8_quan.cc:48-51)
+#pragma unroll
+            for (int p = 0; p < RB; ++p) {
+                if ((unproven >> p) & 1ull) {  // wave-uniform
+                    const int64_t r = row + p * nw < n ? row + p * nw : n - 1;
+                    double accum = 0.0;
+                    for (int e = 0; e < D; ++e) {
+                        const float t = x[r * D + e];
+                        accum += (double)__fmul_rn(t, t);
+                    }
+                    const double nrm = __dsqrt_rn(accum);
+                    if (lane == p) den = (float)(nrm > 1e-12 ? nrm : 1e-12);
+                }
+            }
+        }
+        const DivBy dl = div_by(den);
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            DivBy dd;
+            dd.b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl.b), p));
+            dd.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl.y), p));
+            dd.ok = __builtin_amdgcn_readlane((int)dl.ok, p) != 0;
+            const float ys = __fmul_rn(dd.y, 0x1p60f);   // exact scaling (dd.y <= 2^40 when ok)
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const float e[4] = { cur[p][i].x, cur[p][i].y, cur[p][i].z, cur[p][i].w };
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float pp = __fmul_rn(e[j], ys);
+                    if (!dd.ok || pp < tlo[i][j] || pp > thi[i][j]) {   // a candidate for an extreme (or a row the bound does not cover): exact
+                        const float a = div_rn(e[j], dd);
+                        if (a < mn[i][j]) { mn[i][j] = a; tlo[i][j] = sq8_thr_lo(a); }
+                        if (a > mx[i][j]) { mx[i][j] = a; thi[i][j] = sq8_thr_hi(a); }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int c = 4 * (lane + 64 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { atomicMin(&smin[c + j], f32_key(mn[i][j])); atomicMax(&smax[c + j], f32_key(mx[i][j])); }
+    }
+    __syncthreads();
+    for (int c = tid; c < D; c += kBlock) { atomicMin(&kmin[c], smin[c]); atomicMax(&kmax[c], smax[c]); }
+}
+
+static int g_sq8_filter = 1;   // cvtmi_set_tuning("sq8_filter"): 0 = the exact chain for every element (the round 2 - 4 kernels)
+void set_sq8_filter(int v) { g_sq8_filter = v != 0; }
+constexpr int64_t SQ8_SAMPLE_ROWS = 8192;   // rows of the training pass that seeds every wave's extremes
+
 // workgroups per CU of the wave-per-row training kernel.  A wave keeps RB rows in flight that lie (waves in the grid) rows apart: with a
 // power-of-two grid those streams are a power-of-two distance apart and fall on the same HBM channels -- measured on 2 M x 512-d:
 // 8 per CU 4.62-4.67 TB/s, 4: 4.38, 16: 4.89, 3: 5.04, 24: 5.09 (tools: cvtmi_set_tuning("sq8_wave_blocks"))
@@ -763,7 +1051,20 @@ int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_sc
             // whole rows per wave, no LDS tile (the tile kernel's phases serialise behind its barriers: 3.3 TB/s at d = 512)
             const int64_t rows_per_wg = kBlock / 64;
             const unsigned blocks = (unsigned)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 256 * g_sq8_wave_blocks);
-            if (d == 512) hipLaunchKernelGGL((sq8_train_wave_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax);
+            if (g_sq8_filter) {
+                // sample pass over the first rows (its extremes seed every wave of the main pass: "new extreme" is rare from the start),
+                // then the rest; both through the filter kernel, the sample unseeded
+                const int64_t ns = n >= 8 * SQ8_SAMPLE_ROWS ? SQ8_SAMPLE_ROWS : 0;
+                const float *xr = x + ns * d;
+                const unsigned sblocks = (unsigned)((ns / 16 + rows_per_wg - 1) / rows_per_wg);   // 16 rows per wave of the sample
+                if (d == 512) {
+                    if (ns) hipLaunchKernelGGL((sq8_train_wave_f_kernel<2>), dim3(sblocks), dim3(kBlock), 0, st, x, ns, kmin, kmax, 0);
+                    hipLaunchKernelGGL((sq8_train_wave_f_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, xr, n - ns, kmin, kmax, ns ? 1 : 0);
+                } else {
+                    if (ns) hipLaunchKernelGGL((sq8_train_wave_f_kernel<1>), dim3(sblocks), dim3(kBlock), 0, st, x, ns, kmin, kmax, 0);
+                    hipLaunchKernelGGL((sq8_train_wave_f_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, xr, n - ns, kmin, kmax, ns ? 1 : 0);
+                }
+            } else if (d == 512) hipLaunchKernelGGL((sq8_train_wave_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax);
             else hipLaunchKernelGGL((sq8_train_wave_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax);
         } else if (sq8_tile_ok(d, x, nullptr, nullptr, nullptr)) {
             Sq8Args a{};
@@ -790,6 +1091,12 @@ static int launch_sq8_encode_wave(const float *vmin, const float *vdiff, int d, 
 {
     const int64_t rows_per_wg = kBlock / 64;
     const unsigned blocks = (unsigned)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 256 * g_sq8_wave_blocks);
+    if (l2norm && g_sq8_filter) {
+        if (d == 512) hipLaunchKernelGGL((sq8_encode_wave_f_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes);
+        else hipLaunchKernelGGL((sq8_encode_wave_f_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes);
+        CVTMI_HIP(hipGetLastError());
+        return CVTMI_OK;
+    }
     if (d == 512) {
         if (l2norm) hipLaunchKernelGGL((sq8_encode_wave_kernel<2, true>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes);
         else hipLaunchKernelGGL((sq8_encode_wave_kernel<2, false>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes);

@@ -307,8 +307,77 @@ def test_sq8_normalisation_golden(amd, golden, group):
         w = want[ok]
         for rows in (x[ok], np.tile(x[ok], (-(-4200 // int(ok.sum())), 1))):
             tv, td = amd.sq8_train(torch.from_numpy(rows.copy()).cuda(), l2norm=True)
-            assert np.array_equal(bits(tv.cpu().numpy()), bits(w.min(axis=0)))
-            assert np.array_equal(bits(td.cpu().numpy()), bits(w.max(axis=0) - w.min(axis=0)))
+            tv, td = tv.cpu().numpy(), td.cpu().numpy()
+            # a column whose minimum is zero and that holds zeros of BOTH signs: the sequential loop keeps the first it meets, the
+            # device reduction the negative one (v_min_f32) -- equal as numbers, same codes (x - (+-0) and the clamp see no sign); every
+            # other entry is compared bit for bit
+            zero = (w.min(axis=0) == 0)
+            assert np.array_equal(tv, w.min(axis=0)) and np.array_equal(bits(tv)[~zero], bits(w.min(axis=0))[~zero])
+            assert np.array_equal(bits(td), bits(w.max(axis=0) - w.min(axis=0)))
+
+
+def _same_min(a, b):
+    """column minima: equal as numbers, and bit for bit except for the sign of a zero (see test_sq8_normalisation_golden)"""
+    nz = (b != 0)
+    return np.array_equal(a, b) and np.array_equal(bits(a)[nz], bits(b)[nz])
+
+
+@pytest.mark.parametrize("d", [512, 256])
+@pytest.mark.parametrize("kind", ["relu", "signed", "wide"])
+def test_sq8_decision_filter_equals_the_chain(amd, orc, d, kind):
+    """Round 5: the wave kernels decide most code bytes / column extremes from a bounded approximation and run the reference's chain
+    (two correctly rounded divisions + the byte, int8_quan.cc:46-56, :79-92) only where that cannot decide.  Codes, written-back rows and
+    trained ranges must equal the chain's (filter off) and the oracle's, on: half-zero rows (exact zeros sit ON an integer when vmin = 0),
+    signed rows, rows spanning 40 binades, clamped values on both sides, and columns the bound does not cover (vdiff 0 / tiny / huge,
+    |vmin| >> vdiff, a NaN range), zero rows, huge rows, a non-finite row, negative zeros."""
+    import torch
+    rng = np.random.default_rng(d + len(kind))
+    n = 30_000 + 41
+    x = rng.normal(size=(n, d)).astype(np.float32)
+    if kind == "relu":
+        x = np.maximum(x, 0)
+    elif kind == "wide":
+        x = (x * np.exp2(rng.integers(-20, 20, size=(n, d)))).astype(np.float32)
+        x[rng.random(size=(n, d)) < 0.2] = 0
+    x[3] = 0; x[4, 5] = -0.0; x[11] *= 1e30; x[12] *= 1e-30; x[13, 7] = np.inf; x[14] = -0.0
+    x[20:40, :8] = -0.0
+    for l2 in (1, 2):          # 1 = the reference's in-place normalisation, 2 = rows left alone
+        ovmin, ovdiff = orc.sq8_train(x[50:].copy(), l2norm=True)          # trained without the first rows: some of them clamp
+        hv, hd = ovmin.copy(), ovdiff.copy()
+        hd[1] = 0.0; hd[2] = 1e-41; hd[3] = 1e30; hv[4] = 50.0; hd[4] = 1e-3; hd[5] = np.nan; hv[6] = -0.0; hd[7] = -abs(hd[7])
+        hv[8] = hv[8] + 0.3 * hd[8]; hd[9] *= 0.4                            # values below vmin / above vmin + vdiff: both clamps
+        oc, ox = orc.sq8_encode(hv, hd, x, l2norm=True)
+        got = {}
+        try:
+            for filt in (1, 0):
+                amd.set_tuning("sq8_filter", filt)
+                xt = torch.from_numpy(x.copy()).cuda()
+                codes = amd.sq8_encode(torch.from_numpy(hv).cuda(), torch.from_numpy(hd).cuda(), xt, l2norm=l2)
+                got[filt] = (codes.cpu().numpy(), xt.cpu().numpy())
+        finally:
+            amd.set_tuning("sq8_filter", 1)
+        fin = np.all(np.isfinite(ox), axis=1)                                # (int) NaN is undefined in the reference itself
+        fin_cols = np.isfinite(hd)
+        assert np.array_equal(got[1][0], got[0][0]), (kind, d, l2, "filter vs chain")
+        assert np.array_equal(got[1][0][fin][:, fin_cols], oc[fin][:, fin_cols]), (kind, d, l2, "vs oracle")
+        if l2 == 1:
+            assert np.array_equal(bits(got[1][1]), bits(ox)) and np.array_equal(bits(got[0][1]), bits(ox))
+        else:
+            assert np.array_equal(bits(got[1][1]), bits(x))
+    # training: extremes of the normalised rows, sample pass + seeded main pass
+    xf = x[np.all(np.isfinite(x), axis=1)]
+    ovmin, ovdiff = orc.sq8_train(xf.copy(), l2norm=True)
+    res = {}
+    try:
+        for filt in (1, 0):
+            amd.set_tuning("sq8_filter", filt)
+            for rows in (xf, np.tile(xf, (3, 1))):                           # 3 x: past the 8 x 8192 rows that switch the sample pass on
+                tv, td = amd.sq8_train(torch.from_numpy(rows.copy()).cuda(), l2norm=True)
+                res[(filt, len(rows))] = (tv.cpu().numpy(), td.cpu().numpy())
+    finally:
+        amd.set_tuning("sq8_filter", 1)
+    for key, (tv, td) in res.items():
+        assert _same_min(tv, ovmin) and np.array_equal(bits(td), bits(ovdiff)), (kind, d, key)
 
 
 def test_sq8_parity(amd, orc, golden):
