@@ -770,6 +770,36 @@ __global__ __launch_bounds__(kBlock) void sq8_encode_wave_kernel(const float *__
 //   few inside the 8 u band -- are divided exactly.  Every wave starts from the extremes of the first rows (a sample pass over
 //   8192 rows through the same kernel), so "new extreme" is rare from its first row on.
 // cvtmi_set_tuning("sq8_filter", 0) restores the kernels above (tests run both; results are identical bit for bit).
+// Sum of a double over the 64 lanes of a wave, same value in every lane, in whatever order (the proof above only needs the sum to
+// within 2^-43).  The xor butterfly costs 12 ds_bpermute round trips per row (~100 cycles each, dependent); the kernels of round 5 no
+// longer have the vector work to hide them behind, so the sum runs on DPP moves inside each row of 16 lanes (4 steps, a few cycles
+// each) and the four row sums are combined through scalar registers.
+__device__ __forceinline__ double sq8_dpp_step(double s, const int ctrl_sel)
+{
+    const int lo = __double2loint(s), hi = __double2hiint(s);
+    int lo2, hi2;
+    if (ctrl_sel == 0) { lo2 = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false); }        // quad_perm [1,0,3,2]
+    else if (ctrl_sel == 1) { lo2 = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false); }   // quad_perm [2,3,0,1]
+    else if (ctrl_sel == 2) { lo2 = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xf, 0xf, false); } // row_half_mirror
+    else { lo2 = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xf, 0xf, false); }                    // row_mirror
+    return s + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double sq8_wave_sum(double s, bool dpp)
+{
+    if (dpp) {
+        s = sq8_dpp_step(s, 0); s = sq8_dpp_step(s, 1); s = sq8_dpp_step(s, 2); s = sq8_dpp_step(s, 3);   // every lane: the sum of its row of 16
+        const int lo = __double2loint(s), hi = __double2hiint(s);
+        const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+        const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+        const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+        const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+        return (r0 + r1) + (r2 + r3);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    return s;
+}
+
 struct ColF { float s, c, h; uint32_t code0; };
 __device__ __forceinline__ ColF sq8_col_filter(float lo, float df)
 {
@@ -788,8 +818,9 @@ __device__ __forceinline__ ColF sq8_col_filter(float lo, float df)
 
 template <int NF>
 __global__ __launch_bounds__(kBlock) void sq8_encode_wave_f_kernel(const float *__restrict__ vmin, const float *__restrict__ vdiff, float *x, int64_t n,
-                                                                  int write_back, uint8_t *__restrict__ codes)
+                                                                  int write_back, uint8_t *__restrict__ codes, int flags)
 {
+    const bool dpp = (flags & 1) != 0;
     constexpr int CG = 64 * NF, D = 4 * CG;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 *x4 = reinterpret_cast<float4 *>(x);
@@ -828,8 +859,7 @@ __global__ __launch_bounds__(kBlock) void sq8_encode_wave_f_kernel(const float *
                 s[p] += (double)__fmul_rn(cur[p][i].x, cur[p][i].x); s[p] += (double)__fmul_rn(cur[p][i].y, cur[p][i].y);
                 s[p] += (double)__fmul_rn(cur[p][i].z, cur[p][i].z); s[p] += (double)__fmul_rn(cur[p][i].w, cur[p][i].w);
             }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) s[p] += __shfl_xor(s[p], o, 64);
+            s[p] = sq8_wave_sum(s[p], dpp);
         }
         double mine = s[0];
 #pragma unroll
@@ -886,6 +916,7 @@ __global__ __launch_bounds__(kBlock) void sq8_encode_wave_f_kernel(const float *
                     if (r < n) SQ8_ST(&x4[r * CG + lane + 64 * i], make_float4(e[0], e[1], e[2], e[3]));
                 }
                 uint32_t w = 0u;
+                bool open[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const ColF &f = cf[i][j];
@@ -896,12 +927,18 @@ __global__ __launch_bounds__(kBlock) void sq8_encode_wave_f_kernel(const float *
                     const bool zero = e[j] == 0.0f;   // +-0 in, +-0 out of the division: the column's constant
                     uint32_t b = (uint32_t)__builtin_amdgcn_fmed3f(fl, 0.0f, 255.0f);
                     b = zero ? f.code0 : b;
-                    if (!(sure || zero)) {   // ~2 E of the elements, and whatever the bound does not cover: the chain itself
-                        const int col = 4 * (lane + 64 * i) + j;
-                        const float a = write_back ? e[j] : div_rn(e[j], dd);
-                        b = sq8_byte(a, vmin[col], div_by(vdiff[col]));
-                    }
+                    open[j] = !(sure || zero);
                     w |= b << (8 * j);
+                }
+                if (open[0] || open[1] || open[2] || open[3]) {   // ONE branch per four elements: ~2 E of the elements, and whatever the
+#pragma unroll                                                     // bound does not cover -- the chain itself
+                    for (int j = 0; j < 4; ++j) {
+                        if (open[j]) {
+                            const int col = 4 * (lane + 64 * i) + j;
+                            const float a = write_back ? e[j] : div_rn(e[j], dd);
+                            w = (w & ~(0xffu << (8 * j))) | (sq8_byte(a, vmin[col], div_by(vdiff[col])) << (8 * j));
+                        }
+                    }
                 }
                 if (r < n) SQ8_ST(&c4[r * CG + lane + 64 * i], w);
             }
@@ -927,8 +964,9 @@ __device__ __forceinline__ float sq8_thr_hi(float mx)   // p' <= this  =>  a <= 
 // seeded != 0: every lane starts from the column extremes already in kmin / kmax (the sample pass)
 template <int NF>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void sq8_train_wave_f_kernel(const float *__restrict__ x, int64_t n, uint32_t *kmin,
-                                                                  uint32_t *kmax, int seeded)
+                                                                  uint32_t *kmax, int seeded, int flags)
 {
+    const bool dpp = (flags & 1) != 0;
     constexpr int CG = 64 * NF, D = 4 * CG;
     __shared__ uint32_t smin[D], smax[D];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -973,8 +1011,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
                 s[p] += (double)__fmul_rn(cur[p][i].x, cur[p][i].x); s[p] += (double)__fmul_rn(cur[p][i].y, cur[p][i].y);
                 s[p] += (double)__fmul_rn(cur[p][i].z, cur[p][i].z); s[p] += (double)__fmul_rn(cur[p][i].w, cur[p][i].w);
             }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) s[p] += __shfl_xor(s[p], o, 64);
+            s[p] = sq8_wave_sum(s[p], dpp);
         }
         double mine = s[0];
 #pragma unroll
@@ -1009,13 +1046,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
                 const float e[4] = { cur[p][i].x, cur[p][i].y, cur[p][i].z, cur[p][i].w };
+                bool open[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float pp = __fmul_rn(e[j], ys);
-                    if (!dd.ok || pp < tlo[i][j] || pp > thi[i][j]) {   // a candidate for an extreme (or a row the bound does not cover): exact
-                        const float a = div_rn(e[j], dd);
-                        if (a < mn[i][j]) { mn[i][j] = a; tlo[i][j] = sq8_thr_lo(a); }
-                        if (a > mx[i][j]) { mx[i][j] = a; thi[i][j] = sq8_thr_hi(a); }
+                    open[j] = !dd.ok || pp < tlo[i][j] || pp > thi[i][j];   // a candidate for an extreme (or a row the bound does not cover)
+                }
+                if (open[0] || open[1] || open[2] || open[3]) {   // ONE branch per four elements; the candidates are divided exactly
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (open[j]) {
+                            const float a = div_rn(e[j], dd);
+                            if (a < mn[i][j]) { mn[i][j] = a; tlo[i][j] = sq8_thr_lo(a); }
+                            if (a > mx[i][j]) { mx[i][j] = a; thi[i][j] = sq8_thr_hi(a); }
+                        }
                     }
                 }
             }
@@ -1031,6 +1075,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
     for (int c = tid; c < D; c += kBlock) { atomicMin(&kmin[c], smin[c]); atomicMax(&kmax[c], smax[c]); }
 }
 
+static int g_sq8_flags = 1;    // cvtmi_set_tuning("sq8_flags"): bit 0 = wave sums on DPP instead of the ds_bpermute butterfly
+void set_sq8_flags(int v) { g_sq8_flags = v; }
 static int g_sq8_filter = 1;   // cvtmi_set_tuning("sq8_filter"): 0 = the exact chain for every element (the round 2 - 4 kernels)
 void set_sq8_filter(int v) { g_sq8_filter = v != 0; }
 constexpr int64_t SQ8_SAMPLE_ROWS = 8192;   // rows of the training pass that seeds every wave's extremes
@@ -1058,11 +1104,11 @@ int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_sc
                 const float *xr = x + ns * d;
                 const unsigned sblocks = (unsigned)((ns / 16 + rows_per_wg - 1) / rows_per_wg);   // 16 rows per wave of the sample
                 if (d == 512) {
-                    if (ns) hipLaunchKernelGGL((sq8_train_wave_f_kernel<2>), dim3(sblocks), dim3(kBlock), 0, st, x, ns, kmin, kmax, 0);
-                    hipLaunchKernelGGL((sq8_train_wave_f_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, xr, n - ns, kmin, kmax, ns ? 1 : 0);
+                    if (ns) hipLaunchKernelGGL((sq8_train_wave_f_kernel<2>), dim3(sblocks), dim3(kBlock), 0, st, x, ns, kmin, kmax, 0, g_sq8_flags);
+                    hipLaunchKernelGGL((sq8_train_wave_f_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, xr, n - ns, kmin, kmax, ns ? 1 : 0, g_sq8_flags);
                 } else {
-                    if (ns) hipLaunchKernelGGL((sq8_train_wave_f_kernel<1>), dim3(sblocks), dim3(kBlock), 0, st, x, ns, kmin, kmax, 0);
-                    hipLaunchKernelGGL((sq8_train_wave_f_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, xr, n - ns, kmin, kmax, ns ? 1 : 0);
+                    if (ns) hipLaunchKernelGGL((sq8_train_wave_f_kernel<1>), dim3(sblocks), dim3(kBlock), 0, st, x, ns, kmin, kmax, 0, g_sq8_flags);
+                    hipLaunchKernelGGL((sq8_train_wave_f_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, xr, n - ns, kmin, kmax, ns ? 1 : 0, g_sq8_flags);
                 }
             } else if (d == 512) hipLaunchKernelGGL((sq8_train_wave_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax);
             else hipLaunchKernelGGL((sq8_train_wave_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax);
@@ -1092,8 +1138,8 @@ static int launch_sq8_encode_wave(const float *vmin, const float *vdiff, int d, 
     const int64_t rows_per_wg = kBlock / 64;
     const unsigned blocks = (unsigned)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 256 * g_sq8_wave_blocks);
     if (l2norm && g_sq8_filter) {
-        if (d == 512) hipLaunchKernelGGL((sq8_encode_wave_f_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes);
-        else hipLaunchKernelGGL((sq8_encode_wave_f_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes);
+        if (d == 512) hipLaunchKernelGGL((sq8_encode_wave_f_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes, g_sq8_flags);
+        else hipLaunchKernelGGL((sq8_encode_wave_f_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes, g_sq8_flags);
         CVTMI_HIP(hipGetLastError());
         return CVTMI_OK;
     }

@@ -349,13 +349,15 @@ def test_sq8_decision_filter_equals_the_chain(amd, orc, d, kind):
         oc, ox = orc.sq8_encode(hv, hd, x, l2norm=True)
         got = {}
         try:
-            for filt in (1, 0):
-                amd.set_tuning("sq8_filter", filt)
+            for filt in (1, 2, 0):                                           # 2 = the filter kernel with the ds_bpermute butterfly for its wave sums
+                amd.set_tuning("sq8_filter", 1 if filt else 0)
+                amd.set_tuning("sq8_flags", 0 if filt == 2 else 1)
                 xt = torch.from_numpy(x.copy()).cuda()
                 codes = amd.sq8_encode(torch.from_numpy(hv).cuda(), torch.from_numpy(hd).cuda(), xt, l2norm=l2)
                 got[filt] = (codes.cpu().numpy(), xt.cpu().numpy())
         finally:
-            amd.set_tuning("sq8_filter", 1)
+            amd.set_tuning("sq8_filter", 1); amd.set_tuning("sq8_flags", 1)
+        assert np.array_equal(got[2][0], got[1][0]) and np.array_equal(bits(got[2][1]), bits(got[1][1])), "wave-sum flavours"
         fin = np.all(np.isfinite(ox), axis=1)                                # (int) NaN is undefined in the reference itself
         fin_cols = np.isfinite(hd)
         assert np.array_equal(got[1][0], got[0][0]), (kind, d, l2, "filter vs chain")
@@ -369,13 +371,14 @@ def test_sq8_decision_filter_equals_the_chain(amd, orc, d, kind):
     ovmin, ovdiff = orc.sq8_train(xf.copy(), l2norm=True)
     res = {}
     try:
-        for filt in (1, 0):
-            amd.set_tuning("sq8_filter", filt)
+        for filt in (1, 2, 0):
+            amd.set_tuning("sq8_filter", 1 if filt else 0)
+            amd.set_tuning("sq8_flags", 0 if filt == 2 else 1)
             for rows in (xf, np.tile(xf, (3, 1))):                           # 3 x: past the 8 x 8192 rows that switch the sample pass on
                 tv, td = amd.sq8_train(torch.from_numpy(rows.copy()).cuda(), l2norm=True)
                 res[(filt, len(rows))] = (tv.cpu().numpy(), td.cpu().numpy())
     finally:
-        amd.set_tuning("sq8_filter", 1)
+        amd.set_tuning("sq8_filter", 1); amd.set_tuning("sq8_flags", 1)
     for key, (tv, td) in res.items():
         assert _same_min(tv, ovmin) and np.array_equal(bits(td), bits(ovdiff)), (kind, d, key)
 
