@@ -1205,6 +1205,8 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16a_kernel(const ScanArg
 
 static int g_scan_seed = 1;
 void set_scan_seed(int v) { g_scan_seed = v != 0; }
+static int g_scan_tail_splits = 0;   // cvtmi_set_tuning("scan_tail_splits"): see plan_scan
+void set_scan_tail_splits(int v) { g_scan_tail_splits = v; }
 int scan_seed_enabled() { return g_scan_seed; }
 
 // Row ids travel as 32-bit payloads: one launch covers at most 2^32-1 rows.
@@ -1278,19 +1280,21 @@ ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int 
             if (lo > 1 && cand % 8 == 0) cost *= 0.97;
             if (cost < best_cost * 0.98) { best_cost = cost; best = cand; }
         }
-        // adc_scan16q can also run two regions: `full` whole rounds of S-split workgroups, then the remaining
-        // groups split finer (S2 > S) so that the last round is short instead of mostly idle.  Taken only when
-        // the model promises > 15 % (measured on 1 M rows: 8-14 % at nq = 4500-5000 where it promises ~20 %,
-        // nothing at nq = 6000-10000 where it promises < 10 %).
+        // adc_scan16q can also run two regions: `full` whole rounds of S-split workgroups, then the remaining groups split finer
+        // (S2 > S).  Round 5 measured what the last round really costs (tools/sweep_tail.py, 1 M rows): ONE workgroup keeps a CU's LDS
+        // pipe as busy as two do (6000 queries = 512 + 238 groups run at the per-query rate of 4096 = one exact round), so a last
+        // round is only expensive while it leaves CUs EMPTY: 101 groups past two full rounds (9000 queries) 2.89 -> 3.16 M queries/s
+        // in 2 splits (4: 3.12, 3: 3.01), 226 or 238 groups (10 000 / 6000 queries): nothing to gain (+0.6 % / -6 %).  Rule: cut the
+        // remainder into the power of two of splits that still leaves at most one workgroup per CU.
+        // cvtmi_set_tuning("scan_tail_splits"): 0 = this rule, -1 = never, S > 0 = S splits whenever there is a remainder.
         const int64_t full = groups * best / slots;  // whole rounds of region A
-        if (p.variant >= 3 && full >= 1 && groups * best % slots != 0) {
-            const int64_t ga = full * slots / best, rem = groups - ga;
-            double c_best = best_cost * 0.85;
-            for (int64_t sb = best + 1; sb <= 64 && sb <= 12 * best; ++sb) {
-                if (n_rows / sb < 16384) break;
-                const double c2 = (double)full * wg_cost(best) + rounds_of(rem * sb) * wg_cost(sb) + 20000.0;  // + merge
-                if (c2 < c_best) { c_best = c2; best_ga = ga; best_sb = sb; }
-            }
+        const int64_t rem = groups * best % slots;
+        if (p.variant >= 3 && full >= 1 && rem != 0 && best == 1 && g_scan_tail_splits >= 0) {
+            int64_t sb = 0;
+            if (g_scan_tail_splits > 0) sb = g_scan_tail_splits;
+            else if (rem * 2 <= slots / 2) { sb = 2; while (sb < 8 && rem * sb * 2 <= slots / 2) sb *= 2; }
+            while (sb > best && n_rows / sb < 16384) sb /= 2;   // at least 16 K rows per workgroup
+            if (sb > best) { best_ga = full * slots / best; best_sb = sb; }
         }
         s = (int)best;
         p.groups_a = (int)best_ga;

@@ -467,6 +467,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "sq8_filter")) { set_sq8_filter(value != 0); return CVTMI_OK; }
+    if (!strcmp(name, "scan_tail_splits")) { set_scan_tail_splits((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_flags")) { set_sq8_flags((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_wave_blocks")) {
         if (value < 1 || value > 64) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: sq8_wave_blocks must be 1..64");

@@ -206,6 +206,7 @@ void set_flat_u8_mstream_min(int v);
 void set_sq8_wave_blocks(int v);
 void set_sq8_encode_wave(int v);
 void set_sq8_filter(int v);
+void set_scan_tail_splits(int v);
 void set_sq8_flags(int v);
 size_t flat_u8_stream_scratch(int64_t n, int64_t nq, int *slices, int64_t *ld);
 int launch_flat_u8_stream(int D, const uint8_t *data, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int k, float *scratch,

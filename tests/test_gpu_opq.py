@@ -201,6 +201,39 @@ def test_search_parity_seeded(amd, orc, M, k):
         assert np.array_equal(bits(d), bits(od)), (variant, qt, splits)
 
 
+def test_search_two_region_tail(amd, orc):
+    """Round 5: when the query groups past the last full round of workgroups would leave most CUs empty, adc_scan16q cuts THOSE groups
+    into row splits (plan_scan's two-region plan: 4096 + 160 queries -> 20 groups in 4 splits here).  Same lists as whole groups and as
+    the oracle, ties across the split boundaries included."""
+    import torch
+    D, M, K, k = 128, 16, 256, 20
+    rng = np.random.default_rng(55)
+    books = synth_model(rng, D, M, K, scale=0.1)
+    n = 70_000 + 5
+    codes = rng.integers(0, K, size=(n, M), dtype=np.uint8)
+    codes[17_500:17_520] = codes[3]; codes[35_001] = codes[3]; codes[69_999] = codes[3]    # exact ties on both sides of every boundary
+    nq = 4096 + 160
+    q = (rng.normal(size=(nq, D)) * 0.1).astype(np.float32)
+    q[4100] = q[7]
+    idx = amd.OpqIndex(np.zeros((1, D), np.float32), books)
+    idx.add_codes(codes)
+    idx.set_param("scan_variant", 3)
+    qd = torch.from_numpy(q).cuda()
+    res = {}
+    try:
+        for tail in (0, -1, 2):
+            amd.set_tuning("scan_tail_splits", tail)
+            d, i = idx.search(qd, k, rotate=False)
+            res[tail] = (d.cpu().numpy(), i.cpu().numpy())
+    finally:
+        amd.set_tuning("scan_tail_splits", 0)
+    for tail in (0, 2):
+        assert np.array_equal(res[tail][1], res[-1][1]) and np.array_equal(bits(res[tail][0]), bits(res[-1][0])), tail
+    sel = np.r_[0:8, 4090:4110, nq - 8:nq]
+    od, oi = orc.adc_search(q[sel], books, codes, k)
+    assert np.array_equal(res[0][1][sel], oi) and np.array_equal(bits(res[0][0][sel]), bits(od))
+
+
 def test_search_edge_cases(amd, orc):
     D, M, K = 128, 16, 256
     rng = np.random.default_rng(2)
