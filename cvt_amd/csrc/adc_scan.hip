@@ -709,9 +709,9 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
         for (int r = 0; r < R; ++r) cur[r] = load_rows(it, r);
     }
     for (;;) {
-        uint32_t tpk[QT / 2];
+        uint32_t tpk[QT / 2], bpk[QT / 2];
 #pragma unroll
-        for (int i = 0; i < QT / 2; ++i) tpk[i] = ck.thr_pk[i];
+        for (int i = 0; i < QT / 2; ++i) { tpk[i] = ck.thr_pk[i]; bpk[i] = 0x80008000u - tpk[i]; }   // (both fields of tpk <= 0x7fff: no borrow)
         while (it < n_chunks) {
             const int stop_seen = ck.stop;  // read early, used after the chunk
             const uint32_t base = it * WROWS;
@@ -721,11 +721,14 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 // 16 look-ups, packed 15-bit sums (scan16q_row_sums; all 16 reads in flight here: this kernel has the registers)
-                uint32_t s0, s1, s2, s3;
-                scan16q_row_sums<PREROT, 16>(cur[r], moffp, cr8, cq, lut_b, s0, s1, s2, s3);
-                // sum < T for any of the 8 queries  <=>  a sign bit in the packed (sum - T)  (both < 2^15)
-                const uint32_t sg = (pk_sub_i16(s0, tpk[0]) | pk_sub_i16(s1, tpk[1]) | pk_sub_i16(s2, tpk[2]) | pk_sub_i16(s3, tpk[3])) & 0x80008000u;
+                // the sums start at 0x8000 - T per field (T <= 32767, sum <= 32766: no carry): sum < T for any of the 8 queries  <=>  a CLEAR
+                // bit 15 in one of the eight fields  <=>  the AND of the four words lacks a bit of 0x80008000 -- three ANDs, one AND with
+                // the mask and a compare instead of four packed subtractions, three ORs, the mask and the compare (round 5)
+                uint32_t s0 = bpk[0], s1 = bpk[1], s2 = bpk[2], s3 = bpk[3];
+                scan16q_row_sums<PREROT, 16, true>(cur[r], moffp, cr8, cq, lut_b, s0, s1, s2, s3);
+                const uint32_t sg = (~((s0 & s1) & (s2 & s3))) & 0x80008000u;
                 if (__ballot(sg != 0)) {  // rare once the threshold has tightened
+                    s0 -= bpk[0]; s1 -= bpk[1]; s2 -= bpk[2]; s3 -= bpk[3];   // the plain sums (field-wise: no borrow, each field >= its bias)
                     if (done_for != it) { done = 0; done_for = it; }  // (the bits belong to one chunk; only this path sets or reads them)
                     bool failed = false;
                     uint32_t lrow = base + r * 64 + lane;

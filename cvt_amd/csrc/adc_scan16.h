@@ -241,7 +241,9 @@ __device__ __attribute__((noinline)) int scan_compact_lazy_q(TopKShared<QT, CAP>
 // halves, so they are accumulated with plain 32-bit adds, two look-ups per v_add3_u32 (half the VALU of v_pk_add_u16).  Integer
 // sums, any order.  NG look-ups are in flight at a time: 16 in adc_scan16q; adc_scan16a takes groups of four -- there the scheduler
 // would otherwise form all 16 addresses first, more registers than its waves have left.
-template <bool PREROT, int NG = 4>
+// BIASED: the sums start from s0 .. s3 as passed in instead of zero (adc_scan16q: 0x8000 - T per 16-bit field, so that "sum < T" is a
+// CLEAR bit 15 and the test of a row is an AND over the four words instead of four packed subtractions; sum + 0x8000 - T < 2^16: still no carry)
+template <bool PREROT, int NG = 4, bool BIASED = false>
 __device__ __forceinline__ void scan16q_row_sums(const uint4 &row, const uint32_t (&moffp)[4], uint32_t cr8, uint32_t cq, const char *lut_b,
                                                  uint32_t &s0, uint32_t &s1, uint32_t &s2, uint32_t &s3)
 {
@@ -257,7 +259,7 @@ __device__ __forceinline__ void scan16q_row_sums(const uint4 &row, const uint32_
         d0 = b1 ? e2 : e0; d1 = b1 ? e3 : e1; d2 = b1 ? e0 : e2; d3 = b1 ? e1 : e3;
     }
     const uint32_t rot[4] = { d0, d1, d2, d3 };
-    s0 = 0; s1 = 0; s2 = 0; s3 = 0;
+    if constexpr (!BIASED) { s0 = 0; s1 = 0; s2 = 0; s3 = 0; }
 #pragma unroll
     for (int h = 0; h < 16 / NG; ++h) {
         uint4 v[NG];
