@@ -97,6 +97,15 @@ int cvtmi_set_device(int device);
  *                     L2 / Infinity Cache): 0 = never, 1 = choose (default: everywhere except three query blocks per wave), 2 = always
  *   "scan_seed"       1 (default) = scan variants 3 / 4 / 5 take their first filter thresholds from a histogram of the first 2048 rows of
  *                     a row split instead of starting with "every row passes" (1-4 % on 1 M rows, more on short splits); 0 = off
+ *   "scan_tail_splits" adc_scan16q, query groups past the last full round of workgroups: 0 (default) = cut them into 2 / 4 / 8 row
+ *                     splits while that still leaves at most one workgroup per CU (a last round is only expensive while it leaves CUs
+ *                     empty: 4256 queries over 1 M rows 2.11 -> 2.79 M queries/s, 10 000 queries unchanged); -1 = never; S > 0 = S splits
+ *   "sq8_filter"      1 (default) = the wave-per-row SQ8 kernels (d = 256 / 512) decide code bytes / column extremes from a bounded
+ *                     approximation and run the reference's chain (two correctly rounded divisions + the byte) only where it cannot
+ *                     decide; 0 = the chain for every element.  Same codes, rows and ranges, bit for bit
+ *   "sq8_flags"       bit 0 (default set) = the row-norm sums of those kernels run on DPP moves instead of the ds_bpermute butterfly
+ *   "hnsw_adc_tables" HNSW over OPQ codes: 0 (default) = a query's fp32 distance tables are read from the table scratch (L2 / Infinity
+ *                     Cache), 32 traversals per CU; 1 = copied into LDS first (16 KB per query: 8 traversals per CU, round 2 - 4)
  *   "comm_force_rccl" 1 = cvtmi_comm_create goes through RCCL (ncclCommInitRank, ncclAllGather) for world == 1 too, which
  *                     otherwise needs no transport (test hook for 1-GPU boxes) */
 int cvtmi_set_tuning(const char *name, int64_t value);
