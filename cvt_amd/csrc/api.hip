@@ -333,6 +333,7 @@ static bool host_pinned(const void *p)
     return at.type == hipMemoryTypeHost;
 }
 
+static std::atomic<int> g_hnsw_slots_cap{0};   // cvtmi_set_tuning("hnsw_slots"): cap on traversals per CU (0 = what LDS allows, at most 32)
 static std::atomic<int> g_small_zero_copy{1};   // cvtmi_set_tuning("opq_small_zero_copy"): 1 .. 8-query host-pointer searches read / write the pinned staging area from the kernels
 static std::atomic<int> g_host_chunks{4096};  // cvtmi_set_tuning("opq_host_chunk"): queries per piece of a pipelined host-pointer OPQ batch (0 = one piece)
 static std::atomic<int> g_scanh_key{0};  // bumped when a planner setting of adc_scan16h changes: cached item tables are rebuilt
@@ -464,6 +465,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "host_spin_us")) { g_host_spin_us = value < 0 ? 0 : (int)value; return CVTMI_OK; }
     if (!strcmp(name, "hnsw_top_lds")) { set_hnsw_top_lds((int)value); return CVTMI_OK; }
     if (!strcmp(name, "hnsw_adc_tables")) { set_hnsw_adc_tables((int)value); return CVTMI_OK; }
+    if (!strcmp(name, "hnsw_slots")) { g_hnsw_slots_cap = (int)value; return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "sq8_filter")) { set_sq8_filter(value != 0); return CVTMI_OK; }
@@ -2383,6 +2385,9 @@ static int hnsw_plan(cvtmi_hnsw_t h, HnswScratch &S, int lds_dim, int64_t nq, in
     const int efe = ef > k ? ef : k;
     int per_cu = (159 * 1024) / hnsw_lds_bytes(lds_dim, efe);  // query slots (one wave each) a CU's 160 KB of LDS hold
     per_cu = per_cu > 32 ? 32 : (per_cu < 1 ? 1 : per_cu);
+    if (const int cap = g_hnsw_slots_cap.load(); cap > 0 && per_cu > cap) per_cu = cap;   // cvtmi_set_tuning("hnsw_slots"): measurement hook
+    // (filling the rounds of a batch evenly with fewer slots per CU was measured: no effect -- throughput grows with the traversals in
+    //  flight all the way to 32 per CU: 12 / 16 / 20 / 24 / 28 / 32 slots -> 144 / 164 / 178 / 184 / 192 / 201 K queries/s over codes at ef = 1000)
     pl.slots = h->cus * per_cu;
     if (pl.slots > nq) pl.slots = (int)nq;
     pl.words = (h->g.n + 31) / 32 + 1;
