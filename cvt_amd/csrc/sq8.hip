@@ -1081,6 +1081,53 @@ static int g_sq8_filter = 1;   // cvtmi_set_tuning("sq8_filter"): 0 = the exact 
 void set_sq8_filter(int v) { g_sq8_filter = v != 0; }
 constexpr int64_t SQ8_SAMPLE_ROWS = 8192;   // rows of the training pass that seeds every wave's extremes
 
+// ---- the sign of a zero minimum (round 5) ----------------------------------------------------------------------------------
+// The training reduction keeps column minima as ordered integer keys, where -0.0 sorts below +0.0; the loop it restates (faiss
+// train_NonUniform, RS_minmax: strict '<' in row order, sq_train.cpp:100) keeps the FIRST zero it meets when the minimum is zero.
+// Equal as numbers, identical codes -- but not the same bits when a column holds zeros of both signs.  So: a column whose key says
+// "-0.0" (the only case in which the two can differ: some zero there is negative) is scanned for the first row whose normalised value
+// is a zero, and takes that zero's sign (= the sign of the raw value: the norm is positive).  Rows are normalised exactly as the
+// reference does (index-order double sum), because a quotient can also be a zero through underflow or an infinite norm.  The kernels
+// leave at once unless such a column exists -- three tiny launches per training call otherwise.
+__global__ __launch_bounds__(kBlock) void sq8_zero_first_kernel(const float *__restrict__ x, int64_t n, int d, int l2norm,
+                                                                const float *__restrict__ vmin, uint32_t *__restrict__ first)
+{
+    __shared__ int any_s;
+    if (threadIdx.x == 0) any_s = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int c = threadIdx.x; c < d; c += kBlock) mine |= __float_as_uint(vmin[c]) == 0x80000000u;
+    if (mine) any_s = 1;
+    __syncthreads();
+    if (!any_s) return;   // the common case
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        const float *row = x + r * d;
+        float den = 1.0f;
+        if (l2norm) {   // int8_quan.cc:46-56, in its own order
+            double accum = 0.0;
+            for (int e = 0; e < d; ++e) {
+                const float t = row[e];
+                accum += (double)__fmul_rn(t, t);
+            }
+            const double nrm = __dsqrt_rn(accum);
+            den = (float)(nrm > 1e-12 ? nrm : 1e-12);
+        }
+        for (int c = 0; c < d; ++c) {
+            if (__float_as_uint(vmin[c]) != 0x80000000u) continue;
+            const float a = l2norm ? __fdiv_rn(row[c], den) : row[c];
+            if (a == 0.0f) atomicMin(&first[c], (uint32_t)r);
+        }
+    }
+}
+__global__ __launch_bounds__(kBlock) void sq8_zero_sign_kernel(const float *__restrict__ x, int d, const uint32_t *__restrict__ first,
+                                                               float *__restrict__ vmin)
+{
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= d || __float_as_uint(vmin[c]) != 0x80000000u || first[c] == 0xffffffffu) return;
+    const float v = x[(int64_t)first[c] * d + c];
+    vmin[c] = (__float_as_uint(v) >> 31) ? -0.0f : 0.0f;
+}
+
 // workgroups per CU of the wave-per-row training kernel.  A wave keeps RB rows in flight that lie (waves in the grid) rows apart: with a
 // power-of-two grid those streams are a power-of-two distance apart and fall on the same HBM channels -- measured on 2 M x 512-d:
 // 8 per CU 4.62-4.67 TB/s, 4: 4.38, 16: 4.89, 3: 5.04, 24: 5.09 (tools: cvtmi_set_tuning("sq8_wave_blocks"))
@@ -1128,6 +1175,12 @@ int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_sc
         }
     }
     hipLaunchKernelGGL(sq8_train_finish_kernel, dim3(db), dim3(kBlock), 0, st, kmin, kmax, d, vmin, vdiff);
+    if (n > 0 && n < 0xffffffffLL) {   // the sign of a zero minimum (see sq8_zero_first_kernel); kmax is free again: first[d]
+        CVTMI_HIP(hipMemsetAsync(kmax, 0xff, (size_t)d * sizeof(uint32_t), st));
+        const unsigned zb = (unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 1024);
+        hipLaunchKernelGGL(sq8_zero_first_kernel, dim3(zb), dim3(kBlock), 0, st, x, n, d, l2norm, vmin, kmax);
+        hipLaunchKernelGGL(sq8_zero_sign_kernel, dim3(db), dim3(kBlock), 0, st, x, d, kmax, vmin);
+    }
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

@@ -308,18 +308,49 @@ def test_sq8_normalisation_golden(amd, golden, group):
         for rows in (x[ok], np.tile(x[ok], (-(-4200 // int(ok.sum())), 1))):
             tv, td = amd.sq8_train(torch.from_numpy(rows.copy()).cuda(), l2norm=True)
             tv, td = tv.cpu().numpy(), td.cpu().numpy()
-            # a column whose minimum is zero and that holds zeros of BOTH signs: the sequential loop keeps the first it meets, the
-            # device reduction the negative one (v_min_f32) -- equal as numbers, same codes (x - (+-0) and the clamp see no sign); every
-            # other entry is compared bit for bit
-            zero = (w.min(axis=0) == 0)
-            assert np.array_equal(tv, w.min(axis=0)) and np.array_equal(bits(tv)[~zero], bits(w.min(axis=0))[~zero])
+            # (a column whose minimum is zero and that holds zeros of both signs takes the sign of the FIRST zero in row order, as the
+            # sequential loop does: test_sq8_train_sign_of_a_zero_minimum)
+            first = np.array([w[np.argmax(w[:, c] == w[:, c].min()), c] for c in range(w.shape[1])], np.float32)   # first occurrence of the minimum
+            assert np.array_equal(bits(tv), bits(first))
             assert np.array_equal(bits(td), bits(w.max(axis=0) - w.min(axis=0)))
 
 
 def _same_min(a, b):
-    """column minima: equal as numbers, and bit for bit except for the sign of a zero (see test_sq8_normalisation_golden)"""
-    nz = (b != 0)
-    return np.array_equal(a, b) and np.array_equal(bits(a)[nz], bits(b)[nz])
+    """column minima, bit for bit -- the sign of a zero minimum included (test_sq8_train_sign_of_a_zero_minimum)"""
+    return np.array_equal(bits(a), bits(b))
+
+
+@pytest.mark.parametrize("d,n", [(512, 9000), (256, 70_000), (64, 500), (300, 2000), (12, 64)])
+@pytest.mark.parametrize("l2", [True, False])
+def test_sq8_train_sign_of_a_zero_minimum(amd, orc, d, n, l2):
+    """A column whose minimum is zero and that holds zeros of both signs: the loop this restates (faiss train_NonUniform, RS_minmax:
+    strict '<' in row order behind sq_train.cpp:100) keeps the FIRST zero it meets; the device reduction orders -0.0 below +0.0.  The
+    training call therefore looks such columns up again (sq8_zero_first_kernel).  Every kernel family (wave-per-row with sample pass,
+    tile, two-pass) and both first-zero signs, zeros that only appear through an infinite norm, and columns without any zero."""
+    import torch
+    rng = np.random.default_rng(d + n + int(l2))
+    x = np.abs(rng.normal(size=(n, d))).astype(np.float32)          # non-negative: the minimum of a column with a zero IS zero
+    z = rng.random(size=(n, d)) < 0.05
+    x[z] = 0.0
+    x[z & (rng.random(size=(n, d)) < 0.5)] = -0.0
+    x[:, 0] = np.abs(x[:, 0]) + 0.1                                 # no zero at all
+    x[:, 1] = 1.0; x[n // 2, 1] = -0.0; x[n // 2 + 1, 1] = 0.0      # first zero negative
+    x[:, 2] = 1.0; x[n // 3, 2] = 0.0; x[n // 3 + 5, 2] = -0.0      # first zero positive, a negative one later
+    x[:, 3] = 1.0; x[n - 1, 3] = -0.0                               # a single negative zero, in the last row
+    if l2:
+        x[7] = np.float32(1e30) * np.sign(rng.normal(size=d)).astype(np.float32)   # norm overflows to inf: every quotient of the row is a signed zero
+        x[:7, 4] = 1.0; x[8:, 4] = 1.0                              # column 4's only zero is that row's
+    ovm, ovd = orc.sq8_train(x.copy(), l2norm=l2)
+    for filt in (1, 0):
+        amd.set_tuning("sq8_filter", filt)
+        try:
+            tv, td = amd.sq8_train(torch.from_numpy(x.copy()).cuda(), l2norm=l2)
+        finally:
+            amd.set_tuning("sq8_filter", 1)
+        assert np.array_equal(bits(tv.cpu().numpy()), bits(ovm)), (filt, np.flatnonzero(bits(tv.cpu().numpy()) != bits(ovm))[:8])
+        assert np.array_equal(bits(td.cpu().numpy()), bits(ovd))
+    hv, hd = amd.sq8_train(x.copy(), l2norm=l2)                     # host-pointer entry
+    assert np.array_equal(bits(hv), bits(ovm)) and np.array_equal(bits(hd), bits(ovd))
 
 
 @pytest.mark.parametrize("d", [512, 256])

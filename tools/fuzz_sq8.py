@@ -58,8 +58,7 @@ for it in range(iters):
     tv, td = cvt_amd.sq8_train(torch.from_numpy(xf.copy()).cuda(), l2norm=True)
     ovm, ovd = orc.sq8_train(xf.copy(), l2norm=True)
     tv, td = tv.cpu().numpy(), td.cpu().numpy()
-    nz = ovm != 0
-    ok_t = np.array_equal(tv, ovm) and np.array_equal(bits(tv)[nz], bits(ovm)[nz]) and np.array_equal(bits(td), bits(ovd))
+    ok_t = np.array_equal(bits(tv), bits(ovm)) and np.array_equal(bits(td), bits(ovd))
     if not (ok and ok_t):
         bad = np.argwhere(codes[fin][:, finc] != oc[fin][:, finc])[:5]
         print("MISMATCH", dict(it=it, seed=seed, d=d, n=n, fam=fam, l2=l2, encode_ok=bool(ok), train_ok=bool(ok_t), first_bad=bad.tolist())); sys.exit(1)
