@@ -83,6 +83,9 @@ def parse_args():
                     help="host (alias gloo) = debug: several ranks on ONE GPU, exchange staged through the host")
     ap.add_argument("--comm-timeout", type=float, default=180.0,
                     help="seconds the RCCL communicator creation may take before the ranks fall back to the host transport")
+    ap.add_argument("--n1-point", type=int, default=1,
+                    help="N > 1: rank 0 also runs the SAME workload alone on its GPU afterwards (all rows, same queries, no collective) -> "
+                         "'same_workload_on_one_gpu' and 'speedup_over_one_gpu' in the line (0 = skip)")
     ap.add_argument("--oracle-queries", type=int, default=8,
                     help="N > 1: queries every rank scans over its own shard with the CPU oracle (identity check + cpu_baseline; 0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="queries timed on the CPU baseline (0 = skip)")
@@ -136,6 +139,7 @@ class Ctx:
         self.R = synth.random_rotation(D, seed=7)
         self.books = None
         self.nn = None
+        self.last_out = None
 
     def barrier(self):
         self.rv.barrier()
@@ -366,6 +370,7 @@ def run_sift1b(ctx, q, steps, warmup):
     ctx.barrier(); big.last_scan()
     c0 = ctx.comm.info() if ctx.comm is not None else None
     el, out = ctx.timed(lambda: fn(ql), steps, 0)
+    ctx.last_out = out   # (headline_multi compares the sharded answer with the same workload on ONE GPU)
     sc = big.last_scan()
     res = {"value": round(ql.shape[0] * steps / el, 1), "unit": "queries/s", "ms_per_step": round(el / steps * 1e3, 4),
            "steps": steps, "rows_total": args.large_rows, "rows_per_gpu": l1 - l0, "nq": int(ql.shape[0]), "k": ctx.k,
@@ -533,6 +538,42 @@ def headline_multi(ctx, q):
                 "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
                 "scaling": "strong", "error": res["error"]} if ctx.rank == 0 else None
     extra = {}
+    # The N = 1 point of THIS curve, measured in THIS run: rank 0 alone, every row on its one GPU, the same queries, no collective --
+    # so the line carries its own speed-up (the N = 1 line's headline is BASELINE configs[1], another workload).  The others wait.
+    if args.n1_point:
+        one = None
+        if ctx.rank == 0:
+            try:
+                free_b, _ = ctx.torch.cuda.mem_get_info(ctx.dev)
+                if free_b > args.large_rows * M * 2.3 + (3 << 30):
+                    t0 = time.perf_counter()
+                    solo, _, _ = ctx.build_index(0, args.large_rows, data=args.large_data, seed=0xC0FFEE)
+                    ctx.torch.cuda.synchronize(); t_build = time.perf_counter() - t0
+                    ql = q[:res["nq"]].contiguous()
+                    reps = max(1, min(args.steps, 2))
+                    solo.search(ql, k, rotate=True); ctx.torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        d1, i1 = solo.search(ql, k, rotate=True)
+                    ctx.torch.cuda.synchronize()
+                    el1 = (time.perf_counter() - t0) / reps
+                    ds, is_ = ctx.last_out
+                    one = {"value": round(res["nq"] / el1, 1), "unit": "queries/s", "ms_per_step": round(el1 * 1e3, 3), "steps": reps,
+                           "index_build_s": round(t_build, 2),
+                           "sharded_result_identical": bool(ctx.torch.equal(i1, is_) and
+                                                            ctx.torch.equal(d1.view(ctx.torch.int32), ds.view(ctx.torch.int32))),
+                           "what": "rank 0 alone: all %d rows on one GPU, the same %d queries, cvtmi_opq_search_dev (no communicator)" % (
+                               args.large_rows, res["nq"])}
+                    solo.close()
+                else:
+                    one = {"error": "not enough free HBM on rank 0 for all %d rows" % args.large_rows}
+            except Exception as e:   # the sharded measurement above must survive this side leg
+                one = {"error": "%s: %s" % (type(e).__name__, e)}
+        ctx.rv.barrier()
+        if ctx.rank == 0 and one is not None:
+            extra["same_workload_on_one_gpu"] = one
+            if "value" in one:
+                extra["speedup_over_one_gpu"] = round(res["value"] / one["value"], 3)
     # the small database on N GPUs, for the record: row-sharded through the same library path, and as N replicas
     r0, r1 = cvt.shard_range(args.rows, ctx.rank, world)
     shard, _, _ = ctx.build_index(r0, r1)

@@ -319,6 +319,8 @@ def _check_evidence(line):
     assert cb["kind"] == "port" and cb["cores"] == 2 and cb["value"] > 0
     assert "roofline" in line and line["roofline"]["bound"] == "lds"
     assert line["sift1b"]["comm"]["world"] == 2
+    one = line["same_workload_on_one_gpu"]      # the N = 1 point of the same workload, measured in the same run by rank 0 alone
+    assert one["value"] > 0 and one["sharded_result_identical"] and line["speedup_over_one_gpu"] > 0
 
 
 def test_bench_gpus2_self_launch_host_transport():
