@@ -95,8 +95,8 @@ def parse_args():
     ap.add_argument("--ref-rows", type=int, default=200_000, help="rows of the index the reference itself builds for cpu_baseline (0 = skip)")
     ap.add_argument("--ref-queries", type=int, default=64)
     ap.add_argument("--hnsw-nodes", type=int, default=1_000_000, help="nodes of the config-5 graph (secondary.hnsw_c5)")
-    ap.add_argument("--only", default="", help="development: comma list of secondary sections to run (rotation_encode, sq8, flat_f32, "
-                                               "flat_u8_c3, ivf_query, hnsw_c5); default all")
+    ap.add_argument("--only", default="", help="development: comma list of secondary sections to run (rotation_encode, opq_rotation_learning, "
+                                               "sq8, flat_f32, flat_u8_c3, ivf_query, hnsw_c5); default all")
     ap.add_argument("--host-api", type=int, default=1, help="0 = skip the host-pointer leg (its 4096-query pieces are scan launches too)")
     ap.add_argument("--tune", default="", help="development: cvtmi_set_tuning pairs, name=value,name=value")
     ap.add_argument("--secondary", type=int, default=1,
@@ -140,6 +140,7 @@ class Ctx:
         self.books = None
         self.nn = None
         self.last_out = None
+        self.exact_nn = None
 
     def barrier(self):
         self.rv.barrier()
@@ -640,6 +641,7 @@ def recall_at_1(ctx, q, i_gpu, result):
         m, j = torch.cdist(qs, x).min(dim=1)
         upd = m < best
         best = torch.where(upd, m, best); arg = torch.where(upd, j + a, arg)
+    ctx.exact_nn = arg   # (secondary.opq_rotation_learning measures the same recall under a learned rotation)
     result["recall_at_1"] = round(float((i_gpu[:ns, 0] == arg).float().mean().item()), 4)
     result["recall_at_1_what"] = "ADC top-1 == exact fp32 L2 nearest neighbour, first %d queries" % ns
 
@@ -827,7 +829,8 @@ def secondary(ctx):
     if not only or "rotation_encode" in only:
         sec.update(_sec_rotation_encode(ctx))
     vmin, vdiff = _sec_sq8(ctx, sec) if (not only or "sq8" in only or "flat_u8_c3" in only) else (None, None)
-    for name, fn in (("flat_f32", lambda: _sec_flat_f32(ctx)), ("flat_u8_c3", lambda: _sec_flat_u8_c3(ctx, vmin,
+    for name, fn in (("opq_rotation_learning", lambda: _sec_rotation_learning(ctx)),
+                     ("flat_f32", lambda: _sec_flat_f32(ctx)), ("flat_u8_c3", lambda: _sec_flat_u8_c3(ctx, vmin,
                                                                                                       vdiff)),
                      ("ivf_query", lambda: _ivf_query(ctx)), ("hnsw_c5", lambda: _hnsw_c5(ctx))):
         if only and name not in only:
@@ -871,6 +874,51 @@ def _sec_rotation_encode(ctx):
                                      "kernel, the rows are read through the permutation"}
     ixp.close(); ix.close()
     return sec
+
+
+def _sec_rotation_learning(ctx):
+    """f-3 (optional): the dense rotation LEARNED (cvtmi_opq_learn_rotation: k-means / orthogonal Procrustes alternation) instead of
+    drawn at random as in the headline -- what it costs, and what it buys at the same 16 bytes per row"""
+    torch, cvt, synth, args = ctx.torch, ctx.cvt, ctx.synth, ctx.args
+    M, k, ns = ctx.M, ctx.k, min(1000, ctx.nq)
+    sample = synth.sift_like(100_000, D, seed=0xC0FFEE, device=ctx.dev)
+    res = {"sample_rows": 100_000, "outer_iterations": 8, "kmeans_iterations": 4,
+           "what": "R, books = cvtmi_opq_learn_rotation(sample): X R^T on the fp32 MFMA GEMM, per-sub-space Lloyd iterations, X^T Y in double, "
+                   "R = V U^T by Jacobi on the host; then the %d rows re-encoded and the first %d queries searched, recall@1 = ADC top-1 == exact "
+                   "fp32 neighbour -- next to the same under the identity (plain PQ) and under the headline's random rotation" % (args.rows, ns)}
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    R, books = cvt.opq_learn_rotation(sample, M, K, 8, 4, 1234)
+    torch.cuda.synchronize(); res["learn_s"] = round(time.perf_counter() - t0, 3)
+    Rn = R.cpu().numpy()
+    res["orthonormality_error"] = float(np.abs(Rn.astype(np.float64) @ Rn.astype(np.float64).T - np.eye(D)).max())
+    q = synth.sift_like(ns, D, seed=0xBEEF, device=ctx.dev)
+
+    def evaluate(Rm, bk):
+        ix = cvt.OpqIndex(ctx.zero_coarse, bk, R=Rm)
+        ix.reserve(args.rows)
+        err, step = 0.0, synth.CHUNK * 4
+        for a in range(0, args.rows, step):
+            b = min(args.rows, a + step)
+            x = synth.sift_like(b - a, D, seed=0xC0FFEE, row_begin=a, device=ctx.dev)
+            xr = ix.rotate(x)
+            _, codes = ix.encode(xr)
+            ix.add_codes(codes)
+            if a == 0:   # quantisation error on the first chunk
+                bt = torch.from_numpy(bk).to(ctx.dev)
+                y = torch.cat([bt[m][codes[:, m].long()] for m in range(M)], dim=1)
+                err = float(((xr - y) ** 2).sum(dim=1).mean().item())
+        _, i = ix.search(q, k, rotate=True)
+        ix.close()
+        out = {"mean_squared_quantisation_error": round(err, 6)}
+        if ctx.exact_nn is not None and ctx.exact_nn.shape[0] >= ns:
+            out["recall_at_1"] = round(float((i[:, 0] == ctx.exact_nn[:ns]).float().mean().item()), 4)
+            out["recall_at_%d" % k] = round(float((i == ctx.exact_nn[:ns, None]).any(dim=1).float().mean().item()), 4)
+        return out
+    res["learned"] = evaluate(Rn, books.cpu().numpy())
+    _, b_id = cvt.opq_learn_rotation(sample, M, K, 0, 4, 1234)
+    res["identity"] = evaluate(np.eye(D, dtype=np.float32), b_id.cpu().numpy())
+    res["random_rotation_of_the_headline"] = evaluate(ctx.R, ctx.books)
+    return res
 
 
 def _sec_sq8(ctx, sec):

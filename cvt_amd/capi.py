@@ -689,6 +689,23 @@ def opq_train(x, coarseK, M, K, niter=0, seed=1):
     return coarse, books
 
 
+def opq_learn_rotation(x, M, K, outer, niter=0, seed=1):
+    """cvtmi_opq_learn_rotation: (R [D][D], books [M][K][D/M]) learned from the rows x (numpy -> numpy, torch CUDA -> torch)"""
+    n, D = x.shape
+    if _is_torch(x):
+        import torch
+        R = torch.empty((D, D), dtype=torch.float32, device=x.device)
+        books = torch.empty((M, K, D // M), dtype=torch.float32, device=x.device)
+        _check(lib().cvtmi_opq_learn_rotation_dev(_ptr(x), C.c_int64(n), C.c_int(D), C.c_int(M), C.c_int(K), C.c_int(outer), C.c_int(niter),
+                                                  C.c_uint64(seed), _ptr(R), _ptr(books), _stream()))
+        return R, books
+    x = _np(x, np.float32)
+    R = np.empty((D, D), dtype=np.float32); books = np.empty((M, K, D // M), dtype=np.float32)
+    _check(lib().cvtmi_opq_learn_rotation(_ptr(x), C.c_int64(n), C.c_int(D), C.c_int(M), C.c_int(K), C.c_int(outer), C.c_int(niter),
+                                          C.c_uint64(seed), _ptr(R), _ptr(books)))
+    return R, books
+
+
 def sq8_train(x, l2norm=True):
     n, d = x.shape
     if _is_torch(x):

@@ -424,6 +424,18 @@ int cvtmi_opq_train(const float *x, int64_t n, int D, int coarseK, int M, int K,
                     float *coarse, float *books);
 int cvtmi_opq_train_dev(const float *x, int64_t n, int D, int coarseK, int M, int K, int niter, uint64_t seed,
                         float *coarse, float *books, void *stream);
+/* OPQ rotation learning (optional): the dense D x D rotation the a-R GEMM applies, learned from a sample instead of
+ * handed in.  NOT in the reference (opq/ only permutes dimensions, reorder_ IVFOPQ.cpp:424-439, and reads the permutation from a
+ * file): self-specified, held bit for bit to the oracle's orc_opq_learn_rotation.  Non-parametric alternation (Ge et al. 2013):
+ * R = I; `outer` times { Xr = X R^T (the fp32 MFMA GEMM); per sub-space k-means of Xr (cvtmi_kmeans: K centroids, niter, seed);
+ * Y = the rows' reconstructions; C = X^T Y in double (rows in blocks of 1024, ascending); R = V U^T for C = U S V^T (orthogonal
+ * Procrustes, one-sided Jacobi on the host) }; books = the k-means of the final Xr.  outer = 0 returns the identity and plain PQ
+ * codebooks.  R [D][D] row-major and books [M][K][D/M] feed cvtmi_opq_create (coarseK = 1, a zero centroid: the exhaustive
+ * configuration).  D in {32, 64, 96, 128}. */
+int cvtmi_opq_learn_rotation(const float *x, int64_t n, int D, int M, int K, int outer, int niter, uint64_t seed, float *R,
+                             float *books);
+int cvtmi_opq_learn_rotation_dev(const float *x, int64_t n, int D, int M, int K, int outer, int niter, uint64_t seed, float *R,
+                                 float *books, void *stream);
 
 /* ---------------------------------------------------------------- HNSW search ---------------- */
 /* hnswlib::HierarchicalNSW<float> (hnsw_sifts_retrieval/hnswlib/hnswalg.h), search side.

@@ -225,6 +225,27 @@ class Oracle:
         assert rc == 0
         return coarse, books
 
+    def xty(self, x, y):
+        x = _f32(x); y = _f32(y); n, D = x.shape
+        C_ = np.empty((D, D), np.float64)
+        self.lib.orc_xty(_p(x, C.c_float), _p(y, C.c_float), C.c_int64(n), C.c_int(D), _p(C_, C.c_double))
+        return C_
+
+    def procrustes(self, Cm):
+        Cm = np.ascontiguousarray(Cm, dtype=np.float64); D = Cm.shape[0]
+        R = np.zeros((D, D), np.float32)
+        rc = self.lib.orc_procrustes(_p(Cm, C.c_double), C.c_int(D), _p(R, C.c_float))
+        return rc, R
+
+    def opq_learn_rotation(self, x, M, K, outer, niter=0, seed=1):
+        """(R [D][D], books [M][K][D/M]) -- the specification of cvtmi_opq_learn_rotation (not in the reference)"""
+        x = _f32(x); n, D = x.shape
+        R = np.empty((D, D), np.float32); books = np.empty((M, K, D // M), np.float32)
+        rc = self.lib.orc_opq_learn_rotation(_p(x, C.c_float), C.c_int64(n), C.c_int(D), C.c_int(M), C.c_int(K), C.c_int(outer),
+                                             C.c_int(niter), C.c_uint64(seed), _p(R, C.c_float), _p(books, C.c_float))
+        assert rc == 0
+        return R, books
+
     def hnsw_search(self, index_bytes, metric, D, queries, k, ef):
         """searchKnn over a graph file written by the reference's saveIndex; ascending (dist, label)."""
         buf = np.frombuffer(index_bytes, dtype=np.uint8)

@@ -650,6 +650,163 @@ ORC_API int orc_opq_train(const float *x, int64_t n, int D, int coarseK, int M, 
 }
 
 /* ------------------------------------------------------------------------------------------
+ * OPQ rotation learning ("optional").  NOT in the reference: opq/ only ever permutes
+ * dimensions (reorder_, IVFOPQ.cpp:424-439) and takes that permutation from a file.  What is specified
+ * here is the non-parametric alternation of Ge et al. ("Optimized Product Quantization", 2013) over
+ * pieces that exist on the path already -- the dense rotation (orc_rotate_fma), the fully specified
+ * Lloyd iteration (orc_kmeans) -- plus an orthogonal Procrustes step:
+ *     R = I;  repeat `outer` times:
+ *         Xr = X R^T;  per sub-space m: (books[m], assign[m]) = kmeans(Xr[:, m], K, niter, seed)
+ *         Y[r] = the concatenation of books[m][assign[m][r]]            (the rows' reconstructions)
+ *         C = X^T Y  in double, rows in blocks of 1024: inside a block ascending, then the blocks
+ *             ascending (the order the device kernel can reproduce: one workgroup per block)
+ *         C = U S V^T (one-sided Jacobi, double);  R = V U^T            (argmin_R |X R^T - Y|_F, R orthogonal)
+ *     books = kmeans of the final Xr = X R^T.
+ * A Procrustes step that meets a rank-deficient C keeps the previous R.  Self-specified: the GPU path
+ * (cvtmi_opq_learn_rotation) is held to it bit for bit.
+ * ---------------------------------------------------------------------------------------- */
+#define ORC_XTY_BLOCK 1024
+ORC_API void orc_xty(const float *x, const float *y, int64_t n, int D, double *C /* [D][D] */)
+{
+    double *part = (double *)malloc(sizeof(double) * (size_t)D * D);
+    for (int i = 0; i < D * D; ++i) C[i] = 0.0;
+    for (int64_t b0 = 0; b0 < n; b0 += ORC_XTY_BLOCK) {
+        const int64_t b1 = b0 + ORC_XTY_BLOCK < n ? b0 + ORC_XTY_BLOCK : n;
+        for (int i = 0; i < D * D; ++i) part[i] = 0.0;
+        for (int64_t r = b0; r < b1; ++r)
+            for (int i = 0; i < D; ++i) {
+                const double xi = (double)x[r * D + i];
+                for (int j = 0; j < D; ++j) part[i * D + j] += xi * (double)y[r * D + j];   /* the product of two floats is exact in double */
+            }
+        for (int i = 0; i < D * D; ++i) C[i] += part[i];
+    }
+    free(part);
+}
+
+/* R = V U^T for C = U S V^T.  One-sided Jacobi on the columns of A = C (cyclic sweeps over the pairs p < q, a pair is rotated
+ * when |a_p . a_q| > 1e-15 sqrt(|a_p|^2 |a_q|^2); at most 60 sweeps), V accumulates the rotations, U = the normalised columns.
+ * Returns 1 (R untouched) when C is zero or holds a value that is not finite. */
+ORC_API int orc_procrustes(const double *C, int D, float *R)
+{
+    double *A = (double *)malloc(sizeof(double) * (size_t)D * D), *V = (double *)malloc(sizeof(double) * (size_t)D * D);
+    int rc = 0;
+    for (int i = 0; i < D * D; ++i) { A[i] = C[i]; if (!(C[i] == C[i]) || C[i] - C[i] != 0.0) rc = 1; }
+    for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) V[i * D + j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60 && rc == 0; ++sweep) {
+        int rotated = 0;
+        for (int p = 0; p < D - 1; ++p)
+            for (int q = p + 1; q < D; ++q) {
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                for (int i = 0; i < D; ++i) {
+                    const double ap = A[i * D + p], aq = A[i * D + q];
+                    alpha += ap * ap; beta += aq * aq; gamma += ap * aq;
+                }
+                if (!(fabs(gamma) > 1e-15 * sqrt(alpha * beta))) continue;
+                rotated = 1;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int i = 0; i < D; ++i) {
+                    const double ap = A[i * D + p], aq = A[i * D + q];
+                    A[i * D + p] = c * ap - sn * aq; A[i * D + q] = sn * ap + c * aq;
+                    const double vp = V[i * D + p], vq = V[i * D + q];
+                    V[i * D + p] = c * vp - sn * vq; V[i * D + q] = sn * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double smax = 0.0;
+    if (rc == 0) {
+        for (int j = 0; j < D; ++j) {
+            double s2 = 0.0;
+            for (int i = 0; i < D; ++i) s2 += A[i * D + j] * A[i * D + j];
+            const double sj = sqrt(s2);
+            if (!(sj == sj) || sj - sj != 0.0) { rc = 1; break; }
+            if (sj > smax) smax = sj;
+        }
+    }
+    if (rc == 0 && !(smax > 0.0)) rc = 1;   /* C = 0: nothing to align */
+    if (rc == 0) {
+        /* U: the columns with a length are normalised; a rank-deficient C (fewer distinct reconstructions than dimensions) leaves
+         * columns without one -- any orthonormal completion maximises tr(R C) equally, so they are completed deterministically:
+         * the unit vector e_k with the least of its length inside the span of the columns already final (first minimum),
+         * two rounds of Gram-Schmidt against them, normalised */
+        unsigned char *fin = (unsigned char *)calloc((size_t)D, 1);
+        for (int j = 0; j < D; ++j) {
+            double s2 = 0.0;
+            for (int i = 0; i < D; ++i) s2 += A[i * D + j] * A[i * D + j];
+            const double sj = sqrt(s2);
+            if (sj > 1e-12 * smax) {
+                for (int i = 0; i < D; ++i) A[i * D + j] = A[i * D + j] / sj;
+                fin[j] = 1;
+            }
+        }
+        for (int j = 0; j < D && rc == 0; ++j) {
+            if (fin[j]) continue;
+            int kbest = 0;               /* the unit vector with the least of its length inside the span of the final columns */
+            double ebest = 0.0;
+            for (int k = 0; k < D; ++k) {
+                double e2 = 0.0;
+                for (int c = 0; c < D; ++c)
+                    if (fin[c]) e2 += A[k * D + c] * A[k * D + c];
+                if (k == 0 || e2 < ebest) { ebest = e2; kbest = k; }
+            }
+            for (int i = 0; i < D; ++i) A[i * D + j] = i == kbest ? 1.0 : 0.0;
+            for (int round = 0; round < 2; ++round)
+                for (int c = 0; c < D; ++c) {
+                    if (!fin[c]) continue;
+                    double dot = 0.0;
+                    for (int i = 0; i < D; ++i) dot += A[i * D + j] * A[i * D + c];
+                    for (int i = 0; i < D; ++i) A[i * D + j] = A[i * D + j] - dot * A[i * D + c];
+                }
+            double s2 = 0.0;
+            for (int i = 0; i < D; ++i) s2 += A[i * D + j] * A[i * D + j];
+            const double sj = sqrt(s2);
+            if (!(sj > 1e-8)) { rc = 1; break; }
+            for (int i = 0; i < D; ++i) A[i * D + j] = A[i * D + j] / sj;
+            fin[j] = 1;
+        }
+        free(fin);
+    }
+    if (rc == 0)
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) {   /* R[i][j] = sum_k V[i][k] U[j][k] */
+                double acc = 0.0;
+                for (int k = 0; k < D; ++k) acc += V[i * D + k] * A[j * D + k];
+                R[i * D + j] = (float)acc;
+            }
+    free(A); free(V);
+    return rc;
+}
+
+ORC_API int orc_opq_learn_rotation(const float *x, int64_t n, int D, int M, int K, int outer, int niter, uint64_t seed,
+                                   float *R /* [D][D] out */, float *books /* [M][K][D/M] out */)
+{
+    if (n < K || D < 1 || M < 1 || D % M != 0 || outer < 0) return -1;
+    const int step = D / M;
+    float *xr = (float *)malloc(sizeof(float) * (size_t)n * D), *y = (float *)malloc(sizeof(float) * (size_t)n * D);
+    int32_t *assign = (int32_t *)malloc(sizeof(int32_t) * (size_t)n * M);
+    double *C = (double *)malloc(sizeof(double) * (size_t)D * D);
+    int rc = 0;
+    for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) R[i * D + j] = i == j ? 1.0f : 0.0f;
+    for (int t = 0; t <= outer && rc == 0; ++t) {
+        orc_rotate_fma(R, D, x, n, xr);
+        for (int m = 0; m < M && rc == 0; ++m)
+            rc = orc_kmeans(xr + m * step, D, n, step, K, niter, seed, books + (int64_t)m * K * step, assign + (int64_t)m * n, NULL);
+        if (rc != 0 || t == outer) break;
+        for (int64_t r = 0; r < n; ++r)
+            for (int m = 0; m < M; ++m) {
+                const int32_t a = assign[(int64_t)m * n + r];
+                for (int j = 0; j < step; ++j) y[r * D + m * step + j] = a < 0 ? 0.0f : books[((int64_t)m * K + a) * step + j];
+            }
+        orc_xty(x, y, n, D, C);
+        (void)orc_procrustes(C, D, R);   /* a degenerate step keeps R */
+    }
+    free(xr); free(y); free(assign); free(C);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
  * HNSW search over a graph saved by the reference: HierarchicalNSW::searchKnn
  * (hnsw_sifts_retrieval/hnswlib/hnswalg.h:688-729) = greedy descent through the upper levels (:692-712),
  * then searchBaseLayerST (:217-280) with ef = max(ef_, k), then the k best.

@@ -103,3 +103,68 @@ def test_assignment_matrix_core_filter(amd, orc, n, d, k):
         assert git == oit and np.array_equal(ga, oa) and np.array_equal(bits(gc), bits(oc_))
     finally:
         amd.set_tuning("assign_variant", 0)
+
+
+def _correlated(rng, n, D):
+    """rows whose dimensions are mixed and whose variances decay: what a learned rotation can untangle and balance"""
+    A = rng.normal(size=(D, D))
+    z = rng.normal(size=(n, D)) * np.exp(-np.arange(D) / (D / 5.0))
+    return (z @ A.T).astype(np.float32)
+
+
+def _distortion(orc, R, books, x):
+    """mean squared quantisation error of the rows under (R, books), in the oracle's arithmetic"""
+    M = books.shape[0]
+    xr = orc.rotate_fma(R, x)
+    _, codes = orc.pq_encode(xr, np.zeros((1, x.shape[1]), np.float32), books)
+    y = np.concatenate([books[m][codes[:, m]] for m in range(M)], axis=1)
+    return float(((xr.astype(np.float64) - y) ** 2).sum() / x.shape[0])
+
+
+@pytest.mark.parametrize("n,D,M,K,outer,niter", [(3000, 32, 4, 16, 3, 4), (5000, 64, 8, 32, 2, 3), (2500, 128, 16, 64, 2, 2), (1100, 96, 4, 8, 4, 0)])
+def test_opq_rotation_learning_parity(amd, orc, n, D, M, K, outer, niter):
+    """the dense rotation learned by alternating k-means and orthogonal Procrustes.  Not in the reference (it only
+    permutes): the specification is the oracle's orc_opq_learn_rotation, and the device path -- MFMA rotation, Lloyd iterations,
+    reconstruction, X^T Y in the specified blocked order, host Jacobi -- has to reproduce R and the codebooks bit for bit; host-pointer and
+    device-pointer entries alike; outer = 0 is plain PQ training under the identity."""
+    import torch
+    rng = np.random.default_rng(n + D)
+    x = _correlated(rng, n, D)
+    oR, ob_ = orc.opq_learn_rotation(x, M, K, outer, niter, 7)
+    gR, gb = amd.opq_learn_rotation(x, M, K, outer, niter, 7)
+    assert np.array_equal(bits(gR), bits(oR)), np.abs(gR - oR).max()
+    assert np.array_equal(bits(gb), bits(ob_))
+    tR, tb = amd.opq_learn_rotation(torch.from_numpy(x).cuda(), M, K, outer, niter, 7)
+    assert np.array_equal(bits(tR.cpu().numpy()), bits(oR)) and np.array_equal(bits(tb.cpu().numpy()), bits(ob_))
+    assert np.abs(gR.astype(np.float64) @ gR.astype(np.float64).T - np.eye(D)).max() < 1e-5     # a rotation
+    iR, ib = amd.opq_learn_rotation(x, M, K, 0, niter, 7)
+    assert np.array_equal(iR, np.eye(D, dtype=np.float32))
+    # the learned rotation quantises these rows better than the identity (it is what the alternation minimises)
+    assert _distortion(orc, gR, gb, x) < 0.9 * _distortion(orc, iR, ib, x)
+
+
+def test_opq_rotation_learning_feeds_the_index(amd, orc):
+    """R and books go straight into cvtmi_opq_create: rotate + encode + ADC search under the learned model equal the oracle's, and the
+    search finds more exact neighbours than under the identity with the same budget of bytes"""
+    rng = np.random.default_rng(3)
+    n, D, M, K, k = 20_000, 64, 8, 256, 10
+    both = _correlated(rng, n + 300, D)        # database and queries from the same (mixed, unbalanced) distribution
+    x, q = both[:n].copy(), both[n:].copy()
+    xd, qd = x.astype(np.float64), q.astype(np.float64)
+    exact = np.argmin((qd ** 2).sum(1)[:, None] - 2 * qd @ xd.T + (xd ** 2).sum(1)[None, :], axis=1)
+    hits = {}
+    for outer in (0, 4):
+        R, books = amd.opq_learn_rotation(x[:8000].copy(), M, K, outer, 4, 1)
+        idx = amd.OpqIndex(np.zeros((1, D), np.float32), books, R=R)
+        xr = idx.rotate(x)
+        _, codes = idx.encode(xr)
+        idx.add_codes(codes)
+        d, i = idx.search(q, k, rotate=True)
+        oxr = orc.rotate_fma(R, x)
+        _, ocodes = orc.pq_encode(oxr, np.zeros((1, D), np.float32), books)
+        assert np.array_equal(codes, ocodes)
+        od, oi = orc.adc_search(orc.rotate_fma(R, q), books, ocodes, k)
+        assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od))
+        hits[outer] = float((i == exact[:, None]).any(axis=1).mean())
+        idx.close()
+    assert hits[4] > hits[0], hits

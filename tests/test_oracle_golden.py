@@ -232,3 +232,35 @@ def test_oracle_hnsw_search_matches_reference(orc, golden, case):
     # a different ef / k still runs and returns sorted (dist, label) lists
     d2, lab2 = orc.hnsw_search(g[case + "_index"].tobytes(), metric, D, g[case + "_q"], 3, 5)
     assert np.all(d2[:, 1:] >= d2[:, :-1])
+
+
+def test_oracle_opq_rotation_learning(orc):
+    """orc_opq_learn_rotation (optional; not in the reference: self-specified): the Procrustes step recovers a known
+    rotation and reaches the optimum tr(R C) = sum of singular values also for a rank-deficient C (completed columns); the learned R is
+    orthonormal and quantises mixed, unbalanced rows better than the identity; outer = 0 is plain PQ training."""
+    rng = np.random.default_rng(21)
+    D, M, K, n = 32, 4, 16, 3000
+    A = rng.normal(size=(D, D))
+    x = ((rng.normal(size=(n, D)) * np.exp(-np.arange(D) / 6.0)) @ A.T).astype(np.float32)
+    Q, _ = np.linalg.qr(rng.normal(size=(D, D)))
+    rc, R = orc.procrustes(orc.xty(x, (x @ Q.T).astype(np.float32)))
+    assert rc == 0 and np.abs(R - Q).max() < 1e-5
+    C = orc.xty(x, np.where(np.arange(D)[None, :] < 5, x, 0).astype(np.float32))          # rank 5
+    rc, R = orc.procrustes(C)
+    Rd = R.astype(np.float64)
+    assert rc == 0 and np.abs(Rd @ Rd.T - np.eye(D)).max() < 1e-6
+    assert abs(np.trace(Rd @ C) - np.linalg.svd(C, compute_uv=False).sum()) < 1e-6 * np.abs(C).sum()
+    assert orc.procrustes(np.zeros((D, D)))[0] == 1 and orc.procrustes(np.full((D, D), np.nan))[0] == 1
+    want = x.astype(np.float64).T @ x.astype(np.float64)
+    assert np.abs(orc.xty(x, x) - want).max() <= 1e-12 * np.abs(want).max()
+
+    def distortion(R, books):
+        xr = orc.rotate_fma(R, x)
+        _, codes = orc.pq_encode(xr, np.zeros((1, D), np.float32), books)
+        y = np.concatenate([books[m][codes[:, m]] for m in range(M)], axis=1)
+        return float(((xr.astype(np.float64) - y) ** 2).sum() / n)
+    R0, b0 = orc.opq_learn_rotation(x, M, K, 0, 4, 1)
+    R6, b6 = orc.opq_learn_rotation(x, M, K, 6, 4, 1)
+    assert np.array_equal(R0, np.eye(D, dtype=np.float32))
+    assert np.abs(R6.astype(np.float64) @ R6.astype(np.float64).T - np.eye(D)).max() < 1e-6
+    assert distortion(R6, b6) < 0.6 * distortion(R0, b0)
