@@ -54,8 +54,8 @@ int IVFOPQ::SetDevices(int ndev, long long expected_rows)
     bool ok = true;
     for (int d = 0; d < ndev && ok; ++d) {
         ok = cvtmi_set_device(d) == CVTMI_OK &&
-             cvtmi_opq_create(m_featDim, m_coarseK, m_pq_m, m_pq_k, m_coarse.data(), m_books.data(), NULL,
-                              m_reorder.empty() ? NULL : m_reorder.data(), &hs[d]) == CVTMI_OK &&
+             cvtmi_opq_create(m_featDim, m_coarseK, m_pq_m, m_pq_k, m_coarse.data(), m_books.data(), m_R.empty() ? NULL : m_R.data(),
+                              (!m_R.empty() || m_reorder.empty()) ? NULL : m_reorder.data(), &hs[d]) == CVTMI_OK &&
              cvtmi_opq_set_id_base(hs[d], (long long)d * m_devCap) == CVTMI_OK;
     }
     std::vector<cvtmi_comm_s *> cs(ndev, (cvtmi_comm_s *)NULL);
@@ -71,12 +71,33 @@ int IVFOPQ::SetDevices(int ndev, long long expected_rows)
     return 1;
 }
 
+int IVFOPQ::SetRotation(const float *R)
+{
+    if (!R || m_featDim <= 0) { printf("SetRotation: load a model first\n"); return 0; }
+    if (m_hs.size() > 1 || (m_h && numEntries() != 0)) { printf("SetRotation: the index already holds entries\n"); return 0; }
+    m_R.assign(R, R + (size_t)m_featDim * m_featDim);
+    if (m_h) { cvtmi_opq_destroy(m_h); m_h = NULL; }   // (re-created with the rotation on first use)
+    return ensureHandle() ? 1 : 0;
+}
+
+int IVFOPQ::LoadRotation(std::string rotationFile)
+{
+    ifstream fin(rotationFile.c_str(), ios::binary | ios::ate);
+    if (!fin.is_open() || m_featDim <= 0) { printf("Can not open the rotation file!\n"); return 0; }
+    const size_t want = sizeof(float) * (size_t)m_featDim * m_featDim;
+    if ((size_t)fin.tellg() != want) { printf("rotation file: %zu bytes expected\n", want); return 0; }
+    fin.seekg(0);
+    std::vector<float> R((size_t)m_featDim * m_featDim);
+    fin.read((char *)R.data(), (std::streamsize)want);
+    return SetRotation(R.data());
+}
+
 bool IVFOPQ::ensureHandle()
 {
     if (m_h) return true;
     if (m_featDim <= 0) return false;
-    int rc = cvtmi_opq_create(m_featDim, m_coarseK, m_pq_m, m_pq_k, m_coarse.data(), m_books.data(), NULL,
-                              m_reorder.empty() ? NULL : m_reorder.data(), &m_h);
+    int rc = cvtmi_opq_create(m_featDim, m_coarseK, m_pq_m, m_pq_k, m_coarse.data(), m_books.data(), m_R.empty() ? NULL : m_R.data(),
+                              (!m_R.empty() || m_reorder.empty()) ? NULL : m_reorder.data(), &m_h);
     if (rc != CVTMI_OK) {
         printf("cvtmi_opq_create failed: %s\n", cvtmi_last_error());
         m_h = NULL;

@@ -59,6 +59,11 @@ public:
     // cvtmi_opq_search_sharded_all).  AddRows / SearchTopK / numEntries work in this mode, the per-video calls do not.
     // 1 ok / 0 failure (fewer devices than asked for, RCCL not loadable, entries already present).
     int SetDevices(int ndev, long long expected_rows);
+    // A dense D x D rotation (row-major fp32, y = R x: the fp32 MFMA GEMM of the library) INSTEAD of the model's reorder_ permutation --
+    // e.g. one learned by cvtmi_opq_learn_rotation / TrainPQ::LearnRotation; the model file has no slot for it, so it lives beside the
+    // model as raw fp32 [D][D] (LoadRotation).  Call after LoadModel and before anything is indexed.  1 ok / 0 failure.
+    int SetRotation(const float *R);
+    int LoadRotation(std::string rotationFile);
     int numDevices() const { return (int)m_hs.size() > 1 ? (int)m_hs.size() : 1; }
 
 private:
@@ -73,6 +78,7 @@ private:
     std::vector<cvtmi_comm_s *> m_comms;
     long long m_devCap;
     std::vector<float> m_coarse, m_books;
+    std::vector<float> m_R;               // dense rotation (SetRotation): replaces the permutation when present
     std::vector<int> m_reorder;
     int m_coarseK, m_pq_m, m_pq_k, m_pq_step, m_featDim, m_imgNum, m_maxIndexNum, m_imgCap;
 };

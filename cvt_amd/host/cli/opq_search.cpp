@@ -4,8 +4,9 @@
 // search (retrieval/vlindex/lib/FLANN/mpi/index.h:196-226): every rank indexes a contiguous block of rows, searches it,
 // then ONE all-gather of the per-shard top-k + merge (inside libcvtmi: cvtmi_opq_search_sharded).
 //
-//   opq_search <model> <db_feat.bin> <query_feat.bin> <result.txt> [--k 100] [--gpus N] [--fork] [--transport rccl|shm]
+//   opq_search <model> <db_feat.bin> <query_feat.bin> <result.txt> [--k 100] [--gpus N] [--fork] [--transport rccl|shm] [--rotation R.f32]
 //
+// --rotation: a dense D x D rotation (raw fp32, e.g. opq_train --learn-rotation) instead of the model's permutation (IVFOPQ::LoadRotation).
 // model: LoadModel format with coarseK == 1; feature files: raw fp32 [n][D] (IVFOPQ.cpp:451-457).
 // --gpus N: ONE process drives the N GPUs (IVFOPQ::SetDevices: ncclCommInitAll + grouped all-gathers inside libcvtmi) -- the
 // shape of the reference's own single-process mains.  --fork: one process per GPU instead (rank r -> device r %
@@ -35,6 +36,8 @@
 #include "../../../include/cvtmi.h"
 #include "../IVFOPQ.h"
 using namespace std;
+
+static string g_rotation;   // --rotation: dense rotation file (IVFOPQ::LoadRotation) applied after every LoadModel
 
 struct Shared {
     pthread_barrier_t bar;
@@ -105,6 +108,7 @@ static int run_rank(int rank, int world, bool use_shm, Shared *sh, const string 
     }
     IVFOPQ index;
     if (index.LoadModel(model) != 1) return 1;
+    if (!g_rotation.empty() && index.LoadRotation(g_rotation) != 1) return 1;
     const int D = index.dim();
     const long long n = file_rows(db, D), nq = file_rows(qf, D);
     if (n < 0 || nq < 0) { fprintf(stderr, "cannot stat the feature files\n"); return 1; }
@@ -159,6 +163,7 @@ static int run_single_process(int gpus, const string &model, const string &db, c
 {
     IVFOPQ index;
     if (index.LoadModel(model) != 1) return 1;
+    if (!g_rotation.empty() && index.LoadRotation(g_rotation) != 1) return 1;
     const int D = index.dim();
     const long long n = file_rows(db, D), nq = file_rows(qf, D);
     if (n < 0 || nq < 0) { fprintf(stderr, "cannot stat the feature files\n"); return 1; }
@@ -209,10 +214,11 @@ int main(int argc, char *argv[])
         else if (!strcmp(argv[i], "--fork")) forked = true;
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--transport") && i + 1 < argc) transport = argv[++i];
+        else if (!strcmp(argv[i], "--rotation") && i + 1 < argc) g_rotation = argv[++i];
         else pos.push_back(argv[i]);
     }
     if (pos.size() != 4 || k < 1 || k > 128 || gpus < 1 || (transport != "rccl" && transport != "shm")) {
-        cerr << "usage: opq_search <model> <db_feat.bin> <query_feat.bin> <result.txt> [--k 100] [--gpus N] [--fork] [--transport rccl|shm]" << endl;
+        cerr << "usage: opq_search <model> <db_feat.bin> <query_feat.bin> <result.txt> [--k 100] [--gpus N] [--fork] [--transport rccl|shm] [--rotation R.f32]" << endl;
         return 2;
     }
     const bool use_shm = transport == "shm";

@@ -73,6 +73,23 @@ void TrainPQ::train()
     m_trained = true;
 }
 
+int TrainPQ::LearnRotation(int outer)
+{
+    if (m_coarseK != 1) { std::cout << "LearnRotation: needs coarseK == 1" << std::endl; return 0; }
+    if (m_featNum <= 0) return 0;
+    m_coarse.assign((size_t)m_featDim, 0.0f);
+    m_books.assign((size_t)m_pq_m * m_pq_k * m_pq_step, 0.0f);
+    m_R.assign((size_t)m_featDim * m_featDim, 0.0f);
+    const int rc = cvtmi_opq_learn_rotation(m_feat.data(), m_featNum, m_featDim, m_pq_m, m_pq_k, outer, niter, seed, m_R.data(), m_books.data());
+    if (rc != CVTMI_OK) {
+        std::cout << "rotation learning failed: " << cvtmi_last_error() << std::endl;
+        m_R.clear();
+        return 0;
+    }
+    m_trained = true;
+    return 1;
+}
+
 // The reference trains the coarse quantiser and the sub-quantisers in two calls; here both come out of one
 // device-side pass (the residuals never leave HBM), run by whichever is called first.
 void TrainPQ::CoarseQuan()
@@ -111,4 +128,8 @@ void TrainPQ::SaveCodebook(std::string desDir)
     // the file stays interchangeable with the reference's tools, quirk included.
     out.write(reinterpret_cast<const char *>(reorder_.data()), sizeof(int) * (size_t)m_featDim);
     out.close();
+    if (!m_R.empty()) {   // LearnRotation: the dense rotation beside the model (the model format has no slot for it)
+        std::ofstream rout((m_desDir + ".R.f32").c_str(), std::ios::binary);
+        rout.write(reinterpret_cast<const char *>(m_R.data()), sizeof(float) * m_R.size());
+    }
 }

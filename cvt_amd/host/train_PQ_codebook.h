@@ -22,6 +22,12 @@ public:
     void SaveCodebook(std::string desDir);        // <desDir>/OPQ_db_<n>_dim_<D>_k_<coarseK>_PQ_m<M>_k<K>.fvecs
     void reorder(float *feat);
 
+    // extra (not in the reference, which takes its "rotation" -- a permutation -- from the reorder file): learn a dense D x D rotation
+    // from the loaded sample (cvtmi_opq_learn_rotation: `outer` rounds of per-sub-space k-means + orthogonal Procrustes) together with
+    // the sub-codebooks.  Needs coarseK == 1 (the exhaustive configuration; the coarse centroid is the zero vector).  SaveCodebook then
+    // writes the model as usual and the rotation beside it as raw fp32 [D][D]: <model>.R.f32 (IVFOPQ::LoadRotation).  1 ok / 0 failure.
+    int LearnRotation(int outer);
+    const std::vector<float> &rotation() const { return m_R; }
     // extras (not in the reference): what was produced, for callers that stay in process
     const std::string &modelPath() const { return m_desDir; }
     int featNum() const { return m_featNum; }
@@ -35,6 +41,7 @@ private:
     std::vector<float> m_feat;      // [featNum][featDim], permuted
     std::vector<float> m_coarse;    // [coarseK][featDim]
     std::vector<float> m_books;     // [pq_m][pq_k][pq_step]
+    std::vector<float> m_R;         // [featDim][featDim], LearnRotation only
     std::vector<long int> reorder_; // as read from the reorder file
     bool m_trained = false;
 };

@@ -156,6 +156,40 @@ def test_opq_train_cli(tmp_path, orc):
     assert any(f.startswith("OPQ_Index_db_2_dim_%d_k_%d_PQ_m%d_k%d" % (D, coarseK, M, K)) for f in os.listdir(tmp_path / "idx"))
 
 
+def test_opq_learned_rotation_cli(tmp_path, orc):
+    """opq_train --learn-rotation (TrainPQ::LearnRotation, not in the reference) -> model + <model>.R.f32; opq_search --rotation
+    (IVFOPQ::LoadRotation) indexes and searches under it.  R and the codebooks equal the oracle's orc_opq_learn_rotation bit for bit,
+    the search lists equal the oracle's ADC search over the oracle's codes of the rotated rows."""
+    rng = np.random.default_rng(15)
+    D, M, K, n, nq, k = 32, 4, 32, 3000, 40, 10
+    A = rng.normal(size=(D, D))
+    x = ((rng.normal(size=(n + nq, D)) * np.exp(-np.arange(D) / 6.0)) @ A.T).astype(np.float32)
+    db, q = x[:n], x[n:]
+    (tmp_path / "reorder.bin").write_bytes(np.arange(D, dtype=np.int64).tobytes())     # identity: the rotation does the work
+    (tmp_path / "feats.bin").write_bytes(db.tobytes())
+    run([os.path.join(BIN, "opq_train"), str(tmp_path / "reorder.bin"), str(tmp_path / "feats.bin"), str(tmp_path), str(n), "1", str(D),
+         str(M), str(K), "--learn-rotation=3"], cwd=str(tmp_path))
+    model = tmp_path / ("OPQ_db_%d_dim_%d_k_1_PQ_m%d_k%d.fvecs" % (n, D, M, K))
+    raw = model.read_bytes()
+    books = np.frombuffer(raw, np.float32, K * D, 16 + 4 * D).reshape(M, K, D // M)
+    R = np.frombuffer((tmp_path / (model.name + ".R.f32")).read_bytes(), np.float32).reshape(D, D)
+    oR, ob = orc.opq_learn_rotation(db, M, K, 3, 0, 1)
+    assert np.array_equal(bits(R), bits(oR)) and np.array_equal(bits(books), bits(ob))
+    assert np.all(np.frombuffer(raw, np.float32, D, 16) == 0)                          # the zero coarse centroid
+    proper = tmp_path / "model_int32.bin"                                              # LoadModel reads int32 reorder[D]
+    proper.write_bytes(raw[:16 + 4 * D + 4 * K * D] + np.arange(D, dtype=np.int32).tobytes())
+    (tmp_path / "q.bin").write_bytes(q.tobytes())
+    run([os.path.join(BIN, "opq_search"), str(proper), str(tmp_path / "feats.bin"), str(tmp_path / "q.bin"), str(tmp_path / "res.txt"),
+         "--k", str(k), "--rotation", str(tmp_path / (model.name + ".R.f32"))], cwd=str(tmp_path))
+    _, codes = orc.pq_encode(orc.rotate_fma(oR, db), np.zeros((1, D), np.float32), ob)
+    od, oi = orc.adc_search(orc.rotate_fma(oR, q), ob, codes, k)
+    lines = (tmp_path / "res.txt").read_text().strip().splitlines()
+    assert len(lines) == nq
+    for qi, line in enumerate(lines):
+        ids = [int(t) for t in line.split("topK:")[1].split("dists:")[0].split()]
+        assert ids == list(oi[qi]), qi
+
+
 def test_hnsw_search_cli(tmp_path, golden):
     """hnswlib::HierarchicalNSW mirror (loadIndex + setEf + searchKnnBatch) through its CLI, on a graph file the
     reference wrote: labels and distances of every query equal the reference's own answers."""
