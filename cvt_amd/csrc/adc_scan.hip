@@ -18,6 +18,7 @@
 //   * block -> (query group, row split) mapping keeps a row split on one XCD (block b runs on XCD
 //     b % 8) so each XCD's 4 MiB L2 only ever caches 1/8 of the code matrix.
 #include <algorithm>
+#include <atomic>
 
 #include "adc_scan16.h"
 
@@ -1208,7 +1209,7 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16a_kernel(const ScanArg
 
 static int g_scan_seed = 1;
 void set_scan_seed(int v) { g_scan_seed = v != 0; }
-static int g_scan_tail_splits = 0;   // cvtmi_set_tuning("scan_tail_splits"): see plan_scan
+static std::atomic<int> g_scan_tail_splits{0};   // cvtmi_set_tuning("scan_tail_splits"): see plan_scan
 void set_scan_tail_splits(int v) { g_scan_tail_splits = v; }
 int scan_seed_enabled() { return g_scan_seed; }
 
@@ -1292,9 +1293,10 @@ ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int 
         // cvtmi_set_tuning("scan_tail_splits"): 0 = this rule, -1 = never, S > 0 = S splits whenever there is a remainder.
         const int64_t full = groups * best / slots;  // whole rounds of region A
         const int64_t rem = groups * best % slots;
-        if (p.variant >= 3 && full >= 1 && rem != 0 && best == 1 && g_scan_tail_splits >= 0) {
+        const int tail_req = g_scan_tail_splits.load();
+        if (p.variant >= 3 && full >= 1 && rem != 0 && best == 1 && tail_req >= 0) {
             int64_t sb = 0;
-            if (g_scan_tail_splits > 0) sb = g_scan_tail_splits;
+            if (tail_req > 0) sb = tail_req;
             else if (rem * 2 <= slots / 2) { sb = 2; while (sb < 8 && rem * sb * 2 <= slots / 2) sb *= 2; }
             while (sb > best && n_rows / sb < 16384) sb /= 2;   // at least 16 K rows per workgroup
             if (sb > best) { best_ga = full * slots / best; best_sb = sb; }

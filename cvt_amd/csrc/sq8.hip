@@ -26,6 +26,7 @@
 //  * decode divides by the constant 255.0 in double the same way (3 full-rate fp64 ops instead of a ddiv).
 //  * rows of other widths take the two-pass kernels at the bottom (norms, then an element-wise pass).
 #include <algorithm>
+#include <atomic>
 
 #include "div_rn.h"
 #include "kernels.h"
@@ -1075,10 +1076,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
     for (int c = tid; c < D; c += kBlock) { atomicMin(&kmin[c], smin[c]); atomicMax(&kmax[c], smax[c]); }
 }
 
-static int g_sq8_flags = 1;    // cvtmi_set_tuning("sq8_flags"): bit 0 = wave sums on DPP instead of the ds_bpermute butterfly
+static std::atomic<int> g_sq8_flags{1};    // cvtmi_set_tuning("sq8_flags"): bit 0 = wave sums on DPP instead of the ds_bpermute butterfly
 void set_sq8_flags(int v) { g_sq8_flags = v; }
-static int g_sq8_filter = 1;   // cvtmi_set_tuning("sq8_filter"): 0 = the exact chain for every element (the round 2 - 4 kernels)
-void set_sq8_filter(int v) { g_sq8_filter = v != 0; }
+static std::atomic<int> g_sq8_filter{1};   // cvtmi_set_tuning("sq8_filter"): 0 = the exact chain for every element (the round 2 - 4 kernels)
+void set_sq8_filter(int v) { g_sq8_filter = v != 0 ? 1 : 0; }
 constexpr int64_t SQ8_SAMPLE_ROWS = 8192;   // rows of the training pass that seeds every wave's extremes
 
 // ---- the sign of a zero minimum (round 5) ----------------------------------------------------------------------------------
@@ -1144,18 +1145,18 @@ int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_sc
             // whole rows per wave, no LDS tile (the tile kernel's phases serialise behind its barriers: 3.3 TB/s at d = 512)
             const int64_t rows_per_wg = kBlock / 64;
             const unsigned blocks = (unsigned)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 256 * g_sq8_wave_blocks);
-            if (g_sq8_filter) {
+            if (g_sq8_filter.load()) {
                 // sample pass over the first rows (its extremes seed every wave of the main pass: "new extreme" is rare from the start),
                 // then the rest; both through the filter kernel, the sample unseeded
                 const int64_t ns = n >= 8 * SQ8_SAMPLE_ROWS ? SQ8_SAMPLE_ROWS : 0;
                 const float *xr = x + ns * d;
                 const unsigned sblocks = (unsigned)((ns / 16 + rows_per_wg - 1) / rows_per_wg);   // 16 rows per wave of the sample
                 if (d == 512) {
-                    if (ns) hipLaunchKernelGGL((sq8_train_wave_f_kernel<2>), dim3(sblocks), dim3(kBlock), 0, st, x, ns, kmin, kmax, 0, g_sq8_flags);
-                    hipLaunchKernelGGL((sq8_train_wave_f_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, xr, n - ns, kmin, kmax, ns ? 1 : 0, g_sq8_flags);
+                    if (ns) hipLaunchKernelGGL((sq8_train_wave_f_kernel<2>), dim3(sblocks), dim3(kBlock), 0, st, x, ns, kmin, kmax, 0, g_sq8_flags.load());
+                    hipLaunchKernelGGL((sq8_train_wave_f_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, xr, n - ns, kmin, kmax, ns ? 1 : 0, g_sq8_flags.load());
                 } else {
-                    if (ns) hipLaunchKernelGGL((sq8_train_wave_f_kernel<1>), dim3(sblocks), dim3(kBlock), 0, st, x, ns, kmin, kmax, 0, g_sq8_flags);
-                    hipLaunchKernelGGL((sq8_train_wave_f_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, xr, n - ns, kmin, kmax, ns ? 1 : 0, g_sq8_flags);
+                    if (ns) hipLaunchKernelGGL((sq8_train_wave_f_kernel<1>), dim3(sblocks), dim3(kBlock), 0, st, x, ns, kmin, kmax, 0, g_sq8_flags.load());
+                    hipLaunchKernelGGL((sq8_train_wave_f_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, xr, n - ns, kmin, kmax, ns ? 1 : 0, g_sq8_flags.load());
                 }
             } else if (d == 512) hipLaunchKernelGGL((sq8_train_wave_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax);
             else hipLaunchKernelGGL((sq8_train_wave_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax);
@@ -1190,9 +1191,9 @@ static int launch_sq8_encode_wave(const float *vmin, const float *vdiff, int d, 
 {
     const int64_t rows_per_wg = kBlock / 64;
     const unsigned blocks = (unsigned)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 256 * g_sq8_wave_blocks);
-    if (l2norm && g_sq8_filter) {
-        if (d == 512) hipLaunchKernelGGL((sq8_encode_wave_f_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes, g_sq8_flags);
-        else hipLaunchKernelGGL((sq8_encode_wave_f_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes, g_sq8_flags);
+    if (l2norm && g_sq8_filter.load()) {
+        if (d == 512) hipLaunchKernelGGL((sq8_encode_wave_f_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes, g_sq8_flags.load());
+        else hipLaunchKernelGGL((sq8_encode_wave_f_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes, g_sq8_flags.load());
         CVTMI_HIP(hipGetLastError());
         return CVTMI_OK;
     }
