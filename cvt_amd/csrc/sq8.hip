@@ -817,7 +817,8 @@ __device__ __forceinline__ ColF sq8_col_filter(float lo, float df)
     return f;
 }
 
-template <int NF>
+// NORM = false: rows are encoded as they are (turn_off_l2norm): a = v exactly, the same filter decides the byte
+template <int NF, bool NORM>
 __global__ __launch_bounds__(kBlock) void sq8_encode_wave_f_kernel(const float *__restrict__ vmin, const float *__restrict__ vdiff, float *x, int64_t n,
                                                                   int write_back, uint8_t *__restrict__ codes, int flags)
 {
@@ -851,6 +852,8 @@ __global__ __launch_bounds__(kBlock) void sq8_encode_wave_f_kernel(const float *
             for (int i = 0; i < NF; ++i) cur[p][i] = nxt[p][i];
             fetch(row + (p + RB) * nw, nxt[p]);
         }
+        float den = 1.0f;
+        if constexpr (NORM) {
         double s[RB];
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
@@ -867,7 +870,7 @@ __global__ __launch_bounds__(kBlock) void sq8_encode_wave_f_kernel(const float *
         for (int p = 1; p < RB; ++p) mine = lane == p ? s[p] : mine;
         // same proof as the tile kernel: the float root is order-independent when the roots of sum (1 -+ 2^-42) coincide
         const double rlo = __dsqrt_rn(mine * (1.0 - 0x1p-42)), rhi = __dsqrt_rn(mine * (1.0 + 0x1p-42));
-        float den = (float)(rlo > 1e-12 ? rlo : 1e-12);
+        den = (float)(rlo > 1e-12 ? rlo : 1e-12);
         const float fhi = (float)(rhi > 1e-12 ? rhi : 1e-12);
         const unsigned long long unproven = __ballot(lane < RB && !(den == fhi));
         if (unproven) {  // rare: the reference's own order for those rows (int8_quan.cc:48-51)
@@ -885,6 +888,7 @@ __global__ __launch_bounds__(kBlock) void sq8_encode_wave_f_kernel(const float *
                 }
             }
         }
+        }
         const DivBy dl = div_by(den);
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
@@ -893,7 +897,7 @@ __global__ __launch_bounds__(kBlock) void sq8_encode_wave_f_kernel(const float *
             dd.b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl.b), p));
             dd.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl.y), p));
             dd.ok = __builtin_amdgcn_readlane((int)dl.ok, p) != 0;
-            if (!dd.ok) {   // wave-uniform, rare: a norm outside the guarded range (zero / huge / non-finite rows) -- the chain for the whole row
+            if (NORM && !dd.ok) {   // wave-uniform, rare: a norm outside the guarded range (zero / huge / non-finite rows) -- the chain for the whole row
 #pragma unroll
                 for (int i = 0; i < NF; ++i) {
                     float4 v = cur[p][i];
@@ -911,7 +915,7 @@ __global__ __launch_bounds__(kBlock) void sq8_encode_wave_f_kernel(const float *
             for (int i = 0; i < NF; ++i) {
                 const float4 v = cur[p][i];
                 float e[4] = { v.x, v.y, v.z, v.w };
-                if (write_back) {   // (uniform) the reference's in-place normalisation: the exact quotients are needed anyway
+                if (NORM && write_back) {   // (uniform) the reference's in-place normalisation: the exact quotients are needed anyway
 #pragma unroll
                     for (int j = 0; j < 4; ++j) e[j] = div_rn(e[j], dd);
                     if (r < n) SQ8_ST(&x4[r * CG + lane + 64 * i], make_float4(e[0], e[1], e[2], e[3]));
@@ -921,7 +925,7 @@ __global__ __launch_bounds__(kBlock) void sq8_encode_wave_f_kernel(const float *
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const ColF &f = cf[i][j];
-                    const float pq = write_back ? e[j] : __fmul_rn(e[j], dd.y);
+                    const float pq = (!NORM || write_back) ? e[j] : __fmul_rn(e[j], dd.y);
                     const float T = __fmaf_rn(pq, f.s, f.c);
                     const float fl = floorf(T);
                     const bool sure = fabsf(__fsub_rn(__fsub_rn(T, fl), 0.5f)) < f.h;
@@ -936,7 +940,7 @@ __global__ __launch_bounds__(kBlock) void sq8_encode_wave_f_kernel(const float *
                     for (int j = 0; j < 4; ++j) {
                         if (open[j]) {
                             const int col = 4 * (lane + 64 * i) + j;
-                            const float a = write_back ? e[j] : div_rn(e[j], dd);
+                            const float a = (!NORM || write_back) ? e[j] : div_rn(e[j], dd);
                             w = (w & ~(0xffu << (8 * j))) | (sq8_byte(a, vmin[col], div_by(vdiff[col])) << (8 * j));
                         }
                     }
@@ -1191,9 +1195,12 @@ static int launch_sq8_encode_wave(const float *vmin, const float *vdiff, int d, 
 {
     const int64_t rows_per_wg = kBlock / 64;
     const unsigned blocks = (unsigned)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 256 * g_sq8_wave_blocks);
-    if (l2norm && g_sq8_filter.load()) {
-        if (d == 512) hipLaunchKernelGGL((sq8_encode_wave_f_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes, g_sq8_flags.load());
-        else hipLaunchKernelGGL((sq8_encode_wave_f_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes, g_sq8_flags.load());
+    if (g_sq8_filter.load()) {
+        const int fl = g_sq8_flags.load();
+        if (d == 512 && l2norm) hipLaunchKernelGGL((sq8_encode_wave_f_kernel<2, true>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes, fl);
+        else if (d == 512) hipLaunchKernelGGL((sq8_encode_wave_f_kernel<2, false>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, 0, codes, fl);
+        else if (l2norm) hipLaunchKernelGGL((sq8_encode_wave_f_kernel<1, true>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes, fl);
+        else hipLaunchKernelGGL((sq8_encode_wave_f_kernel<1, false>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, 0, codes, fl);
         CVTMI_HIP(hipGetLastError());
         return CVTMI_OK;
     }

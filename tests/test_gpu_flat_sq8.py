@@ -372,12 +372,13 @@ def test_sq8_decision_filter_equals_the_chain(amd, orc, d, kind):
         x[rng.random(size=(n, d)) < 0.2] = 0
     x[3] = 0; x[4, 5] = -0.0; x[11] *= 1e30; x[12] *= 1e-30; x[13, 7] = np.inf; x[14] = -0.0
     x[20:40, :8] = -0.0
-    for l2 in (1, 2):          # 1 = the reference's in-place normalisation, 2 = rows left alone
-        ovmin, ovdiff = orc.sq8_train(x[50:].copy(), l2norm=True)          # trained without the first rows: some of them clamp
+    for l2 in (1, 2, 0):       # 1 = the reference's in-place normalisation, 2 = normalised codes, rows left alone, 0 = turn_off_l2norm
+        xfin = x[50:][np.all(np.isfinite(x[50:]), axis=1)]
+        ovmin, ovdiff = orc.sq8_train(xfin.copy(), l2norm=(l2 != 0))       # trained without the first rows: some of them clamp
         hv, hd = ovmin.copy(), ovdiff.copy()
         hd[1] = 0.0; hd[2] = 1e-41; hd[3] = 1e30; hv[4] = 50.0; hd[4] = 1e-3; hd[5] = np.nan; hv[6] = -0.0; hd[7] = -abs(hd[7])
         hv[8] = hv[8] + 0.3 * hd[8]; hd[9] *= 0.4                            # values below vmin / above vmin + vdiff: both clamps
-        oc, ox = orc.sq8_encode(hv, hd, x, l2norm=True)
+        oc, ox = orc.sq8_encode(hv, hd, x, l2norm=(l2 != 0))
         got = {}
         try:
             for filt in (1, 2, 0):                                           # 2 = the filter kernel with the ds_bpermute butterfly for its wave sums
@@ -397,6 +398,9 @@ def test_sq8_decision_filter_equals_the_chain(amd, orc, d, kind):
             assert np.array_equal(bits(got[1][1]), bits(ox)) and np.array_equal(bits(got[0][1]), bits(ox))
         else:
             assert np.array_equal(bits(got[1][1]), bits(x))
+        if l2 == 0:   # (no normalisation: every finite ROW is comparable, whatever its norm would have been)
+            fin = np.all(np.isfinite(x), axis=1)
+            assert np.array_equal(got[1][0][fin][:, fin_cols], oc[fin][:, fin_cols])
     # training: extremes of the normalised rows, sample pass + seeded main pass
     xf = x[np.all(np.isfinite(x), axis=1)]
     ovmin, ovdiff = orc.sq8_train(xf.copy(), l2norm=True)

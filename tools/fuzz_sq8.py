@@ -35,7 +35,8 @@ for it in range(iters):
         x[int(rng.integers(0, n)), int(rng.integers(0, d))] = rng.choice([np.inf, -np.inf, np.nan])
     x[:, int(rng.integers(0, d))] = np.float32(rng.normal())          # a constant column (before normalisation)
     sub = x[np.all(np.isfinite(x), axis=1)][: max(64, n // 3)]
-    vm, vd = orc.sq8_train(sub.copy(), l2norm=True)
+    l2 = int(rng.choice([1, 2, 0]))   # 1 in-place normalisation, 2 normalised codes / rows left alone, 0 no normalisation
+    vm, vd = orc.sq8_train(sub.copy(), l2norm=(l2 != 0))
     vm, vd = vm.copy(), vd.copy()
     for c in rng.integers(0, d, size=12):
         kind = int(rng.integers(0, 8))
@@ -47,8 +48,7 @@ for it in range(iters):
         elif kind == 5: vd[c] *= np.float32(0.3)
         elif kind == 6: vm[c] += np.float32(0.4) * vd[c]
         else: vd[c] = np.nan
-    l2 = int(rng.choice([1, 2]))
-    oc, ox = orc.sq8_encode(vm, vd, x, l2norm=True)
+    oc, ox = orc.sq8_encode(vm, vd, x, l2norm=(l2 != 0))
     xt = torch.from_numpy(x.copy()).cuda()
     codes = cvt_amd.sq8_encode(torch.from_numpy(vm).cuda(), torch.from_numpy(vd).cuda(), xt, l2norm=l2).cpu().numpy()
     fin, finc = np.all(np.isfinite(ox), axis=1), np.isfinite(vd)      # (int) NaN is undefined in the reference itself
