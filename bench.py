@@ -385,7 +385,10 @@ def run_sift1b(ctx, q, steps, warmup):
                args.large_rows, ctx.world, (l1 - l0) * ctx.M / 1e9, ql.shape[0], ctx.k,
                "ONE all-gather of the per-shard top-k inside libcvtmi + merge" if ctx.world > 1 else "single shard")}
     if ctx.comm is not None:
-        ctx.comm.status()   # deferred status check of the sharded searches: a rank that failed locally surfaces here
+        try:
+            ctx.comm.status()   # deferred status check of the sharded searches: a rank that failed locally surfaces here
+        except cvt.CvtmiError as e:   # the line still appears, and says so
+            res["error"] = "a rank's local search failed during the timed steps (its results were voided): %s" % e
         c1 = ctx.comm.info()
         res["comm"] = c1
         res["transport"] = c1["transport"]
@@ -620,8 +623,8 @@ def headline_multi(ctx, q):
                 "identical_to_oracle_sample", "cpu_baseline"):
         if key in res:
             result[key] = res[key]
-    if ctx.error:
-        result["error"] = ctx.error
+    if ctx.error or "error" in res:
+        result["error"] = "; ".join(e for e in (ctx.error, res.get("error")) if e)
     result["sift1b"] = res
     result.update(extra)
     return result
@@ -794,7 +797,10 @@ def main():
     if ctx.rank == 0:
         print(json.dumps(result), flush=True)
     if ctx.comm is not None:
-        ctx.comm.close()
+        try:
+            ctx.comm.close()
+        except ctx.cvt.CvtmiError as e:
+            print("bench.py: rank %d: %s" % (ctx.rank, e), file=sys.stderr)
     ctx.rv.barrier()
     ctx.rv.close()
     if ctx.hung_thread:   # a helper thread is still inside ncclCommInitRank: the interpreter's shutdown would wait for RCCL
