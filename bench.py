@@ -141,6 +141,7 @@ class Ctx:
         self.nn = None
         self.last_out = None
         self.exact_nn = None
+        self.search_error = None
 
     def barrier(self):
         self.rv.barrier()
@@ -265,9 +266,21 @@ class Ctx:
         return ix, rows_done, t_acc
 
     def searcher(self, ix):
-        if self.comm is not None:
-            return lambda qq: ix.search_sharded(self.comm, qq, self.k, rotate=True)
-        return lambda qq: ix.search(qq, self.k, rotate=True)
+        if self.comm is None:
+            return lambda qq: ix.search(qq, self.k, rotate=True)
+
+        def sharded(qq):
+            # The rank whose LOCAL search fails gets the error from its own call (it has entered the collective all the same, so its
+            # peers are not left waiting: their results are voided on the device and their status check says so).  The bench keeps
+            # going on every rank -- the line has to appear, with the reason in it.
+            try:
+                return ix.search_sharded(self.comm, qq, self.k, rotate=True)
+            except self.cvt.CvtmiError as e:
+                self.search_error = str(e)
+                torch = self.torch
+                return (torch.full((qq.shape[0], self.k), float("inf"), device=self.dev),
+                        torch.full((qq.shape[0], self.k), -1, dtype=torch.int64, device=self.dev))
+        return sharded
 
 
 def scan_roofline(sc, traffic=None):
@@ -368,14 +381,19 @@ def run_sift1b(ctx, q, steps, warmup):
     fn = ctx.searcher(big)
     for _ in range(warmup):
         fn(ql)
-    ctx.barrier(); big.last_scan()
+    def last_scan():   # (a rank whose local search failed before its scan has nothing profiled: the line survives that too)
+        try:
+            return big.last_scan()
+        except cvt.CvtmiError:
+            return None
+    ctx.barrier(); last_scan()
     c0 = ctx.comm.info() if ctx.comm is not None else None
     el, out = ctx.timed(lambda: fn(ql), steps, 0)
     ctx.last_out = out   # (headline_multi compares the sharded answer with the same workload on ONE GPU)
-    sc = big.last_scan()
+    sc = last_scan()
     res = {"value": round(ql.shape[0] * steps / el, 1), "unit": "queries/s", "ms_per_step": round(el / steps * 1e3, 4),
            "steps": steps, "rows_total": args.large_rows, "rows_per_gpu": l1 - l0, "nq": int(ql.shape[0]), "k": ctx.k,
-           "n_gpus": ctx.world, "scan": scan_roofline(sc, _pmc_traffic_large(args, l1 - l0, int(ql.shape[0]), ctx.k)),
+           "n_gpus": ctx.world, "scan": scan_roofline(sc, _pmc_traffic_large(args, l1 - l0, int(ql.shape[0]), ctx.k)) if sc else None,
            "index_build_s_this_rank": round(t_build, 2),
            "encode_rows_per_s_this_rank": round(enc_rows / enc_t, 1) if enc_t > 0 else None,
            "data": ("synthetic SIFT-shaped rows generated, rotated and PQ-encoded on device"
@@ -389,6 +407,9 @@ def run_sift1b(ctx, q, steps, warmup):
             ctx.comm.status()   # deferred status check of the sharded searches: a rank that failed locally surfaces here
         except cvt.CvtmiError as e:   # the line still appears, and says so
             res["error"] = "a rank's local search failed during the timed steps (its results were voided): %s" % e
+        own = [w for w in ctx.rv.allgather(ctx.search_error or "") if w]   # (the failing rank's own call returned the error to it)
+        if own:
+            res["error"] = "; ".join(([res["error"]] if "error" in res else []) + own)
         c1 = ctx.comm.info()
         res["comm"] = c1
         res["transport"] = c1["transport"]
@@ -601,7 +622,7 @@ def headline_multi(ctx, q):
     rep.close()
     if ctx.rank != 0:
         return None
-    rf = res["scan"]
+    rf = res["scan"] or {"queries_per_pass": None}
     result = {
         "metric": "queries/sec, OPQ-ADC top-%d over 128-d SIFT-1B-shaped rows, row-sharded x%d" % (k, world),
         "value": res["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -616,7 +637,7 @@ def headline_multi(ctx, q):
                        world, "ncclAllGather (RCCL, issued inside libcvtmi)" if res.get("transport") == "rccl"
                        else "all-gather through the HOST transport (cvtmi_comm_create_custom over the TCP rendezvous)", k),
                    "n1_point_of_this_curve": "the N = 1 line's 'sift1b'.value (same rows, same queries, one GPU)"},
-        "roofline": dict(rf, kernel="adc_scan kernel (M=%d, %d queries per pass), rank 0's shard" % (M, rf["queries_per_pass"])),
+        "roofline": dict(rf, kernel="adc_scan kernel (M=%d, %s queries per pass), rank 0's shard" % (M, rf["queries_per_pass"])),
     }
     # the evidence, at the top level of the line: who exchanged what, and that the answer is the CPU reference's
     for key in ("transport", "rccl_ranks", "collectives_per_search", "recall_at_1", "recall_at_1_what",

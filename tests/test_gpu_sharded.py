@@ -338,3 +338,13 @@ def test_bench_gpus2_without_second_gpu_still_prints_a_line():
     line = _bench_line([])
     _check_evidence(line)
     assert "RCCL needs one device per rank" in line["error"]
+
+
+def test_bench_gpus2_failing_rank_still_prints_a_line():
+    """a rank whose LOCAL search fails (comm_inject_failure): nobody hangs, the line appears with the reason, and its identity evidence
+    says what happened -- the voided results are NOT the oracle's"""
+    line = _bench_line(["--backend", "host", "--tune", "comm_inject_failure=1"])
+    assert "injected failure of rank 1" in line["error"] and "voided" in line["error"]
+    assert line["identical_to_oracle_sample"]["ids_identical"] is False
+    assert line["same_workload_on_one_gpu"]["sharded_result_identical"] is False
+    assert line["collectives_per_search"] == 1.0     # the failing rank entered every collective
