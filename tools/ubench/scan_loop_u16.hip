@@ -20,7 +20,7 @@ __device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b)
 }
 
 // QT = 8 (one b128 per code byte) or 16 (two: second at +256)
-template <int NT, int R, int QT, int MINW, int ADD3 = 0>
+template <int NT, int R, int QT, int MINW, int ADD3 = 0, int NLK = 16>
 __global__ __launch_bounds__(NT, MINW) void scan_kernel(const uint4 *__restrict__ rows, int64_t n_rows, const uint32_t *__restrict__ lut_g,
                                                         uint32_t thr, uint32_t *out)
 {
@@ -72,20 +72,19 @@ __global__ __launch_bounds__(NT, MINW) void scan_kernel(const uint4 *__restrict_
             uint32_t acc[QT / 2];
             if (ADD3 && QT == 8) {
                 // packed 15-bit sums never carry across the 16-bit halves: plain 32-bit adds, two look-ups per v_add3_u32
-                uint4 v[16];
+                uint4 v[NLK];
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
+                for (int t = 0; t < NLK; ++t) {
                     const uint32_t sel = 0x0c0c0000u | ((4u + (t & 3)) << 8) | (uint32_t)(t & 3);
                     const uint32_t addr = __builtin_amdgcn_perm(rot[t >> 2], moffp[t >> 2], sel);
                     v[t] = *reinterpret_cast<const uint4 *>(lut_b + addr);
                 }
-                acc[0] = v[0].x; acc[1] = v[0].y; acc[2] = v[0].z; acc[3] = v[0].w;
+                acc[0] = 0; acc[1] = 0; acc[2] = 0; acc[3] = 0;
 #pragma unroll
-                for (int t = 1; t < 15; t += 2) {
+                for (int t = 0; t < NLK; t += 2) {
                     acc[0] = acc[0] + v[t].x + v[t + 1].x; acc[1] = acc[1] + v[t].y + v[t + 1].y;
                     acc[2] = acc[2] + v[t].z + v[t + 1].z; acc[3] = acc[3] + v[t].w + v[t + 1].w;
                 }
-                acc[0] += v[15].x; acc[1] += v[15].y; acc[2] += v[15].z; acc[3] += v[15].w;
             } else {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -123,7 +122,7 @@ __global__ __launch_bounds__(NT, MINW) void scan_kernel(const uint4 *__restrict_
     out[(int64_t)blockIdx.x * NT + tid] = chk + cnt;
 }
 
-template <int NT, int R, int QT, int MINW, int ADD3 = 0>
+template <int NT, int R, int QT, int MINW, int ADD3 = 0, int NLK = 16>
 static void run(const char *name, const uint4 *rows, int64_t n_rows, int nq, const uint32_t *lut, uint32_t *out)
 {
     hipEvent_t e0, e1;
@@ -131,7 +130,7 @@ static void run(const char *name, const uint4 *rows, int64_t n_rows, int nq, con
     const int groups = nq / QT;
     for (int it = 0; it < 2; ++it) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((scan_kernel<NT, R, QT, MINW, ADD3>), dim3(groups), dim3(NT), 0, 0, rows, n_rows, lut, 1u, out);
+        hipLaunchKernelGGL((scan_kernel<NT, R, QT, MINW, ADD3, NLK>), dim3(groups), dim3(NT), 0, 0, rows, n_rows, lut, 1u, out);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
     }
@@ -155,6 +154,13 @@ int main()
     CK(hipMemcpy(rows, h.data(), n * 16, hipMemcpyHostToDevice));
     CK(hipMemcpy(lut, hl.data(), hl.size() * 4, hipMemcpyHostToDevice));
     const int nq = 10240;
+    run<1024, 1, 8, 8, 1, 16>("add3 16 look-ups", rows, n, nq, lut, out);
+    run<1024, 1, 8, 8, 1, 14>("add3 14 look-ups", rows, n, nq, lut, out);
+    run<1024, 1, 8, 8, 1, 12>("add3 12 look-ups", rows, n, nq, lut, out);
+    run<1024, 1, 8, 8, 1, 8>("add3 8 look-ups", rows, n, nq, lut, out);
+    run<1024, 1, 8, 8, 1, 4>("add3 4 look-ups", rows, n, nq, lut, out);
+    run<1024, 1, 8, 8, 1, 16>("add3 16 look-ups", rows, n, nq, lut, out);
+    if (getenv("ONLY_NLK")) return 0;
     run<512, 2, 8, 4>("u16 QT=8", rows, n, nq, lut, out);
     run<512, 1, 8, 4>("u16 QT=8", rows, n, nq, lut, out);
     run<512, 4, 8, 4>("u16 QT=8", rows, n, nq, lut, out);
