@@ -2496,9 +2496,11 @@ static int hnsw_search_adc_leased(cvtmi_hnsw_t h, HnswScratch &S, cvtmi_opq_t op
     CVTMI_TRY(OS.s_lut.reserve((size_t)nq * opq->m.M * opq->m.K * sizeof(float)));
     CVTMI_TRY(launch_lut(opq->m, q_rot, nq, nullptr, OS.s_lut.as<float>(), st));
     HnswPlan pl;
-    CVTMI_TRY(hnsw_plan(h, S, hnsw_adc_state_floats(opq->m.M * opq->m.K), nq, k, ef, pl, st));
+    const int state_floats = hnsw_adc_state_floats(opq->m.M * opq->m.K);   // one reading of the tuning flag for the slot count AND the launch
+    CVTMI_TRY(hnsw_plan(h, S, state_floats, nq, k, ef, pl, st));
     CVTMI_TRY(launch_hnsw_search_adc(h->g, OS.s_lut.as<float>(), opq->codes.as<uint8_t>(), opq->m.M, opq->m.K, nq, k, ef, dist,
-                                     labels, S.s_vis.as<uint32_t>(), S.s_cand.p, pl.slots, pl.words, pl.gcap, S.s_err.as<int>(), st, raw_ids));
+                                     labels, S.s_vis.as<uint32_t>(), S.s_cand.p, pl.slots, pl.words, pl.gcap, S.s_err.as<int>(), st, raw_ids,
+                                     state_floats));
     return hnsw_check_overflow(S, "cvtmi_hnsw_search_adc", ef, st);
 }
 

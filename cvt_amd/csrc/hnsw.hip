@@ -432,14 +432,15 @@ int launch_hnsw_search(const HnswDevGraph &g, int metric, const float *q, int64_
 // same traversal, distances = ADC over the nodes' PQ codes (codes [n][M] in internal-id order, lut [nq][M][K])
 int launch_hnsw_search_adc(const HnswDevGraph &g, const float *lut, const uint8_t *codes, int M, int K, int64_t nq, int k, int ef,
                            float *out_d, int64_t *out_label, uint32_t *visited, void *cand_scratch, int slots, int64_t words,
-                           int64_t gcap, int *err, hipStream_t st, int raw_ids)
+                           int64_t gcap, int *err, hipStream_t st, int raw_ids, int state_floats)
 {
     if (nq <= 0) return CVTMI_OK;
     HnswArgs a;
     hnsw_fill_args(a, g, nq, k, ef, out_d, out_label, visited, cand_scratch, words, gcap, err);
     a.lut = lut; a.codes = codes; a.M = M; a.K = K; a.raw_ids = raw_ids;
-    const bool lds_tables = hnsw_adc_state_floats(M * K) != 0;
-    const size_t lds = (size_t)hnsw_lds_bytes(hnsw_adc_state_floats(M * K), ef > k ? ef : k);
+    // state_floats: what the caller sized the slots for (hnsw_adc_state_floats, read ONCE per search: M K = tables in LDS, 0 = in the scratch)
+    const bool lds_tables = state_floats != 0;
+    const size_t lds = (size_t)hnsw_lds_bytes(state_floats, ef > k ? ef : k);
     if (lds_tables) {
         CVTMI_HIP(hipFuncSetAttribute((const void *)hnsw_search_kernel<DistADC<true> >, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((hnsw_search_kernel<DistADC<true> >), dim3((unsigned)slots), dim3(64), lds, st, a);

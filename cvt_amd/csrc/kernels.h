@@ -276,7 +276,7 @@ int launch_hnsw_search(const HnswDevGraph &g, int metric, const float *q, int64_
                        int *err, hipStream_t st);
 int launch_hnsw_search_adc(const HnswDevGraph &g, const float *lut, const uint8_t *codes, int M, int K, int64_t nq, int k, int ef,
                            float *out_d, int64_t *out_label, uint32_t *visited, void *cand_scratch, int slots, int64_t words,
-                           int64_t gcap, int *err, hipStream_t st, int raw_ids = 0);
+                           int64_t gcap, int *err, hipStream_t st, int raw_ids = 0, int state_floats = 0);
 // exact fp32 distances (reference summation order) of the raw queries to the nodes ids [nq][R] (-1 = padding -> +inf)
 int launch_hnsw_rerank(const HnswDevGraph &g, int metric, const float *q, int64_t nq, int R, const int64_t *ids, float *out_d,
                        hipStream_t st);

@@ -117,10 +117,15 @@ def test_hnsw_over_opq_codes(amd, orc, golden, case, M, K):
     ix = amd.HnswIndex(blob, metric, D)
     q = g[case + "_q"]
     for k2, ef2 in ((k, ef), (10, 40), (1, 1)):
-        d, lab = ix.search_adc(opq, q, k2, ef2)
         od, ol = orc.hnsw_search_adc(blob, books, ocodes, rot(q), k2, ef2)
-        assert np.array_equal(lab, ol), (case, k2, ef2)
-        assert np.array_equal(bits(d), bits(od)), (case, k2, ef2)
+        for tables_in_lds in (0, 1):   # round 5: the tables are read from the scratch (default) or copied into LDS -- the same traversal
+            amd.set_tuning("hnsw_adc_tables", tables_in_lds)
+            try:
+                d, lab = ix.search_adc(opq, q, k2, ef2)
+            finally:
+                amd.set_tuning("hnsw_adc_tables", 0)
+            assert np.array_equal(lab, ol), (case, k2, ef2, tables_in_lds)
+            assert np.array_equal(bits(d), bits(od)), (case, k2, ef2, tables_in_lds)
     # mismatched handles are refused
     small = mk(books)
     small.add_codes(codes[:10])
