@@ -13,6 +13,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _tuning_from_env():
+    """CVTMI_TEST_TUNE="name=value,name=value": run the GPU suite under non-default tuning keys (they never change results)."""
+    spec = os.environ.get("CVTMI_TEST_TUNE", "")
+    if spec:
+        import torch  # (first: the library must meet the HIP runtime torch has loaded, as in every GPU test)
+        torch.cuda.is_available()
+        import cvt_amd as amd
+        for kv in spec.split(","):
+            name, value = kv.split("=")
+            amd.set_tuning(name.strip(), float(value))
+    yield
+
+
 @pytest.fixture(scope="session")
 def orc():
     """The CPU oracle (test infrastructure, oracle/cvt_oracle.c)."""
