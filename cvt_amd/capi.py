@@ -18,12 +18,26 @@ class CvtmiError(RuntimeError):
     pass
 
 
+def _torch_first():
+    """One HIP runtime per process.  libcvtmi.so asks the loader for libamdhip64 / libhsa-runtime64 by SONAME; a PyTorch-ROCm wheel carries
+    its own copies under torch/lib.  Whoever loads first decides which copy the SONAME resolves to, and a process that ends up with the
+    system libamdhip64 over the wheel's HSA runtime (library first, torch second) sees "no ROCm-capable device".  So where torch is
+    installed it is imported before the library; without torch (a C / ctypes host) the system ROCm is the only runtime and nothing is done."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    import importlib.util
+    if importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
 def load_library():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise CvtmiError("libcvtmi.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "or `make -C cvt_amd/csrc`" % LIB_PATH)
+        _torch_first()
         _lib = C.CDLL(LIB_PATH)
         _lib.cvtmi_last_error.restype = C.c_char_p
     return _lib
