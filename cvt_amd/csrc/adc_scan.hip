@@ -810,19 +810,23 @@ __global__ __launch_bounds__(NT, NT / 128) void adc_scan16q_kernel(const ScanArg
         const int qi = group * QT + q;
         if (qi >= a.nq) break;
         const int cnt = tk.cnt[q];
-        const int64_t o = ((int64_t)qi * a.stride + split) * a.k;
+        // a group of the first region that was scanned in one piece holds its queries' final lists: they go where the caller wants them
+        const bool in_place = a.out_d != nullptr && group < a.groups_a;   // (out_d is only set when that region has one split)
+        float *const pd = in_place ? a.out_d : a.part_d;
+        int64_t *const pi = in_place ? a.out_id : a.part_id;
+        const int64_t o = in_place ? (int64_t)qi * a.k : ((int64_t)qi * a.stride + split) * a.k;
         for (int i = tid; i < a.k; i += NT) {
             if (i < cnt) {
                 const unsigned long long e = tk.buf[q][i];
-                a.part_d[o + i] = __uint_as_float((uint32_t)(e >> 32));
-                a.part_id[o + i] = a.id_base + (int64_t)(uint32_t)e;
+                pd[o + i] = __uint_as_float((uint32_t)(e >> 32));
+                pi[o + i] = a.id_base + (int64_t)(uint32_t)e;
             } else {
-                a.part_d[o + i] = __uint_as_float(0x7f800000u);
-                a.part_id[o + i] = -1;
+                pd[o + i] = __uint_as_float(0x7f800000u);
+                pi[o + i] = -1;
             }
         }
         // a region with fewer splits than the partial stride leaves the other slots empty for the merge
-        if (split == 0 && my_splits < a.stride) {
+        if (!in_place && split == 0 && my_splits < a.stride) {
             const int64_t o2 = ((int64_t)qi * a.stride + my_splits) * a.k;
             for (int i = tid; i < (a.stride - my_splits) * a.k; i += NT) {
                 a.part_d[o2 + i] = __uint_as_float(0x7f800000u);
@@ -1381,7 +1385,7 @@ int launch_rotate_codes(const uint8_t *codes, uint8_t *codes_rot, int64_t row0, 
 
 int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, int64_t id_base, const float *q_rot,
                     int64_t nq, int k, const ScanPlan &plan, float *part_d, int64_t *part_id, float *lut_scratch,
-                    const uint8_t *codes_rot, hipStream_t st, uint32_t *gthr, int lazy)
+                    const uint8_t *codes_rot, hipStream_t st, uint32_t *gthr, int lazy, float *final_d, int64_t *final_id)
 {
     if (nq <= 0) return CVTMI_OK;
     if (k < 1 || k > kBigK) return fail(CVTMI_EUNSUPPORTED, "adc_scan: k=%d outside 1..%d", k, kBigK);
@@ -1404,7 +1408,7 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
     if (rps < tile_rows) rps = tile_rows;
     a.rows_per_split = rps;
     a.groups_a = a.groups; a.splits_b = 0; a.stride = plan.splits; a.rows_per_split_b = rps;
-    a.part_d = part_d; a.part_id = part_id; a.lut_g = lut_scratch; a.codes_rot = codes_rot;
+    a.part_d = part_d; a.part_id = part_id; a.out_d = nullptr; a.out_id = nullptr; a.lut_g = lut_scratch; a.codes_rot = codes_rot;
     a.gthr = nullptr; a.lazy = lazy; a.seed = g_scan_seed;
     if (plan.variant >= 3 && m.M == 16 && plan.qtile == 8) {
         if (!lut_scratch) return fail(CVTMI_EINVAL, "adc_scan16q: table scratch missing");
@@ -1416,6 +1420,9 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
             rb = ((rb + tile_rows - 1) / tile_rows) * tile_rows;
             a.rows_per_split_b = rb < tile_rows ? tile_rows : rb;
             blocks = (int64_t)a.groups_a * a.splits + (int64_t)(a.groups - a.groups_a) * a.splits_b;
+        }
+        if (final_d && final_id && scan_in_place_queries(plan, m.M, nq) > 0) {   // (one region without splits: groups_a == groups, all in place)
+            a.out_d = final_d; a.out_id = final_id;
         }
         if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "adc_scan: grid too large (%lld)", (long long)blocks);
         if (gthr && a.stride > 1) {  // the row splits of a query share their filter threshold

@@ -24,6 +24,8 @@ struct ScanArgs {
     int64_t rows_per_split_b;
     float *part_d;
     int64_t *part_id;
+    float *out_d;      // adc_scan16q, two-region plan whose first region has ONE row split: that region's groups write their (final) lists
+    int64_t *out_id;   // straight to [nq][k] here and the merge only visits the other queries (scan_in_place_queries); null: everything to part_*
     const float *lut_g;  // [nq][M][256] fp32 tables in HBM, +inf past K (adc_scan16q only)
     const uint8_t *codes_rot;  // adc_scan16q: copy of the code rows with row r rotated left by r & 15 bytes (or null)
     uint32_t *gthr;            // adc_scan16q: [nq] filter thresholds (table units) shared by the row splits of a query, or null

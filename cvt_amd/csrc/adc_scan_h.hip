@@ -453,7 +453,6 @@ __global__ __launch_bounds__(1024, 8) void adc_scan16h_kernel(const ScanHArgs a)
         }
     };
     const char *lut_b = reinterpret_cast<const char *>(lut);
-    const uint32_t lane16 = (uint32_t)lane * 16u;
     const uint32_t next_chunk_addr = (uint32_t)(uintptr_t)&ck.next_chunk;
 
     for (int round = 0; round < a.rounds; ++round) {

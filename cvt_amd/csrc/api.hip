@@ -335,6 +335,7 @@ static bool host_pinned(const void *p)
 
 static std::atomic<int> g_hnsw_slots_cap{0};   // cvtmi_set_tuning("hnsw_slots"): cap on traversals per CU (0 = what LDS allows, at most 32)
 static std::atomic<int> g_small_zero_copy{1};   // cvtmi_set_tuning("opq_small_zero_copy"): 1 .. 8-query host-pointer searches read / write the pinned staging area from the kernels
+static std::atomic<int> g_host_zero_copy{1};   // cvtmi_set_tuning("opq_host_zero_copy"): page-locked result arrays are written by the kernels themselves, the batch is not cut
 static std::atomic<int> g_host_chunks{4096};  // cvtmi_set_tuning("opq_host_chunk"): queries per piece of a pipelined host-pointer OPQ batch (0 = one piece)
 static std::atomic<int> g_scanh_key{0};  // bumped when a planner setting of adc_scan16h changes: cached item tables are rebuilt
 static std::atomic<int> g_inject_failure{-1};  // cvtmi_set_tuning("comm_inject_failure", r): the local search of rank r of a sharded search fails (tests)
@@ -469,6 +470,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "sq8_filter")) { set_sq8_filter(value != 0); return CVTMI_OK; }
+    if (!strcmp(name, "opq_host_zero_copy")) { g_host_zero_copy = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "scan_tail_splits")) { set_scan_tail_splits((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_flags")) { set_sq8_flags((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_wave_blocks")) {
@@ -996,14 +998,18 @@ static int opq_search_leased(cvtmi_opq_t h, OpqScratch &S, const float *q, int64
         CVTMI_TRY(S.s_gthr.reserve((size_t)nq * sizeof(uint32_t)));
         gthr = S.s_gthr.as<uint32_t>();
     }
+    // (two-region plan, first region in one piece: those queries' lists are written in place by the scan, the merge starts behind them)
+    const int64_t placed = plan.stride() > 1 ? scan_in_place_queries(plan, h->m.M, nq) : 0;
     CVTMI_TRY(launch_adc_scan(h->m, h->codes.as<uint8_t>(), h->n, h->id_base, q_rot, nq, k, plan, pd, pi, lut_scratch,
-                              codes_rot, st, gthr, h->p_lazy));
+                              codes_rot, st, gthr, h->p_lazy, placed ? dist : nullptr, placed ? ids : nullptr));
     if (h->p_profile) {
         CVTMI_HIP(hipEventRecord(h->ev1[slot], st));
         const int64_t groups = (nq + plan.qtile - 1) / plan.qtile;
         opq_note_scan(h, groups * h->n * h->m.M, plan.qtile, plan.splits);  // passes x rows x M code bytes
     }
-    if (plan.stride() > 1) CVTMI_TRY(launch_topk_merge(pd, pi, nq, plan.stride(), k, dist, ids, st));
+    if (plan.stride() > 1)
+        CVTMI_TRY(launch_topk_merge(pd + placed * plan.stride() * k, pi + placed * plan.stride() * k, nq - placed, plan.stride(), k, dist + placed * k,
+                                    ids + placed * k, st));
     return CVTMI_OK;
 }
 
@@ -1040,8 +1046,23 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
     const int D = h->m.D;
     // pieces of `per` queries: 4096 by default = 512 query groups = ONE full round of the scan's workgroups on 256 CUs, so cutting
     // the batch there costs the scan nothing (10 000 queries: 1 + 1 + 0.44 rounds either way)
+    // Page-locked result arrays (cvtmi_host_alloc): the kernels write the lists straight into them (device-visible host memory, posted
+    // PCIe writes: 12 MB over the 3 ms of a 10 000-query scan) -- no device copy of the results, no copy engine, and therefore no
+    // reason to cut the batch: ONE launch chain, the same the device-pointer entry issues; the query groups that are scanned in one
+    // piece deliver their lists as their workgroups end.  Round 5: 3.45-3.55 -> 3.15-3.25 ms per 10 000 queries (device pointers: 3.0-3.1).
+    const bool q_pinned = host_pinned(q), out_pinned = host_pinned(dist) && host_pinned(ids);
+    float *zd = nullptr;
+    int64_t *zi = nullptr;
+    if (out_pinned && g_host_zero_copy.load()) {
+        void *pd = nullptr, *pi = nullptr;
+        if (hipHostGetDevicePointer(&pd, dist, 0) == hipSuccess && hipHostGetDevicePointer(&pi, ids, 0) == hipSuccess && pd && pi) {
+            zd = static_cast<float *>(pd); zi = static_cast<int64_t *>(pi);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     int64_t per = g_host_chunks.load();
-    if (per <= 0 || nq < per + per / 4) per = nq;
+    if (per <= 0 || nq < per + per / 4 || zd) per = nq;
     per = (per + 7) / 8 * 8;   // whole query groups
     const int chunks = (int)((nq + per - 1) / per);
     if (per > (64 << 20) / (int64_t)(D * 4) || (size_t)per * k * 12 > ((size_t)256 << 20)) {
@@ -1065,6 +1086,10 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
     for (int i = 0; i < nsets; ++i) {
         OpqScratch &S = *lease[i].s;
         CVTMI_TRY(S.io_q.reserve(qb));
+        if (zd && nq > 128) {   // (up to 128 queries may take the small-batch form below, which stages everything)
+            if (!q_pinned) CVTMI_TRY(S.io_pin.reserve(qb));
+            continue;
+        }
         CVTMI_TRY(S.io_d.reserve(db));
         CVTMI_TRY(S.io_i.reserve(ib));
         CVTMI_TRY(S.io_pin.reserve(qb + db + ib));   // [queries | distances | ids]
@@ -1114,7 +1139,6 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
         }
         (void)hipGetLastError();
     }
-    const bool q_pinned = host_pinned(q), out_pinned = host_pinned(dist) && host_pinned(ids);
     int c = 0;
     for (int64_t q0 = 0; q0 < nq; q0 += per, ++c) {
         const int i = c % nsets;
@@ -1125,6 +1149,10 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
         const void *src = q + q0 * D;
         if (!q_pinned) { memcpy(S.io_pin.p, src, (size_t)n * D * sizeof(float)); src = S.io_pin.p; }
         CVTMI_HIP(hipMemcpyAsync(S.io_q.p, src, (size_t)n * D * sizeof(float), hipMemcpyHostToDevice, st));
+        if (zd) {   // (one piece: the final wait below is all that is left)
+            CVTMI_TRY(opq_search_leased(h, S, S.io_q.as<float>(), n, rotate, k, zd + q0 * k, zi + q0 * k, st));
+            continue;
+        }
         CVTMI_TRY(opq_search_leased(h, S, S.io_q.as<float>(), n, rotate, k, S.io_d.as<float>(), S.io_i.as<int64_t>(), st));
         if (out_pinned) {  // straight into the caller's page-locked arrays; the final drain only waits for the streams
             CVTMI_HIP(hipMemcpyAsync(dist + q0 * k, S.io_d.p, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost, st));

@@ -52,13 +52,27 @@ struct ScanPlan {
 };
 ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int want_qtile, int want_splits,
                    int want_variant);
+// adc_scan16q under a two-region plan whose first region scans every group in ONE piece: the lists of that region's queries are final
+// when the scan kernel ends, so it writes them to the result arrays itself (launch_adc_scan's final_d / final_id) and the merge starts
+// behind them.  Returns the number of leading queries this holds for (0: none; a multiple of the query tile).
+// A plan without row splits at all (stride 1) has every query in place: nq.
+inline int64_t scan_in_place_queries(const ScanPlan &plan, int M, int64_t nq)
+{
+    const int64_t groups = (nq + plan.qtile - 1) / plan.qtile;
+    if (plan.variant < 3 || plan.variant > 4 || M != 16 || plan.qtile != 8 || plan.splits != 1) return 0;
+    if (!(plan.splits_b > plan.splits && plan.groups_a > 0 && plan.groups_a < groups)) return plan.stride() == 1 ? nq : 0;
+    return (int64_t)plan.groups_a * plan.qtile;
+}
 // part_d / part_id: [nq][plan.stride()][k]
 // lut_scratch: nq * M * K floats, needed when plan.variant >= 3 (see scan_lut_floats)
 // gthr: nq words of scratch (adc_scan16q with more than one row split: shared filter thresholds) or null;
 // lazy: adc_scan16q selects on its integer lower bounds between checkpoints and re-sums exactly once, at the end
 int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, int64_t id_base, const float *q_rot,
                     int64_t nq, int k, const ScanPlan &plan, float *part_d, int64_t *part_id, float *lut_scratch,
-                    const uint8_t *codes_rot, hipStream_t st, uint32_t *gthr = nullptr, int lazy = 1);
+                    const uint8_t *codes_rot, hipStream_t st, uint32_t *gthr = nullptr, int lazy = 1, float *final_d = nullptr,
+                    int64_t *final_id = nullptr);
+// final_d / final_id ([nq][k], or null): where the first scan_in_place_queries() queries' lists go instead of part_* (with stride 1
+// part_* ARE the final arrays: pass them again)
 // M = 16 only: codes_rot rows [row0, n) = the code rows rotated left by (row & 15) bytes, the layout adc_scan16q
 // (plan.variant >= 3) streams when codes_rot is given
 int launch_rotate_codes(const uint8_t *codes, uint8_t *codes_rot, int64_t row0, int64_t n, hipStream_t st);

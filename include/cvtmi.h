@@ -100,6 +100,8 @@ int cvtmi_set_device(int device);
  *   "scan_tail_splits" adc_scan16q, query groups past the last full round of workgroups: 0 (default) = cut them into 2 / 4 / 8 row
  *                     splits while that still leaves at most one workgroup per CU (a last round is only expensive while it leaves CUs
  *                     empty: 4256 queries over 1 M rows 2.11 -> 2.79 M queries/s, 10 000 queries unchanged); -1 = never; S > 0 = S splits
+ *   "opq_host_zero_copy" 1 (default) = cvtmi_opq_search with page-locked result arrays lets the kernels write them (one launch chain);
+ *                     0 = pipelined pieces through device buffers and the copy engines, as for pageable arrays
  *   "sq8_filter"      1 (default) = the wave-per-row SQ8 kernels (d = 256 / 512) decide code bytes / column extremes from a bounded
  *                     approximation and run the reference's chain (two correctly rounded divisions + the byte) only where it cannot
  *                     decide; 0 = the chain for every element.  Same codes, rows and ranges, bit for bit
@@ -228,8 +230,11 @@ int64_t cvtmi_opq_scan_plan(int64_t n_rows, int64_t nq, int splits, int cus, int
                             int *stride);
 
 /* Page-locked host memory.  The host-pointer entries move their arrays through pinned staging areas (one extra host copy each way);
- * arrays that already ARE page-locked -- from here, or the caller's own hipHostMalloc / hipHostRegister -- are handed to the copy
- * engines directly (cvtmi_opq_search: 2.4 -> 2.8 M queries/s with pageable arrays in pipelined pieces, 3.0 with these). */
+ * arrays that already ARE page-locked -- from here, or the caller's own hipHostMalloc / hipHostRegister -- need none: page-locked
+ * queries go to the copy engine as they are, and page-locked RESULT arrays of cvtmi_opq_search are written by the kernels themselves
+ * (device-visible host memory: no device copy of the lists, no copy back, the batch is not cut into pieces; tuning key
+ * "opq_host_zero_copy", default 1).  10 000 queries x top-100 over 1 M rows: pageable arrays in pipelined pieces 2.7 M queries/s,
+ * page-locked arrays 3.1 M, device pointers 3.3 M (round 5, profiles/r05_host_api_sweep.txt). */
 int cvtmi_host_alloc(size_t bytes, void **p);
 int cvtmi_host_free(void *p);
 

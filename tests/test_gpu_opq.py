@@ -232,6 +232,22 @@ def test_search_two_region_tail(amd, orc):
     sel = np.r_[0:8, 4090:4110, nq - 8:nq]
     od, oi = orc.adc_search(q[sel], books, codes, k)
     assert np.array_equal(res[0][1][sel], oi) and np.array_equal(bits(res[0][0][sel]), bits(od))
+    # the host-pointer entry on the same batch: pageable arrays (pipelined pieces), page-locked result arrays through the copy engines
+    # (opq_host_zero_copy 0) and written by the kernels themselves in one launch chain (1, the default) -- the first region's groups
+    # store their lists straight into the caller's memory, the merge fills in the tail's
+    outs = {"pageable": (np.zeros((nq, k), np.float32), np.zeros((nq, k), np.int64)),
+            "page-locked": (amd.pinned_empty((nq, k), np.float32), amd.pinned_empty((nq, k), np.int64))}
+    qp = amd.pinned_empty((nq, D), np.float32); qp[:] = q
+    try:
+        for zc in (0, 1):
+            amd.set_tuning("opq_host_zero_copy", zc)
+            for name, out in outs.items():
+                for qa in (q, qp):
+                    out[0][:] = 0; out[1][:] = -7
+                    idx.search(qa, k, rotate=False, out=out)
+                    assert np.array_equal(out[1], res[-1][1]) and np.array_equal(bits(out[0]), bits(res[-1][0])), (zc, name)
+    finally:
+        amd.set_tuning("opq_host_zero_copy", 1)
 
 
 def test_search_edge_cases(amd, orc):

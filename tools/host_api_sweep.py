@@ -49,11 +49,18 @@ for chunks in [int(v) for v in os.environ.get("CHUNKS", "0,2048,4096,4104,5000,8
 cvt_amd.set_tuning("opq_host_chunk", 4096)
 qp = cvt_amd.pinned_empty((nq, D), np.float32); qp[:] = qh
 outp = (cvt_amd.pinned_empty((nq, k), np.float32), cvt_amd.pinned_empty((nq, k), np.int64))
-for _ in range(3):
-    idx.search(qp, k, rotate=True, out=outp)
-same = bool(np.array_equal(outp[1], ref[1]) and np.array_equal(outp[0].view(np.uint32), ref[0].view(np.uint32)))
-t0 = time.perf_counter()
-for _ in range(8):
-    idx.search(qp, k, rotate=True, out=outp)
-el = (time.perf_counter() - t0) / 8
-print("host pointers, page-locked arrays (cvtmi_host_alloc), pieces of 4096: %.3f ms per batch, %.0f queries/s, same=%s" % (el * 1e3, nq / el, same), flush=True)
+# page-locked result arrays (cvtmi_host_alloc): 0 = pipelined pieces + copy engines, 1 = the kernels write them, one launch chain (round 5)
+for zc in (0, 1):
+    cvt_amd.set_tuning("opq_host_zero_copy", zc)
+    for name, qa in (("pageable", qh), ("page-locked", qp)):
+        for nqs in [int(v) for v in os.environ.get("NQS", str(nq)).split(",")]:
+            oz = (outp[0][:nqs], outp[1][:nqs])
+            for _ in range(3):
+                idx.search(qa[:nqs], k, rotate=True, out=oz)
+            same = bool(np.array_equal(oz[1], ref[1][:nqs]) and np.array_equal(oz[0].view(np.uint32), ref[0][:nqs].view(np.uint32)))
+            t0 = time.perf_counter()
+            for _ in range(8):
+                idx.search(qa[:nqs], k, rotate=True, out=oz)
+            el = (time.perf_counter() - t0) / 8
+            print("host pointers, page-locked results, %s queries, zero_copy=%d, %d queries: %.3f ms per batch, %.0f queries/s, same=%s" % (
+                name, zc, nqs, el * 1e3, nqs / el, same), flush=True)
