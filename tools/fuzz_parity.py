@@ -38,6 +38,41 @@ for it in range(iters):
         fin = np.isfinite(od)
         if not (np.array_equal(i[fin], oi[fin]) and np.array_equal(bits(d)[fin], bits(od)[fin])):
             print("MISMATCH adc", dict(it=it, M=M, K=K, D=D, n=n, nq=nq, k=k, scale=scale, variant=variant)); sys.exit(1)
+    if it % 4 == 0 and M == 16:
+        # large batches (round 5): enough query groups for the scan's two-region plans -- the first region's groups store their final lists
+        # in place, the merge visits the tail only -- through device pointers, pageable host arrays (pipelined pieces) and page-locked
+        # result arrays (written by the kernels); the oracle checks a sample of the queries
+        nL = int(rng.integers(3000, 40000)); nqL = int(rng.integers(4100, 9500)); kL = int(rng.choice([1, 10, 37, 100]))
+        cL = rng.integers(0, K, size=(nL, M), dtype=np.uint8)
+        cL[nL // 2] = cL[0]; cL[nL - 1] = cL[0]
+        qL = (rng.normal(size=(nqL, D)) * scale).astype(np.float32)
+        big = cvt_amd.OpqIndex(np.zeros((1, D), np.float32), books)
+        big.add_codes(cL)
+        big.set_param("scan_variant", 3)
+        ref_d = ref_i = None
+        for tail in (-1, 0, int(rng.choice([2, 4, 8]))):
+            cvt_amd.set_tuning("scan_tail_splits", tail)
+            d, i = big.search(torch.from_numpy(qL).cuda(), kL, rotate=False)
+            d, i = d.cpu().numpy(), i.cpu().numpy()
+            if ref_d is None:
+                ref_d, ref_i = d, i
+                sel = np.unique(np.r_[0:4, rng.integers(0, nqL, size=24), nqL - 4:nqL])
+                od, oi = orc.adc_search(qL[sel], books, cL, kL)
+                if not (np.array_equal(i[sel], oi) and np.array_equal(bits(d[sel]), bits(od))):
+                    print("MISMATCH adc large", dict(it=it, K=K, D=D, n=nL, nq=nqL, k=kL, scale=scale)); sys.exit(1)
+            elif not (np.array_equal(i, ref_i) and np.array_equal(bits(d), bits(ref_d))):
+                print("MISMATCH adc tail plan", dict(it=it, K=K, D=D, n=nL, nq=nqL, k=kL, tail=tail)); sys.exit(1)
+            for zc in (0, 1):
+                cvt_amd.set_tuning("opq_host_zero_copy", zc)
+                outs = [(np.zeros((nqL, kL), np.float32), np.zeros((nqL, kL), np.int64)),
+                        (cvt_amd.pinned_empty((nqL, kL), np.float32), cvt_amd.pinned_empty((nqL, kL), np.int64))]
+                for o in outs:
+                    o[1][:] = -9
+                    big.search(qL, kL, rotate=False, out=o)
+                    if not (np.array_equal(o[1], ref_i) and np.array_equal(bits(o[0]), bits(ref_d))):
+                        print("MISMATCH adc host pointers", dict(it=it, K=K, D=D, n=nL, nq=nqL, k=kL, tail=tail, zero_copy=zc)); sys.exit(1)
+        cvt_amd.set_tuning("scan_tail_splits", 0); cvt_amd.set_tuning("opq_host_zero_copy", 1)
+        big.close()
     # flat fp32 + u8
     Df = int(rng.choice([128, 64, 36, 20, 7, 512])); nf = int(rng.integers(1, 30000)); kf = int(rng.integers(1, 129)); nqf = int(rng.integers(1, 300))
     for metric in (0, 1):
