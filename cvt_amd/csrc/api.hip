@@ -132,6 +132,7 @@ struct FlatScratch {
     DevBuf f_stats, f_thr, f_marg, f_cnt, f_cand, f_sd, f_si, f_sd2, f_si2, f_seld, f_seli;   // matrix-core filter pipelines
     DevBuf fs_redo, fs_scratch;                                                                // fp32 stream
     DevBuf io_q, io_d, io_i;                                                                   // staging of the host-pointer entry
+    PinBuf io_pin;                  // small calls: [queries | distances | labels] in page-locked memory the kernels write into
     hipStream_t own = nullptr;      // stream of the host-pointer entry (created on first use)
     hipEvent_t done = nullptr;
     hipStream_t last = nullptr;
@@ -141,6 +142,7 @@ struct FlatScratch {
         for (DevBuf *b : { &s_part_d, &s_part_id, &s_gthr, &s_stage, &f_stats, &f_thr, &f_marg, &f_cnt, &f_cand, &f_sd, &f_si, &f_sd2,
                            &f_si2, &f_seld, &f_seli, &fs_redo, &fs_scratch, &io_q, &io_d, &io_i })
             b->release();
+        io_pin.release();
         if (own) (void)hipStreamDestroy(own);
         if (done) (void)hipEventDestroy(done);
         own = nullptr; done = nullptr;
@@ -335,6 +337,7 @@ static bool host_pinned(const void *p)
 
 static std::atomic<int> g_hnsw_slots_cap{0};   // cvtmi_set_tuning("hnsw_slots"): cap on traversals per CU (0 = what LDS allows, at most 32)
 static std::atomic<int> g_small_zero_copy{1};   // cvtmi_set_tuning("opq_small_zero_copy"): 1 .. 8-query host-pointer searches read / write the pinned staging area from the kernels
+static std::atomic<int> g_flat_small_zero_copy{1};   // cvtmi_set_tuning("flat_small_zero_copy"): small host-pointer flat searches write their lists into pinned memory from the kernels
 static std::atomic<int> g_host_zero_copy{1};   // cvtmi_set_tuning("opq_host_zero_copy"): page-locked result arrays are written by the kernels themselves, the batch is not cut
 static std::atomic<int> g_host_chunks{4096};  // cvtmi_set_tuning("opq_host_chunk"): queries per piece of a pipelined host-pointer OPQ batch (0 = one piece)
 static std::atomic<int> g_scanh_key{0};  // bumped when a planner setting of adc_scan16h changes: cached item tables are rebuilt
@@ -470,6 +473,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "sq8_filter")) { set_sq8_filter(value != 0); return CVTMI_OK; }
+    if (!strcmp(name, "flat_small_zero_copy")) { g_flat_small_zero_copy = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "opq_host_zero_copy")) { g_host_zero_copy = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "scan_tail_splits")) { set_scan_tail_splits((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_flags")) { set_sq8_flags((int)value); return CVTMI_OK; }
@@ -1990,6 +1994,26 @@ int cvtmi_flat_search(cvtmi_flat_t h, const void *q, int64_t nq, int k, void *di
     FlatScratch &S = *lease.s;
     hipStream_t st = lease.st;
     CVTMI_TRY(S.io_q.reserve((size_t)nq * h->row_bytes));
+    // Small calls (the brute_force CLI's shape, one searchKnn per query: brute_force_search/src/brute_force.cpp:86): the three copies
+    // are a tenth of such a call.  The queries go up from a page-locked staging area (a truly asynchronous copy), and the last kernel of
+    // the search writes the lists straight into that area (device-visible host memory) -- no copy engine on the way back.
+    const size_t qn = (size_t)nq * h->row_bytes, dn = (size_t)nq * k * 4, in = (size_t)nq * k * 8;
+    if (g_flat_small_zero_copy.load() && qn <= ((size_t)64 << 10) && dn + in <= ((size_t)768 << 10)) {
+        const size_t qoff = (qn + 255) & ~(size_t)255, doff = (dn + 255) & ~(size_t)255;
+        CVTMI_TRY(S.io_pin.reserve(std::max(qoff + doff + in, (size_t)1 << 20)));
+        void *pin_dev = nullptr;
+        if (hipHostGetDevicePointer(&pin_dev, S.io_pin.p, 0) == hipSuccess && pin_dev) {
+            char *pin = S.io_pin.as<char>(), *pd = static_cast<char *>(pin_dev);
+            memcpy(pin, q, qn);
+            CVTMI_HIP(hipMemcpyAsync(S.io_q.p, pin, qn, hipMemcpyHostToDevice, st));
+            CVTMI_TRY(flat_search_leased(h, S, S.io_q.p, nq, k, pd + qoff, reinterpret_cast<int64_t *>(pd + qoff + doff), st, tun));
+            CVTMI_HIP(stream_wait(st));
+            memcpy(dist, pin + qoff, dn);
+            memcpy(labels, pin + qoff + doff, in);
+            return CVTMI_OK;
+        }
+        (void)hipGetLastError();
+    }
     CVTMI_TRY(S.io_d.reserve((size_t)nq * k * 4));
     CVTMI_TRY(S.io_i.reserve((size_t)nq * k * 8));
     CVTMI_HIP(hipMemcpyAsync(S.io_q.p, q, (size_t)nq * h->row_bytes, hipMemcpyHostToDevice, st));

@@ -100,6 +100,9 @@ int cvtmi_set_device(int device);
  *   "scan_tail_splits" adc_scan16q, query groups past the last full round of workgroups: 0 (default) = cut them into 2 / 4 / 8 row
  *                     splits while that still leaves at most one workgroup per CU (a last round is only expensive while it leaves CUs
  *                     empty: 4256 queries over 1 M rows 2.11 -> 2.79 M queries/s, 10 000 queries unchanged); -1 = never; S > 0 = S splits
+ *   "flat_small_zero_copy" 1 (default) = a small host-pointer flat search (queries <= 64 KB, lists <= 768 KB: the brute_force CLI's one
+ *                     searchKnn per query) sends its queries up from a page-locked staging area and lets the last kernel write the
+ *                     lists into that area (1 M x 128-d, one query: 137 -> 125 us per call); 0 = three copy-engine copies
  *   "opq_host_zero_copy" 1 (default) = cvtmi_opq_search with page-locked result arrays lets the kernels write them (one launch chain);
  *                     0 = pipelined pieces through device buffers and the copy engines, as for pageable arrays
  *   "sq8_filter"      1 (default) = the wave-per-row SQ8 kernels (d = 256 / 512) decide code bytes / column extremes from a bounded
