@@ -1090,7 +1090,7 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
     for (int i = 0; i < nsets; ++i) {
         OpqScratch &S = *lease[i].s;
         CVTMI_TRY(S.io_q.reserve(qb));
-        if (zd && nq > 128) {   // (up to 128 queries may take the small-batch form below, which stages everything)
+        if (zd && !scans_applies(h->m, h->n, nq, k)) {   // (what may take the small-batch form below stages everything)
             if (!q_pinned) CVTMI_TRY(S.io_pin.reserve(qb));
             continue;
         }
