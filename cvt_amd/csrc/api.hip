@@ -337,6 +337,10 @@ static bool host_pinned(const void *p)
 
 static std::atomic<int> g_hnsw_slots_cap{0};   // cvtmi_set_tuning("hnsw_slots"): cap on traversals per CU (0 = what LDS allows, at most 32)
 static std::atomic<int> g_small_zero_copy{1};   // cvtmi_set_tuning("opq_small_zero_copy"): 1 .. 8-query host-pointer searches read / write the pinned staging area from the kernels
+static std::atomic<int> g_flat_u8_filter_min_nq{129};            // cvtmi_set_tuning("flat_u8_filter_min_nq" / "_min_rows" / "_min_work"): smallest batch, table and
+static std::atomic<int64_t> g_flat_u8_filter_min_rows{524288};   // rows x width x queries (in 1e9) the dispatch hands to the uint8 sample + filter pipeline
+static std::atomic<int64_t> g_flat_u8_filter_min_work{130};
+static std::atomic<int> g_flat_u8_sample_passes{10};  // cvtmi_set_tuning("flat_u8_sample_passes"): the uint8 filter pipeline's sample goes through the streaming kernel up to this many 128-query passes
 static std::atomic<int> g_flat_small_zero_copy{1};   // cvtmi_set_tuning("flat_small_zero_copy"): small host-pointer flat searches write their lists into pinned memory from the kernels
 static std::atomic<int> g_host_zero_copy{1};   // cvtmi_set_tuning("opq_host_zero_copy"): page-locked result arrays are written by the kernels themselves, the batch is not cut
 static std::atomic<int> g_host_chunks{4096};  // cvtmi_set_tuning("opq_host_chunk"): queries per piece of a pipelined host-pointer OPQ batch (0 = one piece)
@@ -473,6 +477,10 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "sq8_filter")) { set_sq8_filter(value != 0); return CVTMI_OK; }
+    if (!strcmp(name, "flat_u8_filter_min_nq")) { g_flat_u8_filter_min_nq = value < 1 ? 1 : value > (1 << 30) ? (1 << 30) : (int)value; return CVTMI_OK; }
+    if (!strcmp(name, "flat_u8_filter_min_rows")) { g_flat_u8_filter_min_rows = value < 0 ? 0 : value; return CVTMI_OK; }
+    if (!strcmp(name, "flat_u8_filter_min_work")) { g_flat_u8_filter_min_work = value < 0 ? 0 : value; return CVTMI_OK; }
+    if (!strcmp(name, "flat_u8_sample_passes")) { g_flat_u8_sample_passes = value < 0 ? 0 : value > 64 ? 64 : (int)value; return CVTMI_OK; }
     if (!strcmp(name, "flat_small_zero_copy")) { g_flat_small_zero_copy = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "opq_host_zero_copy")) { g_host_zero_copy = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "scan_tail_splits")) { set_scan_tail_splits((int)value); return CVTMI_OK; }
@@ -1747,7 +1755,9 @@ static int flat_search_filtered_u8(cvtmi_flat_t h, FlatScratch &S, const uint8_t
     const int D = h->D;
     const int64_t n = h->n;
     if (h->f_pack_n != n) return CVTMI_OK;   // no operand copy (flat_prepare could not build it): the row-tile kernels answer
-    const int64_t ns = std::max<int64_t>(65536, (n / 32 + 63) / 64 * 64);
+    // (at least 262 144 rows where the table has twice that: the smallest sample the streaming kernel takes -- through the row-tile
+    //  kernels a sample costs ~1 ms whatever its size)
+    const int64_t ns = std::max<int64_t>(n >= 2 * 262144 ? 262144 : 65536, (n / 32 + 63) / 64 * 64);
     const int cap = std::min(4096 - k, (48 * k + 1024 + 63) / 64 * 64);
     const uint64_t pair_cap64 = (uint64_t)nq * cap;
     const uint32_t pair_cap = pair_cap64 > 0x7ffffff0ull ? 0x7ffffff0u : (uint32_t)pair_cap64;
@@ -1774,8 +1784,11 @@ static int flat_search_filtered_u8(cvtmi_flat_t h, FlatScratch &S, const uint8_t
     };
     // (a two-level sample -- exact kernels on ns / 8 rows, a first filter stage up to ns, as the fp32 path does -- was measured and lost:
     //  the second stage's launches and host sync cost more than the 1.2 ms of exact search they save; nq = 1000: 6.4 -> 7.0 ms)
-    // (the sample through the streaming kernel: 10 M x 512-d nq = 256 2.5 -> 1.8 ms in all, but 32 passes for nq = 4096 cost 6 ms against 2.1)
-    CVTMI_TRY(flat_search_rows(h, S, ns, q, nq, k, S.f_sd.as<float>(), S.f_si.as<int64_t>(), st, 2));
+    // The sample goes through the streaming kernel (128 queries per pass, ~0.12 ms per pass over 312 K rows) while that is cheaper than the
+    // row-tile kernels' exact search of it (1.0-2.1 ms whatever the batch: every query block warms its thresholds up from scratch): up to
+    // ten passes.  10 M x 512-d, k = 10 (tools/sweep_u8_sample.py, round 5): nq = 256 2.6 -> 1.6 ms, 384 / 512 3.9 -> 3.0, 640 / 768
+    // 5.2 -> 4.5, 1000 6.3 -> 5.9-6.0, 1280 7.6 -> 7.4; equal at 1536, slower from 2048 on (16 passes 11.4 against 11.15 ms).
+    CVTMI_TRY(flat_search_rows(h, S, ns, q, nq, k, S.f_sd.as<float>(), S.f_si.as<int64_t>(), st, g_flat_u8_sample_passes.load()));
     CVTMI_TRY(stage(ns, n, S.f_sd.as<float>(), S.f_si.as<int64_t>(), dist, rows));
     h->f_last_worst = (long long)worst;
     if (worst > (uint32_t)cap) return CVTMI_OK;
@@ -1807,7 +1820,14 @@ static FlatRoute flat_route(const cvtmi_flat_s *h, const void *q, int64_t nq, in
     // flat_variant 2 forces the pipeline wherever it applies, 1 forbids it.
     // (from 256 queries at every width: 10 M x 128-d nq = 256 / 512 / 1000 1.52 / 2.78 / 5.5 ms in streaming passes, 1.03 / 2.08 / 3.25 here;
     //  256-d nq = 256 1.87 against 1.26; between 257 and ~400 queries the two are within 5 %)
-    const bool u8_auto = g_flat_variant == 0 && flat_u8_gfilter_shape(h->D) && nq >= 256 && h->n >= (1 << 20) && k <= 64;
+    // Round 5 (tools/sweep_u8_dispatch.py, profiles/r05_u8_dispatch_sweep.txt): once the pipeline's sample could go through the streaming
+    // kernel on tables of any size (flat_search_filtered_u8: at least 262 144 sample rows) it beats the passes from ~1.3e11 row bytes x
+    // queries on, at every width and table size measured (128 / 256 / 512-d, 0.6 .. 10 M rows, k = 10 / 64) -- 10 M x 512-d from 129
+    // queries (2.2 -> 1.6 ms), 2 M x 512-d from 129 as well (256 queries: 1.47 ms under the old rule, which took the pipeline with a
+    // row-tile sample, 0.49 now), 1 M x 128-d from ~1000; below that the two are within 5-20 % with the passes ahead.
+    const bool u8_auto = g_flat_variant == 0 && flat_u8_gfilter_shape(h->D) && nq >= g_flat_u8_filter_min_nq.load() &&
+                         h->n >= g_flat_u8_filter_min_rows.load() && k <= 64 &&
+                         (double)h->n * (double)h->D * (double)nq >= 1e9 * (double)g_flat_u8_filter_min_work.load();
     r.filt_u8 = (g_flat_variant == 2 || u8_auto) && h->metric == CVTMI_METRIC_L2U8 && aligned && nq <= 65535 * 256 && h->norms.p &&
                 flat_u8_filter_applies(h->D, std::max<int64_t>(h->n, 262144), std::max<int64_t>(nq, 256), k) && h->n >= 2 * 65536;
     return r;

@@ -100,6 +100,11 @@ int cvtmi_set_device(int device);
  *   "scan_tail_splits" adc_scan16q, query groups past the last full round of workgroups: 0 (default) = cut them into 2 / 4 / 8 row
  *                     splits while that still leaves at most one workgroup per CU (a last round is only expensive while it leaves CUs
  *                     empty: 4256 queries over 1 M rows 2.11 -> 2.79 M queries/s, 10 000 queries unchanged); -1 = never; S > 0 = S splits
+ *   "flat_u8_filter_min_nq" / "flat_u8_filter_min_rows" / "flat_u8_filter_min_work"  uint8 search: the sample + matrix-core filter pipeline
+ *                     answers from this many queries (default 129), rows (524 288) and rows x width x queries in units of 1e9
+ *                     (130) on; below, passes of up to 128 queries through the streaming kernel (round 5: the fitted crossover)
+ *   "flat_u8_sample_passes" the uint8 filter pipeline searches its leading sample exactly through the streaming kernel while that takes at
+ *                     most this many 128-query passes (default 10: batches up to 1280 queries), through the row-tile kernels beyond
  *   "flat_small_zero_copy" 1 (default) = a small host-pointer flat search (queries <= 64 KB, lists <= 768 KB: the brute_force CLI's one
  *                     searchKnn per query) sends its queries up from a page-locked staging area and lets the last kernel write the
  *                     lists into that area (1 M x 128-d, one query: 137 -> 125 us per call); 0 = three copy-engine copies
