@@ -1249,7 +1249,14 @@ ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int 
     // 7 = choose: the persistent grid (6) wherever a query group is cut into row segments -- its segments share one histogram per query, so
     // the candidates a segment has to store while its bound is loose fall with the split count (1 M rows: nq = 128 0.24 -> 0.20 ms wall,
     // 1000 0.59 -> 0.47, 3000 1.23 -> 1.10); whole groups (nq > 3200 at 1 M rows) run 4 % faster on adc_scan16q
-    if (want_variant == 7) want_variant = (m.M == 16 && nq >= 100 && nq <= 3200 && n_rows >= 131072 && n_rows * 16 <= (96LL << 20)) ? 6 : 3;
+    // Round 5 swept the table size as well (tools/sweep_scan_dispatch.py, profiles/r05_scan_dispatch_sweep.txt): on a code matrix that
+    // still fits the Infinity Cache (<= 256 MB: 16 M rows) the persistent grid stays ahead up to 512 queries (10 M rows: 64 / 128 / 256 /
+    // 512 queries 0.37 / 0.57 / 0.84 / 1.63 ms against 0.53 / 0.67 / 0.96 / 1.81), level from 1000; and it is ahead from ~33 queries on, not
+    // 100 (what the small-batch form does not take: api.hip scans_chosen).  Beyond 16 M rows the two are within a few per cent.
+    if (want_variant == 7) {
+        const bool resident = n_rows * 16 <= (96LL << 20), near = n_rows * 16 <= (256LL << 20);
+        want_variant = (m.M == 16 && n_rows >= 131072 && nq >= 33 && ((resident && nq <= 3200) || (near && nq <= 512))) ? 6 : 3;
+    }
     if (m.M == 16 && want_variant >= 3 && (nq >= 4 || want_variant == 6) && m.D <= 256) { p.variant = want_variant; qt = 8; }
     else if (m.M == 16 && want_variant >= 1) {
         if (want_variant <= 2 && (want_qtile == 0 || want_qtile == 4) && nq >= 4) { p.variant = want_variant; qt = 4; }

@@ -337,6 +337,7 @@ static bool host_pinned(const void *p)
 
 static std::atomic<int> g_hnsw_slots_cap{0};   // cvtmi_set_tuning("hnsw_slots"): cap on traversals per CU (0 = what LDS allows, at most 32)
 static std::atomic<int> g_small_zero_copy{1};   // cvtmi_set_tuning("opq_small_zero_copy"): 1 .. 8-query host-pointer searches read / write the pinned staging area from the kernels
+static std::atomic<int64_t> g_scans_max_work{(int64_t)48 << 20};   // cvtmi_set_tuning("scans_max_work"): rows x query groups up to which the OPQ small-batch form answers (scans_chosen)
 static std::atomic<int> g_flat_u8_filter_min_nq{129};            // cvtmi_set_tuning("flat_u8_filter_min_nq" / "_min_rows" / "_min_work"): smallest batch, table and
 static std::atomic<int64_t> g_flat_u8_filter_min_rows{524288};   // rows x width x queries (in 1e9) the dispatch hands to the uint8 sample + filter pipeline
 static std::atomic<int64_t> g_flat_u8_filter_min_work{130};
@@ -477,6 +478,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "sq8_filter")) { set_sq8_filter(value != 0); return CVTMI_OK; }
+    if (!strcmp(name, "scans_max_work")) { g_scans_max_work = value < 0 ? 0 : value; return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_filter_min_nq")) { g_flat_u8_filter_min_nq = value < 1 ? 1 : value > (1 << 30) ? (1 << 30) : (int)value; return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_filter_min_rows")) { g_flat_u8_filter_min_rows = value < 0 ? 0 : value; return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_filter_min_work")) { g_flat_u8_filter_min_work = value < 0 ? 0 : value; return CVTMI_OK; }
@@ -943,12 +945,22 @@ static int opq_prepare(cvtmi_opq_t h, int64_t nq, int k, hipStream_t st)
     return CVTMI_OK;
 }
 
+// Does the dispatch take the small-batch form (adc_scan_h.hip: scans, up to 128 queries)?  Its per-group passes over the whole table
+// were fitted at 1 M rows; round 5 swept the table size (tools/sweep_scan_dispatch.py, profiles/r05_scan_dispatch_sweep.txt): it is
+// ahead of the persistent grid while rows x query groups stays under ~48 M (2 M rows: up to 128 queries; 10 M: up to 32; 30 M: 8)
+// and behind by up to 2x beyond (100 M rows, 128 queries: 8.3 against 3.7 ms).
+static bool scans_chosen(const cvtmi_opq_s *h, int64_t nq, int k)
+{
+    return h->p_variant == 7 && h->p_splits == 0 && h->p_qtile == 0 && h->p_small && scans_applies(h->m, h->n, nq, k) &&
+           h->n * ((nq + 7) / 8) <= g_scans_max_work.load();
+}
+
 // one search on stream st with the scratch set S; the caller holds h->rw shared
 static int opq_search_leased(cvtmi_opq_t h, OpqScratch &S, const float *q, int64_t nq, int rotate, int k, float *dist, int64_t *ids, hipStream_t st)
 {
     if (h->n == 0)  // an empty index (e.g. a rank whose row block is empty): all padding, (+inf, -1)
         return launch_topk_select(nullptr, nullptr, nq, 0, k, dist, ids, st);
-    if (h->p_variant == 7 && h->p_splits == 0 && h->p_qtile == 0 && h->p_small && scans_applies(h->m, h->n, nq, k)) {
+    if (scans_chosen(h, nq, k)) {
         // 1 .. 128 queries (up to sixteen query groups): global bounds first, candidate lists, one selection workgroup per query
         // (adc_scan_h.hip) -- four launches, the rotation folded into the first
         const uint8_t *crot = (h->m.M == 16 && h->p_prerot && h->rot_n == h->n && h->codes_rot.p) ? h->codes_rot.as<uint8_t>() : nullptr;
@@ -1133,8 +1145,7 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
     // Small batches (the reference's call pattern: a handful of frames per Query; here whatever takes the small-batch path, up to 128
     // queries): the copies are a third of such a call.  The table kernel reads the queries and the selection kernel writes the results straight from / to the pinned staging area (page-locked
     // host memory is device-visible: one PCIe read of the queries, posted writes of the lists) -- no copy engine in the chain.
-    if (chunks == 1 && g_small_zero_copy.load() && h->n > 0 && h->p_variant == 7 && h->p_splits == 0 && h->p_qtile == 0 && h->p_small &&
-        scans_applies(h->m, h->n, nq, k)) {
+    if (chunks == 1 && g_small_zero_copy.load() && h->n > 0 && scans_chosen(h, nq, k)) {
         OpqScratch &S = *lease[0].s;
         hipStream_t st = lease[0].st;
         void *pin_dev = nullptr;

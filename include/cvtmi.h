@@ -100,6 +100,9 @@ int cvtmi_set_device(int device);
  *   "scan_tail_splits" adc_scan16q, query groups past the last full round of workgroups: 0 (default) = cut them into 2 / 4 / 8 row
  *                     splits while that still leaves at most one workgroup per CU (a last round is only expensive while it leaves CUs
  *                     empty: 4256 queries over 1 M rows 2.11 -> 2.79 M queries/s, 10 000 queries unchanged); -1 = never; S > 0 = S splits
+ *   "scans_max_work"  OPQ search: the small-batch form (<= 128 queries) answers while rows x query groups stays at or under this
+ *                     (default 48 << 20; beyond, its per-group passes over the table lose to the persistent grid: 100 M rows,
+ *                     128 queries 8.3 against 3.7 ms)
  *   "flat_u8_filter_min_nq" / "flat_u8_filter_min_rows" / "flat_u8_filter_min_work"  uint8 search: the sample + matrix-core filter pipeline
  *                     answers from this many queries (default 129), rows (524 288) and rows x width x queries in units of 1e9
  *                     (130) on; below, passes of up to 128 queries through the streaming kernel (round 5: the fitted crossover)
