@@ -2061,7 +2061,7 @@ int cvtmi_sq8_train_dev(const float *x, int64_t n, int d, int l2norm, float *vmi
     if (n < 0 || d < 1 || !vmin || !vdiff || (n > 0 && !x)) return fail(CVTMI_EINVAL, "cvtmi_sq8_train: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     Tmp den, keys;
-    if (l2norm && n > 0 && !sq8_single_pass(d, x, nullptr, nullptr, nullptr)) CVTMI_TRY(den.alloc((size_t)n * sizeof(float)));
+    if (l2norm && n > 0 && !sq8_single_pass(d, x, nullptr, nullptr, nullptr, n)) CVTMI_TRY(den.alloc((size_t)n * sizeof(float)));
     CVTMI_TRY(keys.alloc((size_t)d * 2 * sizeof(uint32_t)));
     CVTMI_TRY(launch_sq8_train(x, n, d, l2norm, den.as<float>(), keys.as<uint32_t>(), keys.as<uint32_t>() + d, vmin, vdiff,
                                st));
@@ -2089,7 +2089,7 @@ int cvtmi_sq8_encode_dev(const float *vmin, const float *vdiff, int d, float *x,
     if (n == 0) return CVTMI_OK;
     hipStream_t st = (hipStream_t)stream;
     Tmp den;
-    const bool two_pass = l2norm && !sq8_single_pass(d, x, codes, vmin, vdiff);
+    const bool two_pass = l2norm && !sq8_single_pass(d, x, codes, vmin, vdiff, n);
     if (two_pass) CVTMI_TRY(den.alloc((size_t)n * sizeof(float)));
     CVTMI_TRY(launch_sq8_encode_rows(vmin, vdiff, d, x, n, l2norm ? 1 : 0, l2norm == 2 ? 0 : 1, codes, den.as<float>(), st));
     if (two_pass) CVTMI_HIP(stream_wait(st));  // the temporary dies with this frame

@@ -244,7 +244,7 @@ int launch_sq8_decode(const float *vmin, const float *vdiff, int d, const uint8_
 int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_scratch, uint32_t *kmin, uint32_t *kmax,
                      float *vmin, float *vdiff, hipStream_t st);
 // true when (d, pointers) take the single-pass kernel, i.e. no den_scratch is needed
-bool sq8_single_pass(int d, const void *x, const void *codes, const void *vmin, const void *vdiff);
+bool sq8_single_pass(int d, const void *x, const void *codes, const void *vmin, const void *vdiff, int64_t n = 0);   // n: rows of the call (the wave kernels take >= 4096)
 
 // ---- kmeans.hip (codebook training) ----
 // assign[r] = nearest of cent[k][d] (first minimum; -1 when no distance is below float(UINT_MAX)); *changed +=

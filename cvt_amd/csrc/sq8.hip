@@ -230,9 +230,11 @@ __global__ __launch_bounds__(SQ_NT) void sq8_tile_kernel(const Sq8Args a)
 }
 
 static bool sq8_tile_ok(int d, const void *x, const void *codes, const void *vmin, const void *vdiff);
-bool sq8_single_pass(int d, const void *x, const void *codes, const void *vmin, const void *vdiff)
+static bool sq8_wave_takes(int d, int64_t n, const void *x, const void *codes, const void *vmin, const void *vdiff);
+// true: the launchers below need no per-row norm scratch for this call (the tile kernel, or the wave-per-row kernels)
+bool sq8_single_pass(int d, const void *x, const void *codes, const void *vmin, const void *vdiff, int64_t n)
 {
-    return sq8_tile_ok(d, x, codes, vmin, vdiff);
+    return sq8_tile_ok(d, x, codes, vmin, vdiff) || sq8_wave_takes(d, n, x, codes, vmin, vdiff);
 }
 static bool sq8_tile_ok(int d, const void *x, const void *codes, const void *vmin, const void *vdiff)
 {
@@ -336,14 +338,27 @@ int launch_sq8_encode(const float *vmin, const float *vdiff, int d, float *x, in
 
 static int launch_sq8_encode_wave(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm, int write_back,
                                   uint8_t *codes, hipStream_t st);
-static int g_sq8_encode_wave = 1;   // cvtmi_set_tuning("sq8_encode_wave"): 0 = the tile kernel for every width
+// row widths the wave-per-row filter kernels take: 256 NF floats with NF in {1, 2, 3, 4, 6, 8} -- 256 ... 2048-d (round 5: beyond 512-d
+// the rows used to go through a row-norm pass + the generic kernels: 0.8 TB/s with normalisation, 3.3 without)
+static bool sq8_wave_width(int d) { return d == 256 || d == 512 || d == 768 || d == 1024 || d == 1536 || d == 2048; }
+static bool sq8_wave_aligned(const void *x, const void *codes, const void *vmin, const void *vdiff)
+{
+    return ((uintptr_t)x & 15) == 0 && ((uintptr_t)codes & 3) == 0 && ((uintptr_t)vmin & 15) == 0 && ((uintptr_t)vdiff & 15) == 0;
+}
+static bool sq8_filter_on();
+static int g_sq8_encode_wave = 1;
+// (conservative: both the training and the encode dispatch take the wave kernels under these conditions)
+static bool sq8_wave_takes(int d, int64_t n, const void *x, const void *codes, const void *vmin, const void *vdiff)
+{
+    return g_sq8_encode_wave && sq8_filter_on() && sq8_wave_width(d) && n >= 4096 && sq8_wave_aligned(x, codes, vmin, vdiff);
+}   // cvtmi_set_tuning("sq8_encode_wave"): 0 = the tile kernel for every width
 void set_sq8_encode_wave(int v) { g_sq8_encode_wave = v; }
 
 int launch_sq8_encode_rows(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm, int write_back,
                            uint8_t *codes, float *den_scratch, hipStream_t st)
 {
     if (n <= 0) return CVTMI_OK;
-    if (g_sq8_encode_wave && (d == 256 || d == 512) && n >= 4096 && sq8_tile_ok(d, x, codes, vmin, vdiff))
+    if (g_sq8_encode_wave && sq8_wave_width(d) && n >= 4096 && sq8_wave_aligned(x, codes, vmin, vdiff) && (d <= 512 || sq8_filter_on()))
         return launch_sq8_encode_wave(vmin, vdiff, d, x, n, l2norm, write_back, codes, st);
     if (sq8_tile_ok(d, x, codes, vmin, vdiff)) {
         Sq8Args a{};
@@ -836,7 +851,7 @@ __global__ __launch_bounds__(kBlock) void sq8_encode_wave_f_kernel(const float *
         cf[i][0] = sq8_col_filter(l4.x, d4.x); cf[i][1] = sq8_col_filter(l4.y, d4.y);
         cf[i][2] = sq8_col_filter(l4.z, d4.z); cf[i][3] = sq8_col_filter(l4.w, d4.w);
     }
-    constexpr int RB = 4;
+    constexpr int RB = NF <= 2 ? 4 : NF <= 4 ? 2 : 1;   // rows in flight per wave: 8 KB either way
     float4 cur[RB][NF], nxt[RB][NF];
     auto fetch = [&](int64_t row, float4 (&o)[NF]) {
         const int64_t r = row < n ? row : n - 1;  // clamped: rows past the end are computed, never stored
@@ -967,9 +982,10 @@ __device__ __forceinline__ float sq8_thr_hi(float mx)   // p' <= this  =>  a <= 
 }
 
 // seeded != 0: every lane starts from the column extremes already in kmin / kmax (the sample pass)
-template <int NF>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void sq8_train_wave_f_kernel(const float *__restrict__ x, int64_t n, uint32_t *kmin,
-                                                                  uint32_t *kmax, int seeded, int flags)
+// NORM = false (turn_off_l2norm): a = v exactly -- the thresholds decide on p' = v 2^60 alike, a candidate IS its own quotient
+template <int NF, bool NORM>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NF <= 4 ? 3 : 2, NF <= 4 ? 3 : 2))) void sq8_train_wave_f_kernel(
+    const float *__restrict__ x, int64_t n, uint32_t *kmin, uint32_t *kmax, int seeded, int flags)
 {
     const bool dpp = (flags & 1) != 0;
     constexpr int CG = 64 * NF, D = 4 * CG;
@@ -991,7 +1007,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
             tlo[i][j] = sq8_thr_lo(mn[i][j]);
             thi[i][j] = sq8_thr_hi(mx[i][j]);
         }
-    constexpr int RB = 4;
+    constexpr int RB = NF <= 2 ? 4 : NF <= 4 ? 2 : 1;
     float4 cur[RB][NF], nxt[RB][NF];
     auto fetch = [&](int64_t row, float4 (&o)[NF]) {
         const int64_t r = row < n ? row : n - 1;  // clamped: the tail re-reads the last row, which changes no extreme
@@ -1007,6 +1023,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
             for (int i = 0; i < NF; ++i) cur[p][i] = nxt[p][i];
             fetch(row + (p + RB) * nw, nxt[p]);
         }
+        float den = 1.0f;
+        if constexpr (NORM) {
         double s[RB];
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
@@ -1022,7 +1040,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
 #pragma unroll
         for (int p = 1; p < RB; ++p) mine = lane == p ? s[p] : mine;
         const double rlo = __dsqrt_rn(mine * (1.0 - 0x1p-42)), rhi = __dsqrt_rn(mine * (1.0 + 0x1p-42));
-        float den = (float)(rlo > 1e-12 ? rlo : 1e-12);
+        den = (float)(rlo > 1e-12 ? rlo : 1e-12);
         const float fhi = (float)(rhi > 1e-12 ? rhi : 1e-12);
         const unsigned long long unproven = __ballot(lane < RB && !(den == fhi));
         if (unproven) {  // rare: not proven, or not finite -- the reference's own order for those rows (int8_quan.cc:48-51)
@@ -1039,6 +1057,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
                     if (lane == p) den = (float)(nrm > 1e-12 ? nrm : 1e-12);
                 }
             }
+        }
         }
         const DivBy dl = div_by(den);
 #pragma unroll
@@ -1061,7 +1080,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (open[j]) {
-                            const float a = div_rn(e[j], dd);
+                            const float a = NORM ? div_rn(e[j], dd) : e[j];
                             if (a < mn[i][j]) { mn[i][j] = a; tlo[i][j] = sq8_thr_lo(a); }
                             if (a > mx[i][j]) { mx[i][j] = a; thi[i][j] = sq8_thr_hi(a); }
                         }
@@ -1084,6 +1103,7 @@ static std::atomic<int> g_sq8_flags{1};    // cvtmi_set_tuning("sq8_flags"): bit
 void set_sq8_flags(int v) { g_sq8_flags = v; }
 static std::atomic<int> g_sq8_filter{1};   // cvtmi_set_tuning("sq8_filter"): 0 = the exact chain for every element (the round 2 - 4 kernels)
 void set_sq8_filter(int v) { g_sq8_filter = v != 0 ? 1 : 0; }
+static bool sq8_filter_on() { return g_sq8_filter.load() != 0; }
 constexpr int64_t SQ8_SAMPLE_ROWS = 8192;   // rows of the training pass that seeds every wave's extremes
 
 // ---- the sign of a zero minimum (round 5) ----------------------------------------------------------------------------------
@@ -1136,6 +1156,24 @@ __global__ __launch_bounds__(kBlock) void sq8_zero_sign_kernel(const float *__re
 // workgroups per CU of the wave-per-row training kernel.  A wave keeps RB rows in flight that lie (waves in the grid) rows apart: with a
 // power-of-two grid those streams are a power-of-two distance apart and fall on the same HBM channels -- measured on 2 M x 512-d:
 // 8 per CU 4.62-4.67 TB/s, 4: 4.38, 16: 4.89, 3: 5.04, 24: 5.09 (tools: cvtmi_set_tuning("sq8_wave_blocks"))
+template <bool NORM>
+static void launch_sq8_train_wave_f_n(int NF, unsigned blocks, hipStream_t st, const float *x, int64_t n, uint32_t *kmin, uint32_t *kmax, int seeded, int flags)
+{
+    switch (NF) {
+        case 1: hipLaunchKernelGGL((sq8_train_wave_f_kernel<1, NORM>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax, seeded, flags); break;
+        case 2: hipLaunchKernelGGL((sq8_train_wave_f_kernel<2, NORM>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax, seeded, flags); break;
+        case 3: hipLaunchKernelGGL((sq8_train_wave_f_kernel<3, NORM>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax, seeded, flags); break;
+        case 4: hipLaunchKernelGGL((sq8_train_wave_f_kernel<4, NORM>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax, seeded, flags); break;
+        case 6: hipLaunchKernelGGL((sq8_train_wave_f_kernel<6, NORM>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax, seeded, flags); break;
+        default: hipLaunchKernelGGL((sq8_train_wave_f_kernel<8, NORM>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax, seeded, flags); break;
+    }
+}
+static void launch_sq8_train_wave_f(int NF, bool norm, unsigned blocks, hipStream_t st, const float *x, int64_t n, uint32_t *kmin, uint32_t *kmax, int seeded,
+                                    int flags)
+{
+    if (norm) launch_sq8_train_wave_f_n<true>(NF, blocks, st, x, n, kmin, kmax, seeded, flags);
+    else launch_sq8_train_wave_f_n<false>(NF, blocks, st, x, n, kmin, kmax, seeded, flags);
+}
 static int g_sq8_wave_blocks = 3;
 void set_sq8_wave_blocks(int v) { g_sq8_wave_blocks = v; }
 // den_scratch: n floats, only used for row widths the tile kernel does not take
@@ -1145,23 +1183,22 @@ int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_sc
     const unsigned db = (unsigned)((d + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(sq8_train_init_kernel, dim3(db), dim3(kBlock), 0, st, kmin, kmax, d);
     if (n > 0) {
-        if (l2norm && (d == 256 || d == 512) && (((uintptr_t)x) & 15) == 0 && n >= 4096) {
+        // the wave-per-row kernels: normalised rows of 256 / 512 floats as before; round 5: through the filter kernel also rows of 768 ...
+        // 2048 floats, and those without normalisation (the tile kernel stops at 512-d; the generic kernels ran at 0.8 / 3.3 TB/s)
+        const bool wave_f = sq8_filter_on() && sq8_wave_width(d);   // (without normalisation too: 4 M x 512-d 5.75 TB/s through the tile kernel, 6.3 here)
+        if ((wave_f || (l2norm && (d == 256 || d == 512))) && (((uintptr_t)x) & 15) == 0 && n >= 4096) {
             // whole rows per wave, no LDS tile (the tile kernel's phases serialise behind its barriers: 3.3 TB/s at d = 512)
             const int64_t rows_per_wg = kBlock / 64;
             const unsigned blocks = (unsigned)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 256 * g_sq8_wave_blocks);
-            if (g_sq8_filter.load()) {
+            if (wave_f) {
                 // sample pass over the first rows (its extremes seed every wave of the main pass: "new extreme" is rare from the start),
                 // then the rest; both through the filter kernel, the sample unseeded
                 const int64_t ns = n >= 8 * SQ8_SAMPLE_ROWS ? SQ8_SAMPLE_ROWS : 0;
                 const float *xr = x + ns * d;
                 const unsigned sblocks = (unsigned)((ns / 16 + rows_per_wg - 1) / rows_per_wg);   // 16 rows per wave of the sample
-                if (d == 512) {
-                    if (ns) hipLaunchKernelGGL((sq8_train_wave_f_kernel<2>), dim3(sblocks), dim3(kBlock), 0, st, x, ns, kmin, kmax, 0, g_sq8_flags.load());
-                    hipLaunchKernelGGL((sq8_train_wave_f_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, xr, n - ns, kmin, kmax, ns ? 1 : 0, g_sq8_flags.load());
-                } else {
-                    if (ns) hipLaunchKernelGGL((sq8_train_wave_f_kernel<1>), dim3(sblocks), dim3(kBlock), 0, st, x, ns, kmin, kmax, 0, g_sq8_flags.load());
-                    hipLaunchKernelGGL((sq8_train_wave_f_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, xr, n - ns, kmin, kmax, ns ? 1 : 0, g_sq8_flags.load());
-                }
+                const int fl = g_sq8_flags.load();
+                if (ns) launch_sq8_train_wave_f(d / 256, l2norm != 0, sblocks, st, x, ns, kmin, kmax, 0, fl);
+                launch_sq8_train_wave_f(d / 256, l2norm != 0, blocks, st, xr, n - ns, kmin, kmax, ns ? 1 : 0, fl);
             } else if (d == 512) hipLaunchKernelGGL((sq8_train_wave_kernel<2>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax);
             else hipLaunchKernelGGL((sq8_train_wave_kernel<1>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax);
         } else if (sq8_tile_ok(d, x, nullptr, nullptr, nullptr)) {
@@ -1197,10 +1234,20 @@ static int launch_sq8_encode_wave(const float *vmin, const float *vdiff, int d, 
     const unsigned blocks = (unsigned)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 256 * g_sq8_wave_blocks);
     if (g_sq8_filter.load()) {
         const int fl = g_sq8_flags.load();
-        if (d == 512 && l2norm) hipLaunchKernelGGL((sq8_encode_wave_f_kernel<2, true>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes, fl);
-        else if (d == 512) hipLaunchKernelGGL((sq8_encode_wave_f_kernel<2, false>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, 0, codes, fl);
-        else if (l2norm) hipLaunchKernelGGL((sq8_encode_wave_f_kernel<1, true>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes, fl);
-        else hipLaunchKernelGGL((sq8_encode_wave_f_kernel<1, false>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, 0, codes, fl);
+#define CVTMI_SQ8_ENC(NF_)                                                                                                                                    \
+        do {                                                                                                                                                  \
+            if (l2norm) hipLaunchKernelGGL((sq8_encode_wave_f_kernel<NF_, true>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes, fl); \
+            else hipLaunchKernelGGL((sq8_encode_wave_f_kernel<NF_, false>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, 0, codes, fl);                 \
+        } while (0)
+        switch (d / 256) {
+            case 1: CVTMI_SQ8_ENC(1); break;
+            case 2: CVTMI_SQ8_ENC(2); break;
+            case 3: CVTMI_SQ8_ENC(3); break;
+            case 4: CVTMI_SQ8_ENC(4); break;
+            case 6: CVTMI_SQ8_ENC(6); break;
+            default: CVTMI_SQ8_ENC(8); break;
+        }
+#undef CVTMI_SQ8_ENC
         CVTMI_HIP(hipGetLastError());
         return CVTMI_OK;
     }

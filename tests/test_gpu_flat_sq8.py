@@ -353,8 +353,8 @@ def test_sq8_train_sign_of_a_zero_minimum(amd, orc, d, n, l2):
     assert np.array_equal(bits(hv), bits(ovm)) and np.array_equal(bits(hd), bits(ovd))
 
 
-@pytest.mark.parametrize("d", [512, 256])
-@pytest.mark.parametrize("kind", ["relu", "signed", "wide"])
+@pytest.mark.parametrize("d,kind", [(d, k) for d in (512, 256) for k in ("relu", "signed", "wide")] +
+                         [(768, "relu"), (1024, "wide"), (1536, "signed"), (2048, "relu"), (2048, "wide")])
 def test_sq8_decision_filter_equals_the_chain(amd, orc, d, kind):
     """Round 5: the wave kernels decide most code bytes / column extremes from a bounded approximation and run the reference's chain
     (two correctly rounded divisions + the byte, int8_quan.cc:46-56, :79-92) only where that cannot decide.  Codes, written-back rows and
@@ -363,7 +363,7 @@ def test_sq8_decision_filter_equals_the_chain(amd, orc, d, kind):
     |vmin| >> vdiff, a NaN range), zero rows, huge rows, a non-finite row, negative zeros."""
     import torch
     rng = np.random.default_rng(d + len(kind))
-    n = 30_000 + 41
+    n = (30_000 if d <= 512 else 9_000) + 41     # (round 5: the same kernels take rows of 768 ... 2048 floats, fewer rows in flight per wave)
     x = rng.normal(size=(n, d)).astype(np.float32)
     if kind == "relu":
         x = np.maximum(x, 0)
@@ -401,21 +401,24 @@ def test_sq8_decision_filter_equals_the_chain(amd, orc, d, kind):
         if l2 == 0:   # (no normalisation: every finite ROW is comparable, whatever its norm would have been)
             fin = np.all(np.isfinite(x), axis=1)
             assert np.array_equal(got[1][0][fin][:, fin_cols], oc[fin][:, fin_cols])
-    # training: extremes of the normalised rows, sample pass + seeded main pass
+    # training: extremes of the (normalised) rows, sample pass + seeded main pass; without normalisation the wave kernels take the rows
+    # wider than the tile kernel's 512 floats
     xf = x[np.all(np.isfinite(x), axis=1)]
-    ovmin, ovdiff = orc.sq8_train(xf.copy(), l2norm=True)
-    res = {}
-    try:
-        for filt in (1, 2, 0):
-            amd.set_tuning("sq8_filter", 1 if filt else 0)
-            amd.set_tuning("sq8_flags", 0 if filt == 2 else 1)
-            for rows in (xf, np.tile(xf, (3, 1))):                           # 3 x: past the 8 x 8192 rows that switch the sample pass on
-                tv, td = amd.sq8_train(torch.from_numpy(rows.copy()).cuda(), l2norm=True)
-                res[(filt, len(rows))] = (tv.cpu().numpy(), td.cpu().numpy())
-    finally:
-        amd.set_tuning("sq8_filter", 1); amd.set_tuning("sq8_flags", 1)
-    for key, (tv, td) in res.items():
-        assert _same_min(tv, ovmin) and np.array_equal(bits(td), bits(ovdiff)), (kind, d, key)
+    times = 3 if d <= 512 else 8                                             # past the 8 x 8192 rows that switch the sample pass on
+    for l2 in (True, False):
+        ovmin, ovdiff = orc.sq8_train(xf.copy(), l2norm=l2)
+        res = {}
+        try:
+            for filt in (1, 2, 0):
+                amd.set_tuning("sq8_filter", 1 if filt else 0)
+                amd.set_tuning("sq8_flags", 0 if filt == 2 else 1)
+                for rows in (xf, np.tile(xf, (times, 1))):
+                    tv, td = amd.sq8_train(torch.from_numpy(rows.copy()).cuda(), l2norm=l2)
+                    res[(filt, len(rows))] = (tv.cpu().numpy(), td.cpu().numpy())
+        finally:
+            amd.set_tuning("sq8_filter", 1); amd.set_tuning("sq8_flags", 1)
+        for key, (tv, td) in res.items():
+            assert _same_min(tv, ovmin) and np.array_equal(bits(td), bits(ovdiff)), (kind, d, l2, key)
 
 
 def test_sq8_parity(amd, orc, golden):
