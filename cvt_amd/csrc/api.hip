@@ -338,6 +338,7 @@ static bool host_pinned(const void *p)
 static std::atomic<int> g_hnsw_slots_cap{0};   // cvtmi_set_tuning("hnsw_slots"): cap on traversals per CU (0 = what LDS allows, at most 32)
 static std::atomic<int> g_small_zero_copy{1};   // cvtmi_set_tuning("opq_small_zero_copy"): 1 .. 8-query host-pointer searches read / write the pinned staging area from the kernels
 static std::atomic<int64_t> g_scans_max_work{(int64_t)48 << 20};   // cvtmi_set_tuning("scans_max_work"): rows x query groups up to which the OPQ small-batch form answers (scans_chosen)
+static std::atomic<int> g_sq8_host_small{1};     // cvtmi_set_tuning("sq8_host_small"): small SQ8 host-pointer calls run out of a page-locked scratch area (Sq8HostScratch)
 static std::atomic<int> g_flat_u8_filter_min_nq{129};            // cvtmi_set_tuning("flat_u8_filter_min_nq" / "_min_rows" / "_min_work"): smallest batch, table and
 static std::atomic<int64_t> g_flat_u8_filter_min_rows{524288};   // rows x width x queries (in 1e9) the dispatch hands to the uint8 sample + filter pipeline
 static std::atomic<int64_t> g_flat_u8_filter_min_work{130};
@@ -478,6 +479,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "sq8_filter")) { set_sq8_filter(value != 0); return CVTMI_OK; }
+    if (!strcmp(name, "sq8_host_small")) { g_sq8_host_small = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "scans_max_work")) { g_scans_max_work = value < 0 ? 0 : value; return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_filter_min_nq")) { g_flat_u8_filter_min_nq = value < 1 ? 1 : value > (1 << 30) ? (1 << 30) : (int)value; return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_filter_min_rows")) { g_flat_u8_filter_min_rows = value < 0 ? 0 : value; return CVTMI_OK; }
@@ -2096,10 +2098,83 @@ int cvtmi_sq8_encode_dev(const float *vmin, const float *vdiff, int d, float *x,
     return CVTMI_OK;
 }
 
+}  // extern "C"
+
+// Small SQ8 calls through the host-pointer entries -- the reference encodes and decodes ONE feature vector per call (int8_quan.cc:72-132) --
+// used to pay four device allocations, four copies and four frees per call (65-80 us, 270 at 2048-d).  They now run out of a page-locked
+// scratch area: the model, the rows and the results live in device-visible host memory, the kernels read and write it directly
+// (everything is touched once), and nothing is allocated per call.  The areas are kept per device for the life of the process (a handful
+// of 1 MB buffers; the SQ8 entries have no handle that could own them).
+namespace {
+struct Sq8HostScratch {
+    PinBuf pin;
+    hipStream_t st = nullptr;
+    int device = -1;
+    bool busy = false;
+};
+std::mutex g_sq8_host_mu;
+std::vector<Sq8HostScratch *> g_sq8_host_pool;   // never shrinks, never freed (process lifetime)
+constexpr size_t SQ8_HOST_SMALL = (size_t)1 << 20;
+struct Sq8HostLease {
+    Sq8HostScratch *s = nullptr;
+    int open()
+    {
+        int dev = 0;
+        CVTMI_HIP(hipGetDevice(&dev));
+        {
+            std::lock_guard<std::mutex> g(g_sq8_host_mu);
+            for (Sq8HostScratch *c : g_sq8_host_pool)
+                if (!c->busy && c->device == dev) { s = c; break; }
+            if (!s) {
+                s = new (std::nothrow) Sq8HostScratch();
+                if (!s) return fail(CVTMI_ENOMEM, "sq8: out of host memory");
+                s->device = dev;
+                g_sq8_host_pool.push_back(s);
+            }
+            s->busy = true;
+        }
+        if (!s->st) CVTMI_HIP(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+        return s->pin.reserve(SQ8_HOST_SMALL + 4096);
+    }
+    ~Sq8HostLease()
+    {
+        if (!s) return;
+        std::lock_guard<std::mutex> g(g_sq8_host_mu);
+        s->busy = false;
+    }
+};
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+}  // namespace
+
+extern "C" {
+
 int cvtmi_sq8_encode(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm, uint8_t *codes)
 {
     if (n < 0 || d < 1 || !vmin || !vdiff || (n > 0 && (!x || !codes))) return fail(CVTMI_EINVAL, "cvtmi_sq8_encode: bad arguments");
     if (n == 0) return CVTMI_OK;
+    {
+        const size_t mb = up256((size_t)d * sizeof(float)), xb = up256((size_t)n * d * sizeof(float)), cb = up256((size_t)n * d);
+        const size_t nb = up256((size_t)n * sizeof(float));   // row norms of the widths that take two passes
+        if (g_sq8_host_small.load() && 2 * mb + xb + cb + nb <= SQ8_HOST_SMALL) {
+            Sq8HostLease lease;
+            CVTMI_TRY(lease.open());
+            void *pd_ = nullptr;
+            if (hipHostGetDevicePointer(&pd_, lease.s->pin.p, 0) == hipSuccess && pd_) {
+                char *pin = lease.s->pin.as<char>(), *pd = static_cast<char *>(pd_);
+                memcpy(pin, vmin, (size_t)d * sizeof(float));
+                memcpy(pin + mb, vdiff, (size_t)d * sizeof(float));
+                memcpy(pin + 2 * mb, x, (size_t)n * d * sizeof(float));
+                CVTMI_TRY(launch_sq8_encode_rows(reinterpret_cast<float *>(pd), reinterpret_cast<float *>(pd + mb), d, reinterpret_cast<float *>(pd + 2 * mb), n,
+                                                 l2norm ? 1 : 0, l2norm == 2 ? 0 : 1, reinterpret_cast<uint8_t *>(pd + 2 * mb + xb),
+                                                 reinterpret_cast<float *>(pd + 2 * mb + xb + cb), lease.s->st));
+                CVTMI_HIP(stream_wait(lease.s->st));
+                memcpy(codes, pin + 2 * mb + xb, (size_t)n * d);
+                if (l2norm == 1) memcpy(x, pin + 2 * mb, (size_t)n * d * sizeof(float));
+                return CVTMI_OK;
+            }
+            (void)hipGetLastError();
+        }
+    }
     Tmp dmin, ddiff, dx, dc;
     CVTMI_TRY(dmin.upload(vmin, (size_t)d * sizeof(float)));
     CVTMI_TRY(ddiff.upload(vdiff, (size_t)d * sizeof(float)));
@@ -2142,6 +2217,26 @@ static int sq8_decode_host_mode(const float *vmin, const float *vdiff, int d, co
 {
     if (n < 0 || d < 1 || !vmin || !vdiff || (n > 0 && (!x || !codes))) return fail(CVTMI_EINVAL, "cvtmi_sq8_decode: bad arguments");
     if (n == 0) return CVTMI_OK;
+    {   // small calls: out of the page-locked scratch area (see Sq8HostScratch)
+        const size_t mb = up256((size_t)d * sizeof(float)), xb = up256((size_t)n * d * sizeof(float)), cb = up256((size_t)n * d);
+        if (g_sq8_host_small.load() && 2 * mb + xb + cb <= SQ8_HOST_SMALL) {
+            Sq8HostLease lease;
+            CVTMI_TRY(lease.open());
+            void *pd_ = nullptr;
+            if (hipHostGetDevicePointer(&pd_, lease.s->pin.p, 0) == hipSuccess && pd_) {
+                char *pin = lease.s->pin.as<char>(), *pd = static_cast<char *>(pd_);
+                memcpy(pin, vmin, (size_t)d * sizeof(float));
+                memcpy(pin + mb, vdiff, (size_t)d * sizeof(float));
+                memcpy(pin + 2 * mb, codes, (size_t)n * d);
+                CVTMI_TRY(sq8_decode_dev_mode(reinterpret_cast<float *>(pd), reinterpret_cast<float *>(pd + mb), d, reinterpret_cast<uint8_t *>(pd + 2 * mb), n,
+                                              reinterpret_cast<float *>(pd + 2 * mb + cb), lease.s->st, mode));
+                CVTMI_HIP(stream_wait(lease.s->st));
+                memcpy(x, pin + 2 * mb + cb, (size_t)n * d * sizeof(float));
+                return CVTMI_OK;
+            }
+            (void)hipGetLastError();
+        }
+    }
     Tmp dmin, ddiff, dx, dc;
     CVTMI_TRY(dmin.upload(vmin, (size_t)d * sizeof(float)));
     CVTMI_TRY(ddiff.upload(vdiff, (size_t)d * sizeof(float)));

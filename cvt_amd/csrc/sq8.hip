@@ -350,7 +350,7 @@ static int g_sq8_encode_wave = 1;
 // (conservative: both the training and the encode dispatch take the wave kernels under these conditions)
 static bool sq8_wave_takes(int d, int64_t n, const void *x, const void *codes, const void *vmin, const void *vdiff)
 {
-    return g_sq8_encode_wave && sq8_filter_on() && sq8_wave_width(d) && n >= 4096 && sq8_wave_aligned(x, codes, vmin, vdiff);
+    return g_sq8_encode_wave && sq8_filter_on() && sq8_wave_width(d) && n >= (d > 512 ? 1 : 4096) && sq8_wave_aligned(x, codes, vmin, vdiff);
 }   // cvtmi_set_tuning("sq8_encode_wave"): 0 = the tile kernel for every width
 void set_sq8_encode_wave(int v) { g_sq8_encode_wave = v; }
 
@@ -358,7 +358,8 @@ int launch_sq8_encode_rows(const float *vmin, const float *vdiff, int d, float *
                            uint8_t *codes, float *den_scratch, hipStream_t st)
 {
     if (n <= 0) return CVTMI_OK;
-    if (g_sq8_encode_wave && sq8_wave_width(d) && n >= 4096 && sq8_wave_aligned(x, codes, vmin, vdiff) && (d <= 512 || sq8_filter_on()))
+    // (rows wider than the tile kernel's 512 floats: at every row count -- the two-pass kernels' norm pass alone costs 100 us for ONE row)
+    if (g_sq8_encode_wave && sq8_wave_width(d) && n >= (d > 512 ? 1 : 4096) && sq8_wave_aligned(x, codes, vmin, vdiff) && (d <= 512 || sq8_filter_on()))
         return launch_sq8_encode_wave(vmin, vdiff, d, x, n, l2norm, write_back, codes, st);
     if (sq8_tile_ok(d, x, codes, vmin, vdiff)) {
         Sq8Args a{};
@@ -1186,7 +1187,7 @@ int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_sc
         // the wave-per-row kernels: normalised rows of 256 / 512 floats as before; round 5: through the filter kernel also rows of 768 ...
         // 2048 floats, and those without normalisation (the tile kernel stops at 512-d; the generic kernels ran at 0.8 / 3.3 TB/s)
         const bool wave_f = sq8_filter_on() && sq8_wave_width(d);   // (without normalisation too: 4 M x 512-d 5.75 TB/s through the tile kernel, 6.3 here)
-        if ((wave_f || (l2norm && (d == 256 || d == 512))) && (((uintptr_t)x) & 15) == 0 && n >= 4096) {
+        if ((wave_f || (l2norm && (d == 256 || d == 512))) && (((uintptr_t)x) & 15) == 0 && n >= (wave_f && d > 512 ? 1 : 4096)) {
             // whole rows per wave, no LDS tile (the tile kernel's phases serialise behind its barriers: 3.3 TB/s at d = 512)
             const int64_t rows_per_wg = kBlock / 64;
             const unsigned blocks = (unsigned)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 256 * g_sq8_wave_blocks);

@@ -421,6 +421,28 @@ def test_sq8_decision_filter_equals_the_chain(amd, orc, d, kind):
             assert _same_min(tv, ovmin) and np.array_equal(bits(td), bits(ovdiff)), (kind, d, l2, key)
 
 
+@pytest.mark.parametrize("d", [64, 512, 2048])
+def test_sq8_one_vector_per_call(amd, orc, d):
+    """The reference's call shape: Int8Encode / Int8Decode on ONE feature vector (int8_quan.cc:72-132).  Small host-pointer calls run out
+    of a page-locked scratch area (round 5; sq8_host_small 0 = the allocate-copy-free form): same codes, rows and decoded values."""
+    rng = np.random.default_rng(d)
+    xs = np.abs(rng.normal(size=(300, d))).astype(np.float32)
+    vmin, vdiff = orc.sq8_train(xs.copy(), l2norm=True)
+    try:
+        for small in (1, 0):
+            amd.set_tuning("sq8_host_small", small)
+            for n in (1, 3):
+                for l2 in (True, False):
+                    x = xs[7:7 + n].copy()
+                    codes = amd.sq8_encode(vmin, vdiff, x, l2norm=l2)
+                    oc, ox = orc.sq8_encode(vmin, vdiff, xs[7:7 + n], l2norm=l2)
+                    assert np.array_equal(codes, oc) and np.array_equal(bits(x), bits(ox)), (d, small, n, l2)
+                dec = amd.sq8_decode(vmin, vdiff, codes)
+                assert np.array_equal(bits(dec), bits(orc.sq8_decode(vmin, vdiff, codes))), (d, small, n)
+    finally:
+        amd.set_tuning("sq8_host_small", 1)
+
+
 def test_sq8_parity(amd, orc, golden):
     rng = np.random.default_rng(8)
     for d in (64, 512, 300):
