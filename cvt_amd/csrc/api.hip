@@ -494,6 +494,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         set_sq8_wave_blocks((int)value);
         return CVTMI_OK;
     }
+    if (!strcmp(name, "flat_u8_mstream_min_rows")) { set_flat_u8_mstream_min_rows(value); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_mstream_min")) {
         if (value < 1 || value > 129) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_u8_mstream_min must be 1..129");
         set_flat_u8_mstream_min((int)value);

@@ -24,6 +24,7 @@
 // (D + 4) u 2Q and |q|^2 (D + 1) u Q in distance units, i.e. ~200 uQ in T units.  thr_q is lowered by 2048 uQ = 2^-13 Q.
 #include <algorithm>
 
+#include <atomic>
 #include "common.h"
 #include "kernels.h"
 
@@ -1240,9 +1241,15 @@ bool flat_u8_gfilter_shape(int D) { return g_u8_gfilter && (D == 64 || D == 128 
 constexpr int MSTREAM_BLOCKS = 256;   // one 4-wave workgroup per CU (one wave per SIMD); 192 / 240 / 252 / 255 measured the same or worse
 static int g_mstream_min_nq = 1;       // measurement hook (flat_u8_mstream_min): below it the row-per-lane / row-tile kernels answer
 void set_flat_u8_mstream_min(int v) { g_mstream_min_nq = v; }
+// Smallest table the stream takes.  Structural bound: the selection needs k waves with at least one 32-row tile each (k <= 128: 4096 rows);
+// waves without a tile publish "no minimum" and are never looked at.  It was 262 144 (eight tiles per wave) until a sweep over table
+// sizes (round 5, tools/sweep_flat_small_tables.py) showed the row-tile kernels 2-20x behind on everything smaller: 65 536 x 512-d,
+// 16 / 100 / 1000 queries 0.39 / 0.84 / 1.06 ms against 0.046 / 0.060 / 0.47.
+static std::atomic<int64_t> g_mstream_min_rows{4096};   // cvtmi_set_tuning("flat_u8_mstream_min_rows")
+void set_flat_u8_mstream_min_rows(int64_t v) { g_mstream_min_rows = v < 4096 ? 4096 : v; }
 bool flat_u8_mstream_applies(int D, int64_t n, int64_t nq, int k)
 {
-    return (D == 128 || D == 256 || D == 512) && nq >= g_mstream_min_nq && nq <= 128 && n >= 262144 && n < 0x7fffffff && k <= 128 &&
+    return (D == 128 || D == 256 || D == 512) && nq >= g_mstream_min_nq && nq <= 128 && n >= g_mstream_min_rows.load() && n < 0x7fffffff && k <= 128 &&
            n / 32 / 64 / (MSTREAM_BLOCKS * 4) + 2 <= 160;   // rounds a finish slice can span (FIN_MAXR, flat.hip): 331 M rows
 }
 // entries of the tile-group minima array: groups of MS_GROUP tiles per wave, (group, wave) major

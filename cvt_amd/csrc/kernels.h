@@ -217,6 +217,7 @@ int launch_flat_u8_mstream_finish(int D, const uint8_t *data, int64_t n, const u
                                   const int32_t *tmin, int nqp, int tile_group, float *part_d, int64_t *part_id, float *out_d, int64_t *out_rows, hipStream_t st);
 int flat_u8_stream_slices();
 void set_flat_u8_mstream_min(int v);
+void set_flat_u8_mstream_min_rows(int64_t v);
 void set_sq8_wave_blocks(int v);
 void set_sq8_encode_wave(int v);
 void set_sq8_filter(int v);

@@ -108,6 +108,8 @@ int cvtmi_set_device(int device);
  *   "flat_u8_filter_min_nq" / "flat_u8_filter_min_rows" / "flat_u8_filter_min_work"  uint8 search: the sample + matrix-core filter pipeline
  *                     answers from this many queries (default 129), rows (524 288) and rows x width x queries in units of 1e9
  *                     (130) on; below, passes of up to 128 queries through the streaming kernel (round 5: the fitted crossover)
+ *   "flat_u8_mstream_min_rows" smallest table the uint8 streaming kernel takes (default 4096 = its structural bound; it was 262 144 until
+ *                     round 5: 65 536 x 512-d, 100 queries 0.84 -> 0.06 ms)
  *   "flat_u8_sample_passes" the uint8 filter pipeline searches its leading sample exactly through the streaming kernel while that takes at
  *                     most this many 128-query passes (default 10: batches up to 1280 queries), through the row-tile kernels beyond
  *   "flat_small_zero_copy" 1 (default) = a small host-pointer flat search (queries <= 64 KB, lists <= 768 KB: the brute_force CLI's one

@@ -709,6 +709,30 @@ def test_flat_u8_tiny_batch_stream(amd, orc, D, nq, k, hi):
     assert out[0][1][0, :min(k, 3)].tolist() == [3, 131_072, n - 1][:min(k, 3)]
 
 
+@pytest.mark.parametrize("n,D,nq,k", [(4096, 512, 1, 128), (4097, 128, 40, 128), (5000, 256, 300, 10), (40_000, 512, 130, 100), (200_000, 128, 64, 1)])
+def test_flat_u8_stream_small_tables(amd, orc, n, D, nq, k):
+    """Round 5: the uint8 stream takes tables from 4096 rows on (it used to start at 262 144; the row-tile kernels were 2-20x behind on
+    everything smaller).  4096 rows is the structural bound -- k <= 128 waves with one 32-row tile each --: most waves hold no tile at
+    all, a batch above 128 queries runs in passes.  Against the exact kernels (flat_variant 1) and the checker, duplicates included."""
+    rng = np.random.default_rng(n + D + k)
+    x = rng.integers(0, 256, size=(n, D), dtype=np.uint8)
+    x[n - 1] = x[3]; x[n // 2] = x[3]
+    q = x[rng.integers(0, n, nq)].copy()
+    q[0] = x[3]
+    out = {}
+    try:
+        for v in (0, 1):
+            amd.set_tuning("flat_variant", v)
+            ix = amd.FlatIndex(L2U8, D); ix.add(x[: n // 3]); ix.add(x[n // 3:])
+            out[v] = ix.search(q, k)
+            ix.close()
+    finally:
+        amd.set_tuning("flat_variant", 0)
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+    od, odi, oi = orc.flat_search(L2U8, x, q, k)
+    assert np.array_equal(out[0][1], oi) and np.array_equal(out[0][0], odi)
+
+
 @pytest.mark.parametrize("metric,nq", [(IP, 16), (L2F, 17), (IP, 40), (L2F, 63)])
 def test_flat_f32_filter_small_batches(amd, orc, metric, nq):
     """16..63 queries take the matrix-core filter by default (flat_variant 0): same answer as the exact kernels and the checker,
