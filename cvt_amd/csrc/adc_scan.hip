@@ -1379,6 +1379,25 @@ __global__ __launch_bounds__(kBlock) void rotate_codes_kernel(const uint4 *__res
     out[r] = make_uint4(d0, d1, d2, d3);
 }
 
+__global__ __launch_bounds__(kBlock) void pad_codes_kernel(const uint8_t *__restrict__ codes, int M, uint4 *__restrict__ out, int64_t row0, int64_t n)
+{
+    const int64_t r = row0 + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    uint32_t w[4] = { 0u, 0u, 0u, 0u };
+    for (int b = 0; b < M; ++b) w[b >> 2] |= (uint32_t)codes[r * M + b] << (8 * (b & 3));
+    out[r] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+int launch_pad_codes(const uint8_t *codes, int M, uint8_t *codes16, int64_t row0, int64_t n, hipStream_t st)
+{
+    if (n <= row0) return CVTMI_OK;
+    if (M < 1 || M > 16) return fail(CVTMI_EINVAL, "pad_codes: M=%d", M);
+    const int64_t blocks = (n - row0 + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "pad_codes: too many rows");
+    hipLaunchKernelGGL(pad_codes_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, codes, M, reinterpret_cast<uint4 *>(codes16), row0, n);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
 int launch_rotate_codes(const uint8_t *codes, uint8_t *codes_rot, int64_t row0, int64_t n, hipStream_t st)
 {
     if (n <= row0) return CVTMI_OK;
@@ -1419,6 +1438,11 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
     a.gthr = nullptr; a.lazy = lazy; a.seed = g_scan_seed;
     if (plan.variant >= 3 && m.M == 16 && plan.qtile == 8) {
         if (!lut_scratch) return fail(CVTMI_EINVAL, "adc_scan16q: table scratch missing");
+        if (plan.real_M > 0) {   // M < 16 through these kernels: the model's own tables, all-zero ones behind them (codes = the padded rows)
+            OpqModelDev mr = m;
+            mr.M = plan.real_M;
+            CVTMI_TRY(launch_lut(mr, q_rot, nq, nullptr, lut_scratch, st, 256, 16));
+        } else
         CVTMI_TRY(launch_lut(m, q_rot, nq, nullptr, lut_scratch, st, 256));  // [nq][16][256] fp32 (+inf past K), once per query
         int64_t blocks = (int64_t)a.groups * a.splits;
         if (plan.splits_b > plan.splits && plan.groups_a > 0 && plan.groups_a < a.groups) {

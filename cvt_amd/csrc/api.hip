@@ -89,6 +89,8 @@ struct cvtmi_opq_s {
     DevBuf codes, lists, videos;
     DevBuf codes_rot;     // M = 16: rows rotated by (row & 15) bytes for adc_scan16q, built lazily at search time
     int64_t rot_n = 0;    // rows of codes_rot that are up to date
+    DevBuf codes16;       // M < 16: the rows padded to 16 bytes with zeros, what the M = 16 scan kernels read (opq_pads; built lazily like codes_rot, which is then its rotation)
+    int64_t pad_n = 0;    // rows of codes16 that are up to date
     int64_t n = 0;
     bool has_lists = false, has_videos = false;
     int64_t id_base = 0;
@@ -338,6 +340,7 @@ static bool host_pinned(const void *p)
 static std::atomic<int> g_hnsw_slots_cap{0};   // cvtmi_set_tuning("hnsw_slots"): cap on traversals per CU (0 = what LDS allows, at most 32)
 static std::atomic<int> g_small_zero_copy{1};   // cvtmi_set_tuning("opq_small_zero_copy"): 1 .. 8-query host-pointer searches read / write the pinned staging area from the kernels
 static std::atomic<int64_t> g_scans_max_work{(int64_t)48 << 20};   // cvtmi_set_tuning("scans_max_work"): rows x query groups up to which the OPQ small-batch form answers (scans_chosen)
+static std::atomic<int> g_scan_pad{1};           // cvtmi_set_tuning("scan_pad_m"): 0 = an OPQ index with M < 16 stays on the row-per-lane scan kernels (opq_pads)
 static std::atomic<int> g_sq8_host_small{1};     // cvtmi_set_tuning("sq8_host_small"): small SQ8 host-pointer calls run out of a page-locked scratch area (Sq8HostScratch)
 static std::atomic<int> g_flat_u8_filter_min_nq{129};            // cvtmi_set_tuning("flat_u8_filter_min_nq" / "_min_rows" / "_min_work"): smallest batch, table and
 static std::atomic<int64_t> g_flat_u8_filter_min_rows{524288};   // rows x width x queries (in 1e9) the dispatch hands to the uint8 sample + filter pipeline
@@ -479,6 +482,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "sq8_filter")) { set_sq8_filter(value != 0); return CVTMI_OK; }
+    if (!strcmp(name, "scan_pad_m")) { g_scan_pad = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "sq8_host_small")) { g_sq8_host_small = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "scans_max_work")) { g_scans_max_work = value < 0 ? 0 : value; return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_filter_min_nq")) { g_flat_u8_filter_min_nq = value < 1 ? 1 : value > (1 << 30) ? (1 << 30) : (int)value; return CVTMI_OK; }
@@ -560,7 +564,7 @@ int cvtmi_opq_destroy(cvtmi_opq_t h)
     if (h->d_books) (void)hipFree(h->d_books);
     if (h->d_R) (void)hipFree(h->d_R);
     if (h->d_perm) (void)hipFree(h->d_perm);
-    h->codes.release(); h->lists.release(); h->videos.release(); h->codes_rot.release();
+    h->codes.release(); h->lists.release(); h->videos.release(); h->codes_rot.release(); h->codes16.release();
     h->csr_codes.release(); h->csr_videos.release(); h->csr_off.release(); h->csr_scratch.release(); h->csr_stats.release();
     h->s_qrot.release(); h->s_probe.release(); h->s_rot.release();
     for (OpqScratch *c : h->pool) { c->release_all(); delete c; }
@@ -769,7 +773,7 @@ int cvtmi_opq_ntotal(cvtmi_opq_t h, int64_t *n)
 int cvtmi_opq_reset(cvtmi_opq_t h)
 {
     CHECK_H_SERIAL(h, nullptr);
-    h->n = 0; h->has_lists = false; h->has_videos = false; h->csr_valid = false; h->rot_n = 0;
+    h->n = 0; h->has_lists = false; h->has_videos = false; h->csr_valid = false; h->rot_n = 0; h->pad_n = 0;
     return CVTMI_OK;
 }
 
@@ -915,8 +919,29 @@ static int opq_search_h(cvtmi_opq_t h, OpqScratch &S, const float *q_rot, int64_
     return CVTMI_OK;
 }
 
+// M < 16 (the reference's own test model has M = 8: opq/src/multi_frame_index_test.cpp) only had the round-1 row-per-lane kernels: 1.0 M
+// queries/s at C2's shape against 3.1 M for M = 16, which does twice the work (round 5, tools/opq_m_sweep.py).  The M = 16 kernels take
+// such an index as it is once the rows are padded to 16 code bytes with zeros and every query gets 16 - M all-zero tables behind its own:
+// a zero byte looks up a zero, integer bounds and fp32 sums are unchanged (x + 0.0f == x for the non-negative sums here), the exact
+// re-sum still adds the model's M entries in the reference's order first.  Costs 16 + 16 bytes per row of derived copies.
+static bool opq_pads(const cvtmi_opq_s *h)
+{
+    return g_scan_pad.load() && h->m.M >= 1 && h->m.M < 16 && h->m.K >= 1 && h->m.K <= 256 && h->m.D <= 256;
+}
 static ScanPlan opq_plan(cvtmi_opq_t h, int64_t nq, int k)
 {
+    if (opq_pads(h) && (h->p_variant == 7 || h->p_variant >= 3) && h->p_qtile == 0) {
+        OpqModelDev m16 = h->m;
+        m16.M = 16;
+        // (the persistent grid and the small-batch form build their tables from the codebooks themselves: adc_scan16q / 16a only)
+        // (planned as at least four queries: below that plan_scan prefers the fp32-table kernels, which build their tables from the codebooks)
+        ScanPlan pp = plan_scan(m16, h->n, std::max<int64_t>(nq, 4), k, 0, h->p_splits, h->p_variant == 4 || h->p_variant == 5 ? h->p_variant : 3);
+        if (pp.variant >= 3 && pp.variant <= 5) {
+            pp.real_M = h->m.M;
+            if (!h->p_tail) { pp.groups_a = 0; pp.splits_b = 0; }
+            return pp;
+        }
+    }
     ScanPlan plan = plan_scan(h->m, h->n, nq, k, h->p_qtile, h->p_splits, h->p_variant);
     if (plan.variant == 6) return plan;
     if (!h->p_tail) { plan.groups_a = 0; plan.splits_b = 0; }
@@ -931,19 +956,36 @@ static ScanPlan opq_plan(cvtmi_opq_t h, int64_t nq, int k)
 // (once per index state; the searches that follow on other streams wait for the event the exclusive call leaves)
 static int opq_prepare(cvtmi_opq_t h, int64_t nq, int k, hipStream_t st)
 {
+    bool padded = false;
     {
         std::shared_lock<std::shared_timed_mutex> rd(h->rw);
-        if (h->n == 0 || !(h->m.M == 16 && h->p_prerot && (opq_plan(h, nq, k).variant >= 3 || scans_applies(h->m, h->n, nq, k)))) return CVTMI_OK;
-        if (h->rot_n == h->n && h->codes_rot.cap >= (size_t)h->n * 16) return CVTMI_OK;
+        if (h->n == 0) return CVTMI_OK;
+        const ScanPlan plan = opq_plan(h, nq, k);
+        padded = plan.real_M > 0;
+        const bool want_rot = h->p_prerot && ((h->m.M == 16 && (plan.variant >= 3 || scans_applies(h->m, h->n, nq, k))) || padded);
+        if (!padded && !want_rot) return CVTMI_OK;
+        const bool pad_ok = !padded || (h->pad_n == h->n && h->codes16.cap >= (size_t)h->n * 16);
+        const bool rot_ok = !want_rot || (h->rot_n == h->n && h->codes_rot.cap >= (size_t)h->n * 16);
+        if (pad_ok && rot_ok) return CVTMI_OK;
     }
     Serial serial(h->sync, st);
     OpqExclusive excl(h, st);
+    if (padded) {   // the 16-byte rows first: the rotated copy is made from them
+        if (h->pad_n > h->n) h->pad_n = 0;
+        if (h->codes16.cap < (size_t)h->n * 16) {
+            CVTMI_TRY(h->codes16.reserve(std::max<size_t>(h->codes.cap / (size_t)h->m.M * 16, (size_t)h->n * 16)));
+            h->pad_n = 0;  // reserve() does not keep the old contents
+        }
+        CVTMI_TRY(launch_pad_codes(h->codes.as<uint8_t>(), h->m.M, h->codes16.as<uint8_t>(), h->pad_n, h->n, st));
+        h->pad_n = h->n;
+        if (!h->p_prerot) return CVTMI_OK;
+    }
     if (h->rot_n > h->n) h->rot_n = 0;
     if (h->codes_rot.cap < (size_t)h->n * 16) {
-        CVTMI_TRY(h->codes_rot.reserve(std::max<size_t>(h->codes.cap, (size_t)h->n * 16)));
+        CVTMI_TRY(h->codes_rot.reserve(std::max<size_t>(padded ? h->codes16.cap : h->codes.cap, (size_t)h->n * 16)));
         h->rot_n = 0;  // reserve() does not keep the old contents
     }
-    CVTMI_TRY(launch_rotate_codes(h->codes.as<uint8_t>(), h->codes_rot.as<uint8_t>(), h->rot_n, h->n, st));
+    CVTMI_TRY(launch_rotate_codes(padded ? h->codes16.as<uint8_t>() : h->codes.as<uint8_t>(), h->codes_rot.as<uint8_t>(), h->rot_n, h->n, st));
     h->rot_n = h->n;
     return CVTMI_OK;
 }
@@ -997,9 +1039,14 @@ static int opq_search_leased(cvtmi_opq_t h, OpqScratch &S, const float *q, int64
         CVTMI_TRY(opq_rotate_impl(h, q, nq, S.s_qrot.as<float>(), st));
         q_rot = S.s_qrot.as<float>();
     }
-    const ScanPlan plan = opq_plan(h, nq, k);
+    ScanPlan plan = opq_plan(h, nq, k);
+    if (plan.real_M > 0 && !(h->pad_n == h->n && h->codes16.p)) plan = plan_scan(h->m, h->n, nq, k, h->p_qtile, h->p_splits, h->p_variant);   // (the padded rows are not there: as before)
+    const bool padded = plan.real_M > 0;
+    OpqModelDev m_scan = h->m;
+    if (padded) m_scan.M = 16;
+    const uint8_t *scan_rows = padded ? h->codes16.as<uint8_t>() : h->codes.as<uint8_t>();
     // the scan streams the pre-rotated copy of the rows when it is up to date (opq_prepare); otherwise it rotates in registers
-    const uint8_t *codes_rot = (plan.variant >= 3 && h->m.M == 16 && h->p_prerot && h->rot_n == h->n && h->codes_rot.p) ? h->codes_rot.as<uint8_t>() : nullptr;
+    const uint8_t *codes_rot = (plan.variant >= 3 && (h->m.M == 16 || padded) && h->p_prerot && h->rot_n == h->n && h->codes_rot.p) ? h->codes_rot.as<uint8_t>() : nullptr;
     if (plan.variant == 6) return opq_search_h(h, S, q_rot, nq, k, dist, ids, codes_rot, st);
     float *pd = dist;
     int64_t *pi = ids;
@@ -1017,7 +1064,7 @@ static int opq_search_leased(cvtmi_opq_t h, OpqScratch &S, const float *q, int64
     }
     float *lut_scratch = nullptr;
     if (plan.variant >= 3) {  // per-query fp32 tables in HBM (16 KB per query at M=16, K=256)
-        CVTMI_TRY(S.s_lut.reserve((size_t)nq * h->m.M * 256 * sizeof(float)));
+        CVTMI_TRY(S.s_lut.reserve((size_t)nq * m_scan.M * 256 * sizeof(float)));
         lut_scratch = S.s_lut.as<float>();
     }
     uint32_t *gthr = nullptr;
@@ -1026,8 +1073,8 @@ static int opq_search_leased(cvtmi_opq_t h, OpqScratch &S, const float *q, int64
         gthr = S.s_gthr.as<uint32_t>();
     }
     // (two-region plan, first region in one piece: those queries' lists are written in place by the scan, the merge starts behind them)
-    const int64_t placed = plan.stride() > 1 ? scan_in_place_queries(plan, h->m.M, nq) : 0;
-    CVTMI_TRY(launch_adc_scan(h->m, h->codes.as<uint8_t>(), h->n, h->id_base, q_rot, nq, k, plan, pd, pi, lut_scratch,
+    const int64_t placed = plan.stride() > 1 ? scan_in_place_queries(plan, m_scan.M, nq) : 0;
+    CVTMI_TRY(launch_adc_scan(m_scan, scan_rows, h->n, h->id_base, q_rot, nq, k, plan, pd, pi, lut_scratch,
                               codes_rot, st, gthr, h->p_lazy, placed ? dist : nullptr, placed ? ids : nullptr));
     if (h->p_profile) {
         CVTMI_HIP(hipEventRecord(h->ev1[slot], st));

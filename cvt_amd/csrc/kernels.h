@@ -36,8 +36,10 @@ int launch_pq_encode(const OpqModelDev &m, const float *x_rot, int64_t n, const 
 bool pq_encode_takes_perm(const OpqModelDev &m, const float *x, int64_t n, int variant);
 bool pq_encode_fuses_lists(const OpqModelDev &m, const float *x_rot, int64_t n, int variant);
 // ld: entries per (query, m) row of the output, 0 = K; ld > K pads with +inf
+// tables: tables per query in the output, 0 = M; tables > M appends all-zero tables (the M < 16 scans: a row padded to 16 code bytes looks
+// its zero bytes up there, and a zero changes no sum)
 int launch_lut(const OpqModelDev &m, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut,
-               hipStream_t st, int ld = 0);
+               hipStream_t st, int ld = 0, int tables = 0);
 
 // ---- adc_scan.hip ----
 struct ScanPlan {
@@ -49,6 +51,9 @@ struct ScanPlan {
     // splits_b == 0: one region.  Partial results are laid out [nq][stride()][k].
     int groups_a = 0, splits_b = 0;
     int stride() const { return splits_b > splits ? splits_b : splits; }
+    // M < 16 served by the M = 16 kernels (api.hip opq_plan): the scan reads a copy of the rows padded to 16 bytes with zeros and
+    // per-query tables padded with all-zero tables; real_M = the model's M (0: not padded)
+    int real_M = 0;
 };
 ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int want_qtile, int want_splits,
                    int want_variant);
@@ -76,6 +81,8 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
 // M = 16 only: codes_rot rows [row0, n) = the code rows rotated left by (row & 15) bytes, the layout adc_scan16q
 // (plan.variant >= 3) streams when codes_rot is given
 int launch_rotate_codes(const uint8_t *codes, uint8_t *codes_rot, int64_t row0, int64_t n, hipStream_t st);
+// rows [row0, n) of M code bytes -> 16 bytes each, zeros behind the M
+int launch_pad_codes(const uint8_t *codes, int M, uint8_t *codes16, int64_t row0, int64_t n, hipStream_t st);
 
 // ---- adc_scan_h.hip: adc_scan16h (plan.variant == 6), a persistent grid walking a host-built item table ----
 // one item = one row segment of one query group: rows [64 * row0_64, 64 * row0_64 + rows) scanned for the group's 8 queries;

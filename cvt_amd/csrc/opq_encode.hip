@@ -669,7 +669,7 @@ extern "C" int cvtmi_debug_encode_stats(unsigned long long *out, int reset)
 __global__ __launch_bounds__(kBlock) void lut_kernel(const float *__restrict__ q_rot, int D, int M, int K, int step,
                                                      const float *__restrict__ coarse,
                                                      const int32_t *__restrict__ list_id,
-                                                     const float *__restrict__ books, float *__restrict__ lut, int ld)
+                                                     const float *__restrict__ books, float *__restrict__ lut, int ld, int tables)
 {
     extern __shared__ __attribute__((aligned(16))) float res[];  // D floats
     const int64_t qi = blockIdx.x;
@@ -677,10 +677,12 @@ __global__ __launch_bounds__(kBlock) void lut_kernel(const float *__restrict__ q
     if (l < 0) l = 0;
     for (int d = threadIdx.x; d < D; d += kBlock) res[d] = __fsub_rn(q_rot[qi * D + d], coarse[(int64_t)l * D + d]);
     __syncthreads();
-    for (int e = threadIdx.x; e < M * ld; e += kBlock) {
+    for (int e = threadIdx.x; e < tables * ld; e += kBlock) {
         const int m = e / ld, j = e - m * ld;
         float acc = __uint_as_float(0x7f800000u);
-        if (j < K) {
+        if (m >= M) {
+            acc = 0.0f;   // appended table: all zeros
+        } else if (j < K) {
             const float *c = books + ((int64_t)m * K + j) * step;
             acc = 0.0f;
             for (int kk = 0; kk < step; ++kk) {
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(kBlock) void lut_kernel(const float *__restrict__ q
                 acc = __fadd_rn(acc, __fmul_rn(t, t));
             }
         }
-        lut[qi * M * ld + e] = acc;
+        lut[qi * tables * ld + e] = acc;
     }
 }
 
@@ -697,7 +699,8 @@ __global__ __launch_bounds__(kBlock) void lut_kernel(const float *__restrict__ q
 // queries: 134 us, 1.2 TB/s of table writes).  Same operations in the same order per entry.
 template <int QB>
 __global__ __launch_bounds__(kBlock) void lut8_kernel(const float *__restrict__ q_rot, int64_t nq, int D, int M, int K, const float *__restrict__ coarse,
-                                                      const int32_t *__restrict__ list_id, const float *__restrict__ books, float *__restrict__ lut, int ld)
+                                                      const int32_t *__restrict__ list_id, const float *__restrict__ books, float *__restrict__ lut, int ld,
+                                                      int tables)
 {
     extern __shared__ __attribute__((aligned(16))) float res[];  // [QB][D]
     const int64_t q0 = (int64_t)blockIdx.x * QB;
@@ -709,12 +712,12 @@ __global__ __launch_bounds__(kBlock) void lut8_kernel(const float *__restrict__ 
         res[i] = __fsub_rn(q_rot[qi * D + d], coarse[(int64_t)l * D + d]);
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < M * ld; e += kBlock) {
+    for (int e = threadIdx.x; e < tables * ld; e += kBlock) {
         const int m = e / ld, j = e - m * ld;
         float acc[QB];
 #pragma unroll
-        for (int q = 0; q < QB; ++q) acc[q] = __uint_as_float(0x7f800000u);
-        if (j < K) {
+        for (int q = 0; q < QB; ++q) acc[q] = m >= M ? 0.0f : __uint_as_float(0x7f800000u);   // (appended tables: all zeros)
+        if (m < M && j < K) {
             const float4 *c = reinterpret_cast<const float4 *>(books + ((int64_t)m * K + j) * 8);
             const float4 c0 = c[0], c1 = c[1];
             const float cv[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
@@ -731,25 +734,26 @@ __global__ __launch_bounds__(kBlock) void lut8_kernel(const float *__restrict__ 
         }
 #pragma unroll
         for (int q = 0; q < QB; ++q)
-            if (q0 + q < nq) lut[(q0 + q) * M * ld + e] = acc[q];
+            if (q0 + q < nq) lut[(q0 + q) * tables * ld + e] = acc[q];
     }
 }
 
 int launch_lut(const OpqModelDev &m, const float *q_rot, int64_t nq, const int32_t *list_id, float *lut, hipStream_t st,
-               int ld)
+               int ld, int tables)
 {
     if (ld <= 0) ld = m.K;
+    if (tables < m.M) tables = m.M;
     if (nq <= 0) return CVTMI_OK;
     if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "lut: nq too large");
     if (m.step == 8 && nq >= 64 && (((uintptr_t)m.books) & 15) == 0) {
         constexpr int QB = 4;
         hipLaunchKernelGGL((lut8_kernel<QB>), dim3((unsigned)((nq + QB - 1) / QB)), dim3(kBlock), (size_t)QB * m.D * sizeof(float), st, q_rot, nq, m.D, m.M, m.K,
-                           m.coarse, list_id, m.books, lut, ld);
+                           m.coarse, list_id, m.books, lut, ld, tables);
         CVTMI_HIP(hipGetLastError());
         return CVTMI_OK;
     }
     hipLaunchKernelGGL(lut_kernel, dim3((unsigned)nq), dim3(kBlock), (size_t)m.D * sizeof(float), st, q_rot, m.D, m.M,
-                       m.K, m.step, m.coarse, list_id, m.books, lut, ld);
+                       m.K, m.step, m.coarse, list_id, m.books, lut, ld, tables);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

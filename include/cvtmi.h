@@ -100,6 +100,10 @@ int cvtmi_set_device(int device);
  *   "scan_tail_splits" adc_scan16q, query groups past the last full round of workgroups: 0 (default) = cut them into 2 / 4 / 8 row
  *                     splits while that still leaves at most one workgroup per CU (a last round is only expensive while it leaves CUs
  *                     empty: 4256 queries over 1 M rows 2.11 -> 2.79 M queries/s, 10 000 queries unchanged); -1 = never; S > 0 = S splits
+ *   "scan_pad_m"      1 (default) = an OPQ index with M < 16 is searched by the M = 16 scan kernels over rows padded to 16 code bytes
+ *                     with zeros (derived copies: 32 bytes per row) and per-query tables padded with all-zero tables -- M = 8 at
+ *                     10 000 queries x 1 M rows: 9.8 -> 3.2 ms, and every M from 1 to 15 is searchable; 0 = the row-per-lane
+ *                     kernels (M = 4 / 8 only)
  *   "sq8_host_small" 1 (default) = SQ8 host-pointer calls of up to 1 MB (the reference's one vector per call) run out of a page-locked
  *                     scratch area the kernels read and write directly (512-d: 80 -> 26 us per call); 0 = allocate, copy, free
  *   "scans_max_work"  OPQ search: the small-batch form (<= 128 queries) answers while rows x query groups stays at or under this

@@ -250,6 +250,42 @@ def test_search_two_region_tail(amd, orc):
         amd.set_tuning("opq_host_zero_copy", 1)
 
 
+@pytest.mark.parametrize("M,step", [(8, 16), (4, 32), (12, 8), (5, 8), (1, 32), (15, 4)])
+def test_search_any_m_through_padded_rows(amd, orc, M, step):
+    """Round 5: an index with M < 16 is searched by the M = 16 kernels over rows padded to 16 code bytes with zeros and all-zero tables
+    behind the model's own (M = 8 at C2's shape: 1.0 -> 3.1 M queries/s).  Same lists as the oracle for every M below 16 -- 12, 5, 1 and
+    15 had no scan kernel at all before --, for one query and for batches, appended rows included; M = 4 / 8 also against their old
+    row-per-lane kernels (scan_pad_m 0)."""
+    import torch
+    D, K = M * step, 256
+    rng = np.random.default_rng(M * 31 + step)
+    books = (rng.normal(size=(M, K, step)) * 0.1).astype(np.float32)
+    n = 70_000 + 7
+    codes = rng.integers(0, K, size=(n, M), dtype=np.uint8)
+    codes[100] = codes[50]; codes[40_000] = codes[50]; codes[n - 1] = codes[50]
+    idx = amd.OpqIndex(np.zeros((1, D), np.float32), books)
+    idx.add_codes(codes[:30_000])
+    try:
+        for nq, k in ((1, 10), (3, 100), (9, 128), (300, 10), (4200, 20)):
+            q = (rng.normal(size=(nq, D)) * 0.1).astype(np.float32)
+            q[0] = books[np.arange(M), codes[50]].reshape(-1)            # the tied rows' own reconstruction: distance 0 three times
+            if nq == 9:
+                idx.add_codes(codes[30_000:])                            # the padded / rotated copies are extended, not rebuilt
+            rows = codes[:idx.ntotal]
+            sel = np.unique(np.r_[0:min(nq, 4), rng.integers(0, nq, size=min(nq, 12))])
+            od, oi = orc.adc_search(q[sel], books, rows, k)
+            for pad in ((1, 0) if M in (4, 8) else (1,)):
+                amd.set_tuning("scan_pad_m", pad)
+                for dev in (False, True):
+                    d, i = idx.search(torch.from_numpy(q).cuda() if dev else q, k, rotate=False)
+                    if dev:
+                        d, i = d.cpu().numpy(), i.cpu().numpy()
+                    assert np.array_equal(i[sel], oi) and np.array_equal(bits(d[sel]), bits(od)), (M, nq, k, pad, dev)
+    finally:
+        amd.set_tuning("scan_pad_m", 1)
+    idx.close()
+
+
 def test_search_edge_cases(amd, orc):
     D, M, K = 128, 16, 256
     rng = np.random.default_rng(2)
