@@ -95,7 +95,7 @@ def parse_args():
     ap.add_argument("--ref-rows", type=int, default=200_000, help="rows of the index the reference itself builds for cpu_baseline (0 = skip)")
     ap.add_argument("--ref-queries", type=int, default=64)
     ap.add_argument("--hnsw-nodes", type=int, default=1_000_000, help="nodes of the config-5 graph (secondary.hnsw_c5)")
-    ap.add_argument("--only", default="", help="development: comma list of secondary sections to run (rotation_encode, opq_rotation_learning, "
+    ap.add_argument("--only", default="", help="development: comma list of secondary sections to run (rotation_encode, opq_m8, opq_rotation_learning, "
                                                "sq8, flat_f32, flat_u8_c3, ivf_query, hnsw_c5); default all")
     ap.add_argument("--host-api", type=int, default=1, help="0 = skip the host-pointer leg (its 4096-query pieces are scan launches too)")
     ap.add_argument("--tune", default="", help="development: cvtmi_set_tuning pairs, name=value,name=value")
@@ -858,7 +858,7 @@ def secondary(ctx):
     if not only or "rotation_encode" in only:
         sec.update(_sec_rotation_encode(ctx))
     vmin, vdiff = _sec_sq8(ctx, sec) if (not only or "sq8" in only or "flat_u8_c3" in only) else (None, None)
-    for name, fn in (("opq_rotation_learning", lambda: _sec_rotation_learning(ctx)),
+    for name, fn in (("opq_m8", lambda: _sec_opq_m8(ctx)), ("opq_rotation_learning", lambda: _sec_rotation_learning(ctx)),
                      ("flat_f32", lambda: _sec_flat_f32(ctx)), ("flat_u8_c3", lambda: _sec_flat_u8_c3(ctx, vmin,
                                                                                                       vdiff)),
                      ("ivf_query", lambda: _ivf_query(ctx)), ("hnsw_c5", lambda: _hnsw_c5(ctx))):
@@ -903,6 +903,44 @@ def _sec_rotation_encode(ctx):
                                      "kernel, the rows are read through the permutation"}
     ixp.close(); ix.close()
     return sec
+
+
+def _sec_opq_m8(ctx):
+    """BASELINE configs[0]'s model shape (M = 8, K = 256: the reference's own test model) at the headline's table size: M < 16 runs
+    through the M = 16 scan kernels over rows padded to 16 code bytes (round 5), next to the row-per-lane kernels it had before"""
+    torch, cvt, synth, args = ctx.torch, ctx.cvt, ctx.synth, ctx.args
+    M8, k, nq = 8, ctx.k, ctx.nq
+    tmp = cvt.OpqIndex(ctx.zero_coarse, np.zeros((M8, K, D // M8), np.float32), R=ctx.R)
+    books = synth.train_books(tmp.rotate(synth.sift_like(100_000, D, seed=0xC0FFEE, device=ctx.dev)), M8, K, iters=4)
+    tmp.close()
+    ix = cvt.OpqIndex(ctx.zero_coarse, books, R=ctx.R)
+    ix.reserve(args.rows)
+    step = synth.CHUNK * 4
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for a in range(0, args.rows, step):
+        b = min(args.rows, a + step)
+        _, codes = ix.encode(ix.rotate(synth.sift_like(b - a, D, seed=0xC0FFEE, row_begin=a, device=ctx.dev)))
+        ix.add_codes(codes)
+    torch.cuda.synchronize(); t_build = time.perf_counter() - t0
+    q = synth.sift_like(nq, D, seed=0xBEEF, device=ctx.dev)
+    res = {"rows": args.rows, "M": M8, "nq": nq, "k": k, "index_build_s": round(t_build, 3),
+           "what": "rotate + encode + ADC top-%d of %d queries over %d rows of 8-byte codes" % (k, nq, args.rows)}
+    ref = None
+    try:
+        for name, pad in (("padded_rows_through_the_m16_kernels", 1), ("row_per_lane_kernels", 0)):
+            cvt.set_tuning("scan_pad_m", pad)
+            ms = _ev_ms(torch, lambda: ix.search(q, k, rotate=True), reps=max(2, min(5, args.steps)), warm=2)
+            d, i = ix.search(q, k, rotate=True)
+            if ref is None:
+                ref = (d, i)
+            res[name] = {"ms": round(ms, 4), "queries_per_s": round(nq / (ms * 1e-3), 1),
+                         "identical": bool(torch.equal(i, ref[1]) and torch.equal(d.view(torch.int32), ref[0].view(torch.int32)))}
+    finally:
+        cvt.set_tuning("scan_pad_m", 1)
+    if ctx.exact_nn is not None and ctx.exact_nn.shape[0] >= nq:
+        res["recall_at_1"] = round(float((ref[1][:, 0] == ctx.exact_nn[:nq]).float().mean().item()), 4)
+    ix.close()
+    return res
 
 
 def _sec_rotation_learning(ctx):
