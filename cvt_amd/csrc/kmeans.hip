@@ -16,6 +16,8 @@
 //    L2 (k n 4 bytes): for coarseK = 8192, n = 1 M that is ~3 ms per iteration, noise next to the assign pass.
 #include <algorithm>
 
+#include <mutex>
+#include "host_util.h"
 #include "kernels.h"
 
 namespace cvtmi {
@@ -230,6 +232,24 @@ int launch_kmeans_assign(const float *x, int64_t ld, int64_t n, int d, const flo
     // 32 <= d <= 128: matrix-core filter + exact resolution of the rows it cannot decide (assign_mfma.hip); same result
     if (g_assign_variant != 1 && assign_filter_applies(x, ld, g_assign_variant == 2 && n < 4096 ? 4096 : n, d, cent, k) && n < 0x7fffffff)
         return launch_assign_filtered(x, ld, n, d, cent, k, assign, changed, st);
+    // Few rows against many centroids -- the reference's index build is IVFOPQ::Add of ONE video, a few hundred frames over 8192 lists
+    // (opq/src/IVFOPQ.cpp:135-163): with one thread per row walking every centroid such a call took 7.6 ms whatever its size (round 5,
+    // tools/sweep_add_video.py).  The centroid range is cut over enough workgroups to fill the chip and folded in ascending order (the
+    // same strict '<': same assignment), as the filter does for the rows it cannot decide.  The scratch is shared: the stream is drained
+    // before the lock is given back, as in launch_assign_filtered.
+    if (g_assign_variant != 1 && changed == nullptr && n < 4096 && k >= 256 && d <= 128) {
+        static std::mutex few_mu;
+        static DevBuf few_scr;
+        std::lock_guard<std::mutex> guard(few_mu);
+        const int row_blocks = (int)((n + kBlock - 1) / kBlock);
+        const int splits = std::max(1, std::min((k + 63) / 64, (1024 + row_blocks - 1) / row_blocks));
+        const size_t b_part = (((size_t)n * splits * sizeof(float)) + 255) & ~(size_t)255;
+        CVTMI_TRY(few_scr.reserve(2 * b_part));
+        const int rc = launch_kmeans_assign_split(x, ld, n, d, cent, k, assign, splits, few_scr.as<float>(),
+                                                  reinterpret_cast<int32_t *>(few_scr.as<char>() + b_part), st);
+        CVTMI_HIP(hipStreamSynchronize(st));
+        return rc;
+    }
     return launch_kmeans_assign_exact(x, ld, n, d, cent, k, assign, changed, st);
 }
 

@@ -586,9 +586,14 @@ static bool encm_ok(const OpqModelDev &m, const float *x_rot)
            ((((uintptr_t)x_rot) | ((uintptr_t)m.books) | ((uintptr_t)m.coarse)) & 15) == 0;
 }
 // does launch_pq_encode take the matrix-core kernel (which can also write the single-list assignment)?
+// Smallest call the matrix-core encode takes when the dispatch chooses.  It was 8192 rows -- and the reference's own call shape is
+// IVFOPQ::Add of ONE video, a few hundred frames (opq/src/IVFOPQ.cpp:135-163): those went to the VALU kernel, whose 1024-row
+// workgroups cost 0.7 ms whatever the row count, against 0.04-0.06 ms here (round 5, tools/sweep_encode_dispatch.py: 64 ... 4096 rows,
+// M = 16 and 8: 13-19x).
+constexpr int64_t ENCM_MIN_ROWS = 1;
 bool pq_encode_fuses_lists(const OpqModelDev &m, const float *x_rot, int64_t n, int variant)
 {
-    return m.coarseK == 1 && encm_ok(m, x_rot) && (variant == 2 || (variant == 0 && n >= 8192));
+    return m.coarseK == 1 && encm_ok(m, x_rot) && (variant == 2 || (variant == 0 && n >= ENCM_MIN_ROWS));
 }
 
 // variant: 0 = choose, 1 = the VALU kernel (reference chain for every centroid), 2 = matrix-core filter + exact resolution
@@ -596,7 +601,7 @@ bool pq_encode_fuses_lists(const OpqModelDev &m, const float *x_rot, int64_t n, 
 // can launch_pq_encode read the rows through the model's permutation (x = rows before reorder_)?
 bool pq_encode_takes_perm(const OpqModelDev &m, const float *x, int64_t n, int variant)
 {
-    return m.perm && m.step == 8 && encm_ok(m, x) && (variant == 2 || (variant == 0 && n >= 8192));
+    return m.perm && m.step == 8 && encm_ok(m, x) && (variant == 2 || (variant == 0 && n >= ENCM_MIN_ROWS));
 }
 
 int launch_pq_encode(const OpqModelDev &m, const float *x_rot, int64_t n, const int32_t *list_id, uint8_t *codes,
@@ -609,7 +614,7 @@ int launch_pq_encode(const OpqModelDev &m, const float *x_rot, int64_t n, const 
     const bool mfma_ok = encm_ok(m, x_rot);
     if (variant == 2 && !mfma_ok) return fail(CVTMI_EUNSUPPORTED, "pq_encode: the matrix-core encode needs K = 256, step 8 or 16, M <= 16, D <= 128");
     if (single_list_out && !pq_encode_fuses_lists(m, x_rot, n, variant)) return fail(CVTMI_EINVAL, "pq_encode: list output without the fused kernel");
-    if (mfma_ok && (variant == 2 || (variant == 0 && n >= 8192))) {
+    if (mfma_ok && (variant == 2 || (variant == 0 && n >= ENCM_MIN_ROWS))) {
         constexpr int waves = ENCM_THREADS / 64;
         const int64_t nbatch = (n + 31) / 32;
         const int64_t blocks = std::min<int64_t>(encm_cus(), (nbatch + waves - 1) / waves);

@@ -129,6 +129,33 @@ def test_encode_parity_seeded(amd, orc, D, M, K, coarseK):
         assert np.array_equal(c2, oc[:nn]) and np.array_equal(l2, ol[:nn])
 
 
+@pytest.mark.parametrize("D,M", [(128, 16), (64, 8)])
+def test_encode_one_video_at_a_time(amd, orc, D, M):
+    """The reference builds its index one video at a time: IVFOPQ::Add of a few hundred frames over 8192 lists (opq/src/IVFOPQ.cpp:135-163).
+    Round 5: such calls take the matrix-core PQ encode at every row count (the VALU kernel cost 0.7 ms per call) and a coarse assignment
+    whose centroid range is cut over workgroups (one thread per row walking 8192 centroids cost 7.6 ms per call).  Lists and codes against
+    the oracle for 1 ... 4095 frames, device and host pointers, with duplicate centroids (first minimum) and a NaN frame."""
+    import torch
+    K, L = 256, 1500
+    rng = np.random.default_rng(D + M)
+    books = synth_model(rng, D, M, K)
+    coarse = rng.normal(size=(L, D)).astype(np.float32)
+    coarse[700] = coarse[20]; coarse[1499] = coarse[20]          # strict '<': list 20 wins every tie
+    idx = amd.OpqIndex(coarse, books)
+    for n in (1, 9, 300, 1000, 4095):
+        x = (coarse[rng.integers(0, L, n)] + 0.3 * rng.normal(size=(n, D))).astype(np.float32)
+        x[0] = coarse[20]
+        if n > 5:
+            x[5] = np.nan
+        ol, oc = orc.pq_encode(x, coarse, books)
+        for dev in (False, True):
+            lists, codes = idx.encode(torch.from_numpy(x).cuda() if dev else x)
+            if dev:
+                lists, codes = lists.cpu().numpy(), codes.cpu().numpy()
+            assert np.array_equal(lists, ol) and np.array_equal(codes, oc), (n, dev)
+        assert ol[0] == 20
+
+
 def test_encode_tie_takes_first_minimum(amd, orc):
     D, M, K = 32, 4, 256
     rng = np.random.default_rng(1)
