@@ -1138,6 +1138,17 @@ def _ivf_query(ctx):
     q = x[torch.randint(0, n, (nq,), generator=g, device=dev)] + 0.01 * torch.randn((nq, D), generator=g, device=dev)
     ix = cvt.OpqIndex(cen.cpu().numpy(), (ctx.books * 0.3).astype(np.float32))
     ms_enc = _ev_ms(torch, lambda: ix.encode(x), reps=2, warm=1)
+    # the reference builds its index one video at a time: IVFOPQ::Add of a few hundred frames (IVFOPQ.cpp:135-163) -- wall time of one
+    # such call through the host-pointer entries (coarse assignment + PQ encode, then the append)
+    xv = x[:300].cpu().numpy(); vid = np.zeros(300, np.int32)
+    tmp_ix = cvt.OpqIndex(cen.cpu().numpy(), (ctx.books * 0.3).astype(np.float32))
+    for _ in range(3):
+        lv, cv = tmp_ix.encode(xv); tmp_ix.add_codes(cv, lv, vid)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        lv, cv = tmp_ix.encode(xv); tmp_ix.add_codes(cv, lv, vid)
+    ms_video = (time.perf_counter() - t0) / 20 * 1e3
+    tmp_ix.close()
     lists, codes = ix.encode(x)
     ix.add_codes(codes, lists, torch.randint(0, n_videos, (n,), generator=g, device=dev, dtype=torch.int32))
     # the first query builds the list-ordered copy
@@ -1148,6 +1159,9 @@ def _ivf_query(ctx):
     return {"entries": n, "lists": L, "nprobe": nk, "videos": n_videos,
             "encode_rows_per_s": round(n / (ms_enc * 1e-3), 1),
             "encode_what": "coarse argmin over 8192 centroids (matrix-core filter + exact resolution) + PQ encode",
+            "add_one_video_300_frames_ms": round(ms_video, 3),
+            "add_one_video_what": "cvtmi_opq_encode + cvtmi_opq_add_codes with host pointers on 300 frames (the reference's Add of one video; 7.9 ms "
+                                  "before the small-call dispatch of round 5)",
             "first_query_ms_incl_list_build": round(ms_first, 3), "frames": nq, "ms": round(ms_q, 3),
             "frames_per_s": round(nq / (ms_q * 1e-3), 1), "ms_9_frames": round(ms_9, 3),
             "what": "IVFOPQ::Query semantics (IVFOPQ.cpp:213-320): coarse top-3 of 8192, residual tables, list scans, "
