@@ -128,7 +128,22 @@ int cvtmi_set_device(int device);
  *   "hnsw_adc_tables" HNSW over OPQ codes: 0 (default) = a query's fp32 distance tables are read from the table scratch (L2 / Infinity
  *                     Cache), 32 traversals per CU; 1 = copied into LDS first (16 KB per query: 8 traversals per CU, round 2 - 4)
  *   "comm_force_rccl" 1 = cvtmi_comm_create goes through RCCL (ncclCommInitRank, ncclAllGather) for world == 1 too, which
- *                     otherwise needs no transport (test hook for 1-GPU boxes) */
+ *                     otherwise needs no transport (test hook for 1-GPU boxes)
+ *   "comm_inject_failure" r >= 0: the local search of rank r of every sharded search fails (tests of the failure path); -1 = off
+ *   "opq_host_chunk"  queries per piece of cvtmi_opq_search's pipelined form for pageable arrays (default 4096 = one full round of
+ *                     workgroups; 0 = one piece)
+ *   "opq_small_zero_copy" 1 (default) = host-pointer OPQ searches that take the small-batch form read their queries from and write their
+ *                     lists to the handle's pinned staging area from the kernels (no copy engine in the chain); 0 = copies
+ *   "host_spin_us"    microseconds a host-pointer entry polls its stream before it blocks (default 200: waking from a blocking wait costs
+ *                     as much again as a small search)
+ *   "scanh_balance" / "scanh_min_rows" / "scanh_tail" / "scanh_fix" / "scanh_share_hist"  planner of the persistent-grid scan (variant
+ *                     6): 0 choose / 1 equal row-time shares / 2 row blocks; smallest row segment; two-region tail on / off; an item's
+ *                     fixed cost in row-equivalents (160 000); one candidate histogram per query shared by its segments (1) or not
+ *   "flat_f32_share"  fp32 stream, batches beyond one wave's queries: 0 choose, 1 private rings only, 2 the shared-ring kernel
+ *   "hnsw_top_lds"    entries of an HNSW traversal's top queue kept in LDS (default 256; 0 = all)
+ *   "hnsw_slots"      cap on HNSW traversals per CU (0 = what LDS allows, at most 32)
+ *   "scans_dbg" / "flat_f32_dbg"  measurement switches of the small-batch scan and of the fp32 stream (phases skipped: results are WRONG
+ *                     when non-zero; development only) */
 int cvtmi_set_tuning(const char *name, int64_t value);
 
 /* ---------------------------------------------------------------- OPQ model + code index ---- */
