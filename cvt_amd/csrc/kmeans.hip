@@ -239,11 +239,15 @@ int launch_kmeans_assign(const float *x, int64_t ld, int64_t n, int d, const flo
     // before the lock is given back, as in launch_assign_filtered.
     if (g_assign_variant != 1 && changed == nullptr && n < 4096 && k >= 256 && d <= 128) {
         static std::mutex few_mu;
-        static DevBuf few_scr;
+        static DevBuf few_scr;       // grow-only; belongs to the device it was allocated on (a process may drive several)
+        static int few_dev = -1;
         std::lock_guard<std::mutex> guard(few_mu);
         const int row_blocks = (int)((n + kBlock - 1) / kBlock);
         const int splits = std::max(1, std::min((k + 63) / 64, (1024 + row_blocks - 1) / row_blocks));
         const size_t b_part = (((size_t)n * splits * sizeof(float)) + 255) & ~(size_t)255;
+        int cur = 0;
+        CVTMI_HIP(hipGetDevice(&cur));
+        if (cur != few_dev) { few_scr.release(); few_dev = cur; }   // (release() frees on the owning device: hipFree takes any device's pointer)
         CVTMI_TRY(few_scr.reserve(2 * b_part));
         const int rc = launch_kmeans_assign_split(x, ld, n, d, cent, k, assign, splits, few_scr.as<float>(),
                                                   reinterpret_cast<int32_t *>(few_scr.as<char>() + b_part), st);
