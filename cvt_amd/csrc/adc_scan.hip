@@ -1256,6 +1256,9 @@ ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int 
     if (want_variant == 7) {
         const bool resident = n_rows * 16 <= (96LL << 20), near = n_rows * 16 <= (256LL << 20);
         want_variant = (m.M == 16 && n_rows >= 131072 && nq >= 33 && ((resident && nq <= 3200) || (near && nq <= 512))) ? 6 : 3;
+        // one to three queries on a table too large for the small-batch form (api.hip scans_chosen): adc_scan16q takes four queries or
+        // more, and what is left below it -- the fp32-table / row-per-lane kernels -- needs 1.9-2.9 ms on 100 M rows against 1.2 ms here
+        if (m.M == 16 && !near && nq < 4) want_variant = 6;
     }
     if (m.M == 16 && want_variant >= 3 && (nq >= 4 || want_variant == 6) && m.D <= 256) { p.variant = want_variant; qt = 8; }
     else if (m.M == 16 && want_variant >= 1) {

@@ -1000,6 +1000,20 @@ static bool scans_chosen(const cvtmi_opq_s *h, int64_t nq, int k)
            h->n * ((nq + 7) / 8) <= g_scans_max_work.load();
 }
 
+// the dispatch a search would take, for inspection and for the CPU tests that pin the rules (include/cvtmi.h)
+extern "C" int cvtmi_opq_describe_dispatch(int D, int M, int K, int64_t n_rows, int64_t nq, int k, int out[7])
+{
+    if (!out || D < 1 || M < 1 || M > 16 || D % M != 0 || K < 1 || K > 256 || n_rows < 0 || nq < 1 || k < 1)
+        return fail(CVTMI_EINVAL, "cvtmi_opq_describe_dispatch: bad arguments");
+    cvtmi_opq_s h;   // default settings; nothing of it touches a device
+    h.m.D = D; h.m.M = M; h.m.K = K; h.m.step = D / M; h.m.coarseK = 1;
+    h.n = n_rows;
+    const bool small = scans_chosen(&h, nq, k);
+    const ScanPlan p = opq_plan(&h, nq, k);
+    out[0] = small ? 1 : 0; out[1] = p.variant; out[2] = p.qtile; out[3] = p.splits; out[4] = p.groups_a; out[5] = p.splits_b; out[6] = p.real_M;
+    return CVTMI_OK;
+}
+
 // one search on stream st with the scratch set S; the caller holds h->rw shared
 static int opq_search_leased(cvtmi_opq_t h, OpqScratch &S, const float *q, int64_t nq, int rotate, int k, float *dist, int64_t *ids, hipStream_t st)
 {

@@ -263,6 +263,14 @@ int cvtmi_opq_last_scan(cvtmi_opq_t h, float *ms, int64_t *code_bytes, int *qtil
 int64_t cvtmi_opq_scan_plan(int64_t n_rows, int64_t nq, int splits, int cus, int64_t *items, int64_t cap, int *grid, int *rounds,
                             int *stride);
 
+/* Which scan form a search of nq queries (top k) over n_rows code rows of a D-dimensional model with M sub-quantisers of K codewords
+ * would take under the default settings (pure host logic: no device needed; 256 CUs are assumed without one).  out[0] = 1: the
+ * small-batch form (up to 128 queries); otherwise out[1] = scan variant (3 / 4 = adc_scan16q, 5 = adc_scan16a, 6 = persistent grid,
+ * 0 .. 2 = the row-per-lane / fp32-table kernels), out[2] = queries per pass, out[3] = row splits, out[4] / out[5] = groups of the first
+ * region and row splits of the second of a two-region plan (0 0: one region), out[6] = M when the M = 16 kernels run over padded rows
+ * (M < 16), else 0.  What tests/test_scan_plan.py pins the dispatch rules of round 5 with. */
+int cvtmi_opq_describe_dispatch(int D, int M, int K, int64_t n_rows, int64_t nq, int k, int out[7]);
+
 /* Page-locked host memory.  The host-pointer entries move their arrays through pinned staging areas (one extra host copy each way);
  * arrays that already ARE page-locked -- from here, or the caller's own hipHostMalloc / hipHostRegister -- need none: page-locked
  * queries go to the copy engine as they are, and page-locked RESULT arrays of cvtmi_opq_search are written by the kernels themselves

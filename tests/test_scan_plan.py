@@ -108,3 +108,43 @@ def test_planner_follows_the_measured_split_counts(nq, want):
     0.70), 3000 queries 2 (1.04 ms; whole groups 1.24), whole groups from 3500 queries on."""
     _, grid, rounds, stride = plan(1_000_000, nq)
     assert stride == want, (nq, stride, grid, rounds)
+
+
+def dispatch(n_rows, nq, M=16, k=100, D=128, K=256):
+    lib = cvt_amd.lib()
+    out = (C.c_int * 7)()
+    assert lib.cvtmi_opq_describe_dispatch(D, M, K, C.c_int64(n_rows), C.c_int64(nq), k, out) == 0
+    return dict(small=out[0], variant=out[1], qtile=out[2], splits=out[3], groups_a=out[4], splits_b=out[5], padded_m=out[6])
+
+
+def test_dispatch_rules_of_round_5():
+    """The OPQ search's choice of scan form (cvtmi_opq_describe_dispatch: host logic, 256 CUs assumed without a device) at the cells
+    the round-5 sweeps fixed (profiles/r05_scan_dispatch_sweep.txt, r05_opq_m_sweep.txt) and at the ones that must not move."""
+    # the headline: whole query groups through adc_scan16q, no tail splits at 10 000 queries, the tail rule at 4256
+    d = dispatch(1_000_000, 10_000)
+    assert (d["small"], d["variant"], d["qtile"], d["splits"], d["splits_b"], d["padded_m"]) == (0, 3, 8, 1, 0, 0)
+    d = dispatch(1_000_000, 4256)
+    assert d["variant"] == 3 and d["splits"] == 1 and d["groups_a"] == 512 and d["splits_b"] > 1
+    # the SIFT-1B-shaped shard keeps adc_scan16q
+    assert dispatch(1 << 30, 1000)["variant"] == 3 and dispatch(128_000_000, 1000)["variant"] == 3
+    # small batches: the small-batch form while rows x query groups <= 48 M ...
+    assert dispatch(1_000_000, 1)["small"] == 1 and dispatch(1_000_000, 128)["small"] == 1 and dispatch(2_000_000, 128)["small"] == 1
+    assert dispatch(10_000_000, 32)["small"] == 1 and dispatch(30_000_000, 8)["small"] == 1
+    # ... and not beyond (30 M rows x 128 queries took 2.6 ms there against 1.3)
+    for n, nq in ((10_000_000, 64), (30_000_000, 16), (30_000_000, 128), (100_000_000, 1), (100_000_000, 128)):
+        assert dispatch(n, nq)["small"] == 0, (n, nq)
+    # the persistent grid: from 33 queries on a cache-resident matrix, up to 512 queries while it fits the Infinity Cache, and for one to
+    # three queries on tables too large for the small-batch form
+    assert dispatch(1_000_000, 1000)["variant"] == 6 and dispatch(3_000_000, 3000)["variant"] == 6 and dispatch(1_000_000, 4096)["variant"] == 3
+    assert dispatch(10_000_000, 64)["variant"] == 6 and dispatch(10_000_000, 512)["variant"] == 6 and dispatch(10_000_000, 1000)["variant"] == 3
+    assert dispatch(30_000_000, 256)["variant"] == 3
+    assert dispatch(100_000_000, 1)["variant"] == 6 and dispatch(100_000_000, 3)["variant"] == 6 and dispatch(100_000_000, 4)["variant"] == 3
+    # M < 16: the M = 16 kernels over padded rows, at every batch size; never the forms that build their tables from the codebooks
+    for M in (8, 4, 12, 1):
+        for nq in (1, 3, 64, 1000, 10_000):
+            d = dispatch(1_000_000, nq, M=M, D=M * 8)
+            assert d["padded_m"] == M and d["variant"] == 3 and d["small"] == 0 and d["qtile"] == 8, (M, nq, d)
+    assert dispatch(1_000_000, 10_000, M=16)["padded_m"] == 0
+    # k > 128: one query per workgroup, the large selection buffer
+    d = dispatch(1_000_000, 100, k=200)
+    assert d["variant"] == 0 and d["qtile"] == 1 and d["small"] == 0
