@@ -1908,6 +1908,25 @@ static FlatRoute flat_route(const cvtmi_flat_s *h, const void *q, int64_t nq, in
     return r;
 }
 
+// which pipeline a flat search would take under the current tuning values, for inspection and for the CPU tests that pin the
+// dispatch rules (include/cvtmi.h)
+extern "C" int cvtmi_flat_describe_dispatch(int metric, int D, int64_t n_rows, int64_t nq, int k, int out[4])
+{
+    if (!out || metric < 0 || metric > 2 || D < 1 || n_rows < 0 || nq < 1 || k < 1) return fail(CVTMI_EINVAL, "cvtmi_flat_describe_dispatch: bad arguments");
+    cvtmi_flat_s h;   // nothing of it touches a device; the buffers a route asks about count as present
+    static char present[16];
+    h.metric = metric; h.D = D; h.n = n_rows;
+    h.fs_bias.p = present; h.fs_stats.p = present; h.norms.p = present;
+    alignas(16) static const char aligned_q[16] = {};
+    const FlatRoute r = flat_route(&h, aligned_q, nq, k, FlatTuning::now());
+    h.fs_bias.p = nullptr; h.fs_stats.p = nullptr; h.norms.p = nullptr;
+    out[0] = r.stream ? 1 : 0;
+    out[1] = r.filt_f32 ? 1 : 0;
+    out[2] = r.filt_u8 ? 1 : 0;
+    out[3] = (metric == CVTMI_METRIC_L2U8 && !r.filt_u8 && flat_u8_mstream_applies(D, n_rows, std::min<int64_t>(nq, 128), k)) ? 1 : 0;
+    return CVTMI_OK;
+}
+
 // The lazily built parts of the index a route needs -- the host copy of the row statistics (fp32 stream), the operand copies of
 // the filter pipelines -- are built under the EXCLUSIVE lock, once per index state, and the stream is drained before the lock
 // is given back.  Called before the search takes its shared lock.

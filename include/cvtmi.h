@@ -271,6 +271,11 @@ int64_t cvtmi_opq_scan_plan(int64_t n_rows, int64_t nq, int splits, int cus, int
  * (M < 16), else 0.  What tests/test_scan_plan.py pins the dispatch rules of round 5 with. */
 int cvtmi_opq_describe_dispatch(int D, int M, int K, int64_t n_rows, int64_t nq, int k, int out[7]);
 
+/* The same for a flat search (metric: CVTMI_METRIC_*; pure host logic): out[0] = the fp32 one-stream kernels, out[1] = the fp32 sample +
+ * matrix-core filter pipeline is eligible behind them, out[2] = the uint8 sample + filter pipeline, out[3] = uint8 streaming passes of up
+ * to 128 queries; all zero: the exact / row-tile kernels. */
+int cvtmi_flat_describe_dispatch(int metric, int D, int64_t n_rows, int64_t nq, int k, int out[4]);
+
 /* Page-locked host memory.  The host-pointer entries move their arrays through pinned staging areas (one extra host copy each way);
  * arrays that already ARE page-locked -- from here, or the caller's own hipHostMalloc / hipHostRegister -- need none: page-locked
  * queries go to the copy engine as they are, and page-locked RESULT arrays of cvtmi_opq_search are written by the kernels themselves

@@ -148,3 +148,36 @@ def test_dispatch_rules_of_round_5():
     # k > 128: one query per workgroup, the large selection buffer
     d = dispatch(1_000_000, 100, k=200)
     assert d["variant"] == 0 and d["qtile"] == 1 and d["small"] == 0
+
+
+def flat_dispatch(metric, D, n_rows, nq, k=10):
+    lib = cvt_amd.lib()
+    out = (C.c_int * 4)()
+    assert lib.cvtmi_flat_describe_dispatch(metric, D, C.c_int64(n_rows), C.c_int64(nq), k, out) == 0
+    return dict(f32_stream=out[0], f32_filter=out[1], u8_filter=out[2], u8_stream=out[3])
+
+
+def test_flat_dispatch_rules_of_round_5():
+    """The flat search's routes (cvtmi_flat_describe_dispatch) at the cells the round-5 sweeps fixed (profiles/r05_u8_dispatch_sweep.txt,
+    r05_flat_small_tables.txt) and at the structural bounds that must stay."""
+    IP, L2F, L2U8 = 0, 1, 2
+    # uint8, C3: one stream up to 128 queries, the filter pipeline from 129 on
+    assert flat_dispatch(L2U8, 512, 10_000_000, 1)["u8_stream"] == 1 and flat_dispatch(L2U8, 512, 10_000_000, 128)["u8_stream"] == 1
+    for nq in (129, 256, 512, 1000, 4096):
+        assert flat_dispatch(L2U8, 512, 10_000_000, nq)["u8_filter"] == 1, nq
+    # mid-size tables: the pipeline from rows x width x queries >= 1.3e11 and 524 288 rows on, streaming passes below
+    assert flat_dispatch(L2U8, 512, 2_000_000, 256)["u8_filter"] == 1 and flat_dispatch(L2U8, 512, 1_048_576, 129)["u8_filter"] == 0
+    assert flat_dispatch(L2U8, 128, 1_048_576, 512)["u8_filter"] == 0 and flat_dispatch(L2U8, 128, 4_000_000, 512)["u8_filter"] == 1
+    assert flat_dispatch(L2U8, 512, 400_000, 1000)["u8_filter"] == 0 and flat_dispatch(L2U8, 512, 400_000, 1000)["u8_stream"] == 1
+    assert flat_dispatch(L2U8, 512, 10_000_000, 1000, k=100)["u8_filter"] == 0          # k > 64: passes through the stream
+    # small tables: the stream from its structural bound of 4096 rows
+    assert flat_dispatch(L2U8, 512, 4096, 100)["u8_stream"] == 1 and flat_dispatch(L2U8, 128, 65_536, 16)["u8_stream"] == 1
+    assert flat_dispatch(L2U8, 512, 4095, 100) == dict(f32_stream=0, f32_filter=0, u8_filter=0, u8_stream=0)
+    assert flat_dispatch(L2U8, 96, 1_000_000, 16)["u8_stream"] == 0                      # widths the matrix-core kernels do not take
+    # fp32: the stream at its widths from 32 768 rows (structural: lowered, it returned a wrong list), exact kernels elsewhere
+    for D in (32, 64, 96, 128, 192, 256):
+        assert flat_dispatch(L2F, D, 32_768, 1, k=100)["f32_stream"] == 1 and flat_dispatch(IP, D, 1_000_000, 1000, k=100)["f32_stream"] == 1
+    assert flat_dispatch(L2F, 128, 32_767, 1, k=100)["f32_stream"] == 0
+    for D in (100, 160, 384, 512):
+        assert flat_dispatch(L2F, D, 1_000_000, 100, k=100)["f32_stream"] == 0
+    assert flat_dispatch(L2F, 128, 1_000_000, 100, k=129)["f32_stream"] == 0
