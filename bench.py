@@ -92,8 +92,9 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=-1,
                     help="threads of the all-cores CPU leg (-1 = all logical cores, 0 = skip)")
     ap.add_argument("--recall-sample", type=int, default=1000)
-    ap.add_argument("--ref-rows", type=int, default=200_000, help="rows of the index the reference itself builds for cpu_baseline (0 = skip)")
-    ap.add_argument("--ref-queries", type=int, default=64)
+    ap.add_argument("--ref-rows", type=int, default=1_000_000,
+                    help="rows of the index the reference itself builds for cpu_baseline: the headline's own size by default, ~12 s of its Add (0 = skip)")
+    ap.add_argument("--ref-queries", type=int, default=1024, help="queries of the reference leg (~4 s at 1 M rows)")
     ap.add_argument("--hnsw-nodes", type=int, default=1_000_000, help="nodes of the config-5 graph (secondary.hnsw_c5)")
     ap.add_argument("--only", default="", help="development: comma list of secondary sections to run (rotation_encode, opq_m8, opq_rotation_learning, "
                                                "sq8, flat_f32, flat_u8_c3, ivf_query, hnsw_c5); default all")
@@ -735,8 +736,11 @@ def cpu_baseline_reference(ctx, q, result):
     result["cpu_baseline"] = {
         "value": round(nqs / t_q * rows_s / args.rows, 2), "unit": "queries/s", "cores": 1, "kind": "reference",
         "sample": "the reference's IVFOPQ::QueryThrehold, %d queries over a %d-row index it built itself from one feature file "
-                  "(IndexDatabase), %.2f s; value = queries/s x %d / %d rows (its scan is linear in the rows); host: %s" % (
-                      nqs, rows_s, t_q, rows_s, args.rows, _cpu_model()),
+                  "(IndexDatabase), %.2f s; %s; host: %s" % (
+                      nqs, rows_s, t_q,
+                      "measured at the headline's own row count" if rows_s == args.rows else
+                      "value = queries/s x %d / %d rows (its scan is linear in the rows)" % (rows_s, args.rows), _cpu_model()),
+        "rows": rows_s, "extrapolated": rows_s != args.rows,
         "queries_per_s_on_the_sample": round(nqs / t_q, 2),
         "reference_index_build_rows_per_s": round(rows_s / t_index, 1),
         "min_score_clamped_at_1": bool(np.all(ms == 1.0)),

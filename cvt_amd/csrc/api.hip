@@ -973,8 +973,13 @@ static int opq_prepare(cvtmi_opq_t h, int64_t nq, int k, hipStream_t st)
     if (padded) {   // the 16-byte rows first: the rotated copy is made from them
         if (h->pad_n > h->n) h->pad_n = 0;
         if (h->codes16.cap < (size_t)h->n * 16) {
-            CVTMI_TRY(h->codes16.reserve(std::max<size_t>(h->codes.cap / (size_t)h->m.M * 16, (size_t)h->n * 16)));
+            // The derived copies are an optimisation (16 + 16 bytes per row beside M): when HBM does not hold them the search must still
+            // answer -- the row-per-lane kernels take the index as it is (opq_search_leased checks pad_n == n).  ADVICE r5.
+            int rc = h->codes16.reserve(std::max<size_t>(h->codes.cap / (size_t)h->m.M * 16, (size_t)h->n * 16));
+            if (rc == CVTMI_ENOMEM) rc = h->codes16.reserve((size_t)h->n * 16);   // without the growth margin of the code buffer
             h->pad_n = 0;  // reserve() does not keep the old contents
+            if (rc == CVTMI_ENOMEM) { (void)hipGetLastError(); g_err.clear(); return CVTMI_OK; }
+            CVTMI_TRY(rc);
         }
         CVTMI_TRY(launch_pad_codes(h->codes.as<uint8_t>(), h->m.M, h->codes16.as<uint8_t>(), h->pad_n, h->n, st));
         h->pad_n = h->n;
@@ -982,8 +987,11 @@ static int opq_prepare(cvtmi_opq_t h, int64_t nq, int k, hipStream_t st)
     }
     if (h->rot_n > h->n) h->rot_n = 0;
     if (h->codes_rot.cap < (size_t)h->n * 16) {
-        CVTMI_TRY(h->codes_rot.reserve(std::max<size_t>(padded ? h->codes16.cap : h->codes.cap, (size_t)h->n * 16)));
+        int rc = h->codes_rot.reserve(std::max<size_t>(padded ? h->codes16.cap : h->codes.cap, (size_t)h->n * 16));
+        if (rc == CVTMI_ENOMEM) rc = h->codes_rot.reserve((size_t)h->n * 16);
         h->rot_n = 0;  // reserve() does not keep the old contents
+        if (rc == CVTMI_ENOMEM) { (void)hipGetLastError(); g_err.clear(); return CVTMI_OK; }   // (the scans rotate in registers without it)
+        CVTMI_TRY(rc);
     }
     CVTMI_TRY(launch_rotate_codes(padded ? h->codes16.as<uint8_t>() : h->codes.as<uint8_t>(), h->codes_rot.as<uint8_t>(), h->rot_n, h->n, st));
     h->rot_n = h->n;
@@ -1150,7 +1158,12 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
         }
     }
     int64_t per = g_host_chunks.load();
+    const int64_t per_default = per > 0 ? per : 4096;
     if (per <= 0 || nq < per + per / 4 || zd) per = nq;
+    // (zero-copy results keep the batch whole only while its QUERIES fit the staging guard below: past that -- more than 131 072
+    //  queries at D = 128 -- the batch goes out in the default pieces, still straight into the caller's arrays, rather than through a
+    //  freshly allocated device copy of everything: ADVICE r5)
+    if (zd && (per > (64 << 20) / (int64_t)(D * 4) || (size_t)per * k * 12 > ((size_t)256 << 20))) per = per_default;
     per = (per + 7) / 8 * 8;   // whole query groups
     const int chunks = (int)((nq + per - 1) / per);
     if (per > (64 << 20) / (int64_t)(D * 4) || (size_t)per * k * 12 > ((size_t)256 << 20)) {
@@ -1227,6 +1240,12 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
         (void)hipGetLastError();
     }
     int c = 0;
+    // a piece that fails leaves earlier pieces in flight, writing into the caller's arrays or the staging areas: nothing is handed
+    // back (and no lease released) before both streams have drained
+    const auto fail_after_drain = [&](int rc) -> int {
+        for (int j = 0; j < nsets; ++j) (void)stream_wait(lease[j].st);
+        return rc;
+    };
     for (int64_t q0 = 0; q0 < nq; q0 += per, ++c) {
         const int i = c % nsets;
         const int64_t n = std::min(per, nq - q0);
@@ -1234,13 +1253,18 @@ int cvtmi_opq_search(cvtmi_opq_t h, const float *q, int64_t nq, int rotate, int 
         OpqScratch &S = *lease[i].s;
         hipStream_t st = lease[i].st;
         const void *src = q + q0 * D;
+        if (zd && c >= nsets) CVTMI_HIP(stream_wait(st));   // (zero-copy pieces: the set's query upload of two pieces ago must have been consumed)
         if (!q_pinned) { memcpy(S.io_pin.p, src, (size_t)n * D * sizeof(float)); src = S.io_pin.p; }
         CVTMI_HIP(hipMemcpyAsync(S.io_q.p, src, (size_t)n * D * sizeof(float), hipMemcpyHostToDevice, st));
-        if (zd) {   // (one piece: the final wait below is all that is left)
-            CVTMI_TRY(opq_search_leased(h, S, S.io_q.as<float>(), n, rotate, k, zd + q0 * k, zi + q0 * k, st));
+        if (zd) {   // (normally one piece: the final wait below is all that is left)
+            const int rc = opq_search_leased(h, S, S.io_q.as<float>(), n, rotate, k, zd + q0 * k, zi + q0 * k, st);
+            if (rc != CVTMI_OK) return fail_after_drain(rc);
             continue;
         }
-        CVTMI_TRY(opq_search_leased(h, S, S.io_q.as<float>(), n, rotate, k, S.io_d.as<float>(), S.io_i.as<int64_t>(), st));
+        {
+            const int rc = opq_search_leased(h, S, S.io_q.as<float>(), n, rotate, k, S.io_d.as<float>(), S.io_i.as<int64_t>(), st);
+            if (rc != CVTMI_OK) return fail_after_drain(rc);
+        }
         if (out_pinned) {  // straight into the caller's page-locked arrays; the final drain only waits for the streams
             CVTMI_HIP(hipMemcpyAsync(dist + q0 * k, S.io_d.p, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost, st));
             CVTMI_HIP(hipMemcpyAsync(ids + q0 * k, S.io_i.p, (size_t)n * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));

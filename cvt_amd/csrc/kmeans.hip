@@ -238,19 +238,25 @@ int launch_kmeans_assign(const float *x, int64_t ld, int64_t n, int d, const flo
     // same strict '<': same assignment), as the filter does for the rows it cannot decide.  The scratch is shared: the stream is drained
     // before the lock is given back, as in launch_assign_filtered.
     if (g_assign_variant != 1 && changed == nullptr && n < 4096 && k >= 256 && d <= 128) {
-        static std::mutex few_mu;
-        static DevBuf few_scr;       // grow-only; belongs to the device it was allocated on (a process may drive several)
-        static int few_dev = -1;
-        std::lock_guard<std::mutex> guard(few_mu);
+        // One grow-only scratch PER DEVICE with its own lock (round 6): handles on different devices (IVFOPQ::SetDevices adds
+        // to them in turn) neither wait for each other nor free and reallocate each other's buffer.  Callers on one device still take
+        // turns, and the stream is drained under the lock -- this entry is not capturable into a graph, like launch_assign_filtered.
+        constexpr int kFewDevs = 16;
+        static std::mutex few_mu[kFewDevs + 1];
+        static DevBuf few_scr[kFewDevs + 1];   // the last slot: any device number past the table (shared, reallocated on a change of device)
+        static int few_other_dev = -1;
+        int cur = 0;
+        CVTMI_HIP(hipGetDevice(&cur));
+        const int slot = cur >= 0 && cur < kFewDevs ? cur : kFewDevs;
+        std::lock_guard<std::mutex> guard(few_mu[slot]);
+        DevBuf &scr = few_scr[slot];
+        if (slot == kFewDevs && cur != few_other_dev) { scr.release(); few_other_dev = cur; }
         const int row_blocks = (int)((n + kBlock - 1) / kBlock);
         const int splits = std::max(1, std::min((k + 63) / 64, (1024 + row_blocks - 1) / row_blocks));
         const size_t b_part = (((size_t)n * splits * sizeof(float)) + 255) & ~(size_t)255;
-        int cur = 0;
-        CVTMI_HIP(hipGetDevice(&cur));
-        if (cur != few_dev) { few_scr.release(); few_dev = cur; }   // (release() frees on the owning device: hipFree takes any device's pointer)
-        CVTMI_TRY(few_scr.reserve(2 * b_part));
-        const int rc = launch_kmeans_assign_split(x, ld, n, d, cent, k, assign, splits, few_scr.as<float>(),
-                                                  reinterpret_cast<int32_t *>(few_scr.as<char>() + b_part), st);
+        CVTMI_TRY(scr.reserve(2 * b_part));
+        const int rc = launch_kmeans_assign_split(x, ld, n, d, cent, k, assign, splits, scr.as<float>(),
+                                                  reinterpret_cast<int32_t *>(scr.as<char>() + b_part), st);
         CVTMI_HIP(hipStreamSynchronize(st));
         return rc;
     }

@@ -972,6 +972,7 @@ __device__ __forceinline__ float sq8_thr_lo(float mn)   // p' >= this  =>  a >= 
     const float am = fabsf(mn);
     if (am == 0.0f) return 0.0f;
     if (!(am >= 0x1p-120f)) return __uint_as_float(0x7f800000u);   // a denormal extreme: every element is divided exactly
+    if (!(am < 0x1p66f)) return __uint_as_float(0x7f800000u);      // the 2^60 scaling would overflow (un-normalised rows only): likewise
     return __fmul_rn(__fmaf_rn(am, 0x1p-21f, mn), 0x1p60f);
 }
 __device__ __forceinline__ float sq8_thr_hi(float mx)   // p' <= this  =>  a <= mx
@@ -979,6 +980,7 @@ __device__ __forceinline__ float sq8_thr_hi(float mx)   // p' <= this  =>  a <= 
     const float am = fabsf(mx);
     if (am == 0.0f) return 0.0f;
     if (!(am >= 0x1p-120f)) return __uint_as_float(0xff800000u);
+    if (!(am < 0x1p66f)) return __uint_as_float(0xff800000u);      // (an element that large makes p' infinite: above any finite threshold, open)
     return __fmul_rn(__fmaf_rn(am, -0x1p-21f, mx), 0x1p60f);
 }
 

@@ -129,7 +129,23 @@ void TrainPQ::SaveCodebook(std::string desDir)
     out.write(reinterpret_cast<const char *>(reorder_.data()), sizeof(int) * (size_t)m_featDim);
     out.close();
     if (!m_R.empty()) {   // LearnRotation: the dense rotation beside the model (the model format has no slot for it)
+        // The sample was permuted by reorder_ when it was loaded (LoadFeatureSample, :80), so R and the codebooks were learned for
+        // y = R (P x) with (P x)[n] = x[reorder_[n]].  IVFOPQ::LoadRotation applies the file's matrix to the RAW vector and drops the
+        // permutation (a handle has a rotation or a permutation), so the file carries the product R P:  R'[i][reorder_[n]] = R[i][n].
+        std::vector<float> folded(m_R.size(), 0.0f);
+        std::vector<char> seen((size_t)m_featDim, 0);
+        for (int n = 0; n < m_featDim; n++) {   // (LoadFeatureSample indexed the rows with these values: they are in range if we got here)
+            const long int j = reorder_[(size_t)n];
+            if (j < 0 || j >= m_featDim || seen[(size_t)j]) {
+                std::cout << "SaveCodebook: the reorder file is not a permutation of 0.." << m_featDim - 1 << ": rotation not written" << std::endl;
+                return;
+            }
+            seen[(size_t)j] = 1;
+        }
+        for (int i = 0; i < m_featDim; i++)
+            for (int n = 0; n < m_featDim; n++)
+                folded[(size_t)i * m_featDim + (size_t)reorder_[(size_t)n]] = m_R[(size_t)i * m_featDim + n];
         std::ofstream rout((m_desDir + ".R.f32").c_str(), std::ios::binary);
-        rout.write(reinterpret_cast<const char *>(m_R.data()), sizeof(float) * m_R.size());
+        rout.write(reinterpret_cast<const char *>(folded.data()), sizeof(float) * folded.size());
     }
 }

@@ -250,6 +250,31 @@ def test_sq8_train_wave_kernel(amd, orc, d):
 
 
 @pytest.mark.parametrize("d", [512, 256])
+def test_sq8_train_unnormalised_huge_magnitudes(amd, orc, d):
+    """without normalisation the wave kernel's decision filter scales elements by 2^60 -- an extreme of 2^68 or more sent
+    its own threshold (and the scaled elements) to infinity, and strictly larger elements were never compared.  Columns whose
+    maximum / minimum climbs through 1e20 .. 3e38 in steps, early and late in the table, filter on and off, against the chain."""
+    import torch
+    rng = np.random.default_rng(d + 99)
+    n = 12_000 + 5
+    x = rng.normal(size=(n, d)).astype(np.float32)
+    steps = np.float32([1e19, 3e20, 2e21, 5e24, 1e30, 3e38])
+    for c in range(0, 24):   # rising maxima in columns 0..11, falling minima in 12..23, spread over the rows of many waves
+        rows = rng.choice(n, size=len(steps), replace=False); rows.sort()
+        x[rows, c] = steps if c < 12 else -steps
+    x[n - 1, 30] = np.float32(2.5e38); x[0, 31] = np.float32(-2.5e38)   # the last / the first row holds the extreme
+    ovm, ovd = orc.sq8_train(x.copy(), l2norm=False)
+    for filt in (1, 0):
+        amd.set_tuning("sq8_filter", filt)
+        try:
+            tv, td = amd.sq8_train(torch.from_numpy(x.copy()).cuda(), l2norm=False)
+        finally:
+            amd.set_tuning("sq8_filter", 1)
+        assert np.array_equal(bits(tv.cpu().numpy()), bits(ovm)), (filt, np.flatnonzero(bits(tv.cpu().numpy()) != bits(ovm))[:8])
+        assert np.array_equal(bits(td.cpu().numpy()), bits(ovd)), (filt, np.flatnonzero(bits(td.cpu().numpy()) != bits(ovd))[:8])
+
+
+@pytest.mark.parametrize("d", [512, 256])
 def test_sq8_encode_wave_kernel(amd, orc, d):
     """Encode at d = 256 / 512 and >= 4096 rows takes the wave-per-row kernel, with and without normalisation: codes and the
     normalised rows written back must equal the oracle's bit for bit (and the tile kernel's), including rows whose norm needs the

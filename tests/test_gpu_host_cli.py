@@ -190,6 +190,49 @@ def test_opq_learned_rotation_cli(tmp_path, orc):
         assert ids == list(oi[qi]), qi
 
 
+def test_opq_learned_rotation_with_a_reorder_file(tmp_path, orc):
+    """opq_train permutes the sample by the reorder file BEFORE it learns R, so R and the codebooks belong to
+    y = R (P x); opq_search --rotation applies the saved matrix to the raw vector and drops the permutation.  The saved matrix must
+    therefore be the product R P -- with a non-identity reorder file: the saved matrix is the oracle's R (learned on the permuted
+    sample) with its columns moved, bit for bit, and the search lists equal the oracle's under that matrix."""
+    rng = np.random.default_rng(16)
+    D, M, K, n, nq, k = 32, 4, 32, 3000, 40, 10
+    A = rng.normal(size=(D, D))
+    x = ((rng.normal(size=(n + nq, D)) * np.exp(-np.arange(D) / 6.0)) @ A.T).astype(np.float32)
+    db, q = x[:n], x[n:]
+    perm = rng.permutation(D)
+    assert not np.array_equal(perm, np.arange(D))
+    (tmp_path / "reorder.bin").write_bytes(perm.astype(np.int64).tobytes())
+    (tmp_path / "feats.bin").write_bytes(db.tobytes())
+    run([os.path.join(BIN, "opq_train"), str(tmp_path / "reorder.bin"), str(tmp_path / "feats.bin"), str(tmp_path), str(n), "1", str(D),
+         str(M), str(K), "--learn-rotation=3"], cwd=str(tmp_path))
+    model = tmp_path / ("OPQ_db_%d_dim_%d_k_1_PQ_m%d_k%d.fvecs" % (n, D, M, K))
+    raw = model.read_bytes()
+    books = np.frombuffer(raw, np.float32, K * D, 16 + 4 * D).reshape(M, K, D // M)
+    Rf = np.frombuffer((tmp_path / (model.name + ".R.f32")).read_bytes(), np.float32).reshape(D, D)
+    oR, ob = orc.opq_learn_rotation(np.ascontiguousarray(db[:, perm]), M, K, 3, 0, 1)     # what the trainer saw: (P x)[n] = x[perm[n]]
+    folded = np.zeros_like(oR)
+    folded[:, perm] = oR                                                                  # R'[i][perm[n]] = R[i][n]
+    assert np.array_equal(bits(Rf), bits(folded)) and np.array_equal(bits(books), bits(ob))
+    proper = tmp_path / "model_int32.bin"
+    proper.write_bytes(raw[:16 + 4 * D + 4 * K * D] + perm.astype(np.int32).tobytes())    # a reorder the rotation must override
+    (tmp_path / "q.bin").write_bytes(q.tobytes())
+    run([os.path.join(BIN, "opq_search"), str(proper), str(tmp_path / "feats.bin"), str(tmp_path / "q.bin"), str(tmp_path / "res.txt"),
+         "--k", str(k), "--rotation", str(tmp_path / (model.name + ".R.f32"))], cwd=str(tmp_path))
+    _, codes = orc.pq_encode(orc.rotate_fma(folded, db), np.zeros((1, D), np.float32), ob)
+    od, oi = orc.adc_search(orc.rotate_fma(folded, q), ob, codes, k)
+    lines = (tmp_path / "res.txt").read_text().strip().splitlines()
+    assert len(lines) == nq
+    for qi, line in enumerate(lines):
+        ids = [int(t) for t in line.split("topK:")[1].split("dists:")[0].split()]
+        assert ids == list(oi[qi]), qi
+    # and the model is a good one: the learned rotation beats the plain permutation on quantisation error of the database rows
+    y = orc.rotate_fma(folded, db)
+    rec = np.concatenate([ob[m][codes[:, m]] for m in range(M)], axis=1)
+    err_rot = float(((y - rec) ** 2).sum(1).mean())
+    assert err_rot < float((db ** 2).sum(1).mean())
+
+
 def test_hnsw_search_cli(tmp_path, golden):
     """hnswlib::HierarchicalNSW mirror (loadIndex + setEf + searchKnnBatch) through its CLI, on a graph file the
     reference wrote: labels and distances of every query equal the reference's own answers."""

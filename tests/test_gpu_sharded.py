@@ -1,9 +1,10 @@
 """GPU: the row-sharded search INSIDE the library (cvtmi_comm_*, cvtmi_opq_search_sharded*, csrc/shard.hip).
 
 * world 1 through real RCCL ("comm_force_rccl"): ncclGetUniqueId / ncclCommInitRank / ncclAllGather are bound and run.
-* world 2 and 3 as separate processes sharing this box's one GPU: RCCL refuses two ranks on one device, so the ranks
-  exchange through the caller-supplied transport (gloo, staged through the host) -- the slot layout, the zero-copy
-  local search into the slot and topk_merge_kernel<true> are exactly what the RCCL transport feeds.
+* world 2, 3 and 8 (BASELINE configs[3]'s rank count, shards of 0 and 1 rows included) as separate processes sharing this
+  box's one GPU: RCCL refuses two ranks on one device, so the ranks exchange through the caller-supplied transport (gloo,
+  staged through the host) -- the slot layout, the zero-copy local search into the slot and topk_merge_kernel<true> are
+  exactly what the RCCL transport feeds.  `bench.py --gpus 8 --backend host` runs the configs[3] bench path at 8 ranks.
 Results must equal a single handle holding every row, and the oracle, bit for bit (ids and distance bits)."""
 import os
 import socket
@@ -24,7 +25,7 @@ def _case(seed, n, nq, D=128, M=16, K=256, dup=0):
     books = (rng.normal(size=(M, K, D // M)) * 0.1).astype(np.float32)
     codes = rng.integers(0, K, size=(n, M), dtype=np.uint8)
     if dup and n > 4:  # exact duplicates on both sides of every shard boundary: ties across ranks
-        for w in (2, 3):
+        for w in (2, 3, 8):
             for r in range(1, w):
                 b = (n // w) * r + min(r, n % w)
                 lo, hi = max(0, b - dup), min(n, b + dup)
@@ -102,7 +103,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,n,nq", [(2, 200_000, 64), (3, 100_001, 33), (3, 2, 5), (2, 300, 9)])
+@pytest.mark.parametrize("world,n,nq", [(2, 200_000, 64), (3, 100_001, 33), (3, 2, 5), (2, 300, 9),
+                                        (8, 200_003, 40), (8, 9, 5), (8, 5, 3)])   # 8 ranks: shards of 25 000, of 2 / 1 and of 1 / 0 rows
 def test_multi_rank_one_gpu_matches_single_handle(world, n, nq, tmp_path, orc):
     import torch
     import cvt_amd
@@ -294,12 +296,12 @@ def test_flat_row_shards_match_single_handle(world, metric, D, n, tmp_path, orc)
         assert int(z["failed"]) == 1 and int(z["failed_now"]) == 1 and int(z["again"]) == 1, (r, int(z["failed"]), int(z["failed_now"]), int(z["again"]))
 
 
-def _bench_line(extra, timeout=600):
-    """`python bench.py --gpus 2 ...` with NO launcher around it and no RANK / WORLD_SIZE in the environment"""
+def _bench_line(extra, timeout=600, gpus=2, large_rows=1 << 22):
+    """`python bench.py --gpus N ...` with NO launcher around it and no RANK / WORLD_SIZE in the environment"""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nq", "600", "--steps", "2", "--warmup", "1",
-           "--rows", "200000", "--large-rows", str(1 << 22), "--oracle-queries", "8", "--comm-timeout", "60"] + extra
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--nq", "600", "--steps", "2", "--warmup", "1",
+           "--rows", "200000", "--large-rows", str(large_rows), "--oracle-queries", "8", "--comm-timeout", "60"] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, stdin=subprocess.DEVNULL)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -307,8 +309,8 @@ def _bench_line(extra, timeout=600):
     return json.loads(lines[0])
 
 
-def _check_evidence(line):
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+def _check_evidence(line, gpus=2):
+    assert line["n_gpus"] == gpus and line["scaling"] == "strong" and line["value"] > 0
     assert line["transport"] == "custom" and line["rccl_ranks"] == 0   # one GPU here: the ranks exchange through the host
     assert line["collectives_per_search"] == 1.0
     ident = line["identical_to_oracle_sample"]
@@ -316,9 +318,9 @@ def _check_evidence(line):
     assert ident["recall_at_1_identical_to_cpu"]
     assert 0.0 <= line["recall_at_1"] <= 1.0
     cb = line["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 2 and cb["value"] > 0
+    assert cb["kind"] == "port" and cb["cores"] == gpus and cb["value"] > 0
     assert "roofline" in line and line["roofline"]["bound"] == "lds"
-    assert line["sift1b"]["comm"]["world"] == 2
+    assert line["sift1b"]["comm"]["world"] == gpus
     one = line["same_workload_on_one_gpu"]      # the N = 1 point of the same workload, measured in the same run by rank 0 alone
     assert one["value"] > 0 and one["sharded_result_identical"] and line["speedup_over_one_gpu"] > 0
 
@@ -328,6 +330,17 @@ def test_bench_gpus2_self_launch_host_transport():
     line = _bench_line(["--backend", "host"])
     _check_evidence(line)
     assert "error" not in line
+
+
+def test_bench_gpus8_configs3_shape_on_one_gpu():
+    """BASELINE configs[3] at its own rank count before an 8-GPU node runs it -- `bench.py --gpus 8` over the host
+    transport on this one GPU: 2^26 SIFT-shaped rows in 8 row shards (8 M rows = 128 MB of codes each), ONE all-gather of per-shard
+    top-k per search, every rank's merged list equal to the oracle sample and to one handle holding all the rows.
+    (Reference shape of the exchange: retrieval/vlindex/lib/FLANN/mpi/index.h:196-226.)"""
+    line = _bench_line(["--backend", "host"], timeout=1500, gpus=8, large_rows=1 << 26)
+    _check_evidence(line, gpus=8)
+    assert "error" not in line
+    assert line["config"]["rows"] == 1 << 26 and line["config"]["rows_per_gpu"] == 1 << 23
 
 
 def test_bench_gpus2_without_second_gpu_still_prints_a_line():
