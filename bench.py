@@ -910,41 +910,48 @@ def _sec_rotation_encode(ctx):
 
 
 def _sec_opq_m8(ctx):
-    """BASELINE configs[0]'s model shape (M = 8, K = 256: the reference's own test model) at the headline's table size: M < 16 runs
-    through the M = 16 scan kernels over rows padded to 16 code bytes (round 5), next to the row-per-lane kernels it had before"""
+    """BASELINE configs[0]'s model shape (M = 8, K = 256: the reference's own test model) at the headline's table size, and M = 4:
+    the native packed scan (round 6, adc_scan16p: 16 / M rows per 16-byte load), next to the padded rows through the M = 16 kernels
+    (round 5) and the row-per-lane kernels it had before -- all three must return the same lists"""
     torch, cvt, synth, args = ctx.torch, ctx.cvt, ctx.synth, ctx.args
-    M8, k, nq = 8, ctx.k, ctx.nq
-    tmp = cvt.OpqIndex(ctx.zero_coarse, np.zeros((M8, K, D // M8), np.float32), R=ctx.R)
-    books = synth.train_books(tmp.rotate(synth.sift_like(100_000, D, seed=0xC0FFEE, device=ctx.dev)), M8, K, iters=4)
-    tmp.close()
-    ix = cvt.OpqIndex(ctx.zero_coarse, books, R=ctx.R)
-    ix.reserve(args.rows)
-    step = synth.CHUNK * 4
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for a in range(0, args.rows, step):
-        b = min(args.rows, a + step)
-        _, codes = ix.encode(ix.rotate(synth.sift_like(b - a, D, seed=0xC0FFEE, row_begin=a, device=ctx.dev)))
-        ix.add_codes(codes)
-    torch.cuda.synchronize(); t_build = time.perf_counter() - t0
-    q = synth.sift_like(nq, D, seed=0xBEEF, device=ctx.dev)
-    res = {"rows": args.rows, "M": M8, "nq": nq, "k": k, "index_build_s": round(t_build, 3),
-           "what": "rotate + encode + ADC top-%d of %d queries over %d rows of 8-byte codes" % (k, nq, args.rows)}
-    ref = None
-    try:
-        for name, pad in (("padded_rows_through_the_m16_kernels", 1), ("row_per_lane_kernels", 0)):
-            cvt.set_tuning("scan_pad_m", pad)
-            ms = _ev_ms(torch, lambda: ix.search(q, k, rotate=True), reps=max(2, min(5, args.steps)), warm=2)
-            d, i = ix.search(q, k, rotate=True)
-            if ref is None:
-                ref = (d, i)
-            res[name] = {"ms": round(ms, 4), "queries_per_s": round(nq / (ms * 1e-3), 1),
-                         "identical": bool(torch.equal(i, ref[1]) and torch.equal(d.view(torch.int32), ref[0].view(torch.int32)))}
-    finally:
-        cvt.set_tuning("scan_pad_m", 1)
-    if ctx.exact_nn is not None and ctx.exact_nn.shape[0] >= nq:
-        res["recall_at_1"] = round(float((ref[1][:, 0] == ctx.exact_nn[:nq]).float().mean().item()), 4)
-    ix.close()
-    return res
+    k, nq = ctx.k, ctx.nq
+    out = {}
+    for Mx in (8, 4):
+        tmp = cvt.OpqIndex(ctx.zero_coarse, np.zeros((Mx, K, D // Mx), np.float32), R=ctx.R)
+        books = synth.train_books(tmp.rotate(synth.sift_like(100_000, D, seed=0xC0FFEE, device=ctx.dev)), Mx, K, iters=4)
+        tmp.close()
+        ix = cvt.OpqIndex(ctx.zero_coarse, books, R=ctx.R)
+        ix.reserve(args.rows)
+        step = synth.CHUNK * 4
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for a in range(0, args.rows, step):
+            b = min(args.rows, a + step)
+            _, codes = ix.encode(ix.rotate(synth.sift_like(b - a, D, seed=0xC0FFEE, row_begin=a, device=ctx.dev)))
+            ix.add_codes(codes)
+        torch.cuda.synchronize(); t_build = time.perf_counter() - t0
+        q = synth.sift_like(nq, D, seed=0xBEEF, device=ctx.dev)
+        res = {"rows": args.rows, "M": Mx, "nq": nq, "k": k, "index_build_s": round(t_build, 3),
+               "what": "rotate + encode + ADC top-%d of %d queries over %d rows of %d-byte codes" % (k, nq, args.rows, Mx)}
+        ref = None
+        try:
+            for name, pad, packed in (("packed_rows_native_scan", 1, 1), ("padded_rows_through_the_m16_kernels", 1, 0), ("row_per_lane_kernels", 0, 0)):
+                cvt.set_tuning("scan_pad_m", pad); cvt.set_tuning("scan_packed_m", packed)
+                ms = _ev_ms(torch, lambda: ix.search(q, k, rotate=True), reps=max(2, min(5, args.steps)), warm=2)
+                d, i = ix.search(q, k, rotate=True)
+                if ref is None:
+                    ref = (d, i)
+                res[name] = {"ms": round(ms, 4), "queries_per_s": round(nq / (ms * 1e-3), 1),
+                             "identical": bool(torch.equal(i, ref[1]) and torch.equal(d.view(torch.int32), ref[0].view(torch.int32)))}
+        finally:
+            cvt.set_tuning("scan_pad_m", 1); cvt.set_tuning("scan_packed_m", 1)
+        if ctx.exact_nn is not None and ctx.exact_nn.shape[0] >= nq:
+            res["recall_at_1"] = round(float((ref[1][:, 0] == ctx.exact_nn[:nq]).float().mean().item()), 4)
+        ix.close()
+        if Mx == 8:
+            out = res
+        else:
+            out["m4"] = res
+    return out
 
 
 def _sec_rotation_learning(ctx):

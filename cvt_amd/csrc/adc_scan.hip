@@ -1463,6 +1463,7 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
             CVTMI_HIP(hipMemsetAsync(gthr, 0xff, (size_t)nq * sizeof(uint32_t), st));
             a.gthr = gthr;
         }
+        if (plan.packed) return launch_adc_scan16p(a, plan.real_M, blocks, st);   // (codes = the model's own rows, codes_rot = their packed rotation)
         const dim3 g((unsigned)blocks);
         if (codes_rot) {
             if (plan.variant == 3) hipLaunchKernelGGL((adc_scan16q_kernel<1024, 1, true>), g, dim3(1024), 0, st, a);

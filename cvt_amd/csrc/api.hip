@@ -91,6 +91,7 @@ struct cvtmi_opq_s {
     int64_t rot_n = 0;    // rows of codes_rot that are up to date
     DevBuf codes16;       // M < 16: the rows padded to 16 bytes with zeros, what the M = 16 scan kernels read (opq_pads; built lazily like codes_rot, which is then its rotation)
     int64_t pad_n = 0;    // rows of codes16 that are up to date
+    int rot_kind = 0;     // what codes_rot holds: 0 = 16-byte rows (M = 16, or the padded copy) rotated by row & 15; 1 = the packed rotation of an M = 8 / 4 index (adc_scan_p.hip)
     int64_t n = 0;
     bool has_lists = false, has_videos = false;
     int64_t id_base = 0;
@@ -340,6 +341,7 @@ static bool host_pinned(const void *p)
 static std::atomic<int> g_hnsw_slots_cap{0};   // cvtmi_set_tuning("hnsw_slots"): cap on traversals per CU (0 = what LDS allows, at most 32)
 static std::atomic<int> g_small_zero_copy{1};   // cvtmi_set_tuning("opq_small_zero_copy"): 1 .. 8-query host-pointer searches read / write the pinned staging area from the kernels
 static std::atomic<int64_t> g_scans_max_work{(int64_t)48 << 20};   // cvtmi_set_tuning("scans_max_work"): rows x query groups up to which the OPQ small-batch form answers (scans_chosen)
+static std::atomic<int> g_scan_packed{1};        // cvtmi_set_tuning("scan_packed_m"): 0 = M = 8 / 4 through the padded rows like every other M < 16 (round 5), 1 = adc_scan16p
 static std::atomic<int> g_scan_pad{1};           // cvtmi_set_tuning("scan_pad_m"): 0 = an OPQ index with M < 16 stays on the row-per-lane scan kernels (opq_pads)
 static std::atomic<int> g_sq8_host_small{1};     // cvtmi_set_tuning("sq8_host_small"): small SQ8 host-pointer calls run out of a page-locked scratch area (Sq8HostScratch)
 static std::atomic<int> g_flat_u8_filter_min_nq{129};            // cvtmi_set_tuning("flat_u8_filter_min_nq" / "_min_rows" / "_min_work"): smallest batch, table and
@@ -483,6 +485,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "sq8_filter")) { set_sq8_filter(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "scan_pad_m")) { g_scan_pad = value != 0; return CVTMI_OK; }
+    if (!strcmp(name, "scan_packed_m")) { g_scan_packed = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "sq8_host_small")) { g_sq8_host_small = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "scans_max_work")) { g_scans_max_work = value < 0 ? 0 : value; return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_filter_min_nq")) { g_flat_u8_filter_min_nq = value < 1 ? 1 : value > (1 << 30) ? (1 << 30) : (int)value; return CVTMI_OK; }
@@ -935,9 +938,14 @@ static ScanPlan opq_plan(cvtmi_opq_t h, int64_t nq, int k)
         m16.M = 16;
         // (the persistent grid and the small-batch form build their tables from the codebooks themselves: adc_scan16q / 16a only)
         // (planned as at least four queries: below that plan_scan prefers the fp32-table kernels, which build their tables from the codebooks)
-        ScanPlan pp = plan_scan(m16, h->n, std::max<int64_t>(nq, 4), k, 0, h->p_splits, h->p_variant == 4 || h->p_variant == 5 ? h->p_variant : 3);
+        // M = 8 / 4 natively (adc_scan16p: 16 / M rows per 16-byte load; needs the pre-rotated copy): planned in units of loads -- a load
+        // costs what an M = 16 row costs, so the split decision sees n / RPL "rows"
+        const bool packed = g_scan_packed.load() && (h->m.M == 8 || h->m.M == 4) && h->p_prerot && h->p_variant != 4 && h->p_variant != 5;
+        const int64_t n_plan = packed ? (h->n * h->m.M + 15) / 16 : h->n;
+        ScanPlan pp = plan_scan(m16, n_plan, std::max<int64_t>(nq, 4), k, 0, h->p_splits, h->p_variant == 4 || h->p_variant == 5 ? h->p_variant : 3);
         if (pp.variant >= 3 && pp.variant <= 5) {
             pp.real_M = h->m.M;
+            pp.packed = packed && pp.variant == 3;
             if (!h->p_tail) { pp.groups_a = 0; pp.splits_b = 0; }
             return pp;
         }
@@ -956,20 +964,38 @@ static ScanPlan opq_plan(cvtmi_opq_t h, int64_t nq, int k)
 // (once per index state; the searches that follow on other streams wait for the event the exclusive call leaves)
 static int opq_prepare(cvtmi_opq_t h, int64_t nq, int k, hipStream_t st)
 {
-    bool padded = false;
+    bool padded = false, packed = false;
     {
         std::shared_lock<std::shared_timed_mutex> rd(h->rw);
         if (h->n == 0) return CVTMI_OK;
         const ScanPlan plan = opq_plan(h, nq, k);
-        padded = plan.real_M > 0;
-        const bool want_rot = h->p_prerot && ((h->m.M == 16 && (plan.variant >= 3 || scans_applies(h->m, h->n, nq, k))) || padded);
+        packed = plan.packed;
+        padded = plan.real_M > 0 && !packed;
+        const bool want_rot = h->p_prerot && ((h->m.M == 16 && (plan.variant >= 3 || scans_applies(h->m, h->n, nq, k))) || padded || packed);
         if (!padded && !want_rot) return CVTMI_OK;
         const bool pad_ok = !padded || (h->pad_n == h->n && h->codes16.cap >= (size_t)h->n * 16);
-        const bool rot_ok = !want_rot || (h->rot_n == h->n && h->codes_rot.cap >= (size_t)h->n * 16);
+        const bool rot_ok = !want_rot || (h->rot_n == h->n && h->rot_kind == (packed ? 1 : 0) &&
+                                          h->codes_rot.cap >= (packed ? ((size_t)h->n * h->m.M + 15) / 16 * 16 : (size_t)h->n * 16));
         if (pad_ok && rot_ok) return CVTMI_OK;
     }
     Serial serial(h->sync, st);
     OpqExclusive excl(h, st);
+    if (packed) {   // the rows themselves, rotated inside their 16-byte groups: M bytes per row, no padded copy
+        if (h->rot_kind != 1) { h->rot_kind = 1; h->rot_n = 0; }
+        if (h->rot_n > h->n) h->rot_n = 0;
+        const size_t need = ((size_t)h->n * h->m.M + 15) / 16 * 16;
+        if (h->codes_rot.cap < need) {
+            int rc = h->codes_rot.reserve(std::max<size_t>((h->codes.cap + 15) / 16 * 16, need));
+            if (rc == CVTMI_ENOMEM) rc = h->codes_rot.reserve(need);
+            h->rot_n = 0;
+            if (rc == CVTMI_ENOMEM) { (void)hipGetLastError(); g_err.clear(); return CVTMI_OK; }   // (the search falls back to the padded / row-per-lane forms)
+            CVTMI_TRY(rc);
+        }
+        CVTMI_TRY(launch_rotate_codes_packed(h->codes.as<uint8_t>(), h->m.M, h->codes_rot.as<uint8_t>(), h->rot_n, h->n, st));
+        h->rot_n = h->n;
+        return CVTMI_OK;
+    }
+    if (h->rot_kind != 0) { h->rot_kind = 0; h->rot_n = 0; }
     if (padded) {   // the 16-byte rows first: the rotated copy is made from them
         if (h->pad_n > h->n) h->pad_n = 0;
         if (h->codes16.cap < (size_t)h->n * 16) {
@@ -1062,13 +1088,16 @@ static int opq_search_leased(cvtmi_opq_t h, OpqScratch &S, const float *q, int64
         q_rot = S.s_qrot.as<float>();
     }
     ScanPlan plan = opq_plan(h, nq, k);
-    if (plan.real_M > 0 && !(h->pad_n == h->n && h->codes16.p)) plan = plan_scan(h->m, h->n, nq, k, h->p_qtile, h->p_splits, h->p_variant);   // (the padded rows are not there: as before)
-    const bool padded = plan.real_M > 0;
+    if (plan.packed && !(h->rot_kind == 1 && h->rot_n == h->n && h->codes_rot.p))   // (the packed rotation is not there: as before)
+        plan = plan_scan(h->m, h->n, nq, k, h->p_qtile, h->p_splits, h->p_variant);
+    if (plan.real_M > 0 && !plan.packed && !(h->pad_n == h->n && h->codes16.p)) plan = plan_scan(h->m, h->n, nq, k, h->p_qtile, h->p_splits, h->p_variant);   // (the padded rows are not there: as before)
+    const bool packed = plan.packed, padded = plan.real_M > 0 && !packed;
     OpqModelDev m_scan = h->m;
-    if (padded) m_scan.M = 16;
+    if (padded || packed) m_scan.M = 16;
     const uint8_t *scan_rows = padded ? h->codes16.as<uint8_t>() : h->codes.as<uint8_t>();
     // the scan streams the pre-rotated copy of the rows when it is up to date (opq_prepare); otherwise it rotates in registers
-    const uint8_t *codes_rot = (plan.variant >= 3 && (h->m.M == 16 || padded) && h->p_prerot && h->rot_n == h->n && h->codes_rot.p) ? h->codes_rot.as<uint8_t>() : nullptr;
+    const uint8_t *codes_rot = packed ? h->codes_rot.as<uint8_t>()
+                             : (plan.variant >= 3 && (h->m.M == 16 || padded) && h->p_prerot && h->rot_kind == 0 && h->rot_n == h->n && h->codes_rot.p) ? h->codes_rot.as<uint8_t>() : nullptr;
     if (plan.variant == 6) return opq_search_h(h, S, q_rot, nq, k, dist, ids, codes_rot, st);
     float *pd = dist;
     int64_t *pi = ids;

@@ -54,6 +54,9 @@ struct ScanPlan {
     // M < 16 served by the M = 16 kernels (api.hip opq_plan): the scan reads a copy of the rows padded to 16 bytes with zeros and
     // per-query tables padded with all-zero tables; real_M = the model's M (0: not padded)
     int real_M = 0;
+    // round 6: M = 8 / M = 4 NATIVE (adc_scan_p.hip: adc_scan16p): the rows as they lie in memory, 16 / M of them per 16-byte load, from
+    // a packed pre-rotated copy (launch_rotate_codes_packed); the tables as for real_M (the model's first, zeros behind).  Set with real_M.
+    bool packed = false;
 };
 ScanPlan plan_scan(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k, int want_qtile, int want_splits,
                    int want_variant);
@@ -83,6 +86,11 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
 int launch_rotate_codes(const uint8_t *codes, uint8_t *codes_rot, int64_t row0, int64_t n, hipStream_t st);
 // rows [row0, n) of M code bytes -> 16 bytes each, zeros behind the M
 int launch_pad_codes(const uint8_t *codes, int M, uint8_t *codes16, int64_t row0, int64_t n, hipStream_t st);
+// ---- adc_scan_p.hip ----  M = 8 / 4: rows [row0, n) of M code bytes -> the packed pre-rotated copy adc_scan16p streams (same size as
+// the rows, rounded up to 16 bytes: 16 / M rows per 16-byte group, each rotated left by (group & (M - 1)) bytes within its M bytes)
+int launch_rotate_codes_packed(const uint8_t *codes, int M, uint8_t *codes_rot, int64_t row0, int64_t n, hipStream_t st);
+struct ScanArgs;
+int launch_adc_scan16p(const ScanArgs &a, int M, int64_t blocks, hipStream_t st);
 
 // ---- adc_scan_h.hip: adc_scan16h (plan.variant == 6), a persistent grid walking a host-built item table ----
 // one item = one row segment of one query group: rows [64 * row0_64, 64 * row0_64 + rows) scanned for the group's 8 queries;

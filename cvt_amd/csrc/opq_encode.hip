@@ -699,10 +699,10 @@ __global__ __launch_bounds__(kBlock) void lut_kernel(const float *__restrict__ q
     }
 }
 
-// The same tables for sub-vectors of 8 (the usual shape), QB queries per workgroup: a thread fetches its centroid once, in two 16-byte
-// loads, and uses it for all QB queries -- the kernel above reads the 128 KB of codebooks once per query, a dword at a time (10 000
-// queries: 134 us, 1.2 TB/s of table writes).  Same operations in the same order per entry.
-template <int QB>
+// The same tables for sub-vectors of 8 (the usual shape; round 6: also 16 and 32 = M = 8 / M = 4 at D = 128), QB queries per workgroup: a
+// thread fetches its centroid once, in 16-byte loads, and uses it for all QB queries -- the kernel above reads the 128 KB of codebooks once
+// per query, a dword at a time (10 000 queries: 134 us, 1.2 TB/s of table writes; M = 4: 177 us).  Same operations in the same order per entry.
+template <int QB, int STEP = 8>
 __global__ __launch_bounds__(kBlock) void lut8_kernel(const float *__restrict__ q_rot, int64_t nq, int D, int M, int K, const float *__restrict__ coarse,
                                                       const int32_t *__restrict__ list_id, const float *__restrict__ books, float *__restrict__ lut, int ld,
                                                       int tables)
@@ -723,15 +723,19 @@ __global__ __launch_bounds__(kBlock) void lut8_kernel(const float *__restrict__ 
 #pragma unroll
         for (int q = 0; q < QB; ++q) acc[q] = m >= M ? 0.0f : __uint_as_float(0x7f800000u);   // (appended tables: all zeros)
         if (m < M && j < K) {
-            const float4 *c = reinterpret_cast<const float4 *>(books + ((int64_t)m * K + j) * 8);
-            const float4 c0 = c[0], c1 = c[1];
-            const float cv[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+            const float4 *c = reinterpret_cast<const float4 *>(books + ((int64_t)m * K + j) * STEP);
+            float cv[STEP];
+#pragma unroll
+            for (int w = 0; w < STEP / 4; ++w) {
+                const float4 c4 = c[w];
+                cv[4 * w] = c4.x; cv[4 * w + 1] = c4.y; cv[4 * w + 2] = c4.z; cv[4 * w + 3] = c4.w;
+            }
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 float a = 0.0f;
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    const float t = __fsub_rn(res[q * D + m * 8 + kk], cv[kk]);
+                for (int kk = 0; kk < STEP; ++kk) {
+                    const float t = __fsub_rn(res[q * D + m * STEP + kk], cv[kk]);
                     a = __fadd_rn(a, __fmul_rn(t, t));
                 }
                 acc[q] = a;
@@ -750,10 +754,13 @@ int launch_lut(const OpqModelDev &m, const float *q_rot, int64_t nq, const int32
     if (tables < m.M) tables = m.M;
     if (nq <= 0) return CVTMI_OK;
     if (nq > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "lut: nq too large");
-    if (m.step == 8 && nq >= 64 && (((uintptr_t)m.books) & 15) == 0) {
+    if ((m.step == 8 || m.step == 16 || m.step == 32) && nq >= 64 && (((uintptr_t)m.books) & 15) == 0) {
         constexpr int QB = 4;
-        hipLaunchKernelGGL((lut8_kernel<QB>), dim3((unsigned)((nq + QB - 1) / QB)), dim3(kBlock), (size_t)QB * m.D * sizeof(float), st, q_rot, nq, m.D, m.M, m.K,
-                           m.coarse, list_id, m.books, lut, ld, tables);
+        const dim3 g((unsigned)((nq + QB - 1) / QB));
+        const size_t lds = (size_t)QB * m.D * sizeof(float);
+        if (m.step == 8) hipLaunchKernelGGL((lut8_kernel<QB, 8>), g, dim3(kBlock), lds, st, q_rot, nq, m.D, m.M, m.K, m.coarse, list_id, m.books, lut, ld, tables);
+        else if (m.step == 16) hipLaunchKernelGGL((lut8_kernel<QB, 16>), g, dim3(kBlock), lds, st, q_rot, nq, m.D, m.M, m.K, m.coarse, list_id, m.books, lut, ld, tables);
+        else hipLaunchKernelGGL((lut8_kernel<QB, 32>), g, dim3(kBlock), lds, st, q_rot, nq, m.D, m.M, m.K, m.coarse, list_id, m.books, lut, ld, tables);
         CVTMI_HIP(hipGetLastError());
         return CVTMI_OK;
     }

@@ -104,6 +104,10 @@ int cvtmi_set_device(int device);
  *                     with zeros (derived copies: 32 bytes per row) and per-query tables padded with all-zero tables -- M = 8 at
  *                     10 000 queries x 1 M rows: 9.8 -> 3.2 ms, and every M from 1 to 15 is searchable; 0 = the row-per-lane
  *                     kernels (M = 4 / 8 only)
+ *   "scan_packed_m"   1 (default) = an OPQ index with M = 8 or M = 4 is scanned as it lies in memory (adc_scan16p, round 6): 16 / M rows
+ *                     per 16-byte load from a pre-rotated copy of the rows (+M bytes per row, no padded copy), 16 / M copies of the M
+ *                     tables in LDS so that the look-ups stay conflict-free -- no look-up is spent on a zero table; 0 = the padded
+ *                     rows of "scan_pad_m" for these M as well
  *   "sq8_host_small" 1 (default) = SQ8 host-pointer calls of up to 1 MB (the reference's one vector per call) run out of a page-locked
  *                     scratch area the kernels read and write directly (512-d: 80 -> 26 us per call); 0 = allocate, copy, free
  *   "scans_max_work"  OPQ search: the small-batch form (<= 128 queries) answers while rows x query groups stays at or under this

@@ -301,15 +301,80 @@ def test_search_any_m_through_padded_rows(amd, orc, M, step):
             rows = codes[:idx.ntotal]
             sel = np.unique(np.r_[0:min(nq, 4), rng.integers(0, nq, size=min(nq, 12))])
             od, oi = orc.adc_search(q[sel], books, rows, k)
-            for pad in ((1, 0) if M in (4, 8) else (1,)):
-                amd.set_tuning("scan_pad_m", pad)
+            # M = 8 / 4: the native packed scan (round 6, default), the padded rows (round 5) and the old row-per-lane kernels
+            for pad, packed in (((1, 1), (1, 0), (0, 0)) if M in (4, 8) else ((1, 1),)):
+                amd.set_tuning("scan_pad_m", pad); amd.set_tuning("scan_packed_m", packed)
                 for dev in (False, True):
                     d, i = idx.search(torch.from_numpy(q).cuda() if dev else q, k, rotate=False)
                     if dev:
                         d, i = d.cpu().numpy(), i.cpu().numpy()
-                    assert np.array_equal(i[sel], oi) and np.array_equal(bits(d[sel]), bits(od)), (M, nq, k, pad, dev)
+                    assert np.array_equal(i[sel], oi) and np.array_equal(bits(d[sel]), bits(od)), (M, nq, k, pad, packed, dev)
     finally:
-        amd.set_tuning("scan_pad_m", 1)
+        amd.set_tuning("scan_pad_m", 1); amd.set_tuning("scan_packed_m", 1)
+    idx.close()
+
+
+@pytest.mark.parametrize("M,step", [(8, 16), (4, 8), (8, 4)])
+def test_search_packed_rows_m8_m4(amd, orc, M, step):
+    """Round 6: adc_scan16p -- an M = 8 / M = 4 index scanned as it lies in memory, 16 / M rows per 16-byte load, table
+    copies per lane group, no padded rows.  Against the oracle: ragged row counts (last group / last load partly filled), rows appended at
+    odd counts (the packed rotation is extended from the middle of a group), forced row splits (shared thresholds, ties across the
+    boundaries), an id base, all-identical rows (every distance ties), descending distances (every row beats the threshold: the
+    full-buffer retry path), fewer rows than k; and the same lists from the padded-row form (opq/src/IVFOPQ.h:24-29: any M <= 16)."""
+    import torch
+    D, K = M * step, 256
+    rng = np.random.default_rng(M * 131 + step)
+    books = (rng.normal(size=(M, K, step)) * 0.1).astype(np.float32)
+    idx = amd.OpqIndex(np.zeros((1, D), np.float32), books)
+    try:
+        # growing index: every size is searched right after an append at an odd row count
+        total = 0
+        allc = np.zeros((0, M), np.uint8)
+        for add in (3, 60, 2048 + 1, 40_000 + 3, 150_000 + 5):
+            c = rng.integers(0, K, size=(add, M), dtype=np.uint8)
+            if total:
+                c[0] = allc[total // 2]; c[add - 1] = allc[total // 2]      # exact duplicates of an older row: ties
+            idx.add_codes(c); allc = np.concatenate([allc, c]); total += add
+            for nq, k in ((8, 100), (37, 10)) if total < 100_000 else ((8, 100), (37, 10), (2500, 100)):
+                q = (rng.normal(size=(nq, D)) * 0.1).astype(np.float32)
+                q[0] = books[np.arange(M), allc[total // 2]].reshape(-1)
+                sel = np.unique(np.r_[0:min(nq, 4), rng.integers(0, nq, size=min(nq, 12))])
+                od, oi = orc.adc_search(q[sel], books, allc, k)
+                d, i = idx.search(torch.from_numpy(q).cuda(), k, rotate=False)
+                d, i = d.cpu().numpy(), i.cpu().numpy()
+                assert np.array_equal(i[sel], oi) and np.array_equal(bits(d[sel]), bits(od)), (M, total, nq, k)
+        # forced row splits + an id base; the padded form must agree bit for bit
+        q = (rng.normal(size=(64, D)) * 0.1).astype(np.float32)
+        q[1] = books[np.arange(M), allc[7]].reshape(-1)
+        od, oi = orc.adc_search(q, books, allc, 100)
+        idx.set_id_base(1 << 34)
+        for splits in (1, 2, 3, 8):
+            idx.set_param("splits", splits)
+            for packed in (1, 0):
+                amd.set_tuning("scan_packed_m", packed)
+                d, i = idx.search(torch.from_numpy(q).cuda(), 100, rotate=False)
+                assert np.array_equal(i.cpu().numpy(), oi + (1 << 34)) and np.array_equal(bits(d.cpu().numpy()), bits(od)), (M, splits, packed)
+        amd.set_tuning("scan_packed_m", 1)
+        idx.set_param("splits", 0); idx.set_id_base(0)
+        # all rows identical; descending distances
+        idx.reset()
+        idx.add_codes(np.tile(allc[:1], (5001, 1)))
+        d, i = idx.search(q[:9], 100, rotate=False)
+        assert np.array_equal(i, np.tile(np.arange(100), (9, 1)))
+        idx.reset()
+        lut = orc.lut(q[0], np.zeros(D, np.float32), books)
+        ranks = np.argsort(-lut[0], kind="stable")
+        n = 6001
+        desc = np.zeros((n, M), dtype=np.uint8)
+        desc[:, 0] = ranks[(np.arange(n) * 256 // n)]
+        idx.add_codes(desc)
+        od, oi = orc.adc_search(q[:9], books, desc, 100)
+        for splits in (1, 2):
+            idx.set_param("splits", splits)
+            d, i = idx.search(q[:9], 100, rotate=False)
+            assert np.array_equal(i, oi) and np.array_equal(bits(d), bits(od)), (M, "descending", splits)
+    finally:
+        amd.set_tuning("scan_packed_m", 1)
     idx.close()
 
 

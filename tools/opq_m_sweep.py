@@ -10,7 +10,7 @@ D, K, k = 128, 256, int(os.environ.get("K", 100))
 rows = int(os.environ.get("ROWS", 1_000_000))
 rng = np.random.default_rng(0)
 g = torch.Generator(device=dev); g.manual_seed(1)
-for M in (16, 8, 4):
+for M in [int(v) for v in os.environ.get("MS", "16,8,4").split(",")]:
     books = (rng.normal(size=(M, K, D // M)) * 0.05).astype(np.float32)
     idx = cvt_amd.OpqIndex(np.zeros((1, D), np.float32), books, R=synth.random_rotation(D))
     idx.add_codes(torch.randint(0, 256, (rows, M), generator=g, device=dev, dtype=torch.uint8))
