@@ -146,6 +146,8 @@ __global__ __launch_bounds__(kBlock, CAP > SCAN_CAP ? 1 : ScanOcc<QT>::waves) vo
         }
     }
 
+    if (QT == 1 && a.only && a.only[group] == 0u) return;   // workgroup-uniform: this query has its answer already (big-k pipeline)
+
     topk_init(tk);
     build_lut_lds<M, QT>(lut, reinterpret_cast<float *>(&tk.buf[0][0]), a, group);  // ends with a barrier
 
@@ -1414,7 +1416,7 @@ int launch_rotate_codes(const uint8_t *codes, uint8_t *codes_rot, int64_t row0, 
 
 int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, int64_t id_base, const float *q_rot,
                     int64_t nq, int k, const ScanPlan &plan, float *part_d, int64_t *part_id, float *lut_scratch,
-                    const uint8_t *codes_rot, hipStream_t st, uint32_t *gthr, int lazy, float *final_d, int64_t *final_id)
+                    const uint8_t *codes_rot, hipStream_t st, uint32_t *gthr, int lazy, float *final_d, int64_t *final_id, const uint32_t *only)
 {
     if (nq <= 0) return CVTMI_OK;
     if (k < 1 || k > kBigK) return fail(CVTMI_EUNSUPPORTED, "adc_scan: k=%d outside 1..%d", k, kBigK);
@@ -1438,7 +1440,7 @@ int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, 
     a.rows_per_split = rps;
     a.groups_a = a.groups; a.splits_b = 0; a.stride = plan.splits; a.rows_per_split_b = rps;
     a.part_d = part_d; a.part_id = part_id; a.out_d = nullptr; a.out_id = nullptr; a.lut_g = lut_scratch; a.codes_rot = codes_rot;
-    a.gthr = nullptr; a.lazy = lazy; a.seed = g_scan_seed;
+    a.gthr = nullptr; a.lazy = lazy; a.seed = g_scan_seed; a.only = only;
     if (plan.variant >= 3 && m.M == 16 && plan.qtile == 8) {
         if (!lut_scratch) return fail(CVTMI_EINVAL, "adc_scan16q: table scratch missing");
         if (plan.real_M > 0) {   // M < 16 through these kernels: the model's own tables, all-zero ones behind them (codes = the padded rows)

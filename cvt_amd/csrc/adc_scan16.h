@@ -31,6 +31,8 @@ struct ScanArgs {
     uint32_t *gthr;            // adc_scan16q: [nq] filter thresholds (table units) shared by the row splits of a query, or null
     int lazy;                  // adc_scan16q: 1 = intermediate compactions select on the integer lower bounds (exact sums only at the end)
     int seed;                  // adc_scan16q / 16a: 1 = first thresholds from a histogram of the split's first rows (scan16q_seed)
+    const uint32_t *only = nullptr;  // adc_scan_kernel with one query per workgroup (k > 128): answer query g only when only[g] != 0 (the
+                                     // big-k filter pipeline's fall-back, adc_scan_h.hip); null: every query
 };
 
 #ifdef CVTMI_SCAN_TIMING

@@ -1188,6 +1188,394 @@ int launch_adc_scan_small(const OpqModelDev &m, const uint8_t *codes, const uint
     return CVTMI_OK;
 }
 
+// =====================================================================================================================
+// k = 129 .. CVTMI_K_MAX through the filter scan (round 6; get_sort_results(score_total, num_show) takes any num_show:
+// opq/src/common.h:25-37).  The checkpoint / spill protocols above keep k + band entries per query in 15 KB of LDS: k <= 128.  Beyond
+// that the exact kernel answered with ONE query per workgroup and a 4096-entry selection buffer -- 11x slower at 10 000 x 1 M rows.
+// The bound-first form of the small-batch path needs no selection while it scans, so it takes any k:
+//   scan16h_prep_kernel      tables of every query group (fp32 + the quantised LDS image), as for adc_scan16h
+//   scan16s_hist_kernel      every 4th chunk of the rows, all groups: one 256-bin histogram of the integer sums per query.  The first
+//                            bin at which the cumulative count reaches k proves k rows below its edge: T = edge + slack admits every row
+//                            that can be among the k best (~4 k rows pass)
+//   scan16k_collect_kernel   all rows against T: the rows below it to per-(workgroup, query) lists in HBM (wave-aggregated LDS counter)
+//   scan16k_select_kernel    one workgroup per query: k-th smallest integer sum of its list (two histogram passes) -> S_k; the rows
+//                            below S_k + slack (k + a band) get exact reference-order sums (IVFOPQ.cpp:302-306) and are sorted by
+//                            (distance, id) in LDS (bitonic, 4096 entries); the first k are the answer -- bit-identical to the
+//                            reference's.  A list that overflowed, more than 4096 rows inside the band (masses of equal rows) or sums
+//                            that bound nothing (non-finite tables) raise the query's flag: the exact kernel answers those queries.
+// =====================================================================================================================
+constexpr int SK_NSEL = 4096;   // entries the selection sorts (k <= 2048 + the band)
+
+// histogram pass of the big-k pipeline: scan16s_hist_kernel's sample (every 4th chunk), two workgroups per CU, and a CUT-OFF -- as soon
+// as the workgroup's own histogram proves k rows below a bin edge, rows above that edge cannot move the final bound (it can only lie at
+// or below it): they are skipped by one packed compare per chunk instead of eight LDS atomics per row (the atomics were 60 % of the pass).
+template <bool PREROT>
+__global__ __launch_bounds__(1024, 8) void scan16k_hist_kernel(const ScanSArgs a)
+{
+    constexpr int NT = 1024, QT = SQ_QT;
+    __shared__ __attribute__((aligned(16))) uint32_t lut[256 * 16 * QT / 2];
+    __shared__ __attribute__((aligned(16))) uint32_t hist[QT][SH_BINS];
+    __shared__ uint32_t cut_pk[QT / 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = blockIdx.y;
+    const uint4 *qlut = a.qlut + (size_t)grp * 4096;
+    uint32_t *ctl = a.ctl + (size_t)grp * SS_WORDS;
+    {
+        uint4 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = qlut[tid + i * NT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) reinterpret_cast<uint4 *>(lut)[tid + i * NT] = t[i];
+    }
+    for (int i = tid; i < QT * SH_BINS; i += NT) (&hist[0][0])[i] = 0;
+    if (tid < QT / 2) cut_pk[tid] = 0x7fff7fffu;
+    __syncthreads();
+    const uint32_t c = tid & 15, cr8 = (c & 3) * 8, cq = c >> 2;
+    uint32_t moffp[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        moffp[w] = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) moffp[w] |= (((4 * w + b + c) & 15u) * 16u) << (8 * b);
+    }
+    const char *lut_b = reinterpret_cast<const char *>(lut);
+    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_hist_wg;
+    int64_t r1 = r0 + a.rows_per_hist_wg;
+    r1 = r1 < a.n_rows ? r1 : a.n_rows;
+    const uint4 *rows = reinterpret_cast<const uint4 *>(PREROT ? a.codes_rot : a.codes);
+    const int64_t stride = (int64_t)(NT / 64) << (6 + SS_SAMPLE_SHIFT);
+    uint32_t cpk[QT / 2];
+#pragma unroll
+    for (int i = 0; i < QT / 2; ++i) cpk[i] = 0x7fff7fffu;
+    int round = 0;
+    for (int64_t base = r0 + ((int64_t)wave << (6 + SS_SAMPLE_SHIFT)); base < r1; base += stride, ++round) {
+        const int64_t row = base + lane;
+        const uint4 v = rows[row < r1 ? row : r1 - 1];
+        uint32_t sm[4];
+        scan16q_row_sums<PREROT>(v, moffp, cr8, cq, lut_b, sm[0], sm[1], sm[2], sm[3]);
+        uint32_t d4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d4[i] = pk_sub_i16(sm[i], cpk[i]);   // sign per 16-bit field: sum < cut-off
+        const bool inr = row < r1;
+        if (__ballot(inr && ((d4[0] | d4[1] | d4[2] | d4[3]) & 0x80008000u) != 0)) {  // wave-uniform
+            if (inr) {
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+                    const bool below = (q & 1) ? (int32_t)d4[q >> 1] < 0 : (d4[q >> 1] & 0x8000u) != 0;
+                    if (below) atomicAdd(&hist[q][((sm[q >> 1] >> (16 * (q & 1))) & 0xffffu) >> 7], 1u);
+                }
+            }
+        }
+        if ((round & 15) == 15) {   // every 16 sampled chunks per wave (1024 rows): the cut-offs the workgroup's counts allow so far
+            if (wave < QT) {        // (no barrier: counts only grow, so a snapshot's bound is valid; a stale cut-off is only looser)
+                const uint32_t t = scanh_hist_bound(hist[wave], a.k, 0u);   // edge of the bin that holds the k-th of the rows counted so far
+                if (lane == 0 && t < 32767u) reinterpret_cast<uint16_t *>(cut_pk)[wave] = (uint16_t)t;
+            }
+#pragma unroll
+            for (int i = 0; i < QT / 2; ++i) cpk[i] = __hip_atomic_load(&cut_pk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < QT * SH_BINS; i += NT) {
+        const uint32_t v = (&hist[0][0])[i];
+        if (v) atomicAdd(&ctl[i], v);
+    }
+}
+
+template <bool PREROT>
+__global__ __launch_bounds__(1024, 8) void scan16k_collect_kernel(const ScanSArgs a, int wcap)
+{
+    constexpr int NT = 1024, QT = SQ_QT;
+    __shared__ __attribute__((aligned(16))) uint32_t lut[256 * 16 * QT / 2];
+    __shared__ __attribute__((aligned(16))) uint32_t hist[QT][SH_BINS];
+    __shared__ QuantParams qp;
+    __shared__ uint32_t T[QT], tpk_s[QT / 2];
+    __shared__ uint32_t cnt[QT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = blockIdx.y;
+    const uint4 *qlut = a.qlut + (size_t)grp * 4096;
+    uint32_t *ctl = a.ctl + (size_t)grp * SS_WORDS;
+    {
+        uint4 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = qlut[tid + i * NT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) reinterpret_cast<uint4 *>(lut)[tid + i * NT] = t[i];
+    }
+    if (tid < (int)(sizeof(QuantParams) / 4)) reinterpret_cast<uint32_t *>(&qp)[tid] = reinterpret_cast<const uint32_t *>(a.qp_g + grp)[tid];
+    for (int i = tid; i < QT * SH_BINS; i += NT) (&hist[0][0])[i] = ctl[i];
+    if (tid < QT) cnt[tid] = 0;
+    __syncthreads();
+    if (wave < QT) {  // the bound of query `wave` from the global histogram (a sample: every 4th chunk of every row block)
+        const uint32_t sl = qp.slack[wave];
+        uint32_t t = sl ? scanh_hist_bound(hist[wave], a.k, sl) : 0xffffffffu;
+        if (t > 32767u) t = 32767u;  // fewer than k rows sampled, or sums that bound nothing: the exact kernel answers (select raises the flag)
+        if (lane == 0) {
+            T[wave] = t;
+            if (blockIdx.x == 0) ctl[QT * SH_BINS + wave] = t;
+        }
+    }
+    __syncthreads();
+    if (tid < QT / 2) tpk_s[tid] = T[2 * tid] | (T[2 * tid + 1] << 16);
+    __syncthreads();
+    bool any_open = false;   // a query without a bound would send every row to its list: nothing is collected for it
+#pragma unroll
+    for (int q = 0; q < QT; ++q) any_open |= T[q] >= 32767u;
+    const uint32_t c = tid & 15, cr8 = (c & 3) * 8, cq = c >> 2;
+    uint32_t moffp[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        moffp[w] = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) moffp[w] |= (((4 * w + b + c) & 15u) * 16u) << (8 * b);
+    }
+    const char *lut_b = reinterpret_cast<const char *>(lut);
+    uint32_t tpk[QT / 2];
+#pragma unroll
+    for (int i = 0; i < QT / 2; ++i) {
+        uint32_t t2 = tpk_s[i];
+        if (any_open) {   // (rare) open queries compare against 0: no candidate
+            if ((t2 & 0xffffu) >= 32767u) t2 &= 0xffff0000u;
+            if ((t2 >> 16) >= 32767u) t2 &= 0x0000ffffu;
+        }
+        tpk[i] = t2;
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_wg;
+    int64_t r1 = r0 + a.rows_per_wg;
+    r1 = r1 < a.n_rows ? r1 : a.n_rows;
+    const uint4 *rows = reinterpret_cast<const uint4 *>(PREROT ? a.codes_rot : a.codes);
+    unsigned long long *mine = a.gcand + ((size_t)grp * a.G + blockIdx.x) * QT * (size_t)wcap;
+    uint4 v = rows[r0 + ((int64_t)wave << 6) + lane < r1 ? r0 + ((int64_t)wave << 6) + lane : (r1 > 0 ? r1 - 1 : 0)];
+    for (int64_t base = r0 + ((int64_t)wave << 6); base < r1; base += NT) {
+        const int64_t row = base + lane, nrow = row + NT;
+        const uint4 vn = rows[nrow < r1 ? nrow : r1 - 1];   // next chunk of this wave, in flight during the look-ups
+        uint32_t s4[4];
+        scan16q_row_sums<PREROT, 16>(v, moffp, cr8, cq, lut_b, s4[0], s4[1], s4[2], s4[3]);
+        v = vn;
+        uint32_t d4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d4[i] = pk_sub_i16(s4[i], tpk[i]);
+        const bool inr = row < r1;
+        if (__ballot(inr && ((d4[0] | d4[1] | d4[2] | d4[3]) & 0x80008000u) != 0) == 0) continue;  // wave-uniform
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            const bool cand = inr && ((q & 1) ? (int32_t)d4[q >> 1] < 0 : (d4[q >> 1] & 0x8000u) != 0);
+            const unsigned long long m = __ballot(cand);
+            if (!m) continue;  // scalar
+            uint32_t basep = 0;
+            if (lane == 0) basep = atomicAdd(&cnt[q], (uint32_t)__popcll(m));   // LDS
+            basep = (uint32_t)__builtin_amdgcn_readfirstlane((int)basep);
+            const uint32_t pos = basep + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (cand && pos < (uint32_t)wcap) {
+                const uint32_t sq = (q & 1) ? s4[q >> 1] >> 16 : s4[q >> 1] & 0xffffu;
+                mine[(size_t)q * wcap + pos] = ((unsigned long long)sq << 32) | (uint32_t)row;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < QT) a.wcnt[((size_t)grp * a.G + blockIdx.x) * QT + tid] = cnt[tid];
+}
+
+// ascending bitonic sort of n (a power of two, <= SK_NSEL) 64-bit keys in LDS by the whole workgroup
+template <int NT>
+__device__ __forceinline__ void block_bitonic_u64(unsigned long long *e, int n)
+{
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < n / 2; i += NT) {
+                const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;   // lo = (i / stride) * 2 stride + i % stride
+                const bool up = (lo & size) == 0;
+                const unsigned long long a0 = e[lo], a1 = e[hi];
+                if ((a0 > a1) == up) { e[lo] = a1; e[hi] = a0; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void scan16k_select_kernel(const ScanSArgs a, int wcap, uint32_t *__restrict__ flags)
+{
+    constexpr int NT = 1024, QT = SQ_QT;
+    __shared__ __attribute__((aligned(16))) unsigned long long sel[SK_NSEL];
+    __shared__ __attribute__((aligned(16))) uint32_t h[SH_BINS];
+    __shared__ QuantParams qp;
+    __shared__ uint32_t off[64 + 1];
+    __shared__ uint32_t s_n, s_bin, s_cum, s_sk;
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, q = blockIdx.x, grp = q / QT, ql = q % QT;
+    if (tid < (int)(sizeof(QuantParams) / 4)) reinterpret_cast<uint32_t *>(&qp)[tid] = reinterpret_cast<const uint32_t *>(a.qp_g + grp)[tid];
+    if (tid == 0) { s_bad = 0; s_n = 0; }
+    for (int i = tid; i < SH_BINS; i += NT) h[i] = 0;
+    __syncthreads();
+    if (tid < a.G) {   // G <= 64 collect workgroups per group
+        const uint32_t c = a.wcnt[((size_t)grp * a.G + tid) * QT + ql];
+        off[tid] = c;
+        if (c > (uint32_t)wcap) s_bad = 1;   // that workgroup dropped candidates
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int g = 0; g < a.G; ++g) { const uint32_t v = off[g]; off[g] = run; run += v; }
+        off[a.G] = run;
+    }
+    __syncthreads();
+    const uint32_t n = off[a.G];
+    const uint32_t Tq = a.ctl[(size_t)grp * SS_WORDS + QT * SH_BINS + ql];
+    const uint32_t slack = qp.slack[ql];
+    if (s_bad || Tq >= 32767u || !slack || n < (uint32_t)(a.k < a.n_rows ? a.k : a.n_rows)) {   // workgroup-uniform: the exact kernel answers this query
+        if (tid == 0) flags[q] = 1u;
+        return;
+    }
+    const auto list_of = [&](int g) -> const unsigned long long * { return a.gcand + (((size_t)grp * a.G + g) * QT + ql) * (size_t)wcap; };
+    // pass 1: bins of 128 units
+    for (int g = 0; g < a.G; ++g) {
+        const unsigned long long *src = list_of(g);
+        const uint32_t cg = off[g + 1] - off[g];
+        for (uint32_t i = tid; i < cg; i += NT) atomicAdd(&h[(uint32_t)(src[i] >> 32) >> 7], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const uint4 cb = *reinterpret_cast<const uint4 *>(h + lane * 4);
+        const uint32_t mine = cb.x + cb.y + cb.z + cb.w, incl = wave_incl_scan_add(mine);
+        const unsigned long long reach = __ballot(incl >= (uint32_t)a.k);
+        const int l0 = reach ? __ffsll((long long)reach) - 1 : 63;
+        uint32_t cum = (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), l0);
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cb.x, l0), c1 = (uint32_t)__builtin_amdgcn_readlane((int)cb.y, l0),
+                       c2 = (uint32_t)__builtin_amdgcn_readlane((int)cb.z, l0);
+        uint32_t b = (uint32_t)l0 * 4u;
+        if (cum + c0 < (uint32_t)a.k) { cum += c0; ++b; if (cum + c1 < (uint32_t)a.k) { cum += c1; ++b; if (cum + c2 < (uint32_t)a.k) { cum += c2; ++b; } } }
+        if (lane == 0) { s_bin = b; s_cum = cum; }   // cum rows lie below bin b; the k-th is the (k - cum)-th smallest inside it
+    }
+    __syncthreads();
+    for (int i = tid; i < 128; i += NT) h[i] = 0;
+    __syncthreads();
+    const uint32_t bin = s_bin;
+    for (int g = 0; g < a.G; ++g) {   // pass 2: position inside the bin
+        const unsigned long long *src = list_of(g);
+        const uint32_t cg = off[g + 1] - off[g];
+        for (uint32_t i = tid; i < cg; i += NT) {
+            const uint32_t sv = (uint32_t)(src[i] >> 32);
+            if ((sv >> 7) == bin) atomicAdd(&h[sv & 127u], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const uint32_t f0 = h[lane * 2], f1 = h[lane * 2 + 1];
+        const uint32_t inc2 = wave_incl_scan_add(f0 + f1);
+        const uint32_t need = (uint32_t)a.k - s_cum;
+        const unsigned long long r2 = __ballot(inc2 >= need);
+        const int l2 = r2 ? __ffsll((long long)r2) - 1 : 63;
+        const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)(inc2 - f0 - f1), l2);
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)f0, l2);
+        if (lane == 0) s_sk = (bin << 7) + (uint32_t)l2 * 2u + (before + g0 >= need ? 0u : 1u);
+    }
+    __syncthreads();
+    uint32_t Tsel = s_sk + slack;
+    Tsel = Tsel < Tq ? Tsel : Tq;
+    // the rows inside the band -> LDS (order is irrelevant: the sort decides)
+    for (int g = 0; g < a.G; ++g) {
+        const unsigned long long *src = list_of(g);
+        const uint32_t cg = off[g + 1] - off[g];
+        for (uint32_t i0 = 0; i0 < cg; i0 += NT) {
+            const uint32_t i = i0 + tid;
+            const unsigned long long e = i < cg ? src[i] : ~0ull;
+            const bool in = i < cg && (uint32_t)(e >> 32) < Tsel;
+            const unsigned long long m = __ballot(in);
+            uint32_t basep = 0;
+            if (lane == 0 && m) basep = atomicAdd(&s_n, (uint32_t)__popcll(m));
+            basep = (uint32_t)__builtin_amdgcn_readfirstlane((int)basep);
+            const uint32_t pos = basep + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (in && pos < (uint32_t)SK_NSEL) sel[pos] = e;
+        }
+    }
+    __syncthreads();
+    const uint32_t ns = s_n;
+    if (ns > (uint32_t)SK_NSEL) {   // a crowded band (masses of equal rows): the exact kernel
+        if (tid == 0) flags[q] = 1u;
+        return;
+    }
+    const ExactFromLut fix{ reinterpret_cast<const uint4 *>(a.codes), a.lut_g, a.K, a.nq, grp };
+    int np = 256;
+    while (np < (int)ns) np <<= 1;
+    for (int i = tid; i < np; i += NT) sel[i] = (uint32_t)i < ns ? fix(ql, sel[i]) : ~0ull;   // exact (distance bits, row); padding sorts last
+    block_bitonic_u64<NT>(sel, np);
+    for (int i = tid; i < a.k; i += NT) {
+        if ((uint32_t)i < ns) {
+            const unsigned long long e = sel[i];
+            a.out_d[(int64_t)q * a.k + i] = __uint_as_float((uint32_t)(e >> 32));
+            a.out_id[(int64_t)q * a.k + i] = a.id_base + (int64_t)(uint32_t)e;
+        } else {
+            a.out_d[(int64_t)q * a.k + i] = __uint_as_float(0x7f800000u);
+            a.out_id[(int64_t)q * a.k + i] = -1;
+        }
+    }
+}
+
+// collect workgroups per query group and list capacity per (workgroup, query) of a big-k search
+static void scank_shape(int64_t n_rows, int64_t nq, int k, int *G, int *wcap)
+{
+    const int64_t groups = (nq + SQ_QT - 1) / SQ_QT;
+    int64_t g = (scanh_slots() / 2 + groups - 1) / groups;            // enough workgroups for one per CU
+    g = std::max<int64_t>(1, std::min<int64_t>(g, std::min<int64_t>(64, (n_rows + 16383) / 16384)));
+    *G = (int)g;
+    *wcap = (int)((8LL * k + g - 1) / g + 1024);   // ~4 k rows pass the sampled bound in all; twice that plus a margin, spread over the workgroups
+}
+bool scank_applies(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k)
+{
+    return m.M == 16 && m.D <= 256 && m.K >= 1 && m.K <= 256 && nq >= 1 && k > 128 && k <= 2048 && n_rows >= 65536 && n_rows <= 0xfffffffeLL &&
+           (int64_t)k * 8 <= n_rows;
+}
+size_t scank_scratch_bytes(int64_t n_rows, int64_t nq, int k)
+{
+    int G, wcap;
+    scank_shape(n_rows, nq, k, &G, &wcap);
+    const size_t groups = (size_t)((nq + SQ_QT - 1) / SQ_QT);
+    return (groups * SS_WORDS * 4 + 63) / 64 * 64 + (groups * G * SQ_QT * 4 + 63) / 64 * 64 + ((size_t)nq * 4 + 63) / 64 * 64 +
+           groups * G * SQ_QT * (size_t)wcap * sizeof(unsigned long long);
+}
+// q_rot: rotated queries.  flags_out: [nq] words, 1 = the query was NOT answered (the caller runs the exact kernel for those)
+int launch_adc_scan_bigk(const OpqModelDev &m, const uint8_t *codes, const uint8_t *codes_rot, int64_t n_rows, int64_t id_base, const float *q_rot,
+                         int64_t nq, int k, float *dist, int64_t *ids, float *lut_g, void *qlut, void *qp_g, void *scratch, int lazy,
+                         uint32_t **flags_out, hipStream_t st)
+{
+    if (!scank_applies(m, n_rows, nq, k)) return fail(CVTMI_EUNSUPPORTED, "adc_scan16k: shape not covered");
+    int G, wcap;
+    scank_shape(n_rows, nq, k, &G, &wcap);
+    const size_t groups = (size_t)((nq + SQ_QT - 1) / SQ_QT);
+    if (groups > 65535) return fail(CVTMI_EUNSUPPORTED, "adc_scan16k: more than 65535 query groups per call");
+    char *sc = reinterpret_cast<char *>(scratch);
+    uint32_t *ctl = reinterpret_cast<uint32_t *>(sc);
+    sc += (groups * SS_WORDS * 4 + 63) / 64 * 64;
+    ScanSArgs a;
+    a.wcnt = reinterpret_cast<uint32_t *>(sc);
+    sc += (groups * G * SQ_QT * 4 + 63) / 64 * 64;
+    uint32_t *flags = reinterpret_cast<uint32_t *>(sc);
+    sc += ((size_t)nq * 4 + 63) / 64 * 64;
+    a.gcand = reinterpret_cast<unsigned long long *>(sc);
+    CVTMI_HIP(hipMemsetAsync(flags, 0, (size_t)nq * 4, st));
+    hipLaunchKernelGGL(scan16h_prep_kernel, dim3((unsigned)groups), dim3(1024), 0, st, q_rot, (int)nq, m.D, m.step, m.K, m.books, m.coarse, lut_g,
+                       reinterpret_cast<uint4 *>(qlut), reinterpret_cast<QuantParams *>(qp_g), lazy, (const float *)nullptr, (const int32_t *)nullptr,
+                       ctl, SS_WORDS);
+    CVTMI_HIP(hipGetLastError());
+    a.codes = codes; a.codes_rot = codes_rot; a.n_rows = n_rows; a.id_base = id_base;
+    a.rows_per_wg = ((n_rows + G - 1) / G + 255) / 256 * 256;   // whole groups of four chunks: the histogram's sample
+    a.rows_per_hist_wg = a.rows_per_wg;
+    a.nq = (int)nq; a.k = k; a.K = m.K; a.G = (int)((n_rows + a.rows_per_wg - 1) / a.rows_per_wg);
+    a.qlut = reinterpret_cast<const uint4 *>(qlut); a.qp_g = reinterpret_cast<const QuantParams *>(qp_g); a.lut_g = lut_g;
+    a.ctl = ctl; a.out_d = dist; a.out_id = ids; a.dbg = 0;
+    const dim3 grid((unsigned)a.G, (unsigned)groups);
+    if (codes_rot) {
+        hipLaunchKernelGGL((scan16k_hist_kernel<true>), grid, dim3(1024), 0, st, a);
+        hipLaunchKernelGGL((scan16k_collect_kernel<true>), grid, dim3(1024), 0, st, a, wcap);
+    } else {
+        hipLaunchKernelGGL((scan16k_hist_kernel<false>), grid, dim3(1024), 0, st, a);
+        hipLaunchKernelGGL((scan16k_collect_kernel<false>), grid, dim3(1024), 0, st, a, wcap);
+    }
+    hipLaunchKernelGGL(scan16k_select_kernel, dim3((unsigned)nq), dim3(1024), 0, st, a, wcap, flags);
+    CVTMI_HIP(hipGetLastError());
+    *flags_out = flags;
+    return CVTMI_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side: the item table
 // ---------------------------------------------------------------------------------------------------------------------

@@ -341,6 +341,7 @@ static bool host_pinned(const void *p)
 static std::atomic<int> g_hnsw_slots_cap{0};   // cvtmi_set_tuning("hnsw_slots"): cap on traversals per CU (0 = what LDS allows, at most 32)
 static std::atomic<int> g_small_zero_copy{1};   // cvtmi_set_tuning("opq_small_zero_copy"): 1 .. 8-query host-pointer searches read / write the pinned staging area from the kernels
 static std::atomic<int64_t> g_scans_max_work{(int64_t)48 << 20};   // cvtmi_set_tuning("scans_max_work"): rows x query groups up to which the OPQ small-batch form answers (scans_chosen)
+static std::atomic<int> g_scan_bigk{1};          // cvtmi_set_tuning("scan_bigk"): 0 = k > 128 on the exact kernels only (one query per workgroup: rounds 4-5), 1 = the filter pipeline
 static std::atomic<int> g_scan_packed{1};        // cvtmi_set_tuning("scan_packed_m"): 0 = M = 8 / 4 through the padded rows like every other M < 16 (round 5), 1 = adc_scan16p
 static std::atomic<int> g_scan_pad{1};           // cvtmi_set_tuning("scan_pad_m"): 0 = an OPQ index with M < 16 stays on the row-per-lane scan kernels (opq_pads)
 static std::atomic<int> g_sq8_host_small{1};     // cvtmi_set_tuning("sq8_host_small"): small SQ8 host-pointer calls run out of a page-locked scratch area (Sq8HostScratch)
@@ -486,6 +487,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "sq8_filter")) { set_sq8_filter(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "scan_pad_m")) { g_scan_pad = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "scan_packed_m")) { g_scan_packed = value != 0; return CVTMI_OK; }
+    if (!strcmp(name, "scan_bigk")) { g_scan_bigk = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "sq8_host_small")) { g_sq8_host_small = value != 0; return CVTMI_OK; }
     if (!strcmp(name, "scans_max_work")) { g_scans_max_work = value < 0 ? 0 : value; return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_filter_min_nq")) { g_flat_u8_filter_min_nq = value < 1 ? 1 : value > (1 << 30) ? (1 << 30) : (int)value; return CVTMI_OK; }
@@ -971,7 +973,8 @@ static int opq_prepare(cvtmi_opq_t h, int64_t nq, int k, hipStream_t st)
         const ScanPlan plan = opq_plan(h, nq, k);
         packed = plan.packed;
         padded = plan.real_M > 0 && !packed;
-        const bool want_rot = h->p_prerot && ((h->m.M == 16 && (plan.variant >= 3 || scans_applies(h->m, h->n, nq, k))) || padded || packed);
+        const bool want_rot = h->p_prerot && ((h->m.M == 16 && (plan.variant >= 3 || scans_applies(h->m, h->n, nq, k) ||
+                                                                (g_scan_bigk.load() && scank_applies(h->m, h->n, nq, k)))) || padded || packed);
         if (!padded && !want_rot) return CVTMI_OK;
         const bool pad_ok = !padded || (h->pad_n == h->n && h->codes16.cap >= (size_t)h->n * 16);
         const bool rot_ok = !want_rot || (h->rot_n == h->n && h->rot_kind == (packed ? 1 : 0) &&
@@ -1086,6 +1089,38 @@ static int opq_search_leased(cvtmi_opq_t h, OpqScratch &S, const float *q, int64
         CVTMI_TRY(S.s_qrot.reserve((size_t)nq * h->m.D * sizeof(float)));
         CVTMI_TRY(opq_rotate_impl(h, q, nq, S.s_qrot.as<float>(), st));
         q_rot = S.s_qrot.as<float>();
+    }
+    if (g_scan_bigk.load() && h->p_variant == 7 && h->p_qtile == 0 && h->p_splits == 0 && scank_applies(h->m, h->n, nq, k)) {
+        // k = 129 .. 2048 (round 6): sampled histogram bound, candidate lists, one selection workgroup per query (adc_scan_h.hip); the
+        // queries it could not answer (a list that overflowed, a crowded band, tables that bound nothing) are flagged and go through the
+        // exact kernel behind it.  Batches whose candidate lists would pass 1 GB go in pieces.
+        const uint8_t *crot = (h->p_prerot && h->rot_kind == 0 && h->rot_n == h->n && h->codes_rot.p) ? h->codes_rot.as<uint8_t>() : nullptr;
+        int64_t per = nq;
+        while (per > 8 && scank_scratch_bytes(h->n, per, k) > ((size_t)1 << 30)) per = ((per / 2) + 7) / 8 * 8;
+        CVTMI_TRY(S.s_lut.reserve((size_t)((per + 7) / 8 * 8) * 16 * 256 * sizeof(float)));
+        CVTMI_TRY(S.s_qlut.reserve(scanh_qlut_bytes(per)));
+        CVTMI_TRY(S.s_qp.reserve(scanh_qp_bytes(per)));
+        CVTMI_TRY(S.s_spill.reserve(scank_scratch_bytes(h->n, per, k)));
+        int slot = 0;
+        if (h->p_profile) {
+            CVTMI_TRY(opq_profile_slot(h, &slot));
+            CVTMI_HIP(hipEventRecord(h->ev0[slot], st));
+        }
+        ScanPlan exact;
+        exact.qtile = 1; exact.splits = 1; exact.variant = 0;
+        for (int64_t q0 = 0; q0 < nq; q0 += per) {
+            const int64_t n1 = std::min(per, nq - q0);
+            uint32_t *flags = nullptr;
+            CVTMI_TRY(launch_adc_scan_bigk(h->m, h->codes.as<uint8_t>(), crot, h->n, h->id_base, q_rot + q0 * h->m.D, n1, k, dist + q0 * k, ids + q0 * k,
+                                           S.s_lut.as<float>(), S.s_qlut.p, S.s_qp.p, S.s_spill.p, h->p_lazy, &flags, st));
+            CVTMI_TRY(launch_adc_scan(h->m, h->codes.as<uint8_t>(), h->n, h->id_base, q_rot + q0 * h->m.D, n1, k, exact, dist + q0 * k, ids + q0 * k,
+                                      nullptr, nullptr, st, nullptr, h->p_lazy, nullptr, nullptr, flags));
+        }
+        if (h->p_profile) {
+            CVTMI_HIP(hipEventRecord(h->ev1[slot], st));
+            opq_note_scan(h, ((nq + 7) / 8) * h->n * h->m.M * 5 / 4, 8, 1);   // passes x rows x M code bytes, the sampled pass included
+        }
+        return CVTMI_OK;
     }
     ScanPlan plan = opq_plan(h, nq, k);
     if (plan.packed && !(h->rot_kind == 1 && h->rot_n == h->n && h->codes_rot.p))   // (the packed rotation is not there: as before)

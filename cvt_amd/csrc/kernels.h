@@ -78,7 +78,8 @@ inline int64_t scan_in_place_queries(const ScanPlan &plan, int M, int64_t nq)
 int launch_adc_scan(const OpqModelDev &m, const uint8_t *codes, int64_t n_rows, int64_t id_base, const float *q_rot,
                     int64_t nq, int k, const ScanPlan &plan, float *part_d, int64_t *part_id, float *lut_scratch,
                     const uint8_t *codes_rot, hipStream_t st, uint32_t *gthr = nullptr, int lazy = 1, float *final_d = nullptr,
-                    int64_t *final_id = nullptr);
+                    int64_t *final_id = nullptr, const uint32_t *only = nullptr);
+// only ([nq] words or null; k > 128 with one query per workgroup and ONE row split): answer query g only when only[g] != 0
 // final_d / final_id ([nq][k], or null): where the first scan_in_place_queries() queries' lists go instead of part_* (with stride 1
 // part_* ARE the final arrays: pass them again)
 // M = 16 only: codes_rot rows [row0, n) = the code rows rotated left by (row & 15) bytes, the layout adc_scan16q
@@ -110,6 +111,13 @@ struct ScanHPlan {
 };
 void scanh_plan(int64_t n_rows, int64_t nq, int splits, ScanHPlan &p, int cus = 0);   // cus = 0: the device's CU count
 size_t scanh_spill_bytes(int grid);
+// k = 129 .. 2048 through the filter scan (adc_scan_h.hip, round 6): sampled histogram bound -> candidate lists -> one selection workgroup
+// per query; *flags_out ([nq] words inside `scratch`): 1 = not answered, the caller runs the exact kernel for those (launch_adc_scan's `only`)
+bool scank_applies(const OpqModelDev &m, int64_t n_rows, int64_t nq, int k);
+size_t scank_scratch_bytes(int64_t n_rows, int64_t nq, int k);
+int launch_adc_scan_bigk(const OpqModelDev &m, const uint8_t *codes, const uint8_t *codes_rot, int64_t n_rows, int64_t id_base, const float *q_rot,
+                         int64_t nq, int k, float *dist, int64_t *ids, float *lut_g, void *qlut, void *qp_g, void *scratch, int lazy,
+                         uint32_t **flags_out, hipStream_t st);
 size_t scanh_qlut_bytes(int64_t nq);
 size_t scanh_qp_bytes(int64_t nq);
 void set_scanh_balance(int v);       // 0 = choose, 1 = equal shares of the flat (group x row) space, 2 = (group, split) blocks

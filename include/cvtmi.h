@@ -104,6 +104,10 @@ int cvtmi_set_device(int device);
  *                     with zeros (derived copies: 32 bytes per row) and per-query tables padded with all-zero tables -- M = 8 at
  *                     10 000 queries x 1 M rows: 9.8 -> 3.2 ms, and every M from 1 to 15 is searchable; 0 = the row-per-lane
  *                     kernels (M = 4 / 8 only)
+ *   "scan_bigk"       1 (default) = an OPQ search (M = 16, >= 65 536 rows) with k = 129 .. 2048 runs through the filter scan: a sampled
+ *                     histogram bound per query, candidate lists, one selection workgroup per query, the exact kernel behind it for the
+ *                     queries it could not answer (round 6: k = 1000 at 10 000 queries x 1 M rows within 2x of k = 100); 0 = the exact
+ *                     kernel for every query (one query per workgroup: 11x slower at that size)
  *   "scan_packed_m"   1 (default) = an OPQ index with M = 8 or M = 4 is scanned as it lies in memory (adc_scan16p, round 6): 16 / M rows
  *                     per 16-byte load from a pre-rotated copy of the rows (+M bytes per row, no padded copy), 16 / M copies of the M
  *                     tables in LDS so that the look-ups stay conflict-free -- no look-up is spent on a zero table; 0 = the padded

@@ -764,6 +764,57 @@ def test_search_any_k(amd, orc, M):
 
 
 @pytest.mark.gpu
+def test_search_big_k_through_the_filter_scan(amd, orc):
+    """Round 6: k = 129 .. 2048 at M = 16 on >= 65 536 rows through the bound-first filter pipeline (adc_scan_h.hip:
+    sampled histogram bound -> candidate lists -> one selection workgroup per query) instead of the exact kernel with one query per
+    workgroup.  Same lists as the oracle and as the exact kernel ("scan_bigk" 0), bit for bit: exact ties at the top and across the k-th
+    place, 5000 copies of one query's nearest row (its band holds more than the selection sorts: that query is flagged and answered by
+    the exact kernel behind the pipeline), a NaN query (tables that bound nothing: flagged), appended rows, an id base, rotation on,
+    host and device pointers; get_sort_results takes any num_show (opq/src/common.h:25-37)."""
+    import torch
+    from cvt_amd import synth
+    D, M, K = 128, 16, 256
+    rng = np.random.default_rng(77)
+    books = synth_model(rng, D, M, K, scale=0.1)
+    R = synth.random_rotation(D, seed=3)
+    n = 150_000 + 11
+    codes = rng.integers(0, K, size=(n, M), dtype=np.uint8)
+    codes[100] = codes[50]; codes[140_000] = codes[50]; codes[12000:12300] = codes[77]
+    codes[60_000:65_000] = codes[99]                                     # 5000 equal rows: a crowded band for the query that hits them
+    idx = amd.OpqIndex(np.zeros((1, D), np.float32), books, R=R)
+    idx.add_codes(codes[:100_000])
+    idx.add_codes(codes[100_000:])
+    idx.set_id_base(1 << 35)
+    nq = 41
+    qr = (rng.normal(size=(nq, D)) * 0.1).astype(np.float32)            # queries in the ROTATED space ...
+    qr[1] = np.concatenate([books[m, codes[77][m]] for m in range(M)])  # 300 exact ties at distance 0
+    qr[2] = np.concatenate([books[m, codes[99][m]] for m in range(M)])  # 5000 exact ties at distance 0
+    qr[3] = np.concatenate([books[m, codes[50][m]] for m in range(M)])
+    q = (qr.astype(np.float64) @ R.astype(np.float64)).astype(np.float32)   # ... brought back: the library rotates them (y = R x)
+    q[5, 7] = np.nan
+    q_rot = orc.rotate_fma(R, q)
+    try:
+        for k in (129, 300, 1000, 2048):
+            od, oi = orc.adc_search(q_rot, books, codes, k)
+            ok = ~np.isnan(q_rot).any(axis=1)                            # (a NaN query: every distance is NaN; the order is the kernels' own)
+            ref = None
+            for bigk in (1, 0):
+                amd.set_tuning("scan_bigk", bigk)
+                for dev in (True, False):
+                    d, i = idx.search(torch.from_numpy(q).cuda() if dev else q, k, rotate=True)
+                    if dev:
+                        d, i = d.cpu().numpy(), i.cpu().numpy()
+                    assert np.array_equal(i[ok], oi[ok] + (1 << 35)), (k, bigk, dev)
+                    assert np.array_equal(bits(d[ok]), bits(od[ok])), (k, bigk, dev)
+                    if ref is None:
+                        ref = (d, i)
+                    assert np.array_equal(i, ref[1]) and np.array_equal(bits(d), bits(ref[0])), (k, bigk, dev, "NaN query included")
+    finally:
+        amd.set_tuning("scan_bigk", 1)
+    idx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rotation", ["dense", "perm", "none"])
 def test_small_batch_path(amd, orc, rotation):
     """1 .. 128 queries (the reference's own call pattern: 1-9 query frames per Query) through the small-batch path -- rotation folded

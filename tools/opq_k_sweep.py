@@ -10,9 +10,9 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 rows = 1_000_000
 idx = cvt_amd.OpqIndex(np.zeros((1, D), np.float32), books, R=synth.random_rotation(D))
 idx.add_codes(torch.randint(0, 256, (rows, M), generator=g, device=dev, dtype=torch.uint8))
-for nq in (10000, 1000, 8):
+for nq in [int(v) for v in os.environ.get('NQS', '10000,1000,8').split(',')]:
     q = torch.randn((nq, D), generator=g, device=dev) * 0.1
-    for k in (1, 10, 50, 100, 128, 129, 200, 500, 1000, 2048):
+    for k in [int(v) for v in os.environ.get('KS', '1,10,50,100,128,129,200,500,1000,2048').split(',')]:
         for _ in range(2): idx.search(q, k)
         torch.cuda.synchronize()
         t0 = time.perf_counter(); reps = 3
