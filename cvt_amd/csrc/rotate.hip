@@ -118,12 +118,21 @@ __global__ __launch_bounds__(ROT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     float4 pre[4];
     if (first < n_slabs) fetch(first, 0, pre);
     int cur = 0;
-    for (int64_t slab = first; slab < n_slabs; slab += step) {
-        f32x16 acc[NT];
+    // Round 6: a slab's 64 result stores and the zeroing of its accumulators used to sit between two slabs' matrix instructions -- with
+    // only four chunks per slab at D = 128 that fill and drain was a third of a slab's life (PMC: 70 % of the wave cycles issue-stalled,
+    // 0.57 of the fp32 matrix peak).  Now the accumulators are double-buffered: slab s + 1 starts from SrcC = 0 (no zeroing moves) into
+    // the other register set, and the stores of slab s are issued four at a time between the matrix instructions of its first chunk
+    // (16 k-steps x NT stores = the slab's NT x 16 values), where they run in the shadow of the 64-cycle instructions.
+    // Same products in the same k order per accumulator: bits unchanged.
+    f32x16 accA[NT], accB[NT];
+    auto store_e = [&](const f32x16 (&acc)[NT], int64_t row0, int e) {   // C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * lk;
+        if (row0 + r < n) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+            for (int t = 0; t < NT; ++t) y[(row0 + r) * D + t * 32 + li] = acc[t][e];
+        }
+    };
+    auto slab_body = [&](f32x16 (&acc)[NT], const f32x16 (&prev)[NT], bool has_prev, int64_t prev_row0, int64_t slab) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             float *buf = Xw + cur * (32 * ROT_XLD);
@@ -141,21 +150,37 @@ __global__ __launch_bounds__(ROT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
             for (int kk = 0; kk < ROT_KC; kk += 2) {
                 const float a = xa[kk];
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Rl[(t * 32) * LD + c * ROT_KC + kk], acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) {
+                    const float b = Rl[(t * 32) * LD + c * ROT_KC + kk];
+                    if (c == 0 && kk == 0) {
+                        const f32x16 zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, zero, 0, 0, 0);
+                    } else {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                    }
+                }
+                if (c == 0 && has_prev) store_e(prev, prev_row0, kk >> 1);   // (wave-uniform) the previous slab's values e = kk / 2 of every tile
             }
             cur ^= 1;
         }
-        // C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-        const int64_t row0 = slab * 32;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int r = (e & 3) + 8 * (e >> 2) + 4 * lk;
-                if (row0 + r < n) y[(row0 + r) * D + t * 32 + li] = acc[t][e];
-            }
+    };
+    bool pending_a = false, pending_b = false;
+    int64_t row_a = 0, row_b = 0;
+    for (int64_t slab = first; slab < n_slabs; slab += 2 * step) {
+        slab_body(accA, accB, pending_b, row_b, slab);
+        pending_b = false; pending_a = true; row_a = slab * 32;
+        if (slab + step < n_slabs) {
+            slab_body(accB, accA, true, row_a, slab + step);
+            pending_a = false; pending_b = true; row_b = (slab + step) * 32;
         }
+    }
+    if (pending_a) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) store_e(accA, row_a, e);
+    }
+    if (pending_b) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) store_e(accB, row_b, e);
     }
 }
 
