@@ -354,10 +354,14 @@ static bool sq8_wave_takes(int d, int64_t n, const void *x, const void *codes, c
 }   // cvtmi_set_tuning("sq8_encode_wave"): 0 = the tile kernel for every width
 void set_sq8_encode_wave(int v) { g_sq8_encode_wave = v; }
 
+static int launch_sq8_encode_group(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm, int write_back, uint8_t *codes, hipStream_t st);
 int launch_sq8_encode_rows(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm, int write_back,
                            uint8_t *codes, float *den_scratch, hipStream_t st)
 {
     if (n <= 0) return CVTMI_OK;
+    // 64-d / 128-d rows (round 6): several rows per wave through the same decision filter (sq8_encode_group_f_kernel)
+    if (g_sq8_encode_wave && sq8_filter_on() && (d == 64 || d == 128) && n >= 4096 && sq8_wave_aligned(x, codes, vmin, vdiff))
+        return launch_sq8_encode_group(vmin, vdiff, d, x, n, l2norm, write_back, codes, st);
     // (rows wider than the tile kernel's 512 floats: at every row count -- the two-pass kernels' norm pass alone costs 100 us for ONE row)
     if (g_sq8_encode_wave && sq8_wave_width(d) && n >= (d > 512 ? 1 : 4096) && sq8_wave_aligned(x, codes, vmin, vdiff) && (d <= 512 || sq8_filter_on()))
         return launch_sq8_encode_wave(vmin, vdiff, d, x, n, l2norm, write_back, codes, st);
@@ -1102,6 +1106,229 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NF <= 4 
     for (int c = tid; c < D; c += kBlock) { atomicMin(&kmin[c], smin[c]); atomicMax(&kmax[c], smax[c]); }
 }
 
+// ---- rows narrower than a wave's 256 floats (round 6): 64-d and 128-d -- the reference's own demo vector is 64-d
+// (scalar_quantization/int8_quan_test.cpp:26) and these rows stayed on the tile kernel at 1.0-3.5 TB/s.  Rows are contiguous, so 64 / LPR
+// consecutive rows ARE one 1 KB "wave row" (LPR = lanes per data row: 16 at 64-d, 32 at 128-d): the loads, the code stores and the
+// write-back keep the wide kernels' coalesced form and only three things change -- the sum of squares stops at the row's own LPR lanes
+// (the DPP steps inside a row of 16 lanes, one more exchange at 128-d), the per-row work (two double roots, the reciprocal) is done by
+// lane p of every 16-lane row for register-row p, all data rows of the iteration at once, and handed to the row's lanes by one
+// v_mov_b32 row_newbcast each; and a lane's columns are those of lane % LPR.  Same decision filters, same chains behind them: same bits.
+template <int LPR>
+__device__ __forceinline__ double sq8_group_sum(double s)
+{
+    s = sq8_dpp_step(s, 0); s = sq8_dpp_step(s, 1); s = sq8_dpp_step(s, 2); s = sq8_dpp_step(s, 3);   // every lane: the sum of its row of 16
+    if constexpr (LPR == 32) s += __shfl_xor(s, 16, 64);
+    return s;
+}
+template <int P> __device__ __forceinline__ int sq8_row_bcast(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + P, 0xf, 0xf, false); }   // row_newbcast:P
+__device__ __forceinline__ DivBy sq8_bcast_divby(const DivBy &dl, int p)   // lane p of every 16-lane row -> that row's lanes (p a constant after unrolling)
+{
+    DivBy dd;
+    const int b = __float_as_int(dl.b), y = __float_as_int(dl.y), ok = (int)dl.ok;
+    int rb, ry, rk;
+    switch (p) {
+        case 0: rb = sq8_row_bcast<0>(b); ry = sq8_row_bcast<0>(y); rk = sq8_row_bcast<0>(ok); break;
+        case 1: rb = sq8_row_bcast<1>(b); ry = sq8_row_bcast<1>(y); rk = sq8_row_bcast<1>(ok); break;
+        case 2: rb = sq8_row_bcast<2>(b); ry = sq8_row_bcast<2>(y); rk = sq8_row_bcast<2>(ok); break;
+        default: rb = sq8_row_bcast<3>(b); ry = sq8_row_bcast<3>(y); rk = sq8_row_bcast<3>(ok); break;
+    }
+    dd.b = __int_as_float(rb); dd.y = __int_as_float(ry); dd.ok = rk != 0;
+    return dd;
+}
+// the per-row denominators of the RB register-rows of one iteration: leader lanes ((lane & 15) == p) return theirs, everybody else 1.0
+// g0: group of register-row 0, gstep: groups between register-rows
+template <int LPR, int RB>
+__device__ __forceinline__ float sq8_group_den(const float *__restrict__ x, int64_t n, const float4 (&cur)[RB], int64_t g0, int64_t gstep)
+{
+    constexpr int SUB = 64 / LPR, D = 4 * LPR;
+    const int lane = threadIdx.x & 63, l16 = lane & 15;
+    double s[RB];
+#pragma unroll
+    for (int p = 0; p < RB; ++p) {
+        s[p] = 0.0;
+        s[p] += (double)__fmul_rn(cur[p].x, cur[p].x); s[p] += (double)__fmul_rn(cur[p].y, cur[p].y);
+        s[p] += (double)__fmul_rn(cur[p].z, cur[p].z); s[p] += (double)__fmul_rn(cur[p].w, cur[p].w);
+        s[p] = sq8_group_sum<LPR>(s[p]);
+    }
+    double mine = s[0];
+#pragma unroll
+    for (int p = 1; p < RB; ++p) mine = l16 == p ? s[p] : mine;
+    // same proof as the tile kernel: the float root is order-independent when the roots of sum (1 -+ 2^-42) coincide
+    const double rlo = __dsqrt_rn(mine * (1.0 - 0x1p-42)), rhi = __dsqrt_rn(mine * (1.0 + 0x1p-42));
+    float den = (float)(rlo > 1e-12 ? rlo : 1e-12);
+    const float fhi = (float)(rhi > 1e-12 ? rhi : 1e-12);
+    unsigned long long unproven = __ballot(l16 < RB && !(den == fhi));
+    while (unproven) {  // rare: the reference's own order for those rows (int8_quan.cc:48-51); wave-uniform loop
+        const int lb = __ffsll((long long)unproven) - 1;
+        unproven &= unproven - 1;
+        int64_t r = (g0 + (int64_t)(lb & 15) * gstep) * SUB + lb / LPR;
+        r = r < n ? r : n - 1;
+        double accum = 0.0;
+        for (int e = 0; e < D; ++e) {
+            const float t = x[r * D + e];
+            accum += (double)__fmul_rn(t, t);
+        }
+        const double nrm = __dsqrt_rn(accum);
+        if (lane == lb) den = (float)(nrm > 1e-12 ? nrm : 1e-12);
+    }
+    return den;
+}
+
+template <int LPR, bool NORM>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void sq8_train_group_f_kernel(
+    const float *__restrict__ x, int64_t n, uint32_t *kmin, uint32_t *kmax, int seeded)
+{
+    constexpr int SUB = 64 / LPR, D = 4 * LPR, RB = 4;
+    __shared__ uint32_t smin[D], smax[D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane % LPR, lr = lane / LPR;
+    for (int c = tid; c < D; c += kBlock) { smin[c] = 0xffffffffu; smax[c] = 0u; }
+    __syncthreads();
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    const int64_t ng = (n + SUB - 1) / SUB;
+    const int64_t nw = (int64_t)gridDim.x * (kBlock / 64), w0 = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    float mn[4], mx[4], tlo[4], thi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * lc + j;
+        mn[j] = seeded ? key_f32(kmin[c]) : __uint_as_float(0x7f800000u);
+        mx[j] = seeded ? key_f32(kmax[c]) : __uint_as_float(0xff800000u);
+        if (!(mn[j] <= mx[j])) { mn[j] = __uint_as_float(0x7f800000u); mx[j] = __uint_as_float(0xff800000u); }   // an empty / all-NaN sample
+        tlo[j] = sq8_thr_lo(mn[j]);
+        thi[j] = sq8_thr_hi(mx[j]);
+    }
+    float4 cur[RB], nxt[RB];
+    auto fetch = [&](int64_t g, float4 &o) {
+        int64_t r = g * SUB + lr;
+        r = r < n ? r : n - 1;  // clamped per lane: the tail re-reads the last row, which changes no extreme
+        o = SQ8_LD(&x4[r * LPR + lc]);
+    };
+#pragma unroll
+    for (int p = 0; p < RB; ++p) fetch(w0 + p * nw, nxt[p]);
+    for (int64_t g = w0; g < ng; g += RB * nw) {
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            cur[p] = nxt[p];
+            fetch(g + (p + RB) * nw, nxt[p]);
+        }
+        float den = 1.0f;
+        if constexpr (NORM) den = sq8_group_den<LPR, RB>(x, n, cur, g, nw);
+        const DivBy dl = div_by(den);
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            const DivBy dd = sq8_bcast_divby(dl, p);
+            const float ys = __fmul_rn(dd.y, 0x1p60f);   // exact scaling (dd.y <= 2^40 when ok)
+            const float e[4] = { cur[p].x, cur[p].y, cur[p].z, cur[p].w };
+            bool open[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pp = __fmul_rn(e[j], ys);
+                open[j] = !dd.ok || pp < tlo[j] || pp > thi[j];   // a candidate for an extreme (or a row the bound does not cover)
+            }
+            if (open[0] || open[1] || open[2] || open[3]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (open[j]) {
+                        const float a = NORM ? div_rn(e[j], dd) : e[j];
+                        if (a < mn[j]) { mn[j] = a; tlo[j] = sq8_thr_lo(a); }
+                        if (a > mx[j]) { mx[j] = a; thi[j] = sq8_thr_hi(a); }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { atomicMin(&smin[4 * lc + j], f32_key(mn[j])); atomicMax(&smax[4 * lc + j], f32_key(mx[j])); }
+    __syncthreads();
+    for (int c = tid; c < D; c += kBlock) { atomicMin(&kmin[c], smin[c]); atomicMax(&kmax[c], smax[c]); }
+}
+
+template <int LPR, bool NORM>
+__global__ __launch_bounds__(kBlock) void sq8_encode_group_f_kernel(const float *__restrict__ vmin, const float *__restrict__ vdiff, float *x, int64_t n,
+                                                                   int write_back, uint8_t *__restrict__ codes)
+{
+    constexpr int SUB = 64 / LPR, RB = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lc = lane % LPR, lr = lane / LPR;
+    float4 *x4 = reinterpret_cast<float4 *>(x);
+    uint32_t *c4 = reinterpret_cast<uint32_t *>(codes);
+    const int64_t ng = (n + SUB - 1) / SUB;
+    const int64_t nw = (int64_t)gridDim.x * (kBlock / 64), w0 = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    ColF cf[4];
+    {
+        const float4 l4 = reinterpret_cast<const float4 *>(vmin)[lc];
+        const float4 d4 = reinterpret_cast<const float4 *>(vdiff)[lc];
+        cf[0] = sq8_col_filter(l4.x, d4.x); cf[1] = sq8_col_filter(l4.y, d4.y);
+        cf[2] = sq8_col_filter(l4.z, d4.z); cf[3] = sq8_col_filter(l4.w, d4.w);
+    }
+    float4 cur[RB], nxt[RB];
+    auto fetch = [&](int64_t g, float4 &o) {
+        int64_t r = g * SUB + lr;
+        r = r < n ? r : n - 1;  // clamped per lane: rows past the end are computed, never stored
+        o = SQ8_LD(&x4[r * LPR + lc]);
+    };
+#pragma unroll
+    for (int p = 0; p < RB; ++p) fetch(w0 + p * nw, nxt[p]);
+    for (int64_t g = w0; g < ng; g += RB * nw) {
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            cur[p] = nxt[p];
+            fetch(g + (p + RB) * nw, nxt[p]);
+        }
+        float den = 1.0f;
+        if constexpr (NORM) den = sq8_group_den<LPR, RB>(x, n, cur, g, nw);
+        const DivBy dl = div_by(den);
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            const int64_t r = (g + p * nw) * SUB + lr;
+            const bool live = r < n;
+            const DivBy dd = sq8_bcast_divby(dl, p);
+            const float4 v = cur[p];
+            float e[4] = { v.x, v.y, v.z, v.w };
+            uint32_t w = 0u;
+            if (NORM && !dd.ok) {   // (per data row, rare) a norm outside the guarded range (zero / huge / non-finite rows): the chain for the whole row
+                float4 q = v;
+                q.x = div_rn(q.x, dd); q.y = div_rn(q.y, dd); q.z = div_rn(q.z, dd); q.w = div_rn(q.w, dd);
+                if (write_back && live) SQ8_ST(&x4[r * LPR + lc], q);
+                const float4 l4 = reinterpret_cast<const float4 *>(vmin)[lc];
+                const float4 d4 = reinterpret_cast<const float4 *>(vdiff)[lc];
+                w = sq8_byte(q.x, l4.x, div_by(d4.x)) | (sq8_byte(q.y, l4.y, div_by(d4.y)) << 8) |
+                    (sq8_byte(q.z, l4.z, div_by(d4.z)) << 16) | (sq8_byte(q.w, l4.w, div_by(d4.w)) << 24);
+            } else {
+                if (NORM && write_back) {   // (uniform) the reference's in-place normalisation: the exact quotients are needed anyway
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e[j] = div_rn(e[j], dd);
+                    if (live) SQ8_ST(&x4[r * LPR + lc], make_float4(e[0], e[1], e[2], e[3]));
+                }
+                bool open[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const ColF &f = cf[j];
+                    const float pq = (!NORM || write_back) ? e[j] : __fmul_rn(e[j], dd.y);
+                    const float T = __fmaf_rn(pq, f.s, f.c);
+                    const float fl = floorf(T);
+                    const bool sure = fabsf(__fsub_rn(__fsub_rn(T, fl), 0.5f)) < f.h;
+                    const bool zero = e[j] == 0.0f;   // +-0 in, +-0 out of the division: the column's constant
+                    uint32_t b = (uint32_t)__builtin_amdgcn_fmed3f(fl, 0.0f, 255.0f);
+                    b = zero ? f.code0 : b;
+                    open[j] = !(sure || zero);
+                    w |= b << (8 * j);
+                }
+                if (open[0] || open[1] || open[2] || open[3]) {   // ONE branch per four elements: the chain itself for what the bound does not decide
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (open[j]) {
+                            const int col = 4 * lc + j;
+                            const float a = (!NORM || write_back) ? e[j] : div_rn(e[j], dd);
+                            w = (w & ~(0xffu << (8 * j))) | (sq8_byte(a, vmin[col], div_by(vdiff[col])) << (8 * j));
+                        }
+                    }
+                }
+            }
+            if (live) SQ8_ST(&c4[r * LPR + lc], w);
+        }
+    }
+}
+static bool sq8_group_width(int d) { return d == 64 || d == 128; }
+
 static std::atomic<int> g_sq8_flags{1};    // cvtmi_set_tuning("sq8_flags"): bit 0 = wave sums on DPP instead of the ds_bpermute butterfly
 void set_sq8_flags(int v) { g_sq8_flags = v; }
 static std::atomic<int> g_sq8_filter{1};   // cvtmi_set_tuning("sq8_filter"): 0 = the exact chain for every element (the round 2 - 4 kernels)
@@ -1179,6 +1406,34 @@ static void launch_sq8_train_wave_f(int NF, bool norm, unsigned blocks, hipStrea
 }
 static int g_sq8_wave_blocks = 3;
 void set_sq8_wave_blocks(int v) { g_sq8_wave_blocks = v; }
+static unsigned sq8_group_blocks(int64_t n, int d)
+{
+    const int64_t groups = (n * d + 255) / 256, per_wg = kBlock / 64;
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((groups + per_wg - 1) / per_wg, 256 * g_sq8_wave_blocks));
+}
+static void launch_sq8_train_group(int d, bool norm, unsigned blocks, hipStream_t st, const float *x, int64_t n, uint32_t *kmin, uint32_t *kmax, int seeded)
+{
+    if (d == 64) {
+        if (norm) hipLaunchKernelGGL((sq8_train_group_f_kernel<16, true>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax, seeded);
+        else hipLaunchKernelGGL((sq8_train_group_f_kernel<16, false>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax, seeded);
+    } else {
+        if (norm) hipLaunchKernelGGL((sq8_train_group_f_kernel<32, true>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax, seeded);
+        else hipLaunchKernelGGL((sq8_train_group_f_kernel<32, false>), dim3(blocks), dim3(kBlock), 0, st, x, n, kmin, kmax, seeded);
+    }
+}
+static int launch_sq8_encode_group(const float *vmin, const float *vdiff, int d, float *x, int64_t n, int l2norm, int write_back, uint8_t *codes, hipStream_t st)
+{
+    const unsigned blocks = sq8_group_blocks(n, d);
+    if (d == 64) {
+        if (l2norm) hipLaunchKernelGGL((sq8_encode_group_f_kernel<16, true>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes);
+        else hipLaunchKernelGGL((sq8_encode_group_f_kernel<16, false>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, 0, codes);
+    } else {
+        if (l2norm) hipLaunchKernelGGL((sq8_encode_group_f_kernel<32, true>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, write_back, codes);
+        else hipLaunchKernelGGL((sq8_encode_group_f_kernel<32, false>), dim3(blocks), dim3(kBlock), 0, st, vmin, vdiff, x, n, 0, codes);
+    }
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
 // den_scratch: n floats, only used for row widths the tile kernel does not take
 int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_scratch, uint32_t *kmin, uint32_t *kmax,
                      float *vmin, float *vdiff, hipStream_t st)
@@ -1189,7 +1444,12 @@ int launch_sq8_train(const float *x, int64_t n, int d, int l2norm, float *den_sc
         // the wave-per-row kernels: normalised rows of 256 / 512 floats as before; round 5: through the filter kernel also rows of 768 ...
         // 2048 floats, and those without normalisation (the tile kernel stops at 512-d; the generic kernels ran at 0.8 / 3.3 TB/s)
         const bool wave_f = sq8_filter_on() && sq8_wave_width(d);   // (without normalisation too: 4 M x 512-d 5.75 TB/s through the tile kernel, 6.3 here)
-        if ((wave_f || (l2norm && (d == 256 || d == 512))) && (((uintptr_t)x) & 15) == 0 && n >= (wave_f && d > 512 ? 1 : 4096)) {
+        if (sq8_filter_on() && sq8_group_width(d) && (((uintptr_t)x) & 15) == 0 && n >= 4096) {
+            // 64-d / 128-d rows (round 6): several rows per wave, sample pass + seeded pass like the wide rows
+            const int64_t ns = n >= 8 * SQ8_SAMPLE_ROWS ? SQ8_SAMPLE_ROWS : 0;
+            if (ns) launch_sq8_train_group(d, l2norm != 0, sq8_group_blocks(ns / 16, d), st, x, ns, kmin, kmax, 0);
+            launch_sq8_train_group(d, l2norm != 0, sq8_group_blocks(n - ns, d), st, x + ns * d, n - ns, kmin, kmax, ns ? 1 : 0);
+        } else if ((wave_f || (l2norm && (d == 256 || d == 512))) && (((uintptr_t)x) & 15) == 0 && n >= (wave_f && d > 512 ? 1 : 4096)) {
             // whole rows per wave, no LDS tile (the tile kernel's phases serialise behind its barriers: 3.3 TB/s at d = 512)
             const int64_t rows_per_wg = kBlock / 64;
             const unsigned blocks = (unsigned)std::min<int64_t>((n + rows_per_wg - 1) / rows_per_wg, 256 * g_sq8_wave_blocks);

@@ -379,7 +379,8 @@ def test_sq8_train_sign_of_a_zero_minimum(amd, orc, d, n, l2):
 
 
 @pytest.mark.parametrize("d,kind", [(d, k) for d in (512, 256) for k in ("relu", "signed", "wide")] +
-                         [(768, "relu"), (1024, "wide"), (1536, "signed"), (2048, "relu"), (2048, "wide")])
+                         [(768, "relu"), (1024, "wide"), (1536, "signed"), (2048, "relu"), (2048, "wide")] +
+                         [(128, "relu"), (128, "wide"), (64, "signed"), (64, "relu"), (64, "wide")])   # round 6: several rows per wave (sq8_*_group_f_kernel)
 def test_sq8_decision_filter_equals_the_chain(amd, orc, d, kind):
     """Round 5: the wave kernels decide most code bytes / column extremes from a bounded approximation and run the reference's chain
     (two correctly rounded divisions + the byte, int8_quan.cc:46-56, :79-92) only where that cannot decide.  Codes, written-back rows and
