@@ -473,7 +473,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     }
     if (!strcmp(name, "flat_f32_dbg")) { set_flat_f32_dbg((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_share")) {
-        if (value < 0 || value > 2) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_f32_share must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_f32_share must be 0 .. 3");
         set_flat_f32_share((int)value);
         return CVTMI_OK;
     }

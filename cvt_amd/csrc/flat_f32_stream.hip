@@ -954,12 +954,16 @@ static std::atomic<int> g_fs_share{0};   // cvtmi_set_tuning("flat_f32_share"): 
 void set_flat_f32_share(int v) { g_fs_share = v; }
 // the shared-ring kernel wants whole K steps per wave: D / 16 a multiple of the wave count
 constexpr int FS_MANY = 12;   // waves of the many-wave form of the shared-ring kernel (three per SIMD)
+// round 6, "flat_f32_share" 3: eight waves (two per SIMD) of 64 queries each -- 512 queries per pass instead of 384 (1000 queries: two
+// passes over the rows instead of three)
+static bool fs_wide() { return g_fs_share == 3; }
+static int fs_many_queries() { return fs_wide() ? 8 * 64 : 32 * FS_MANY; }
 static bool fs_eight(int D) { return g_fs_share != 1 && (D == 64 || D == 128); }
 static bool fs_four(int D) { return (D / 16) % 4 == 0; }
 int flat_f32_stream_qmax(int D)
 {
     if (D != 32 && D != 64 && D != 96 && D != 128 && D != 192 && D != 256) return 0;
-    return fs_eight(D) ? 32 * FS_MANY : (fs_four(D) ? 128 : 32) * fs_qb_max(D / 16);
+    return fs_eight(D) ? fs_many_queries() : (fs_four(D) ? 128 : 32) * fs_qb_max(D / 16);
 }
 static bool fs_shared(int D, int64_t nq) { return nq > 32 * fs_qb_max(D / 16); }
 // the most queries a pass of the private-ring kernel takes (more go to the shared ring, up to flat_f32_stream_qmax)
@@ -1020,6 +1024,14 @@ static int fs_launch_eight(const FsStreamArgs &a, hipStream_t st)
     if constexpr (NCH == 4 || NCH == 8) {
         static std::atomic<bool> attr_set[16] = {};
         const size_t lds = FssGeom<NCH, NCH>::LDS;
+        if (fs_wide()) {
+            static std::atomic<bool> attr_set_w[16] = {};
+            CVTMI_TRY(fs_set_lds((const void *)flat_f32_mshare_kernel<NCH, 2, 8, NCH>, lds, attr_set_w));
+            hipLaunchKernelGGL((flat_f32_mshare_kernel<NCH, 2, 8, NCH>), dim3(FSS_STREAMS), dim3(64 * 8), lds, st, a.X, a.bias, a.n_tiles, a.q,
+                               a.nq, a.G, a.NG, a.gb, a.wm, a.redo, a.cnt, g_fs_dbgflags | (fs_nt(true, 1) ? 16 : 0));
+            CVTMI_HIP(hipGetLastError());
+            return CVTMI_OK;
+        }
         CVTMI_TRY(fs_set_lds((const void *)flat_f32_mshare_kernel<NCH, 1, FS_MANY, NCH>, lds, attr_set));
         hipLaunchKernelGGL((flat_f32_mshare_kernel<NCH, 1, FS_MANY, NCH>), dim3(FSS_STREAMS), dim3(64 * FS_MANY), lds, st, a.X, a.bias, a.n_tiles, a.q,
                            a.nq, a.G, a.NG, a.gb, a.wm, a.redo, a.cnt, g_fs_dbgflags | (fs_nt(true, 1) ? 16 : 0));

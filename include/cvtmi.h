@@ -147,7 +147,9 @@ int cvtmi_set_device(int device);
  *   "scanh_balance" / "scanh_min_rows" / "scanh_tail" / "scanh_fix" / "scanh_share_hist"  planner of the persistent-grid scan (variant
  *                     6): 0 choose / 1 equal row-time shares / 2 row blocks; smallest row segment; two-region tail on / off; an item's
  *                     fixed cost in row-equivalents (160 000); one candidate histogram per query shared by its segments (1) or not
- *   "flat_f32_share"  fp32 stream, batches beyond one wave's queries: 0 choose, 1 private rings only, 2 the shared-ring kernel
+ *   "flat_f32_share"  fp32 stream, batches beyond one wave's queries: 0 choose, 1 private rings only, 2 the shared-ring kernel,
+ *                     3 = the shared ring with eight waves of 64 queries (512 queries per pass over the rows instead of 384; round 6,
+ *                     measured: 385 .. 512 queries 0.74 -> 0.51 ms on 1 M x 128-d, 1000 queries unchanged -- its registers spill)
  *   "hnsw_top_lds"    entries of an HNSW traversal's top queue kept in LDS (default 256; 0 = all)
  *   "hnsw_slots"      cap on HNSW traversals per CU (0 = what LDS allows, at most 32)
  *   "scans_dbg" / "flat_f32_dbg"  measurement switches of the small-batch scan and of the fp32 stream (phases skipped: results are WRONG
