@@ -1,6 +1,12 @@
-"""CPU, world_size 2 (gloo): the row-shard -> all-gather -> merge plumbing of cvt_amd/sharded.py gives the
-same answer as one process over the whole database.  The per-shard search and the merge are the CPU
-oracle here (test infrastructure); on the GPU box the same class is driven by the HIP kernels."""
+"""CPU, world_size 2 / 3 (gloo): the row-shard -> all-gather -> merge plumbing of cvt_amd/sharded.py (46 lines of torch.distributed
+glue) gives the same answer as one process over the whole database.  The per-shard search and the merge are the CPU oracle here
+(test infrastructure).
+
+What this file does NOT cover: the library's own exchange, csrc/shard.hip (slot layout, the in-place ncclAllGather / the
+caller-supplied transport, topk_merge_kernel<true>, the status word).  That is exercised on the GPU box only -- world 1 through
+real RCCL, worlds 2 / 3 / 8 through the custom transport, bench.py --gpus 2 / 8: tests/test_gpu_sharded.py.  This file proves the
+N > 1 decomposition (shard ranges, id bases, ties across boundaries, k larger than a shard) on the CPU; that one proves the code
+that ships."""
 import os
 import socket
 
