@@ -172,7 +172,7 @@ struct cvtmi_flat_s {
     DevBuf f_pack, f_bias, f_istats;   // f_istats: [0] max |x|^2, [1] rows with a non-finite value (of the operand copy)
     int64_t f_pack_n = -1;      // rows the copy covers (-1: none)
     bool f_nonfinite = false;   // a row holds inf / NaN: the filter is not used
-    std::atomic<int> f_last_filtered{0};    // how the last search was answered (0 exact, 1 filter pipeline, 2 fp32 stream)
+    std::atomic<int> f_last_filtered{0};    // how the last search was answered (0 exact, 1 filter pipeline, 2 fp32 stream, 3 fp32 threshold filter)
     std::atomic<long long> f_last_worst{0};  // its largest candidate list
     // fp32 stream (flat_f32_stream.hip): per-row score bias, statistics of the rows ([0] max |x|^2, [1] non-finite rows)
     DevBuf fs_bias, fs_stats;
@@ -472,6 +472,8 @@ int cvtmi_set_tuning(const char *name, int64_t value)
         return CVTMI_OK;
     }
     if (!strcmp(name, "flat_f32_dbg")) { set_flat_f32_dbg((int)value); return CVTMI_OK; }
+    if (!strcmp(name, "flat_f32_tfilter")) { set_flat_f32_tfilter((int)value); return CVTMI_OK; }
+    if (!strcmp(name, "flat_f32_tfilter_min")) { set_flat_f32_tfilter_min((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_share")) {
         if (value < 0 || value > 3) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_f32_share must be 0 .. 3");
         set_flat_f32_share((int)value);
@@ -1823,12 +1825,27 @@ static int flat_search_rows(cvtmi_flat_t h, FlatScratch &S, int64_t n_rows, cons
 }
 
 // fp32 search as a stream over the rows (flat_f32_stream.hip).  *done = false: not applicable, the other paths answer
-static int flat_search_streamed(cvtmi_flat_t h, FlatScratch &S, const float *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st, bool *done)
+static int flat_search_streamed(cvtmi_flat_t h, FlatScratch &S, const float *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st, bool *done,
+                                int *how = nullptr)
 {
     *done = false;
     const int D = h->D;
     const int64_t n = h->n;
     if (!h->fs_bias.p || !h->fs_stats.p || h->fs_stats_n != n || h->fs_nonfinite) return CVTMI_OK;
+    if (flat_f32_tfilter_applies(h->metric, D, n, nq, k) && h->f_pack.p && h->f_pack_n == n && !h->f_nonfinite &&
+        S.fs_scratch.reserve(flat_f32_tfilter_scratch(nq)) == CVTMI_OK) {
+        // large batches (round 6, flat_f32_tfilter.hip): sample maxima -> per-query threshold -> barrier-free threshold filter (queries in
+        // LDS, the rows' bf16 operand copy in registers) -> exact distances of the candidates; flagged queries go through the exact
+        // kernels below, as for the stream
+        CVTMI_TRY(S.fs_redo.reserve((size_t)nq * 2 * sizeof(uint32_t)));
+        CVTMI_TRY(launch_flat_f32_tfilter(h->metric, D, h->data.as<float>(), h->f_pack.p, h->fs_bias.as<float>(), h->fs_stats.as<uint32_t>(), n, q, nq, k,
+                                          S.fs_scratch.p, dist, rows, S.fs_redo.as<uint32_t>(), st));
+        CVTMI_TRY(flat_search_rows(h, S, n, q, nq, k, dist, rows, st, INT64_MAX, S.fs_redo.as<uint32_t>()));
+        *done = true;
+        if (how) *how = 3;
+        return CVTMI_OK;
+    }
+    (void)hipGetLastError();
     const int qmax = flat_f32_stream_qmax(D), qpriv = flat_f32_stream_private_max(D);
     int64_t passes = (nq + qmax - 1) / qmax;
     // just past one private-ring pass, two of them beat one pass of the shared ring (1 M x 128-d, 128 queries: 0.28 against 0.32 ms)
@@ -2008,7 +2025,7 @@ extern "C" int cvtmi_flat_describe_dispatch(int metric, int D, int64_t n_rows, i
     alignas(16) static const char aligned_q[16] = {};
     const FlatRoute r = flat_route(&h, aligned_q, nq, k, FlatTuning::now());
     h.fs_bias.p = nullptr; h.fs_stats.p = nullptr; h.norms.p = nullptr;
-    out[0] = r.stream ? 1 : 0;
+    out[0] = r.stream ? (flat_f32_tfilter_applies(metric, D, n_rows, nq, k) ? 2 : 1) : 0;
     out[1] = r.filt_f32 ? 1 : 0;
     out[2] = r.filt_u8 ? 1 : 0;
     out[3] = (metric == CVTMI_METRIC_L2U8 && !r.filt_u8 && flat_u8_mstream_applies(D, n_rows, std::min<int64_t>(nq, 128), k)) ? 1 : 0;
@@ -2027,7 +2044,8 @@ static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStr
             std::shared_lock<std::shared_timed_mutex> rd(h->rw);
             r = flat_route(h, q, nq, k, tun);
             need_fs = r.stream && h->fs_stats_n != h->n;
-            need_f32 = r.filt_f32 && h->f_pack_n != h->n && !(r.stream && !need_fs && !h->fs_nonfinite);   // (the stream answers: no copy needed)
+            const bool tf = r.stream && !h->fs_nonfinite && flat_f32_tfilter_applies(h->metric, h->D, h->n, nq, k);   // the threshold filter reads the copy too
+            need_f32 = h->f_pack_n != h->n && (tf ? !need_fs : (r.filt_f32 && !(r.stream && !need_fs && !h->fs_nonfinite)));   // (the stream answers: no copy needed)
             need_u8 = r.filt_u8 && h->f_pack_n != h->n;
             if (!need_fs && !need_f32 && !need_u8) return CVTMI_OK;
         }
@@ -2074,8 +2092,9 @@ static int flat_search_leased(cvtmi_flat_t h, FlatScratch &S, const void *q, int
     int how = 0;
     const FlatRoute r = flat_route(h, q, nq, k, tun);
     if (r.stream) {
-        CVTMI_TRY(flat_search_streamed(h, S, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
-        if (done) how = 2;
+        int how_s = 2;
+        CVTMI_TRY(flat_search_streamed(h, S, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done, &how_s));
+        if (done) how = how_s;
     }
     if (!done && r.filt_f32)
         CVTMI_TRY(flat_search_filtered(h, S, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));

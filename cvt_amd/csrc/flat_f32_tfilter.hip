@@ -1,0 +1,590 @@
+// flat_f32_tfilter.hip -- exhaustive fp32 search (BruteforceSearch<float>::searchKnn, brutoforce.hpp:73-93, with InnerProductSpace,
+// space_ip.hpp:211-239, or L2Space, space_l2.h:153-184) for LARGE BATCHES of 64-d / 128-d queries as a threshold filter (round 6).
+//
+// The answer -- the k smallest (distance, row) per query, distances in the reference's own summation order -- comes out bit for
+// bit because every reported distance is evaluated by the exact code (fs_exact, dist_f32.h order).  The matrix cores only decide
+// WHICH rows need one.  The stream kernels of flat_f32_stream.hip do that with the queries in registers and a (best, second) pair
+// per lane, query and group: 0.32-0.36 ms per pass of 384 queries over 1 M x 128-d rows whatever the pass carries, 0.27 of the bf16
+// matrix peak at 1000 queries.  Here the operands swap roles and nothing is shared between waves:
+//   * a workgroup (8 waves, two per SIMD) keeps up to 512 QUERIES in LDS for its whole life, as bf16 matrix operands
+//     ([block of 32][K step][term][64 lanes] x 16 B: one conflict-free ds_read_b128 per operand);
+//   * a wave takes RT 32-row tiles of the bf16 operand copy of the rows (flat_pack_kernel: [tile][K step][hi | lo][64 lanes] x 16 B,
+//     1 KB per load instruction) straight into REGISTERS and walks the query blocks: T = x.q + b_x (b_x = -|x|^2/2 for L2, 0 for
+//     the inner product: the start value of the accumulators, SrcC of a block's first matrix instruction).  With A = rows and
+//     B = queries a lane ends up with the scores of ITS QUERY against 16 rows per tile, so the query's threshold is a per-lane
+//     constant: a v_max3 tree and one compare per tile and block, no ring, no barrier, no (best, second);
+//   * NPROD says how much of the two-term bf16 split is multiplied: 3 = x1.q1 + x2.q1 + x1.q2 (error 2^-13 Q as in the stream
+//     kernels), 2 = (x1 + x2).q1, 1 = x1.q1 alone.  Fewer products = a wider margin = more candidates (1 M SIFT-like rows, top-100,
+//     sample of an eighth: 850 / 1330 / 2040 per query) for a third / two thirds less matrix work; the rows that get exact
+//     distances in the end stay k and a few (101 / 119 / 136);
+//   * a lane whose 16 scores reach its threshold writes them as ONE record (16 scores, query, first row: 80 bytes) into its
+//     wave's own region of a record area -- no atomic, no wait; `wcnt` counts a wave's records.
+// Pipeline: (1) MAX mode over a leading sample of the rows: 1024 maxima of disjoint row sets per query (global atomic max, no
+// return); the k-th largest of them is reached by k distinct rows, so it bounds the k-th best score from below, and theta - margin
+// admits every row that can be among the k best (ft_theta_kernel).  (2) FILTER mode over all rows.  (3) ft_bucket_kernel: the
+// records' scores at or above the threshold go to per-query candidate lists.  (4) ft_finish_kernel, one workgroup per query: the
+// k-th largest candidate score by a radix select, the candidates at or above it minus the margin get exact distances, ranked by
+// (distance, row).  A query whose list runs over, whose sample has fewer than k slots filled, whose bound does not hold (non-finite
+// values, magnitudes outside 2^-60 .. 2^60) or whose wave region ran full is flagged in redo[]: the exact kernels answer it.
+// Workgroups that hold DIFFERENT query chunks walk the SAME tiles on the same XCD: the rows cross the fabric once per XCD.
+//
+// Bound (u = 2^-24, Q = |q|^2 + max |x|^2 >= 2 |x||q|, |T| <= Q): bf16 keeps 8 significant bits and rounds to nearest even,
+// |v - v1| <= e |v| with e = 2^-8 (half a unit in the last place, relative to the smallest v of a binade), |v - v1 - v2| <= e^2 |v|.
+// Accumulation of m terms whose partial sums stay below Q / 2 in magnitude: 2u per term, m u Q.  Reference sum ~200 uQ in T units.
+//   NPROD 3: omitted x2.q2 <= e^2 |x||q| = 128 uQ, the two split residuals 256 uQ, 3 D + 1 terms 385 uQ, b_x 8 uQ: 777 uQ;
+//            margin 2^-13 Q = 2048 uQ >= 2 (777 + 200).
+//   NPROD 2: x.q - (x1 + x2).q1 = (x - x1 - x2).q + (x1 + x2).(q - q1) <= 128 uQ + (1 + e^2) max |x| |q - q1| =: 128 uQ + W_q, 2 D + 1 terms
+//            257 uQ, b_x 8 uQ.  W_q is evaluated per query (ft_qlow: the residues of the query's own rounding, Cauchy-Schwarz against
+//            the longest row) instead of its worst case e |x||q| = 32 768 uQ -- a query's residues add up to a third of that:
+//            margin 2^-13 Q + 2 W_q >= 2 (393 uQ + W_q + 200 uQ).
+//   NPROD 1: x.q - x1.q1 = (x - x1).q + x1.(q - q1) <= e (2 + e) |x||q| <= 65 664 uQ, D + 1 terms 129 uQ, b_x 8 uQ: 65 801 uQ;
+//            margin 2^-7 Q + 2^-11 Q = 139 264 uQ >= 2 (65 801 + 200).
+#include <algorithm>
+#include <atomic>
+#include <vector>
+
+#include "common.h"
+#include "flat_f32_common.h"
+#include "kernels.h"
+
+namespace cvtmi {
+
+namespace {
+
+constexpr int FT_WAVES = 8;          // per workgroup: two per SIMD
+constexpr int FT_GRID = 256;         // workgroups: one per CU
+constexpr int FT_SLOTS = 1024;       // sample maxima per query
+constexpr int FT_CAP = 4096;         // candidates per query the finish takes
+constexpr int FT_NBMAX = 16;         // query blocks a workgroup holds
+constexpr int FT_PASS = 1024;        // queries per pass of the pipeline (sizes the record area)
+constexpr int FT_KEEP = 1024;        // rows per query the finish gives exact distances
+constexpr int FT_SLACK = 4096;       // bytes of LDS behind the queries' operands that the operand prefetch may read
+
+struct FtArgs {
+    const uint4 *pack;       // bf16 operand copy of the rows
+    const float *bias;       // b_x per row (padding rows: FS_PAD_BIAS)
+    int64_t t1, n_tiles;     // tiles [0, t1) of n_tiles
+    const float *Q;
+    int nq, chunks, qper;    // queries of chunk c: [c qper, min(nq, (c + 1) qper)), qper a multiple of 32
+    uint32_t *smax;          // MAX mode: [nq][FT_SLOTS] ordered keys (zeroed by the caller)
+    const float *thr;        // FILTER mode: [nq] (NaN: nothing passes)
+    uint4 *rec;              // FILTER mode: [FT_GRID FT_WAVES][cap] records of 5 x 16 bytes
+    uint32_t *wcnt;          // FILTER mode: [FT_GRID FT_WAVES] records a wave had (beyond cap: not stored)
+    uint32_t cap;
+    int dbg;                 // timing experiments ("flat_f32_dbg"): 8 = the filter passes alone (results stale), 16 = the younger waves at priority 1
+};
+
+__device__ __forceinline__ float ft_max3(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float ft_max16(const f32x16 &v)
+{
+    float m = ft_max3(v[0], v[1], v[2]);
+    m = ft_max3(m, v[3], v[4]);
+    m = ft_max3(m, v[5], v[6]);
+    m = ft_max3(m, v[7], v[8]);
+    m = ft_max3(m, v[9], v[10]);
+    m = ft_max3(m, v[11], v[12]);
+    m = ft_max3(m, v[13], v[14]);
+    return fmaxf(m, v[15]);
+}
+
+template <int NCH, int NPROD, int RT, bool MAXMODE>
+__global__ __launch_bounds__(64 * FT_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void flat_f32_tfilter_kernel(const FtArgs a)
+{
+    constexpr int NT = NPROD == 3 ? 2 : 1;    // terms of a query in LDS
+    constexpr int NA = NPROD >= 2 ? 2 : 1;    // terms of a row in registers
+    constexpr int D = 16 * NCH;
+    extern __shared__ __attribute__((aligned(16))) uint8_t ft_q[];   // [block][K step][term] x 1 KB, then the blocks' thresholds
+    const int tid = threadIdx.x, lane = tid & 63, lj = lane & 31, lk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup -> (chunk, slice): the workgroups of one XCD (blockIdx & 7) that hold different chunks share their slices
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int chunk = idx % a.chunks, slices = 8 * ((int)(gridDim.x >> 3) / a.chunks), slice = xcd + 8 * (idx / a.chunks);
+    const int q0 = chunk * a.qper;
+    const int nqc = a.nq - q0 < a.qper ? a.nq - q0 : a.qper;
+    const int wave_g = blockIdx.x * FT_WAVES + wave;
+    if (nqc <= 0) {
+        if (!MAXMODE && lane == 0) a.wcnt[wave_g] = 0u;
+        return;
+    }
+    const int nb = (nqc + 31) >> 5;
+    float *thr_s = reinterpret_cast<float *>(ft_q + (size_t)nb * NCH * NT * 1024 + FT_SLACK);
+    for (int i = tid; i < nb * 32 * NCH * 2; i += 64 * FT_WAVES) {   // (query, K step, half) -> its 16-byte slots of the terms
+        const int hl = i & 1, ss = (i >> 1) % NCH, qq = i / (2 * NCH);
+        const int qi = q0 + (qq < nqc ? qq : nqc - 1);
+        const float *qp = a.Q + (int64_t)qi * D + 16 * ss + 8 * hl;
+        float v[8];
+        *reinterpret_cast<float4 *>(&v[0]) = *reinterpret_cast<const float4 *>(qp);
+        *reinterpret_cast<float4 *>(&v[4]) = *reinterpret_cast<const float4 *>(qp + 4);
+        bf16x8 h, l;
+        fs_split(v, h, l);
+        uint8_t *dst = ft_q + ((size_t)(((qq >> 5) * NCH + ss) * NT) * 1024) + (size_t)(hl * 32 + (qq & 31)) * 16;
+        *reinterpret_cast<bf16x8 *>(dst) = h;
+        if constexpr (NT == 2) *reinterpret_cast<bf16x8 *>(dst + 1024) = l;
+    }
+    if constexpr (!MAXMODE)
+        for (int i = tid; i < nb * 32; i += 64 * FT_WAVES) thr_s[i] = i < nqc ? a.thr[q0 + i] : __uint_as_float(0x7fc00000u);   // NaN: no comparison succeeds
+    __syncthreads();
+    // groups of RT tiles: wave w of slice s takes groups s + slices (w + FT_WAVES i)
+    const int64_t n_groups = (a.t1 + RT - 1) / RT, stride = (int64_t)slices * FT_WAVES;
+    if ((a.dbg & 16) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    const int slot = (slice * (FT_WAVES * 2) + wave * 2 + lk) & (FT_SLOTS - 1);
+    uint32_t wcnt = 0;
+    bf16x8 xa[RT][NCH][NA];
+    f32x16 bias[RT];
+    auto fetch = [&](int64_t g) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int64_t t = g * RT + r;
+            const int64_t tc = t < a.t1 ? t : a.t1 - 1;
+            const uint4 *tp = a.pack + (tc * NCH * 2) * 64 + lane;
+#pragma unroll
+            for (int s_ = 0; s_ < NCH; ++s_)
+#pragma unroll
+                for (int x = 0; x < NA; ++x) {
+                    const uint4 w = tp[(s_ * 2 + x) * 64];
+                    xa[r][s_][x] = __builtin_bit_cast(bf16x8, w);
+                }
+            // the biases of the 16 rows a lane's accumulators stand for: row (e & 3) + 8 (e >> 2) + 4 lk of the tile
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 bb = *reinterpret_cast<const float4 *>(a.bias + tc * 32 + 8 * g4 + 4 * lk);
+                if (t >= a.t1) bb = make_float4(FS_PAD_BIAS, FS_PAD_BIAS, FS_PAD_BIAS, FS_PAD_BIAS);
+                bias[r][4 * g4] = bb.x; bias[r][4 * g4 + 1] = bb.y; bias[r][4 * g4 + 2] = bb.z; bias[r][4 * g4 + 3] = bb.w;
+            }
+        }
+    };
+    for (int64_t g = slice + (int64_t)slices * wave; g < n_groups; g += stride) {
+        fetch(g);
+        // the queries' operands are one linear stream over (block, K step) in LDS; they are requested two K steps ahead of the
+        // matrix instructions that use them, across the block boundary (left to itself the compiler reads a K step's operands, waits,
+        // multiplies: an LDS round trip in front of every six matrix instructions)
+        bf16x8 bq[4][NT];
+        auto request = [&](int j, int set) __attribute__((always_inline)) {
+            const uint8_t *p_ = ft_q + (size_t)j * (NT * 1024) + lane * 16;
+#pragma unroll
+            for (int x = 0; x < NT; ++x) bq[set][x] = *reinterpret_cast<const bf16x8 *>(p_ + x * 1024);
+        };
+        request(0, 0);
+        request(1, 1);
+#pragma unroll 1
+        for (int b = 0; b < nb; ++b) {
+            f32x16 acc[RT];
+#pragma unroll
+            for (int s_ = 0; s_ < NCH; ++s_) {
+                request(b * NCH + s_ + 2, (s_ + 2) & 3);   // (the last two of a group read the slack behind the operands: unused)
+                __builtin_amdgcn_sched_barrier(0);         // (the scheduler would sink the request down to its first use)
+                const bf16x8 qh = bq[s_ & 3][0];
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[r][s_][0], qh, s_ == 0 ? bias[r] : acc[r], 0, 0, 0);   // b_x rides in as SrcC
+                if constexpr (NPROD >= 2) {
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[r][s_][1], qh, acc[r], 0, 0, 0);
+                }
+                if constexpr (NPROD == 3) {
+                    const bf16x8 ql = bq[s_ & 3][1];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[r][s_][0], ql, acc[r], 0, 0, 0);
+                }
+            }
+            // the maxima below are inline assembly: the compiler's hazard recogniser does not put the wait states between a matrix
+            // instruction's result and a vector instruction that reads it in front of those (measured: rows lost), so they are spelled out
+            static_assert(RT >= 2 && RT <= 4, "operand lists below");
+            if constexpr (RT == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));
+            if constexpr (RT == 3) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
+            if constexpr (RT == 4) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+            const int qq = 32 * b + lj;
+            if constexpr (MAXMODE) {
+                float m = ft_max16(acc[0]);
+#pragma unroll
+                for (int r = 1; r < RT; ++r) m = fmaxf(m, ft_max16(acc[r]));
+                if (qq < nqc && m > FS_EMPTY) atomicMax(&a.smax[(size_t)(q0 + qq) * FT_SLOTS + slot], f32_key(m));
+            } else {
+                const float tb = thr_s[qq];
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    const bool hit = ft_max16(acc[r]) >= tb;
+                    const unsigned long long hm = __ballot(hit);
+                    if (hm) {   // some row of the tile reaches some query's threshold: the lanes concerned write their 16 scores
+                        const uint32_t pos = wcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                        wcnt += (uint32_t)__popcll(hm);
+                        if (hit && pos < a.cap) {
+                            uint4 *dst = a.rec + ((size_t)wave_g * a.cap + pos) * 5;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                dst[j] = make_uint4(__float_as_uint(acc[r][4 * j]), __float_as_uint(acc[r][4 * j + 1]), __float_as_uint(acc[r][4 * j + 2]),
+                                                    __float_as_uint(acc[r][4 * j + 3]));
+                            dst[4] = make_uint4((uint32_t)(q0 + qq), (uint32_t)((g * RT + r) * 32 + 4 * lk), 0u, 0u);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (!MAXMODE)
+        if (lane == 0) a.wcnt[wave_g] = wcnt;
+}
+
+// margin of a query: Qb = (|q|^2 + max |x|^2) 1.001, xq2 = sqrt(max |x|^2) |q - q1| 1.01 (Cauchy-Schwarz on the omitted low term of
+// the query: the worst case e |x||q| is two to three times larger than what a query's own rounding residues add up to)
+template <bool IP>
+__device__ __forceinline__ float ft_margin(float Qb, float xq2, float theta, int nprod)
+{
+    float m = nprod == 3 ? Qb * 0x1p-13f : (nprod == 2 ? Qb * 0x1p-13f + 2.0f * xq2 : Qb * (0x1p-7f + 0x1p-11f));
+    if (IP) m += (2.0f + fabsf(theta)) * 0x1p-20f;   // the rounding of 1 - sum in the reference
+    return m;
+}
+// |q - q1|^2 by one wave, q1 = the bf16 operand of fs_split (the same conversion, value for value)
+__device__ __forceinline__ float ft_qlow(const float *q, int D)
+{
+    float s_ = 0.0f;
+    for (int e0 = 8 * (threadIdx.x & 63); e0 < D; e0 += 512) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = q[e0 + e];
+        bf16x8 h, l;
+        fs_split(v, h, l);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float r = v[e] - (float)h[e];   // exact (Sterbenz-like: q1 is q rounded to 8 bits)
+            s_ = __fmaf_rn(r, r, s_);
+        }
+    }
+    return fs_wave_sum(s_);
+}
+
+// one wave per query: theta = the k-th largest of its sample maxima, thr = theta - margin (NaN + redo when the bound does not hold)
+template <bool IP>
+__global__ __launch_bounds__(256) void ft_theta_kernel(const uint32_t *__restrict__ smax, const float *__restrict__ Q, int nq, int D, int k, int nprod,
+                                                       const uint32_t *__restrict__ stats, float *__restrict__ thr, float *__restrict__ qbnd,
+                                                       uint32_t *__restrict__ redo)
+{
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    uint32_t key[FT_SLOTS / 64];
+#pragma unroll
+    for (int j = 0; j < FT_SLOTS / 64; ++j) key[j] = smax[(size_t)q * FT_SLOTS + j * 64 + lane];
+    const float qq = fs_qnorm(Q + (int64_t)q * D, D);
+    const float Qb = (qq + __uint_as_float(stats[0])) * 1.001f;
+    const float xq2 = sqrtf(__uint_as_float(stats[0]) * ft_qlow(Q + (int64_t)q * D, D)) * 1.01f;
+    float cut = __uint_as_float(0x7fc00000u);
+    if (Qb > 0x1p-60f && Qb < 0x1p60f) {
+        const uint32_t sel = fs_wave_select(key, k, k + k / 4 + 8);
+        if (sel != 0u) {   // at least k slots hold a row
+            const float theta = key_f32(sel);
+            cut = theta - ft_margin<IP>(Qb, xq2, theta, nprod);
+        }
+    }
+    if (lane == 0) {
+        thr[q] = cut;
+        qbnd[q] = Qb;
+        qbnd[nq + q] = xq2;
+        if (!(cut == cut)) redo[q] = 1u;
+    }
+}
+
+// Records -> per-query candidate lists.  One workgroup per workgroup of the filter (its eight wave regions: one query chunk), two
+// passes over the records: (A) the scores at or above their query's threshold are counted per query in LDS, ONE global atomic per
+// query with hits then reserves that many places of the query's list (an atomic per candidate measured 0.29 ms per million:
+// returning device-scope atomics run at ~3.5 G/s whatever their addresses), (B) the hits are written behind the reserved base.
+constexpr int FT_BUCKET_T = 1024;
+__global__ __launch_bounds__(FT_BUCKET_T) void ft_bucket_kernel(const uint4 *__restrict__ rec, const uint32_t *__restrict__ wcnt, uint32_t cap,
+                                                                const float *__restrict__ thr, uint32_t *__restrict__ cnt, uint2 *__restrict__ cand,
+                                                                int chunks, int qper, int nq, uint32_t *__restrict__ redo)
+{
+    __shared__ uint32_t hist[32 * FT_NBMAX], base_s[32 * FT_NBMAX];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int chunk = (j >> 3) % chunks, q0 = chunk * qper;
+    const int nqc = nq - q0 < qper ? nq - q0 : qper;
+    if (nqc <= 0) return;
+    for (int i = tid; i < nqc; i += FT_BUCKET_T) hist[i] = 0u;
+    const int r = tid >> 7, t = tid & 127;   // 128 threads per wave region
+    uint32_t n = wcnt[j * FT_WAVES + r];
+    if (n > cap) {   // the region ran full: the exact kernels answer the queries its workgroup held
+        for (int i = t; i < nqc; i += 128) redo[q0 + i] = 1u;
+        n = cap;
+    }
+    const uint4 *rp = rec + (size_t)(j * FT_WAVES + r) * cap * 5;
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 128) {
+        const uint4 h = rp[(size_t)i * 5 + 4];
+        const float tb = thr[h.x];
+        uint32_t c = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const uint4 s4 = rp[(size_t)i * 5 + jj];
+            c += (__uint_as_float(s4.x) >= tb ? 1u : 0u) + (__uint_as_float(s4.y) >= tb ? 1u : 0u) + (__uint_as_float(s4.z) >= tb ? 1u : 0u) +
+                 (__uint_as_float(s4.w) >= tb ? 1u : 0u);
+        }
+        if (c) atomicAdd(&hist[h.x - (uint32_t)q0], c);
+    }
+    __syncthreads();
+    for (int i = tid; i < nqc; i += FT_BUCKET_T) {
+        const uint32_t c = hist[i];
+        base_s[i] = c ? atomicAdd(&cnt[q0 + i], c) : 0u;
+        hist[i] = 0u;
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 128) {
+        const uint4 h = rp[(size_t)i * 5 + 4];
+        const float tb = thr[h.x];
+        const uint32_t ql = h.x - (uint32_t)q0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const uint4 s4 = rp[(size_t)i * 5 + jj];
+            const uint32_t sv[4] = { s4.x, s4.y, s4.z, s4.w };
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (__uint_as_float(sv[e]) >= tb) {
+                    const uint32_t pos = base_s[ql] + atomicAdd(&hist[ql], 1u);
+                    if (pos < (uint32_t)FT_CAP) cand[(size_t)h.x * FT_CAP + pos] = make_uint2(sv[e], h.y + (uint32_t)(e + 8 * jj));
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t ft_dist_key(float d)
+{
+    const uint32_t dk = f32_key(d);
+    return dk >= 0xfffffff0u ? 0xffffffefu : dk;   // (NaN patterns: keep the absent-row codes free)
+}
+
+// one workgroup per query.  The candidates carry their matrix-core scores: the k-th largest of them (k distinct rows reach it) is
+// theta, found by a radix select over the keys (8 bits a round, counted in LDS); only the candidates at or above theta - margin --
+// k and a few, not the 1-2 k the sample's threshold let through -- get exact reference-order distances (32 pieces 1 KB apart per
+// row in the blocked layout) and are ranked by (distance, row) by counting.
+template <bool IP, int LANES>
+__global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict__ X, int64_t n, int D, const float *__restrict__ Q, int k, int nprod,
+                                                        const float *__restrict__ thr, const float *__restrict__ qbnd, const uint32_t *__restrict__ cnt,
+                                                        const uint2 *__restrict__ cand, float *__restrict__ out_d, int64_t *__restrict__ out_i,
+                                                        uint32_t *__restrict__ redo)
+{
+    __shared__ unsigned long long sel[FT_KEEP];
+    __shared__ __attribute__((aligned(16))) float q_s[256];
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t pick_s[2];
+    __shared__ int m2_s;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const float cut = thr[q];
+    const uint32_t nc = cnt[q];
+    const int64_t want = k < n ? k : n;
+    if (redo[q] != 0u) return;
+    if (!(cut == cut) || nc > (uint32_t)FT_CAP || (int64_t)nc < want) {   // workgroup-uniform: the exact kernels answer this query
+        if (tid == 0) redo[q] = 1u;
+        return;
+    }
+    if (tid < D) q_s[tid] = Q[(int64_t)q * D + tid];
+    if (tid == 0) m2_s = 0;
+    constexpr int PER = FT_CAP / 256;
+    uint32_t key[PER], row[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t i = (uint32_t)(tid + j * 256);
+        key[j] = 0u; row[j] = 0u;
+        if (i < nc) {
+            const uint2 c = cand[(size_t)q * FT_CAP + i];
+            key[j] = f32_key(__uint_as_float(c.x));
+            key[j] = key[j] == 0u ? 1u : key[j];
+            row[j] = c.y;
+        }
+    }
+    // radix select of the want-th largest key: prefix / mask grow by 8 bits a round
+    uint32_t prefix = 0u, mask = 0u, remaining = (uint32_t)want;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (key[j] != 0u && (key[j] & mask) == prefix) atomicAdd(&hist[(key[j] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (tid < 64) {   // bins 4 lane .. 4 lane + 3; suffix sums from the top bin down
+            const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const uint32_t mine = h0 + h1 + h2 + h3;
+            uint32_t above = mine;   // inclusive suffix sum over lanes >= this one
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_down((int)above, o, 64);
+                if (lane + o < 64) above += v;
+            }
+            const uint32_t excl = above - mine;   // keys in bins above this lane's four
+            if (excl < remaining && remaining <= above) {   // exactly one lane
+                uint32_t acc_ = excl, bin = 0u;
+                const uint32_t hh[4] = { h0, h1, h2, h3 };
+#pragma unroll
+                for (int b = 3; b >= 0; --b) {
+                    if (acc_ < remaining && remaining <= acc_ + hh[b]) { bin = (uint32_t)(4 * lane + b); pick_s[1] = remaining - acc_; }
+                    acc_ += hh[b];
+                }
+                pick_s[0] = bin;
+            }
+        }
+        __syncthreads();
+        prefix |= pick_s[0] << shift;
+        mask |= 255u << shift;
+        remaining = pick_s[1];
+        __syncthreads();
+    }
+    const float theta = key_f32(prefix);
+    const float cut2 = theta - ft_margin<IP>(qbnd[q], qbnd[gridDim.x + q], theta, nprod);
+    const uint32_t cut2_key = f32_key(cut2);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        if (key[j] != 0u && key[j] >= cut2_key) {
+            const int pos = atomicAdd(&m2_s, 1);
+            if (pos < FT_KEEP) sel[pos] = row[j];
+        }
+    }
+    __syncthreads();
+    const int m2 = m2_s;
+    if (m2 > FT_KEEP) {   // masses of near ties
+        if (tid == 0) redo[q] = 1u;
+        return;
+    }
+    unsigned long long mine[FT_KEEP / 256];
+#pragma unroll
+    for (int j = 0; j < FT_KEEP / 256; ++j) {
+        const int i = tid + j * 256;
+        mine[j] = ~0ull;
+        if (i < m2) {
+            const uint32_t r = (uint32_t)sel[i];
+            if ((int64_t)r < n) mine[j] = ((unsigned long long)ft_dist_key(fs_exact<IP, LANES>(X, D, r, reinterpret_cast<const float4 *>(q_s))) << 32) | r;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < FT_KEEP / 256; ++j)
+        if (tid + j * 256 < m2) sel[tid + j * 256] = mine[j];
+    __syncthreads();
+    // rank by counting: the keys are distinct (the row is part of them)
+#pragma unroll
+    for (int j = 0; j < FT_KEEP / 256; ++j) {
+        if (tid + j * 256 < m2 && mine[j] != ~0ull) {
+            int rank = 0;
+            for (int i = 0; i < m2; ++i) rank += sel[i] < mine[j] ? 1 : 0;
+            if (rank < k) {
+                out_d[(int64_t)q * k + rank] = key_f32((uint32_t)(mine[j] >> 32));
+                out_i[(int64_t)q * k + rank] = (int64_t)(uint32_t)mine[j];
+            }
+        }
+    }
+    for (int i = (int)want + tid; i < k; i += 256) {   // fewer rows than k
+        out_d[(int64_t)q * k + i] = __uint_as_float(0x7f800000u);
+        out_i[(int64_t)q * k + i] = -1;
+    }
+}
+
+}  // namespace
+
+// ---- host side ----
+static std::atomic<int> g_ft_on{2};        // cvtmi_set_tuning("flat_f32_tfilter"): 0 = the stream kernels for every batch, 1 .. 3 = products
+static std::atomic<int> g_ft_min_nq{129};  // cvtmi_set_tuning("flat_f32_tfilter_min"): smallest batch that takes the pipeline
+void set_flat_f32_tfilter(int v) { g_ft_on = v < 0 ? 0 : (v > 3 ? 3 : v); }
+void set_flat_f32_tfilter_min(int v) { g_ft_min_nq = v < 1 ? 1 : v; }
+bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k)
+{
+    return g_ft_on.load() && (metric == CVTMI_METRIC_IP || metric == CVTMI_METRIC_L2F) && (D == 64 || D == 128) && n >= 262144 && n < 0xffffffe0LL &&
+           nq >= g_ft_min_nq.load() && k >= 1 && k <= 128;
+}
+static uint32_t ft_rec_cap(int64_t m) { return (uint32_t)std::min<int64_t>(3072, std::max<int64_t>(256, 3 * m)); }
+size_t flat_f32_tfilter_scratch(int64_t nq)
+{
+    const int64_t m = std::min<int64_t>(nq, FT_PASS);
+    return (size_t)m * (FT_SLOTS + 6) * sizeof(uint32_t) + (size_t)m * FT_CAP * sizeof(uint2) + (size_t)FT_GRID * FT_WAVES * (sizeof(uint32_t) + (size_t)ft_rec_cap(m) * 80) + 1024;
+}
+
+template <int NCH, int NPROD, int RT>
+static int ft_launch(bool maxmode, const FtArgs &a, size_t lds, hipStream_t st)
+{
+    static std::atomic<bool> attr_a[16] = {}, attr_b[16] = {};
+    if (maxmode) {
+        CVTMI_TRY(fs_set_lds((const void *)flat_f32_tfilter_kernel<NCH, NPROD, RT, true>, 163840, attr_a));
+        hipLaunchKernelGGL((flat_f32_tfilter_kernel<NCH, NPROD, RT, true>), dim3(FT_GRID), dim3(64 * FT_WAVES), lds, st, a);
+    } else {
+        CVTMI_TRY(fs_set_lds((const void *)flat_f32_tfilter_kernel<NCH, NPROD, RT, false>, 163840, attr_b));
+        hipLaunchKernelGGL((flat_f32_tfilter_kernel<NCH, NPROD, RT, false>), dim3(FT_GRID), dim3(64 * FT_WAVES), lds, st, a);
+    }
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+static int ft_launch_any(int D, int nprod, bool maxmode, const FtArgs &a, size_t lds, hipStream_t st)
+{
+    if (D == 128) {
+        if (nprod == 3) return ft_launch<8, 3, 2>(maxmode, a, lds, st);
+        if (nprod == 2) return ft_launch<8, 2, 2>(maxmode, a, lds, st);
+        return ft_launch<8, 1, 3>(maxmode, a, lds, st);
+    }
+    if (nprod == 3) return ft_launch<4, 3, 3>(maxmode, a, lds, st);
+    if (nprod == 2) return ft_launch<4, 2, 3>(maxmode, a, lds, st);
+    return ft_launch<4, 1, 4>(maxmode, a, lds, st);
+}
+
+// nq queries against rows [0, n); results for the queries whose redo flag stays 0 (redo[nq] is zeroed here)
+int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack, const float *bias, const uint32_t *stats, int64_t n, const float *q,
+                            int64_t nq, int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, hipStream_t st)
+{
+    if (!flat_f32_tfilter_applies(metric, D, n, nq, k)) return fail(CVTMI_EINVAL, "flat_f32_tfilter: D=%d nq=%lld", D, (long long)nq);
+    const int nprod = g_ft_on.load();
+    const int nt = nprod == 3 ? 2 : 1;
+    const int qcap = std::min(32 * FT_NBMAX, (int)((size_t)(160 * 1024 - 32 * FT_NBMAX * 4 - FT_SLACK) / ((size_t)(D / 16) * nt * 1024)) * 32);   // queries a workgroup holds
+    CVTMI_HIP(hipMemsetAsync(redo, 0, (size_t)nq * sizeof(uint32_t), st));
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t ts = std::min<int64_t>(n_tiles, std::max<int64_t>(2048, n_tiles / 8));   // the sample: an eighth of the rows, at least 65 536
+    for (int64_t a0 = 0; a0 < nq; a0 += FT_PASS) {
+        const int64_t m = std::min<int64_t>(nq - a0, FT_PASS);
+        int chunks = 1;
+        while (chunks < 32 && (m + chunks - 1) / chunks > qcap) chunks *= 2;
+        const int qper = (int)(((m + chunks - 1) / chunks + 31) / 32 * 32);
+        const uint32_t cap = ft_rec_cap(m);
+        uint32_t *smax = reinterpret_cast<uint32_t *>(scratch);
+        float *thr = reinterpret_cast<float *>(smax + (size_t)m * FT_SLOTS);
+        float *qbnd = thr + m;
+        uint32_t *cnt = reinterpret_cast<uint32_t *>(qbnd + 2 * m);
+        uint32_t *wcnt = cnt + m + (m & 1);
+        uint2 *cand = reinterpret_cast<uint2 *>(wcnt + FT_GRID * FT_WAVES);
+        uint4 *rec = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(cand + (size_t)m * FT_CAP) + 256 - (((uintptr_t)(cand + (size_t)m * FT_CAP)) & 15));
+        CVTMI_HIP(hipMemsetAsync(smax, 0, (size_t)m * FT_SLOTS * sizeof(uint32_t), st));
+        CVTMI_HIP(hipMemsetAsync(cnt, 0, (size_t)m * sizeof(uint32_t), st));
+        FtArgs a;
+        a.pack = reinterpret_cast<const uint4 *>(pack); a.bias = bias; a.n_tiles = n_tiles; a.Q = q + a0 * D; a.nq = (int)m; a.chunks = chunks; a.qper = qper;
+        a.smax = smax; a.thr = thr; a.rec = rec; a.wcnt = wcnt; a.cap = cap; a.dbg = get_flat_f32_dbg();
+        const size_t lds = (size_t)(qper / 32) * (D / 16) * nt * 1024 + FT_SLACK + (size_t)qper * sizeof(float);
+        a.t1 = ts;
+        CVTMI_TRY(ft_launch_any(D, nprod, true, a, lds, st));
+        const unsigned tg = (unsigned)((m + 3) / 4);
+        if (metric == CVTMI_METRIC_IP) hipLaunchKernelGGL((ft_theta_kernel<true>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, thr, qbnd, redo + a0);
+        else hipLaunchKernelGGL((ft_theta_kernel<false>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, thr, qbnd, redo + a0);
+        a.t1 = n_tiles;
+        CVTMI_TRY(ft_launch_any(D, nprod, false, a, lds, st));
+        if (a.dbg & 8) continue;   // timing experiments: the filter passes alone (results stale)
+        hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), 0, st, rec, wcnt, cap, thr, cnt, cand, chunks, qper, (int)m, redo + a0);
+        if (metric == CVTMI_METRIC_IP)
+            hipLaunchKernelGGL((ft_finish_kernel<true, 4>), dim3((unsigned)m), dim3(256), 0, st, X, n, D, a.Q, k, nprod, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0);
+        else
+            hipLaunchKernelGGL((ft_finish_kernel<false, 8>), dim3((unsigned)m), dim3(256), 0, st, X, n, D, a.Q, k, nprod, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0);
+        CVTMI_HIP(hipGetLastError());
+        if (getenv("CVTMI_FT_DEBUG")) {   // counts of the pass (synchronises)
+            CVTMI_HIP(hipStreamSynchronize(st));
+            std::vector<uint32_t> hc(m), hw(FT_GRID * FT_WAVES), hr(m);
+            std::vector<float> ht(m);
+            CVTMI_HIP(hipMemcpy(hc.data(), cnt, m * 4, hipMemcpyDeviceToHost));
+            CVTMI_HIP(hipMemcpy(hw.data(), wcnt, hw.size() * 4, hipMemcpyDeviceToHost));
+            CVTMI_HIP(hipMemcpy(hr.data(), redo + a0, m * 4, hipMemcpyDeviceToHost));
+            CVTMI_HIP(hipMemcpy(ht.data(), thr, m * 4, hipMemcpyDeviceToHost));
+            double sc = 0, sw = 0; uint32_t mc = 0, mw = 0, nr = 0;
+            for (auto v : hc) { sc += v; mc = std::max(mc, v); }
+            for (auto v : hw) { sw += v; mw = std::max(mw, v); }
+            for (auto v : hr) nr += v != 0;
+            fprintf(stderr, "ft debug: nprod %d m %lld chunks %d qper %d cap %u: candidates mean %.0f max %u; records total %.0f per wave max %u; redo %u; thr[0] %g\n",
+                    nprod, (long long)m, chunks, qper, cap, sc / m, mc, sw, mw, nr, ht[0]);
+        }
+    }
+    return CVTMI_OK;
+}
+
+}  // namespace cvtmi

@@ -211,10 +211,20 @@ int launch_flat_block(const float *src, int64_t n, int D, int64_t row0, float *d
 // exact distances of the candidates); D % 16 == 0, 16 <= D <= 256, up to flat_f32_stream_qmax(D) queries per pass
 int flat_f32_stream_qmax(int D);
 int flat_f32_stream_private_max(int D);   // queries per pass of the private-ring kernel
+int get_flat_f32_dbg();
 void set_flat_f32_dbg(int v);     // timing experiments, results wrong when non-zero
 void set_flat_f32_share(int v);   // shared-ring kernel: 0 choose, 1 four waves x 32 QB queries, 2 eight waves x 32 queries
 void set_flat_f32_nt(int v);     // 0 = never, 1 = choose (default), 2 = always: non-temporal hint on the stream kernels' row loads
 bool flat_f32_stream_applies(int metric, int D, int64_t n, int k);
+// round 6 (flat_f32_tfilter.hip): large batches (D = 64 / 128, >= 262 144 rows, k <= 128) as a threshold filter: queries in LDS, the rows'
+// bf16 operand copy (launch_flat_pack) in registers, per-query thresholds from sample maxima, candidate lists, exact finish;
+// redo[nq] (zeroed inside): 1 = the exact kernels must answer the query
+bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k);
+size_t flat_f32_tfilter_scratch(int64_t nq);
+int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack, const float *bias, const uint32_t *stats, int64_t n, const float *q,
+                            int64_t nq, int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, hipStream_t st);
+void set_flat_f32_tfilter(int v);
+void set_flat_f32_tfilter_min(int v);
 size_t flat_f32_stream_scratch(int D, int64_t n, int64_t nq_pass);
 // bias[r] (and zeroed padding rows) for rows [row0, row1); stats[0] = max |x|^2 bits, stats[1] = non-finite rows (both accumulate)
 int launch_flat_f32_bias(float *X, int D, int metric, int64_t row0, int64_t row1, float *bias, uint32_t *stats, hipStream_t st);

@@ -147,6 +147,13 @@ int cvtmi_set_device(int device);
  *   "scanh_balance" / "scanh_min_rows" / "scanh_tail" / "scanh_fix" / "scanh_share_hist"  planner of the persistent-grid scan (variant
  *                     6): 0 choose / 1 equal row-time shares / 2 row blocks; smallest row segment; two-region tail on / off; an item's
  *                     fixed cost in row-equivalents (160 000); one candidate histogram per query shared by its segments (1) or not
+ *   "flat_f32_tfilter" fp32 searches (64 / 128-d, >= 262 144 rows, k <= 128) of "flat_f32_tfilter_min" (default 129) queries or more run as a
+ *                     threshold filter (round 6, flat_f32_tfilter.hip): sample maxima -> per-query threshold -> queries in LDS, the rows'
+ *                     bf16 operand copy in registers, no barrier, hits recorded -> per-query lists -> exact distances.  The value is
+ *                     the number of bf16 products per term: 2 (default: (x1 + x2).q1, the margin follows each query's own rounding
+ *                     residue), 3 (x1.q1 + x2.q1 + x1.q2, the stream kernels' margin), 1 (x1.q1, worst-case margin: for
+ *                     measurements); 0 = the stream kernels for every batch.  1 M x 128-d, top-100: 1000 queries 0.97 -> 0.69 ms
+ *   "flat_f32_tfilter_min"  smallest batch that takes that pipeline
  *   "flat_f32_share"  fp32 stream, batches beyond one wave's queries: 0 choose, 1 private rings only, 2 the shared-ring kernel,
  *                     3 = the shared ring with eight waves of 64 queries (512 queries per pass over the rows instead of 384; round 6,
  *                     measured: 385 .. 512 queries 0.74 -> 0.51 ms on 1 M x 128-d, 1000 queries unchanged -- its registers spill)
@@ -281,8 +288,9 @@ int64_t cvtmi_opq_scan_plan(int64_t n_rows, int64_t nq, int splits, int cus, int
  * (M < 16), else 0.  What tests/test_scan_plan.py pins the dispatch rules of round 5 with. */
 int cvtmi_opq_describe_dispatch(int D, int M, int K, int64_t n_rows, int64_t nq, int k, int out[7]);
 
-/* The same for a flat search (metric: CVTMI_METRIC_*; pure host logic): out[0] = the fp32 one-stream kernels, out[1] = the fp32 sample +
- * matrix-core filter pipeline is eligible behind them, out[2] = the uint8 sample + filter pipeline, out[3] = uint8 streaming passes of up
+/* The same for a flat search (metric: CVTMI_METRIC_*; pure host logic): out[0] = 1 the fp32 one-stream kernels / 2 the fp32 threshold filter
+ * (round 6: 64 / 128-d, >= 262 144 rows, batches from "flat_f32_tfilter_min" queries on), out[1] = the fp32 sample + matrix-core filter
+ * pipeline is eligible behind them, out[2] = the uint8 sample + filter pipeline, out[3] = uint8 streaming passes of up
  * to 128 queries; all zero: the exact / row-tile kernels. */
 int cvtmi_flat_describe_dispatch(int metric, int D, int64_t n_rows, int64_t nq, int k, int out[4]);
 

@@ -922,6 +922,81 @@ def test_flat_f32_stream_shared_ring_variants(amd, share):
         amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_share", 0)
 
 
+@pytest.mark.parametrize("metric,D,k,prods", [(L2F, 128, 100, 2), (IP, 128, 100, 2), (L2F, 64, 10, 2), (IP, 64, 128, 2), (L2F, 128, 1, 3), (IP, 128, 37, 3),
+                                               (L2F, 128, 100, 1), (IP, 64, 100, 1), (L2F, 64, 64, 3)])
+def test_flat_f32_threshold_filter(amd, orc, metric, D, k, prods):
+    """large fp32 batches as a threshold filter (round 6, flat_f32_tfilter.hip: sample maxima -> per-query threshold -> queries in
+    LDS, the rows' bf16 operand copy in registers, records of 16 scores per hit -> per-query lists -> radix select, exact distances)
+    with 1 / 2 / 3 bf16 products, against the exact kernels (flat_variant 1) on every query and the checker on a few: ragged row
+    count, batch sizes around the query-block, workgroup-chunk and pass boundaries, duplicated rows (ties by row number, more of them
+    than k), queries that are rows, rows appended between searches (the operand copy is rebuilt)"""
+    rng = np.random.default_rng(D * 7 + k * 3 + metric + prods)
+    n = 262_144 + 8_000 + 37
+    x = _clustered(rng, n, D, metric)
+    x[200_000:200_150] = x[5]
+    x[77] = x[5]
+    x[n - 1] = x[123]
+    try:
+        amd.set_tuning("flat_f32_tfilter", prods)
+        ix = amd.FlatIndex(metric, D); ix.add(x[:n - 5_000])
+        out = {}
+        for nq in (129, 160, 513, 1030):
+            q = (x[rng.integers(0, n - 5_000, nq)] + 0.05 * rng.normal(size=(nq, D))).astype(np.float32)
+            q[0] = x[5]; q[3] = x[123]
+            q = np.ascontiguousarray(q, np.float32)
+            ds, is_ = ix.search(q, k)
+            assert ix.last_search()[0] == 3, nq
+            out[nq] = (q, ds, is_)
+        ix.add(x[n - 5_000:])                   # append after searches
+        q160 = out[160][0]
+        ds2, is2 = ix.search(q160, k)
+        assert ix.last_search()[0] == 3
+        amd.set_tuning("flat_variant", 1)
+        de2, ie2 = ix.search(q160, k)
+        assert ix.last_search()[0] == 0
+        ix.close()
+        ix = amd.FlatIndex(metric, D); ix.add(x[:n - 5_000])
+        for nq, (q, ds, is_) in out.items():
+            de, ie = ix.search(q, k)
+            assert np.array_equal(is_, ie) and np.array_equal(bits(ds), bits(de)), nq
+        ix.close()
+    finally:
+        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_tfilter", 2)
+    assert np.array_equal(is2, ie2) and np.array_equal(bits(ds2), bits(de2))
+    od, _, oi = orc.flat_search(metric, x, q160[:4], k, flavour=4 if metric == IP else 8)
+    assert np.array_equal(is2[:4], oi) and np.array_equal(bits(ds2[:4]), bits(od))
+
+
+def test_flat_f32_threshold_filter_hands_hard_queries_to_the_exact_kernels(amd):
+    """what the filter's bound does not cover is re-run by the exact kernels inside the same call, per query: non-finite queries, a
+    query 2^70 times larger than the rows, masses of exact ties around the k-th place (more rows at the threshold than a list
+    holds), a zero query; a non-finite ROW sends the whole index to the other paths; a small batch forced through the pipeline
+    ("flat_f32_tfilter_min").  Same results as flat_variant 1 everywhere, labels included"""
+    rng = np.random.default_rng(6)
+    n, D, nq, k = 270_000, 128, 150, 10
+    x = rng.normal(size=(n, D)).astype(np.float32)
+    x[2_000:8_000] = x[1]                                   # 6000 equal rows: every one ties at the k-th place of query 1
+    q = rng.normal(size=(nq, D)).astype(np.float32)
+    q[1] = x[1]
+    q[3, 0] = np.nan; q[4, 5] = np.inf; q[6] *= np.float32(2.0 ** 70); q[7] = 0
+    labels = np.arange(n, dtype=np.int64) * 3 + 5
+    xn = x.copy(); xn[265_000, 7] = np.inf
+    try:
+        for name, xx, lab, qq in (("ties", x, None, q), ("labels", x, labels, q), ("inf row", xn, None, q), ("five queries", x, None, q[:5])):
+            out = {}
+            for v in (0, 1):
+                amd.set_tuning("flat_variant", v); amd.set_tuning("flat_f32_tfilter_min", 1 if name == "five queries" else 129)
+                ix = amd.FlatIndex(L2F, D); ix.add(xx, labels=lab)
+                out[v] = ix.search(qq, k)
+                if v == 0:
+                    assert ix.last_search()[0] == (3 if name != "inf row" else 0), name
+                ix.close()
+            assert np.array_equal(out[0][1], out[1][1]), name
+            assert np.array_equal(bits(out[0][0]), bits(out[1][0])), name
+    finally:
+        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_tfilter_min", 129)
+
+
 @pytest.mark.parametrize("d,n", [(512, 20_000), (256, 17_001), (128, 40_000), (100, 16_385), (516, 16_400), (4, 70_000)])
 def test_sq8_decode_through_table(amd, orc, d, n):
     """>= 16384 rows decode through the per-column tables in LDS (sq8_decode_lut_kernel): every byte value of every column,
