@@ -474,6 +474,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "flat_f32_dbg")) { set_flat_f32_dbg((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter")) { set_flat_f32_tfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_min")) { set_flat_f32_tfilter_min((int)value); return CVTMI_OK; }
+    if (!strcmp(name, "flat_f32_tfilter_one")) { set_flat_f32_tfilter_one((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_share")) {
         if (value < 0 || value > 3) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_f32_share must be 0 .. 3");
         set_flat_f32_share((int)value);
@@ -1838,7 +1839,7 @@ static int flat_search_streamed(cvtmi_flat_t h, FlatScratch &S, const float *q, 
         // LDS, the rows' bf16 operand copy in registers) -> exact distances of the candidates; flagged queries go through the exact
         // kernels below, as for the stream
         CVTMI_TRY(S.fs_redo.reserve((size_t)nq * 2 * sizeof(uint32_t)));
-        CVTMI_TRY(launch_flat_f32_tfilter(h->metric, D, h->data.as<float>(), h->f_pack.p, h->fs_bias.as<float>(), h->fs_stats.as<uint32_t>(), n, q, nq, k,
+        CVTMI_TRY(launch_flat_f32_tfilter(h->metric, D, h->data.as<float>(), h->f_pack.p, h->f_istats.as<uint32_t>(), h->fs_bias.as<float>(), h->fs_stats.as<uint32_t>(), n, q, nq, k,
                                           S.fs_scratch.p, dist, rows, S.fs_redo.as<uint32_t>(), st));
         CVTMI_TRY(flat_search_rows(h, S, n, q, nq, k, dist, rows, st, INT64_MAX, S.fs_redo.as<uint32_t>()));
         *done = true;

@@ -58,7 +58,7 @@ constexpr int FT_CAP = 4096;         // candidates per query the finish takes
 constexpr int FT_NBMAX = 16;         // query blocks a workgroup holds
 constexpr int FT_PASS = 1024;        // queries per pass of the pipeline (sizes the record area)
 constexpr int FT_KEEP = 1024;        // rows per query the finish gives exact distances
-constexpr int FT_SLACK = 4096;       // bytes of LDS behind the queries' operands that the operand prefetch may read
+constexpr int FT_SLACK = 0;          // bytes of LDS kept free behind the queries' operands
 
 struct FtArgs {
     const uint4 *pack;       // bf16 operand copy of the rows
@@ -71,7 +71,7 @@ struct FtArgs {
     uint4 *rec;              // FILTER mode: [FT_GRID FT_WAVES][cap] records of 5 x 16 bytes
     uint32_t *wcnt;          // FILTER mode: [FT_GRID FT_WAVES] records a wave had (beyond cap: not stored)
     uint32_t cap;
-    int dbg;                 // timing experiments ("flat_f32_dbg"): 8 = the filter passes alone (results stale), 16 = the younger waves at priority 1
+    int dbg;                 // timing experiments ("flat_f32_dbg"): 8 = the filter passes alone (results stale)
 };
 
 __device__ __forceinline__ float ft_max3(float a, float b, float c)
@@ -131,7 +131,9 @@ __global__ __launch_bounds__(64 * FT_WAVES) __attribute__((amdgpu_waves_per_eu(2
     __syncthreads();
     // groups of RT tiles: wave w of slice s takes groups s + slices (w + FT_WAVES i)
     const int64_t n_groups = (a.t1 + RT - 1) / RT, stride = (int64_t)slices * FT_WAVES;
-    if ((a.dbg & 16) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    // the second-dispatched half of the workgroup loses every arbitration by age: static priority for it (MI355X_MICROARCH.md "two waves
+    // per SIMD"; measured 0.65 -> 0.59 ms on the filter passes of 1000 queries x 1 M rows)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int slot = (slice * (FT_WAVES * 2) + wave * 2 + lk) & (FT_SLOTS - 1);
     uint32_t wcnt = 0;
     bf16x8 xa[RT][NCH][NA];
@@ -160,34 +162,25 @@ __global__ __launch_bounds__(64 * FT_WAVES) __attribute__((amdgpu_waves_per_eu(2
     };
     for (int64_t g = slice + (int64_t)slices * wave; g < n_groups; g += stride) {
         fetch(g);
-        // the queries' operands are one linear stream over (block, K step) in LDS; they are requested two K steps ahead of the
-        // matrix instructions that use them, across the block boundary (left to itself the compiler reads a K step's operands, waits,
-        // multiplies: an LDS round trip in front of every six matrix instructions)
-        bf16x8 bq[4][NT];
-        auto request = [&](int j, int set) __attribute__((always_inline)) {
-            const uint8_t *p_ = ft_q + (size_t)j * (NT * 1024) + lane * 16;
-#pragma unroll
-            for (int x = 0; x < NT; ++x) bq[set][x] = *reinterpret_cast<const bf16x8 *>(p_ + x * 1024);
-        };
-        request(0, 0);
-        request(1, 1);
+        // (requesting the queries' operands two or three K steps ahead of their matrix instructions -- pinned with sched_barrier, across
+        //  the block boundary -- or a block's operands at its start measured 0 .. 8 % SLOWER than the compiler's own order: read a K
+        //  step's operands, wait, multiply; the partner wave of the SIMD covers the round trip)
 #pragma unroll 1
         for (int b = 0; b < nb; ++b) {
+            const uint8_t *qb = ft_q + (size_t)b * (NCH * NT * 1024) + lane * 16;
             f32x16 acc[RT];
 #pragma unroll
             for (int s_ = 0; s_ < NCH; ++s_) {
-                request(b * NCH + s_ + 2, (s_ + 2) & 3);   // (the last two of a group read the slack behind the operands: unused)
-                __builtin_amdgcn_sched_barrier(0);         // (the scheduler would sink the request down to its first use)
-                const bf16x8 qh = bq[s_ & 3][0];
+                const bf16x8 qh = *reinterpret_cast<const bf16x8 *>(qb + (s_ * NT) * 1024);
 #pragma unroll
                 for (int r = 0; r < RT; ++r)
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[r][s_][0], qh, s_ == 0 ? bias[r] : acc[r], 0, 0, 0);   // b_x rides in as SrcC
-                if constexpr (NPROD >= 2) {
+                if constexpr (NPROD >= 2) {   // (the low terms on accumulators of their own, four independent chains: no faster)
 #pragma unroll
                     for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[r][s_][1], qh, acc[r], 0, 0, 0);
                 }
                 if constexpr (NPROD == 3) {
-                    const bf16x8 ql = bq[s_ & 3][1];
+                    const bf16x8 ql = *reinterpret_cast<const bf16x8 *>(qb + (s_ * NT + 1) * 1024);
 #pragma unroll
                     for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[r][s_][0], ql, acc[r], 0, 0, 0);
                 }
@@ -230,12 +223,13 @@ __global__ __launch_bounds__(64 * FT_WAVES) __attribute__((amdgpu_waves_per_eu(2
         if (lane == 0) a.wcnt[wave_g] = wcnt;
 }
 
-// margin of a query: Qb = (|q|^2 + max |x|^2) 1.001, xq2 = sqrt(max |x|^2) |q - q1| 1.01 (Cauchy-Schwarz on the omitted low term of
-// the query: the worst case e |x||q| is two to three times larger than what a query's own rounding residues add up to)
+// margin of a query: Qb = (|q|^2 + max |x|^2) 1.001; w = what the omitted low terms can add up to for THIS query, by Cauchy-Schwarz
+// against the longest row / the row with the largest rounding residue (ft_theta_kernel): the worst case e |x||q| per omitted term
+// is two to three times larger than a query's own residues
 template <bool IP>
-__device__ __forceinline__ float ft_margin(float Qb, float xq2, float theta, int nprod)
+__device__ __forceinline__ float ft_margin(float Qb, float w, float theta)
 {
-    float m = nprod == 3 ? Qb * 0x1p-13f : (nprod == 2 ? Qb * 0x1p-13f + 2.0f * xq2 : Qb * (0x1p-7f + 0x1p-11f));
+    float m = Qb * 0x1p-13f + 2.0f * w;
     if (IP) m += (2.0f + fabsf(theta)) * 0x1p-20f;   // the rounding of 1 - sum in the reference
     return m;
 }
@@ -261,7 +255,7 @@ __device__ __forceinline__ float ft_qlow(const float *q, int D)
 // one wave per query: theta = the k-th largest of its sample maxima, thr = theta - margin (NaN + redo when the bound does not hold)
 template <bool IP>
 __global__ __launch_bounds__(256) void ft_theta_kernel(const uint32_t *__restrict__ smax, const float *__restrict__ Q, int nq, int D, int k, int nprod,
-                                                       const uint32_t *__restrict__ stats, float *__restrict__ thr, float *__restrict__ qbnd,
+                                                       const uint32_t *__restrict__ stats, const uint32_t *__restrict__ pstats, float *__restrict__ thr, float *__restrict__ qbnd,
                                                        uint32_t *__restrict__ redo)
 {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -271,13 +265,16 @@ __global__ __launch_bounds__(256) void ft_theta_kernel(const uint32_t *__restric
     for (int j = 0; j < FT_SLOTS / 64; ++j) key[j] = smax[(size_t)q * FT_SLOTS + j * 64 + lane];
     const float qq = fs_qnorm(Q + (int64_t)q * D, D);
     const float Qb = (qq + __uint_as_float(stats[0])) * 1.001f;
-    const float xq2 = sqrtf(__uint_as_float(stats[0]) * ft_qlow(Q + (int64_t)q * D, D)) * 1.01f;
+    // nprod 2: (x1 + x2).(q - q1) <= (1 + e^2) max |x| |q - q1|; nprod 1: that and (x - x1).q <= max |x - x1| |q|
+    float xq2 = 0.0f;
+    if (nprod <= 2) xq2 = sqrtf(__uint_as_float(stats[0]) * ft_qlow(Q + (int64_t)q * D, D)) * 1.01f;
+    if (nprod == 1) xq2 += sqrtf(__uint_as_float(pstats[2]) * qq) * 1.01f;
     float cut = __uint_as_float(0x7fc00000u);
     if (Qb > 0x1p-60f && Qb < 0x1p60f) {
         const uint32_t sel = fs_wave_select(key, k, k + k / 4 + 8);
         if (sel != 0u) {   // at least k slots hold a row
             const float theta = key_f32(sel);
-            cut = theta - ft_margin<IP>(Qb, xq2, theta, nprod);
+            cut = theta - ft_margin<IP>(Qb, xq2, theta);
         }
     }
     if (lane == 0) {
@@ -360,7 +357,7 @@ __device__ __forceinline__ uint32_t ft_dist_key(float d)
 // k and a few, not the 1-2 k the sample's threshold let through -- get exact reference-order distances (32 pieces 1 KB apart per
 // row in the blocked layout) and are ranked by (distance, row) by counting.
 template <bool IP, int LANES>
-__global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict__ X, int64_t n, int D, const float *__restrict__ Q, int k, int nprod,
+__global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict__ X, int64_t n, int D, const float *__restrict__ Q, int k,
                                                         const float *__restrict__ thr, const float *__restrict__ qbnd, const uint32_t *__restrict__ cnt,
                                                         const uint2 *__restrict__ cand, float *__restrict__ out_d, int64_t *__restrict__ out_i,
                                                         uint32_t *__restrict__ redo)
@@ -431,7 +428,7 @@ __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict_
         __syncthreads();
     }
     const float theta = key_f32(prefix);
-    const float cut2 = theta - ft_margin<IP>(qbnd[q], qbnd[gridDim.x + q], theta, nprod);
+    const float cut2 = theta - ft_margin<IP>(qbnd[q], qbnd[gridDim.x + q], theta);
     const uint32_t cut2_key = f32_key(cut2);
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
@@ -482,9 +479,11 @@ __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict_
 }  // namespace
 
 // ---- host side ----
-static std::atomic<int> g_ft_on{2};        // cvtmi_set_tuning("flat_f32_tfilter"): 0 = the stream kernels for every batch, 1 .. 3 = products
+static std::atomic<int> g_ft_on{4};        // cvtmi_set_tuning("flat_f32_tfilter"): 0 = the stream kernels for every batch, 1 .. 3 = products, 4 = choose
+static std::atomic<int> g_ft_one_max{512}; // "flat_f32_tfilter_one": largest batch that multiplies one product (the pass is bound by the rows it reads)
 static std::atomic<int> g_ft_min_nq{129};  // cvtmi_set_tuning("flat_f32_tfilter_min"): smallest batch that takes the pipeline
-void set_flat_f32_tfilter(int v) { g_ft_on = v < 0 ? 0 : (v > 3 ? 3 : v); }
+void set_flat_f32_tfilter(int v) { g_ft_on = v < 0 ? 0 : (v > 4 ? 4 : v); }
+void set_flat_f32_tfilter_one(int v) { g_ft_one_max = v < 0 ? 0 : v; }
 void set_flat_f32_tfilter_min(int v) { g_ft_min_nq = v < 1 ? 1 : v; }
 bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k)
 {
@@ -525,11 +524,12 @@ static int ft_launch_any(int D, int nprod, bool maxmode, const FtArgs &a, size_t
 }
 
 // nq queries against rows [0, n); results for the queries whose redo flag stays 0 (redo[nq] is zeroed here)
-int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack, const float *bias, const uint32_t *stats, int64_t n, const float *q,
-                            int64_t nq, int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, hipStream_t st)
+int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack, const uint32_t *pstats, const float *bias, const uint32_t *stats, int64_t n,
+                            const float *q, int64_t nq, int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, hipStream_t st)
 {
     if (!flat_f32_tfilter_applies(metric, D, n, nq, k)) return fail(CVTMI_EINVAL, "flat_f32_tfilter: D=%d nq=%lld", D, (long long)nq);
-    const int nprod = g_ft_on.load();
+    const int mode = g_ft_on.load();
+    const int nprod = mode == 4 ? (nq <= g_ft_one_max.load() ? 1 : 2) : mode;
     const int nt = nprod == 3 ? 2 : 1;
     const int qcap = std::min(32 * FT_NBMAX, (int)((size_t)(160 * 1024 - 32 * FT_NBMAX * 4 - FT_SLACK) / ((size_t)(D / 16) * nt * 1024)) * 32);   // queries a workgroup holds
     CVTMI_HIP(hipMemsetAsync(redo, 0, (size_t)nq * sizeof(uint32_t), st));
@@ -557,16 +557,16 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
         a.t1 = ts;
         CVTMI_TRY(ft_launch_any(D, nprod, true, a, lds, st));
         const unsigned tg = (unsigned)((m + 3) / 4);
-        if (metric == CVTMI_METRIC_IP) hipLaunchKernelGGL((ft_theta_kernel<true>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, thr, qbnd, redo + a0);
-        else hipLaunchKernelGGL((ft_theta_kernel<false>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, thr, qbnd, redo + a0);
+        if (metric == CVTMI_METRIC_IP) hipLaunchKernelGGL((ft_theta_kernel<true>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, thr, qbnd, redo + a0);
+        else hipLaunchKernelGGL((ft_theta_kernel<false>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, thr, qbnd, redo + a0);
         a.t1 = n_tiles;
         CVTMI_TRY(ft_launch_any(D, nprod, false, a, lds, st));
         if (a.dbg & 8) continue;   // timing experiments: the filter passes alone (results stale)
         hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), 0, st, rec, wcnt, cap, thr, cnt, cand, chunks, qper, (int)m, redo + a0);
         if (metric == CVTMI_METRIC_IP)
-            hipLaunchKernelGGL((ft_finish_kernel<true, 4>), dim3((unsigned)m), dim3(256), 0, st, X, n, D, a.Q, k, nprod, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0);
+            hipLaunchKernelGGL((ft_finish_kernel<true, 4>), dim3((unsigned)m), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0);
         else
-            hipLaunchKernelGGL((ft_finish_kernel<false, 8>), dim3((unsigned)m), dim3(256), 0, st, X, n, D, a.Q, k, nprod, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0);
+            hipLaunchKernelGGL((ft_finish_kernel<false, 8>), dim3((unsigned)m), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0);
         CVTMI_HIP(hipGetLastError());
         if (getenv("CVTMI_FT_DEBUG")) {   // counts of the pass (synchronises)
             CVTMI_HIP(hipStreamSynchronize(st));

@@ -42,7 +42,7 @@ __device__ __forceinline__ float blocked_at(const float *X, int D, int64_t row, 
 }
 
 // one thread per (tile, lane): lane (li, lk) of tile t owns row 32 t + li, dimensions 16 c + 8 lk .. + 8 of chunk c.
-// stats[0] = max |x|^2 (uint bits), stats[1] = number of rows holding a non-finite value
+// stats[0] = max |x|^2 (uint bits), stats[1] = number of rows holding a non-finite value, stats[2] = max |x - x1|^2 (x1: the first bf16 term)
 __global__ __launch_bounds__(kBlock) void flat_pack_kernel(const float *__restrict__ X, int64_t n, int D, int l2, int64_t ntiles,
                                                            uint4 *__restrict__ pack, uint32_t *__restrict__ bias,
                                                            uint32_t *__restrict__ stats)
@@ -77,6 +77,12 @@ __global__ __launch_bounds__(kBlock) void flat_pack_kernel(const float *__restri
             }
             b = l2 ? -0.5f * s : 0.0f;
             atomicMax(&stats[0], __float_as_uint(s));  // NaN / inf show up as such: the call takes the exact path
+            float r2 = 0.0f;   // |x - x1|^2: what the first bf16 term leaves out (flat_f32_tfilter.hip, one product)
+            for (int e = 0; e < D; ++e) {
+                const float v = blocked_at(X, D, row, e), r = v - (float)(__bf16)v;
+                r2 = __fmaf_rn(r, r, r2);
+            }
+            atomicMax(&stats[2], __float_as_uint(r2));
         }
         const __bf16 a = (__bf16)b, c2 = (__bf16)(b - (float)a);
         bias[row] = (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, c2) << 16);
@@ -1423,7 +1429,7 @@ size_t flat_pack_bytes(int D, int64_t n) { return (size_t)((n + 31) / 32) * (D /
 int launch_flat_pack(const float *X, int64_t n, int D, int metric, uint4 *pack, uint32_t *bias, uint32_t *stats, hipStream_t st)
 {
     const int64_t ntiles = (n + 31) / 32;
-    CVTMI_HIP(hipMemsetAsync(stats, 0, 8, st));
+    CVTMI_HIP(hipMemsetAsync(stats, 0, 12, st));
     hipLaunchKernelGGL(flat_pack_kernel, dim3((unsigned)((ntiles * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, X, n, D,
                        metric == CVTMI_METRIC_L2F ? 1 : 0, ntiles, pack, bias, stats);
     CVTMI_HIP(hipGetLastError());

@@ -221,10 +221,11 @@ bool flat_f32_stream_applies(int metric, int D, int64_t n, int k);
 // redo[nq] (zeroed inside): 1 = the exact kernels must answer the query
 bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k);
 size_t flat_f32_tfilter_scratch(int64_t nq);
-int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack, const float *bias, const uint32_t *stats, int64_t n, const float *q,
-                            int64_t nq, int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, hipStream_t st);
+int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack, const uint32_t *pstats, const float *bias, const uint32_t *stats, int64_t n,
+                            const float *q, int64_t nq, int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, hipStream_t st);
 void set_flat_f32_tfilter(int v);
 void set_flat_f32_tfilter_min(int v);
+void set_flat_f32_tfilter_one(int v);
 size_t flat_f32_stream_scratch(int D, int64_t n, int64_t nq_pass);
 // bias[r] (and zeroed padding rows) for rows [row0, row1); stats[0] = max |x|^2 bits, stats[1] = non-finite rows (both accumulate)
 int launch_flat_f32_bias(float *X, int D, int metric, int64_t row0, int64_t row1, float *bias, uint32_t *stats, hipStream_t st);

@@ -961,7 +961,7 @@ def test_flat_f32_threshold_filter(amd, orc, metric, D, k, prods):
             assert np.array_equal(is_, ie) and np.array_equal(bits(ds), bits(de)), nq
         ix.close()
     finally:
-        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_tfilter", 2)
+        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_tfilter", 4)
     assert np.array_equal(is2, ie2) and np.array_equal(bits(ds2), bits(de2))
     od, _, oi = orc.flat_search(metric, x, q160[:4], k, flavour=4 if metric == IP else 8)
     assert np.array_equal(is2[:4], oi) and np.array_equal(bits(ds2[:4]), bits(od))

@@ -21,5 +21,5 @@ for metric in (0, 1):
             if ref is not None: same = " identical=%s" % bool(torch.equal(i, ref[1]) and torch.equal(d.view(torch.int32), ref[0].view(torch.int32)))
             else: ref = (d, i)
             print("metric %d nq %d tfilter %d: %.3f ms%s" % (metric, nq, tf, ms, same), flush=True)
-    cvt_amd.set_tuning("flat_f32_tfilter", 1)
+    cvt_amd.set_tuning("flat_f32_tfilter", 4)
     ix.close()

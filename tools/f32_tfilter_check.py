@@ -24,5 +24,5 @@ for D in (128, 64):
                     msg = " first bad query %d: %d ids differ, first at rank %d; missing from the set: %d" % (
                         b, int((i[b] != i0[b]).sum()), int((i[b] != i0[b]).nonzero()[0]), len(set(i0[b].tolist()) - set(i[b].tolist())))
                 print("D %d metric %d nq %d tf %d: bad ids %d bad dists %d%s" % (D, metric, nq, tf, int(bad.sum()), int(badd.sum()), msg), flush=True)
-        cvt_amd.set_tuning("flat_f32_tfilter", 1)
+        cvt_amd.set_tuning("flat_f32_tfilter", 4)
         ix.close()

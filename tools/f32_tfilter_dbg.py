@@ -8,9 +8,9 @@ n, D, k, nq = 1_000_000, 128, 100, int(os.environ.get("NQ", 1000))
 x = synth.sift_like(n, D, device=dev)
 ix = cvt_amd.FlatIndex(1, D); ix.add(x)
 q = synth.sift_like(nq, D, seed=0xBEEF, device=dev)
-for tf in [int(v) for v in os.environ.get("TFS", "3,2").split(",")]:
+for tf in [int(v) for v in os.environ.get("TFS", "2").split(",")]:
     cvt_amd.set_tuning("flat_f32_tfilter", tf)
-    for dbg in (0, 16, 8, 24):
+    for dbg in (8, 8 + 32, 8 + 96, 8 + 16, 8 + 16 + 96):
         cvt_amd.set_tuning("flat_f32_dbg", dbg)
         for _ in range(2): ix.search(q, k)
         torch.cuda.synchronize(); t0 = time.perf_counter(); reps = 5
