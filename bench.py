@@ -1050,23 +1050,27 @@ def _sec_flat_f32(ctx):
     for metric, tag in ((cvt.IP, "ip"), (cvt.L2F, "l2")):
         ix = cvt.FlatIndex(metric, D)
         ix.add(xd)
-        for nq in (1, 64, 1000):
+        for nq in (1, 64, 128, 1000):
             qq = qd[:nq].contiguous()
             ms = _ev_ms(torch, lambda: ix.search(qq, k), reps=5, warm=2)
             c = {"ms": round(ms, 4), "queries_per_s": round(nq / (ms * 1e-3), 1), "path": ix.last_search()[0]}
-            if nq <= 96:   # one stream over the rows: bound by HBM
+            if c["path"] == 3 and nq <= 512:   # threshold filter, one bf16 product: bound by the first-term plane of the operand copy
+                c["roofline"] = _hbm(n * D * 2, ms)
+                c["roofline"]["note"] = "algorithmic bytes = the first bf16 term of every row once (the sample pass re-reads an eighth)"
+            elif nq <= 96:   # one stream over the rows: bound by HBM
                 c["roofline"] = _hbm(n * D * 4, ms)
-            else:          # bf16 matrix cores: three products per (query, row, dimension)
-                tf = 3 * 2.0 * nq * n * D / (ms * 1e-3) / 1e12
+            else:          # bf16 matrix cores: products per (query, row, dimension)
+                prods = 2 if c["path"] == 3 else 3
+                tf = prods * 2.0 * nq * n * D / (ms * 1e-3) / 1e12
                 c["roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TF,
-                                 "unit": "TFLOP/s (bf16, three two-term products)",
-                                     "frac": round(tf / BF16_MFMA_PEAK_TF, 4)}
+                                 "unit": "TFLOP/s (bf16, %d products per term%s)" % (prods, ", plus the sample pass over an eighth of the rows" if prods == 2 else ""),
+                                 "frac": round(tf / BF16_MFMA_PEAK_TF, 4)}
             res["cases"]["%s nq=%d" % (tag, nq)] = c
         if metric == cvt.IP:
             outs = {nq: ix.search(qd[:nq].contiguous(), k) for nq in (1, 64)}
         ix.close()
     res["path_codes"] = ("0 exact kernels, 1 sample + matrix-core filter pipeline, 2 one stream over the rows "
-                         "(flat_f32_stream.hip)")
+                         "(flat_f32_stream.hip), 3 threshold filter (flat_f32_tfilter.hip, round 6)")
     if args.cpu_sample > 0:
         from oracle import binding as ob
         if ob.ref_available():

@@ -481,7 +481,8 @@ __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict_
 // ---- host side ----
 static std::atomic<int> g_ft_on{4};        // cvtmi_set_tuning("flat_f32_tfilter"): 0 = the stream kernels for every batch, 1 .. 3 = products, 4 = choose
 static std::atomic<int> g_ft_one_max{512}; // "flat_f32_tfilter_one": largest batch that multiplies one product (the pass is bound by the rows it reads)
-static std::atomic<int> g_ft_min_nq{129};  // cvtmi_set_tuning("flat_f32_tfilter_min"): smallest batch that takes the pipeline
+static std::atomic<int> g_ft_min_nq{16};   // cvtmi_set_tuning("flat_f32_tfilter_min"): smallest batch that takes the pipeline (1 M x 128-d: 16 queries 0.119 -> 0.107 ms,
+                                           // 128 queries 0.25 -> 0.16; below, the pipeline's five launches cost more than the stream's two)
 void set_flat_f32_tfilter(int v) { g_ft_on = v < 0 ? 0 : (v > 4 ? 4 : v); }
 void set_flat_f32_tfilter_one(int v) { g_ft_one_max = v < 0 ? 0 : v; }
 void set_flat_f32_tfilter_min(int v) { g_ft_min_nq = v < 1 ? 1 : v; }

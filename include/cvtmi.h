@@ -147,13 +147,13 @@ int cvtmi_set_device(int device);
  *   "scanh_balance" / "scanh_min_rows" / "scanh_tail" / "scanh_fix" / "scanh_share_hist"  planner of the persistent-grid scan (variant
  *                     6): 0 choose / 1 equal row-time shares / 2 row blocks; smallest row segment; two-region tail on / off; an item's
  *                     fixed cost in row-equivalents (160 000); one candidate histogram per query shared by its segments (1) or not
- *   "flat_f32_tfilter" fp32 searches (64 / 128-d, >= 262 144 rows, k <= 128) of "flat_f32_tfilter_min" (default 129) queries or more run as a
+ *   "flat_f32_tfilter" fp32 searches (64 / 128-d, >= 262 144 rows, k <= 128) of "flat_f32_tfilter_min" (default 16) queries or more run as a
  *                     threshold filter (round 6, flat_f32_tfilter.hip): sample maxima -> per-query threshold -> queries in LDS, the rows'
  *                     bf16 operand copy in registers, no barrier, hits recorded -> per-query lists -> exact distances.  1 .. 3 = the
  *                     bf16 products per term: 1 (x1.q1), 2 ((x1 + x2).q1; both with margins from each query's own rounding residues),
  *                     3 (x1.q1 + x2.q1 + x1.q2, the stream kernels' margin); 4 (default) = one product up to "flat_f32_tfilter_one"
  *                     (default 512) queries -- the pass is bound by the rows it reads --, two beyond; 0 = the stream kernels for every
- *                     batch.  1 M x 128-d, top-100: 1000 queries 0.97 -> 0.69 ms, 130 queries 0.31 -> 0.18 ms
+ *                     batch.  1 M x 128-d, top-100: 1000 queries 0.97 -> 0.69 ms, 128 queries 0.25 -> 0.16 ms, 16 queries 0.119 -> 0.107 ms
  *   "flat_f32_tfilter_min"  smallest batch that takes that pipeline
  *   "flat_f32_tfilter_one"  largest batch that multiplies one product under "flat_f32_tfilter" 4
  *   "flat_f32_share"  fp32 stream, batches beyond one wave's queries: 0 choose, 1 private rings only, 2 the shared-ring kernel,

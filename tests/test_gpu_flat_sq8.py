@@ -940,7 +940,7 @@ def test_flat_f32_threshold_filter(amd, orc, metric, D, k, prods):
         amd.set_tuning("flat_f32_tfilter", prods)
         ix = amd.FlatIndex(metric, D); ix.add(x[:n - 5_000])
         out = {}
-        for nq in (129, 160, 513, 1030):
+        for nq in (16, 129, 160, 513, 1030):
             q = (x[rng.integers(0, n - 5_000, nq)] + 0.05 * rng.normal(size=(nq, D))).astype(np.float32)
             q[0] = x[5]; q[3] = x[123]
             q = np.ascontiguousarray(q, np.float32)
@@ -985,7 +985,7 @@ def test_flat_f32_threshold_filter_hands_hard_queries_to_the_exact_kernels(amd):
         for name, xx, lab, qq in (("ties", x, None, q), ("labels", x, labels, q), ("inf row", xn, None, q), ("five queries", x, None, q[:5])):
             out = {}
             for v in (0, 1):
-                amd.set_tuning("flat_variant", v); amd.set_tuning("flat_f32_tfilter_min", 1 if name == "five queries" else 129)
+                amd.set_tuning("flat_variant", v); amd.set_tuning("flat_f32_tfilter_min", 1 if name == "five queries" else 16)
                 ix = amd.FlatIndex(L2F, D); ix.add(xx, labels=lab)
                 out[v] = ix.search(qq, k)
                 if v == 0:
@@ -994,7 +994,7 @@ def test_flat_f32_threshold_filter_hands_hard_queries_to_the_exact_kernels(amd):
             assert np.array_equal(out[0][1], out[1][1]), name
             assert np.array_equal(bits(out[0][0]), bits(out[1][0])), name
     finally:
-        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_tfilter_min", 129)
+        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_tfilter_min", 16)
 
 
 @pytest.mark.parametrize("d,n", [(512, 20_000), (256, 17_001), (128, 40_000), (100, 16_385), (516, 16_400), (4, 70_000)])
