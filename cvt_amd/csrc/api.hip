@@ -1687,7 +1687,7 @@ static int flat_add_common(cvtmi_flat_t h, const void *x, const int64_t *labels,
             src = h->add_stage.as<float>();
         }
         CVTMI_TRY(launch_flat_block(src, n, h->D, h->n, h->data.as<float>(), st));
-        if (flat_f32_stream_qmax(h->D) > 0) {   // score bias + row statistics of the streaming search, padding rows zeroed
+        if (flat_f32_stream_qmax(h->D) > 0 || flat_f32_tfilter_width(h->D)) {   // score bias + row statistics of the streaming search / the threshold filter, padding rows zeroed
             if (!h->fs_stats.p) {
                 CVTMI_TRY(h->fs_stats.reserve(16));
                 CVTMI_HIP(hipMemsetAsync(h->fs_stats.p, 0, 16, st));
@@ -1847,6 +1847,7 @@ static int flat_search_streamed(cvtmi_flat_t h, FlatScratch &S, const float *q, 
         return CVTMI_OK;
     }
     (void)hipGetLastError();
+    if (!flat_f32_stream_applies(h->metric, D, n, k)) return CVTMI_OK;   // (a width only the threshold filter takes)
     const int qmax = flat_f32_stream_qmax(D), qpriv = flat_f32_stream_private_max(D);
     int64_t passes = (nq + qmax - 1) / qmax;
     // just past one private-ring pass, two of them beat one pass of the shared ring (1 M x 128-d, 128 queries: 0.28 against 0.32 ms)
@@ -1978,7 +1979,7 @@ static int flat_search_filtered_u8(cvtmi_flat_t h, FlatScratch &S, const uint8_t
 }
 
 // which of the pipelines a search of nq queries takes (the dispatch rules, in one place: flat_prepare builds what they need)
-struct FlatRoute { bool stream, filt_f32, filt_u8; };
+struct FlatRoute { bool stream, tfilter, filt_f32, filt_u8; };
 // the tuning values a search dispatches on, read ONCE per call: flat_prepare and flat_search_leased must see the same route even if
 // another thread calls cvtmi_set_tuning between the two
 struct FlatTuning {
@@ -1988,11 +1989,13 @@ struct FlatTuning {
 static FlatRoute flat_route(const cvtmi_flat_s *h, const void *q, int64_t nq, int k, const FlatTuning &tun)
 {
     const int g_flat_variant = tun.variant, g_flat_f32_stream = tun.f32_stream;  // (this call's snapshot shadows the globals)
-    FlatRoute r = { false, false, false };
+    FlatRoute r = { false, false, false, false };
     const bool aligned = ((uintptr_t)q & 15) == 0;
     // fp32: one stream over the rows (flat_f32_stream.hip).  flat_variant 2 asks for the older sample + filter pipeline, 1 for the exact kernels
-    r.stream = ((g_flat_variant == 0 && g_flat_f32_stream == 1) || (g_flat_variant != 1 && g_flat_f32_stream == 2)) && aligned &&
-               flat_f32_stream_applies(h->metric, h->D, h->n, k) && h->fs_bias.p && h->fs_stats.p;
+    const bool f32_fast = ((g_flat_variant == 0 && g_flat_f32_stream == 1) || (g_flat_variant != 1 && g_flat_f32_stream == 2)) && aligned &&
+                          h->fs_bias.p && h->fs_stats.p;
+    r.stream = f32_fast && flat_f32_stream_applies(h->metric, h->D, h->n, k);
+    r.tfilter = f32_fast && flat_f32_tfilter_applies(h->metric, h->D, h->n, nq, k);   // batches as a threshold filter (round 6), widths up to 512-d
     r.filt_f32 = g_flat_variant != 1 && aligned && nq <= 65535 &&
                  flat_filter_applies(h->metric, h->D, g_flat_variant == 2 ? std::max<int64_t>(h->n, 131072) : h->n,
                                      g_flat_variant == 2 ? std::max<int64_t>(nq, 16) : nq, k) && h->n >= 2 * 65536;
@@ -2026,7 +2029,7 @@ extern "C" int cvtmi_flat_describe_dispatch(int metric, int D, int64_t n_rows, i
     alignas(16) static const char aligned_q[16] = {};
     const FlatRoute r = flat_route(&h, aligned_q, nq, k, FlatTuning::now());
     h.fs_bias.p = nullptr; h.fs_stats.p = nullptr; h.norms.p = nullptr;
-    out[0] = r.stream ? (flat_f32_tfilter_applies(metric, D, n_rows, nq, k) ? 2 : 1) : 0;
+    out[0] = r.tfilter ? 2 : (r.stream ? 1 : 0);
     out[1] = r.filt_f32 ? 1 : 0;
     out[2] = r.filt_u8 ? 1 : 0;
     out[3] = (metric == CVTMI_METRIC_L2U8 && !r.filt_u8 && flat_u8_mstream_applies(D, n_rows, std::min<int64_t>(nq, 128), k)) ? 1 : 0;
@@ -2044,8 +2047,8 @@ static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStr
         {
             std::shared_lock<std::shared_timed_mutex> rd(h->rw);
             r = flat_route(h, q, nq, k, tun);
-            need_fs = r.stream && h->fs_stats_n != h->n;
-            const bool tf = r.stream && !h->fs_nonfinite && flat_f32_tfilter_applies(h->metric, h->D, h->n, nq, k);   // the threshold filter reads the copy too
+            need_fs = (r.stream || r.tfilter) && h->fs_stats_n != h->n;
+            const bool tf = r.tfilter && !h->fs_nonfinite;   // the threshold filter reads the copy too
             need_f32 = h->f_pack_n != h->n && (tf ? !need_fs : (r.filt_f32 && !(r.stream && !need_fs && !h->fs_nonfinite)));   // (the stream answers: no copy needed)
             need_u8 = r.filt_u8 && h->f_pack_n != h->n;
             if (!need_fs && !need_f32 && !need_u8) return CVTMI_OK;
@@ -2092,7 +2095,7 @@ static int flat_search_leased(cvtmi_flat_t h, FlatScratch &S, const void *q, int
     h->f_last_worst = worst0;
     int how = 0;
     const FlatRoute r = flat_route(h, q, nq, k, tun);
-    if (r.stream) {
+    if (r.stream || r.tfilter) {
         int how_s = 2;
         CVTMI_TRY(flat_search_streamed(h, S, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done, &how_s));
         if (done) how = how_s;

@@ -58,6 +58,7 @@ constexpr int FT_CAP = 4096;         // candidates per query the finish takes
 constexpr int FT_NBMAX = 16;         // query blocks a workgroup holds
 constexpr int FT_PASS = 1024;        // queries per pass of the pipeline (sizes the record area)
 constexpr int FT_KEEP = 1024;        // rows per query the finish gives exact distances
+constexpr int FT_DMAX = 1024;        // widest row
 constexpr int FT_SLACK = 0;          // bytes of LDS kept free behind the queries' operands
 
 struct FtArgs {
@@ -68,8 +69,8 @@ struct FtArgs {
     int nq, chunks, qper;    // queries of chunk c: [c qper, min(nq, (c + 1) qper)), qper a multiple of 32
     uint32_t *smax;          // MAX mode: [nq][FT_SLOTS] ordered keys (zeroed by the caller)
     const float *thr;        // FILTER mode: [nq] (NaN: nothing passes)
-    uint4 *rec;              // FILTER mode: [FT_GRID FT_WAVES][cap] records of 5 x 16 bytes
-    uint32_t *wcnt;          // FILTER mode: [FT_GRID FT_WAVES] records a wave had (beyond cap: not stored)
+    uint4 *rec;              // FILTER mode: [FT_GRID waves][cap] records of 5 x 16 bytes
+    uint32_t *wcnt;          // FILTER mode: [FT_GRID waves] records a wave had (beyond cap: not stored)
     uint32_t cap;
     int dbg;                 // timing experiments ("flat_f32_dbg"): 8 = the filter passes alone (results stale)
 };
@@ -92,8 +93,8 @@ __device__ __forceinline__ float ft_max16(const f32x16 &v)
     return fmaxf(m, v[15]);
 }
 
-template <int NCH, int NPROD, int RT, bool MAXMODE>
-__global__ __launch_bounds__(64 * FT_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void flat_f32_tfilter_kernel(const FtArgs a)
+template <int NCH, int NPROD, int RT, bool MAXMODE, int NW = FT_WAVES>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void flat_f32_tfilter_kernel(const FtArgs a)
 {
     constexpr int NT = NPROD == 3 ? 2 : 1;    // terms of a query in LDS
     constexpr int NA = NPROD >= 2 ? 2 : 1;    // terms of a row in registers
@@ -106,14 +107,14 @@ __global__ __launch_bounds__(64 * FT_WAVES) __attribute__((amdgpu_waves_per_eu(2
     const int chunk = idx % a.chunks, slices = 8 * ((int)(gridDim.x >> 3) / a.chunks), slice = xcd + 8 * (idx / a.chunks);
     const int q0 = chunk * a.qper;
     const int nqc = a.nq - q0 < a.qper ? a.nq - q0 : a.qper;
-    const int wave_g = blockIdx.x * FT_WAVES + wave;
+    const int wave_g = blockIdx.x * NW + wave;
     if (nqc <= 0) {
         if (!MAXMODE && lane == 0) a.wcnt[wave_g] = 0u;
         return;
     }
     const int nb = (nqc + 31) >> 5;
     float *thr_s = reinterpret_cast<float *>(ft_q + (size_t)nb * NCH * NT * 1024 + FT_SLACK);
-    for (int i = tid; i < nb * 32 * NCH * 2; i += 64 * FT_WAVES) {   // (query, K step, half) -> its 16-byte slots of the terms
+    for (int i = tid; i < nb * 32 * NCH * 2; i += 64 * NW) {   // (query, K step, half) -> its 16-byte slots of the terms
         const int hl = i & 1, ss = (i >> 1) % NCH, qq = i / (2 * NCH);
         const int qi = q0 + (qq < nqc ? qq : nqc - 1);
         const float *qp = a.Q + (int64_t)qi * D + 16 * ss + 8 * hl;
@@ -127,14 +128,19 @@ __global__ __launch_bounds__(64 * FT_WAVES) __attribute__((amdgpu_waves_per_eu(2
         if constexpr (NT == 2) *reinterpret_cast<bf16x8 *>(dst + 1024) = l;
     }
     if constexpr (!MAXMODE)
-        for (int i = tid; i < nb * 32; i += 64 * FT_WAVES) thr_s[i] = i < nqc ? a.thr[q0 + i] : __uint_as_float(0x7fc00000u);   // NaN: no comparison succeeds
+        for (int i = tid; i < nb * 32; i += 64 * NW) thr_s[i] = i < nqc ? a.thr[q0 + i] : __uint_as_float(0x7fc00000u);   // NaN: no comparison succeeds
     __syncthreads();
     // groups of RT tiles: wave w of slice s takes groups s + slices (w + FT_WAVES i)
-    const int64_t n_groups = (a.t1 + RT - 1) / RT, stride = (int64_t)slices * FT_WAVES;
+    const int64_t n_groups = (a.t1 + RT - 1) / RT, stride = (int64_t)slices * NW;
     // the second-dispatched half of the workgroup loses every arbitration by age: static priority for it (MI355X_MICROARCH.md "two waves
     // per SIMD"; measured 0.65 -> 0.59 ms on the filter passes of 1000 queries x 1 M rows)
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-    const int slot = (slice * (FT_WAVES * 2) + wave * 2 + lk) & (FT_SLOTS - 1);
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    // sample maxima: FT_SLOTS disjoint row sets per query -- (wave, half) of the chunk's workgroups, and when those are fewer than
+    // FT_SLOTS (many chunks: few slices each) every wave deals its tile groups round-robin to sub_slots sets of its own (a threshold
+    // from 128 maxima for k = 100 let 8 000 - 22 000 rows per query through)
+    const int wave_slots = slices * NW * 2, sub_slots = wave_slots >= FT_SLOTS ? 1 : FT_SLOTS / wave_slots;
+    const int slot0 = ((slice * NW + wave) * 2 + lk) * sub_slots;
+    int it = 0;
     uint32_t wcnt = 0;
     bf16x8 xa[RT][NCH][NA];
     f32x16 bias[RT];
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) __attribute__((amdgpu_waves_per_eu(2
             }
         }
     };
-    for (int64_t g = slice + (int64_t)slices * wave; g < n_groups; g += stride) {
+    for (int64_t g = slice + (int64_t)slices * wave; g < n_groups; g += stride, ++it) {
         fetch(g);
         // (requesting the queries' operands two or three K steps ahead of their matrix instructions -- pinned with sched_barrier, across
         //  the block boundary -- or a block's operands at its start measured 0 .. 8 % SLOWER than the compiler's own order: read a K
@@ -187,7 +193,8 @@ __global__ __launch_bounds__(64 * FT_WAVES) __attribute__((amdgpu_waves_per_eu(2
             }
             // the maxima below are inline assembly: the compiler's hazard recogniser does not put the wait states between a matrix
             // instruction's result and a vector instruction that reads it in front of those (measured: rows lost), so they are spelled out
-            static_assert(RT >= 2 && RT <= 4, "operand lists below");
+            static_assert(RT >= 1 && RT <= 4, "operand lists below");
+            if constexpr (RT == 1) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]));
             if constexpr (RT == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));
             if constexpr (RT == 3) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
             if constexpr (RT == 4) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(64 * FT_WAVES) __attribute__((amdgpu_waves_per_eu(2
                 float m = ft_max16(acc[0]);
 #pragma unroll
                 for (int r = 1; r < RT; ++r) m = fmaxf(m, ft_max16(acc[r]));
-                if (qq < nqc && m > FS_EMPTY) atomicMax(&a.smax[(size_t)(q0 + qq) * FT_SLOTS + slot], f32_key(m));
+                if (qq < nqc && m > FS_EMPTY) atomicMax(&a.smax[(size_t)(q0 + qq) * FT_SLOTS + ((slot0 + (it & (sub_slots - 1))) & (FT_SLOTS - 1))], f32_key(m));
             } else {
                 const float tb = thr_s[qq];
 #pragma unroll
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(256) void ft_theta_kernel(const uint32_t *__restric
 constexpr int FT_BUCKET_T = 1024;
 __global__ __launch_bounds__(FT_BUCKET_T) void ft_bucket_kernel(const uint4 *__restrict__ rec, const uint32_t *__restrict__ wcnt, uint32_t cap,
                                                                 const float *__restrict__ thr, uint32_t *__restrict__ cnt, uint2 *__restrict__ cand,
-                                                                int chunks, int qper, int nq, uint32_t *__restrict__ redo)
+                                                                int chunks, int qper, int nq, uint32_t *__restrict__ redo, int nw)
 {
     __shared__ uint32_t hist[32 * FT_NBMAX], base_s[32 * FT_NBMAX];
     const int j = blockIdx.x, tid = threadIdx.x;
@@ -300,15 +307,15 @@ __global__ __launch_bounds__(FT_BUCKET_T) void ft_bucket_kernel(const uint4 *__r
     const int nqc = nq - q0 < qper ? nq - q0 : qper;
     if (nqc <= 0) return;
     for (int i = tid; i < nqc; i += FT_BUCKET_T) hist[i] = 0u;
-    const int r = tid >> 7, t = tid & 127;   // 128 threads per wave region
-    uint32_t n = wcnt[j * FT_WAVES + r];
+    const int per = FT_BUCKET_T / nw, r = tid / per, t = tid % per;   // 128 (256) threads per wave region
+    uint32_t n = wcnt[j * nw + r];
     if (n > cap) {   // the region ran full: the exact kernels answer the queries its workgroup held
-        for (int i = t; i < nqc; i += 128) redo[q0 + i] = 1u;
+        for (int i = t; i < nqc; i += per) redo[q0 + i] = 1u;
         n = cap;
     }
-    const uint4 *rp = rec + (size_t)(j * FT_WAVES + r) * cap * 5;
+    const uint4 *rp = rec + (size_t)(j * nw + r) * cap * 5;
     __syncthreads();
-    for (uint32_t i = t; i < n; i += 128) {
+    for (uint32_t i = t; i < n; i += per) {
         const uint4 h = rp[(size_t)i * 5 + 4];
         const float tb = thr[h.x];
         uint32_t c = 0;
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(FT_BUCKET_T) void ft_bucket_kernel(const uint4 *__r
         hist[i] = 0u;
     }
     __syncthreads();
-    for (uint32_t i = t; i < n; i += 128) {
+    for (uint32_t i = t; i < n; i += per) {
         const uint4 h = rp[(size_t)i * 5 + 4];
         const float tb = thr[h.x];
         const uint32_t ql = h.x - (uint32_t)q0;
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict_
                                                         uint32_t *__restrict__ redo)
 {
     __shared__ unsigned long long sel[FT_KEEP];
-    __shared__ __attribute__((aligned(16))) float q_s[256];
+    __shared__ __attribute__((aligned(16))) float q_s[FT_DMAX];
     __shared__ uint32_t hist[256];
     __shared__ uint32_t pick_s[2];
     __shared__ int m2_s;
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict_
         if (tid == 0) redo[q] = 1u;
         return;
     }
-    if (tid < D) q_s[tid] = Q[(int64_t)q * D + tid];
+    for (int i = tid; i < D; i += 256) q_s[i] = Q[(int64_t)q * D + i];
     if (tid == 0) m2_s = 0;
     constexpr int PER = FT_CAP / 256;
     uint32_t key[PER], row[PER];
@@ -486,9 +493,11 @@ static std::atomic<int> g_ft_min_nq{16};   // cvtmi_set_tuning("flat_f32_tfilter
 void set_flat_f32_tfilter(int v) { g_ft_on = v < 0 ? 0 : (v > 4 ? 4 : v); }
 void set_flat_f32_tfilter_one(int v) { g_ft_one_max = v < 0 ? 0 : v; }
 void set_flat_f32_tfilter_min(int v) { g_ft_min_nq = v < 1 ? 1 : v; }
+// widths: D / 16 K steps of a row tile stay in a wave's registers (RT tiles of 32 rows: RT x D / 16 x terms x 4 registers <= 128)
+bool flat_f32_tfilter_width(int D) { return D == 32 || D == 64 || D == 96 || D == 128 || D == 160 || D == 192 || D == 256 || D == 384 || D == 512 || D == 768 || D == 1024; }
 bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k)
 {
-    return g_ft_on.load() && (metric == CVTMI_METRIC_IP || metric == CVTMI_METRIC_L2F) && (D == 64 || D == 128) && n >= 262144 && n < 0xffffffe0LL &&
+    return g_ft_on.load() && (metric == CVTMI_METRIC_IP || metric == CVTMI_METRIC_L2F) && flat_f32_tfilter_width(D) && n >= 262144 && n < 0xffffffe0LL &&
            nq >= g_ft_min_nq.load() && k >= 1 && k <= 128;
 }
 static uint32_t ft_rec_cap(int64_t m) { return (uint32_t)std::min<int64_t>(3072, std::max<int64_t>(256, 3 * m)); }
@@ -498,30 +507,53 @@ size_t flat_f32_tfilter_scratch(int64_t nq)
     return (size_t)m * (FT_SLOTS + 6) * sizeof(uint32_t) + (size_t)m * FT_CAP * sizeof(uint2) + (size_t)FT_GRID * FT_WAVES * (sizeof(uint32_t) + (size_t)ft_rec_cap(m) * 80) + 1024;
 }
 
-template <int NCH, int NPROD, int RT>
+template <int NCH, int NPROD, int RT, int NW = FT_WAVES>
 static int ft_launch(bool maxmode, const FtArgs &a, size_t lds, hipStream_t st)
 {
     static std::atomic<bool> attr_a[16] = {}, attr_b[16] = {};
     if (maxmode) {
-        CVTMI_TRY(fs_set_lds((const void *)flat_f32_tfilter_kernel<NCH, NPROD, RT, true>, 163840, attr_a));
-        hipLaunchKernelGGL((flat_f32_tfilter_kernel<NCH, NPROD, RT, true>), dim3(FT_GRID), dim3(64 * FT_WAVES), lds, st, a);
+        CVTMI_TRY(fs_set_lds((const void *)flat_f32_tfilter_kernel<NCH, NPROD, RT, true, NW>, 163840, attr_a));
+        hipLaunchKernelGGL((flat_f32_tfilter_kernel<NCH, NPROD, RT, true, NW>), dim3(FT_GRID), dim3(64 * NW), lds, st, a);
     } else {
-        CVTMI_TRY(fs_set_lds((const void *)flat_f32_tfilter_kernel<NCH, NPROD, RT, false>, 163840, attr_b));
-        hipLaunchKernelGGL((flat_f32_tfilter_kernel<NCH, NPROD, RT, false>), dim3(FT_GRID), dim3(64 * FT_WAVES), lds, st, a);
+        CVTMI_TRY(fs_set_lds((const void *)flat_f32_tfilter_kernel<NCH, NPROD, RT, false, NW>, 163840, attr_b));
+        hipLaunchKernelGGL((flat_f32_tfilter_kernel<NCH, NPROD, RT, false, NW>), dim3(FT_GRID), dim3(64 * NW), lds, st, a);
     }
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
+// products a width can multiply (two / three need both terms of a row tile in registers)
+static int ft_products(int D, int want)
+{
+    const int most = D <= 128 ? 3 : (D <= 256 ? 2 : 1);
+    return want < most ? want : most;
+}
 static int ft_launch_any(int D, int nprod, bool maxmode, const FtArgs &a, size_t lds, hipStream_t st)
 {
-    if (D == 128) {
-        if (nprod == 3) return ft_launch<8, 3, 2>(maxmode, a, lds, st);
-        if (nprod == 2) return ft_launch<8, 2, 2>(maxmode, a, lds, st);
-        return ft_launch<8, 1, 3>(maxmode, a, lds, st);
+    switch (D / 16 * 4 + nprod) {
+    case 2 * 4 + 1: return ft_launch<2, 1, 4>(maxmode, a, lds, st);
+    case 2 * 4 + 2: return ft_launch<2, 2, 4>(maxmode, a, lds, st);
+    case 2 * 4 + 3: return ft_launch<2, 3, 4>(maxmode, a, lds, st);
+    case 4 * 4 + 1: return ft_launch<4, 1, 4>(maxmode, a, lds, st);
+    case 4 * 4 + 2: return ft_launch<4, 2, 3>(maxmode, a, lds, st);
+    case 4 * 4 + 3: return ft_launch<4, 3, 3>(maxmode, a, lds, st);
+    case 6 * 4 + 1: return ft_launch<6, 1, 3>(maxmode, a, lds, st);
+    case 6 * 4 + 2: return ft_launch<6, 2, 2>(maxmode, a, lds, st);
+    case 6 * 4 + 3: return ft_launch<6, 3, 2>(maxmode, a, lds, st);
+    case 8 * 4 + 1: return ft_launch<8, 1, 3>(maxmode, a, lds, st);
+    case 8 * 4 + 2: return ft_launch<8, 2, 2>(maxmode, a, lds, st);
+    case 8 * 4 + 3: return ft_launch<8, 3, 2>(maxmode, a, lds, st);
+    case 10 * 4 + 1: return ft_launch<10, 1, 3>(maxmode, a, lds, st);
+    case 10 * 4 + 2: return ft_launch<10, 2, 1>(maxmode, a, lds, st);
+    case 12 * 4 + 1: return ft_launch<12, 1, 2>(maxmode, a, lds, st);
+    case 12 * 4 + 2: return ft_launch<12, 2, 1>(maxmode, a, lds, st);
+    case 16 * 4 + 1: return ft_launch<16, 1, 2>(maxmode, a, lds, st);
+    case 16 * 4 + 2: return ft_launch<16, 2, 1>(maxmode, a, lds, st);
+    case 24 * 4 + 1: return ft_launch<24, 1, 1>(maxmode, a, lds, st);
+    case 32 * 4 + 1: return ft_launch<32, 1, 1>(maxmode, a, lds, st);
+    case 48 * 4 + 1: return ft_launch<48, 1, 1, 4>(maxmode, a, lds, st);   // 768-d, 1024-d: one wave per SIMD (512 registers)
+    case 64 * 4 + 1: return ft_launch<64, 1, 1, 4>(maxmode, a, lds, st);   // 1024-d: a row tile's 64 K steps take 256 registers -- one wave per SIMD
     }
-    if (nprod == 3) return ft_launch<4, 3, 3>(maxmode, a, lds, st);
-    if (nprod == 2) return ft_launch<4, 2, 3>(maxmode, a, lds, st);
-    return ft_launch<4, 1, 4>(maxmode, a, lds, st);
+    return fail(CVTMI_EINVAL, "flat_f32_tfilter: no kernel for D=%d with %d products", D, nprod);
 }
 
 // nq queries against rows [0, n); results for the queries whose redo flag stays 0 (redo[nq] is zeroed here)
@@ -530,7 +562,7 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
 {
     if (!flat_f32_tfilter_applies(metric, D, n, nq, k)) return fail(CVTMI_EINVAL, "flat_f32_tfilter: D=%d nq=%lld", D, (long long)nq);
     const int mode = g_ft_on.load();
-    const int nprod = mode == 4 ? (nq <= g_ft_one_max.load() ? 1 : 2) : mode;
+    const int nprod = ft_products(D, mode == 4 ? (nq <= g_ft_one_max.load() ? 1 : 2) : mode);
     const int nt = nprod == 3 ? 2 : 1;
     const int qcap = std::min(32 * FT_NBMAX, (int)((size_t)(160 * 1024 - 32 * FT_NBMAX * 4 - FT_SLACK) / ((size_t)(D / 16) * nt * 1024)) * 32);   // queries a workgroup holds
     CVTMI_HIP(hipMemsetAsync(redo, 0, (size_t)nq * sizeof(uint32_t), st));
@@ -541,7 +573,8 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
         int chunks = 1;
         while (chunks < 32 && (m + chunks - 1) / chunks > qcap) chunks *= 2;
         const int qper = (int)(((m + chunks - 1) / chunks + 31) / 32 * 32);
-        const uint32_t cap = ft_rec_cap(m);
+        const int nw = D > 512 ? 4 : FT_WAVES;   // waves per workgroup of the filter kernel
+        const uint32_t cap = ft_rec_cap(m) * (uint32_t)(FT_WAVES / nw);   // (the record area is the same: fewer, larger regions)
         uint32_t *smax = reinterpret_cast<uint32_t *>(scratch);
         float *thr = reinterpret_cast<float *>(smax + (size_t)m * FT_SLOTS);
         float *qbnd = thr + m;
@@ -563,7 +596,7 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
         a.t1 = n_tiles;
         CVTMI_TRY(ft_launch_any(D, nprod, false, a, lds, st));
         if (a.dbg & 8) continue;   // timing experiments: the filter passes alone (results stale)
-        hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), 0, st, rec, wcnt, cap, thr, cnt, cand, chunks, qper, (int)m, redo + a0);
+        hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), 0, st, rec, wcnt, cap, thr, cnt, cand, chunks, qper, (int)m, redo + a0, nw);
         if (metric == CVTMI_METRIC_IP)
             hipLaunchKernelGGL((ft_finish_kernel<true, 4>), dim3((unsigned)m), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0);
         else

@@ -967,6 +967,35 @@ def test_flat_f32_threshold_filter(amd, orc, metric, D, k, prods):
     assert np.array_equal(is2[:4], oi) and np.array_equal(bits(ds2[:4]), bits(od))
 
 
+@pytest.mark.parametrize("metric,D,nq,k", [(L2F, 32, 300, 100), (IP, 96, 64, 10), (L2F, 160, 200, 100), (IP, 192, 700, 50), (L2F, 256, 129, 128),
+                                            (IP, 384, 100, 100), (L2F, 512, 520, 20), (IP, 512, 33, 100), (L2F, 768, 150, 10), (IP, 1024, 100, 100),
+                                            (L2F, 1024, 1100, 5)])
+def test_flat_f32_threshold_filter_widths(amd, orc, metric, D, nq, k):
+    """the threshold filter at every width it takes (32 ... 1024-d; 768 / 1024-d with one wave per SIMD), products as the dispatch picks
+    them, against the exact kernels on every query and the checker on three: ragged row count, duplicates, queries that are rows"""
+    rng = np.random.default_rng(D + nq + k + metric)
+    n = 262_144 + 1_000 + 13
+    x = _clustered(rng, n, D, metric)
+    x[100_000:100_140] = x[5]
+    x[n - 1] = x[123]
+    q = (x[rng.integers(0, n, nq)] + 0.05 * rng.normal(size=(nq, D))).astype(np.float32)
+    q[0] = x[5]; q[3] = x[123]
+    q = np.ascontiguousarray(q, np.float32)
+    try:
+        ix = amd.FlatIndex(metric, D); ix.add(x)
+        ds, is_ = ix.search(q, k)
+        assert ix.last_search()[0] == 3
+        amd.set_tuning("flat_variant", 1)
+        de, ie = ix.search(q, k)
+        assert ix.last_search()[0] == 0
+        ix.close()
+    finally:
+        amd.set_tuning("flat_variant", 0)
+    assert np.array_equal(is_, ie) and np.array_equal(bits(ds), bits(de))
+    od, _, oi = orc.flat_search(metric, x, q[:3], k, flavour=4 if metric == IP else 8)
+    assert np.array_equal(is_[:3], oi) and np.array_equal(bits(ds[:3]), bits(od))
+
+
 def test_flat_f32_threshold_filter_hands_hard_queries_to_the_exact_kernels(amd):
     """what the filter's bound does not cover is re-run by the exact kernels inside the same call, per query: non-finite queries, a
     query 2^70 times larger than the rows, masses of exact ties around the k-th place (more rows at the threshold than a list
