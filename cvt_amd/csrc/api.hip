@@ -171,6 +171,7 @@ struct cvtmi_flat_s {
     // matrix-core filter of the fp32 search (flat_mfma.hip): bf16 operand copy of the rows, built on first use
     DevBuf f_pack, f_bias, f_istats;   // f_istats: [0] max |x|^2, [1] rows with a non-finite value (of the operand copy)
     int64_t f_pack_n = -1;      // rows the copy covers (-1: none)
+    int f_pack_nch = 0;         // its K steps per row (the threshold filter of a width between two kernels pads with zeros)
     bool f_nonfinite = false;   // a row holds inf / NaN: the filter is not used
     std::atomic<int> f_last_filtered{0};    // how the last search was answered (0 exact, 1 filter pipeline, 2 fp32 stream, 3 fp32 threshold filter)
     std::atomic<long long> f_last_worst{0};  // its largest candidate list
@@ -1803,8 +1804,10 @@ static int flat_search_rows(cvtmi_flat_t h, FlatScratch &S, int64_t n_rows, cons
     const int qt = mfma ? flat_u8_mfma_qtile(h->D, k, nq) : (k > 128 ? 1 : flat_qtile(nq));   // k > 128: one query per workgroup (kernels.h: kBigK)
     int splits = mfma ? flat_u8_mfma_splits(n_rows, nq, qt) : flat_plan_splits(n_rows, nq, qt);
     if (mfma && splits >= 8) splits = (splits / 8) * 8;  // a row split per XCD: query groups share its L2
-    // a predicated re-run normally finds nothing to do: keep its grid small (an empty workgroup still costs a dispatch)
-    if (only_if) splits = (int)std::max<int64_t>(std::min<int64_t>(splits, 8), std::min<int64_t>(splits, 128 / ((nq + qt - 1) / qt)));
+    // a predicated re-run normally finds nothing to do, and what it finds is a few queries: its row splits do not follow the plan for the
+    // whole batch (1000 queries: one or two splits -- ONE flagged query then waited for a single workgroup to read every row: 5 ms on
+    // 0.5 GB of 300-d rows) but are 32 wherever the rows allow it; an empty workgroup costs a dispatch and the read of its flags
+    if (only_if && !mfma) splits = (int)std::max<int64_t>(1, std::min<int64_t>(32, n_rows / 8192));
     float *pd = dist;
     int64_t *pi = rows;
     if (splits > 1) {
@@ -1833,7 +1836,7 @@ static int flat_search_streamed(cvtmi_flat_t h, FlatScratch &S, const float *q, 
     const int D = h->D;
     const int64_t n = h->n;
     if (!h->fs_bias.p || !h->fs_stats.p || h->fs_stats_n != n || h->fs_nonfinite) return CVTMI_OK;
-    if (flat_f32_tfilter_applies(h->metric, D, n, nq, k) && h->f_pack.p && h->f_pack_n == n && !h->f_nonfinite &&
+    if (flat_f32_tfilter_applies(h->metric, D, n, nq, k) && h->f_pack.p && h->f_pack_n == n && h->f_pack_nch == flat_f32_tfilter_nch(D) && !h->f_nonfinite &&
         S.fs_scratch.reserve(flat_f32_tfilter_scratch(nq)) == CVTMI_OK) {
         // large batches (round 6, flat_f32_tfilter.hip): sample maxima -> per-query threshold -> barrier-free threshold filter (queries in
         // LDS, the rows' bf16 operand copy in registers) -> exact distances of the candidates; flagged queries go through the exact
@@ -1873,7 +1876,7 @@ static int flat_search_filtered(cvtmi_flat_t h, FlatScratch &S, const float *q, 
     *done = false;
     const int D = h->D;
     const int64_t n = h->n;
-    if (h->f_pack_n != n || h->f_nonfinite) return CVTMI_OK;   // no operand copy (flat_prepare could not build it) / non-finite rows: exact path
+    if (h->f_pack_n != n || h->f_pack_nch != D / 16 || h->f_nonfinite) return CVTMI_OK;   // no operand copy (flat_prepare could not build it) / non-finite rows: exact path
     CVTMI_TRY(S.f_stats.reserve(16));
     CVTMI_HIP(hipMemcpyAsync(S.f_stats.p, h->f_istats.p, 8, hipMemcpyDeviceToDevice, st));   // [0] max |x|^2, [1] non-finite rows; [2], [3] are this call's
     // 1. exact search of a leading sample: its k-th best bounds the global k-th best
@@ -2044,12 +2047,15 @@ static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStr
     for (int attempt = 0; attempt < 2; ++attempt) {
         FlatRoute r;
         bool need_fs, need_f32, need_u8;
+        int want_nch = 0;
         {
             std::shared_lock<std::shared_timed_mutex> rd(h->rw);
             r = flat_route(h, q, nq, k, tun);
             need_fs = (r.stream || r.tfilter) && h->fs_stats_n != h->n;
             const bool tf = r.tfilter && !h->fs_nonfinite;   // the threshold filter reads the copy too
-            need_f32 = h->f_pack_n != h->n && (tf ? !need_fs : (r.filt_f32 && !(r.stream && !need_fs && !h->fs_nonfinite)));   // (the stream answers: no copy needed)
+            want_nch = tf ? flat_f32_tfilter_nch(h->D) : h->D / 16;
+            need_f32 = (h->f_pack_n != h->n || h->f_pack_nch != want_nch) &&
+                       (tf ? !need_fs : (r.filt_f32 && !(r.stream && !need_fs && !h->fs_nonfinite)));   // (the stream answers: no copy needed)
             need_u8 = r.filt_u8 && h->f_pack_n != h->n;
             if (!need_fs && !need_f32 && !need_u8) return CVTMI_OK;
         }
@@ -2063,17 +2069,19 @@ static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStr
             h->fs_stats_n = n;
             continue;   // the route may not need an operand copy after all
         }
-        if (need_f32 && h->f_pack_n != n) {   // bf16 operand copy of the rows (same bytes as the fp32 rows)
-            if (h->f_pack.reserve(flat_pack_bytes(h->D, n)) != CVTMI_OK) return CVTMI_OK;   // no room: the exact path answers
+        if (need_f32 && (h->f_pack_n != n || h->f_pack_nch != want_nch)) {   // bf16 operand copy of the rows (same bytes as the fp32 rows)
+            h->f_pack_n = -1;
+            if (h->f_pack.reserve(flat_pack_bytes(want_nch, n)) != CVTMI_OK) return CVTMI_OK;   // no room: the exact path answers
             CVTMI_TRY(h->f_bias.reserve((size_t)((n + 31) / 32) * 32 * sizeof(uint32_t)));
             CVTMI_TRY(h->f_istats.reserve(16));
-            CVTMI_TRY(launch_flat_pack(h->data.as<float>(), n, h->D, h->metric, h->f_pack.as<uint4>(), h->f_bias.as<uint32_t>(),
+            CVTMI_TRY(launch_flat_pack(h->data.as<float>(), n, h->D, want_nch, h->metric, h->f_pack.as<uint4>(), h->f_bias.as<uint32_t>(),
                                        h->f_istats.as<uint32_t>(), st));
             uint32_t stats[2] = { 0, 0 };
             CVTMI_HIP(hipMemcpyAsync(stats, h->f_istats.p, sizeof stats, hipMemcpyDeviceToHost, st));
             CVTMI_HIP(stream_wait(st));
             h->f_nonfinite = stats[1] != 0 || !(__builtin_bit_cast(float, stats[0]) <= 3.0e38f);
             h->f_pack_n = n;
+            h->f_pack_nch = want_nch;
         }
         if (need_u8 && h->f_pack_n != n) {    // operand-ordered copy of the rows (x - 128 as int8)
             if (h->f_pack.reserve(flat_u8_pack_bytes(h->D, n)) != CVTMI_OK) return CVTMI_OK;

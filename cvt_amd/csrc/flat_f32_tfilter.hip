@@ -66,6 +66,7 @@ struct FtArgs {
     const float *bias;       // b_x per row (padding rows: FS_PAD_BIAS)
     int64_t t1, n_tiles;     // tiles [0, t1) of n_tiles
     const float *Q;
+    int D;                   // floats per query (<= 16 NCH: the operands are zero beyond it)
     int nq, chunks, qper;    // queries of chunk c: [c qper, min(nq, (c + 1) qper)), qper a multiple of 32
     uint32_t *smax;          // MAX mode: [nq][FT_SLOTS] ordered keys (zeroed by the caller)
     const float *thr;        // FILTER mode: [nq] (NaN: nothing passes)
@@ -98,7 +99,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
 {
     constexpr int NT = NPROD == 3 ? 2 : 1;    // terms of a query in LDS
     constexpr int NA = NPROD >= 2 ? 2 : 1;    // terms of a row in registers
-    constexpr int D = 16 * NCH;
     extern __shared__ __attribute__((aligned(16))) uint8_t ft_q[];   // [block][K step][term] x 1 KB, then the blocks' thresholds
     const int tid = threadIdx.x, lane = tid & 63, lj = lane & 31, lk = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,10 +117,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     for (int i = tid; i < nb * 32 * NCH * 2; i += 64 * NW) {   // (query, K step, half) -> its 16-byte slots of the terms
         const int hl = i & 1, ss = (i >> 1) % NCH, qq = i / (2 * NCH);
         const int qi = q0 + (qq < nqc ? qq : nqc - 1);
-        const float *qp = a.Q + (int64_t)qi * D + 16 * ss + 8 * hl;
-        float v[8];
-        *reinterpret_cast<float4 *>(&v[0]) = *reinterpret_cast<const float4 *>(qp);
-        *reinterpret_cast<float4 *>(&v[4]) = *reinterpret_cast<const float4 *>(qp + 4);
+        const int e0 = 16 * ss + 8 * hl;
+        const float *qp = a.Q + (int64_t)qi * a.D + e0;
+        float v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // (widths between two kernels' K steps: zeros beyond D, as in the rows' operand copy)
+        if (e0 < a.D) *reinterpret_cast<float4 *>(&v[0]) = *reinterpret_cast<const float4 *>(qp);
+        if (e0 + 4 < a.D) *reinterpret_cast<float4 *>(&v[4]) = *reinterpret_cast<const float4 *>(qp + 4);
         bf16x8 h, l;
         fs_split(v, h, l);
         uint8_t *dst = ft_q + ((size_t)(((qq >> 5) * NCH + ss) * NT) * 1024) + (size_t)(hl * 32 + (qq & 31)) * 16;
@@ -493,8 +494,18 @@ static std::atomic<int> g_ft_min_nq{16};   // cvtmi_set_tuning("flat_f32_tfilter
 void set_flat_f32_tfilter(int v) { g_ft_on = v < 0 ? 0 : (v > 4 ? 4 : v); }
 void set_flat_f32_tfilter_one(int v) { g_ft_one_max = v < 0 ? 0 : v; }
 void set_flat_f32_tfilter_min(int v) { g_ft_min_nq = v < 1 ? 1 : v; }
-// widths: D / 16 K steps of a row tile stay in a wave's registers (RT tiles of 32 rows: RT x D / 16 x terms x 4 registers <= 128)
-bool flat_f32_tfilter_width(int D) { return D == 32 || D == 64 || D == 96 || D == 128 || D == 160 || D == 192 || D == 256 || D == 384 || D == 512 || D == 768 || D == 1024; }
+// widths: the K steps (16 dimensions each) of a row tile stay in a wave's registers (RT tiles of 32 rows: RT x K steps x terms x 4 registers
+// <= 128, 256 with one wave per SIMD).  A kernel exists for 2 / 4 / 6 / 8 / 10 / 12 / 16 / 24 / 32 / 48 / 64 K steps; a width in between (any
+// multiple of 4 up to 1024: 100-d, 200-d, 300-d ...) runs on the next one over zero-padded operands.  0: no kernel
+int flat_f32_tfilter_nch(int D)
+{
+    static const int steps[] = { 2, 4, 6, 8, 10, 12, 16, 24, 32, 48, 64 };
+    if (D < 4 || D > 1024 || D % 4 != 0) return 0;
+    for (int s_ : steps)
+        if (16 * s_ >= D) return s_;
+    return 0;
+}
+bool flat_f32_tfilter_width(int D) { return flat_f32_tfilter_nch(D) != 0; }
 bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k)
 {
     return g_ft_on.load() && (metric == CVTMI_METRIC_IP || metric == CVTMI_METRIC_L2F) && flat_f32_tfilter_width(D) && n >= 262144 && n < 0xffffffe0LL &&
@@ -524,12 +535,12 @@ static int ft_launch(bool maxmode, const FtArgs &a, size_t lds, hipStream_t st)
 // products a width can multiply (two / three need both terms of a row tile in registers)
 static int ft_products(int D, int want)
 {
-    const int most = D <= 128 ? 3 : (D <= 256 ? 2 : 1);
+    const int nch = flat_f32_tfilter_nch(D), most = nch <= 8 ? 3 : (nch <= 16 ? 2 : 1);
     return want < most ? want : most;
 }
 static int ft_launch_any(int D, int nprod, bool maxmode, const FtArgs &a, size_t lds, hipStream_t st)
 {
-    switch (D / 16 * 4 + nprod) {
+    switch (flat_f32_tfilter_nch(D) * 4 + nprod) {
     case 2 * 4 + 1: return ft_launch<2, 1, 4>(maxmode, a, lds, st);
     case 2 * 4 + 2: return ft_launch<2, 2, 4>(maxmode, a, lds, st);
     case 2 * 4 + 3: return ft_launch<2, 3, 4>(maxmode, a, lds, st);
@@ -564,7 +575,8 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
     const int mode = g_ft_on.load();
     const int nprod = ft_products(D, mode == 4 ? (nq <= g_ft_one_max.load() ? 1 : 2) : mode);
     const int nt = nprod == 3 ? 2 : 1;
-    const int qcap = std::min(32 * FT_NBMAX, (int)((size_t)(160 * 1024 - 32 * FT_NBMAX * 4 - FT_SLACK) / ((size_t)(D / 16) * nt * 1024)) * 32);   // queries a workgroup holds
+    const int nch = flat_f32_tfilter_nch(D);
+    const int qcap = std::min(32 * FT_NBMAX, (int)((size_t)(160 * 1024 - 32 * FT_NBMAX * 4 - FT_SLACK) / ((size_t)nch * nt * 1024)) * 32);   // queries a workgroup holds
     CVTMI_HIP(hipMemsetAsync(redo, 0, (size_t)nq * sizeof(uint32_t), st));
     const int64_t n_tiles = (n + 31) / 32;
     const int64_t ts = std::min<int64_t>(n_tiles, std::max<int64_t>(2048, n_tiles / 8));   // the sample: an eighth of the rows, at least 65 536
@@ -573,7 +585,7 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
         int chunks = 1;
         while (chunks < 32 && (m + chunks - 1) / chunks > qcap) chunks *= 2;
         const int qper = (int)(((m + chunks - 1) / chunks + 31) / 32 * 32);
-        const int nw = D > 512 ? 4 : FT_WAVES;   // waves per workgroup of the filter kernel
+        const int nw = nch > 32 ? 4 : FT_WAVES;   // waves per workgroup of the filter kernel
         const uint32_t cap = ft_rec_cap(m) * (uint32_t)(FT_WAVES / nw);   // (the record area is the same: fewer, larger regions)
         uint32_t *smax = reinterpret_cast<uint32_t *>(scratch);
         float *thr = reinterpret_cast<float *>(smax + (size_t)m * FT_SLOTS);
@@ -585,9 +597,9 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
         CVTMI_HIP(hipMemsetAsync(smax, 0, (size_t)m * FT_SLOTS * sizeof(uint32_t), st));
         CVTMI_HIP(hipMemsetAsync(cnt, 0, (size_t)m * sizeof(uint32_t), st));
         FtArgs a;
-        a.pack = reinterpret_cast<const uint4 *>(pack); a.bias = bias; a.n_tiles = n_tiles; a.Q = q + a0 * D; a.nq = (int)m; a.chunks = chunks; a.qper = qper;
+        a.pack = reinterpret_cast<const uint4 *>(pack); a.bias = bias; a.n_tiles = n_tiles; a.Q = q + a0 * D; a.D = D; a.nq = (int)m; a.chunks = chunks; a.qper = qper;
         a.smax = smax; a.thr = thr; a.rec = rec; a.wcnt = wcnt; a.cap = cap; a.dbg = get_flat_f32_dbg();
-        const size_t lds = (size_t)(qper / 32) * (D / 16) * nt * 1024 + FT_SLACK + (size_t)qper * sizeof(float);
+        const size_t lds = (size_t)(qper / 32) * nch * nt * 1024 + FT_SLACK + (size_t)qper * sizeof(float);
         a.t1 = ts;
         CVTMI_TRY(ft_launch_any(D, nprod, true, a, lds, st));
         const unsigned tg = (unsigned)((m + 3) / 4);
@@ -599,8 +611,10 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
         hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), 0, st, rec, wcnt, cap, thr, cnt, cand, chunks, qper, (int)m, redo + a0, nw);
         if (metric == CVTMI_METRIC_IP)
             hipLaunchKernelGGL((ft_finish_kernel<true, 4>), dim3((unsigned)m), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0);
-        else
+        else if (D % 16 == 0)   // (the reference's L2 sums in 8 lanes when D % 16 == 0, in 4 lanes otherwise: space_l2.h:40-151)
             hipLaunchKernelGGL((ft_finish_kernel<false, 8>), dim3((unsigned)m), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0);
+        else
+            hipLaunchKernelGGL((ft_finish_kernel<false, 4>), dim3((unsigned)m), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0);
         CVTMI_HIP(hipGetLastError());
         if (getenv("CVTMI_FT_DEBUG")) {   // counts of the pass (synchronises)
             CVTMI_HIP(hipStreamSynchronize(st));

@@ -43,21 +43,21 @@ __device__ __forceinline__ float blocked_at(const float *X, int D, int64_t row, 
 
 // one thread per (tile, lane): lane (li, lk) of tile t owns row 32 t + li, dimensions 16 c + 8 lk .. + 8 of chunk c.
 // stats[0] = max |x|^2 (uint bits), stats[1] = number of rows holding a non-finite value, stats[2] = max |x - x1|^2 (x1: the first bf16 term)
-__global__ __launch_bounds__(kBlock) void flat_pack_kernel(const float *__restrict__ X, int64_t n, int D, int l2, int64_t ntiles,
+__global__ __launch_bounds__(kBlock) void flat_pack_kernel(const float *__restrict__ X, int64_t n, int D, int nch, int l2, int64_t ntiles,
                                                            uint4 *__restrict__ pack, uint32_t *__restrict__ bias,
                                                            uint32_t *__restrict__ stats)
 {
     const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (g >= ntiles * 64) return;
     const int64_t t = g >> 6;
-    const int lane = (int)(g & 63), li = lane & 31, lk = lane >> 5, nch = D / 16;
+    const int lane = (int)(g & 63), li = lane & 31, lk = lane >> 5;   // nch K steps of 16 dimensions (>= D / 16: zeros beyond D)
     const int64_t row = t * 32 + li;
     bool finite = true;
     for (int c = 0; c < nch; ++c) {
         union { bf16x8 v; uint4 u; } h1, h2;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = row < n ? blocked_at(X, D, row, 16 * c + 8 * lk + e) : 0.0f;
+            const float v = (row < n && 16 * c + 8 * lk + e < D) ? blocked_at(X, D, row, 16 * c + 8 * lk + e) : 0.0f;
             finite = finite && (fabsf(v) <= 3.0e38f);
             const __bf16 a = (__bf16)v;
             h1.v[e] = a;
@@ -1424,13 +1424,13 @@ bool flat_filter_applies(int metric, int D, int64_t n, int64_t nq, int k)
            k <= 128;   // from 16 queries: 1 M x 128-d nq = 16 / 32 took 0.40-0.46 / 0.63-0.71 ms on the exact kernels, 0.42-0.44 through the filter
 }
 
-size_t flat_pack_bytes(int D, int64_t n) { return (size_t)((n + 31) / 32) * (D / 16) * 2 * 64 * sizeof(uint4); }
+size_t flat_pack_bytes(int nch, int64_t n) { return (size_t)((n + 31) / 32) * nch * 2 * 64 * sizeof(uint4); }
 
-int launch_flat_pack(const float *X, int64_t n, int D, int metric, uint4 *pack, uint32_t *bias, uint32_t *stats, hipStream_t st)
+int launch_flat_pack(const float *X, int64_t n, int D, int nch, int metric, uint4 *pack, uint32_t *bias, uint32_t *stats, hipStream_t st)
 {
     const int64_t ntiles = (n + 31) / 32;
     CVTMI_HIP(hipMemsetAsync(stats, 0, 12, st));
-    hipLaunchKernelGGL(flat_pack_kernel, dim3((unsigned)((ntiles * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, X, n, D,
+    hipLaunchKernelGGL(flat_pack_kernel, dim3((unsigned)((ntiles * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, X, n, D, nch,
                        metric == CVTMI_METRIC_L2F ? 1 : 0, ntiles, pack, bias, stats);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;

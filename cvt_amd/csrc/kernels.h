@@ -187,8 +187,8 @@ int launch_flat_u8_norms(const uint8_t *x, int64_t n, int D, int32_t *norms, hip
 inline bool flat_blocked(int metric, int D) { return metric != CVTMI_METRIC_L2U8 && (D % 4) == 0; }
 // flat_mfma.hip: fp32 IP / L2 search through the bf16 matrix-core filter (32 <= D <= 128, D % 16 == 0, nq >= 64)
 bool flat_filter_applies(int metric, int D, int64_t n, int64_t nq, int k);
-size_t flat_pack_bytes(int D, int64_t n);
-int launch_flat_pack(const float *X, int64_t n, int D, int metric, uint4 *pack, uint32_t *bias, uint32_t *stats, hipStream_t st);
+size_t flat_pack_bytes(int nch, int64_t n);   // nch K steps of 16 dimensions per row (>= D / 16: zeros beyond D)
+int launch_flat_pack(const float *X, int64_t n, int D, int nch, int metric, uint4 *pack, uint32_t *bias, uint32_t *stats, hipStream_t st);
 int launch_flat_thr(const float *q, int64_t nq, int D, int metric, const float *sample_d, int k, uint32_t *stats, float *thr,
                     float *margin, hipStream_t st);
 int launch_flat_filter(const float *q, int64_t nq, int D, const uint4 *pack, const uint32_t *bias, const float *thr, int64_t row_begin,
@@ -219,6 +219,7 @@ bool flat_f32_stream_applies(int metric, int D, int64_t n, int k);
 // round 6 (flat_f32_tfilter.hip): batches (D = 32 .. 512 in the widths of flat_f32_tfilter_width, >= 262 144 rows, k <= 128) as a threshold filter: queries in LDS, the rows'
 // bf16 operand copy (launch_flat_pack) in registers, per-query thresholds from sample maxima, candidate lists, exact finish;
 // redo[nq] (zeroed inside): 1 = the exact kernels must answer the query
+int flat_f32_tfilter_nch(int D);   // K steps of the kernel that takes D-dimensional rows (0: none)
 bool flat_f32_tfilter_width(int D);
 bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k);
 size_t flat_f32_tfilter_scratch(int64_t nq);

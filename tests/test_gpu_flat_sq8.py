@@ -969,10 +969,11 @@ def test_flat_f32_threshold_filter(amd, orc, metric, D, k, prods):
 
 @pytest.mark.parametrize("metric,D,nq,k", [(L2F, 32, 300, 100), (IP, 96, 64, 10), (L2F, 160, 200, 100), (IP, 192, 700, 50), (L2F, 256, 129, 128),
                                             (IP, 384, 100, 100), (L2F, 512, 520, 20), (IP, 512, 33, 100), (L2F, 768, 150, 10), (IP, 1024, 100, 100),
-                                            (L2F, 1024, 1100, 5)])
+                                            (L2F, 1024, 1100, 5), (IP, 100, 200, 100), (L2F, 100, 600, 10), (L2F, 20, 64, 100), (IP, 200, 128, 50),
+                                            (L2F, 300, 1000, 100), (IP, 900, 40, 100)])
 def test_flat_f32_threshold_filter_widths(amd, orc, metric, D, nq, k):
-    """the threshold filter at every width it takes (32 ... 1024-d; 768 / 1024-d with one wave per SIMD), products as the dispatch picks
-    them, against the exact kernels on every query and the checker on three: ragged row count, duplicates, queries that are rows"""
+    """the threshold filter at every width it takes (the kernels' 32 ... 1024-d, 768 / 1024-d with one wave per SIMD; widths in between --
+    100-d, 200-d, 300-d, 900-d, 20-d -- on the next kernel over zero-padded operands), products as the dispatch picks them, against the exact kernels on every query and the checker on three: ragged row count, duplicates, queries that are rows"""
     rng = np.random.default_rng(D + nq + k + metric)
     n = 262_144 + 1_000 + 13
     x = _clustered(rng, n, D, metric)
