@@ -65,6 +65,7 @@ struct FtArgs {
     const uint4 *pack;       // bf16 operand copy of the rows
     const float *bias;       // b_x per row (padding rows: FS_PAD_BIAS)
     int64_t t1, n_tiles;     // tiles [0, t1) of n_tiles
+    int gstride;             // MAX mode: the sample is every gstride-th group of RT tiles (rows arrive video by video: a leading block would be the first videos only)
     const float *Q;
     int D;                   // floats per query (<= 16 NCH: the operands are zero beyond it)
     int nq, chunks, qper;    // queries of chunk c: [c qper, min(nq, (c + 1) qper)), qper a multiple of 32
@@ -73,7 +74,9 @@ struct FtArgs {
     uint4 *rec;              // FILTER mode: [FT_GRID waves][cap] records of 5 x 16 bytes
     uint32_t *wcnt;          // FILTER mode: [FT_GRID waves] records a wave had (beyond cap: not stored)
     uint32_t cap;
-    int dbg;                 // timing experiments ("flat_f32_dbg"): 8 = the filter passes alone (results stale)
+    const uint32_t *qlist;   // second attempt (FILTER mode, chunks == 1): the pass's queries are qlist[0 .. min(*qcount, qper)) -- both on the device
+    const uint32_t *qcount;
+    int dbg;                 // "flat_f32_dbg": 8 = the filter passes alone (timing; results stale), 32 = thresholds loosened by 0.02 Q (tests: lists run over)
 };
 
 __device__ __forceinline__ float ft_max3(float a, float b, float c)
@@ -106,7 +109,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int chunk = idx % a.chunks, slices = 8 * ((int)(gridDim.x >> 3) / a.chunks), slice = xcd + 8 * (idx / a.chunks);
     const int q0 = chunk * a.qper;
-    const int nqc = a.nq - q0 < a.qper ? a.nq - q0 : a.qper;
+    int nq_all = a.nq;
+    if (a.qlist) {   // (wave-uniform: a scalar load)
+        const int listed = (int)*a.qcount;
+        nq_all = listed < a.qper ? listed : a.qper;
+    }
+    const int nqc = nq_all - q0 < a.qper ? nq_all - q0 : a.qper;
     const int wave_g = blockIdx.x * NW + wave;
     if (nqc <= 0) {
         if (!MAXMODE && lane == 0) a.wcnt[wave_g] = 0u;
@@ -116,7 +124,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     float *thr_s = reinterpret_cast<float *>(ft_q + (size_t)nb * NCH * NT * 1024 + FT_SLACK);
     for (int i = tid; i < nb * 32 * NCH * 2; i += 64 * NW) {   // (query, K step, half) -> its 16-byte slots of the terms
         const int hl = i & 1, ss = (i >> 1) % NCH, qq = i / (2 * NCH);
-        const int qi = q0 + (qq < nqc ? qq : nqc - 1);
+        int qi = q0 + (qq < nqc ? qq : nqc - 1);
+        if (a.qlist) qi = (int)a.qlist[qi];
         const int e0 = 16 * ss + 8 * hl;
         const float *qp = a.Q + (int64_t)qi * a.D + e0;
         float v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // (widths between two kernels' K steps: zeros beyond D, as in the rows' operand copy)
@@ -128,11 +137,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         *reinterpret_cast<bf16x8 *>(dst) = h;
         if constexpr (NT == 2) *reinterpret_cast<bf16x8 *>(dst + 1024) = l;
     }
+    uint32_t *id_s = reinterpret_cast<uint32_t *>(thr_s + nb * 32);   // the blocks' query numbers
     if constexpr (!MAXMODE)
-        for (int i = tid; i < nb * 32; i += 64 * NW) thr_s[i] = i < nqc ? a.thr[q0 + i] : __uint_as_float(0x7fc00000u);   // NaN: no comparison succeeds
+        for (int i = tid; i < nb * 32; i += 64 * NW) {
+            const uint32_t id = i < nqc ? (a.qlist ? a.qlist[q0 + i] : (uint32_t)(q0 + i)) : 0u;
+            id_s[i] = id;
+            thr_s[i] = i < nqc ? a.thr[id] : __uint_as_float(0x7fc00000u);   // NaN: no comparison succeeds
+        }
     __syncthreads();
     // groups of RT tiles: wave w of slice s takes groups s + slices (w + FT_WAVES i)
-    const int64_t n_groups = (a.t1 + RT - 1) / RT, stride = (int64_t)slices * NW;
+    const int64_t all_groups = (a.t1 + RT - 1) / RT, n_groups = MAXMODE ? (all_groups + a.gstride - 1) / a.gstride : all_groups, stride = (int64_t)slices * NW;
     // the second-dispatched half of the workgroup loses every arbitration by age: static priority for it (MI355X_MICROARCH.md "two waves
     // per SIMD"; measured 0.65 -> 0.59 ms on the filter passes of 1000 queries x 1 M rows)
     if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -168,7 +182,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         }
     };
     for (int64_t g = slice + (int64_t)slices * wave; g < n_groups; g += stride, ++it) {
-        fetch(g);
+        fetch(MAXMODE ? g * a.gstride : g);
         // (requesting the queries' operands two or three K steps ahead of their matrix instructions -- pinned with sched_barrier, across
         //  the block boundary -- or a block's operands at its start measured 0 .. 8 % SLOWER than the compiler's own order: read a K
         //  step's operands, wait, multiply; the partner wave of the SIMD covers the round trip)
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                             for (int j = 0; j < 4; ++j)
                                 dst[j] = make_uint4(__float_as_uint(acc[r][4 * j]), __float_as_uint(acc[r][4 * j + 1]), __float_as_uint(acc[r][4 * j + 2]),
                                                     __float_as_uint(acc[r][4 * j + 3]));
-                            dst[4] = make_uint4((uint32_t)(q0 + qq), (uint32_t)((g * RT + r) * 32 + 4 * lk), 0u, 0u);
+                            dst[4] = make_uint4(id_s[qq], (uint32_t)((g * RT + r) * 32 + 4 * lk), (uint32_t)qq, 0u);   // (query, first row, query within the chunk)
                         }
                     }
                 }
@@ -263,7 +277,7 @@ __device__ __forceinline__ float ft_qlow(const float *q, int D)
 // one wave per query: theta = the k-th largest of its sample maxima, thr = theta - margin (NaN + redo when the bound does not hold)
 template <bool IP>
 __global__ __launch_bounds__(256) void ft_theta_kernel(const uint32_t *__restrict__ smax, const float *__restrict__ Q, int nq, int D, int k, int nprod,
-                                                       const uint32_t *__restrict__ stats, const uint32_t *__restrict__ pstats, float *__restrict__ thr, float *__restrict__ qbnd,
+                                                       const uint32_t *__restrict__ stats, const uint32_t *__restrict__ pstats, float loosen, float *__restrict__ thr, float *__restrict__ qbnd,
                                                        uint32_t *__restrict__ redo)
 {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -282,7 +296,7 @@ __global__ __launch_bounds__(256) void ft_theta_kernel(const uint32_t *__restric
         const uint32_t sel = fs_wave_select(key, k, k + k / 4 + 8);
         if (sel != 0u) {   // at least k slots hold a row
             const float theta = key_f32(sel);
-            cut = theta - ft_margin<IP>(Qb, xq2, theta);
+            cut = theta - ft_margin<IP>(Qb, xq2, theta) - loosen * Qb;   // (loosen: test hook, "flat_f32_dbg" 32 -- lists run over, second attempts happen)
         }
     }
     if (lane == 0) {
@@ -300,18 +314,20 @@ __global__ __launch_bounds__(256) void ft_theta_kernel(const uint32_t *__restric
 constexpr int FT_BUCKET_T = 1024;
 __global__ __launch_bounds__(FT_BUCKET_T) void ft_bucket_kernel(const uint4 *__restrict__ rec, const uint32_t *__restrict__ wcnt, uint32_t cap,
                                                                 const float *__restrict__ thr, uint32_t *__restrict__ cnt, uint2 *__restrict__ cand,
-                                                                int chunks, int qper, int nq, uint32_t *__restrict__ redo, int nw)
+                                                                int chunks, int qper, int nq, uint32_t *__restrict__ redo, int nw,
+                                                                const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ qcount)
 {
     __shared__ uint32_t hist[32 * FT_NBMAX], base_s[32 * FT_NBMAX];
     const int j = blockIdx.x, tid = threadIdx.x;
     const int chunk = (j >> 3) % chunks, q0 = chunk * qper;
+    if (qlist) nq = (int)*qcount < qper ? (int)*qcount : qper;   // second attempt: one chunk of listed queries
     const int nqc = nq - q0 < qper ? nq - q0 : qper;
     if (nqc <= 0) return;
     for (int i = tid; i < nqc; i += FT_BUCKET_T) hist[i] = 0u;
     const int per = FT_BUCKET_T / nw, r = tid / per, t = tid % per;   // 128 (256) threads per wave region
     uint32_t n = wcnt[j * nw + r];
     if (n > cap) {   // the region ran full: the exact kernels answer the queries its workgroup held
-        for (int i = t; i < nqc; i += per) redo[q0 + i] = 1u;
+        for (int i = t; i < nqc; i += per) redo[qlist ? qlist[q0 + i] : (uint32_t)(q0 + i)] = 1u;
         n = cap;
     }
     const uint4 *rp = rec + (size_t)(j * nw + r) * cap * 5;
@@ -326,19 +342,19 @@ __global__ __launch_bounds__(FT_BUCKET_T) void ft_bucket_kernel(const uint4 *__r
             c += (__uint_as_float(s4.x) >= tb ? 1u : 0u) + (__uint_as_float(s4.y) >= tb ? 1u : 0u) + (__uint_as_float(s4.z) >= tb ? 1u : 0u) +
                  (__uint_as_float(s4.w) >= tb ? 1u : 0u);
         }
-        if (c) atomicAdd(&hist[h.x - (uint32_t)q0], c);
+        if (c) atomicAdd(&hist[h.z], c);
     }
     __syncthreads();
     for (int i = tid; i < nqc; i += FT_BUCKET_T) {
         const uint32_t c = hist[i];
-        base_s[i] = c ? atomicAdd(&cnt[q0 + i], c) : 0u;
+        base_s[i] = c ? atomicAdd(&cnt[qlist ? qlist[q0 + i] : (uint32_t)(q0 + i)], c) : 0u;
         hist[i] = 0u;
     }
     __syncthreads();
     for (uint32_t i = t; i < n; i += per) {
         const uint4 h = rp[(size_t)i * 5 + 4];
         const float tb = thr[h.x];
-        const uint32_t ql = h.x - (uint32_t)q0;
+        const uint32_t ql = h.z;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const uint4 s4 = rp[(size_t)i * 5 + jj];
@@ -366,24 +382,35 @@ __device__ __forceinline__ uint32_t ft_dist_key(float d)
 // row in the blocked layout) and are ranked by (distance, row) by counting.
 template <bool IP, int LANES>
 __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict__ X, int64_t n, int D, const float *__restrict__ Q, int k,
-                                                        const float *__restrict__ thr, const float *__restrict__ qbnd, const uint32_t *__restrict__ cnt,
+                                                        float *__restrict__ thr, const float *__restrict__ qbnd, uint32_t *__restrict__ cnt,
                                                         const uint2 *__restrict__ cand, float *__restrict__ out_d, int64_t *__restrict__ out_i,
-                                                        uint32_t *__restrict__ redo)
+                                                        uint32_t *__restrict__ redo, uint32_t *__restrict__ rcount, uint32_t *__restrict__ rlist, int rcap, int second, int nqb)
 {
     __shared__ unsigned long long sel[FT_KEEP];
     __shared__ __attribute__((aligned(16))) float q_s[FT_DMAX];
     __shared__ uint32_t hist[256];
     __shared__ uint32_t pick_s[2];
     __shared__ int m2_s;
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    int q = blockIdx.x;
+    if (second) {   // the queries the first attempt listed
+        if ((uint32_t)q >= *rcount || q >= rcap) return;
+        q = (int)rlist[q];
+    }
     const float cut = thr[q];
-    const uint32_t nc = cnt[q];
+    uint32_t nc = cnt[q];
     const int64_t want = k < n ? k : n;
     if (redo[q] != 0u) return;
-    if (!(cut == cut) || nc > (uint32_t)FT_CAP || (int64_t)nc < want) {   // workgroup-uniform: the exact kernels answer this query
+    // A list that ran over (a sharp shell of neighbours the sample's threshold does not see: 46 000 rows above it for one query of
+    // 1000 on clustered 300-d rows) still holds FT_CAP rows that reach the threshold: their k-th best is a lower bound of the k-th
+    // best score too, and a much tighter one.  The first attempt lists such a query for ONE second filter pass under the new
+    // threshold (rcap queries at most); the exact kernels -- a millisecond and more per query -- answer only what runs over twice.
+    const bool over = nc > (uint32_t)FT_CAP;
+    if (!(cut == cut) || (int64_t)nc < want || (over && (second || !rlist))) {   // workgroup-uniform: the exact kernels answer this query
         if (tid == 0) redo[q] = 1u;
         return;
     }
+    if (over) nc = (uint32_t)FT_CAP;
     for (int i = tid; i < D; i += 256) q_s[i] = Q[(int64_t)q * D + i];
     if (tid == 0) m2_s = 0;
     constexpr int PER = FT_CAP / 256;
@@ -436,7 +463,20 @@ __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict_
         __syncthreads();
     }
     const float theta = key_f32(prefix);
-    const float cut2 = theta - ft_margin<IP>(qbnd[q], qbnd[gridDim.x + q], theta);
+    const float cut2 = theta - ft_margin<IP>(qbnd[q], qbnd[nqb + q], theta);
+    if (over) {   // (workgroup-uniform)
+        if (tid == 0) {
+            const uint32_t pos = cut2 > cut ? atomicAdd(rcount, 1u) : 0xffffffffu;
+            if (pos < (uint32_t)rcap) {
+                thr[q] = cut2;
+                cnt[q] = 0u;
+                rlist[pos] = (uint32_t)q;
+            } else {
+                redo[q] = 1u;
+            }
+        }
+        return;
+    }
     const uint32_t cut2_key = f32_key(cut2);
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
@@ -488,11 +528,13 @@ __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict_
 
 // ---- host side ----
 static std::atomic<int> g_ft_on{4};        // cvtmi_set_tuning("flat_f32_tfilter"): 0 = the stream kernels for every batch, 1 .. 3 = products, 4 = choose
+static std::atomic<int> g_ft_retry{0};     // "flat_f32_tfilter_retry": 1 = a second filter pass for the queries whose candidate lists ran over, 0 (default) = the exact kernels at once
 static std::atomic<int> g_ft_one_max{512}; // "flat_f32_tfilter_one": largest batch that multiplies one product (the pass is bound by the rows it reads)
 static std::atomic<int> g_ft_min_nq{16};   // cvtmi_set_tuning("flat_f32_tfilter_min"): smallest batch that takes the pipeline (1 M x 128-d: 16 queries 0.119 -> 0.107 ms,
                                            // 128 queries 0.25 -> 0.16; below, the pipeline's five launches cost more than the stream's two)
 void set_flat_f32_tfilter(int v) { g_ft_on = v < 0 ? 0 : (v > 4 ? 4 : v); }
 void set_flat_f32_tfilter_one(int v) { g_ft_one_max = v < 0 ? 0 : v; }
+void set_flat_f32_tfilter_retry(int v) { g_ft_retry = v != 0; }
 void set_flat_f32_tfilter_min(int v) { g_ft_min_nq = v < 1 ? 1 : v; }
 // widths: the K steps (16 dimensions each) of a row tile stay in a wave's registers (RT tiles of 32 rows: RT x K steps x terms x 4 registers
 // <= 128, 256 with one wave per SIMD).  A kernel exists for 2 / 4 / 6 / 8 / 10 / 12 / 16 / 24 / 32 / 48 / 64 K steps; a width in between (any
@@ -515,7 +557,7 @@ static uint32_t ft_rec_cap(int64_t m) { return (uint32_t)std::min<int64_t>(3072,
 size_t flat_f32_tfilter_scratch(int64_t nq)
 {
     const int64_t m = std::min<int64_t>(nq, FT_PASS);
-    return (size_t)m * (FT_SLOTS + 6) * sizeof(uint32_t) + (size_t)m * FT_CAP * sizeof(uint2) + (size_t)FT_GRID * FT_WAVES * (sizeof(uint32_t) + (size_t)ft_rec_cap(m) * 80) + 1024;
+    return (size_t)m * (FT_SLOTS + 8) * sizeof(uint32_t) + (size_t)m * FT_CAP * sizeof(uint2) + (size_t)FT_GRID * FT_WAVES * (sizeof(uint32_t) + (size_t)ft_rec_cap(m) * 80) + 1024;
 }
 
 template <int NCH, int NPROD, int RT, int NW = FT_WAVES>
@@ -576,10 +618,11 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
     const int nprod = ft_products(D, mode == 4 ? (nq <= g_ft_one_max.load() ? 1 : 2) : mode);
     const int nt = nprod == 3 ? 2 : 1;
     const int nch = flat_f32_tfilter_nch(D);
-    const int qcap = std::min(32 * FT_NBMAX, (int)((size_t)(160 * 1024 - 32 * FT_NBMAX * 4 - FT_SLACK) / ((size_t)nch * nt * 1024)) * 32);   // queries a workgroup holds
+    const int qcap = std::min(32 * FT_NBMAX, (int)((size_t)(160 * 1024 - 32 * FT_NBMAX * 8 - FT_SLACK) / ((size_t)nch * nt * 1024)) * 32);   // queries a workgroup holds
     CVTMI_HIP(hipMemsetAsync(redo, 0, (size_t)nq * sizeof(uint32_t), st));
     const int64_t n_tiles = (n + 31) / 32;
-    const int64_t ts = std::min<int64_t>(n_tiles, std::max<int64_t>(2048, n_tiles / 8));   // the sample: an eighth of the rows, at least 65 536
+    // the sample: every sample_stride-th group of row tiles -- an eighth of the rows, at least ~65 536
+    const int sample_stride = (int)std::max<int64_t>(1, std::min<int64_t>(8, n_tiles / 2048));
     for (int64_t a0 = 0; a0 < nq; a0 += FT_PASS) {
         const int64_t m = std::min<int64_t>(nq - a0, FT_PASS);
         int chunks = 1;
@@ -591,30 +634,48 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
         float *thr = reinterpret_cast<float *>(smax + (size_t)m * FT_SLOTS);
         float *qbnd = thr + m;
         uint32_t *cnt = reinterpret_cast<uint32_t *>(qbnd + 2 * m);
-        uint32_t *wcnt = cnt + m + (m & 1);
+        uint32_t *rlist = cnt + m;                 // queries of the second attempt, their number in front of the wave counters
+        uint32_t *rcount = rlist + m;
+        uint32_t *wcnt = rcount + 1 + ((5 * m + 1) & 1);   // (the candidate lists behind the wave counters start on 8 bytes)
         uint2 *cand = reinterpret_cast<uint2 *>(wcnt + FT_GRID * FT_WAVES);
         uint4 *rec = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(cand + (size_t)m * FT_CAP) + 256 - (((uintptr_t)(cand + (size_t)m * FT_CAP)) & 15));
         CVTMI_HIP(hipMemsetAsync(smax, 0, (size_t)m * FT_SLOTS * sizeof(uint32_t), st));
-        CVTMI_HIP(hipMemsetAsync(cnt, 0, (size_t)m * sizeof(uint32_t), st));
+        CVTMI_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * m + 1) * sizeof(uint32_t), st));   // counters, list, its length
         FtArgs a;
         a.pack = reinterpret_cast<const uint4 *>(pack); a.bias = bias; a.n_tiles = n_tiles; a.Q = q + a0 * D; a.D = D; a.nq = (int)m; a.chunks = chunks; a.qper = qper;
-        a.smax = smax; a.thr = thr; a.rec = rec; a.wcnt = wcnt; a.cap = cap; a.dbg = get_flat_f32_dbg();
-        const size_t lds = (size_t)(qper / 32) * nch * nt * 1024 + FT_SLACK + (size_t)qper * sizeof(float);
-        a.t1 = ts;
+        a.smax = smax; a.thr = thr; a.rec = rec; a.wcnt = wcnt; a.cap = cap; a.qlist = nullptr; a.qcount = nullptr; a.dbg = get_flat_f32_dbg();
+        const size_t lds = (size_t)(qper / 32) * nch * nt * 1024 + FT_SLACK + (size_t)qper * 2 * sizeof(float);
+        a.t1 = n_tiles; a.gstride = sample_stride;   // MAX mode walks groups g * gstride below t1: set n_groups through t1
         CVTMI_TRY(ft_launch_any(D, nprod, true, a, lds, st));
         const unsigned tg = (unsigned)((m + 3) / 4);
-        if (metric == CVTMI_METRIC_IP) hipLaunchKernelGGL((ft_theta_kernel<true>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, thr, qbnd, redo + a0);
-        else hipLaunchKernelGGL((ft_theta_kernel<false>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, thr, qbnd, redo + a0);
-        a.t1 = n_tiles;
+        const float loosen = (a.dbg & 32) ? 0.02f : 0.0f;
+        if (metric == CVTMI_METRIC_IP) hipLaunchKernelGGL((ft_theta_kernel<true>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0);
+        else hipLaunchKernelGGL((ft_theta_kernel<false>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0);
+        a.t1 = n_tiles; a.gstride = 1;
         CVTMI_TRY(ft_launch_any(D, nprod, false, a, lds, st));
         if (a.dbg & 8) continue;   // timing experiments: the filter passes alone (results stale)
-        hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), 0, st, rec, wcnt, cap, thr, cnt, cand, chunks, qper, (int)m, redo + a0, nw);
-        if (metric == CVTMI_METRIC_IP)
-            hipLaunchKernelGGL((ft_finish_kernel<true, 4>), dim3((unsigned)m), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0);
-        else if (D % 16 == 0)   // (the reference's L2 sums in 8 lanes when D % 16 == 0, in 4 lanes otherwise: space_l2.h:40-151)
-            hipLaunchKernelGGL((ft_finish_kernel<false, 8>), dim3((unsigned)m), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0);
-        else
-            hipLaunchKernelGGL((ft_finish_kernel<false, 4>), dim3((unsigned)m), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0);
+        const bool retry = g_ft_retry.load() != 0;
+        const int rcap = std::min<int>(qcap, (int)((m + 31) / 32 * 32));   // queries one second attempt takes (a single chunk)
+        auto finish = [&](int second) {
+            const unsigned grid = second ? (unsigned)rcap : (unsigned)m;
+            uint32_t *rl = retry ? rlist : nullptr;
+            if (metric == CVTMI_METRIC_IP)
+                hipLaunchKernelGGL((ft_finish_kernel<true, 4>), dim3(grid), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m);
+            else if (D % 16 == 0)   // (the reference's L2 sums in 8 lanes when D % 16 == 0, in 4 lanes otherwise: space_l2.h:40-151)
+                hipLaunchKernelGGL((ft_finish_kernel<false, 8>), dim3(grid), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m);
+            else
+                hipLaunchKernelGGL((ft_finish_kernel<false, 4>), dim3(grid), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m);
+        };
+        hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), 0, st, rec, wcnt, cap, thr, cnt, cand, chunks, qper, (int)m, redo + a0, nw, nullptr, nullptr);
+        finish(0);
+        if (retry) {   // the queries whose lists ran over, under the thresholds their own candidates give (nothing listed: three empty launches)
+            FtArgs b = a;
+            b.qlist = rlist; b.qcount = rcount; b.chunks = 1; b.qper = rcap;
+            const size_t lds2 = (size_t)(rcap / 32) * nch * nt * 1024 + FT_SLACK + (size_t)rcap * 2 * sizeof(float);
+            CVTMI_TRY(ft_launch_any(D, nprod, false, b, lds2, st));
+            hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), 0, st, rec, wcnt, cap, thr, cnt, cand, 1, rcap, (int)m, redo + a0, nw, rlist, rcount);
+            finish(1);
+        }
         CVTMI_HIP(hipGetLastError());
         if (getenv("CVTMI_FT_DEBUG")) {   // counts of the pass (synchronises)
             CVTMI_HIP(hipStreamSynchronize(st));
@@ -628,8 +689,10 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
             for (auto v : hc) { sc += v; mc = std::max(mc, v); }
             for (auto v : hw) { sw += v; mw = std::max(mw, v); }
             for (auto v : hr) nr += v != 0;
-            fprintf(stderr, "ft debug: nprod %d m %lld chunks %d qper %d cap %u: candidates mean %.0f max %u; records total %.0f per wave max %u; redo %u; thr[0] %g\n",
-                    nprod, (long long)m, chunks, qper, cap, sc / m, mc, sw, mw, nr, ht[0]);
+            uint32_t hrc = 0;
+            CVTMI_HIP(hipMemcpy(&hrc, rcount, 4, hipMemcpyDeviceToHost));
+            fprintf(stderr, "ft debug: nprod %d m %lld chunks %d qper %d cap %u: candidates mean %.0f max %u; records total %.0f per wave max %u; second attempts %u; redo %u; thr[0] %g\n",
+                    nprod, (long long)m, chunks, qper, cap, sc / m, mc, sw, mw, hrc, nr, ht[0]);
         }
     }
     return CVTMI_OK;

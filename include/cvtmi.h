@@ -156,6 +156,10 @@ int cvtmi_set_device(int device);
  *                     batch.  1 M x 128-d, top-100: 1000 queries 0.97 -> 0.69 ms, 128 queries 0.25 -> 0.16 ms, 16 queries 0.119 -> 0.107 ms
  *   "flat_f32_tfilter_min"  smallest batch that takes that pipeline
  *   "flat_f32_tfilter_one"  largest batch that multiplies one product under "flat_f32_tfilter" 4
+ *   "flat_f32_tfilter_retry"  1 = a query whose candidate list ran over takes ONE second filter pass under the threshold its own stored
+ *                     candidates give (it helps when the rows above the sample's threshold are many, not when the rows inside the
+ *                     margin band are: measured no gain on clustered 300-d rows, three empty launches = ~10 us on every search);
+ *                     0 (default) = the exact kernels at once
  *   "flat_f32_share"  fp32 stream, batches beyond one wave's queries: 0 choose, 1 private rings only, 2 the shared-ring kernel,
  *                     3 = the shared ring with eight waves of 64 queries (512 queries per pass over the rows instead of 384; round 6,
  *                     measured: 385 .. 512 queries 0.74 -> 0.51 ms on 1 M x 128-d, 1000 queries unchanged -- its registers spill)

@@ -997,6 +997,31 @@ def test_flat_f32_threshold_filter_widths(amd, orc, metric, D, nq, k):
     assert np.array_equal(is_[:3], oi) and np.array_equal(bits(ds[:3]), bits(od))
 
 
+def test_flat_f32_threshold_filter_second_attempt(amd):
+    """candidate lists that run over: with "flat_f32_tfilter_retry" 1 such a query takes a second filter pass under the threshold its
+    stored candidates give ("flat_f32_dbg" 32 loosens the sample's thresholds so that lists do run over and second attempts succeed),
+    without it the exact kernels answer; masses of ties make no progress and go to the exact kernels either way.  Same lists"""
+    rng = np.random.default_rng(11)
+    n, D, nq, k = 280_000, 128, 200, 20
+    x = _clustered(rng, n, D, L2F)
+    x[5_000:11_000] = x[1]
+    q = (x[rng.integers(0, n, nq)] + 0.05 * rng.normal(size=(nq, D))).astype(np.float32)
+    q[1] = x[1]
+    try:
+        ix = amd.FlatIndex(L2F, D); ix.add(x)
+        amd.set_tuning("flat_variant", 1)
+        de, ie = ix.search(q, k)
+        amd.set_tuning("flat_variant", 0)
+        for retry, dbg in ((0, 0), (1, 0), (1, 32), (0, 32)):
+            amd.set_tuning("flat_f32_tfilter_retry", retry); amd.set_tuning("flat_f32_dbg", dbg)
+            ds, is_ = ix.search(q, k)
+            assert ix.last_search()[0] == 3
+            assert np.array_equal(is_, ie) and np.array_equal(bits(ds), bits(de)), (retry, dbg)
+        ix.close()
+    finally:
+        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_tfilter_retry", 0); amd.set_tuning("flat_f32_dbg", 0)
+
+
 def test_flat_f32_threshold_filter_hands_hard_queries_to_the_exact_kernels(amd):
     """what the filter's bound does not cover is re-run by the exact kernels inside the same call, per query: non-finite queries, a
     query 2^70 times larger than the rows, masses of exact ties around the k-th place (more rows at the threshold than a list
