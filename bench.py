@@ -1069,6 +1069,30 @@ def _sec_flat_f32(ctx):
         if metric == cvt.IP:
             outs = {nq: ix.search(qd[:nq].contiguous(), k) for nq in (1, 64)}
         ix.close()
+    # widths of the reference's CNN features (pca_online / scalar_quantization: 512 / 1024-d): 1 GB of rows each, 1000 queries
+    del xd
+    res["widths"] = {"rows_bytes": 1 << 30, "nq": 1000, "k": k, "cases": {}}
+    base = res["cases"].get("ip nq=1000", {}).get("ms")
+    for d2 in (512, 1024):
+        n2 = (1 << 30) // (4 * d2)
+        g = torch.Generator(device=ctx.dev); g.manual_seed(d2)
+        cen2 = torch.randn((2000, d2), generator=g, device=ctx.dev)
+        x2 = cen2[torch.randint(0, 2000, (n2,), generator=g, device=ctx.dev)] + 0.7 * torch.randn((n2, d2), generator=g, device=ctx.dev)
+        x2 = x2 / x2.norm(dim=1, keepdim=True)
+        q2 = x2[torch.randint(0, n2, (1000,), generator=g, device=ctx.dev)] + 0.2 * torch.randn((1000, d2), generator=g, device=ctx.dev)
+        q2 = (q2 / q2.norm(dim=1, keepdim=True)).contiguous()
+        ix = cvt.FlatIndex(cvt.IP, d2)
+        ix.add(x2)
+        ms = _ev_ms(torch, lambda: ix.search(q2, k), reps=3, warm=2)
+        c = {"rows": n2, "ms": round(ms, 4), "path": ix.last_search()[0], "ms_per_GB_of_rows": round(ms, 4)}
+        if base:
+            c["vs_128d_per_byte"] = round(ms / (base / (n * D * 4 / float(1 << 30))), 3)
+        cvt.set_tuning("flat_variant", 1)
+        c["exact_kernels_ms"] = round(_ev_ms(torch, lambda: ix.search(q2, k), reps=1, warm=1), 3)
+        cvt.set_tuning("flat_variant", 0)
+        res["widths"]["cases"]["ip %dd" % d2] = c
+        ix.close()
+        del x2, q2
     res["path_codes"] = ("0 exact kernels, 1 sample + matrix-core filter pipeline, 2 one stream over the rows "
                          "(flat_f32_stream.hip), 3 threshold filter (flat_f32_tfilter.hip, round 6)")
     if args.cpu_sample > 0:
