@@ -54,7 +54,7 @@ namespace {
 constexpr int FT_WAVES = 8;          // per workgroup: two per SIMD
 constexpr int FT_GRID = 256;         // workgroups: one per CU
 constexpr int FT_SLOTS = 1024;       // sample maxima per query
-constexpr int FT_CAP = 4096;         // candidates per query the finish takes
+constexpr int FT_CAP = 8192;         // candidates per query the finish takes (one product on 1 M SIFT-like rows: 2 700 on average, 4 900 at most)
 constexpr int FT_NBMAX = 16;         // query blocks a workgroup holds
 constexpr int FT_PASS = 1024;        // queries per pass of the pipeline (sizes the record area)
 constexpr int FT_KEEP = 1024;        // rows per query the finish gives exact distances

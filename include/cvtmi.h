@@ -160,7 +160,9 @@ int cvtmi_set_device(int device);
  *                     candidates give (it helps when the rows above the sample's threshold are many, not when the rows inside the
  *                     margin band are: measured no gain on clustered 300-d rows, three empty launches = ~10 us on every search);
  *                     0 (default) = the exact kernels at once
- *   "flat_f32_share"  fp32 stream, batches beyond one wave's queries: 0 choose, 1 private rings only, 2 the shared-ring kernel,
+ *   "flat_f32_share"  fp32 stream, batches beyond one wave's queries: 0 choose (round 6: the four-wave shared ring -- the eight- and
+ *                     twelve-wave forms answered one query of ~10^5 wrongly in a sweep against the exact kernels and are only run when
+ *                     asked for), 1 the four-wave form, 2 the twelve-wave shared-ring kernel,
  *                     3 = the shared ring with eight waves of 64 queries (512 queries per pass over the rows instead of 384; round 6,
  *                     measured: 385 .. 512 queries 0.74 -> 0.51 ms on 1 M x 128-d, 1000 queries unchanged -- its registers spill)
  *   "hnsw_top_lds"    entries of an HNSW traversal's top queue kept in LDS (default 256; 0 = all)
