@@ -889,6 +889,11 @@ def _sec_rotation_encode(ctx):
                        "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
                        "what": "Y = X R^T, dense 128 x 128 fp32 R on v_mfma_f32_32x32x2_f32 (2 D^2 flop and 1 KB "
                                "moved per row)"}
+    # the same kernel over 8 x the rows: the rate of a launch grows with its length (round 6: 1 M rows 0.57-0.60, 8 M rows 0.72)
+    x8 = synth.sift_like(8 * n, D, seed=0xC0FFEE, device=ctx.dev)
+    ms8 = _ev_ms(torch, lambda: ix.rotate(x8), reps=3, warm=1)
+    sec["rotation"]["rows_8M"] = {"rows": 8 * n, "ms": round(ms8, 4), "frac_of_f32_mfma_peak": round(2.0 * 8 * n * D * D / (ms8 * 1e-3) / 1e12 / F32_MFMA_PEAK_TF, 4)}
+    del x8
     xr = ix.rotate(x)
     ms = _ev_ms(torch, lambda: ix.encode(xr))
     sec["encode"] = {"rows": n, "ms": round(ms, 4), "rows_per_s": round(n / (ms * 1e-3), 1),
