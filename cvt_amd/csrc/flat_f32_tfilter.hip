@@ -307,23 +307,31 @@ __global__ __launch_bounds__(256) void ft_theta_kernel(const uint32_t *__restric
     }
 }
 
-// Records -> per-query candidate lists.  One workgroup per workgroup of the filter (its eight wave regions: one query chunk), two
-// passes over the records: (A) the scores at or above their query's threshold are counted per query in LDS, ONE global atomic per
-// query with hits then reserves that many places of the query's list (an atomic per candidate measured 0.29 ms per million:
-// returning device-scope atomics run at ~3.5 G/s whatever their addresses), (B) the hits are written behind the reserved base.
+// Records -> per-query candidate lists.  One workgroup per workgroup of the filter (its eight wave regions: one query chunk).  The
+// scores at or above their query's threshold are counted per query in LDS AND kept there (score, row, query within the chunk: 10 bytes
+// a hit, FT_STAGE of them); ONE global atomic per query with hits then reserves that many places of the query's list (an atomic per
+// candidate measured 0.29 ms per million: returning device-scope atomics run at ~3.5 G/s whatever their addresses) and the staged hits
+// are written behind the reserved base -- the 80-byte records are read once (2.7 M records of 1000 queries: 0.137 -> ~0.08 ms).  A
+// workgroup with more hits than the stage holds reads its records a second time instead.
 constexpr int FT_BUCKET_T = 1024;
+constexpr int FT_STAGE = 12288;
 __global__ __launch_bounds__(FT_BUCKET_T) void ft_bucket_kernel(const uint4 *__restrict__ rec, const uint32_t *__restrict__ wcnt, uint32_t cap,
                                                                 const float *__restrict__ thr, uint32_t *__restrict__ cnt, uint2 *__restrict__ cand,
                                                                 int chunks, int qper, int nq, uint32_t *__restrict__ redo, int nw,
                                                                 const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ qcount)
 {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ft_stage[];   // uint2 [FT_STAGE] (score, row), then uint16 [FT_STAGE] query within the chunk
     __shared__ uint32_t hist[32 * FT_NBMAX], base_s[32 * FT_NBMAX];
+    __shared__ uint32_t nstage_s;
+    uint2 *st_sr = reinterpret_cast<uint2 *>(ft_stage);
+    uint16_t *st_q = reinterpret_cast<uint16_t *>(ft_stage + (size_t)FT_STAGE * sizeof(uint2));
     const int j = blockIdx.x, tid = threadIdx.x;
     const int chunk = (j >> 3) % chunks, q0 = chunk * qper;
     if (qlist) nq = (int)*qcount < qper ? (int)*qcount : qper;   // second attempt: one chunk of listed queries
     const int nqc = nq - q0 < qper ? nq - q0 : qper;
     if (nqc <= 0) return;
     for (int i = tid; i < nqc; i += FT_BUCKET_T) hist[i] = 0u;
+    if (tid == 0) nstage_s = 0u;
     const int per = FT_BUCKET_T / nw, r = tid / per, t = tid % per;   // 128 (256) threads per wave region
     uint32_t n = wcnt[j * nw + r];
     if (n > cap) {   // the region ran full: the exact kernels answer the queries its workgroup held
@@ -339,19 +347,39 @@ __global__ __launch_bounds__(FT_BUCKET_T) void ft_bucket_kernel(const uint4 *__r
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const uint4 s4 = rp[(size_t)i * 5 + jj];
-            c += (__uint_as_float(s4.x) >= tb ? 1u : 0u) + (__uint_as_float(s4.y) >= tb ? 1u : 0u) + (__uint_as_float(s4.z) >= tb ? 1u : 0u) +
-                 (__uint_as_float(s4.w) >= tb ? 1u : 0u);
+            const uint32_t sv[4] = { s4.x, s4.y, s4.z, s4.w };
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (__uint_as_float(sv[e]) >= tb) {
+                    ++c;
+                    const uint32_t pos = atomicAdd(&nstage_s, 1u);
+                    if (pos < (uint32_t)FT_STAGE) {
+                        st_sr[pos] = make_uint2(sv[e], h.y + (uint32_t)(e + 8 * jj));
+                        st_q[pos] = (uint16_t)h.z;
+                    }
+                }
+            }
         }
         if (c) atomicAdd(&hist[h.z], c);
     }
     __syncthreads();
+    const uint32_t nstage = nstage_s;
     for (int i = tid; i < nqc; i += FT_BUCKET_T) {
         const uint32_t c = hist[i];
         base_s[i] = c ? atomicAdd(&cnt[qlist ? qlist[q0 + i] : (uint32_t)(q0 + i)], c) : 0u;
         hist[i] = 0u;
     }
     __syncthreads();
-    for (uint32_t i = t; i < n; i += per) {
+    if (nstage <= (uint32_t)FT_STAGE) {   // (workgroup-uniform)
+        for (uint32_t i = tid; i < nstage; i += FT_BUCKET_T) {
+            const uint32_t ql = st_q[i];
+            const uint32_t q = qlist ? qlist[q0 + ql] : (uint32_t)(q0 + ql);
+            const uint32_t pos = base_s[ql] + atomicAdd(&hist[ql], 1u);
+            if (pos < (uint32_t)FT_CAP) cand[(size_t)q * FT_CAP + pos] = st_sr[i];
+        }
+        return;
+    }
+    for (uint32_t i = t; i < n; i += per) {   // more hits than the stage holds: the records once more
         const uint4 h = rp[(size_t)i * 5 + 4];
         const float tb = thr[h.x];
         const uint32_t ql = h.z;
@@ -426,9 +454,23 @@ __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict_
             row[j] = c.y;
         }
     }
-    // radix select of the want-th largest key: prefix / mask grow by 8 bits a round
-    uint32_t prefix = 0u, mask = 0u, remaining = (uint32_t)want;
-    for (int shift = 24; shift >= 0; shift -= 8) {
+    // radix select of the want-th largest key: prefix / mask grow by 8 bits a round.  The candidates' scores lie in a narrow band: the
+    // rounds start at the first byte in which two keys differ (with all of them in ONE bin of the top bytes a round was 2 700 LDS
+    // atomics on one address)
+    uint32_t kmx = 0u, kmn = 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+        if (key[j] != 0u) { kmx = key[j] > kmx ? key[j] : kmx; kmn = key[j] < kmn ? key[j] : kmn; }
+    kmx = fs_wave_max_u32(kmx); kmn = fs_wave_min_u32(kmn);
+    if (lane == 0) { hist[tid >> 6] = kmx; hist[4 + (tid >> 6)] = kmn; }
+    __syncthreads();
+    kmx = max(max(hist[0], hist[1]), max(hist[2], hist[3]));
+    kmn = min(min(hist[4], hist[5]), min(hist[6], hist[7]));
+    __syncthreads();
+    const int top_byte = kmx == kmn ? -1 : (31 - __builtin_clz(kmx ^ kmn)) >> 3;   // -1: all keys equal
+    uint32_t mask = top_byte >= 3 ? 0u : (0xffffffffu << (8 * (top_byte + 1)));
+    uint32_t prefix = kmx & mask, remaining = (uint32_t)want;
+    for (int shift = 8 * top_byte; shift >= 0; shift -= 8) {
         hist[tid] = 0u;
         __syncthreads();
 #pragma unroll
@@ -529,7 +571,8 @@ __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict_
 // ---- host side ----
 static std::atomic<int> g_ft_on{4};        // cvtmi_set_tuning("flat_f32_tfilter"): 0 = the stream kernels for every batch, 1 .. 3 = products, 4 = choose
 static std::atomic<int> g_ft_retry{0};     // "flat_f32_tfilter_retry": 1 = a second filter pass for the queries whose candidate lists ran over, 0 (default) = the exact kernels at once
-static std::atomic<int> g_ft_one_max{512}; // "flat_f32_tfilter_one": largest batch that multiplies one product (the pass is bound by the rows it reads)
+static std::atomic<int> g_ft_one_max{1 << 30}; // "flat_f32_tfilter_one": largest batch that multiplies one product (with the staged bucket pass one product wins at every
+                                           // batch size measured: 1000 queries 0.74 -> 0.64 ms, 4096 2.9 -> 2.5, 10 000 7.0 -> 6.5; two products beyond this many queries)
 static std::atomic<int> g_ft_min_nq{16};   // cvtmi_set_tuning("flat_f32_tfilter_min"): smallest batch that takes the pipeline (1 M x 128-d: 16 queries 0.119 -> 0.107 ms,
                                            // 128 queries 0.25 -> 0.16; below, the pipeline's five launches cost more than the stream's two)
 void set_flat_f32_tfilter(int v) { g_ft_on = v < 0 ? 0 : (v > 4 ? 4 : v); }
@@ -655,6 +698,11 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
         CVTMI_TRY(ft_launch_any(D, nprod, false, a, lds, st));
         if (a.dbg & 8) continue;   // timing experiments: the filter passes alone (results stale)
         const bool retry = g_ft_retry.load() != 0;
+        const size_t bucket_lds = (size_t)FT_STAGE * (sizeof(uint2) + sizeof(uint16_t));
+        {
+            static std::atomic<bool> attr_k[16] = {};
+            CVTMI_TRY(fs_set_lds((const void *)ft_bucket_kernel, bucket_lds, attr_k));
+        }
         const int rcap = std::min<int>(qcap, (int)((m + 31) / 32 * 32));   // queries one second attempt takes (a single chunk)
         auto finish = [&](int second) {
             const unsigned grid = second ? (unsigned)rcap : (unsigned)m;
@@ -666,14 +714,14 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
             else
                 hipLaunchKernelGGL((ft_finish_kernel<false, 4>), dim3(grid), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m);
         };
-        hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), 0, st, rec, wcnt, cap, thr, cnt, cand, chunks, qper, (int)m, redo + a0, nw, nullptr, nullptr);
+        hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), bucket_lds, st, rec, wcnt, cap, thr, cnt, cand, chunks, qper, (int)m, redo + a0, nw, nullptr, nullptr);
         finish(0);
         if (retry) {   // the queries whose lists ran over, under the thresholds their own candidates give (nothing listed: three empty launches)
             FtArgs b = a;
             b.qlist = rlist; b.qcount = rcount; b.chunks = 1; b.qper = rcap;
             const size_t lds2 = (size_t)(rcap / 32) * nch * nt * 1024 + FT_SLACK + (size_t)rcap * 2 * sizeof(float);
             CVTMI_TRY(ft_launch_any(D, nprod, false, b, lds2, st));
-            hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), 0, st, rec, wcnt, cap, thr, cnt, cand, 1, rcap, (int)m, redo + a0, nw, rlist, rcount);
+            hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), bucket_lds, st, rec, wcnt, cap, thr, cnt, cand, 1, rcap, (int)m, redo + a0, nw, rlist, rcount);
             finish(1);
         }
         CVTMI_HIP(hipGetLastError());

@@ -152,7 +152,7 @@ int cvtmi_set_device(int device);
  *                     bf16 operand copy in registers, no barrier, hits recorded -> per-query lists -> exact distances.  1 .. 3 = the
  *                     bf16 products per term: 1 (x1.q1), 2 ((x1 + x2).q1; both with margins from each query's own rounding residues),
  *                     3 (x1.q1 + x2.q1 + x1.q2, the stream kernels' margin); 4 (default) = one product up to "flat_f32_tfilter_one"
- *                     (default 512) queries -- the pass is bound by the rows it reads --, two beyond; 0 = the stream kernels for every
+ *                     (default: no limit -- measured ahead at every batch size) queries, two beyond; 0 = the stream kernels for every
  *                     batch.  1 M x 128-d, top-100: 1000 queries 0.97 -> 0.69 ms, 128 queries 0.25 -> 0.16 ms, 16 queries 0.119 -> 0.107 ms
  *   "flat_f32_tfilter_min"  smallest batch that takes that pipeline
  *   "flat_f32_tfilter_one"  largest batch that multiplies one product under "flat_f32_tfilter" 4
