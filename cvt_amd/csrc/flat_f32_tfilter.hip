@@ -65,7 +65,8 @@ struct FtArgs {
     const uint4 *pack;       // bf16 operand copy of the rows
     const float *bias;       // b_x per row (padding rows: FS_PAD_BIAS)
     int64_t t1, n_tiles;     // tiles [0, t1) of n_tiles
-    int gstride;             // MAX mode: the sample is every gstride-th group of RT tiles (rows arrive video by video: a leading block would be the first videos only)
+    int64_t n_sample;        // MAX mode: the sample is n_sample groups of RT tiles spread evenly over all groups (rows arrive video by video: a leading
+                             // block would be the first videos only) -- a whole number of groups per wave, or the pass waits for the waves with one more
     const float *Q;
     int D;                   // floats per query (<= 16 NCH: the operands are zero beyond it)
     int nq, chunks, qper;    // queries of chunk c: [c qper, min(nq, (c + 1) qper)), qper a multiple of 32
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         }
     __syncthreads();
     // groups of RT tiles: wave w of slice s takes groups s + slices (w + FT_WAVES i)
-    const int64_t all_groups = (a.t1 + RT - 1) / RT, n_groups = MAXMODE ? (all_groups + a.gstride - 1) / a.gstride : all_groups, stride = (int64_t)slices * NW;
+    const int64_t all_groups = (a.t1 + RT - 1) / RT, n_groups = MAXMODE ? a.n_sample : all_groups, stride = (int64_t)slices * NW;
     // the second-dispatched half of the workgroup loses every arbitration by age: static priority for it (MI355X_MICROARCH.md "two waves
     // per SIMD"; measured 0.65 -> 0.59 ms on the filter passes of 1000 queries x 1 M rows)
     if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     const int slot0 = ((slice * NW + wave) * 2 + lk) * sub_slots;
     int it = 0;
     uint32_t wcnt = 0;
+    uint8_t *rec_w = reinterpret_cast<uint8_t *>(a.rec) + (size_t)wave_g * a.cap * 80;   // (wave-uniform)
     bf16x8 xa[RT][NCH][NA];
     f32x16 bias[RT];
     auto fetch = [&](int64_t g) {
@@ -182,7 +184,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         }
     };
     for (int64_t g = slice + (int64_t)slices * wave; g < n_groups; g += stride, ++it) {
-        fetch(MAXMODE ? g * a.gstride : g);
+        fetch(MAXMODE ? g * all_groups / a.n_sample : g);
+        const uint32_t tile_row = (uint32_t)(g * RT * 32 + 4 * lk);   // first of a lane's rows in the group's first tile
         // (requesting the queries' operands two or three K steps ahead of their matrix instructions -- pinned with sched_barrier, across
         //  the block boundary -- or a block's operands at its start measured 0 .. 8 % SLOWER than the compiler's own order: read a K
         //  step's operands, wait, multiply; the partner wave of the SIMD covers the round trip)
@@ -218,9 +221,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                 float m = ft_max16(acc[0]);
 #pragma unroll
                 for (int r = 1; r < RT; ++r) m = fmaxf(m, ft_max16(acc[r]));
-                if (qq < nqc && m > FS_EMPTY) atomicMax(&a.smax[(size_t)(q0 + qq) * FT_SLOTS + ((slot0 + (it & (sub_slots - 1))) & (FT_SLOTS - 1))], f32_key(m));
+                // (32-bit offset from the scalar base: the 64-bit address arithmetic of a 64-lane scatter was a third of this pass)
+                const uint32_t off = (uint32_t)(q0 + qq) * (uint32_t)FT_SLOTS + (uint32_t)((slot0 + (it & (sub_slots - 1))) & (FT_SLOTS - 1));
+                if (qq < nqc && m > FS_EMPTY) atomicMax(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(a.smax) + off * 4u), f32_key(m));
             } else {
                 const float tb = thr_s[qq];
+                const uint32_t qid = id_s[qq];   // (read beside the threshold: the hit path waits for nothing)
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
                     const bool hit = ft_max16(acc[r]) >= tb;
@@ -229,12 +235,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                         const uint32_t pos = wcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
                         wcnt += (uint32_t)__popcll(hm);
                         if (hit && pos < a.cap) {
-                            uint4 *dst = a.rec + ((size_t)wave_g * a.cap + pos) * 5;
+                            // the wave's region as a scalar base + a 32-bit byte offset (one multiply per record instead of two 64-bit ones)
+                            uint8_t *dst = rec_w + pos * 80u;
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
-                                dst[j] = make_uint4(__float_as_uint(acc[r][4 * j]), __float_as_uint(acc[r][4 * j + 1]), __float_as_uint(acc[r][4 * j + 2]),
-                                                    __float_as_uint(acc[r][4 * j + 3]));
-                            dst[4] = make_uint4(id_s[qq], (uint32_t)((g * RT + r) * 32 + 4 * lk), (uint32_t)qq, 0u);   // (query, first row, query within the chunk)
+                                *reinterpret_cast<uint4 *>(dst + 16 * j) = make_uint4(__float_as_uint(acc[r][4 * j]), __float_as_uint(acc[r][4 * j + 1]),
+                                                                                      __float_as_uint(acc[r][4 * j + 2]), __float_as_uint(acc[r][4 * j + 3]));
+                            *reinterpret_cast<uint4 *>(dst + 64) = make_uint4(qid, tile_row + (uint32_t)(32 * r), (uint32_t)qq, 0u);   // (query, first row, query within the chunk)
                         }
                     }
                 }
@@ -570,6 +577,7 @@ __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict_
 
 // ---- host side ----
 static std::atomic<int> g_ft_on{4};        // cvtmi_set_tuning("flat_f32_tfilter"): 0 = the stream kernels for every batch, 1 .. 3 = products, 4 = choose
+static std::atomic<int> g_ft_sample_div{5};   // "flat_f32_tfilter_sample": the sample is about 1 / this of the rows
 static std::atomic<int> g_ft_retry{0};     // "flat_f32_tfilter_retry": 1 = a second filter pass for the queries whose candidate lists ran over, 0 (default) = the exact kernels at once
 static std::atomic<int> g_ft_one_max{1 << 30}; // "flat_f32_tfilter_one": largest batch that multiplies one product (with the staged bucket pass one product wins at every
                                            // batch size measured: 1000 queries 0.74 -> 0.64 ms, 4096 2.9 -> 2.5, 10 000 7.0 -> 6.5; two products beyond this many queries)
@@ -578,6 +586,7 @@ static std::atomic<int> g_ft_min_nq{16};   // cvtmi_set_tuning("flat_f32_tfilter
 void set_flat_f32_tfilter(int v) { g_ft_on = v < 0 ? 0 : (v > 4 ? 4 : v); }
 void set_flat_f32_tfilter_one(int v) { g_ft_one_max = v < 0 ? 0 : v; }
 void set_flat_f32_tfilter_retry(int v) { g_ft_retry = v != 0; }
+void set_flat_f32_tfilter_sample(int v) { g_ft_sample_div = v < 1 ? 1 : (v > 64 ? 64 : v); }
 void set_flat_f32_tfilter_min(int v) { g_ft_min_nq = v < 1 ? 1 : v; }
 // widths: the K steps (16 dimensions each) of a row tile stay in a wave's registers (RT tiles of 32 rows: RT x K steps x terms x 4 registers
 // <= 128, 256 with one wave per SIMD).  A kernel exists for 2 / 4 / 6 / 8 / 10 / 12 / 16 / 24 / 32 / 48 / 64 K steps; a width in between (any
@@ -623,6 +632,15 @@ static int ft_products(int D, int want)
     const int nch = flat_f32_tfilter_nch(D), most = nch <= 8 ? 3 : (nch <= 16 ? 2 : 1);
     return want < most ? want : most;
 }
+// row tiles per group of the kernel ft_launch_any picks (the table below)
+static int ft_rt(int nch, int nprod)
+{
+    if (nprod == 1) return nch <= 4 ? 4 : (nch <= 10 ? 3 : (nch <= 16 ? 2 : 1));
+    if (nch == 2) return 4;
+    if (nch == 4) return 3;
+    if (nch <= 8) return 2;
+    return 1;
+}
 static int ft_launch_any(int D, int nprod, bool maxmode, const FtArgs &a, size_t lds, hipStream_t st)
 {
     switch (flat_f32_tfilter_nch(D) * 4 + nprod) {
@@ -664,8 +682,6 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
     const int qcap = std::min(32 * FT_NBMAX, (int)((size_t)(160 * 1024 - 32 * FT_NBMAX * 8 - FT_SLACK) / ((size_t)nch * nt * 1024)) * 32);   // queries a workgroup holds
     CVTMI_HIP(hipMemsetAsync(redo, 0, (size_t)nq * sizeof(uint32_t), st));
     const int64_t n_tiles = (n + 31) / 32;
-    // the sample: every sample_stride-th group of row tiles -- an eighth of the rows, at least ~65 536
-    const int sample_stride = (int)std::max<int64_t>(1, std::min<int64_t>(8, n_tiles / 2048));
     for (int64_t a0 = 0; a0 < nq; a0 += FT_PASS) {
         const int64_t m = std::min<int64_t>(nq - a0, FT_PASS);
         int chunks = 1;
@@ -688,13 +704,19 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
         a.pack = reinterpret_cast<const uint4 *>(pack); a.bias = bias; a.n_tiles = n_tiles; a.Q = q + a0 * D; a.D = D; a.nq = (int)m; a.chunks = chunks; a.qper = qper;
         a.smax = smax; a.thr = thr; a.rec = rec; a.wcnt = wcnt; a.cap = cap; a.qlist = nullptr; a.qcount = nullptr; a.dbg = get_flat_f32_dbg();
         const size_t lds = (size_t)(qper / 32) * nch * nt * 1024 + FT_SLACK + (size_t)qper * 2 * sizeof(float);
-        a.t1 = n_tiles; a.gstride = sample_stride;   // MAX mode walks groups g * gstride below t1: set n_groups through t1
+        a.t1 = n_tiles;
+        {   // the sample: about an eighth of the groups (at least ~65 536 rows), a whole number per wave of a chunk
+            const int rt = ft_rt(nch, nprod);
+            const int64_t all_groups = (n_tiles + rt - 1) / rt, streams = (int64_t)(FT_GRID / chunks) * nw;
+            const int64_t want = std::max<int64_t>(all_groups / g_ft_sample_div.load(), std::min<int64_t>(all_groups, (2048 + rt - 1) / rt));
+            a.n_sample = std::min<int64_t>(all_groups, std::max<int64_t>(1, (want + streams / 2) / streams) * streams);
+        }
         CVTMI_TRY(ft_launch_any(D, nprod, true, a, lds, st));
         const unsigned tg = (unsigned)((m + 3) / 4);
         const float loosen = (a.dbg & 32) ? 0.02f : 0.0f;
         if (metric == CVTMI_METRIC_IP) hipLaunchKernelGGL((ft_theta_kernel<true>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0);
         else hipLaunchKernelGGL((ft_theta_kernel<false>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0);
-        a.t1 = n_tiles; a.gstride = 1;
+        a.t1 = n_tiles; a.n_sample = 0;
         CVTMI_TRY(ft_launch_any(D, nprod, false, a, lds, st));
         if (a.dbg & 8) continue;   // timing experiments: the filter passes alone (results stale)
         const bool retry = g_ft_retry.load() != 0;
