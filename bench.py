@@ -1059,16 +1059,17 @@ def _sec_flat_f32(ctx):
             qq = qd[:nq].contiguous()
             ms = _ev_ms(torch, lambda: ix.search(qq, k), reps=5, warm=2)
             c = {"ms": round(ms, 4), "queries_per_s": round(nq / (ms * 1e-3), 1), "path": ix.last_search()[0]}
-            if c["path"] == 3 and nq <= 512:   # threshold filter, one bf16 product: bound by the first-term plane of the operand copy
+            if c["path"] == 3 and nq <= 256:   # threshold filter, one bf16 product: bound by the first-term plane of the operand copy
                 c["roofline"] = _hbm(n * D * 2, ms)
-                c["roofline"]["note"] = "algorithmic bytes = the first bf16 term of every row once (the sample pass re-reads an eighth)"
+                c["roofline"]["note"] = "algorithmic bytes = the first bf16 term of every row once (the sample pass re-reads a fifth)"
             elif nq <= 96:   # one stream over the rows: bound by HBM
                 c["roofline"] = _hbm(n * D * 4, ms)
             else:          # bf16 matrix cores: products per (query, row, dimension)
-                prods = 2 if c["path"] == 3 else 3
+                prods = 1 if c["path"] == 3 else 3
                 tf = prods * 2.0 * nq * n * D / (ms * 1e-3) / 1e12
                 c["roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TF,
-                                 "unit": "TFLOP/s (bf16, %d products per term%s)" % (prods, ", plus the sample pass over an eighth of the rows" if prods == 2 else ""),
+                                 "unit": "TFLOP/s (bf16, %s)" % ("one product per term over all rows (+ a fifth of them in the sample pass); the whole "
+                                                                   "pipeline's time, of which the filter pass is half" if prods == 1 else "three two-term products"),
                                  "frac": round(tf / BF16_MFMA_PEAK_TF, 4)}
             res["cases"]["%s nq=%d" % (tag, nq)] = c
         if metric == cvt.IP:

@@ -59,7 +59,7 @@ constexpr int FT_NBMAX = 16;         // query blocks a workgroup holds
 constexpr int FT_PASS = 1024;        // queries per pass of the pipeline (sizes the record area)
 constexpr int FT_KEEP = 1024;        // rows per query the finish gives exact distances
 constexpr int FT_DMAX = 1024;        // widest row
-constexpr int FT_SLACK = 0;          // bytes of LDS kept free behind the queries' operands
+constexpr int FT_SLACK = 4096;       // bytes of LDS behind the queries' operands that the one-wave-per-SIMD form's operand requests may read
 
 struct FtArgs {
     const uint4 *pack;       // bf16 operand copy of the rows
@@ -189,13 +189,32 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         // (requesting the queries' operands two or three K steps ahead of their matrix instructions -- pinned with sched_barrier, across
         //  the block boundary -- or a block's operands at its start measured 0 .. 8 % SLOWER than the compiler's own order: read a K
         //  step's operands, wait, multiply; the partner wave of the SIMD covers the round trip)
+        //  ONE wave per SIMD (NW == 4: 768 / 1024-d) has no partner: there the operands ARE requested PD K steps ahead, across the block
+        //  boundary, through a ring of four register sets.
+        constexpr bool RING = NW == 4 && NT == 1;
+        constexpr int PD = 3;
+        bf16x8 bq[RING ? 4 : 1];
+        auto request = [&](int j_, int set) __attribute__((always_inline)) {
+            bq[set] = *reinterpret_cast<const bf16x8 *>(ft_q + (size_t)j_ * 1024 + lane * 16);   // (the last PD of a group read the slack behind the operands: unused)
+        };
+        if constexpr (RING) {
+#pragma unroll
+            for (int j_ = 0; j_ < PD; ++j_) request(j_, j_);
+        }
 #pragma unroll 1
         for (int b = 0; b < nb; ++b) {
             const uint8_t *qb = ft_q + (size_t)b * (NCH * NT * 1024) + lane * 16;
             f32x16 acc[RT];
 #pragma unroll
             for (int s_ = 0; s_ < NCH; ++s_) {
-                const bf16x8 qh = *reinterpret_cast<const bf16x8 *>(qb + (s_ * NT) * 1024);
+                bf16x8 qh;
+                if constexpr (RING) {
+                    request(b * NCH + s_ + PD, (s_ + PD) & 3);
+                    __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the request down to its first use)
+                    qh = bq[s_ & 3];
+                } else {
+                    qh = *reinterpret_cast<const bf16x8 *>(qb + (s_ * NT) * 1024);
+                }
 #pragma unroll
                 for (int r = 0; r < RT; ++r)
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[r][s_][0], qh, s_ == 0 ? bias[r] : acc[r], 0, 0, 0);   // b_x rides in as SrcC
