@@ -435,7 +435,7 @@ def _pmc_traffic(args, nq, k, M):
                      and not args.splits and args.variant < 0)
     if not default_shape:
         return None, None
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         p = os.path.join(ROOT, "profiles", "%s_scan_traffic.json" % tag)
         if os.path.exists(p):
             try:
@@ -449,7 +449,7 @@ def _pmc_traffic(args, nq, k, M):
 
 def _pmc_traffic_large(args, rows, nq, k):
     """the same for the HBM-resident shard shape the round's profile covers (128 M rows x 2048 queries), else null"""
-    for tag in ("r05", "r04", "r03", "r02"):
+    for tag in ("r06", "r05", "r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", "%s_scan_traffic_128m.json" % tag)
         if os.path.exists(p):
             try:
