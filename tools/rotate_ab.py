@@ -1,4 +1,5 @@
-"""Rotation GEMM (Y = X R^T, 128-d) over batch sizes: the rate depends on the rows per launch (1 M rows 0.57-0.60 of the fp32 matrix peak, 8 M rows 0.72).
+"""Rotation GEMM (Y = X R^T, 128-d) over batch sizes.  What the five-launch timing of rounds 1-5 measured (1 M rows 0.57-0.60 of the fp32 matrix peak, 8 M rows 0.72) was the clocks' ramp after
+an idle gap: 400 back-to-back launches of 1 M rows run at 0.73 (bench.py: _ev_ms_steady).
 Round 6 also measured, and removed: R in registers with one wave per SIMD (512 registers, no R in LDS: 0.54-0.61 / 0.66-0.72) and slabs handed out by an
 atomic counter instead of a fixed stride (0.535 / 0.57) -- bits equal, neither faster."""
 import os, sys, time
