@@ -477,6 +477,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "flat_f32_tfilter_min")) { set_flat_f32_tfilter_min((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_one")) { set_flat_f32_tfilter_one((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_retry")) { set_flat_f32_tfilter_retry((int)value); return CVTMI_OK; }
+    if (!strcmp(name, "flat_f32_tfilter_min_rows")) { set_flat_f32_tfilter_min_rows((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_sample")) { set_flat_f32_tfilter_sample((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_share")) {
         if (value < 0 || value > 3) return fail(CVTMI_EINVAL, "cvtmi_set_tuning: flat_f32_share must be 0 .. 3");

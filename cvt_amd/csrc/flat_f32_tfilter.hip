@@ -596,6 +596,7 @@ __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict_
 
 // ---- host side ----
 static std::atomic<int> g_ft_on{4};        // cvtmi_set_tuning("flat_f32_tfilter"): 0 = the stream kernels for every batch, 1 .. 3 = products, 4 = choose
+static std::atomic<int> g_ft_min_rows{262144};   // "flat_f32_tfilter_min_rows": smallest table that takes the pipeline
 static std::atomic<int> g_ft_sample_div{5};   // "flat_f32_tfilter_sample": the sample is about 1 / this of the rows
 static std::atomic<int> g_ft_retry{0};     // "flat_f32_tfilter_retry": 1 = a second filter pass for the queries whose candidate lists ran over, 0 (default) = the exact kernels at once
 static std::atomic<int> g_ft_one_max{1 << 30}; // "flat_f32_tfilter_one": largest batch that multiplies one product (with the staged bucket pass one product wins at every
@@ -605,6 +606,7 @@ static std::atomic<int> g_ft_min_nq{16};   // cvtmi_set_tuning("flat_f32_tfilter
 void set_flat_f32_tfilter(int v) { g_ft_on = v < 0 ? 0 : (v > 4 ? 4 : v); }
 void set_flat_f32_tfilter_one(int v) { g_ft_one_max = v < 0 ? 0 : v; }
 void set_flat_f32_tfilter_retry(int v) { g_ft_retry = v != 0; }
+void set_flat_f32_tfilter_min_rows(int v) { g_ft_min_rows = v < 32768 ? 32768 : v; }
 void set_flat_f32_tfilter_sample(int v) { g_ft_sample_div = v < 1 ? 1 : (v > 64 ? 64 : v); }
 void set_flat_f32_tfilter_min(int v) { g_ft_min_nq = v < 1 ? 1 : v; }
 // widths: the K steps (16 dimensions each) of a row tile stay in a wave's registers (RT tiles of 32 rows: RT x K steps x terms x 4 registers
@@ -621,7 +623,7 @@ int flat_f32_tfilter_nch(int D)
 bool flat_f32_tfilter_width(int D) { return flat_f32_tfilter_nch(D) != 0; }
 bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k)
 {
-    return g_ft_on.load() && (metric == CVTMI_METRIC_IP || metric == CVTMI_METRIC_L2F) && flat_f32_tfilter_width(D) && n >= 262144 && n < 0xffffffe0LL &&
+    return g_ft_on.load() && (metric == CVTMI_METRIC_IP || metric == CVTMI_METRIC_L2F) && flat_f32_tfilter_width(D) && n >= g_ft_min_rows.load() && n < 0xffffffe0LL &&
            nq >= g_ft_min_nq.load() && k >= 1 && k <= 128;
 }
 static uint32_t ft_rec_cap(int64_t m) { return (uint32_t)std::min<int64_t>(3072, std::max<int64_t>(256, 3 * m)); }

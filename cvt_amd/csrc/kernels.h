@@ -230,6 +230,7 @@ void set_flat_f32_tfilter_min(int v);
 void set_flat_f32_tfilter_one(int v);
 void set_flat_f32_tfilter_retry(int v);
 void set_flat_f32_tfilter_sample(int v);
+void set_flat_f32_tfilter_min_rows(int v);
 size_t flat_f32_stream_scratch(int D, int64_t n, int64_t nq_pass);
 // bias[r] (and zeroed padding rows) for rows [row0, row1); stats[0] = max |x|^2 bits, stats[1] = non-finite rows (both accumulate)
 int launch_flat_f32_bias(float *X, int D, int metric, int64_t row0, int64_t row1, float *bias, uint32_t *stats, hipStream_t st);

@@ -156,6 +156,8 @@ int cvtmi_set_device(int device);
  *                     batch.  1 M x 128-d, top-100: 1000 queries 0.97 -> 0.69 ms, 128 queries 0.25 -> 0.16 ms, 16 queries 0.119 -> 0.107 ms
  *   "flat_f32_tfilter_min"  smallest batch that takes that pipeline
  *   "flat_f32_tfilter_one"  largest batch that multiplies one product under "flat_f32_tfilter" 4
+ *   "flat_f32_tfilter_min_rows"  smallest table that takes that pipeline (default 262 144; >= 32 768.  Measured on 128-d: below ~130 K rows the stream
+ *                     kernels are ahead for fewer than 128 queries and level beyond; 200 K rows, 1000 queries 0.42 -> 0.32 ms)
  *   "flat_f32_tfilter_sample"  the sample that sets the thresholds is about 1 / this (default 5) of the row-tile groups, spread evenly over the
  *                     rows and rounded to a whole number of groups per wave (1 M x 128-d, 1000 queries: 1/8 0.63 ms, 1/5 0.505, 1/3 0.52)
  *   "flat_f32_tfilter_retry"  1 = a query whose candidate list ran over takes ONE second filter pass under the threshold its own stored
