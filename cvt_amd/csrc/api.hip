@@ -1658,7 +1658,7 @@ static int flat_add_common(cvtmi_flat_t h, const void *x, const int64_t *labels,
     if (n == 0) return CVTMI_OK;
     const int64_t total = h->n + n;
     if (total > 0xfffffffeLL) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_add: more than 2^32-2 rows per handle");
-    h->f_pack_n = -1;
+    if (h->metric == CVTMI_METRIC_L2U8) h->f_pack_n = -1;   // (fp32: the operand copy keeps covering its rows; flat_prepare packs the appended ones)
     bool explicit_labels = labels != nullptr;
     if (explicit_labels && kind == hipMemcpyHostToDevice && h->identity) {
         bool same = true;
@@ -2073,12 +2073,22 @@ static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStr
             continue;   // the route may not need an operand copy after all
         }
         if (need_f32 && (h->f_pack_n != n || h->f_pack_nch != want_nch)) {   // bf16 operand copy of the rows (same bytes as the fp32 rows)
+            // rows appended since the copy was made (the reference adds video by video): only those are packed, the buffers grow by halves
+            int64_t row0 = (h->f_pack.p && h->f_bias.p && h->f_istats.p && h->f_pack_nch == want_nch && h->f_pack_n > 0 && h->f_pack_n < n) ? h->f_pack_n : 0;
             h->f_pack_n = -1;
-            if (h->f_pack.reserve(flat_pack_bytes(want_nch, n)) != CVTMI_OK) return CVTMI_OK;   // no room: the exact path answers
-            CVTMI_TRY(h->f_bias.reserve((size_t)((n + 31) / 32) * 32 * sizeof(uint32_t)));
-            CVTMI_TRY(h->f_istats.reserve(16));
+            const size_t need_p = flat_pack_bytes(want_nch, n), need_b = (size_t)((n + 31) / 32) * 32 * sizeof(uint32_t);
+            if (row0 > 0) {
+                const size_t keep_p = flat_pack_bytes(want_nch, row0), keep_b = (size_t)((row0 + 31) / 32) * 32 * sizeof(uint32_t);
+                if (need_p > h->f_pack.cap && h->f_pack.grow(std::max(need_p, h->f_pack.cap + h->f_pack.cap / 2), keep_p, st) != CVTMI_OK) { (void)hipGetLastError(); row0 = 0; }
+                if (row0 > 0 && need_b > h->f_bias.cap) CVTMI_TRY(h->f_bias.grow(std::max(need_b, h->f_bias.cap + h->f_bias.cap / 2), keep_b, st));
+            }
+            if (row0 == 0) {
+                if (h->f_pack.reserve(need_p) != CVTMI_OK) return CVTMI_OK;   // no room: the exact path answers
+                CVTMI_TRY(h->f_bias.reserve(need_b));
+                CVTMI_TRY(h->f_istats.reserve(16));
+            }
             CVTMI_TRY(launch_flat_pack(h->data.as<float>(), n, h->D, want_nch, h->metric, h->f_pack.as<uint4>(), h->f_bias.as<uint32_t>(),
-                                       h->f_istats.as<uint32_t>(), st));
+                                       h->f_istats.as<uint32_t>(), st, row0));
             uint32_t stats[2] = { 0, 0 };
             CVTMI_HIP(hipMemcpyAsync(stats, h->f_istats.p, sizeof stats, hipMemcpyDeviceToHost, st));
             CVTMI_HIP(stream_wait(st));

@@ -43,11 +43,11 @@ __device__ __forceinline__ float blocked_at(const float *X, int D, int64_t row, 
 
 // one thread per (tile, lane): lane (li, lk) of tile t owns row 32 t + li, dimensions 16 c + 8 lk .. + 8 of chunk c.
 // stats[0] = max |x|^2 (uint bits), stats[1] = number of rows holding a non-finite value, stats[2] = max |x - x1|^2 (x1: the first bf16 term)
-__global__ __launch_bounds__(kBlock) void flat_pack_kernel(const float *__restrict__ X, int64_t n, int D, int nch, int l2, int64_t ntiles,
+__global__ __launch_bounds__(kBlock) void flat_pack_kernel(const float *__restrict__ X, int64_t n, int D, int nch, int l2, int64_t tile0, int64_t ntiles,
                                                            uint4 *__restrict__ pack, uint32_t *__restrict__ bias,
                                                            uint32_t *__restrict__ stats)
 {
-    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x + tile0 * 64;   // tiles [tile0, ntiles)
     if (g >= ntiles * 64) return;
     const int64_t t = g >> 6;
     const int lane = (int)(g & 63), li = lane & 31, lk = lane >> 5;   // nch K steps of 16 dimensions (>= D / 16: zeros beyond D)
@@ -1426,12 +1426,14 @@ bool flat_filter_applies(int metric, int D, int64_t n, int64_t nq, int k)
 
 size_t flat_pack_bytes(int nch, int64_t n) { return (size_t)((n + 31) / 32) * nch * 2 * 64 * sizeof(uint4); }
 
-int launch_flat_pack(const float *X, int64_t n, int D, int nch, int metric, uint4 *pack, uint32_t *bias, uint32_t *stats, hipStream_t st)
+// rows [row0, n) (row0 > 0: appended rows -- the tile that holds row0 is packed again, the statistics keep accumulating)
+int launch_flat_pack(const float *X, int64_t n, int D, int nch, int metric, uint4 *pack, uint32_t *bias, uint32_t *stats, hipStream_t st, int64_t row0)
 {
-    const int64_t ntiles = (n + 31) / 32;
-    CVTMI_HIP(hipMemsetAsync(stats, 0, 12, st));
-    hipLaunchKernelGGL(flat_pack_kernel, dim3((unsigned)((ntiles * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, X, n, D, nch,
-                       metric == CVTMI_METRIC_L2F ? 1 : 0, ntiles, pack, bias, stats);
+    const int64_t ntiles = (n + 31) / 32, tile0 = row0 / 32;
+    if (row0 == 0) CVTMI_HIP(hipMemsetAsync(stats, 0, 12, st));
+    if (tile0 >= ntiles) return CVTMI_OK;
+    hipLaunchKernelGGL(flat_pack_kernel, dim3((unsigned)(((ntiles - tile0) * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, X, n, D, nch,
+                       metric == CVTMI_METRIC_L2F ? 1 : 0, tile0, ntiles, pack, bias, stats);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

@@ -188,7 +188,7 @@ inline bool flat_blocked(int metric, int D) { return metric != CVTMI_METRIC_L2U8
 // flat_mfma.hip: fp32 IP / L2 search through the bf16 matrix-core filter (32 <= D <= 128, D % 16 == 0, nq >= 64)
 bool flat_filter_applies(int metric, int D, int64_t n, int64_t nq, int k);
 size_t flat_pack_bytes(int nch, int64_t n);   // nch K steps of 16 dimensions per row (>= D / 16: zeros beyond D)
-int launch_flat_pack(const float *X, int64_t n, int D, int nch, int metric, uint4 *pack, uint32_t *bias, uint32_t *stats, hipStream_t st);
+int launch_flat_pack(const float *X, int64_t n, int D, int nch, int metric, uint4 *pack, uint32_t *bias, uint32_t *stats, hipStream_t st, int64_t row0 = 0);
 int launch_flat_thr(const float *q, int64_t nq, int D, int metric, const float *sample_d, int k, uint32_t *stats, float *thr,
                     float *margin, hipStream_t st);
 int launch_flat_filter(const float *q, int64_t nq, int D, const uint4 *pack, const uint32_t *bias, const float *thr, int64_t row_begin,
