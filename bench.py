@@ -1087,10 +1087,10 @@ def _sec_flat_f32(ctx):
         ix.close()
     # widths of the reference's CNN features (pca_online / scalar_quantization: 512 / 1024-d): 1 GB of rows each, 1000 queries
     del xd
-    res["widths"] = {"rows_bytes": 1 << 30, "nq": 1000, "k": k, "cases": {}}
+    res["widths"] = {"rows_bytes": "1 GB per width (2048-d: 2 GB)", "nq": 1000, "k": k, "cases": {}}
     base = res["cases"].get("ip nq=1000", {}).get("ms")
-    for d2 in (512, 1024):
-        n2 = (1 << 30) // (4 * d2)
+    for d2 in (512, 1024, 2048):
+        n2 = max((1 << 30) // (4 * d2), 262144)   # (2048-d: 2 GB of rows -- the pipeline takes tables from 262 144 rows on)
         g = torch.Generator(device=ctx.dev); g.manual_seed(d2)
         cen2 = torch.randn((2000, d2), generator=g, device=ctx.dev)
         x2 = cen2[torch.randint(0, 2000, (n2,), generator=g, device=ctx.dev)] + 0.7 * torch.randn((n2, d2), generator=g, device=ctx.dev)
@@ -1100,9 +1100,10 @@ def _sec_flat_f32(ctx):
         ix = cvt.FlatIndex(cvt.IP, d2)
         ix.add(x2)
         ms = _ev_ms(torch, lambda: ix.search(q2, k), reps=3, warm=2)
-        c = {"rows": n2, "ms": round(ms, 4), "path": ix.last_search()[0], "ms_per_GB_of_rows": round(ms, 4)}
+        gb2 = n2 * d2 * 4 / float(1 << 30)
+        c = {"rows": n2, "ms": round(ms, 4), "path": ix.last_search()[0], "ms_per_GB_of_rows": round(ms / gb2, 4)}
         if base:
-            c["vs_128d_per_byte"] = round(ms / (base / (n * D * 4 / float(1 << 30))), 3)
+            c["vs_128d_per_byte"] = round((ms / gb2) / (base / (n * D * 4 / float(1 << 30))), 3)
         cvt.set_tuning("flat_variant", 1)
         c["exact_kernels_ms"] = round(_ev_ms(torch, lambda: ix.search(q2, k), reps=1, warm=1), 3)
         cvt.set_tuning("flat_variant", 0)

@@ -58,7 +58,7 @@ constexpr int FT_CAP = 8192;         // candidates per query the finish takes (o
 constexpr int FT_NBMAX = 16;         // query blocks a workgroup holds
 constexpr int FT_PASS = 1024;        // queries per pass of the pipeline (sizes the record area)
 constexpr int FT_KEEP = 1024;        // rows per query the finish gives exact distances
-constexpr int FT_DMAX = 1024;        // widest row
+constexpr int FT_DMAX = 2048;        // widest row
 constexpr int FT_SLACK = 4096;       // bytes of LDS behind the queries' operands that the one-wave-per-SIMD form's operand requests may read
 
 struct FtArgs {
@@ -98,9 +98,13 @@ __device__ __forceinline__ float ft_max16(const f32x16 &v)
     return fmaxf(m, v[15]);
 }
 
-template <int NCH, int NPROD, int RT, bool MAXMODE, int NW = FT_WAVES>
+// KH = 2 (1536 / 2048-d): a row tile's K steps do not fit 512 registers -- a wave holds HALF of them at a time (NCH K steps), the
+// accumulators of its ONE query block (32 queries: 128 KB of operands at 2048-d) run through both halves.
+template <int NCH, int NPROD, int RT, bool MAXMODE, int NW = FT_WAVES, int KH = 1>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void flat_f32_tfilter_kernel(const FtArgs a)
 {
+    constexpr int NCHT = NCH * KH;            // K steps of a row
+    static_assert(KH == 1 || (KH == 2 && NW == 4 && NPROD == 1 && RT == 1), "two K halves: one wave per SIMD, one tile, one product");
     constexpr int NT = NPROD == 3 ? 2 : 1;    // terms of a query in LDS
     constexpr int NA = NPROD >= 2 ? 2 : 1;    // terms of a row in registers
     extern __shared__ __attribute__((aligned(16))) uint8_t ft_q[];   // [block][K step][term] x 1 KB, then the blocks' thresholds
@@ -122,9 +126,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         return;
     }
     const int nb = (nqc + 31) >> 5;
-    float *thr_s = reinterpret_cast<float *>(ft_q + (size_t)nb * NCH * NT * 1024 + FT_SLACK);
-    for (int i = tid; i < nb * 32 * NCH * 2; i += 64 * NW) {   // (query, K step, half) -> its 16-byte slots of the terms
-        const int hl = i & 1, ss = (i >> 1) % NCH, qq = i / (2 * NCH);
+    float *thr_s = reinterpret_cast<float *>(ft_q + (size_t)nb * NCHT * NT * 1024 + FT_SLACK);
+    for (int i = tid; i < nb * 32 * NCHT * 2; i += 64 * NW) {   // (query, K step, half) -> its 16-byte slots of the terms
+        const int hl = i & 1, ss = (i >> 1) % NCHT, qq = i / (2 * NCHT);
         int qi = q0 + (qq < nqc ? qq : nqc - 1);
         if (a.qlist) qi = (int)a.qlist[qi];
         const int e0 = 16 * ss + 8 * hl;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         if (e0 + 4 < a.D) *reinterpret_cast<float4 *>(&v[4]) = *reinterpret_cast<const float4 *>(qp + 4);
         bf16x8 h, l;
         fs_split(v, h, l);
-        uint8_t *dst = ft_q + ((size_t)(((qq >> 5) * NCH + ss) * NT) * 1024) + (size_t)(hl * 32 + (qq & 31)) * 16;
+        uint8_t *dst = ft_q + ((size_t)(((qq >> 5) * NCHT + ss) * NT) * 1024) + (size_t)(hl * 32 + (qq & 31)) * 16;
         *reinterpret_cast<bf16x8 *>(dst) = h;
         if constexpr (NT == 2) *reinterpret_cast<bf16x8 *>(dst + 1024) = l;
     }
@@ -161,19 +165,32 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     uint8_t *rec_w = reinterpret_cast<uint8_t *>(a.rec) + (size_t)wave_g * a.cap * 80;   // (wave-uniform)
     bf16x8 xa[RT][NCH][NA];
     f32x16 bias[RT];
-    auto fetch = [&](int64_t g) {
+    auto fetch = [&](int64_t g, int half) {
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
             const int64_t t = g * RT + r;
             const int64_t tc = t < a.t1 ? t : a.t1 - 1;
-            const uint4 *tp = a.pack + (tc * NCH * 2) * 64 + lane;
+            const uint4 *tp = a.pack + ((tc * NCHT + half * NCH) * 2) * 64 + lane;
+            if constexpr (NCH >= 24 && NA == 1) {
+                // a running pointer the compiler cannot see through: left alone it keeps one 64-bit address per K step in registers (the
+                // 2 KB stride is beyond the loads' immediate offsets) -- 128 of them at 64 K steps, more than the operands themselves
 #pragma unroll
-            for (int s_ = 0; s_ < NCH; ++s_)
-#pragma unroll
-                for (int x = 0; x < NA; ++x) {
-                    const uint4 w = tp[(s_ * 2 + x) * 64];
-                    xa[r][s_][x] = __builtin_bit_cast(bf16x8, w);
+                for (int s_ = 0; s_ < NCH; s_ += 2) {
+                    asm volatile("" : "+v"(tp));
+                    xa[r][s_][0] = __builtin_bit_cast(bf16x8, tp[0]);
+                    if (s_ + 1 < NCH) xa[r][s_ + 1][0] = __builtin_bit_cast(bf16x8, tp[2 * 64]);
+                    tp += 4 * 64;
                 }
+            } else {
+#pragma unroll
+                for (int s_ = 0; s_ < NCH; ++s_)
+#pragma unroll
+                    for (int x = 0; x < NA; ++x) {
+                        const uint4 w = tp[(s_ * 2 + x) * 64];
+                        xa[r][s_][x] = __builtin_bit_cast(bf16x8, w);
+                    }
+            }
+            if (half != 0) continue;
             // the biases of the 16 rows a lane's accumulators stand for: row (e & 3) + 8 (e >> 2) + 4 lk of the tile
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -184,7 +201,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         }
     };
     for (int64_t g = slice + (int64_t)slices * wave; g < n_groups; g += stride, ++it) {
-        fetch(MAXMODE ? g * all_groups / a.n_sample : g);
+        const int64_t g_rows = MAXMODE ? g * all_groups / a.n_sample : g;
+        fetch(g_rows, 0);
         const uint32_t tile_row = (uint32_t)(g * RT * 32 + 4 * lk);   // first of a lane's rows in the group's first tile
         // (requesting the queries' operands two or three K steps ahead of their matrix instructions -- pinned with sched_barrier, across
         //  the block boundary -- or a block's operands at its start measured 0 .. 8 % SLOWER than the compiler's own order: read a K
@@ -203,21 +221,28 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         }
 #pragma unroll 1
         for (int b = 0; b < nb; ++b) {
-            const uint8_t *qb = ft_q + (size_t)b * (NCH * NT * 1024) + lane * 16;
+            const uint8_t *qb = ft_q + (size_t)b * (NCHT * NT * 1024) + lane * 16;
             f32x16 acc[RT];
+#pragma unroll
+          for (int half = 0; half < KH; ++half) {
+            if (half != 0) {   // (KH == 2: one query block per workgroup, so a group's halves are fetched once each)
+                __builtin_amdgcn_sched_barrier(0);   // (not above the first half's matrix instructions: both halves do not fit the registers)
+                asm volatile("" ::: "memory");
+                fetch(g_rows, half);
+            }
 #pragma unroll
             for (int s_ = 0; s_ < NCH; ++s_) {
                 bf16x8 qh;
                 if constexpr (RING) {
-                    request(b * NCH + s_ + PD, (s_ + PD) & 3);
+                    request(b * NCHT + half * NCH + s_ + PD, (half * NCH + s_ + PD) & 3);
                     __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the request down to its first use)
-                    qh = bq[s_ & 3];
+                    qh = bq[(half * NCH + s_) & 3];
                 } else {
                     qh = *reinterpret_cast<const bf16x8 *>(qb + (s_ * NT) * 1024);
                 }
 #pragma unroll
                 for (int r = 0; r < RT; ++r)
-                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[r][s_][0], qh, s_ == 0 ? bias[r] : acc[r], 0, 0, 0);   // b_x rides in as SrcC
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[r][s_][0], qh, (s_ == 0 && half == 0) ? bias[r] : acc[r], 0, 0, 0);   // b_x rides in as SrcC
                 if constexpr (NPROD >= 2) {   // (the low terms on accumulators of their own, four independent chains: no faster)
 #pragma unroll
                     for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[r][s_][1], qh, acc[r], 0, 0, 0);
@@ -227,6 +252,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
                     for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[r][s_][0], ql, acc[r], 0, 0, 0);
                 }
+            }
+          }
+            if (KH > 1 && b + 1 < nb) {   // (more than one block with two halves: the first half again)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" ::: "memory");
+                fetch(g_rows, 0);
             }
             // the maxima below are inline assembly: the compiler's hazard recogniser does not put the wait states between a matrix
             // instruction's result and a vector instruction that reads it in front of those (measured: rows lost), so they are spelled out
@@ -610,12 +641,13 @@ void set_flat_f32_tfilter_min_rows(int v) { g_ft_min_rows = v < 32768 ? 32768 : 
 void set_flat_f32_tfilter_sample(int v) { g_ft_sample_div = v < 1 ? 1 : (v > 64 ? 64 : v); }
 void set_flat_f32_tfilter_min(int v) { g_ft_min_nq = v < 1 ? 1 : v; }
 // widths: the K steps (16 dimensions each) of a row tile stay in a wave's registers (RT tiles of 32 rows: RT x K steps x terms x 4 registers
-// <= 128, 256 with one wave per SIMD).  A kernel exists for 2 / 4 / 6 / 8 / 10 / 12 / 16 / 24 / 32 / 48 / 64 K steps; a width in between (any
-// multiple of 4 up to 1024: 100-d, 200-d, 300-d ...) runs on the next one over zero-padded operands.  0: no kernel
+// <= 128, 256 with one wave per SIMD; 96 / 128 K steps in two halves of 48 / 64).  A kernel exists for 2 / 4 / 6 / 8 / 10 / 12 / 16 / 24 / 32 /
+// 48 / 64 / 96 / 128 K steps; a width in between (any multiple of 4 up to 2048: 100-d, 200-d, 300-d ...) runs on the next one over
+// zero-padded operands.  0: no kernel
 int flat_f32_tfilter_nch(int D)
 {
-    static const int steps[] = { 2, 4, 6, 8, 10, 12, 16, 24, 32, 48, 64 };
-    if (D < 4 || D > 1024 || D % 4 != 0) return 0;
+    static const int steps[] = { 2, 4, 6, 8, 10, 12, 16, 24, 32, 48, 64, 96, 128 };
+    if (D < 4 || D > 2048 || D % 4 != 0) return 0;
     for (int s_ : steps)
         if (16 * s_ >= D) return s_;
     return 0;
@@ -633,16 +665,16 @@ size_t flat_f32_tfilter_scratch(int64_t nq)
     return (size_t)m * (FT_SLOTS + 8) * sizeof(uint32_t) + (size_t)m * FT_CAP * sizeof(uint2) + (size_t)FT_GRID * FT_WAVES * (sizeof(uint32_t) + (size_t)ft_rec_cap(m) * 80) + 1024;
 }
 
-template <int NCH, int NPROD, int RT, int NW = FT_WAVES>
+template <int NCH, int NPROD, int RT, int NW = FT_WAVES, int KH = 1>
 static int ft_launch(bool maxmode, const FtArgs &a, size_t lds, hipStream_t st)
 {
     static std::atomic<bool> attr_a[16] = {}, attr_b[16] = {};
     if (maxmode) {
-        CVTMI_TRY(fs_set_lds((const void *)flat_f32_tfilter_kernel<NCH, NPROD, RT, true, NW>, 163840, attr_a));
-        hipLaunchKernelGGL((flat_f32_tfilter_kernel<NCH, NPROD, RT, true, NW>), dim3(FT_GRID), dim3(64 * NW), lds, st, a);
+        CVTMI_TRY(fs_set_lds((const void *)flat_f32_tfilter_kernel<NCH, NPROD, RT, true, NW, KH>, 163840, attr_a));
+        hipLaunchKernelGGL((flat_f32_tfilter_kernel<NCH, NPROD, RT, true, NW, KH>), dim3(FT_GRID), dim3(64 * NW), lds, st, a);
     } else {
-        CVTMI_TRY(fs_set_lds((const void *)flat_f32_tfilter_kernel<NCH, NPROD, RT, false, NW>, 163840, attr_b));
-        hipLaunchKernelGGL((flat_f32_tfilter_kernel<NCH, NPROD, RT, false, NW>), dim3(FT_GRID), dim3(64 * NW), lds, st, a);
+        CVTMI_TRY(fs_set_lds((const void *)flat_f32_tfilter_kernel<NCH, NPROD, RT, false, NW, KH>, 163840, attr_b));
+        hipLaunchKernelGGL((flat_f32_tfilter_kernel<NCH, NPROD, RT, false, NW, KH>), dim3(FT_GRID), dim3(64 * NW), lds, st, a);
     }
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
@@ -686,7 +718,9 @@ static int ft_launch_any(int D, int nprod, bool maxmode, const FtArgs &a, size_t
     case 24 * 4 + 1: return ft_launch<24, 1, 1>(maxmode, a, lds, st);
     case 32 * 4 + 1: return ft_launch<32, 1, 1>(maxmode, a, lds, st);
     case 48 * 4 + 1: return ft_launch<48, 1, 1, 4>(maxmode, a, lds, st);   // 768-d, 1024-d: one wave per SIMD (512 registers)
-    case 64 * 4 + 1: return ft_launch<64, 1, 1, 4>(maxmode, a, lds, st);   // 1024-d: a row tile's 64 K steps take 256 registers -- one wave per SIMD
+    case 64 * 4 + 1: return ft_launch<64, 1, 1, 4>(maxmode, a, lds, st);   // 1024-d
+    case 96 * 4 + 1: return ft_launch<48, 1, 1, 4, 2>(maxmode, a, lds, st);   // 1536-d, 2048-d: a row tile's K steps in two halves
+    case 128 * 4 + 1: return ft_launch<64, 1, 1, 4, 2>(maxmode, a, lds, st);
     }
     return fail(CVTMI_EINVAL, "flat_f32_tfilter: no kernel for D=%d with %d products", D, nprod);
 }

@@ -147,7 +147,7 @@ int cvtmi_set_device(int device);
  *   "scanh_balance" / "scanh_min_rows" / "scanh_tail" / "scanh_fix" / "scanh_share_hist"  planner of the persistent-grid scan (variant
  *                     6): 0 choose / 1 equal row-time shares / 2 row blocks; smallest row segment; two-region tail on / off; an item's
  *                     fixed cost in row-equivalents (160 000); one candidate histogram per query shared by its segments (1) or not
- *   "flat_f32_tfilter" fp32 searches (32 / 64 / 96 / 128 / 160 / 192 / 256 / 384 / 512 / 768 / 1024-d, >= 262 144 rows, k <= 128) of "flat_f32_tfilter_min" (default 16) queries or more run as a
+ *   "flat_f32_tfilter" fp32 searches (any width that is a multiple of 4 up to 2048-d, >= 262 144 rows, k <= 128) of "flat_f32_tfilter_min" (default 16) queries or more run as a
  *                     threshold filter (round 6, flat_f32_tfilter.hip): sample maxima -> per-query threshold -> queries in LDS, the rows'
  *                     bf16 operand copy in registers, no barrier, hits recorded -> per-query lists -> exact distances.  1 .. 3 = the
  *                     bf16 products per term: 1 (x1.q1), 2 ((x1 + x2).q1; both with margins from each query's own rounding residues),
@@ -301,7 +301,7 @@ int64_t cvtmi_opq_scan_plan(int64_t n_rows, int64_t nq, int splits, int cus, int
 int cvtmi_opq_describe_dispatch(int D, int M, int K, int64_t n_rows, int64_t nq, int k, int out[7]);
 
 /* The same for a flat search (metric: CVTMI_METRIC_*; pure host logic): out[0] = 1 the fp32 one-stream kernels / 2 the fp32 threshold filter
- * (round 6: 32 ... 1024-d in the widths listed under "flat_f32_tfilter", >= 262 144 rows, batches from "flat_f32_tfilter_min" queries on), out[1] = the fp32 sample + matrix-core filter
+ * (round 6: any width that is a multiple of 4 up to 2048-d, >= 262 144 rows, batches from "flat_f32_tfilter_min" queries on), out[1] = the fp32 sample + matrix-core filter
  * pipeline is eligible behind them, out[2] = the uint8 sample + filter pipeline, out[3] = uint8 streaming passes of up
  * to 128 queries; all zero: the exact / row-tile kernels. */
 int cvtmi_flat_describe_dispatch(int metric, int D, int64_t n_rows, int64_t nq, int k, int out[4]);

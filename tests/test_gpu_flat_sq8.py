@@ -997,6 +997,35 @@ def test_flat_f32_threshold_filter_widths(amd, orc, metric, D, nq, k):
     assert np.array_equal(is_[:3], oi) and np.array_equal(bits(ds[:3]), bits(od))
 
 
+@pytest.mark.parametrize("metric,D,nq,k", [(L2F, 2048, 70, 10), (IP, 2048, 33, 100), (IP, 1536, 100, 100), (L2F, 1200, 64, 20)])
+def test_flat_f32_threshold_filter_two_k_halves(amd, orc, metric, D, nq, k):
+    """1536 / 2048-d rows (and widths padded up to them): a row tile's K steps go through a wave's registers in two halves, one query
+    block per workgroup.  A table of 40 000 rows takes the pipeline through "flat_f32_tfilter_min_rows"; against the exact kernels on
+    every query and the checker on three"""
+    rng = np.random.default_rng(D + nq + k + metric)
+    n = 40_000 + 13
+    x = _clustered(rng, n, D, metric)
+    x[10_000:10_140] = x[5]
+    x[n - 1] = x[123]
+    q = (x[rng.integers(0, n, nq)] + 0.05 * rng.normal(size=(nq, D))).astype(np.float32)
+    q[0] = x[5]; q[3] = x[123]
+    q = np.ascontiguousarray(q, np.float32)
+    try:
+        amd.set_tuning("flat_f32_tfilter_min_rows", 32768)
+        ix = amd.FlatIndex(metric, D); ix.add(x)
+        ds, is_ = ix.search(q, k)
+        assert ix.last_search()[0] == 3
+        amd.set_tuning("flat_variant", 1)
+        de, ie = ix.search(q, k)
+        assert ix.last_search()[0] == 0
+        ix.close()
+    finally:
+        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_tfilter_min_rows", 262144)
+    assert np.array_equal(is_, ie) and np.array_equal(bits(ds), bits(de))
+    od, _, oi = orc.flat_search(metric, x, q[:3], k, flavour=4 if metric == IP else 8)
+    assert np.array_equal(is_[:3], oi) and np.array_equal(bits(ds[:3]), bits(od))
+
+
 def test_flat_f32_threshold_filter_second_attempt(amd):
     """candidate lists that run over: with "flat_f32_tfilter_retry" 1 such a query takes a second filter pass under the threshold its
     stored candidates give ("flat_f32_dbg" 32 loosens the sample's thresholds so that lists do run over and second attempts succeed),

@@ -183,9 +183,9 @@ def test_flat_dispatch_rules_of_round_5():
         assert flat_dispatch(L2F, D, 1_000_000, 15, k=100)["f32_stream"] == 1 and flat_dispatch(L2F, D, 1_000_000, 16, k=100)["f32_stream"] == 2
         assert flat_dispatch(IP, D, 262_143, 1000, k=100)["f32_stream"] == 1 and flat_dispatch(IP, D, 262_144, 1000, k=128)["f32_stream"] == 2
     assert flat_dispatch(L2F, 128, 32_767, 1, k=100)["f32_stream"] == 0
-    for D in (102, 1028, 2048):
+    for D in (102, 2052, 4096):
         assert flat_dispatch(L2F, D, 1_000_000, 100, k=100)["f32_stream"] == 0
-    for D in (100, 160, 320, 384, 512, 768, 900, 1024):   # round 6: widths only the threshold filter takes (from 16 queries over 262 144 rows on)
+    for D in (100, 160, 320, 384, 512, 768, 900, 1024, 1536, 2048):   # round 6: widths only the threshold filter takes (from 16 queries over 262 144 rows on)
         assert flat_dispatch(L2F, D, 1_000_000, 100, k=100)["f32_stream"] == 2 and flat_dispatch(IP, D, 1_000_000, 15, k=100)["f32_stream"] == 0
         assert flat_dispatch(L2F, D, 262_143, 100, k=100)["f32_stream"] == 0
     assert flat_dispatch(L2F, 128, 1_000_000, 100, k=129)["f32_stream"] == 0
