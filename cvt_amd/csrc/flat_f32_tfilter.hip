@@ -1,5 +1,6 @@
 // flat_f32_tfilter.hip -- exhaustive fp32 search (BruteforceSearch<float>::searchKnn, brutoforce.hpp:73-93, with InnerProductSpace,
-// space_ip.hpp:211-239, or L2Space, space_l2.h:153-184) for LARGE BATCHES of 64-d / 128-d queries as a threshold filter (round 6).
+// space_ip.hpp:211-239, or L2Space, space_l2.h:153-184) for BATCHES (16 queries and more, 262 144 rows and more) of any width that is a
+// multiple of 4 up to 2048-d, as a threshold filter (round 6).
 //
 // The answer -- the k smallest (distance, row) per query, distances in the reference's own summation order -- comes out bit for
 // bit because every reported distance is evaluated by the exact code (fs_exact, dist_f32.h order).  The matrix cores only decide
@@ -19,7 +20,7 @@
 //     distances in the end stay k and a few (101 / 119 / 136);
 //   * a lane whose 16 scores reach its threshold writes them as ONE record (16 scores, query, first row: 80 bytes) into its
 //     wave's own region of a record area -- no atomic, no wait; `wcnt` counts a wave's records.
-// Pipeline: (1) MAX mode over a leading sample of the rows: 1024 maxima of disjoint row sets per query (global atomic max, no
+// Pipeline: (1) MAX mode over a sample of the rows (a fifth of the tile groups, spread evenly): 1024 maxima of disjoint row sets per query (global atomic max, no
 // return); the k-th largest of them is reached by k distinct rows, so it bounds the k-th best score from below, and theta - margin
 // admits every row that can be among the k best (ft_theta_kernel).  (2) FILTER mode over all rows.  (3) ft_bucket_kernel: the
 // records' scores at or above the threshold go to per-query candidate lists.  (4) ft_finish_kernel, one workgroup per query: the

@@ -216,7 +216,7 @@ void set_flat_f32_dbg(int v);     // timing experiments, results wrong when non-
 void set_flat_f32_share(int v);   // shared-ring kernel: 0 choose, 1 four waves x 32 QB queries, 2 eight waves x 32 queries
 void set_flat_f32_nt(int v);     // 0 = never, 1 = choose (default), 2 = always: non-temporal hint on the stream kernels' row loads
 bool flat_f32_stream_applies(int metric, int D, int64_t n, int k);
-// round 6 (flat_f32_tfilter.hip): batches (D = 32 .. 512 in the widths of flat_f32_tfilter_width, >= 262 144 rows, k <= 128) as a threshold filter: queries in LDS, the rows'
+// round 6 (flat_f32_tfilter.hip): batches (any width that is a multiple of 4 up to 2048-d, >= 262 144 rows, k <= 128) as a threshold filter: queries in LDS, the rows'
 // bf16 operand copy (launch_flat_pack) in registers, per-query thresholds from sample maxima, candidate lists, exact finish;
 // redo[nq] (zeroed inside): 1 = the exact kernels must answer the query
 int flat_f32_tfilter_nch(int D);   // K steps of the kernel that takes D-dimensional rows (0: none)
