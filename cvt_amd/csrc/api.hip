@@ -477,6 +477,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "flat_f32_tfilter_min")) { set_flat_f32_tfilter_min((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_one")) { set_flat_f32_tfilter_one((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_retry")) { set_flat_f32_tfilter_retry((int)value); return CVTMI_OK; }
+    if (!strcmp(name, "flat_f32_packed")) { set_flat_f32_packed((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_min_rows")) { set_flat_f32_tfilter_min_rows((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_sample")) { set_flat_f32_tfilter_sample((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_share")) {
@@ -1861,11 +1862,14 @@ static int flat_search_streamed(cvtmi_flat_t h, FlatScratch &S, const float *q, 
     const int64_t per = (nq + passes - 1) / passes;
     if (S.fs_scratch.reserve(flat_f32_stream_scratch(D, n, per)) != CVTMI_OK) return CVTMI_OK;   // no room: the exact path answers
     CVTMI_TRY(S.fs_redo.reserve((size_t)nq * 2 * sizeof(uint32_t)));   // redo flags, then list counters
+    // round 6: the bf16 operand copy of the threshold filter, when the handle keeps one, is what a small batch streams (half the bytes)
+    const bool have_pack = h->f_pack.p && h->f_istats.p && h->f_pack_n == n && D % 16 == 0 && h->f_pack_nch == D / 16 && !h->f_nonfinite;
     for (int64_t a = 0; a < nq; a += per) {
         const int64_t m = std::min(per, nq - a);
         CVTMI_TRY(launch_flat_f32_stream(h->metric, D, h->data.as<float>(), h->fs_bias.as<float>(), h->fs_stats.as<uint32_t>(), n, q + a * D, m, k,
                                          S.fs_scratch.p, dist + a * k, rows + a * k, S.fs_redo.as<uint32_t>() + a,
-                                         S.fs_redo.as<uint32_t>() + nq + a, st));
+                                         S.fs_redo.as<uint32_t>() + nq + a, st, have_pack ? h->f_pack.p : nullptr,
+                                         have_pack ? h->f_istats.as<uint32_t>() : nullptr));
     }
     // queries the bound does not cover / whose lists ran over: the exact kernels, predicated on the flags (they exit at once otherwise)
     CVTMI_TRY(flat_search_rows(h, S, n, q, nq, k, dist, rows, st, INT64_MAX, S.fs_redo.as<uint32_t>()));
@@ -2055,7 +2059,9 @@ static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStr
             std::shared_lock<std::shared_timed_mutex> rd(h->rw);
             r = flat_route(h, q, nq, k, tun);
             need_fs = (r.stream || r.tfilter) && h->fs_stats_n != h->n;
-            const bool tf = r.tfilter && !h->fs_nonfinite;   // the threshold filter reads the copy too
+            // the threshold filter reads the copy, and so do the stream kernels for small batches on tables of its size
+            const bool tf = (r.tfilter || (r.stream && h->D % 16 == 0 && flat_f32_tfilter_nch(h->D) == h->D / 16 && h->n >= flat_f32_tfilter_min_rows())) &&
+                            !h->fs_nonfinite;
             want_nch = tf ? flat_f32_tfilter_nch(h->D) : h->D / 16;
             need_f32 = (h->f_pack_n != h->n || h->f_pack_nch != want_nch) &&
                        (tf ? !need_fs : (r.filt_f32 && !(r.stream && !need_fs && !h->fs_nonfinite)));   // (the stream answers: no copy needed)

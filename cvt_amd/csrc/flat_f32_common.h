@@ -128,6 +128,25 @@ __device__ __forceinline__ uint32_t fs_wave_select(const uint32_t (&key)[NK], in
     return c;
 }
 
+// |q - q1|^2 by one wave, q1 = the bf16 operand of fs_split (the same conversion, value for value)
+__device__ __forceinline__ float fs_qlow(const float *q, int D)
+{
+    float s_ = 0.0f;
+    for (int e0 = 8 * (threadIdx.x & 63); e0 < D; e0 += 512) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = q[e0 + e];
+        bf16x8 h, l;
+        fs_split(v, h, l);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float r = v[e] - (float)h[e];   // exact (Sterbenz-like: q1 is q rounded to 8 bits)
+            s_ = __fmaf_rn(r, r, s_);
+        }
+    }
+    return fs_wave_sum(s_);
+}
+
 // (host) the dynamic-LDS attribute of a kernel, once per device
 static int fs_set_lds(const void *fn, size_t lds, std::atomic<bool> (&done)[16])
 {

@@ -109,25 +109,27 @@ __device__ __forceinline__ void fs_fold_max(float (&s_)[V], int sub)
 constexpr int fs_log2(int v) { return v <= 1 ? 0 : 1 + fs_log2(v / 2); }
 
 // ring geometry: a UNIT is UK K steps (16 dimensions each) of one tile = 2 UK pieces of 1 KB
-template <int NCH> struct FsGeom {
+// PACKED (round 6): the rows come from the bf16 operand copy of the threshold filter (flat_pack_kernel) -- ONE ready-made 1 KB piece
+// per K step (the first term) instead of two fp32 pieces that are split on the fly: half the bytes of a pass, one product per term.
+template <int NCH, bool PACKED = false> struct FsGeom {
     static constexpr int UK = NCH % 4 == 0 ? 4 : (NCH % 2 == 0 ? 2 : 1);
     static constexpr int NU = NCH / UK;                        // units per tile
-    static constexpr int UNIT = UK * 2048;                     // bytes
+    static constexpr int UNIT = UK * (PACKED ? 1024 : 2048);   // bytes
     static constexpr int RU = 32768 / UNIT;                    // ring units per wave (32 KB)
     static constexpr int RB = RU / NU + 3;                     // bias slots (256 B each): tiles that can be in flight + 1
     static constexpr int WAVE_LDS = RU * UNIT + RB * 256;
-    static constexpr int OPS = 2 * UK + 1;                     // DMA requests per unit
+    static constexpr int OPS = (PACKED ? UK : 2 * UK) + 1;     // DMA requests per unit
 };
 
 // X: blocked fp32 rows (float4 c of the 64 rows of block b contiguous: ((b * D/4 + c) * 64 + r) float4); bias[n_tiles * 32];
 // gb[((q * NG + g) * FS_WAVES + wave) * 32 + j] = (best, second) of rows (wave + (g G + p) FS_WAVES) * 32 + j, p < G;
 // wm[q * FS_WAVES + wave] = the largest best of the wave (the finish derives its first threshold from these 1024 values)
-template <int NCH, int QB>
+template <int NCH, int QB, bool PACKED = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flat_f32_mstream_kernel(
     const float *__restrict__ X, const float *__restrict__ bias, int64_t n_tiles, const float *__restrict__ Q, int nq, int G, int NG,
     float2 *__restrict__ gb, float *__restrict__ wm, uint32_t *__restrict__ zero_a, uint32_t *__restrict__ zero_b, int nt)
 {
-    using Ge = FsGeom<NCH>;
+    using Ge = FsGeom<NCH, PACKED>;
     constexpr int D = 16 * NCH, UK = Ge::UK, NU = Ge::NU, UNIT = Ge::UNIT, RU = Ge::RU, RB = Ge::RB, OPS = Ge::OPS;
     constexpr int NACC = QB == 1 ? 2 : QB;                     // QB == 1: two chains so that back-to-back products are independent
     extern __shared__ __attribute__((aligned(16))) uint8_t fs_ring[];   // [4 waves][RU units | RB bias slots]
@@ -161,13 +163,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int i = uc / NU;
         const int part = uc - i * NU;
         const int64_t t = wave_g + (int64_t)i * FS_WAVES;
-        const float *tile = X + ((t >> 1) * (int64_t)(D / 4) * 64 + (t & 1) * 32 + lj) * 4;   // row j of the tile, float4 0
         const uint32_t dst = ring_b + (uint32_t)((uc % RU) * UNIT);
+        if constexpr (PACKED) {   // X = the operand copy: [tile][K step][first | second term][64 lanes] x 16 bytes
+            const uint8_t *tile = reinterpret_cast<const uint8_t *>(X) + ((t * NCH + part * UK) * 2) * 1024 + lane * 16;
 #pragma unroll
-        for (int s = 0; s < UK; ++s)
+            for (int s = 0; s < UK; ++s) fs_glds16(tile + (size_t)s * 2048, dst + (uint32_t)(s * 1024), nt);
+        } else {
+            const float *tile = X + ((t >> 1) * (int64_t)(D / 4) * 64 + (t & 1) * 32 + lj) * 4;   // row j of the tile, float4 0
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-                fs_glds16(tile + (int64_t)(4 * (part * UK + s) + 2 * lk + h) * 256, dst + (uint32_t)((2 * s + h) * 1024), nt);
+            for (int s = 0; s < UK; ++s)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    fs_glds16(tile + (int64_t)(4 * (part * UK + s) + 2 * lk + h) * 256, dst + (uint32_t)((2 * s + h) * 1024), nt);
+        }
         fs_glds4(bias + t * 32 + lj, bias_b + (uint32_t)((i % RB) * 256));
     };
     if (my_tiles > 0) {
@@ -202,12 +210,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
 #pragma unroll
             for (int s = 0; s < UK; ++s) {
+                const int ks = part * UK + s;
+                if constexpr (PACKED) {
+                    const bf16x8 xp = *reinterpret_cast<const bf16x8 *>(ub + s * 1024);
+                    if constexpr (QB == 1) {   // two chains over alternate K steps: back-to-back products stay independent
+                        acc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[0][ks], xp, acc[s & 1], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[b][ks], xp, acc[b], 0, 0, 0);
+                    }
+                    continue;
+                }
                 float v[8];
                 *reinterpret_cast<float4 *>(&v[0]) = *reinterpret_cast<const float4 *>(ub + (2 * s) * 1024);
                 *reinterpret_cast<float4 *>(&v[4]) = *reinterpret_cast<const float4 *>(ub + (2 * s + 1) * 1024);
                 bf16x8 xh, xl;
                 fs_split(v, xh, xl);
-                const int ks = part * UK + s;
                 if constexpr (QB == 1) {
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[0][ks], xh, acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[0][ks], xl, acc[1], 0, 0, 0);
@@ -576,8 +594,9 @@ struct FsFinishArgs {
     const float2 *gb; const float *wm; int G, NG, S;
     int ns_log;                  // log2 of the row streams of the pass (1024 waves, or 256 workgroups of the shared-ring kernel)
     const uint32_t *stats;       // [0] max |x|^2
+    const uint32_t *pstats;      // packed form (one product over the operand copy's first terms): [2] max |x - x1|^2; null otherwise
     uint32_t *cnt;               // [nq] listed groups (zeroed by the caller)
-    float *qb;                   // [nq] Q = (|q|^2 + max |x|^2) * 1.001 of the query (collect -> finish)
+    float *qb;                   // [nq] Q = (|q|^2 + max |x|^2) * 1.001 of the query, [nq] its margin term W (collect -> finish)
     uint4 *list;                 // [nq][FSF_LIST] (best bits, second bits, entry, -)
     float *out_d; int64_t *out_i;
     uint32_t *redo;              // [nq]: 1 = the exact kernels must answer this query
@@ -629,8 +648,11 @@ __global__ __launch_bounds__(kBlock) void flat_f32_stream_collect_kernel(const F
         if (Qb > 0x1p-60f && Qb < 0x1p60f) {   // (false for a non-finite query as well)
             const float theta1 = key_f32(fs_wave_select(key, a.k, a.k + a.k / 4 + 8));
             if (theta1 > FS_EMPTY) {           // else: fewer than k waves saw a row, not this kernel's case
-                cut1 = theta1 - fs_margin<IP>(Qb, a.D, theta1);
-                if (sl == 0 && lane == 0) a.qb[qi] = Qb;
+                // packed form: what the omitted low terms can add up to for this query (flat_f32_tfilter.hip, NPROD 1)
+                float w = 0.0f;
+                if (a.pstats) w = (sqrtf(__uint_as_float(a.stats[0]) * fs_qlow(a.Q + qi * a.D, a.D)) + sqrtf(__uint_as_float(a.pstats[2]) * qq)) * 1.01f;
+                cut1 = theta1 - fs_margin<IP>(Qb, a.D, theta1) - 2.0f * w;
+                if (sl == 0 && lane == 0) { a.qb[qi] = Qb; a.qb[a.nq + qi] = w; }
             }
         }
         if (lane == 0) {
@@ -741,7 +763,7 @@ __global__ __launch_bounds__(kBlock) void flat_f32_stream_finish_kernel(const Fs
     __syncthreads();
     FS_T(9);
     const float theta = key_f32(theta_s);
-    const float cut = theta - fs_margin<IP>(Qb, D, theta);
+    const float cut = theta - fs_margin<IP>(Qb, D, theta) - (a.pstats ? 2.0f * a.qb[a.nq + qi] : 0.0f);
     // candidates: the best row of a qualifying group comes with its exact distance; a group whose second best qualifies as well
     // has all its rows evaluated here
     __shared__ int ndone_s;
@@ -832,6 +854,8 @@ static int fs_qb_max(int nch)
 static std::atomic<int> g_fs_dbgflags{0};     // timing experiments (results wrong when non-zero): cvtmi_set_tuning("flat_f32_dbg")
 void set_flat_f32_dbg(int v) { g_fs_dbgflags = v; }
 int get_flat_f32_dbg() { return g_fs_dbgflags.load(); }
+static std::atomic<int> g_fs_packed{1};  // cvtmi_set_tuning("flat_f32_packed"): 1 = small batches stream the bf16 operand copy when there is one
+void set_flat_f32_packed(int v) { g_fs_packed = v != 0; }
 static std::atomic<int> g_fs_nt{1};      // cvtmi_set_tuning("flat_f32_nt"): 0 = never, 1 = choose, 2 = always
 void set_flat_f32_nt(int v) { g_fs_nt = v; }
 // non-temporal row loads: measured better wherever the stream kernel is bound by the rows (one query 0.119 -> 0.106 ms,
@@ -923,6 +947,26 @@ static int fs_launch_eight(const FsStreamArgs &a, hipStream_t st)
         return fail(CVTMI_EINVAL, "flat_f32_stream: eight waves at D=%d", 16 * NCH);
     }
 }
+template <int NCH, int QB>
+static int fs_launch_packed_qb(const FsStreamArgs &a, const void *pack, hipStream_t st)
+{
+    static std::atomic<bool> attr_set[16] = {};
+    const size_t lds = (size_t)4 * FsGeom<NCH, true>::WAVE_LDS;
+    CVTMI_TRY(fs_set_lds((const void *)flat_f32_mstream_kernel<NCH, QB, true>, lds, attr_set));
+    hipLaunchKernelGGL((flat_f32_mstream_kernel<NCH, QB, true>), dim3(FS_BLOCKS), dim3(256), lds, st, reinterpret_cast<const float *>(pack), a.bias, a.n_tiles, a.q, a.nq,
+                       a.G, a.NG, a.gb, a.wm, a.redo, a.cnt, fs_nt(false, QB) ? 1 : 0);
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+template <int NCH>
+static int fs_launch_packed(int qb, const FsStreamArgs &a, const void *pack, hipStream_t st)
+{
+    if constexpr (3 * (8 * NCH + 48) <= 368) {
+        if (qb == 3) return fs_launch_packed_qb<NCH, 3>(a, pack, st);
+    }
+    if (qb == 2) return fs_launch_packed_qb<NCH, 2>(a, pack, st);
+    return fs_launch_packed_qb<NCH, 1>(a, pack, st);
+}
 template <int NCH, int QB, bool SHARED>
 static int fs_launch_stream(const FsStreamArgs &a, hipStream_t st)
 {
@@ -960,7 +1004,8 @@ static int fs_launch_qb(int qb, const FsStreamArgs &a, hipStream_t st)
 // one pass: nq <= flat_f32_stream_qmax(D) queries against rows [0, n); results for queries whose redo flag stays 0.
 // redo[nq] and cnt[nq] are zeroed inside
 int launch_flat_f32_stream(int metric, int D, const float *X, const float *bias, const uint32_t *stats, int64_t n, const float *q, int64_t nq,
-                           int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, uint32_t *cnt, hipStream_t st)
+                           int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, uint32_t *cnt, hipStream_t st, const void *pack,
+                           const uint32_t *pstats)
 {
     const int qmax = flat_f32_stream_qmax(D);
     if (qmax == 0 || nq < 1 || nq > qmax) return fail(CVTMI_EINVAL, "flat_f32_stream: D=%d nq=%lld", D, (long long)nq);
@@ -975,8 +1020,10 @@ int launch_flat_f32_stream(int metric, int D, const float *X, const float *bias,
     const FsStreamArgs sa = { X, bias, (n + 31) / 32, q, (int)nq, G, NG, gb, wm, redo, cnt };
     const int qb = shared ? (int)((nq + 127) / 128) : (int)((nq + 31) / 32);
     const bool eight = shared && fs_eight(D);
+    // round 6: up to 32 queries over the bf16 operand copy of the rows when the handle keeps one (half the bytes, one product per term)
+    const bool packed = pack != nullptr && pstats != nullptr && !shared && qb <= 3 && g_fs_packed.load() != 0;
 #define CVTMI_FS(NCH_) \
-    case NCH_: CVTMI_TRY(eight ? fs_launch_eight<NCH_>(sa, st) : shared ? (fs_launch_qb<NCH_, true>(qb, sa, st)) : (fs_launch_qb<NCH_, false>(qb, sa, st))); break;
+    case NCH_: CVTMI_TRY(packed ? fs_launch_packed<NCH_>(qb, sa, pack, st) : eight ? fs_launch_eight<NCH_>(sa, st) : shared ? (fs_launch_qb<NCH_, true>(qb, sa, st)) : (fs_launch_qb<NCH_, false>(qb, sa, st))); break;
     switch (D / 16) {
         CVTMI_FS(2) CVTMI_FS(4) CVTMI_FS(6) CVTMI_FS(8) CVTMI_FS(12) CVTMI_FS(16)
         default: return fail(CVTMI_EUNSUPPORTED, "flat_f32_stream: D=%d", D);
@@ -984,6 +1031,7 @@ int launch_flat_f32_stream(int metric, int D, const float *X, const float *bias,
 #undef CVTMI_FS
     FsFinishArgs fa;
     fa.X = X; fa.n = n; fa.D = D; fa.Q = q; fa.nq = nq; fa.k = k; fa.gb = gb; fa.wm = wm; fa.G = G; fa.NG = NG; fa.stats = stats;
+    fa.pstats = packed ? pstats : nullptr;
     fa.ns_log = shared ? 8 : 10;
     fa.cnt = cnt; fa.list = list; fa.qb = qbuf; fa.out_d = out_d; fa.out_i = out_i; fa.redo = redo;
     // slices per query: one batch of loads per thread (2048 entries per slice) while that keeps the grid near one round of workgroups

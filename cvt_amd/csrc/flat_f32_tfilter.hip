@@ -313,25 +313,6 @@ __device__ __forceinline__ float ft_margin(float Qb, float w, float theta)
     if (IP) m += (2.0f + fabsf(theta)) * 0x1p-20f;   // the rounding of 1 - sum in the reference
     return m;
 }
-// |q - q1|^2 by one wave, q1 = the bf16 operand of fs_split (the same conversion, value for value)
-__device__ __forceinline__ float ft_qlow(const float *q, int D)
-{
-    float s_ = 0.0f;
-    for (int e0 = 8 * (threadIdx.x & 63); e0 < D; e0 += 512) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = q[e0 + e];
-        bf16x8 h, l;
-        fs_split(v, h, l);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float r = v[e] - (float)h[e];   // exact (Sterbenz-like: q1 is q rounded to 8 bits)
-            s_ = __fmaf_rn(r, r, s_);
-        }
-    }
-    return fs_wave_sum(s_);
-}
-
 // one wave per query: theta = the k-th largest of its sample maxima, thr = theta - margin (NaN + redo when the bound does not hold)
 template <bool IP>
 __global__ __launch_bounds__(256) void ft_theta_kernel(const uint32_t *__restrict__ smax, const float *__restrict__ Q, int nq, int D, int k, int nprod,
@@ -347,7 +328,7 @@ __global__ __launch_bounds__(256) void ft_theta_kernel(const uint32_t *__restric
     const float Qb = (qq + __uint_as_float(stats[0])) * 1.001f;
     // nprod 2: (x1 + x2).(q - q1) <= (1 + e^2) max |x| |q - q1|; nprod 1: that and (x - x1).q <= max |x - x1| |q|
     float xq2 = 0.0f;
-    if (nprod <= 2) xq2 = sqrtf(__uint_as_float(stats[0]) * ft_qlow(Q + (int64_t)q * D, D)) * 1.01f;
+    if (nprod <= 2) xq2 = sqrtf(__uint_as_float(stats[0]) * fs_qlow(Q + (int64_t)q * D, D)) * 1.01f;
     if (nprod == 1) xq2 += sqrtf(__uint_as_float(pstats[2]) * qq) * 1.01f;
     float cut = __uint_as_float(0x7fc00000u);
     if (Qb > 0x1p-60f && Qb < 0x1p60f) {
@@ -633,14 +614,16 @@ static std::atomic<int> g_ft_sample_div{5};   // "flat_f32_tfilter_sample": the 
 static std::atomic<int> g_ft_retry{0};     // "flat_f32_tfilter_retry": 1 = a second filter pass for the queries whose candidate lists ran over, 0 (default) = the exact kernels at once
 static std::atomic<int> g_ft_one_max{1 << 30}; // "flat_f32_tfilter_one": largest batch that multiplies one product (with the staged bucket pass one product wins at every
                                            // batch size measured: 1000 queries 0.74 -> 0.64 ms, 4096 2.9 -> 2.5, 10 000 7.0 -> 6.5; two products beyond this many queries)
-static std::atomic<int> g_ft_min_nq{16};   // cvtmi_set_tuning("flat_f32_tfilter_min"): smallest batch that takes the pipeline (1 M x 128-d: 16 queries 0.119 -> 0.107 ms,
-                                           // 128 queries 0.25 -> 0.16; below, the pipeline's five launches cost more than the stream's two)
+static std::atomic<int> g_ft_min_nq{0};    // cvtmi_set_tuning("flat_f32_tfilter_min"): smallest batch that takes the pipeline; 0 = choose: 65 at the widths the
+                                           // stream kernels take (up to 64 queries they stream the operand copy's first terms: 1 M x 128-d, 16 / 64 queries
+                                           // 0.079 / 0.096 ms against 0.112 / 0.125 here, level at 80-96), 16 elsewhere (against the exact kernels)
 void set_flat_f32_tfilter(int v) { g_ft_on = v < 0 ? 0 : (v > 4 ? 4 : v); }
 void set_flat_f32_tfilter_one(int v) { g_ft_one_max = v < 0 ? 0 : v; }
 void set_flat_f32_tfilter_retry(int v) { g_ft_retry = v != 0; }
 void set_flat_f32_tfilter_min_rows(int v) { g_ft_min_rows = v < 32768 ? 32768 : v; }
+int64_t flat_f32_tfilter_min_rows() { return g_ft_min_rows.load(); }
 void set_flat_f32_tfilter_sample(int v) { g_ft_sample_div = v < 1 ? 1 : (v > 64 ? 64 : v); }
-void set_flat_f32_tfilter_min(int v) { g_ft_min_nq = v < 1 ? 1 : v; }
+void set_flat_f32_tfilter_min(int v) { g_ft_min_nq = v < 0 ? 0 : v; }
 // widths: the K steps (16 dimensions each) of a row tile stay in a wave's registers (RT tiles of 32 rows: RT x K steps x terms x 4 registers
 // <= 128, 256 with one wave per SIMD; 96 / 128 K steps in two halves of 48 / 64).  A kernel exists for 2 / 4 / 6 / 8 / 10 / 12 / 16 / 24 / 32 /
 // 48 / 64 / 96 / 128 K steps; a width in between (any multiple of 4 up to 2048: 100-d, 200-d, 300-d ...) runs on the next one over
@@ -657,7 +640,7 @@ bool flat_f32_tfilter_width(int D) { return flat_f32_tfilter_nch(D) != 0; }
 bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k)
 {
     return g_ft_on.load() && (metric == CVTMI_METRIC_IP || metric == CVTMI_METRIC_L2F) && flat_f32_tfilter_width(D) && n >= g_ft_min_rows.load() && n < 0xffffffe0LL &&
-           nq >= g_ft_min_nq.load() && k >= 1 && k <= 128;
+           nq >= (g_ft_min_nq.load() > 0 ? g_ft_min_nq.load() : (flat_f32_stream_qmax(D) > 0 ? 65 : 16)) && k >= 1 && k <= 128;
 }
 static uint32_t ft_rec_cap(int64_t m) { return (uint32_t)std::min<int64_t>(3072, std::max<int64_t>(256, 3 * m)); }
 size_t flat_f32_tfilter_scratch(int64_t nq)

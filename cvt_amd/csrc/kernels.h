@@ -231,12 +231,15 @@ void set_flat_f32_tfilter_one(int v);
 void set_flat_f32_tfilter_retry(int v);
 void set_flat_f32_tfilter_sample(int v);
 void set_flat_f32_tfilter_min_rows(int v);
+int64_t flat_f32_tfilter_min_rows();
 size_t flat_f32_stream_scratch(int D, int64_t n, int64_t nq_pass);
 // bias[r] (and zeroed padding rows) for rows [row0, row1); stats[0] = max |x|^2 bits, stats[1] = non-finite rows (both accumulate)
 int launch_flat_f32_bias(float *X, int D, int metric, int64_t row0, int64_t row1, float *bias, uint32_t *stats, hipStream_t st);
 // redo[nq], cnt[nq] (zeroed inside): redo is set to 1 for queries the exact kernels must answer
 int launch_flat_f32_stream(int metric, int D, const float *X, const float *bias, const uint32_t *stats, int64_t n, const float *q, int64_t nq,
-                           int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, uint32_t *cnt, hipStream_t st);
+                           int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, uint32_t *cnt, hipStream_t st, const void *pack = nullptr,
+                           const uint32_t *pstats = nullptr);
+void set_flat_f32_packed(int v);   // 1 (default): up to 32 queries stream the bf16 operand copy (launch_flat_pack) when pack / pstats are given
 int flat_u8_mfma_qtile(int D, int k, int64_t nq);  // queries per workgroup, 0 = shape not covered
 int flat_u8_mfma_splits(int64_t n, int64_t nq, int qt);
 // gthr: nq uint32 scratch (set to 0xff.. inside) through which the row splits of a query share their k-th best

@@ -147,15 +147,19 @@ int cvtmi_set_device(int device);
  *   "scanh_balance" / "scanh_min_rows" / "scanh_tail" / "scanh_fix" / "scanh_share_hist"  planner of the persistent-grid scan (variant
  *                     6): 0 choose / 1 equal row-time shares / 2 row blocks; smallest row segment; two-region tail on / off; an item's
  *                     fixed cost in row-equivalents (160 000); one candidate histogram per query shared by its segments (1) or not
- *   "flat_f32_tfilter" fp32 searches (any width that is a multiple of 4 up to 2048-d, >= 262 144 rows, k <= 128) of "flat_f32_tfilter_min" (default 16) queries or more run as a
+ *   "flat_f32_tfilter" fp32 searches (any width that is a multiple of 4 up to 2048-d, >= 262 144 rows, k <= 128) of "flat_f32_tfilter_min" queries or more run as a
  *                     threshold filter (round 6, flat_f32_tfilter.hip): sample maxima -> per-query threshold -> queries in LDS, the rows'
  *                     bf16 operand copy in registers, no barrier, hits recorded -> per-query lists -> exact distances.  1 .. 3 = the
  *                     bf16 products per term: 1 (x1.q1), 2 ((x1 + x2).q1; both with margins from each query's own rounding residues),
  *                     3 (x1.q1 + x2.q1 + x1.q2, the stream kernels' margin); 4 (default) = one product up to "flat_f32_tfilter_one"
  *                     (default: no limit -- measured ahead at every batch size) queries, two beyond; 0 = the stream kernels for every
  *                     batch.  1 M x 128-d, top-100: 1000 queries 0.97 -> 0.69 ms, 128 queries 0.25 -> 0.16 ms, 16 queries 0.119 -> 0.107 ms
- *   "flat_f32_tfilter_min"  smallest batch that takes that pipeline
+ *   "flat_f32_tfilter_min"  smallest batch that takes that pipeline; 0 (default) = choose: 65 at the widths the stream kernels take (smaller batches
+ *                     stream the operand copy, "flat_f32_packed"), 16 at the others
  *   "flat_f32_tfilter_one"  largest batch that multiplies one product under "flat_f32_tfilter" 4
+ *   "flat_f32_packed" 1 (default) = fp32 searches of up to 32 queries (the stream kernels' private rings) read the bf16 operand copy the threshold
+ *                     filter keeps -- one ready-made term per value, half the bytes of the fp32 rows, one product, margins from the query's
+ *                     own rounding residues -- on tables that have one (>= "flat_f32_tfilter_min_rows" rows); 0 = the fp32 rows, split on the fly
  *   "flat_f32_tfilter_min_rows"  smallest table that takes that pipeline (default 262 144; >= 32 768.  Measured on 128-d: below ~130 K rows the stream
  *                     kernels are ahead for fewer than 128 queries and level beyond; 200 K rows, 1000 queries 0.42 -> 0.32 ms)
  *   "flat_f32_tfilter_sample"  the sample that sets the thresholds is about 1 / this (default 5) of the row-tile groups, spread evenly over the

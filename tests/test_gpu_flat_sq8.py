@@ -937,7 +937,7 @@ def test_flat_f32_threshold_filter(amd, orc, metric, D, k, prods):
     x[77] = x[5]
     x[n - 1] = x[123]
     try:
-        amd.set_tuning("flat_f32_tfilter", prods)
+        amd.set_tuning("flat_f32_tfilter", prods); amd.set_tuning("flat_f32_tfilter_min", 16)
         ix = amd.FlatIndex(metric, D); ix.add(x[:n - 5_000])
         out = {}
         for nq in (16, 129, 160, 513, 1030):
@@ -961,13 +961,13 @@ def test_flat_f32_threshold_filter(amd, orc, metric, D, k, prods):
             assert np.array_equal(is_, ie) and np.array_equal(bits(ds), bits(de)), nq
         ix.close()
     finally:
-        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_tfilter", 4)
+        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_tfilter", 4); amd.set_tuning("flat_f32_tfilter_min", 0)
     assert np.array_equal(is2, ie2) and np.array_equal(bits(ds2), bits(de2))
     od, _, oi = orc.flat_search(metric, x, q160[:4], k, flavour=4 if metric == IP else 8)
     assert np.array_equal(is2[:4], oi) and np.array_equal(bits(ds2[:4]), bits(od))
 
 
-@pytest.mark.parametrize("metric,D,nq,k", [(L2F, 32, 300, 100), (IP, 96, 64, 10), (L2F, 160, 200, 100), (IP, 192, 700, 50), (L2F, 256, 129, 128),
+@pytest.mark.parametrize("metric,D,nq,k", [(L2F, 32, 300, 100), (IP, 96, 70, 10), (L2F, 160, 200, 100), (IP, 192, 700, 50), (L2F, 256, 129, 128),
                                             (IP, 384, 100, 100), (L2F, 512, 520, 20), (IP, 512, 33, 100), (L2F, 768, 150, 10), (IP, 1024, 100, 100),
                                             (L2F, 1024, 1100, 5), (IP, 100, 200, 100), (L2F, 100, 600, 10), (L2F, 20, 64, 100), (IP, 200, 128, 50),
                                             (L2F, 300, 1000, 100), (IP, 900, 40, 100)])
@@ -1026,6 +1026,42 @@ def test_flat_f32_threshold_filter_two_k_halves(amd, orc, metric, D, nq, k):
     assert np.array_equal(is_[:3], oi) and np.array_equal(bits(ds[:3]), bits(od))
 
 
+@pytest.mark.parametrize("metric,D,k", [(L2F, 128, 100), (IP, 128, 10), (L2F, 64, 128), (IP, 256, 100), (L2F, 32, 1), (IP, 192, 50)])
+def test_flat_f32_stream_over_operand_copy(amd, orc, metric, D, k):
+    """small batches (1 ... 64 queries) on a table that keeps the threshold filter's bf16 operand copy stream that copy's first terms
+    ("flat_f32_packed" 1, round 6: half the bytes, one product, margins from the query's own rounding residues) instead of the fp32 rows:
+    same lists and bits as the fp32 stream and the exact kernels; one / two / three query blocks per wave, ragged last tile, duplicates,
+    queries that are rows, a non-finite query and a huge one (handed to the exact kernels), rows appended between searches"""
+    rng = np.random.default_rng(D + k + metric)
+    n = 262_144 + 3_000 + 21
+    x = _clustered(rng, n, D, metric)
+    x[150_000:150_140] = x[5]
+    x[n - 1] = x[123]
+    try:
+        ix = amd.FlatIndex(metric, D); ix.add(x[:n - 2_000])
+        for nq in (1, 5, 33, 64):
+            q = (x[rng.integers(0, n - 2_000, nq)] + 0.05 * rng.normal(size=(nq, D))).astype(np.float32)
+            q[0] = x[5]
+            if nq > 4:
+                q[2, 0] = np.nan; q[4] *= np.float32(2.0 ** 70)
+            q = np.ascontiguousarray(q, np.float32)
+            amd.set_tuning("flat_variant", 1); de, ie = ix.search(q, k); amd.set_tuning("flat_variant", 0)
+            for pk in (1, 0):
+                amd.set_tuning("flat_f32_packed", pk)
+                ds, is_ = ix.search(q, k)
+                assert ix.last_search()[0] == 2, (nq, pk)
+                assert np.array_equal(is_, ie) and np.array_equal(bits(ds), bits(de)), (nq, pk)
+        amd.set_tuning("flat_f32_packed", 1)
+        ix.add(x[n - 2_000:])
+        q = np.ascontiguousarray(x[[5, 123, n - 1, 77]] + np.float32(0.01))
+        ds, is_ = ix.search(q, k)
+        od, _, oi = orc.flat_search(metric, x, q, k, flavour=4 if metric == IP else 8)
+        assert np.array_equal(is_, oi) and np.array_equal(bits(ds), bits(od))
+        ix.close()
+    finally:
+        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_packed", 1)
+
+
 def test_flat_f32_threshold_filter_second_attempt(amd):
     """candidate lists that run over: with "flat_f32_tfilter_retry" 1 such a query takes a second filter pass under the threshold its
     stored candidates give ("flat_f32_dbg" 32 loosens the sample's thresholds so that lists do run over and second attempts succeed),
@@ -1069,7 +1105,7 @@ def test_flat_f32_threshold_filter_hands_hard_queries_to_the_exact_kernels(amd):
         for name, xx, lab, qq in (("ties", x, None, q), ("labels", x, labels, q), ("inf row", xn, None, q), ("five queries", x, None, q[:5])):
             out = {}
             for v in (0, 1):
-                amd.set_tuning("flat_variant", v); amd.set_tuning("flat_f32_tfilter_min", 1 if name == "five queries" else 16)
+                amd.set_tuning("flat_variant", v); amd.set_tuning("flat_f32_tfilter_min", 1 if name == "five queries" else 0)
                 ix = amd.FlatIndex(L2F, D); ix.add(xx, labels=lab)
                 out[v] = ix.search(qq, k)
                 if v == 0:
@@ -1078,7 +1114,7 @@ def test_flat_f32_threshold_filter_hands_hard_queries_to_the_exact_kernels(amd):
             assert np.array_equal(out[0][1], out[1][1]), name
             assert np.array_equal(bits(out[0][0]), bits(out[1][0])), name
     finally:
-        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_tfilter_min", 16)
+        amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_tfilter_min", 0)
 
 
 @pytest.mark.parametrize("d,n", [(512, 20_000), (256, 17_001), (128, 40_000), (100, 16_385), (516, 16_400), (4, 70_000)])

@@ -175,12 +175,13 @@ def test_flat_dispatch_rules_of_round_5():
     assert flat_dispatch(L2U8, 512, 4095, 100) == dict(f32_stream=0, f32_filter=0, u8_filter=0, u8_stream=0)
     assert flat_dispatch(L2U8, 96, 1_000_000, 16)["u8_stream"] == 0                      # widths the matrix-core kernels do not take
     # fp32: the stream at its widths from 32 768 rows (structural: lowered, it returned a wrong list), exact kernels elsewhere
-    # (round 6: 64 / 128-d batches of 16 queries or more over 262 144 rows or more take the threshold filter, route 2)
+    # (round 6: batches of 65 queries or more -- 16 at the widths the stream kernels do not take -- over 262 144 rows or more take the threshold
+    #  filter, route 2)
     for D in (32, 64, 96, 128, 192, 256):
         assert flat_dispatch(L2F, D, 32_768, 1, k=100)["f32_stream"] == 1
         assert flat_dispatch(IP, D, 1_000_000, 1000, k=100)["f32_stream"] == 2
     for D in (32, 64, 96, 128, 192, 256):
-        assert flat_dispatch(L2F, D, 1_000_000, 15, k=100)["f32_stream"] == 1 and flat_dispatch(L2F, D, 1_000_000, 16, k=100)["f32_stream"] == 2
+        assert flat_dispatch(L2F, D, 1_000_000, 64, k=100)["f32_stream"] == 1 and flat_dispatch(L2F, D, 1_000_000, 65, k=100)["f32_stream"] == 2
         assert flat_dispatch(IP, D, 262_143, 1000, k=100)["f32_stream"] == 1 and flat_dispatch(IP, D, 262_144, 1000, k=128)["f32_stream"] == 2
     assert flat_dispatch(L2F, 128, 32_767, 1, k=100)["f32_stream"] == 0
     for D in (102, 2052, 4096):
