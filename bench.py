@@ -1072,8 +1072,10 @@ def _sec_flat_f32(ctx):
             if c["path"] == 3 and nq <= 256:   # threshold filter, one bf16 product: bound by the first-term plane of the operand copy
                 c["roofline"] = _hbm(n * D * 2, ms)
                 c["roofline"]["note"] = "algorithmic bytes = the first bf16 term of every row once (the sample pass re-reads a fifth)"
-            elif nq <= 96:   # one stream over the rows: bound by HBM
-                c["roofline"] = _hbm(n * D * 4, ms)
+            elif nq <= 96:   # one stream over the rows: bound by HBM -- round 6: over the first bf16 terms of the operand copy (2 bytes per value)
+                c["roofline"] = _hbm(n * D * 2, ms)
+                c["roofline"]["note"] = ("algorithmic bytes = the first bf16 term of every row once (\"flat_f32_packed\": the stream kernels read the threshold "
+                                         "filter's operand copy; rounds 3-5 streamed the 4-byte rows: %.3f of the HBM peak on those bytes)" % (n * D * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
             else:          # bf16 matrix cores: products per (query, row, dimension)
                 prods = 1 if c["path"] == 3 else 3
                 tf = prods * 2.0 * nq * n * D / (ms * 1e-3) / 1e12
