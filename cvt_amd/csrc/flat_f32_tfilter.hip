@@ -614,7 +614,7 @@ static std::atomic<int> g_ft_sample_div{5};   // "flat_f32_tfilter_sample": the 
 static std::atomic<int> g_ft_retry{0};     // "flat_f32_tfilter_retry": 1 = a second filter pass for the queries whose candidate lists ran over, 0 (default) = the exact kernels at once
 static std::atomic<int> g_ft_one_max{1 << 30}; // "flat_f32_tfilter_one": largest batch that multiplies one product (with the staged bucket pass one product wins at every
                                            // batch size measured: 1000 queries 0.74 -> 0.64 ms, 4096 2.9 -> 2.5, 10 000 7.0 -> 6.5; two products beyond this many queries)
-static std::atomic<int> g_ft_min_nq{0};    // cvtmi_set_tuning("flat_f32_tfilter_min"): smallest batch that takes the pipeline; 0 = choose: 65 at the widths the
+static std::atomic<int> g_ft_min_nq{0};    // cvtmi_set_tuning("flat_f32_tfilter_min"): smallest batch that takes the pipeline; 0 = choose (ft_auto_min): 65 - 97 at the widths the
                                            // stream kernels take (up to 64 queries they stream the operand copy's first terms: 1 M x 128-d, 16 / 64 queries
                                            // 0.079 / 0.096 ms against 0.112 / 0.125 here, level at 80-96), 16 elsewhere (against the exact kernels)
 void set_flat_f32_tfilter(int v) { g_ft_on = v < 0 ? 0 : (v > 4 ? 4 : v); }
@@ -637,10 +637,17 @@ int flat_f32_tfilter_nch(int D)
     return 0;
 }
 bool flat_f32_tfilter_width(int D) { return flat_f32_tfilter_nch(D) != 0; }
+// smallest batch under "flat_f32_tfilter_min" 0: beyond what one pass of the private-ring stream takes over the operand copy where that is
+// ahead (128-d: 96 queries 0.125 against 0.143 ms here; 64-d: 80 queries 0.137 against 0.129), 16 at widths the stream does not take
+static int ft_auto_min(int D)
+{
+    if (flat_f32_stream_qmax(D) == 0) return 16;
+    return D >= 96 ? std::max(65, flat_f32_stream_private_max(D) + 1) : 65;
+}
 bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k)
 {
     return g_ft_on.load() && (metric == CVTMI_METRIC_IP || metric == CVTMI_METRIC_L2F) && flat_f32_tfilter_width(D) && n >= g_ft_min_rows.load() && n < 0xffffffe0LL &&
-           nq >= (g_ft_min_nq.load() > 0 ? g_ft_min_nq.load() : (flat_f32_stream_qmax(D) > 0 ? 65 : 16)) && k >= 1 && k <= 128;
+           nq >= (g_ft_min_nq.load() > 0 ? g_ft_min_nq.load() : ft_auto_min(D)) && k >= 1 && k <= 128;
 }
 static uint32_t ft_rec_cap(int64_t m) { return (uint32_t)std::min<int64_t>(3072, std::max<int64_t>(256, 3 * m)); }
 size_t flat_f32_tfilter_scratch(int64_t nq)

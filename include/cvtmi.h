@@ -154,7 +154,7 @@ int cvtmi_set_device(int device);
  *                     3 (x1.q1 + x2.q1 + x1.q2, the stream kernels' margin); 4 (default) = one product up to "flat_f32_tfilter_one"
  *                     (default: no limit -- measured ahead at every batch size) queries, two beyond; 0 = the stream kernels for every
  *                     batch.  1 M x 128-d, top-100: 1000 queries 0.97 -> 0.69 ms, 128 queries 0.25 -> 0.16 ms, 16 queries 0.119 -> 0.107 ms
- *   "flat_f32_tfilter_min"  smallest batch that takes that pipeline; 0 (default) = choose: 65 at the widths the stream kernels take (smaller batches
+ *   "flat_f32_tfilter_min"  smallest batch that takes that pipeline; 0 (default) = choose: 65 ... 97 at the widths the stream kernels take (smaller batches
  *                     stream the operand copy, "flat_f32_packed"), 16 at the others
  *   "flat_f32_tfilter_one"  largest batch that multiplies one product under "flat_f32_tfilter" 4
  *   "flat_f32_packed" 1 (default) = fp32 searches of up to 32 queries (the stream kernels' private rings) read the bf16 operand copy the threshold

@@ -967,7 +967,7 @@ def test_flat_f32_threshold_filter(amd, orc, metric, D, k, prods):
     assert np.array_equal(is2[:4], oi) and np.array_equal(bits(ds2[:4]), bits(od))
 
 
-@pytest.mark.parametrize("metric,D,nq,k", [(L2F, 32, 300, 100), (IP, 96, 70, 10), (L2F, 160, 200, 100), (IP, 192, 700, 50), (L2F, 256, 129, 128),
+@pytest.mark.parametrize("metric,D,nq,k", [(L2F, 32, 300, 100), (IP, 96, 100, 10), (L2F, 160, 200, 100), (IP, 192, 700, 50), (L2F, 256, 129, 128),
                                             (IP, 384, 100, 100), (L2F, 512, 520, 20), (IP, 512, 33, 100), (L2F, 768, 150, 10), (IP, 1024, 100, 100),
                                             (L2F, 1024, 1100, 5), (IP, 100, 200, 100), (L2F, 100, 600, 10), (L2F, 20, 64, 100), (IP, 200, 128, 50),
                                             (L2F, 300, 1000, 100), (IP, 900, 40, 100)])

@@ -181,8 +181,9 @@ def test_flat_dispatch_rules_of_round_5():
         assert flat_dispatch(L2F, D, 32_768, 1, k=100)["f32_stream"] == 1
         assert flat_dispatch(IP, D, 1_000_000, 1000, k=100)["f32_stream"] == 2
     for D in (32, 64, 96, 128, 192, 256):
-        assert flat_dispatch(L2F, D, 1_000_000, 64, k=100)["f32_stream"] == 1 and flat_dispatch(L2F, D, 1_000_000, 65, k=100)["f32_stream"] == 2
+        assert flat_dispatch(L2F, D, 1_000_000, 64, k=100)["f32_stream"] == 1 and flat_dispatch(L2F, D, 1_000_000, 97, k=100)["f32_stream"] == 2
         assert flat_dispatch(IP, D, 262_143, 1000, k=100)["f32_stream"] == 1 and flat_dispatch(IP, D, 262_144, 1000, k=128)["f32_stream"] == 2
+    assert flat_dispatch(L2F, 64, 1_000_000, 65, k=100)["f32_stream"] == 2 and flat_dispatch(L2F, 128, 1_000_000, 96, k=100)["f32_stream"] == 1
     assert flat_dispatch(L2F, 128, 32_767, 1, k=100)["f32_stream"] == 0
     for D in (102, 2052, 4096):
         assert flat_dispatch(L2F, D, 1_000_000, 100, k=100)["f32_stream"] == 0
