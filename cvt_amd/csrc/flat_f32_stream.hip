@@ -872,7 +872,9 @@ static int fs_many_queries() { return fs_wide() ? 8 * 64 : 32 * FS_MANY; }
 // Round 6: the eight- / twelve-wave forms are no longer chosen, only asked for ("flat_f32_share" 2 / 3).  A width sweep against the
 // exact kernels found ONE query of ~10^5 (2 M x 64-d rows, 1000 queries, L2: the row at rank 99 missing, tools/f32_tfilter_widths.py)
 // that both of them answer wrongly and the four-wave form, the private rings and the threshold filter answer correctly -- not
-// understood (the feeders / non-feeders protocol is the difference), so not trusted.  Batches of 16 queries and more over 262 144
+// understood, so not trusted.  What is known: deterministic (the same query and row on every run, whatever the non-temporal hints), it
+// needs the whole 2 M rows (the first 1.9 M: right) AND the query at its place in a pass of 334 or 500 queries -- the same query in the same
+// wave of a pass of 200 queries is answered correctly, as it is in passes that start at query 60 or 64.  Batches of 16 queries and more over 262 144
 // rows and more go through flat_f32_tfilter.hip anyway; what is left to the shared ring are large batches on smaller tables.
 static bool fs_eight(int D) { return g_fs_share >= 2 && (D == 64 || D == 128); }
 static bool fs_four(int D) { return (D / 16) % 4 == 0; }
