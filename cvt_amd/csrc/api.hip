@@ -476,6 +476,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "flat_f32_tfilter")) { set_flat_f32_tfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_min")) { set_flat_f32_tfilter_min((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_one")) { set_flat_f32_tfilter_one((int)value); return CVTMI_OK; }
+    if (!strcmp(name, "flat_f32_tfilter_bigk")) { set_flat_f32_tfilter_bigk((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_retry")) { set_flat_f32_tfilter_retry((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_packed")) { set_flat_f32_packed((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_min_rows")) { set_flat_f32_tfilter_min_rows((int)value); return CVTMI_OK; }
@@ -1841,7 +1842,7 @@ static int flat_search_streamed(cvtmi_flat_t h, FlatScratch &S, const float *q, 
     const int64_t n = h->n;
     if (!h->fs_bias.p || !h->fs_stats.p || h->fs_stats_n != n || h->fs_nonfinite) return CVTMI_OK;
     if (flat_f32_tfilter_applies(h->metric, D, n, nq, k) && h->f_pack.p && h->f_pack_n == n && h->f_pack_nch == flat_f32_tfilter_nch(D) && !h->f_nonfinite &&
-        S.fs_scratch.reserve(flat_f32_tfilter_scratch(nq)) == CVTMI_OK) {
+        S.fs_scratch.reserve(flat_f32_tfilter_scratch(nq, k)) == CVTMI_OK) {
         // large batches (round 6, flat_f32_tfilter.hip): sample maxima -> per-query threshold -> barrier-free threshold filter (queries in
         // LDS, the rows' bf16 operand copy in registers) -> exact distances of the candidates; flagged queries go through the exact
         // kernels below, as for the stream

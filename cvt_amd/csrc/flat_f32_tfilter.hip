@@ -54,7 +54,11 @@ namespace {
 
 constexpr int FT_WAVES = 8;          // per workgroup: two per SIMD
 constexpr int FT_GRID = 256;         // workgroups: one per CU
-constexpr int FT_SLOTS = 1024;       // sample maxima per query
+constexpr int FT_SLOTS = 1024;       // sample maxima per query (k <= 128)
+constexpr int FT_SLOTS_BIG = 4096;   // k = 129 .. 2048
+constexpr int FT_CAP_BIG = 32768;    // candidates per query of ft_finish_big_kernel (its keys fill 128 KB of LDS)
+constexpr int FT_KEEP_BIG = 4096;    // rows per query it gives exact distances (k and the rows inside the margin band)
+constexpr int FT_PASS_BIG = 256;     // queries per pass for k > 128 (the record area: ~k ln-ish times more hits per query)
 constexpr int FT_CAP = 8192;         // candidates per query the finish takes (one product on 1 M SIFT-like rows: 2 700 on average, 4 900 at most)
 constexpr int FT_NBMAX = 16;         // query blocks a workgroup holds
 constexpr int FT_PASS = 1024;        // queries per pass of the pipeline (sizes the record area)
@@ -71,7 +75,8 @@ struct FtArgs {
     const float *Q;
     int D;                   // floats per query (<= 16 NCH: the operands are zero beyond it)
     int nq, chunks, qper;    // queries of chunk c: [c qper, min(nq, (c + 1) qper)), qper a multiple of 32
-    uint32_t *smax;          // MAX mode: [nq][FT_SLOTS] ordered keys (zeroed by the caller)
+    uint32_t *smax;          // MAX mode: [nq][nslots] ordered keys (zeroed by the caller)
+    int nslots;              // sample maxima per query (a power of two)
     const float *thr;        // FILTER mode: [nq] (NaN: nothing passes)
     uint4 *rec;              // FILTER mode: [FT_GRID waves][cap] records of 5 x 16 bytes
     uint32_t *wcnt;          // FILTER mode: [FT_GRID waves] records a wave had (beyond cap: not stored)
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     // sample maxima: FT_SLOTS disjoint row sets per query -- (wave, half) of the chunk's workgroups, and when those are fewer than
     // FT_SLOTS (many chunks: few slices each) every wave deals its tile groups round-robin to sub_slots sets of its own (a threshold
     // from 128 maxima for k = 100 let 8 000 - 22 000 rows per query through)
-    const int wave_slots = slices * NW * 2, sub_slots = wave_slots >= FT_SLOTS ? 1 : FT_SLOTS / wave_slots;
+    const int wave_slots = slices * NW * 2, sub_slots = wave_slots >= a.nslots ? 1 : a.nslots / wave_slots;
     const int slot0 = ((slice * NW + wave) * 2 + lk) * sub_slots;
     int it = 0;
     uint32_t wcnt = 0;
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
                 for (int r = 1; r < RT; ++r) m = fmaxf(m, ft_max16(acc[r]));
                 // (32-bit offset from the scalar base: the 64-bit address arithmetic of a 64-lane scatter was a third of this pass)
-                const uint32_t off = (uint32_t)(q0 + qq) * (uint32_t)FT_SLOTS + (uint32_t)((slot0 + (it & (sub_slots - 1))) & (FT_SLOTS - 1));
+                const uint32_t off = (uint32_t)(q0 + qq) * (uint32_t)a.nslots + (uint32_t)((slot0 + (it & (sub_slots - 1))) & (a.nslots - 1));
                 if (qq < nqc && m > FS_EMPTY) atomicMax(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(a.smax) + off * 4u), f32_key(m));
             } else {
                 const float tb = thr_s[qq];
@@ -314,16 +319,16 @@ __device__ __forceinline__ float ft_margin(float Qb, float w, float theta)
     return m;
 }
 // one wave per query: theta = the k-th largest of its sample maxima, thr = theta - margin (NaN + redo when the bound does not hold)
-template <bool IP>
+template <bool IP, int NK>
 __global__ __launch_bounds__(256) void ft_theta_kernel(const uint32_t *__restrict__ smax, const float *__restrict__ Q, int nq, int D, int k, int nprod,
                                                        const uint32_t *__restrict__ stats, const uint32_t *__restrict__ pstats, float loosen, float *__restrict__ thr, float *__restrict__ qbnd,
                                                        uint32_t *__restrict__ redo)
 {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq) return;
-    uint32_t key[FT_SLOTS / 64];
+    uint32_t key[NK];   // NK x 64 sample maxima
 #pragma unroll
-    for (int j = 0; j < FT_SLOTS / 64; ++j) key[j] = smax[(size_t)q * FT_SLOTS + j * 64 + lane];
+    for (int j = 0; j < NK; ++j) key[j] = smax[(size_t)q * (NK * 64) + j * 64 + lane];
     const float qq = fs_qnorm(Q + (int64_t)q * D, D);
     const float Qb = (qq + __uint_as_float(stats[0])) * 1.001f;
     // nprod 2: (x1 + x2).(q - q1) <= (1 + e^2) max |x| |q - q1|; nprod 1: that and (x - x1).q <= max |x - x1| |q|
@@ -357,7 +362,7 @@ constexpr int FT_STAGE = 12288;
 __global__ __launch_bounds__(FT_BUCKET_T) void ft_bucket_kernel(const uint4 *__restrict__ rec, const uint32_t *__restrict__ wcnt, uint32_t cap,
                                                                 const float *__restrict__ thr, uint32_t *__restrict__ cnt, uint2 *__restrict__ cand,
                                                                 int chunks, int qper, int nq, uint32_t *__restrict__ redo, int nw,
-                                                                const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ qcount)
+                                                                const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ qcount, uint32_t fcap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t ft_stage[];   // uint2 [FT_STAGE] (score, row), then uint16 [FT_STAGE] query within the chunk
     __shared__ uint32_t hist[32 * FT_NBMAX], base_s[32 * FT_NBMAX];
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(FT_BUCKET_T) void ft_bucket_kernel(const uint4 *__r
             const uint32_t ql = st_q[i];
             const uint32_t q = qlist ? qlist[q0 + ql] : (uint32_t)(q0 + ql);
             const uint32_t pos = base_s[ql] + atomicAdd(&hist[ql], 1u);
-            if (pos < (uint32_t)FT_CAP) cand[(size_t)q * FT_CAP + pos] = st_sr[i];
+            if (pos < fcap) cand[(size_t)q * fcap + pos] = st_sr[i];
         }
         return;
     }
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(FT_BUCKET_T) void ft_bucket_kernel(const uint4 *__r
             for (int e = 0; e < 4; ++e) {
                 if (__uint_as_float(sv[e]) >= tb) {
                     const uint32_t pos = base_s[ql] + atomicAdd(&hist[ql], 1u);
-                    if (pos < (uint32_t)FT_CAP) cand[(size_t)h.x * FT_CAP + pos] = make_uint2(sv[e], h.y + (uint32_t)(e + 8 * jj));
+                    if (pos < fcap) cand[(size_t)h.x * fcap + pos] = make_uint2(sv[e], h.y + (uint32_t)(e + 8 * jj));
                 }
             }
         }
@@ -605,12 +610,146 @@ __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict_
     }
 }
 
+
+// k = 129 .. 2048: one workgroup of 1024 threads per query, the candidates' keys in LDS (FT_CAP_BIG of them), the same steps as above --
+// radix select of the k-th largest score, the rows at or above it minus the margin (at most FT_KEEP_BIG) get exact distances -- and a
+// bitonic sort of the (distance, row) pairs instead of ranking by counting.
+__device__ __forceinline__ void ft_bitonic_u64(unsigned long long *e, int np, int nthreads)
+{
+    for (int size = 2; size <= np; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < np / 2; i += nthreads) {
+                const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long a0 = e[lo], a1 = e[hi];
+                if ((a0 > a1) == up) { e[lo] = a1; e[hi] = a0; }
+            }
+        }
+    }
+    __syncthreads();
+}
+template <bool IP, int LANES>
+__global__ __launch_bounds__(1024) void ft_finish_big_kernel(const float *__restrict__ X, int64_t n, int D, const float *__restrict__ Q, int k,
+                                                             const float *__restrict__ thr, const float *__restrict__ qbnd, const uint32_t *__restrict__ cnt,
+                                                             const uint2 *__restrict__ cand, float *__restrict__ out_d, int64_t *__restrict__ out_i,
+                                                             uint32_t *__restrict__ redo, int nqb)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t fb_keys[];   // [FT_CAP_BIG] keys; later [FT_KEEP_BIG] (distance, row) pairs
+    __shared__ __attribute__((aligned(16))) float q_s[FT_DMAX];
+    __shared__ uint32_t rows_s[FT_KEEP_BIG];
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t pick_s[2];
+    __shared__ int m2_s;
+    constexpr int NTH = 1024;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const float cut = thr[q];
+    const uint32_t nc = cnt[q];
+    const int64_t want = k < n ? k : n;
+    if (redo[q] != 0u) return;
+    if (!(cut == cut) || nc > (uint32_t)FT_CAP_BIG || (int64_t)nc < want) {   // workgroup-uniform: the exact kernels answer this query
+        if (tid == 0) redo[q] = 1u;
+        return;
+    }
+    for (int i = tid; i < D; i += NTH) q_s[i] = Q[(int64_t)q * D + i];
+    if (tid == 0) m2_s = 0;
+    const uint2 *cq = cand + (size_t)q * FT_CAP_BIG;
+    uint32_t kmx = 0u, kmn = 0xffffffffu;
+    for (uint32_t i = tid; i < nc; i += NTH) {
+        uint32_t key = f32_key(__uint_as_float(cq[i].x));
+        key = key == 0u ? 1u : key;
+        fb_keys[i] = key;
+        kmx = key > kmx ? key : kmx; kmn = key < kmn ? key : kmn;
+    }
+    kmx = fs_wave_max_u32(kmx); kmn = fs_wave_min_u32(kmn);
+    if (lane == 0) { hist[tid >> 6] = kmx; hist[16 + (tid >> 6)] = kmn; }
+    __syncthreads();
+    kmx = 0u; kmn = 0xffffffffu;
+    for (int w = 0; w < 16; ++w) { kmx = hist[w] > kmx ? hist[w] : kmx; kmn = hist[16 + w] < kmn ? hist[16 + w] : kmn; }
+    __syncthreads();
+    const int top_byte = kmx == kmn ? -1 : (31 - __builtin_clz(kmx ^ kmn)) >> 3;
+    uint32_t mask = top_byte >= 3 ? 0u : (0xffffffffu << (8 * (top_byte + 1)));
+    uint32_t prefix = kmx & mask, remaining = (uint32_t)want;
+    for (int shift = 8 * top_byte; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        for (uint32_t i = tid; i < nc; i += NTH) {
+            const uint32_t key = fb_keys[i];
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {   // bins 4 lane .. 4 lane + 3; suffix sums from the top bin down
+            const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const uint32_t mine = h0 + h1 + h2 + h3;
+            uint32_t above = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_down((int)above, o, 64);
+                if (lane + o < 64) above += v;
+            }
+            const uint32_t excl = above - mine;
+            if (excl < remaining && remaining <= above) {
+                uint32_t acc_ = excl, bin = 0u;
+                const uint32_t hh[4] = { h0, h1, h2, h3 };
+#pragma unroll
+                for (int b = 3; b >= 0; --b) {
+                    if (acc_ < remaining && remaining <= acc_ + hh[b]) { bin = (uint32_t)(4 * lane + b); pick_s[1] = remaining - acc_; }
+                    acc_ += hh[b];
+                }
+                pick_s[0] = bin;
+            }
+        }
+        __syncthreads();
+        prefix |= pick_s[0] << shift;
+        mask |= 255u << shift;
+        remaining = pick_s[1];
+        __syncthreads();
+    }
+    const float theta = key_f32(prefix);
+    const uint32_t cut2_key = f32_key(theta - ft_margin<IP>(qbnd[q], qbnd[nqb + q], theta));
+    for (uint32_t i = tid; i < nc; i += NTH) {
+        if (fb_keys[i] >= cut2_key) {
+            const int pos = atomicAdd(&m2_s, 1);
+            if (pos < FT_KEEP_BIG) rows_s[pos] = cq[i].y;
+        }
+    }
+    __syncthreads();
+    const int m2 = m2_s;
+    if (m2 > FT_KEEP_BIG) {   // masses of near ties
+        if (tid == 0) redo[q] = 1u;
+        return;
+    }
+    int np2 = 256;
+    while (np2 < m2) np2 <<= 1;
+    unsigned long long *sel = reinterpret_cast<unsigned long long *>(fb_keys);   // (every thread has passed the barrier behind the last read of the keys)
+    for (int i = tid; i < np2; i += NTH) {
+        unsigned long long e = ~0ull;
+        if (i < m2) {
+            const uint32_t r = rows_s[i];
+            if ((int64_t)r < n) e = ((unsigned long long)ft_dist_key(fs_exact<IP, LANES>(X, D, r, reinterpret_cast<const float4 *>(q_s))) << 32) | r;
+        }
+        sel[i] = e;
+    }
+    ft_bitonic_u64(sel, np2, NTH);
+    for (int i = tid; i < k; i += NTH) {
+        const unsigned long long e = i < np2 ? sel[i] : ~0ull;
+        if ((uint32_t)(e >> 32) < 0xfffffff0u && i < want) {
+            out_d[(int64_t)q * k + i] = key_f32((uint32_t)(e >> 32));
+            out_i[(int64_t)q * k + i] = (int64_t)(uint32_t)e;
+        } else {
+            out_d[(int64_t)q * k + i] = __uint_as_float(0x7f800000u);
+            out_i[(int64_t)q * k + i] = -1;
+        }
+    }
+}
+
 }  // namespace
 
 // ---- host side ----
 static std::atomic<int> g_ft_on{4};        // cvtmi_set_tuning("flat_f32_tfilter"): 0 = the stream kernels for every batch, 1 .. 3 = products, 4 = choose
 static std::atomic<int> g_ft_min_rows{262144};   // "flat_f32_tfilter_min_rows": smallest table that takes the pipeline
 static std::atomic<int> g_ft_sample_div{5};   // "flat_f32_tfilter_sample": the sample is about 1 / this of the rows
+static std::atomic<int> g_ft_bigk{1};      // "flat_f32_tfilter_bigk": 1 = k = 129 .. 2048 through the pipeline (4096 sample maxima, lists of 32 768, ft_finish_big_kernel), 0 = exact kernels
 static std::atomic<int> g_ft_retry{0};     // "flat_f32_tfilter_retry": 1 = a second filter pass for the queries whose candidate lists ran over, 0 (default) = the exact kernels at once
 static std::atomic<int> g_ft_one_max{1 << 30}; // "flat_f32_tfilter_one": largest batch that multiplies one product (with the staged bucket pass one product wins at every
                                            // batch size measured: 1000 queries 0.74 -> 0.64 ms, 4096 2.9 -> 2.5, 10 000 7.0 -> 6.5; two products beyond this many queries)
@@ -620,6 +759,7 @@ static std::atomic<int> g_ft_min_nq{0};    // cvtmi_set_tuning("flat_f32_tfilter
 void set_flat_f32_tfilter(int v) { g_ft_on = v < 0 ? 0 : (v > 4 ? 4 : v); }
 void set_flat_f32_tfilter_one(int v) { g_ft_one_max = v < 0 ? 0 : v; }
 void set_flat_f32_tfilter_retry(int v) { g_ft_retry = v != 0; }
+void set_flat_f32_tfilter_bigk(int v) { g_ft_bigk = v != 0; }
 void set_flat_f32_tfilter_min_rows(int v) { g_ft_min_rows = v < 32768 ? 32768 : v; }
 int64_t flat_f32_tfilter_min_rows() { return g_ft_min_rows.load(); }
 void set_flat_f32_tfilter_sample(int v) { g_ft_sample_div = v < 1 ? 1 : (v > 64 ? 64 : v); }
@@ -647,13 +787,21 @@ static int ft_auto_min(int D)
 bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k)
 {
     return g_ft_on.load() && (metric == CVTMI_METRIC_IP || metric == CVTMI_METRIC_L2F) && flat_f32_tfilter_width(D) && n >= g_ft_min_rows.load() && n < 0xffffffe0LL &&
-           nq >= (g_ft_min_nq.load() > 0 ? g_ft_min_nq.load() : ft_auto_min(D)) && k >= 1 && k <= 128;
+           k >= 1 && k <= CVTMI_K_MAX && g_ft_bigk.load() + (k <= 128) > 0 &&   // (k > 128: the stream kernels do not take it -- every batch size comes here)
+           (k > 128 || nq >= (g_ft_min_nq.load() > 0 ? g_ft_min_nq.load() : ft_auto_min(D)));
 }
-static uint32_t ft_rec_cap(int64_t m) { return (uint32_t)std::min<int64_t>(3072, std::max<int64_t>(256, 3 * m)); }
-size_t flat_f32_tfilter_scratch(int64_t nq)
+// records a wave region holds: three times what 1 M SIFT-like rows gave per wave at k = 100, scaled with k beyond 128
+static uint32_t ft_rec_cap(int64_t m, int k)
 {
-    const int64_t m = std::min<int64_t>(nq, FT_PASS);
-    return (size_t)m * (FT_SLOTS + 8) * sizeof(uint32_t) + (size_t)m * FT_CAP * sizeof(uint2) + (size_t)FT_GRID * FT_WAVES * (sizeof(uint32_t) + (size_t)ft_rec_cap(m) * 80) + 1024;
+    const int64_t f = k <= 128 ? 1 : 1 + k / 256;
+    return (uint32_t)std::min<int64_t>(8192, std::max<int64_t>(256, 3 * m * f));
+}
+size_t flat_f32_tfilter_scratch(int64_t nq, int k)
+{
+    const bool big = k > 128;
+    const int64_t m = std::min<int64_t>(nq, big ? FT_PASS_BIG : FT_PASS);
+    return (size_t)m * ((big ? FT_SLOTS_BIG : FT_SLOTS) + 8) * sizeof(uint32_t) + (size_t)m * (big ? FT_CAP_BIG : FT_CAP) * sizeof(uint2) +
+           (size_t)FT_GRID * FT_WAVES * (sizeof(uint32_t) + (size_t)ft_rec_cap(m, k) * 80) + 1024;
 }
 
 template <int NCH, int NPROD, int RT, int NW = FT_WAVES, int KH = 1>
@@ -722,50 +870,62 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
 {
     if (!flat_f32_tfilter_applies(metric, D, n, nq, k)) return fail(CVTMI_EINVAL, "flat_f32_tfilter: D=%d nq=%lld", D, (long long)nq);
     const int mode = g_ft_on.load();
-    const int nprod = ft_products(D, mode == 4 ? (nq <= g_ft_one_max.load() ? 1 : 2) : mode);
+    // (k > 384: as many products as the width has -- the narrower margin keeps the rows that need exact distances near k: at k = 2048 one
+    //  product put more than FT_KEEP_BIG rows inside the band and every query went to the exact kernels)
+    //  (1000 queries, one / three products: k = 129 1.28 / 1.73 ms, 256 1.53 / 2.05, 1000 3.17 / 2.42, 2048 42 / 3.25)
+    const int nprod = ft_products(D, mode == 4 ? (k > 384 ? 3 : (nq <= g_ft_one_max.load() ? 1 : 2)) : mode);
     const int nt = nprod == 3 ? 2 : 1;
     const int nch = flat_f32_tfilter_nch(D);
     const int qcap = std::min(32 * FT_NBMAX, (int)((size_t)(160 * 1024 - 32 * FT_NBMAX * 8 - FT_SLACK) / ((size_t)nch * nt * 1024)) * 32);   // queries a workgroup holds
     CVTMI_HIP(hipMemsetAsync(redo, 0, (size_t)nq * sizeof(uint32_t), st));
     const int64_t n_tiles = (n + 31) / 32;
-    for (int64_t a0 = 0; a0 < nq; a0 += FT_PASS) {
-        const int64_t m = std::min<int64_t>(nq - a0, FT_PASS);
+    const bool big = k > 128;
+    const int pass = big ? FT_PASS_BIG : FT_PASS, nslots = big ? FT_SLOTS_BIG : FT_SLOTS;
+    const uint32_t fcap = big ? FT_CAP_BIG : FT_CAP;
+    for (int64_t a0 = 0; a0 < nq; a0 += pass) {
+        const int64_t m = std::min<int64_t>(nq - a0, pass);
         int chunks = 1;
         while (chunks < 32 && (m + chunks - 1) / chunks > qcap) chunks *= 2;
         const int qper = (int)(((m + chunks - 1) / chunks + 31) / 32 * 32);
         const int nw = nch > 32 ? 4 : FT_WAVES;   // waves per workgroup of the filter kernel
-        const uint32_t cap = ft_rec_cap(m) * (uint32_t)(FT_WAVES / nw);   // (the record area is the same: fewer, larger regions)
+        const uint32_t cap = ft_rec_cap(m, k) * (uint32_t)(FT_WAVES / nw);   // (the record area is the same: fewer, larger regions)
         uint32_t *smax = reinterpret_cast<uint32_t *>(scratch);
-        float *thr = reinterpret_cast<float *>(smax + (size_t)m * FT_SLOTS);
+        float *thr = reinterpret_cast<float *>(smax + (size_t)m * nslots);
         float *qbnd = thr + m;
         uint32_t *cnt = reinterpret_cast<uint32_t *>(qbnd + 2 * m);
         uint32_t *rlist = cnt + m;                 // queries of the second attempt, their number in front of the wave counters
         uint32_t *rcount = rlist + m;
         uint32_t *wcnt = rcount + 1 + ((5 * m + 1) & 1);   // (the candidate lists behind the wave counters start on 8 bytes)
         uint2 *cand = reinterpret_cast<uint2 *>(wcnt + FT_GRID * FT_WAVES);
-        uint4 *rec = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(cand + (size_t)m * FT_CAP) + 256 - (((uintptr_t)(cand + (size_t)m * FT_CAP)) & 15));
-        CVTMI_HIP(hipMemsetAsync(smax, 0, (size_t)m * FT_SLOTS * sizeof(uint32_t), st));
+        uint4 *rec = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(cand + (size_t)m * fcap) + 256 - (((uintptr_t)(cand + (size_t)m * fcap)) & 15));
+        CVTMI_HIP(hipMemsetAsync(smax, 0, (size_t)m * nslots * sizeof(uint32_t), st));
         CVTMI_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * m + 1) * sizeof(uint32_t), st));   // counters, list, its length
         FtArgs a;
         a.pack = reinterpret_cast<const uint4 *>(pack); a.bias = bias; a.n_tiles = n_tiles; a.Q = q + a0 * D; a.D = D; a.nq = (int)m; a.chunks = chunks; a.qper = qper;
-        a.smax = smax; a.thr = thr; a.rec = rec; a.wcnt = wcnt; a.cap = cap; a.qlist = nullptr; a.qcount = nullptr; a.dbg = get_flat_f32_dbg();
+        a.smax = smax; a.nslots = nslots; a.thr = thr; a.rec = rec; a.wcnt = wcnt; a.cap = cap; a.qlist = nullptr; a.qcount = nullptr; a.dbg = get_flat_f32_dbg();
         const size_t lds = (size_t)(qper / 32) * nch * nt * 1024 + FT_SLACK + (size_t)qper * 2 * sizeof(float);
         a.t1 = n_tiles;
         {   // the sample: about an eighth of the groups (at least ~65 536 rows), a whole number per wave of a chunk
             const int rt = ft_rt(nch, nprod);
             const int64_t all_groups = (n_tiles + rt - 1) / rt, streams = (int64_t)(FT_GRID / chunks) * nw;
-            const int64_t want = std::max<int64_t>(all_groups / g_ft_sample_div.load(), std::min<int64_t>(all_groups, (2048 + rt - 1) / rt));
+            // (k > 128: a third of the rows -- the k-th largest of 4096 maxima needs many more rows than k behind it)
+            const int64_t want = std::max<int64_t>(all_groups / (big ? std::min(3, g_ft_sample_div.load()) : g_ft_sample_div.load()), std::min<int64_t>(all_groups, (2048 + rt - 1) / rt));
             a.n_sample = std::min<int64_t>(all_groups, std::max<int64_t>(1, (want + streams / 2) / streams) * streams);
         }
         CVTMI_TRY(ft_launch_any(D, nprod, true, a, lds, st));
         const unsigned tg = (unsigned)((m + 3) / 4);
         const float loosen = (a.dbg & 32) ? 0.02f : 0.0f;
-        if (metric == CVTMI_METRIC_IP) hipLaunchKernelGGL((ft_theta_kernel<true>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0);
-        else hipLaunchKernelGGL((ft_theta_kernel<false>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0);
+        if (metric == CVTMI_METRIC_IP) {
+            if (big) hipLaunchKernelGGL((ft_theta_kernel<true, FT_SLOTS_BIG / 64>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0);
+            else hipLaunchKernelGGL((ft_theta_kernel<true, FT_SLOTS / 64>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0);
+        } else {
+            if (big) hipLaunchKernelGGL((ft_theta_kernel<false, FT_SLOTS_BIG / 64>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0);
+            else hipLaunchKernelGGL((ft_theta_kernel<false, FT_SLOTS / 64>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0);
+        }
         a.t1 = n_tiles; a.n_sample = 0;
         CVTMI_TRY(ft_launch_any(D, nprod, false, a, lds, st));
         if (a.dbg & 8) continue;   // timing experiments: the filter passes alone (results stale)
-        const bool retry = g_ft_retry.load() != 0;
+        const bool retry = g_ft_retry.load() != 0 && !big;
         const size_t bucket_lds = (size_t)FT_STAGE * (sizeof(uint2) + sizeof(uint16_t));
         {
             static std::atomic<bool> attr_k[16] = {};
@@ -773,6 +933,21 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
         }
         const int rcap = std::min<int>(qcap, (int)((m + 31) / 32 * 32));   // queries one second attempt takes (a single chunk)
         auto finish = [&](int second) {
+            if (big) {   // k = 129 .. 2048: the candidates' keys in LDS, a bitonic sort of the exact distances
+                const size_t lds_b = (size_t)FT_CAP_BIG * sizeof(uint32_t);
+                static std::atomic<bool> attr_f[3][16] = {};
+                if (metric == CVTMI_METRIC_IP) {
+                    (void)fs_set_lds((const void *)ft_finish_big_kernel<true, 4>, lds_b, attr_f[0]);
+                    hipLaunchKernelGGL((ft_finish_big_kernel<true, 4>), dim3((unsigned)m), dim3(1024), lds_b, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, (int)m);
+                } else if (D % 16 == 0) {
+                    (void)fs_set_lds((const void *)ft_finish_big_kernel<false, 8>, lds_b, attr_f[1]);
+                    hipLaunchKernelGGL((ft_finish_big_kernel<false, 8>), dim3((unsigned)m), dim3(1024), lds_b, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, (int)m);
+                } else {
+                    (void)fs_set_lds((const void *)ft_finish_big_kernel<false, 4>, lds_b, attr_f[2]);
+                    hipLaunchKernelGGL((ft_finish_big_kernel<false, 4>), dim3((unsigned)m), dim3(1024), lds_b, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, (int)m);
+                }
+                return;
+            }
             const unsigned grid = second ? (unsigned)rcap : (unsigned)m;
             uint32_t *rl = retry ? rlist : nullptr;
             if (metric == CVTMI_METRIC_IP)
@@ -782,14 +957,14 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
             else
                 hipLaunchKernelGGL((ft_finish_kernel<false, 4>), dim3(grid), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m);
         };
-        hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), bucket_lds, st, rec, wcnt, cap, thr, cnt, cand, chunks, qper, (int)m, redo + a0, nw, nullptr, nullptr);
+        hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), bucket_lds, st, rec, wcnt, cap, thr, cnt, cand, chunks, qper, (int)m, redo + a0, nw, nullptr, nullptr, fcap);
         finish(0);
         if (retry) {   // the queries whose lists ran over, under the thresholds their own candidates give (nothing listed: three empty launches)
             FtArgs b = a;
             b.qlist = rlist; b.qcount = rcount; b.chunks = 1; b.qper = rcap;
             const size_t lds2 = (size_t)(rcap / 32) * nch * nt * 1024 + FT_SLACK + (size_t)rcap * 2 * sizeof(float);
             CVTMI_TRY(ft_launch_any(D, nprod, false, b, lds2, st));
-            hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), bucket_lds, st, rec, wcnt, cap, thr, cnt, cand, 1, rcap, (int)m, redo + a0, nw, rlist, rcount);
+            hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), bucket_lds, st, rec, wcnt, cap, thr, cnt, cand, 1, rcap, (int)m, redo + a0, nw, rlist, rcount, fcap);
             finish(1);
         }
         CVTMI_HIP(hipGetLastError());

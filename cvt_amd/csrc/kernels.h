@@ -222,13 +222,14 @@ bool flat_f32_stream_applies(int metric, int D, int64_t n, int k);
 int flat_f32_tfilter_nch(int D);   // K steps of the kernel that takes D-dimensional rows (0: none)
 bool flat_f32_tfilter_width(int D);
 bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k);
-size_t flat_f32_tfilter_scratch(int64_t nq);
+size_t flat_f32_tfilter_scratch(int64_t nq, int k);
 int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack, const uint32_t *pstats, const float *bias, const uint32_t *stats, int64_t n,
                             const float *q, int64_t nq, int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, hipStream_t st);
 void set_flat_f32_tfilter(int v);
 void set_flat_f32_tfilter_min(int v);
 void set_flat_f32_tfilter_one(int v);
 void set_flat_f32_tfilter_retry(int v);
+void set_flat_f32_tfilter_bigk(int v);
 void set_flat_f32_tfilter_sample(int v);
 void set_flat_f32_tfilter_min_rows(int v);
 int64_t flat_f32_tfilter_min_rows();

@@ -147,7 +147,7 @@ int cvtmi_set_device(int device);
  *   "scanh_balance" / "scanh_min_rows" / "scanh_tail" / "scanh_fix" / "scanh_share_hist"  planner of the persistent-grid scan (variant
  *                     6): 0 choose / 1 equal row-time shares / 2 row blocks; smallest row segment; two-region tail on / off; an item's
  *                     fixed cost in row-equivalents (160 000); one candidate histogram per query shared by its segments (1) or not
- *   "flat_f32_tfilter" fp32 searches (any width that is a multiple of 4 up to 2048-d, >= 262 144 rows, k <= 128) of "flat_f32_tfilter_min" queries or more run as a
+ *   "flat_f32_tfilter" fp32 searches (any width that is a multiple of 4 up to 2048-d, >= 262 144 rows, k <= 128; k up to 2048: "flat_f32_tfilter_bigk") of "flat_f32_tfilter_min" queries or more run as a
  *                     threshold filter (round 6, flat_f32_tfilter.hip): sample maxima -> per-query threshold -> queries in LDS, the rows'
  *                     bf16 operand copy in registers, no barrier, hits recorded -> per-query lists -> exact distances.  1 .. 3 = the
  *                     bf16 products per term: 1 (x1.q1), 2 ((x1 + x2).q1; both with margins from each query's own rounding residues),
@@ -164,6 +164,9 @@ int cvtmi_set_device(int device);
  *                     kernels are ahead for fewer than 128 queries and level beyond; 200 K rows, 1000 queries 0.42 -> 0.32 ms)
  *   "flat_f32_tfilter_sample"  the sample that sets the thresholds is about 1 / this (default 5) of the row-tile groups, spread evenly over the
  *                     rows and rounded to a whole number of groups per wave (1 M x 128-d, 1000 queries: 1/8 0.63 ms, 1/5 0.505, 1/3 0.52)
+ *   "flat_f32_tfilter_bigk"  1 (default) = fp32 searches with k = 129 .. 2048 (every batch size, tables of "flat_f32_tfilter_min_rows" rows and more)
+ *                     run through the threshold filter with 4096 sample maxima, candidate lists of 32 768 and a workgroup-wide selection
+ *                     (1 M x 128-d, 1000 queries: k = 129 46.6 -> 1.3 ms, k = 1000 47.8 -> 2.4, k = 2048 53.5 -> 3.2); 0 = the exact kernels
  *   "flat_f32_tfilter_retry"  1 = a query whose candidate list ran over takes ONE second filter pass under the threshold its own stored
  *                     candidates give (it helps when the rows above the sample's threshold are many, not when the rows inside the
  *                     margin band are: measured no gain on clustered 300-d rows, three empty launches = ~10 us on every search);

@@ -1062,6 +1062,35 @@ def test_flat_f32_stream_over_operand_copy(amd, orc, metric, D, k):
         amd.set_tuning("flat_variant", 0); amd.set_tuning("flat_f32_packed", 1)
 
 
+@pytest.mark.parametrize("metric,D,nq,k", [(L2F, 128, 1, 129), (IP, 128, 70, 300), (L2F, 64, 300, 1000), (IP, 128, 20, 2048), (L2F, 256, 33, 500),
+                                            (IP, 512, 10, 200)])
+def test_flat_f32_threshold_filter_big_k(amd, orc, metric, D, nq, k):
+    """k = 129 ... 2048 (round 6: 4096 sample maxima, candidate lists of 32 768, ft_finish_big_kernel: keys in LDS, radix select, bitonic
+    sort of the exact distances) against the exact kernels ("flat_f32_tfilter_bigk" 0) on every query and the checker on two: duplicates
+    (more of them than k for the smaller k), queries that are rows, ragged row count"""
+    rng = np.random.default_rng(D + nq + k + metric)
+    n = 262_144 + 4_000 + 7
+    x = _clustered(rng, n, D, metric)
+    x[100_000:100_400] = x[5]
+    x[n - 1] = x[123]
+    q = (x[rng.integers(0, n, nq)] + 0.05 * rng.normal(size=(nq, D))).astype(np.float32)
+    q[0] = x[5]
+    q = np.ascontiguousarray(q, np.float32)
+    try:
+        ix = amd.FlatIndex(metric, D); ix.add(x)
+        ds, is_ = ix.search(q, k)
+        assert ix.last_search()[0] == 3
+        amd.set_tuning("flat_f32_tfilter_bigk", 0)
+        de, ie = ix.search(q, k)
+        assert ix.last_search()[0] == 0
+        ix.close()
+    finally:
+        amd.set_tuning("flat_f32_tfilter_bigk", 1)
+    assert np.array_equal(is_, ie) and np.array_equal(bits(ds), bits(de))
+    od, _, oi = orc.flat_search(metric, x, q[:2], k, flavour=4 if metric == IP else 8)
+    assert np.array_equal(is_[:2], oi) and np.array_equal(bits(ds[:2]), bits(od))
+
+
 def test_flat_f32_threshold_filter_second_attempt(amd):
     """candidate lists that run over: with "flat_f32_tfilter_retry" 1 such a query takes a second filter pass under the threshold its
     stored candidates give ("flat_f32_dbg" 32 loosens the sample's thresholds so that lists do run over and second attempts succeed),
