@@ -491,6 +491,11 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "hnsw_top_lds")) { set_hnsw_top_lds((int)value); return CVTMI_OK; }
     if (!strcmp(name, "hnsw_adc_tables")) { set_hnsw_adc_tables((int)value); return CVTMI_OK; }
     if (!strcmp(name, "hnsw_slots")) { g_hnsw_slots_cap = (int)value; return CVTMI_OK; }
+    if (!strcmp(name, "flat_u8_tfilter")) { set_flat_u8_tfilter((int)value); return CVTMI_OK; }
+    if (!strcmp(name, "flat_u8_tfilter_min_k")) { set_flat_u8_tfilter_min_k((int)std::min<int64_t>(value, 1 << 20)); return CVTMI_OK; }
+    if (!strcmp(name, "flat_u8_tfilter_min_nq_k65")) { set_flat_u8_tfilter_min_nq_k65((int)std::min<int64_t>(value, 1 << 30)); return CVTMI_OK; }
+    if (!strcmp(name, "flat_u8_tfilter_min_nq")) { set_flat_u8_tfilter_min_nq((int)std::min<int64_t>(value, 1 << 30)); return CVTMI_OK; }
+    if (!strcmp(name, "flat_u8_tfilter_sample")) { set_flat_u8_tfilter_sample((int)std::min<int64_t>(value, 64)); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "sq8_filter")) { set_sq8_filter(value != 0); return CVTMI_OK; }
@@ -1660,7 +1665,7 @@ static int flat_add_common(cvtmi_flat_t h, const void *x, const int64_t *labels,
     if (n == 0) return CVTMI_OK;
     const int64_t total = h->n + n;
     if (total > 0xfffffffeLL) return fail(CVTMI_EUNSUPPORTED, "cvtmi_flat_add: more than 2^32-2 rows per handle");
-    if (h->metric == CVTMI_METRIC_L2U8) h->f_pack_n = -1;   // (fp32: the operand copy keeps covering its rows; flat_prepare packs the appended ones)
+    // (the operand copies keep covering their rows; flat_prepare packs the appended ones)
     bool explicit_labels = labels != nullptr;
     if (explicit_labels && kind == hipMemcpyHostToDevice && h->identity) {
         bool same = true;
@@ -1989,8 +1994,26 @@ static int flat_search_filtered_u8(cvtmi_flat_t h, FlatScratch &S, const uint8_t
     return CVTMI_OK;
 }
 
+// uint8 L2 with k > 128 as a threshold filter (flat_u8_tfilter.hip).  *done = false: not applicable / some query's list ran over or
+// tied beyond what the finish keeps -- the exact kernels answer the call (they take no predicate on this metric)
+static int flat_search_bigk_u8(cvtmi_flat_t h, FlatScratch &S, const uint8_t *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st, bool *done)
+{
+    *done = false;
+    const int64_t n = h->n;
+    if (h->f_pack_n != n) return CVTMI_OK;   // no operand copy (flat_prepare could not build it)
+    if (S.fs_scratch.reserve(flat_u8_tfilter_scratch(nq, k)) != CVTMI_OK) { (void)hipGetLastError(); return CVTMI_OK; }
+    CVTMI_TRY(S.f_stats.reserve(16));
+    uint32_t *flag = S.f_stats.as<uint32_t>() + 2, host_flag = 0;
+    CVTMI_TRY(launch_flat_u8_tfilter(h->D, h->f_pack.p, h->norms.as<int32_t>(), n, q, nq, k, S.fs_scratch.p, dist, rows, flag, st));
+    CVTMI_HIP(hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, st));
+    CVTMI_HIP(stream_wait(st));
+    h->f_last_worst = (long long)host_flag;
+    *done = host_flag == 0;
+    return CVTMI_OK;
+}
+
 // which of the pipelines a search of nq queries takes (the dispatch rules, in one place: flat_prepare builds what they need)
-struct FlatRoute { bool stream, tfilter, filt_f32, filt_u8; };
+struct FlatRoute { bool stream, tfilter, filt_f32, filt_u8, big_u8; };
 // the tuning values a search dispatches on, read ONCE per call: flat_prepare and flat_search_leased must see the same route even if
 // another thread calls cvtmi_set_tuning between the two
 struct FlatTuning {
@@ -2000,7 +2023,7 @@ struct FlatTuning {
 static FlatRoute flat_route(const cvtmi_flat_s *h, const void *q, int64_t nq, int k, const FlatTuning &tun)
 {
     const int g_flat_variant = tun.variant, g_flat_f32_stream = tun.f32_stream;  // (this call's snapshot shadows the globals)
-    FlatRoute r = { false, false, false, false };
+    FlatRoute r = { false, false, false, false, false };
     const bool aligned = ((uintptr_t)q & 15) == 0;
     // fp32: one stream over the rows (flat_f32_stream.hip).  flat_variant 2 asks for the older sample + filter pipeline, 1 for the exact kernels
     const bool f32_fast = ((g_flat_variant == 0 && g_flat_f32_stream == 1) || (g_flat_variant != 1 && g_flat_f32_stream == 2)) && aligned &&
@@ -2025,6 +2048,9 @@ static FlatRoute flat_route(const cvtmi_flat_s *h, const void *q, int64_t nq, in
                          (double)h->n * (double)h->D * (double)nq >= 1e9 * (double)g_flat_u8_filter_min_work.load();
     r.filt_u8 = (g_flat_variant == 2 || u8_auto) && h->metric == CVTMI_METRIC_L2U8 && aligned && nq <= 65535 * 256 && h->norms.p &&
                 flat_u8_filter_applies(h->D, std::max<int64_t>(h->n, 262144), std::max<int64_t>(nq, 256), k) && h->n >= 2 * 65536;
+    // k > 128 (round 6, flat_u8_tfilter.hip): the stream and the pipeline above stop at 128 / 64 neighbours, the exact kernels behind them
+    // take one query per workgroup (2 M x 512-d, 1000 queries: k = 128 3.9 ms, k = 129 139 ms)
+    r.big_u8 = (g_flat_variant == 0 || (g_flat_variant == 2 && k > 128)) && h->metric == CVTMI_METRIC_L2U8 && aligned && h->norms.p && flat_u8_tfilter_applies(h->D, h->n, nq, k);
     return r;
 }
 
@@ -2042,8 +2068,8 @@ extern "C" int cvtmi_flat_describe_dispatch(int metric, int D, int64_t n_rows, i
     h.fs_bias.p = nullptr; h.fs_stats.p = nullptr; h.norms.p = nullptr;
     out[0] = r.tfilter ? 2 : (r.stream ? 1 : 0);
     out[1] = r.filt_f32 ? 1 : 0;
-    out[2] = r.filt_u8 ? 1 : 0;
-    out[3] = (metric == CVTMI_METRIC_L2U8 && !r.filt_u8 && flat_u8_mstream_applies(D, n_rows, std::min<int64_t>(nq, 128), k)) ? 1 : 0;
+    out[2] = r.big_u8 ? 2 : (r.filt_u8 ? 1 : 0);
+    out[3] = (metric == CVTMI_METRIC_L2U8 && !r.filt_u8 && !r.big_u8 && flat_u8_mstream_applies(D, n_rows, std::min<int64_t>(nq, 128), k)) ? 1 : 0;
     return CVTMI_OK;
 }
 
@@ -2066,7 +2092,7 @@ static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStr
             want_nch = tf ? flat_f32_tfilter_nch(h->D) : h->D / 16;
             need_f32 = (h->f_pack_n != h->n || h->f_pack_nch != want_nch) &&
                        (tf ? !need_fs : (r.filt_f32 && !(r.stream && !need_fs && !h->fs_nonfinite)));   // (the stream answers: no copy needed)
-            need_u8 = r.filt_u8 && h->f_pack_n != h->n;
+            need_u8 = (r.filt_u8 || r.big_u8) && h->f_pack_n != h->n;
             if (!need_fs && !need_f32 && !need_u8) return CVTMI_OK;
         }
         FlatMutation mut(h, st);
@@ -2104,8 +2130,14 @@ static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStr
             h->f_pack_nch = want_nch;
         }
         if (need_u8 && h->f_pack_n != n) {    // operand-ordered copy of the rows (x - 128 as int8)
-            if (h->f_pack.reserve(flat_u8_pack_bytes(h->D, n)) != CVTMI_OK) return CVTMI_OK;
-            CVTMI_TRY(launch_flat_u8_pack(h->data.as<uint8_t>(), n, h->D, h->f_pack.as<uint4>(), st));
+            // rows appended since the copy was made: only their tiles are packed (from the last, partly filled one on), the buffer grows by halves
+            int64_t row0 = (h->f_pack.p && h->f_pack_n > 0 && h->f_pack_n < n) ? h->f_pack_n / 32 * 32 : 0;
+            h->f_pack_n = -1;
+            const size_t need_p = flat_u8_pack_bytes(h->D, n);
+            if (row0 > 0 && need_p > h->f_pack.cap &&
+                h->f_pack.grow(std::max(need_p, h->f_pack.cap + h->f_pack.cap / 2), flat_u8_pack_bytes(h->D, row0), st) != CVTMI_OK) { (void)hipGetLastError(); row0 = 0; }
+            if (row0 == 0 && h->f_pack.reserve(need_p) != CVTMI_OK) return CVTMI_OK;
+            CVTMI_TRY(launch_flat_u8_pack(h->data.as<uint8_t>(), n, h->D, h->f_pack.as<uint4>(), st, row0));
             CVTMI_HIP(stream_wait(st));
             h->f_pack_n = n;
         }
@@ -2130,6 +2162,10 @@ static int flat_search_leased(cvtmi_flat_t h, FlatScratch &S, const void *q, int
     }
     if (!done && r.filt_f32)
         CVTMI_TRY(flat_search_filtered(h, S, reinterpret_cast<const float *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
+    if (!done && r.big_u8) {
+        CVTMI_TRY(flat_search_bigk_u8(h, S, reinterpret_cast<const uint8_t *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
+        if (done) how = 4;
+    }
     if (!done && r.filt_u8)
         CVTMI_TRY(flat_search_filtered_u8(h, S, reinterpret_cast<const uint8_t *>(q), nq, k, reinterpret_cast<float *>(dist), labels, st, &done));
     h->f_last_filtered = done ? (how ? how : 1) : 0;

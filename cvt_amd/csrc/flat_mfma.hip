@@ -391,11 +391,11 @@ using i32x16 = __attribute__((ext_vector_type(16))) int;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 
 // [tile][s][lane] 16 bytes: row 32 t + (lane & 31), dimensions 32 s + 16 (lane >> 5) .. + 16, each byte ^ 0x80 (x - 128 as int8)
-__global__ __launch_bounds__(kBlock) void flat_u8_pack_kernel(const uint8_t *__restrict__ X, int64_t n, int D, int64_t ntiles,
+__global__ __launch_bounds__(kBlock) void flat_u8_pack_kernel(const uint8_t *__restrict__ X, int64_t n, int D, int64_t tile0, int64_t ntiles,
                                                               uint4 *__restrict__ pack)
 {
     const int ks = D / 32;
-    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t g = tile0 * ks * 64 + (int64_t)blockIdx.x * kBlock + threadIdx.x;   // tiles [tile0, ntiles)
     if (g >= ntiles * ks * 64) return;
     const int lane = (int)(g & 63);
     const int64_t ts = g >> 6, t = ts / ks;
@@ -1307,10 +1307,12 @@ bool flat_u8_filter_applies(int D, int64_t n, int64_t nq, int k)
 }
 size_t flat_u8_pack_bytes(int D, int64_t n) { return (size_t)((n + 31) / 32) * (D / 32) * 64 * sizeof(uint4); }
 
-int launch_flat_u8_pack(const uint8_t *X, int64_t n, int D, uint4 *pack, hipStream_t st)
+// rows [row0, n) (row0 a multiple of 32; the tiles before it stay as they are)
+int launch_flat_u8_pack(const uint8_t *X, int64_t n, int D, uint4 *pack, hipStream_t st, int64_t row0)
 {
-    const int64_t ntiles = (n + 31) / 32, total = ntiles * (D / 32) * 64;
-    hipLaunchKernelGGL(flat_u8_pack_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, X, n, D, ntiles, pack);
+    const int64_t ntiles = (n + 31) / 32, tile0 = row0 / 32, total = (ntiles - tile0) * (D / 32) * 64;
+    if (total <= 0) return CVTMI_OK;
+    hipLaunchKernelGGL(flat_u8_pack_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, X, n, D, tile0, ntiles, pack);
     CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }

@@ -1,0 +1,512 @@
+// flat_u8_tfilter.hip -- exhaustive uint8 L2 search (BruteforceSearch + L2SpaceI, brutoforce.hpp:73-93, space_l2.h:186-245) with k = 129 .. 2048
+// (round 6).  The stream and filter pipelines of flat_mfma.hip stop at k = 128 / 64; behind them the exact kernel took one query per
+// workgroup (2 M x 512-d, 1000 queries: k = 128 3.9 ms, k = 129 139 ms).  This is the fp32 threshold filter of flat_f32_tfilter.hip on
+// v_mfma_i32_32x32x32_i8 over the packed rows (flat_u8_pack_kernel: x - 128 as int8, [tile][K step of 32][64 lanes] x 16 B):
+//   * the scores are EXACT integers -- with x' = x - 128, q' = q - 128: d = |x'|^2 + |q'|^2 - 2 x'.q' -- so there is no margin and no
+//     second evaluation: a row's accumulator starts at -(|x'|^2 >> 1) and ends as a = x'.q' - (|x'|^2 >> 1), d = |q'|^2 - 2 a + (|x'|^2 & 1);
+//   * a workgroup keeps up to 256 queries in LDS (128 KB at 512-d), a wave RT row tiles in registers; a lane ends up with 16 values of
+//     ITS query per tile: v_max3_i32 tree, one compare, 80-byte records into the wave's own region (no atomics);
+//   * sample pass: 4096 maxima of a over disjoint row sets per query; the k-th largest, A, is reached by k distinct rows, whose
+//     distances are <= |q'|^2 - 2 A + 1 =: tau.  A row with d <= tau has a >= A - (1 - parity) / 2, i.e. a >= A: the threshold is A itself;
+//   * bucket pass: the records' values at or above the threshold become (distance, row) candidates, per query; finish: one workgroup
+//     of 1024 threads per query, the distances in LDS, radix select of the k-th smallest, everything at or below it sorted by
+//     (distance, row).
+// A query whose sample has fewer than k filled slots, whose list or wave region runs over or whose k-th distance ties with more rows
+// than the finish keeps raises ONE flag for the call: the caller then runs the exact kernels for every query (they take no predicate
+// on this metric).  Distances come out as int32 bits in the float array, as from every uint8 path.
+#include <algorithm>
+#include <atomic>
+
+#include "common.h"
+#include "flat_f32_common.h"
+#include "kernels.h"
+
+namespace cvtmi {
+
+namespace {
+
+using i32x16 = __attribute__((ext_vector_type(16))) int;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+constexpr int UT_WAVES = 8, UT_GRID = 256, UT_SLOTS = 4096, UT_CAP = 32768, UT_KEEP = 4096, UT_PASS = 256, UT_NBMAX = 16, UT_STAGE = 12288;
+constexpr int UT_NBQ = UT_PASS / 32;   // query blocks of a pass
+constexpr int UT_NEG = -(1 << 30);   // start value of a padding row's accumulator: never reaches a threshold
+
+struct UtArgs {
+    const uint4 *pack; const int32_t *norms; int64_t n, n_tiles, n_sample;
+    const uint8_t *Q; int D, nq, chunks, qper;
+    uint32_t *smax;          // MAX mode: [nq][UT_SLOTS] (a ^ 0x80000000), zeroed by the caller
+    const int32_t *thr;      // FILTER mode: [nq] (INT_MAX: nothing passes)
+    uint4 *rec; uint32_t *wcnt; uint32_t cap;
+};
+
+__device__ __forceinline__ int ut_max3(int a, int b, int c)
+{
+    int r;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int ut_max16(const i32x16 &v)
+{
+    int m = ut_max3(v[0], v[1], v[2]);
+    m = ut_max3(m, v[3], v[4]);
+    m = ut_max3(m, v[5], v[6]);
+    m = ut_max3(m, v[7], v[8]);
+    m = ut_max3(m, v[9], v[10]);
+    m = ut_max3(m, v[11], v[12]);
+    m = ut_max3(m, v[13], v[14]);
+    return m > v[15] ? m : v[15];
+}
+
+// KS K steps of 32 dimensions, RT row tiles per wave
+template <int KS, int RT, bool MAXMODE>
+__global__ __launch_bounds__(64 * UT_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void flat_u8_tfilter_kernel(const UtArgs a)
+{
+    constexpr int NW = UT_WAVES;
+    extern __shared__ __attribute__((aligned(16))) uint8_t ut_q[];   // [block][K step] x 1 KB, then the blocks' thresholds
+    const int tid = threadIdx.x, lane = tid & 63, lj = lane & 31, lk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int chunk = idx % a.chunks, slices = 8 * ((int)(gridDim.x >> 3) / a.chunks), slice = xcd + 8 * (idx / a.chunks);
+    const int q0 = chunk * a.qper;
+    const int nqc = a.nq - q0 < a.qper ? a.nq - q0 : a.qper;
+    const int wave_g = blockIdx.x * NW + wave;
+    if (nqc <= 0) {
+        if (!MAXMODE && lane == 0) a.wcnt[wave_g] = 0u;
+        return;
+    }
+    const int nb = (nqc + 31) >> 5;
+    int *thr_s = reinterpret_cast<int *>(ut_q + (size_t)nb * KS * 1024);
+    for (int i = tid; i < nb * 32 * KS * 2; i += 64 * NW) {   // (query, K step, half) -> its 16-byte slot
+        const int hl = i & 1, ss = (i >> 1) % KS, qq = i / (2 * KS);
+        const int qi = q0 + (qq < nqc ? qq : nqc - 1);
+        uint4 v = *reinterpret_cast<const uint4 *>(a.Q + (int64_t)qi * a.D + 32 * ss + 16 * hl);
+        v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+        *reinterpret_cast<uint4 *>(ut_q + ((size_t)((qq >> 5) * KS + ss) * 1024) + (size_t)(hl * 32 + (qq & 31)) * 16) = v;
+    }
+    if constexpr (!MAXMODE)
+        for (int i = tid; i < nb * 32; i += 64 * NW) thr_s[i] = i < nqc ? a.thr[q0 + i] : 0x7fffffff;
+    __syncthreads();
+    const int64_t all_groups = (a.n_tiles + RT - 1) / RT, n_groups = MAXMODE ? a.n_sample : all_groups, stride = (int64_t)slices * NW;
+    const int slot = (slice * NW + wave) * 2 + lk;   // MAX mode: this half wave's own slot (UT_GRID x UT_WAVES x 2 = UT_SLOTS; one chunk, see the launcher)
+    int mreg[UT_NBQ];                                // ... its maxima per query block, in registers until the rows are through
+#pragma unroll
+    for (int b = 0; b < UT_NBQ; ++b) mreg[b] = UT_NEG;
+    uint32_t wcnt = 0;
+    uint8_t *rec_w = reinterpret_cast<uint8_t *>(a.rec) + (size_t)wave_g * a.cap * 80;
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    i32x4 xa[RT][KS];
+    i32x16 bias[RT];
+    for (int64_t g = slice + (int64_t)slices * wave; g < n_groups; g += stride) {
+        const int64_t g_rows = MAXMODE ? g * all_groups / a.n_sample : g;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int64_t t = g_rows * RT + r;
+            const int64_t tc = t < a.n_tiles ? t : a.n_tiles - 1;
+            const uint4 *tp = a.pack + (tc * KS) * 64 + lane;
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) xa[r][s_] = __builtin_bit_cast(i32x4, tp[s_ * 64]);
+            // element e: row (e & 3) + 8 (e >> 2) + 4 lk of the tile
+            if (t < a.n_tiles && (tc + 1) * 32 <= a.n) {
+                const int4 *np = reinterpret_cast<const int4 *>(a.norms + tc * 32 + 4 * lk);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int4 v = np[2 * j];
+                    bias[r][4 * j] = -(v.x >> 1); bias[r][4 * j + 1] = -(v.y >> 1); bias[r][4 * j + 2] = -(v.z >> 1); bias[r][4 * j + 3] = -(v.w >> 1);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = tc * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                    bias[r][e] = (t < a.n_tiles && row < a.n) ? -(a.norms[row] >> 1) : UT_NEG;
+                }
+            }
+        }
+        const uint32_t tile_row = (uint32_t)(g_rows * RT * 32 + 4 * lk);
+        auto block = [&](const int b, int &mx) {
+            const uint8_t *qb = ut_q + (size_t)b * (KS * 1024) + lane * 16;
+            i32x16 acc[RT];
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                const i32x4 qv = *reinterpret_cast<const i32x4 *>(qb + s_ * 1024);
+#pragma unroll
+                for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[r][s_], qv, s_ == 0 ? bias[r] : acc[r], 0, 0, 0);
+            }
+            // (inline-assembly readers of matrix results: the wait states are spelled out, see flat_f32_tfilter.hip)
+            static_assert(RT >= 2 && RT <= 4, "operand lists below");
+            if constexpr (RT == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));
+            if constexpr (RT == 3) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
+            if constexpr (RT == 4) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+            const int qq = 32 * b + lj;
+            if constexpr (MAXMODE) {
+                int m = ut_max16(acc[0]);
+#pragma unroll
+                for (int r = 1; r < RT; ++r) { const int m2 = ut_max16(acc[r]); m = m2 > m ? m2 : m; }
+                mx = m > mx ? m : mx;
+            } else {
+                const int tb = thr_s[qq];
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    const bool hit = ut_max16(acc[r]) >= tb;
+                    const unsigned long long hm = __ballot(hit);
+                    if (hm) {
+                        const uint32_t pos = wcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                        wcnt += (uint32_t)__popcll(hm);
+                        if (hit && pos < a.cap) {
+                            uint8_t *dst = rec_w + pos * 80u;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                *reinterpret_cast<uint4 *>(dst + 16 * j) = make_uint4((uint32_t)acc[r][4 * j], (uint32_t)acc[r][4 * j + 1], (uint32_t)acc[r][4 * j + 2], (uint32_t)acc[r][4 * j + 3]);
+                            *reinterpret_cast<uint4 *>(dst + 64) = make_uint4((uint32_t)(q0 + qq), tile_row + (uint32_t)(32 * r), (uint32_t)qq, 0u);
+                        }
+                    }
+                }
+            }
+        };
+        if constexpr (MAXMODE) {
+#pragma unroll
+            for (int b = 0; b < UT_NBQ; ++b)
+                if (b < nb) block(b, mreg[b]);
+        } else {
+            int none = 0;
+#pragma unroll 1
+            for (int b = 0; b < nb; ++b) block(b, none);
+        }
+    }
+    if constexpr (MAXMODE) {
+#pragma unroll
+        for (int b = 0; b < UT_NBQ; ++b) {   // (a slot nobody's rows reached stays 0 = empty: the caller zeroed the array)
+            const int qq = 32 * b + lj;
+            if (b < nb && qq < nqc && mreg[b] > UT_NEG / 2) a.smax[(size_t)(q0 + qq) * UT_SLOTS + slot] = (uint32_t)mreg[b] ^ 0x80000000u;
+        }
+    } else {
+        if (lane == 0) a.wcnt[wave_g] = wcnt;
+    }
+}
+
+// one wave per query: |q'|^2 and the threshold A = the k-th largest sample maximum (INT_MAX + the call's flag when fewer than k slots hold a row)
+template <int NK>   // NK x 64 maxima per query: the 4096 slots, or (NK = 16) the maxima of four neighbours each -- row sets stay disjoint
+__global__ __launch_bounds__(256) void ut_theta_kernel(const uint32_t *__restrict__ smax, const uint8_t *__restrict__ Q, int nq, int D, int k,
+                                                       int32_t *__restrict__ thr, int32_t *__restrict__ qq_out, uint32_t *__restrict__ flag)
+{
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    uint32_t key[NK];
+    if constexpr (NK == UT_SLOTS / 64) {
+#pragma unroll
+        for (int j = 0; j < NK; ++j) key[j] = smax[(size_t)q * UT_SLOTS + j * 64 + lane];
+    } else {
+        static_assert(NK * 256 == UT_SLOTS, "four slots per key");
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(smax + (size_t)q * UT_SLOTS + (size_t)(j * 64 + lane) * 4);
+            const uint32_t m0 = v.x > v.y ? v.x : v.y, m1 = v.z > v.w ? v.z : v.w;
+            key[j] = m0 > m1 ? m0 : m1;
+        }
+    }
+    int s_ = 0;
+    for (int e = lane; e < D; e += 64) { const int v = (int)Q[(int64_t)q * D + e] - 128; s_ += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o, 64);
+    const uint32_t sel = fs_wave_select(key, k, k + k / 4 + 8);
+    if (lane == 0) {
+        thr[q] = sel != 0u ? (int32_t)(sel ^ 0x80000000u) : 0x7fffffff;
+        qq_out[q] = s_;
+        if (sel == 0u) atomicOr(flag, 1u);
+    }
+}
+
+// records -> per-query (distance, row) lists: as ft_bucket_kernel (flat_f32_tfilter.hip), the distance made exact on the way
+__global__ __launch_bounds__(1024) void ut_bucket_kernel(const uint4 *__restrict__ rec, const uint32_t *__restrict__ wcnt, uint32_t cap,
+                                                         const int32_t *__restrict__ thr, const int32_t *__restrict__ qqv, const int32_t *__restrict__ norms,
+                                                         uint32_t *__restrict__ cnt, uint2 *__restrict__ cand, int chunks, int qper, int nq, uint32_t *__restrict__ flag)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t ut_stage[];
+    __shared__ uint32_t hist[32 * UT_NBMAX], base_s[32 * UT_NBMAX];
+    __shared__ uint32_t nstage_s;
+    uint2 *st_dr = reinterpret_cast<uint2 *>(ut_stage);
+    uint16_t *st_q = reinterpret_cast<uint16_t *>(ut_stage + (size_t)UT_STAGE * sizeof(uint2));
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int chunk = (j >> 3) % chunks, q0 = chunk * qper;
+    const int nqc = nq - q0 < qper ? nq - q0 : qper;
+    if (nqc <= 0) return;
+    for (int i = tid; i < nqc; i += 1024) hist[i] = 0u;
+    if (tid == 0) nstage_s = 0u;
+    const int per = 1024 / UT_WAVES, r = tid / per, t = tid % per;
+    uint32_t n = wcnt[j * UT_WAVES + r];
+    if (n > cap) { if (t == 0) atomicOr(flag, 1u); n = cap; }
+    const uint4 *rp = rec + (size_t)(j * UT_WAVES + r) * cap * 5;
+    __syncthreads();
+    auto each_hit = [&](auto &&f) {
+        for (uint32_t i = t; i < n; i += per) {
+            const uint4 h = rp[(size_t)i * 5 + 4];
+            const int tb = thr[h.x], qq = qqv[h.x];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const uint4 s4 = rp[(size_t)i * 5 + jj];
+                const int sv[4] = { (int)s4.x, (int)s4.y, (int)s4.z, (int)s4.w };
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (sv[e] >= tb) {
+                        const uint32_t row = h.y + (uint32_t)(e + 8 * jj);
+                        f(h.x, h.z, (uint32_t)(qq - 2 * sv[e] + (norms[row] & 1)), row);
+                    }
+            }
+        }
+    };
+    each_hit([&](uint32_t, uint32_t ql, uint32_t d, uint32_t row) {
+        atomicAdd(&hist[ql], 1u);
+        const uint32_t pos = atomicAdd(&nstage_s, 1u);
+        if (pos < (uint32_t)UT_STAGE) { st_dr[pos] = make_uint2(d, row); st_q[pos] = (uint16_t)ql; }
+    });
+    __syncthreads();
+    const uint32_t nstage = nstage_s;
+    for (int i = tid; i < nqc; i += 1024) {
+        const uint32_t c = hist[i];
+        base_s[i] = c ? atomicAdd(&cnt[q0 + i], c) : 0u;
+        hist[i] = 0u;
+    }
+    __syncthreads();
+    if (nstage <= (uint32_t)UT_STAGE) {
+        for (uint32_t i = tid; i < nstage; i += 1024) {
+            const uint32_t ql = st_q[i];
+            const uint32_t pos = base_s[ql] + atomicAdd(&hist[ql], 1u);
+            if (pos < (uint32_t)UT_CAP) cand[(size_t)(q0 + ql) * UT_CAP + pos] = st_dr[i];
+        }
+        return;
+    }
+    each_hit([&](uint32_t q, uint32_t ql, uint32_t d, uint32_t row) {   // more hits than the stage holds: the records once more
+        const uint32_t pos = base_s[ql] + atomicAdd(&hist[ql], 1u);
+        if (pos < (uint32_t)UT_CAP) cand[(size_t)q * UT_CAP + pos] = make_uint2(d, row);
+    });
+}
+
+__device__ __forceinline__ void ut_bitonic_u64(unsigned long long *e, int np)
+{
+    for (int size = 2; size <= np; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < np / 2; i += 1024) {
+                const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long a0 = e[lo], a1 = e[hi];
+                if ((a0 > a1) == up) { e[lo] = a1; e[hi] = a0; }
+            }
+        }
+    }
+    __syncthreads();
+}
+// one workgroup of 1024 threads per query: the k-th smallest distance by a radix select over the list in LDS, everything at or below it
+// sorted by (distance, row)
+__global__ __launch_bounds__(1024) void ut_finish_kernel(int64_t n, int k, const uint32_t *__restrict__ cnt, const uint2 *__restrict__ cand,
+                                                         float *__restrict__ out_d, int64_t *__restrict__ out_i, uint32_t *__restrict__ flag)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t ub_keys[];   // [UT_CAP] keys = ~distance; later [UT_KEEP] (distance, row) pairs
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t pick_s[2];
+    __shared__ int m2_s;
+    constexpr int NTH = 1024;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const uint32_t nc = cnt[q];
+    const int64_t want = k < n ? k : n;
+    if (nc > (uint32_t)UT_CAP || (int64_t)nc < want) {
+        if (tid == 0) atomicOr(flag, 1u);
+        return;
+    }
+    if (tid == 0) m2_s = 0;
+    const uint2 *cq = cand + (size_t)q * UT_CAP;
+    uint32_t kmx = 0u, kmn = 0xffffffffu;
+    for (uint32_t i = tid; i < nc; i += NTH) {
+        const uint32_t key = ~cq[i].x;   // (distances stay far below 2^32 - 1: keys are never 0)
+        ub_keys[i] = key;
+        kmx = key > kmx ? key : kmx; kmn = key < kmn ? key : kmn;
+    }
+    kmx = fs_wave_max_u32(kmx); kmn = fs_wave_min_u32(kmn);
+    if (lane == 0) { hist[tid >> 6] = kmx; hist[16 + (tid >> 6)] = kmn; }
+    __syncthreads();
+    kmx = 0u; kmn = 0xffffffffu;
+    for (int w = 0; w < 16; ++w) { kmx = hist[w] > kmx ? hist[w] : kmx; kmn = hist[16 + w] < kmn ? hist[16 + w] : kmn; }
+    __syncthreads();
+    const int top_byte = kmx == kmn ? -1 : (31 - __builtin_clz(kmx ^ kmn)) >> 3;
+    uint32_t mask = top_byte >= 3 ? 0u : (0xffffffffu << (8 * (top_byte + 1)));
+    uint32_t prefix = kmx & mask, remaining = (uint32_t)want;
+    for (int shift = 8 * top_byte; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        for (uint32_t i = tid; i < nc; i += NTH) {
+            const uint32_t key = ub_keys[i];
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const uint32_t mine = h0 + h1 + h2 + h3;
+            uint32_t above = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_down((int)above, o, 64);
+                if (lane + o < 64) above += v;
+            }
+            const uint32_t excl = above - mine;
+            if (excl < remaining && remaining <= above) {
+                uint32_t acc_ = excl, bin = 0u;
+                const uint32_t hh[4] = { h0, h1, h2, h3 };
+#pragma unroll
+                for (int b = 3; b >= 0; --b) {
+                    if (acc_ < remaining && remaining <= acc_ + hh[b]) { bin = (uint32_t)(4 * lane + b); pick_s[1] = remaining - acc_; }
+                    acc_ += hh[b];
+                }
+                pick_s[0] = bin;
+            }
+        }
+        __syncthreads();
+        prefix |= pick_s[0] << shift;
+        mask |= 255u << shift;
+        remaining = pick_s[1];
+        __syncthreads();
+    }
+    // prefix = ~(the k-th smallest distance): everything at or below that distance is kept
+    __shared__ uint32_t keep_i[UT_KEEP];
+    for (uint32_t i = tid; i < nc; i += NTH) {
+        if (ub_keys[i] >= prefix) {
+            const int pos = atomicAdd(&m2_s, 1);
+            if (pos < UT_KEEP) keep_i[pos] = i;
+        }
+    }
+    __syncthreads();
+    const int m2 = m2_s;
+    if (m2 > UT_KEEP) {   // masses of rows at the k-th distance
+        if (tid == 0) atomicOr(flag, 1u);
+        return;
+    }
+    int np2 = 256;
+    while (np2 < m2) np2 <<= 1;
+    unsigned long long *sel = reinterpret_cast<unsigned long long *>(ub_keys);
+    unsigned long long mine[UT_KEEP / NTH];
+#pragma unroll
+    for (int j = 0; j < UT_KEEP / NTH; ++j) {
+        const int i = tid + j * NTH;
+        mine[j] = ~0ull;
+        if (i < m2) { const uint2 c = cq[keep_i[i]]; mine[j] = ((unsigned long long)c.x << 32) | c.y; }
+    }
+    __syncthreads();   // (the keys have been read by everybody: their space takes the pairs)
+#pragma unroll
+    for (int j = 0; j < UT_KEEP / NTH; ++j)
+        if (tid + j * NTH < np2) sel[tid + j * NTH] = mine[j];
+    ut_bitonic_u64(sel, np2);
+    for (int i = tid; i < k; i += NTH) {
+        const unsigned long long e = i < np2 ? sel[i] : ~0ull;
+        if (e != ~0ull && i < want) {
+            out_d[(int64_t)q * k + i] = __uint_as_float((uint32_t)(e >> 32));   // int32 distance bits
+            out_i[(int64_t)q * k + i] = (int64_t)(uint32_t)e;
+        } else {
+            out_d[(int64_t)q * k + i] = __uint_as_float(0x7f800000u);
+            out_i[(int64_t)q * k + i] = -1;
+        }
+    }
+}
+
+template <int KS, int RT>
+static int ut_launch(bool maxmode, const UtArgs &a, size_t lds, hipStream_t st)
+{
+    static std::atomic<bool> attr_a[16] = {}, attr_b[16] = {};
+    if (maxmode) {
+        CVTMI_TRY(fs_set_lds((const void *)flat_u8_tfilter_kernel<KS, RT, true>, 163840, attr_a));
+        hipLaunchKernelGGL((flat_u8_tfilter_kernel<KS, RT, true>), dim3(UT_GRID), dim3(64 * UT_WAVES), lds, st, a);
+    } else {
+        CVTMI_TRY(fs_set_lds((const void *)flat_u8_tfilter_kernel<KS, RT, false>, 163840, attr_b));
+        hipLaunchKernelGGL((flat_u8_tfilter_kernel<KS, RT, false>), dim3(UT_GRID), dim3(64 * UT_WAVES), lds, st, a);
+    }
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
+}  // namespace
+
+static std::atomic<int> g_ut_on{1};   // cvtmi_set_tuning("flat_u8_tfilter"): 1 = uint8 searches with k = 129 .. 2048 take this pipeline, 0 = the exact kernels
+// "flat_u8_tfilter_min_k" / "_min_nq": k <= 128 from this k and this batch on.  Measured (tools/flat_u8_bigk.py, profiles/r06_flat_u8_tfilter.txt; 1 M x 256-d,
+// 2 M x 512-d, 10 M x 128-d, 10 M x 512-d; k = 10 / 64 / 100 / 128): from 128 queries on this pipeline is level with or ahead of both the
+// streaming passes and the sample + filter pipeline of flat_mfma.hip at every point (k = 10: 0.9-1.0 x at 128 queries, 0.75-0.95 x from 256;
+// k = 100: 0.7 x at 128 queries, 0.42-0.55 x from 256); below, one streaming pass over the raw rows wins
+static std::atomic<int> g_ut_min_k{1}, g_ut_min_nq{129}, g_ut_min_nq_k65{97};   // ("_min_nq_k65": the batch bound for k = 65 .. 128, where a streaming pass costs more)
+static std::atomic<int> g_ut_sample{0};   // "flat_u8_tfilter_sample": the sample pass takes one tile group in this many (0: by k -- 8 up to k = 512, 5 up to 1024, 3 beyond)
+void set_flat_u8_tfilter(int v) { g_ut_on = v != 0; }
+void set_flat_u8_tfilter_min_k(int v) { g_ut_min_k = v < 1 ? 1 : v; }
+void set_flat_u8_tfilter_min_nq(int v) { g_ut_min_nq = v < 1 ? 1 : v; }
+void set_flat_u8_tfilter_min_nq_k65(int v) { g_ut_min_nq_k65 = v < 1 ? 1 : v; }
+void set_flat_u8_tfilter_sample(int v) { g_ut_sample = v < 0 ? 0 : v > 64 ? 64 : v; }
+bool flat_u8_tfilter_width(int D) { return D == 64 || D == 96 || D == 128 || D == 192 || D == 256 || D == 384 || D == 512; }
+bool flat_u8_tfilter_applies(int D, int64_t n, int64_t nq, int k)
+{
+    if (!g_ut_on.load() || !flat_u8_tfilter_width(D) || n < 262144 || n >= 0x7fffffe0LL || nq < 1 || k > CVTMI_K_MAX) return false;
+    return k > 128 || (k >= g_ut_min_k.load() && nq >= (k > 64 ? std::min(g_ut_min_nq.load(), g_ut_min_nq_k65.load()) : g_ut_min_nq.load()));
+}
+// the sample pass takes one tile group in so many: about k x div rows pass the threshold (~0.7 x 4096 x div at k = 2048)
+static int ut_sample_div(int k) { return g_ut_sample.load() ? g_ut_sample.load() : (k <= 32 ? 32 : (k <= 128 ? 16 : (k <= 512 ? 8 : (k <= 1024 ? 5 : 3)))); }
+// records per wave: three times the expected count (rows reach the waves tile group by tile group, evenly)
+static uint32_t ut_rec_cap(int64_t m, int k)
+{
+    const double pass = std::min<double>((double)k, 0.7 * UT_SLOTS) * ut_sample_div(k) * 1.5;
+    return (uint32_t)std::min<double>(8192.0, std::max<double>(512.0, 3.0 * (double)m * pass / (UT_GRID * UT_WAVES)));
+}
+size_t flat_u8_tfilter_scratch(int64_t nq, int k)
+{
+    const int64_t m = std::min<int64_t>(nq, UT_PASS);
+    return (size_t)m * (UT_SLOTS + 4) * sizeof(uint32_t) + (size_t)m * UT_CAP * sizeof(uint2) + (size_t)UT_GRID * UT_WAVES * (sizeof(uint32_t) + (size_t)ut_rec_cap(m, k) * 80) + 1024;
+}
+
+// nq queries against rows [0, n); *flag (device, zeroed here) != 0 afterwards: some query could not be answered -- run the exact kernels
+int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int k, void *scratch, float *out_d,
+                           int64_t *out_i, uint32_t *flag, hipStream_t st)
+{
+    if (!flat_u8_tfilter_applies(D, n, nq, k)) return fail(CVTMI_EINVAL, "flat_u8_tfilter: D=%d nq=%lld k=%d", D, (long long)nq, k);
+    const int ks = D / 32, rt = ks >= 12 ? 2 : (ks >= 4 ? 3 : 4);   // (tiles per wave: RT x (4 KS + 32) registers of 256)
+    const int qcap = std::min(32 * UT_NBMAX, (int)((size_t)(160 * 1024 - 32 * UT_NBMAX * 4) / ((size_t)ks * 1024)) * 32);
+    CVTMI_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), st));
+    const int64_t n_tiles = (n + 31) / 32;
+    for (int64_t a0 = 0; a0 < nq; a0 += UT_PASS) {
+        const int64_t m = std::min<int64_t>(nq - a0, UT_PASS);
+        int chunks = 1;
+        while (chunks < 32 && (m + chunks - 1) / chunks > qcap) chunks *= 2;
+        if (chunks != 1) return fail(CVTMI_EINVAL, "flat_u8_tfilter: a pass of %lld queries does not fit the LDS at D=%d", (long long)m, D);
+        const int qper = (int)(((m + chunks - 1) / chunks + 31) / 32 * 32);
+        const uint32_t cap = ut_rec_cap(m, k);
+        uint32_t *smax = reinterpret_cast<uint32_t *>(scratch);
+        int32_t *thr = reinterpret_cast<int32_t *>(smax + (size_t)m * UT_SLOTS);
+        int32_t *qqv = thr + m;
+        uint32_t *cnt = reinterpret_cast<uint32_t *>(qqv + m);
+        uint32_t *wcnt = cnt + m + (m & 1);
+        uint2 *cand = reinterpret_cast<uint2 *>(wcnt + UT_GRID * UT_WAVES);
+        uint4 *rec = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(cand + (size_t)m * UT_CAP) + 256 - (((uintptr_t)(cand + (size_t)m * UT_CAP)) & 15));
+        CVTMI_HIP(hipMemsetAsync(smax, 0, (size_t)m * UT_SLOTS * sizeof(uint32_t), st));
+        CVTMI_HIP(hipMemsetAsync(cnt, 0, (size_t)m * sizeof(uint32_t), st));
+        UtArgs a;
+        a.pack = reinterpret_cast<const uint4 *>(pack); a.norms = norms; a.n = n; a.n_tiles = n_tiles; a.Q = q + a0 * D; a.D = D; a.nq = (int)m;
+        a.chunks = chunks; a.qper = qper; a.smax = smax; a.thr = thr; a.rec = rec; a.wcnt = wcnt; a.cap = cap;
+        {   // the sample: a whole number of tile groups per wave of a chunk
+            const int64_t all_groups = (n_tiles + rt - 1) / rt, streams = (int64_t)(UT_GRID / chunks) * UT_WAVES;
+            const int div = ut_sample_div(k);
+            const int64_t want = std::max<int64_t>(all_groups / div, std::min<int64_t>(all_groups, 2048 / rt));
+            a.n_sample = std::min<int64_t>(all_groups, std::max<int64_t>(1, (want + streams / 2) / streams) * streams);
+        }
+        const size_t lds = (size_t)(qper / 32) * ks * 1024 + (size_t)qper * sizeof(int);
+#define CVTMI_UT(MAXM) \
+        (ks == 16 ? ut_launch<16, 2>(MAXM, a, lds, st) : ks == 12 ? ut_launch<12, 2>(MAXM, a, lds, st) : ks == 8 ? ut_launch<8, 3>(MAXM, a, lds, st) : \
+         ks == 6 ? ut_launch<6, 3>(MAXM, a, lds, st) : ks == 4 ? ut_launch<4, 3>(MAXM, a, lds, st) : ks == 3 ? ut_launch<3, 4>(MAXM, a, lds, st) : ut_launch<2, 4>(MAXM, a, lds, st))
+        CVTMI_TRY(CVTMI_UT(true));
+        if (k <= 128) hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 256>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flag);
+        else hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 64>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flag);
+        CVTMI_TRY(CVTMI_UT(false));
+#undef CVTMI_UT
+        const size_t bucket_lds = (size_t)UT_STAGE * (sizeof(uint2) + sizeof(uint16_t)), fin_lds = (size_t)UT_CAP * sizeof(uint32_t);
+        static std::atomic<bool> attr_k[16] = {}, attr_f[16] = {};
+        CVTMI_TRY(fs_set_lds((const void *)ut_bucket_kernel, bucket_lds, attr_k));
+        CVTMI_TRY(fs_set_lds((const void *)ut_finish_kernel, fin_lds, attr_f));
+        hipLaunchKernelGGL(ut_bucket_kernel, dim3(UT_GRID), dim3(1024), bucket_lds, st, rec, wcnt, cap, thr, qqv, norms, cnt, cand, chunks, qper, (int)m, flag);
+        hipLaunchKernelGGL(ut_finish_kernel, dim3((unsigned)m), dim3(1024), fin_lds, st, n, k, cnt, cand, out_d + a0 * k, out_i + a0 * k, flag);
+        CVTMI_HIP(hipGetLastError());
+    }
+    return CVTMI_OK;
+}
+
+}  // namespace cvtmi

@@ -200,7 +200,7 @@ int launch_flat_finish(int metric, const float *X, int64_t n, int D, const float
 // uint8 L2 through the same pipeline (exact integer distances on the i8 matrix cores: no bound, no second cut)
 bool flat_u8_filter_applies(int D, int64_t n, int64_t nq, int k);
 size_t flat_u8_pack_bytes(int D, int64_t n);
-int launch_flat_u8_pack(const uint8_t *X, int64_t n, int D, uint4 *pack, hipStream_t st);
+int launch_flat_u8_pack(const uint8_t *X, int64_t n, int D, uint4 *pack, hipStream_t st, int64_t row0 = 0);   // rows [row0, n), row0 % 32 == 0
 int launch_flat_u8_filter(const uint8_t *q, int64_t nq, int D, const uint4 *pack, const int32_t *norms, const float *sample_d, int k,
                           int64_t row_begin, int64_t n, uint32_t pair_cap, uint32_t *pair_cnt, uint4 *pairs, hipStream_t st);
 int launch_flat_u8_finish(int64_t nq, const uint32_t *pair_cnt, uint32_t pair_cap, const uint4 *pairs, int cap, int k, const float *sample_d,
@@ -234,6 +234,19 @@ void set_flat_f32_tfilter_sample(int v);
 void set_flat_f32_tfilter_min_rows(int v);
 int64_t flat_f32_tfilter_min_rows();
 size_t flat_f32_stream_scratch(int D, int64_t n, int64_t nq_pass);
+// round 6 (flat_u8_tfilter.hip): uint8 L2 batches (from 128 queries; any batch when k = 129 .. CVTMI_K_MAX; 64 .. 512-d in steps the kernels exist for,
+// >= 262 144 rows) as a threshold filter over the int8 operand copy
+// (launch_flat_u8_pack): exact integer scores, so no margins; *flag (device, zeroed inside) != 0 afterwards: the exact kernels must answer the call
+bool flat_u8_tfilter_width(int D);
+bool flat_u8_tfilter_applies(int D, int64_t n, int64_t nq, int k);
+size_t flat_u8_tfilter_scratch(int64_t nq, int k);
+int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int k, void *scratch, float *out_d,
+                           int64_t *out_i, uint32_t *flag, hipStream_t st);
+void set_flat_u8_tfilter(int v);
+void set_flat_u8_tfilter_min_k(int v);
+void set_flat_u8_tfilter_min_nq(int v);
+void set_flat_u8_tfilter_min_nq_k65(int v);
+void set_flat_u8_tfilter_sample(int v);
 // bias[r] (and zeroed padding rows) for rows [row0, row1); stats[0] = max |x|^2 bits, stats[1] = non-finite rows (both accumulate)
 int launch_flat_f32_bias(float *X, int D, int metric, int64_t row0, int64_t row1, float *bias, uint32_t *stats, hipStream_t st);
 // redo[nq], cnt[nq] (zeroed inside): redo is set to 1 for queries the exact kernels must answer

@@ -1176,3 +1176,42 @@ def test_sq8_decode_through_table(amd, orc, d, n):
         c1 = amd.sq8_encode(tv, td, x1, l2norm=True)
         c2 = amd.sq8_encode(tv, td, x2, l2norm=2)
         assert np.array_equal(c1, c2) and np.array_equal(bits(x2), bits(x)) and not np.array_equal(bits(x1), bits(x))
+
+
+@pytest.mark.parametrize("D,nq,k,hi", [(512, 300, 129, 256), (512, 7, 2048, 256), (256, 260, 500, 256), (128, 40, 1000, 256), (128, 300, 200, 6),
+                                       (512, 1000, 10, 256), (384, 129, 64, 256), (192, 257, 100, 256), (96, 300, 1, 256), (64, 513, 128, 256), (128, 130, 33, 6)])
+def test_flat_u8_threshold_filter(amd, orc, D, nq, k, hi):
+    """uint8 L2 batches and every batch with k = 129 .. 2048 (round 6, flat_u8_tfilter.hip: exact integer scores on the i8 matrix cores
+    over the operand copy, 4096 sample maxima -> the threshold itself, candidate lists, radix select + sort) against the round-5 paths
+    ("flat_u8_tfilter" 0: stream passes / sample + filter pipeline / exact kernels) on every query and the checker on two; every width
+    with a kernel, query counts around the 256-query passes and their 32-query blocks; duplicates (more of them than k for the smaller k), queries that are rows, a ragged row
+    count, appends; few distinct byte values (hi = 6: masses of equal distances -- the call may fall back as a whole, same lists)"""
+    rng = np.random.default_rng(D + nq + k + hi)
+    n = 262_144 + 4_000 + 7
+    x = rng.integers(0, hi, size=(n, D), dtype=np.uint8)
+    centres = rng.integers(0, hi, size=(64, D), dtype=np.uint8)
+    near = rng.integers(0, n, 40_000)
+    x[near] = centres[rng.integers(0, 64, near.size)]
+    x[near, rng.integers(0, D, near.size)] ^= 1            # clusters: thousands of rows a step or two from each centre
+    x[100_000:100_400] = x[5]
+    x[n - 1] = x[123]
+    q = x[rng.integers(0, n, nq)].copy()
+    q[:, :3] ^= 1
+    q[0] = x[5]
+    q[1] = centres[3]
+    try:
+        ix = amd.FlatIndex(L2U8, D); ix.add(x[:100_000]); ix.add(x[100_000:n - 3_001])
+        ix.search(q, k)                      # (the operand copy exists from here on: the rows added next are packed behind it, from a partly filled tile on)
+        ix.add(x[n - 3_001:])
+        ds, is_ = ix.search(q, k)
+        how = ix.last_search()[0]
+        assert how == 4 or hi < 256
+        amd.set_tuning("flat_u8_tfilter", 0)
+        de, ie = ix.search(q, k)
+        assert ix.last_search()[0] != 4
+        ix.close()
+    finally:
+        amd.set_tuning("flat_u8_tfilter", 1)
+    assert np.array_equal(is_, ie) and np.array_equal(ds, de)
+    _, odi, oi = orc.flat_search(L2U8, x, q[:2], k)
+    assert np.array_equal(is_[:2], oi) and np.array_equal(ds[:2], odi)

@@ -161,15 +161,32 @@ def test_flat_dispatch_rules_of_round_5():
     """The flat search's routes (cvtmi_flat_describe_dispatch) at the cells the round-5 sweeps fixed (profiles/r05_u8_dispatch_sweep.txt,
     r05_flat_small_tables.txt) and at the structural bounds that must stay."""
     IP, L2F, L2U8 = 0, 1, 2
-    # uint8, C3: one stream up to 128 queries, the filter pipeline from 129 on
+    # uint8, C3: one stream up to 128 queries; from 129 on the threshold filter of round 6 (u8_filter == 2; it replaced the sample + filter
+    # pipeline, u8_filter == 1, wherever its kernels exist: 64 .. 512-d in steps, >= 262 144 rows)
     assert flat_dispatch(L2U8, 512, 10_000_000, 1)["u8_stream"] == 1 and flat_dispatch(L2U8, 512, 10_000_000, 128)["u8_stream"] == 1
     for nq in (129, 256, 512, 1000, 4096):
-        assert flat_dispatch(L2U8, 512, 10_000_000, nq)["u8_filter"] == 1, nq
-    # mid-size tables: the pipeline from rows x width x queries >= 1.3e11 and 524 288 rows on, streaming passes below
-    assert flat_dispatch(L2U8, 512, 2_000_000, 256)["u8_filter"] == 1 and flat_dispatch(L2U8, 512, 1_048_576, 129)["u8_filter"] == 0
-    assert flat_dispatch(L2U8, 128, 1_048_576, 512)["u8_filter"] == 0 and flat_dispatch(L2U8, 128, 4_000_000, 512)["u8_filter"] == 1
-    assert flat_dispatch(L2U8, 512, 400_000, 1000)["u8_filter"] == 0 and flat_dispatch(L2U8, 512, 400_000, 1000)["u8_stream"] == 1
-    assert flat_dispatch(L2U8, 512, 10_000_000, 1000, k=100)["u8_filter"] == 0          # k > 64: passes through the stream
+        assert flat_dispatch(L2U8, 512, 10_000_000, nq) == dict(f32_stream=0, f32_filter=0, u8_filter=2, u8_stream=0), nq
+    assert flat_dispatch(L2U8, 512, 2_000_000, 256)["u8_filter"] == 2 and flat_dispatch(L2U8, 512, 1_048_576, 129)["u8_filter"] == 2
+    assert flat_dispatch(L2U8, 128, 1_048_576, 512)["u8_filter"] == 2 and flat_dispatch(L2U8, 128, 4_000_000, 512)["u8_filter"] == 2
+    assert flat_dispatch(L2U8, 512, 262_143, 1000)["u8_filter"] == 0 and flat_dispatch(L2U8, 512, 262_143, 1000)["u8_stream"] == 1
+    assert flat_dispatch(L2U8, 512, 10_000_000, 1000, k=100)["u8_filter"] == 2
+    # k = 65 .. 128 from 97 queries on; k = 129 .. 2048 at every batch size (the exact kernels behind took one query per workgroup)
+    assert flat_dispatch(L2U8, 128, 10_000_000, 97, k=100)["u8_filter"] == 2 and flat_dispatch(L2U8, 128, 10_000_000, 96, k=100)["u8_stream"] == 1
+    assert flat_dispatch(L2U8, 128, 10_000_000, 97, k=64)["u8_stream"] == 1
+    assert flat_dispatch(L2U8, 512, 2_000_000, 1, k=129)["u8_filter"] == 2 and flat_dispatch(L2U8, 512, 2_000_000, 1000, k=2048)["u8_filter"] == 2
+    assert flat_dispatch(L2U8, 512, 100_000, 1000, k=129) == dict(f32_stream=0, f32_filter=0, u8_filter=0, u8_stream=0)
+    # "flat_u8_tfilter" 0 brings the rules of round 5 back: the sample + filter pipeline from rows x width x queries >= 1.3e11 and 524 288 rows on
+    try:
+        cvt_amd.set_tuning("flat_u8_tfilter", 0)
+        for nq in (129, 256, 512, 1000, 4096):
+            assert flat_dispatch(L2U8, 512, 10_000_000, nq)["u8_filter"] == 1, nq
+        assert flat_dispatch(L2U8, 512, 2_000_000, 256)["u8_filter"] == 1 and flat_dispatch(L2U8, 512, 1_048_576, 129)["u8_filter"] == 0
+        assert flat_dispatch(L2U8, 128, 1_048_576, 512)["u8_filter"] == 0 and flat_dispatch(L2U8, 128, 4_000_000, 512)["u8_filter"] == 1
+        assert flat_dispatch(L2U8, 512, 400_000, 1000)["u8_filter"] == 0 and flat_dispatch(L2U8, 512, 400_000, 1000)["u8_stream"] == 1
+        assert flat_dispatch(L2U8, 512, 10_000_000, 1000, k=100)["u8_filter"] == 0          # k > 64: passes through the stream
+        assert flat_dispatch(L2U8, 512, 2_000_000, 1000, k=129) == dict(f32_stream=0, f32_filter=0, u8_filter=0, u8_stream=0)
+    finally:
+        cvt_amd.set_tuning("flat_u8_tfilter", 1)
     # small tables: the stream from its structural bound of 4096 rows
     assert flat_dispatch(L2U8, 512, 4096, 100)["u8_stream"] == 1 and flat_dispatch(L2U8, 128, 65_536, 16)["u8_stream"] == 1
     assert flat_dispatch(L2U8, 512, 4095, 100) == dict(f32_stream=0, f32_filter=0, u8_filter=0, u8_stream=0)
