@@ -495,6 +495,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "flat_u8_tfilter_min_k")) { set_flat_u8_tfilter_min_k((int)std::min<int64_t>(value, 1 << 20)); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_tfilter_min_nq_k65")) { set_flat_u8_tfilter_min_nq_k65((int)std::min<int64_t>(value, 1 << 30)); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_tfilter_min_nq")) { set_flat_u8_tfilter_min_nq((int)std::min<int64_t>(value, 1 << 30)); return CVTMI_OK; }
+    if (!strcmp(name, "flat_u8_tfilter_chunks")) { set_flat_u8_tfilter_chunks((int)std::min<int64_t>(value, 4)); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_tfilter_sample")) { set_flat_u8_tfilter_sample((int)std::min<int64_t>(value, 64)); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }

@@ -16,6 +16,7 @@
 // on this metric).  Distances come out as int32 bits in the float array, as from every uint8 path.
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 
 #include "common.h"
 #include "flat_f32_common.h"
@@ -28,8 +29,8 @@ namespace {
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 
-constexpr int UT_WAVES = 8, UT_GRID = 256, UT_SLOTS = 4096, UT_CAP = 32768, UT_KEEP = 4096, UT_PASS = 256, UT_NBMAX = 16, UT_STAGE = 12288;
-constexpr int UT_NBQ = UT_PASS / 32;   // query blocks of a pass
+constexpr int UT_WAVES = 8, UT_GRID = 256, UT_SLOTS = 4096, UT_CAP = 32768, UT_KEEP = 4096, UT_QPER = 256, UT_NBMAX = 16, UT_STAGE = 12288;
+constexpr int UT_NBQ = UT_QPER / 32;   // query blocks of a workgroup
 constexpr int UT_NEG = -(1 << 30);   // start value of a padding row's accumulator: never reaches a threshold
 
 struct UtArgs {
@@ -38,6 +39,7 @@ struct UtArgs {
     uint32_t *smax;          // MAX mode: [nq][UT_SLOTS] (a ^ 0x80000000), zeroed by the caller
     const int32_t *thr;      // FILTER mode: [nq] (INT_MAX: nothing passes)
     uint4 *rec; uint32_t *wcnt; uint32_t cap;
+    int dbg;   // CVTMI_UT_DBG timing experiments (results wrong): 1 = no epilogue, 2 = rows loaded once
 };
 
 __device__ __forceinline__ int ut_max3(int a, int b, int c)
@@ -63,7 +65,7 @@ template <int KS, int RT, bool MAXMODE>
 __global__ __launch_bounds__(64 * UT_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void flat_u8_tfilter_kernel(const UtArgs a)
 {
     constexpr int NW = UT_WAVES;
-    extern __shared__ __attribute__((aligned(16))) uint8_t ut_q[];   // [block][K step] x 1 KB, then the blocks' thresholds
+    extern __shared__ __attribute__((aligned(16))) uint8_t ut_q[];   // [block][K step] x 1 KB, the blocks' thresholds, the waves' row terms, 3 KB of padding
     const int tid = threadIdx.x, lane = tid & 63, lj = lane & 31, lk = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -93,12 +95,18 @@ __global__ __launch_bounds__(64 * UT_WAVES) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
     for (int b = 0; b < UT_NBQ; ++b) mreg[b] = UT_NEG;
     uint32_t wcnt = 0;
+    int none = 0;   // (the timing experiments' sink)
     uint8_t *rec_w = reinterpret_cast<uint8_t *>(a.rec) + (size_t)wave_g * a.cap * 80;
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     i32x4 xa[RT][KS];
-    i32x16 bias[RT];
+    // the rows' starting values -(|x'|^2 >> 1) reach the accumulators through the wave's own LDS words (no registers held for them);
+    // the queries' operands through a ring of R registers, R - 1 K steps ahead across the blocks of a group
+    int *bias_w = thr_s + nb * 32 + wave * (RT * 32);
+    constexpr int R = KS % 4 == 0 ? 4 : (KS % 3 == 0 ? 3 : 2);
+    const uint8_t *qp = ut_q + lane * 16;
     for (int64_t g = slice + (int64_t)slices * wave; g < n_groups; g += stride) {
         const int64_t g_rows = MAXMODE ? g * all_groups / a.n_sample : g;
+        if (!(a.dbg & 2) || g < stride) {
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
             const int64_t t = g_rows * RT + r;
@@ -106,31 +114,36 @@ __global__ __launch_bounds__(64 * UT_WAVES) __attribute__((amdgpu_waves_per_eu(2
             const uint4 *tp = a.pack + (tc * KS) * 64 + lane;
 #pragma unroll
             for (int s_ = 0; s_ < KS; ++s_) xa[r][s_] = __builtin_bit_cast(i32x4, tp[s_ * 64]);
-            // element e: row (e & 3) + 8 (e >> 2) + 4 lk of the tile
-            if (t < a.n_tiles && (tc + 1) * 32 <= a.n) {
-                const int4 *np = reinterpret_cast<const int4 *>(a.norms + tc * 32 + 4 * lk);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int4 v = np[2 * j];
-                    bias[r][4 * j] = -(v.x >> 1); bias[r][4 * j + 1] = -(v.y >> 1); bias[r][4 * j + 2] = -(v.z >> 1); bias[r][4 * j + 3] = -(v.w >> 1);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int64_t row = tc * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-                    bias[r][e] = (t < a.n_tiles && row < a.n) ? -(a.norms[row] >> 1) : UT_NEG;
-                }
-            }
         }
+        }
+#pragma unroll
+        for (int i = lane; i < RT * 32; i += 64) {
+            const int64_t row = g_rows * RT * 32 + i;
+            bias_w[i] = row < a.n ? -(a.norms[row] >> 1) : UT_NEG;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         const uint32_t tile_row = (uint32_t)(g_rows * RT * 32 + 4 * lk);
+        i32x4 qr[R];
+#pragma unroll
+        for (int j = 0; j < R - 1; ++j) qr[j] = *reinterpret_cast<const i32x4 *>(qp + j * 1024);
         auto block = [&](const int b, int &mx) {
-            const uint8_t *qb = ut_q + (size_t)b * (KS * 1024) + lane * 16;
             i32x16 acc[RT];
 #pragma unroll
-            for (int s_ = 0; s_ < KS; ++s_) {
-                const i32x4 qv = *reinterpret_cast<const i32x4 *>(qb + s_ * 1024);
+            for (int r = 0; r < RT; ++r)
 #pragma unroll
-                for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[r][s_], qv, s_ == 0 ? bias[r] : acc[r], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {   // element 4 j + i: row i + 8 j + 4 lk of the tile
+                    const int4 v = *reinterpret_cast<const int4 *>(bias_w + r * 32 + 8 * j + 4 * lk);
+                    acc[r][4 * j] = v.x; acc[r][4 * j + 1] = v.y; acc[r][4 * j + 2] = v.z; acc[r][4 * j + 3] = v.w;
+                }
+            const uint8_t *qb = qp + (size_t)b * (KS * 1024);
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                // (the last R - 1 steps of the last block read past the queries, into the thresholds and the padding behind them: never used)
+                qr[(s_ + R - 1) % R] = *reinterpret_cast<const i32x4 *>(qb + (s_ + R - 1) * 1024);
+#pragma unroll
+                for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[r][s_], qr[s_ % R], acc[r], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             // (inline-assembly readers of matrix results: the wait states are spelled out, see flat_f32_tfilter.hip)
             static_assert(RT >= 2 && RT <= 4, "operand lists below");
@@ -138,6 +151,7 @@ __global__ __launch_bounds__(64 * UT_WAVES) __attribute__((amdgpu_waves_per_eu(2
             if constexpr (RT == 3) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
             if constexpr (RT == 4) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
             const int qq = 32 * b + lj;
+            if (a.dbg & 1) { mx = acc[0][0] + acc[RT - 1][3] > mx ? acc[0][0] : mx; return; }
             if constexpr (MAXMODE) {
                 int m = ut_max16(acc[0]);
 #pragma unroll
@@ -168,7 +182,6 @@ __global__ __launch_bounds__(64 * UT_WAVES) __attribute__((amdgpu_waves_per_eu(2
             for (int b = 0; b < UT_NBQ; ++b)
                 if (b < nb) block(b, mreg[b]);
         } else {
-            int none = 0;
 #pragma unroll 1
             for (int b = 0; b < nb; ++b) block(b, none);
         }
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(64 * UT_WAVES) __attribute__((amdgpu_waves_per_eu(2
             if (b < nb && qq < nqc && mreg[b] > UT_NEG / 2) a.smax[(size_t)(q0 + qq) * UT_SLOTS + slot] = (uint32_t)mreg[b] ^ 0x80000000u;
         }
     } else {
-        if (lane == 0) a.wcnt[wave_g] = wcnt;
+        if (lane == 0) a.wcnt[wave_g] = wcnt + (none == 0x12345678 ? 1u : 0u);
     }
 }
 
@@ -443,6 +456,12 @@ bool flat_u8_tfilter_applies(int D, int64_t n, int64_t nq, int k)
 }
 // the sample pass takes one tile group in so many: about k x div rows pass the threshold (~0.7 x 4096 x div at k = 2048)
 static int ut_sample_div(int k) { return g_ut_sample.load() ? g_ut_sample.load() : (k <= 32 ? 32 : (k <= 128 ? 16 : (k <= 512 ? 8 : (k <= 1024 ? 5 : 3)))); }
+// Workgroups that hold different queries walk the same rows in the same order on the same XCD ("chunks" of a pass): the rows come from
+// HBM once and from the caches behind it for the others -- as many chunks as the sample's slots allow (4096 / chunks of them are filled;
+// twice k wanted), "flat_u8_tfilter_chunks" caps it
+static std::atomic<int> g_ut_chunks{4};
+void set_flat_u8_tfilter_chunks(int v) { g_ut_chunks = v >= 4 ? 4 : (v >= 2 ? 2 : 1); }
+static int ut_chunks_max(int k) { return std::min(g_ut_chunks.load(), k <= 512 ? 4 : (k <= 1024 ? 2 : 1)); }
 // records per wave: three times the expected count (rows reach the waves tile group by tile group, evenly)
 static uint32_t ut_rec_cap(int64_t m, int k)
 {
@@ -451,7 +470,7 @@ static uint32_t ut_rec_cap(int64_t m, int k)
 }
 size_t flat_u8_tfilter_scratch(int64_t nq, int k)
 {
-    const int64_t m = std::min<int64_t>(nq, UT_PASS);
+    const int64_t m = std::min<int64_t>(nq, (int64_t)UT_QPER * ut_chunks_max(k));
     return (size_t)m * (UT_SLOTS + 4) * sizeof(uint32_t) + (size_t)m * UT_CAP * sizeof(uint2) + (size_t)UT_GRID * UT_WAVES * (sizeof(uint32_t) + (size_t)ut_rec_cap(m, k) * 80) + 1024;
 }
 
@@ -461,14 +480,14 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
 {
     if (!flat_u8_tfilter_applies(D, n, nq, k)) return fail(CVTMI_EINVAL, "flat_u8_tfilter: D=%d nq=%lld k=%d", D, (long long)nq, k);
     const int ks = D / 32, rt = ks >= 12 ? 2 : (ks >= 4 ? 3 : 4);   // (tiles per wave: RT x (4 KS + 32) registers of 256)
-    const int qcap = std::min(32 * UT_NBMAX, (int)((size_t)(160 * 1024 - 32 * UT_NBMAX * 4) / ((size_t)ks * 1024)) * 32);
+    const int qcap = std::min(32 * UT_NBMAX, (int)((size_t)(160 * 1024 - 32 * UT_NBMAX * 4 - UT_WAVES * 4 * 32 * 4 - 3072) / ((size_t)ks * 1024)) * 32);
     CVTMI_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), st));
     const int64_t n_tiles = (n + 31) / 32;
-    for (int64_t a0 = 0; a0 < nq; a0 += UT_PASS) {
-        const int64_t m = std::min<int64_t>(nq - a0, UT_PASS);
-        int chunks = 1;
-        while (chunks < 32 && (m + chunks - 1) / chunks > qcap) chunks *= 2;
-        if (chunks != 1) return fail(CVTMI_EINVAL, "flat_u8_tfilter: a pass of %lld queries does not fit the LDS at D=%d", (long long)m, D);
+    const int64_t pass = (int64_t)UT_QPER * ut_chunks_max(k);
+    if (qcap < UT_QPER) return fail(CVTMI_EINVAL, "flat_u8_tfilter: %d queries do not fit the LDS at D=%d", UT_QPER, D);
+    for (int64_t a0 = 0; a0 < nq; a0 += pass) {
+        const int64_t m = std::min<int64_t>(nq - a0, pass);
+        const int chunks = m <= UT_QPER ? 1 : (m <= 2 * UT_QPER ? 2 : 4);
         const int qper = (int)(((m + chunks - 1) / chunks + 31) / 32 * 32);
         const uint32_t cap = ut_rec_cap(m, k);
         uint32_t *smax = reinterpret_cast<uint32_t *>(scratch);
@@ -482,6 +501,7 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
         CVTMI_HIP(hipMemsetAsync(cnt, 0, (size_t)m * sizeof(uint32_t), st));
         UtArgs a;
         a.pack = reinterpret_cast<const uint4 *>(pack); a.norms = norms; a.n = n; a.n_tiles = n_tiles; a.Q = q + a0 * D; a.D = D; a.nq = (int)m;
+        { const char *e = getenv("CVTMI_UT_DBG"); a.dbg = e ? atoi(e) : 0; }
         a.chunks = chunks; a.qper = qper; a.smax = smax; a.thr = thr; a.rec = rec; a.wcnt = wcnt; a.cap = cap;
         {   // the sample: a whole number of tile groups per wave of a chunk
             const int64_t all_groups = (n_tiles + rt - 1) / rt, streams = (int64_t)(UT_GRID / chunks) * UT_WAVES;
@@ -489,12 +509,13 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
             const int64_t want = std::max<int64_t>(all_groups / div, std::min<int64_t>(all_groups, 2048 / rt));
             a.n_sample = std::min<int64_t>(all_groups, std::max<int64_t>(1, (want + streams / 2) / streams) * streams);
         }
-        const size_t lds = (size_t)(qper / 32) * ks * 1024 + (size_t)qper * sizeof(int);
+        const size_t lds = (size_t)(qper / 32) * ks * 1024 + (size_t)qper * sizeof(int) + (size_t)UT_WAVES * rt * 32 * sizeof(int) + 3072;
 #define CVTMI_UT(MAXM) \
         (ks == 16 ? ut_launch<16, 2>(MAXM, a, lds, st) : ks == 12 ? ut_launch<12, 2>(MAXM, a, lds, st) : ks == 8 ? ut_launch<8, 3>(MAXM, a, lds, st) : \
          ks == 6 ? ut_launch<6, 3>(MAXM, a, lds, st) : ks == 4 ? ut_launch<4, 3>(MAXM, a, lds, st) : ks == 3 ? ut_launch<3, 4>(MAXM, a, lds, st) : ut_launch<2, 4>(MAXM, a, lds, st))
         CVTMI_TRY(CVTMI_UT(true));
-        if (k <= 128) hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 256>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flag);
+        // (merged keys while that leaves eight per neighbour wanted)
+        if (k * 8 <= UT_SLOTS / 4 / chunks) hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 256>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flag);
         else hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 64>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flag);
         CVTMI_TRY(CVTMI_UT(false));
 #undef CVTMI_UT

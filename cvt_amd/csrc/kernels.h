@@ -247,6 +247,7 @@ void set_flat_u8_tfilter_min_k(int v);
 void set_flat_u8_tfilter_min_nq(int v);
 void set_flat_u8_tfilter_min_nq_k65(int v);
 void set_flat_u8_tfilter_sample(int v);
+void set_flat_u8_tfilter_chunks(int v);
 // bias[r] (and zeroed padding rows) for rows [row0, row1); stats[0] = max |x|^2 bits, stats[1] = non-finite rows (both accumulate)
 int launch_flat_f32_bias(float *X, int D, int metric, int64_t row0, int64_t row1, float *bias, uint32_t *stats, hipStream_t st);
 // redo[nq], cnt[nq] (zeroed inside): redo is set to 1 for queries the exact kernels must answer
