@@ -1158,7 +1158,7 @@ def _sec_flat_u8_c3(ctx, vmin, vdiff):
         ms = _ev_ms(torch, lambda: flat.search(qq, k3), reps=3, warm=1)
         outs[nq3] = flat.search(qq, k3)
         ops = 2.0 * nq3 * n3 * d3 / (ms * 1e-3)
-        c = {"ms": round(ms, 4), "queries_per_s": round(nq3 / (ms * 1e-3), 1)}
+        c = {"ms": round(ms, 4), "queries_per_s": round(nq3 / (ms * 1e-3), 1), "path": int(flat.last_search()[0])}
         if nq3 <= 128:   # one stream over the rows (flat_u8_mstream_kernel): bound by HBM
             c["roofline"] = _hbm(n3 * d3, ms)
         else:
@@ -1167,6 +1167,27 @@ def _sec_flat_u8_c3(ctx, vmin, vdiff):
                              "peak_measured": I8_MFMA_MEASURED_TOPS,
                              "frac_of_measured_peak": round(ops / 1e12 / I8_MFMA_MEASURED_TOPS, 4)}
         c3["cases"]["nq=%d" % nq3] = c
+    c3["path_codes"] = ("0 streaming passes over the raw rows / exact kernels, 1 sample + matrix-core filter pipeline (round 2-5), 4 threshold filter over the int8 "
+                        "operand copy (flat_u8_tfilter.hip, round 6: from 129 queries, and every batch with k > 128); the matrix-core rooflines count the "
+                        "algorithmic operations, 2 x queries x rows x d (the filter's sample pass re-scores 1/32 .. 1/3 of the rows on top)")
+    # more neighbours (round 6): the stream kernels stop at k = 128, the pipeline of rounds 2-5 at 64; behind them the exact kernels took one
+    # query per workgroup
+    qq = q3[:1000].contiguous()
+    c3["more_neighbours"] = {"nq": 1000, "cases": {}}
+    for kk in (100, 129, 1000):
+        ms = _ev_ms(torch, lambda: flat.search(qq, kk), reps=3, warm=1)
+        c = {"ms": round(ms, 4), "queries_per_s": round(1000 / (ms * 1e-3), 1), "path": int(flat.last_search()[0]),
+             "frac_of_measured_i8_peak": round(2.0 * 1000 * n3 * d3 / (ms * 1e-3) / 1e12 / I8_MFMA_MEASURED_TOPS, 4)}
+        if kk in (100, 1000):
+            got = flat.search(qq, kk)
+            cvt.set_tuning("flat_u8_tfilter", 0)
+            try:
+                c["round_5_paths_ms"] = round(_ev_ms(torch, lambda: flat.search(qq, kk), reps=1, warm=1 if kk <= 128 else 0), 3)
+                ref = flat.search(qq, kk)
+            finally:
+                cvt.set_tuning("flat_u8_tfilter", 1)
+            c["identical"] = bool(torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]))
+        c3["more_neighbours"]["cases"]["k=%d" % kk] = c
     if args.cpu_sample > 0:
         from oracle import binding as ob
         orc = ob.Oracle(o3=True)
