@@ -2002,7 +2002,7 @@ static int flat_search_bigk_u8(cvtmi_flat_t h, FlatScratch &S, const uint8_t *q,
     *done = false;
     const int64_t n = h->n;
     if (h->f_pack_n != n) return CVTMI_OK;   // no operand copy (flat_prepare could not build it)
-    if (S.fs_scratch.reserve(flat_u8_tfilter_scratch(nq, k)) != CVTMI_OK) { (void)hipGetLastError(); return CVTMI_OK; }
+    if (S.fs_scratch.reserve(flat_u8_tfilter_scratch(h->D, n, nq, k)) != CVTMI_OK) { (void)hipGetLastError(); return CVTMI_OK; }
     CVTMI_TRY(S.f_stats.reserve(16));
     uint32_t *flag = S.f_stats.as<uint32_t>() + 2, host_flag = 0;
     CVTMI_TRY(launch_flat_u8_tfilter(h->D, h->f_pack.p, h->norms.as<int32_t>(), n, q, nq, k, S.fs_scratch.p, dist, rows, flag, st));

@@ -1,21 +1,26 @@
-// flat_u8_tfilter.hip -- exhaustive uint8 L2 search (BruteforceSearch + L2SpaceI, brutoforce.hpp:73-93, space_l2.h:186-245) with k = 129 .. 2048
-// (round 6).  The stream and filter pipelines of flat_mfma.hip stop at k = 128 / 64; behind them the exact kernel took one query per
-// workgroup (2 M x 512-d, 1000 queries: k = 128 3.9 ms, k = 129 139 ms).  This is the fp32 threshold filter of flat_f32_tfilter.hip on
-// v_mfma_i32_32x32x32_i8 over the packed rows (flat_u8_pack_kernel: x - 128 as int8, [tile][K step of 32][64 lanes] x 16 B):
+// flat_u8_tfilter.hip -- exhaustive uint8 L2 search (BruteforceSearch + L2SpaceI, brutoforce.hpp:73-93, space_l2.h:186-245) as a threshold
+// filter (round 6): every batch with k = 129 .. 2048 and, for k <= 128, batches from 129 queries on.  The stream and filter
+// pipelines of flat_mfma.hip stop at k = 128 / 64; behind them the exact kernel took one query per workgroup (2 M x 512-d, 1000 queries:
+// k = 128 3.9 ms, k = 129 139 ms).  This is the fp32 threshold filter of flat_f32_tfilter.hip on v_mfma_i32_32x32x32_i8 over the packed
+// rows (flat_u8_pack_kernel: x - 128 as int8, [tile][K step of 32][64 lanes] x 16 B):
 //   * the scores are EXACT integers -- with x' = x - 128, q' = q - 128: d = |x'|^2 + |q'|^2 - 2 x'.q' -- so there is no margin and no
 //     second evaluation: a row's accumulator starts at -(|x'|^2 >> 1) and ends as a = x'.q' - (|x'|^2 >> 1), d = |q'|^2 - 2 a + (|x'|^2 & 1);
 //   * a workgroup keeps up to 256 queries in LDS (128 KB at 512-d), a wave RT row tiles in registers; a lane ends up with 16 values of
 //     ITS query per tile: v_max3_i32 tree, one compare, 80-byte records into the wave's own region (no atomics);
-//   * sample pass: 4096 maxima of a over disjoint row sets per query; the k-th largest, A, is reached by k distinct rows, whose
-//     distances are <= |q'|^2 - 2 A + 1 =: tau.  A row with d <= tau has a >= A - (1 - parity) / 2, i.e. a >= A: the threshold is A itself;
+//   * up to four query chunks per pass: workgroups with different queries walk the same rows in the same order on the same XCD, so the
+//     rows leave HBM once per pass of 1024 queries;
+//   * sample pass: up to 4096 maxima of a over disjoint row sets per query (a half wave's own slot, kept in registers until its rows are
+//     through); the k-th largest, A, is reached by k distinct rows, whose distances are <= |q'|^2 - 2 A + 1 =: tau.  A row with d <= tau
+//     has a >= A - (1 - parity) / 2, i.e. a >= A: the threshold is A itself;
 //   * bucket pass: the records' values at or above the threshold become (distance, row) candidates, per query; finish: one workgroup
 //     of 1024 threads per query, the distances in LDS, radix select of the k-th smallest, everything at or below it sorted by
 //     (distance, row).
 // A query whose sample has fewer than k filled slots, whose list or wave region runs over or whose k-th distance ties with more rows
-// than the finish keeps raises ONE flag for the call: the caller then runs the exact kernels for every query (they take no predicate
-// on this metric).  Distances come out as int32 bits in the float array, as from every uint8 path.
+// than the finish keeps raises ONE flag for the call: the caller then lets the round-5 paths answer every query (the exact kernels take
+// no predicate on this metric).  Distances come out as int32 bits in the float array, as from every uint8 path.
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdlib>
 
 #include "common.h"
@@ -455,7 +460,16 @@ bool flat_u8_tfilter_applies(int D, int64_t n, int64_t nq, int k)
     return k > 128 || (k >= g_ut_min_k.load() && nq >= (k > 64 ? std::min(g_ut_min_nq.load(), g_ut_min_nq_k65.load()) : g_ut_min_nq.load()));
 }
 // the sample pass takes one tile group in so many: about k x div rows pass the threshold (~0.7 x 4096 x div at k = 2048)
-static int ut_sample_div(int k) { return g_ut_sample.load() ? g_ut_sample.load() : (k <= 32 ? 32 : (k <= 128 ? 16 : (k <= 512 ? 8 : (k <= 1024 ? 5 : 3)))); }
+// Measured (tools/flat_u8_sample_sweep.py, profiles/r06_flat_u8_sample_sweep.txt: 0.26 .. 5 GB of rows, k = 10 .. 1024): the sample pass costs
+// bytes / div, the candidates' way through the bucket and finish kernels k x div -- the best div follows sqrt(8000 x GB / k) within a few per
+// cent everywhere; beyond ~4096 / k the lists and the waves' record regions run over (the call falls back)
+static int ut_sample_div(int k, int64_t n, int D)
+{
+    if (g_ut_sample.load()) return g_ut_sample.load();
+    const double want = std::sqrt(8000.0 * ((double)n * D * 1e-9) / (double)k);
+    const int hi = std::min(32, std::max(3, 4096 / k));
+    return std::max(2, std::min(hi, (int)(want + 0.5)));
+}
 // Workgroups that hold different queries walk the same rows in the same order on the same XCD ("chunks" of a pass): the rows come from
 // HBM once and from the caches behind it for the others -- as many chunks as the sample's slots allow (4096 / chunks of them are filled;
 // twice k wanted), "flat_u8_tfilter_chunks" caps it
@@ -463,15 +477,15 @@ static std::atomic<int> g_ut_chunks{4};
 void set_flat_u8_tfilter_chunks(int v) { g_ut_chunks = v >= 4 ? 4 : (v >= 2 ? 2 : 1); }
 static int ut_chunks_max(int k) { return std::min(g_ut_chunks.load(), k <= 512 ? 4 : (k <= 1024 ? 2 : 1)); }
 // records per wave: three times the expected count (rows reach the waves tile group by tile group, evenly)
-static uint32_t ut_rec_cap(int64_t m, int k)
+static uint32_t ut_rec_cap(int64_t m, int k, int div)
 {
-    const double pass = std::min<double>((double)k, 0.7 * UT_SLOTS) * ut_sample_div(k) * 1.5;
+    const double pass = std::min<double>((double)k, 0.7 * UT_SLOTS) * div * 1.5;
     return (uint32_t)std::min<double>(8192.0, std::max<double>(512.0, 3.0 * (double)m * pass / (UT_GRID * UT_WAVES)));
 }
-size_t flat_u8_tfilter_scratch(int64_t nq, int k)
+size_t flat_u8_tfilter_scratch(int D, int64_t n, int64_t nq, int k)
 {
     const int64_t m = std::min<int64_t>(nq, (int64_t)UT_QPER * ut_chunks_max(k));
-    return (size_t)m * (UT_SLOTS + 4) * sizeof(uint32_t) + (size_t)m * UT_CAP * sizeof(uint2) + (size_t)UT_GRID * UT_WAVES * (sizeof(uint32_t) + (size_t)ut_rec_cap(m, k) * 80) + 1024;
+    return (size_t)m * (UT_SLOTS + 4) * sizeof(uint32_t) + (size_t)m * UT_CAP * sizeof(uint2) + (size_t)UT_GRID * UT_WAVES * (sizeof(uint32_t) + (size_t)ut_rec_cap(m, k, ut_sample_div(k, n, D)) * 80) + 1024;
 }
 
 // nq queries against rows [0, n); *flag (device, zeroed here) != 0 afterwards: some query could not be answered -- run the exact kernels
@@ -489,7 +503,8 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
         const int64_t m = std::min<int64_t>(nq - a0, pass);
         const int chunks = m <= UT_QPER ? 1 : (m <= 2 * UT_QPER ? 2 : 4);
         const int qper = (int)(((m + chunks - 1) / chunks + 31) / 32 * 32);
-        const uint32_t cap = ut_rec_cap(m, k);
+        const int div = ut_sample_div(k, n, D);
+        const uint32_t cap = ut_rec_cap(m, k, div);
         uint32_t *smax = reinterpret_cast<uint32_t *>(scratch);
         int32_t *thr = reinterpret_cast<int32_t *>(smax + (size_t)m * UT_SLOTS);
         int32_t *qqv = thr + m;
@@ -505,9 +520,8 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
         a.chunks = chunks; a.qper = qper; a.smax = smax; a.thr = thr; a.rec = rec; a.wcnt = wcnt; a.cap = cap;
         {   // the sample: a whole number of tile groups per wave of a chunk
             const int64_t all_groups = (n_tiles + rt - 1) / rt, streams = (int64_t)(UT_GRID / chunks) * UT_WAVES;
-            const int div = ut_sample_div(k);
             const int64_t want = std::max<int64_t>(all_groups / div, std::min<int64_t>(all_groups, 2048 / rt));
-            a.n_sample = std::min<int64_t>(all_groups, std::max<int64_t>(1, (want + streams / 2) / streams) * streams);
+            a.n_sample = std::min<int64_t>(all_groups, std::max<int64_t>(1, (want + streams - 1) / streams) * streams);   // (never a smaller sample than asked for)
         }
         const size_t lds = (size_t)(qper / 32) * ks * 1024 + (size_t)qper * sizeof(int) + (size_t)UT_WAVES * rt * 32 * sizeof(int) + 3072;
 #define CVTMI_UT(MAXM) \

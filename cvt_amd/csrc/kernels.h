@@ -239,7 +239,7 @@ size_t flat_f32_stream_scratch(int D, int64_t n, int64_t nq_pass);
 // (launch_flat_u8_pack): exact integer scores, so no margins; *flag (device, zeroed inside) != 0 afterwards: the exact kernels must answer the call
 bool flat_u8_tfilter_width(int D);
 bool flat_u8_tfilter_applies(int D, int64_t n, int64_t nq, int k);
-size_t flat_u8_tfilter_scratch(int64_t nq, int k);
+size_t flat_u8_tfilter_scratch(int D, int64_t n, int64_t nq, int k);
 int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int k, void *scratch, float *out_d,
                            int64_t *out_i, uint32_t *flag, hipStream_t st);
 void set_flat_u8_tfilter(int v);

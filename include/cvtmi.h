@@ -125,7 +125,8 @@ int cvtmi_set_device(int device);
  *                     from 4096 sample maxima, no margins): every batch when k = 129 .. 2048 (2 M x 512-d, 1000 queries, k = 129: 139 -> 1.5 ms),
  *                     k <= 128 from "flat_u8_tfilter_min_nq" (129) queries on, k = 65 .. 128 from "flat_u8_tfilter_min_nq_k65" (97) on and only
  *                     for k >= "flat_u8_tfilter_min_k" (1); 0 = the streaming passes / the sample + filter pipeline / the exact kernels as in
- *                     round 5.  "flat_u8_tfilter_sample": the sample pass takes one tile group in this many (0 = by k: 32 .. 3)
+ *                     round 5.  "flat_u8_tfilter_sample": the sample pass takes one tile group in this many (0 = sqrt(8000 x GB of rows / k) within 2 .. 32);
+ *                     "flat_u8_tfilter_chunks": query chunks (1 / 2 / 4, default 4) that share one pass over the rows
  *   "flat_u8_mstream_min_rows" smallest table the uint8 streaming kernel takes (default 4096 = its structural bound; it was 262 144 until
  *                     round 5: 65 536 x 512-d, 100 queries 0.84 -> 0.06 ms)
  *   "flat_u8_sample_passes" the uint8 filter pipeline searches its leading sample exactly through the streaming kernel while that takes at
