@@ -546,7 +546,8 @@ class FlatIndex:
         return d, i
 
     def last_search(self):
-        """(how the last search was answered: 0 exact kernels, 1 sample + matrix-core filter, 2 fp32 stream, 3 fp32 threshold filter; largest candidate list)"""
+        """(how the last search was answered: 0 exact / streaming kernels, 1 sample + matrix-core filter, 2 fp32 stream, 3 fp32 threshold filter, 4 uint8
+        threshold filter; largest candidate list -- for 4: the queries it handed to the other kernels)"""
         f = C.c_int(0); m = C.c_int64(0)
         _check(lib().cvtmi_flat_last_search(self.h, C.byref(f), C.byref(m)))
         return f.value, m.value

@@ -1995,21 +1995,42 @@ static int flat_search_filtered_u8(cvtmi_flat_t h, FlatScratch &S, const uint8_t
     return CVTMI_OK;
 }
 
-// uint8 L2 with k > 128 as a threshold filter (flat_u8_tfilter.hip).  *done = false: not applicable / some query's list ran over or
-// tied beyond what the finish keeps -- the exact kernels answer the call (they take no predicate on this metric)
+// uint8 L2 as a threshold filter (flat_u8_tfilter.hip: batches, and every search with k > 128).  Queries it could not answer (sample not
+// filled, list over, masses of ties at the k-th place) are gathered and answered by the streaming / exact kernels -- those take no
+// per-query predicate on this metric --, their lists written over the filter's.  *done = false: not applicable / the call as a whole
+// (a wave's record region ran over, or more than a quarter of the queries are flagged): the round-5 paths answer it
 static int flat_search_bigk_u8(cvtmi_flat_t h, FlatScratch &S, const uint8_t *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st, bool *done)
 {
     *done = false;
     const int64_t n = h->n;
+    const int D = h->D;
     if (h->f_pack_n != n) return CVTMI_OK;   // no operand copy (flat_prepare could not build it)
-    if (S.fs_scratch.reserve(flat_u8_tfilter_scratch(h->D, n, nq, k)) != CVTMI_OK) { (void)hipGetLastError(); return CVTMI_OK; }
-    CVTMI_TRY(S.f_stats.reserve(16));
-    uint32_t *flag = S.f_stats.as<uint32_t>() + 2, host_flag = 0;
-    CVTMI_TRY(launch_flat_u8_tfilter(h->D, h->f_pack.p, h->norms.as<int32_t>(), n, q, nq, k, S.fs_scratch.p, dist, rows, flag, st));
-    CVTMI_HIP(hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, st));
+    if (S.fs_scratch.reserve(flat_u8_tfilter_scratch(D, n, nq, k)) != CVTMI_OK) { (void)hipGetLastError(); return CVTMI_OK; }
+    CVTMI_TRY(S.fs_redo.reserve((size_t)(nq + 1) * sizeof(uint32_t)));
+    uint32_t *flags = S.fs_redo.as<uint32_t>();
+    CVTMI_TRY(launch_flat_u8_tfilter(D, h->f_pack.p, h->norms.as<int32_t>(), n, q, nq, k, S.fs_scratch.p, dist, rows, flags, st));
+    std::vector<uint32_t> hf((size_t)nq + 1);
+    CVTMI_HIP(hipMemcpyAsync(hf.data(), flags, hf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     CVTMI_HIP(stream_wait(st));
-    h->f_last_worst = (long long)host_flag;
-    *done = host_flag == 0;
+    std::vector<int64_t> again;
+    for (int64_t i = 0; i < nq; ++i)
+        if (hf[(size_t)i + 1]) again.push_back(i);
+    h->f_last_worst = (long long)(hf[0] ? nq : (int64_t)again.size());
+    if (hf[0] || (int64_t)again.size() * 4 > nq + 3) return CVTMI_OK;
+    if (!again.empty()) {
+        const int64_t m = (int64_t)again.size();
+        CVTMI_TRY(S.f_seld.reserve((size_t)m * D));
+        CVTMI_TRY(S.f_sd2.reserve((size_t)m * k * sizeof(float)));
+        CVTMI_TRY(S.f_si2.reserve((size_t)m * k * sizeof(int64_t)));
+        uint8_t *qa = S.f_seld.as<uint8_t>();
+        for (int64_t j = 0; j < m; ++j) CVTMI_HIP(hipMemcpyAsync(qa + j * D, q + again[(size_t)j] * D, (size_t)D, hipMemcpyDeviceToDevice, st));
+        CVTMI_TRY(flat_search_rows(h, S, n, qa, m, k, S.f_sd2.as<float>(), S.f_si2.as<int64_t>(), st));
+        for (int64_t j = 0; j < m; ++j) {
+            CVTMI_HIP(hipMemcpyAsync(dist + again[(size_t)j] * k, S.f_sd2.as<float>() + j * k, (size_t)k * sizeof(float), hipMemcpyDeviceToDevice, st));
+            CVTMI_HIP(hipMemcpyAsync(rows + again[(size_t)j] * k, S.f_si2.as<int64_t>() + j * k, (size_t)k * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+        }
+    }
+    *done = true;
     return CVTMI_OK;
 }
 

@@ -15,9 +15,10 @@
 //   * bucket pass: the records' values at or above the threshold become (distance, row) candidates, per query; finish: one workgroup
 //     of 1024 threads per query, the distances in LDS, radix select of the k-th smallest, everything at or below it sorted by
 //     (distance, row).
-// A query whose sample has fewer than k filled slots, whose list or wave region runs over or whose k-th distance ties with more rows
-// than the finish keeps raises ONE flag for the call: the caller then lets the round-5 paths answer every query (the exact kernels take
-// no predicate on this metric).  Distances come out as int32 bits in the float array, as from every uint8 path.
+// A query whose sample has fewer than k filled slots, whose list runs over or whose k-th distance ties with more rows than the finish
+// keeps raises ITS flag; a wave region that runs over raises the call's.  The caller reads the flags (the exact kernels take no predicate
+// on this metric) and lets the round-5 paths answer the flagged queries, or the whole call.  Distances come out as int32 bits in the
+// float array, as from every uint8 path.
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void ut_theta_kernel(const uint32_t *__restric
     if (lane == 0) {
         thr[q] = sel != 0u ? (int32_t)(sel ^ 0x80000000u) : 0x7fffffff;
         qq_out[q] = s_;
-        if (sel == 0u) atomicOr(flag, 1u);
+        if (sel == 0u) flag[q] = 1u;   // (this query's own word)
     }
 }
 
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(1024) void ut_bucket_kernel(const uint4 *__restrict
     if (tid == 0) nstage_s = 0u;
     const int per = 1024 / UT_WAVES, r = tid / per, t = tid % per;
     uint32_t n = wcnt[j * UT_WAVES + r];
-    if (n > cap) { if (t == 0) atomicOr(flag, 1u); n = cap; }
+    if (n > cap) { if (t == 0) atomicOr(flag, 2u); n = cap; }   // (the call's word: whose records were lost is not known)
     const uint4 *rp = rec + (size_t)(j * UT_WAVES + r) * cap * 5;
     __syncthreads();
     auto each_hit = [&](auto &&f) {
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(1024) void ut_finish_kernel(int64_t n, int k, const
     const uint32_t nc = cnt[q];
     const int64_t want = k < n ? k : n;
     if (nc > (uint32_t)UT_CAP || (int64_t)nc < want) {
-        if (tid == 0) atomicOr(flag, 1u);
+        if (tid == 0) flag[q] = 1u;
         return;
     }
     if (tid == 0) m2_s = 0;
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(1024) void ut_finish_kernel(int64_t n, int k, const
     __syncthreads();
     const int m2 = m2_s;
     if (m2 > UT_KEEP) {   // masses of rows at the k-th distance
-        if (tid == 0) atomicOr(flag, 1u);
+        if (tid == 0) flag[q] = 1u;
         return;
     }
     int np2 = 256;
@@ -488,14 +489,15 @@ size_t flat_u8_tfilter_scratch(int D, int64_t n, int64_t nq, int k)
     return (size_t)m * (UT_SLOTS + 4) * sizeof(uint32_t) + (size_t)m * UT_CAP * sizeof(uint2) + (size_t)UT_GRID * UT_WAVES * (sizeof(uint32_t) + (size_t)ut_rec_cap(m, k, ut_sample_div(k, n, D)) * 80) + 1024;
 }
 
-// nq queries against rows [0, n); *flag (device, zeroed here) != 0 afterwards: some query could not be answered -- run the exact kernels
+// nq queries against rows [0, n); flags[nq + 1] (device, zeroed here): flags[0] != 0 afterwards = the call could not be answered, flags[1 + q] != 0 =
+// query q could not -- the caller runs the other paths for those
 int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int k, void *scratch, float *out_d,
-                           int64_t *out_i, uint32_t *flag, hipStream_t st)
+                           int64_t *out_i, uint32_t *flags, hipStream_t st)
 {
     if (!flat_u8_tfilter_applies(D, n, nq, k)) return fail(CVTMI_EINVAL, "flat_u8_tfilter: D=%d nq=%lld k=%d", D, (long long)nq, k);
     const int ks = D / 32, rt = ks >= 12 ? 2 : (ks >= 4 ? 3 : 4);   // (tiles per wave: RT x (4 KS + 32) registers of 256)
     const int qcap = std::min(32 * UT_NBMAX, (int)((size_t)(160 * 1024 - 32 * UT_NBMAX * 4 - UT_WAVES * 4 * 32 * 4 - 3072) / ((size_t)ks * 1024)) * 32);
-    CVTMI_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), st));
+    CVTMI_HIP(hipMemsetAsync(flags, 0, (size_t)(nq + 1) * sizeof(uint32_t), st));
     const int64_t n_tiles = (n + 31) / 32;
     const int64_t pass = (int64_t)UT_QPER * ut_chunks_max(k);
     if (qcap < UT_QPER) return fail(CVTMI_EINVAL, "flat_u8_tfilter: %d queries do not fit the LDS at D=%d", UT_QPER, D);
@@ -529,16 +531,16 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
          ks == 6 ? ut_launch<6, 3>(MAXM, a, lds, st) : ks == 4 ? ut_launch<4, 3>(MAXM, a, lds, st) : ks == 3 ? ut_launch<3, 4>(MAXM, a, lds, st) : ut_launch<2, 4>(MAXM, a, lds, st))
         CVTMI_TRY(CVTMI_UT(true));
         // (merged keys while that leaves eight per neighbour wanted)
-        if (k * 8 <= UT_SLOTS / 4 / chunks) hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 256>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flag);
-        else hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 64>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flag);
+        if (k * 8 <= UT_SLOTS / 4 / chunks) hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 256>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flags + 1 + a0);
+        else hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 64>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flags + 1 + a0);
         CVTMI_TRY(CVTMI_UT(false));
 #undef CVTMI_UT
         const size_t bucket_lds = (size_t)UT_STAGE * (sizeof(uint2) + sizeof(uint16_t)), fin_lds = (size_t)UT_CAP * sizeof(uint32_t);
         static std::atomic<bool> attr_k[16] = {}, attr_f[16] = {};
         CVTMI_TRY(fs_set_lds((const void *)ut_bucket_kernel, bucket_lds, attr_k));
         CVTMI_TRY(fs_set_lds((const void *)ut_finish_kernel, fin_lds, attr_f));
-        hipLaunchKernelGGL(ut_bucket_kernel, dim3(UT_GRID), dim3(1024), bucket_lds, st, rec, wcnt, cap, thr, qqv, norms, cnt, cand, chunks, qper, (int)m, flag);
-        hipLaunchKernelGGL(ut_finish_kernel, dim3((unsigned)m), dim3(1024), fin_lds, st, n, k, cnt, cand, out_d + a0 * k, out_i + a0 * k, flag);
+        hipLaunchKernelGGL(ut_bucket_kernel, dim3(UT_GRID), dim3(1024), bucket_lds, st, rec, wcnt, cap, thr, qqv, norms, cnt, cand, chunks, qper, (int)m, flags);
+        hipLaunchKernelGGL(ut_finish_kernel, dim3((unsigned)m), dim3(1024), fin_lds, st, n, k, cnt, cand, out_d + a0 * k, out_i + a0 * k, flags + 1 + a0);
         CVTMI_HIP(hipGetLastError());
     }
     return CVTMI_OK;

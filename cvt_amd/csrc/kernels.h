@@ -236,12 +236,13 @@ int64_t flat_f32_tfilter_min_rows();
 size_t flat_f32_stream_scratch(int D, int64_t n, int64_t nq_pass);
 // round 6 (flat_u8_tfilter.hip): uint8 L2 batches (from 128 queries; any batch when k = 129 .. CVTMI_K_MAX; 64 .. 512-d in steps the kernels exist for,
 // >= 262 144 rows) as a threshold filter over the int8 operand copy
-// (launch_flat_u8_pack): exact integer scores, so no margins; *flag (device, zeroed inside) != 0 afterwards: the exact kernels must answer the call
+// (launch_flat_u8_pack): exact integer scores, so no margins; flags[nq + 1] (device, zeroed inside): [0] != 0 afterwards = the other paths must answer the
+// call, [1 + q] != 0 = query q
 bool flat_u8_tfilter_width(int D);
 bool flat_u8_tfilter_applies(int D, int64_t n, int64_t nq, int k);
 size_t flat_u8_tfilter_scratch(int D, int64_t n, int64_t nq, int k);
 int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int k, void *scratch, float *out_d,
-                           int64_t *out_i, uint32_t *flag, hipStream_t st);
+                           int64_t *out_i, uint32_t *flags, hipStream_t st);
 void set_flat_u8_tfilter(int v);
 void set_flat_u8_tfilter_min_k(int v);
 void set_flat_u8_tfilter_min_nq(int v);

@@ -1215,3 +1215,32 @@ def test_flat_u8_threshold_filter(amd, orc, D, nq, k, hi):
     assert np.array_equal(is_, ie) and np.array_equal(ds, de)
     _, odi, oi = orc.flat_search(L2U8, x, q[:2], k)
     assert np.array_equal(is_[:2], oi) and np.array_equal(ds[:2], odi)
+
+
+def test_flat_u8_threshold_filter_hands_hard_queries_to_the_other_kernels(amd, orc):
+    """queries the uint8 threshold filter cannot answer are re-run one by one inside the call: 6000 equal rows tie at the k-th place of the
+    query that equals them (the finish keeps 4096), and 40 000 copies of another row overflow that query's candidate list; the rest of the
+    batch stays with the filter.  Same lists as "flat_u8_tfilter" 0, labels included"""
+    rng = np.random.default_rng(12)
+    n, D, nq, k = 300_000, 128, 200, 10
+    x = rng.integers(0, 256, size=(n, D), dtype=np.uint8)
+    x[2_000:8_000] = x[1]
+    x[50_000:90_000] = x[3]
+    q = x[rng.integers(100_000, n, nq)].copy()
+    q[:, :3] ^= 1
+    q[1] = x[1]; q[7] = x[3]; q[7, 0] ^= 1
+    labels = rng.permutation(n).astype(np.int64)
+    try:
+        ix = amd.FlatIndex(L2U8, D); ix.add(x, labels)
+        ds, is_ = ix.search(q, k)
+        how, again = ix.last_search()
+        assert how == 4 and 1 <= again <= 4, (how, again)
+        amd.set_tuning("flat_u8_tfilter", 0)
+        de, ie = ix.search(q, k)
+        assert ix.last_search()[0] != 4
+        ix.close()
+    finally:
+        amd.set_tuning("flat_u8_tfilter", 1)
+    assert np.array_equal(is_, ie) and np.array_equal(ds, de)
+    _, odi, oi = orc.flat_search(L2U8, x, q[[1, 7, 20]], k)
+    assert np.array_equal(is_[[1, 7, 20]], labels[oi]) and np.array_equal(ds[[1, 7, 20]], odi)
