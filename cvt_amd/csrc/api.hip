@@ -478,6 +478,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "flat_f32_tfilter_one")) { set_flat_f32_tfilter_one((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_bigk")) { set_flat_f32_tfilter_bigk((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_retry")) { set_flat_f32_tfilter_retry((int)value); return CVTMI_OK; }
+    if (!strcmp(name, "flat_f32_tfilter_wide_band")) { set_flat_f32_tfilter_wide_band((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_packed")) { set_flat_f32_packed((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_min_rows")) { set_flat_f32_tfilter_min_rows((int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_f32_tfilter_sample")) { set_flat_f32_tfilter_sample((int)value); return CVTMI_OK; }

@@ -41,6 +41,7 @@
 //   NPROD 1: x.q - x1.q1 = (x - x1).q + x1.(q - q1) <= e (2 + e) |x||q| <= 65 664 uQ, D + 1 terms 129 uQ, b_x 8 uQ: 65 801 uQ;
 //            margin 2^-7 Q + 2^-11 Q = 139 264 uQ >= 2 (65 801 + 200).
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <vector>
 
@@ -456,7 +457,8 @@ template <bool IP, int LANES>
 __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict__ X, int64_t n, int D, const float *__restrict__ Q, int k,
                                                         float *__restrict__ thr, const float *__restrict__ qbnd, uint32_t *__restrict__ cnt,
                                                         const uint2 *__restrict__ cand, float *__restrict__ out_d, int64_t *__restrict__ out_i,
-                                                        uint32_t *__restrict__ redo, uint32_t *__restrict__ rcount, uint32_t *__restrict__ rlist, int rcap, int second, int nqb)
+                                                        uint32_t *__restrict__ redo, uint32_t *__restrict__ rcount, uint32_t *__restrict__ rlist, int rcap, int second, int nqb,
+                                                        uint32_t *__restrict__ bcount, uint32_t *__restrict__ blist)
 {
     __shared__ unsigned long long sel[FT_KEEP];
     __shared__ __attribute__((aligned(16))) float q_s[FT_DMAX];
@@ -573,8 +575,12 @@ __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict_
     }
     __syncthreads();
     const int m2 = m2_s;
-    if (m2 > FT_KEEP) {   // masses of near ties
-        if (tid == 0) redo[q] = 1u;
+    if (m2 > FT_KEEP) {   // more rows inside the margin band than this kernel ranks (tight scores on wide rows; masses of near ties): 2 = ft_finish_big_kernel tries (up to FT_KEEP_BIG)
+        if (tid == 0) {
+            redo[q] = 2u;
+            if (bcount) blist[atomicAdd(bcount, 1u)] = (uint32_t)q;   // (at most one entry per query of the pass)
+            else redo[q] = 1u;
+        }
         return;
     }
     unsigned long long mine[FT_KEEP / 256];
@@ -633,8 +639,10 @@ template <bool IP, int LANES>
 __global__ __launch_bounds__(1024) void ft_finish_big_kernel(const float *__restrict__ X, int64_t n, int D, const float *__restrict__ Q, int k,
                                                              const float *__restrict__ thr, const float *__restrict__ qbnd, const uint32_t *__restrict__ cnt,
                                                              const uint2 *__restrict__ cand, float *__restrict__ out_d, int64_t *__restrict__ out_i,
-                                                             uint32_t *__restrict__ redo, int nqb)
+                                                             uint32_t *__restrict__ redo, int nqb, int cstride, int only2, const uint32_t *__restrict__ bcount, const uint32_t *__restrict__ blist)
 {
+    // only2: the second chance of the queries ft_finish_kernel marked 2 (their lists are whole, their margin band holds more than FT_KEEP rows):
+    // cstride = that kernel's list stride; the mark becomes 0 (answered here) or 1 (the exact kernels)
     extern __shared__ __attribute__((aligned(16))) uint32_t fb_keys[];   // [FT_CAP_BIG] keys; later [FT_KEEP_BIG] (distance, row) pairs
     __shared__ __attribute__((aligned(16))) float q_s[FT_DMAX];
     __shared__ uint32_t rows_s[FT_KEEP_BIG];
@@ -642,18 +650,23 @@ __global__ __launch_bounds__(1024) void ft_finish_big_kernel(const float *__rest
     __shared__ uint32_t pick_s[2];
     __shared__ int m2_s;
     constexpr int NTH = 1024;
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t n_list = only2 ? *bcount : 0u;
+    for (uint32_t it = blockIdx.x; it < (only2 ? n_list : gridDim.x); it += gridDim.x) {   // (only2: a fixed grid walks the list -- an empty list costs one round of empty workgroups)
+    __syncthreads();
+    const int q = only2 ? (int)blist[it] : (int)it;
+    [&]() {
     const float cut = thr[q];
     const uint32_t nc = cnt[q];
     const int64_t want = k < n ? k : n;
-    if (redo[q] != 0u) return;
+    if (only2 ? redo[q] != 2u : redo[q] != 0u) return;
     if (!(cut == cut) || nc > (uint32_t)FT_CAP_BIG || (int64_t)nc < want) {   // workgroup-uniform: the exact kernels answer this query
         if (tid == 0) redo[q] = 1u;
         return;
     }
     for (int i = tid; i < D; i += NTH) q_s[i] = Q[(int64_t)q * D + i];
     if (tid == 0) m2_s = 0;
-    const uint2 *cq = cand + (size_t)q * FT_CAP_BIG;
+    const uint2 *cq = cand + (size_t)q * (size_t)cstride;
     uint32_t kmx = 0u, kmn = 0xffffffffu;
     for (uint32_t i = tid; i < nc; i += NTH) {
         uint32_t key = f32_key(__uint_as_float(cq[i].x));
@@ -731,6 +744,7 @@ __global__ __launch_bounds__(1024) void ft_finish_big_kernel(const float *__rest
         sel[i] = e;
     }
     ft_bitonic_u64(sel, np2, NTH);
+    if (only2 && tid == 0) redo[q] = 0u;
     for (int i = tid; i < k; i += NTH) {
         const unsigned long long e = i < np2 ? sel[i] : ~0ull;
         if ((uint32_t)(e >> 32) < 0xfffffff0u && i < want) {
@@ -741,6 +755,8 @@ __global__ __launch_bounds__(1024) void ft_finish_big_kernel(const float *__rest
             out_i[(int64_t)q * k + i] = -1;
         }
     }
+    }();
+    }
 }
 
 }  // namespace
@@ -748,8 +764,19 @@ __global__ __launch_bounds__(1024) void ft_finish_big_kernel(const float *__rest
 // ---- host side ----
 static std::atomic<int> g_ft_on{4};        // cvtmi_set_tuning("flat_f32_tfilter"): 0 = the stream kernels for every batch, 1 .. 3 = products, 4 = choose
 static std::atomic<int> g_ft_min_rows{262144};   // "flat_f32_tfilter_min_rows": smallest table that takes the pipeline
-static std::atomic<int> g_ft_sample_div{5};   // "flat_f32_tfilter_sample": the sample is about 1 / this of the rows
+// "flat_f32_tfilter_sample": the sample is about 1 / this of the rows; 0 (default) = 5, more for few neighbours on large tables -- the sample pass costs bytes / div, the
+// candidates k x div: sqrt(1280 x GB of rows / k) within 5 .. 32 (tools/f32_sample_sweep.py, profiles/r06_f32_sample_sweep.txt: 1 M x 128-d k = 10 0.41 -> 0.36 ms per
+// 1000 queries, 4 M x 128-d 1.31 -> 1.04, 524 288 x 512-d 0.82 -> 0.71; k = 100 keeps 5: above 8 its lists run over on tight data)
+static std::atomic<int> g_ft_sample_div{0};
+static int ft_sample_div(int k, int64_t n, int D)
+{
+    const int v = g_ft_sample_div.load();
+    if (v) return v;
+    const double want = std::sqrt(1280.0 * ((double)n * D * 4e-9) / (double)k);
+    return std::max(5, std::min(32, (int)(want + 0.5)));
+}
 static std::atomic<int> g_ft_bigk{1};      // "flat_f32_tfilter_bigk": 1 = k = 129 .. 2048 through the pipeline (4096 sample maxima, lists of 32 768, ft_finish_big_kernel), 0 = exact kernels
+static std::atomic<int> g_ft_wide_band{1};   // "flat_f32_tfilter_wide_band": 1 = queries with more than FT_KEEP rows inside the margin band get a second finish (ft_finish_big_kernel), 0 = the exact kernels
 static std::atomic<int> g_ft_retry{0};     // "flat_f32_tfilter_retry": 1 = a second filter pass for the queries whose candidate lists ran over, 0 (default) = the exact kernels at once
 static std::atomic<int> g_ft_one_max{1 << 30}; // "flat_f32_tfilter_one": largest batch that multiplies one product (with the staged bucket pass one product wins at every
                                            // batch size measured: 1000 queries 0.74 -> 0.64 ms, 4096 2.9 -> 2.5, 10 000 7.0 -> 6.5; two products beyond this many queries)
@@ -758,11 +785,12 @@ static std::atomic<int> g_ft_min_nq{0};    // cvtmi_set_tuning("flat_f32_tfilter
                                            // 0.079 / 0.096 ms against 0.112 / 0.125 here, level at 80-96), 16 elsewhere (against the exact kernels)
 void set_flat_f32_tfilter(int v) { g_ft_on = v < 0 ? 0 : (v > 4 ? 4 : v); }
 void set_flat_f32_tfilter_one(int v) { g_ft_one_max = v < 0 ? 0 : v; }
+void set_flat_f32_tfilter_wide_band(int v) { g_ft_wide_band = v != 0; }
 void set_flat_f32_tfilter_retry(int v) { g_ft_retry = v != 0; }
 void set_flat_f32_tfilter_bigk(int v) { g_ft_bigk = v != 0; }
 void set_flat_f32_tfilter_min_rows(int v) { g_ft_min_rows = v < 32768 ? 32768 : v; }
 int64_t flat_f32_tfilter_min_rows() { return g_ft_min_rows.load(); }
-void set_flat_f32_tfilter_sample(int v) { g_ft_sample_div = v < 1 ? 1 : (v > 64 ? 64 : v); }
+void set_flat_f32_tfilter_sample(int v) { g_ft_sample_div = v < 0 ? 0 : (v > 64 ? 64 : v); }
 void set_flat_f32_tfilter_min(int v) { g_ft_min_nq = v < 0 ? 0 : v; }
 // widths: the K steps (16 dimensions each) of a row tile stay in a wave's registers (RT tiles of 32 rows: RT x K steps x terms x 4 registers
 // <= 128, 256 with one wave per SIMD; 96 / 128 K steps in two halves of 48 / 64).  A kernel exists for 2 / 4 / 6 / 8 / 10 / 12 / 16 / 24 / 32 /
@@ -895,11 +923,13 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
         uint32_t *cnt = reinterpret_cast<uint32_t *>(qbnd + 2 * m);
         uint32_t *rlist = cnt + m;                 // queries of the second attempt, their number in front of the wave counters
         uint32_t *rcount = rlist + m;
-        uint32_t *wcnt = rcount + 1 + ((5 * m + 1) & 1);   // (the candidate lists behind the wave counters start on 8 bytes)
+        uint32_t *bcount = rcount + 1;             // queries whose margin band is wider than ft_finish_kernel ranks: their number, then the list
+        uint32_t *blist = bcount + 1;
+        uint32_t *wcnt = blist + m + (((uintptr_t)(blist + m) & 7) ? 1 : 0);   // (the candidate lists behind the wave counters start on 8 bytes)
         uint2 *cand = reinterpret_cast<uint2 *>(wcnt + FT_GRID * FT_WAVES);
         uint4 *rec = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(cand + (size_t)m * fcap) + 256 - (((uintptr_t)(cand + (size_t)m * fcap)) & 15));
         CVTMI_HIP(hipMemsetAsync(smax, 0, (size_t)m * nslots * sizeof(uint32_t), st));
-        CVTMI_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * m + 1) * sizeof(uint32_t), st));   // counters, list, its length
+        CVTMI_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * m + 2) * sizeof(uint32_t), st));   // counters, list, its length, the wide bands' count
         FtArgs a;
         a.pack = reinterpret_cast<const uint4 *>(pack); a.bias = bias; a.n_tiles = n_tiles; a.Q = q + a0 * D; a.D = D; a.nq = (int)m; a.chunks = chunks; a.qper = qper;
         a.smax = smax; a.nslots = nslots; a.thr = thr; a.rec = rec; a.wcnt = wcnt; a.cap = cap; a.qlist = nullptr; a.qcount = nullptr; a.dbg = get_flat_f32_dbg();
@@ -909,7 +939,7 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
             const int rt = ft_rt(nch, nprod);
             const int64_t all_groups = (n_tiles + rt - 1) / rt, streams = (int64_t)(FT_GRID / chunks) * nw;
             // (k > 128: a third of the rows -- the k-th largest of 4096 maxima needs many more rows than k behind it)
-            const int64_t want = std::max<int64_t>(all_groups / (big ? std::min(3, g_ft_sample_div.load()) : g_ft_sample_div.load()), std::min<int64_t>(all_groups, (2048 + rt - 1) / rt));
+            const int64_t want = std::max<int64_t>(all_groups / (big ? std::min(3, ft_sample_div(k, n, D)) : ft_sample_div(k, n, D)), std::min<int64_t>(all_groups, (2048 + rt - 1) / rt));
             a.n_sample = std::min<int64_t>(all_groups, std::max<int64_t>(1, (want + streams / 2) / streams) * streams);
         }
         CVTMI_TRY(ft_launch_any(D, nprod, true, a, lds, st));
@@ -932,30 +962,33 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
             CVTMI_TRY(fs_set_lds((const void *)ft_bucket_kernel, bucket_lds, attr_k));
         }
         const int rcap = std::min<int>(qcap, (int)((m + 31) / 32 * 32));   // queries one second attempt takes (a single chunk)
+        const bool wide = !big && D >= 256 && g_ft_wide_band.load() != 0;   // (narrow rows: the exact kernels' turn costs less than this launch on every call)
         auto finish = [&](int second) {
-            if (big) {   // k = 129 .. 2048: the candidates' keys in LDS, a bitonic sort of the exact distances
+            if (big || second == 2) {   // k = 129 .. 2048: the candidates' keys in LDS, a bitonic sort of the exact distances (2: the second chance of the other form's wide bands)
+                const int cstride = big ? FT_CAP_BIG : FT_CAP, only2 = big ? 0 : 1;
+                const unsigned bgrid = big ? (unsigned)m : (unsigned)std::min<int64_t>(m, 256);
                 const size_t lds_b = (size_t)FT_CAP_BIG * sizeof(uint32_t);
                 static std::atomic<bool> attr_f[3][16] = {};
                 if (metric == CVTMI_METRIC_IP) {
                     (void)fs_set_lds((const void *)ft_finish_big_kernel<true, 4>, lds_b, attr_f[0]);
-                    hipLaunchKernelGGL((ft_finish_big_kernel<true, 4>), dim3((unsigned)m), dim3(1024), lds_b, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, (int)m);
+                    hipLaunchKernelGGL((ft_finish_big_kernel<true, 4>), dim3(bgrid), dim3(1024), lds_b, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, (int)m, cstride, only2, bcount, blist);
                 } else if (D % 16 == 0) {
                     (void)fs_set_lds((const void *)ft_finish_big_kernel<false, 8>, lds_b, attr_f[1]);
-                    hipLaunchKernelGGL((ft_finish_big_kernel<false, 8>), dim3((unsigned)m), dim3(1024), lds_b, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, (int)m);
+                    hipLaunchKernelGGL((ft_finish_big_kernel<false, 8>), dim3(bgrid), dim3(1024), lds_b, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, (int)m, cstride, only2, bcount, blist);
                 } else {
                     (void)fs_set_lds((const void *)ft_finish_big_kernel<false, 4>, lds_b, attr_f[2]);
-                    hipLaunchKernelGGL((ft_finish_big_kernel<false, 4>), dim3((unsigned)m), dim3(1024), lds_b, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, (int)m);
+                    hipLaunchKernelGGL((ft_finish_big_kernel<false, 4>), dim3(bgrid), dim3(1024), lds_b, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, (int)m, cstride, only2, bcount, blist);
                 }
                 return;
             }
             const unsigned grid = second ? (unsigned)rcap : (unsigned)m;
             uint32_t *rl = retry ? rlist : nullptr;
             if (metric == CVTMI_METRIC_IP)
-                hipLaunchKernelGGL((ft_finish_kernel<true, 4>), dim3(grid), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m);
+                hipLaunchKernelGGL((ft_finish_kernel<true, 4>), dim3(grid), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m, wide ? bcount : nullptr, blist);
             else if (D % 16 == 0)   // (the reference's L2 sums in 8 lanes when D % 16 == 0, in 4 lanes otherwise: space_l2.h:40-151)
-                hipLaunchKernelGGL((ft_finish_kernel<false, 8>), dim3(grid), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m);
+                hipLaunchKernelGGL((ft_finish_kernel<false, 8>), dim3(grid), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m, wide ? bcount : nullptr, blist);
             else
-                hipLaunchKernelGGL((ft_finish_kernel<false, 4>), dim3(grid), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m);
+                hipLaunchKernelGGL((ft_finish_kernel<false, 4>), dim3(grid), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m, wide ? bcount : nullptr, blist);
         };
         hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), bucket_lds, st, rec, wcnt, cap, thr, cnt, cand, chunks, qper, (int)m, redo + a0, nw, nullptr, nullptr, fcap);
         finish(0);
@@ -967,6 +1000,7 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
             hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), bucket_lds, st, rec, wcnt, cap, thr, cnt, cand, 1, rcap, (int)m, redo + a0, nw, rlist, rcount, fcap);
             finish(1);
         }
+        if (wide) finish(2);
         CVTMI_HIP(hipGetLastError());
         if (getenv("CVTMI_FT_DEBUG")) {   // counts of the pass (synchronises)
             CVTMI_HIP(hipStreamSynchronize(st));

@@ -229,6 +229,7 @@ void set_flat_f32_tfilter(int v);
 void set_flat_f32_tfilter_min(int v);
 void set_flat_f32_tfilter_one(int v);
 void set_flat_f32_tfilter_retry(int v);
+void set_flat_f32_tfilter_wide_band(int v);
 void set_flat_f32_tfilter_bigk(int v);
 void set_flat_f32_tfilter_sample(int v);
 void set_flat_f32_tfilter_min_rows(int v);

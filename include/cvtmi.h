@@ -169,8 +169,12 @@ int cvtmi_set_device(int device);
  *                     own rounding residues -- on tables that have one (>= "flat_f32_tfilter_min_rows" rows); 0 = the fp32 rows, split on the fly
  *   "flat_f32_tfilter_min_rows"  smallest table that takes that pipeline (default 262 144; >= 32 768.  Measured on 128-d: below ~130 K rows the stream
  *                     kernels are ahead for fewer than 128 queries and level beyond; 200 K rows, 1000 queries 0.42 -> 0.32 ms)
- *   "flat_f32_tfilter_sample"  the sample that sets the thresholds is about 1 / this (default 5) of the row-tile groups, spread evenly over the
- *                     rows and rounded to a whole number of groups per wave (1 M x 128-d, 1000 queries: 1/8 0.63 ms, 1/5 0.505, 1/3 0.52)
+ *   "flat_f32_tfilter_sample"  the sample that sets the thresholds is about 1 / this of the row-tile groups, spread evenly over the
+ *                     rows and rounded to a whole number of groups per wave (1 M x 128-d, 1000 queries, k = 100: 1/8 0.63 ms, 1/5 0.505, 1/3 0.52);
+ *                     0 (default) = 5, up to 32 for few neighbours on large tables (sqrt(1280 x GB / k): 4 M x 128-d, k = 10: 1.31 -> 1.04 ms)
+ *   "flat_f32_tfilter_wide_band"  1 (default) = rows of 256 dimensions or more: a query with more than 1024 rows inside the margin band of its k-th
+ *                     score (tight, non-negative features) gets a second finish that ranks up to 4096 (262 144 x 1024-d RootSIFT-shaped rows,
+ *                     k = 128: 18.6 -> 6.2 ms per 1000 queries); 0 = the exact kernels answer such a query
  *   "flat_f32_tfilter_bigk"  1 (default) = fp32 searches with k = 129 .. 2048 (every batch size, tables of "flat_f32_tfilter_min_rows" rows and more)
  *                     run through the threshold filter with 4096 sample maxima, candidate lists of 32 768 and a workgroup-wide selection
  *                     (1 M x 128-d, 1000 queries: k = 129 46.6 -> 1.3 ms, k = 1000 47.8 -> 2.4, k = 2048 53.5 -> 3.2); 0 = the exact kernels

@@ -1,18 +1,13 @@
-#!/usr/bin/env python3
-"""one fp32 flat-search shape for a profiler run: ROWS x D rows (METRIC 0 = IP, 1 = L2), NQ queries, top-K, REPS timed searches"""
+"""one fp32 flat search configuration on RootSIFT-shaped rows for the profiler: python tools/f32_one.py rows D nq k [metric]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import torch, cvt_amd
-dev = torch.device("cuda", 0)
-n, D, metric = int(os.environ.get("ROWS", 1_000_000)), int(os.environ.get("D", 128)), int(os.environ.get("METRIC", 0))
-nq, k, reps = int(os.environ.get("NQ", 1)), int(os.environ.get("K", 100)), int(os.environ.get("REPS", 3))
-g = torch.Generator(device=dev); g.manual_seed(5)
-ix = cvt_amd.FlatIndex(metric, D)
-ix.add(torch.randn((n, D), generator=g, device=dev))
-q = torch.randn((nq, D), generator=g, device=dev)
-ix.search(q, k); torch.cuda.synchronize()
-for _ in range(reps):
-    ix.search(q, k)
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch, cvt_amd as amd
+from cvt_amd import synth
+n, D, nq, k = (int(v) for v in sys.argv[1:5])
+metric = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+x = synth.sift_like(n, D, device=torch.device("cuda", 0))
+q = synth.sift_like(nq, D, seed=0xBEEF, device=torch.device("cuda", 0))
+ix = amd.FlatIndex(metric, D); ix.add(x)
+for _ in range(6): ix.search(q, k)
 torch.cuda.synchronize()
-print("done", n, D, nq, k, ix.last_search())
+print("path", ix.last_search())
