@@ -1091,13 +1091,19 @@ def _sec_flat_f32(ctx):
     del xd
     res["widths"] = {"rows_bytes": "1 GB per width (2048-d: 2 GB)", "nq": 1000, "k": k, "cases": {}}
     base = res["cases"].get("ip nq=1000", {}).get("ms")
-    for d2 in (512, 1024, 2048):
+    for d2, relu in ((512, False), (1024, False), (2048, False), (512, True), (1024, True)):
+        # relu: the same rows after a ReLU (non-negative, like post-activation CNN features): every score is positive and the scores of unrelated rows
+        # lie close together, which is what widens the filter's margin band (DESIGN 4.4 "tight, non-negative rows")
         n2 = max((1 << 30) // (4 * d2), 262144)   # (2048-d: 2 GB of rows -- the pipeline takes tables from 262 144 rows on)
         g = torch.Generator(device=ctx.dev); g.manual_seed(d2)
         cen2 = torch.randn((2000, d2), generator=g, device=ctx.dev)
         x2 = cen2[torch.randint(0, 2000, (n2,), generator=g, device=ctx.dev)] + 0.7 * torch.randn((n2, d2), generator=g, device=ctx.dev)
+        if relu:
+            x2.clamp_(min=0)
         x2 = x2 / x2.norm(dim=1, keepdim=True)
         q2 = x2[torch.randint(0, n2, (1000,), generator=g, device=ctx.dev)] + 0.2 * torch.randn((1000, d2), generator=g, device=ctx.dev)
+        if relu:
+            q2.clamp_(min=0)
         q2 = (q2 / q2.norm(dim=1, keepdim=True)).contiguous()
         ix = cvt.FlatIndex(cvt.IP, d2)
         ix.add(x2)
@@ -1109,7 +1115,7 @@ def _sec_flat_f32(ctx):
         cvt.set_tuning("flat_variant", 1)
         c["exact_kernels_ms"] = round(_ev_ms(torch, lambda: ix.search(q2, k), reps=1, warm=1), 3)
         cvt.set_tuning("flat_variant", 0)
-        res["widths"]["cases"]["ip %dd" % d2] = c
+        res["widths"]["cases"]["ip %dd%s" % (d2, " relu" if relu else "")] = c
         ix.close()
         del x2, q2
     res["path_codes"] = ("0 exact kernels, 1 sample + matrix-core filter pipeline, 2 one stream over the rows "
