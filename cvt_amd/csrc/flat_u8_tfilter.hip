@@ -454,11 +454,23 @@ void set_flat_u8_tfilter_min_k(int v) { g_ut_min_k = v < 1 ? 1 : v; }
 void set_flat_u8_tfilter_min_nq(int v) { g_ut_min_nq = v < 1 ? 1 : v; }
 void set_flat_u8_tfilter_min_nq_k65(int v) { g_ut_min_nq_k65 = v < 1 ? 1 : v; }
 void set_flat_u8_tfilter_sample(int v) { g_ut_sample = v < 0 ? 0 : v > 64 ? 64 : v; }
+// Workgroups that hold different queries walk the same rows in the same order on the same XCD ("chunks" of a pass): the rows come from
+// HBM once and from the caches behind it for the others -- as many chunks as the sample's slots allow (4096 / chunks of them are filled;
+// twice k wanted), "flat_u8_tfilter_chunks" caps it
+static std::atomic<int> g_ut_chunks{4};
+void set_flat_u8_tfilter_chunks(int v) { g_ut_chunks = v >= 4 ? 4 : (v >= 2 ? 2 : 1); }
+static int ut_chunks_max(int k) { return std::min(g_ut_chunks.load(), k <= 512 ? 4 : (k <= 1024 ? 2 : 1)); }
 bool flat_u8_tfilter_width(int D) { return D == 64 || D == 96 || D == 128 || D == 192 || D == 256 || D == 384 || D == 512; }
 bool flat_u8_tfilter_applies(int D, int64_t n, int64_t nq, int k)
 {
-    if (!g_ut_on.load() || !flat_u8_tfilter_width(D) || n < 262144 || n >= 0x7fffffe0LL || nq < 1 || k > CVTMI_K_MAX) return false;
-    return k > 128 || (k >= g_ut_min_k.load() && nq >= (k > 64 ? std::min(g_ut_min_nq.load(), g_ut_min_nq_k65.load()) : g_ut_min_nq.load()));
+    if (!g_ut_on.load() || !flat_u8_tfilter_width(D) || n >= 0x7fffffe0LL || nq < 1 || k > CVTMI_K_MAX) return false;
+    if (k > 128) {   // smaller tables too, while the sample can fill 1.25 k slots (two per wave that gets a tile group): nothing else is fast there
+        const int ks = D / 32, rt = ks >= 12 ? 2 : (ks >= 4 ? 3 : 4);
+        const int64_t groups = (n + 32 * rt - 1) / (32 * rt);
+        return n >= 65536 && 8 * std::min<int64_t>(groups, UT_GRID * UT_WAVES / ut_chunks_max(k)) >= 5 * (int64_t)k;
+    }
+    if (n < 262144) return false;
+    return (k >= g_ut_min_k.load() && nq >= (k > 64 ? std::min(g_ut_min_nq.load(), g_ut_min_nq_k65.load()) : g_ut_min_nq.load()));
 }
 // the sample pass takes one tile group in so many: about k x div rows pass the threshold (~0.7 x 4096 x div at k = 2048)
 // Measured (tools/flat_u8_sample_sweep.py, profiles/r06_flat_u8_sample_sweep.txt: 0.26 .. 5 GB of rows, k = 10 .. 1024): the sample pass costs
@@ -471,12 +483,6 @@ static int ut_sample_div(int k, int64_t n, int D)
     const int hi = std::min(32, std::max(3, 4096 / k));
     return std::max(2, std::min(hi, (int)(want + 0.5)));
 }
-// Workgroups that hold different queries walk the same rows in the same order on the same XCD ("chunks" of a pass): the rows come from
-// HBM once and from the caches behind it for the others -- as many chunks as the sample's slots allow (4096 / chunks of them are filled;
-// twice k wanted), "flat_u8_tfilter_chunks" caps it
-static std::atomic<int> g_ut_chunks{4};
-void set_flat_u8_tfilter_chunks(int v) { g_ut_chunks = v >= 4 ? 4 : (v >= 2 ? 2 : 1); }
-static int ut_chunks_max(int k) { return std::min(g_ut_chunks.load(), k <= 512 ? 4 : (k <= 1024 ? 2 : 1)); }
 // records per wave: three times the expected count (rows reach the waves tile group by tile group, evenly)
 static uint32_t ut_rec_cap(int64_t m, int k, int div)
 {

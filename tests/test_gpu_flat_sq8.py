@@ -1244,3 +1244,28 @@ def test_flat_u8_threshold_filter_hands_hard_queries_to_the_other_kernels(amd, o
     assert np.array_equal(is_, ie) and np.array_equal(ds, de)
     _, odi, oi = orc.flat_search(L2U8, x, q[[1, 7, 20]], k)
     assert np.array_equal(is_[[1, 7, 20]], labels[oi]) and np.array_equal(ds[[1, 7, 20]], odi)
+
+
+@pytest.mark.parametrize("D,n,nq,k", [(512, 65_536 + 5, 300, 129), (128, 70_000, 50, 1000), (256, 200_003, 1000, 2048), (512, 131_072, 3, 2048)])
+def test_flat_u8_threshold_filter_big_k_small_tables(amd, orc, D, n, nq, k):
+    """k > 128 on tables from 65 536 rows (the sample fills two slots per wave that gets a tile group; every group is in it): against the exact
+    kernels on every query and the checker on two"""
+    rng = np.random.default_rng(D + n + k)
+    x = rng.integers(0, 256, size=(n, D), dtype=np.uint8)
+    x[1_000:1_300] = x[5]
+    q = x[rng.integers(0, n, nq)].copy()
+    q[:, :3] ^= 1
+    q[0] = x[5]
+    try:
+        ix = amd.FlatIndex(L2U8, D); ix.add(x)
+        ds, is_ = ix.search(q, k)
+        assert ix.last_search()[0] == 4
+        amd.set_tuning("flat_u8_tfilter", 0)
+        de, ie = ix.search(q, k)
+        assert ix.last_search()[0] == 0
+        ix.close()
+    finally:
+        amd.set_tuning("flat_u8_tfilter", 1)
+    assert np.array_equal(is_, ie) and np.array_equal(ds, de)
+    _, odi, oi = orc.flat_search(L2U8, x, q[:2], k)
+    assert np.array_equal(is_[:2], oi) and np.array_equal(ds[:2], odi)

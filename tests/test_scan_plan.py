@@ -174,7 +174,10 @@ def test_flat_dispatch_rules_of_round_5():
     assert flat_dispatch(L2U8, 128, 10_000_000, 97, k=100)["u8_filter"] == 2 and flat_dispatch(L2U8, 128, 10_000_000, 96, k=100)["u8_stream"] == 1
     assert flat_dispatch(L2U8, 128, 10_000_000, 97, k=64)["u8_stream"] == 1
     assert flat_dispatch(L2U8, 512, 2_000_000, 1, k=129)["u8_filter"] == 2 and flat_dispatch(L2U8, 512, 2_000_000, 1000, k=2048)["u8_filter"] == 2
-    assert flat_dispatch(L2U8, 512, 100_000, 1000, k=129) == dict(f32_stream=0, f32_filter=0, u8_filter=0, u8_stream=0)
+    # ... on tables from 65 536 rows while the sample can fill 1.25 k slots (k <= 128 leaves smaller tables to the stream)
+    assert flat_dispatch(L2U8, 512, 100_000, 1000, k=129)["u8_filter"] == 2 and flat_dispatch(L2U8, 512, 100_000, 1000, k=128)["u8_stream"] == 1
+    assert flat_dispatch(L2U8, 128, 65_536, 10, k=1000)["u8_filter"] == 2 and flat_dispatch(L2U8, 128, 65_536, 10, k=2048)["u8_filter"] == 0
+    assert flat_dispatch(L2U8, 512, 65_535, 1000, k=129) == dict(f32_stream=0, f32_filter=0, u8_filter=0, u8_stream=0)
     # "flat_u8_tfilter" 0 brings the rules of round 5 back: the sample + filter pipeline from rows x width x queries >= 1.3e11 and 524 288 rows on
     try:
         cvt_amd.set_tuning("flat_u8_tfilter", 0)
