@@ -1269,3 +1269,27 @@ def test_flat_u8_threshold_filter_big_k_small_tables(amd, orc, D, n, nq, k):
     assert np.array_equal(is_, ie) and np.array_equal(ds, de)
     _, odi, oi = orc.flat_search(L2U8, x, q[:2], k)
     assert np.array_equal(is_[:2], oi) and np.array_equal(ds[:2], odi)
+
+
+@pytest.mark.parametrize("metric,D,n,nq,k", [(IP, 128, 65_536, 200, 129), (L2F, 96, 70_001, 50, 1000), (L2F, 512, 100_000, 300, 2048), (IP, 1024, 80_000, 40, 200)])
+def test_flat_f32_threshold_filter_big_k_small_tables(amd, orc, metric, D, n, nq, k):
+    """k > 128 on tables from 65 536 rows and 48 k (below the pipeline's 262 144): against the exact kernels on every query, the checker on two"""
+    rng = np.random.default_rng(D + n + k)
+    x = _clustered(rng, n, D, metric)
+    x[10_000:10_300] = x[5]
+    q = (x[rng.integers(0, n, nq)] + 0.05 * rng.normal(size=(nq, D))).astype(np.float32)
+    q[0] = x[5]
+    q = np.ascontiguousarray(q, np.float32)
+    try:
+        ix = amd.FlatIndex(metric, D); ix.add(x)
+        ds, is_ = ix.search(q, k)
+        assert ix.last_search()[0] == 3
+        amd.set_tuning("flat_f32_tfilter_bigk", 0)
+        de, ie = ix.search(q, k)
+        assert ix.last_search()[0] == 0
+        ix.close()
+    finally:
+        amd.set_tuning("flat_f32_tfilter_bigk", 1)
+    assert np.array_equal(is_, ie) and np.array_equal(bits(ds), bits(de))
+    od, _, oi = orc.flat_search(metric, x, q[:2], k, flavour=4 if metric == IP else 8)
+    assert np.array_equal(is_[:2], oi) and np.array_equal(bits(ds[:2]), bits(od))

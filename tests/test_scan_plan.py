@@ -212,4 +212,8 @@ def test_flat_dispatch_rules_of_round_5():
         assert flat_dispatch(L2F, D, 262_143, 100, k=100)["f32_stream"] == 0
     # (round 6: k = 129 .. 2048 take the threshold filter at every batch size; the stream kernels stop at 128)
     assert flat_dispatch(L2F, 128, 1_000_000, 100, k=129)["f32_stream"] == 2 and flat_dispatch(L2F, 128, 1_000_000, 1, k=2048)["f32_stream"] == 2
-    assert flat_dispatch(L2F, 128, 100_000, 100, k=129)["f32_stream"] == 0
+    # ... on tables from 65 536 rows and 48 k (the sample still fills its slots); k <= 128 leaves such tables to the stream / exact kernels
+    assert flat_dispatch(L2F, 128, 100_000, 100, k=129)["f32_stream"] == 2 and flat_dispatch(L2F, 128, 100_000, 100, k=128)["f32_stream"] == 1
+    assert flat_dispatch(L2F, 128, 100_000, 100, k=2048)["f32_stream"] == 2 and flat_dispatch(L2F, 128, 98_000, 100, k=2048)["f32_stream"] == 0
+    assert flat_dispatch(L2F, 128, 65_535, 100, k=129)["f32_stream"] == 0
+    assert flat_dispatch(IP, 1024, 200_000, 1, k=129)["f32_stream"] == 0 and flat_dispatch(IP, 1024, 200_000, 16, k=129)["f32_stream"] == 2
