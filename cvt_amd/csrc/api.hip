@@ -493,6 +493,8 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "hnsw_adc_tables")) { set_hnsw_adc_tables((int)value); return CVTMI_OK; }
     if (!strcmp(name, "hnsw_slots")) { g_hnsw_slots_cap = (int)value; return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_tfilter")) { set_flat_u8_tfilter((int)value); return CVTMI_OK; }
+    if (!strcmp(name, "flat_u8_tfilter_min_rows")) { set_flat_u8_tfilter_min_rows(value); return CVTMI_OK; }
+    if (!strcmp(name, "flat_u8_tfilter_small_min_nq")) { set_flat_u8_tfilter_small_min_nq((int)std::min<int64_t>(value, 1 << 30)); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_tfilter_min_k")) { set_flat_u8_tfilter_min_k((int)std::min<int64_t>(value, 1 << 20)); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_tfilter_min_nq_k65")) { set_flat_u8_tfilter_min_nq_k65((int)std::min<int64_t>(value, 1 << 30)); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_tfilter_min_nq")) { set_flat_u8_tfilter_min_nq((int)std::min<int64_t>(value, 1 << 30)); return CVTMI_OK; }

@@ -448,8 +448,12 @@ static std::atomic<int> g_ut_on{1};   // cvtmi_set_tuning("flat_u8_tfilter"): 1 
 // streaming passes and the sample + filter pipeline of flat_mfma.hip at every point (k = 10: 0.9-1.0 x at 128 queries, 0.75-0.95 x from 256;
 // k = 100: 0.7 x at 128 queries, 0.42-0.55 x from 256); below, one streaming pass over the raw rows wins
 static std::atomic<int> g_ut_min_k{1}, g_ut_min_nq{129}, g_ut_min_nq_k65{97};   // ("_min_nq_k65": the batch bound for k = 65 .. 128, where a streaming pass costs more)
+static std::atomic<int64_t> g_ut_min_rows{262144};   // "flat_u8_tfilter_min_rows": tables under it (from 65 536 rows) come here from "flat_u8_tfilter_small_min_nq" queries on
+static std::atomic<int> g_ut_small_min_nq{129};   // (tools/flat_u8_small_tables.py, profiles/r06_flat_u8_small_tables.txt: ahead of the streaming passes from 129 queries on at every size, 2-6 x at 1000)
 static std::atomic<int> g_ut_sample{0};   // "flat_u8_tfilter_sample": the sample pass takes one tile group in this many (0: by k -- 8 up to k = 512, 5 up to 1024, 3 beyond)
 void set_flat_u8_tfilter(int v) { g_ut_on = v != 0; }
+void set_flat_u8_tfilter_min_rows(int64_t v) { g_ut_min_rows = v < 65536 ? 65536 : v; }
+void set_flat_u8_tfilter_small_min_nq(int v) { g_ut_small_min_nq = v < 1 ? 1 : v; }
 void set_flat_u8_tfilter_min_k(int v) { g_ut_min_k = v < 1 ? 1 : v; }
 void set_flat_u8_tfilter_min_nq(int v) { g_ut_min_nq = v < 1 ? 1 : v; }
 void set_flat_u8_tfilter_min_nq_k65(int v) { g_ut_min_nq_k65 = v < 1 ? 1 : v; }
@@ -469,7 +473,20 @@ bool flat_u8_tfilter_applies(int D, int64_t n, int64_t nq, int k)
         const int64_t groups = (n + 32 * rt - 1) / (32 * rt);
         return n >= 65536 && 8 * std::min<int64_t>(groups, UT_GRID * UT_WAVES / ut_chunks_max(k)) >= 5 * (int64_t)k;
     }
-    if (n < 262144) return false;
+    // widths the streaming kernel does not take (it exists at 128 / 256 / 512-d): the row-tile kernels behind cost 0.1 .. 4 ms whatever the batch -- every
+    // batch of two queries or more comes here (1 M x 96-d, 8 queries: 0.43 -> 0.08 ms)
+    const bool has_stream = D == 128 || D == 256 || D == 512;
+    if (!has_stream && n >= 65536 && nq >= 2 && k >= g_ut_min_k.load()) {
+        const int ks = D / 32, rt = ks >= 12 ? 2 : (ks >= 4 ? 3 : 4);
+        const int64_t groups = (n + 32 * rt - 1) / (32 * rt);
+        if (8 * std::min<int64_t>(groups, UT_GRID * UT_WAVES / 4) >= 5 * (int64_t)k) return true;
+    }
+    if (n < g_ut_min_rows.load()) {   // small tables, k <= 128: large batches only (the stream's passes are short there), and while the sample fills its slots
+        const int ks = D / 32, rt = ks >= 12 ? 2 : (ks >= 4 ? 3 : 4);
+        const int64_t groups = (n + 32 * rt - 1) / (32 * rt);
+        if (n < 65536 || nq < g_ut_small_min_nq.load() || k < g_ut_min_k.load() || 8 * std::min<int64_t>(groups, UT_GRID * UT_WAVES / 4) < 5 * (int64_t)k) return false;
+        return true;
+    }
     return (k >= g_ut_min_k.load() && nq >= (k > 64 ? std::min(g_ut_min_nq.load(), g_ut_min_nq_k65.load()) : g_ut_min_nq.load()));
 }
 // the sample pass takes one tile group in so many: about k x div rows pass the threshold (~0.7 x 4096 x div at k = 2048)

@@ -246,6 +246,8 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
                            int64_t *out_i, uint32_t *flags, hipStream_t st);
 void set_flat_u8_tfilter(int v);
 void set_flat_u8_tfilter_min_k(int v);
+void set_flat_u8_tfilter_min_rows(int64_t v);
+void set_flat_u8_tfilter_small_min_nq(int v);
 void set_flat_u8_tfilter_min_nq(int v);
 void set_flat_u8_tfilter_min_nq_k65(int v);
 void set_flat_u8_tfilter_sample(int v);

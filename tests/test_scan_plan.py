@@ -168,14 +168,18 @@ def test_flat_dispatch_rules_of_round_5():
         assert flat_dispatch(L2U8, 512, 10_000_000, nq) == dict(f32_stream=0, f32_filter=0, u8_filter=2, u8_stream=0), nq
     assert flat_dispatch(L2U8, 512, 2_000_000, 256)["u8_filter"] == 2 and flat_dispatch(L2U8, 512, 1_048_576, 129)["u8_filter"] == 2
     assert flat_dispatch(L2U8, 128, 1_048_576, 512)["u8_filter"] == 2 and flat_dispatch(L2U8, 128, 4_000_000, 512)["u8_filter"] == 2
-    assert flat_dispatch(L2U8, 512, 262_143, 1000)["u8_filter"] == 0 and flat_dispatch(L2U8, 512, 262_143, 1000)["u8_stream"] == 1
     assert flat_dispatch(L2U8, 512, 10_000_000, 1000, k=100)["u8_filter"] == 2
+    # tables from 65 536 rows on (round 6, late): the same batch bound; widths without a streaming kernel (64 / 96 / 192 / 384-d) from two queries on
+    assert flat_dispatch(L2U8, 512, 65_536, 129)["u8_filter"] == 2 and flat_dispatch(L2U8, 512, 65_536, 128)["u8_stream"] == 1
+    assert flat_dispatch(L2U8, 512, 65_535, 1000)["u8_filter"] == 0 and flat_dispatch(L2U8, 512, 65_535, 1000)["u8_stream"] == 1
+    assert flat_dispatch(L2U8, 96, 1_000_000, 2)["u8_filter"] == 2 and flat_dispatch(L2U8, 96, 1_000_000, 1)["u8_filter"] == 0
+    assert flat_dispatch(L2U8, 384, 65_536, 8, k=100)["u8_filter"] == 2 and flat_dispatch(L2U8, 320, 1_000_000, 8)["u8_filter"] == 0
     # k = 65 .. 128 from 97 queries on; k = 129 .. 2048 at every batch size (the exact kernels behind took one query per workgroup)
     assert flat_dispatch(L2U8, 128, 10_000_000, 97, k=100)["u8_filter"] == 2 and flat_dispatch(L2U8, 128, 10_000_000, 96, k=100)["u8_stream"] == 1
     assert flat_dispatch(L2U8, 128, 10_000_000, 97, k=64)["u8_stream"] == 1
     assert flat_dispatch(L2U8, 512, 2_000_000, 1, k=129)["u8_filter"] == 2 and flat_dispatch(L2U8, 512, 2_000_000, 1000, k=2048)["u8_filter"] == 2
-    # ... on tables from 65 536 rows while the sample can fill 1.25 k slots (k <= 128 leaves smaller tables to the stream)
-    assert flat_dispatch(L2U8, 512, 100_000, 1000, k=129)["u8_filter"] == 2 and flat_dispatch(L2U8, 512, 100_000, 1000, k=128)["u8_stream"] == 1
+    # ... on tables from 65 536 rows while the sample can fill 1.25 k slots
+    assert flat_dispatch(L2U8, 512, 100_000, 1000, k=129)["u8_filter"] == 2 and flat_dispatch(L2U8, 512, 100_000, 100, k=128)["u8_stream"] == 1
     assert flat_dispatch(L2U8, 128, 65_536, 10, k=1000)["u8_filter"] == 2 and flat_dispatch(L2U8, 128, 65_536, 10, k=2048)["u8_filter"] == 0
     assert flat_dispatch(L2U8, 512, 65_535, 1000, k=129) == dict(f32_stream=0, f32_filter=0, u8_filter=0, u8_stream=0)
     # "flat_u8_tfilter" 0 brings the rules of round 5 back: the sample + filter pipeline from rows x width x queries >= 1.3e11 and 524 288 rows on
