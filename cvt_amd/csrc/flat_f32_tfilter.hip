@@ -817,7 +817,11 @@ bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k)
     return g_ft_on.load() && (metric == CVTMI_METRIC_IP || metric == CVTMI_METRIC_L2F) && flat_f32_tfilter_width(D) &&
            // (k > 128: nothing else is fast on a small table either -- from 65 536 rows and 48 k, where the sample still fills its slots; measured in
            //  tools/flat_bigk_small_tables.py, profiles/r06_flat_bigk_small_tables.txt: 100 000 x 128-d, 1000 queries, k = 129 2.3 -> 0.58 ms)
-           (n >= g_ft_min_rows.load() || (k > 128 && n >= std::max<int64_t>(65536, 48 * (int64_t)k) && (D <= 512 || nq >= 16))) && n < 0xffffffe0LL &&
+           // (k <= 128 at the widths the stream kernels do not take: the exact kernels are all there is under 262 144 rows -- from 65 536 rows on,
+           //  rows wider than 512-d with more than 32 neighbours from 129 queries; tools/f32_small_tables.py, profiles/r06_f32_small_tables.txt:
+           //  100 000 x 512-d, 1000 queries, k = 10 2.97 -> 0.30 ms)
+           (n >= g_ft_min_rows.load() || (k > 128 && n >= std::max<int64_t>(65536, 48 * (int64_t)k) && (D <= 512 || nq >= 16)) ||
+            (k <= 128 && n >= std::min<int64_t>(65536, g_ft_min_rows.load()) && flat_f32_stream_qmax(D) == 0 && (D <= 512 || k <= 32 || nq >= 129))) && n < 0xffffffe0LL &&
            k >= 1 && k <= CVTMI_K_MAX && g_ft_bigk.load() + (k <= 128) > 0 &&   // (k > 128: the stream kernels do not take it -- every batch size comes here)
            (k > 128 || nq >= (g_ft_min_nq.load() > 0 ? g_ft_min_nq.load() : ft_auto_min(D)));
 }

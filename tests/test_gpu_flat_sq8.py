@@ -1295,3 +1295,29 @@ def test_flat_f32_threshold_filter_big_k_small_tables(amd, orc, metric, D, n, nq
     assert np.array_equal(is_, ie) and np.array_equal(bits(ds), bits(de))
     od, _, oi = orc.flat_search(metric, x, q[:2], k, flavour=4 if metric == IP else 8)
     assert np.array_equal(is_[:2], oi) and np.array_equal(bits(ds[:2]), bits(od))
+
+
+@pytest.mark.parametrize("metric,D,n,nq,k", [(IP, 512, 65_536, 200, 10), (L2F, 100, 70_001, 16, 100), (L2F, 1024, 100_000, 130, 100), (IP, 1024, 80_000, 20, 32),
+                                             (L2F, 2048, 66_000, 64, 5)])
+def test_flat_f32_threshold_filter_small_tables(amd, orc, metric, D, n, nq, k):
+    """k <= 128 at the widths without a stream kernel on tables from 65 536 rows (below the pipeline's 262 144): against the exact kernels on
+    every query, the checker on two"""
+    rng = np.random.default_rng(D + n + k)
+    x = _clustered(rng, n, D, metric)
+    x[10_000:10_300] = x[5]
+    q = (x[rng.integers(0, n, nq)] + 0.05 * rng.normal(size=(nq, D))).astype(np.float32)
+    q[0] = x[5]
+    q = np.ascontiguousarray(q, np.float32)
+    try:
+        ix = amd.FlatIndex(metric, D); ix.add(x)
+        ds, is_ = ix.search(q, k)
+        assert ix.last_search()[0] == 3
+        amd.set_tuning("flat_variant", 1)
+        de, ie = ix.search(q, k)
+        assert ix.last_search()[0] == 0
+        ix.close()
+    finally:
+        amd.set_tuning("flat_variant", 0)
+    assert np.array_equal(is_, ie) and np.array_equal(bits(ds), bits(de))
+    od, _, oi = orc.flat_search(metric, x, q[:2], k, flavour=4 if metric == IP else (8 if D % 16 == 0 else 4))
+    assert np.array_equal(is_[:2], oi) and np.array_equal(bits(ds[:2]), bits(od))
