@@ -807,9 +807,12 @@ int flat_f32_tfilter_nch(int D)
 bool flat_f32_tfilter_width(int D) { return flat_f32_tfilter_nch(D) != 0; }
 // smallest batch under "flat_f32_tfilter_min" 0: beyond what one pass of the private-ring stream takes over the operand copy where that is
 // ahead (128-d: 96 queries 0.125 against 0.143 ms here; 64-d: 80 queries 0.137 against 0.129), 16 at widths the stream does not take
-static int ft_auto_min(int D)
+static int ft_auto_min(int D, int k)
 {
-    if (flat_f32_stream_qmax(D) == 0) return 16;
+    // (no stream kernel: the exact kernels are the alternative -- tools/f32_tiny_batches.py, profiles/r06_f32_tiny_batches.txt: one query over 524 288 x 512-d
+    //  0.35 -> 0.17 ms, over 1 M x 100-d 0.16 -> 0.10; rows wider than 512-d with more than 32 neighbours stay at 16: on tight rows a query's exact finish
+    //  costs more there than its share of an exact scan)
+    if (flat_f32_stream_qmax(D) == 0) return (D <= 512 || k <= 32) ? 1 : 16;
     return D >= 96 ? std::max(65, flat_f32_stream_private_max(D) + 1) : 65;
 }
 bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k)
@@ -823,7 +826,7 @@ bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k)
            (n >= g_ft_min_rows.load() || (k > 128 && n >= std::max<int64_t>(65536, 48 * (int64_t)k) && (D <= 512 || nq >= 16)) ||
             (k <= 128 && n >= std::min<int64_t>(65536, g_ft_min_rows.load()) && flat_f32_stream_qmax(D) == 0 && (D <= 512 || k <= 32 || nq >= 129))) && n < 0xffffffe0LL &&
            k >= 1 && k <= CVTMI_K_MAX && g_ft_bigk.load() + (k <= 128) > 0 &&   // (k > 128: the stream kernels do not take it -- every batch size comes here)
-           (k > 128 || nq >= (g_ft_min_nq.load() > 0 ? g_ft_min_nq.load() : ft_auto_min(D)));
+           (k > 128 || nq >= (g_ft_min_nq.load() > 0 ? g_ft_min_nq.load() : ft_auto_min(D, k)));
 }
 // records a wave region holds: three times what 1 M SIFT-like rows gave per wave at k = 100, scaled with k beyond 128
 static uint32_t ft_rec_cap(int64_t m, int k)

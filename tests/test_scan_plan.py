@@ -212,7 +212,9 @@ def test_flat_dispatch_rules_of_round_5():
     for D in (102, 2052, 4096):
         assert flat_dispatch(L2F, D, 1_000_000, 100, k=100)["f32_stream"] == 0
     for D in (100, 160, 320, 384, 512, 768, 900, 1024, 1536, 2048):   # round 6: widths only the threshold filter takes (from 16 queries over 262 144 rows on)
-        assert flat_dispatch(L2F, D, 1_000_000, 100, k=100)["f32_stream"] == 2 and flat_dispatch(IP, D, 1_000_000, 15, k=100)["f32_stream"] == 0
+        # (from one query on up to 512-d, and wider with k <= 32; wider rows with more neighbours from 16 queries)
+        assert flat_dispatch(L2F, D, 1_000_000, 100, k=100)["f32_stream"] == 2 and flat_dispatch(IP, D, 1_000_000, 15, k=100)["f32_stream"] == (2 if D <= 512 else 0)
+        assert flat_dispatch(IP, D, 1_000_000, 1, k=32)["f32_stream"] == 2 and flat_dispatch(IP, D, 1_000_000, 16, k=100)["f32_stream"] == 2
         # (late round 6: these widths from 65 536 rows on -- nothing but the exact kernels is there; rows wider than 512-d with k > 32 from 129 queries)
         assert flat_dispatch(L2F, D, 65_535, 1000, k=100)["f32_stream"] == 0 and flat_dispatch(L2F, D, 65_536, 1000, k=100)["f32_stream"] == 2
         assert flat_dispatch(L2F, D, 100_000, 100, k=100)["f32_stream"] == (2 if D <= 512 else 0) and flat_dispatch(L2F, D, 100_000, 100, k=32)["f32_stream"] == 2
