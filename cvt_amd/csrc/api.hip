@@ -2028,11 +2028,11 @@ static int flat_search_bigk_u8(cvtmi_flat_t h, FlatScratch &S, const uint8_t *q,
         CVTMI_TRY(S.f_sd2.reserve((size_t)m * k * sizeof(float)));
         CVTMI_TRY(S.f_si2.reserve((size_t)m * k * sizeof(int64_t)));
         uint8_t *qa = S.f_seld.as<uint8_t>();
-        for (int64_t j = 0; j < m; ++j) CVTMI_HIP(hipMemcpyAsync(qa + j * D, q + again[(size_t)j] * D, (size_t)D, hipMemcpyDeviceToDevice, st));
+        for (int64_t j = 0; j < m; ++j) CVTMI_HIP(hipMemcpyAsync(qa + j * D, q + again[(size_t)j] * D, (size_t)D, hipMemcpyDefault, st));
         CVTMI_TRY(flat_search_rows(h, S, n, qa, m, k, S.f_sd2.as<float>(), S.f_si2.as<int64_t>(), st));
         for (int64_t j = 0; j < m; ++j) {
-            CVTMI_HIP(hipMemcpyAsync(dist + again[(size_t)j] * k, S.f_sd2.as<float>() + j * k, (size_t)k * sizeof(float), hipMemcpyDeviceToDevice, st));
-            CVTMI_HIP(hipMemcpyAsync(rows + again[(size_t)j] * k, S.f_si2.as<int64_t>() + j * k, (size_t)k * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+            CVTMI_HIP(hipMemcpyAsync(dist + again[(size_t)j] * k, S.f_sd2.as<float>() + j * k, (size_t)k * sizeof(float), hipMemcpyDefault, st));
+            CVTMI_HIP(hipMemcpyAsync(rows + again[(size_t)j] * k, S.f_si2.as<int64_t>() + j * k, (size_t)k * sizeof(int64_t), hipMemcpyDefault, st));
         }
     }
     *done = true;
