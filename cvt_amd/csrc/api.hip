@@ -171,6 +171,9 @@ struct cvtmi_flat_s {
     // matrix-core filter of the fp32 search (flat_mfma.hip): bf16 operand copy of the rows, built on first use
     DevBuf f_pack, f_bias, f_istats;   // f_istats: [0] max |x|^2, [1] rows with a non-finite value (of the operand copy)
     int64_t f_pack_n = -1;      // rows the copy covers (-1: none)
+    DevBuf f_rows;              // fp32: row-major copy of the rows for the threshold filter's exact finish ("flat_f32_rows_copy"; the blocked layout gathers 16 of every 128 bytes it fetches)
+    int64_t f_rows_n = -1;      // rows it covers (-1: none)
+    bool f_rows_failed = false; // it did not fit once: not tried again on this handle
     int f_pack_nch = 0;         // its K steps per row (the threshold filter of a width between two kernels pads with zeros)
     bool f_nonfinite = false;   // a row holds inf / NaN: the filter is not used
     std::atomic<int> f_last_filtered{0};    // how the last search was answered (0 exact, 1 filter pipeline, 2 fp32 stream, 3 fp32 threshold filter)
@@ -346,6 +349,8 @@ static std::atomic<int> g_scan_bigk{1};          // cvtmi_set_tuning("scan_bigk"
 static std::atomic<int> g_scan_packed{1};        // cvtmi_set_tuning("scan_packed_m"): 0 = M = 8 / 4 through the padded rows like every other M < 16 (round 5), 1 = adc_scan16p
 static std::atomic<int> g_scan_pad{1};           // cvtmi_set_tuning("scan_pad_m"): 0 = an OPQ index with M < 16 stays on the row-per-lane scan kernels (opq_pads)
 static std::atomic<int> g_sq8_host_small{1};     // cvtmi_set_tuning("sq8_host_small"): small SQ8 host-pointer calls run out of a page-locked scratch area (Sq8HostScratch)
+static std::atomic<int> g_flat_f32_rows_copy{4};   // cvtmi_set_tuning("flat_f32_rows_copy"): narrowest fp32 row that gets a row-major copy beside the blocked rows once the threshold filter
+                                                  // answers on the handle (0 = never): + 4 D bytes per row, the exact finish reads whole cache lines
 static std::atomic<int> g_flat_u8_filter_min_nq{129};            // cvtmi_set_tuning("flat_u8_filter_min_nq" / "_min_rows" / "_min_work"): smallest batch, table and
 static std::atomic<int64_t> g_flat_u8_filter_min_rows{524288};   // rows x width x queries (in 1e9) the dispatch hands to the uint8 sample + filter pipeline
 static std::atomic<int64_t> g_flat_u8_filter_min_work{130};
@@ -500,6 +505,7 @@ int cvtmi_set_tuning(const char *name, int64_t value)
     if (!strcmp(name, "flat_u8_tfilter_min_nq")) { set_flat_u8_tfilter_min_nq((int)std::min<int64_t>(value, 1 << 30)); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_tfilter_chunks")) { set_flat_u8_tfilter_chunks((int)std::min<int64_t>(value, 4)); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_tfilter_sample")) { set_flat_u8_tfilter_sample((int)std::min<int64_t>(value, 64)); return CVTMI_OK; }
+    if (!strcmp(name, "flat_f32_rows_copy")) { g_flat_f32_rows_copy = value < 0 ? 0 : (value > (1 << 20) ? (1 << 20) : (int)value); return CVTMI_OK; }
     if (!strcmp(name, "flat_u8_gfilter")) { set_flat_u8_gfilter((int)value); return CVTMI_OK; }
     if (!strcmp(name, "sq8_encode_wave")) { set_sq8_encode_wave(value != 0); return CVTMI_OK; }
     if (!strcmp(name, "sq8_filter")) { set_sq8_filter(value != 0); return CVTMI_OK; }
@@ -1649,7 +1655,7 @@ int cvtmi_flat_destroy(cvtmi_flat_t h)
     if (!h) return CVTMI_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf *b : { &h->data, &h->labels, &h->norms, &h->add_stage, &h->f_pack, &h->f_bias, &h->f_istats, &h->fs_bias, &h->fs_stats })
+    for (DevBuf *b : { &h->data, &h->labels, &h->norms, &h->add_stage, &h->f_pack, &h->f_bias, &h->f_istats, &h->fs_bias, &h->fs_stats, &h->f_rows })
         b->release();
     for (FlatScratch *c : h->pool) { c->release_all(); delete c; }
     if (h->mutated) (void)hipEventDestroy(h->mutated);
@@ -1778,11 +1784,11 @@ int cvtmi_flat_reset(cvtmi_flat_t h)
 {
     CHECK_H(h);
     FlatMutation mut(h, nullptr);
-    h->n = 0; h->identity = true; h->f_pack_n = -1;
+    h->n = 0; h->identity = true; h->f_pack_n = -1; h->f_rows_n = -1;
     h->fs_stats_n = -1; h->fs_nonfinite = false;
     (void)hipDeviceSynchronize();
     if (h->fs_stats.p) CVTMI_HIP(hipMemset(h->fs_stats.p, 0, 16));
-    h->f_pack.release(); h->f_bias.release();  // the filter's operand copy is as large as the rows: give it back
+    h->f_pack.release(); h->f_bias.release(); h->f_rows.release(); h->f_rows_failed = false;  // the filter's copies are as large as the rows: give them back
     return CVTMI_OK;
 }
 
@@ -1858,7 +1864,7 @@ static int flat_search_streamed(cvtmi_flat_t h, FlatScratch &S, const float *q, 
         // LDS, the rows' bf16 operand copy in registers) -> exact distances of the candidates; flagged queries go through the exact
         // kernels below, as for the stream
         CVTMI_TRY(S.fs_redo.reserve((size_t)nq * 2 * sizeof(uint32_t)));
-        CVTMI_TRY(launch_flat_f32_tfilter(h->metric, D, h->data.as<float>(), h->f_pack.p, h->f_istats.as<uint32_t>(), h->fs_bias.as<float>(), h->fs_stats.as<uint32_t>(), n, q, nq, k,
+        CVTMI_TRY(launch_flat_f32_tfilter(h->metric, D, h->data.as<float>(), (h->f_rows.p && h->f_rows_n == n) ? h->f_rows.as<float>() : nullptr, h->f_pack.p, h->f_istats.as<uint32_t>(), h->fs_bias.as<float>(), h->fs_stats.as<uint32_t>(), n, q, nq, k,
                                           S.fs_scratch.p, dist, rows, S.fs_redo.as<uint32_t>(), st));
         CVTMI_TRY(flat_search_rows(h, S, n, q, nq, k, dist, rows, st, INT64_MAX, S.fs_redo.as<uint32_t>()));
         *done = true;
@@ -2107,7 +2113,7 @@ static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStr
 {
     for (int attempt = 0; attempt < 2; ++attempt) {
         FlatRoute r;
-        bool need_fs, need_f32, need_u8;
+        bool need_fs, need_f32, need_u8, need_rm;
         int want_nch = 0;
         {
             std::shared_lock<std::shared_timed_mutex> rd(h->rw);
@@ -2120,7 +2126,9 @@ static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStr
             need_f32 = (h->f_pack_n != h->n || h->f_pack_nch != want_nch) &&
                        (tf ? !need_fs : (r.filt_f32 && !(r.stream && !need_fs && !h->fs_nonfinite)));   // (the stream answers: no copy needed)
             need_u8 = (r.filt_u8 || r.big_u8) && h->f_pack_n != h->n;
-            if (!need_fs && !need_f32 && !need_u8) return CVTMI_OK;
+            need_rm = r.tfilter && !h->fs_nonfinite && g_flat_f32_rows_copy.load() != 0 && h->D >= g_flat_f32_rows_copy.load() && h->D % 4 == 0 && h->f_rows_n != h->n &&
+                      !h->f_rows_failed;
+            if (!need_fs && !need_f32 && !need_u8 && !need_rm) return CVTMI_OK;
         }
         FlatMutation mut(h, st);
         const int64_t n = h->n;
@@ -2155,6 +2163,20 @@ static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStr
             h->f_nonfinite = stats[1] != 0 || !(__builtin_bit_cast(float, stats[0]) <= 3.0e38f);
             h->f_pack_n = n;
             h->f_pack_nch = want_nch;
+        }
+        if (need_rm && h->f_rows_n != n && !need_fs) {   // row-major copy for the exact finish: the rows appended since it was made, the buffer grows by halves
+            int64_t row0 = (h->f_rows.p && h->f_rows_n > 0 && h->f_rows_n < n) ? h->f_rows_n : 0;
+            h->f_rows_n = -1;
+            const size_t need_b = (size_t)n * h->D * sizeof(float);
+            bool ok = true;
+            if (row0 > 0 && need_b > h->f_rows.cap &&
+                h->f_rows.grow(std::max(need_b, h->f_rows.cap + h->f_rows.cap / 2), (size_t)row0 * h->D * sizeof(float), st) != CVTMI_OK) { (void)hipGetLastError(); row0 = 0; }
+            if (row0 == 0 && h->f_rows.reserve(need_b) != CVTMI_OK) { (void)hipGetLastError(); ok = false; h->f_rows_failed = true; }   // no room: the finish gathers from the blocked rows
+            if (ok) {
+                CVTMI_TRY(launch_flat_unblock(h->data.as<float>(), row0, n, h->D, h->f_rows.as<float>(), st));
+                CVTMI_HIP(stream_wait(st));
+                h->f_rows_n = n;
+            }
         }
         if (need_u8 && h->f_pack_n != n) {    // operand-ordered copy of the rows (x - 128 as int8)
             // rows appended since the copy was made: only their tiles are packed (from the last, partly filled one on), the buffer grows by halves

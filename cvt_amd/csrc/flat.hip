@@ -255,6 +255,37 @@ int launch_flat_block(const float *src, int64_t n, int D, int64_t row0, float *d
     return CVTMI_OK;
 }
 
+// the inverse, for the threshold filter's exact finish (round 6): rows [row0 / 64 * 64, n) of the blocked layout -> row-major dst.  A workgroup moves 16
+// pieces of a 64-row block through LDS: 1 KB reads, 256-byte writes
+__global__ __launch_bounds__(kBlock) void flat_unblock_kernel(const float4 *__restrict__ src, int64_t b0, int64_t n, int D4, float4 *__restrict__ dst)
+{
+    __shared__ float4 t_s[64][17];
+    const int cgroups = (D4 + 15) / 16;
+    const int64_t b = b0 + blockIdx.x / cgroups;
+    const int c0 = (int)(blockIdx.x % cgroups) * 16;
+    for (int i = threadIdx.x; i < 64 * 16; i += kBlock) {
+        const int c = i >> 6, r = i & 63;
+        if (c0 + c < D4) t_s[r][c] = src[(b * D4 + c0 + c) * 64 + r];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 16; i += kBlock) {
+        const int r = i >> 4, c = i & 15;
+        const int64_t row = b * 64 + r;
+        if (c0 + c < D4 && row < n) dst[row * D4 + c0 + c] = t_s[r][c];
+    }
+}
+int launch_flat_unblock(const float *blocked, int64_t row0, int64_t n, int D, float *dst, hipStream_t st)
+{
+    const int64_t b0 = row0 / 64, b1 = (n + 63) / 64;
+    if (b1 <= b0) return CVTMI_OK;
+    const int64_t blocks = (b1 - b0) * ((D / 4 + 15) / 16);
+    if (blocks > 0x7fffffffLL) return fail(CVTMI_EINVAL, "flat_unblock: too many blocks");
+    hipLaunchKernelGGL(flat_unblock_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, reinterpret_cast<const float4 *>(blocked), b0, n, D / 4,
+                       reinterpret_cast<float4 *>(dst));
+    CVTMI_HIP(hipGetLastError());
+    return CVTMI_OK;
+}
+
 // uint8 rows.  VEC: rows are 16-byte aligned multiples of 16 (D % 16 == 0) -> dwordx4 loads + dot4
 template <bool VEC, int QT, int CAP = FLAT_CAP, int TRIG = FLAT_TRIG>
 __global__ __launch_bounds__(kBlock) void flat_u8_kernel(const FlatArgs a)

@@ -63,16 +63,19 @@ __device__ __forceinline__ float fs_qnorm(const float *q, int D)
 // exact distance of blocked row `row` to the query qv (LDS) in the reference's summation order (dist_f32.h): the row's D / 4
 // pieces (16 bytes each, 1 KB apart in the blocked layout) are requested 32 at a time
 template <bool IP, int LANES>
-__device__ __forceinline__ float fs_exact(const float *X, int D, int64_t row, const float4 *qv)
+__device__ __forceinline__ float fs_exact(const float *X, int D, int64_t row, const float4 *qv, const bool rowmajor = false)
 {
     float acc[LANES];
 #pragma unroll
     for (int l = 0; l < LANES; ++l) acc[l] = 0.0f;
-    const float4 *xr = reinterpret_cast<const float4 *>(X) + (row >> 6) * (int64_t)(D >> 2) * 64 + (row & 63);
+    // rowmajor: X is the row-major copy of the rows (flat_unblock_kernel) -- the same pieces in the same order out of whole cache lines
+    // (a piece of the blocked layout shares its 128-byte line with seven other rows: a gathered row costs eight times its bytes)
+    const int64_t stride = rowmajor ? 1 : 64;
+    const float4 *xr = reinterpret_cast<const float4 *>(X) + (rowmajor ? row * (int64_t)(D >> 2) : (row >> 6) * (int64_t)(D >> 2) * 64 + (row & 63));
     for (int c0 = 0; c0 < D / 4; c0 += 32) {
         float4 xv[32];
 #pragma unroll
-        for (int c = 0; c < 32; ++c) xv[c] = xr[(int64_t)(c0 + c < D / 4 ? c0 + c : 0) * 64];
+        for (int c = 0; c < 32; ++c) xv[c] = xr[(int64_t)(c0 + c < D / 4 ? c0 + c : 0) * stride];
 #pragma unroll
         for (int c = 0; c < 32; ++c) {
             if (c0 + c < D / 4) {

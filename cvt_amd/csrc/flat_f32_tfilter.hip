@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict_
                                                         float *__restrict__ thr, const float *__restrict__ qbnd, uint32_t *__restrict__ cnt,
                                                         const uint2 *__restrict__ cand, float *__restrict__ out_d, int64_t *__restrict__ out_i,
                                                         uint32_t *__restrict__ redo, uint32_t *__restrict__ rcount, uint32_t *__restrict__ rlist, int rcap, int second, int nqb,
-                                                        uint32_t *__restrict__ bcount, uint32_t *__restrict__ blist)
+                                                        uint32_t *__restrict__ bcount, uint32_t *__restrict__ blist, int rowmajor)
 {
     __shared__ unsigned long long sel[FT_KEEP];
     __shared__ __attribute__((aligned(16))) float q_s[FT_DMAX];
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void ft_finish_kernel(const float *__restrict_
         mine[j] = ~0ull;
         if (i < m2) {
             const uint32_t r = (uint32_t)sel[i];
-            if ((int64_t)r < n) mine[j] = ((unsigned long long)ft_dist_key(fs_exact<IP, LANES>(X, D, r, reinterpret_cast<const float4 *>(q_s))) << 32) | r;
+            if ((int64_t)r < n) mine[j] = ((unsigned long long)ft_dist_key(fs_exact<IP, LANES>(X, D, r, reinterpret_cast<const float4 *>(q_s), rowmajor != 0)) << 32) | r;
         }
     }
     __syncthreads();
@@ -639,7 +639,7 @@ template <bool IP, int LANES>
 __global__ __launch_bounds__(1024) void ft_finish_big_kernel(const float *__restrict__ X, int64_t n, int D, const float *__restrict__ Q, int k,
                                                              const float *__restrict__ thr, const float *__restrict__ qbnd, const uint32_t *__restrict__ cnt,
                                                              const uint2 *__restrict__ cand, float *__restrict__ out_d, int64_t *__restrict__ out_i,
-                                                             uint32_t *__restrict__ redo, int nqb, int cstride, int only2, const uint32_t *__restrict__ bcount, const uint32_t *__restrict__ blist)
+                                                             uint32_t *__restrict__ redo, int nqb, int cstride, int only2, const uint32_t *__restrict__ bcount, const uint32_t *__restrict__ blist, int rowmajor)
 {
     // only2: the second chance of the queries ft_finish_kernel marked 2 (their lists are whole, their margin band holds more than FT_KEEP rows):
     // cstride = that kernel's list stride; the mark becomes 0 (answered here) or 1 (the exact kernels)
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(1024) void ft_finish_big_kernel(const float *__rest
         unsigned long long e = ~0ull;
         if (i < m2) {
             const uint32_t r = rows_s[i];
-            if ((int64_t)r < n) e = ((unsigned long long)ft_dist_key(fs_exact<IP, LANES>(X, D, r, reinterpret_cast<const float4 *>(q_s))) << 32) | r;
+            if ((int64_t)r < n) e = ((unsigned long long)ft_dist_key(fs_exact<IP, LANES>(X, D, r, reinterpret_cast<const float4 *>(q_s), rowmajor != 0)) << 32) | r;
         }
         sel[i] = e;
     }
@@ -903,10 +903,12 @@ static int ft_launch_any(int D, int nprod, bool maxmode, const FtArgs &a, size_t
 }
 
 // nq queries against rows [0, n); results for the queries whose redo flag stays 0 (redo[nq] is zeroed here)
-int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack, const uint32_t *pstats, const float *bias, const uint32_t *stats, int64_t n,
+int launch_flat_f32_tfilter(int metric, int D, const float *X, const float *Xrows, const void *pack, const uint32_t *pstats, const float *bias, const uint32_t *stats, int64_t n,
                             const float *q, int64_t nq, int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, hipStream_t st)
 {
     if (!flat_f32_tfilter_applies(metric, D, n, nq, k)) return fail(CVTMI_EINVAL, "flat_f32_tfilter: D=%d nq=%lld", D, (long long)nq);
+    const float *Xe = Xrows ? Xrows : X;   // what the finish kernels gather exact distances from: the row-major copy when the handle keeps one
+    const int rm = Xrows ? 1 : 0;
     const int mode = g_ft_on.load();
     // (k > 384: as many products as the width has -- the narrower margin keeps the rows that need exact distances near k: at k = 2048 one
     //  product put more than FT_KEEP_BIG rows inside the band and every query went to the exact kernels)
@@ -981,24 +983,24 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack,
                 static std::atomic<bool> attr_f[3][16] = {};
                 if (metric == CVTMI_METRIC_IP) {
                     (void)fs_set_lds((const void *)ft_finish_big_kernel<true, 4>, lds_b, attr_f[0]);
-                    hipLaunchKernelGGL((ft_finish_big_kernel<true, 4>), dim3(bgrid), dim3(1024), lds_b, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, (int)m, cstride, only2, bcount, blist);
+                    hipLaunchKernelGGL((ft_finish_big_kernel<true, 4>), dim3(bgrid), dim3(1024), lds_b, st, Xe, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, (int)m, cstride, only2, bcount, blist, rm);
                 } else if (D % 16 == 0) {
                     (void)fs_set_lds((const void *)ft_finish_big_kernel<false, 8>, lds_b, attr_f[1]);
-                    hipLaunchKernelGGL((ft_finish_big_kernel<false, 8>), dim3(bgrid), dim3(1024), lds_b, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, (int)m, cstride, only2, bcount, blist);
+                    hipLaunchKernelGGL((ft_finish_big_kernel<false, 8>), dim3(bgrid), dim3(1024), lds_b, st, Xe, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, (int)m, cstride, only2, bcount, blist, rm);
                 } else {
                     (void)fs_set_lds((const void *)ft_finish_big_kernel<false, 4>, lds_b, attr_f[2]);
-                    hipLaunchKernelGGL((ft_finish_big_kernel<false, 4>), dim3(bgrid), dim3(1024), lds_b, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, (int)m, cstride, only2, bcount, blist);
+                    hipLaunchKernelGGL((ft_finish_big_kernel<false, 4>), dim3(bgrid), dim3(1024), lds_b, st, Xe, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, (int)m, cstride, only2, bcount, blist, rm);
                 }
                 return;
             }
             const unsigned grid = second ? (unsigned)rcap : (unsigned)m;
             uint32_t *rl = retry ? rlist : nullptr;
             if (metric == CVTMI_METRIC_IP)
-                hipLaunchKernelGGL((ft_finish_kernel<true, 4>), dim3(grid), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m, wide ? bcount : nullptr, blist);
+                hipLaunchKernelGGL((ft_finish_kernel<true, 4>), dim3(grid), dim3(256), 0, st, Xe, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m, wide ? bcount : nullptr, blist, rm);
             else if (D % 16 == 0)   // (the reference's L2 sums in 8 lanes when D % 16 == 0, in 4 lanes otherwise: space_l2.h:40-151)
-                hipLaunchKernelGGL((ft_finish_kernel<false, 8>), dim3(grid), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m, wide ? bcount : nullptr, blist);
+                hipLaunchKernelGGL((ft_finish_kernel<false, 8>), dim3(grid), dim3(256), 0, st, Xe, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m, wide ? bcount : nullptr, blist, rm);
             else
-                hipLaunchKernelGGL((ft_finish_kernel<false, 4>), dim3(grid), dim3(256), 0, st, X, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m, wide ? bcount : nullptr, blist);
+                hipLaunchKernelGGL((ft_finish_kernel<false, 4>), dim3(grid), dim3(256), 0, st, Xe, n, D, a.Q, k, thr, qbnd, cnt, cand, out_d + a0 * k, out_i + a0 * k, redo + a0, rcount, rl, rcap, second, (int)m, wide ? bcount : nullptr, blist, rm);
         };
         hipLaunchKernelGGL(ft_bucket_kernel, dim3(FT_GRID), dim3(FT_BUCKET_T), bucket_lds, st, rec, wcnt, cap, thr, cnt, cand, chunks, qper, (int)m, redo + a0, nw, nullptr, nullptr, fcap);
         finish(0);

@@ -206,6 +206,7 @@ int launch_flat_u8_filter(const uint8_t *q, int64_t nq, int D, const uint4 *pack
 int launch_flat_u8_finish(int64_t nq, const uint32_t *pair_cnt, uint32_t pair_cap, const uint4 *pairs, int cap, int k, const float *sample_d,
                           const int64_t *sample_i, uint32_t *cand_cnt, float *cand_d, int32_t *cand_row, float *out_d, int64_t *out_i,
                           uint32_t *overflow, hipStream_t st);
+int launch_flat_unblock(const float *blocked, int64_t row0, int64_t n, int D, float *dst, hipStream_t st);   // rows [row0 / 64 * 64, n) of the blocked layout -> row-major dst
 int launch_flat_block(const float *src, int64_t n, int D, int64_t row0, float *dst, hipStream_t st);
 // flat_f32_stream.hip: fp32 IP / L2 search as one stream over the blocked rows (bf16 matrix-core scores, group best / second best,
 // exact distances of the candidates); D % 16 == 0, 16 <= D <= 256, up to flat_f32_stream_qmax(D) queries per pass
@@ -223,7 +224,8 @@ int flat_f32_tfilter_nch(int D);   // K steps of the kernel that takes D-dimensi
 bool flat_f32_tfilter_width(int D);
 bool flat_f32_tfilter_applies(int metric, int D, int64_t n, int64_t nq, int k);
 size_t flat_f32_tfilter_scratch(int64_t nq, int k);
-int launch_flat_f32_tfilter(int metric, int D, const float *X, const void *pack, const uint32_t *pstats, const float *bias, const uint32_t *stats, int64_t n,
+// Xrows: row-major copy of the rows (launch_flat_unblock) for the exact finish, or null (it gathers from the blocked layout: eight times the bytes)
+int launch_flat_f32_tfilter(int metric, int D, const float *X, const float *Xrows, const void *pack, const uint32_t *pstats, const float *bias, const uint32_t *stats, int64_t n,
                             const float *q, int64_t nq, int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, hipStream_t st);
 void set_flat_f32_tfilter(int v);
 void set_flat_f32_tfilter_min(int v);

@@ -1321,3 +1321,36 @@ def test_flat_f32_threshold_filter_small_tables(amd, orc, metric, D, n, nq, k):
     assert np.array_equal(is_, ie) and np.array_equal(bits(ds), bits(de))
     od, _, oi = orc.flat_search(metric, x, q[:2], k, flavour=4 if metric == IP else (8 if D % 16 == 0 else 4))
     assert np.array_equal(is_[:2], oi) and np.array_equal(bits(ds[:2]), bits(od))
+
+
+@pytest.mark.parametrize("metric,D", [(IP, 128), (L2F, 100), (L2F, 1024)])
+def test_flat_f32_rows_copy(amd, metric, D):
+    """the threshold filter's exact finish out of the row-major copy of the rows ("flat_f32_rows_copy", round 6: the blocked layout gathers 16 of every
+    128 bytes it fetches) -- built at the first such search, extended behind itself after appends that end inside a 64-row block; same lists and
+    bits as without the copy and as the exact kernels"""
+    rng = np.random.default_rng(D)
+    n, nq, k = 262_144 + 4_000 + 7, 150, 20
+    x = _clustered(rng, n, D, metric)
+    x[100_000:100_200] = x[5]
+    q = (x[rng.integers(0, n, nq)] + 0.05 * rng.normal(size=(nq, D))).astype(np.float32)
+    q[0] = x[5]
+    q = np.ascontiguousarray(q, np.float32)
+    out = {}
+    try:
+        for copy in (4, 0):
+            amd.set_tuning("flat_f32_rows_copy", copy)
+            ix = amd.FlatIndex(metric, D); ix.add(x[:262_144 + 33])
+            ix.search(q, k)                                   # the copy covers the first rows from here on
+            ix.add(x[262_144 + 33:n - 1_001]); ix.search(q[:70], k)
+            ix.add(x[n - 1_001:])
+            out[copy] = ix.search(q, k)
+            assert ix.last_search()[0] == 3
+            if copy == 0:
+                amd.set_tuning("flat_variant", 1)
+                out["exact"] = ix.search(q, k)
+                amd.set_tuning("flat_variant", 0)
+            ix.close()
+    finally:
+        amd.set_tuning("flat_f32_rows_copy", 4); amd.set_tuning("flat_variant", 0)
+    for key in (0, "exact"):
+        assert np.array_equal(out[4][1], out[key][1]) and np.array_equal(bits(out[4][0]), bits(out[key][0])), key
