@@ -1887,7 +1887,8 @@ static int flat_search_streamed(cvtmi_flat_t h, FlatScratch &S, const float *q, 
         CVTMI_TRY(launch_flat_f32_stream(h->metric, D, h->data.as<float>(), h->fs_bias.as<float>(), h->fs_stats.as<uint32_t>(), n, q + a * D, m, k,
                                          S.fs_scratch.p, dist + a * k, rows + a * k, S.fs_redo.as<uint32_t>() + a,
                                          S.fs_redo.as<uint32_t>() + nq + a, st, have_pack ? h->f_pack.p : nullptr,
-                                         have_pack ? h->f_istats.as<uint32_t>() : nullptr));
+                                         have_pack ? h->f_istats.as<uint32_t>() : nullptr,
+                                         (h->f_rows.p && h->f_rows_n == n) ? h->f_rows.as<float>() : nullptr));
     }
     // queries the bound does not cover / whose lists ran over: the exact kernels, predicated on the flags (they exit at once otherwise)
     CVTMI_TRY(flat_search_rows(h, S, n, q, nq, k, dist, rows, st, INT64_MAX, S.fs_redo.as<uint32_t>()));
@@ -2126,7 +2127,7 @@ static int flat_prepare(cvtmi_flat_t h, const void *q, int64_t nq, int k, hipStr
             need_f32 = (h->f_pack_n != h->n || h->f_pack_nch != want_nch) &&
                        (tf ? !need_fs : (r.filt_f32 && !(r.stream && !need_fs && !h->fs_nonfinite)));   // (the stream answers: no copy needed)
             need_u8 = (r.filt_u8 || r.big_u8) && h->f_pack_n != h->n;
-            need_rm = r.tfilter && !h->fs_nonfinite && g_flat_f32_rows_copy.load() != 0 && h->D >= g_flat_f32_rows_copy.load() && h->D % 4 == 0 && h->f_rows_n != h->n &&
+            need_rm = tf && g_flat_f32_rows_copy.load() != 0 && h->D >= g_flat_f32_rows_copy.load() && h->D % 4 == 0 && h->f_rows_n != h->n &&
                       !h->f_rows_failed;
             if (!need_fs && !need_f32 && !need_u8 && !need_rm) return CVTMI_OK;
         }

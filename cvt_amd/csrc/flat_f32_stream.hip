@@ -590,6 +590,7 @@ constexpr int FSF_KEEP = 1024;   // rows that get an exact distance
 
 struct FsFinishArgs {
     const float *X; int64_t n; int D;
+    const float *Xr;             // row-major copy of the rows for the exact distances, or null (they are gathered from the blocked rows)
     const float *Q; int64_t nq; int k;
     const float2 *gb; const float *wm; int G, NG, S;
     int ns_log;                  // log2 of the row streams of the pass (1024 waves, or 256 workgroups of the shared-ring kernel)
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(kBlock) void flat_f32_stream_collect_kernel(const F
         const uint32_t e = h.z;
         const int64_t j = e & 31, wv = (e >> 5) & ((1u << a.ns_log) - 1), g = e >> (5 + a.ns_log), pp = h.x & ((1u << FS_POS_BITS) - 1);
         const int64_t row = (wv + ((g * a.G + pp) << a.ns_log)) * 32 + j;
-        h.w = row < a.n ? __float_as_uint(fs_exact<IP, LANES>(a.X, a.D, row, reinterpret_cast<const float4 *>(q_s))) : 0x7fc00000u;
+        h.w = row < a.n ? __float_as_uint(fs_exact<IP, LANES>(a.Xr ? a.Xr : a.X, a.D, row, reinterpret_cast<const float4 *>(q_s), a.Xr != nullptr)) : 0x7fc00000u;
         list[base_s + i] = h;
     }
     FS_T(2);
@@ -805,7 +806,7 @@ __global__ __launch_bounds__(kBlock) void flat_f32_stream_finish_kernel(const Fs
         for (int i = tid; i < nrow; i += kBlock) {
             unsigned long long ekey = ~0ull - (unsigned)(ndone + i);   // an absent row: a key above every real one, distinct per slot
             if (row_s[i] != 0xffffffffu)
-                ekey = ((unsigned long long)dist_key(fs_exact<IP, LANES>(a.X, D, row_s[i], reinterpret_cast<const float4 *>(work_s))) << 32) | row_s[i];
+                ekey = ((unsigned long long)dist_key(fs_exact<IP, LANES>(a.Xr ? a.Xr : a.X, D, row_s[i], reinterpret_cast<const float4 *>(work_s), a.Xr != nullptr)) << 32) | row_s[i];
             sort_s[ndone + i] = ekey;
         }
         __syncthreads();
@@ -1007,7 +1008,7 @@ static int fs_launch_qb(int qb, const FsStreamArgs &a, hipStream_t st)
 // redo[nq] and cnt[nq] are zeroed inside
 int launch_flat_f32_stream(int metric, int D, const float *X, const float *bias, const uint32_t *stats, int64_t n, const float *q, int64_t nq,
                            int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, uint32_t *cnt, hipStream_t st, const void *pack,
-                           const uint32_t *pstats)
+                           const uint32_t *pstats, const float *Xrows)
 {
     const int qmax = flat_f32_stream_qmax(D);
     if (qmax == 0 || nq < 1 || nq > qmax) return fail(CVTMI_EINVAL, "flat_f32_stream: D=%d nq=%lld", D, (long long)nq);
@@ -1032,7 +1033,7 @@ int launch_flat_f32_stream(int metric, int D, const float *X, const float *bias,
     }
 #undef CVTMI_FS
     FsFinishArgs fa;
-    fa.X = X; fa.n = n; fa.D = D; fa.Q = q; fa.nq = nq; fa.k = k; fa.gb = gb; fa.wm = wm; fa.G = G; fa.NG = NG; fa.stats = stats;
+    fa.X = X; fa.Xr = Xrows; fa.n = n; fa.D = D; fa.Q = q; fa.nq = nq; fa.k = k; fa.gb = gb; fa.wm = wm; fa.G = G; fa.NG = NG; fa.stats = stats;
     fa.pstats = packed ? pstats : nullptr;
     fa.ns_log = shared ? 8 : 10;
     fa.cnt = cnt; fa.list = list; fa.qb = qbuf; fa.out_d = out_d; fa.out_i = out_i; fa.redo = redo;

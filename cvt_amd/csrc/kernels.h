@@ -259,7 +259,7 @@ int launch_flat_f32_bias(float *X, int D, int metric, int64_t row0, int64_t row1
 // redo[nq], cnt[nq] (zeroed inside): redo is set to 1 for queries the exact kernels must answer
 int launch_flat_f32_stream(int metric, int D, const float *X, const float *bias, const uint32_t *stats, int64_t n, const float *q, int64_t nq,
                            int k, void *scratch, float *out_d, int64_t *out_i, uint32_t *redo, uint32_t *cnt, hipStream_t st, const void *pack = nullptr,
-                           const uint32_t *pstats = nullptr);
+                           const uint32_t *pstats = nullptr, const float *Xrows = nullptr);   // Xrows: row-major copy of the rows for the exact distances, or null
 void set_flat_f32_packed(int v);   // 1 (default): up to 32 queries stream the bf16 operand copy (launch_flat_pack) when pack / pstats are given
 int flat_u8_mfma_qtile(int D, int k, int64_t nq);  // queries per workgroup, 0 = shape not covered
 int flat_u8_mfma_splits(int64_t n, int64_t nq, int qt);
