@@ -62,7 +62,7 @@ __device__ __forceinline__ float fs_qnorm(const float *q, int D)
 
 // exact distance of blocked row `row` to the query qv (LDS) in the reference's summation order (dist_f32.h): the row's D / 4
 // pieces (16 bytes each, 1 KB apart in the blocked layout) are requested 32 at a time
-template <bool IP, int LANES>
+template <bool IP, int LANES, int NLOAD = 32>   // NLOAD pieces requested at a time (a 1024-thread workgroup has 128 registers per lane: 16)
 __device__ __forceinline__ float fs_exact(const float *X, int D, int64_t row, const float4 *qv, const bool rowmajor = false)
 {
     float acc[LANES];
@@ -72,16 +72,16 @@ __device__ __forceinline__ float fs_exact(const float *X, int D, int64_t row, co
     // (a piece of the blocked layout shares its 128-byte line with seven other rows: a gathered row costs eight times its bytes)
     const int64_t stride = rowmajor ? 1 : 64;
     const float4 *xr = reinterpret_cast<const float4 *>(X) + (rowmajor ? row * (int64_t)(D >> 2) : (row >> 6) * (int64_t)(D >> 2) * 64 + (row & 63));
-    for (int c0 = 0; c0 < D / 4; c0 += 32) {
-        float4 xv[32];
+    for (int c0 = 0; c0 < D / 4; c0 += NLOAD) {
+        float4 xv[NLOAD];
 #pragma unroll
-        for (int c = 0; c < 32; ++c) xv[c] = xr[(int64_t)(c0 + c < D / 4 ? c0 + c : 0) * stride];
+        for (int c = 0; c < NLOAD; ++c) xv[c] = xr[(int64_t)(c0 + c < D / 4 ? c0 + c : 0) * stride];
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
+        for (int c = 0; c < NLOAD; ++c) {
             if (c0 + c < D / 4) {
                 const float4 qw = qv[c0 + c];
                 const float xs[4] = { xv[c].x, xv[c].y, xv[c].z, xv[c].w }, qs[4] = { qw.x, qw.y, qw.z, qw.w };
-                const int l0 = 4 * (c % (LANES / 4));   // (c0 is a multiple of 32)
+                const int l0 = 4 * (c % (LANES / 4));   // (c0 is a multiple of NLOAD, NLOAD of LANES / 4)
 #pragma unroll
                 for (int l = 0; l < 4; ++l) {
                     if constexpr (IP) {

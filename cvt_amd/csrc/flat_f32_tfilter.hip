@@ -169,6 +169,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     const int slot0 = ((slice * NW + wave) * 2 + lk) * sub_slots;
     int it = 0;
     uint32_t wcnt = 0;
+    float mreg[MAXMODE && KH == 1 ? FT_NBMAX : 1];   // MAX mode: the wave's maxima per query block
+#pragma unroll
+    for (int b = 0; b < (MAXMODE && KH == 1 ? FT_NBMAX : 1); ++b) mreg[b] = FS_EMPTY;
     uint8_t *rec_w = reinterpret_cast<uint8_t *>(a.rec) + (size_t)wave_g * a.cap * 80;   // (wave-uniform)
     bf16x8 xa[RT][NCH][NA];
     f32x16 bias[RT];
@@ -226,8 +229,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
             for (int j_ = 0; j_ < PD; ++j_) request(j_, j_);
         }
-#pragma unroll 1
-        for (int b = 0; b < nb; ++b) {
+        auto block = [&](const int b, float &mx) __attribute__((always_inline)) {
             const uint8_t *qb = ft_q + (size_t)b * (NCHT * NT * 1024) + lane * 16;
             f32x16 acc[RT];
 #pragma unroll
@@ -279,8 +281,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
                 for (int r = 1; r < RT; ++r) m = fmaxf(m, ft_max16(acc[r]));
                 // (32-bit offset from the scalar base: the 64-bit address arithmetic of a 64-lane scatter was a third of this pass)
-                const uint32_t off = (uint32_t)(q0 + qq) * (uint32_t)a.nslots + (uint32_t)((slot0 + (it & (sub_slots - 1))) & (a.nslots - 1));
-                if (qq < nqc && m > FS_EMPTY) atomicMax(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(a.smax) + off * 4u), f32_key(m));
+                if (KH == 1 && sub_slots == 1) {   // one slot for all of the wave's groups: the maximum stays in a register until the rows are through (a lane's atomic
+                    mx = fmaxf(mx, m);  // touches a cache line of its own -- 64 per instruction, once per block and GROUP they were half of this pass)
+                } else {
+                    const uint32_t off = (uint32_t)(q0 + qq) * (uint32_t)a.nslots + (uint32_t)((slot0 + (it & (sub_slots - 1))) & (a.nslots - 1));
+                    if (qq < nqc && m > FS_EMPTY) atomicMax(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(a.smax) + off * 4u), f32_key(m));
+                }
             } else {
                 const float tb = thr_s[qq];
                 const uint32_t qid = id_s[qq];   // (read beside the threshold: the hit path waits for nothing)
@@ -303,10 +309,30 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                     }
                 }
             }
+        };
+        if constexpr (MAXMODE && KH == 1) {
+#pragma unroll
+            for (int b = 0; b < FT_NBMAX; ++b)
+                if (b < nb) block(b, mreg[b]);
+        } else {
+#pragma unroll 1
+            for (int b = 0; b < nb; ++b) block(b, mreg[0]);
         }
     }
-    if constexpr (!MAXMODE)
+    if constexpr (MAXMODE) {
+        if (sub_slots == 1) {
+            if constexpr (KH == 1) {
+#pragma unroll
+                for (int b = 0; b < FT_NBMAX; ++b) {
+                    const int qq = 32 * b + lj;
+                    const uint32_t off = (uint32_t)(q0 + qq) * (uint32_t)a.nslots + (uint32_t)(slot0 & (a.nslots - 1));
+                    if (b < nb && qq < nqc && mreg[b] > FS_EMPTY) atomicMax(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(a.smax) + off * 4u), f32_key(mreg[b]));
+                }
+            }   // (two K halves: the maxima went out block by block)
+        }
+    } else {
         if (lane == 0) a.wcnt[wave_g] = wcnt;
+    }
 }
 
 // margin of a query: Qb = (|q|^2 + max |x|^2) 1.001; w = what the omitted low terms can add up to for THIS query, by Cauchy-Schwarz
@@ -739,7 +765,7 @@ __global__ __launch_bounds__(1024) void ft_finish_big_kernel(const float *__rest
         unsigned long long e = ~0ull;
         if (i < m2) {
             const uint32_t r = rows_s[i];
-            if ((int64_t)r < n) e = ((unsigned long long)ft_dist_key(fs_exact<IP, LANES>(X, D, r, reinterpret_cast<const float4 *>(q_s), rowmajor != 0)) << 32) | r;
+            if ((int64_t)r < n) e = ((unsigned long long)ft_dist_key(fs_exact<IP, LANES, 16>(X, D, r, reinterpret_cast<const float4 *>(q_s), rowmajor != 0)) << 32) | r;
         }
         sel[i] = e;
     }
