@@ -1354,3 +1354,13 @@ def test_flat_f32_rows_copy(amd, metric, D):
         amd.set_tuning("flat_f32_rows_copy", 4); amd.set_tuning("flat_variant", 0)
     for key in (0, "exact"):
         assert np.array_equal(out[4][1], out[key][1]) and np.array_equal(bits(out[4][0]), bits(out[key][0])), key
+
+
+def test_flat_threshold_filters_random_shapes(amd):
+    """tools/flat_fuzz_ab.py: random rows / width / batch / k / duplicates / appends around the threshold filters' dispatch bounds, uint8 and fp32 -- the
+    default routes against the round-5 kernels, lists and distance bits (1020 cases of it ran clean at the end of round 6)"""
+    import importlib.util, pathlib
+    spec = importlib.util.spec_from_file_location("flat_fuzz_ab", pathlib.Path(__file__).resolve().parent.parent / "tools" / "flat_fuzz_ab.py")
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    bad, paths = mod.run(40, 11, verbose=False)
+    assert bad == 0 and paths.get(3, 0) > 5 and paths.get(4, 0) > 5, (bad, paths)
