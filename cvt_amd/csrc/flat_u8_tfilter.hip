@@ -464,12 +464,14 @@ void set_flat_u8_tfilter_sample(int v) { g_ut_sample = v < 0 ? 0 : v > 64 ? 64 :
 static std::atomic<int> g_ut_chunks{4};
 void set_flat_u8_tfilter_chunks(int v) { g_ut_chunks = v >= 4 ? 4 : (v >= 2 ? 2 : 1); }
 static int ut_chunks_max(int k) { return std::min(g_ut_chunks.load(), k <= 512 ? 4 : (k <= 1024 ? 2 : 1)); }
+static int ut_rt(int ks) { return ks >= 12 ? 2 : (ks >= 4 ? 3 : 4); }   // row tiles per wave: RT x 4 KS + 16 RT registers of 256 (four at 128-d: 5 % faster on large
+                                                                          // tables, but a third fewer tile groups -- sample slots -- on small ones: three)
 bool flat_u8_tfilter_width(int D) { return D == 64 || D == 96 || D == 128 || D == 192 || D == 256 || D == 384 || D == 512; }
 bool flat_u8_tfilter_applies(int D, int64_t n, int64_t nq, int k)
 {
     if (!g_ut_on.load() || !flat_u8_tfilter_width(D) || n >= 0x7fffffe0LL || nq < 1 || k > CVTMI_K_MAX) return false;
     if (k > 128) {   // smaller tables too, while the sample can fill 1.25 k slots (two per wave that gets a tile group): nothing else is fast there
-        const int ks = D / 32, rt = ks >= 12 ? 2 : (ks >= 4 ? 3 : 4);
+        const int ks = D / 32, rt = ut_rt(ks);
         const int64_t groups = (n + 32 * rt - 1) / (32 * rt);
         return n >= 65536 && 8 * std::min<int64_t>(groups, UT_GRID * UT_WAVES / ut_chunks_max(k)) >= 5 * (int64_t)k;
     }
@@ -477,12 +479,12 @@ bool flat_u8_tfilter_applies(int D, int64_t n, int64_t nq, int k)
     // batch of two queries or more comes here (1 M x 96-d, 8 queries: 0.43 -> 0.08 ms)
     const bool has_stream = D == 128 || D == 256 || D == 512;
     if (!has_stream && n >= 65536 && nq >= 2 && k >= g_ut_min_k.load()) {
-        const int ks = D / 32, rt = ks >= 12 ? 2 : (ks >= 4 ? 3 : 4);
+        const int ks = D / 32, rt = ut_rt(ks);
         const int64_t groups = (n + 32 * rt - 1) / (32 * rt);
         if (8 * std::min<int64_t>(groups, UT_GRID * UT_WAVES / 4) >= 5 * (int64_t)k) return true;
     }
     if (n < g_ut_min_rows.load()) {   // small tables, k <= 128: large batches only (the stream's passes are short there), and while the sample fills its slots
-        const int ks = D / 32, rt = ks >= 12 ? 2 : (ks >= 4 ? 3 : 4);
+        const int ks = D / 32, rt = ut_rt(ks);
         const int64_t groups = (n + 32 * rt - 1) / (32 * rt);
         if (n < 65536 || nq < g_ut_small_min_nq.load() || k < g_ut_min_k.load() || 8 * std::min<int64_t>(groups, UT_GRID * UT_WAVES / 4) < 5 * (int64_t)k) return false;
         return true;
@@ -518,7 +520,7 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
                            int64_t *out_i, uint32_t *flags, hipStream_t st)
 {
     if (!flat_u8_tfilter_applies(D, n, nq, k)) return fail(CVTMI_EINVAL, "flat_u8_tfilter: D=%d nq=%lld k=%d", D, (long long)nq, k);
-    const int ks = D / 32, rt = ks >= 12 ? 2 : (ks >= 4 ? 3 : 4);   // (tiles per wave: RT x (4 KS + 32) registers of 256)
+    const int ks = D / 32, rt = ut_rt(ks);   // (tiles per wave: RT x (4 KS + 32) registers of 256)
     const int qcap = std::min(32 * UT_NBMAX, (int)((size_t)(160 * 1024 - 32 * UT_NBMAX * 4 - UT_WAVES * 4 * 32 * 4 - 3072) / ((size_t)ks * 1024)) * 32);
     CVTMI_HIP(hipMemsetAsync(flags, 0, (size_t)(nq + 1) * sizeof(uint32_t), st));
     const int64_t n_tiles = (n + 31) / 32;
