@@ -95,14 +95,14 @@ __device__ __forceinline__ float ft_max3(float a, float b, float c)
 }
 __device__ __forceinline__ float ft_max16(const f32x16 &v)
 {
-    float m = ft_max3(v[0], v[1], v[2]);
-    m = ft_max3(m, v[3], v[4]);
-    m = ft_max3(m, v[5], v[6]);
-    m = ft_max3(m, v[7], v[8]);
-    m = ft_max3(m, v[9], v[10]);
-    m = ft_max3(m, v[11], v[12]);
-    m = ft_max3(m, v[13], v[14]);
-    return fmaxf(m, v[15]);
+    // two chains of four (a chain of eight dependent instructions left the vector pipe idle between them), no canonicalising v_max at the end
+    float m0 = ft_max3(v[0], v[1], v[2]), m1 = ft_max3(v[3], v[4], v[5]);
+    m0 = ft_max3(m0, v[6], v[7]); m1 = ft_max3(m1, v[8], v[9]);
+    m0 = ft_max3(m0, v[10], v[11]); m1 = ft_max3(m1, v[12], v[13]);
+    m0 = ft_max3(m0, v[14], v[15]);
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(m0), "v"(m1));
+    return r;
 }
 
 // KH = 2 (1536 / 2048-d): a row tile's K steps do not fit 512 registers -- a wave holds HALF of them at a time (NCH K steps), the
@@ -290,9 +290,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
             } else {
                 const float tb = thr_s[qq];
                 const uint32_t qid = id_s[qq];   // (read beside the threshold: the hit path waits for nothing)
+                float tmax[RT];   // (all of the block's tiles first: their chains interleave; the tests and the rare hit path after)
+#pragma unroll
+                for (int r = 0; r < RT; ++r) tmax[r] = ft_max16(acc[r]);
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
-                    const bool hit = ft_max16(acc[r]) >= tb;
+                    const bool hit = tmax[r] >= tb;
                     const unsigned long long hm = __ballot(hit);
                     if (hm) {   // some row of the tile reaches some query's threshold: the lanes concerned write their 16 scores
                         const uint32_t pos = wcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));

@@ -56,14 +56,12 @@ __device__ __forceinline__ int ut_max3(int a, int b, int c)
 }
 __device__ __forceinline__ int ut_max16(const i32x16 &v)
 {
-    int m = ut_max3(v[0], v[1], v[2]);
-    m = ut_max3(m, v[3], v[4]);
-    m = ut_max3(m, v[5], v[6]);
-    m = ut_max3(m, v[7], v[8]);
-    m = ut_max3(m, v[9], v[10]);
-    m = ut_max3(m, v[11], v[12]);
-    m = ut_max3(m, v[13], v[14]);
-    return m > v[15] ? m : v[15];
+    // two chains of four (a chain of eight dependent instructions leaves the vector pipe idle between them)
+    int m0 = ut_max3(v[0], v[1], v[2]), m1 = ut_max3(v[3], v[4], v[5]);
+    m0 = ut_max3(m0, v[6], v[7]); m1 = ut_max3(m1, v[8], v[9]);
+    m0 = ut_max3(m0, v[10], v[11]); m1 = ut_max3(m1, v[12], v[13]);
+    m0 = ut_max3(m0, v[14], v[15]);
+    return m0 > m1 ? m0 : m1;
 }
 
 // KS K steps of 32 dimensions, RT row tiles per wave
@@ -165,9 +163,12 @@ __global__ __launch_bounds__(64 * UT_WAVES) __attribute__((amdgpu_waves_per_eu(2
                 mx = m > mx ? m : mx;
             } else {
                 const int tb = thr_s[qq];
+                int tmax[RT];   // (all of the block's tiles first: their chains interleave; the tests and the rare hit path after)
+#pragma unroll
+                for (int r = 0; r < RT; ++r) tmax[r] = ut_max16(acc[r]);
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
-                    const bool hit = ut_max16(acc[r]) >= tb;
+                    const bool hit = tmax[r] >= tb;
                     const unsigned long long hm = __ballot(hit);
                     if (hm) {
                         const uint32_t pos = wcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
