@@ -1364,3 +1364,30 @@ def test_flat_threshold_filters_random_shapes(amd):
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     bad, paths = mod.run(40, 11, verbose=False)
     assert bad == 0 and paths.get(3, 0) > 5 and paths.get(4, 0) > 5, (bad, paths)
+
+
+@pytest.mark.parametrize("metric,D", [(L2U8, 128), (IP, 128), (L2F, 512)])
+def test_flat_threshold_filters_concurrent_searches_on_one_handle(amd, metric, D):
+    """eight host threads search ONE handle at once through the threshold filters (host-pointer entry: every call leases its own scratch set and
+    stream; the operand copies are built once under the exclusive lock), batches of different sizes and k, while a ninth appends rows in between
+    two rounds: every answer equals the serial one on the same rows"""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(D + metric)
+    n = 270_000
+    if metric == L2U8:
+        x = rng.integers(0, 256, size=(n, D), dtype=np.uint8)
+        qs = [x[rng.integers(0, n, nq)].copy() for nq in (130, 257, 300, 1, 513, 140, 200, 1000)]
+        for q in qs: q[:, :3] ^= 1
+    else:
+        x = _clustered(rng, n, D, metric)
+        qs = [np.ascontiguousarray(x[rng.integers(0, n, nq)] + 0.05 * rng.normal(size=(nq, D)), np.float32) for nq in (130, 257, 300, 100, 513, 140, 200, 1000)]
+    ks = (10, 100, 129, 300, 1, 64, 128, 20)
+    ix = amd.FlatIndex(metric, D); ix.add(x[:265_000])
+    same = lambda a, b: np.array_equal(a[1], b[1]) and np.array_equal(bits(a[0]) if metric != L2U8 else a[0], bits(b[0]) if metric != L2U8 else b[0])
+    for rnd in range(2):
+        with ThreadPoolExecutor(max_workers=8) as ex:
+            got = list(ex.map(lambda j: ix.search(qs[j], ks[j]), range(8)))
+        want = [ix.search(qs[j], ks[j]) for j in range(8)]
+        assert all(same(g, w) for g, w in zip(got, want)), rnd
+        if rnd == 0: ix.add(x[265_000:])
+    ix.close()
