@@ -942,7 +942,11 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const float *Xrow
     // (k > 384: as many products as the width has -- the narrower margin keeps the rows that need exact distances near k: at k = 2048 one
     //  product put more than FT_KEEP_BIG rows inside the band and every query went to the exact kernels)
     //  (1000 queries, one / three products: k = 129 1.28 / 1.73 ms, 256 1.53 / 2.05, 1000 3.17 / 2.42, 2048 42 / 3.25)
-    const int nprod = ft_products(D, mode == 4 ? (k > 384 ? 3 : (nq <= g_ft_one_max.load() ? 1 : 2)) : mode);
+    //  End of round 6 (the exact finish reads a row-major copy now, so rows inside a wide band cost less; tools/f32_products_by_k.py,
+    //  profiles/r06_f32_products_by_k.txt, one / three products, ms per 1000 queries): 1 M x 128-d k = 512 1.13 / 1.35, 768 1.38 / 1.42, 1024 1.62 / 1.52,
+    //  1536 26.9 / 1.68; 4 M: 768 2.16 / 3.67, 1024 2.47 / 3.87, 1536 6.4 / 4.1; 10 M: 768 4.1 / 8.5, 1536 5.5 / 9.0, 2048 31.9 / 9.5; 2 M x 256-d: 768 2.7 / 3.3,
+    //  1024 3.50 / 3.56, 1536 258 / 4.1 -- three products cost in proportion to the rows, one product's band overflows somewhere past k = 1024: one up to 768
+    const int nprod = ft_products(D, mode == 4 ? (k > 768 ? 3 : (nq <= g_ft_one_max.load() ? 1 : 2)) : mode);
     const int nt = nprod == 3 ? 2 : 1;
     const int nch = flat_f32_tfilter_nch(D);
     const int qcap = std::min(32 * FT_NBMAX, (int)((size_t)(160 * 1024 - 32 * FT_NBMAX * 8 - FT_SLACK) / ((size_t)nch * nt * 1024)) * 32);   // queries a workgroup holds
