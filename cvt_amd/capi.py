@@ -547,7 +547,7 @@ class FlatIndex:
 
     def last_search(self):
         """(how the last search was answered: 0 exact / streaming kernels, 1 sample + matrix-core filter, 2 fp32 stream, 3 fp32 threshold filter, 4 uint8
-        threshold filter; largest candidate list -- for 4: the queries it handed to the other kernels)"""
+        threshold filter; largest candidate list (0 for the threshold filters: nothing of theirs is read back))"""
         f = C.c_int(0); m = C.c_int64(0)
         _check(lib().cvtmi_flat_last_search(self.h, C.byref(f), C.byref(m)))
         return f.value, m.value

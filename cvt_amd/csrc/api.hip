@@ -1801,7 +1801,7 @@ static int flat_search_rows(cvtmi_flat_t h, FlatScratch &S, int64_t n_rows, cons
     // uint8: anything the filter pipeline did not take goes through the streaming matrix-core kernel, 128 queries per pass (its cost hardly
     // depends on k: 10 M x 512-d, k = 128: nq = 1000 40.6 -> 10 ms, nq = 4096 117 -> 40 ms against the row-tile kernels)
     if (h->metric == CVTMI_METRIC_L2U8 && g_flat_variant != 1 && h->norms.p && nq >= 1 && flat_u8_mstream_applies(h->D, n_rows, std::min<int64_t>(nq, 128), k) &&
-        ((uintptr_t)q & 15) == 0 && (nq + 127) / 128 <= max_stream_passes) {
+        ((uintptr_t)q & 15) == 0 && (nq + 127) / 128 <= max_stream_passes && !only_if) {   // (a predicated run: the row-per-lane kernels, which take one)
         const int64_t passes = (nq + 127) / 128, per = (nq + passes - 1) / passes;   // balanced: 129 queries = 65 + 64
         const int NS = flat_u8_stream_slices();
         int nqp = 0, waves = 0;
@@ -1820,7 +1820,7 @@ static int flat_search_rows(cvtmi_flat_t h, FlatScratch &S, int64_t n_rows, cons
         }
         return CVTMI_OK;
     }
-    const bool mfma = h->metric == CVTMI_METRIC_L2U8 && flat_u8_mfma_qtile(h->D, k, nq) > 0;
+    const bool mfma = h->metric == CVTMI_METRIC_L2U8 && !only_if && flat_u8_mfma_qtile(h->D, k, nq) > 0;
     const int qt = mfma ? flat_u8_mfma_qtile(h->D, k, nq) : (k > 128 ? 1 : flat_qtile(nq));   // k > 128: one query per workgroup (kernels.h: kBigK)
     int splits = mfma ? flat_u8_mfma_splits(n_rows, nq, qt) : flat_plan_splits(n_rows, nq, qt);
     if (mfma && splits >= 8) splits = (splits / 8) * 8;  // a row split per XCD: query groups share its L2
@@ -2008,9 +2008,9 @@ static int flat_search_filtered_u8(cvtmi_flat_t h, FlatScratch &S, const uint8_t
 }
 
 // uint8 L2 as a threshold filter (flat_u8_tfilter.hip: batches, and every search with k > 128).  Queries it could not answer (sample not
-// filled, list over, masses of ties at the k-th place) are gathered and answered by the streaming / exact kernels -- those take no
-// per-query predicate on this metric --, their lists written over the filter's.  *done = false: not applicable / the call as a whole
-// (a wave's record region ran over, or more than a quarter of the queries are flagged): the round-5 paths answer it
+// filled, list over, masses of ties at the k-th place; every query of a pass in which a wave's record region ran over) are re-run by the
+// row-per-lane kernels under the flags as a predicate, their lists written over the filter's -- nothing on this path waits for the device.
+// *done = false: not applicable (no operand copy / no room for the scratch): the round-5 paths answer the call
 static int flat_search_bigk_u8(cvtmi_flat_t h, FlatScratch &S, const uint8_t *q, int64_t nq, int k, float *dist, int64_t *rows, hipStream_t st, bool *done)
 {
     *done = false;
@@ -2021,27 +2021,8 @@ static int flat_search_bigk_u8(cvtmi_flat_t h, FlatScratch &S, const uint8_t *q,
     CVTMI_TRY(S.fs_redo.reserve((size_t)(nq + 1) * sizeof(uint32_t)));
     uint32_t *flags = S.fs_redo.as<uint32_t>();
     CVTMI_TRY(launch_flat_u8_tfilter(D, h->f_pack.p, h->norms.as<int32_t>(), n, q, nq, k, S.fs_scratch.p, dist, rows, flags, st));
-    std::vector<uint32_t> hf((size_t)nq + 1);
-    CVTMI_HIP(hipMemcpyAsync(hf.data(), flags, hf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    CVTMI_HIP(stream_wait(st));
-    std::vector<int64_t> again;
-    for (int64_t i = 0; i < nq; ++i)
-        if (hf[(size_t)i + 1]) again.push_back(i);
-    h->f_last_worst = (long long)(hf[0] ? nq : (int64_t)again.size());
-    if (hf[0] || (int64_t)again.size() * 4 > nq + 3) return CVTMI_OK;
-    if (!again.empty()) {
-        const int64_t m = (int64_t)again.size();
-        CVTMI_TRY(S.f_seld.reserve((size_t)m * D));
-        CVTMI_TRY(S.f_sd2.reserve((size_t)m * k * sizeof(float)));
-        CVTMI_TRY(S.f_si2.reserve((size_t)m * k * sizeof(int64_t)));
-        uint8_t *qa = S.f_seld.as<uint8_t>();
-        for (int64_t j = 0; j < m; ++j) CVTMI_HIP(hipMemcpyAsync(qa + j * D, q + again[(size_t)j] * D, (size_t)D, hipMemcpyDefault, st));
-        CVTMI_TRY(flat_search_rows(h, S, n, qa, m, k, S.f_sd2.as<float>(), S.f_si2.as<int64_t>(), st));
-        for (int64_t j = 0; j < m; ++j) {
-            CVTMI_HIP(hipMemcpyAsync(dist + again[(size_t)j] * k, S.f_sd2.as<float>() + j * k, (size_t)k * sizeof(float), hipMemcpyDefault, st));
-            CVTMI_HIP(hipMemcpyAsync(rows + again[(size_t)j] * k, S.f_si2.as<int64_t>() + j * k, (size_t)k * sizeof(int64_t), hipMemcpyDefault, st));
-        }
-    }
+    CVTMI_TRY(flat_search_rows(h, S, n, q, nq, k, dist, rows, st, INT64_MAX, flags + 1));
+    h->f_last_worst = 0;
     *done = true;
     return CVTMI_OK;
 }

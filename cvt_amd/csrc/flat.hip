@@ -294,6 +294,7 @@ __global__ __launch_bounds__(kBlock) void flat_u8_kernel(const FlatArgs a)
     __shared__ TopKShared<QT, CAP> tk;
     __shared__ uint32_t qq[QT];
     const int split = blockIdx.x % a.splits, group = blockIdx.x / a.splits;
+    if (flat_skip<QT>(a, group)) return;   // (round 6: the uint8 threshold filter's flagged queries come here under a predicate)
     const int tid = threadIdx.x;
     const int Dq = (a.D >> 2) << 2;  // the reference drops a dim % 4 tail (space_l2.h:198)
     const int W = Dq >> 2;           // 32-bit words per row that take part
@@ -1408,7 +1409,6 @@ int launch_flat_search(int metric, int D, const void *data, int64_t n, const voi
     a.rows_per_split = rps;
     a.part_d = part_d; a.part_id = part_id;
     a.only_if = only_if;
-    if (only_if && metric == CVTMI_METRIC_L2U8) return fail(CVTMI_EINVAL, "flat_search: predicate on the uint8 metric");
     const int64_t groups = (nq + qtile - 1) / qtile;
     const int64_t blocks = groups * splits;
     if (blocks > 0x7fffffff) return fail(CVTMI_EUNSUPPORTED, "flat_search: grid too large");

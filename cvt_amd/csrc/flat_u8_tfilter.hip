@@ -426,6 +426,13 @@ __global__ __launch_bounds__(1024) void ut_finish_kernel(int64_t n, int k, const
     }
 }
 
+// a wave's record region ran over somewhere in the call (flags[0]): whose hits were lost is not known -- every query is re-run
+__global__ __launch_bounds__(256) void ut_spread_kernel(uint32_t *__restrict__ flags, int64_t nq)
+{
+    if (flags[0] == 0u) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nq; i += (int64_t)gridDim.x * 256) flags[1 + i] = 1u;
+}
+
 template <int KS, int RT>
 static int ut_launch(bool maxmode, const UtArgs &a, size_t lds, hipStream_t st)
 {
@@ -515,8 +522,8 @@ size_t flat_u8_tfilter_scratch(int D, int64_t n, int64_t nq, int k)
     return (size_t)m * (UT_SLOTS + 4) * sizeof(uint32_t) + (size_t)m * UT_CAP * sizeof(uint2) + (size_t)UT_GRID * UT_WAVES * (sizeof(uint32_t) + (size_t)ut_rec_cap(m, k, ut_sample_div(k, n, D)) * 80) + 1024;
 }
 
-// nq queries against rows [0, n); flags[nq + 1] (device, zeroed here): flags[0] != 0 afterwards = the call could not be answered, flags[1 + q] != 0 =
-// query q could not -- the caller runs the other paths for those
+// nq queries against rows [0, n); flags[nq + 1] (device, zeroed here): flags[1 + q] != 0 afterwards = query q could not be answered (flags[0]: a wave's record
+// region ran over in some pass -- then every query is flagged) -- the caller re-runs those under flags + 1 as a predicate
 int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int k, void *scratch, float *out_d,
                            int64_t *out_i, uint32_t *flags, hipStream_t st)
 {
@@ -569,6 +576,8 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
         hipLaunchKernelGGL(ut_finish_kernel, dim3((unsigned)m), dim3(1024), fin_lds, st, n, k, cnt, cand, out_d + a0 * k, out_i + a0 * k, flags + 1 + a0);
         CVTMI_HIP(hipGetLastError());
     }
+    hipLaunchKernelGGL(ut_spread_kernel, dim3((unsigned)std::min<int64_t>(64, (nq + 255) / 256)), dim3(256), 0, st, flags, nq);
+    CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
 

@@ -1219,7 +1219,8 @@ def test_flat_u8_threshold_filter(amd, orc, D, nq, k, hi):
 
 
 def test_flat_u8_threshold_filter_hands_hard_queries_to_the_other_kernels(amd, orc):
-    """queries the uint8 threshold filter cannot answer are re-run one by one inside the call: 6000 equal rows tie at the k-th place of the
+    """queries the uint8 threshold filter cannot answer are re-run inside the call, by the row-per-lane kernels under the flags as a predicate (nothing
+    waits for the device): 6000 equal rows tie at the k-th place of the
     query that equals them (the finish keeps 4096), and 40 000 copies of another row overflow that query's candidate list; the rest of the
     batch stays with the filter.  Same lists as "flat_u8_tfilter" 0, labels included"""
     rng = np.random.default_rng(12)
@@ -1234,8 +1235,8 @@ def test_flat_u8_threshold_filter_hands_hard_queries_to_the_other_kernels(amd, o
     try:
         ix = amd.FlatIndex(L2U8, D); ix.add(x, labels)
         ds, is_ = ix.search(q, k)
-        how, again = ix.last_search()
-        assert how == 4 and 1 <= again <= 4, (how, again)
+        how, _ = ix.last_search()
+        assert how == 4
         amd.set_tuning("flat_u8_tfilter", 0)
         de, ie = ix.search(q, k)
         assert ix.last_search()[0] != 4
