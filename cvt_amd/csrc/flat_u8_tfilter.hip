@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * UT_WAVES) __attribute__((amdgpu_waves_per_eu(2
     // the rows' starting values -(|x'|^2 >> 1) reach the accumulators through the wave's own LDS words (no registers held for them);
     // the queries' operands through a ring of R registers, R - 1 K steps ahead across the blocks of a group
     int *bias_w = thr_s + nb * 32 + wave * (RT * 32);
-    constexpr int R = KS % 4 == 0 ? 4 : (KS % 3 == 0 ? 3 : 2);
+    constexpr int R = KS % 4 == 0 ? 4 : (KS % 3 == 0 ? 3 : (KS % 2 == 0 ? 2 : 1));   // (the ring runs on across the blocks: R divides KS; 1 = read, then use)
     const uint8_t *qp = ut_q + lane * 16;
     for (int64_t g = slice + (int64_t)slices * wave; g < n_groups; g += stride) {
         const int64_t g_rows = MAXMODE ? g * all_groups / a.n_sample : g;
@@ -474,7 +474,7 @@ void set_flat_u8_tfilter_chunks(int v) { g_ut_chunks = v >= 4 ? 4 : (v >= 2 ? 2 
 static int ut_chunks_max(int k) { return std::min(g_ut_chunks.load(), k <= 512 ? 4 : (k <= 1024 ? 2 : 1)); }
 static int ut_rt(int ks) { return ks >= 12 ? 2 : (ks >= 4 ? 3 : 4); }   // row tiles per wave: RT x 4 KS + 16 RT registers of 256 (four at 128-d: 5 % faster on large
                                                                           // tables, but a third fewer tile groups -- sample slots -- on small ones: three)
-bool flat_u8_tfilter_width(int D) { return D == 64 || D == 96 || D == 128 || D == 192 || D == 256 || D == 384 || D == 512; }
+bool flat_u8_tfilter_width(int D) { return D % 32 == 0 && D >= 32 && D <= 512; }   // (a kernel per K-step count: 32 .. 512 bytes per row in steps of 32)
 bool flat_u8_tfilter_applies(int D, int64_t n, int64_t nq, int k)
 {
     if (!g_ut_on.load() || !flat_u8_tfilter_width(D) || n >= 0x7fffffe0LL || nq < 1 || k > CVTMI_K_MAX) return false;
@@ -560,8 +560,11 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
         }
         const size_t lds = (size_t)(qper / 32) * ks * 1024 + (size_t)qper * sizeof(int) + (size_t)UT_WAVES * rt * 32 * sizeof(int) + 3072;
 #define CVTMI_UT(MAXM) \
-        (ks == 16 ? ut_launch<16, 2>(MAXM, a, lds, st) : ks == 12 ? ut_launch<12, 2>(MAXM, a, lds, st) : ks == 8 ? ut_launch<8, 3>(MAXM, a, lds, st) : \
-         ks == 6 ? ut_launch<6, 3>(MAXM, a, lds, st) : ks == 4 ? ut_launch<4, 3>(MAXM, a, lds, st) : ks == 3 ? ut_launch<3, 4>(MAXM, a, lds, st) : ut_launch<2, 4>(MAXM, a, lds, st))
+        (ks == 16 ? ut_launch<16, 2>(MAXM, a, lds, st) : ks == 15 ? ut_launch<15, 2>(MAXM, a, lds, st) : ks == 14 ? ut_launch<14, 2>(MAXM, a, lds, st) : \
+         ks == 13 ? ut_launch<13, 2>(MAXM, a, lds, st) : ks == 12 ? ut_launch<12, 2>(MAXM, a, lds, st) : ks == 11 ? ut_launch<11, 3>(MAXM, a, lds, st) : \
+         ks == 10 ? ut_launch<10, 3>(MAXM, a, lds, st) : ks == 9 ? ut_launch<9, 3>(MAXM, a, lds, st) : ks == 8 ? ut_launch<8, 3>(MAXM, a, lds, st) : \
+         ks == 7 ? ut_launch<7, 3>(MAXM, a, lds, st) : ks == 6 ? ut_launch<6, 3>(MAXM, a, lds, st) : ks == 5 ? ut_launch<5, 3>(MAXM, a, lds, st) : \
+         ks == 4 ? ut_launch<4, 3>(MAXM, a, lds, st) : ks == 3 ? ut_launch<3, 4>(MAXM, a, lds, st) : ks == 2 ? ut_launch<2, 4>(MAXM, a, lds, st) : ut_launch<1, 4>(MAXM, a, lds, st))
         CVTMI_TRY(CVTMI_UT(true));
         // (merged keys while that leaves eight per neighbour wanted)
         if (k * 8 <= UT_SLOTS / 4 / chunks) hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 256>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flags + 1 + a0);

@@ -237,7 +237,7 @@ void set_flat_f32_tfilter_sample(int v);
 void set_flat_f32_tfilter_min_rows(int v);
 int64_t flat_f32_tfilter_min_rows();
 size_t flat_f32_stream_scratch(int D, int64_t n, int64_t nq_pass);
-// round 6 (flat_u8_tfilter.hip): uint8 L2 batches (from 128 queries; any batch when k = 129 .. CVTMI_K_MAX; 64 .. 512-d in steps the kernels exist for,
+// round 6 (flat_u8_tfilter.hip): uint8 L2 batches (from 128 queries; any batch when k = 129 .. CVTMI_K_MAX; 32 .. 512-d in steps of 32,
 // >= 262 144 rows) as a threshold filter over the int8 operand copy
 // (launch_flat_u8_pack): exact integer scores, so no margins; flags[nq + 1] (device, zeroed inside): [0] != 0 afterwards = the other paths must answer the
 // call, [1 + q] != 0 = query q

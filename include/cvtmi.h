@@ -120,7 +120,7 @@ int cvtmi_set_device(int device);
  *   "flat_u8_filter_min_nq" / "flat_u8_filter_min_rows" / "flat_u8_filter_min_work"  uint8 search: the sample + matrix-core filter pipeline
  *                     answers from this many queries (default 129), rows (524 288) and rows x width x queries in units of 1e9
  *                     (130) on; below, passes of up to 128 queries through the streaming kernel (round 5: the fitted crossover)
- *   "flat_u8_tfilter" 1 (default) = uint8 batches over >= 65 536 rows of 64 / 96 / 128 / 192 / 256 / 384 / 512 bytes go through the threshold
+ *   "flat_u8_tfilter" 1 (default) = uint8 batches over >= 65 536 rows of 32 … 512 bytes in steps of 32 go through the threshold
  *                     filter of round 6 (flat_u8_tfilter.hip: exact integer scores on the i8 matrix cores, 256 queries in LDS per pass, thresholds
  *                     from 4096 sample maxima, no margins): every batch when k = 129 .. 2048 (2 M x 512-d, 1000 queries, k = 129: 139 -> 1.5 ms),
  *                     k <= 128 from "flat_u8_tfilter_min_nq" (129) queries on, k = 65 .. 128 from "flat_u8_tfilter_min_nq_k65" (97) on and only
@@ -128,7 +128,7 @@ int cvtmi_set_device(int device);
  *                     round 5.  "flat_u8_tfilter_sample": the sample pass takes one tile group in this many (0 = sqrt(8000 x GB of rows / k) within 2 .. 32);
  *                     "flat_u8_tfilter_chunks": query chunks (1 / 2 / 4, default 4) that share one pass over the rows;
  *                     "flat_u8_tfilter_min_rows" (262 144) / "flat_u8_tfilter_small_min_nq" (129): tables under _min_rows come here from that many queries on;
- *                     widths without a streaming kernel (64 / 96 / 192 / 384 bytes) from two queries on
+ *                     widths without a streaming kernel (all but 128 / 256 / 512 bytes) from two queries on
  *   "flat_u8_mstream_min_rows" smallest table the uint8 streaming kernel takes (default 4096 = its structural bound; it was 262 144 until
  *                     round 5: 65 536 x 512-d, 100 queries 0.84 -> 0.06 ms)
  *   "flat_u8_sample_passes" the uint8 filter pipeline searches its leading sample exactly through the streaming kernel while that takes at

@@ -1180,7 +1180,9 @@ def test_sq8_decode_through_table(amd, orc, d, n):
 
 @pytest.mark.parametrize("D,nq,k,hi", [(512, 300, 129, 256), (512, 7, 2048, 256), (256, 260, 500, 256), (128, 40, 1000, 256), (128, 300, 200, 6),
                                        (512, 1000, 10, 256), (384, 129, 64, 256), (192, 257, 100, 256), (96, 300, 1, 256), (64, 513, 128, 256), (128, 130, 33, 6),
-                                       (96, 5, 10, 256), (64, 2, 100, 256), (384, 33, 128, 256), (128, 1100, 10, 256), (256, 2100, 600, 256)])
+                                       (96, 5, 10, 256), (64, 2, 100, 256), (384, 33, 128, 256), (128, 1100, 10, 256), (256, 2100, 600, 256),
+                                       (32, 300, 10, 256), (160, 7, 100, 256), (224, 130, 129, 256), (288, 64, 10, 256), (320, 1000, 64, 256), (352, 2, 1, 256),
+                                       (416, 200, 500, 256), (448, 31, 10, 256), (480, 257, 100, 256)])
 def test_flat_u8_threshold_filter(amd, orc, D, nq, k, hi):
     """uint8 L2 batches and every batch with k = 129 .. 2048 (round 6, flat_u8_tfilter.hip: exact integer scores on the i8 matrix cores
     over the operand copy, 4096 sample maxima -> the threshold itself, candidate lists, radix select + sort) against the round-5 paths

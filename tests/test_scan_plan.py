@@ -173,7 +173,9 @@ def test_flat_dispatch_rules_of_round_5():
     assert flat_dispatch(L2U8, 512, 65_536, 129)["u8_filter"] == 2 and flat_dispatch(L2U8, 512, 65_536, 128)["u8_stream"] == 1
     assert flat_dispatch(L2U8, 512, 65_535, 1000)["u8_filter"] == 0 and flat_dispatch(L2U8, 512, 65_535, 1000)["u8_stream"] == 1
     assert flat_dispatch(L2U8, 96, 1_000_000, 2)["u8_filter"] == 2 and flat_dispatch(L2U8, 96, 1_000_000, 1)["u8_filter"] == 0
-    assert flat_dispatch(L2U8, 384, 65_536, 8, k=100)["u8_filter"] == 2 and flat_dispatch(L2U8, 320, 1_000_000, 8)["u8_filter"] == 0
+    assert flat_dispatch(L2U8, 384, 65_536, 8, k=100)["u8_filter"] == 2 and flat_dispatch(L2U8, 320, 1_000_000, 8)["u8_filter"] == 2
+    assert flat_dispatch(L2U8, 32, 1_000_000, 2)["u8_filter"] == 2 and flat_dispatch(L2U8, 480, 70_000, 2, k=129)["u8_filter"] == 2
+    assert flat_dispatch(L2U8, 100, 1_000_000, 1000)["u8_filter"] == 0 and flat_dispatch(L2U8, 544, 1_000_000, 1000)["u8_filter"] == 0   # (not 32 .. 512 in steps of 32)
     # k = 65 .. 128 from 97 queries on; k = 129 .. 2048 at every batch size (the exact kernels behind took one query per workgroup)
     assert flat_dispatch(L2U8, 128, 10_000_000, 97, k=100)["u8_filter"] == 2 and flat_dispatch(L2U8, 128, 10_000_000, 96, k=100)["u8_stream"] == 1
     assert flat_dispatch(L2U8, 128, 10_000_000, 97, k=64)["u8_stream"] == 1

@@ -13,7 +13,7 @@ def run(cases, seed, verbose=True):
     paths = {}
     for c in range(cases):
         u8 = bool(rng.integers(0, 2))
-        D = int(rng.choice([64, 96, 128, 192, 256, 384, 512]) if u8 else rng.choice([32, 64, 100, 128, 160, 256, 384, 512, 768, 1024]))
+        D = int(rng.choice([32, 64, 96, 128, 160, 192, 224, 256, 288, 320, 352, 384, 416, 448, 480, 512]) if u8 else rng.choice([32, 64, 100, 128, 160, 256, 384, 512, 768, 1024]))
         n = int(rng.choice([65_536, 65_537, 70_001, 100_000, 131_072, 200_003, 262_143, 262_144, 270_001, 400_000]))
         nq = int(rng.choice([1, 2, 3, 15, 16, 17, 64, 65, 96, 97, 128, 129, 130, 255, 256, 257, 300, 511, 513, 1000, 1025, 1100]))
         k = int(rng.choice([1, 5, 10, 32, 33, 64, 65, 100, 128, 129, 200, 512, 513, 1000, 1024, 1025, 2048]))
