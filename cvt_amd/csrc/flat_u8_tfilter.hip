@@ -497,7 +497,10 @@ bool flat_u8_tfilter_applies(int D, int64_t n, int64_t nq, int k)
         if (n < 65536 || nq < g_ut_small_min_nq.load() || k < g_ut_min_k.load() || 8 * std::min<int64_t>(groups, UT_GRID * UT_WAVES / 4) < 5 * (int64_t)k) return false;
         return true;
     }
-    return (k >= g_ut_min_k.load() && nq >= (k > 64 ? std::min(g_ut_min_nq.load(), g_ut_min_nq_k65.load()) : g_ut_min_nq.load()));
+    // (the lower batch bound also for tables of a GB and more at any k: 10 M x 128-d, 96 queries, k = 10 0.43 -> 0.31 ms, 10 M x 512-d 1.15 -> 0.97; at 1 M x 256-d
+    //  the streaming pass is still ahead there, 0.113 against 0.123)
+    const bool low = k > 64 || (double)n * D >= 1e9;
+    return (k >= g_ut_min_k.load() && nq >= (low ? std::min(g_ut_min_nq.load(), g_ut_min_nq_k65.load()) : g_ut_min_nq.load()));
 }
 // the sample pass takes one tile group in so many: about k x div rows pass the threshold (~0.7 x 4096 x div at k = 2048)
 // Measured (tools/flat_u8_sample_sweep.py, profiles/r06_flat_u8_sample_sweep.txt: 0.26 .. 5 GB of rows, k = 10 .. 1024): the sample pass costs

@@ -123,7 +123,7 @@ int cvtmi_set_device(int device);
  *   "flat_u8_tfilter" 1 (default) = uint8 batches over >= 65 536 rows of 32 … 512 bytes in steps of 32 go through the threshold
  *                     filter of round 6 (flat_u8_tfilter.hip: exact integer scores on the i8 matrix cores, 256 queries in LDS per pass, thresholds
  *                     from 4096 sample maxima, no margins): every batch when k = 129 .. 2048 (2 M x 512-d, 1000 queries, k = 129: 139 -> 1.5 ms),
- *                     k <= 128 from "flat_u8_tfilter_min_nq" (129) queries on, k = 65 .. 128 from "flat_u8_tfilter_min_nq_k65" (97) on and only
+ *                     k <= 128 from "flat_u8_tfilter_min_nq" (129) queries on, k = 65 .. 128 and tables of a GB or more from "flat_u8_tfilter_min_nq_k65" (97) on and only
  *                     for k >= "flat_u8_tfilter_min_k" (1); 0 = the streaming passes / the sample + filter pipeline / the exact kernels as in
  *                     round 5.  "flat_u8_tfilter_sample": the sample pass takes one tile group in this many (0 = sqrt(8000 x GB of rows / k) within 2 .. 32);
  *                     "flat_u8_tfilter_chunks": query chunks (1 / 2 / 4, default 4) that share one pass over the rows;

@@ -161,10 +161,11 @@ def test_flat_dispatch_rules_of_round_5():
     """The flat search's routes (cvtmi_flat_describe_dispatch) at the cells the round-5 sweeps fixed (profiles/r05_u8_dispatch_sweep.txt,
     r05_flat_small_tables.txt) and at the structural bounds that must stay."""
     IP, L2F, L2U8 = 0, 1, 2
-    # uint8, C3: one stream up to 128 queries; from 129 on the threshold filter of round 6 (u8_filter == 2; it replaced the sample + filter
-    # pipeline, u8_filter == 1, wherever its kernels exist: 64 .. 512-d in steps, >= 262 144 rows)
-    assert flat_dispatch(L2U8, 512, 10_000_000, 1)["u8_stream"] == 1 and flat_dispatch(L2U8, 512, 10_000_000, 128)["u8_stream"] == 1
-    for nq in (129, 256, 512, 1000, 4096):
+    # uint8, C3: one stream up to 96 queries (128 on tables under a GB); beyond, the threshold filter of round 6 (u8_filter == 2; it replaced the sample +
+    # filter pipeline, u8_filter == 1, wherever its kernels exist: 32 .. 512-d in steps of 32, >= 65 536 rows)
+    assert flat_dispatch(L2U8, 512, 10_000_000, 1)["u8_stream"] == 1 and flat_dispatch(L2U8, 512, 10_000_000, 96)["u8_stream"] == 1
+    assert flat_dispatch(L2U8, 512, 1_000_000, 128)["u8_stream"] == 1
+    for nq in (97, 129, 256, 512, 1000, 4096):
         assert flat_dispatch(L2U8, 512, 10_000_000, nq) == dict(f32_stream=0, f32_filter=0, u8_filter=2, u8_stream=0), nq
     assert flat_dispatch(L2U8, 512, 2_000_000, 256)["u8_filter"] == 2 and flat_dispatch(L2U8, 512, 1_048_576, 129)["u8_filter"] == 2
     assert flat_dispatch(L2U8, 128, 1_048_576, 512)["u8_filter"] == 2 and flat_dispatch(L2U8, 128, 4_000_000, 512)["u8_filter"] == 2
@@ -178,7 +179,8 @@ def test_flat_dispatch_rules_of_round_5():
     assert flat_dispatch(L2U8, 100, 1_000_000, 1000)["u8_filter"] == 0 and flat_dispatch(L2U8, 544, 1_000_000, 1000)["u8_filter"] == 0   # (not 32 .. 512 in steps of 32)
     # k = 65 .. 128 from 97 queries on; k = 129 .. 2048 at every batch size (the exact kernels behind took one query per workgroup)
     assert flat_dispatch(L2U8, 128, 10_000_000, 97, k=100)["u8_filter"] == 2 and flat_dispatch(L2U8, 128, 10_000_000, 96, k=100)["u8_stream"] == 1
-    assert flat_dispatch(L2U8, 128, 10_000_000, 97, k=64)["u8_stream"] == 1
+    assert flat_dispatch(L2U8, 128, 10_000_000, 97, k=64)["u8_filter"] == 2 and flat_dispatch(L2U8, 128, 10_000_000, 96, k=64)["u8_stream"] == 1   # (a GB of rows and more: 97 at any k)
+    assert flat_dispatch(L2U8, 128, 2_000_000, 97, k=64)["u8_stream"] == 1
     assert flat_dispatch(L2U8, 512, 2_000_000, 1, k=129)["u8_filter"] == 2 and flat_dispatch(L2U8, 512, 2_000_000, 1000, k=2048)["u8_filter"] == 2
     # ... on tables from 65 536 rows while the sample can fill 1.25 k slots
     assert flat_dispatch(L2U8, 512, 100_000, 1000, k=129)["u8_filter"] == 2 and flat_dispatch(L2U8, 512, 100_000, 100, k=128)["u8_stream"] == 1
