@@ -55,9 +55,19 @@ __global__ __launch_bounds__(kBlock) void flat_pack_kernel(const float *__restri
     bool finite = true;
     for (int c = 0; c < nch; ++c) {
         union { bf16x8 v; uint4 u; } h1, h2;
+        // the lane's eight dimensions are two 16-byte pieces of the blocked layout (consecutive lanes = consecutive rows: 512 contiguous bytes per piece)
+        float xv[8] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int d0 = 16 * c + 8 * lk + 4 * p;
+            if (row < n && d0 < D) {   // (D % 4 == 0: a piece is inside the row or past it)
+                const float4 t4 = reinterpret_cast<const float4 *>(X)[((row >> 6) * (int64_t)(D >> 2) + (d0 >> 2)) * 64 + (row & 63)];
+                xv[4 * p] = t4.x; xv[4 * p + 1] = t4.y; xv[4 * p + 2] = t4.z; xv[4 * p + 3] = t4.w;
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = (row < n && 16 * c + 8 * lk + e < D) ? blocked_at(X, D, row, 16 * c + 8 * lk + e) : 0.0f;
+            const float v = xv[e];
             finite = finite && (fabsf(v) <= 3.0e38f);
             const __bf16 a = (__bf16)v;
             h1.v[e] = a;
@@ -70,18 +80,20 @@ __global__ __launch_bounds__(kBlock) void flat_pack_kernel(const float *__restri
     if (lk == 0) {
         float b = kPadBias;
         if (row < n) {
-            float s = 0.0f;
-            for (int e = 0; e < D; ++e) {
-                const float v = blocked_at(X, D, row, e);
-                s = __fmaf_rn(v, v, s);
+            float s = 0.0f, r2 = 0.0f;   // |x|^2 and |x - x1|^2 (what the first bf16 term leaves out: flat_f32_tfilter.hip, one product), both in dimension order
+            const float4 *xr = reinterpret_cast<const float4 *>(X) + (row >> 6) * (int64_t)(D >> 2) * 64 + (row & 63);
+            for (int c4 = 0; c4 < (D >> 2); ++c4) {
+                const float4 t4 = xr[(int64_t)c4 * 64];
+                const float tv[4] = { t4.x, t4.y, t4.z, t4.w };
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = tv[e], r = v - (float)(__bf16)v;
+                    s = __fmaf_rn(v, v, s);
+                    r2 = __fmaf_rn(r, r, r2);
+                }
             }
             b = l2 ? -0.5f * s : 0.0f;
             atomicMax(&stats[0], __float_as_uint(s));  // NaN / inf show up as such: the call takes the exact path
-            float r2 = 0.0f;   // |x - x1|^2: what the first bf16 term leaves out (flat_f32_tfilter.hip, one product)
-            for (int e = 0; e < D; ++e) {
-                const float v = blocked_at(X, D, row, e), r = v - (float)(__bf16)v;
-                r2 = __fmaf_rn(r, r, r2);
-            }
             atomicMax(&stats[2], __float_as_uint(r2));
         }
         const __bf16 a = (__bf16)b, c2 = (__bf16)(b - (float)a);
