@@ -207,7 +207,8 @@ __global__ __launch_bounds__(64 * UT_WAVES) __attribute__((amdgpu_waves_per_eu(2
 // one wave per query: |q'|^2 and the threshold A = the k-th largest sample maximum (INT_MAX + the call's flag when fewer than k slots hold a row)
 template <int NK>   // NK x 64 maxima per query: the 4096 slots, or (NK = 16) the maxima of four neighbours each -- row sets stay disjoint
 __global__ __launch_bounds__(256) void ut_theta_kernel(const uint32_t *__restrict__ smax, const uint8_t *__restrict__ Q, int nq, int D, int k,
-                                                       int32_t *__restrict__ thr, int32_t *__restrict__ qq_out, uint32_t *__restrict__ flag)
+                                                       int32_t *__restrict__ thr, int32_t *__restrict__ qq_out, uint32_t *__restrict__ flag, uint32_t *__restrict__ cnt,
+                                                       uint32_t *__restrict__ call_flag)
 {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq) return;
@@ -232,7 +233,9 @@ __global__ __launch_bounds__(256) void ut_theta_kernel(const uint32_t *__restric
     if (lane == 0) {
         thr[q] = sel != 0u ? (int32_t)(sel ^ 0x80000000u) : 0x7fffffff;
         qq_out[q] = s_;
-        if (sel == 0u) flag[q] = 1u;   // (this query's own word)
+        flag[q] = sel == 0u ? 1u : 0u;   // (this query's own word; its list counter starts here too: two memsets less per pass)
+        cnt[q] = 0u;
+        if (call_flag && q == 0) *call_flag = 0u;   // (the call's first pass: the word the bucket pass raises when a wave's region runs over)
     }
 }
 
@@ -533,7 +536,6 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
     if (!flat_u8_tfilter_applies(D, n, nq, k)) return fail(CVTMI_EINVAL, "flat_u8_tfilter: D=%d nq=%lld k=%d", D, (long long)nq, k);
     const int ks = D / 32, rt = ut_rt(ks);   // (tiles per wave: RT x (4 KS + 32) registers of 256)
     const int qcap = std::min(32 * UT_NBMAX, (int)((size_t)(160 * 1024 - 32 * UT_NBMAX * 4 - UT_WAVES * 4 * 32 * 4 - 3072) / ((size_t)ks * 1024)) * 32);
-    CVTMI_HIP(hipMemsetAsync(flags, 0, (size_t)(nq + 1) * sizeof(uint32_t), st));
     const int64_t n_tiles = (n + 31) / 32;
     const int64_t pass = (int64_t)UT_QPER * ut_chunks_max(k);
     if (qcap < UT_QPER) return fail(CVTMI_EINVAL, "flat_u8_tfilter: %d queries do not fit the LDS at D=%d", UT_QPER, D);
@@ -551,7 +553,6 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
         uint2 *cand = reinterpret_cast<uint2 *>(wcnt + UT_GRID * UT_WAVES);
         uint4 *rec = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(cand + (size_t)m * UT_CAP) + 256 - (((uintptr_t)(cand + (size_t)m * UT_CAP)) & 15));
         CVTMI_HIP(hipMemsetAsync(smax, 0, (size_t)m * UT_SLOTS * sizeof(uint32_t), st));
-        CVTMI_HIP(hipMemsetAsync(cnt, 0, (size_t)m * sizeof(uint32_t), st));
         UtArgs a;
         a.pack = reinterpret_cast<const uint4 *>(pack); a.norms = norms; a.n = n; a.n_tiles = n_tiles; a.Q = q + a0 * D; a.D = D; a.nq = (int)m;
         { const char *e = getenv("CVTMI_UT_DBG"); a.dbg = e ? atoi(e) : 0; }
@@ -570,8 +571,8 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
          ks == 4 ? ut_launch<4, 3>(MAXM, a, lds, st) : ks == 3 ? ut_launch<3, 4>(MAXM, a, lds, st) : ks == 2 ? ut_launch<2, 4>(MAXM, a, lds, st) : ut_launch<1, 4>(MAXM, a, lds, st))
         CVTMI_TRY(CVTMI_UT(true));
         // (merged keys while that leaves eight per neighbour wanted)
-        if (k * 8 <= UT_SLOTS / 4 / chunks) hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 256>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flags + 1 + a0);
-        else hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 64>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flags + 1 + a0);
+        if (k * 8 <= UT_SLOTS / 4 / chunks) hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 256>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flags + 1 + a0, cnt, a0 == 0 ? flags : nullptr);
+        else hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 64>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flags + 1 + a0, cnt, a0 == 0 ? flags : nullptr);
         CVTMI_TRY(CVTMI_UT(false));
 #undef CVTMI_UT
         const size_t bucket_lds = (size_t)UT_STAGE * (sizeof(uint2) + sizeof(uint16_t)), fin_lds = (size_t)UT_CAP * sizeof(uint32_t);
