@@ -352,7 +352,7 @@ __device__ __forceinline__ float ft_margin(float Qb, float w, float theta)
 template <bool IP, int NK>
 __global__ __launch_bounds__(256) void ft_theta_kernel(const uint32_t *__restrict__ smax, const float *__restrict__ Q, int nq, int D, int k, int nprod,
                                                        const uint32_t *__restrict__ stats, const uint32_t *__restrict__ pstats, float loosen, float *__restrict__ thr, float *__restrict__ qbnd,
-                                                       uint32_t *__restrict__ redo)
+                                                       uint32_t *__restrict__ redo, uint32_t *__restrict__ cnt)
 {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq) return;
@@ -377,7 +377,9 @@ __global__ __launch_bounds__(256) void ft_theta_kernel(const uint32_t *__restric
         thr[q] = cut;
         qbnd[q] = Qb;
         qbnd[nq + q] = xq2;
-        if (!(cut == cut)) redo[q] = 1u;
+        redo[q] = (cut == cut) ? 0u : 1u;   // (the query's flag and list counter start here, the pass's list lengths with query 0: two memsets less per pass)
+        cnt[q] = 0u;
+        if (q == 0) { cnt[2 * nq] = 0u; cnt[2 * nq + 1] = 0u; }
     }
 }
 
@@ -950,7 +952,6 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const float *Xrow
     const int nt = nprod == 3 ? 2 : 1;
     const int nch = flat_f32_tfilter_nch(D);
     const int qcap = std::min(32 * FT_NBMAX, (int)((size_t)(160 * 1024 - 32 * FT_NBMAX * 8 - FT_SLACK) / ((size_t)nch * nt * 1024)) * 32);   // queries a workgroup holds
-    CVTMI_HIP(hipMemsetAsync(redo, 0, (size_t)nq * sizeof(uint32_t), st));
     const int64_t n_tiles = (n + 31) / 32;
     const bool big = k > 128;
     const int pass = big ? FT_PASS_BIG : FT_PASS, nslots = big ? FT_SLOTS_BIG : FT_SLOTS;
@@ -974,7 +975,6 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const float *Xrow
         uint2 *cand = reinterpret_cast<uint2 *>(wcnt + FT_GRID * FT_WAVES);
         uint4 *rec = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(cand + (size_t)m * fcap) + 256 - (((uintptr_t)(cand + (size_t)m * fcap)) & 15));
         CVTMI_HIP(hipMemsetAsync(smax, 0, (size_t)m * nslots * sizeof(uint32_t), st));
-        CVTMI_HIP(hipMemsetAsync(cnt, 0, (size_t)(2 * m + 2) * sizeof(uint32_t), st));   // counters, list, its length, the wide bands' count
         FtArgs a;
         a.pack = reinterpret_cast<const uint4 *>(pack); a.bias = bias; a.n_tiles = n_tiles; a.Q = q + a0 * D; a.D = D; a.nq = (int)m; a.chunks = chunks; a.qper = qper;
         a.smax = smax; a.nslots = nslots; a.thr = thr; a.rec = rec; a.wcnt = wcnt; a.cap = cap; a.qlist = nullptr; a.qcount = nullptr; a.dbg = get_flat_f32_dbg();
@@ -991,11 +991,11 @@ int launch_flat_f32_tfilter(int metric, int D, const float *X, const float *Xrow
         const unsigned tg = (unsigned)((m + 3) / 4);
         const float loosen = (a.dbg & 32) ? 0.02f : 0.0f;
         if (metric == CVTMI_METRIC_IP) {
-            if (big) hipLaunchKernelGGL((ft_theta_kernel<true, FT_SLOTS_BIG / 64>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0);
-            else hipLaunchKernelGGL((ft_theta_kernel<true, FT_SLOTS / 64>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0);
+            if (big) hipLaunchKernelGGL((ft_theta_kernel<true, FT_SLOTS_BIG / 64>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0, cnt);
+            else hipLaunchKernelGGL((ft_theta_kernel<true, FT_SLOTS / 64>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0, cnt);
         } else {
-            if (big) hipLaunchKernelGGL((ft_theta_kernel<false, FT_SLOTS_BIG / 64>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0);
-            else hipLaunchKernelGGL((ft_theta_kernel<false, FT_SLOTS / 64>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0);
+            if (big) hipLaunchKernelGGL((ft_theta_kernel<false, FT_SLOTS_BIG / 64>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0, cnt);
+            else hipLaunchKernelGGL((ft_theta_kernel<false, FT_SLOTS / 64>), dim3(tg), dim3(256), 0, st, smax, a.Q, (int)m, D, k, nprod, stats, pstats, loosen, thr, qbnd, redo + a0, cnt);
         }
         a.t1 = n_tiles; a.n_sample = 0;
         CVTMI_TRY(ft_launch_any(D, nprod, false, a, lds, st));
