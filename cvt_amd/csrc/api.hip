@@ -1829,7 +1829,12 @@ static int flat_search_rows(cvtmi_flat_t h, FlatScratch &S, int64_t n_rows, cons
     // 0.5 GB of 300-d rows) but are 32 wherever the rows allow it; an empty workgroup costs a dispatch and the read of its flags
     // (never fewer than the plan's own: a small batch has few query groups and the plan cuts the rows finer for it -- 15 queries over 300 000 x
     //  2048-d rows, 11 of them flagged: 146 splits instead of 32, 5.4 -> 1.9 ms)
-    if (only_if && !mfma) splits = (int)std::max<int64_t>(splits, std::min<int64_t>(32, n_rows / 8192));
+    if (only_if && !mfma) {
+        splits = (int)std::max<int64_t>(splits, std::min<int64_t>(32, n_rows / 8192));
+        // (the partial lists of a re-run are sized for every query, flagged or not: at most ~1 GB of them)
+        const int64_t room = std::max<int64_t>(1, (int64_t)(1LL << 30) / std::max<int64_t>(1, nq * (int64_t)k * 12));
+        if (splits > room) splits = (int)room;
+    }
     float *pd = dist;
     int64_t *pi = rows;
     if (splits > 1) {
