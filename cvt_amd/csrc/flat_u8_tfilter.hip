@@ -45,7 +45,7 @@ struct UtArgs {
     uint32_t *smax;          // MAX mode: [nq][UT_SLOTS] (a ^ 0x80000000), zeroed by the caller
     const int32_t *thr;      // FILTER mode: [nq] (INT_MAX: nothing passes)
     uint4 *rec; uint32_t *wcnt; uint32_t cap;
-    int dbg;   // CVTMI_UT_DBG timing experiments (results wrong): 1 = no epilogue, 2 = rows loaded once
+    int dbg;   // CVTMI_UT_DBG: timing experiments (results wrong) 1 = no epilogue, 2 = rows loaded once; test hook (results right) 4 = record regions of two records
 };
 
 __device__ __forceinline__ int ut_max3(int a, int b, int c)
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void ut_theta_kernel(const uint32_t *__restric
         qq_out[q] = s_;
         flag[q] = sel == 0u ? 1u : 0u;   // (this query's own word; its list counter starts here too: two memsets less per pass)
         cnt[q] = 0u;
-        if (call_flag && q == 0) *call_flag = 0u;   // (the call's first pass: the word the bucket pass raises when a wave's region runs over)
+        if (q == 0) *call_flag = 0u;   // (the word this pass's bucket kernel raises when a wave's region ran over: the pass's finish flags every query then)
     }
 }
 
@@ -322,7 +322,7 @@ __device__ __forceinline__ void ut_bitonic_u64(unsigned long long *e, int np)
 // one workgroup of 1024 threads per query: the k-th smallest distance by a radix select over the list in LDS, everything at or below it
 // sorted by (distance, row)
 __global__ __launch_bounds__(1024) void ut_finish_kernel(int64_t n, int k, const uint32_t *__restrict__ cnt, const uint2 *__restrict__ cand,
-                                                         float *__restrict__ out_d, int64_t *__restrict__ out_i, uint32_t *__restrict__ flag)
+                                                         float *__restrict__ out_d, int64_t *__restrict__ out_i, uint32_t *__restrict__ flag, const uint32_t *__restrict__ pass_flag)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t ub_keys[];   // [UT_CAP] keys = ~distance; later [UT_KEEP] (distance, row) pairs
     __shared__ uint32_t hist[256];
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(1024) void ut_finish_kernel(int64_t n, int k, const
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const uint32_t nc = cnt[q];
     const int64_t want = k < n ? k : n;
-    if (nc > (uint32_t)UT_CAP || (int64_t)nc < want) {
+    if (*pass_flag != 0u || nc > (uint32_t)UT_CAP || (int64_t)nc < want) {   // (pass_flag: a wave's record region ran over in this pass -- whose hits were lost is not known)
         if (tid == 0) flag[q] = 1u;
         return;
     }
@@ -429,13 +429,6 @@ __global__ __launch_bounds__(1024) void ut_finish_kernel(int64_t n, int k, const
     }
 }
 
-// a wave's record region ran over somewhere in the call (flags[0]): whose hits were lost is not known -- every query is re-run
-__global__ __launch_bounds__(256) void ut_spread_kernel(uint32_t *__restrict__ flags, int64_t nq)
-{
-    if (flags[0] == 0u) return;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nq; i += (int64_t)gridDim.x * 256) flags[1 + i] = 1u;
-}
-
 template <int KS, int RT>
 static int ut_launch(bool maxmode, const UtArgs &a, size_t lds, hipStream_t st)
 {
@@ -529,7 +522,7 @@ size_t flat_u8_tfilter_scratch(int D, int64_t n, int64_t nq, int k)
 }
 
 // nq queries against rows [0, n); flags[nq + 1] (device, zeroed here): flags[1 + q] != 0 afterwards = query q could not be answered (flags[0]: a wave's record
-// region ran over in some pass -- then every query is flagged) -- the caller re-runs those under flags + 1 as a predicate
+// region ran over in the last pass -- every query of such a pass is flagged) -- the caller re-runs those under flags + 1 as a predicate
 int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_t n, const uint8_t *q, int64_t nq, int k, void *scratch, float *out_d,
                            int64_t *out_i, uint32_t *flags, hipStream_t st)
 {
@@ -544,7 +537,9 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
         const int chunks = m <= UT_QPER ? 1 : (m <= 2 * UT_QPER ? 2 : 4);
         const int qper = (int)(((m + chunks - 1) / chunks + 31) / 32 * 32);
         const int div = ut_sample_div(k, n, D);
-        const uint32_t cap = ut_rec_cap(m, k, div);
+        // (CVTMI_UT_DBG 4, test hook: regions of two records -- every wave's runs over, the pass flags all of its queries, the predicated kernels answer)
+        const char *dbg_env = getenv("CVTMI_UT_DBG");
+        const uint32_t cap = (dbg_env && (atoi(dbg_env) & 4)) ? 2u : ut_rec_cap(m, k, div);
         uint32_t *smax = reinterpret_cast<uint32_t *>(scratch);
         int32_t *thr = reinterpret_cast<int32_t *>(smax + (size_t)m * UT_SLOTS);
         int32_t *qqv = thr + m;
@@ -571,8 +566,8 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
          ks == 4 ? ut_launch<4, 3>(MAXM, a, lds, st) : ks == 3 ? ut_launch<3, 4>(MAXM, a, lds, st) : ks == 2 ? ut_launch<2, 4>(MAXM, a, lds, st) : ut_launch<1, 4>(MAXM, a, lds, st))
         CVTMI_TRY(CVTMI_UT(true));
         // (merged keys while that leaves eight per neighbour wanted)
-        if (k * 8 <= UT_SLOTS / 4 / chunks) hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 256>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flags + 1 + a0, cnt, a0 == 0 ? flags : nullptr);
-        else hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 64>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flags + 1 + a0, cnt, a0 == 0 ? flags : nullptr);
+        if (k * 8 <= UT_SLOTS / 4 / chunks) hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 256>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flags + 1 + a0, cnt, flags);
+        else hipLaunchKernelGGL(ut_theta_kernel<UT_SLOTS / 64>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, smax, a.Q, (int)m, D, k, thr, qqv, flags + 1 + a0, cnt, flags);
         CVTMI_TRY(CVTMI_UT(false));
 #undef CVTMI_UT
         const size_t bucket_lds = (size_t)UT_STAGE * (sizeof(uint2) + sizeof(uint16_t)), fin_lds = (size_t)UT_CAP * sizeof(uint32_t);
@@ -580,11 +575,9 @@ int launch_flat_u8_tfilter(int D, const void *pack, const int32_t *norms, int64_
         CVTMI_TRY(fs_set_lds((const void *)ut_bucket_kernel, bucket_lds, attr_k));
         CVTMI_TRY(fs_set_lds((const void *)ut_finish_kernel, fin_lds, attr_f));
         hipLaunchKernelGGL(ut_bucket_kernel, dim3(UT_GRID), dim3(1024), bucket_lds, st, rec, wcnt, cap, thr, qqv, norms, cnt, cand, chunks, qper, (int)m, flags);
-        hipLaunchKernelGGL(ut_finish_kernel, dim3((unsigned)m), dim3(1024), fin_lds, st, n, k, cnt, cand, out_d + a0 * k, out_i + a0 * k, flags + 1 + a0);
+        hipLaunchKernelGGL(ut_finish_kernel, dim3((unsigned)m), dim3(1024), fin_lds, st, n, k, cnt, cand, out_d + a0 * k, out_i + a0 * k, flags + 1 + a0, flags);
         CVTMI_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(ut_spread_kernel, dim3((unsigned)std::min<int64_t>(64, (nq + 255) / 256)), dim3(256), 0, st, flags, nq);
-    CVTMI_HIP(hipGetLastError());
     return CVTMI_OK;
 }
 

@@ -1394,3 +1394,26 @@ def test_flat_threshold_filters_concurrent_searches_on_one_handle(amd, metric, D
         assert all(same(g, w) for g, w in zip(got, want)), rnd
         if rnd == 0: ix.add(x[265_000:])
     ix.close()
+
+
+def test_flat_u8_threshold_filter_record_regions_run_over(amd):
+    """CVTMI_UT_DBG 4 shrinks the waves' record regions to two records: every pass raises its flag, its finish flags every query, and the row-per-lane
+    kernels answer under the predicate -- same lists as without the hook and as "flat_u8_tfilter" 0 (two passes: 1100 queries)"""
+    import os
+    rng = np.random.default_rng(4)
+    n, D, nq, k = 270_000, 128, 1100, 10
+    x = rng.integers(0, 256, size=(n, D), dtype=np.uint8)
+    q = x[rng.integers(0, n, nq)].copy(); q[:, :3] ^= 1
+    ix = amd.FlatIndex(L2U8, D); ix.add(x)
+    want = ix.search(q, k)
+    assert ix.last_search()[0] == 4
+    try:
+        os.environ["CVTMI_UT_DBG"] = "4"
+        got = ix.search(q, k)
+        assert ix.last_search()[0] == 4
+    finally:
+        del os.environ["CVTMI_UT_DBG"]
+    again = ix.search(q, k)
+    ix.close()
+    for g in (got, again):
+        assert np.array_equal(g[1], want[1]) and np.array_equal(g[0], want[0])
