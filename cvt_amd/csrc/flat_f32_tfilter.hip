@@ -795,8 +795,8 @@ __global__ __launch_bounds__(1024) void ft_finish_big_kernel(const float *__rest
 // ---- host side ----
 static std::atomic<int> g_ft_on{4};        // cvtmi_set_tuning("flat_f32_tfilter"): 0 = the stream kernels for every batch, 1 .. 3 = products, 4 = choose
 static std::atomic<int> g_ft_min_rows{262144};   // "flat_f32_tfilter_min_rows": smallest table that takes the pipeline
-// "flat_f32_tfilter_sample": the sample is about 1 / this of the rows; 0 (default) = 5, more for few neighbours on large tables -- the sample pass costs bytes / div, the
-// candidates k x div: sqrt(1280 x GB of rows / k) within 5 .. 32 (tools/f32_sample_sweep.py, profiles/r06_f32_sample_sweep.txt: 1 M x 128-d k = 10 0.41 -> 0.36 ms per
+// "flat_f32_tfilter_sample": the sample is about 1 / this of the rows; 0 (default) = 3 .. 32 by the table's bytes and k -- the sample pass costs bytes / div, the
+// candidates k x div: sqrt(1280 x GB of rows / k) within 3 .. 32 (tools/f32_sample_sweep.py, profiles/r06_f32_sample_sweep.txt: 1 M x 128-d k = 10 0.41 -> 0.36 ms per
 // 1000 queries, 4 M x 128-d 1.31 -> 1.04, 524 288 x 512-d 0.82 -> 0.71; k = 100 keeps 5: above 8 its lists run over on tight data)
 static std::atomic<int> g_ft_sample_div{0};
 static int ft_sample_div(int k, int64_t n, int D)
@@ -804,7 +804,7 @@ static int ft_sample_div(int k, int64_t n, int D)
     const int v = g_ft_sample_div.load();
     if (v) return v;
     const double want = std::sqrt(1280.0 * ((double)n * D * 4e-9) / (double)k);
-    return std::max(5, std::min(32, (int)(want + 0.5)));
+    return std::max(3, std::min(32, (int)(want + 0.5)));   // (3, not 5, since the sample pass keeps its maxima in registers: 1 M x 128-d, k = 100 0.419 -> 0.403 ms)
 }
 static std::atomic<int> g_ft_bigk{1};      // "flat_f32_tfilter_bigk": 1 = k = 129 .. 2048 through the pipeline (4096 sample maxima, lists of 32 768, ft_finish_big_kernel), 0 = exact kernels
 static std::atomic<int> g_ft_wide_band{1};   // "flat_f32_tfilter_wide_band": 1 = queries with more than FT_KEEP rows inside the margin band get a second finish (ft_finish_big_kernel), 0 = the exact kernels

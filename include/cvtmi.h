@@ -173,7 +173,7 @@ int cvtmi_set_device(int device);
  *                     kernels are ahead for fewer than 128 queries and level beyond; 200 K rows, 1000 queries 0.42 -> 0.32 ms)
  *   "flat_f32_tfilter_sample"  the sample that sets the thresholds is about 1 / this of the row-tile groups, spread evenly over the
  *                     rows and rounded to a whole number of groups per wave (1 M x 128-d, 1000 queries, k = 100: 1/8 0.63 ms, 1/5 0.505, 1/3 0.52);
- *                     0 (default) = 5, up to 32 for few neighbours on large tables (sqrt(1280 x GB / k): 4 M x 128-d, k = 10: 1.31 -> 1.04 ms)
+ *                     0 (default) = sqrt(1280 x GB / k) within 3 .. 32 (: 4 M x 128-d, k = 10: 1.31 -> 1.04 ms)
  *   "flat_f32_rows_copy"  narrowest fp32 row (default 4 = every width the threshold filter takes; 0 = never) that gets a row-major copy beside the
  *                     blocked rows once the filter answers on the handle: + 4 D bytes per row, the exact finish reads whole cache lines instead of 16 of
  *                     every 128 bytes (262 144 x 1024-d, 1000 queries: 1.89 -> 1.14 ms; 1 M x 128-d 0.53 -> 0.47); skipped where it does not fit
