@@ -1071,7 +1071,7 @@ def _sec_flat_f32(ctx):
                  "path": ix.last_search()[0]}
             if c["path"] == 3 and nq <= 256:   # threshold filter, one bf16 product: bound by the first-term plane of the operand copy
                 c["roofline"] = _hbm(n * D * 2, ms)
-                c["roofline"]["note"] = "algorithmic bytes = the first bf16 term of every row once (the sample pass re-reads a fifth)"
+                c["roofline"]["note"] = "algorithmic bytes = the first bf16 term of every row once (the sample pass re-reads a third .. a thirty-second of them, by table size and k)"
             elif nq <= 96:   # one stream over the rows: bound by HBM -- round 6: over the first bf16 terms of the operand copy (2 bytes per value)
                 c["roofline"] = _hbm(n * D * 2, ms)
                 c["roofline"]["note"] = ("algorithmic bytes = the first bf16 term of every row once (\"flat_f32_packed\": the stream kernels read the threshold "
@@ -1080,7 +1080,7 @@ def _sec_flat_f32(ctx):
                 prods = 1 if c["path"] == 3 else 3
                 tf = prods * 2.0 * nq * n * D / (ms * 1e-3) / 1e12
                 c["roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TF,
-                                 "unit": "TFLOP/s (bf16, %s)" % ("one product per term over all rows (+ a fifth of them in the sample pass); the whole "
+                                 "unit": "TFLOP/s (bf16, %s)" % ("one product per term over all rows (+ the sample pass over a third .. a thirty-second of them); the whole "
                                                                    "pipeline's time, of which the filter pass is half" if prods == 1 else "three two-term products"),
                                  "frac": round(tf / BF16_MFMA_PEAK_TF, 4)}
             res["cases"]["%s nq=%d" % (tag, nq)] = c
